@@ -1,0 +1,122 @@
+/*
+ * osfm_mi355.h -- C ABI of libosfm_mi355.so, the MI355X-native drop-in for OpenSfM's
+ * feature-matching + bundle-adjustment hot path.
+ *
+ * Every entry point is plain C: pointers + sizes, int status return (0 = OK, <0 = error, text via
+ * osfm_last_error()), no exceptions, no torch types.  Host pointers unless a name says "dev".
+ * The library never retains a caller pointer past the call; device memory is owned by the opaque
+ * handles below.  Each entry point cites the reference interface it replaces.
+ *
+ * Index conventions follow the reference: a match is (feature idx in image 1, feature idx in
+ * image 2) after the swap done at opensfm/matching.py:697,717-718; keypoints are normalized image
+ * coordinates (opensfm/features.py:324-331); poses are angle-axis camera->world rotation + camera
+ * ORIGIN (opensfm/src/bundle/data/pose.h:34-43).
+ */
+#ifndef OSFM_MI355_H
+#define OSFM_MI355_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OSFM_OK 0
+#define OSFM_E_INVALID (-1)     /* bad argument (size mismatch, null pointer, ...) */
+#define OSFM_E_HIP (-2)         /* HIP runtime error (see osfm_last_error) */
+#define OSFM_E_UNSUPPORTED (-3) /* input outside the implemented domain */
+#define OSFM_E_NOMEM (-4)
+#define OSFM_E_NUMERIC (-5) /* NaN/Inf in results: reference throws (ba_helpers.cc:780-814) */
+
+#define OSFM_DESC_DIM 128
+#define OSFM_MAX_FEATURES 4096 /* per image, fused matcher limit */
+
+typedef struct osfm_ctx osfm_ctx;     /* one per process/GPU: device, streams, scratch */
+typedef struct osfm_store osfm_store; /* device-resident descriptor + keypoint store */
+
+/* Thread-local text of the last error raised on the calling thread. */
+const char *osfm_last_error(void);
+/* Library version string and the gfx arch the kernels were compiled for. */
+const char *osfm_version(void);
+
+int osfm_ctx_create(int device, osfm_ctx **out);
+void osfm_ctx_destroy(osfm_ctx *ctx);
+/* Device the context is bound to and its CU count (0 on error). */
+int osfm_ctx_device(const osfm_ctx *ctx);
+int osfm_ctx_num_cus(const osfm_ctx *ctx);
+
+/* ------------------------------------------------------------------------------------------
+ * Descriptor store.  Replaces FeatureLoader.load_all_data (opensfm/feature_loading.py:106-173):
+ * instead of an LRU of per-image npz loads, all images' masked features live in HBM.
+ * counts[n_images] = features per image (0..OSFM_MAX_FEATURES).
+ * desc: sum(counts) x 128, integer-valued in [0,255] (features.py:526-534); float32 or uint8.
+ * pts:  sum(counts) x 2 float64 normalized image coordinates (features_data.points[:, :2]).
+ * ------------------------------------------------------------------------------------------ */
+int osfm_store_create(osfm_ctx *ctx, int n_images, const int32_t *counts, osfm_store **out);
+int osfm_store_upload_f32(osfm_store *s, const float *desc, const double *pts);
+int osfm_store_upload_u8(osfm_store *s, const uint8_t *desc, const double *pts);
+void osfm_store_destroy(osfm_store *s);
+int64_t osfm_store_bytes(const osfm_store *s); /* device bytes held */
+
+typedef struct {
+  double lowes_ratio;                /* config["lowes_ratio"], 0.8            (config.py:97)  */
+  int32_t symmetric;                 /* config["symmetric_matching"]           (config.py:101) */
+  int32_t robust;                    /* 1: run the geometric stage (matching.py:599-603)        */
+  int32_t robust_matching_min_match; /* 20                                     (config.py:195) */
+  double robust_matching_threshold;  /* 0.004                                  (config.py:191) */
+  double ransac_confidence;          /* 0.9999 (matching.py:795)                               */
+  int32_t ransac_max_iters;          /* 1000 (cv2.findFundamentalMat default)                  */
+  int32_t reserved;                  /* bit 0 (debug): run every pair on the exact VALU kernel */
+} osfm_match_params;
+
+void osfm_match_params_default(osfm_match_params *p);
+
+typedef struct {
+  double ms_total;         /* stream time of the whole call (HIP events)                 */
+  double ms_match_kernel;  /* sum of fused distance/top-2/ratio/mutual kernel launches   */
+  double ms_ransac_kernel; /* sum of RANSAC kernel launches                              */
+  int64_t match_launches;
+  int64_t pairs;           /* pairs processed                                            */
+  int64_t pairs_exact_path; /* pairs re-run on the exact float-key kernel (d^2 >= 2^22)   */
+  int64_t pairs_ransac;    /* pairs that reached the geometric stage                     */
+} osfm_match_timings;
+
+/* Opaque result of a batched run: per pair a count and a list of (i, j) int32. */
+typedef struct osfm_match_result osfm_match_result;
+
+/*
+ * Batched pair matching: replaces the body of match_images_with_pairs
+ * (opensfm/matching.py:63-98; per pair: match(), matching.py:563-634, BRUTEFORCE symmetric +
+ * robust_match_fundamental).  pairs: n_pairs x 2 image indices into the store.
+ */
+int osfm_match_pairs(osfm_ctx *ctx, const osfm_store *store, const int32_t *pairs, int64_t n_pairs,
+                     const osfm_match_params *params, osfm_match_result **out,
+                     osfm_match_timings *timings_or_null);
+int64_t osfm_result_num_pairs(const osfm_match_result *r);
+int64_t osfm_result_total_matches(const osfm_match_result *r);
+/* counts[n_pairs]; matches[total x 2] concatenated in pair order, each pair sorted by (i, j). */
+int osfm_result_fetch(const osfm_match_result *r, int32_t *counts, int32_t *matches);
+void osfm_result_destroy(osfm_match_result *r);
+
+/*
+ * Leaf: one pair from host buffers.  Drop-in for match_brute_force (symmetric = 0,
+ * matching.py:723-756) and match_brute_force_symmetric (symmetric = 1, matching.py:759-777).
+ * A: nA x dim, B: nB x dim float32 (integer-valued, dim must be 128).
+ * out_pairs: cap x 2 int32, *out_n = number found (may exceed cap; only cap are written).
+ */
+int osfm_match_l2_ratio(osfm_ctx *ctx, const float *A, int nA, const float *B, int nB, int dim,
+                        double ratio, int symmetric, int32_t *out_pairs, int cap, int *out_n);
+
+/*
+ * Leaf: cv2.findFundamentalMat(p1, p2, FM_RANSAC, thr, conf) as used by
+ * robust_match_fundamental (matching.py:780-802).  p1, p2: n x 2 float64.
+ * Returns OSFM_OK with *found = 1 (F row-major, mask n bytes) or *found = 0 (F is None).
+ */
+int osfm_ransac_fundamental(osfm_ctx *ctx, const double *p1, const double *p2, int n, double thr,
+                            double conf, int max_iters, double F[9], uint8_t *mask, int *found,
+                            int *iters_run_or_null);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OSFM_MI355_H */

@@ -1,0 +1,374 @@
+// api.hip -- C ABI entry points of libosfm_mi355.so (context, descriptor store, batched matching).
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "osfm_internal.h"
+
+static thread_local char g_err[1024] = "";
+
+void osfm_set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char *osfm_last_error(void) { return g_err; }
+extern "C" const char *osfm_version(void) { return "osfm-mi355 0.1 (gfx950)"; }
+
+extern "C" int osfm_ctx_create(int device, osfm_ctx **out) {
+  OSFM_REQUIRE(out != nullptr, OSFM_E_INVALID, "osfm_ctx_create: out is null");
+  *out = nullptr;
+  int ndev = 0;
+  OSFM_HIP(hipGetDeviceCount(&ndev));
+  OSFM_REQUIRE(device >= 0 && device < ndev, OSFM_E_INVALID, "device %d out of range (%d visible)", device, ndev);
+  OSFM_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  OSFM_HIP(hipGetDeviceProperties(&prop, device));
+  osfm_ctx *c = new (std::nothrow) osfm_ctx();
+  OSFM_REQUIRE(c != nullptr, OSFM_E_NOMEM, "out of host memory");
+  c->device = device;
+  c->num_cus = prop.multiProcessorCount;
+  OSFM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  for (int i = 0; i < 8; ++i) OSFM_HIP(hipEventCreate(&c->ev[i]));
+  *out = c;
+  return OSFM_OK;
+}
+
+extern "C" void osfm_ctx_destroy(osfm_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (int i = 0; i < 8; ++i)
+    if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" int osfm_ctx_device(const osfm_ctx *c) { return c ? c->device : -1; }
+extern "C" int osfm_ctx_num_cus(const osfm_ctx *c) { return c ? c->num_cus : 0; }
+
+// ------------------------------------------------------------------------------------------
+// store
+// ------------------------------------------------------------------------------------------
+extern "C" int osfm_store_create(osfm_ctx *ctx, int n_images, const int32_t *counts, osfm_store **out) {
+  OSFM_REQUIRE(ctx && counts && out, OSFM_E_INVALID, "osfm_store_create: null argument");
+  OSFM_REQUIRE(n_images >= 0, OSFM_E_INVALID, "n_images < 0");
+  *out = nullptr;
+  osfm_store *s = new (std::nothrow) osfm_store();
+  OSFM_REQUIRE(s != nullptr, OSFM_E_NOMEM, "out of host memory");
+  s->ctx = ctx;
+  s->n_images = n_images;
+  s->counts.assign(counts, counts + n_images);
+  s->row_off.resize(n_images + 1);
+  s->tile_off.resize(n_images + 1);
+  s->row_off[0] = 0;
+  s->tile_off[0] = 0;
+  for (int i = 0; i < n_images; ++i) {
+    if (counts[i] < 0 || counts[i] > OSFM_MAX_FEATURES) {
+      osfm_set_error("image %d has %d features (supported: 0..%d)", i, counts[i], OSFM_MAX_FEATURES);
+      delete s;
+      return OSFM_E_UNSUPPORTED;
+    }
+    s->row_off[i + 1] = s->row_off[i] + counts[i];
+    s->tile_off[i + 1] = s->tile_off[i] + (counts[i] + OSFM_TILE_ROWS - 1) / OSFM_TILE_ROWS;
+    if (counts[i] > s->max_count) s->max_count = counts[i];
+  }
+  (void)hipSetDevice(ctx->device);
+  const int64_t nt = s->tile_off[n_images] + 4;  // +4 tiles of slack: chunk loads never run off the end
+  hipError_t e;
+  bool ok = true;
+  ok = ok && (e = hipMalloc((void **)&s->d_tiles, (size_t)nt * OSFM_TILE_BYTES)) == hipSuccess;
+  ok = ok && (e = hipMalloc((void **)&s->d_norms, (size_t)nt * 32 * sizeof(int32_t))) == hipSuccess;
+  ok = ok && (e = hipMalloc((void **)&s->d_pts, (size_t)nt * 32 * 2 * sizeof(double))) == hipSuccess;
+  ok = ok && (e = hipMalloc((void **)&s->d_counts, (size_t)(n_images + 1) * sizeof(int32_t))) == hipSuccess;
+  ok = ok && (e = hipMalloc((void **)&s->d_tile_off, (size_t)(n_images + 1) * sizeof(int64_t))) == hipSuccess;
+  if (!ok) {
+    osfm_set_error("hipMalloc failed for a store of %lld tiles: %s", (long long)nt, hipGetErrorString(e));
+    osfm_store_destroy(s);
+    return OSFM_E_NOMEM;
+  }
+  s->bytes = nt * (OSFM_TILE_BYTES + 32 * 4 + 32 * 16) + (int64_t)(n_images + 1) * 12;
+  *out = s;
+  return OSFM_OK;
+}
+
+extern "C" void osfm_store_destroy(osfm_store *s) {
+  if (!s) return;
+  if (s->ctx) (void)hipSetDevice(s->ctx->device);
+  (void)hipFree(s->d_tiles);
+  (void)hipFree(s->d_norms);
+  (void)hipFree(s->d_pts);
+  (void)hipFree(s->d_counts);
+  (void)hipFree(s->d_tile_off);
+  delete s;
+}
+
+extern "C" int64_t osfm_store_bytes(const osfm_store *s) { return s ? s->bytes : 0; }
+
+template <typename T>
+static int store_upload(osfm_store *s, const T *desc, const double *pts) {
+  OSFM_REQUIRE(s && desc && pts, OSFM_E_INVALID, "osfm_store_upload: null argument");
+  (void)hipSetDevice(s->ctx->device);
+  const int64_t nt = s->tile_off[s->n_images] + 4;
+  std::vector<int8_t> tiles((size_t)nt * OSFM_TILE_BYTES, 0);
+  std::vector<int32_t> norms((size_t)nt * 32, OSFM_PAD_NORM);
+  std::vector<double> hp((size_t)nt * 64, 0.0);
+  for (int im = 0; im < s->n_images; ++im) {
+    const int n = s->counts[im];
+    const T *d = desc + s->row_off[im] * OSFM_DESC_DIM;
+    const double *pp = pts + s->row_off[im] * 2;
+    for (int r = 0; r < n; ++r) {
+      const int64_t tile = s->tile_off[im] + r / 32;
+      int8_t *t = tiles.data() + tile * OSFM_TILE_BYTES;
+      const int rr = r & 31;
+      int32_t nrm = 0;
+      for (int k = 0; k < OSFM_DESC_DIM; ++k) {
+        const double v = (double)d[(size_t)r * OSFM_DESC_DIM + k];
+        if (!(v >= 0.0 && v <= 255.0) || v != std::floor(v)) {
+          osfm_set_error("descriptor value %g (image %d, feature %d, dim %d) is not an integer in [0,255]: only "
+                         "uint8-valued descriptors (features.py:526-534) are supported by the exact int8 path",
+                         v, im, r, k);
+          return OSFM_E_UNSUPPORTED;
+        }
+        const int q = (int)v - 128;
+        nrm += q * q;
+        t[(k >> 5) * 1024 + ((((k & 31) >> 4) * 32) + rr) * 16 + (k & 15)] = (int8_t)q;
+      }
+      norms[(size_t)tile * 32 + rr] = nrm;
+      hp[((size_t)tile * 32 + rr) * 2] = pp[2 * r];
+      hp[((size_t)tile * 32 + rr) * 2 + 1] = pp[2 * r + 1];
+    }
+  }
+  OSFM_HIP(hipMemcpy(s->d_tiles, tiles.data(), tiles.size(), hipMemcpyHostToDevice));
+  OSFM_HIP(hipMemcpy(s->d_norms, norms.data(), norms.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  OSFM_HIP(hipMemcpy(s->d_pts, hp.data(), hp.size() * sizeof(double), hipMemcpyHostToDevice));
+  std::vector<int32_t> cnt(s->counts);
+  cnt.push_back(0);
+  OSFM_HIP(hipMemcpy(s->d_counts, cnt.data(), cnt.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  OSFM_HIP(hipMemcpy(s->d_tile_off, s->tile_off.data(), s->tile_off.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+  return OSFM_OK;
+}
+
+extern "C" int osfm_store_upload_f32(osfm_store *s, const float *desc, const double *pts) {
+  return store_upload<float>(s, desc, pts);
+}
+extern "C" int osfm_store_upload_u8(osfm_store *s, const uint8_t *desc, const double *pts) {
+  return store_upload<uint8_t>(s, desc, pts);
+}
+
+// ------------------------------------------------------------------------------------------
+// batched matching
+// ------------------------------------------------------------------------------------------
+extern "C" void osfm_match_params_default(osfm_match_params *p) {
+  if (!p) return;
+  p->lowes_ratio = 0.8;
+  p->symmetric = 1;
+  p->robust = 1;
+  p->robust_matching_min_match = 20;
+  p->robust_matching_threshold = 0.004;
+  p->ransac_confidence = 0.9999;
+  p->ransac_max_iters = 1000;
+  p->reserved = 0;
+}
+
+namespace {
+__global__ void gather_matches_kernel(const int32_t *counts, const int64_t *offsets, const uint32_t *matches, int cap,
+                                      int32_t *out, long n_pairs) {
+  const long p = blockIdx.x;
+  if (p >= n_pairs) return;
+  const int n = min(counts[p], cap);
+  const int64_t o = offsets[p];
+  for (int k = threadIdx.x; k < n; k += blockDim.x) {
+    const uint32_t m = matches[p * cap + k];
+    out[2 * (o + k)] = (int32_t)(m & 0xFFFFu);
+    out[2 * (o + k) + 1] = (int32_t)(m >> 16);
+  }
+}
+
+struct DevBuf {
+  void *p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+  template <typename T>
+  T *as() {
+    return (T *)p;
+  }
+};
+}  // namespace
+
+extern "C" int osfm_match_pairs(osfm_ctx *ctx, const osfm_store *store, const int32_t *pairs, int64_t n_pairs,
+                                const osfm_match_params *params, osfm_match_result **out,
+                                osfm_match_timings *tm) {
+  OSFM_REQUIRE(ctx && store && params && out && (pairs || n_pairs == 0), OSFM_E_INVALID, "osfm_match_pairs: null argument");
+  OSFM_REQUIRE(n_pairs >= 0, OSFM_E_INVALID, "n_pairs < 0");
+  OSFM_REQUIRE(!params->robust || params->robust_matching_min_match >= 15, OSFM_E_UNSUPPORTED,
+               "robust_matching_min_match < 15 would take cv2's LMedS branch, which is not implemented");
+  *out = nullptr;
+  for (int64_t k = 0; k < 2 * n_pairs; ++k)
+    OSFM_REQUIRE(pairs[k] >= 0 && pairs[k] < store->n_images, OSFM_E_INVALID, "pair %lld references image %d (store has %d)",
+                 (long long)(k / 2), pairs[k], store->n_images);
+  OSFM_HIP(hipSetDevice(ctx->device));
+  if (tm) memset(tm, 0, sizeof(*tm));
+
+  const int cap = store->max_count > 0 ? store->max_count : 1;
+  const int64_t chunk_pairs = 1 << 17;  // 131072 pairs -> <= 1 GiB of match slots at cap 2048
+  const int64_t cp = n_pairs < chunk_pairs ? n_pairs : chunk_pairs;
+  DevBuf d_pairs, d_counts, d_matches, d_flags, d_offsets, d_gather;
+  size_t gather_cap = 0;
+  hipError_t e = hipSuccess;
+  bool ok = true;
+  ok = ok && (e = d_pairs.alloc((size_t)cp * 2 * sizeof(int32_t))) == hipSuccess;
+  ok = ok && (e = d_counts.alloc((size_t)cp * sizeof(int32_t))) == hipSuccess;
+  ok = ok && (e = d_flags.alloc((size_t)cp * sizeof(int32_t))) == hipSuccess;
+  ok = ok && (e = d_offsets.alloc((size_t)cp * sizeof(int64_t))) == hipSuccess;
+  ok = ok && (e = d_matches.alloc((size_t)cp * cap * sizeof(uint32_t))) == hipSuccess;
+  OSFM_REQUIRE(ok, OSFM_E_NOMEM, "hipMalloc failed for match buffers: %s", hipGetErrorString(e));
+
+  osfm_match_result *res = new (std::nothrow) osfm_match_result();
+  OSFM_REQUIRE(res != nullptr, OSFM_E_NOMEM, "out of host memory");
+  struct Guard {
+    osfm_match_result *r;
+    ~Guard() { delete r; }
+  } guard{res};
+  res->counts.assign((size_t)n_pairs, 0);
+  std::vector<int32_t> hflags((size_t)cp);
+  std::vector<int64_t> hoff((size_t)cp);
+  double ms_match = 0.0, ms_ransac = 0.0;
+  OSFM_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+  for (int64_t p0 = 0; p0 < n_pairs; p0 += cp) {
+    const int64_t np = (n_pairs - p0) < cp ? (n_pairs - p0) : cp;
+    OSFM_HIP(hipMemcpyAsync(d_pairs.p, pairs + 2 * p0, (size_t)np * 2 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    OSFM_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+    int rc;
+    if (params->reserved & 1) {
+      // debug/cross-check mode: every pair on the exact VALU kernel
+      OSFM_HIP(hipMemsetAsync(d_flags.p, 0, (size_t)np * sizeof(int32_t), ctx->stream));
+      rc = osfm_launch_match(ctx, store, d_pairs.as<int32_t>(), np, params->lowes_ratio, params->symmetric, cap,
+                             d_counts.as<int32_t>(), d_matches.as<uint32_t>(), nullptr, true);
+      if (rc != OSFM_OK) return rc;
+      OSFM_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+    } else {
+      rc = osfm_launch_match(ctx, store, d_pairs.as<int32_t>(), np, params->lowes_ratio, params->symmetric, cap,
+                             d_counts.as<int32_t>(), d_matches.as<uint32_t>(), d_flags.as<int32_t>(), false);
+      if (rc != OSFM_OK) return rc;
+      OSFM_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+      // rare exact path: pairs whose second-nearest d^2 >= 2^22 (sqrtf is not injective there)
+      rc = osfm_launch_match(ctx, store, d_pairs.as<int32_t>(), np, params->lowes_ratio, params->symmetric, cap,
+                             d_counts.as<int32_t>(), d_matches.as<uint32_t>(), d_flags.as<int32_t>(), true);
+      if (rc != OSFM_OK) return rc;
+    }
+    OSFM_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
+    if (params->robust) {
+      rc = osfm_launch_ransac_pairs(ctx, store, d_pairs.as<int32_t>(), np, cap, params->robust_matching_min_match,
+                                    params->robust_matching_threshold, params->ransac_confidence,
+                                    params->ransac_max_iters, d_counts.as<int32_t>(), d_matches.as<uint32_t>(), nullptr);
+      if (rc != OSFM_OK) return rc;
+    }
+    OSFM_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
+    OSFM_HIP(hipMemcpyAsync(res->counts.data() + p0, d_counts.p, (size_t)np * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    OSFM_HIP(hipMemcpyAsync(hflags.data(), d_flags.p, (size_t)np * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    OSFM_HIP(hipStreamSynchronize(ctx->stream));
+    int64_t total = 0;
+    for (int64_t k = 0; k < np; ++k) {
+      int32_t &cnt = res->counts[(size_t)(p0 + k)];
+      if (cnt > cap) cnt = cap;
+      hoff[(size_t)k] = total;
+      total += cnt;
+      if (tm) tm->pairs_exact_path += hflags[(size_t)k] != 0;
+    }
+    const size_t base = res->matches.size();
+    res->matches.resize(base + (size_t)total * 2);
+    if (total > 0) {
+      if ((size_t)total > gather_cap) {
+        if (d_gather.p) (void)hipFree(d_gather.p);
+        d_gather.p = nullptr;
+        gather_cap = (size_t)total + (size_t)total / 4;
+        OSFM_REQUIRE(d_gather.alloc(gather_cap * 2 * sizeof(int32_t)) == hipSuccess, OSFM_E_NOMEM,
+                     "hipMalloc failed for gathered matches");
+      }
+      OSFM_HIP(hipMemcpyAsync(d_offsets.p, hoff.data(), (size_t)np * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+      hipLaunchKernelGGL(gather_matches_kernel, dim3((unsigned)np), dim3(64), 0, ctx->stream, d_counts.as<int32_t>(),
+                         d_offsets.as<int64_t>(), d_matches.as<uint32_t>(), cap, d_gather.as<int32_t>(), (long)np);
+      OSFM_HIP(hipGetLastError());
+      OSFM_HIP(hipMemcpyAsync(res->matches.data() + base, d_gather.p, (size_t)total * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+      OSFM_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    if (tm) {
+      float ms = 0.f;
+      OSFM_HIP(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]));
+      ms_match += ms;
+      OSFM_HIP(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]));
+      ms_ransac += ms;
+      tm->match_launches += 1;
+    }
+  }
+  OSFM_HIP(hipEventRecord(ctx->ev[5], ctx->stream));
+  OSFM_HIP(hipStreamSynchronize(ctx->stream));
+  if (tm) {
+    float ms = 0.f;
+    OSFM_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[5]));
+    tm->ms_total = ms;
+    tm->ms_match_kernel = ms_match;
+    tm->ms_ransac_kernel = ms_ransac;
+    tm->pairs = n_pairs;
+  }
+  guard.r = nullptr;
+  *out = res;
+  return OSFM_OK;
+}
+
+extern "C" int64_t osfm_result_num_pairs(const osfm_match_result *r) { return r ? (int64_t)r->counts.size() : 0; }
+extern "C" int64_t osfm_result_total_matches(const osfm_match_result *r) { return r ? (int64_t)(r->matches.size() / 2) : 0; }
+extern "C" int osfm_result_fetch(const osfm_match_result *r, int32_t *counts, int32_t *matches) {
+  OSFM_REQUIRE(r != nullptr, OSFM_E_INVALID, "osfm_result_fetch: null result");
+  if (counts && !r->counts.empty()) memcpy(counts, r->counts.data(), r->counts.size() * sizeof(int32_t));
+  if (matches && !r->matches.empty()) memcpy(matches, r->matches.data(), r->matches.size() * sizeof(int32_t));
+  return OSFM_OK;
+}
+extern "C" void osfm_result_destroy(osfm_match_result *r) { delete r; }
+
+// Leaf: one pair from host buffers (matching.py:723-777).
+extern "C" int osfm_match_l2_ratio(osfm_ctx *ctx, const float *A, int nA, const float *B, int nB, int dim, double ratio,
+                                   int symmetric, int32_t *out_pairs, int cap, int *out_n) {
+  OSFM_REQUIRE(ctx && out_n && (out_pairs || cap == 0), OSFM_E_INVALID, "osfm_match_l2_ratio: null argument");
+  OSFM_REQUIRE(dim == OSFM_DESC_DIM, OSFM_E_UNSUPPORTED, "descriptor dim %d (only 128 is implemented)", dim);
+  OSFM_REQUIRE(nA >= 0 && nB >= 0 && (A || nA == 0) && (B || nB == 0), OSFM_E_INVALID, "bad descriptor arrays");
+  *out_n = 0;
+  if (nA < 2 || nB < 2) return OSFM_OK;  // knnMatch returns < 2 neighbours -> no match (matching.py:750)
+  const int32_t counts[2] = {nA, nB};
+  osfm_store *st = nullptr;
+  int rc = osfm_store_create(ctx, 2, counts, &st);
+  if (rc != OSFM_OK) return rc;
+  std::vector<float> desc((size_t)(nA + nB) * OSFM_DESC_DIM);
+  memcpy(desc.data(), A, (size_t)nA * OSFM_DESC_DIM * sizeof(float));
+  memcpy(desc.data() + (size_t)nA * OSFM_DESC_DIM, B, (size_t)nB * OSFM_DESC_DIM * sizeof(float));
+  std::vector<double> pts((size_t)(nA + nB) * 2, 0.0);
+  rc = osfm_store_upload_f32(st, desc.data(), pts.data());
+  osfm_match_result *res = nullptr;
+  if (rc == OSFM_OK) {
+    osfm_match_params prm;
+    osfm_match_params_default(&prm);
+    prm.lowes_ratio = ratio;
+    prm.symmetric = symmetric;
+    prm.robust = 0;
+    const int32_t pair[2] = {0, 1};
+    rc = osfm_match_pairs(ctx, st, pair, 1, &prm, &res, nullptr);
+  }
+  if (rc == OSFM_OK) {
+    const int n = res->counts[0];
+    *out_n = n;
+    for (int k = 0; k < n && k < cap; ++k) {
+      out_pairs[2 * k] = res->matches[2 * k];
+      out_pairs[2 * k + 1] = res->matches[2 * k + 1];
+    }
+  }
+  osfm_result_destroy(res);
+  osfm_store_destroy(st);
+  return rc;
+}

@@ -1,0 +1,473 @@
+// match.hip -- fused descriptor distance + top-2 + Lowe ratio + mutual check for gfx950 (MI355X).
+//
+// Replaces, per image pair, the cv2 calls under opensfm/matching.py:723-777
+// (match_brute_force / match_brute_force_symmetric): an n1 x n2 x 128 distance computation, the
+// two nearest neighbours of every feature in BOTH directions, the ratio test and the set
+// intersection -- in ONE kernel, one workgroup per pair.  The n1 x n2 distance matrix never
+// leaves the register file.
+//
+// Arithmetic (exact, integer): descriptors are integer-valued in [0,255] (features.py:526-534);
+// stored as int8 a' = a - 128.  d^2(a,b) = |a'|^2 + |b'|^2 - 2 a'.b'  with a'.b' from
+// v_mfma_i32_32x32x32_i8.  All quantities are exact int32, so the result is bit-identical to the
+// fp32 computation cv2 performs (every partial sum < 2^24).
+//
+// Epilogue trick (the kernel is VALU-bound, not MFMA-bound, because K is only 128): top-2 are
+// kept as PACKED int32 keys  key = (2S - norm_other) * 2^k + (2^k - 1 - local_index)  so that
+// one v_max_i32 + one v_med3_i32 per element maintain (best, second) with lowest-index tie
+// breaking, and  key = (S << s) + c  is a single v_lshl_add_u32.
+//   row direction  : state per (row, lane-column-class) lives in registers over the whole column
+//                    loop; 32 classes are merged by a butterfly once per row block.
+//   column direction: reduced in-lane over the 32 rows a lane holds, merged across the two
+//                    half-waves and the 4 waves through a small LDS scratch once per column tile.
+#include "osfm_internal.h"
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = 4;
+constexpr int kRT = 2;                         // 32-row tiles per wave
+constexpr int kRowsPerWG = kWaves * kRT * 32;  // 256
+constexpr int kCT = 4;                         // 32-col tiles per staged chunk
+constexpr int kChunkCols = kCT * 32;           // 128
+constexpr int kChunkBytes = kCT * OSFM_TILE_BYTES;  // 16 KiB
+constexpr int kNone = 0xFFFF;
+constexpr int kCollisionD2 = 1 << 22;  // above this sqrtf() is no longer injective on integers
+
+__device__ __forceinline__ int med3i(int a, int b, int c) { return max(min(a, b), min(max(a, b), c)); }
+
+// Lowe ratio exactly as the reference evaluates it: float32 distances (cv2), compared in Python
+// doubles: m.distance < ratio * n.distance (matching.py:752).  d^2 are exact ints < 2^24.
+__device__ __forceinline__ bool ratio_ok(int d1sq, int d2sq, double ratio) {
+  const float f1 = sqrtf((float)d1sq), f2 = sqrtf((float)d2sq);
+  return (double)f1 < ratio * (double)f2;
+}
+
+__device__ __forceinline__ long xcd_remap(long b, long n) {
+  // blocks are dealt round-robin to the 8 XCDs; give every XCD a contiguous range of pairs so
+  // that the pairs in flight on one L2 share their first image (bijective for any n).
+  const long q = n >> 3, r = n & 7;
+  const long xcd = b & 7, within = b >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+}
+
+struct MatchArgs {
+  const int8_t *tiles;
+  const int32_t *norms;
+  const int64_t *tile_off;
+  const int32_t *counts;
+  const int32_t *pairs;
+  long n_pairs;
+  double ratio;
+  int symmetric;
+  int cap;
+  int ncap;  // LDS capacity (features), multiple of 128
+  int32_t *out_counts;
+  uint32_t *out_matches;
+  int32_t *out_flags;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Shared tail: ratio test on the column side, mutual check, ordered compaction.
+// colBI[c] = row index of the best row for column c (or kNone), rowres[r] = best column for row r
+// after the ratio test (or kNone).  Emits (c, r) sorted by c.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void emit_matches(const MatchArgs &a, long p, int nC, const int *colBI,
+                                             const unsigned short *rowres, int *misc, int tid) {
+  const int lane = tid & 63, w = tid >> 6;
+  int base = 0;
+  for (int j0 = 0; j0 < nC; j0 += kThreads) {
+    const int j = j0 + tid;
+    bool m = false;
+    int r = kNone;
+    if (j < nC) {
+      r = colBI[j];
+      m = (r != kNone) && (!a.symmetric || rowres[r] == j);
+    }
+    const unsigned long long bal = __ballot(m);
+    const int prefix = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) misc[w] = __popcll(bal);
+    __syncthreads();
+    int woff = 0, total = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < kWaves; ++w2) {
+      const int cnt = misc[w2];
+      woff += (w2 < w) ? cnt : 0;
+      total += cnt;
+    }
+    if (m) {
+      const int k = base + woff + prefix;
+      if (k < a.cap) a.out_matches[p * a.cap + k] = (uint32_t)j | ((uint32_t)r << 16);
+    }
+    base += total;
+    __syncthreads();
+  }
+  if (tid == 0) a.out_counts[p] = base;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused MFMA kernel.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads, 2) match_fused_kernel(MatchArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char *bbuf = smem;                                      // [2][16 KiB]
+  int2 *scratch = (int2 *)(smem + 2 * kChunkBytes);                // [2][4][128]
+  int *colBV = (int *)(smem + 2 * kChunkBytes + 2 * kWaves * kChunkCols * 8);
+  int *colSV = colBV + a.ncap;
+  int *colBI = colSV + a.ncap;
+  unsigned short *rowres = (unsigned short *)(colBI + a.ncap);
+  int *misc = (int *)(rowres + a.ncap);  // [16]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long p = xcd_remap(blockIdx.x, a.n_pairs);
+
+  const int imgC = a.pairs[2 * p], imgR = a.pairs[2 * p + 1];
+  const int nC = a.counts[imgC], nR = a.counts[imgR];
+  if (nC < 2 || nR < 2) {  // matching.py:363-374 / knnMatch returns < 2 neighbours
+    if (tid == 0) {
+      a.out_counts[p] = 0;
+      a.out_flags[p] = 0;
+    }
+    return;
+  }
+  const int tC = (nC + 31) >> 5, tR = (nR + 31) >> 5;
+  const int8_t *tilesC = a.tiles + a.tile_off[imgC] * OSFM_TILE_BYTES;
+  const int8_t *tilesR = a.tiles + a.tile_off[imgR] * OSFM_TILE_BYTES;
+  const int32_t *normC = a.norms + a.tile_off[imgC] * 32;
+  const int32_t *normR = a.norms + a.tile_off[imgR] * 32;
+
+  for (int j = tid; j < a.ncap; j += kThreads) {
+    colBV[j] = INT_MIN;
+    colSV[j] = INT_MIN;
+    colBI[j] = kNone;
+    rowres[j] = kNone;
+  }
+  if (tid == 0) misc[8] = 0;
+
+  const int nchunks = (tC + kCT - 1) / kCT;
+  const int nrb = (tR + kWaves * kRT - 1) / (kWaves * kRT);
+  const int nsteps = nrb * nchunks;
+
+  // ---- stage chunk 0 ----
+  uint4 pre[kCT];
+#pragma unroll
+  for (int q = 0; q < kCT; ++q) {
+    pre[q] = make_uint4(0, 0, 0, 0);
+    if (q < tC) pre[q] = *(const uint4 *)(tilesC + (long)q * OSFM_TILE_BYTES + tid * 16);
+  }
+#pragma unroll
+  for (int q = 0; q < kCT; ++q) *(uint4 *)(bbuf + q * OSFM_TILE_BYTES + tid * 16) = pre[q];
+  __syncthreads();
+
+  v4i afrag[kRT][4];
+  int Rk[kRT][16];
+  int rbst[kRT][16], rsnd[kRT][16];
+  int nrt = 0, rt0 = 0;
+  int rb = 0, c = 0;
+  int flag = 0;
+
+  for (int s = 0; s < nsteps; ++s) {
+    if (c == 0) {
+      // ---- new row block: A operands + per-row constants into registers ----
+      rt0 = rb * (kWaves * kRT) + w * kRT;
+      nrt = min(kRT, max(0, tR - rt0));
+#pragma unroll
+      for (int rt = 0; rt < kRT; ++rt) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          v4i z = {0, 0, 0, 0};
+          afrag[rt][ks] = z;
+          if (rt < nrt)
+            afrag[rt][ks] = *(const v4i *)(tilesR + (long)(rt0 + rt) * OSFM_TILE_BYTES + ks * 1024 + lane * 16);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rowintile = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const int il = rt * 32 + rowintile;
+          int na = OSFM_PAD_NORM;
+          if (rt < nrt) na = normR[(rt0 + rt) * 32 + rowintile];
+          Rk[rt][r] = -(na << 6) + (63 - il);
+          rbst[rt][r] = INT_MIN;
+          rsnd[rt][r] = INT_MIN;
+        }
+      }
+    }
+    // ---- prefetch the next chunk of the column image into registers ----
+    const bool has_next = (s + 1 < nsteps);
+    const int cn = (c + 1 == nchunks) ? 0 : c + 1;
+    if (has_next) {
+#pragma unroll
+      for (int q = 0; q < kCT; ++q) {
+        pre[q] = make_uint4(0, 0, 0, 0);
+        if (cn * kCT + q < tC)
+          pre[q] = *(const uint4 *)(tilesC + (long)(cn * kCT + q) * OSFM_TILE_BYTES + tid * 16);
+      }
+    }
+    // ---- fold the previous step's per-wave column partials into the column state ----
+    if (s > 0 && tid < kChunkCols) {
+      const int sp = s - 1;
+      const int cp = (c == 0) ? nchunks - 1 : c - 1;
+      const int rbp = (c == 0) ? rb - 1 : rb;
+      const int j = cp * kChunkCols + tid;
+      int bv = colBV[j], sv = colSV[j], bi = colBI[j];
+#pragma unroll
+      for (int w2 = 0; w2 < kWaves; ++w2) {
+        const int2 pp = scratch[((sp & 1) * kWaves + w2) * kChunkCols + tid];
+        if (pp.x != INT_MIN) {
+          const int pv = pp.x >> 6;
+          const int pi = rbp * kRowsPerWG + w2 * (kRT * 32) + (63 - (pp.x & 63));
+          const int psv = pp.y >> 6;
+          sv = max(min(bv, pv), max(sv, psv));
+          if (pv > bv) {
+            bv = pv;
+            bi = pi;
+          }
+        }
+      }
+      colBV[j] = bv;
+      colSV[j] = sv;
+      colBI[j] = bi;
+    }
+    // ---- compute: 4 column tiles x nrt row tiles ----
+    const unsigned char *bb = bbuf + (s & 1) * kChunkBytes;
+#pragma unroll
+    for (int ct = 0; ct < kCT; ++ct) {
+      const int gct = c * kCT + ct;
+      int2 part = make_int2(INT_MIN, INT_MIN);
+      if (gct < tC && nrt > 0) {
+        v4i bf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) bf[ks] = *(const v4i *)(bb + ct * OSFM_TILE_BYTES + ks * 1024 + lane * 16);
+        const int nb = normC[gct * 32 + (lane & 31)];
+        const int ck = -(nb << 7) + (127 - gct);
+        int cb = INT_MIN, cs = INT_MIN;
+#pragma unroll
+        for (int rt = 0; rt < kRT; ++rt) {
+          if (rt < nrt) {
+            v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+              acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[rt][ks], bf[ks], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int sdot = acc[r];
+              const int key = (sdot << 8) + ck;  // (2S - nb) * 128 + (127 - gct)
+              rsnd[rt][r] = med3i(rbst[rt][r], rsnd[rt][r], key);
+              rbst[rt][r] = max(rbst[rt][r], key);
+              const int u = (sdot << 7) + Rk[rt][r];  // (2S - na) * 64 + (63 - il)
+              cs = med3i(cb, cs, u);
+              cb = max(cb, u);
+            }
+          }
+        }
+        const int ob = __shfl_xor(cb, 32), os = __shfl_xor(cs, 32);
+        part.x = max(cb, ob);
+        part.y = max(min(cb, ob), max(cs, os));
+      }
+      if (lane < 32) scratch[((s & 1) * kWaves + w) * kChunkCols + ct * 32 + lane] = part;
+    }
+    // ---- end of a row block: merge the 32 column classes of every row, ratio test ----
+    if (c == nchunks - 1) {
+#pragma unroll
+      for (int rt = 0; rt < kRT; ++rt) {
+        if (rt < nrt) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int kb = rbst[rt][r], k2 = rsnd[rt][r];
+            int bv = kb >> 7;
+            int bj = (127 - (kb & 127)) * 32 + (lane & 31);
+            int sv = k2 >> 7;
+#pragma unroll
+            for (int m = 1; m < 32; m <<= 1) {
+              const int ov = __shfl_xor(bv, m), oj = __shfl_xor(bj, m), os = __shfl_xor(sv, m);
+              const int nsv = max(min(bv, ov), max(sv, os));
+              const bool take = (ov > bv) || (ov == bv && oj < bj);
+              bv = take ? ov : bv;
+              bj = take ? oj : bj;
+              sv = nsv;
+            }
+            const int rowintile = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int row = (rt0 + rt) * 32 + rowintile;
+            if ((lane & 31) == 0 && row < nR) {
+              const int na = normR[row];
+              const int d1 = na - bv, d2 = na - sv;
+              rowres[row] = ratio_ok(d1, d2, a.ratio) ? bj : kNone;
+              if (d2 >= kCollisionD2) flag = 1;
+            }
+          }
+        }
+      }
+    }
+    // ---- publish the prefetched chunk ----
+    if (has_next) {
+      unsigned char *nb2 = bbuf + ((s + 1) & 1) * kChunkBytes;
+#pragma unroll
+      for (int q = 0; q < kCT; ++q) *(uint4 *)(nb2 + q * OSFM_TILE_BYTES + tid * 16) = pre[q];
+    }
+    __syncthreads();
+    ++c;
+    if (c == nchunks) {
+      c = 0;
+      ++rb;
+    }
+  }
+  // ---- last step's column partials ----
+  if (tid < kChunkCols) {
+    const int sp = nsteps - 1;
+    const int j = (nchunks - 1) * kChunkCols + tid;
+    int bv = colBV[j], sv = colSV[j], bi = colBI[j];
+#pragma unroll
+    for (int w2 = 0; w2 < kWaves; ++w2) {
+      const int2 pp = scratch[((sp & 1) * kWaves + w2) * kChunkCols + tid];
+      if (pp.x != INT_MIN) {
+        const int pv = pp.x >> 6;
+        const int pi = (nrb - 1) * kRowsPerWG + w2 * (kRT * 32) + (63 - (pp.x & 63));
+        const int psv = pp.y >> 6;
+        sv = max(min(bv, pv), max(sv, psv));
+        if (pv > bv) {
+          bv = pv;
+          bi = pi;
+        }
+      }
+    }
+    colBV[j] = bv;
+    colSV[j] = sv;
+    colBI[j] = bi;
+  }
+  __syncthreads();
+  // ---- column side ratio test ----
+  for (int j = tid; j < nC; j += kThreads) {
+    const int nb = normC[j];
+    const int d1 = nb - colBV[j], d2 = nb - colSV[j];
+    if (!ratio_ok(d1, d2, a.ratio)) colBI[j] = kNone;
+    if (d2 >= kCollisionD2) flag = 1;
+  }
+  if (flag) misc[8] = 1;
+  __syncthreads();
+  if (tid == 0) a.out_flags[p] = misc[8];
+  emit_matches(a, p, nC, colBI, rowres, misc, tid);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Exact kernel: float-key semantics of cv2 (top-2 selected on sqrtf(d^2) with lowest-index
+// ties), VALU only.  Used (a) for the rare pairs whose second-nearest d^2 >= 2^22, where distinct
+// integers may round to the same float distance, and (b) as an on-GPU cross-check of the fused
+// kernel.  One workgroup per pair, one thread per query feature.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_row(const int8_t *tiles, int row, v4i out[8]) {
+  const int8_t *t = tiles + (long)(row >> 5) * OSFM_TILE_BYTES + (row & 31) * 16;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    out[2 * ks] = *(const v4i *)(t + ks * 1024);
+    out[2 * ks + 1] = *(const v4i *)(t + ks * 1024 + 512);
+  }
+}
+
+__device__ void exact_direction(const int8_t *tilesQ, const int32_t *normQ, int nQ, const int8_t *tilesT,
+                                const int32_t *normT, int nT, double ratio, int tid, int *res_int,
+                                unsigned short *res_u16) {
+  for (int q = tid; q < nQ; q += kThreads) {
+    v4i qa[8];
+    load_row(tilesQ, q, qa);
+    const int nq = normQ[q];
+    float bd0 = INFINITY, bd1 = INFINITY;
+    int bi0 = kNone;
+    for (int t = 0; t < nT; ++t) {
+      v4i ta[8];
+      load_row(tilesT, t, ta);
+      int sdot = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sdot = __builtin_amdgcn_sdot4(qa[k][e], ta[k][e], sdot, false);
+      const int d2i = nq + normT[t] - 2 * sdot;
+      const float d = sqrtf((float)d2i);
+      if (d < bd1) {  // cv2 batchDistance K=2 insertion
+        if (bd0 > d) {
+          bd1 = bd0;
+          bd0 = d;
+          bi0 = t;
+        } else {
+          bd1 = d;
+        }
+      }
+    }
+    const bool ok = (double)bd0 < ratio * (double)bd1;
+    const int v = ok ? bi0 : kNone;
+    if (res_int) res_int[q] = v;
+    if (res_u16) res_u16[q] = (unsigned short)v;
+  }
+}
+
+__global__ void __launch_bounds__(kThreads) match_exact_kernel(MatchArgs a, int only_flagged) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int *colBI = (int *)smem;
+  unsigned short *rowres = (unsigned short *)(colBI + a.ncap);
+  int *misc = (int *)(rowres + a.ncap);
+  const int tid = threadIdx.x;
+  const long p = blockIdx.x;
+  if (only_flagged && a.out_flags[p] == 0) return;
+  const int imgC = a.pairs[2 * p], imgR = a.pairs[2 * p + 1];
+  const int nC = a.counts[imgC], nR = a.counts[imgR];
+  if (nC < 2 || nR < 2) {
+    if (tid == 0) a.out_counts[p] = 0;
+    return;
+  }
+  const int8_t *tilesC = a.tiles + a.tile_off[imgC] * OSFM_TILE_BYTES;
+  const int8_t *tilesR = a.tiles + a.tile_off[imgR] * OSFM_TILE_BYTES;
+  const int32_t *normC = a.norms + a.tile_off[imgC] * 32;
+  const int32_t *normR = a.norms + a.tile_off[imgR] * 32;
+  exact_direction(tilesC, normC, nC, tilesR, normR, nR, a.ratio, tid, colBI, nullptr);
+  if (a.symmetric) exact_direction(tilesR, normR, nR, tilesC, normC, nC, a.ratio, tid, nullptr, rowres);
+  __syncthreads();
+  emit_matches(a, p, nC, colBI, rowres, misc, tid);
+}
+
+}  // namespace
+
+size_t osfm_match_lds_bytes(int ncap) {
+  return (size_t)2 * kChunkBytes + 2 * kWaves * kChunkCols * 8 + (size_t)ncap * 14 + 64;
+}
+
+int osfm_launch_match(osfm_ctx *ctx, const osfm_store *store, const int32_t *d_pairs, int64_t n_pairs,
+                      double ratio, int symmetric, int cap, int32_t *d_counts, uint32_t *d_matches,
+                      int32_t *d_flags, bool exact_kernel) {
+  if (n_pairs == 0) return OSFM_OK;
+  MatchArgs a;
+  a.tiles = store->d_tiles;
+  a.norms = store->d_norms;
+  a.tile_off = store->d_tile_off;
+  a.counts = store->d_counts;
+  a.pairs = d_pairs;
+  a.n_pairs = n_pairs;
+  a.ratio = ratio;
+  a.symmetric = symmetric;
+  a.cap = cap;
+  a.ncap = ((store->max_count + 127) / 128) * 128;
+  if (a.ncap < 128) a.ncap = 128;
+  a.out_counts = d_counts;
+  a.out_matches = d_matches;
+  a.out_flags = d_flags;
+  OSFM_REQUIRE(a.ncap <= OSFM_MAX_FEATURES, OSFM_E_UNSUPPORTED, "more than %d features in an image", OSFM_MAX_FEATURES);
+  OSFM_REQUIRE(n_pairs < (1ll << 31), OSFM_E_INVALID, "too many pairs in one launch");
+  if (!exact_kernel) {
+    const size_t lds = osfm_match_lds_bytes(a.ncap);
+    static bool attr_set = false;
+    if (!attr_set) {
+      OSFM_HIP(hipFuncSetAttribute((const void *)match_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      OSFM_HIP(hipFuncSetAttribute((const void *)match_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(match_fused_kernel, dim3((unsigned)n_pairs), dim3(kThreads), lds, ctx->stream, a);
+  } else {
+    const size_t lds = (size_t)a.ncap * 6 + 64;
+    hipLaunchKernelGGL(match_exact_kernel, dim3((unsigned)n_pairs), dim3(kThreads), lds, ctx->stream, a,
+                       d_flags != nullptr ? 1 : 0);
+  }
+  OSFM_HIP(hipGetLastError());
+  return OSFM_OK;
+}

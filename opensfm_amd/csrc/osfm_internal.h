@@ -1,0 +1,76 @@
+// Internal declarations shared by the translation units of libosfm_mi355.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/osfm_mi355.h"
+
+void osfm_set_error(const char *fmt, ...);
+
+#define OSFM_HIP(call)                                                                      \
+  do {                                                                                      \
+    hipError_t e_ = (call);                                                                 \
+    if (e_ != hipSuccess) {                                                                 \
+      osfm_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_));  \
+      return OSFM_E_HIP;                                                                    \
+    }                                                                                       \
+  } while (0)
+
+#define OSFM_REQUIRE(cond, code, ...) \
+  do {                                \
+    if (!(cond)) {                    \
+      osfm_set_error(__VA_ARGS__);    \
+      return (code);                  \
+    }                                 \
+  } while (0)
+
+struct osfm_ctx {
+  int device = 0;
+  int num_cus = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+
+// Tile = 32 descriptors x 128 int8 in MFMA-operand order (4 KiB):
+//   byte offset of (row r, k) = (k/32)*1024 + (((k%32)/16)*32 + r)*16 + (k%16)
+// i.e. [ks 0..3][lane 0..63][16 B] with lane = half*32 + row, so one wave loads an A/B operand
+// of v_mfma_i32_32x32x32_i8 with a single fully coalesced 1 KiB dwordx4 load per k-step.
+constexpr int OSFM_TILE_ROWS = 32;
+constexpr int OSFM_TILE_BYTES = 4096;
+constexpr int OSFM_PAD_NORM = 1 << 23;  // norm of padding rows: never wins a top-2
+
+struct osfm_store {
+  osfm_ctx *ctx = nullptr;
+  int n_images = 0;
+  std::vector<int32_t> counts;      // features per image
+  std::vector<int64_t> row_off;     // unpadded row offsets (n_images + 1)
+  std::vector<int64_t> tile_off;    // tile offsets (n_images + 1)
+  int max_count = 0;
+  int8_t *d_tiles = nullptr;        // total_tiles * 4096 : (u8 - 128) in tile order
+  int32_t *d_norms = nullptr;       // total_tiles * 32 : sum (u8-128)^2, padding = OSFM_PAD_NORM
+  double *d_pts = nullptr;          // total_tiles * 32 * 2 (padded rows zero)
+  int32_t *d_counts = nullptr;      // n_images
+  int64_t *d_tile_off = nullptr;    // n_images + 1
+  int64_t bytes = 0;
+};
+
+struct osfm_match_result {
+  std::vector<int32_t> counts;
+  std::vector<int32_t> matches;  // total x 2
+};
+
+// match.hip
+int osfm_launch_match(osfm_ctx *ctx, const osfm_store *store, const int32_t *d_pairs, int64_t n_pairs,
+                      double ratio, int symmetric, int cap, int32_t *d_counts, uint32_t *d_matches,
+                      int32_t *d_flags, bool exact_kernel);
+// ransac.hip
+// in place: counts/matches of each pair are replaced by the inliers (or 0 when the pair fails a gate)
+int osfm_launch_ransac_pairs(osfm_ctx *ctx, const osfm_store *store, const int32_t *d_pairs,
+                             int64_t n_pairs, int cap, int min_match, double thr, double conf,
+                             int max_iters, int32_t *d_counts, uint32_t *d_matches, double *d_F_or_null);
+int osfm_launch_ransac_single(osfm_ctx *ctx, const double *d_p1, const double *d_p2, int n, double thr,
+                              double conf, int max_iters, double *d_F, uint8_t *d_mask,
+                              int32_t *d_info);

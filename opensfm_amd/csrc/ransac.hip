@@ -1,0 +1,601 @@
+// ransac.hip -- batched fundamental-matrix RANSAC for gfx950 (MI355X).
+//
+// Replaces cv2.findFundamentalMat(p1, p2, FM_RANSAC, 0.004, 0.9999) as called by
+// robust_match_fundamental (opensfm/matching.py:780-802), plus the two min-match gates of
+// matching.match (matching.py:590-598, 632-634), for every pair of a batch: one workgroup per
+// image pair.  Results are bit-identical to the sequential algorithm (same RNG stream, same
+// hypothesis order, same adaptive stopping rule), but executed batch-parallel:
+//   1. lane 0 draws the next kBatch 7-point subsets from the cv::RNG stream (sequential, cheap);
+//   2. kBatch lanes solve their 7-point problems in parallel (fp64 Gauss-Jordan + cubic);
+//   3. every wavefront scores whole models: 64 correspondences per step, ballot + popcount
+//      ("wavefront-per-model reduction");
+//   4. lane 0 replays the batch in order, applying `good > max(best, 6)` and
+//      RANSACUpdateNumIters, and stops exactly where the sequential loop would.
+// All fp64 arithmetic is plain + - * / sqrt in a fixed order (this file is compiled with
+// -ffp-contract=off), so it reproduces the CPU statement of the same algorithm bit for bit.
+#include "osfm_internal.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = 4;
+constexpr int kBatch = 64;  // hypotheses generated per round
+constexpr int kMaxPts = OSFM_MAX_FEATURES;
+
+struct CvRng {
+  unsigned long long state;
+  __device__ unsigned next() {
+    state = (unsigned long long)(unsigned)state * 4164903690ULL + (unsigned)(state >> 32);
+    return (unsigned)state;
+  }
+  __device__ int uniform(int a, int b) { return a == b ? a : (int)(next() % (unsigned)(b - a) + (unsigned)a); }
+};
+
+__device__ double det_log(double x) {
+  int e;
+  double m = frexp(x, &e);
+  if (m < 0.70710678118654752440) {
+    m = m * 2.0;
+    e -= 1;
+  }
+  const double t = (m - 1.0) / (m + 1.0);
+  const double t2 = t * t;
+  double s = 1.0 / 27.0;
+  s = s * t2 + 1.0 / 25.0;
+  s = s * t2 + 1.0 / 23.0;
+  s = s * t2 + 1.0 / 21.0;
+  s = s * t2 + 1.0 / 19.0;
+  s = s * t2 + 1.0 / 17.0;
+  s = s * t2 + 1.0 / 15.0;
+  s = s * t2 + 1.0 / 13.0;
+  s = s * t2 + 1.0 / 11.0;
+  s = s * t2 + 1.0 / 9.0;
+  s = s * t2 + 1.0 / 7.0;
+  s = s * t2 + 1.0 / 5.0;
+  s = s * t2 + 1.0 / 3.0;
+  s = s * t2 + 1.0;
+  return (double)e * 0x1.62e42fefa39efp-1 + 2.0 * t * s;
+}
+
+__device__ int update_num_iters(double p, double ep, int max_iters) {
+  if (p < 0.) p = 0.;
+  if (p > 1.) p = 1.;
+  if (ep < 0.) ep = 0.;
+  if (ep > 1.) ep = 1.;
+  double num = 1. - p;
+  if (num < 2.2250738585072014e-308) num = 2.2250738585072014e-308;
+  const double w = 1. - ep, w2 = w * w, w4 = w2 * w2;
+  const double wn = w4 * w2 * w;
+  double denom = 1. - wn;
+  if (denom < 2.2250738585072014e-308) return 0;
+  num = det_log(num);
+  denom = det_log(denom);
+  if (denom >= 0 || -num >= max_iters * (-denom)) return max_iters;
+  return (int)rint(num / denom);
+}
+
+__device__ __forceinline__ double det3(const double *a, const double *b, const double *c) {
+  return a[0] * (b[1] * c[2] - b[2] * c[1]) - a[1] * (b[0] * c[2] - b[2] * c[0]) + a[2] * (b[0] * c[1] - b[1] * c[0]);
+}
+
+__device__ int solve_cubic_monic(double a, double b, double c, double *roots) {
+  double R = fabs(a);
+  if (fabs(b) > R) R = fabs(b);
+  if (fabs(c) > R) R = fabs(c);
+  R = R + 1.0;
+  if (!(R < 1e300)) return 0;
+  double lo = -R, hi = R;
+  for (int it = 0; it < 2200; it++) {
+    const double mid = 0.5 * (lo + hi);
+    if (!(mid > lo && mid < hi)) break;
+    const double pm = ((mid + a) * mid + b) * mid + c;
+    if (pm > 0)
+      hi = mid;
+    else
+      lo = mid;
+  }
+  const double plo = ((lo + a) * lo + b) * lo + c, phi = ((hi + a) * hi + b) * hi + c;
+  const double r = (fabs(plo) <= fabs(phi)) ? lo : hi;
+  int n = 0;
+  roots[n++] = r;
+  const double p = a + r;
+  const double q = b + p * r;
+  const double disc = p * p - 4.0 * q;
+  if (disc > 0) {
+    const double sq = sqrt(disc);
+    const double t = (p >= 0) ? -0.5 * (p + sq) : -0.5 * (p - sq);
+    roots[n++] = t;
+    if (t != 0) roots[n++] = q / t;
+  } else if (disc == 0) {
+    roots[n++] = -0.5 * p;
+  }
+  return n;
+}
+
+// 7-point algorithm; A is kept in private memory (7x9 doubles).
+__device__ int run_7point(const double *m1, const double *m2, double *F) {
+  double A[7][9];
+  for (int i = 0; i < 7; i++) {
+    const double x0 = m1[2 * i], y0 = m1[2 * i + 1], x1 = m2[2 * i], y1 = m2[2 * i + 1];
+    A[i][0] = x1 * x0;
+    A[i][1] = x1 * y0;
+    A[i][2] = x1;
+    A[i][3] = y1 * x0;
+    A[i][4] = y1 * y0;
+    A[i][5] = y1;
+    A[i][6] = x0;
+    A[i][7] = y0;
+    A[i][8] = 1.0;
+  }
+  int colperm[9];
+  for (int c = 0; c < 9; c++) colperm[c] = c;
+  for (int k = 0; k < 7; k++) {
+    int pr = k, pc = k;
+    double best = -1.0;
+    for (int r = k; r < 7; r++)
+      for (int c = k; c < 9; c++) {
+        const double v = fabs(A[r][c]);
+        if (v > best) {
+          best = v;
+          pr = r;
+          pc = c;
+        }
+      }
+    if (!(best > 1e-300)) return 0;
+    if (pr != k)
+      for (int c = 0; c < 9; c++) {
+        const double t = A[k][c];
+        A[k][c] = A[pr][c];
+        A[pr][c] = t;
+      }
+    if (pc != k) {
+      for (int r = 0; r < 7; r++) {
+        const double t = A[r][k];
+        A[r][k] = A[r][pc];
+        A[r][pc] = t;
+      }
+      const int t = colperm[k];
+      colperm[k] = colperm[pc];
+      colperm[pc] = t;
+    }
+    const double inv = 1.0 / A[k][k];
+    for (int c = 0; c < 9; c++) A[k][c] = A[k][c] * inv;
+    for (int r = 0; r < 7; r++) {
+      if (r == k) continue;
+      const double f = A[r][k];
+      for (int c = 0; c < 9; c++) A[r][c] = A[r][c] - f * A[k][c];
+    }
+  }
+  double v1[9], v2[9];
+  for (int k = 0; k < 7; k++) {
+    v1[colperm[k]] = -A[k][7];
+    v2[colperm[k]] = -A[k][8];
+  }
+  v1[colperm[7]] = 1.0;
+  v1[colperm[8]] = 0.0;
+  v2[colperm[7]] = 0.0;
+  v2[colperm[8]] = 1.0;
+  double U[9], W[9];
+  for (int i = 0; i < 9; i++) {
+    U[i] = v1[i] - v2[i];
+    W[i] = v2[i];
+  }
+  const double a3 = det3(U, U + 3, U + 6);
+  const double a0 = det3(W, W + 3, W + 6);
+  const double a2 = det3(W, U + 3, U + 6) + det3(U, W + 3, U + 6) + det3(U, U + 3, W + 6);
+  const double a1 = det3(U, W + 3, W + 6) + det3(W, U + 3, W + 6) + det3(W, W + 3, U + 6);
+  double roots[3];
+  int nr = 0;
+  if (a3 != 0) {
+    nr = solve_cubic_monic(a2 / a3, a1 / a3, a0 / a3, roots);
+  } else if (a2 != 0) {
+    const double p = a1 / a2, q = a0 / a2;
+    const double disc = p * p - 4.0 * q;
+    if (disc > 0) {
+      const double sq = sqrt(disc);
+      const double t = (p >= 0) ? -0.5 * (p + sq) : -0.5 * (p - sq);
+      roots[nr++] = t;
+      if (t != 0) roots[nr++] = q / t;
+    } else if (disc == 0) {
+      roots[nr++] = -0.5 * p;
+    }
+  } else if (a1 != 0) {
+    roots[nr++] = -a0 / a1;
+  }
+  int n = 0;
+  for (int k = 0; k < nr; k++) {
+    double lambda = roots[k], mu = 1.0;
+    const double s = U[8] * lambda + W[8];
+    double *Fk = F + 9 * n;
+    if (fabs(s) > 2.220446049250313e-16) {
+      mu = 1.0 / s;
+      lambda = lambda * mu;
+      Fk[8] = 1.0;
+    } else {
+      Fk[8] = 0.0;
+    }
+    int ok = 1;
+    for (int i = 0; i < 8; i++) {
+      Fk[i] = U[i] * lambda + W[i] * mu;
+      if (!(fabs(Fk[i]) < 1e300)) ok = 0;
+    }
+    if (ok) n++;
+  }
+  return n;
+}
+
+__device__ __forceinline__ float epi_error(const double *F, double x1, double y1, double x2, double y2) {
+  double a, b, c, d1, d2, s1, s2;
+  a = F[0] * x1 + F[1] * y1 + F[2];
+  b = F[3] * x1 + F[4] * y1 + F[5];
+  c = F[6] * x1 + F[7] * y1 + F[8];
+  s2 = 1. / (a * a + b * b);
+  d2 = x2 * a + y2 * b + c;
+  a = F[0] * x2 + F[3] * y2 + F[6];
+  b = F[1] * x2 + F[4] * y2 + F[7];
+  c = F[2] * x2 + F[5] * y2 + F[8];
+  s1 = 1. / (a * a + b * b);
+  d1 = x1 * a + y1 * b + c;
+  const double e1 = d1 * d1 * s1, e2 = d2 * d2 * s2;
+  return (float)((e1 < e2) ? e2 : e1);
+}
+
+__device__ bool have_collinear(const double *m, int count) {
+  const int i = count - 1;
+  for (int j = 0; j < i; j++) {
+    const double dx1 = m[2 * j] - m[2 * i];
+    const double dy1 = m[2 * j + 1] - m[2 * i + 1];
+    for (int k = 0; k < j; k++) {
+      const double dx2 = m[2 * k] - m[2 * i];
+      const double dy2 = m[2 * k + 1] - m[2 * i + 1];
+      if (fabs(dx2 * dy1 - dy2 * dx1) <= 1.1920928955078125e-07 * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2)))
+        return true;
+    }
+  }
+  return false;
+}
+
+// LDS image of a RANSAC problem: correspondences as float4 (x1, y1, x2, y2) -- cv2 converts the
+// points to CV_32F before estimating, so float storage is exact.
+struct RansacShared {
+  float4 *pts;  // [n] in dynamic LDS behind this struct
+  double models[kBatch][27];
+  unsigned short subset[kBatch][8];
+  unsigned char nmodels[kBatch];
+  unsigned char subset_ok[kBatch];
+  int good[kBatch][3];
+  double best[9];
+  int ctrl[8];  // 0: niters, 1: max_good, 2: done, 3: iters run, 4: found_any
+  unsigned long long rng_state;
+};
+
+// Runs the RANSAC loop over the n correspondences already staged in sh.pts.
+// On return sh.ctrl[1] = inlier count of the best model (0: none), sh.best = its F.
+__device__ void ransac_core(RansacShared &sh, int n, double thr, double conf, int max_iters, int tid) {
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (thr <= 0) thr = 3;
+  if (conf < 2.220446049250313e-16 || conf > 1 - 2.220446049250313e-16) conf = 0.99;
+  const float t = (float)(thr * thr);
+  if (tid == 0) {
+    sh.ctrl[0] = max_iters > 1 ? max_iters : 1;
+    sh.ctrl[1] = 0;
+    sh.ctrl[2] = 0;
+    sh.ctrl[3] = 0;
+    sh.rng_state = ~0ull;
+  }
+  __syncthreads();
+  for (int it0 = 0;; it0 += kBatch) {
+    // ---- 1. subsets (sequential RNG stream) ----
+    if (tid == 0) {
+      CvRng rng{sh.rng_state};
+      const int niters = sh.ctrl[0];
+      for (int b = 0; b < kBatch; ++b) sh.subset_ok[b] = 0;
+      for (int b = 0; b < kBatch; ++b) {
+        if (it0 + b >= niters) break;  // never consumed by the sequential loop
+        int idx[7];
+        double ms1[14], ms2[14];
+        bool found = false;
+        for (int attempt = 0; attempt < 10000 && !found; ++attempt) {
+          for (int i = 0; i < 7; ++i) {
+            int idx_i;
+            for (;;) {
+              idx_i = rng.uniform(0, n);
+              bool dup = false;
+              for (int j = 0; j < i; j++)
+                if (idx[j] == idx_i) dup = true;
+              if (!dup) break;
+            }
+            idx[i] = idx_i;
+            const float4 q = sh.pts[idx_i];
+            ms1[2 * i] = (double)q.x;
+            ms1[2 * i + 1] = (double)q.y;
+            ms2[2 * i] = (double)q.z;
+            ms2[2 * i + 1] = (double)q.w;
+          }
+          found = !have_collinear(ms1, 7) && !have_collinear(ms2, 7);
+        }
+        if (found) {
+          sh.subset_ok[b] = 1;
+          for (int i = 0; i < 7; ++i) sh.subset[b][i] = (unsigned short)idx[i];
+        } else {
+          break;  // sequential loop stops here (iter == 0: no model at all)
+        }
+      }
+      sh.rng_state = rng.state;
+    }
+    __syncthreads();
+    // ---- 2. hypotheses ----
+    if (tid < kBatch) {
+      int nm = 0;
+      if (sh.subset_ok[tid]) {
+        double ms1[14], ms2[14];
+        for (int i = 0; i < 7; ++i) {
+          const float4 q = sh.pts[sh.subset[tid][i]];
+          ms1[2 * i] = (double)q.x;
+          ms1[2 * i + 1] = (double)q.y;
+          ms2[2 * i] = (double)q.z;
+          ms2[2 * i + 1] = (double)q.w;
+        }
+        nm = run_7point(ms1, ms2, sh.models[tid]);
+      }
+      sh.nmodels[tid] = (unsigned char)nm;
+    }
+    __syncthreads();
+    // ---- 3. scoring: one wavefront per model ----
+    for (int mi = w; mi < kBatch * 3; mi += kWaves) {
+      const int b = mi / 3, k = mi - 3 * b;
+      if (k >= sh.nmodels[b]) continue;
+      double F[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) F[i] = sh.models[b][9 * k + i];
+      int good = 0;
+      for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        bool in = false;
+        if (i < n) {
+          const float4 q = sh.pts[i];
+          in = epi_error(F, (double)q.x, (double)q.y, (double)q.z, (double)q.w) <= t;
+        }
+        good += __popcll(__ballot(in));
+      }
+      if (lane == 0) sh.good[b][k] = good;
+    }
+    __syncthreads();
+    // ---- 4. sequential replay of the batch ----
+    if (tid == 0) {
+      int niters = sh.ctrl[0], max_good = sh.ctrl[1];
+      int iter = it0;
+      bool done = false;
+      for (int b = 0; b < kBatch; ++b, ++iter) {
+        if (iter >= niters) {
+          done = true;
+          break;
+        }
+        if (!sh.subset_ok[b]) {  // getSubset failed: `if (iter == 0) return false; break;`
+          done = true;
+          break;
+        }
+        const int nm = sh.nmodels[b];
+        for (int k = 0; k < nm; ++k) {
+          const int good = sh.good[b][k];
+          const int lim = max_good > 6 ? max_good : 6;
+          if (good > lim) {
+            for (int i = 0; i < 9; ++i) sh.best[i] = sh.models[b][9 * k + i];
+            max_good = good;
+            niters = update_num_iters(conf, (double)(n - good) / n, niters);
+          }
+        }
+      }
+      if (!done && iter >= niters) done = true;
+      sh.ctrl[0] = niters;
+      sh.ctrl[1] = max_good;
+      sh.ctrl[2] = done ? 1 : 0;
+      sh.ctrl[3] = iter;
+    }
+    __syncthreads();
+    if (sh.ctrl[2]) break;
+  }
+}
+
+struct RansacPairsArgs {
+  const double *pts;  // store keypoints, padded tile rows
+  const int64_t *tile_off;
+  const int32_t *pairs;
+  long n_pairs;
+  int cap;
+  int min_match;
+  double thr, conf;
+  int max_iters;
+  int32_t *counts;
+  uint32_t *matches;
+  double *F_out;
+};
+
+__global__ void __launch_bounds__(kThreads) ransac_pairs_kernel(RansacPairsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  RansacShared &sh = *reinterpret_cast<RansacShared *>(smem);
+  const int capr = (a.cap + 3) & ~3;
+  float4 *ptsbuf = reinterpret_cast<float4 *>(smem + sizeof(RansacShared));  // [capr]
+  uint32_t *mlist = reinterpret_cast<uint32_t *>(ptsbuf + capr);             // [capr]
+  int *misc = reinterpret_cast<int *>(mlist + capr);                         // [8]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, w = tid >> 6;
+  const long p = blockIdx.x;
+  const int n = min(a.counts[p], a.cap);
+  // gates: matching.py:590-598 (min match) and matching.py:787-788 (< 8)
+  if (n < a.min_match || n < 8) {
+    if (tid == 0) a.counts[p] = 0;
+    return;
+  }
+  const int img1 = a.pairs[2 * p], img2 = a.pairs[2 * p + 1];
+  const double *pts1 = a.pts + a.tile_off[img1] * 64;
+  const double *pts2 = a.pts + a.tile_off[img2] * 64;
+  if (tid == 0) sh.pts = ptsbuf;
+  for (int k = tid; k < n; k += kThreads) {
+    const uint32_t m = a.matches[p * a.cap + k];
+    mlist[k] = m;
+    const int i = m & 0xFFFF, j = m >> 16;
+    ptsbuf[k] = make_float4((float)pts1[2 * i], (float)pts1[2 * i + 1], (float)pts2[2 * j], (float)pts2[2 * j + 1]);
+  }
+  __syncthreads();
+  ransac_core(sh, n, a.thr, a.conf, a.max_iters, tid);
+  const int max_good = sh.ctrl[1];
+  if (a.F_out && tid < 9) a.F_out[p * 9 + tid] = max_good > 0 ? sh.best[tid] : 0.0;
+  // matching.py:798-800: F is None or F[2,2] == 0 -> no matches
+  if (max_good <= 0 || sh.best[8] == 0.0) {
+    if (tid == 0) a.counts[p] = 0;
+    return;
+  }
+  double F[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) F[i] = sh.best[i];
+  const double thr = a.thr <= 0 ? 3 : a.thr;
+  const float t = (float)(thr * thr);
+  // final mask + ordered compaction, in place
+  int base = 0;
+  for (int k0 = 0; k0 < n; k0 += kThreads) {
+    const int k = k0 + tid;
+    bool in = false;
+    if (k < n) {
+      const float4 q = sh.pts[k];
+      in = epi_error(F, (double)q.x, (double)q.y, (double)q.z, (double)q.w) <= t;
+    }
+    const unsigned long long bal = __ballot(in);
+    const int prefix = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) misc[w] = __popcll(bal);
+    __syncthreads();
+    int woff = 0, total = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < kWaves; ++w2) {
+      const int cnt = misc[w2];
+      woff += (w2 < w) ? cnt : 0;
+      total += cnt;
+    }
+    if (in) a.matches[p * a.cap + base + woff + prefix] = mlist[k];
+    base += total;
+    __syncthreads();
+  }
+  // matching.py:632-634
+  if (tid == 0) a.counts[p] = base >= a.min_match ? base : 0;
+}
+
+__global__ void __launch_bounds__(kThreads) ransac_single_kernel(const double *p1, const double *p2, int n, double thr,
+                                                                   double conf, int max_iters, double *F_out,
+                                                                   uint8_t *mask, int32_t *info) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  RansacShared &sh = *reinterpret_cast<RansacShared *>(smem);
+  const int tid = threadIdx.x;
+  float4 *ptsbuf = reinterpret_cast<float4 *>(smem + sizeof(RansacShared));
+  if (tid == 0) sh.pts = ptsbuf;
+  for (int k = tid; k < n; k += kThreads)
+    ptsbuf[k] = make_float4((float)p1[2 * k], (float)p1[2 * k + 1], (float)p2[2 * k], (float)p2[2 * k + 1]);
+  __syncthreads();
+  ransac_core(sh, n, thr, conf, max_iters, tid);
+  const int max_good = sh.ctrl[1];
+  if (tid == 0) {
+    info[0] = max_good > 0 ? 1 : 0;
+    info[1] = sh.ctrl[3];
+    info[2] = max_good;
+  }
+  if (tid < 9) F_out[tid] = max_good > 0 ? sh.best[tid] : 0.0;
+  double F[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) F[i] = sh.best[i];
+  const double thr2 = thr <= 0 ? 3 : thr;
+  const float t = (float)(thr2 * thr2);
+  for (int k = tid; k < n; k += kThreads) {
+    const float4 q = sh.pts[k];
+    mask[k] = (max_good > 0 && epi_error(F, (double)q.x, (double)q.y, (double)q.z, (double)q.w) <= t) ? 1 : 0;
+  }
+}
+
+}  // namespace
+
+int osfm_launch_ransac_pairs(osfm_ctx *ctx, const osfm_store *store, const int32_t *d_pairs, int64_t n_pairs, int cap,
+                             int min_match, double thr, double conf, int max_iters, int32_t *d_counts,
+                             uint32_t *d_matches, double *d_F_or_null) {
+  if (n_pairs == 0) return OSFM_OK;
+  OSFM_REQUIRE(cap <= kMaxPts, OSFM_E_UNSUPPORTED, "cap %d > %d", cap, kMaxPts);
+  RansacPairsArgs a;
+  a.pts = store->d_pts;
+  a.tile_off = store->d_tile_off;
+  a.pairs = d_pairs;
+  a.n_pairs = n_pairs;
+  a.cap = cap;
+  a.min_match = min_match;
+  a.thr = thr;
+  a.conf = conf;
+  a.max_iters = max_iters;
+  a.counts = d_counts;
+  a.matches = d_matches;
+  a.F_out = d_F_or_null;
+  const size_t lds = sizeof(RansacShared) + (size_t)((cap + 3) & ~3) * 20 + 64;
+  static bool attr_set = false;
+  if (!attr_set) {
+    OSFM_HIP(hipFuncSetAttribute((const void *)ransac_pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    OSFM_HIP(hipFuncSetAttribute((const void *)ransac_single_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(ransac_pairs_kernel, dim3((unsigned)n_pairs), dim3(kThreads), lds, ctx->stream, a);
+  OSFM_HIP(hipGetLastError());
+  return OSFM_OK;
+}
+
+int osfm_launch_ransac_single(osfm_ctx *ctx, const double *d_p1, const double *d_p2, int n, double thr, double conf,
+                              int max_iters, double *d_F, uint8_t *d_mask, int32_t *d_info) {
+  OSFM_REQUIRE(n <= kMaxPts, OSFM_E_UNSUPPORTED, "more than %d correspondences", kMaxPts);
+  static bool attr_set = false;
+  if (!attr_set) {
+    OSFM_HIP(hipFuncSetAttribute((const void *)ransac_single_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(ransac_single_kernel, dim3(1), dim3(kThreads), sizeof(RansacShared) + (size_t)((n + 3) & ~3) * 16 + 64, ctx->stream, d_p1, d_p2, n,
+                     thr, conf, max_iters, d_F, d_mask, d_info);
+  OSFM_HIP(hipGetLastError());
+  return OSFM_OK;
+}
+
+extern "C" int osfm_ransac_fundamental(osfm_ctx *ctx, const double *p1, const double *p2, int n, double thr, double conf,
+                                       int max_iters, double F[9], uint8_t *mask, int *found, int *iters_run) {
+  OSFM_REQUIRE(ctx && p1 && p2 && F && mask && found, OSFM_E_INVALID, "osfm_ransac_fundamental: null argument");
+  *found = 0;
+  if (iters_run) *iters_run = 0;
+  for (int i = 0; i < n; ++i) mask[i] = 0;
+  if (n < 7) return OSFM_OK;  // cv2: npoints < 7 -> empty Mat
+  OSFM_REQUIRE(n >= 15, OSFM_E_UNSUPPORTED, "n = %d < 15 takes cv2's LMedS / 7-point branch, which is not implemented", n);
+  OSFM_HIP(hipSetDevice(ctx->device));
+  double *d_p1 = nullptr, *d_p2 = nullptr, *d_F = nullptr;
+  uint8_t *d_mask = nullptr;
+  int32_t *d_info = nullptr;
+  OSFM_HIP(hipMalloc((void **)&d_p1, (size_t)n * 16));
+  OSFM_HIP(hipMalloc((void **)&d_p2, (size_t)n * 16));
+  OSFM_HIP(hipMalloc((void **)&d_F, 9 * 8));
+  OSFM_HIP(hipMalloc((void **)&d_mask, (size_t)n));
+  OSFM_HIP(hipMalloc((void **)&d_info, 16));
+  int rc = OSFM_OK;
+  hipError_t e;
+  do {
+    if ((e = hipMemcpyAsync(d_p1, p1, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
+    if ((e = hipMemcpyAsync(d_p2, p2, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
+    rc = osfm_launch_ransac_single(ctx, d_p1, d_p2, n, thr, conf, max_iters, d_F, d_mask, d_info);
+    if (rc != OSFM_OK) break;
+    int32_t info[4] = {0, 0, 0, 0};
+    if ((e = hipMemcpyAsync(F, d_F, 72, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
+    if ((e = hipMemcpyAsync(mask, d_mask, (size_t)n, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
+    if ((e = hipMemcpyAsync(info, d_info, 12, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
+    if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) break;
+    *found = info[0];
+    if (iters_run) *iters_run = info[1];
+  } while (0);
+  (void)hipFree(d_p1);
+  (void)hipFree(d_p2);
+  (void)hipFree(d_F);
+  (void)hipFree(d_mask);
+  (void)hipFree(d_info);
+  if (rc == OSFM_OK && e != hipSuccess) {
+    osfm_set_error("osfm_ransac_fundamental: %s", hipGetErrorString(e));
+    rc = OSFM_E_HIP;
+  }
+  return rc;
+}

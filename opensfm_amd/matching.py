@@ -1,0 +1,305 @@
+"""Host-side mirror of the reference's pair-matching interface, backed by the HIP kernels.
+
+Same names, argument meaning and return types as ``opensfm/matching.py`` for the hot path:
+
+================================  =====================================================
+this module                        reference
+================================  =====================================================
+``match_brute_force``              ``opensfm/matching.py:723-756``
+``match_brute_force_symmetric``    ``opensfm/matching.py:759-777``
+``robust_match_fundamental``       ``opensfm/matching.py:780-802``
+``robust_match``                   ``opensfm/matching.py:906-929`` (pinhole branch)
+``match`` semantics (per pair)     ``opensfm/matching.py:563-634`` (inside ``match_pairs``)
+``match_images_with_pairs``        ``opensfm/matching.py:63-98``
+``unfilter_matches``               ``opensfm/matching.py:932-936``
+================================  =====================================================
+
+Differences that are deliberate: the unordered ``set`` intersection of the reference is returned
+sorted by ``(i, j)``; the batched entry point keeps all descriptors resident in HBM
+(``DescriptorStore``) instead of the reference's LRU of npz loads (``feature_loading.py``).
+There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import MatchParams, MatchTimings, OsfmError, check, default_context
+
+DEFAULT_CONFIG: Dict[str, Any] = {
+    # opensfm/config.py:97-101,191-195
+    "lowes_ratio": 0.8,
+    "matcher_type": "BRUTEFORCE",
+    "symmetric_matching": True,
+    "robust_matching_threshold": 0.004,
+    "robust_matching_min_match": 20,
+}
+
+
+def _cfg(config: Optional[Dict[str, Any]], key: str):
+    if config is not None and key in config:
+        return config[key]
+    return DEFAULT_CONFIG[key]
+
+
+def _fptr(a: np.ndarray, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+# --------------------------------------------------------------------------------------------
+# leaf functions (drop-ins)
+# --------------------------------------------------------------------------------------------
+def _match_leaf(f1: np.ndarray, f2: np.ndarray, ratio: float, symmetric: bool, ctx=None) -> np.ndarray:
+    assert f1.dtype.type == f2.dtype.type  # matching.py:737
+    if f1.dtype.type == np.uint8:
+        # matching.py:738-739: uint8 descriptors switch cv2 to Hamming; never reached by HAHOG/SIFT
+        # (descriptors are float32 after loading, features.py:259-262)
+        raise NotImplementedError("uint8 descriptors take the reference's BruteForce-Hamming branch")
+    ctx = ctx or default_context()
+    lib = _lib.load()
+    a = np.ascontiguousarray(f1, np.float32)
+    b = np.ascontiguousarray(f2, np.float32)
+    dim = a.shape[1] if a.ndim == 2 and len(a) else (b.shape[1] if b.ndim == 2 and len(b) else 128)
+    cap = max(1, min(len(a), len(b)) if symmetric else len(a))
+    out = np.empty((cap, 2), np.int32)
+    n = C.c_int(0)
+    check(
+        lib.osfm_match_l2_ratio(ctx.handle, _fptr(a, C.c_float), len(a), _fptr(b, C.c_float), len(b), dim,
+                                float(ratio), int(symmetric), _fptr(out, C.c_int32), cap, C.byref(n)),
+        "osfm_match_l2_ratio",
+    )
+    return out[: n.value]
+
+
+def match_brute_force(f1: np.ndarray, f2: np.ndarray, config: Dict[str, Any], maskij: Optional[np.ndarray] = None,
+                      ) -> List[Tuple[int, int]]:
+    """Brute force matching and Lowe's ratio filtering (``matching.py:723-756``)."""
+    if maskij is not None:
+        raise NotImplementedError("guided matching mask (maskij) is not implemented on the GPU path yet")
+    m = _match_leaf(f1, f2, _cfg(config, "lowes_ratio"), False)
+    return [(int(a), int(b)) for a, b in m]
+
+
+def match_brute_force_symmetric(fi: np.ndarray, fj: np.ndarray, config: Dict[str, Any],
+                                maskij: Optional[np.ndarray] = None) -> List[Tuple[int, int]]:
+    """Match with brute force in both directions and keep consistent matches (``matching.py:759-777``)."""
+    if maskij is not None:
+        raise NotImplementedError("guided matching mask (maskij) is not implemented on the GPU path yet")
+    m = _match_leaf(fi, fj, _cfg(config, "lowes_ratio"), True)
+    return [(int(a), int(b)) for a, b in m]
+
+
+def find_fundamental_ransac(p1: np.ndarray, p2: np.ndarray, threshold: float, confidence: float = 0.9999,
+                            max_iters: int = 1000, ctx=None) -> Tuple[Optional[np.ndarray], np.ndarray]:
+    """``cv2.findFundamentalMat(p1, p2, cv2.FM_RANSAC, threshold, confidence)`` -> (F or None, mask (n,1) uint8)."""
+    ctx = ctx or default_context()
+    lib = _lib.load()
+    a = np.ascontiguousarray(p1, np.float64)
+    b = np.ascontiguousarray(p2, np.float64)
+    n = len(a)
+    F = np.zeros(9, np.float64)
+    mask = np.zeros(max(n, 1), np.uint8)
+    found = C.c_int(0)
+    iters = C.c_int(0)
+    check(
+        lib.osfm_ransac_fundamental(ctx.handle, _fptr(a, C.c_double), _fptr(b, C.c_double), n, float(threshold),
+                                    float(confidence), int(max_iters), _fptr(F, C.c_double), _fptr(mask, C.c_uint8),
+                                    C.byref(found), C.byref(iters)),
+        "osfm_ransac_fundamental",
+    )
+    find_fundamental_ransac.last_iters = iters.value  # type: ignore[attr-defined]
+    return (F.reshape(3, 3) if found.value else None), mask[:n].reshape(-1, 1)
+
+
+def robust_match_fundamental(p1: np.ndarray, p2: np.ndarray, matches: np.ndarray, config: Dict[str, Any],
+                             ) -> Tuple[Any, np.ndarray]:
+    """Filter matches by estimating the Fundamental matrix via RANSAC (``matching.py:780-802``)."""
+    if len(matches) < 8:
+        return np.array([]), np.array([])
+    matches = np.asarray(matches)
+    x1 = p1[matches[:, 0]][:, :2].copy()
+    x2 = p2[matches[:, 1]][:, :2].copy()
+    threshold = _cfg(config, "robust_matching_threshold")
+    F, mask = find_fundamental_ransac(x1, x2, threshold, 0.9999)
+    inliers = mask.ravel().nonzero()
+    if F is None or F[2, 2] == 0.0:
+        return F, np.array([])
+    return F, matches[inliers]
+
+
+def robust_match(p1, p2, camera1, camera2, matches, config) -> np.ndarray:
+    """``matching.py:906-929``: F-matrix path for undistorted perspective/brown cameras."""
+
+    def pinhole(c) -> bool:
+        return c.projection_type in ["perspective", "brown"] and c.k1 == 0.0 and c.k2 == 0.0
+
+    if pinhole(camera1) and pinhole(camera2):
+        return robust_match_fundamental(p1, p2, matches, config)[1]
+    raise NotImplementedError("calibrated (essential-matrix) robust matching is not on the GPU path yet (SURVEY 8f-3)")
+
+
+def unfilter_matches(matches: np.ndarray, m1: np.ndarray, m2: np.ndarray) -> np.ndarray:
+    """Given matches and masking arrays, get matches with un-masked indexes (``matching.py:932-936``)."""
+    i1 = np.flatnonzero(m1)
+    i2 = np.flatnonzero(m2)
+    return np.array([(i1[match[0]], i2[match[1]]) for match in matches])
+
+
+# --------------------------------------------------------------------------------------------
+# batched path
+# --------------------------------------------------------------------------------------------
+class DescriptorStore:
+    """All images' (masked) descriptors + keypoints resident in HBM.
+
+    Replaces ``FeatureLoader.load_all_data`` + its LRU caches (``feature_loading.py:106-173``).
+    ``descriptors``: list of (n_i, 128) arrays, float32 (integer-valued) or uint8;
+    ``points``: list of (n_i, >=2) arrays (normalized image coordinates, ``features.py:324-331``).
+    """
+
+    def __init__(self, descriptors: Sequence[np.ndarray], points: Sequence[np.ndarray], ctx=None):
+        self.ctx = ctx or default_context()
+        lib = _lib.load()
+        counts = np.asarray([len(d) for d in descriptors], np.int32)
+        self.counts = counts
+        self.n_images = len(counts)
+        h = C.c_void_p()
+        check(lib.osfm_store_create(self.ctx.handle, self.n_images, _fptr(counts, C.c_int32), C.byref(h)),
+              "osfm_store_create")
+        self.handle = h
+        total = int(counts.sum())
+        pts = np.zeros((max(total, 1), 2), np.float64)
+        if total:
+            pts[:total] = np.concatenate([np.asarray(p, np.float64)[:, :2].reshape(-1, 2) for p in points])
+        all_u8 = all(np.asarray(d).dtype == np.uint8 for d in descriptors)
+        if all_u8:
+            desc = np.zeros((max(total, 1), 128), np.uint8)
+            if total:
+                desc[:total] = np.concatenate([np.asarray(d).reshape(-1, 128) for d in descriptors])
+            rc = lib.osfm_store_upload_u8(h, _fptr(desc, C.c_uint8), _fptr(pts, C.c_double))
+        else:
+            desc = np.zeros((max(total, 1), 128), np.float32)
+            if total:
+                desc[:total] = np.concatenate([np.asarray(d, np.float32).reshape(-1, 128) for d in descriptors])
+            rc = lib.osfm_store_upload_f32(h, _fptr(desc, C.c_float), _fptr(pts, C.c_double))
+        if rc != 0:
+            msg = lib.osfm_last_error().decode()
+            lib.osfm_store_destroy(h)
+            self.handle = None
+            raise OsfmError(f"osfm_store_upload failed ({rc}): {msg}")
+
+    @classmethod
+    def from_packed(cls, desc: np.ndarray, pts: np.ndarray, offsets: np.ndarray, ctx=None) -> "DescriptorStore":
+        ds = [desc[offsets[i]: offsets[i + 1]] for i in range(len(offsets) - 1)]
+        ps = [pts[offsets[i]: offsets[i + 1]] for i in range(len(offsets) - 1)]
+        return cls(ds, ps, ctx)
+
+    @property
+    def device_bytes(self) -> int:
+        return int(_lib.load().osfm_store_bytes(self.handle))
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            _lib.load().osfm_store_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def make_params(config: Optional[Dict[str, Any]] = None, robust: bool = True) -> MatchParams:
+    p = MatchParams()
+    _lib.load().osfm_match_params_default(C.byref(p))
+    p.lowes_ratio = float(_cfg(config, "lowes_ratio"))
+    p.symmetric = int(bool(_cfg(config, "symmetric_matching")))
+    p.robust = int(robust)
+    p.robust_matching_min_match = int(_cfg(config, "robust_matching_min_match"))
+    p.robust_matching_threshold = float(_cfg(config, "robust_matching_threshold"))
+    return p
+
+
+def match_pairs(store: DescriptorStore, pairs: np.ndarray, config: Optional[Dict[str, Any]] = None,
+                robust: bool = True, timings: Optional[MatchTimings] = None) -> Tuple[np.ndarray, np.ndarray]:
+    """Run ``matching.match`` (``matching.py:563-634``) for every pair, on the GPU.
+
+    Returns ``(counts, matches)``: ``counts[p]`` matches for pair ``p`` (0 where the reference returns
+    ``[]``), ``matches`` the concatenated ``(K, 2)`` int32 arrays in pair order.
+    """
+    lib = _lib.load()
+    pairs = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+    prm = make_params(config, robust)
+    res = C.c_void_p()
+    tm = timings if timings is not None else MatchTimings()
+    check(lib.osfm_match_pairs(store.ctx.handle, store.handle, _fptr(pairs, C.c_int32), len(pairs), C.byref(prm),
+                               C.byref(res), C.byref(tm)), "osfm_match_pairs")
+    try:
+        n = lib.osfm_result_num_pairs(res)
+        total = lib.osfm_result_total_matches(res)
+        counts = np.zeros(max(n, 1), np.int32)
+        matches = np.zeros((max(total, 1), 2), np.int32)
+        check(lib.osfm_result_fetch(res, _fptr(counts, C.c_int32), _fptr(matches, C.c_int32)), "osfm_result_fetch")
+    finally:
+        lib.osfm_result_destroy(res)
+    return counts[:n], matches[:total]
+
+
+def split_matches(counts: np.ndarray, matches: np.ndarray) -> List[np.ndarray]:
+    off = np.concatenate([[0], np.cumsum(counts)])
+    return [matches[off[i]: off[i + 1]] for i in range(len(counts))]
+
+
+def match_images_with_pairs(data, config_override: Dict[str, Any], exifs: Dict[str, Any],
+                            pairs: List[Tuple[str, str]], poses=None) -> Dict[Tuple[str, str], np.ndarray]:
+    """Perform pair matchings given pairs (``matching.py:63-98``), all pairs in one GPU batch.
+
+    ``data`` must offer the ``DataSetBase`` methods the reference uses on this path:
+    ``config``, ``load_camera_models()``, ``load_features(image)`` (``.points``, ``.descriptors``) and
+    optionally ``load_features_mask(image, points)`` (``feature_loading.py:61-71``).
+    Only the configuration the GPU path implements is accepted: ``matcher_type: BRUTEFORCE``,
+    undistorted perspective cameras, no guided matching.
+    """
+    if poses:
+        raise NotImplementedError("guided matching is not implemented on the GPU path")
+    config = dict(data.config)
+    config.update(config_override)
+    if str(config.get("matcher_type", "BRUTEFORCE")).upper() != "BRUTEFORCE":
+        raise NotImplementedError("GPU path implements matcher_type BRUTEFORCE (exact); FLANN is approximate/randomised")
+    cameras = data.load_camera_models()
+    images = sorted({im for pair in pairs for im in pair})
+    index = {im: k for k, im in enumerate(images)}
+    descs, pts, masks = [], [], []
+    for im in images:
+        cam = cameras[exifs[im]["camera"]]
+        if not (cam.projection_type in ["perspective", "brown"] and cam.k1 == 0.0 and cam.k2 == 0.0):
+            raise NotImplementedError(f"camera of {im} needs the calibrated robust-matching branch (not on GPU yet)")
+        fd = data.load_features(im)
+        points = np.asarray(fd.points)
+        desc = np.asarray(fd.descriptors)
+        mask = None
+        if hasattr(data, "load_features_mask"):
+            mask = np.asarray(data.load_features_mask(im, points[:, :2]), bool)
+            points, desc = points[mask], desc[mask]
+        descs.append(desc)
+        pts.append(points)
+        masks.append(mask)
+    store = DescriptorStore(descs, pts)
+    try:
+        ipairs = np.asarray([(index[a], index[b]) for a, b in pairs], np.int32).reshape(-1, 2)
+        counts, matches = match_pairs(store, ipairs, config, robust=True)
+    finally:
+        store.close()
+    out: Dict[Tuple[str, str], np.ndarray] = {}
+    for (im1, im2), m in zip(pairs, split_matches(counts, matches)):
+        if len(m) == 0:
+            out[im1, im2] = np.array([])  # matching.py:598,634
+            continue
+        m1, m2 = masks[index[im1]], masks[index[im2]]
+        if m1 is not None and m2 is not None:
+            m = unfilter_matches(m, m1, m2)
+        out[im1, im2] = np.array(m, dtype=int)
+    return out

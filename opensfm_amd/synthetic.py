@@ -1,0 +1,166 @@
+"""Seeded synthetic inputs for the matching + bundle-adjustment hot path.
+
+Recipes follow SURVEY.md 8(d), which in turn mirrors the reference's own synthetic fixtures:
+
+* descriptors: HAHOG-style integer-valued float32 in [0, 255]
+  (``opensfm/features.py:526-534``: ``sqrt`` -> ``x362`` -> ``clip(0,255)`` -> ``round``; stored
+  uint8, loaded back as float32 ``features.py:259-262``);
+* keypoints: normalized image coordinates ``(px + 0.5 - w/2) / max(w, h)``
+  (``features.py:324-331``), focal 0.85, 1 px noise at 2000 px;
+* BA scenes: one shared perspective camera ``[k1, k2, focal]``, sigma 0.004
+  (``opensfm/synthetic_data/synthetic_generator.py:404``), 1 px noise, outliers.
+
+Everything here is input generation; none of it is on the timed path.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Tuple
+
+import numpy as np
+
+
+def _hahog_like(rng: np.random.Generator, n: int, dim: int = 128) -> np.ndarray:
+    """Non-negative sparse-ish vectors -> L1 normalise -> sqrt -> x362 -> clip -> round (uint8)."""
+    v = np.abs(rng.standard_normal((n, dim), dtype=np.float32))
+    keep = rng.random((n, dim), dtype=np.float32) < 0.6
+    v *= keep
+    v[:, 0] += 1e-3  # never all-zero
+    v /= v.sum(axis=1, keepdims=True)
+    d = np.sqrt(v) * 362.0
+    return np.clip(np.rint(d), 0, 255).astype(np.uint8)
+
+
+@dataclass
+class MatchingScene:
+    """A set of images: ragged descriptors/keypoints packed back to back."""
+
+    desc: np.ndarray  # (sum_n, 128) uint8, integer-valued descriptors
+    pts: np.ndarray  # (sum_n, 2) float64 normalized image coordinates
+    offsets: np.ndarray  # (n_images + 1,) int64 row offsets
+    point_ids: np.ndarray  # (sum_n,) int64 scene point id, -1 for distractors
+
+    @property
+    def n_images(self) -> int:
+        return len(self.offsets) - 1
+
+    def image(self, i: int) -> Tuple[np.ndarray, np.ndarray]:
+        a, b = self.offsets[i], self.offsets[i + 1]
+        return self.desc[a:b], self.pts[a:b]
+
+    def desc_f32(self, i: int) -> np.ndarray:
+        a, b = self.offsets[i], self.offsets[i + 1]
+        return self.desc[a:b].astype(np.float32)
+
+
+def all_pairs(n_images: int) -> np.ndarray:
+    """All i<j pairs in lexicographic order: what ``pairs_selection.py:624-644`` emits when every
+    selector is 0 (exhaustive matching)."""
+    i, j = np.triu_indices(n_images, k=1)
+    return np.stack([i, j], axis=1).astype(np.int32)
+
+
+def make_matching_scene(
+    n_images: int,
+    n_features: int = 2000,
+    seed: int = 42,
+    distractor_frac: float = 0.3,
+    desc_noise: float = 4.0,
+    px_noise: float = 1.0 / 2000.0,
+    ragged: bool = False,
+    dim: int = 128,
+) -> MatchingScene:
+    """Street scene: cameras advance along +x looking at a cloud of points at depth 4..12.
+
+    Neighbouring cameras share scene points (true matches with a consistent epipolar geometry);
+    distant cameras share none, so most pairs of an exhaustive run fail the min-match gate, as in
+    a real exhaustive matching job.
+    """
+    rng = np.random.default_rng(seed)
+    focal = 0.85
+    step = 1.0
+    n_real_target = int(round(n_features * (1.0 - distractor_frac)))
+    # density so that ~2x n_real_target points are visible per camera
+    depth_lo, depth_hi = 4.0, 12.0
+    x_extent = n_images * step + 2 * depth_hi
+    # visible volume per camera: integrate over depth of (z/f) * (0.75 z/f) -> area in (x, y)
+    vol = (1.0 / focal) * (0.75 / focal) * (depth_hi**3 - depth_lo**3) / 3.0
+    total_vol = x_extent * (2 * 0.375 * depth_hi / focal) * (depth_hi - depth_lo)
+    n_points = int(2.0 * n_real_target * total_vol / vol)
+    X = np.empty((n_points, 3))
+    X[:, 0] = rng.uniform(-depth_hi, n_images * step + depth_hi, n_points)
+    X[:, 2] = rng.uniform(depth_lo, depth_hi, n_points)
+    X[:, 1] = rng.uniform(-0.375 * depth_hi / focal, 0.375 * depth_hi / focal, n_points)
+    order = np.argsort(X[:, 0])
+    X = X[order]
+    base_desc = _hahog_like(rng, n_points, dim)
+
+    descs: List[np.ndarray] = []
+    ptss: List[np.ndarray] = []
+    ids: List[np.ndarray] = []
+    offsets = [0]
+    for i in range(n_images):
+        n_i = n_features
+        if ragged:
+            n_i = int(rng.integers(max(2, n_features // 2), n_features + 1))
+        cam = np.array([i * step, rng.normal(0, 0.05), rng.normal(0, 0.05)])
+        ang = rng.normal(0, 0.03, 3)
+        Rm = _rodrigues(ang)
+        lo = np.searchsorted(X[:, 0], cam[0] - depth_hi * 0.6 / focal)
+        hi = np.searchsorted(X[:, 0], cam[0] + depth_hi * 0.6 / focal)
+        Xc = (X[lo:hi] - cam) @ Rm.T
+        z = Xc[:, 2]
+        u = focal * Xc[:, 0] / z
+        v = focal * Xc[:, 1] / z
+        vis = np.flatnonzero((z > 0.1) & (np.abs(u) < 0.5) & (np.abs(v) < 0.375))
+        n_real = min(int(round(n_i * (1.0 - distractor_frac))), len(vis))
+        pick = rng.choice(vis, n_real, replace=False)
+        pid = pick + lo
+        d = base_desc[pid].astype(np.int16) + np.rint(rng.normal(0, desc_noise, (n_real, dim))).astype(np.int16)
+        d = np.clip(d, 0, 255).astype(np.uint8)
+        p = np.stack([u[pick], v[pick]], axis=1) + rng.normal(0, px_noise, (n_real, 2))
+        n_dis = n_i - n_real
+        dd = _hahog_like(rng, n_dis, dim)
+        pd = np.stack([rng.uniform(-0.5, 0.5, n_dis), rng.uniform(-0.375, 0.375, n_dis)], axis=1)
+        perm = rng.permutation(n_i)
+        descs.append(np.concatenate([d, dd])[perm])
+        ptss.append(np.concatenate([p, pd])[perm])
+        ids.append(np.concatenate([pid, -np.ones(n_dis, dtype=np.int64)])[perm])
+        offsets.append(offsets[-1] + n_i)
+    return MatchingScene(
+        desc=np.ascontiguousarray(np.concatenate(descs)),
+        pts=np.ascontiguousarray(np.concatenate(ptss)),
+        offsets=np.asarray(offsets, dtype=np.int64),
+        point_ids=np.concatenate(ids),
+    )
+
+
+def _rodrigues(r: np.ndarray) -> np.ndarray:
+    th = float(np.linalg.norm(r))
+    K = np.array([[0, -r[2], r[1]], [r[2], 0, -r[0]], [-r[1], r[0], 0]])
+    if th < 1e-12:
+        return np.eye(3) + K
+    return np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th**2 * (K @ K)
+
+
+def make_two_view(
+    n: int, inlier_frac: float = 0.6, seed: int = 42, px_noise: float = 1.0 / 2000.0
+) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """Correspondences (p1, p2, is_inlier) between two pinhole views with outliers, normalized
+    image coordinates (what ``robust_match_fundamental`` receives, ``matching.py:790-791``)."""
+    rng = np.random.default_rng(seed)
+    focal = 0.85
+    X = np.stack(
+        [rng.uniform(-3, 3, n), rng.uniform(-2, 2, n), rng.uniform(4, 12, n)], axis=1
+    )
+    R2 = _rodrigues(np.array([0.02, -0.1, 0.03]))
+    t2 = np.array([1.0, 0.1, 0.2])
+    p1 = focal * X[:, :2] / X[:, 2:3]
+    Xc = (X - t2) @ R2.T
+    p2 = focal * Xc[:, :2] / Xc[:, 2:3]
+    p1 = p1 + rng.normal(0, px_noise, p1.shape)
+    p2 = p2 + rng.normal(0, px_noise, p2.shape)
+    inl = rng.random(n) < inlier_frac
+    n_out = int((~inl).sum())
+    p2[~inl] = np.stack([rng.uniform(-0.5, 0.5, n_out), rng.uniform(-0.375, 0.375, n_out)], axis=1)
+    return np.ascontiguousarray(p1), np.ascontiguousarray(p2), inl

@@ -1,0 +1,141 @@
+"""ctypes front-end of the CPU oracle (``oracle/*.c`` -> ``oracle/liboracle.so``).
+
+TEST INFRASTRUCTURE ONLY.  Imported by ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` -- never by ``opensfm_amd`` (the product path fails loudly
+when its HIP library is missing; it has no CPU fallback).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB: Optional[C.CDLL] = None
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith(".c")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib() -> C.CDLL:
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(so):
+            build()
+        _LIB = C.CDLL(so)
+        _LIB.oracle_det_log.restype = C.c_double
+        _LIB.oracle_det_log.argtypes = [C.c_double]
+    return _LIB
+
+
+def _p(a: np.ndarray, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def knn2(f1: np.ndarray, f2: np.ndarray):
+    f1 = np.ascontiguousarray(f1, np.float32)
+    f2 = np.ascontiguousarray(f2, np.float32)
+    n1 = len(f1)
+    idx = np.empty(n1, np.int32)
+    d1 = np.empty(n1, np.float32)
+    d2 = np.empty(n1, np.float32)
+    s1 = np.empty(n1, np.float32)
+    s2 = np.empty(n1, np.float32)
+    lib().oracle_knn2_l2(_p(f1, C.c_float), n1, _p(f2, C.c_float), len(f2), f1.shape[1] if n1 else f2.shape[1],
+                         _p(idx, C.c_int), _p(d1, C.c_float), _p(d2, C.c_float), _p(s1, C.c_float), _p(s2, C.c_float))
+    return idx, d1, d2, s1, s2
+
+
+def match_brute_force(f1: np.ndarray, f2: np.ndarray, ratio: float = 0.8, squared: bool = False) -> np.ndarray:
+    """``matching.py:723-756``; returns array (K, 2) of (queryIdx, trainIdx)."""
+    f1 = np.ascontiguousarray(f1, np.float32)
+    f2 = np.ascontiguousarray(f2, np.float32)
+    n1 = len(f1)
+    good = np.empty(max(n1, 1), np.int32)
+    dim = f1.shape[1] if f1.ndim == 2 else 128
+    lib().oracle_match_brute_force(_p(f1, C.c_float), n1, _p(f2, C.c_float), len(f2), dim,
+                                   C.c_double(ratio), int(squared), _p(good, C.c_int))
+    good = good[:n1]
+    i = np.flatnonzero(good >= 0)
+    return np.stack([i, good[i]], axis=1).astype(np.int32)
+
+
+def match_brute_force_symmetric(fi: np.ndarray, fj: np.ndarray, ratio: float = 0.8, squared: bool = False) -> np.ndarray:
+    """``matching.py:759-777``; (K, 2) sorted by (i, j)."""
+    fi = np.ascontiguousarray(fi, np.float32)
+    fj = np.ascontiguousarray(fj, np.float32)
+    cap = max(1, min(len(fi), len(fj)))
+    out = np.empty((cap, 2), np.int32)
+    dim = fi.shape[1] if fi.ndim == 2 else 128
+    n = lib().oracle_match_brute_force_symmetric(_p(fi, C.c_float), len(fi), _p(fj, C.c_float), len(fj), dim,
+                                                 C.c_double(ratio), int(squared), _p(out, C.c_int), cap)
+    return out[:n].copy()
+
+
+def find_fundamental_ransac(p1: np.ndarray, p2: np.ndarray, thr: float = 0.004, conf: float = 0.9999,
+                            max_iters: int = 1000) -> Tuple[Optional[np.ndarray], np.ndarray, int]:
+    """``cv2.findFundamentalMat(p1, p2, FM_RANSAC, thr, conf)`` restated; returns (F|None, mask, iters)."""
+    p1 = np.ascontiguousarray(p1, np.float64)
+    p2 = np.ascontiguousarray(p2, np.float64)
+    n = len(p1)
+    F = np.zeros(9, np.float64)
+    mask = np.zeros(max(n, 1), np.uint8)
+    it = C.c_int(0)
+    r = lib().oracle_find_fundamental_ransac(_p(p1, C.c_double), _p(p2, C.c_double), n, C.c_double(thr),
+                                             C.c_double(conf), max_iters, _p(F, C.c_double), _p(mask, C.c_uint8), C.byref(it))
+    if r < 0:
+        raise NotImplementedError("n < 15: cv2 takes the LMedS branch, not restated")
+    return (F.reshape(3, 3) if r == 1 else None), mask[:n].astype(bool), it.value
+
+
+def run_7point(m1: np.ndarray, m2: np.ndarray) -> np.ndarray:
+    m1 = np.ascontiguousarray(m1, np.float64)
+    m2 = np.ascontiguousarray(m2, np.float64)
+    F = np.zeros(27, np.float64)
+    n = lib().oracle_run_7point(_p(m1, C.c_double), _p(m2, C.c_double), _p(F, C.c_double))
+    return F.reshape(3, 3, 3)[:n]
+
+
+def det_log(x: float) -> float:
+    return lib().oracle_det_log(C.c_double(x))
+
+
+def update_num_iters(p: float, ep: float, max_iters: int) -> int:
+    return lib().oracle_update_num_iters(C.c_double(p), C.c_double(ep), max_iters)
+
+
+def cvrng_sequence(seed: int, count: int) -> np.ndarray:
+    out = np.empty(count, np.uint32)
+    lib().oracle_cvrng_sequence(C.c_uint64(seed & (2**64 - 1)), count, _p(out, C.c_uint))
+    return out
+
+
+def match_pairs(desc_f32: np.ndarray, pts: np.ndarray, offsets: np.ndarray, pairs: np.ndarray,
+                ratio: float = 0.8, min_match: int = 20, thr: float = 0.004, conf: float = 0.9999,
+                stage: int = 1):
+    """``matching.py:63-98`` over a packed store; returns list of (K,2) int32 arrays per pair."""
+    desc_f32 = np.ascontiguousarray(desc_f32, np.float32)
+    pts = np.ascontiguousarray(pts, np.float64)
+    offsets = np.ascontiguousarray(offsets, np.int64)
+    pairs = np.ascontiguousarray(pairs, np.int32)
+    npairs = len(pairs)
+    cap = int(np.max(np.diff(offsets))) if len(offsets) > 1 else 1
+    counts = np.zeros(max(npairs, 1), np.int32)
+    out = np.zeros((max(npairs, 1), cap, 2), np.int32)
+    lib().oracle_match_pairs(_p(desc_f32, C.c_float), _p(pts, C.c_double), _p(offsets, C.c_int64), desc_f32.shape[1],
+                             _p(pairs, C.c_int), npairs, C.c_double(ratio), min_match, C.c_double(thr), C.c_double(conf),
+                             stage, _p(counts, C.c_int), _p(out, C.c_int), cap)
+    return [out[p, : counts[p]].copy() for p in range(npairs)]
+
+
+def num_threads() -> int:
+    return lib().oracle_num_threads()

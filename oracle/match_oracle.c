@@ -1,0 +1,160 @@
+/*
+ * match_oracle.c -- TEST INFRASTRUCTURE ONLY (CPU oracle, never shipped, never on the product path).
+ *
+ * CPU restatement of the descriptor-matching half of OpenSfM's pair-matching hot path:
+ *
+ *   opensfm/matching.py:723-756  match_brute_force           (cv2 BruteForce L2 knnMatch k=2 + Lowe ratio)
+ *   opensfm/matching.py:759-777  match_brute_force_symmetric (both directions + set intersection)
+ *   opensfm/matching.py:683-720  match_flann[_symmetric]     (ratio on SQUARED distances, fp32 compare)
+ *
+ * The arithmetic of knnMatch lives in OpenCV (opencv-python>=4.8, pyproject.toml:31), which is
+ * NOT vendored under /root/reference.  We restate its published behaviour (modules/core/src/
+ * batch_distance.cpp + modules/features2d/src/matchers.cpp, from documentation/memory):
+ *   - L2 distance between float32 rows = sqrtf( float sum_k (a_k-b_k)^2 )
+ *   - k=2 nearest by insertion with strict '<' against the current K-th, '>' when shifting:
+ *     among equal float distances the LOWEST train index stays in front
+ *   - ratio test is done by the reference in Python doubles on the float32 distances:
+ *         double(m.distance) < ratio * double(n.distance)            (matching.py:752)
+ * PARITY STATUS: "parity unpinned" against cv2 itself (no golden vectors exist in the reference
+ * for this path).  For integer-valued descriptors in [0,255] (the HAHOG/SIFT uint8
+ * round trip, features.py:526-534,259-262) every partial sum is an integer < 2^24, hence exactly
+ * representable in fp32 under ANY summation order -- so on that domain this restatement is
+ * independent of OpenCV's SIMD accumulation order and the result is well defined.
+ *
+ * Build: see oracle/Makefile (gcc -O3 -march=native -fopenmp -ffp-contract=off).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* float sum of squared differences; 4 accumulators of 8 lanes, the structure of OpenCV's
+ * normL2Sqr_ on an AVX2 build (4 x v_float32x8, then lane reduction, then scalar tail). */
+typedef float v8f __attribute__((vector_size(32), aligned(4)));
+
+static inline float l2sqr_f32(const float *a, const float *b, int n) {
+  v8f d0 = {0}, d1 = {0}, d2 = {0}, d3 = {0};
+  int j = 0;
+  for (; j + 32 <= n; j += 32) {
+    v8f t0 = *(const v8f *)(a + j) - *(const v8f *)(b + j);
+    v8f t1 = *(const v8f *)(a + j + 8) - *(const v8f *)(b + j + 8);
+    v8f t2 = *(const v8f *)(a + j + 16) - *(const v8f *)(b + j + 16);
+    v8f t3 = *(const v8f *)(a + j + 24) - *(const v8f *)(b + j + 24);
+    d0 += t0 * t0;
+    d1 += t1 * t1;
+    d2 += t2 * t2;
+    d3 += t3 * t3;
+  }
+  v8f s = (d0 + d1) + (d2 + d3);
+  float d = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  for (; j < n; j++) {
+    float t = a[j] - b[j];
+    d += t * t;
+  }
+  return d;
+}
+
+/* One direction: for every row i of f1 (n1 x dim) find the two nearest rows of f2 (n2 x dim).
+ * out_idx[i] = best train index (or -1 when n2 < 2: knnMatch returns <2 neighbours and
+ * matching.py:750 drops the row), out_d1[i], out_d2[i] = the float32 L2 distances.
+ * Restates BFMatcher::knnMatchImpl -> batchDistance(K=2). */
+void oracle_knn2_l2(const float *f1, int n1, const float *f2, int n2, int dim, int *out_idx,
+                    float *out_d1, float *out_d2, float *out_s1, float *out_s2) {
+#pragma omp parallel for schedule(dynamic, 16)
+  for (int i = 0; i < n1; i++) {
+    float bd0 = INFINITY, bd1 = INFINITY, bs0 = INFINITY, bs1 = INFINITY;
+    int bi0 = -1, bi1 = -1;
+    const float *a = f1 + (size_t)i * dim;
+    for (int j = 0; j < n2; j++) {
+      float sq = l2sqr_f32(a, f2 + (size_t)j * dim, dim);
+      float d = sqrtf(sq);
+      /* batchDistance top-K insertion: if (d < dist[K-1]) shift while dist[k] > d */
+      if (d < bd1) {
+        if (bd0 > d) {
+          bd1 = bd0;
+          bs1 = bs0;
+          bi1 = bi0;
+          bd0 = d;
+          bs0 = sq;
+          bi0 = j;
+        } else {
+          bd1 = d;
+          bs1 = sq;
+          bi1 = j;
+        }
+      }
+    }
+    (void)bi1;
+    if (n2 < 2) bi0 = -1;
+    out_idx[i] = bi0;
+    out_d1[i] = bd0;
+    out_d2[i] = bd1;
+    if (out_s1) out_s1[i] = bs0;
+    if (out_s2) out_s2[i] = bs1;
+  }
+}
+
+/* matching.py:723-756: returns good[i] = j or -1.  squared_mode restates match_flann's test
+ * (matching.py:695-696): numpy float32 array * python float stays float32:
+ *     d0 < float32(ratio**2) * d1     on SQUARED distances. */
+void oracle_match_brute_force(const float *f1, int n1, const float *f2, int n2, int dim,
+                              double ratio, int squared_mode, int *good) {
+  int *idx = (int *)malloc(sizeof(int) * (size_t)(n1 > 0 ? n1 : 1));
+  float *d1 = (float *)malloc(sizeof(float) * (size_t)(n1 > 0 ? n1 : 1));
+  float *d2 = (float *)malloc(sizeof(float) * (size_t)(n1 > 0 ? n1 : 1));
+  float *s1 = (float *)malloc(sizeof(float) * (size_t)(n1 > 0 ? n1 : 1));
+  float *s2 = (float *)malloc(sizeof(float) * (size_t)(n1 > 0 ? n1 : 1));
+  oracle_knn2_l2(f1, n1, f2, n2, dim, idx, d1, d2, s1, s2);
+  for (int i = 0; i < n1; i++) {
+    int ok = 0;
+    if (idx[i] >= 0) {
+      if (squared_mode) {
+        float r2 = (float)(ratio * ratio);
+        ok = s1[i] < r2 * s2[i];
+      } else {
+        ok = (double)d1[i] < ratio * (double)d2[i];
+      }
+    }
+    good[i] = ok ? idx[i] : -1;
+  }
+  free(idx);
+  free(d1);
+  free(d2);
+  free(s1);
+  free(s2);
+}
+
+/* matching.py:759-777.  Output pairs (i, j) sorted by (i, j) (the reference returns an unordered
+ * python set; we canonicalise).  Returns the number of pairs written (<= cap). */
+int oracle_match_brute_force_symmetric(const float *fi, int ni, const float *fj, int nj, int dim,
+                                       double ratio, int squared_mode, int *out_pairs, int cap) {
+  int *gij = (int *)malloc(sizeof(int) * (size_t)(ni > 0 ? ni : 1));
+  int *gji = (int *)malloc(sizeof(int) * (size_t)(nj > 0 ? nj : 1));
+  oracle_match_brute_force(fi, ni, fj, nj, dim, ratio, squared_mode, gij);
+  oracle_match_brute_force(fj, nj, fi, ni, dim, ratio, squared_mode, gji);
+  int n = 0;
+  for (int i = 0; i < ni; i++) {
+    int j = gij[i];
+    if (j >= 0 && gji[j] == i) {
+      if (n < cap) {
+        out_pairs[2 * n] = i;
+        out_pairs[2 * n + 1] = j;
+      }
+      n++;
+    }
+  }
+  free(gij);
+  free(gji);
+  return n;
+}
+
+int oracle_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}

@@ -1,0 +1,63 @@
+"""world_size-2 gloo test of the sharding + all-gather of the match graph (runs on CPU)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_pairs, seed, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    from opensfm_amd import dist as odist
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    rng = np.random.default_rng(seed)
+    counts_all = rng.integers(0, 7, n_pairs).astype(np.int32)
+    counts_all[rng.random(n_pairs) < 0.5] = 0
+    off = np.concatenate([[0], np.cumsum(counts_all)])
+    matches_all = rng.integers(0, 2000, (int(off[-1]), 2)).astype(np.int32)
+    idx = odist.shard_indices(n_pairs, rank, world, block=16)
+    mine = np.concatenate([matches_all[off[i]: off[i + 1]] for i in idx]) if len(idx) else np.zeros((0, 2), np.int32)
+    c, m = odist.all_gather_match_graph(counts_all[idx], mine, n_pairs, rank, world, block=16)
+    ok = np.array_equal(c, counts_all) and np.array_equal(m, matches_all)
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_pairs", [1, 37, 1000])
+def test_all_gather_match_graph_world2(n_pairs):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_pairs, 3, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_shards_partition_the_pair_list():
+    from opensfm_amd import dist as odist
+
+    for world in (1, 2, 4, 8):
+        idx = np.concatenate([odist.shard_indices(100000, r, world) for r in range(world)])
+        assert np.array_equal(np.sort(idx), np.arange(100000))
+        sizes = [len(odist.shard_indices(499500, r, world)) for r in range(world)]
+        assert max(sizes) - min(sizes) <= odist.BLOCK

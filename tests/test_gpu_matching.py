@@ -1,0 +1,136 @@
+"""GPU parity: fused MFMA matcher == CPU oracle, bit for bit, through the C ABI."""
+import numpy as np
+import pytest
+
+from opensfm_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def _as_set(m):
+    return {tuple(int(v) for v in x) for x in m}
+
+
+def _rand_desc(rng, n, hi=256):
+    return rng.integers(0, hi, (n, 128)).astype(np.float32)
+
+
+@pytest.mark.parametrize(
+    "n1,n2,seed",
+    [(2, 2, 0), (3, 40, 1), (31, 33, 2), (32, 32, 3), (64, 257, 4), (300, 100, 5), (1000, 777, 6), (2000, 2000, 7),
+     (129, 4096, 8), (4096, 300, 9)],
+)
+def test_leaf_symmetric_equals_oracle(oracle_lib, gpu_ctx, n1, n2, seed):
+    from opensfm_amd import matching
+
+    rng = np.random.default_rng(seed)
+    f1 = synthetic._hahog_like(rng, n1).astype(np.float32)
+    f2 = synthetic._hahog_like(rng, n2).astype(np.float32)
+    k = min(n1, n2) // 2
+    f2[:k] = np.clip(f1[rng.permutation(n1)[:k]] + np.rint(rng.normal(0, 3, (k, 128))), 0, 255)
+    cfg = {"lowes_ratio": 0.8}
+    got = matching.match_brute_force_symmetric(f1, f2, cfg)
+    want = oracle_lib.match_brute_force_symmetric(f1, f2)
+    assert got == [tuple(int(v) for v in x) for x in want]
+    got1 = matching.match_brute_force(f1, f2, cfg)
+    want1 = oracle_lib.match_brute_force(f1, f2)
+    assert got1 == [tuple(int(v) for v in x) for x in want1]
+    if k >= 8:
+        assert len(want) >= k // 2
+
+
+def test_ties_and_duplicates(oracle_lib, gpu_ctx):
+    """Duplicate train rows: lowest index wins and the ratio test (strict <) fails on equal distances."""
+    from opensfm_amd import matching
+
+    rng = np.random.default_rng(11)
+    f1 = _rand_desc(rng, 100, 64)
+    f2 = np.concatenate([f1[:50], f1[:50], _rand_desc(rng, 30, 64)])  # every query has two exact copies
+    f2 = f2[rng.permutation(len(f2))]
+    for ratio in (0.8, 1.0, 1.5):
+        got = matching._match_leaf(f1, f2, ratio, False)
+        want = oracle_lib.match_brute_force(f1, f2, ratio)
+        assert np.array_equal(got, want)
+        gots = matching._match_leaf(f1, f2, ratio, True)
+        wants = oracle_lib.match_brute_force_symmetric(f1, f2, ratio)
+        assert np.array_equal(gots, wants)
+
+
+def test_extreme_range_takes_exact_path(oracle_lib, gpu_ctx):
+    """Descriptors at 0/255: d^2 up to 128*255^2 > 2^22, where sqrtf() merges neighbouring integers;
+    the flagged pairs must be re-run on the exact float-key kernel and still equal the oracle."""
+    from opensfm_amd import matching
+
+    rng = np.random.default_rng(12)
+    f1 = (rng.random((200, 128)) < 0.5).astype(np.float32) * 255
+    f2 = 255 - f1[rng.permutation(200)]
+    flip = rng.random(f2.shape) < 0.02
+    f2 = np.where(flip, 255 - f2, f2).astype(np.float32)
+    store = matching.DescriptorStore([f1, f2], [np.zeros((200, 2)), np.zeros((200, 2))])
+    from opensfm_amd._lib import MatchTimings
+
+    tm = MatchTimings()
+    counts, m = matching.match_pairs(store, np.array([[0, 1]], np.int32), {"lowes_ratio": 0.999}, robust=False, timings=tm)
+    want = oracle_lib.match_brute_force_symmetric(f1, f2, 0.999)
+    assert tm.pairs_exact_path == 1
+    assert np.array_equal(m, want)
+
+
+def test_rejects_non_integer_descriptors(gpu_ctx):
+    from opensfm_amd import matching
+    from opensfm_amd._lib import OsfmError
+
+    f = np.full((10, 128), 0.5, np.float32)
+    with pytest.raises(OsfmError):
+        matching.match_brute_force_symmetric(f, f, {})
+    with pytest.raises(NotImplementedError):
+        matching.match_brute_force(f.astype(np.uint8), f.astype(np.uint8), {})
+
+
+def test_batched_descriptor_stage_equals_oracle_ragged(oracle_lib, gpu_ctx):
+    """All pairs of a ragged 10-image scene, descriptor stage only (ratio + mutual)."""
+    from opensfm_amd import matching
+
+    sc = synthetic.make_matching_scene(10, 600, seed=21, ragged=True)
+    pairs = synthetic.all_pairs(10)
+    store = matching.DescriptorStore.from_packed(sc.desc, sc.pts, sc.offsets)
+    counts, m = matching.match_pairs(store, pairs, robust=False)
+    want = oracle_lib.match_pairs(sc.desc.astype(np.float32), sc.pts, sc.offsets, pairs, stage=0)
+    got = matching.split_matches(counts, m)
+    assert [len(g) for g in got] == [len(w) for w in want]
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    assert sum(len(w) for w in want) > 500
+
+
+def test_fused_equals_exact_kernel_full_size(gpu_ctx):
+    """Size-independent cross-check at BASELINE's per-image size (2000 x 128): the MFMA kernel and
+    the VALU float-key kernel must produce identical match lists for every pair."""
+    from opensfm_amd import matching
+
+    sc = synthetic.make_matching_scene(24, 2000, seed=33)
+    pairs = synthetic.all_pairs(24)
+    store = matching.DescriptorStore.from_packed(sc.desc, sc.pts, sc.offsets)
+    c1, m1 = matching.match_pairs(store, pairs, robust=False)
+    prm_cfg = {}
+    import ctypes as C
+
+    from opensfm_amd import _lib
+
+    prm = matching.make_params(prm_cfg, robust=False)
+    prm.reserved = 1
+    res = C.c_void_p()
+    lib = _lib.load()
+    _lib.check(lib.osfm_match_pairs(store.ctx.handle, store.handle, pairs.ctypes.data_as(C.POINTER(C.c_int32)), len(pairs),
+                                    C.byref(prm), C.byref(res), None))
+    n, tot = lib.osfm_result_num_pairs(res), lib.osfm_result_total_matches(res)
+    c2 = np.zeros(n, np.int32)
+    m2 = np.zeros((max(tot, 1), 2), np.int32)
+    _lib.check(lib.osfm_result_fetch(res, c2.ctypes.data_as(C.POINTER(C.c_int32)), m2.ctypes.data_as(C.POINTER(C.c_int32))))
+    lib.osfm_result_destroy(res)
+    assert np.array_equal(c1, c2)
+    assert np.array_equal(m1, m2[:tot])
+    assert c1.sum() > 5000
+    # mutual matches are a partial injection: each feature appears at most once per pair
+    for g in matching.split_matches(c1, m1):
+        assert len(set(g[:, 0])) == len(g) and len(set(g[:, 1])) == len(g)

@@ -1,0 +1,82 @@
+"""CPU: the F-RANSAC oracle -- algebraic properties of the 7-point solver, the restated
+RANSACUpdateNumIters, statistical recovery in the style of opensfm/test/test_robust.py."""
+import math
+
+import numpy as np
+import pytest
+
+from opensfm_amd import synthetic
+
+
+def test_det_log_is_log(oracle_lib):
+    for x in [1e-300, 1e-4, 0.3, 0.5, 0.70710678, 0.9999, 1.0, 1.5, 7.0, 1e10]:
+        assert oracle_lib.det_log(x) == pytest.approx(math.log(x), rel=1e-15, abs=1e-16)
+
+
+def test_update_num_iters_matches_formula(oracle_lib):
+    for ep in [0.0, 0.1, 0.3, 0.5, 0.8, 0.95, 1.0]:
+        got = oracle_lib.update_num_iters(0.9999, ep, 1000)
+        denom = 1 - (1 - ep) ** 7
+        if denom < 1e-300:
+            want = 0
+        else:
+            num, den = math.log(1 - 0.9999), math.log(denom) if denom < 1 else 0.0
+            want = 1000 if den >= 0 or -num >= 1000 * -den else round(num / den)
+        assert got == want
+
+
+def test_cvrng_is_multiply_with_carry(oracle_lib):
+    seq = oracle_lib.cvrng_sequence(-1, 4)
+    state = 2**64 - 1
+    for v in seq:
+        state = (state & 0xFFFFFFFF) * 4164903690 + (state >> 32)
+        state &= 2**64 - 1
+        assert int(v) == state & 0xFFFFFFFF
+
+
+def test_seven_point_models_satisfy_constraints(oracle_lib):
+    p1, p2, _ = synthetic.make_two_view(7, inlier_frac=1.1, seed=3, px_noise=0.0)
+    Fs = oracle_lib.run_7point(p1, p2)
+    assert 1 <= len(Fs) <= 3
+    for F in Fs:
+        res = [abs(np.array([x2[0], x2[1], 1.0]) @ F @ np.array([x1[0], x1[1], 1.0])) for x1, x2 in zip(p1, p2)]
+        assert max(res) < 1e-9 * np.abs(F).max()
+        assert abs(np.linalg.det(F)) < 1e-9 * np.abs(F).max() ** 3
+
+
+@pytest.mark.parametrize("n,frac,seed", [(100, 0.7, 0), (300, 0.5, 1), (1000, 0.35, 2), (20, 0.9, 3)])
+def test_ransac_recovers_inliers(oracle_lib, n, frac, seed):
+    # style of test_robust.py: inlier count within tolerance of the injected one
+    p1, p2, inl = synthetic.make_two_view(n, frac, seed)
+    F, mask, iters = oracle_lib.find_fundamental_ransac(p1, p2, 0.004, 0.9999)
+    assert F is not None and F[2, 2] == 1.0
+    assert 1 <= iters <= 1000
+    assert (mask & inl).sum() >= 0.9 * inl.sum()
+    assert (mask & ~inl).sum() <= 0.15 * max(1, (~inl).sum()) + 3
+
+
+def test_ransac_is_deterministic(oracle_lib):
+    p1, p2, _ = synthetic.make_two_view(200, 0.6, 9)
+    a = oracle_lib.find_fundamental_ransac(p1, p2)
+    b = oracle_lib.find_fundamental_ransac(p1, p2)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+
+
+def test_lmeds_branch_is_flagged(oracle_lib):
+    p1, p2, _ = synthetic.make_two_view(12, 1.1, 1)
+    with pytest.raises(NotImplementedError):
+        oracle_lib.find_fundamental_ransac(p1, p2)
+
+
+def test_pipeline_gates(oracle_lib):
+    """matching.py:590-598,632-634: pairs under 20 matches (before or after RANSAC) return []."""
+    sc = synthetic.make_matching_scene(6, 300, seed=4)
+    pairs = synthetic.all_pairs(6)
+    full = oracle_lib.match_pairs(sc.desc.astype(np.float32), sc.pts, sc.offsets, pairs, stage=1)
+    desc_only = oracle_lib.match_pairs(sc.desc.astype(np.float32), sc.pts, sc.offsets, pairs, stage=0)
+    for f, d in zip(full, desc_only):
+        assert len(f) == 0 or len(f) >= 20
+        assert len(f) <= len(d)
+        if len(f):
+            assert {tuple(x) for x in f} <= {tuple(x) for x in d}
+    assert sum(len(f) > 0 for f in full) >= 3
