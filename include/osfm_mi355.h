@@ -116,6 +116,74 @@ int osfm_ransac_fundamental(osfm_ctx *ctx, const double *p1, const double *p2, i
                             double conf, int max_iters, double F[9], uint8_t *mask, int *found,
                             int *iters_run_or_null);
 
+/* ==========================================================================================
+ * Bundle adjustment.  Replaces pysfm.BAHelpers.bundle (opensfm/src/sfm/src/ba_helpers.cc:581-763,
+ * python seam opensfm/reconstruction.py:69-86) == bundle::BundleAdjuster::Run
+ * (opensfm/src/bundle/src/bundle_adjuster.cc:595-1121) for the residual families BAHelpers::Bundle
+ * adds on a plain reconstruction: reprojection errors with a shared robust loss
+ * (projection_errors.h:59-208), camera-intrinsics priors (bundle_adjuster.cc:568-593) and
+ * position priors on the shot origins (bundle_adjuster.cc:745-778, identity bias).
+ * Flat SoA problem; all arrays are host pointers, in/out arrays are overwritten with the optimum.
+ * ========================================================================================== */
+#define OSFM_LOSS_TRIVIAL 0  /* "TrivialLoss"  (bundle_adjuster.cc:414-429) */
+#define OSFM_LOSS_SOFTLONE 1 /* "SoftLOneLoss" -- the reference default (config.py:241) */
+#define OSFM_LOSS_HUBER 2    /* "HuberLoss"    */
+#define OSFM_LOSS_CAUCHY 3   /* "CauchyLoss"   */
+
+typedef struct {
+  int32_t n_cameras, n_shots, n_points;
+  int64_t n_obs;
+  double *cam_params;        /* n_cameras x 3: k1, k2, focal (geometry/src/camera.cc:9-17)   in/out */
+  const double *cam_prior;   /* n_cameras x 3                                                       */
+  const double *cam_sigma;   /* n_cameras x 3: prior sd of k1, k2, focal (focal: log-ratio)         */
+  const uint8_t *cam_fixed;  /* n_cameras: 1 = constant (optimize_camera_parameters False)          */
+  double *shot_pose;         /* n_shots x 6: rx ry rz tx ty tz (bundle/data/pose.h:17,34-43) in/out */
+  const int32_t *shot_camera;    /* n_shots                                                         */
+  const uint8_t *shot_fixed;     /* n_shots or NULL                                                 */
+  const double *shot_gps;        /* n_shots x 3 or NULL: prior on the origin                        */
+  const double *shot_gps_sigma;  /* n_shots or NULL: sd (<= 0: no prior for that shot)              */
+  double *points;                /* n_points x 3                                             in/out */
+  const uint8_t *point_fixed;    /* n_points or NULL                                                */
+  const int32_t *obs_shot;       /* n_obs                                                           */
+  const int32_t *obs_point;      /* n_obs                                                           */
+  const double *obs_xy;          /* n_obs x 2 normalized image coordinates (observation.point)     */
+  const double *obs_sigma;       /* n_obs: observation.scale == std_deviation (tracking.py:108)     */
+  double *reproj_err;            /* n_obs x 2 or NULL: out, residual with sigma 1                   */
+                                 /* (ComputeReprojectionErrors, bundle_adjuster.cc:1196-1208)        */
+} osfm_ba_problem;
+
+typedef struct {
+  int32_t loss;               /* OSFM_LOSS_*                 config["loss_function"]           */
+  double loss_threshold;      /* config["loss_function_threshold"] = 1 (config.py:243)        */
+  int32_t max_iterations;     /* config["bundle_max_iterations"] = 100 (config.py:283)        */
+  double function_tolerance;  /* ceres default 1e-6                                           */
+  double gradient_tolerance;  /* ceres default 1e-10                                          */
+  double parameter_tolerance; /* ceres default 1e-8                                           */
+  double initial_radius;      /* ceres initial_trust_region_radius 1e4                        */
+  int32_t verbose;
+  double pcg_tolerance;       /* relative residual of the Schur-PCG solve (default 1e-10)     */
+  int32_t pcg_max_iterations; /* default 1000                                                 */
+} osfm_ba_options;
+
+void osfm_ba_options_default(osfm_ba_options *o);
+
+typedef struct {
+  int32_t iterations;       /* LM iterations (successful + unsuccessful), ceres' num_iterations - 1 */
+  int32_t successful_steps;
+  int32_t termination;      /* 0 max iterations, 1 function tol, 2 gradient tol, 3 parameter tol,
+                               4 min trust region radius, -1 failure */
+  double initial_cost, final_cost;
+  double rmse_normalized_initial, rmse_normalized_final; /* sqrt(mean |pi(X) - obs|^2), x max(w,h) = px */
+  double seconds_total, seconds_linear_solver;           /* wall_times (ba_helpers.cc:749-753)          */
+  double cost_history[256];
+  int64_t pcg_iterations_total;
+  double ms_matvec_total;    /* HIP-event time spent in the Schur mat-vec kernels */
+  int64_t matvec_calls;
+} osfm_ba_report;
+
+int osfm_ba_solve(osfm_ctx *ctx, osfm_ba_problem *problem, const osfm_ba_options *options,
+                  osfm_ba_report *report);
+
 #ifdef __cplusplus
 }
 #endif

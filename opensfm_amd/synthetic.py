@@ -164,3 +164,79 @@ def make_two_view(
     n_out = int((~inl).sum())
     p2[~inl] = np.stack([rng.uniform(-0.5, 0.5, n_out), rng.uniform(-0.375, 0.375, n_out)], axis=1)
     return np.ascontiguousarray(p1), np.ascontiguousarray(p2), inl
+
+
+# ------------------------------------------------------------------------------------------------
+# bundle adjustment scenes (SURVEY.md 8d "Synthetic BA inputs")
+# ------------------------------------------------------------------------------------------------
+def project_perspective(X: np.ndarray, pose: np.ndarray, cam: np.ndarray) -> np.ndarray:
+    """PoseFunctor + perspective [k1, k2, focal] (transformations_functions.h:112-144,
+    camera_projections_functions.h:88-93, camera_distortions_functions.h:106-113)."""
+    out = np.empty((len(X), 2))
+    R = _rodrigues(-np.asarray(pose[:3], float))
+    Xc = (X - pose[3:6]) @ R.T
+    u, v = Xc[:, 0] / Xc[:, 2], Xc[:, 1] / Xc[:, 2]
+    r2 = u * u + v * v
+    d = 1 + r2 * (cam[0] + cam[1] * r2)
+    out[:, 0] = cam[2] * d * u
+    out[:, 1] = cam[2] * d * v
+    return out
+
+
+def make_ba_scene(n_shots: int, n_points: int, track_len: int = 10, seed: int = 42, outlier_frac: float = 0.05,
+                  px_noise: float = 1.0 / 2000.0, pose_noise_t: float = 0.05, pose_noise_r: float = 0.01,
+                  point_noise: float = 0.05, gps_sigma: float = 5.0, use_gps: bool = True) -> dict:
+    """Street scene with `n_points` tracks of length `track_len` over `n_shots` cameras.
+
+    Returns the flat problem dict consumed by ``bundle_arrays`` / ``oracle.ba_solve``; ground truth
+    under the ``gt_*`` keys.  Camera = shared perspective [k1, k2, focal] = [-0.1, 0.01, 0.7]
+    (synthetic_examples.py:56,81), observation sigma 0.004 (synthetic_generator.py:404)."""
+    rng = np.random.default_rng(seed)
+    cam = np.array([-0.1, 0.01, 0.7])
+    L = min(track_len, n_shots)
+    step = min(0.5, 5.0 / max(L, 1))
+    gt_pose = np.zeros((n_shots, 6))
+    gt_pose[:, 0:3] = rng.normal(0, 0.03, (n_shots, 3))
+    gt_pose[:, 3] = np.arange(n_shots) * step
+    gt_pose[:, 4:6] = rng.normal(0, 0.05, (n_shots, 2))
+    first = rng.integers(0, max(1, n_shots - L + 1), n_points)
+    centre = (first + (L - 1) / 2.0) * step
+    gt_pts = np.stack([centre + rng.uniform(-0.4, 0.4, n_points), rng.uniform(-1.5, 1.5, n_points),
+                       rng.uniform(4.0, 12.0, n_points)], axis=1)
+    obs_point = np.repeat(np.arange(n_points, dtype=np.int32), L)
+    obs_shot = (first[:, None] + np.arange(L)[None, :]).reshape(-1).astype(np.int32)
+    order = np.lexsort((obs_point, obs_shot))  # shot-major like BAHelpers::Bundle's loops (ba_helpers.cc:685-699)
+    obs_shot, obs_point = obs_shot[order], obs_point[order]
+    xy = np.empty((len(obs_shot), 2))
+    bounds = np.searchsorted(obs_shot, np.arange(n_shots + 1))
+    for s in range(n_shots):
+        a, b = bounds[s], bounds[s + 1]
+        xy[a:b] = project_perspective(gt_pts[obs_point[a:b]], gt_pose[s], cam)
+    xy += rng.normal(0, px_noise, xy.shape)
+    out = rng.random(len(xy)) < outlier_frac
+    xy[out] += rng.uniform(-0.03, 0.03, (int(out.sum()), 2))  # gross mismatches: up to +-60 px at 2000 px
+    pose0 = gt_pose.copy()
+    pose0[:, 0:3] += rng.normal(0, pose_noise_r, (n_shots, 3))
+    pose0[:, 3:6] += rng.normal(0, pose_noise_t, (n_shots, 3))
+    pts0 = gt_pts + rng.normal(0, point_noise, gt_pts.shape)
+    prob = {
+        "cam_params": cam[None, :].copy(),
+        "cam_prior": cam[None, :].copy(),
+        "cam_sigma": np.full((1, 3), 0.01),  # config.py:247-263
+        "cam_fixed": np.zeros(1, np.uint8),
+        "shot_pose": pose0,
+        "shot_camera": np.zeros(n_shots, np.int32),
+        "points": pts0,
+        "obs_shot": obs_shot,
+        "obs_point": obs_point,
+        "obs_xy": xy,
+        "obs_sigma": np.full(len(xy), 0.004),
+        "gt_pose": gt_pose,
+        "gt_points": gt_pts,
+        "gt_cam": cam,
+        "is_outlier": out,
+    }
+    if use_gps:
+        prob["shot_gps"] = gt_pose[:, 3:6] + rng.normal(0, gps_sigma / 10.0, (n_shots, 3))
+        prob["shot_gps_sigma"] = np.full(n_shots, gps_sigma)
+    return prob

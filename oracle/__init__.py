@@ -139,3 +139,95 @@ def match_pairs(desc_f32: np.ndarray, pts: np.ndarray, offsets: np.ndarray, pair
 
 def num_threads() -> int:
     return lib().oracle_num_threads()
+
+
+# ------------------------------------------------------------------------------------------------
+# bundle adjustment oracle (oracle/ba_oracle.c)
+# ------------------------------------------------------------------------------------------------
+class _BaProblem(C.Structure):
+    _fields_ = [
+        ("n_cameras", C.c_int32), ("n_shots", C.c_int32), ("n_points", C.c_int32), ("n_obs", C.c_int64),
+        ("cam_params", C.POINTER(C.c_double)), ("cam_prior", C.POINTER(C.c_double)), ("cam_sigma", C.POINTER(C.c_double)),
+        ("cam_fixed", C.POINTER(C.c_uint8)),
+        ("shot_pose", C.POINTER(C.c_double)), ("shot_camera", C.POINTER(C.c_int32)), ("shot_fixed", C.POINTER(C.c_uint8)),
+        ("shot_gps", C.POINTER(C.c_double)), ("shot_gps_sigma", C.POINTER(C.c_double)),
+        ("points", C.POINTER(C.c_double)), ("point_fixed", C.POINTER(C.c_uint8)),
+        ("obs_shot", C.POINTER(C.c_int32)), ("obs_point", C.POINTER(C.c_int32)),
+        ("obs_xy", C.POINTER(C.c_double)), ("obs_sigma", C.POINTER(C.c_double)), ("reproj_err", C.POINTER(C.c_double)),
+    ]
+
+
+class _BaOptions(C.Structure):
+    _fields_ = [("loss", C.c_int32), ("loss_threshold", C.c_double), ("max_iterations", C.c_int32),
+                ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
+                ("initial_radius", C.c_double), ("verbose", C.c_int32)]
+
+
+class _BaReport(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("successful_steps", C.c_int32), ("termination", C.c_int32),
+                ("initial_cost", C.c_double), ("final_cost", C.c_double),
+                ("rmse_normalized_initial", C.c_double), ("rmse_normalized_final", C.c_double),
+                ("seconds_total", C.c_double), ("seconds_linear_solver", C.c_double), ("cost_history", C.c_double * 256)]
+
+
+LOSSES = {"TrivialLoss": 0, "SoftLOneLoss": 1, "HuberLoss": 2, "CauchyLoss": 3}
+
+
+def ba_solve(problem: dict, loss: str = "SoftLOneLoss", loss_threshold: float = 1.0, max_iterations: int = 100,
+             function_tolerance: float = 1e-6, gradient_tolerance: float = 1e-10, parameter_tolerance: float = 1e-8,
+             verbose: bool = False) -> dict:
+    """Solve a flat BA problem (see opensfm_amd.synthetic.make_ba_scene for the dict layout).
+    Returns a dict with the optimised arrays and the report.  Inputs are not modified."""
+    f64 = lambda k: np.ascontiguousarray(problem[k], np.float64).copy()
+    i32 = lambda k: np.ascontiguousarray(problem[k], np.int32)
+    cams, poses, pts = f64("cam_params"), f64("shot_pose"), f64("points")
+    cam_prior = np.ascontiguousarray(problem.get("cam_prior", problem["cam_params"]), np.float64)
+    cam_sigma = np.ascontiguousarray(problem.get("cam_sigma", np.full_like(cams, 0.01)), np.float64)
+    cam_fixed = np.ascontiguousarray(problem.get("cam_fixed", np.zeros(len(cams), np.uint8)), np.uint8)
+    shot_camera = i32("shot_camera")
+    obs_shot, obs_point = i32("obs_shot"), i32("obs_point")
+    obs_xy = np.ascontiguousarray(problem["obs_xy"], np.float64)
+    obs_sigma = np.ascontiguousarray(problem["obs_sigma"], np.float64)
+    reproj = np.zeros((len(obs_shot), 2), np.float64)
+    keep = [cams, poses, pts, cam_prior, cam_sigma, cam_fixed, shot_camera, obs_shot, obs_point, obs_xy, obs_sigma, reproj]
+    P = _BaProblem()
+    P.n_cameras, P.n_shots, P.n_points, P.n_obs = len(cams), len(poses), len(pts), len(obs_shot)
+    P.cam_params, P.cam_prior, P.cam_sigma = _p(cams, C.c_double), _p(cam_prior, C.c_double), _p(cam_sigma, C.c_double)
+    P.cam_fixed = _p(cam_fixed, C.c_uint8)
+    P.shot_pose, P.shot_camera = _p(poses, C.c_double), _p(shot_camera, C.c_int32)
+    for key, fld, t, ct in (("shot_fixed", "shot_fixed", np.uint8, C.c_uint8), ("point_fixed", "point_fixed", np.uint8, C.c_uint8),
+                            ("shot_gps", "shot_gps", np.float64, C.c_double), ("shot_gps_sigma", "shot_gps_sigma", np.float64, C.c_double)):
+        if problem.get(key) is not None:
+            arr = np.ascontiguousarray(problem[key], t)
+            keep.append(arr)
+            setattr(P, fld, _p(arr, ct))
+    P.points = _p(pts, C.c_double)
+    P.obs_shot, P.obs_point = _p(obs_shot, C.c_int32), _p(obs_point, C.c_int32)
+    P.obs_xy, P.obs_sigma, P.reproj_err = _p(obs_xy, C.c_double), _p(obs_sigma, C.c_double), _p(reproj, C.c_double)
+    O = _BaOptions(LOSSES[loss], loss_threshold, max_iterations, function_tolerance, gradient_tolerance,
+                   parameter_tolerance, 1e4, int(verbose))
+    R = _BaReport()
+    lib().oracle_ba_solve(C.byref(P), C.byref(O), C.byref(R))
+    return {
+        "cam_params": cams, "shot_pose": poses, "points": pts, "reproj_err": reproj,
+        "iterations": R.iterations, "successful_steps": R.successful_steps, "termination": R.termination,
+        "initial_cost": R.initial_cost, "final_cost": R.final_cost,
+        "rmse_initial": R.rmse_normalized_initial, "rmse_final": R.rmse_normalized_final,
+        "seconds_total": R.seconds_total, "seconds_linear_solver": R.seconds_linear_solver,
+        "cost_history": np.array(R.cost_history[: R.iterations + 1]),
+    }
+
+
+def ba_project(X, pose, cam, obs, sigma):
+    """One observation: residual (2), Jp (2x3), Jc (2x6: d/d(rx,ry,rz,tx,ty,tz)), Jk (2x3: d/d(k1,k2,f))."""
+    X, pose, cam, obs = (np.ascontiguousarray(a, np.float64) for a in (X, pose, cam, obs))
+    res, Jp, Jc, Jk = np.zeros(2), np.zeros(6), np.zeros(12), np.zeros(6)
+    lib().oracle_ba_project(_p(X, C.c_double), _p(pose, C.c_double), _p(cam, C.c_double), _p(obs, C.c_double),
+                            C.c_double(sigma), _p(res, C.c_double), _p(Jp, C.c_double), _p(Jc, C.c_double), _p(Jk, C.c_double))
+    return res, Jp.reshape(2, 3), Jc.reshape(2, 6), Jk.reshape(2, 3)
+
+
+def ba_loss(loss: str, a: float, s: float):
+    out = np.zeros(2)
+    lib().oracle_ba_loss(LOSSES[loss], C.c_double(a), C.c_double(s), _p(out, C.c_double))
+    return out[0], out[1]

@@ -1,0 +1,91 @@
+"""Generates tests/golden/reprojection_golden.json: residual + Jacobian of the reference's
+reprojection error at the reference's OWN test inputs, evaluated independently of any C code.
+
+Inputs: opensfm/src/bundle/test/reprojection_errors_test.cc:17-18,105-111,123-128 (point (1,2,3),
+rt (0.1..0.6), observed (0.5,0.5), std_deviation 0.1, perspective camera array {0.3, 0.1, -0.03}
+in native parameter order [k1, k2, focal]) and opensfm/src/geometry/test/camera_functions_test.cc
+(point (0.1,0.2,0.3) style inputs, focal 0.4, k1 -0.1, k2 0.01).  The reference's expected values
+are "autodiff of the same formulas"; here the formulas of transformations_functions.h:112-144,
+camera_projections_functions.h:88-93, camera_distortions_functions.h:106-113,
+transformations_functions.h:55-58 and projection_errors.h:203-205 are written in mpmath (50
+digits) and differentiated numerically in 50-digit arithmetic (central differences, h = 1e-20),
+i.e. accurate to far better than the 1e-14 the reference asserts.
+
+Run:  python tests/golden/gen_reprojection_golden.py
+"""
+import json
+import os
+
+import mpmath as mp
+
+mp.mp.dps = 50
+
+
+def residual(X, pose, cam, obs, sd):
+    r, t = pose[:3], pose[3:]
+    p = [X[i] - t[i] for i in range(3)]
+    a = [-r[i] for i in range(3)]
+    th2 = sum(v * v for v in a)
+    cp = [a[1] * p[2] - a[2] * p[1], a[2] * p[0] - a[0] * p[2], a[0] * p[1] - a[1] * p[0]]
+    if th2 > mp.mpf(2) ** -52:
+        th = mp.sqrt(th2)
+        c, s = mp.cos(th), mp.sin(th) / th
+        dot = sum(a[i] * p[i] for i in range(3)) * (1 - c) / th2
+        Xc = [p[i] * c + s * cp[i] + a[i] * dot for i in range(3)]
+    else:
+        Xc = [p[i] + cp[i] for i in range(3)]
+    u, v = Xc[0] / Xc[2], Xc[1] / Xc[2]
+    r2 = u * u + v * v
+    k1, k2, f = cam
+    d = 1 + r2 * (k1 + k2 * r2)
+    return [(f * d * u - obs[0]) / sd, (f * d * v - obs[1]) / sd]
+
+
+def jac(fun, x):
+    h = mp.mpf(10) ** -20
+    cols = []
+    for i in range(len(x)):
+        xp, xm = list(x), list(x)
+        xp[i] += h
+        xm[i] -= h
+        fp, fm = fun(xp), fun(xm)
+        cols.append([(fp[k] - fm[k]) / (2 * h) for k in range(2)])
+    return [[cols[i][k] for i in range(len(x))] for k in range(2)]
+
+
+CASES = [
+    # reprojection_errors_test.cc PerspectiveAnalyticErrorEvaluatesOK inputs (single pose)
+    dict(X=[1.0, 2.0, 3.0], pose=[0.1, 0.2, 0.3, 0.4, 0.5, 0.6], cam=[0.3, 0.1, -0.03], obs=[0.5, 0.5], sd=0.1),
+    # camera_functions_test.cc style: focal 0.4, k1 -0.1, k2 0.01
+    dict(X=[0.1, 0.2, 0.3], pose=[0.1, 0.2, 0.3, 0.4, 0.5, 0.6], cam=[-0.1, 0.01, 0.4], obs=[0.0, 0.0], sd=1.0),
+    # synthetic scene camera (synthetic_examples.py:56,81), generic pose, sigma 0.004
+    dict(X=[3.7, -1.2, 9.5], pose=[0.02, -0.03, 0.01, 3.1, 0.05, -0.02], cam=[-0.1, 0.01, 0.7], obs=[0.04, -0.09], sd=0.004),
+    # tiny rotation (below the reference's epsilon branch) and a small-but-regular one
+    dict(X=[0.5, 0.4, 6.0], pose=[1e-9, -2e-9, 1e-9, 0.1, 0.0, 0.0], cam=[-0.1, 0.01, 0.7], obs=[0.1, 0.1], sd=0.004),
+    dict(X=[0.5, 0.4, 6.0], pose=[1e-4, -2e-4, 1e-4, 0.1, 0.0, 0.0], cam=[-0.1, 0.01, 0.7], obs=[0.1, 0.1], sd=0.004),
+    dict(X=[-2.0, 1.0, 5.0], pose=[1.2, -0.7, 2.1, -1.0, 0.3, 0.8], cam=[0.05, -0.002, 0.9], obs=[-0.2, 0.3], sd=0.01),
+]
+
+
+def main():
+    out = []
+    for c in CASES:
+        X = [mp.mpf(repr(v)) for v in c["X"]]
+        pose = [mp.mpf(repr(v)) for v in c["pose"]]
+        cam = [mp.mpf(repr(v)) for v in c["cam"]]
+        obs = [mp.mpf(repr(v)) for v in c["obs"]]
+        sd = mp.mpf(repr(c["sd"]))
+        r = residual(X, pose, cam, obs, sd)
+        Jp = jac(lambda x: residual(x, pose, cam, obs, sd), X)
+        Jc = jac(lambda x: residual(X, x, cam, obs, sd), pose)
+        Jk = jac(lambda x: residual(X, pose, x, obs, sd), cam)
+        f = lambda m: [[float(v) for v in row] for row in m]
+        out.append(dict(c, residual=[float(v) for v in r], Jp=f(Jp), Jc=f(Jc), Jk=f(Jk)))
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reprojection_golden.json")
+    with open(path, "w") as fh:
+        json.dump(out, fh, indent=1)
+    print("wrote", path, len(out), "cases")
+
+
+if __name__ == "__main__":
+    main()
