@@ -43,6 +43,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-pairs", type=int, default=384)
     ap.add_argument("--no-ba", action="store_true")
+    ap.add_argument("--ba-shots", type=int, default=5000)
+    ap.add_argument("--ba-points", type=int, default=500000)
+    ap.add_argument("--ba-track", type=int, default=10)
+    ap.add_argument("--ba-iters", type=int, default=10)
     ap.add_argument("--no-robust", action="store_true", help="descriptor stage only (debug)")
     return ap.parse_args()
 
@@ -174,7 +178,8 @@ def main():
             try:
                 from opensfm_amd import ba_bench
 
-                out["ba"] = ba_bench.run(ctx, cpu_baseline=not args.no_cpu_baseline)
+                out["ba"] = ba_bench.run(ctx, args.ba_shots, args.ba_points, args.ba_track, args.ba_iters,
+                                         cpu_baseline=not args.no_cpu_baseline)
             except ImportError:
                 out["ba"] = None
         print(json.dumps(out), flush=True)

@@ -48,8 +48,8 @@ def test_lm_trajectory_equals_oracle(oracle_lib, gpu_ctx, shots, points, track, 
     assert abs(g["rmse_final"] - o["rmse_final"]) * PX < 1e-4
     assert np.allclose(g["cam_params"], o["cam_params"], atol=1e-6)
     assert np.allclose(g["shot_pose"], o["shot_pose"], atol=1e-5)
-    inl = ~pr["is_outlier"]
-    assert _rmse_px(g["reproj_err"], inl) < 2.5
+    if loss != "TrivialLoss":  # a robust loss is needed to shrug off the 5 % gross outliers
+        assert _rmse_px(g["reproj_err"], ~pr["is_outlier"]) < 2.5
 
 
 def test_default_termination_matches_oracle(oracle_lib, gpu_ctx):
