@@ -163,6 +163,8 @@ typedef struct {
   int32_t verbose;
   double pcg_tolerance;       /* relative residual of the Schur-PCG solve (default 1e-10)     */
   int32_t pcg_max_iterations; /* default 1000                                                 */
+  int32_t preconditioner;     /* 0 auto: banded block Cholesky when the shot coupling is banded
+                                 (half-width <= 15 shots), else block Jacobi; 1: block Jacobi  */
 } osfm_ba_options;
 
 void osfm_ba_options_default(osfm_ba_options *o);
@@ -179,6 +181,8 @@ typedef struct {
   int64_t pcg_iterations_total;
   double ms_matvec_total;    /* HIP-event time spent in the Schur mat-vec kernels */
   int64_t matvec_calls;
+  int32_t shot_bandwidth;           /* max |shot_a - shot_b| over shots sharing a point          */
+  int32_t preconditioner_bandwidth; /* block half-width of the banded preconditioner, 0 = Jacobi */
 } osfm_ba_report;
 
 int osfm_ba_solve(osfm_ctx *ctx, osfm_ba_problem *problem, const osfm_ba_options *options,

@@ -20,7 +20,7 @@ class BaOptions(C.Structure):
         ("loss", C.c_int32), ("loss_threshold", C.c_double), ("max_iterations", C.c_int32),
         ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
         ("initial_radius", C.c_double), ("verbose", C.c_int32), ("pcg_tolerance", C.c_double),
-        ("pcg_max_iterations", C.c_int32),
+        ("pcg_max_iterations", C.c_int32), ("preconditioner", C.c_int32),
     ]
 
 
@@ -31,6 +31,7 @@ class BaReport(C.Structure):
         ("rmse_normalized_initial", C.c_double), ("rmse_normalized_final", C.c_double),
         ("seconds_total", C.c_double), ("seconds_linear_solver", C.c_double), ("cost_history", C.c_double * 256),
         ("pcg_iterations_total", C.c_int64), ("ms_matvec_total", C.c_double), ("matvec_calls", C.c_int64),
+        ("shot_bandwidth", C.c_int32), ("preconditioner_bandwidth", C.c_int32),
     ]
 
 

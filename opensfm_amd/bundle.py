@@ -124,6 +124,7 @@ def bundle_arrays(problem: Dict[str, np.ndarray], config: Optional[Dict[str, Any
         "rmse_initial": R.rmse_normalized_initial, "rmse_final": R.rmse_normalized_final,
         "cost_history": np.array(R.cost_history[: min(R.iterations, 255) + 1]),
         "pcg_iterations": int(R.pcg_iterations_total),
+        "shot_bandwidth": int(R.shot_bandwidth), "preconditioner_bandwidth": int(R.preconditioner_bandwidth),
         "seconds_solver": R.seconds_total, "seconds_linear_solver": R.seconds_linear_solver,
         "ms_per_matvec": (R.ms_matvec_total / R.matvec_calls) if R.matvec_calls else None,
         # report dict of BAHelpers::Bundle (ba_helpers.cc:743-762)

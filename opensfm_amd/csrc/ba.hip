@@ -206,6 +206,11 @@ struct Dev {
   double *Hcc;      // 21 x S (obs part of the shot block), then 6 x NC
   double *Binv;     // 36 x S, then 9 x NC
   double *part;     // per-shot partials for camera blocks: 9 x S
+  double *camred;   // 9 x NC: per-camera sums of `part` (deterministic block reduction)
+  // banded preconditioner (shot-shot part of the Schur complement inside a block band of half-width bw)
+  int bw;           // block half-bandwidth actually used (0: block-Jacobi only)
+  double *band;     // S x (bw+1) x 36: block (s, s-k), after factorisation the Cholesky factor L
+  double *dinv;     // S x 36: inverse of the diagonal blocks of L
   double *zc;       // nred (unscaled J^T w)
   double *y;        // nred
   // pcg
@@ -384,14 +389,26 @@ __global__ void __launch_bounds__(64) shot_grad_kernel(Dev d, const double *pose
   }
 }
 
-// camera blocks: sum the per-shot partials (deterministic order) + prior
+
+// camred[c][i] = sum over the shots of camera c of part[s][i]   (one block per camera, fixed order)
+__global__ void __launch_bounds__(TPB) cam_reduce_kernel(Dev d, int ncomp) {
+  __shared__ double lds[64];
+  const int c = blockIdx.x;
+  double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int s = threadIdx.x; s < d.S; s += TPB)
+    if (d.shot_camera[s] == c)
+      for (int i = 0; i < ncomp; i++) v[i] += d.part[9 * (long)s + i];
+  block_sum<9>(v, lds);
+  if (threadIdx.x == 0)
+    for (int i = 0; i < ncomp; i++) d.camred[9 * c + i] = v[i];
+}
+
+// camera blocks: per-shot partials (already reduced into camred) + prior
 __global__ void cam_grad_kernel(Dev d, const double *cams) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= d.NC) return;
-  double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int s = 0; s < d.S; s++)
-    if (d.shot_camera[s] == c)
-      for (int i = 0; i < 9; i++) v[i] += d.part[9 * (long)s + i];
+  double v[9];
+  for (int i = 0; i < 9; i++) v[i] = d.camred[9 * c + i];
   const bool fixed = d.cam_fixed[c];
   const double *q = cams + 3 * c, *pr = d.cam_prior + 3 * c, *sg = d.cam_sigma + 3 * c;
   const double w0 = 1.0 / fmax(sg[0], kEps), w1 = 1.0 / fmax(sg[1], kEps), w2 = 1.0 / fmax(sg[2], kEps);
@@ -552,10 +569,8 @@ __global__ void __launch_bounds__(64) precond_shot_kernel(Dev d, double radius) 
 __global__ void precond_cam_kernel(Dev d, double radius) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= d.NC) return;
-  double v[6] = {0, 0, 0, 0, 0, 0};
-  for (int s = 0; s < d.S; s++)
-    if (d.shot_camera[s] == c)
-      for (int i = 0; i < 6; i++) v[i] += d.part[9 * (long)s + i];
+  double v[6];
+  for (int i = 0; i < 6; i++) v[i] = d.camred[9 * c + i];
   double B[3][3];
   int q = 0;
   for (int i = 0; i < 3; i++)
@@ -578,6 +593,282 @@ __global__ void precond_cam_kernel(Dev d, double radius) {
   o[0] = c00 * id; o[1] = c01 * id; o[2] = c02 * id;
   o[3] = o[1]; o[4] = (B[0][0] * B[2][2] - B[0][2] * B[0][2]) * id; o[5] = (B[0][2] * B[0][1] - B[0][0] * B[1][2]) * id;
   o[6] = o[2]; o[7] = o[5]; o[8] = (B[0][0] * B[1][1] - B[0][1] * B[0][1]) * id;
+}
+
+
+// ---- banded preconditioner ---------------------------------------------------------------------
+// Sequence-like captures (the street-level case OpenSfM was written for) give a reduced camera
+// system whose shot-shot part is block banded: two shots interact only if they share a point.
+// M = band_bw(S_shots) (+ the 3x3 camera blocks) is assembled explicitly, factorised by a
+// sequential block Cholesky inside ONE wavefront (the dependency chain is S long, each link is a
+// few 6x6 products: latency bound, ~1 us per block row), and applied by two banded triangular
+// sweeps per CG iteration.  When bw covers every co-visibility, M equals the shot part of the
+// Schur complement exactly and CG only has to resolve the rank-3 coupling to the shared camera.
+constexpr int kMaxBw = 15;
+
+__device__ __forceinline__ void jred_jp(const Dev &d, long o, double E[6][3]) {
+  double jp[6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) jp[j] = Jcomp(d, 2 + j)[o];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    const double a = Jcomp(d, 8 + i)[o], b = Jcomp(d, 14 + i)[o];
+#pragma unroll
+    for (int j = 0; j < 3; j++) E[i][j] = a * jp[j] + b * jp[3 + j];
+  }
+}
+
+__global__ void __launch_bounds__(TPB) band_assemble_kernel(Dev d, double radius) {
+  __shared__ double acc[(kMaxBw + 1) * 36];
+  const int s = blockIdx.x, nb = (d.bw + 1) * 36;
+  for (int t = threadIdx.x; t < nb; t += TPB) acc[t] = 0.0;
+  __syncthreads();
+  for (long k = d.shot_off[s] + threadIdx.x; k < d.shot_off[s + 1]; k += TPB) {
+    const long o = d.shot_obs[k];
+    const int p = d.o_point[o];
+    const double *Hh = d.Hhat + 6 * (long)p;
+    const double h[9] = {Hh[0], Hh[1], Hh[2], Hh[1], Hh[3], Hh[4], Hh[2], Hh[4], Hh[5]};
+    double Ea[6][3], EH[6][3];
+    jred_jp(d, o, Ea);
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) EH[i][j] = Ea[i][0] * h[j] + Ea[i][1] * h[3 + j] + Ea[i][2] * h[6 + j];
+    for (long o2 = d.pt_off[p]; o2 < d.pt_off[p + 1]; o2++) {
+      const int dk = s - d.o_shot[o2];
+      if (dk < 0 || dk > d.bw) continue;
+      double Eb[6][3];
+      jred_jp(d, o2, Eb);
+#pragma unroll
+      for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j < 6; j++)
+          atomicAdd(&acc[dk * 36 + i * 6 + j], EH[i][0] * Eb[j][0] + EH[i][1] * Eb[j][1] + EH[i][2] * Eb[j][2]);
+    }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < nb; t += TPB) {
+    const int dk = t / 36, ij = t % 36, i = ij / 6, j = ij % 6;
+    const int s2 = s - dk;
+    double val = 0.0;
+    if (s2 >= 0) {
+      val = -acc[t];
+      if (dk == 0) {
+        const int hi = i > j ? i : j, lo = i > j ? j : i;
+        val += d.Hcc[21 * (long)s + hi * (hi + 1) / 2 + lo];
+        if (i == j) val += d.prior_diag[6 * s + i];
+      }
+      val *= d.sc_red[6 * s + i] * d.sc_red[6 * s2 + j];
+      if (dk == 0 && i == j) val += d.D_red[6 * s + i] / radius;
+    }
+    d.band[((long)s * (d.bw + 1) + dk) * 36 + ij] = val;
+  }
+}
+
+// sequential banded block Cholesky, one wavefront; ring[] keeps the last bw+1 factor rows in LDS
+__global__ void __launch_bounds__(64) band_cholesky_kernel(Dev d, int *status) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int R = d.bw + 1;            // ring rows == blocks per row
+  double *ring = lds;                // [R][R*36]
+  double *dinvr = ring + R * R * 36; // [R][36]
+  double *T = dinvr + R * 36;        // [36]
+  double *Lc = T + 36;               // [36] work: diagonal factor
+  const int lane = threadIdx.x;
+  const int r = lane / 6, c = lane % 6;  // valid for lane < 36
+  int bad = 0;
+  if (lane == 0) *status = 0;
+  // software prefetch of the next band row (the factorisation itself is a latency-bound chain)
+  constexpr int kPre = ((kMaxBw + 1) * 36 + 63) / 64;
+  double pre[kPre];
+#pragma unroll
+  for (int u = 0; u < kPre; u++) pre[u] = (lane + 64 * u < R * 36) ? d.band[lane + 64 * u] : 0.0;
+  for (int i = 0; i < d.S; i++) {
+    double *cur = ring + (i % R) * R * 36;
+#pragma unroll
+    for (int u = 0; u < kPre; u++)
+      if (lane + 64 * u < R * 36) cur[lane + 64 * u] = pre[u];
+    if (i + 1 < d.S) {
+#pragma unroll
+      for (int u = 0; u < kPre; u++) pre[u] = (lane + 64 * u < R * 36) ? d.band[(long)(i + 1) * R * 36 + lane + 64 * u] : 0.0;
+    }
+    __syncthreads();
+    for (int kk = d.bw; kk >= 1; kk--) {
+      const int j = i - kk;
+      if (j < 0) continue;
+      const double *rowj = ring + (j % R) * R * 36;
+      if (lane < 36) {
+        double t = cur[kk * 36 + lane];
+        const int m0 = (i - d.bw > j - d.bw ? i - d.bw : j - d.bw);
+        for (int m = (m0 < 0 ? 0 : m0); m < j; m++) {
+          const double *Lim = cur + (i - m) * 36, *Ljm = rowj + (j - m) * 36;
+#pragma unroll
+          for (int q = 0; q < 6; q++) t -= Lim[r * 6 + q] * Ljm[c * 6 + q];
+        }
+        T[lane] = t;
+      }
+      __syncthreads();
+      if (lane < 36) {
+        const double *dj = dinvr + (j % R) * 36;  // L_jj^-1 ; L_ij = T * L_jj^-T
+        double v = 0;
+#pragma unroll
+        for (int q = 0; q < 6; q++) v += T[r * 6 + q] * dj[c * 6 + q];
+        cur[kk * 36 + lane] = v;
+      }
+      __syncthreads();
+    }
+    // diagonal block
+    if (lane < 36) {
+      double t = cur[lane];
+      const int m0 = i - d.bw;
+      for (int m = (m0 < 0 ? 0 : m0); m < i; m++) {
+        const double *Lim = cur + (i - m) * 36;
+#pragma unroll
+        for (int q = 0; q < 6; q++) t -= Lim[r * 6 + q] * Lim[c * 6 + q];
+      }
+      T[lane] = t;
+      Lc[lane] = 0.0;
+    }
+    __syncthreads();
+    // 6x6 Cholesky, lane rr owns row rr
+    for (int cc = 0; cc < 6; cc++) {
+      if (lane < 6 && lane >= cc) {
+        double sum = T[lane * 6 + cc];
+        for (int q = 0; q < cc; q++) sum -= Lc[lane * 6 + q] * Lc[cc * 6 + q];
+        if (lane == cc) {
+          if (!(sum > 0)) { bad = 1; sum = 1.0; }
+          Lc[cc * 6 + cc] = sqrt(sum);
+        } else {
+          T[lane * 6 + cc] = sum;  // numerator, divided once the pivot is known
+        }
+      }
+      __syncthreads();
+      if (lane < 6 && lane > cc) Lc[lane * 6 + cc] = T[lane * 6 + cc] / Lc[cc * 6 + cc];
+      __syncthreads();
+    }
+    // inverse of the lower-triangular factor: lane cc computes column cc
+    double *di = dinvr + (i % R) * 36;
+    if (lane < 6) {
+      const int cc = lane;
+      double col[6];
+      for (int rr = 0; rr < 6; rr++) {
+        double sum = (rr == cc) ? 1.0 : 0.0;
+        for (int q = cc; q < rr; q++) sum -= Lc[rr * 6 + q] * col[q];
+        col[rr] = (rr >= cc) ? sum / Lc[rr * 6 + rr] : 0.0;
+      }
+      for (int rr = 0; rr < 6; rr++) di[rr * 6 + cc] = col[rr];
+    }
+    if (lane < 36) cur[lane] = Lc[lane];
+    __syncthreads();
+    for (int t = lane; t < R * 36; t += 64) d.band[(long)i * R * 36 + t] = cur[t];
+    if (lane < 36) d.dinv[(long)i * 36 + lane] = di[lane];
+    __syncthreads();
+  }
+  if (bad) *status = 1;
+}
+
+// z_shots = (L L^T)^-1 r_shots   (one wavefront, two banded sweeps); camera rows: 3x3 block Jacobi
+__global__ void __launch_bounds__(64) band_solve_kernel(Dev d, const double *rin, double *z) {
+  __shared__ double part[36];
+  __shared__ double tv[6];
+  __shared__ double yring[(kMaxBw + 1) * 6];
+  const int R = d.bw + 1;
+  const int lane = threadIdx.x, r = lane / 6, c = lane % 6;
+  // forward: y_i = Linv_ii (r_i - sum_k L_{i,i-k} y_{i-k}); operands of row i+1 are prefetched into
+  // registers while row i is in flight (the sweep is a latency-bound dependency chain)
+  double lb[kMaxBw], ld[6], lr = 0.0;
+  const int l36 = lane < 36 ? lane : 0, l6 = lane < 6 ? lane : 0;
+#pragma unroll
+  for (int k = 1; k <= kMaxBw; k++) lb[k - 1] = (k <= d.bw) ? d.band[(long)k * 36 + l36] : 0.0;
+#pragma unroll
+  for (int q = 0; q < 6; q++) ld[q] = d.dinv[l6 * 6 + q];
+  lr = rin[l6];
+  for (int i = 0; i < d.S; i++) {
+    double cb[kMaxBw], cd[6];
+    const double cr = lr;
+#pragma unroll
+    for (int k = 0; k < kMaxBw; k++) cb[k] = lb[k];
+#pragma unroll
+    for (int q = 0; q < 6; q++) cd[q] = ld[q];
+    if (i + 1 < d.S) {
+#pragma unroll
+      for (int k = 1; k <= kMaxBw; k++) lb[k - 1] = (k <= d.bw) ? d.band[((long)(i + 1) * R + k) * 36 + l36] : 0.0;
+#pragma unroll
+      for (int q = 0; q < 6; q++) ld[q] = d.dinv[(long)(i + 1) * 36 + l6 * 6 + q];
+      lr = rin[6 * (i + 1) + l6];
+    }
+    if (lane < 36) {
+      double acc = 0;
+#pragma unroll
+      for (int k = 1; k <= kMaxBw; k++)
+        if (k <= d.bw && k <= i) acc += cb[k - 1] * yring[((i - k) % R) * 6 + c];
+      part[lane] = acc;
+    }
+    __syncthreads();
+    if (lane < 6) {
+      double t = cr;
+      for (int q = 0; q < 6; q++) t -= part[lane * 6 + q];
+      tv[lane] = t;
+    }
+    __syncthreads();
+    if (lane < 6) {
+      double y = 0;
+#pragma unroll
+      for (int q = 0; q < 6; q++) y += cd[q] * tv[q];
+      yring[(i % R) * 6 + lane] = y;
+      z[6 * i + lane] = y;
+    }
+    __syncthreads();
+  }
+  // backward: x_i = Linv_ii^T (y_i - sum_k L_{i+k,i}^T x_{i+k})
+  const int lt = lane < 36 ? c * 6 + r : 0;
+  {
+    const int i = d.S - 1;
+#pragma unroll
+    for (int k = 1; k <= kMaxBw; k++) lb[k - 1] = (k <= d.bw && i + k < d.S) ? d.band[((long)(i + k) * R + k) * 36 + lt] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 6; q++) ld[q] = d.dinv[(long)i * 36 + q * 6 + l6];
+  }
+  for (int i = d.S - 1; i >= 0; i--) {
+    double cb[kMaxBw], cd[6];
+#pragma unroll
+    for (int k = 0; k < kMaxBw; k++) cb[k] = lb[k];
+#pragma unroll
+    for (int q = 0; q < 6; q++) cd[q] = ld[q];
+    if (i > 0) {
+#pragma unroll
+      for (int k = 1; k <= kMaxBw; k++)
+        lb[k - 1] = (k <= d.bw && i - 1 + k < d.S) ? d.band[((long)(i - 1 + k) * R + k) * 36 + lt] : 0.0;
+#pragma unroll
+      for (int q = 0; q < 6; q++) ld[q] = d.dinv[(long)(i - 1) * 36 + q * 6 + l6];
+    }
+    if (lane < 36) {
+      double acc = 0;
+#pragma unroll
+      for (int k = 1; k <= kMaxBw; k++)
+        if (k <= d.bw && i + k < d.S) acc += cb[k - 1] * yring[((i + k) % R) * 6 + c];
+      part[lane] = acc;
+    }
+    __syncthreads();
+    if (lane < 6) {
+      double t = z[6 * i + lane];
+      for (int q = 0; q < 6; q++) t -= part[lane * 6 + q];
+      tv[lane] = t;
+    }
+    __syncthreads();
+    if (lane < 6) {
+      double x = 0;
+#pragma unroll
+      for (int q = 0; q < 6; q++) x += cd[q] * tv[q];
+      yring[(i % R) * 6 + lane] = x;
+      z[6 * i + lane] = x;
+    }
+    __syncthreads();
+  }
+  // camera blocks
+  for (int cm = lane; cm < d.NC; cm += 64) {
+    const double *Bi = d.Binv + 36 * (long)d.S + 9 * cm, *rr = rin + d.cam0 + 3 * cm;
+    for (int i = 0; i < 3; i++) z[d.cam0 + 3 * cm + i] = Bi[3 * i] * rr[0] + Bi[3 * i + 1] * rr[1] + Bi[3 * i + 2] * rr[2];
+  }
 }
 
 // ---- Schur mat-vec ------------------------------------------------------------------------
@@ -677,9 +968,7 @@ __global__ void schur_finish_kernel(Dev d, const double *x, const double *y, dou
     zc = d.zc[i];
   } else {
     const int c = (i - d.cam0) / 3, k = (i - d.cam0) % 3;
-    zc = 0;
-    for (int s = 0; s < d.S; s++)
-      if (d.shot_camera[s] == c) zc += d.part[9 * (long)s + k];
+    zc = d.camred[9 * c + k];
   }
   if (mode == 0)
     out[i] = d.sc_red[i] * (zc + d.prior_diag[i] * y[i]) + d.D_red[i] / radius * x[i];
@@ -913,12 +1202,21 @@ struct Solver {
   void gradients() {
     hipLaunchKernelGGL(point_grad_kernel, dim3(nblk(d.P)), dim3(TPB), 0, st, d);
     hipLaunchKernelGGL(shot_grad_kernel, dim3(d.S), dim3(64), 0, st, d, d.poses);
+    hipLaunchKernelGGL(cam_reduce_kernel, dim3(d.NC), dim3(TPB), 0, st, d, 9);
     hipLaunchKernelGGL(cam_grad_kernel, dim3(nblk(d.NC, 64)), dim3(64), 0, st, d, d.cams);
+  }
+  bool use_band = false;
+  void precond(const double *r, double *z) {
+    if (use_band)
+      hipLaunchKernelGGL(band_solve_kernel, dim3(1), dim3(64), 0, st, d, r, z);
+    else
+      hipLaunchKernelGGL(precond_apply_kernel, dim3(nblk(d.S + d.NC)), dim3(TPB), 0, st, d, r, z);
   }
   void matvec(const double *x, double *out, double radius) {
     hipLaunchKernelGGL(scale_vec_kernel, dim3(nblk(d.nred)), dim3(TPB), 0, st, d.sc_red, x, d.y, d.nred);
     hipLaunchKernelGGL(schur_point_kernel<0>, dim3(nblk(d.P)), dim3(TPB), 0, st, d, d.y);
     hipLaunchKernelGGL(schur_shot_kernel, dim3(d.S), dim3(64), 0, st, d);
+    hipLaunchKernelGGL(cam_reduce_kernel, dim3(d.NC), dim3(TPB), 0, st, d, 3);
     hipLaunchKernelGGL(schur_finish_kernel, dim3(nblk(d.nred)), dim3(TPB), 0, st, d, x, d.y, out, radius, 0);
   }
 };
@@ -937,6 +1235,7 @@ extern "C" void osfm_ba_options_default(osfm_ba_options *o) {
   o->verbose = 0;
   o->pcg_tolerance = 1e-10;
   o->pcg_max_iterations = 1000;
+  o->preconditioner = 0;
 }
 
 extern "C" int osfm_ba_solve(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_options *O, osfm_ba_report *Rp) {
@@ -1039,6 +1338,7 @@ extern "C" int osfm_ba_solve(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_op
   d.Hcc = A.alloc<double>((size_t)21 * S + 6 * NC, e);
   d.Binv = A.alloc<double>((size_t)36 * S + 9 * NC, e);
   d.part = A.alloc<double>((size_t)9 * S, e);
+  d.camred = A.alloc<double>((size_t)9 * NC, e);
   d.zc = A.alloc<double>(nr, e);
   d.y = A.alloc<double>(nr, e);
   d.x = A.alloc<double>(nr, e);
@@ -1050,6 +1350,21 @@ extern "C" int osfm_ba_solve(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_op
   d.scal = A.alloc<double>(32, e);
   const long nbmax = std::max<long>(nblk(M), nblk(3L * NP));
   d.partial = A.alloc<double>((size_t)2 * nbmax + 16, e);
+  // block half-bandwidth of the shot-shot coupling (shots in caller order)
+  int bw_true = 0;
+  for (int p = 0; p < NP; p++) {
+    int mn = 1 << 30, mx = -1;
+    for (long k = pt_off[(size_t)p]; k < pt_off[(size_t)p + 1]; k++) {
+      mn = std::min(mn, o_shot[(size_t)k]);
+      mx = std::max(mx, o_shot[(size_t)k]);
+    }
+    if (mx >= 0) bw_true = std::max(bw_true, mx - mn);
+  }
+  d.bw = O->preconditioner == 1 ? 0 : std::min(bw_true, kMaxBw);
+  if (S < 2) d.bw = 0;
+  d.band = A.alloc<double>((size_t)S * (d.bw + 1) * 36, e);
+  d.dinv = A.alloc<double>((size_t)S * 36, e);
+  int *d_status = A.alloc<int>(4, e);
   double *d_reproj = P->reproj_err ? A.alloc<double>((size_t)2 * M, e) : nullptr;
   OSFM_REQUIRE(e == hipSuccess, OSFM_E_NOMEM, "BA device allocation/upload failed: %s", hipGetErrorString(e));
   OSFM_HIP(hipMemsetAsync(d.scal, 0, 32 * sizeof(double), sv.st));
@@ -1094,14 +1409,26 @@ extern "C" int osfm_ba_solve(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_op
     // ---- linear solve: PCG on the implicit Schur complement ----
     hipLaunchKernelGGL(point_hhat_kernel, dim3(nblk(NP)), dim3(TPB), 0, st, d, radius);
     hipLaunchKernelGGL(precond_shot_kernel, dim3(S), dim3(64), 0, st, d, radius);
+    hipLaunchKernelGGL(cam_reduce_kernel, dim3(NC), dim3(TPB), 0, st, d, 6);
     hipLaunchKernelGGL(precond_cam_kernel, dim3(nblk(NC, 64)), dim3(64), 0, st, d, radius);
+    sv.use_band = false;
+    if (d.bw > 0) {
+      const int R = d.bw + 1;
+      hipLaunchKernelGGL(band_assemble_kernel, dim3(S), dim3(TPB), 0, st, d, radius);
+      hipLaunchKernelGGL(band_cholesky_kernel, dim3(1), dim3(64), (size_t)(R * R * 36 + R * 36 + 72) * sizeof(double), st, d, d_status);
+      int hstatus = 1;
+      OSFM_HIP(hipMemcpyAsync(&hstatus, d_status, sizeof(int), hipMemcpyDeviceToHost, st));
+      OSFM_HIP(hipStreamSynchronize(st));
+      sv.use_band = (hstatus == 0);  // a truncated band may lose positive definiteness: fall back to block Jacobi
+    }
     // rhs
     hipLaunchKernelGGL(schur_point_kernel<1>, dim3(nblk(NP)), dim3(TPB), 0, st, d, d.y);
     hipLaunchKernelGGL(schur_shot_kernel, dim3(S), dim3(64), 0, st, d);
+    hipLaunchKernelGGL(cam_reduce_kernel, dim3(NC), dim3(TPB), 0, st, d, 3);
     hipLaunchKernelGGL(schur_finish_kernel, dim3(nbr), dim3(TPB), 0, st, d, d.x, d.y, d.b, radius, 1);
     OSFM_HIP(hipMemsetAsync(d.x, 0, nred * sizeof(double), st));
     OSFM_HIP(hipMemcpyAsync(d.r, d.b, nred * sizeof(double), hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(precond_apply_kernel, dim3(nblk(S + NC)), dim3(TPB), 0, st, d, d.r, d.z);
+    sv.precond(d.r, d.z);
     OSFM_HIP(hipMemcpyAsync(d.p, d.z, nred * sizeof(double), hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(dot2_kernel, dim3(1), dim3(1024), 0, st, d.r, d.z, d.b, d.b, nred, d.scal + 0, d.scal + 4);
     OSFM_HIP(hipMemcpyAsync(hs.data(), d.scal, 5 * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -1117,7 +1444,7 @@ extern "C" int osfm_ba_solve(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_op
         hipLaunchKernelGGL(dot2_kernel, dim3(1), dim3(1024), 0, st, d.p, d.Ap, (const double *)nullptr, (const double *)nullptr,
                            nred, d.scal + 1, d.scal + 15);
         hipLaunchKernelGGL(pcg_step1_kernel, dim3(nbr), dim3(TPB), 0, st, d.x, d.r, d.p, d.Ap, nred, d.scal);
-        hipLaunchKernelGGL(precond_apply_kernel, dim3(nblk(S + NC)), dim3(TPB), 0, st, d, d.r, d.z);
+        sv.precond(d.r, d.z);
         hipLaunchKernelGGL(dot2_kernel, dim3(1), dim3(1024), 0, st, d.r, d.z, d.r, d.r, nred, d.scal + 2, d.scal + 3);
         hipLaunchKernelGGL(pcg_step2_kernel, dim3(nbr), dim3(TPB), 0, st, d.p, d.z, nred, d.scal);
         hipLaunchKernelGGL(pcg_shift_kernel, dim3(1), dim3(1), 0, st, d.scal);
@@ -1184,6 +1511,8 @@ extern "C" int osfm_ba_solve(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_op
   {
     const int reps = 10;
     hipLaunchKernelGGL(point_hhat_kernel, dim3(nblk(NP)), dim3(TPB), 0, st, d, radius);
+    Rp->preconditioner_bandwidth = sv.use_band ? d.bw : 0;
+    Rp->shot_bandwidth = bw_true;
     OSFM_HIP(hipEventRecord(ctx->ev[6], st));
     for (int i = 0; i < reps; i++) sv.matvec(d.p, d.Ap, radius);
     OSFM_HIP(hipEventRecord(ctx->ev[7], st));
