@@ -606,6 +606,15 @@ __global__ void precond_cam_kernel(Dev d, double radius) {
 // Schur complement exactly and CG only has to resolve the rank-3 coupling to the shared camera.
 constexpr int kMaxBw = 15;
 
+// Single-wavefront kernels: LDS operations of one wave are executed in issue order, so a compiler
+// barrier is all that is needed between a ds_write and a dependent ds_read of another lane.
+// (__syncthreads() would also drain vmcnt and kill the software prefetch of the next band row.)
+__device__ __forceinline__ void WAVE_SYNC() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ void jred_jp(const Dev &d, long o, double E[6][3]) {
   double jp[6];
 #pragma unroll
@@ -691,7 +700,7 @@ __global__ void __launch_bounds__(64) band_cholesky_kernel(Dev d, int *status) {
 #pragma unroll
       for (int u = 0; u < kPre; u++) pre[u] = (lane + 64 * u < R * 36) ? d.band[(long)(i + 1) * R * 36 + lane + 64 * u] : 0.0;
     }
-    __syncthreads();
+    WAVE_SYNC();
     for (int kk = d.bw; kk >= 1; kk--) {
       const int j = i - kk;
       if (j < 0) continue;
@@ -706,7 +715,7 @@ __global__ void __launch_bounds__(64) band_cholesky_kernel(Dev d, int *status) {
         }
         T[lane] = t;
       }
-      __syncthreads();
+      WAVE_SYNC();
       if (lane < 36) {
         const double *dj = dinvr + (j % R) * 36;  // L_jj^-1 ; L_ij = T * L_jj^-T
         double v = 0;
@@ -714,7 +723,7 @@ __global__ void __launch_bounds__(64) band_cholesky_kernel(Dev d, int *status) {
         for (int q = 0; q < 6; q++) v += T[r * 6 + q] * dj[c * 6 + q];
         cur[kk * 36 + lane] = v;
       }
-      __syncthreads();
+      WAVE_SYNC();
     }
     // diagonal block
     if (lane < 36) {
@@ -728,7 +737,7 @@ __global__ void __launch_bounds__(64) band_cholesky_kernel(Dev d, int *status) {
       T[lane] = t;
       Lc[lane] = 0.0;
     }
-    __syncthreads();
+    WAVE_SYNC();
     // 6x6 Cholesky, lane rr owns row rr
     for (int cc = 0; cc < 6; cc++) {
       if (lane < 6 && lane >= cc) {
@@ -741,9 +750,9 @@ __global__ void __launch_bounds__(64) band_cholesky_kernel(Dev d, int *status) {
           T[lane * 6 + cc] = sum;  // numerator, divided once the pivot is known
         }
       }
-      __syncthreads();
+      WAVE_SYNC();
       if (lane < 6 && lane > cc) Lc[lane * 6 + cc] = T[lane * 6 + cc] / Lc[cc * 6 + cc];
-      __syncthreads();
+      WAVE_SYNC();
     }
     // inverse of the lower-triangular factor: lane cc computes column cc
     double *di = dinvr + (i % R) * 36;
@@ -758,111 +767,139 @@ __global__ void __launch_bounds__(64) band_cholesky_kernel(Dev d, int *status) {
       for (int rr = 0; rr < 6; rr++) di[rr * 6 + cc] = col[rr];
     }
     if (lane < 36) cur[lane] = Lc[lane];
-    __syncthreads();
+    WAVE_SYNC();
     for (int t = lane; t < R * 36; t += 64) d.band[(long)i * R * 36 + t] = cur[t];
     if (lane < 36) d.dinv[(long)i * 36 + lane] = di[lane];
-    __syncthreads();
+    WAVE_SYNC();
   }
   if (bad) *status = 1;
 }
 
-// z_shots = (L L^T)^-1 r_shots   (one wavefront, two banded sweeps); camera rows: 3x3 block Jacobi
+// z_shots = (L L^T)^-1 r_shots   (one wavefront, two banded sweeps); camera rows: 3x3 block Jacobi.
+// The sweeps are dependency chains S links long; what can be taken off the chain is: operands are
+// fetched kPD rows ahead into a register pipeline (an L2/MALL miss is ~1 us, a link ~0.3 us), and
+// the band product is accumulated in three independent partial sums.
+constexpr int kPD = 4;
 __global__ void __launch_bounds__(64) band_solve_kernel(Dev d, const double *rin, double *z) {
   __shared__ double part[36];
   __shared__ double tv[6];
   __shared__ double yring[(kMaxBw + 1) * 6];
   const int R = d.bw + 1;
   const int lane = threadIdx.x, r = lane / 6, c = lane % 6;
-  // forward: y_i = Linv_ii (r_i - sum_k L_{i,i-k} y_{i-k}); operands of row i+1 are prefetched into
-  // registers while row i is in flight (the sweep is a latency-bound dependency chain)
-  double lb[kMaxBw], ld[6], lr = 0.0;
   const int l36 = lane < 36 ? lane : 0, l6 = lane < 6 ? lane : 0;
-#pragma unroll
-  for (int k = 1; k <= kMaxBw; k++) lb[k - 1] = (k <= d.bw) ? d.band[(long)k * 36 + l36] : 0.0;
-#pragma unroll
-  for (int q = 0; q < 6; q++) ld[q] = d.dinv[l6 * 6 + q];
-  lr = rin[l6];
-  for (int i = 0; i < d.S; i++) {
-    double cb[kMaxBw], cd[6];
-    const double cr = lr;
-#pragma unroll
-    for (int k = 0; k < kMaxBw; k++) cb[k] = lb[k];
-#pragma unroll
-    for (int q = 0; q < 6; q++) cd[q] = ld[q];
-    if (i + 1 < d.S) {
-#pragma unroll
-      for (int k = 1; k <= kMaxBw; k++) lb[k - 1] = (k <= d.bw) ? d.band[((long)(i + 1) * R + k) * 36 + l36] : 0.0;
-#pragma unroll
-      for (int q = 0; q < 6; q++) ld[q] = d.dinv[(long)(i + 1) * 36 + l6 * 6 + q];
-      lr = rin[6 * (i + 1) + l6];
-    }
-    if (lane < 36) {
-      double acc = 0;
-#pragma unroll
-      for (int k = 1; k <= kMaxBw; k++)
-        if (k <= d.bw && k <= i) acc += cb[k - 1] * yring[((i - k) % R) * 6 + c];
-      part[lane] = acc;
-    }
-    __syncthreads();
-    if (lane < 6) {
-      double t = cr;
-      for (int q = 0; q < 6; q++) t -= part[lane * 6 + q];
-      tv[lane] = t;
-    }
-    __syncthreads();
-    if (lane < 6) {
-      double y = 0;
-#pragma unroll
-      for (int q = 0; q < 6; q++) y += cd[q] * tv[q];
-      yring[(i % R) * 6 + lane] = y;
-      z[6 * i + lane] = y;
-    }
-    __syncthreads();
-  }
-  // backward: x_i = Linv_ii^T (y_i - sum_k L_{i+k,i}^T x_{i+k})
   const int lt = lane < 36 ? c * 6 + r : 0;
-  {
-    const int i = d.S - 1;
+  double pb[kPD][kMaxBw], pdv[kPD][6], pr[kPD];
+  // ---------------- forward: y_i = Linv_ii (r_i - sum_k L_{i,i-k} y_{i-k}) ----------------
 #pragma unroll
-    for (int k = 1; k <= kMaxBw; k++) lb[k - 1] = (k <= d.bw && i + k < d.S) ? d.band[((long)(i + k) * R + k) * 36 + lt] : 0.0;
+  for (int u = 0; u < kPD; u++) {
+    const int row = u < d.S ? u : d.S - 1;
 #pragma unroll
-    for (int q = 0; q < 6; q++) ld[q] = d.dinv[(long)i * 36 + q * 6 + l6];
+    for (int k = 1; k <= kMaxBw; k++) pb[u][k - 1] = d.band[((long)row * R + (k <= d.bw ? k : 0)) * 36 + l36];
+#pragma unroll
+    for (int q = 0; q < 6; q++) pdv[u][q] = d.dinv[(long)row * 36 + l6 * 6 + q];
+    pr[u] = rin[6 * row + l6];
   }
-  for (int i = d.S - 1; i >= 0; i--) {
-    double cb[kMaxBw], cd[6];
+  for (int i0 = 0; i0 < d.S; i0 += kPD) {
 #pragma unroll
-    for (int k = 0; k < kMaxBw; k++) cb[k] = lb[k];
+    for (int u = 0; u < kPD; u++) {  // slot u always serves rows == u (mod kPD): no register rotation
+      const int i = i0 + u;
+      if (i < d.S) {
+        double cb[kMaxBw], cd[6];
+        const double cr = pr[u];
 #pragma unroll
-    for (int q = 0; q < 6; q++) cd[q] = ld[q];
-    if (i > 0) {
+        for (int k = 0; k < kMaxBw; k++) cb[k] = pb[u][k];
 #pragma unroll
-      for (int k = 1; k <= kMaxBw; k++)
-        lb[k - 1] = (k <= d.bw && i - 1 + k < d.S) ? d.band[((long)(i - 1 + k) * R + k) * 36 + lt] : 0.0;
+        for (int q = 0; q < 6; q++) cd[q] = pdv[u][q];
+        {
+          const int row = i + kPD < d.S ? i + kPD : d.S - 1;
 #pragma unroll
-      for (int q = 0; q < 6; q++) ld[q] = d.dinv[(long)(i - 1) * 36 + q * 6 + l6];
+          for (int k = 1; k <= kMaxBw; k++) pb[u][k - 1] = d.band[((long)row * R + (k <= d.bw ? k : 0)) * 36 + l36];
+#pragma unroll
+          for (int q = 0; q < 6; q++) pdv[u][q] = d.dinv[(long)row * 36 + l6 * 6 + q];
+          pr[u] = rin[6 * row + l6];
+        }
+        if (lane < 36) {
+          double a[3] = {0, 0, 0};
+#pragma unroll
+          for (int k = 1; k <= kMaxBw; k++) {
+            const bool on = (k <= d.bw) && (k <= i);
+            const double yv = yring[((on ? i - k : i) % R) * 6 + c];
+            a[(k - 1) % 3] += (on ? cb[k - 1] : 0.0) * yv;
+          }
+          part[lane] = (a[0] + a[1]) + a[2];
+        }
+        WAVE_SYNC();
+        if (lane < 6) {
+          const double t = cr - (((part[lane * 6] + part[lane * 6 + 1]) + (part[lane * 6 + 2] + part[lane * 6 + 3])) +
+                                 (part[lane * 6 + 4] + part[lane * 6 + 5]));
+          tv[lane] = t;
+        }
+        WAVE_SYNC();
+        if (lane < 6) {
+          const double y = ((cd[0] * tv[0] + cd[1] * tv[1]) + (cd[2] * tv[2] + cd[3] * tv[3])) + (cd[4] * tv[4] + cd[5] * tv[5]);
+          yring[(i % R) * 6 + lane] = y;
+          z[6 * i + lane] = y;
+        }
+        WAVE_SYNC();
+      }
     }
-    if (lane < 36) {
-      double acc = 0;
+  }
+  // ---------------- backward: x_i = Linv_ii^T (y_i - sum_k L_{i+k,i}^T x_{i+k}) ----------------
 #pragma unroll
-      for (int k = 1; k <= kMaxBw; k++)
-        if (k <= d.bw && i + k < d.S) acc += cb[k - 1] * yring[((i + k) % R) * 6 + c];
-      part[lane] = acc;
-    }
-    __syncthreads();
-    if (lane < 6) {
-      double t = z[6 * i + lane];
-      for (int q = 0; q < 6; q++) t -= part[lane * 6 + q];
-      tv[lane] = t;
-    }
-    __syncthreads();
-    if (lane < 6) {
-      double x = 0;
+  for (int u = 0; u < kPD; u++) {
+    const int row = d.S - 1 - u >= 0 ? d.S - 1 - u : 0;
 #pragma unroll
-      for (int q = 0; q < 6; q++) x += cd[q] * tv[q];
-      yring[(i % R) * 6 + lane] = x;
-      z[6 * i + lane] = x;
+    for (int k = 1; k <= kMaxBw; k++)
+      pb[u][k - 1] = d.band[((long)(row + k < d.S ? row + k : row) * R + (k <= d.bw ? k : 0)) * 36 + lt];
+#pragma unroll
+    for (int q = 0; q < 6; q++) pdv[u][q] = d.dinv[(long)row * 36 + q * 6 + l6];
+    pr[u] = z[6 * row + l6];  // y of the forward sweep (written by this lane)
+  }
+  for (int i0 = d.S - 1; i0 >= 0; i0 -= kPD) {
+#pragma unroll
+    for (int u = 0; u < kPD; u++) {
+      const int i = i0 - u;
+      if (i >= 0) {
+        double cb[kMaxBw], cd[6];
+#pragma unroll
+        for (int k = 0; k < kMaxBw; k++) cb[k] = pb[u][k];
+#pragma unroll
+        for (int q = 0; q < 6; q++) cd[q] = pdv[u][q];
+        {
+          const int row = i - kPD >= 0 ? i - kPD : 0;
+#pragma unroll
+          for (int k = 1; k <= kMaxBw; k++)
+            pb[u][k - 1] = d.band[((long)(row + k < d.S ? row + k : row) * R + (k <= d.bw ? k : 0)) * 36 + lt];
+#pragma unroll
+          for (int q = 0; q < 6; q++) pdv[u][q] = d.dinv[(long)row * 36 + q * 6 + l6];
+        }
+        const double yi = pr[u];
+        pr[u] = z[6 * (i - kPD >= 0 ? i - kPD : 0) + l6];
+        if (lane < 36) {
+          double a[3] = {0, 0, 0};
+#pragma unroll
+          for (int k = 1; k <= kMaxBw; k++) {
+            const bool on = (k <= d.bw) && (i + k < d.S);
+            const double yv = yring[((on ? i + k : i) % R) * 6 + c];
+            a[(k - 1) % 3] += (on ? cb[k - 1] : 0.0) * yv;
+          }
+          part[lane] = (a[0] + a[1]) + a[2];
+        }
+        WAVE_SYNC();
+        if (lane < 6) {
+          const double t = yi - (((part[lane * 6] + part[lane * 6 + 1]) + (part[lane * 6 + 2] + part[lane * 6 + 3])) +
+                                 (part[lane * 6 + 4] + part[lane * 6 + 5]));
+          tv[lane] = t;
+        }
+        WAVE_SYNC();
+        if (lane < 6) {
+          const double x = ((cd[0] * tv[0] + cd[1] * tv[1]) + (cd[2] * tv[2] + cd[3] * tv[3])) + (cd[4] * tv[4] + cd[5] * tv[5]);
+          yring[(i % R) * 6 + lane] = x;
+          z[6 * i + lane] = x;
+        }
+        WAVE_SYNC();
+      }
     }
-    __syncthreads();
   }
   // camera blocks
   for (int cm = lane; cm < d.NC; cm += 64) {
