@@ -677,10 +677,11 @@ __global__ void __launch_bounds__(TPB) band_assemble_kernel(Dev d, double radius
 // sequential banded block Cholesky, one wavefront; ring[] keeps the last bw+1 factor rows in LDS
 __global__ void __launch_bounds__(64) band_cholesky_kernel(Dev d, int *status) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int R = d.bw + 1;            // ring rows == blocks per row
-  double *ring = lds;                // [R][R*36]
-  double *dinvr = ring + R * R * 36; // [R][36]
-  double *T = dinvr + R * 36;        // [36]
+  const int R = d.bw + 1;            // blocks per row
+  constexpr int NR = kMaxBw + 1;     // ring rows (power of two: slot = row & kMaxBw)
+  double *ring = lds;                 // [NR][R*36]
+  double *dinvr = ring + NR * R * 36; // [NR][36]
+  double *T = dinvr + NR * 36;        // [36]
   double *Lc = T + 36;               // [36] work: diagonal factor
   const int lane = threadIdx.x;
   const int r = lane / 6, c = lane % 6;  // valid for lane < 36
@@ -692,7 +693,7 @@ __global__ void __launch_bounds__(64) band_cholesky_kernel(Dev d, int *status) {
 #pragma unroll
   for (int u = 0; u < kPre; u++) pre[u] = (lane + 64 * u < R * 36) ? d.band[lane + 64 * u] : 0.0;
   for (int i = 0; i < d.S; i++) {
-    double *cur = ring + (i % R) * R * 36;
+    double *cur = ring + (i & kMaxBw) * R * 36;
 #pragma unroll
     for (int u = 0; u < kPre; u++)
       if (lane + 64 * u < R * 36) cur[lane + 64 * u] = pre[u];
@@ -704,7 +705,7 @@ __global__ void __launch_bounds__(64) band_cholesky_kernel(Dev d, int *status) {
     for (int kk = d.bw; kk >= 1; kk--) {
       const int j = i - kk;
       if (j < 0) continue;
-      const double *rowj = ring + (j % R) * R * 36;
+      const double *rowj = ring + (j & kMaxBw) * R * 36;
       if (lane < 36) {
         double t = cur[kk * 36 + lane];
         const int m0 = (i - d.bw > j - d.bw ? i - d.bw : j - d.bw);
@@ -717,7 +718,7 @@ __global__ void __launch_bounds__(64) band_cholesky_kernel(Dev d, int *status) {
       }
       WAVE_SYNC();
       if (lane < 36) {
-        const double *dj = dinvr + (j % R) * 36;  // L_jj^-1 ; L_ij = T * L_jj^-T
+        const double *dj = dinvr + (j & kMaxBw) * 36;  // L_jj^-1 ; L_ij = T * L_jj^-T
         double v = 0;
 #pragma unroll
         for (int q = 0; q < 6; q++) v += T[r * 6 + q] * dj[c * 6 + q];
@@ -755,7 +756,7 @@ __global__ void __launch_bounds__(64) band_cholesky_kernel(Dev d, int *status) {
       WAVE_SYNC();
     }
     // inverse of the lower-triangular factor: lane cc computes column cc
-    double *di = dinvr + (i % R) * 36;
+    double *di = dinvr + (i & kMaxBw) * 36;
     if (lane < 6) {
       const int cc = lane;
       double col[6];
@@ -780,23 +781,31 @@ __global__ void __launch_bounds__(64) band_cholesky_kernel(Dev d, int *status) {
 // fetched kPD rows ahead into a register pipeline (an L2/MALL miss is ~1 us, a link ~0.3 us), and
 // the band product is accumulated in three independent partial sums.
 constexpr int kPD = 4;
+// BW (block half-bandwidth) is a template parameter: the per-row instruction count IS the run time
+// of this kernel (one wavefront issues ~1 instruction per 4 cycles), so no masks, no runtime loops.
+template <int BW>
 __global__ void __launch_bounds__(64) band_solve_kernel(Dev d, const double *rin, double *z) {
   __shared__ double part[36];
   __shared__ double tv[6];
   __shared__ double yring[(kMaxBw + 1) * 6];
-  const int R = d.bw + 1;
+  constexpr int R = BW + 1;
+  constexpr long kRow = (long)R * 36;
   const int lane = threadIdx.x, r = lane / 6, c = lane % 6;
   const int l36 = lane < 36 ? lane : 0, l6 = lane < 6 ? lane : 0;
   const int lt = lane < 36 ? c * 6 + r : 0;
-  double pb[kPD][kMaxBw], pdv[kPD][6], pr[kPD];
+  double pb[kPD][BW], pdv[kPD][6], pr[kPD];
+  for (int t = lane; t < (kMaxBw + 1) * 6; t += 64) yring[t] = 0.0;  // rows < 0 / >= S contribute zero
+  WAVE_SYNC();
   // ---------------- forward: y_i = Linv_ii (r_i - sum_k L_{i,i-k} y_{i-k}) ----------------
+  const double *bp = d.band + 36 + l36;    // block k = 1 of row 0, this lane's element
+  const double *dp = d.dinv + l6 * 6;
 #pragma unroll
   for (int u = 0; u < kPD; u++) {
-    const int row = u < d.S ? u : d.S - 1;
+    const long row = u < d.S ? u : d.S - 1;
 #pragma unroll
-    for (int k = 1; k <= kMaxBw; k++) pb[u][k - 1] = d.band[((long)row * R + (k <= d.bw ? k : 0)) * 36 + l36];
+    for (int k = 0; k < BW; k++) pb[u][k] = bp[row * kRow + k * 36];
 #pragma unroll
-    for (int q = 0; q < 6; q++) pdv[u][q] = d.dinv[(long)row * 36 + l6 * 6 + q];
+    for (int q = 0; q < 6; q++) pdv[u][q] = dp[row * 36 + q];
     pr[u] = rin[6 * row + l6];
   }
   for (int i0 = 0; i0 < d.S; i0 += kPD) {
@@ -804,29 +813,27 @@ __global__ void __launch_bounds__(64) band_solve_kernel(Dev d, const double *rin
     for (int u = 0; u < kPD; u++) {  // slot u always serves rows == u (mod kPD): no register rotation
       const int i = i0 + u;
       if (i < d.S) {
-        double cb[kMaxBw], cd[6];
+        double cb[BW], cd[6];
         const double cr = pr[u];
 #pragma unroll
-        for (int k = 0; k < kMaxBw; k++) cb[k] = pb[u][k];
+        for (int k = 0; k < BW; k++) cb[k] = pb[u][k];
 #pragma unroll
         for (int q = 0; q < 6; q++) cd[q] = pdv[u][q];
         {
-          const int row = i + kPD < d.S ? i + kPD : d.S - 1;
+          const long row = i + kPD < d.S ? i + kPD : d.S - 1;
 #pragma unroll
-          for (int k = 1; k <= kMaxBw; k++) pb[u][k - 1] = d.band[((long)row * R + (k <= d.bw ? k : 0)) * 36 + l36];
+          for (int k = 0; k < BW; k++) pb[u][k] = bp[row * kRow + k * 36];
 #pragma unroll
-          for (int q = 0; q < 6; q++) pdv[u][q] = d.dinv[(long)row * 36 + l6 * 6 + q];
+          for (int q = 0; q < 6; q++) pdv[u][q] = dp[row * 36 + q];
           pr[u] = rin[6 * row + l6];
         }
-        if (lane < 36) {
+        {
+          // band rows of the first BW shots hold zero blocks for columns < 0 (band_assemble), and
+          // yring starts zeroed, so no boundary predicate is needed
           double a[3] = {0, 0, 0};
 #pragma unroll
-          for (int k = 1; k <= kMaxBw; k++) {
-            const bool on = (k <= d.bw) && (k <= i);
-            const double yv = yring[((on ? i - k : i) % R) * 6 + c];
-            a[(k - 1) % 3] += (on ? cb[k - 1] : 0.0) * yv;
-          }
-          part[lane] = (a[0] + a[1]) + a[2];
+          for (int k = 1; k <= BW; k++) a[(k - 1) % 3] += cb[k - 1] * yring[((i - k) & kMaxBw) * 6 + c];
+          if (lane < 36) part[lane] = (a[0] + a[1]) + a[2];
         }
         WAVE_SYNC();
         if (lane < 6) {
@@ -837,7 +844,7 @@ __global__ void __launch_bounds__(64) band_solve_kernel(Dev d, const double *rin
         WAVE_SYNC();
         if (lane < 6) {
           const double y = ((cd[0] * tv[0] + cd[1] * tv[1]) + (cd[2] * tv[2] + cd[3] * tv[3])) + (cd[4] * tv[4] + cd[5] * tv[5]);
-          yring[(i % R) * 6 + lane] = y;
+          yring[(i & kMaxBw) * 6 + lane] = y;
           z[6 * i + lane] = y;
         }
         WAVE_SYNC();
@@ -845,14 +852,18 @@ __global__ void __launch_bounds__(64) band_solve_kernel(Dev d, const double *rin
     }
   }
   // ---------------- backward: x_i = Linv_ii^T (y_i - sum_k L_{i+k,i}^T x_{i+k}) ----------------
+  // x of rows >= S must read as zero: clear the ring slots the first BW rows will look at
+  for (int t = lane; t < (kMaxBw + 1) * 6; t += 64) yring[t] = 0.0;
+  WAVE_SYNC();
+  const double *bq = d.band + lt;  // element (c, r) of a block: L^T
+  const double *dq = d.dinv + l6;
 #pragma unroll
   for (int u = 0; u < kPD; u++) {
-    const int row = d.S - 1 - u >= 0 ? d.S - 1 - u : 0;
+    const long row = d.S - 1 - u >= 0 ? d.S - 1 - u : 0;
 #pragma unroll
-    for (int k = 1; k <= kMaxBw; k++)
-      pb[u][k - 1] = d.band[((long)(row + k < d.S ? row + k : row) * R + (k <= d.bw ? k : 0)) * 36 + lt];
+    for (int k = 1; k <= BW; k++) pb[u][k - 1] = bq[(row + k < d.S ? row + k : row) * kRow + k * 36];
 #pragma unroll
-    for (int q = 0; q < 6; q++) pdv[u][q] = d.dinv[(long)row * 36 + q * 6 + l6];
+    for (int q = 0; q < 6; q++) pdv[u][q] = dq[row * 36 + q * 6];
     pr[u] = z[6 * row + l6];  // y of the forward sweep (written by this lane)
   }
   for (int i0 = d.S - 1; i0 >= 0; i0 -= kPD) {
@@ -860,30 +871,25 @@ __global__ void __launch_bounds__(64) band_solve_kernel(Dev d, const double *rin
     for (int u = 0; u < kPD; u++) {
       const int i = i0 - u;
       if (i >= 0) {
-        double cb[kMaxBw], cd[6];
+        double cb[BW], cd[6];
 #pragma unroll
-        for (int k = 0; k < kMaxBw; k++) cb[k] = pb[u][k];
+        for (int k = 0; k < BW; k++) cb[k] = pb[u][k];
 #pragma unroll
         for (int q = 0; q < 6; q++) cd[q] = pdv[u][q];
-        {
-          const int row = i - kPD >= 0 ? i - kPD : 0;
-#pragma unroll
-          for (int k = 1; k <= kMaxBw; k++)
-            pb[u][k - 1] = d.band[((long)(row + k < d.S ? row + k : row) * R + (k <= d.bw ? k : 0)) * 36 + lt];
-#pragma unroll
-          for (int q = 0; q < 6; q++) pdv[u][q] = d.dinv[(long)row * 36 + q * 6 + l6];
-        }
         const double yi = pr[u];
-        pr[u] = z[6 * (i - kPD >= 0 ? i - kPD : 0) + l6];
-        if (lane < 36) {
+        {
+          const long row = i - kPD >= 0 ? i - kPD : 0;
+#pragma unroll
+          for (int k = 1; k <= BW; k++) pb[u][k - 1] = bq[(row + k < d.S ? row + k : row) * kRow + k * 36];
+#pragma unroll
+          for (int q = 0; q < 6; q++) pdv[u][q] = dq[row * 36 + q * 6];
+          pr[u] = z[6 * row + l6];
+        }
+        {
           double a[3] = {0, 0, 0};
 #pragma unroll
-          for (int k = 1; k <= kMaxBw; k++) {
-            const bool on = (k <= d.bw) && (i + k < d.S);
-            const double yv = yring[((on ? i + k : i) % R) * 6 + c];
-            a[(k - 1) % 3] += (on ? cb[k - 1] : 0.0) * yv;
-          }
-          part[lane] = (a[0] + a[1]) + a[2];
+          for (int k = 1; k <= BW; k++) a[(k - 1) % 3] += cb[k - 1] * yring[((i + k) & kMaxBw) * 6 + c];
+          if (lane < 36) part[lane] = (a[0] + a[1]) + a[2];
         }
         WAVE_SYNC();
         if (lane < 6) {
@@ -894,7 +900,7 @@ __global__ void __launch_bounds__(64) band_solve_kernel(Dev d, const double *rin
         WAVE_SYNC();
         if (lane < 6) {
           const double x = ((cd[0] * tv[0] + cd[1] * tv[1]) + (cd[2] * tv[2] + cd[3] * tv[3])) + (cd[4] * tv[4] + cd[5] * tv[5]);
-          yring[(i % R) * 6 + lane] = x;
+          yring[(i & kMaxBw) * 6 + lane] = x;
           z[6 * i + lane] = x;
         }
         WAVE_SYNC();
@@ -905,6 +911,27 @@ __global__ void __launch_bounds__(64) band_solve_kernel(Dev d, const double *rin
   for (int cm = lane; cm < d.NC; cm += 64) {
     const double *Bi = d.Binv + 36 * (long)d.S + 9 * cm, *rr = rin + d.cam0 + 3 * cm;
     for (int i = 0; i < 3; i++) z[d.cam0 + 3 * cm + i] = Bi[3 * i] * rr[0] + Bi[3 * i + 1] * rr[1] + Bi[3 * i + 2] * rr[2];
+  }
+}
+
+typedef void (*band_solve_fn)(Dev, const double *, double *);
+inline band_solve_fn band_solve_for(int bw) {
+  switch (bw) {
+    case 1: return band_solve_kernel<1>;
+    case 2: return band_solve_kernel<2>;
+    case 3: return band_solve_kernel<3>;
+    case 4: return band_solve_kernel<4>;
+    case 5: return band_solve_kernel<5>;
+    case 6: return band_solve_kernel<6>;
+    case 7: return band_solve_kernel<7>;
+    case 8: return band_solve_kernel<8>;
+    case 9: return band_solve_kernel<9>;
+    case 10: return band_solve_kernel<10>;
+    case 11: return band_solve_kernel<11>;
+    case 12: return band_solve_kernel<12>;
+    case 13: return band_solve_kernel<13>;
+    case 14: return band_solve_kernel<14>;
+    default: return band_solve_kernel<15>;
   }
 }
 
@@ -1245,7 +1272,7 @@ struct Solver {
   bool use_band = false;
   void precond(const double *r, double *z) {
     if (use_band)
-      hipLaunchKernelGGL(band_solve_kernel, dim3(1), dim3(64), 0, st, d, r, z);
+      hipLaunchKernelGGL(band_solve_for(d.bw), dim3(1), dim3(64), 0, st, d, r, z);
     else
       hipLaunchKernelGGL(precond_apply_kernel, dim3(nblk(d.S + d.NC)), dim3(TPB), 0, st, d, r, z);
   }
@@ -1452,7 +1479,12 @@ extern "C" int osfm_ba_solve(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_op
     if (d.bw > 0) {
       const int R = d.bw + 1;
       hipLaunchKernelGGL(band_assemble_kernel, dim3(S), dim3(TPB), 0, st, d, radius);
-      hipLaunchKernelGGL(band_cholesky_kernel, dim3(1), dim3(64), (size_t)(R * R * 36 + R * 36 + 72) * sizeof(double), st, d, d_status);
+      static bool chol_attr = false;
+      if (!chol_attr) {
+        OSFM_HIP(hipFuncSetAttribute((const void *)band_cholesky_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        chol_attr = true;
+      }
+      hipLaunchKernelGGL(band_cholesky_kernel, dim3(1), dim3(64), (size_t)((kMaxBw + 1) * R * 36 + (kMaxBw + 1) * 36 + 72) * sizeof(double), st, d, d_status);
       int hstatus = 1;
       OSFM_HIP(hipMemcpyAsync(&hstatus, d_status, sizeof(int), hipMemcpyDeviceToHost, st));
       OSFM_HIP(hipStreamSynchronize(st));
