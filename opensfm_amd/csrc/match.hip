@@ -19,6 +19,8 @@
 //                    loop; 32 classes are merged by a butterfly once per row block.
 //   column direction: reduced in-lane over the 32 rows a lane holds, merged across the two
 //                    half-waves and the 4 waves through a small LDS scratch once per column tile.
+#include <cstdlib>
+
 #include "osfm_internal.h"
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -353,6 +355,369 @@ __global__ void __launch_bounds__(kThreads, 2) match_fused_kernel(MatchArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Fused MFMA kernel, version 2: "best-only + lazy exact second".
+//
+// v1 spends 6 integer VALU ops per distance-matrix element keeping an exact (best, second) pair in
+// both directions, and sits on the VALU issue roofline (profiles/r01_match_v1_rocprof.txt).  The
+// second-nearest neighbour is only needed for the ratio test, and only its VALUE.  v2 keeps, per
+// class of candidates (row direction: the 32 column classes j mod 32 held by the 32 lanes of a
+// half-wave; column direction: the 32 rows one lane sees), only the BEST key:
+//     best = v_max3_i32(best, key_a, key_b)          -> 1.5 ops / element / direction
+// and merges classes into (global best, second largest class-best =: s_c).  The true second s
+// satisfies s >= s_c, i.e. d2_true <= d2_c, and the ratio test is monotone in d2:
+//   * fails with d2_c  => fails with d2_true: final, no extra work (the vast majority of features);
+//   * passes with d2_c => the winner's own class (<= 64 / 32 candidates) is re-examined exactly with
+//     v_dot4 dot products by the whole wavefront, s = max(s_c, best of the class without the
+//     winner), and the test is repeated.  Results are bit-identical to v1 / the oracle.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_row_frag(const int8_t *tiles, int row, v4i out[8]);
+
+__device__ __forceinline__ int dot128(const v4i a[8], const v4i b[8]) {
+  int sdot = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sdot = __builtin_amdgcn_sdot4(a[k][e], b[k][e], sdot, false);
+  return sdot;
+}
+
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m));
+  return v;
+}
+
+__global__ void __launch_bounds__(kThreads, 2) match_fused2_kernel(MatchArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char *bbuf = smem;                                      // [2][16 KiB]
+  int2 *scratch = (int2 *)(smem + 2 * kChunkBytes);                // [2][4][128]
+  int *colBV = (int *)(smem + 2 * kChunkBytes + 2 * kWaves * kChunkCols * 8);
+  int *colSV = colBV + a.ncap;
+  int *colBI = colSV + a.ncap;
+  unsigned short *rowres = (unsigned short *)(colBI + a.ncap);
+  unsigned short *clist = rowres + a.ncap;
+  int *misc = (int *)(clist + a.ncap);  // [16]
+  int *req = misc + 16;                 // [4 waves][64 rows][3]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long p = xcd_remap(blockIdx.x, a.n_pairs);
+
+  const int imgC = a.pairs[2 * p], imgR = a.pairs[2 * p + 1];
+  const int nC = a.counts[imgC], nR = a.counts[imgR];
+  if (nC < 2 || nR < 2) {
+    if (tid == 0) {
+      a.out_counts[p] = 0;
+      a.out_flags[p] = 0;
+    }
+    return;
+  }
+  const int tC = (nC + 31) >> 5, tR = (nR + 31) >> 5;
+  const int8_t *tilesC = a.tiles + a.tile_off[imgC] * OSFM_TILE_BYTES;
+  const int8_t *tilesR = a.tiles + a.tile_off[imgR] * OSFM_TILE_BYTES;
+  const int32_t *normC = a.norms + a.tile_off[imgC] * 32;
+  const int32_t *normR = a.norms + a.tile_off[imgR] * 32;
+
+  for (int j = tid; j < a.ncap; j += kThreads) {
+    colBV[j] = INT_MIN;
+    colSV[j] = INT_MIN;
+    colBI[j] = kNone;
+    rowres[j] = kNone;
+  }
+  if (tid == 0) {
+    misc[8] = 0;
+    misc[9] = 0;
+  }
+
+  const int nchunks = (tC + kCT - 1) / kCT;
+  const int nrb = (tR + kWaves * kRT - 1) / (kWaves * kRT);
+  const int nsteps = nrb * nchunks;
+
+  uint4 pre[kCT];
+#pragma unroll
+  for (int q = 0; q < kCT; ++q) {
+    pre[q] = make_uint4(0, 0, 0, 0);
+    if (q < tC) pre[q] = *(const uint4 *)(tilesC + (long)q * OSFM_TILE_BYTES + tid * 16);
+  }
+#pragma unroll
+  for (int q = 0; q < kCT; ++q) *(uint4 *)(bbuf + q * OSFM_TILE_BYTES + tid * 16) = pre[q];
+  __syncthreads();
+
+  v4i afrag[kRT][4];
+  int Rk[kRT][16];
+  int rbst[kRT][16];
+  int nrt = 0, rt0 = 0;
+  int rb = 0, c = 0;
+  int flag = 0;
+
+  for (int s = 0; s < nsteps; ++s) {
+    if (c == 0) {
+      rt0 = rb * (kWaves * kRT) + w * kRT;
+      nrt = min(kRT, max(0, tR - rt0));
+#pragma unroll
+      for (int rt = 0; rt < kRT; ++rt) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          v4i z = {0, 0, 0, 0};
+          afrag[rt][ks] = z;
+          if (rt < nrt)
+            afrag[rt][ks] = *(const v4i *)(tilesR + (long)(rt0 + rt) * OSFM_TILE_BYTES + ks * 1024 + lane * 16);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rowintile = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const int il = rt * 32 + rowintile;
+          int na = OSFM_PAD_NORM;
+          if (rt < nrt) na = normR[(rt0 + rt) * 32 + rowintile];
+          Rk[rt][r] = -(na << 6) + (63 - il);
+          rbst[rt][r] = INT_MIN;
+        }
+      }
+    }
+    const bool has_next = (s + 1 < nsteps);
+    const int cn = (c + 1 == nchunks) ? 0 : c + 1;
+    if (has_next) {
+#pragma unroll
+      for (int q = 0; q < kCT; ++q) {
+        pre[q] = make_uint4(0, 0, 0, 0);
+        if (cn * kCT + q < tC)
+          pre[q] = *(const uint4 *)(tilesC + (long)(cn * kCT + q) * OSFM_TILE_BYTES + tid * 16);
+      }
+    }
+    // fold the previous step's per-wave column partials (best, second-largest class best)
+    if (s > 0 && tid < kChunkCols) {
+      const int sp = s - 1;
+      const int cp = (c == 0) ? nchunks - 1 : c - 1;
+      const int rbp = (c == 0) ? rb - 1 : rb;
+      const int j = cp * kChunkCols + tid;
+      int bv = colBV[j], sv = colSV[j], bi = colBI[j];
+#pragma unroll
+      for (int w2 = 0; w2 < kWaves; ++w2) {
+        const int2 pp = scratch[((sp & 1) * kWaves + w2) * kChunkCols + tid];
+        if (pp.x != INT_MIN) {
+          const int pv = pp.x >> 6;
+          const int pi = rbp * kRowsPerWG + w2 * (kRT * 32) + (63 - (pp.x & 63));
+          const int psv = pp.y >> 6;
+          sv = max(min(bv, pv), max(sv, psv));
+          if (pv > bv) {
+            bv = pv;
+            bi = pi;
+          }
+        }
+      }
+      colBV[j] = bv;
+      colSV[j] = sv;
+      colBI[j] = bi;
+    }
+    // ---- compute: column tiles in pairs so that v_max3 takes two new keys per op ----
+    const unsigned char *bb = bbuf + (s & 1) * kChunkBytes;
+#pragma unroll
+    for (int cp2 = 0; cp2 < kCT / 2; ++cp2) {
+      const int ct0 = 2 * cp2, ct1 = 2 * cp2 + 1;
+      const int g0 = c * kCT + ct0, g1 = g0 + 1;
+      int2 part0 = make_int2(INT_MIN, INT_MIN), part1 = make_int2(INT_MIN, INT_MIN);
+      if (g0 < tC && nrt > 0) {
+        const bool v1ok = g1 < tC;
+        v4i bf0[4], bf1[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          bf0[ks] = *(const v4i *)(bb + ct0 * OSFM_TILE_BYTES + ks * 1024 + lane * 16);
+          v4i z = {0, 0, 0, 0};
+          bf1[ks] = z;
+          if (v1ok) bf1[ks] = *(const v4i *)(bb + ct1 * OSFM_TILE_BYTES + ks * 1024 + lane * 16);
+        }
+        const int nb0 = normC[g0 * 32 + (lane & 31)];
+        const int nb1 = v1ok ? normC[g1 * 32 + (lane & 31)] : OSFM_PAD_NORM;
+        const int ck0 = -(nb0 << 7) + (127 - g0);
+        const int ck1 = -(nb1 << 7) + (127 - (g1 & 127));
+        int cb0 = INT_MIN, cb1 = INT_MIN;
+#pragma unroll
+        for (int rt = 0; rt < kRT; ++rt) {
+          if (rt < nrt) {
+            v16i acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            v16i acc1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[rt][ks], bf0[ks], acc0, 0, 0, 0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[rt][ks], bf1[ks], acc1, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int k0 = (acc0[r] << 8) + ck0, k1 = (acc1[r] << 8) + ck1;
+              rbst[rt][r] = max(max(rbst[rt][r], k0), k1);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+              const int u0a = (acc0[r] << 7) + Rk[rt][r], u0b = (acc0[r + 1] << 7) + Rk[rt][r + 1];
+              const int u1a = (acc1[r] << 7) + Rk[rt][r], u1b = (acc1[r + 1] << 7) + Rk[rt][r + 1];
+              cb0 = max(max(cb0, u0a), u0b);
+              cb1 = max(max(cb1, u1a), u1b);
+            }
+          }
+        }
+        const int ob0 = __shfl_xor(cb0, 32), ob1 = __shfl_xor(cb1, 32);
+        part0.x = max(cb0, ob0);
+        part0.y = min(cb0, ob0);
+        if (v1ok) {
+          part1.x = max(cb1, ob1);
+          part1.y = min(cb1, ob1);
+        }
+      }
+      if (lane < 32) {
+        scratch[((s & 1) * kWaves + w) * kChunkCols + ct0 * 32 + lane] = part0;
+        scratch[((s & 1) * kWaves + w) * kChunkCols + ct1 * 32 + lane] = part1;
+      }
+    }
+    // ---- end of a row block: merge the 32 column classes of every row ----
+    if (c == nchunks - 1) {
+      int *myreq = req + w * 192;
+#pragma unroll
+      for (int rt = 0; rt < kRT; ++rt) {
+        if (rt < nrt) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int kb = rbst[rt][r];
+            // 1) largest key of the 32 classes (value, then lowest tile); ties between lanes share
+            //    the same (value, tile): the lowest lane is the lowest column index
+            int km = kb;
+#pragma unroll
+            for (int m = 1; m < 32; m <<= 1) km = max(km, __shfl_xor(km, m));
+            const unsigned long long eq = __ballot(kb == km);
+            const unsigned half = (lane < 32) ? (unsigned)eq : (unsigned)(eq >> 32);
+            const int blane = __builtin_ctz(half);  // half != 0
+            // 2) second largest CLASS best (value only)
+            int k2 = ((lane & 31) == blane) ? INT_MIN : kb;
+#pragma unroll
+            for (int m = 1; m < 32; m <<= 1) k2 = max(k2, __shfl_xor(k2, m));
+            const int bv = km >> 7, bj = (127 - (km & 127)) * 32 + blane, sv = k2 >> 7;
+            const int rowintile = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int il = rt * 32 + rowintile;
+            const int row = (rt0 + rt) * 32 + rowintile;
+            if ((lane & 31) == 0) {
+              int rq = -1;
+              if (row < nR) {
+                const int na = normR[row];
+                const int d1 = na - bv, d2 = na - sv;
+                if (d2 >= kCollisionD2) flag = 1;
+                if (ratio_ok(d1, d2, a.ratio)) rq = bj;  // passes against the class bound: re-examine
+                else rowres[row] = kNone;
+              }
+              myreq[il * 3] = rq;
+              myreq[il * 3 + 1] = bv;
+              myreq[il * 3 + 2] = sv;
+            }
+          }
+        } else {
+          if (lane < 32) myreq[(rt * 32 + lane) * 3] = -1;
+        }
+      }
+      // 3) exact second for the rows that passed: the winner's class = columns {t*32 + (bj&31)}
+      for (int il = 0; il < kRT * 32; ++il) {
+        const int bj = __builtin_amdgcn_readfirstlane(myreq[il * 3]);
+        if (bj < 0) continue;
+        const int bv = __builtin_amdgcn_readfirstlane(myreq[il * 3 + 1]);
+        const int sv = __builtin_amdgcn_readfirstlane(myreq[il * 3 + 2]);
+        const int row = rt0 * 32 + il;
+        v4i ra[8];
+        load_row_frag(tilesR, row, ra);
+        int mx = INT_MIN;
+        for (int t0 = 0; t0 < tC; t0 += 64) {
+          const int t = t0 + lane;
+          const int j = t * 32 + (bj & 31);
+          if (t < tC && j != bj) {
+            v4i cbv[8];
+            load_row_frag(tilesC, j, cbv);
+            mx = max(mx, 2 * dot128(ra, cbv) - normC[j]);
+          }
+        }
+        mx = wave_max(mx);
+        if (lane == 0) {
+          const int na = normR[row];
+          const int s2 = max(sv, mx);
+          rowres[row] = ratio_ok(na - bv, na - s2, a.ratio) ? bj : kNone;
+        }
+      }
+    }
+    if (has_next) {
+      unsigned char *nb2 = bbuf + ((s + 1) & 1) * kChunkBytes;
+#pragma unroll
+      for (int q = 0; q < kCT; ++q) *(uint4 *)(nb2 + q * OSFM_TILE_BYTES + tid * 16) = pre[q];
+    }
+    __syncthreads();
+    ++c;
+    if (c == nchunks) {
+      c = 0;
+      ++rb;
+    }
+  }
+  if (tid < kChunkCols) {
+    const int sp = nsteps - 1;
+    const int j = (nchunks - 1) * kChunkCols + tid;
+    int bv = colBV[j], sv = colSV[j], bi = colBI[j];
+#pragma unroll
+    for (int w2 = 0; w2 < kWaves; ++w2) {
+      const int2 pp = scratch[((sp & 1) * kWaves + w2) * kChunkCols + tid];
+      if (pp.x != INT_MIN) {
+        const int pv = pp.x >> 6;
+        const int pi = (nrb - 1) * kRowsPerWG + w2 * (kRT * 32) + (63 - (pp.x & 63));
+        const int psv = pp.y >> 6;
+        sv = max(min(bv, pv), max(sv, psv));
+        if (pv > bv) {
+          bv = pv;
+          bi = pi;
+        }
+      }
+    }
+    colBV[j] = bv;
+    colSV[j] = sv;
+    colBI[j] = bi;
+  }
+  __syncthreads();
+  // ---- column side: ratio test against the class bound, list the survivors ----
+  for (int j = tid; j < nC; j += kThreads) {
+    const int nb = normC[j];
+    const int d1 = nb - colBV[j], d2 = nb - colSV[j];
+    if (d2 >= kCollisionD2) flag = 1;
+    if (!ratio_ok(d1, d2, a.ratio)) {
+      colBI[j] = kNone;
+    } else {
+      const int k = atomicAdd(&misc[9], 1);
+      clist[k] = (unsigned short)j;
+    }
+  }
+  if (flag) misc[8] = 1;
+  __syncthreads();
+  // ---- exact second for the surviving columns: the winner's class = the 32 rows one lane saw ----
+  {
+    const int nlist = misc[9];
+    for (int e = w; e < nlist; e += kWaves) {
+      const int j = clist[e];
+      const int bi = colBI[j];
+      const int base = (bi >> 6) << 6;                  // row block + wave: rb*256 + w*64
+      const int h = ((bi & 31) >> 2) & 1;               // half-wave of the winning lane
+      const int rtq = lane >> 4, rq = lane & 15;
+      const int row = base + rtq * 32 + (rq & 3) + 8 * (rq >> 2) + 4 * h;
+      int v = INT_MIN;
+      if (lane < 32 && row < tR * 32 && row != bi) {
+        v4i cbv[8], ra[8];
+        load_row_frag(tilesC, j, cbv);
+        load_row_frag(tilesR, row, ra);
+        v = 2 * dot128(ra, cbv) - normR[row];
+      }
+      v = wave_max(v);
+      if (lane == 0) {
+        const int nb = normC[j];
+        const int s2 = max(colSV[j], v);
+        if (!ratio_ok(nb - colBV[j], nb - s2, a.ratio)) colBI[j] = kNone;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) a.out_flags[p] = misc[8];
+  emit_matches(a, p, nC, colBI, rowres, misc, tid);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Exact kernel: float-key semantics of cv2 (top-2 selected on sqrtf(d^2) with lowest-index
 // ties), VALU only.  Used (a) for the rare pairs whose second-nearest d^2 >= 2^22, where distinct
 // integers may round to the same float distance, and (b) as an on-GPU cross-check of the fused
@@ -366,6 +731,8 @@ __device__ __forceinline__ void load_row(const int8_t *tiles, int row, v4i out[8
     out[2 * ks + 1] = *(const v4i *)(t + ks * 1024 + 512);
   }
 }
+
+__device__ __forceinline__ void load_row_frag(const int8_t *tiles, int row, v4i out[8]) { load_row(tiles, row, out); }
 
 __device__ void exact_direction(const int8_t *tilesQ, const int32_t *normQ, int nQ, const int8_t *tilesT,
                                 const int32_t *normT, int nT, double ratio, int tid, int *res_int,
@@ -432,6 +799,17 @@ __global__ void __launch_bounds__(kThreads) match_exact_kernel(MatchArgs a, int 
 size_t osfm_match_lds_bytes(int ncap) {
   return (size_t)2 * kChunkBytes + 2 * kWaves * kChunkCols * 8 + (size_t)ncap * 14 + 64;
 }
+size_t osfm_match2_lds_bytes(int ncap) {
+  return (size_t)2 * kChunkBytes + 2 * kWaves * kChunkCols * 8 + (size_t)ncap * 16 + 64 + kWaves * 192 * 4;
+}
+static int match_kernel_version() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("OSFM_MATCH_KERNEL");
+    v = (e && e[0] == '1') ? 1 : 2;
+  }
+  return v;
+}
 
 int osfm_launch_match(osfm_ctx *ctx, const osfm_store *store, const int32_t *d_pairs, int64_t n_pairs,
                       double ratio, int symmetric, int cap, int32_t *d_counts, uint32_t *d_matches,
@@ -459,10 +837,14 @@ int osfm_launch_match(osfm_ctx *ctx, const osfm_store *store, const int32_t *d_p
     static bool attr_set = false;
     if (!attr_set) {
       OSFM_HIP(hipFuncSetAttribute((const void *)match_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      OSFM_HIP(hipFuncSetAttribute((const void *)match_fused2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       OSFM_HIP(hipFuncSetAttribute((const void *)match_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
       attr_set = true;
     }
-    hipLaunchKernelGGL(match_fused_kernel, dim3((unsigned)n_pairs), dim3(kThreads), lds, ctx->stream, a);
+    if (match_kernel_version() == 1)
+      hipLaunchKernelGGL(match_fused_kernel, dim3((unsigned)n_pairs), dim3(kThreads), lds, ctx->stream, a);
+    else
+      hipLaunchKernelGGL(match_fused2_kernel, dim3((unsigned)n_pairs), dim3(kThreads), osfm_match2_lds_bytes(a.ncap), ctx->stream, a);
   } else {
     const size_t lds = (size_t)a.ncap * 6 + 64;
     hipLaunchKernelGGL(match_exact_kernel, dim3((unsigned)n_pairs), dim3(kThreads), lds, ctx->stream, a,

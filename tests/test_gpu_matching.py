@@ -132,3 +132,33 @@ def test_fused_equals_exact_kernel_full_size(gpu_ctx):
     # mutual matches are a partial injection: each feature appears at most once per pair
     for g in matching.split_matches(c1, m1):
         assert len(set(g[:, 0])) == len(g) and len(set(g[:, 1])) == len(g)
+
+
+def test_second_best_in_the_same_class_as_the_best(oracle_lib, gpu_ctx):
+    """Rule-26 style forced branch for the v2 kernel: the true second-nearest neighbour sits in the
+    winner's own class (same column modulo 32 / same lane's rows), so the class-level bound passes
+    the ratio test while the exact second must make it FAIL (or pass, for the control half)."""
+    from opensfm_amd import matching
+
+    rng = np.random.default_rng(77)
+    n1, n2 = 200, 420
+    f1 = rng.integers(60, 196, (n1, 128)).astype(np.float32)
+    f2 = rng.integers(0, 30, (n2, 128)).astype(np.float32)  # far background
+    for i in range(96):
+        a = (i * 3) % 32 + 32 * (i % 3)  # winner column
+        b = a + 32 * (3 + i % 5)  # same class (a mod 32), different tile
+        near = f1[i] + rng.integers(-2, 3, 128)
+        f2[a] = np.clip(near, 0, 255)
+        eps = 3 if i % 2 == 0 else 40  # even: second almost as close (ratio fails); odd: clearly farther
+        f2[b] = np.clip(f1[i] + rng.integers(-eps, eps + 1, 128), 0, 255)
+    for ratio in (0.8, 0.95):
+        for sym in (False, True):
+            got = matching._match_leaf(f1, f2, ratio, sym)
+            want = (oracle_lib.match_brute_force_symmetric if sym else oracle_lib.match_brute_force)(f1, f2, ratio)
+            assert np.array_equal(got, want)
+            got_t = matching._match_leaf(f2, f1, ratio, sym)  # transposed roles: column-direction lazy path
+            want_t = (oracle_lib.match_brute_force_symmetric if sym else oracle_lib.match_brute_force)(f2, f1, ratio)
+            assert np.array_equal(got_t, want_t)
+    # sanity: the construction really produces both outcomes
+    m = oracle_lib.match_brute_force(f1, f2, 0.8)
+    assert 10 < len(m) < 96
