@@ -69,6 +69,8 @@ struct MatchArgs {
   int32_t *out_counts;
   uint32_t *out_matches;
   int32_t *out_flags;
+  int debug_no_recheck;  // perf experiments only (results wrong)
+  const int32_t *pad_norm;  // one device int holding OSFM_PAD_NORM (source for out-of-range norm DMA)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -381,6 +383,24 @@ __device__ __forceinline__ int dot128(const v4i a[8], const v4i b[8]) {
   return sdot;
 }
 
+// a'.b' of two stored descriptors (tile layout), 4 k-steps x (2 + 2) 16-byte loads: few live registers
+__device__ __forceinline__ int dot_rows(const int8_t *tilesA, int rowA, const int8_t *tilesB, int rowB) {
+  const int8_t *pa = tilesA + (long)(rowA >> 5) * OSFM_TILE_BYTES + (rowA & 31) * 16;
+  const int8_t *pb = tilesB + (long)(rowB >> 5) * OSFM_TILE_BYTES + (rowB & 31) * 16;
+  int sdot = 0;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const v4i a0 = *(const v4i *)(pa + ks * 1024), a1 = *(const v4i *)(pa + ks * 1024 + 512);
+    const v4i b0 = *(const v4i *)(pb + ks * 1024), b1 = *(const v4i *)(pb + ks * 1024 + 512);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      sdot = __builtin_amdgcn_sdot4(a0[e], b0[e], sdot, false);
+      sdot = __builtin_amdgcn_sdot4(a1[e], b1[e], sdot, false);
+    }
+  }
+  return sdot;
+}
+
 __device__ __forceinline__ int wave_max(int v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m));
@@ -398,6 +418,7 @@ __global__ void __launch_bounds__(kThreads, 2) match_fused2_kernel(MatchArgs a) 
   unsigned short *clist = rowres + a.ncap;
   int *misc = (int *)(clist + a.ncap);  // [16]
   int *req = misc + 16;                 // [4 waves][64 rows][3]
+  int *nbuf = req + kWaves * 192;       // [2][128] column norms of the staged chunk
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -442,19 +463,25 @@ __global__ void __launch_bounds__(kThreads, 2) match_fused2_kernel(MatchArgs a) 
   }
 #pragma unroll
   for (int q = 0; q < kCT; ++q) *(uint4 *)(bbuf + q * OSFM_TILE_BYTES + tid * 16) = pre[q];
+  if (tid < kChunkCols) nbuf[tid] = (tid < tC * 32) ? normC[tid] : OSFM_PAD_NORM;
   __syncthreads();
 
   v4i afrag[kRT][4];
   int Rk[kRT][16];
   int rbst[kRT][16];
-  int nrt = 0, rt0 = 0;
-  int rb = 0, c = 0;
   int flag = 0;
 
-  for (int s = 0; s < nsteps; ++s) {
-    if (c == 0) {
-      rt0 = rb * (kWaves * kRT) + w * kRT;
-      nrt = min(kRT, max(0, tR - rt0));
+  // Nested loops (row block, column chunk): the A operands and row norms are loaded between the
+  // inner loops with nothing else in flight, so inside the inner loop no s_waitcnt ever has to
+  // drain the chunk prefetch (a flattened loop with `if (c == 0)` loads made hipcc wait vmcnt(0)
+  // in front of the first MFMA of every step).
+  for (int rb = 0; rb < nrb; ++rb) {
+    const int rt0 = rb * (kWaves * kRT) + w * kRT;
+    const int nrt = min(kRT, max(0, tR - rt0));
+    {
+      // one coalesced load: lane l holds the norm of row rt0*32 + l (64 rows of this wave)
+      int nrm = OSFM_PAD_NORM;
+      if (lane < nrt * 32) nrm = normR[rt0 * 32 + lane];
 #pragma unroll
       for (int rt = 0; rt < kRT; ++rt) {
 #pragma unroll
@@ -468,21 +495,39 @@ __global__ void __launch_bounds__(kThreads, 2) match_fused2_kernel(MatchArgs a) 
         for (int r = 0; r < 16; ++r) {
           const int rowintile = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
           const int il = rt * 32 + rowintile;
-          int na = OSFM_PAD_NORM;
-          if (rt < nrt) na = normR[(rt0 + rt) * 32 + rowintile];
+          const int na = __shfl(nrm, il);
           Rk[rt][r] = -(na << 6) + (63 - il);
           rbst[rt][r] = INT_MIN;
         }
       }
     }
+    // make hipcc wait for the A operands HERE (nothing else is in flight) instead of in front of the
+    // first MFMA of every inner iteration, where the wait would also drain the chunk prefetch
+#pragma unroll
+    for (int rt = 0; rt < kRT; ++rt)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(afrag[rt][ks]));
+    for (int c = 0; c < nchunks; ++c) {
+    const int s = rb * nchunks + c;
     const bool has_next = (s + 1 < nsteps);
     const int cn = (c + 1 == nchunks) ? 0 : c + 1;
     if (has_next) {
+      // next chunk of the column image: global -> LDS DMA (no staging registers, no ds_write);
+      // the LDS image is lane-linear, exactly the order the lanes ask for.  hipcc drains it
+      // (vmcnt(0)) in front of the __syncthreads() that closes this step.
+      unsigned char *nb2 = bbuf + ((s + 1) & 1) * kChunkBytes;
 #pragma unroll
       for (int q = 0; q < kCT; ++q) {
-        pre[q] = make_uint4(0, 0, 0, 0);
-        if (cn * kCT + q < tC)
-          pre[q] = *(const uint4 *)(tilesC + (long)(cn * kCT + q) * OSFM_TILE_BYTES + tid * 16);
+        const int gt = cn * kCT + q;
+        const int8_t *src = tilesC + (long)(gt < tC ? gt : 0) * OSFM_TILE_BYTES + tid * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(nb2 + q * OSFM_TILE_BYTES + w * 1024), 16, 0, 0);
+      }
+      if (w < 2) {
+        const int jn = cn * kChunkCols + tid;
+        const int32_t *srcn = (jn < tC * 32) ? normC + jn : a.pad_norm;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)srcn,
+                                         (__attribute__((address_space(3))) void *)(nbuf + ((s + 1) & 1) * kChunkCols + w * 64), 4, 0, 0);
       }
     }
     // fold the previous step's per-wave column partials (best, second-largest class best)
@@ -527,8 +572,9 @@ __global__ void __launch_bounds__(kThreads, 2) match_fused2_kernel(MatchArgs a) 
           bf1[ks] = z;
           if (v1ok) bf1[ks] = *(const v4i *)(bb + ct1 * OSFM_TILE_BYTES + ks * 1024 + lane * 16);
         }
-        const int nb0 = normC[g0 * 32 + (lane & 31)];
-        const int nb1 = v1ok ? normC[g1 * 32 + (lane & 31)] : OSFM_PAD_NORM;
+        const int *nbs = nbuf + (s & 1) * kChunkCols;
+        const int nb0 = nbs[ct0 * 32 + (lane & 31)];
+        const int nb1 = nbs[ct1 * 32 + (lane & 31)];  // padding norm when the tile does not exist
         const int ck0 = -(nb0 << 7) + (127 - g0);
         const int ck1 = -(nb1 << 7) + (127 - (g1 & 127));
         int cb0 = INT_MIN, cb1 = INT_MIN;
@@ -569,44 +615,62 @@ __global__ void __launch_bounds__(kThreads, 2) match_fused2_kernel(MatchArgs a) 
       }
     }
     // ---- end of a row block: merge the 32 column classes of every row ----
+    // Transposed through LDS instead of 32 cross-lane butterflies: each lane drops its class-bests
+    // into a [row][class] image (the chunk buffer this step just finished reading, hence the extra
+    // barrier, once per row block), then lane (row, half of the classes) scans 16 ints.
     if (c == nchunks - 1) {
       int *myreq = req + w * 192;
+      __syncthreads();
+      int *tr = (int *)(bbuf + (s & 1) * kChunkBytes) + w * 1024;  // 4 KiB per wave
 #pragma unroll
       for (int rt = 0; rt < kRT; ++rt) {
         if (rt < nrt) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int kb = rbst[rt][r];
-            // 1) largest key of the 32 classes (value, then lowest tile); ties between lanes share
-            //    the same (value, tile): the lowest lane is the lowest column index
-            int km = kb;
+          for (int r = 0; r < 16; ++r) tr[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = rbst[rt][r];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          const int row32 = lane >> 1, hc = lane & 1;
+          int bkey = INT_MIN, bcls = 0, skey = INT_MIN;
 #pragma unroll
-            for (int m = 1; m < 32; m <<= 1) km = max(km, __shfl_xor(km, m));
-            const unsigned long long eq = __ballot(kb == km);
-            const unsigned half = (lane < 32) ? (unsigned)eq : (unsigned)(eq >> 32);
-            const int blane = __builtin_ctz(half);  // half != 0
-            // 2) second largest CLASS best (value only)
-            int k2 = ((lane & 31) == blane) ? INT_MIN : kb;
+          for (int q = 0; q < 4; ++q) {
+            const int4 v4 = *(const int4 *)(tr + row32 * 32 + hc * 16 + q * 4);
+            const int vv[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
-            for (int m = 1; m < 32; m <<= 1) k2 = max(k2, __shfl_xor(k2, m));
-            const int bv = km >> 7, bj = (127 - (km & 127)) * 32 + blane, sv = k2 >> 7;
-            const int rowintile = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const int il = rt * 32 + rowintile;
-            const int row = (rt0 + rt) * 32 + rowintile;
-            if ((lane & 31) == 0) {
-              int rq = -1;
-              if (row < nR) {
-                const int na = normR[row];
-                const int d1 = na - bv, d2 = na - sv;
-                if (d2 >= kCollisionD2) flag = 1;
-                if (ratio_ok(d1, d2, a.ratio)) rq = bj;  // passes against the class bound: re-examine
-                else rowres[row] = kNone;
-              }
-              myreq[il * 3] = rq;
-              myreq[il * 3 + 1] = bv;
-              myreq[il * 3 + 2] = sv;
+            for (int e = 0; e < 4; ++e) {
+              skey = max(skey, min(bkey, vv[e]));
+              const bool up = vv[e] > bkey;  // strict: the lowest class keeps ties (lowest column)
+              bcls = up ? hc * 16 + q * 4 + e : bcls;
+              bkey = up ? vv[e] : bkey;
             }
           }
+          {
+            const int pk = __shfl_xor(bkey, 1), pc = __shfl_xor(bcls, 1), ps = __shfl_xor(skey, 1);
+            const int nsk = max(min(bkey, pk), max(skey, ps));
+            const bool take = (pk > bkey) || (pk == bkey && pc < bcls);
+            bcls = take ? pc : bcls;
+            bkey = take ? pk : bkey;
+            skey = nsk;
+          }
+          const int il = rt * 32 + row32;
+          const int row = (rt0 + rt) * 32 + row32;
+          if (hc == 0) {
+            int rq = -1;
+            const int bv = bkey >> 7, bj = (127 - (bkey & 127)) * 32 + bcls, sv = skey >> 7;
+            if (row < nR) {
+              const int na = normR[row];
+              const int d1 = na - bv, d2 = na - sv;
+              if (d2 >= kCollisionD2) flag = 1;
+              if (ratio_ok(d1, d2, a.ratio)) rq = bj;  // passes against the class bound: re-examine
+              else rowres[row] = kNone;
+            }
+            myreq[il * 3] = rq;
+            myreq[il * 3 + 1] = bv;
+            myreq[il * 3 + 2] = sv;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         } else {
           if (lane < 32) myreq[(rt * 32 + lane) * 3] = -1;
         }
@@ -614,21 +678,15 @@ __global__ void __launch_bounds__(kThreads, 2) match_fused2_kernel(MatchArgs a) 
       // 3) exact second for the rows that passed: the winner's class = columns {t*32 + (bj&31)}
       for (int il = 0; il < kRT * 32; ++il) {
         const int bj = __builtin_amdgcn_readfirstlane(myreq[il * 3]);
-        if (bj < 0) continue;
+        if (bj < 0 || a.debug_no_recheck) continue;
         const int bv = __builtin_amdgcn_readfirstlane(myreq[il * 3 + 1]);
         const int sv = __builtin_amdgcn_readfirstlane(myreq[il * 3 + 2]);
         const int row = rt0 * 32 + il;
-        v4i ra[8];
-        load_row_frag(tilesR, row, ra);
         int mx = INT_MIN;
         for (int t0 = 0; t0 < tC; t0 += 64) {
           const int t = t0 + lane;
           const int j = t * 32 + (bj & 31);
-          if (t < tC && j != bj) {
-            v4i cbv[8];
-            load_row_frag(tilesC, j, cbv);
-            mx = max(mx, 2 * dot128(ra, cbv) - normC[j]);
-          }
+          if (t < tC && j != bj) mx = max(mx, 2 * dot_rows(tilesR, row, tilesC, j) - normC[j]);
         }
         mx = wave_max(mx);
         if (lane == 0) {
@@ -638,18 +696,9 @@ __global__ void __launch_bounds__(kThreads, 2) match_fused2_kernel(MatchArgs a) 
         }
       }
     }
-    if (has_next) {
-      unsigned char *nb2 = bbuf + ((s + 1) & 1) * kChunkBytes;
-#pragma unroll
-      for (int q = 0; q < kCT; ++q) *(uint4 *)(nb2 + q * OSFM_TILE_BYTES + tid * 16) = pre[q];
-    }
     __syncthreads();
-    ++c;
-    if (c == nchunks) {
-      c = 0;
-      ++rb;
-    }
-  }
+    }  // chunks
+  }    // row blocks
   if (tid < kChunkCols) {
     const int sp = nsteps - 1;
     const int j = (nchunks - 1) * kChunkCols + tid;
@@ -689,7 +738,7 @@ __global__ void __launch_bounds__(kThreads, 2) match_fused2_kernel(MatchArgs a) 
   __syncthreads();
   // ---- exact second for the surviving columns: the winner's class = the 32 rows one lane saw ----
   {
-    const int nlist = misc[9];
+    const int nlist = a.debug_no_recheck ? 0 : misc[9];
     for (int e = w; e < nlist; e += kWaves) {
       const int j = clist[e];
       const int bi = colBI[j];
@@ -698,12 +747,7 @@ __global__ void __launch_bounds__(kThreads, 2) match_fused2_kernel(MatchArgs a) 
       const int rtq = lane >> 4, rq = lane & 15;
       const int row = base + rtq * 32 + (rq & 3) + 8 * (rq >> 2) + 4 * h;
       int v = INT_MIN;
-      if (lane < 32 && row < tR * 32 && row != bi) {
-        v4i cbv[8], ra[8];
-        load_row_frag(tilesC, j, cbv);
-        load_row_frag(tilesR, row, ra);
-        v = 2 * dot128(ra, cbv) - normR[row];
-      }
+      if (lane < 32 && row < tR * 32 && row != bi) v = 2 * dot_rows(tilesR, row, tilesC, j) - normR[row];
       v = wave_max(v);
       if (lane == 0) {
         const int nb = normC[j];
@@ -800,7 +844,7 @@ size_t osfm_match_lds_bytes(int ncap) {
   return (size_t)2 * kChunkBytes + 2 * kWaves * kChunkCols * 8 + (size_t)ncap * 14 + 64;
 }
 size_t osfm_match2_lds_bytes(int ncap) {
-  return (size_t)2 * kChunkBytes + 2 * kWaves * kChunkCols * 8 + (size_t)ncap * 16 + 64 + kWaves * 192 * 4;
+  return (size_t)2 * kChunkBytes + 2 * kWaves * kChunkCols * 8 + (size_t)ncap * 16 + 64 + kWaves * 192 * 4 + 2 * kChunkCols * 4;
 }
 static int match_kernel_version() {
   static int v = -1;
@@ -830,6 +874,8 @@ int osfm_launch_match(osfm_ctx *ctx, const osfm_store *store, const int32_t *d_p
   a.out_counts = d_counts;
   a.out_matches = d_matches;
   a.out_flags = d_flags;
+  a.debug_no_recheck = getenv("OSFM_DEBUG_NO_RECHECK") != nullptr;
+  a.pad_norm = store->d_norms + store->tile_off[store->n_images] * 32;  // first slack row: padding norm
   OSFM_REQUIRE(a.ncap <= OSFM_MAX_FEATURES, OSFM_E_UNSUPPORTED, "more than %d features in an image", OSFM_MAX_FEATURES);
   OSFM_REQUIRE(n_pairs < (1ll << 31), OSFM_E_INVALID, "too many pairs in one launch");
   if (!exact_kernel) {
