@@ -211,6 +211,11 @@ struct Dev {
   int bw;           // block half-bandwidth actually used (0: block-Jacobi only)
   double *band;     // S x (bw+1) x 36: block (s, s-k), after factorisation the Cholesky factor L
   double *dinv;     // S x 36: inverse of the diagonal blocks of L
+  // cluster block-tridiagonal form of the same band (cs >= bw shots per cluster, dense ncd x ncd blocks)
+  int cs, ncl, ncd;
+  double *cD;               // ncl x ncd^2: diagonal blocks of the factor (lower triangular)
+  double *cW, *cWt;         // L_{c,c-1} and its transpose
+  double *cLi, *cLit;       // inverse of the diagonal Cholesky factors and its transpose
   double *zc;       // nred (unscaled J^T w)
   double *y;        // nred
   // pcg
@@ -935,6 +940,152 @@ inline band_solve_fn band_solve_for(int bw) {
   }
 }
 
+
+// ---- cluster block-tridiagonal factorisation of the band ---------------------------------------
+// With cs >= bw shots per cluster the banded shot system is exactly block TRIdiagonal in dense
+// (6 cs)^2 blocks.  One 256-thread workgroup walks the chain: per cluster two small GEMMs, a dense
+// Cholesky and a triangular inverse, all in LDS; the solve is then two sweeps of dense mat-vecs.
+// ~500 chain links instead of 5 000, each with enough parallel work for a whole workgroup.
+// The cluster factors are just a re-blocking of the band Cholesky factor (Cholesky is unique):
+// L_{c,c} = the (6 cs)^2 lower-triangular diagonal block, L_{c,c-1} = the block below it.  So the
+// sequential part stays band_cholesky_kernel; what is added is embarrassingly parallel: scatter
+// the 6x6 factor blocks into dense cluster blocks and invert every diagonal block (one workgroup
+// per cluster), so that the triangular sweeps become dense mat-vecs.
+__global__ void ctri_scatterL_kernel(Dev d) {
+  const int s = blockIdx.x;
+  const int R1 = d.bw + 1;
+  const long n2 = (long)d.ncd * d.ncd;
+  for (int t = threadIdx.x; t < R1 * 36; t += blockDim.x) {
+    const int k = t / 36, ij = t % 36, i = ij / 6, j = ij % 6;
+    const int s2 = s - k;
+    if (s2 < 0) continue;
+    const double val = d.band[((long)s * R1 + k) * 36 + ij];
+    const int c = s / d.cs, c2 = s2 / d.cs;
+    const int rl = 6 * s + i - c * d.ncd;
+    if (c2 == c) {
+      const int cl = 6 * s2 + j - c * d.ncd;
+      d.cD[c * n2 + (long)rl * d.ncd + cl] = val;  // lower triangular (k == 0 blocks have a zero upper part)
+    } else {
+      const int cl = 6 * s2 + j - c2 * d.ncd;
+      d.cW[c * n2 + (long)rl * d.ncd + cl] = val;
+      d.cWt[c * n2 + (long)cl * d.ncd + rl] = val;
+    }
+  }
+}
+__global__ void ctri_pad_kernel(Dev d) {  // identity on the padding rows of the last cluster
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int first = 6 * d.S - (d.ncl - 1) * d.ncd;
+  if (p >= first && p < d.ncd) d.cD[(long)(d.ncl - 1) * d.ncd * d.ncd + (long)p * d.ncd + p] = 1.0;
+}
+// one workgroup (one wavefront) per cluster: inverse of the lower triangular diagonal block
+__global__ void __launch_bounds__(64) ctri_inverse_kernel(Dev d) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int n = d.ncd, n2 = n * n, c = blockIdx.x, tid = threadIdx.x;
+  double *L = lds, *X = lds + n2;
+  const double *gL = d.cD + (long)c * n2;
+  for (int t = tid; t < n2; t += 64) L[t] = gL[t];
+  __syncthreads();
+  if (tid < n) {
+    const int cc = tid;
+    for (int r = 0; r < n; r++) {
+      double sum = (r == cc) ? 1.0 : 0.0;
+      if (r >= cc) {
+        double s0 = 0, s1 = 0;
+        int q = cc;
+        for (; q + 1 < r; q += 2) {
+          s0 += L[r * n + q] * X[q * n + cc];
+          s1 += L[r * n + q + 1] * X[(q + 1) * n + cc];
+        }
+        if (q < r) s0 += L[r * n + q] * X[q * n + cc];
+        X[r * n + cc] = (sum - (s0 + s1)) / L[r * n + r];
+      } else {
+        X[r * n + cc] = 0.0;
+      }
+    }
+  }
+  __syncthreads();
+  for (int t = tid; t < n2; t += 64) {
+    const int r = t / n, q = t - r * n;
+    d.cLi[(long)c * n2 + t] = X[t];
+    d.cLit[(long)c * n2 + (long)q * n + r] = X[t];
+  }
+}
+
+// z_shots = (L L^T)^-1 r_shots with the cluster factors; camera rows: 3x3 block Jacobi
+__global__ void __launch_bounds__(256) ctri_solve_kernel(Dev d, const double *rin, double *z) {
+  __shared__ double yprev[64], tvec[64], part[4][64];
+  const int n = d.ncd, n2 = n * n;
+  const int tid = threadIdx.x, r = tid & 63, pq = tid >> 6;
+  const int q0 = pq * 16;
+  const int nshot = 6 * d.S;
+  if (tid < 64) yprev[tid] = 0.0;
+  __syncthreads();
+  // forward: y_c = Li_c (b_c - W_c y_{c-1})
+  for (int c = 0; c < d.ncl; c++) {
+    const double *Wc = d.cW + (long)c * n2, *Li = d.cLi + (long)c * n2;
+    double acc = 0;
+    if (c > 0 && r < n)
+#pragma unroll 4
+      for (int q = q0; q < q0 + 16 && q < n; q++) acc += Wc[r * n + q] * yprev[q];
+    part[pq][r] = acc;
+    __syncthreads();
+    if (tid < 64) {
+      const int g = c * n + tid;
+      const double b = (tid < n && g < nshot) ? rin[g] : 0.0;
+      tvec[tid] = b - ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]));
+    }
+    __syncthreads();
+    acc = 0;
+    if (r < n)
+#pragma unroll 4
+      for (int q = q0; q < q0 + 16 && q < n; q++) acc += Li[r * n + q] * tvec[q];
+    part[pq][r] = acc;
+    __syncthreads();
+    if (tid < 64) {
+      const double y = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+      yprev[tid] = y;
+      const int g = c * n + tid;
+      if (tid < n && g < nshot) z[g] = y;
+    }
+    __syncthreads();
+  }
+  // backward: x_c = Li_c^T (y_c - W_{c+1}^T x_{c+1})
+  if (tid < 64) yprev[tid] = 0.0;
+  __syncthreads();
+  for (int c = d.ncl - 1; c >= 0; c--) {
+    const double *Wt = d.cWt + (long)(c + 1) * n2, *Lit = d.cLit + (long)c * n2;
+    double acc = 0;
+    if (c + 1 < d.ncl && r < n)
+#pragma unroll 4
+      for (int q = q0; q < q0 + 16 && q < n; q++) acc += Wt[r * n + q] * yprev[q];
+    part[pq][r] = acc;
+    __syncthreads();
+    if (tid < 64) {
+      const int g = c * n + tid;
+      const double y = (tid < n && g < nshot) ? z[g] : 0.0;
+      tvec[tid] = y - ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]));
+    }
+    __syncthreads();
+    acc = 0;
+    if (r < n)
+#pragma unroll 4
+      for (int q = q0; q < q0 + 16 && q < n; q++) acc += Lit[r * n + q] * tvec[q];
+    part[pq][r] = acc;
+    __syncthreads();
+    if (tid < 64) {
+      const double x = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+      yprev[tid] = x;
+      const int g = c * n + tid;
+      if (tid < n && g < nshot) z[g] = x;
+    }
+    __syncthreads();
+  }
+  for (int cm = tid; cm < d.NC; cm += 256) {
+    const double *Bi = d.Binv + 36 * (long)d.S + 9 * cm, *rr = rin + d.cam0 + 3 * cm;
+    for (int i = 0; i < 3; i++) z[d.cam0 + 3 * cm + i] = Bi[3 * i] * rr[0] + Bi[3 * i + 1] * rr[1] + Bi[3 * i + 2] * rr[2];
+  }
+}
+
 // ---- Schur mat-vec ------------------------------------------------------------------------
 __global__ void scale_vec_kernel(const double *sc, const double *x, double *y, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1269,9 +1420,11 @@ struct Solver {
     hipLaunchKernelGGL(cam_reduce_kernel, dim3(d.NC), dim3(TPB), 0, st, d, 9);
     hipLaunchKernelGGL(cam_grad_kernel, dim3(nblk(d.NC, 64)), dim3(64), 0, st, d, d.cams);
   }
-  bool use_band = false;
+  bool use_band = false, use_ctri = false;
   void precond(const double *r, double *z) {
-    if (use_band)
+    if (use_ctri)
+      hipLaunchKernelGGL(ctri_solve_kernel, dim3(1), dim3(256), 0, st, d, r, z);
+    else if (use_band)
       hipLaunchKernelGGL(band_solve_for(d.bw), dim3(1), dim3(64), 0, st, d, r, z);
     else
       hipLaunchKernelGGL(precond_apply_kernel, dim3(nblk(d.S + d.NC)), dim3(TPB), 0, st, d, r, z);
@@ -1428,6 +1581,18 @@ extern "C" int osfm_ba_solve(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_op
   if (S < 2) d.bw = 0;
   d.band = A.alloc<double>((size_t)S * (d.bw + 1) * 36, e);
   d.dinv = A.alloc<double>((size_t)S * 36, e);
+  d.cs = 0; d.ncl = 0; d.ncd = 0;
+  if (d.bw >= 1 && d.bw <= 10 && d.bw == bw_true && O->preconditioner == 0) {  // exact band, dense clusters fit LDS
+    d.cs = d.bw < 2 ? 2 : d.bw;
+    d.ncd = 6 * d.cs;
+    d.ncl = (S + d.cs - 1) / d.cs;
+    const size_t nb = (size_t)d.ncl * d.ncd * d.ncd;
+    d.cD = A.alloc<double>(nb, e);
+    d.cW = A.alloc<double>(nb + (size_t)d.ncd * d.ncd, e);
+    d.cWt = A.alloc<double>(nb + (size_t)d.ncd * d.ncd, e);
+    d.cLi = A.alloc<double>(nb, e);
+    d.cLit = A.alloc<double>(nb, e);
+  }
   int *d_status = A.alloc<int>(4, e);
   double *d_reproj = P->reproj_err ? A.alloc<double>((size_t)2 * M, e) : nullptr;
   OSFM_REQUIRE(e == hipSuccess, OSFM_E_NOMEM, "BA device allocation/upload failed: %s", hipGetErrorString(e));
@@ -1479,6 +1644,8 @@ extern "C" int osfm_ba_solve(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_op
     if (d.bw > 0) {
       const int R = d.bw + 1;
       hipLaunchKernelGGL(band_assemble_kernel, dim3(S), dim3(TPB), 0, st, d, radius);
+      sv.use_ctri = false;
+      {
       static bool chol_attr = false;
       if (!chol_attr) {
         OSFM_HIP(hipFuncSetAttribute((const void *)band_cholesky_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1489,6 +1656,22 @@ extern "C" int osfm_ba_solve(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_op
       OSFM_HIP(hipMemcpyAsync(&hstatus, d_status, sizeof(int), hipMemcpyDeviceToHost, st));
       OSFM_HIP(hipStreamSynchronize(st));
       sv.use_band = (hstatus == 0);  // a truncated band may lose positive definiteness: fall back to block Jacobi
+      if (sv.use_band && d.ncl > 0) {
+        const size_t n2 = (size_t)d.ncd * d.ncd;
+        OSFM_HIP(hipMemsetAsync(d.cD, 0, (size_t)d.ncl * n2 * sizeof(double), st));
+        OSFM_HIP(hipMemsetAsync(d.cW, 0, (size_t)(d.ncl + 1) * n2 * sizeof(double), st));
+        OSFM_HIP(hipMemsetAsync(d.cWt, 0, (size_t)(d.ncl + 1) * n2 * sizeof(double), st));
+        hipLaunchKernelGGL(ctri_pad_kernel, dim3(1), dim3(64), 0, st, d);
+        hipLaunchKernelGGL(ctri_scatterL_kernel, dim3(S), dim3(TPB), 0, st, d);
+        static bool ctri_attr = false;
+        if (!ctri_attr) {
+          OSFM_HIP(hipFuncSetAttribute((const void *)ctri_inverse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+          ctri_attr = true;
+        }
+        hipLaunchKernelGGL(ctri_inverse_kernel, dim3(d.ncl), dim3(64), 2 * n2 * sizeof(double), st, d);
+        sv.use_ctri = true;
+      }
+      }
     }
     // rhs
     hipLaunchKernelGGL(schur_point_kernel<1>, dim3(nblk(NP)), dim3(TPB), 0, st, d, d.y);
@@ -1580,7 +1763,7 @@ extern "C" int osfm_ba_solve(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_op
   {
     const int reps = 10;
     hipLaunchKernelGGL(point_hhat_kernel, dim3(nblk(NP)), dim3(TPB), 0, st, d, radius);
-    Rp->preconditioner_bandwidth = sv.use_band ? d.bw : 0;
+    Rp->preconditioner_bandwidth = (sv.use_band || sv.use_ctri) ? d.bw : 0;
     Rp->shot_bandwidth = bw_true;
     OSFM_HIP(hipEventRecord(ctx->ev[6], st));
     for (int i = 0; i < reps; i++) sv.matvec(d.p, d.Ap, radius);
