@@ -197,7 +197,11 @@ struct Dev {
   const long *shot_off;  // S + 1
   const int *shot_obs;   // M: indices into the point-major arrays, grouped by shot
   double *shotR;         // S x 36
-  double *J;             // 26 x M SoA: res(2) Jp(6) Jc(12) Jk(6)
+  // per-observation residual + Jacobian blocks, components: res(2) Jp(6) Jc(12) Jk(6), kept twice:
+  double *Jpm;           // [M][26] AoS in POINT-major order: one thread walks a track, 208 contiguous B per obs
+  double *Jsm;           // [26][M] SoA in SHOT-major order: a wavefront walks a shot's observations, coalesced
+  const int *sm_shot, *sm_point;        // observation data in shot-major order (static)
+  const double *sm_x, *sm_y, *sm_sigma;
   double *w;             // 2 x M
   // points
   double *g_pt, *Hpp, *Hhat, *sc_pt, *D_pt, *d_pt;
@@ -224,7 +228,8 @@ struct Dev {
   double *partial;  // block partial sums
 };
 
-__device__ __forceinline__ double *Jcomp(const Dev &d, int c) { return d.J + (long)c * d.M; }
+#define JA(o, c) d.Jpm[(long)(o) * 26 + (c)]   /* point-major AoS */
+#define JS(k, c) d.Jsm[(long)(c) * d.M + (k)]  /* shot-major SoA  */
 
 __global__ void shot_rot_kernel(Dev d, const double *poses) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -232,20 +237,23 @@ __global__ void shot_rot_kernel(Dev d, const double *poses) {
   rot_and_derivs(poses + 6 * s, d.shotR + 36 * (long)s, d.shotR + 36 * (long)s + 9);
 }
 
-// residuals (+ Jacobian blocks), robust corrector, cost partials
-template <bool JAC>
+// residuals (+ Jacobian blocks), robust corrector, cost partials.
+// SM = false: point-major thread order, writes the AoS copy and the cost partials;
+// SM = true : shot-major thread order, writes the SoA copy only (the projection is recomputed --
+//             ~300 flops per observation are far cheaper than an uncoalesced 208-byte scatter).
+template <bool JAC, bool SM>
 __global__ void __launch_bounds__(TPB) eval_kernel(Dev d, const double *cams, const double *poses, const double *pts,
                                                     int loss, double a) {
   __shared__ double lds[8];
   const long o = (long)blockIdx.x * TPB + threadIdx.x;
   double acc[2] = {0.0, 0.0};
   if (o < d.M) {
-    const int s = d.o_shot[o], p = d.o_point[o];
+    const int s = SM ? d.sm_shot[o] : d.o_shot[o], p = SM ? d.sm_point[o] : d.o_point[o];
     const double *R = d.shotR + 36 * (long)s;
     double r[2], Jp[6], Jc[12], Jk[6];
-    const double sg = d.o_sigma[o];
-    project_obs<JAC>(pts + 3 * (long)p, poses + 6 * (long)s, R, R + 9, cams + 3 * d.shot_camera[s], d.o_x[o], d.o_y[o],
-                     1.0 / sg, r, Jp, Jc, Jk);
+    const double sg = SM ? d.sm_sigma[o] : d.o_sigma[o];
+    project_obs<JAC>(pts + 3 * (long)p, poses + 6 * (long)s, R, R + 9, cams + 3 * d.shot_camera[s], SM ? d.sm_x[o] : d.o_x[o],
+                     SM ? d.sm_y[o] : d.o_y[o], 1.0 / sg, r, Jp, Jc, Jk);
     const double sq = r[0] * r[0] + r[1] * r[1];
     double rho, rho1;
     loss_eval(loss, a, sq, rho, rho1);
@@ -253,20 +261,33 @@ __global__ void __launch_bounds__(TPB) eval_kernel(Dev d, const double *cams, co
     acc[1] = sq * sg * sg;
     if (JAC) {
       const double wt = sqrt(rho1);
-      Jcomp(d, 0)[o] = wt * r[0];
-      Jcomp(d, 1)[o] = wt * r[1];
+      if (SM) {
+        JS(o, 0) = wt * r[0];
+        JS(o, 1) = wt * r[1];
 #pragma unroll
-      for (int i = 0; i < 6; i++) Jcomp(d, 2 + i)[o] = wt * Jp[i];
+        for (int i = 0; i < 6; i++) JS(o, 2 + i) = wt * Jp[i];
 #pragma unroll
-      for (int i = 0; i < 12; i++) Jcomp(d, 8 + i)[o] = wt * Jc[i];
+        for (int i = 0; i < 12; i++) JS(o, 8 + i) = wt * Jc[i];
 #pragma unroll
-      for (int i = 0; i < 6; i++) Jcomp(d, 20 + i)[o] = wt * Jk[i];
+        for (int i = 0; i < 6; i++) JS(o, 20 + i) = wt * Jk[i];
+      } else {
+        double2 *dst = (double2 *)(d.Jpm + o * 26);
+        dst[0] = make_double2(wt * r[0], wt * r[1]);
+#pragma unroll
+        for (int i = 0; i < 3; i++) dst[1 + i] = make_double2(wt * Jp[2 * i], wt * Jp[2 * i + 1]);
+#pragma unroll
+        for (int i = 0; i < 6; i++) dst[4 + i] = make_double2(wt * Jc[2 * i], wt * Jc[2 * i + 1]);
+#pragma unroll
+        for (int i = 0; i < 3; i++) dst[10 + i] = make_double2(wt * Jk[2 * i], wt * Jk[2 * i + 1]);
+      }
     }
   }
-  block_sum<2>(acc, lds);
-  if (threadIdx.x == 0) {
-    d.partial[2 * blockIdx.x] = acc[0];
-    d.partial[2 * blockIdx.x + 1] = acc[1];
+  if (!SM) {
+    block_sum<2>(acc, lds);
+    if (threadIdx.x == 0) {
+      d.partial[2 * blockIdx.x] = acc[0];
+      d.partial[2 * blockIdx.x + 1] = acc[1];
+    }
   }
 }
 
@@ -312,12 +333,12 @@ __global__ void __launch_bounds__(TPB) point_grad_kernel(Dev d) {
   double g[3] = {0, 0, 0}, H[6] = {0, 0, 0, 0, 0, 0};
   if (!(d.point_fixed && d.point_fixed[p])) {
     for (long o = d.pt_off[p]; o < d.pt_off[p + 1]; o++) {
-      const double r0 = Jcomp(d, 0)[o], r1 = Jcomp(d, 1)[o];
+      const double r0 = JA(o, 0), r1 = JA(o, 1);
       double a[3], b[3];
 #pragma unroll
       for (int j = 0; j < 3; j++) {
-        a[j] = Jcomp(d, 2 + j)[o];
-        b[j] = Jcomp(d, 5 + j)[o];
+        a[j] = JA(o, 2 + j);
+        b[j] = JA(o, 5 + j);
         g[j] += a[j] * r0 + b[j] * r1;
       }
       H[0] += a[0] * a[0] + b[0] * b[0];
@@ -341,13 +362,12 @@ __global__ void __launch_bounds__(64) shot_grad_kernel(Dev d, const double *pose
 #pragma unroll
   for (int i = 0; i < 36; i++) v[i] = 0;
   for (long k = d.shot_off[s] + lane; k < d.shot_off[s + 1]; k += 64) {
-    const long o = d.shot_obs[k];
-    const double r0 = Jcomp(d, 0)[o], r1 = Jcomp(d, 1)[o];
+    const double r0 = JS(k, 0), r1 = JS(k, 1);
     double a[6], b[6];
 #pragma unroll
     for (int j = 0; j < 6; j++) {
-      a[j] = Jcomp(d, 8 + j)[o];
-      b[j] = Jcomp(d, 14 + j)[o];
+      a[j] = JS(k, 8 + j);
+      b[j] = JS(k, 14 + j);
       v[j] += a[j] * r0 + b[j] * r1;
     }
     int q = 6;
@@ -358,8 +378,8 @@ __global__ void __launch_bounds__(64) shot_grad_kernel(Dev d, const double *pose
     double ka[3], kb[3];
 #pragma unroll
     for (int j = 0; j < 3; j++) {
-      ka[j] = Jcomp(d, 20 + j)[o];
-      kb[j] = Jcomp(d, 23 + j)[o];
+      ka[j] = JS(k, 20 + j);
+      kb[j] = JS(k, 23 + j);
       v[27 + j] += ka[j] * r0 + kb[j] * r1;
     }
     v[30] += ka[0] * ka[0] + kb[0] * kb[0];
@@ -487,23 +507,22 @@ __global__ void __launch_bounds__(64) precond_shot_kernel(Dev d, double radius) 
 #pragma unroll
   for (int i = 0; i < 27; i++) v[i] = 0;
   for (long k = d.shot_off[s] + lane; k < d.shot_off[s + 1]; k += 64) {
-    const long o = d.shot_obs[k];
-    const int p = d.o_point[o];
+    const int p = d.sm_point[k];
     const double *Hh = d.Hhat + 6 * (long)p;
     const double h[9] = {Hh[0], Hh[1], Hh[2], Hh[1], Hh[3], Hh[4], Hh[2], Hh[4], Hh[5]};
     double jp[6];
 #pragma unroll
-    for (int j = 0; j < 6; j++) jp[j] = Jcomp(d, 2 + j)[o];
+    for (int j = 0; j < 6; j++) jp[j] = JS(k, 2 + j);
     double E[9][3];  // rows: 6 shot + 3 camera ; E = Jred^T Jp
 #pragma unroll
     for (int i = 0; i < 6; i++) {
-      const double a = Jcomp(d, 8 + i)[o], b = Jcomp(d, 14 + i)[o];
+      const double a = JS(k, 8 + i), b = JS(k, 14 + i);
 #pragma unroll
       for (int j = 0; j < 3; j++) E[i][j] = a * jp[j] + b * jp[3 + j];
     }
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-      const double a = Jcomp(d, 20 + i)[o], b = Jcomp(d, 23 + i)[o];
+      const double a = JS(k, 20 + i), b = JS(k, 23 + i);
 #pragma unroll
       for (int j = 0; j < 3; j++) E[6 + i][j] = a * jp[j] + b * jp[3 + j];
     }
@@ -620,13 +639,14 @@ __device__ __forceinline__ void WAVE_SYNC() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+template <bool SM>
 __device__ __forceinline__ void jred_jp(const Dev &d, long o, double E[6][3]) {
   double jp[6];
 #pragma unroll
-  for (int j = 0; j < 6; j++) jp[j] = Jcomp(d, 2 + j)[o];
+  for (int j = 0; j < 6; j++) jp[j] = SM ? JS(o, 2 + j) : JA(o, 2 + j);
 #pragma unroll
   for (int i = 0; i < 6; i++) {
-    const double a = Jcomp(d, 8 + i)[o], b = Jcomp(d, 14 + i)[o];
+    const double a = SM ? JS(o, 8 + i) : JA(o, 8 + i), b = SM ? JS(o, 14 + i) : JA(o, 14 + i);
 #pragma unroll
     for (int j = 0; j < 3; j++) E[i][j] = a * jp[j] + b * jp[3 + j];
   }
@@ -638,12 +658,11 @@ __global__ void __launch_bounds__(TPB) band_assemble_kernel(Dev d, double radius
   for (int t = threadIdx.x; t < nb; t += TPB) acc[t] = 0.0;
   __syncthreads();
   for (long k = d.shot_off[s] + threadIdx.x; k < d.shot_off[s + 1]; k += TPB) {
-    const long o = d.shot_obs[k];
-    const int p = d.o_point[o];
+    const int p = d.sm_point[k];
     const double *Hh = d.Hhat + 6 * (long)p;
     const double h[9] = {Hh[0], Hh[1], Hh[2], Hh[1], Hh[3], Hh[4], Hh[2], Hh[4], Hh[5]};
     double Ea[6][3], EH[6][3];
-    jred_jp(d, o, Ea);
+    jred_jp<true>(d, k, Ea);
 #pragma unroll
     for (int i = 0; i < 6; i++)
 #pragma unroll
@@ -652,7 +671,7 @@ __global__ void __launch_bounds__(TPB) band_assemble_kernel(Dev d, double radius
       const int dk = s - d.o_shot[o2];
       if (dk < 0 || dk > d.bw) continue;
       double Eb[6][3];
-      jred_jp(d, o2, Eb);
+      jred_jp<false>(d, o2, Eb);
 #pragma unroll
       for (int i = 0; i < 6; i++)
 #pragma unroll
@@ -712,14 +731,15 @@ __global__ void __launch_bounds__(64) band_cholesky_kernel(Dev d, int *status) {
       if (j < 0) continue;
       const double *rowj = ring + (j & kMaxBw) * R * 36;
       if (lane < 36) {
-        double t = cur[kk * 36 + lane];
         const int m0 = (i - d.bw > j - d.bw ? i - d.bw : j - d.bw);
+        double a0 = 0, a1 = 0, a2 = 0;  // independent partial sums: the chain was FMA-latency bound
         for (int m = (m0 < 0 ? 0 : m0); m < j; m++) {
           const double *Lim = cur + (i - m) * 36, *Ljm = rowj + (j - m) * 36;
-#pragma unroll
-          for (int q = 0; q < 6; q++) t -= Lim[r * 6 + q] * Ljm[c * 6 + q];
+          a0 += Lim[r * 6 + 0] * Ljm[c * 6 + 0] + Lim[r * 6 + 3] * Ljm[c * 6 + 3];
+          a1 += Lim[r * 6 + 1] * Ljm[c * 6 + 1] + Lim[r * 6 + 4] * Ljm[c * 6 + 4];
+          a2 += Lim[r * 6 + 2] * Ljm[c * 6 + 2] + Lim[r * 6 + 5] * Ljm[c * 6 + 5];
         }
-        T[lane] = t;
+        T[lane] = cur[kk * 36 + lane] - ((a0 + a1) + a2);
       }
       WAVE_SYNC();
       if (lane < 36) {
@@ -733,14 +753,15 @@ __global__ void __launch_bounds__(64) band_cholesky_kernel(Dev d, int *status) {
     }
     // diagonal block
     if (lane < 36) {
-      double t = cur[lane];
       const int m0 = i - d.bw;
+      double a0 = 0, a1 = 0, a2 = 0;
       for (int m = (m0 < 0 ? 0 : m0); m < i; m++) {
         const double *Lim = cur + (i - m) * 36;
-#pragma unroll
-        for (int q = 0; q < 6; q++) t -= Lim[r * 6 + q] * Lim[c * 6 + q];
+        a0 += Lim[r * 6 + 0] * Lim[c * 6 + 0] + Lim[r * 6 + 3] * Lim[c * 6 + 3];
+        a1 += Lim[r * 6 + 1] * Lim[c * 6 + 1] + Lim[r * 6 + 4] * Lim[c * 6 + 4];
+        a2 += Lim[r * 6 + 2] * Lim[c * 6 + 2] + Lim[r * 6 + 5] * Lim[c * 6 + 5];
       }
-      T[lane] = t;
+      T[lane] = cur[lane] - ((a0 + a1) + a2);
       Lc[lane] = 0.0;
     }
     WAVE_SYNC();
@@ -1108,20 +1129,20 @@ __global__ void __launch_bounds__(TPB) schur_point_kernel(Dev d, const double *y
       double t0 = 0, t1 = 0;
 #pragma unroll
       for (int j = 0; j < 6; j++) {
-        t0 += Jcomp(d, 8 + j)[o] * ys[j];
-        t1 += Jcomp(d, 14 + j)[o] * ys[j];
+        t0 += JA(o, 8 + j) * ys[j];
+        t1 += JA(o, 14 + j) * ys[j];
       }
 #pragma unroll
       for (int j = 0; j < 3; j++) {
-        t0 += Jcomp(d, 20 + j)[o] * yk[j];
-        t1 += Jcomp(d, 23 + j)[o] * yk[j];
+        t0 += JA(o, 20 + j) * yk[j];
+        t1 += JA(o, 23 + j) * yk[j];
       }
       if (MODE == 0) {
-        d.w[o] = t0;
-        d.w[d.M + o] = t1;
+        d.w[2 * o] = t0;
+        d.w[2 * o + 1] = t1;
       }
 #pragma unroll
-      for (int j = 0; j < 3; j++) u[j] += Jcomp(d, 2 + j)[o] * t0 + Jcomp(d, 5 + j)[o] * t1;
+      for (int j = 0; j < 3; j++) u[j] += JA(o, 2 + j) * t0 + JA(o, 5 + j) * t1;
     }
   }
   const double *Hh = d.Hhat + 6 * (long)p;
@@ -1139,14 +1160,14 @@ __global__ void __launch_bounds__(TPB) schur_point_kernel(Dev d, const double *y
     return;
   }
   for (long o = o0; o < o1; o++) {
-    const double m0 = Jcomp(d, 2)[o] * v0 + Jcomp(d, 3)[o] * v1 + Jcomp(d, 4)[o] * v2;
-    const double m1 = Jcomp(d, 5)[o] * v0 + Jcomp(d, 6)[o] * v1 + Jcomp(d, 7)[o] * v2;
+    const double m0 = JA(o, 2) * v0 + JA(o, 3) * v1 + JA(o, 4) * v2;
+    const double m1 = JA(o, 5) * v0 + JA(o, 6) * v1 + JA(o, 7) * v2;
     if (MODE == 0) {
-      d.w[o] -= m0;
-      d.w[d.M + o] -= m1;
+      d.w[2 * o] -= m0;
+      d.w[2 * o + 1] -= m1;
     } else {
-      d.w[o] = -m0;
-      d.w[d.M + o] = -m1;
+      d.w[2 * o] = -m0;
+      d.w[2 * o + 1] = -m1;
     }
   }
 }
@@ -1156,12 +1177,12 @@ __global__ void __launch_bounds__(64) schur_shot_kernel(Dev d) {
   const int s = blockIdx.x, lane = threadIdx.x;
   double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (long k = d.shot_off[s] + lane; k < d.shot_off[s + 1]; k += 64) {
-    const long o = d.shot_obs[k];
-    const double w0 = d.w[o], w1 = d.w[d.M + o];
+    const long o = d.shot_obs[k];  // w lives in point-major order: 2 gathered doubles per observation
+    const double w0 = d.w[2 * o], w1 = d.w[2 * o + 1];
 #pragma unroll
-    for (int j = 0; j < 6; j++) v[j] += Jcomp(d, 8 + j)[o] * w0 + Jcomp(d, 14 + j)[o] * w1;
+    for (int j = 0; j < 6; j++) v[j] += JS(k, 8 + j) * w0 + JS(k, 14 + j) * w1;
 #pragma unroll
-    for (int j = 0; j < 3; j++) v[6 + j] += Jcomp(d, 20 + j)[o] * w0 + Jcomp(d, 23 + j)[o] * w1;
+    for (int j = 0; j < 3; j++) v[6 + j] += JS(k, 20 + j) * w0 + JS(k, 23 + j) * w1;
   }
 #pragma unroll
   for (int i = 0; i < 9; i++)
@@ -1247,20 +1268,20 @@ __global__ void __launch_bounds__(TPB) model_change_kernel(Dev d, const double *
     double m0 = 0, m1 = 0;
 #pragma unroll
     for (int j = 0; j < 3; j++) {
-      m0 += Jcomp(d, 2 + j)[o] * dp[j];
-      m1 += Jcomp(d, 5 + j)[o] * dp[j];
+      m0 += JA(o, 2 + j) * dp[j];
+      m1 += JA(o, 5 + j) * dp[j];
     }
 #pragma unroll
     for (int j = 0; j < 6; j++) {
-      m0 += Jcomp(d, 8 + j)[o] * ys[j];
-      m1 += Jcomp(d, 14 + j)[o] * ys[j];
+      m0 += JA(o, 8 + j) * ys[j];
+      m1 += JA(o, 14 + j) * ys[j];
     }
 #pragma unroll
     for (int j = 0; j < 3; j++) {
-      m0 += Jcomp(d, 20 + j)[o] * yk[j];
-      m1 += Jcomp(d, 23 + j)[o] * yk[j];
+      m0 += JA(o, 20 + j) * yk[j];
+      m1 += JA(o, 23 + j) * yk[j];
     }
-    acc[0] = -(m0 * (Jcomp(d, 0)[o] + 0.5 * m0) + m1 * (Jcomp(d, 1)[o] + 0.5 * m1));
+    acc[0] = -(m0 * (JA(o, 0) + 0.5 * m0) + m1 * (JA(o, 1) + 0.5 * m1));
   }
   block_sum<1>(acc, lds);
   if (threadIdx.x == 0) d.partial[blockIdx.x] = acc[0];
@@ -1402,10 +1423,12 @@ struct Solver {
   int eval(const double *cams, const double *poses, const double *pts, bool jac, double *cost, double *sumsq) {
     rot(poses);
     const int nb = nblk(d.M);
-    if (jac)
-      hipLaunchKernelGGL(eval_kernel<true>, dim3(nb), dim3(TPB), 0, st, d, cams, poses, pts, loss, loss_a);
-    else
-      hipLaunchKernelGGL(eval_kernel<false>, dim3(nb), dim3(TPB), 0, st, d, cams, poses, pts, loss, loss_a);
+    if (jac) {
+      hipLaunchKernelGGL((eval_kernel<true, false>), dim3(nb), dim3(TPB), 0, st, d, cams, poses, pts, loss, loss_a);
+      hipLaunchKernelGGL((eval_kernel<true, true>), dim3(nb), dim3(TPB), 0, st, d, cams, poses, pts, loss, loss_a);
+    } else {
+      hipLaunchKernelGGL((eval_kernel<false, false>), dim3(nb), dim3(TPB), 0, st, d, cams, poses, pts, loss, loss_a);
+    }
     hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(1024), 0, st, d.partial, (long)nb, 2, d.scal + 8);
     hipLaunchKernelGGL(prior_cost_kernel, dim3(1), dim3(256), 0, st, d, cams, poses, d.scal + 8);
     OSFM_HIP(hipMemcpyAsync(hscal.data(), d.scal + 8, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -1538,7 +1561,25 @@ extern "C" int osfm_ba_solve(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_op
   d.shot_off = A.upload(shot_off.data(), (size_t)S + 1, e);
   d.shot_obs = A.upload(shot_obs.data(), (size_t)M, e);
   d.shotR = A.alloc<double>((size_t)36 * S, e);
-  d.J = A.alloc<double>((size_t)26 * M, e);
+  d.Jpm = A.alloc<double>((size_t)26 * M, e);
+  d.Jsm = A.alloc<double>((size_t)26 * M, e);
+  {
+    std::vector<int> sshot((size_t)M), spoint((size_t)M);
+    std::vector<double> sx((size_t)M), sy((size_t)M), ssg((size_t)M);
+    for (long k = 0; k < M; k++) {
+      const long o = shot_obs[(size_t)k];
+      sshot[(size_t)k] = o_shot[(size_t)o];
+      spoint[(size_t)k] = o_point[(size_t)o];
+      sx[(size_t)k] = o_x[(size_t)o];
+      sy[(size_t)k] = o_y[(size_t)o];
+      ssg[(size_t)k] = o_sg[(size_t)o];
+    }
+    d.sm_shot = A.upload(sshot.data(), (size_t)M, e);
+    d.sm_point = A.upload(spoint.data(), (size_t)M, e);
+    d.sm_x = A.upload(sx.data(), (size_t)M, e);
+    d.sm_y = A.upload(sy.data(), (size_t)M, e);
+    d.sm_sigma = A.upload(ssg.data(), (size_t)M, e);
+  }
   d.w = A.alloc<double>((size_t)2 * M, e);
   d.g_pt = A.alloc<double>((size_t)3 * NP, e);
   d.Hpp = A.alloc<double>((size_t)6 * NP, e);
