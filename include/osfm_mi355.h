@@ -183,6 +183,9 @@ typedef struct {
   int64_t matvec_calls;
   int32_t shot_bandwidth;           /* max |shot_a - shot_b| over shots sharing a point          */
   int32_t preconditioner_bandwidth; /* block half-width of the banded preconditioner, 0 = Jacobi */
+  /* wall_times of BAHelpers::Bundle (ba_helpers.cc:749-753): setup = index build + H2D,
+     run = the LM loop (what ceres::Solve covers), teardown = D2H of parameters and errors */
+  double seconds_setup, seconds_run, seconds_teardown;
 } osfm_ba_report;
 
 int osfm_ba_solve(osfm_ctx *ctx, osfm_ba_problem *problem, const osfm_ba_options *options,

@@ -126,10 +126,11 @@ def bundle_arrays(problem: Dict[str, np.ndarray], config: Optional[Dict[str, Any
         "pcg_iterations": int(R.pcg_iterations_total),
         "shot_bandwidth": int(R.shot_bandwidth), "preconditioner_bandwidth": int(R.preconditioner_bandwidth),
         "seconds_solver": R.seconds_total, "seconds_linear_solver": R.seconds_linear_solver,
+        "seconds_setup": R.seconds_setup, "seconds_run": R.seconds_run, "seconds_teardown": R.seconds_teardown,
         "ms_per_matvec": (R.ms_matvec_total / R.matvec_calls) if R.matvec_calls else None,
         # report dict of BAHelpers::Bundle (ba_helpers.cc:743-762)
         "brief_report": brief,
-        "wall_times": {"setup": t1 - t0, "run": t2 - t1, "teardown": 0.0},
+        "wall_times": {"setup": (t1 - t0) + R.seconds_setup, "run": R.seconds_run, "teardown": R.seconds_teardown},
         "num_images": len(poses), "num_points": len(pts), "num_reprojections": len(obs_shot),
     }
 

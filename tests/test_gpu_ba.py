@@ -168,3 +168,16 @@ def test_wide_bandwidth_falls_back_or_truncates(oracle_lib, gpu_ctx):
     o = oracle_lib.ba_solve(pr, max_iterations=8, **NO_TOL)
     assert g["shot_bandwidth"] > 15
     assert np.allclose(g["cost_history"], o["cost_history"], rtol=1e-7)
+
+
+def test_long_tracks_take_the_strided_matvec_path(oracle_lib, gpu_ctx):
+    """Tracks longer than the cooperative mat-vec tile (128 observations) use the strided
+    workgroup path; the shot band is far wider than the preconditioner can hold."""
+    from opensfm_amd import bundle
+
+    pr = synthetic.make_ba_scene(170, 120, 150, seed=15, outlier_frac=0.0)
+    g = bundle.bundle_arrays(pr, {"bundle_max_iterations": 6}, **NO_TOL)
+    o = oracle_lib.ba_solve(pr, max_iterations=6, **NO_TOL)
+    assert g["shot_bandwidth"] > 128
+    assert np.allclose(g["cost_history"], o["cost_history"], rtol=1e-7)
+    assert abs(_rmse_px(g["reproj_err"]) - _rmse_px(o["reproj_err"])) < 1e-4

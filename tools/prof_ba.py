@@ -10,4 +10,4 @@ iters = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 pr = synthetic.make_ba_scene(shots, pts, track, seed=42)
 no_tol = dict(function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
 g = bundle.bundle_arrays(pr, {"bundle_max_iterations": iters}, **no_tol)
-print(g["brief_report"]); print("solver s", g["seconds_solver"], "lin", g["seconds_linear_solver"], "ms/matvec", g["ms_per_matvec"], "bw", g["preconditioner_bandwidth"])
+print(g["brief_report"]); print("setup", g["seconds_setup"], "run", g["seconds_run"], "teardown", g["seconds_teardown"]); print("solver s", g["seconds_solver"], "lin", g["seconds_linear_solver"], "ms/matvec", g["ms_per_matvec"], "bw", g["preconditioner_bandwidth"])
