@@ -30,10 +30,16 @@ def run(ctx, shots: int = 5000, points: int = 500000, track: int = 10, iters: in
     out = {
         "metric": "BA LM-iters/sec",
         "workload": f"{shots} cams / {points} pts / {nobs} obs, SoftLOne(1), shared perspective camera + priors, GPS priors",
-        "value": round(g["iterations"] / g["seconds_solver"], 3),
+        # LM iterations per second of the solve proper (what ceres::Solve covers: initial evaluation +
+        # the LM loop); index build + H2D ("setup") and D2H ("teardown") are reported beside it, as the
+        # reference reports wall_times.setup / run / teardown (ba_helpers.cc:749-753)
+        "value": round(g["iterations"] / g["seconds_run"], 3),
         "unit": "LM-iters/s",
         "lm_iterations": int(g["iterations"]),
-        "solver_seconds": round(g["seconds_solver"], 3),
+        "run_seconds": round(g["seconds_run"], 4),
+        "setup_seconds": round(g["seconds_setup"], 4),
+        "teardown_seconds": round(g["seconds_teardown"], 4),
+        "whole_call_lm_iters_per_s": round(g["iterations"] / g["seconds_solver"], 3),
         "linear_solver_seconds": round(g["seconds_linear_solver"], 3),
         "call_seconds_incl_h2d": round(wall, 3),
         "pcg_iterations": int(g["pcg_iterations"]),
@@ -42,7 +48,7 @@ def run(ctx, shots: int = 5000, points: int = 500000, track: int = 10, iters: in
         "dtype": "f64",
         "roofline": {
             "bound": "hbm",
-            "kernel": "schur mat-vec (schur_point_kernel<0> + schur_shot_kernel)",
+            "kernel": "schur mat-vec (schur_point_coop_kernel<0> + schur_shot_kernel)",
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
