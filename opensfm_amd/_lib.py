@@ -10,7 +10,7 @@ import threading
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libosfm_mi355.so")
+LIB_PATH = os.environ.get("OSFM_MI355_LIB") or os.path.join(_HERE, "csrc", "libosfm_mi355.so")  # env: instrumented builds
 
 
 class OsfmError(RuntimeError):

@@ -79,7 +79,7 @@ struct MatchArgs {
 // after the ratio test (or kNone).  Emits (c, r) sorted by c.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void emit_matches(const MatchArgs &a, long p, int nC, const int *colBI,
-                                             const unsigned short *rowres, int *misc, int tid) {
+                                             const unsigned short *rowres, int *misc, int tid, int stride = 1) {
   const int lane = tid & 63, w = tid >> 6;
   int base = 0;
   for (int j0 = 0; j0 < nC; j0 += kThreads) {
@@ -87,7 +87,7 @@ __device__ __forceinline__ void emit_matches(const MatchArgs &a, long p, int nC,
     bool m = false;
     int r = kNone;
     if (j < nC) {
-      r = colBI[j];
+      r = colBI[j * stride];
       m = (r != kNone) && (!a.symmetric || rowres[r] == j);
     }
     const unsigned long long bal = __ballot(m);
@@ -401,20 +401,46 @@ __device__ __forceinline__ int dot_rows(const int8_t *tilesA, int rowA, const in
   return sdot;
 }
 
+// same, all 16 loads issued before the first use: one memory latency per candidate instead of four
+__device__ __forceinline__ int dot_rows8(const int8_t *tilesA, int rowA, const int8_t *tilesB, int rowB) {
+  const int8_t *pa = tilesA + (long)(rowA >> 5) * OSFM_TILE_BYTES + (rowA & 31) * 16;
+  const int8_t *pb = tilesB + (long)(rowB >> 5) * OSFM_TILE_BYTES + (rowB & 31) * 16;
+  v4i av[8], bv[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    av[q] = *(const v4i *)(pa + q * 512);
+    bv[q] = *(const v4i *)(pb + q * 512);
+  }
+  int s0 = 0, s1 = 0;
+#pragma unroll
+  for (int q = 0; q < 8; q += 2)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      s0 = __builtin_amdgcn_sdot4(av[q][e], bv[q][e], s0, false);
+      s1 = __builtin_amdgcn_sdot4(av[q + 1][e], bv[q + 1][e], s1, false);
+    }
+  return s0 + s1;
+}
+
 __device__ __forceinline__ int wave_max(int v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m));
   return v;
 }
 
+#ifdef OSFM_PHASE_TIMING
+__device__ unsigned long long g_phase[8];
+#endif
 __global__ void __launch_bounds__(kThreads, 2) match_fused2_kernel(MatchArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char *bbuf = smem;                                      // [2][16 KiB]
-  int2 *scratch = (int2 *)(smem + 2 * kChunkBytes);                // [2][4][128]
-  int *colBV = (int *)(smem + 2 * kChunkBytes + 2 * kWaves * kChunkCols * 8);
-  int *colSV = colBV + a.ncap;
-  int *colBI = colSV + a.ncap;
-  unsigned short *rowres = (unsigned short *)(colBI + a.ncap);
+  // column state: colB[j] = (best key : 32 | 4095 - class : 32), class = row block * 4 + wave, updated by
+  // 64-bit LDS atomic max straight from the wave that produced a partial (order independent);
+  // colSV[j] = second-largest class best = max over all "losers" of those updates
+  long long *colB = (long long *)(smem + 2 * kChunkBytes);
+  int *colP = (int *)colB;  // after the main loop: colP[2j] = best row (or kNone), colP[2j+1] = best value
+  int *colSV = (int *)(colB + a.ncap);
+  unsigned short *rowres = (unsigned short *)(colSV + a.ncap);
   unsigned short *clist = rowres + a.ncap;
   int *misc = (int *)(clist + a.ncap);  // [16]
   int *req = misc + 16;                 // [4 waves][64 rows][3]
@@ -441,9 +467,8 @@ __global__ void __launch_bounds__(kThreads, 2) match_fused2_kernel(MatchArgs a) 
   const int32_t *normR = a.norms + a.tile_off[imgR] * 32;
 
   for (int j = tid; j < a.ncap; j += kThreads) {
-    colBV[j] = INT_MIN;
+    colB[j] = (long long)(INT_MIN >> 6) << 32;
     colSV[j] = INT_MIN;
-    colBI[j] = kNone;
     rowres[j] = kNone;
   }
   if (tid == 0) {
@@ -466,7 +491,14 @@ __global__ void __launch_bounds__(kThreads, 2) match_fused2_kernel(MatchArgs a) 
   if (tid < kChunkCols) nbuf[tid] = (tid < tC * 32) ? normC[tid] : OSFM_PAD_NORM;
   __syncthreads();
 
-  v4i afrag[kRT][4];
+#ifdef OSFM_PHASE_TIMING
+  long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = clock64(), tn;
+#define PH(i) { tn = clock64(); ph[i] += tn - tq; tq = tn; }
+#else
+#define PH(i)
+#endif
+  v4i afrag[kRT][4], anext[kRT][4];
+  int nrm = OSFM_PAD_NORM, nrm_next = OSFM_PAD_NORM;
   int Rk[kRT][16];
   int rbst[kRT][16];
   int flag = 0;
@@ -478,12 +510,12 @@ __global__ void __launch_bounds__(kThreads, 2) match_fused2_kernel(MatchArgs a) 
   for (int rb = 0; rb < nrb; ++rb) {
     const int rt0 = rb * (kWaves * kRT) + w * kRT;
     const int nrt = min(kRT, max(0, tR - rt0));
-    {
+    if (rb == 0) {
       // one coalesced load: lane l holds the norm of row rt0*32 + l (64 rows of this wave)
-      int nrm = OSFM_PAD_NORM;
+      nrm = OSFM_PAD_NORM;
       if (lane < nrt * 32) nrm = normR[rt0 * 32 + lane];
 #pragma unroll
-      for (int rt = 0; rt < kRT; ++rt) {
+      for (int rt = 0; rt < kRT; ++rt)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           v4i z = {0, 0, 0, 0};
@@ -491,14 +523,22 @@ __global__ void __launch_bounds__(kThreads, 2) match_fused2_kernel(MatchArgs a) 
           if (rt < nrt)
             afrag[rt][ks] = *(const v4i *)(tilesR + (long)(rt0 + rt) * OSFM_TILE_BYTES + ks * 1024 + lane * 16);
         }
+    } else {  // prefetched during the previous row block's merge
+      nrm = nrm_next;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rowintile = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          const int il = rt * 32 + rowintile;
-          const int na = __shfl(nrm, il);
-          Rk[rt][r] = -(na << 6) + (63 - il);
-          rbst[rt][r] = INT_MIN;
-        }
+      for (int rt = 0; rt < kRT; ++rt)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) afrag[rt][ks] = anext[rt][ks];
+    }
+#pragma unroll
+    for (int rt = 0; rt < kRT; ++rt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rowintile = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int il = rt * 32 + rowintile;
+        const int na = __shfl(nrm, il);
+        Rk[rt][r] = -(na << 6) + (63 - il);
+        rbst[rt][r] = INT_MIN;
       }
     }
     // make hipcc wait for the A operands HERE (nothing else is in flight) instead of in front of the
@@ -507,11 +547,17 @@ __global__ void __launch_bounds__(kThreads, 2) match_fused2_kernel(MatchArgs a) 
     for (int rt = 0; rt < kRT; ++rt)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(afrag[rt][ks]));
+    PH(0)
     for (int c = 0; c < nchunks; ++c) {
     const int s = rb * nchunks + c;
     const bool has_next = (s + 1 < nsteps);
     const int cn = (c + 1 == nchunks) ? 0 : c + 1;
-    if (has_next) {
+    // Order matters for hipcc's waitcnt insertion: every ds_write issued while an LDS DMA is in
+    // flight gets an s_waitcnt vmcnt(0) in front of it (WAW on LDS cannot be disproved), which would
+    // expose the whole DMA latency in the middle of the step.  So the step's own LDS updates (column
+    // partials) are kept until just before the closing barrier, where the DMA has to be complete.
+    PH(1)
+    if (has_next && !(a.debug_no_recheck & 8)) {
       // next chunk of the column image: global -> LDS DMA (no staging registers, no ds_write);
       // the LDS image is lane-linear, exactly the order the lanes ask for.  hipcc drains it
       // (vmcnt(0)) in front of the __syncthreads() that closes this step.
@@ -530,39 +576,16 @@ __global__ void __launch_bounds__(kThreads, 2) match_fused2_kernel(MatchArgs a) 
                                          (__attribute__((address_space(3))) void *)(nbuf + ((s + 1) & 1) * kChunkCols + w * 64), 4, 0, 0);
       }
     }
-    // fold the previous step's per-wave column partials (best, second-largest class best)
-    if (s > 0 && tid < kChunkCols) {
-      const int sp = s - 1;
-      const int cp = (c == 0) ? nchunks - 1 : c - 1;
-      const int rbp = (c == 0) ? rb - 1 : rb;
-      const int j = cp * kChunkCols + tid;
-      int bv = colBV[j], sv = colSV[j], bi = colBI[j];
-#pragma unroll
-      for (int w2 = 0; w2 < kWaves; ++w2) {
-        const int2 pp = scratch[((sp & 1) * kWaves + w2) * kChunkCols + tid];
-        if (pp.x != INT_MIN) {
-          const int pv = pp.x >> 6;
-          const int pi = rbp * kRowsPerWG + w2 * (kRT * 32) + (63 - (pp.x & 63));
-          const int psv = pp.y >> 6;
-          sv = max(min(bv, pv), max(sv, psv));
-          if (pv > bv) {
-            bv = pv;
-            bi = pi;
-          }
-        }
-      }
-      colBV[j] = bv;
-      colSV[j] = sv;
-      colBI[j] = bi;
-    }
+    PH(2)
     // ---- compute: column tiles in pairs so that v_max3 takes two new keys per op ----
     const unsigned char *bb = bbuf + (s & 1) * kChunkBytes;
+    int2 parts[kCT];
 #pragma unroll
     for (int cp2 = 0; cp2 < kCT / 2; ++cp2) {
       const int ct0 = 2 * cp2, ct1 = 2 * cp2 + 1;
       const int g0 = c * kCT + ct0, g1 = g0 + 1;
       int2 part0 = make_int2(INT_MIN, INT_MIN), part1 = make_int2(INT_MIN, INT_MIN);
-      if (g0 < tC && nrt > 0) {
+      if (g0 < tC && nrt > 0 && !(a.debug_no_recheck & 16)) {
         const bool v1ok = g1 < tC;
         v4i bf0[4], bf1[4];
 #pragma unroll
@@ -609,24 +632,57 @@ __global__ void __launch_bounds__(kThreads, 2) match_fused2_kernel(MatchArgs a) 
           part1.y = min(cb1, ob1);
         }
       }
-      if (lane < 32) {
-        scratch[((s & 1) * kWaves + w) * kChunkCols + ct0 * 32 + lane] = part0;
-        scratch[((s & 1) * kWaves + w) * kChunkCols + ct1 * 32 + lane] = part1;
+      parts[ct0] = part0;
+      parts[ct1] = part1;
+    }
+    PH(3)
+    if (lane < 32 && nrt > 0 && !(a.debug_no_recheck & 32)) {
+      const unsigned clsinv = 4095u - (unsigned)(rb * kWaves + w);
+#pragma unroll
+      for (int q = 0; q < kCT; ++q) {
+        if (c * kCT + q < tC) {
+          const int j = (c * kCT + q) * 32 + lane;
+          // order: value, then lowest class (64-row block), then lowest row inside it = lowest row index
+          const long long mine = ((long long)(parts[q].x >> 6) << 32) | (long long)((clsinv << 6) | (unsigned)(parts[q].x & 63));
+          const long long old = __hip_atomic_fetch_max(&colB[j], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          const int loser = (int)((old < mine ? old : mine) >> 32);
+          __hip_atomic_fetch_max(&colSV[j], max(loser, parts[q].y >> 6), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
       }
     }
+    PH(4)
+    PH(5)
+    if (!(a.debug_no_recheck & 4)) __syncthreads();
+    PH(6)
     // ---- end of a row block: merge the 32 column classes of every row ----
     // Transposed through LDS instead of 32 cross-lane butterflies: each lane drops its class-bests
-    // into a [row][class] image (the chunk buffer this step just finished reading, hence the extra
-    // barrier, once per row block), then lane (row, half of the classes) scans 16 ints.
-    if (c == nchunks - 1) {
-      int *myreq = req + w * 192;
-      __syncthreads();
-      int *tr = (int *)(bbuf + (s & 1) * kChunkBytes) + w * 1024;  // 4 KiB per wave
+    // into a [row][class] image, then lane (row, half of the classes) scans 16 ints.  The image lives
+    // in the chunk buffer this step just finished with (nobody reads it after the barrier above), in
+    // the four 1 KiB slices that only this wave's OWN next DMA overwrites: no extra barrier.
+    if (c == nchunks - 1 && !(a.debug_no_recheck & 64)) {
+      // next row block's A operands + norms: issued here so that their latency hides behind the merge
+      if (rb + 1 < nrb) {
+        const int rt0n = rt0 + kWaves * kRT;
+        const int nrtn = min(kRT, max(0, tR - rt0n));
+        nrm_next = OSFM_PAD_NORM;
+        if (lane < nrtn * 32) nrm_next = normR[rt0n * 32 + lane];
+#pragma unroll
+        for (int rt = 0; rt < kRT; ++rt)
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            v4i z = {0, 0, 0, 0};
+            anext[rt][ks] = z;
+            if (rt < nrtn)
+              anext[rt][ks] = *(const v4i *)(tilesR + (long)(rt0n + rt) * OSFM_TILE_BYTES + ks * 1024 + lane * 16);
+          }
+      }
+      unsigned char *trb = bbuf + (s & 1) * kChunkBytes + w * 1024;
 #pragma unroll
       for (int rt = 0; rt < kRT; ++rt) {
         if (rt < nrt) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) tr[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = rbst[rt][r];
+          for (int r = 0; r < 16; ++r)  // row = (r&3) + 8*(r>>2) + 4*half: slice r>>2, line (r&3) + 4*half
+            *(int *)(trb + (r >> 2) * OSFM_TILE_BYTES + ((r & 3) + 4 * (lane >> 5)) * 128 + (lane & 31) * 4) = rbst[rt][r];
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -634,7 +690,7 @@ __global__ void __launch_bounds__(kThreads, 2) match_fused2_kernel(MatchArgs a) 
           int bkey = INT_MIN, bcls = 0, skey = INT_MIN;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const int4 v4 = *(const int4 *)(tr + row32 * 32 + hc * 16 + q * 4);
+            const int4 v4 = *(const int4 *)(trb + (row32 >> 3) * OSFM_TILE_BYTES + (row32 & 7) * 128 + hc * 64 + q * 16);
             const int vv[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -654,82 +710,57 @@ __global__ void __launch_bounds__(kThreads, 2) match_fused2_kernel(MatchArgs a) 
           }
           const int il = rt * 32 + row32;
           const int row = (rt0 + rt) * 32 + row32;
-          if (hc == 0) {
-            int rq = -1;
-            const int bv = bkey >> 7, bj = (127 - (bkey & 127)) * 32 + bcls, sv = skey >> 7;
-            if (row < nR) {
-              const int na = normR[row];
-              const int d1 = na - bv, d2 = na - sv;
-              if (d2 >= kCollisionD2) flag = 1;
-              if (ratio_ok(d1, d2, a.ratio)) rq = bj;  // passes against the class bound: re-examine
-              else rowres[row] = kNone;
+          const int na = __shfl(nrm, il);
+          const int bv = bkey >> 7, bj = (127 - (bkey & 127)) * 32 + bcls, sv = skey >> 7;
+          bool want = false;
+          if (hc == 0 && row < nR) {
+            const int d1 = na - bv, d2 = na - sv;
+            if (d2 >= kCollisionD2) flag = 1;
+            want = ratio_ok(d1, d2, a.ratio);  // passes against the class bound: re-examine
+            if (!want) rowres[row] = kNone;
+          }
+          // the rows that passed: exact second inside the winner's class = columns {t*32 + (bj&31)}
+          unsigned long long pending = (a.debug_no_recheck & 1) ? 0ull : __ballot(want);
+          while (pending) {
+            const int src = __builtin_ctzll(pending);
+            pending &= pending - 1;
+            const int qbj = __shfl(bj, src), qbv = __shfl(bv, src), qsv = __shfl(sv, src), qna = __shfl(na, src);
+            const int qrow = (rt0 + rt) * 32 + (src >> 1);
+            int mx = INT_MIN;
+            for (int t0 = 0; t0 < tC; t0 += 64) {
+              const int t = t0 + lane;
+              const int j = t * 32 + (qbj & 31);
+              if (t < tC && j != qbj) mx = max(mx, 2 * dot_rows8(tilesR, qrow, tilesC, j) - normC[j]);
             }
-            myreq[il * 3] = rq;
-            myreq[il * 3 + 1] = bv;
-            myreq[il * 3 + 2] = sv;
+            mx = wave_max(mx);
+            if (lane == 0) {
+              const int s2 = max(qsv, mx);
+              rowres[qrow] = ratio_ok(qna - qbv, qna - s2, a.ratio) ? qbj : kNone;
+            }
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        } else {
-          if (lane < 32) myreq[(rt * 32 + lane) * 3] = -1;
-        }
-      }
-      // 3) exact second for the rows that passed: the winner's class = columns {t*32 + (bj&31)}
-      for (int il = 0; il < kRT * 32; ++il) {
-        const int bj = __builtin_amdgcn_readfirstlane(myreq[il * 3]);
-        if (bj < 0 || a.debug_no_recheck) continue;
-        const int bv = __builtin_amdgcn_readfirstlane(myreq[il * 3 + 1]);
-        const int sv = __builtin_amdgcn_readfirstlane(myreq[il * 3 + 2]);
-        const int row = rt0 * 32 + il;
-        int mx = INT_MIN;
-        for (int t0 = 0; t0 < tC; t0 += 64) {
-          const int t = t0 + lane;
-          const int j = t * 32 + (bj & 31);
-          if (t < tC && j != bj) mx = max(mx, 2 * dot_rows(tilesR, row, tilesC, j) - normC[j]);
-        }
-        mx = wave_max(mx);
-        if (lane == 0) {
-          const int na = normR[row];
-          const int s2 = max(sv, mx);
-          rowres[row] = ratio_ok(na - bv, na - s2, a.ratio) ? bj : kNone;
         }
       }
     }
-    __syncthreads();
     }  // chunks
   }    // row blocks
-  if (tid < kChunkCols) {
-    const int sp = nsteps - 1;
-    const int j = (nchunks - 1) * kChunkCols + tid;
-    int bv = colBV[j], sv = colSV[j], bi = colBI[j];
-#pragma unroll
-    for (int w2 = 0; w2 < kWaves; ++w2) {
-      const int2 pp = scratch[((sp & 1) * kWaves + w2) * kChunkCols + tid];
-      if (pp.x != INT_MIN) {
-        const int pv = pp.x >> 6;
-        const int pi = (nrb - 1) * kRowsPerWG + w2 * (kRT * 32) + (63 - (pp.x & 63));
-        const int psv = pp.y >> 6;
-        sv = max(min(bv, pv), max(sv, psv));
-        if (pv > bv) {
-          bv = pv;
-          bi = pi;
-        }
-      }
-    }
-    colBV[j] = bv;
-    colSV[j] = sv;
-    colBI[j] = bi;
-  }
   __syncthreads();
-  // ---- column side: ratio test against the class bound, list the survivors ----
+  if (a.debug_no_recheck & 128) return;
+  // ---- column side: decode the best, ratio test against the class bound, list the survivors ----
   for (int j = tid; j < nC; j += kThreads) {
+    const long long cbst = colB[j];
+    const unsigned lo = (unsigned)(cbst & 0xFFFFFFFFll);
+    const int bv = (int)(cbst >> 32), bi = (4095 - (int)(lo >> 6)) * 64 + (63 - (int)(lo & 63));
     const int nb = normC[j];
-    const int d1 = nb - colBV[j], d2 = nb - colSV[j];
+    const int d1 = nb - bv, d2 = nb - colSV[j];
     if (d2 >= kCollisionD2) flag = 1;
+    colP[2 * j + 1] = bv;
     if (!ratio_ok(d1, d2, a.ratio)) {
-      colBI[j] = kNone;
+      colP[2 * j] = kNone;
     } else {
+      colP[2 * j] = bi;
       const int k = atomicAdd(&misc[9], 1);
       clist[k] = (unsigned short)j;
     }
@@ -738,27 +769,33 @@ __global__ void __launch_bounds__(kThreads, 2) match_fused2_kernel(MatchArgs a) 
   __syncthreads();
   // ---- exact second for the surviving columns: the winner's class = the 32 rows one lane saw ----
   {
-    const int nlist = a.debug_no_recheck ? 0 : misc[9];
+    const int nlist = (a.debug_no_recheck & 1) ? 0 : misc[9];
     for (int e = w; e < nlist; e += kWaves) {
       const int j = clist[e];
-      const int bi = colBI[j];
+      const int bi = colP[2 * j];
       const int base = (bi >> 6) << 6;                  // row block + wave: rb*256 + w*64
       const int h = ((bi & 31) >> 2) & 1;               // half-wave of the winning lane
       const int rtq = lane >> 4, rq = lane & 15;
       const int row = base + rtq * 32 + (rq & 3) + 8 * (rq >> 2) + 4 * h;
       int v = INT_MIN;
-      if (lane < 32 && row < tR * 32 && row != bi) v = 2 * dot_rows(tilesR, row, tilesC, j) - normR[row];
+      if (lane < 32 && row < tR * 32 && row != bi) v = 2 * dot_rows8(tilesR, row, tilesC, j) - normR[row];
       v = wave_max(v);
       if (lane == 0) {
         const int nb = normC[j];
         const int s2 = max(colSV[j], v);
-        if (!ratio_ok(nb - colBV[j], nb - s2, a.ratio)) colBI[j] = kNone;
+        if (!ratio_ok(nb - colP[2 * j + 1], nb - s2, a.ratio)) colP[2 * j] = kNone;
       }
     }
   }
   __syncthreads();
   if (tid == 0) a.out_flags[p] = misc[8];
-  emit_matches(a, p, nC, colBI, rowres, misc, tid);
+  emit_matches(a, p, nC, colP, rowres, misc, tid, 2);
+#ifdef OSFM_PHASE_TIMING
+  PH(7)
+  if (lane == 0)
+    for (int i = 0; i < 8; i++) atomicAdd(&g_phase[i], (unsigned long long)ph[i]);
+#endif
+#undef PH
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -844,7 +881,7 @@ size_t osfm_match_lds_bytes(int ncap) {
   return (size_t)2 * kChunkBytes + 2 * kWaves * kChunkCols * 8 + (size_t)ncap * 14 + 64;
 }
 size_t osfm_match2_lds_bytes(int ncap) {
-  return (size_t)2 * kChunkBytes + 2 * kWaves * kChunkCols * 8 + (size_t)ncap * 16 + 64 + kWaves * 192 * 4 + 2 * kChunkCols * 4;
+  return (size_t)2 * kChunkBytes + (size_t)ncap * 16 + 64 + kWaves * 192 * 4 + 2 * kChunkCols * 4;
 }
 static int match_kernel_version() {
   static int v = -1;
@@ -874,7 +911,7 @@ int osfm_launch_match(osfm_ctx *ctx, const osfm_store *store, const int32_t *d_p
   a.out_counts = d_counts;
   a.out_matches = d_matches;
   a.out_flags = d_flags;
-  a.debug_no_recheck = getenv("OSFM_DEBUG_NO_RECHECK") != nullptr;
+  a.debug_no_recheck = getenv("OSFM_DEBUG_NO_RECHECK") ? atoi(getenv("OSFM_DEBUG_NO_RECHECK")) : 0;  // bit0 rechecks, bit2 step barrier, bit3 chunk DMA, bit4 compute
   a.pad_norm = store->d_norms + store->tile_off[store->n_images] * 32;  // first slack row: padding norm
   OSFM_REQUIRE(a.ncap <= OSFM_MAX_FEATURES, OSFM_E_UNSUPPORTED, "more than %d features in an image", OSFM_MAX_FEATURES);
   OSFM_REQUIRE(n_pairs < (1ll << 31), OSFM_E_INVALID, "too many pairs in one launch");
@@ -896,6 +933,20 @@ int osfm_launch_match(osfm_ctx *ctx, const osfm_store *store, const int32_t *d_p
     hipLaunchKernelGGL(match_exact_kernel, dim3((unsigned)n_pairs), dim3(kThreads), lds, ctx->stream, a,
                        d_flags != nullptr ? 1 : 0);
   }
+#ifdef OSFM_PHASE_TIMING
+  if (!exact_kernel && match_kernel_version() == 2) {
+    OSFM_HIP(hipStreamSynchronize(ctx->stream));
+    unsigned long long h[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    OSFM_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof(h)));
+    OSFM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)));
+    const char *nm[8] = {"rowblock prologue (A operands, norms)", "fold of column partials", "chunk DMA issue", "compute (B frag reads, MFMA, epilogue)",
+                         "column partials -> LDS (drains the DMA)", "row-block merge + row rechecks", "step barrier", "tail (column tests, rechecks, emit)"};
+    unsigned long long tot = 0;
+    for (int i = 0; i < 8; i++) tot += h[i];
+    for (int i = 0; i < 8; i++)
+      fprintf(stderr, "[phase] %-48s %8.3f M wave-ticks  %5.1f %%\n", nm[i], h[i] * 1e-6, 100.0 * h[i] / (double)tot);
+  }
+#endif
   OSFM_HIP(hipGetLastError());
   return OSFM_OK;
 }

@@ -1,0 +1,91 @@
+// Microbenchmark: do int8 MFMAs and integer VALU ops of the SAME or of DIFFERENT wavefronts overlap
+// on a gfx950 SIMD?  Each workgroup = 256 threads (one wave per SIMD); blocks-per-CU 1 or 2.
+//   mode 0: MFMA only (4 x 32x32x32 i8 per iteration, two independent accumulators)
+//   mode 1: VALU only (V x {v_lshl_add_u32, v_max3_i32} per iteration, 8 independent chains)
+//   mode 2: both in the same wave
+//   mode 3: even waves (by block) MFMA only, odd blocks VALU only  (needs 2 blocks / CU)
+// build: hipcc --offload-arch=gfx950 -O3 -Wno-unused-result tools/ubench_overlap.hip -o tools/ubench_overlap
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+template <int MODE, int V>
+__global__ void __launch_bounds__(256, 2) k(int *out, int iters, int seed) {
+  v4i a = {seed, seed + 1, seed + 2, seed + 3}, b = {seed * 3, seed * 5, seed * 7, seed * 9};
+  v16i acc0 = {0}, acc1 = {0};
+  int x[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) x[i] = threadIdx.x * (i + 1) + seed;
+  int c0 = seed * 11, c1 = seed * 13;
+  const bool do_m = MODE == 0 || MODE == 2 || (MODE == 3 && (blockIdx.x & 1) == 0);
+  const bool do_v = MODE == 1 || MODE == 2 || (MODE == 3 && (blockIdx.x & 1) == 1);
+  for (int it = 0; it < iters; it++) {
+    if (do_m) {
+      acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(b, a, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(b, a, acc1, 0, 0, 0);
+    }
+    if (do_v) {
+#pragma unroll
+      for (int q = 0; q < V / 16; q++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          int t;
+          asm volatile("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(t) : "v"(x[i]), "v"(c0));
+          asm volatile("v_max3_i32 %0, %1, %2, %3" : "=v"(x[i]) : "v"(x[i]), "v"(t), "v"(c1));
+        }
+      }
+    }
+  }
+  int r = 0;
+#pragma unroll
+  for (int i = 0; i < 16; i++) r += acc0[i] + acc1[i];
+#pragma unroll
+  for (int i = 0; i < 8; i++) r += x[i];
+  if (r == 0x12345678) out[threadIdx.x] = r;
+}
+
+template <int MODE, int V>
+float run(int blocks, int iters) {
+  int *d;
+  hipMalloc(&d, 4096);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  hipLaunchKernelGGL((k<MODE, V>), dim3(blocks), dim3(256), 0, 0, d, iters / 10, 3);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  hipLaunchKernelGGL((k<MODE, V>), dim3(blocks), dim3(256), 0, 0, d, iters, 3);
+  hipEventRecord(e1);
+  hipDeviceSynchronize();
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  hipFree(d);
+  return ms;
+}
+
+int main() {
+  hipDeviceProp_t p;
+  hipGetDeviceProperties(&p, 0);
+  const int cus = p.multiProcessorCount;
+  const int iters = 200000;
+  printf("CUs %d, clock %d kHz\n", cus, p.clockRate);
+  for (int bpc = 1; bpc <= 2; bpc++) {
+    const int blocks = cus * bpc;
+    const float m = run<0, 48>(blocks, iters), v48 = run<1, 48>(blocks, iters), v96 = run<1, 96>(blocks, iters);
+    const float b48 = run<2, 48>(blocks, iters), b96 = run<2, 96>(blocks, iters);
+    printf("waves/SIMD %d: MFMA-only %.2f ms | VALU48 %.2f | VALU96 %.2f | same-wave MFMA+VALU48 %.2f | +VALU96 %.2f\n", bpc, m, v48,
+           v96, b48, b96);
+    const double cyc = 1e-3 * p.clockRate * 1e3 / iters;  // cycles per ms per iteration
+    printf("   cycles/iter/wave-slot: MFMA(4) %.0f  VALU48 %.0f  VALU96 %.0f  both48 %.0f  both96 %.0f\n", m * cyc / bpc * bpc, v48 * cyc,
+           v96 * cyc, b48 * cyc, b96 * cyc);
+  }
+  {
+    const float x48 = run<3, 48>(cus * 2, iters), x96 = run<3, 96>(cus * 2, iters);
+    printf("2 waves/SIMD, one MFMA-only + one VALU-only: VALU48 %.2f ms, VALU96 %.2f ms\n", x48, x96);
+  }
+  return 0;
+}
