@@ -123,7 +123,7 @@ def main():
     achieved = flop_pair * pairs_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
     roofline = {
         "bound": "mfma",
-        "kernel": "match_fused2_kernel",
+        "kernel": "match_fused4_kernel",
         "achieved": round(achieved, 2),
         "peak": PEAK_I8_TOPS,
         "unit": "TFLOP/s",

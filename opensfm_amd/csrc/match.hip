@@ -799,6 +799,359 @@ __global__ void __launch_bounds__(kThreads, 2) match_fused2_kernel(MatchArgs a) 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Fused MFMA kernel, version 4: "one direction at a time".
+//
+// Measured on MI355X (tools/prof_match.py + compile-time variants of v2): the kernel time is
+//   skeleton (chunk DMA, barriers, LDS operand reads, column atomics, merges)  +  VALU epilogue  +
+//   MFMA time, and the three do NOT overlap: removing the MFMAs or removing the epilogue saves the
+//   same ~5 ms out of 15.6 (19 900 pairs of 2000x2000), removing both leaves 5.1 ms.
+// The MFMA part is at its floor, so v4 removes VALU and skeleton work instead: the distance matrix
+// is only reduced along ONE direction per pass (1.5 VALU ops per element instead of 3, no column
+// partials, no LDS atomics):
+//   pass A: rows = image A in registers, image B streamed; resA[a] = best b if it passes the ratio
+//           test (class bests + lazy exact second, exactly as v2's row direction);
+//   pass B: (symmetric matching only) the mutual check needs "best a for b" only for the b that some
+//           row chose: those candidates (typically a small subset of image B) become the rows of a
+//           second, much smaller pass against the streamed image A;
+//   a pair (a, b) is emitted iff resA[a] == b and resB[b] == a.
+// For symmetric matching A is the pair's SECOND image, so that the image streamed by the big pass
+// is the first one, which the ~64 pairs in flight on an XCD share in L2 (xcd_remap).
+// Results are bit-identical to v1/v2/the exact kernel/the oracle.
+// ---------------------------------------------------------------------------------------------
+struct RowPassShared {
+  unsigned char *bbuf;  // [2][16 KiB] chunk double buffer
+  int *nbuf;            // [2][128] norms of the staged chunk
+  const int32_t *pad_norm;
+};
+
+// rows: slot q in [0, nslots) is feature rowsel[q] of image X (rowsel == nullptr: identity).
+// out[feature of X] = best feature of Y (ratio test passed) or kNone.  Returns the collision flag.
+template <bool GATHER>
+__device__ __forceinline__ int row_pass(const RowPassShared &sh, const int8_t *tilesX, const int32_t *normX, int nX, int nslots,
+                                        const unsigned short *rowsel, const int8_t *tilesY, const int32_t *normY, int nY,
+                                        unsigned short *out, double ratio, int debug, int tid) {
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tY = (nY + 31) >> 5;
+  const int tS = (nslots + 31) >> 5;  // row tiles (slots)
+  const int nchunks = (tY + kCT - 1) / kCT;
+  const int nrb = (tS + kWaves * kRT - 1) / (kWaves * kRT);
+  const int nsteps = nrb * nchunks;
+  unsigned char *bbuf = sh.bbuf;
+  int *nbuf = sh.nbuf;
+  int flag = 0;
+
+  // first chunk of Y: global -> registers -> LDS
+  {
+    uint4 pre[kCT];
+#pragma unroll
+    for (int q = 0; q < kCT; ++q) {
+      pre[q] = make_uint4(0, 0, 0, 0);
+      if (q < tY) pre[q] = *(const uint4 *)(tilesY + (long)q * OSFM_TILE_BYTES + tid * 16);
+    }
+#pragma unroll
+    for (int q = 0; q < kCT; ++q) *(uint4 *)(bbuf + q * OSFM_TILE_BYTES + tid * 16) = pre[q];
+    if (tid < kChunkCols) nbuf[tid] = (tid < tY * 32) ? normY[tid] : OSFM_PAD_NORM;
+  }
+  __syncthreads();
+
+  v4i afrag[kRT][4], anext[kRT][4];
+  int nrm = OSFM_PAD_NORM, nrm_next = OSFM_PAD_NORM;
+  int xrow = 0, xrow_next = 0;  // feature index of the row slot this lane describes (lane = slot - rt0*32)
+  int rbst[kRT][16];
+
+  // A operands (+ norm, + feature index) of the 64 row slots of this wave in row block rb
+  auto load_rows = [&](int rb, v4i (&af)[kRT][4], int &nr, int &xr) {
+    const int slot0 = (rb * (kWaves * kRT) + w * kRT) * 32;
+    {
+      const int q = slot0 + lane;
+      xr = (q < nslots) ? (GATHER ? (int)rowsel[q] : q) : -1;
+      nr = (xr >= 0 && xr < nX) ? normX[xr] : OSFM_PAD_NORM;
+    }
+#pragma unroll
+    for (int rt = 0; rt < kRT; ++rt) {
+      const int q = slot0 + rt * 32 + (lane & 31);
+      int f = (q < nslots) ? (GATHER ? (int)rowsel[q] : q) : -1;
+      if (!GATHER && q >= tS * 32) f = -1;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        v4i z = {0, 0, 0, 0};
+        af[rt][ks] = z;
+        // operand layout: lane = half*32 + row-in-tile holds bytes [ks*32 + half*16, +16) of that row
+        if (f >= 0) af[rt][ks] = *(const v4i *)(tilesX + (long)(f >> 5) * OSFM_TILE_BYTES + ks * 1024 + (lane >> 5) * 512 + (f & 31) * 16);
+      }
+    }
+  };
+
+  for (int rb = 0; rb < nrb; ++rb) {
+    const int rt0 = rb * (kWaves * kRT) + w * kRT;
+    const int nrt = min(kRT, max(0, tS - rt0));
+    if (rb == 0) {
+      load_rows(0, afrag, nrm, xrow);
+    } else {
+      nrm = nrm_next;
+      xrow = xrow_next;
+#pragma unroll
+      for (int rt = 0; rt < kRT; ++rt)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) afrag[rt][ks] = anext[rt][ks];
+    }
+#pragma unroll
+    for (int rt = 0; rt < kRT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rbst[rt][r] = INT_MIN;
+#pragma unroll
+    for (int rt = 0; rt < kRT; ++rt)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(afrag[rt][ks]));
+
+    for (int c = 0; c < nchunks; ++c) {
+      const int s = rb * nchunks + c;
+      const bool has_next = (s + 1 < nsteps);
+      const int cn = (c + 1 == nchunks) ? 0 : c + 1;
+      if (has_next) {
+        unsigned char *nb2 = bbuf + ((s + 1) & 1) * kChunkBytes;
+#pragma unroll
+        for (int q = 0; q < kCT; ++q) {
+          const int gt = cn * kCT + q;
+          const int8_t *src = tilesY + (long)(gt < tY ? gt : 0) * OSFM_TILE_BYTES + tid * 16;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                           (__attribute__((address_space(3))) void *)(nb2 + q * OSFM_TILE_BYTES + w * 1024), 16, 0, 0);
+        }
+        if (w < 2) {
+          const int jn = cn * kChunkCols + tid;
+          const int32_t *srcn = (jn < tY * 32) ? normY + jn : sh.pad_norm;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)srcn,
+                                           (__attribute__((address_space(3))) void *)(nbuf + ((s + 1) & 1) * kChunkCols + w * 64), 4, 0, 0);
+        }
+      }
+      // ---- compute: column tiles in pairs so that v_max3 takes two new keys per op ----
+      const unsigned char *bb = bbuf + (s & 1) * kChunkBytes;
+      if (nrt > 0) {
+#pragma unroll
+        for (int cp2 = 0; cp2 < kCT / 2; ++cp2) {
+          const int ct0 = 2 * cp2, ct1 = 2 * cp2 + 1;
+          const int g0 = c * kCT + ct0, g1 = g0 + 1;
+          if (g0 < tY) {
+            v4i bf0[4], bf1[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+              bf0[ks] = *(const v4i *)(bb + ct0 * OSFM_TILE_BYTES + ks * 1024 + lane * 16);
+              bf1[ks] = *(const v4i *)(bb + ct1 * OSFM_TILE_BYTES + ks * 1024 + lane * 16);
+            }
+            const int *nbs = nbuf + (s & 1) * kChunkCols;
+            const int nb0 = nbs[ct0 * 32 + (lane & 31)];
+            const int nb1 = nbs[ct1 * 32 + (lane & 31)];  // padding norm when the tile does not exist: can never win
+            const int ck0 = -(nb0 << 7) + (127 - g0);
+            const int ck1 = -(nb1 << 7) + (127 - (g1 & 127));
+#pragma unroll
+            for (int rt = 0; rt < kRT; ++rt) {
+              if (rt < nrt) {
+                v16i acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                v16i acc1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[rt][ks], bf0[ks], acc0, 0, 0, 0);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[rt][ks], bf1[ks], acc1, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                  const int k0 = (acc0[r] << 8) + ck0, k1 = (acc1[r] << 8) + ck1;
+                  rbst[rt][r] = max(max(rbst[rt][r], k0), k1);
+                }
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();
+      // ---- end of a row block: merge the 32 column classes of every row (see v2) ----
+      if (c == nchunks - 1) {
+        if (rb + 1 < nrb) load_rows(rb + 1, anext, nrm_next, xrow_next);
+        unsigned char *trb = bbuf + (s & 1) * kChunkBytes + w * 1024;
+#pragma unroll
+        for (int rt = 0; rt < kRT; ++rt) {
+          if (rt < nrt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              *(int *)(trb + (r >> 2) * OSFM_TILE_BYTES + ((r & 3) + 4 * (lane >> 5)) * 128 + (lane & 31) * 4) = rbst[rt][r];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int row32 = lane >> 1, hc = lane & 1;
+            int bkey = INT_MIN, bcls = 0, skey = INT_MIN;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int4 v4 = *(const int4 *)(trb + (row32 >> 3) * OSFM_TILE_BYTES + (row32 & 7) * 128 + hc * 64 + q * 16);
+              const int vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                skey = max(skey, min(bkey, vv[e]));
+                const bool up = vv[e] > bkey;  // strict: the lowest class keeps ties (lowest column)
+                bcls = up ? hc * 16 + q * 4 + e : bcls;
+                bkey = up ? vv[e] : bkey;
+              }
+            }
+            {
+              const int pk = __shfl_xor(bkey, 1), pc = __shfl_xor(bcls, 1), ps = __shfl_xor(skey, 1);
+              const int nsk = max(min(bkey, pk), max(skey, ps));
+              const bool take = (pk > bkey) || (pk == bkey && pc < bcls);
+              bcls = take ? pc : bcls;
+              bkey = take ? pk : bkey;
+              skey = nsk;
+            }
+            const int il = rt * 32 + row32;
+            const int na = __shfl(nrm, il);
+            const int xr = __shfl(xrow, il);
+            const int bv = bkey >> 7, bj = (127 - (bkey & 127)) * 32 + bcls, sv = skey >> 7;
+            bool want = false;
+            if (hc == 0 && xr >= 0 && xr < nX) {
+              const int d1 = na - bv, d2 = na - sv;
+              if (d2 >= kCollisionD2) flag = 1;
+              want = ratio_ok(d1, d2, ratio);  // passes against the class bound: re-examine
+              if (!want) out[xr] = kNone;
+            }
+            // the rows that passed: exact second inside the winner's class = columns {t*32 + (bj&31)}
+            unsigned long long pending = (debug & 1) ? 0ull : __ballot(want);
+            while (pending) {
+              const int src = __builtin_ctzll(pending);
+              pending &= pending - 1;
+              const int qbj = __shfl(bj, src), qbv = __shfl(bv, src), qsv = __shfl(sv, src), qna = __shfl(na, src), qxr = __shfl(xr, src);
+              int mx = INT_MIN;
+              for (int t0 = 0; t0 < tY; t0 += 64) {
+                const int t = t0 + lane;
+                const int j = t * 32 + (qbj & 31);
+                if (t < tY && j != qbj) mx = max(mx, 2 * dot_rows8(tilesX, qxr, tilesY, j) - normY[j]);
+              }
+              mx = wave_max(mx);
+              if (lane == 0) {
+                const int s2 = max(qsv, mx);
+                out[qxr] = ratio_ok(qna - qbv, qna - s2, ratio) ? qbj : kNone;
+              }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          }
+        }
+      }
+    }  // chunks
+  }    // row blocks
+  __syncthreads();
+  return flag;
+}
+
+__global__ void __launch_bounds__(kThreads, 2) match_fused4_kernel(MatchArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  RowPassShared sh;
+  sh.bbuf = smem;                                                  // [2][16 KiB]
+  sh.nbuf = (int *)(smem + 2 * kChunkBytes);                       // [2][128]
+  sh.pad_norm = a.pad_norm;
+  int *misc = sh.nbuf + 2 * kChunkCols;                            // [16]
+  unsigned short *resA = (unsigned short *)(misc + 16);            // [ncap] per feature of image A
+  unsigned short *resB = resA + a.ncap;                            // [ncap] per feature of image B
+  unsigned short *cand = resB + a.ncap;                            // [ncap] candidate list (features of B)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, w = tid >> 6;
+  const long p = xcd_remap(blockIdx.x, a.n_pairs);
+  const int img1 = a.pairs[2 * p], img2 = a.pairs[2 * p + 1];
+  const int n1 = a.counts[img1], n2 = a.counts[img2];
+  if (n1 < 2 || n2 < 2) {  // matching.py:363-374 / knnMatch returns < 2 neighbours
+    if (tid == 0) {
+      a.out_counts[p] = 0;
+      a.out_flags[p] = 0;
+    }
+    return;
+  }
+  // symmetric: A = second image (rows of the big pass), B = first image (streamed, shared in L2)
+  const int imgA = a.symmetric ? img2 : img1, imgB = a.symmetric ? img1 : img2;
+  const int nA = a.symmetric ? n2 : n1, nB = a.symmetric ? n1 : n2;
+  const int8_t *tilesA = a.tiles + a.tile_off[imgA] * OSFM_TILE_BYTES;
+  const int8_t *tilesB = a.tiles + a.tile_off[imgB] * OSFM_TILE_BYTES;
+  const int32_t *normA = a.norms + a.tile_off[imgA] * 32;
+  const int32_t *normB = a.norms + a.tile_off[imgB] * 32;
+
+  for (int j = tid; j < a.ncap; j += kThreads) {
+    resA[j] = kNone;
+    resB[j] = kNone;
+  }
+  if (tid == 0) {
+    misc[8] = 0;
+    misc[9] = 0;
+  }
+  __syncthreads();
+  int flag = row_pass<false>(sh, tilesA, normA, nA, nA, nullptr, tilesB, normB, nB, resA, a.ratio, a.debug_no_recheck, tid);
+  if (a.symmetric) {
+    // candidates: the features of B that some row of A chose.  resB doubles as the mark array
+    // (0 = chosen) until the candidate list is built, in ascending feature order.
+    for (int q = tid; q < nA; q += kThreads) {
+      const int b = resA[q];
+      if (b != kNone) resB[b] = 0;
+    }
+    __syncthreads();
+    int base = 0;
+    for (int j0 = 0; j0 < nB; j0 += kThreads) {
+      const int j = j0 + tid;
+      const bool m = j < nB && resB[j] == 0;
+      const unsigned long long bal = __ballot(m);
+      if (lane == 0) misc[w] = __popcll(bal);
+      __syncthreads();
+      int woff = 0, total = 0;
+#pragma unroll
+      for (int w2 = 0; w2 < kWaves; ++w2) {
+        const int cnt = misc[w2];
+        woff += (w2 < w) ? cnt : 0;
+        total += cnt;
+      }
+      if (m) {
+        cand[base + woff + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)j;
+        resB[j] = kNone;
+      }
+      base += total;
+      __syncthreads();
+    }
+    const int nK = base;
+    if (nK > 0) flag |= row_pass<true>(sh, tilesB, normB, nB, nK, cand, tilesA, normA, nA, resB, a.ratio, a.debug_no_recheck, tid);
+  }
+  if (flag) misc[8] = 1;
+  __syncthreads();
+  if (tid == 0) a.out_flags[p] = misc[8];
+  // ---- ordered emission over the features of the pair's first image ----
+  {
+    const unsigned short *res1 = a.symmetric ? resB : resA;  // indexed by feature of image 1 -> feature of image 2
+    const unsigned short *res2 = a.symmetric ? resA : nullptr;
+    int base = 0;
+    for (int j0 = 0; j0 < n1; j0 += kThreads) {
+      const int j = j0 + tid;
+      bool m = false;
+      int r = kNone;
+      if (j < n1) {
+        r = res1[j];
+        m = (r != kNone) && (!res2 || res2[r] == j);
+      }
+      const unsigned long long bal = __ballot(m);
+      const int prefix = __popcll(bal & ((1ull << lane) - 1ull));
+      if (lane == 0) misc[w] = __popcll(bal);
+      __syncthreads();
+      int woff = 0, total = 0;
+#pragma unroll
+      for (int w2 = 0; w2 < kWaves; ++w2) {
+        const int cnt = misc[w2];
+        woff += (w2 < w) ? cnt : 0;
+        total += cnt;
+      }
+      if (m) {
+        const int k = base + woff + prefix;
+        if (k < a.cap) a.out_matches[p * a.cap + k] = (uint32_t)j | ((uint32_t)r << 16);
+      }
+      base += total;
+      __syncthreads();
+    }
+    if (tid == 0) a.out_counts[p] = base;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Exact kernel: float-key semantics of cv2 (top-2 selected on sqrtf(d^2) with lowest-index
 // ties), VALU only.  Used (a) for the rare pairs whose second-nearest d^2 >= 2^22, where distinct
 // integers may round to the same float distance, and (b) as an on-GPU cross-check of the fused
@@ -883,11 +1236,12 @@ size_t osfm_match_lds_bytes(int ncap) {
 size_t osfm_match2_lds_bytes(int ncap) {
   return (size_t)2 * kChunkBytes + (size_t)ncap * 16 + 64 + kWaves * 192 * 4 + 2 * kChunkCols * 4;
 }
+size_t osfm_match4_lds_bytes(int ncap) { return (size_t)2 * kChunkBytes + 2 * kChunkCols * 4 + 64 + (size_t)ncap * 6; }
 static int match_kernel_version() {
   static int v = -1;
   if (v < 0) {
     const char *e = getenv("OSFM_MATCH_KERNEL");
-    v = (e && e[0] == '1') ? 1 : 2;
+    v = (e && e[0] == '1') ? 1 : (e && e[0] == '2') ? 2 : 4;
   }
   return v;
 }
@@ -921,13 +1275,16 @@ int osfm_launch_match(osfm_ctx *ctx, const osfm_store *store, const int32_t *d_p
     if (!attr_set) {
       OSFM_HIP(hipFuncSetAttribute((const void *)match_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       OSFM_HIP(hipFuncSetAttribute((const void *)match_fused2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      OSFM_HIP(hipFuncSetAttribute((const void *)match_fused4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       OSFM_HIP(hipFuncSetAttribute((const void *)match_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
       attr_set = true;
     }
     if (match_kernel_version() == 1)
       hipLaunchKernelGGL(match_fused_kernel, dim3((unsigned)n_pairs), dim3(kThreads), lds, ctx->stream, a);
-    else
+    else if (match_kernel_version() == 2)
       hipLaunchKernelGGL(match_fused2_kernel, dim3((unsigned)n_pairs), dim3(kThreads), osfm_match2_lds_bytes(a.ncap), ctx->stream, a);
+    else
+      hipLaunchKernelGGL(match_fused4_kernel, dim3((unsigned)n_pairs), dim3(kThreads), osfm_match4_lds_bytes(a.ncap), ctx->stream, a);
   } else {
     const size_t lds = (size_t)a.ncap * 6 + 64;
     hipLaunchKernelGGL(match_exact_kernel, dim3((unsigned)n_pairs), dim3(kThreads), lds, ctx->stream, a,
