@@ -949,15 +949,30 @@ __device__ __forceinline__ int row_pass(const RowPassShared &sh, const int8_t *t
               if (rt < nrt) {
                 v16i acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
                 v16i acc1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#ifdef OSFM_DBG_NOMFMA
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[rt][ks], bf0[ks], acc0, 0, 0, 0);
+                for (int ks = 0; ks < 4; ++ks) {
+                  acc0[ks] += afrag[rt][ks][0] ^ bf0[ks][1];
+                  acc1[ks] += afrag[rt][ks][1] ^ bf1[ks][0];
+                }
+#else
+                // the two accumulation chains are interleaved: a dependent back-to-back MFMA issues
+                // ~1.5x slower than an independent one (measured: 6.2 vs 4.1 ms of pure MFMA time)
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[rt][ks], bf1[ks], acc1, 0, 0, 0);
+                for (int ks = 0; ks < 4; ++ks) {
+                  acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[rt][ks], bf0[ks], acc0, 0, 0, 0);
+                  acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[rt][ks], bf1[ks], acc1, 0, 0, 0);
+                }
+#endif
+#ifdef OSFM_DBG_NOEPI
+                rbst[rt][0] = max(rbst[rt][0], acc0[0] + acc1[5] + ck0 + ck1);
+#else
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                   const int k0 = (acc0[r] << 8) + ck0, k1 = (acc1[r] << 8) + ck1;
                   rbst[rt][r] = max(max(rbst[rt][r], k0), k1);
                 }
+#endif
               }
             }
           }

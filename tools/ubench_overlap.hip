@@ -19,8 +19,8 @@ __global__ void __launch_bounds__(256, 2) k(int *out, int iters, int seed) {
 #pragma unroll
   for (int i = 0; i < 8; i++) x[i] = threadIdx.x * (i + 1) + seed;
   int c0 = seed * 11, c1 = seed * 13;
-  const bool do_m = MODE == 0 || MODE == 2 || (MODE == 3 && (blockIdx.x & 1) == 0);
-  const bool do_v = MODE == 1 || MODE == 2 || (MODE == 3 && (blockIdx.x & 1) == 1);
+  const bool do_m = MODE == 0 || MODE == 2 || MODE == 4 || MODE == 5 || (MODE == 3 && (blockIdx.x & 1) == 0);
+  const bool do_v = MODE == 1 || MODE == 2 || MODE == 4 || MODE == 5 || (MODE == 3 && (blockIdx.x & 1) == 1);
   for (int it = 0; it < iters; it++) {
     if (do_m) {
       acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc0, 0, 0, 0);
@@ -28,7 +28,28 @@ __global__ void __launch_bounds__(256, 2) k(int *out, int iters, int seed) {
       acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(b, a, acc1, 0, 0, 0);
     }
-    if (do_v) {
+    if (do_v && MODE == 4) {  // epilogue-like: keys built from the accumulator of the PREVIOUS iteration's MFMAs
+      v16i prev = acc1;
+#pragma unroll
+      for (int q = 0; q < V / 16; q++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          int t;
+          asm volatile("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(t) : "v"(prev[(q * 8 + i) & 15]), "v"(c0));
+          asm volatile("v_max3_i32 %0, %1, %2, %3" : "=v"(x[i]) : "v"(x[i]), "v"(t), "v"(c1));
+        }
+      }
+    } else if (do_v && MODE == 5) {  // keys from the accumulator just produced (true dependency)
+#pragma unroll
+      for (int q = 0; q < V / 16; q++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          int t;
+          asm volatile("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(t) : "v"(acc0[(q * 8 + i) & 15]), "v"(c0));
+          asm volatile("v_max3_i32 %0, %1, %2, %3" : "=v"(x[i]) : "v"(x[i]), "v"(t), "v"(c1));
+        }
+      }
+    } else if (do_v) {
 #pragma unroll
       for (int q = 0; q < V / 16; q++) {
 #pragma unroll
@@ -82,6 +103,10 @@ int main() {
     const double cyc = 1e-3 * p.clockRate * 1e3 / iters;  // cycles per ms per iteration
     printf("   cycles/iter/wave-slot: MFMA(4) %.0f  VALU48 %.0f  VALU96 %.0f  both48 %.0f  both96 %.0f\n", m * cyc / bpc * bpc, v48 * cyc,
            v96 * cyc, b48 * cyc, b96 * cyc);
+  }
+  for (int bpc = 1; bpc <= 2; bpc++) {
+    const float p48 = run<4, 48>(cus * bpc, iters), d48 = run<5, 48>(cus * bpc, iters);
+    printf("waves/SIMD %d: MFMA + VALU48 reading the OTHER accumulator %.2f ms | reading the accumulator just produced %.2f ms\n", bpc, p48, d48);
   }
   {
     const float x48 = run<3, 48>(cus * 2, iters), x96 = run<3, 96>(cus * 2, iters);
