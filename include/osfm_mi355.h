@@ -149,6 +149,11 @@ typedef struct {
   const double *obs_xy;          /* n_obs x 2 normalized image coordinates (observation.point)     */
   const double *obs_sigma;       /* n_obs: observation.scale == std_deviation (tracking.py:108)     */
   double *reproj_err;            /* n_obs x 2 or NULL: out, residual with sigma 1                   */
+  /* absolute up-vector prior (BAHelpers::Bundle with align_method orientation_prior,
+     ba_helpers.cc:609-621,688-692; UpVectorError, absolute_motion_errors.h:12-39; CauchyLoss(1),
+     bundle_adjuster.cc:955-970): residual (R(rotation) * up - e_z) / sd per shot */
+  const double *shot_up;         /* n_shots x 3 or NULL (normalised by the library)                 */
+  const double *shot_up_sigma;   /* n_shots or NULL: sd (<= 0: no prior for that shot)              */
                                  /* (ComputeReprojectionErrors, bundle_adjuster.cc:1196-1208)        */
 } osfm_ba_problem;
 

@@ -101,7 +101,8 @@ def bundle_arrays(problem: Dict[str, np.ndarray], config: Optional[Dict[str, Any
     P.shot_pose, P.shot_camera = _dp(poses, C.c_double), _dp(shot_camera, C.c_int32)
     use_gps = bool(_cfg(config, "bundle_use_gps"))
     for key, t, ct in (("shot_fixed", np.uint8, C.c_uint8), ("point_fixed", np.uint8, C.c_uint8),
-                       ("shot_gps", np.float64, C.c_double), ("shot_gps_sigma", np.float64, C.c_double)):
+                       ("shot_gps", np.float64, C.c_double), ("shot_gps_sigma", np.float64, C.c_double),
+                       ("shot_up", np.float64, C.c_double), ("shot_up_sigma", np.float64, C.c_double)):
         if problem.get(key) is not None and (use_gps or not key.startswith("shot_gps")):
             arr = np.ascontiguousarray(problem[key], t)
             keep.append(arr)
@@ -197,6 +198,11 @@ class BundleAdjuster:
                 sh["gps"] = np.asarray(position, float)
                 sh["gps_sd"] = float(np.mean(std_deviation))
 
+    def add_absolute_up_vector(self, shot_id, up_vector, std_deviation):
+        """``BundleAdjuster::AddAbsoluteUpVector`` (bundle_adjuster.cc:300-308)."""
+        self._shots[shot_id]["up"] = np.asarray(up_vector, float)
+        self._shots[shot_id]["up_sd"] = float(std_deviation)
+
     def add_point(self, point_id, position, constant):
         self._points[point_id] = {"p": np.asarray(position, float), "fixed": bool(constant)}
 
@@ -258,6 +264,9 @@ class BundleAdjuster:
         }
         if gps_sd.max() > 0:
             prob["shot_gps"], prob["shot_gps_sigma"] = gps, gps_sd
+        if any("up" in s for s in self._shots.values()):
+            prob["shot_up"] = np.array([self._shots[k].get("up", np.zeros(3)) for k in shot_ids])
+            prob["shot_up_sigma"] = np.array([self._shots[k].get("up_sd", 0.0) for k in shot_ids])
         cfg = {"loss_function": self._loss[0], "loss_function_threshold": self._loss[1], "bundle_max_iterations": self._max_iter}
         r = bundle_arrays(prob, cfg)
         for k in cam_ids:

@@ -188,6 +188,10 @@ struct Dev {
   // parameters (current / candidate)
   double *cams, *poses, *pts, *cams_n, *poses_n, *pts_n;
   const double *cam_prior, *cam_sigma, *gps, *gps_sigma;
+  // absolute up-vector prior per shot (absolute_motion_errors.h:12-39, CauchyLoss(1), bundle_adjuster.cc:955-970)
+  const double *up, *up_sigma;  // unit vectors (3 per shot), sd (<= 0: none) -- or null
+  double *up_r, *up_J;          // corrected residual (3) and Jacobian w.r.t. the rotation (3x3) per shot
+  double *prior_rot;            // J^T J of that prior: symmetric 3x3 per shot, packed (00,10,11,20,21,22)
   const uint8_t *cam_fixed, *shot_fixed, *point_fixed;
   const int *shot_camera;
   // observations, point-major
@@ -310,7 +314,24 @@ __global__ void finish_reduce_kernel(const double *partial, long n, int ncomp, d
 }
 
 // cost of the prior residuals (camera intrinsics, shot position), added to out[0]
-__global__ void prior_cost_kernel(Dev d, const double *cams, const double *poses, double *out) {
+// up-vector residual of shot s from the rotation block shotR (R = world->camera, dR[k] = dR/da_k, a = -rot):
+// r = (R^T u - e_z)/sd, J[i][k] = d r_i / d rot_k = -(dR_k^T u)_i / sd
+__device__ __forceinline__ void up_residual(const Dev &d, int s, double r[3], double J[9]) {
+  const double *R = d.shotR + 36 * (long)s, *u = d.up + 3 * (long)s;
+  const double isd = 1.0 / d.up_sigma[s];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const double z = R[i] * u[0] + R[3 + i] * u[1] + R[6 + i] * u[2];
+    r[i] = isd * (z - (i == 2 ? 1.0 : 0.0));
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const double *dR = R + 9 + 9 * k;
+      J[3 * i + k] = -isd * (dR[i] * u[0] + dR[3 + i] * u[1] + dR[6 + i] * u[2]);
+    }
+  }
+}
+
+__global__ void prior_cost_kernel(Dev d, const double *cams, const double *poses, double *out, int jac) {
   __shared__ double lds[16];
   double v[1] = {0.0};
   for (int c = threadIdx.x; c < d.NC; c += blockDim.x) {
@@ -326,6 +347,19 @@ __global__ void prior_cost_kernel(Dev d, const double *cams, const double *poses
       for (int i = 0; i < 3; i++) {
         const double e = (poses[6 * s + 3 + i] - d.gps[3 * s + i]) / d.gps_sigma[s];
         v[0] += 0.5 * e * e;
+      }
+    }
+  if (d.up && d.up_sigma)
+    for (int s = threadIdx.x; s < d.S; s += blockDim.x) {
+      if (!(d.up_sigma[s] > 0) || (d.shot_fixed && d.shot_fixed[s])) continue;
+      double r[3], J[9], rho, rho1;
+      up_residual(d, s, r, J);
+      loss_eval(OSFM_LOSS_CAUCHY, 1.0, r[0] * r[0] + r[1] * r[1] + r[2] * r[2], rho, rho1);
+      v[0] += 0.5 * rho;
+      if (jac) {
+        const double wt = sqrt(rho1);
+        for (int i = 0; i < 3; i++) d.up_r[3 * s + i] = wt * r[i];
+        for (int i = 0; i < 9; i++) d.up_J[9 * s + i] = wt * J[i];
       }
     }
   block_sum<1>(v, lds);
@@ -407,6 +441,21 @@ __global__ void __launch_bounds__(64) shot_grad_kernel(Dev d, const double *pose
       for (int k = 0; k < 3; k++) {
         v[3 + k] += wgt * wgt * (poses[6 * s + 3 + k] - d.gps[3 * s + k]);
         pd[3 + k] = wgt * wgt;
+      }
+    }
+    if (d.prior_rot) {
+      double pr[6] = {0, 0, 0, 0, 0, 0};
+      if (!fixed && d.up && d.up_sigma && d.up_sigma[s] > 0) {
+        const double *ru = d.up_r + 3 * s, *Ju = d.up_J + 9 * s;
+        int q = 0;
+        for (int i = 0; i < 3; i++) {
+          v[i] += Ju[i] * ru[0] + Ju[3 + i] * ru[1] + Ju[6 + i] * ru[2];
+          for (int j = 0; j <= i; j++) pr[q++] = Ju[i] * Ju[j] + Ju[3 + i] * Ju[3 + j] + Ju[6 + i] * Ju[6 + j];
+        }
+      }
+      for (int q = 0; q < 6; q++) {
+        d.prior_rot[6 * (long)s + q] = pr[q];
+        v[6 + q] += pr[q];  // rotation block of H: the preconditioners and the LM diagonal see the prior through Hcc
       }
     }
     const int dg[6] = {0, 2, 5, 9, 14, 20};
@@ -1668,6 +1717,12 @@ __global__ void schur_finish_kernel(Dev d, const double *x, const double *y, dou
     const int c = (i - d.cam0) / 3, k = (i - d.cam0) % 3;
     zc = d.camred[9 * c + k];
   }
+  if (mode == 0 && d.prior_rot && i < d.cam0 && (i % 6) < 3) {  // up-vector prior: dense 3x3 on the rotation
+    const int s = i / 6, k = i % 6;
+    const double *pr = d.prior_rot + 6 * (long)s, *yr = y + 6 * s;
+    const int ix[3][3] = {{0, 1, 3}, {1, 2, 4}, {3, 4, 5}};
+    zc += pr[ix[k][0]] * yr[0] + pr[ix[k][1]] * yr[1] + pr[ix[k][2]] * yr[2];
+  }
   if (mode == 0)
     out[i] = d.sc_red[i] * (zc + d.prior_diag[i] * y[i]) + d.D_red[i] / radius * x[i];
   else
@@ -1785,6 +1840,13 @@ __global__ void candidate_kernel(Dev d, const double *y, double *out) {
         v[0] -= m * (e + 0.5 * m);
       }
     }
+    if (!fixed && d.up && d.up_sigma && d.up_sigma[s] > 0) {
+      const double *ru = d.up_r + 3 * s, *Ju = d.up_J + 9 * s;
+      for (int i = 0; i < 3; i++) {
+        const double m = Ju[3 * i] * y[6 * s] + Ju[3 * i + 1] * y[6 * s + 1] + Ju[3 * i + 2] * y[6 * s + 2];
+        v[0] -= m * (ru[i] + 0.5 * m);
+      }
+    }
     for (int k = 0; k < 6; k++) {
       const double dl = fixed ? 0.0 : y[6 * s + k];
       d.poses_n[6 * s + k] = d.poses[6 * s + k] + dl;
@@ -1895,7 +1957,7 @@ struct Solver {
       hipLaunchKernelGGL((eval_kernel<false, false>), dim3(nb), dim3(TPB), 0, st, d, cams, poses, pts, loss, loss_a);
     }
     hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(1024), 0, st, d.partial, (long)nb, 2, d.scal + 8);
-    hipLaunchKernelGGL(prior_cost_kernel, dim3(1), dim3(256), 0, st, d, cams, poses, d.scal + 8);
+    hipLaunchKernelGGL(prior_cost_kernel, dim3(1), dim3(256), 0, st, d, cams, poses, d.scal + 8, jac ? 1 : 0);
     OSFM_HIP(hipMemcpyAsync(hscal.data(), d.scal + 8, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
     OSFM_HIP(hipStreamSynchronize(st));
     *cost = hscal[0];
@@ -2028,6 +2090,20 @@ extern "C" int osfm_ba_solve(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_op
   d.point_fixed = P->point_fixed ? A.upload(P->point_fixed, (size_t)NP, e) : nullptr;
   d.gps = (P->shot_gps && P->shot_gps_sigma) ? A.upload(P->shot_gps, (size_t)3 * S, e) : nullptr;
   d.gps_sigma = (P->shot_gps && P->shot_gps_sigma) ? A.upload(P->shot_gps_sigma, (size_t)S, e) : nullptr;
+  if (P->shot_up && P->shot_up_sigma) {
+    std::vector<double> un((size_t)3 * S);
+    for (int s = 0; s < S; s++) {
+      const double *u = P->shot_up + 3 * (size_t)s;
+      const double nrm = std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+      OSFM_REQUIRE(!(P->shot_up_sigma[s] > 0) || nrm >= 1e-10, OSFM_E_INVALID, "UpVectorError: acceleration vector has near-zero magnitude");
+      for (int i = 0; i < 3; i++) un[(size_t)3 * s + i] = nrm > 0 ? u[i] / nrm : 0.0;
+    }
+    d.up = A.upload(un.data(), (size_t)3 * S, e);
+    d.up_sigma = A.upload(P->shot_up_sigma, (size_t)S, e);
+    d.up_r = A.alloc<double>((size_t)3 * S, e);
+    d.up_J = A.alloc<double>((size_t)9 * S, e);
+    d.prior_rot = A.alloc<double>((size_t)6 * S, e);
+  }
   d.o_shot = A.upload(o_shot.data(), (size_t)M, e);
   d.o_point = A.upload(o_point.data(), (size_t)M, e);
   d.o_x = A.upload(o_x.data(), (size_t)M, e);

@@ -154,6 +154,7 @@ class _BaProblem(C.Structure):
         ("points", C.POINTER(C.c_double)), ("point_fixed", C.POINTER(C.c_uint8)),
         ("obs_shot", C.POINTER(C.c_int32)), ("obs_point", C.POINTER(C.c_int32)),
         ("obs_xy", C.POINTER(C.c_double)), ("obs_sigma", C.POINTER(C.c_double)), ("reproj_err", C.POINTER(C.c_double)),
+        ("shot_up", C.POINTER(C.c_double)), ("shot_up_sigma", C.POINTER(C.c_double)),
     ]
 
 
@@ -196,7 +197,8 @@ def ba_solve(problem: dict, loss: str = "SoftLOneLoss", loss_threshold: float = 
     P.cam_fixed = _p(cam_fixed, C.c_uint8)
     P.shot_pose, P.shot_camera = _p(poses, C.c_double), _p(shot_camera, C.c_int32)
     for key, fld, t, ct in (("shot_fixed", "shot_fixed", np.uint8, C.c_uint8), ("point_fixed", "point_fixed", np.uint8, C.c_uint8),
-                            ("shot_gps", "shot_gps", np.float64, C.c_double), ("shot_gps_sigma", "shot_gps_sigma", np.float64, C.c_double)):
+                            ("shot_gps", "shot_gps", np.float64, C.c_double), ("shot_gps_sigma", "shot_gps_sigma", np.float64, C.c_double),
+                            ("shot_up", "shot_up", np.float64, C.c_double), ("shot_up_sigma", "shot_up_sigma", np.float64, C.c_double)):
         if problem.get(key) is not None:
             arr = np.ascontiguousarray(problem[key], t)
             keep.append(arr)
@@ -216,6 +218,14 @@ def ba_solve(problem: dict, loss: str = "SoftLOneLoss", loss_threshold: float = 
         "seconds_total": R.seconds_total, "seconds_linear_solver": R.seconds_linear_solver,
         "cost_history": np.array(R.cost_history[: R.iterations + 1]),
     }
+
+
+def ba_up(pose, up, sigma):
+    """Up-vector residual (3) and its Jacobian w.r.t. the shot rotation (3x3) -- absolute_motion_errors.h:12-39."""
+    pose, up = np.ascontiguousarray(pose, np.float64), np.ascontiguousarray(up, np.float64)
+    r, J = np.zeros(3), np.zeros(9)
+    lib().oracle_ba_up(_p(pose, C.c_double), _p(up, C.c_double), C.c_double(sigma), _p(r, C.c_double), _p(J, C.c_double))
+    return r, J.reshape(3, 3)
 
 
 def ba_project(X, pose, cam, obs, sigma):

@@ -56,6 +56,10 @@ typedef struct {
   const double *obs_xy;    /* n_obs x 2 */
   const double *obs_sigma; /* n_obs */
   double *reproj_err;      /* n_obs x 2 out (sigma = 1), may be NULL */
+  /* absolute up-vector prior (bundle_adjuster.cc:955-970, absolute_motion_errors.h:12-39):
+     r = (R(rot) * up - e_z) / sd, CauchyLoss(1) per shot; NULL or sd <= 0: none */
+  const double *shot_up;       /* n_shots x 3 (normalised here) or NULL */
+  const double *shot_up_sigma; /* n_shots or NULL */
 } ba_problem;
 
 typedef struct {
@@ -224,9 +228,38 @@ typedef struct {
   /* per observation storage */
   double *res;    /* 2 (corrected) */
   double *Jp, *Jc, *Jk; /* 6, 12, 6 (corrected, UNscaled) */
+  double *up_r, *up_J;  /* per shot: corrected up-vector residual (3) and its 3x3 Jacobian w.r.t. the rotation */
   /* point-major observation lists */
   int64_t *pt_off; int64_t *pt_obs;
 } ba_ctx;
+
+/* up-vector residual of one shot: r = (Rw^T u - e_z)/sd with Rw = R(-rot) (world -> camera), i.e. R(rot) u;
+ * J[i][k] = d r_i / d rot_k = -(dRw_k^T u)_i / sd  (dRw_k = d Rw / d a_k, a = -rot) */
+static int up_residual(const ba_problem *P, int s, const double *R, const double (*dR)[9], double r[3], double J[9]) {
+  if (!(P->shot_up && P->shot_up_sigma) || !(P->shot_up_sigma[s] > 0)) return 0;
+  const double *u0 = P->shot_up + 3 * (size_t)s;
+  const double nrm = sqrt(u0[0] * u0[0] + u0[1] * u0[1] + u0[2] * u0[2]);
+  const double u[3] = {u0[0] / nrm, u0[1] / nrm, u0[2] / nrm};
+  const double isd = 1.0 / P->shot_up_sigma[s];
+  for (int i = 0; i < 3; i++) {
+    const double z = R[i] * u[0] + R[3 + i] * u[1] + R[6 + i] * u[2]; /* (Rw^T u)_i */
+    r[i] = isd * (z - (i == 2 ? 1.0 : 0.0));
+    if (J)
+      for (int k = 0; k < 3; k++) J[3 * i + k] = -isd * (dR[k][i] * u[0] + dR[k][3 + i] * u[1] + dR[k][6 + i] * u[2]);
+  }
+  return 1;
+}
+
+/* exposed for the tests: up-vector residual and Jacobian of one shot */
+void oracle_ba_up(const double *pose, const double *up, double sigma, double *r, double *J) {
+  double R[9], dR[3][9];
+  rot_and_derivs(pose, R, dR);
+  ba_problem P;
+  memset(&P, 0, sizeof(P));
+  P.shot_up = up;
+  P.shot_up_sigma = &sigma;
+  up_residual(&P, 0, R, (const double (*)[9])dR, r, J);
+}
 
 static double eval_cost(const ba_ctx *C, const double *cams, const double *poses, const double *pts,
                         int with_jac, double *sumsq_out) {
@@ -273,6 +306,23 @@ static double eval_cost(const ba_ctx *C, const double *cams, const double *poses
       for (int i = 0; i < 3; i++) {
         const double e = (poses[6 * s + 3 + i] - P->shot_gps[3 * s + i]) / P->shot_gps_sigma[s];
         cost += 0.5 * e * e;
+      }
+    }
+  /* up-vector priors: 3 residuals per shot under one CauchyLoss(1) */
+  if (P->shot_up && P->shot_up_sigma)
+    for (int s = 0; s < P->n_shots; s++) {
+      if (C->shot_var[s] < 0) continue;
+      double r[3], J[9];
+      const double *R = Rall + 36 * (size_t)s;
+      if (!up_residual(P, s, R, (const double (*)[9])(R + 9), r, J)) continue;
+      const double sq = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+      double rho, rho1;
+      loss_eval(3, 1.0, sq, &rho, &rho1);
+      cost += 0.5 * rho;
+      if (with_jac) {
+        const double w = sqrt(rho1);
+        for (int i = 0; i < 3; i++) C->up_r[3 * s + i] = w * r[i];
+        for (int i = 0; i < 9; i++) C->up_J[9 * s + i] = w * J[i];
       }
     }
   free(Rall);
@@ -353,6 +403,8 @@ int oracle_ba_solve(ba_problem *P, const ba_options *O, ba_report *Rp) {
   C.Jp = (double *)malloc(sizeof(double) * 6 * (size_t)M);
   C.Jc = (double *)malloc(sizeof(double) * 12 * (size_t)M);
   C.Jk = (double *)malloc(sizeof(double) * 6 * (size_t)M);
+  C.up_r = (double *)calloc(3 * (size_t)P->n_shots + 1, sizeof(double));
+  C.up_J = (double *)calloc(9 * (size_t)P->n_shots + 1, sizeof(double));
   /* point-major lists */
   C.pt_off = (int64_t *)calloc((size_t)NP + 1, sizeof(int64_t));
   C.pt_obs = (int64_t *)malloc(sizeof(int64_t) * (size_t)(M > 0 ? M : 1));
@@ -488,6 +540,17 @@ int oracle_ba_solve(ba_problem *P, const ba_options *O, ba_report *Rp) {
           diag_red[6 * sv + 3 + k] += w * w;
         }
       }
+    if (P->shot_up && P->shot_up_sigma)
+      for (int s = 0; s < S; s++) {
+        const int sv = C.shot_var[s];
+        if (sv < 0 || !(P->shot_up_sigma[s] > 0)) continue;
+        const double *r = C.up_r + 3 * s, *J = C.up_J + 9 * s;
+        for (int k = 0; k < 3; k++)
+          for (int i = 0; i < 3; i++) {
+            g_red[6 * sv + k] += J[3 * i + k] * r[i];
+            diag_red[6 * sv + k] += J[3 * i + k] * J[3 * i + k];
+          }
+      }
     if (!have_scale) { /* jacobi scaling, once (ceres trust_region_minimizer: jacobian_scaling_) */
       for (int i = 0; i < nred; i++) sc_red[i] = 1.0 / (1.0 + sqrt(diag_red[i]));
       for (int i = 0; i < 3 * NP; i++) sc_pt[i] = 1.0 / (1.0 + sqrt(diag_pt[i]));
@@ -543,6 +606,15 @@ int oracle_ba_solve(ba_problem *P, const ba_options *O, ba_report *Rp) {
           if (sv < 0 || !(P->shot_gps_sigma[s] > 0)) continue;
           const double w = 1.0 / P->shot_gps_sigma[s];
           for (int k = 0; k < 3; k++) SKY(6 * sv + 3 + k, 6 * sv + 3 + k) += w * w * sc_red[6 * sv + 3 + k] * sc_red[6 * sv + 3 + k];
+        }
+      if (P->shot_up && P->shot_up_sigma)
+        for (int s = 0; s < S; s++) {
+          const int sv = C.shot_var[s];
+          if (sv < 0 || !(P->shot_up_sigma[s] > 0)) continue;
+          const double *J = C.up_J + 9 * s;
+          for (int i = 0; i < 3; i++)
+            for (int j = 0; j <= i; j++)
+              SKY(6 * sv + i, 6 * sv + j) += (J[i] * J[j] + J[3 + i] * J[3 + j] + J[6 + i] * J[6 + j]) * sc_red[6 * sv + i] * sc_red[6 * sv + j];
         }
       for (int i = 0; i < nred; i++) SKY(i, i) += Dred[i] / radius;
       /* eliminate points */
@@ -706,6 +778,17 @@ int oracle_ba_solve(ba_problem *P, const ba_options *O, ba_report *Rp) {
             model_change -= m * (e + 0.5 * m);
           }
         }
+      if (P->shot_up && P->shot_up_sigma)
+        for (int s = 0; s < S; s++) {
+          const int sv = C.shot_var[s];
+          if (sv < 0 || !(P->shot_up_sigma[s] > 0)) continue;
+          const double *r = C.up_r + 3 * s, *J = C.up_J + 9 * s;
+          for (int i = 0; i < 3; i++) {
+            double m = 0;
+            for (int k = 0; k < 3; k++) m += J[3 * i + k] * dx[6 * sv + k] * sc_red[6 * sv + k];
+            model_change -= m * (r[i] + 0.5 * m);
+          }
+        }
       /* candidate */
       double step_sq = 0, x_sq = 0;
       memcpy(cams_n, cams, sizeof(double) * 3 * (size_t)NC);
@@ -799,7 +882,7 @@ int oracle_ba_solve(ba_problem *P, const ba_options *O, ba_report *Rp) {
     Rp->rmse_normalized_final = sqrt(ss / (double)(M > 0 ? M : 1));
   }
   Rp->seconds_total = now_s() - t_start;
-  free(C.cam_var); free(C.shot_var); free(C.res); free(C.Jp); free(C.Jc); free(C.Jk); free(C.pt_off); free(C.pt_obs);
+  free(C.cam_var); free(C.shot_var); free(C.res); free(C.Jp); free(C.Jc); free(C.Jk); free(C.up_r); free(C.up_J); free(C.pt_off); free(C.pt_obs);
   free(A.first); free(A.off); free(A.v);
   free(cams); free(poses); free(pts); free(cams_n); free(poses_n); free(pts_n);
   free(sc_red); free(sc_pt); free(g_red); free(g_pt); free(diag_red); free(diag_pt); free(Hpp_inv); free(d_red); free(d_pt); free(rhs);

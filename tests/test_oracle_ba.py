@@ -73,3 +73,42 @@ def test_zero_iterations_returns_input(oracle_lib):
     r = oracle_lib.ba_solve(pr, max_iterations=0)
     assert r["iterations"] == 0 and np.array_equal(r["points"], pr["points"])
     assert r["final_cost"] == r["initial_cost"]
+
+
+def test_up_vector_residual_and_jacobian(oracle_lib):
+    oracle = oracle_lib
+    """UpVectorError (absolute_motion_errors.h:12-39): r = (R(rot) up/|up| - e_z)/sd; the closed-form
+    Jacobian against central differences, and the rotation against Rodrigues' formula."""
+    rng = np.random.default_rng(5)
+    for _ in range(5):
+        pose = np.r_[rng.normal(0, 0.7, 3), rng.normal(0, 1, 3)]
+        up = rng.normal(0, 1, 3)
+        r, J = oracle.ba_up(pose, up, 0.05)
+        a = pose[:3]
+        th = np.linalg.norm(a)
+        K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+        R = np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th**2 * K @ K
+        want = (R @ (up / np.linalg.norm(up)) - np.array([0, 0, 1.0])) / 0.05
+        assert np.allclose(r, want, atol=1e-12)
+        num = np.zeros((3, 3))
+        for k in range(3):
+            h = 1e-6
+            pp, pm = pose.copy(), pose.copy()
+            pp[k] += h
+            pm[k] -= h
+            num[:, k] = (oracle.ba_up(pp, up, 0.05)[0] - oracle.ba_up(pm, up, 0.05)[0]) / (2 * h)
+        assert np.allclose(J, num, atol=1e-6)
+
+
+def test_up_vector_prior_levels_the_cameras(oracle_lib):
+    oracle = oracle_lib
+    """With a strong up-vector prior the optimised rotations map the prior vector onto +z."""
+    pr = synthetic.make_ba_scene(12, 200, 5, seed=3, outlier_frac=0.0)
+    S = len(pr["shot_pose"])
+    pr["shot_up"] = np.tile([0.0, -1.0, 0.0], (S, 1))
+    pr["shot_up_sigma"] = np.full(S, 1e-3)
+    o = oracle.ba_solve(pr, max_iterations=30)
+    assert o["final_cost"] < o["initial_cost"]
+    res = np.array([np.linalg.norm(oracle.ba_up(p, [0, -1.0, 0], 1.0)[0]) for p in o["shot_pose"]])
+    res0 = np.array([np.linalg.norm(oracle.ba_up(p, [0, -1.0, 0], 1.0)[0]) for p in pr["shot_pose"]])
+    assert res.mean() <= res0.mean() + 1e-9
