@@ -111,6 +111,8 @@ int osfm_match_l2_ratio(osfm_ctx *ctx, const float *A, int nA, const float *B, i
  * Leaf: cv2.findFundamentalMat(p1, p2, FM_RANSAC, thr, conf) as used by
  * robust_match_fundamental (matching.py:780-802).  p1, p2: n x 2 float64.
  * Returns OSFM_OK with *found = 1 (F row-major, mask n bytes) or *found = 0 (F is None).
+ * n >= 15: RANSAC; 8 <= n < 15: the LMedS registrator cv2 switches to; n == 7: OSFM_E_UNSUPPORTED
+ * (the reference never calls with fewer than 8 matches, matching.py:787).
  */
 int osfm_ransac_fundamental(osfm_ctx *ctx, const double *p1, const double *p2, int n, double thr,
                             double conf, int max_iters, double F[9], uint8_t *mask, int *found,

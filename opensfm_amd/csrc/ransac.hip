@@ -510,6 +510,149 @@ __global__ void __launch_bounds__(kThreads) ransac_single_kernel(const double *p
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// LMedS branch: cv2.findFundamentalMat(FM_RANSAC) with 8 <= n < 15 points runs the LMedS registrator
+// (fundam.cpp: RANSAC only for npoints >= 15).  Published algorithm (ptsetreg.cpp): a FIXED number of
+// iterations niters = max(RANSACUpdateNumIters(conf, 0.45, 7, maxIters), 3); per hypothesis the median
+// = element n/2 of the sorted float errors; smallest median wins (strict <, first in stream order);
+// sigma = 2.5*1.4826*(1 + 5/(n-7))*sqrt(minMedian) >= 0.001; inliers err <= sigma^2; success iff >= 7.
+// Same batch-parallel scheme as ransac_core: lane 0 draws 64 subsets from the RNG stream, 64 lanes
+// solve and score them (n <= 14 points: a 14-element insertion sort per hypothesis), lane 0 replays.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) lmeds_single_kernel(const double *p1, const double *p2, int n, double conf, int max_iters,
+                                                           double *F_out, uint8_t *mask, int32_t *info) {
+  __shared__ float4 pts[16];
+  __shared__ unsigned short subset[kBatch][8];
+  __shared__ unsigned char subset_ok[kBatch];
+  __shared__ double models[kBatch][27];
+  __shared__ float med[kBatch][3];
+  __shared__ unsigned char nmodels[kBatch];
+  __shared__ double best[9];
+  __shared__ int ctrl[4];
+  __shared__ unsigned long long rng_state;
+  const int tid = threadIdx.x;
+  if (tid < n) pts[tid] = make_float4((float)p1[2 * tid], (float)p1[2 * tid + 1], (float)p2[2 * tid], (float)p2[2 * tid + 1]);
+  if (conf < 2.220446049250313e-16 || conf > 1 - 2.220446049250313e-16) conf = 0.99;
+  int niters = update_num_iters(conf, 0.45, max_iters);
+  if (niters < 3) niters = 3;
+  double min_median = 1.7976931348623157e308;
+  if (tid == 0) {
+    rng_state = ~0ull;
+    ctrl[0] = 0;  // done
+    ctrl[1] = 0;  // iterations run
+    ctrl[2] = 0;  // a model exists
+  }
+  __syncthreads();
+  for (int it0 = 0; it0 < niters; it0 += kBatch) {
+    if (tid == 0) {
+      CvRng rng{rng_state};
+      for (int b = 0; b < kBatch; ++b) subset_ok[b] = 0;
+      for (int b = 0; b < kBatch && it0 + b < niters; ++b) {
+        int idx[7];
+        double ms1[14], ms2[14];
+        bool found = false;
+        for (int attempt = 0; attempt < 10000 && !found; ++attempt) {
+          for (int i = 0; i < 7; ++i) {
+            int idx_i;
+            for (;;) {
+              idx_i = rng.uniform(0, n);
+              bool dup = false;
+              for (int j = 0; j < i; j++)
+                if (idx[j] == idx_i) dup = true;
+              if (!dup) break;
+            }
+            idx[i] = idx_i;
+            const float4 q = pts[idx_i];
+            ms1[2 * i] = (double)q.x;
+            ms1[2 * i + 1] = (double)q.y;
+            ms2[2 * i] = (double)q.z;
+            ms2[2 * i + 1] = (double)q.w;
+          }
+          found = !have_collinear(ms1, 7) && !have_collinear(ms2, 7);
+        }
+        if (!found) break;
+        subset_ok[b] = 1;
+        for (int i = 0; i < 7; ++i) subset[b][i] = (unsigned short)idx[i];
+      }
+      rng_state = rng.state;
+    }
+    __syncthreads();
+    {
+      int nm = 0;
+      if (subset_ok[tid]) {
+        double ms1[14], ms2[14];
+        for (int i = 0; i < 7; ++i) {
+          const float4 q = pts[subset[tid][i]];
+          ms1[2 * i] = (double)q.x;
+          ms1[2 * i + 1] = (double)q.y;
+          ms2[2 * i] = (double)q.z;
+          ms2[2 * i + 1] = (double)q.w;
+        }
+        nm = run_7point(ms1, ms2, models[tid]);
+        for (int k = 0; k < nm; ++k) {
+          float e[16];
+          for (int i = 0; i < n; ++i) {
+            const float4 q = pts[i];
+            e[i] = epi_error(models[tid] + 9 * k, (double)q.x, (double)q.y, (double)q.z, (double)q.w);
+          }
+          for (int i = 1; i < n; ++i) {
+            const float v = e[i];
+            int j = i - 1;
+            for (; j >= 0 && e[j] > v; --j) e[j + 1] = e[j];
+            e[j + 1] = v;
+          }
+          med[tid][k] = e[n / 2];
+        }
+      }
+      nmodels[tid] = (unsigned char)nm;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int iter = it0;
+      bool done = false;
+      for (int b = 0; b < kBatch; ++b, ++iter) {
+        if (iter >= niters) { done = true; break; }
+        if (!subset_ok[b]) { done = true; break; }  // getSubset failed: `if (iter == 0) return false; break;`
+        for (int k = 0; k < nmodels[b]; ++k) {
+          const double median = (double)med[b][k];
+          if (median < min_median) {
+            min_median = median;
+            for (int i = 0; i < 9; ++i) best[i] = models[b][9 * k + i];
+            ctrl[2] = 1;
+          }
+        }
+      }
+      ctrl[0] = done ? 1 : 0;
+      ctrl[1] = iter;
+    }
+    __syncthreads();
+    if (ctrl[0]) break;
+  }
+  // lane 0 owns min_median; the others only need the verdict
+  __shared__ float tsq;
+  if (tid == 0) {
+    double sigma = 2.5 * 1.4826 * (1 + 5. / (n - 7)) * sqrt(min_median);
+    if (sigma < 0.001) sigma = 0.001;
+    tsq = (float)(sigma * sigma);
+  }
+  __syncthreads();
+  const bool have = ctrl[2] != 0;
+  bool in = false;
+  if (have && tid < n) {
+    const float4 q = pts[tid];
+    in = epi_error(best, (double)q.x, (double)q.y, (double)q.z, (double)q.w) <= tsq;
+  }
+  const int count = __popcll(__ballot(in));
+  const bool ok = have && count >= 7;
+  if (tid < n) mask[tid] = (ok && in) ? 1 : 0;
+  if (tid < 9) F_out[tid] = ok ? best[tid] : 0.0;
+  if (tid == 0) {
+    info[0] = ok ? 1 : 0;
+    info[1] = ctrl[1];
+    info[2] = ok ? count : 0;
+  }
+}
+
 }  // namespace
 
 int osfm_launch_ransac_pairs(osfm_ctx *ctx, const osfm_store *store, const int32_t *d_pairs, int64_t n_pairs, int cap,
@@ -550,8 +693,11 @@ int osfm_launch_ransac_single(osfm_ctx *ctx, const double *d_p1, const double *d
     OSFM_HIP(hipFuncSetAttribute((const void *)ransac_single_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL(ransac_single_kernel, dim3(1), dim3(kThreads), sizeof(RansacShared) + (size_t)((n + 3) & ~3) * 16 + 64, ctx->stream, d_p1, d_p2, n,
-                     thr, conf, max_iters, d_F, d_mask, d_info);
+  if (n < 15)  // cv2 switches to LMedS below 15 correspondences
+    hipLaunchKernelGGL(lmeds_single_kernel, dim3(1), dim3(64), 0, ctx->stream, d_p1, d_p2, n, conf, max_iters, d_F, d_mask, d_info);
+  else
+    hipLaunchKernelGGL(ransac_single_kernel, dim3(1), dim3(kThreads), sizeof(RansacShared) + (size_t)((n + 3) & ~3) * 16 + 64, ctx->stream, d_p1, d_p2,
+                       n, thr, conf, max_iters, d_F, d_mask, d_info);
   OSFM_HIP(hipGetLastError());
   return OSFM_OK;
 }
@@ -563,7 +709,7 @@ extern "C" int osfm_ransac_fundamental(osfm_ctx *ctx, const double *p1, const do
   if (iters_run) *iters_run = 0;
   for (int i = 0; i < n; ++i) mask[i] = 0;
   if (n < 7) return OSFM_OK;  // cv2: npoints < 7 -> empty Mat
-  OSFM_REQUIRE(n >= 15, OSFM_E_UNSUPPORTED, "n = %d < 15 takes cv2's LMedS / 7-point branch, which is not implemented", n);
+  OSFM_REQUIRE(n >= 8, OSFM_E_UNSUPPORTED, "n = 7: cv2 returns the stacked 7-point solutions; the reference requires >= 8 matches (matching.py:787)");
   OSFM_HIP(hipSetDevice(ctx->device));
   double *d_p1 = nullptr, *d_p2 = nullptr, *d_F = nullptr;
   uint8_t *d_mask = nullptr;

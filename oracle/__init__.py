@@ -93,7 +93,7 @@ def find_fundamental_ransac(p1: np.ndarray, p2: np.ndarray, thr: float = 0.004, 
     r = lib().oracle_find_fundamental_ransac(_p(p1, C.c_double), _p(p2, C.c_double), n, C.c_double(thr),
                                              C.c_double(conf), max_iters, _p(F, C.c_double), _p(mask, C.c_uint8), C.byref(it))
     if r < 0:
-        raise NotImplementedError("n < 15: cv2 takes the LMedS branch, not restated")
+        raise NotImplementedError("n == 7: cv2 returns the stacked 7-point solutions; the reference requires >= 8 matches")
     return (F.reshape(3, 3) if r == 1 else None), mask[:n].astype(bool), it.value
 
 

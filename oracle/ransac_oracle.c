@@ -312,12 +312,75 @@ static int get_subset(const double *m1, const double *m2, int count, cvrng_t *rn
  * a model was found; 0 when F would be None (mask zeroed).  n < 15 returns -1 (LMedS branch, not
  * restated in this round).
  */
+/* cv2.findFundamentalMat(FM_RANSAC) with 8 <= n < 15 correspondences silently switches to the LMedS
+ * registrator (fundam.cpp: `(method & ~3) == FM_RANSAC && npoints >= 15` else createLMeDSPointSetRegistrator).
+ * Restated from the published algorithm (ptsetreg.cpp, LMeDSPointSetRegistrator::run): a FIXED number of
+ * iterations niters = max(RANSACUpdateNumIters(confidence, 0.45, 7, maxIters), 3); per hypothesis the
+ * median (element count/2 of the sorted float errors); the model with the smallest median wins (strict <);
+ * then sigma = 2.5*1.4826*(1 + 5/(count-7))*sqrt(minMedian), clamped to >= 0.001, inliers = err <= sigma^2,
+ * success iff at least 7 inliers.  parity unpinned vs cv2 (no golden vectors; same caveats as RANSAC). */
+static int find_fundamental_lmeds(const double *p1, const double *p2, int n, double conf, int max_iters, double *F,
+                                  uint8_t *mask, int *iters_run) {
+  double m1[2 * 16], m2[2 * 16];
+  for (int i = 0; i < 2 * n; i++) {
+    m1[i] = (double)(float)p1[i];
+    m2[i] = (double)(float)p2[i];
+  }
+  if (conf < 2.220446049250313e-16 || conf > 1 - 2.220446049250313e-16) conf = 0.99;
+  cvrng_t rng = {(uint64_t)-1};
+  int niters = update_num_iters(conf, 0.45, MODEL_POINTS, max_iters);
+  if (niters < 3) niters = 3;
+  double min_median = 1.7976931348623157e308;
+  double best[9], models[27], ms1[14], ms2[14];
+  int idx[MODEL_POINTS];
+  int iter;
+  for (iter = 0; iter < niters; iter++) {
+    if (!get_subset(m1, m2, n, &rng, 10000, ms1, ms2, idx)) {
+      if (iter == 0) return 0;
+      break;
+    }
+    const int nm = run_7point(ms1, ms2, models);
+    for (int k = 0; k < nm; k++) {
+      float e[16];
+      for (int i = 0; i < n; i++) e[i] = epi_error(models + 9 * k, m1[2 * i], m1[2 * i + 1], m2[2 * i], m2[2 * i + 1]);
+      for (int i = 1; i < n; i++) { /* std::nth_element(count/2): the value at that rank */
+        const float v = e[i];
+        int j = i - 1;
+        for (; j >= 0 && e[j] > v; j--) e[j + 1] = e[j];
+        e[j + 1] = v;
+      }
+      const double median = (double)e[n / 2];
+      if (median < min_median) {
+        min_median = median;
+        memcpy(best, models + 9 * k, sizeof(best));
+      }
+    }
+  }
+  if (iters_run) *iters_run = iter;
+  if (!(min_median < 1.7976931348623157e308)) return 0;
+  double sigma = 2.5 * 1.4826 * (1 + 5. / (n - MODEL_POINTS)) * sqrt(min_median);
+  if (sigma < 0.001) sigma = 0.001;
+  const float t = (float)(sigma * sigma);
+  int count = 0;
+  for (int i = 0; i < n; i++) {
+    mask[i] = epi_error(best, m1[2 * i], m1[2 * i + 1], m2[2 * i], m2[2 * i + 1]) <= t;
+    count += mask[i];
+  }
+  memcpy(F, best, sizeof(best));
+  if (count < MODEL_POINTS) {
+    memset(mask, 0, (size_t)n);
+    return 0;
+  }
+  return 1;
+}
+
 int oracle_find_fundamental_ransac(const double *p1, const double *p2, int n, double thr,
                                    double conf, int max_iters, double *F, uint8_t *mask,
                                    int *iters_run) {
   if (iters_run) *iters_run = 0;
   memset(mask, 0, (size_t)(n > 0 ? n : 0));
-  if (n < 15) return -1;
+  if (n >= 8 && n < 15) return find_fundamental_lmeds(p1, p2, n, conf, max_iters, F, mask, iters_run);
+  if (n < 15) return -1; /* n == 7: cv2 returns all 7-point solutions stacked; the reference never gets here (matching.py:787) */
   double *m1 = (double *)malloc(sizeof(double) * 2 * (size_t)n);
   double *m2 = (double *)malloc(sizeof(double) * 2 * (size_t)n);
   for (int i = 0; i < 2 * n; i++) {

@@ -62,8 +62,22 @@ def test_ransac_is_deterministic(oracle_lib):
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
 
 
-def test_lmeds_branch_is_flagged(oracle_lib):
-    p1, p2, _ = synthetic.make_two_view(12, 1.1, 1)
+def test_lmeds_branch(oracle_lib):
+    """8 <= n < 15: cv2 runs the LMedS registrator (fixed 600 iterations at confidence 0.9999,
+    outlier ratio 0.45); the result satisfies the epipolar constraint on its inliers and is
+    deterministic.  n == 7 (stacked 7-point solutions) is outside the reference's contract."""
+    assert oracle_lib.update_num_iters(0.9999, 0.45, 1000) == 600
+    for n in (8, 11, 14):
+        p1, p2, inl = synthetic.make_two_view(n, 1.1, n)
+        F, mask, it = oracle_lib.find_fundamental_ransac(p1, p2)
+        assert F is not None and it == 600 and mask.sum() >= 7
+        x1 = np.c_[p1.astype(np.float32), np.ones(n)]
+        x2 = np.c_[p2.astype(np.float32), np.ones(n)]
+        alg = np.abs(np.einsum("ni,ij,nj->n", x2, F, x1))[mask]
+        assert alg.max() < 1e-2 * np.abs(F).max()
+        F2, mask2, _ = oracle_lib.find_fundamental_ransac(p1, p2)
+        assert np.array_equal(F, F2) and np.array_equal(mask, mask2)
+    p1, p2, _ = synthetic.make_two_view(7, 1.1, 1)
     with pytest.raises(NotImplementedError):
         oracle_lib.find_fundamental_ransac(p1, p2)
 
