@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-pairs", type=int, default=384)
     ap.add_argument("--no-ba", action="store_true")
+    ap.add_argument("--no-tracks", action="store_true")
     ap.add_argument("--ba-shots", type=int, default=5000)
     ap.add_argument("--ba-points", type=int, default=500000)
     ap.add_argument("--ba-track", type=int, default=10)
@@ -174,6 +175,8 @@ def main():
     if rank == 0:
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, pairs_all, args.cpu_sample_pairs, graph)
+        if not args.no_tracks and graph is not None:
+            out["tracks"] = tracks_bench(ctx, scene, pairs_all, graph, not args.no_cpu_baseline)
         if not args.no_ba:
             try:
                 from opensfm_amd import ba_bench
@@ -186,6 +189,42 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def tracks_bench(ctx, scene, pairs_all, graph, with_cpu):
+    """Next row after the hot path: link the all-gathered match graph into tracks
+    (tracking.create_tracks_manager's union-find + _good_track) on the GPU, next to the CPU oracle."""
+    from opensfm_amd import tracking
+
+    counts, matches = graph
+    ea, eb = tracking.edges_from_match_graph(pairs_all, counts, matches, scene.offsets)
+    tracking.create_tracks_arrays(ea[:1000], eb[:1000], scene.offsets, 2, ctx)  # warm-up (hipCUB kernels)
+    tm = {}
+    t0 = time.perf_counter()
+    nt, ot, oi, of = tracking.create_tracks_arrays(ea, eb, scene.offsets, 2, ctx, timings=tm)
+    wall = time.perf_counter() - t0
+    out = {
+        "metric": "matches linked into tracks / s",
+        "workload": f"{len(ea)} matches over {len(scene.offsets) - 1} images x {int(scene.offsets[-1])} features, min_track_length 2",
+        "value": round(len(ea) / (tm["ms_device"] * 1e-3), 1),
+        "unit": "matches/s",
+        "device_ms": round(tm["ms_device"], 3),
+        "call_ms_incl_h2d_d2h": round(1e3 * wall, 3),
+        "tracks": int(nt),
+        "observations": int(len(ot)),
+    }
+    if with_cpu:
+        import oracle
+
+        t0 = time.perf_counter()
+        nt_o, ot_o, oi_o, of_o = oracle.tracks(ea, eb, scene.offsets, 2)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {
+            "value": round(len(ea) / dt, 1), "unit": "matches/s", "cores": 1, "kind": "port",
+            "sample": f"the same {len(ea)} matches, {dt * 1e3:.1f} ms, sequential union-find in C (the reference is pure Python)",
+            "parity": bool(nt_o == nt and np.array_equal(ot_o, ot) and np.array_equal(oi_o, oi) and np.array_equal(of_o, of)),
+        }
+    return out
 
 
 def cpu_baseline(scene, pairs_all, n_sample, graph):

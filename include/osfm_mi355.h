@@ -198,6 +198,26 @@ typedef struct {
 int osfm_ba_solve(osfm_ctx *ctx, osfm_ba_problem *problem, const osfm_ba_options *options,
                   osfm_ba_report *report);
 
+/* =====================================================================================
+ * Tracks (next row after the hot path: SURVEY.md 8f-1)
+ * Replaces the grouping of tracking.create_tracks_manager (opensfm/tracking.py:68-98, union-find
+ * opensfm/unionfind.py:67-103, _good_track tracking.py:238-244): links every match
+ * (im1, f1) -- (im2, f2) into connected components, lists the components in the order of their
+ * first-inserted member, members in insertion order, keeps those with >= min_length members and
+ * no image twice; track_id = index in that list.
+ * edge_a/edge_b: global node ids in the reference's union order (pair by pair, match by match);
+ * node id of feature f of image i = node_offsets[i] + f; node_offsets has n_images + 1 entries.
+ * ===================================================================================== */
+typedef struct osfm_tracks osfm_tracks;
+int osfm_tracks_create(osfm_ctx *ctx, const int32_t *edge_a, const int32_t *edge_b, int64_t n_edges,
+                       const int64_t *node_offsets, int32_t n_images, int32_t min_length, osfm_tracks **out);
+int64_t osfm_tracks_num_tracks(const osfm_tracks *t);
+int64_t osfm_tracks_num_observations(const osfm_tracks *t);
+double osfm_tracks_device_ms(const osfm_tracks *t); /* HIP-event time of the device part */
+/* each n_observations long, grouped by track in track order, members in insertion order */
+int osfm_tracks_fetch(const osfm_tracks *t, int32_t *obs_track, int32_t *obs_image, int32_t *obs_feature);
+void osfm_tracks_destroy(osfm_tracks *t);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,6 +50,13 @@ SIGNATURES = {
     "osfm_ctx_destroy": (None, [C.c_void_p]),
     "osfm_ctx_device": (C.c_int, [C.c_void_p]),
     "osfm_ctx_num_cus": (C.c_int, [C.c_void_p]),
+    "osfm_tracks_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int64, C.POINTER(C.c_int64),
+                                     C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "osfm_tracks_num_tracks": (C.c_int64, [C.c_void_p]),
+    "osfm_tracks_num_observations": (C.c_int64, [C.c_void_p]),
+    "osfm_tracks_device_ms": (C.c_double, [C.c_void_p]),
+    "osfm_tracks_fetch": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "osfm_tracks_destroy": (None, [C.c_void_p]),
     "osfm_store_create": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_void_p)]),
     "osfm_store_upload_f32": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double)]),
     "osfm_store_upload_u8": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_double)]),

@@ -241,3 +241,21 @@ def ba_loss(loss: str, a: float, s: float):
     out = np.zeros(2)
     lib().oracle_ba_loss(LOSSES[loss], C.c_double(a), C.c_double(s), _p(out, C.c_double))
     return out[0], out[1]
+
+
+# ------------------------------------------------------------------------------------------------
+# tracks oracle (oracle/tracks_oracle.c)
+# ------------------------------------------------------------------------------------------------
+def tracks(edge_a, edge_b, node_offsets, min_length: int = 2):
+    """-> (n_tracks, obs_track, obs_image, obs_feature) -- tracking.py:82-98 + _good_track."""
+    ea = np.ascontiguousarray(edge_a, np.int32)
+    eb = np.ascontiguousarray(edge_b, np.int32)
+    off = np.ascontiguousarray(node_offsets, np.int64)
+    n = int(off[-1])
+    ot, oi, of = (np.zeros(max(n, 1), np.int32) for _ in range(3))
+    nt = C.c_int64(0)
+    f = lib().oracle_tracks
+    f.restype = C.c_int64
+    nobs = f(_p(ea, C.c_int32), _p(eb, C.c_int32), C.c_int64(len(ea)), _p(off, C.c_int64), C.c_int32(len(off) - 1),
+             C.c_int32(min_length), _p(ot, C.c_int32), _p(oi, C.c_int32), _p(of, C.c_int32), C.byref(nt))
+    return int(nt.value), ot[:nobs], oi[:nobs], of[:nobs]
