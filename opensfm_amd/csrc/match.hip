@@ -818,6 +818,9 @@ __global__ void __launch_bounds__(kThreads, 2) match_fused2_kernel(MatchArgs a) 
 // is the first one, which the ~64 pairs in flight on an XCD share in L2 (xcd_remap).
 // Results are bit-identical to v1/v2/the exact kernel/the oracle.
 // ---------------------------------------------------------------------------------------------
+constexpr int kCT4 = 8;                              // v4 stages 256 columns per chunk: half the barriers / DMA issues of v2
+constexpr int kChunkCols4 = kCT4 * 32;
+constexpr int kChunkBytes4 = kCT4 * OSFM_TILE_BYTES;  // 32 KiB, double buffered
 struct RowPassShared {
   unsigned char *bbuf;  // [2][16 KiB] chunk double buffer
   int *nbuf;            // [2][128] norms of the staged chunk
@@ -834,7 +837,7 @@ __device__ __forceinline__ int row_pass(const RowPassShared &sh, const int8_t *t
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tY = (nY + 31) >> 5;
   const int tS = (nslots + 31) >> 5;  // row tiles (slots)
-  const int nchunks = (tY + kCT - 1) / kCT;
+  const int nchunks = (tY + kCT4 - 1) / kCT4;
   const int nrb = (tS + kWaves * kRT - 1) / (kWaves * kRT);
   const int nsteps = nrb * nchunks;
   unsigned char *bbuf = sh.bbuf;
@@ -843,15 +846,15 @@ __device__ __forceinline__ int row_pass(const RowPassShared &sh, const int8_t *t
 
   // first chunk of Y: global -> registers -> LDS
   {
-    uint4 pre[kCT];
+    uint4 pre[kCT4];
 #pragma unroll
-    for (int q = 0; q < kCT; ++q) {
+    for (int q = 0; q < kCT4; ++q) {
       pre[q] = make_uint4(0, 0, 0, 0);
       if (q < tY) pre[q] = *(const uint4 *)(tilesY + (long)q * OSFM_TILE_BYTES + tid * 16);
     }
 #pragma unroll
-    for (int q = 0; q < kCT; ++q) *(uint4 *)(bbuf + q * OSFM_TILE_BYTES + tid * 16) = pre[q];
-    if (tid < kChunkCols) nbuf[tid] = (tid < tY * 32) ? normY[tid] : OSFM_PAD_NORM;
+    for (int q = 0; q < kCT4; ++q) *(uint4 *)(bbuf + q * OSFM_TILE_BYTES + tid * 16) = pre[q];
+    for (int j = tid; j < kChunkCols4; j += kThreads) nbuf[j] = (j < tY * 32) ? normY[j] : OSFM_PAD_NORM;
   }
   __syncthreads();
 
@@ -910,28 +913,28 @@ __device__ __forceinline__ int row_pass(const RowPassShared &sh, const int8_t *t
       const bool has_next = (s + 1 < nsteps);
       const int cn = (c + 1 == nchunks) ? 0 : c + 1;
       if (has_next) {
-        unsigned char *nb2 = bbuf + ((s + 1) & 1) * kChunkBytes;
+        unsigned char *nb2 = bbuf + ((s + 1) & 1) * kChunkBytes4;
 #pragma unroll
-        for (int q = 0; q < kCT; ++q) {
-          const int gt = cn * kCT + q;
+        for (int q = 0; q < kCT4; ++q) {
+          const int gt = cn * kCT4 + q;
           const int8_t *src = tilesY + (long)(gt < tY ? gt : 0) * OSFM_TILE_BYTES + tid * 16;
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                            (__attribute__((address_space(3))) void *)(nb2 + q * OSFM_TILE_BYTES + w * 1024), 16, 0, 0);
         }
-        if (w < 2) {
-          const int jn = cn * kChunkCols + tid;
+        if (w * 64 < kChunkCols4) {
+          const int jn = cn * kChunkCols4 + tid;
           const int32_t *srcn = (jn < tY * 32) ? normY + jn : sh.pad_norm;
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)srcn,
-                                           (__attribute__((address_space(3))) void *)(nbuf + ((s + 1) & 1) * kChunkCols + w * 64), 4, 0, 0);
+                                           (__attribute__((address_space(3))) void *)(nbuf + ((s + 1) & 1) * kChunkCols4 + w * 64), 4, 0, 0);
         }
       }
       // ---- compute: column tiles in pairs so that v_max3 takes two new keys per op ----
-      const unsigned char *bb = bbuf + (s & 1) * kChunkBytes;
+      const unsigned char *bb = bbuf + (s & 1) * kChunkBytes4;
       if (nrt > 0) {
 #pragma unroll
-        for (int cp2 = 0; cp2 < kCT / 2; ++cp2) {
+        for (int cp2 = 0; cp2 < kCT4 / 2; ++cp2) {
           const int ct0 = 2 * cp2, ct1 = 2 * cp2 + 1;
-          const int g0 = c * kCT + ct0, g1 = g0 + 1;
+          const int g0 = c * kCT4 + ct0, g1 = g0 + 1;
           if (g0 < tY) {
             v4i bf0[4], bf1[4];
 #pragma unroll
@@ -939,7 +942,7 @@ __device__ __forceinline__ int row_pass(const RowPassShared &sh, const int8_t *t
               bf0[ks] = *(const v4i *)(bb + ct0 * OSFM_TILE_BYTES + ks * 1024 + lane * 16);
               bf1[ks] = *(const v4i *)(bb + ct1 * OSFM_TILE_BYTES + ks * 1024 + lane * 16);
             }
-            const int *nbs = nbuf + (s & 1) * kChunkCols;
+            const int *nbs = nbuf + (s & 1) * kChunkCols4;
             const int nb0 = nbs[ct0 * 32 + (lane & 31)];
             const int nb1 = nbs[ct1 * 32 + (lane & 31)];  // padding norm when the tile does not exist: can never win
             const int ck0 = -(nb0 << 7) + (127 - g0);
@@ -982,7 +985,7 @@ __device__ __forceinline__ int row_pass(const RowPassShared &sh, const int8_t *t
       // ---- end of a row block: merge the 32 column classes of every row (see v2) ----
       if (c == nchunks - 1) {
         if (rb + 1 < nrb) load_rows(rb + 1, anext, nrm_next, xrow_next);
-        unsigned char *trb = bbuf + (s & 1) * kChunkBytes + w * 1024;
+        unsigned char *trb = bbuf + (s & 1) * kChunkBytes4 + w * 1024;
 #pragma unroll
         for (int rt = 0; rt < kRT; ++rt) {
           if (rt < nrt) {
@@ -1059,9 +1062,9 @@ __global__ void __launch_bounds__(kThreads, 2) match_fused4_kernel(MatchArgs a) 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   RowPassShared sh;
   sh.bbuf = smem;                                                  // [2][16 KiB]
-  sh.nbuf = (int *)(smem + 2 * kChunkBytes);                       // [2][128]
+  sh.nbuf = (int *)(smem + 2 * kChunkBytes4);                       // [2][128]
   sh.pad_norm = a.pad_norm;
-  int *misc = sh.nbuf + 2 * kChunkCols;                            // [16]
+  int *misc = sh.nbuf + 2 * kChunkCols4;                            // [16]
   unsigned short *resA = (unsigned short *)(misc + 16);            // [ncap] per feature of image A
   unsigned short *resB = resA + a.ncap;                            // [ncap] per feature of image B
   unsigned short *cand = resB + a.ncap;                            // [ncap] candidate list (features of B)
@@ -1251,7 +1254,7 @@ size_t osfm_match_lds_bytes(int ncap) {
 size_t osfm_match2_lds_bytes(int ncap) {
   return (size_t)2 * kChunkBytes + (size_t)ncap * 16 + 64 + kWaves * 192 * 4 + 2 * kChunkCols * 4;
 }
-size_t osfm_match4_lds_bytes(int ncap) { return (size_t)2 * kChunkBytes + 2 * kChunkCols * 4 + 64 + (size_t)ncap * 6; }
+size_t osfm_match4_lds_bytes(int ncap) { return (size_t)2 * kChunkBytes4 + 2 * kChunkCols4 * 4 + 64 + (size_t)ncap * 6; }
 static int match_kernel_version() {
   static int v = -1;
   if (v < 0) {
