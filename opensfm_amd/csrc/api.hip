@@ -219,16 +219,45 @@ extern "C" int osfm_match_pairs(osfm_ctx *ctx, const osfm_store *store, const in
   const int cap = store->max_count > 0 ? store->max_count : 1;
   const int64_t chunk_pairs = 1 << 17;  // 131072 pairs -> <= 1 GiB of match slots at cap 2048
   const int64_t cp = n_pairs < chunk_pairs ? n_pairs : chunk_pairs;
-  DevBuf d_pairs, d_counts, d_matches, d_flags, d_offsets, d_gather;
-  size_t gather_cap = 0;
+  const int64_t nchunks = (n_pairs + cp - 1) / (cp > 0 ? cp : 1);
+  // Two chunk buffer sets: while stream B runs RANSAC + gather + D2H of chunk k (a few thousand
+  // workgroups, latency bound, plus two host round trips), stream A already runs the fused matcher
+  // of chunk k + 1, which fills the machine on its own.
+  struct ChunkSet {
+    DevBuf pairs, counts, matches, flags, offsets, gather;
+    size_t gather_cap = 0;
+    hipEvent_t m0 = nullptr, m1 = nullptr, r0 = nullptr, r1 = nullptr;
+    ~ChunkSet() {
+      for (hipEvent_t ev : {m0, m1, r0, r1})
+        if (ev) (void)hipEventDestroy(ev);
+    }
+  } sets[2];
+  const int nsets = nchunks > 1 ? 2 : 1;
   hipError_t e = hipSuccess;
   bool ok = true;
-  ok = ok && (e = d_pairs.alloc((size_t)cp * 2 * sizeof(int32_t))) == hipSuccess;
-  ok = ok && (e = d_counts.alloc((size_t)cp * sizeof(int32_t))) == hipSuccess;
-  ok = ok && (e = d_flags.alloc((size_t)cp * sizeof(int32_t))) == hipSuccess;
-  ok = ok && (e = d_offsets.alloc((size_t)cp * sizeof(int64_t))) == hipSuccess;
-  ok = ok && (e = d_matches.alloc((size_t)cp * cap * sizeof(uint32_t))) == hipSuccess;
+  for (int q = 0; q < nsets; ++q) {
+    ok = ok && (e = sets[q].pairs.alloc((size_t)cp * 2 * sizeof(int32_t))) == hipSuccess;
+    ok = ok && (e = sets[q].counts.alloc((size_t)cp * sizeof(int32_t))) == hipSuccess;
+    ok = ok && (e = sets[q].flags.alloc((size_t)cp * sizeof(int32_t))) == hipSuccess;
+    ok = ok && (e = sets[q].offsets.alloc((size_t)cp * sizeof(int64_t))) == hipSuccess;
+    ok = ok && (e = sets[q].matches.alloc((size_t)cp * cap * sizeof(uint32_t))) == hipSuccess;
+    ok = ok && (e = hipEventCreate(&sets[q].m0)) == hipSuccess && (e = hipEventCreate(&sets[q].m1)) == hipSuccess;
+    ok = ok && (e = hipEventCreate(&sets[q].r0)) == hipSuccess && (e = hipEventCreate(&sets[q].r1)) == hipSuccess;
+  }
   OSFM_REQUIRE(ok, OSFM_E_NOMEM, "hipMalloc failed for match buffers: %s", hipGetErrorString(e));
+  struct StreamB {
+    hipStream_t s = nullptr;
+    ~StreamB() {
+      if (s) (void)hipStreamDestroy(s);
+    }
+  } sb;
+  OSFM_HIP(hipStreamCreateWithFlags(&sb.s, hipStreamNonBlocking));
+  hipStream_t stA = ctx->stream, stB = sb.s;
+  struct StreamSwap {  // the launch helpers use ctx->stream
+    osfm_ctx *c;
+    hipStream_t orig;
+    ~StreamSwap() { c->stream = orig; }
+  } swap_guard{ctx, stA};
 
   osfm_match_result *res = new (std::nothrow) osfm_match_result();
   OSFM_REQUIRE(res != nullptr, OSFM_E_NOMEM, "out of host memory");
@@ -240,76 +269,98 @@ extern "C" int osfm_match_pairs(osfm_ctx *ctx, const osfm_store *store, const in
   std::vector<int32_t> hflags((size_t)cp);
   std::vector<int64_t> hoff((size_t)cp);
   double ms_match = 0.0, ms_ransac = 0.0;
-  OSFM_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
-  for (int64_t p0 = 0; p0 < n_pairs; p0 += cp) {
-    const int64_t np = (n_pairs - p0) < cp ? (n_pairs - p0) : cp;
-    OSFM_HIP(hipMemcpyAsync(d_pairs.p, pairs + 2 * p0, (size_t)np * 2 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    OSFM_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+  OSFM_HIP(hipEventRecord(ctx->ev[0], stA));
+
+  auto enqueue_match = [&](int64_t k) -> int {  // stream A: pairs H2D + fused matcher (+ rare exact re-run)
+    ChunkSet &S = sets[k & 1];
+    const int64_t p0 = k * cp, np = (n_pairs - p0) < cp ? (n_pairs - p0) : cp;
+    ctx->stream = stA;
+    OSFM_HIP(hipMemcpyAsync(S.pairs.p, pairs + 2 * p0, (size_t)np * 2 * sizeof(int32_t), hipMemcpyHostToDevice, stA));
+    OSFM_HIP(hipEventRecord(S.m0, stA));
     int rc;
     if (params->reserved & 1) {
       // debug/cross-check mode: every pair on the exact VALU kernel
-      OSFM_HIP(hipMemsetAsync(d_flags.p, 0, (size_t)np * sizeof(int32_t), ctx->stream));
-      rc = osfm_launch_match(ctx, store, d_pairs.as<int32_t>(), np, params->lowes_ratio, params->symmetric, cap,
-                             d_counts.as<int32_t>(), d_matches.as<uint32_t>(), nullptr, true);
+      OSFM_HIP(hipMemsetAsync(S.flags.p, 0, (size_t)np * sizeof(int32_t), stA));
+      rc = osfm_launch_match(ctx, store, S.pairs.as<int32_t>(), np, params->lowes_ratio, params->symmetric, cap,
+                             S.counts.as<int32_t>(), S.matches.as<uint32_t>(), nullptr, true);
       if (rc != OSFM_OK) return rc;
-      OSFM_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+      OSFM_HIP(hipEventRecord(S.m1, stA));
     } else {
-      rc = osfm_launch_match(ctx, store, d_pairs.as<int32_t>(), np, params->lowes_ratio, params->symmetric, cap,
-                             d_counts.as<int32_t>(), d_matches.as<uint32_t>(), d_flags.as<int32_t>(), false);
+      rc = osfm_launch_match(ctx, store, S.pairs.as<int32_t>(), np, params->lowes_ratio, params->symmetric, cap,
+                             S.counts.as<int32_t>(), S.matches.as<uint32_t>(), S.flags.as<int32_t>(), false);
       if (rc != OSFM_OK) return rc;
-      OSFM_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+      OSFM_HIP(hipEventRecord(S.m1, stA));
       // rare exact path: pairs whose second-nearest d^2 >= 2^22 (sqrtf is not injective there)
-      rc = osfm_launch_match(ctx, store, d_pairs.as<int32_t>(), np, params->lowes_ratio, params->symmetric, cap,
-                             d_counts.as<int32_t>(), d_matches.as<uint32_t>(), d_flags.as<int32_t>(), true);
+      rc = osfm_launch_match(ctx, store, S.pairs.as<int32_t>(), np, params->lowes_ratio, params->symmetric, cap,
+                             S.counts.as<int32_t>(), S.matches.as<uint32_t>(), S.flags.as<int32_t>(), true);
       if (rc != OSFM_OK) return rc;
     }
-    OSFM_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
+    OSFM_HIP(hipEventRecord(S.r0, stA));  // everything of the descriptor stage is enqueued
+    return OSFM_OK;
+  };
+
+  if (nchunks > 0) {
+    const int rc0 = enqueue_match(0);
+    if (rc0 != OSFM_OK) return rc0;
+  }
+  for (int64_t k = 0; k < nchunks; ++k) {
+    ChunkSet &S = sets[k & 1];
+    const int64_t p0 = k * cp, np = (n_pairs - p0) < cp ? (n_pairs - p0) : cp;
+    if (k + 1 < nchunks) {  // its buffer set was released when chunk k - 1 finished (host synchronised on B)
+      const int rc1 = enqueue_match(k + 1);
+      if (rc1 != OSFM_OK) return rc1;
+    }
+    ctx->stream = stB;
+    OSFM_HIP(hipStreamWaitEvent(stB, S.r0, 0));
+    hipEvent_t rb0 = ctx->ev[3], rb1 = ctx->ev[4];
+    OSFM_HIP(hipEventRecord(rb0, stB));
     if (params->robust) {
-      rc = osfm_launch_ransac_pairs(ctx, store, d_pairs.as<int32_t>(), np, cap, params->robust_matching_min_match,
-                                    params->robust_matching_threshold, params->ransac_confidence,
-                                    params->ransac_max_iters, d_counts.as<int32_t>(), d_matches.as<uint32_t>(), nullptr);
+      const int rc = osfm_launch_ransac_pairs(ctx, store, S.pairs.as<int32_t>(), np, cap, params->robust_matching_min_match,
+                                              params->robust_matching_threshold, params->ransac_confidence,
+                                              params->ransac_max_iters, S.counts.as<int32_t>(), S.matches.as<uint32_t>(), nullptr);
       if (rc != OSFM_OK) return rc;
     }
-    OSFM_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
-    OSFM_HIP(hipMemcpyAsync(res->counts.data() + p0, d_counts.p, (size_t)np * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    OSFM_HIP(hipMemcpyAsync(hflags.data(), d_flags.p, (size_t)np * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    OSFM_HIP(hipStreamSynchronize(ctx->stream));
+    OSFM_HIP(hipEventRecord(rb1, stB));
+    OSFM_HIP(hipMemcpyAsync(res->counts.data() + p0, S.counts.p, (size_t)np * sizeof(int32_t), hipMemcpyDeviceToHost, stB));
+    OSFM_HIP(hipMemcpyAsync(hflags.data(), S.flags.p, (size_t)np * sizeof(int32_t), hipMemcpyDeviceToHost, stB));
+    OSFM_HIP(hipStreamSynchronize(stB));
     int64_t total = 0;
-    for (int64_t k = 0; k < np; ++k) {
-      int32_t &cnt = res->counts[(size_t)(p0 + k)];
+    for (int64_t q = 0; q < np; ++q) {
+      int32_t &cnt = res->counts[(size_t)(p0 + q)];
       if (cnt > cap) cnt = cap;
-      hoff[(size_t)k] = total;
+      hoff[(size_t)q] = total;
       total += cnt;
-      if (tm) tm->pairs_exact_path += hflags[(size_t)k] != 0;
+      if (tm) tm->pairs_exact_path += hflags[(size_t)q] != 0;
     }
     const size_t base = res->matches.size();
     res->matches.resize(base + (size_t)total * 2);
     if (total > 0) {
-      if ((size_t)total > gather_cap) {
-        if (d_gather.p) (void)hipFree(d_gather.p);
-        d_gather.p = nullptr;
-        gather_cap = (size_t)total + (size_t)total / 4;
-        OSFM_REQUIRE(d_gather.alloc(gather_cap * 2 * sizeof(int32_t)) == hipSuccess, OSFM_E_NOMEM,
+      if ((size_t)total > S.gather_cap) {
+        if (S.gather.p) (void)hipFree(S.gather.p);
+        S.gather.p = nullptr;
+        S.gather_cap = (size_t)total + (size_t)total / 4;
+        OSFM_REQUIRE(S.gather.alloc(S.gather_cap * 2 * sizeof(int32_t)) == hipSuccess, OSFM_E_NOMEM,
                      "hipMalloc failed for gathered matches");
       }
-      OSFM_HIP(hipMemcpyAsync(d_offsets.p, hoff.data(), (size_t)np * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
-      hipLaunchKernelGGL(gather_matches_kernel, dim3((unsigned)np), dim3(64), 0, ctx->stream, d_counts.as<int32_t>(),
-                         d_offsets.as<int64_t>(), d_matches.as<uint32_t>(), cap, d_gather.as<int32_t>(), (long)np);
+      OSFM_HIP(hipMemcpyAsync(S.offsets.p, hoff.data(), (size_t)np * sizeof(int64_t), hipMemcpyHostToDevice, stB));
+      hipLaunchKernelGGL(gather_matches_kernel, dim3((unsigned)np), dim3(64), 0, stB, S.counts.as<int32_t>(),
+                         S.offsets.as<int64_t>(), S.matches.as<uint32_t>(), cap, S.gather.as<int32_t>(), (long)np);
       OSFM_HIP(hipGetLastError());
-      OSFM_HIP(hipMemcpyAsync(res->matches.data() + base, d_gather.p, (size_t)total * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-      OSFM_HIP(hipStreamSynchronize(ctx->stream));
+      OSFM_HIP(hipMemcpyAsync(res->matches.data() + base, S.gather.p, (size_t)total * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, stB));
+      OSFM_HIP(hipStreamSynchronize(stB));
     }
     if (tm) {
       float ms = 0.f;
-      OSFM_HIP(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]));
+      OSFM_HIP(hipEventElapsedTime(&ms, S.m0, S.m1));
       ms_match += ms;
-      OSFM_HIP(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]));
+      OSFM_HIP(hipEventElapsedTime(&ms, rb0, rb1));
       ms_ransac += ms;
       tm->match_launches += 1;
     }
   }
-  OSFM_HIP(hipEventRecord(ctx->ev[5], ctx->stream));
-  OSFM_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->stream = stA;
+  OSFM_HIP(hipEventRecord(ctx->ev[5], stA));
+  OSFM_HIP(hipStreamSynchronize(stA));
   if (tm) {
     float ms = 0.f;
     OSFM_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[5]));
