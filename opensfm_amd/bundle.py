@@ -40,6 +40,10 @@ DEFAULT_CONFIG: Dict[str, Any] = {
     "radial_distortion_k2_sd": 0.01,
     "optimize_camera_parameters": True,
     "bundle_use_gps": True,
+    # opensfm/config.py:296-300
+    "local_bundle_radius": 3,
+    "local_bundle_min_common_points": 20,
+    "local_bundle_max_shots": 30,
 }
 
 
@@ -134,6 +138,134 @@ def bundle_arrays(problem: Dict[str, np.ndarray], config: Optional[Dict[str, Any
         "wall_times": {"setup": (t1 - t0) + R.seconds_setup, "run": R.seconds_run, "teardown": R.seconds_teardown},
         "num_images": len(poses), "num_points": len(pts), "num_reprojections": len(obs_shot),
     }
+
+
+# ------------------------------------------------------------------------------------------------
+# local bundle adjustment / pose-only bundle adjustment
+# ------------------------------------------------------------------------------------------------
+def _direct_shot_neighbors(obs_shot, obs_point, n_shots, n_points, inside: np.ndarray, min_common: int, max_neighbors: int):
+    """``BAHelpers::DirectShotNeighbors`` (ba_helpers.cc:68-115): shots outside ``inside`` ranked by
+    the number of points they share with it (the reference sorts an unordered_map, so ties come out
+    in an unspecified order there; here ties go to the lower shot index)."""
+    pt_in = np.zeros(n_points, bool)
+    pt_in[obs_point[inside[obs_shot]]] = True
+    sel = pt_in[obs_point] & ~inside[obs_shot]
+    common = np.bincount(obs_shot[sel], minlength=n_shots)
+    order = np.argsort(-common, kind="stable")
+    order = order[common[order] >= max(1, min_common)][:max_neighbors]
+    out = np.zeros(n_shots, bool)
+    out[order] = True
+    return out
+
+
+def shot_neighborhood(problem: Dict[str, np.ndarray], central_shot: int, radius: int, min_common_points: int,
+                      max_interior_size: int):
+    """``BAHelpers::ShotNeighborhood`` (ba_helpers.cc:36-66) on flat arrays -> (interior, boundary)
+    boolean masks over the shots (one shot per rig instance)."""
+    obs_shot = np.asarray(problem["obs_shot"], np.int64)
+    obs_point = np.asarray(problem["obs_point"], np.int64)
+    n_shots, n_points = len(problem["shot_pose"]), len(problem["points"])
+    interior = np.zeros(n_shots, bool)
+    interior[central_shot] = True
+    distance = 1
+    while distance < radius and interior.sum() < max_interior_size:
+        remaining = max_interior_size - int(interior.sum())
+        interior |= _direct_shot_neighbors(obs_shot, obs_point, n_shots, n_points, interior, min_common_points, remaining)
+        distance += 1
+    boundary = _direct_shot_neighbors(obs_shot, obs_point, n_shots, n_points, interior, 1, 1000000)
+    return interior, boundary
+
+
+def _sub_problem(problem, shots_free: np.ndarray, shots_fixed: np.ndarray, point_mask: np.ndarray, obs_mask: np.ndarray,
+                 points_fixed: bool, use_gps: bool):
+    shot_ids = np.flatnonzero(shots_free | shots_fixed)
+    pt_ids = np.flatnonzero(point_mask)
+    smap = -np.ones(len(problem["shot_pose"]), np.int64)
+    smap[shot_ids] = np.arange(len(shot_ids))
+    pmap = -np.ones(len(problem["points"]), np.int64)
+    pmap[pt_ids] = np.arange(len(pt_ids))
+    sub = {
+        "cam_params": np.asarray(problem["cam_params"], np.float64),
+        "cam_prior": np.asarray(problem.get("cam_prior", problem["cam_params"]), np.float64),
+        "cam_fixed": np.ones(len(problem["cam_params"]), np.uint8),  # constexpr bool fix_cameras{true}
+        "shot_pose": np.asarray(problem["shot_pose"], np.float64)[shot_ids],
+        "shot_camera": np.asarray(problem["shot_camera"], np.int32)[shot_ids],
+        "shot_fixed": shots_fixed[shot_ids].astype(np.uint8),
+        "points": np.asarray(problem["points"], np.float64)[pt_ids],
+        "point_fixed": np.full(len(pt_ids), 1 if points_fixed else 0, np.uint8),
+        "obs_shot": smap[np.asarray(problem["obs_shot"], np.int64)[obs_mask]].astype(np.int32),
+        "obs_point": pmap[np.asarray(problem["obs_point"], np.int64)[obs_mask]].astype(np.int32),
+        "obs_xy": np.asarray(problem["obs_xy"], np.float64)[obs_mask],
+        "obs_sigma": np.asarray(problem["obs_sigma"], np.float64)[obs_mask],
+    }
+    if "cam_sigma" in problem:
+        sub["cam_sigma"] = problem["cam_sigma"]
+    if use_gps and problem.get("shot_gps") is not None and problem.get("shot_gps_sigma") is not None:
+        sub["shot_gps"] = np.asarray(problem["shot_gps"], np.float64)[shot_ids]
+        sub["shot_gps_sigma"] = np.where(shots_free[shot_ids], np.asarray(problem["shot_gps_sigma"], np.float64)[shot_ids], 0.0)
+    return sub, shot_ids, pt_ids
+
+
+def local_problem(problem: Dict[str, np.ndarray], central_shot: int, config: Optional[Dict[str, Any]] = None):
+    """The problem ``BAHelpers::BundleLocal`` builds (ba_helpers.cc:117-222): interior shots free,
+    boundary shots and every camera constant, the points seen from the interior free, all their
+    observations from interior and boundary shots, position priors on interior shots only."""
+    interior, boundary = shot_neighborhood(problem, central_shot, int(_cfg(config, "local_bundle_radius")),
+                                           int(_cfg(config, "local_bundle_min_common_points")),
+                                           int(_cfg(config, "local_bundle_max_shots")))
+    obs_shot = np.asarray(problem["obs_shot"], np.int64)
+    obs_point = np.asarray(problem["obs_point"], np.int64)
+    point_mask = np.zeros(len(problem["points"]), bool)
+    point_mask[obs_point[interior[obs_shot]]] = True
+    obs_mask = interior[obs_shot] | (boundary[obs_shot] & point_mask[obs_point])
+    sub, shot_ids, pt_ids = _sub_problem(problem, interior, boundary, point_mask, obs_mask, False, bool(_cfg(config, "bundle_use_gps")))
+    return sub, shot_ids, pt_ids, interior, boundary
+
+
+def bundle_local_arrays(problem: Dict[str, np.ndarray], central_shot: int, config: Optional[Dict[str, Any]] = None, ctx=None,
+                        **overrides):
+    """``pysfm.BAHelpers.bundle_local`` (ba_helpers.cc:117-311) on flat arrays: 10 LM iterations over the
+    neighbourhood of ``central_shot``.  Returns (point ids, report); ``report["shot_pose"]`` /
+    ``report["points"]`` are full-size copies of the inputs with the adjusted blocks written back."""
+    sub, shot_ids, pt_ids, interior, boundary = local_problem(problem, central_shot, config)
+    cfg = dict(config or {})
+    cfg["bundle_max_iterations"] = 10  # ba.SetMaxNumIterations(10), ba_helpers.cc:259
+    r = bundle_arrays(sub, cfg, ctx=ctx, **overrides)
+    poses = np.array(problem["shot_pose"], np.float64, copy=True)
+    pts = np.array(problem["points"], np.float64, copy=True)
+    poses[shot_ids] = r["shot_pose"]
+    pts[pt_ids] = r["points"]
+    report = {
+        "brief_report": r["brief_report"], "wall_times": r["wall_times"],
+        "num_images": int(interior.sum()), "num_interior_images": int(interior.sum()),
+        "num_boundary_images": int(boundary.sum()),
+        "num_other_images": int(len(poses) - interior.sum() - boundary.sum()),
+        "num_points": int(len(pt_ids)), "num_reprojections": int(len(sub["obs_shot"])),
+        "shot_pose": poses, "points": pts, "reproj_err": r["reproj_err"], "sub_problem": sub,
+        "iterations": r["iterations"], "cost_history": r["cost_history"],
+    }
+    return pt_ids, report
+
+
+def bundle_shot_poses_arrays(problem: Dict[str, np.ndarray], shot_ids, config: Optional[Dict[str, Any]] = None, ctx=None,
+                             **overrides):
+    """``pysfm.BAHelpers.bundle_shot_poses`` (ba_helpers.cc:408-579): only the poses of ``shot_ids`` move;
+    cameras and points are constant; 10 LM iterations."""
+    free = np.zeros(len(problem["shot_pose"]), bool)
+    free[np.asarray(shot_ids, np.int64)] = True
+    obs_shot = np.asarray(problem["obs_shot"], np.int64)
+    obs_point = np.asarray(problem["obs_point"], np.int64)
+    obs_mask = free[obs_shot]
+    point_mask = np.zeros(len(problem["points"]), bool)
+    point_mask[obs_point[obs_mask]] = True
+    sub, sids, pids = _sub_problem(problem, free, np.zeros_like(free), point_mask, obs_mask, True, bool(_cfg(config, "bundle_use_gps")))
+    cfg = dict(config or {})
+    cfg["bundle_max_iterations"] = 10
+    r = bundle_arrays(sub, cfg, ctx=ctx, **overrides)
+    poses = np.array(problem["shot_pose"], np.float64, copy=True)
+    poses[sids] = r["shot_pose"]
+    return {"brief_report": r["brief_report"], "wall_times": r["wall_times"], "shot_pose": poses, "sub_problem": sub,
+            "iterations": r["iterations"], "cost_history": r["cost_history"]}
 
 
 class _Point:

@@ -202,3 +202,53 @@ def test_up_vector_prior_matches_oracle(oracle_lib, gpu_ctx):
     assert np.allclose(g["shot_pose"], o["shot_pose"], atol=1e-6)
     b = bundle.bundle_arrays(pr, {"bundle_max_iterations": 10}, preconditioner=1, **NO_TOL)  # block-Jacobi path
     assert np.allclose(b["cost_history"], o["cost_history"], rtol=1e-7)
+
+
+def test_several_cameras_one_fixed(oracle_lib, gpu_ctx):
+    """Three camera models shared cyclically by the shots (one of them held constant): the camera
+    border of the reduced system has 6 free unknowns coupled to every shot."""
+    from opensfm_amd import bundle
+
+    pr = synthetic.make_ba_scene(45, 900, 6, seed=23)
+    S = len(pr["shot_pose"])
+    base = pr["cam_params"][0]
+    pr["cam_params"] = np.array([base, base * [1.1, 0.9, 1.02], base * [0.9, 1.2, 0.99]])
+    pr["cam_prior"] = np.tile(pr["cam_prior"][0], (3, 1))
+    pr["cam_sigma"] = np.tile(pr["cam_sigma"][0], (3, 1))
+    pr["cam_fixed"] = np.array([0, 0, 1], np.uint8)
+    pr["shot_camera"] = (np.arange(S) % 3).astype(np.int32)
+    g = bundle.bundle_arrays(pr, {"bundle_max_iterations": 10}, **NO_TOL)
+    o = oracle_lib.ba_solve(pr, max_iterations=10, **NO_TOL)
+    assert g["successful_steps"] == o["successful_steps"]
+    assert np.allclose(g["cost_history"], o["cost_history"], rtol=1e-7)
+    assert abs(_rmse_px(g["reproj_err"]) - _rmse_px(o["reproj_err"])) < 1e-4
+    assert np.allclose(g["cam_params"], o["cam_params"], atol=1e-6)
+    assert np.array_equal(g["cam_params"][2], pr["cam_params"][2])
+
+
+def test_bundle_local_and_shot_poses(oracle_lib, gpu_ctx):
+    """BundleLocal / BundleShotPoses (ba_helpers.cc:117-311,408-579): neighbourhood selection, the
+    sub-problem (boundary shots, cameras [and points] constant), 10 iterations -- against the oracle
+    on the same sub-problem."""
+    from opensfm_amd import bundle
+
+    pr = synthetic.make_ba_scene(60, 1500, 8, seed=31)
+    cfg = {"local_bundle_radius": 3, "local_bundle_min_common_points": 20, "local_bundle_max_shots": 9}
+    interior, boundary = bundle.shot_neighborhood(pr, 30, 3, 20, 9)
+    assert interior[30] and 1 < interior.sum() <= 9 and boundary.sum() > 0 and not (interior & boundary).any()
+    pt_ids, rep = bundle.bundle_local_arrays(pr, 30, cfg)
+    sub = rep["sub_problem"]
+    assert sub["cam_fixed"].all() and rep["num_interior_images"] == interior.sum() and rep["num_boundary_images"] == boundary.sum()
+    o = oracle_lib.ba_solve(sub, max_iterations=10)
+    assert rep["iterations"] == o["iterations"]
+    assert np.allclose(rep["cost_history"], o["cost_history"], rtol=1e-7)
+    moved = np.abs(rep["shot_pose"] - pr["shot_pose"]).max(axis=1) > 0
+    assert np.array_equal(moved, interior)  # boundary and other shots untouched
+    assert np.allclose(rep["points"][pt_ids], o["points"], atol=1e-7)
+    sp = bundle.bundle_shot_poses_arrays(pr, [10, 11], cfg)
+    o2 = oracle_lib.ba_solve(sp["sub_problem"], max_iterations=10)
+    assert np.allclose(sp["cost_history"], o2["cost_history"], rtol=1e-7)
+    assert np.allclose(sp["shot_pose"][[10, 11]], o2["shot_pose"], atol=1e-7)
+    other = np.ones(60, bool)
+    other[[10, 11]] = False
+    assert np.array_equal(sp["shot_pose"][other], pr["shot_pose"][other])
