@@ -132,6 +132,9 @@ int osfm_ransac_fundamental(osfm_ctx *ctx, const double *p1, const double *p2, i
 #define OSFM_LOSS_HUBER 2    /* "HuberLoss"    */
 #define OSFM_LOSS_CAUCHY 3   /* "CauchyLoss"   */
 
+#define OSFM_CAMERA_PERSPECTIVE 0 /* "perspective" */
+#define OSFM_CAMERA_FISHEYE 1     /* "fisheye"     */
+
 typedef struct {
   int32_t n_cameras, n_shots, n_points;
   int64_t n_obs;
@@ -156,6 +159,11 @@ typedef struct {
      bundle_adjuster.cc:955-970): residual (R(rotation) * up - e_z) / sd per shot */
   const double *shot_up;         /* n_shots x 3 or NULL (normalised by the library)                 */
   const double *shot_up_sigma;   /* n_shots or NULL: sd (<= 0: no prior for that shot)              */
+  /* projection type per camera (geometry::ProjectionType, camera_instances.h:8-20,183-190), or NULL
+     = all PERSPECTIVE.  Both supported types carry the same parameters [k1, k2, focal]:
+     PerspectiveCamera = <PerspectiveProjection, Disto24, UniformScale>,
+     FisheyeCamera     = <FisheyeProjection,     Disto24, UniformScale>. */
+  const int32_t *cam_model;      /* n_cameras or NULL: OSFM_CAMERA_*                                */
                                  /* (ComputeReprojectionErrors, bundle_adjuster.cc:1196-1208)        */
 } osfm_ba_problem;
 

@@ -74,8 +74,39 @@ __device__ void rot_and_derivs(const double *r, double *R, double *dR /*[3][9]*/
   }
 }
 
+// PROJ stage of the camera (camera_projections_functions.h): PerspectiveProjection (:88-117) or
+// FisheyeProjection (:9-85: theta / r * (x, y), theta = atan2(r, z); perspective below r = 1e-8).
 template <bool JAC>
-__device__ __forceinline__ void project_obs(const double *X, const double *pose, const double *R, const double *dR,
+__device__ __forceinline__ void project_stage(int model, const double *Xc, double &u, double &v, double *jp) {
+  const double x = Xc[0], y = Xc[1], z = Xc[2];
+  const double r2 = x * x + y * y, r = sqrt(r2);
+  if (model == OSFM_CAMERA_FISHEYE && !(r < 1e-8)) {
+    const double theta = atan2(r, z);
+    u = theta / r * x;
+    v = theta / r * y;
+    if (JAC) {
+      const double R2 = r2 + z * z, x2 = x * x, y2 = y * y, z2 = z * z;
+      const double inv_denom = 1.0 / (r2 * R2 * r);
+      jp[0] = (x2 * y2 * theta + y2 * y2 * theta + y2 * z2 * theta + x2 * z * r) * inv_denom;
+      jp[1] = x * (y * z * r - y * theta * R2) * inv_denom;
+      jp[2] = -x / R2;
+      jp[3] = y * (x * z * r - x * theta * R2) * inv_denom;
+      jp[4] = (x2 * y2 * theta + x2 * x2 * theta + x2 * z2 * theta + y2 * z * r) * inv_denom;
+      jp[5] = -y / R2;
+    }
+    return;
+  }
+  const double iz = 1.0 / z;
+  u = x * iz;
+  v = y * iz;
+  if (JAC) {
+    jp[0] = iz; jp[1] = 0.0; jp[2] = -x * iz * iz;
+    jp[3] = 0.0; jp[4] = iz; jp[5] = -y * iz * iz;
+  }
+}
+
+template <bool JAC>
+__device__ __forceinline__ void project_obs(int model, const double *X, const double *pose, const double *R, const double *dR,
                                             const double *cam, double ox, double oy, double inv_sigma, double *res,
                                             double *Jp, double *Jc, double *Jk) {
   const double p[3] = {X[0] - pose[3], X[1] - pose[4], X[2] - pose[5]};
@@ -83,8 +114,8 @@ __device__ __forceinline__ void project_obs(const double *X, const double *pose,
 #pragma unroll
   for (int i = 0; i < 3; i++) Xc[i] = R[3 * i] * p[0] + R[3 * i + 1] * p[1] + R[3 * i + 2] * p[2];
   const double k1 = cam[0], k2 = cam[1], f = cam[2];
-  const double iz = 1.0 / Xc[2];
-  const double u = Xc[0] * iz, v = Xc[1] * iz;
+  double u, v, jp[6];
+  project_stage<JAC>(model, Xc, u, v, jp);
   const double r2 = u * u + v * v;
   const double d = 1.0 + r2 * (k1 + k2 * r2);
   res[0] = inv_sigma * (f * d * u - ox);
@@ -95,7 +126,6 @@ __device__ __forceinline__ void project_obs(const double *X, const double *pose,
   const double jd01 = u * (2.0 * k1 * v + 4.0 * k2 * v * r2);
   const double jd10 = v * (2.0 * k1 * u + 4.0 * k2 * u * r2);
   const double jd11 = 5.0 * k2 * y4 + 3.0 * k1 * y2 + 6.0 * k2 * y2 * x2 + k2 * x4 + k1 * x2 + 1.0;
-  const double jp[6] = {iz, 0.0, -Xc[0] * iz * iz, 0.0, iz, -Xc[1] * iz * iz};
   double M[6];
 #pragma unroll
   for (int j = 0; j < 3; j++) {
@@ -194,6 +224,7 @@ struct Dev {
   double *prior_rot;            // J^T J of that prior: symmetric 3x3 per shot, packed (00,10,11,20,21,22)
   const uint8_t *cam_fixed, *shot_fixed, *point_fixed;
   const int *shot_camera;
+  const int *cam_model;  // per camera (or null: all PERSPECTIVE)
   // observations, point-major
   const int *o_shot, *o_point;
   const double *o_x, *o_y, *o_sigma;
@@ -262,7 +293,7 @@ __global__ void __launch_bounds__(TPB) eval_kernel(Dev d, const double *cams, co
     const double *R = d.shotR + 36 * (long)s;
     double r[2], Jp[6], Jc[12], Jk[6];
     const double sg = SM ? d.sm_sigma[o] : d.o_sigma[o];
-    project_obs<JAC>(pts + 3 * (long)p, poses + 6 * (long)s, R, R + 9, cams + 3 * d.shot_camera[s], SM ? d.sm_x[o] : d.o_x[o],
+    project_obs<JAC>(d.cam_model ? d.cam_model[d.shot_camera[s]] : 0, pts + 3 * (long)p, poses + 6 * (long)s, R, R + 9, cams + 3 * d.shot_camera[s], SM ? d.sm_x[o] : d.o_x[o],
                      SM ? d.sm_y[o] : d.o_y[o], 1.0 / sg, r, Jp, Jc, Jk);
     const double sq = r[0] * r[0] + r[1] * r[1];
     double rho, rho1;
@@ -1904,7 +1935,7 @@ __global__ void reproj_kernel(Dev d, double *out) {
   const int s = d.o_shot[o], p = d.o_point[o];
   const double *R = d.shotR + 36 * (long)s;
   double r[2];
-  project_obs<false>(d.pts + 3 * (long)p, d.poses + 6 * (long)s, R, R + 9, d.cams + 3 * d.shot_camera[s], d.o_x[o], d.o_y[o],
+  project_obs<false>(d.cam_model ? d.cam_model[d.shot_camera[s]] : 0, d.pts + 3 * (long)p, d.poses + 6 * (long)s, R, R + 9, d.cams + 3 * d.shot_camera[s], d.o_x[o], d.o_y[o],
                      1.0, r, nullptr, nullptr, nullptr);
   out[2 * o] = r[0];
   out[2 * o + 1] = r[1];
@@ -2033,6 +2064,10 @@ extern "C" int osfm_ba_solve(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_op
                  "observation %ld references shot %d / point %d", o, P->obs_shot[o], P->obs_point[o]);
     OSFM_REQUIRE(P->obs_sigma[o] > 0, OSFM_E_INVALID, "observation %ld has std_deviation <= 0", o);
   }
+  if (P->cam_model)
+    for (int c = 0; c < NC; c++)
+      OSFM_REQUIRE(P->cam_model[c] == OSFM_CAMERA_PERSPECTIVE || P->cam_model[c] == OSFM_CAMERA_FISHEYE, OSFM_E_UNSUPPORTED,
+                   "camera %d: projection type %d is not on the GPU path (PERSPECTIVE and FISHEYE are)", c, P->cam_model[c]);
   for (int s = 0; s < S; s++)
     OSFM_REQUIRE(P->shot_camera[s] >= 0 && P->shot_camera[s] < NC, OSFM_E_INVALID, "shot %d references camera %d", s, P->shot_camera[s]);
 
@@ -2086,6 +2121,7 @@ extern "C" int osfm_ba_solve(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_op
   d.cam_sigma = A.upload(P->cam_sigma, (size_t)3 * NC, e);
   d.cam_fixed = A.upload(P->cam_fixed, (size_t)NC, e);
   d.shot_camera = A.upload(P->shot_camera, (size_t)S, e);
+  d.cam_model = P->cam_model ? A.upload(P->cam_model, (size_t)NC, e) : nullptr;
   d.shot_fixed = P->shot_fixed ? A.upload(P->shot_fixed, (size_t)S, e) : nullptr;
   d.point_fixed = P->point_fixed ? A.upload(P->point_fixed, (size_t)NP, e) : nullptr;
   d.gps = (P->shot_gps && P->shot_gps_sigma) ? A.upload(P->shot_gps, (size_t)3 * S, e) : nullptr;

@@ -169,13 +169,18 @@ def make_two_view(
 # ------------------------------------------------------------------------------------------------
 # bundle adjustment scenes (SURVEY.md 8d "Synthetic BA inputs")
 # ------------------------------------------------------------------------------------------------
-def project_perspective(X: np.ndarray, pose: np.ndarray, cam: np.ndarray) -> np.ndarray:
-    """PoseFunctor + perspective [k1, k2, focal] (transformations_functions.h:112-144,
-    camera_projections_functions.h:88-93, camera_distortions_functions.h:106-113)."""
+def project_perspective(X: np.ndarray, pose: np.ndarray, cam: np.ndarray, model: str = "perspective") -> np.ndarray:
+    """PoseFunctor + camera [k1, k2, focal] (transformations_functions.h:112-144,
+    camera_projections_functions.h:88-93 perspective / :11-22 fisheye, camera_distortions_functions.h:106-113)."""
     out = np.empty((len(X), 2))
     R = _rodrigues(-np.asarray(pose[:3], float))
     Xc = (X - pose[3:6]) @ R.T
-    u, v = Xc[:, 0] / Xc[:, 2], Xc[:, 1] / Xc[:, 2]
+    if model == "fisheye":
+        r = np.hypot(Xc[:, 0], Xc[:, 1])
+        s = np.arctan2(r, Xc[:, 2]) / np.maximum(r, 1e-300)
+        u, v = s * Xc[:, 0], s * Xc[:, 1]
+    else:
+        u, v = Xc[:, 0] / Xc[:, 2], Xc[:, 1] / Xc[:, 2]
     r2 = u * u + v * v
     d = 1 + r2 * (cam[0] + cam[1] * r2)
     out[:, 0] = cam[2] * d * u
@@ -185,7 +190,7 @@ def project_perspective(X: np.ndarray, pose: np.ndarray, cam: np.ndarray) -> np.
 
 def make_ba_scene(n_shots: int, n_points: int, track_len: int = 10, seed: int = 42, outlier_frac: float = 0.05,
                   px_noise: float = 1.0 / 2000.0, pose_noise_t: float = 0.05, pose_noise_r: float = 0.01,
-                  point_noise: float = 0.05, gps_sigma: float = 5.0, use_gps: bool = True) -> dict:
+                  point_noise: float = 0.05, gps_sigma: float = 5.0, use_gps: bool = True, model: str = "perspective") -> dict:
     """Street scene with `n_points` tracks of length `track_len` over `n_shots` cameras.
 
     Returns the flat problem dict consumed by ``bundle_arrays`` / ``oracle.ba_solve``; ground truth
@@ -211,7 +216,7 @@ def make_ba_scene(n_shots: int, n_points: int, track_len: int = 10, seed: int = 
     bounds = np.searchsorted(obs_shot, np.arange(n_shots + 1))
     for s in range(n_shots):
         a, b = bounds[s], bounds[s + 1]
-        xy[a:b] = project_perspective(gt_pts[obs_point[a:b]], gt_pose[s], cam)
+        xy[a:b] = project_perspective(gt_pts[obs_point[a:b]], gt_pose[s], cam, model)
     xy += rng.normal(0, px_noise, xy.shape)
     out = rng.random(len(xy)) < outlier_frac
     xy[out] += rng.uniform(-0.03, 0.03, (int(out.sum()), 2))  # gross mismatches: up to +-60 px at 2000 px
@@ -239,4 +244,6 @@ def make_ba_scene(n_shots: int, n_points: int, track_len: int = 10, seed: int = 
     if use_gps:
         prob["shot_gps"] = gt_pose[:, 3:6] + rng.normal(0, gps_sigma / 10.0, (n_shots, 3))
         prob["shot_gps_sigma"] = np.full(n_shots, gps_sigma)
+    if model != "perspective":
+        prob["cam_model"] = np.full(1, {"perspective": 0, "fisheye": 1}[model], np.int32)
     return prob

@@ -60,6 +60,7 @@ typedef struct {
      r = (R(rot) * up - e_z) / sd, CauchyLoss(1) per shot; NULL or sd <= 0: none */
   const double *shot_up;       /* n_shots x 3 (normalised here) or NULL */
   const double *shot_up_sigma; /* n_shots or NULL */
+  const int32_t *cam_model;    /* n_cameras or NULL: 0 PERSPECTIVE, 1 FISHEYE (camera_instances.h:183-190) */
 } ba_problem;
 
 typedef struct {
@@ -131,15 +132,42 @@ static void rot_and_derivs(const double *r, double R[9], double dR[3][9]) {
 
 /* One observation: residual (pi - o)/sigma and Jacobians 2x3 (point), 2x6 (pose), 2x3 (k1,k2,f),
  * already multiplied by 1/sigma (projection_errors.h:150-205).  R, dR: of the shot. */
-static void project_obs(const double *X, const double *pose, const double *R, const double (*dR)[9],
+/* PROJ stage (camera_projections_functions.h): PerspectiveProjection :88-117 or FisheyeProjection :9-85
+ * (theta / r * (x, y), theta = atan2(r, z), r = |(x, y)|; perspective below r = 1e-8).  uv (2), jp (2x3). */
+static void project_stage(int model, const double *Xc, double *uv, double *jp) {
+  const double x = Xc[0], y = Xc[1], z = Xc[2];
+  const double r2 = x * x + y * y, r = sqrt(r2);
+  if (model == 1 && !(r < 1e-8)) {
+    const double theta = atan2(r, z);
+    uv[0] = theta / r * x;
+    uv[1] = theta / r * y;
+    const double R2 = r2 + z * z, x2 = x * x, y2 = y * y, z2 = z * z;
+    const double inv_denom = 1.0 / (r2 * R2 * r);
+    jp[0] = (x2 * y2 * theta + y2 * y2 * theta + y2 * z2 * theta + x2 * z * r) * inv_denom;
+    jp[1] = x * (y * z * r - y * theta * R2) * inv_denom;
+    jp[2] = -x / R2;
+    jp[3] = y * (x * z * r - x * theta * R2) * inv_denom;
+    jp[4] = (x2 * y2 * theta + x2 * x2 * theta + x2 * z2 * theta + y2 * z * r) * inv_denom;
+    jp[5] = -y / R2;
+    return;
+  }
+  const double iz = 1.0 / z;
+  uv[0] = x * iz;
+  uv[1] = y * iz;
+  jp[0] = iz; jp[1] = 0.0; jp[2] = -x * iz * iz;
+  jp[3] = 0.0; jp[4] = iz; jp[5] = -y * iz * iz;
+}
+
+static void project_obs(int model, const double *X, const double *pose, const double *R, const double (*dR)[9],
                         const double *cam, const double *obs, double inv_sigma, double *res,
                         double *Jp, double *Jc, double *Jk) {
   const double p[3] = {X[0] - pose[3], X[1] - pose[4], X[2] - pose[5]};
   double Xc[3];
   for (int i = 0; i < 3; i++) Xc[i] = R[3 * i] * p[0] + R[3 * i + 1] * p[1] + R[3 * i + 2] * p[2];
   const double k1 = cam[0], k2 = cam[1], f = cam[2];
-  const double iz = 1.0 / Xc[2];
-  const double u = Xc[0] * iz, v = Xc[1] * iz;
+  double uv[2], jp[6];
+  project_stage(model, Xc, uv, jp);
+  const double u = uv[0], v = uv[1];
   const double r2 = u * u + v * v;
   const double d = 1.0 + r2 * (k1 + k2 * r2);
   res[0] = inv_sigma * (f * d * u - obs[0]);
@@ -151,7 +179,6 @@ static void project_obs(const double *X, const double *pose, const double *R, co
   const double jd01 = u * (2.0 * k1 * v + 4.0 * k2 * v * r2);
   const double jd10 = v * (2.0 * k1 * u + 4.0 * k2 * u * r2);
   const double jd11 = 5.0 * k2 * y4 + 3.0 * k1 * y2 + 6.0 * k2 * y2 * x2 + k2 * x4 + k1 * x2 + 1.0;
-  const double jp[6] = {iz, 0.0, -Xc[0] * iz * iz, 0.0, iz, -Xc[1] * iz * iz};
   double M[6]; /* 2x3 = f * Jd * Jproj * inv_sigma */
   for (int j = 0; j < 3; j++) {
     M[j] = inv_sigma * f * (jd00 * jp[j] + jd01 * jp[3 + j]);
@@ -209,10 +236,10 @@ static void loss_eval(int loss, double a, double s, double *rho, double *rho1) {
 
 /* exposed for the golden-vector tests */
 void oracle_ba_project(const double *X, const double *pose, const double *cam, const double *obs,
-                       double sigma, double *res, double *Jp, double *Jc, double *Jk) {
+                       double sigma, double *res, double *Jp, double *Jc, double *Jk, int model) {
   double R[9], dR[3][9];
   rot_and_derivs(pose, R, dR);
-  project_obs(X, pose, R, (const double (*)[9])dR, cam, obs, 1.0 / sigma, res, Jp, Jc, Jk);
+  project_obs(model, X, pose, R, (const double (*)[9])dR, cam, obs, 1.0 / sigma, res, Jp, Jc, Jk);
 }
 void oracle_ba_loss(int loss, double a, double s, double *out2) { loss_eval(loss, a, s, &out2[0], &out2[1]); }
 
@@ -274,8 +301,8 @@ static double eval_cost(const ba_ctx *C, const double *cams, const double *poses
     const double *R = Rall + 36 * (size_t)s;
     double r[2], Jp[6], Jc[12], Jk[6];
     const double isg = 1.0 / P->obs_sigma[o];
-    project_obs(pts + 3 * (size_t)p, poses + 6 * (size_t)s, R, (const double (*)[9])(R + 9),
-                cams + 3 * (size_t)P->shot_camera[s], P->obs_xy + 2 * o, isg, r, with_jac ? Jp : NULL, Jc, Jk);
+    project_obs(P->cam_model ? P->cam_model[P->shot_camera[s]] : 0, pts + 3 * (size_t)p, poses + 6 * (size_t)s, R,
+                (const double (*)[9])(R + 9), cams + 3 * (size_t)P->shot_camera[s], P->obs_xy + 2 * o, isg, r, with_jac ? Jp : NULL, Jc, Jk);
     const double sq = r[0] * r[0] + r[1] * r[1];
     double rho, rho1;
     loss_eval(C->O->loss, C->O->loss_threshold, sq, &rho, &rho1);
@@ -871,7 +898,7 @@ int oracle_ba_solve(ba_problem *P, const ba_options *O, ba_report *Rp) {
       const int s = P->obs_shot[o], p = P->obs_point[o];
       double R[9], dR[3][9], r[2];
       rot_and_derivs(poses + 6 * s, R, dR);
-      project_obs(pts + 3 * (size_t)p, poses + 6 * (size_t)s, R, (const double (*)[9])dR,
+      project_obs(P->cam_model ? P->cam_model[P->shot_camera[s]] : 0, pts + 3 * (size_t)p, poses + 6 * (size_t)s, R, (const double (*)[9])dR,
                   cams + 3 * (size_t)P->shot_camera[s], P->obs_xy + 2 * o, 1.0, r, NULL, NULL, NULL);
       if (P->reproj_err) {
         P->reproj_err[2 * o] = r[0];

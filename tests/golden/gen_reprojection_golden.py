@@ -4,7 +4,8 @@ reprojection error at the reference's OWN test inputs, evaluated independently o
 Inputs: opensfm/src/bundle/test/reprojection_errors_test.cc:17-18,105-111,123-128 (point (1,2,3),
 rt (0.1..0.6), observed (0.5,0.5), std_deviation 0.1, perspective camera array {0.3, 0.1, -0.03}
 in native parameter order [k1, k2, focal]) and opensfm/src/geometry/test/camera_functions_test.cc
-(point (0.1,0.2,0.3) style inputs, focal 0.4, k1 -0.1, k2 0.01).  The reference's expected values
+(point (0.1,0.2,0.3) style inputs, focal 0.4, k1 -0.1, k2 0.01); the FISHEYE cases use the fisheye test's
+inputs (reprojection_errors_test.cc:131-137) and FisheyeProjection::Forward (camera_projections_functions.h:11-22).  The reference's expected values
 are "autodiff of the same formulas"; here the formulas of transformations_functions.h:112-144,
 camera_projections_functions.h:88-93, camera_distortions_functions.h:106-113,
 transformations_functions.h:55-58 and projection_errors.h:203-205 are written in mpmath (50
@@ -21,7 +22,7 @@ import mpmath as mp
 mp.mp.dps = 50
 
 
-def residual(X, pose, cam, obs, sd):
+def residual(X, pose, cam, obs, sd, model="perspective"):
     r, t = pose[:3], pose[3:]
     p = [X[i] - t[i] for i in range(3)]
     a = [-r[i] for i in range(3)]
@@ -34,7 +35,12 @@ def residual(X, pose, cam, obs, sd):
         Xc = [p[i] * c + s * cp[i] + a[i] * dot for i in range(3)]
     else:
         Xc = [p[i] + cp[i] for i in range(3)]
-    u, v = Xc[0] / Xc[2], Xc[1] / Xc[2]
+    if model == "fisheye":  # camera_projections_functions.h:11-22 (FisheyeProjection::Forward)
+        r = mp.sqrt(Xc[0] ** 2 + Xc[1] ** 2)
+        theta = mp.atan2(r, Xc[2])
+        u, v = theta / r * Xc[0], theta / r * Xc[1]
+    else:
+        u, v = Xc[0] / Xc[2], Xc[1] / Xc[2]
     r2 = u * u + v * v
     k1, k2, f = cam
     d = 1 + r2 * (k1 + k2 * r2)
@@ -64,6 +70,11 @@ CASES = [
     dict(X=[0.5, 0.4, 6.0], pose=[1e-9, -2e-9, 1e-9, 0.1, 0.0, 0.0], cam=[-0.1, 0.01, 0.7], obs=[0.1, 0.1], sd=0.004),
     dict(X=[0.5, 0.4, 6.0], pose=[1e-4, -2e-4, 1e-4, 0.1, 0.0, 0.0], cam=[-0.1, 0.01, 0.7], obs=[0.1, 0.1], sd=0.004),
     dict(X=[-2.0, 1.0, 5.0], pose=[1.2, -0.7, 2.1, -1.0, 0.3, 0.8], cam=[0.05, -0.002, 0.9], obs=[-0.2, 0.3], sd=0.01),
+    # reprojection_errors_test.cc:131-137 FisheyeAnalyticErrorEvaluatesOK inputs (same point / pose / camera array)
+    dict(model="fisheye", X=[1.0, 2.0, 3.0], pose=[0.1, 0.2, 0.3, 0.4, 0.5, 0.6], cam=[0.3, 0.1, -0.03], obs=[0.5, 0.5], sd=0.1),
+    # fisheye, wide angle (70 degrees off axis) and a point behind the image plane (theta > 90 degrees)
+    dict(model="fisheye", X=[5.5, -1.0, 2.0], pose=[0.02, -0.03, 0.01, 0.1, 0.05, -0.02], cam=[-0.05, 0.004, 0.45], obs=[0.3, -0.1], sd=0.004),
+    dict(model="fisheye", X=[2.0, 1.5, -0.5], pose=[0.3, 0.1, -0.2, 0.0, 0.1, 0.2], cam=[-0.02, 0.001, 0.4], obs=[0.4, 0.35], sd=0.004),
 ]
 
 
@@ -75,10 +86,11 @@ def main():
         cam = [mp.mpf(repr(v)) for v in c["cam"]]
         obs = [mp.mpf(repr(v)) for v in c["obs"]]
         sd = mp.mpf(repr(c["sd"]))
-        r = residual(X, pose, cam, obs, sd)
-        Jp = jac(lambda x: residual(x, pose, cam, obs, sd), X)
-        Jc = jac(lambda x: residual(X, x, cam, obs, sd), pose)
-        Jk = jac(lambda x: residual(X, pose, x, obs, sd), cam)
+        model = c.get("model", "perspective")
+        r = residual(X, pose, cam, obs, sd, model)
+        Jp = jac(lambda x: residual(x, pose, cam, obs, sd, model), X)
+        Jc = jac(lambda x: residual(X, x, cam, obs, sd, model), pose)
+        Jk = jac(lambda x: residual(X, pose, x, obs, sd, model), cam)
         f = lambda m: [[float(v) for v in row] for row in m]
         out.append(dict(c, residual=[float(v) for v in r], Jp=f(Jp), Jc=f(Jc), Jk=f(Jk)))
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reprojection_golden.json")

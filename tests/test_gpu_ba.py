@@ -252,3 +252,25 @@ def test_bundle_local_and_shot_poses(oracle_lib, gpu_ctx):
     other = np.ones(60, bool)
     other[[10, 11]] = False
     assert np.array_equal(sp["shot_pose"][other], pr["shot_pose"][other])
+
+
+def test_fisheye_camera_model(oracle_lib, gpu_ctx):
+    """FisheyeCamera = <FisheyeProjection, Disto24, UniformScale> (camera_instances.h:187): same
+    [k1, k2, focal] parameters, equidistant projection; mixed with a perspective camera."""
+    from opensfm_amd import bundle
+
+    pr = synthetic.make_ba_scene(30, 600, 6, seed=41, model="fisheye")
+    g = bundle.bundle_arrays(pr, {"bundle_max_iterations": 10}, **NO_TOL)
+    o = oracle_lib.ba_solve(pr, max_iterations=10, **NO_TOL)
+    assert g["successful_steps"] == o["successful_steps"]
+    assert np.allclose(g["cost_history"], o["cost_history"], rtol=1e-7)
+    assert abs(_rmse_px(g["reproj_err"]) - _rmse_px(o["reproj_err"])) < 1e-4
+    assert np.allclose(g["cam_params"], o["cam_params"], atol=1e-6)
+    assert _rmse_px(g["reproj_err"], ~pr["is_outlier"]) < 2.5
+    # solving the fisheye data with the perspective model must NOT fit (the model flag is honoured)
+    pr_wrong = dict(pr)
+    pr_wrong.pop("cam_model")
+    w = bundle.bundle_arrays(pr_wrong, {"bundle_max_iterations": 10}, **NO_TOL)
+    assert w["final_cost"] > 1.05 * g["final_cost"]  # narrow field of view: Disto24 absorbs most of the difference
+    z = bundle.bundle_arrays(pr, {"bundle_max_iterations": 0})
+    assert np.allclose(z["reproj_err"], oracle_lib.ba_solve(pr, max_iterations=0)["reproj_err"], rtol=0, atol=1e-13)
