@@ -928,58 +928,77 @@ __device__ __forceinline__ int row_pass(const RowPassShared &sh, const int8_t *t
                                            (__attribute__((address_space(3))) void *)(nbuf + ((s + 1) & 1) * kChunkCols4 + w * 64), 4, 0, 0);
         }
       }
-      // ---- compute: column tiles in pairs so that v_max3 takes two new keys per op ----
+      // ---- compute: a hand-made software pipeline over the step's 8 work items ----
+      // item = (pair of column tiles, row tile): 8 MFMAs (two accumulation chains) + a 48-op integer
+      // epilogue (2 v_lshl_add + 1 v_max3 per row register).  Inside one wavefront the chain
+      // LDS read -> MFMA -> epilogue is strictly dependent, and with two waves per SIMD the hardware
+      // cannot hide it (tools/ubench_overlap.hip: +24 % from pipelining exactly this shape).  So:
+      // the B operands of the NEXT pair are read from LDS one pair ahead, and every MFMA of item i+1 is
+      // followed by one eighth of the epilogue of item i, pinned with sched_barrier; operands and
+      // accumulators ping-pong between two register sets (no copies).  Branch-free: row tiles beyond the
+      // image have zero operands and padding norms, column tiles beyond it carry the padding norm, so
+      // neither can win.
       const unsigned char *bb = bbuf + (s & 1) * kChunkBytes4;
       if (nrt > 0) {
-#pragma unroll
-        for (int cp2 = 0; cp2 < kCT4 / 2; ++cp2) {
-          const int ct0 = 2 * cp2, ct1 = 2 * cp2 + 1;
-          const int g0 = c * kCT4 + ct0, g1 = g0 + 1;
-          if (g0 < tY) {
-            v4i bf0[4], bf1[4];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-              bf0[ks] = *(const v4i *)(bb + ct0 * OSFM_TILE_BYTES + ks * 1024 + lane * 16);
-              bf1[ks] = *(const v4i *)(bb + ct1 * OSFM_TILE_BYTES + ks * 1024 + lane * 16);
-            }
-            const int *nbs = nbuf + (s & 1) * kChunkCols4;
-            const int nb0 = nbs[ct0 * 32 + (lane & 31)];
-            const int nb1 = nbs[ct1 * 32 + (lane & 31)];  // padding norm when the tile does not exist: can never win
-            const int ck0 = -(nb0 << 7) + (127 - g0);
-            const int ck1 = -(nb1 << 7) + (127 - (g1 & 127));
-#pragma unroll
-            for (int rt = 0; rt < kRT; ++rt) {
-              if (rt < nrt) {
-                v16i acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                v16i acc1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const int *nbs = nbuf + (s & 1) * kChunkCols4;
+        v4i bf[2][2][4];
+        int ck[2][2];
+        v16i acc[2][2];
+#define OSFM_LOAD_PAIR(BUF, PR)                                                                              \
+  {                                                                                                          \
+    _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                          \
+      _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                       \
+        bf[BUF][h][ks] = *(const v4i *)(bb + (2 * (PR) + h) * OSFM_TILE_BYTES + ks * 1024 + lane * 16);     \
+      const int nb = nbs[(2 * (PR) + h) * 32 + (lane & 31)];                                                 \
+      ck[BUF][h] = -(nb << 7) + (127 - ((c * kCT4 + 2 * (PR) + h) & 127));                                   \
+    }                                                                                                        \
+  }
 #ifdef OSFM_DBG_NOMFMA
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                  acc0[ks] += afrag[rt][ks][0] ^ bf0[ks][1];
-                  acc1[ks] += afrag[rt][ks][1] ^ bf1[ks][0];
-                }
+#define OSFM_MFMA(AB, RT, BUF, I) acc[AB][(I) & 1][(I) >> 1] += afrag[RT][(I) >> 1][0] ^ bf[BUF][(I) & 1][(I) >> 1][1];
 #else
-                // the two accumulation chains are interleaved: a dependent back-to-back MFMA issues
-                // ~1.5x slower than an independent one (measured: 6.2 vs 4.1 ms of pure MFMA time)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                  acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[rt][ks], bf0[ks], acc0, 0, 0, 0);
-                  acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[rt][ks], bf1[ks], acc1, 0, 0, 0);
-                }
+#define OSFM_MFMA(AB, RT, BUF, I) \
+  acc[AB][(I) & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[RT][(I) >> 1], bf[BUF][(I) & 1][(I) >> 1], acc[AB][(I) & 1], 0, 0, 0);
 #endif
 #ifdef OSFM_DBG_NOEPI
-                rbst[rt][0] = max(rbst[rt][0], acc0[0] + acc1[5] + ck0 + ck1);
+#define OSFM_EPI(AB, RT, BUF, I) \
+  if ((I) == 7) rbst[RT][0] = max(rbst[RT][0], acc[AB][0][0] + acc[AB][1][5] + ck[BUF][0] + ck[BUF][1]);
 #else
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                  const int k0 = (acc0[r] << 8) + ck0, k1 = (acc1[r] << 8) + ck1;
-                  rbst[rt][r] = max(max(rbst[rt][r], k0), k1);
-                }
+#define OSFM_EPI(AB, RT, BUF, I)                                                                             \
+  {                                                                                                          \
+    _Pragma("unroll") for (int rr = 2 * (I); rr < 2 * (I) + 2; ++rr) {                                       \
+      const int k0 = (acc[AB][0][rr] << 8) + ck[BUF][0], k1 = (acc[AB][1][rr] << 8) + ck[BUF][1];            \
+      rbst[RT][rr] = max(max(rbst[RT][rr], k0), k1);                                                         \
+    }                                                                                                        \
+  }
 #endif
-              }
-            }
+        const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        OSFM_LOAD_PAIR(0, 0)
+        acc[0][0] = zero16;
+        acc[0][1] = zero16;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) OSFM_MFMA(0, 0, 0, i)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int item = 1; item < kCT4; ++item) {  // kCT4 / 2 pairs x 2 row tiles = kCT4 items
+          const int pr = item >> 1, rt = item & 1, buf = pr & 1, ab = item & 1;
+          const int ppr = (item - 1) >> 1, prt = (item - 1) & 1, pbuf = ppr & 1, pab = (item - 1) & 1;
+          if (rt == 1 && pr + 1 < kCT4 / 2) OSFM_LOAD_PAIR(buf ^ 1, pr + 1)  // one pair ahead of its first use
+          acc[ab][0] = zero16;
+          acc[ab][1] = zero16;
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            OSFM_MFMA(ab, rt, buf, i)
+            __builtin_amdgcn_sched_barrier(0);
+            OSFM_EPI(pab, prt, pbuf, i)
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) OSFM_EPI((kCT4 - 1) & 1, (kCT4 - 1) & 1, ((kCT4 - 1) >> 1) & 1, i)
+#undef OSFM_LOAD_PAIR
+#undef OSFM_MFMA
+#undef OSFM_EPI
       }
       __syncthreads();
       // ---- end of a row block: merge the 32 column classes of every row (see v2) ----
