@@ -129,7 +129,7 @@ def main():
         "peak": PEAK_I8_TOPS,
         "unit": "TFLOP/s",
         "frac": round(achieved / PEAK_I8_TOPS, 4),
-        "traffic": None,
+        "traffic": None,  # PMC passes cannot run inside this process: see profiles/r01_final_match_pmc.txt (36.7 GB read / launch)
         "avg_launch_ms": round(avg_ms, 3),
         "launches": launches,
         "algorithmic_flop_per_pair": flop_pair,
