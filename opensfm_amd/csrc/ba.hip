@@ -1944,6 +1944,35 @@ __global__ void reproj_kernel(Dev d, double *out) {
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
+// ---- setup helpers: the observation arrays are permuted on the device (host only builds the index lists) ----
+__global__ void gather_pm_kernel(const int *perm, const double *raw_xy, const double *raw_sigma, long M, double *o_x, double *o_y,
+                                 double *o_sigma) {
+  const long k = (long)blockIdx.x * TPB + threadIdx.x;
+  if (k >= M) return;
+  const long o = perm[k];
+  o_x[k] = raw_xy[2 * o];
+  o_y[k] = raw_xy[2 * o + 1];
+  o_sigma[k] = raw_sigma[o];
+}
+__global__ void gather_sm_kernel(const int *shot_obs, const int *o_shot, const int *o_point, const double *o_x, const double *o_y,
+                                 const double *o_sigma, long M, int *s_shot, int *s_point, double *s_x, double *s_y, double *s_sigma) {
+  const long k = (long)blockIdx.x * TPB + threadIdx.x;
+  if (k >= M) return;
+  const long o = shot_obs[k];
+  s_shot[k] = o_shot[o];
+  s_point[k] = o_point[o];
+  s_x[k] = o_x[o];
+  s_y[k] = o_y[o];
+  s_sigma[k] = o_sigma[o];
+}
+__global__ void unpermute2_kernel(const int *perm, const double *in, long M, double *out) {
+  const long k = (long)blockIdx.x * TPB + threadIdx.x;
+  if (k >= M) return;
+  const long o = perm[k];
+  out[2 * o] = in[2 * k];
+  out[2 * o + 1] = in[2 * k + 1];
+}
+
 struct Arena {
   std::vector<void *> ptrs;
   ~Arena() {
@@ -2075,20 +2104,19 @@ extern "C" int osfm_ba_solve(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_op
   std::vector<long> pt_off((size_t)NP + 1, 0), shot_off((size_t)S + 1, 0);
   for (long o = 0; o < M; o++) pt_off[(size_t)P->obs_point[o] + 1]++;
   for (int p = 0; p < NP; p++) pt_off[(size_t)p + 1] += pt_off[p];
-  std::vector<long> perm((size_t)M);  // point-major position -> original index
+  OSFM_REQUIRE(M < (1L << 31), OSFM_E_UNSUPPORTED, "more than 2^31 observations");
+  std::vector<int> perm((size_t)M);  // point-major position -> original index
   {
     std::vector<long> fill(pt_off.begin(), pt_off.end() - 1);
-    for (long o = 0; o < M; o++) perm[(size_t)fill[(size_t)P->obs_point[o]]++] = o;
+    for (long o = 0; o < M; o++) perm[(size_t)fill[(size_t)P->obs_point[o]]++] = (int)o;
   }
+  // only the two index arrays are permuted on the host (the shot lists and the band width need them);
+  // coordinates and sigmas are uploaded as they are and gathered on the device
   std::vector<int> o_shot((size_t)M), o_point((size_t)M), shot_obs((size_t)M);
-  std::vector<double> o_x((size_t)M), o_y((size_t)M), o_sg((size_t)M);
   for (long k = 0; k < M; k++) {
     const long o = perm[(size_t)k];
     o_shot[(size_t)k] = P->obs_shot[o];
     o_point[(size_t)k] = P->obs_point[o];
-    o_x[(size_t)k] = P->obs_xy[2 * o];
-    o_y[(size_t)k] = P->obs_xy[2 * o + 1];
-    o_sg[(size_t)k] = P->obs_sigma[o];
     shot_off[(size_t)o_shot[(size_t)k] + 1]++;
   }
   for (int s = 0; s < S; s++) shot_off[(size_t)s + 1] += shot_off[s];
@@ -2096,7 +2124,6 @@ extern "C" int osfm_ba_solve(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_op
     std::vector<long> fill(shot_off.begin(), shot_off.end() - 1);
     for (long k = 0; k < M; k++) shot_obs[(size_t)fill[(size_t)o_shot[(size_t)k]]++] = (int)k;
   }
-  OSFM_REQUIRE(M < (1L << 31), OSFM_E_UNSUPPORTED, "more than 2^31 observations");
 
   // ---- device image ----
   Arena A;
@@ -2142,9 +2169,15 @@ extern "C" int osfm_ba_solve(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_op
   }
   d.o_shot = A.upload(o_shot.data(), (size_t)M, e);
   d.o_point = A.upload(o_point.data(), (size_t)M, e);
-  d.o_x = A.upload(o_x.data(), (size_t)M, e);
-  d.o_y = A.upload(o_y.data(), (size_t)M, e);
-  d.o_sigma = A.upload(o_sg.data(), (size_t)M, e);
+  int *d_perm = A.upload(perm.data(), (size_t)M, e);
+  {
+    double *raw_xy = A.upload(P->obs_xy, (size_t)2 * M, e), *raw_sg = A.upload(P->obs_sigma, (size_t)M, e);
+    double *ox = A.alloc<double>((size_t)M, e), *oy = A.alloc<double>((size_t)M, e), *osg = A.alloc<double>((size_t)M, e);
+    if (e == hipSuccess) hipLaunchKernelGGL(gather_pm_kernel, dim3(nblk(M)), dim3(TPB), 0, sv.st, d_perm, raw_xy, raw_sg, M, ox, oy, osg);
+    d.o_x = ox;
+    d.o_y = oy;
+    d.o_sigma = osg;
+  }
   d.pt_off = A.upload(pt_off.data(), (size_t)NP + 1, e);
   {
     std::vector<int> wg_pt;
@@ -2165,21 +2198,16 @@ extern "C" int osfm_ba_solve(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_op
   d.Jpm = A.alloc<double>((size_t)26 * M, e);
   d.Jsm = A.alloc<double>((size_t)26 * M, e);
   {
-    std::vector<int> sshot((size_t)M), spoint((size_t)M);
-    std::vector<double> sx((size_t)M), sy((size_t)M), ssg((size_t)M);
-    for (long k = 0; k < M; k++) {
-      const long o = shot_obs[(size_t)k];
-      sshot[(size_t)k] = o_shot[(size_t)o];
-      spoint[(size_t)k] = o_point[(size_t)o];
-      sx[(size_t)k] = o_x[(size_t)o];
-      sy[(size_t)k] = o_y[(size_t)o];
-      ssg[(size_t)k] = o_sg[(size_t)o];
-    }
-    d.sm_shot = A.upload(sshot.data(), (size_t)M, e);
-    d.sm_point = A.upload(spoint.data(), (size_t)M, e);
-    d.sm_x = A.upload(sx.data(), (size_t)M, e);
-    d.sm_y = A.upload(sy.data(), (size_t)M, e);
-    d.sm_sigma = A.upload(ssg.data(), (size_t)M, e);
+    int *ss = A.alloc<int>((size_t)M, e), *sp = A.alloc<int>((size_t)M, e);
+    double *sx = A.alloc<double>((size_t)M, e), *sy = A.alloc<double>((size_t)M, e), *ssg = A.alloc<double>((size_t)M, e);
+    if (e == hipSuccess)
+      hipLaunchKernelGGL(gather_sm_kernel, dim3(nblk(M)), dim3(TPB), 0, sv.st, d.shot_obs, d.o_shot, d.o_point, d.o_x, d.o_y, d.o_sigma, M, ss,
+                         sp, sx, sy, ssg);
+    d.sm_shot = ss;
+    d.sm_point = sp;
+    d.sm_x = sx;
+    d.sm_y = sy;
+    d.sm_sigma = ssg;
   }
   d.w = A.alloc<double>((size_t)2 * M, e);
   d.g_pt = A.alloc<double>((size_t)3 * NP, e);
@@ -2464,17 +2492,13 @@ extern "C" int osfm_ba_solve(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_op
   OSFM_HIP(hipMemcpyAsync(P->cam_params, d.cams, (size_t)3 * NC * sizeof(double), hipMemcpyDeviceToHost, st));
   OSFM_HIP(hipMemcpyAsync(P->shot_pose, d.poses, (size_t)6 * S * sizeof(double), hipMemcpyDeviceToHost, st));
   OSFM_HIP(hipMemcpyAsync(P->points, d.pts, (size_t)3 * NP * sizeof(double), hipMemcpyDeviceToHost, st));
-  std::vector<double> rp;
-  if (d_reproj) {
-    rp.resize((size_t)2 * M);
-    OSFM_HIP(hipMemcpyAsync(rp.data(), d_reproj, (size_t)2 * M * sizeof(double), hipMemcpyDeviceToHost, st));
+  if (d_reproj) {  // back to the caller's observation order on the device, one contiguous copy
+    double *d_out = A.alloc<double>((size_t)2 * M, e);
+    OSFM_REQUIRE(e == hipSuccess, OSFM_E_NOMEM, "BA device allocation failed: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(unpermute2_kernel, dim3(nblk(M)), dim3(TPB), 0, st, d_perm, d_reproj, M, d_out);
+    OSFM_HIP(hipMemcpyAsync(P->reproj_err, d_out, (size_t)2 * M * sizeof(double), hipMemcpyDeviceToHost, st));
   }
   OSFM_HIP(hipStreamSynchronize(st));
-  if (d_reproj)
-    for (long k = 0; k < M; k++) {
-      P->reproj_err[2 * perm[(size_t)k]] = rp[(size_t)2 * k];
-      P->reproj_err[2 * perm[(size_t)k] + 1] = rp[(size_t)2 * k + 1];
-    }
   Rp->rmse_normalized_final = std::sqrt(sumsq / (double)M);
   Rp->seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
   Rp->seconds_teardown = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_tear).count();
