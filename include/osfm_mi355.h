@@ -201,6 +201,10 @@ typedef struct {
   /* wall_times of BAHelpers::Bundle (ba_helpers.cc:749-753): setup = index build + H2D,
      run = the LM loop (what ceres::Solve covers), teardown = D2H of parameters and errors */
   double seconds_setup, seconds_run, seconds_teardown;
+  /* 1: the shots were renumbered internally (reverse Cuthill-McKee on the co-visibility graph) because
+     the caller's order had a half-width above what the banded preconditioner holds; shot_bandwidth is
+     then the half-width after renumbering and shot_bandwidth_input the caller's. */
+  int32_t shots_reordered, shot_bandwidth_input;
 } osfm_ba_report;
 
 int osfm_ba_solve(osfm_ctx *ctx, osfm_ba_problem *problem, const osfm_ba_options *options,

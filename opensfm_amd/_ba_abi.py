@@ -35,6 +35,7 @@ class BaReport(C.Structure):
         ("pcg_iterations_total", C.c_int64), ("ms_matvec_total", C.c_double), ("matvec_calls", C.c_int64),
         ("shot_bandwidth", C.c_int32), ("preconditioner_bandwidth", C.c_int32),
         ("seconds_setup", C.c_double), ("seconds_run", C.c_double), ("seconds_teardown", C.c_double),
+        ("shots_reordered", C.c_int32), ("shot_bandwidth_input", C.c_int32),
     ]
 
 

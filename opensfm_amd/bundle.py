@@ -131,6 +131,7 @@ def bundle_arrays(problem: Dict[str, np.ndarray], config: Optional[Dict[str, Any
         "cost_history": np.array(R.cost_history[: min(R.iterations, 255) + 1]),
         "pcg_iterations": int(R.pcg_iterations_total),
         "shot_bandwidth": int(R.shot_bandwidth), "preconditioner_bandwidth": int(R.preconditioner_bandwidth),
+        "shots_reordered": bool(R.shots_reordered), "shot_bandwidth_input": int(R.shot_bandwidth_input),
         "seconds_solver": R.seconds_total, "seconds_linear_solver": R.seconds_linear_solver,
         "seconds_setup": R.seconds_setup, "seconds_run": R.seconds_run, "seconds_teardown": R.seconds_teardown,
         "ms_per_matvec": (R.ms_matvec_total / R.matvec_calls) if R.matvec_calls else None,

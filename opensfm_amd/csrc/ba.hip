@@ -2076,7 +2076,159 @@ extern "C" void osfm_ba_options_default(osfm_ba_options *o) {
   o->preconditioner = 0;
 }
 
+// ---- shot ordering --------------------------------------------------------------------------------
+// The banded preconditioner needs shots that share points to be close in index.  Sequences come that
+// way; unordered collections do not.  When the caller's order has a co-visibility half-width above
+// what the band can hold, the shots are renumbered by reverse Cuthill-McKee on the co-visibility
+// graph (chain links inside every track: O(observations)); the solve runs in that numbering and the
+// poses are written back in the caller's.  Pure relabelling: results are unchanged.
+static int covis_half_bandwidth(const osfm_ba_problem *P, const std::vector<int> &new_of_old) {
+  const int NP = P->n_points;
+  std::vector<int> mn((size_t)NP, 1 << 30), mx((size_t)NP, -1);
+  for (long o = 0; o < P->n_obs; o++) {
+    const int s = new_of_old[(size_t)P->obs_shot[o]], p = P->obs_point[o];
+    mn[(size_t)p] = std::min(mn[(size_t)p], s);
+    mx[(size_t)p] = std::max(mx[(size_t)p], s);
+  }
+  int bw = 0;
+  for (int p = 0; p < NP; p++)
+    if (mx[(size_t)p] >= 0) bw = std::max(bw, mx[(size_t)p] - mn[(size_t)p]);
+  return bw;
+}
+
+static void rcm_shot_order(const osfm_ba_problem *P, std::vector<int> &new_of_old) {
+  const int S = P->n_shots, NP = P->n_points;
+  const long M = P->n_obs;
+  // chain links: consecutive observations of a point (in the caller's order) connect their shots
+  std::vector<int> last((size_t)NP, -1);
+  std::vector<long> deg((size_t)S + 1, 0);
+  for (long o = 0; o < M; o++) {
+    const int s = P->obs_shot[o], p = P->obs_point[o];
+    if (last[(size_t)p] >= 0 && last[(size_t)p] != s) {
+      deg[(size_t)s + 1]++;
+      deg[(size_t)last[(size_t)p] + 1]++;
+    }
+    last[(size_t)p] = s;
+  }
+  for (int s = 0; s < S; s++) deg[(size_t)s + 1] += deg[(size_t)s];
+  std::vector<int> adj((size_t)deg[(size_t)S]);
+  {
+    std::vector<long> fill(deg.begin(), deg.end() - 1);
+    std::fill(last.begin(), last.end(), -1);
+    for (long o = 0; o < M; o++) {
+      const int s = P->obs_shot[o], p = P->obs_point[o];
+      const int l = last[(size_t)p];
+      if (l >= 0 && l != s) {
+        adj[(size_t)fill[(size_t)s]++] = l;
+        adj[(size_t)fill[(size_t)l]++] = s;
+      }
+      last[(size_t)p] = s;
+    }
+  }
+  auto degree = [&](int v) { return deg[(size_t)v + 1] - deg[(size_t)v]; };
+  std::vector<int> order;
+  order.reserve((size_t)S);
+  std::vector<char> seen((size_t)S, 0);
+  std::vector<int> level((size_t)S, 0), nb;
+  auto bfs = [&](int root, std::vector<int> &out, bool commit) -> int {  // returns the last vertex of the deepest level
+    std::vector<char> vis = commit ? std::vector<char>() : std::vector<char>(seen);
+    std::vector<char> &mark = commit ? seen : vis;
+    const size_t start = out.size();
+    out.push_back(root);
+    mark[(size_t)root] = 1;
+    for (size_t h = start; h < out.size(); h++) {
+      const int v = out[h];
+      nb.clear();
+      for (long q = deg[(size_t)v]; q < deg[(size_t)v + 1]; q++) {
+        const int u = adj[(size_t)q];
+        if (!mark[(size_t)u]) {
+          mark[(size_t)u] = 1;
+          nb.push_back(u);
+        }
+      }
+      std::sort(nb.begin(), nb.end(), [&](int a, int b) { return degree(a) != degree(b) ? degree(a) < degree(b) : a < b; });
+      for (int u : nb) out.push_back(u);
+    }
+    const int far = out.back();
+    if (!commit) out.resize(start);
+    return far;
+  };
+  for (int s0 = 0; s0 < S; s0++) {
+    if (seen[(size_t)s0]) continue;
+    // pseudo-peripheral start: the far end of a BFS from the far end of a BFS
+    int root = s0;
+    for (int sweep = 0; sweep < 2; sweep++) root = bfs(root, order, false);
+    bfs(root, order, true);
+  }
+  new_of_old.assign((size_t)S, 0);
+  for (int i = 0; i < S; i++) new_of_old[(size_t)order[(size_t)(S - 1 - i)]] = i;  // reversed
+}
+
+static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_options *O, osfm_ba_report *Rp);
+
 extern "C" int osfm_ba_solve(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_options *O, osfm_ba_report *Rp) {
+  OSFM_REQUIRE(ctx && P && O && Rp, OSFM_E_INVALID, "osfm_ba_solve: null argument");
+  if (!(P->n_shots > 2 && P->n_points > 0 && P->n_obs > 0 && P->obs_shot && P->obs_point && P->shot_pose && P->shot_camera) ||
+      O->preconditioner == 1)
+    return ba_solve_impl(ctx, P, O, Rp);
+  const int S = P->n_shots;
+  for (long o = 0; o < P->n_obs; o++)
+    if (P->obs_shot[o] < 0 || P->obs_shot[o] >= S || P->obs_point[o] < 0 || P->obs_point[o] >= P->n_points)
+      return ba_solve_impl(ctx, P, O, Rp);  // reports the invalid index
+  std::vector<int> ident((size_t)S), new_of_old;
+  for (int s = 0; s < S; s++) ident[(size_t)s] = s;
+  const int bw0 = covis_half_bandwidth(P, ident);
+  if (bw0 <= 10) return ba_solve_impl(ctx, P, O, Rp);  // already a narrow band: the exact cyclic-reduction path
+  rcm_shot_order(P, new_of_old);
+  const int bw1 = covis_half_bandwidth(P, new_of_old);
+  if (bw1 >= bw0) return ba_solve_impl(ctx, P, O, Rp);
+  // relabelled copy of every per-shot input
+  std::vector<int> old_of_new((size_t)S);
+  for (int s = 0; s < S; s++) old_of_new[(size_t)new_of_old[(size_t)s]] = s;
+  std::vector<double> pose((size_t)6 * S), gps, gps_sg, up, up_sg;
+  std::vector<int32_t> cam((size_t)S), oshot((size_t)P->n_obs);
+  std::vector<uint8_t> fixed;
+  for (int i = 0; i < S; i++) {
+    const int q = old_of_new[(size_t)i];
+    for (int k = 0; k < 6; k++) pose[(size_t)6 * i + k] = P->shot_pose[6 * (size_t)q + k];
+    cam[(size_t)i] = P->shot_camera[q];
+  }
+  auto permute = [&](const double *src, int width, std::vector<double> &dst) {
+    dst.resize((size_t)width * S);
+    for (int i = 0; i < S; i++)
+      for (int k = 0; k < width; k++) dst[(size_t)width * i + k] = src[(size_t)width * old_of_new[(size_t)i] + k];
+  };
+  osfm_ba_problem Q = *P;
+  Q.shot_pose = pose.data();
+  Q.shot_camera = cam.data();
+  if (P->shot_fixed) {
+    fixed.resize((size_t)S);
+    for (int i = 0; i < S; i++) fixed[(size_t)i] = P->shot_fixed[old_of_new[(size_t)i]];
+    Q.shot_fixed = fixed.data();
+  }
+  if (P->shot_gps && P->shot_gps_sigma) {
+    permute(P->shot_gps, 3, gps);
+    permute(P->shot_gps_sigma, 1, gps_sg);
+    Q.shot_gps = gps.data();
+    Q.shot_gps_sigma = gps_sg.data();
+  }
+  if (P->shot_up && P->shot_up_sigma) {
+    permute(P->shot_up, 3, up);
+    permute(P->shot_up_sigma, 1, up_sg);
+    Q.shot_up = up.data();
+    Q.shot_up_sigma = up_sg.data();
+  }
+  for (long o = 0; o < P->n_obs; o++) oshot[(size_t)o] = new_of_old[(size_t)P->obs_shot[o]];
+  Q.obs_shot = oshot.data();
+  const int rc = ba_solve_impl(ctx, &Q, O, Rp);
+  for (int i = 0; i < S; i++)
+    for (int k = 0; k < 6; k++) P->shot_pose[6 * (size_t)old_of_new[(size_t)i] + k] = pose[(size_t)6 * i + k];
+  Rp->shots_reordered = 1;
+  Rp->shot_bandwidth_input = bw0;
+  return rc;
+}
+
+static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_options *O, osfm_ba_report *Rp) {
   OSFM_REQUIRE(ctx && P && O && Rp, OSFM_E_INVALID, "osfm_ba_solve: null argument");
   OSFM_REQUIRE(P->n_cameras > 0 && P->n_shots > 0 && P->n_points > 0 && P->n_obs > 0, OSFM_E_INVALID, "empty BA problem");
   OSFM_REQUIRE(P->cam_params && P->cam_prior && P->cam_sigma && P->cam_fixed && P->shot_pose && P->shot_camera && P->points &&
