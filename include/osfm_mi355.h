@@ -134,6 +134,15 @@ int osfm_ransac_fundamental(osfm_ctx *ctx, const double *p1, const double *p2, i
 
 #define OSFM_CAMERA_PERSPECTIVE 0 /* "perspective" */
 #define OSFM_CAMERA_FISHEYE 1     /* "fisheye"     */
+/* the other 2-D projection types: as CONSTANT cameras only (cam_fixed = 1 + cam_ext), which is how
+   BundleLocal / BundleShotPoses always use cameras (ba_helpers.cc:137,415) */
+#define OSFM_CAMERA_BROWN 2          /* [k1 k2 k3 p1 p2 | focal ar cx cy]                    */
+#define OSFM_CAMERA_FISHEYE_OPENCV 3 /* [k1 k2 k3 k4 | focal ar cx cy]                       */
+#define OSFM_CAMERA_FISHEYE62 4      /* [k1..k6 p1 p2 | focal ar cx cy]                      */
+#define OSFM_CAMERA_FISHEYE624 5     /* [k1..k6 p1 p2 s0 s1 s2 s3 | focal ar cx cy]          */
+#define OSFM_CAMERA_DUAL 6           /* [transition | k1 k2 | focal]                         */
+#define OSFM_CAMERA_RADIAL 7         /* [k1 k2 | focal ar cx cy]                             */
+#define OSFM_CAMERA_SIMPLE_RADIAL 8  /* [k1 | focal ar cx cy]                                */
 
 typedef struct {
   int32_t n_cameras, n_shots, n_points;
@@ -164,6 +173,9 @@ typedef struct {
      PerspectiveCamera = <PerspectiveProjection, Disto24, UniformScale>,
      FisheyeCamera     = <FisheyeProjection,     Disto24, UniformScale>. */
   const int32_t *cam_model;      /* n_cameras or NULL: OSFM_CAMERA_*                                */
+  /* native parameters [projection][distortion][affine] (camera_instances.h:127-160), 16 per camera,
+     of the constant cameras whose cam_model is >= 2; NULL when there are none */
+  const double *cam_ext;         /* n_cameras x 16 or NULL                                          */
                                  /* (ComputeReprojectionErrors, bundle_adjuster.cc:1196-1208)        */
 } osfm_ba_problem;
 

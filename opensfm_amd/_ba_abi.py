@@ -13,7 +13,7 @@ class BaProblem(C.Structure):
         ("obs_shot", C.POINTER(C.c_int32)), ("obs_point", C.POINTER(C.c_int32)),
         ("obs_xy", C.POINTER(C.c_double)), ("obs_sigma", C.POINTER(C.c_double)), ("reproj_err", C.POINTER(C.c_double)),
         ("shot_up", C.POINTER(C.c_double)), ("shot_up_sigma", C.POINTER(C.c_double)),
-        ("cam_model", C.POINTER(C.c_int32)),
+        ("cam_model", C.POINTER(C.c_int32)), ("cam_ext", C.POINTER(C.c_double)),
     ]
 
 

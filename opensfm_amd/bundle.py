@@ -107,7 +107,7 @@ def bundle_arrays(problem: Dict[str, np.ndarray], config: Optional[Dict[str, Any
     for key, t, ct in (("shot_fixed", np.uint8, C.c_uint8), ("point_fixed", np.uint8, C.c_uint8),
                        ("shot_gps", np.float64, C.c_double), ("shot_gps_sigma", np.float64, C.c_double),
                        ("shot_up", np.float64, C.c_double), ("shot_up_sigma", np.float64, C.c_double),
-                       ("cam_model", np.int32, C.c_int32)):
+                       ("cam_model", np.int32, C.c_int32), ("cam_ext", np.float64, C.c_double)):
         if problem.get(key) is not None and (use_gps or not key.startswith("shot_gps")):
             arr = np.ascontiguousarray(problem[key], t)
             keep.append(arr)
@@ -200,7 +200,7 @@ def _sub_problem(problem, shots_free: np.ndarray, shots_fixed: np.ndarray, point
         "obs_xy": np.asarray(problem["obs_xy"], np.float64)[obs_mask],
         "obs_sigma": np.asarray(problem["obs_sigma"], np.float64)[obs_mask],
     }
-    for key in ("cam_sigma", "cam_model"):
+    for key in ("cam_sigma", "cam_model", "cam_ext"):
         if key in problem:
             sub[key] = problem[key]
     if use_gps and problem.get("shot_gps") is not None and problem.get("shot_gps_sigma") is not None:

@@ -105,6 +105,93 @@ __device__ __forceinline__ void project_stage(int model, const double *Xc, doubl
   }
 }
 
+// ---- the other 2-D camera models, for CONSTANT cameras (no intrinsics Jacobian needed) ----------------
+// ProjectGeneric<PROJ, DISTO, AFF> (camera_instances.h:127-160), parameters [PROJ][DISTO][AFF] in the
+// reference's native order.  The 2x2 Jacobian of the distortion stage is taken by forward-mode duals
+// (what the reference's autodiff twin does with the same formulas), the projection stage analytically.
+struct D2 {
+  double v, a, b;  // value, d/dx, d/dy
+};
+__device__ __forceinline__ D2 d2c(double c) { return D2{c, 0.0, 0.0}; }
+__device__ __forceinline__ D2 operator+(D2 p, D2 q) { return D2{p.v + q.v, p.a + q.a, p.b + q.b}; }
+__device__ __forceinline__ D2 operator*(D2 p, D2 q) { return D2{p.v * q.v, p.a * q.v + p.v * q.a, p.b * q.v + p.v * q.b}; }
+__device__ __forceinline__ D2 operator*(D2 p, double c) { return D2{p.v * c, p.a * c, p.b * c}; }
+
+__device__ __forceinline__ void model_layout(int model, int &proj, int &kind, int &nd, int &na) {
+  switch (model) {
+    case OSFM_CAMERA_BROWN: proj = 0; kind = 3; nd = 5; na = 4; break;
+    case OSFM_CAMERA_FISHEYE_OPENCV: proj = 1; kind = 2; nd = 4; na = 4; break;
+    case OSFM_CAMERA_FISHEYE62: proj = 1; kind = 4; nd = 8; na = 4; break;
+    case OSFM_CAMERA_FISHEYE624: proj = 1; kind = 5; nd = 12; na = 4; break;
+    case OSFM_CAMERA_DUAL: proj = 2; kind = 1; nd = 2; na = 1; break;
+    case OSFM_CAMERA_RADIAL: proj = 0; kind = 1; nd = 2; na = 4; break;
+    default: proj = 0; kind = 0; nd = 1; na = 4; break;  // SIMPLE_RADIAL
+  }
+}
+
+__device__ void distort_d2(int kind, const double *k, D2 x, D2 y, D2 &ox, D2 &oy) {
+  const D2 r2 = x * x + y * y;
+  D2 rad, tx = d2c(0.0), ty = d2c(0.0);
+  switch (kind) {
+    case 0: rad = d2c(1.0) + r2 * k[0]; break;
+    case 1: rad = d2c(1.0) + r2 * (d2c(k[0]) + r2 * k[1]); break;
+    case 2: rad = d2c(1.0) + r2 * (d2c(k[0]) + r2 * (d2c(k[1]) + r2 * (d2c(k[2]) + r2 * k[3]))); break;
+    case 3: rad = d2c(1.0) + r2 * (d2c(k[0]) + r2 * (d2c(k[1]) + r2 * k[2])); break;
+    default: {  // six radial coefficients, Horner as RadialDistortion (camera_distortions_functions.h:481-485)
+      D2 acc = d2c(k[4]) + r2 * k[5];
+      acc = d2c(k[3]) + r2 * acc;
+      acc = d2c(k[2]) + r2 * acc;
+      acc = d2c(k[1]) + r2 * acc;
+      acc = d2c(k[0]) + r2 * acc;
+      rad = d2c(1.0) + r2 * acc;
+    } break;
+  }
+  if (kind >= 3) {  // tangential: 2 p1 x y + p2 (r2 + 2 x^2), 2 p2 x y + p1 (r2 + 2 y^2)
+    const double p1 = kind == 3 ? k[3] : k[6], p2 = kind == 3 ? k[4] : k[7];
+    const D2 xy = x * y;
+    tx = xy * (2.0 * p1) + (r2 + (x * x) * 2.0) * p2;
+    ty = xy * (2.0 * p2) + (r2 + (y * y) * 2.0) * p1;
+  }
+  if (kind == 5) {  // thin prism: s0 r2 + s1 r2^2, s2 r2 + s3 r2^2
+    const D2 r4 = r2 * r2;
+    tx = tx + (r2 * k[8] + r4 * k[9]);
+    ty = ty + (r2 * k[10] + r4 * k[11]);
+  }
+  ox = x * rad + tx;
+  oy = y * rad + ty;
+}
+
+// projection of a camera-frame point by a constant camera of model >= 2: out (2), J (2x3 w.r.t. Xc)
+template <bool JAC>
+__device__ void project_generic(int model, const double *par, const double *Xc, double *out, double *J) {
+  int proj, kind, nd, na;
+  model_layout(model, proj, kind, nd, na);
+  const double *kd = par + (proj == 2 ? 1 : 0), *ka = kd + nd;
+  double u, v, jp[6];
+  if (proj == 2) {  // DualProjection: t * perspective + (1 - t) * fisheye (camera_projections_functions.h:122-134)
+    double ua, va, ja[6], ub, vb, jb[6];
+    project_stage<true>(OSFM_CAMERA_PERSPECTIVE, Xc, ua, va, ja);
+    project_stage<true>(OSFM_CAMERA_FISHEYE, Xc, ub, vb, jb);
+    const double t = par[0];
+    u = t * ua + (1.0 - t) * ub;
+    v = t * va + (1.0 - t) * vb;
+    for (int i = 0; i < 6; i++) jp[i] = t * ja[i] + (1.0 - t) * jb[i];
+  } else {
+    project_stage<true>(proj, Xc, u, v, jp);
+  }
+  D2 dx, dy;
+  distort_d2(kind, kd, D2{u, 1.0, 0.0}, D2{v, 0.0, 1.0}, dx, dy);
+  const double fx = ka[0], fy = na == 4 ? ka[0] * ka[1] : ka[0];
+  const double cx = na == 4 ? ka[2] : 0.0, cy = na == 4 ? ka[3] : 0.0;
+  out[0] = fx * dx.v + cx;
+  out[1] = fy * dy.v + cy;
+  if (JAC)
+    for (int j = 0; j < 3; j++) {
+      J[j] = fx * (dx.a * jp[j] + dx.b * jp[3 + j]);
+      J[3 + j] = fy * (dy.a * jp[j] + dy.b * jp[3 + j]);
+    }
+}
+
 template <bool JAC>
 __device__ __forceinline__ void project_obs(int model, const double *X, const double *pose, const double *R, const double *dR,
                                             const double *cam, double ox, double oy, double inv_sigma, double *res,
@@ -113,6 +200,27 @@ __device__ __forceinline__ void project_obs(int model, const double *X, const do
   double Xc[3];
 #pragma unroll
   for (int i = 0; i < 3; i++) Xc[i] = R[3 * i] * p[0] + R[3 * i + 1] * p[1] + R[3 * i + 2] * p[2];
+  if (model >= 2) {  // constant camera of another 2-D model: cam points at its 16 native parameters
+    double out[2], J[6], M[6];
+    project_generic<JAC>(model, cam, Xc, out, J);
+    res[0] = inv_sigma * (out[0] - ox);
+    res[1] = inv_sigma * (out[1] - oy);
+    if (!JAC) return;
+    for (int j = 0; j < 6; j++) M[j] = inv_sigma * J[j];
+    for (int i = 0; i < 2; i++)
+      for (int j = 0; j < 3; j++) {
+        const double mr = M[3 * i] * R[j] + M[3 * i + 1] * R[3 + j] + M[3 * i + 2] * R[6 + j];
+        Jp[3 * i + j] = mr;
+        Jc[6 * i + 3 + j] = -mr;
+      }
+    for (int k = 0; k < 3; k++) {
+      double q[3];
+      for (int i = 0; i < 3; i++) q[i] = dR[9 * k + 3 * i] * p[0] + dR[9 * k + 3 * i + 1] * p[1] + dR[9 * k + 3 * i + 2] * p[2];
+      for (int i = 0; i < 2; i++) Jc[6 * i + k] = -(M[3 * i] * q[0] + M[3 * i + 1] * q[1] + M[3 * i + 2] * q[2]);
+    }
+    for (int i = 0; i < 6; i++) Jk[i] = 0.0;
+    return;
+  }
   const double k1 = cam[0], k2 = cam[1], f = cam[2];
   double u, v, jp[6];
   project_stage<JAC>(model, Xc, u, v, jp);
@@ -225,6 +333,7 @@ struct Dev {
   const uint8_t *cam_fixed, *shot_fixed, *point_fixed;
   const int *shot_camera;
   const int *cam_model;  // per camera (or null: all PERSPECTIVE)
+  const double *cam_ext; // 16 native parameters per camera, for the constant cameras of models >= 2
   // observations, point-major
   const int *o_shot, *o_point;
   const double *o_x, *o_y, *o_sigma;
@@ -293,7 +402,9 @@ __global__ void __launch_bounds__(TPB) eval_kernel(Dev d, const double *cams, co
     const double *R = d.shotR + 36 * (long)s;
     double r[2], Jp[6], Jc[12], Jk[6];
     const double sg = SM ? d.sm_sigma[o] : d.o_sigma[o];
-    project_obs<JAC>(d.cam_model ? d.cam_model[d.shot_camera[s]] : 0, pts + 3 * (long)p, poses + 6 * (long)s, R, R + 9, cams + 3 * d.shot_camera[s], SM ? d.sm_x[o] : d.o_x[o],
+    const int cmodel = d.cam_model ? d.cam_model[d.shot_camera[s]] : 0;
+    project_obs<JAC>(cmodel, pts + 3 * (long)p, poses + 6 * (long)s, R, R + 9,
+                     cmodel >= 2 ? d.cam_ext + 16 * d.shot_camera[s] : cams + 3 * d.shot_camera[s], SM ? d.sm_x[o] : d.o_x[o],
                      SM ? d.sm_y[o] : d.o_y[o], 1.0 / sg, r, Jp, Jc, Jk);
     const double sq = r[0] * r[0] + r[1] * r[1];
     double rho, rho1;
@@ -1935,7 +2046,9 @@ __global__ void reproj_kernel(Dev d, double *out) {
   const int s = d.o_shot[o], p = d.o_point[o];
   const double *R = d.shotR + 36 * (long)s;
   double r[2];
-  project_obs<false>(d.cam_model ? d.cam_model[d.shot_camera[s]] : 0, d.pts + 3 * (long)p, d.poses + 6 * (long)s, R, R + 9, d.cams + 3 * d.shot_camera[s], d.o_x[o], d.o_y[o],
+  const int cmodel = d.cam_model ? d.cam_model[d.shot_camera[s]] : 0;
+  project_obs<false>(cmodel, d.pts + 3 * (long)p, d.poses + 6 * (long)s, R, R + 9,
+                     cmodel >= 2 ? d.cam_ext + 16 * d.shot_camera[s] : d.cams + 3 * d.shot_camera[s], d.o_x[o], d.o_y[o],
                      1.0, r, nullptr, nullptr, nullptr);
   out[2 * o] = r[0];
   out[2 * o + 1] = r[1];
@@ -2247,8 +2360,13 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
   }
   if (P->cam_model)
     for (int c = 0; c < NC; c++)
-      OSFM_REQUIRE(P->cam_model[c] == OSFM_CAMERA_PERSPECTIVE || P->cam_model[c] == OSFM_CAMERA_FISHEYE, OSFM_E_UNSUPPORTED,
-                   "camera %d: projection type %d is not on the GPU path (PERSPECTIVE and FISHEYE are)", c, P->cam_model[c]);
+    {
+      OSFM_REQUIRE(P->cam_model[c] >= OSFM_CAMERA_PERSPECTIVE && P->cam_model[c] <= OSFM_CAMERA_SIMPLE_RADIAL, OSFM_E_UNSUPPORTED,
+                   "camera %d: projection type %d is not on the GPU path (SPHERICAL has a 3-D residual)", c, P->cam_model[c]);
+      OSFM_REQUIRE(P->cam_model[c] < 2 || (P->cam_fixed[c] && P->cam_ext), OSFM_E_UNSUPPORTED,
+                   "camera %d: projection type %d is supported as a CONSTANT camera only (cam_fixed = 1 and cam_ext given); its "
+                   "intrinsics are not optimised on the GPU path", c, P->cam_model[c]);
+    }
   for (int s = 0; s < S; s++)
     OSFM_REQUIRE(P->shot_camera[s] >= 0 && P->shot_camera[s] < NC, OSFM_E_INVALID, "shot %d references camera %d", s, P->shot_camera[s]);
 
@@ -2301,6 +2419,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
   d.cam_fixed = A.upload(P->cam_fixed, (size_t)NC, e);
   d.shot_camera = A.upload(P->shot_camera, (size_t)S, e);
   d.cam_model = P->cam_model ? A.upload(P->cam_model, (size_t)NC, e) : nullptr;
+  d.cam_ext = P->cam_ext ? A.upload(P->cam_ext, (size_t)16 * NC, e) : nullptr;
   d.shot_fixed = P->shot_fixed ? A.upload(P->shot_fixed, (size_t)S, e) : nullptr;
   d.point_fixed = P->point_fixed ? A.upload(P->point_fixed, (size_t)NP, e) : nullptr;
   d.gps = (P->shot_gps && P->shot_gps_sigma) ? A.upload(P->shot_gps, (size_t)3 * S, e) : nullptr;

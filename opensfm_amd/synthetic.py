@@ -169,6 +169,59 @@ def make_two_view(
 # ------------------------------------------------------------------------------------------------
 # bundle adjustment scenes (SURVEY.md 8d "Synthetic BA inputs")
 # ------------------------------------------------------------------------------------------------
+# model -> (projection, distortion, #distortion parameters, #affine parameters) -- camera_instances.h:183-192
+GENERIC_MODELS = {
+    "brown": ("perspective", "brown", 5, 4), "fisheye_opencv": ("fisheye", "disto2468", 4, 4),
+    "fisheye62": ("fisheye", "disto62", 8, 4), "fisheye624": ("fisheye", "disto624", 12, 4),
+    "dual": ("dual", "disto24", 2, 1), "radial": ("perspective", "disto24", 2, 4),
+    "simple_radial": ("perspective", "disto2", 1, 4),
+}
+CAMERA_MODEL_IDS = {"perspective": 0, "fisheye": 1, "brown": 2, "fisheye_opencv": 3, "fisheye62": 4, "fisheye624": 5, "dual": 6,
+                    "radial": 7, "simple_radial": 8}
+
+
+def project_generic(X: np.ndarray, pose: np.ndarray, par: np.ndarray, model: str) -> np.ndarray:
+    """ProjectGeneric<PROJ, DISTO, AFF>::Forward for the other 2-D models, parameters in the native
+    order [projection][distortion][affine] (camera_instances.h:127-160)."""
+    proj, disto, nd, na = GENERIC_MODELS[model]
+    R = _rodrigues(-np.asarray(pose[:3], float))
+    Xc = (X - pose[3:6]) @ R.T
+    k = list(np.asarray(par, float))
+    pu, pv = Xc[:, 0] / Xc[:, 2], Xc[:, 1] / Xc[:, 2]
+    r = np.hypot(Xc[:, 0], Xc[:, 1])
+    s = np.arctan2(r, Xc[:, 2]) / np.maximum(r, 1e-300)
+    fu, fv = s * Xc[:, 0], s * Xc[:, 1]
+    if proj == "dual":
+        t = k.pop(0)
+        u, v = t * pu + (1 - t) * fu, t * pv + (1 - t) * fv
+    elif proj == "fisheye":
+        u, v = fu, fv
+    else:
+        u, v = pu, pv
+    kd, ka = k[:nd], k[nd:nd + na]
+    r2 = u * u + v * v
+    tx = ty = 0.0
+    if disto == "disto2":
+        rad = 1 + r2 * kd[0]
+    elif disto == "disto24":
+        rad = 1 + r2 * (kd[0] + kd[1] * r2)
+    elif disto == "disto2468":
+        rad = 1 + r2 * (kd[0] + r2 * (kd[1] + r2 * (kd[2] + r2 * kd[3])))
+    elif disto == "brown":
+        rad = 1 + r2 * (kd[0] + r2 * (kd[1] + r2 * kd[2]))
+        tx, ty = 2 * kd[3] * u * v + kd[4] * (r2 + 2 * u * u), 2 * kd[4] * u * v + kd[3] * (r2 + 2 * v * v)
+    else:
+        rad = 1 + r2 * (kd[0] + r2 * (kd[1] + r2 * (kd[2] + r2 * (kd[3] + r2 * (kd[4] + r2 * kd[5])))))
+        tx, ty = 2 * kd[6] * u * v + kd[7] * (r2 + 2 * u * u), 2 * kd[7] * u * v + kd[6] * (r2 + 2 * v * v)
+        if disto == "disto624":
+            tx = tx + kd[8] * r2 + kd[9] * r2 * r2
+            ty = ty + kd[10] * r2 + kd[11] * r2 * r2
+    du, dv = u * rad + tx, v * rad + ty
+    if na == 4:
+        return np.stack([ka[0] * du + ka[2], ka[0] * ka[1] * dv + ka[3]], axis=1)
+    return np.stack([ka[0] * du, ka[0] * dv], axis=1)
+
+
 def project_perspective(X: np.ndarray, pose: np.ndarray, cam: np.ndarray, model: str = "perspective") -> np.ndarray:
     """PoseFunctor + camera [k1, k2, focal] (transformations_functions.h:112-144,
     camera_projections_functions.h:88-93 perspective / :11-22 fisheye, camera_distortions_functions.h:106-113)."""
@@ -190,7 +243,8 @@ def project_perspective(X: np.ndarray, pose: np.ndarray, cam: np.ndarray, model:
 
 def make_ba_scene(n_shots: int, n_points: int, track_len: int = 10, seed: int = 42, outlier_frac: float = 0.05,
                   px_noise: float = 1.0 / 2000.0, pose_noise_t: float = 0.05, pose_noise_r: float = 0.01,
-                  point_noise: float = 0.05, gps_sigma: float = 5.0, use_gps: bool = True, model: str = "perspective") -> dict:
+                  point_noise: float = 0.05, gps_sigma: float = 5.0, use_gps: bool = True, model: str = "perspective",
+                  generic_params=None) -> dict:
     """Street scene with `n_points` tracks of length `track_len` over `n_shots` cameras.
 
     Returns the flat problem dict consumed by ``bundle_arrays`` / ``oracle.ba_solve``; ground truth
@@ -216,7 +270,10 @@ def make_ba_scene(n_shots: int, n_points: int, track_len: int = 10, seed: int = 
     bounds = np.searchsorted(obs_shot, np.arange(n_shots + 1))
     for s in range(n_shots):
         a, b = bounds[s], bounds[s + 1]
-        xy[a:b] = project_perspective(gt_pts[obs_point[a:b]], gt_pose[s], cam, model)
+        if model in GENERIC_MODELS:
+            xy[a:b] = project_generic(gt_pts[obs_point[a:b]], gt_pose[s], generic_params, model)
+        else:
+            xy[a:b] = project_perspective(gt_pts[obs_point[a:b]], gt_pose[s], cam, model)
     xy += rng.normal(0, px_noise, xy.shape)
     out = rng.random(len(xy)) < outlier_frac
     xy[out] += rng.uniform(-0.03, 0.03, (int(out.sum()), 2))  # gross mismatches: up to +-60 px at 2000 px
@@ -245,5 +302,10 @@ def make_ba_scene(n_shots: int, n_points: int, track_len: int = 10, seed: int = 
         prob["shot_gps"] = gt_pose[:, 3:6] + rng.normal(0, gps_sigma / 10.0, (n_shots, 3))
         prob["shot_gps_sigma"] = np.full(n_shots, gps_sigma)
     if model != "perspective":
-        prob["cam_model"] = np.full(1, {"perspective": 0, "fisheye": 1}[model], np.int32)
+        prob["cam_model"] = np.full(1, CAMERA_MODEL_IDS[model], np.int32)
+    if model in GENERIC_MODELS:  # constant camera: its native parameters, intrinsics not optimised
+        ext = np.zeros((1, 16))
+        ext[0, : len(generic_params)] = generic_params
+        prob["cam_ext"] = ext
+        prob["cam_fixed"] = np.ones(1, np.uint8)
     return prob

@@ -155,7 +155,7 @@ class _BaProblem(C.Structure):
         ("obs_shot", C.POINTER(C.c_int32)), ("obs_point", C.POINTER(C.c_int32)),
         ("obs_xy", C.POINTER(C.c_double)), ("obs_sigma", C.POINTER(C.c_double)), ("reproj_err", C.POINTER(C.c_double)),
         ("shot_up", C.POINTER(C.c_double)), ("shot_up_sigma", C.POINTER(C.c_double)),
-        ("cam_model", C.POINTER(C.c_int32)),
+        ("cam_model", C.POINTER(C.c_int32)), ("cam_ext", C.POINTER(C.c_double)),
     ]
 
 
@@ -200,7 +200,7 @@ def ba_solve(problem: dict, loss: str = "SoftLOneLoss", loss_threshold: float = 
     for key, fld, t, ct in (("shot_fixed", "shot_fixed", np.uint8, C.c_uint8), ("point_fixed", "point_fixed", np.uint8, C.c_uint8),
                             ("shot_gps", "shot_gps", np.float64, C.c_double), ("shot_gps_sigma", "shot_gps_sigma", np.float64, C.c_double),
                             ("shot_up", "shot_up", np.float64, C.c_double), ("shot_up_sigma", "shot_up_sigma", np.float64, C.c_double),
-                            ("cam_model", "cam_model", np.int32, C.c_int32)):
+                            ("cam_model", "cam_model", np.int32, C.c_int32), ("cam_ext", "cam_ext", np.float64, C.c_double)):
         if problem.get(key) is not None:
             arr = np.ascontiguousarray(problem[key], t)
             keep.append(arr)
@@ -230,12 +230,14 @@ def ba_up(pose, up, sigma):
     return r, J.reshape(3, 3)
 
 
-CAMERA_MODELS = {"perspective": 0, "fisheye": 1}
+CAMERA_MODELS = {"perspective": 0, "fisheye": 1, "brown": 2, "fisheye_opencv": 3, "fisheye62": 4, "fisheye624": 5, "dual": 6,
+                 "radial": 7, "simple_radial": 8}
 
 
 def ba_project(X, pose, cam, obs, sigma, model="perspective"):
     """One observation: residual (2), Jp (2x3), Jc (2x6: d/d(rx,ry,rz,tx,ty,tz)), Jk (2x3: d/d(k1,k2,f))."""
     X, pose, cam, obs = (np.ascontiguousarray(a, np.float64) for a in (X, pose, cam, obs))
+    cam = np.ascontiguousarray(np.r_[cam, np.zeros(16 - len(cam))])  # models >= 2 read up to 16 native parameters
     res, Jp, Jc, Jk = np.zeros(2), np.zeros(6), np.zeros(12), np.zeros(6)
     lib().oracle_ba_project(_p(X, C.c_double), _p(pose, C.c_double), _p(cam, C.c_double), _p(obs, C.c_double),
                             C.c_double(sigma), _p(res, C.c_double), _p(Jp, C.c_double), _p(Jc, C.c_double), _p(Jk, C.c_double),

@@ -60,7 +60,11 @@ typedef struct {
      r = (R(rot) * up - e_z) / sd, CauchyLoss(1) per shot; NULL or sd <= 0: none */
   const double *shot_up;       /* n_shots x 3 (normalised here) or NULL */
   const double *shot_up_sigma; /* n_shots or NULL */
-  const int32_t *cam_model;    /* n_cameras or NULL: 0 PERSPECTIVE, 1 FISHEYE (camera_instances.h:183-190) */
+  const int32_t *cam_model;    /* n_cameras or NULL: 0 PERSPECTIVE, 1 FISHEYE (camera_instances.h:183-190); 2.. see below */
+  /* models 2..8 (BROWN, FISHEYE_OPENCV, FISHEYE62, FISHEYE624, DUAL, RADIAL, SIMPLE_RADIAL): CONSTANT cameras only
+     (cam_fixed = 1, as BundleLocal / BundleShotPoses always have them, ba_helpers.cc:137,415); their parameters in
+     the reference's native order [projection][distortion][affine] (camera_instances.h:100-160), 16 per camera */
+  const double *cam_ext;       /* n_cameras x 16 or NULL */
 } ba_problem;
 
 typedef struct {
@@ -158,12 +162,116 @@ static void project_stage(int model, const double *Xc, double *uv, double *jp) {
   jp[3] = 0.0; jp[4] = iz; jp[5] = -y * iz * iz;
 }
 
+/* ---- the other 2-D camera models, for CONSTANT cameras (no intrinsics Jacobian needed) ----------------
+ * ProjectGeneric<PROJ, DISTO, AFF> (camera_instances.h:127-160); parameters [PROJ][DISTO][AFF].
+ * The 2x2 Jacobian of the distortion stage is taken by forward-mode duals (the reference's autodiff twin of
+ * the same formulas, camera_distortions_functions.h), the projection stage analytically as above. */
+typedef struct { double v, a, b; } d2; /* value, d/dx, d/dy */
+static inline d2 d2c(double c) { d2 r = {c, 0, 0}; return r; }
+static inline d2 d2add(d2 p, d2 q) { d2 r = {p.v + q.v, p.a + q.a, p.b + q.b}; return r; }
+static inline d2 d2mul(d2 p, d2 q) { d2 r = {p.v * q.v, p.a * q.v + p.v * q.a, p.b * q.v + p.v * q.b}; return r; }
+static inline d2 d2scale(d2 p, double c) { d2 r = {p.v * c, p.a * c, p.b * c}; return r; }
+
+/* model -> (projection: 0 perspective / 1 fisheye / 2 dual, #distortion params and kind, affine: 1 uniform / 4 affine) */
+static void model_layout(int model, int *proj, int *kind, int *nd, int *na) {
+  switch (model) {
+    case 2: *proj = 0; *kind = 3; *nd = 5;  *na = 4; break; /* BROWN: DistoBrown k1 k2 k3 p1 p2 */
+    case 3: *proj = 1; *kind = 2; *nd = 4;  *na = 4; break; /* FISHEYE_OPENCV: Disto2468 */
+    case 4: *proj = 1; *kind = 4; *nd = 8;  *na = 4; break; /* FISHEYE62: Disto62 k1..k6 p1 p2 */
+    case 5: *proj = 1; *kind = 5; *nd = 12; *na = 4; break; /* FISHEYE624: + s0..s3 */
+    case 6: *proj = 2; *kind = 1; *nd = 2;  *na = 1; break; /* DUAL: transition | Disto24 | focal */
+    case 7: *proj = 0; *kind = 1; *nd = 2;  *na = 4; break; /* RADIAL: Disto24 | Affine */
+    default: *proj = 0; *kind = 0; *nd = 1; *na = 4; break; /* 8 SIMPLE_RADIAL: Disto2 | Affine */
+  }
+}
+
+static void distort_d2(int kind, const double *k, d2 x, d2 y, d2 *ox, d2 *oy) {
+  const d2 r2 = d2add(d2mul(x, x), d2mul(y, y));
+  d2 rad, tx = d2c(0), ty = d2c(0);
+  switch (kind) {
+    case 0: rad = d2add(d2c(1.0), d2scale(r2, k[0])); break;
+    case 1: rad = d2add(d2c(1.0), d2mul(r2, d2add(d2c(k[0]), d2scale(r2, k[1])))); break;
+    case 2: rad = d2add(d2c(1.0), d2mul(r2, d2add(d2c(k[0]), d2mul(r2, d2add(d2c(k[1]), d2mul(r2, d2add(d2c(k[2]), d2scale(r2, k[3])))))))); break;
+    case 3: rad = d2add(d2c(1.0), d2mul(r2, d2add(d2c(k[0]), d2mul(r2, d2add(d2c(k[1]), d2scale(r2, k[2])))))); break;
+    default: { /* 4, 5: six radial coefficients */
+      d2 acc = d2add(d2c(k[4]), d2scale(r2, k[5])); /* Horner, as RadialDistortion (camera_distortions_functions.h:481-485) */
+      acc = d2add(d2c(k[3]), d2mul(r2, acc));
+      acc = d2add(d2c(k[2]), d2mul(r2, acc));
+      acc = d2add(d2c(k[1]), d2mul(r2, acc));
+      acc = d2add(d2c(k[0]), d2mul(r2, acc));
+      rad = d2add(d2c(1.0), d2mul(r2, acc));
+    } break;
+  }
+  if (kind >= 3) { /* tangential: 2 p1 x y + p2 (r2 + 2 x^2), 2 p2 x y + p1 (r2 + 2 y^2) */
+    const double p1 = kind == 3 ? k[3] : k[6], p2 = kind == 3 ? k[4] : k[7];
+    const d2 xy = d2mul(x, y);
+    tx = d2add(d2scale(xy, 2.0 * p1), d2scale(d2add(r2, d2scale(d2mul(x, x), 2.0)), p2));
+    ty = d2add(d2scale(xy, 2.0 * p2), d2scale(d2add(r2, d2scale(d2mul(y, y), 2.0)), p1));
+  }
+  if (kind == 5) { /* thin prism: s0 r2 + s1 r2^2, s2 r2 + s3 r2^2 */
+    const d2 r4 = d2mul(r2, r2);
+    tx = d2add(tx, d2add(d2scale(r2, k[8]), d2scale(r4, k[9])));
+    ty = d2add(ty, d2add(d2scale(r2, k[10]), d2scale(r4, k[11])));
+  }
+  *ox = d2add(d2mul(x, rad), tx);
+  *oy = d2add(d2mul(y, rad), ty);
+}
+
+/* projection of a camera-frame point by a constant camera of model 2..8: out (2), J (2x3 w.r.t. Xc) */
+static void project_generic(int model, const double *par, const double *Xc, double *out, double *J) {
+  int proj, kind, nd, na;
+  model_layout(model, &proj, &kind, &nd, &na);
+  const double *kd = par + (proj == 2 ? 1 : 0), *ka = kd + nd;
+  double uv[2], jp[6];
+  if (proj == 2) { /* DualProjection: t * perspective + (1 - t) * fisheye */
+    double a[2], ja[6], b[2], jb[6];
+    project_stage(0, Xc, a, ja);
+    project_stage(1, Xc, b, jb);
+    const double t = par[0];
+    for (int i = 0; i < 2; i++) uv[i] = t * a[i] + (1.0 - t) * b[i];
+    for (int i = 0; i < 6; i++) jp[i] = t * ja[i] + (1.0 - t) * jb[i];
+  } else {
+    project_stage(proj, Xc, uv, jp);
+  }
+  d2 x = {uv[0], 1, 0}, y = {uv[1], 0, 1}, dx, dy;
+  distort_d2(kind, kd, x, y, &dx, &dy);
+  const double fx = ka[0], fy = na == 4 ? ka[0] * ka[1] : ka[0];
+  const double cx = na == 4 ? ka[2] : 0.0, cy = na == 4 ? ka[3] : 0.0;
+  out[0] = fx * dx.v + cx;
+  out[1] = fy * dy.v + cy;
+  for (int j = 0; j < 3; j++) {
+    J[j] = fx * (dx.a * jp[j] + dx.b * jp[3 + j]);
+    J[3 + j] = fy * (dy.a * jp[j] + dy.b * jp[3 + j]);
+  }
+}
+
 static void project_obs(int model, const double *X, const double *pose, const double *R, const double (*dR)[9],
                         const double *cam, const double *obs, double inv_sigma, double *res,
                         double *Jp, double *Jc, double *Jk) {
   const double p[3] = {X[0] - pose[3], X[1] - pose[4], X[2] - pose[5]};
   double Xc[3];
   for (int i = 0; i < 3; i++) Xc[i] = R[3 * i] * p[0] + R[3 * i + 1] * p[1] + R[3 * i + 2] * p[2];
+  if (model >= 2) { /* constant camera of another 2-D model: cam points at its 16 native parameters */
+    double out[2], J[6], M[6];
+    project_generic(model, cam, Xc, out, J);
+    res[0] = inv_sigma * (out[0] - obs[0]);
+    res[1] = inv_sigma * (out[1] - obs[1]);
+    if (!Jp) return;
+    for (int j = 0; j < 6; j++) M[j] = inv_sigma * J[j];
+    for (int i = 0; i < 2; i++)
+      for (int j = 0; j < 3; j++) {
+        const double mr = M[3 * i] * R[j] + M[3 * i + 1] * R[3 + j] + M[3 * i + 2] * R[6 + j];
+        Jp[3 * i + j] = mr;
+        Jc[6 * i + 3 + j] = -mr;
+      }
+    for (int k = 0; k < 3; k++) {
+      double q[3];
+      for (int i = 0; i < 3; i++) q[i] = dR[k][3 * i] * p[0] + dR[k][3 * i + 1] * p[1] + dR[k][3 * i + 2] * p[2];
+      for (int i = 0; i < 2; i++) Jc[6 * i + k] = -(M[3 * i] * q[0] + M[3 * i + 1] * q[1] + M[3 * i + 2] * q[2]);
+    }
+    for (int i = 0; i < 6; i++) Jk[i] = 0.0;
+    return;
+  }
   const double k1 = cam[0], k2 = cam[1], f = cam[2];
   double uv[2], jp[6];
   project_stage(model, Xc, uv, jp);
@@ -301,8 +409,9 @@ static double eval_cost(const ba_ctx *C, const double *cams, const double *poses
     const double *R = Rall + 36 * (size_t)s;
     double r[2], Jp[6], Jc[12], Jk[6];
     const double isg = 1.0 / P->obs_sigma[o];
-    project_obs(P->cam_model ? P->cam_model[P->shot_camera[s]] : 0, pts + 3 * (size_t)p, poses + 6 * (size_t)s, R,
-                (const double (*)[9])(R + 9), cams + 3 * (size_t)P->shot_camera[s], P->obs_xy + 2 * o, isg, r, with_jac ? Jp : NULL, Jc, Jk);
+    const int cmodel = P->cam_model ? P->cam_model[P->shot_camera[s]] : 0;
+    project_obs(cmodel, pts + 3 * (size_t)p, poses + 6 * (size_t)s, R,
+                (const double (*)[9])(R + 9), cmodel >= 2 ? P->cam_ext + 16 * (size_t)P->shot_camera[s] : cams + 3 * (size_t)P->shot_camera[s], P->obs_xy + 2 * o, isg, r, with_jac ? Jp : NULL, Jc, Jk);
     const double sq = r[0] * r[0] + r[1] * r[1];
     double rho, rho1;
     loss_eval(C->O->loss, C->O->loss_threshold, sq, &rho, &rho1);
@@ -898,8 +1007,10 @@ int oracle_ba_solve(ba_problem *P, const ba_options *O, ba_report *Rp) {
       const int s = P->obs_shot[o], p = P->obs_point[o];
       double R[9], dR[3][9], r[2];
       rot_and_derivs(poses + 6 * s, R, dR);
-      project_obs(P->cam_model ? P->cam_model[P->shot_camera[s]] : 0, pts + 3 * (size_t)p, poses + 6 * (size_t)s, R, (const double (*)[9])dR,
-                  cams + 3 * (size_t)P->shot_camera[s], P->obs_xy + 2 * o, 1.0, r, NULL, NULL, NULL);
+      const int cmodel = P->cam_model ? P->cam_model[P->shot_camera[s]] : 0;
+      project_obs(cmodel, pts + 3 * (size_t)p, poses + 6 * (size_t)s, R, (const double (*)[9])dR,
+                  cmodel >= 2 ? P->cam_ext + 16 * (size_t)P->shot_camera[s] : cams + 3 * (size_t)P->shot_camera[s], P->obs_xy + 2 * o, 1.0, r,
+                  NULL, NULL, NULL);
       if (P->reproj_err) {
         P->reproj_err[2 * o] = r[0];
         P->reproj_err[2 * o + 1] = r[1];

@@ -301,3 +301,43 @@ def test_unordered_shots_are_renumbered(oracle_lib, gpu_ctx):
     assert np.allclose(g["shot_pose"], ref["shot_pose"][perm], atol=1e-6)
     assert g["pcg_iterations"] <= 2 * ref["pcg_iterations"]
     assert abs(_rmse_px(g["reproj_err"]) - _rmse_px(o["reproj_err"])) < 1e-4
+
+
+GENERIC_PARAMS = {
+    "brown": [-0.12, 0.03, -0.004, 0.001, -0.0007, 0.72, 1.003, 0.004, -0.006],
+    "fisheye_opencv": [-0.03, 0.004, -0.0006, 0.0001, 0.45, 0.999, 0.002, -0.001],
+    "fisheye62": [-0.03, 0.004, -0.0006, 0.0001, 0.00002, -0.000004, 0.0004, -0.0003, 0.45, 0.999, 0.002, -0.001],
+    "fisheye624": [-0.03, 0.004, -0.0006, 0.0001, 0.00002, -0.000004, 0.0004, -0.0003, 0.0002, -0.0001, 0.0003, 0.00005, 0.45, 0.999, 0.002,
+                   -0.001],
+    "dual": [0.4, -0.05, 0.004, 0.6],
+    "radial": [-0.1, 0.01, 0.7, 0.998, -0.003, 0.002],
+    "simple_radial": [-0.08, 0.7, 1.01, 0.001, 0.002],
+}
+
+
+@pytest.mark.parametrize("model", sorted(GENERIC_PARAMS))
+def test_constant_cameras_of_the_other_2d_models(oracle_lib, gpu_ctx, model):
+    """BROWN / FISHEYE_OPENCV / FISHEYE62 / FISHEYE624 / DUAL / RADIAL / SIMPLE_RADIAL as CONSTANT cameras (how
+    BundleLocal and BundleShotPoses use every camera): poses and points are optimised through their projection."""
+    from opensfm_amd import bundle
+
+    pr = synthetic.make_ba_scene(24, 400, 6, seed=61, model=model, generic_params=GENERIC_PARAMS[model])
+    g = bundle.bundle_arrays(pr, {"bundle_max_iterations": 8}, **NO_TOL)
+    o = oracle_lib.ba_solve(pr, max_iterations=8, **NO_TOL)
+    assert g["successful_steps"] == o["successful_steps"]
+    assert np.allclose(g["cost_history"], o["cost_history"], rtol=1e-7)
+    assert abs(_rmse_px(g["reproj_err"]) - _rmse_px(o["reproj_err"])) < 1e-4
+    assert np.allclose(g["shot_pose"], o["shot_pose"], atol=1e-6)
+    assert _rmse_px(g["reproj_err"], ~pr["is_outlier"]) < 2.5
+    z = bundle.bundle_arrays(pr, {"bundle_max_iterations": 0})
+    assert np.allclose(z["reproj_err"], oracle_lib.ba_solve(pr, max_iterations=0)["reproj_err"], rtol=0, atol=1e-13)
+
+
+def test_other_models_must_be_constant(gpu_ctx):
+    from opensfm_amd import bundle
+    from opensfm_amd._lib import OsfmError
+
+    pr = synthetic.make_ba_scene(10, 100, 4, seed=62, model="brown", generic_params=GENERIC_PARAMS["brown"])
+    pr["cam_fixed"] = np.zeros(1, np.uint8)
+    with pytest.raises(OsfmError):
+        bundle.bundle_arrays(pr, {"bundle_max_iterations": 2})
