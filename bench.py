@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--features", type=int, default=2000)
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-pairs", type=int, default=384)
+    ap.add_argument("--cpu-sample-pairs", type=int, default=3072)  # ~15 s of host work on 128 threads
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--no-tracks", action="store_true")
     ap.add_argument("--ba-shots", type=int, default=5000)
