@@ -29,7 +29,7 @@ extern "C" {
 #define OSFM_E_NUMERIC (-5) /* NaN/Inf in results: reference throws (ba_helpers.cc:780-814) */
 
 #define OSFM_DESC_DIM 128
-#define OSFM_MAX_FEATURES 4096 /* per image, fused matcher limit */
+#define OSFM_MAX_FEATURES 8192 /* per image: LDS-resident per-feature state of the matcher and of the RANSAC kernel */
 
 typedef struct osfm_ctx osfm_ctx;     /* one per process/GPU: device, streams, scratch */
 typedef struct osfm_store osfm_store; /* device-resident descriptor + keypoint store */

@@ -217,7 +217,8 @@ extern "C" int osfm_match_pairs(osfm_ctx *ctx, const osfm_store *store, const in
   if (tm) memset(tm, 0, sizeof(*tm));
 
   const int cap = store->max_count > 0 ? store->max_count : 1;
-  const int64_t chunk_pairs = 1 << 17;  // 131072 pairs -> <= 1 GiB of match slots at cap 2048
+  // 131072 pairs per chunk at cap <= 2048 (1 GiB of match slots per buffer set), fewer for larger images
+  const int64_t chunk_pairs = std::max<int64_t>(4096, std::min<int64_t>(1 << 17, ((int64_t)1 << 28) / cap));
   const int64_t cp = n_pairs < chunk_pairs ? n_pairs : chunk_pairs;
   const int64_t nchunks = (n_pairs + cp - 1) / (cp > 0 ? cp : 1);
   // Two chunk buffer sets: while stream B runs RANSAC + gather + D2H of chunk k (a few thousand

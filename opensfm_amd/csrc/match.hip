@@ -843,6 +843,10 @@ __device__ __forceinline__ int row_pass(const RowPassShared &sh, const int8_t *t
   unsigned char *bbuf = sh.bbuf;
   int *nbuf = sh.nbuf;
   int flag = 0;
+  // images above 4096 features (128 tiles) do not fit a tile index into the 32-bit keys: value-only keys, and the
+  // re-examination of the rows that pass also has to find the winner (cold path)
+  const bool big = tY > 128;
+  const int ksh = big ? 1 : 8;
 
   // first chunk of Y: global -> registers -> LDS
   {
@@ -950,7 +954,8 @@ __device__ __forceinline__ int row_pass(const RowPassShared &sh, const int8_t *t
       _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                       \
         bf[BUF][h][ks] = *(const v4i *)(bb + (2 * (PR) + h) * OSFM_TILE_BYTES + ks * 1024 + lane * 16);     \
       const int nb = nbs[(2 * (PR) + h) * 32 + (lane & 31)];                                                 \
-      ck[BUF][h] = -(nb << 7) + (127 - ((c * kCT4 + 2 * (PR) + h) & 127));                                   \
+      /* <= 128 tiles: key = value * 128 + (127 - tile): the winner's tile rides in the key.  More tiles: the value alone */ \
+      ck[BUF][h] = big ? -nb : -(nb << 7) + (127 - ((c * kCT4 + 2 * (PR) + h) & 127));                     \
     }                                                                                                        \
   }
 #ifdef OSFM_DBG_NOMFMA
@@ -966,7 +971,7 @@ __device__ __forceinline__ int row_pass(const RowPassShared &sh, const int8_t *t
 #define OSFM_EPI(AB, RT, BUF, I)                                                                             \
   {                                                                                                          \
     _Pragma("unroll") for (int rr = 2 * (I); rr < 2 * (I) + 2; ++rr) {                                       \
-      const int k0 = (acc[AB][0][rr] << 8) + ck[BUF][0], k1 = (acc[AB][1][rr] << 8) + ck[BUF][1];            \
+      const int k0 = (acc[AB][0][rr] << ksh) + ck[BUF][0], k1 = (acc[AB][1][rr] << ksh) + ck[BUF][1];        \
       rbst[RT][rr] = max(max(rbst[RT][rr], k0), k1);                                                         \
     }                                                                                                        \
   }
@@ -1039,7 +1044,20 @@ __device__ __forceinline__ int row_pass(const RowPassShared &sh, const int8_t *t
             const int il = rt * 32 + row32;
             const int na = __shfl(nrm, il);
             const int xr = __shfl(xrow, il);
-            const int bv = bkey >> 7, bj = (127 - (bkey & 127)) * 32 + bcls, sv = skey >> 7;
+            const int bv = big ? bkey : bkey >> 7, sv = big ? skey : skey >> 7;
+            const int bj = (127 - (bkey & 127)) * 32 + bcls;  // winner's column when the key carries its tile (!big)
+            // value-only keys: every class whose best equals the overall best may hold the lowest-index winner
+            unsigned tmask = 0;
+            if (big) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const int4 v4 = *(const int4 *)(trb + (row32 >> 3) * OSFM_TILE_BYTES + (row32 & 7) * 128 + hc * 64 + q * 16);
+                const int vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tmask |= (vv[e] == bkey) ? (1u << (hc * 16 + q * 4 + e)) : 0u;
+              }
+              tmask |= __shfl_xor(tmask, 1);
+            }
             bool want = false;
             if (hc == 0 && xr >= 0 && xr < nX) {
               const int d1 = na - bv, d2 = na - sv;
@@ -1047,22 +1065,53 @@ __device__ __forceinline__ int row_pass(const RowPassShared &sh, const int8_t *t
               want = ratio_ok(d1, d2, ratio);  // passes against the class bound: re-examine
               if (!want) out[xr] = kNone;
             }
-            // the rows that passed: exact second inside the winner's class = columns {t*32 + (bj&31)}
             unsigned long long pending = (debug & 1) ? 0ull : __ballot(want);
             while (pending) {
               const int src = __builtin_ctzll(pending);
               pending &= pending - 1;
-              const int qbj = __shfl(bj, src), qbv = __shfl(bv, src), qsv = __shfl(sv, src), qna = __shfl(na, src), qxr = __shfl(xr, src);
-              int mx = INT_MIN;
-              for (int t0 = 0; t0 < tY; t0 += 64) {
-                const int t = t0 + lane;
-                const int j = t * 32 + (qbj & 31);
-                if (t < tY && j != qbj) mx = max(mx, 2 * dot_rows8(tilesX, qxr, tilesY, j) - normY[j]);
-              }
-              mx = wave_max(mx);
-              if (lane == 0) {
-                const int s2 = max(qsv, mx);
-                out[qxr] = ratio_ok(qna - qbv, qna - s2, ratio) ? qbj : kNone;
+              const int qsv = __shfl(sv, src), qna = __shfl(na, src), qxr = __shfl(xr, src);
+              if (!big) {
+                // exact second inside the winner's class = columns {t*32 + (bj&31)}
+                const int qbj = __shfl(bj, src), qbv = __shfl(bv, src);
+                int mx = INT_MIN;
+                for (int t0 = 0; t0 < tY; t0 += 64) {
+                  const int t = t0 + lane;
+                  const int j = t * 32 + (qbj & 31);
+                  if (t < tY && j != qbj) mx = max(mx, 2 * dot_rows8(tilesX, qxr, tilesY, j) - normY[j]);
+                }
+                mx = wave_max(mx);
+                if (lane == 0) {
+                  const int s2 = max(qsv, mx);
+                  out[qxr] = ratio_ok(qna - qbv, qna - s2, ratio) ? qbj : kNone;
+                }
+              } else {
+                // the classes that reach the best value are re-examined exactly: lowest index among equals
+                // (cv2's rule) and exact second
+                unsigned qmask = (unsigned)__shfl((int)tmask, src);
+                int lv = INT_MIN, lj = INT_MAX, ls = INT_MIN;
+                while (qmask) {
+                  const int qcls = __builtin_ctz(qmask);
+                  qmask &= qmask - 1;
+                  for (int t0 = 0; t0 < tY; t0 += 64) {
+                    const int t = t0 + lane;
+                    if (t < tY) {
+                      const int j = t * 32 + qcls;
+                      const int v = 2 * dot_rows8(tilesX, qxr, tilesY, j) - normY[j];
+                      ls = max(ls, min(lv, v));
+                      if (v > lv || (v == lv && j < lj)) {
+                        lv = v;
+                        lj = j;
+                      }
+                    }
+                  }
+                }
+                const int m1 = wave_max(lv);
+                const int jwin = -wave_max(lv == m1 ? -lj : INT_MIN);
+                const int m2 = wave_max(lj == jwin ? ls : lv);
+                if (lane == 0) {
+                  const int s2 = max(qsv, m2);
+                  out[qxr] = ratio_ok(qna - m1, qna - s2, ratio) ? jwin : kNone;
+                }
               }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1305,6 +1354,8 @@ int osfm_launch_match(osfm_ctx *ctx, const osfm_store *store, const int32_t *d_p
   a.debug_no_recheck = getenv("OSFM_DEBUG_NO_RECHECK") ? atoi(getenv("OSFM_DEBUG_NO_RECHECK")) : 0;  // bit0 rechecks, bit2 step barrier, bit3 chunk DMA, bit4 compute
   a.pad_norm = store->d_norms + store->tile_off[store->n_images] * 32;  // first slack row: padding norm
   OSFM_REQUIRE(a.ncap <= OSFM_MAX_FEATURES, OSFM_E_UNSUPPORTED, "more than %d features in an image", OSFM_MAX_FEATURES);
+  OSFM_REQUIRE(exact_kernel || match_kernel_version() == 4 || a.ncap <= 4096, OSFM_E_UNSUPPORTED,
+               "the v1/v2 matcher kernels pack a 7-bit tile index into their keys: at most 4096 features per image (v4 has no such limit)");
   OSFM_REQUIRE(n_pairs < (1ll << 31), OSFM_E_INVALID, "too many pairs in one launch");
   if (!exact_kernel) {
     const size_t lds = osfm_match_lds_bytes(a.ncap);

@@ -417,8 +417,7 @@ __global__ void __launch_bounds__(kThreads) ransac_pairs_kernel(RansacPairsArgs 
   RansacShared &sh = *reinterpret_cast<RansacShared *>(smem);
   const int capr = (a.cap + 3) & ~3;
   float4 *ptsbuf = reinterpret_cast<float4 *>(smem + sizeof(RansacShared));  // [capr]
-  uint32_t *mlist = reinterpret_cast<uint32_t *>(ptsbuf + capr);             // [capr]
-  int *misc = reinterpret_cast<int *>(mlist + capr);                         // [8]
+  int *misc = reinterpret_cast<int *>(ptsbuf + capr);                        // [8]
   const int tid = threadIdx.x;
   const int lane = tid & 63, w = tid >> 6;
   const long p = blockIdx.x;
@@ -434,7 +433,6 @@ __global__ void __launch_bounds__(kThreads) ransac_pairs_kernel(RansacPairsArgs 
   if (tid == 0) sh.pts = ptsbuf;
   for (int k = tid; k < n; k += kThreads) {
     const uint32_t m = a.matches[p * a.cap + k];
-    mlist[k] = m;
     const int i = m & 0xFFFF, j = m >> 16;
     ptsbuf[k] = make_float4((float)pts1[2 * i], (float)pts1[2 * i + 1], (float)pts2[2 * j], (float)pts2[2 * j + 1]);
   }
@@ -457,9 +455,11 @@ __global__ void __launch_bounds__(kThreads) ransac_pairs_kernel(RansacPairsArgs 
   for (int k0 = 0; k0 < n; k0 += kThreads) {
     const int k = k0 + tid;
     bool in = false;
+    uint32_t mk = 0;  // read before the barrier below: the in-place writes of this round only go to slots <= k
     if (k < n) {
       const float4 q = sh.pts[k];
       in = epi_error(F, (double)q.x, (double)q.y, (double)q.z, (double)q.w) <= t;
+      mk = a.matches[p * a.cap + k];
     }
     const unsigned long long bal = __ballot(in);
     const int prefix = __popcll(bal & ((1ull << lane) - 1ull));
@@ -472,7 +472,7 @@ __global__ void __launch_bounds__(kThreads) ransac_pairs_kernel(RansacPairsArgs 
       woff += (w2 < w) ? cnt : 0;
       total += cnt;
     }
-    if (in) a.matches[p * a.cap + base + woff + prefix] = mlist[k];
+    if (in) a.matches[p * a.cap + base + woff + prefix] = mk;
     base += total;
     __syncthreads();
   }
@@ -673,7 +673,7 @@ int osfm_launch_ransac_pairs(osfm_ctx *ctx, const osfm_store *store, const int32
   a.counts = d_counts;
   a.matches = d_matches;
   a.F_out = d_F_or_null;
-  const size_t lds = sizeof(RansacShared) + (size_t)((cap + 3) & ~3) * 20 + 64;
+  const size_t lds = sizeof(RansacShared) + (size_t)((cap + 3) & ~3) * 16 + 64;
   static bool attr_set = false;
   if (!attr_set) {
     OSFM_HIP(hipFuncSetAttribute((const void *)ransac_pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -18,7 +18,7 @@ def _rand_desc(rng, n, hi=256):
 @pytest.mark.parametrize(
     "n1,n2,seed",
     [(2, 2, 0), (3, 40, 1), (31, 33, 2), (32, 32, 3), (64, 257, 4), (300, 100, 5), (1000, 777, 6), (2000, 2000, 7),
-     (129, 4096, 8), (4096, 300, 9)],
+     (129, 4096, 8), (4096, 300, 9), (5000, 6000, 10), (8192, 777, 11), (300, 8000, 12)],
 )
 def test_leaf_symmetric_equals_oracle(oracle_lib, gpu_ctx, n1, n2, seed):
     from opensfm_amd import matching
@@ -162,3 +162,35 @@ def test_second_best_in_the_same_class_as_the_best(oracle_lib, gpu_ctx):
     # sanity: the construction really produces both outcomes
     m = oracle_lib.match_brute_force(f1, f2, 0.8)
     assert 10 < len(m) < 96
+
+
+def test_more_than_4096_features_full_pipeline(oracle_lib, gpu_ctx):
+    """Images above 4096 features (OpenSfM's HAHOG default asks for >= 4000 per image): the v4 keys carry no tile
+    index, the per-feature LDS state and the RANSAC point buffer hold up to OSFM_MAX_FEATURES = 8192."""
+    from opensfm_amd import matching
+
+    sc = synthetic.make_matching_scene(5, 5200, seed=19)
+    pairs = synthetic.all_pairs(5)
+    store = matching.DescriptorStore.from_packed(sc.desc, sc.pts, sc.offsets)
+    counts, m = matching.match_pairs(store, pairs)
+    want = oracle_lib.match_pairs(sc.desc.astype(np.float32), sc.pts, sc.offsets, pairs)
+    got = matching.split_matches(counts, m)
+    assert [len(g) for g in got] == [len(w) for w in want]
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    assert counts.sum() > 1000
+
+
+def test_ties_and_duplicates_above_4096_features(oracle_lib, gpu_ctx):
+    """Value-only keys (> 128 column tiles): with ratio > 1 equal distances pass the ratio test and cv2's
+    lowest-index rule decides, across tiles AND across the column classes the kernel reduces over."""
+    from opensfm_amd import matching
+
+    rng = np.random.default_rng(21)
+    f1 = _rand_desc(rng, 200, 64)
+    f2 = np.concatenate([f1[:100], f1[:100], f1[50:150], _rand_desc(rng, 4300, 64)])
+    f2 = f2[rng.permutation(len(f2))]
+    for ratio in (0.8, 1.0, 1.5):
+        for sym, fo in ((False, oracle_lib.match_brute_force), (True, oracle_lib.match_brute_force_symmetric)):
+            assert np.array_equal(matching._match_leaf(f1, f2, ratio, sym), fo(f1, f2, ratio))
+            assert np.array_equal(matching._match_leaf(f2, f1, ratio, sym), fo(f2, f1, ratio))
