@@ -1,0 +1,73 @@
+"""Host-side logic that needs no GPU: the neighbourhood selection and sub-problem extraction of the
+local bundle adjustment (ba_helpers.cc:36-115,117-222) against a set-based transcription, and the
+flattening of a match graph into the reference's union order."""
+import numpy as np
+
+from opensfm_amd import bundle, synthetic, tracking
+
+
+def _direct_neighbors_sets(shots_of_point, points_of_shot, inside, min_common, max_neighbors):
+    # BAHelpers::DirectShotNeighbors, ba_helpers.cc:68-115 (ties broken by lower shot id, as the adapter documents)
+    points = set()
+    for s in inside:
+        points |= points_of_shot[s]
+    common = {}
+    for p in points:
+        for s in shots_of_point[p]:
+            if s not in inside:
+                common[s] = common.get(s, 0) + 1
+    pairs = sorted(common.items(), key=lambda kv: (-kv[1], kv[0]))
+    out = set()
+    for idx, (s, n) in enumerate(pairs):
+        if n >= min_common and idx < min(max_neighbors, len(pairs)):
+            out.add(s)
+        else:
+            break
+    return out
+
+
+def _neighborhood_sets(pr, central, radius, min_common, max_interior):
+    shots_of_point, points_of_shot = {}, {}
+    for s, p in zip(pr["obs_shot"], pr["obs_point"]):
+        shots_of_point.setdefault(int(p), set()).add(int(s))
+        points_of_shot.setdefault(int(s), set()).add(int(p))
+    interior = {central}
+    distance = 1
+    while distance < radius and len(interior) < max_interior:
+        remaining = max_interior - len(interior)
+        interior |= _direct_neighbors_sets(shots_of_point, points_of_shot, interior, min_common, remaining)
+        distance += 1
+    boundary = _direct_neighbors_sets(shots_of_point, points_of_shot, interior, 1, 1000000)
+    return interior, boundary
+
+
+def test_shot_neighborhood_matches_set_transcription():
+    pr = synthetic.make_ba_scene(50, 1200, 7, seed=5)
+    for central, radius, mc, mx in ((25, 3, 20, 30), (0, 2, 5, 4), (49, 4, 50, 12), (10, 1, 20, 30)):
+        i_m, b_m = bundle.shot_neighborhood(pr, central, radius, mc, mx)
+        i_s, b_s = _neighborhood_sets(pr, central, radius, mc, mx)
+        assert set(np.flatnonzero(i_m)) == i_s and set(np.flatnonzero(b_m)) == b_s
+        assert not (i_m & b_m).any() and i_m[central]
+
+
+def test_local_problem_structure():
+    pr = synthetic.make_ba_scene(40, 900, 6, seed=6)
+    sub, shot_ids, pt_ids, interior, boundary = bundle.local_problem(pr, 20, {"local_bundle_max_shots": 7})
+    assert sub["cam_fixed"].all()  # constexpr bool fix_cameras{true}, ba_helpers.cc:137
+    assert np.array_equal(sub["shot_fixed"].astype(bool), boundary[shot_ids])  # boundary instances are constant
+    # every point seen from the interior is in, with all its observations from interior and boundary shots
+    seen = np.unique(pr["obs_point"][interior[pr["obs_shot"]]])
+    assert np.array_equal(pt_ids, seen)
+    n_expected = int((np.isin(pr["obs_point"], seen) & (interior | boundary)[pr["obs_shot"]]).sum())
+    assert len(sub["obs_shot"]) == n_expected
+    assert (sub["shot_gps_sigma"][sub["shot_fixed"].astype(bool)] == 0).all()  # position priors on interior shots only
+    assert np.array_equal(sub["shot_pose"], pr["shot_pose"][shot_ids])
+
+
+def test_edges_follow_the_reference_union_order():
+    pairs = np.array([[0, 2], [1, 2], [0, 1]], np.int32)
+    counts = np.array([2, 0, 3], np.int32)
+    matches = np.array([[5, 7], [1, 0], [2, 2], [3, 9], [0, 4]], np.int32)
+    off = np.array([0, 10, 20, 30], np.int64)
+    ea, eb = tracking.edges_from_match_graph(pairs, counts, matches, off)
+    assert list(ea) == [5, 1, 2, 3, 0] and list(eb) == [27, 20, 12, 19, 14]
