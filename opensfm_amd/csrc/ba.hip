@@ -2057,6 +2057,51 @@ __global__ void reproj_kernel(Dev d, double *out) {
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
+// ---- exact elimination of the camera border of the preconditioner -----------------------------------
+// With the exact band A (shot block of the reduced system) the only thing block Jacobi on the camera rows
+// leaves to CG is the coupling B to the few shared intrinsics.  For nb = 3 * cameras <= 6 border unknowns the
+// border is eliminated exactly instead:  W = A^-1 B (nb cyclic-reduction solves),  Sigma = C - B^T W,
+//   z_s = A^-1 r_s,   z_c = Sigma^-1 (r_c - B^T z_s),   z_s -= W z_c,
+// which makes the preconditioner the reduced matrix itself: CG converges in one or two iterations.
+__global__ void unit_vec_kernel(double *x, int n, int j) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = i == j ? 1.0 : 0.0;
+}
+// out[i * nb + j] = Bc_i . W_j   (one block per entry)
+__global__ void border_dots_kernel(const double *Bc, const double *W, int nb, int n, double *out) {
+  __shared__ double lds[32];
+  const int i = blockIdx.x / nb, j = blockIdx.x % nb;
+  double v[1] = {0.0};
+  for (int t = threadIdx.x; t < n; t += blockDim.x) v[0] += Bc[(long)i * n + t] * W[(long)j * n + t];
+  block_sum<1>(v, lds);
+  if (threadIdx.x == 0) out[blockIdx.x] = v[0];
+}
+// z_c = SigInv (r_c - B^T z_s)   (single block)
+__global__ void border_rhs_kernel(const double *Bc, const double *SigInv, const double *r, double *z, int nb, int n, int cam0) {
+  __shared__ double lds[32];
+  __shared__ double y[8];
+  for (int i = 0; i < nb; i++) {
+    double v[1] = {0.0};
+    for (int t = threadIdx.x; t < n; t += blockDim.x) v[0] += Bc[(long)i * n + t] * z[t];
+    block_sum<1>(v, lds);
+    if (threadIdx.x == 0) y[i] = r[cam0 + i] - v[0];
+    __syncthreads();
+  }
+  if (threadIdx.x < nb) {
+    double acc = 0.0;
+    for (int j = 0; j < nb; j++) acc += SigInv[threadIdx.x * nb + j] * y[j];
+    z[cam0 + threadIdx.x] = acc;
+  }
+}
+// z_s -= W z_c
+__global__ void border_update_kernel(const double *W, double *z, int nb, int n, int cam0) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  double acc = 0.0;
+  for (int j = 0; j < nb; j++) acc += W[(long)j * n + t] * z[cam0 + j];
+  z[t] -= acc;
+}
+
 // ---- setup helpers: the observation arrays are permuted on the device (host only builds the index lists) ----
 __global__ void gather_pm_kernel(const int *perm, const double *raw_xy, const double *raw_sigma, long M, double *o_x, double *o_y,
                                  double *o_sigma) {
@@ -2143,7 +2188,8 @@ struct Solver {
     hipLaunchKernelGGL(cam_reduce_kernel, dim3(d.NC), dim3(TPB), 0, st, d, 9);
     hipLaunchKernelGGL(cam_grad_kernel, dim3(nblk(d.NC, 64)), dim3(64), 0, st, d, d.cams);
   }
-  bool use_band = false, use_ctri = false, use_bcr = false;
+  bool use_band = false, use_ctri = false, use_bcr = false, use_border = false;
+  double *Bc = nullptr, *Wb = nullptr, *SigInv = nullptr, *dots = nullptr;  // border elimination (nb x 6S, nb x 6S, nb x nb, nb x nb)
   void bcr_solve(const double *r, double *z) {
     const int N = d.ncl;
     hipLaunchKernelGGL(bcr_load_kernel, dim3(nblk((long)N * d.ncd)), dim3(TPB), 0, st, d, r);
@@ -2154,7 +2200,12 @@ struct Solver {
     hipLaunchKernelGGL(bcr_store_kernel, dim3(nblk(6L * d.S)), dim3(TPB), 0, st, d, r, z);
   }
   void precond(const double *r, double *z) {
-    if (use_bcr)
+    if (use_bcr && use_border) {
+      const int nb = 3 * d.NC, n = 6 * d.S;
+      bcr_solve(r, z);
+      hipLaunchKernelGGL(border_rhs_kernel, dim3(1), dim3(1024), 0, st, Bc, SigInv, r, z, nb, n, d.cam0);
+      hipLaunchKernelGGL(border_update_kernel, dim3(nblk(n)), dim3(TPB), 0, st, Wb, z, nb, n, d.cam0);
+    } else if (use_bcr)
       bcr_solve(r, z);
     else if (use_ctri)
       hipLaunchKernelGGL(ctri_solve_kernel, dim3(1), dim3(256), 0, st, d, r, z);
@@ -2539,7 +2590,16 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     d.bG = A.alloc<double>(nb, e);
     d.bH = A.alloc<double>(nb, e);
     d.bx = A.alloc<double>((size_t)d.ncl * d.ncd, e);
+    if (3 * NC <= 6) {  // exact camera border: see border_rhs_kernel
+      sv.Bc = A.alloc<double>((size_t)3 * NC * 6 * S, e);
+      sv.Wb = A.alloc<double>((size_t)3 * NC * 6 * S, e);
+      sv.SigInv = A.alloc<double>(36, e);
+      sv.dots = A.alloc<double>(36, e);
+    }
   }
+  bool border_ok = getenv("OSFM_BA_NO_BORDER") == nullptr;  // exact camera border: every camera free
+  for (int c = 0; c < NC; c++)
+    if (P->cam_fixed[c]) border_ok = false;
   int *d_status = A.alloc<int>(4, e);
   double *d_reproj = P->reproj_err ? A.alloc<double>((size_t)2 * M, e) : nullptr;
   OSFM_REQUIRE(e == hipSuccess, OSFM_E_NOMEM, "BA device allocation/upload failed: %s", hipGetErrorString(e));
@@ -2624,6 +2684,54 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
         OSFM_HIP(hipMemcpyAsync(&hst, d_status, sizeof(int), hipMemcpyDeviceToHost, st));
         OSFM_HIP(hipStreamSynchronize(st));
         sv.use_bcr = (hst == 0);
+        // exact camera border (few cameras, all free): B = S e_j restricted to the shot rows, W = A^-1 B
+        sv.use_border = false;
+        if (sv.use_bcr && sv.Bc && border_ok) {
+          const int nb = 3 * NC, n6 = 6 * S;
+          std::vector<double> Cm((size_t)nb * nb), Sg((size_t)nb * nb), col((size_t)nb);
+          for (int j = 0; j < nb; j++) {
+            hipLaunchKernelGGL(unit_vec_kernel, dim3(nbr), dim3(TPB), 0, st, d.p, nred, d.cam0 + j);
+            sv.matvec(d.p, d.Ap, radius);
+            OSFM_HIP(hipMemcpyAsync(sv.Bc + (size_t)j * n6, d.Ap, (size_t)n6 * sizeof(double), hipMemcpyDeviceToDevice, st));
+            OSFM_HIP(hipMemcpyAsync(col.data(), d.Ap + d.cam0, (size_t)nb * sizeof(double), hipMemcpyDeviceToHost, st));
+            // r = [B e_j ; 0]  ->  z_s = A^-1 B e_j
+            OSFM_HIP(hipMemsetAsync(d.Ap + d.cam0, 0, (size_t)nb * sizeof(double), st));
+            sv.bcr_solve(d.Ap, d.z);
+            OSFM_HIP(hipMemcpyAsync(sv.Wb + (size_t)j * n6, d.z, (size_t)n6 * sizeof(double), hipMemcpyDeviceToDevice, st));
+            OSFM_HIP(hipStreamSynchronize(st));
+            for (int i = 0; i < nb; i++) Cm[(size_t)i * nb + j] = col[(size_t)i];
+          }
+          hipLaunchKernelGGL(border_dots_kernel, dim3(nb * nb), dim3(TPB), 0, st, sv.Bc, sv.Wb, nb, n6, sv.dots);
+          OSFM_HIP(hipMemcpyAsync(Sg.data(), sv.dots, (size_t)nb * nb * sizeof(double), hipMemcpyDeviceToHost, st));
+          OSFM_HIP(hipStreamSynchronize(st));
+          for (int i = 0; i < nb * nb; i++) Sg[(size_t)i] = Cm[(size_t)i] - Sg[(size_t)i];
+          // Sigma^-1 by Gauss-Jordan with partial pivoting (nb <= 6)
+          std::vector<double> Inv((size_t)nb * nb, 0.0);
+          for (int i = 0; i < nb; i++) Inv[(size_t)i * nb + i] = 1.0;
+          bool ok_inv = true;
+          for (int c = 0; c < nb && ok_inv; c++) {
+            int piv = c;
+            for (int r2 = c + 1; r2 < nb; r2++)
+              if (std::fabs(Sg[(size_t)r2 * nb + c]) > std::fabs(Sg[(size_t)piv * nb + c])) piv = r2;
+            if (!(std::fabs(Sg[(size_t)piv * nb + c]) > 0) || !std::isfinite(Sg[(size_t)piv * nb + c])) { ok_inv = false; break; }
+            for (int q = 0; q < nb; q++) {
+              std::swap(Sg[(size_t)c * nb + q], Sg[(size_t)piv * nb + q]);
+              std::swap(Inv[(size_t)c * nb + q], Inv[(size_t)piv * nb + q]);
+            }
+            const double ip = 1.0 / Sg[(size_t)c * nb + c];
+            for (int q = 0; q < nb; q++) { Sg[(size_t)c * nb + q] *= ip; Inv[(size_t)c * nb + q] *= ip; }
+            for (int r2 = 0; r2 < nb; r2++) {
+              if (r2 == c) continue;
+              const double f = Sg[(size_t)r2 * nb + c];
+              for (int q = 0; q < nb; q++) { Sg[(size_t)r2 * nb + q] -= f * Sg[(size_t)c * nb + q]; Inv[(size_t)r2 * nb + q] -= f * Inv[(size_t)c * nb + q]; }
+            }
+          }
+          if (ok_inv) {
+            OSFM_HIP(hipMemcpyAsync(sv.SigInv, Inv.data(), (size_t)nb * nb * sizeof(double), hipMemcpyHostToDevice, st));
+            OSFM_HIP(hipStreamSynchronize(st));
+            sv.use_border = true;
+          }
+        }
       }
       if (!sv.use_bcr) {
       static bool chol_attr = false;
@@ -2680,7 +2788,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
         hipLaunchKernelGGL(dot2_kernel, dim3(1), dim3(1024), 0, st, d.r, d.z, d.r, d.r, nred, d.scal + 2, d.scal + 3);
         hipLaunchKernelGGL(pcg_step2_kernel, dim3(nbr), dim3(TPB), 0, st, d.p, d.z, nred, d.scal);
         hipLaunchKernelGGL(pcg_shift_kernel, dim3(1), dim3(1), 0, st, d.scal);
-        if ((k & 3) == 0 || k == kmax) {
+        if ((k & 3) == 0 || k == kmax || (sv.use_border && k <= 2)) {
           OSFM_HIP(hipMemcpyAsync(hs.data(), d.scal, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
           OSFM_HIP(hipStreamSynchronize(st));
           if (!(hs[3] == hs[3])) { bad = true; break; }
