@@ -11,7 +11,8 @@ same code runs over gloo on CPU tensors for the world-size-2 tests.
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple
+from functools import lru_cache
+from typing import List, Optional, Tuple
 
 import numpy as np
 
@@ -25,14 +26,27 @@ def shard_indices(n_pairs: int, rank: int, world: int, block: int = BLOCK) -> np
     return idx[(idx // block) % world == rank]
 
 
+@lru_cache(maxsize=8)
+def _all_shards(n_pairs: int, world: int, block: int) -> List[np.ndarray]:
+    return [shard_indices(n_pairs, r, world, block) for r in range(world)]
+
+
+def gathered_pair_order(n_pairs: int, world: int, block: int = BLOCK) -> np.ndarray:
+    """Order of the pairs in the graph ``all_gather_match_graph(..., reorder=False)`` returns: rank 0's
+    shard, then rank 1's, ... (``pairs[gathered_pair_order(...)]`` is the matching pair list)."""
+    return np.concatenate(_all_shards(n_pairs, world, block)) if world > 1 else np.arange(n_pairs, dtype=np.int64)
+
+
 def shard_pairs(pairs: np.ndarray, rank: int, world: int, block: int = BLOCK) -> np.ndarray:
     return np.ascontiguousarray(pairs[shard_indices(len(pairs), rank, world, block)])
 
 
 def all_gather_match_graph(counts: np.ndarray, matches: np.ndarray, n_pairs: int, rank: int, world: int,
-                           local_rank: Optional[int] = None, block: int = BLOCK) -> Tuple[np.ndarray, np.ndarray]:
+                           local_rank: Optional[int] = None, block: int = BLOCK, reorder: bool = True) -> Tuple[np.ndarray, np.ndarray]:
     """Every rank contributes (counts, matches) of its shard; every rank returns the global
-    (counts[n_pairs], matches[total, 2]) in the order of the original pair list."""
+    (counts[n_pairs], matches[total, 2]): in the order of the original pair list (``reorder=True``), or
+    rank-major -- shard after shard, the order ``gathered_pair_order`` describes -- which needs no
+    scatter of the tens of millions of match rows on the host (``reorder=False``)."""
     if world == 1:
         return counts, matches
     import torch
@@ -40,7 +54,7 @@ def all_gather_match_graph(counts: np.ndarray, matches: np.ndarray, n_pairs: int
 
     on_gpu = dist.get_backend() == "nccl"
     dev = torch.device("cuda", local_rank if local_rank is not None else rank) if on_gpu else torch.device("cpu")
-    idx = [shard_indices(n_pairs, r, world, block) for r in range(world)]
+    idx = _all_shards(n_pairs, world, block)
     maxn = max(len(i) for i in idx)
     c = torch.zeros(maxn, dtype=torch.int32)
     c[: len(counts)] = torch.from_numpy(np.ascontiguousarray(counts, np.int32))
@@ -56,6 +70,11 @@ def all_gather_match_graph(counts: np.ndarray, matches: np.ndarray, n_pairs: int
     m = m.to(dev)
     allm = [torch.empty_like(m) for _ in range(world)]
     dist.all_gather(allm, m)
+    if not reorder:
+        counts_g = np.concatenate([allc[r][: len(idx[r])] for r in range(world)])
+        hm = [allm[r].cpu().numpy() for r in range(world)]
+        matches_g = np.concatenate([hm[r][: 2 * totals[r]] for r in range(world)]).reshape(-1, 2)
+        return counts_g, matches_g
     counts_g = np.zeros(n_pairs, np.int32)
     for r in range(world):
         counts_g[idx[r]] = allc[r][: len(idx[r])]

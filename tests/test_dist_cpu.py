@@ -33,6 +33,12 @@ def _worker(rank, world, port, n_pairs, seed, q):
     mine = np.concatenate([matches_all[off[i]: off[i + 1]] for i in idx]) if len(idx) else np.zeros((0, 2), np.int32)
     c, m = odist.all_gather_match_graph(counts_all[idx], mine, n_pairs, rank, world, block=16)
     ok = np.array_equal(c, counts_all) and np.array_equal(m, matches_all)
+    # rank-major variant: the same graph, pairs in gathered_pair_order
+    c2, m2 = odist.all_gather_match_graph(counts_all[idx], mine, n_pairs, rank, world, block=16, reorder=False)
+    order = odist.gathered_pair_order(n_pairs, world, block=16)
+    want_m = np.concatenate([matches_all[off[i]: off[i + 1]] for i in order]) if n_pairs else np.zeros((0, 2), np.int32)
+    ok = ok and np.array_equal(c2, counts_all[order]) and np.array_equal(m2, want_m.reshape(-1, 2))
+    ok = ok and np.array_equal(np.sort(order), np.arange(n_pairs))
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 
