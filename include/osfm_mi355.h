@@ -222,6 +222,11 @@ typedef struct {
 int osfm_ba_solve(osfm_ctx *ctx, osfm_ba_problem *problem, const osfm_ba_options *options,
                   osfm_ba_report *report);
 
+/* Host-only (no GPU): the shot renumbering osfm_ba_solve applies to unordered collections (reverse
+   Cuthill-McKee on the co-visibility graph) and the co-visibility half-width before / after it. */
+int osfm_ba_shot_order(const osfm_ba_problem *problem, int32_t *new_of_old, int32_t *half_width_before,
+                       int32_t *half_width_after);
+
 /* =====================================================================================
  * Tracks (next row after the hot path: SURVEY.md 8f-1)
  * Replaces the grouping of tracking.create_tracks_manager (opensfm/tracking.py:68-98, union-find

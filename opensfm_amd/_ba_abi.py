@@ -42,4 +42,5 @@ class BaReport(C.Structure):
 SIGNATURES = {
     "osfm_ba_options_default": (None, [C.POINTER(BaOptions)]),
     "osfm_ba_solve": (C.c_int, [C.c_void_p, C.POINTER(BaProblem), C.POINTER(BaOptions), C.POINTER(BaReport)]),
+    "osfm_ba_shot_order": (C.c_int, [C.POINTER(BaProblem), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
 }

@@ -2330,6 +2330,23 @@ static void rcm_shot_order(const osfm_ba_problem *P, std::vector<int> &new_of_ol
 
 static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_options *O, osfm_ba_report *Rp);
 
+// Host-only helper (no GPU needed): the renumbering osfm_ba_solve would apply.  new_of_old[n_shots] receives the
+// reverse Cuthill-McKee order; returns the co-visibility half-width in the caller's order / after renumbering.
+extern "C" int osfm_ba_shot_order(const osfm_ba_problem *P, int32_t *new_of_old, int32_t *half_width_before, int32_t *half_width_after) {
+  OSFM_REQUIRE(P && new_of_old && P->n_shots > 0 && P->n_points > 0 && P->n_obs > 0 && P->obs_shot && P->obs_point, OSFM_E_INVALID,
+               "osfm_ba_shot_order: bad argument");
+  for (long o = 0; o < P->n_obs; o++)
+    OSFM_REQUIRE(P->obs_shot[o] >= 0 && P->obs_shot[o] < P->n_shots && P->obs_point[o] >= 0 && P->obs_point[o] < P->n_points,
+                 OSFM_E_INVALID, "observation %ld references shot %d / point %d", o, P->obs_shot[o], P->obs_point[o]);
+  std::vector<int> ident((size_t)P->n_shots), order;
+  for (int s = 0; s < P->n_shots; s++) ident[(size_t)s] = s;
+  rcm_shot_order(P, order);
+  if (half_width_before) *half_width_before = covis_half_bandwidth(P, ident);
+  if (half_width_after) *half_width_after = covis_half_bandwidth(P, order);
+  for (int s = 0; s < P->n_shots; s++) new_of_old[s] = order[(size_t)s];
+  return OSFM_OK;
+}
+
 extern "C" int osfm_ba_solve(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_options *O, osfm_ba_report *Rp) {
   OSFM_REQUIRE(ctx && P && O && Rp, OSFM_E_INVALID, "osfm_ba_solve: null argument");
   if (!(P->n_shots > 2 && P->n_points > 0 && P->n_obs > 0 && P->obs_shot && P->obs_point && P->shot_pose && P->shot_camera) ||

@@ -71,3 +71,35 @@ def test_edges_follow_the_reference_union_order():
     off = np.array([0, 10, 20, 30], np.int64)
     ea, eb = tracking.edges_from_match_graph(pairs, counts, matches, off)
     assert list(ea) == [5, 1, 2, 3, 0] and list(eb) == [27, 20, 12, 19, 14]
+
+
+def test_shot_renumbering_restores_the_band_of_a_shuffled_sequence():
+    """osfm_ba_shot_order is host-only code of the library (reverse Cuthill-McKee on the co-visibility graph): a
+    shuffled street sequence gets its narrow band back; the result is a permutation."""
+    import ctypes as C
+
+    from opensfm_amd import _lib
+    from opensfm_amd._ba_abi import BaProblem
+
+    lib = _lib.load()
+    pr = synthetic.make_ba_scene(300, 6000, 8, seed=9)
+    rng = np.random.default_rng(2)
+    inv = np.argsort(rng.permutation(300))
+    obs_shot = np.ascontiguousarray(inv[pr["obs_shot"]], np.int32)
+    obs_point = np.ascontiguousarray(pr["obs_point"], np.int32)
+    P = BaProblem()
+    P.n_cameras, P.n_shots, P.n_points, P.n_obs = 1, 300, 6000, len(obs_shot)
+    P.obs_shot = obs_shot.ctypes.data_as(C.POINTER(C.c_int32))
+    P.obs_point = obs_point.ctypes.data_as(C.POINTER(C.c_int32))
+    order = np.zeros(300, np.int32)
+    b0, b1 = C.c_int32(), C.c_int32()
+    rc = lib.osfm_ba_shot_order(C.byref(P), order.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(b0), C.byref(b1))
+    assert rc == 0
+    assert b0.value > 150 and b1.value <= 10
+    assert np.array_equal(np.sort(order), np.arange(300))
+    new_shot = order[obs_shot]
+    span = np.zeros(6000, np.int64)
+    for p in range(6000):
+        s = new_shot[obs_point == p]
+        span[p] = s.max() - s.min()
+    assert span.max() == b1.value
