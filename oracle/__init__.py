@@ -267,3 +267,15 @@ def tracks(edge_a, edge_b, node_offsets, min_length: int = 2):
     nobs = f(_p(ea, C.c_int32), _p(eb, C.c_int32), C.c_int64(len(ea)), _p(off, C.c_int64), C.c_int32(len(off) - 1),
              C.c_int32(min_length), _p(ot, C.c_int32), _p(oi, C.c_int32), _p(of, C.c_int32), C.byref(nt))
     return int(nt.value), ot[:nobs], oi[:nobs], of[:nobs]
+
+
+# ------------------------------------------------------------------------------------------------
+# relative pose oracle -- groundwork for the calibrated robust-matching branch (oracle/relpose_oracle.c)
+# ------------------------------------------------------------------------------------------------
+def essential_five_points(b1, b2) -> np.ndarray:
+    """geometry::EssentialFivePoints (essential.h:99-160): 5 bearing pairs -> (k, 3, 3), x2^T E x1 = 0."""
+    b1 = np.ascontiguousarray(b1, np.float64).reshape(5, 3)
+    b2 = np.ascontiguousarray(b2, np.float64).reshape(5, 3)
+    out = np.zeros(90, np.float64)
+    n = lib().oracle_essential_five_points(_p(b1, C.c_double), _p(b2, C.c_double), _p(out, C.c_double))
+    return out.reshape(10, 3, 3)[:n]

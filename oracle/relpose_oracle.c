@@ -1,0 +1,329 @@
+/* relpose_oracle.c -- CPU restatement of the calibrated (essential-matrix) branch of robust matching.
+ *
+ * TEST INFRASTRUCTURE ONLY, and GROUNDWORK: the product path does not implement this branch yet
+ * (opensfm_amd.matching raises NotImplementedError for cameras that need it).
+ * This file pins down the numerics the GPU kernel will have to reproduce.
+ *
+ * Stage 1 (this file): the five-point essential-matrix solver.
+ *   reference: geometry::EssentialFivePoints (opensfm/src/geometry/essential.h:99-160,
+ *   opensfm/src/geometry/src/essential.cc:54-143), i.e. Stewenius/Nister: null space of the 5 x 9
+ *   epipolar system, the ten cubic constraints det(E) = 0 and 2 E E^T E - tr(E E^T) E = 0 in the
+ *   monomial basis [xxx xxy xyy yyy xxz xyz yyz xzz yzz zzz | xx xy yy xz yz zz x y z 1], Gauss-Jordan,
+ *   the 10 x 10 action matrix of multiplication by x, its real eigen-pairs.
+ *   Deliberate differences (every step uses only + - * / sqrt so that a GPU thread can reproduce it
+ *   bit for bit): the null space comes from Gauss-Jordan with complete pivoting instead of a Jacobi SVD
+ *   (the solution set does not depend on the basis), the Gauss-Jordan of the constraint matrix pivots,
+ *   eigenvalues come from Hessenberg + shifted QR written out here instead of Eigen::EigenSolver, and
+ *   eigenvectors from the null space of (A - lambda I).
+ * Parity: unpinned vs the reference binary (Eigen is not available); pinned by algebraic known answers
+ * (tests/test_oracle_relpose.py): every returned E satisfies the five epipolar equations, det E = 0 and
+ * the trace constraint, and the ground-truth essential matrix of a synthetic two-view set is among them
+ * (the reference's own check in opensfm/test/test_multiview.py::test_essential_five_points).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+/* monomials of degree <= 3 in (x, y, z), the reference's order (essential.h:30-61) */
+static const int MONO[20][3] = {{3, 0, 0}, {2, 1, 0}, {1, 2, 0}, {0, 3, 0}, {2, 0, 1}, {1, 1, 1}, {0, 2, 1}, {1, 0, 2}, {0, 1, 2}, {0, 0, 3},
+                                {2, 0, 0}, {1, 1, 0}, {0, 2, 0}, {1, 0, 1}, {0, 1, 1}, {0, 0, 2}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {0, 0, 0}};
+static int mono_index(int a, int b, int c) {
+  for (int i = 0; i < 20; i++)
+    if (MONO[i][0] == a && MONO[i][1] == b && MONO[i][2] == c) return i;
+  return -1;
+}
+typedef struct { double c[20]; } poly;
+static poly pzero(void) { poly p; memset(&p, 0, sizeof(p)); return p; }
+static poly padd(poly a, poly b) { for (int i = 0; i < 20; i++) a.c[i] += b.c[i]; return a; }
+static poly psub(poly a, poly b) { for (int i = 0; i < 20; i++) a.c[i] -= b.c[i]; return a; }
+static poly pscale(poly a, double s) { for (int i = 0; i < 20; i++) a.c[i] *= s; return a; }
+static poly pmul(poly a, poly b) { /* total degree of the product must stay <= 3 */
+  poly r = pzero();
+  for (int i = 0; i < 20; i++) {
+    if (a.c[i] == 0.0) continue;
+    for (int j = 0; j < 20; j++) {
+      if (b.c[j] == 0.0) continue;
+      const int k = mono_index(MONO[i][0] + MONO[j][0], MONO[i][1] + MONO[j][1], MONO[i][2] + MONO[j][2]);
+      if (k >= 0) r.c[k] += a.c[i] * b.c[j];
+    }
+  }
+  return r;
+}
+
+/* null space of an m x n system (m < n) by Gauss-Jordan with complete pivoting: basis[n][n - m] */
+static int nullspace(double *A, int m, int n, double *basis) {
+  int colperm[16];
+  for (int j = 0; j < n; j++) colperm[j] = j;
+  for (int k = 0; k < m; k++) {
+    int pr = k, pc = k;
+    double best = 0;
+    for (int i = k; i < m; i++)
+      for (int j = k; j < n; j++)
+        if (fabs(A[i * n + j]) > best) { best = fabs(A[i * n + j]); pr = i; pc = j; }
+    if (!(best > 0)) return 0;
+    for (int j = 0; j < n; j++) { double t = A[k * n + j]; A[k * n + j] = A[pr * n + j]; A[pr * n + j] = t; }
+    for (int i = 0; i < m; i++) { double t = A[i * n + k]; A[i * n + k] = A[i * n + pc]; A[i * n + pc] = t; }
+    { int t = colperm[k]; colperm[k] = colperm[pc]; colperm[pc] = t; }
+    const double ip = 1.0 / A[k * n + k];
+    for (int j = 0; j < n; j++) A[k * n + j] *= ip;
+    for (int i = 0; i < m; i++) {
+      if (i == k) continue;
+      const double f = A[i * n + k];
+      if (f == 0.0) continue;
+      for (int j = 0; j < n; j++) A[i * n + j] -= f * A[k * n + j];
+    }
+  }
+  const int nf = n - m; /* free variables: permuted columns m .. n-1 */
+  for (int f = 0; f < nf; f++) {
+    for (int j = 0; j < n; j++) basis[j * nf + f] = 0.0;
+    basis[colperm[m + f] * nf + f] = 1.0;
+    for (int k = 0; k < m; k++) basis[colperm[k] * nf + f] = -A[k * n + m + f];
+  }
+  return 1;
+}
+
+/* real eigenvalues of a general n x n matrix (n <= 10): Hessenberg reduction + shifted QR (Francis double
+ * shift in the real Schur form, EISPACK hqr); returns the number of REAL eigenvalues written to wr */
+static int real_eigenvalues(double *a, int n, double *wr) {
+  /* Hessenberg by stabilised elementary similarity transformations (elmhes) */
+  for (int m = 1; m < n - 1; m++) {
+    double x = 0.0;
+    int i = m;
+    for (int j = m; j < n; j++)
+      if (fabs(a[j * n + m - 1]) > fabs(x)) { x = a[j * n + m - 1]; i = j; }
+    if (i != m) {
+      for (int j = m - 1; j < n; j++) { double t = a[i * n + j]; a[i * n + j] = a[m * n + j]; a[m * n + j] = t; }
+      for (int j = 0; j < n; j++) { double t = a[j * n + i]; a[j * n + i] = a[j * n + m]; a[j * n + m] = t; }
+    }
+    if (x != 0.0) {
+      for (i = m + 1; i < n; i++) {
+        double y = a[i * n + m - 1];
+        if (y != 0.0) {
+          y /= x;
+          a[i * n + m - 1] = y;
+          for (int j = m; j < n; j++) a[i * n + j] -= y * a[m * n + j];
+          for (int j = 0; j < n; j++) a[j * n + m] += y * a[j * n + i];
+        }
+      }
+    }
+  }
+  for (int i = 2; i < n; i++)
+    for (int j = 0; j < i - 1; j++) a[i * n + j] = 0.0;
+  /* hqr */
+  int nreal = 0, nn = n - 1, its;
+  double anorm = 0.0, t = 0.0, p = 0, q = 0, r = 0, s, w, x, y, z;
+  for (int i = 0; i < n; i++)
+    for (int j = (i > 0 ? i - 1 : 0); j < n; j++) anorm += fabs(a[i * n + j]);
+  while (nn >= 0) {
+    its = 0;
+    int l;
+    do {
+      for (l = nn; l >= 1; l--) {
+        s = fabs(a[(l - 1) * n + l - 1]) + fabs(a[l * n + l]);
+        if (s == 0.0) s = anorm;
+        if (fabs(a[l * n + l - 1]) + s == s) { a[l * n + l - 1] = 0.0; break; }
+      }
+      x = a[nn * n + nn];
+      if (l == nn) { /* one real root */
+        wr[nreal++] = x + t;
+        nn--;
+      } else {
+        y = a[(nn - 1) * n + nn - 1];
+        w = a[nn * n + nn - 1] * a[(nn - 1) * n + nn];
+        if (l == nn - 1) { /* two roots */
+          p = 0.5 * (y - x);
+          q = p * p + w;
+          z = sqrt(fabs(q));
+          x += t;
+          if (q >= 0.0) { /* a real pair */
+            z = p + (p >= 0.0 ? fabs(z) : -fabs(z));
+            wr[nreal] = wr[nreal + 1] = x + z;
+            if (z != 0.0) wr[nreal + 1] = x - w / z;
+            nreal += 2;
+          }
+          nn -= 2;
+        } else {
+          if (its == 60) return nreal; /* no convergence: report what was found */
+          if (its == 10 || its == 20) { /* exceptional shift */
+            t += x;
+            for (int i = 0; i <= nn; i++) a[i * n + i] -= x;
+            s = fabs(a[nn * n + nn - 1]) + fabs(a[(nn - 1) * n + nn - 2]);
+            y = x = 0.75 * s;
+            w = -0.4375 * s * s;
+          }
+          ++its;
+          int m;
+          for (m = nn - 2; m >= l; m--) {
+            z = a[m * n + m];
+            r = x - z;
+            s = y - z;
+            p = (r * s - w) / a[(m + 1) * n + m] + a[m * n + m + 1];
+            q = a[(m + 1) * n + m + 1] - z - r - s;
+            r = a[(m + 2) * n + m + 1];
+            s = fabs(p) + fabs(q) + fabs(r);
+            p /= s; q /= s; r /= s;
+            if (m == l) break;
+            const double u = fabs(a[m * n + m - 1]) * (fabs(q) + fabs(r));
+            const double v = fabs(p) * (fabs(a[(m - 1) * n + m - 1]) + fabs(z) + fabs(a[(m + 1) * n + m + 1]));
+            if (u + v == v) break;
+          }
+          for (int i = m + 2; i <= nn; i++) {
+            a[i * n + i - 2] = 0.0;
+            if (i != m + 2) a[i * n + i - 3] = 0.0;
+          }
+          for (int k = m; k <= nn - 1; k++) {
+            if (k != m) {
+              p = a[k * n + k - 1];
+              q = a[(k + 1) * n + k - 1];
+              r = 0.0;
+              if (k != nn - 1) r = a[(k + 2) * n + k - 1];
+              if ((x = fabs(p) + fabs(q) + fabs(r)) != 0.0) { p /= x; q /= x; r /= x; }
+            }
+            const double sg = sqrt(p * p + q * q + r * r);
+            s = p >= 0.0 ? sg : -sg;
+            if (s != 0.0) {
+              if (k == m) {
+                if (l != m) a[k * n + k - 1] = -a[k * n + k - 1];
+              } else {
+                a[k * n + k - 1] = -s * x;
+              }
+              p += s;
+              x = p / s; y = q / s; z = r / s;
+              q /= p; r /= p;
+              for (int j = k; j <= nn; j++) {
+                p = a[k * n + j] + q * a[(k + 1) * n + j];
+                if (k != nn - 1) { p += r * a[(k + 2) * n + j]; a[(k + 2) * n + j] -= p * z; }
+                a[(k + 1) * n + j] -= p * y;
+                a[k * n + j] -= p * x;
+              }
+              const int mmin = nn < k + 3 ? nn : k + 3;
+              for (int i = l; i <= mmin; i++) {
+                p = x * a[i * n + k] + y * a[i * n + k + 1];
+                if (k != nn - 1) { p += z * a[i * n + k + 2]; a[i * n + k + 2] -= p * r; }
+                a[i * n + k + 1] -= p * q;
+                a[i * n + k] -= p;
+              }
+            }
+          }
+        }
+      }
+    } while (l < nn - 1);
+  }
+  return nreal;
+}
+
+/* b1, b2: 5 x 3 bearings (x2^T E x1 = 0, essential.h:63-72).  Es: up to 10 row-major 3 x 3 matrices of unit
+ * Frobenius norm.  Returns their number. */
+int oracle_essential_five_points(const double *b1, const double *b2, double *Es) {
+  double A[5 * 9], basis[9 * 4];
+  for (int i = 0; i < 5; i++)
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) A[i * 9 + 3 * r + c] = b2[3 * i + r] * b1[3 * i + c];
+  if (!nullspace(A, 5, 9, basis)) return 0;
+  /* E(x, y, z) = x E0 + y E1 + z E2 + E3 */
+  poly E[3][3];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      E[i][j] = pzero();
+      E[i][j].c[16] = basis[(3 * i + j) * 4 + 0];
+      E[i][j].c[17] = basis[(3 * i + j) * 4 + 1];
+      E[i][j].c[18] = basis[(3 * i + j) * 4 + 2];
+      E[i][j].c[19] = basis[(3 * i + j) * 4 + 3];
+    }
+  double M[10 * 20];
+  int row = 0;
+  { /* det E = 0 */
+    poly d = pmul(psub(pmul(E[0][1], E[1][2]), pmul(E[0][2], E[1][1])), E[2][0]);
+    d = padd(d, pmul(psub(pmul(E[0][2], E[1][0]), pmul(E[0][0], E[1][2])), E[2][1]));
+    d = padd(d, pmul(psub(pmul(E[0][0], E[1][1]), pmul(E[0][1], E[1][0])), E[2][2]));
+    memcpy(M + 20 * row++, d.c, sizeof(d.c));
+  }
+  { /* (E E^T - 1/2 tr(E E^T) I) E = 0 */
+    poly L[3][3];
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) L[i][j] = padd(padd(pmul(E[i][0], E[j][0]), pmul(E[i][1], E[j][1])), pmul(E[i][2], E[j][2]));
+    const poly tr = pscale(padd(padd(L[0][0], L[1][1]), L[2][2]), 0.5);
+    for (int i = 0; i < 3; i++) L[i][i] = psub(L[i][i], tr);
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) {
+        const poly le = padd(padd(pmul(L[i][0], E[0][j]), pmul(L[i][1], E[1][j])), pmul(L[i][2], E[2][j]));
+        memcpy(M + 20 * row++, le.c, sizeof(le.c));
+      }
+  }
+  /* Gauss-Jordan on the cubic monomials (columns 0..9), partial pivoting */
+  for (int k = 0; k < 10; k++) {
+    int pr = k;
+    for (int i = k + 1; i < 10; i++)
+      if (fabs(M[i * 20 + k]) > fabs(M[pr * 20 + k])) pr = i;
+    if (!(fabs(M[pr * 20 + k]) > 0)) return 0;
+    for (int j = 0; j < 20; j++) { double t = M[k * 20 + j]; M[k * 20 + j] = M[pr * 20 + j]; M[pr * 20 + j] = t; }
+    const double ip = 1.0 / M[k * 20 + k];
+    for (int j = 0; j < 20; j++) M[k * 20 + j] *= ip;
+    for (int i = 0; i < 10; i++) {
+      if (i == k) continue;
+      const double f = M[i * 20 + k];
+      if (f == 0.0) continue;
+      for (int j = 0; j < 20; j++) M[i * 20 + j] -= f * M[k * 20 + j];
+    }
+  }
+  /* action matrix of "multiply by x" on the basis [xx xy yy xz yz zz x y z 1] (essential.h:116-131) */
+  double At[100], Aq[100];
+  memset(At, 0, sizeof(At));
+  const int src[6] = {0, 1, 2, 4, 5, 7}; /* x*xx = xxx, x*xy = xxy, x*yy = xyy, x*xz = xxz, x*yz = xyz, x*zz = xzz */
+  for (int r = 0; r < 6; r++)
+    for (int j = 0; j < 10; j++) At[r * 10 + j] = -M[src[r] * 20 + 10 + j];
+  At[6 * 10 + 0] = 1.0; /* x*x = xx */
+  At[7 * 10 + 1] = 1.0; /* x*y = xy */
+  At[8 * 10 + 3] = 1.0; /* x*z = xz */
+  At[9 * 10 + 6] = 1.0; /* x*1 = x  */
+  memcpy(Aq, At, sizeof(At));
+  double wr[10];
+  const int nreal = real_eigenvalues(Aq, 10, wr);
+  int count = 0;
+  for (int e = 0; e < nreal && count < 10; e++) {
+    /* the monomial vector at a solution is the eigenvector: null space of (At - lambda I) */
+    double S[10 * 10], v[10];
+    for (int i = 0; i < 100; i++) S[i] = At[i];
+    for (int i = 0; i < 10; i++) S[i * 10 + i] -= wr[e];
+    /* drop the most dependent row: complete-pivot elimination of a 9 x 10 system leaves one free variable */
+    {
+      int colperm[10], rowperm[10];
+      for (int j = 0; j < 10; j++) colperm[j] = rowperm[j] = j;
+      int ok = 1;
+      for (int k = 0; k < 9 && ok; k++) {
+        int pr = k, pc = k;
+        double best = 0;
+        for (int i = k; i < 10; i++)
+          for (int j = k; j < 10; j++)
+            if (fabs(S[i * 10 + j]) > best) { best = fabs(S[i * 10 + j]); pr = i; pc = j; }
+        if (!(best > 0)) { ok = 0; break; }
+        for (int j = 0; j < 10; j++) { double t = S[k * 10 + j]; S[k * 10 + j] = S[pr * 10 + j]; S[pr * 10 + j] = t; }
+        for (int i = 0; i < 10; i++) { double t = S[i * 10 + k]; S[i * 10 + k] = S[i * 10 + pc]; S[i * 10 + pc] = t; }
+        { int t = colperm[k]; colperm[k] = colperm[pc]; colperm[pc] = t; }
+        const double ip = 1.0 / S[k * 10 + k];
+        for (int j = 0; j < 10; j++) S[k * 10 + j] *= ip;
+        for (int i = 0; i < 10; i++) {
+          if (i == k) continue;
+          const double f = S[i * 10 + k];
+          if (f == 0.0) continue;
+          for (int j = 0; j < 10; j++) S[i * 10 + j] -= f * S[k * 10 + j];
+        }
+      }
+      if (!ok) continue;
+      v[colperm[9]] = 1.0;
+      for (int k = 0; k < 9; k++) v[colperm[k]] = -S[k * 10 + 9];
+    }
+    if (v[9] == 0.0) continue;
+    const double x = v[6] / v[9], y = v[7] / v[9], z = v[8] / v[9];
+    double Em[9], nrm = 0.0;
+    for (int i = 0; i < 9; i++) {
+      Em[i] = x * basis[i * 4 + 0] + y * basis[i * 4 + 1] + z * basis[i * 4 + 2] + basis[i * 4 + 3];
+      nrm += Em[i] * Em[i];
+    }
+    nrm = sqrt(nrm);
+    if (!(nrm > 0) || !isfinite(nrm)) continue;
+    for (int i = 0; i < 9; i++) Es[9 * count + i] = Em[i] / nrm;
+    count++;
+  }
+  return count;
+}

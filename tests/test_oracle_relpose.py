@@ -1,0 +1,50 @@
+"""Groundwork for the calibrated robust-matching branch: the five-point solver of
+the oracle against algebraic known answers, as opensfm/test/test_multiview.py checks the reference's."""
+import numpy as np
+
+
+def _rodrigues(r):
+    th = np.linalg.norm(r)
+    K = np.array([[0, -r[2], r[1]], [r[2], 0, -r[0]], [-r[1], r[0], 0]])
+    return np.eye(3) if th == 0 else np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th**2 * K @ K
+
+
+def _two_views(rng, n):
+    R = _rodrigues(rng.normal(0, 0.3, 3))
+    t = rng.normal(0, 1, 3)
+    t /= np.linalg.norm(t)
+    X = np.c_[rng.uniform(-2, 2, n), rng.uniform(-2, 2, n), rng.uniform(4, 9, n)]
+    b1 = X / np.linalg.norm(X, axis=1, keepdims=True)
+    X2 = X @ R.T + t
+    b2 = X2 / np.linalg.norm(X2, axis=1, keepdims=True)
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    E = tx @ R
+    return b1, b2, E / np.linalg.norm(E)
+
+
+def test_five_point_solutions_satisfy_the_constraints_and_contain_the_truth(oracle_lib):
+    rng = np.random.default_rng(4)
+    found = 0
+    for trial in range(30):
+        b1, b2, Egt = _two_views(rng, 5)
+        Es = oracle_lib.essential_five_points(b1, b2)
+        assert 1 <= len(Es) <= 10
+        best = 1.0
+        for E in Es:
+            assert abs(np.linalg.norm(E) - 1) < 1e-12
+            assert np.abs(np.einsum("ni,ij,nj->n", b2, E, b1)).max() < 1e-9  # the five epipolar equations
+            assert abs(np.linalg.det(E)) < 1e-9
+            assert np.abs(2 * E @ E.T @ E - np.trace(E @ E.T) * E).max() < 1e-8  # two equal singular values, one zero
+            best = min(best, np.linalg.norm(E - Egt), np.linalg.norm(E + Egt))
+        found += best < 1e-7
+    assert found == 30
+
+
+def test_five_point_is_deterministic_and_handles_degenerate_input(oracle_lib):
+    rng = np.random.default_rng(5)
+    b1, b2, _ = _two_views(rng, 5)
+    a = oracle_lib.essential_five_points(b1, b2)
+    b = oracle_lib.essential_five_points(b1, b2)
+    assert np.array_equal(a, b)
+    z = oracle_lib.essential_five_points(np.zeros((5, 3)), np.zeros((5, 3)))
+    assert len(z) == 0
