@@ -279,3 +279,13 @@ def essential_five_points(b1, b2) -> np.ndarray:
     out = np.zeros(90, np.float64)
     n = lib().oracle_essential_five_points(_p(b1, C.c_double), _p(b2, C.c_double), _p(out, C.c_double))
     return out.reshape(10, 3, 3)[:n]
+
+
+def relative_pose_from_essential(E, b1, b2):
+    """RelativePoseFromEssential (relative_pose.h:12-84) -> 3 x 4 [R | t] with x2 ~ R x1 + t, or None."""
+    E = np.ascontiguousarray(E, np.float64).reshape(3, 3)
+    b1 = np.ascontiguousarray(b1, np.float64).reshape(-1, 3)
+    b2 = np.ascontiguousarray(b2, np.float64).reshape(-1, 3)
+    RT = np.zeros(12, np.float64)
+    ok = lib().oracle_relative_pose_from_essential(_p(E, C.c_double), _p(b1, C.c_double), _p(b2, C.c_double), len(b1), _p(RT, C.c_double))
+    return RT.reshape(3, 4) if ok else None

@@ -327,3 +327,135 @@ int oracle_essential_five_points(const double *b1, const double *b2, double *Es)
   }
   return count;
 }
+
+/* ---- Stage 2: relative pose from an essential matrix --------------------------------------------------
+ * reference: RelativePoseFromEssential (opensfm/src/geometry/relative_pose.h:12-84) with
+ * geometry::TriangulateTwoBearingsMidpointSolve (opensfm/src/geometry/triangulation.h:84-108).
+ * The 3 x 3 SVD is a one-sided Jacobi (Hestenes) sweep written out here: for an essential matrix the
+ * two candidate rotations U W V^T, U W^T V^T and the translation +-u3 do not depend on which SVD is used. */
+static void svd3(const double *A, double *U, double *S, double *V) {
+  double G[9];
+  memcpy(G, A, sizeof(G));
+  for (int i = 0; i < 9; i++) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 60; sweep++) {
+    double off = 0.0;
+    for (int p = 0; p < 2; p++)
+      for (int q = p + 1; q < 3; q++) {
+        double alpha = 0, beta = 0, gamma = 0;
+        for (int k = 0; k < 3; k++) {
+          alpha += G[3 * k + p] * G[3 * k + p];
+          beta += G[3 * k + q] * G[3 * k + q];
+          gamma += G[3 * k + p] * G[3 * k + q];
+        }
+        if (gamma == 0.0) continue;
+        off = fmax(off, fabs(gamma) / sqrt(alpha * beta + 1e-300));
+        const double zeta = (beta - alpha) / (2.0 * gamma);
+        const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+        for (int k = 0; k < 3; k++) {
+          const double gp = G[3 * k + p], gq = G[3 * k + q];
+          G[3 * k + p] = c * gp - s * gq;
+          G[3 * k + q] = s * gp + c * gq;
+          const double vp = V[3 * k + p], vq = V[3 * k + q];
+          V[3 * k + p] = c * vp - s * vq;
+          V[3 * k + q] = s * vp + c * vq;
+        }
+      }
+    if (off < 1e-16) break;
+  }
+  /* singular values = column norms, sorted descending */
+  int order[3] = {0, 1, 2};
+  double nrm[3];
+  for (int j = 0; j < 3; j++) nrm[j] = sqrt(G[j] * G[j] + G[3 + j] * G[3 + j] + G[6 + j] * G[6 + j]);
+  for (int a = 0; a < 2; a++)
+    for (int b = a + 1; b < 3; b++)
+      if (nrm[order[b]] > nrm[order[a]]) { int t = order[a]; order[a] = order[b]; order[b] = t; }
+  double Vs[9];
+  for (int j = 0; j < 3; j++) {
+    const int o = order[j];
+    S[j] = nrm[o];
+    for (int k = 0; k < 3; k++) {
+      Vs[3 * k + j] = V[3 * k + o];
+      U[3 * k + j] = nrm[o] > 0 ? G[3 * k + o] / nrm[o] : 0.0;
+    }
+  }
+  memcpy(V, Vs, sizeof(Vs));
+  /* a (numerically) zero singular value leaves its left vector undefined: complete U to an orthonormal basis */
+  if (!(S[2] > 1e-12 * S[0])) {
+    const double *u0 = U, *u1 = U + 1; /* columns 0 and 1 (stride 3) */
+    U[2] = u0[3] * u1[6] - u0[6] * u1[3];
+    U[5] = u0[6] * u1[0] - u0[0] * u1[6];
+    U[8] = u0[0] * u1[3] - u0[3] * u1[0];
+  }
+}
+static double det3m(const double *M) {
+  return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+/* centers (2 x 3), bearings (2 x 3) -> midpoint of the two closest points; returns 0 when the rays are parallel */
+static int triangulate_midpoint2(const double *c0, const double *c1, const double *r0, const double *r1, double *X) {
+  const double t[3] = {c1[0] - c0[0], c1[1] - c0[1], c1[2] - c0[2]};
+  const double b0 = t[0] * r0[0] + t[1] * r0[1] + t[2] * r0[2], b1 = t[0] * r1[0] + t[1] * r1[1] + t[2] * r1[2];
+  const double a00 = r0[0] * r0[0] + r0[1] * r0[1] + r0[2] * r0[2];
+  const double a10 = r0[0] * r1[0] + r0[1] * r1[1] + r0[2] * r1[2];
+  const double a01 = -a10, a11 = -(r1[0] * r1[0] + r1[1] * r1[1] + r1[2] * r1[2]);
+  const double det = a00 * a11 - a01 * a10;
+  if (-1e-10 < det && det < 1e-10) return 0;
+  const double l0 = (a11 * b0 - a01 * b1) / det, l1 = (-a10 * b0 + a00 * b1) / det;
+  for (int i = 0; i < 3; i++) X[i] = 0.5 * ((c0[i] + l0 * r0[i]) + (c1[i] + l1 * r1[i]));
+  return 1;
+}
+
+/* E (row-major, x2^T E x1 = 0), n bearing pairs -> RT (3 x 4 row-major: [R | t], x2 ~ R x1 + t).
+ * Returns 1 when a decomposition scored > 0 (the reference returns an uninitialised matrix otherwise). */
+int oracle_relative_pose_from_essential(const double *E, const double *b1, const double *b2, int n, double *RT) {
+  double U[9], S[3], V[9], Vt[9];
+  svd3(E, U, S, V);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) Vt[3 * i + j] = V[3 * j + i];
+  if (det3m(U) < 0)
+    for (int k = 0; k < 3; k++) U[3 * k + 2] = -U[3 * k + 2];
+  if (det3m(Vt) < 0)
+    for (int k = 0; k < 3; k++) Vt[6 + k] = -Vt[6 + k];
+  const double W[9] = {0, -1, 0, 1, 0, 0, 0, 0, 1}, Wt[9] = {0, 1, 0, -1, 0, 0, 0, 0, 1};
+  double best = 0.0;
+  int found = 0;
+  for (int i = 0; i < 2; i++) {
+    double t[3] = {U[2], U[5], U[8]};
+    if (i == 1)
+      for (int k = 0; k < 3; k++) t[k] = -t[k];
+    const double tn = sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
+    for (int k = 0; k < 3; k++) t[k] /= tn;
+    for (int j = 0; j < 2; j++) {
+      const double *Wm = j == 0 ? W : Wt;
+      double UW[9], R[9];
+      for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) UW[3 * a + b] = U[3 * a] * Wm[b] + U[3 * a + 1] * Wm[3 + b] + U[3 * a + 2] * Wm[6 + b];
+      for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) R[3 * a + b] = UW[3 * a] * Vt[b] + UW[3 * a + 1] * Vt[3 + b] + UW[3 * a + 2] * Vt[6 + b];
+      const double c0[3] = {0, 0, 0};
+      double c1[3];
+      for (int a = 0; a < 3; a++) c1[a] = -(R[a] * t[0] + R[3 + a] * t[1] + R[6 + a] * t[2]); /* -R^T t */
+      double score = 0.0;
+      for (int s = 0; s < n; s++) {
+        const double *x = b1 + 3 * s, *y = b2 + 3 * s;
+        double ry[3], X[3];
+        for (int a = 0; a < 3; a++) ry[a] = R[a] * y[0] + R[3 + a] * y[1] + R[6 + a] * y[2]; /* R^T y */
+        if (!triangulate_midpoint2(c0, c1, x, ry, X)) continue;
+        const double nx = sqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2]);
+        double Y[3];
+        for (int a = 0; a < 3; a++) Y[a] = R[3 * a] * X[0] + R[3 * a + 1] * X[1] + R[3 * a + 2] * X[2] + t[a];
+        const double ny = sqrt(Y[0] * Y[0] + Y[1] * Y[1] + Y[2] * Y[2]);
+        score += 0.5 * ((X[0] * x[0] + X[1] * x[1] + X[2] * x[2]) / nx + (Y[0] * y[0] + Y[1] * y[1] + Y[2] * y[2]) / ny);
+      }
+      if (score > best) {
+        best = score;
+        found = 1;
+        for (int a = 0; a < 3; a++) {
+          for (int b = 0; b < 3; b++) RT[4 * a + b] = R[3 * a + b];
+          RT[4 * a + 3] = t[a];
+        }
+      }
+    }
+  }
+  return found;
+}

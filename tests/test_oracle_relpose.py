@@ -48,3 +48,29 @@ def test_five_point_is_deterministic_and_handles_degenerate_input(oracle_lib):
     assert np.array_equal(a, b)
     z = oracle_lib.essential_five_points(np.zeros((5, 3)), np.zeros((5, 3)))
     assert len(z) == 0
+
+
+def test_relative_pose_from_essential_recovers_the_motion(oracle_lib):
+    """opensfm/test/test_multiview.py checks the reference the same way: the decomposition selected by the
+    cheirality score is the true (R, t) for noise-free bearings, for the true E and for its five-point estimate."""
+    rng = np.random.default_rng(6)
+    for trial in range(20):
+        b1, b2, Egt = _two_views(rng, 12)
+        # ground truth of _two_views: x2 ~ R x1 + t with E = [t]x R
+        U, _, Vt = np.linalg.svd(Egt)
+        RT = oracle_lib.relative_pose_from_essential(Egt, b1, b2)
+        assert RT is not None
+        R, t = RT[:, :3], RT[:, 3]
+        assert abs(np.linalg.det(R) - 1) < 1e-9 and np.allclose(R @ R.T, np.eye(3), atol=1e-9) and abs(np.linalg.norm(t) - 1) < 1e-12
+        tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+        Erec = tx @ R
+        Erec /= np.linalg.norm(Erec)
+        assert min(np.linalg.norm(Erec - Egt), np.linalg.norm(Erec + Egt)) < 1e-8
+        # cheirality: every point is in front of both cameras for the chosen decomposition
+        X = b1  # directions only; depth sign checked through the triangulated depths along the bearings
+        y = (b1 * 5.0) @ R.T + t  # a point 5 units along each first-view bearing lands in front of the second camera
+        assert (np.einsum("ni,ni->n", y / np.linalg.norm(y, axis=1, keepdims=True), b2) > 0).all()
+        Es = oracle_lib.essential_five_points(b1[:5], b2[:5])
+        errs = [min(np.linalg.norm(E - Egt), np.linalg.norm(E + Egt)) for E in Es]
+        RT5 = oracle_lib.relative_pose_from_essential(Es[int(np.argmin(errs))], b1, b2)
+        assert np.allclose(RT5, RT, atol=1e-6)
