@@ -289,3 +289,20 @@ def relative_pose_from_essential(E, b1, b2):
     RT = np.zeros(12, np.float64)
     ok = lib().oracle_relative_pose_from_essential(_p(E, C.c_double), _p(b1, C.c_double), _p(b2, C.c_double), len(b1), _p(RT, C.c_double))
     return RT.reshape(3, 4) if ok else None
+
+
+def ransac_relative_pose(b1, b2, threshold: float, iterations: int = 1000, probability: float = 0.99, use_lo: bool = True,
+                         lo_iterations: int = 10):
+    """pyrobust.ransac_relative_pose(b1, b2, threshold, params, RANSAC) (instanciations.cc:33-48).  The Python caller
+    (multiview.relative_pose_ransac, multiview.py:494-517) only sets params.iterations: probability stays 0.99.
+    -> dict(score, model, lo_model, inliers, iterations)"""
+    b1 = np.ascontiguousarray(b1, np.float64).reshape(-1, 3)
+    b2 = np.ascontiguousarray(b2, np.float64).reshape(-1, 3)
+    n = len(b1)
+    model, lo = np.zeros(12), np.zeros(12)
+    inl = np.zeros(max(n, 1), np.int32)
+    it = C.c_int(0)
+    score = lib().oracle_ransac_relative_pose(_p(b1, C.c_double), _p(b2, C.c_double), n, C.c_double(threshold), iterations,
+                                              C.c_double(probability), int(use_lo), lo_iterations, _p(model, C.c_double), _p(lo, C.c_double),
+                                              _p(inl, C.c_int32), C.byref(it))
+    return {"score": score, "model": model.reshape(3, 4), "lo_model": lo.reshape(3, 4), "inliers": inl[:score].copy(), "iterations": it.value}

@@ -459,3 +459,223 @@ int oracle_relative_pose_from_essential(const double *E, const double *b1, const
   }
   return found;
 }
+
+/* ---- Stage 3: LO-RANSAC for the relative pose ----------------------------------------------------------
+ * reference: robust::RANSACRelativePose -> RunEstimation<RelativePose> -> Estimate<RansacScoring, RelativePose>
+ * (opensfm/src/robust/src/instanciations.cc:33-48, robust_estimator.h:37-119, scorer.h:23-41,
+ * random_sampler.h, relative_pose_model.h), EssentialNPoints (geometry/essential.h:162-192) with
+ * foundation::SolveAX0 (foundation/numeric.h:20-43).
+ * The sampler is std::mt19937(42) + std::uniform_int_distribution<uint32_t>(0, n - 1).  mt19937 is fixed by the
+ * C++ standard; the distribution is NOT (libstdc++ changed its algorithm in GCC 11), so which samples the
+ * reference draws depends on the toolchain that built it: parity with a reference binary is not defined for this
+ * branch, only statistically (opensfm/test/test_robust.py:192-274).  Restated here with libstdc++'s classic
+ * rejection-downscaling (< GCC 11).  The 9 x 9 and 3 x 3 decompositions are cyclic Jacobi (+ - * / sqrt only). */
+typedef struct { uint32_t mt[624]; int idx; } mt19937_t;
+static void mt_seed(mt19937_t *g, uint32_t seed) {
+  g->mt[0] = seed;
+  for (int i = 1; i < 624; i++) g->mt[i] = 1812433253u * (g->mt[i - 1] ^ (g->mt[i - 1] >> 30)) + (uint32_t)i;
+  g->idx = 624;
+}
+static uint32_t mt_next(mt19937_t *g) {
+  if (g->idx >= 624) {
+    for (int i = 0; i < 624; i++) {
+      const uint32_t y = (g->mt[i] & 0x80000000u) | (g->mt[(i + 1) % 624] & 0x7fffffffu);
+      g->mt[i] = g->mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    g->idx = 0;
+  }
+  uint32_t y = g->mt[g->idx++];
+  y ^= y >> 11;
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= y >> 18;
+  return y;
+}
+static uint32_t mt_uniform(mt19937_t *g, uint32_t range_max) { /* [0, range_max] */
+  const uint64_t urange = (uint64_t)range_max + 1;
+  const uint64_t scaling = 4294967296ull / urange, past = urange * scaling;
+  uint32_t r;
+  do r = mt_next(g); while ((uint64_t)r >= past);
+  return (uint32_t)(r / scaling);
+}
+static void draw_sample(mt19937_t *g, int size, int n, int *idx) { /* GenerateOneSample: distinct indices */
+  for (int i = 0; i < size; i++) {
+    int dup;
+    do {
+      idx[i] = (int)mt_uniform(g, (uint32_t)(n - 1));
+      dup = 0;
+      for (int j = 0; j < i; j++) dup |= idx[j] == idx[i];
+    } while (dup);
+  }
+}
+/* symmetric eigen-decomposition by cyclic Jacobi: A (n x n, destroyed) -> eigenvalues w, eigenvectors V (columns) */
+static void jacobi_eig(double *A, int n, double *w, double *V) {
+  for (int i = 0; i < n * n; i++) V[i] = (i % (n + 1) == 0) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 100; sweep++) {
+    double off = 0.0;
+    for (int p = 0; p < n - 1; p++)
+      for (int q = p + 1; q < n; q++) off += A[p * n + q] * A[p * n + q];
+    if (!(off > 1e-300)) break;
+    for (int p = 0; p < n - 1; p++)
+      for (int q = p + 1; q < n; q++) {
+        const double apq = A[p * n + q];
+        if (apq == 0.0) continue;
+        const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < n; k++) {
+          const double akp = A[k * n + p], akq = A[k * n + q];
+          A[k * n + p] = c * akp - s * akq;
+          A[k * n + q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < n; k++) {
+          const double apk = A[p * n + k], aqk = A[q * n + k];
+          A[p * n + k] = c * apk - s * aqk;
+          A[q * n + k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < n; k++) {
+          const double vkp = V[k * n + p], vkq = V[k * n + q];
+          V[k * n + p] = c * vkp - s * vkq;
+          V[k * n + q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  for (int i = 0; i < n; i++) w[i] = A[i * n + i];
+}
+/* EssentialNPoints: returns 0 or 1 matrices (row-major) */
+static int essential_n_points(const double *b1, const double *b2, const int *idx, int count, double *E) {
+  if (count < 9) return 0; /* SolveAX0: under-constrained systems are not solved (rows < cols) */
+  double AtA[81], w[9], V[81];
+  memset(AtA, 0, sizeof(AtA));
+  for (int s = 0; s < count; s++) {
+    const double *x1 = b1 + 3 * idx[s], *x2 = b2 + 3 * idx[s];
+    double row[9];
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) row[3 * r + c] = x2[r] * x1[c];
+    for (int i = 0; i < 9; i++)
+      for (int j = 0; j < 9; j++) AtA[9 * i + j] += row[i] * row[j];
+  }
+  jacobi_eig(AtA, 9, w, V);
+  int lo = 0, lo2 = -1; /* smallest and second smallest eigenvalue of A^T A = squared singular values */
+  for (int i = 1; i < 9; i++)
+    if (w[i] < w[lo]) lo = i;
+  for (int i = 0; i < 9; i++)
+    if (i != lo && (lo2 < 0 || w[i] < w[lo2])) lo2 = i;
+  const double s_small = sqrt(fmax(w[lo], 0.0)), s_next = sqrt(fmax(w[lo2], 0.0));
+  if (!(s_next / s_small > 4.0)) return 0; /* ratio of the two smallest singular values (numeric.h:31-41) */
+  double Em[9];
+  for (int i = 0; i < 9; i++) Em[i] = V[9 * i + lo]; /* solution reshaped row-major (Map<Matrix3d>.transpose()) */
+  /* count > 8: enforce two equal singular values and a zero one */
+  double U[9], S[3], Vv[9];
+  svd3(Em, U, S, Vv);
+  const double d = 0.5 * (S[0] + S[1]);
+  for (int a = 0; a < 3; a++)
+    for (int b = 0; b < 3; b++) E[3 * a + b] = d * (U[3 * a] * Vv[3 * b] + U[3 * a + 1] * Vv[3 * b + 1]);
+  return 1;
+}
+static double relpose_error(const double *RT, const double *x0, const double *y0) { /* RelativePose::Evaluate */
+  double x[3], y[3], R[9], t[3];
+  const double nx = sqrt(x0[0] * x0[0] + x0[1] * x0[1] + x0[2] * x0[2]), ny = sqrt(y0[0] * y0[0] + y0[1] * y0[1] + y0[2] * y0[2]);
+  for (int a = 0; a < 3; a++) {
+    x[a] = x0[a] / nx;
+    y[a] = y0[a] / ny;
+    t[a] = RT[4 * a + 3];
+    for (int b = 0; b < 3; b++) R[3 * a + b] = RT[4 * a + b];
+  }
+  const double c0[3] = {0, 0, 0};
+  double c1[3], ry[3], X[3], Y[3];
+  for (int a = 0; a < 3; a++) {
+    c1[a] = -(R[a] * t[0] + R[3 + a] * t[1] + R[6 + a] * t[2]);
+    ry[a] = R[a] * y[0] + R[3 + a] * y[1] + R[6 + a] * y[2];
+  }
+  if (!triangulate_midpoint2(c0, c1, x, ry, X)) return 1.0;
+  for (int a = 0; a < 3; a++) Y[a] = R[3 * a] * X[0] + R[3 * a + 1] * X[1] + R[3 * a + 2] * X[2] + t[a];
+  const double nX = sqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2]), nY = sqrt(Y[0] * Y[0] + Y[1] * Y[1] + Y[2] * Y[2]);
+  return 1.0 - 0.5 * ((X[0] * x[0] + X[1] * x[1] + X[2] * x[2]) / nX + (Y[0] * y[0] + Y[1] * y[1] + Y[2] * y[2]) / nY);
+}
+static int score_model(const double *RT, const double *b1, const double *b2, int n, double thr, int *inl) {
+  int cnt = 0;
+  for (int i = 0; i < n; i++)
+    if (fabs(relpose_error(RT, b1 + 3 * i, b2 + 3 * i)) < thr) inl[cnt++] = i; /* it->norm() < threshold_ */
+  return cnt;
+}
+
+/* b1, b2: n x 3 bearings; threshold in radians; iterations / probability / LO as RobustEstimatorParams.
+ * Outputs: model and lo_model (3 x 4 each), inlier indices of the best score.  Returns the best score. */
+int oracle_ransac_relative_pose(const double *b1, const double *b2, int n, double threshold_angle, int iterations, double probability,
+                                int use_lo, int lo_iterations, double *model, double *lo_model, int *inliers, int *iters_run) {
+  const double thr = 1.0 - cos(threshold_angle); /* RelativePose::ThresholdAdapter */
+  mt19937_t gen;
+  mt_seed(&gen, 42u);
+  int best_score = 0, best_n = 0, it = 0, should_stop = 0;
+  int *tmp = (int *)__builtin_alloca(sizeof(int) * (size_t)(n > 0 ? n : 1));
+  int *gather = (int *)__builtin_alloca(sizeof(int) * (size_t)(n > 0 ? n : 1));
+  memset(model, 0, 12 * sizeof(double));
+  memset(lo_model, 0, 12 * sizeof(double));
+  if (n < 5) { if (iters_run) *iters_run = 0; return 0; }
+  for (it = 0; it < iterations && !should_stop; it++) {
+    int sidx[5];
+    draw_sample(&gen, 5, n, sidx);
+    double s1[15], s2[15], Es[90];
+    for (int k = 0; k < 5; k++)
+      for (int a = 0; a < 3; a++) {
+        s1[3 * k + a] = b1[3 * sidx[k] + a];
+        s2[3 * k + a] = b2[3 * sidx[k] + a];
+      }
+    const int nm = oracle_essential_five_points(s1, s2, Es);
+    for (int j = 0; j < nm && !should_stop; j++) {
+      double RT[12];
+      memset(RT, 0, sizeof(RT)); /* the reference leaves the model uninitialised when no decomposition scores > 0 */
+      oracle_relative_pose_from_essential(Es + 9 * j, s1, s2, 5, RT);
+      const int cnt = score_model(RT, b1, b2, n, thr, tmp);
+      /* best_score = max(score, best_score): replaced only when strictly larger */
+      int best_found = 0;
+      if (cnt > best_score) {
+        best_score = cnt;
+        best_n = cnt;
+        memcpy(inliers, tmp, sizeof(int) * (size_t)cnt);
+        memcpy(model, RT, sizeof(RT));
+        memcpy(lo_model, RT, sizeof(RT));
+      }
+      best_found = (cnt == best_score) && cnt >= 5;
+      if (best_found && use_lo) {
+        for (int k = 0; k < lo_iterations; k++) {
+          const int ninl = best_n;
+          memcpy(gather, inliers, sizeof(int) * (size_t)ninl);
+          int lo_size = (int)(ninl * 0.5);
+          if (lo_size > 12) lo_size = 12;
+          if (lo_size < 5) lo_size = 5;
+          int lidx[12], pick[12];
+          draw_sample(&gen, lo_size, ninl, pick);
+          for (int q = 0; q < lo_size; q++) lidx[q] = gather[pick[q]];
+          double Elo[9];
+          if (!essential_n_points(b1, b2, lidx, lo_size, Elo)) continue;
+          double l1[36], l2[36], RTlo[12];
+          for (int q = 0; q < lo_size; q++)
+            for (int a = 0; a < 3; a++) {
+              l1[3 * q + a] = b1[3 * lidx[q] + a];
+              l2[3 * q + a] = b2[3 * lidx[q] + a];
+            }
+          memset(RTlo, 0, sizeof(RTlo));
+          oracle_relative_pose_from_essential(Elo, l1, l2, lo_size, RTlo);
+          const int c2 = score_model(RTlo, b1, b2, n, thr, tmp);
+          if (c2 > best_score) { /* lo_score.model = best_score.model ; lo_score.lo_model = lo_models[l] */
+            best_score = c2;
+            best_n = c2;
+            memcpy(inliers, tmp, sizeof(int) * (size_t)c2);
+            memcpy(lo_model, RTlo, sizeof(RTlo));
+          }
+        }
+      }
+      { /* ShouldStop */
+        const double ratio = (double)best_n / (double)n;
+        double p1 = 1.0 - ratio * ratio * ratio * ratio * ratio;
+        if (p1 > 1.0 - 2.220446049250313e-16) p1 = 1.0 - 2.220446049250313e-16;
+        const double max_it = log(1.0 - probability) / log(p1);
+        should_stop = max_it < (double)it;
+      }
+    }
+  }
+  if (iters_run) *iters_run = it;
+  return best_score;
+}
