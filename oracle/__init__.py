@@ -306,3 +306,25 @@ def ransac_relative_pose(b1, b2, threshold: float, iterations: int = 1000, proba
                                               C.c_double(probability), int(use_lo), lo_iterations, _p(model, C.c_double), _p(lo, C.c_double),
                                               _p(inl, C.c_int32), C.byref(it))
     return {"score": score, "model": model.reshape(3, 4), "lo_model": lo.reshape(3, 4), "inliers": inl[:score].copy(), "iterations": it.value}
+
+
+def pixel_bearings(model, cam, px) -> np.ndarray:
+    """Camera.pixel_bearing_many for the PERSPECTIVE (0) / FISHEYE (1) models, cam = [k1, k2, focal]."""
+    cam = np.ascontiguousarray(cam, np.float64)
+    px = np.ascontiguousarray(px, np.float64).reshape(-1, 2)
+    out = np.zeros((len(px), 3))
+    lib().oracle_pixel_bearings(int(CAMERA_MODELS[model] if isinstance(model, str) else model), _p(cam, C.c_double), _p(px, C.c_double),
+                                len(px), _p(out, C.c_double))
+    return out
+
+
+def inliers_bearings(b1, b2, R, t, threshold: float = 0.01) -> np.ndarray:
+    """matching.compute_inliers_bearings (matching.py:805-844): R, t from the second image to the first."""
+    b1 = np.ascontiguousarray(b1, np.float64).reshape(-1, 3)
+    b2 = np.ascontiguousarray(b2, np.float64).reshape(-1, 3)
+    R = np.ascontiguousarray(R, np.float64).reshape(3, 3)
+    t = np.ascontiguousarray(t, np.float64).reshape(3)
+    mask = np.zeros(max(len(b1), 1), np.uint8)
+    lib().oracle_inliers_bearings(_p(b1, C.c_double), _p(b2, C.c_double), len(b1), _p(R, C.c_double), _p(t, C.c_double),
+                                  C.c_double(threshold), _p(mask, C.c_uint8))
+    return mask[: len(b1)].astype(bool)

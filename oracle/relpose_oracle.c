@@ -679,3 +679,69 @@ int oracle_ransac_relative_pose(const double *b1, const double *b2, int n, doubl
   if (iters_run) *iters_run = it;
   return best_score;
 }
+
+/* ---- Stage 4: bearings and the inlier test of robust_match_calibrated ------------------------------------
+ * reference: Camera::BearingsMany -> ProjectGeneric::Backward (opensfm/src/geometry/camera_instances.h:154-160) =
+ * UniformScale::Backward (transformations_functions.h:74-78), Disto24::Backward (camera_distortions_functions.h:
+ * 149-174: Newton-Raphson on r (1 + k1 r^2 + k2 r^4) = rd, 10 iterations, stop when the decrement is < 1e-6 BEFORE
+ * applying it, foundation/newton_raphson.h:76-90), PerspectiveProjection::Backward / FisheyeProjection::Backward
+ * (camera_projections_functions.h:108-116, 68-84); compute_inliers_bearings (opensfm/matching.py:805-844). */
+void oracle_pixel_bearings(int model, const double *cam /* k1 k2 focal */, const double *px, int n, double *out) {
+  const double k1 = cam[0], k2 = cam[1], f = cam[2];
+  for (int i = 0; i < n; i++) {
+    const double xd = px[2 * i] / f, yd = px[2 * i + 1] / f;
+    double xu = xd, yu = yd;
+    const double rd = sqrt(xd * xd + yd * yd);
+    if (!(rd < 2.220446049250313e-16)) {
+      double r = rd;
+      for (int it = 0; it < 10; it++) {
+        const double r2 = r * r;
+        const double fv = r * (1.0 + r2 * (k1 + k2 * r2)) - rd;
+        const double dv = 1.0 + r2 * 2.0 * (k1 + 2.0 * k2 * r2);
+        const double decr = fv / dv;
+        if (fabs(decr) < 1e-6) break;
+        r -= decr;
+      }
+      const double r2 = r * r, dist = 1.0 + r2 * (k1 + k2 * r2);
+      xu = xd / dist;
+      yu = yd / dist;
+    }
+    double *b = out + 3 * i;
+    if (model == 1) { /* fisheye: the undistorted radius is the angle from the optical axis */
+      const double theta = sqrt(xu * xu + yu * yu);
+      const double s = theta > 1e-8 ? sin(theta) / theta : 1.0;
+      b[0] = xu * s;
+      b[1] = yu * s;
+      b[2] = cos(theta);
+    } else {
+      const double inv = 1.0 / sqrt(xu * xu + yu * yu + 1.0);
+      b[0] = xu * inv;
+      b[1] = yu * inv;
+      b[2] = inv;
+    }
+  }
+}
+
+/* R, t: rotation and translation from the SECOND image to the first (matching.py:813-817); mask[n] */
+void oracle_inliers_bearings(const double *b1, const double *b2, int n, const double *R, const double *t, double threshold, uint8_t *mask) {
+  for (int i = 0; i < n; i++) {
+    mask[i] = 0;
+    const double *x = b1 + 3 * i, *y = b2 + 3 * i;
+    /* triangulate_two_bearings_midpoint_many(b1, b2, R, t): centers (0, t), bearings (b1, R b2) */
+    const double c0[3] = {0, 0, 0};
+    double ry[3], X[3];
+    for (int a = 0; a < 3; a++) ry[a] = R[3 * a] * y[0] + R[3 * a + 1] * y[1] + R[3 * a + 2] * y[2];
+    if (!triangulate_midpoint2(c0, t, x, ry, X)) continue;
+    const double n1 = sqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2]);
+    double d[3] = {X[0] - t[0], X[1] - t[1], X[2] - t[2]}, q[3];
+    for (int a = 0; a < 3; a++) q[a] = R[a] * d[0] + R[3 + a] * d[1] + R[6 + a] * d[2]; /* R^T (X - t) */
+    const double n2 = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+    double e1 = 0, e2 = 0;
+    for (int a = 0; a < 3; a++) {
+      const double u = X[a] / n1 - x[a], v = q[a] / n2 - y[a];
+      e1 += u * u;
+      e2 += v * v;
+    }
+    mask[i] = (sqrt(e1) < threshold) && (sqrt(e2) < threshold);
+  }
+}

@@ -120,3 +120,43 @@ def test_ransac_relative_pose_recovers_pose_with_outliers(oracle_lib):
         assert (inl & out).sum() <= 0.15 * max(1, out.sum()) + 2
         if ratio == 0.0:
             assert r["iterations"] < 50  # iteration reduction (robust_estimator.h:20-35)
+
+
+def test_pixel_bearings_invert_the_projection(oracle_lib):
+    """Backward of the PERSPECTIVE / FISHEYE cameras: projecting the bearing gives the pixel back (the Newton
+    undistortion stops at a 1e-6 decrement, camera_distortions_functions.h:149-174)."""
+    from opensfm_amd import synthetic
+
+    rng = np.random.default_rng(8)
+    px = np.c_[rng.uniform(-0.45, 0.45, 200), rng.uniform(-0.35, 0.35, 200)]
+    for model in ("perspective", "fisheye"):
+        cam = np.array([-0.1, 0.01, 0.7]) if model == "perspective" else np.array([-0.03, 0.002, 0.5])
+        b = oracle_lib.pixel_bearings(model, cam, px)
+        assert np.allclose(np.linalg.norm(b, axis=1), 1, atol=1e-12)
+        back = synthetic.project_perspective(b * 3.0, np.zeros(6), cam, model)
+        assert np.abs(back - px).max() < 1e-6
+    assert np.allclose(oracle_lib.pixel_bearings("perspective", [0.0, 0.0, 1.0], [[0.0, 0.0]]), [[0, 0, 1]])
+
+
+def test_inliers_bearings_matches_the_numpy_statement(oracle_lib):
+    rng = np.random.default_rng(9)
+    b1, b2, _ = _two_views(rng, 60)
+    # pose of the SECOND camera in the first one's frame from the RANSAC result: R^T, -R^T t (multiview.py:511-516)
+    r = oracle_lib.ransac_relative_pose(b1, b2, 0.004)
+    R21, t21 = r["lo_model"][:, :3].T, -r["lo_model"][:, :3].T @ r["lo_model"][:, 3]
+    b2n = b2.copy()
+    b2n[:10] = np.roll(b2n[:10], 3, axis=0)  # ten wrong correspondences
+    got = oracle_lib.inliers_bearings(b1, b2n, R21, t21, 0.004)
+    want = np.zeros(60, bool)
+    for i in range(60):  # matching.py:824-843 written out for one correspondence
+        A = np.array([[b1[i] @ b1[i], -(b1[i] @ (R21 @ b2n[i]))], [b1[i] @ (R21 @ b2n[i]), -((R21 @ b2n[i]) @ (R21 @ b2n[i]))]])
+        if abs(np.linalg.det(A)) < 1e-10:
+            continue
+        lam = np.linalg.solve(A, [t21 @ b1[i], t21 @ (R21 @ b2n[i])])
+        X = 0.5 * (lam[0] * b1[i] + t21 + lam[1] * (R21 @ b2n[i]))
+        br1 = X / np.linalg.norm(X)
+        br2 = R21.T @ (X - t21)
+        br2 /= np.linalg.norm(br2)
+        want[i] = np.linalg.norm(br1 - b1[i]) < 0.004 and np.linalg.norm(br2 - b2n[i]) < 0.004
+    assert np.array_equal(got, want)
+    assert got[10:].sum() >= 45 and got[:10].sum() <= 3
