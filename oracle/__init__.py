@@ -328,3 +328,53 @@ def inliers_bearings(b1, b2, R, t, threshold: float = 0.01) -> np.ndarray:
     lib().oracle_inliers_bearings(_p(b1, C.c_double), _p(b2, C.c_double), len(b1), _p(R, C.c_double), _p(t, C.c_double),
                                   C.c_double(threshold), _p(mask, C.c_uint8))
     return mask[: len(b1)].astype(bool)
+
+
+def glibc_rand(seed: int, count: int) -> np.ndarray:
+    out = np.zeros(count, np.int32)
+    lib().oracle_glibc_rand(C.c_uint32(seed), count, _p(out, C.c_int32))
+    return out
+
+
+def relpose_cost(b1, b2, params):
+    """RelativePoseCost (relative_pose.h:86-147) at params = [angle-axis of R, centre of the second camera]:
+    -> residuals (101), Jacobian (101 x 6)."""
+    b1 = np.ascontiguousarray(b1, np.float64).reshape(-1, 3)
+    b2 = np.ascontiguousarray(b2, np.float64).reshape(-1, 3)
+    par = np.ascontiguousarray(params, np.float64)
+    res, jac = np.zeros(101), np.zeros(606)
+    lib().oracle_relpose_cost(_p(b1, C.c_double), _p(b2, C.c_double), len(b1), _p(par, C.c_double), _p(res, C.c_double), _p(jac, C.c_double))
+    return res, jac.reshape(101, 6)
+
+
+def relative_pose_refinement(RT, b1, b2, iterations: int):
+    """pygeometry.relative_pose_refinement (relative_pose.h:149-183): -> (RT refined 3 x 4, iterations, (cost0, cost1))."""
+    RT = np.ascontiguousarray(RT, np.float64).reshape(3, 4).copy()
+    b1 = np.ascontiguousarray(b1, np.float64).reshape(-1, 3)
+    b2 = np.ascontiguousarray(b2, np.float64).reshape(-1, 3)
+    costs = np.zeros(2)
+    it = lib().oracle_relative_pose_refinement(_p(RT, C.c_double), _p(b1, C.c_double), _p(b2, C.c_double), len(b1), int(iterations),
+                                               _p(costs, C.c_double))
+    return RT, it, (float(costs[0]), float(costs[1]))
+
+
+def robust_match_calibrated(p1, p2, cam1, cam2, model1, model2, matches, threshold: float = 0.004, refine_iterations: int = 10):
+    """matching.robust_match_calibrated (matching.py:871-903) for PERSPECTIVE / FISHEYE cameras [k1, k2, focal]:
+    bearings -> LO-RANSAC (1000 iterations) -> 3 x (inliers at 4, 2, 1 x threshold -> refinement) -> inliers."""
+    matches = np.asarray(matches, np.int64).reshape(-1, 2)
+    if len(matches) < 8:
+        return np.zeros((0, 2), np.int64)
+    b1 = pixel_bearings(model1, cam1, np.asarray(p1, np.float64)[matches[:, 0], :2])
+    b2 = pixel_bearings(model2, cam2, np.asarray(p2, np.float64)[matches[:, 1], :2])
+    r = ransac_relative_pose(b1, b2, threshold, 1000)
+    lo = r["lo_model"]
+    R, t = lo[:, :3].T.copy(), -lo[:, :3].T @ lo[:, 3]  # multiview.relative_pose_ransac: pose of camera 2 in camera 1
+    for relax in (4, 2, 1):
+        inl = inliers_bearings(b1, b2, R, t, relax * threshold)
+        if inl.sum() < 8:
+            return np.zeros((0, 2), np.int64)
+        RT = np.c_[R.T, -R.T @ t]  # relative_pose_optimize_nonlinear (multiview.py:541-553)
+        RT, _, _ = relative_pose_refinement(RT, b1[inl], b2[inl], refine_iterations)
+        R, t = RT[:, :3].T.copy(), -RT[:, :3].T @ RT[:, 3]
+    inl = inliers_bearings(b1, b2, R, t, threshold)
+    return matches[inl]
