@@ -247,6 +247,48 @@ double osfm_tracks_device_ms(const osfm_tracks *t); /* HIP-event time of the dev
 int osfm_tracks_fetch(const osfm_tracks *t, int32_t *obs_track, int32_t *obs_image, int32_t *obs_feature);
 void osfm_tracks_destroy(osfm_tracks *t);
 
+/* =====================================================================================
+ * Calibrated robust matching (row M-a9 / SURVEY.md 8f-3): essential-matrix LO-RANSAC on bearings.
+ * STATUS round 1: numerics pinned bit for bit against the CPU oracle through a host emulation of the
+ * wavefront code (tests/test_relpose_core_host.py); not yet run on an MI355X, so opensfm_amd.matching
+ * does not route pairs here yet (it still raises NotImplementedError for non-pinhole cameras).
+ *
+ * osfm_pixel_bearings  replaces camera.pixel_bearing_many(points) (opensfm/src/geometry/camera.cc ->
+ *   camera_instances.h:154-160) for OSFM_CAMERA_PERSPECTIVE / OSFM_CAMERA_FISHEYE, cam = [k1, k2, focal];
+ *   px: n x 2 normalised image coordinates, bearings: n x 3.
+ * osfm_relpose_pairs   a batch of pairs; pair p owns the correspondences offsets[p] .. offsets[p+1]-1 of the
+ *   concatenated bearing arrays b1, b2 (total x 3, doubles, second-image bearing y and first-image bearing x
+ *   with y ~ R x + t for the models below).
+ *   mode OSFM_RELPOSE_RANSAC: pyrobust.ransac_relative_pose(b1, b2, threshold, params, RANSAC)
+ *     (opensfm/src/robust/src/instanciations.cc:33-48, robust_estimator.h:37-119): result.model / lo_model
+ *     (3 x 4 row-major), score, iterations; mask = inliers of the best score.
+ *   mode OSFM_RELPOSE_MATCH: the body of matching.robust_match_calibrated after the bearings
+ *     (opensfm/matching.py:886-903): RANSAC, three rounds of compute_inliers_bearings (4, 2, 1 x threshold)
+ *     + relative_pose_refinement, final compute_inliers_bearings; mask = the inliers the reference keeps
+ *     (all zero where it returns an empty array), R / t = pose of the second camera in the first.
+ *   The sampler is std::mt19937(42) with libstdc++'s classic uniform_int_distribution (see oracle/relpose_oracle.c
+ *   on why parity with a reference BINARY is toolchain dependent on this branch).
+ * ===================================================================================== */
+enum { OSFM_RELPOSE_RANSAC = 0, OSFM_RELPOSE_MATCH = 1 };
+typedef struct osfm_relpose_params {
+  double threshold;          /* radians: config robust_matching_calib_threshold (0.004) */
+  double probability;        /* RobustEstimatorParams::probability (0.99; the Python caller never sets it) */
+  int32_t iterations;        /* 1000 (matching.py:889) */
+  int32_t use_lo;            /* RobustEstimatorParams::use_local_optimization (1) */
+  int32_t lo_iterations;     /* ::local_optimization_iterations (10) */
+  int32_t refine_iterations; /* config five_point_refine_match_iterations (10) */
+} osfm_relpose_params;
+typedef struct osfm_relpose_result {
+  double model[12], lo_model[12]; /* ScoreInfo::model / lo_model, [R | t] row-major */
+  double R[9], t[3];              /* MATCH mode: after the last refinement (zeros when rejected) */
+  int32_t score, iterations;      /* best inlier count of the RANSAC, iterations it ran */
+  int32_t n_inliers, pad;         /* number of ones in this pair's mask */
+} osfm_relpose_result;
+int osfm_pixel_bearings(osfm_ctx *ctx, int model, const double cam[3], const double *px, int n, double *bearings);
+int osfm_relpose_pairs(osfm_ctx *ctx, const double *b1, const double *b2, const int64_t *offsets, int n_pairs,
+                       const osfm_relpose_params *params, int mode, osfm_relpose_result *results, uint8_t *mask,
+                       double *kernel_ms /* may be NULL: HIP-event time of the kernels */);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,6 +42,30 @@ class MatchTimings(C.Structure):
     ]
 
 
+class RelposeParams(C.Structure):
+    _fields_ = [
+        ("threshold", C.c_double),
+        ("probability", C.c_double),
+        ("iterations", C.c_int32),
+        ("use_lo", C.c_int32),
+        ("lo_iterations", C.c_int32),
+        ("refine_iterations", C.c_int32),
+    ]
+
+
+class RelposeResult(C.Structure):
+    _fields_ = [
+        ("model", C.c_double * 12),
+        ("lo_model", C.c_double * 12),
+        ("R", C.c_double * 9),
+        ("t", C.c_double * 3),
+        ("score", C.c_int32),
+        ("iterations", C.c_int32),
+        ("n_inliers", C.c_int32),
+        ("pad", C.c_int32),
+    ]
+
+
 # name -> (restype, argtypes).  tests/test_abi.py checks every symbol of the header is here and exported.
 SIGNATURES = {
     "osfm_last_error": (C.c_char_p, []),
@@ -76,6 +100,12 @@ SIGNATURES = {
         C.c_int,
         [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_double, C.c_int,
          C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int)],
+    ),
+    "osfm_pixel_bearings": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double)]),
+    "osfm_relpose_pairs": (
+        C.c_int,
+        [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int, C.POINTER(RelposeParams), C.c_int,
+         C.POINTER(RelposeResult), C.POINTER(C.c_uint8), C.POINTER(C.c_double)],
     ),
     "osfm_ransac_fundamental": (
         C.c_int,

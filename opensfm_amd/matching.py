@@ -27,7 +27,7 @@ from typing import Any, Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _lib
-from ._lib import MatchParams, MatchTimings, OsfmError, check, default_context
+from ._lib import MatchParams, MatchTimings, OsfmError, RelposeParams, RelposeResult, check, default_context
 
 DEFAULT_CONFIG: Dict[str, Any] = {
     # opensfm/config.py:97-101,191-195
@@ -36,6 +36,8 @@ DEFAULT_CONFIG: Dict[str, Any] = {
     "symmetric_matching": True,
     "robust_matching_threshold": 0.004,
     "robust_matching_min_match": 20,
+    "robust_matching_calib_threshold": 0.004,
+    "five_point_refine_match_iterations": 10,
 }
 
 
@@ -128,6 +130,69 @@ def robust_match_fundamental(p1: np.ndarray, p2: np.ndarray, matches: np.ndarray
     if F is None or F[2, 2] == 0.0:
         return F, np.array([])
     return F, matches[inliers]
+
+
+_BEARING_MODELS = {"perspective": 0, "fisheye": 1}  # OSFM_CAMERA_PERSPECTIVE / OSFM_CAMERA_FISHEYE
+
+
+def pixel_bearing_many(camera, points: np.ndarray, ctx=None) -> np.ndarray:
+    """``camera.pixel_bearing_many(points)`` (pygeometry.Camera) for perspective / fisheye cameras: (n, 2) normalised
+    image coordinates -> (n, 3) unit bearings."""
+    if camera.projection_type not in _BEARING_MODELS:
+        raise NotImplementedError(f"pixel_bearing_many: projection type {camera.projection_type!r} is not on the GPU path")
+    ctx = ctx or default_context()
+    px = np.ascontiguousarray(np.asarray(points, np.float64)[:, :2])
+    cam = np.array([camera.k1, camera.k2, camera.focal], np.float64)
+    out = np.zeros((len(px), 3), np.float64)
+    check(_lib.load().osfm_pixel_bearings(ctx.handle, _BEARING_MODELS[camera.projection_type], _fptr(cam, C.c_double),
+                                          _fptr(px, C.c_double), len(px), _fptr(out, C.c_double)), "osfm_pixel_bearings")
+    return out
+
+
+def relpose_pairs(b1: np.ndarray, b2: np.ndarray, offsets: Sequence[int], threshold: float, mode: str = "match",
+                  iterations: int = 1000, probability: float = 0.99, use_lo: bool = True, lo_iterations: int = 10,
+                  refine_iterations: int = 10, ctx=None) -> Tuple[List[Dict[str, Any]], np.ndarray, float]:
+    """Batched ``pyrobust.ransac_relative_pose`` (mode "ransac") or the body of ``robust_match_calibrated`` after the bearings
+    (mode "match") for pairs whose correspondences are the slices offsets[p]:offsets[p+1] of b1 / b2.
+    -> (per-pair dicts, inlier mask over all correspondences, kernel milliseconds)."""
+    ctx = ctx or default_context()
+    b1 = np.ascontiguousarray(b1, np.float64).reshape(-1, 3)
+    b2 = np.ascontiguousarray(b2, np.float64).reshape(-1, 3)
+    off = np.ascontiguousarray(offsets, np.int64)
+    n_pairs = len(off) - 1
+    assert n_pairs >= 0 and len(b1) == len(b2) and (n_pairs == 0 or off[-1] == len(b1))
+    prm = RelposeParams(float(threshold), float(probability), int(iterations), int(bool(use_lo)), int(lo_iterations), int(refine_iterations))
+    res = (RelposeResult * max(n_pairs, 1))()
+    mask = np.zeros(max(len(b1), 1), np.uint8)
+    ms = C.c_double(0.0)
+    check(_lib.load().osfm_relpose_pairs(ctx.handle, _fptr(b1, C.c_double), _fptr(b2, C.c_double), _fptr(off, C.c_int64), n_pairs,
+                                         C.byref(prm), {"ransac": 0, "match": 1}[mode], res, _fptr(mask, C.c_uint8), C.byref(ms)),
+          "osfm_relpose_pairs")
+    out = []
+    for p in range(n_pairs):
+        r = res[p]
+        out.append({"model": np.array(r.model).reshape(3, 4), "lo_model": np.array(r.lo_model).reshape(3, 4), "R": np.array(r.R).reshape(3, 3),
+                    "t": np.array(r.t), "score": r.score, "iterations": r.iterations, "n_inliers": r.n_inliers})
+    return out, mask[: len(b1)].astype(bool), ms.value
+
+
+def robust_match_calibrated(p1: np.ndarray, p2: np.ndarray, camera1, camera2, matches: np.ndarray, config: Dict[str, Any],
+                            ctx=None) -> np.ndarray:
+    """Filter matches by estimating the Essential matrix via RANSAC (``matching.py:871-903``): same arguments, same return.
+    Not yet reachable through ``robust_match`` / ``match_images_with_pairs``: the kernel has not been validated on an
+    MI355X (see include/osfm_mi355.h), so the dispatchers keep raising NotImplementedError for non-pinhole cameras."""
+    if len(matches) < 8:
+        return np.array([])
+    matches = np.asarray(matches)
+    x1 = np.asarray(p1)[matches[:, 0]][:, :2].copy()
+    x2 = np.asarray(p2)[matches[:, 1]][:, :2].copy()
+    b1 = pixel_bearing_many(camera1, x1, ctx)
+    b2 = pixel_bearing_many(camera2, x2, ctx)
+    _, mask, _ = relpose_pairs(b1, b2, [0, len(b1)], _cfg(config, "robust_matching_calib_threshold"), "match", 1000, 0.99, True, 10,
+                               _cfg(config, "five_point_refine_match_iterations"), ctx)
+    if not mask.any():
+        return np.array([])
+    return matches[mask]
 
 
 def robust_match(p1, p2, camera1, camera2, matches, config) -> np.ndarray:

@@ -378,3 +378,20 @@ def robust_match_calibrated(p1, p2, cam1, cam2, model1, model2, matches, thresho
         R, t = RT[:, :3].T.copy(), -RT[:, :3].T @ RT[:, 3]
     inl = inliers_bearings(b1, b2, R, t, threshold)
     return matches[inl]
+
+
+def robust_match_calibrated_bearings(b1, b2, threshold: float = 0.004, iterations: int = 1000, probability: float = 0.99,
+                                     use_lo: bool = True, lo_iterations: int = 10, refine_iterations: int = 10):
+    """robust_match_calibrated (matching.py:871-903) on bearings, every step in C with written-out sums (what the
+    product has to match bit for bit).  -> dict(mask, R, t, model, lo_model, score, iterations)."""
+    b1 = np.ascontiguousarray(b1, np.float64).reshape(-1, 3)
+    b2 = np.ascontiguousarray(b2, np.float64).reshape(-1, 3)
+    n = len(b1)
+    R, t, models, info = np.zeros(9), np.zeros(3), np.zeros(24), np.zeros(2, np.int32)
+    mask = np.zeros(max(n, 1), np.uint8)
+    lib().oracle_robust_match_calibrated(_p(b1, C.c_double), _p(b2, C.c_double), n, C.c_double(threshold), int(iterations),
+                                         C.c_double(probability), int(use_lo), int(lo_iterations), int(refine_iterations),
+                                         _p(R, C.c_double), _p(t, C.c_double), _p(mask, C.c_uint8), _p(models, C.c_double),
+                                         _p(info, C.c_int32))
+    return {"mask": mask[:n].astype(bool), "R": R.reshape(3, 3), "t": t, "model": models[:12].reshape(3, 4),
+            "lo_model": models[12:].reshape(3, 4), "score": int(info[0]), "iterations": int(info[1])}

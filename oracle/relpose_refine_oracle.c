@@ -323,3 +323,57 @@ int oracle_relative_pose_refinement(double *RT, const double *b1, const double *
   }
   return it;
 }
+
+/* ---- Stage 6: robust_match_calibrated on bearings, end to end (opensfm/matching.py:871-903 with
+ * multiview.relative_pose_ransac / relative_pose_optimize_nonlinear, opensfm/multiview.py:494-553).
+ * The small matrix conversions are written out (left-to-right sums) so that another implementation can match bits.
+ * Returns the number of inliers (0 = the reference returns an empty array); mask[n]; R, t = second camera in the first. */
+int oracle_ransac_relative_pose(const double *b1, const double *b2, int n, double threshold_angle, int iterations, double probability,
+                                int use_lo, int lo_iterations, double *model, double *lo_model, int *inliers, int *iters_run);
+void oracle_inliers_bearings(const double *b1, const double *b2, int n, const double *R, const double *t, double threshold, uint8_t *mask);
+int oracle_robust_match_calibrated(const double *b1, const double *b2, int n, double threshold, int iterations, double probability,
+                                   int use_lo, int lo_iterations, int refine_iterations, double *R, double *t, uint8_t *mask,
+                                   double *ransac_models /* 24 */, int *ransac_info /* score, iterations */) {
+  memset(mask, 0, (size_t)(n > 0 ? n : 0));
+  memset(R, 0, 9 * sizeof(double));
+  memset(t, 0, 3 * sizeof(double));
+  if (ransac_models) memset(ransac_models, 0, 24 * sizeof(double));
+  if (ransac_info) ransac_info[0] = ransac_info[1] = 0;
+  if (n < 8) return 0;
+  double model[12], lo[12];
+  int *inl = (int *)__builtin_alloca(sizeof(int) * (size_t)n), iters = 0;
+  const int score = oracle_ransac_relative_pose(b1, b2, n, threshold, iterations, probability, use_lo, lo_iterations, model, lo, inl, &iters);
+  if (ransac_models) { memcpy(ransac_models, model, sizeof(model)); memcpy(ransac_models + 12, lo, sizeof(lo)); }
+  if (ransac_info) { ransac_info[0] = score; ransac_info[1] = iters; }
+  for (int a = 0; a < 3; a++) {
+    for (int b = 0; b < 3; b++) R[3 * a + b] = lo[4 * b + a];
+    t[a] = -(lo[a] * lo[3] + lo[4 + a] * lo[7] + lo[8 + a] * lo[11]);
+  }
+  double *s1 = (double *)__builtin_alloca(sizeof(double) * 3 * (size_t)n), *s2 = (double *)__builtin_alloca(sizeof(double) * 3 * (size_t)n);
+  const double relax[3] = {4.0, 2.0, 1.0};
+  for (int stage = 0; stage < 3; stage++) {
+    oracle_inliers_bearings(b1, b2, n, R, t, relax[stage] * threshold, mask);
+    int cnt = 0;
+    for (int i = 0; i < n; i++)
+      if (mask[i]) {
+        memcpy(s1 + 3 * cnt, b1 + 3 * i, 3 * sizeof(double));
+        memcpy(s2 + 3 * cnt, b2 + 3 * i, 3 * sizeof(double));
+        cnt++;
+      }
+    if (cnt < 8) { memset(mask, 0, (size_t)n); return 0; }
+    double RT[12];
+    for (int a = 0; a < 3; a++) {
+      for (int b = 0; b < 3; b++) RT[4 * a + b] = R[3 * b + a];
+      RT[4 * a + 3] = -(R[a] * t[0] + R[3 + a] * t[1] + R[6 + a] * t[2]);
+    }
+    oracle_relative_pose_refinement(RT, s1, s2, cnt, refine_iterations, NULL);
+    for (int a = 0; a < 3; a++) {
+      for (int b = 0; b < 3; b++) R[3 * a + b] = RT[4 * b + a];
+      t[a] = -(RT[a] * RT[3] + RT[4 + a] * RT[7] + RT[8 + a] * RT[11]);
+    }
+  }
+  oracle_inliers_bearings(b1, b2, n, R, t, threshold, mask);
+  int cnt = 0;
+  for (int i = 0; i < n; i++) cnt += mask[i];
+  return cnt;
+}

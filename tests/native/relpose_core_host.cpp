@@ -1,0 +1,97 @@
+// relpose_core_host.cpp -- TEST INFRASTRUCTURE: compiles the product's per-lane numerics (opensfm_amd/csrc/relpose_core.h)
+// and its wavefront orchestration (relpose_wave.h) for the HOST with a loop-based wave policy, so that
+// tests/test_relpose_core_host.py can compare them bit for bit with the CPU oracle without a GPU.
+// Nothing in the product links or loads this file.
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../opensfm_amd/csrc/relpose_wave.h"
+
+using namespace osfm_rp;
+
+template <int WIDTH>
+struct LoopWave {  // "lanes" are loop iterations; single() runs once
+  static constexpr int width = WIDTH;
+  template <class F> void single(F f) { f(); }
+  template <class F> void parallel_for(int n, F f) { for (int i = 0; i < n; i++) f(i); }
+  template <class P> int count_if(int n, P p) { int c = 0; for (int i = 0; i < n; i++) c += p(i) ? 1 : 0; return c; }
+  template <class P> int compact(int n, P p, int* out) { int c = 0; for (int i = 0; i < n; i++) if (p(i)) out[c++] = i; return c; }
+};
+
+template <int WIDTH>
+static int ransac_impl(const double* b1, const double* b2, int n, double thr, int iterations, double probability, int use_lo, int lo_it,
+                       double* model, double* lo_model, int* inliers, int* iters_run) {
+  LoopWave<WIDTH> w;
+  std::vector<double> models((size_t)kWave * kMaxModels * 12);
+  std::vector<int> inl(n > 0 ? n : 1), sub(n > 0 ? n : 1);
+  WaveShared* s = new WaveShared;
+  PairWork P{b1, b2, n, models.data(), inl.data(), sub.data()};
+  RansacParams prm{thr, iterations, probability, use_lo, lo_it};
+  RansacResult r;
+  ransac_relative_pose_wave(w, *s, P, prm, r);
+  delete s;
+  memcpy(model, r.model, sizeof(r.model));
+  memcpy(lo_model, r.lo_model, sizeof(r.lo_model));
+  for (int i = 0; i < r.best_score; i++) inliers[i] = inl[i];
+  *iters_run = r.iterations_run;
+  return r.best_score;
+}
+extern "C" {
+
+int host_essential_five_points(const double* b1, const double* b2, double* Es) { return essential_five_points(b1, b2, Es); }
+int host_relative_pose_from_essential(const double* E, const double* b1, const double* b2, int n, double* RT) {
+  return relative_pose_from_essential(E, b1, b2, nullptr, n, RT);
+}
+void host_pixel_bearings(int model, const double* cam, const double* px, int n, double* out) {
+  for (int i = 0; i < n; i++) pixel_bearing(model, cam[0], cam[1], cam[2], px[2 * i], px[2 * i + 1], out + 3 * i);
+}
+void host_inliers_bearings(const double* b1, const double* b2, int n, const double* R, const double* t, double thr, uint8_t* mask) {
+  for (int i = 0; i < n; i++) mask[i] = (uint8_t)inlier_bearing(b1 + 3 * i, b2 + 3 * i, R, t, thr);
+}
+void host_refinement_picks(int n, int* picked) { refinement_picks(n, picked); }
+
+int host_ransac_relative_pose(int width, const double* b1, const double* b2, int n, double thr, int iterations, double probability,
+                              int use_lo, int lo_it, double* model, double* lo_model, int* inliers, int* iters_run) {
+  switch (width) {
+    case 1: return ransac_impl<1>(b1, b2, n, thr, iterations, probability, use_lo, lo_it, model, lo_model, inliers, iters_run);
+    case 7: return ransac_impl<7>(b1, b2, n, thr, iterations, probability, use_lo, lo_it, model, lo_model, inliers, iters_run);
+    default: return ransac_impl<64>(b1, b2, n, thr, iterations, probability, use_lo, lo_it, model, lo_model, inliers, iters_run);
+  }
+}
+
+int host_relative_pose_refinement(double* RT, const double* b1, const double* b2, int n, int iterations, double* costs) {
+  LoopWave<64> w;
+  WaveShared* s = new WaveShared;
+  std::vector<int> subset(n);
+  for (int i = 0; i < n; i++) subset[i] = i;
+  refinement_picks(n, s->picked);
+  WaveRefineEval<LoopWave<64>> ev{w, *s, b1, b2, subset.data()};
+  const int it = refine_relative_pose(RT, iterations, ev, costs);
+  delete s;
+  return it;
+}
+
+int host_robust_match_calibrated(const double* b1, const double* b2, int n, double thr, int iterations, double probability, int use_lo,
+                                 int lo_it, int refine_iterations, double* R, double* t, uint8_t* mask, double* ransac_models,
+                                 int* ransac_info) {
+  LoopWave<64> w;
+  std::vector<double> models((size_t)kWave * kMaxModels * 12);
+  std::vector<int> inl(n > 0 ? n : 1), sub(n > 0 ? n : 1);
+  WaveShared* s = new WaveShared;
+  PairWork P{b1, b2, n, models.data(), inl.data(), sub.data()};
+  RansacParams prm{thr, iterations, probability, use_lo, lo_it};
+  MatchResult r;
+  robust_match_calibrated_wave(w, *s, P, prm, refine_iterations, r);
+  delete s;
+  memset(mask, 0, (size_t)(n > 0 ? n : 0));
+  for (int i = 0; i < r.n_inliers; i++) mask[sub[i]] = 1;
+  memcpy(R, r.R, sizeof(r.R));
+  memcpy(t, r.t, sizeof(r.t));
+  memcpy(ransac_models, r.ransac.model, sizeof(r.ransac.model));
+  memcpy(ransac_models + 12, r.ransac.lo_model, sizeof(r.ransac.lo_model));
+  ransac_info[0] = r.ransac.best_score;
+  ransac_info[1] = r.ransac.iterations_run;
+  return r.n_inliers;
+}
+}

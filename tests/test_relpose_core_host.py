@@ -1,0 +1,161 @@
+"""The product's calibrated-matching numerics (opensfm_amd/csrc/relpose_core.h) and their wavefront orchestration
+(relpose_wave.h), compiled for the host with a loop-based wave policy (tests/native/relpose_core_host.cpp), against
+the CPU oracle -- bit for bit.  This pins everything of relpose.hip except the 40 lines of the GPU wave policy."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+@pytest.fixture(scope="module")
+def host():
+    src = os.path.join(HERE, "native", "relpose_core_host.cpp")
+    out_dir = os.path.join(HERE, "native", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, "relpose_core_host.so")
+    deps = [src] + [os.path.join(HERE, "..", "opensfm_amd", "csrc", h) for h in ("relpose_core.h", "relpose_wave.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-o", so, src])
+    return C.CDLL(so)
+
+
+def _rodrigues(r):
+    th = np.linalg.norm(r)
+    K = np.array([[0, -r[2], r[1]], [r[2], 0, -r[0]], [-r[1], r[0], 0]])
+    return np.eye(3) if th == 0 else np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th**2 * K @ K
+
+
+def _scene(rng, n, outliers=0.3, noise=1e-3):
+    R = _rodrigues(rng.normal(0, 0.3, 3))
+    t = rng.normal(0, 1, 3)
+    t /= np.linalg.norm(t)
+    X = np.c_[rng.uniform(-2, 2, n), rng.uniform(-2, 2, n), rng.uniform(4, 9, n)]
+    b1 = X + rng.normal(0, noise, X.shape)
+    X2 = X @ R.T + t + rng.normal(0, noise, X.shape)
+    bad = rng.random(n) < outliers
+    X2[bad] = np.c_[rng.uniform(-2, 2, bad.sum()), rng.uniform(-2, 2, bad.sum()), rng.uniform(4, 9, bad.sum())]
+    b1 /= np.linalg.norm(b1, axis=1, keepdims=True)
+    b2 = X2 / np.linalg.norm(X2, axis=1, keepdims=True)
+    return np.ascontiguousarray(b1), np.ascontiguousarray(b2), ~bad
+
+
+def test_five_point_and_pose_bits(host, oracle_lib):
+    rng = np.random.default_rng(0)
+    for trial in range(200):
+        b1, b2, _ = _scene(rng, 5, outliers=0.0, noise=1e-2 if trial % 2 else 0.0)
+        ref = oracle_lib.essential_five_points(b1, b2)
+        Es = np.zeros(90)
+        k = host.host_essential_five_points(_p(b1, C.c_double), _p(b2, C.c_double), _p(Es, C.c_double))
+        assert k == len(ref)
+        got = Es[: 9 * k].reshape(k, 3, 3)
+        assert np.array_equal(got.view(np.uint64), np.asarray(ref).reshape(k, 3, 3).view(np.uint64))
+        for E in got:
+            want = oracle_lib.relative_pose_from_essential(E, b1, b2)
+            RT = np.zeros(12)
+            ok = host.host_relative_pose_from_essential(_p(np.ascontiguousarray(E), C.c_double), _p(b1, C.c_double), _p(b2, C.c_double), 5,
+                                                        _p(RT, C.c_double))
+            assert bool(ok) == (want is not None)
+            if ok:
+                assert np.array_equal(RT.view(np.uint64), np.ascontiguousarray(want).reshape(-1).view(np.uint64))
+    # degenerate input must not loop or crash
+    z = np.zeros((5, 3))
+    assert host.host_essential_five_points(_p(z, C.c_double), _p(z, C.c_double), _p(np.zeros(90), C.c_double)) == 0
+
+
+def test_bearings_inliers_and_picks_bits(host, oracle_lib):
+    rng = np.random.default_rng(1)
+    for model in (0, 1):
+        cam = np.array([-0.1, 0.01, 0.9])
+        px = np.ascontiguousarray(rng.uniform(-0.6, 0.6, (500, 2)))
+        px[0] = 0.0
+        out = np.zeros((500, 3))
+        host.host_pixel_bearings(model, _p(cam, C.c_double), _p(px, C.c_double), 500, _p(out, C.c_double))
+        assert np.array_equal(out.view(np.uint64), oracle_lib.pixel_bearings(model, cam, px).view(np.uint64))
+    b1, b2, _ = _scene(rng, 400)
+    R = _rodrigues(rng.normal(0, 0.2, 3))
+    t = rng.normal(0, 1, 3)
+    for thr in (0.004, 0.05, 0.5):
+        mask = np.zeros(400, np.uint8)
+        host.host_inliers_bearings(_p(b1, C.c_double), _p(b2, C.c_double), 400, _p(np.ascontiguousarray(R), C.c_double), _p(t, C.c_double),
+                                   C.c_double(thr), _p(mask, C.c_uint8))
+        assert np.array_equal(mask.astype(bool), oracle_lib.inliers_bearings(b1, b2, R, t, thr))
+    # the 100 correspondences the refinement looks at: float(rand()) / RAND_MAX * n after srand(42)
+    r = oracle_lib.glibc_rand(42, 100)
+    for n in (8, 100, 1777):
+        picked = np.zeros(100, np.int32)
+        host.host_refinement_picks(n, _p(picked, C.c_int32))
+        want = np.minimum((r.astype(np.float32) / np.float32(2147483647) * np.float32(n)).astype(np.int64), n - 1)
+        assert np.array_equal(picked, want)
+
+
+@pytest.mark.parametrize("width", [1, 7, 64])
+def test_ransac_decision_sequence_bits(host, oracle_lib, width):
+    """width = how many iterations are solved speculatively per batch: 1 is the reference's sequential loop; 7 and 64
+    exercise the generator rewind when the local optimisation fires in the middle of a batch."""
+    rng = np.random.default_rng(2)
+    cases = [(5, 0.0), (6, 0.0), (9, 0.2), (30, 0.3), (200, 0.5), (500, 0.2), (120, 0.9)]
+    for n, outl in cases:
+        for use_lo, iters in ((1, 1000), (0, 150), (1, 37)):
+            b1, b2, _ = _scene(rng, n, outliers=outl)
+            want = oracle_lib.ransac_relative_pose(b1, b2, 0.004, iters, 0.99, bool(use_lo), 10)
+            model, lo = np.zeros(12), np.zeros(12)
+            inl = np.zeros(n, np.int32)
+            it = C.c_int(0)
+            score = host.host_ransac_relative_pose(width, _p(b1, C.c_double), _p(b2, C.c_double), n, C.c_double(0.004), iters, C.c_double(0.99),
+                                                   use_lo, 10, _p(model, C.c_double), _p(lo, C.c_double), _p(inl, C.c_int32), C.byref(it))
+            assert (score, it.value) == (want["score"], want["iterations"]), (n, outl, use_lo, iters)
+            assert np.array_equal(inl[:score], want["inliers"])
+            assert np.array_equal(model.view(np.uint64), want["model"].reshape(-1).view(np.uint64))
+            assert np.array_equal(lo.view(np.uint64), want["lo_model"].reshape(-1).view(np.uint64))
+    # fewer than five correspondences: nothing runs
+    b1, b2, _ = _scene(rng, 4)
+    it = C.c_int(7)
+    assert host.host_ransac_relative_pose(width, _p(b1, C.c_double), _p(b2, C.c_double), 4, C.c_double(0.004), 100, C.c_double(0.99), 1, 10,
+                                          _p(np.zeros(12), C.c_double), _p(np.zeros(12), C.c_double), _p(np.zeros(4, np.int32), C.c_int32),
+                                          C.byref(it)) == 0 and it.value == 0
+
+
+def test_refinement_bits(host, oracle_lib):
+    rng = np.random.default_rng(3)
+    for trial in range(20):
+        n = int(rng.integers(8, 400))
+        b1, b2, good = _scene(rng, n, outliers=0.0, noise=2e-3)
+        r = oracle_lib.ransac_relative_pose(b1, b2, 0.004, 200)
+        RT0 = r["lo_model"].copy()
+        if trial % 3 == 0:  # a perturbed start: more LM iterations, rejected steps
+            RT0[:, :3] = _rodrigues(rng.normal(0, 0.02, 3)) @ RT0[:, :3]
+        want, it_w, costs_w = oracle_lib.relative_pose_refinement(RT0, b1, b2, 10)
+        RT = np.ascontiguousarray(RT0.reshape(-1).copy())
+        costs = np.zeros(2)
+        it = host.host_relative_pose_refinement(_p(RT, C.c_double), _p(b1, C.c_double), _p(b2, C.c_double), n, 10, _p(costs, C.c_double))
+        assert it == it_w
+        assert np.array_equal(RT.view(np.uint64), want.reshape(-1).view(np.uint64))
+        assert tuple(costs) == costs_w
+
+
+def test_robust_match_calibrated_bits(host, oracle_lib):
+    rng = np.random.default_rng(4)
+    for n, outl in ((7, 0.0), (8, 0.0), (40, 0.3), (300, 0.4), (1000, 0.6), (150, 0.97)):
+        b1, b2, good = _scene(rng, n, outliers=outl)
+        want = oracle_lib.robust_match_calibrated_bearings(b1, b2, 0.004, 1000, 0.99, True, 10, 10)
+        R, t, models, info = np.zeros(9), np.zeros(3), np.zeros(24), np.zeros(2, np.int32)
+        mask = np.zeros(n, np.uint8)
+        cnt = host.host_robust_match_calibrated(_p(b1, C.c_double), _p(b2, C.c_double), n, C.c_double(0.004), 1000, C.c_double(0.99), 1, 10, 10,
+                                                _p(R, C.c_double), _p(t, C.c_double), _p(mask, C.c_uint8), _p(models, C.c_double),
+                                                _p(info, C.c_int32))
+        assert cnt == want["mask"].sum()
+        assert np.array_equal(mask.astype(bool), want["mask"])
+        assert (int(info[0]), int(info[1])) == (want["score"], want["iterations"])
+        if cnt:
+            assert np.array_equal(R.view(np.uint64), want["R"].reshape(-1).view(np.uint64))
+            assert np.array_equal(t.view(np.uint64), want["t"].view(np.uint64))
+            if outl < 0.9:  # the inliers are the true correspondences (a few noisy ones may fall outside the threshold)
+                assert (want["mask"] & ~good).sum() <= 0.02 * n and (want["mask"] & good).sum() >= 0.8 * good.sum()
