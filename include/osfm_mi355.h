@@ -250,8 +250,9 @@ void osfm_tracks_destroy(osfm_tracks *t);
 /* =====================================================================================
  * Calibrated robust matching (row M-a9 / SURVEY.md 8f-3): essential-matrix LO-RANSAC on bearings.
  * STATUS round 1: numerics pinned bit for bit against the CPU oracle through a host emulation of the
- * wavefront code (tests/test_relpose_core_host.py); not yet run on an MI355X, so opensfm_amd.matching
- * does not route pairs here yet (it still raises NotImplementedError for non-pinhole cameras).
+ * wavefront code (tests/test_relpose_core_host.py); first MI355X run at the very end of the round
+ * (profiles/r01_relpose_bringup.txt): RANSAC stage bit-identical to the oracle, inlier sets identical
+ * after the refinement; a first-correct kernel, not yet profiled or tuned.
  *
  * osfm_pixel_bearings  replaces camera.pixel_bearing_many(points) (opensfm/src/geometry/camera.cc ->
  *   camera_instances.h:154-160) for OSFM_CAMERA_PERSPECTIVE / OSFM_CAMERA_FISHEYE, cam = [k1, k2, focal];

@@ -7,8 +7,12 @@
 // nothing is shared between pairs, a launch of P pairs fills the chip once P >> 256 CUs x resident waves.
 //
 // STATUS (round 1): the orchestration and every number it produces are pinned bit for bit against the CPU oracle by
-// the host emulation (tests/test_relpose_core_host.py); the GPU wave policy below compiled for gfx950 but has not
-// run on an MI355X yet (the round's GPU budget was spent) -- tests/test_gpu_relpose.py is what validates it.
+// the host emulation (tests/test_relpose_core_host.py); first MI355X run at the end of the round
+// (profiles/r01_relpose_bringup.txt, tests/test_gpu_zz_relpose.py): RANSAC bit-identical, inlier sets identical.
+// First-correct version: everything is inlined into one kernel (256 VGPRs + spills, 12.6 KiB scratch per lane,
+// 1 wave per SIMD) and measured 3.65 k pairs/s at 300 correspondences per pair -- tuning is round-2 work.
+#include <math.h>
+
 #include <algorithm>
 
 #include "osfm_internal.h"
@@ -67,8 +71,7 @@ static_assert(sizeof(PairOut) == sizeof(osfm_relpose_result), "PairOut must mirr
 __global__ __launch_bounds__(kWave) void relpose_pairs_kernel(const double *__restrict__ b1, const double *__restrict__ b2,
                                                               const int64_t *__restrict__ offsets, int pair0, int n_pairs,
                                                               RansacParams prm, int refine_iterations, int mode,
-                                                              double *__restrict__ models_ws, int *__restrict__ inl_ws,
-                                                              int *__restrict__ sub_ws, uint8_t *__restrict__ mask, PairOut *__restrict__ out) {
+                                                              double *models_ws, int *inl_ws, int *sub_ws, uint8_t *mask, PairOut *out) {
   __shared__ WaveShared sh;
   const int p = pair0 + (int)blockIdx.x;
   if (p >= pair0 + n_pairs) return;
@@ -193,7 +196,7 @@ extern "C" int osfm_relpose_pairs(osfm_ctx *ctx, const double *b1, const double 
     OSFM_HIP(hipMemcpyAsync(d_b2.p, b2, (size_t)total * 24, hipMemcpyHostToDevice, ctx->stream));
   }
   OSFM_HIP(hipMemcpyAsync(d_off.p, offsets, (size_t)(n_pairs + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-  const RansacParams rp{prm->threshold, (int)prm->iterations, prm->probability, (int)prm->use_lo, (int)prm->lo_iterations};
+  const RansacParams rp{prm->threshold, 1.0 - cos(prm->threshold), (int)prm->iterations, prm->probability, (int)prm->use_lo, (int)prm->lo_iterations};
   OSFM_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
   for (int p0 = 0; p0 < n_pairs; p0 += chunk) {
     const int np = std::min(chunk, n_pairs - p0);

@@ -26,6 +26,8 @@ constexpr int kMaxModels = 10;
 
 struct RansacParams {
   double threshold_angle;  // radians (robust_matching_calib_threshold)
+  double threshold_score;  // 1 - cos(threshold_angle) (RelativePose::ThresholdAdapter), computed by the HOST libm so that the
+                           // device math library cannot move the inlier boundary
   int iterations;          // RobustEstimatorParams::iterations
   double probability;      // ::probability
   int use_lo;              // ::use_local_optimization
@@ -88,7 +90,7 @@ OSFM_HD void draw_sample_shared(WaveShared& s, int size, int n, int* idx) {
 template <class W>
 OSFM_HD void ransac_relative_pose_wave(W& w, WaveShared& s, const PairWork& P, const RansacParams& prm, RansacResult& out) {
   const int n = P.n;
-  const double thr = 1.0 - cos(prm.threshold_angle);  // RelativePose::ThresholdAdapter
+  const double thr = prm.threshold_score;
   for (int i = 0; i < 12; i++) out.model[i] = out.lo_model[i] = 0.0;
   out.best_score = 0;
   out.iterations_run = 0;

@@ -8,7 +8,9 @@ this module                        reference
 ``match_brute_force``              ``opensfm/matching.py:723-756``
 ``match_brute_force_symmetric``    ``opensfm/matching.py:759-777``
 ``robust_match_fundamental``       ``opensfm/matching.py:780-802``
-``robust_match``                   ``opensfm/matching.py:906-929`` (pinhole branch)
+``robust_match``                   ``opensfm/matching.py:906-929``
+``robust_match_calibrated``        ``opensfm/matching.py:871-903`` (perspective / fisheye cameras)
+``pixel_bearing_many``             ``pygeometry.Camera.pixel_bearing_many`` (same two models)
 ``match`` semantics (per pair)     ``opensfm/matching.py:563-634`` (inside ``match_pairs``)
 ``match_images_with_pairs``        ``opensfm/matching.py:63-98``
 ``unfilter_matches``               ``opensfm/matching.py:932-936``
@@ -179,8 +181,7 @@ def relpose_pairs(b1: np.ndarray, b2: np.ndarray, offsets: Sequence[int], thresh
 def robust_match_calibrated(p1: np.ndarray, p2: np.ndarray, camera1, camera2, matches: np.ndarray, config: Dict[str, Any],
                             ctx=None) -> np.ndarray:
     """Filter matches by estimating the Essential matrix via RANSAC (``matching.py:871-903``): same arguments, same return.
-    Not yet reachable through ``robust_match`` / ``match_images_with_pairs``: the kernel has not been validated on an
-    MI355X (see include/osfm_mi355.h), so the dispatchers keep raising NotImplementedError for non-pinhole cameras."""
+    One wavefront of ``relpose_pairs_kernel`` does the whole pair; use ``match_pairs_calibrated`` for batches."""
     if len(matches) < 8:
         return np.array([])
     matches = np.asarray(matches)
@@ -195,15 +196,17 @@ def robust_match_calibrated(p1: np.ndarray, p2: np.ndarray, camera1, camera2, ma
     return matches[mask]
 
 
+def _is_pinhole(c) -> bool:
+    """matching.py:918-925: cameras that take the fundamental-matrix branch."""
+    return c.projection_type in ["perspective", "brown"] and c.k1 == 0.0 and c.k2 == 0.0
+
+
 def robust_match(p1, p2, camera1, camera2, matches, config) -> np.ndarray:
-    """``matching.py:906-929``: F-matrix path for undistorted perspective/brown cameras."""
-
-    def pinhole(c) -> bool:
-        return c.projection_type in ["perspective", "brown"] and c.k1 == 0.0 and c.k2 == 0.0
-
-    if pinhole(camera1) and pinhole(camera2):
+    """``matching.py:906-929``: F-matrix path for undistorted perspective/brown cameras, E-matrix path otherwise
+    (perspective / fisheye cameras; other projection types raise NotImplementedError in ``pixel_bearing_many``)."""
+    if _is_pinhole(camera1) and _is_pinhole(camera2):
         return robust_match_fundamental(p1, p2, matches, config)[1]
-    raise NotImplementedError("calibrated (essential-matrix) robust matching is not on the GPU path yet (SURVEY 8f-3)")
+    return robust_match_calibrated(p1, p2, camera1, camera2, matches, config)
 
 
 def unfilter_matches(matches: np.ndarray, m1: np.ndarray, m2: np.ndarray) -> np.ndarray:
@@ -313,6 +316,38 @@ def match_pairs(store: DescriptorStore, pairs: np.ndarray, config: Optional[Dict
     return counts[:n], matches[:total]
 
 
+def match_pairs_calibrated(store: DescriptorStore, pairs: np.ndarray, cameras: Sequence[Any], points: Sequence[np.ndarray],
+                           config: Optional[Dict[str, Any]] = None) -> Tuple[np.ndarray, np.ndarray]:
+    """``matching.match`` for pairs that take the calibrated branch of ``robust_match`` (``matching.py:563-634,871-929``):
+    descriptor matching on the GPU for all pairs, the ``robust_matching_min_match`` gate, bearings once per image, one
+    ``osfm_relpose_pairs`` launch for the surviving pairs, the gate again.  ``cameras[i]`` / ``points[i]`` belong to image i
+    of the store.  Same return convention as ``match_pairs``.
+    (The correspondences are gathered on the host between the two launches; fusing that step is the next item.)"""
+    pairs = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+    min_match = int(_cfg(config, "robust_matching_min_match"))
+    counts, matches = match_pairs(store, pairs, config, robust=False)
+    per_pair = split_matches(counts, matches)
+    keep = [p for p, m in enumerate(per_pair) if len(m) >= max(min_match, 1)]
+    out_counts = np.zeros(len(pairs), np.int32)
+    if not keep:
+        return out_counts, np.zeros((0, 2), np.int32)
+    bearings: Dict[int, np.ndarray] = {}
+    for im in sorted({int(i) for p in keep for i in pairs[p]}):
+        bearings[im] = pixel_bearing_many(cameras[im], np.asarray(points[im], np.float64)[:, :2], store.ctx)
+    b1 = np.concatenate([bearings[int(pairs[p, 0])][per_pair[p][:, 0]] for p in keep])
+    b2 = np.concatenate([bearings[int(pairs[p, 1])][per_pair[p][:, 1]] for p in keep])
+    off = np.r_[0, np.cumsum([len(per_pair[p]) for p in keep])].astype(np.int64)
+    _, mask, _ = relpose_pairs(b1, b2, off, _cfg(config, "robust_matching_calib_threshold"), "match", 1000, 0.99, True, 10,
+                               _cfg(config, "five_point_refine_match_iterations"), store.ctx)
+    chunks = []
+    for k, p in enumerate(keep):
+        rm = per_pair[p][mask[off[k]: off[k + 1]]]
+        if len(rm) >= min_match and len(rm) > 0:
+            out_counts[p] = len(rm)
+            chunks.append(rm)
+    return out_counts, (np.concatenate(chunks) if chunks else np.zeros((0, 2), np.int32))
+
+
 def split_matches(counts: np.ndarray, matches: np.ndarray) -> List[np.ndarray]:
     off = np.concatenate([[0], np.cumsum(counts)])
     return [matches[off[i]: off[i + 1]] for i in range(len(counts))]
@@ -325,8 +360,10 @@ def match_images_with_pairs(data, config_override: Dict[str, Any], exifs: Dict[s
     ``data`` must offer the ``DataSetBase`` methods the reference uses on this path:
     ``config``, ``load_camera_models()``, ``load_features(image)`` (``.points``, ``.descriptors``) and
     optionally ``load_features_mask(image, points)`` (``feature_loading.py:61-71``).
-    Only the configuration the GPU path implements is accepted: ``matcher_type: BRUTEFORCE``,
-    undistorted perspective cameras, no guided matching.
+    Only the configuration the GPU path implements is accepted: ``matcher_type: BRUTEFORCE``, no guided matching;
+    pairs of undistorted perspective/brown cameras take the fused matcher + fundamental-matrix RANSAC launch, pairs with a
+    distorted perspective or a fisheye camera the calibrated route (``match_pairs_calibrated``); other projection types
+    raise NotImplementedError.
     """
     if poses:
         raise NotImplementedError("guided matching is not implemented on the GPU path")
@@ -337,11 +374,12 @@ def match_images_with_pairs(data, config_override: Dict[str, Any], exifs: Dict[s
     cameras = data.load_camera_models()
     images = sorted({im for pair in pairs for im in pair})
     index = {im: k for k, im in enumerate(images)}
-    descs, pts, masks = [], [], []
+    descs, pts, masks, cams = [], [], [], []
     for im in images:
         cam = cameras[exifs[im]["camera"]]
-        if not (cam.projection_type in ["perspective", "brown"] and cam.k1 == 0.0 and cam.k2 == 0.0):
-            raise NotImplementedError(f"camera of {im} needs the calibrated robust-matching branch (not on GPU yet)")
+        if not _is_pinhole(cam) and cam.projection_type not in _BEARING_MODELS:
+            raise NotImplementedError(f"camera of {im}: projection type {cam.projection_type!r} has no bearing kernel on the GPU path yet")
+        cams.append(cam)
         fd = data.load_features(im)
         points = np.asarray(fd.points)
         desc = np.asarray(fd.descriptors)
@@ -355,11 +393,20 @@ def match_images_with_pairs(data, config_override: Dict[str, Any], exifs: Dict[s
     store = DescriptorStore(descs, pts)
     try:
         ipairs = np.asarray([(index[a], index[b]) for a, b in pairs], np.int32).reshape(-1, 2)
-        counts, matches = match_pairs(store, ipairs, config, robust=True)
+        pin = np.array([_is_pinhole(cams[a]) and _is_pinhole(cams[b]) for a, b in ipairs], bool)
+        per_pair: List[np.ndarray] = [np.zeros((0, 2), np.int32)] * len(ipairs)
+        if pin.any():
+            counts, matches = match_pairs(store, ipairs[pin], config, robust=True)
+            for p, m in zip(np.flatnonzero(pin), split_matches(counts, matches)):
+                per_pair[p] = m
+        if (~pin).any():
+            counts, matches = match_pairs_calibrated(store, ipairs[~pin], cams, pts, config)
+            for p, m in zip(np.flatnonzero(~pin), split_matches(counts, matches)):
+                per_pair[p] = m
     finally:
         store.close()
     out: Dict[Tuple[str, str], np.ndarray] = {}
-    for (im1, im2), m in zip(pairs, split_matches(counts, matches)):
+    for (im1, im2), m in zip(pairs, per_pair):
         if len(m) == 0:
             out[im1, im2] = np.array([])  # matching.py:598,634
             continue

@@ -2,6 +2,7 @@
 // and its wavefront orchestration (relpose_wave.h) for the HOST with a loop-based wave policy, so that
 // tests/test_relpose_core_host.py can compare them bit for bit with the CPU oracle without a GPU.
 // Nothing in the product links or loads this file.
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -27,7 +28,7 @@ static int ransac_impl(const double* b1, const double* b2, int n, double thr, in
   std::vector<int> inl(n > 0 ? n : 1), sub(n > 0 ? n : 1);
   WaveShared* s = new WaveShared;
   PairWork P{b1, b2, n, models.data(), inl.data(), sub.data()};
-  RansacParams prm{thr, iterations, probability, use_lo, lo_it};
+  RansacParams prm{thr, 1.0 - cos(thr), iterations, probability, use_lo, lo_it};
   RansacResult r;
   ransac_relative_pose_wave(w, *s, P, prm, r);
   delete s;
@@ -80,7 +81,7 @@ int host_robust_match_calibrated(const double* b1, const double* b2, int n, doub
   std::vector<int> inl(n > 0 ? n : 1), sub(n > 0 ? n : 1);
   WaveShared* s = new WaveShared;
   PairWork P{b1, b2, n, models.data(), inl.data(), sub.data()};
-  RansacParams prm{thr, iterations, probability, use_lo, lo_it};
+  RansacParams prm{thr, 1.0 - cos(thr), iterations, probability, use_lo, lo_it};
   MatchResult r;
   robust_match_calibrated_wave(w, *s, P, prm, refine_iterations, r);
   delete s;

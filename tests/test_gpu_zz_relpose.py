@@ -1,21 +1,17 @@
 """Calibrated robust matching on the GPU (row M-a9): osfm_pixel_bearings / osfm_relpose_pairs through the C ABI
 against the CPU oracle.  The sampler, the five-point solver, the scoring and the local optimisation use + - * / sqrt
-only, so the RANSAC stage has to match bit for bit; the refinement goes through sin / cos / atan2 (device math library
-vs glibc), so poses after it are compared to 1e-12 and inlier sets exactly.
+only, so the RANSAC stage has to match bit for bit (it does: profiles/r01_relpose_bringup.txt).  The refinement goes
+through sin / cos / atan2 (device math library vs glibc) and three rounds of Levenberg-Marquardt amplify the last-bit
+differences to ~1e-10 in R (measured; an accept/reject or stop decision of the 10-iteration LM may also flip), so poses
+after it are compared to 1e-6 and inlier sets exactly.
 
-The file sorts last on purpose and is opt-in (OSFM_TEST_UNVALIDATED=1) until the kernel has run once on an MI355X: round 1
-ended with the GPU budget spent, the numerics are pinned by tests/test_relpose_core_host.py in the meantime."""
-import os
+The file sorts last on purpose: it is the newest kernel (first run on an MI355X at the very end of round 1)."""
 from types import SimpleNamespace
 
 import numpy as np
 import pytest
 
-pytestmark = [
-    pytest.mark.gpu,
-    pytest.mark.skipif(os.environ.get("OSFM_TEST_UNVALIDATED") != "1",
-                       reason="relpose.hip has not been validated on an MI355X yet; set OSFM_TEST_UNVALIDATED=1 to run"),
-]
+pytestmark = pytest.mark.gpu
 
 
 def _rodrigues(r):
@@ -94,7 +90,7 @@ def test_robust_match_calibrated_batch(oracle_lib):
         assert np.array_equal(mask[s], want["mask"]), p
         assert res[p]["n_inliers"] == want["mask"].sum()
         if res[p]["n_inliers"]:
-            assert np.abs(res[p]["R"] - want["R"]).max() < 1e-12 and np.abs(res[p]["t"] - want["t"]).max() < 1e-12
+            assert np.abs(res[p]["R"] - want["R"]).max() < 1e-6 and np.abs(res[p]["t"] - want["t"]).max() < 1e-6
 
 
 def test_robust_match_calibrated_leaf(oracle_lib):
@@ -129,3 +125,31 @@ def test_robust_match_calibrated_leaf(oracle_lib):
     assert np.array_equal(np.asarray(got), np.asarray(want))
     assert good[np.asarray(got)[:, 0]].mean() > 0.98 and len(got) > 0.8 * good.sum()
     assert len(matching.robust_match_calibrated(p1, p2, cams[0], cams[1], matches[:7], cfg)) == 0
+
+
+def test_match_pairs_calibrated_pipeline(oracle_lib, gpu_ctx):
+    """All pairs of a small street scene whose cameras are (slightly) distorted perspectives, so every pair takes the
+    calibrated branch: GPU descriptor stage -> gate -> bearings -> one relpose launch -> gate, against the same flow on
+    the oracle (matching.py:563-634 with robust_match_calibrated)."""
+    from opensfm_amd import matching, synthetic
+
+    sc = synthetic.make_matching_scene(8, 600, seed=33, ragged=True)
+    pairs = synthetic.all_pairs(8)
+    cam = SimpleNamespace(projection_type="perspective", k1=1e-3, k2=0.0, focal=0.85)
+    pts = [sc.pts[sc.offsets[i]: sc.offsets[i + 1]] for i in range(8)]
+    store = matching.DescriptorStore.from_packed(sc.desc, sc.pts, sc.offsets)
+    counts, m = matching.match_pairs_calibrated(store, pairs, [cam] * 8, pts, {})
+    got = matching.split_matches(counts, m)
+    stage0 = oracle_lib.match_pairs(sc.desc.astype(np.float32), sc.pts, sc.offsets, pairs, stage=0)
+    survivors = 0
+    for (a, b), g, m0 in zip(pairs, got, stage0):
+        want = np.zeros((0, 2), np.int32)
+        if len(m0) >= 20:
+            b1 = oracle_lib.pixel_bearings(0, [cam.k1, cam.k2, cam.focal], pts[a][m0[:, 0], :2])
+            b2 = oracle_lib.pixel_bearings(0, [cam.k1, cam.k2, cam.focal], pts[b][m0[:, 1], :2])
+            r = oracle_lib.robust_match_calibrated_bearings(b1, b2, 0.004, 1000, 0.99, True, 10, 10)
+            if r["mask"].sum() >= 20:
+                want = m0[r["mask"]]
+        assert np.array_equal(g, want), (a, b)
+        survivors += len(want) > 0
+    assert survivors >= 7  # neighbouring cameras of the street share points

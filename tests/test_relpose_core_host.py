@@ -47,6 +47,36 @@ def _scene(rng, n, outliers=0.3, noise=1e-3):
     return np.ascontiguousarray(b1), np.ascontiguousarray(b2), ~bad
 
 
+def _emulated_calls(host):
+    """(pixel_bearing_many, relpose_pairs) of opensfm_amd.matching served by the host emulation instead of the C ABI."""
+
+    def bearings(camera, points, ctx=None):
+        px = np.ascontiguousarray(np.asarray(points, np.float64)[:, :2])
+        out = np.zeros((len(px), 3))
+        cam = np.array([camera.k1, camera.k2, camera.focal])
+        host.host_pixel_bearings({"perspective": 0, "fisheye": 1}[camera.projection_type], _p(cam, C.c_double), _p(px, C.c_double), len(px),
+                                 _p(out, C.c_double))
+        return out
+
+    def relpose_pairs(b1, b2, offsets, threshold, mode="match", iterations=1000, probability=0.99, use_lo=True, lo_iterations=10,
+                      refine_iterations=10, ctx=None):
+        assert mode == "match"
+        mask = np.zeros(len(b1), bool)
+        for p in range(len(offsets) - 1):
+            s = slice(int(offsets[p]), int(offsets[p + 1]))
+            x, y = np.ascontiguousarray(b1[s]), np.ascontiguousarray(b2[s])
+            k = len(x)
+            R, t, models, info = np.zeros(9), np.zeros(3), np.zeros(24), np.zeros(2, np.int32)
+            m = np.zeros(max(k, 1), np.uint8)
+            host.host_robust_match_calibrated(_p(x, C.c_double), _p(y, C.c_double), k, C.c_double(threshold), iterations,
+                                              C.c_double(probability), int(use_lo), lo_iterations, refine_iterations, _p(R, C.c_double),
+                                              _p(t, C.c_double), _p(m, C.c_uint8), _p(models, C.c_double), _p(info, C.c_int32))
+            mask[s] = m[:k].astype(bool)
+        return [{}] * (len(offsets) - 1), mask, 0.0
+
+    return bearings, relpose_pairs
+
+
 def test_five_point_and_pose_bits(host, oracle_lib):
     rng = np.random.default_rng(0)
     for trial in range(200):
@@ -159,3 +189,148 @@ def test_robust_match_calibrated_bits(host, oracle_lib):
             assert np.array_equal(t.view(np.uint64), want["t"].view(np.uint64))
             if outl < 0.9:  # the inliers are the true correspondences (a few noisy ones may fall outside the threshold)
                 assert (want["mask"] & ~good).sum() <= 0.02 * n and (want["mask"] & good).sum() >= 0.8 * good.sum()
+
+
+def test_product_host_function_on_the_emulation(host, oracle_lib, monkeypatch):
+    """opensfm_amd.matching.robust_match_calibrated (the reference's signature) with its two C-ABI calls redirected to the
+    host emulation: checks the Python glue and the logic of the GPU leaf test without a GPU."""
+    from opensfm_amd import matching
+
+    import test_gpu_zz_relpose as gpu_tests
+
+    bearings, relpose_pairs = _emulated_calls(host)
+    monkeypatch.setattr(matching, "pixel_bearing_many", bearings)
+    monkeypatch.setattr(matching, "relpose_pairs", relpose_pairs)
+    gpu_tests.test_robust_match_calibrated_leaf(oracle_lib)
+
+
+def test_match_images_with_pairs_routes_calibrated_pairs(host, oracle_lib, monkeypatch):
+    """match_images_with_pairs on a mixed collection (two pinhole cameras, a fisheye, a distorted perspective): pinhole
+    pairs go to the fused launch, the others through match_pairs_calibrated = the reference's match() flow
+    (matching.py:563-634) with robust_match_calibrated; the C-ABI calls are redirected (descriptor stage: canned matches,
+    bearings / relative pose: host emulation) so that the host logic -- gates, gathering, unfiltering -- runs without a GPU."""
+    from types import SimpleNamespace
+
+    from opensfm_amd import matching
+
+    import test_gpu_zz_relpose as gpu_tests
+
+    rng = np.random.default_rng(7)
+    cams = {"pin": SimpleNamespace(projection_type="perspective", k1=0.0, k2=0.0, focal=0.8),
+            "fish": SimpleNamespace(projection_type="fisheye", k1=-0.05, k2=0.01, focal=0.7),
+            "dist": SimpleNamespace(projection_type="perspective", k1=-0.1, k2=0.02, focal=0.85)}
+    images = ["a", "b", "c", "d"]
+    cam_of = {"a": "pin", "b": "pin", "c": "fish", "d": "dist"}
+    n = 260
+    X = np.c_[rng.uniform(-2, 2, n), rng.uniform(-2, 2, n), rng.uniform(4, 9, n)]
+
+    def forward(cam, b):
+        if cam.projection_type == "fisheye":
+            l = np.hypot(b[:, 0], b[:, 1])
+            u = b[:, :2] * (np.arctan2(l, b[:, 2]) / np.maximum(l, 1e-300))[:, None]
+        else:
+            u = b[:, :2] / b[:, 2:3]
+        r2 = (u**2).sum(1)
+        return cam.focal * u * (1 + r2 * (cam.k1 + cam.k2 * r2))[:, None]
+
+    feats, masks, order = {}, {}, {}
+    for im in images:
+        R = _rodrigues(rng.normal(0, 0.15, 3))
+        t = rng.normal(0, 0.4, 3)
+        Y = X @ R.T + t + rng.normal(0, 1e-3, X.shape)
+        perm = rng.permutation(n)
+        order[im] = perm  # feature f of the image shows point perm[f]
+        feats[im] = SimpleNamespace(points=np.c_[forward(cams[cam_of[im]], Y / np.linalg.norm(Y, axis=1, keepdims=True))[perm], np.ones((n, 2))],
+                                    descriptors=np.zeros((n, 128), np.float32))
+        masks[im] = rng.random(n) > 0.1
+    data = SimpleNamespace(config={"matcher_type": "BRUTEFORCE", "robust_matching_min_match": 20, "robust_matching_calib_threshold": 0.004,
+                                   "five_point_refine_match_iterations": 10, "lowes_ratio": 0.8, "symmetric_matching": True},
+                           load_camera_models=lambda: cams, load_features=lambda im: feats[im],
+                           load_features_mask=lambda im, pts: masks[im])
+    exifs = {im: {"camera": cam_of[im]} for im in images}
+    pairs = [(a, b) for i, a in enumerate(images) for b in images[i + 1:]]
+
+    class FakeStore:
+        ctx = None
+
+        def __init__(self, descs, pts, ctx=None):
+            self.pts = pts
+
+        def close(self):
+            pass
+
+    stage = {}
+
+    def fake_match_pairs(store, ipairs, config=None, robust=True, timings=None):
+        """descriptor stage: the true correspondences among the unmasked features, 25 % replaced by wrong ones; the pair (a, c)
+        gets only 15 so that the first min-match gate fires."""
+        counts, chunks = [], []
+        for a, b in np.asarray(ipairs):
+            ia, ib = images[a], images[b]
+            fa = np.flatnonzero(masks[ia])
+            fb = np.flatnonzero(masks[ib])
+            pos_b = {int(order[ib][f]): k for k, f in enumerate(fb)}
+            m = np.array([(k, pos_b[int(order[ia][f])]) for k, f in enumerate(fa) if int(order[ia][f]) in pos_b], np.int32)
+            wrong = rng.random(len(m)) < 0.25
+            m[wrong, 1] = rng.integers(0, len(fb), wrong.sum())
+            if (ia, ib) == ("a", "c"):
+                m = m[:15]
+            stage[(ia, ib, bool(robust))] = m
+            counts.append(len(m))
+            chunks.append(m)
+        return np.asarray(counts, np.int32), np.concatenate(chunks) if chunks else np.zeros((0, 2), np.int32)
+
+    bearings, relpose_pairs = _emulated_calls(host)
+    monkeypatch.setattr(matching, "DescriptorStore", FakeStore)
+    monkeypatch.setattr(matching, "match_pairs", fake_match_pairs)
+    monkeypatch.setattr(matching, "pixel_bearing_many", bearings)
+    monkeypatch.setattr(matching, "relpose_pairs", relpose_pairs)
+    got = matching.match_images_with_pairs(data, {}, exifs, pairs)
+    assert set(got) == set(pairs)
+    assert ("a", "b", True) in stage and all((a, b, False) in stage for a, b in pairs if (a, b) != ("a", "b"))
+    for (ia, ib) in pairs:
+        if (ia, ib) == ("a", "b"):  # pinhole pair: whatever the fused launch returned, unfiltered
+            want = matching.unfilter_matches(stage[ia, ib, True], masks[ia], masks[ib])
+            assert np.array_equal(got[ia, ib], want)
+            continue
+        m = stage[ia, ib, False]
+        if len(m) < 20:
+            assert (ia, ib) == ("a", "c") and len(got[ia, ib]) == 0
+            continue
+        c1, c2 = cams[cam_of[ia]], cams[cam_of[ib]]
+        rm = oracle_lib.robust_match_calibrated(feats[ia].points[masks[ia]], feats[ib].points[masks[ib]], [c1.k1, c1.k2, c1.focal],
+                                                [c2.k1, c2.k2, c2.focal], c1.projection_type, c2.projection_type, m, 0.004, 10)
+        assert len(rm) >= 20
+        want = matching.unfilter_matches(rm, masks[ia], masks[ib])
+        assert np.array_equal(got[ia, ib], np.asarray(want))
+        # and they are true correspondences
+        assert (order[ia][got[ia, ib][:, 0]] == order[ib][got[ia, ib][:, 1]]).mean() > 0.98
+
+
+def test_gpu_pipeline_test_logic_on_the_emulation(host, oracle_lib, monkeypatch):
+    """tests/test_gpu_zz_relpose.py::test_match_pairs_calibrated_pipeline with the descriptor stage served by the oracle and the
+    bearing / relative-pose calls by the host emulation: the expectations of the GPU test are themselves checked on CPU."""
+    from opensfm_amd import matching
+
+    import test_gpu_zz_relpose as gpu_tests
+
+    class FakeStore:
+        ctx = None
+
+        @classmethod
+        def from_packed(cls, desc, pts, offsets, ctx=None):
+            s = cls()
+            s.desc, s.pts, s.offsets = desc, pts, offsets
+            return s
+
+    def fake_match_pairs(store, ipairs, config=None, robust=True, timings=None):
+        assert not robust
+        per = oracle_lib.match_pairs(store.desc.astype(np.float32), store.pts, store.offsets, ipairs, stage=0)
+        return np.asarray([len(m) for m in per], np.int32), np.concatenate(per)
+
+    bearings, relpose_pairs = _emulated_calls(host)
+    monkeypatch.setattr(matching, "DescriptorStore", FakeStore)
+    monkeypatch.setattr(matching, "match_pairs", fake_match_pairs)
+    monkeypatch.setattr(matching, "pixel_bearing_many", bearings)
+    monkeypatch.setattr(matching, "relpose_pairs", relpose_pairs)
+    gpu_tests.test_match_pairs_calibrated_pipeline(oracle_lib, None)
