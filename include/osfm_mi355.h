@@ -143,6 +143,7 @@ int osfm_ransac_fundamental(osfm_ctx *ctx, const double *p1, const double *p2, i
 #define OSFM_CAMERA_DUAL 6           /* [transition | k1 k2 | focal]                         */
 #define OSFM_CAMERA_RADIAL 7         /* [k1 k2 | focal ar cx cy]                             */
 #define OSFM_CAMERA_SIMPLE_RADIAL 8  /* [k1 | focal ar cx cy]                                */
+#define OSFM_CAMERA_SPHERICAL 9      /* no parameters; bearings only (osfm_pixel_bearings), not a BA camera model */
 
 typedef struct {
   int32_t n_cameras, n_shots, n_points;
@@ -255,8 +256,10 @@ void osfm_tracks_destroy(osfm_tracks *t);
  * after the refinement; a first-correct kernel, not yet profiled or tuned.
  *
  * osfm_pixel_bearings  replaces camera.pixel_bearing_many(points) (opensfm/src/geometry/camera.cc ->
- *   camera_instances.h:154-160) for OSFM_CAMERA_PERSPECTIVE / OSFM_CAMERA_FISHEYE, cam = [k1, k2, focal];
- *   px: n x 2 normalised image coordinates, bearings: n x 3.
+ *   ProjectGeneric::Backward, camera_instances.h:154-160) for every OSFM_CAMERA_* model; cam = the model's
+ *   parameters in the native order listed at the OSFM_CAMERA_* definitions ([k1, k2, focal] for PERSPECTIVE /
+ *   FISHEYE, may be NULL for SPHERICAL); px: n x 2 normalised image coordinates, bearings: n x 3.
+ *   (PERSPECTIVE / FISHEYE ran on the MI355X in round 1; the other models so far only in the host emulation.)
  * osfm_relpose_pairs   a batch of pairs; pair p owns the correspondences offsets[p] .. offsets[p+1]-1 of the
  *   concatenated bearing arrays b1, b2 (total x 3, doubles, second-image bearing y and first-image bearing x
  *   with y ~ R x + t for the models below).
@@ -285,7 +288,7 @@ typedef struct osfm_relpose_result {
   int32_t score, iterations;      /* best inlier count of the RANSAC, iterations it ran */
   int32_t n_inliers, pad;         /* number of ones in this pair's mask */
 } osfm_relpose_result;
-int osfm_pixel_bearings(osfm_ctx *ctx, int model, const double cam[3], const double *px, int n, double *bearings);
+int osfm_pixel_bearings(osfm_ctx *ctx, int model, const double *cam, const double *px, int n, double *bearings);
 int osfm_relpose_pairs(osfm_ctx *ctx, const double *b1, const double *b2, const int64_t *offsets, int n_pairs,
                        const osfm_relpose_params *params, int mode, osfm_relpose_result *results, uint8_t *mask,
                        double *kernel_ms /* may be NULL: HIP-event time of the kernels */);

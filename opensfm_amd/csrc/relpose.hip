@@ -119,11 +119,15 @@ __global__ __launch_bounds__(kWave) void relpose_pairs_kernel(const double *__re
   if (w.lane == 0) out[p] = r;
 }
 
-__global__ void pixel_bearings_kernel(int model, double k1, double k2, double f, const double *__restrict__ px, int n, double *__restrict__ out) {
+struct CameraParams {
+  double v[16];  // native order [projection][distortion][affine]
+};
+
+__global__ void pixel_bearings_kernel(int model, CameraParams cam, const double *__restrict__ px, int n, double *__restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   double b[3];
-  pixel_bearing(model, k1, k2, f, px[2 * i], px[2 * i + 1], b);
+  pixel_bearing_generic(model, cam.v, px[2 * i], px[2 * i + 1], b);
   out[3 * i] = b[0];
   out[3 * i + 1] = b[1];
   out[3 * i + 2] = b[2];
@@ -143,19 +147,26 @@ struct DevBuf {  // frees on scope exit
 
 }  // namespace
 
-extern "C" int osfm_pixel_bearings(osfm_ctx *ctx, int model, const double cam[3], const double *px, int n, double *bearings) {
-  OSFM_REQUIRE(ctx && cam && (n == 0 || (px && bearings)), OSFM_E_INVALID, "osfm_pixel_bearings: null argument");
-  OSFM_REQUIRE(model == OSFM_CAMERA_PERSPECTIVE || model == OSFM_CAMERA_FISHEYE, OSFM_E_UNSUPPORTED,
-               "osfm_pixel_bearings: camera model %d (only PERSPECTIVE and FISHEYE have a backward projection here)", model);
+extern "C" int osfm_pixel_bearings(osfm_ctx *ctx, int model, const double *cam, const double *px, int n, double *bearings) {
+  OSFM_REQUIRE(ctx && (cam || model == OSFM_CAMERA_SPHERICAL) && (n == 0 || (px && bearings)), OSFM_E_INVALID,
+               "osfm_pixel_bearings: null argument");
+  OSFM_REQUIRE(model >= OSFM_CAMERA_PERSPECTIVE && model <= OSFM_CAMERA_SPHERICAL, OSFM_E_INVALID, "osfm_pixel_bearings: camera model %d", model);
   OSFM_REQUIRE(n >= 0, OSFM_E_INVALID, "osfm_pixel_bearings: n < 0");
+  CameraParams cp;
+  {
+    int proj, kind, nd, na;
+    camera_layout(model, &proj, &kind, &nd, &na);
+    const int np = (proj == 2 ? 1 : 0) + nd + na;
+    for (int i = 0; i < 16; i++) cp.v[i] = i < np ? cam[i] : 0.0;
+  }
   if (n == 0) return OSFM_OK;
   OSFM_HIP(hipSetDevice(ctx->device));
   DevBuf d_px, d_out;
   OSFM_HIP(d_px.alloc((size_t)n * 16));
   OSFM_HIP(d_out.alloc((size_t)n * 24));
   OSFM_HIP(hipMemcpyAsync(d_px.p, px, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(pixel_bearings_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, model, cam[0], cam[1], cam[2],
-                     d_px.as<double>(), n, d_out.as<double>());
+  hipLaunchKernelGGL(pixel_bearings_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, model, cp, d_px.as<double>(), n,
+                     d_out.as<double>());
   OSFM_HIP(hipGetLastError());
   OSFM_HIP(hipMemcpyAsync(bearings, d_out.p, (size_t)n * 24, hipMemcpyDeviceToHost, ctx->stream));
   OSFM_HIP(hipStreamSynchronize(ctx->stream));

@@ -691,36 +691,178 @@ OSFM_HD double max_iterations_for(int best_n, int n, double probability) {
 // ---------------------------------------------------------------------------------------------------------------
 // Bearings and the inlier test of robust_match_calibrated (camera_instances.h:154-160, matching.py:805-844)
 // ---------------------------------------------------------------------------------------------------------------
-OSFM_HD void pixel_bearing(int model, double k1, double k2, double f, double px, double py, double* b) {
-  const double xd = px / f, yd = py / f;
-  double xu = xd, yu = yd;
+// Camera models (OSFM_CAMERA_* of include/osfm_mi355.h) as ProjectGeneric<PROJ, DISTO, AFF> (camera_instances.h:127-160):
+//   proj  0 perspective, 1 fisheye, 2 dual (leading parameter "transition"), 3 spherical
+//   kind  0 Disto2, 1 Disto24, 2 Disto2468, 3 DistoBrown, 4 Disto62, 5 Disto624, -1 none
+//   na    1 UniformScale [focal], 4 Affine [focal aspect_ratio cx cy], 0 none
+// parameters in the native order [PROJ][DISTO][AFF]; models 0 / 1 are [k1 k2 focal].
+OSFM_HD void camera_layout(int model, int* proj, int* kind, int* nd, int* na) {
+  switch (model) {
+    case 0: *proj = 0; *kind = 1; *nd = 2; *na = 1; break;
+    case 1: *proj = 1; *kind = 1; *nd = 2; *na = 1; break;
+    case 2: *proj = 0; *kind = 3; *nd = 5; *na = 4; break;
+    case 3: *proj = 1; *kind = 2; *nd = 4; *na = 4; break;
+    case 4: *proj = 1; *kind = 4; *nd = 8; *na = 4; break;
+    case 5: *proj = 1; *kind = 5; *nd = 12; *na = 4; break;
+    case 6: *proj = 2; *kind = 1; *nd = 2; *na = 1; break;
+    case 7: *proj = 0; *kind = 1; *nd = 2; *na = 4; break;
+    case 8: *proj = 0; *kind = 0; *nd = 1; *na = 4; break;
+    default: *proj = 3; *kind = -1; *nd = 0; *na = 0; break;  // 9: spherical
+  }
+}
+// radial polynomial of the 1-D distortions and the "derivative" the reference's Newton iteration divides by
+// (camera_distortions_functions.h:93-101, 191-199, 307-321: Disto2 / Disto24 use 1 + 2 k1 r2 (+ 4 k2 r4), not d(r D)/dr)
+OSFM_HD double radial_1d(int kind, const double* k, double r2) {
+  if (kind == 0) return 1.0 + r2 * k[0];
+  if (kind == 1) return 1.0 + r2 * (k[0] + k[1] * r2);
+  return 1.0 + r2 * (k[0] + r2 * (k[1] + r2 * (k[2] + r2 * k[3])));
+}
+OSFM_HD double radial_1d_derivative(int kind, const double* k, double r2) {
+  if (kind == 0) return 1.0 + r2 * 2.0 * k[0];
+  if (kind == 1) return 1.0 + r2 * 2.0 * (k[0] + 2.0 * k[1] * r2);
+  return 1.0 + r2 * (3.0 * k[0] + r2 * (5.0 * k[1] + r2 * (7.0 * k[2] + r2 * 9.0 * k[3])));
+}
+// forward value and the four derivative entries [dX/dx, dX/dy, dY/dx, dY/dy] of the 2-D distortions, as
+// ForwardDerivatives<T, false> writes them (camera_distortions_functions.h:348-385 Disto62, :527-566 Disto624, :726-753 Brown)
+OSFM_HD void distort_2d(int kind, const double* k, double x, double y, double* out, double* jac) {
+  const double x2 = x * x, y2 = y * y, r2 = x2 + y2;
+  if (kind == 3) {
+    const double k1 = k[0], k2 = k[1], k3 = k[2], p1 = k[3], p2 = k[4];
+    const double x4 = x2 * x2, y4 = y2 * y2, r4 = r2 * r2, r6 = r4 * r2;
+    const double rad = 1.0 + r2 * (k1 + r2 * (k2 + r2 * k3));
+    out[0] = x * rad + (2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x));
+    out[1] = y * rad + (2.0 * p2 * x * y + p1 * (r2 + 2.0 * y * y));
+    jac[0] = 5.0 * k2 * x4 + 3.0 * k1 * x2 + 6.0 * k3 * x2 * r4 + 6.0 * k2 * x2 * y2 + k3 * r6 + k2 * y4 + k1 * y2 + 1.0 + 2.0 * p1 * y +
+             6.0 * p2 * x;
+    jac[1] = x * (2.0 * k1 * y + 4.0 * k2 * y * r2 + 6.0 * k3 * y * r4) + 2.0 * p1 * x + 2.0 * p2 * y;
+    jac[3] = 5.0 * k2 * y4 + 3.0 * k1 * y2 + 6.0 * k3 * y2 * r4 + 6.0 * k2 * x2 * y2 + k3 * r6 + k2 * x4 + k1 * x2 + 1.0 + 2.0 * p2 * x +
+             6.0 * p1 * y;
+    jac[2] = y * (2.0 * k1 * x + 4.0 * k2 * x * r2 + 6.0 * k3 * x * r4) + 2.0 * p2 * y + 2.0 * p1 * x;
+    return;
+  }
+  const double k1 = k[0], k2 = k[1], k3 = k[2], k4 = k[3], k5 = k[4], k6 = k[5], p1 = k[6], p2 = k[7];
+  const double r2_2 = r2 * r2, r2_3 = r2_2 * r2, r2_4 = r2_3 * r2, r2_5 = r2_4 * r2;
+  const double rad = 1.0 + r2 * (k1 + r2 * (k2 + r2 * (k3 + r2 * (k4 + r2 * (k5 + r2 * k6)))));
+  double tx = 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x), ty = 2.0 * p2 * x * y + p1 * (r2 + 2.0 * y * y);
+  const double dx_dxt = 2.0 * y * p1 + 6.0 * p2 * x, dx_dyt = 2.0 * x * p1 + 2.0 * p2 * y, dy_dxt = dx_dyt,
+               dy_dyt = 2.0 * x * p2 + 6.0 * p1 * y;
+  const double dr_dx = 2.0 * x, dr_dy = 2.0 * y;
+  const double dp_dr = k1 + 2.0 * k2 * r2 + 3.0 * k3 * r2_2 + 4.0 * k4 * r2_3 + 5.0 * k5 * r2_4 + 6.0 * k6 * r2_5;
+  if (kind == 5) {
+    const double s0 = k[8], s1 = k[9], s2 = k[10], s3 = k[11];
+    out[0] = x * rad + tx + (s0 * r2 + s1 * r2 * r2);
+    out[1] = y * rad + ty + (s2 * r2 + s3 * r2 * r2);
+    const double dx_dx_tp = s0 * 2.0 * x + s1 * 4.0 * x * r2, dx_dy_tp = s0 * 2.0 * y + s1 * 4.0 * y * r2;
+    const double dy_dx_tp = s2 * 2.0 * x + s3 * 4.0 * x * r2, dy_dy_tp = s2 * 2.0 * y + s3 * 4.0 * y * r2;
+    jac[0] = rad + x * dp_dr * dr_dx + dx_dxt + dx_dx_tp;
+    jac[1] = x * dp_dr * dr_dy + dx_dyt + dx_dy_tp;
+    jac[2] = y * dp_dr * dr_dx + dy_dxt + dy_dx_tp;
+    jac[3] = rad + y * dp_dr * dr_dy + dy_dyt + dy_dy_tp;
+  } else {
+    out[0] = x * rad + tx;
+    out[1] = y * rad + ty;
+    jac[0] = rad + x * dp_dr * dr_dx + dx_dxt;
+    jac[1] = x * dp_dr * dr_dy + dx_dyt;
+    jac[2] = y * dp_dr * dr_dx + dy_dxt;
+    jac[3] = rad + y * dp_dr * dr_dy + dy_dyt;
+  }
+}
+// DISTO::Backward: Newton-Raphson, 10 iterations, stop when the decrement is below 1e-6 BEFORE applying it
+// (foundation/newton_raphson.h:76-90).  1-D kinds iterate on the radius; 2-D kinds on the point with
+// decr = ((M^T M)^-1 M^T) f where M is the reference's Mat2 filled through .data(), i.e. the TRANSPOSE of the Jacobian
+// (column-major storage; it only matters for the thin-prism terms of Disto624, whose Jacobian is not symmetric).
+OSFM_HD void undistort(int kind, const double* k, double xd, double yd, double* xu, double* yu) {
+  *xu = xd;
+  *yu = yd;
+  if (kind < 0) return;
   const double rd = sqrt(xd * xd + yd * yd);
-  if (!(rd < kEps)) {
+  if (rd < kEps) return;
+  if (kind <= 2) {
     double r = rd;
     for (int it = 0; it < 10; it++) {
       const double r2 = r * r;
-      const double fv = r * (1.0 + r2 * (k1 + k2 * r2)) - rd;
-      const double dv = 1.0 + r2 * 2.0 * (k1 + 2.0 * k2 * r2);
-      const double decr = fv / dv;
+      const double fv = r * radial_1d(kind, k, r2) - rd;
+      const double dv = radial_1d_derivative(kind, k, r2);
+      const double decr = dv == 0.0 ? 0.0 : fv / dv;
       if (fabs(decr) < 1e-6) break;
       r -= decr;
     }
-    const double r2 = r * r, dist = 1.0 + r2 * (k1 + k2 * r2);
-    xu = xd / dist;
-    yu = yd / dist;
+    const double dist = radial_1d(kind, k, r * r);
+    *xu = xd / dist;
+    *yu = yd / dist;
+    return;
   }
-  if (model == 1) {  // OSFM_CAMERA_FISHEYE
+  double cx = xd, cy = yd;
+  for (int it = 0; it < 10; it++) {
+    double o[2], j[4];
+    distort_2d(kind, k, cx, cy, o, j);
+    const double f0 = o[0] - xd, f1 = o[1] - yd;
+    const double m00 = j[0], m10 = j[1], m01 = j[2], m11 = j[3];  // M(row, col), filled column by column
+    const double a00 = m00 * m00 + m10 * m10, a01 = m00 * m01 + m10 * m11, a10 = m01 * m00 + m11 * m10, a11 = m01 * m01 + m11 * m11;
+    const double invdet = 1.0 / (a00 * a11 - a10 * a01);
+    const double i00 = a11 * invdet, i01 = -a01 * invdet, i10 = -a10 * invdet, i11 = a00 * invdet;
+    // P = A^-1 M^T, decr = P f
+    const double p00 = i00 * m00 + i01 * m01, p01 = i00 * m10 + i01 * m11, p10 = i10 * m00 + i11 * m01, p11 = i10 * m10 + i11 * m11;
+    const double d0 = p00 * f0 + p01 * f1, d1 = p10 * f0 + p11 * f1;
+    if (sqrt(d0 * d0 + d1 * d1) < 1e-6) break;
+    cx -= d0;
+    cy -= d1;
+  }
+  *xu = cx;
+  *yu = cy;
+}
+// Camera::Bearing -> ProjectGeneric::Backward = PROJ::Backward(DISTO::Backward(AFF::Backward(pixel)))
+OSFM_HD void pixel_bearing_generic(int model, const double* par, double px, double py, double* b) {
+  int proj, kind, nd, na;
+  camera_layout(model, &proj, &kind, &nd, &na);
+  const double* kd = par + (proj == 2 ? 1 : 0);
+  const double* ka = kd + nd;
+  double xd = px, yd = py;
+  if (na == 1) {  // UniformScale::Backward
+    xd = px / ka[0];
+    yd = py / ka[0];
+  } else if (na == 4) {  // Affine::Backward
+    xd = (px - ka[2]) / ka[0];
+    yd = (py - ka[3]) / (ka[1] * ka[0]);
+  }
+  double xu, yu;
+  undistort(kind, kd, xd, yd, &xu, &yu);
+  if (proj == 1) {  // FisheyeProjection::Backward: the undistorted radius is the angle from the optical axis
     const double theta = sqrt(xu * xu + yu * yu);
     const double s = theta > 1e-8 ? sin(theta) / theta : 1.0;
     b[0] = xu * s;
     b[1] = yu * s;
     b[2] = cos(theta);
+  } else if (proj == 3) {  // SphericalProjection::Backward
+    const double lon = xu * 2 * M_PI, lat = -yu * 2 * M_PI;
+    b[0] = cos(lat) * sin(lon);
+    b[1] = -sin(lat);
+    b[2] = cos(lat) * cos(lon);
   } else {
+    if (proj == 2) {  // DualProjection::Backward: theta from r by 5 Newton steps (the first with a doubled derivative)
+      const double t = par[0], r = sqrt(xu * xu + yu * yu);
+      double theta = 0.0;
+      for (int it = 0; it < 5; it++) {
+        const double fv = t * tan(theta) + (1.0 - t) * theta - r;
+        const double secant = 1.0 / cos(theta);
+        const double dv = (it == 0 ? 2.0 : 1.0) * (t * secant * secant - t + 1);
+        const double decr = dv == 0.0 ? 0.0 : fv / dv;
+        if (fabs(decr) < 1e-6) break;
+        theta -= decr;
+      }
+      const double s = tan(theta) / (t * tan(theta) + (1.0 - t) * theta);  // NaN at the exact image centre, as the reference
+      xu = s * xu;
+      yu = s * yu;
+    }
     const double inv = 1.0 / sqrt(xu * xu + yu * yu + 1.0);
     b[0] = xu * inv;
     b[1] = yu * inv;
     b[2] = inv;
   }
+}
+OSFM_HD void pixel_bearing(int model, double k1, double k2, double f, double px, double py, double* b) {
+  const double par[3] = {k1, k2, f};
+  pixel_bearing_generic(model, par, px, py, b);
 }
 // R (row-major), t: second camera expressed in the first (matching.py:813-817)
 OSFM_HD int inlier_bearing(const double* x, const double* y, const double* R, const double* t, double threshold) {

@@ -9,8 +9,8 @@ this module                        reference
 ``match_brute_force_symmetric``    ``opensfm/matching.py:759-777``
 ``robust_match_fundamental``       ``opensfm/matching.py:780-802``
 ``robust_match``                   ``opensfm/matching.py:906-929``
-``robust_match_calibrated``        ``opensfm/matching.py:871-903`` (perspective / fisheye cameras)
-``pixel_bearing_many``             ``pygeometry.Camera.pixel_bearing_many`` (same two models)
+``robust_match_calibrated``        ``opensfm/matching.py:871-903``
+``pixel_bearing_many``             ``pygeometry.Camera.pixel_bearing_many``
 ``match`` semantics (per pair)     ``opensfm/matching.py:563-634`` (inside ``match_pairs``)
 ``match_images_with_pairs``        ``opensfm/matching.py:63-98``
 ``unfilter_matches``               ``opensfm/matching.py:932-936``
@@ -134,20 +134,46 @@ def robust_match_fundamental(p1: np.ndarray, p2: np.ndarray, matches: np.ndarray
     return F, matches[inliers]
 
 
-_BEARING_MODELS = {"perspective": 0, "fisheye": 1}  # OSFM_CAMERA_PERSPECTIVE / OSFM_CAMERA_FISHEYE
+# projection_type -> (OSFM_CAMERA_* id, attribute names in the native parameter order [projection][distortion][affine]);
+# "cx" / "cy" stand for principal_point[0] / [1] (pygeometry.Camera, opensfm/src/geometry/python/pybind.cc:113-292)
+_BEARING_MODELS = {
+    "perspective": (0, ("k1", "k2", "focal")),
+    "fisheye": (1, ("k1", "k2", "focal")),
+    "brown": (2, ("k1", "k2", "k3", "p1", "p2", "focal", "aspect_ratio", "cx", "cy")),
+    "fisheye_opencv": (3, ("k1", "k2", "k3", "k4", "focal", "aspect_ratio", "cx", "cy")),
+    "fisheye62": (4, ("k1", "k2", "k3", "k4", "k5", "k6", "p1", "p2", "focal", "aspect_ratio", "cx", "cy")),
+    "fisheye624": (5, ("k1", "k2", "k3", "k4", "k5", "k6", "p1", "p2", "s0", "s1", "s2", "s3", "focal", "aspect_ratio", "cx", "cy")),
+    "dual": (6, ("transition", "k1", "k2", "focal")),
+    "radial": (7, ("k1", "k2", "focal", "aspect_ratio", "cx", "cy")),
+    "simple_radial": (8, ("k1", "focal", "aspect_ratio", "cx", "cy")),
+    "spherical": (9, ()),
+    "equirectangular": (9, ()),
+}
+
+
+def camera_parameters(camera) -> Tuple[int, np.ndarray]:
+    """(OSFM_CAMERA_* id, parameters in the native order) of a pygeometry.Camera-like object (attributes as in the reference)."""
+    if camera.projection_type not in _BEARING_MODELS:
+        raise NotImplementedError(f"projection type {camera.projection_type!r} is not on the GPU path")
+    model, names = _BEARING_MODELS[camera.projection_type]
+
+    def get(name: str) -> float:
+        if name in ("cx", "cy"):
+            return float(camera.principal_point[0 if name == "cx" else 1])
+        return float(getattr(camera, name))
+
+    return model, np.array([get(n) for n in names] + [0.0] * (16 - len(names)), np.float64)
 
 
 def pixel_bearing_many(camera, points: np.ndarray, ctx=None) -> np.ndarray:
-    """``camera.pixel_bearing_many(points)`` (pygeometry.Camera) for perspective / fisheye cameras: (n, 2) normalised
-    image coordinates -> (n, 3) unit bearings."""
-    if camera.projection_type not in _BEARING_MODELS:
-        raise NotImplementedError(f"pixel_bearing_many: projection type {camera.projection_type!r} is not on the GPU path")
+    """``camera.pixel_bearing_many(points)`` (pygeometry.Camera): (n, 2) normalised image coordinates -> (n, 3) unit bearings,
+    every projection type of the reference (``camera_instances.h:154-160``)."""
+    model, par = camera_parameters(camera)
     ctx = ctx or default_context()
     px = np.ascontiguousarray(np.asarray(points, np.float64)[:, :2])
-    cam = np.array([camera.k1, camera.k2, camera.focal], np.float64)
     out = np.zeros((len(px), 3), np.float64)
-    check(_lib.load().osfm_pixel_bearings(ctx.handle, _BEARING_MODELS[camera.projection_type], _fptr(cam, C.c_double),
-                                          _fptr(px, C.c_double), len(px), _fptr(out, C.c_double)), "osfm_pixel_bearings")
+    check(_lib.load().osfm_pixel_bearings(ctx.handle, model, _fptr(par, C.c_double), _fptr(px, C.c_double), len(px),
+                                          _fptr(out, C.c_double)), "osfm_pixel_bearings")
     return out
 
 
@@ -202,8 +228,7 @@ def _is_pinhole(c) -> bool:
 
 
 def robust_match(p1, p2, camera1, camera2, matches, config) -> np.ndarray:
-    """``matching.py:906-929``: F-matrix path for undistorted perspective/brown cameras, E-matrix path otherwise
-    (perspective / fisheye cameras; other projection types raise NotImplementedError in ``pixel_bearing_many``)."""
+    """``matching.py:906-929``: F-matrix path for undistorted perspective/brown cameras, E-matrix path otherwise."""
     if _is_pinhole(camera1) and _is_pinhole(camera2):
         return robust_match_fundamental(p1, p2, matches, config)[1]
     return robust_match_calibrated(p1, p2, camera1, camera2, matches, config)
@@ -361,9 +386,8 @@ def match_images_with_pairs(data, config_override: Dict[str, Any], exifs: Dict[s
     ``config``, ``load_camera_models()``, ``load_features(image)`` (``.points``, ``.descriptors``) and
     optionally ``load_features_mask(image, points)`` (``feature_loading.py:61-71``).
     Only the configuration the GPU path implements is accepted: ``matcher_type: BRUTEFORCE``, no guided matching;
-    pairs of undistorted perspective/brown cameras take the fused matcher + fundamental-matrix RANSAC launch, pairs with a
-    distorted perspective or a fisheye camera the calibrated route (``match_pairs_calibrated``); other projection types
-    raise NotImplementedError.
+    pairs of undistorted perspective/brown cameras take the fused matcher + fundamental-matrix RANSAC launch, every other
+    pair the calibrated route (``match_pairs_calibrated``).
     """
     if poses:
         raise NotImplementedError("guided matching is not implemented on the GPU path")
@@ -378,7 +402,7 @@ def match_images_with_pairs(data, config_override: Dict[str, Any], exifs: Dict[s
     for im in images:
         cam = cameras[exifs[im]["camera"]]
         if not _is_pinhole(cam) and cam.projection_type not in _BEARING_MODELS:
-            raise NotImplementedError(f"camera of {im}: projection type {cam.projection_type!r} has no bearing kernel on the GPU path yet")
+            raise NotImplementedError(f"camera of {im}: unknown projection type {cam.projection_type!r}")
         cams.append(cam)
         fd = data.load_features(im)
         points = np.asarray(fd.points)

@@ -318,6 +318,20 @@ def pixel_bearings(model, cam, px) -> np.ndarray:
     return out
 
 
+BEARING_MODELS = dict(CAMERA_MODELS, spherical=9)
+
+
+def pixel_bearings_generic(model, par, px) -> np.ndarray:
+    """Camera.pixel_bearing_many for every projection type; par in the native order [projection][distortion][affine]
+    (models 0 / 1: [k1, k2, focal])."""
+    par = np.ascontiguousarray(np.r_[np.asarray(par, np.float64).reshape(-1), np.zeros(16)][:16])
+    px = np.ascontiguousarray(px, np.float64).reshape(-1, 2)
+    out = np.zeros((len(px), 3))
+    lib().oracle_pixel_bearings_generic(int(BEARING_MODELS[model] if isinstance(model, str) else model), _p(par, C.c_double),
+                                        _p(px, C.c_double), len(px), _p(out, C.c_double))
+    return out
+
+
 def inliers_bearings(b1, b2, R, t, threshold: float = 0.01) -> np.ndarray:
     """matching.compute_inliers_bearings (matching.py:805-844): R, t from the second image to the first."""
     b1 = np.ascontiguousarray(b1, np.float64).reshape(-1, 3)

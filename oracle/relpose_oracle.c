@@ -745,3 +745,163 @@ void oracle_inliers_bearings(const double *b1, const double *b2, int n, const do
     mask[i] = (sqrt(e1) < threshold) && (sqrt(e2) < threshold);
   }
 }
+
+/* ---- Stage 4b: Camera::Bearing for every 2-D camera model and the spherical one -----------------------------
+ * ProjectGeneric<PROJ, DISTO, AFF>::Backward = PROJ::Backward o DISTO::Backward o AFF::Backward
+ * (camera_instances.h:154-160, 189-201); parameters in the native order [PROJ][DISTO][AFF]:
+ *   0 perspective  [k1 k2 | focal]                 Perspective  / Disto24   / UniformScale
+ *   1 fisheye      [k1 k2 | focal]                 Fisheye      / Disto24   / UniformScale
+ *   2 brown        [k1 k2 k3 p1 p2 | f ar cx cy]   Perspective  / DistoBrown/ Affine
+ *   3 fisheye_opencv [k1..k4 | f ar cx cy]         Fisheye      / Disto2468 / Affine
+ *   4 fisheye62    [k1..k6 p1 p2 | f ar cx cy]     Fisheye      / Disto62   / Affine
+ *   5 fisheye624   [k1..k6 p1 p2 s0..s3 | f ar cx cy]           / Disto624
+ *   6 dual         [transition | k1 k2 | focal]    Dual         / Disto24   / UniformScale
+ *   7 radial       [k1 k2 | f ar cx cy]            Perspective  / Disto24   / Affine
+ *   8 simple_radial [k1 | f ar cx cy]              Perspective  / Disto2    / Affine
+ *   9 spherical    []                              Spherical    / Identity  / Identity
+ * Affine::Backward transformations_functions.h:42-47, UniformScale::Backward :74-78; the distortions'
+ * Backward camera_distortions_functions.h:49-101 (Disto2), :148-199 (Disto24), :265-321 (Disto2468), :419-470 (Disto62),
+ * :626-690 (Disto624), :774-826 (DistoBrown) with foundation::NewtonRaphson (newton_raphson.h:60-90: scalar decrement
+ * f / d, 0 when d == 0; 2-D decrement ((d^T d)^-1 d^T) f); the 2-D cases fill an Eigen (column-major) Mat2 through
+ * .data() with row-major derivative entries, i.e. they iterate with the TRANSPOSED Jacobian -- restated as is.
+ * Projections' Backward camera_projections_functions.h:70-84 (fisheye), :110-116 (perspective), :173-210 (dual),
+ * :243-250 (spherical).  Parity: unpinned vs the reference binary; pinned by the round trip against the forward
+ * projections that the mpmath golden vectors pin (tests/test_oracle_relpose.py). */
+static double rad1(int kind, const double *k, double r2) {
+  switch (kind) {
+    case 0: return 1.0 + r2 * k[0];
+    case 1: return 1.0 + r2 * (k[0] + k[1] * r2);
+    default: return 1.0 + r2 * (k[0] + r2 * (k[1] + r2 * (k[2] + r2 * k[3])));
+  }
+}
+static double rad1_derivative(int kind, const double *k, double r2) {
+  switch (kind) {
+    case 0: return 1.0 + r2 * 2.0 * k[0];
+    case 1: return 1.0 + r2 * 2.0 * (k[0] + 2.0 * k[1] * r2);
+    default: return 1.0 + r2 * (3.0 * k[0] + r2 * (5.0 * k[1] + r2 * (7.0 * k[2] + r2 * 9.0 * k[3])));
+  }
+}
+static void disto2d(int kind, const double *k, double x, double y, double *out, double *jac) {
+  const double x2 = x * x, y2 = y * y, r2 = x2 + y2;
+  if (kind == 3) { /* DistoBrown */
+    const double k1 = k[0], k2 = k[1], k3 = k[2], p1 = k[3], p2 = k[4];
+    const double x4 = x2 * x2, y4 = y2 * y2, r4 = r2 * r2, r6 = r4 * r2;
+    const double rad = 1.0 + r2 * (k1 + r2 * (k2 + r2 * k3));
+    out[0] = x * rad + (2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x));
+    out[1] = y * rad + (2.0 * p2 * x * y + p1 * (r2 + 2.0 * y * y));
+    jac[0] = 5.0 * k2 * x4 + 3.0 * k1 * x2 + 6.0 * k3 * x2 * r4 + 6.0 * k2 * x2 * y2 + k3 * r6 + k2 * y4 + k1 * y2 + 1.0 + 2.0 * p1 * y + 6.0 * p2 * x;
+    jac[1] = x * (2.0 * k1 * y + 4.0 * k2 * y * r2 + 6.0 * k3 * y * r4) + 2.0 * p1 * x + 2.0 * p2 * y;
+    jac[3] = 5.0 * k2 * y4 + 3.0 * k1 * y2 + 6.0 * k3 * y2 * r4 + 6.0 * k2 * x2 * y2 + k3 * r6 + k2 * x4 + k1 * x2 + 1.0 + 2.0 * p2 * x + 6.0 * p1 * y;
+    jac[2] = y * (2.0 * k1 * x + 4.0 * k2 * x * r2 + 6.0 * k3 * x * r4) + 2.0 * p2 * y + 2.0 * p1 * x;
+    return;
+  }
+  const double k1 = k[0], k2 = k[1], k3 = k[2], k4 = k[3], k5 = k[4], k6 = k[5], p1 = k[6], p2 = k[7];
+  const double r2_2 = r2 * r2, r2_3 = r2_2 * r2, r2_4 = r2_3 * r2, r2_5 = r2_4 * r2;
+  const double rad = 1.0 + r2 * (k1 + r2 * (k2 + r2 * (k3 + r2 * (k4 + r2 * (k5 + r2 * k6)))));
+  const double tx = 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x), ty = 2.0 * p2 * x * y + p1 * (r2 + 2.0 * y * y);
+  const double dx_dxt = 2.0 * y * p1 + 6.0 * p2 * x, dx_dyt = 2.0 * x * p1 + 2.0 * p2 * y, dy_dxt = dx_dyt, dy_dyt = 2.0 * x * p2 + 6.0 * p1 * y;
+  const double dr_dx = 2.0 * x, dr_dy = 2.0 * y;
+  const double dp_dr = k1 + 2.0 * k2 * r2 + 3.0 * k3 * r2_2 + 4.0 * k4 * r2_3 + 5.0 * k5 * r2_4 + 6.0 * k6 * r2_5;
+  double tpx = 0, tpy = 0, jtp[4] = {0, 0, 0, 0};
+  if (kind == 5) { /* thin prism */
+    const double s0 = k[8], s1 = k[9], s2 = k[10], s3 = k[11];
+    tpx = s0 * r2 + s1 * r2 * r2;
+    tpy = s2 * r2 + s3 * r2 * r2;
+    jtp[0] = s0 * 2.0 * x + s1 * 4.0 * x * r2;
+    jtp[1] = s0 * 2.0 * y + s1 * 4.0 * y * r2;
+    jtp[2] = s2 * 2.0 * x + s3 * 4.0 * x * r2;
+    jtp[3] = s2 * 2.0 * y + s3 * 4.0 * y * r2;
+    out[0] = x * rad + tx + tpx;
+    out[1] = y * rad + ty + tpy;
+    jac[0] = rad + x * dp_dr * dr_dx + dx_dxt + jtp[0];
+    jac[1] = x * dp_dr * dr_dy + dx_dyt + jtp[1];
+    jac[2] = y * dp_dr * dr_dx + dy_dxt + jtp[2];
+    jac[3] = rad + y * dp_dr * dr_dy + dy_dyt + jtp[3];
+    return;
+  }
+  out[0] = x * rad + tx;
+  out[1] = y * rad + ty;
+  jac[0] = rad + x * dp_dr * dr_dx + dx_dxt;
+  jac[1] = x * dp_dr * dr_dy + dx_dyt;
+  jac[2] = y * dp_dr * dr_dx + dy_dxt;
+  jac[3] = rad + y * dp_dr * dr_dy + dy_dyt;
+}
+void oracle_pixel_bearings_generic(int model, const double *par, const double *px, int n, double *out) {
+  static const int LAYOUT[10][4] = {/* proj, kind, nd, na */
+                                    {0, 1, 2, 1}, {1, 1, 2, 1}, {0, 3, 5, 4}, {1, 2, 4, 4}, {1, 4, 8, 4},
+                                    {1, 5, 12, 4}, {2, 1, 2, 1}, {0, 1, 2, 4}, {0, 0, 1, 4}, {3, -1, 0, 0}};
+  const int proj = LAYOUT[model][0], kind = LAYOUT[model][1], nd = LAYOUT[model][2], na = LAYOUT[model][3];
+  const double *kd = par + (proj == 2 ? 1 : 0), *ka = kd + nd;
+  for (int i = 0; i < n; i++) {
+    double xd = px[2 * i], yd = px[2 * i + 1];
+    if (na == 1) { xd = xd / ka[0]; yd = yd / ka[0]; }
+    if (na == 4) { xd = (xd - ka[2]) / ka[0]; yd = (yd - ka[3]) / (ka[1] * ka[0]); }
+    double xu = xd, yu = yd;
+    const double rd = sqrt(xd * xd + yd * yd);
+    if (kind >= 0 && !(rd < 2.220446049250313e-16)) {
+      if (kind <= 2) {
+        double r = rd;
+        for (int it = 0; it < 10; it++) {
+          const double r2 = r * r, fv = r * rad1(kind, kd, r2) - rd, dv = rad1_derivative(kind, kd, r2);
+          const double decr = dv == 0.0 ? 0.0 : fv / dv;
+          if (fabs(decr) < 1e-6) break;
+          r -= decr;
+        }
+        const double dist = rad1(kind, kd, r * r);
+        xu = xd / dist;
+        yu = yd / dist;
+      } else {
+        double cx = xd, cy = yd;
+        for (int it = 0; it < 10; it++) {
+          double o[2], j[4];
+          disto2d(kind, kd, cx, cy, o, j);
+          const double f0 = o[0] - xd, f1 = o[1] - yd;
+          const double m00 = j[0], m10 = j[1], m01 = j[2], m11 = j[3];
+          const double a00 = m00 * m00 + m10 * m10, a01 = m00 * m01 + m10 * m11, a10 = m01 * m00 + m11 * m10, a11 = m01 * m01 + m11 * m11;
+          const double invdet = 1.0 / (a00 * a11 - a10 * a01);
+          const double i00 = a11 * invdet, i01 = -a01 * invdet, i10 = -a10 * invdet, i11 = a00 * invdet;
+          const double p00 = i00 * m00 + i01 * m01, p01 = i00 * m10 + i01 * m11, p10 = i10 * m00 + i11 * m01, p11 = i10 * m10 + i11 * m11;
+          const double d0 = p00 * f0 + p01 * f1, d1 = p10 * f0 + p11 * f1;
+          if (sqrt(d0 * d0 + d1 * d1) < 1e-6) break;
+          cx -= d0;
+          cy -= d1;
+        }
+        xu = cx;
+        yu = cy;
+      }
+    }
+    double *b = out + 3 * i;
+    if (proj == 1) {
+      const double theta = sqrt(xu * xu + yu * yu);
+      const double s = theta > 1e-8 ? sin(theta) / theta : 1.0;
+      b[0] = xu * s;
+      b[1] = yu * s;
+      b[2] = cos(theta);
+    } else if (proj == 3) {
+      const double lon = xu * 2 * M_PI, lat = -yu * 2 * M_PI;
+      b[0] = cos(lat) * sin(lon);
+      b[1] = -sin(lat);
+      b[2] = cos(lat) * cos(lon);
+    } else {
+      if (proj == 2) {
+        const double t = par[0], r = sqrt(xu * xu + yu * yu);
+        double theta = 0.0;
+        for (int it = 0; it < 5; it++) {
+          const double fv = t * tan(theta) + (1.0 - t) * theta - r;
+          const double secant = 1.0 / cos(theta);
+          const double dv = (it == 0 ? 2.0 : 1.0) * (t * secant * secant - t + 1);
+          const double decr = dv == 0.0 ? 0.0 : fv / dv;
+          if (fabs(decr) < 1e-6) break;
+          theta -= decr;
+        }
+        const double s = tan(theta) / (t * tan(theta) + (1.0 - t) * theta);
+        xu = s * xu;
+        yu = s * yu;
+      }
+      const double inv = 1.0 / sqrt(xu * xu + yu * yu + 1.0);
+      b[0] = xu * inv;
+      b[1] = yu * inv;
+      b[2] = inv;
+    }
+  }
+}

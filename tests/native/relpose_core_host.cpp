@@ -47,6 +47,9 @@ int host_relative_pose_from_essential(const double* E, const double* b1, const d
 void host_pixel_bearings(int model, const double* cam, const double* px, int n, double* out) {
   for (int i = 0; i < n; i++) pixel_bearing(model, cam[0], cam[1], cam[2], px[2 * i], px[2 * i + 1], out + 3 * i);
 }
+void host_pixel_bearings_generic(int model, const double* par, const double* px, int n, double* out) {
+  for (int i = 0; i < n; i++) pixel_bearing_generic(model, par, px[2 * i], px[2 * i + 1], out + 3 * i);
+}
 void host_inliers_bearings(const double* b1, const double* b2, int n, const double* R, const double* t, double thr, uint8_t* mask) {
   for (int i = 0; i < n; i++) mask[i] = (uint8_t)inlier_bearing(b1 + 3 * i, b2 + 3 * i, R, t, thr);
 }

@@ -234,3 +234,82 @@ def test_robust_match_calibrated_end_to_end(oracle_lib):
     assert (kept & ~bad).sum() >= 0.9 * (~bad).sum()
     assert (kept & bad).sum() <= 0.1 * bad.sum() + 2
     assert len(oracle_lib.robust_match_calibrated(p1, p2, cam, cam, "fisheye", "fisheye", matches[:7])) == 0
+
+
+# ---- bearings of every camera model (Camera::Bearing = ProjectGeneric::Backward) ----------------------------------
+_BEARING_CAMERAS = {  # native order [projection][distortion][affine]
+    "perspective": [-0.1, 0.01, 0.85],
+    "fisheye": [-0.05, 0.004, 0.45],
+    "brown": [-0.12, 0.03, -0.004, 0.001, -0.0007, 0.72, 1.003, 0.004, -0.006],
+    "fisheye_opencv": [-0.03, 0.004, -0.0006, 0.0001, 0.42, 0.999, 0.002, -0.001],
+    "fisheye62": [-0.03, 0.004, -0.0006, 0.0001, 2e-05, -4e-06, 0.0004, -0.0003, 0.42, 0.999, 0.002, -0.001],
+    "fisheye624": [-0.03, 0.004, -0.0006, 0.0001, 2e-05, -4e-06, 0.0004, -0.0003, 0.0002, -0.0001, 0.0003, 5e-05, 0.42, 0.999, 0.002, -0.001],
+    "dual": [0.4, -0.05, 0.004, 0.6],
+    "radial": [-0.1, 0.01, 0.7, 0.998, -0.003, 0.002],
+    "simple_radial": [-0.08, 0.65, 1.01, 0.001, 0.002],
+}
+
+
+def _forward(model, par, X):
+    from opensfm_amd import synthetic
+
+    pose0 = np.zeros(6)
+    if model in ("perspective", "fisheye"):
+        return synthetic.project_perspective(X, pose0, np.asarray(par, float), model)
+    return synthetic.project_generic(X, pose0, np.asarray(par, float), model)
+
+
+def test_bearings_invert_the_forward_projection_of_every_model(oracle_lib):
+    """The reference checks its cameras by round trips too (opensfm/test/test_types.py); the forward projections used here are
+    the ones the mpmath golden vectors pin (tests/test_oracle_ba.py).  Tolerance = the Newton stop (decrement < 1e-6 before
+    it is applied; quadratic for the true Jacobians, linear for Disto2 / Disto24's simplified derivative)."""
+    rng = np.random.default_rng(11)
+    for model, par in _BEARING_CAMERAS.items():
+        # dual: the reference runs only 5 Newton steps on theta (the first one halved), good to 2e-8 up to 0.9 rad and 3e-5 at 1.2 rad
+        ang = rng.uniform(0, 1.2 if model.startswith("fisheye") else 0.9 if model == "dual" else 0.55, 400)
+        phi = rng.uniform(0, 2 * np.pi, 400)
+        ang[0] = 1e-9 if model != "dual" else 1e-3  # (almost) on the optical axis
+        X = np.c_[np.sin(ang) * np.cos(phi), np.sin(ang) * np.sin(phi), np.cos(ang)] * rng.uniform(0.5, 20, 400)[:, None]
+        px = _forward(model, par, X)
+        b = oracle_lib.pixel_bearings_generic(model, par, px)
+        assert np.abs(np.linalg.norm(b, axis=1) - 1).max() < 1e-12
+        err = np.abs(b - X / np.linalg.norm(X, axis=1, keepdims=True)).max()
+        assert err < 2e-6, (model, err)
+    # spherical: (lon, lat) / 2 pi
+    X = rng.normal(0, 1, (200, 3))
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    lon, lat = np.arctan2(X[:, 0], X[:, 2]), np.arctan2(-X[:, 1], np.hypot(X[:, 0], X[:, 2]))
+    b = oracle_lib.pixel_bearings_generic("spherical", [], np.c_[lon, -lat] / (2 * np.pi))
+    assert np.abs(b - X).max() < 1e-14
+
+
+def test_bearings_on_the_golden_projections(oracle_lib):
+    """pixel = residual * sd + observation of the golden reprojection cases with moderate cameras -> the bearing is the
+    direction of the camera-frame point."""
+    import json
+    import os
+
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reprojection_golden.json")))
+    used = 0
+    for c in gold:
+        model = c.get("model", "perspective")
+        if abs(c["cam"][0]) > 0.2:  # the reference's synthetic test arrays (k1 = 0.3, focal < 0 ...) are not invertible cameras
+            continue
+        px = np.array(c["residual"]) * c["sd"] + np.array(c["obs"])
+        Xc = _rodrigues(-np.array(c["pose"][:3])) @ (np.array(c["X"]) - np.array(c["pose"][3:]))
+        if Xc[2] <= 0:
+            continue
+        b = oracle_lib.pixel_bearings_generic(model, c["cam"], px[None])[0]
+        assert np.abs(b - Xc / np.linalg.norm(Xc)).max() < 2e-6, model
+        used += 1
+    assert used >= 8
+
+
+def test_generic_bearings_keep_the_bits_of_the_two_model_version(oracle_lib):
+    rng = np.random.default_rng(12)
+    px = rng.uniform(-0.6, 0.6, (300, 2))
+    px[0] = 0
+    for model in (0, 1):
+        a = oracle_lib.pixel_bearings(model, [-0.1, 0.01, 0.9], px)
+        b = oracle_lib.pixel_bearings_generic(model, [-0.1, 0.01, 0.9], px)
+        assert np.array_equal(a.view(np.uint64), b.view(np.uint64))

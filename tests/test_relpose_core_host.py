@@ -51,11 +51,12 @@ def _emulated_calls(host):
     """(pixel_bearing_many, relpose_pairs) of opensfm_amd.matching served by the host emulation instead of the C ABI."""
 
     def bearings(camera, points, ctx=None):
+        from opensfm_amd import matching
+
+        model, par = matching.camera_parameters(camera)
         px = np.ascontiguousarray(np.asarray(points, np.float64)[:, :2])
         out = np.zeros((len(px), 3))
-        cam = np.array([camera.k1, camera.k2, camera.focal])
-        host.host_pixel_bearings({"perspective": 0, "fisheye": 1}[camera.projection_type], _p(cam, C.c_double), _p(px, C.c_double), len(px),
-                                 _p(out, C.c_double))
+        host.host_pixel_bearings_generic(model, _p(par, C.c_double), _p(px, C.c_double), len(px), _p(out, C.c_double))
         return out
 
     def relpose_pairs(b1, b2, offsets, threshold, mode="match", iterations=1000, probability=0.99, use_lo=True, lo_iterations=10,
@@ -109,6 +110,18 @@ def test_bearings_inliers_and_picks_bits(host, oracle_lib):
         out = np.zeros((500, 3))
         host.host_pixel_bearings(model, _p(cam, C.c_double), _p(px, C.c_double), 500, _p(out, C.c_double))
         assert np.array_equal(out.view(np.uint64), oracle_lib.pixel_bearings(model, cam, px).view(np.uint64))
+    import test_oracle_relpose as cams
+
+    for model, par in list(cams._BEARING_CAMERAS.items()) + [("spherical", [])]:  # every projection type, bit for bit
+        ang, phi = rng.uniform(0, 0.9, 300), rng.uniform(0, 2 * np.pi, 300)
+        X = np.c_[np.sin(ang) * np.cos(phi), np.sin(ang) * np.sin(phi), np.cos(ang)]
+        px = np.ascontiguousarray(rng.uniform(-0.3, 0.3, (300, 2)) if model == "spherical" else cams._forward(model, par, X))
+        px[0] = 0.0
+        p16 = np.r_[np.asarray(par, float), np.zeros(16 - len(par))]
+        out = np.zeros((300, 3))
+        host.host_pixel_bearings_generic(oracle_lib.BEARING_MODELS[model], _p(p16, C.c_double), _p(px, C.c_double), 300, _p(out, C.c_double))
+        want = oracle_lib.pixel_bearings_generic(model, par, px)
+        assert np.array_equal(out.view(np.uint64), want.view(np.uint64)), model  # NaN at the centre of the dual model included
     b1, b2, _ = _scene(rng, 400)
     R = _rodrigues(rng.normal(0, 0.2, 3))
     t = rng.normal(0, 1, 3)
@@ -334,3 +347,22 @@ def test_gpu_pipeline_test_logic_on_the_emulation(host, oracle_lib, monkeypatch)
     monkeypatch.setattr(matching, "pixel_bearing_many", bearings)
     monkeypatch.setattr(matching, "relpose_pairs", relpose_pairs)
     gpu_tests.test_match_pairs_calibrated_pipeline(oracle_lib, None)
+
+
+def test_gpu_bearing_tests_logic_on_the_emulation(host, oracle_lib, monkeypatch):
+    """The two bearing tests of tests/test_gpu_zz_relpose.py with pixel_bearing_many served by the host emulation (this also runs
+    matching.camera_parameters: attribute names and native parameter order of every projection type)."""
+    from opensfm_amd import matching
+
+    import test_gpu_zz_relpose as gpu_tests
+
+    bearings, _ = _emulated_calls(host)
+
+    def checked(camera, points, ctx=None):
+        if camera.projection_type not in matching._BEARING_MODELS:
+            raise NotImplementedError(camera.projection_type)
+        return bearings(camera, points, ctx)
+
+    monkeypatch.setattr(matching, "pixel_bearing_many", checked)
+    gpu_tests.test_pixel_bearings(oracle_lib)
+    gpu_tests.test_pixel_bearings_every_projection_type(oracle_lib)
