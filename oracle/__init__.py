@@ -409,3 +409,41 @@ def robust_match_calibrated_bearings(b1, b2, threshold: float = 0.004, iteration
                                          _p(info, C.c_int32))
     return {"mask": mask[:n].astype(bool), "R": R.reshape(3, 3), "t": t, "model": models[:12].reshape(3, 4),
             "lo_model": models[12:].reshape(3, 4), "score": int(info[0]), "iterations": int(info[1])}
+
+
+# ------------------------------------------------------------------------------------------------
+# guided matching (oracle/guided_oracle.c) -- groundwork, no product counterpart yet
+# ------------------------------------------------------------------------------------------------
+def epipolar_mask(b1, b2, R, t, threshold: float):
+    """matching.compute_inliers_bearing_epipolar (matching.py:847-868): R = pose.get_R_cam_to_world(), t = pose.get_origin() of the
+    second camera relative to the first.  -> (mask (n1, n2) bool, angle (n1, n2))."""
+    b1 = np.ascontiguousarray(b1, np.float32).reshape(-1, 3)
+    b2 = np.ascontiguousarray(b2, np.float32).reshape(-1, 3)
+    R = np.ascontiguousarray(R, np.float64).reshape(3, 3)
+    t = np.ascontiguousarray(t, np.float64).reshape(3)
+    ang = np.zeros((len(b1), len(b2)))
+    mask = np.zeros((len(b1), len(b2)), np.uint8)
+    lib().oracle_epipolar_mask(_p(b1, C.c_float), len(b1), _p(b2, C.c_float), len(b2), _p(R, C.c_double), _p(t, C.c_double),
+                               C.c_double(threshold), _p(ang, C.c_double), _p(mask, C.c_uint8))
+    return mask.astype(bool), ang
+
+
+def match_brute_force_masked(f1, f2, mask, ratio: float = 0.8, symmetric: bool = True) -> np.ndarray:
+    """match_brute_force[_symmetric](f1, f2, config, maskij) (matching.py:723-777) -> (K, 2) sorted by (i, j)."""
+    f1 = np.ascontiguousarray(f1, np.float32)
+    f2 = np.ascontiguousarray(f2, np.float32)
+    mask = np.ascontiguousarray(mask, np.uint8)
+    assert mask.shape == (len(f1), len(f2))
+    dim = f1.shape[1]
+    if symmetric:
+        cap = max(1, min(len(f1), len(f2)))
+        out = np.empty((cap, 2), np.int32)
+        n = lib().oracle_match_brute_force_symmetric_masked(_p(f1, C.c_float), len(f1), _p(f2, C.c_float), len(f2), dim, C.c_double(ratio),
+                                                            _p(mask, C.c_uint8), _p(out, C.c_int), cap)
+        return out[:n].copy()
+    good = np.empty(max(len(f1), 1), np.int32)
+    lib().oracle_match_brute_force_masked(_p(f1, C.c_float), len(f1), _p(f2, C.c_float), len(f2), dim, C.c_double(ratio), _p(mask, C.c_uint8),
+                                          _p(good, C.c_int))
+    good = good[: len(f1)]
+    i = np.flatnonzero(good >= 0)
+    return np.stack([i, good[i]], axis=1).astype(np.int32)
