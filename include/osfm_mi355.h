@@ -293,6 +293,25 @@ int osfm_relpose_pairs(osfm_ctx *ctx, const double *b1, const double *b2, const 
                        const osfm_relpose_params *params, int mode, osfm_relpose_result *results, uint8_t *mask,
                        double *kernel_ms /* may be NULL: HIP-event time of the kernels */);
 
+/* =====================================================================================
+ * Masked / guided descriptor matching (second half of row M-a9 / SURVEY.md 8f-3).
+ * Drop-in for match_brute_force(f1, f2, config, maskij) (symmetric = 0, opensfm/matching.py:723-756) and
+ * match_brute_force_symmetric(fi, fj, config, maskij) (symmetric = 1, matching.py:759-777: the reverse direction uses
+ * the transposed mask).  The mask is EITHER explicit (mask: n1 x n2 bytes, non-zero = allowed) OR, with mask == NULL,
+ * the epipolar mask of guided matching evaluated on the fly (never materialised):
+ *   compute_inliers_bearing_epipolar(b1, b2, pose, threshold) (matching.py:847-868 ->
+ *   geometry::EpipolarAngleTwoBearingsMany, opensfm/src/geometry/src/triangulation.cc:195-219) with b1 / b2 the float32
+ *   bearings of the two images, R = pose.get_R_cam_to_world() (row-major), t = pose.get_origin() of the relative pose
+ *   (pose2.relative_to(pose1), matching.py:204-207), threshold = config guided_matching_threshold (radians).
+ * f1: n1 x dim, f2: n2 x dim float32 (integer-valued in [0, 255], dim must be 128); out_pairs: cap x 2 int32 sorted by
+ * (i, j); *out_n = number found (may exceed cap; only cap are written).
+ * STATUS round 1: first-correct kernels (one wavefront per query descriptor), numerics pinned bit for bit against the
+ * CPU oracle through a host emulation (tests/test_guided_host.py); not yet run on an MI355X.
+ * ===================================================================================== */
+int osfm_match_guided(osfm_ctx *ctx, const float *f1, int n1, const float *f2, int n2, int dim, const uint8_t *mask,
+                      const float *b1, const float *b2, const double *R, const double *t, double threshold, double ratio,
+                      int symmetric, int32_t *out_pairs, int cap, int *out_n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -107,6 +107,12 @@ SIGNATURES = {
         [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int, C.POINTER(RelposeParams), C.c_int,
          C.POINTER(RelposeResult), C.POINTER(C.c_uint8), C.POINTER(C.c_double)],
     ),
+    "osfm_match_guided": (
+        C.c_int,
+        [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int, C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_float),
+         C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_double, C.c_int, C.POINTER(C.c_int32), C.c_int,
+         C.POINTER(C.c_int)],
+    ),
     "osfm_ransac_fundamental": (
         C.c_int,
         [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.c_double, C.c_double, C.c_int,

@@ -39,6 +39,7 @@ DEFAULT_CONFIG: Dict[str, Any] = {
     "robust_matching_threshold": 0.004,
     "robust_matching_min_match": 20,
     "robust_matching_calib_threshold": 0.004,
+    "guided_matching_threshold": 0.006,
     "five_point_refine_match_iterations": 10,
 }
 
@@ -78,12 +79,43 @@ def _match_leaf(f1: np.ndarray, f2: np.ndarray, ratio: float, symmetric: bool, c
     return out[: n.value]
 
 
+def _match_guided_leaf(f1: np.ndarray, f2: np.ndarray, ratio: float, symmetric: bool, maskij: Optional[np.ndarray] = None,
+                       bearings1: Optional[np.ndarray] = None, bearings2: Optional[np.ndarray] = None, R: Optional[np.ndarray] = None,
+                       t: Optional[np.ndarray] = None, threshold: float = 0.0, ctx=None) -> np.ndarray:
+    """``osfm_match_guided``: explicit ``maskij`` (n1 x n2) or the epipolar mask of (bearings, R, t, threshold) evaluated on the fly."""
+    assert f1.dtype.type == f2.dtype.type
+    if f1.dtype.type == np.uint8:
+        raise NotImplementedError("uint8 descriptors take the reference's BruteForce-Hamming branch")
+    ctx = ctx or default_context()
+    a = np.ascontiguousarray(f1, np.float32).reshape(-1, 128)
+    b = np.ascontiguousarray(f2, np.float32).reshape(-1, 128)
+    cap = max(1, len(a))
+    out = np.empty((cap, 2), np.int32)
+    n = C.c_int(0)
+    null_f, null_d = C.POINTER(C.c_float)(), C.POINTER(C.c_double)()
+    if maskij is not None:
+        m = np.ascontiguousarray(np.asarray(maskij) != 0, np.uint8)
+        assert m.shape == (len(a), len(b)), "maskij must be len(f1) x len(f2)"
+        args = (_fptr(m, C.c_uint8), null_f, null_f, null_d, null_d, 0.0)
+    else:
+        b1 = np.ascontiguousarray(bearings1, np.float32).reshape(-1, 3)  # matching.py:859-860: bearings are cast to float32
+        b2 = np.ascontiguousarray(bearings2, np.float32).reshape(-1, 3)
+        Rm = np.ascontiguousarray(R, np.float64).reshape(3, 3)
+        tv = np.ascontiguousarray(t, np.float64).reshape(3)
+        assert len(b1) == len(a) and len(b2) == len(b)
+        args = (C.POINTER(C.c_uint8)(), _fptr(b1, C.c_float), _fptr(b2, C.c_float), _fptr(Rm, C.c_double), _fptr(tv, C.c_double), float(threshold))
+    check(_lib.load().osfm_match_guided(ctx.handle, _fptr(a, C.c_float), len(a), _fptr(b, C.c_float), len(b), 128, *args, float(ratio),
+                                        int(symmetric), _fptr(out, C.c_int32), cap, C.byref(n)), "osfm_match_guided")
+    return out[: n.value]
+
+
 def match_brute_force(f1: np.ndarray, f2: np.ndarray, config: Dict[str, Any], maskij: Optional[np.ndarray] = None,
                       ) -> List[Tuple[int, int]]:
     """Brute force matching and Lowe's ratio filtering (``matching.py:723-756``)."""
     if maskij is not None:
-        raise NotImplementedError("guided matching mask (maskij) is not implemented on the GPU path yet")
-    m = _match_leaf(f1, f2, _cfg(config, "lowes_ratio"), False)
+        m = _match_guided_leaf(f1, f2, _cfg(config, "lowes_ratio"), False, maskij)
+    else:
+        m = _match_leaf(f1, f2, _cfg(config, "lowes_ratio"), False)
     return [(int(a), int(b)) for a, b in m]
 
 
@@ -91,9 +123,19 @@ def match_brute_force_symmetric(fi: np.ndarray, fj: np.ndarray, config: Dict[str
                                 maskij: Optional[np.ndarray] = None) -> List[Tuple[int, int]]:
     """Match with brute force in both directions and keep consistent matches (``matching.py:759-777``)."""
     if maskij is not None:
-        raise NotImplementedError("guided matching mask (maskij) is not implemented on the GPU path yet")
-    m = _match_leaf(fi, fj, _cfg(config, "lowes_ratio"), True)
+        m = _match_guided_leaf(fi, fj, _cfg(config, "lowes_ratio"), True, maskij)
+    else:
+        m = _match_leaf(fi, fj, _cfg(config, "lowes_ratio"), True)
     return [(int(a), int(b)) for a, b in m]
+
+
+def match_guided(d1: np.ndarray, d2: np.ndarray, bearings1: np.ndarray, bearings2: np.ndarray, relative_pose, config: Dict[str, Any],
+                 ctx=None) -> np.ndarray:
+    """The matching step of ``_match_descriptors_guided_impl`` (``matching.py:313-319``): ``compute_inliers_bearing_epipolar`` fused
+    into ``match_brute_force_symmetric`` -- the n1 x n2 mask is evaluated inside the kernel, never stored.
+    ``relative_pose``: ``pose2.relative_to(pose1)`` (anything with ``get_R_cam_to_world()`` and ``get_origin()``).  -> (K, 2) int32."""
+    return _match_guided_leaf(d1, d2, _cfg(config, "lowes_ratio"), True, None, bearings1, bearings2, relative_pose.get_R_cam_to_world(),
+                              relative_pose.get_origin(), _cfg(config, "guided_matching_threshold"), ctx)
 
 
 def find_fundamental_ransac(p1: np.ndarray, p2: np.ndarray, threshold: float, confidence: float = 0.9999,
@@ -385,12 +427,11 @@ def match_images_with_pairs(data, config_override: Dict[str, Any], exifs: Dict[s
     ``data`` must offer the ``DataSetBase`` methods the reference uses on this path:
     ``config``, ``load_camera_models()``, ``load_features(image)`` (``.points``, ``.descriptors``) and
     optionally ``load_features_mask(image, points)`` (``feature_loading.py:61-71``).
-    Only the configuration the GPU path implements is accepted: ``matcher_type: BRUTEFORCE``, no guided matching;
+    Only the configuration the GPU path implements is accepted: ``matcher_type: BRUTEFORCE``; with ``poses`` the descriptor
+    stage is the guided (epipolar-masked) matcher, pair by pair;
     pairs of undistorted perspective/brown cameras take the fused matcher + fundamental-matrix RANSAC launch, every other
     pair the calibrated route (``match_pairs_calibrated``).
     """
-    if poses:
-        raise NotImplementedError("guided matching is not implemented on the GPU path")
     config = dict(data.config)
     config.update(config_override)
     if str(config.get("matcher_type", "BRUTEFORCE")).upper() != "BRUTEFORCE":
@@ -419,11 +460,26 @@ def match_images_with_pairs(data, config_override: Dict[str, Any], exifs: Dict[s
         ipairs = np.asarray([(index[a], index[b]) for a, b in pairs], np.int32).reshape(-1, 2)
         pin = np.array([_is_pinhole(cams[a]) and _is_pinhole(cams[b]) for a, b in ipairs], bool)
         per_pair: List[np.ndarray] = [np.zeros((0, 2), np.int32)] * len(ipairs)
-        if pin.any():
+        if poses:  # guided matching (matching.py:204-207,260-337,576-634): one pair at a time, first-correct route
+            bearings = [pixel_bearing_many(cams[k], np.asarray(pts[k], np.float64)[:, :2], store.ctx) if len(pts[k]) else np.zeros((0, 3))
+                        for k in range(len(images))]
+            min_match = int(_cfg(config, "robust_matching_min_match"))
+            for p, ((im1, im2), (a, b)) in enumerate(zip(pairs, ipairs)):
+                if len(pts[a]) < 2 or len(pts[b]) < 2:
+                    continue
+                rel = poses[im2].relative_to(poses[im1])
+                m = match_guided(descs[a], descs[b], bearings[a], bearings[b], rel, config, store.ctx)
+                if len(m) < min_match:
+                    continue
+                rm = np.asarray(robust_match(pts[a], pts[b], cams[a], cams[b], m, config))
+                if len(rm) >= min_match and len(rm) > 0:
+                    per_pair[p] = rm.astype(np.int32)
+            pin = np.zeros(len(ipairs), bool)
+        elif pin.any():
             counts, matches = match_pairs(store, ipairs[pin], config, robust=True)
             for p, m in zip(np.flatnonzero(pin), split_matches(counts, matches)):
                 per_pair[p] = m
-        if (~pin).any():
+        if not poses and (~pin).any():
             counts, matches = match_pairs_calibrated(store, ipairs[~pin], cams, pts, config)
             for p, m in zip(np.flatnonzero(~pin), split_matches(counts, matches)):
                 per_pair[p] = m

@@ -180,3 +180,97 @@ def test_match_pairs_calibrated_pipeline(oracle_lib, gpu_ctx):
         assert np.array_equal(g, want), (a, b)
         survivors += len(want) > 0
     assert survivors >= 7  # neighbouring cameras of the street share points
+
+
+# ---- guided (epipolar-masked) matching: osfm_match_guided ------------------------------------------------------------
+class _Pose:
+    """the three methods of pygeometry.Pose the guided route uses (world-to-camera rotation R, origin o)"""
+
+    def __init__(self, R, o):
+        self.R, self.o = np.asarray(R, float), np.asarray(o, float)
+
+    def relative_to(self, base):  # pose.h:133-144: T_this_w * T_w_base
+        return _Pose(self.R @ base.R.T, base.R @ (self.o - base.o))
+
+    def get_R_cam_to_world(self):
+        return self.R.T.copy()
+
+    def get_origin(self):
+        return self.o.copy()
+
+
+def test_masked_and_guided_leaf(oracle_lib):
+    """match_brute_force[_symmetric](f1, f2, config, maskij) with explicit masks, and the fused epipolar mask of guided matching,
+    against the oracle (same cases as the host emulation, tests/test_guided_host.py)."""
+    import test_guided_host as gh
+    from opensfm_amd import matching, synthetic
+
+    rng = np.random.default_rng(0)
+    sc = synthetic.make_matching_scene(2, 300, seed=9, ragged=True)
+    f1 = sc.desc[sc.offsets[0]: sc.offsets[1]].astype(np.float32)
+    f2 = sc.desc[sc.offsets[1]: sc.offsets[2]].astype(np.float32)
+    for density in (1.0, 0.5, 0.05, 0.004, 0.0):
+        mask = rng.random((len(f1), len(f2))) < density
+        for ratio in (0.8, 0.999):
+            cfg = {"lowes_ratio": ratio}
+            want = oracle_lib.match_brute_force_masked(f1, f2, mask, ratio, symmetric=True)
+            assert matching.match_brute_force_symmetric(f1, f2, cfg, mask) == [tuple(map(int, m)) for m in want]
+            want = oracle_lib.match_brute_force_masked(f1, f2, mask, ratio, symmetric=False)
+            assert matching.match_brute_force(f1, f2, cfg, mask) == [tuple(map(int, m)) for m in want]
+    for n, thr in ((60, 0.005), (150, 0.02), (97, 0.3), (1000, 0.006)):
+        d1, d2, b1, b2, R, o, perm = gh.guided_scene(rng, n)
+        mask, _ = oracle_lib.epipolar_mask(b1, b2, R, o, thr)
+        want = oracle_lib.match_brute_force_masked(d1, d2, mask, 0.8, symmetric=True)
+        rel = _Pose(R.T, o)  # get_R_cam_to_world() = R, get_origin() = o
+        got = matching.match_guided(d1, d2, b1, b2, rel, {"lowes_ratio": 0.8, "guided_matching_threshold": thr})
+        assert np.array_equal(got, want), (n, thr)
+    assert (perm[got[:, 1]] == got[:, 0]).mean() > 0.95 and len(got) > 1200
+
+
+def test_guided_match_images_with_pairs(oracle_lib):
+    """match_images_with_pairs(..., poses): guided descriptor stage -> gate -> robust_match -> gate -> unfilter
+    (matching.py:204-207, 563-634) for three views of a repetitive scene with slightly distorted perspective cameras."""
+    import test_guided_host as gh
+    from opensfm_amd import matching
+
+    rng = np.random.default_rng(4)
+    cam = SimpleNamespace(projection_type="perspective", k1=1e-3, k2=0.0, focal=0.85)
+    n = 400
+    X = np.c_[rng.uniform(-2, 2, n), rng.uniform(-2, 2, n), rng.uniform(4, 9, n)]
+    base = rng.integers(0, 255, (n // 2, 128))
+    images, poses, feats, masks, order = ["a", "b", "c"], {}, {}, {}, {}
+    for im in images:
+        R = gh._rodrigues(rng.normal(0, 0.1, 3))
+        o = rng.normal(0, 0.5, 3)
+        poses[im] = _Pose(R, o)
+        Y = (X - o) @ R.T
+        u = Y[:, :2] / Y[:, 2:3]
+        r2 = (u**2).sum(1)
+        px = cam.focal * u * (1 + r2 * (cam.k1 + cam.k2 * r2))[:, None] + rng.normal(0, 2e-4, (n, 2))
+        perm = rng.permutation(n)
+        order[im] = perm
+        desc = np.clip(np.concatenate([base, base]) + rng.integers(-3, 4, (n, 128)), 0, 255).astype(np.float32)
+        feats[im] = SimpleNamespace(points=np.c_[px[perm], np.ones((n, 2))], descriptors=desc[perm])
+        masks[im] = rng.random(n) > 0.1
+    data = SimpleNamespace(config={"matcher_type": "BRUTEFORCE", "robust_matching_min_match": 20, "robust_matching_calib_threshold": 0.004,
+                                   "five_point_refine_match_iterations": 10, "lowes_ratio": 0.8, "symmetric_matching": True,
+                                   "guided_matching_threshold": 0.006},
+                           load_camera_models=lambda: {"cam": cam}, load_features=lambda im: feats[im],
+                           load_features_mask=lambda im, pts: masks[im])
+    exifs = {im: {"camera": "cam"} for im in images}
+    pairs = [("a", "b"), ("a", "c"), ("b", "c")]
+    got = matching.match_images_with_pairs(data, {}, exifs, pairs, poses)
+    par = [cam.k1, cam.k2, cam.focal]
+    for (ia, ib) in pairs:
+        pa, pb = feats[ia].points[masks[ia]], feats[ib].points[masks[ib]]
+        b1 = oracle_lib.pixel_bearings(0, par, pa[:, :2])
+        b2 = oracle_lib.pixel_bearings(0, par, pb[:, :2])
+        rel = poses[ib].relative_to(poses[ia])
+        emask, _ = oracle_lib.epipolar_mask(b1, b2, rel.get_R_cam_to_world(), rel.get_origin(), 0.006)
+        m = oracle_lib.match_brute_force_masked(feats[ia].descriptors[masks[ia]], feats[ib].descriptors[masks[ib]], emask, 0.8, symmetric=True)
+        assert len(m) >= 100  # the plain matcher finds (almost) nothing here: every descriptor exists twice
+        r = oracle_lib.robust_match_calibrated_bearings(b1[m[:, 0]], b2[m[:, 1]], 0.004, 1000, 0.99, True, 10, 10)
+        assert r["mask"].sum() >= 20
+        want = matching.unfilter_matches(m[r["mask"]], masks[ia], masks[ib])
+        assert np.array_equal(got[ia, ib], np.asarray(want))
+        assert (order[ia][got[ia, ib][:, 0]] == order[ib][got[ia, ib][:, 1]]).mean() > 0.97

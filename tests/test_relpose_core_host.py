@@ -15,8 +15,7 @@ def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t))
 
 
-@pytest.fixture(scope="module")
-def host():
+def build_host():
     src = os.path.join(HERE, "native", "relpose_core_host.cpp")
     out_dir = os.path.join(HERE, "native", "_build")
     os.makedirs(out_dir, exist_ok=True)
@@ -25,6 +24,11 @@ def host():
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-o", so, src])
     return C.CDLL(so)
+
+
+@pytest.fixture(scope="module")
+def host():
+    return build_host()
 
 
 def _rodrigues(r):
