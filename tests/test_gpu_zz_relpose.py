@@ -57,33 +57,6 @@ def test_pixel_bearings(oracle_lib):
         matching.pixel_bearing_many(SimpleNamespace(projection_type="pushbroom", k1=0, k2=0, focal=1), px)
 
 
-def test_pixel_bearings_every_projection_type(oracle_lib):
-    """ProjectGeneric::Backward of the nine 2-D models and the spherical one.  Affine / distortion stages are + - * / sqrt
-    only; the projection stage goes through the device sin / cos / tan, hence 1e-12."""
-    import test_oracle_relpose as cams
-    from opensfm_amd import matching
-
-    rng = np.random.default_rng(5)
-    names = {"brown": ("k1", "k2", "k3", "p1", "p2", "focal", "aspect_ratio", "cx", "cy"),
-             "fisheye_opencv": ("k1", "k2", "k3", "k4", "focal", "aspect_ratio", "cx", "cy"),
-             "fisheye62": ("k1", "k2", "k3", "k4", "k5", "k6", "p1", "p2", "focal", "aspect_ratio", "cx", "cy"),
-             "fisheye624": ("k1", "k2", "k3", "k4", "k5", "k6", "p1", "p2", "s0", "s1", "s2", "s3", "focal", "aspect_ratio", "cx", "cy"),
-             "dual": ("transition", "k1", "k2", "focal"), "radial": ("k1", "k2", "focal", "aspect_ratio", "cx", "cy"),
-             "simple_radial": ("k1", "focal", "aspect_ratio", "cx", "cy"), "perspective": ("k1", "k2", "focal"),
-             "fisheye": ("k1", "k2", "focal"), "spherical": ()}
-    for model, par in list(cams._BEARING_CAMERAS.items()) + [("spherical", [])]:
-        attrs = dict(zip(names[model], par))
-        cam = SimpleNamespace(projection_type=model, principal_point=[attrs.pop("cx", 0.0), attrs.pop("cy", 0.0)], **attrs)
-        ang, phi = rng.uniform(0, 0.9, 2000), rng.uniform(0, 2 * np.pi, 2000)
-        X = np.c_[np.sin(ang) * np.cos(phi), np.sin(ang) * np.sin(phi), np.cos(ang)]
-        px = rng.uniform(-0.3, 0.3, (2000, 2)) if model == "spherical" else cams._forward(model, par, X)
-        got = matching.pixel_bearing_many(cam, px)
-        want = oracle_lib.pixel_bearings_generic(model, par, px)
-        assert np.abs(got - want).max() < 1e-12, model
-        if model != "spherical":
-            assert np.abs(got - X).max() < 2e-6, model
-
-
 def test_ransac_relative_pose_batch_bits(oracle_lib):
     from opensfm_amd import matching
 
@@ -182,7 +155,36 @@ def test_match_pairs_calibrated_pipeline(oracle_lib, gpu_ctx):
     assert survivors >= 7  # neighbouring cameras of the street share points
 
 
+def test_pixel_bearings_every_projection_type(oracle_lib):
+    """ProjectGeneric::Backward of the nine 2-D models and the spherical one.  Affine / distortion stages are + - * / sqrt
+    only; the projection stage goes through the device sin / cos / tan, hence 1e-12."""
+    import test_oracle_relpose as cams
+    from opensfm_amd import matching
+
+    rng = np.random.default_rng(5)
+    names = {"brown": ("k1", "k2", "k3", "p1", "p2", "focal", "aspect_ratio", "cx", "cy"),
+             "fisheye_opencv": ("k1", "k2", "k3", "k4", "focal", "aspect_ratio", "cx", "cy"),
+             "fisheye62": ("k1", "k2", "k3", "k4", "k5", "k6", "p1", "p2", "focal", "aspect_ratio", "cx", "cy"),
+             "fisheye624": ("k1", "k2", "k3", "k4", "k5", "k6", "p1", "p2", "s0", "s1", "s2", "s3", "focal", "aspect_ratio", "cx", "cy"),
+             "dual": ("transition", "k1", "k2", "focal"), "radial": ("k1", "k2", "focal", "aspect_ratio", "cx", "cy"),
+             "simple_radial": ("k1", "focal", "aspect_ratio", "cx", "cy"), "perspective": ("k1", "k2", "focal"),
+             "fisheye": ("k1", "k2", "focal"), "spherical": ()}
+    for model, par in list(cams._BEARING_CAMERAS.items()) + [("spherical", [])]:
+        attrs = dict(zip(names[model], par))
+        cam = SimpleNamespace(projection_type=model, principal_point=[attrs.pop("cx", 0.0), attrs.pop("cy", 0.0)], **attrs)
+        ang, phi = rng.uniform(0, 0.9, 2000), rng.uniform(0, 2 * np.pi, 2000)
+        X = np.c_[np.sin(ang) * np.cos(phi), np.sin(ang) * np.sin(phi), np.cos(ang)]
+        px = rng.uniform(-0.3, 0.3, (2000, 2)) if model == "spherical" else cams._forward(model, par, X)
+        got = matching.pixel_bearing_many(cam, px)
+        want = oracle_lib.pixel_bearings_generic(model, par, px)
+        assert np.abs(got - want).max() < 1e-12, model
+        if model != "spherical":
+            assert np.abs(got - X).max() < 2e-6, model
+
+
 # ---- guided (epipolar-masked) matching: osfm_match_guided ------------------------------------------------------------
+
+
 class _Pose:
     """the three methods of pygeometry.Pose the guided route uses (world-to-camera rotation R, origin o)"""
 
