@@ -259,7 +259,8 @@ void osfm_tracks_destroy(osfm_tracks *t);
  *   ProjectGeneric::Backward, camera_instances.h:154-160) for every OSFM_CAMERA_* model; cam = the model's
  *   parameters in the native order listed at the OSFM_CAMERA_* definitions ([k1, k2, focal] for PERSPECTIVE /
  *   FISHEYE, may be NULL for SPHERICAL); px: n x 2 normalised image coordinates, bearings: n x 3.
- *   (PERSPECTIVE / FISHEYE ran on the MI355X in round 1; the other models so far only in the host emulation.)
+ *   (MI355X vs oracle, profiles/r01_guided_bringup.txt: bit-identical for the perspective-projection models, <= 2.3e-16
+ *   for those that go through the device sin / cos / tan.)
  * osfm_relpose_pairs   a batch of pairs; pair p owns the correspondences offsets[p] .. offsets[p+1]-1 of the
  *   concatenated bearing arrays b1, b2 (total x 3, doubles, second-image bearing y and first-image bearing x
  *   with y ~ R x + t for the models below).
@@ -306,7 +307,8 @@ int osfm_relpose_pairs(osfm_ctx *ctx, const double *b1, const double *b2, const 
  * f1: n1 x dim, f2: n2 x dim float32 (integer-valued in [0, 255], dim must be 128); out_pairs: cap x 2 int32 sorted by
  * (i, j); *out_n = number found (may exceed cap; only cap are written).
  * STATUS round 1: first-correct kernels (one wavefront per query descriptor), numerics pinned bit for bit against the
- * CPU oracle through a host emulation (tests/test_guided_host.py); not yet run on an MI355X.
+ * CPU oracle through a host emulation (tests/test_guided_host.py); first MI355X run in the last GPU call of the round
+ * (profiles/r01_guided_bringup.txt): explicit and epipolar masks, both directions, identical to the oracle.
  * ===================================================================================== */
 int osfm_match_guided(osfm_ctx *ctx, const float *f1, int n1, const float *f2, int n2, int dim, const uint8_t *mask,
                       const float *b1, const float *b2, const double *R, const double *t, double threshold, double ratio,

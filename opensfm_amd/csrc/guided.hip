@@ -4,7 +4,8 @@
 // _match_descriptors_guided_impl (matching.py:260-337, 847-868; geometry/src/triangulation.cc:195-219).
 // First-correct version: one wavefront per query descriptor (guided_wave.h); the mask is either an explicit n1 x n2 byte
 // array or evaluated on the fly from per-feature epipolar vectors (never materialised).
-// STATUS: numerics pinned bit for bit by the host emulation (tests/test_guided_host.py); not yet run on an MI355X.
+// STATUS: numerics pinned bit for bit by the host emulation (tests/test_guided_host.py); first MI355X run at the end of round 1
+// (profiles/r01_guided_bringup.txt): identical to the oracle; 2000 x 2000 guided pair in 0.7 ms including the copies.
 #include <math.h>
 
 #include <vector>
