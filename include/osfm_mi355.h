@@ -271,8 +271,9 @@ void osfm_tracks_destroy(osfm_tracks *t);
  *     (opensfm/matching.py:886-903): RANSAC, three rounds of compute_inliers_bearings (4, 2, 1 x threshold)
  *     + relative_pose_refinement, final compute_inliers_bearings; mask = the inliers the reference keeps
  *     (all zero where it returns an empty array), R / t = pose of the second camera in the first.
- *   The sampler is std::mt19937(42) with libstdc++'s classic uniform_int_distribution (see oracle/relpose_oracle.c
- *   on why parity with a reference BINARY is toolchain dependent on this branch).
+ *   The sampler is std::mt19937(42) with std::uniform_int_distribution as libstdc++ >= 11 implements it (Lemire's
+ *   multiply-shift); ties between scores keep the newcomer (std::max).  Both are pinned against the reference's own
+ *   robust_estimator.h / random_sampler.h compiled on the build box (oracle/_ref).
  * ===================================================================================== */
 enum { OSFM_RELPOSE_RANSAC = 0, OSFM_RELPOSE_MATCH = 1 };
 typedef struct osfm_relpose_params {

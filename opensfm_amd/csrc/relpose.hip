@@ -14,6 +14,7 @@
 #include <math.h>
 
 #include <algorithm>
+#include <vector>
 
 #include "osfm_internal.h"
 #include "relpose_wave.h"
@@ -71,14 +72,16 @@ static_assert(sizeof(PairOut) == sizeof(osfm_relpose_result), "PairOut must mirr
 __global__ __launch_bounds__(kWave) void relpose_pairs_kernel(const double *__restrict__ b1, const double *__restrict__ b2,
                                                               const int64_t *__restrict__ offsets, int pair0, int n_pairs,
                                                               RansacParams prm, int refine_iterations, int mode,
-                                                              double *models_ws, int *inl_ws, int *sub_ws, uint8_t *mask, PairOut *out) {
+                                                              const double *__restrict__ stop_bound, double *models_ws, int *inl_ws,
+                                                              int *sub_ws, uint8_t *mask, PairOut *out) {
   __shared__ WaveShared sh;
   const int p = pair0 + (int)blockIdx.x;
   if (p >= pair0 + n_pairs) return;
   GpuWave w{(int)threadIdx.x};
   const int64_t o = offsets[p];
   const int n = (int)(offsets[p + 1] - o);
-  PairWork P{b1 + 3 * o, b2 + 3 * o, n, models_ws + (size_t)blockIdx.x * kWave * kMaxModels * 12, inl_ws + o, sub_ws + o};
+  PairWork P{b1 + 3 * o, b2 + 3 * o, n, models_ws + (size_t)blockIdx.x * kWave * kMaxModels * 12, inl_ws + o, sub_ws + o,
+             stop_bound + o + p};  // pair p's table has n + 1 entries: tables are laid out back to back
   for (int i = w.lane; i < n; i += kWave) mask[o + i] = 0;
   PairOut r;
   for (int i = 0; i < 9; i++) r.R[i] = 0.0;
@@ -193,7 +196,16 @@ extern "C" int osfm_relpose_pairs(osfm_ctx *ctx, const double *b1, const double 
   OSFM_HIP(hipSetDevice(ctx->device));
   constexpr int kChunk = 8192;  // pairs per launch: bounds the model workspace (60 KiB per pair)
   const int chunk = std::min(n_pairs, kChunk);
-  DevBuf d_b1, d_b2, d_off, d_models, d_inl, d_sub, d_mask, d_out;
+  DevBuf d_b1, d_b2, d_off, d_models, d_inl, d_sub, d_mask, d_out, d_stop;
+  // ShouldStop's bound for every possible best inlier count of every pair, with the host libm (see relpose_core.h)
+  std::vector<double> stop((size_t)total + (size_t)n_pairs);
+  for (int p = 0; p < n_pairs; p++) {
+    const int n = (int)(offsets[p + 1] - offsets[p]);
+    double *tab = stop.data() + offsets[p] + p;
+    for (int c = 0; c <= n; c++) tab[c] = max_iterations_for(c, n > 0 ? n : 1, prm->probability);
+  }
+  OSFM_HIP(d_stop.alloc(stop.size() * 8));
+  OSFM_HIP(hipMemcpyAsync(d_stop.p, stop.data(), stop.size() * 8, hipMemcpyHostToDevice, ctx->stream));
   OSFM_HIP(d_b1.alloc((size_t)total * 24));
   OSFM_HIP(d_b2.alloc((size_t)total * 24));
   OSFM_HIP(d_off.alloc((size_t)(n_pairs + 1) * 8));
@@ -212,7 +224,7 @@ extern "C" int osfm_relpose_pairs(osfm_ctx *ctx, const double *b1, const double 
   for (int p0 = 0; p0 < n_pairs; p0 += chunk) {
     const int np = std::min(chunk, n_pairs - p0);
     hipLaunchKernelGGL(relpose_pairs_kernel, dim3(np), dim3(kWave), 0, ctx->stream, d_b1.as<double>(), d_b2.as<double>(),
-                       d_off.as<int64_t>(), p0, np, rp, prm->refine_iterations, mode, d_models.as<double>(), d_inl.as<int>(),
+                       d_off.as<int64_t>(), p0, np, rp, prm->refine_iterations, mode, d_stop.as<double>(), d_models.as<double>(), d_inl.as<int>(),
                        d_sub.as<int>(), d_mask.as<uint8_t>(), d_out.as<PairOut>());
     OSFM_HIP(hipGetLastError());
   }

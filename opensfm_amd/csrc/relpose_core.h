@@ -549,8 +549,8 @@ OSFM_HD int relative_pose_from_essential(const double* E, const double* b1, cons
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Sampler: std::mt19937(42) + classic libstdc++ uniform_int_distribution (robust/random_sampler.h); the state
-// lives wherever the caller puts it (LDS in the kernel).
+// Sampler: std::mt19937(42) + libstdc++'s uniform_int_distribution (robust/random_sampler.h); the state lives wherever the caller
+// puts it (LDS in the kernel).
 // ---------------------------------------------------------------------------------------------------------------
 struct Mt19937 {
   uint32_t* mt;  // 624 words
@@ -576,13 +576,20 @@ OSFM_HD uint32_t mt_next(Mt19937& g) {
   y ^= y >> 18;
   return y;
 }
+// std::uniform_int_distribution<unsigned long>(0, range_max) on a 32-bit generator as libstdc++ >= 11 compiles it: Lemire's
+// multiply-shift with rejection (the oracle pins this against the reference's random_sampler.h compiled on the build box)
 OSFM_HD uint32_t mt_uniform(Mt19937& g, uint32_t range_max) {  // [0, range_max]
-  const uint64_t urange = (uint64_t)range_max + 1;
-  const uint64_t scaling = 4294967296ull / urange, past = urange * scaling;
-  uint32_t r;
-  do r = mt_next(g);
-  while ((uint64_t)r >= past);
-  return (uint32_t)(r / scaling);
+  const uint32_t range = range_max + 1u;
+  uint64_t product = (uint64_t)mt_next(g) * (uint64_t)range;
+  uint32_t low = (uint32_t)product;
+  if (low < range) {
+    const uint32_t threshold = (0u - range) % range;
+    while (low < threshold) {
+      product = (uint64_t)mt_next(g) * (uint64_t)range;
+      low = (uint32_t)product;
+    }
+  }
+  return (uint32_t)(product >> 32);
 }
 OSFM_HD void draw_sample(Mt19937& g, int size, int n, int* idx) {  // distinct indices (n >= size is the caller's duty)
   for (int i = 0; i < size; i++) {
@@ -680,10 +687,12 @@ OSFM_HD double relpose_error(const double* RT, const double* x0, const double* y
   const double nX = sqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2]), nY = sqrt(Y[0] * Y[0] + Y[1] * Y[1] + Y[2] * Y[2]);
   return 1.0 - 0.5 * ((X[0] * x[0] + X[1] * x[1] + X[2] * x[2]) / nX + (Y[0] * y[0] + Y[1] * y[1] + Y[2] * y[2]) / nY);
 }
-// ShouldStop (robust/robust_estimator.h:20-35) for MINIMAL_SAMPLES = 5
-OSFM_HD double max_iterations_for(int best_n, int n, double probability) {
+// ShouldStop (robust/robust_estimator.h:20-35) for MINIMAL_SAMPLES = 5: the bound depends only on (best inlier count, n,
+// probability) and goes through std::pow / std::log, so the HOST tabulates it with its libm for every possible count (n + 1
+// doubles per pair) and the kernel only looks it up -- the device math library cannot move a stopping decision.
+inline double max_iterations_for(int best_n, int n, double probability) {  // host only
   const double ratio = (double)best_n / (double)n;
-  double p1 = 1.0 - ratio * ratio * ratio * ratio * ratio;
+  double p1 = 1.0 - pow(ratio, 5.0);
   if (p1 > 1.0 - kEps) p1 = 1.0 - kEps;
   return log(1.0 - probability) / log(p1);
 }

@@ -33,6 +33,7 @@ struct RansacParams {
   int use_lo;              // ::use_local_optimization
   int lo_iterations;       // ::local_optimization_iterations
 };
+// (probability only enters through PairWork::stop_bound, tabulated on the host)
 
 // per-pair scratch that every lane may read and write (LDS on the GPU)
 struct WaveShared {
@@ -56,6 +57,7 @@ struct PairWork {
   double* models;  // kWave * kMaxModels * 12 doubles (global workspace)
   int* inliers;    // n ints: inlier list of the best score
   int* subset;     // n ints: inlier list of the refinement stages
+  const double* stop_bound;  // n + 1 doubles: max_iterations_for(best inlier count) of ShouldStop, tabulated by the host
 };
 
 struct RansacResult {
@@ -75,12 +77,17 @@ OSFM_HD void draw_sample_shared(WaveShared& s, int size, int n, int* idx) {
   for (int i = 0; i < size; i++) {
     int dup;
     do {
-      const uint64_t urange = (uint64_t)(uint32_t)(n - 1) + 1;
-      const uint64_t scaling = 4294967296ull / urange, past = urange * scaling;
-      uint32_t r;
-      do r = mt_next_counted(s);
-      while ((uint64_t)r >= past);
-      idx[i] = (int)(uint32_t)(r / scaling);
+      const uint32_t range = (uint32_t)n;  // Lemire's multiply-shift, as mt_uniform()
+      uint64_t product = (uint64_t)mt_next_counted(s) * (uint64_t)range;
+      uint32_t low = (uint32_t)product;
+      if (low < range) {
+        const uint32_t threshold = (0u - range) % range;
+        while (low < threshold) {
+          product = (uint64_t)mt_next_counted(s) * (uint64_t)range;
+          low = (uint32_t)product;
+        }
+      }
+      idx[i] = (int)(uint32_t)(product >> 32);
       dup = 0;
       for (int j = 0; j < i; j++) dup |= idx[j] == idx[i];
     } while (dup);
@@ -102,8 +109,6 @@ OSFM_HD void ransac_relative_pose_wave(W& w, WaveShared& s, const PairWork& P, c
     s.calls = 0;
   });
   int best_score = 0, best_n = 0, it = 0, stop = 0;
-  double max_it = 0.0;  // cached ShouldStop bound for best_n
-  int max_it_for = -1;
   while (it < prm.iterations && !stop) {
     const int B = (prm.iterations - it) < W::width ? (prm.iterations - it) : W::width;
     w.single([&]() {  // snapshot + speculative draws
@@ -142,7 +147,7 @@ OSFM_HD void ransac_relative_pose_wave(W& w, WaveShared& s, const PairWork& P, c
           for (int i = 0; i < 12; i++) RT[i] = src[i];
         }
         const int cnt = w.count_if(n, [&](int i) { return fabs(relpose_error(RT, P.b1 + 3 * i, P.b2 + 3 * i)) < thr; });
-        if (cnt > best_score) {
+        if (cnt >= best_score) {  // std::max(score, best_score) returns its first argument on a tie: the newcomer replaces the best
           best_score = cnt;
           best_n = cnt;
           w.compact(n, [&](int i) { return fabs(relpose_error(RT, P.b1 + 3 * i, P.b2 + 3 * i)) < thr; }, P.inliers);
@@ -182,7 +187,7 @@ OSFM_HD void ransac_relative_pose_wave(W& w, WaveShared& s, const PairWork& P, c
             double RTlo[12];
             for (int i = 0; i < 12; i++) RTlo[i] = s.lo_rt[i];
             const int c2 = w.count_if(n, [&](int i) { return fabs(relpose_error(RTlo, P.b1 + 3 * i, P.b2 + 3 * i)) < thr; });
-            if (c2 > best_score) {
+            if (c2 >= best_score) {  // ties included, as above
               best_score = c2;
               best_n = c2;
               w.compact(n, [&](int i) { return fabs(relpose_error(RTlo, P.b1 + 3 * i, P.b2 + 3 * i)) < thr; }, P.inliers);
@@ -190,11 +195,7 @@ OSFM_HD void ransac_relative_pose_wave(W& w, WaveShared& s, const PairWork& P, c
             }
           }
         }
-        if (max_it_for != best_n) {
-          max_it = max_iterations_for(best_n, n, prm.probability);
-          max_it_for = best_n;
-        }
-        stop = max_it < (double)(it + k);
+        stop = P.stop_bound[best_n] < (double)(it + k);
       }
       if (rolled) {  // the speculative samples after this iteration are void
         k++;

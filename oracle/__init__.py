@@ -25,6 +25,97 @@ def build(force: bool = False) -> str:
     return so
 
 
+REFERENCE_ROBUST = "/root/reference/opensfm/src/robust"
+
+
+def build_ref(force: bool = False) -> Optional[str]:
+    """oracle/_ref/librobust_ref.so: the reference's own robust_estimator.h / random_sampler.h / scorer.h compiled from where they
+    lie under /root/reference around this oracle's model numerics (ref_adapters/robust_ref.cc).  Rebuilt only where the reference
+    is mounted; elsewhere the prebuilt file (it travels with the repo snapshot) is used if present.  -> path or None."""
+    so = os.path.join(_HERE, "_ref", "librobust_ref.so")
+    if os.path.isdir(REFERENCE_ROBUST):
+        deps = [os.path.join(_HERE, "ref_adapters", "robust_ref.cc"), os.path.join(_HERE, "relpose_oracle.c")]
+        if force or not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+            subprocess.check_call(["make", "-C", _HERE, "-B", "_ref/librobust_ref.so"], stdout=subprocess.DEVNULL)
+    return so if os.path.exists(so) else None
+
+
+def build_camera_ref(force: bool = False) -> Optional[str]:
+    """oracle/_ref/libcamera_ref.so: the reference's scalar camera functions (camera_projections_functions.h,
+    camera_distortions_functions.h, newton_raphson.h) compiled from /root/reference (ref_adapters/camera_ref.cc)."""
+    so = os.path.join(_HERE, "_ref", "libcamera_ref.so")
+    if os.path.isdir(REFERENCE_ROBUST):
+        deps = [os.path.join(_HERE, "ref_adapters", "camera_ref.cc"), os.path.join(_HERE, "ref_adapters", "stubs", "Eigen", "Eigen")]
+        if force or not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+            subprocess.check_call(["make", "-C", _HERE, "-B", "_ref/libcamera_ref.so"], stdout=subprocess.DEVNULL)
+    return so if os.path.exists(so) else None
+
+
+_CAMREF = None
+
+
+def camera_ref_lib() -> Optional[C.CDLL]:
+    global _CAMREF
+    if _CAMREF is None:
+        so = build_camera_ref()
+        if so is None:
+            return None
+        _CAMREF = C.CDLL(so)
+    return _CAMREF
+
+
+def ref_camera(model, par, pts, backward: bool) -> Optional[np.ndarray]:
+    """The REFERENCE's PROJ / DISTO ::Forward (pts: camera-frame points, n x 3 -> n x 2) or ::Backward (pts: normalised image
+    coordinates, n x 2 -> bearings n x 3), native parameter order.  None for the models that need real Eigen (brown, fisheye62/624)."""
+    mid = int(BEARING_MODELS[model] if isinstance(model, str) else model)
+    par = np.ascontiguousarray(np.r_[np.asarray(par, np.float64).reshape(-1), np.zeros(16)][:16])
+    pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 2 if backward else 3)
+    out = np.zeros((len(pts), 3 if backward else 2))
+    ok = camera_ref_lib().ref_camera(mid, int(backward), _p(par, C.c_double), _p(pts, C.c_double), len(pts), _p(out, C.c_double))
+    return out if ok else None
+
+
+_REF = None
+
+
+def ref_lib() -> Optional[C.CDLL]:
+    global _REF
+    if _REF is None:
+        so = build_ref()
+        if so is None:
+            return None
+        _REF = C.CDLL(so)
+    return _REF
+
+
+def ref_random_samples(n: int, size: int, count: int) -> np.ndarray:
+    """The first `count` index samples RandomSamplesGenerator<std::mt19937>(42) of the REFERENCE hands out (random_sampler.h)."""
+    out = np.zeros((count, size), np.int32)
+    ref_lib().ref_random_samples(int(n), int(size), int(count), _p(out, C.c_int32))
+    return out
+
+
+def ref_ransac_relative_pose(b1, b2, threshold: float, iterations: int = 1000, probability: float = 0.99, use_lo: bool = True,
+                             lo_iterations: int = 10):
+    """The REFERENCE's Estimate<RansacScoring, MODEL> (robust_estimator.h:37-119) with this oracle's relative-pose numerics as MODEL."""
+    b1 = np.ascontiguousarray(b1, np.float64).reshape(-1, 3)
+    b2 = np.ascontiguousarray(b2, np.float64).reshape(-1, 3)
+    n = len(b1)
+    model, lo = np.zeros(12), np.zeros(12)
+    inl = np.zeros(max(n, 1), np.int32)
+    score = ref_lib().ref_ransac_relative_pose(_p(b1, C.c_double), _p(b2, C.c_double), n, C.c_double(threshold), int(iterations),
+                                               C.c_double(probability), int(use_lo), int(lo_iterations), _p(model, C.c_double),
+                                               _p(lo, C.c_double), _p(inl, C.c_int32))
+    return {"score": score, "model": model.reshape(3, 4), "lo_model": lo.reshape(3, 4), "inliers": inl[:score].copy()}
+
+
+def ransac_draws(n: int, size: int, count: int) -> np.ndarray:
+    """The oracle's own sampler (mt19937(42) + its restated uniform_int_distribution): first `count` samples of `size` out of n."""
+    out = np.zeros((count, size), np.int32)
+    lib().oracle_random_samples(int(n), int(size), int(count), _p(out, C.c_int32))
+    return out
+
+
 def lib() -> C.CDLL:
     global _LIB
     if _LIB is None:

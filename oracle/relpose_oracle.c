@@ -465,11 +465,13 @@ int oracle_relative_pose_from_essential(const double *E, const double *b1, const
  * (opensfm/src/robust/src/instanciations.cc:33-48, robust_estimator.h:37-119, scorer.h:23-41,
  * random_sampler.h, relative_pose_model.h), EssentialNPoints (geometry/essential.h:162-192) with
  * foundation::SolveAX0 (foundation/numeric.h:20-43).
- * The sampler is std::mt19937(42) + std::uniform_int_distribution<uint32_t>(0, n - 1).  mt19937 is fixed by the
- * C++ standard; the distribution is NOT (libstdc++ changed its algorithm in GCC 11), so which samples the
- * reference draws depends on the toolchain that built it: parity with a reference binary is not defined for this
- * branch, only statistically (opensfm/test/test_robust.py:192-274).  Restated here with libstdc++'s classic
- * rejection-downscaling (< GCC 11).  The 9 x 9 and 3 x 3 decompositions are cyclic Jacobi (+ - * / sqrt only). */
+ * The sampler is std::mt19937(42) + std::uniform_int_distribution<unsigned long>(0, n - 1).  mt19937 is fixed by the
+ * C++ standard; the distribution is NOT (libstdc++ changed its algorithm in GCC 11), so which samples a reference
+ * BINARY draws depends on the toolchain that built it.  Restated here as this image's toolchain (GCC 11.4) compiles the
+ * reference's random_sampler.h, and PINNED against exactly that: oracle/_ref/librobust_ref.so is the reference's own
+ * robust_estimator.h + random_sampler.h + scorer.h compiled from /root/reference around this file's model numerics
+ * (oracle/ref_adapters/robust_ref.cc); tests/test_oracle_relpose.py requires identical samples, scores, inlier lists and
+ * models.  The 9 x 9 and 3 x 3 decompositions are cyclic Jacobi (+ - * / sqrt only). */
 typedef struct { uint32_t mt[624]; int idx; } mt19937_t;
 static void mt_seed(mt19937_t *g, uint32_t seed) {
   g->mt[0] = seed;
@@ -491,12 +493,21 @@ static uint32_t mt_next(mt19937_t *g) {
   y ^= y >> 18;
   return y;
 }
+/* std::uniform_int_distribution<unsigned long>(0, range_max)(std::mt19937&) as libstdc++ >= 11 compiles it: the generator's range is
+ * exactly 32 bits, so the draw is Lemire's multiply-shift with rejection (bits/uniform_int_dist.h, _S_nd<uint64_t>).
+ * Pinned against the reference's random_sampler.h compiled on this box (oracle/_ref/librobust_ref.so, ref_random_samples). */
 static uint32_t mt_uniform(mt19937_t *g, uint32_t range_max) { /* [0, range_max] */
-  const uint64_t urange = (uint64_t)range_max + 1;
-  const uint64_t scaling = 4294967296ull / urange, past = urange * scaling;
-  uint32_t r;
-  do r = mt_next(g); while ((uint64_t)r >= past);
-  return (uint32_t)(r / scaling);
+  const uint32_t range = range_max + 1u;
+  uint64_t product = (uint64_t)mt_next(g) * (uint64_t)range;
+  uint32_t low = (uint32_t)product;
+  if (low < range) {
+    const uint32_t threshold = (0u - range) % range;
+    while (low < threshold) {
+      product = (uint64_t)mt_next(g) * (uint64_t)range;
+      low = (uint32_t)product;
+    }
+  }
+  return (uint32_t)(product >> 32);
 }
 static void draw_sample(mt19937_t *g, int size, int n, int *idx) { /* GenerateOneSample: distinct indices */
   for (int i = 0; i < size; i++) {
@@ -628,9 +639,10 @@ int oracle_ransac_relative_pose(const double *b1, const double *b2, int n, doubl
       memset(RT, 0, sizeof(RT)); /* the reference leaves the model uninitialised when no decomposition scores > 0 */
       oracle_relative_pose_from_essential(Es + 9 * j, s1, s2, 5, RT);
       const int cnt = score_model(RT, b1, b2, n, thr, tmp);
-      /* best_score = max(score, best_score): replaced only when strictly larger */
+      /* best_score = std::max(score, best_score): std::max returns its FIRST argument when the two compare equal, so a tie
+       * replaces the best score (model, lo_model and inlier list) by the newcomer */
       int best_found = 0;
-      if (cnt > best_score) {
+      if (cnt >= best_score) {
         best_score = cnt;
         best_n = cnt;
         memcpy(inliers, tmp, sizeof(int) * (size_t)cnt);
@@ -659,7 +671,7 @@ int oracle_ransac_relative_pose(const double *b1, const double *b2, int n, doubl
           memset(RTlo, 0, sizeof(RTlo));
           oracle_relative_pose_from_essential(Elo, l1, l2, lo_size, RTlo);
           const int c2 = score_model(RTlo, b1, b2, n, thr, tmp);
-          if (c2 > best_score) { /* lo_score.model = best_score.model ; lo_score.lo_model = lo_models[l] */
+          if (c2 >= best_score) { /* std::max(lo_score, best_score), ties included; lo_score.model = best_score.model ; lo_score.lo_model = lo_models[l] */
             best_score = c2;
             best_n = c2;
             memcpy(inliers, tmp, sizeof(int) * (size_t)c2);
@@ -669,7 +681,7 @@ int oracle_ransac_relative_pose(const double *b1, const double *b2, int n, doubl
       }
       { /* ShouldStop */
         const double ratio = (double)best_n / (double)n;
-        double p1 = 1.0 - ratio * ratio * ratio * ratio * ratio;
+        double p1 = 1.0 - pow(ratio, 5.0); /* std::pow(inliers_ratio, double(MINIMAL_SAMPLES)) */
         if (p1 > 1.0 - 2.220446049250313e-16) p1 = 1.0 - 2.220446049250313e-16;
         const double max_it = log(1.0 - probability) / log(p1);
         should_stop = max_it < (double)it;
@@ -904,4 +916,26 @@ void oracle_pixel_bearings_generic(int model, const double *par, const double *p
       b[2] = inv;
     }
   }
+}
+
+/* exported for oracle/ref_adapters/robust_ref.cc (the reference's RANSAC template running on these numerics) */
+int oracle_essential_n_points_contiguous(const double *b1, const double *b2, int count, double *E) {
+  int idx[64];
+  if (count > 64) return 0;
+  for (int i = 0; i < count; i++) idx[i] = i;
+  return essential_n_points(b1, b2, idx, count, E);
+}
+double oracle_relpose_error(const double *RT, const double *x, const double *y) { return relpose_error(RT, x, y); }
+/* ShouldStop's bound (robust_estimator.h:20-35) for a best inlier count: the iteration index above which the loop ends */
+double oracle_ransac_stop_bound(int best_n, int n, double probability) {
+  const double ratio = (double)best_n / (double)n;
+  double p1 = 1.0 - pow(ratio, 5.0);
+  if (p1 > 1.0 - 2.220446049250313e-16) p1 = 1.0 - 2.220446049250313e-16;
+  return log(1.0 - probability) / log(p1);
+}
+/* the sampler alone, for the pin against the reference's random_sampler.h */
+void oracle_random_samples(int n, int size, int count, int *out) {
+  mt19937_t gen;
+  mt_seed(&gen, 42u);
+  for (int c = 0; c < count; c++) draw_sample(&gen, size, n, out + c * size);
 }

@@ -27,7 +27,9 @@ static int ransac_impl(const double* b1, const double* b2, int n, double thr, in
   std::vector<double> models((size_t)kWave * kMaxModels * 12);
   std::vector<int> inl(n > 0 ? n : 1), sub(n > 0 ? n : 1);
   WaveShared* s = new WaveShared;
-  PairWork P{b1, b2, n, models.data(), inl.data(), sub.data()};
+  std::vector<double> stop(n + 1);
+  for (int c = 0; c <= n; c++) stop[c] = max_iterations_for(c, n > 0 ? n : 1, probability);
+  PairWork P{b1, b2, n, models.data(), inl.data(), sub.data(), stop.data()};
   RansacParams prm{thr, 1.0 - cos(thr), iterations, probability, use_lo, lo_it};
   RansacResult r;
   ransac_relative_pose_wave(w, *s, P, prm, r);
@@ -83,7 +85,9 @@ int host_robust_match_calibrated(const double* b1, const double* b2, int n, doub
   std::vector<double> models((size_t)kWave * kMaxModels * 12);
   std::vector<int> inl(n > 0 ? n : 1), sub(n > 0 ? n : 1);
   WaveShared* s = new WaveShared;
-  PairWork P{b1, b2, n, models.data(), inl.data(), sub.data()};
+  std::vector<double> stop(n + 1);
+  for (int c = 0; c <= n; c++) stop[c] = max_iterations_for(c, n > 0 ? n : 1, probability);
+  PairWork P{b1, b2, n, models.data(), inl.data(), sub.data(), stop.data()};
   RansacParams prm{thr, 1.0 - cos(thr), iterations, probability, use_lo, lo_it};
   MatchResult r;
   robust_match_calibrated_wave(w, *s, P, prm, refine_iterations, r);

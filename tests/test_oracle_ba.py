@@ -114,3 +114,27 @@ def test_up_vector_prior_levels_the_cameras(oracle_lib):
     res = np.array([np.linalg.norm(oracle.ba_up(p, [0, -1.0, 0], 1.0)[0]) for p in o["shot_pose"]])
     res0 = np.array([np.linalg.norm(oracle.ba_up(p, [0, -1.0, 0], 1.0)[0]) for p in pr["shot_pose"]])
     assert res.mean() <= res0.mean() + 1e-9
+
+
+def test_projection_values_against_the_reference_forward_functions(oracle_lib):
+    """The reference's own PROJ::Forward / DISTO::Forward compiled on this box (oracle/_ref/libcamera_ref.so, built from
+    /root/reference by oracle/Makefile): the BA oracle's projection is within 2 ulp of it for the six 2-D camera models whose
+    reference code is plain scalar C++ (the oracle multiplies by 1 / z where the reference divides, hence not bit-identical)."""
+    import pytest
+
+    import test_oracle_relpose as cams
+
+    if oracle_lib.camera_ref_lib() is None:
+        pytest.skip("oracle/_ref/libcamera_ref.so is absent and /root/reference is not mounted")
+    rng = np.random.default_rng(8)
+    covered = 0
+    for model, par in cams._BEARING_CAMERAS.items():
+        ang, phi = rng.uniform(0, 0.9, 300), rng.uniform(0, 2 * np.pi, 300)
+        X = np.c_[np.sin(ang) * np.cos(phi), np.sin(ang) * np.sin(phi), np.cos(ang)] * rng.uniform(0.5, 20, 300)[:, None]
+        ref = oracle_lib.ref_camera(model, par, X, backward=False)
+        if ref is None:
+            continue
+        mine = np.array([oracle_lib.ba_project(x, np.zeros(6), np.array(par), np.zeros(2), 1.0, model)[0] for x in X])
+        assert np.abs(mine - ref).max() <= 4.5e-16, model
+        covered += 1
+    assert covered == 6

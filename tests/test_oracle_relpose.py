@@ -313,3 +313,69 @@ def test_generic_bearings_keep_the_bits_of_the_two_model_version(oracle_lib):
         a = oracle_lib.pixel_bearings(model, [-0.1, 0.01, 0.9], px)
         b = oracle_lib.pixel_bearings_generic(model, [-0.1, 0.01, 0.9], px)
         assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+
+
+# ---- pins against the REFERENCE's own code compiled on this box (oracle/_ref, built from /root/reference by oracle/Makefile) ----
+import pytest  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ref(oracle_lib):
+    if oracle_lib.ref_lib() is None:
+        pytest.skip("oracle/_ref/librobust_ref.so is absent and /root/reference is not mounted")
+    return oracle_lib
+
+
+def test_sampler_equals_the_reference_random_sampler(ref):
+    """random_sampler.h (std::mt19937(42) + this toolchain's std::uniform_int_distribution): identical index samples for pool
+    sizes that include powers of two, tiny pools (many duplicate rejections) and large ones."""
+    for n in (5, 6, 7, 8, 9, 12, 16, 31, 32, 33, 64, 100, 255, 256, 1000, 4096, 5000, 65536, 100003, 1 << 20):
+        for size in (5, 12):
+            if size > n:
+                continue
+            assert np.array_equal(ref.ransac_draws(n, size, 400), ref.ref_random_samples(n, size, 400)), (n, size)
+
+
+def test_ransac_equals_the_reference_estimate_template(ref):
+    """robust_estimator.h Estimate<RansacScoring, MODEL> compiled from the reference, with the oracle's model numerics plugged in:
+    same score, same inlier list, same model and lo_model bits -- sampler order, ties (std::max keeps the newcomer), local
+    optimisation and the stopping rule all agree."""
+    rng = np.random.default_rng(21)
+    for trial in range(40):
+        n = int(rng.integers(8, 500))
+        b1, b2, _ = _two_views(rng, n)
+        bad = rng.random(n) < rng.uniform(0, 0.8)
+        b2[bad] = _two_views(rng, int(bad.sum()))[1] if bad.any() else b2[bad]
+        b2 = b2 + rng.normal(0, 5e-4, b2.shape)
+        b2 /= np.linalg.norm(b2, axis=1, keepdims=True)
+        for iters, lo in ((1000, True), (60, True), (200, False)):
+            a = ref.ransac_relative_pose(b1, b2, 0.004, iters, 0.99, lo, 10)
+            b = ref.ref_ransac_relative_pose(b1, b2, 0.004, iters, 0.99, lo, 10)
+            assert a["score"] == b["score"] and np.array_equal(a["inliers"], b["inliers"]), (trial, n, iters, lo)
+            assert np.array_equal(a["model"].view(np.uint64), b["model"].view(np.uint64))
+            assert np.array_equal(a["lo_model"].view(np.uint64), b["lo_model"].view(np.uint64))
+
+
+def test_bearings_equal_the_reference_camera_functions(oracle_lib):
+    """The reference's own PROJ::Backward / DISTO::Backward (camera_projections_functions.h, camera_distortions_functions.h with
+    foundation::NewtonRaphson) compiled on this box: the oracle's bearings are the same doubles, bit for bit, for the seven camera
+    models whose code is plain scalar C++ (brown / fisheye62 / fisheye624 need Eigen types and stay pinned by round trips only)."""
+    if oracle_lib.camera_ref_lib() is None:
+        pytest.skip("oracle/_ref/libcamera_ref.so is absent and /root/reference is not mounted")
+    rng = np.random.default_rng(31)
+    covered = 0
+    for model, par in list(_BEARING_CAMERAS.items()) + [("spherical", [])]:
+        ang, phi = rng.uniform(0, 1.0, 3000), rng.uniform(0, 2 * np.pi, 3000)
+        X = np.c_[np.sin(ang) * np.cos(phi), np.sin(ang) * np.sin(phi), np.cos(ang)] * rng.uniform(0.5, 20, 3000)[:, None]
+        px = oracle_lib.ref_camera(model, par, X, backward=False)  # the reference's own forward projection makes the pixels
+        if px is None:
+            assert model in ("brown", "fisheye62", "fisheye624")
+            continue
+        px[0] = 0.0
+        if model != "spherical":
+            assert np.abs(px[1:] - _forward(model, par, X)[1:]).max() < 1e-15  # and agrees with the numpy forward used elsewhere
+        want = oracle_lib.ref_camera(model, par, px, backward=True)
+        got = oracle_lib.pixel_bearings_generic(model, par, px)
+        assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), model
+        covered += 1
+    assert covered == 7
