@@ -107,3 +107,22 @@ int oracle_match_brute_force_symmetric_masked(const float *fi, int ni, const flo
   free(gji);
   return n;
 }
+
+/* cv2 knnMatch(k = 2, masks) as numbers (for tests/test_reference_flow.py, which hands them to the reference's own Python):
+ * idx[2 i], idx[2 i + 1] = the two nearest allowed train indices of query i (-1 = fewer candidates), dist likewise; mask may be NULL */
+void oracle_knn2_masked(const float *f1, int n1, const float *f2, int n2, int dim, const uint8_t *mask, int *idx, float *dist) {
+  for (int i = 0; i < n1; i++) {
+    float bd0 = INFINITY, bd1 = INFINITY;
+    int bi0 = -1, bi1 = -1;
+    for (int j = 0; j < n2; j++) {
+      if (mask && !mask[(size_t)i * n2 + j]) continue;
+      const float d = sqrtf(l2sqr(f1 + (size_t)i * dim, f2 + (size_t)j * dim, dim));
+      if (d < bd1) {
+        if (bd0 > d) { bd1 = bd0; bi1 = bi0; bd0 = d; bi0 = j; }
+        else { bd1 = d; bi1 = j; }
+      }
+    }
+    idx[2 * i] = bi0; idx[2 * i + 1] = bi1;
+    dist[2 * i] = bd0; dist[2 * i + 1] = bd1;
+  }
+}

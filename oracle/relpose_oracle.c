@@ -939,3 +939,16 @@ void oracle_random_samples(int n, int size, int count, int *out) {
   mt_seed(&gen, 42u);
   for (int c = 0; c < count; c++) draw_sample(&gen, size, n, out + c * size);
 }
+
+/* pygeometry.triangulate_two_bearings_midpoint_many(b1, b2, R, t) (geometry/src/triangulation.cc:180-193): centres (0, t),
+ * bearings (b1_i, R b2_i); ok[i] = 0 when the rays are parallel.  Exported for the flow pins of tests/test_reference_flow.py. */
+void oracle_triangulate_two_bearings_midpoint_many(const double *b1, const double *b2, int n, const double *R, const double *t, uint8_t *ok,
+                                                   double *X) {
+  const double c0[3] = {0, 0, 0};
+  for (int i = 0; i < n; i++) {
+    const double *y = b2 + 3 * i;
+    double ry[3];
+    for (int a = 0; a < 3; a++) ry[a] = R[3 * a] * y[0] + R[3 * a + 1] * y[1] + R[3 * a + 2] * y[2];
+    ok[i] = (uint8_t)triangulate_midpoint2(c0, t, b1 + 3 * i, ry, X + 3 * i);
+  }
+}

@@ -49,3 +49,13 @@ def test_tracks_edge_cases(gpu_ctx):
     assert nt == 1 and list(oi) == [0, 1, 2] and list(of) == [1, 2, 3]
     nt, *_ = tracking.create_tracks_arrays(np.array([1, 7, 4]), np.array([7, 13, 13]), off, 2)
     assert nt == 0
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_the_reference_tracks():
+    """The committed output of the reference's own create_tracks_manager (tests/golden/tracks_golden.json)."""
+    import test_oracle_tracks as t
+
+    from opensfm_amd import tracking
+
+    t.check_against_golden(tracking.create_tracks_manager)
