@@ -16,8 +16,7 @@ def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
 
 
-@pytest.fixture(scope="module")
-def host():
+def build_host():
     src = os.path.join(HERE, "native", "guided_host.cpp")
     out_dir = os.path.join(HERE, "native", "_build")
     os.makedirs(out_dir, exist_ok=True)
@@ -26,6 +25,11 @@ def host():
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-o", so, src])
     return C.CDLL(so)
+
+
+@pytest.fixture(scope="module")
+def host():
+    return build_host()
 
 
 def host_match(host, f1, f2, mask=None, b1=None, b2=None, R=None, t=None, threshold=0.0, ratio=0.8, symmetric=True):

@@ -206,3 +206,127 @@ def test_inlier_and_unfilter_helpers(ref, oracle_lib):
     m1, m2 = rng.random(50) > 0.3, rng.random(60) > 0.3
     m = np.c_[rng.integers(0, m1.sum(), 20), rng.integers(0, m2.sum(), 20)]
     assert np.array_equal(matching.unfilter_matches(m, m1, m2), product.unfilter_matches(m, m1, m2))
+
+
+class _RefPose:
+    """pygeometry.Pose as far as match_unwrap_args / compute_inliers_bearing_epipolar use it (world-to-camera R, origin o)"""
+
+    def __init__(self, R, o):
+        self.R, self.o = np.asarray(R, float), np.asarray(o, float)
+
+    def relative_to(self, base):
+        return _RefPose(self.R @ base.R.T, base.R @ (self.o - base.o))
+
+    def get_R_cam_to_world(self):
+        return self.R.T.copy()
+
+    def get_origin(self):
+        return self.o.copy()
+
+
+def _collection(oracle_lib, rng, guided):
+    """4 images of one repetitive scene (every descriptor exists twice when `guided`), mixed cameras, feature masks"""
+    import test_relpose_core_host as rp
+
+    cams = {"pin": _camera(oracle_lib, "perspective", 0.0, 0.0, 0.8), "fish": _camera(oracle_lib, "fisheye", -0.05, 0.01, 0.7),
+            "dist": _camera(oracle_lib, "perspective", -0.1, 0.02, 0.85)}
+    images = ["a", "b", "c", "d"]
+    cam_of = {"a": "pin", "b": "pin", "c": "fish", "d": "dist"}
+    n = 300
+    X = np.c_[rng.uniform(-2, 2, n), rng.uniform(-2, 2, n), rng.uniform(4, 9, n)]
+    base = rng.integers(0, 255, (n // 2 if guided else n, 128))
+    feats, masks, poses = {}, {}, {}
+    for im in images:
+        R, o = rp._rodrigues(rng.normal(0, 0.1, 3)), rng.normal(0, 0.4, 3)
+        poses[im] = _RefPose(R, o)
+        Y = (X - o) @ R.T + rng.normal(0, 3e-4, X.shape)
+        cam = cams[cam_of[im]]
+        b = Y / np.linalg.norm(Y, axis=1, keepdims=True)
+        if cam.projection_type == "fisheye":
+            l = np.hypot(b[:, 0], b[:, 1])
+            u = b[:, :2] * (np.arctan2(l, b[:, 2]) / np.maximum(l, 1e-300))[:, None]
+        else:
+            u = b[:, :2] / b[:, 2:3]
+        r2 = (u**2).sum(1)
+        px = cam.focal * u * (1 + r2 * (cam.k1 + cam.k2 * r2))[:, None]
+        perm = rng.permutation(n)
+        desc = np.clip((np.concatenate([base, base]) if guided else base) + rng.integers(-3, 4, (n, 128)), 0, 255).astype(np.float32)
+        feats[im] = types.SimpleNamespace(points=np.c_[px[perm], np.ones((n, 2))], descriptors=desc[perm])
+        masks[im] = rng.random(n) > 0.1
+    config = {"matcher_type": "BRUTEFORCE", "symmetric_matching": True, "lowes_ratio": 0.8, "robust_matching_min_match": 20,
+              "robust_matching_threshold": 0.004, "robust_matching_calib_threshold": 0.004, "five_point_refine_match_iterations": 10,
+              "matching_use_filters": False, "matching_use_segmentation": False, "guided_matching_threshold": 0.006, "processes": 1}
+    return images, cams, cam_of, feats, masks, poses, config
+
+
+@pytest.mark.parametrize("guided", [False, True])
+def test_match_flow_equals_the_product_host_flow(ref, oracle_lib, monkeypatch, guided):
+    """The reference's match_unwrap_args -> match() (matching.py:182-214, 563-634; guided: 260-337) executed from its own file for
+    every pair of a mixed collection, against opensfm_amd.matching.match_images_with_pairs with its C-ABI calls redirected to the
+    host emulations: same gates, same dispatch, same unfiltered result for every pair."""
+    import test_guided_host as gh
+    import test_relpose_core_host as rp
+    from opensfm_amd import matching as product
+
+    matching, _ = ref
+    rng = np.random.default_rng(17 if guided else 16)
+    images, cams, cam_of, feats, masks, poses, config = _collection(oracle_lib, rng, guided)
+    exifs = {im: {"camera": cam_of[im]} for im in images}
+    pairs = [(a, b) for i, a in enumerate(images) for b in images[i + 1:]]
+    # ---- the reference side ----
+    feats_masked = {im: types.SimpleNamespace(points=feats[im].points[masks[im]], descriptors=feats[im].descriptors[masks[im]]) for im in images}
+    loader = types.SimpleNamespace(
+        load_all_data=lambda data, im, masked=True, segmentation_in_descriptor=False: feats_masked[im],
+        load_mask=lambda data, im: masks[im],
+        load_bearings=lambda data, im, masked=True, camera=None: camera.pixel_bearing_many(np.array(feats_masked[im].points[:, :2], dtype=float)))
+    monkeypatch.setattr(matching.feature_loader, "instance", loader, raising=False)
+    monkeypatch.setattr(matching.log, "setup", lambda: None, raising=False)
+    data = types.SimpleNamespace(config=config, load_camera_models=lambda: cams, load_features=lambda im: feats[im],
+                                 load_features_mask=lambda im, pts: masks[im])
+    want = {}
+    for im1, im2 in pairs:
+        _, _, m = matching.match_unwrap_args((im1, im2, cams, exifs, data, {}, poses if guided else None))
+        want[im1, im2] = np.asarray(m)
+    # ---- the product side, leaves on the emulations ----
+    bearings, relpose_pairs = rp._emulated_calls(rp.build_host())
+    ghost = gh.build_host()
+
+    def guided_leaf(f1, f2, ratio, symmetric, maskij=None, bearings1=None, bearings2=None, R=None, t=None, threshold=0.0, ctx=None):
+        return gh.host_match(ghost, f1, f2, b1=bearings1, b2=bearings2, R=R, t=t, threshold=threshold, ratio=ratio, symmetric=symmetric)
+
+    class FakeStore:
+        ctx = None
+
+        def __init__(self, descs, pts, ctx=None):
+            self.off = np.r_[0, np.cumsum([len(d) for d in descs])].astype(np.int64)
+            self.desc = np.concatenate(descs).astype(np.float32)
+            self.pts = np.concatenate([np.asarray(p, float)[:, :2] for p in pts])
+
+        def close(self):
+            pass
+
+    def fake_match_pairs(store, ipairs, cfg=None, robust=True, timings=None):
+        per = oracle_lib.match_pairs(store.desc, store.pts, store.off, np.asarray(ipairs, np.int32), ratio=0.8, min_match=20, thr=0.004,
+                                     conf=0.9999, stage=1 if robust else 0)
+        return np.asarray([len(m) for m in per], np.int32), (np.concatenate(per) if len(per) else np.zeros((0, 2), np.int32))
+
+    def fundamental_leaf(p1, p2, threshold, confidence=0.9999, max_iters=1000, ctx=None):
+        F, mask, _ = oracle_lib.find_fundamental_ransac(p1, p2, threshold, confidence, max_iters)
+        return F, mask.astype(np.uint8).reshape(-1, 1)
+
+    monkeypatch.setattr(product, "DescriptorStore", FakeStore)
+    monkeypatch.setattr(product, "match_pairs", fake_match_pairs)
+    monkeypatch.setattr(product, "pixel_bearing_many", bearings)
+    monkeypatch.setattr(product, "relpose_pairs", relpose_pairs)
+    monkeypatch.setattr(product, "_match_guided_leaf", guided_leaf)
+    monkeypatch.setattr(product, "find_fundamental_ransac", fundamental_leaf)
+    got = product.match_images_with_pairs(data, {}, exifs, pairs, poses if guided else None)
+    survivors = 0
+    def rows(a):  # the reference returns a python set's order (matching.py:777), the product sorts by (i, j): compare as sets of rows
+        a = np.asarray(a).reshape(-1, 2)
+        return a[np.lexsort((a[:, 1], a[:, 0]))]
+
+    for pair in pairs:
+        assert np.array_equal(rows(got[pair]), rows(want[pair])), pair
+        survivors += len(want[pair]) > 0
+    assert survivors >= 5
