@@ -75,6 +75,16 @@ def ref_camera(model, par, pts, backward: bool) -> Optional[np.ndarray]:
     return out if ok else None
 
 
+def ref_camera_jacobian(model, par, X):
+    """(Jx n x 2 x 3, Jk n x 2 x 3) through the REFERENCE's ForwardDerivatives of PROJ and Disto24, models 0 / 1 ([k1, k2, focal])."""
+    mid = int(BEARING_MODELS[model] if isinstance(model, str) else model)
+    par = np.ascontiguousarray(np.r_[np.asarray(par, np.float64).reshape(-1), np.zeros(16)][:16])
+    X = np.ascontiguousarray(X, np.float64).reshape(-1, 3)
+    Jx, Jk = np.zeros((len(X), 2, 3)), np.zeros((len(X), 2, 3))
+    ok = camera_ref_lib().ref_camera_jacobian(mid, _p(par, C.c_double), _p(X, C.c_double), len(X), _p(Jx, C.c_double), _p(Jk, C.c_double))
+    return (Jx, Jk) if ok else None
+
+
 _REF = None
 
 

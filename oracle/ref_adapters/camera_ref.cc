@@ -48,6 +48,29 @@ void forward(const double* proj_par, const double* disto_par, const double* aff,
 }
 }  // namespace
 
+// Jacobians through the reference's own analytic derivative functions (ForwardDerivatives of PROJ and DISTO; the composition
+// and the focal scaling are written out here, as ComposeForwardDerivatives needs Eigen): Jx = d pixel / d camera-frame point (2 x 3),
+// Jk = d pixel / d [k1, k2, focal] (2 x 3) for the Perspective / Fisheye + Disto24 + UniformScale cameras (model 0 / 1).
+extern "C" int ref_camera_jacobian(int model, const double* par, const double* X, int n, double* Jx, double* Jk) {
+  if (model != 0 && model != 1) return 0;
+  for (int i = 0; i < n; i++) {
+    double u[2], jp[6], d[2], jd[8];
+    if (model == 0)
+      PerspectiveProjection::ForwardDerivatives<double, false>(X + 3 * i, par, u, jp);
+    else
+      FisheyeProjection::ForwardDerivatives<double, false>(X + 3 * i, par, u, jp);
+    Disto24::ForwardDerivatives<double, true>(u, par, d, jd);  // rows of stride 4: [d/du, d/dv, d/dk1, d/dk2]
+    const double f = par[2];
+    for (int r = 0; r < 2; r++) {
+      for (int c = 0; c < 3; c++) Jx[6 * i + 3 * r + c] = f * (jd[4 * r] * jp[c] + jd[4 * r + 1] * jp[3 + c]);
+      Jk[6 * i + 3 * r + 0] = f * jd[4 * r + 2];
+      Jk[6 * i + 3 * r + 1] = f * jd[4 * r + 3];
+      Jk[6 * i + 3 * r + 2] = d[r];
+    }
+  }
+  return 1;
+}
+
 // model ids as OSFM_CAMERA_*; par in the native order [projection][distortion][affine].  Returns 0 for models this file cannot cover.
 extern "C" int ref_camera(int model, int backward_not_forward, const double* par, const double* in, int n, double* out) {
   for (int i = 0; i < n; i++) {

@@ -138,3 +138,22 @@ def test_projection_values_against_the_reference_forward_functions(oracle_lib):
         assert np.abs(mine - ref).max() <= 4.5e-16, model
         covered += 1
     assert covered == 6
+
+
+def test_jacobians_against_the_reference_derivative_functions(oracle_lib):
+    """PerspectiveProjection / FisheyeProjection ::ForwardDerivatives and Disto24::ForwardDerivatives compiled from the reference
+    (oracle/_ref/libcamera_ref.so; the chain rule and the focal scaling written out in the adapter): the BA oracle's point and
+    intrinsics Jacobians of the two optimised camera models agree to a few ulp (pose = identity)."""
+    import pytest
+
+    if oracle_lib.camera_ref_lib() is None:
+        pytest.skip("oracle/_ref/libcamera_ref.so is absent and /root/reference is not mounted")
+    rng = np.random.default_rng(9)
+    for model, par in (("perspective", [-0.1, 0.01, 0.85]), ("fisheye", [-0.05, 0.004, 0.45]), ("perspective", [0.3, 0.1, -0.03])):
+        ang, phi = rng.uniform(0, 0.9, 200), rng.uniform(0, 2 * np.pi, 200)
+        X = np.c_[np.sin(ang) * np.cos(phi), np.sin(ang) * np.sin(phi), np.cos(ang)] * rng.uniform(0.5, 20, 200)[:, None]
+        Jx, Jk = oracle_lib.ref_camera_jacobian(model, par, X)
+        for i, x in enumerate(X):
+            _, Jp, _, Jkk = oracle_lib.ba_project(x, np.zeros(6), np.array(par), np.zeros(2), 1.0, model)
+            assert np.abs(Jp - Jx[i]).max() <= 4e-15 * np.abs(Jx[i]).max()
+            assert np.abs(Jkk - Jk[i]).max() <= 4e-15 * np.abs(Jk[i]).max()
