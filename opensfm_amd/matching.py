@@ -495,3 +495,57 @@ def match_images_with_pairs(data, config_override: Dict[str, Any], exifs: Dict[s
             m = unfilter_matches(m, m1, m2)
         out[im1, im2] = np.array(m, dtype=int)
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# the match graph on disk (``dataset.py:344-392``, ``matching.py:128-157``)
+# --------------------------------------------------------------------------------------------
+def save_matches(data, images_ref: Sequence[str], matched_pairs: Dict[Tuple[str, str], Any]) -> None:
+    """Given pairwise matches (image 1, image 2) -> matches, save them such as only {image E images_ref} will store the matches
+    (``matching.py:128-157``): groups the pairs per reference image and calls ``data.save_matches(image, {other: matches})``."""
+    images_ref_set = set(images_ref)
+    matches_per_im1: Dict[str, Dict[str, Any]] = {im: {} for im in images_ref}
+    for (im1, im2), m in matched_pairs.items():
+        if im1 in images_ref_set:
+            matches_per_im1[im1][im2] = m
+        elif im2 in images_ref_set:
+            matches_per_im1[im2][im1] = m
+        else:
+            raise RuntimeError("Couldn't save matches for {}. No image found in images_ref.".format((im1, im2)))
+    for im1, im1_matches in matches_per_im1.items():
+        data.save_matches(im1, im1_matches)
+
+
+def write_matches_files(data_path: str, images: Sequence[str], pairs: np.ndarray, counts: np.ndarray, matches: np.ndarray,
+                        images_ref: Optional[Sequence[str]] = None) -> List[str]:
+    """The batched result of ``match_pairs`` (image indices ``pairs``, ``counts``, concatenated ``matches``) straight into the
+    reference's on-disk format, ``<data_path>/matches/<image>_matches.pkl.gz`` = gzip(pickle({other image: (K, 2) int array})),
+    what ``DataSet.save_matches`` writes and ``DataSet.load_matches`` / ``find_matches`` read (``dataset.py:344-404``), with the
+    grouping of ``matching.save_matches``: the pair is stored under its first image when that is a reference image, else under the
+    second.  Pairs without matches store ``np.array([])`` as the reference does (``matching.py:598,634``).  -> written files."""
+    import gzip
+    import os
+    import pickle
+
+    ref = list(images) if images_ref is None else list(images_ref)
+    ref_set = set(ref)
+    per_image: Dict[str, Dict[str, np.ndarray]] = {im: {} for im in ref}
+    for (a, b), m in zip(np.asarray(pairs).reshape(-1, 2), split_matches(np.asarray(counts), np.asarray(matches).reshape(-1, 2))):
+        im1, im2 = images[int(a)], images[int(b)]
+        value = np.array(m, dtype=int) if len(m) else np.array([])
+        if im1 in ref_set:
+            per_image[im1][im2] = value
+        elif im2 in ref_set:
+            per_image[im2][im1] = value
+        else:
+            raise RuntimeError("Couldn't save matches for {}. No image found in images_ref.".format((im1, im2)))
+    out_dir = os.path.join(data_path, "matches")
+    os.makedirs(out_dir, exist_ok=True)
+    written = []
+    for im, d in per_image.items():
+        path = os.path.join(out_dir, "{}_matches.pkl.gz".format(im))
+        with open(path, "wb") as fw, gzip.GzipFile(fileobj=fw, mode="w") as fzip:
+            pickle.dump(d, fzip)
+        written.append(path)
+    return written
+
