@@ -409,6 +409,15 @@ def ransac_relative_pose(b1, b2, threshold: float, iterations: int = 1000, proba
     return {"score": score, "model": model.reshape(3, 4), "lo_model": lo.reshape(3, 4), "inliers": inl[:score].copy(), "iterations": it.value}
 
 
+def essential_n_points(b1, b2):
+    """pygeometry.essential_n_points (geometry/essential.h:162-192) -> list with 0 or 1 matrices (3 x 3)."""
+    b1 = np.ascontiguousarray(b1, np.float64).reshape(-1, 3)
+    b2 = np.ascontiguousarray(b2, np.float64).reshape(-1, 3)
+    E = np.zeros(9)
+    ok = lib().oracle_essential_n_points_contiguous(_p(b1, C.c_double), _p(b2, C.c_double), len(b1), _p(E, C.c_double))
+    return [E.reshape(3, 3)] if ok else []
+
+
 def pixel_bearings(model, cam, px) -> np.ndarray:
     """Camera.pixel_bearing_many for the PERSPECTIVE (0) / FISHEYE (1) models, cam = [k1, k2, focal]."""
     cam = np.ascontiguousarray(cam, np.float64)

@@ -920,8 +920,7 @@ void oracle_pixel_bearings_generic(int model, const double *par, const double *p
 
 /* exported for oracle/ref_adapters/robust_ref.cc (the reference's RANSAC template running on these numerics) */
 int oracle_essential_n_points_contiguous(const double *b1, const double *b2, int count, double *E) {
-  int idx[64];
-  if (count > 64) return 0;
+  int *idx = (int *)__builtin_alloca(sizeof(int) * (size_t)(count > 0 ? count : 1));
   for (int i = 0; i < count; i++) idx[i] = i;
   return essential_n_points(b1, b2, idx, count, E);
 }

@@ -1,0 +1,217 @@
+"""The reference's OWN test functions for this path, executed against this repository's implementations.
+
+opensfm/test/test_multiview.py, test_robust.py, test_triangulation.py and test_matching.py are loaded from /root/reference; the
+compiled modules they call (pygeometry, pyrobust) are stand-ins served by the CPU oracle and, in a second pass, by the PRODUCT's
+per-lane / wavefront code compiled for the host -- i.e. the reference's assertions, tolerances and call conventions judge both.  Their fixtures come from the reference's synthetic-scene generator (compiled code), so
+`pairs_and_their_E` is rebuilt here with the same contents (bearings of a camera pair, E = R [o]x normalised, the relative pose;
+opensfm/test/conftest.py:166-194).  Skipped where /root/reference is not mounted."""
+import copy
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+
+REF = "/root/reference/opensfm"
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="/root/reference is not mounted")
+
+
+class _Stub(types.ModuleType):
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        cls = type(name, (), {})
+        setattr(self, name, cls)
+        return cls
+
+
+def _rodrigues(r):
+    th = np.linalg.norm(r)
+    K = np.array([[0, -r[2], r[1]], [r[2], 0, -r[0]], [-r[1], r[0], 0]])
+    return np.eye(3) if th == 0 else np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th**2 * K @ K
+
+
+class Pose:
+    """pygeometry.Pose as the tests use it: rotation (angle-axis, world to camera) and translation are plain attributes"""
+
+    def __init__(self, rotation, translation):
+        self.rotation, self.translation = np.array(rotation, float), np.array(translation, float)
+
+    def get_rotation_matrix(self):
+        return _rodrigues(self.rotation)
+
+    def get_origin(self):
+        return -self.get_rotation_matrix().T @ self.translation
+
+    def get_world_to_cam(self):
+        T = np.eye(4)
+        T[:3, :3], T[:3, 3] = self.get_rotation_matrix(), self.translation
+        return T
+
+
+class _ProductEmulation:
+    """the same calls served by the PRODUCT's per-lane / wavefront code compiled for the host (tests/native/relpose_core_host.cpp)"""
+
+    def __init__(self, oracle_lib):
+        import ctypes as C
+
+        import test_relpose_core_host as rp
+
+        self.C, self.h, self.o, self.p = C, rp.build_host(), oracle_lib, rp._p
+
+    def lib(self):
+        return self.o.lib()  # midpoint triangulation: only the oracle exports it stand-alone
+
+    def essential_five_points(self, f1, f2):
+        C = self.C
+        f1, f2 = np.ascontiguousarray(f1, np.float64), np.ascontiguousarray(f2, np.float64)
+        Es = np.zeros(90)
+        k = self.h.host_essential_five_points(self.p(f1, C.c_double), self.p(f2, C.c_double), self.p(Es, C.c_double))
+        return Es[: 9 * k].reshape(k, 3, 3).copy()
+
+    def essential_n_points(self, f1, f2):
+        return self.o.essential_n_points(f1, f2)  # not exported stand-alone by the emulation; covered inside its RANSAC
+
+    def relative_pose_from_essential(self, E, f1, f2):
+        C = self.C
+        E, f1, f2 = (np.ascontiguousarray(a, np.float64) for a in (E, f1, f2))
+        RT = np.zeros(12)
+        ok = self.h.host_relative_pose_from_essential(self.p(E, C.c_double), self.p(f1, C.c_double), self.p(f2, C.c_double), len(f1),
+                                                      self.p(RT, C.c_double))
+        return RT.reshape(3, 4) if ok else None
+
+    def relative_pose_refinement(self, Rt, f1, f2, iterations):
+        C = self.C
+        RT = np.ascontiguousarray(np.asarray(Rt, np.float64).reshape(-1).copy())
+        f1, f2 = np.ascontiguousarray(f1, np.float64), np.ascontiguousarray(f2, np.float64)
+        costs = np.zeros(2)
+        it = self.h.host_relative_pose_refinement(self.p(RT, C.c_double), self.p(f1, C.c_double), self.p(f2, C.c_double), len(f1), int(iterations),
+                                                  self.p(costs, C.c_double))
+        return RT.reshape(3, 4), it, tuple(costs)
+
+    def ransac_relative_pose(self, b1, b2, threshold, iterations, probability, use_lo, lo_iterations):
+        C = self.C
+        b1, b2 = np.ascontiguousarray(b1, np.float64), np.ascontiguousarray(b2, np.float64)
+        n = len(b1)
+        model, lo, inl, it = np.zeros(12), np.zeros(12), np.zeros(max(n, 1), np.int32), C.c_int(0)
+        s = self.h.host_ransac_relative_pose(64, self.p(b1, C.c_double), self.p(b2, C.c_double), n, C.c_double(threshold), int(iterations),
+                                             C.c_double(probability), int(use_lo), int(lo_iterations), self.p(model, C.c_double),
+                                             self.p(lo, C.c_double), self.p(inl, C.c_int32), C.byref(it))
+        return {"score": s, "model": model.reshape(3, 4), "lo_model": lo.reshape(3, 4), "inliers": inl[:s].copy(), "iterations": it.value}
+
+
+@pytest.fixture(scope="module", params=["oracle", "product-emulation"])
+def reference_tests(request, oracle_lib):
+    import ctypes as C
+
+    o = oracle_lib if request.param == "oracle" else _ProductEmulation(oracle_lib)
+    saved = {k: sys.modules.get(k) for k in list(sys.modules) if k == "cv2" or k == "opensfm" or k.startswith("opensfm.")}
+    pkg = _Stub("opensfm")
+    pkg.__path__ = [REF]
+    pygeometry, pyrobust = _Stub("opensfm.pygeometry"), _Stub("opensfm.pyrobust")
+    pygeometry.Pose = Pose
+    pygeometry.essential_five_points = lambda f1, f2: list(o.essential_five_points(f1, f2))
+    pygeometry.essential_n_points = lambda f1, f2: o.essential_n_points(f1, f2)
+    pygeometry.relative_pose_from_essential = lambda E, f1, f2: o.relative_pose_from_essential(E, f1, f2)
+    pygeometry.relative_pose_refinement = lambda Rt, f1, f2, it: o.relative_pose_refinement(Rt, f1, f2, it)[0]
+
+    def tri2(centers, bearings):
+        centers, bearings = np.asarray(centers, float), np.asarray(bearings, float)
+        ok, X = np.zeros(1, np.uint8), np.zeros((1, 3))
+        b1, b2 = np.ascontiguousarray(bearings[:1]), np.ascontiguousarray(bearings[1:2])
+        R, t = np.ascontiguousarray(np.eye(3)), np.ascontiguousarray(centers[1] - centers[0])
+        o.lib().oracle_triangulate_two_bearings_midpoint_many(b1.ctypes.data_as(C.POINTER(C.c_double)), b2.ctypes.data_as(C.POINTER(C.c_double)), 1,
+                                                              R.ctypes.data_as(C.POINTER(C.c_double)), t.ctypes.data_as(C.POINTER(C.c_double)),
+                                                              ok.ctypes.data_as(C.POINTER(C.c_uint8)), X.ctypes.data_as(C.POINTER(C.c_double)))
+        return bool(ok[0]), X[0] + centers[0]
+
+    pygeometry.triangulate_two_bearings_midpoint = tri2
+
+    class RobustEstimatorParams:
+        def __init__(self):
+            self.iterations, self.probability, self.use_local_optimization = 100, 0.99, True
+            self.use_iteration_reduction, self.local_optimization_iterations = True, 10
+
+    pyrobust.RobustEstimatorParams = RobustEstimatorParams
+    pyrobust.RansacType = types.SimpleNamespace(RANSAC=0)
+
+    def ransac_relative_pose(b1, b2, threshold, params, kind):
+        r = o.ransac_relative_pose(b1, b2, threshold, params.iterations, params.probability, params.use_local_optimization,
+                                   params.local_optimization_iterations)
+        return types.SimpleNamespace(lo_model=r["lo_model"], model=r["model"], inliers_indices=list(r["inliers"]), score=r["score"])
+
+    pyrobust.ransac_relative_pose = ransac_relative_pose
+    mods = {"cv2": _Stub("cv2"), "opensfm": pkg, "opensfm.pygeometry": pygeometry, "opensfm.pyrobust": pyrobust}
+    for name in ("pymap", "pyfeatures", "context", "feature_loader", "log", "pairs_selection", "dataset_base", "bow", "config", "io",
+                 "reconstruction", "synthetic_data", "synthetic_data.synthetic_dataset", "synthetic_data.synthetic_scene"):
+        mods["opensfm." + name] = _Stub("opensfm." + name)
+    mods["opensfm.dataset_base"].DataSetBase = object
+    mods["opensfm.synthetic_data"].synthetic_dataset = mods["opensfm.synthetic_data.synthetic_dataset"]
+    mods["opensfm.synthetic_data"].synthetic_scene = mods["opensfm.synthetic_data.synthetic_scene"]
+    for name, m in mods.items():
+        sys.modules[name] = m
+        if name.startswith("opensfm.") and name.count(".") == 1:
+            setattr(pkg, name.split(".")[1], m)
+    loaded = {}
+    for name, path in (("transformations", "transformations.py"), ("multiview", "multiview.py"), ("matching", "matching.py"),
+                       ("test.test_multiview", "test/test_multiview.py"), ("test.test_robust", "test/test_robust.py"),
+                       ("test.test_triangulation", "test/test_triangulation.py"), ("test.test_matching", "test/test_matching.py")):
+        spec = importlib.util.spec_from_file_location("opensfm." + name, os.path.join(REF, path))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules["opensfm." + name] = mod
+        if "." not in name:
+            setattr(pkg, name, mod)
+        spec.loader.exec_module(mod)
+        loaded[name.split(".")[-1]] = mod
+    yield loaded
+    for k in [k for k in sys.modules if k == "cv2" or k == "opensfm" or k.startswith("opensfm.")]:
+        del sys.modules[k]
+    sys.modules.update({k: v for k, v in saved.items() if v is not None})
+
+
+@pytest.fixture()
+def pairs_and_their_E(reference_tests):
+    """20 camera pairs as opensfm/test/conftest.py:166-194 hands them out: (f1, f2, E, pose) with f2 ~ R f1 d + t, E = R [o]x / |.|"""
+    multiview = reference_tests["multiview"]
+    rng = np.random.default_rng(42)
+    out = []
+    for _ in range(20):
+        n = int(rng.integers(40, 300))
+        pose = Pose(rng.normal(0, 0.2, 3), rng.normal(0, 1.0, 3))
+        X = np.c_[rng.uniform(-3, 3, n), rng.uniform(-3, 3, n), rng.uniform(4, 12, n)]
+        Y = X @ pose.get_rotation_matrix().T + pose.translation
+        f1 = X / np.linalg.norm(X, axis=1, keepdims=True)
+        f2 = Y / np.linalg.norm(Y, axis=1, keepdims=True)
+        e = pose.get_rotation_matrix().dot(multiview.cross_product_matrix(pose.get_origin()))
+        out.append((f1, f2, e / np.linalg.norm(e), pose))
+    return out
+
+
+def test_reference_multiview_tests_pass_on_the_oracle(reference_tests, pairs_and_their_E):
+    np.random.seed(0)
+    t = reference_tests["test_multiview"]
+    t.test_essential_five_points(copy.deepcopy(pairs_and_their_E))
+    t.test_essential_n_points(copy.deepcopy(pairs_and_their_E))
+    t.test_relative_pose_from_essential(copy.deepcopy(pairs_and_their_E))
+    t.test_relative_pose_refinement(copy.deepcopy(pairs_and_their_E))
+
+
+def test_reference_robust_test_passes_on_the_oracle(reference_tests, pairs_and_their_E):
+    np.random.seed(1)
+    reference_tests["test_robust"].test_outliers_relative_pose_ransac(copy.deepcopy(pairs_and_their_E))
+
+
+def test_reference_triangulation_tests_pass_on_the_oracle(reference_tests):
+    t = reference_tests["test_triangulation"]
+    t.test_triangulate_two_bearings_midpoint()
+    t.test_triangulate_two_bearings_midpoint_failed()
+
+
+def test_reference_unfilter_test_passes_on_the_product(reference_tests, monkeypatch):
+    from opensfm_amd import matching as product
+
+    t = reference_tests["test_matching"]
+    monkeypatch.setattr(t, "matching", product)
+    t.test_unfilter_matches()
