@@ -12,6 +12,7 @@
 // First-correct version: everything is inlined into one kernel (256 VGPRs + spills, 12.6 KiB scratch per lane,
 // 1 wave per SIMD) and measured 3.65 k pairs/s at 300 correspondences per pair -- tuning is round-2 work.
 #include <math.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <vector>
@@ -219,7 +220,11 @@ extern "C" int osfm_relpose_pairs(osfm_ctx *ctx, const double *b1, const double 
     OSFM_HIP(hipMemcpyAsync(d_b2.p, b2, (size_t)total * 24, hipMemcpyHostToDevice, ctx->stream));
   }
   OSFM_HIP(hipMemcpyAsync(d_off.p, offsets, (size_t)(n_pairs + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-  const RansacParams rp{prm->threshold, 1.0 - cos(prm->threshold), (int)prm->iterations, prm->probability, (int)prm->use_lo, (int)prm->lo_iterations};
+  // OSFM_RELPOSE_BATCH0: width of the first speculative batch and of the batch after every rewind (default 64 = always full
+  // batches); a tuning knob for round 2, the results do not depend on it
+  const char *b0 = getenv("OSFM_RELPOSE_BATCH0");
+  const RansacParams rp{prm->threshold, 1.0 - cos(prm->threshold), (int)prm->iterations, prm->probability, (int)prm->use_lo, (int)prm->lo_iterations,
+                        b0 ? atoi(b0) : kWave};
   OSFM_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
   for (int p0 = 0; p0 < n_pairs; p0 += chunk) {
     const int np = std::min(chunk, n_pairs - p0);

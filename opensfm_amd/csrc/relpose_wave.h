@@ -32,6 +32,8 @@ struct RansacParams {
   double probability;      // ::probability
   int use_lo;              // ::use_local_optimization
   int lo_iterations;       // ::local_optimization_iterations
+  int batch0;              // speculative batch schedule: width of the first batch and of the batch after every rewind; it doubles
+                           // (up to the wavefront width) while no local optimisation fires.  Results do not depend on it.
 };
 // (probability only enters through PairWork::stop_bound, tabulated on the host)
 
@@ -109,8 +111,9 @@ OSFM_HD void ransac_relative_pose_wave(W& w, WaveShared& s, const PairWork& P, c
     s.calls = 0;
   });
   int best_score = 0, best_n = 0, it = 0, stop = 0;
+  int width = prm.batch0 < 1 ? 1 : (prm.batch0 > W::width ? W::width : prm.batch0);
   while (it < prm.iterations && !stop) {
-    const int B = (prm.iterations - it) < W::width ? (prm.iterations - it) : W::width;
+    const int B = (prm.iterations - it) < width ? (prm.iterations - it) : width;
     w.single([&]() {  // snapshot + speculative draws
       for (int i = 0; i < 624; i++) s.mt_bak[i] = s.mt[i];
       s.mt_idx_bak = s.mt_idx;
@@ -203,6 +206,10 @@ OSFM_HD void ransac_relative_pose_wave(W& w, WaveShared& s, const PairWork& P, c
       }
     }
     it += k;
+    if (rolled)
+      width = prm.batch0 < 1 ? 1 : (prm.batch0 > W::width ? W::width : prm.batch0);
+    else
+      width = 2 * width > W::width ? W::width : 2 * width;
   }
   out.best_score = best_score;
   out.iterations_run = it;

@@ -11,6 +11,9 @@
 
 using namespace osfm_rp;
 
+static int g_batch0 = 64;  // speculative batch schedule (RansacParams::batch0); results must not depend on it
+extern "C" void host_set_batch0(int b) { g_batch0 = b; }
+
 template <int WIDTH>
 struct LoopWave {  // "lanes" are loop iterations; single() runs once
   static constexpr int width = WIDTH;
@@ -30,7 +33,7 @@ static int ransac_impl(const double* b1, const double* b2, int n, double thr, in
   std::vector<double> stop(n + 1);
   for (int c = 0; c <= n; c++) stop[c] = max_iterations_for(c, n > 0 ? n : 1, probability);
   PairWork P{b1, b2, n, models.data(), inl.data(), sub.data(), stop.data()};
-  RansacParams prm{thr, 1.0 - cos(thr), iterations, probability, use_lo, lo_it};
+  RansacParams prm{thr, 1.0 - cos(thr), iterations, probability, use_lo, lo_it, g_batch0};
   RansacResult r;
   ransac_relative_pose_wave(w, *s, P, prm, r);
   delete s;
@@ -88,7 +91,7 @@ int host_robust_match_calibrated(const double* b1, const double* b2, int n, doub
   std::vector<double> stop(n + 1);
   for (int c = 0; c <= n; c++) stop[c] = max_iterations_for(c, n > 0 ? n : 1, probability);
   PairWork P{b1, b2, n, models.data(), inl.data(), sub.data(), stop.data()};
-  RansacParams prm{thr, 1.0 - cos(thr), iterations, probability, use_lo, lo_it};
+  RansacParams prm{thr, 1.0 - cos(thr), iterations, probability, use_lo, lo_it, g_batch0};
   MatchResult r;
   robust_match_calibrated_wave(w, *s, P, prm, refine_iterations, r);
   delete s;

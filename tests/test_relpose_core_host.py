@@ -170,6 +170,24 @@ def test_ransac_decision_sequence_bits(host, oracle_lib, width):
                                           C.byref(it)) == 0 and it.value == 0
 
 
+def test_batch_schedule_does_not_change_results(host, oracle_lib):
+    """RansacParams::batch0 (first speculative batch and the one after every rewind, doubling afterwards) is a pure tuning knob"""
+    rng = np.random.default_rng(22)
+    try:
+        for n, outl in ((30, 0.3), (200, 0.5), (400, 0.8)):
+            b1, b2, _ = _scene(rng, n, outliers=outl)
+            want = oracle_lib.ransac_relative_pose(b1, b2, 0.004, 1000, 0.99, True, 10)
+            for b0 in (1, 2, 4, 16, 64):
+                host.host_set_batch0(b0)
+                model, lo, inl, it = np.zeros(12), np.zeros(12), np.zeros(n, np.int32), C.c_int(0)
+                score = host.host_ransac_relative_pose(64, _p(b1, C.c_double), _p(b2, C.c_double), n, C.c_double(0.004), 1000, C.c_double(0.99), 1, 10,
+                                                       _p(model, C.c_double), _p(lo, C.c_double), _p(inl, C.c_int32), C.byref(it))
+                assert (score, it.value) == (want["score"], want["iterations"]) and np.array_equal(inl[:score], want["inliers"])
+                assert np.array_equal(lo.view(np.uint64), want["lo_model"].reshape(-1).view(np.uint64))
+    finally:
+        host.host_set_batch0(64)
+
+
 def test_refinement_bits(host, oracle_lib):
     rng = np.random.default_rng(3)
     for trial in range(20):
