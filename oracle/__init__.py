@@ -346,6 +346,18 @@ def ba_project(X, pose, cam, obs, sigma, model="perspective"):
     return res, Jp.reshape(2, 3), Jc.reshape(2, 6), Jk.reshape(2, 3)
 
 
+def ba_project_intrinsics(X, pose, par, obs, sigma, model):
+    """Residual (2) and its Jacobian w.r.t. every intrinsic parameter of a camera of model 2..8 (2 x n_params, native order)."""
+    X, pose, obs = (np.ascontiguousarray(a, np.float64) for a in (X, pose, obs))
+    n = len(par)
+    par = np.ascontiguousarray(np.r_[np.asarray(par, np.float64), np.zeros(16 - n)])
+    res, Jk = np.zeros(2), np.zeros((2, 16))
+    lib().oracle_ba_project_intrinsics(C.c_int(CAMERA_MODELS[model] if isinstance(model, str) else int(model)), _p(X, C.c_double),
+                                       _p(pose, C.c_double), _p(par, C.c_double), _p(obs, C.c_double), C.c_double(sigma), _p(res, C.c_double),
+                                       _p(Jk, C.c_double))
+    return res, Jk[:, :n].copy()
+
+
 def ba_loss(loss: str, a: float, s: float):
     out = np.zeros(2)
     lib().oracle_ba_loss(LOSSES[loss], C.c_double(a), C.c_double(s), _p(out, C.c_double))

@@ -351,6 +351,76 @@ void oracle_ba_project(const double *X, const double *pose, const double *cam, c
 }
 void oracle_ba_loss(int loss, double a, double s, double *out2) { loss_eval(loss, a, s, &out2[0], &out2[1]); }
 
+/* GROUNDWORK (no product counterpart yet: the GPU solver keeps the 4-16 parameter cameras constant): the Jacobian of the
+ * reprojection residual w.r.t. EVERY intrinsic parameter of a camera of model 2..8, in the native order
+ * [projection][distortion][affine] -- what ForwardDerivatives<T, DERIV_PARAMS = true> composes in the reference
+ * (camera_projections_functions.h:137-171 dual transition; camera_distortions_functions.h: the parameter columns of each
+ * distortion's ForwardDerivatives; transformations_functions.h:22-40 Affine, :60-72 UniformScale).  Jk: 2 x 16 row-major
+ * (unused columns zero), already multiplied by 1 / sigma.  Pinned by the mpmath golden vectors (tests/test_oracle_ba.py). */
+void oracle_ba_project_intrinsics(int model, const double *X, const double *pose, const double *par, const double *obs, double sigma,
+                                  double *res, double *Jk) {
+  double R[9], dR[3][9];
+  rot_and_derivs(pose, R, dR);
+  const double p[3] = {X[0] - pose[3], X[1] - pose[4], X[2] - pose[5]};
+  double Xc[3];
+  for (int i = 0; i < 3; i++) Xc[i] = R[3 * i] * p[0] + R[3 * i + 1] * p[1] + R[3 * i + 2] * p[2];
+  int proj, kind, nd, na;
+  model_layout(model, &proj, &kind, &nd, &na);
+  const int np0 = proj == 2 ? 1 : 0;
+  const double *kd = par + np0, *ka = kd + nd;
+  double uv[2], jp[6], dt[2] = {0, 0};
+  if (proj == 2) {
+    double a[2], ja[6], b[2], jb[6];
+    project_stage(0, Xc, a, ja);
+    project_stage(1, Xc, b, jb);
+    for (int i = 0; i < 2; i++) {
+      uv[i] = par[0] * a[i] + (1.0 - par[0]) * b[i];
+      dt[i] = a[i] - b[i]; /* d uv / d transition */
+    }
+  } else {
+    project_stage(proj, Xc, uv, jp);
+  }
+  d2 x = {uv[0], 1, 0}, y = {uv[1], 0, 1}, dx, dy;
+  distort_d2(kind, kd, x, y, &dx, &dy);
+  const double u = uv[0], v = uv[1], r2 = u * u + v * v;
+  const double fx = ka[0], fy = na == 4 ? ka[0] * ka[1] : ka[0];
+  const double cx = na == 4 ? ka[2] : 0.0, cy = na == 4 ? ka[3] : 0.0;
+  const double is = 1.0 / sigma;
+  res[0] = is * (fx * dx.v + cx - obs[0]);
+  res[1] = is * (fy * dy.v + cy - obs[1]);
+  for (int i = 0; i < 32; i++) Jk[i] = 0.0;
+#define OSFM_SET(col, a, b) { Jk[(col)] = is * fx * (a); Jk[16 + (col)] = is * fy * (b); }
+  if (proj == 2) OSFM_SET(0, dx.a * dt[0] + dx.b * dt[1], dy.a * dt[0] + dy.b * dt[1]);
+  /* distortion parameters: derivatives of (du, dv) */
+  const int nrad = kind == 0 ? 1 : kind == 1 ? 2 : kind == 2 ? 4 : kind == 3 ? 3 : 6;
+  double pw = r2;
+  for (int i = 0; i < nrad; i++) { /* radial coefficient k_{i+1} multiplies r2^(i+1) */
+    OSFM_SET(np0 + i, u * pw, v * pw);
+    pw *= r2;
+  }
+  if (kind >= 3) {
+    const int ip = np0 + (kind == 3 ? 3 : 6);
+    OSFM_SET(ip, 2.0 * u * v, r2 + 2.0 * v * v);     /* p1 */
+    OSFM_SET(ip + 1, r2 + 2.0 * u * u, 2.0 * u * v); /* p2 */
+  }
+  if (kind == 5) {
+    OSFM_SET(np0 + 8, r2, 0.0);
+    OSFM_SET(np0 + 9, r2 * r2, 0.0);
+    OSFM_SET(np0 + 10, 0.0, r2);
+    OSFM_SET(np0 + 11, 0.0, r2 * r2);
+  }
+#undef OSFM_SET
+  /* affine parameters */
+  const int ia = np0 + nd;
+  Jk[ia] = is * dx.v;                          /* focal */
+  Jk[16 + ia] = is * (na == 4 ? ka[1] : 1.0) * dy.v;
+  if (na == 4) {
+    Jk[16 + ia + 1] = is * ka[0] * dy.v;       /* aspect ratio */
+    Jk[ia + 2] = is;                           /* cx */
+    Jk[16 + ia + 3] = is;                      /* cy */
+  }
+}
+
 /* ---------------------------------------------------------------------------------------- */
 typedef struct {
   const ba_problem *P;

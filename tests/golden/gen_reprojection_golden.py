@@ -161,8 +161,9 @@ def main():
         Jc = jac(lambda x: residual(X, x, cam, obs, sd, model), pose)
         f = lambda m: [[float(v) for v in row] for row in m]
         rec = dict(c, residual=[float(v) for v in r], Jp=f(Jp), Jc=f(Jc))
-        if model not in GENERIC:  # intrinsics Jacobian only for the models whose intrinsics the solver optimises
-            rec["Jk"] = f(jac(lambda x: residual(X, pose, x, obs, sd, model), cam))
+        # intrinsics Jacobian: "Jk" for the models whose intrinsics the solver optimises ([k1, k2, focal]); "Jk_full" (2 x all native
+        # parameters) for the others, groundwork for optimising them too
+        rec["Jk" if model not in GENERIC else "Jk_full"] = f(jac(lambda x: residual(X, pose, x, obs, sd, model), cam))
         out.append(rec)
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reprojection_golden.json")
     with open(path, "w") as fh:

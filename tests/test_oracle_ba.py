@@ -157,3 +157,20 @@ def test_jacobians_against_the_reference_derivative_functions(oracle_lib):
             _, Jp, _, Jkk = oracle_lib.ba_project(x, np.zeros(6), np.array(par), np.zeros(2), 1.0, model)
             assert np.abs(Jp - Jx[i]).max() <= 4e-15 * np.abs(Jx[i]).max()
             assert np.abs(Jkk - Jk[i]).max() <= 4e-15 * np.abs(Jk[i]).max()
+
+
+def test_full_intrinsics_jacobian_matches_golden(oracle_lib):
+    """Groundwork for optimising the intrinsics of the 4-16 parameter cameras: d residual / d (every native parameter), against the
+    50-digit golden vectors at the reference's own test camera arrays (brown, fisheye_opencv, fisheye62, fisheye624, dual, radial,
+    simple_radial)."""
+    gold = json.load(open(GOLD))
+    used = 0
+    for c in gold:
+        if "Jk_full" not in c:
+            continue
+        res, Jk = oracle_lib.ba_project_intrinsics(c["X"], c["pose"], c["cam"], c["obs"], c["sd"], c["model"])
+        want = np.array(c["Jk_full"])
+        assert np.allclose(res, c["residual"], rtol=1e-12, atol=1e-12)
+        assert Jk.shape == want.shape and np.abs(Jk - want).max() <= 1e-11 * max(1.0, np.abs(want).max()), c["model"]
+        used += 1
+    assert used == 9
