@@ -151,6 +151,11 @@ struct DevBuf {  // frees on scope exit
 
 }  // namespace
 
+// relpose_v2.hip
+int osfm_launch_relpose_v2(osfm_ctx *ctx, const double *d_b1, const double *d_b2, const int64_t *d_off, int n_pairs, const double thr_angle,
+                           const double thr_score, int iterations, double probability, int use_lo, int lo_iterations, int refine_iterations,
+                           int mode, const double *d_stop, int *d_inl, int *d_sub, uint8_t *d_mask, void *d_out);
+
 extern "C" int osfm_pixel_bearings(osfm_ctx *ctx, int model, const double *cam, const double *px, int n, double *bearings) {
   OSFM_REQUIRE(ctx && (cam || model == OSFM_CAMERA_SPHERICAL) && (n == 0 || (px && bearings)), OSFM_E_INVALID,
                "osfm_pixel_bearings: null argument");
@@ -226,7 +231,16 @@ extern "C" int osfm_relpose_pairs(osfm_ctx *ctx, const double *b1, const double 
   const RansacParams rp{prm->threshold, 1.0 - cos(prm->threshold), (int)prm->iterations, prm->probability, (int)prm->use_lo, (int)prm->lo_iterations,
                         b0 ? atoi(b0) : kWave};
   OSFM_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
-  for (int p0 = 0; p0 < n_pairs; p0 += chunk) {
+  // OSFM_RELPOSE_V2=1: the cooperative organisation (relpose_v2.hip, relpose_coop.h) -- same results, opt-in until it has been measured
+  const char *v2 = getenv("OSFM_RELPOSE_V2");
+  const bool use_v2 = v2 && atoi(v2) != 0;
+  if (use_v2) {
+    const int rc = osfm_launch_relpose_v2(ctx, d_b1.as<double>(), d_b2.as<double>(), d_off.as<int64_t>(), n_pairs, rp.threshold_angle,
+                                          rp.threshold_score, rp.iterations, rp.probability, rp.use_lo, rp.lo_iterations, prm->refine_iterations,
+                                          mode, d_stop.as<double>(), d_inl.as<int>(), d_sub.as<int>(), d_mask.as<uint8_t>(), d_out.p);
+    if (rc != OSFM_OK) return rc;
+  }
+  for (int p0 = 0; !use_v2 && p0 < n_pairs; p0 += chunk) {
     const int np = std::min(chunk, n_pairs - p0);
     hipLaunchKernelGGL(relpose_pairs_kernel, dim3(np), dim3(kWave), 0, ctx->stream, d_b1.as<double>(), d_b2.as<double>(),
                        d_off.as<int64_t>(), p0, np, rp, prm->refine_iterations, mode, d_stop.as<double>(), d_models.as<double>(), d_inl.as<int>(),

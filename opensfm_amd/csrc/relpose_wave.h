@@ -244,18 +244,21 @@ struct MatchResult {
 };
 
 // robust_match_calibrated on bearings: LO-RANSAC, 3 x (inliers at 4, 2, 1 x threshold -> refinement), inliers.
-template <class W>
-OSFM_HD void robust_match_calibrated_wave(W& w, WaveShared& s, const PairWork& P, const RansacParams& prm, int refine_iterations,
-                                          MatchResult& out) {
+// Part 1 (before the RANSAC): the `len(matches) < 8` gate; returns 0 when the pair is rejected outright.
+OSFM_HD int robust_match_begin(const PairWork& P, MatchResult& out) {
   out.n_inliers = 0;
   for (int i = 0; i < 9; i++) out.R[i] = 0.0;
   for (int i = 0; i < 3; i++) out.t[i] = 0.0;
   if (P.n < 8) {  // matching.py:881-882
     for (int i = 0; i < 12; i++) out.ransac.model[i] = out.ransac.lo_model[i] = 0.0;
     out.ransac.best_score = out.ransac.iterations_run = 0;
-    return;
+    return 0;
   }
-  ransac_relative_pose_wave(w, s, P, prm, out.ransac);
+  return 1;
+}
+// Part 2 (after the RANSAC, which left its result in out.ransac)
+template <class W>
+OSFM_HD void robust_match_finish_wave(W& w, WaveShared& s, const PairWork& P, const RansacParams& prm, int refine_iterations, MatchResult& out) {
   double R[9], t[3];
   {  // multiview.relative_pose_ransac (multiview.py:494-516): R = R_lo^T, t = -R_lo^T t_lo
     const double* lo = out.ransac.lo_model;
@@ -286,6 +289,13 @@ OSFM_HD void robust_match_calibrated_wave(W& w, WaveShared& s, const PairWork& P
       w.compact(P.n, [&](int i) { return inlier_bearing(P.b1 + 3 * i, P.b2 + 3 * i, R, t, prm.threshold_angle) != 0; }, P.subset);
   for (int i = 0; i < 9; i++) out.R[i] = R[i];
   for (int i = 0; i < 3; i++) out.t[i] = t[i];
+}
+template <class W>
+OSFM_HD void robust_match_calibrated_wave(W& w, WaveShared& s, const PairWork& P, const RansacParams& prm, int refine_iterations,
+                                          MatchResult& out) {
+  if (!robust_match_begin(P, out)) return;
+  ransac_relative_pose_wave(w, s, P, prm, out.ransac);
+  robust_match_finish_wave(w, s, P, prm, refine_iterations, out);
 }
 
 }  // namespace osfm_rp

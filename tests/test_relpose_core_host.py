@@ -388,3 +388,95 @@ def test_gpu_bearing_tests_logic_on_the_emulation(host, oracle_lib, monkeypatch)
     monkeypatch.setattr(matching, "pixel_bearing_many", checked)
     gpu_tests.test_pixel_bearings(oracle_lib)
     gpu_tests.test_pixel_bearings_every_projection_type(oracle_lib)
+
+
+# ---- the cooperative organisation (relpose_coop.h, opt-in kernel) -----------------------------------------------------------------
+@pytest.mark.parametrize("order", [0, 1, 2])
+def test_coop_five_point_bits_in_any_item_order(host, oracle_lib, order):
+    """One minimal problem solved by the whole wavefront on shared matrices: the same doubles as the per-lane solver / the oracle,
+    whatever the order in which the items of each parallel step run (forwards, backwards, shuffled) -- i.e. no step reads what
+    another item of the same step writes."""
+    rng = np.random.default_rng(40)
+    host.host_set_item_order(order)
+    try:
+        for trial in range(150):
+            b1, b2, _ = _scene(rng, 5, outliers=0.0, noise=1e-2 if trial % 2 else 0.0)
+            ref = np.asarray(oracle_lib.essential_five_points(b1, b2))
+            Es = np.zeros(90)
+            k = host.host_essential_five_points_v2(_p(b1, C.c_double), _p(b2, C.c_double), _p(Es, C.c_double))
+            assert k == len(ref)
+            assert np.array_equal(Es[: 9 * k].view(np.uint64), ref.reshape(-1).view(np.uint64))
+        z = np.zeros((5, 3))
+        assert host.host_essential_five_points_v2(_p(z, C.c_double), _p(z, C.c_double), _p(np.zeros(90), C.c_double)) == 0
+    finally:
+        host.host_set_item_order(0)
+
+
+@pytest.mark.parametrize("order", [0, 2])
+def test_coop_ransac_and_match_bits(host, oracle_lib, order):
+    rng = np.random.default_rng(41)
+    host.host_set_item_order(order)
+    try:
+        for n, outl in ((5, 0.0), (9, 0.2), (30, 0.3), (200, 0.5), (500, 0.2), (120, 0.9)):
+            for use_lo, iters in ((1, 1000), (0, 150), (1, 37)):
+                b1, b2, _ = _scene(rng, n, outliers=outl)
+                want = oracle_lib.ransac_relative_pose(b1, b2, 0.004, iters, 0.99, bool(use_lo), 10)
+                model, lo, inl, it = np.zeros(12), np.zeros(12), np.zeros(n, np.int32), C.c_int(0)
+                score = host.host_ransac_relative_pose_v2(_p(b1, C.c_double), _p(b2, C.c_double), n, C.c_double(0.004), iters, C.c_double(0.99),
+                                                          use_lo, 10, _p(model, C.c_double), _p(lo, C.c_double), _p(inl, C.c_int32), C.byref(it))
+                assert (score, it.value) == (want["score"], want["iterations"]), (n, outl, use_lo, iters)
+                assert np.array_equal(inl[:score], want["inliers"])
+                assert np.array_equal(model.view(np.uint64), want["model"].reshape(-1).view(np.uint64))
+                assert np.array_equal(lo.view(np.uint64), want["lo_model"].reshape(-1).view(np.uint64))
+        for n, outl in ((7, 0.0), (8, 0.0), (40, 0.3), (300, 0.4), (1000, 0.6), (150, 0.97)):
+            b1, b2, good = _scene(rng, n, outliers=outl)
+            want = oracle_lib.robust_match_calibrated_bearings(b1, b2, 0.004, 1000, 0.99, True, 10, 10)
+            R, t, models, info = np.zeros(9), np.zeros(3), np.zeros(24), np.zeros(2, np.int32)
+            mask = np.zeros(n, np.uint8)
+            cnt = host.host_robust_match_calibrated_v2(_p(b1, C.c_double), _p(b2, C.c_double), n, C.c_double(0.004), 1000, C.c_double(0.99), 1, 10, 10,
+                                                       _p(R, C.c_double), _p(t, C.c_double), _p(mask, C.c_uint8), _p(models, C.c_double),
+                                                       _p(info, C.c_int32))
+            assert cnt == want["mask"].sum() and np.array_equal(mask.astype(bool), want["mask"])
+            assert (int(info[0]), int(info[1])) == (want["score"], want["iterations"])
+            if cnt:
+                assert np.array_equal(R.view(np.uint64), want["R"].reshape(-1).view(np.uint64))
+    finally:
+        host.host_set_item_order(0)
+
+
+def test_gpu_v2_test_logic_on_the_emulation(host, oracle_lib, monkeypatch):
+    """tests/test_gpu_zz_relpose.py::test_cooperative_organisation_gives_the_same_results with relpose_pairs served by the host
+    emulation of relpose_coop.h"""
+    from opensfm_amd import matching
+
+    import test_gpu_zz_relpose as gpu_tests
+
+    def relpose_pairs(b1, b2, offsets, threshold, mode="match", iterations=1000, probability=0.99, use_lo=True, lo_iterations=10,
+                      refine_iterations=10, ctx=None):
+        assert os.environ.get("OSFM_RELPOSE_V2") == "1"
+        res, mask = [], np.zeros(len(b1), bool)
+        for p in range(len(offsets) - 1):
+            s = slice(int(offsets[p]), int(offsets[p + 1]))
+            x, y = np.ascontiguousarray(b1[s]), np.ascontiguousarray(b2[s])
+            n = len(x)
+            if mode == "ransac":
+                model, lo, inl, it = np.zeros(12), np.zeros(12), np.zeros(max(n, 1), np.int32), C.c_int(0)
+                sc = host.host_ransac_relative_pose_v2(_p(x, C.c_double), _p(y, C.c_double), n, C.c_double(threshold), iterations,
+                                                       C.c_double(probability), int(use_lo), lo_iterations, _p(model, C.c_double),
+                                                       _p(lo, C.c_double), _p(inl, C.c_int32), C.byref(it))
+                m = np.zeros(n, bool)
+                m[inl[:sc]] = True
+                mask[s] = m
+                res.append({"score": sc, "iterations": it.value, "model": model.reshape(3, 4), "lo_model": lo.reshape(3, 4), "n_inliers": sc})
+            else:
+                R, t, models, info = np.zeros(9), np.zeros(3), np.zeros(24), np.zeros(2, np.int32)
+                mk = np.zeros(max(n, 1), np.uint8)
+                c = host.host_robust_match_calibrated_v2(_p(x, C.c_double), _p(y, C.c_double), n, C.c_double(threshold), iterations,
+                                                         C.c_double(probability), int(use_lo), lo_iterations, refine_iterations, _p(R, C.c_double),
+                                                         _p(t, C.c_double), _p(mk, C.c_uint8), _p(models, C.c_double), _p(info, C.c_int32))
+                mask[s] = mk[:n].astype(bool)
+                res.append({"score": int(info[0]), "iterations": int(info[1]), "n_inliers": c, "R": R.reshape(3, 3), "t": t})
+        return res, mask, 0.0
+
+    monkeypatch.setattr(matching, "relpose_pairs", relpose_pairs)
+    gpu_tests.test_cooperative_organisation_gives_the_same_results(oracle_lib, monkeypatch)
