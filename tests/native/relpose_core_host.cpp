@@ -73,6 +73,23 @@ extern "C" {
 
 void host_set_item_order(int order) { g_order = order; }
 
+// real eigenvalues of a general 10 x 10: per-lane routine (which = 0) or the cooperative one (which = 1)
+int host_real_eigenvalues10(const double* a_in, int which, double* wr) {
+  if (which == 0) {
+    double a[100];
+    memcpy(a, a_in, sizeof(a));
+    return real_eigenvalues10(a, wr);
+  }
+  OrderWave w;
+  CoopShared* c = new CoopShared;
+  memset(c, 0xff, sizeof(CoopShared));
+  memcpy(c->Aq, a_in, sizeof(double) * 100);
+  const int n = real_eigenvalues10_coop(w, *c, c->Aq);
+  memcpy(wr, c->wr, sizeof(double) * (size_t)n);
+  delete c;
+  return n;
+}
+
 int host_essential_five_points_v2(const double* b1, const double* b2, double* Es) {
   OrderWave w;
   CoopShared* c = new CoopShared;

@@ -480,3 +480,36 @@ def test_gpu_v2_test_logic_on_the_emulation(host, oracle_lib, monkeypatch):
 
     monkeypatch.setattr(matching, "relpose_pairs", relpose_pairs)
     gpu_tests.test_cooperative_organisation_gives_the_same_results(oracle_lib, monkeypatch)
+
+
+@pytest.mark.parametrize("order", [0, 1, 2])
+def test_coop_hessenberg_qr_bits_on_general_matrices(host, order):
+    """The cooperative Hessenberg-QR against the per-lane routine on matrices the five-point solver rarely produces: random dense and
+    sparse ones, companion matrices with clustered roots, and cyclic shifts (eigenvalues on the unit circle: the textbook case that
+    needs the exceptional shifts at iterations 10 and 20)."""
+    rng = np.random.default_rng(50)
+    mats = [rng.normal(0, 1, (10, 10)) for _ in range(300)]
+    mats += [rng.normal(0, 1, (10, 10)) * (rng.random((10, 10)) < 0.3) for _ in range(300)]
+    for _ in range(100):  # companion matrices of polynomials with clustered real roots
+        roots = np.r_[np.full(4, rng.normal()), rng.normal(0, 1, 6)] + rng.normal(0, 1e-6, 10)
+        comp = np.zeros((10, 10))
+        comp[0] = -np.poly(roots)[1:]
+        comp[np.arange(1, 10), np.arange(9)] = 1.0
+        mats.append(comp)
+    shift = np.roll(np.eye(10), 1, axis=0)
+    mats += [shift, shift.T, 2.5 * shift, shift + 1e-9 * rng.normal(0, 1, (10, 10)), np.zeros((10, 10)), np.eye(10), np.triu(rng.normal(0, 1, (10, 10)))]
+    host.host_set_item_order(order)
+    try:
+        slow = 0
+        for idx, M in enumerate(mats):
+            a = np.ascontiguousarray(M, np.float64)
+            w0, w1 = np.zeros(10), np.zeros(10)
+            n0 = host.host_real_eigenvalues10(_p(a, C.c_double), 0, _p(w0, C.c_double))
+            n1 = host.host_real_eigenvalues10(_p(a, C.c_double), 1, _p(w1, C.c_double))
+            assert n0 == n1 and np.array_equal(w0[:n0].view(np.uint64), w1[:n1].view(np.uint64))
+            if idx < 300:  # dense random matrices, well-separated spectra: the count of real eigenvalues must agree with LAPACK's
+                ev = np.linalg.eigvals(M)
+                slow += n0 != int((np.abs(ev.imag) < 1e-9).sum())
+        assert slow == 0
+    finally:
+        host.host_set_item_order(0)
