@@ -181,7 +181,7 @@ def main():
             out["tracks"] = tracks_bench(ctx, scene, pairs_gathered, graph, not args.no_cpu_baseline)
         if not args.no_ba:
             try:
-                from opensfm_amd import ba_bench
+                import bench_ba as ba_bench
 
                 out["ba"] = ba_bench.run(ctx, args.ba_shots, args.ba_points, args.ba_track, args.ba_iters,
                                          cpu_baseline=not args.no_cpu_baseline)

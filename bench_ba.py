@@ -1,12 +1,13 @@
 """Second half of the headline metric: LM iterations / s of global BA at BASELINE.json configs[4]
-(5 000 cameras / 500 000 points / 5 000 000 observations) on one MI355X, next to the CPU oracle."""
+(5 000 cameras / 500 000 points / 5 000 000 observations) on one MI355X, next to the CPU oracle.
+A leg of bench.py (kept outside the product package: it times the oracle as the CPU baseline)."""
 from __future__ import annotations
 
 import time
 
 import numpy as np
 
-from . import bundle, synthetic
+from opensfm_amd import bundle, synthetic
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 MATVEC_BYTES_PER_OBS = 288.0  # stored point+pose blocks (144 B) read twice per Schur mat-vec

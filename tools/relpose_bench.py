@@ -2,9 +2,9 @@
 calibrated robust matching (osfm_relpose_pairs, MATCH mode) in pairs / s and guided matching (osfm_match_guided) in pairs / s,
 each next to the CPU oracle on a bounded sample.
 
-    python -m opensfm_amd.relpose_bench [--pairs 2048] [--matches 300] [--outliers 0.4] [--features 2000]
+    python tools/relpose_bench.py [--pairs 2048] [--matches 300] [--outliers 0.4] [--features 2000]
 
-Meant for `rocprofv3 --kernel-trace --stats -- python -m opensfm_amd.relpose_bench`: the kernels are relpose_pairs_kernel and
+Meant for `rocprofv3 --kernel-trace --stats -- python tools/relpose_bench.py`: the kernels are relpose_pairs_kernel and
 guided_match_kernel.  Algorithmic work: ~150 fp64 operations per (model, correspondence) score evaluation,
 ~6 models per iteration; the fp64 vector peak is ~78.6 TFLOP/s."""
 from __future__ import annotations
@@ -15,8 +15,12 @@ import time
 
 import numpy as np
 
-from . import matching
-from ._lib import default_context
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from opensfm_amd import matching  # noqa: E402
+from opensfm_amd._lib import default_context  # noqa: E402
 
 FP64_PEAK_TFLOPS = 78.6
 SCORE_FLOPS = 150.0
