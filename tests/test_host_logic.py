@@ -103,3 +103,19 @@ def test_shot_renumbering_restores_the_band_of_a_shuffled_sequence():
         s = new_shot[obs_point == p]
         span[p] = s.max() - s.min()
     assert span.max() == b1.value
+
+
+def test_product_package_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under opensfm_amd/ (Python or HIP sources) may import, include or load it."""
+    import os
+    import re
+
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "opensfm_amd")
+    offenders = []
+    for dirpath, _, files in os.walk(root):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".sh")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                if re.search(r"^\s*(import|from)\s+oracle\b|liboracle|oracle/[a-z_]+\.(c|so)\b.*#include|#include\s+\"[^\"]*oracle", text, re.M):
+                    offenders.append(os.path.join(dirpath, f))
+    assert offenders == []
