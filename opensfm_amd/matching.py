@@ -500,20 +500,26 @@ def match_images_with_pairs(data, config_override: Dict[str, Any], exifs: Dict[s
 # --------------------------------------------------------------------------------------------
 # the match graph on disk (``dataset.py:344-392``, ``matching.py:128-157``)
 # --------------------------------------------------------------------------------------------
+def _owner_of_pair(im1: str, im2: str, reference_images) -> Tuple[str, str]:
+    """(image whose matches file stores the pair, the other image): the first image when it is a reference image, else the second
+    (``matching.py:139-150``); raises like the reference when neither is."""
+    if im1 in reference_images:
+        return im1, im2
+    if im2 in reference_images:
+        return im2, im1
+    raise RuntimeError("Couldn't save matches for {}. No image found in images_ref.".format((im1, im2)))
+
+
 def save_matches(data, images_ref: Sequence[str], matched_pairs: Dict[Tuple[str, str], Any]) -> None:
-    """Given pairwise matches (image 1, image 2) -> matches, save them such as only {image E images_ref} will store the matches
-    (``matching.py:128-157``): groups the pairs per reference image and calls ``data.save_matches(image, {other: matches})``."""
-    images_ref_set = set(images_ref)
-    matches_per_im1: Dict[str, Dict[str, Any]] = {im: {} for im in images_ref}
+    """``matching.save_matches`` (``matching.py:128-157``): one ``data.save_matches(image, {other image: matches})`` call per reference
+    image, every pair filed under the reference image that owns it (also the reference images that own nothing get their call)."""
+    reference_images = set(images_ref)
+    per_image: Dict[str, Dict[str, Any]] = {im: {} for im in images_ref}
     for (im1, im2), m in matched_pairs.items():
-        if im1 in images_ref_set:
-            matches_per_im1[im1][im2] = m
-        elif im2 in images_ref_set:
-            matches_per_im1[im2][im1] = m
-        else:
-            raise RuntimeError("Couldn't save matches for {}. No image found in images_ref.".format((im1, im2)))
-    for im1, im1_matches in matches_per_im1.items():
-        data.save_matches(im1, im1_matches)
+        owner, other = _owner_of_pair(im1, im2, reference_images)
+        per_image[owner][other] = m
+    for image, its_matches in per_image.items():
+        data.save_matches(image, its_matches)
 
 
 def write_matches_files(data_path: str, images: Sequence[str], pairs: np.ndarray, counts: np.ndarray, matches: np.ndarray,
@@ -532,13 +538,8 @@ def write_matches_files(data_path: str, images: Sequence[str], pairs: np.ndarray
     per_image: Dict[str, Dict[str, np.ndarray]] = {im: {} for im in ref}
     for (a, b), m in zip(np.asarray(pairs).reshape(-1, 2), split_matches(np.asarray(counts), np.asarray(matches).reshape(-1, 2))):
         im1, im2 = images[int(a)], images[int(b)]
-        value = np.array(m, dtype=int) if len(m) else np.array([])
-        if im1 in ref_set:
-            per_image[im1][im2] = value
-        elif im2 in ref_set:
-            per_image[im2][im1] = value
-        else:
-            raise RuntimeError("Couldn't save matches for {}. No image found in images_ref.".format((im1, im2)))
+        owner, other = _owner_of_pair(im1, im2, ref_set)
+        per_image[owner][other] = np.array(m, dtype=int) if len(m) else np.array([])
     out_dir = os.path.join(data_path, "matches")
     os.makedirs(out_dir, exist_ok=True)
     written = []
