@@ -455,36 +455,37 @@ def match_images_with_pairs(data, config_override: Dict[str, Any], exifs: Dict[s
         descs.append(desc)
         pts.append(points)
         masks.append(mask)
-    store = DescriptorStore(descs, pts)
-    try:
-        ipairs = np.asarray([(index[a], index[b]) for a, b in pairs], np.int32).reshape(-1, 2)
-        pin = np.array([_is_pinhole(cams[a]) and _is_pinhole(cams[b]) for a, b in ipairs], bool)
-        per_pair: List[np.ndarray] = [np.zeros((0, 2), np.int32)] * len(ipairs)
-        if poses:  # guided matching (matching.py:204-207,260-337,576-634): one pair at a time, first-correct route
-            bearings = [pixel_bearing_many(cams[k], np.asarray(pts[k], np.float64)[:, :2], store.ctx) if len(pts[k]) else np.zeros((0, 3))
-                        for k in range(len(images))]
-            min_match = int(_cfg(config, "robust_matching_min_match"))
-            for p, ((im1, im2), (a, b)) in enumerate(zip(pairs, ipairs)):
-                if len(pts[a]) < 2 or len(pts[b]) < 2:
-                    continue
-                rel = poses[im2].relative_to(poses[im1])
-                m = match_guided(descs[a], descs[b], bearings[a], bearings[b], rel, config, store.ctx)
-                if len(m) < min_match:
-                    continue
-                rm = np.asarray(robust_match(pts[a], pts[b], cams[a], cams[b], m, config))
-                if len(rm) >= min_match and len(rm) > 0:
-                    per_pair[p] = rm.astype(np.int32)
-            pin = np.zeros(len(ipairs), bool)
-        elif pin.any():
-            counts, matches = match_pairs(store, ipairs[pin], config, robust=True)
-            for p, m in zip(np.flatnonzero(pin), split_matches(counts, matches)):
-                per_pair[p] = m
-        if not poses and (~pin).any():
-            counts, matches = match_pairs_calibrated(store, ipairs[~pin], cams, pts, config)
-            for p, m in zip(np.flatnonzero(~pin), split_matches(counts, matches)):
-                per_pair[p] = m
-    finally:
-        store.close()
+    ipairs = np.asarray([(index[a], index[b]) for a, b in pairs], np.int32).reshape(-1, 2)
+    per_pair: List[np.ndarray] = [np.zeros((0, 2), np.int32)] * len(ipairs)
+    if poses:  # guided matching (matching.py:204-207,260-337,576-634): one pair at a time from host buffers, first-correct route
+        ctx = default_context()
+        bearings = [pixel_bearing_many(cams[k], np.asarray(pts[k], np.float64)[:, :2], ctx) if len(pts[k]) else np.zeros((0, 3))
+                    for k in range(len(images))]
+        min_match = int(_cfg(config, "robust_matching_min_match"))
+        for p, ((im1, im2), (a, b)) in enumerate(zip(pairs, ipairs)):
+            if len(pts[a]) < 2 or len(pts[b]) < 2:
+                continue
+            rel = poses[im2].relative_to(poses[im1])
+            m = match_guided(descs[a], descs[b], bearings[a], bearings[b], rel, config, ctx)
+            if len(m) < min_match:
+                continue
+            rm = np.asarray(robust_match(pts[a], pts[b], cams[a], cams[b], m, config))
+            if len(rm) >= min_match and len(rm) > 0:
+                per_pair[p] = rm.astype(np.int32)
+    else:
+        store = DescriptorStore(descs, pts)  # all descriptors resident in HBM for the batched launches
+        try:
+            pin = np.array([_is_pinhole(cams[a]) and _is_pinhole(cams[b]) for a, b in ipairs], bool)
+            if pin.any():
+                counts, matches = match_pairs(store, ipairs[pin], config, robust=True)
+                for p, m in zip(np.flatnonzero(pin), split_matches(counts, matches)):
+                    per_pair[p] = m
+            if (~pin).any():
+                counts, matches = match_pairs_calibrated(store, ipairs[~pin], cams, pts, config)
+                for p, m in zip(np.flatnonzero(~pin), split_matches(counts, matches)):
+                    per_pair[p] = m
+        finally:
+            store.close()
     out: Dict[Tuple[str, str], np.ndarray] = {}
     for (im1, im2), m in zip(pairs, per_pair):
         if len(m) == 0:

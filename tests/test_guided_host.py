@@ -152,5 +152,6 @@ def test_gpu_guided_tests_logic_on_the_emulation(host, oracle_lib, monkeypatch):
     monkeypatch.setattr(matching, "pixel_bearing_many", bearings)
     monkeypatch.setattr(matching, "relpose_pairs", relpose_pairs)
     monkeypatch.setattr(matching, "DescriptorStore", FakeStore)
+    monkeypatch.setattr(matching, "default_context", lambda device=None: None)
     gpu_tests.test_masked_and_guided_leaf(oracle_lib)
     gpu_tests.test_guided_match_images_with_pairs(oracle_lib)

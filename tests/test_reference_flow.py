@@ -315,6 +315,7 @@ def test_match_flow_equals_the_product_host_flow(ref, oracle_lib, monkeypatch, g
         return F, mask.astype(np.uint8).reshape(-1, 1)
 
     monkeypatch.setattr(product, "DescriptorStore", FakeStore)
+    monkeypatch.setattr(product, "default_context", lambda device=None: None)
     monkeypatch.setattr(product, "match_pairs", fake_match_pairs)
     monkeypatch.setattr(product, "pixel_bearing_many", bearings)
     monkeypatch.setattr(product, "relpose_pairs", relpose_pairs)
