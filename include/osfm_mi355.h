@@ -66,8 +66,15 @@ typedef struct {
   double robust_matching_threshold;  /* 0.004                                  (config.py:191) */
   double ransac_confidence;          /* 0.9999 (matching.py:795)                               */
   int32_t ransac_max_iters;          /* 1000 (cv2.findFundamentalMat default)                  */
-  int32_t reserved;                  /* bit 0 (debug): run every pair on the exact VALU kernel */
+  int32_t flags;                     /* OSFM_MATCH_* bits below                                 */
 } osfm_match_params;
+#define OSFM_MATCH_EXACT_KERNEL 1  /* cross-check: run every pair on the exact VALU kernel (float keys, no MFMA)          */
+#define OSFM_MATCH_SQUARED_RATIO 2 /* matcher_type FLANN semantics on an EXACT 2-NN search: match_flann[_symmetric]
+                                      (matching.py:683-720) keeps d0 < float32(lowes_ratio^2) * d1 on SQUARED float32
+                                      distances; one-way matching then queries with the pair's SECOND image against the
+                                      first (match_flann(index1, f2)) and lists the matches in query order.  The
+                                      reference's own index (cv2.flann_Index, KMEANS, checks=20, features.py:638-674) is
+                                      approximate and randomised; this is its exact limit (checks -> infinity). */
 
 void osfm_match_params_default(osfm_match_params *p);
 
@@ -100,12 +107,16 @@ void osfm_result_destroy(osfm_match_result *r);
 
 /*
  * Leaf: one pair from host buffers.  Drop-in for match_brute_force (symmetric = 0,
- * matching.py:723-756) and match_brute_force_symmetric (symmetric = 1, matching.py:759-777).
+ * matching.py:723-756) and match_brute_force_symmetric (symmetric = 1, matching.py:759-777);
+ * osfm_match_l2_ratio_ex with flags = OSFM_MATCH_SQUARED_RATIO for match_flann / match_flann_symmetric
+ * (matching.py:683-720) on an exact search.
  * A: nA x dim, B: nB x dim float32 (integer-valued, dim must be 128).
  * out_pairs: cap x 2 int32, *out_n = number found (may exceed cap; only cap are written).
  */
 int osfm_match_l2_ratio(osfm_ctx *ctx, const float *A, int nA, const float *B, int nB, int dim,
                         double ratio, int symmetric, int32_t *out_pairs, int cap, int *out_n);
+int osfm_match_l2_ratio_ex(osfm_ctx *ctx, const float *A, int nA, const float *B, int nB, int dim,
+                           double ratio, int symmetric, int flags, int32_t *out_pairs, int cap, int *out_n);
 
 /*
  * Leaf: cv2.findFundamentalMat(p1, p2, FM_RANSAC, thr, conf) as used by

@@ -26,7 +26,7 @@ class MatchParams(C.Structure):
         ("robust_matching_threshold", C.c_double),
         ("ransac_confidence", C.c_double),
         ("ransac_max_iters", C.c_int32),
-        ("reserved", C.c_int32),
+        ("flags", C.c_int32),
     ]
 
 
@@ -101,6 +101,11 @@ SIGNATURES = {
         [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_double, C.c_int,
          C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int)],
     ),
+    "osfm_match_l2_ratio_ex": (
+        C.c_int,
+        [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
+         C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int)],
+    ),
     "osfm_pixel_bearings": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double)]),
     "osfm_relpose_pairs": (
         C.c_int,
@@ -160,7 +165,11 @@ def check(status: int, what: str = "") -> None:
         raise OsfmError(f"{what or 'osfm call'} failed ({status}): {msg.decode() if msg else ''}")
 
 
-_ctx_by_device = {}
+_tls = threading.local()
+
+MAX_FEATURES = 8192      # OSFM_MAX_FEATURES
+MATCH_EXACT_KERNEL = 1   # OSFM_MATCH_EXACT_KERNEL
+MATCH_SQUARED_RATIO = 2  # OSFM_MATCH_SQUARED_RATIO
 
 
 class Context:
@@ -187,13 +196,17 @@ class Context:
 
 
 def default_context(device: Optional[int] = None) -> Context:
-    """Process-wide context for `device` (default: LOCAL_RANK or 0)."""
+    """The calling THREAD's context for `device` (default: LOCAL_RANK or 0).
+
+    The reference calls the leaf functions from a joblib thread pool (``opensfm/context.py:47-67``); a context owns one HIP
+    stream, its events and the buffers of the call in flight, so every thread gets its own (the C library additionally
+    serialises calls that share a context, ``osfm_ctx::mu``)."""
     if device is None:
         device = int(os.environ.get("LOCAL_RANK", "0"))
-    with _lock:
-        ctx = _ctx_by_device.get(device)
+    by_device = getattr(_tls, "ctx", None)
+    if by_device is None:
+        by_device = _tls.ctx = {}
+    ctx = by_device.get(device)
     if ctx is None:
-        ctx = Context(device)
-        with _lock:
-            _ctx_by_device[device] = ctx
+        ctx = by_device[device] = Context(device)
     return ctx

@@ -57,6 +57,7 @@ extern "C" int osfm_ctx_num_cus(const osfm_ctx *c) { return c ? c->num_cus : 0; 
 extern "C" int osfm_store_create(osfm_ctx *ctx, int n_images, const int32_t *counts, osfm_store **out) {
   OSFM_REQUIRE(ctx && counts && out, OSFM_E_INVALID, "osfm_store_create: null argument");
   OSFM_REQUIRE(n_images >= 0, OSFM_E_INVALID, "n_images < 0");
+  OSFM_CTX_LOCK(ctx);
   *out = nullptr;
   osfm_store *s = new (std::nothrow) osfm_store();
   OSFM_REQUIRE(s != nullptr, OSFM_E_NOMEM, "out of host memory");
@@ -112,6 +113,7 @@ extern "C" int64_t osfm_store_bytes(const osfm_store *s) { return s ? s->bytes :
 template <typename T>
 static int store_upload(osfm_store *s, const T *desc, const double *pts) {
   OSFM_REQUIRE(s && desc && pts, OSFM_E_INVALID, "osfm_store_upload: null argument");
+  OSFM_CTX_LOCK(s->ctx);
   (void)hipSetDevice(s->ctx->device);
   const int64_t nt = s->tile_off[s->n_images] + 4;
   std::vector<int8_t> tiles((size_t)nt * OSFM_TILE_BYTES, 0);
@@ -172,7 +174,7 @@ extern "C" void osfm_match_params_default(osfm_match_params *p) {
   p->robust_matching_threshold = 0.004;
   p->ransac_confidence = 0.9999;
   p->ransac_max_iters = 1000;
-  p->reserved = 0;
+  p->flags = 0;
 }
 
 namespace {
@@ -213,6 +215,7 @@ extern "C" int osfm_match_pairs(osfm_ctx *ctx, const osfm_store *store, const in
   for (int64_t k = 0; k < 2 * n_pairs; ++k)
     OSFM_REQUIRE(pairs[k] >= 0 && pairs[k] < store->n_images, OSFM_E_INVALID, "pair %lld references image %d (store has %d)",
                  (long long)(k / 2), pairs[k], store->n_images);
+  OSFM_CTX_LOCK(ctx);
   OSFM_HIP(hipSetDevice(ctx->device));
   if (tm) memset(tm, 0, sizeof(*tm));
 
@@ -254,11 +257,6 @@ extern "C" int osfm_match_pairs(osfm_ctx *ctx, const osfm_store *store, const in
   } sb;
   OSFM_HIP(hipStreamCreateWithFlags(&sb.s, hipStreamNonBlocking));
   hipStream_t stA = ctx->stream, stB = sb.s;
-  struct StreamSwap {  // the launch helpers use ctx->stream
-    osfm_ctx *c;
-    hipStream_t orig;
-    ~StreamSwap() { c->stream = orig; }
-  } swap_guard{ctx, stA};
 
   osfm_match_result *res = new (std::nothrow) osfm_match_result();
   OSFM_REQUIRE(res != nullptr, OSFM_E_NOMEM, "out of host memory");
@@ -275,25 +273,24 @@ extern "C" int osfm_match_pairs(osfm_ctx *ctx, const osfm_store *store, const in
   auto enqueue_match = [&](int64_t k) -> int {  // stream A: pairs H2D + fused matcher (+ rare exact re-run)
     ChunkSet &S = sets[k & 1];
     const int64_t p0 = k * cp, np = (n_pairs - p0) < cp ? (n_pairs - p0) : cp;
-    ctx->stream = stA;
     OSFM_HIP(hipMemcpyAsync(S.pairs.p, pairs + 2 * p0, (size_t)np * 2 * sizeof(int32_t), hipMemcpyHostToDevice, stA));
     OSFM_HIP(hipEventRecord(S.m0, stA));
     int rc;
-    if (params->reserved & 1) {
+    if (params->flags & OSFM_MATCH_EXACT_KERNEL) {
       // debug/cross-check mode: every pair on the exact VALU kernel
       OSFM_HIP(hipMemsetAsync(S.flags.p, 0, (size_t)np * sizeof(int32_t), stA));
-      rc = osfm_launch_match(ctx, store, S.pairs.as<int32_t>(), np, params->lowes_ratio, params->symmetric, cap,
-                             S.counts.as<int32_t>(), S.matches.as<uint32_t>(), nullptr, true);
+      rc = osfm_launch_match(ctx, store, S.pairs.as<int32_t>(), np, params->lowes_ratio, params->symmetric, (params->flags & OSFM_MATCH_SQUARED_RATIO) ? 1 : 0, cap,
+                             S.counts.as<int32_t>(), S.matches.as<uint32_t>(), nullptr, true, stA);
       if (rc != OSFM_OK) return rc;
       OSFM_HIP(hipEventRecord(S.m1, stA));
     } else {
-      rc = osfm_launch_match(ctx, store, S.pairs.as<int32_t>(), np, params->lowes_ratio, params->symmetric, cap,
-                             S.counts.as<int32_t>(), S.matches.as<uint32_t>(), S.flags.as<int32_t>(), false);
+      rc = osfm_launch_match(ctx, store, S.pairs.as<int32_t>(), np, params->lowes_ratio, params->symmetric, (params->flags & OSFM_MATCH_SQUARED_RATIO) ? 1 : 0, cap,
+                             S.counts.as<int32_t>(), S.matches.as<uint32_t>(), S.flags.as<int32_t>(), false, stA);
       if (rc != OSFM_OK) return rc;
       OSFM_HIP(hipEventRecord(S.m1, stA));
       // rare exact path: pairs whose second-nearest d^2 >= 2^22 (sqrtf is not injective there)
-      rc = osfm_launch_match(ctx, store, S.pairs.as<int32_t>(), np, params->lowes_ratio, params->symmetric, cap,
-                             S.counts.as<int32_t>(), S.matches.as<uint32_t>(), S.flags.as<int32_t>(), true);
+      rc = osfm_launch_match(ctx, store, S.pairs.as<int32_t>(), np, params->lowes_ratio, params->symmetric, (params->flags & OSFM_MATCH_SQUARED_RATIO) ? 1 : 0, cap,
+                             S.counts.as<int32_t>(), S.matches.as<uint32_t>(), S.flags.as<int32_t>(), true, stA);
       if (rc != OSFM_OK) return rc;
     }
     OSFM_HIP(hipEventRecord(S.r0, stA));  // everything of the descriptor stage is enqueued
@@ -311,14 +308,13 @@ extern "C" int osfm_match_pairs(osfm_ctx *ctx, const osfm_store *store, const in
       const int rc1 = enqueue_match(k + 1);
       if (rc1 != OSFM_OK) return rc1;
     }
-    ctx->stream = stB;
     OSFM_HIP(hipStreamWaitEvent(stB, S.r0, 0));
     hipEvent_t rb0 = ctx->ev[3], rb1 = ctx->ev[4];
     OSFM_HIP(hipEventRecord(rb0, stB));
     if (params->robust) {
       const int rc = osfm_launch_ransac_pairs(ctx, store, S.pairs.as<int32_t>(), np, cap, params->robust_matching_min_match,
                                               params->robust_matching_threshold, params->ransac_confidence,
-                                              params->ransac_max_iters, S.counts.as<int32_t>(), S.matches.as<uint32_t>(), nullptr);
+                                              params->ransac_max_iters, S.counts.as<int32_t>(), S.matches.as<uint32_t>(), nullptr, stB);
       if (rc != OSFM_OK) return rc;
     }
     OSFM_HIP(hipEventRecord(rb1, stB));
@@ -359,7 +355,6 @@ extern "C" int osfm_match_pairs(osfm_ctx *ctx, const osfm_store *store, const in
       tm->match_launches += 1;
     }
   }
-  ctx->stream = stA;
   OSFM_HIP(hipEventRecord(ctx->ev[5], stA));
   OSFM_HIP(hipStreamSynchronize(stA));
   if (tm) {
@@ -388,10 +383,16 @@ extern "C" void osfm_result_destroy(osfm_match_result *r) { delete r; }
 // Leaf: one pair from host buffers (matching.py:723-777).
 extern "C" int osfm_match_l2_ratio(osfm_ctx *ctx, const float *A, int nA, const float *B, int nB, int dim, double ratio,
                                    int symmetric, int32_t *out_pairs, int cap, int *out_n) {
+  return osfm_match_l2_ratio_ex(ctx, A, nA, B, nB, dim, ratio, symmetric, 0, out_pairs, cap, out_n);
+}
+
+extern "C" int osfm_match_l2_ratio_ex(osfm_ctx *ctx, const float *A, int nA, const float *B, int nB, int dim, double ratio,
+                                      int symmetric, int flags, int32_t *out_pairs, int cap, int *out_n) {
   OSFM_REQUIRE(ctx && out_n && (out_pairs || cap == 0), OSFM_E_INVALID, "osfm_match_l2_ratio: null argument");
   OSFM_REQUIRE(dim == OSFM_DESC_DIM, OSFM_E_UNSUPPORTED, "descriptor dim %d (only 128 is implemented)", dim);
   OSFM_REQUIRE(nA >= 0 && nB >= 0 && (A || nA == 0) && (B || nB == 0), OSFM_E_INVALID, "bad descriptor arrays");
   *out_n = 0;
+  OSFM_CTX_LOCK(ctx);
   if (nA < 2 || nB < 2) return OSFM_OK;  // knnMatch returns < 2 neighbours -> no match (matching.py:750)
   const int32_t counts[2] = {nA, nB};
   osfm_store *st = nullptr;
@@ -408,6 +409,7 @@ extern "C" int osfm_match_l2_ratio(osfm_ctx *ctx, const float *A, int nA, const 
     osfm_match_params_default(&prm);
     prm.lowes_ratio = ratio;
     prm.symmetric = symmetric;
+    prm.flags = flags;
     prm.robust = 0;
     const int32_t pair[2] = {0, 1};
     rc = osfm_match_pairs(ctx, st, pair, 1, &prm, &res, nullptr);

@@ -2418,6 +2418,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
   OSFM_REQUIRE(O->loss >= 0 && O->loss <= 3, OSFM_E_INVALID, "unknown loss %d (bundle_adjuster.cc:427 throws)", O->loss);
   const auto t_start = std::chrono::steady_clock::now();
   memset(Rp, 0, sizeof(*Rp));
+  OSFM_CTX_LOCK(ctx);
   OSFM_HIP(hipSetDevice(ctx->device));
   const int S = P->n_shots, NP = P->n_points, NC = P->n_cameras;
   const long M = P->n_obs;
@@ -2663,6 +2664,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     if (gmax <= O->gradient_tolerance) { Rp->termination = 2; break; }
     if (radius < 1e-32) { Rp->termination = 4; break; }
     iter++;
+    if (iter < 256) Rp->cost_history[iter] = cost;  // every exit below (tolerances, invalid step) leaves the slot of this iteration defined
     const auto t_lin = std::chrono::steady_clock::now();
     // ---- linear solve: PCG on the implicit Schur complement ----
     hipLaunchKernelGGL(point_hhat_kernel, dim3(nblk(NP)), dim3(TPB), 0, st, d, radius);
@@ -2682,13 +2684,16 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
         OSFM_HIP(hipMemsetAsync(d.bE, 0, (size_t)N * n2 * sizeof(double), st));
         hipLaunchKernelGGL(bcr_pad_kernel, dim3(1), dim3(64), 0, st, d);
         hipLaunchKernelGGL(bcr_scatter_kernel, dim3(S), dim3(TPB), 0, st, d);
-        static bool bcr_attr = false;
-        if (!bcr_attr) {
-          for (int q = 2; q <= 10; q++) {
-            OSFM_HIP(hipFuncSetAttribute((const void *)bcr_elim_for(q), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            OSFM_HIP(hipFuncSetAttribute((const void *)bcr_update_for(q), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-          }
-          bcr_attr = true;
+        {
+          static OsfmPerDeviceOnce once;
+          const int rca = once.run(ctx->device, []() -> int {
+            for (int q = 2; q <= 10; q++) {
+              OSFM_HIP(hipFuncSetAttribute((const void *)bcr_elim_for(q), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+              OSFM_HIP(hipFuncSetAttribute((const void *)bcr_update_for(q), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            }
+            return OSFM_OK;
+          });
+          if (rca != OSFM_OK) return rca;
         }
         OSFM_HIP(hipMemsetAsync(d_status, 0, sizeof(int), st));
         for (int stq = 1; stq < N; stq *= 2) {
@@ -2751,10 +2756,13 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
         }
       }
       if (!sv.use_bcr) {
-      static bool chol_attr = false;
-      if (!chol_attr) {
-        OSFM_HIP(hipFuncSetAttribute((const void *)band_cholesky_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        chol_attr = true;
+      {
+        static OsfmPerDeviceOnce once;
+        const int rca = once.run(ctx->device, []() -> int {
+          OSFM_HIP(hipFuncSetAttribute((const void *)band_cholesky_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+          return OSFM_OK;
+        });
+        if (rca != OSFM_OK) return rca;
       }
       hipLaunchKernelGGL(band_cholesky_kernel, dim3(1), dim3(64), (size_t)((kMaxBw + 1) * R * 36 + (kMaxBw + 1) * 36 + 72) * sizeof(double), st, d, d_status);
       int hstatus = 1;
@@ -2768,10 +2776,13 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
         OSFM_HIP(hipMemsetAsync(d.cWt, 0, (size_t)(d.ncl + 1) * n2 * sizeof(double), st));
         hipLaunchKernelGGL(ctri_pad_kernel, dim3(1), dim3(64), 0, st, d);
         hipLaunchKernelGGL(ctri_scatterL_kernel, dim3(S), dim3(TPB), 0, st, d);
-        static bool ctri_attr = false;
-        if (!ctri_attr) {
-          OSFM_HIP(hipFuncSetAttribute((const void *)ctri_inverse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-          ctri_attr = true;
+        {
+          static OsfmPerDeviceOnce once;
+          const int rca = once.run(ctx->device, []() -> int {
+            OSFM_HIP(hipFuncSetAttribute((const void *)ctri_inverse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            return OSFM_OK;
+          });
+          if (rca != OSFM_OK) return rca;
         }
         hipLaunchKernelGGL(ctri_inverse_kernel, dim3(d.ncl), dim3(64), 2 * n2 * sizeof(double), st, d);
         sv.use_ctri = true;

@@ -129,6 +129,7 @@ extern "C" int osfm_match_guided(osfm_ctx *ctx, const float *f1, int n1, const f
   std::vector<int> nr1, nr2;
   OSFM_REQUIRE(to_u8(f1, n1, u1, nr1) && to_u8(f2, n2, u2, nr2), OSFM_E_UNSUPPORTED,
                "osfm_match_guided: descriptors must be integer-valued in [0, 255] (cv2's float result depends on its SIMD build)");
+  OSFM_CTX_LOCK(ctx);
   OSFM_HIP(hipSetDevice(ctx->device));
   DevBuf d_u1, d_u2, d_n1, d_n2, d_mask, d_b1, d_b2, d_rt, d_f6, d_s6, d_g12, d_g21, d_out, d_cnt;
   OSFM_HIP(d_u1.alloc(u1.size()));

@@ -11,14 +11,17 @@
 // v_mfma_i32_32x32x32_i8.  All quantities are exact int32, so the result is bit-identical to the
 // fp32 computation cv2 performs (every partial sum < 2^24).
 //
-// Epilogue trick (the kernel is VALU-bound, not MFMA-bound, because K is only 128): top-2 are
-// kept as PACKED int32 keys  key = (2S - norm_other) * 2^k + (2^k - 1 - local_index)  so that
-// one v_max_i32 + one v_med3_i32 per element maintain (best, second) with lowest-index tie
-// breaking, and  key = (S << s) + c  is a single v_lshl_add_u32.
-//   row direction  : state per (row, lane-column-class) lives in registers over the whole column
-//                    loop; 32 classes are merged by a butterfly once per row block.
-//   column direction: reduced in-lane over the 32 rows a lane holds, merged across the two
-//                    half-waves and the 4 waves through a small LDS scratch once per column tile.
+// Epilogue (the kernel is bounded by integer VALU + skeleton work next to the matrix pipe, K is only
+// 128): "best-only + lazy exact second".  The second-nearest neighbour is only needed for the ratio
+// test, and only its VALUE.  Per class of candidates (the 32 column classes j mod 32 held by the 32
+// lanes of a half-wave) only the BEST packed key is kept:  best = v_max3_i32(best, key_a, key_b),
+// key = (2S - norm_other) * 2^k + tile tag (one v_lshl_add_u32).  Classes are merged into (global best,
+// second-largest class best =: s_c).  The true second s satisfies s >= s_c and the ratio test is
+// monotone in d2:  fails with s_c => fails (final, the vast majority);  passes with s_c => the winner's
+// own class is re-examined exactly by the whole wavefront with v_dot4 dot products.
+// (Earlier generations -- exact top-2 in both directions, both directions per pass -- measured 0.16 and
+// 0.24 of the int8 peak, profiles/r01_match_v1_rocprof.txt / r01_match_v2_pmc.txt; they were removed in
+// round 2, the exact VALU kernel below remains as the on-GPU cross-check.)
 #include <cstdlib>
 
 #include "osfm_internal.h"
@@ -31,18 +34,16 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kWaves = 4;
 constexpr int kRT = 2;                         // 32-row tiles per wave
-constexpr int kRowsPerWG = kWaves * kRT * 32;  // 256
-constexpr int kCT = 4;                         // 32-col tiles per staged chunk
-constexpr int kChunkCols = kCT * 32;           // 128
-constexpr int kChunkBytes = kCT * OSFM_TILE_BYTES;  // 16 KiB
 constexpr int kNone = 0xFFFF;
 constexpr int kCollisionD2 = 1 << 22;  // above this sqrtf() is no longer injective on integers
 
-__device__ __forceinline__ int med3i(int a, int b, int c) { return max(min(a, b), min(max(a, b), c)); }
-
 // Lowe ratio exactly as the reference evaluates it: float32 distances (cv2), compared in Python
 // doubles: m.distance < ratio * n.distance (matching.py:752).  d^2 are exact ints < 2^24.
+// Squared mode (ratio < 0 encodes it: -ratio is then float32(lowes_ratio^2)) is match_flann's test on SQUARED
+// distances (matching.py:695-696): a numpy float32 array times a Python float stays float32, so
+//     d0 < float32(ratio^2) * d1     with one float32 rounding of the product.
 __device__ __forceinline__ bool ratio_ok(int d1sq, int d2sq, double ratio) {
+  if (ratio < 0.0) return (float)d1sq < (float)(-ratio) * (float)d2sq;
   const float f1 = sqrtf((float)d1sq), f2 = sqrtf((float)d2sq);
   return (double)f1 < ratio * (double)f2;
 }
@@ -62,14 +63,14 @@ struct MatchArgs {
   const int32_t *counts;
   const int32_t *pairs;
   long n_pairs;
-  double ratio;
+  double ratio;      // Lowe ratio; NEGATIVE = squared mode: -ratio is float32(lowes_ratio^2) (see ratio_ok)
   int symmetric;
+  int query_second;  // one-way matching with the SECOND image as the query set (match_flann(index1, f2), matching.py:683-697)
   int cap;
   int ncap;  // LDS capacity (features), multiple of 128
   int32_t *out_counts;
   uint32_t *out_matches;
   int32_t *out_flags;
-  int debug_no_recheck;  // perf experiments only (results wrong)
   const int32_t *pad_norm;  // one device int holding OSFM_PAD_NORM (source for out-of-range norm DMA)
 };
 
@@ -79,7 +80,7 @@ struct MatchArgs {
 // after the ratio test (or kNone).  Emits (c, r) sorted by c.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void emit_matches(const MatchArgs &a, long p, int nC, const int *colBI,
-                                             const unsigned short *rowres, int *misc, int tid, int stride = 1) {
+                                             const unsigned short *rowres, int *misc, int tid, bool swap_halves) {
   const int lane = tid & 63, w = tid >> 6;
   int base = 0;
   for (int j0 = 0; j0 < nC; j0 += kThreads) {
@@ -87,7 +88,7 @@ __device__ __forceinline__ void emit_matches(const MatchArgs &a, long p, int nC,
     bool m = false;
     int r = kNone;
     if (j < nC) {
-      r = colBI[j * stride];
+      r = colBI[j];
       m = (r != kNone) && (!a.symmetric || rowres[r] == j);
     }
     const unsigned long long bal = __ballot(m);
@@ -111,297 +112,7 @@ __device__ __forceinline__ void emit_matches(const MatchArgs &a, long p, int nC,
   if (tid == 0) a.out_counts[p] = base;
 }
 
-// ---------------------------------------------------------------------------------------------
-// Fused MFMA kernel.
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kThreads, 2) match_fused_kernel(MatchArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char *bbuf = smem;                                      // [2][16 KiB]
-  int2 *scratch = (int2 *)(smem + 2 * kChunkBytes);                // [2][4][128]
-  int *colBV = (int *)(smem + 2 * kChunkBytes + 2 * kWaves * kChunkCols * 8);
-  int *colSV = colBV + a.ncap;
-  int *colBI = colSV + a.ncap;
-  unsigned short *rowres = (unsigned short *)(colBI + a.ncap);
-  int *misc = (int *)(rowres + a.ncap);  // [16]
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const long p = xcd_remap(blockIdx.x, a.n_pairs);
-
-  const int imgC = a.pairs[2 * p], imgR = a.pairs[2 * p + 1];
-  const int nC = a.counts[imgC], nR = a.counts[imgR];
-  if (nC < 2 || nR < 2) {  // matching.py:363-374 / knnMatch returns < 2 neighbours
-    if (tid == 0) {
-      a.out_counts[p] = 0;
-      a.out_flags[p] = 0;
-    }
-    return;
-  }
-  const int tC = (nC + 31) >> 5, tR = (nR + 31) >> 5;
-  const int8_t *tilesC = a.tiles + a.tile_off[imgC] * OSFM_TILE_BYTES;
-  const int8_t *tilesR = a.tiles + a.tile_off[imgR] * OSFM_TILE_BYTES;
-  const int32_t *normC = a.norms + a.tile_off[imgC] * 32;
-  const int32_t *normR = a.norms + a.tile_off[imgR] * 32;
-
-  for (int j = tid; j < a.ncap; j += kThreads) {
-    colBV[j] = INT_MIN;
-    colSV[j] = INT_MIN;
-    colBI[j] = kNone;
-    rowres[j] = kNone;
-  }
-  if (tid == 0) misc[8] = 0;
-
-  const int nchunks = (tC + kCT - 1) / kCT;
-  const int nrb = (tR + kWaves * kRT - 1) / (kWaves * kRT);
-  const int nsteps = nrb * nchunks;
-
-  // ---- stage chunk 0 ----
-  uint4 pre[kCT];
-#pragma unroll
-  for (int q = 0; q < kCT; ++q) {
-    pre[q] = make_uint4(0, 0, 0, 0);
-    if (q < tC) pre[q] = *(const uint4 *)(tilesC + (long)q * OSFM_TILE_BYTES + tid * 16);
-  }
-#pragma unroll
-  for (int q = 0; q < kCT; ++q) *(uint4 *)(bbuf + q * OSFM_TILE_BYTES + tid * 16) = pre[q];
-  __syncthreads();
-
-  v4i afrag[kRT][4];
-  int Rk[kRT][16];
-  int rbst[kRT][16], rsnd[kRT][16];
-  int nrt = 0, rt0 = 0;
-  int rb = 0, c = 0;
-  int flag = 0;
-
-  for (int s = 0; s < nsteps; ++s) {
-    if (c == 0) {
-      // ---- new row block: A operands + per-row constants into registers ----
-      rt0 = rb * (kWaves * kRT) + w * kRT;
-      nrt = min(kRT, max(0, tR - rt0));
-#pragma unroll
-      for (int rt = 0; rt < kRT; ++rt) {
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          v4i z = {0, 0, 0, 0};
-          afrag[rt][ks] = z;
-          if (rt < nrt)
-            afrag[rt][ks] = *(const v4i *)(tilesR + (long)(rt0 + rt) * OSFM_TILE_BYTES + ks * 1024 + lane * 16);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rowintile = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          const int il = rt * 32 + rowintile;
-          int na = OSFM_PAD_NORM;
-          if (rt < nrt) na = normR[(rt0 + rt) * 32 + rowintile];
-          Rk[rt][r] = -(na << 6) + (63 - il);
-          rbst[rt][r] = INT_MIN;
-          rsnd[rt][r] = INT_MIN;
-        }
-      }
-    }
-    // ---- prefetch the next chunk of the column image into registers ----
-    const bool has_next = (s + 1 < nsteps);
-    const int cn = (c + 1 == nchunks) ? 0 : c + 1;
-    if (has_next) {
-#pragma unroll
-      for (int q = 0; q < kCT; ++q) {
-        pre[q] = make_uint4(0, 0, 0, 0);
-        if (cn * kCT + q < tC)
-          pre[q] = *(const uint4 *)(tilesC + (long)(cn * kCT + q) * OSFM_TILE_BYTES + tid * 16);
-      }
-    }
-    // ---- fold the previous step's per-wave column partials into the column state ----
-    if (s > 0 && tid < kChunkCols) {
-      const int sp = s - 1;
-      const int cp = (c == 0) ? nchunks - 1 : c - 1;
-      const int rbp = (c == 0) ? rb - 1 : rb;
-      const int j = cp * kChunkCols + tid;
-      int bv = colBV[j], sv = colSV[j], bi = colBI[j];
-#pragma unroll
-      for (int w2 = 0; w2 < kWaves; ++w2) {
-        const int2 pp = scratch[((sp & 1) * kWaves + w2) * kChunkCols + tid];
-        if (pp.x != INT_MIN) {
-          const int pv = pp.x >> 6;
-          const int pi = rbp * kRowsPerWG + w2 * (kRT * 32) + (63 - (pp.x & 63));
-          const int psv = pp.y >> 6;
-          sv = max(min(bv, pv), max(sv, psv));
-          if (pv > bv) {
-            bv = pv;
-            bi = pi;
-          }
-        }
-      }
-      colBV[j] = bv;
-      colSV[j] = sv;
-      colBI[j] = bi;
-    }
-    // ---- compute: 4 column tiles x nrt row tiles ----
-    const unsigned char *bb = bbuf + (s & 1) * kChunkBytes;
-#pragma unroll
-    for (int ct = 0; ct < kCT; ++ct) {
-      const int gct = c * kCT + ct;
-      int2 part = make_int2(INT_MIN, INT_MIN);
-      if (gct < tC && nrt > 0) {
-        v4i bf[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) bf[ks] = *(const v4i *)(bb + ct * OSFM_TILE_BYTES + ks * 1024 + lane * 16);
-        const int nb = normC[gct * 32 + (lane & 31)];
-        const int ck = -(nb << 7) + (127 - gct);
-        int cb = INT_MIN, cs = INT_MIN;
-#pragma unroll
-        for (int rt = 0; rt < kRT; ++rt) {
-          if (rt < nrt) {
-            v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-              acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[rt][ks], bf[ks], acc, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int sdot = acc[r];
-              const int key = (sdot << 8) + ck;  // (2S - nb) * 128 + (127 - gct)
-              rsnd[rt][r] = med3i(rbst[rt][r], rsnd[rt][r], key);
-              rbst[rt][r] = max(rbst[rt][r], key);
-              const int u = (sdot << 7) + Rk[rt][r];  // (2S - na) * 64 + (63 - il)
-              cs = med3i(cb, cs, u);
-              cb = max(cb, u);
-            }
-          }
-        }
-        const int ob = __shfl_xor(cb, 32), os = __shfl_xor(cs, 32);
-        part.x = max(cb, ob);
-        part.y = max(min(cb, ob), max(cs, os));
-      }
-      if (lane < 32) scratch[((s & 1) * kWaves + w) * kChunkCols + ct * 32 + lane] = part;
-    }
-    // ---- end of a row block: merge the 32 column classes of every row, ratio test ----
-    if (c == nchunks - 1) {
-#pragma unroll
-      for (int rt = 0; rt < kRT; ++rt) {
-        if (rt < nrt) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int kb = rbst[rt][r], k2 = rsnd[rt][r];
-            int bv = kb >> 7;
-            int bj = (127 - (kb & 127)) * 32 + (lane & 31);
-            int sv = k2 >> 7;
-#pragma unroll
-            for (int m = 1; m < 32; m <<= 1) {
-              const int ov = __shfl_xor(bv, m), oj = __shfl_xor(bj, m), os = __shfl_xor(sv, m);
-              const int nsv = max(min(bv, ov), max(sv, os));
-              const bool take = (ov > bv) || (ov == bv && oj < bj);
-              bv = take ? ov : bv;
-              bj = take ? oj : bj;
-              sv = nsv;
-            }
-            const int rowintile = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const int row = (rt0 + rt) * 32 + rowintile;
-            if ((lane & 31) == 0 && row < nR) {
-              const int na = normR[row];
-              const int d1 = na - bv, d2 = na - sv;
-              rowres[row] = ratio_ok(d1, d2, a.ratio) ? bj : kNone;
-              if (d2 >= kCollisionD2) flag = 1;
-            }
-          }
-        }
-      }
-    }
-    // ---- publish the prefetched chunk ----
-    if (has_next) {
-      unsigned char *nb2 = bbuf + ((s + 1) & 1) * kChunkBytes;
-#pragma unroll
-      for (int q = 0; q < kCT; ++q) *(uint4 *)(nb2 + q * OSFM_TILE_BYTES + tid * 16) = pre[q];
-    }
-    __syncthreads();
-    ++c;
-    if (c == nchunks) {
-      c = 0;
-      ++rb;
-    }
-  }
-  // ---- last step's column partials ----
-  if (tid < kChunkCols) {
-    const int sp = nsteps - 1;
-    const int j = (nchunks - 1) * kChunkCols + tid;
-    int bv = colBV[j], sv = colSV[j], bi = colBI[j];
-#pragma unroll
-    for (int w2 = 0; w2 < kWaves; ++w2) {
-      const int2 pp = scratch[((sp & 1) * kWaves + w2) * kChunkCols + tid];
-      if (pp.x != INT_MIN) {
-        const int pv = pp.x >> 6;
-        const int pi = (nrb - 1) * kRowsPerWG + w2 * (kRT * 32) + (63 - (pp.x & 63));
-        const int psv = pp.y >> 6;
-        sv = max(min(bv, pv), max(sv, psv));
-        if (pv > bv) {
-          bv = pv;
-          bi = pi;
-        }
-      }
-    }
-    colBV[j] = bv;
-    colSV[j] = sv;
-    colBI[j] = bi;
-  }
-  __syncthreads();
-  // ---- column side ratio test ----
-  for (int j = tid; j < nC; j += kThreads) {
-    const int nb = normC[j];
-    const int d1 = nb - colBV[j], d2 = nb - colSV[j];
-    if (!ratio_ok(d1, d2, a.ratio)) colBI[j] = kNone;
-    if (d2 >= kCollisionD2) flag = 1;
-  }
-  if (flag) misc[8] = 1;
-  __syncthreads();
-  if (tid == 0) a.out_flags[p] = misc[8];
-  emit_matches(a, p, nC, colBI, rowres, misc, tid);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Fused MFMA kernel, version 2: "best-only + lazy exact second".
-//
-// v1 spends 6 integer VALU ops per distance-matrix element keeping an exact (best, second) pair in
-// both directions, and sits on the VALU issue roofline (profiles/r01_match_v1_rocprof.txt).  The
-// second-nearest neighbour is only needed for the ratio test, and only its VALUE.  v2 keeps, per
-// class of candidates (row direction: the 32 column classes j mod 32 held by the 32 lanes of a
-// half-wave; column direction: the 32 rows one lane sees), only the BEST key:
-//     best = v_max3_i32(best, key_a, key_b)          -> 1.5 ops / element / direction
-// and merges classes into (global best, second largest class-best =: s_c).  The true second s
-// satisfies s >= s_c, i.e. d2_true <= d2_c, and the ratio test is monotone in d2:
-//   * fails with d2_c  => fails with d2_true: final, no extra work (the vast majority of features);
-//   * passes with d2_c => the winner's own class (<= 64 / 32 candidates) is re-examined exactly with
-//     v_dot4 dot products by the whole wavefront, s = max(s_c, best of the class without the
-//     winner), and the test is repeated.  Results are bit-identical to v1 / the oracle.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void load_row_frag(const int8_t *tiles, int row, v4i out[8]);
-
-__device__ __forceinline__ int dot128(const v4i a[8], const v4i b[8]) {
-  int sdot = 0;
-#pragma unroll
-  for (int k = 0; k < 8; ++k)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) sdot = __builtin_amdgcn_sdot4(a[k][e], b[k][e], sdot, false);
-  return sdot;
-}
-
-// a'.b' of two stored descriptors (tile layout), 4 k-steps x (2 + 2) 16-byte loads: few live registers
-__device__ __forceinline__ int dot_rows(const int8_t *tilesA, int rowA, const int8_t *tilesB, int rowB) {
-  const int8_t *pa = tilesA + (long)(rowA >> 5) * OSFM_TILE_BYTES + (rowA & 31) * 16;
-  const int8_t *pb = tilesB + (long)(rowB >> 5) * OSFM_TILE_BYTES + (rowB & 31) * 16;
-  int sdot = 0;
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    const v4i a0 = *(const v4i *)(pa + ks * 1024), a1 = *(const v4i *)(pa + ks * 1024 + 512);
-    const v4i b0 = *(const v4i *)(pb + ks * 1024), b1 = *(const v4i *)(pb + ks * 1024 + 512);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      sdot = __builtin_amdgcn_sdot4(a0[e], b0[e], sdot, false);
-      sdot = __builtin_amdgcn_sdot4(a1[e], b1[e], sdot, false);
-    }
-  }
-  return sdot;
-}
-
-// same, all 16 loads issued before the first use: one memory latency per candidate instead of four
+// a'.b' of two stored descriptors (tile layout): all 16 loads issued before the first use, one memory latency per candidate
 __device__ __forceinline__ int dot_rows8(const int8_t *tilesA, int rowA, const int8_t *tilesB, int rowB) {
   const int8_t *pa = tilesA + (long)(rowA >> 5) * OSFM_TILE_BYTES + (rowA & 31) * 16;
   const int8_t *pb = tilesB + (long)(rowB >> 5) * OSFM_TILE_BYTES + (rowB & 31) * 16;
@@ -426,376 +137,6 @@ __device__ __forceinline__ int wave_max(int v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m));
   return v;
-}
-
-#ifdef OSFM_PHASE_TIMING
-__device__ unsigned long long g_phase[8];
-#endif
-__global__ void __launch_bounds__(kThreads, 2) match_fused2_kernel(MatchArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char *bbuf = smem;                                      // [2][16 KiB]
-  // column state: colB[j] = (best key : 32 | 4095 - class : 32), class = row block * 4 + wave, updated by
-  // 64-bit LDS atomic max straight from the wave that produced a partial (order independent);
-  // colSV[j] = second-largest class best = max over all "losers" of those updates
-  long long *colB = (long long *)(smem + 2 * kChunkBytes);
-  int *colP = (int *)colB;  // after the main loop: colP[2j] = best row (or kNone), colP[2j+1] = best value
-  int *colSV = (int *)(colB + a.ncap);
-  unsigned short *rowres = (unsigned short *)(colSV + a.ncap);
-  unsigned short *clist = rowres + a.ncap;
-  int *misc = (int *)(clist + a.ncap);  // [16]
-  int *req = misc + 16;                 // [4 waves][64 rows][3]
-  int *nbuf = req + kWaves * 192;       // [2][128] column norms of the staged chunk
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const long p = xcd_remap(blockIdx.x, a.n_pairs);
-
-  const int imgC = a.pairs[2 * p], imgR = a.pairs[2 * p + 1];
-  const int nC = a.counts[imgC], nR = a.counts[imgR];
-  if (nC < 2 || nR < 2) {
-    if (tid == 0) {
-      a.out_counts[p] = 0;
-      a.out_flags[p] = 0;
-    }
-    return;
-  }
-  const int tC = (nC + 31) >> 5, tR = (nR + 31) >> 5;
-  const int8_t *tilesC = a.tiles + a.tile_off[imgC] * OSFM_TILE_BYTES;
-  const int8_t *tilesR = a.tiles + a.tile_off[imgR] * OSFM_TILE_BYTES;
-  const int32_t *normC = a.norms + a.tile_off[imgC] * 32;
-  const int32_t *normR = a.norms + a.tile_off[imgR] * 32;
-
-  for (int j = tid; j < a.ncap; j += kThreads) {
-    colB[j] = (long long)(INT_MIN >> 6) << 32;
-    colSV[j] = INT_MIN;
-    rowres[j] = kNone;
-  }
-  if (tid == 0) {
-    misc[8] = 0;
-    misc[9] = 0;
-  }
-
-  const int nchunks = (tC + kCT - 1) / kCT;
-  const int nrb = (tR + kWaves * kRT - 1) / (kWaves * kRT);
-  const int nsteps = nrb * nchunks;
-
-  uint4 pre[kCT];
-#pragma unroll
-  for (int q = 0; q < kCT; ++q) {
-    pre[q] = make_uint4(0, 0, 0, 0);
-    if (q < tC) pre[q] = *(const uint4 *)(tilesC + (long)q * OSFM_TILE_BYTES + tid * 16);
-  }
-#pragma unroll
-  for (int q = 0; q < kCT; ++q) *(uint4 *)(bbuf + q * OSFM_TILE_BYTES + tid * 16) = pre[q];
-  if (tid < kChunkCols) nbuf[tid] = (tid < tC * 32) ? normC[tid] : OSFM_PAD_NORM;
-  __syncthreads();
-
-#ifdef OSFM_PHASE_TIMING
-  long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = clock64(), tn;
-#define PH(i) { tn = clock64(); ph[i] += tn - tq; tq = tn; }
-#else
-#define PH(i)
-#endif
-  v4i afrag[kRT][4], anext[kRT][4];
-  int nrm = OSFM_PAD_NORM, nrm_next = OSFM_PAD_NORM;
-  int Rk[kRT][16];
-  int rbst[kRT][16];
-  int flag = 0;
-
-  // Nested loops (row block, column chunk): the A operands and row norms are loaded between the
-  // inner loops with nothing else in flight, so inside the inner loop no s_waitcnt ever has to
-  // drain the chunk prefetch (a flattened loop with `if (c == 0)` loads made hipcc wait vmcnt(0)
-  // in front of the first MFMA of every step).
-  for (int rb = 0; rb < nrb; ++rb) {
-    const int rt0 = rb * (kWaves * kRT) + w * kRT;
-    const int nrt = min(kRT, max(0, tR - rt0));
-    if (rb == 0) {
-      // one coalesced load: lane l holds the norm of row rt0*32 + l (64 rows of this wave)
-      nrm = OSFM_PAD_NORM;
-      if (lane < nrt * 32) nrm = normR[rt0 * 32 + lane];
-#pragma unroll
-      for (int rt = 0; rt < kRT; ++rt)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          v4i z = {0, 0, 0, 0};
-          afrag[rt][ks] = z;
-          if (rt < nrt)
-            afrag[rt][ks] = *(const v4i *)(tilesR + (long)(rt0 + rt) * OSFM_TILE_BYTES + ks * 1024 + lane * 16);
-        }
-    } else {  // prefetched during the previous row block's merge
-      nrm = nrm_next;
-#pragma unroll
-      for (int rt = 0; rt < kRT; ++rt)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) afrag[rt][ks] = anext[rt][ks];
-    }
-#pragma unroll
-    for (int rt = 0; rt < kRT; ++rt) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rowintile = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int il = rt * 32 + rowintile;
-        const int na = __shfl(nrm, il);
-        Rk[rt][r] = -(na << 6) + (63 - il);
-        rbst[rt][r] = INT_MIN;
-      }
-    }
-    // make hipcc wait for the A operands HERE (nothing else is in flight) instead of in front of the
-    // first MFMA of every inner iteration, where the wait would also drain the chunk prefetch
-#pragma unroll
-    for (int rt = 0; rt < kRT; ++rt)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(afrag[rt][ks]));
-    PH(0)
-    for (int c = 0; c < nchunks; ++c) {
-    const int s = rb * nchunks + c;
-    const bool has_next = (s + 1 < nsteps);
-    const int cn = (c + 1 == nchunks) ? 0 : c + 1;
-    // Order matters for hipcc's waitcnt insertion: every ds_write issued while an LDS DMA is in
-    // flight gets an s_waitcnt vmcnt(0) in front of it (WAW on LDS cannot be disproved), which would
-    // expose the whole DMA latency in the middle of the step.  So the step's own LDS updates (column
-    // partials) are kept until just before the closing barrier, where the DMA has to be complete.
-    PH(1)
-    if (has_next && !(a.debug_no_recheck & 8)) {
-      // next chunk of the column image: global -> LDS DMA (no staging registers, no ds_write);
-      // the LDS image is lane-linear, exactly the order the lanes ask for.  hipcc drains it
-      // (vmcnt(0)) in front of the __syncthreads() that closes this step.
-      unsigned char *nb2 = bbuf + ((s + 1) & 1) * kChunkBytes;
-#pragma unroll
-      for (int q = 0; q < kCT; ++q) {
-        const int gt = cn * kCT + q;
-        const int8_t *src = tilesC + (long)(gt < tC ? gt : 0) * OSFM_TILE_BYTES + tid * 16;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                         (__attribute__((address_space(3))) void *)(nb2 + q * OSFM_TILE_BYTES + w * 1024), 16, 0, 0);
-      }
-      if (w < 2) {
-        const int jn = cn * kChunkCols + tid;
-        const int32_t *srcn = (jn < tC * 32) ? normC + jn : a.pad_norm;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)srcn,
-                                         (__attribute__((address_space(3))) void *)(nbuf + ((s + 1) & 1) * kChunkCols + w * 64), 4, 0, 0);
-      }
-    }
-    PH(2)
-    // ---- compute: column tiles in pairs so that v_max3 takes two new keys per op ----
-    const unsigned char *bb = bbuf + (s & 1) * kChunkBytes;
-    int2 parts[kCT];
-#pragma unroll
-    for (int cp2 = 0; cp2 < kCT / 2; ++cp2) {
-      const int ct0 = 2 * cp2, ct1 = 2 * cp2 + 1;
-      const int g0 = c * kCT + ct0, g1 = g0 + 1;
-      int2 part0 = make_int2(INT_MIN, INT_MIN), part1 = make_int2(INT_MIN, INT_MIN);
-      if (g0 < tC && nrt > 0 && !(a.debug_no_recheck & 16)) {
-        const bool v1ok = g1 < tC;
-        v4i bf0[4], bf1[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          bf0[ks] = *(const v4i *)(bb + ct0 * OSFM_TILE_BYTES + ks * 1024 + lane * 16);
-          v4i z = {0, 0, 0, 0};
-          bf1[ks] = z;
-          if (v1ok) bf1[ks] = *(const v4i *)(bb + ct1 * OSFM_TILE_BYTES + ks * 1024 + lane * 16);
-        }
-        const int *nbs = nbuf + (s & 1) * kChunkCols;
-        const int nb0 = nbs[ct0 * 32 + (lane & 31)];
-        const int nb1 = nbs[ct1 * 32 + (lane & 31)];  // padding norm when the tile does not exist
-        const int ck0 = -(nb0 << 7) + (127 - g0);
-        const int ck1 = -(nb1 << 7) + (127 - (g1 & 127));
-        int cb0 = INT_MIN, cb1 = INT_MIN;
-#pragma unroll
-        for (int rt = 0; rt < kRT; ++rt) {
-          if (rt < nrt) {
-            v16i acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            v16i acc1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[rt][ks], bf0[ks], acc0, 0, 0, 0);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[rt][ks], bf1[ks], acc1, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int k0 = (acc0[r] << 8) + ck0, k1 = (acc1[r] << 8) + ck1;
-              rbst[rt][r] = max(max(rbst[rt][r], k0), k1);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-              const int u0a = (acc0[r] << 7) + Rk[rt][r], u0b = (acc0[r + 1] << 7) + Rk[rt][r + 1];
-              const int u1a = (acc1[r] << 7) + Rk[rt][r], u1b = (acc1[r + 1] << 7) + Rk[rt][r + 1];
-              cb0 = max(max(cb0, u0a), u0b);
-              cb1 = max(max(cb1, u1a), u1b);
-            }
-          }
-        }
-        const int ob0 = __shfl_xor(cb0, 32), ob1 = __shfl_xor(cb1, 32);
-        part0.x = max(cb0, ob0);
-        part0.y = min(cb0, ob0);
-        if (v1ok) {
-          part1.x = max(cb1, ob1);
-          part1.y = min(cb1, ob1);
-        }
-      }
-      parts[ct0] = part0;
-      parts[ct1] = part1;
-    }
-    PH(3)
-    if (lane < 32 && nrt > 0 && !(a.debug_no_recheck & 32)) {
-      const unsigned clsinv = 4095u - (unsigned)(rb * kWaves + w);
-#pragma unroll
-      for (int q = 0; q < kCT; ++q) {
-        if (c * kCT + q < tC) {
-          const int j = (c * kCT + q) * 32 + lane;
-          // order: value, then lowest class (64-row block), then lowest row inside it = lowest row index
-          const long long mine = ((long long)(parts[q].x >> 6) << 32) | (long long)((clsinv << 6) | (unsigned)(parts[q].x & 63));
-          const long long old = __hip_atomic_fetch_max(&colB[j], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          const int loser = (int)((old < mine ? old : mine) >> 32);
-          __hip_atomic_fetch_max(&colSV[j], max(loser, parts[q].y >> 6), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-      }
-    }
-    PH(4)
-    PH(5)
-    if (!(a.debug_no_recheck & 4)) __syncthreads();
-    PH(6)
-    // ---- end of a row block: merge the 32 column classes of every row ----
-    // Transposed through LDS instead of 32 cross-lane butterflies: each lane drops its class-bests
-    // into a [row][class] image, then lane (row, half of the classes) scans 16 ints.  The image lives
-    // in the chunk buffer this step just finished with (nobody reads it after the barrier above), in
-    // the four 1 KiB slices that only this wave's OWN next DMA overwrites: no extra barrier.
-    if (c == nchunks - 1 && !(a.debug_no_recheck & 64)) {
-      // next row block's A operands + norms: issued here so that their latency hides behind the merge
-      if (rb + 1 < nrb) {
-        const int rt0n = rt0 + kWaves * kRT;
-        const int nrtn = min(kRT, max(0, tR - rt0n));
-        nrm_next = OSFM_PAD_NORM;
-        if (lane < nrtn * 32) nrm_next = normR[rt0n * 32 + lane];
-#pragma unroll
-        for (int rt = 0; rt < kRT; ++rt)
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) {
-            v4i z = {0, 0, 0, 0};
-            anext[rt][ks] = z;
-            if (rt < nrtn)
-              anext[rt][ks] = *(const v4i *)(tilesR + (long)(rt0n + rt) * OSFM_TILE_BYTES + ks * 1024 + lane * 16);
-          }
-      }
-      unsigned char *trb = bbuf + (s & 1) * kChunkBytes + w * 1024;
-#pragma unroll
-      for (int rt = 0; rt < kRT; ++rt) {
-        if (rt < nrt) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r)  // row = (r&3) + 8*(r>>2) + 4*half: slice r>>2, line (r&3) + 4*half
-            *(int *)(trb + (r >> 2) * OSFM_TILE_BYTES + ((r & 3) + 4 * (lane >> 5)) * 128 + (lane & 31) * 4) = rbst[rt][r];
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          const int row32 = lane >> 1, hc = lane & 1;
-          int bkey = INT_MIN, bcls = 0, skey = INT_MIN;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int4 v4 = *(const int4 *)(trb + (row32 >> 3) * OSFM_TILE_BYTES + (row32 & 7) * 128 + hc * 64 + q * 16);
-            const int vv[4] = {v4.x, v4.y, v4.z, v4.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              skey = max(skey, min(bkey, vv[e]));
-              const bool up = vv[e] > bkey;  // strict: the lowest class keeps ties (lowest column)
-              bcls = up ? hc * 16 + q * 4 + e : bcls;
-              bkey = up ? vv[e] : bkey;
-            }
-          }
-          {
-            const int pk = __shfl_xor(bkey, 1), pc = __shfl_xor(bcls, 1), ps = __shfl_xor(skey, 1);
-            const int nsk = max(min(bkey, pk), max(skey, ps));
-            const bool take = (pk > bkey) || (pk == bkey && pc < bcls);
-            bcls = take ? pc : bcls;
-            bkey = take ? pk : bkey;
-            skey = nsk;
-          }
-          const int il = rt * 32 + row32;
-          const int row = (rt0 + rt) * 32 + row32;
-          const int na = __shfl(nrm, il);
-          const int bv = bkey >> 7, bj = (127 - (bkey & 127)) * 32 + bcls, sv = skey >> 7;
-          bool want = false;
-          if (hc == 0 && row < nR) {
-            const int d1 = na - bv, d2 = na - sv;
-            if (d2 >= kCollisionD2) flag = 1;
-            want = ratio_ok(d1, d2, a.ratio);  // passes against the class bound: re-examine
-            if (!want) rowres[row] = kNone;
-          }
-          // the rows that passed: exact second inside the winner's class = columns {t*32 + (bj&31)}
-          unsigned long long pending = (a.debug_no_recheck & 1) ? 0ull : __ballot(want);
-          while (pending) {
-            const int src = __builtin_ctzll(pending);
-            pending &= pending - 1;
-            const int qbj = __shfl(bj, src), qbv = __shfl(bv, src), qsv = __shfl(sv, src), qna = __shfl(na, src);
-            const int qrow = (rt0 + rt) * 32 + (src >> 1);
-            int mx = INT_MIN;
-            for (int t0 = 0; t0 < tC; t0 += 64) {
-              const int t = t0 + lane;
-              const int j = t * 32 + (qbj & 31);
-              if (t < tC && j != qbj) mx = max(mx, 2 * dot_rows8(tilesR, qrow, tilesC, j) - normC[j]);
-            }
-            mx = wave_max(mx);
-            if (lane == 0) {
-              const int s2 = max(qsv, mx);
-              rowres[qrow] = ratio_ok(qna - qbv, qna - s2, a.ratio) ? qbj : kNone;
-            }
-          }
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-      }
-    }
-    }  // chunks
-  }    // row blocks
-  __syncthreads();
-  if (a.debug_no_recheck & 128) return;
-  // ---- column side: decode the best, ratio test against the class bound, list the survivors ----
-  for (int j = tid; j < nC; j += kThreads) {
-    const long long cbst = colB[j];
-    const unsigned lo = (unsigned)(cbst & 0xFFFFFFFFll);
-    const int bv = (int)(cbst >> 32), bi = (4095 - (int)(lo >> 6)) * 64 + (63 - (int)(lo & 63));
-    const int nb = normC[j];
-    const int d1 = nb - bv, d2 = nb - colSV[j];
-    if (d2 >= kCollisionD2) flag = 1;
-    colP[2 * j + 1] = bv;
-    if (!ratio_ok(d1, d2, a.ratio)) {
-      colP[2 * j] = kNone;
-    } else {
-      colP[2 * j] = bi;
-      const int k = atomicAdd(&misc[9], 1);
-      clist[k] = (unsigned short)j;
-    }
-  }
-  if (flag) misc[8] = 1;
-  __syncthreads();
-  // ---- exact second for the surviving columns: the winner's class = the 32 rows one lane saw ----
-  {
-    const int nlist = (a.debug_no_recheck & 1) ? 0 : misc[9];
-    for (int e = w; e < nlist; e += kWaves) {
-      const int j = clist[e];
-      const int bi = colP[2 * j];
-      const int base = (bi >> 6) << 6;                  // row block + wave: rb*256 + w*64
-      const int h = ((bi & 31) >> 2) & 1;               // half-wave of the winning lane
-      const int rtq = lane >> 4, rq = lane & 15;
-      const int row = base + rtq * 32 + (rq & 3) + 8 * (rq >> 2) + 4 * h;
-      int v = INT_MIN;
-      if (lane < 32 && row < tR * 32 && row != bi) v = 2 * dot_rows8(tilesR, row, tilesC, j) - normR[row];
-      v = wave_max(v);
-      if (lane == 0) {
-        const int nb = normC[j];
-        const int s2 = max(colSV[j], v);
-        if (!ratio_ok(nb - colP[2 * j + 1], nb - s2, a.ratio)) colP[2 * j] = kNone;
-      }
-    }
-  }
-  __syncthreads();
-  if (tid == 0) a.out_flags[p] = misc[8];
-  emit_matches(a, p, nC, colP, rowres, misc, tid, 2);
-#ifdef OSFM_PHASE_TIMING
-  PH(7)
-  if (lane == 0)
-    for (int i = 0; i < 8; i++) atomicAdd(&g_phase[i], (unsigned long long)ph[i]);
-#endif
-#undef PH
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -832,7 +173,7 @@ struct RowPassShared {
 template <bool GATHER>
 __device__ __forceinline__ int row_pass(const RowPassShared &sh, const int8_t *tilesX, const int32_t *normX, int nX, int nslots,
                                         const unsigned short *rowsel, const int8_t *tilesY, const int32_t *normY, int nY,
-                                        unsigned short *out, double ratio, int debug, int tid) {
+                                        unsigned short *out, double ratio, int tid) {
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tY = (nY + 31) >> 5;
@@ -1061,11 +402,11 @@ __device__ __forceinline__ int row_pass(const RowPassShared &sh, const int8_t *t
             bool want = false;
             if (hc == 0 && xr >= 0 && xr < nX) {
               const int d1 = na - bv, d2 = na - sv;
-              if (d2 >= kCollisionD2) flag = 1;
+              if (d2 >= kCollisionD2 && ratio >= 0.0) flag = 1;  // squared mode never takes a square root
               want = ratio_ok(d1, d2, ratio);  // passes against the class bound: re-examine
               if (!want) out[xr] = kNone;
             }
-            unsigned long long pending = (debug & 1) ? 0ull : __ballot(want);
+            unsigned long long pending = __ballot(want);
             while (pending) {
               const int src = __builtin_ctzll(pending);
               pending &= pending - 1;
@@ -1150,8 +491,9 @@ __global__ void __launch_bounds__(kThreads, 2) match_fused4_kernel(MatchArgs a) 
     return;
   }
   // symmetric: A = second image (rows of the big pass), B = first image (streamed, shared in L2)
-  const int imgA = a.symmetric ? img2 : img1, imgB = a.symmetric ? img1 : img2;
-  const int nA = a.symmetric ? n2 : n1, nB = a.symmetric ? n1 : n2;
+  const bool rows_second = a.symmetric || a.query_second;
+  const int imgA = rows_second ? img2 : img1, imgB = rows_second ? img1 : img2;
+  const int nA = rows_second ? n2 : n1, nB = rows_second ? n1 : n2;
   const int8_t *tilesA = a.tiles + a.tile_off[imgA] * OSFM_TILE_BYTES;
   const int8_t *tilesB = a.tiles + a.tile_off[imgB] * OSFM_TILE_BYTES;
   const int32_t *normA = a.norms + a.tile_off[imgA] * 32;
@@ -1166,7 +508,7 @@ __global__ void __launch_bounds__(kThreads, 2) match_fused4_kernel(MatchArgs a) 
     misc[9] = 0;
   }
   __syncthreads();
-  int flag = row_pass<false>(sh, tilesA, normA, nA, nA, nullptr, tilesB, normB, nB, resA, a.ratio, a.debug_no_recheck, tid);
+  int flag = row_pass<false>(sh, tilesA, normA, nA, nA, nullptr, tilesB, normB, nB, resA, a.ratio, tid);
   if (a.symmetric) {
     // candidates: the features of B that some row of A chose.  resB doubles as the mark array
     // (0 = chosen) until the candidate list is built, in ascending feature order.
@@ -1197,21 +539,24 @@ __global__ void __launch_bounds__(kThreads, 2) match_fused4_kernel(MatchArgs a) 
       __syncthreads();
     }
     const int nK = base;
-    if (nK > 0) flag |= row_pass<true>(sh, tilesB, normB, nB, nK, cand, tilesA, normA, nA, resB, a.ratio, a.debug_no_recheck, tid);
+    if (nK > 0) flag |= row_pass<true>(sh, tilesB, normB, nB, nK, cand, tilesA, normA, nA, resB, a.ratio, tid);
   }
   if (flag) misc[8] = 1;
   __syncthreads();
   if (tid == 0) a.out_flags[p] = misc[8];
-  // ---- ordered emission over the features of the pair's first image ----
+  // ---- ordered emission: over the features of the pair's first image, or (query_second) of its second image,
+  //      the order in which the reference lists the matches of match_flann (matching.py:697) ----
   {
-    const unsigned short *res1 = a.symmetric ? resB : resA;  // indexed by feature of image 1 -> feature of image 2
+    const bool qs = !a.symmetric && a.query_second;
+    const unsigned short *res1 = a.symmetric ? resB : resA;  // indexed by the emission feature -> its partner
     const unsigned short *res2 = a.symmetric ? resA : nullptr;
+    const int nE = qs ? n2 : n1;
     int base = 0;
-    for (int j0 = 0; j0 < n1; j0 += kThreads) {
+    for (int j0 = 0; j0 < nE; j0 += kThreads) {
       const int j = j0 + tid;
       bool m = false;
       int r = kNone;
-      if (j < n1) {
+      if (j < nE) {
         r = res1[j];
         m = (r != kNone) && (!res2 || res2[r] == j);
       }
@@ -1228,7 +573,8 @@ __global__ void __launch_bounds__(kThreads, 2) match_fused4_kernel(MatchArgs a) 
       }
       if (m) {
         const int k = base + woff + prefix;
-        if (k < a.cap) a.out_matches[p * a.cap + k] = (uint32_t)j | ((uint32_t)r << 16);
+        // low half = feature of image 1, high half = feature of image 2
+        if (k < a.cap) a.out_matches[p * a.cap + k] = qs ? ((uint32_t)r | ((uint32_t)j << 16)) : ((uint32_t)j | ((uint32_t)r << 16));
       }
       base += total;
       __syncthreads();
@@ -1252,8 +598,6 @@ __device__ __forceinline__ void load_row(const int8_t *tiles, int row, v4i out[8
   }
 }
 
-__device__ __forceinline__ void load_row_frag(const int8_t *tiles, int row, v4i out[8]) { load_row(tiles, row, out); }
-
 __device__ void exact_direction(const int8_t *tilesQ, const int32_t *normQ, int nQ, const int8_t *tilesT,
                                 const int32_t *normT, int nT, double ratio, int tid, int *res_int,
                                 unsigned short *res_u16) {
@@ -1272,7 +616,7 @@ __device__ void exact_direction(const int8_t *tilesQ, const int32_t *normQ, int 
 #pragma unroll
         for (int e = 0; e < 4; ++e) sdot = __builtin_amdgcn_sdot4(qa[k][e], ta[k][e], sdot, false);
       const int d2i = nq + normT[t] - 2 * sdot;
-      const float d = sqrtf((float)d2i);
+      const float d = ratio < 0.0 ? (float)d2i : sqrtf((float)d2i);  // squared mode: FLANN reports and compares squared distances
       if (d < bd1) {  // cv2 batchDistance K=2 insertion
         if (bd0 > d) {
           bd1 = bd0;
@@ -1283,7 +627,7 @@ __device__ void exact_direction(const int8_t *tilesQ, const int32_t *normQ, int 
         }
       }
     }
-    const bool ok = (double)bd0 < ratio * (double)bd1;
+    const bool ok = ratio < 0.0 ? (bd0 < (float)(-ratio) * bd1) : ((double)bd0 < ratio * (double)bd1);
     const int v = ok ? bi0 : kNone;
     if (res_int) res_int[q] = v;
     if (res_u16) res_u16[q] = (unsigned short)v;
@@ -1298,7 +642,8 @@ __global__ void __launch_bounds__(kThreads) match_exact_kernel(MatchArgs a, int 
   const int tid = threadIdx.x;
   const long p = blockIdx.x;
   if (only_flagged && a.out_flags[p] == 0) return;
-  const int imgC = a.pairs[2 * p], imgR = a.pairs[2 * p + 1];
+  const bool qs = !a.symmetric && a.query_second;  // queries = the pair's second image (match_flann)
+  const int imgC = a.pairs[2 * p + (qs ? 1 : 0)], imgR = a.pairs[2 * p + (qs ? 0 : 1)];
   const int nC = a.counts[imgC], nR = a.counts[imgR];
   if (nC < 2 || nR < 2) {
     if (tid == 0) a.out_counts[p] = 0;
@@ -1311,30 +656,25 @@ __global__ void __launch_bounds__(kThreads) match_exact_kernel(MatchArgs a, int 
   exact_direction(tilesC, normC, nC, tilesR, normR, nR, a.ratio, tid, colBI, nullptr);
   if (a.symmetric) exact_direction(tilesR, normR, nR, tilesC, normC, nC, a.ratio, tid, nullptr, rowres);
   __syncthreads();
-  emit_matches(a, p, nC, colBI, rowres, misc, tid);
+  emit_matches(a, p, nC, colBI, rowres, misc, tid, qs);
 }
 
 }  // namespace
 
-size_t osfm_match_lds_bytes(int ncap) {
-  return (size_t)2 * kChunkBytes + 2 * kWaves * kChunkCols * 8 + (size_t)ncap * 14 + 64;
-}
-size_t osfm_match2_lds_bytes(int ncap) {
-  return (size_t)2 * kChunkBytes + (size_t)ncap * 16 + 64 + kWaves * 192 * 4 + 2 * kChunkCols * 4;
-}
 size_t osfm_match4_lds_bytes(int ncap) { return (size_t)2 * kChunkBytes4 + 2 * kChunkCols4 * 4 + 64 + (size_t)ncap * 6; }
-static int match_kernel_version() {
-  static int v = -1;
-  if (v < 0) {
-    const char *e = getenv("OSFM_MATCH_KERNEL");
-    v = (e && e[0] == '1') ? 1 : (e && e[0] == '2') ? 2 : 4;
-  }
-  return v;
+
+static int ensure_kernel_attributes(int device) {
+  static OsfmPerDeviceOnce once;
+  return once.run(device, []() -> int {
+    OSFM_HIP(hipFuncSetAttribute((const void *)match_fused4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    OSFM_HIP(hipFuncSetAttribute((const void *)match_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    return OSFM_OK;
+  });
 }
 
 int osfm_launch_match(osfm_ctx *ctx, const osfm_store *store, const int32_t *d_pairs, int64_t n_pairs,
-                      double ratio, int symmetric, int cap, int32_t *d_counts, uint32_t *d_matches,
-                      int32_t *d_flags, bool exact_kernel) {
+                      double ratio, int symmetric, int squared_ratio, int cap, int32_t *d_counts, uint32_t *d_matches,
+                      int32_t *d_flags, bool exact_kernel, hipStream_t stream) {
   if (n_pairs == 0) return OSFM_OK;
   MatchArgs a;
   a.tiles = store->d_tiles;
@@ -1343,55 +683,30 @@ int osfm_launch_match(osfm_ctx *ctx, const osfm_store *store, const int32_t *d_p
   a.counts = store->d_counts;
   a.pairs = d_pairs;
   a.n_pairs = n_pairs;
-  a.ratio = ratio;
+  // squared mode (FLANN semantics, matching.py:683-720): the kernels see -float32(ratio^2); one-way matching then queries
+  // with the pair's second image, as match_flann(index1, f2) does
+  a.ratio = squared_ratio ? -(double)(float)(ratio * ratio) : ratio;
   a.symmetric = symmetric;
+  a.query_second = squared_ratio && !symmetric;
   a.cap = cap;
   a.ncap = ((store->max_count + 127) / 128) * 128;
   if (a.ncap < 128) a.ncap = 128;
   a.out_counts = d_counts;
   a.out_matches = d_matches;
   a.out_flags = d_flags;
-  a.debug_no_recheck = getenv("OSFM_DEBUG_NO_RECHECK") ? atoi(getenv("OSFM_DEBUG_NO_RECHECK")) : 0;  // bit0 rechecks, bit2 step barrier, bit3 chunk DMA, bit4 compute
   a.pad_norm = store->d_norms + store->tile_off[store->n_images] * 32;  // first slack row: padding norm
   OSFM_REQUIRE(a.ncap <= OSFM_MAX_FEATURES, OSFM_E_UNSUPPORTED, "more than %d features in an image", OSFM_MAX_FEATURES);
-  OSFM_REQUIRE(exact_kernel || match_kernel_version() == 4 || a.ncap <= 4096, OSFM_E_UNSUPPORTED,
-               "the v1/v2 matcher kernels pack a 7-bit tile index into their keys: at most 4096 features per image (v4 has no such limit)");
   OSFM_REQUIRE(n_pairs < (1ll << 31), OSFM_E_INVALID, "too many pairs in one launch");
+  {
+    const int rc = ensure_kernel_attributes(ctx->device);
+    if (rc != OSFM_OK) return rc;
+  }
   if (!exact_kernel) {
-    const size_t lds = osfm_match_lds_bytes(a.ncap);
-    static bool attr_set = false;
-    if (!attr_set) {
-      OSFM_HIP(hipFuncSetAttribute((const void *)match_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      OSFM_HIP(hipFuncSetAttribute((const void *)match_fused2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      OSFM_HIP(hipFuncSetAttribute((const void *)match_fused4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      OSFM_HIP(hipFuncSetAttribute((const void *)match_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-      attr_set = true;
-    }
-    if (match_kernel_version() == 1)
-      hipLaunchKernelGGL(match_fused_kernel, dim3((unsigned)n_pairs), dim3(kThreads), lds, ctx->stream, a);
-    else if (match_kernel_version() == 2)
-      hipLaunchKernelGGL(match_fused2_kernel, dim3((unsigned)n_pairs), dim3(kThreads), osfm_match2_lds_bytes(a.ncap), ctx->stream, a);
-    else
-      hipLaunchKernelGGL(match_fused4_kernel, dim3((unsigned)n_pairs), dim3(kThreads), osfm_match4_lds_bytes(a.ncap), ctx->stream, a);
+    hipLaunchKernelGGL(match_fused4_kernel, dim3((unsigned)n_pairs), dim3(kThreads), osfm_match4_lds_bytes(a.ncap), stream, a);
   } else {
     const size_t lds = (size_t)a.ncap * 6 + 64;
-    hipLaunchKernelGGL(match_exact_kernel, dim3((unsigned)n_pairs), dim3(kThreads), lds, ctx->stream, a,
-                       d_flags != nullptr ? 1 : 0);
+    hipLaunchKernelGGL(match_exact_kernel, dim3((unsigned)n_pairs), dim3(kThreads), lds, stream, a, d_flags != nullptr ? 1 : 0);
   }
-#ifdef OSFM_PHASE_TIMING
-  if (!exact_kernel && match_kernel_version() == 2) {
-    OSFM_HIP(hipStreamSynchronize(ctx->stream));
-    unsigned long long h[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    OSFM_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof(h)));
-    OSFM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)));
-    const char *nm[8] = {"rowblock prologue (A operands, norms)", "fold of column partials", "chunk DMA issue", "compute (B frag reads, MFMA, epilogue)",
-                         "column partials -> LDS (drains the DMA)", "row-block merge + row rechecks", "step barrier", "tail (column tests, rechecks, emit)"};
-    unsigned long long tot = 0;
-    for (int i = 0; i < 8; i++) tot += h[i];
-    for (int i = 0; i < 8; i++)
-      fprintf(stderr, "[phase] %-48s %8.3f M wave-ticks  %5.1f %%\n", nm[i], h[i] * 1e-6, 100.0 * h[i] / (double)tot);
-  }
-#endif
   OSFM_HIP(hipGetLastError());
   return OSFM_OK;
 }

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -28,6 +29,11 @@ void osfm_set_error(const char *fmt, ...);
   } while (0)
 
 struct osfm_ctx {
+  // Every entry point that takes the context holds this lock for the duration of the call: the stream, the events and the
+  // device buffers a call allocates are then used by one host thread at a time.  Threads that want concurrency on one GPU
+  // create one context each (the Python layer keeps a context per thread, _lib.default_context).  Recursive: the leaf
+  // functions are implemented on top of the batched entry points.
+  std::recursive_mutex mu;
   int device = 0;
   int num_cus = 0;
   hipStream_t stream = nullptr;
@@ -62,15 +68,31 @@ struct osfm_match_result {
   std::vector<int32_t> matches;  // total x 2
 };
 
+#define OSFM_CTX_LOCK(ctx) std::lock_guard<std::recursive_mutex> osfm_ctx_lock_((ctx)->mu)
+
+// Per-device one-time hipFuncSetAttribute bookkeeping (attributes are per device, the flags must not be process-wide booleans)
+struct OsfmPerDeviceOnce {
+  std::mutex mu;
+  bool done[64] = {false};
+  template <class F>
+  int run(int device, F f) {
+    std::lock_guard<std::mutex> lk(mu);
+    if (device >= 0 && device < 64 && done[device]) return OSFM_OK;
+    const int rc = f();
+    if (rc == OSFM_OK && device >= 0 && device < 64) done[device] = true;
+    return rc;
+  }
+};
+
 // match.hip
 int osfm_launch_match(osfm_ctx *ctx, const osfm_store *store, const int32_t *d_pairs, int64_t n_pairs,
-                      double ratio, int symmetric, int cap, int32_t *d_counts, uint32_t *d_matches,
-                      int32_t *d_flags, bool exact_kernel);
+                      double ratio, int symmetric, int squared_ratio, int cap, int32_t *d_counts, uint32_t *d_matches,
+                      int32_t *d_flags, bool exact_kernel, hipStream_t stream);
 // ransac.hip
 // in place: counts/matches of each pair are replaced by the inliers (or 0 when the pair fails a gate)
 int osfm_launch_ransac_pairs(osfm_ctx *ctx, const osfm_store *store, const int32_t *d_pairs,
                              int64_t n_pairs, int cap, int min_match, double thr, double conf,
-                             int max_iters, int32_t *d_counts, uint32_t *d_matches, double *d_F_or_null);
+                             int max_iters, int32_t *d_counts, uint32_t *d_matches, double *d_F_or_null, hipStream_t stream);
 int osfm_launch_ransac_single(osfm_ctx *ctx, const double *d_p1, const double *d_p2, int n, double thr,
                               double conf, int max_iters, double *d_F, uint8_t *d_mask,
                               int32_t *d_info);

@@ -655,9 +655,18 @@ __global__ void __launch_bounds__(64) lmeds_single_kernel(const double *p1, cons
 
 }  // namespace
 
+static int ensure_ransac_attributes(int device) {
+  static OsfmPerDeviceOnce once;
+  return once.run(device, []() -> int {
+    OSFM_HIP(hipFuncSetAttribute((const void *)ransac_pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    OSFM_HIP(hipFuncSetAttribute((const void *)ransac_single_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return OSFM_OK;
+  });
+}
+
 int osfm_launch_ransac_pairs(osfm_ctx *ctx, const osfm_store *store, const int32_t *d_pairs, int64_t n_pairs, int cap,
                              int min_match, double thr, double conf, int max_iters, int32_t *d_counts,
-                             uint32_t *d_matches, double *d_F_or_null) {
+                             uint32_t *d_matches, double *d_F_or_null, hipStream_t stream) {
   if (n_pairs == 0) return OSFM_OK;
   OSFM_REQUIRE(cap <= kMaxPts, OSFM_E_UNSUPPORTED, "cap %d > %d", cap, kMaxPts);
   RansacPairsArgs a;
@@ -674,13 +683,11 @@ int osfm_launch_ransac_pairs(osfm_ctx *ctx, const osfm_store *store, const int32
   a.matches = d_matches;
   a.F_out = d_F_or_null;
   const size_t lds = sizeof(RansacShared) + (size_t)((cap + 3) & ~3) * 16 + 64;
-  static bool attr_set = false;
-  if (!attr_set) {
-    OSFM_HIP(hipFuncSetAttribute((const void *)ransac_pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    OSFM_HIP(hipFuncSetAttribute((const void *)ransac_single_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
+  {
+    const int rc = ensure_ransac_attributes(ctx->device);
+    if (rc != OSFM_OK) return rc;
   }
-  hipLaunchKernelGGL(ransac_pairs_kernel, dim3((unsigned)n_pairs), dim3(kThreads), lds, ctx->stream, a);
+  hipLaunchKernelGGL(ransac_pairs_kernel, dim3((unsigned)n_pairs), dim3(kThreads), lds, stream, a);
   OSFM_HIP(hipGetLastError());
   return OSFM_OK;
 }
@@ -688,10 +695,9 @@ int osfm_launch_ransac_pairs(osfm_ctx *ctx, const osfm_store *store, const int32
 int osfm_launch_ransac_single(osfm_ctx *ctx, const double *d_p1, const double *d_p2, int n, double thr, double conf,
                               int max_iters, double *d_F, uint8_t *d_mask, int32_t *d_info) {
   OSFM_REQUIRE(n <= kMaxPts, OSFM_E_UNSUPPORTED, "more than %d correspondences", kMaxPts);
-  static bool attr_set = false;
-  if (!attr_set) {
-    OSFM_HIP(hipFuncSetAttribute((const void *)ransac_single_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
+  {
+    const int rc = ensure_ransac_attributes(ctx->device);
+    if (rc != OSFM_OK) return rc;
   }
   if (n < 15)  // cv2 switches to LMedS below 15 correspondences
     hipLaunchKernelGGL(lmeds_single_kernel, dim3(1), dim3(64), 0, ctx->stream, d_p1, d_p2, n, conf, max_iters, d_F, d_mask, d_info);
@@ -710,6 +716,7 @@ extern "C" int osfm_ransac_fundamental(osfm_ctx *ctx, const double *p1, const do
   for (int i = 0; i < n; ++i) mask[i] = 0;
   if (n < 7) return OSFM_OK;  // cv2: npoints < 7 -> empty Mat
   OSFM_REQUIRE(n >= 8, OSFM_E_UNSUPPORTED, "n = 7: cv2 returns the stacked 7-point solutions; the reference requires >= 8 matches (matching.py:787)");
+  OSFM_CTX_LOCK(ctx);
   OSFM_HIP(hipSetDevice(ctx->device));
   double *d_p1 = nullptr, *d_p2 = nullptr, *d_F = nullptr;
   uint8_t *d_mask = nullptr;

@@ -169,6 +169,7 @@ extern "C" int osfm_pixel_bearings(osfm_ctx *ctx, int model, const double *cam, 
     for (int i = 0; i < 16; i++) cp.v[i] = i < np ? cam[i] : 0.0;
   }
   if (n == 0) return OSFM_OK;
+  OSFM_CTX_LOCK(ctx);
   OSFM_HIP(hipSetDevice(ctx->device));
   DevBuf d_px, d_out;
   OSFM_HIP(d_px.alloc((size_t)n * 16));
@@ -199,6 +200,7 @@ extern "C" int osfm_relpose_pairs(osfm_ctx *ctx, const double *b1, const double 
                  "osfm_relpose_pairs: offsets must ascend (pair %d)", p);
   const int64_t total = offsets[n_pairs];
   OSFM_REQUIRE(total == 0 || (b1 && b2 && mask), OSFM_E_INVALID, "osfm_relpose_pairs: null bearings / mask");
+  OSFM_CTX_LOCK(ctx);
   OSFM_HIP(hipSetDevice(ctx->device));
   constexpr int kChunk = 8192;  // pairs per launch: bounds the model workspace (60 KiB per pair)
   const int chunk = std::min(n_pairs, kChunk);

@@ -13,8 +13,11 @@
 //   tracks      = one stable 64-bit radix sort by (rank of the root, rank): components come out in
 //                 the order of their first-inserted member, members in insertion order;
 //   _good_track = a second sort by (root rank, image) exposes repeated images as equal neighbours.
-// Everything else is scans (hipCUB).  Bit-identical to oracle/tracks_oracle.c.
-#include <hipcub/hipcub.hpp>
+// Everything else is scans (rocPRIM).  Bit-identical to oracle/tracks_oracle.c.
+#include <cstring>  // rocprim's texture iterator calls the host memset
+#include <memory>
+
+#include <rocprim/rocprim.hpp>
 
 #include <vector>
 
@@ -164,19 +167,25 @@ struct osfm_tracks {
 
 extern "C" int osfm_tracks_create(osfm_ctx *ctx, const int32_t *edge_a, const int32_t *edge_b, int64_t n_edges,
                                   const int64_t *node_offsets, int32_t n_images, int32_t min_length, osfm_tracks **out) {
-  OSFM_REQUIRE(ctx && out && node_offsets && n_images > 0 && n_edges >= 0 && (n_edges == 0 || (edge_a && edge_b)), OSFM_E_INVALID,
+  OSFM_REQUIRE(ctx && out && node_offsets && n_images >= 0 && n_edges >= 0 && (n_edges == 0 || (edge_a && edge_b)), OSFM_E_INVALID,
                "osfm_tracks_create: bad argument");
+  *out = nullptr;
   OSFM_REQUIRE(n_edges < (1ll << 31) - 1, OSFM_E_UNSUPPORTED, "more than 2^31 matches");
   const long N = node_offsets[n_images], E = n_edges;
   OSFM_REQUIRE(N >= 0 && N < (1ll << 31), OSFM_E_UNSUPPORTED, "more than 2^31 features");
   for (int64_t i = 0; i < E; ++i)
     OSFM_REQUIRE(edge_a[i] >= 0 && edge_a[i] < N && edge_b[i] >= 0 && edge_b[i] < N, OSFM_E_INVALID, "match %lld references node %d / %d",
                  (long long)i, edge_a[i], edge_b[i]);
+  OSFM_CTX_LOCK(ctx);
   OSFM_HIP(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
-  osfm_tracks *T = new osfm_tracks();
-  *out = T;
-  if (E == 0 || N == 0) return OSFM_OK;
+  // the result object is handed to the caller only on success: no leak when a later step fails
+  std::unique_ptr<osfm_tracks> owner(new osfm_tracks());
+  osfm_tracks *T = owner.get();
+  if (E == 0 || N == 0) {  // no images or no matches: an empty table, as tracking.create_tracks_manager returns an empty manager
+    *out = owner.release();
+    return OSFM_OK;
+  }
   DevBuf B;
   int *ea = B.alloc<int>(E), *eb = B.alloc<int>(E);
   long long *off = B.alloc<long long>((size_t)n_images + 1);
@@ -189,13 +198,13 @@ extern "C" int osfm_tracks_create(osfm_ctx *ctx, const int32_t *edge_a, const in
   int *o_track = B.alloc<int>(N), *o_image = B.alloc<int>(N), *o_feature = B.alloc<int>(N);
   int *counter = B.alloc<int>(4);
   size_t tmp_bytes = 0, need = 0;
-  hipcub::DeviceRadixSort::SortPairs(nullptr, need, keys_in, keys, nodes_in, nodes, (int)N, 0, 64, st);
+  (void)rocprim::radix_sort_pairs(nullptr, need, keys_in, keys, nodes_in, nodes, (size_t)N, 0u, 64u, st);
   tmp_bytes = need;
-  hipcub::DeviceRadixSort::SortKeys(nullptr, need, keys2_in, keys2, (int)N, 0, 64, st);
+  (void)rocprim::radix_sort_keys(nullptr, need, keys2_in, keys2, (size_t)N, 0u, 64u, st);
   tmp_bytes = std::max(tmp_bytes, need);
-  hipcub::DeviceScan::InclusiveSum(nullptr, need, head, segincl, (int)N, st);
+  (void)rocprim::inclusive_scan(nullptr, need, head, segincl, (size_t)N, rocprim::plus<int>(), st);
   tmp_bytes = std::max(tmp_bytes, need);
-  hipcub::DeviceScan::ExclusiveSum(nullptr, need, flag, obsidx, (int)N, st);
+  (void)rocprim::exclusive_scan(nullptr, need, flag, obsidx, 0, (size_t)N, rocprim::plus<int>(), st);
   tmp_bytes = std::max(tmp_bytes, need);
   unsigned char *tmp = B.alloc<unsigned char>(tmp_bytes + 256);
   OSFM_REQUIRE(B.err == hipSuccess, OSFM_E_NOMEM, "tracks: device allocation failed: %s", hipGetErrorString(B.err));
@@ -211,30 +220,33 @@ extern "C" int osfm_tracks_create(osfm_ctx *ctx, const int32_t *edge_a, const in
   hipLaunchKernelGGL(hook_kernel, dim3(nblk(E)), dim3(TPB), 0, st, ea, eb, E, rank, parent);
   hipLaunchKernelGGL(key_kernel, dim3(nblk(N)), dim3(TPB), 0, st, rank, parent, N, keys_in, counter);
   size_t tb = tmp_bytes;
-  OSFM_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb, keys_in, keys, nodes_in, nodes, (int)N, 0, 64, st));
+  OSFM_HIP(rocprim::radix_sort_pairs(tmp, tb, keys_in, keys, nodes_in, nodes, (size_t)N, 0u, 64u, st));
   int h_count[4] = {0, 0, 0, 0};
   OSFM_HIP(hipMemcpyAsync(h_count, counter, 4, hipMemcpyDeviceToHost, st));
   OSFM_HIP(hipStreamSynchronize(st));
   const long Na = h_count[0];  // nodes that appear in a match, now the first Na sorted entries
-  if (Na == 0) return OSFM_OK;
+  if (Na == 0) {
+    *out = owner.release();
+    return OSFM_OK;
+  }
   hipLaunchKernelGGL(head_kernel, dim3(nblk(Na)), dim3(TPB), 0, st, keys, Na, head);
   tb = tmp_bytes;
-  OSFM_HIP(hipcub::DeviceScan::InclusiveSum(tmp, tb, head, segincl, (int)Na, st));
+  OSFM_HIP(rocprim::inclusive_scan(tmp, tb, head, segincl, (size_t)Na, rocprim::plus<int>(), st));
   int nseg = 0;
   OSFM_HIP(hipMemcpyAsync(&nseg, segincl + (Na - 1), 4, hipMemcpyDeviceToHost, st));
   OSFM_HIP(hipStreamSynchronize(st));
   hipLaunchKernelGGL(segstart_kernel, dim3(nblk(Na)), dim3(TPB), 0, st, head, segincl, Na, segstart);
   hipLaunchKernelGGL(key2_kernel, dim3(nblk(Na)), dim3(TPB), 0, st, keys, nodes, Na, off, n_images, keys2_in);
   tb = tmp_bytes;
-  OSFM_HIP(hipcub::DeviceRadixSort::SortKeys(tmp, tb, keys2_in, keys2, (int)Na, 0, 64, st));
+  OSFM_HIP(rocprim::radix_sort_keys(tmp, tb, keys2_in, keys2, (size_t)Na, 0u, 64u, st));
   OSFM_HIP(hipMemsetAsync(bad, 0, (size_t)nseg * 4, st));
   hipLaunchKernelGGL(dup_kernel, dim3(nblk(Na)), dim3(TPB), 0, st, keys2, segincl, Na, bad);
   hipLaunchKernelGGL(good_kernel, dim3(nblk(nseg)), dim3(TPB), 0, st, segstart, bad, nseg, Na, min_length, good);
   tb = tmp_bytes;
-  OSFM_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, good, trackid, nseg, st));
+  OSFM_HIP(rocprim::exclusive_scan(tmp, tb, good, trackid, 0, (size_t)nseg, rocprim::plus<int>(), st));
   hipLaunchKernelGGL(obsflag_kernel, dim3(nblk(Na)), dim3(TPB), 0, st, segincl, good, Na, flag);
   tb = tmp_bytes;
-  OSFM_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tb, flag, obsidx, (int)Na, st));
+  OSFM_HIP(rocprim::exclusive_scan(tmp, tb, flag, obsidx, 0, (size_t)Na, rocprim::plus<int>(), st));
   int last[4] = {0, 0, 0, 0};  // trackid[nseg-1], good[nseg-1], obsidx[Na-1], flag[Na-1]
   OSFM_HIP(hipMemcpyAsync(&last[0], trackid + (nseg - 1), 4, hipMemcpyDeviceToHost, st));
   OSFM_HIP(hipMemcpyAsync(&last[1], good + (nseg - 1), 4, hipMemcpyDeviceToHost, st));
@@ -258,6 +270,7 @@ extern "C" int osfm_tracks_create(osfm_ctx *ctx, const int32_t *edge_a, const in
   float ms = 0.f;
   OSFM_HIP(hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]));
   T->ms_device = ms;
+  *out = owner.release();
   return OSFM_OK;
 }
 extern "C" int64_t osfm_tracks_num_tracks(const osfm_tracks *t) { return t ? t->n_tracks : 0; }

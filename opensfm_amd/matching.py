@@ -7,6 +7,9 @@ this module                        reference
 ================================  =====================================================
 ``match_brute_force``              ``opensfm/matching.py:723-756``
 ``match_brute_force_symmetric``    ``opensfm/matching.py:759-777``
+``build_flann_index``              ``opensfm/features.py:638-674`` (exact index, see below)
+``match_flann``                    ``opensfm/matching.py:683-697``
+``match_flann_symmetric``          ``opensfm/matching.py:700-720``
 ``robust_match_fundamental``       ``opensfm/matching.py:780-802``
 ``robust_match``                   ``opensfm/matching.py:906-929``
 ``robust_match_calibrated``        ``opensfm/matching.py:871-903``
@@ -18,7 +21,10 @@ this module                        reference
 
 Differences that are deliberate: the unordered ``set`` intersection of the reference is returned
 sorted by ``(i, j)``; the batched entry point keeps all descriptors resident in HBM
-(``DescriptorStore``) instead of the reference's LRU of npz loads (``feature_loading.py``).
+(``DescriptorStore``) instead of the reference's LRU of npz loads (``feature_loading.py``);
+``matcher_type: FLANN`` runs the reference's FLANN *semantics* (ratio test on squared float32 distances,
+query direction of ``match_flann``) on an EXACT 2-NN search -- the reference's k-means index is approximate and
+randomly initialised, so its own output is not reproducible; the exact search is its ``checks -> infinity`` limit.
 There is no CPU fallback.
 """
 from __future__ import annotations
@@ -57,7 +63,7 @@ def _fptr(a: np.ndarray, t):
 # --------------------------------------------------------------------------------------------
 # leaf functions (drop-ins)
 # --------------------------------------------------------------------------------------------
-def _match_leaf(f1: np.ndarray, f2: np.ndarray, ratio: float, symmetric: bool, ctx=None) -> np.ndarray:
+def _match_leaf(f1: np.ndarray, f2: np.ndarray, ratio: float, symmetric: bool, ctx=None, flags: int = 0) -> np.ndarray:
     assert f1.dtype.type == f2.dtype.type  # matching.py:737
     if f1.dtype.type == np.uint8:
         # matching.py:738-739: uint8 descriptors switch cv2 to Hamming; never reached by HAHOG/SIFT
@@ -68,12 +74,12 @@ def _match_leaf(f1: np.ndarray, f2: np.ndarray, ratio: float, symmetric: bool, c
     a = np.ascontiguousarray(f1, np.float32)
     b = np.ascontiguousarray(f2, np.float32)
     dim = a.shape[1] if a.ndim == 2 and len(a) else (b.shape[1] if b.ndim == 2 and len(b) else 128)
-    cap = max(1, min(len(a), len(b)) if symmetric else len(a))
+    cap = max(1, min(len(a), len(b)) if symmetric else max(len(a), len(b)))
     out = np.empty((cap, 2), np.int32)
     n = C.c_int(0)
     check(
-        lib.osfm_match_l2_ratio(ctx.handle, _fptr(a, C.c_float), len(a), _fptr(b, C.c_float), len(b), dim,
-                                float(ratio), int(symmetric), _fptr(out, C.c_int32), cap, C.byref(n)),
+        lib.osfm_match_l2_ratio_ex(ctx.handle, _fptr(a, C.c_float), len(a), _fptr(b, C.c_float), len(b), dim,
+                                   float(ratio), int(symmetric), int(flags), _fptr(out, C.c_int32), cap, C.byref(n)),
         "osfm_match_l2_ratio",
     )
     return out[: n.value]
@@ -126,6 +132,43 @@ def match_brute_force_symmetric(fi: np.ndarray, fj: np.ndarray, config: Dict[str
         m = _match_guided_leaf(fi, fj, _cfg(config, "lowes_ratio"), True, maskij)
     else:
         m = _match_leaf(fi, fj, _cfg(config, "lowes_ratio"), True)
+    return [(int(a), int(b)) for a, b in m]
+
+
+class ExactIndex:
+    """What ``build_flann_index`` returns here: the image's descriptors, searched EXACTLY on the GPU.
+
+    The reference builds ``cv2.flann_Index(features, algorithm=KMEANS, branching=8, iterations=10)`` (``features.py:638-674``) and
+    searches it with ``checks=flann_checks`` (20): an approximate nearest-neighbour search whose k-means centres are drawn at
+    random, so neither the index nor its results are reproducible run to run.  The drop-in keeps the interface (an opaque object
+    handed to ``match_flann``; ``knnSearch(queries, 2)`` -> ``(indices, squared float32 distances)``) and answers every query with
+    the true two nearest neighbours, i.e. the result the reference converges to as ``checks`` grows."""
+
+    def __init__(self, features: np.ndarray):
+        self.features = np.ascontiguousarray(features, np.float32).reshape(-1, 128)
+
+    def __len__(self) -> int:
+        return len(self.features)
+
+
+def build_flann_index(descriptors: np.ndarray, config: Dict[str, Any]) -> ExactIndex:
+    """``features.build_flann_index`` (``opensfm/features.py:638-674``): same arguments; the ``flann_*`` tuning keys of ``config``
+    have no meaning for an exact search and are ignored."""
+    return ExactIndex(descriptors)
+
+
+def match_flann(index: ExactIndex, f2: np.ndarray, config: Dict[str, Any]) -> List[Tuple[int, int]]:
+    """Match using the index of the first image and apply Lowe's ratio filter on squared distances (``matching.py:683-697``):
+    for every descriptor of ``f2`` its two nearest neighbours in the index, kept iff ``d0 < float32(lowes_ratio ** 2) * d1``;
+    returns ``(index feature, f2 feature)`` in the order of the ``f2`` features, as the reference."""
+    m = _match_leaf(index.features, f2, _cfg(config, "lowes_ratio"), False, flags=_lib.MATCH_SQUARED_RATIO)
+    return [(int(a), int(b)) for a, b in m]
+
+
+def match_flann_symmetric(fi: np.ndarray, indexi: ExactIndex, fj: np.ndarray, indexj: ExactIndex, config: Dict[str, Any],
+                          ) -> List[Tuple[int, int]]:
+    """Match using FLANN semantics in both directions and keep consistent matches (``matching.py:700-720``)."""
+    m = _match_leaf(indexi.features, indexj.features, _cfg(config, "lowes_ratio"), True, flags=_lib.MATCH_SQUARED_RATIO)
     return [(int(a), int(b)) for a, b in m]
 
 
@@ -347,9 +390,20 @@ class DescriptorStore:
             pass
 
 
+def _matcher_flags(config: Optional[Dict[str, Any]]) -> int:
+    """matcher_type -> OSFM_MATCH_* flags; raises for the matchers that are not on the GPU path."""
+    mt = str(_cfg(config, "matcher_type")).upper()
+    if mt == "BRUTEFORCE":
+        return 0
+    if mt == "FLANN":  # FLANN semantics on the exact search (see the module docstring)
+        return _lib.MATCH_SQUARED_RATIO
+    raise NotImplementedError(f"matcher_type {mt!r} is not on the GPU path (BRUTEFORCE, FLANN)")
+
+
 def make_params(config: Optional[Dict[str, Any]] = None, robust: bool = True) -> MatchParams:
     p = MatchParams()
     _lib.load().osfm_match_params_default(C.byref(p))
+    p.flags = _matcher_flags(config)
     p.lowes_ratio = float(_cfg(config, "lowes_ratio"))
     p.symmetric = int(bool(_cfg(config, "symmetric_matching")))
     p.robust = int(robust)
@@ -434,8 +488,13 @@ def match_images_with_pairs(data, config_override: Dict[str, Any], exifs: Dict[s
     """
     config = dict(data.config)
     config.update(config_override)
-    if str(config.get("matcher_type", "BRUTEFORCE")).upper() != "BRUTEFORCE":
-        raise NotImplementedError("GPU path implements matcher_type BRUTEFORCE (exact); FLANN is approximate/randomised")
+    _matcher_flags(config)  # raises for matchers that are not on the GPU path (WORDS)
+    for key in ("matching_use_filters", "matching_use_segmentation"):
+        if config.get(key):  # matching.py:352,618-628: would change the result, and is not implemented here
+            raise NotImplementedError(f"config {key!r} is not implemented on the GPU path")
+    if int(_cfg(config, "robust_matching_min_match")) < 15:
+        raise NotImplementedError("robust_matching_min_match < 15 reaches cv2's LMedS branch inside match(); only the leaf "
+                                  "find_fundamental_ransac implements it")
     cameras = data.load_camera_models()
     images = sorted({im for pair in pairs for im in pair})
     index = {im: k for k, im in enumerate(images)}
@@ -446,12 +505,23 @@ def match_images_with_pairs(data, config_override: Dict[str, Any], exifs: Dict[s
             raise NotImplementedError(f"camera of {im}: unknown projection type {cam.projection_type!r}")
         cams.append(cam)
         fd = data.load_features(im)
-        points = np.asarray(fd.points)
-        desc = np.asarray(fd.descriptors)
+        # an image without (usable) features is a count-0 image: every pair it takes part in returns np.array([]) like the
+        # reference's dummy result (matching.py:359-374: features_data is None / fewer than 2 points / no descriptors)
+        points = np.zeros((0, 3)) if fd is None or fd.points is None else np.asarray(fd.points)
+        desc = None if fd is None else fd.descriptors
         mask = None
-        if hasattr(data, "load_features_mask"):
-            mask = np.asarray(data.load_features_mask(im, points[:, :2]), bool)
-            points, desc = points[mask], desc[mask]
+        if points.ndim != 2 or len(points) == 0 or desc is None:
+            points, desc = np.zeros((0, 3)), np.zeros((0, 128), np.float32)
+        else:
+            desc = np.asarray(desc)
+            if hasattr(data, "load_features_mask"):
+                mask = np.asarray(data.load_features_mask(im, points[:, :2]), bool)
+                points, desc = points[mask], desc[mask]
+            if len(points) < 2:  # the masked set decides (load_all_data(masked=True), matching.py:354-366)
+                points, desc = np.zeros((0, 3)), np.zeros((0, 128), np.float32)
+        if len(points) > _lib.MAX_FEATURES:
+            raise NotImplementedError(f"image {im} has {len(points)} features after masking; the GPU path holds at most "
+                                      f"{_lib.MAX_FEATURES} per image (OSFM_MAX_FEATURES)")
         descs.append(desc)
         pts.append(points)
         masks.append(mask)

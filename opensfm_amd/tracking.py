@@ -15,7 +15,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from ._lib import Context, check, default_context, load
+from ._lib import Context, OsfmError, check, default_context, load
 
 
 def _ip(a, t):
@@ -31,6 +31,8 @@ def edges_from_match_graph(pairs: np.ndarray, counts: np.ndarray, matches: np.nd
     matches = np.asarray(matches, np.int64).reshape(-1, 2)
     rep = np.repeat(np.arange(len(pairs)), counts)
     node_offsets = np.asarray(node_offsets, np.int64)
+    if len(node_offsets) and node_offsets[-1] >= 2 ** 31:  # node ids are int32 at the C ABI: refuse instead of wrapping
+        raise OsfmError("more than 2^31 features: node ids do not fit the int32 of osfm_tracks_create")
     ea = node_offsets[pairs[rep, 0]] + matches[:, 0]
     eb = node_offsets[pairs[rep, 1]] + matches[:, 1]
     return np.ascontiguousarray(ea, np.int32), np.ascontiguousarray(eb, np.int32)
@@ -42,9 +44,17 @@ def create_tracks_arrays(edge_a: np.ndarray, edge_b: np.ndarray, node_offsets: n
     reference's track order, members in the reference's insertion order."""
     ctx = ctx or default_context()
     lib = load()
+    off = np.ascontiguousarray(node_offsets, np.int64)
+    if len(off) and off[-1] >= 2 ** 31:
+        raise OsfmError("more than 2^31 features: node ids do not fit the int32 of osfm_tracks_create")
+    for e in (edge_a, edge_b):  # the cast below must not wrap an out-of-range id into a valid one
+        e = np.asarray(e)
+        if e.size and (e.min() < 0 or e.max() >= 2 ** 31):
+            raise OsfmError("match references a node id outside [0, 2^31)")
     ea = np.ascontiguousarray(edge_a, np.int32)
     eb = np.ascontiguousarray(edge_b, np.int32)
-    off = np.ascontiguousarray(node_offsets, np.int64)
+    if len(off) == 0:
+        off = np.zeros(1, np.int64)
     h = C.c_void_p()
     check(lib.osfm_tracks_create(ctx.handle, _ip(ea, C.c_int32), _ip(eb, C.c_int32), len(ea), _ip(off, C.c_int64), len(off) - 1,
                                  int(min_length), C.byref(h)), "osfm_tracks_create")

@@ -182,6 +182,16 @@ def match_brute_force_symmetric(fi: np.ndarray, fj: np.ndarray, ratio: float = 0
     return out[:n].copy()
 
 
+def match_flann(f1: np.ndarray, f2: np.ndarray, ratio: float = 0.8) -> np.ndarray:
+    """``matching.py:683-697`` with an exact search: index over ``f1``, queries ``f2``; (K, 2) of (index row, query row) in query order."""
+    f1 = np.ascontiguousarray(f1, np.float32)
+    f2 = np.ascontiguousarray(f2, np.float32)
+    cap = max(1, len(f2))
+    out = np.empty((cap, 2), np.int32)
+    n = lib().oracle_match_flann(_p(f1, C.c_float), len(f1), _p(f2, C.c_float), len(f2), 128, C.c_double(ratio), _p(out, C.c_int), cap)
+    return out[:n].copy()
+
+
 def find_fundamental_ransac(p1: np.ndarray, p2: np.ndarray, thr: float = 0.004, conf: float = 0.9999,
                             max_iters: int = 1000) -> Tuple[Optional[np.ndarray], np.ndarray, int]:
     """``cv2.findFundamentalMat(p1, p2, FM_RANSAC, thr, conf)`` restated; returns (F|None, mask, iters)."""

@@ -100,6 +100,32 @@ void oracle_knn2_l2(const float *f1, int n1, const float *f2, int n2, int dim, i
 /* matching.py:723-756: returns good[i] = j or -1.  squared_mode restates match_flann's test
  * (matching.py:695-696): numpy float32 array * python float stays float32:
  *     d0 < float32(ratio**2) * d1     on SQUARED distances. */
+/* The exact limit of index.knnSearch(f2, 2) (matching.py:694): FLANN computes, compares and returns SQUARED L2 distances,
+ * no square root anywhere; two nearest by the same insertion rule (lowest index first among equals). */
+static void knn2_squared(const float *f1, int n1, const float *f2, int n2, int dim, int *out_idx, float *out_s1, float *out_s2) {
+#pragma omp parallel for schedule(dynamic, 16)
+  for (int i = 0; i < n1; i++) {
+    float bs0 = INFINITY, bs1 = INFINITY;
+    int bi0 = -1;
+    const float *a = f1 + (size_t)i * dim;
+    for (int j = 0; j < n2; j++) {
+      float sq = l2sqr_f32(a, f2 + (size_t)j * dim, dim);
+      if (sq < bs1) {
+        if (bs0 > sq) {
+          bs1 = bs0;
+          bs0 = sq;
+          bi0 = j;
+        } else {
+          bs1 = sq;
+        }
+      }
+    }
+    out_idx[i] = n2 < 2 ? -1 : bi0;
+    out_s1[i] = bs0;
+    out_s2[i] = bs1;
+  }
+}
+
 void oracle_match_brute_force(const float *f1, int n1, const float *f2, int n2, int dim,
                               double ratio, int squared_mode, int *good) {
   int *idx = (int *)malloc(sizeof(int) * (size_t)(n1 > 0 ? n1 : 1));
@@ -107,7 +133,10 @@ void oracle_match_brute_force(const float *f1, int n1, const float *f2, int n2, 
   float *d2 = (float *)malloc(sizeof(float) * (size_t)(n1 > 0 ? n1 : 1));
   float *s1 = (float *)malloc(sizeof(float) * (size_t)(n1 > 0 ? n1 : 1));
   float *s2 = (float *)malloc(sizeof(float) * (size_t)(n1 > 0 ? n1 : 1));
-  oracle_knn2_l2(f1, n1, f2, n2, dim, idx, d1, d2, s1, s2);
+  if (squared_mode)
+    knn2_squared(f1, n1, f2, n2, dim, idx, s1, s2);
+  else
+    oracle_knn2_l2(f1, n1, f2, n2, dim, idx, d1, d2, s1, s2);
   for (int i = 0; i < n1; i++) {
     int ok = 0;
     if (idx[i] >= 0) {
@@ -127,8 +156,26 @@ void oracle_match_brute_force(const float *f1, int n1, const float *f2, int n2, 
   free(s2);
 }
 
-/* matching.py:759-777.  Output pairs (i, j) sorted by (i, j) (the reference returns an unordered
- * python set; we canonicalise).  Returns the number of pairs written (<= cap). */
+/* matching.py:683-697 match_flann(index of image 1, f2): queries are the rows of f2, the index holds f1; returns (index row,
+ * query row) in QUERY order, as `list(zip(results[good, 0], good.nonzero()[0]))` does.  Returns the number of pairs. */
+int oracle_match_flann(const float *f1, int n1, const float *f2, int n2, int dim, double ratio, int *out_pairs, int cap) {
+  int *g = (int *)malloc(sizeof(int) * (size_t)(n2 > 0 ? n2 : 1));
+  oracle_match_brute_force(f2, n2, f1, n1, dim, ratio, 1, g);
+  int n = 0;
+  for (int j = 0; j < n2; j++)
+    if (g[j] >= 0) {
+      if (n < cap) {
+        out_pairs[2 * n] = g[j];
+        out_pairs[2 * n + 1] = j;
+      }
+      n++;
+    }
+  free(g);
+  return n;
+}
+
+/* matching.py:759-777 (and, with squared_mode, match_flann_symmetric :700-720).  Output pairs (i, j) sorted by (i, j) (the
+ * reference returns an unordered python set; we canonicalise).  Returns the number of pairs written (<= cap). */
 int oracle_match_brute_force_symmetric(const float *fi, int ni, const float *fj, int nj, int dim,
                                        double ratio, int squared_mode, int *out_pairs, int cap) {
   int *gij = (int *)malloc(sizeof(int) * (size_t)(ni > 0 ? ni : 1));

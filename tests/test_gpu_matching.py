@@ -116,7 +116,7 @@ def test_fused_equals_exact_kernel_full_size(gpu_ctx):
     from opensfm_amd import _lib
 
     prm = matching.make_params(prm_cfg, robust=False)
-    prm.reserved = 1
+    prm.flags = 1
     res = C.c_void_p()
     lib = _lib.load()
     _lib.check(lib.osfm_match_pairs(store.ctx.handle, store.handle, pairs.ctypes.data_as(C.POINTER(C.c_int32)), len(pairs),
@@ -194,3 +194,81 @@ def test_ties_and_duplicates_above_4096_features(oracle_lib, gpu_ctx):
         for sym, fo in ((False, oracle_lib.match_brute_force), (True, oracle_lib.match_brute_force_symmetric)):
             assert np.array_equal(matching._match_leaf(f1, f2, ratio, sym), fo(f1, f2, ratio))
             assert np.array_equal(matching._match_leaf(f2, f1, ratio, sym), fo(f2, f1, ratio))
+
+
+@pytest.mark.parametrize("n1,n2,seed,ratio", [(2, 2, 0, 0.8), (40, 3, 1, 0.8), (300, 100, 2, 0.8), (1000, 777, 3, 0.7), (2000, 2000, 4, 0.8),
+                                              (4500, 300, 5, 0.9)])
+def test_flann_semantics_equal_oracle(oracle_lib, gpu_ctx, n1, n2, seed, ratio):
+    """matcher_type FLANN on the GPU = match_flann / match_flann_symmetric (matching.py:683-720) with an exact search: squared
+    float32 ratio test, queries of the one-way variant are the SECOND image, matches listed in query order."""
+    from opensfm_amd import matching
+
+    rng = np.random.default_rng(seed)
+    f1 = synthetic._hahog_like(rng, n1).astype(np.float32)
+    f2 = synthetic._hahog_like(rng, n2).astype(np.float32)
+    k = min(n1, n2) // 2
+    f2[:k] = np.clip(f1[rng.permutation(n1)[:k]] + np.rint(rng.normal(0, 3, (k, 128))), 0, 255)
+    cfg = {"lowes_ratio": ratio}
+    i1, i2 = matching.build_flann_index(f1, cfg), matching.build_flann_index(f2, cfg)
+    got = matching.match_flann(i1, f2, cfg)
+    want = oracle_lib.match_flann(f1, f2, ratio)
+    assert got == [tuple(int(v) for v in x) for x in want]
+    gots = matching.match_flann_symmetric(f1, i1, f2, i2, cfg)
+    wants = oracle_lib.match_brute_force_symmetric(f1, f2, ratio, squared=True)
+    assert gots == [tuple(int(v) for v in x) for x in wants]
+    if k >= 8:
+        assert len(wants) >= k // 2
+
+
+def test_flann_semantics_batched_pipeline(oracle_lib, gpu_ctx):
+    """matcher_type FLANN through the batched entry point: squared-ratio descriptor stage + the same geometric stage."""
+    from opensfm_amd import matching
+
+    sc = synthetic.make_matching_scene(6, 500, seed=21)
+    pairs = synthetic.all_pairs(6)
+    store = matching.DescriptorStore.from_packed(sc.desc, sc.pts, sc.offsets, gpu_ctx)
+    counts, m = matching.match_pairs(store, pairs, {"matcher_type": "FLANN"}, robust=False)
+    got = matching.split_matches(counts, m)
+    d = sc.desc.astype(np.float32)
+    for (a, b), g in zip(pairs, got):
+        want = oracle_lib.match_brute_force_symmetric(d[sc.offsets[a]:sc.offsets[a + 1]], d[sc.offsets[b]:sc.offsets[b + 1]], 0.8, squared=True)
+        assert np.array_equal(g, want)
+    store.close()
+
+
+def test_two_threads_share_the_library(oracle_lib, gpu_ctx):
+    """The reference calls the leaf functions from a joblib thread pool (context.py:47-67): concurrent leaf calls -- each thread
+    on its own default context, and two threads sharing ONE context -- must give the single-threaded results."""
+    import threading
+
+    from opensfm_amd import _lib, matching
+
+    rng = np.random.default_rng(77)
+    jobs = []
+    for k in range(6):
+        f1 = synthetic._hahog_like(rng, 700 + 50 * k).astype(np.float32)
+        f2 = synthetic._hahog_like(rng, 900 - 30 * k).astype(np.float32)
+        f2[:300] = np.clip(f1[rng.permutation(len(f1))[:300]] + np.rint(rng.normal(0, 3, (300, 128))), 0, 255)
+        jobs.append((f1, f2, [tuple(int(v) for v in x) for x in oracle_lib.match_brute_force_symmetric(f1, f2)]))
+    for shared in (None, gpu_ctx):
+        errors, seen_ctx = [], set()
+
+        def work(tid):
+            try:
+                ctx = shared or _lib.default_context(0)
+                seen_ctx.add(id(ctx))
+                for rep in range(4):
+                    for f1, f2, want in jobs[tid::2]:
+                        got = matching._match_leaf(f1, f2, 0.8, True, ctx)
+                        if [tuple(int(v) for v in x) for x in got] != want:
+                            errors.append((tid, rep))
+            except Exception as e:  # noqa: BLE001
+                errors.append(repr(e))
+
+        threads = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert errors == []
+        assert len(seen_ctx) == (1 if shared is not None else 2)  # per-thread default contexts

@@ -88,3 +88,36 @@ def test_flann_squared_ratio_variant(oracle_lib):
         if s[o[0]] < r2 * s[o[1]]:
             want.append((i, o[0]))
     assert np.array_equal(got, np.asarray(want, np.int32).reshape(-1, 2))
+
+
+def numpy_flann(f1, f2, ratio=0.8):
+    """matching.py:683-697 with an exact search, in plain numpy: index over f1, queries f2, squared float32 distances,
+    `dists[:, 0] < squared_ratio * dists[:, 1]` evaluated by numpy itself (float32 array * python float)."""
+    if len(f1) < 2:
+        return np.zeros((0, 2), np.int32)
+    results = np.zeros((len(f2), 2), np.int64)
+    dists = np.zeros((len(f2), 2), np.float32)
+    for j, b in enumerate(f2):
+        d = ((f1 - b) ** 2).sum(axis=1, dtype=np.float32).astype(np.float32)
+        order = np.argsort(d, kind="stable")
+        results[j] = order[:2]
+        dists[j] = d[order[:2]]
+    squared_ratio = ratio**2
+    good = dists[:, 0] < squared_ratio * dists[:, 1]
+    return np.asarray(list(zip(results[good, 0], good.nonzero()[0])), np.int32).reshape(-1, 2)
+
+
+@pytest.mark.parametrize("n1,n2,seed,ratio", [(60, 45, 0, 0.8), (45, 60, 1, 0.8), (2, 30, 2, 0.9), (80, 80, 3, 0.6), (30, 1, 4, 0.8)])
+def test_oracle_flann_semantics_equal_numpy(oracle_lib, n1, n2, seed, ratio):
+    """match_flann's squared float32 ratio test, query direction (second image against the index of the first) and result order."""
+    rng = np.random.default_rng(seed)
+    f1 = reference_descriptors(rng, n1)
+    f2 = reference_descriptors(rng, n2)
+    k = min(n1, n2) // 2
+    f2[:k] = np.clip(f1[rng.permutation(n1)[:k]] + rng.integers(-3, 4, (k, 128)), 0, 255)
+    assert np.array_equal(oracle_lib.match_flann(f1, f2, ratio), numpy_flann(f1, f2, ratio))
+    # symmetric: intersection of both directions, canonically sorted
+    a = {tuple(x) for x in numpy_flann(f1, f2, ratio)}
+    b = {(j, i) for i, j in numpy_flann(f2, f1, ratio)}
+    want = np.asarray(sorted(a & b), np.int32).reshape(-1, 2)
+    assert np.array_equal(oracle_lib.match_brute_force_symmetric(f1, f2, ratio, squared=True), want)
