@@ -45,6 +45,7 @@ extern "C" void osfm_ctx_destroy(osfm_ctx *c) {
   for (int i = 0; i < 8; ++i)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->d_rng_table) (void)hipFree(c->d_rng_table);
   delete c;
 }
 

@@ -38,6 +38,7 @@ struct osfm_ctx {
   int num_cus = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  void *d_rng_table = nullptr;  // relpose.hip: the tabulated std::mt19937(42) stream, made on first use
 };
 
 // Tile = 32 descriptors x 128 int8 in MFMA-operand order (4 KiB):

@@ -17,8 +17,15 @@
 
 #if defined(__HIPCC__)
 #define OSFM_HD __host__ __device__ inline
+// Loops with a fixed trip count are unrolled on the device: a lane runs these routines alone on its SIMD (one wavefront per CU in
+// the solver kernels), so the only latency hiding there is comes from issuing the LDS reads of a whole row before the arithmetic.
+// Variable-length loops are written over their full range with a predicate for the same reason (same operations per element).
+#define OSFM_UNROLL _Pragma("unroll")
+#define OSFM_NOUNROLL _Pragma("unroll 1")  // long-bodied outer loops: unrolling them only multiplies the live registers
 #else
 #define OSFM_HD inline
+#define OSFM_UNROLL
+#define OSFM_NOUNROLL
 #endif
 
 namespace osfm_rp {
@@ -51,28 +58,41 @@ OSFM_HD void mul_quad_lin(const double* q, const double* b, double* c) {
     for (int j = 16; j < 20; j++) c[mul_slot(i, j)] += q[i - 10] * b[j - 16];
 }
 
-// Null space of the 5 x 9 epipolar system by Gauss-Jordan with complete pivoting: basis[9][4].
-OSFM_HD int nullspace_5x9(double* A, double* basis) {
+// Per-lane arrays whose element i lives at p[i * STRIDE].  STRIDE = 1 is an ordinary array (host code, register / stack arrays);
+// the lane-per-problem solver kernels keep their matrices in LDS with STRIDE = 64 (element-major, lane-minor: lane l owns
+// p[l], p[64 + l], ...), so that ANY per-lane dynamic index hits the lane's own bank -- pivoting and deflation loops index their
+// matrices differently in every lane and would otherwise live in scratch memory.  The numerics below take "anything indexable".
+template <class T, int STRIDE>
+struct LaneArr {
+  T* p;
+  OSFM_HD T& operator[](int i) const { return p[i * STRIDE]; }
+  OSFM_HD LaneArr operator+(int k) const { return LaneArr{p + k * STRIDE}; }
+};
+
+// Null space of the 5 x 9 epipolar system by Gauss-Jordan with complete pivoting: basis[9][4].  colperm: 9 ints of work space.
+template <class PA, class PB, class PI>
+OSFM_HD int nullspace_5x9(PA A, PB basis, PI colperm) {
   constexpr int m = 5, n = 9;
-  int colperm[9];
-  for (int j = 0; j < n; j++) colperm[j] = j;
+  OSFM_UNROLL for (int j = 0; j < n; j++) colperm[j] = j;
   for (int k = 0; k < m; k++) {
     int pr = k, pc = k;
     double best = 0;
-    for (int i = k; i < m; i++)
-      for (int j = k; j < n; j++)
-        if (fabs(A[i * n + j]) > best) {
-          best = fabs(A[i * n + j]);
+    OSFM_UNROLL for (int i = 0; i < m; i++)
+      OSFM_UNROLL for (int j = 0; j < n; j++) {
+        const double a = fabs(A[i * n + j]);
+        if (i >= k && j >= k && a > best) {
+          best = a;
           pr = i;
           pc = j;
         }
+      }
     if (!(best > 0)) return 0;
-    for (int j = 0; j < n; j++) {
+    OSFM_UNROLL for (int j = 0; j < n; j++) {
       const double t = A[k * n + j];
       A[k * n + j] = A[pr * n + j];
       A[pr * n + j] = t;
     }
-    for (int i = 0; i < m; i++) {
+    OSFM_UNROLL for (int i = 0; i < m; i++) {
       const double t = A[i * n + k];
       A[i * n + k] = A[i * n + pc];
       A[i * n + pc] = t;
@@ -83,47 +103,75 @@ OSFM_HD int nullspace_5x9(double* A, double* basis) {
       colperm[pc] = t;
     }
     const double ip = 1.0 / A[k * n + k];
-    for (int j = 0; j < n; j++) A[k * n + j] *= ip;
+    double rowk[n];
+    OSFM_UNROLL for (int j = 0; j < n; j++) {
+      rowk[j] = A[k * n + j] * ip;
+      A[k * n + j] = rowk[j];
+    }
     for (int i = 0; i < m; i++) {
       if (i == k) continue;
       const double f = A[i * n + k];
       if (f == 0.0) continue;
-      for (int j = 0; j < n; j++) A[i * n + j] -= f * A[k * n + j];
+      OSFM_UNROLL for (int j = 0; j < n; j++) A[i * n + j] -= f * rowk[j];
     }
   }
   constexpr int nf = n - m;
   for (int f = 0; f < nf; f++) {
-    for (int j = 0; j < n; j++) basis[j * nf + f] = 0.0;
+    OSFM_UNROLL for (int j = 0; j < n; j++) basis[j * nf + f] = 0.0;
     // colperm[] is indexed dynamically: written as a select chain so that it stays in registers
-    for (int j = 0; j < n; j++)
-      if (j == colperm[m + f]) basis[j * nf + f] = 1.0;
-    for (int k = 0; k < m; k++) basis[colperm[k] * nf + f] = -A[k * n + m + f];
+    const int cf = colperm[m + f];
+    OSFM_UNROLL for (int j = 0; j < n; j++)
+      if (j == cf) basis[j * nf + f] = 1.0;
+    OSFM_UNROLL for (int k = 0; k < m; k++) basis[colperm[k] * nf + f] = -A[k * n + m + f];
   }
   return 1;
+}
+OSFM_HD int nullspace_5x9(double* A, double* basis) {
+  int colperm[9];
+  return nullspace_5x9(A, basis, colperm);
 }
 
 // Real eigenvalues of a general 10 x 10 matrix (destroyed): elementary-similarity Hessenberg reduction and
 // Francis double-shift QR on the real Schur form, with the classic 60-iteration cap (so the loop is bounded).
-OSFM_HD int real_eigenvalues10(double* a, double* wr) {
+// put(k, value) receives the k-th real eigenvalue, k = 0, 1, ... in the order the iteration deflates them
+template <class PA, class Put>
+OSFM_HD int real_eigenvalues10_put(PA a, Put put) {
   constexpr int n = 10;
   for (int m = 1; m < n - 1; m++) {
     double x = 0.0;
     int i = m;
-    for (int j = m; j < n; j++)
-      if (fabs(a[j * n + m - 1]) > fabs(x)) {
-        x = a[j * n + m - 1];
-        i = j;
-      }
+    {
+      double col[n];
+      OSFM_UNROLL for (int j = 0; j < n; j++) col[j] = a[j * n + m - 1];
+      OSFM_UNROLL for (int j = 0; j < n; j++)
+        if (j >= m && fabs(col[j]) > fabs(x)) {
+          x = col[j];
+          i = j;
+        }
+    }
     if (i != m) {
-      for (int j = m - 1; j < n; j++) {
-        const double t = a[i * n + j];
-        a[i * n + j] = a[m * n + j];
-        a[m * n + j] = t;
+      {
+        double ri[n], rm[n];
+        OSFM_UNROLL for (int j = 0; j < n; j++) {
+          ri[j] = a[i * n + j];
+          rm[j] = a[m * n + j];
+        }
+        OSFM_UNROLL for (int j = 0; j < n; j++)
+          if (j >= m - 1) {
+            a[i * n + j] = rm[j];
+            a[m * n + j] = ri[j];
+          }
       }
-      for (int j = 0; j < n; j++) {
-        const double t = a[j * n + i];
-        a[j * n + i] = a[j * n + m];
-        a[j * n + m] = t;
+      {
+        double ci[n], cm[n];
+        OSFM_UNROLL for (int j = 0; j < n; j++) {
+          ci[j] = a[j * n + i];
+          cm[j] = a[j * n + m];
+        }
+        OSFM_UNROLL for (int j = 0; j < n; j++) {
+          a[j * n + i] = cm[j];
+          a[j * n + m] = ci[j];
+        }
       }
     }
     if (x != 0.0) {
@@ -132,14 +180,29 @@ OSFM_HD int real_eigenvalues10(double* a, double* wr) {
         if (y != 0.0) {
           y /= x;
           a[i * n + m - 1] = y;
-          for (int j = m; j < n; j++) a[i * n + j] -= y * a[m * n + j];
-          for (int j = 0; j < n; j++) a[j * n + m] += y * a[j * n + i];
+          {
+            double ri[n], rm[n];
+            OSFM_UNROLL for (int j = 0; j < n; j++) {
+              ri[j] = a[i * n + j];
+              rm[j] = a[m * n + j];
+            }
+            OSFM_UNROLL for (int j = 0; j < n; j++)
+              if (j >= m) a[i * n + j] = ri[j] - y * rm[j];
+          }
+          {
+            double ci[n], cm[n];
+            OSFM_UNROLL for (int j = 0; j < n; j++) {
+              ci[j] = a[j * n + i];
+              cm[j] = a[j * n + m];
+            }
+            OSFM_UNROLL for (int j = 0; j < n; j++) a[j * n + m] = cm[j] + y * ci[j];
+          }
         }
       }
     }
   }
-  for (int i = 2; i < n; i++)
-    for (int j = 0; j < i - 1; j++) a[i * n + j] = 0.0;
+  OSFM_UNROLL for (int i = 2; i < n; i++)
+    OSFM_UNROLL for (int j = 0; j < i - 1; j++) a[i * n + j] = 0.0;
   int nreal = 0, nn = n - 1, its;
   double anorm = 0.0, t = 0.0, p = 0, q = 0, r = 0, s, w, x, y, z;
   for (int i = 0; i < n; i++)
@@ -158,7 +221,8 @@ OSFM_HD int real_eigenvalues10(double* a, double* wr) {
       }
       x = a[nn * n + nn];
       if (l == nn) {
-        wr[nreal++] = x + t;
+        put(nreal, x + t);
+        nreal++;
         nn--;
       } else {
         y = a[(nn - 1) * n + nn - 1];
@@ -170,8 +234,8 @@ OSFM_HD int real_eigenvalues10(double* a, double* wr) {
           x += t;
           if (q >= 0.0) {
             z = p + (p >= 0.0 ? fabs(z) : -fabs(z));
-            wr[nreal] = wr[nreal + 1] = x + z;
-            if (z != 0.0) wr[nreal + 1] = x - w / z;
+            put(nreal, x + z);
+            put(nreal + 1, z != 0.0 ? x - w / z : x + z);
             nreal += 2;
           }
           nn -= 2;
@@ -232,24 +296,44 @@ OSFM_HD int real_eigenvalues10(double* a, double* wr) {
               z = r / s;
               q /= p;
               r /= p;
-              for (int j = k; j <= nn; j++) {
-                p = a[k * n + j] + q * a[(k + 1) * n + j];
-                if (k != nn - 1) {
-                  p += r * a[(k + 2) * n + j];
-                  a[(k + 2) * n + j] -= p * z;
+              {  // rows k, k + 1 (, k + 2), columns k .. nn
+                const bool three = (k != nn - 1);
+                double r0[n], r1[n], r2[n];
+                OSFM_UNROLL for (int j = 0; j < n; j++) {
+                  r0[j] = a[k * n + j];
+                  r1[j] = a[(k + 1) * n + j];
+                  r2[j] = three ? a[(k + 2) * n + j] : 0.0;
                 }
-                a[(k + 1) * n + j] -= p * y;
-                a[k * n + j] -= p * x;
+                OSFM_UNROLL for (int j = 0; j < n; j++)
+                  if (j >= k && j <= nn) {
+                    double pj = r0[j] + q * r1[j];
+                    if (three) {
+                      pj += r * r2[j];
+                      a[(k + 2) * n + j] = r2[j] - pj * z;
+                    }
+                    a[(k + 1) * n + j] = r1[j] - pj * y;
+                    a[k * n + j] = r0[j] - pj * x;
+                  }
               }
-              const int mmin = nn < k + 3 ? nn : k + 3;
-              for (int i = l; i <= mmin; i++) {
-                p = x * a[i * n + k] + y * a[i * n + k + 1];
-                if (k != nn - 1) {
-                  p += z * a[i * n + k + 2];
-                  a[i * n + k + 2] -= p * r;
+              {  // columns k, k + 1 (, k + 2), rows l .. min(nn, k + 3)
+                const int mmin = nn < k + 3 ? nn : k + 3;
+                const bool three = (k != nn - 1);
+                double c0[n], c1[n], c2[n];
+                OSFM_UNROLL for (int i = 0; i < n; i++) {
+                  c0[i] = a[i * n + k];
+                  c1[i] = a[i * n + k + 1];
+                  c2[i] = three ? a[i * n + k + 2] : 0.0;
                 }
-                a[i * n + k + 1] -= p * q;
-                a[i * n + k] -= p;
+                OSFM_UNROLL for (int i = 0; i < n; i++)
+                  if (i >= l && i <= mmin) {
+                    double pi = x * c0[i] + y * c1[i];
+                    if (three) {
+                      pi += z * c2[i];
+                      a[i * n + k + 2] = c2[i] - pi * r;
+                    }
+                    a[i * n + k + 1] = c1[i] - pi * q;
+                    a[i * n + k] = c0[i] - pi;
+                  }
               }
             }
           }
@@ -260,159 +344,280 @@ OSFM_HD int real_eigenvalues10(double* a, double* wr) {
   return nreal;
 }
 
-// Five-point solver.  b1, b2: 5 x 3 bearings (x2^T E x1 = 0); Es: up to 10 row-major 3 x 3 matrices of unit
-// Frobenius norm; returns how many.  (geometry/essential.h:99-160, geometry/src/essential.cc:54-143)
-OSFM_HD int essential_five_points(const double* b1, const double* b2, double* Es) {
-  double A[5 * 9], basis[9 * 4];
+template <class PA, class PW>
+OSFM_HD int real_eigenvalues10(PA a, PW wr) {
+  return real_eigenvalues10_put(a, [&](int k, double v) { wr[k] = v; });
+}
+
+// Five-point solver in two stages, so that a kernel can give each the work space it needs (relpose.hip):
+//   stage A  five_point_action_matrix: epipolar null space -> ten cubic constraints -> Gauss-Jordan -> the six non-trivial rows of the
+//            10 x 10 action matrix of "multiply by x" (work space: basis 36, M 200 doubles, colperm 9 ints, per-lane dynamic indices)
+//   stage B  five_point_solutions: its real eigenvalues (Hessenberg-QR) and, per eigenvalue, the eigenvector by complete-pivot
+//            elimination -> essential matrices (work space: ONE 10 x 10 matrix; everything else is kept in registers through
+//            select chains / unrolled loops, so that three wavefronts fit the LDS of a CU instead of one)
+// D = "array of double", I = "array of int" (LaneArr or plain pointers).
+// q[10] = a * b for linear polynomials read through any indexable type, same accumulation order as mul_lin_lin
+template <class PA, class PB>
+OSFM_HD void mul_lin_lin_t(PA a, PB b, double* q) {
+  OSFM_UNROLL for (int k = 0; k < 10; k++) q[k] = 0.0;
+  OSFM_UNROLL for (int i = 16; i < 20; i++)
+    OSFM_UNROLL for (int j = 16; j < 20; j++) q[mul_slot(i, j) - 10] += a[i - 16] * b[j - 16];
+}
+template <class PB>
+OSFM_HD void mul_quad_lin_t(const double* q, PB b, double* c) {
+  OSFM_UNROLL for (int k = 0; k < 20; k++) c[k] = 0.0;
+  OSFM_UNROLL for (int i = 10; i < 20; i++)
+    OSFM_UNROLL for (int j = 16; j < 20; j++) c[mul_slot(i, j)] += q[i - 10] * b[j - 16];
+}
+// L(i, j) = row i of E times row j of E (quadratic): (E_i0 E_j0 + E_i1 E_j1) + E_i2 E_j2
+template <class D>
+OSFM_HD void five_point_L(D basis, int i, int j, double* L) {
+  double q1[10], q2[10];
+  mul_lin_lin_t(basis + (3 * i + 0) * 4, basis + (3 * j + 0) * 4, L);
+  mul_lin_lin_t(basis + (3 * i + 1) * 4, basis + (3 * j + 1) * 4, q1);
+  mul_lin_lin_t(basis + (3 * i + 2) * 4, basis + (3 * j + 2) * 4, q2);
+  OSFM_UNROLL for (int k = 0; k < 10; k++) L[k] = (L[k] + q1[k]) + q2[k];
+}
+
+// Stage A.  b1, b2: 5 x 3 bearings (x2^T E x1 = 0).  On success (return 1) basis[36] holds the null space and M[0 .. 59] rows 0..5 of
+// the action matrix (rows 6..9 are the constant rows e0, e1, e3, e6).  The 5 x 9 epipolar system lives in M's first 45 entries first.
+template <class D, class I>
+OSFM_HD int five_point_action_matrix(const double* b1, const double* b2, D basis, D M, I colperm) {
+  D A = M;
   for (int i = 0; i < 5; i++)
     for (int r = 0; r < 3; r++)
       for (int c = 0; c < 3; c++) A[i * 9 + 3 * r + c] = b2[3 * i + r] * b1[3 * i + c];
-  if (!nullspace_5x9(A, basis)) return 0;
+  if (!nullspace_5x9(A, basis, colperm)) return 0;
   // E(x, y, z) = x E0 + y E1 + z E2 + E3: entry (i, j) is the linear polynomial basis[(3 i + j) * 4 + 0..3]
 #define OSFM_E(i, j) (basis + (3 * (i) + (j)) * 4)
-  double M[10 * 20];
-  {  // det E = 0
+  {  // det E = 0: row 0 = (c_a + c_b) + c_c, the three cofactor expansions along the third row
     double qa[10], qb[10], c[20];
-    double* d = M;
-    mul_lin_lin(OSFM_E(0, 1), OSFM_E(1, 2), qa);
-    mul_lin_lin(OSFM_E(0, 2), OSFM_E(1, 1), qb);
-    for (int k = 0; k < 10; k++) qa[k] -= qb[k];
-    mul_quad_lin(qa, OSFM_E(2, 0), d);
-    mul_lin_lin(OSFM_E(0, 2), OSFM_E(1, 0), qa);
-    mul_lin_lin(OSFM_E(0, 0), OSFM_E(1, 2), qb);
-    for (int k = 0; k < 10; k++) qa[k] -= qb[k];
-    mul_quad_lin(qa, OSFM_E(2, 1), c);
-    for (int k = 0; k < 20; k++) d[k] += c[k];
-    mul_lin_lin(OSFM_E(0, 0), OSFM_E(1, 1), qa);
-    mul_lin_lin(OSFM_E(0, 1), OSFM_E(1, 0), qb);
-    for (int k = 0; k < 10; k++) qa[k] -= qb[k];
-    mul_quad_lin(qa, OSFM_E(2, 2), c);
-    for (int k = 0; k < 20; k++) d[k] += c[k];
+    mul_lin_lin_t(OSFM_E(0, 1), OSFM_E(1, 2), qa);
+    mul_lin_lin_t(OSFM_E(0, 2), OSFM_E(1, 1), qb);
+    OSFM_UNROLL for (int k = 0; k < 10; k++) qa[k] -= qb[k];
+    mul_quad_lin_t(qa, OSFM_E(2, 0), c);
+    OSFM_UNROLL for (int k = 0; k < 20; k++) M[k] = c[k];
+    mul_lin_lin_t(OSFM_E(0, 2), OSFM_E(1, 0), qa);
+    mul_lin_lin_t(OSFM_E(0, 0), OSFM_E(1, 2), qb);
+    OSFM_UNROLL for (int k = 0; k < 10; k++) qa[k] -= qb[k];
+    mul_quad_lin_t(qa, OSFM_E(2, 1), c);
+    OSFM_UNROLL for (int k = 0; k < 20; k++) M[k] += c[k];
+    mul_lin_lin_t(OSFM_E(0, 0), OSFM_E(1, 1), qa);
+    mul_lin_lin_t(OSFM_E(0, 1), OSFM_E(1, 0), qb);
+    OSFM_UNROLL for (int k = 0; k < 10; k++) qa[k] -= qb[k];
+    mul_quad_lin_t(qa, OSFM_E(2, 2), c);
+    OSFM_UNROLL for (int k = 0; k < 20; k++) M[k] += c[k];
   }
-  {  // (E E^T - 1/2 tr(E E^T) I) E = 0
-    double L[9][10];
-    for (int i = 0; i < 3; i++)
-      for (int j = 0; j < 3; j++) {
-        double q1[10], q2[10];
-        mul_lin_lin(OSFM_E(i, 0), OSFM_E(j, 0), L[3 * i + j]);
-        mul_lin_lin(OSFM_E(i, 1), OSFM_E(j, 1), q1);
-        mul_lin_lin(OSFM_E(i, 2), OSFM_E(j, 2), q2);
-        for (int k = 0; k < 10; k++) L[3 * i + j][k] = (L[3 * i + j][k] + q1[k]) + q2[k];
-      }
+  {  // (E E^T - 1/2 tr(E E^T) I) E = 0: rows 1..9.  Only the three L(i, .) of one i are alive at a time (the diagonal ones are
+     // evaluated twice, once for the trace: the same operations give the same doubles)
     double tr[10];
-    for (int k = 0; k < 10; k++) tr[k] = ((L[0][k] + L[4][k]) + L[8][k]) * 0.5;
-    for (int i = 0; i < 3; i++)
-      for (int k = 0; k < 10; k++) L[4 * i][k] -= tr[k];
-    int row = 1;
-    for (int i = 0; i < 3; i++)
+    {
+      double l0[10], l1[10];
+      five_point_L(basis, 0, 0, l0);
+      five_point_L(basis, 1, 1, l1);
+      OSFM_UNROLL for (int k = 0; k < 10; k++) tr[k] = l0[k] + l1[k];
+      five_point_L(basis, 2, 2, l0);
+      OSFM_UNROLL for (int k = 0; k < 10; k++) tr[k] = (tr[k] + l0[k]) * 0.5;
+    }
+    for (int i = 0; i < 3; i++) {
+      double Li[3][10];
+      OSFM_UNROLL for (int q = 0; q < 3; q++) five_point_L(basis, i, q, Li[q]);
+      OSFM_UNROLL for (int q = 0; q < 3; q++)
+        if (q == i) {
+          OSFM_UNROLL for (int k = 0; k < 10; k++) Li[q][k] -= tr[k];
+        }
       for (int j = 0; j < 3; j++) {
-        double c1[20], c2[20];
-        double* le = M + 20 * row++;
-        mul_quad_lin(L[3 * i + 0], OSFM_E(0, j), le);
-        mul_quad_lin(L[3 * i + 1], OSFM_E(1, j), c1);
-        mul_quad_lin(L[3 * i + 2], OSFM_E(2, j), c2);
-        for (int k = 0; k < 20; k++) le[k] = (le[k] + c1[k]) + c2[k];
+        D le = M + 20 * (1 + 3 * i + j);
+        double c[20];
+        mul_quad_lin_t(Li[0], OSFM_E(0, j), c);
+        OSFM_UNROLL for (int k = 0; k < 20; k++) le[k] = c[k];
+        mul_quad_lin_t(Li[1], OSFM_E(1, j), c);
+        OSFM_UNROLL for (int k = 0; k < 20; k++) le[k] += c[k];
+        mul_quad_lin_t(Li[2], OSFM_E(2, j), c);
+        OSFM_UNROLL for (int k = 0; k < 20; k++) le[k] += c[k];
       }
+    }
   }
 #undef OSFM_E
   // Gauss-Jordan on the cubic monomials (columns 0..9), partial pivoting
   for (int k = 0; k < 10; k++) {
     int pr = k;
-    for (int i = k + 1; i < 10; i++)
-      if (fabs(M[i * 20 + k]) > fabs(M[pr * 20 + k])) pr = i;
-    if (!(fabs(M[pr * 20 + k]) > 0)) return 0;
-    for (int j = 0; j < 20; j++) {
-      const double t = M[k * 20 + j];
-      M[k * 20 + j] = M[pr * 20 + j];
-      M[pr * 20 + j] = t;
+    {
+      double col[10];
+      OSFM_UNROLL for (int i = 0; i < 10; i++) col[i] = fabs(M[i * 20 + k]);
+      double bestv = 0.0;  // |M[pr][k]| of the running choice; the first candidate is row k itself
+      OSFM_UNROLL for (int i = 0; i < 10; i++) {
+        if (i == k) bestv = col[i];
+        if (i > k && col[i] > bestv) {
+          bestv = col[i];
+          pr = i;
+        }
+      }
+      if (!(bestv > 0)) return 0;
     }
-    const double ip = 1.0 / M[k * 20 + k];
-    for (int j = 0; j < 20; j++) M[k * 20 + j] *= ip;
+    double rowk[20];
+    {  // swap rows k and pr, scale the new row k
+      double rowp[20];
+      OSFM_UNROLL for (int j = 0; j < 20; j++) {
+        rowk[j] = M[k * 20 + j];
+        rowp[j] = M[pr * 20 + j];
+      }
+      OSFM_UNROLL for (int j = 0; j < 20; j++) M[pr * 20 + j] = rowk[j];
+      double piv = 0.0;
+      OSFM_UNROLL for (int j = 0; j < 10; j++)
+        if (j == k) piv = rowp[j];
+      const double ipv = 1.0 / piv;
+      OSFM_UNROLL for (int j = 0; j < 20; j++) {
+        rowk[j] = rowp[j] * ipv;
+        M[k * 20 + j] = rowk[j];
+      }
+    }
     for (int i = 0; i < 10; i++) {
       if (i == k) continue;
       const double f = M[i * 20 + k];
       if (f == 0.0) continue;
-      for (int j = 0; j < 20; j++) M[i * 20 + j] -= f * M[k * 20 + j];
+      OSFM_UNROLL for (int j = 0; j < 20; j++) M[i * 20 + j] -= f * rowk[j];
     }
   }
-  // action matrix of "multiply by x" on [xx xy yy xz yz zz x y z 1]
-  double At[100], Aq[100];
-  for (int i = 0; i < 100; i++) At[i] = 0.0;
+  // action matrix of "multiply by x" on [xx xy yy xz yz zz x y z 1]: rows 0..5 = minus the right half of rows {0, 1, 2, 4, 5, 7} of
+  // the eliminated M.  They take the start of M's storage, row by row, in an order in which every row of M is read before its
+  // storage is overwritten (row r reads M row src[r] >= r, columns 10..19).
   {
     constexpr int src[6] = {0, 1, 2, 4, 5, 7};
-    for (int r = 0; r < 6; r++)
-      for (int j = 0; j < 10; j++) At[r * 10 + j] = -M[src[r] * 20 + 10 + j];
+    OSFM_UNROLL for (int r = 0; r < 6; r++) {
+      double row[10];
+      OSFM_UNROLL for (int j = 0; j < 10; j++) row[j] = -M[src[r] * 20 + 10 + j];
+      OSFM_UNROLL for (int j = 0; j < 10; j++) M[r * 10 + j] = row[j];
+    }
   }
-  At[6 * 10 + 0] = 1.0;
-  At[7 * 10 + 1] = 1.0;
-  At[8 * 10 + 3] = 1.0;
-  At[9 * 10 + 6] = 1.0;
-  for (int i = 0; i < 100; i++) Aq[i] = At[i];
+  return 1;
+}
+
+// entry i (row-major, 0..99) of the action matrix given its rows 0..5
+template <class PA>
+OSFM_HD double action_matrix_entry(PA At6, int i) {
+  return i < 60 ? At6[i] : ((i == 60 || i == 71 || i == 83 || i == 96) ? 1.0 : 0.0);
+}
+
+// Stage B.  At6: rows 0..5 of the action matrix (60 entries, read-only), basis: the null space (36, read-only), S: 100 doubles of
+// work space.  Every real solution is handed to emit(E) -- a row-major 3 x 3 of unit Frobenius norm -- in eigenvalue order;
+// returns how many (<= 10).
+template <class PA, class PB, class PS, class Emit>
+OSFM_HD int five_point_solutions(PA At6, PB basis, PS S, Emit emit) {
+  OSFM_UNROLL for (int i = 0; i < 100; i++) S[i] = action_matrix_entry(At6, i);
   double wr[10];
-  const int nreal = real_eigenvalues10(Aq, wr);
+  OSFM_UNROLL for (int q = 0; q < 10; q++) wr[q] = 0.0;
+  const int nreal = real_eigenvalues10_put(S, [&](int k, double val) {
+    OSFM_UNROLL for (int q = 0; q < 10; q++)
+      if (q == k) wr[q] = val;
+  });
   int count = 0;
-  double* S = Aq;  // the Hessenberg copy is dead: reuse its storage for (At - lambda I)
   for (int e = 0; e < nreal && count < 10; e++) {
-    double v[10];
-    for (int i = 0; i < 100; i++) S[i] = At[i];
-    for (int i = 0; i < 10; i++) S[i * 10 + i] -= wr[e];
-    int colperm[10];
-    for (int j = 0; j < 10; j++) colperm[j] = j;
+    double lam = 0.0;
+    OSFM_UNROLL for (int q = 0; q < 10; q++)
+      if (q == e) lam = wr[q];
+    OSFM_UNROLL for (int i = 0; i < 100; i++) S[i] = (i % 11 == 0) ? action_matrix_entry(At6, i) - lam : action_matrix_entry(At6, i);
+    int cp[10];  // column permutation, in registers: k is a constant in the unrolled elimination, pc goes through a select chain
+    OSFM_UNROLL for (int j = 0; j < 10; j++) cp[j] = j;
     int ok = 1;
-    for (int k = 0; k < 9 && ok; k++) {
-      int pr = k, pc = k;
-      double best = 0;
-      for (int i = k; i < 10; i++)
-        for (int j = k; j < 10; j++)
-          if (fabs(S[i * 10 + j]) > best) {
-            best = fabs(S[i * 10 + j]);
-            pr = i;
-            pc = j;
+    OSFM_UNROLL for (int k = 0; k < 9; k++) {
+      if (ok) {
+        int pr = k, pc = k;
+        double best = 0;
+        OSFM_UNROLL for (int i = k; i < 10; i++) {
+          double row[10];
+          OSFM_UNROLL for (int j = k; j < 10; j++) row[j] = fabs(S[i * 10 + j]);
+          OSFM_UNROLL for (int j = k; j < 10; j++)
+            if (row[j] > best) {
+              best = row[j];
+              pr = i;
+              pc = j;
+            }
+        }
+        if (!(best > 0)) {
+          ok = 0;
+        } else {
+          double rowk[10];
+          {  // row swap k <-> pr
+            double rowp[10];
+            OSFM_UNROLL for (int j = 0; j < 10; j++) {
+              rowk[j] = S[k * 10 + j];
+              rowp[j] = S[pr * 10 + j];
+            }
+            OSFM_UNROLL for (int j = 0; j < 10; j++) {
+              S[pr * 10 + j] = rowk[j];
+              S[k * 10 + j] = rowp[j];
+            }
           }
-      if (!(best > 0)) {
-        ok = 0;
-        break;
-      }
-      for (int j = 0; j < 10; j++) {
-        const double t = S[k * 10 + j];
-        S[k * 10 + j] = S[pr * 10 + j];
-        S[pr * 10 + j] = t;
-      }
-      for (int i = 0; i < 10; i++) {
-        const double t = S[i * 10 + k];
-        S[i * 10 + k] = S[i * 10 + pc];
-        S[i * 10 + pc] = t;
-      }
-      {
-        const int t = colperm[k];
-        colperm[k] = colperm[pc];
-        colperm[pc] = t;
-      }
-      const double ip = 1.0 / S[k * 10 + k];
-      for (int j = 0; j < 10; j++) S[k * 10 + j] *= ip;
-      for (int i = 0; i < 10; i++) {
-        if (i == k) continue;
-        const double f = S[i * 10 + k];
-        if (f == 0.0) continue;
-        for (int j = 0; j < 10; j++) S[i * 10 + j] -= f * S[k * 10 + j];
+          {  // column swap k <-> pc
+            double ck[10], cq[10];
+            OSFM_UNROLL for (int i = 0; i < 10; i++) {
+              ck[i] = S[i * 10 + k];
+              cq[i] = S[i * 10 + pc];
+            }
+            OSFM_UNROLL for (int i = 0; i < 10; i++) {
+              S[i * 10 + k] = cq[i];
+              S[i * 10 + pc] = ck[i];
+            }
+          }
+          {
+            const int t = cp[k];
+            int u = t;
+            OSFM_UNROLL for (int q = 0; q < 10; q++)
+              if (q == pc) u = cp[q];
+            OSFM_UNROLL for (int q = 0; q < 10; q++)
+              if (q == pc) cp[q] = t;
+            cp[k] = u;
+          }
+          const double ip = 1.0 / S[k * 10 + k];
+          OSFM_UNROLL for (int j = 0; j < 10; j++) {
+            rowk[j] = S[k * 10 + j] * ip;
+            S[k * 10 + j] = rowk[j];
+          }
+          for (int i = 0; i < 10; i++) {
+            if (i == k) continue;
+            const double f = S[i * 10 + k];
+            if (f == 0.0) continue;
+            OSFM_UNROLL for (int j = 0; j < 10; j++) S[i * 10 + j] -= f * rowk[j];
+          }
+        }
       }
     }
     if (!ok) continue;
-    v[colperm[9]] = 1.0;
-    for (int k = 0; k < 9; k++) v[colperm[k]] = -S[k * 10 + 9];
-    if (v[9] == 0.0) continue;
-    const double x = v[6] / v[9], y = v[7] / v[9], z = v[8] / v[9];
+    // v[cp[9]] = 1, v[cp[k]] = -S[k][9]; only the entries 6..9 (x, y, z, 1) of the monomial vector are needed
+    double v6 = 0.0, v7 = 0.0, v8 = 0.0, v9 = 0.0;
+    OSFM_UNROLL for (int k = 0; k < 10; k++) {
+      const double val = (k == 9) ? 1.0 : -S[k * 10 + 9];
+      if (cp[k] == 6) v6 = val;
+      if (cp[k] == 7) v7 = val;
+      if (cp[k] == 8) v8 = val;
+      if (cp[k] == 9) v9 = val;
+    }
+    if (v9 == 0.0) continue;
+    const double x = v6 / v9, y = v7 / v9, z = v8 / v9;
     double Em[9], nrm = 0.0;
-    for (int i = 0; i < 9; i++) {
+    OSFM_UNROLL for (int i = 0; i < 9; i++) {
       Em[i] = x * basis[i * 4 + 0] + y * basis[i * 4 + 1] + z * basis[i * 4 + 2] + basis[i * 4 + 3];
       nrm += Em[i] * Em[i];
     }
     nrm = sqrt(nrm);
     if (!(nrm > 0) || !isfinite(nrm)) continue;
-    for (int i = 0; i < 9; i++) Es[9 * count + i] = Em[i] / nrm;
+    OSFM_UNROLL for (int i = 0; i < 9; i++) Em[i] = Em[i] / nrm;
+    emit(Em);
     count++;
   }
   return count;
+}
+// both stages with the work space on the stack: Es receives up to 10 row-major 3 x 3 matrices; returns how many
+OSFM_HD int essential_five_points(const double* b1, const double* b2, double* Es) {
+  double basis[36], M[200], S[100];
+  int colperm[9];
+  if (!five_point_action_matrix(b1, b2, basis, M, colperm)) return 0;
+  int n = 0;
+  return five_point_solutions(M, basis, S, [&](const double* Em) {
+    for (int i = 0; i < 9; i++) Es[9 * n + i] = Em[i];
+    n++;
+  });
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -422,7 +627,7 @@ OSFM_HD void svd3(const double* A, double* U, double* S, double* V) {
   double G[9];
   for (int i = 0; i < 9; i++) G[i] = A[i];
   for (int i = 0; i < 9; i++) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
-  for (int sweep = 0; sweep < 60; sweep++) {
+  OSFM_NOUNROLL for (int sweep = 0; sweep < 60; sweep++) {
     double off = 0.0;
     for (int p = 0; p < 2; p++)
       for (int q = p + 1; q < 3; q++) {
@@ -448,23 +653,35 @@ OSFM_HD void svd3(const double* A, double* U, double* S, double* V) {
       }
     if (off < 1e-16) break;
   }
-  int order[3] = {0, 1, 2};
+  // columns sorted by decreasing norm (the same three compare-and-swap steps as a selection sort on an index array), with the
+  // run-time column indices resolved through selects so that nothing is indexed dynamically
   double nrm[3];
-  for (int j = 0; j < 3; j++) nrm[j] = sqrt(G[j] * G[j] + G[3 + j] * G[3 + j] + G[6 + j] * G[6 + j]);
-  for (int a = 0; a < 2; a++)
-    for (int b = a + 1; b < 3; b++)
-      if (nrm[order[b]] > nrm[order[a]]) {
-        const int t = order[a];
-        order[a] = order[b];
-        order[b] = t;
-      }
+  OSFM_UNROLL for (int j = 0; j < 3; j++) nrm[j] = sqrt(G[j] * G[j] + G[3 + j] * G[3 + j] + G[6 + j] * G[6 + j]);
+  int o0 = 0, o1 = 1, o2 = 2;
+  auto pick = [](const double* a, int stride, int i) { return i == 0 ? a[0] : (i == 1 ? a[stride] : a[2 * stride]); };
+  if (pick(nrm, 1, o1) > pick(nrm, 1, o0)) {
+    const int t = o0;
+    o0 = o1;
+    o1 = t;
+  }
+  if (pick(nrm, 1, o2) > pick(nrm, 1, o0)) {
+    const int t = o0;
+    o0 = o2;
+    o2 = t;
+  }
+  if (pick(nrm, 1, o2) > pick(nrm, 1, o1)) {
+    const int t = o1;
+    o1 = o2;
+    o2 = t;
+  }
   double Vs[9];
-  for (int j = 0; j < 3; j++) {
-    const int o = order[j];
-    S[j] = nrm[o];
-    for (int k = 0; k < 3; k++) {
-      Vs[3 * k + j] = V[3 * k + o];
-      U[3 * k + j] = nrm[o] > 0 ? G[3 * k + o] / nrm[o] : 0.0;
+  OSFM_UNROLL for (int j = 0; j < 3; j++) {
+    const int o = j == 0 ? o0 : (j == 1 ? o1 : o2);
+    const double nj = pick(nrm, 1, o);
+    S[j] = nj;
+    OSFM_UNROLL for (int k = 0; k < 3; k++) {
+      Vs[3 * k + j] = pick(V + 3 * k, 1, o);
+      U[3 * k + j] = nj > 0 ? pick(G + 3 * k, 1, o) / nj : 0.0;
     }
   }
   for (int i = 0; i < 9; i++) V[i] = Vs[i];
@@ -502,13 +719,13 @@ OSFM_HD int relative_pose_from_essential(const double* E, const double* b1, cons
     for (int k = 0; k < 3; k++) Vt[6 + k] = -Vt[6 + k];
   double best = 0.0;
   int found = 0;
-  for (int i = 0; i < 2; i++) {
+  OSFM_NOUNROLL for (int i = 0; i < 2; i++) {
     double t[3] = {U[2], U[5], U[8]};
     if (i == 1)
       for (int k = 0; k < 3; k++) t[k] = -t[k];
     const double tn = sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
     for (int k = 0; k < 3; k++) t[k] /= tn;
-    for (int j = 0; j < 2; j++) {
+    OSFM_NOUNROLL for (int j = 0; j < 2; j++) {
       // W = [0 -1 0; 1 0 0; 0 0 1] (j == 0) or its transpose
       double Wm[9] = {0, -1, 0, 1, 0, 0, 0, 0, 1};
       if (j == 1) {
@@ -523,7 +740,7 @@ OSFM_HD int relative_pose_from_essential(const double* E, const double* b1, cons
       double c1[3];
       for (int a = 0; a < 3; a++) c1[a] = -(R[a] * t[0] + R[3 + a] * t[1] + R[6 + a] * t[2]);
       double score = 0.0;
-      for (int s = 0; s < n; s++) {
+      OSFM_NOUNROLL for (int s = 0; s < n; s++) {
         const int m = idx ? idx[s] : s;
         const double *x = b1 + 3 * m, *y = b2 + 3 * m;
         double ry[3], X[3];
@@ -603,63 +820,105 @@ OSFM_HD void draw_sample(Mt19937& g, int size, int n, int* idx) {  // distinct i
 }
 
 // Cyclic Jacobi eigen-decomposition of a symmetric 9 x 9 (destroyed): eigenvalues w, eigenvectors V (columns).
-OSFM_HD void jacobi_eig9(double* A, double* w, double* V) {
+template <class PA, class PW, class PV>
+OSFM_HD void jacobi_eig9(PA A, PW w, PV V) {
   constexpr int n = 9;
-  for (int i = 0; i < n * n; i++) V[i] = (i % (n + 1) == 0) ? 1.0 : 0.0;
+  OSFM_UNROLL for (int i = 0; i < n * n; i++) V[i] = (i % (n + 1) == 0) ? 1.0 : 0.0;
   for (int sweep = 0; sweep < 100; sweep++) {
     double off = 0.0;
-    for (int p = 0; p < n - 1; p++)
-      for (int q = p + 1; q < n; q++) off += A[p * n + q] * A[p * n + q];
+    OSFM_UNROLL for (int p = 0; p < n - 1; p++)
+      OSFM_UNROLL for (int q = p + 1; q < n; q++) {
+        const double apq = A[p * n + q];
+        off += apq * apq;
+      }
     if (!(off > 1e-300)) break;
-    for (int p = 0; p < n - 1; p++)
-      for (int q = p + 1; q < n; q++) {
+    // the 36 rotations of a sweep are unrolled: p and q are then constants, and a matrix kept in a local array stays in registers
+    OSFM_UNROLL for (int p = 0; p < n - 1; p++)
+      OSFM_UNROLL for (int q = p + 1; q < n; q++) {
         const double apq = A[p * n + q];
         if (apq == 0.0) continue;
         const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
         const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
         const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-        for (int k = 0; k < n; k++) {
-          const double akp = A[k * n + p], akq = A[k * n + q];
-          A[k * n + p] = c * akp - s * akq;
-          A[k * n + q] = s * akp + c * akq;
+        {  // columns p, q of A
+          double cp[n], cq[n];
+          OSFM_UNROLL for (int k = 0; k < n; k++) {
+            cp[k] = A[k * n + p];
+            cq[k] = A[k * n + q];
+          }
+          OSFM_UNROLL for (int k = 0; k < n; k++) {
+            A[k * n + p] = c * cp[k] - s * cq[k];
+            A[k * n + q] = s * cp[k] + c * cq[k];
+          }
         }
-        for (int k = 0; k < n; k++) {
-          const double apk = A[p * n + k], aqk = A[q * n + k];
-          A[p * n + k] = c * apk - s * aqk;
-          A[q * n + k] = s * apk + c * aqk;
-        }
-        for (int k = 0; k < n; k++) {
-          const double vkp = V[k * n + p], vkq = V[k * n + q];
-          V[k * n + p] = c * vkp - s * vkq;
-          V[k * n + q] = s * vkp + c * vkq;
+        {  // rows p, q of A; columns p, q of V
+          double rp[n], rq[n], vp[n], vq[n];
+          OSFM_UNROLL for (int k = 0; k < n; k++) {
+            rp[k] = A[p * n + k];
+            rq[k] = A[q * n + k];
+            vp[k] = V[k * n + p];
+            vq[k] = V[k * n + q];
+          }
+          OSFM_UNROLL for (int k = 0; k < n; k++) {
+            A[p * n + k] = c * rp[k] - s * rq[k];
+            A[q * n + k] = s * rp[k] + c * rq[k];
+            V[k * n + p] = c * vp[k] - s * vq[k];
+            V[k * n + q] = s * vp[k] + c * vq[k];
+          }
         }
       }
   }
-  for (int i = 0; i < n; i++) w[i] = A[i * n + i];
+  OSFM_UNROLL for (int i = 0; i < n; i++) w[i] = A[i * n + i];
 }
 // EssentialNPoints (geometry/essential.h:162-192) with foundation::SolveAX0 (foundation/numeric.h:20-43): 0 or 1 model
-OSFM_HD int essential_n_points(const double* b1, const double* b2, const int* idx, int count, double* E) {
+// AtA, V: 81 doubles each, w: 9 -- work space, one per problem (LaneArr in the solver kernel, stack arrays below)
+template <class D>
+OSFM_HD int essential_n_points_ws(const double* b1, const double* b2, const int* idx, int count, double* E, D AtA, D V, D w) {
   if (count < 9) return 0;
-  double AtA[81], w[9], V[81];
-  for (int i = 0; i < 81; i++) AtA[i] = 0.0;
-  for (int s = 0; s < count; s++) {
-    const double *x1 = b1 + 3 * idx[s], *x2 = b2 + 3 * idx[s];
-    double row[9];
-    for (int r = 0; r < 3; r++)
-      for (int c = 0; c < 3; c++) row[3 * r + c] = x2[r] * x1[c];
-    for (int i = 0; i < 9; i++)
-      for (int j = 0; j < 9; j++) AtA[9 * i + j] += row[i] * row[j];
+  // A^T A = sum over the samples of row^T row, every entry summed over s = 0, 1, ... from 0.0.  Three rows of the result at a time
+  // stay in registers (27 accumulators) instead of 81 read-modify-writes of the work space per sample.
+  OSFM_UNROLL for (int i0 = 0; i0 < 9; i0 += 3) {
+    double acc[3][9];
+    OSFM_UNROLL for (int a = 0; a < 3; a++)
+      OSFM_UNROLL for (int j = 0; j < 9; j++) acc[a][j] = 0.0;
+    for (int s = 0; s < count; s++) {
+      const double *x1 = b1 + 3 * idx[s], *x2 = b2 + 3 * idx[s];
+      double row[9];
+      OSFM_UNROLL for (int r = 0; r < 3; r++)
+        OSFM_UNROLL for (int c = 0; c < 3; c++) row[3 * r + c] = x2[r] * x1[c];
+      OSFM_UNROLL for (int a = 0; a < 3; a++)
+        OSFM_UNROLL for (int j = 0; j < 9; j++) acc[a][j] += row[i0 + a] * row[j];
+    }
+    OSFM_UNROLL for (int a = 0; a < 3; a++)
+      OSFM_UNROLL for (int j = 0; j < 9; j++) AtA[9 * (i0 + a) + j] = acc[a][j];
   }
   jacobi_eig9(AtA, w, V);
+  // smallest and second smallest eigenvalue (first occurrence wins), without indexing w / V by a run-time value
   int lo = 0, lo2 = -1;
-  for (int i = 1; i < 9; i++)
-    if (w[i] < w[lo]) lo = i;
-  for (int i = 0; i < 9; i++)
-    if (i != lo && (lo2 < 0 || w[i] < w[lo2])) lo2 = i;
-  const double s_small = sqrt(fmax(w[lo], 0.0)), s_next = sqrt(fmax(w[lo2], 0.0));
+  double w_lo = w[0], w_lo2 = 0.0;
+  OSFM_UNROLL for (int i = 1; i < 9; i++) {
+    const double wi = w[i];
+    if (wi < w_lo) {
+      w_lo = wi;
+      lo = i;
+    }
+  }
+  OSFM_UNROLL for (int i = 0; i < 9; i++) {
+    const double wi = w[i];
+    if (i != lo && (lo2 < 0 || wi < w_lo2)) {
+      w_lo2 = wi;
+      lo2 = i;
+    }
+  }
+  const double s_small = sqrt(fmax(w_lo, 0.0)), s_next = sqrt(fmax(w_lo2, 0.0));
   if (!(s_next / s_small > 4.0)) return 0;
   double Em[9];
-  for (int i = 0; i < 9; i++) Em[i] = V[9 * i + lo];
+  OSFM_UNROLL for (int i = 0; i < 9; i++) {
+    double e = 0.0;
+    OSFM_UNROLL for (int c = 0; c < 9; c++)
+      if (c == lo) e = V[9 * i + c];
+    Em[i] = e;
+  }
   double U[9], S[3], Vv[9];
   svd3(Em, U, S, Vv);
   const double d = 0.5 * (S[0] + S[1]);
@@ -667,13 +926,15 @@ OSFM_HD int essential_n_points(const double* b1, const double* b2, const int* id
     for (int b = 0; b < 3; b++) E[3 * a + b] = d * (U[3 * a] * Vv[3 * b] + U[3 * a + 1] * Vv[3 * b + 1]);
   return 1;
 }
+OSFM_HD int essential_n_points(const double* b1, const double* b2, const int* idx, int count, double* E) {
+  double AtA[81], w[9], V[81];
+  return essential_n_points_ws<double*>(b1, b2, idx, count, E, AtA, V, w);
+}
 // RelativePose::Evaluate (robust/relative_pose_model.h): 1 - mean cosine between the bearings and the midpoint
-OSFM_HD double relpose_error(const double* RT, const double* x0, const double* y0) {
-  double x[3], y[3], R[9], t[3];
-  const double nx = sqrt(x0[0] * x0[0] + x0[1] * x0[1] + x0[2] * x0[2]), ny = sqrt(y0[0] * y0[0] + y0[1] * y0[1] + y0[2] * y0[2]);
+// x, y: the two bearings already divided by their norms (the first step of Evaluate)
+OSFM_HD double relpose_error_unit(const double* RT, const double* x, const double* y) {
+  double R[9], t[3];
   for (int a = 0; a < 3; a++) {
-    x[a] = x0[a] / nx;
-    y[a] = y0[a] / ny;
     t[a] = RT[4 * a + 3];
     for (int b = 0; b < 3; b++) R[3 * a + b] = RT[4 * a + b];
   }
@@ -686,6 +947,17 @@ OSFM_HD double relpose_error(const double* RT, const double* x0, const double* y
   for (int a = 0; a < 3; a++) Y[a] = R[3 * a] * X[0] + R[3 * a + 1] * X[1] + R[3 * a + 2] * X[2] + t[a];
   const double nX = sqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2]), nY = sqrt(Y[0] * Y[0] + Y[1] * Y[1] + Y[2] * Y[2]);
   return 1.0 - 0.5 * ((X[0] * x[0] + X[1] * x[1] + X[2] * x[2]) / nX + (Y[0] * y[0] + Y[1] * y[1] + Y[2] * y[2]) / nY);
+}
+// d.first.normalized() / d.second.normalized() of Evaluate: done once per correspondence, every model then scores the unit bearings
+OSFM_HD void normalise_bearing(const double* v, double* u) {
+  const double nv = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  for (int a = 0; a < 3; a++) u[a] = v[a] / nv;
+}
+OSFM_HD double relpose_error(const double* RT, const double* x0, const double* y0) {
+  double x[3], y[3];
+  normalise_bearing(x0, x);
+  normalise_bearing(y0, y);
+  return relpose_error_unit(RT, x, y);
 }
 // ShouldStop (robust/robust_estimator.h:20-35) for MINIMAL_SAMPLES = 5: the bound depends only on (best inlier count, n,
 // probability) and goes through std::pow / std::log, so the HOST tabulates it with its libm for every possible count (n + 1
@@ -1148,28 +1420,28 @@ OSFM_HD int refine_relative_pose(double* RT, int iterations, Eval& ev, double* c
   for (int a = 0; a < 3; a++) x[3 + a] = -(R[a] * RT[3] + R[3 + a] * RT[7] + R[6 + a] * RT[11]);
   double scal[6], jtj[36], g[6], cost = 0;
   int have_scale = 0, it = 0;
+  // every sum below runs over the residuals i = 0 .. NR - 1 in order, from 0.0 (the oracle's order); ev.reduce() may give each
+  // sum to a different lane
   auto update = [&]() {
     ev.eval(x, 1);
     if (!have_scale) {
-      for (int k = 0; k < 6; k++) {
-        double s = 0;
-        for (int i = 0; i < NR; i++) s += ev.jac(i, k) * ev.jac(i, k);
-        scal[k] = 1.0 / (1.0 + sqrt(s));
-      }
+      double ss[6];
+      ev.reduce(6, [&](int k, int i) { return ev.jac(i, k) * ev.jac(i, k); }, ss);
+      for (int k = 0; k < 6; k++) scal[k] = 1.0 / (1.0 + sqrt(ss[k]));
       have_scale = 1;
     }
-    for (int a = 0; a < 6; a++) {
-      g[a] = 0;
-      for (int i = 0; i < NR; i++) g[a] += (ev.jac(i, a) * scal[a]) * (-ev.res(i));
-      for (int b = 0; b < 6; b++) {
-        double s = 0;
-        for (int i = 0; i < NR; i++) s += (ev.jac(i, a) * scal[a]) * (ev.jac(i, b) * scal[b]);
-        jtj[6 * a + b] = s;
+    double sums[43];
+    ev.reduce(43, [&](int q, int i) {
+      if (q < 6) return (ev.jac(i, q) * scal[q]) * (-ev.res(i));
+      if (q < 42) {
+        const int a = (q - 6) / 6, b = (q - 6) % 6;
+        return (ev.jac(i, a) * scal[a]) * (ev.jac(i, b) * scal[b]);
       }
-    }
-    cost = 0;
-    for (int i = 0; i < NR; i++) cost += (-ev.res(i)) * (-ev.res(i));
-    cost *= 0.5;
+      return (-ev.res(i)) * (-ev.res(i));
+    }, sums);
+    for (int a = 0; a < 6; a++) g[a] = sums[a];
+    for (int k = 0; k < 36; k++) jtj[k] = sums[6 + k];
+    cost = sums[42] * 0.5;
   };
   update();
   if (costs) costs[0] = cost;
@@ -1196,7 +1468,7 @@ OSFM_HD int refine_relative_pose(double* RT, int iterations, Eval& ev, double* c
       for (int k = 0; k < 6; k++) xn[k] = x[k] + dx[k];
       ev.eval(xn, 0);
       double fn2 = 0;
-      for (int i = 0; i < NR; i++) fn2 += ev.res(i) * ev.res(i);
+      ev.reduce(1, [&](int, int i) { return ev.res(i) * ev.res(i); }, &fn2);
       const double cost_change = 2.0 * cost - fn2;
       double mc = 0;
       for (int a = 0; a < 6; a++) {

@@ -775,6 +775,7 @@ int oracle_ba_solve(ba_problem *P, const ba_options *O, ba_report *Rp) {
     if (gmax <= O->gradient_tolerance) { Rp->termination = 2; break; }
     if (radius < 1e-32) { Rp->termination = 4; break; }
     iter++;
+    if (iter < 256) Rp->cost_history[iter] = cost; /* defined on every exit of this iteration (tolerances, invalid step) */
     {
       const double t_lin = now_s();
       /* ---- Schur complement in the scaled space ---- */

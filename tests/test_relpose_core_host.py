@@ -1,6 +1,7 @@
-"""The product's calibrated-matching numerics (opensfm_amd/csrc/relpose_core.h) and their wavefront orchestration
-(relpose_wave.h), compiled for the host with a loop-based wave policy (tests/native/relpose_core_host.cpp), against
-the CPU oracle -- bit for bit.  This pins everything of relpose.hip except the 40 lines of the GPU wave policy."""
+"""The product's calibrated-matching numerics (opensfm_amd/csrc/relpose_core.h) and the round-based orchestration of the LO-RANSAC
+(relpose_rounds.h: walk / solve5 / solveN over work lists), compiled for the host with loops in place of kernels
+(tests/native/relpose_core_host.cpp), against the CPU oracle -- bit for bit.  This pins everything of relpose.hip except the GPU
+wave policy, the kernel wrappers and the host loop that launches the rounds."""
 import ctypes as C
 import os
 import subprocess
@@ -20,7 +21,7 @@ def build_host():
     out_dir = os.path.join(HERE, "native", "_build")
     os.makedirs(out_dir, exist_ok=True)
     so = os.path.join(out_dir, "relpose_core_host.so")
-    deps = [src] + [os.path.join(HERE, "..", "opensfm_amd", "csrc", h) for h in ("relpose_core.h", "relpose_wave.h")]
+    deps = [src] + [os.path.join(HERE, "..", "opensfm_amd", "csrc", h) for h in ("relpose_core.h", "relpose_rounds.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-o", so, src])
     return C.CDLL(so)
@@ -145,8 +146,8 @@ def test_bearings_inliers_and_picks_bits(host, oracle_lib):
 
 @pytest.mark.parametrize("width", [1, 7, 64])
 def test_ransac_decision_sequence_bits(host, oracle_lib, width):
-    """width = how many iterations are solved speculatively per batch: 1 is the reference's sequential loop; 7 and 64
-    exercise the generator rewind when the local optimisation fires in the middle of a batch."""
+    """width = cap on how many iterations are sampled and solved speculatively per round: 1 is the reference's sequential loop;
+    7 and 64 (= the kernel's 16) exercise discarded speculation when the local optimisation fires in the middle of a batch."""
     rng = np.random.default_rng(2)
     cases = [(5, 0.0), (6, 0.0), (9, 0.2), (30, 0.3), (200, 0.5), (500, 0.2), (120, 0.9)]
     for n, outl in cases:
@@ -170,22 +171,44 @@ def test_ransac_decision_sequence_bits(host, oracle_lib, width):
                                           C.byref(it)) == 0 and it.value == 0
 
 
-def test_batch_schedule_does_not_change_results(host, oracle_lib):
-    """RansacParams::batch0 (first speculative batch and the one after every rewind, doubling afterwards) is a pure tuning knob"""
+def test_sampler_on_the_tabulated_stream(host, oracle_lib):
+    """draw_sample_tab on the table of raw std::mt19937(42) outputs == the oracle's sampler (itself pinned against the reference's
+    random_sampler.h compiled on the build box)"""
+    for n, size in ((5, 5), (6, 5), (13, 5), (300, 5), (40, 12), (12, 12), (100000, 5)):
+        out = np.zeros((200, size), np.int32)
+        host.host_draw_samples(n, size, 200, _p(out, C.c_int32))
+        assert np.array_equal(out, oracle_lib.ransac_draws(n, size, 200))
+
+
+def test_a_batch_of_pairs_goes_through_the_rounds_together(host, oracle_lib):
+    """many pairs of different sizes share the work lists: every pair still gets the oracle's result, in any speculation width"""
     rng = np.random.default_rng(22)
+    sizes = [4, 5, 9, 30, 77, 200, 400, 64, 130, 12, 0, 300]
+    outl = [0.0, 0.0, 0.2, 0.3, 0.5, 0.5, 0.8, 0.95, 0.1, 0.0, 0.0, 0.4]
+    scenes = [_scene(rng, n, outliers=o) if n else (np.zeros((0, 3)), np.zeros((0, 3)), None) for n, o in zip(sizes, outl)]
+    b1 = np.ascontiguousarray(np.concatenate([s[0] for s in scenes]))
+    b2 = np.ascontiguousarray(np.concatenate([s[1] for s in scenes]))
+    off = np.r_[0, np.cumsum(sizes)].astype(np.int64)
+    want = [oracle_lib.ransac_relative_pose(s[0], s[1], 0.004, 1000, 0.99, True, 10) if n >= 5 else None for s, n in zip(scenes, sizes)]
     try:
-        for n, outl in ((30, 0.3), (200, 0.5), (400, 0.8)):
-            b1, b2, _ = _scene(rng, n, outliers=outl)
-            want = oracle_lib.ransac_relative_pose(b1, b2, 0.004, 1000, 0.99, True, 10)
-            for b0 in (1, 2, 4, 16, 64):
-                host.host_set_batch0(b0)
-                model, lo, inl, it = np.zeros(12), np.zeros(12), np.zeros(n, np.int32), C.c_int(0)
-                score = host.host_ransac_relative_pose(64, _p(b1, C.c_double), _p(b2, C.c_double), n, C.c_double(0.004), 1000, C.c_double(0.99), 1, 10,
-                                                       _p(model, C.c_double), _p(lo, C.c_double), _p(inl, C.c_int32), C.byref(it))
-                assert (score, it.value) == (want["score"], want["iterations"]) and np.array_equal(inl[:score], want["inliers"])
-                assert np.array_equal(lo.view(np.uint64), want["lo_model"].reshape(-1).view(np.uint64))
+        for width in (1, 3, 16):
+            host.host_set_max_width(width)
+            scores, iters = np.zeros(len(sizes), np.int32), np.zeros(len(sizes), np.int32)
+            models, mask = np.zeros((len(sizes), 24)), np.zeros(max(len(b1), 1), np.uint8)
+            rounds = host.host_rounds_ransac_batch(_p(b1, C.c_double), _p(b2, C.c_double), _p(off, C.c_int64), len(sizes), C.c_double(0.004), 1000,
+                                                   C.c_double(0.99), 1, 10, _p(scores, C.c_int32), _p(iters, C.c_int32), _p(models, C.c_double),
+                                                   _p(mask, C.c_uint8))
+            assert rounds > 1
+            for p, w in enumerate(want):
+                if w is None:
+                    assert scores[p] == 0 and iters[p] == 0 and not mask[off[p]:off[p + 1]].any()
+                    continue
+                assert (scores[p], iters[p]) == (w["score"], w["iterations"]), (p, width)
+                assert np.array_equal(np.flatnonzero(mask[off[p]:off[p + 1]]), w["inliers"])
+                assert np.array_equal(models[p, :12].view(np.uint64), w["model"].reshape(-1).view(np.uint64))
+                assert np.array_equal(models[p, 12:].view(np.uint64), w["lo_model"].reshape(-1).view(np.uint64))
     finally:
-        host.host_set_batch0(64)
+        host.host_set_max_width(16)
 
 
 def test_refinement_bits(host, oracle_lib):
@@ -388,128 +411,3 @@ def test_gpu_bearing_tests_logic_on_the_emulation(host, oracle_lib, monkeypatch)
     monkeypatch.setattr(matching, "pixel_bearing_many", checked)
     gpu_tests.test_pixel_bearings(oracle_lib)
     gpu_tests.test_pixel_bearings_every_projection_type(oracle_lib)
-
-
-# ---- the cooperative organisation (relpose_coop.h, opt-in kernel) -----------------------------------------------------------------
-@pytest.mark.parametrize("order", [0, 1, 2])
-def test_coop_five_point_bits_in_any_item_order(host, oracle_lib, order):
-    """One minimal problem solved by the whole wavefront on shared matrices: the same doubles as the per-lane solver / the oracle,
-    whatever the order in which the items of each parallel step run (forwards, backwards, shuffled) -- i.e. no step reads what
-    another item of the same step writes."""
-    rng = np.random.default_rng(40)
-    host.host_set_item_order(order)
-    try:
-        for trial in range(150):
-            b1, b2, _ = _scene(rng, 5, outliers=0.0, noise=1e-2 if trial % 2 else 0.0)
-            ref = np.asarray(oracle_lib.essential_five_points(b1, b2))
-            Es = np.zeros(90)
-            k = host.host_essential_five_points_v2(_p(b1, C.c_double), _p(b2, C.c_double), _p(Es, C.c_double))
-            assert k == len(ref)
-            assert np.array_equal(Es[: 9 * k].view(np.uint64), ref.reshape(-1).view(np.uint64))
-        z = np.zeros((5, 3))
-        assert host.host_essential_five_points_v2(_p(z, C.c_double), _p(z, C.c_double), _p(np.zeros(90), C.c_double)) == 0
-    finally:
-        host.host_set_item_order(0)
-
-
-@pytest.mark.parametrize("order", [0, 2])
-def test_coop_ransac_and_match_bits(host, oracle_lib, order):
-    rng = np.random.default_rng(41)
-    host.host_set_item_order(order)
-    try:
-        for n, outl in ((5, 0.0), (9, 0.2), (30, 0.3), (200, 0.5), (500, 0.2), (120, 0.9)):
-            for use_lo, iters in ((1, 1000), (0, 150), (1, 37)):
-                b1, b2, _ = _scene(rng, n, outliers=outl)
-                want = oracle_lib.ransac_relative_pose(b1, b2, 0.004, iters, 0.99, bool(use_lo), 10)
-                model, lo, inl, it = np.zeros(12), np.zeros(12), np.zeros(n, np.int32), C.c_int(0)
-                score = host.host_ransac_relative_pose_v2(_p(b1, C.c_double), _p(b2, C.c_double), n, C.c_double(0.004), iters, C.c_double(0.99),
-                                                          use_lo, 10, _p(model, C.c_double), _p(lo, C.c_double), _p(inl, C.c_int32), C.byref(it))
-                assert (score, it.value) == (want["score"], want["iterations"]), (n, outl, use_lo, iters)
-                assert np.array_equal(inl[:score], want["inliers"])
-                assert np.array_equal(model.view(np.uint64), want["model"].reshape(-1).view(np.uint64))
-                assert np.array_equal(lo.view(np.uint64), want["lo_model"].reshape(-1).view(np.uint64))
-        for n, outl in ((7, 0.0), (8, 0.0), (40, 0.3), (300, 0.4), (1000, 0.6), (150, 0.97)):
-            b1, b2, good = _scene(rng, n, outliers=outl)
-            want = oracle_lib.robust_match_calibrated_bearings(b1, b2, 0.004, 1000, 0.99, True, 10, 10)
-            R, t, models, info = np.zeros(9), np.zeros(3), np.zeros(24), np.zeros(2, np.int32)
-            mask = np.zeros(n, np.uint8)
-            cnt = host.host_robust_match_calibrated_v2(_p(b1, C.c_double), _p(b2, C.c_double), n, C.c_double(0.004), 1000, C.c_double(0.99), 1, 10, 10,
-                                                       _p(R, C.c_double), _p(t, C.c_double), _p(mask, C.c_uint8), _p(models, C.c_double),
-                                                       _p(info, C.c_int32))
-            assert cnt == want["mask"].sum() and np.array_equal(mask.astype(bool), want["mask"])
-            assert (int(info[0]), int(info[1])) == (want["score"], want["iterations"])
-            if cnt:
-                assert np.array_equal(R.view(np.uint64), want["R"].reshape(-1).view(np.uint64))
-    finally:
-        host.host_set_item_order(0)
-
-
-def test_gpu_v2_test_logic_on_the_emulation(host, oracle_lib, monkeypatch):
-    """tests/test_gpu_zz_relpose.py::test_cooperative_organisation_gives_the_same_results with relpose_pairs served by the host
-    emulation of relpose_coop.h"""
-    from opensfm_amd import matching
-
-    import test_gpu_zz_relpose as gpu_tests
-
-    def relpose_pairs(b1, b2, offsets, threshold, mode="match", iterations=1000, probability=0.99, use_lo=True, lo_iterations=10,
-                      refine_iterations=10, ctx=None):
-        assert os.environ.get("OSFM_RELPOSE_V2") == "1"
-        res, mask = [], np.zeros(len(b1), bool)
-        for p in range(len(offsets) - 1):
-            s = slice(int(offsets[p]), int(offsets[p + 1]))
-            x, y = np.ascontiguousarray(b1[s]), np.ascontiguousarray(b2[s])
-            n = len(x)
-            if mode == "ransac":
-                model, lo, inl, it = np.zeros(12), np.zeros(12), np.zeros(max(n, 1), np.int32), C.c_int(0)
-                sc = host.host_ransac_relative_pose_v2(_p(x, C.c_double), _p(y, C.c_double), n, C.c_double(threshold), iterations,
-                                                       C.c_double(probability), int(use_lo), lo_iterations, _p(model, C.c_double),
-                                                       _p(lo, C.c_double), _p(inl, C.c_int32), C.byref(it))
-                m = np.zeros(n, bool)
-                m[inl[:sc]] = True
-                mask[s] = m
-                res.append({"score": sc, "iterations": it.value, "model": model.reshape(3, 4), "lo_model": lo.reshape(3, 4), "n_inliers": sc})
-            else:
-                R, t, models, info = np.zeros(9), np.zeros(3), np.zeros(24), np.zeros(2, np.int32)
-                mk = np.zeros(max(n, 1), np.uint8)
-                c = host.host_robust_match_calibrated_v2(_p(x, C.c_double), _p(y, C.c_double), n, C.c_double(threshold), iterations,
-                                                         C.c_double(probability), int(use_lo), lo_iterations, refine_iterations, _p(R, C.c_double),
-                                                         _p(t, C.c_double), _p(mk, C.c_uint8), _p(models, C.c_double), _p(info, C.c_int32))
-                mask[s] = mk[:n].astype(bool)
-                res.append({"score": int(info[0]), "iterations": int(info[1]), "n_inliers": c, "R": R.reshape(3, 3), "t": t})
-        return res, mask, 0.0
-
-    monkeypatch.setattr(matching, "relpose_pairs", relpose_pairs)
-    gpu_tests.test_cooperative_organisation_gives_the_same_results(oracle_lib, monkeypatch)
-
-
-@pytest.mark.parametrize("order", [0, 1, 2])
-def test_coop_hessenberg_qr_bits_on_general_matrices(host, order):
-    """The cooperative Hessenberg-QR against the per-lane routine on matrices the five-point solver rarely produces: random dense and
-    sparse ones, companion matrices with clustered roots, and cyclic shifts (eigenvalues on the unit circle: the textbook case that
-    needs the exceptional shifts at iterations 10 and 20)."""
-    rng = np.random.default_rng(50)
-    mats = [rng.normal(0, 1, (10, 10)) for _ in range(300)]
-    mats += [rng.normal(0, 1, (10, 10)) * (rng.random((10, 10)) < 0.3) for _ in range(300)]
-    for _ in range(100):  # companion matrices of polynomials with clustered real roots
-        roots = np.r_[np.full(4, rng.normal()), rng.normal(0, 1, 6)] + rng.normal(0, 1e-6, 10)
-        comp = np.zeros((10, 10))
-        comp[0] = -np.poly(roots)[1:]
-        comp[np.arange(1, 10), np.arange(9)] = 1.0
-        mats.append(comp)
-    shift = np.roll(np.eye(10), 1, axis=0)
-    mats += [shift, shift.T, 2.5 * shift, shift + 1e-9 * rng.normal(0, 1, (10, 10)), np.zeros((10, 10)), np.eye(10), np.triu(rng.normal(0, 1, (10, 10)))]
-    host.host_set_item_order(order)
-    try:
-        slow = 0
-        for idx, M in enumerate(mats):
-            a = np.ascontiguousarray(M, np.float64)
-            w0, w1 = np.zeros(10), np.zeros(10)
-            n0 = host.host_real_eigenvalues10(_p(a, C.c_double), 0, _p(w0, C.c_double))
-            n1 = host.host_real_eigenvalues10(_p(a, C.c_double), 1, _p(w1, C.c_double))
-            assert n0 == n1 and np.array_equal(w0[:n0].view(np.uint64), w1[:n1].view(np.uint64))
-            if idx < 300:  # dense random matrices, well-separated spectra: the count of real eigenvalues must agree with LAPACK's
-                ev = np.linalg.eigvals(M)
-                slow += n0 != int((np.abs(ev.imag) < 1e-9).sum())
-        assert slow == 0
-    finally:
-        host.host_set_item_order(0)

@@ -1,0 +1,14 @@
+#!/bin/bash
+# One gpurun call: the whole GPU suite, then the calibrated-matching benchmark with and without the profiler.
+OUT=/root/repo/gpurun_out/r02_relpose
+mkdir -p $OUT
+cd /root/repo
+timeout 900 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; tail -5 $OUT/pytest_gpu.log
+for P in 2048 8192 16384; do
+  timeout 300 python tools/relpose_bench.py --pairs $P --matches 300 > $OUT/relpose_bench_$P.json 2> $OUT/relpose_bench_$P.err
+  echo "pairs=$P: $(head -c 700 $OUT/relpose_bench_$P.json)"
+done
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python /root/repo/tools/relpose_bench.py --pairs 8192 --matches 300 --no-cpu > $OUT/relpose_prof.json 2> $OUT/relpose_prof.err
+python /root/repo/tools/rocpd_summary.py $(ls $OUT/trace/*.db $OUT/trace/*/*.db 2>/dev/null | head -1) > $OUT/relpose_rocprof_stats.txt 2>&1
+head -30 $OUT/relpose_rocprof_stats.txt

@@ -4,8 +4,8 @@ each next to the CPU oracle on a bounded sample.
 
     python tools/relpose_bench.py [--pairs 2048] [--matches 300] [--outliers 0.4] [--features 2000]
 
-Meant for `rocprofv3 --kernel-trace --stats -- python tools/relpose_bench.py`: the kernels are relpose_pairs_kernel and
-guided_match_kernel.  Algorithmic work: ~150 fp64 operations per (model, correspondence) score evaluation,
+Meant for `rocprofv3 --kernel-trace --stats -- python tools/relpose_bench.py`: the kernels are rp_walk_kernel / rp_solve5_kernel /
+rp_solveN_kernel / rp_finish_kernel (relpose.hip, rounds) and guided_match_kernel.  Algorithmic work: ~150 fp64 operations per (model, correspondence) score evaluation,
 ~6 models per iteration; the fp64 vector peak is ~78.6 TFLOP/s."""
 from __future__ import annotations
 
@@ -57,7 +57,7 @@ def run_relpose(ctx, pairs: int, matches: int, outliers: float, cpu_pairs: int =
     wall = time.perf_counter() - t0
     iters = np.array([r["iterations"] for r in res])
     flops = SCORE_FLOPS * 6.0 * float(iters.sum()) * matches  # scoring only: the dominant term of the cost model
-    out = {"kernel": "relpose_pairs_kernel", "pairs": pairs, "matches_per_pair": matches, "outlier_fraction": outliers,
+    out = {"kernel": "rp_walk + rp_solve5 + rp_solveN + rp_finish (rounds)", "pairs": pairs, "matches_per_pair": matches, "outlier_fraction": outliers,
            "kernel_ms": round(ms, 3), "pairs_per_s": round(pairs / (ms * 1e-3), 1), "pairs_per_s_incl_copies": round(pairs / wall, 1),
            "mean_ransac_iterations": round(float(iters.mean()), 1), "mean_inliers": round(float(np.mean([r["n_inliers"] for r in res])), 1),
            "scoring_tflops": round(flops / (ms * 1e-3) / 1e12, 4), "frac_of_fp64_peak": round(flops / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 5)}
@@ -100,7 +100,7 @@ def run_guided(ctx, features: int, repeats: int = 20, seed: int = 2) -> dict:
 
 def main() -> None:
     ap = argparse.ArgumentParser()
-    ap.add_argument("--pairs", type=int, default=2048)
+    ap.add_argument("--pairs", type=int, default=8192)
     ap.add_argument("--matches", type=int, default=300)
     ap.add_argument("--outliers", type=float, default=0.4)
     ap.add_argument("--features", type=int, default=2000)
