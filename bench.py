@@ -30,6 +30,10 @@ sys.path.insert(0, ROOT)
 
 PEAK_I8_TOPS = 5000.0  # dense int8 MFMA peak of MI355X (2x the 2.5 PFLOP/s bf16 dense peak); ubench ceiling 4404
 FLOP_PER_PAIR = 2.0 * 2000 * 2000 * 128  # one distance matrix serves both directions
+PEAK_F64_VALU_TFLOPS = 78.6  # fp64 vector peak (half the 157.3 TFLOP/s fp32 rate of MI355X_MICROARCH.md)
+RANSAC_FLOP_PER_MODEL_POINT = 40.0  # symmetric epipolar error of one correspondence under one F: two 3x3 products, two norms, compare
+RELPOSE_FLOP_PER_MODEL_POINT = 150.0  # RelativePose::Evaluate: rotate, midpoint triangulation, two reprojection cosines
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_match_pmc.json")  # HBM bytes per launch from the rocprofv3 --pmc passes of this command
 
 
 def parse():
@@ -49,6 +53,11 @@ def parse():
     ap.add_argument("--ba-track", type=int, default=10)
     ap.add_argument("--ba-iters", type=int, default=10)
     ap.add_argument("--no-robust", action="store_true", help="descriptor stage only (debug)")
+    ap.add_argument("--strong", action="store_true", help="fixed total work for every N (configs[3]: --images 10000 --strong)")
+    ap.add_argument("--no-overlap", action="store_true", help="skip the neighbour-preselected workload")
+    ap.add_argument("--overlap-neighbors", type=int, default=16)
+    ap.add_argument("--no-calibrated", action="store_true", help="skip the calibrated (essential-matrix) branch legs")
+    ap.add_argument("--full-parity", action="store_true", help="check EVERY pair with matches + 5000 empties against the oracle (~1.5 min)")
     return ap.parse_args()
 
 
@@ -76,11 +85,11 @@ def main():
     ctx = default_context(local_rank)
     # ---- workload: exhaustive pairs over n_images(N) images so that pairs ~= N * pairs(images) ----
     p1 = args.images * (args.images - 1) // 2
-    n_images = args.images if world == 1 else int(math.ceil((1 + math.sqrt(1 + 8.0 * world * p1)) / 2))
+    n_images = args.images if (world == 1 or args.strong) else int(math.ceil((1 + math.sqrt(1 + 8.0 * world * p1)) / 2))
     t0 = time.time()
     scene = synthetic.make_matching_scene(n_images, args.features, seed=args.seed)
     pairs_all = synthetic.all_pairs(n_images)
-    pairs_all = pairs_all[: world * p1]
+    pairs_all = pairs_all[: (p1 if args.strong else world * p1)]
     my_pairs = odist.shard_pairs(pairs_all, rank, world)
     pairs_gathered = pairs_all[odist.gathered_pair_order(len(pairs_all), world)]  # pair list of the gathered graph
     store = matching.DescriptorStore.from_packed(scene.desc, scene.pts, scene.offsets, ctx)
@@ -131,11 +140,33 @@ def main():
         "peak": PEAK_I8_TOPS,
         "unit": "TFLOP/s",
         "frac": round(achieved / PEAK_I8_TOPS, 4),
-        "traffic": None,  # PMC passes cannot run inside this process: see profiles/r01_final_match_pmc.txt (36.7 GB read / launch)
+        "traffic": None,
         "avg_launch_ms": round(avg_ms, 3),
         "launches": launches,
         "algorithmic_flop_per_pair": flop_pair,
     }
+
+    # HBM traffic per launch: PMC passes cannot run inside this process, so the committed counters of the same command
+    # (tools/pmc_match.sh -> profiles/r02_match_pmc.json: FETCH_SIZE doubled as the gfx950 guide prescribes, + WRITE_SIZE) are quoted,
+    # scaled to this run's pairs per launch
+    if os.path.exists(PMC_FILE):
+        try:
+            pmc = json.load(open(PMC_FILE))
+            k = pairs_per_launch / float(pmc["pairs_per_launch"])
+            roofline["traffic"] = {"hbm_read_bytes": pmc["fetch_bytes_corrected"] * k, "hbm_write_bytes": pmc["write_bytes"] * k,
+                                   "algorithmic_bytes": 2 * n_avg * 128 * pairs_per_launch, "source": pmc["source"]}
+        except (KeyError, ValueError):
+            pass
+    rs_ms = sum(float(t.ms_ransac_kernel) for t in tms)
+    rs_work = sum(int(t.ransac_model_points) for t in tms)
+    ransac_line = {
+        "bound": "valu-f64", "kernel": "ransac_pairs_kernel", "unit": "TFLOP/s", "peak": PEAK_F64_VALU_TFLOPS,
+        "model_points_per_s": round(rs_work / (rs_ms * 1e-3), 1) if rs_ms > 0 else 0.0,
+        "achieved": round(rs_work * RANSAC_FLOP_PER_MODEL_POINT / (rs_ms * 1e-3) / 1e12, 4) if rs_ms > 0 else 0.0,
+        "flop_per_model_point": RANSAC_FLOP_PER_MODEL_POINT,
+        "note": "hypotheses x correspondences scored per second of its own stream time; it runs underneath the matcher of the next chunk",
+    }
+    ransac_line["frac"] = round(ransac_line["achieved"] / PEAK_F64_VALU_TFLOPS, 5)
 
     out = {
         "metric": "image-pairs matched/sec (+ BA LM-iters/sec, 5k cams / 500k pts)",
@@ -146,7 +177,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if args.strong else "weak",
         "vs_baseline": None,
         "dtype": "i8 (exact int32 accumulate) + f64 RANSAC",
         "data": "synthetic",
@@ -161,6 +192,7 @@ def main():
             "parallelism": f"pair-sharded x{world}, descriptors replicated, all-gather of match graph",
         },
         "roofline": roofline,
+        "roofline_ransac": ransac_line,
         "stage_ms_per_step": {
             "match_kernel": round(ms_kernel / args.steps, 3),
             "ransac_kernel": round(sum(float(t.ms_ransac_kernel) for t in tms) / args.steps, 3),
@@ -175,8 +207,12 @@ def main():
     }
 
     if rank == 0:
+        if not args.no_overlap:
+            out["overlap_workload"] = overlap_bench(args, ctx, store, scene, n_images, not args.no_cpu_baseline)
+        if not args.no_calibrated:
+            out["calibrated"] = calibrated_bench(args, ctx, store, scene, n_images, not args.no_cpu_baseline)
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene, pairs_gathered, args.cpu_sample_pairs, graph)
+            out["cpu_baseline"] = cpu_baseline(scene, pairs_gathered, args.cpu_sample_pairs, graph, args.full_parity)
         if not args.no_tracks and graph is not None:
             out["tracks"] = tracks_bench(ctx, scene, pairs_gathered, graph, not args.no_cpu_baseline)
         if not args.no_ba:
@@ -229,9 +265,127 @@ def tracks_bench(ctx, scene, pairs_all, graph, with_cpu):
     return out
 
 
-def cpu_baseline(scene, pairs_all, n_sample, graph):
+def neighbour_pairs(n_images: int, k: int) -> np.ndarray:
+    """(i, j), i < j <= i + k: what pairs_selection emits with matching_order_neighbors = k (opensfm/pairs_selection.py:347-368) on a
+    sequence -- every pair sees common scene points, unlike the exhaustive list where 98 % of the pairs are empty."""
+    i = np.repeat(np.arange(n_images), k)
+    j = i + np.tile(np.arange(1, k + 1), n_images)
+    keep = j < n_images
+    return np.stack([i[keep], j[keep]], 1).astype(np.int32)
+
+
+def overlap_bench(args, ctx, store, scene, n_images, with_cpu):
+    """Second timed workload on the same store: the neighbour-preselected pair list (the normal OpenSfM use).  Every pair has work
+    for the ratio / mutual re-examination and for the RANSAC stage."""
+    from opensfm_amd import matching
+    from opensfm_amd._lib import MatchTimings
+
+    pairs = neighbour_pairs(n_images, args.overlap_neighbors)
+    matching.match_pairs(store, pairs[:512])
+    tms = []
+    t0 = time.perf_counter()
+    for _ in range(max(1, args.steps)):
+        tm = MatchTimings()
+        counts, m = matching.match_pairs(store, pairs, timings=tm)
+        tms.append(tm)
+    dt = (time.perf_counter() - t0) / max(1, args.steps)
+    c0, _ = matching.match_pairs(store, pairs, robust=False)
+    ms_k = float(np.mean([t.ms_match_kernel for t in tms]))
+    ms_r = float(np.mean([t.ms_ransac_kernel for t in tms]))
+    n_avg = float(np.mean(np.diff(scene.offsets)))
+    flop = 2.0 * n_avg * n_avg * 128 * len(pairs)
+    out = {
+        "workload": f"{len(pairs)} pairs (i, j), j - i <= {args.overlap_neighbors}, of the same {n_images} x {args.features} store",
+        "value": round(len(pairs) / dt, 1), "unit": "pairs/s",
+        "descriptor_stage_pairs_per_s": round(len(pairs) / (ms_k * 1e-3), 1),
+        "match_kernel_ms": round(ms_k, 3), "ransac_kernel_ms": round(ms_r, 3), "call_ms": round(1e3 * dt, 3),
+        "ransac_share_of_stream_time": round(ms_r / max(ms_k + ms_r, 1e-9), 3),
+        "pairs_reaching_ransac": int((c0 >= 20).sum()), "pairs_with_matches": int((counts > 0).sum()),
+        "descriptor_matches_per_pair": round(float(c0.mean()), 1), "inlier_matches_per_pair": round(float(counts.mean()), 1),
+        "roofline": {"bound": "mfma", "kernel": "match_fused4_kernel", "unit": "TFLOP/s", "peak": PEAK_I8_TOPS,
+                     "achieved": round(flop / (ms_k * 1e-3) / 1e12, 2), "frac": round(flop / (ms_k * 1e-3) / 1e12 / PEAK_I8_TOPS, 4)},
+        "roofline_ransac": {"bound": "valu-f64", "kernel": "ransac_pairs_kernel", "unit": "TFLOP/s", "peak": PEAK_F64_VALU_TFLOPS,
+                            "model_points_per_s": round(float(np.mean([t.ransac_model_points for t in tms])) / (ms_r * 1e-3), 1),
+                            "achieved": round(float(np.mean([t.ransac_model_points for t in tms])) * RANSAC_FLOP_PER_MODEL_POINT / (ms_r * 1e-3) / 1e12, 4)},
+    }
+    out["roofline_ransac"]["frac"] = round(out["roofline_ransac"]["achieved"] / PEAK_F64_VALU_TFLOPS, 5)
+    if with_cpu:
+        import oracle
+
+        sel = np.linspace(0, len(pairs) - 1, 768).astype(np.int64)
+        t0 = time.perf_counter()
+        res = oracle.match_pairs(scene.desc.astype(np.float32), scene.pts, scene.offsets, pairs[sel])
+        dtc = time.perf_counter() - t0
+        off = np.concatenate([[0], np.cumsum(counts)])
+        out["cpu_baseline"] = {"value": round(len(sel) / dtc, 3), "unit": "pairs/s", "cores": oracle.num_threads(), "kind": "port",
+                               "sample": f"{len(sel)} pairs strided over the list, {dtc:.1f} s, OpenMP over pairs",
+                               "parity_on_sample": bool(all(np.array_equal(m[off[p]: off[p + 1]], r) for p, r in zip(sel, res)))}
+    return out
+
+
+def calibrated_bench(args, ctx, store, scene, n_images, with_cpu):
+    """The essential-matrix branch of robust_match (every camera that is not an undistorted perspective one, matching.py:906-929):
+    (a) the geometric stage alone on synthetic bearing sets (osfm_relpose_pairs, 300 correspondences per pair, 40 % outliers), with
+    its fp64-VALU roofline line; (b) matching.match end to end (osfm_match_pairs_calibrated, device-resident) on the neighbour list
+    of the same store under a slightly distorted camera."""
+    from types import SimpleNamespace
+
+    from opensfm_amd import matching
+    from opensfm_amd._lib import MatchTimings
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from relpose_bench import two_view_bearings
+
+    rng = np.random.default_rng(1)
+    n_pairs, n = 16384, 300
+    base = [two_view_bearings(rng, n, 0.4) for _ in range(256)]  # 256 distinct problems, tiled: the rounds do not care
+    b1 = np.concatenate([base[k % 256][0] for k in range(n_pairs)])
+    b2 = np.concatenate([base[k % 256][1] for k in range(n_pairs)])
+    off = np.arange(n_pairs + 1, dtype=np.int64) * n
+    matching.relpose_pairs(b1[: 64 * n], b2[: 64 * n], off[:65], 0.004, "match", ctx=ctx)
+    res, mask, ms = matching.relpose_pairs(b1, b2, off, 0.004, "match", ctx=ctx)
+    iters = np.array([r["iterations"] for r in res])
+    flops = RELPOSE_FLOP_PER_MODEL_POINT * 6.0 * float(iters.sum()) * n
+    out = {"geometric_stage": {
+        "workload": f"{n_pairs} pairs x {n} correspondences, 40 % outliers, threshold 0.004 rad, LO-RANSAC + 3 refinement rounds",
+        "value": round(n_pairs / (ms * 1e-3), 1), "unit": "pairs/s", "device_ms": round(ms, 2),
+        "mean_ransac_iterations": round(float(iters.mean()), 1),
+        "roofline": {"bound": "valu-f64", "kernel": "rp_walk_kernel (+ rp_solve5a/b, rp_solveN, rp_pose, rp_finish)", "unit": "TFLOP/s",
+                     "peak": PEAK_F64_VALU_TFLOPS, "achieved": round(flops / (ms * 1e-3) / 1e12, 3),
+                     "frac": round(flops / (ms * 1e-3) / 1e12 / PEAK_F64_VALU_TFLOPS, 4),
+                     "algorithmic_flop": "150 per (model, correspondence) x ~6 models per iteration: the scoring only; the solvers are not counted"}}}
+    if with_cpu:
+        import oracle
+
+        t0 = time.perf_counter()
+        same = 0
+        for p in range(24):
+            sl = slice(off[p], off[p + 1])
+            w = oracle.robust_match_calibrated_bearings(b1[sl], b2[sl], 0.004, 1000, 0.99, True, 10, 10)
+            same += bool(np.array_equal(w["mask"], mask[sl]))
+        dtc = time.perf_counter() - t0
+        out["geometric_stage"]["cpu_baseline"] = {"value": round(24 / dtc, 2), "unit": "pairs/s", "cores": 1, "kind": "port",
+                                                   "sample": f"24 pairs, {dtc:.1f} s, one thread", "parity_on_sample": f"{same}/24 identical inlier sets"}
+    pairs = neighbour_pairs(n_images, args.overlap_neighbors)
+    cam = SimpleNamespace(projection_type="perspective", k1=1e-3, k2=0.0, focal=0.85)
+    cams = [cam] * n_images
+    matching.match_pairs_calibrated(store, pairs[:256], cams)
+    tm = MatchTimings()
+    t0 = time.perf_counter()
+    counts, m = matching.match_pairs_calibrated(store, pairs, cams, timings=tm)
+    dt = time.perf_counter() - t0
+    out["match_end_to_end"] = {
+        "workload": f"{len(pairs)} neighbour pairs of the {n_images} x {args.features} store, camera perspective k1 = 1e-3 (calibrated branch)",
+        "value": round(len(pairs) / dt, 1), "unit": "pairs/s", "call_ms": round(1e3 * dt, 2), "match_kernel_ms": round(float(tm.ms_match_kernel), 2),
+        "geometric_stage_ms": round(float(tm.ms_ransac_kernel), 2), "pairs_reaching_geometric_stage": int(tm.pairs_ransac),
+        "pairs_with_matches": int((counts > 0).sum()), "inlier_matches_per_pair": round(float(counts.mean()), 1)}
+    return out
+
+
+def cpu_baseline(scene, pairs_all, n_sample, graph, full_parity=False):
     """The CPU oracle (a port of the reference's cv2 path, see oracle/*.c) timed on this box's host
-    cores on a bounded, strided sample of the same pair list; also re-checks parity on the sample."""
+    cores on a bounded, strided sample of the same pair list; also re-checks parity on the sample.
+    --full-parity: additionally EVERY pair of the list that produced matches and 5000 random empty ones."""
     import oracle
 
     n_sample = min(n_sample, len(pairs_all))
@@ -246,7 +400,7 @@ def cpu_baseline(scene, pairs_all, n_sample, graph):
         counts, matches = graph
         off = np.concatenate([[0], np.cumsum(counts)])
         ok = all(np.array_equal(matches[off[p]: off[p + 1]], r) for p, r in zip(sel, res))
-    return {
+    out = {
         "value": round(n_sample / dt, 3),
         "unit": "pairs/s",
         "cores": oracle.num_threads(),
@@ -254,6 +408,22 @@ def cpu_baseline(scene, pairs_all, n_sample, graph):
         "sample": f"{n_sample} pairs strided over the same pair list, {dt:.1f} s, OpenMP over pairs",
         "parity_on_sample": ok,
     }
+    if full_parity and graph is not None:
+        counts, matches = graph
+        off = np.concatenate([[0], np.cumsum(counts)])
+        hit = np.flatnonzero(counts > 0)
+        rng = np.random.default_rng(5)
+        empty = rng.choice(np.flatnonzero(counts == 0), min(5000, int((counts == 0).sum())), replace=False)
+        chk = np.concatenate([hit, empty])
+        t0 = time.perf_counter()
+        bad = 0
+        for lo in range(0, len(chk), 2048):
+            part = chk[lo: lo + 2048]
+            res = oracle.match_pairs(desc, scene.pts, scene.offsets, pairs_all[part])
+            bad += sum(not np.array_equal(matches[off[p]: off[p + 1]], r) for p, r in zip(part, res))
+        out["full_parity"] = {"pairs_with_matches_checked": int(len(hit)), "empty_pairs_checked": int(len(empty)), "mismatches": int(bad),
+                              "seconds": round(time.perf_counter() - t0, 1)}
+    return out
 
 
 if __name__ == "__main__":

@@ -85,7 +85,8 @@ typedef struct {
   int64_t match_launches;
   int64_t pairs;           /* pairs processed                                            */
   int64_t pairs_exact_path; /* pairs re-run on the exact float-key kernel (d^2 >= 2^22)   */
-  int64_t pairs_ransac;    /* pairs that reached the geometric stage                     */
+  int64_t pairs_ransac;    /* calibrated branch: pairs that reached the geometric stage  */
+  int64_t ransac_model_points; /* F-RANSAC: sum over pairs of (models scored) x (correspondences): the work its roofline counts */
 } osfm_match_timings;
 
 /* Opaque result of a batched run: per pair a count and a list of (i, j) int32. */
@@ -261,10 +262,13 @@ void osfm_tracks_destroy(osfm_tracks *t);
 
 /* =====================================================================================
  * Calibrated robust matching (row M-a9 / SURVEY.md 8f-3): essential-matrix LO-RANSAC on bearings.
- * STATUS round 1: numerics pinned bit for bit against the CPU oracle through a host emulation of the
- * wavefront code (tests/test_relpose_core_host.py); first MI355X run at the very end of the round
- * (profiles/r01_relpose_bringup.txt): RANSAC stage bit-identical to the oracle, inlier sets identical
- * after the refinement; a first-correct kernel, not yet profiled or tuned.
+ * Organisation (round 2, relpose.hip / relpose_rounds.h): all pairs of a call go through rounds of kernels together -- walk (one
+ * wavefront per pair: scoring, the reference's decision rules, the draws), solve5a / solve5b / solveN (one lane per minimal /
+ * non-minimal problem), pose (one lane per essential matrix) -- then one launch of the refinement stage.  The numerics and the
+ * round logic are pinned bit for bit against the CPU oracle by a host emulation (tests/test_relpose_core_host.py); on the MI355X
+ * the RANSAC stage is bit-identical to the oracle and the inlier sets after the refinement are identical
+ * (tests/test_gpu_zz_relpose.py).  128 k pairs / s at 300 correspondences per pair in 16 k-pair calls, 180 k in 64 k-pair calls
+ * (profiles/r02_relpose_*.json).
  *
  * osfm_pixel_bearings  replaces camera.pixel_bearing_many(points) (opensfm/src/geometry/camera.cc ->
  *   ProjectGeneric::Backward, camera_instances.h:154-160) for every OSFM_CAMERA_* model; cam = the model's
@@ -305,6 +309,19 @@ int osfm_pixel_bearings(osfm_ctx *ctx, int model, const double *cam, const doubl
 int osfm_relpose_pairs(osfm_ctx *ctx, const double *b1, const double *b2, const int64_t *offsets, int n_pairs,
                        const osfm_relpose_params *params, int mode, osfm_relpose_result *results, uint8_t *mask,
                        double *kernel_ms /* may be NULL: HIP-event time of the kernels */);
+
+/*
+ * Batched pair matching for the pairs that take the calibrated branch of robust_match (opensfm/matching.py:906-929: every pair with
+ * a camera that is not an undistorted perspective / brown one): per pair matching.match (matching.py:563-634) = descriptor stage,
+ * the robust_matching_min_match gate, robust_match_calibrated (matching.py:871-903) on the bearings of the matched features, the
+ * gate again.  cam_model[n_images] (OSFM_CAMERA_*) and cam_params[n_images x 16] (native parameter order, as osfm_pixel_bearings)
+ * describe the camera of every image of the store.  Everything between the two stages stays on the device: bearings of all features
+ * once per call, gather of the matched bearings, the LO-RANSAC / refinement rounds, ordered compaction of the inliers.
+ * Same result object as osfm_match_pairs.
+ */
+int osfm_match_pairs_calibrated(osfm_ctx *ctx, const osfm_store *store, const int32_t *cam_model, const double *cam_params,
+                                const int32_t *pairs, int64_t n_pairs, const osfm_match_params *params,
+                                const osfm_relpose_params *relpose, osfm_match_result **out, osfm_match_timings *timings_or_null);
 
 /* =====================================================================================
  * Masked / guided descriptor matching (second half of row M-a9 / SURVEY.md 8f-3).

@@ -39,6 +39,7 @@ class MatchTimings(C.Structure):
         ("pairs", C.c_int64),
         ("pairs_exact_path", C.c_int64),
         ("pairs_ransac", C.c_int64),
+        ("ransac_model_points", C.c_int64),
     ]
 
 
@@ -91,6 +92,11 @@ SIGNATURES = {
         C.c_int,
         [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int64, C.POINTER(MatchParams), C.POINTER(C.c_void_p),
          C.POINTER(MatchTimings)],
+    ),
+    "osfm_match_pairs_calibrated": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_int64, C.POINTER(MatchParams),
+         C.POINTER(RelposeParams), C.POINTER(C.c_void_p), C.POINTER(MatchTimings)],
     ),
     "osfm_result_num_pairs": (C.c_int64, [C.c_void_p]),
     "osfm_result_total_matches": (C.c_int64, [C.c_void_p]),

@@ -205,12 +205,12 @@ struct DevBuf {
 };
 }  // namespace
 
-extern "C" int osfm_match_pairs(osfm_ctx *ctx, const osfm_store *store, const int32_t *pairs, int64_t n_pairs,
-                                const osfm_match_params *params, osfm_match_result **out,
-                                osfm_match_timings *tm) {
+static int match_pairs_impl(osfm_ctx *ctx, const osfm_store *store, const int32_t *pairs, int64_t n_pairs,
+                            const osfm_match_params *params, const OsfmCalibStage *calib, osfm_match_result **out,
+                            osfm_match_timings *tm) {
   OSFM_REQUIRE(ctx && store && params && out && (pairs || n_pairs == 0), OSFM_E_INVALID, "osfm_match_pairs: null argument");
   OSFM_REQUIRE(n_pairs >= 0, OSFM_E_INVALID, "n_pairs < 0");
-  OSFM_REQUIRE(!params->robust || params->robust_matching_min_match >= 15, OSFM_E_UNSUPPORTED,
+  OSFM_REQUIRE(calib || !params->robust || params->robust_matching_min_match >= 15, OSFM_E_UNSUPPORTED,
                "robust_matching_min_match < 15 would take cv2's LMedS branch, which is not implemented");
   *out = nullptr;
   for (int64_t k = 0; k < 2 * n_pairs; ++k)
@@ -223,7 +223,10 @@ extern "C" int osfm_match_pairs(osfm_ctx *ctx, const osfm_store *store, const in
   const int cap = store->max_count > 0 ? store->max_count : 1;
   // 131072 pairs per chunk at cap <= 2048 (1 GiB of match slots per buffer set), fewer for larger images
   const int64_t chunk_pairs = std::max<int64_t>(4096, std::min<int64_t>(1 << 17, ((int64_t)1 << 28) / cap));
-  const int64_t cp = n_pairs < chunk_pairs ? n_pairs : chunk_pairs;
+  // at least four chunks once there is enough work for that (>= 4096 pairs each): the geometric stage of chunk k runs on stream
+  // B underneath the matcher of chunk k + 1, which a neighbour-preselected list (every pair reaches RANSAC) needs most
+  int64_t cp = n_pairs < chunk_pairs ? n_pairs : chunk_pairs;
+  if (n_pairs >= 8192) cp = std::min<int64_t>(cp, std::max<int64_t>(4096, (n_pairs + 3) / 4));
   const int64_t nchunks = (n_pairs + cp - 1) / (cp > 0 ? cp : 1);
   // Two chunk buffer sets: while stream B runs RANSAC + gather + D2H of chunk k (a few thousand
   // workgroups, latency bound, plus two host round trips), stream A already runs the fused matcher
@@ -259,6 +262,10 @@ extern "C" int osfm_match_pairs(osfm_ctx *ctx, const osfm_store *store, const in
   OSFM_HIP(hipStreamCreateWithFlags(&sb.s, hipStreamNonBlocking));
   hipStream_t stA = ctx->stream, stB = sb.s;
 
+  DevBuf d_work;  // models x correspondences scored by the RANSAC kernel (osfm_match_timings::ransac_model_points)
+  OSFM_HIP(d_work.alloc(8));
+  OSFM_HIP(hipMemsetAsync(d_work.p, 0, 8, stA));
+  OSFM_HIP(hipStreamSynchronize(stA));
   osfm_match_result *res = new (std::nothrow) osfm_match_result();
   OSFM_REQUIRE(res != nullptr, OSFM_E_NOMEM, "out of host memory");
   struct Guard {
@@ -312,10 +319,16 @@ extern "C" int osfm_match_pairs(osfm_ctx *ctx, const osfm_store *store, const in
     OSFM_HIP(hipStreamWaitEvent(stB, S.r0, 0));
     hipEvent_t rb0 = ctx->ev[3], rb1 = ctx->ev[4];
     OSFM_HIP(hipEventRecord(rb0, stB));
-    if (params->robust) {
+    if (calib) {  // essential-matrix branch of robust_match (matching.py:871-929), device-resident between the two stages
+      int64_t nf = 0;
+      const int rc = osfm_calibrated_filter_chunk(ctx, store, *calib, pairs + 2 * p0, S.pairs.as<int32_t>(), np, cap, params->robust_matching_min_match,
+                                                  S.counts.as<int32_t>(), S.matches.as<uint32_t>(), stB, &nf);
+      if (rc != OSFM_OK) return rc;
+      if (tm) tm->pairs_ransac += nf;
+    } else if (params->robust) {
       const int rc = osfm_launch_ransac_pairs(ctx, store, S.pairs.as<int32_t>(), np, cap, params->robust_matching_min_match,
                                               params->robust_matching_threshold, params->ransac_confidence,
-                                              params->ransac_max_iters, S.counts.as<int32_t>(), S.matches.as<uint32_t>(), nullptr, stB);
+                                              params->ransac_max_iters, S.counts.as<int32_t>(), S.matches.as<uint32_t>(), nullptr, stB, d_work.as<unsigned long long>());
       if (rc != OSFM_OK) return rc;
     }
     OSFM_HIP(hipEventRecord(rb1, stB));
@@ -365,10 +378,33 @@ extern "C" int osfm_match_pairs(osfm_ctx *ctx, const osfm_store *store, const in
     tm->ms_match_kernel = ms_match;
     tm->ms_ransac_kernel = ms_ransac;
     tm->pairs = n_pairs;
+    unsigned long long work = 0;
+    OSFM_HIP(hipMemcpy(&work, d_work.p, 8, hipMemcpyDeviceToHost));
+    tm->ransac_model_points = (int64_t)work;
   }
   guard.r = nullptr;
   *out = res;
   return OSFM_OK;
+}
+
+extern "C" int osfm_match_pairs(osfm_ctx *ctx, const osfm_store *store, const int32_t *pairs, int64_t n_pairs,
+                                const osfm_match_params *params, osfm_match_result **out, osfm_match_timings *tm) {
+  return match_pairs_impl(ctx, store, pairs, n_pairs, params, nullptr, out, tm);
+}
+
+extern "C" int osfm_match_pairs_calibrated(osfm_ctx *ctx, const osfm_store *store, const int32_t *cam_model, const double *cam_params,
+                                           const int32_t *pairs, int64_t n_pairs, const osfm_match_params *params,
+                                           const osfm_relpose_params *relpose, osfm_match_result **out, osfm_match_timings *tm) {
+  OSFM_REQUIRE(ctx && store && cam_model && cam_params && params && relpose && out, OSFM_E_INVALID, "osfm_match_pairs_calibrated: null argument");
+  OSFM_CTX_LOCK(ctx);
+  OSFM_HIP(hipSetDevice(ctx->device));
+  double *d_bearings = nullptr;
+  int rc = osfm_store_bearings(ctx, store, cam_model, cam_params, &d_bearings);
+  if (rc != OSFM_OK) return rc;
+  const OsfmCalibStage cs{d_bearings, relpose};
+  rc = match_pairs_impl(ctx, store, pairs, n_pairs, params, &cs, out, tm);
+  (void)hipFree(d_bearings);
+  return rc;
 }
 
 extern "C" int64_t osfm_result_num_pairs(const osfm_match_result *r) { return r ? (int64_t)r->counts.size() : 0; }

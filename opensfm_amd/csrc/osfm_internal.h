@@ -89,11 +89,24 @@ struct OsfmPerDeviceOnce {
 int osfm_launch_match(osfm_ctx *ctx, const osfm_store *store, const int32_t *d_pairs, int64_t n_pairs,
                       double ratio, int symmetric, int squared_ratio, int cap, int32_t *d_counts, uint32_t *d_matches,
                       int32_t *d_flags, bool exact_kernel, hipStream_t stream);
+// relpose.hip: the LO-RANSAC rounds (+ refinement in MATCH mode) over device-resident bearings; fills d_mask and d_out
+int osfm_relpose_run_device(osfm_ctx *ctx, hipStream_t st, const double *d_b1, const double *d_b2, const int64_t *d_off, const int64_t *offsets,
+                            int n_pairs, const osfm_relpose_params *prm, int mode, uint8_t *d_mask, void *d_out, int *rounds_out);
+// calib.hip: the geometric stage of the calibrated branch on a chunk's device buffers (in place, like osfm_launch_ransac_pairs)
+struct OsfmCalibStage {
+  const double *d_bearings;  // unit bearings of every feature of the store, padded tile layout (tile * 32 + row) x 3
+  const osfm_relpose_params *relpose;
+};
+int osfm_calibrated_filter_chunk(osfm_ctx *ctx, const osfm_store *store, const OsfmCalibStage &cs, const int32_t *h_pairs, const int32_t *d_pairs,
+                                 int64_t n_pairs, int cap, int min_match, int32_t *d_counts, uint32_t *d_matches, hipStream_t stream,
+                                 int64_t *pairs_filtered);
+int osfm_store_bearings(osfm_ctx *ctx, const osfm_store *store, const int32_t *cam_model, const double *cam_params, double **d_out);
 // ransac.hip
 // in place: counts/matches of each pair are replaced by the inliers (or 0 when the pair fails a gate)
 int osfm_launch_ransac_pairs(osfm_ctx *ctx, const osfm_store *store, const int32_t *d_pairs,
                              int64_t n_pairs, int cap, int min_match, double thr, double conf,
-                             int max_iters, int32_t *d_counts, uint32_t *d_matches, double *d_F_or_null, hipStream_t stream);
+                             int max_iters, int32_t *d_counts, uint32_t *d_matches, double *d_F_or_null, hipStream_t stream,
+                             unsigned long long *d_work_or_null = nullptr);
 int osfm_launch_ransac_single(osfm_ctx *ctx, const double *d_p1, const double *d_p2, int n, double thr,
                               double conf, int max_iters, double *d_F, uint8_t *d_mask,
                               int32_t *d_info);

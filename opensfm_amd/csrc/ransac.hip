@@ -265,7 +265,7 @@ struct RansacShared {
   unsigned char subset_ok[kBatch];
   int good[kBatch][3];
   double best[9];
-  int ctrl[8];  // 0: niters, 1: max_good, 2: done, 3: iters run, 4: found_any
+  int ctrl[8];  // 0: niters, 1: max_good, 2: done, 3: iters run, 4: found_any, 5: models scored so far
   unsigned long long rng_state;
 };
 
@@ -282,6 +282,7 @@ __device__ void ransac_core(RansacShared &sh, int n, double thr, double conf, in
     sh.ctrl[1] = 0;
     sh.ctrl[2] = 0;
     sh.ctrl[3] = 0;
+    sh.ctrl[5] = 0;
     sh.rng_state = ~0ull;
   }
   __syncthreads();
@@ -367,6 +368,11 @@ __device__ void ransac_core(RansacShared &sh, int n, double thr, double conf, in
       int niters = sh.ctrl[0], max_good = sh.ctrl[1];
       int iter = it0;
       bool done = false;
+      {
+        int scored = 0;
+        for (int b = 0; b < kBatch; ++b) scored += sh.nmodels[b];
+        sh.ctrl[5] += scored;
+      }
       for (int b = 0; b < kBatch; ++b, ++iter) {
         if (iter >= niters) {
           done = true;
@@ -410,6 +416,7 @@ struct RansacPairsArgs {
   int32_t *counts;
   uint32_t *matches;
   double *F_out;
+  unsigned long long *work;  // optional: += (models scored) x (correspondences) of every pair, the work the roofline line counts
 };
 
 __global__ void __launch_bounds__(kThreads) ransac_pairs_kernel(RansacPairsArgs a) {
@@ -439,6 +446,7 @@ __global__ void __launch_bounds__(kThreads) ransac_pairs_kernel(RansacPairsArgs 
   __syncthreads();
   ransac_core(sh, n, a.thr, a.conf, a.max_iters, tid);
   const int max_good = sh.ctrl[1];
+  if (a.work && tid == 0) atomicAdd(a.work, (unsigned long long)sh.ctrl[5] * (unsigned long long)n);
   if (a.F_out && tid < 9) a.F_out[p * 9 + tid] = max_good > 0 ? sh.best[tid] : 0.0;
   // matching.py:798-800: F is None or F[2,2] == 0 -> no matches
   if (max_good <= 0 || sh.best[8] == 0.0) {
@@ -666,7 +674,7 @@ static int ensure_ransac_attributes(int device) {
 
 int osfm_launch_ransac_pairs(osfm_ctx *ctx, const osfm_store *store, const int32_t *d_pairs, int64_t n_pairs, int cap,
                              int min_match, double thr, double conf, int max_iters, int32_t *d_counts,
-                             uint32_t *d_matches, double *d_F_or_null, hipStream_t stream) {
+                             uint32_t *d_matches, double *d_F_or_null, hipStream_t stream, unsigned long long *d_work_or_null) {
   if (n_pairs == 0) return OSFM_OK;
   OSFM_REQUIRE(cap <= kMaxPts, OSFM_E_UNSUPPORTED, "cap %d > %d", cap, kMaxPts);
   RansacPairsArgs a;
@@ -682,6 +690,7 @@ int osfm_launch_ransac_pairs(osfm_ctx *ctx, const osfm_store *store, const int32
   a.counts = d_counts;
   a.matches = d_matches;
   a.F_out = d_F_or_null;
+  a.work = d_work_or_null;
   const size_t lds = sizeof(RansacShared) + (size_t)((cap + 3) & ~3) * 16 + 64;
   {
     const int rc = ensure_ransac_attributes(ctx->device);

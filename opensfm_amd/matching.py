@@ -426,6 +426,10 @@ def match_pairs(store: DescriptorStore, pairs: np.ndarray, config: Optional[Dict
     tm = timings if timings is not None else MatchTimings()
     check(lib.osfm_match_pairs(store.ctx.handle, store.handle, _fptr(pairs, C.c_int32), len(pairs), C.byref(prm),
                                C.byref(res), C.byref(tm)), "osfm_match_pairs")
+    return _fetch_result(lib, res)
+
+
+def _fetch_result(lib, res) -> Tuple[np.ndarray, np.ndarray]:
     try:
         n = lib.osfm_result_num_pairs(res)
         total = lib.osfm_result_total_matches(res)
@@ -437,36 +441,27 @@ def match_pairs(store: DescriptorStore, pairs: np.ndarray, config: Optional[Dict
     return counts[:n], matches[:total]
 
 
-def match_pairs_calibrated(store: DescriptorStore, pairs: np.ndarray, cameras: Sequence[Any], points: Sequence[np.ndarray],
-                           config: Optional[Dict[str, Any]] = None) -> Tuple[np.ndarray, np.ndarray]:
-    """``matching.match`` for pairs that take the calibrated branch of ``robust_match`` (``matching.py:563-634,871-929``):
-    descriptor matching on the GPU for all pairs, the ``robust_matching_min_match`` gate, bearings once per image, one
-    ``osfm_relpose_pairs`` launch for the surviving pairs, the gate again.  ``cameras[i]`` / ``points[i]`` belong to image i
-    of the store.  Same return convention as ``match_pairs``.
-    (The correspondences are gathered on the host between the two launches; fusing that step is the next item.)"""
+def match_pairs_calibrated(store: DescriptorStore, pairs: np.ndarray, cameras: Sequence[Any], points: Optional[Sequence[np.ndarray]] = None,
+                           config: Optional[Dict[str, Any]] = None, timings: Optional[MatchTimings] = None) -> Tuple[np.ndarray, np.ndarray]:
+    """``matching.match`` for pairs that take the calibrated branch of ``robust_match`` (``matching.py:563-634,871-929``), one
+    ``osfm_match_pairs_calibrated`` call: descriptor matching, the ``robust_matching_min_match`` gate, bearings of the matched
+    features, the LO-RANSAC + refinement rounds, the gate again -- device-resident from the descriptors to the inlier lists.
+    ``cameras[i]`` is the camera of image i of the store (``points`` is not needed any more: the keypoints live in the store).
+    Same return convention as ``match_pairs``."""
+    lib = _lib.load()
     pairs = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
-    min_match = int(_cfg(config, "robust_matching_min_match"))
-    counts, matches = match_pairs(store, pairs, config, robust=False)
-    per_pair = split_matches(counts, matches)
-    keep = [p for p, m in enumerate(per_pair) if len(m) >= max(min_match, 1)]
-    out_counts = np.zeros(len(pairs), np.int32)
-    if not keep:
-        return out_counts, np.zeros((0, 2), np.int32)
-    bearings: Dict[int, np.ndarray] = {}
-    for im in sorted({int(i) for p in keep for i in pairs[p]}):
-        bearings[im] = pixel_bearing_many(cameras[im], np.asarray(points[im], np.float64)[:, :2], store.ctx)
-    b1 = np.concatenate([bearings[int(pairs[p, 0])][per_pair[p][:, 0]] for p in keep])
-    b2 = np.concatenate([bearings[int(pairs[p, 1])][per_pair[p][:, 1]] for p in keep])
-    off = np.r_[0, np.cumsum([len(per_pair[p]) for p in keep])].astype(np.int64)
-    _, mask, _ = relpose_pairs(b1, b2, off, _cfg(config, "robust_matching_calib_threshold"), "match", 1000, 0.99, True, 10,
-                               _cfg(config, "five_point_refine_match_iterations"), store.ctx)
-    chunks = []
-    for k, p in enumerate(keep):
-        rm = per_pair[p][mask[off[k]: off[k + 1]]]
-        if len(rm) >= min_match and len(rm) > 0:
-            out_counts[p] = len(rm)
-            chunks.append(rm)
-    return out_counts, (np.concatenate(chunks) if chunks else np.zeros((0, 2), np.int32))
+    models = np.zeros(max(store.n_images, 1), np.int32)
+    params = np.zeros((max(store.n_images, 1), 16), np.float64)
+    for i in range(store.n_images):
+        models[i], params[i] = camera_parameters(cameras[i])
+    prm = make_params(config, robust=True)
+    rp = RelposeParams(float(_cfg(config, "robust_matching_calib_threshold")), 0.99, 1000, 1, 10, int(_cfg(config, "five_point_refine_match_iterations")))
+    res = C.c_void_p()
+    tm = timings if timings is not None else MatchTimings()
+    check(lib.osfm_match_pairs_calibrated(store.ctx.handle, store.handle, _fptr(models, C.c_int32), _fptr(params, C.c_double),
+                                          _fptr(pairs, C.c_int32), len(pairs), C.byref(prm), C.byref(rp), C.byref(res), C.byref(tm)),
+          "osfm_match_pairs_calibrated")
+    return _fetch_result(lib, res)
 
 
 def split_matches(counts: np.ndarray, matches: np.ndarray) -> List[np.ndarray]:

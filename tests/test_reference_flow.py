@@ -319,6 +319,9 @@ def test_match_flow_equals_the_product_host_flow(ref, oracle_lib, monkeypatch, g
     monkeypatch.setattr(product, "match_pairs", fake_match_pairs)
     monkeypatch.setattr(product, "pixel_bearing_many", bearings)
     monkeypatch.setattr(product, "relpose_pairs", relpose_pairs)
+    # osfm_match_pairs_calibrated composed on the host from its (emulated) stages
+    monkeypatch.setattr(product, "match_pairs_calibrated", rp._composed_match_pairs_calibrated(
+        product, lambda st: [st.pts[st.off[i]: st.off[i + 1]] for i in range(len(st.off) - 1)]))
     monkeypatch.setattr(product, "_match_guided_leaf", guided_leaf)
     monkeypatch.setattr(product, "find_fundamental_ransac", fundamental_leaf)
     got = product.match_images_with_pairs(data, {}, exifs, pairs, poses if guided else None)

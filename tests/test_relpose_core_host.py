@@ -52,6 +52,38 @@ def _scene(rng, n, outliers=0.3, noise=1e-3):
     return np.ascontiguousarray(b1), np.ascontiguousarray(b2), ~bad
 
 
+def _composed_match_pairs_calibrated(matching, pts_of_store):
+    """What osfm_match_pairs_calibrated does on the device, composed on the host from its stages (descriptor stage, gate, bearings,
+    gather, relative-pose batch, compaction, gate): stands in for the C-ABI call where the tests redirect the stages to emulations."""
+
+    def run(store, pairs, cameras, points=None, config=None, timings=None):
+        points = points if points is not None else pts_of_store(store)
+        pairs = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+        min_match = int(matching._cfg(config, "robust_matching_min_match"))
+        counts, matches = matching.match_pairs(store, pairs, config, robust=False)
+        per_pair = matching.split_matches(counts, matches)
+        keep = [p for p, m in enumerate(per_pair) if len(m) >= max(min_match, 1)]
+        out_counts = np.zeros(len(pairs), np.int32)
+        if not keep:
+            return out_counts, np.zeros((0, 2), np.int32)
+        bearings = {im: matching.pixel_bearing_many(cameras[im], np.asarray(points[im], np.float64)[:, :2], store.ctx)
+                    for im in sorted({int(i) for p in keep for i in pairs[p]})}
+        b1 = np.concatenate([bearings[int(pairs[p, 0])][per_pair[p][:, 0]] for p in keep])
+        b2 = np.concatenate([bearings[int(pairs[p, 1])][per_pair[p][:, 1]] for p in keep])
+        off = np.r_[0, np.cumsum([len(per_pair[p]) for p in keep])].astype(np.int64)
+        _, mask, _ = matching.relpose_pairs(b1, b2, off, matching._cfg(config, "robust_matching_calib_threshold"), "match", 1000, 0.99, True, 10,
+                                            matching._cfg(config, "five_point_refine_match_iterations"), store.ctx)
+        chunks = []
+        for k, p in enumerate(keep):
+            rm = per_pair[p][mask[off[k]: off[k + 1]]]
+            if len(rm) >= min_match and len(rm) > 0:
+                out_counts[p] = len(rm)
+                chunks.append(rm)
+        return out_counts, (np.concatenate(chunks) if chunks else np.zeros((0, 2), np.int32))
+
+    return run
+
+
 def _emulated_calls(host):
     """(pixel_bearing_many, relpose_pairs) of opensfm_amd.matching served by the host emulation instead of the C ABI."""
 
@@ -343,6 +375,7 @@ def test_match_images_with_pairs_routes_calibrated_pairs(host, oracle_lib, monke
     monkeypatch.setattr(matching, "match_pairs", fake_match_pairs)
     monkeypatch.setattr(matching, "pixel_bearing_many", bearings)
     monkeypatch.setattr(matching, "relpose_pairs", relpose_pairs)
+    monkeypatch.setattr(matching, "match_pairs_calibrated", _composed_match_pairs_calibrated(matching, lambda st: st.pts))
     got = matching.match_images_with_pairs(data, {}, exifs, pairs)
     assert set(got) == set(pairs)
     assert ("a", "b", True) in stage and all((a, b, False) in stage for a, b in pairs if (a, b) != ("a", "b"))
@@ -391,6 +424,8 @@ def test_gpu_pipeline_test_logic_on_the_emulation(host, oracle_lib, monkeypatch)
     monkeypatch.setattr(matching, "match_pairs", fake_match_pairs)
     monkeypatch.setattr(matching, "pixel_bearing_many", bearings)
     monkeypatch.setattr(matching, "relpose_pairs", relpose_pairs)
+    monkeypatch.setattr(matching, "match_pairs_calibrated", _composed_match_pairs_calibrated(
+        matching, lambda st: [st.pts[st.offsets[i]: st.offsets[i + 1]] for i in range(len(st.offsets) - 1)]))
     gpu_tests.test_match_pairs_calibrated_pipeline(oracle_lib, None)
 
 
