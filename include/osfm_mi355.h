@@ -240,6 +240,60 @@ int osfm_ba_solve(osfm_ctx *ctx, osfm_ba_problem *problem, const osfm_ba_options
 int osfm_ba_shot_order(const osfm_ba_problem *problem, int32_t *new_of_old, int32_t *half_width_before,
                        int32_t *half_width_after);
 
+/* ------------------------------------------------------------------------------------------
+ * The general bundle adjustment: everything BAHelpers::Bundle (ba_helpers.cc:581-763) hands to bundle::BundleAdjuster and Run
+ * (bundle_adjuster.cc:595-1121) solves -- every projection type with all of its native parameters free or constant
+ * (camera_instances.h, AddCameraPriorError bundle_adjuster.cc:568-593 with logarithmic focal / aspect ratio, the dual camera's
+ * ParameterBarrier), the SPHERICAL 3-D bearing residual (projection_errors.h:208-376), rig cameras with pose priors and rig
+ * instances (error_utils.h:68-85 WorldToCameraCoordinatesRig), rig instance position priors through a per-camera GPS bias
+ * (SimilarityPriorTransform, bias.h:33-53, bundle_adjuster.cc:745-778), point priors = ground control points
+ * (bundle_adjuster.cc:688-707, ba_helpers.cc:349-406), absolute up vectors (absolute_motion_errors.h:12-39, Cauchy(1)).
+ * Points are eliminated; the reduced system over all other free parameters is formed dense on the device and factorised
+ * (the exact solve of Ceres' SPARSE_SCHUR).  osfm_ba_solve above is the streaming solver for the perspective / fisheye
+ * [k1 k2 focal] configuration at benchmark scale; this entry point is the general one.
+ * Poses are CAM_TO_WORLD [rx ry rz tx ty tz] (bundle/data/pose.h:17,34-43); camera parameters in the native order of the
+ * OSFM_CAMERA_* definitions, 16 slots per camera; in/out arrays are overwritten with the optimum.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t n_cameras;
+  const int32_t *cam_model;        /* n_cameras: OSFM_CAMERA_*                                                         */
+  double *cam_params;              /* n_cameras x 16                                                            in/out */
+  const double *cam_prior;         /* n_cameras x 16                                                                   */
+  const double *cam_sigma;         /* n_cameras x 16: GetDefaultCameraSigma (bundle_adjuster.cc:47-69)                 */
+  const uint8_t *cam_fixed;        /* n_cameras                                                                        */
+  double *bias;                    /* n_cameras x 7 [rx ry rz tx ty tz scale] (bias.h:10-31) or NULL = identity  in/out */
+  const uint8_t *bias_fixed;       /* n_cameras or NULL = all constant (AddCamera's default, bundle_adjuster.cc:98-106) */
+  int32_t n_rig_cameras;
+  double *rig_camera_pose;         /* n_rig_cameras x 6                                                          in/out */
+  const double *rig_camera_prior;  /* n_rig_cameras x 6 or NULL                                                         */
+  const double *rig_camera_sigma;  /* n_rig_cameras x 6 or NULL (GetDefaultRigPoseSigma)                                */
+  const uint8_t *rig_camera_fixed; /* n_rig_cameras                                                                     */
+  int32_t n_rig_instances;
+  double *rig_instance_pose;       /* n_rig_instances x 6                                                        in/out */
+  const uint8_t *rig_instance_fixed;       /* n_rig_instances or NULL                                                   */
+  const double *rig_instance_gps;          /* n_rig_instances x 3 or NULL: AddRigInstancePositionPrior                  */
+  const double *rig_instance_gps_sigma;    /* n_rig_instances x 3; [3 i] <= 0: no prior for instance i                  */
+  const int32_t *rig_instance_bias_camera; /* n_rig_instances: the camera whose bias applies (its first shot's camera,
+                                              bundle_adjuster.cc:757-764)                                               */
+  int32_t n_shots;
+  const int32_t *shot_rig_instance, *shot_rig_camera, *shot_camera; /* n_shots each                                     */
+  const double *shot_up;           /* n_shots x 3 or NULL: AddAbsoluteUpVector                                          */
+  const double *shot_up_sigma;     /* n_shots; <= 0: none                                                               */
+  int32_t n_points;
+  double *points;                  /* n_points x 3                                                               in/out */
+  const uint8_t *point_fixed;      /* n_points or NULL                                                                  */
+  const double *point_prior;       /* n_points x 3 or NULL: AddPointPrior                                               */
+  const double *point_prior_sigma; /* n_points x 3; [3 p] <= 0: no prior for point p                                    */
+  const uint8_t *point_prior_has_altitude; /* n_points or NULL = all 1: 0 constrains x, y only                          */
+  int64_t n_obs;
+  const int32_t *obs_shot, *obs_point;
+  const double *obs_xy;            /* n_obs x 2 normalized image coordinates                                            */
+  const double *obs_sigma;         /* n_obs                                                                             */
+  double *reproj_err;              /* n_obs x 3 or NULL: out, residual with sigma 1 (third component: spherical only)   */
+} osfm_bundle_problem;
+
+int osfm_bundle_solve(osfm_ctx *ctx, osfm_bundle_problem *problem, const osfm_ba_options *options, osfm_ba_report *report);
+
 /* =====================================================================================
  * Tracks (next row after the hot path: SURVEY.md 8f-1)
  * Replaces the grouping of tracking.create_tracks_manager (opensfm/tracking.py:68-98, union-find

@@ -23,7 +23,7 @@ from typing import Any, Dict, List, Optional
 import numpy as np
 
 from . import _lib
-from ._ba_abi import BaOptions, BaProblem, BaReport
+from ._ba_abi import BaOptions, BaProblem, BaReport, fill_bundle_problem
 from ._lib import check, default_context
 
 LOSSES = {"TrivialLoss": 0, "SoftLOneLoss": 1, "HuberLoss": 2, "CauchyLoss": 3}
@@ -140,6 +140,35 @@ def bundle_arrays(problem: Dict[str, np.ndarray], config: Optional[Dict[str, Any
         "wall_times": {"setup": (t1 - t0) + R.seconds_setup, "run": R.seconds_run, "teardown": R.seconds_teardown},
         "num_images": len(poses), "num_points": len(pts), "num_reprojections": len(obs_shot),
     }
+
+
+def bundle_general_arrays(problem: Dict[str, Any], config: Optional[Dict[str, Any]] = None, ctx=None, **overrides) -> Dict[str, Any]:
+    """The general bundle adjustment over flat arrays (``osfm_bundle_solve``; field names and shapes: ``_ba_abi.BUNDLE_FIELDS`` =
+    ``osfm_bundle_problem`` of ``include/osfm_mi355.h``): every camera model with free or constant intrinsics, rig cameras, rig
+    instances, GPS priors through per-camera biases, point priors (ground control points), up vectors.  Inputs are not modified;
+    returns the optimised parameter arrays, ``reproj_err`` (n_obs x 3, sigma 1) and the report."""
+    ctx = ctx or default_context()
+    lib = _lib.load()
+    P, arr = fill_bundle_problem(problem)
+    O = make_options(config, **overrides)
+    R = BaReport()
+    check(lib.osfm_bundle_solve(ctx.handle, C.byref(P), C.byref(O), C.byref(R)), "osfm_bundle_solve")
+    out = {k: arr[k] for k in ("cam_params", "rig_camera_pose", "rig_instance_pose", "points") if k in arr}
+    if "bias" in arr:
+        out["bias"] = arr["bias"]
+    out.update({
+        "reproj_err": arr["reproj_err"][: int(P.n_obs)],
+        "iterations": R.iterations, "successful_steps": R.successful_steps, "termination": R.termination,
+        "initial_cost": R.initial_cost, "final_cost": R.final_cost,
+        "cost_history": np.array(R.cost_history[: min(R.iterations, 255) + 1]),
+        "seconds_setup": R.seconds_setup, "seconds_run": R.seconds_run, "seconds_teardown": R.seconds_teardown,
+        "seconds_linear_solver": R.seconds_linear_solver,
+        "brief_report": "osfm-mi355 LM (dense Schur): iterations %d (successful %d), initial cost %.6e, final cost %.6e, termination: %s"
+                        % (R.iterations, R.successful_steps, R.initial_cost, R.final_cost, TERMINATION.get(R.termination, str(R.termination))),
+        "wall_times": {"setup": R.seconds_setup, "run": R.seconds_run, "teardown": R.seconds_teardown},
+        "num_images": int(P.n_shots), "num_points": int(P.n_points), "num_reprojections": int(P.n_obs),
+    })
+    return out
 
 
 # ------------------------------------------------------------------------------------------------

@@ -309,3 +309,132 @@ def make_ba_scene(n_shots: int, n_points: int, track_len: int = 10, seed: int = 
         prob["cam_ext"] = ext
         prob["cam_fixed"] = np.ones(1, np.uint8)
     return prob
+
+
+# ------------------------------------------------------------------------------------------------
+# scenes for the general bundle adjustment (osfm_bundle_solve): rigs, every camera model, biases, control points
+# ------------------------------------------------------------------------------------------------
+BUNDLE_TEST_CAMERAS = {  # native parameters [projection][distortion][affine]
+    "perspective": [-0.1, 0.01, 0.7],
+    "fisheye": [-0.05, 0.01, 0.6],
+    "brown": [-0.08, 0.01, 0.002, 0.001, -0.001, 0.75, 1.02, 0.01, -0.015],
+    "fisheye_opencv": [-0.03, 0.006, -0.001, 0.0002, 0.55, 0.99, 0.005, 0.01],
+    "fisheye62": [-0.03, 0.005, -0.001, 0.0003, -0.0001, 0.00002, 0.0008, -0.0006, 0.56, 1.01, 0.004, -0.006],
+    "fisheye624": [-0.03, 0.005, -0.001, 0.0003, -0.0001, 0.00002, 0.0008, -0.0006, 0.0005, -0.0002, 0.0004, 0.0001, 0.56, 1.01, 0.004, -0.006],
+    "dual": [0.4, -0.06, 0.008, 0.65],
+    "radial": [-0.07, 0.009, 0.72, 1.01, 0.006, -0.004],
+    "simple_radial": [-0.05, 0.7, 0.99, -0.005, 0.008],
+    "spherical": [],
+}
+MODEL_IDS = dict(CAMERA_MODEL_IDS, spherical=9)
+
+
+def _compose_world_to_cam(inst: np.ndarray, rc: np.ndarray, X: np.ndarray) -> np.ndarray:
+    """WorldToCameraCoordinatesRig (error_utils.h:68-85): x_cam = R_rc^T (R_i^T (x - t_i) - t_rc), poses CAM_TO_WORLD"""
+    Xi = (X - inst[3:6]) @ _rodrigues(-inst[:3]).T
+    return (Xi - rc[3:6]) @ _rodrigues(-rc[:3]).T
+
+
+def project_model(model: str, par, Xc: np.ndarray) -> np.ndarray:
+    """projection of camera-frame points by any model; spherical: (lon, lat) / 2 pi (geometry/camera_projections_functions.h)"""
+    if model == "spherical":
+        lon = np.arctan2(Xc[:, 0], Xc[:, 2])
+        lat = np.arctan2(-Xc[:, 1], np.hypot(Xc[:, 0], Xc[:, 2]))
+        return np.stack([lon / (2 * np.pi), -lat / (2 * np.pi)], axis=1)
+    ident = np.zeros(6)
+    if model in GENERIC_MODELS:
+        return project_generic(Xc, ident, np.asarray(par, float), model)
+    return project_perspective(Xc, ident, np.asarray(par, float), model)
+
+
+def make_bundle_scene(models=("perspective", "brown"), n_instances: int = 12, n_points: int = 150, rig: bool = True, seed: int = 3,
+                      free_cameras: bool = True, free_rig_camera: bool = True, gps: bool = True, free_bias: bool = True,
+                      n_gcp: int = 4, up_vectors: bool = True, px_noise: float = 2e-4, outlier_frac: float = 0.03) -> dict:
+    """A small scene exercising every parameter block and residual family of ``osfm_bundle_solve``: one camera per entry of
+    ``models`` (shots alternate between them), a rig of two rig cameras (the first a constant identity, the second with an offset
+    and a prior), instances along a street, GPS priors generated THROUGH a non-identity bias per camera, a few control points
+    with position priors, gravity-aligned up vectors.  Returns the dict form of an ``osfm_bundle_problem`` plus ``gt_*``."""
+    rng = np.random.default_rng(seed)
+    NC = len(models)
+    cam_gt = np.zeros((NC, 16))
+    for c, m in enumerate(models):
+        cam_gt[c, : len(BUNDLE_TEST_CAMERAS[m])] = BUNDLE_TEST_CAMERAS[m]
+    NR = 2 if rig else 1
+    rc_gt = np.zeros((NR, 6))
+    if rig:
+        rc_gt[1] = [0.02, -0.3, 0.01, 0.4, 0.02, -0.05]
+    NI = n_instances
+    inst_gt = np.zeros((NI, 6))
+    inst_gt[:, 0:3] = rng.normal(0, 0.03, (NI, 3))
+    inst_gt[:, 3] = np.arange(NI) * 0.5
+    inst_gt[:, 4:6] = rng.normal(0, 0.05, (NI, 2))
+    shot_inst = np.repeat(np.arange(NI), NR).astype(np.int32)
+    shot_rc = np.tile(np.arange(NR), NI).astype(np.int32)
+    shot_cam = ((np.arange(NI * NR) // NR + np.arange(NI * NR) % NR) % NC).astype(np.int32)
+    S = NI * NR
+    pts_gt = np.stack([rng.uniform(-1.0, NI * 0.5 + 1.0, n_points), rng.uniform(-1.5, 1.5, n_points), rng.uniform(4.0, 10.0, n_points)], axis=1)
+    obs_shot, obs_point, obs_xy = [], [], []
+    for s in range(S):
+        m = models[shot_cam[s]]
+        Xc = _compose_world_to_cam(inst_gt[shot_inst[s]], rc_gt[shot_rc[s]], pts_gt)
+        uv = project_model(m, cam_gt[shot_cam[s]], Xc)
+        ang = np.arctan2(np.hypot(Xc[:, 0], Xc[:, 1]), Xc[:, 2])
+        vis = np.flatnonzero(((Xc[:, 2] > 0.5) & (ang < 0.6)) if m != "spherical" else np.ones(len(Xc), bool))
+        vis = vis[np.abs(pts_gt[vis, 0] - inst_gt[shot_inst[s], 3]) < 3.0]
+        obs_shot += [s] * len(vis)
+        obs_point += list(vis)
+        obs_xy.append(uv[vis])
+    obs_shot, obs_point = np.asarray(obs_shot, np.int32), np.asarray(obs_point, np.int32)
+    obs_xy = np.concatenate(obs_xy) + rng.normal(0, px_noise, (len(obs_shot), 2))
+    outl = rng.random(len(obs_xy)) < outlier_frac
+    obs_xy[outl] += rng.uniform(-0.02, 0.02, (int(outl.sum()), 2))
+    seen = np.bincount(obs_point, minlength=n_points) >= 2
+    remap = -np.ones(n_points, np.int64)
+    remap[seen] = np.arange(int(seen.sum()))
+    keep = seen[obs_point]
+    obs_shot, obs_point, obs_xy, outl = obs_shot[keep], remap[obs_point[keep]].astype(np.int32), obs_xy[keep], outl[keep]
+    pts_gt = pts_gt[seen]
+    NP = len(pts_gt)
+    cam0 = cam_gt.copy()
+    for c, m in enumerate(models):
+        nk = len(BUNDLE_TEST_CAMERAS[m])
+        cam0[c, :nk] *= 1.0 + rng.normal(0, 0.01, nk) * (1 if free_cameras else 0)
+    sig = np.full((NC, 16), 0.01)
+    prob = {
+        "cam_model": np.asarray([MODEL_IDS[m] for m in models], np.int32), "cam_params": cam0, "cam_prior": cam_gt.copy(), "cam_sigma": sig,
+        "cam_fixed": np.full(NC, 0 if free_cameras else 1, np.uint8),
+        "rig_camera_pose": rc_gt + (np.r_[np.zeros((1, 6)), rng.normal(0, 0.01, (NR - 1, 6))] if free_rig_camera else 0.0),
+        "rig_camera_prior": rc_gt.copy(), "rig_camera_sigma": np.tile([1.0, 1.0, 1.0, 0.1, 0.1, 0.1], (NR, 1)),
+        "rig_camera_fixed": np.asarray([1] + [0 if free_rig_camera else 1] * (NR - 1), np.uint8),
+        "rig_instance_pose": inst_gt + np.c_[rng.normal(0, 0.01, (NI, 3)), rng.normal(0, 0.05, (NI, 3))],
+        "shot_rig_instance": shot_inst, "shot_rig_camera": shot_rc, "shot_camera": shot_cam,
+        "points": pts_gt + rng.normal(0, 0.05, pts_gt.shape),
+        "obs_shot": obs_shot, "obs_point": obs_point, "obs_xy": obs_xy, "obs_sigma": np.full(len(obs_xy), 0.004),
+        "gt_cam": cam_gt, "gt_rig_camera": rc_gt, "gt_rig_instance": inst_gt, "gt_points": pts_gt, "is_outlier": outl, "models": list(models),
+    }
+    if gps:
+        # measured positions g with t = s R(b) g + t_b: the bias maps measurements to the reconstruction frame
+        bias_gt = np.tile([0.0, 0.0, 0.02, 0.3, -0.2, 0.1, 1.01], (NC, 1))
+        bc = shot_cam[::NR].astype(np.int32)  # the instance's first shot
+        g = np.zeros((NI, 3))
+        for i in range(NI):
+            b = bias_gt[bc[i]]
+            g[i] = ((inst_gt[i, 3:6] - b[3:6]) @ _rodrigues(b[:3])) / b[6]  # R^T (t - t_b) / s
+        prob.update({"rig_instance_gps": g + rng.normal(0, 0.01, g.shape), "rig_instance_gps_sigma": np.full((NI, 3), 0.5),
+                     "rig_instance_bias_camera": bc, "bias": np.tile([0, 0, 0, 0, 0, 0, 1.0], (NC, 1)),
+                     "bias_fixed": np.full(NC, 0 if free_bias else 1, np.uint8), "gt_bias": bias_gt})
+    if n_gcp:
+        pick = rng.choice(NP, min(n_gcp, NP), replace=False)
+        pp, ps = np.zeros((NP, 3)), np.zeros((NP, 3))
+        pp[pick] = pts_gt[pick] + rng.normal(0, 0.005, (len(pick), 3))
+        ps[pick] = [0.01, 0.01, 0.02]
+        alt = np.ones(NP, np.uint8)
+        alt[pick[::2]] = 0
+        prob.update({"point_prior": pp, "point_prior_sigma": ps, "point_prior_has_altitude": alt})
+    if up_vectors:
+        up = np.zeros((S, 3))
+        for s in range(S):  # the up vector in camera coordinates: R_shot^T e_z with R_shot = R_i R_rc (camera to world)
+            Rcw = _rodrigues(inst_gt[shot_inst[s], :3]) @ _rodrigues(rc_gt[shot_rc[s], :3])
+            up[s] = Rcw.T @ np.array([0.0, 0.0, 1.0]) + rng.normal(0, 1e-3, 3)
+        prob.update({"shot_up": up, "shot_up_sigma": np.full(S, 1e-2)})
+    return prob

@@ -19,7 +19,7 @@ _LIB: Optional[C.CDLL] = None
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith(".c")]
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".cc"))]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -331,6 +331,46 @@ def ba_solve(problem: dict, loss: str = "SoftLOneLoss", loss_threshold: float = 
         "seconds_total": R.seconds_total, "seconds_linear_solver": R.seconds_linear_solver,
         "cost_history": np.array(R.cost_history[: R.iterations + 1]),
     }
+
+
+def bundle_general(problem: dict, loss: str = "SoftLOneLoss", loss_threshold: float = 1.0, max_iterations: int = 100,
+                   function_tolerance: float = 1e-6, gradient_tolerance: float = 1e-10, parameter_tolerance: float = 1e-8) -> dict:
+    """oracle_bundle_solve (bundle_general_oracle.cc) on the dict form of an osfm_bundle_problem (field list shared with the product's
+    ctypes binding: it describes the C struct, not an algorithm)."""
+    from opensfm_amd._ba_abi import BundleProblem, fill_bundle_problem
+
+    P, arr = fill_bundle_problem(problem, BundleProblem)
+    O = _BaOptions()
+    O.loss = {"TrivialLoss": 0, "SoftLOneLoss": 1, "HuberLoss": 2, "CauchyLoss": 3}[loss]
+    O.loss_threshold, O.max_iterations = loss_threshold, max_iterations
+    O.function_tolerance, O.gradient_tolerance, O.parameter_tolerance, O.initial_radius = function_tolerance, gradient_tolerance, parameter_tolerance, 1e4
+
+    class _Rep(C.Structure):
+        _fields_ = [("iterations", C.c_int32), ("successful_steps", C.c_int32), ("termination", C.c_int32), ("initial_cost", C.c_double),
+                    ("final_cost", C.c_double), ("cost_history", C.c_double * 256)]
+
+    R = _Rep()
+    f = lib().oracle_bundle_solve
+    f.restype = C.c_int
+    f(C.byref(P), C.byref(O), C.byref(R))
+    out = {k: arr[k] for k in ("cam_params", "rig_camera_pose", "rig_instance_pose", "points", "bias") if k in arr}
+    out.update({"reproj_err": arr["reproj_err"][: int(P.n_obs)], "iterations": R.iterations, "successful_steps": R.successful_steps,
+                "termination": R.termination, "initial_cost": R.initial_cost, "final_cost": R.final_cost,
+                "cost_history": np.array(R.cost_history[: min(R.iterations, 255) + 1])})
+    return out
+
+
+def bundle_reprojection(model: int, cam, inst, rcam, use_rig_camera: bool, pt, obs, sigma: float):
+    """one reprojection residual (2 or 3 values) and its Jacobian (nres x 31: camera 16 | rig instance 6 | rig camera 6 | point 3), by jets"""
+    cam16 = np.zeros(16)
+    cam16[: len(cam)] = cam
+    res, J = np.zeros(3), np.zeros(93)
+    f = lib().oracle_bundle_reprojection
+    f.restype = C.c_int
+    n = f(int(model), _p(cam16, C.c_double), _p(np.ascontiguousarray(inst, np.float64), C.c_double), _p(np.ascontiguousarray(rcam, np.float64), C.c_double),
+          int(use_rig_camera), _p(np.ascontiguousarray(pt, np.float64), C.c_double), _p(np.ascontiguousarray(obs, np.float64), C.c_double),
+          C.c_double(sigma), _p(res, C.c_double), _p(J, C.c_double))
+    return res[:n].copy(), J[: 31 * n].reshape(n, 31).copy()
 
 
 def ba_up(pose, up, sigma):

@@ -1,0 +1,106 @@
+"""CPU: the general bundle-adjustment oracle (oracle/bundle_general_oracle.cc, jets + full dense normal equations) against the older
+C oracle (oracle/ba_oracle.c, hand-written derivatives + Schur complement, itself pinned by the mpmath golden vectors) wherever
+their domains overlap, and basic recovery properties of the new residual families."""
+import numpy as np
+import pytest
+
+from opensfm_amd import synthetic
+
+
+def _as_general(pr):
+    """a flat problem of the streaming solver (perspective [k1 k2 focal], one shot per instance) in the general layout"""
+    nc, ns = len(pr["cam_params"]), len(pr["shot_pose"])
+    cam = np.zeros((nc, 16))
+    cam[:, :3] = pr["cam_params"]
+    prior = np.zeros((nc, 16))
+    prior[:, :3] = pr["cam_prior"]
+    sig = np.ones((nc, 16))
+    sig[:, :3] = pr["cam_sigma"]
+    g = {"cam_model": np.zeros(nc, np.int32), "cam_params": cam, "cam_prior": prior, "cam_sigma": sig, "cam_fixed": pr["cam_fixed"],
+         "rig_camera_pose": np.zeros((1, 6)), "rig_camera_fixed": np.ones(1, np.uint8), "rig_instance_pose": pr["shot_pose"],
+         "shot_rig_instance": np.arange(ns, dtype=np.int32), "shot_rig_camera": np.zeros(ns, np.int32), "shot_camera": pr["shot_camera"],
+         "points": pr["points"], "obs_shot": pr["obs_shot"], "obs_point": pr["obs_point"], "obs_xy": pr["obs_xy"], "obs_sigma": pr["obs_sigma"]}
+    if "shot_gps" in pr:
+        g["rig_instance_gps"] = pr["shot_gps"]
+        g["rig_instance_gps_sigma"] = np.repeat(np.asarray(pr["shot_gps_sigma"], float)[:, None], 3, 1)
+        g["rig_instance_bias_camera"] = pr["shot_camera"]
+    return g
+
+
+def test_general_oracle_equals_the_schur_oracle_on_its_domain(oracle_lib):
+    """same LM trajectory (costs to 1e-9 relative) as oracle/ba_oracle.c on a perspective scene with GPS priors: two independent
+    derivations (jets vs analytic) and two linear-algebra routes (full dense vs Schur + skyline Cholesky)"""
+    pr = synthetic.make_ba_scene(14, 160, 5, seed=4)
+    no_tol = dict(function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
+    a = oracle_lib.ba_solve(pr, max_iterations=6, **no_tol)
+    b = oracle_lib.bundle_general(_as_general(pr), max_iterations=6, **no_tol)
+    assert a["iterations"] == b["iterations"] == 6
+    assert np.allclose(a["cost_history"], b["cost_history"], rtol=1e-9)
+    assert np.allclose(a["shot_pose"], b["rig_instance_pose"], atol=1e-8)
+    assert np.allclose(a["cam_params"], b["cam_params"][:, :3], atol=1e-9)
+    assert np.allclose(a["reproj_err"], b["reproj_err"][:, :2], atol=1e-9)
+
+
+@pytest.mark.parametrize("model", list(synthetic.BUNDLE_TEST_CAMERAS))
+def test_jet_jacobians_equal_central_differences(oracle_lib, model):
+    """every block of the reprojection Jacobian of every camera model (with and without a rig camera) against finite differences of
+    the residual itself -- the jets are what the LM consumes"""
+    rng = np.random.default_rng(11)
+    mid = synthetic.MODEL_IDS[model]
+    cam = np.zeros(16)
+    par = synthetic.BUNDLE_TEST_CAMERAS[model]
+    cam[: len(par)] = par
+    inst = np.r_[rng.normal(0, 0.2, 3), rng.normal(0, 0.5, 3)]
+    rc = np.r_[rng.normal(0, 0.2, 3), rng.normal(0, 0.2, 3)]
+    X = np.array([0.4, -0.3, 6.0]) + rng.normal(0, 0.2, 3)
+    obs = np.array([0.03, -0.02])
+    for use_rc in (False, True):
+        r0, J = oracle_lib.bundle_reprojection(mid, cam, inst, rc, use_rc, X, obs, 0.004)
+        x0 = np.r_[cam, inst, rc, X]
+        for k in range(31):
+            if k < 16 and k >= len(par):
+                assert not J[:, k].any()
+                continue
+            h = 1e-6 * max(1.0, abs(x0[k]))
+            xp, xm = x0.copy(), x0.copy()
+            xp[k] += h
+            xm[k] -= h
+            rp, _ = oracle_lib.bundle_reprojection(mid, xp[:16], xp[16:22], xp[22:28], use_rc, xp[28:], obs, 0.004)
+            rm, _ = oracle_lib.bundle_reprojection(mid, xm[:16], xm[16:22], xm[22:28], use_rc, xm[28:], obs, 0.004)
+            fd = (rp - rm) / (2 * h)
+            assert np.allclose(J[:, k], fd, rtol=2e-5, atol=2e-5 * max(1.0, np.abs(J).max())), (model, use_rc, k, J[:, k], fd)
+        if not use_rc:
+            assert not J[:, 22:28].any()
+
+
+def test_projection_values_equal_the_golden_pinned_oracle(oracle_lib):
+    """the templated projections of the new oracle against oracle_ba_project_intrinsics (pinned by tests/golden/reprojection_golden.json)"""
+    rng = np.random.default_rng(2)
+    for model, par in synthetic.BUNDLE_TEST_CAMERAS.items():
+        if model == "spherical":
+            continue
+        cam = np.zeros(16)
+        cam[: len(par)] = par
+        for _ in range(5):
+            pose = np.r_[rng.normal(0, 0.2, 3), rng.normal(0, 0.5, 3)]
+            X = np.array([0.4, -0.3, 6.0]) + rng.normal(0, 0.3, 3)
+            obs = rng.normal(0, 0.05, 2)
+            got, J = oracle_lib.bundle_reprojection(synthetic.MODEL_IDS[model], cam, pose, np.zeros(6), False, X, obs, 0.004)
+            if model in ("perspective", "fisheye"):  # the [k1 k2 focal] models of the streaming solver's oracle
+                want = oracle_lib.ba_project(X, pose, cam[:3], obs, 0.004, model)[0]
+                assert np.allclose(got, want, rtol=1e-12, atol=1e-12)
+                continue
+            want, Jk = oracle_lib.ba_project_intrinsics(X, pose, np.asarray(par, float), obs, 0.004, model)
+            assert np.allclose(got, want, rtol=1e-12, atol=1e-12)
+            assert np.allclose(J[:, : len(par)], Jk, rtol=1e-9, atol=1e-9)
+
+
+def test_full_scene_recovers_ground_truth(oracle_lib):
+    """rigs + two camera models + biased GPS + control points + up vectors: the minimum is near the ground truth"""
+    pr = synthetic.make_bundle_scene(models=("perspective", "brown"), n_instances=8, n_points=90, seed=5)
+    r = oracle_lib.bundle_general(pr, max_iterations=40)
+    assert r["final_cost"] < 0.05 * r["initial_cost"]
+    inl = ~pr["is_outlier"]
+    assert np.sqrt((r["reproj_err"][inl, :2] ** 2).sum(1).mean()) < 6e-4
+    assert np.abs(r["rig_camera_pose"][1] - pr["gt_rig_camera"][1]).max() < 0.02
+    assert np.abs(r["bias"][:, 3:6] - pr["gt_bias"][:, 3:6]).max() < 0.1  # the bias absorbs the GPS offset
