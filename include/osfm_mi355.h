@@ -290,6 +290,9 @@ typedef struct {
   const double *obs_xy;            /* n_obs x 2 normalized image coordinates                                            */
   const double *obs_sigma;         /* n_obs                                                                             */
   double *reproj_err;              /* n_obs x 3 or NULL: out, residual with sigma 1 (third component: spherical only)   */
+  /* compass / inclinometer priors per shot (AddAbsolutePan / Tilt / Roll, absolute_motion_errors.h:40-137, Cauchy(1)):
+     angle in radians and its sd (<= 0: none); NULL = none at all */
+  const double *shot_pan, *shot_pan_sigma, *shot_tilt, *shot_tilt_sigma, *shot_roll, *shot_roll_sigma;
 } osfm_bundle_problem;
 
 int osfm_bundle_solve(osfm_ctx *ctx, osfm_bundle_problem *problem, const osfm_ba_options *options, osfm_ba_report *report);

@@ -56,6 +56,8 @@ class BundleProblem(C.Structure):
         ("point_prior", C.POINTER(C.c_double)), ("point_prior_sigma", C.POINTER(C.c_double)), ("point_prior_has_altitude", C.POINTER(C.c_uint8)),
         ("n_obs", C.c_int64), ("obs_shot", C.POINTER(C.c_int32)), ("obs_point", C.POINTER(C.c_int32)), ("obs_xy", C.POINTER(C.c_double)),
         ("obs_sigma", C.POINTER(C.c_double)), ("reproj_err", C.POINTER(C.c_double)),
+        ("shot_pan", C.POINTER(C.c_double)), ("shot_pan_sigma", C.POINTER(C.c_double)), ("shot_tilt", C.POINTER(C.c_double)),
+        ("shot_tilt_sigma", C.POINTER(C.c_double)), ("shot_roll", C.POINTER(C.c_double)), ("shot_roll_sigma", C.POINTER(C.c_double)),
     ]
 
 
@@ -75,6 +77,9 @@ BUNDLE_FIELDS = [
     ("point_prior_sigma", "float64", 3, False, False), ("point_prior_has_altitude", "uint8", None, False, False),
     ("obs_shot", "int32", None, True, False), ("obs_point", "int32", None, True, False), ("obs_xy", "float64", 2, True, False),
     ("obs_sigma", "float64", None, True, False),
+    ("shot_pan", "float64", None, False, False), ("shot_pan_sigma", "float64", None, False, False),
+    ("shot_tilt", "float64", None, False, False), ("shot_tilt_sigma", "float64", None, False, False),
+    ("shot_roll", "float64", None, False, False), ("shot_roll_sigma", "float64", None, False, False),
 ]
 _CT = {"int32": C.c_int32, "float64": C.c_double, "uint8": C.c_uint8}
 
@@ -106,6 +111,8 @@ def fill_bundle_problem(problem, struct_cls=BundleProblem):
                     ("rig_camera_fixed", P.n_rig_cameras), ("rig_instance_fixed", P.n_rig_instances), ("rig_instance_gps", P.n_rig_instances),
                     ("rig_instance_gps_sigma", P.n_rig_instances), ("rig_instance_bias_camera", P.n_rig_instances),
                     ("shot_rig_instance", P.n_shots), ("shot_rig_camera", P.n_shots), ("shot_up", P.n_shots), ("shot_up_sigma", P.n_shots),
+                    ("shot_pan", P.n_shots), ("shot_pan_sigma", P.n_shots), ("shot_tilt", P.n_shots), ("shot_tilt_sigma", P.n_shots),
+                    ("shot_roll", P.n_shots), ("shot_roll_sigma", P.n_shots),
                     ("point_fixed", P.n_points), ("point_prior", P.n_points), ("point_prior_sigma", P.n_points),
                     ("point_prior_has_altitude", P.n_points), ("obs_point", P.n_obs), ("obs_xy", P.n_obs), ("obs_sigma", P.n_obs)):
         if name in arrays and len(arrays[name]) != n:

@@ -300,89 +300,133 @@ def bundle_shot_poses_arrays(problem: Dict[str, np.ndarray], shot_ids, config: O
             "iterations": r["iterations"], "cost_history": r["cost_history"]}
 
 
-class _Point:
-    def __init__(self, pid, p):
-        self.id = pid
+class _BAPoint:
+    """``bundle::Point`` as ``get_point`` returns it: ``id``, ``p`` and ``reprojection_errors`` (shot id -> residual with sigma 1)"""
+
+    def __init__(self, point_id, p, errors):
+        self.id = point_id
         self.p = np.asarray(p, float)
-        self.reprojection_errors: Dict[str, np.ndarray] = {}
+        self.reprojection_errors = errors
 
 
-class _Pose:
-    """What ``get_rig_instance_pose`` returns in the reference is a ``pygeometry.Pose``; here a light
-    value object with the same two accessors the callers use."""
-
-    def __init__(self, rt):
-        self.rotation = np.asarray(rt[:3], float)  # angle-axis, camera -> world (bundle/data/pose.h:34-43)
-        self._origin = np.asarray(rt[3:6], float)
-
-    def get_origin(self):
-        return self._origin
+def _pose_c2w(pose) -> np.ndarray:
+    """bundle::Pose data [rx ry rz tx ty tz] (CAM_TO_WORLD, bundle/data/pose.h:34-43) of a pygeometry.Pose-like object"""
+    if hasattr(pose, "cam_to_world_parameters"):
+        return np.asarray(pose.cam_to_world_parameters(), float)
+    rot = np.asarray(pose.rotation, float).reshape(3)
+    return np.r_[-rot, np.asarray(pose.get_origin(), float).reshape(3)]
 
 
 class BundleAdjuster:
-    """Builder with the method names of ``pybundle.BundleAdjuster`` (``bundle/python/pybind.cc:45-117``)
-    for the subset ``BAHelpers::Bundle`` uses; string ids are turned into dense indices at ``run()``.
-
-    Cameras are given as ``(k1, k2, focal)`` triples of a PERSPECTIVE camera (the reference passes a
-    ``pygeometry.Camera``; any object with ``projection_type``, ``k1``, ``k2``, ``focal`` works)."""
+    """``pybundle.BundleAdjuster`` (``bundle/python/pybind.cc:45-117``, ``bundle_adjuster.h:178-300``): same method names, argument
+    order and meaning for everything ``BAHelpers::Bundle`` / ``BundleLocal`` / ``BundleShotPoses`` call, plus the absolute pan / tilt /
+    roll priors.  String ids become dense indices at ``run()``, which hands the problem to ``osfm_bundle_solve`` (every camera
+    model, rigs, biases, control points) -- or to the streaming ``osfm_ba_solve`` when the problem is in its domain (perspective /
+    fisheye cameras, one constant identity rig camera, one shot per instance, identity biases, no point priors).
+    Cameras / poses / similarities are any objects with the reference's attributes (``geometry_types`` has plain ones).
+    Not implemented (raise): relative motions / rotations, common positions, heatmaps, linear motion, reconstructions with shared
+    scales, depth priors, covariances -- none of which ``BAHelpers`` uses."""
 
     def __init__(self):
         self._cams: Dict[str, Dict[str, Any]] = {}
+        self._bias: Dict[str, Any] = {}
+        self._rig_cameras: Dict[str, Dict[str, Any]] = {}
+        self._instances: Dict[str, Dict[str, Any]] = {}
         self._shots: Dict[str, Dict[str, Any]] = {}
         self._points: Dict[str, Dict[str, Any]] = {}
         self._obs: List[Any] = []
-        self._loss = ("SoftLOneLoss", 1.0)
-        self._sd = {"focal": 0.01, "k1": 0.01, "k2": 0.01}
-        self._max_iter = 100
+        self._loss = ("CauchyLoss", 1.0)  # the constructor's default, bundle_adjuster.cc:25
+        self._sd = dict(focal=1.0, aspect_ratio=1.0, c=1.0, k1=1.0, k2=1.0, p1=1.0, p2=1.0, k3=1.0, k4=1.0)
+        self._rig_sd = (1.0, 1.0)  # translation, rotation (bundle_adjuster.h:350-351)
+        self._max_iter = 500
         self._report: Optional[Dict[str, Any]] = None
+        self.force_general = False  # tests: never take the streaming solver
 
-    @staticmethod
-    def _cam_values(cam):
-        if hasattr(cam, "projection_type"):
-            if cam.projection_type != "perspective":
-                raise NotImplementedError("only PERSPECTIVE cameras are on the GPU path")
-            return np.array([cam.k1, cam.k2, cam.focal], float)
-        return np.asarray(cam, float).reshape(3)
-
+    # ---- variables ----
     def add_camera(self, cam_id, camera, camera_prior, constant):
-        self._cams[cam_id] = {"v": self._cam_values(camera), "prior": self._cam_values(camera_prior), "fixed": bool(constant)}
+        self._cams[cam_id] = {"camera": camera, "prior": camera_prior, "fixed": bool(constant)}
+        self._bias.setdefault(cam_id, None)  # identity, constant (bundle_adjuster.cc:98-106)
 
-    def add_rig_instance(self, rig_instance_id, rotation, origin, shot_cameras: Dict[str, str], fixed=False):
-        """One shot per rig instance (identity rig camera, the plain-reconstruction case)."""
-        if len(shot_cameras) != 1:
-            raise NotImplementedError("multi-camera rigs are not on the GPU path")
-        (shot_id, cam_id), = shot_cameras.items()
-        self._shots[shot_id] = {"rt": np.concatenate([np.asarray(rotation, float), np.asarray(origin, float)]),
-                                "camera": cam_id, "fixed": bool(fixed), "gps": None, "gps_sd": 0.0,
-                                "instance": rig_instance_id}
+    def set_camera_bias(self, camera_id, bias):
+        if camera_id not in self._cams:
+            raise RuntimeError("Camera " + str(camera_id) + " doesn't exist.")
+        self._bias[camera_id] = bias  # a fresh Similarity data block: free (SetCameraBias, bundle_adjuster.cc:109-116)
+
+    def add_rig_camera(self, rig_camera_id, pose, pose_prior, fixed):
+        if rig_camera_id in self._rig_cameras:
+            raise RuntimeError("Rig model " + str(rig_camera_id) + " already exist.")
+        self._rig_cameras[rig_camera_id] = {"v": _pose_c2w(pose), "prior": _pose_c2w(pose_prior), "fixed": bool(fixed)}
+
+    def add_rig_instance(self, rig_instance_id, rig_instance_pose, shot_cameras: Dict[str, str], shot_rig_cameras: Dict[str, str], fixed):
+        self._instances[rig_instance_id] = {"v": _pose_c2w(rig_instance_pose), "fixed": bool(fixed), "gps": None, "gps_sd": None,
+                                            "shots": list(shot_cameras)}
+        for shot_id, cam_id in shot_cameras.items():
+            rc_id = shot_rig_cameras[shot_id]
+            if cam_id not in self._cams:
+                raise RuntimeError("Camera " + str(cam_id) + " doesn't exist.")
+            if rc_id not in self._rig_cameras:
+                raise RuntimeError("Rig camera " + str(rc_id) + " doesn't exist.")
+            self._shots[shot_id] = {"instance": rig_instance_id, "camera": cam_id, "rig_camera": rc_id}
 
     def add_rig_instance_position_prior(self, instance_id, position, std_deviation, scale_group=""):
-        for sh in self._shots.values():
-            if sh["instance"] == instance_id:
-                sh["gps"] = np.asarray(position, float)
-                sh["gps_sd"] = float(np.mean(std_deviation))
-
-    def add_absolute_up_vector(self, shot_id, up_vector, std_deviation):
-        """``BundleAdjuster::AddAbsoluteUpVector`` (bundle_adjuster.cc:300-308)."""
-        self._shots[shot_id]["up"] = np.asarray(up_vector, float)
-        self._shots[shot_id]["up_sd"] = float(std_deviation)
+        if instance_id not in self._instances:
+            raise RuntimeError("Rig instance " + str(instance_id) + " doesn't exist.")
+        self._instances[instance_id]["gps"] = np.asarray(position, float).reshape(3)
+        self._instances[instance_id]["gps_sd"] = np.broadcast_to(np.asarray(std_deviation, float), (3,)).copy()
 
     def add_point(self, point_id, position, constant):
-        self._points[point_id] = {"p": np.asarray(position, float), "fixed": bool(constant)}
+        self._points[point_id] = {"p": np.asarray(position, float).reshape(3).copy(), "fixed": bool(constant), "prior": None}
+
+    def add_point_prior(self, point_id, position, std_deviation, has_altitude_prior):
+        if point_id not in self._points:
+            raise RuntimeError("Point " + str(point_id) + " doesn't exist.")
+        self._points[point_id]["prior"] = (np.asarray(position, float).reshape(3), np.asarray(std_deviation, float).reshape(3), bool(has_altitude_prior))
 
     def has_point(self, point_id):
         return point_id in self._points
 
     def add_point_projection_observation(self, shot, point, observation, std_deviation, depth_prior=None):
         if depth_prior is not None:
-            raise NotImplementedError("depth priors are not on the GPU path")
+            raise NotImplementedError("depth priors (RelativeDepthError) are not on the GPU path")
+        if shot not in self._shots or point not in self._points:
+            raise IndexError("unknown shot or point")  # std::map::at
         self._obs.append((shot, point, float(observation[0]), float(observation[1]), float(std_deviation)))
 
+    def _shot_prior(self, key, shot_id, value, std_deviation):
+        self._shots[shot_id][key] = (value, float(std_deviation))
+
+    def add_absolute_up_vector(self, shot_id, up_vector, std_deviation):
+        """``BundleAdjuster::AddAbsoluteUpVector`` (bundle_adjuster.cc:300-308)."""
+        self._shot_prior("up", shot_id, np.asarray(up_vector, float).reshape(3), std_deviation)
+
+    def add_absolute_pan(self, shot_id, angle, std_deviation):
+        self._shot_prior("pan", shot_id, float(angle), std_deviation)
+
+    def add_absolute_tilt(self, shot_id, angle, std_deviation):
+        self._shot_prior("tilt", shot_id, float(angle), std_deviation)
+
+    def add_absolute_roll(self, shot_id, angle, std_deviation):
+        self._shot_prior("roll", shot_id, float(angle), std_deviation)
+
+    # ---- the rest of the reference's builder surface: not on this path ----
+    def _unsupported(self, *a, **k):
+        raise NotImplementedError("this residual family is not implemented on the GPU path (BAHelpers does not use it)")
+
+    add_relative_motion = add_relative_rotation = add_common_position = add_heatmap = add_absolute_position_heatmap = _unsupported
+    add_linear_motion = add_reconstruction = add_reconstruction_instance = set_scale_sharing = set_gauge_fix_shots = _unsupported
+
+    # ---- minimisation setup ----
     def set_point_projection_loss_function(self, name, threshold):
         self._loss = (name, float(threshold))
 
+    def set_relative_motion_loss_function(self, name, threshold):
+        pass  # no relative motion residuals on this path
+
     def set_internal_parameters_prior_sd(self, focal_sd, aspect_ratio_sd, c_sd, k1_sd, k2_sd, p1_sd, p2_sd, k3_sd, k4_sd):
-        self._sd = {"focal": focal_sd, "k1": k1_sd, "k2": k2_sd}
+        self._sd = dict(focal=focal_sd, aspect_ratio=aspect_ratio_sd, c=c_sd, k1=k1_sd, k2=k2_sd, p1=p1_sd, p2=p2_sd, k3=k3_sd, k4=k4_sd)
+
+    def set_rig_parameters_prior_sd(self, rig_translation_sd, rig_rotation_sd):
+        self._rig_sd = (float(rig_translation_sd), float(rig_rotation_sd))
 
     def set_max_num_iterations(self, n):
         self._max_iter = int(n)
@@ -391,7 +435,7 @@ class BundleAdjuster:
         pass
 
     def set_linear_solver_type(self, t):
-        if t not in ("SPARSE_SCHUR", "DENSE_SCHUR", "ITERATIVE_SCHUR"):
+        if t not in ("SPARSE_SCHUR", "DENSE_SCHUR", "ITERATIVE_SCHUR", "DENSE_QR", "SPARSE_NORMAL_CHOLESKY"):
             raise RuntimeError("Linear solver type " + str(t) + " doesn't exist.")  # bundle_adjuster.cc:1107
 
     def set_use_analytic_derivatives(self, v):
@@ -400,63 +444,192 @@ class BundleAdjuster:
     def set_compute_reprojection_errors(self, v):
         pass
 
-    def run(self):
-        cam_ids, shot_ids, pt_ids = list(self._cams), list(self._shots), list(self._points)
-        ci = {k: i for i, k in enumerate(cam_ids)}
-        si = {k: i for i, k in enumerate(shot_ids)}
-        pi = {k: i for i, k in enumerate(pt_ids)}
-        gps = np.zeros((len(shot_ids), 3))
-        gps_sd = np.zeros(len(shot_ids))
-        for k, s in self._shots.items():
-            if s["gps"] is not None:
-                gps[si[k]] = s["gps"]
-                gps_sd[si[k]] = s["gps_sd"]
-        prob = {
-            "cam_params": np.array([self._cams[k]["v"] for k in cam_ids]),
-            "cam_prior": np.array([self._cams[k]["prior"] for k in cam_ids]),
-            "cam_sigma": np.tile([self._sd["k1"], self._sd["k2"], self._sd["focal"]], (len(cam_ids), 1)).astype(float),
+    def set_compute_covariances(self, v):
+        if v:
+            raise NotImplementedError("covariance estimation is not on the GPU path")
+
+    def set_adjust_absolute_position_std(self, v):
+        if v:
+            raise NotImplementedError("adjusting the GPS standard deviations is not on the GPU path")
+
+    def get_covariance_estimation_valid(self):
+        return False
+
+    # ---- flattening ----
+    def _camera_sigma(self, camera) -> np.ndarray:
+        """GetDefaultCameraSigma (bundle_adjuster.cc:47-69): parameter types without an entry (k4 .. k6, s0 .. s3) get sigma 0, i.e. the
+        prior pins them -- exactly what the reference's std::unordered_map::operator[] default does"""
+        from .geometry_types import CAMERA_PARAMETERS
+
+        key = {"focal": "focal", "aspect_ratio": "aspect_ratio", "cx": "c", "cy": "c", "k1": "k1", "k2": "k2", "k3": "k3", "p1": "p1", "p2": "p2"}
+        names = CAMERA_PARAMETERS["spherical" if camera.projection_type == "equirectangular" else camera.projection_type]
+        out = np.ones(16)
+        for k, n in enumerate(names):
+            out[k] = 1.0 if n == "transition" else (self._sd[key[n]] if n in key else 0.0)
+        return out
+
+    def _problem(self) -> Dict[str, Any]:
+        from .geometry_types import CAMERA_MODEL_IDS, camera_parameter_values
+
+        cam_ids, rc_ids, inst_ids = list(self._cams), list(self._rig_cameras), list(self._instances)
+        shot_ids, pt_ids = list(self._shots), list(self._points)
+        ci, ri, ii = ({k: n for n, k in enumerate(x)} for x in (cam_ids, rc_ids, inst_ids))
+        si, pi = ({k: n for n, k in enumerate(x)} for x in (shot_ids, pt_ids))
+        self._index = dict(cam=cam_ids, rc=rc_ids, inst=inst_ids, shot=shot_ids, pt=pt_ids)
+        NC, NR, NI, S, NP = len(cam_ids), len(rc_ids), len(inst_ids), len(shot_ids), len(pt_ids)
+        bias = np.tile([0, 0, 0, 0, 0, 0, 1.0], (NC, 1))
+        bias_fixed = np.ones(NC, np.uint8)
+        for k, b in self._bias.items():
+            if b is not None:
+                bias[ci[k]] = np.r_[np.asarray(b.rotation, float), np.asarray(b.translation, float), float(b.scale)]
+                bias_fixed[ci[k]] = 0
+        gps, gps_sd, bias_cam = np.zeros((NI, 3)), np.zeros((NI, 3)), np.zeros(NI, np.int32)
+        for k, inst in self._instances.items():
+            if inst["gps"] is not None:
+                gps[ii[k]], gps_sd[ii[k]] = inst["gps"], inst["gps_sd"]
+                if not inst["shots"]:
+                    raise RuntimeError("Reference camera of RigInstance " + str(k) + " doesn't have associated Bias")
+                # rig_instance.shot_cameras.begin(): the smallest shot id of the std::map / first of the unordered_map
+                bias_cam[ii[k]] = ci[self._shots[sorted(inst["shots"])[0]]["camera"]]
+        tr_sd, rot_sd = self._rig_sd
+        prob: Dict[str, Any] = {
+            "cam_model": np.array([CAMERA_MODEL_IDS[self._cams[k]["camera"].projection_type] for k in cam_ids], np.int32),
+            "cam_params": np.array([camera_parameter_values(self._cams[k]["camera"]) for k in cam_ids]).reshape(NC, 16),
+            "cam_prior": np.array([camera_parameter_values(self._cams[k]["prior"]) for k in cam_ids]).reshape(NC, 16),
+            "cam_sigma": np.array([self._camera_sigma(self._cams[k]["camera"]) for k in cam_ids]).reshape(NC, 16),
             "cam_fixed": np.array([self._cams[k]["fixed"] for k in cam_ids], np.uint8),
-            "shot_pose": np.array([self._shots[k]["rt"] for k in shot_ids]),
+            "bias": bias, "bias_fixed": bias_fixed,
+            "rig_camera_pose": np.array([self._rig_cameras[k]["v"] for k in rc_ids]).reshape(NR, 6),
+            "rig_camera_prior": np.array([self._rig_cameras[k]["prior"] for k in rc_ids]).reshape(NR, 6),
+            "rig_camera_sigma": np.tile([rot_sd] * 3 + [tr_sd] * 3, (NR, 1)).astype(float),
+            "rig_camera_fixed": np.array([self._rig_cameras[k]["fixed"] for k in rc_ids], np.uint8),
+            "rig_instance_pose": np.array([self._instances[k]["v"] for k in inst_ids]).reshape(NI, 6),
+            "rig_instance_fixed": np.array([self._instances[k]["fixed"] for k in inst_ids], np.uint8),
+            "shot_rig_instance": np.array([ii[self._shots[k]["instance"]] for k in shot_ids], np.int32),
+            "shot_rig_camera": np.array([ri[self._shots[k]["rig_camera"]] for k in shot_ids], np.int32),
             "shot_camera": np.array([ci[self._shots[k]["camera"]] for k in shot_ids], np.int32),
-            "shot_fixed": np.array([self._shots[k]["fixed"] for k in shot_ids], np.uint8),
-            "points": np.array([self._points[k]["p"] for k in pt_ids]),
+            "points": np.array([self._points[k]["p"] for k in pt_ids]).reshape(NP, 3),
             "point_fixed": np.array([self._points[k]["fixed"] for k in pt_ids], np.uint8),
-            "obs_shot": np.array([si[o[0]] for o in self._obs], np.int32),
-            "obs_point": np.array([pi[o[1]] for o in self._obs], np.int32),
-            "obs_xy": np.array([[o[2], o[3]] for o in self._obs]),
-            "obs_sigma": np.array([o[4] for o in self._obs]),
+            "obs_shot": np.array([si[o[0]] for o in self._obs], np.int32), "obs_point": np.array([pi[o[1]] for o in self._obs], np.int32),
+            "obs_xy": np.array([[o[2], o[3]] for o in self._obs]).reshape(-1, 2), "obs_sigma": np.array([o[4] for o in self._obs]),
         }
         if gps_sd.max() > 0:
-            prob["shot_gps"], prob["shot_gps_sigma"] = gps, gps_sd
-        if any("up" in s for s in self._shots.values()):
-            prob["shot_up"] = np.array([self._shots[k].get("up", np.zeros(3)) for k in shot_ids])
-            prob["shot_up_sigma"] = np.array([self._shots[k].get("up_sd", 0.0) for k in shot_ids])
+            prob.update(rig_instance_gps=gps, rig_instance_gps_sigma=gps_sd, rig_instance_bias_camera=bias_cam)
+        if any(p["prior"] is not None for p in self._points.values()):
+            pp, ps, alt = np.zeros((NP, 3)), np.zeros((NP, 3)), np.ones(NP, np.uint8)
+            for k, p in self._points.items():
+                if p["prior"] is not None:
+                    pp[pi[k]], ps[pi[k]], alt[pi[k]] = p["prior"][0], np.maximum(p["prior"][1], 1e-300), p["prior"][2]
+            prob.update(point_prior=pp, point_prior_sigma=ps, point_prior_has_altitude=alt)
+        if any("up" in sh for sh in self._shots.values()):
+            prob["shot_up"] = np.array([self._shots[k]["up"][0] if "up" in self._shots[k] else np.zeros(3) for k in shot_ids]).reshape(S, 3)
+            prob["shot_up_sigma"] = np.array([self._shots[k]["up"][1] if "up" in self._shots[k] else 0.0 for k in shot_ids])
+        for key in ("pan", "tilt", "roll"):
+            if any(key in sh for sh in self._shots.values()):
+                prob["shot_" + key] = np.array([self._shots[k][key][0] if key in self._shots[k] else 0.0 for k in shot_ids])
+                prob["shot_" + key + "_sigma"] = np.array([self._shots[k][key][1] if key in self._shots[k] else 0.0 for k in shot_ids])
+        return prob
+
+    @staticmethod
+    def _streaming_form(prob: Dict[str, Any]) -> Optional[Dict[str, Any]]:
+        """the same problem in the layout of ``osfm_ba_solve`` when it lies in that solver's domain, else None"""
+        NI, S = len(prob["rig_instance_pose"]), len(prob["shot_camera"])
+        if (S != NI or len(prob["rig_camera_pose"]) != 1 or not prob["rig_camera_fixed"][0] or prob["rig_camera_pose"].any()
+                or (prob["cam_model"] > 1).any() or not prob["bias_fixed"].all() or (prob["bias"] != [0, 0, 0, 0, 0, 0, 1.0]).any()
+                or "point_prior" in prob or any(k in prob for k in ("shot_pan", "shot_tilt", "shot_roll"))
+                or not np.array_equal(np.sort(prob["shot_rig_instance"]), np.arange(NI)) or len(prob["obs_shot"]) == 0):
+            return None
+        if "rig_instance_gps_sigma" in prob:
+            sd = prob["rig_instance_gps_sigma"]
+            if not (np.allclose(sd[:, 0], sd[:, 1]) and np.allclose(sd[:, 0], sd[:, 2])):
+                return None  # the streaming solver takes one sd per position prior
+        order = np.argsort(prob["shot_rig_instance"])  # shot s of the streaming problem = the shot of instance s
+        inv = np.empty(S, np.int64)
+        inv[order] = np.arange(S)
+        out = {"cam_params": prob["cam_params"][:, :3], "cam_prior": prob["cam_prior"][:, :3], "cam_sigma": prob["cam_sigma"][:, :3],
+               "cam_fixed": prob["cam_fixed"], "cam_model": prob["cam_model"], "shot_pose": prob["rig_instance_pose"],
+               "shot_camera": prob["shot_camera"][order], "shot_fixed": prob.get("rig_instance_fixed", np.zeros(NI, np.uint8)), "points": prob["points"],
+               "point_fixed": prob.get("point_fixed", np.zeros(len(prob["points"]), np.uint8)), "obs_shot": inv[prob["obs_shot"]].astype(np.int32), "obs_point": prob["obs_point"],
+               "obs_xy": prob["obs_xy"], "obs_sigma": prob["obs_sigma"]}
+        if "rig_instance_gps" in prob:
+            out["shot_gps"], out["shot_gps_sigma"] = prob["rig_instance_gps"], prob["rig_instance_gps_sigma"][:, 0]
+        if "shot_up" in prob:
+            out["shot_up"], out["shot_up_sigma"] = prob["shot_up"][order], prob["shot_up_sigma"][order]
+        return out
+
+    def run(self):
+        from .geometry_types import set_camera_parameter_values
+
+        if not self._cams or not self._rig_cameras or not self._instances or not self._shots:
+            raise RuntimeError("BundleAdjuster.run: nothing to adjust")
+        prob = self._problem()
         cfg = {"loss_function": self._loss[0], "loss_function_threshold": self._loss[1], "bundle_max_iterations": self._max_iter}
-        r = bundle_arrays(prob, cfg)
-        for k in cam_ids:
-            self._cams[k]["v"] = r["cam_params"][ci[k]]
-        for k in shot_ids:
-            self._shots[k]["rt"] = r["shot_pose"][si[k]]
-        for k in pt_ids:
-            self._points[k]["p"] = r["points"][pi[k]]
+        stream = None if self.force_general else self._streaming_form(prob)
+        if stream is not None:
+            r = bundle_arrays(stream, dict(cfg, bundle_use_gps=True))
+            cam = prob["cam_params"].copy()
+            cam[:, :3] = r["cam_params"]
+            res = {"cam_params": cam, "bias": prob["bias"], "rig_camera_pose": prob["rig_camera_pose"], "rig_instance_pose": r["shot_pose"],
+                   "points": r["points"], "reproj_err": np.c_[r["reproj_err"], np.zeros(len(r["reproj_err"]))]}
+            self.solver = "osfm_ba_solve"
+        else:
+            r = bundle_general_arrays(prob, cfg)
+            res = r
+            self.solver = "osfm_bundle_solve"
+        ix = self._index
+        for n, k in enumerate(ix["cam"]):
+            cam = self._cams[k]["camera"]
+            cam = cam.copy() if hasattr(cam, "copy") else __import__("copy").deepcopy(cam)
+            set_camera_parameter_values(cam, res["cam_params"][n])
+            self._cams[k]["result"] = cam
+            self._cams[k]["bias_result"] = res["bias"][n]
+        for n, k in enumerate(ix["rc"]):
+            self._rig_cameras[k]["v"] = np.asarray(res["rig_camera_pose"][n])
+        for n, k in enumerate(ix["inst"]):
+            self._instances[k]["v"] = np.asarray(res["rig_instance_pose"][n])
+        for n, k in enumerate(ix["pt"]):
+            self._points[k]["p"] = np.asarray(res["points"][n])
             self._points[k]["errors"] = {}
-        for (shot, point, *_), e in zip(self._obs, r["reproj_err"]):
-            self._points[point]["errors"][shot] = e
+        spherical = {k for k in ix["cam"] if self._cams[k]["camera"].projection_type in ("spherical", "equirectangular")}
+        for (shot, point, *_), e in zip(self._obs, res["reproj_err"]):
+            self._points[point]["errors"][shot] = np.asarray(e if self._shots[shot]["camera"] in spherical else e[:2])
         self._report = r
 
+    # ---- getters ----
     def get_camera(self, cam_id):
-        return self._cams[cam_id]["v"]
+        c = self._cams[cam_id]
+        return c.get("result", c["camera"])
+
+    def get_bias(self, cam_id):
+        from .geometry_types import Similarity
+
+        b = self._cams[cam_id].get("bias_result")
+        if b is None:
+            return self._bias[cam_id] or Similarity()
+        return Similarity(b[:3], b[3:6], b[6])
+
+    def _pose_object(self, v):
+        from .geometry_types import Pose
+
+        return Pose.from_cam_to_world(v[:3], v[3:6])
+
+    def get_rig_camera_pose(self, rig_camera_id):
+        return self._pose_object(self._rig_cameras[rig_camera_id]["v"])
 
     def get_rig_instance_pose(self, rig_instance_id):
-        for s in self._shots.values():
-            if s["instance"] == rig_instance_id:
-                return _Pose(s["rt"])
-        raise KeyError(rig_instance_id)
+        return self._pose_object(self._instances[rig_instance_id]["v"])
 
     def get_point(self, point_id):
-        p = _Point(point_id, self._points[point_id]["p"])
-        p.reprojection_errors = self._points[point_id].get("errors", {})
-        return p
+        return _BAPoint(point_id, self._points[point_id]["p"], self._points[point_id].get("errors", {}))
+
+    def get_projections_count(self):
+        return len(self._obs)
+
+    def get_relative_motions_count(self):
+        return 0
+
+    def get_rig_instances(self):
+        return {k: self.get_rig_instance_pose(k) for k in self._instances}
 
     def brief_report(self):
         return self._report["brief_report"] if self._report else ""

@@ -49,6 +49,7 @@ struct GDev {
   const double *gps, *gps_sigma;              // NI x 3 each, or null
   const int *inst_bias_cam;
   const double *up, *up_sigma;                // S x 3, S, or null
+  const double *pan, *pan_sigma, *tilt, *tilt_sigma, *roll, *roll_sigma;  // S each, or null
   const double *pt_prior, *pt_prior_sigma;    // P x 3 each, or null
   const unsigned char *pt_prior_alt;
   // reduced index of the first parameter of every block, -1 when the block is constant
@@ -319,6 +320,23 @@ __device__ __forceinline__ Jet<N> jatan2(const Jet<N> &y, const Jet<N> &x) {
   return r;
 }
 template <int N>
+__device__ __forceinline__ Jet<N> jasin(const Jet<N> &a) {
+  Jet<N> r;
+  r.v = asin(a.v);
+  const double k = 1.0 / sqrt(1.0 - a.v * a.v);
+  for (int i = 0; i < N; i++) r.d[i] = a.d[i] * k;
+  return r;
+}
+// DiffBetweenAngles (error_utils.h:88-97)
+template <int N>
+__device__ __forceinline__ Jet<N> jdiff_angles(const Jet<N> &a, double b) {
+  Jet<N> dd = a;
+  dd.v -= b;
+  if (dd.v > M_PI) dd.v -= 2 * M_PI;
+  else if (dd.v < -M_PI) dd.v += 2 * M_PI;
+  return dd;
+}
+template <int N>
 __device__ __forceinline__ Jet<N> jlog(const Jet<N> &a) {
   Jet<N> r;
   r.v = log(a.v);
@@ -487,6 +505,54 @@ __global__ void g_prior_kernel(GDev d, const double *cam, const double *bias, co
       loss_eval(OSFM_LOSS_CAUCHY, 1.0, sq, rho, rho1);
       cost += 0.5 * rho;
       finish(r, 3, sqrt(rho1), d.inst_idx[i], 6, d.rc_idx[q], 6);
+    }
+  }
+  else if (t < d.NC + d.NR + d.NI + 4 * d.S) {  // ---- absolute pan / tilt / roll of a shot, CauchyLoss(1) each ----
+    const int u = t - d.NC - d.NR - d.NI - d.S, which = u / d.S, s = u % d.S;
+    const double *ang = which == 0 ? d.pan : (which == 1 ? d.tilt : d.roll), *sg = which == 0 ? d.pan_sigma : (which == 1 ? d.tilt_sigma : d.roll_sigma);
+    if (ang && sg && sg[s] > 0) {
+      const int i = d.shot_inst[s], q = d.shot_rc[s];
+      constexpr int N = 12;
+      Jet<N> ri[3], rr[3], R[3], r[1];
+      for (int k = 0; k < 3; k++) {
+        ri[k] = jv<N>(instp[6 * i + k], k);
+        rr[k] = jv<N>(rcp[6 * q + k], 6 + k);
+      }
+      j_mult_rotations(ri, rr, R);
+      const Jet<N> ex[3] = {jc<N>(1.0), jc<N>(0.0), jc<N>(0.0)}, ez[3] = {jc<N>(0.0), jc<N>(0.0), jc<N>(1.0)};
+      Jet<N> zw[3];
+      j_rotate(R, ez, zw);
+      const double is = 1.0 / sg[s];
+      bool zero = false;
+      if (which == 0) {  // PanAngleError
+        if (fabs(zw[0].v) < 1e-8 && fabs(zw[1].v) < 1e-8) zero = true;
+        else r[0] = jdiff_angles(jatan2(zw[0], zw[1]), ang[s]) * is;
+      } else if (which == 1) {  // TiltAngleError
+        const Jet<N> l = jsqrt(zw[0] * zw[0] + zw[1] * zw[1]);
+        r[0] = jdiff_angles(jc<N>(0.0) - jatan2(zw[2], l), ang[s]) * is;
+      } else {  // RollAngleError
+        Jet<N> xw[3];
+        j_rotate(R, ex, xw);
+        Jet<N> a0 = zw[1], a1 = jc<N>(0.0) - zw[0];
+        const Jet<N> la = jsqrt(a0 * a0 + a1 * a1);
+        if (la.v < 1e-5) {
+          zero = true;
+        } else {
+          a0 = a0 / la;
+          a1 = a1 / la;
+          // b = Rt_ex x a with a = (a0, a1, 0)
+          const Jet<N> b0 = jc<N>(0.0) - xw[2] * a1, b1 = xw[2] * a0, b2 = xw[0] * a1 - xw[1] * a0;
+          const Jet<N> sin_roll = zw[0] * b0 + zw[1] * b1 + zw[2] * b2;
+          if (sin_roll.v <= -(1.0 - 1e-5)) zero = true;
+          else r[0] = jdiff_angles(jasin(sin_roll), ang[s]) * is;
+        }
+      }
+      if (!zero) {
+        double rho, rho1;
+        loss_eval(OSFM_LOSS_CAUCHY, 1.0, r[0].v * r[0].v, rho, rho1);
+        cost += 0.5 * rho;
+        finish(r, 1, sqrt(rho1), d.inst_idx[i], 6, d.rc_idx[q], 6);
+      }
     }
   }
   block_accumulate(cost, d.scal);
@@ -909,6 +975,9 @@ extern "C" int osfm_bundle_solve(osfm_ctx *ctx, osfm_bundle_problem *P, const os
     d.up = A.upload(P->shot_up, (size_t)S * 3, st);
     d.up_sigma = A.upload(P->shot_up_sigma, (size_t)S, st);
   }
+  if (P->shot_pan && P->shot_pan_sigma) { d.pan = A.upload(P->shot_pan, (size_t)S, st); d.pan_sigma = A.upload(P->shot_pan_sigma, (size_t)S, st); }
+  if (P->shot_tilt && P->shot_tilt_sigma) { d.tilt = A.upload(P->shot_tilt, (size_t)S, st); d.tilt_sigma = A.upload(P->shot_tilt_sigma, (size_t)S, st); }
+  if (P->shot_roll && P->shot_roll_sigma) { d.roll = A.upload(P->shot_roll, (size_t)S, st); d.roll_sigma = A.upload(P->shot_roll_sigma, (size_t)S, st); }
   if (P->point_prior && P->point_prior_sigma && NP > 0) {
     d.pt_prior = A.upload(P->point_prior, (size_t)NP * 3, st);
     d.pt_prior_sigma = A.upload(P->point_prior_sigma, (size_t)NP * 3, st);
@@ -952,7 +1021,7 @@ extern "C" int osfm_bundle_solve(osfm_ctx *ctx, osfm_bundle_problem *P, const os
   } blas_guard{blas};
   rocblas_set_stream(blas, st);
 
-  const int nprior = NC + NR + NI + S;
+  const int nprior = NC + NR + NI + 4 * S;
   std::vector<double> hs(16);
   // cost at (cam, bias, rc, inst, pts); jac: also fills the rows and the normal equations
   auto evaluate = [&](const double *cam, const double *bs, const double *rc, const double *inst, const double *pts, bool jac, double *cost) -> int {

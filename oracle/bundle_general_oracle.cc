@@ -66,6 +66,7 @@ JOP operator/(double c, const Jet<N>& a) { return Jet<N>(c) / a; }
 JOP sqrt(const Jet<N>& a) { Jet<N> r; r.v = std::sqrt(a.v); const double h = 0.5 / r.v; for (int i = 0; i < N; i++) r.d[i] = a.d[i] * h; return r; }
 JOP sin(const Jet<N>& a) { Jet<N> r; r.v = std::sin(a.v); const double c = std::cos(a.v); for (int i = 0; i < N; i++) r.d[i] = a.d[i] * c; return r; }
 JOP cos(const Jet<N>& a) { Jet<N> r; r.v = std::cos(a.v); const double s = -std::sin(a.v); for (int i = 0; i < N; i++) r.d[i] = a.d[i] * s; return r; }
+JOP asin(const Jet<N>& a) { Jet<N> r; r.v = std::asin(a.v); const double k = 1.0 / std::sqrt(1.0 - a.v * a.v); for (int i = 0; i < N; i++) r.d[i] = a.d[i] * k; return r; }
 JOP log(const Jet<N>& a) { Jet<N> r; r.v = std::log(a.v); const double ia = 1.0 / a.v; for (int i = 0; i < N; i++) r.d[i] = a.d[i] * ia; return r; }
 JOP atan2(const Jet<N>& y, const Jet<N>& x) { Jet<N> r; r.v = std::atan2(y.v, x.v); const double den = 1.0 / (x.v * x.v + y.v * y.v); for (int i = 0; i < N; i++) r.d[i] = (x.v * y.d[i] - y.v * x.d[i]) * den; return r; }
 template <int N> inline bool operator<(const Jet<N>& a, double c) { return a.v < c; }
@@ -255,6 +256,7 @@ struct Problem {  // mirrors osfm_bundle_problem (include/osfm_mi355.h)
   const double* obs_xy;
   const double* obs_sigma;
   double* reproj_err;
+  const double *shot_pan, *shot_pan_sigma, *shot_tilt, *shot_tilt_sigma, *shot_roll, *shot_roll_sigma;
 };
 struct Options {  // mirrors osfm_ba_options
   int32_t loss;
@@ -496,6 +498,63 @@ double evaluate(const Problem& P, const Options& O, const Layout& L, const State
       cost += 0.5 * rho;
       add_block<12>(A, r, 3, std::sqrt(rho1), idx);
     }
+  // ---- absolute pan / tilt / roll (absolute_motion_errors.h:40-137), CauchyLoss(1) each (bundle_adjuster.cc:972-1022) ----
+  for (int which = 0; which < 3; which++) {
+    const double* ang = which == 0 ? P.shot_pan : (which == 1 ? P.shot_tilt : P.shot_roll);
+    const double* sg = which == 0 ? P.shot_pan_sigma : (which == 1 ? P.shot_tilt_sigma : P.shot_roll_sigma);
+    if (!ang || !sg) continue;
+    for (int s = 0; s < P.n_shots; s++) {
+      if (!(sg[s] > 0)) continue;
+      const int i = P.shot_rig_instance[s], q = P.shot_rig_camera[s];
+      typedef Jet<12> T;
+      T ri[3], rr[3], R[3], zw[3], xw[3], r[1];
+      int idx[12];
+      for (int k = 0; k < 3; k++) {
+        ri[k] = T(X.inst[6 * i + k], k);
+        rr[k] = T(X.rc[6 * q + k], 6 + k);
+      }
+      for (int k = 0; k < 6; k++) {
+        idx[k] = L.inst[i] >= 0 ? L.inst[i] + k : -1;
+        idx[6 + k] = L.rc[q] >= 0 ? L.rc[q] + k : -1;
+      }
+      MultRotations<T>(ri, rr, R);
+      const T ex[3] = {T(1.0), T(0.0), T(0.0)}, ez[3] = {T(0.0), T(0.0), T(1.0)};
+      AngleAxisRotatePoint<T>(R, ez, zw);
+      auto diff = [](const T& a, double b) {  // DiffBetweenAngles, error_utils.h:88-97
+        T dd = a - b;
+        if (dd.v > M_PI) return dd - 2 * M_PI;
+        if (dd.v < -M_PI) return dd + 2 * M_PI;
+        return dd;
+      };
+      bool zero = false;
+      if (which == 0) {
+        if (std::fabs(zw[0].v) < 1e-8 && std::fabs(zw[1].v) < 1e-8) zero = true;
+        else r[0] = diff(atan2(zw[0], zw[1]), ang[s]) * (1.0 / sg[s]);
+      } else if (which == 1) {
+        const T l = sqrt(zw[0] * zw[0] + zw[1] * zw[1]);
+        r[0] = diff(-atan2(zw[2], l), ang[s]) * (1.0 / sg[s]);
+      } else {
+        AngleAxisRotatePoint<T>(R, ex, xw);
+        T a[3] = {zw[1], -zw[0], T(0.0)};
+        const T la = sqrt(a[0] * a[0] + a[1] * a[1]);
+        if (la.v < 1e-5) {
+          zero = true;
+        } else {
+          a[0] = a[0] / la;
+          a[1] = a[1] / la;
+          const T b[3] = {xw[1] * a[2] - xw[2] * a[1], xw[2] * a[0] - xw[0] * a[2], xw[0] * a[1] - xw[1] * a[0]};  // ceres::CrossProduct
+          const T sin_roll = zw[0] * b[0] + zw[1] * b[1] + zw[2] * b[2];
+          if (sin_roll.v <= -(1.0 - 1e-5)) zero = true;
+          else r[0] = diff(asin(sin_roll), ang[s]) * (1.0 / sg[s]);
+        }
+      }
+      if (zero) continue;
+      double rho, rho1;
+      loss_eval(3, 1.0, r[0].v * r[0].v, &rho, &rho1);
+      cost += 0.5 * rho;
+      add_block<12>(A, r, 1, std::sqrt(rho1), idx);
+    }
+  }
   if (A) A->cost = cost;
   return cost;
 }

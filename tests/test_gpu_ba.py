@@ -107,14 +107,19 @@ def test_lund_scale_config(oracle_lib, gpu_ctx):
 
 
 def test_bundle_adjuster_builder_api(gpu_ctx):
-    """pybundle.BundleAdjuster-style use (test_bundle.py:116-165 style): ids, run(), getters."""
+    """pybundle.BundleAdjuster use as BAHelpers does it (ba_helpers.cc:590-741): ids, run(), getters; a perspective problem with one
+    constant identity rig camera goes to the streaming solver."""
     from opensfm_amd import bundle
+    from opensfm_amd.geometry_types import Camera, Pose
 
     pr = synthetic.make_ba_scene(6, 60, 4, seed=9, outlier_frac=0.0)
     ba = bundle.BundleAdjuster()
-    ba.add_camera("cam", pr["cam_params"][0], pr["cam_prior"][0], False)
+    k1, k2, f = pr["cam_params"][0]
+    k1p, k2p, fp = pr["cam_prior"][0]
+    ba.add_camera("cam", Camera.create_perspective(f, k1, k2), Camera.create_perspective(fp, k1p, k2p), False)
+    ba.add_rig_camera("cam", Pose(), Pose(), True)
     for s in range(6):
-        ba.add_rig_instance(f"inst{s}", pr["shot_pose"][s, :3], pr["shot_pose"][s, 3:], {f"shot{s}": "cam"}, False)
+        ba.add_rig_instance(f"inst{s}", Pose.from_cam_to_world(pr["shot_pose"][s, :3], pr["shot_pose"][s, 3:]), {f"shot{s}": "cam"}, {f"shot{s}": "cam"}, False)
         ba.add_rig_instance_position_prior(f"inst{s}", pr["shot_gps"][s], np.full(3, 5.0), "")
     for p in range(60):
         ba.add_point(f"p{p}", pr["points"][p], False)
@@ -126,11 +131,13 @@ def test_bundle_adjuster_builder_api(gpu_ctx):
     ba.set_max_num_iterations(30)
     ba.set_linear_solver_type("SPARSE_SCHUR")
     ba.run()
+    assert ba.solver == "osfm_ba_solve"
     errs = np.array([e for p in range(60) for e in ba.get_point(f"p{p}").reprojection_errors.values()])
     assert len(errs) == len(pr["obs_shot"])
     assert np.sqrt((errs**2).sum(1).mean()) * PX < 2.0
     assert "iterations" in ba.brief_report()
     assert ba.get_rig_instance_pose("inst0").get_origin().shape == (3,)
+    assert ba.get_camera("cam").focal != f  # free intrinsics moved
     with pytest.raises(RuntimeError):
         bundle.BundleAdjuster().set_linear_solver_type("NOPE")
     with pytest.raises(RuntimeError):
