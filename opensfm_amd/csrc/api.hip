@@ -85,6 +85,7 @@ extern "C" int osfm_store_create(osfm_ctx *ctx, int n_images, const int32_t *cou
   bool ok = true;
   ok = ok && (e = hipMalloc((void **)&s->d_tiles, (size_t)nt * OSFM_TILE_BYTES)) == hipSuccess;
   ok = ok && (e = hipMalloc((void **)&s->d_norms, (size_t)nt * 32 * sizeof(int32_t))) == hipSuccess;
+  ok = ok && (e = hipMalloc((void **)&s->d_hneg, (size_t)nt * 32 * sizeof(int32_t))) == hipSuccess;
   ok = ok && (e = hipMalloc((void **)&s->d_pts, (size_t)nt * 32 * 2 * sizeof(double))) == hipSuccess;
   ok = ok && (e = hipMalloc((void **)&s->d_counts, (size_t)(n_images + 1) * sizeof(int32_t))) == hipSuccess;
   ok = ok && (e = hipMalloc((void **)&s->d_tile_off, (size_t)(n_images + 1) * sizeof(int64_t))) == hipSuccess;
@@ -93,7 +94,7 @@ extern "C" int osfm_store_create(osfm_ctx *ctx, int n_images, const int32_t *cou
     osfm_store_destroy(s);
     return OSFM_E_NOMEM;
   }
-  s->bytes = nt * (OSFM_TILE_BYTES + 32 * 4 + 32 * 16) + (int64_t)(n_images + 1) * 12;
+  s->bytes = nt * (OSFM_TILE_BYTES + 32 * 8 + 32 * 16) + (int64_t)(n_images + 1) * 12;
   *out = s;
   return OSFM_OK;
 }
@@ -103,6 +104,7 @@ extern "C" void osfm_store_destroy(osfm_store *s) {
   if (s->ctx) (void)hipSetDevice(s->ctx->device);
   (void)hipFree(s->d_tiles);
   (void)hipFree(s->d_norms);
+  (void)hipFree(s->d_hneg);
   (void)hipFree(s->d_pts);
   (void)hipFree(s->d_counts);
   (void)hipFree(s->d_tile_off);
@@ -148,6 +150,11 @@ static int store_upload(osfm_store *s, const T *desc, const double *pts) {
   }
   OSFM_HIP(hipMemcpy(s->d_tiles, tiles.data(), tiles.size(), hipMemcpyHostToDevice));
   OSFM_HIP(hipMemcpy(s->d_norms, norms.data(), norms.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  {
+    std::vector<int32_t> hneg(norms.size());
+    for (size_t k = 0; k < norms.size(); ++k) hneg[k] = -((norms[k] + 1) >> 1);
+    OSFM_HIP(hipMemcpy(s->d_hneg, hneg.data(), hneg.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
   OSFM_HIP(hipMemcpy(s->d_pts, hp.data(), hp.size() * sizeof(double), hipMemcpyHostToDevice));
   std::vector<int32_t> cnt(s->counts);
   cnt.push_back(0);

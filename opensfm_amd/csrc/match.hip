@@ -59,6 +59,7 @@ __device__ __forceinline__ long xcd_remap(long b, long n) {
 struct MatchArgs {
   const int8_t *tiles;
   const int32_t *norms;
+  const int32_t *hneg;  // -ceil(norm / 2): accumulator seeds
   const int64_t *tile_off;
   const int32_t *counts;
   const int32_t *pairs;
@@ -467,13 +468,262 @@ __device__ __forceinline__ int row_pass(const RowPassShared &sh, const int8_t *t
   return flag;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Version 5 of the pass: "targets in registers, queries in LDS, the norm in the accumulator".
+//
+// v4's pass is bounded by its integer epilogue (6.6 VALU per MFMA, profiles/r01_final_match_pmc.txt: VALU port 48 %, matrix pipe
+// 45 %, and on gfx950 one integer VALU instruction of a 64-wide wave costs 5-6 cycles of a SIMD, profiles/r01_ubench_valu_issue.txt --
+// more than the 32 cycles of the MFMA they follow).  Every one of those instructions builds or compares a key
+// (2 a.b - |b|^2) * 2^k + tag.  v5 removes the key arithmetic:
+//   * the QUERIES are the streamed operand (columns, one per lane), the TARGETS the register operand (rows, one per accumulator
+//     register).  The quantity to maximise over the targets i of a query j is v = 2 a_i.b_j - |a_i|^2; the per-target constant now
+//     belongs to a REGISTER, so it rides in the accumulator seed: the first MFMA of a K chain takes C = -ceil(|a_i|^2 / 2) (a
+//     16-register tuple per row tile that stays put while the queries stream by), and the chain ends with
+//     u = a_i.b_j - ceil(|a_i|^2 / 2), v = 2u + (|a_i|^2 & 1).  No shift, no add.
+//   * per query and class (the 32 targets a lane sees in one step) only max u is kept: a v_max3 tree over the 32 accumulators,
+//     then second = med3(best, m, second), class = m > best ? step : class, best = max(best, m): 20 VALU per 8 MFMAs.
+//   * u orders v up to the parity bit, which is all the lazy scheme needs: the winner has u = max u; the other classes bound the
+//     second neighbour between 2 s and 2 s + 1.  A query is final when the ratio test fails even with the most favourable of those
+//     bounds (the vast majority); otherwise the winner's class (32 targets) is re-examined exactly with v_dot4, and if the answer
+//     still depends on the unknown parity bit, or two classes tie, the query is re-done exactly against all targets.
+//   * the chunk of 256 queries stays in LDS for the whole sweep over the targets, so there is no barrier, no DMA wait and no
+//     merge inside the sweep: each wave streams its own target rows global -> VGPR one step ahead.
+// Results are bit-identical to v4 / the exact kernel / the oracle (tests/test_gpu_matching.py).
+// ---------------------------------------------------------------------------------------------
+constexpr int kPadHneg = -(1 << 23);  // accumulator seed of a padding target: can never be the maximum
+
+struct QueryPassShared {
+  unsigned char *bbuf;  // [2][32 KiB] query chunks (tile layout); the drained one doubles as the merge scratch
+};
+
+// queries: slot q in [0, nslots) is feature qsel[q] of image Q (qsel == nullptr: identity); targets: all nT features of image T.
+// out[query feature] = its nearest target if the ratio test passes, else kNone.  Returns the collision flag.
+template <bool GATHER>
+__device__ __forceinline__ int query_pass(const QueryPassShared &sh, const int8_t *tilesQ, const int32_t *normQ, int nQ, int nslots,
+                                          const unsigned short *qsel, const int8_t *tilesT, const int32_t *normT, const int32_t *hnegT,
+                                          int nT, unsigned short *out, double ratio, int tid) {
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tT = (nT + 31) >> 5;
+  const int tS = (nslots + 31) >> 5;
+  const int nchunks = (tS + kCT4 - 1) / kCT4;
+  const int nrb = (tT + kWaves * kRT - 1) / (kWaves * kRT);
+  int flag = 0;
+
+  // one chunk = 8 query tiles, global -> LDS by DMA; thread (w, lane) moves bytes [w*1024 + lane*16, +16) of every tile, i.e. the
+  // K slice w of feature (lane & 31), half (lane >> 5) -- which is also how a gathered query is addressed
+  auto dma_chunk = [&](int c) {
+    unsigned char *dst = sh.bbuf + (c & 1) * kChunkBytes4;
+#pragma unroll
+    for (int q = 0; q < kCT4; ++q) {
+      const int gt = c * kCT4 + q;
+      const int8_t *src;
+      if (GATHER) {
+        const int slot = gt * 32 + (lane & 31);
+        const int f = slot < nslots ? (int)qsel[slot] : 0;
+        src = tilesQ + (long)(f >> 5) * OSFM_TILE_BYTES + w * 1024 + (lane >> 5) * 512 + (f & 31) * 16;
+      } else {
+        src = tilesQ + (long)(gt < tS ? gt : 0) * OSFM_TILE_BYTES + tid * 16;
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                       (__attribute__((address_space(3))) void *)(dst + q * OSFM_TILE_BYTES + w * 1024), 16, 0, 0);
+    }
+  };
+
+  // the wave's two target row tiles of row block rb: A operands and accumulator seeds
+  auto load_targets = [&](int rb, v4i (&af)[kRT][4], v16i (&hn)[kRT]) {
+#pragma unroll
+    for (int rt = 0; rt < kRT; ++rt) {
+      const int t = rb * (kWaves * kRT) + w * kRT + rt;
+      const bool live = t < tT;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        v4i z = {0, 0, 0, 0};
+        af[rt][ks] = z;
+        if (live) af[rt][ks] = *(const v4i *)(tilesT + (long)t * OSFM_TILE_BYTES + ks * 1024 + lane * 16);
+      }
+      // accumulator register r of half h belongs to row (r & 3) + 8 (r >> 2) + 4 h of the tile
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        v4i hv = {kPadHneg, kPadHneg, kPadHneg, kPadHneg};
+        if (live) hv = *(const v4i *)(hnegT + (long)t * 32 + 8 * g + 4 * (lane >> 5));
+        hn[rt][4 * g + 0] = hv[0];
+        hn[rt][4 * g + 1] = hv[1];
+        hn[rt][4 * g + 2] = hv[2];
+        hn[rt][4 * g + 3] = hv[3];
+      }
+    }
+  };
+
+  dma_chunk(0);
+  v4i afrag[kRT][4], anext[kRT][4];
+  v16i hinit[kRT], hnext[kRT];
+  load_targets(0, afrag, hinit);
+
+  for (int c = 0; c < nchunks; ++c) {
+    // the query this thread decides at the end of the chunk (slot c*256 + tid): its norm, fetched now
+    const int myslot = c * kChunkCols4 + tid;
+    const int myf = myslot < nslots ? (GATHER ? (int)qsel[myslot] : myslot) : -1;
+    const int myna = (myf >= 0 && myf < nQ) ? normQ[myf] : OSFM_PAD_NORM;
+    if (c + 1 < nchunks) dma_chunk(c + 1);  // its buffer was released by the merge of chunk c - 1
+    // chunk c has landed once all but the newest kCT4 DMAs of this thread have (the first chunk: all of them)
+    if (c + 1 < nchunks)
+      __builtin_amdgcn_s_waitcnt(0x0070 | (kCT4 & 15) | (((kCT4 >> 4) & 3) << 14));  // vmcnt(kCT4), keep lgkm/exp
+    else
+      __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0)
+    __syncthreads();
+    const unsigned char *bb = sh.bbuf + (c & 1) * kChunkBytes4;
+
+    int cb[kCT4], cs[kCT4], ci[kCT4];
+#pragma unroll
+    for (int t = 0; t < kCT4; ++t) {
+      cb[t] = INT_MIN;
+      cs[t] = INT_MIN;
+      ci[t] = 0;
+    }
+
+    for (int rb = 0; rb < nrb; ++rb) {
+      // next step's targets, one step ahead (the next chunk starts over at row block 0)
+      {
+        const int rbn = (rb + 1 < nrb) ? rb + 1 : 0;
+        if (rb + 1 < nrb || c + 1 < nchunks) load_targets(rbn, anext, hnext);
+      }
+      const int t0 = rb * (kWaves * kRT) + w * kRT;
+      if (t0 < tT) {
+        v4i bf[2][4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) bf[0][ks] = *(const v4i *)(bb + ks * 1024 + lane * 16);
+#pragma unroll
+        for (int t = 0; t < kCT4; ++t) {
+          const int cur = t & 1;
+          if (t + 1 < kCT4) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) bf[cur ^ 1][ks] = *(const v4i *)(bb + (t + 1) * OSFM_TILE_BYTES + ks * 1024 + lane * 16);
+          }
+          v16i acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[0][0], bf[cur][0], hinit[0], 0, 0, 0);
+          v16i acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[1][0], bf[cur][0], hinit[1], 0, 0, 0);
+#pragma unroll
+          for (int ks = 1; ks < 4; ++ks) {
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[0][ks], bf[cur][ks], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[1][ks], bf[cur][ks], acc1, 0, 0, 0);
+          }
+          // max over the 32 targets of this lane: four independent v_max3 chains, then the class update
+          int m0 = max(max(acc0[0], acc0[1]), acc0[2]), m1 = max(max(acc0[8], acc0[9]), acc0[10]);
+          int m2 = max(max(acc1[0], acc1[1]), acc1[2]), m3 = max(max(acc1[8], acc1[9]), acc1[10]);
+          m0 = max(max(m0, acc0[3]), acc0[4]);
+          m1 = max(max(m1, acc0[11]), acc0[12]);
+          m2 = max(max(m2, acc1[3]), acc1[4]);
+          m3 = max(max(m3, acc1[11]), acc1[12]);
+          m0 = max(max(m0, acc0[5]), acc0[6]);
+          m1 = max(max(m1, acc0[13]), acc0[14]);
+          m2 = max(max(m2, acc1[5]), acc1[6]);
+          m3 = max(max(m3, acc1[13]), acc1[14]);
+          m0 = max(max(m0, acc0[7]), acc0[15]);
+          m2 = max(max(m2, acc1[7]), acc1[15]);
+          const int m = max(max(m0, m1), max(m2, m3));
+          asm("v_med3_i32 %0, %1, %2, %3" : "=v"(cs[t]) : "v"(cb[t]), "v"(m), "v"(cs[t]));  // cs <= cb: the second-largest of {cb, m, cs}
+          ci[t] = m > cb[t] ? rb : ci[t];
+          cb[t] = max(cb[t], m);
+        }
+      }
+      if (rb + 1 < nrb || c + 1 < nchunks) {
+#pragma unroll
+        for (int rt = 0; rt < kRT; ++rt) {
+          hinit[rt] = hnext[rt];
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) afrag[rt][ks] = anext[rt][ks];
+        }
+      }
+    }  // row blocks
+
+    // ---- end of the chunk: merge the 8 partial classes (4 waves x 2 halves) of every query, decide, re-examine ----
+    __syncthreads();  // everyone is done reading the chunk: its buffer becomes the scratch
+    int *scr = (int *)(sh.bbuf + (c & 1) * kChunkBytes4);  // [8 parts][3][256]
+    {
+      const int part = w * 2 + (lane >> 5);
+#pragma unroll
+      for (int t = 0; t < kCT4; ++t) {
+        scr[(part * 3 + 0) * kChunkCols4 + t * 32 + (lane & 31)] = cb[t];
+        scr[(part * 3 + 1) * kChunkCols4 + t * 32 + (lane & 31)] = cs[t];
+        scr[(part * 3 + 2) * kChunkCols4 + t * 32 + (lane & 31)] = ci[t];
+      }
+    }
+    __syncthreads();
+    int b = INT_MIN, s2 = INT_MIN, id = 0;
+#pragma unroll
+    for (int part = 0; part < 2 * kWaves; ++part) {
+      const int pb = scr[(part * 3 + 0) * kChunkCols4 + tid], ps = scr[(part * 3 + 1) * kChunkCols4 + tid];
+      const int pi = scr[(part * 3 + 2) * kChunkCols4 + tid];
+      s2 = max(max(s2, ps), min(b, pb));
+      id = pb > b ? (pi * 8 + part) : id;
+      b = max(b, pb);
+    }
+    __syncthreads();  // scratch read: the buffer may be refilled by the next chunk's prefetch (issued at the top of the loop)
+    bool want = false;
+    if (myf >= 0 && myf < nQ) {
+      // v_best in {2b, 2b+1}; the best of the other classes in {2 s2, 2 s2 + 1}, the true second is at least that
+      const int d1lo = max(myna - (2 * b + 1), 0), d2hi = myna - 2 * s2;
+      if (d2hi >= kCollisionD2 && ratio >= 0.0) flag = 1;  // squared mode never takes a square root
+      want = ratio_ok(d1lo, d2hi, ratio);
+      if (!want) out[myf] = kNone;
+    }
+    unsigned long long pending = __ballot(want);
+    while (pending) {
+      const int src = __builtin_ctzll(pending);
+      pending &= pending - 1;
+      const int qf = __shfl(myf, src), qna = __shfl(myna, src), qb = __shfl(b, src), qs = __shfl(s2, src), qid = __shfl(id, src);
+      bool full = (qs == qb);  // two classes tie on u: the winner may sit in either
+      int win = kNone;
+      if (!full) {
+        const int qrb = qid >> 3, qw = (qid >> 1) & 3, qh = qid & 1;
+        const int rtl = (lane >> 4) & 1, r = lane & 15;
+        const int row = (qrb * (kWaves * kRT) + qw * kRT + rtl) * 32 + (r & 3) + 8 * (r >> 2) + 4 * qh;
+        int v = INT_MIN;
+        if (lane < 32 && row < nT) v = 2 * dot_rows8(tilesQ, qf, tilesT, row) - normT[row];
+        const int m1 = wave_max(v);
+        const int jwin = -wave_max(v == m1 ? -row : INT_MIN);  // lowest index among equals (cv2's rule)
+        const int m2 = wave_max((lane < 32 && row != jwin) ? v : INT_MIN);
+        const int sa = max(m2, 2 * qs), sb = max(m2, 2 * qs + 1);
+        const bool ra = ratio_ok(qna - m1, qna - sa, ratio), rbb = ratio_ok(qna - m1, qna - sb, ratio);
+        if (ra == rbb)
+          win = ra ? jwin : kNone;
+        else
+          full = true;  // the decision hangs on the parity bit of a norm in another class
+      }
+      if (full) {
+        int lv = INT_MIN, lj = INT_MAX, ls = INT_MIN;
+        for (int i = lane; i < nT; i += 64) {
+          const int v = 2 * dot_rows8(tilesQ, qf, tilesT, i) - normT[i];
+          ls = max(ls, min(lv, v));
+          if (v > lv) {  // ascending i within a lane: the first maximum is the lowest index
+            lv = v;
+            lj = i;
+          }
+        }
+        const int m1 = wave_max(lv);
+        const int jwin = -wave_max(lv == m1 ? -lj : INT_MIN);
+        const int m2 = wave_max(lj == jwin ? ls : lv);
+        win = ratio_ok(qna - m1, qna - m2, ratio) ? jwin : kNone;
+      }
+      if (lane == 0) out[qf] = (unsigned short)win;
+    }
+  }  // chunks
+  __syncthreads();
+  return flag;
+}
+
 __global__ void __launch_bounds__(kThreads, 2) match_fused4_kernel(MatchArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef OSFM_MATCH_V4
   RowPassShared sh;
-  sh.bbuf = smem;                                                  // [2][16 KiB]
-  sh.nbuf = (int *)(smem + 2 * kChunkBytes4);                       // [2][128]
+  sh.bbuf = smem;                                                  // [2][32 KiB]
+  sh.nbuf = (int *)(smem + 2 * kChunkBytes4);                       // [2][256]
   sh.pad_norm = a.pad_norm;
-  int *misc = sh.nbuf + 2 * kChunkCols4;                            // [16]
+#else
+  QueryPassShared sh;
+  sh.bbuf = smem;  // [2][32 KiB]
+#endif
+  int *misc = (int *)(smem + 2 * kChunkBytes4) + 2 * kChunkCols4;  // [16]
   unsigned short *resA = (unsigned short *)(misc + 16);            // [ncap] per feature of image A
   unsigned short *resB = resA + a.ncap;                            // [ncap] per feature of image B
   unsigned short *cand = resB + a.ncap;                            // [ncap] candidate list (features of B)
@@ -498,6 +748,8 @@ __global__ void __launch_bounds__(kThreads, 2) match_fused4_kernel(MatchArgs a) 
   const int8_t *tilesB = a.tiles + a.tile_off[imgB] * OSFM_TILE_BYTES;
   const int32_t *normA = a.norms + a.tile_off[imgA] * 32;
   const int32_t *normB = a.norms + a.tile_off[imgB] * 32;
+  const int32_t *hnegA = a.hneg + a.tile_off[imgA] * 32;
+  const int32_t *hnegB = a.hneg + a.tile_off[imgB] * 32;
 
   for (int j = tid; j < a.ncap; j += kThreads) {
     resA[j] = kNone;
@@ -508,7 +760,13 @@ __global__ void __launch_bounds__(kThreads, 2) match_fused4_kernel(MatchArgs a) 
     misc[9] = 0;
   }
   __syncthreads();
+#ifdef OSFM_MATCH_V4
   int flag = row_pass<false>(sh, tilesA, normA, nA, nA, nullptr, tilesB, normB, nB, resA, a.ratio, tid);
+  (void)hnegA;
+  (void)hnegB;
+#else
+  int flag = query_pass<false>(sh, tilesA, normA, nA, nA, nullptr, tilesB, normB, hnegB, nB, resA, a.ratio, tid);
+#endif
   if (a.symmetric) {
     // candidates: the features of B that some row of A chose.  resB doubles as the mark array
     // (0 = chosen) until the candidate list is built, in ascending feature order.
@@ -539,7 +797,11 @@ __global__ void __launch_bounds__(kThreads, 2) match_fused4_kernel(MatchArgs a) 
       __syncthreads();
     }
     const int nK = base;
+#ifdef OSFM_MATCH_V4
     if (nK > 0) flag |= row_pass<true>(sh, tilesB, normB, nB, nK, cand, tilesA, normA, nA, resB, a.ratio, tid);
+#else
+    if (nK > 0) flag |= query_pass<true>(sh, tilesB, normB, nB, nK, cand, tilesA, normA, hnegA, nA, resB, a.ratio, tid);
+#endif
   }
   if (flag) misc[8] = 1;
   __syncthreads();
@@ -679,6 +941,7 @@ int osfm_launch_match(osfm_ctx *ctx, const osfm_store *store, const int32_t *d_p
   MatchArgs a;
   a.tiles = store->d_tiles;
   a.norms = store->d_norms;
+  a.hneg = store->d_hneg;
   a.tile_off = store->d_tile_off;
   a.counts = store->d_counts;
   a.pairs = d_pairs;

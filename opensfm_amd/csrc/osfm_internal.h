@@ -58,6 +58,7 @@ struct osfm_store {
   int max_count = 0;
   int8_t *d_tiles = nullptr;        // total_tiles * 4096 : (u8 - 128) in tile order
   int32_t *d_norms = nullptr;       // total_tiles * 32 : sum (u8-128)^2, padding = OSFM_PAD_NORM
+  int32_t *d_hneg = nullptr;        // total_tiles * 32 : -ceil(norm / 2), the accumulator seed of the matcher (match.hip)
   double *d_pts = nullptr;          // total_tiles * 32 * 2 (padded rows zero)
   int32_t *d_counts = nullptr;      // n_images
   int64_t *d_tile_off = nullptr;    // n_images + 1

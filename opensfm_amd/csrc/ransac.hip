@@ -112,6 +112,68 @@ __device__ int solve_cubic_monic(double a, double b, double c, double *roots) {
   return n;
 }
 
+// cv2's basis of the null space (fundam.cpp run7Point takes the last two rows of V from SVDecomp(A, FULL_UV), which JacobiSVDImpl_
+// builds from two fixed pseudo-random +-1/9 vectors -- cv::RNG(0x12345678), bit 8 of a draw -- projected onto the complement of the
+// computed singular vectors): f1 = P r1 / |P r1|, f2 likewise from r2 minus its f1 component.
+struct CvSvdFill {
+  double r[2][9];
+  constexpr CvSvdFill() : r{} {
+    unsigned long long state = 0x12345678ULL;
+    for (int i = 0; i < 2; i++)
+      for (int k = 0; k < 9; k++) {
+        state = (unsigned long long)(unsigned)state * 4164903690ULL + (unsigned)(state >> 32);
+        r[i][k] = ((unsigned)state & 256u) != 0 ? 1.0 / 9.0 : -(1.0 / 9.0);
+      }
+  }
+};
+__constant__ CvSvdFill kCvSvdFill{};
+
+__device__ __forceinline__ double dot9(const double *a, const double *b) {
+  double s = 0.0;
+  for (int i = 0; i < 9; i++) s = s + a[i] * b[i];
+  return s;
+}
+
+__device__ int cv_null_basis(const double *v1, const double *v2, double *f1, double *f2) {
+  double n1[9], n2[9];
+  double s = sqrt(dot9(v1, v1));
+  if (!(s > 1e-300)) return 0;
+  for (int i = 0; i < 9; i++) n1[i] = v1[i] / s;
+  double d = dot9(v2, n1);
+  for (int i = 0; i < 9; i++) n2[i] = v2[i] - d * n1[i];
+  s = sqrt(dot9(n2, n2));
+  if (!(s > 1e-300)) return 0;
+  for (int i = 0; i < 9; i++) n2[i] = n2[i] / s;
+  double a = dot9(kCvSvdFill.r[0], n1), b = dot9(kCvSvdFill.r[0], n2);
+  for (int i = 0; i < 9; i++) f1[i] = a * n1[i] + b * n2[i];
+  s = sqrt(dot9(f1, f1));
+  if (!(s > 1e-12)) return 0;
+  for (int i = 0; i < 9; i++) f1[i] = f1[i] / s;
+  a = dot9(kCvSvdFill.r[1], n1);
+  b = dot9(kCvSvdFill.r[1], n2);
+  for (int i = 0; i < 9; i++) f2[i] = a * n1[i] + b * n2[i];
+  d = dot9(f2, f1);
+  for (int i = 0; i < 9; i++) f2[i] = f2[i] - d * f1[i];
+  s = sqrt(dot9(f2, f2));
+  if (!(s > 1e-12)) return 0;
+  for (int i = 0; i < 9; i++) f2[i] = f2[i] / s;
+  return 1;
+}
+
+// three distinct real roots in cv::solveCubic's output order: smallest, largest, middle
+__device__ void cv_root_order3(double *r) {
+  double lo = r[0], hi = r[0], mid = r[0];
+  for (int k = 1; k < 3; k++) {
+    if (r[k] < lo) lo = r[k];
+    if (r[k] > hi) hi = r[k];
+  }
+  for (int k = 0; k < 3; k++)
+    if (r[k] != lo && r[k] != hi) mid = r[k];
+  r[0] = lo;
+  r[1] = hi;
+  r[2] = mid;
+}
+
 // 7-point algorithm; A is kept in private memory (7x9 doubles).
 __device__ int run_7point(const double *m1, const double *m2, double *F) {
   double A[7][9];
@@ -176,10 +238,8 @@ __device__ int run_7point(const double *m1, const double *m2, double *F) {
   v2[colperm[7]] = 0.0;
   v2[colperm[8]] = 1.0;
   double U[9], W[9];
-  for (int i = 0; i < 9; i++) {
-    U[i] = v1[i] - v2[i];
-    W[i] = v2[i];
-  }
+  if (!cv_null_basis(v1, v2, U, W)) return 0;
+  for (int i = 0; i < 9; i++) U[i] = U[i] - W[i];
   const double a3 = det3(U, U + 3, U + 6);
   const double a0 = det3(W, W + 3, W + 6);
   const double a2 = det3(W, U + 3, U + 6) + det3(U, W + 3, U + 6) + det3(U, U + 3, W + 6);
@@ -188,16 +248,20 @@ __device__ int run_7point(const double *m1, const double *m2, double *F) {
   int nr = 0;
   if (a3 != 0) {
     nr = solve_cubic_monic(a2 / a3, a1 / a3, a0 / a3, roots);
-  } else if (a2 != 0) {
-    const double p = a1 / a2, q = a0 / a2;
-    const double disc = p * p - 4.0 * q;
-    if (disc > 0) {
+    if (nr == 3) {
+      if (roots[0] != roots[1] && roots[1] != roots[2] && roots[0] != roots[2])
+        cv_root_order3(roots);
+      else
+        nr = 1;
+    }
+  } else if (a2 != 0) {  // solveCubic's quadratic branch: the root of larger |q| first
+    const double disc = a1 * a1 - 4.0 * a2 * a0;
+    if (disc >= 0) {
       const double sq = sqrt(disc);
-      const double t = (p >= 0) ? -0.5 * (p + sq) : -0.5 * (p - sq);
-      roots[nr++] = t;
-      if (t != 0) roots[nr++] = q / t;
-    } else if (disc == 0) {
-      roots[nr++] = -0.5 * p;
+      const double q1 = (-a1 + sq) * 0.5, q2 = (a1 + sq) * -0.5;
+      const double q = fabs(q1) > fabs(q2) ? q1 : q2;
+      roots[nr++] = q / a2;
+      if (disc > 0) roots[nr++] = a0 / q;
     }
   } else if (a1 != 0) {
     roots[nr++] = -a0 / a1;

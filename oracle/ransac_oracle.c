@@ -22,11 +22,22 @@
  *     inlier iff err <= (float)(thr*thr);
  *   - a model replaces the best iff goodCount > max(bestCount, 6); then
  *     niters = RANSACUpdateNumIters(conf, (n - good)/n, 7, niters).
- * What is NOT restated from OpenCV: the null space is obtained by Gauss-Jordan elimination with
- * complete pivoting (OpenCV: Jacobi SVD) and the cubic by bisection + deflation (OpenCV:
- * trigonometric solveCubic); log() in RANSACUpdateNumIters is an explicit atanh series.  All of
- * it uses only + - * / sqrt so that the HIP path can reproduce every bit (both sides are
- * compiled with -ffp-contract=off).  Mathematically the same models, rounding differs.
+ * The 7-point kernel follows cv2's ROUTE, because a model only replaces the best on strictly more inliers and so the ORDER in which
+ * the <= 3 solutions are scored decides ties:
+ *   - the basis (f1, f2) of the null space is the one SVDecomp(A, FULL_UV) hands run7Point: JacobiSVDImpl_ fills the two right
+ *     singular vectors a 7x9 matrix does not determine with two fixed pseudo-random vectors (entries +-1/9, the sign = bit 8 of
+ *     successive draws of cv::RNG(0x12345678)), projected onto the orthogonal complement of the vectors found so far and
+ *     normalised -- i.e. f1 = P r1 / |P r1|, f2 = the same for r2 after removing its f1 component (P = projector onto the null
+ *     space).  That basis depends only on the null space, so it is reproduced here from ANY null-space basis (Gauss-Jordan with
+ *     complete pivoting, then Gram-Schmidt) up to rounding;
+ *   - lambda parametrises F = lambda (f1 - f2) + f2; the roots are scored in solveCubic's output order: three distinct real roots
+ *     come out as smallest, largest, middle (x_k = -2 sqrt(Q) cos((theta + 2 pi k) / 3) - a1 / 3), a simple + a double root as
+ *     (simple, double), the quadratic case (leading coefficient exactly 0) larger-magnitude root first.
+ * What is NOT restated from OpenCV: the root VALUES come from bisection + deflation (OpenCV: the trigonometric closed form) and the
+ * projector from Gauss-Jordan (OpenCV: the seven Jacobi-rotated rows); log() in RANSACUpdateNumIters is an explicit atanh series.
+ * All of it uses only + - * / sqrt so that the HIP path can reproduce every bit (both sides are compiled with
+ * -ffp-contract=off).  Same models in the same order, rounding differs; a rank-deficient 7x9 system (where JacobiSVD would also
+ * regenerate some of the first seven vectors) gives no model here.
  * PARITY STATUS: "parity unpinned" -- the reference holds no golden vector for this call
  *  and cv2 is absent; inlier-set identity is defined GPU == this oracle.
  */
@@ -135,6 +146,63 @@ static int solve_cubic_monic(double a, double b, double c, double *roots) {
   return n;
 }
 
+/* sign pattern of the two vectors JacobiSVDImpl_ starts the missing singular vectors from: cv::RNG(0x12345678), bit 8 of a draw */
+static void cv_svd_fill_signs(double r[2][9]) {
+  cvrng_t rng = {0x12345678ULL};
+  for (int i = 0; i < 2; i++)
+    for (int k = 0; k < 9; k++) r[i][k] = (cvrng_next(&rng) & 256) != 0 ? 1.0 / 9.0 : -(1.0 / 9.0);
+}
+void oracle_cv_svd_fill_signs(double *r18) { cv_svd_fill_signs((double(*)[9])r18); }
+
+static double dot9(const double *a, const double *b) {
+  double s = 0.0;
+  for (int i = 0; i < 9; i++) s = s + a[i] * b[i];
+  return s;
+}
+
+/* (v1, v2): any basis of the null space -> (f1, f2): the basis cv2's SVDecomp(FULL_UV) produces.  0 when degenerate. */
+static int cv_null_basis(const double *v1, const double *v2, double *f1, double *f2) {
+  double r[2][9], n1[9], n2[9];
+  cv_svd_fill_signs(r);
+  double s = sqrt(dot9(v1, v1));
+  if (!(s > 1e-300)) return 0;
+  for (int i = 0; i < 9; i++) n1[i] = v1[i] / s;
+  double d = dot9(v2, n1);
+  for (int i = 0; i < 9; i++) n2[i] = v2[i] - d * n1[i];
+  s = sqrt(dot9(n2, n2));
+  if (!(s > 1e-300)) return 0;
+  for (int i = 0; i < 9; i++) n2[i] = n2[i] / s;
+  double a = dot9(r[0], n1), b = dot9(r[0], n2);
+  for (int i = 0; i < 9; i++) f1[i] = a * n1[i] + b * n2[i];
+  s = sqrt(dot9(f1, f1));
+  if (!(s > 1e-12)) return 0;
+  for (int i = 0; i < 9; i++) f1[i] = f1[i] / s;
+  a = dot9(r[1], n1);
+  b = dot9(r[1], n2);
+  for (int i = 0; i < 9; i++) f2[i] = a * n1[i] + b * n2[i];
+  d = dot9(f2, f1);
+  for (int i = 0; i < 9; i++) f2[i] = f2[i] - d * f1[i];
+  s = sqrt(dot9(f2, f2));
+  if (!(s > 1e-12)) return 0;
+  for (int i = 0; i < 9; i++) f2[i] = f2[i] / s;
+  return 1;
+}
+
+/* three distinct real roots in solveCubic's order: smallest, largest, middle */
+static void cv_root_order3(double *r) {
+  double lo = r[0], hi = r[0];
+  for (int k = 1; k < 3; k++) {
+    if (r[k] < lo) lo = r[k];
+    if (r[k] > hi) hi = r[k];
+  }
+  double mid = r[0];
+  for (int k = 0; k < 3; k++)
+    if (r[k] != lo && r[k] != hi) mid = r[k];
+  r[0] = lo;
+  r[1] = hi;
+  r[2] = mid;
+}
+
 /* 7-point algorithm.  m1, m2: 7 points (x,y).  F: up to 3 models x 9.  returns #models. */
 static int run_7point(const double *m1, const double *m2, double *F) {
   double A[7][9];
@@ -200,11 +268,9 @@ static int run_7point(const double *m1, const double *m2, double *F) {
   v1[colperm[8]] = 0.0;
   v2[colperm[7]] = 0.0;
   v2[colperm[8]] = 1.0;
-  double U[9], W[9];
-  for (int i = 0; i < 9; i++) {
-    U[i] = v1[i] - v2[i];
-    W[i] = v2[i];
-  }
+  double U[9], W[9], f1[9];
+  if (!cv_null_basis(v1, v2, f1, W)) return 0;
+  for (int i = 0; i < 9; i++) U[i] = f1[i] - W[i];
   /* det(lambda*U + W) = a3 l^3 + a2 l^2 + a1 l + a0 */
   double a3 = det3(U, U + 3, U + 6);
   double a0 = det3(W, W + 3, W + 6);
@@ -214,16 +280,20 @@ static int run_7point(const double *m1, const double *m2, double *F) {
   int nr = 0;
   if (a3 != 0) {
     nr = solve_cubic_monic(a2 / a3, a1 / a3, a0 / a3, roots);
-  } else if (a2 != 0) {
-    double p = a1 / a2, q = a0 / a2;
-    double disc = p * p - 4.0 * q;
-    if (disc > 0) {
+    if (nr == 3) {
+      if (roots[0] != roots[1] && roots[1] != roots[2] && roots[0] != roots[2])
+        cv_root_order3(roots);
+      else
+        nr = 1; /* solveCubic reports three roots only when they are distinct (d > 0); a numerically repeated root is its n = 1 */
+    }
+  } else if (a2 != 0) { /* solveCubic's quadratic branch: q1 = (-b + d) / 2, q2 = -(b + d) / 2, the larger |q| first */
+    double disc = a1 * a1 - 4.0 * a2 * a0;
+    if (disc >= 0) {
       double sq = sqrt(disc);
-      double t = (p >= 0) ? -0.5 * (p + sq) : -0.5 * (p - sq);
-      roots[nr++] = t;
-      if (t != 0) roots[nr++] = q / t;
-    } else if (disc == 0) {
-      roots[nr++] = -0.5 * p;
+      double q1 = (-a1 + sq) * 0.5, q2 = (a1 + sq) * -0.5;
+      double q = fabs(q1) > fabs(q2) ? q1 : q2;
+      roots[nr++] = q / a2;
+      if (disc > 0) roots[nr++] = a0 / q;
     }
   } else if (a1 != 0) {
     roots[nr++] = -a0 / a1;

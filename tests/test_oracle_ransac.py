@@ -44,6 +44,58 @@ def test_seven_point_models_satisfy_constraints(oracle_lib):
         assert abs(np.linalg.det(F)) < 1e-9 * np.abs(F).max() ** 3
 
 
+def _cv_jacobi_fill(A):
+    """the two right singular vectors SVDecomp(A, FULL_UV) appends for a 7x9 A, the way JacobiSVDImpl_ builds them (lapack.cpp): a
+    +-1/m vector from cv::RNG(0x12345678) (bit 8 of each draw), two rounds of Gram-Schmidt against every earlier row with an L1
+    rescale in between, then an L2 normalisation.  Independent of the oracle's C: numpy SVD for the seven determined rows."""
+    rows = list(np.linalg.svd(A)[2][:7])
+    state = 0x12345678
+    for _ in range(2):
+        v = np.zeros(9)
+        for k in range(9):
+            state = ((state & 0xFFFFFFFF) * 4164903690 + (state >> 32)) & (2**64 - 1)
+            v[k] = 1.0 / 9 if (state & 0xFFFFFFFF) & 256 else -1.0 / 9
+        for _ in range(2):
+            for u in rows:
+                v = v - (v @ u) * u
+                v = v / np.abs(v).sum()
+        rows.append(v / np.linalg.norm(v))
+    return rows[7], rows[8]
+
+
+def test_seven_point_follows_cv2s_basis_and_root_order(oracle_lib):
+    """the solutions come out as cv2's run7Point emits them: lambda measured in the (f1 - f2, f2) basis of SVDecomp's fill vectors,
+    three roots as smallest, largest, middle (solveCubic), each normalised to F[2,2] = 1"""
+    signs = np.zeros(18)
+    oracle_lib.lib().oracle_cv_svd_fill_signs(signs.ctypes.data_as(__import__("ctypes").POINTER(__import__("ctypes").c_double)))
+    state, want = 0x12345678, []
+    for _ in range(18):
+        state = ((state & 0xFFFFFFFF) * 4164903690 + (state >> 32)) & (2**64 - 1)
+        want.append(1 / 9 if state & 256 else -1 / 9)
+    assert np.array_equal(signs, want)
+    seen3 = 0
+    for seed in range(40):
+        p1, p2, _ = synthetic.make_two_view(7, inlier_frac=1.1, seed=100 + seed, px_noise=0.0)
+        Fs = oracle_lib.run_7point(p1, p2)
+        A = np.array([[x2 * x1, x2 * y1, x2, y2 * x1, y2 * y1, y2, x1, y1, 1.0] for (x1, y1), (x2, y2) in zip(p1, p2)])
+        f1, f2 = _cv_jacobi_fill(A)
+        # F ~ lambda (f1 - f2) + f2, then scaled so F[8] = 1: recover lambda by least squares on the direction
+        lams = []
+        for F in Fs:
+            coef, *_ = np.linalg.lstsq(np.stack([f1 - f2, f2], 1), F.reshape(9), rcond=None)
+            assert np.allclose(np.stack([f1 - f2, f2], 1) @ coef, F.reshape(9), atol=1e-7 * np.abs(F).max())
+            lams.append(coef[0] / coef[1])
+            assert F[2, 2] == 1.0
+        if len(lams) == 3:
+            seen3 += 1
+            assert lams[0] < lams[2] < lams[1]
+        # and they are the real roots of det(lambda (f1 - f2) + f2)
+        for lam in lams:
+            M = (lam * (f1 - f2) + f2).reshape(3, 3)
+            assert abs(np.linalg.det(M)) < 1e-10
+    assert seen3 >= 5
+
+
 @pytest.mark.parametrize("n,frac,seed", [(100, 0.7, 0), (300, 0.5, 1), (1000, 0.35, 2), (20, 0.9, 3)])
 def test_ransac_recovers_inliers(oracle_lib, n, frac, seed):
     # style of test_robust.py: inlier count within tolerance of the injected one
