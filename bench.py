@@ -135,7 +135,7 @@ def main():
     achieved = flop_pair * pairs_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
     roofline = {
         "bound": "mfma",
-        "kernel": "match_fused4_kernel",
+        "kernel": "match_fused_kernel",
         "achieved": round(achieved, 2),
         "peak": PEAK_I8_TOPS,
         "unit": "TFLOP/s",
@@ -302,7 +302,7 @@ def overlap_bench(args, ctx, store, scene, n_images, with_cpu):
         "ransac_share_of_stream_time": round(ms_r / max(ms_k + ms_r, 1e-9), 3),
         "pairs_reaching_ransac": int((c0 >= 20).sum()), "pairs_with_matches": int((counts > 0).sum()),
         "descriptor_matches_per_pair": round(float(c0.mean()), 1), "inlier_matches_per_pair": round(float(counts.mean()), 1),
-        "roofline": {"bound": "mfma", "kernel": "match_fused4_kernel", "unit": "TFLOP/s", "peak": PEAK_I8_TOPS,
+        "roofline": {"bound": "mfma", "kernel": "match_fused_kernel", "unit": "TFLOP/s", "peak": PEAK_I8_TOPS,
                      "achieved": round(flop / (ms_k * 1e-3) / 1e12, 2), "frac": round(flop / (ms_k * 1e-3) / 1e12 / PEAK_I8_TOPS, 4)},
         "roofline_ransac": {"bound": "valu-f64", "kernel": "ransac_pairs_kernel", "unit": "TFLOP/s", "peak": PEAK_F64_VALU_TFLOPS,
                             "model_points_per_s": round(float(np.mean([t.ransac_model_points for t in tms])) / (ms_r * 1e-3), 1),

@@ -11,17 +11,14 @@
 // v_mfma_i32_32x32x32_i8.  All quantities are exact int32, so the result is bit-identical to the
 // fp32 computation cv2 performs (every partial sum < 2^24).
 //
-// Epilogue (the kernel is bounded by integer VALU + skeleton work next to the matrix pipe, K is only
-// 128): "best-only + lazy exact second".  The second-nearest neighbour is only needed for the ratio
-// test, and only its VALUE.  Per class of candidates (the 32 column classes j mod 32 held by the 32
-// lanes of a half-wave) only the BEST packed key is kept:  best = v_max3_i32(best, key_a, key_b),
-// key = (2S - norm_other) * 2^k + tile tag (one v_lshl_add_u32).  Classes are merged into (global best,
-// second-largest class best =: s_c).  The true second s satisfies s >= s_c and the ratio test is
-// monotone in d2:  fails with s_c => fails (final, the vast majority);  passes with s_c => the winner's
-// own class is re-examined exactly by the whole wavefront with v_dot4 dot products.
-// (Earlier generations -- exact top-2 in both directions, both directions per pass -- measured 0.16 and
-// 0.24 of the int8 peak, profiles/r01_match_v1_rocprof.txt / r01_match_v2_pmc.txt; they were removed in
-// round 2, the exact VALU kernel below remains as the on-GPU cross-check.)
+// Reduction: "best-only + lazy exact second" (see query_pass below).  The second-nearest neighbour is only needed for the
+// ratio test, and only its VALUE; per query and class of 32 targets only the best accumulator value is kept, the norm of the
+// target riding in the accumulator seed.  Classes are merged into (best, second-largest class best =: s_c); the true second s
+// satisfies s >= s_c and the ratio test is monotone in d2: fails with s_c => fails (final, the vast majority); passes with
+// s_c => the winner's own class is re-examined exactly with v_dot4 dot products.
+// (Earlier generations -- exact top-2 in both directions 0.16, both directions per pass 0.24, one direction per pass with packed
+// keys 0.39 of the int8 peak, profiles/r01_*, r02_bench_mid.json -- were removed; the exact VALU kernel below remains as the
+// on-GPU cross-check.)
 #include <cstdlib>
 
 #include "osfm_internal.h"
@@ -72,7 +69,7 @@ struct MatchArgs {
   int32_t *out_counts;
   uint32_t *out_matches;
   int32_t *out_flags;
-  const int32_t *pad_norm;  // one device int holding OSFM_PAD_NORM (source for out-of-range norm DMA)
+  long pad_tile;            // index of the store's first slack tile
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -140,333 +137,27 @@ __device__ __forceinline__ int wave_max(int v) {
   return v;
 }
 
+// max over the 16 lanes of a DPP row, in every lane of the row (no LDS traffic): quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
+__device__ __forceinline__ int row16_max(int x) {
+  x = max(x, __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false));
+  x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false));
+  x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false));
+  x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x140, 0xF, 0xF, false));
+  return x;
+}
+
 // ---------------------------------------------------------------------------------------------
-// Fused MFMA kernel, version 4: "one direction at a time".
-//
-// Measured on MI355X (tools/prof_match.py + compile-time variants of v2): the kernel time is
-//   skeleton (chunk DMA, barriers, LDS operand reads, column atomics, merges)  +  VALU epilogue  +
-//   MFMA time, and the three do NOT overlap: removing the MFMAs or removing the epilogue saves the
-//   same ~5 ms out of 15.6 (19 900 pairs of 2000x2000), removing both leaves 5.1 ms.
-// The MFMA part is at its floor, so v4 removes VALU and skeleton work instead: the distance matrix
-// is only reduced along ONE direction per pass (1.5 VALU ops per element instead of 3, no column
-// partials, no LDS atomics):
-//   pass A: rows = image A in registers, image B streamed; resA[a] = best b if it passes the ratio
-//           test (class bests + lazy exact second, exactly as v2's row direction);
-//   pass B: (symmetric matching only) the mutual check needs "best a for b" only for the b that some
-//           row chose: those candidates (typically a small subset of image B) become the rows of a
-//           second, much smaller pass against the streamed image A;
+// Fused MFMA kernel: "one direction at a time".
+//   pass A: the queries are the features of image A, the targets those of image B; resA[a] = best b if it passes the ratio test;
+//   pass B: (symmetric matching only) the mutual check needs "best a for b" only for the b that some a chose: those candidates
+//           (typically a small subset of image B) become the gathered queries of a second, much smaller pass against image A;
 //   a pair (a, b) is emitted iff resA[a] == b and resB[b] == a.
-// For symmetric matching A is the pair's SECOND image, so that the image streamed by the big pass
-// is the first one, which the ~64 pairs in flight on an XCD share in L2 (xcd_remap).
-// Results are bit-identical to v1/v2/the exact kernel/the oracle.
+// For symmetric matching A is the pair's SECOND image, so that the image whose row blocks every step re-reads is the first one,
+// which the ~64 pairs in flight on an XCD share in L2 (xcd_remap).
 // ---------------------------------------------------------------------------------------------
-constexpr int kCT4 = 8;                              // v4 stages 256 columns per chunk: half the barriers / DMA issues of v2
+constexpr int kCT4 = 8;                              // a chunk stages 256 queries
 constexpr int kChunkCols4 = kCT4 * 32;
 constexpr int kChunkBytes4 = kCT4 * OSFM_TILE_BYTES;  // 32 KiB, double buffered
-struct RowPassShared {
-  unsigned char *bbuf;  // [2][16 KiB] chunk double buffer
-  int *nbuf;            // [2][128] norms of the staged chunk
-  const int32_t *pad_norm;
-};
-
-// rows: slot q in [0, nslots) is feature rowsel[q] of image X (rowsel == nullptr: identity).
-// out[feature of X] = best feature of Y (ratio test passed) or kNone.  Returns the collision flag.
-template <bool GATHER>
-__device__ __forceinline__ int row_pass(const RowPassShared &sh, const int8_t *tilesX, const int32_t *normX, int nX, int nslots,
-                                        const unsigned short *rowsel, const int8_t *tilesY, const int32_t *normY, int nY,
-                                        unsigned short *out, double ratio, int tid) {
-  const int lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tY = (nY + 31) >> 5;
-  const int tS = (nslots + 31) >> 5;  // row tiles (slots)
-  const int nchunks = (tY + kCT4 - 1) / kCT4;
-  const int nrb = (tS + kWaves * kRT - 1) / (kWaves * kRT);
-  const int nsteps = nrb * nchunks;
-  unsigned char *bbuf = sh.bbuf;
-  int *nbuf = sh.nbuf;
-  int flag = 0;
-  // images above 4096 features (128 tiles) do not fit a tile index into the 32-bit keys: value-only keys, and the
-  // re-examination of the rows that pass also has to find the winner (cold path)
-  const bool big = tY > 128;
-  const int ksh = big ? 1 : 8;
-
-  // first chunk of Y: global -> registers -> LDS
-  {
-    uint4 pre[kCT4];
-#pragma unroll
-    for (int q = 0; q < kCT4; ++q) {
-      pre[q] = make_uint4(0, 0, 0, 0);
-      if (q < tY) pre[q] = *(const uint4 *)(tilesY + (long)q * OSFM_TILE_BYTES + tid * 16);
-    }
-#pragma unroll
-    for (int q = 0; q < kCT4; ++q) *(uint4 *)(bbuf + q * OSFM_TILE_BYTES + tid * 16) = pre[q];
-    for (int j = tid; j < kChunkCols4; j += kThreads) nbuf[j] = (j < tY * 32) ? normY[j] : OSFM_PAD_NORM;
-  }
-  __syncthreads();
-
-  v4i afrag[kRT][4], anext[kRT][4];
-  int nrm = OSFM_PAD_NORM, nrm_next = OSFM_PAD_NORM;
-  int xrow = 0, xrow_next = 0;  // feature index of the row slot this lane describes (lane = slot - rt0*32)
-  int rbst[kRT][16];
-
-  // A operands (+ norm, + feature index) of the 64 row slots of this wave in row block rb
-  auto load_rows = [&](int rb, v4i (&af)[kRT][4], int &nr, int &xr) {
-    const int slot0 = (rb * (kWaves * kRT) + w * kRT) * 32;
-    {
-      const int q = slot0 + lane;
-      xr = (q < nslots) ? (GATHER ? (int)rowsel[q] : q) : -1;
-      nr = (xr >= 0 && xr < nX) ? normX[xr] : OSFM_PAD_NORM;
-    }
-#pragma unroll
-    for (int rt = 0; rt < kRT; ++rt) {
-      const int q = slot0 + rt * 32 + (lane & 31);
-      int f = (q < nslots) ? (GATHER ? (int)rowsel[q] : q) : -1;
-      if (!GATHER && q >= tS * 32) f = -1;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        v4i z = {0, 0, 0, 0};
-        af[rt][ks] = z;
-        // operand layout: lane = half*32 + row-in-tile holds bytes [ks*32 + half*16, +16) of that row
-        if (f >= 0) af[rt][ks] = *(const v4i *)(tilesX + (long)(f >> 5) * OSFM_TILE_BYTES + ks * 1024 + (lane >> 5) * 512 + (f & 31) * 16);
-      }
-    }
-  };
-
-  for (int rb = 0; rb < nrb; ++rb) {
-    const int rt0 = rb * (kWaves * kRT) + w * kRT;
-    const int nrt = min(kRT, max(0, tS - rt0));
-    if (rb == 0) {
-      load_rows(0, afrag, nrm, xrow);
-    } else {
-      nrm = nrm_next;
-      xrow = xrow_next;
-#pragma unroll
-      for (int rt = 0; rt < kRT; ++rt)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) afrag[rt][ks] = anext[rt][ks];
-    }
-#pragma unroll
-    for (int rt = 0; rt < kRT; ++rt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) rbst[rt][r] = INT_MIN;
-#pragma unroll
-    for (int rt = 0; rt < kRT; ++rt)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(afrag[rt][ks]));
-
-    for (int c = 0; c < nchunks; ++c) {
-      const int s = rb * nchunks + c;
-      const bool has_next = (s + 1 < nsteps);
-      const int cn = (c + 1 == nchunks) ? 0 : c + 1;
-      if (has_next) {
-        unsigned char *nb2 = bbuf + ((s + 1) & 1) * kChunkBytes4;
-#pragma unroll
-        for (int q = 0; q < kCT4; ++q) {
-          const int gt = cn * kCT4 + q;
-          const int8_t *src = tilesY + (long)(gt < tY ? gt : 0) * OSFM_TILE_BYTES + tid * 16;
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                           (__attribute__((address_space(3))) void *)(nb2 + q * OSFM_TILE_BYTES + w * 1024), 16, 0, 0);
-        }
-        if (w * 64 < kChunkCols4) {
-          const int jn = cn * kChunkCols4 + tid;
-          const int32_t *srcn = (jn < tY * 32) ? normY + jn : sh.pad_norm;
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)srcn,
-                                           (__attribute__((address_space(3))) void *)(nbuf + ((s + 1) & 1) * kChunkCols4 + w * 64), 4, 0, 0);
-        }
-      }
-      // ---- compute: a hand-made software pipeline over the step's 8 work items ----
-      // item = (pair of column tiles, row tile): 8 MFMAs (two accumulation chains) + a 48-op integer
-      // epilogue (2 v_lshl_add + 1 v_max3 per row register).  Inside one wavefront the chain
-      // LDS read -> MFMA -> epilogue is strictly dependent, and with two waves per SIMD the hardware
-      // cannot hide it (tools/ubench_overlap.hip: +24 % from pipelining exactly this shape).  So:
-      // the B operands of the NEXT pair are read from LDS one pair ahead, and every MFMA of item i+1 is
-      // followed by one eighth of the epilogue of item i, pinned with sched_barrier; operands and
-      // accumulators ping-pong between two register sets (no copies).  Branch-free: row tiles beyond the
-      // image have zero operands and padding norms, column tiles beyond it carry the padding norm, so
-      // neither can win.
-      const unsigned char *bb = bbuf + (s & 1) * kChunkBytes4;
-      if (nrt > 0) {
-        const int *nbs = nbuf + (s & 1) * kChunkCols4;
-        v4i bf[2][2][4];
-        int ck[2][2];
-        v16i acc[2][2];
-#define OSFM_LOAD_PAIR(BUF, PR)                                                                              \
-  {                                                                                                          \
-    _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                          \
-      _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                       \
-        bf[BUF][h][ks] = *(const v4i *)(bb + (2 * (PR) + h) * OSFM_TILE_BYTES + ks * 1024 + lane * 16);     \
-      const int nb = nbs[(2 * (PR) + h) * 32 + (lane & 31)];                                                 \
-      /* <= 128 tiles: key = value * 128 + (127 - tile): the winner's tile rides in the key.  More tiles: the value alone */ \
-      ck[BUF][h] = big ? -nb : -(nb << 7) + (127 - ((c * kCT4 + 2 * (PR) + h) & 127));                     \
-    }                                                                                                        \
-  }
-#ifdef OSFM_DBG_NOMFMA
-#define OSFM_MFMA(AB, RT, BUF, I) acc[AB][(I) & 1][(I) >> 1] += afrag[RT][(I) >> 1][0] ^ bf[BUF][(I) & 1][(I) >> 1][1];
-#else
-#define OSFM_MFMA(AB, RT, BUF, I) \
-  acc[AB][(I) & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[RT][(I) >> 1], bf[BUF][(I) & 1][(I) >> 1], acc[AB][(I) & 1], 0, 0, 0);
-#endif
-#ifdef OSFM_DBG_NOEPI
-#define OSFM_EPI(AB, RT, BUF, I) \
-  if ((I) == 7) rbst[RT][0] = max(rbst[RT][0], acc[AB][0][0] + acc[AB][1][5] + ck[BUF][0] + ck[BUF][1]);
-#else
-#define OSFM_EPI(AB, RT, BUF, I)                                                                             \
-  {                                                                                                          \
-    _Pragma("unroll") for (int rr = 2 * (I); rr < 2 * (I) + 2; ++rr) {                                       \
-      const int k0 = (acc[AB][0][rr] << ksh) + ck[BUF][0], k1 = (acc[AB][1][rr] << ksh) + ck[BUF][1];        \
-      rbst[RT][rr] = max(max(rbst[RT][rr], k0), k1);                                                         \
-    }                                                                                                        \
-  }
-#endif
-        const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        OSFM_LOAD_PAIR(0, 0)
-        acc[0][0] = zero16;
-        acc[0][1] = zero16;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) OSFM_MFMA(0, 0, 0, i)
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int item = 1; item < kCT4; ++item) {  // kCT4 / 2 pairs x 2 row tiles = kCT4 items
-          const int pr = item >> 1, rt = item & 1, buf = pr & 1, ab = item & 1;
-          const int ppr = (item - 1) >> 1, prt = (item - 1) & 1, pbuf = ppr & 1, pab = (item - 1) & 1;
-          if (rt == 1 && pr + 1 < kCT4 / 2) OSFM_LOAD_PAIR(buf ^ 1, pr + 1)  // one pair ahead of its first use
-          acc[ab][0] = zero16;
-          acc[ab][1] = zero16;
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            OSFM_MFMA(ab, rt, buf, i)
-            __builtin_amdgcn_sched_barrier(0);
-            OSFM_EPI(pab, prt, pbuf, i)
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) OSFM_EPI((kCT4 - 1) & 1, (kCT4 - 1) & 1, ((kCT4 - 1) >> 1) & 1, i)
-#undef OSFM_LOAD_PAIR
-#undef OSFM_MFMA
-#undef OSFM_EPI
-      }
-      __syncthreads();
-      // ---- end of a row block: merge the 32 column classes of every row (see v2) ----
-      if (c == nchunks - 1) {
-        if (rb + 1 < nrb) load_rows(rb + 1, anext, nrm_next, xrow_next);
-        unsigned char *trb = bbuf + (s & 1) * kChunkBytes4 + w * 1024;
-#pragma unroll
-        for (int rt = 0; rt < kRT; ++rt) {
-          if (rt < nrt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              *(int *)(trb + (r >> 2) * OSFM_TILE_BYTES + ((r & 3) + 4 * (lane >> 5)) * 128 + (lane & 31) * 4) = rbst[rt][r];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const int row32 = lane >> 1, hc = lane & 1;
-            int bkey = INT_MIN, bcls = 0, skey = INT_MIN;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int4 v4 = *(const int4 *)(trb + (row32 >> 3) * OSFM_TILE_BYTES + (row32 & 7) * 128 + hc * 64 + q * 16);
-              const int vv[4] = {v4.x, v4.y, v4.z, v4.w};
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                skey = max(skey, min(bkey, vv[e]));
-                const bool up = vv[e] > bkey;  // strict: the lowest class keeps ties (lowest column)
-                bcls = up ? hc * 16 + q * 4 + e : bcls;
-                bkey = up ? vv[e] : bkey;
-              }
-            }
-            {
-              const int pk = __shfl_xor(bkey, 1), pc = __shfl_xor(bcls, 1), ps = __shfl_xor(skey, 1);
-              const int nsk = max(min(bkey, pk), max(skey, ps));
-              const bool take = (pk > bkey) || (pk == bkey && pc < bcls);
-              bcls = take ? pc : bcls;
-              bkey = take ? pk : bkey;
-              skey = nsk;
-            }
-            const int il = rt * 32 + row32;
-            const int na = __shfl(nrm, il);
-            const int xr = __shfl(xrow, il);
-            const int bv = big ? bkey : bkey >> 7, sv = big ? skey : skey >> 7;
-            const int bj = (127 - (bkey & 127)) * 32 + bcls;  // winner's column when the key carries its tile (!big)
-            // value-only keys: every class whose best equals the overall best may hold the lowest-index winner
-            unsigned tmask = 0;
-            if (big) {
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const int4 v4 = *(const int4 *)(trb + (row32 >> 3) * OSFM_TILE_BYTES + (row32 & 7) * 128 + hc * 64 + q * 16);
-                const int vv[4] = {v4.x, v4.y, v4.z, v4.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) tmask |= (vv[e] == bkey) ? (1u << (hc * 16 + q * 4 + e)) : 0u;
-              }
-              tmask |= __shfl_xor(tmask, 1);
-            }
-            bool want = false;
-            if (hc == 0 && xr >= 0 && xr < nX) {
-              const int d1 = na - bv, d2 = na - sv;
-              if (d2 >= kCollisionD2 && ratio >= 0.0) flag = 1;  // squared mode never takes a square root
-              want = ratio_ok(d1, d2, ratio);  // passes against the class bound: re-examine
-              if (!want) out[xr] = kNone;
-            }
-            unsigned long long pending = __ballot(want);
-            while (pending) {
-              const int src = __builtin_ctzll(pending);
-              pending &= pending - 1;
-              const int qsv = __shfl(sv, src), qna = __shfl(na, src), qxr = __shfl(xr, src);
-              if (!big) {
-                // exact second inside the winner's class = columns {t*32 + (bj&31)}
-                const int qbj = __shfl(bj, src), qbv = __shfl(bv, src);
-                int mx = INT_MIN;
-                for (int t0 = 0; t0 < tY; t0 += 64) {
-                  const int t = t0 + lane;
-                  const int j = t * 32 + (qbj & 31);
-                  if (t < tY && j != qbj) mx = max(mx, 2 * dot_rows8(tilesX, qxr, tilesY, j) - normY[j]);
-                }
-                mx = wave_max(mx);
-                if (lane == 0) {
-                  const int s2 = max(qsv, mx);
-                  out[qxr] = ratio_ok(qna - qbv, qna - s2, ratio) ? qbj : kNone;
-                }
-              } else {
-                // the classes that reach the best value are re-examined exactly: lowest index among equals
-                // (cv2's rule) and exact second
-                unsigned qmask = (unsigned)__shfl((int)tmask, src);
-                int lv = INT_MIN, lj = INT_MAX, ls = INT_MIN;
-                while (qmask) {
-                  const int qcls = __builtin_ctz(qmask);
-                  qmask &= qmask - 1;
-                  for (int t0 = 0; t0 < tY; t0 += 64) {
-                    const int t = t0 + lane;
-                    if (t < tY) {
-                      const int j = t * 32 + qcls;
-                      const int v = 2 * dot_rows8(tilesX, qxr, tilesY, j) - normY[j];
-                      ls = max(ls, min(lv, v));
-                      if (v > lv || (v == lv && j < lj)) {
-                        lv = v;
-                        lj = j;
-                      }
-                    }
-                  }
-                }
-                const int m1 = wave_max(lv);
-                const int jwin = -wave_max(lv == m1 ? -lj : INT_MIN);
-                const int m2 = wave_max(lj == jwin ? ls : lv);
-                if (lane == 0) {
-                  const int s2 = max(qsv, m2);
-                  out[qxr] = ratio_ok(qna - m1, qna - s2, ratio) ? jwin : kNone;
-                }
-              }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          }
-        }
-      }
-    }  // chunks
-  }    // row blocks
-  __syncthreads();
-  return flag;
-}
 
 // ---------------------------------------------------------------------------------------------
 // Version 5 of the pass: "targets in registers, queries in LDS, the norm in the accumulator".
@@ -490,10 +181,9 @@ __device__ __forceinline__ int row_pass(const RowPassShared &sh, const int8_t *t
 //     merge inside the sweep: each wave streams its own target rows global -> VGPR one step ahead.
 // Results are bit-identical to v4 / the exact kernel / the oracle (tests/test_gpu_matching.py).
 // ---------------------------------------------------------------------------------------------
-constexpr int kPadHneg = -(1 << 23);  // accumulator seed of a padding target: can never be the maximum
-
 struct QueryPassShared {
   unsigned char *bbuf;  // [2][32 KiB] query chunks (tile layout); the drained one doubles as the merge scratch
+  int *hbuf;            // [2][256] accumulator seeds of the row block in flight / the next one
 };
 
 // queries: slot q in [0, nslots) is feature qsel[q] of image Q (qsel == nullptr: identity); targets: all nT features of image T.
@@ -501,7 +191,8 @@ struct QueryPassShared {
 template <bool GATHER>
 __device__ __forceinline__ int query_pass(const QueryPassShared &sh, const int8_t *tilesQ, const int32_t *normQ, int nQ, int nslots,
                                           const unsigned short *qsel, const int8_t *tilesT, const int32_t *normT, const int32_t *hnegT,
-                                          int nT, unsigned short *out, double ratio, int tid) {
+                                          int nT, const int8_t *tiles_pad, const int32_t *hneg_pad, unsigned short *out, double ratio,
+                                          int tid) {
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tT = (nT + 31) >> 5;
@@ -530,51 +221,167 @@ __device__ __forceinline__ int query_pass(const QueryPassShared &sh, const int8_
     }
   };
 
-  // the wave's two target row tiles of row block rb: A operands and accumulator seeds
-  auto load_targets = [&](int rb, v4i (&af)[kRT][4], v16i (&hn)[kRT]) {
+  // the wave's two target row tiles of row block rb.  Branch-free: a row tile beyond the image reads the store's slack tile (zero
+  // descriptors, padding norms), whose seed -2^22 can never be a maximum.
+  //   A operands: global -> VGPR, one step ahead, into the register set the running step does not use;
+  //   accumulator seeds: global -> LDS by DMA (each wave stages the 64 seeds of its own two row tiles, so only its own vmcnt
+  //   orders them), read into the seed tuples as soon as the running step has issued its last seeded MFMA.
+  auto load_targets = [&](int rb, v4i (&af)[kRT][4], int slot) {
+    {
+      const int t = rb * (kWaves * kRT) + w * kRT + (lane >> 5);
+      const int32_t *hp = ((t < tT) ? hnegT + (long)t * 32 : hneg_pad) + (lane & 31);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)hp,
+                                       (__attribute__((address_space(3))) void *)(sh.hbuf + slot * 256 + w * 64), 4, 0, 0);
+    }
 #pragma unroll
     for (int rt = 0; rt < kRT; ++rt) {
-      const int t = rb * (kWaves * kRT) + w * kRT + rt;
-      const bool live = t < tT;
+      const int t = rb * (kWaves * kRT) + w * kRT + rt;  // wave-uniform
+      const int8_t *tp = (t < tT) ? tilesT + (long)t * OSFM_TILE_BYTES : tiles_pad;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        v4i z = {0, 0, 0, 0};
-        af[rt][ks] = z;
-        if (live) af[rt][ks] = *(const v4i *)(tilesT + (long)t * OSFM_TILE_BYTES + ks * 1024 + lane * 16);
-      }
-      // accumulator register r of half h belongs to row (r & 3) + 8 (r >> 2) + 4 h of the tile
+      for (int ks = 0; ks < 4; ++ks) af[rt][ks] = *(const v4i *)(tp + ks * 1024 + lane * 16);
+    }
+  };
+  v16i hn[kRT];
+  // accumulator register r of half h belongs to row (r & 3) + 8 (r >> 2) + 4 h of the tile
+  auto read_seeds = [&](int slot) {
+#pragma unroll
+    for (int rt = 0; rt < kRT; ++rt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        v4i hv = {kPadHneg, kPadHneg, kPadHneg, kPadHneg};
-        if (live) hv = *(const v4i *)(hnegT + (long)t * 32 + 8 * g + 4 * (lane >> 5));
+        const v4i hv = *(const v4i *)(sh.hbuf + slot * 256 + w * 64 + rt * 32 + 8 * g + 4 * (lane >> 5));
         hn[rt][4 * g + 0] = hv[0];
         hn[rt][4 * g + 1] = hv[1];
         hn[rt][4 * g + 2] = hv[2];
         hn[rt][4 * g + 3] = hv[3];
       }
+  };
+
+  int cb[kCT4], cs[kCT4], ci[kCT4];
+  const unsigned char *bb = sh.bbuf;
+  v4i bf[4];  // B operands of the tile in flight; slice ks is refilled for the next tile as soon as both chains have consumed it
+
+  // max over the 16 accumulators of one chain: two interleaved v_max3 chains
+#define OSFM_TREE_A(X, A, B)             \
+  A = max(max(X[0], X[1]), X[2]);        \
+  B = max(max(X[8], X[9]), X[10]);
+#define OSFM_TREE_B(X, A, B)             \
+  A = max(max(A, X[3]), X[4]);           \
+  B = max(max(B, X[11]), X[12]);
+#define OSFM_TREE_C(X, A, B)             \
+  A = max(max(A, X[5]), X[6]);           \
+  B = max(max(B, X[13]), X[14]);
+#define OSFM_TREE_D(X, A, B, M)          \
+  M = max(max(A, B), X[7]);              \
+  M = max(M, X[15]);
+#define OSFM_PIN __builtin_amdgcn_sched_barrier(0);
+
+  // One step = this wave's 64 targets (af, hn) against the 8 query tiles of the chunk: 64 MFMAs.  Per tile two K chains (one per row
+  // tile) run interleaved on two of THREE accumulator tuples; the tuples of the previous tile are reduced in the issue gaps of the
+  // current one (an in-order wavefront hides about five plain VALU instructions behind a 32-cycle MFMA, MI355X_MICROARCH.md), and the
+  // first chain's tuple of tile t-1 becomes the second chain's tuple of tile t.  The class update of tile t-1 rides in the later gaps.
+  auto step = [&](const v4i (&af)[kRT][4], int rb, int next_slot, bool chunk_dma_in_flight) {
+    v16i T[3];
+    int mp = 0;
+#pragma unroll
+    for (int t = 0; t < kCT4; ++t) {
+      v16i &C1 = T[(2 * t) % 3];
+      v16i &C2 = T[(2 * t + 1) % 3];      // = chain 1 of tile t-1: reduced in the first gap
+      v16i &P2 = T[(2 * t + 2) % 3];      // = chain 2 of tile t-1
+      const unsigned char *nb = bb + ((t + 1) & (kCT4 - 1)) * OSFM_TILE_BYTES + lane * 16;  // tile 7 prefetches tile 0 (next step)
+      int a0 = 0, b0 = 0, a1 = 0, b1 = 0, m2 = 0;
+      C1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0][0], bf[0], hn[0], 0, 0, 0);
+      OSFM_PIN
+      if (t > 0) {
+        OSFM_TREE_A(C2, a0, b0)
+        OSFM_TREE_B(C2, a0, b0)
+        OSFM_TREE_C(C2, a0, b0)
+        OSFM_TREE_D(C2, a0, b0, mp)
+      }
+      OSFM_PIN
+      C2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[1][0], bf[0], hn[1], 0, 0, 0);
+      OSFM_PIN
+      if (t == kCT4 - 1) {
+        // the step's last seeded MFMAs are out: fetch the next step's seeds.  Their DMA is older than this step's 8 A-operand loads
+        // (and than the 8 DMAs of the next chunk, when those were issued in this step)
+        if (chunk_dma_in_flight)
+          __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * kRT * 4 + kCT4));  // vmcnt(16)
+        else
+          __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * kRT * 4));  // vmcnt(8)
+        read_seeds(next_slot);
+      }
+      bf[0] = *(const v4i *)(nb);
+      if (t > 0) { OSFM_TREE_A(P2, a1, b1) }
+      OSFM_PIN
+      C1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0][1], bf[1], C1, 0, 0, 0);
+      OSFM_PIN
+      if (t > 0) { OSFM_TREE_B(P2, a1, b1) }
+      OSFM_PIN
+      C2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[1][1], bf[1], C2, 0, 0, 0);
+      OSFM_PIN
+      bf[1] = *(const v4i *)(nb + 1024);
+      if (t > 0) { OSFM_TREE_C(P2, a1, b1) }
+      OSFM_PIN
+      C1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0][2], bf[2], C1, 0, 0, 0);
+      OSFM_PIN
+      if (t > 0) { OSFM_TREE_D(P2, a1, b1, m2) }
+      OSFM_PIN
+      C2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[1][2], bf[2], C2, 0, 0, 0);
+      OSFM_PIN
+      bf[2] = *(const v4i *)(nb + 2048);
+      if (t > 0) {
+        m2 = max(m2, mp);
+        asm("v_med3_i32 %0, %1, %2, %3" : "=v"(cs[t - 1]) : "v"(cb[t - 1]), "v"(m2), "v"(cs[t - 1]));  // cs <= cb: the second-largest of {cb, m, cs}
+      }
+      OSFM_PIN
+      C1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0][3], bf[3], C1, 0, 0, 0);
+      OSFM_PIN
+      if (t > 0) ci[t - 1] = m2 > cb[t - 1] ? rb : ci[t - 1];
+      OSFM_PIN
+      C2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[1][3], bf[3], C2, 0, 0, 0);
+      OSFM_PIN
+      bf[3] = *(const v4i *)(nb + 3072);
+      if (t > 0) cb[t - 1] = max(cb[t - 1], m2);
+      OSFM_PIN
+    }
+    {  // drain: the last tile's tuples
+      v16i &Q1 = T[(2 * (kCT4 - 1)) % 3];
+      v16i &Q2 = T[(2 * (kCT4 - 1) + 1) % 3];
+      int a0, b0, a1, b1, m1, m2;
+      OSFM_TREE_A(Q1, a0, b0)
+      OSFM_TREE_B(Q1, a0, b0)
+      OSFM_TREE_C(Q1, a0, b0)
+      OSFM_TREE_D(Q1, a0, b0, m1)
+      OSFM_TREE_A(Q2, a1, b1)
+      OSFM_TREE_B(Q2, a1, b1)
+      OSFM_TREE_C(Q2, a1, b1)
+      OSFM_TREE_D(Q2, a1, b1, m2)
+      m2 = max(m2, m1);
+      asm("v_med3_i32 %0, %1, %2, %3" : "=v"(cs[kCT4 - 1]) : "v"(cb[kCT4 - 1]), "v"(m2), "v"(cs[kCT4 - 1]));
+      ci[kCT4 - 1] = m2 > cb[kCT4 - 1] ? rb : ci[kCT4 - 1];
+      cb[kCT4 - 1] = max(cb[kCT4 - 1], m2);
     }
   };
 
   dma_chunk(0);
-  v4i afrag[kRT][4], anext[kRT][4];
-  v16i hinit[kRT], hnext[kRT];
-  load_targets(0, afrag, hinit);
+  // two register sets for the A operands: the step that computes on one set fetches the next step's targets into the other
+  v4i afA[kRT][4], afB[kRT][4];
+  load_targets(0, afA, 0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): chunk 0, the first targets and their seeds
+  read_seeds(0);
+  int sidx = 0;  // global step counter: the seeds of step s are staged in slot s & 1
 
   for (int c = 0; c < nchunks; ++c) {
     // the query this thread decides at the end of the chunk (slot c*256 + tid): its norm, fetched now
     const int myslot = c * kChunkCols4 + tid;
     const int myf = myslot < nslots ? (GATHER ? (int)qsel[myslot] : myslot) : -1;
     const int myna = (myf >= 0 && myf < nQ) ? normQ[myf] : OSFM_PAD_NORM;
-    if (c + 1 < nchunks) dma_chunk(c + 1);  // its buffer was released by the merge of chunk c - 1
-    // chunk c has landed once all but the newest kCT4 DMAs of this thread have (the first chunk: all of them)
-    if (c + 1 < nchunks)
-      __builtin_amdgcn_s_waitcnt(0x0070 | (kCT4 & 15) | (((kCT4 >> 4) & 3) << 14));  // vmcnt(kCT4), keep lgkm/exp
-    else
-      __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0)
+    // chunk c was requested during the first step of chunk c - 1 (chunk 0: above); everything this thread has in flight is older
+    // than what the coming step will issue
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     __syncthreads();
-    const unsigned char *bb = sh.bbuf + (c & 1) * kChunkBytes4;
-
-    int cb[kCT4], cs[kCT4], ci[kCT4];
+    bb = sh.bbuf + (c & 1) * kChunkBytes4;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) bf[ks] = *(const v4i *)(bb + ks * 1024 + lane * 16);
 #pragma unroll
     for (int t = 0; t < kCT4; ++t) {
       cb[t] = INT_MIN;
@@ -582,59 +389,35 @@ __device__ __forceinline__ int query_pass(const QueryPassShared &sh, const int8_
       ci[t] = 0;
     }
 
-    for (int rb = 0; rb < nrb; ++rb) {
-      // next step's targets, one step ahead (the next chunk starts over at row block 0)
-      {
-        const int rbn = (rb + 1 < nrb) ? rb + 1 : 0;
-        if (rb + 1 < nrb || c + 1 < nchunks) load_targets(rbn, anext, hnext);
+    // steps come in pairs: the first computes on set A and fetches into set B, the second the other way round; an odd last step
+    // computes on A and then moves B (the next chunk's first targets) to A, so that every chunk starts on set A
+    auto one_step = [&](const v4i (&cur)[kRT][4], v4i (&nxt)[kRT][4], int rb) {
+      const int rbn = (rb + 1 < nrb) ? rb + 1 : 0;  // the next chunk starts over at row block 0 (the very last prefetch is unused)
+      const bool live = rb * (kWaves * kRT) + w * kRT < tT;
+      const bool dma = (rb == 0) && (c + 1 < nchunks);
+      const int nslot = (sidx + 1) & 1;
+      load_targets(rbn, nxt, nslot);
+      if (dma) dma_chunk(c + 1);  // its buffer was released by the merge of chunk c - 1
+      if (live) {
+        step(cur, rb, nslot, dma);
+      } else {  // a wave without targets in this row block still has to pick up the next step's seeds
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        read_seeds(nslot);
       }
-      const int t0 = rb * (kWaves * kRT) + w * kRT;
-      if (t0 < tT) {
-        v4i bf[2][4];
+      ++sidx;
+    };
+    int rb = 0;
+    for (; rb + 1 < nrb; rb += 2) {
+      one_step(afA, afB, rb);
+      one_step(afB, afA, rb + 1);
+    }
+    if (rb < nrb) {
+      one_step(afA, afB, rb);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) bf[0][ks] = *(const v4i *)(bb + ks * 1024 + lane * 16);
+      for (int rt = 0; rt < kRT; ++rt)
 #pragma unroll
-        for (int t = 0; t < kCT4; ++t) {
-          const int cur = t & 1;
-          if (t + 1 < kCT4) {
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) bf[cur ^ 1][ks] = *(const v4i *)(bb + (t + 1) * OSFM_TILE_BYTES + ks * 1024 + lane * 16);
-          }
-          v16i acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[0][0], bf[cur][0], hinit[0], 0, 0, 0);
-          v16i acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[1][0], bf[cur][0], hinit[1], 0, 0, 0);
-#pragma unroll
-          for (int ks = 1; ks < 4; ++ks) {
-            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[0][ks], bf[cur][ks], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[1][ks], bf[cur][ks], acc1, 0, 0, 0);
-          }
-          // max over the 32 targets of this lane: four independent v_max3 chains, then the class update
-          int m0 = max(max(acc0[0], acc0[1]), acc0[2]), m1 = max(max(acc0[8], acc0[9]), acc0[10]);
-          int m2 = max(max(acc1[0], acc1[1]), acc1[2]), m3 = max(max(acc1[8], acc1[9]), acc1[10]);
-          m0 = max(max(m0, acc0[3]), acc0[4]);
-          m1 = max(max(m1, acc0[11]), acc0[12]);
-          m2 = max(max(m2, acc1[3]), acc1[4]);
-          m3 = max(max(m3, acc1[11]), acc1[12]);
-          m0 = max(max(m0, acc0[5]), acc0[6]);
-          m1 = max(max(m1, acc0[13]), acc0[14]);
-          m2 = max(max(m2, acc1[5]), acc1[6]);
-          m3 = max(max(m3, acc1[13]), acc1[14]);
-          m0 = max(max(m0, acc0[7]), acc0[15]);
-          m2 = max(max(m2, acc1[7]), acc1[15]);
-          const int m = max(max(m0, m1), max(m2, m3));
-          asm("v_med3_i32 %0, %1, %2, %3" : "=v"(cs[t]) : "v"(cb[t]), "v"(m), "v"(cs[t]));  // cs <= cb: the second-largest of {cb, m, cs}
-          ci[t] = m > cb[t] ? rb : ci[t];
-          cb[t] = max(cb[t], m);
-        }
-      }
-      if (rb + 1 < nrb || c + 1 < nchunks) {
-#pragma unroll
-        for (int rt = 0; rt < kRT; ++rt) {
-          hinit[rt] = hnext[rt];
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) afrag[rt][ks] = anext[rt][ks];
-        }
-      }
-    }  // row blocks
+        for (int ks = 0; ks < 4; ++ks) afA[rt][ks] = afB[rt][ks];
+    }
 
     // ---- end of the chunk: merge the 8 partial classes (4 waves x 2 halves) of every query, decide, re-examine ----
     __syncthreads();  // everyone is done reading the chunk: its buffer becomes the scratch
@@ -665,64 +448,113 @@ __device__ __forceinline__ int query_pass(const QueryPassShared &sh, const int8_
       const int d1lo = max(myna - (2 * b + 1), 0), d2hi = myna - 2 * s2;
       if (d2hi >= kCollisionD2 && ratio >= 0.0) flag = 1;  // squared mode never takes a square root
       want = ratio_ok(d1lo, d2hi, ratio);
+#ifdef OSFM_DBG_NORECHECK
+      want = false;
+#endif
       if (!want) out[myf] = kNone;
     }
+    // ---- re-examination, four queries at a time: one query per 16-lane row, two of the winner class's 32 targets per lane.  The
+    //      candidates travel as packed keys v * 32 + (31 - ordinal) (ordinal = position in ascending target order), so one max
+    //      gives the winner with cv2's lowest-index rule and a second max the runner-up; both are DPP reductions inside the row.
     unsigned long long pending = __ballot(want);
+    unsigned long long redo = 0;  // queries that have to be re-done against all targets
     while (pending) {
-      const int src = __builtin_ctzll(pending);
-      pending &= pending - 1;
-      const int qf = __shfl(myf, src), qna = __shfl(myna, src), qb = __shfl(b, src), qs = __shfl(s2, src), qid = __shfl(id, src);
-      bool full = (qs == qb);  // two classes tie on u: the winner may sit in either
-      int win = kNone;
-      if (!full) {
-        const int qrb = qid >> 3, qw = (qid >> 1) & 3, qh = qid & 1;
-        const int rtl = (lane >> 4) & 1, r = lane & 15;
-        const int row = (qrb * (kWaves * kRT) + qw * kRT + rtl) * 32 + (r & 3) + 8 * (r >> 2) + 4 * qh;
-        int v = INT_MIN;
-        if (lane < 32 && row < nT) v = 2 * dot_rows8(tilesQ, qf, tilesT, row) - normT[row];
-        const int m1 = wave_max(v);
-        const int jwin = -wave_max(v == m1 ? -row : INT_MIN);  // lowest index among equals (cv2's rule)
-        const int m2 = wave_max((lane < 32 && row != jwin) ? v : INT_MIN);
-        const int sa = max(m2, 2 * qs), sb = max(m2, 2 * qs + 1);
-        const bool ra = ratio_ok(qna - m1, qna - sa, ratio), rbb = ratio_ok(qna - m1, qna - sb, ratio);
-        if (ra == rbb)
-          win = ra ? jwin : kNone;
-        else
-          full = true;  // the decision hangs on the parity bit of a norm in another class
+      int srcs[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        srcs[g] = pending ? (int)__builtin_ctzll(pending) : -1;
+        pending &= pending - 1;  // 0 stays 0
       }
-      if (full) {
-        int lv = INT_MIN, lj = INT_MAX, ls = INT_MIN;
-        for (int i = lane; i < nT; i += 64) {
-          const int v = 2 * dot_rows8(tilesQ, qf, tilesT, i) - normT[i];
-          ls = max(ls, min(lv, v));
-          if (v > lv) {  // ascending i within a lane: the first maximum is the lowest index
-            lv = v;
-            lj = i;
-          }
+      const int g = lane >> 4, sl = lane & 15;
+      const int src = g == 0 ? srcs[0] : g == 1 ? srcs[1] : g == 2 ? srcs[2] : srcs[3];
+      const int ssrc = src < 0 ? 0 : src;
+      const int qf = __shfl(myf, ssrc), qna = __shfl(myna, ssrc), qb = __shfl(b, ssrc), qs = __shfl(s2, ssrc), qid = __shfl(id, ssrc);
+      const bool tie = (qs == qb);  // two classes tie on u: the winner may sit in either
+      const int qrb = qid >> 3, qw = (qid >> 1) & 3, qh = qid & 1;
+      const int row0 = (qrb * (kWaves * kRT) + qw * kRT) * 32 + (sl & 3) + 8 * (sl >> 2) + 4 * qh, row1 = row0 + 32;
+      int k0 = INT_MIN, k1 = INT_MIN;
+      if (src >= 0 && !tie) {
+        const int8_t *pa = tilesQ + (long)(qf >> 5) * OSFM_TILE_BYTES + (qf & 31) * 16;
+        const int8_t *p0 = tilesT + (long)(row0 >> 5) * OSFM_TILE_BYTES + (row0 & 31) * 16;
+        const int8_t *p1 = tilesT + (long)(row1 >> 5) * OSFM_TILE_BYTES + (row1 & 31) * 16;
+        const bool ok0 = row0 < nT, ok1 = row1 < nT;
+        v4i av[8], bv0[8], bv1[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          av[q] = *(const v4i *)(pa + q * 512);
+          bv0[q] = ok0 ? *(const v4i *)(p0 + q * 512) : av[q];
+          bv1[q] = ok1 ? *(const v4i *)(p1 + q * 512) : av[q];
         }
-        const int m1 = wave_max(lv);
-        const int jwin = -wave_max(lv == m1 ? -lj : INT_MIN);
-        const int m2 = wave_max(lj == jwin ? ls : lv);
-        win = ratio_ok(qna - m1, qna - m2, ratio) ? jwin : kNone;
+        const int n0 = ok0 ? normT[row0] : 0, n1 = ok1 ? normT[row1] : 0;
+        int s0 = 0, s1 = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            s0 = __builtin_amdgcn_sdot4(av[q][e], bv0[q][e], s0, false);
+            s1 = __builtin_amdgcn_sdot4(av[q][e], bv1[q][e], s1, false);
+          }
+        if (ok0) k0 = (2 * s0 - n0) * 32 + (31 - sl);
+        if (ok1) k1 = (2 * s1 - n1) * 32 + (15 - sl);
       }
-      if (lane == 0) out[qf] = (unsigned short)win;
+      const int kmax = row16_max(max(k0, k1));
+      const int ksec = row16_max(k0 == kmax ? k1 : (k1 == kmax ? k0 : max(k0, k1)));
+      if (src >= 0) {
+        bool full = tie;
+        int win = kNone;
+        if (!tie) {
+          const int m1 = kmax >> 5, ord = 31 - (kmax & 31);
+          const int jwin = (qrb * (kWaves * kRT) + qw * kRT + (ord >> 4)) * 32 + (ord & 3) + 8 * ((ord & 15) >> 2) + 4 * qh;
+          const int m2 = ksec >> 5;  // INT_MIN >> 5 when the class has a single target: far below any bound
+          const int sa = max(m2, 2 * qs), sb = max(m2, 2 * qs + 1);
+          const bool ra = ratio_ok(qna - m1, qna - sa, ratio), rbb = ratio_ok(qna - m1, qna - sb, ratio);
+          if (ra == rbb)
+            win = ra ? jwin : kNone;
+          else
+            full = true;  // the decision hangs on the parity bit of a norm in another class
+        }
+        if (sl == 0 && !full) out[qf] = (unsigned short)win;
+        redo |= (full && sl == 0) ? (1ull << src) : 0ull;
+      }
+    }
+    // the rare queries whose decision needs every target: exact best (lowest index among equals) and exact second, by the whole wave
+    {
+      unsigned lo = (unsigned)redo, hi = (unsigned)(redo >> 32);
+#pragma unroll
+      for (int m = 32; m >= 16; m >>= 1) {  // lanes 0, 16, 32, 48 hold the bits of their rows
+        lo |= (unsigned)__shfl_xor((int)lo, m);
+        hi |= (unsigned)__shfl_xor((int)hi, m);
+      }
+      redo = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)hi) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)lo);
+    }
+    while (redo) {
+      const int src = __builtin_ctzll(redo);
+      redo &= redo - 1;
+      const int qf = __shfl(myf, src), qna = __shfl(myna, src);
+      int lv = INT_MIN, lj = INT_MAX, ls = INT_MIN;
+      for (int i = lane; i < nT; i += 64) {
+        const int v = 2 * dot_rows8(tilesQ, qf, tilesT, i) - normT[i];
+        ls = max(ls, min(lv, v));
+        if (v > lv) {  // ascending i within a lane: the first maximum is the lowest index
+          lv = v;
+          lj = i;
+        }
+      }
+      const int m1 = wave_max(lv);
+      const int jwin = -wave_max(lv == m1 ? -lj : INT_MIN);
+      const int m2 = wave_max(lj == jwin ? ls : lv);
+      if (lane == 0) out[qf] = (unsigned short)(ratio_ok(qna - m1, qna - m2, ratio) ? jwin : kNone);
     }
   }  // chunks
   __syncthreads();
   return flag;
 }
 
-__global__ void __launch_bounds__(kThreads, 2) match_fused4_kernel(MatchArgs a) {
+__global__ void __launch_bounds__(kThreads, 2) match_fused_kernel(MatchArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-#ifdef OSFM_MATCH_V4
-  RowPassShared sh;
-  sh.bbuf = smem;                                                  // [2][32 KiB]
-  sh.nbuf = (int *)(smem + 2 * kChunkBytes4);                       // [2][256]
-  sh.pad_norm = a.pad_norm;
-#else
   QueryPassShared sh;
-  sh.bbuf = smem;  // [2][32 KiB]
-#endif
+  sh.bbuf = smem;                               // [2][32 KiB]
+  sh.hbuf = (int *)(smem + 2 * kChunkBytes4);  // [2][256]
   int *misc = (int *)(smem + 2 * kChunkBytes4) + 2 * kChunkCols4;  // [16]
   unsigned short *resA = (unsigned short *)(misc + 16);            // [ncap] per feature of image A
   unsigned short *resB = resA + a.ncap;                            // [ncap] per feature of image B
@@ -750,6 +582,8 @@ __global__ void __launch_bounds__(kThreads, 2) match_fused4_kernel(MatchArgs a) 
   const int32_t *normB = a.norms + a.tile_off[imgB] * 32;
   const int32_t *hnegA = a.hneg + a.tile_off[imgA] * 32;
   const int32_t *hnegB = a.hneg + a.tile_off[imgB] * 32;
+  const int8_t *tiles_pad = a.tiles + a.pad_tile * OSFM_TILE_BYTES;  // the store's first slack tile: zero descriptors, padding norms
+  const int32_t *hneg_pad = a.hneg + a.pad_tile * 32;
 
   for (int j = tid; j < a.ncap; j += kThreads) {
     resA[j] = kNone;
@@ -760,13 +594,7 @@ __global__ void __launch_bounds__(kThreads, 2) match_fused4_kernel(MatchArgs a) 
     misc[9] = 0;
   }
   __syncthreads();
-#ifdef OSFM_MATCH_V4
-  int flag = row_pass<false>(sh, tilesA, normA, nA, nA, nullptr, tilesB, normB, nB, resA, a.ratio, tid);
-  (void)hnegA;
-  (void)hnegB;
-#else
-  int flag = query_pass<false>(sh, tilesA, normA, nA, nA, nullptr, tilesB, normB, hnegB, nB, resA, a.ratio, tid);
-#endif
+  int flag = query_pass<false>(sh, tilesA, normA, nA, nA, nullptr, tilesB, normB, hnegB, nB, tiles_pad, hneg_pad, resA, a.ratio, tid);
   if (a.symmetric) {
     // candidates: the features of B that some row of A chose.  resB doubles as the mark array
     // (0 = chosen) until the candidate list is built, in ascending feature order.
@@ -797,11 +625,7 @@ __global__ void __launch_bounds__(kThreads, 2) match_fused4_kernel(MatchArgs a) 
       __syncthreads();
     }
     const int nK = base;
-#ifdef OSFM_MATCH_V4
-    if (nK > 0) flag |= row_pass<true>(sh, tilesB, normB, nB, nK, cand, tilesA, normA, nA, resB, a.ratio, tid);
-#else
-    if (nK > 0) flag |= query_pass<true>(sh, tilesB, normB, nB, nK, cand, tilesA, normA, hnegA, nA, resB, a.ratio, tid);
-#endif
+    if (nK > 0) flag |= query_pass<true>(sh, tilesB, normB, nB, nK, cand, tilesA, normA, hnegA, nA, tiles_pad, hneg_pad, resB, a.ratio, tid);
   }
   if (flag) misc[8] = 1;
   __syncthreads();
@@ -923,12 +747,12 @@ __global__ void __launch_bounds__(kThreads) match_exact_kernel(MatchArgs a, int 
 
 }  // namespace
 
-size_t osfm_match4_lds_bytes(int ncap) { return (size_t)2 * kChunkBytes4 + 2 * kChunkCols4 * 4 + 64 + (size_t)ncap * 6; }
+size_t osfm_match_lds_bytes(int ncap) { return (size_t)2 * kChunkBytes4 + 2 * kChunkCols4 * 4 + 64 + (size_t)ncap * 6; }
 
 static int ensure_kernel_attributes(int device) {
   static OsfmPerDeviceOnce once;
   return once.run(device, []() -> int {
-    OSFM_HIP(hipFuncSetAttribute((const void *)match_fused4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    OSFM_HIP(hipFuncSetAttribute((const void *)match_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     OSFM_HIP(hipFuncSetAttribute((const void *)match_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     return OSFM_OK;
   });
@@ -957,7 +781,7 @@ int osfm_launch_match(osfm_ctx *ctx, const osfm_store *store, const int32_t *d_p
   a.out_counts = d_counts;
   a.out_matches = d_matches;
   a.out_flags = d_flags;
-  a.pad_norm = store->d_norms + store->tile_off[store->n_images] * 32;  // first slack row: padding norm
+  a.pad_tile = store->tile_off[store->n_images];
   OSFM_REQUIRE(a.ncap <= OSFM_MAX_FEATURES, OSFM_E_UNSUPPORTED, "more than %d features in an image", OSFM_MAX_FEATURES);
   OSFM_REQUIRE(n_pairs < (1ll << 31), OSFM_E_INVALID, "too many pairs in one launch");
   {
@@ -965,7 +789,7 @@ int osfm_launch_match(osfm_ctx *ctx, const osfm_store *store, const int32_t *d_p
     if (rc != OSFM_OK) return rc;
   }
   if (!exact_kernel) {
-    hipLaunchKernelGGL(match_fused4_kernel, dim3((unsigned)n_pairs), dim3(kThreads), osfm_match4_lds_bytes(a.ncap), stream, a);
+    hipLaunchKernelGGL(match_fused_kernel, dim3((unsigned)n_pairs), dim3(kThreads), osfm_match_lds_bytes(a.ncap), stream, a);
   } else {
     const size_t lds = (size_t)a.ncap * 6 + 64;
     hipLaunchKernelGGL(match_exact_kernel, dim3((unsigned)n_pairs), dim3(kThreads), lds, stream, a, d_flags != nullptr ? 1 : 0);

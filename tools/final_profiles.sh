@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-end measurement: full bench under rocprofv3 kernel trace, then separate PMC passes over the
-# matching-only bench (1 step) for the HBM traffic of match_fused4_kernel.
+# matching-only bench (1 step) for the HBM traffic of match_fused_kernel.
 cd /tmp && export TMPDIR=/tmp
 OUT=/root/repo/gpurun_out/final
 mkdir -p $OUT

@@ -1,5 +1,5 @@
 """rocprofv3 --pmc databases of `bench.py` (one pass with FETCH_SIZE, one with WRITE_SIZE) -> profiles/r02_match_pmc.json: HBM bytes
-per launch of match_fused4_kernel.  FETCH_SIZE is doubled (MI355X_MICROARCH.md, HBM section: on gfx950 it reports half of the bytes of
+per launch of match_fused_kernel.  FETCH_SIZE is doubled (MI355X_MICROARCH.md, HBM section: on gfx950 it reports half of the bytes of
 wide coalesced reads); FETCH_SIZE / WRITE_SIZE are in KiB... the unit is taken from the counter description: kilobytes.
 usage: pmc_to_json.py <fetch.db> <write.db> <pairs_per_launch> <out.json>"""
 import collections, json, sqlite3, sys
@@ -29,9 +29,9 @@ def per_call(path, kernel_substr, counter):
 
 def main():
     fetch_db, write_db, ppl, out = sys.argv[1], sys.argv[2], float(sys.argv[3]), sys.argv[4]
-    f, nf = per_call(fetch_db, 'match_fused4_kernel', 'FETCH_SIZE')
-    w, nw = per_call(write_db, 'match_fused4_kernel', 'WRITE_SIZE')
-    json.dump({"kernel": "match_fused4_kernel", "pairs_per_launch": ppl, "launches_sampled": [nf, nw],
+    f, nf = per_call(fetch_db, 'match_fused_kernel', 'FETCH_SIZE')
+    w, nw = per_call(write_db, 'match_fused_kernel', 'WRITE_SIZE')
+    json.dump({"kernel": "match_fused_kernel", "pairs_per_launch": ppl, "launches_sampled": [nf, nw],
                "fetch_size_kb_raw": f, "write_size_kb_raw": w,
                "fetch_bytes_corrected": 2.0 * f * 1024.0, "write_bytes": w * 1024.0,
                "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `python bench.py --steps 1 --warmup 0 --no-ba --no-tracks "
