@@ -619,3 +619,42 @@ def match_brute_force_masked(f1, f2, mask, ratio: float = 0.8, symmetric: bool =
     good = good[: len(f1)]
     i = np.flatnonzero(good >= 0)
     return np.stack([i, good[i]], axis=1).astype(np.int32)
+
+
+def match_words(f1, w1, f2, w2, ratio: float = 0.8, max_checks: int = 20) -> np.ndarray:
+    """pyfeatures.match_using_words(f1, words1, f2, words2[:, 0], ratio, checks) (features/src/matching.cc:24-88): (m, 2) int32"""
+    f1 = np.ascontiguousarray(f1, np.float32)
+    f2 = np.ascontiguousarray(f2, np.float32)
+    w1 = np.ascontiguousarray(np.asarray(w1, np.int32).reshape(len(f1), -1))
+    w2 = np.ascontiguousarray(np.asarray(w2, np.int32).reshape(-1))
+    out = np.zeros((max(len(f1), 1), 2), np.int32)
+    f = lib().oracle_match_words
+    f.restype = C.c_int
+    n = f(_p(f1, C.c_float), _p(w1, C.c_int32), len(f1), w1.shape[1] if len(f1) else 0, _p(f2, C.c_float), _p(w2, C.c_int32), len(f2),
+          f1.shape[1] if f1.ndim == 2 else 0, C.c_float(ratio), int(max_checks), _p(out, C.c_int32))
+    return out[:n].copy()
+
+
+def match_words_symmetric(f1, w1, f2, w2, ratio: float = 0.8, max_checks: int = 20):
+    """matching.match_words_symmetric (matching.py:659-680) as a sorted list of (i, j)"""
+    w1 = np.asarray(w1, np.int32).reshape(len(f1), -1)
+    w2 = np.asarray(w2, np.int32).reshape(len(f2), -1)
+    ij = {(int(a), int(b)) for a, b in match_words(f1, w1, f2, w2[:, 0], ratio, max_checks)}
+    ji = {(int(b), int(a)) for a, b in match_words(f2, w2, f1, w1[:, 0], ratio, max_checks)}
+    return sorted(ij & ji)
+
+
+def vlad_descriptor(features, centers) -> np.ndarray:
+    features = np.ascontiguousarray(features, np.float32)
+    centers = np.ascontiguousarray(centers, np.float32)
+    out = np.zeros(centers.size, np.float32)
+    lib().oracle_vlad_descriptor(_p(features, C.c_float), len(features), _p(centers, C.c_float), len(centers), centers.shape[1], _p(out, C.c_float))
+    return out
+
+
+def vlad_distances(ref, others) -> np.ndarray:
+    ref = np.ascontiguousarray(ref, np.float32)
+    others = np.ascontiguousarray(others, np.float32).reshape(-1, len(ref))
+    out = np.zeros(len(others), np.float64)
+    lib().oracle_vlad_distances(_p(ref, C.c_float), _p(others, C.c_float), len(others), len(ref), _p(out, C.c_double))
+    return out

@@ -13,4 +13,5 @@ python /root/repo/tools/pmc_to_json.py $(ls $OUT/pmc_fetch/*.db $OUT/pmc_fetch/*
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_prof.json 2> $OUT/bench_prof.err
 python /root/repo/tools/rocpd_summary.py $(ls $OUT/trace/*.db $OUT/trace/*/*.db 2>/dev/null | head -1) > $OUT/bench_rocprof_stats.txt 2>&1
 head -40 $OUT/bench_rocprof_stats.txt
+timeout 900 python /root/repo/bench.py --full-parity --steps 1 --warmup 0 --no-ba --no-tracks --no-overlap --no-calibrated > $OUT/bench_full_parity.json 2> $OUT/bench_full_parity.err; tail -c 1200 $OUT/bench_full_parity.json
 rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/trace
