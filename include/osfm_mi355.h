@@ -400,6 +400,36 @@ int osfm_match_guided(osfm_ctx *ctx, const float *f1, int n1, const float *f2, i
                       const float *b1, const float *b2, const double *R, const double *t, double threshold, double ratio,
                       int symmetric, int32_t *out_pairs, int cap, int *out_n);
 
+/* =====================================================================================
+ * Bag-of-words side of pair matching and pair preselection.
+ *
+ * osfm_words_store / osfm_match_words_pairs  replace pyfeatures.match_using_words (opensfm/src/features/src/matching.cc:24-88) as
+ *   matching.match_words / match_words_symmetric call it (opensfm/matching.py:637-680), for a whole pair list: descriptors
+ *   (float32, total x 128) and the n closest vocabulary words of every feature (int32, total x words_per_feature, data.load_words)
+ *   are uploaded once; per pair, every feature of one image checks the features of the other image filed under its words, in word
+ *   order, stopping after the word that brings the count to max_checks; Lowe's test best < ratio * second in float; symmetric = the
+ *   intersection of both directions.  counts[p] matches (i, j) of pair p land in matches[(p * max_count + k) * 2 ..], ordered by i
+ *   (the reference returns them in set order, i.e. unspecified), max_count = osfm_words_store_max_count.
+ * osfm_vlad_descriptor  replaces pyfeatures.compute_vlad_descriptor (matching.cc:93-124; the caller normalises, vlad.py);
+ * osfm_vlad_distances   replaces the distance loop of compute_vlad_distances (matching.cc:126-152): L2 norms of reference - others[j];
+ * osfm_knn_points / osfm_radius_points  replace spatial.cKDTree(points).query(point, k, distance_upper_bound) of
+ *   match_candidates_by_distance (opensfm/pairs_selection.py:188-212): the k nearest candidates within max_distance in ascending
+ *   distance (missing: index -1, distance inf), or -- when k covers every candidate -- the bit mask of the candidates within range.
+ * ===================================================================================== */
+typedef struct osfm_words_store osfm_words_store;
+int osfm_words_store_create(osfm_ctx *ctx, int n_images, const int32_t *counts, int dim, int words_per_feature, const float *desc,
+                            const int32_t *words, osfm_words_store **out);
+void osfm_words_store_destroy(osfm_words_store *s);
+int osfm_words_store_max_count(const osfm_words_store *s);
+int osfm_match_words_pairs(osfm_ctx *ctx, const osfm_words_store *store, const int32_t *pairs, int64_t n_pairs, float lowes_ratio,
+                           int max_checks, int symmetric, int32_t *counts, int32_t *matches, double *kernel_ms);
+int osfm_vlad_descriptor(osfm_ctx *ctx, const float *features, int n, const float *centers, int n_centers, int dim, float *out);
+int osfm_vlad_distances(osfm_ctx *ctx, const float *reference, const float *others, int m, int len, double *out);
+int osfm_knn_points(osfm_ctx *ctx, const double *candidates, int n_candidates, const double *queries, int n_queries, int k,
+                    double max_distance, double *out_distance, int32_t *out_index);
+int osfm_radius_points(osfm_ctx *ctx, const double *candidates, int n_candidates, const double *queries, int n_queries,
+                       double max_distance, uint32_t *out_mask);
+
 #ifdef __cplusplus
 }
 #endif

@@ -124,6 +124,17 @@ SIGNATURES = {
          C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_double, C.c_int, C.POINTER(C.c_int32), C.c_int,
          C.POINTER(C.c_int)],
     ),
+    "osfm_words_store_create": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int32),
+                                          C.POINTER(C.c_void_p)]),
+    "osfm_words_store_destroy": (None, [C.c_void_p]),
+    "osfm_words_store_max_count": (C.c_int, [C.c_void_p]),
+    "osfm_match_words_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int64, C.c_float, C.c_int, C.c_int, C.POINTER(C.c_int32),
+                                         C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
+    "osfm_vlad_descriptor": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "osfm_vlad_distances": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "osfm_knn_points": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_double,
+                                  C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    "osfm_radius_points": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_int, C.c_double, C.POINTER(C.c_uint32)]),
     "osfm_ransac_fundamental": (
         C.c_int,
         [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.c_double, C.c_double, C.c_int,

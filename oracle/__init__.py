@@ -625,7 +625,8 @@ def match_words(f1, w1, f2, w2, ratio: float = 0.8, max_checks: int = 20) -> np.
     """pyfeatures.match_using_words(f1, words1, f2, words2[:, 0], ratio, checks) (features/src/matching.cc:24-88): (m, 2) int32"""
     f1 = np.ascontiguousarray(f1, np.float32)
     f2 = np.ascontiguousarray(f2, np.float32)
-    w1 = np.ascontiguousarray(np.asarray(w1, np.int32).reshape(len(f1), -1))
+    f1, f2 = f1.reshape(-1, 128), f2.reshape(-1, 128)
+    w1 = np.ascontiguousarray(np.asarray(w1, np.int32).reshape(len(f1), -1)) if len(f1) else np.zeros((0, 1), np.int32)
     w2 = np.ascontiguousarray(np.asarray(w2, np.int32).reshape(-1))
     out = np.zeros((max(len(f1), 1), 2), np.int32)
     f = lib().oracle_match_words
@@ -637,8 +638,8 @@ def match_words(f1, w1, f2, w2, ratio: float = 0.8, max_checks: int = 20) -> np.
 
 def match_words_symmetric(f1, w1, f2, w2, ratio: float = 0.8, max_checks: int = 20):
     """matching.match_words_symmetric (matching.py:659-680) as a sorted list of (i, j)"""
-    w1 = np.asarray(w1, np.int32).reshape(len(f1), -1)
-    w2 = np.asarray(w2, np.int32).reshape(len(f2), -1)
+    w1 = np.asarray(w1, np.int32).reshape(len(f1), -1) if len(f1) else np.zeros((0, 1), np.int32)
+    w2 = np.asarray(w2, np.int32).reshape(len(f2), -1) if len(f2) else np.zeros((0, 1), np.int32)
     ij = {(int(a), int(b)) for a, b in match_words(f1, w1, f2, w2[:, 0], ratio, max_checks)}
     ji = {(int(b), int(a)) for a, b in match_words(f2, w2, f1, w1[:, 0], ratio, max_checks)}
     return sorted(ij & ji)

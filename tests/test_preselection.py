@@ -1,0 +1,221 @@
+"""Host logic of pair preselection (opensfm_amd/preselection.py) against the reference's own pairs_selection.py, executed from
+/root/reference with its compiled / cv2 dependencies stubbed.  The neighbour search itself (a HIP kernel in the product) is replaced
+by scipy's kd-tree here; tests/test_gpu_words.py checks the kernels against the same kd-tree on the GPU."""
+import importlib.util
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+from scipy import spatial
+from scipy.spatial.transform import Rotation
+
+from opensfm_amd import preselection
+from opensfm_amd.geometry_types import TopocentricConverter
+
+REF = "/root/reference/opensfm"
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="/root/reference is not mounted")
+
+
+class _Stub(types.ModuleType):
+    def __getattr__(self, name):
+        raise AttributeError(name)
+
+
+@pytest.fixture(scope="module")
+def refps():
+    saved = {k: sys.modules.get(k) for k in list(sys.modules) if k == "opensfm" or k.startswith("opensfm.")}
+    pkg = _Stub("opensfm")
+    pkg.__path__ = [REF]
+    mods = {"opensfm": pkg}
+    for name in ("bow", "context", "feature_loader", "geo", "geometry", "vlad", "dataset_base"):
+        mods["opensfm." + name] = _Stub("opensfm." + name)
+    mods["opensfm.dataset_base"].DataSetBase = object
+    mods["opensfm.geo"].TopocentricConverter = TopocentricConverter
+
+    def rotation_from_opk(omega, phi, kappa):  # geometry.py:72-91 with scipy in place of cv2.Rodrigues
+        Rw = Rotation.from_rotvec([-omega, 0, 0]).as_matrix()
+        Rp = Rotation.from_rotvec([0, -phi, 0]).as_matrix()
+        Rk = Rotation.from_rotvec([0, 0, -kappa]).as_matrix()
+        return np.array([[1, 0, 0], [0, -1, 0], [0, 0, -1]]) @ Rk @ Rp @ Rw
+
+    mods["opensfm.geometry"].rotation_from_opk = rotation_from_opk
+    for name, m in mods.items():
+        sys.modules[name] = m
+        if "." in name:
+            setattr(pkg, name.split(".")[1], m)
+    spec = importlib.util.spec_from_file_location("opensfm.pairs_selection", os.path.join(REF, "pairs_selection.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["opensfm.pairs_selection"] = mod
+    spec.loader.exec_module(mod)
+    yield mod
+    for k in [k for k in sys.modules if k == "opensfm" or k.startswith("opensfm.")]:
+        del sys.modules[k]
+    sys.modules.update({k: v for k, v in saved.items() if v is not None})
+
+
+def kdtree_neighbours(points, queries, k_of_query, max_distance):
+    tree = spatial.cKDTree(points)
+    out = []
+    for q, k in zip(queries, k_of_query):
+        _, idx = tree.query(q, k=int(k), distance_upper_bound=max_distance)
+        idx = np.atleast_1d(idx)
+        out.append(idx[idx < len(points)])
+    return out
+
+
+@pytest.fixture()
+def host_search(monkeypatch):
+    monkeypatch.setattr(preselection, "_neighbours", kdtree_neighbours)
+
+
+def make_exifs(n, seed, opk=False, spread=300.0):
+    rng = np.random.default_rng(seed)
+    exifs = {}
+    for i in range(n):
+        e = {"gps": {"latitude": 45.0 + rng.uniform(-1, 1) * spread / 111000.0, "longitude": 7.0 + rng.uniform(-1, 1) * spread / 78000.0, "altitude": 200.0},
+             "capture_time": 1.6e9 + float(rng.integers(0, 5000)) + i * 1e-3, "camera": "cam%d" % (i % 3)}
+        if opk:
+            e["opk"] = {"omega": float(rng.uniform(-10, 10)), "phi": float(rng.uniform(-10, 10)), "kappa": float(rng.uniform(-180, 180))}
+        exifs["im%03d.jpg" % i] = e
+    return exifs
+
+
+@pytest.mark.parametrize("opk", [False, True])
+def test_representative_points(refps, opk):
+    exifs = make_exifs(40, 1, opk)
+    reference = TopocentricConverter(45.0, 7.0, 0.0)
+    images = sorted(exifs)
+    mine = preselection.get_representative_points(images, exifs, reference)
+    theirs = refps.get_representative_points(images, exifs, reference)
+    assert set(mine) == set(theirs)
+    for k in mine:
+        assert np.allclose(mine[k], theirs[k], rtol=1e-9, atol=1e-6)
+    exifs["im000.jpg"]["ypr"] = {}
+    with pytest.raises(RuntimeError):
+        preselection.get_representative_points(images, exifs, reference)
+
+
+@pytest.mark.parametrize("neighbors,distance", [(6, 0), (0, 120.0), (4, 150.0), (0, 0)])
+def test_by_distance_matches_the_reference(refps, host_search, neighbors, distance):
+    exifs = make_exifs(60, 2)
+    reference = TopocentricConverter(45.0, 7.0, 0.0)
+    images = sorted(exifs)
+    for ref_im, cand in ((images[:1], images[1:]), (images, images), (images[:20], images[10:])):
+        assert preselection.match_candidates_by_distance(list(ref_im), list(cand), exifs, reference, neighbors, distance) == \
+            refps.match_candidates_by_distance(list(ref_im), list(cand), exifs, reference, neighbors, distance)
+    # an image without GPS among the inputs: no pairs at all
+    del exifs[images[3]]["gps"]
+    assert preselection.match_candidates_by_distance(images, images, exifs, reference, 6, 0) == set()
+
+
+@pytest.mark.parametrize("neighbors", [0, 1, 5, 100])
+def test_by_time_and_order_match_the_reference(refps, host_search, neighbors):
+    exifs = make_exifs(50, 3)
+    images = sorted(exifs)
+    for ref_im, cand in ((images[:1], images[1:]), (images, images), (images[:15], images[5:])):
+        assert preselection.match_candidates_by_time(list(ref_im), list(cand), exifs, neighbors) == \
+            refps.match_candidates_by_time(list(ref_im), list(cand), exifs, neighbors)
+        assert preselection.match_candidates_by_order(list(ref_im), list(cand), neighbors) == \
+            refps.match_candidates_by_order(list(ref_im), list(cand), neighbors)
+
+
+def test_construct_pairs_and_preemption(refps, host_search):
+    exifs = make_exifs(30, 4)
+    reference = TopocentricConverter(45.0, 7.0, 0.0)
+    images = sorted(exifs)
+    rng = np.random.default_rng(0)
+    results = []
+    for im in images[:10]:
+        others = [o for o in images if o != im][: int(rng.integers(3, 20))]
+        results.append((im, list(rng.random(len(others))), others))
+    for enforce in (False, True):
+        assert preselection.construct_pairs(results, 4, exifs, enforce) == refps.construct_pairs(results, 4, exifs, enforce)
+    for nb, dist in ((5, 0), (0, 100.0), (0, 0)):
+        mk, mn = preselection.preempt_candidates(images[:8], images, exifs, reference, nb, dist)
+        rk, rn = refps.preempt_candidates(images[:8], images, exifs, reference, nb, dist)
+        assert mn == rn and {k: sorted(v) for k, v in mk.items()} == {k: sorted(v) for k, v in rk.items()}
+
+
+def test_ordered_pairs_properties():
+    rng = np.random.default_rng(5)
+    images = ["im%02d" % i for i in range(25)]
+    pairs = {preselection.sorted_pair(images[a], images[b]) for a, b in rng.integers(0, 25, (80, 2)) if a != b}
+    for refs in (images, images[:7], images[3:4]):
+        out = preselection.ordered_pairs(pairs, list(refs))
+        assert len(out) == len(set(out))
+        assert all((b, a) not in set(out) for a, b in out)
+        assert all(a in refs for a, _ in out)
+        # every pair that touches a reference image is there once, in one of the two orientations
+        want = {p for p in pairs if p[0] in refs or p[1] in refs}
+        assert {preselection.sorted_pair(a, b) for a, b in out} == want
+
+
+class _Data:
+    def __init__(self, config, reference):
+        self.config = config
+        self._reference = reference
+
+    def init_reference(self):
+        pass
+
+    def load_reference(self):
+        return self._reference
+
+
+def test_from_metadata_unions_the_strategies(refps, host_search, monkeypatch):
+    exifs = make_exifs(40, 6)
+    images = sorted(exifs)
+    reference = TopocentricConverter(45.0, 7.0, 0.0)
+    base = {k: 0 for k in preselection.CONFIG_DEFAULTS}
+    base.update(matching_bow_other_cameras=False, matching_vlad_other_cameras=False)
+    for override in ({"matching_gps_neighbors": 5}, {"matching_gps_distance": 80}, {"matching_time_neighbors": 4}, {"matching_order_neighbors": 6},
+                     {"matching_gps_neighbors": 3, "matching_order_neighbors": 4, "matching_time_neighbors": 2}, {}):
+        mine, rep = preselection.match_candidates_from_metadata(images[:10], images, exifs, _Data(dict(base), reference), override)
+        monkeypatch.setattr(refps, "match_candidates_with_bow", lambda *a, **k: {})
+        monkeypatch.setattr(refps, "match_candidates_with_vlad", lambda *a, **k: {})
+        theirs, rrep = refps.match_candidates_from_metadata(images[:10], images, exifs, _Data(dict(base), reference), override)
+        assert {preselection.sorted_pair(*p) for p in mine} == {preselection.sorted_pair(*p) for p in theirs}
+        assert all(p[0] in images[:10] for p in mine)
+        assert rep == rrep
+    with pytest.raises(NotImplementedError):
+        preselection.match_candidates_from_metadata(images[:3], images, exifs, _Data(dict(base), reference), {"matching_graph_rounds": 5})
+    # images without GPS switch the GPS strategies off (and with nothing else enabled every pair is matched)
+    del exifs[images[0]]["gps"]
+    mine, _ = preselection.match_candidates_from_metadata(images[:2], images[:5], exifs, _Data(dict(base), reference), {"matching_gps_neighbors": 5})
+    assert len(mine) == 4 + 3
+
+
+def test_vlad_candidates_with_known_histograms(refps, host_search, monkeypatch):
+    """GPS preemption + descriptor distances + construct_pairs; the distance call (a HIP kernel) is replaced by numpy here"""
+    from opensfm_amd import words
+
+    def np_vlad_distances(image, other_images, histograms, ctx=None):
+        if image not in histograms:
+            return image, [], []
+        others = [o for o in sorted(set(other_images)) if o != image and o in histograms]
+        return image, [float(np.linalg.norm(histograms[image] - histograms[o])) for o in others], others
+
+    monkeypatch.setattr(words, "vlad_distances", np_vlad_distances)
+    exifs = make_exifs(30, 7)
+    images = sorted(exifs)
+    reference = TopocentricConverter(45.0, 7.0, 0.0)
+    rng = np.random.default_rng(1)
+    hist = {im: rng.normal(size=64).astype(np.float32) for im in images}
+    mods = sys.modules["opensfm.vlad"]
+    mods.vlad_distances = lambda image, others, h: np_vlad_distances(image, others, h)
+    mods.vlad_histograms = lambda need, data: {}
+    ctx = sys.modules["opensfm.context"]
+    ctx.processes_that_fit_in_memory = lambda p, per: 1
+    ctx.parallel_map = lambda f, args, processes, batch: [f(a) for a in args]
+    data = _Data({"processes": 1}, reference)
+    for nb, dist, enforce in ((4, 0, False), (3, 150.0, True), (0, 0, False)):
+        mine = preselection.match_candidates_with_vlad(images[:6], images, exifs, reference, 5, dist, nb, enforce, dict(hist))
+        theirs = refps.match_candidates_with_vlad(data, images[:6], images, exifs, reference, 5, dist, nb, enforce, dict(hist))
+        assert mine.keys() == theirs.keys()
+        assert all(math.isclose(mine[k], theirs[k], rel_tol=1e-6) for k in mine)
+    assert preselection.match_candidates_with_vlad(images[:6], images, exifs, reference, 0, 0, 0, False, {}) == {}
+    with pytest.raises(ValueError):
+        preselection.match_candidates_with_vlad(images[:2], images, exifs, reference, 3, 0, 0, False, {})
