@@ -476,14 +476,19 @@ def match_images_with_pairs(data, config_override: Dict[str, Any], exifs: Dict[s
     ``data`` must offer the ``DataSetBase`` methods the reference uses on this path:
     ``config``, ``load_camera_models()``, ``load_features(image)`` (``.points``, ``.descriptors``) and
     optionally ``load_features_mask(image, points)`` (``feature_loading.py:61-71``).
-    Only the configuration the GPU path implements is accepted: ``matcher_type: BRUTEFORCE``; with ``poses`` the descriptor
-    stage is the guided (epipolar-masked) matcher, pair by pair;
+    Only the configuration the GPU path implements is accepted: ``matcher_type`` BRUTEFORCE, FLANN (exact search with FLANN's
+    squared-ratio semantics) or WORDS (``data.load_words(image)`` supplies the closest vocabulary words); with ``poses`` the
+    descriptor stage is the guided (epipolar-masked) matcher, pair by pair;
     pairs of undistorted perspective/brown cameras take the fused matcher + fundamental-matrix RANSAC launch, every other
     pair the calibrated route (``match_pairs_calibrated``).
     """
     config = dict(data.config)
     config.update(config_override)
-    _matcher_flags(config)  # raises for matchers that are not on the GPU path (WORDS)
+    use_words = str(_cfg(config, "matcher_type")).upper() == "WORDS"
+    if not use_words:
+        _matcher_flags(config)  # raises for matchers that are not on the GPU path
+    elif poses:
+        raise NotImplementedError("guided matching goes with the BRUTEFORCE matcher (matching.py:260-337)")
     for key in ("matching_use_filters", "matching_use_segmentation"):
         if config.get(key):  # matching.py:352,618-628: would change the result, and is not implemented here
             raise NotImplementedError(f"config {key!r} is not implemented on the GPU path")
@@ -494,6 +499,7 @@ def match_images_with_pairs(data, config_override: Dict[str, Any], exifs: Dict[s
     images = sorted({im for pair in pairs for im in pair})
     index = {im: k for k, im in enumerate(images)}
     descs, pts, masks, cams = [], [], [], []
+    wordlists: List[np.ndarray] = []
     for im in images:
         cam = cameras[exifs[im]["camera"]]
         if not _is_pinhole(cam) and cam.projection_type not in _BEARING_MODELS:
@@ -520,6 +526,12 @@ def match_images_with_pairs(data, config_override: Dict[str, Any], exifs: Dict[s
         descs.append(desc)
         pts.append(points)
         masks.append(mask)
+        if use_words:  # feature_loader.load_words(data, image, masked=True) (feature_loader.py:96-107)
+            w = np.zeros((0, 1), np.int32)
+            if len(points):
+                w = np.asarray(data.load_words(im))
+                w = (w[mask] if mask is not None else w).astype(np.int32).reshape(len(points), -1)
+            wordlists.append(w)
     ipairs = np.asarray([(index[a], index[b]) for a, b in pairs], np.int32).reshape(-1, 2)
     per_pair: List[np.ndarray] = [np.zeros((0, 2), np.int32)] * len(ipairs)
     if poses:  # guided matching (matching.py:204-207,260-337,576-634): one pair at a time from host buffers, first-correct route
@@ -532,6 +544,23 @@ def match_images_with_pairs(data, config_override: Dict[str, Any], exifs: Dict[s
                 continue
             rel = poses[im2].relative_to(poses[im1])
             m = match_guided(descs[a], descs[b], bearings[a], bearings[b], rel, config, ctx)
+            if len(m) < min_match:
+                continue
+            rm = np.asarray(robust_match(pts[a], pts[b], cams[a], cams[b], m, config))
+            if len(rm) >= min_match and len(rm) > 0:
+                per_pair[p] = rm.astype(np.int32)
+    elif use_words:  # matching.py:388-398: match_words[_symmetric], then the robust stage pair by pair
+        from . import words as _words
+
+        nw = max([w.shape[1] for w in wordlists if len(w)] or [1])
+        wstore = _words.WordsStore([np.asarray(d, np.float32).reshape(-1, 128) for d in descs],
+                                   [w if len(w) else np.zeros((0, nw), np.int32) for w in wordlists])
+        try:
+            found, _ = _words.match_words_pairs(wstore, ipairs, config, symmetric=bool(_cfg(config, "symmetric_matching")))
+        finally:
+            wstore.close()
+        min_match = int(_cfg(config, "robust_matching_min_match"))
+        for p, ((a, b), m) in enumerate(zip(ipairs, found)):
             if len(m) < min_match:
                 continue
             rm = np.asarray(robust_match(pts[a], pts[b], cams[a], cams[b], m, config))

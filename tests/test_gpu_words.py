@@ -109,3 +109,42 @@ def test_preselection_on_the_device_equals_the_kdtree_version(gpu_ctx, monkeypat
     host = [preselection.match_candidates_by_distance(images[:50], images, exifs, reference, nb, dist) for nb, dist in ((6, 0), (0, 100.0), (5, 150.0))]
     assert device == host and all(len(x) > 50 for x in device)
     assert device_t == preselection.match_candidates_by_time(images[:50], images, exifs, 5)
+
+
+def test_match_images_with_pairs_words_matcher(gpu_ctx, oracle_lib):
+    """matcher_type WORDS through match_images_with_pairs (matching.py:388-398, 563-634): masked features and words, match_words_symmetric,
+    gate, fundamental-matrix RANSAC, gate, unfilter -- against the same chain built from the oracle's pieces"""
+    from types import SimpleNamespace
+
+    from opensfm_amd import matching, synthetic
+
+    rng = np.random.default_rng(8)
+    cam = SimpleNamespace(projection_type="perspective", k1=0.0, k2=0.0, focal=0.85)
+    n = 500
+    p1, p2, inl = synthetic.make_two_view(n, 0.8, 5)
+    base = rng.random((n, 128)).astype(np.float32)
+    vocabulary = rng.random((60, 128)).astype(np.float32)
+    feats, wds, masks = {}, {}, {}
+    for im, pts in (("a", p1), ("b", p2), ("c", p1[::-1].copy())):
+        desc = (base if im != "c" else base[::-1]) + rng.normal(0, 0.01, (n, 128)).astype(np.float32)
+        feats[im] = SimpleNamespace(points=np.c_[pts, np.ones((n, 2))], descriptors=desc.astype(np.float32))
+        wds[im] = wc.assign_words(desc, vocabulary, 3)
+        masks[im] = rng.random(n) > 0.05
+    config = {"matcher_type": "WORDS", "robust_matching_min_match": 20, "robust_matching_threshold": 0.004, "lowes_ratio": 0.8,
+              "symmetric_matching": True, "bow_num_checks": 20}
+    data = SimpleNamespace(config=config, load_camera_models=lambda: {"cam": cam}, load_features=lambda im: feats[im],
+                           load_features_mask=lambda im, pts: masks[im], load_words=lambda im: wds[im])
+    exifs = {im: {"camera": "cam"} for im in feats}
+    pairs = [("a", "b"), ("a", "c"), ("b", "c")]
+    got = matching.match_images_with_pairs(data, {}, exifs, pairs)
+    for ia, ib in pairs:
+        fa, fb = feats[ia].descriptors[masks[ia]], feats[ib].descriptors[masks[ib]]
+        m = np.array(oracle_lib.match_words_symmetric(fa, wds[ia][masks[ia]], fb, wds[ib][masks[ib]], 0.8, 20), np.int32).reshape(-1, 2)
+        want = np.array([])
+        if len(m) >= 20:
+            pa, pb = feats[ia].points[masks[ia]][m[:, 0], :2], feats[ib].points[masks[ib]][m[:, 1], :2]
+            F, mask, _ = oracle_lib.find_fundamental_ransac(pa, pb, 0.004, 0.9999)
+            if F is not None and F[2, 2] != 0.0 and mask.sum() >= 20:
+                want = matching.unfilter_matches(m[mask], masks[ia], masks[ib])
+        assert np.array_equal(np.asarray(got[ia, ib]).reshape(-1, 2), np.asarray(want).reshape(-1, 2)), (ia, ib)
+    assert len(got["a", "b"]) > 100
