@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--ba-shots", type=int, default=5000)
     ap.add_argument("--ba-points", type=int, default=500000)
     ap.add_argument("--ba-track", type=int, default=10)
-    ap.add_argument("--ba-iters", type=int, default=10)
+    ap.add_argument("--ba-iters", type=int, default=20)
     ap.add_argument("--no-robust", action="store_true", help="descriptor stage only (debug)")
     ap.add_argument("--strong", action="store_true", help="fixed total work for every N (configs[3]: --images 10000 --strong)")
     ap.add_argument("--no-overlap", action="store_true", help="skip the neighbour-preselected workload")

@@ -13,8 +13,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 MATVEC_BYTES_PER_OBS = 288.0  # stored point+pose blocks (144 B) read twice per Schur mat-vec
 
 
-def run(ctx, shots: int = 5000, points: int = 500000, track: int = 10, iters: int = 10, cpu_baseline: bool = True,
-        cpu_iters: int = 2, seed: int = 42) -> dict:
+def run(ctx, shots: int = 5000, points: int = 500000, track: int = 10, iters: int = 20, cpu_baseline: bool = True,
+        cpu_iters: int = 5, seed: int = 42) -> dict:
     t0 = time.time()
     pr = synthetic.make_ba_scene(shots, points, track, seed=seed)
     t_gen = time.time() - t0
@@ -77,5 +77,8 @@ def run(ctx, shots: int = 5000, points: int = 500000, track: int = 10, iters: in
             "sample": f"{cpu_iters} LM iterations of the same problem ({dt:.1f} s; exact Schur + skyline Cholesky, "
                       "OpenMP residuals, serial elimination)",
             "rmse_px_diff_vs_gpu_same_iters": abs(rm_o - rm_g),
+            "cost_history_max_rel_diff": float(np.max(np.abs(np.asarray(o["cost_history"]) - np.asarray(g2["cost_history"]))
+                                                      / np.maximum(np.abs(np.asarray(o["cost_history"])), 1e-300))),
+            "max_abs_diff": {"points": float(np.abs(o["points"] - g2["points"]).max()), "shot_pose": float(np.abs(o["shot_pose"] - g2["shot_pose"]).max())},
         }
     return out
