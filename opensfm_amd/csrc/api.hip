@@ -105,6 +105,7 @@ extern "C" void osfm_store_destroy(osfm_store *s) {
   (void)hipFree(s->d_tiles);
   (void)hipFree(s->d_norms);
   (void)hipFree(s->d_hneg);
+  (void)hipFree(s->d_descf);
   (void)hipFree(s->d_pts);
   (void)hipFree(s->d_counts);
   (void)hipFree(s->d_tile_off);
@@ -122,6 +123,16 @@ static int store_upload(osfm_store *s, const T *desc, const double *pts) {
   std::vector<int8_t> tiles((size_t)nt * OSFM_TILE_BYTES, 0);
   std::vector<int32_t> norms((size_t)nt * 32, OSFM_PAD_NORM);
   std::vector<double> hp((size_t)nt * 64, 0.0);
+  // integer-valued descriptors in [0, 255] (the HAHOG / SIFT uchar round trip, features.py:526-534) take the exact int8 MFMA path;
+  // anything else (root-SIFT floats, ...) is kept as float32 and matched by the exact float kernel
+  bool integral = true;
+  for (int64_t k = 0, n = s->row_off[s->n_images] * OSFM_DESC_DIM; k < n && integral; ++k) {
+    const double v = (double)desc[k];
+    integral = (v >= 0.0 && v <= 255.0) && v == std::floor(v);
+  }
+  s->is_float = !integral;
+  std::vector<float> descf;
+  if (!integral) descf.assign((size_t)nt * 32 * OSFM_DESC_DIM, 0.0f);
   for (int im = 0; im < s->n_images; ++im) {
     const int n = s->counts[im];
     const T *d = desc + s->row_off[im] * OSFM_DESC_DIM;
@@ -130,23 +141,29 @@ static int store_upload(osfm_store *s, const T *desc, const double *pts) {
       const int64_t tile = s->tile_off[im] + r / 32;
       int8_t *t = tiles.data() + tile * OSFM_TILE_BYTES;
       const int rr = r & 31;
-      int32_t nrm = 0;
-      for (int k = 0; k < OSFM_DESC_DIM; ++k) {
-        const double v = (double)d[(size_t)r * OSFM_DESC_DIM + k];
-        if (!(v >= 0.0 && v <= 255.0) || v != std::floor(v)) {
-          osfm_set_error("descriptor value %g (image %d, feature %d, dim %d) is not an integer in [0,255]: only "
-                         "uint8-valued descriptors (features.py:526-534) are supported by the exact int8 path",
-                         v, im, r, k);
-          return OSFM_E_UNSUPPORTED;
+      if (integral) {
+        int32_t nrm = 0;
+        for (int k = 0; k < OSFM_DESC_DIM; ++k) {
+          const int q = (int)d[(size_t)r * OSFM_DESC_DIM + k] - 128;
+          nrm += q * q;
+          t[(k >> 5) * 1024 + ((((k & 31) >> 4) * 32) + rr) * 16 + (k & 15)] = (int8_t)q;
         }
-        const int q = (int)v - 128;
-        nrm += q * q;
-        t[(k >> 5) * 1024 + ((((k & 31) >> 4) * 32) + rr) * 16 + (k & 15)] = (int8_t)q;
+        norms[(size_t)tile * 32 + rr] = nrm;
+      } else {
+        float *f = descf.data() + ((size_t)tile * 32 + rr) * OSFM_DESC_DIM;
+        for (int k = 0; k < OSFM_DESC_DIM; ++k) f[k] = (float)d[(size_t)r * OSFM_DESC_DIM + k];
       }
-      norms[(size_t)tile * 32 + rr] = nrm;
       hp[((size_t)tile * 32 + rr) * 2] = pp[2 * r];
       hp[((size_t)tile * 32 + rr) * 2 + 1] = pp[2 * r + 1];
     }
+  }
+  if (!integral) {
+    if (!s->d_descf) {
+      OSFM_REQUIRE(hipMalloc((void **)&s->d_descf, descf.size() * sizeof(float)) == hipSuccess, OSFM_E_NOMEM,
+                   "osfm_store_upload: out of device memory for %lld float descriptors", (long long)(descf.size() / OSFM_DESC_DIM));
+      s->bytes += (int64_t)descf.size() * (int64_t)sizeof(float);
+    }
+    OSFM_HIP(hipMemcpy(s->d_descf, descf.data(), descf.size() * sizeof(float), hipMemcpyHostToDevice));
   }
   OSFM_HIP(hipMemcpy(s->d_tiles, tiles.data(), tiles.size(), hipMemcpyHostToDevice));
   OSFM_HIP(hipMemcpy(s->d_norms, norms.data(), norms.size() * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -437,15 +454,23 @@ extern "C" int osfm_match_l2_ratio_ex(osfm_ctx *ctx, const float *A, int nA, con
   OSFM_REQUIRE(nA >= 0 && nB >= 0 && (A || nA == 0) && (B || nB == 0), OSFM_E_INVALID, "bad descriptor arrays");
   *out_n = 0;
   OSFM_CTX_LOCK(ctx);
-  if (nA < 2 || nB < 2) return OSFM_OK;  // knnMatch returns < 2 neighbours -> no match (matching.py:750)
-  const int32_t counts[2] = {nA, nB};
+  // knnMatch returns < 2 neighbours when the TRAIN set has < 2 rows -> no match (matching.py:750); a single QUERY is fine in
+  // one-way matching (symmetric matching then has an empty second direction).  The batched kernels implement match()'s rule
+  // (both images need two features, matching.py:363-374), so a lone query is presented twice and its copy dropped.
+  const bool query_is_b = !symmetric && (flags & OSFM_MATCH_SQUARED_RATIO);  // match_flann(index1, f2): f2 queries
+  const int n_query = query_is_b ? nB : nA, n_train = query_is_b ? nA : nB;
+  if (n_train < 2 || n_query < 1 || (symmetric && n_query < 2)) return OSFM_OK;
+  const bool lone = n_query == 1;
+  const int mA = (lone && !query_is_b) ? 2 : nA, mB = (lone && query_is_b) ? 2 : nB;
+  const int32_t counts[2] = {mA, mB};
   osfm_store *st = nullptr;
   int rc = osfm_store_create(ctx, 2, counts, &st);
   if (rc != OSFM_OK) return rc;
-  std::vector<float> desc((size_t)(nA + nB) * OSFM_DESC_DIM);
-  memcpy(desc.data(), A, (size_t)nA * OSFM_DESC_DIM * sizeof(float));
-  memcpy(desc.data() + (size_t)nA * OSFM_DESC_DIM, B, (size_t)nB * OSFM_DESC_DIM * sizeof(float));
-  std::vector<double> pts((size_t)(nA + nB) * 2, 0.0);
+  std::vector<float> desc((size_t)(mA + mB) * OSFM_DESC_DIM);
+  for (int r = 0; r < mA; ++r) memcpy(desc.data() + (size_t)r * OSFM_DESC_DIM, A + (size_t)(r < nA ? r : 0) * OSFM_DESC_DIM, OSFM_DESC_DIM * sizeof(float));
+  for (int r = 0; r < mB; ++r)
+    memcpy(desc.data() + (size_t)(mA + r) * OSFM_DESC_DIM, B + (size_t)(r < nB ? r : 0) * OSFM_DESC_DIM, OSFM_DESC_DIM * sizeof(float));
+  std::vector<double> pts((size_t)(mA + mB) * 2, 0.0);
   rc = osfm_store_upload_f32(st, desc.data(), pts.data());
   osfm_match_result *res = nullptr;
   if (rc == OSFM_OK) {
@@ -459,12 +484,17 @@ extern "C" int osfm_match_l2_ratio_ex(osfm_ctx *ctx, const float *A, int nA, con
     rc = osfm_match_pairs(ctx, st, pair, 1, &prm, &res, nullptr);
   }
   if (rc == OSFM_OK) {
-    const int n = res->counts[0];
-    *out_n = n;
-    for (int k = 0; k < n && k < cap; ++k) {
-      out_pairs[2 * k] = res->matches[2 * k];
-      out_pairs[2 * k + 1] = res->matches[2 * k + 1];
+    int n = 0;
+    for (int k = 0; k < res->counts[0]; ++k) {
+      const int i = res->matches[2 * k], j = res->matches[2 * k + 1];
+      if (i >= nA || j >= nB) continue;  // the copy of a lone query
+      if (n < cap) {
+        out_pairs[2 * n] = i;
+        out_pairs[2 * n + 1] = j;
+      }
+      ++n;
     }
+    *out_n = n;
   }
   osfm_result_destroy(res);
   osfm_store_destroy(st);

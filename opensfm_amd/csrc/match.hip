@@ -57,6 +57,7 @@ struct MatchArgs {
   const int8_t *tiles;
   const int32_t *norms;
   const int32_t *hneg;  // -ceil(norm / 2): accumulator seeds
+  const float *descf;   // float store: row (tile * 32 + r) x 128
   const int64_t *tile_off;
   const int32_t *counts;
   const int32_t *pairs;
@@ -102,7 +103,8 @@ __device__ __forceinline__ void emit_matches(const MatchArgs &a, long p, int nC,
     }
     if (m) {
       const int k = base + woff + prefix;
-      if (k < a.cap) a.out_matches[p * a.cap + k] = (uint32_t)j | ((uint32_t)r << 16);
+      // low half = feature of image 1, high half = feature of image 2
+      if (k < a.cap) a.out_matches[p * a.cap + k] = swap_halves ? ((uint32_t)r | ((uint32_t)j << 16)) : ((uint32_t)j | ((uint32_t)r << 16));
     }
     base += total;
     __syncthreads();
@@ -745,6 +747,112 @@ __global__ void __launch_bounds__(kThreads) match_exact_kernel(MatchArgs a, int 
   emit_matches(a, p, nC, colBI, rowres, misc, tid, qs);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Float kernel: descriptors that are not integers in [0, 255] (root-SIFT ...; opensfm/features.py:292-298 with feature_root).
+// cv2's float semantics as the oracle restates them (oracle/match_oracle.c): squared distance accumulated in four
+// 8-lane float vectors over blocks of 32 dimensions (normL2Sqr_ on an AVX2 build), reduced (d0 + d1) + (d2 + d3) and then
+// ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7)); sqrtf; K = 2 insertion with the lowest index first among equals; Lowe's
+// test in doubles (squared mode: in float on the squared distances).  Every float operation is the oracle's, in its order
+// (-ffp-contract=off), so the result is bit-identical -- on the VALU: one thread per query with its descriptor in registers,
+// the targets staged through LDS 32 at a time and read as broadcasts.  ~13 k pairs/s at 2000 x 2000: the functional path for
+// float descriptors; a half-precision MFMA candidate pass with an exact re-examination is the planned fast one.
+// ---------------------------------------------------------------------------------------------
+constexpr int kFloatTileFloats = 32 * OSFM_DESC_DIM;
+
+__device__ void float_direction(const float *descQ, int nQ, const float *descT, int nT, double ratio, int tid, float *stage, int *res_int,
+                                unsigned short *res_u16) {
+  const int tT = (nT + 31) >> 5;
+  for (int q0 = 0; q0 < nQ; q0 += kThreads) {
+    const int q = q0 + tid;
+    const bool live = q < nQ;
+    float qa[OSFM_DESC_DIM];
+#pragma unroll
+    for (int k4 = 0; k4 < OSFM_DESC_DIM; k4 += 4) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (live) v = *(const float4 *)(descQ + (size_t)q * OSFM_DESC_DIM + k4);
+      qa[k4] = v.x;
+      qa[k4 + 1] = v.y;
+      qa[k4 + 2] = v.z;
+      qa[k4 + 3] = v.w;
+    }
+    float bd0 = INFINITY, bd1 = INFINITY;
+    int bi0 = kNone;
+    for (int tt = 0; tt < tT; ++tt) {
+      __syncthreads();
+      for (int k = tid * 4; k < kFloatTileFloats; k += kThreads * 4) *(float4 *)(stage + k) = *(const float4 *)(descT + (size_t)tt * kFloatTileFloats + k);
+      __syncthreads();
+      const int nt = min(32, nT - tt * 32);
+      for (int t = 0; t < nt; ++t) {
+        const float *b = stage + t * OSFM_DESC_DIM;
+        float acc[4][8];
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+          for (int l = 0; l < 8; ++l) acc[v][l] = 0.f;
+#pragma unroll
+        for (int jb = 0; jb < OSFM_DESC_DIM; jb += 32)
+#pragma unroll
+          for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int l4 = 0; l4 < 8; l4 += 4) {
+              const float4 c = *(const float4 *)(b + jb + 8 * v + l4);
+              const float cc[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float d = qa[jb + 8 * v + l4 + e] - cc[e];
+                const float sq = d * d;
+                acc[v][l4 + e] = acc[v][l4 + e] + sq;
+              }
+            }
+        float sv[8];
+#pragma unroll
+        for (int l = 0; l < 8; ++l) sv[l] = (acc[0][l] + acc[1][l]) + (acc[2][l] + acc[3][l]);
+        const float sqd = ((sv[0] + sv[1]) + (sv[2] + sv[3])) + ((sv[4] + sv[5]) + (sv[6] + sv[7]));
+        const float d = ratio < 0.0 ? sqd : sqrtf(sqd);
+        if (d < bd1) {  // cv2 batchDistance K = 2 insertion
+          if (bd0 > d) {
+            bd1 = bd0;
+            bd0 = d;
+            bi0 = tt * 32 + t;
+          } else {
+            bd1 = d;
+          }
+        }
+      }
+    }
+    if (live) {
+      const bool ok = ratio < 0.0 ? (bd0 < (float)(-ratio) * bd1) : ((double)bd0 < ratio * (double)bd1);
+      const int v = ok ? bi0 : kNone;
+      if (res_int) res_int[q] = v;
+      if (res_u16) res_u16[q] = (unsigned short)v;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kThreads) match_float_kernel(MatchArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float *stage = (float *)smem;  // 32 target descriptors
+  int *colBI = (int *)(stage + kFloatTileFloats);
+  unsigned short *rowres = (unsigned short *)(colBI + a.ncap);
+  int *misc = (int *)(rowres + a.ncap);
+  const int tid = threadIdx.x;
+  const long p = blockIdx.x;
+  if (tid == 0 && a.out_flags) a.out_flags[p] = 0;
+  const bool qs = !a.symmetric && a.query_second;  // queries = the pair's second image (match_flann)
+  const int imgC = a.pairs[2 * p + (qs ? 1 : 0)], imgR = a.pairs[2 * p + (qs ? 0 : 1)];
+  const int nC = a.counts[imgC], nR = a.counts[imgR];
+  if (nC < 2 || nR < 2) {
+    if (tid == 0) a.out_counts[p] = 0;
+    return;
+  }
+  const float *descC = a.descf + a.tile_off[imgC] * kFloatTileFloats;
+  const float *descR = a.descf + a.tile_off[imgR] * kFloatTileFloats;
+  float_direction(descC, nC, descR, nR, a.ratio, tid, stage, colBI, nullptr);
+  if (a.symmetric) float_direction(descR, nR, descC, nC, a.ratio, tid, stage, nullptr, rowres);
+  __syncthreads();
+  emit_matches(a, p, nC, colBI, rowres, misc, tid, qs);
+}
+
 }  // namespace
 
 size_t osfm_match_lds_bytes(int ncap) { return (size_t)2 * kChunkBytes4 + 2 * kChunkCols4 * 4 + 64 + (size_t)ncap * 6; }
@@ -754,6 +862,7 @@ static int ensure_kernel_attributes(int device) {
   return once.run(device, []() -> int {
     OSFM_HIP(hipFuncSetAttribute((const void *)match_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     OSFM_HIP(hipFuncSetAttribute((const void *)match_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    OSFM_HIP(hipFuncSetAttribute((const void *)match_float_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     return OSFM_OK;
   });
 }
@@ -766,6 +875,7 @@ int osfm_launch_match(osfm_ctx *ctx, const osfm_store *store, const int32_t *d_p
   a.tiles = store->d_tiles;
   a.norms = store->d_norms;
   a.hneg = store->d_hneg;
+  a.descf = store->d_descf;
   a.tile_off = store->d_tile_off;
   a.counts = store->d_counts;
   a.pairs = d_pairs;
@@ -788,7 +898,10 @@ int osfm_launch_match(osfm_ctx *ctx, const osfm_store *store, const int32_t *d_p
     const int rc = ensure_kernel_attributes(ctx->device);
     if (rc != OSFM_OK) return rc;
   }
-  if (!exact_kernel) {
+  if (store->is_float) {
+    const size_t lds = (size_t)kFloatTileFloats * sizeof(float) + (size_t)a.ncap * 6 + 64;
+    hipLaunchKernelGGL(match_float_kernel, dim3((unsigned)n_pairs), dim3(kThreads), lds, stream, a);
+  } else if (!exact_kernel) {
     hipLaunchKernelGGL(match_fused_kernel, dim3((unsigned)n_pairs), dim3(kThreads), osfm_match_lds_bytes(a.ncap), stream, a);
   } else {
     const size_t lds = (size_t)a.ncap * 6 + 64;

@@ -59,6 +59,8 @@ struct osfm_store {
   int8_t *d_tiles = nullptr;        // total_tiles * 4096 : (u8 - 128) in tile order
   int32_t *d_norms = nullptr;       // total_tiles * 32 : sum (u8-128)^2, padding = OSFM_PAD_NORM
   int32_t *d_hneg = nullptr;        // total_tiles * 32 : -ceil(norm / 2), the accumulator seed of the matcher (match.hip)
+  float *d_descf = nullptr;         // float store only: total_tiles * 32 rows x 128 floats (padding rows zero), row = tile * 32 + r
+  bool is_float = false;            // the descriptors are not integers in [0, 255]: the exact float kernel matches them (match.hip)
   double *d_pts = nullptr;          // total_tiles * 32 * 2 (padded rows zero)
   int32_t *d_counts = nullptr;      // n_images
   int64_t *d_tile_off = nullptr;    // n_images + 1
