@@ -49,7 +49,11 @@ int osfm_ctx_num_cus(const osfm_ctx *ctx);
  * Descriptor store.  Replaces FeatureLoader.load_all_data (opensfm/feature_loading.py:106-173):
  * instead of an LRU of per-image npz loads, all images' masked features live in HBM.
  * counts[n_images] = features per image (0..OSFM_MAX_FEATURES).
- * desc: sum(counts) x 128, integer-valued in [0,255] (features.py:526-534); float32 or uint8.
+ * desc: sum(counts) x 128; float32 or uint8.  Integer-valued in [0,255] (HAHOG / SIFT uchar round trip, features.py:526-534):
+ *       exact int8 matrix path.  Any other finite float32 values (root-SIFT with feature_root, features.py:292-298): the store
+ *       also keeps the float rows and an 8-bit quantisation; the same kernel decides with rigorous error bounds and evaluates
+ *       the undecided queries in float32 exactly as cv2 accumulates (results identical to cv2's float arithmetic as the oracle
+ *       restates it).  Non-finite values: OSFM_E_INVALID.
  * pts:  sum(counts) x 2 float64 normalized image coordinates (features_data.points[:, :2]).
  * ------------------------------------------------------------------------------------------ */
 int osfm_store_create(osfm_ctx *ctx, int n_images, const int32_t *counts, osfm_store **out);
@@ -68,7 +72,8 @@ typedef struct {
   int32_t ransac_max_iters;          /* 1000 (cv2.findFundamentalMat default)                  */
   int32_t flags;                     /* OSFM_MATCH_* bits below                                 */
 } osfm_match_params;
-#define OSFM_MATCH_EXACT_KERNEL 1  /* cross-check: run every pair on the exact VALU kernel (float keys, no MFMA)          */
+#define OSFM_MATCH_EXACT_KERNEL 1  /* cross-check: run every pair on the exact VALU kernel (float keys, no MFMA; float stores:
+                                      the exact float32 kernel)                                                             */
 #define OSFM_MATCH_SQUARED_RATIO 2 /* matcher_type FLANN semantics on an EXACT 2-NN search: match_flann[_symmetric]
                                       (matching.py:683-720) keeps d0 < float32(lowes_ratio^2) * d1 on SQUARED float32
                                       distances; one-way matching then queries with the pair's SECOND image against the
@@ -84,7 +89,8 @@ typedef struct {
   double ms_ransac_kernel; /* sum of RANSAC kernel launches                              */
   int64_t match_launches;
   int64_t pairs;           /* pairs processed                                            */
-  int64_t pairs_exact_path; /* pairs re-run on the exact float-key kernel (d^2 >= 2^22)   */
+  int64_t pairs_exact_path; /* pairs re-run on the exact float-key kernel (d^2 >= 2^22); float store: pairs in which at least
+                               one query went through the float32 evaluation                */
   int64_t pairs_ransac;    /* calibrated branch: pairs that reached the geometric stage  */
   int64_t ransac_model_points; /* F-RANSAC: sum over pairs of (models scored) x (correspondences): the work its roofline counts */
 } osfm_match_timings;
@@ -111,7 +117,7 @@ void osfm_result_destroy(osfm_match_result *r);
  * matching.py:723-756) and match_brute_force_symmetric (symmetric = 1, matching.py:759-777);
  * osfm_match_l2_ratio_ex with flags = OSFM_MATCH_SQUARED_RATIO for match_flann / match_flann_symmetric
  * (matching.py:683-720) on an exact search.
- * A: nA x dim, B: nB x dim float32 (integer-valued, dim must be 128).
+ * A: nA x dim, B: nB x dim float32 (dim must be 128; integer-valued or not, see the descriptor store).
  * out_pairs: cap x 2 int32, *out_n = number found (may exceed cap; only cap are written).
  */
 int osfm_match_l2_ratio(osfm_ctx *ctx, const float *A, int nA, const float *B, int nB, int dim,

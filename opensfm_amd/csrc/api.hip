@@ -106,6 +106,7 @@ extern "C" void osfm_store_destroy(osfm_store *s) {
   (void)hipFree(s->d_norms);
   (void)hipFree(s->d_hneg);
   (void)hipFree(s->d_descf);
+  (void)hipFree(s->d_qerr);
   (void)hipFree(s->d_pts);
   (void)hipFree(s->d_counts);
   (void)hipFree(s->d_tile_off);
@@ -132,30 +133,69 @@ static int store_upload(osfm_store *s, const T *desc, const double *pts) {
   }
   s->is_float = !integral;
   std::vector<float> descf;
-  if (!integral) descf.assign((size_t)nt * 32 * OSFM_DESC_DIM, 0.0f);
+  // float store: next to the float rows an 8-bit quantisation on the store's value range [lo, hi]; ||x^_q - x^_t|| differs from the
+  // (scaled) float distance by at most the two rows' residual norms, which the fused kernel turns into rigorous accept / reject
+  // bounds -- everything it cannot decide is evaluated in float (match.hip, FQ mode)
+  double lo = 0.0, scale = 1.0;
+  std::vector<float> qerr;
+  s->quantised = false;
+  if (!integral) {
+    descf.assign((size_t)nt * 32 * OSFM_DESC_DIM, 0.0f);
+    double hi = 0.0;
+    bool finite = true, first = true;
+    for (int64_t k = 0, n = s->row_off[s->n_images] * OSFM_DESC_DIM; k < n; ++k) {
+      const double v = (double)(float)desc[k];
+      if (!std::isfinite(v)) finite = false;
+      if (first || v < lo) lo = v;
+      if (first || v > hi) hi = v;
+      first = false;
+    }
+    OSFM_REQUIRE(finite, OSFM_E_INVALID, "osfm_store_upload: non-finite descriptor value");
+    // outside this range the float32 squares of the reference's own computation lose their relative accuracy (underflow /
+    // overflow) and the bounds below would not hold: such stores stay on the exact float kernel
+    s->quantised = (hi - lo) > 1e-6 && std::fabs(lo) < 1e15 && std::fabs(hi) < 1e15;
+    if (s->quantised) scale = 255.0 / (hi - lo);
+    qerr.assign((size_t)s->n_images + 1, 0.0f);
+  }
   for (int im = 0; im < s->n_images; ++im) {
     const int n = s->counts[im];
     const T *d = desc + s->row_off[im] * OSFM_DESC_DIM;
     const double *pp = pts + s->row_off[im] * 2;
+    double emax = 0.0;
     for (int r = 0; r < n; ++r) {
       const int64_t tile = s->tile_off[im] + r / 32;
       int8_t *t = tiles.data() + tile * OSFM_TILE_BYTES;
       const int rr = r & 31;
+      int32_t nrm = 0;
       if (integral) {
-        int32_t nrm = 0;
         for (int k = 0; k < OSFM_DESC_DIM; ++k) {
           const int q = (int)d[(size_t)r * OSFM_DESC_DIM + k] - 128;
           nrm += q * q;
           t[(k >> 5) * 1024 + ((((k & 31) >> 4) * 32) + rr) * 16 + (k & 15)] = (int8_t)q;
         }
-        norms[(size_t)tile * 32 + rr] = nrm;
       } else {
         float *f = descf.data() + ((size_t)tile * 32 + rr) * OSFM_DESC_DIM;
-        for (int k = 0; k < OSFM_DESC_DIM; ++k) f[k] = (float)d[(size_t)r * OSFM_DESC_DIM + k];
+        double e2 = 0.0;
+        for (int k = 0; k < OSFM_DESC_DIM; ++k) {
+          f[k] = (float)d[(size_t)r * OSFM_DESC_DIM + k];
+          if (s->quantised) {
+            const double x = ((double)f[k] - lo) * scale - 128.0;
+            double xq = std::nearbyint(x);
+            xq = xq < -128.0 ? -128.0 : (xq > 127.0 ? 127.0 : xq);
+            e2 += (x - xq) * (x - xq);
+            const int q = (int)xq;
+            nrm += q * q;
+            t[(k >> 5) * 1024 + ((((k & 31) >> 4) * 32) + rr) * 16 + (k & 15)] = (int8_t)q;
+          }
+        }
+        const double e = std::sqrt(e2) * (1.0 + 1e-9) + 1e-9;
+        if (e > emax) emax = e;
       }
+      if (integral || s->quantised) norms[(size_t)tile * 32 + rr] = nrm;
       hp[((size_t)tile * 32 + rr) * 2] = pp[2 * r];
       hp[((size_t)tile * 32 + rr) * 2 + 1] = pp[2 * r + 1];
     }
+    if (!integral) qerr[im] = std::nextafterf((float)emax, INFINITY);
   }
   if (!integral) {
     if (!s->d_descf) {
@@ -164,6 +204,9 @@ static int store_upload(osfm_store *s, const T *desc, const double *pts) {
       s->bytes += (int64_t)descf.size() * (int64_t)sizeof(float);
     }
     OSFM_HIP(hipMemcpy(s->d_descf, descf.data(), descf.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (!s->d_qerr)
+      OSFM_REQUIRE(hipMalloc((void **)&s->d_qerr, qerr.size() * sizeof(float)) == hipSuccess, OSFM_E_NOMEM, "osfm_store_upload: out of device memory");
+    OSFM_HIP(hipMemcpy(s->d_qerr, qerr.data(), qerr.size() * sizeof(float), hipMemcpyHostToDevice));
   }
   OSFM_HIP(hipMemcpy(s->d_tiles, tiles.data(), tiles.size(), hipMemcpyHostToDevice));
   OSFM_HIP(hipMemcpy(s->d_norms, norms.data(), norms.size() * sizeof(int32_t), hipMemcpyHostToDevice));

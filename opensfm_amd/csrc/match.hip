@@ -58,6 +58,7 @@ struct MatchArgs {
   const int32_t *norms;
   const int32_t *hneg;  // -ceil(norm / 2): accumulator seeds
   const float *descf;   // float store: row (tile * 32 + r) x 128
+  const float *qerr;    // float store: per image, max residual norm of the 8-bit quantisation (quantised units)
   const int64_t *tile_off;
   const int32_t *counts;
   const int32_t *pairs;
@@ -149,6 +150,66 @@ __device__ __forceinline__ int row16_max(int x) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// FQ mode of the fused kernel: float descriptors (root-SIFT ...) through the int8 matrix pipe with rigorous bounds.
+// The store holds x^ = round(x) of x = (v - lo) * 255 / (hi - lo) - 128 next to the float rows, and per image E = max ||x - x^||.
+// With D^ = ||x^_q - x^_t|| (an exact integer square root away) and D = scale * (the float32 distance cv2 computes),
+//     | D - D^ |  <=  eps + kappa * D,      eps = E_Q + E_T   (triangle inequality; kappa covers the float32 roundings of the
+//                                                               reference's accumulation: < 11 ulp on the squared sum)
+// so the sweep's (best, class-level second) bounds decide most queries outright:
+//     surely fails:   lower bound of the best   >= ratio * upper bound of the second     (the vast majority)
+//     surely passes:  upper bound of the best   <  ratio * lower bound of the second, which also makes the integer winner the
+//                     float winner (every other target is farther than the winner's upper bound)
+// and whatever is left is evaluated in float32, operation for operation as the oracle / cv2 does (l2sqr_rows_f32), against every
+// target whose quantised distance does not exclude it from the top two.  Results are bit-identical to the exact float kernel.
+// ---------------------------------------------------------------------------------------------
+constexpr double kFqSlack = 8e-6;
+__device__ __forceinline__ double fq_ratio(double ratio) { return ratio < 0.0 ? sqrt(-ratio) : ratio; }  // squared mode compares d^2
+__device__ __forceinline__ bool fq_surely_fails(int d0lo_sq, int d1hi_sq, double eps, double r) {
+  const double D0lo = fmax(sqrt((double)max(d0lo_sq, 0)) - eps, 0.0) * (1.0 - kFqSlack);
+  const double D1hi = (sqrt((double)max(d1hi_sq, 0)) + eps) * (1.0 + kFqSlack);
+  return D0lo >= r * D1hi;
+}
+__device__ __forceinline__ bool fq_surely_passes(int d0hi_sq, int d1lo_sq, double eps, double r) {
+  const double D0hi = (sqrt((double)max(d0hi_sq, 0)) + eps) * (1.0 + kFqSlack);
+  const double D1lo = fmax(sqrt((double)max(d1lo_sq, 0)) - eps, 0.0) * (1.0 - kFqSlack);
+  return D0hi < r * D1lo && D0hi < D1lo;
+}
+// cv2's normL2Sqr_ on an AVX2 build as the oracle restates it (oracle/match_oracle.c l2sqr_f32): four 8-lane accumulators over
+// blocks of 32 dimensions, (d0 + d1) + (d2 + d3), then ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7)); no contraction
+__device__ __forceinline__ float l2sqr_rows_f32(const float *a, const float *b) {
+  float acc[4][8];
+#pragma unroll
+  for (int v = 0; v < 4; ++v)
+#pragma unroll
+    for (int l = 0; l < 8; ++l) acc[v][l] = 0.f;
+#pragma unroll
+  for (int jb = 0; jb < OSFM_DESC_DIM; jb += 32)
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+      for (int l4 = 0; l4 < 8; l4 += 4) {
+        const float4 x = *(const float4 *)(a + jb + 8 * v + l4);
+        const float4 y = *(const float4 *)(b + jb + 8 * v + l4);
+        const float xx[4] = {x.x, x.y, x.z, x.w}, yy[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = xx[e] - yy[e];
+          const float sq = d * d;
+          acc[v][l4 + e] = acc[v][l4 + e] + sq;
+        }
+      }
+  float sv[8];
+#pragma unroll
+  for (int l = 0; l < 8; ++l) sv[l] = (acc[0][l] + acc[1][l]) + (acc[2][l] + acc[3][l]);
+  return ((sv[0] + sv[1]) + (sv[2] + sv[3])) + ((sv[4] + sv[5]) + (sv[6] + sv[7]));
+}
+__device__ __forceinline__ float wave_minf(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fminf(v, __shfl_xor(v, m));
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Fused MFMA kernel: "one direction at a time".
 //   pass A: the queries are the features of image A, the targets those of image B; resA[a] = best b if it passes the ratio test;
 //   pass B: (symmetric matching only) the mutual check needs "best a for b" only for the b that some a chose: those candidates
@@ -190,11 +251,11 @@ struct QueryPassShared {
 
 // queries: slot q in [0, nslots) is feature qsel[q] of image Q (qsel == nullptr: identity); targets: all nT features of image T.
 // out[query feature] = its nearest target if the ratio test passes, else kNone.  Returns the collision flag.
-template <bool GATHER>
+template <bool GATHER, bool FQ>
 __device__ __forceinline__ int query_pass(const QueryPassShared &sh, const int8_t *tilesQ, const int32_t *normQ, int nQ, int nslots,
                                           const unsigned short *qsel, const int8_t *tilesT, const int32_t *normT, const int32_t *hnegT,
                                           int nT, const int8_t *tiles_pad, const int32_t *hneg_pad, unsigned short *out, double ratio,
-                                          int tid) {
+                                          int tid, const float *descQ, const float *descT, double eps) {
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tT = (nT + 31) >> 5;
@@ -448,8 +509,12 @@ __device__ __forceinline__ int query_pass(const QueryPassShared &sh, const int8_
     if (myf >= 0 && myf < nQ) {
       // v_best in {2b, 2b+1}; the best of the other classes in {2 s2, 2 s2 + 1}, the true second is at least that
       const int d1lo = max(myna - (2 * b + 1), 0), d2hi = myna - 2 * s2;
-      if (d2hi >= kCollisionD2 && ratio >= 0.0) flag = 1;  // squared mode never takes a square root
-      want = ratio_ok(d1lo, d2hi, ratio);
+      if (FQ) {
+        want = !fq_surely_fails(d1lo, d2hi, eps, fq_ratio(ratio));
+      } else {
+        if (d2hi >= kCollisionD2 && ratio >= 0.0) flag = 1;  // squared mode never takes a square root
+        want = ratio_ok(d1lo, d2hi, ratio);
+      }
 #ifdef OSFM_DBG_NORECHECK
       want = false;
 #endif
@@ -509,11 +574,20 @@ __device__ __forceinline__ int query_pass(const QueryPassShared &sh, const int8_
           const int jwin = (qrb * (kWaves * kRT) + qw * kRT + (ord >> 4)) * 32 + (ord & 3) + 8 * ((ord & 15) >> 2) + 4 * qh;
           const int m2 = ksec >> 5;  // INT_MIN >> 5 when the class has a single target: far below any bound
           const int sa = max(m2, 2 * qs), sb = max(m2, 2 * qs + 1);
-          const bool ra = ratio_ok(qna - m1, qna - sa, ratio), rbb = ratio_ok(qna - m1, qna - sb, ratio);
-          if (ra == rbb)
-            win = ra ? jwin : kNone;
-          else
-            full = true;  // the decision hangs on the parity bit of a norm in another class
+          if (FQ) {
+            // m1 is the exact quantised best; the quantised second lies in [sa, sb]
+            const double r = fq_ratio(ratio);
+            if (fq_surely_passes(qna - m1, qna - sb, eps, r))
+              win = jwin;
+            else if (!fq_surely_fails(qna - m1, qna - sa, eps, r))
+              full = true;  // the bounds do not decide: float evaluation
+          } else {
+            const bool ra = ratio_ok(qna - m1, qna - sa, ratio), rbb = ratio_ok(qna - m1, qna - sb, ratio);
+            if (ra == rbb)
+              win = ra ? jwin : kNone;
+            else
+              full = true;  // the decision hangs on the parity bit of a norm in another class
+          }
         }
         if (sl == 0 && !full) out[qf] = (unsigned short)win;
         redo |= (full && sl == 0) ? (1ull << src) : 0ull;
@@ -529,7 +603,43 @@ __device__ __forceinline__ int query_pass(const QueryPassShared &sh, const int8_
       }
       redo = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)hi) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)lo);
     }
-    while (redo) {
+    if (FQ) flag += __popcll(redo);  // diagnostic: queries that needed the float evaluation (per wave, summed by the caller)
+    while (FQ && redo) {
+      // float evaluation of one query by the whole wave: every target whose quantised distance does not exclude it from the float
+      // top two (D^ <= upper bound of the quantised second + 2 eps) is evaluated exactly as the oracle does; cv2's K = 2 insertion
+      // (lowest index first among equals) per lane in ascending index order, then across the lanes
+      const int src = __builtin_ctzll(redo);
+      redo &= redo - 1;
+      const int qf = __shfl(myf, src), qna = __shfl(myna, src), qs2 = __shfl(s2, src);
+      const double T = (sqrt((double)max(qna - 2 * qs2, 0)) + 2.0 * eps) * (1.0 + 4.0 * kFqSlack) + 1e-6;
+      const double T2 = T * T;
+      const int vthr = T2 >= 2.0e9 ? INT_MIN : qna - (int)T2 - 1;
+      const float *qrow = descQ + (long)qf * OSFM_DESC_DIM;
+      float bd0 = INFINITY, bd1 = INFINITY;
+      int bi0 = INT_MAX;
+      for (int i = lane; i < nT; i += 64) {
+        const int v = 2 * dot_rows8(tilesQ, qf, tilesT, i) - normT[i];
+        if (v >= vthr) {
+          const float sq = l2sqr_rows_f32(qrow, descT + (long)i * OSFM_DESC_DIM);
+          const float d = ratio < 0.0 ? sq : sqrtf(sq);
+          if (d < bd1) {
+            if (bd0 > d) {
+              bd1 = bd0;
+              bd0 = d;
+              bi0 = i;
+            } else {
+              bd1 = d;
+            }
+          }
+        }
+      }
+      const float m = wave_minf(bd0);
+      const int jwin = -wave_max(bd0 == m ? -bi0 : INT_MIN);
+      const float sec = wave_minf(bi0 == jwin ? bd1 : bd0);
+      const bool ok = ratio < 0.0 ? (m < (float)(-ratio) * sec) : ((double)m < ratio * (double)sec);
+      if (lane == 0) out[qf] = (unsigned short)(ok ? jwin : kNone);
+    }
+    while (!FQ && redo) {
       const int src = __builtin_ctzll(redo);
       redo &= redo - 1;
       const int qf = __shfl(myf, src), qna = __shfl(myna, src);
@@ -552,6 +662,7 @@ __device__ __forceinline__ int query_pass(const QueryPassShared &sh, const int8_
   return flag;
 }
 
+template <bool FQ>
 __global__ void __launch_bounds__(kThreads, 2) match_fused_kernel(MatchArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   QueryPassShared sh;
@@ -596,7 +707,12 @@ __global__ void __launch_bounds__(kThreads, 2) match_fused_kernel(MatchArgs a) {
     misc[9] = 0;
   }
   __syncthreads();
-  int flag = query_pass<false>(sh, tilesA, normA, nA, nA, nullptr, tilesB, normB, hnegB, nB, tiles_pad, hneg_pad, resA, a.ratio, tid);
+  // FQ: the float rows of the two images and the quantisation error bound of the pair
+  const float *descA = FQ ? a.descf + a.tile_off[imgA] * (long)(32 * OSFM_DESC_DIM) : nullptr;
+  const float *descB = FQ ? a.descf + a.tile_off[imgB] * (long)(32 * OSFM_DESC_DIM) : nullptr;
+  const double eps = FQ ? (double)a.qerr[imgA] + (double)a.qerr[imgB] : 0.0;
+  int flag = query_pass<false, FQ>(sh, tilesA, normA, nA, nA, nullptr, tilesB, normB, hnegB, nB, tiles_pad, hneg_pad, resA, a.ratio, tid,
+                                   descA, descB, eps);
   if (a.symmetric) {
     // candidates: the features of B that some row of A chose.  resB doubles as the mark array
     // (0 = chosen) until the candidate list is built, in ascending feature order.
@@ -627,9 +743,16 @@ __global__ void __launch_bounds__(kThreads, 2) match_fused_kernel(MatchArgs a) {
       __syncthreads();
     }
     const int nK = base;
-    if (nK > 0) flag |= query_pass<true>(sh, tilesB, normB, nB, nK, cand, tilesA, normA, hnegA, nA, tiles_pad, hneg_pad, resB, a.ratio, tid);
+    if (nK > 0)
+      flag += query_pass<true, FQ>(sh, tilesB, normB, nB, nK, cand, tilesA, normA, hnegA, nA, tiles_pad, hneg_pad, resB, a.ratio, tid, descB, descA,
+                                   eps);
   }
-  if (flag) misc[8] = 1;
+  // integer store: flag = the pair has to be re-run by the exact kernel; float store: the number of queries evaluated in float
+  if (FQ) {
+    if (lane == 0 && flag) atomicAdd(&misc[8], flag);
+  } else if (flag) {
+    misc[8] = 1;
+  }
   __syncthreads();
   if (tid == 0) a.out_flags[p] = misc[8];
   // ---- ordered emission: over the features of the pair's first image, or (query_second) of its second image,
@@ -860,7 +983,8 @@ size_t osfm_match_lds_bytes(int ncap) { return (size_t)2 * kChunkBytes4 + 2 * kC
 static int ensure_kernel_attributes(int device) {
   static OsfmPerDeviceOnce once;
   return once.run(device, []() -> int {
-    OSFM_HIP(hipFuncSetAttribute((const void *)match_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    OSFM_HIP(hipFuncSetAttribute((const void *)match_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    OSFM_HIP(hipFuncSetAttribute((const void *)match_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     OSFM_HIP(hipFuncSetAttribute((const void *)match_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     OSFM_HIP(hipFuncSetAttribute((const void *)match_float_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     return OSFM_OK;
@@ -876,6 +1000,7 @@ int osfm_launch_match(osfm_ctx *ctx, const osfm_store *store, const int32_t *d_p
   a.norms = store->d_norms;
   a.hneg = store->d_hneg;
   a.descf = store->d_descf;
+  a.qerr = store->d_qerr;
   a.tile_off = store->d_tile_off;
   a.counts = store->d_counts;
   a.pairs = d_pairs;
@@ -899,10 +1024,19 @@ int osfm_launch_match(osfm_ctx *ctx, const osfm_store *store, const int32_t *d_p
     if (rc != OSFM_OK) return rc;
   }
   if (store->is_float) {
-    const size_t lds = (size_t)kFloatTileFloats * sizeof(float) + (size_t)a.ncap * 6 + 64;
-    hipLaunchKernelGGL(match_float_kernel, dim3((unsigned)n_pairs), dim3(kThreads), lds, stream, a);
+    // float store: the fused kernel on the 8-bit quantisation with rigorous bounds and float evaluation of what they leave open
+    // (FQ mode); the exact float kernel for every pair when asked for (cross-check) or when the store could not be quantised.
+    // Nothing is ever flagged for a second run: out_flags then counts the queries that went through the float evaluation.
+    if (exact_kernel && d_flags != nullptr) return OSFM_OK;  // "re-run the flagged pairs": none
+    if (!exact_kernel && store->quantised) {
+      hipLaunchKernelGGL(match_fused_kernel<true>, dim3((unsigned)n_pairs), dim3(kThreads), osfm_match_lds_bytes(a.ncap), stream, a);
+    } else {
+      if (d_flags) OSFM_HIP(hipMemsetAsync(d_flags, 0, (size_t)n_pairs * sizeof(int32_t), stream));
+      const size_t lds = (size_t)kFloatTileFloats * sizeof(float) + (size_t)a.ncap * 6 + 64;
+      hipLaunchKernelGGL(match_float_kernel, dim3((unsigned)n_pairs), dim3(kThreads), lds, stream, a);
+    }
   } else if (!exact_kernel) {
-    hipLaunchKernelGGL(match_fused_kernel, dim3((unsigned)n_pairs), dim3(kThreads), osfm_match_lds_bytes(a.ncap), stream, a);
+    hipLaunchKernelGGL(match_fused_kernel<false>, dim3((unsigned)n_pairs), dim3(kThreads), osfm_match_lds_bytes(a.ncap), stream, a);
   } else {
     const size_t lds = (size_t)a.ncap * 6 + 64;
     hipLaunchKernelGGL(match_exact_kernel, dim3((unsigned)n_pairs), dim3(kThreads), lds, stream, a, d_flags != nullptr ? 1 : 0);

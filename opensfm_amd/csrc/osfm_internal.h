@@ -60,7 +60,10 @@ struct osfm_store {
   int32_t *d_norms = nullptr;       // total_tiles * 32 : sum (u8-128)^2, padding = OSFM_PAD_NORM
   int32_t *d_hneg = nullptr;        // total_tiles * 32 : -ceil(norm / 2), the accumulator seed of the matcher (match.hip)
   float *d_descf = nullptr;         // float store only: total_tiles * 32 rows x 128 floats (padding rows zero), row = tile * 32 + r
-  bool is_float = false;            // the descriptors are not integers in [0, 255]: the exact float kernel matches them (match.hip)
+  bool is_float = false;            // the descriptors are not integers in [0, 255] (root-SIFT ...): d_descf holds them, d_tiles an 8-bit
+                                    // quantisation x^ = round((v - lo) * 255 / (hi - lo)) - 128 whose distances BOUND the float ones (match.hip)
+  bool quantised = false;           // float store with a usable quantisation (finite values, sane dynamic range): fused kernel, FQ mode
+  float *d_qerr = nullptr;          // float store: per image max_row ||x - x^||_2 in quantised units, rounded up (n_images + 1)
   double *d_pts = nullptr;          // total_tiles * 32 * 2 (padded rows zero)
   int32_t *d_counts = nullptr;      // n_images
   int64_t *d_tile_off = nullptr;    // n_images + 1

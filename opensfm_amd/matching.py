@@ -333,7 +333,8 @@ class DescriptorStore:
     """All images' (masked) descriptors + keypoints resident in HBM.
 
     Replaces ``FeatureLoader.load_all_data`` + its LRU caches (``feature_loading.py:106-173``).
-    ``descriptors``: list of (n_i, 128) arrays, float32 (integer-valued) or uint8;
+    ``descriptors``: list of (n_i, 128) arrays, float32 (integer-valued: exact int8 path; otherwise, e.g. root-SIFT: quantised
+    candidates + float32 evaluation, same results) or uint8;
     ``points``: list of (n_i, >=2) arrays (normalized image coordinates, ``features.py:324-331``).
     """
 

@@ -74,13 +74,18 @@ def test_extreme_range_takes_exact_path(oracle_lib, gpu_ctx):
     assert np.array_equal(m, want)
 
 
-def test_rejects_non_integer_descriptors(gpu_ctx):
+def test_descriptor_value_validation(gpu_ctx):
+    """non-integer descriptors are matched in float (tests/test_gpu_float_descriptors.py); a constant float store has no value range
+    to quantise and every distance 0: no match, as cv2 (0 < ratio * 0 is false); non-finite values and 8-bit dtypes are rejected"""
     from opensfm_amd import matching
     from opensfm_amd._lib import OsfmError
 
     f = np.full((10, 128), 0.5, np.float32)
+    assert matching.match_brute_force_symmetric(f, f, {}) == []
+    g = f.copy()
+    g[3, 7] = np.nan
     with pytest.raises(OsfmError):
-        matching.match_brute_force_symmetric(f, f, {})
+        matching.match_brute_force_symmetric(g, f, {})
     with pytest.raises(NotImplementedError):
         matching.match_brute_force(f.astype(np.uint8), f.astype(np.uint8), {})
 
