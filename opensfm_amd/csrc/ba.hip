@@ -662,6 +662,7 @@ __global__ void precond_cam_kernel(Dev d, double radius) {
 // sweeps per CG iteration.  When bw covers every co-visibility, M equals the shot part of the
 // Schur complement exactly and CG only has to resolve the rank-3 coupling to the shared camera.
 constexpr int kMaxBw = 15;
+constexpr int kBandCopies = 8;
 
 // Single-wavefront kernels: LDS operations of one wave are executed in issue order, so a compiler
 // barrier is all that is needed between a ds_write and a dependent ds_read of another lane.
@@ -708,9 +709,13 @@ __global__ void __launch_bounds__(TPB) epm_kernel(Dev d) {
 }
 
 __global__ void __launch_bounds__(TPB) band_assemble_kernel(Dev d, double radius) {
-  __shared__ double acc[(kMaxBw + 1) * 36];
+  // kBandCopies private copies of the accumulators, copy = lane & (kBandCopies - 1), interleaved so that the copies of one entry sit
+  // in different banks: the lanes of a wavefront add into a handful of (dk, i, j) entries at a time, and same-address fp64 LDS
+  // atomics serialise
+  __shared__ double acc[(kMaxBw + 1) * 36 * kBandCopies];
   const int s = blockIdx.x, nb = (d.bw + 1) * 36;
-  for (int t = threadIdx.x; t < nb; t += TPB) acc[t] = 0.0;
+  const int copy = threadIdx.x & (kBandCopies - 1);
+  for (int t = threadIdx.x; t < nb * kBandCopies; t += TPB) acc[t] = 0.0;
   __syncthreads();
   for (long k = d.shot_off[s] + threadIdx.x; k < d.shot_off[s + 1]; k += TPB) {
     const int p = d.sm_point[k];
@@ -739,7 +744,7 @@ __global__ void __launch_bounds__(TPB) band_assemble_kernel(Dev d, double radius
       for (int i = 0; i < 6; i++)
 #pragma unroll
         for (int j = 0; j < 6; j++)
-          atomicAdd(&acc[dk * 36 + i * 6 + j], EH[i][0] * Eb[j][0] + EH[i][1] * Eb[j][1] + EH[i][2] * Eb[j][2]);
+          atomicAdd(&acc[(dk * 36 + i * 6 + j) * kBandCopies + copy], EH[i][0] * Eb[j][0] + EH[i][1] * Eb[j][1] + EH[i][2] * Eb[j][2]);
     }
   }
   __syncthreads();
@@ -748,7 +753,10 @@ __global__ void __launch_bounds__(TPB) band_assemble_kernel(Dev d, double radius
     const int s2 = s - dk;
     double val = 0.0;
     if (s2 >= 0) {
-      val = -acc[t];
+      double sum = 0.0;
+#pragma unroll
+      for (int c = 0; c < kBandCopies; c++) sum += acc[t * kBandCopies + c];
+      val = -sum;
       if (dk == 0) {
         const int hi = i > j ? i : j, lo = i > j ? j : i;
         val += d.Hcc[21 * (long)s + hi * (hi + 1) / 2 + lo];
@@ -1186,6 +1194,27 @@ __device__ void dense_chol_inverse(double *A, double *X, int tid, int &bad) {
   __syncthreads();
 }
 
+// acc (6 x 3 tile at rows 6 tr.., columns 3 tq..) += sum_{v >= v0} A(r, v) B(v, q) with both n x n operands in LDS; TA / TB: the operand is
+// stored transposed.  One tile per thread (n = 6 CS: CS x 2 CS tiles <= 200 threads): 9 LDS reads per 18 multiply-adds instead of the
+// 36 of an element-per-thread product -- the dense products of the cyclic reduction are LDS-bandwidth bound.
+template <int n, bool TA, bool TB>
+__device__ __forceinline__ void tile_mac(const double *A, const double *B, int tr, int tq, int v0, double (&acc)[6][3]) {
+#pragma unroll 2
+  for (int v = v0; v < n; v++) {
+    double a[6], b[3];
+#pragma unroll
+    for (int i = 0; i < 6; i++) a[i] = TA ? A[v * n + 6 * tr + i] : A[(6 * tr + i) * n + v];
+#pragma unroll
+    for (int c = 0; c < 3; c++) b[c] = TB ? B[(3 * tq + c) * n + v] : B[v * n + 3 * tq + c];
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) acc[i][c] += a[i] * b[c];
+  }
+}
+#define OSFM_TILE_ZERO(acc)          \
+  _Pragma("unroll") for (int i_ = 0; i_ < 6; i_++) _Pragma("unroll") for (int c_ = 0; c_ < 3; c_++) acc[i_][c_] = 0.0;
+
 template <int CS>
 __global__ void __launch_bounds__(256) bcr_elim_kernel(Dev d, int st, int root, int *status) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -1198,17 +1227,18 @@ __global__ void __launch_bounds__(256) bcr_elim_kernel(Dev d, int st, int root, 
   for (int t = tid; t < n2; t += 256) B0[t] = d.bD[(long)i * n2 + t];
   __syncthreads();
   dense_chol_inverse<CS>(B0, B1, tid, bad);
-  // Dinv = X^T X  (X lower triangular): Dinv[r][q] = sum_{v >= max(r,q)} X[v][r] X[v][q]
-  for (int t = tid; t < n2; t += 256) {
-    const int r = t / n, q = t - r * n;
-    double a0 = 0, a1 = 0;
-    int v = r > q ? r : q;
-    for (; v + 1 < n; v += 2) {
-      a0 += B1[v * n + r] * B1[v * n + q];
-      a1 += B1[(v + 1) * n + r] * B1[(v + 1) * n + q];
-    }
-    if (v < n) a0 += B1[v * n + r] * B1[v * n + q];
-    B2[t] = a0 + a1;
+  // Dinv = X^T X  (X lower triangular, zeros above the diagonal): Dinv[r][q] = sum_{v >= max(r,q)} X[v][r] X[v][q]
+  constexpr int ntq = n / 3, ntile = (n / 6) * ntq;
+  const bool has_tile = tid < ntile;
+  const int tr = tid / ntq, tq = tid - tr * ntq;
+  double acc[6][3];
+  if (has_tile) {
+    OSFM_TILE_ZERO(acc)
+    tile_mac<n, true, false>(B1, B1, tr, tq, 6 * tr > 3 * tq ? 6 * tr : 3 * tq, acc);
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) B2[(6 * tr + i) * n + 3 * tq + c] = acc[i][c];
   }
   __syncthreads();
   for (int t = tid; t < n2; t += 256) {
@@ -1222,15 +1252,13 @@ __global__ void __launch_bounds__(256) bcr_elim_kernel(Dev d, int st, int root, 
   if (i - st >= 0) {
     for (int t = tid; t < n2; t += 256) B1[t] = d.bE[(long)i * n2 + t];
     __syncthreads();
-    for (int t = tid; t < n2; t += 256) {
-      const int r = t / n, q = t - r * n;
-      double a0 = 0, a1 = 0;
-#pragma unroll 3
-      for (int v = 0; v < n; v += 2) {
-        a0 += B0[r * n + v] * B1[v * n + q];
-        a1 += B0[r * n + v + 1] * B1[(v + 1) * n + q];
-      }
-      d.bG[(long)i * n2 + t] = a0 + a1;
+    if (has_tile) {
+      OSFM_TILE_ZERO(acc)
+      tile_mac<n, false, false>(B0, B1, tr, tq, 0, acc);
+#pragma unroll
+      for (int ii = 0; ii < 6; ii++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) d.bG[(long)i * n2 + (6 * tr + ii) * n + 3 * tq + c] = acc[ii][c];
     }
     __syncthreads();
   }
@@ -1238,15 +1266,13 @@ __global__ void __launch_bounds__(256) bcr_elim_kernel(Dev d, int st, int root, 
   if (i + st < d.ncl) {
     for (int t = tid; t < n2; t += 256) B1[t] = d.bE[(long)(i + st) * n2 + t];
     __syncthreads();
-    for (int t = tid; t < n2; t += 256) {
-      const int r = t / n, q = t - r * n;
-      double a0 = 0, a1 = 0;
-#pragma unroll 3
-      for (int v = 0; v < n; v += 2) {
-        a0 += B0[r * n + v] * B1[q * n + v];
-        a1 += B0[r * n + v + 1] * B1[q * n + v + 1];
-      }
-      d.bH[(long)i * n2 + t] = a0 + a1;
+    if (has_tile) {
+      OSFM_TILE_ZERO(acc)
+      tile_mac<n, false, true>(B0, B1, tr, tq, 0, acc);
+#pragma unroll
+      for (int ii = 0; ii < 6; ii++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) d.bH[(long)i * n2 + (6 * tr + ii) * n + 3 * tq + c] = acc[ii][c];
     }
   }
 }
@@ -1255,47 +1281,35 @@ template <int CS>
 __global__ void __launch_bounds__(256) bcr_update_kernel(Dev d, int st) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int n = 6 * CS, n2 = n * n;
+  constexpr int ntq = n / 3, ntile = (n / 6) * ntq;
   double *B0 = lds, *B1 = lds + n2;
   const int tid = threadIdx.x;
   const int j = 2 * blockIdx.x * st;
   if (j >= d.ncl) return;
   const int i1 = j - st, i2 = j + st;
-  double dacc[(n2 + 255) / 256];
-#pragma unroll
-  for (int u = 0; u < (n2 + 255) / 256; u++) dacc[u] = 0.0;
+  const bool has_tile = tid < ntile;
+  const int tr = tid / ntq, tq = tid - tr * ntq;
+  double dacc[6][3];
+  OSFM_TILE_ZERO(dacc)
   if (i1 >= 0) {
     for (int t = tid; t < n2; t += 256) {
       B0[t] = d.bE[(long)j * n2 + t];
       B1[t] = d.bH[(long)i1 * n2 + t];
     }
     __syncthreads();
-#pragma unroll
-    for (int u = 0; u < (n2 + 255) / 256; u++) {
-      const int t = tid + 256 * u;
-      if (t < n2) {
-        const int r = t / n, q = t - r * n;
-        double a0 = 0, a1 = 0;
-#pragma unroll 3
-        for (int v = 0; v < n; v += 2) {
-          a0 += B0[r * n + v] * B1[v * n + q];
-          a1 += B0[r * n + v + 1] * B1[(v + 1) * n + q];
-        }
-        dacc[u] += a0 + a1;
-      }
-    }
+    if (has_tile) tile_mac<n, false, false>(B0, B1, tr, tq, 0, dacc);  // E_j H_{i1}
     __syncthreads();
     if (i1 - st >= 0) {  // new coupling to j - 2 st:  E_j <- -E_j G_{i1}
       for (int t = tid; t < n2; t += 256) B1[t] = d.bG[(long)i1 * n2 + t];
       __syncthreads();
-      for (int t = tid; t < n2; t += 256) {
-        const int r = t / n, q = t - r * n;
-        double a0 = 0, a1 = 0;
-#pragma unroll 3
-        for (int v = 0; v < n; v += 2) {
-          a0 += B0[r * n + v] * B1[v * n + q];
-          a1 += B0[r * n + v + 1] * B1[(v + 1) * n + q];
-        }
-        d.bE[(long)j * n2 + t] = -(a0 + a1);
+      if (has_tile) {
+        double e[6][3];
+        OSFM_TILE_ZERO(e)
+        tile_mac<n, false, false>(B0, B1, tr, tq, 0, e);
+#pragma unroll
+        for (int ii = 0; ii < 6; ii++)
+#pragma unroll
+          for (int c = 0; c < 3; c++) d.bE[(long)j * n2 + (6 * tr + ii) * n + 3 * tq + c] = -e[ii][c];
       }
       __syncthreads();
     }
@@ -1306,25 +1320,13 @@ __global__ void __launch_bounds__(256) bcr_update_kernel(Dev d, int st) {
       B1[t] = d.bG[(long)i2 * n2 + t];
     }
     __syncthreads();
-#pragma unroll
-    for (int u = 0; u < (n2 + 255) / 256; u++) {
-      const int t = tid + 256 * u;
-      if (t < n2) {
-        const int r = t / n, q = t - r * n;
-        double a0 = 0, a1 = 0;
-#pragma unroll 3
-        for (int v = 0; v < n; v += 2) {  // (E_{i2}^T G_{i2})[r][q] = sum_v E[v][r] G[v][q]
-          a0 += B0[v * n + r] * B1[v * n + q];
-          a1 += B0[(v + 1) * n + r] * B1[(v + 1) * n + q];
-        }
-        dacc[u] += a0 + a1;
-      }
-    }
+    if (has_tile) tile_mac<n, true, false>(B0, B1, tr, tq, 0, dacc);  // (E_{i2}^T G_{i2})[r][q] = sum_v E[v][r] G[v][q]
   }
+  if (has_tile) {
 #pragma unroll
-  for (int u = 0; u < (n2 + 255) / 256; u++) {
-    const int t = tid + 256 * u;
-    if (t < n2) d.bD[(long)j * n2 + t] -= dacc[u];
+    for (int ii = 0; ii < 6; ii++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) d.bD[(long)j * n2 + (6 * tr + ii) * n + 3 * tq + c] -= dacc[ii][c];
   }
 }
 
@@ -1373,24 +1375,30 @@ __device__ __forceinline__ double coldot(const double *M, int n, int r, const do
   }
   return a0 + a1;
 }
-__global__ void bcr_load_kernel(Dev d, const double *rin) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g < d.ncl * d.ncd) d.bx[g] = g < 6 * d.S ? rin[g] : 0.0;
+// The solve kernels take several right-hand sides at once (grid y = right-hand side q; vectors rin + q * rin_stride, z + q * z_stride,
+// work vector bx + q * ncl * ncd): the columns of the camera border go through one walk of the levels instead of one walk each.
+// (A single persistent launch for the whole walk was measured and dropped: cross-XCD synchronisation inside a kernel -- agent-scope
+// fences ~60 us, an arrival counter ~25 us, per-cluster progress words with sc1 accesses ~25 us per level -- costs more than the
+// 5-10 us of a back-to-back launch on this part.)
+__global__ void bcr_load_kernel(Dev d, const double *rin, long rin_stride) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x, q = blockIdx.y;
+  if (g < d.ncl * d.ncd) d.bx[(long)q * d.ncl * d.ncd + g] = g < 6 * d.S ? rin[q * rin_stride + g] : 0.0;
 }
 __global__ void __launch_bounds__(64) bcr_down_kernel(Dev d, int st) {
   __shared__ double xl[64], xr[64];
   const int n = d.ncd, n2 = n * n, r = threadIdx.x;
   const int j = 2 * blockIdx.x * st;
   if (j >= d.ncl) return;
+  double *bx = d.bx + (long)blockIdx.y * d.ncl * n;
   const int i1 = j - st, i2 = j + st;
-  xl[r] = (i1 >= 0 && r < n) ? d.bx[(long)i1 * n + r] : 0.0;
-  xr[r] = (i2 < d.ncl && r < n) ? d.bx[(long)i2 * n + r] : 0.0;
+  xl[r] = (i1 >= 0 && r < n) ? bx[(long)i1 * n + r] : 0.0;
+  xr[r] = (i2 < d.ncl && r < n) ? bx[(long)i2 * n + r] : 0.0;
   __syncthreads();
   if (r < n) {
-    double v = d.bx[(long)j * n + r];
+    double v = bx[(long)j * n + r];
     if (i1 >= 0) v -= coldot(d.bH + (long)i1 * n2, n, r, xl);
     if (i2 < d.ncl) v -= coldot(d.bG + (long)i2 * n2, n, r, xr);
-    d.bx[(long)j * n + r] = v;
+    bx[(long)j * n + r] = v;
   }
 }
 __global__ void __launch_bounds__(64) bcr_up_kernel(Dev d, int st, int root) {
@@ -1398,22 +1406,24 @@ __global__ void __launch_bounds__(64) bcr_up_kernel(Dev d, int st, int root) {
   const int n = d.ncd, n2 = n * n, r = threadIdx.x;
   const int i = root ? 0 : (2 * blockIdx.x + 1) * st;
   if (i >= d.ncl) return;
+  double *bx = d.bx + (long)blockIdx.y * d.ncl * n;
   const int l = i - st, rr = i + st;
-  xs[r] = r < n ? d.bx[(long)i * n + r] : 0.0;
-  xl[r] = (!root && l >= 0 && r < n) ? d.bx[(long)l * n + r] : 0.0;
-  xr[r] = (!root && rr < d.ncl && r < n) ? d.bx[(long)rr * n + r] : 0.0;
+  xs[r] = r < n ? bx[(long)i * n + r] : 0.0;
+  xl[r] = (!root && l >= 0 && r < n) ? bx[(long)l * n + r] : 0.0;
+  xr[r] = (!root && rr < d.ncl && r < n) ? bx[(long)rr * n + r] : 0.0;
   __syncthreads();
   if (r < n) {
     double v = rowdot(d.bD + (long)i * n2, n, r, xs);
     if (!root && l >= 0) v -= rowdot(d.bG + (long)i * n2, n, r, xl);
     if (!root && rr < d.ncl) v -= rowdot(d.bH + (long)i * n2, n, r, xr);
-    d.bx[(long)i * n + r] = v;
+    bx[(long)i * n + r] = v;
   }
 }
-__global__ void bcr_store_kernel(Dev d, const double *rin, double *z) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g < 6 * d.S) z[g] = d.bx[g];
-  if (g < d.NC) {
+// cam_rows: also the camera rows of z (3x3 block Jacobi), single right-hand side
+__global__ void bcr_store_kernel(Dev d, const double *rin, double *z, long z_stride, int cam_rows) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x, q = blockIdx.y;
+  if (g < 6 * d.S) z[q * z_stride + g] = d.bx[(long)q * d.ncl * d.ncd + g];
+  if (cam_rows && g < d.NC) {
     const double *Bi = d.Binv + 36 * (long)d.S + 9 * g, *rr = rin + d.cam0 + 3 * g;
     for (int i = 0; i < 3; i++) z[d.cam0 + 3 * g + i] = Bi[3 * i] * rr[0] + Bi[3 * i + 1] * rr[1] + Bi[3 * i + 2] * rr[2];
   }
@@ -1938,6 +1948,206 @@ __global__ void border_update_kernel(const double *W, double *z, int nb, int n, 
   z[t] -= acc;
 }
 
+
+// ---- exact camera border: every column of B = S [0; I] in one pass ------------------------------------------------------------
+// The columns of the reduced matrix that belong to the camera unknowns used to come from 3 NC mat-vecs with unit vectors (two
+// streaming passes over all observations each).  A unit vector has no shot part and touches an observation through its own
+// camera's three columns only, so all NB = 3 NC columns are formed together: pass A reads Jp and Jk once (t_o is 2 x 3 on the
+// observation's camera columns, u_p = sum Jp^T t and v_p = Hhat u_p are 3 x NB per point, w_o = t_o - Jp v_p is 2 x NB), pass B reads
+// Jc and Jk once.  Same summation orders as schur_point_coop_kernel<0> / schur_shot_kernel column by column.
+template <int NB>
+__global__ void __launch_bounds__(kCoopObs) border_point_kernel(Dev d, double *wB) {
+  constexpr int NC_ = NB / 3;
+  __shared__ double gsum[kCoopObs * 9];
+  __shared__ int gcam[kCoopObs];
+  __shared__ double vpt[kCoopObs * 3 * NB];
+  const int tid = threadIdx.x;
+  const int p0 = d.wg_pt[blockIdx.x], p1 = d.wg_pt[blockIdx.x + 1];
+  const long o0 = d.pt_off[p0], o1 = d.pt_off[p1];
+  const int nobs = (int)(o1 - o0);
+  if (nobs <= kCoopObs) {
+    double t0[3] = {0, 0, 0}, t1[3] = {0, 0, 0}, jp[6] = {0, 0, 0, 0, 0, 0};
+    int pl = 0, cam = 0;
+    const long o = o0 + tid;
+    if (tid < nobs) {
+      pl = d.o_point[o] - p0;
+      cam = d.shot_camera[d.o_shot[o]];
+      const double *sck = d.sc_red + d.cam0 + 3 * cam;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        t0[k] = JA(o, 20 + k) * sck[k];
+        t1[k] = JA(o, 23 + k) * sck[k];
+      }
+#pragma unroll
+      for (int j = 0; j < 6; j++) jp[j] = JA(o, 2 + j);
+#pragma unroll
+      for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) gsum[9 * tid + 3 * k + j] = jp[j] * t0[k] + jp[3 + j] * t1[k];
+      gcam[tid] = cam;
+    }
+    __syncthreads();
+    if (tid < p1 - p0) {
+      const int p = p0 + tid;
+      double u[NB][3];
+#pragma unroll
+      for (int c = 0; c < NB; c++) u[c][0] = u[c][1] = u[c][2] = 0.0;
+      const int a = (int)(d.pt_off[p] - o0), b = (int)(d.pt_off[p + 1] - o0);
+      for (int k = a; k < b; k++) {
+        const int cc = gcam[k];
+#pragma unroll
+        for (int c = 0; c < NC_; c++)
+          if (c == cc)
+#pragma unroll
+            for (int q = 0; q < 3; q++)
+#pragma unroll
+              for (int j = 0; j < 3; j++) u[3 * c + q][j] += gsum[9 * k + 3 * q + j];
+      }
+      const double *Hh = d.Hhat + 6 * (long)p;
+#pragma unroll
+      for (int c = 0; c < NB; c++) {
+        vpt[(3 * tid + 0) * NB + c] = Hh[0] * u[c][0] + Hh[1] * u[c][1] + Hh[2] * u[c][2];
+        vpt[(3 * tid + 1) * NB + c] = Hh[1] * u[c][0] + Hh[3] * u[c][1] + Hh[4] * u[c][2];
+        vpt[(3 * tid + 2) * NB + c] = Hh[2] * u[c][0] + Hh[4] * u[c][1] + Hh[5] * u[c][2];
+      }
+    }
+    __syncthreads();
+    if (tid < nobs) {
+      double2 *dst = reinterpret_cast<double2 *>(wB + 2L * NB * o);
+#pragma unroll
+      for (int c = 0; c < NB; c++) {
+        const double v0 = vpt[(3 * pl + 0) * NB + c], v1 = vpt[(3 * pl + 1) * NB + c], v2 = vpt[(3 * pl + 2) * NB + c];
+        const bool own = (c / 3) == cam;
+        double2 wv;
+        wv.x = (own ? t0[c % 3] : 0.0) - (jp[0] * v0 + jp[1] * v1 + jp[2] * v2);
+        wv.y = (own ? t1[c % 3] : 0.0) - (jp[3] * v0 + jp[4] * v1 + jp[5] * v2);
+        dst[c] = wv;
+      }
+    }
+    return;
+  }
+  // one long track: strided over the workgroup, fixed-order tree reduction (through vpt)
+  double u[NB][3];
+#pragma unroll
+  for (int c = 0; c < NB; c++) u[c][0] = u[c][1] = u[c][2] = 0.0;
+  for (long o = o0 + tid; o < o1; o += kCoopObs) {
+    const int cam = d.shot_camera[d.o_shot[o]];
+    const double *sck = d.sc_red + d.cam0 + 3 * cam;
+#pragma unroll
+    for (int c = 0; c < NC_; c++)
+      if (c == cam)
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const double t0 = JA(o, 20 + k) * sck[k], t1 = JA(o, 23 + k) * sck[k];
+#pragma unroll
+          for (int j = 0; j < 3; j++) u[3 * c + k][j] += JA(o, 2 + j) * t0 + JA(o, 5 + j) * t1;
+        }
+  }
+#pragma unroll
+  for (int c = 0; c < NB; c++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) vpt[(3 * tid + j) * NB + c] = u[c][j];
+  __syncthreads();
+  for (int h = kCoopObs / 2; h >= 1; h >>= 1) {
+    if (tid < h)
+      for (int q = 0; q < 3 * NB; q++) vpt[3 * NB * tid + q] += vpt[3 * NB * (tid + h) + q];
+    __syncthreads();
+  }
+  const double *Hh = d.Hhat + 6 * (long)p0;
+  double v[NB][3];
+#pragma unroll
+  for (int c = 0; c < NB; c++) {
+    const double u0 = vpt[0 * NB + c], u1 = vpt[1 * NB + c], u2 = vpt[2 * NB + c];
+    v[c][0] = Hh[0] * u0 + Hh[1] * u1 + Hh[2] * u2;
+    v[c][1] = Hh[1] * u0 + Hh[3] * u1 + Hh[4] * u2;
+    v[c][2] = Hh[2] * u0 + Hh[4] * u1 + Hh[5] * u2;
+  }
+  for (long o = o0 + tid; o < o1; o += kCoopObs) {
+    const int cam = d.shot_camera[d.o_shot[o]];
+    const double *sck = d.sc_red + d.cam0 + 3 * cam;
+#pragma unroll
+    for (int c = 0; c < NB; c++) {
+      const bool own = (c / 3) == cam;
+      const double t0 = own ? JA(o, 20 + c % 3) * sck[c % 3] : 0.0, t1 = own ? JA(o, 23 + c % 3) * sck[c % 3] : 0.0;
+      wB[(2L * NB * o) + 2 * c] = t0 - (JA(o, 2) * v[c][0] + JA(o, 3) * v[c][1] + JA(o, 4) * v[c][2]);
+      wB[(2L * NB * o) + 2 * c + 1] = t1 - (JA(o, 5) * v[c][0] + JA(o, 6) * v[c][1] + JA(o, 7) * v[c][2]);
+    }
+  }
+}
+
+// pass B: wavefront per shot.  Bc[c][6 s + j] = sc (sum Jc^T w_c) (the finish of the mat-vec on shot rows: no diagonal terms for a
+// camera unit vector), partB[s][3 x NB] = sum Jk^T w_c
+template <int NB>
+__global__ void __launch_bounds__(64) border_shot_kernel(Dev d, const double *wB, double *Bc, double *partB) {
+  const int s = blockIdx.x, lane = threadIdx.x;
+  double v[NB][9];
+#pragma unroll
+  for (int c = 0; c < NB; c++)
+#pragma unroll
+    for (int i = 0; i < 9; i++) v[c][i] = 0.0;
+  for (long k = d.shot_off[s] + lane; k < d.shot_off[s + 1]; k += 64) {
+    const long o = d.shot_obs[k];
+    const double2 *src = reinterpret_cast<const double2 *>(wB + 2L * NB * o);
+    double jc0[6], jc1[6], jk0[3], jk1[3];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      jc0[j] = JS(k, 8 + j);
+      jc1[j] = JS(k, 14 + j);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      jk0[j] = JS(k, 20 + j);
+      jk1[j] = JS(k, 23 + j);
+    }
+#pragma unroll
+    for (int c = 0; c < NB; c++) {
+      const double2 wv = src[c];
+#pragma unroll
+      for (int j = 0; j < 6; j++) v[c][j] += jc0[j] * wv.x + jc1[j] * wv.y;
+#pragma unroll
+      for (int j = 0; j < 3; j++) v[c][6 + j] += jk0[j] * wv.x + jk1[j] * wv.y;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NB; c++)
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) v[c][i] += __shfl_xor(v[c][i], m);
+  if (lane == 0) {
+    const long n6 = 6L * d.S;
+#pragma unroll
+    for (int c = 0; c < NB; c++) {
+      for (int j = 0; j < 6; j++) Bc[c * n6 + 6 * s + j] = d.sc_red[6 * s + j] * v[c][j];
+      for (int j = 0; j < 3; j++) partB[(long)s * 3 * NB + 3 * c + j] = v[c][6 + j];
+    }
+  }
+}
+
+// camera rows of the columns: Cm[(3 cam + k) * NB + c] = sc_i (sum over the camera's shots of partB + prior_diag_i y_i) + D_i / radius [i == c],
+// y = sc e_c  (schur_finish_kernel, mode 0, on the camera rows); one block per camera, fixed order
+template <int NB>
+__global__ void __launch_bounds__(TPB) border_cam_kernel(Dev d, const double *partB, double *Cm, double radius) {
+  __shared__ double lds[4 * 3 * NB];
+  const int cam = blockIdx.x;
+  double v[3 * NB];
+#pragma unroll
+  for (int i = 0; i < 3 * NB; i++) v[i] = 0.0;
+  for (int s = threadIdx.x; s < d.S; s += TPB)
+    if (d.shot_camera[s] == cam)
+#pragma unroll
+      for (int i = 0; i < 3 * NB; i++) v[i] += partB[(long)s * 3 * NB + i];
+  block_sum<3 * NB>(v, lds);
+  if (threadIdx.x == 0)
+    for (int c = 0; c < NB; c++)
+      for (int k = 0; k < 3; k++) {
+        const int i = d.cam0 + 3 * cam + k;
+        const bool diag = (3 * cam + k) == c;
+        const double y = diag ? d.sc_red[i] : 0.0;
+        Cm[(3 * cam + k) * NB + c] = d.sc_red[i] * (v[3 * c + k] + d.prior_diag[i] * y) + (diag ? d.D_red[i] / radius : 0.0);
+      }
+}
+
 // ---- setup helpers: the observation arrays are permuted on the device (host only builds the index lists) ----
 __global__ void gather_pm_kernel(const int *perm, const double *raw_xy, const double *raw_sigma, long M, double *o_x, double *o_y,
                                  double *o_sigma) {
@@ -2026,15 +2236,19 @@ struct Solver {
   }
   bool use_band = false, use_ctri = false, use_bcr = false, use_border = false;
   double *Bc = nullptr, *Wb = nullptr, *SigInv = nullptr, *dots = nullptr;  // border elimination (nb x 6S, nb x 6S, nb x nb, nb x nb)
-  void bcr_solve(const double *r, double *z) {
+  double *wB = nullptr, *partB = nullptr, *dCm = nullptr;                     // its columns in one pass: w (2 nb per observation), camera partials, C
+  // z_q = A^-1 r_q for nrhs right-hand sides (strides in doubles) in one walk of the levels
+  void bcr_solve_multi(const double *r, long r_stride, double *z, long z_stride, int nrhs, bool cam_rows) {
     const int N = d.ncl;
-    hipLaunchKernelGGL(bcr_load_kernel, dim3(nblk((long)N * d.ncd)), dim3(TPB), 0, st, d, r);
+    const unsigned q = (unsigned)nrhs;
+    hipLaunchKernelGGL(bcr_load_kernel, dim3(nblk((long)N * d.ncd), q), dim3(TPB), 0, st, d, r, r_stride);
     int stq = 1;
-    for (; stq < N; stq *= 2) hipLaunchKernelGGL(bcr_down_kernel, dim3((N + 2 * stq - 1) / (2 * stq)), dim3(64), 0, st, d, stq);
-    hipLaunchKernelGGL(bcr_up_kernel, dim3(1), dim3(64), 0, st, d, 0, 1);
-    for (stq /= 2; stq >= 1; stq /= 2) hipLaunchKernelGGL(bcr_up_kernel, dim3((N + 2 * stq - 1) / (2 * stq)), dim3(64), 0, st, d, stq, 0);
-    hipLaunchKernelGGL(bcr_store_kernel, dim3(nblk(6L * d.S)), dim3(TPB), 0, st, d, r, z);
+    for (; stq < N; stq *= 2) hipLaunchKernelGGL(bcr_down_kernel, dim3((N + 2 * stq - 1) / (2 * stq), q), dim3(64), 0, st, d, stq);
+    hipLaunchKernelGGL(bcr_up_kernel, dim3(1, q), dim3(64), 0, st, d, 0, 1);
+    for (stq /= 2; stq >= 1; stq /= 2) hipLaunchKernelGGL(bcr_up_kernel, dim3((N + 2 * stq - 1) / (2 * stq), q), dim3(64), 0, st, d, stq, 0);
+    hipLaunchKernelGGL(bcr_store_kernel, dim3(nblk(6L * d.S), q), dim3(TPB), 0, st, d, r, z, z_stride, cam_rows ? 1 : 0);
   }
+  void bcr_solve(const double *r, double *z) { bcr_solve_multi(r, 0, z, 0, 1, true); }
   void precond(const double *r, double *z) {
     if (use_bcr && use_border) {
       const int nb = 3 * d.NC, n = 6 * d.S;
@@ -2443,12 +2657,15 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     d.bE = A.alloc<double>(nb, e);
     d.bG = A.alloc<double>(nb, e);
     d.bH = A.alloc<double>(nb, e);
-    d.bx = A.alloc<double>((size_t)d.ncl * d.ncd, e);
+    d.bx = A.alloc<double>((size_t)6 * d.ncl * d.ncd, e);  // up to 6 right-hand sides at a time (the camera border)
     if (3 * NC <= 6) {  // exact camera border: see border_rhs_kernel
       sv.Bc = A.alloc<double>((size_t)3 * NC * 6 * S, e);
       sv.Wb = A.alloc<double>((size_t)3 * NC * 6 * S, e);
       sv.SigInv = A.alloc<double>(36, e);
       sv.dots = A.alloc<double>(36, e);
+      sv.dCm = A.alloc<double>(36, e);
+      sv.wB = A.alloc<double>((size_t)2 * 3 * NC * M, e);
+      sv.partB = A.alloc<double>((size_t)S * 9 * NC, e);
     }
   }
   bool border_ok = getenv("OSFM_BA_NO_BORDER") == nullptr;  // exact camera border: every camera free
@@ -2504,9 +2721,6 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     const auto t_lin = std::chrono::steady_clock::now();
     // ---- linear solve: PCG on the implicit Schur complement ----
     hipLaunchKernelGGL(point_hhat_kernel, dim3(nblk(NP)), dim3(TPB), 0, st, d, radius);
-    hipLaunchKernelGGL(precond_shot_kernel, dim3(S), dim3(64), 0, st, d, radius);
-    hipLaunchKernelGGL(cam_reduce_kernel, dim3(NC), dim3(TPB), 0, st, d, 6);
-    hipLaunchKernelGGL(precond_cam_kernel, dim3(nblk(NC, 64)), dim3(64), 0, st, d, radius);
     sv.use_band = false;
     if (d.bw > 0) {
       const int R = d.bw + 1;
@@ -2546,19 +2760,19 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
         sv.use_border = false;
         if (sv.use_bcr && sv.Bc && border_ok) {
           const int nb = 3 * NC, n6 = 6 * S;
-          std::vector<double> Cm((size_t)nb * nb), Sg((size_t)nb * nb), col((size_t)nb);
-          for (int j = 0; j < nb; j++) {
-            hipLaunchKernelGGL(unit_vec_kernel, dim3(nbr), dim3(TPB), 0, st, d.p, nred, d.cam0 + j);
-            sv.matvec(d.p, d.Ap, radius);
-            OSFM_HIP(hipMemcpyAsync(sv.Bc + (size_t)j * n6, d.Ap, (size_t)n6 * sizeof(double), hipMemcpyDeviceToDevice, st));
-            OSFM_HIP(hipMemcpyAsync(col.data(), d.Ap + d.cam0, (size_t)nb * sizeof(double), hipMemcpyDeviceToHost, st));
-            // r = [B e_j ; 0]  ->  z_s = A^-1 B e_j
-            OSFM_HIP(hipMemsetAsync(d.Ap + d.cam0, 0, (size_t)nb * sizeof(double), st));
-            sv.bcr_solve(d.Ap, d.z);
-            OSFM_HIP(hipMemcpyAsync(sv.Wb + (size_t)j * n6, d.z, (size_t)n6 * sizeof(double), hipMemcpyDeviceToDevice, st));
-            OSFM_HIP(hipStreamSynchronize(st));
-            for (int i = 0; i < nb; i++) Cm[(size_t)i * nb + j] = col[(size_t)i];
+          std::vector<double> Cm((size_t)nb * nb), Sg((size_t)nb * nb);
+          // all nb columns of B (and of the camera block C) in one pass over the observations, W = A^-1 B in one solve launch
+          if (nb == 3) {
+            hipLaunchKernelGGL(border_point_kernel<3>, dim3(d.nwg), dim3(kCoopObs), 0, st, d, sv.wB);
+            hipLaunchKernelGGL(border_shot_kernel<3>, dim3(S), dim3(64), 0, st, d, sv.wB, sv.Bc, sv.partB);
+            hipLaunchKernelGGL(border_cam_kernel<3>, dim3(NC), dim3(TPB), 0, st, d, sv.partB, sv.dCm, radius);
+          } else {
+            hipLaunchKernelGGL(border_point_kernel<6>, dim3(d.nwg), dim3(kCoopObs), 0, st, d, sv.wB);
+            hipLaunchKernelGGL(border_shot_kernel<6>, dim3(S), dim3(64), 0, st, d, sv.wB, sv.Bc, sv.partB);
+            hipLaunchKernelGGL(border_cam_kernel<6>, dim3(NC), dim3(TPB), 0, st, d, sv.partB, sv.dCm, radius);
           }
+          sv.bcr_solve_multi(sv.Bc, n6, sv.Wb, n6, nb, false);
+          OSFM_HIP(hipMemcpyAsync(Cm.data(), sv.dCm, (size_t)nb * nb * sizeof(double), hipMemcpyDeviceToHost, st));
           hipLaunchKernelGGL(border_dots_kernel, dim3(nb * nb), dim3(TPB), 0, st, sv.Bc, sv.Wb, nb, n6, sv.dots);
           OSFM_HIP(hipMemcpyAsync(Sg.data(), sv.dots, (size_t)nb * nb * sizeof(double), hipMemcpyDeviceToHost, st));
           OSFM_HIP(hipStreamSynchronize(st));
@@ -2624,6 +2838,13 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
         sv.use_ctri = true;
       }
       }
+    }
+    // block-Jacobi blocks (6x6 per shot, 3x3 per camera): the fallback preconditioner, and the camera rows of the band
+    // preconditioners -- not needed when the cyclic reduction came out with the exact camera border
+    if (!(sv.use_bcr && sv.use_border)) {
+      hipLaunchKernelGGL(precond_shot_kernel, dim3(S), dim3(64), 0, st, d, radius);
+      hipLaunchKernelGGL(cam_reduce_kernel, dim3(NC), dim3(TPB), 0, st, d, 6);
+      hipLaunchKernelGGL(precond_cam_kernel, dim3(nblk(NC, 64)), dim3(64), 0, st, d, radius);
     }
     // rhs
     hipLaunchKernelGGL(schur_point_coop_kernel<1>, dim3(d.nwg), dim3(kCoopObs), 0, st, d, d.y);
