@@ -29,7 +29,8 @@ extern "C" {
 #define OSFM_E_NUMERIC (-5) /* NaN/Inf in results: reference throws (ba_helpers.cc:780-814) */
 
 #define OSFM_DESC_DIM 128
-#define OSFM_MAX_FEATURES 8192 /* per image: LDS-resident per-feature state of the matcher and of the RANSAC kernel */
+#define OSFM_MAX_FEATURES 16000 /* per image (feature_min_frames_panorama, config.py:31): the matcher keeps 6 B of LDS per feature
+                                   (160 KiB at 16000); the RANSAC kernel stages its correspondences in LDS up to ~9000 and in HBM above */
 
 typedef struct osfm_ctx osfm_ctx;     /* one per process/GPU: device, streams, scratch */
 typedef struct osfm_store osfm_store; /* device-resident descriptor + keypoint store */

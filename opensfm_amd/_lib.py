@@ -184,7 +184,7 @@ def check(status: int, what: str = "") -> None:
 
 _tls = threading.local()
 
-MAX_FEATURES = 8192      # OSFM_MAX_FEATURES
+MAX_FEATURES = 16000     # OSFM_MAX_FEATURES
 MATCH_EXACT_KERNEL = 1   # OSFM_MATCH_EXACT_KERNEL
 MATCH_SQUARED_RATIO = 2  # OSFM_MATCH_SQUARED_RATIO
 

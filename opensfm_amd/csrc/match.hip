@@ -985,8 +985,8 @@ static int ensure_kernel_attributes(int device) {
   return once.run(device, []() -> int {
     OSFM_HIP(hipFuncSetAttribute((const void *)match_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     OSFM_HIP(hipFuncSetAttribute((const void *)match_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    OSFM_HIP(hipFuncSetAttribute((const void *)match_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    OSFM_HIP(hipFuncSetAttribute((const void *)match_float_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    OSFM_HIP(hipFuncSetAttribute((const void *)match_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    OSFM_HIP(hipFuncSetAttribute((const void *)match_float_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return OSFM_OK;
   });
 }

@@ -481,14 +481,16 @@ struct RansacPairsArgs {
   uint32_t *matches;
   double *F_out;
   unsigned long long *work;  // optional: += (models scored) x (correspondences) of every pair, the work the roofline line counts
+  float4 *scratch;           // images with more features than the LDS point buffer holds: n_pairs x capr correspondences in HBM
+  int lds_pts;               // capacity of the LDS point buffer (correspondences)
 };
 
 __global__ void __launch_bounds__(kThreads) ransac_pairs_kernel(RansacPairsArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   RansacShared &sh = *reinterpret_cast<RansacShared *>(smem);
   const int capr = (a.cap + 3) & ~3;
-  float4 *ptsbuf = reinterpret_cast<float4 *>(smem + sizeof(RansacShared));  // [capr]
-  int *misc = reinterpret_cast<int *>(ptsbuf + capr);                        // [8]
+  float4 *ptsbuf = reinterpret_cast<float4 *>(smem + sizeof(RansacShared));  // [lds_pts]
+  int *misc = reinterpret_cast<int *>(ptsbuf + a.lds_pts);                   // [8]
   const int tid = threadIdx.x;
   const int lane = tid & 63, w = tid >> 6;
   const long p = blockIdx.x;
@@ -501,6 +503,7 @@ __global__ void __launch_bounds__(kThreads) ransac_pairs_kernel(RansacPairsArgs 
   const int img1 = a.pairs[2 * p], img2 = a.pairs[2 * p + 1];
   const double *pts1 = a.pts + a.tile_off[img1] * 64;
   const double *pts2 = a.pts + a.tile_off[img2] * 64;
+  if (n > a.lds_pts) ptsbuf = a.scratch + p * capr;  // a pair of large images with more matches than LDS holds (uniform per workgroup)
   if (tid == 0) sh.pts = ptsbuf;
   for (int k = tid; k < n; k += kThreads) {
     const uint32_t m = a.matches[p * a.cap + k];
@@ -554,11 +557,11 @@ __global__ void __launch_bounds__(kThreads) ransac_pairs_kernel(RansacPairsArgs 
 
 __global__ void __launch_bounds__(kThreads) ransac_single_kernel(const double *p1, const double *p2, int n, double thr,
                                                                    double conf, int max_iters, double *F_out,
-                                                                   uint8_t *mask, int32_t *info) {
+                                                                   uint8_t *mask, int32_t *info, float4 *scratch) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   RansacShared &sh = *reinterpret_cast<RansacShared *>(smem);
   const int tid = threadIdx.x;
-  float4 *ptsbuf = reinterpret_cast<float4 *>(smem + sizeof(RansacShared));
+  float4 *ptsbuf = scratch ? scratch : reinterpret_cast<float4 *>(smem + sizeof(RansacShared));
   if (tid == 0) sh.pts = ptsbuf;
   for (int k = tid; k < n; k += kThreads)
     ptsbuf[k] = make_float4((float)p1[2 * k], (float)p1[2 * k + 1], (float)p2[2 * k], (float)p2[2 * k + 1]);
@@ -727,6 +730,8 @@ __global__ void __launch_bounds__(64) lmeds_single_kernel(const double *p1, cons
 
 }  // namespace
 
+int osfm_ransac_lds_points() { return (int)((160 * 1024 - sizeof(RansacShared) - 64) / 16) & ~3; }
+
 static int ensure_ransac_attributes(int device) {
   static OsfmPerDeviceOnce once;
   return once.run(device, []() -> int {
@@ -738,9 +743,9 @@ static int ensure_ransac_attributes(int device) {
 
 int osfm_launch_ransac_pairs(osfm_ctx *ctx, const osfm_store *store, const int32_t *d_pairs, int64_t n_pairs, int cap,
                              int min_match, double thr, double conf, int max_iters, int32_t *d_counts,
-                             uint32_t *d_matches, double *d_F_or_null, hipStream_t stream, unsigned long long *d_work_or_null) {
+                             uint32_t *d_matches, double *d_F_or_null, hipStream_t stream, unsigned long long *d_work_or_null,
+                             void *d_scratch_or_null) {
   if (n_pairs == 0) return OSFM_OK;
-  OSFM_REQUIRE(cap <= kMaxPts, OSFM_E_UNSUPPORTED, "cap %d > %d", cap, kMaxPts);
   RansacPairsArgs a;
   a.pts = store->d_pts;
   a.tile_off = store->d_tile_off;
@@ -755,7 +760,11 @@ int osfm_launch_ransac_pairs(osfm_ctx *ctx, const osfm_store *store, const int32
   a.matches = d_matches;
   a.F_out = d_F_or_null;
   a.work = d_work_or_null;
-  const size_t lds = sizeof(RansacShared) + (size_t)((cap + 3) & ~3) * 16 + 64;
+  const int capr = (cap + 3) & ~3;
+  a.lds_pts = std::min(capr, osfm_ransac_lds_points());
+  a.scratch = (float4 *)d_scratch_or_null;
+  OSFM_REQUIRE(capr <= a.lds_pts || a.scratch != nullptr, OSFM_E_INVALID, "ransac: cap %d needs the HBM correspondence buffer", cap);
+  const size_t lds = sizeof(RansacShared) + (size_t)a.lds_pts * 16 + 64;
   {
     const int rc = ensure_ransac_attributes(ctx->device);
     if (rc != OSFM_OK) return rc;
@@ -766,8 +775,9 @@ int osfm_launch_ransac_pairs(osfm_ctx *ctx, const osfm_store *store, const int32
 }
 
 int osfm_launch_ransac_single(osfm_ctx *ctx, const double *d_p1, const double *d_p2, int n, double thr, double conf,
-                              int max_iters, double *d_F, uint8_t *d_mask, int32_t *d_info) {
-  OSFM_REQUIRE(n <= kMaxPts, OSFM_E_UNSUPPORTED, "more than %d correspondences", kMaxPts);
+                              int max_iters, double *d_F, uint8_t *d_mask, int32_t *d_info, void *d_scratch_or_null) {
+  const bool in_lds = ((n + 3) & ~3) <= osfm_ransac_lds_points();
+  OSFM_REQUIRE(in_lds || d_scratch_or_null, OSFM_E_INVALID, "ransac: %d correspondences need the HBM buffer", n);
   {
     const int rc = ensure_ransac_attributes(ctx->device);
     if (rc != OSFM_OK) return rc;
@@ -775,8 +785,8 @@ int osfm_launch_ransac_single(osfm_ctx *ctx, const double *d_p1, const double *d
   if (n < 15)  // cv2 switches to LMedS below 15 correspondences
     hipLaunchKernelGGL(lmeds_single_kernel, dim3(1), dim3(64), 0, ctx->stream, d_p1, d_p2, n, conf, max_iters, d_F, d_mask, d_info);
   else
-    hipLaunchKernelGGL(ransac_single_kernel, dim3(1), dim3(kThreads), sizeof(RansacShared) + (size_t)((n + 3) & ~3) * 16 + 64, ctx->stream, d_p1, d_p2,
-                       n, thr, conf, max_iters, d_F, d_mask, d_info);
+    hipLaunchKernelGGL(ransac_single_kernel, dim3(1), dim3(kThreads), sizeof(RansacShared) + (in_lds ? (size_t)((n + 3) & ~3) * 16 : 0) + 64, ctx->stream,
+                       d_p1, d_p2, n, thr, conf, max_iters, d_F, d_mask, d_info, in_lds ? (float4 *)nullptr : (float4 *)d_scratch_or_null);
   OSFM_HIP(hipGetLastError());
   return OSFM_OK;
 }
@@ -799,12 +809,14 @@ extern "C" int osfm_ransac_fundamental(osfm_ctx *ctx, const double *p1, const do
   OSFM_HIP(hipMalloc((void **)&d_F, 9 * 8));
   OSFM_HIP(hipMalloc((void **)&d_mask, (size_t)n));
   OSFM_HIP(hipMalloc((void **)&d_info, 16));
+  void *d_scratch = nullptr;
+  if (((n + 3) & ~3) > osfm_ransac_lds_points()) OSFM_HIP(hipMalloc(&d_scratch, (size_t)((n + 3) & ~3) * 16));
   int rc = OSFM_OK;
   hipError_t e;
   do {
     if ((e = hipMemcpyAsync(d_p1, p1, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
     if ((e = hipMemcpyAsync(d_p2, p2, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
-    rc = osfm_launch_ransac_single(ctx, d_p1, d_p2, n, thr, conf, max_iters, d_F, d_mask, d_info);
+    rc = osfm_launch_ransac_single(ctx, d_p1, d_p2, n, thr, conf, max_iters, d_F, d_mask, d_info, d_scratch);
     if (rc != OSFM_OK) break;
     int32_t info[4] = {0, 0, 0, 0};
     if ((e = hipMemcpyAsync(F, d_F, 72, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
@@ -819,6 +831,7 @@ extern "C" int osfm_ransac_fundamental(osfm_ctx *ctx, const double *p1, const do
   (void)hipFree(d_F);
   (void)hipFree(d_mask);
   (void)hipFree(d_info);
+  (void)hipFree(d_scratch);
   if (rc == OSFM_OK && e != hipSuccess) {
     osfm_set_error("osfm_ransac_fundamental: %s", hipGetErrorString(e));
     rc = OSFM_E_HIP;

@@ -171,7 +171,7 @@ def test_second_best_in_the_same_class_as_the_best(oracle_lib, gpu_ctx):
 
 def test_more_than_4096_features_full_pipeline(oracle_lib, gpu_ctx):
     """Images above 4096 features (OpenSfM's HAHOG default asks for >= 4000 per image): the v4 keys carry no tile
-    index, the per-feature LDS state and the RANSAC point buffer hold up to OSFM_MAX_FEATURES = 8192."""
+    index, the per-feature LDS state holds up to OSFM_MAX_FEATURES = 16000."""
     from opensfm_amd import matching
 
     sc = synthetic.make_matching_scene(5, 5200, seed=19)
@@ -184,6 +184,33 @@ def test_more_than_4096_features_full_pipeline(oracle_lib, gpu_ctx):
     for g, w in zip(got, want):
         assert np.array_equal(g, w)
     assert counts.sum() > 1000
+
+
+def test_panorama_sized_images_full_pipeline(oracle_lib, gpu_ctx):
+    """feature_min_frames_panorama = 16000 (config.py:31): images at OSFM_MAX_FEATURES -- 160 KiB of LDS in the matcher, the RANSAC
+    correspondences of the dense pair in HBM (more matches than its LDS point buffer holds) -- against the oracle"""
+    from opensfm_amd import matching
+
+    rng = np.random.default_rng(3)
+    n = 16000
+    base = rng.integers(0, 140, (n, 128))
+    d0 = np.clip(base + rng.integers(-4, 5, base.shape), 0, 255).astype(np.uint8)
+    d1 = np.clip(base + rng.integers(-4, 5, base.shape), 0, 255).astype(np.uint8)   # 16000 true matches with image 0
+    d2 = np.clip(np.concatenate([base[:3000], rng.integers(0, 140, (9500, 128))]) + rng.integers(-4, 5, (12500, 128)), 0, 255).astype(np.uint8)
+    p1, p2, _ = synthetic.make_two_view(n, 0.97, 5)
+    pts = np.concatenate([p1, p2, np.concatenate([p1[:3000], rng.uniform(-0.4, 0.4, (9500, 2))])])  # image 2 = view 1 again: a proper pair with image 1
+    desc = np.concatenate([d0, d1, d2])
+    offsets = np.array([0, n, 2 * n, 2 * n + 12500])
+    pairs = np.array([[0, 1], [0, 2], [1, 2]], np.int32)
+    store = matching.DescriptorStore.from_packed(desc, pts, offsets)
+    counts, m = matching.match_pairs(store, pairs)
+    want = oracle_lib.match_pairs(desc.astype(np.float32), pts, offsets, pairs)
+    got = matching.split_matches(counts, m)
+    assert [len(g) for g in got] == [len(w) for w in want]
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    assert counts[0] > 12000 and counts[2] > 2000
+    store.close()
 
 
 def test_ties_and_duplicates_above_4096_features(oracle_lib, gpu_ctx):

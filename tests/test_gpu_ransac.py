@@ -10,7 +10,8 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize(
     "n,frac,seed", [(8, 1.1, 20), (9, 0.8, 21), (12, 0.7, 22), (14, 1.1, 23), (14, 0.5, 24),  # LMedS branch (n < 15)
                     (15, 0.9, 0), (20, 0.8, 1), (64, 0.7, 2), (65, 0.5, 3), (300, 0.6, 4), (1000, 0.3, 5), (2000, 0.45, 6),
-                    (100, 0.0, 7), (4096, 0.5, 8), (8192, 0.55, 13)]
+                    (100, 0.0, 7), (4096, 0.5, 8), (8192, 0.55, 13),
+                    (12000, 0.6, 14)]  # above the LDS point buffer: correspondences staged in HBM
 )
 def test_leaf_equals_oracle_bitwise(oracle_lib, gpu_ctx, n, frac, seed):
     from opensfm_amd import matching
