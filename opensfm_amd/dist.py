@@ -41,39 +41,71 @@ def shard_pairs(pairs: np.ndarray, rank: int, world: int, block: int = BLOCK) ->
     return np.ascontiguousarray(pairs[shard_indices(len(pairs), rank, world, block)])
 
 
+_PINNED = {}  # (tag, dtype) -> pinned host tensor, grown on demand: page-locked staging for the exchange step
+
+
+def _pinned(tag: str, n: int, dtype):
+    import torch
+
+    t = _PINNED.get((tag, dtype))
+    if t is None or t.numel() < n:
+        t = torch.empty(max(n, 1) + max(n, 1) // 4, dtype=dtype, pin_memory=True)
+        _PINNED[(tag, dtype)] = t
+    return t[:n]
+
+
+def _all_gather_padded(local: np.ndarray, maxlen: int, world: int, dev, on_gpu: bool, tag: str) -> np.ndarray:
+    """all-gather of one int32 vector per rank, padded to ``maxlen``; returns a (world, maxlen) host array.
+    RCCL: one ``all_gather_into_tensor`` between device buffers, page-locked staging on both sides (one H2D of the local shard,
+    one D2H of the gathered graph); gloo (CPU tests): the list form on host tensors."""
+    import torch
+    import torch.distributed as dist
+
+    local = np.ascontiguousarray(local, np.int32).reshape(-1)
+    if on_gpu:
+        stage = _pinned(tag + "_in", maxlen, torch.int32)
+        stage[: local.size].copy_(torch.from_numpy(local))
+        if local.size < maxlen:
+            stage[local.size:].zero_()
+        send = torch.empty(maxlen, dtype=torch.int32, device=dev)
+        send.copy_(stage, non_blocking=True)
+        recv = torch.empty(world * maxlen, dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(recv, send)
+        out = _pinned(tag + "_out", world * maxlen, torch.int32)
+        out.copy_(recv, non_blocking=True)
+        torch.cuda.current_stream(dev).synchronize()
+        return out.numpy().reshape(world, maxlen)
+    send = torch.zeros(maxlen, dtype=torch.int32)
+    send[: local.size] = torch.from_numpy(local)
+    parts = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(parts, send)
+    return np.stack([t.numpy() for t in parts])
+
+
 def all_gather_match_graph(counts: np.ndarray, matches: np.ndarray, n_pairs: int, rank: int, world: int,
-                           local_rank: Optional[int] = None, block: int = BLOCK, reorder: bool = True) -> Tuple[np.ndarray, np.ndarray]:
+                           local_rank: Optional[int] = None, block: int = BLOCK, reorder: bool = True,
+                           force_collective: bool = False) -> Tuple[np.ndarray, np.ndarray]:
     """Every rank contributes (counts, matches) of its shard; every rank returns the global
     (counts[n_pairs], matches[total, 2]): in the order of the original pair list (``reorder=True``), or
     rank-major -- shard after shard, the order ``gathered_pair_order`` describes -- which needs no
-    scatter of the tens of millions of match rows on the host (``reorder=False``)."""
-    if world == 1:
+    scatter of the tens of millions of match rows on the host (``reorder=False``).
+    ``force_collective``: go through the collectives even with one rank (exercises the RCCL calls on a single GPU)."""
+    if world == 1 and not force_collective:
         return counts, matches
     import torch
     import torch.distributed as dist
 
     on_gpu = dist.get_backend() == "nccl"
     dev = torch.device("cuda", local_rank if local_rank is not None else rank) if on_gpu else torch.device("cpu")
-    idx = _all_shards(n_pairs, world, block)
-    maxn = max(len(i) for i in idx)
-    c = torch.zeros(maxn, dtype=torch.int32)
-    c[: len(counts)] = torch.from_numpy(np.ascontiguousarray(counts, np.int32))
-    c = c.to(dev)
-    allc = [torch.empty_like(c) for _ in range(world)]
-    dist.all_gather(allc, c)
-    allc = [t.cpu().numpy() for t in allc]
+    idx = _all_shards(n_pairs, world, block) if world > 1 else [np.arange(n_pairs, dtype=np.int64)]
+    maxn = max(1, max(len(i) for i in idx))
+    allc = _all_gather_padded(counts, maxn, world, dev, on_gpu, "counts").copy()  # the staging buffer is reused below
     totals = [int(allc[r][: len(idx[r])].sum()) for r in range(world)]
     maxm = max(1, max(totals))
-    m = torch.zeros(maxm * 2, dtype=torch.int32)
-    flat = np.ascontiguousarray(matches, np.int32).reshape(-1)
-    m[: flat.size] = torch.from_numpy(flat)
-    m = m.to(dev)
-    allm = [torch.empty_like(m) for _ in range(world)]
-    dist.all_gather(allm, m)
+    allm = _all_gather_padded(matches, 2 * maxm, world, dev, on_gpu, "matches")
     if not reorder:
         counts_g = np.concatenate([allc[r][: len(idx[r])] for r in range(world)])
-        hm = [allm[r].cpu().numpy() for r in range(world)]
-        matches_g = np.concatenate([hm[r][: 2 * totals[r]] for r in range(world)]).reshape(-1, 2)
+        matches_g = np.concatenate([allm[r][: 2 * totals[r]] for r in range(world)]).reshape(-1, 2)
         return counts_g, matches_g
     counts_g = np.zeros(n_pairs, np.int32)
     for r in range(world):
@@ -87,5 +119,5 @@ def all_gather_match_graph(counts: np.ndarray, matches: np.ndarray, n_pairs: int
             continue
         roff = np.concatenate([[0], np.cumsum(cr)])[:-1]
         dest = np.repeat(goff[idx[r]] - roff, cr) + np.arange(tot)
-        matches_g[dest] = allm[r].cpu().numpy()[: 2 * tot].reshape(-1, 2)
+        matches_g[dest] = allm[r][: 2 * tot].reshape(-1, 2)
     return counts_g, matches_g
