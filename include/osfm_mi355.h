@@ -407,6 +407,23 @@ int osfm_match_guided(osfm_ctx *ctx, const float *f1, int n1, const float *f2, i
                       const float *b1, const float *b2, const double *R, const double *t, double threshold, double ratio,
                       int symmetric, int32_t *out_pairs, int cap, int *out_n);
 
+/*
+ * Guided matching for a whole pair list over the resident store: the body of match_images_with_pairs when `poses` are given
+ * (opensfm/matching.py:63-98 -> match_unwrap_args :204-207 -> match() :563-634 with _match_descriptors_guided_impl :260-337):
+ * per pair the epipolar mask compute_inliers_bearing_epipolar (:847-868), match_brute_force[_symmetric] under that mask, the
+ * robust_matching_min_match gates and robust_match -- descriptor stage in three launches per chunk of pairs (guided.hip), robust
+ * stage as in osfm_match_pairs (params->robust: fundamental-matrix RANSAC) or osfm_match_pairs_calibrated (cam_model / cam_params /
+ * relpose given; otherwise pass all three as NULL).
+ * bearings: sum(counts) x 3 float32 in the store's image / feature order (feature_loader.load_bearings);
+ * poses:    n_pairs x 12, per pair R = relative_pose.get_R_cam_to_world() (row-major) then t = relative_pose.get_origin(),
+ *           relative_pose = pose2.relative_to(pose1) (matching.py:204-207);
+ * threshold: config guided_matching_threshold (radians).  Integer-valued descriptors only.
+ */
+int osfm_match_pairs_guided(osfm_ctx *ctx, const osfm_store *store, const float *bearings, const int32_t *pairs, int64_t n_pairs,
+                            const double *poses, double threshold, const osfm_match_params *params, const int32_t *cam_model_or_null,
+                            const double *cam_params_or_null, const osfm_relpose_params *relpose_or_null, osfm_match_result **out,
+                            osfm_match_timings *timings_or_null);
+
 /* =====================================================================================
  * Bag-of-words side of pair matching and pair preselection.
  *

@@ -98,6 +98,11 @@ SIGNATURES = {
         [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_int64, C.POINTER(MatchParams),
          C.POINTER(RelposeParams), C.POINTER(C.c_void_p), C.POINTER(MatchTimings)],
     ),
+    "osfm_match_pairs_guided": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_int64, C.POINTER(C.c_double), C.c_double, C.POINTER(MatchParams),
+         C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(RelposeParams), C.POINTER(C.c_void_p), C.POINTER(MatchTimings)],
+    ),
     "osfm_result_num_pairs": (C.c_int64, [C.c_void_p]),
     "osfm_result_total_matches": (C.c_int64, [C.c_void_p]),
     "osfm_result_fetch": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

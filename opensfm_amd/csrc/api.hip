@@ -274,7 +274,7 @@ struct DevBuf {
 
 static int match_pairs_impl(osfm_ctx *ctx, const osfm_store *store, const int32_t *pairs, int64_t n_pairs,
                             const osfm_match_params *params, const OsfmCalibStage *calib, osfm_match_result **out,
-                            osfm_match_timings *tm) {
+                            osfm_match_timings *tm, const OsfmGuidedStage *guided = nullptr) {
   OSFM_REQUIRE(ctx && store && params && out && (pairs || n_pairs == 0), OSFM_E_INVALID, "osfm_match_pairs: null argument");
   OSFM_REQUIRE(n_pairs >= 0, OSFM_E_INVALID, "n_pairs < 0");
   OSFM_REQUIRE(calib || !params->robust || params->robust_matching_min_match >= 15, OSFM_E_UNSUPPORTED,
@@ -294,12 +294,14 @@ static int match_pairs_impl(osfm_ctx *ctx, const osfm_store *store, const int32_
   // B underneath the matcher of chunk k + 1, which a neighbour-preselected list (every pair reaches RANSAC) needs most
   int64_t cp = n_pairs < chunk_pairs ? n_pairs : chunk_pairs;
   if (n_pairs >= 8192) cp = std::min<int64_t>(cp, std::max<int64_t>(4096, (n_pairs + 3) / 4));
+  if (guided) cp = std::min<int64_t>(cp, 8192);  // 96 B of epipolar vectors + 8 B of results per feature and pair in the chunk's scratch
   const int64_t nchunks = (n_pairs + cp - 1) / (cp > 0 ? cp : 1);
   // Two chunk buffer sets: while stream B runs RANSAC + gather + D2H of chunk k (a few thousand
   // workgroups, latency bound, plus two host round trips), stream A already runs the fused matcher
   // of chunk k + 1, which fills the machine on its own.
   struct ChunkSet {
     DevBuf pairs, counts, matches, flags, offsets, gather;
+    DevBuf poses, six, good;  // guided matching: relative poses, per-pair epipolar vectors, per-direction results
     size_t gather_cap = 0;
     hipEvent_t m0 = nullptr, m1 = nullptr, r0 = nullptr, r1 = nullptr;
     ~ChunkSet() {
@@ -316,6 +318,13 @@ static int match_pairs_impl(osfm_ctx *ctx, const osfm_store *store, const int32_
     ok = ok && (e = sets[q].flags.alloc((size_t)cp * sizeof(int32_t))) == hipSuccess;
     ok = ok && (e = sets[q].offsets.alloc((size_t)cp * sizeof(int64_t))) == hipSuccess;
     ok = ok && (e = sets[q].matches.alloc((size_t)cp * cap * sizeof(uint32_t))) == hipSuccess;
+    if (guided) {
+      size_t six_bytes = 0, good_bytes = 0;
+      osfm_guided_scratch_bytes(cap, cp, &six_bytes, &good_bytes);
+      ok = ok && (e = sets[q].poses.alloc((size_t)cp * 12 * sizeof(double))) == hipSuccess;
+      ok = ok && (e = sets[q].six.alloc(six_bytes)) == hipSuccess;
+      ok = ok && (e = sets[q].good.alloc(good_bytes)) == hipSuccess;
+    }
     ok = ok && (e = hipEventCreate(&sets[q].m0)) == hipSuccess && (e = hipEventCreate(&sets[q].m1)) == hipSuccess;
     ok = ok && (e = hipEventCreate(&sets[q].r0)) == hipSuccess && (e = hipEventCreate(&sets[q].r1)) == hipSuccess;
   }
@@ -355,7 +364,13 @@ static int match_pairs_impl(osfm_ctx *ctx, const osfm_store *store, const int32_
     OSFM_HIP(hipMemcpyAsync(S.pairs.p, pairs + 2 * p0, (size_t)np * 2 * sizeof(int32_t), hipMemcpyHostToDevice, stA));
     OSFM_HIP(hipEventRecord(S.m0, stA));
     int rc;
-    if (params->flags & OSFM_MATCH_EXACT_KERNEL) {
+    if (guided) {  // epipolar-masked descriptor stage (guided.hip); the robust stage below is the same
+      OSFM_HIP(hipMemcpyAsync(S.poses.p, guided->h_poses + 12 * p0, (size_t)np * 12 * sizeof(double), hipMemcpyHostToDevice, stA));
+      rc = osfm_launch_guided_pairs(ctx, store, *guided, S.pairs.as<int32_t>(), S.poses.as<double>(), np, params->lowes_ratio, params->symmetric, cap,
+                                    S.counts.as<int32_t>(), S.matches.as<uint32_t>(), S.flags.as<int32_t>(), S.six.as<double>(), S.good.as<int32_t>(), stA);
+      if (rc != OSFM_OK) return rc;
+      OSFM_HIP(hipEventRecord(S.m1, stA));
+    } else if (params->flags & OSFM_MATCH_EXACT_KERNEL) {
       // debug/cross-check mode: every pair on the exact VALU kernel
       OSFM_HIP(hipMemsetAsync(S.flags.p, 0, (size_t)np * sizeof(int32_t), stA));
       rc = osfm_launch_match(ctx, store, S.pairs.as<int32_t>(), np, params->lowes_ratio, params->symmetric, (params->flags & OSFM_MATCH_SQUARED_RATIO) ? 1 : 0, cap,
@@ -477,6 +492,41 @@ extern "C" int osfm_match_pairs_calibrated(osfm_ctx *ctx, const osfm_store *stor
   rc = match_pairs_impl(ctx, store, pairs, n_pairs, params, &cs, out, tm);
   (void)hipFree(d_bearings);
   return rc;
+}
+
+// Guided matching for every pair (matching.py:204-207,260-337: _match_descriptors_guided_impl per pair, then robust_match as usual)
+extern "C" int osfm_match_pairs_guided(osfm_ctx *ctx, const osfm_store *store, const float *bearings, const int32_t *pairs, int64_t n_pairs,
+                                       const double *poses, double threshold, const osfm_match_params *params, const int32_t *cam_model,
+                                       const double *cam_params, const osfm_relpose_params *relpose, osfm_match_result **out,
+                                       osfm_match_timings *tm) {
+  OSFM_REQUIRE(ctx && store && params && out && (bearings || store->row_off[store->n_images] == 0) && (poses || n_pairs == 0), OSFM_E_INVALID,
+               "osfm_match_pairs_guided: null argument");
+  OSFM_REQUIRE((cam_model && cam_params && relpose) || (!cam_model && !cam_params && !relpose), OSFM_E_INVALID,
+               "osfm_match_pairs_guided: give all of (cam_model, cam_params, relpose) for the calibrated robust stage, or none");
+  OSFM_REQUIRE(!(params->flags & (OSFM_MATCH_SQUARED_RATIO | OSFM_MATCH_EXACT_KERNEL)), OSFM_E_UNSUPPORTED,
+               "guided matching goes with the BRUTEFORCE matcher (matching.py:272-279)");
+  OSFM_CTX_LOCK(ctx);
+  OSFM_HIP(hipSetDevice(ctx->device));
+  // float32 bearings in the store's padded row order
+  const int64_t rows = (store->tile_off[store->n_images] + 4) * 32;
+  std::vector<float> hb((size_t)rows * 3, 0.0f);
+  for (int im = 0; im < store->n_images; ++im)
+    if (store->counts[im] > 0)
+      memcpy(hb.data() + (size_t)store->tile_off[im] * 32 * 3, bearings + (size_t)store->row_off[im] * 3, (size_t)store->counts[im] * 3 * sizeof(float));
+  DevBuf d_b;
+  OSFM_REQUIRE(d_b.alloc(hb.size() * sizeof(float)) == hipSuccess, OSFM_E_NOMEM, "hipMalloc failed for the bearings");
+  OSFM_HIP(hipMemcpy(d_b.p, hb.data(), hb.size() * sizeof(float), hipMemcpyHostToDevice));
+  const OsfmGuidedStage gs{d_b.as<float>(), poses, osfm_guided_cos_threshold(threshold)};
+  if (cam_model) {
+    double *d_bearings = nullptr;
+    int rc = osfm_store_bearings(ctx, store, cam_model, cam_params, &d_bearings);
+    if (rc != OSFM_OK) return rc;
+    const OsfmCalibStage cs{d_bearings, relpose};
+    rc = match_pairs_impl(ctx, store, pairs, n_pairs, params, &cs, out, tm, &gs);
+    (void)hipFree(d_bearings);
+    return rc;
+  }
+  return match_pairs_impl(ctx, store, pairs, n_pairs, params, nullptr, out, tm, &gs);
 }
 
 extern "C" int64_t osfm_result_num_pairs(const osfm_match_result *r) { return r ? (int64_t)r->counts.size() : 0; }

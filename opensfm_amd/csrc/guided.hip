@@ -184,3 +184,299 @@ extern "C" int osfm_match_guided(osfm_ctx *ctx, const float *f1, int n1, const f
   if (nw > 0) OSFM_HIP(hipMemcpy(out_pairs, d_out.p, (size_t)nw * 8, hipMemcpyDeviceToHost));
   return OSFM_OK;
 }
+
+// =================================================================================================================================
+// Batched guided matching over the resident store (osfm_match_pairs_guided): every pair of a chunk in three launches.
+//
+// The epipolar mask leaves a query a band of candidates (a percent or two of the other image at the default 0.006 rad), so the work
+// is the PREDICATE on all n1 x n2 combinations (a dozen fp64 operations each) and a handful of descriptor distances per query -- not a
+// dense distance matrix; the matrix cores have nothing to do here.
+//   guided_pairs_prep_kernel   per pair and feature: [x, e1] / [w, e2] (epipolar_precompute, as the leaf), 48 B per feature
+//   guided_pairs_match_kernel  one wavefront per 64 queries of one direction, a lane owns a query.  Phase 1: the targets' vectors are
+//                              wave-uniform (scalar loads), the lane keeps one bit per target in LDS -- the mask is never in HBM.  Phase 2:
+//                              the lane walks the set bits of its row in ascending order: exact integer distance from the store's int8
+//                              tiles (the query's descriptor in registers), sqrtf, cv2's K = 2 insertion in cv2's own order, Lowe's test.
+//   guided_pairs_emit_kernel   mutual check + ordered compaction into the chunk's match buffer (the robust stage follows as usual).
+// The predicate is the reference's  pi/2 - acos((a + b) / 2) < threshold  (matching.py:847-868, triangulation.cc:195-219) rewritten as
+// (a + b) / 2 < c*, with c* found on the host by bisection over the doubles with the same libm acos the oracle calls: the two tests
+// agree wherever acos is monotone, and (a + b) / 2 is computed by the same operations in the same order.
+// =================================================================================================================================
+namespace {
+
+typedef int v4i_g __attribute__((ext_vector_type(4)));
+
+// a'.b' of two stored descriptors (int8 tile layout of the store, osfm_internal.h)
+__device__ __forceinline__ int tile_dot(const int8_t *tilesA, int rowA, const int8_t *tilesB, int rowB) {
+  const int8_t *pa = tilesA + (long)(rowA >> 5) * OSFM_TILE_BYTES + (rowA & 31) * 16;
+  const int8_t *pb = tilesB + (long)(rowB >> 5) * OSFM_TILE_BYTES + (rowB & 31) * 16;
+  v4i_g av[8], bv[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    av[q] = *(const v4i_g *)(pa + q * 512);
+    bv[q] = *(const v4i_g *)(pb + q * 512);
+  }
+  int s0 = 0, s1 = 0;
+#pragma unroll
+  for (int q = 0; q < 8; q += 2)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      s0 = __builtin_amdgcn_sdot4(av[q][e], bv[q][e], s0, false);
+      s1 = __builtin_amdgcn_sdot4(av[q + 1][e], bv[q + 1][e], s1, false);
+    }
+  return s0 + s1;
+}
+
+struct GuidedPairsArgs {
+  const int8_t *tiles;
+  const int32_t *norms;
+  const int64_t *tile_off;
+  const int32_t *counts;
+  const float *bearings;  // store rows (tile * 32 + row) x 3, float32 as the reference's bearings
+  const int32_t *pairs;
+  const double *poses;  // n_pairs x 12: R (row-major) and t of the relative pose
+  long n_pairs;
+  int capr;             // rows per image side in the scratch arrays
+  double cstar, ratio;
+  int symmetric, cap;
+  double *six;          // [n_pairs][2][capr][6]
+  int32_t *good;        // [n_pairs][2][capr]
+  int32_t *out_counts;
+  uint32_t *out_matches;
+  int32_t *out_flags;
+  int wpad;             // LDS words per query (odd)
+};
+
+__global__ void __launch_bounds__(256) guided_pairs_prep_kernel(GuidedPairsArgs a) {
+  const long p = blockIdx.z;
+  const int side = blockIdx.y;
+  const int img = a.pairs[2 * p + side];
+  const int n = a.counts[img];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double *Rt = a.poses + 12 * p;
+  double tn[3] = {Rt[9], Rt[10], Rt[11]};
+  normalized3(tn);
+  epipolar_precompute(side, a.bearings + (a.tile_off[img] * 32 + i) * 3, Rt, tn, a.six + ((p * 2 + side) * a.capr + i) * 6);
+}
+
+__device__ __forceinline__ Top2 top2_shfl_xor(const Top2 &t, int m) {
+  Top2 r;
+  r.d0 = __shfl_xor(t.d0, m);
+  r.d1 = __shfl_xor(t.d1, m);
+  r.j0 = __shfl_xor(t.j0, m);
+  r.n = __shfl_xor(t.n, m);
+  return r;
+}
+
+template <int DIR>  // 0: the queries are the features of the pair's first image, 1: of its second image (the transposed mask)
+__device__ __forceinline__ void guided_pairs_match_body(const GuidedPairsArgs &a, unsigned long long *bits) {
+  const long p = blockIdx.z;
+  const int lane = threadIdx.x;
+  const int imgQ = a.pairs[2 * p + DIR], imgT = a.pairs[2 * p + 1 - DIR];
+  const int nQ = a.counts[imgQ], nT = a.counts[imgT];
+  const int q0 = blockIdx.x * 64;
+  if (q0 >= nQ) return;
+  const int q = q0 + lane;
+  const bool valid = q < nQ;
+  const int W = (nT + 63) >> 6;
+  double Q[6];
+  {
+    const double *src = a.six + ((p * 2 + DIR) * a.capr + (valid ? q : q0)) * 6;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Q[k] = src[k];
+  }
+  const double *T6 = a.six + ((p * 2 + 1 - DIR) * (long)a.capr) * 6;
+  const double cstar = a.cstar;
+  // ---- phase 1: the mask row of this lane's query, one bit per target (32 targets per register so that a bit costs a select + or) ----
+  // The targets' vectors come through the scalar cache, kUnroll targets per round trip (the loop is bound by that latency, not by
+  // the fp64 pipe); rows beyond nT exist in the scratch (capr is a multiple of 64) and their bits are cleared afterwards.
+  constexpr int kUnroll = 4;
+  for (int jh = 0; jh < 2 * W; ++jh) {
+    unsigned half = 0;
+    const int jn = min(32, nT - jh * 32);
+#pragma unroll 1
+    for (int b0 = 0; b0 < 32; b0 += kUnroll) {
+      if (b0 >= jn) break;
+      double sv[kUnroll][6];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sv[u][k] = T6[(long)(jh * 32 + b0 + u) * 6 + k];  // wave-uniform: scalar loads
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        const double *s = sv[u];
+        double ea, eb;
+        if (DIR == 0) {  // first6 = Q, second6 = s
+          ea = fabs(Q[3] * s[0] + Q[4] * s[1] + Q[5] * s[2]);
+          eb = fabs(Q[0] * s[3] + Q[1] * s[4] + Q[2] * s[5]);
+        } else {  // first6 = s, second6 = Q
+          ea = fabs(s[3] * Q[0] + s[4] * Q[1] + s[5] * Q[2]);
+          eb = fabs(s[0] * Q[3] + s[1] * Q[4] + s[2] * Q[5]);
+        }
+        const double c = (ea + eb) / 2.0;
+        half |= (c < cstar) ? (1u << (b0 + u)) : 0u;
+      }
+    }
+    if (jn < 32) half &= jn > 0 ? ((1u << jn) - 1u) : 0u;
+    reinterpret_cast<unsigned *>(bits + (long)lane * a.wpad)[jh] = valid ? half : 0u;
+  }
+  // ---- phase 2: every lane walks the set bits of ITS query in ascending target order -- cv2's own insertion order, so no merge --
+  //      with the query's descriptor in registers; exact integer distance from the store's int8 tiles, sqrtf, K = 2 insertion ----
+  const int8_t *tilesQ = a.tiles + a.tile_off[imgQ] * OSFM_TILE_BYTES;
+  const int8_t *tilesT = a.tiles + a.tile_off[imgT] * OSFM_TILE_BYTES;
+  const int32_t *normT = a.norms + a.tile_off[imgT] * 32;
+  const int qs = valid ? q : q0;
+  const int nqn = (a.norms + a.tile_off[imgQ] * 32)[qs];
+  v4i_g av[8];
+  {
+    const int8_t *pa = tilesQ + (long)(qs >> 5) * OSFM_TILE_BYTES + (qs & 31) * 16;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) av[k] = *(const v4i_g *)(pa + k * 512);
+  }
+  const unsigned long long *myrow = bits + (long)lane * a.wpad;
+  int w = 0;
+  unsigned long long word = W > 0 ? myrow[0] : 0ull;
+  Top2 t = top2_empty();
+  for (;;) {
+    while (word == 0ull && w + 1 < W) word = myrow[++w];
+    const bool has = word != 0ull;
+    if (!__any(has)) break;
+    if (has) {
+      const int b = __builtin_ctzll(word);
+      word &= word - 1;
+      const int j = w * 64 + b;
+      const int8_t *pb = tilesT + (long)(j >> 5) * OSFM_TILE_BYTES + (j & 31) * 16;
+      v4i_g bv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) bv[k] = *(const v4i_g *)(pb + k * 512);
+      int s0 = 0, s1 = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k += 2)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s0 = __builtin_amdgcn_sdot4(av[k][e], bv[k][e], s0, false);
+          s1 = __builtin_amdgcn_sdot4(av[k + 1][e], bv[k + 1][e], s1, false);
+        }
+      const int d2 = nqn + normT[j] - 2 * (s0 + s1);
+      top2_insert(t, sqrtf((float)d2), j);
+    }
+  }
+  if (valid) a.good[(p * 2 + DIR) * a.capr + q] = (t.n >= 2 && (double)t.d0 < a.ratio * (double)t.d1) ? t.j0 : -1;
+}
+
+__global__ void __launch_bounds__(64) guided_pairs_match_kernel(GuidedPairsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned long long *bits = reinterpret_cast<unsigned long long *>(smem);  // [64 queries][wpad words]
+  if (blockIdx.y == 0)
+    guided_pairs_match_body<0>(a, bits);
+  else if (a.symmetric)
+    guided_pairs_match_body<1>(a, bits);
+}
+
+// pairs (i, j) sorted by i: good12[i] == j and (symmetric) good21[j] == i; packed like the fused matcher's output
+__global__ void __launch_bounds__(256) guided_pairs_emit_kernel(GuidedPairsArgs a) {
+  __shared__ int misc[4];
+  const long p = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int n1 = a.counts[a.pairs[2 * p]], n2 = a.counts[a.pairs[2 * p + 1]];
+  if (tid == 0 && a.out_flags) a.out_flags[p] = 0;
+  if (n1 < 2 || n2 < 2) {  // matching.py:291-300
+    if (tid == 0) a.out_counts[p] = 0;
+    return;
+  }
+  const int32_t *g12 = a.good + (p * 2) * a.capr, *g21 = a.good + (p * 2 + 1) * a.capr;
+  int base = 0;
+  for (int i0 = 0; i0 < n1; i0 += 256) {
+    const int i = i0 + tid;
+    int j = -1;
+    if (i < n1) {
+      j = g12[i];
+      if (j >= 0 && a.symmetric && g21[j] != i) j = -1;
+    }
+    const unsigned long long bal = __ballot(j >= 0);
+    const int prefix = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) misc[w] = __popcll(bal);
+    __syncthreads();
+    int woff = 0, total = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < 4; ++w2) {
+      const int cnt = misc[w2];
+      woff += (w2 < w) ? cnt : 0;
+      total += cnt;
+    }
+    if (j >= 0) {
+      const int k = base + woff + prefix;
+      if (k < a.cap) a.out_matches[p * a.cap + k] = (uint32_t)i | ((uint32_t)j << 16);
+    }
+    base += total;
+    __syncthreads();
+  }
+  if (tid == 0) a.out_counts[p] = base;
+}
+
+}  // namespace
+
+// c* = the smallest double whose epipolar angle pi/2 - acos(c) is NOT below the threshold (bisection over the ordered doubles in [0, 1+])
+double osfm_guided_cos_threshold(double threshold) {
+  auto below = [&](double c) { return M_PI / 2.0 - acos(c) < threshold; };  // NaN (c > 1) compares false, as in the reference
+  if (!below(0.0)) return 0.0;   // nothing is allowed (threshold <= 0)
+  if (below(1.0)) return nextafter(1.0, 2.0);  // everything with a defined angle is allowed
+  double lo = 0.0, hi = 1.0;  // below(lo), !below(hi)
+  for (;;) {
+    const double mid = lo + (hi - lo) / 2.0;
+    if (!(mid > lo && mid < hi)) break;
+    if (below(mid)) lo = mid; else hi = mid;
+  }
+  return hi;
+}
+
+int osfm_guided_scratch_bytes(int cap, int64_t n_pairs, size_t *six_bytes, size_t *good_bytes) {
+  const int capr = (cap + 63) & ~63;
+  *six_bytes = (size_t)n_pairs * 2 * capr * 6 * sizeof(double);
+  *good_bytes = (size_t)n_pairs * 2 * capr * sizeof(int32_t);
+  return capr;
+}
+
+int osfm_launch_guided_pairs(osfm_ctx *ctx, const osfm_store *store, const OsfmGuidedStage &gs, const int32_t *d_pairs, const double *d_poses,
+                             int64_t n_pairs, double ratio, int symmetric, int cap, int32_t *d_counts, uint32_t *d_matches, int32_t *d_flags,
+                             double *d_six, int32_t *d_good, hipStream_t stream) {
+  if (n_pairs == 0) return OSFM_OK;
+  OSFM_REQUIRE(!store->is_float, OSFM_E_UNSUPPORTED, "guided matching needs integer-valued descriptors in [0, 255]");
+  OSFM_REQUIRE(n_pairs <= 65535, OSFM_E_INVALID, "guided chunk of %lld pairs", (long long)n_pairs);
+  GuidedPairsArgs a;
+  a.tiles = store->d_tiles;
+  a.norms = store->d_norms;
+  a.tile_off = store->d_tile_off;
+  a.counts = store->d_counts;
+  a.bearings = gs.d_bearings;
+  a.pairs = d_pairs;
+  a.poses = d_poses;
+  a.n_pairs = n_pairs;
+  a.capr = (cap + 63) & ~63;
+  a.cstar = gs.cstar;
+  a.ratio = ratio;
+  a.symmetric = symmetric;
+  a.cap = cap;
+  a.six = d_six;
+  a.good = d_good;
+  a.out_counts = d_counts;
+  a.out_matches = d_matches;
+  a.out_flags = d_flags;
+  const int W = (store->max_count + 63) / 64;
+  a.wpad = W | 1;
+  const size_t lds = (size_t)64 * a.wpad * sizeof(unsigned long long);
+  {
+    static OsfmPerDeviceOnce once;
+    const int rc = once.run(ctx->device, []() -> int {
+      OSFM_HIP(hipFuncSetAttribute((const void *)guided_pairs_match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      return OSFM_OK;
+    });
+    if (rc != OSFM_OK) return rc;
+  }
+  const unsigned blocks = (unsigned)((store->max_count + 255) / 256), qblocks = (unsigned)((store->max_count + 63) / 64);
+  hipLaunchKernelGGL(guided_pairs_prep_kernel, dim3(blocks ? blocks : 1, 2, (unsigned)n_pairs), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(guided_pairs_match_kernel, dim3(qblocks ? qblocks : 1, 2, (unsigned)n_pairs), dim3(64), lds, stream, a);
+  hipLaunchKernelGGL(guided_pairs_emit_kernel, dim3((unsigned)n_pairs), dim3(256), 0, stream, a);
+  OSFM_HIP(hipGetLastError());
+  return OSFM_OK;
+}

@@ -107,6 +107,17 @@ int osfm_calibrated_filter_chunk(osfm_ctx *ctx, const osfm_store *store, const O
                                  int64_t n_pairs, int cap, int min_match, int32_t *d_counts, uint32_t *d_matches, hipStream_t stream,
                                  int64_t *pairs_filtered);
 int osfm_store_bearings(osfm_ctx *ctx, const osfm_store *store, const int32_t *cam_model, const double *cam_params, double **d_out);
+// guided.hip: the descriptor stage of guided matching on a chunk's device buffers (fills counts / matches like osfm_launch_match)
+struct OsfmGuidedStage {
+  const float *d_bearings;  // float32 bearings of every feature of the store, padded tile layout (tile * 32 + row) x 3
+  const double *h_poses;    // n_pairs x 12 on the host: R (row-major) and t of every pair's relative pose
+  double cstar;             // osfm_guided_cos_threshold(guided_matching_threshold)
+};
+double osfm_guided_cos_threshold(double threshold);
+int osfm_guided_scratch_bytes(int cap, int64_t n_pairs, size_t *six_bytes, size_t *good_bytes);
+int osfm_launch_guided_pairs(osfm_ctx *ctx, const osfm_store *store, const OsfmGuidedStage &gs, const int32_t *d_pairs, const double *d_poses,
+                             int64_t n_pairs, double ratio, int symmetric, int cap, int32_t *d_counts, uint32_t *d_matches, int32_t *d_flags,
+                             double *d_six, int32_t *d_good, hipStream_t stream);
 // ransac.hip
 // in place: counts/matches of each pair are replaced by the inliers (or 0 when the pair fails a gate)
 int osfm_launch_ransac_pairs(osfm_ctx *ctx, const osfm_store *store, const int32_t *d_pairs,

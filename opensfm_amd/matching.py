@@ -465,6 +465,46 @@ def match_pairs_calibrated(store: DescriptorStore, pairs: np.ndarray, cameras: S
     return _fetch_result(lib, res)
 
 
+def match_pairs_guided(store: DescriptorStore, pairs: np.ndarray, bearings: Sequence[np.ndarray], relative_poses: Sequence[Any],
+                       config: Optional[Dict[str, Any]] = None, robust: bool = True, cameras: Optional[Sequence[Any]] = None,
+                       timings: Optional[MatchTimings] = None) -> Tuple[np.ndarray, np.ndarray]:
+    """``matching.match`` with guided matching (``matching.py:204-207,260-337,563-634``) for every pair, one ``osfm_match_pairs_guided``
+    call: the epipolar mask of the pair's relative pose, ``match_brute_force[_symmetric]`` under it, the gates and the robust stage
+    (fundamental-matrix RANSAC, or -- with ``cameras`` -- the calibrated branch), device-resident.
+    ``bearings[i]``: (n_i, 3) bearings of image i of the store; ``relative_poses[p]``: ``pose2.relative_to(pose1)`` of pair p
+    (anything with ``get_R_cam_to_world()`` / ``get_origin()``, or a flat 12-vector R|t).  Same return convention as ``match_pairs``."""
+    lib = _lib.load()
+    pairs = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+    b = np.ascontiguousarray(np.concatenate([np.asarray(x, np.float32).reshape(-1, 3) for x in bearings]) if len(bearings) else np.zeros((0, 3)),
+                             np.float32)
+    if len(b) != int(np.sum(store.counts)):
+        raise ValueError("bearings do not match the store's feature counts")
+    rt = np.zeros((max(len(pairs), 1), 12), np.float64)
+    for p, rel in enumerate(relative_poses):
+        if hasattr(rel, "get_R_cam_to_world"):
+            rt[p, :9] = np.asarray(rel.get_R_cam_to_world(), np.float64).reshape(9)
+            rt[p, 9:] = np.asarray(rel.get_origin(), np.float64).reshape(3)
+        else:
+            rt[p] = np.asarray(rel, np.float64).reshape(12)
+    prm = make_params(config, robust)
+    res = C.c_void_p()
+    tm = timings if timings is not None else MatchTimings()
+    thr = float(_cfg(config, "guided_matching_threshold"))
+    if cameras is not None:
+        models = np.zeros(max(store.n_images, 1), np.int32)
+        params = np.zeros((max(store.n_images, 1), 16), np.float64)
+        for i in range(store.n_images):
+            models[i], params[i] = camera_parameters(cameras[i])
+        rp = RelposeParams(float(_cfg(config, "robust_matching_calib_threshold")), 0.99, 1000, 1, 10, int(_cfg(config, "five_point_refine_match_iterations")))
+        check(lib.osfm_match_pairs_guided(store.ctx.handle, store.handle, _fptr(b, C.c_float), _fptr(pairs, C.c_int32), len(pairs), _fptr(rt, C.c_double),
+                                          thr, C.byref(prm), _fptr(models, C.c_int32), _fptr(params, C.c_double), C.byref(rp), C.byref(res), C.byref(tm)),
+              "osfm_match_pairs_guided")
+    else:
+        check(lib.osfm_match_pairs_guided(store.ctx.handle, store.handle, _fptr(b, C.c_float), _fptr(pairs, C.c_int32), len(pairs), _fptr(rt, C.c_double),
+                                          thr, C.byref(prm), None, None, None, C.byref(res), C.byref(tm)), "osfm_match_pairs_guided")
+    return _fetch_result(lib, res)
+
+
 def split_matches(counts: np.ndarray, matches: np.ndarray) -> List[np.ndarray]:
     off = np.concatenate([[0], np.cumsum(counts)])
     return [matches[off[i]: off[i + 1]] for i in range(len(counts))]
@@ -479,7 +519,7 @@ def match_images_with_pairs(data, config_override: Dict[str, Any], exifs: Dict[s
     optionally ``load_features_mask(image, points)`` (``feature_loading.py:61-71``).
     Only the configuration the GPU path implements is accepted: ``matcher_type`` BRUTEFORCE, FLANN (exact search with FLANN's
     squared-ratio semantics) or WORDS (``data.load_words(image)`` supplies the closest vocabulary words); with ``poses`` the
-    descriptor stage is the guided (epipolar-masked) matcher, pair by pair;
+    descriptor stage is the guided (epipolar-masked) matcher, batched (``match_pairs_guided``);
     pairs of undistorted perspective/brown cameras take the fused matcher + fundamental-matrix RANSAC launch, every other
     pair the calibrated route (``match_pairs_calibrated``).
     """
@@ -535,21 +575,26 @@ def match_images_with_pairs(data, config_override: Dict[str, Any], exifs: Dict[s
             wordlists.append(w)
     ipairs = np.asarray([(index[a], index[b]) for a, b in pairs], np.int32).reshape(-1, 2)
     per_pair: List[np.ndarray] = [np.zeros((0, 2), np.int32)] * len(ipairs)
-    if poses:  # guided matching (matching.py:204-207,260-337,576-634): one pair at a time from host buffers, first-correct route
+    if poses:  # guided matching (matching.py:204-207,260-337,576-634): every pair in one osfm_match_pairs_guided call per robust branch
         ctx = default_context()
         bearings = [pixel_bearing_many(cams[k], np.asarray(pts[k], np.float64)[:, :2], ctx) if len(pts[k]) else np.zeros((0, 3))
                     for k in range(len(images))]
-        min_match = int(_cfg(config, "robust_matching_min_match"))
-        for p, ((im1, im2), (a, b)) in enumerate(zip(pairs, ipairs)):
-            if len(pts[a]) < 2 or len(pts[b]) < 2:
-                continue
-            rel = poses[im2].relative_to(poses[im1])
-            m = match_guided(descs[a], descs[b], bearings[a], bearings[b], rel, config, ctx)
-            if len(m) < min_match:
-                continue
-            rm = np.asarray(robust_match(pts[a], pts[b], cams[a], cams[b], m, config))
-            if len(rm) >= min_match and len(rm) > 0:
-                per_pair[p] = rm.astype(np.int32)
+        cfg_g = dict(config)
+        cfg_g["matcher_type"] = "BRUTEFORCE"  # matching.py:272-279: guided matching always runs the brute-force matcher ...
+        cfg_g["symmetric_matching"] = True    # ... and match_brute_force_symmetric (matching.py:319)
+        rels = [poses[im2].relative_to(poses[im1]) for im1, im2 in pairs]
+        store = DescriptorStore(descs, pts)
+        try:
+            pin = np.array([_is_pinhole(cams[a]) and _is_pinhole(cams[b]) for a, b in ipairs], bool)
+            for sel, camarg in ((pin, None), (~pin, cams)):
+                if not sel.any():
+                    continue
+                idx = np.flatnonzero(sel)
+                counts, matches = match_pairs_guided(store, ipairs[idx], bearings, [rels[p] for p in idx], cfg_g, robust=True, cameras=camarg)
+                for p, m in zip(idx, split_matches(counts, matches)):
+                    per_pair[p] = m
+        finally:
+            store.close()
     elif use_words:  # matching.py:388-398: match_words[_symmetric], then the robust stage pair by pair
         from . import words as _words
 

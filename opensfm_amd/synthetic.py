@@ -39,6 +39,8 @@ class MatchingScene:
     pts: np.ndarray  # (sum_n, 2) float64 normalized image coordinates
     offsets: np.ndarray  # (n_images + 1,) int64 row offsets
     point_ids: np.ndarray  # (sum_n,) int64 scene point id, -1 for distractors
+    cam_R: Optional[np.ndarray] = None  # (n_images, 3, 3) world-to-camera rotations of the views
+    cam_o: Optional[np.ndarray] = None  # (n_images, 3) camera origins
 
     @property
     def n_images(self) -> int:
@@ -99,6 +101,7 @@ def make_matching_scene(
     ptss: List[np.ndarray] = []
     ids: List[np.ndarray] = []
     offsets = [0]
+    cam_Rs, cam_os = [], []
     for i in range(n_images):
         n_i = n_features
         if ragged:
@@ -106,6 +109,8 @@ def make_matching_scene(
         cam = np.array([i * step, rng.normal(0, 0.05), rng.normal(0, 0.05)])
         ang = rng.normal(0, 0.03, 3)
         Rm = _rodrigues(ang)
+        cam_Rs.append(Rm)
+        cam_os.append(cam)
         lo = np.searchsorted(X[:, 0], cam[0] - depth_hi * 0.6 / focal)
         hi = np.searchsorted(X[:, 0], cam[0] + depth_hi * 0.6 / focal)
         Xc = (X[lo:hi] - cam) @ Rm.T
@@ -132,6 +137,8 @@ def make_matching_scene(
         pts=np.ascontiguousarray(np.concatenate(ptss)),
         offsets=np.asarray(offsets, dtype=np.int64),
         point_ids=np.concatenate(ids),
+        cam_R=np.asarray(cam_Rs),
+        cam_o=np.asarray(cam_os),
     )
 
 

@@ -303,3 +303,76 @@ def test_large_batch_through_the_rounds(oracle_lib):
         s = slice(off[p], off[p + 1])
         want = oracle_lib.robust_match_calibrated_bearings(b1[s], b2[s], 0.004, 1000, 0.99, True, 10, 10)
         assert np.array_equal(mask[s], want["mask"]), (p, sizes[p])
+
+
+def test_batched_guided_descriptor_stage_equals_oracle(oracle_lib):
+    """osfm_match_pairs_guided, descriptor stage (robust = 0): several pairs of different sizes over one store, thresholds from a narrow
+    band to "everything allowed", both the symmetric and the one-way matcher -- against the oracle's epipolar mask + masked matcher.
+    The kernel tests (a + b) / 2 < c* instead of pi/2 - acos(.) < threshold: the mask it implies must be the oracle's."""
+    import test_guided_host as gh
+    from opensfm_amd import matching
+
+    rng = np.random.default_rng(11)
+    sizes = [130, 700, 64, 333, 1000]
+    scenes = [gh.guided_scene(rng, n // 2) for n in sizes]
+    # image 2k = first view of scene k, image 2k + 1 = its second view
+    descs, bears, pairs, rels = [], [], [], []
+    for k, (d1, d2, b1, b2, R, o, perm) in enumerate(scenes):
+        descs += [d1, d2]
+        bears += [b1, b2]
+        pairs.append((2 * k, 2 * k + 1))
+        rels.append(np.concatenate([np.asarray(R).reshape(9), np.asarray(o).reshape(3)]))
+    pairs.append((1, 0))  # a pair listed the other way round: inverse relative pose
+    R0, o0 = np.asarray(scenes[0][4]), np.asarray(scenes[0][5])
+    rels.append(np.concatenate([R0.T.reshape(9), (-R0.T @ o0).reshape(3)]))
+    pts = [np.zeros((len(d), 2)) for d in descs]
+    store = matching.DescriptorStore(descs, pts)
+    for thr in (0.002, 0.006, 0.05, 2.0):
+        for sym in (True, False):
+            cfg = {"lowes_ratio": 0.8, "guided_matching_threshold": thr, "symmetric_matching": sym}
+            counts, m = matching.match_pairs_guided(store, np.asarray(pairs, np.int32), bears, rels, cfg, robust=False)
+            got = matching.split_matches(counts, m)
+            for (a, b), rel, g in zip(pairs, rels, got):
+                emask, _ = oracle_lib.epipolar_mask(bears[a], bears[b], rel[:9].reshape(3, 3), rel[9:], thr)
+                want = oracle_lib.match_brute_force_masked(descs[a], descs[b], emask, 0.8, symmetric=sym)
+                assert np.array_equal(g, want), (thr, sym, a, b, len(g), len(want))
+            if thr == 0.006 and sym:
+                assert counts.sum() > 1000  # the band separates the two copies of every descriptor
+    store.close()
+
+
+def test_batched_guided_with_fundamental_ransac(oracle_lib):
+    """pinhole cameras: guided descriptor stage + gate + fundamental-matrix RANSAC + gate in one call == the oracle chain"""
+    import test_guided_host as gh
+    from opensfm_amd import matching
+
+    rng = np.random.default_rng(12)
+    n, focal = 600, 0.85
+    X = np.c_[rng.uniform(-2, 2, n), rng.uniform(-2, 2, n), rng.uniform(4, 9, n)]
+    base = rng.integers(0, 255, (n // 2, 128))
+    descs, pts, bears, poses = [], [], [], []
+    for _ in range(3):
+        R = gh._rodrigues(rng.normal(0, 0.1, 3))
+        o = rng.normal(0, 0.5, 3)
+        Y = (X - o) @ R.T
+        px = focal * Y[:, :2] / Y[:, 2:3] + rng.normal(0, 2e-4, (n, 2))
+        perm = rng.permutation(n)
+        d = np.clip(np.concatenate([base, base]) + rng.integers(-3, 4, (n, 128)), 0, 255).astype(np.float32)
+        descs.append(d[perm])
+        pts.append(px[perm])
+        bears.append(np.asarray(oracle_lib.pixel_bearings(0, [0.0, 0.0, focal], px[perm]), np.float32))
+        poses.append(_Pose(R, o))
+    pairs = [(0, 1), (0, 2), (1, 2)]
+    rels = [poses[b].relative_to(poses[a]) for a, b in pairs]
+    store = matching.DescriptorStore(descs, pts)
+    cfg = {"lowes_ratio": 0.8, "guided_matching_threshold": 0.006, "robust_matching_min_match": 20, "robust_matching_threshold": 0.004}
+    counts, m = matching.match_pairs_guided(store, np.asarray(pairs, np.int32), bears, rels, cfg, robust=True)
+    for (a, b), rel, g in zip(pairs, rels, matching.split_matches(counts, m)):
+        emask, _ = oracle_lib.epipolar_mask(bears[a], bears[b], rel.get_R_cam_to_world(), rel.get_origin(), 0.006)
+        mm = oracle_lib.match_brute_force_masked(descs[a], descs[b], emask, 0.8, symmetric=True)
+        assert len(mm) >= 100
+        F, mask, _ = oracle_lib.find_fundamental_ransac(pts[a][mm[:, 0]], pts[b][mm[:, 1]], 0.004, 0.9999)
+        want = mm[mask] if F is not None and F[2, 2] != 0.0 else np.zeros((0, 2), np.int32)
+        assert np.array_equal(g, want if len(want) >= 20 else np.zeros((0, 2), np.int32))
+        assert len(g) > 80
+    store.close()

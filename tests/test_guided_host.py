@@ -143,11 +143,31 @@ def test_gpu_guided_tests_logic_on_the_emulation(host, oracle_lib, monkeypatch):
         ctx = None
 
         def __init__(self, descs, pts, ctx=None):
-            pass
+            self.descs, self.pts = descs, pts
+            self.counts = np.asarray([len(d) for d in descs], np.int32)
+            self.n_images = len(descs)
 
         def close(self):
             pass
 
+    def match_pairs_guided(store, pairs, bearings, relative_poses, config=None, robust=True, cameras=None, timings=None):
+        """what osfm_match_pairs_guided does per pair, from the emulated leaves: guided descriptor stage, gate, robust stage, gate"""
+        assert config["matcher_type"] == "BRUTEFORCE" and config["symmetric_matching"] is True
+        min_match = int(matching._cfg(config, "robust_matching_min_match"))
+        out = []
+        for (a, b), rel in zip(pairs, relative_poses):
+            m = np.zeros((0, 2), np.int32)
+            if len(store.pts[a]) >= 2 and len(store.pts[b]) >= 2:
+                m = np.asarray(guided_leaf(store.descs[a], store.descs[b], matching._cfg(config, "lowes_ratio"), True, None, bearings[a], bearings[b],
+                                           rel.get_R_cam_to_world(), rel.get_origin(), matching._cfg(config, "guided_matching_threshold")), np.int32).reshape(-1, 2)
+            if len(m) >= min_match and robust:
+                assert cameras is not None  # the scene's cameras are distorted: the calibrated branch
+                m = np.asarray(matching.robust_match(store.pts[a], store.pts[b], cameras[a], cameras[b], m, config), np.int32).reshape(-1, 2)
+            out.append(m if len(m) >= min_match else np.zeros((0, 2), np.int32))
+        counts = np.asarray([len(m) for m in out], np.int32)
+        return counts, (np.concatenate(out) if len(out) else np.zeros((0, 2), np.int32))
+
+    monkeypatch.setattr(matching, "match_pairs_guided", match_pairs_guided)
     monkeypatch.setattr(matching, "_match_guided_leaf", guided_leaf)
     monkeypatch.setattr(matching, "pixel_bearing_many", bearings)
     monkeypatch.setattr(matching, "relpose_pairs", relpose_pairs)
