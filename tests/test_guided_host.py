@@ -123,6 +123,33 @@ def test_ties_and_tiny_inputs(host, oracle_lib):
         assert np.array_equal(host_match(host, a, b, mask=mm, ratio=0.99), want)
 
 
+def composed_match_pairs_guided(product, guided_leaf, descs_of, pts_of):
+    """what osfm_match_pairs_guided does per pair, composed on the host from (emulated) leaves: guided descriptor stage, gate, robust
+    stage (product.robust_match over whatever leaves the caller patched in), gate"""
+    def match_pairs_guided(store, pairs, bearings, relative_poses, config=None, robust=True, cameras=None, timings=None):
+        assert config["matcher_type"] == "BRUTEFORCE" and config["symmetric_matching"] is True
+        descs, pts = descs_of(store), pts_of(store)
+        min_match = int(product._cfg(config, "robust_matching_min_match"))
+        out = []
+        for (a, b), rel in zip(pairs, relative_poses):
+            m = np.zeros((0, 2), np.int32)
+            if len(pts[a]) >= 2 and len(pts[b]) >= 2:
+                m = np.asarray(guided_leaf(descs[a], descs[b], product._cfg(config, "lowes_ratio"), True, None, bearings[a], bearings[b],
+                                           rel.get_R_cam_to_world(), rel.get_origin(), product._cfg(config, "guided_matching_threshold")), np.int32).reshape(-1, 2)
+            if len(m) >= min_match and robust:
+                if cameras is not None:
+                    cam_a, cam_b = cameras[a], cameras[b]
+                else:  # the batch takes the fundamental-matrix branch: any undistorted perspective camera selects it in robust_match
+                    from types import SimpleNamespace
+                    cam_a = cam_b = SimpleNamespace(projection_type="perspective", k1=0.0, k2=0.0, focal=1.0)
+                m = np.asarray(product.robust_match(pts[a], pts[b], cam_a, cam_b, m, config), np.int32).reshape(-1, 2)
+            out.append(m if len(m) >= min_match else np.zeros((0, 2), np.int32))
+        counts = np.asarray([len(m) for m in out], np.int32)
+        return counts, (np.concatenate(out) if len(out) else np.zeros((0, 2), np.int32))
+
+    return match_pairs_guided
+
+
 def test_gpu_guided_tests_logic_on_the_emulation(host, oracle_lib, monkeypatch):
     """The two guided-matching GPU tests (tests/test_gpu_zz_relpose.py) with the C-ABI calls redirected: osfm_match_guided -> this
     file's host emulation, bearings / relative pose -> the relpose host emulation.  Checks the Python glue (match_brute_force* with
@@ -150,22 +177,7 @@ def test_gpu_guided_tests_logic_on_the_emulation(host, oracle_lib, monkeypatch):
         def close(self):
             pass
 
-    def match_pairs_guided(store, pairs, bearings, relative_poses, config=None, robust=True, cameras=None, timings=None):
-        """what osfm_match_pairs_guided does per pair, from the emulated leaves: guided descriptor stage, gate, robust stage, gate"""
-        assert config["matcher_type"] == "BRUTEFORCE" and config["symmetric_matching"] is True
-        min_match = int(matching._cfg(config, "robust_matching_min_match"))
-        out = []
-        for (a, b), rel in zip(pairs, relative_poses):
-            m = np.zeros((0, 2), np.int32)
-            if len(store.pts[a]) >= 2 and len(store.pts[b]) >= 2:
-                m = np.asarray(guided_leaf(store.descs[a], store.descs[b], matching._cfg(config, "lowes_ratio"), True, None, bearings[a], bearings[b],
-                                           rel.get_R_cam_to_world(), rel.get_origin(), matching._cfg(config, "guided_matching_threshold")), np.int32).reshape(-1, 2)
-            if len(m) >= min_match and robust:
-                assert cameras is not None  # the scene's cameras are distorted: the calibrated branch
-                m = np.asarray(matching.robust_match(store.pts[a], store.pts[b], cameras[a], cameras[b], m, config), np.int32).reshape(-1, 2)
-            out.append(m if len(m) >= min_match else np.zeros((0, 2), np.int32))
-        counts = np.asarray([len(m) for m in out], np.int32)
-        return counts, (np.concatenate(out) if len(out) else np.zeros((0, 2), np.int32))
+    match_pairs_guided = composed_match_pairs_guided(matching, guided_leaf, lambda st: st.descs, lambda st: st.pts)
 
     monkeypatch.setattr(matching, "match_pairs_guided", match_pairs_guided)
     monkeypatch.setattr(matching, "_match_guided_leaf", guided_leaf)

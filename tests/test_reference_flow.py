@@ -324,6 +324,10 @@ def test_match_flow_equals_the_product_host_flow(ref, oracle_lib, monkeypatch, g
         product, lambda st: [st.pts[st.off[i]: st.off[i + 1]] for i in range(len(st.off) - 1)]))
     monkeypatch.setattr(product, "_match_guided_leaf", guided_leaf)
     monkeypatch.setattr(product, "find_fundamental_ransac", fundamental_leaf)
+    # osfm_match_pairs_guided composed on the host from the same (emulated) leaves
+    split = lambda st, arr: [arr[st.off[i]: st.off[i + 1]] for i in range(len(st.off) - 1)]
+    monkeypatch.setattr(product, "match_pairs_guided", gh.composed_match_pairs_guided(product, guided_leaf, lambda st: split(st, st.desc),
+                                                                                       lambda st: split(st, st.pts)))
     got = product.match_images_with_pairs(data, {}, exifs, pairs, poses if guided else None)
     survivors = 0
     def rows(a):  # the reference returns a python set's order (matching.py:777), the product sorts by (i, j): compare as sets of rows
