@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true", help="skip the neighbour-preselected workload")
     ap.add_argument("--overlap-neighbors", type=int, default=16)
     ap.add_argument("--no-calibrated", action="store_true", help="skip the calibrated (essential-matrix) branch legs")
+    ap.add_argument("--no-float", action="store_true", help="skip the float-descriptor (root-SIFT) workload")
+    ap.add_argument("--no-guided", action="store_true", help="skip the guided-matching workload")
     ap.add_argument("--full-parity", action="store_true", help="check EVERY pair with matches + 5000 empties against the oracle (~1.5 min)")
     return ap.parse_args()
 
@@ -211,6 +213,10 @@ def main():
             out["overlap_workload"] = overlap_bench(args, ctx, store, scene, n_images, not args.no_cpu_baseline)
         if not args.no_calibrated:
             out["calibrated"] = calibrated_bench(args, ctx, store, scene, n_images, not args.no_cpu_baseline)
+        if not args.no_float:
+            out["float_descriptors"] = float_bench(args, ctx, scene, pairs_all if world == 1 else pairs_all[:p1], n_images, not args.no_cpu_baseline)
+        if not args.no_guided:
+            out["guided"] = guided_bench(args, ctx, store, scene, n_images, not args.no_cpu_baseline)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, pairs_gathered, args.cpu_sample_pairs, graph, args.full_parity)
         if not args.no_tracks and graph is not None:
@@ -320,6 +326,120 @@ def overlap_bench(args, ctx, store, scene, n_images, with_cpu):
         out["cpu_baseline"] = {"value": round(len(sel) / dtc, 3), "unit": "pairs/s", "cores": oracle.num_threads(), "kind": "port",
                                "sample": f"{len(sel)} pairs strided over the list, {dtc:.1f} s, OpenMP over pairs",
                                "parity_on_sample": bool(all(np.array_equal(m[off[p]: off[p + 1]], r) for p, r in zip(sel, res)))}
+    return out
+
+
+def root_features(desc_u8: np.ndarray) -> np.ndarray:
+    """features.root_feature (opensfm/features.py:292-298): L1-normalise, square root -- what feature_root = True (the default) makes
+    of SIFT descriptors: float32 values that are not integers"""
+    d = desc_u8.astype(np.float32)
+    d /= np.maximum(d.sum(1, keepdims=True), 1e-7)
+    return np.sqrt(d).astype(np.float32)
+
+
+def float_bench(args, ctx, scene, pairs_all, n_images, with_cpu):
+    """configs[1] again on root (non-integer float32) descriptors: the fused kernel in FQ mode -- int8 quantisation with rigorous bounds on
+    the matrix pipe, float32 evaluation of the undecided queries -- same pair list, same semantics, results identical to cv2's float
+    arithmetic as the oracle restates it."""
+    from opensfm_amd import matching
+    from opensfm_amd._lib import MatchTimings
+
+    desc = root_features(scene.desc)
+    store = matching.DescriptorStore.from_packed(desc, scene.pts, scene.offsets, ctx)
+    try:
+        near = neighbour_pairs(n_images, args.overlap_neighbors)
+        matching.match_pairs(store, near[:512])
+        res = {}
+        for name, pl in (("exhaustive", pairs_all), ("neighbour", near)):
+            tm = MatchTimings()
+            t0 = time.perf_counter()
+            counts, m = matching.match_pairs(store, pl, timings=tm)
+            dt = time.perf_counter() - t0
+            n_avg = float(np.mean(np.diff(scene.offsets)))
+            flop = 2.0 * n_avg * n_avg * 128 * len(pl)
+            res[name] = {"pairs": int(len(pl)), "value": round(len(pl) / dt, 1), "unit": "pairs/s",
+                         "descriptor_stage_pairs_per_s": round(len(pl) / (tm.ms_match_kernel * 1e-3), 1),
+                         "match_kernel_ms": round(float(tm.ms_match_kernel), 3), "call_ms": round(1e3 * dt, 3),
+                         "pairs_with_float_evaluation": int(tm.pairs_exact_path), "pairs_with_matches": int((counts > 0).sum()),
+                         "total_inlier_matches": int(counts.sum()),
+                         "roofline": {"bound": "mfma", "kernel": "match_fused_kernel<FQ>", "unit": "TFLOP/s", "peak": PEAK_I8_TOPS,
+                                      "achieved": round(flop / (tm.ms_match_kernel * 1e-3) / 1e12, 2),
+                                      "frac": round(flop / (tm.ms_match_kernel * 1e-3) / 1e12 / PEAK_I8_TOPS, 4)}}
+        out = {"workload": f"{n_images} images x {args.features} x 128-D root descriptors (float32, L2-normalised; features.py:292-298), the same pair lists",
+               "dtype": "i8 quantised candidates (exact int32) + f32 evaluation in cv2's accumulation order + f64 RANSAC", **res}
+        if with_cpu:
+            import oracle
+
+            sel = np.linspace(0, len(near) - 1, 96).astype(np.int64)
+            t0 = time.perf_counter()
+            want = oracle.match_pairs(desc, scene.pts, scene.offsets, near[sel])
+            dtc = time.perf_counter() - t0
+            c, m = matching.match_pairs(store, near[sel])
+            got = matching.split_matches(c, m)
+            out["cpu_baseline"] = {"value": round(len(sel) / dtc, 3), "unit": "pairs/s", "cores": oracle.num_threads(), "kind": "port",
+                                   "sample": f"{len(sel)} neighbour pairs, {dtc:.1f} s, OpenMP over pairs (float32 brute force)",
+                                   "parity_on_sample": bool(all(np.array_equal(g, w) for g, w in zip(got, want)))}
+        return out
+    finally:
+        store.close()
+
+
+def guided_bench(args, ctx, store, scene, n_images, with_cpu):
+    """Guided matching (match_images_with_pairs with poses, matching.py:204-207,260-337) on the neighbour list of the first images of the
+    same store, with the views' true relative poses: epipolar mask (guided_matching_threshold 0.006 rad) + masked symmetric matcher +
+    gates + fundamental-matrix RANSAC, one osfm_match_pairs_guided call."""
+    from opensfm_amd import matching
+    from opensfm_amd._lib import MatchTimings
+
+    n_g = min(n_images, 300)
+    pairs = neighbour_pairs(n_g, args.overlap_neighbors)
+    focal = 0.85
+    b = np.c_[scene.pts / focal, np.ones(len(scene.pts))]
+    b /= np.linalg.norm(b, axis=1, keepdims=True)
+    bears = [b[scene.offsets[i]: scene.offsets[i + 1]].astype(np.float32) for i in range(n_images)]
+    rels = []
+    for a, c in pairs:
+        Ra, Rc, oa, oc = scene.cam_R[a], scene.cam_R[c], scene.cam_o[a], scene.cam_o[c]
+        rels.append(np.concatenate([(Rc @ Ra.T).T.reshape(9), Ra @ (oc - oa)]))  # pose_c.relative_to(pose_a): R cam-to-world, origin
+    cfg = {"guided_matching_threshold": 0.006}
+    matching.match_pairs_guided(store, pairs[:256], bears, rels[:256], cfg)
+    tm = MatchTimings()
+    t0 = time.perf_counter()
+    counts, m = matching.match_pairs_guided(store, pairs, bears, rels, cfg, robust=True, timings=tm)
+    dt = time.perf_counter() - t0
+    out = {"workload": f"{len(pairs)} neighbour pairs of the first {n_g} images (2000 x 2000 features), true relative poses, threshold 0.006 rad",
+           "value": round(len(pairs) / dt, 1), "unit": "pairs/s",
+           "descriptor_stage_pairs_per_s": round(len(pairs) / (tm.ms_match_kernel * 1e-3), 1),
+           "descriptor_stage_ms": round(float(tm.ms_match_kernel), 3), "call_ms": round(1e3 * dt, 3),
+           "pairs_with_matches": int((counts > 0).sum()), "inlier_matches_per_pair": round(float(counts.mean()), 1),
+           "roofline": {"bound": "valu-f64", "kernel": "guided_pairs_match_kernel", "unit": "TFLOP/s", "peak": PEAK_F64_VALU_TFLOPS,
+                        "algorithmic_flop": "13 per (query, target) and direction: the epipolar predicate on all n1 x n2 combinations",
+                        "achieved": round(13.0 * 2 * sum(float(len(bears[a])) * len(bears[c]) for a, c in pairs) / (tm.ms_match_kernel * 1e-3) / 1e12, 3)}}
+    out["roofline"]["frac"] = round(out["roofline"]["achieved"] / PEAK_F64_VALU_TFLOPS, 4)
+    if with_cpu:
+        import oracle
+
+        sel = np.linspace(0, len(pairs) - 1, 6).astype(np.int64)
+        t0 = time.perf_counter()
+        ok = True
+        off = np.concatenate([[0], np.cumsum(counts)])
+        d32 = scene.desc.astype(np.float32)
+        for p in sel:
+            a, c = pairs[p]
+            da, dc = d32[scene.offsets[a]: scene.offsets[a + 1]], d32[scene.offsets[c]: scene.offsets[c + 1]]
+            pa, pc = scene.pts[scene.offsets[a]: scene.offsets[a + 1]], scene.pts[scene.offsets[c]: scene.offsets[c + 1]]
+            emask, _ = oracle.epipolar_mask(bears[a], bears[c], rels[p][:9].reshape(3, 3), rels[p][9:], 0.006)
+            mm = oracle.match_brute_force_masked(da, dc, emask, 0.8, symmetric=True)
+            want = np.zeros((0, 2), np.int32)
+            if len(mm) >= 20:
+                F, mask, _ = oracle.find_fundamental_ransac(pa[mm[:, 0]], pc[mm[:, 1]], 0.004, 0.9999)
+                if F is not None and F[2, 2] != 0.0 and mask.sum() >= 20:
+                    want = mm[mask]
+            ok = ok and np.array_equal(m[off[p]: off[p + 1]], want)
+        dtc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(len(sel) / dtc, 3), "unit": "pairs/s", "cores": 1, "kind": "port",
+                               "sample": f"{len(sel)} pairs strided over the list, {dtc:.1f} s, one thread (mask + masked matcher + RANSAC)",
+                               "parity_on_sample": bool(ok)}
     return out
 
 

@@ -60,6 +60,24 @@ def run(ctx, shots: int = 5000, points: int = 500000, track: int = 10, iters: in
         },
         "scene_gen_s": round(t_gen, 2),
     }
+    # HBM traffic of one mat-vec: PMC passes cannot run inside this process; the committed counters of `tools/prof_ba.py` at the same size
+    # (tools/pmc_ba.sh -> profiles/r02_ba_pmc.json: FETCH_SIZE doubled as the gfx950 guide prescribes, + WRITE_SIZE) are quoted
+    import json
+    import os
+
+    pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_ba_pmc.json")
+    if os.path.exists(pmc_file):
+        try:
+            pmc = json.load(open(pmc_file))
+            k = nobs / float(pmc["units_per_launch"])
+            out["roofline"]["traffic"] = {"hbm_read_bytes": pmc["fetch_bytes_corrected"] * k, "hbm_write_bytes": pmc["write_bytes"] * k,
+                                          "algorithmic_bytes": MATVEC_BYTES_PER_OBS * nobs, "source": pmc["source"]}
+        except (KeyError, ValueError):
+            pass
+    out["lm_iteration"] = {"ms": round(1e3 * g["seconds_run"] / max(1, g["iterations"]), 3),
+                           "matvecs_per_iteration": round(g["pcg_iterations"] / max(1, g["iterations"]), 2),
+                           "note": "per LM iteration: Jacobian + gradients, band assembly, cyclic-reduction factor, camera border (one pass for all "
+                                   "columns), right-hand side, PCG (1-2 mat-vecs), back-substitution, candidate cost"}
     if cpu_baseline:
         import oracle
 
@@ -74,6 +92,7 @@ def run(ctx, shots: int = 5000, points: int = 500000, track: int = 10, iters: in
             "unit": "LM-iters/s",
             "cores": oracle.num_threads(),
             "kind": "port",
+            "kind_note": "port, serial Schur elimination",
             "sample": f"{cpu_iters} LM iterations of the same problem ({dt:.1f} s; exact Schur + skyline Cholesky, "
                       "OpenMP residuals, serial elimination)",
             "rmse_px_diff_vs_gpu_same_iters": abs(rm_o - rm_g),
