@@ -152,6 +152,15 @@ __device__ __forceinline__ void block_sum(double *v, double *lds /* [4*NV] */) {
     }
 }
 
+// Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  The per-shot kernels gather rows that the neighbouring shots
+// want too (the E blocks / w entries of the points they share), so every XCD gets a CONTIGUOUS range of shots: band assembly 1.76 ->
+// 1.11 ms at configs[4] from this mapping alone.
+__device__ __forceinline__ long xcd_contiguous(long b, long n) {  // bijection for any n
+  const long q = n >> 3, r = n & 7;
+  const long xcd = b & 7, within = b >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+}
+
 // ------------------------------------------------------------------------------------------
 // device problem image
 // ------------------------------------------------------------------------------------------
@@ -662,6 +671,7 @@ __global__ void precond_cam_kernel(Dev d, double radius) {
 // sweeps per CG iteration.  When bw covers every co-visibility, M equals the shot part of the
 // Schur complement exactly and CG only has to resolve the rank-3 coupling to the shared camera.
 constexpr int kMaxBw = 15;
+constexpr int kBandCopies = 8;
 
 // Single-wavefront kernels: LDS operations of one wave are executed in issue order, so a compiler
 // barrier is all that is needed between a ds_write and a dependent ds_read of another lane.
@@ -707,77 +717,63 @@ __global__ void __launch_bounds__(TPB) epm_kernel(Dev d) {
   }
 }
 
-// Band assembly without atomics (deterministic): one workgroup per shot s builds the blocks (s, s - dk), dk = 0 .. bw.
+// Band assembly: one workgroup per shot s builds the blocks (s, s - dk), dk = 0 .. bw:
 //   S_(s, s2) -= sum over the points p seen by both of  (E_o Hhat_p) E_o2^T,   o / o2 = the observations of p in s / s2.
-// Per batch of 256 observations of the shot:
-//   phase 1 (thread = observation): EH_o = E_o Hhat_p into LDS, and the observation's partner in every band column: a point is seen
-//            at most once per shot, so partner[dk][o] is a plain table (no list building, no ordering question);
-//   phase 2 (thread = (dk, row i of the 6 x 6 block, part)): walks the table of its dk in ascending order over its part of the
-//            batch and accumulates its six outputs in registers: 3 LDS reads + 18 gathered doubles (the partner's E, shared by the
-//            six row threads) per 18 multiply-adds.
-// The parts are summed in a fixed order at the end.  (Round 1 / the start of round 2 added every product into LDS with fp64 atomics:
-// 900 M atomics per assembly, 1.76 ms at the LDS atomic rate and run-to-run different rounding.)
-constexpr int kBandBatch = 256;
-__global__ void __launch_bounds__(kBandBatch) band_assemble_kernel(Dev d, double radius) {
-  __shared__ double ehb[kBandBatch * 18];                 // EH of the batch; at the end the partial sums of the parts
-  __shared__ int partner[(kMaxBw + 1) * kBandBatch];
-  const int s = blockIdx.x, tid = threadIdx.x;
-  const int R1 = d.bw + 1, nb = R1 * 36;
-  const int P = (kBandBatch / (6 * R1)) >= 4 ? 4 : ((kBandBatch / (6 * R1)) >= 2 ? 2 : 1);  // parts per (dk, i): bw <= 9 -> 4, <= 15 -> 2
-  const bool worker = tid < R1 * 6 * P;
-  const int part = tid % P, wi = (tid / P) % 6, wdk = tid / (6 * P);
-  double acc[6] = {0, 0, 0, 0, 0, 0};
-  for (long k0 = d.shot_off[s]; k0 < d.shot_off[s + 1]; k0 += kBandBatch) {
-    const long k = k0 + tid;
-    const int nbatch = (int)min((long)kBandBatch, d.shot_off[s + 1] - k0);
-    __syncthreads();  // the previous batch is consumed
-    for (int q = 0; q < R1; q++) partner[q * kBandBatch + tid] = -1;
-    if (tid < nbatch) {
-      const int p = d.sm_point[k];
-      const double *Hh = d.Hhat + 6 * (long)p;
-      const double h[9] = {Hh[0], Hh[1], Hh[2], Hh[1], Hh[3], Hh[4], Hh[2], Hh[4], Hh[5]};
-      double Ea[6][3];
-      jred_jp(d, k, Ea);
+// Thread per observation of s, its track's E rows gathered from the point-major array, products added into LDS with fp64 atomics
+// (privatised x8; the summation order, hence the last bits of the PRECONDITIONER, vary from run to run -- the mat-vec, gradients and
+// cost are atomics-free).  An atomics-free variant was measured in round 2 (partner table per band column, one (dk, row, part) thread
+// per six outputs accumulating in registers, deterministic): 2.28 ms with one gather in flight, 2.77 ms with two and 512 threads,
+// against 1.76 ms here -- the kernel is bound by the ~4 GB gather of partner blocks (every E row is wanted by the ~10 shots that see
+// its point, in ten different orders: the reuse misses the 4 MB L2s), not by the accumulation.
+__global__ void __launch_bounds__(TPB) band_assemble_kernel(Dev d, double radius) {
+  // kBandCopies private copies of the accumulators, copy = lane & (kBandCopies - 1), interleaved so that the copies of one entry sit
+  // in different banks: the lanes of a wavefront add into a handful of (dk, i, j) entries at a time, and same-address fp64 LDS
+  // atomics serialise
+  __shared__ double acc[(kMaxBw + 1) * 36 * kBandCopies];
+  // blocks are dealt round-robin to the 8 XCDs: give every XCD a contiguous range of shots, whose workgroups gather the same E rows
+  const int s = (int)xcd_contiguous(blockIdx.x, gridDim.x), nb = (d.bw + 1) * 36;
+  const int copy = threadIdx.x & (kBandCopies - 1);
+  for (int t = threadIdx.x; t < nb * kBandCopies; t += TPB) acc[t] = 0.0;
+  __syncthreads();
+  for (long k = d.shot_off[s] + threadIdx.x; k < d.shot_off[s + 1]; k += TPB) {
+    const int p = d.sm_point[k];
+    const double *Hh = d.Hhat + 6 * (long)p;
+    const double h[9] = {Hh[0], Hh[1], Hh[2], Hh[1], Hh[3], Hh[4], Hh[2], Hh[4], Hh[5]};
+    double Ea[6][3], EH[6][3];
+    jred_jp(d, k, Ea);
 #pragma unroll
-      for (int i = 0; i < 6; i++)
+    for (int i = 0; i < 6; i++)
 #pragma unroll
-        for (int j = 0; j < 3; j++) ehb[tid * 18 + i * 3 + j] = Ea[i][0] * h[j] + Ea[i][1] * h[3 + j] + Ea[i][2] * h[6 + j];
-      for (long o2 = d.pt_off[p]; o2 < d.pt_off[p + 1]; o2++) {
-        const int dk = s - d.o_shot[o2];
-        if (dk >= 0 && dk <= d.bw) partner[dk * kBandBatch + tid] = (int)o2;
-      }
-    }
-    __syncthreads();
-    if (worker) {
-      for (int slot = part; slot < nbatch; slot += P) {
-        const int o2 = partner[wdk * kBandBatch + slot];
-        if (o2 < 0) continue;
-        const double e0 = ehb[slot * 18 + wi * 3], e1 = ehb[slot * 18 + wi * 3 + 1], e2 = ehb[slot * 18 + wi * 3 + 2];
-        const double2 *src = reinterpret_cast<const double2 *>(d.Epm + 18 * (long)o2);
-        double eb[18];
+      for (int j = 0; j < 3; j++) EH[i][j] = Ea[i][0] * h[j] + Ea[i][1] * h[3 + j] + Ea[i][2] * h[6 + j];
+    for (long o2 = d.pt_off[p]; o2 < d.pt_off[p + 1]; o2++) {
+      const int dk = s - d.o_shot[o2];
+      if (dk < 0 || dk > d.bw) continue;
+      double Eb[6][3];
+      {
+        const double2 *src = reinterpret_cast<const double2 *>(d.Epm + 18 * o2);
 #pragma unroll
         for (int q = 0; q < 9; q++) {
           const double2 v = src[q];
-          eb[2 * q] = v.x;
-          eb[2 * q + 1] = v.y;
+          Eb[(2 * q) / 3][(2 * q) % 3] = v.x;
+          Eb[(2 * q + 1) / 3][(2 * q + 1) % 3] = v.y;
         }
-#pragma unroll
-        for (int j = 0; j < 6; j++) acc[j] += e0 * eb[3 * j] + e1 * eb[3 * j + 1] + e2 * eb[3 * j + 2];
       }
+#pragma unroll
+      for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j < 6; j++)
+          atomicAdd(&acc[(dk * 36 + i * 6 + j) * kBandCopies + copy], EH[i][0] * Eb[j][0] + EH[i][1] * Eb[j][1] + EH[i][2] * Eb[j][2]);
     }
   }
   __syncthreads();
-  if (worker)
-#pragma unroll
-    for (int j = 0; j < 6; j++) ehb[part * nb + wdk * 36 + wi * 6 + j] = acc[j];
-  __syncthreads();
-  for (int t = tid; t < nb; t += kBandBatch) {
+  for (int t = threadIdx.x; t < nb; t += TPB) {
     const int dk = t / 36, ij = t % 36, i = ij / 6, j = ij % 6;
     const int s2 = s - dk;
     double val = 0.0;
     if (s2 >= 0) {
       double sum = 0.0;
-      for (int c = 0; c < P; c++) sum += ehb[c * nb + t];
+#pragma unroll
+      for (int c = 0; c < kBandCopies; c++) sum += acc[t * kBandCopies + c];
       val = -sum;
       if (dk == 0) {
         const int hi = i > j ? i : j, lo = i > j ? j : i;
@@ -1695,7 +1691,7 @@ __global__ void __launch_bounds__(kCoopObs) schur_point_coop_kernel(Dev d, const
 
 // pass B, wavefront per shot: zc_s = sum Jc^T w ; camera partials
 __global__ void __launch_bounds__(64) schur_shot_kernel(Dev d) {
-  const int s = blockIdx.x, lane = threadIdx.x;
+  const int s = (int)xcd_contiguous(blockIdx.x, gridDim.x), lane = threadIdx.x;
   double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (long k = d.shot_off[s] + lane; k < d.shot_off[s + 1]; k += 64) {
     const long o = d.shot_obs[k];  // w lives in point-major order: 2 gathered doubles per observation
@@ -2101,7 +2097,7 @@ __global__ void __launch_bounds__(kCoopObs) border_point_kernel(Dev d, double *w
 // camera unit vector), partB[s][3 x NB] = sum Jk^T w_c
 template <int NB>
 __global__ void __launch_bounds__(64) border_shot_kernel(Dev d, const double *wB, double *Bc, double *partB) {
-  const int s = blockIdx.x, lane = threadIdx.x;
+  const int s = (int)xcd_contiguous(blockIdx.x, gridDim.x), lane = threadIdx.x;
   double v[NB][9];
 #pragma unroll
   for (int c = 0; c < NB; c++)
@@ -2746,7 +2742,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     sv.use_band = false;
     if (d.bw > 0) {
       const int R = d.bw + 1;
-      hipLaunchKernelGGL(band_assemble_kernel, dim3(S), dim3(kBandBatch), 0, st, d, radius);
+      hipLaunchKernelGGL(band_assemble_kernel, dim3(S), dim3(TPB), 0, st, d, radius);
       sv.use_ctri = false;
       sv.use_bcr = false;
       if (d.ncl > 0 && O->preconditioner == 0) {
