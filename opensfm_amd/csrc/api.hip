@@ -336,12 +336,9 @@ static int match_pairs_impl(osfm_ctx *ctx, const osfm_store *store, const int32_
     }
   } sb;
   OSFM_HIP(hipStreamCreateWithFlags(&sb.s, hipStreamNonBlocking));
-  hipStream_t stA = ctx->stream, stB = sb.s;
+  // measurement knob: OSFM_MATCH_ONE_STREAM=1 runs the robust stage on the matcher's stream (no overlap between chunks)
+  hipStream_t stA = ctx->stream, stB = getenv("OSFM_MATCH_ONE_STREAM") ? ctx->stream : sb.s;
 
-  // images with more features than the RANSAC kernel's LDS point buffer holds: its correspondences of a chunk live in HBM
-  DevBuf d_ransac_scratch;
-  if (params->robust && !calib && ((cap + 3) & ~3) > osfm_ransac_lds_points())
-    OSFM_REQUIRE(d_ransac_scratch.alloc((size_t)cp * ((cap + 3) & ~3) * 16) == hipSuccess, OSFM_E_NOMEM, "hipMalloc failed for the RANSAC correspondence buffer");
   DevBuf d_work;  // models x correspondences scored by the RANSAC kernel (osfm_match_timings::ransac_model_points)
   OSFM_HIP(d_work.alloc(8));
   OSFM_HIP(hipMemsetAsync(d_work.p, 0, 8, stA));
@@ -414,8 +411,7 @@ static int match_pairs_impl(osfm_ctx *ctx, const osfm_store *store, const int32_
     } else if (params->robust) {
       const int rc = osfm_launch_ransac_pairs(ctx, store, S.pairs.as<int32_t>(), np, cap, params->robust_matching_min_match,
                                               params->robust_matching_threshold, params->ransac_confidence,
-                                              params->ransac_max_iters, S.counts.as<int32_t>(), S.matches.as<uint32_t>(), nullptr, stB, d_work.as<unsigned long long>(),
-                                              d_ransac_scratch.p);
+                                              params->ransac_max_iters, S.counts.as<int32_t>(), S.matches.as<uint32_t>(), nullptr, stB, d_work.as<unsigned long long>());
       if (rc != OSFM_OK) return rc;
     }
     OSFM_HIP(hipEventRecord(rb1, stB));

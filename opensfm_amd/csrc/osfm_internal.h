@@ -123,9 +123,10 @@ int osfm_launch_guided_pairs(osfm_ctx *ctx, const osfm_store *store, const OsfmG
 int osfm_launch_ransac_pairs(osfm_ctx *ctx, const osfm_store *store, const int32_t *d_pairs,
                              int64_t n_pairs, int cap, int min_match, double thr, double conf,
                              int max_iters, int32_t *d_counts, uint32_t *d_matches, double *d_F_or_null, hipStream_t stream,
-                             unsigned long long *d_work_or_null = nullptr, void *d_scratch_or_null = nullptr);
-// correspondences the RANSAC kernels stage in LDS; pairs / calls with more need an HBM buffer of 16 B per correspondence
-int osfm_ransac_lds_points();
+                             unsigned long long *d_work_or_null = nullptr);
+// correspondences the RANSAC kernels stage in LDS; pairs / calls with more read them from HBM
+int osfm_ransac_lds_points();        // the single-problem kernel
+int osfm_ransac_pairs_lds_points();  // the batched kernel
 int osfm_launch_ransac_single(osfm_ctx *ctx, const double *d_p1, const double *d_p2, int n, double thr,
                               double conf, int max_iters, double *d_F, uint8_t *d_mask,
-                              int32_t *d_info, void *d_scratch_or_null = nullptr);
+                              int32_t *d_info);

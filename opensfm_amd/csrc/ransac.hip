@@ -21,6 +21,7 @@ constexpr int kThreads = 256;
 constexpr int kWaves = 4;
 constexpr int kBatch = 64;  // hypotheses generated per round
 constexpr int kMaxPts = OSFM_MAX_FEATURES;
+constexpr int kFirstBatch = 8;  // hypotheses of the first round (ransac_core)
 
 struct CvRng {
   unsigned long long state;
@@ -174,29 +175,32 @@ __device__ void cv_root_order3(double *r) {
   r[2] = mid;
 }
 
-// 7-point algorithm; A is kept in private memory (7x9 doubles).
-__device__ int run_7point(const double *m1, const double *m2, double *F) {
-  double A[7][9];
+// 7-point algorithm.  The 7 x 9 system is eliminated with FULL pivoting (dynamic row / column indices): as a private array it lived
+// in scratch memory and every access of the elimination was a dependent round trip through the vector memory path (~0.3 ms per solve,
+// the latency that bound the whole RANSAC kernel).  It now lives in LDS, lane-minor (element e of lane l at priv[e * 64 + l]: any
+// per-lane dynamic index is bank-conflict free): elements 0..62 = A, 63..71 = v1, 72..80 = v2; the column permutation in ipriv.
+constexpr int kPrivDoubles = 81;
+#define OSFM_A(r, c) priv[((r) * 9 + (c)) * 64]
+__device__ int run_7point(const double *m1, const double *m2, double *F, double *priv, int *ipriv) {
   for (int i = 0; i < 7; i++) {
     const double x0 = m1[2 * i], y0 = m1[2 * i + 1], x1 = m2[2 * i], y1 = m2[2 * i + 1];
-    A[i][0] = x1 * x0;
-    A[i][1] = x1 * y0;
-    A[i][2] = x1;
-    A[i][3] = y1 * x0;
-    A[i][4] = y1 * y0;
-    A[i][5] = y1;
-    A[i][6] = x0;
-    A[i][7] = y0;
-    A[i][8] = 1.0;
+    OSFM_A(i, 0) = x1 * x0;
+    OSFM_A(i, 1) = x1 * y0;
+    OSFM_A(i, 2) = x1;
+    OSFM_A(i, 3) = y1 * x0;
+    OSFM_A(i, 4) = y1 * y0;
+    OSFM_A(i, 5) = y1;
+    OSFM_A(i, 6) = x0;
+    OSFM_A(i, 7) = y0;
+    OSFM_A(i, 8) = 1.0;
   }
-  int colperm[9];
-  for (int c = 0; c < 9; c++) colperm[c] = c;
+  for (int c = 0; c < 9; c++) ipriv[c * 64] = c;
   for (int k = 0; k < 7; k++) {
     int pr = k, pc = k;
     double best = -1.0;
     for (int r = k; r < 7; r++)
       for (int c = k; c < 9; c++) {
-        const double v = fabs(A[r][c]);
+        const double v = fabs(OSFM_A(r, c));
         if (v > best) {
           best = v;
           pr = r;
@@ -206,37 +210,53 @@ __device__ int run_7point(const double *m1, const double *m2, double *F) {
     if (!(best > 1e-300)) return 0;
     if (pr != k)
       for (int c = 0; c < 9; c++) {
-        const double t = A[k][c];
-        A[k][c] = A[pr][c];
-        A[pr][c] = t;
+        const double t = OSFM_A(k, c);
+        OSFM_A(k, c) = OSFM_A(pr, c);
+        OSFM_A(pr, c) = t;
       }
     if (pc != k) {
       for (int r = 0; r < 7; r++) {
-        const double t = A[r][k];
-        A[r][k] = A[r][pc];
-        A[r][pc] = t;
+        const double t = OSFM_A(r, k);
+        OSFM_A(r, k) = OSFM_A(r, pc);
+        OSFM_A(r, pc) = t;
       }
-      const int t = colperm[k];
-      colperm[k] = colperm[pc];
-      colperm[pc] = t;
+      const int t = ipriv[k * 64];
+      ipriv[k * 64] = ipriv[pc * 64];
+      ipriv[pc * 64] = t;
     }
-    const double inv = 1.0 / A[k][k];
-    for (int c = 0; c < 9; c++) A[k][c] = A[k][c] * inv;
+    const double inv = 1.0 / OSFM_A(k, k);
+    double rowk[9];
+#pragma unroll
+    for (int c = 0; c < 9; c++) {
+      rowk[c] = OSFM_A(k, c) * inv;
+      OSFM_A(k, c) = rowk[c];
+    }
     for (int r = 0; r < 7; r++) {
       if (r == k) continue;
-      const double f = A[r][k];
-      for (int c = 0; c < 9; c++) A[r][c] = A[r][c] - f * A[k][c];
+      const double f = OSFM_A(r, k);
+#pragma unroll
+      for (int c = 0; c < 9; c++) OSFM_A(r, c) = OSFM_A(r, c) - f * rowk[c];
     }
   }
-  double v1[9], v2[9];
+  double *v1p = priv + 63 * 64, *v2p = priv + 72 * 64;
   for (int k = 0; k < 7; k++) {
-    v1[colperm[k]] = -A[k][7];
-    v2[colperm[k]] = -A[k][8];
+    const int cp = ipriv[k * 64];
+    v1p[cp * 64] = -OSFM_A(k, 7);
+    v2p[cp * 64] = -OSFM_A(k, 8);
   }
-  v1[colperm[7]] = 1.0;
-  v1[colperm[8]] = 0.0;
-  v2[colperm[7]] = 0.0;
-  v2[colperm[8]] = 1.0;
+  {
+    const int c7 = ipriv[7 * 64], c8 = ipriv[8 * 64];
+    v1p[c7 * 64] = 1.0;
+    v1p[c8 * 64] = 0.0;
+    v2p[c7 * 64] = 0.0;
+    v2p[c8 * 64] = 1.0;
+  }
+  double v1[9], v2[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    v1[i] = v1p[i * 64];
+    v2[i] = v2p[i * 64];
+  }
   double U[9], W[9];
   if (!cv_null_basis(v1, v2, U, W)) return 0;
   for (int i = 0; i < 9; i++) U[i] = U[i] - W[i];
@@ -322,7 +342,9 @@ __device__ bool have_collinear(const double *m, int count) {
 // LDS image of a RANSAC problem: correspondences as float4 (x1, y1, x2, y2) -- cv2 converts the
 // points to CV_32F before estimating, so float storage is exact.
 struct RansacShared {
-  float4 *pts;  // [n] in dynamic LDS behind this struct
+  float4 *pts;  // [n] in dynamic LDS behind this struct -- or null: more correspondences than the buffer holds, read through:
+  const uint32_t *gm;        //   the pair's packed match list (i | j << 16), or null: correspondence k = (gp1[k], gp2[k])
+  const double *gp1, *gp2;   //   keypoints of the two images (x, y per feature)
   double models[kBatch][27];
   unsigned short subset[kBatch][8];
   unsigned char nmodels[kBatch];
@@ -333,9 +355,21 @@ struct RansacShared {
   unsigned long long rng_state;
 };
 
-// Runs the RANSAC loop over the n correspondences already staged in sh.pts.
+// correspondence k as cv2 sees it (CV_32F): from the LDS buffer, or -- pairs with more matches than it holds, rare -- gathered from HBM
+__device__ __forceinline__ float4 ransac_pt(const RansacShared &sh, int k) {
+  if (sh.pts) return sh.pts[k];
+  int i = k, j = k;
+  if (sh.gm) {
+    const uint32_t m = sh.gm[k];
+    i = (int)(m & 0xFFFFu);
+    j = (int)(m >> 16);
+  }
+  return make_float4((float)sh.gp1[2 * i], (float)sh.gp1[2 * i + 1], (float)sh.gp2[2 * j], (float)sh.gp2[2 * j + 1]);
+}
+
+// Runs the RANSAC loop over the n correspondences of sh (ransac_pt).
 // On return sh.ctrl[1] = inlier count of the best model (0: none), sh.best = its F.
-__device__ void ransac_core(RansacShared &sh, int n, double thr, double conf, int max_iters, int tid) {
+__device__ void ransac_core(RansacShared &sh, int n, double thr, double conf, int max_iters, int tid, double *priv, int *ipriv) {
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (thr <= 0) thr = 3;
@@ -350,13 +384,18 @@ __device__ void ransac_core(RansacShared &sh, int n, double thr, double conf, in
     sh.rng_state = ~0ull;
   }
   __syncthreads();
-  for (int it0 = 0;; it0 += kBatch) {
+  // Speculation depth: the batch a round solves and scores ahead of the sequential decision.  cv2 stops after niters iterations and
+  // niters collapses as soon as a good model is found (6 iterations at 97 % inliers), so the first rounds are short -- 8, 16, 32, then 64
+  // hypotheses -- and only pairs that really need hundreds of iterations pay for full batches.  The subsets are drawn in stream
+  // order whatever the batch boundaries are, so the result does not depend on this schedule.
+  int bs = kFirstBatch;
+  for (int it0 = 0;;) {
     // ---- 1. subsets (sequential RNG stream) ----
     if (tid == 0) {
       CvRng rng{sh.rng_state};
       const int niters = sh.ctrl[0];
-      for (int b = 0; b < kBatch; ++b) sh.subset_ok[b] = 0;
-      for (int b = 0; b < kBatch; ++b) {
+      for (int b = 0; b < bs; ++b) sh.subset_ok[b] = 0;
+      for (int b = 0; b < bs; ++b) {
         if (it0 + b >= niters) break;  // never consumed by the sequential loop
         int idx[7];
         double ms1[14], ms2[14];
@@ -372,7 +411,7 @@ __device__ void ransac_core(RansacShared &sh, int n, double thr, double conf, in
               if (!dup) break;
             }
             idx[i] = idx_i;
-            const float4 q = sh.pts[idx_i];
+            const float4 q = ransac_pt(sh, idx_i);
             ms1[2 * i] = (double)q.x;
             ms1[2 * i + 1] = (double)q.y;
             ms2[2 * i] = (double)q.z;
@@ -391,24 +430,24 @@ __device__ void ransac_core(RansacShared &sh, int n, double thr, double conf, in
     }
     __syncthreads();
     // ---- 2. hypotheses ----
-    if (tid < kBatch) {
+    if (tid < bs) {
       int nm = 0;
       if (sh.subset_ok[tid]) {
         double ms1[14], ms2[14];
         for (int i = 0; i < 7; ++i) {
-          const float4 q = sh.pts[sh.subset[tid][i]];
+          const float4 q = ransac_pt(sh, sh.subset[tid][i]);
           ms1[2 * i] = (double)q.x;
           ms1[2 * i + 1] = (double)q.y;
           ms2[2 * i] = (double)q.z;
           ms2[2 * i + 1] = (double)q.w;
         }
-        nm = run_7point(ms1, ms2, sh.models[tid]);
+        nm = run_7point(ms1, ms2, sh.models[tid], priv + tid, ipriv + tid);
       }
       sh.nmodels[tid] = (unsigned char)nm;
     }
     __syncthreads();
     // ---- 3. scoring: one wavefront per model ----
-    for (int mi = w; mi < kBatch * 3; mi += kWaves) {
+    for (int mi = w; mi < bs * 3; mi += kWaves) {
       const int b = mi / 3, k = mi - 3 * b;
       if (k >= sh.nmodels[b]) continue;
       double F[9];
@@ -419,7 +458,7 @@ __device__ void ransac_core(RansacShared &sh, int n, double thr, double conf, in
         const int i = i0 + lane;
         bool in = false;
         if (i < n) {
-          const float4 q = sh.pts[i];
+          const float4 q = ransac_pt(sh, i);
           in = epi_error(F, (double)q.x, (double)q.y, (double)q.z, (double)q.w) <= t;
         }
         good += __popcll(__ballot(in));
@@ -434,10 +473,10 @@ __device__ void ransac_core(RansacShared &sh, int n, double thr, double conf, in
       bool done = false;
       {
         int scored = 0;
-        for (int b = 0; b < kBatch; ++b) scored += sh.nmodels[b];
+        for (int b = 0; b < bs; ++b) scored += sh.nmodels[b];
         sh.ctrl[5] += scored;
       }
-      for (int b = 0; b < kBatch; ++b, ++iter) {
+      for (int b = 0; b < bs; ++b, ++iter) {
         if (iter >= niters) {
           done = true;
           break;
@@ -465,6 +504,8 @@ __device__ void ransac_core(RansacShared &sh, int n, double thr, double conf, in
     }
     __syncthreads();
     if (sh.ctrl[2]) break;
+    it0 += bs;
+    bs = bs * 2 < kBatch ? bs * 2 : kBatch;
   }
 }
 
@@ -481,7 +522,6 @@ struct RansacPairsArgs {
   uint32_t *matches;
   double *F_out;
   unsigned long long *work;  // optional: += (models scored) x (correspondences) of every pair, the work the roofline line counts
-  float4 *scratch;           // images with more features than the LDS point buffer holds: n_pairs x capr correspondences in HBM
   int lds_pts;               // capacity of the LDS point buffer (correspondences)
 };
 
@@ -489,8 +529,10 @@ __global__ void __launch_bounds__(kThreads) ransac_pairs_kernel(RansacPairsArgs 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   RansacShared &sh = *reinterpret_cast<RansacShared *>(smem);
   const int capr = (a.cap + 3) & ~3;
-  float4 *ptsbuf = reinterpret_cast<float4 *>(smem + sizeof(RansacShared));  // [lds_pts]
-  int *misc = reinterpret_cast<int *>(ptsbuf + a.lds_pts);                   // [8]
+  double *priv = reinterpret_cast<double *>(smem + sizeof(RansacShared));     // [kPrivDoubles][64]: the 7-point systems (run_7point)
+  int *ipriv = reinterpret_cast<int *>(priv + kPrivDoubles * 64);             // [9][64]
+  float4 *ptsbuf = reinterpret_cast<float4 *>(ipriv + 9 * 64);                // [lds_pts]
+  int *misc = reinterpret_cast<int *>(ptsbuf + a.lds_pts);                    // [8]
   const int tid = threadIdx.x;
   const int lane = tid & 63, w = tid >> 6;
   const long p = blockIdx.x;
@@ -503,15 +545,21 @@ __global__ void __launch_bounds__(kThreads) ransac_pairs_kernel(RansacPairsArgs 
   const int img1 = a.pairs[2 * p], img2 = a.pairs[2 * p + 1];
   const double *pts1 = a.pts + a.tile_off[img1] * 64;
   const double *pts2 = a.pts + a.tile_off[img2] * 64;
-  if (n > a.lds_pts) ptsbuf = a.scratch + p * capr;  // a pair of large images with more matches than LDS holds (uniform per workgroup)
-  if (tid == 0) sh.pts = ptsbuf;
-  for (int k = tid; k < n; k += kThreads) {
-    const uint32_t m = a.matches[p * a.cap + k];
-    const int i = m & 0xFFFF, j = m >> 16;
-    ptsbuf[k] = make_float4((float)pts1[2 * i], (float)pts1[2 * i + 1], (float)pts2[2 * j], (float)pts2[2 * j + 1]);
+  const bool in_lds = n <= a.lds_pts;  // uniform per workgroup
+  if (tid == 0) {
+    sh.pts = in_lds ? ptsbuf : nullptr;
+    sh.gm = a.matches + p * a.cap;
+    sh.gp1 = pts1;
+    sh.gp2 = pts2;
   }
+  if (in_lds)
+    for (int k = tid; k < n; k += kThreads) {
+      const uint32_t m = a.matches[p * a.cap + k];
+      const int i = m & 0xFFFF, j = m >> 16;
+      ptsbuf[k] = make_float4((float)pts1[2 * i], (float)pts1[2 * i + 1], (float)pts2[2 * j], (float)pts2[2 * j + 1]);
+    }
   __syncthreads();
-  ransac_core(sh, n, a.thr, a.conf, a.max_iters, tid);
+  ransac_core(sh, n, a.thr, a.conf, a.max_iters, tid, priv, ipriv);
   const int max_good = sh.ctrl[1];
   if (a.work && tid == 0) atomicAdd(a.work, (unsigned long long)sh.ctrl[5] * (unsigned long long)n);
   if (a.F_out && tid < 9) a.F_out[p * 9 + tid] = max_good > 0 ? sh.best[tid] : 0.0;
@@ -532,7 +580,7 @@ __global__ void __launch_bounds__(kThreads) ransac_pairs_kernel(RansacPairsArgs 
     bool in = false;
     uint32_t mk = 0;  // read before the barrier below: the in-place writes of this round only go to slots <= k
     if (k < n) {
-      const float4 q = sh.pts[k];
+      const float4 q = ransac_pt(sh, k);
       in = epi_error(F, (double)q.x, (double)q.y, (double)q.z, (double)q.w) <= t;
       mk = a.matches[p * a.cap + k];
     }
@@ -557,16 +605,24 @@ __global__ void __launch_bounds__(kThreads) ransac_pairs_kernel(RansacPairsArgs 
 
 __global__ void __launch_bounds__(kThreads) ransac_single_kernel(const double *p1, const double *p2, int n, double thr,
                                                                    double conf, int max_iters, double *F_out,
-                                                                   uint8_t *mask, int32_t *info, float4 *scratch) {
+                                                                   uint8_t *mask, int32_t *info, int in_lds) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   RansacShared &sh = *reinterpret_cast<RansacShared *>(smem);
   const int tid = threadIdx.x;
-  float4 *ptsbuf = scratch ? scratch : reinterpret_cast<float4 *>(smem + sizeof(RansacShared));
-  if (tid == 0) sh.pts = ptsbuf;
-  for (int k = tid; k < n; k += kThreads)
-    ptsbuf[k] = make_float4((float)p1[2 * k], (float)p1[2 * k + 1], (float)p2[2 * k], (float)p2[2 * k + 1]);
+  double *priv = reinterpret_cast<double *>(smem + sizeof(RansacShared));
+  int *ipriv = reinterpret_cast<int *>(priv + kPrivDoubles * 64);
+  float4 *ptsbuf = reinterpret_cast<float4 *>(ipriv + 9 * 64);
+  if (tid == 0) {
+    sh.pts = in_lds ? ptsbuf : nullptr;
+    sh.gm = nullptr;
+    sh.gp1 = p1;
+    sh.gp2 = p2;
+  }
+  if (in_lds)
+    for (int k = tid; k < n; k += kThreads)
+      ptsbuf[k] = make_float4((float)p1[2 * k], (float)p1[2 * k + 1], (float)p2[2 * k], (float)p2[2 * k + 1]);
   __syncthreads();
-  ransac_core(sh, n, thr, conf, max_iters, tid);
+  ransac_core(sh, n, thr, conf, max_iters, tid, priv, ipriv);
   const int max_good = sh.ctrl[1];
   if (tid == 0) {
     info[0] = max_good > 0 ? 1 : 0;
@@ -580,7 +636,7 @@ __global__ void __launch_bounds__(kThreads) ransac_single_kernel(const double *p
   const double thr2 = thr <= 0 ? 3 : thr;
   const float t = (float)(thr2 * thr2);
   for (int k = tid; k < n; k += kThreads) {
-    const float4 q = sh.pts[k];
+    const float4 q = ransac_pt(sh, k);
     mask[k] = (max_good > 0 && epi_error(F, (double)q.x, (double)q.y, (double)q.z, (double)q.w) <= t) ? 1 : 0;
   }
 }
@@ -602,6 +658,8 @@ __global__ void __launch_bounds__(64) lmeds_single_kernel(const double *p1, cons
   __shared__ double models[kBatch][27];
   __shared__ float med[kBatch][3];
   __shared__ unsigned char nmodels[kBatch];
+  __shared__ double priv[kPrivDoubles * 64];
+  __shared__ int ipriv[9 * 64];
   __shared__ double best[9];
   __shared__ int ctrl[4];
   __shared__ unsigned long long rng_state;
@@ -663,7 +721,7 @@ __global__ void __launch_bounds__(64) lmeds_single_kernel(const double *p1, cons
           ms2[2 * i] = (double)q.z;
           ms2[2 * i + 1] = (double)q.w;
         }
-        nm = run_7point(ms1, ms2, models[tid]);
+        nm = run_7point(ms1, ms2, models[tid], priv + tid, ipriv + tid);
         for (int k = 0; k < nm; ++k) {
           float e[16];
           for (int i = 0; i < n; ++i) {
@@ -730,7 +788,12 @@ __global__ void __launch_bounds__(64) lmeds_single_kernel(const double *p1, cons
 
 }  // namespace
 
-int osfm_ransac_lds_points() { return (int)((160 * 1024 - sizeof(RansacShared) - 64) / 16) & ~3; }
+static constexpr size_t kRansacFixedLds = sizeof(RansacShared) + (size_t)kPrivDoubles * 64 * sizeof(double) + 9 * 64 * sizeof(int);
+// correspondences the single-problem kernel stages in LDS (it owns a CU); the batched kernel keeps at most kPairsLdsPts (two workgroups
+// per CU) and takes pairs with more matches from HBM
+int osfm_ransac_lds_points() { return (int)((160 * 1024 - kRansacFixedLds - 64) / 16) & ~3; }
+static constexpr int kPairsLdsPts = 1024;
+int osfm_ransac_pairs_lds_points() { return kPairsLdsPts; }
 
 static int ensure_ransac_attributes(int device) {
   static OsfmPerDeviceOnce once;
@@ -743,8 +806,7 @@ static int ensure_ransac_attributes(int device) {
 
 int osfm_launch_ransac_pairs(osfm_ctx *ctx, const osfm_store *store, const int32_t *d_pairs, int64_t n_pairs, int cap,
                              int min_match, double thr, double conf, int max_iters, int32_t *d_counts,
-                             uint32_t *d_matches, double *d_F_or_null, hipStream_t stream, unsigned long long *d_work_or_null,
-                             void *d_scratch_or_null) {
+                             uint32_t *d_matches, double *d_F_or_null, hipStream_t stream, unsigned long long *d_work_or_null) {
   if (n_pairs == 0) return OSFM_OK;
   RansacPairsArgs a;
   a.pts = store->d_pts;
@@ -761,10 +823,8 @@ int osfm_launch_ransac_pairs(osfm_ctx *ctx, const osfm_store *store, const int32
   a.F_out = d_F_or_null;
   a.work = d_work_or_null;
   const int capr = (cap + 3) & ~3;
-  a.lds_pts = std::min(capr, osfm_ransac_lds_points());
-  a.scratch = (float4 *)d_scratch_or_null;
-  OSFM_REQUIRE(capr <= a.lds_pts || a.scratch != nullptr, OSFM_E_INVALID, "ransac: cap %d needs the HBM correspondence buffer", cap);
-  const size_t lds = sizeof(RansacShared) + (size_t)a.lds_pts * 16 + 64;
+  a.lds_pts = std::min(capr, kPairsLdsPts);
+  const size_t lds = kRansacFixedLds + (size_t)a.lds_pts * 16 + 64;
   {
     const int rc = ensure_ransac_attributes(ctx->device);
     if (rc != OSFM_OK) return rc;
@@ -775,9 +835,8 @@ int osfm_launch_ransac_pairs(osfm_ctx *ctx, const osfm_store *store, const int32
 }
 
 int osfm_launch_ransac_single(osfm_ctx *ctx, const double *d_p1, const double *d_p2, int n, double thr, double conf,
-                              int max_iters, double *d_F, uint8_t *d_mask, int32_t *d_info, void *d_scratch_or_null) {
+                              int max_iters, double *d_F, uint8_t *d_mask, int32_t *d_info) {
   const bool in_lds = ((n + 3) & ~3) <= osfm_ransac_lds_points();
-  OSFM_REQUIRE(in_lds || d_scratch_or_null, OSFM_E_INVALID, "ransac: %d correspondences need the HBM buffer", n);
   {
     const int rc = ensure_ransac_attributes(ctx->device);
     if (rc != OSFM_OK) return rc;
@@ -785,8 +844,8 @@ int osfm_launch_ransac_single(osfm_ctx *ctx, const double *d_p1, const double *d
   if (n < 15)  // cv2 switches to LMedS below 15 correspondences
     hipLaunchKernelGGL(lmeds_single_kernel, dim3(1), dim3(64), 0, ctx->stream, d_p1, d_p2, n, conf, max_iters, d_F, d_mask, d_info);
   else
-    hipLaunchKernelGGL(ransac_single_kernel, dim3(1), dim3(kThreads), sizeof(RansacShared) + (in_lds ? (size_t)((n + 3) & ~3) * 16 : 0) + 64, ctx->stream,
-                       d_p1, d_p2, n, thr, conf, max_iters, d_F, d_mask, d_info, in_lds ? (float4 *)nullptr : (float4 *)d_scratch_or_null);
+    hipLaunchKernelGGL(ransac_single_kernel, dim3(1), dim3(kThreads), kRansacFixedLds + (in_lds ? (size_t)((n + 3) & ~3) * 16 : 0) + 64, ctx->stream,
+                       d_p1, d_p2, n, thr, conf, max_iters, d_F, d_mask, d_info, in_lds ? 1 : 0);
   OSFM_HIP(hipGetLastError());
   return OSFM_OK;
 }
@@ -809,14 +868,12 @@ extern "C" int osfm_ransac_fundamental(osfm_ctx *ctx, const double *p1, const do
   OSFM_HIP(hipMalloc((void **)&d_F, 9 * 8));
   OSFM_HIP(hipMalloc((void **)&d_mask, (size_t)n));
   OSFM_HIP(hipMalloc((void **)&d_info, 16));
-  void *d_scratch = nullptr;
-  if (((n + 3) & ~3) > osfm_ransac_lds_points()) OSFM_HIP(hipMalloc(&d_scratch, (size_t)((n + 3) & ~3) * 16));
   int rc = OSFM_OK;
   hipError_t e;
   do {
     if ((e = hipMemcpyAsync(d_p1, p1, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
     if ((e = hipMemcpyAsync(d_p2, p2, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
-    rc = osfm_launch_ransac_single(ctx, d_p1, d_p2, n, thr, conf, max_iters, d_F, d_mask, d_info, d_scratch);
+    rc = osfm_launch_ransac_single(ctx, d_p1, d_p2, n, thr, conf, max_iters, d_F, d_mask, d_info);
     if (rc != OSFM_OK) break;
     int32_t info[4] = {0, 0, 0, 0};
     if ((e = hipMemcpyAsync(F, d_F, 72, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
@@ -831,7 +888,6 @@ extern "C" int osfm_ransac_fundamental(osfm_ctx *ctx, const double *p1, const do
   (void)hipFree(d_F);
   (void)hipFree(d_mask);
   (void)hipFree(d_info);
-  (void)hipFree(d_scratch);
   if (rc == OSFM_OK && e != hipSuccess) {
     osfm_set_error("osfm_ransac_fundamental: %s", hipGetErrorString(e));
     rc = OSFM_E_HIP;
