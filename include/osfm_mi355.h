@@ -449,6 +449,9 @@ int osfm_match_words_pairs(osfm_ctx *ctx, const osfm_words_store *store, const i
                            int max_checks, int symmetric, int32_t *counts, int32_t *matches, double *kernel_ms);
 int osfm_vlad_descriptor(osfm_ctx *ctx, const float *features, int n, const float *centers, int n_centers, int dim, float *out);
 int osfm_vlad_distances(osfm_ctx *ctx, const float *reference, const float *others, int m, int len, double *out);
+/* pairs_selection.bow_distances (opensfm/pairs_selection.py:690-708): out[c] = np.fabs(reference - others[c]).sum() over float64 BoW
+ * histograms (bow.py:34-36), in numpy's summation order (pairwise blocks of 128 with eight accumulators, 8192-element chunks). */
+int osfm_bow_distances(osfm_ctx *ctx, const double *reference, const double *others, int m, int len, double *out);
 int osfm_knn_points(osfm_ctx *ctx, const double *candidates, int n_candidates, const double *queries, int n_queries, int k,
                     double max_distance, double *out_distance, int32_t *out_index);
 int osfm_radius_points(osfm_ctx *ctx, const double *candidates, int n_candidates, const double *queries, int n_queries,

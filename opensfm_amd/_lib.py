@@ -137,6 +137,7 @@ SIGNATURES = {
                                          C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     "osfm_vlad_descriptor": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "osfm_vlad_distances": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "osfm_bow_distances": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "osfm_knn_points": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_double,
                                   C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "osfm_radius_points": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_int, C.c_double, C.POINTER(C.c_uint32)]),

@@ -216,6 +216,69 @@ __global__ void __launch_bounds__(64) vlad_distance_kernel(const float *__restri
   out[j] = (double)sqrtf(s);
 }
 
+// ---- BoW affinity: np.fabs(h - h2).sum() over float64 histograms (pairs_selection.py:690-708, bow.py:34-36) ----
+// The value is defined by numpy's summation order (DOUBLE_pairwise_sum + the 8192-element buffering of reductions, restated in
+// oracle/words_oracle.c): a binary tree over leaves of <= 128 elements, each leaf summed by eight interleaved accumulators.  The host
+// flattens the tree once per histogram length into a leaf table and a postfix program; on the device one wavefront takes a candidate:
+// eight lanes per leaf (one accumulator each) sum eight leaves at a time, then lane 0 folds the leaf sums in the program's order.
+struct BowPlan {
+  const int *leaf_off, *leaf_len;  // n_leaves
+  const int *prog;                 // postfix: >= 0 push leaf, -1 add the two top entries, -2 fold into the running sum (end of a chunk)
+  int n_leaves, n_prog;
+};
+__global__ void __launch_bounds__(64) bow_distance_kernel(const double *__restrict__ ref, const double *__restrict__ others, int m, int len,
+                                                          BowPlan plan, double *__restrict__ out) {
+  extern __shared__ double leaf_sum[];  // n_leaves
+  const int c = blockIdx.x, lane = threadIdx.x;
+  const double *g = others + (size_t)c * len;
+  const int q = lane >> 3, j = lane & 7;
+  for (int l0 = 0; l0 < plan.n_leaves; l0 += 8) {
+    const int l = l0 + q;
+    double r = 0.0;
+    int off = 0, n = 0;
+    if (l < plan.n_leaves) {
+      off = plan.leaf_off[l];
+      n = plan.leaf_len[l];
+    }
+    const bool wide = n >= 8;
+    if (wide) {
+      r = fabs(ref[off + j] - g[off + j]);
+      for (int i = 8; i < n - (n % 8); i += 8) r += fabs(ref[off + i + j] - g[off + i + j]);
+    }
+    // ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)) inside each group of eight lanes
+    const double s1 = r + __shfl_xor(r, 1);
+    const double s2 = s1 + __shfl_xor(s1, 2);
+    double res = s2 + __shfl_xor(s2, 4);
+    if (j == 0 && l < plan.n_leaves) {
+      if (wide) {
+        for (int i = n - (n % 8); i < n; i++) res += fabs(ref[off + i] - g[off + i]);
+      } else {  // n < 8: sequential from zero
+        res = 0.0;
+        for (int i = 0; i < n; i++) res += fabs(ref[off + i] - g[off + i]);
+      }
+      leaf_sum[l] = res;
+    }
+  }
+  __syncthreads();
+  if (lane == 0) {
+    double stack[40];
+    int sp = 0;
+    double total = 0.0;
+    for (int k = 0; k < plan.n_prog; k++) {
+      const int op = plan.prog[k];
+      if (op >= 0) {
+        stack[sp++] = leaf_sum[op];
+      } else if (op == -1) {
+        const double b = stack[--sp], a = stack[--sp];
+        stack[sp++] = a + b;
+      } else {
+        total = total + stack[--sp];
+      }
+    }
+    out[c] = total;
+  }
+}
+
 // ---- k nearest points within a radius: one thread per query, the candidates stream through LDS; insertion into a sorted list of k
 //      (distance, index) kept in global scratch rows (k can be the whole set) ----
 __global__ void __launch_bounds__(256) knn_points_kernel(const double *__restrict__ cand, int nc, const double *__restrict__ query, int nq, int k,
@@ -485,6 +548,58 @@ extern "C" int osfm_vlad_distances(osfm_ctx *ctx, const float *reference, const 
   OSFM_HIP(hipMemcpyAsync(d_r, reference, (size_t)len * sizeof(float), hipMemcpyHostToDevice, st));
   OSFM_HIP(hipMemcpyAsync(d_o, others, (size_t)m * len * sizeof(float), hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(vlad_distance_kernel, dim3((m + 63) / 64), dim3(64), 0, st, d_r, d_o, m, len, d_d);
+  OSFM_HIP(hipGetLastError());
+  OSFM_HIP(hipMemcpyAsync(out, d_d, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, st));
+  OSFM_HIP(hipStreamSynchronize(st));
+  return OSFM_OK;
+}
+
+static void bow_plan_rec(int off, int n, std::vector<int> &lo, std::vector<int> &ll, std::vector<int> &prog) {
+  if (n <= 128) {
+    prog.push_back((int)lo.size());
+    lo.push_back(off);
+    ll.push_back(n);
+    return;
+  }
+  int n2 = n / 2;
+  n2 -= n2 % 8;
+  bow_plan_rec(off, n2, lo, ll, prog);
+  bow_plan_rec(off + n2, n - n2, lo, ll, prog);
+  prog.push_back(-1);
+}
+
+extern "C" int osfm_bow_distances(osfm_ctx *ctx, const double *reference, const double *others, int m, int len, double *out) {
+  OSFM_REQUIRE(ctx && reference && (others || m == 0) && (out || m == 0), OSFM_E_INVALID, "osfm_bow_distances: null argument");
+  OSFM_REQUIRE(m >= 0 && len > 0, OSFM_E_INVALID, "osfm_bow_distances: bad sizes");
+  if (m == 0) return OSFM_OK;
+  std::vector<int> lo, ll, prog;
+  for (int c = 0; c < len; c += 8192) {  // numpy reduces through an 8192-element buffer: one pairwise tree per chunk, folded in order
+    bow_plan_rec(c, std::min(8192, len - c), lo, ll, prog);
+    prog.push_back(-2);
+  }
+  OSFM_CTX_LOCK(ctx);
+  OSFM_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  double *d_r = nullptr, *d_o = nullptr, *d_d = nullptr;
+  int *d_plan = nullptr;
+  struct Free {
+    void **p[4];
+    ~Free() {
+      for (auto q : p) (void)hipFree(*q);
+    }
+  } guard{{(void **)&d_r, (void **)&d_o, (void **)&d_d, (void **)&d_plan}};
+  const size_t nl = lo.size(), np_ = prog.size();
+  OSFM_REQUIRE(dev_alloc(&d_r, (size_t)len) == OSFM_OK && dev_alloc(&d_o, (size_t)m * len) == OSFM_OK && dev_alloc(&d_d, (size_t)m) == OSFM_OK &&
+                   dev_alloc(&d_plan, 2 * nl + np_) == OSFM_OK,
+               OSFM_E_NOMEM, "osfm_bow_distances: out of device memory");
+  OSFM_HIP(hipMemcpyAsync(d_r, reference, (size_t)len * sizeof(double), hipMemcpyHostToDevice, st));
+  OSFM_HIP(hipMemcpyAsync(d_o, others, (size_t)m * len * sizeof(double), hipMemcpyHostToDevice, st));
+  OSFM_HIP(hipMemcpyAsync(d_plan, lo.data(), nl * sizeof(int), hipMemcpyHostToDevice, st));
+  OSFM_HIP(hipMemcpyAsync(d_plan + nl, ll.data(), nl * sizeof(int), hipMemcpyHostToDevice, st));
+  OSFM_HIP(hipMemcpyAsync(d_plan + 2 * nl, prog.data(), np_ * sizeof(int), hipMemcpyHostToDevice, st));
+  const BowPlan plan{d_plan, d_plan + nl, d_plan + 2 * nl, (int)nl, (int)np_};
+  OSFM_REQUIRE(nl * sizeof(double) <= 60 * 1024, OSFM_E_UNSUPPORTED, "osfm_bow_distances: histogram of %d bins", len);
+  hipLaunchKernelGGL(bow_distance_kernel, dim3(m), dim3(64), nl * sizeof(double), st, d_r, d_o, m, len, plan, d_d);
   OSFM_HIP(hipGetLastError());
   OSFM_HIP(hipMemcpyAsync(out, d_d, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, st));
   OSFM_HIP(hipStreamSynchronize(st));

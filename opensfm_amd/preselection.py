@@ -6,7 +6,10 @@ unions), with the neighbour searches and descriptor distances on the MI355X (``c
   * by capture time  -- ``match_candidates_by_time`` (:527-558): the same search on a one-dimensional point set;
   * by order         -- ``match_candidates_by_order`` (:561-578): index arithmetic;
   * by VLAD distance -- ``match_candidates_with_vlad`` (:351-440): GPS preemption, then ``osfm_vlad_distances``;
-  * graph rounds (Delaunay, :220-293) and BoW histograms (:295-349) are NOT here: they raise ``NotImplementedError`` when asked for.
+  * by BoW distance  -- ``match_candidates_with_bow`` (:285-349, :690-730): GPS preemption, then ``osfm_bow_distances`` (L1 over the word
+    histograms, summed in numpy's order);
+  * graph rounds     -- ``match_candidates_by_graph`` (:220-282): Delaunay triangulations of the (jittered) positions; scipy on the
+    host as in the reference -- a few thousand points, nothing for the GPU.
 
 Exifs / reference / dataset objects are the reference's (duck-typed: ``exifs[image]["gps"]["latitude"]``,
 ``reference.to_topocentric(lat, lon, alt)``, ``data.config``).  Ties (equal distances at the k-th place) resolve to the lower candidate
@@ -264,6 +267,60 @@ def match_candidates_with_vlad(images_ref, images_cand, exifs, reference, max_ne
     return construct_pairs(results, max_neighbors, exifs, enforce_other_cameras)
 
 
+def match_candidates_with_bow(images_ref, images_cand, exifs, reference, max_neighbors: int, max_gps_distance: float, max_gps_neighbors: int,
+                              enforce_other_cameras: bool, histograms: Dict[str, np.ndarray],
+                              compute_histograms: Optional[Callable[[Set[str]], Dict[str, np.ndarray]]] = None) -> Dict[Tuple[str, str], float]:
+    """pairs_selection.py:285-349.  ``histograms`` holds the BoW histograms already known; ``compute_histograms(images)`` supplies the
+    missing ones (the reference's ``load_histograms``: ``bows.histogram(words[:, 0])`` for images with more than 8 masked words, see
+    ``words.bow_histogram``); images without a histogram drop out, as in ``bow_distances``."""
+    if max_neighbors <= 0:
+        return {}
+    kept, need = preempt_candidates(images_ref, images_cand, exifs, reference, max_gps_neighbors, max_gps_distance)
+    need = {im for im in need if im not in histograms}
+    if need and compute_histograms is not None:
+        histograms.update(compute_histograms(need))
+    results = [words.bow_distances(im, cands, histograms) for im, cands in kept.items()]
+    return construct_pairs(results, max_neighbors, exifs, enforce_other_cameras)
+
+
+def match_candidates_by_graph(images_ref: List[str], images_cand: List[str], exifs: Dict[str, Any], reference, rounds: int,
+                              rng: Optional[np.random.Generator] = None) -> Set[Tuple[str, str]]:
+    """pairs_selection.py:220-282: the edges of the Delaunay triangulation of the images' X/Y positions, plus those of ``rounds``
+    triangulations of positions jittered by up to the median edge length.  Host code over scipy, like the reference (which draws the
+    jitter from numpy's global generator; pass ``rng`` for a reproducible one)."""
+    from scipy import spatial
+
+    if len(images_cand) < 4 or rounds < 1:
+        return set()
+    cand, ref = set(images_cand), set(images_ref)
+    images = list(cand | ref)
+    rep = get_representative_points(images, exifs, reference)
+    xy = np.array([rep[im][0:2] for im in images], float).reshape(-1, 2)
+
+    def edges(simplices):
+        for tri in simplices:
+            for u, v in ((tri[0], tri[1]), (tri[0], tri[2]), (tri[1], tri[2])):
+                a, b = images[u], images[v]
+                if a != b and ((a in cand and b in ref) or (b in cand and a in ref)):
+                    yield sorted_pair(a, b), (u, v)
+
+    try:
+        first = spatial.Delaunay(xy).simplices
+    except spatial.QhullError:  # flat initial simplex: let qhull rescale the input
+        first = spatial.Delaunay(xy, qhull_options="Qbb Qc Qz Q12 QbB").simplices
+    pairs: Set[Tuple[str, str]] = set()
+    lengths = []
+    for pair, (u, v) in edges(first):
+        pairs.add(pair)
+        lengths.append(float(np.hypot(*(xy[u] - xy[v]))))
+    scale = np.median(lengths)
+    for _ in range(rounds):
+        jitter = (rng.random(xy.shape) if rng is not None else np.random.rand(*xy.shape)) * scale
+        for pair, _uv in edges(spatial.Delaunay(xy + jitter).simplices):
+            pairs.add(pair)
+    return pairs
+
+
 def vlad_histogram(features: np.ndarray, vlad_words: np.ndarray) -> Optional[np.ndarray]:
     """``VladCache.vlad_histogram`` without the dataset plumbing (vlad.py:66-78): unnormalised VLAD on the device, SSR normalisation"""
     if vlad_words.shape[1] != features.shape[1] or vlad_words.dtype != features.dtype:
@@ -306,7 +363,9 @@ def ordered_pairs(pairs: Iterable[Tuple[str, str]], images_ref: List[str]) -> Li
 
 def match_candidates_from_metadata(images_ref: List[str], images_cand: List[str], exifs: Dict[str, Any], data, config_override: Dict[str, Any],
                                    vlad_histograms: Optional[Dict[str, np.ndarray]] = None,
-                                   compute_vlad_histograms: Optional[Callable[[Set[str]], Dict[str, np.ndarray]]] = None):
+                                   compute_vlad_histograms: Optional[Callable[[Set[str]], Dict[str, np.ndarray]]] = None,
+                                   bow_histograms: Optional[Dict[str, np.ndarray]] = None,
+                                   compute_bow_histograms: Optional[Callable[[Set[str]], Dict[str, np.ndarray]]] = None):
     """``pairs_selection.match_candidates_from_metadata`` (pairs_selection.py:581-687): the union of the enabled strategies, as a list
     of pairs (im1, im2) with im1 in images_ref, and the per-strategy report."""
     cfg = dict(CONFIG_DEFAULTS)
@@ -327,20 +386,22 @@ def match_candidates_from_metadata(images_ref: List[str], images_cand: List[str]
     t: Set[Tuple[str, str]] = set()
     o: Set[Tuple[str, str]] = set()
     v: Dict[Tuple[str, str], float] = {}
+    g: Set[Tuple[str, str]] = set()
+    b: Dict[Tuple[str, str], float] = {}
     if max_distance == gps_neighbors == time_neighbors == order_neighbors == bow_neighbors == vlad_neighbors == graph_rounds == 0:
         pairs = {sorted_pair(i, j) for i in images_ref for j in images_cand if i != j}  # nothing enabled: match everything
     else:
-        if graph_rounds:
-            raise NotImplementedError("matching_graph_rounds (Delaunay rounds, pairs_selection.py:220-293) is not on the GPU path")
-        if bow_neighbors:
-            raise NotImplementedError("matching_bow_neighbors (BoW histograms, pairs_selection.py:295-349) is not on the GPU path")
         d = match_candidates_by_distance(images_ref, images_cand, exifs, reference, gps_neighbors, max_distance)
         t = match_candidates_by_time(images_ref, images_cand, exifs, time_neighbors)
         o = match_candidates_by_order(images_ref, images_cand, order_neighbors)
         v = match_candidates_with_vlad(images_ref, images_cand, exifs, reference, vlad_neighbors, cfg["matching_vlad_gps_distance"],
                                        cfg["matching_vlad_gps_neighbors"], cfg["matching_vlad_other_cameras"],
                                        vlad_histograms if vlad_histograms is not None else {}, compute_vlad_histograms)
-        pairs = d | t | o | set(v)
-    report = {"num_pairs_distance": len(d), "num_pairs_graph": 0, "num_pairs_time": len(t), "num_pairs_order": len(o), "num_pairs_bow": 0,
-              "num_pairs_vlad": len(v)}
+        g = match_candidates_by_graph(images_ref, images_cand, exifs, reference, graph_rounds)
+        b = match_candidates_with_bow(images_ref, images_cand, exifs, reference, bow_neighbors, cfg["matching_bow_gps_distance"],
+                                      cfg["matching_bow_gps_neighbors"], cfg["matching_bow_other_cameras"],
+                                      bow_histograms if bow_histograms is not None else {}, compute_bow_histograms)
+        pairs = d | g | t | o | set(b) | set(v)
+    report = {"num_pairs_distance": len(d), "num_pairs_graph": len(g), "num_pairs_time": len(t), "num_pairs_order": len(o),
+              "num_pairs_bow": len(b), "num_pairs_vlad": len(v)}
     return ordered_pairs(pairs, images_ref), report

@@ -126,3 +126,27 @@ def vlad_distances(image: str, other_images: Iterable[str], histograms: Dict[str
     check(_lib.load().osfm_vlad_distances(ctx.handle, _fp(ref, C.c_float), _fp(mat, C.c_float), len(others), len(ref), _fp(out, C.c_double)),
           "osfm_vlad_distances")
     return image, list(out), others
+
+
+def bow_distances(image: str, other_images: Iterable[str], histograms: Dict[str, np.ndarray], ctx=None) -> Tuple[str, List[float], List[str]]:
+    """``pairs_selection.bow_distances`` (pairs_selection.py:690-708): L1 distances between the BoW histogram of ``image`` and those of the
+    other images that have one, in the order given (the reference iterates ``other_images`` as is); ``osfm_bow_distances`` sums in
+    numpy's order, so the values are the reference's bit for bit."""
+    if image not in histograms:
+        return image, [], []
+    others = [o for o in other_images if o != image and o in histograms]
+    if not others:
+        return image, [], []
+    ctx = ctx or default_context()
+    ref = np.ascontiguousarray(histograms[image], np.float64)
+    mat = np.ascontiguousarray(np.stack([np.asarray(histograms[o], np.float64) for o in others]))
+    out = np.zeros(len(others), np.float64)
+    check(_lib.load().osfm_bow_distances(ctx.handle, _fp(ref, C.c_double), _fp(mat, C.c_double), len(others), len(ref), _fp(out, C.c_double)),
+          "osfm_bow_distances")
+    return image, list(out), others
+
+
+def bow_histogram(words_of_image: np.ndarray, n_words: int, weights: np.ndarray) -> np.ndarray:
+    """``BagOfWords.histogram`` (bow.py:34-36): weighted, normalised word counts (host arithmetic, as in the reference)"""
+    h = np.bincount(np.asarray(words_of_image).astype(np.int64), minlength=n_words) * weights
+    return h / h.sum()

@@ -653,6 +653,15 @@ def vlad_descriptor(features, centers) -> np.ndarray:
     return out
 
 
+def bow_distances(ref, others) -> np.ndarray:
+    """np.fabs(h - h2).sum() for every row h2 of others, in numpy's summation order (pairs_selection.py:690-708)"""
+    ref = np.ascontiguousarray(ref, np.float64)
+    others = np.ascontiguousarray(others, np.float64).reshape(-1, len(ref))
+    out = np.zeros(len(others), np.float64)
+    lib().oracle_bow_distances(_p(ref, C.c_double), _p(others, C.c_double), len(others), len(ref), _p(out, C.c_double))
+    return out
+
+
 def vlad_distances(ref, others) -> np.ndarray:
     ref = np.ascontiguousarray(ref, np.float32)
     others = np.ascontiguousarray(others, np.float32).reshape(-1, len(ref))

@@ -131,3 +131,43 @@ void oracle_vlad_distances(const float *ref, const float *others, int m, int len
     out[j] = (double)sqrtf(s);
   }
 }
+
+/* ---------------------------------------------------------------------------------------------------------------------------------
+ * BoW affinity: pairs_selection.bow_distances (opensfm/pairs_selection.py:690-708) = np.fabs(h - h2).sum() over float64 histograms
+ * (bow.py:34-36).  The value depends on numpy's summation order, restated here (numpy/_core/src/umath/loops_utils.h.src,
+ * DOUBLE_pairwise_sum, and the 8192-element buffering of the reduction):
+ *   sum = fold over chunks of 8192 elements of   res = res + pairwise(chunk),   res starting at 0;
+ *   pairwise(a, n): n < 8: sequential from 0;  n <= 128: eight accumulators r[j] = a[j], r[j] += a[i + j] for i = 8, 16, ... while
+ *   i < n - n % 8, then ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)), then the n % 8 tail sequentially;  else split at
+ *   n2 = n / 2 rounded down to a multiple of 8: pairwise(a, n2) + pairwise(a + n2, n - n2).
+ * Pinned against numpy itself (tests/test_oracle_words.py runs the reference's bow_distances from its file).
+ * --------------------------------------------------------------------------------------------------------------------------------- */
+static double np_pairwise_absdiff(const double *h, const double *g, long n) {
+  if (n < 8) {
+    double res = 0.0;
+    for (long i = 0; i < n; i++) res += fabs(h[i] - g[i]);
+    return res;
+  }
+  if (n <= 128) {
+    double r[8];
+    for (int j = 0; j < 8; j++) r[j] = fabs(h[j] - g[j]);
+    long i;
+    for (i = 8; i < n - (n % 8); i += 8)
+      for (int j = 0; j < 8; j++) r[j] += fabs(h[i + j] - g[i + j]);
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res += fabs(h[i] - g[i]);
+    return res;
+  }
+  long n2 = n / 2;
+  n2 -= n2 % 8;
+  return np_pairwise_absdiff(h, g, n2) + np_pairwise_absdiff(h + n2, g + n2, n - n2);
+}
+
+void oracle_bow_distances(const double *ref, const double *others, int m, int len, double *out) {
+  for (int j = 0; j < m; ++j) {
+    const double *g = others + (size_t)j * len;
+    double res = 0.0;
+    for (long c = 0; c < len; c += 8192) res = res + np_pairwise_absdiff(ref + c, g + c, (len - c) < 8192 ? (len - c) : 8192);
+    out[j] = res;
+  }
+}

@@ -148,3 +148,20 @@ def test_match_images_with_pairs_words_matcher(gpu_ctx, oracle_lib):
                 want = matching.unfilter_matches(m[mask], masks[ia], masks[ib])
         assert np.array_equal(np.asarray(got[ia, ib]).reshape(-1, 2), np.asarray(want).reshape(-1, 2)), (ia, ib)
     assert len(got["a", "b"]) > 100
+
+
+@pytest.mark.parametrize("n", [5, 8, 100, 129, 1000, 8192, 8193, 10000, 20001])
+def test_bow_distances_equal_numpy(oracle_lib, gpu_ctx, n):
+    """osfm_bow_distances = np.fabs(h - h2).sum() (pairs_selection.py:690-708) in numpy's own summation order: equal to numpy and to the
+    oracle bit for bit, for lengths on both sides of the 8 / 128 / 8192 boundaries of the pairwise sum"""
+    from opensfm_amd import words
+
+    rng = np.random.default_rng(n)
+    h = np.abs(rng.normal(size=(9, n)))
+    h /= h.sum(1, keepdims=True)
+    hist = {"im%d" % i: h[i] for i in range(9)}
+    _, dist, other = words.bow_distances("im0", list(hist), hist)
+    assert other == ["im%d" % i for i in range(1, 9)]
+    want = [float(np.fabs(h[0] - h[i]).sum()) for i in range(1, 9)]
+    assert dist == want
+    assert np.array_equal(np.asarray(dist), oracle_lib.bow_distances(h[0], h[1:]))

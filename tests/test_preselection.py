@@ -180,8 +180,13 @@ def test_from_metadata_unions_the_strategies(refps, host_search, monkeypatch):
         assert {preselection.sorted_pair(*p) for p in mine} == {preselection.sorted_pair(*p) for p in theirs}
         assert all(p[0] in images[:10] for p in mine)
         assert rep == rrep
-    with pytest.raises(NotImplementedError):
-        preselection.match_candidates_from_metadata(images[:3], images, exifs, _Data(dict(base), reference), {"matching_graph_rounds": 5})
+    # graph rounds: the first (unjittered) triangulation is deterministic; with the jitter drawn from the same generator state the
+    # reference's pairs are reproduced exactly
+    np.random.seed(7)
+    theirs = refps.match_candidates_by_graph(images[:12], images, exifs, reference, 3)
+    np.random.seed(7)
+    mine = preselection.match_candidates_by_graph(images[:12], images, exifs, reference, 3)
+    assert mine == theirs and len(mine) > 20
     # images without GPS switch the GPS strategies off (and with nothing else enabled every pair is matched)
     del exifs[images[0]]["gps"]
     mine, _ = preselection.match_candidates_from_metadata(images[:2], images[:5], exifs, _Data(dict(base), reference), {"matching_gps_neighbors": 5})
@@ -219,3 +224,45 @@ def test_vlad_candidates_with_known_histograms(refps, host_search, monkeypatch):
     assert preselection.match_candidates_with_vlad(images[:6], images, exifs, reference, 0, 0, 0, False, {}) == {}
     with pytest.raises(ValueError):
         preselection.match_candidates_with_vlad(images[:2], images, exifs, reference, 3, 0, 0, False, {})
+
+
+def test_bow_candidates_equal_the_reference(refps, host_search, monkeypatch):
+    """match_candidates_with_bow: GPS preemption + L1 histogram distances + construct_pairs against the reference executed from file; the
+    distance call (a HIP kernel in the product) is replaced by the oracle's restatement of numpy's summation, which this test also pins
+    against numpy itself (the reference's bow_distances)."""
+    import oracle
+    from opensfm_amd import words
+
+    def oracle_bow_distances(image, other_images, histograms, ctx=None):
+        if image not in histograms:
+            return image, [], []
+        others = [o for o in other_images if o != image and o in histograms]
+        if not others:
+            return image, [], []
+        return image, list(oracle.bow_distances(histograms[image], np.stack([histograms[o] for o in others]))), others
+
+    monkeypatch.setattr(words, "bow_distances", oracle_bow_distances)
+    exifs = make_exifs(30, 7)
+    images = sorted(exifs)
+    reference = TopocentricConverter(45.0, 7.0, 0.0)
+    rng = np.random.default_rng(2)
+    weights = rng.uniform(0.5, 2.0, 10000)
+    hist = {}
+    for im in images[:-2]:  # two images have no histogram (too few words): they drop out on both sides
+        hist[im] = words.bow_histogram(rng.integers(0, 10000, 1500), 10000, weights)
+    # the oracle's sum is numpy's, bit for bit, on the reference's own function
+    for im in images[:5]:
+        _, dist_ref, other_ref = refps.bow_distances(im, images, hist)
+        _, dist_mine, other_mine = oracle_bow_distances(im, images, hist)
+        assert other_ref == other_mine and dist_ref == dist_mine
+    ctx = sys.modules["opensfm.context"]
+    ctx.processes_that_fit_in_memory = lambda p, per: 1
+    ctx.parallel_map = lambda f, args, processes, batch: [f(a) for a in args]
+    monkeypatch.setattr(refps, "load_histograms", lambda data, need: {im: hist[im] for im in need if im in hist})
+    data = _Data({"processes": 1}, reference)
+    for nb, dist, enforce in ((4, 0, False), (3, 150.0, True), (0, 0, False)):
+        mine = preselection.match_candidates_with_bow(images[:6], images, exifs, reference, 5, dist, nb, enforce, dict(hist))
+        theirs = refps.match_candidates_with_bow(data, images[:6], images, exifs, reference, 5, dist, nb, enforce)
+        assert mine.keys() == theirs.keys() and len(mine) > 0
+        assert all(mine[k] == theirs[k] for k in mine)
+    assert preselection.match_candidates_with_bow(images[:6], images, exifs, reference, 0, 0, 0, False, {}) == {}
