@@ -268,6 +268,8 @@ __device__ __forceinline__ Top2 top2_shfl_xor(const Top2 &t, int m) {
   return r;
 }
 
+constexpr int kGuidedWin = 512;                   // targets per window
+constexpr int kGuidedWpad = kGuidedWin / 64 + 1;  // 64-bit words per query row in LDS (odd: conflict-free per-lane rows)
 template <int DIR>  // 0: the queries are the features of the pair's first image, 1: of its second image (the transposed mask)
 __device__ __forceinline__ void guided_pairs_match_body(const GuidedPairsArgs &a, unsigned long long *bits) {
   const long p = blockIdx.z;
@@ -278,7 +280,6 @@ __device__ __forceinline__ void guided_pairs_match_body(const GuidedPairsArgs &a
   if (q0 >= nQ) return;
   const int q = q0 + lane;
   const bool valid = q < nQ;
-  const int W = (nT + 63) >> 6;
   double Q[6];
   {
     const double *src = a.six + ((p * 2 + DIR) * a.capr + (valid ? q : q0)) * 6;
@@ -287,86 +288,95 @@ __device__ __forceinline__ void guided_pairs_match_body(const GuidedPairsArgs &a
   }
   const double *T6 = a.six + ((p * 2 + 1 - DIR) * (long)a.capr) * 6;
   const double cstar = a.cstar;
-  // ---- phase 1: the mask row of this lane's query, one bit per target (32 targets per register so that a bit costs a select + or) ----
-  // The targets' vectors come through the scalar cache, kUnroll targets per round trip (the loop is bound by that latency, not by
-  // the fp64 pipe); rows beyond nT exist in the scratch (capr is a multiple of 64) and their bits are cleared afterwards.
-  constexpr int kUnroll = 4;
-  for (int jh = 0; jh < 2 * W; ++jh) {
-    unsigned half = 0;
-    const int jn = min(32, nT - jh * 32);
-#pragma unroll 1
-    for (int b0 = 0; b0 < 32; b0 += kUnroll) {
-      if (b0 >= jn) break;
-      double sv[kUnroll][6];
-#pragma unroll
-      for (int u = 0; u < kUnroll; ++u)
-#pragma unroll
-        for (int k = 0; k < 6; ++k) sv[u][k] = T6[(long)(jh * 32 + b0 + u) * 6 + k];  // wave-uniform: scalar loads
-#pragma unroll
-      for (int u = 0; u < kUnroll; ++u) {
-        const double *s = sv[u];
-        double ea, eb;
-        if (DIR == 0) {  // first6 = Q, second6 = s
-          ea = fabs(Q[3] * s[0] + Q[4] * s[1] + Q[5] * s[2]);
-          eb = fabs(Q[0] * s[3] + Q[1] * s[4] + Q[2] * s[5]);
-        } else {  // first6 = s, second6 = Q
-          ea = fabs(s[3] * Q[0] + s[4] * Q[1] + s[5] * Q[2]);
-          eb = fabs(s[0] * Q[3] + s[1] * Q[4] + s[2] * Q[5]);
-        }
-        const double c = (ea + eb) / 2.0;
-        half |= (c < cstar) ? (1u << (b0 + u)) : 0u;
-      }
-    }
-    if (jn < 32) half &= jn > 0 ? ((1u << jn) - 1u) : 0u;
-    reinterpret_cast<unsigned *>(bits + (long)lane * a.wpad)[jh] = valid ? half : 0u;
-  }
-  // ---- phase 2: every lane walks the set bits of ITS query in ascending target order -- cv2's own insertion order, so no merge --
-  //      with the query's descriptor in registers; exact integer distance from the store's int8 tiles, sqrtf, K = 2 insertion ----
   const int8_t *tilesQ = a.tiles + a.tile_off[imgQ] * OSFM_TILE_BYTES;
   const int8_t *tilesT = a.tiles + a.tile_off[imgT] * OSFM_TILE_BYTES;
   const int32_t *normT = a.norms + a.tile_off[imgT] * 32;
   const int qs = valid ? q : q0;
   const int nqn = (a.norms + a.tile_off[imgQ] * 32)[qs];
-  v4i_g av[8];
+  v4i_g av[8];  // the query's descriptor stays in registers
   {
     const int8_t *pa = tilesQ + (long)(qs >> 5) * OSFM_TILE_BYTES + (qs & 31) * 16;
 #pragma unroll
     for (int k = 0; k < 8; ++k) av[k] = *(const v4i_g *)(pa + k * 512);
   }
-  const unsigned long long *myrow = bits + (long)lane * a.wpad;
-  int w = 0;
-  unsigned long long word = W > 0 ? myrow[0] : 0ull;
+  unsigned long long *myrow_w = bits + (long)lane * kGuidedWpad;
+  const volatile unsigned long long *myrow = myrow_w;  // written and read by this lane only, in program order
   Top2 t = top2_empty();
-  for (;;) {
-    while (word == 0ull && w + 1 < W) word = myrow[++w];
-    const bool has = word != 0ull;
-    if (!__any(has)) break;
-    if (has) {
-      const int b = __builtin_ctzll(word);
-      word &= word - 1;
-      const int j = w * 64 + b;
-      const int8_t *pb = tilesT + (long)(j >> 5) * OSFM_TILE_BYTES + (j & 31) * 16;
-      v4i_g bv[8];
+  // The targets go by in windows of kGuidedWin: a window's mask bits (64 B per query, 4.6 KB of LDS per wavefront instead of one bit per
+  // target of the whole image) keep the occupancy at the register limit, which is what hides the scalar-load latency of phase 1.
+  for (int t0 = 0; t0 < nT; t0 += kGuidedWin) {
+    const int nW = min(kGuidedWin, nT - t0);
+    // ---- phase 1: this lane's mask bits for the window; the targets' vectors come through the scalar cache, kUnroll per round trip;
+    //      rows beyond nT exist in the scratch (capr is a multiple of 64) and their bits are cleared afterwards ----
+    constexpr int kUnroll = 4;
+    unsigned lo_half = 0;
+    for (int jh = 0; jh < kGuidedWin / 32; ++jh) {
+      unsigned half = 0;
+      const int jn = min(32, nW - jh * 32);
+#pragma unroll 1
+      for (int b0 = 0; b0 < 32; b0 += kUnroll) {
+        if (b0 >= jn) break;
+        double sv[kUnroll][6];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) bv[k] = *(const v4i_g *)(pb + k * 512);
-      int s0 = 0, s1 = 0;
+        for (int u = 0; u < kUnroll; ++u)
 #pragma unroll
-      for (int k = 0; k < 8; k += 2)
+          for (int k = 0; k < 6; ++k) sv[u][k] = T6[(long)(t0 + jh * 32 + b0 + u) * 6 + k];  // wave-uniform: scalar loads
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          s0 = __builtin_amdgcn_sdot4(av[k][e], bv[k][e], s0, false);
-          s1 = __builtin_amdgcn_sdot4(av[k + 1][e], bv[k + 1][e], s1, false);
+        for (int u = 0; u < kUnroll; ++u) {
+          const double *s = sv[u];
+          double ea, eb;
+          if (DIR == 0) {  // first6 = Q, second6 = s
+            ea = fabs(Q[3] * s[0] + Q[4] * s[1] + Q[5] * s[2]);
+            eb = fabs(Q[0] * s[3] + Q[1] * s[4] + Q[2] * s[5]);
+          } else {  // first6 = s, second6 = Q
+            ea = fabs(s[3] * Q[0] + s[4] * Q[1] + s[5] * Q[2]);
+            eb = fabs(s[0] * Q[3] + s[1] * Q[4] + s[2] * Q[5]);
+          }
+          const double c = (ea + eb) / 2.0;
+          half |= (c < cstar) ? (1u << (b0 + u)) : 0u;
         }
-      const int d2 = nqn + normT[j] - 2 * (s0 + s1);
-      top2_insert(t, sqrtf((float)d2), j);
+      }
+      if (jn < 32) half &= jn > 0 ? ((1u << jn) - 1u) : 0u;
+      if (!valid) half = 0u;
+      if (jh & 1)
+        myrow_w[jh >> 1] = (unsigned long long)lo_half | ((unsigned long long)half << 32);  // one type for the row: no aliasing games
+      else
+        lo_half = half;
+    }
+    // ---- phase 2: the lane walks the set bits of ITS row in ascending target order -- cv2's own insertion order, so no merge:
+    //      exact integer distance from the store's int8 tiles, sqrtf, K = 2 insertion ----
+    int w = 0;
+    unsigned long long word = myrow[0];
+    for (;;) {
+      while (word == 0ull && w + 1 < kGuidedWin / 64) word = myrow[++w];
+      const bool has = word != 0ull;
+      if (!__any(has)) break;
+      if (has) {
+        const int b = __builtin_ctzll(word);
+        word &= word - 1;
+        const int j = t0 + w * 64 + b;
+        const int8_t *pb = tilesT + (long)(j >> 5) * OSFM_TILE_BYTES + (j & 31) * 16;
+        v4i_g bv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) bv[k] = *(const v4i_g *)(pb + k * 512);
+        int s0 = 0, s1 = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k += 2)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            s0 = __builtin_amdgcn_sdot4(av[k][e], bv[k][e], s0, false);
+            s1 = __builtin_amdgcn_sdot4(av[k + 1][e], bv[k + 1][e], s1, false);
+          }
+        const int d2 = nqn + normT[j] - 2 * (s0 + s1);
+        top2_insert(t, sqrtf((float)d2), j);
+      }
     }
   }
   if (valid) a.good[(p * 2 + DIR) * a.capr + q] = (t.n >= 2 && (double)t.d0 < a.ratio * (double)t.d1) ? t.j0 : -1;
 }
 
-__global__ void __launch_bounds__(64) guided_pairs_match_kernel(GuidedPairsArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned long long *bits = reinterpret_cast<unsigned long long *>(smem);  // [64 queries][wpad words]
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) guided_pairs_match_kernel(GuidedPairsArgs a) {
+  __shared__ unsigned long long bits[64 * kGuidedWpad];  // [64 queries][kGuidedWpad words]: the mask bits of the current target window
   if (blockIdx.y == 0)
     guided_pairs_match_body<0>(a, bits);
   else if (a.symmetric)
@@ -462,20 +472,10 @@ int osfm_launch_guided_pairs(osfm_ctx *ctx, const osfm_store *store, const OsfmG
   a.out_counts = d_counts;
   a.out_matches = d_matches;
   a.out_flags = d_flags;
-  const int W = (store->max_count + 63) / 64;
-  a.wpad = W | 1;
-  const size_t lds = (size_t)64 * a.wpad * sizeof(unsigned long long);
-  {
-    static OsfmPerDeviceOnce once;
-    const int rc = once.run(ctx->device, []() -> int {
-      OSFM_HIP(hipFuncSetAttribute((const void *)guided_pairs_match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      return OSFM_OK;
-    });
-    if (rc != OSFM_OK) return rc;
-  }
+  a.wpad = kGuidedWpad;
   const unsigned blocks = (unsigned)((store->max_count + 255) / 256), qblocks = (unsigned)((store->max_count + 63) / 64);
   hipLaunchKernelGGL(guided_pairs_prep_kernel, dim3(blocks ? blocks : 1, 2, (unsigned)n_pairs), dim3(256), 0, stream, a);
-  hipLaunchKernelGGL(guided_pairs_match_kernel, dim3(qblocks ? qblocks : 1, 2, (unsigned)n_pairs), dim3(64), lds, stream, a);
+  hipLaunchKernelGGL(guided_pairs_match_kernel, dim3(qblocks ? qblocks : 1, 2, (unsigned)n_pairs), dim3(64), 0, stream, a);
   hipLaunchKernelGGL(guided_pairs_emit_kernel, dim3((unsigned)n_pairs), dim3(256), 0, stream, a);
   OSFM_HIP(hipGetLastError());
   return OSFM_OK;
