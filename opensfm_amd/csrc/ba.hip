@@ -2253,6 +2253,10 @@ struct Solver {
     hipLaunchKernelGGL(cam_grad_kernel, dim3(nblk(d.NC, 64)), dim3(64), 0, st, d, d.cams);
   }
   bool use_band = false, use_ctri = false, use_bcr = false, use_border = false;
+  // second stream: the camera-border columns and the right-hand side only need the Jacobian and Hhat, so they run underneath the
+  // cyclic-reduction factorisation (a latency chain of ~22 small launches that leaves most CUs idle)
+  hipStream_t st2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   double *Bc = nullptr, *Wb = nullptr, *SigInv = nullptr, *dots = nullptr;  // border elimination (nb x 6S, nb x 6S, nb x nb, nb x nb)
   double *wB = nullptr, *partB = nullptr, *dCm = nullptr;                     // its columns in one pass: w (2 nb per observation), camera partials, C
   // z_q = A^-1 r_q for nrhs right-hand sides (strides in doubles) in one walk of the levels
@@ -2538,6 +2542,19 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
   Solver sv;
   sv.ctx = ctx;
   sv.st = ctx->stream;
+  struct SideStream {
+    Solver &sv;
+    ~SideStream() {
+      if (sv.ev_fork) (void)hipEventDestroy(sv.ev_fork);
+      if (sv.ev_join) (void)hipEventDestroy(sv.ev_join);
+      if (sv.st2) (void)hipStreamDestroy(sv.st2);
+    }
+  } side_stream{sv};
+  if (getenv("OSFM_BA_ONE_STREAM") == nullptr) {  // measurement knob: everything on one stream
+    OSFM_HIP(hipStreamCreateWithFlags(&sv.st2, hipStreamNonBlocking));
+    OSFM_HIP(hipEventCreateWithFlags(&sv.ev_fork, hipEventDisableTiming));
+    OSFM_HIP(hipEventCreateWithFlags(&sv.ev_join, hipEventDisableTiming));
+  }
   sv.loss = O->loss;
   sv.loss_a = O->loss_threshold;
   Dev &d = sv.d;
@@ -2741,10 +2758,42 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     hipLaunchKernelGGL(point_hhat_kernel, dim3(nblk(NP)), dim3(TPB), 0, st, d, radius);
     sv.use_band = false;
     if (d.bw > 0) {
-      const int R = d.bw + 1;
       hipLaunchKernelGGL(band_assemble_kernel, dim3(S), dim3(TPB), 0, st, d, radius);
       sv.use_ctri = false;
       sv.use_bcr = false;
+    }
+    // ---- fork: camera-border columns (if this problem uses them) and the right-hand side, concurrently with the factorisation ----
+    const bool want_border = d.bw > 0 && d.ncl > 0 && O->preconditioner == 0 && sv.Bc && border_ok;
+    hipStream_t sx = sv.st2 ? sv.st2 : st;
+    if (sv.st2) {
+      OSFM_HIP(hipEventRecord(sv.ev_fork, st));
+      OSFM_HIP(hipStreamWaitEvent(sv.st2, sv.ev_fork, 0));
+    }
+    if (want_border) {  // all nb columns of B (and of the camera block C) in one pass over the observations
+      if (3 * NC == 3) {
+        hipLaunchKernelGGL(border_point_kernel<3>, dim3(d.nwg), dim3(kCoopObs), 0, sx, d, sv.wB);
+        hipLaunchKernelGGL(border_shot_kernel<3>, dim3(S), dim3(64), 0, sx, d, sv.wB, sv.Bc, sv.partB);
+        hipLaunchKernelGGL(border_cam_kernel<3>, dim3(NC), dim3(TPB), 0, sx, d, sv.partB, sv.dCm, radius);
+      } else {
+        hipLaunchKernelGGL(border_point_kernel<6>, dim3(d.nwg), dim3(kCoopObs), 0, sx, d, sv.wB);
+        hipLaunchKernelGGL(border_shot_kernel<6>, dim3(S), dim3(64), 0, sx, d, sv.wB, sv.Bc, sv.partB);
+        hipLaunchKernelGGL(border_cam_kernel<6>, dim3(NC), dim3(TPB), 0, sx, d, sv.partB, sv.dCm, radius);
+      }
+    }
+    // rhs
+    hipLaunchKernelGGL(schur_point_coop_kernel<1>, dim3(d.nwg), dim3(kCoopObs), 0, sx, d, d.y);
+    hipLaunchKernelGGL(schur_shot_kernel, dim3(S), dim3(64), 0, sx, d);
+    hipLaunchKernelGGL(cam_reduce_kernel, dim3(NC), dim3(TPB), 0, sx, d, 3);
+    hipLaunchKernelGGL(schur_finish_kernel, dim3(nbr), dim3(TPB), 0, sx, d, d.x, d.y, d.b, radius, 1);
+    if (sv.st2) OSFM_HIP(hipEventRecord(sv.ev_join, sv.st2));
+    bool joined = sv.st2 == nullptr;
+    auto join = [&]() -> int {  // the main stream continues after the side stream's work
+      if (!joined) OSFM_HIP(hipStreamWaitEvent(st, sv.ev_join, 0));
+      joined = true;
+      return OSFM_OK;
+    };
+    if (d.bw > 0) {
+      const int R = d.bw + 1;
       if (d.ncl > 0 && O->preconditioner == 0) {
         const size_t n2 = (size_t)d.ncd * d.ncd;
         const int N = d.ncl;
@@ -2779,15 +2828,10 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
         if (sv.use_bcr && sv.Bc && border_ok) {
           const int nb = 3 * NC, n6 = 6 * S;
           std::vector<double> Cm((size_t)nb * nb), Sg((size_t)nb * nb);
-          // all nb columns of B (and of the camera block C) in one pass over the observations, W = A^-1 B in one solve launch
-          if (nb == 3) {
-            hipLaunchKernelGGL(border_point_kernel<3>, dim3(d.nwg), dim3(kCoopObs), 0, st, d, sv.wB);
-            hipLaunchKernelGGL(border_shot_kernel<3>, dim3(S), dim3(64), 0, st, d, sv.wB, sv.Bc, sv.partB);
-            hipLaunchKernelGGL(border_cam_kernel<3>, dim3(NC), dim3(TPB), 0, st, d, sv.partB, sv.dCm, radius);
-          } else {
-            hipLaunchKernelGGL(border_point_kernel<6>, dim3(d.nwg), dim3(kCoopObs), 0, st, d, sv.wB);
-            hipLaunchKernelGGL(border_shot_kernel<6>, dim3(S), dim3(64), 0, st, d, sv.wB, sv.Bc, sv.partB);
-            hipLaunchKernelGGL(border_cam_kernel<6>, dim3(NC), dim3(TPB), 0, st, d, sv.partB, sv.dCm, radius);
+          // the columns of B and C were formed on the side stream; W = A^-1 B for all of them in one walk of the levels
+          {
+            const int rcj = join();
+            if (rcj != OSFM_OK) return rcj;
           }
           sv.bcr_solve_multi(sv.Bc, n6, sv.Wb, n6, nb, false);
           OSFM_HIP(hipMemcpyAsync(Cm.data(), sv.dCm, (size_t)nb * nb * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -2859,16 +2903,15 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     }
     // block-Jacobi blocks (6x6 per shot, 3x3 per camera): the fallback preconditioner, and the camera rows of the band
     // preconditioners -- not needed when the cyclic reduction came out with the exact camera border
+    {
+      const int rcj = join();  // the right-hand side (and its use of part / camred) is complete
+      if (rcj != OSFM_OK) return rcj;
+    }
     if (!(sv.use_bcr && sv.use_border)) {
       hipLaunchKernelGGL(precond_shot_kernel, dim3(S), dim3(64), 0, st, d, radius);
       hipLaunchKernelGGL(cam_reduce_kernel, dim3(NC), dim3(TPB), 0, st, d, 6);
       hipLaunchKernelGGL(precond_cam_kernel, dim3(nblk(NC, 64)), dim3(64), 0, st, d, radius);
     }
-    // rhs
-    hipLaunchKernelGGL(schur_point_coop_kernel<1>, dim3(d.nwg), dim3(kCoopObs), 0, st, d, d.y);
-    hipLaunchKernelGGL(schur_shot_kernel, dim3(S), dim3(64), 0, st, d);
-    hipLaunchKernelGGL(cam_reduce_kernel, dim3(NC), dim3(TPB), 0, st, d, 3);
-    hipLaunchKernelGGL(schur_finish_kernel, dim3(nbr), dim3(TPB), 0, st, d, d.x, d.y, d.b, radius, 1);
     OSFM_HIP(hipMemsetAsync(d.x, 0, nred * sizeof(double), st));
     OSFM_HIP(hipMemcpyAsync(d.r, d.b, nred * sizeof(double), hipMemcpyDeviceToDevice, st));
     sv.precond(d.r, d.z);
