@@ -293,7 +293,11 @@ static int match_pairs_impl(osfm_ctx *ctx, const osfm_store *store, const int32_
   // at least four chunks once there is enough work for that (>= 4096 pairs each): the geometric stage of chunk k runs on stream
   // B underneath the matcher of chunk k + 1, which a neighbour-preselected list (every pair reaches RANSAC) needs most
   int64_t cp = n_pairs < chunk_pairs ? n_pairs : chunk_pairs;
-  if (n_pairs >= 8192) cp = std::min<int64_t>(cp, std::max<int64_t>(4096, (n_pairs + 3) / 4));
+  {
+    const char *e = getenv("OSFM_MATCH_CHUNKS");  // measurement knob
+    const int64_t nch = e ? std::max(1, atoi(e)) : 4;
+    if (n_pairs >= 8192) cp = std::min<int64_t>(cp, std::max<int64_t>(4096, (n_pairs + nch - 1) / nch));
+  }
   if (guided) cp = std::min<int64_t>(cp, 8192);  // 96 B of epipolar vectors + 8 B of results per feature and pair in the chunk's scratch
   const int64_t nchunks = (n_pairs + cp - 1) / (cp > 0 ? cp : 1);
   // Two chunk buffer sets: while stream B runs RANSAC + gather + D2H of chunk k (a few thousand

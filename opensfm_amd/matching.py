@@ -434,8 +434,8 @@ def _fetch_result(lib, res) -> Tuple[np.ndarray, np.ndarray]:
     try:
         n = lib.osfm_result_num_pairs(res)
         total = lib.osfm_result_total_matches(res)
-        counts = np.zeros(max(n, 1), np.int32)
-        matches = np.zeros((max(total, 1), 2), np.int32)
+        counts = np.empty(max(n, 1), np.int32)  # osfm_result_fetch fills both completely
+        matches = np.empty((max(total, 1), 2), np.int32)
         check(lib.osfm_result_fetch(res, _fptr(counts, C.c_int32), _fptr(matches, C.c_int32)), "osfm_result_fetch")
     finally:
         lib.osfm_result_destroy(res)
