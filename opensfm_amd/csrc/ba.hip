@@ -21,6 +21,8 @@
 #include <numeric>
 #include <vector>
 
+#include <rocprim/rocprim.hpp>
+
 #include "ba_math.h"
 #include "osfm_internal.h"
 
@@ -2166,6 +2168,42 @@ __global__ void __launch_bounds__(TPB) border_cam_kernel(Dev d, const double *pa
       }
 }
 
+// ---- setup on the device: the point-major order and the shot-major index lists (two stable radix sorts + lower bounds) ----
+__global__ void iota_int_kernel(int *a, long n) {
+  const long i = (long)blockIdx.x * TPB + threadIdx.x;
+  if (i < n) a[i] = (int)i;
+}
+__global__ void gather_int_kernel(const int *idx, const int *src, long n, int *dst) {
+  const long i = (long)blockIdx.x * TPB + threadIdx.x;
+  if (i < n) dst[i] = src[idx[i]];
+}
+// off[v] = first position k with sorted[k] >= v, v = 0 .. nv (off[nv] = n)
+__global__ void lower_bound_kernel(const int *sorted, long n, int nv, long *off) {
+  const long v = (long)blockIdx.x * TPB + threadIdx.x;
+  if (v > nv) return;
+  long lo = 0, hi = n;
+  while (lo < hi) {
+    const long mid = (lo + hi) >> 1;
+    if (sorted[mid] < (int)v)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  off[v] = lo;
+}
+// largest (max shot - min shot) over the tracks: the block half-bandwidth of the shot-shot coupling
+__global__ void track_width_kernel(const long *pt_off, const int *o_shot, int np, int *out) {
+  const int p = blockIdx.x * TPB + threadIdx.x;
+  if (p >= np) return;
+  int mn = 1 << 30, mx = -1;
+  for (long k = pt_off[p]; k < pt_off[p + 1]; k++) {
+    const int s = o_shot[k];
+    mn = min(mn, s);
+    mx = max(mx, s);
+  }
+  if (mx >= 0) atomicMax(out, mx - mn);
+}
+
 // ---- setup helpers: the observation arrays are permuted on the device (host only builds the index lists) ----
 __global__ void gather_pm_kernel(const int *perm, const double *raw_xy, const double *raw_sigma, long M, double *o_x, double *o_y,
                                  double *o_sigma) {
@@ -2511,30 +2549,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
   for (int s = 0; s < S; s++)
     OSFM_REQUIRE(P->shot_camera[s] >= 0 && P->shot_camera[s] < NC, OSFM_E_INVALID, "shot %d references camera %d", s, P->shot_camera[s]);
 
-  // ---- host: point-major observation order + shot-major index lists ----
-  std::vector<long> pt_off((size_t)NP + 1, 0), shot_off((size_t)S + 1, 0);
-  for (long o = 0; o < M; o++) pt_off[(size_t)P->obs_point[o] + 1]++;
-  for (int p = 0; p < NP; p++) pt_off[(size_t)p + 1] += pt_off[p];
   OSFM_REQUIRE(M < (1L << 31), OSFM_E_UNSUPPORTED, "more than 2^31 observations");
-  std::vector<int> perm((size_t)M);  // point-major position -> original index
-  {
-    std::vector<long> fill(pt_off.begin(), pt_off.end() - 1);
-    for (long o = 0; o < M; o++) perm[(size_t)fill[(size_t)P->obs_point[o]]++] = (int)o;
-  }
-  // only the two index arrays are permuted on the host (the shot lists and the band width need them);
-  // coordinates and sigmas are uploaded as they are and gathered on the device
-  std::vector<int> o_shot((size_t)M), o_point((size_t)M), shot_obs((size_t)M);
-  for (long k = 0; k < M; k++) {
-    const long o = perm[(size_t)k];
-    o_shot[(size_t)k] = P->obs_shot[o];
-    o_point[(size_t)k] = P->obs_point[o];
-    shot_off[(size_t)o_shot[(size_t)k] + 1]++;
-  }
-  for (int s = 0; s < S; s++) shot_off[(size_t)s + 1] += shot_off[s];
-  {
-    std::vector<long> fill(shot_off.begin(), shot_off.end() - 1);
-    for (long k = 0; k < M; k++) shot_obs[(size_t)fill[(size_t)o_shot[(size_t)k]]++] = (int)k;
-  }
 
   // ---- device image ----
   Arena A;
@@ -2592,9 +2607,46 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     d.up_J = A.alloc<double>((size_t)9 * S, e);
     d.prior_rot = A.alloc<double>((size_t)6 * S, e);
   }
-  d.o_shot = A.upload(o_shot.data(), (size_t)M, e);
-  d.o_point = A.upload(o_point.data(), (size_t)M, e);
-  int *d_perm = A.upload(perm.data(), (size_t)M, e);
+  // ---- point-major observation order and shot-major index lists, built on the device: perm = stable argsort of the observations by
+  //      point (the order a host counting sort gives), shot_obs = stable argsort of the point-major positions by shot; offsets by
+  //      lower bounds.  (The host version of this -- five passes with random scatters over 20 MB arrays -- was 35-40 ms of the 60 ms
+  //      setup at configs[4].) ----
+  std::vector<long> pt_off((size_t)NP + 1, 0);
+  int *d_perm = A.alloc<int>((size_t)M, e);
+  int bw_true = 0;
+  {
+    int *raw_shot = A.upload(P->obs_shot, (size_t)M, e), *raw_point = A.upload(P->obs_point, (size_t)M, e);
+    int *iota = A.alloc<int>((size_t)M, e), *o_point = A.alloc<int>((size_t)M, e), *o_shot = A.alloc<int>((size_t)M, e);
+    int *sm_keys = A.alloc<int>((size_t)M, e), *shot_obs = A.alloc<int>((size_t)M, e);
+    long *d_pt_off = A.alloc<long>((size_t)NP + 1, e), *d_shot_off = A.alloc<long>((size_t)S + 1, e);
+    int *d_bw = A.alloc<int>(4, e);
+    auto bits_for = [](long n) { unsigned b = 1; while (b < 32 && (1L << b) < n) b++; return b; };
+    const unsigned pbits = bits_for(NP), sbits = bits_for(S);
+    size_t need1 = 0, need2 = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, need1, raw_point, o_point, iota, d_perm, (size_t)M, 0u, pbits, sv.st);
+    (void)rocprim::radix_sort_pairs(nullptr, need2, o_shot, sm_keys, iota, shot_obs, (size_t)M, 0u, sbits, sv.st);
+    const size_t tb = std::max(need1, need2);
+    unsigned char *tmp = A.alloc<unsigned char>(tb + 256, e);
+    OSFM_REQUIRE(e == hipSuccess, OSFM_E_NOMEM, "BA device allocation/upload failed: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(iota_int_kernel, dim3(nblk(M)), dim3(TPB), 0, sv.st, iota, M);
+    size_t tb1 = tb, tb2 = tb;
+    OSFM_HIP(rocprim::radix_sort_pairs(tmp, tb1, raw_point, o_point, iota, d_perm, (size_t)M, 0u, pbits, sv.st));
+    hipLaunchKernelGGL(gather_int_kernel, dim3(nblk(M)), dim3(TPB), 0, sv.st, d_perm, raw_shot, M, o_shot);
+    hipLaunchKernelGGL(lower_bound_kernel, dim3(nblk(NP + 1L)), dim3(TPB), 0, sv.st, o_point, M, NP, d_pt_off);
+    OSFM_HIP(rocprim::radix_sort_pairs(tmp, tb2, o_shot, sm_keys, iota, shot_obs, (size_t)M, 0u, sbits, sv.st));
+    hipLaunchKernelGGL(lower_bound_kernel, dim3(nblk(S + 1L)), dim3(TPB), 0, sv.st, sm_keys, M, S, d_shot_off);
+    OSFM_HIP(hipMemsetAsync(d_bw, 0, sizeof(int), sv.st));
+    hipLaunchKernelGGL(track_width_kernel, dim3(nblk(NP)), dim3(TPB), 0, sv.st, d_pt_off, o_shot, NP, d_bw);
+    OSFM_HIP(hipGetLastError());
+    OSFM_HIP(hipMemcpyAsync(pt_off.data(), d_pt_off, ((size_t)NP + 1) * sizeof(long), hipMemcpyDeviceToHost, sv.st));
+    OSFM_HIP(hipMemcpyAsync(&bw_true, d_bw, sizeof(int), hipMemcpyDeviceToHost, sv.st));
+    OSFM_HIP(hipStreamSynchronize(sv.st));
+    d.o_shot = o_shot;
+    d.o_point = o_point;
+    d.pt_off = d_pt_off;
+    d.shot_off = d_shot_off;
+    d.shot_obs = shot_obs;
+  }
   {
     double *raw_xy = A.upload(P->obs_xy, (size_t)2 * M, e), *raw_sg = A.upload(P->obs_sigma, (size_t)M, e);
     double *ox = A.alloc<double>((size_t)M, e), *oy = A.alloc<double>((size_t)M, e), *osg = A.alloc<double>((size_t)M, e);
@@ -2603,7 +2655,6 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     d.o_y = oy;
     d.o_sigma = osg;
   }
-  d.pt_off = A.upload(pt_off.data(), (size_t)NP + 1, e);
   {
     std::vector<int> wg_pt;
     wg_pt.push_back(0);
@@ -2617,8 +2668,6 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     d.nwg = (int)wg_pt.size() - 1;
     d.wg_pt = A.upload(wg_pt.data(), wg_pt.size(), e);
   }
-  d.shot_off = A.upload(shot_off.data(), (size_t)S + 1, e);
-  d.shot_obs = A.upload(shot_obs.data(), (size_t)M, e);
   d.shotR = A.alloc<double>((size_t)36 * S, e);
   d.Jpm = A.alloc<double>((size_t)26 * M, e);
   d.Jsm = A.alloc<double>((size_t)26 * M, e);
@@ -2662,16 +2711,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
   d.scal = A.alloc<double>(32, e);
   const long nbmax = std::max<long>(nblk(M), nblk(3L * NP));
   d.partial = A.alloc<double>((size_t)2 * nbmax + 16, e);
-  // block half-bandwidth of the shot-shot coupling (shots in caller order)
-  int bw_true = 0;
-  for (int p = 0; p < NP; p++) {
-    int mn = 1 << 30, mx = -1;
-    for (long k = pt_off[(size_t)p]; k < pt_off[(size_t)p + 1]; k++) {
-      mn = std::min(mn, o_shot[(size_t)k]);
-      mx = std::max(mx, o_shot[(size_t)k]);
-    }
-    if (mx >= 0) bw_true = std::max(bw_true, mx - mn);
-  }
+  // block half-bandwidth of the shot-shot coupling (shots in caller order): bw_true, from track_width_kernel above
   d.bw = O->preconditioner == 1 ? 0 : std::min(bw_true, kMaxBw);
   if (S < 2) d.bw = 0;
   d.band = A.alloc<double>((size_t)S * (d.bw + 1) * 36, e);
