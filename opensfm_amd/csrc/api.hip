@@ -354,6 +354,7 @@ static int match_pairs_impl(osfm_ctx *ctx, const osfm_store *store, const int32_
     ~Guard() { delete r; }
   } guard{res};
   res->counts.assign((size_t)n_pairs, 0);
+  (void)res->matches.reserve(ctx->match_hint + ctx->match_hint / 8);  // what the previous call on this context produced
   std::vector<int32_t> hflags((size_t)cp);
   std::vector<int64_t> hoff((size_t)cp);
   double ms_match = 0.0, ms_ransac = 0.0;
@@ -431,7 +432,7 @@ static int match_pairs_impl(osfm_ctx *ctx, const osfm_store *store, const int32_
       if (tm) tm->pairs_exact_path += hflags[(size_t)q] != 0;
     }
     const size_t base = res->matches.size();
-    res->matches.resize(base + (size_t)total * 2);
+    OSFM_REQUIRE(res->matches.resize(base + (size_t)total * 2), OSFM_E_NOMEM, "out of host memory for %lld matches", (long long)total);
     if (total > 0) {
       if ((size_t)total > S.gather_cap) {
         if (S.gather.p) (void)hipFree(S.gather.p);
@@ -469,6 +470,7 @@ static int match_pairs_impl(osfm_ctx *ctx, const osfm_store *store, const int32_
     OSFM_HIP(hipMemcpy(&work, d_work.p, 8, hipMemcpyDeviceToHost));
     tm->ransac_model_points = (int64_t)work;
   }
+  ctx->match_hint = res->matches.size();
   guard.r = nullptr;
   *out = res;
   return OSFM_OK;

@@ -5,6 +5,7 @@
 
 #include <mutex>
 #include <string>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/osfm_mi355.h"
@@ -39,6 +40,7 @@ struct osfm_ctx {
   hipStream_t stream = nullptr;
   hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   void *d_rng_table = nullptr;  // relpose.hip: the tabulated std::mt19937(42) stream, made on first use
+  size_t match_hint = 0;        // int32 entries of the last batched call's match list: the next call reserves that much up front
 };
 
 // Tile = 32 descriptors x 128 int8 in MFMA-operand order (4 KiB):
@@ -70,9 +72,39 @@ struct osfm_store {
   int64_t bytes = 0;
 };
 
+// growable array without value-initialisation (the match list is tens of MB per call and every entry is overwritten by a D2H copy)
+template <typename T>
+struct OsfmRawVec {
+  T *p = nullptr;
+  size_t n = 0, cap = 0;
+  OsfmRawVec() = default;
+  OsfmRawVec(const OsfmRawVec &) = delete;
+  OsfmRawVec &operator=(const OsfmRawVec &) = delete;
+  ~OsfmRawVec() { free(p); }
+  bool reserve(size_t want) {
+    if (want <= cap) return true;
+    T *q = (T *)realloc(p, want * sizeof(T));
+    if (!q) return false;
+    p = q;
+    cap = want;
+    return true;
+  }
+  bool resize(size_t want) {
+    if (want > cap && !reserve(want + want / 2)) return false;
+    n = want;
+    return true;
+  }
+  size_t size() const { return n; }
+  bool empty() const { return n == 0; }
+  T *data() { return p; }
+  const T *data() const { return p; }
+  T &operator[](size_t i) { return p[i]; }
+  const T &operator[](size_t i) const { return p[i]; }
+};
+
 struct osfm_match_result {
   std::vector<int32_t> counts;
-  std::vector<int32_t> matches;  // total x 2
+  OsfmRawVec<int32_t> matches;  // total x 2
 };
 
 #define OSFM_CTX_LOCK(ctx) std::lock_guard<std::recursive_mutex> osfm_ctx_lock_((ctx)->mu)
