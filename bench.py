@@ -209,26 +209,34 @@ def main():
     }
 
     if rank == 0:
-        if not args.no_overlap:
-            out["overlap_workload"] = overlap_bench(args, ctx, store, scene, n_images, not args.no_cpu_baseline)
-        if not args.no_calibrated:
-            out["calibrated"] = calibrated_bench(args, ctx, store, scene, n_images, not args.no_cpu_baseline)
-        if not args.no_float:
-            out["float_descriptors"] = float_bench(args, ctx, scene, pairs_all if world == 1 else pairs_all[:p1], n_images, not args.no_cpu_baseline)
-        if not args.no_guided:
-            out["guided"] = guided_bench(args, ctx, store, scene, n_images, not args.no_cpu_baseline)
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene, pairs_gathered, args.cpu_sample_pairs, graph, args.full_parity)
-        if not args.no_tracks and graph is not None:
-            out["tracks"] = tracks_bench(ctx, scene, pairs_gathered, graph, not args.no_cpu_baseline)
-        if not args.no_ba:
+        def section(name, fn, *a):
+            """the secondary workloads must not take the headline line down with them: a failure is recorded in place of the numbers"""
             try:
+                out[name] = fn(*a)
+            except Exception as exc:  # noqa: BLE001
+                import traceback
+
+                out[name] = {"error": f"{type(exc).__name__}: {exc}", "traceback": traceback.format_exc()[-1500:]}
+
+        if not args.no_overlap:
+            section("overlap_workload", overlap_bench, args, ctx, store, scene, n_images, not args.no_cpu_baseline)
+        if not args.no_calibrated:
+            section("calibrated", calibrated_bench, args, ctx, store, scene, n_images, not args.no_cpu_baseline)
+        if not args.no_float:
+            section("float_descriptors", float_bench, args, ctx, scene, pairs_all if world == 1 else pairs_all[:p1], n_images, not args.no_cpu_baseline)
+        if not args.no_guided:
+            section("guided", guided_bench, args, ctx, store, scene, n_images, not args.no_cpu_baseline)
+        if not args.no_cpu_baseline:
+            section("cpu_baseline", cpu_baseline, scene, pairs_gathered, args.cpu_sample_pairs, graph, args.full_parity)
+        if not args.no_tracks and graph is not None:
+            section("tracks", tracks_bench, ctx, scene, pairs_gathered, graph, not args.no_cpu_baseline)
+        if not args.no_ba:
+            def ba_section():
                 import bench_ba as ba_bench
 
-                out["ba"] = ba_bench.run(ctx, args.ba_shots, args.ba_points, args.ba_track, args.ba_iters,
-                                         cpu_baseline=not args.no_cpu_baseline)
-            except ImportError:
-                out["ba"] = None
+                return ba_bench.run(ctx, args.ba_shots, args.ba_points, args.ba_track, args.ba_iters, cpu_baseline=not args.no_cpu_baseline)
+
+            section("ba", ba_section)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
