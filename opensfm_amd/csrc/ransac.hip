@@ -20,7 +20,6 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kWaves = 4;
 constexpr int kBatch = 64;  // hypotheses generated per round
-constexpr int kMaxPts = OSFM_MAX_FEATURES;
 constexpr int kFirstBatch = 8;  // hypotheses of the first round (ransac_core)
 
 struct CvRng {
@@ -528,7 +527,6 @@ struct RansacPairsArgs {
 __global__ void __launch_bounds__(kThreads) ransac_pairs_kernel(RansacPairsArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   RansacShared &sh = *reinterpret_cast<RansacShared *>(smem);
-  const int capr = (a.cap + 3) & ~3;
   double *priv = reinterpret_cast<double *>(smem + sizeof(RansacShared));     // [kPrivDoubles][64]: the 7-point systems (run_7point)
   int *ipriv = reinterpret_cast<int *>(priv + kPrivDoubles * 64);             // [9][64]
   float4 *ptsbuf = reinterpret_cast<float4 *>(ipriv + 9 * 64);                // [lds_pts]

@@ -1412,7 +1412,6 @@ OSFM_HD int ldlt_solve6(const double* A, const double* b, double* x) {
 // RT (3 x 4 row-major, x2 ~ R x1 + t) is refined in place; returns the TinySolver iteration count.
 template <class Eval>
 OSFM_HD int refine_relative_pose(double* RT, int iterations, Eval& ev, double* costs) {
-  constexpr int NR = kRefineResiduals + 1;
   double R[9], x[6];
   for (int a = 0; a < 3; a++)
     for (int b = 0; b < 3; b++) R[3 * a + b] = RT[4 * a + b];
