@@ -510,6 +510,63 @@ def split_matches(counts: np.ndarray, matches: np.ndarray) -> List[np.ndarray]:
     return [matches[off[i]: off[i + 1]] for i in range(len(counts))]
 
 
+# --------------------------------------------------------------------------------------------
+# ad-hoc filters (``matching_use_filters``, matching.py:939-1064): per-match predicates on the keypoints between the descriptor stage and
+# the gates / robust stage -- host numpy, as in the reference (a few hundred matches per pair)
+# --------------------------------------------------------------------------------------------
+def _is_panorama(projection_type: str) -> bool:
+    return projection_type in ("equirectangular", "spherical")  # pygeometry.Camera.is_panorama
+
+
+def apply_adhoc_filters(data, matches: np.ndarray, im1: str, camera1, p1: np.ndarray, im2: str, camera2, p2: np.ndarray) -> np.ndarray:
+    """``apply_adhoc_filters`` (matching.py:939-957): static matches, panorama poles, Vermont and BlackVue watermarks, in that order"""
+    m = np.asarray(matches, np.int64).reshape(-1, 2)
+    p1, p2 = np.asarray(p1, np.float64), np.asarray(p2, np.float64)
+    # _non_static_matches (:960-981): drop matches that do not move, unless that would drop more than 85 % of them
+    d = p1[m[:, 0], :2] - p2[m[:, 1], :2]
+    keep = d[:, 0] ** 2 + d[:, 1] ** 2 >= 0.001 ** 2
+    if not (1 - int(keep.sum()) / max(len(m), 1) > 0.85):
+        m = m[keep]
+    # _not_on_pano_poles_matches (:983-1007)
+    pano1, pano2 = _is_panorama(camera1.projection_type), _is_panorama(camera2.projection_type)
+    if pano1 or pano2:
+        y1, y2 = p1[m[:, 0], 1], p2[m[:, 1], 1]
+        ok = np.ones(len(m), bool)
+        if pano1:
+            ok &= (-0.125 < y1) & (y1 < 0.125)
+        if pano2:
+            ok &= (-0.125 < y2) & (y2 < 0.125)
+        m = m[ok]
+    # _not_on_vermont_watermark (:1010-1035), _not_on_blackvue_watermark (:1038-1064)
+    meta1, meta2 = data.load_exif(im1), data.load_exif(im2)
+    if meta1["make"] == "VTrans_Camera" and meta1["model"] == "VTrans_Camera":
+        m = m[p1[m[:, 0], 1] > -0.255]
+    if meta2["make"] == "VTrans_Camera" and meta2["model"] == "VTrans_Camera":
+        m = m[p2[m[:, 1], 1] > -0.255]
+    if meta1["make"].lower() == "blackvue":
+        m = m[p1[m[:, 0], 1] < 0.263]
+    if meta2["make"].lower() == "blackvue":
+        m = m[p2[m[:, 1], 1] < 0.263]
+    return m.astype(np.int32)
+
+
+def _filter_then_robust(data, config, pairs, ipairs, found, pts, cams) -> List[np.ndarray]:
+    """matching.py:576-634 with ``matching_use_filters``: descriptor-stage matches -> ad-hoc filters -> gate -> robust_match -> gate.
+    The filters sit between two device stages, so the robust stage runs pair by pair through the leaves here."""
+    min_match = int(_cfg(config, "robust_matching_min_match"))
+    out: List[np.ndarray] = []
+    for (im1, im2), (a, b), m in zip(pairs, ipairs, found):
+        res = np.zeros((0, 2), np.int32)
+        if len(m):
+            m = apply_adhoc_filters(data, m, im1, cams[a], pts[a], im2, cams[b], pts[b])
+        if len(m) >= min_match:
+            rm = np.asarray(robust_match(pts[a], pts[b], cams[a], cams[b], m, config)).reshape(-1, 2)
+            if len(rm) >= min_match and len(rm) > 0:
+                res = rm.astype(np.int32)
+        out.append(res)
+    return out
+
+
 def match_images_with_pairs(data, config_override: Dict[str, Any], exifs: Dict[str, Any],
                             pairs: List[Tuple[str, str]], poses=None) -> Dict[Tuple[str, str], np.ndarray]:
     """Perform pair matchings given pairs (``matching.py:63-98``), all pairs in one GPU batch.
@@ -530,9 +587,9 @@ def match_images_with_pairs(data, config_override: Dict[str, Any], exifs: Dict[s
         _matcher_flags(config)  # raises for matchers that are not on the GPU path
     elif poses:
         raise NotImplementedError("guided matching goes with the BRUTEFORCE matcher (matching.py:260-337)")
-    for key in ("matching_use_filters", "matching_use_segmentation"):
-        if config.get(key):  # matching.py:352,618-628: would change the result, and is not implemented here
-            raise NotImplementedError(f"config {key!r} is not implemented on the GPU path")
+    if config.get("matching_use_segmentation"):  # matching.py:352: segmentation labels inside the descriptors: not implemented here
+        raise NotImplementedError("config 'matching_use_segmentation' is not implemented on the GPU path")
+    use_filters = bool(config.get("matching_use_filters"))
     if int(_cfg(config, "robust_matching_min_match")) < 15:
         raise NotImplementedError("robust_matching_min_match < 15 reaches cv2's LMedS branch inside match(); only the leaf "
                                   "find_fundamental_ransac implements it")
@@ -586,6 +643,10 @@ def match_images_with_pairs(data, config_override: Dict[str, Any], exifs: Dict[s
         store = DescriptorStore(descs, pts)
         try:
             pin = np.array([_is_pinhole(cams[a]) and _is_pinhole(cams[b]) for a, b in ipairs], bool)
+            if use_filters:  # matching.py:323-334: the filters follow the guided descriptor stage
+                counts, matches = match_pairs_guided(store, ipairs, bearings, rels, cfg_g, robust=False)
+                per_pair = _filter_then_robust(data, config, pairs, ipairs, split_matches(counts, matches), pts, cams)
+                pin = np.zeros(0, bool)
             for sel, camarg in ((pin, None), (~pin, cams)):
                 if not sel.any():
                     continue
@@ -606,6 +667,9 @@ def match_images_with_pairs(data, config_override: Dict[str, Any], exifs: Dict[s
         finally:
             wstore.close()
         min_match = int(_cfg(config, "robust_matching_min_match"))
+        if use_filters:
+            per_pair = _filter_then_robust(data, config, pairs, ipairs, found, pts, cams)
+            found = []
         for p, ((a, b), m) in enumerate(zip(ipairs, found)):
             if len(m) < min_match:
                 continue
@@ -616,6 +680,10 @@ def match_images_with_pairs(data, config_override: Dict[str, Any], exifs: Dict[s
         store = DescriptorStore(descs, pts)  # all descriptors resident in HBM for the batched launches
         try:
             pin = np.array([_is_pinhole(cams[a]) and _is_pinhole(cams[b]) for a, b in ipairs], bool)
+            if use_filters:  # matching.py:399-411: descriptor stage for every pair, filters on the host, robust stage through the leaves
+                counts, matches = match_pairs(store, ipairs, config, robust=False)
+                per_pair = _filter_then_robust(data, config, pairs, ipairs, split_matches(counts, matches), pts, cams)
+                pin = np.zeros(0, bool)
             if pin.any():
                 counts, matches = match_pairs(store, ipairs[pin], config, robust=True)
                 for p, m in zip(np.flatnonzero(pin), split_matches(counts, matches)):

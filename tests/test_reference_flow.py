@@ -76,7 +76,7 @@ def ref(oracle_lib):
     pkg = _Stub("opensfm")
     pkg.__path__ = [REF]
     pygeometry = _Stub("opensfm.pygeometry")
-    pygeometry.Camera = object
+    pygeometry.Camera = type("Camera", (), {"is_panorama": staticmethod(lambda t: t in ("equirectangular", "spherical"))})
     pygeometry.Pose = object
 
     def tri_many(b1, b2, R, t):
@@ -259,8 +259,34 @@ def _collection(oracle_lib, rng, guided):
     return images, cams, cam_of, feats, masks, poses, config
 
 
-@pytest.mark.parametrize("guided", [False, True])
-def test_match_flow_equals_the_product_host_flow(ref, oracle_lib, monkeypatch, guided):
+def test_adhoc_filters_equal_the_reference(ref):
+    """apply_adhoc_filters (matching.py:939-1064) executed from the reference's file against the product's vectorised version: static
+    matches (below and above the 85 % rule), panorama poles, Vermont and BlackVue watermarks"""
+    from opensfm_amd import matching as product
+
+    matching, _ = ref
+    rng = np.random.default_rng(8)
+    makes = {"plain": {"make": "Canon", "model": "X"}, "vt": {"make": "VTrans_Camera", "model": "VTrans_Camera"}, "bv": {"make": "BlackVue", "model": "DR900"},
+             "vt_other": {"make": "VTrans_Camera", "model": "other"}}
+    data = types.SimpleNamespace(load_exif=lambda im: makes[im])
+    cam = lambda t: types.SimpleNamespace(projection_type=t)  # noqa: E731
+    n = 400
+    for static_frac in (0.0, 0.3, 0.9):
+        for t1, t2 in (("perspective", "perspective"), ("spherical", "perspective"), ("fisheye", "equirectangular"), ("spherical", "spherical")):
+            for im1, im2 in (("plain", "plain"), ("vt", "plain"), ("plain", "bv"), ("bv", "vt"), ("vt_other", "plain")):
+                p1 = np.c_[rng.uniform(-0.5, 0.5, n), rng.uniform(-0.375, 0.375, n), rng.uniform(0, 1, n)]
+                p2 = np.c_[rng.uniform(-0.5, 0.5, n), rng.uniform(-0.375, 0.375, n), rng.uniform(0, 1, n)]
+                m = np.c_[rng.permutation(n)[:250], rng.permutation(n)[:250]]
+                k = int(static_frac * len(m))
+                p2[m[:k, 1], :2] = p1[m[:k, 0], :2] + rng.uniform(-5e-4, 5e-4, (k, 2))  # (almost) static matches
+                want = matching.apply_adhoc_filters(data, [tuple(x) for x in m], im1, cam(t1), p1, im2, cam(t2), p2)
+                got = product.apply_adhoc_filters(data, m, im1, cam(t1), p1, im2, cam(t2), p2)
+                assert [tuple(int(v) for v in g) for g in got] == [tuple(int(v) for v in w) for w in want], (static_frac, t1, t2, im1, im2)
+    assert len(product.apply_adhoc_filters(data, np.zeros((0, 2), int), "plain", cam("perspective"), p1, "plain", cam("perspective"), p2)) == 0
+
+
+@pytest.mark.parametrize("guided,filters", [(False, False), (True, False), (False, True), (True, True)])
+def test_match_flow_equals_the_product_host_flow(ref, oracle_lib, monkeypatch, guided, filters):
     """The reference's match_unwrap_args -> match() (matching.py:182-214, 563-634; guided: 260-337) executed from its own file for
     every pair of a mixed collection, against opensfm_amd.matching.match_images_with_pairs with its C-ABI calls redirected to the
     host emulations: same gates, same dispatch, same unfiltered result for every pair."""
@@ -273,6 +299,9 @@ def test_match_flow_equals_the_product_host_flow(ref, oracle_lib, monkeypatch, g
     images, cams, cam_of, feats, masks, poses, config = _collection(oracle_lib, rng, guided)
     exifs = {im: {"camera": cam_of[im]} for im in images}
     pairs = [(a, b) for i, a in enumerate(images) for b in images[i + 1:]]
+    config["matching_use_filters"] = filters  # the ad-hoc filters between the descriptor stage and the gates (matching.py:323-334,399-411)
+    exif_of = {"a": {"make": "BlackVue", "model": "DR900"}, "b": {"make": "Canon", "model": "X"}, "c": {"make": "VTrans_Camera", "model": "VTrans_Camera"},
+               "d": {"make": "blackvue", "model": "x"}}
     # ---- the reference side ----
     feats_masked = {im: types.SimpleNamespace(points=feats[im].points[masks[im]], descriptors=feats[im].descriptors[masks[im]]) for im in images}
     loader = types.SimpleNamespace(
@@ -282,7 +311,7 @@ def test_match_flow_equals_the_product_host_flow(ref, oracle_lib, monkeypatch, g
     monkeypatch.setattr(matching.feature_loader, "instance", loader, raising=False)
     monkeypatch.setattr(matching.log, "setup", lambda: None, raising=False)
     data = types.SimpleNamespace(config=config, load_camera_models=lambda: cams, load_features=lambda im: feats[im],
-                                 load_features_mask=lambda im, pts: masks[im])
+                                 load_features_mask=lambda im, pts: masks[im], load_exif=lambda im: exif_of[im])
     want = {}
     for im1, im2 in pairs:
         _, _, m = matching.match_unwrap_args((im1, im2, cams, exifs, data, {}, poses if guided else None))
