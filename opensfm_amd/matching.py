@@ -706,6 +706,18 @@ def match_images_with_pairs(data, config_override: Dict[str, Any], exifs: Dict[s
     return out
 
 
+def match_images(data, config_override: Dict[str, Any], ref_images: List[str], cand_images: List[str], **preselection_kwargs):
+    """``matching.match_images`` (matching.py:27-60): pair preselection from the metadata (``preselection.match_candidates_from_metadata``,
+    the union of the enabled strategies), then every selected pair in one batch.  Returns ``(matches, preselection_report)``.
+    ``preselection_kwargs``: the histogram dictionaries / callables of the BoW and VLAD strategies (see ``preselection``)."""
+    from . import preselection
+
+    all_images = list(set(ref_images + cand_images))
+    exifs = {im: data.load_exif(im) for im in all_images}
+    pairs, preport = preselection.match_candidates_from_metadata(list(ref_images), list(cand_images), exifs, data, config_override, **preselection_kwargs)
+    return match_images_with_pairs(data, config_override, exifs, pairs), preport
+
+
 # --------------------------------------------------------------------------------------------
 # the match graph on disk (SURVEY.md 8f-1: ``dataset.py:344-392``, ``matching.py:128-157``)
 # --------------------------------------------------------------------------------------------

@@ -119,3 +119,29 @@ def test_product_package_never_touches_the_oracle():
                 if re.search(r"^\s*(import|from)\s+oracle\b|liboracle|oracle/[a-z_]+\.(c|so)\b.*#include|#include\s+\"[^\"]*oracle", text, re.M):
                     offenders.append(os.path.join(dirpath, f))
     assert offenders == []
+
+
+def test_match_images_is_preselection_then_batch(monkeypatch):
+    """matching.match_images (matching.py:27-60): exifs of every image, match_candidates_from_metadata, match_images_with_pairs"""
+    import types
+
+    import numpy as np
+
+    from opensfm_amd import matching, preselection
+
+    calls = {}
+
+    def from_metadata(ref, cand, exifs, data, cfg, **kw):
+        calls["pre"] = (tuple(ref), tuple(cand), sorted(exifs), kw)
+        return [("a", "b")], {"num_pairs_order": 1}
+
+    def with_pairs(data, cfg, exifs, pairs, poses=None):
+        calls["match"] = (list(pairs), sorted(exifs))
+        return {("a", "b"): np.zeros((3, 2), int)}
+
+    monkeypatch.setattr(preselection, "match_candidates_from_metadata", from_metadata)
+    monkeypatch.setattr(matching, "match_images_with_pairs", with_pairs)
+    data = types.SimpleNamespace(load_exif=lambda im: {"camera": im})
+    m, rep = matching.match_images(data, {"matching_order_neighbors": 2}, ["a"], ["a", "b"], bow_histograms={})
+    assert calls["pre"][:3] == (("a",), ("a", "b"), ["a", "b"]) and calls["pre"][3] == {"bow_histograms": {}}
+    assert calls["match"] == ([("a", "b")], ["a", "b"]) and rep == {"num_pairs_order": 1} and list(m) == [("a", "b")]
