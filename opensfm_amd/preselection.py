@@ -103,9 +103,36 @@ def _rotation_from_opk(omega: float, phi: float, kappa: float) -> np.ndarray:
     return flip @ rz(-kappa) @ ry(-phi) @ rx(-omega)
 
 
+def get_gps_point(exif: Dict[str, Any], reference) -> Tuple[np.ndarray, np.ndarray]:
+    """pairs_selection.py:35-46: the GPS position at altitude 0 and a vertical viewing direction"""
+    gps = exif["gps"]
+    return np.array(reference.to_topocentric(gps["latitude"], gps["longitude"], 0)), np.array([0, 0, 1])
+
+
+def get_gps_opk_point(exif: Dict[str, Any], reference) -> Tuple[np.ndarray, np.ndarray]:
+    """pairs_selection.py:58-74: the same position with the camera's viewing axis from omega / phi / kappa, scaled to |z| = DEFAULT_Z"""
+    opk = exif["opk"]
+    z_axis = _rotation_from_opk(math.radians(opk["omega"]), math.radians(opk["phi"]), math.radians(opk["kappa"]))[2]
+    return get_gps_point(exif, reference)[0], z_axis / ((1.0 if z_axis[2] > 0.0 else -1.0) * z_axis[2]) * DEFAULT_Z
+
+
+def find_best_altitude(origin: Dict[str, np.ndarray], directions: Dict[str, np.ndarray]) -> float:
+    """pairs_selection.py:77-105: the altitude in [0, MAXIMUM_Z] that makes the X / Y footprint smallest -- the squared diagonal sampled
+    every SAMPLE_Z, the extremum of the fitted parabola; DEFAULT_Z when it is negative (diverging views)"""
+    o, d = np.array(list(origin.values())), np.array(list(directions.values()))
+    zs = np.arange(1, MAXIMUM_Z, SAMPLE_Z)
+    size = []
+    for z in zs:
+        s = o + d / DEFAULT_Z * z
+        size.append((s[:, 0].max() - s[:, 0].min()) ** 2 + (s[:, 1].max() - s[:, 1].min()) ** 2)
+    c = np.polyfit(zs, size, 2)
+    altitude = -c[1] / (2 * c[0])
+    return DEFAULT_Z if altitude < 0 else altitude
+
+
 def get_representative_points(images: Sequence[str], exifs: Dict[str, Any], reference) -> Dict[str, np.ndarray]:
-    """a topocentric point per image with GPS: its position at altitude 0, pushed along the viewing direction to the altitude that
-    makes the footprint smallest when any image carries an orientation (opk)"""
+    """pairs_selection.py:108-151: a topocentric point per image with GPS: its position at altitude 0, pushed along the viewing direction to
+    the altitude that makes the footprint smallest when any image carries an orientation (opk)"""
     origin: Dict[str, np.ndarray] = {}
     direction: Dict[str, np.ndarray] = {}
     oriented = False
@@ -115,31 +142,18 @@ def get_representative_points(images: Sequence[str], exifs: Dict[str, Any], refe
             continue
         if "ypr" in exif:
             raise RuntimeError(f"GPS / OPK / YPR {(True, 'opk' in exif, True)} tag combination unsupported")
-        origin[image] = np.asarray(reference.to_topocentric(exif["gps"]["latitude"], exif["gps"]["longitude"], 0), float)
         if "opk" in exif:
             oriented = True
-            opk = exif["opk"]
-            z_axis = _rotation_from_opk(math.radians(opk["omega"]), math.radians(opk["phi"]), math.radians(opk["kappa"]))[2]
-            direction[image] = z_axis / ((1.0 if z_axis[2] > 0.0 else -1.0) * z_axis[2]) * DEFAULT_Z
+            origin[image], direction[image] = get_gps_opk_point(exif, reference)
         else:
-            direction[image] = np.array([0.0, 0.0, 1.0])
+            o, d = get_gps_point(exif, reference)
+            origin[image], direction[image] = np.asarray(o, float), np.asarray(d, float)
     if not oriented:
         return origin
-    # find_best_altitude (pairs_selection.py:77-105): parabola through the squared footprint diagonal sampled every 100 m
-    o, d = np.array(list(origin.values())), np.array(list(direction.values()))
-    zs = np.arange(1, MAXIMUM_Z, SAMPLE_Z)
-    size = []
-    for z in zs:
-        s = o + d / DEFAULT_Z * z
-        size.append((s[:, 0].max() - s[:, 0].min()) ** 2 + (s[:, 1].max() - s[:, 1].min()) ** 2)
-    c = np.polyfit(zs, size, 2)
-    altitude = -c[1] / (2 * c[0])
-    if altitude < 0:
-        altitude = DEFAULT_Z
+    altitude = find_best_altitude(origin, direction)
     return {k: origin[k] + direction[k] / DEFAULT_Z * altitude for k in images}
 
 
-# ---- strategies ----
 def match_candidates_by_distance(images_ref: List[str], images_cand: List[str], exifs: Dict[str, Any], reference, max_neighbors: int,
                                  max_distance: float) -> Set[Tuple[str, str]]:
     """pairs_selection.py:154-212.  Faithful to the detail that the point array has one row per distinct image of cand + ref but only

@@ -266,3 +266,36 @@ def test_bow_candidates_equal_the_reference(refps, host_search, monkeypatch):
         assert mine.keys() == theirs.keys() and len(mine) > 0
         assert all(mine[k] == theirs[k] for k in mine)
     assert preselection.match_candidates_with_bow(images[:6], images, exifs, reference, 0, 0, 0, False, {}) == {}
+
+
+def test_the_references_own_known_answer_tests_pass_on_the_product():
+    """opensfm/test/test_pairs_selection.py executed from the reference's file with `pairs_selection` bound to the PRODUCT's module:
+    its four self-contained known-answer tests (GPS point, GPS + OPK point, best altitude for converging / diverging views).  The
+    dataset-driven tests of that file need the lund images and feature extraction, which are outside this repository's path."""
+    saved = {k: sys.modules.get(k) for k in list(sys.modules) if k == "opensfm" or k.startswith("opensfm.")}
+    try:
+        pkg = _Stub("opensfm")
+        pkg.__path__ = [REF]
+        mods = {"opensfm": pkg}
+        for name in ("commands", "dataset", "feature_loader", "geo", "dataset_base", "test", "test.data_generation"):
+            mods["opensfm." + name] = _Stub("opensfm." + name)
+        mods["opensfm.dataset_base"].DataSetBase = object
+        mods["opensfm.geo"].TopocentricConverter = TopocentricConverter
+        mods["opensfm.test"].data_generation = mods["opensfm.test.data_generation"]
+        mods["opensfm.test"].__path__ = [os.path.join(REF, "test")]
+        mods["opensfm.pairs_selection"] = preselection  # the product under the reference's name
+        for name, m in mods.items():
+            sys.modules[name] = m
+            if name.count(".") == 1:
+                setattr(pkg, name.split(".")[1], m)
+        spec = importlib.util.spec_from_file_location("opensfm.test.test_pairs_selection", os.path.join(REF, "test", "test_pairs_selection.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.test_get_gps_point()
+        mod.test_get_gps_opk_point()
+        mod.test_find_best_altitude_convergent()
+        mod.test_find_best_altitude_divergent()
+    finally:
+        for k in [k for k in sys.modules if k == "opensfm" or k.startswith("opensfm.")]:
+            del sys.modules[k]
+        sys.modules.update({k: v for k, v in saved.items() if v is not None})
