@@ -60,14 +60,39 @@ def parse():
     ap.add_argument("--no-float", action="store_true", help="skip the float-descriptor (root-SIFT) workload")
     ap.add_argument("--no-guided", action="store_true", help="skip the guided-matching workload")
     ap.add_argument("--full-parity", action="store_true", help="check EVERY pair with matches + 5000 empties against the oracle (~1.5 min)")
-    return ap.parse_args()
+    ap.add_argument("--headline-only", action="store_true", help="only the headline workload + its cpu_baseline (configs[3] runs)")
+    a = ap.parse_args()
+    if a.headline_only:
+        a.no_ba = a.no_tracks = a.no_overlap = a.no_calibrated = a.no_float = a.no_guided = True
+    return a
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks here (one process per GPU, RCCL rendezvous on 127.0.0.1),
+    exactly as the driver's `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N` does; rank 0 of
+    the children prints the JSON line."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # a run can never be labelled with a GPU count it did not use
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or without a launcher)"
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
@@ -99,9 +124,15 @@ def main():
     robust = not args.no_robust
 
     def step(tm=None):
-        counts, m = matching.match_pairs(store, my_pairs, robust=robust, timings=tm)
-        # rank-major gathered order: no host-side scatter of the match rows inside the timed region
-        return odist.all_gather_match_graph(counts, m, len(pairs_all), rank, world, local_rank, reorder=False)
+        if world == 1:
+            return matching.match_pairs(store, my_pairs, robust=robust, timings=tm)
+        # N ranks: the shard's match rows stay in HBM and the exchange step all-gathers from there (RCCL over xGMI); rank-major
+        # gathered order: no host-side scatter of the match rows inside the timed region
+        g = matching.match_pairs(store, my_pairs, robust=robust, timings=tm, keep_device=True)
+        try:
+            return odist.all_gather_match_graph_device(g, len(pairs_all), rank, world, local_rank, reorder=False)
+        finally:
+            g.close()
 
     def barrier():
         if dist is not None:
@@ -517,24 +548,45 @@ def cpu_baseline(scene, pairs_all, n_sample, graph, full_parity=False):
     import oracle
 
     n_sample = min(n_sample, len(pairs_all))
-    sel = np.linspace(0, len(pairs_all) - 1, n_sample).astype(np.int64)
+    n_img = len(scene.offsets) - 1
+    sample_note = "strided over the same pair list"
+    if n_img <= 2000 or graph is None:
+        sel = np.linspace(0, len(pairs_all) - 1, n_sample).astype(np.int64)
+    else:
+        # large stores (configs[3]: 10 000 images = 10 GB as float32): runs of 64 consecutive pairs at strided anchors, so the
+        # sample touches ~n_sample / 64 * 65 images, of which only those are converted; a quarter of the sample is taken from the
+        # pairs that produced matches (0.2 % of an exhaustive list, a strided sample would hold a handful)
+        hit = np.flatnonzero(graph[0] > 0)
+        n_hit = min(len(hit), n_sample // 4)
+        anchors = np.linspace(0, len(pairs_all) - 65, max(1, (n_sample - n_hit) // 64)).astype(np.int64)
+        runs = (anchors[:, None] + np.arange(64)[None, :]).reshape(-1)
+        sel = np.unique(np.concatenate([runs, hit[np.linspace(0, len(hit) - 1, n_hit).astype(np.int64)] if n_hit else runs[:0]]))
+        n_sample = len(sel)
+        sample_note = f"{len(anchors)} runs of 64 consecutive pairs at strided anchors + {n_hit} pairs with matches, of the same pair list"
     sample = pairs_all[sel]
-    desc = scene.desc.astype(np.float32)
+    # only the images the sample touches, renumbered
+    used, inv = np.unique(sample.reshape(-1), return_inverse=True)
+    sample_c = inv.reshape(-1, 2).astype(np.int32)
+    rows = np.concatenate([np.arange(scene.offsets[i], scene.offsets[i + 1]) for i in used])
+    offs_c = np.concatenate([[0], np.cumsum([scene.offsets[i + 1] - scene.offsets[i] for i in used])]).astype(np.int64)
+    desc = scene.desc[rows].astype(np.float32)
+    pts_c = scene.pts[rows]
     t0 = time.perf_counter()
-    res = oracle.match_pairs(desc, scene.pts, scene.offsets, sample)
+    res = oracle.match_pairs(desc, pts_c, offs_c, sample_c)
     dt = time.perf_counter() - t0
     ok = None
     if graph is not None:
         counts, matches = graph
-        off = np.concatenate([[0], np.cumsum(counts)])
+        off = np.concatenate([[0], np.cumsum(counts, dtype=np.int64)])
         ok = all(np.array_equal(matches[off[p]: off[p + 1]], r) for p, r in zip(sel, res))
     out = {
         "value": round(n_sample / dt, 3),
         "unit": "pairs/s",
         "cores": oracle.num_threads(),
         "kind": "port",
-        "sample": f"{n_sample} pairs strided over the same pair list, {dt:.1f} s, OpenMP over pairs",
+        "sample": f"{n_sample} pairs {sample_note}, {dt:.1f} s, OpenMP over pairs",
         "parity_on_sample": ok,
+        "sample_pairs_with_matches": int(sum(len(r) > 0 for r in res)),
     }
     if full_parity and graph is not None:
         counts, matches = graph
@@ -545,6 +597,7 @@ def cpu_baseline(scene, pairs_all, n_sample, graph, full_parity=False):
         chk = np.concatenate([hit, empty])
         t0 = time.perf_counter()
         bad = 0
+        desc = scene.desc.astype(np.float32)
         for lo in range(0, len(chk), 2048):
             part = chk[lo: lo + 2048]
             res = oracle.match_pairs(desc, scene.pts, scene.offsets, pairs_all[part])

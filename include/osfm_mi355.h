@@ -81,6 +81,10 @@ typedef struct {
                                       first (match_flann(index1, f2)) and lists the matches in query order.  The
                                       reference's own index (cv2.flann_Index, KMEANS, checks=20, features.py:638-674) is
                                       approximate and randomised; this is its exact limit (checks -> infinity). */
+#define OSFM_MATCH_KEEP_DEVICE 4   /* the result keeps its match rows in HBM (osfm_result_dev_ptrs) instead of copying them to the
+                                      host chunk by chunk: the exchange step of the multi-GPU path (all-gather of the match graph,
+                                      the fan-in of matching.py:83-98 across ranks) reads them from there.  osfm_result_fetch still
+                                      works (one D2H copy on demand).                                                           */
 
 void osfm_match_params_default(osfm_match_params *p);
 
@@ -111,6 +115,11 @@ int64_t osfm_result_num_pairs(const osfm_match_result *r);
 int64_t osfm_result_total_matches(const osfm_match_result *r);
 /* counts[n_pairs]; matches[total x 2] concatenated in pair order, each pair sorted by (i, j). */
 int osfm_result_fetch(const osfm_match_result *r, int32_t *counts, int32_t *matches);
+/* Results of a call made with OSFM_MATCH_KEEP_DEVICE: device pointers (on osfm_result_device) to counts[n_pairs] and to the
+ * concatenated matches[total x 2], valid until osfm_result_destroy; every kernel that wrote them has completed when the matching
+ * call returns.  OSFM_E_INVALID for a result that was not kept on the device. */
+int osfm_result_dev_ptrs(const osfm_match_result *r, const int32_t **d_counts, const int32_t **d_matches);
+int osfm_result_device(const osfm_match_result *r);
 void osfm_result_destroy(osfm_match_result *r);
 
 /*

@@ -106,6 +106,8 @@ SIGNATURES = {
     "osfm_result_num_pairs": (C.c_int64, [C.c_void_p]),
     "osfm_result_total_matches": (C.c_int64, [C.c_void_p]),
     "osfm_result_fetch": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "osfm_result_dev_ptrs": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "osfm_result_device": (C.c_int, [C.c_void_p]),
     "osfm_result_destroy": (None, [C.c_void_p]),
     "osfm_match_l2_ratio": (
         C.c_int,
@@ -193,6 +195,7 @@ _tls = threading.local()
 MAX_FEATURES = 16000     # OSFM_MAX_FEATURES
 MATCH_EXACT_KERNEL = 1   # OSFM_MATCH_EXACT_KERNEL
 MATCH_SQUARED_RATIO = 2  # OSFM_MATCH_SQUARED_RATIO
+MATCH_KEEP_DEVICE = 4    # OSFM_MATCH_KEEP_DEVICE
 
 
 class Context:

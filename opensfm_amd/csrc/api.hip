@@ -247,10 +247,11 @@ extern "C" void osfm_match_params_default(osfm_match_params *p) {
 
 namespace {
 __global__ void gather_matches_kernel(const int32_t *counts, const int64_t *offsets, const uint32_t *matches, int cap,
-                                      int32_t *out, long n_pairs) {
+                                      int32_t *out, long n_pairs, int32_t *counts_out) {
   const long p = blockIdx.x;
   if (p >= n_pairs) return;
   const int n = min(counts[p], cap);
+  if (counts_out && threadIdx.x == 0) counts_out[p] = n;
   const int64_t o = offsets[p];
   for (int k = threadIdx.x; k < n; k += blockDim.x) {
     const uint32_t m = matches[p * cap + k];
@@ -354,7 +355,19 @@ static int match_pairs_impl(osfm_ctx *ctx, const osfm_store *store, const int32_
     ~Guard() { delete r; }
   } guard{res};
   res->counts.assign((size_t)n_pairs, 0);
-  (void)res->matches.reserve(ctx->match_hint + ctx->match_hint / 8);  // what the previous call on this context produced
+  const bool keep_dev = (params->flags & OSFM_MATCH_KEEP_DEVICE) != 0;
+  if (keep_dev) {  // the match rows stay in HBM: one growing device buffer instead of the host vector
+    res->on_device = true;
+    res->device = ctx->device;
+    res->d_cap = (ctx->match_hint + ctx->match_hint / 8) / 2 + 1024;  // rows; what the previous call on this context produced
+    OSFM_REQUIRE(hipMalloc((void **)&res->d_counts, (size_t)(n_pairs > 0 ? n_pairs : 1) * sizeof(int32_t)) == hipSuccess &&
+                     hipMalloc((void **)&res->d_matches, res->d_cap * 2 * sizeof(int32_t)) == hipSuccess,
+                 OSFM_E_NOMEM, "hipMalloc failed for the device-resident result of %lld pairs", (long long)n_pairs);
+    OSFM_HIP(hipMemsetAsync(res->d_counts, 0, (size_t)(n_pairs > 0 ? n_pairs : 1) * sizeof(int32_t), stA));
+    OSFM_HIP(hipStreamSynchronize(stA));
+  } else {
+    (void)res->matches.reserve(ctx->match_hint + ctx->match_hint / 8);  // what the previous call on this context produced
+  }
   std::vector<int32_t> hflags((size_t)cp);
   std::vector<int64_t> hoff((size_t)cp);
   double ms_match = 0.0, ms_ransac = 0.0;
@@ -431,6 +444,31 @@ static int match_pairs_impl(osfm_ctx *ctx, const osfm_store *store, const int32_
       total += cnt;
       if (tm) tm->pairs_exact_path += hflags[(size_t)q] != 0;
     }
+    if (keep_dev) {
+      const size_t base = res->d_total;
+      if (base + (size_t)total > res->d_cap) {  // grow: D2D copy of what is there (stream B is idle, the host waited on it above)
+        const size_t ncap = (base + (size_t)total) + (base + (size_t)total) / 2;
+        int32_t *nb = nullptr;
+        OSFM_REQUIRE(hipMalloc((void **)&nb, ncap * 2 * sizeof(int32_t)) == hipSuccess, OSFM_E_NOMEM, "hipMalloc failed for %lld device-resident matches",
+                     (long long)ncap);
+        hipError_t ce = base ? hipMemcpyAsync(nb, res->d_matches, base * 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, stB) : hipSuccess;
+        if (ce == hipSuccess) ce = hipStreamSynchronize(stB);
+        if (ce != hipSuccess) {
+          (void)hipFree(nb);
+          osfm_set_error("growing the device-resident result: %s", hipGetErrorString(ce));
+          return OSFM_E_HIP;
+        }
+        (void)hipFree(res->d_matches);
+        res->d_matches = nb;
+        res->d_cap = ncap;
+      }
+      OSFM_HIP(hipMemcpyAsync(S.offsets.p, hoff.data(), (size_t)np * sizeof(int64_t), hipMemcpyHostToDevice, stB));
+      hipLaunchKernelGGL(gather_matches_kernel, dim3((unsigned)np), dim3(64), 0, stB, S.counts.as<int32_t>(), S.offsets.as<int64_t>(),
+                         S.matches.as<uint32_t>(), cap, res->d_matches + 2 * base, (long)np, res->d_counts + p0);
+      OSFM_HIP(hipGetLastError());
+      OSFM_HIP(hipStreamSynchronize(stB));  // the chunk's buffer set is handed back to the matcher
+      res->d_total = base + (size_t)total;
+    } else {
     const size_t base = res->matches.size();
     OSFM_REQUIRE(res->matches.resize(base + (size_t)total * 2), OSFM_E_NOMEM, "out of host memory for %lld matches", (long long)total);
     if (total > 0) {
@@ -443,10 +481,11 @@ static int match_pairs_impl(osfm_ctx *ctx, const osfm_store *store, const int32_
       }
       OSFM_HIP(hipMemcpyAsync(S.offsets.p, hoff.data(), (size_t)np * sizeof(int64_t), hipMemcpyHostToDevice, stB));
       hipLaunchKernelGGL(gather_matches_kernel, dim3((unsigned)np), dim3(64), 0, stB, S.counts.as<int32_t>(),
-                         S.offsets.as<int64_t>(), S.matches.as<uint32_t>(), cap, S.gather.as<int32_t>(), (long)np);
+                         S.offsets.as<int64_t>(), S.matches.as<uint32_t>(), cap, S.gather.as<int32_t>(), (long)np, (int32_t *)nullptr);
       OSFM_HIP(hipGetLastError());
       OSFM_HIP(hipMemcpyAsync(res->matches.data() + base, S.gather.p, (size_t)total * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, stB));
       OSFM_HIP(hipStreamSynchronize(stB));
+    }
     }
     if (tm) {
       float ms = 0.f;
@@ -470,7 +509,7 @@ static int match_pairs_impl(osfm_ctx *ctx, const osfm_store *store, const int32_
     OSFM_HIP(hipMemcpy(&work, d_work.p, 8, hipMemcpyDeviceToHost));
     tm->ransac_model_points = (int64_t)work;
   }
-  ctx->match_hint = res->matches.size();
+  ctx->match_hint = keep_dev ? res->d_total * 2 : res->matches.size();
   guard.r = nullptr;
   *out = res;
   return OSFM_OK;
@@ -532,13 +571,30 @@ extern "C" int osfm_match_pairs_guided(osfm_ctx *ctx, const osfm_store *store, c
 }
 
 extern "C" int64_t osfm_result_num_pairs(const osfm_match_result *r) { return r ? (int64_t)r->counts.size() : 0; }
-extern "C" int64_t osfm_result_total_matches(const osfm_match_result *r) { return r ? (int64_t)(r->matches.size() / 2) : 0; }
+extern "C" int64_t osfm_result_total_matches(const osfm_match_result *r) {
+  return r ? (int64_t)(r->on_device ? r->d_total : r->matches.size() / 2) : 0;
+}
 extern "C" int osfm_result_fetch(const osfm_match_result *r, int32_t *counts, int32_t *matches) {
   OSFM_REQUIRE(r != nullptr, OSFM_E_INVALID, "osfm_result_fetch: null result");
   if (counts && !r->counts.empty()) memcpy(counts, r->counts.data(), r->counts.size() * sizeof(int32_t));
+  if (r->on_device) {  // kept in HBM (OSFM_MATCH_KEEP_DEVICE): one D2H copy on demand
+    if (matches && r->d_total > 0) {
+      OSFM_HIP(hipSetDevice(r->device));
+      OSFM_HIP(hipMemcpy(matches, r->d_matches, r->d_total * 2 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
+    return OSFM_OK;
+  }
   if (matches && !r->matches.empty()) memcpy(matches, r->matches.data(), r->matches.size() * sizeof(int32_t));
   return OSFM_OK;
 }
+extern "C" int osfm_result_dev_ptrs(const osfm_match_result *r, const int32_t **d_counts, const int32_t **d_matches) {
+  OSFM_REQUIRE(r && d_counts && d_matches, OSFM_E_INVALID, "osfm_result_dev_ptrs: null argument");
+  OSFM_REQUIRE(r->on_device, OSFM_E_INVALID, "osfm_result_dev_ptrs: the result was not made with OSFM_MATCH_KEEP_DEVICE");
+  *d_counts = r->d_counts;
+  *d_matches = r->d_matches;
+  return OSFM_OK;
+}
+extern "C" int osfm_result_device(const osfm_match_result *r) { return r ? r->device : -1; }
 extern "C" void osfm_result_destroy(osfm_match_result *r) { delete r; }
 
 // Leaf: one pair from host buffers (matching.py:723-777).

@@ -105,6 +105,18 @@ struct OsfmRawVec {
 struct osfm_match_result {
   std::vector<int32_t> counts;
   OsfmRawVec<int32_t> matches;  // total x 2
+  // OSFM_MATCH_KEEP_DEVICE: the match rows stay in HBM (the exchange step of the multi-GPU path all-gathers from there) and only
+  // reach the host when osfm_result_fetch asks for them; the counts are in both places.
+  bool on_device = false;
+  int device = 0;
+  int32_t *d_counts = nullptr;   // n_pairs
+  int32_t *d_matches = nullptr;  // d_total x 2 used, d_cap x 2 allocated
+  size_t d_total = 0, d_cap = 0;
+  ~osfm_match_result() {
+    if (d_counts || d_matches) (void)hipSetDevice(device);
+    if (d_counts) (void)hipFree(d_counts);
+    if (d_matches) (void)hipFree(d_matches);
+  }
 };
 
 #define OSFM_CTX_LOCK(ctx) std::lock_guard<std::recursive_mutex> osfm_ctx_lock_((ctx)->mu)

@@ -82,6 +82,66 @@ def _all_gather_padded(local: np.ndarray, maxlen: int, world: int, dev, on_gpu: 
     return np.stack([t.numpy() for t in parts])
 
 
+def _assemble(allc: np.ndarray, allm: np.ndarray, idx, totals, n_pairs: int, world: int, reorder: bool):
+    """(world, maxn) counts + (world, 2 maxm) match rows -> the global graph, rank-major or in the original pair order"""
+    if not reorder:
+        counts_g = np.concatenate([allc[r][: len(idx[r])] for r in range(world)])
+        matches_g = np.concatenate([allm[r][: 2 * totals[r]] for r in range(world)]).reshape(-1, 2)
+        return counts_g, matches_g
+    counts_g = np.zeros(n_pairs, np.int32)
+    for r in range(world):
+        counts_g[idx[r]] = allc[r][: len(idx[r])]
+    goff = np.concatenate([[0], np.cumsum(counts_g, dtype=np.int64)])
+    matches_g = np.zeros((int(goff[-1]), 2), np.int32)
+    for r in range(world):
+        cr = allc[r][: len(idx[r])].astype(np.int64)
+        tot = int(cr.sum())
+        if tot == 0:
+            continue
+        roff = np.concatenate([[0], np.cumsum(cr)])[:-1]
+        dest = np.repeat(goff[idx[r]] - roff, cr) + np.arange(tot)
+        matches_g[dest] = allm[r][: 2 * tot].reshape(-1, 2)
+    return counts_g, matches_g
+
+
+def all_gather_match_graph_device(graph, n_pairs: int, rank: int, world: int, local_rank: Optional[int] = None, block: int = BLOCK,
+                                  reorder: bool = True, force_collective: bool = False) -> Tuple[np.ndarray, np.ndarray]:
+    """The exchange step straight from HBM: ``graph`` is the ``DeviceMatchGraph`` of this rank's shard
+    (``matching.match_pairs(..., keep_device=True)``).  The counts and the match rows are all-gathered (RCCL,
+    ``all_gather_into_tensor``) from the buffers the kernels wrote -- no D2H / H2D hop of the shard -- and the gathered graph comes
+    to the host once, into page-locked memory.  Same return value as ``all_gather_match_graph``.  RCCL only (the gloo tests go
+    through the host variant)."""
+    if world == 1 and not force_collective:
+        return graph.fetch()
+    import torch
+    import torch.distributed as dist
+
+    dev = torch.device("cuda", local_rank if local_rank is not None else rank)
+    idx = _all_shards(n_pairs, world, block) if world > 1 else [np.arange(n_pairs, dtype=np.int64)]
+    maxn = max(1, max(len(i) for i in idx))
+    assert graph.n_pairs == len(idx[rank]), (graph.n_pairs, len(idx[rank]))
+    # counts: shards differ by at most one block, so the send buffer is the device counts padded with zeros
+    send = torch.zeros(maxn, dtype=torch.int32, device=dev)
+    send[: graph.n_pairs].copy_(graph.counts_tensor())
+    recv = torch.empty(world * maxn, dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(recv, send)
+    allc = _pinned("counts_out", world * maxn, torch.int32)
+    allc.copy_(recv, non_blocking=True)
+    torch.cuda.current_stream(dev).synchronize()
+    allc = allc.numpy().reshape(world, maxn).copy()
+    totals = [int(allc[r][: len(idx[r])].sum()) for r in range(world)]
+    assert totals[rank] == graph.total, (totals[rank], graph.total)
+    maxm = max(1, max(totals))
+    sendm = torch.empty(2 * maxm, dtype=torch.int32, device=dev)
+    sendm[: 2 * graph.total].copy_(graph.matches_tensor())  # D2D; the tail is never read
+    recvm = torch.empty(world * 2 * maxm, dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(recvm, sendm)
+    allm = _pinned("matches_out", world * 2 * maxm, torch.int32)
+    allm.copy_(recvm, non_blocking=True)
+    torch.cuda.current_stream(dev).synchronize()
+    return _assemble(allc, allm.numpy().reshape(world, 2 * maxm), idx, totals, n_pairs, world, reorder)
+
+
 def all_gather_match_graph(counts: np.ndarray, matches: np.ndarray, n_pairs: int, rank: int, world: int,
                            local_rank: Optional[int] = None, block: int = BLOCK, reorder: bool = True,
                            force_collective: bool = False) -> Tuple[np.ndarray, np.ndarray]:
@@ -103,21 +163,4 @@ def all_gather_match_graph(counts: np.ndarray, matches: np.ndarray, n_pairs: int
     totals = [int(allc[r][: len(idx[r])].sum()) for r in range(world)]
     maxm = max(1, max(totals))
     allm = _all_gather_padded(matches, 2 * maxm, world, dev, on_gpu, "matches")
-    if not reorder:
-        counts_g = np.concatenate([allc[r][: len(idx[r])] for r in range(world)])
-        matches_g = np.concatenate([allm[r][: 2 * totals[r]] for r in range(world)]).reshape(-1, 2)
-        return counts_g, matches_g
-    counts_g = np.zeros(n_pairs, np.int32)
-    for r in range(world):
-        counts_g[idx[r]] = allc[r][: len(idx[r])]
-    goff = np.concatenate([[0], np.cumsum(counts_g, dtype=np.int64)])
-    matches_g = np.zeros((int(goff[-1]), 2), np.int32)
-    for r in range(world):
-        cr = allc[r][: len(idx[r])].astype(np.int64)
-        tot = int(cr.sum())
-        if tot == 0:
-            continue
-        roff = np.concatenate([[0], np.cumsum(cr)])[:-1]
-        dest = np.repeat(goff[idx[r]] - roff, cr) + np.arange(tot)
-        matches_g[dest] = allm[r][: 2 * tot].reshape(-1, 2)
-    return counts_g, matches_g
+    return _assemble(allc, allm, idx, totals, n_pairs, world, reorder)

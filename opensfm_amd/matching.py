@@ -413,20 +413,78 @@ def make_params(config: Optional[Dict[str, Any]] = None, robust: bool = True) ->
     return p
 
 
+class DeviceMatchGraph:
+    """Result of ``match_pairs(..., keep_device=True)``: the per-pair counts on the host AND in HBM, the concatenated match rows in
+    HBM only (``OSFM_MATCH_KEEP_DEVICE``).  The multi-GPU exchange step (``dist.all_gather_match_graph_device``) all-gathers from
+    these buffers; ``fetch()`` brings the rows to the host with one copy.  Owns the C result until ``close()``."""
+
+    def __init__(self, lib, handle):
+        self._lib, self.handle = lib, handle
+        self.n_pairs = int(lib.osfm_result_num_pairs(handle))
+        self.total = int(lib.osfm_result_total_matches(handle))
+        self.device = int(lib.osfm_result_device(handle))
+        self.counts = np.empty(max(self.n_pairs, 1), np.int32)
+        check(lib.osfm_result_fetch(handle, _fptr(self.counts, C.c_int32), None), "osfm_result_fetch")
+        self.counts = self.counts[: self.n_pairs]
+        dc, dm = C.c_void_p(), C.c_void_p()
+        check(lib.osfm_result_dev_ptrs(handle, C.byref(dc), C.byref(dm)), "osfm_result_dev_ptrs")
+        self.d_counts, self.d_matches = int(dc.value or 0), int(dm.value or 0)
+
+    def _tensor(self, ptr: int, n: int):
+        """a torch view (no copy) of n int32 at a device address, through __cuda_array_interface__"""
+        import torch
+
+        class _Buf:
+            pass
+
+        b = _Buf()
+        b.__cuda_array_interface__ = {"shape": (max(n, 1),), "typestr": "<i4", "data": (ptr, False), "version": 2}
+        b._keepalive = self
+        return torch.as_tensor(b, device=torch.device("cuda", self.device))[:n]
+
+    def counts_tensor(self):
+        return self._tensor(self.d_counts, self.n_pairs)
+
+    def matches_tensor(self):
+        """flat int32 tensor of 2 * total entries (row k = entries 2k, 2k + 1)"""
+        return self._tensor(self.d_matches, 2 * self.total)
+
+    def fetch(self) -> Tuple[np.ndarray, np.ndarray]:
+        matches = np.empty((max(self.total, 1), 2), np.int32)
+        check(self._lib.osfm_result_fetch(self.handle, None, _fptr(matches, C.c_int32)), "osfm_result_fetch")
+        return self.counts, matches[: self.total]
+
+    def close(self) -> None:
+        if self.handle:
+            self._lib.osfm_result_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def match_pairs(store: DescriptorStore, pairs: np.ndarray, config: Optional[Dict[str, Any]] = None,
-                robust: bool = True, timings: Optional[MatchTimings] = None) -> Tuple[np.ndarray, np.ndarray]:
+                robust: bool = True, timings: Optional[MatchTimings] = None, keep_device: bool = False):
     """Run ``matching.match`` (``matching.py:563-634``) for every pair, on the GPU.
 
     Returns ``(counts, matches)``: ``counts[p]`` matches for pair ``p`` (0 where the reference returns
-    ``[]``), ``matches`` the concatenated ``(K, 2)`` int32 arrays in pair order.
+    ``[]``), ``matches`` the concatenated ``(K, 2)`` int32 arrays in pair order.  ``keep_device``: a ``DeviceMatchGraph``
+    instead (the match rows stay in HBM for the multi-GPU exchange step).
     """
     lib = _lib.load()
     pairs = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
     prm = make_params(config, robust)
+    if keep_device:
+        prm.flags |= _lib.MATCH_KEEP_DEVICE
     res = C.c_void_p()
     tm = timings if timings is not None else MatchTimings()
     check(lib.osfm_match_pairs(store.ctx.handle, store.handle, _fptr(pairs, C.c_int32), len(pairs), C.byref(prm),
                                C.byref(res), C.byref(tm)), "osfm_match_pairs")
+    if keep_device:
+        return DeviceMatchGraph(lib, res)
     return _fetch_result(lib, res)
 
 

@@ -145,3 +145,36 @@ def test_match_images_is_preselection_then_batch(monkeypatch):
     m, rep = matching.match_images(data, {"matching_order_neighbors": 2}, ["a"], ["a", "b"], bow_histograms={})
     assert calls["pre"][:3] == (("a",), ("a", "b"), ["a", "b"]) and calls["pre"][3] == {"bow_histograms": {}}
     assert calls["match"] == ([("a", "b")], ["a", "b"]) and rep == {"num_pairs_order": 1} and list(m) == [("a", "b")]
+
+
+def test_bench_gpus_flag_launches_ranks_and_never_mislabels(monkeypatch):
+    """bench.py --gpus N: without a launcher it re-executes itself under torch.distributed.run with N ranks; under a launcher whose
+    WORLD_SIZE differs from --gpus it refuses to print a line (`--gpus 8` used to be a silent 1-GPU run)"""
+    import importlib
+    import os
+    import subprocess
+    import sys
+    import types
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    assert bench.self_launch(types.SimpleNamespace(gpus=4)) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "2"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # a launcher that started 2 ranks for --gpus 4: assertion before anything is measured
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    import pytest
+
+    with pytest.raises(AssertionError, match="--gpus 4 but WORLD_SIZE=2"):
+        bench.main()
