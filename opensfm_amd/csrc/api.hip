@@ -46,6 +46,7 @@ extern "C" void osfm_ctx_destroy(osfm_ctx *c) {
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->d_rng_table) (void)hipFree(c->d_rng_table);
+  if (c->d_fr_scratch) (void)hipFree(c->d_fr_scratch);
   delete c;
 }
 

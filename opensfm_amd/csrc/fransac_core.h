@@ -18,7 +18,7 @@
 #include <stdint.h>
 
 #if defined(__HIPCC__)
-#define FR_FN __host__ __device__ __forceinline__
+#define FR_FN __host__ __device__ inline
 #define FR_CONST __constant__
 #else
 #define FR_FN inline
@@ -168,10 +168,12 @@ FR_FN int cv_null_basis(const double *v1, const double *v2, double *f1, double *
 // three distinct real roots in cv::solveCubic's output order: smallest, largest, middle
 FR_FN void cv_root_order3(double *r) {
   double lo = r[0], hi = r[0], mid = r[0];
+#pragma unroll
   for (int k = 1; k < 3; k++) {
     if (r[k] < lo) lo = r[k];
     if (r[k] > hi) hi = r[k];
   }
+#pragma unroll
   for (int k = 0; k < 3; k++)
     if (r[k] != lo && r[k] != hi) mid = r[k];
   r[0] = lo;
@@ -292,7 +294,9 @@ FR_FN int run_7point(const double *m1, const double *m2, double *F, double *priv
     roots[nr++] = -a0 / a1;
   }
   int n = 0;
-  for (int k = 0; k < nr; k++) {
+#pragma unroll
+  for (int k = 0; k < 3; k++) {  // unrolled: roots[] is indexed statically and stays in registers
+    if (k >= nr) break;
     double lambda = roots[k], mu = 1.0;
     const double s = U[8] * lambda + W[8];
     double *Fk = F + 9 * n;
@@ -366,9 +370,13 @@ struct DrawBuf {
   unsigned char slot[LMAX];        // accepted attempt -> iteration slot of this round (0xFF: none)
   unsigned short tmp[LMAX][8];     // the 7 indices of every attempt
   int nraw, nchain;
+};
+// what a round of draws hands on (kept apart from DrawBuf, whose storage the 7-point systems reuse afterwards)
+struct DrawOut {
   int nsub;                      // iterations (accepted subsets) this round produced
   int fail;                      // 1: the iteration after those exhausted getSubset's 10000 attempts (it returned false)
   int rej_run;                   // in / out: rejected attempts of the pending getSubset call so far
+  int done;                      // set by the replay: the RANSAC loop has ended
   unsigned long long state_out;  // RNG state after the last value an attempt of this round consumed
 };
 
@@ -443,8 +451,8 @@ FR_FN void draw_check(DrawBuf<RAW, LMAX> &B, int e, const PTS &pts) {
 }
 // phase 6 (one lane): iteration slots in stream order, the 10000-attempt rule, the state the next round continues from
 template <int RAW, int LMAX>
-FR_FN void draw_slots(DrawBuf<RAW, LMAX> &B, unsigned long long state_in) {
-  int run = B.rej_run, nsub = 0, fail = 0, last = -1;
+FR_FN void draw_slots(DrawBuf<RAW, LMAX> &B, DrawOut &O, unsigned long long state_in) {
+  int run = O.rej_run, nsub = 0, fail = 0, last = -1;
   for (int e = 0; e < B.nchain && !fail; ++e) {
     last = e;
     if (B.acc[e]) {
@@ -456,10 +464,10 @@ FR_FN void draw_slots(DrawBuf<RAW, LMAX> &B, unsigned long long state_in) {
     }
   }
   for (int e = last + 1; e < B.nchain; ++e) B.slot[e] = 0xFF;
-  B.nsub = nsub;
-  B.fail = fail;
-  B.rej_run = run;
-  B.state_out = last >= 0 ? B.states[B.chain[last] + B.clen[B.chain[last]] - 1] : state_in;
+  O.nsub = nsub;
+  O.fail = fail;
+  O.rej_run = run;
+  O.state_out = last >= 0 ? B.states[B.chain[last] + B.clen[B.chain[last]] - 1] : state_in;
 }
 // phase 7 (lane e < nchain): accepted attempts into their iteration slots; subset: [LMAX][8]
 template <int RAW, int LMAX>
@@ -472,8 +480,8 @@ FR_FN void draw_emit(const DrawBuf<RAW, LMAX> &B, int e, unsigned short (*subset
 }
 // The stream position the table could not resolve (a subset that needs more values than the buffer holds: n close to 7 and a long
 // run of duplicates): ONE getSubset attempt drawn the plain sequential way by one lane.  Practically never taken.
-template <int RAW, int LMAX, class PTS>
-FR_FN void draw_one_sequential(DrawBuf<RAW, LMAX> &B, unsigned long long state, int n, const PTS &pts, unsigned short (*subset)[8]) {
+template <class PTS>
+FR_FN void draw_one_sequential(DrawOut &B, unsigned long long state, int n, const PTS &pts, unsigned short (*subset)[8]) {
   CvRng rng{state};
   unsigned short idx[7];
 #pragma unroll
@@ -568,6 +576,53 @@ FR_FN bool replay_round(PairState &s, int n, double conf, int nsub, int fail, co
   if (!done && fail) done = true;  // iter < niters and getSubset found nothing
   s.iters = iter;
   return done;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// One round for one pair: draw up to lmax subsets, solve them, score the models, apply the sequential decisions.
+// EX supplies the parallelism: one(f) runs f on one lane, par(n, f) runs f(i) for i < n across the lanes, both followed by a barrier;
+// score(...) counts the inliers of every model.  On the GPU EX is a wavefront (first kernel) or a 256-thread workgroup (long runs);
+// the host emulation uses loops.  st, D, O, subset, models, nmodels, good, priv, ipriv live in memory all lanes share (LDS).
+// D may alias priv: the draws are finished (and handed on through O and subset) before the first 7-point system is written.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int RAW, int LMAX, int STRIDE, class EX, class PTS>
+FR_FN bool fransac_round(EX &ex, PairState &st, DrawBuf<RAW, LMAX> &D, DrawOut &O, unsigned short (*subset)[8], double (*models)[27],
+                         unsigned char *nmodels, int (*good)[3], double *priv, int *ipriv, const PTS &pts, int n, float t, double conf,
+                         int lmax, int raw_cap = RAW) {
+  ex.one([&]() {
+    O.rej_run = st.rej_run;
+    draw_gen(D, st.rng, draw_raw_count(lmax, n, raw_cap < RAW ? raw_cap : RAW));
+  });
+  ex.par(D.nraw, [&](int s) { draw_mod(D, s, n); });
+  ex.par(D.nraw, [&](int s) { draw_len(D, s); });
+  ex.one([&]() { draw_chain(D, lmax); });
+  if (D.nchain == 0) {
+    ex.one([&]() { draw_one_sequential(O, st.rng, n, pts, subset); });
+  } else {
+    ex.par(D.nchain, [&](int e) { draw_check(D, e, pts); });
+    ex.one([&]() { draw_slots(D, O, st.rng); });
+    ex.par(D.nchain, [&](int e) { draw_emit(D, e, subset); });
+  }
+  ex.one([&]() {
+    st.rng = O.state_out;
+    st.rej_run = O.rej_run;
+  });
+  ex.par(O.nsub, [&](int b) {
+    double ms1[14], ms2[14];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const Pt4 q = pts(subset[b][i]);
+      ms1[2 * i] = (double)q.x;
+      ms1[2 * i + 1] = (double)q.y;
+      ms2[2 * i] = (double)q.z;
+      ms2[2 * i + 1] = (double)q.w;
+    }
+    nmodels[b] = (unsigned char)run_7point<STRIDE>(ms1, ms2, models[b], priv + b, ipriv + b);
+  });
+  ex.score(O.nsub, models, nmodels, pts, n, t, good);
+  ex.one([&]() { O.done = replay_round(st, n, conf, O.nsub, O.fail, models, nmodels, good) ? 1 : 0; });
+  return O.done != 0;
 }
 
 }  // namespace fransac

@@ -40,6 +40,8 @@ struct osfm_ctx {
   hipStream_t stream = nullptr;
   hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   void *d_rng_table = nullptr;  // relpose.hip: the tabulated std::mt19937(42) stream, made on first use
+  void *d_fr_scratch = nullptr;  // ransac.hip: per-pair states + the list the first kernel hands to the long-run kernel
+  size_t fr_scratch_bytes = 0;
   size_t match_hint = 0;        // int32 entries of the last batched call's match list: the next call reserves that much up front
 };
 

@@ -68,3 +68,25 @@ def test_full_pipeline_equals_oracle(oracle_lib, gpu_ctx):
     for g, w in zip(got, want):
         assert np.array_equal(g, w)
     assert sum(len(w) > 0 for w in want) >= 10 and sum(len(w) == 0 for w in want) >= 1
+
+
+@pytest.mark.parametrize("n_images,n_features,px_noise,seed", [(10, 1500, 0.003, 9), (6, 4000, 1.0 / 2000.0, 3), (8, 2500, 0.002, 4)])
+def test_pipeline_long_runs_and_large_pairs(oracle_lib, gpu_ctx, n_images, n_features, px_noise, seed):
+    """Pairs the first kernel cannot finish: keypoint noise of the order of the threshold (low inlier ratio: hundreds of iterations
+    in the long-run kernel), more than 512 correspondences (handed over from the start) and more than 1024 (read through from HBM)."""
+    from opensfm_amd import matching
+
+    sc = synthetic.make_matching_scene(n_images, n_features, seed=seed, px_noise=px_noise, distractor_frac=0.1)
+    pairs = synthetic.all_pairs(n_images)
+    store = matching.DescriptorStore.from_packed(sc.desc, sc.pts, sc.offsets)
+    c0, _ = matching.match_pairs(store, pairs, robust=False)
+    counts, m = matching.match_pairs(store, pairs)
+    want = oracle_lib.match_pairs(sc.desc.astype(np.float32), sc.pts, sc.offsets, pairs, stage=1)
+    got = matching.split_matches(counts, m)
+    assert [len(g) for g in got] == [len(w) for w in want]
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    assert (c0 >= 20).sum() >= 5
+    if n_features >= 4000:
+        assert c0.max() > 1024
+    store.close()
