@@ -580,16 +580,15 @@ FR_FN bool replay_round(PairState &s, int n, double conf, int nsub, int fail, co
 
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// One round for one pair: draw up to lmax subsets, solve them, score the models, apply the sequential decisions.
+// One round for one pair in three stages: draw up to lmax subsets; solve them; score the models and apply the sequential decisions.
 // EX supplies the parallelism: one(f) runs f on one lane, par(n, f) runs f(i) for i < n across the lanes, both followed by a barrier;
-// score(...) counts the inliers of every model.  On the GPU EX is a wavefront (first kernel) or a 256-thread workgroup (long runs);
-// the host emulation uses loops.  st, D, O, subset, models, nmodels, good, priv, ipriv live in memory all lanes share (LDS).
+// score(...) counts the inliers of every model.  On the GPU EX is a wavefront or a 256-thread workgroup; the host emulation uses
+// loops.  st, D, O, subset, models, nmodels, good, priv, ipriv live in memory all lanes share (LDS).
 // D may alias priv: the draws are finished (and handed on through O and subset) before the first 7-point system is written.
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <int RAW, int LMAX, int STRIDE, class EX, class PTS>
-FR_FN bool fransac_round(EX &ex, PairState &st, DrawBuf<RAW, LMAX> &D, DrawOut &O, unsigned short (*subset)[8], double (*models)[27],
-                         unsigned char *nmodels, int (*good)[3], double *priv, int *ipriv, const PTS &pts, int n, float t, double conf,
-                         int lmax, int raw_cap = RAW) {
+template <int RAW, int LMAX, class EX, class PTS>
+FR_FN void round_draw(EX &ex, PairState &st, DrawBuf<RAW, LMAX> &D, DrawOut &O, unsigned short (*subset)[8], const PTS &pts, int n, int lmax,
+                      int raw_cap = RAW) {
   ex.one([&]() {
     O.rej_run = st.rej_run;
     draw_gen(D, st.rng, draw_raw_count(lmax, n, raw_cap < RAW ? raw_cap : RAW));
@@ -608,21 +607,70 @@ FR_FN bool fransac_round(EX &ex, PairState &st, DrawBuf<RAW, LMAX> &D, DrawOut &
     st.rng = O.state_out;
     st.rej_run = O.rej_run;
   });
-  ex.par(O.nsub, [&](int b) {
-    double ms1[14], ms2[14];
+}
+// the 7 correspondences of a subset as the 7-point solver takes them
+template <class PTS>
+FR_FN void subset_points(const unsigned short *idx, const PTS &pts, double *ms1, double *ms2) {
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-      const Pt4 q = pts(subset[b][i]);
-      ms1[2 * i] = (double)q.x;
-      ms1[2 * i + 1] = (double)q.y;
-      ms2[2 * i] = (double)q.z;
-      ms2[2 * i + 1] = (double)q.w;
-    }
+  for (int i = 0; i < 7; ++i) {
+    const Pt4 q = pts(idx[i]);
+    ms1[2 * i] = (double)q.x;
+    ms1[2 * i + 1] = (double)q.y;
+    ms2[2 * i] = (double)q.z;
+    ms2[2 * i + 1] = (double)q.w;
+  }
+}
+template <int STRIDE, class EX, class PTS>
+FR_FN void round_solve(EX &ex, int nsub, const unsigned short (*subset)[8], const PTS &pts, double (*models)[27], unsigned char *nmodels,
+                       double *priv, int *ipriv) {
+  ex.par(nsub, [&](int b) {
+    double ms1[14], ms2[14];
+    subset_points(subset[b], pts, ms1, ms2);
     nmodels[b] = (unsigned char)run_7point<STRIDE>(ms1, ms2, models[b], priv + b, ipriv + b);
   });
+}
+template <int RAW, int LMAX, int STRIDE, class EX, class PTS>
+FR_FN bool fransac_round(EX &ex, PairState &st, DrawBuf<RAW, LMAX> &D, DrawOut &O, unsigned short (*subset)[8], double (*models)[27],
+                         unsigned char *nmodels, int (*good)[3], double *priv, int *ipriv, const PTS &pts, int n, float t, double conf,
+                         int lmax, int raw_cap = RAW) {
+  round_draw(ex, st, D, O, subset, pts, n, lmax, raw_cap);
+  round_solve<STRIDE>(ex, O.nsub, subset, pts, models, nmodels, priv, ipriv);
   ex.score(O.nsub, models, nmodels, pts, n, t, good);
   ex.one([&]() { O.done = replay_round(st, n, conf, O.nsub, O.fail, models, nmodels, good) ? 1 : 0; });
   return O.done != 0;
+}
+
+// The decisions with LAZY scoring, for a single wavefront whose lanes all carry the same state: a model is only scored when the
+// sequential loop would reach it -- niters collapses after the first good model (to ~6 at 97 % inliers), and the hypotheses drawn and
+// solved beyond it are never looked at.  CNT: model (9 doubles) -> number of inliers, the same value on every lane.
+// models: [nsub][27], nmodels: [nsub].  Same return value as replay_round.
+template <class CNT>
+FR_FN bool decide_lazy(PairState &s, int n, double conf, int nsub, int fail, const double *models, const unsigned char *nmodels, const CNT &count) {
+  int iter = s.iters;
+  bool done = false;
+  for (int b = 0; b < nsub; ++b, ++iter) {
+    if (iter >= s.niters) {
+      done = true;
+      break;
+    }
+    const int nm = nmodels[b];
+    s.scored += (unsigned long long)nm;
+    for (int k = 0; k < nm; ++k) {
+      const double *Fm = models + 27 * b + 9 * k;
+      const int g = count(Fm);
+      const int lim = s.max_good > 6 ? s.max_good : 6;
+      if (g > lim) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) s.best[i] = Fm[i];
+        s.max_good = g;
+        s.niters = update_num_iters(conf, (double)(n - g) / n, s.niters);
+      }
+    }
+  }
+  if (!done && iter >= s.niters) done = true;
+  if (!done && fail) done = true;
+  s.iters = iter;
+  return done;
 }
 
 }  // namespace fransac

@@ -5,15 +5,19 @@
 // batch.  Results are bit-identical to the sequential algorithm (same RNG stream, same hypothesis order, same adaptive stopping rule);
 // the numerics and the per-pair logic are in fransac_core.h, shared with the host emulation that pins them against the CPU oracle.
 //
-// Organisation (round 3):
-//   fransac_first_kernel  one WAVEFRONT per pair: gate, the pair's correspondences into LDS, the first 8 hypotheses -- draws from the
-//                         cv::RNG stream by the table scheme of fransac_core.h, 8 lanes solve their 7-point problems side by side,
-//                         the wave scores every model (64 correspondences per step, ballot + popcount), the sequential decisions
-//                         (good > max(best, 6), RANSACUpdateNumIters) -- and, where the loop has ended (niters collapses to ~6 at the
-//                         inlier ratios pair preselection produces), the final mask and the in-place ordered compaction.  ~15 KB of
-//                         LDS per wave: ten pairs per CU in flight.  Pairs that need more go on a list with their state.
-//   fransac_rest_kernel   a persistent grid (two workgroups per CU) pulls pairs from that list: 16, 32, 64, 64, ... hypotheses per
-//                         round, 64 lanes solve, four waves score whole models each.
+// Organisation (round 3): the first 16 hypotheses of EVERY pair in three launches, pooled across pairs where lanes would idle; at the
+// inlier ratios pair preselection produces cv2's adaptive iteration count collapses to ~6 after the first all-inlier sample and 99 %
+// of the pairs end inside these 16 (median 6 iterations).
+//   fransac_draw_kernel    one wavefront per pair: the gates, then 16 subsets from the cv::RNG stream by the table scheme of
+//                          fransac_core.h (lane 0 only steps the generator; dedup, subset boundaries and collinearity tests run
+//                          across the lanes).  2.6 KB of LDS: the whole chunk is resident at once.
+//   fransac_solve_kernel   one LANE per 7-point problem, 64 problems of 4 pairs side by side in a wave (the 7 x 9 systems lane-minor
+//                          in LDS): the solver's ~7 k instructions are issued once per 64 problems instead of once per 8.
+//   fransac_decide_kernel  one wavefront per pair: correspondences into LDS, then the sequential decisions with LAZY scoring -- a
+//                          model is scored (64 correspondences per step, ballot + popcount) only when the loop reaches it -- and,
+//                          where the loop has ended, the final mask and the in-place ordered compaction.  The rest go on a list.
+//   fransac_rest_kernel    a persistent grid (two workgroups per CU) pulls pairs from that list: 32, 64, 64, ... hypotheses per
+//                          round, 64 lanes solve, four waves score whole models each.
 // Round 2 ran one 256-thread workgroup per pair with lane 0 drawing every subset in a loop (indices and points in scratch memory):
 // 0.63 ms per pair, 14.4 ms for the 11.6 k overlapping pairs of the neighbour list.
 #include "osfm_internal.h"
@@ -27,9 +31,9 @@ constexpr int kThreads = 256;  // long-run kernel
 constexpr int kWaves = 4;
 constexpr int kBatch = 64;     // hypotheses per round, long runs
 constexpr int kRawLong = 512;  // values of the RNG stream per round, long runs
-constexpr int kFirst = 8;      // hypotheses of the first kernel
-constexpr int kRawFirst = 80;
-constexpr int kFirstPts = 512;   // correspondences the first kernel stages (pairs with more go straight to the long-run kernel)
+constexpr int kFirst = 16;     // hypotheses of the first round (draw / solve / decide kernels)
+constexpr int kRawFirst = 192;
+constexpr int kFirstPts = 768;  // correspondences the decide kernel stages in LDS; pairs with more read them from HBM
 constexpr int kPairsLdsPts = 1024;  // correspondences the long-run kernel stages in LDS; pairs with more read them from HBM
 
 // correspondence k as cv2 sees it (CV_32F): from LDS, or -- more matches than the buffer holds, rare -- gathered from HBM
@@ -131,10 +135,14 @@ struct RansacPairsArgs {
   uint32_t *matches;
   double *F_out;
   unsigned long long *work;  // optional: += (models scored) x (correspondences) of every pair, the work the roofline line counts
-  // hand-over from the first kernel to the long-run kernel
-  PairState *states;  // [n_pairs]
-  int32_t *list;      // [n_pairs] pairs that continue
-  int32_t *ctl;       // [0] entries of the list, [1] the long-run kernel's pull cursor
+  // hand-over between the kernels
+  PairState *states;         // [n_pairs]
+  int32_t *list;             // [n_pairs] pairs that continue in the long-run kernel
+  int32_t *ctl;              // [0] entries of the list, [1] the long-run kernel's pull cursor
+  int32_t *hdr;              // [n_pairs][2]: subsets the draw kernel produced (-1: the pair failed a gate), getSubset-failed flag
+  unsigned short *subsets;   // [n_pairs][kFirst][8]
+  double *models;            // [n_pairs][kFirst][27]
+  unsigned char *nmodels;    // [n_pairs][kFirst]
 };
 
 // After the RANSAC loop: the verdict (matching.py:798-800), the final mask with the best F and the ordered in-place compaction of the
@@ -143,7 +151,10 @@ template <int NW, class PTS>
 __device__ __forceinline__ void finish_pair(const RansacPairsArgs &a, long p, int n, const PairState &st, const PTS &pts, int tid, int *misc) {
   const int lane = tid & 63, w = tid >> 6;
   if (a.work && tid == 0) atomicAdd(a.work, st.scored * (unsigned long long)n);
-  if (a.F_out && tid < 9) a.F_out[p * 9 + tid] = st.max_good > 0 ? st.best[tid] : 0.0;
+  if (a.F_out && tid == 0) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) a.F_out[p * 9 + i] = st.max_good > 0 ? st.best[i] : 0.0;  // static indices: st may live in registers
+  }
   if (st.max_good <= 0 || st.best[8] == 0.0) {  // F is None or F[2,2] == 0 -> no matches
     if (tid == 0) a.counts[p] = 0;
     return;
@@ -181,65 +192,105 @@ __device__ __forceinline__ void finish_pair(const RansacPairsArgs &a, long p, in
   if (tid == 0) a.counts[p] = base >= a.min_match ? base : 0;
 }
 
-struct FirstShared {
+struct DrawShared {
   PairState st;
   DrawOut O;
   unsigned short subset[kFirst][8];
-  double models[kFirst][27];
-  int good[kFirst][3];
-  unsigned char nmodels[kFirst];
-  int misc[4];
-  double priv[kPrivDoubles * kFirst];  // the 7-point systems of 8 lanes; before that, the table of the draws
-  int ipriv[9 * kFirst];
-  Pt4 pts[kFirstPts];
+  DrawBuf<kRawFirst, kFirst> D;
 };
-static_assert(sizeof(DrawBuf<kRawFirst, kFirst>) <= sizeof(double) * kPrivDoubles * kFirst, "the draw table must fit the 7-point scratch");
 
-__global__ void __launch_bounds__(64) fransac_first_kernel(RansacPairsArgs a) {
-  __shared__ FirstShared sh;
+__global__ void __launch_bounds__(64) fransac_draw_kernel(RansacPairsArgs a) {
+  __shared__ DrawShared sh;
   const int lane = threadIdx.x;
   const long p = blockIdx.x;
   const int n = min(a.counts[p], a.cap);
   // gates: matching.py:590-598 (min match) and matching.py:787-788 (< 8)
   if (n < a.min_match || n < 8) {
-    if (lane == 0) a.counts[p] = 0;
-    return;
-  }
-  if (lane == 0) state_init(sh.st, a.max_iters);
-  if (n > kFirstPts) {  // more correspondences than a wave stages: the long-run kernel takes the pair from the start
-    __syncthreads();
     if (lane == 0) {
-      a.states[p] = sh.st;
-      a.list[atomicAdd(a.ctl, 1)] = (int32_t)p;
+      a.counts[p] = 0;
+      a.hdr[2 * p] = -1;
     }
     return;
   }
+  if (lane == 0) state_init(sh.st, a.max_iters);
+  __syncthreads();
+  const int img1 = a.pairs[2 * p], img2 = a.pairs[2 * p + 1];
+  const PtsAny pts{nullptr, a.matches + p * a.cap, a.pts + a.tile_off[img1] * 64, a.pts + a.tile_off[img2] * 64};
+  WaveEx ex{lane};
+  round_draw(ex, sh.st, sh.D, sh.O, sh.subset, pts, n, kFirst);
+  const int nsub = sh.O.nsub;
+  for (int k = lane; k < nsub * 8; k += 64) a.subsets[p * (kFirst * 8) + k] = sh.subset[k >> 3][k & 7];
+  if (lane == 0) {
+    a.hdr[2 * p] = nsub;
+    a.hdr[2 * p + 1] = sh.O.fail;
+    a.states[p] = sh.st;
+  }
+}
+
+// lane g solves subset (g % kFirst) of pair (g / kFirst)
+__global__ void __launch_bounds__(64) fransac_solve_kernel(RansacPairsArgs a) {
+  __shared__ double priv[kPrivDoubles * 64];
+  __shared__ int ipriv[9 * 64];
+  const int lane = threadIdx.x;
+  const long g = (long)blockIdx.x * 64 + lane;
+  const long p = g / kFirst;
+  const int b = (int)(g - p * kFirst);
+  const bool active = p < a.n_pairs && b < a.hdr[2 * p];
+  if (__ballot(active) == 0ull) return;
+  if (!active) return;  // no barrier below: every lane works on its own columns of priv / ipriv
+  const int img1 = a.pairs[2 * p], img2 = a.pairs[2 * p + 1];
+  const PtsAny pts{nullptr, a.matches + p * a.cap, a.pts + a.tile_off[img1] * 64, a.pts + a.tile_off[img2] * 64};
+  unsigned short idx[8];
+  {
+    const uint4 v = *reinterpret_cast<const uint4 *>(a.subsets + (p * kFirst + b) * 8);
+    idx[0] = v.x & 0xFFFF, idx[1] = v.x >> 16, idx[2] = v.y & 0xFFFF, idx[3] = v.y >> 16;
+    idx[4] = v.z & 0xFFFF, idx[5] = v.z >> 16, idx[6] = v.w & 0xFFFF, idx[7] = 0;
+  }
+  double ms1[14], ms2[14];
+  subset_points(idx, pts, ms1, ms2);
+  a.nmodels[p * kFirst + b] = (unsigned char)run_7point<64>(ms1, ms2, a.models + (p * kFirst + b) * 27, priv + lane, ipriv + lane);
+}
+
+struct DecideShared {
+  int misc[4];
+  Pt4 pts[kFirstPts];
+};
+
+__global__ void __launch_bounds__(64) fransac_decide_kernel(RansacPairsArgs a) {
+  __shared__ DecideShared sh;
+  const int lane = threadIdx.x;
+  const long p = blockIdx.x;
+  const int nsub = a.hdr[2 * p];
+  if (nsub < 0) return;  // failed a gate (the draw kernel cleared its count)
+  const int fail = a.hdr[2 * p + 1];
+  const int n = min(a.counts[p], a.cap);
   const int img1 = a.pairs[2 * p], img2 = a.pairs[2 * p + 1];
   const double *pts1 = a.pts + a.tile_off[img1] * 64;
   const double *pts2 = a.pts + a.tile_off[img2] * 64;
-  for (int k = lane; k < n; k += 64) {
-    const uint32_t m = a.matches[p * a.cap + k];
-    const int i = m & 0xFFFF, j = m >> 16;
-    sh.pts[k] = Pt4{(float)pts1[2 * i], (float)pts1[2 * i + 1], (float)pts2[2 * j], (float)pts2[2 * j + 1]};
-  }
+  const bool in_lds = n <= kFirstPts;
+  if (in_lds)
+    for (int k = lane; k < n; k += 64) {
+      const uint32_t m = a.matches[p * a.cap + k];
+      const int i = m & 0xFFFF, j = m >> 16;
+      sh.pts[k] = Pt4{(float)pts1[2 * i], (float)pts1[2 * i + 1], (float)pts2[2 * j], (float)pts2[2 * j + 1]};
+    }
   __syncthreads();
   double thr = a.thr, conf = a.conf;
   if (thr <= 0) thr = 3;
   if (conf < 2.220446049250313e-16 || conf > 1 - 2.220446049250313e-16) conf = 0.99;
   const float t = (float)(thr * thr);
-  const PtsAny pts{sh.pts, nullptr, nullptr, nullptr};
-  WaveEx ex{lane};
-  auto &D = *reinterpret_cast<DrawBuf<kRawFirst, kFirst> *>(sh.priv);
-  const bool done = fransac_round<kRawFirst, kFirst, kFirst>(ex, sh.st, D, sh.O, sh.subset, sh.models, sh.nmodels, sh.good, sh.priv, sh.ipriv, pts,
-                                                             n, t, conf, kFirst);
+  const PtsAny pts{in_lds ? sh.pts : nullptr, a.matches + p * a.cap, pts1, pts2};
+  PairState st = a.states[p];  // the same value on every lane
+  const bool done = decide_lazy(st, n, conf, nsub, fail, a.models + p * (kFirst * 27), a.nmodels + p * kFirst,
+                                [&](const double *Fm) { return count_inliers(Fm, pts, n, t, lane); });
   if (!done) {
     if (lane == 0) {
-      a.states[p] = sh.st;
+      a.states[p] = st;
       a.list[atomicAdd(a.ctl, 1)] = (int32_t)p;
     }
     return;
   }
-  finish_pair<1>(a, p, n, sh.st, pts, lane, sh.misc);
+  finish_pair<1>(a, p, n, st, pts, lane, sh.misc);
 }
 
 // LDS of the long-run kernels: fixed part, then the staged correspondences
@@ -302,7 +353,7 @@ __global__ void __launch_bounds__(kThreads) fransac_rest_kernel(RansacPairsArgs 
       }
     __syncthreads();
     const PtsAny pts{in_lds ? ptsbuf : nullptr, a.matches + p * a.cap, pts1, pts2};
-    long_run(sh, pts, n, a.thr, a.conf, tid, 16);
+    long_run(sh, pts, n, a.thr, a.conf, tid, 32);
     finish_pair<kWaves>(a, p, n, sh.st, pts, tid, sh.misc);
   }
 }
@@ -319,7 +370,7 @@ __global__ void __launch_bounds__(kThreads) ransac_single_kernel(const double *p
     for (int k = tid; k < n; k += kThreads) ptsbuf[k] = Pt4{(float)p1[2 * k], (float)p1[2 * k + 1], (float)p2[2 * k], (float)p2[2 * k + 1]};
   __syncthreads();
   const PtsAny pts{in_lds ? ptsbuf : nullptr, nullptr, p1, p2};
-  long_run(sh, pts, n, thr, conf, tid, kFirst);
+  long_run(sh, pts, n, thr, conf, tid, 8);
   const int max_good = sh.st.max_good;
   if (tid == 0) {
     info[0] = max_good > 0 ? 1 : 0;
@@ -504,14 +555,15 @@ int osfm_launch_ransac_pairs(osfm_ctx *ctx, const osfm_store *store, const int32
                              int min_match, double thr, double conf, int max_iters, int32_t *d_counts,
                              uint32_t *d_matches, double *d_F_or_null, hipStream_t stream, unsigned long long *d_work_or_null) {
   if (n_pairs == 0) return OSFM_OK;
-  // hand-over buffers between the two kernels, kept by the context (grown on demand; one robust stage runs at a time per context)
-  const size_t need = (size_t)n_pairs * (sizeof(PairState) + sizeof(int32_t)) + 64;
+  // hand-over buffers between the kernels, kept by the context (grown on demand; one robust stage runs at a time per context)
+  const size_t per_pair = sizeof(PairState) + sizeof(int32_t) + 2 * sizeof(int32_t) + (size_t)kFirst * (8 * sizeof(unsigned short) + 27 * sizeof(double) + 1);
+  const size_t need = (size_t)n_pairs * per_pair + 256;
   if (need > ctx->fr_scratch_bytes) {
     if (ctx->d_fr_scratch) (void)hipFree(ctx->d_fr_scratch);
     ctx->d_fr_scratch = nullptr;
     ctx->fr_scratch_bytes = 0;
-    OSFM_REQUIRE(hipMalloc(&ctx->d_fr_scratch, need + need / 4) == hipSuccess, OSFM_E_NOMEM, "hipMalloc failed for the RANSAC hand-over buffers");
-    ctx->fr_scratch_bytes = need + need / 4;
+    OSFM_REQUIRE(hipMalloc(&ctx->d_fr_scratch, need + need / 8) == hipSuccess, OSFM_E_NOMEM, "hipMalloc failed for the RANSAC hand-over buffers");
+    ctx->fr_scratch_bytes = need + need / 8;
   }
   RansacPairsArgs a;
   a.pts = store->d_pts;
@@ -528,8 +580,12 @@ int osfm_launch_ransac_pairs(osfm_ctx *ctx, const osfm_store *store, const int32
   a.F_out = d_F_or_null;
   a.work = d_work_or_null;
   a.ctl = (int32_t *)ctx->d_fr_scratch;
-  a.states = (PairState *)((char *)ctx->d_fr_scratch + 64);
-  a.list = (int32_t *)(a.states + n_pairs);
+  a.models = (double *)((char *)ctx->d_fr_scratch + 64);  // 8-byte members first, 16-byte aligned subsets, then the rest
+  a.states = (PairState *)(a.models + (size_t)n_pairs * kFirst * 27);
+  a.subsets = (unsigned short *)(((uintptr_t)(a.states + n_pairs) + 15) & ~(uintptr_t)15);
+  a.hdr = (int32_t *)(a.subsets + (size_t)n_pairs * kFirst * 8);
+  a.list = a.hdr + 2 * n_pairs;
+  a.nmodels = (unsigned char *)(a.list + n_pairs);
   const int capr = (cap + 3) & ~3;
   const int lds_pts = std::min(capr, kPairsLdsPts);
   const size_t lds = kRansacFixedLds + (size_t)lds_pts * 16 + 64;
@@ -538,7 +594,9 @@ int osfm_launch_ransac_pairs(osfm_ctx *ctx, const osfm_store *store, const int32
     if (rc != OSFM_OK) return rc;
   }
   OSFM_HIP(hipMemsetAsync(a.ctl, 0, 64, stream));
-  hipLaunchKernelGGL(fransac_first_kernel, dim3((unsigned)n_pairs), dim3(64), 0, stream, a);
+  hipLaunchKernelGGL(fransac_draw_kernel, dim3((unsigned)n_pairs), dim3(64), 0, stream, a);
+  hipLaunchKernelGGL(fransac_solve_kernel, dim3((unsigned)((n_pairs * kFirst + 63) / 64)), dim3(64), 0, stream, a);
+  hipLaunchKernelGGL(fransac_decide_kernel, dim3((unsigned)n_pairs), dim3(64), 0, stream, a);
   OSFM_HIP(hipGetLastError());
   const unsigned grid = (unsigned)std::min<int64_t>(n_pairs, 2 * (int64_t)std::max(1, ctx->num_cus));
   hipLaunchKernelGGL(fransac_rest_kernel, dim3(grid), dim3(kThreads), lds, stream, a, lds_pts);

@@ -1,6 +1,7 @@
 // Host emulation of the fundamental-matrix RANSAC kernels (opensfm_amd/csrc/ransac.hip): the same fransac_core.h functions with loops
-// in place of lanes -- the first round of 8 hypotheses with the first kernel's buffer shapes (80 raw values, 8 lanes side by side in
-// the 7-point systems), then the long-run kernel's rounds (16, 32, 64, 64, ... hypotheses, 512 raw values, 64 lanes).
+// in place of lanes.  mode 0 = the batched path: draw kernel (16 subsets from a 192-value table), solve kernel (64 lanes side by
+// side), decide kernel (lazy scoring), then the long-run kernel's rounds (32, 64, 64, ... hypotheses, 512 raw values).  mode 1 = the
+// single-problem kernel of the leaf: rounds of 8, 16, 32, 64, ... hypotheses, eager scoring.
 // tests/test_fransac_host.py compares F, the inlier mask and the iteration count with the CPU oracle bit for bit.
 #include <cstring>
 #include <vector>
@@ -37,7 +38,7 @@ struct Pts {
 }  // namespace
 
 extern "C" int fransac_host_run(const double *p1, const double *p2, int n, double thr, double conf, int max_iters, int raw_cap_long,
-                                double *F, uint8_t *mask, int *iters, long long *scored, int *rounds) {
+                                int mode, double *F, uint8_t *mask, int *iters, long long *scored, int *rounds) {
   std::vector<Pt4> pv((size_t)n);
   for (int i = 0; i < n; ++i) pv[i] = Pt4{(float)p1[2 * i], (float)p1[2 * i + 1], (float)p2[2 * i], (float)p2[2 * i + 1]};
   const Pts pts{pv.data()};
@@ -49,27 +50,36 @@ extern "C" int fransac_host_run(const double *p1, const double *p2, int n, doubl
   HostEx ex;
   DrawOut O;
   int nr = 0;
-  bool done;
-  {  // first kernel
-    static DrawBuf<80, 8> D;
-    unsigned short subset[8][8];
-    double models[8][27];
-    unsigned char nmodels[8];
-    int good[8][3];
-    double priv[81 * 8];
-    int ipriv[9 * 8];
-    done = fransac_round<80, 8, 8>(ex, st, D, O, subset, models, nmodels, good, priv, ipriv, pts, n, t, conf, 8);
+  bool done = false;
+  int lmax = 8;
+  static unsigned short subset[64][8];
+  static double models[64][27];
+  static unsigned char nmodels[64];
+  static int good[64][3];
+  static double priv[81 * 64];
+  static int ipriv[9 * 64];
+  if (mode == 0) {
+    {  // fransac_draw_kernel
+      static DrawBuf<192, 16> D;
+      round_draw(ex, st, D, O, subset, pts, n, 16);
+    }
+    // fransac_solve_kernel: the pair's subsets sit in lanes 16 .. 31 of a wave that also holds other pairs' problems
+    for (int b = O.nsub - 1; b >= 0; --b) {
+      double ms1[14], ms2[14];
+      subset_points(subset[b], pts, ms1, ms2);
+      nmodels[b] = (unsigned char)run_7point<64>(ms1, ms2, models[b], priv + 16 + b, ipriv + 16 + b);
+    }
+    // fransac_decide_kernel
+    done = decide_lazy(st, n, conf, O.nsub, O.fail, &models[0][0], nmodels, [&](const double *Fm) {
+      int g = 0;
+      for (int i = 0; i < n; ++i) g += epi_error(Fm, (double)pv[i].x, (double)pv[i].y, (double)pv[i].z, (double)pv[i].w) <= t;
+      return g;
+    });
     ++nr;
+    lmax = 32;
   }
-  int lmax = 16;
-  while (!done) {  // long-run kernel
+  while (!done) {  // fransac_rest_kernel / ransac_single_kernel
     static DrawBuf<512, 64> D;
-    static unsigned short subset[64][8];
-    static double models[64][27];
-    static unsigned char nmodels[64];
-    static int good[64][3];
-    static double priv[81 * 64];
-    static int ipriv[9 * 64];
     // raw_cap_long < 512: test knob that starves the table so that short rounds and the sequential fallback occur
     done = fransac_round<512, 64, 64>(ex, st, D, O, subset, models, nmodels, good, priv, ipriv, pts, n, t, conf, lmax,
                                       raw_cap_long > 0 ? raw_cap_long : 512);

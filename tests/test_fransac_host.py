@@ -30,14 +30,14 @@ def host():
     return C.CDLL(so)
 
 
-def run_host(host, p1, p2, thr=0.004, conf=0.9999, max_iters=1000, raw_cap=0):
+def run_host(host, p1, p2, thr=0.004, conf=0.9999, max_iters=1000, raw_cap=0, mode=0):
     p1 = np.ascontiguousarray(p1, np.float64)
     p2 = np.ascontiguousarray(p2, np.float64)
     n = len(p1)
     F = np.zeros(9)
     mask = np.zeros(max(n, 1), np.uint8)
     it, rounds, scored = C.c_int(0), C.c_int(0), C.c_longlong(0)
-    r = host.fransac_host_run(_p(p1, C.c_double), _p(p2, C.c_double), n, C.c_double(thr), C.c_double(conf), max_iters, raw_cap,
+    r = host.fransac_host_run(_p(p1, C.c_double), _p(p2, C.c_double), n, C.c_double(thr), C.c_double(conf), max_iters, raw_cap, mode,
                               _p(F, C.c_double), _p(mask, C.c_uint8), C.byref(it), C.byref(scored), C.byref(rounds))
     assert r >= 0
     return (F.reshape(3, 3) if r == 1 else None), mask[:n].astype(bool), it.value, rounds.value
@@ -46,11 +46,12 @@ def run_host(host, p1, p2, thr=0.004, conf=0.9999, max_iters=1000, raw_cap=0):
 def check(host, oracle_lib, p1, p2, **kw):
     raw_cap = kw.pop("raw_cap", 0)
     Fo, mo, io = oracle_lib.find_fundamental_ransac(p1, p2, kw.get("thr", 0.004), kw.get("conf", 0.9999), kw.get("max_iters", 1000))
-    Fh, mh, ih, rounds = run_host(host, p1, p2, raw_cap=raw_cap, **kw)
-    assert (Fo is None) == (Fh is None)
-    if Fo is not None:
-        assert np.array_equal(Fo.view(np.uint64), Fh.view(np.uint64))
-    assert np.array_equal(mo, mh) and io == ih
+    for mode in (0, 1):  # the batched path (draw / solve / decide kernels + long runs) and the single-problem kernel
+        Fh, mh, ih, rounds = run_host(host, p1, p2, raw_cap=raw_cap, mode=mode, **kw)
+        assert (Fo is None) == (Fh is None)
+        if Fo is not None:
+            assert np.array_equal(Fo.view(np.uint64), Fh.view(np.uint64))
+        assert np.array_equal(mo, mh) and io == ih
     return io, rounds
 
 
@@ -63,12 +64,12 @@ def test_emulated_kernels_equal_oracle(host, oracle_lib, n, inliers):
 
 
 def test_long_runs_cross_many_rounds(host, oracle_lib):
-    """pure outliers: the full 1000 iterations, 8 + 16 + 32 + 64 + ... hypotheses per round"""
+    """pure outliers: the full 1000 iterations over many rounds of both schedules"""
     rng = np.random.default_rng(5)
     for n in (15, 40, 300):
         p1, p2 = rng.uniform(-0.5, 0.5, (n, 2)), rng.uniform(-0.5, 0.5, (n, 2))
         it, rounds = check(host, oracle_lib, p1, p2)
-        assert it >= 300 and rounds >= 8 and (n < 300 or (it == 1000 and rounds >= 18))
+        assert it >= 300 and rounds >= 8 and (n < 300 or (it == 1000 and rounds >= 18))  # rounds: of the single-problem schedule
 
 
 def test_small_n_many_duplicate_draws_and_starved_table(host, oracle_lib):
