@@ -47,6 +47,8 @@ extern "C" void osfm_ctx_destroy(osfm_ctx *c) {
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->d_rng_table) (void)hipFree(c->d_rng_table);
   if (c->d_fr_scratch) (void)hipFree(c->d_fr_scratch);
+  for (auto &b : c->pool) (void)hipFree(b.p);
+  if (c->stream_b) (void)hipStreamDestroy(c->stream_b);
   delete c;
 }
 
@@ -263,10 +265,47 @@ __global__ void gather_matches_kernel(const int32_t *counts, const int64_t *offs
 
 struct DevBuf {
   void *p = nullptr;
-  ~DevBuf() {
-    if (p) (void)hipFree(p);
+  size_t bytes = 0;
+  osfm_ctx *pool = nullptr;  // non-null: taken from / returned to the context's cache (the caller holds the context lock)
+  ~DevBuf() { release(); }
+  void release() {
+    if (!p) return;
+    if (pool && pool->pool_bytes + bytes <= osfm_ctx::kPoolBytes && pool->pool.size() < 64) {
+      pool->pool.push_back({p, bytes});
+      pool->pool_bytes += bytes;
+    } else {
+      (void)hipFree(p);
+    }
+    p = nullptr;
   }
-  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+  hipError_t alloc(size_t want) {
+    bytes = want ? want : 16;
+    return hipMalloc(&p, bytes);
+  }
+  hipError_t alloc(osfm_ctx *ctx, size_t want) {
+    want = want ? want : 16;
+    pool = ctx;
+    int best = -1;
+    for (int i = 0; i < (int)ctx->pool.size(); ++i)
+      if (ctx->pool[i].bytes >= want && ctx->pool[i].bytes <= 2 * want + 4096 && (best < 0 || ctx->pool[i].bytes < ctx->pool[best].bytes)) best = i;
+    if (best >= 0) {
+      p = ctx->pool[best].p;
+      bytes = ctx->pool[best].bytes;
+      ctx->pool_bytes -= bytes;
+      ctx->pool.erase(ctx->pool.begin() + best);
+      return hipSuccess;
+    }
+    bytes = want;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess && !ctx->pool.empty()) {  // out of memory with blocks cached: drop the cache and try again
+      for (auto &b : ctx->pool) (void)hipFree(b.p);
+      ctx->pool.clear();
+      ctx->pool_bytes = 0;
+      (void)hipGetLastError();
+      e = hipMalloc(&p, bytes);
+    }
+    return e;
+  }
   template <typename T>
   T *as() {
     return (T *)p;
@@ -309,9 +348,9 @@ static int match_pairs_impl(osfm_ctx *ctx, const osfm_store *store, const int32_
     DevBuf pairs, counts, matches, flags, offsets, gather;
     DevBuf poses, six, good;  // guided matching: relative poses, per-pair epipolar vectors, per-direction results
     size_t gather_cap = 0;
-    hipEvent_t m0 = nullptr, m1 = nullptr, r0 = nullptr, r1 = nullptr;
+    hipEvent_t m0 = nullptr, m1 = nullptr, r0 = nullptr, r1 = nullptr, q0 = nullptr, q1 = nullptr;
     ~ChunkSet() {
-      for (hipEvent_t ev : {m0, m1, r0, r1})
+      for (hipEvent_t ev : {m0, m1, r0, r1, q0, q1})
         if (ev) (void)hipEventDestroy(ev);
     }
   } sets[2];
@@ -319,34 +358,35 @@ static int match_pairs_impl(osfm_ctx *ctx, const osfm_store *store, const int32_
   hipError_t e = hipSuccess;
   bool ok = true;
   for (int q = 0; q < nsets; ++q) {
-    ok = ok && (e = sets[q].pairs.alloc((size_t)cp * 2 * sizeof(int32_t))) == hipSuccess;
-    ok = ok && (e = sets[q].counts.alloc((size_t)cp * sizeof(int32_t))) == hipSuccess;
-    ok = ok && (e = sets[q].flags.alloc((size_t)cp * sizeof(int32_t))) == hipSuccess;
-    ok = ok && (e = sets[q].offsets.alloc((size_t)cp * sizeof(int64_t))) == hipSuccess;
-    ok = ok && (e = sets[q].matches.alloc((size_t)cp * cap * sizeof(uint32_t))) == hipSuccess;
+    ok = ok && (e = sets[q].pairs.alloc(ctx, (size_t)cp * 2 * sizeof(int32_t))) == hipSuccess;
+    ok = ok && (e = sets[q].counts.alloc(ctx, (size_t)cp * sizeof(int32_t))) == hipSuccess;
+    ok = ok && (e = sets[q].flags.alloc(ctx, (size_t)cp * sizeof(int32_t))) == hipSuccess;
+    ok = ok && (e = sets[q].offsets.alloc(ctx, (size_t)cp * sizeof(int64_t))) == hipSuccess;
+    ok = ok && (e = sets[q].matches.alloc(ctx, (size_t)cp * cap * sizeof(uint32_t))) == hipSuccess;
     if (guided) {
       size_t six_bytes = 0, good_bytes = 0;
       osfm_guided_scratch_bytes(cap, cp, &six_bytes, &good_bytes);
-      ok = ok && (e = sets[q].poses.alloc((size_t)cp * 12 * sizeof(double))) == hipSuccess;
-      ok = ok && (e = sets[q].six.alloc(six_bytes)) == hipSuccess;
-      ok = ok && (e = sets[q].good.alloc(good_bytes)) == hipSuccess;
+      ok = ok && (e = sets[q].poses.alloc(ctx, (size_t)cp * 12 * sizeof(double))) == hipSuccess;
+      ok = ok && (e = sets[q].six.alloc(ctx, six_bytes)) == hipSuccess;
+      ok = ok && (e = sets[q].good.alloc(ctx, good_bytes)) == hipSuccess;
     }
     ok = ok && (e = hipEventCreate(&sets[q].m0)) == hipSuccess && (e = hipEventCreate(&sets[q].m1)) == hipSuccess;
     ok = ok && (e = hipEventCreate(&sets[q].r0)) == hipSuccess && (e = hipEventCreate(&sets[q].r1)) == hipSuccess;
+    ok = ok && (e = hipEventCreate(&sets[q].q0)) == hipSuccess && (e = hipEventCreate(&sets[q].q1)) == hipSuccess;
   }
   OSFM_REQUIRE(ok, OSFM_E_NOMEM, "hipMalloc failed for match buffers: %s", hipGetErrorString(e));
-  struct StreamB {
-    hipStream_t s = nullptr;
-    ~StreamB() {
-      if (s) (void)hipStreamDestroy(s);
-    }
-  } sb;
-  OSFM_HIP(hipStreamCreateWithFlags(&sb.s, hipStreamNonBlocking));
-  // measurement knob: OSFM_MATCH_ONE_STREAM=1 runs the robust stage on the matcher's stream (no overlap between chunks)
-  hipStream_t stA = ctx->stream, stB = getenv("OSFM_MATCH_ONE_STREAM") ? ctx->stream : sb.s;
+  if (!ctx->stream_b) OSFM_HIP(hipStreamCreateWithFlags(&ctx->stream_b, hipStreamNonBlocking));
+  // measurement knob: OSFM_MATCH_ONE_STREAM=1 puts everything on the matcher's stream (no overlap between chunks)
+  hipStream_t stA = ctx->stream, stB = getenv("OSFM_MATCH_ONE_STREAM") ? ctx->stream : ctx->stream_b;
+  // The fundamental-matrix RANSAC runs on the MATCHER's stream, right behind its chunk: the matcher owns every SIMD's registers and
+  // nearly all LDS (2 x 78 KiB per CU), so kernels of a second stream only get in where a matcher workgroup retires -- measured on the
+  // neighbour list, the robust stage takes 1.0 ms on its own and 9 ms of stream time underneath the matcher, which it slows down in
+  // turn (tools/prof_neighbour.py, profiles/r03_prof_neighbour.json).  Stream B keeps what does overlap for free: counts D2H, the
+  // gather of the match rows and their D2H copy.  The calibrated branch (host-driven rounds) stays on stream B.
+  const bool ransac_on_a = !calib && params->robust && !getenv("OSFM_MATCH_RANSAC_STREAM_B");
 
   DevBuf d_work;  // models x correspondences scored by the RANSAC kernel (osfm_match_timings::ransac_model_points)
-  OSFM_HIP(d_work.alloc(8));
+  OSFM_HIP(d_work.alloc(ctx, 8));
   OSFM_HIP(hipMemsetAsync(d_work.p, 0, 8, stA));
   OSFM_HIP(hipStreamSynchronize(stA));
   osfm_match_result *res = new (std::nothrow) osfm_match_result();
@@ -403,7 +443,15 @@ static int match_pairs_impl(osfm_ctx *ctx, const osfm_store *store, const int32_
                              S.counts.as<int32_t>(), S.matches.as<uint32_t>(), S.flags.as<int32_t>(), true, stA);
       if (rc != OSFM_OK) return rc;
     }
-    OSFM_HIP(hipEventRecord(S.r0, stA));  // everything of the descriptor stage is enqueued
+    if (ransac_on_a) {
+      OSFM_HIP(hipEventRecord(S.q0, stA));
+      rc = osfm_launch_ransac_pairs(ctx, store, S.pairs.as<int32_t>(), np, cap, params->robust_matching_min_match, params->robust_matching_threshold,
+                                    params->ransac_confidence, params->ransac_max_iters, S.counts.as<int32_t>(), S.matches.as<uint32_t>(), nullptr, stA,
+                                    d_work.as<unsigned long long>());
+      if (rc != OSFM_OK) return rc;
+      OSFM_HIP(hipEventRecord(S.q1, stA));
+    }
+    OSFM_HIP(hipEventRecord(S.r0, stA));  // everything of the descriptor stage (and the F-RANSAC) is enqueued
     return OSFM_OK;
   };
 
@@ -427,7 +475,7 @@ static int match_pairs_impl(osfm_ctx *ctx, const osfm_store *store, const int32_
                                                   S.counts.as<int32_t>(), S.matches.as<uint32_t>(), stB, &nf);
       if (rc != OSFM_OK) return rc;
       if (tm) tm->pairs_ransac += nf;
-    } else if (params->robust) {
+    } else if (params->robust && !ransac_on_a) {
       const int rc = osfm_launch_ransac_pairs(ctx, store, S.pairs.as<int32_t>(), np, cap, params->robust_matching_min_match,
                                               params->robust_matching_threshold, params->ransac_confidence,
                                               params->ransac_max_iters, S.counts.as<int32_t>(), S.matches.as<uint32_t>(), nullptr, stB, d_work.as<unsigned long long>());
@@ -474,10 +522,9 @@ static int match_pairs_impl(osfm_ctx *ctx, const osfm_store *store, const int32_
     OSFM_REQUIRE(res->matches.resize(base + (size_t)total * 2), OSFM_E_NOMEM, "out of host memory for %lld matches", (long long)total);
     if (total > 0) {
       if ((size_t)total > S.gather_cap) {
-        if (S.gather.p) (void)hipFree(S.gather.p);
-        S.gather.p = nullptr;
+        S.gather.release();
         S.gather_cap = (size_t)total + (size_t)total / 4;
-        OSFM_REQUIRE(S.gather.alloc(S.gather_cap * 2 * sizeof(int32_t)) == hipSuccess, OSFM_E_NOMEM,
+        OSFM_REQUIRE(S.gather.alloc(ctx, S.gather_cap * 2 * sizeof(int32_t)) == hipSuccess, OSFM_E_NOMEM,
                      "hipMalloc failed for gathered matches");
       }
       OSFM_HIP(hipMemcpyAsync(S.offsets.p, hoff.data(), (size_t)np * sizeof(int64_t), hipMemcpyHostToDevice, stB));
@@ -492,7 +539,10 @@ static int match_pairs_impl(osfm_ctx *ctx, const osfm_store *store, const int32_
       float ms = 0.f;
       OSFM_HIP(hipEventElapsedTime(&ms, S.m0, S.m1));
       ms_match += ms;
-      OSFM_HIP(hipEventElapsedTime(&ms, rb0, rb1));
+      if (ransac_on_a)
+        OSFM_HIP(hipEventElapsedTime(&ms, S.q0, S.q1));
+      else
+        OSFM_HIP(hipEventElapsedTime(&ms, rb0, rb1));
       ms_ransac += ms;
       tm->match_launches += 1;
     }

@@ -42,6 +42,16 @@ struct osfm_ctx {
   void *d_rng_table = nullptr;  // relpose.hip: the tabulated std::mt19937(42) stream, made on first use
   void *d_fr_scratch = nullptr;  // ransac.hip: per-pair states + the list the first kernel hands to the long-run kernel
   size_t fr_scratch_bytes = 0;
+  // device buffers of the batched matching calls, kept between calls (hipMalloc / hipFree of the chunk buffers cost ~0.5 ms per call):
+  // a free block is reused when it is large enough and at most twice the request; at most kPoolBytes stay cached
+  struct PoolBlock {
+    void *p;
+    size_t bytes;
+  };
+  std::vector<PoolBlock> pool;
+  size_t pool_bytes = 0;
+  static constexpr size_t kPoolBytes = (size_t)6 << 30;
+  hipStream_t stream_b = nullptr;  // second stream of the batched matching calls (gather + D2H of chunk k under the matcher of k + 1)
   size_t match_hint = 0;        // int32 entries of the last batched call's match list: the next call reserves that much up front
 };
 
