@@ -331,12 +331,13 @@ static int match_pairs_impl(osfm_ctx *ctx, const osfm_store *store, const int32_
   const int cap = store->max_count > 0 ? store->max_count : 1;
   // 131072 pairs per chunk at cap <= 2048 (1 GiB of match slots per buffer set), fewer for larger images
   const int64_t chunk_pairs = std::max<int64_t>(4096, std::min<int64_t>(1 << 17, ((int64_t)1 << 28) / cap));
-  // at least four chunks once there is enough work for that (>= 4096 pairs each): the geometric stage of chunk k runs on stream
-  // B underneath the matcher of chunk k + 1, which a neighbour-preselected list (every pair reaches RANSAC) needs most
+  // at least two chunks once there is enough work for that (>= 4096 pairs each): gather + D2H of chunk k run on stream B underneath the
+  // matcher of chunk k + 1.  More chunks than memory asks for only add per-chunk fixed costs (measured on the 15 864-pair neighbour
+  // list, profiles/r03_prof_neighbour.json: 1 chunk 13.05 ms, 2 chunks 12.54 ms, 4 chunks 13.43 ms).
   int64_t cp = n_pairs < chunk_pairs ? n_pairs : chunk_pairs;
   {
     const char *e = getenv("OSFM_MATCH_CHUNKS");  // measurement knob
-    const int64_t nch = e ? std::max(1, atoi(e)) : 4;
+    const int64_t nch = e ? std::max(1, atoi(e)) : 2;
     if (n_pairs >= 8192) cp = std::min<int64_t>(cp, std::max<int64_t>(4096, (n_pairs + nch - 1) / nch));
   }
   if (guided) cp = std::min<int64_t>(cp, 8192);  // 96 B of epipolar vectors + 8 B of results per feature and pair in the chunk's scratch
