@@ -13,8 +13,43 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 MATVEC_BYTES_PER_OBS = 288.0  # stored point+pose blocks (144 B) read twice per Schur mat-vec
 
 
+# per LM iteration the stored-Jacobian pass moves 0.88 GB at B5 (5e6 obs x (32 + 144) B) and every PCG mat-vec 1.44 GB
+# (5e6 x 288 B): an LM iteration is bounded by (176 + 288 x matvecs) B per observation / HBM bandwidth
+LM_BYTES_PER_OBS_FIXED = 176.0
+
+
+def lm_iteration_line(g: dict, nobs: int) -> dict:
+    ms = 1e3 * g["seconds_run"] / max(1, g["iterations"])
+    mv = g["pcg_iterations"] / max(1, g["iterations"])
+    bound_ms = (LM_BYTES_PER_OBS_FIXED + MATVEC_BYTES_PER_OBS * mv) * nobs / (HBM_PEAK_GBS * 1e9) * 1e3
+    return {"ms": round(ms, 3), "matvecs_per_iteration": round(mv, 2),
+            "hbm_bound_ms": round(bound_ms, 4), "roofline_frac": round(bound_ms / ms, 4) if ms > 0 else None,
+            "roofline_note": "whole LM iteration against SURVEY.md 8(d)'s bound ((176 + 288 x matvecs) B per observation at 8 TB/s); the "
+                             "'roofline' block above is the Schur mat-vec kernel pair alone",
+            "note": "per LM iteration: Jacobian + gradients, band assembly, cyclic-reduction factor, camera border (one pass for all "
+                    "columns), right-hand side, PCG (1-2 mat-vecs), back-substitution, candidate cost"}
+
+
+def run_grid(ctx, rows: int = 50, cols: int = 100, points: int = 500000, track: int = 9, iters: int = 10, seed: int = 42) -> dict:
+    """The same size on a NON-sequence topology: a rows x cols block survey, shots numbered line after line, every
+    point seen from ~3 lines -- co-visibility half-width ~2 x cols in shot order, far above what the banded preconditioner holds."""
+    pr = synthetic.make_ba_scene_grid(rows, cols, points, track, seed=seed)
+    nobs = len(pr["obs_shot"])
+    no_tol = dict(function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
+    bundle.bundle_arrays(pr, {"bundle_max_iterations": 1}, ctx=ctx, **no_tol)
+    g = bundle.bundle_arrays(pr, {"bundle_max_iterations": iters}, ctx=ctx, **no_tol)
+    inl = ~pr["is_outlier"]
+    return {"workload": f"{rows} x {cols} grid of cameras / {points} pts / {nobs} obs (block survey: each point seen from 3 lines)",
+            "value": round(g["iterations"] / g["seconds_run"], 3), "unit": "LM-iters/s", "lm_iterations": int(g["iterations"]),
+            "pcg_iterations": int(g["pcg_iterations"]), "shot_bandwidth_input": int(g.get("shot_bandwidth_input", -1)),
+            "shot_bandwidth": int(g.get("shot_bandwidth", -1)), "shots_reordered": int(g.get("shots_reordered", 0)),
+            "preconditioner_bandwidth": int(g.get("preconditioner_bandwidth", -1)),
+            "inlier_rmse_px": round(float(np.sqrt((g["reproj_err"][inl] ** 2).sum(1).mean()) * 2000.0), 4),
+            "cost": [float(g["initial_cost"]), float(g["final_cost"])], "lm_iteration": lm_iteration_line(g, nobs)}
+
+
 def run(ctx, shots: int = 5000, points: int = 500000, track: int = 10, iters: int = 20, cpu_baseline: bool = True,
-        cpu_iters: int = 5, seed: int = 42) -> dict:
+        cpu_iters: int = 20, seed: int = 42, grid: bool = True) -> dict:
     t0 = time.time()
     pr = synthetic.make_ba_scene(shots, points, track, seed=seed)
     t_gen = time.time() - t0
@@ -74,10 +109,12 @@ def run(ctx, shots: int = 5000, points: int = 500000, track: int = 10, iters: in
                                           "algorithmic_bytes": MATVEC_BYTES_PER_OBS * nobs, "source": pmc["source"]}
         except (KeyError, ValueError):
             pass
-    out["lm_iteration"] = {"ms": round(1e3 * g["seconds_run"] / max(1, g["iterations"]), 3),
-                           "matvecs_per_iteration": round(g["pcg_iterations"] / max(1, g["iterations"]), 2),
-                           "note": "per LM iteration: Jacobian + gradients, band assembly, cyclic-reduction factor, camera border (one pass for all "
-                                   "columns), right-hand side, PCG (1-2 mat-vecs), back-substitution, candidate cost"}
+    out["lm_iteration"] = lm_iteration_line(g, nobs)
+    if grid:
+        try:
+            out["grid_topology"] = run_grid(ctx, points=points, seed=seed)
+        except Exception as exc:  # noqa: BLE001  (a secondary workload must not take the line down)
+            out["grid_topology"] = {"error": f"{type(exc).__name__}: {exc}"}
     if cpu_baseline:
         import oracle
 
@@ -92,9 +129,10 @@ def run(ctx, shots: int = 5000, points: int = 500000, track: int = 10, iters: in
             "unit": "LM-iters/s",
             "cores": oracle.num_threads(),
             "kind": "port",
-            "kind_note": "port, serial Schur elimination",
-            "sample": f"{cpu_iters} LM iterations of the same problem ({dt:.1f} s; exact Schur + skyline Cholesky, "
-                      "OpenMP residuals, serial elimination)",
+            "kind_note": "port; OpenMP residuals / Jacobians AND Schur elimination (entry-owner partition), skyline Cholesky serial",
+            "sample": f"all {cpu_iters} LM iterations of the same problem ({dt:.1f} s; exact Schur + skyline Cholesky on "
+                      f"{oracle.num_threads()} threads)",
+            "parity_iterations": int(cpu_iters),
             "rmse_px_diff_vs_gpu_same_iters": abs(rm_o - rm_g),
             "cost_history_max_rel_diff": float(np.max(np.abs(np.asarray(o["cost_history"]) - np.asarray(g2["cost_history"]))
                                                       / np.maximum(np.abs(np.asarray(o["cost_history"])), 1e-300))),

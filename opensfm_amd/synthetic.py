@@ -318,6 +318,55 @@ def make_ba_scene(n_shots: int, n_points: int, track_len: int = 10, seed: int = 
     return prob
 
 
+def make_ba_scene_grid(rows: int, cols: int, n_points: int, track_len: int = 10, seed: int = 42, outlier_frac: float = 0.05,
+                       px_noise: float = 1.0 / 2000.0, pose_noise_t: float = 0.05, pose_noise_r: float = 0.01, point_noise: float = 0.05,
+                       gps_sigma: float = 5.0) -> dict:
+    """A block survey instead of a sequence: rows x cols cameras on a 2-D grid (flight lines, numbered line after line), every point seen
+    from a window of ~3 lines x ~track_len / 3 cameras.  Shots of neighbouring lines share points, so the co-visibility half-width in
+    shot order is ~2 x cols -- far above what the banded preconditioner of the streaming solver holds.  Same camera,
+    noise model and dict layout as ``make_ba_scene``."""
+    rng = np.random.default_rng(seed)
+    cam = np.array([-0.1, 0.01, 0.7])
+    n_shots = rows * cols
+    wr = min(3, rows)
+    wc = max(1, min(cols, int(round(track_len / wr))))
+    L = wr * wc
+    step = 0.5
+    gt_pose = np.zeros((n_shots, 6))
+    gt_pose[:, 0:3] = rng.normal(0, 0.03, (n_shots, 3))
+    rr, cc = np.divmod(np.arange(n_shots), cols)
+    gt_pose[:, 3] = cc * step
+    gt_pose[:, 4] = rr * step
+    gt_pose[:, 5] = rng.normal(0, 0.05, n_shots)
+    r0 = rng.integers(0, rows - wr + 1, n_points)
+    c0 = rng.integers(0, cols - wc + 1, n_points)
+    gt_pts = np.stack([(c0 + (wc - 1) / 2.0) * step + rng.uniform(-0.4, 0.4, n_points), (r0 + (wr - 1) / 2.0) * step + rng.uniform(-0.4, 0.4, n_points),
+                       rng.uniform(4.0, 12.0, n_points)], axis=1)
+    dr, dc = np.divmod(np.arange(L), wc)
+    obs_point = np.repeat(np.arange(n_points, dtype=np.int32), L)
+    obs_shot = ((r0[:, None] + dr[None, :]) * cols + c0[:, None] + dc[None, :]).reshape(-1).astype(np.int32)
+    order = np.lexsort((obs_point, obs_shot))
+    obs_shot, obs_point = obs_shot[order], obs_point[order]
+    xy = np.empty((len(obs_shot), 2))
+    bounds = np.searchsorted(obs_shot, np.arange(n_shots + 1))
+    for s in range(n_shots):
+        a, b = bounds[s], bounds[s + 1]
+        xy[a:b] = project_perspective(gt_pts[obs_point[a:b]], gt_pose[s], cam, "perspective")
+    xy += rng.normal(0, px_noise, xy.shape)
+    out = rng.random(len(xy)) < outlier_frac
+    xy[out] += rng.uniform(-0.03, 0.03, (int(out.sum()), 2))
+    pose0 = gt_pose.copy()
+    pose0[:, 0:3] += rng.normal(0, pose_noise_r, (n_shots, 3))
+    pose0[:, 3:6] += rng.normal(0, pose_noise_t, (n_shots, 3))
+    return {
+        "cam_params": cam[None, :].copy(), "cam_prior": cam[None, :].copy(), "cam_sigma": np.full((1, 3), 0.01), "cam_fixed": np.zeros(1, np.uint8),
+        "shot_pose": pose0, "shot_camera": np.zeros(n_shots, np.int32), "points": gt_pts + rng.normal(0, point_noise, gt_pts.shape),
+        "obs_shot": obs_shot, "obs_point": obs_point, "obs_xy": xy, "obs_sigma": np.full(len(xy), 0.004),
+        "gt_pose": gt_pose, "gt_points": gt_pts, "gt_cam": cam, "is_outlier": out,
+        "shot_gps": gt_pose[:, 3:6] + rng.normal(0, gps_sigma / 10.0, (n_shots, 3)), "shot_gps_sigma": np.full(n_shots, gps_sigma),
+    }
+
+
 # ------------------------------------------------------------------------------------------------
 # scenes for the general bundle adjustment (osfm_bundle_solve): rigs, every camera model, biases, control points
 # ------------------------------------------------------------------------------------------------

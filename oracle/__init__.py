@@ -252,6 +252,15 @@ def num_threads() -> int:
     return lib().oracle_num_threads()
 
 
+def set_num_threads(n: int) -> None:
+    lib().oracle_set_num_threads(int(n))
+
+
+def ba_set_parallel(on: bool) -> None:
+    """the BA oracle's Schur elimination on all cores (default) or with the serial loops that define its summation order"""
+    lib().oracle_ba_set_parallel(int(bool(on)))
+
+
 # ------------------------------------------------------------------------------------------------
 # bundle adjustment oracle (oracle/ba_oracle.c)
 # ------------------------------------------------------------------------------------------------

@@ -590,6 +590,12 @@ static double now_s(void) {
 #endif
 }
 
+/* 1 (default): the Schur elimination runs on all cores (entry-owner partition, see below); 0: the serial loops (kept: they define the
+ * summation order the parallel path reproduces, and tests compare the two) */
+static int g_ba_parallel = 1;
+void oracle_ba_set_parallel(int on) { g_ba_parallel = on; }
+void oracle_set_num_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }
+
 int oracle_ba_solve(ba_problem *P, const ba_options *O, ba_report *Rp) {
   memset(Rp, 0, sizeof(*Rp));
   const double t_start = now_s();
@@ -779,6 +785,206 @@ int oracle_ba_solve(ba_problem *P, const ba_options *O, ba_report *Rp) {
     {
       const double t_lin = now_s();
       /* ---- Schur complement in the scaled space ---- */
+      /* All cores ("OpenMP Jacobian + block Schur + Cholesky"): every entry of the reduced system has ONE owner thread
+       * -- the thread that owns the shot of its row (shot rows) or of its column (camera rows) -- which adds the contributions in the
+       * order of the serial loops below, so those entries come out bit-identical to the serial elimination for any number of threads.
+       * Only the small camera x camera block and the camera rows of the right-hand side, which every observation touches, are summed
+       * from partial sums over a FIXED number of chunks (in chunk order: independent of the thread count as well). */
+      const int ncc = 3 * C.ncv;
+      if (g_ba_parallel && ncc <= 24 && C.nsv > 0) {
+        enum { KCH = 256 };
+        const int ncc2 = ncc * ncc;
+        double *part1 = (double *)calloc((size_t)KCH * (size_t)(ncc2 + 1), sizeof(double));            /* camera-side blocks */
+        double *part2 = (double *)calloc((size_t)KCH * (size_t)(ncc2 + ncc + 1), sizeof(double));      /* elimination: block + rhs */
+        for (int64_t i = 0; i < A.off[nred]; i++) A.v[i] = 0;
+        for (int i = 0; i < nred; i++) rhs[i] = -g_red[i] * sc_red[i];
+#pragma omp parallel for schedule(static)
+        for (int p = 0; p < NP; p++) {
+          double *Hi = Hpp_inv + 9 * (size_t)p;
+          if (P->point_fixed && P->point_fixed[p]) {
+            for (int i = 0; i < 9; i++) Hi[i] = 0;
+            continue;
+          }
+          double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+          for (int64_t q = C.pt_off[p]; q < C.pt_off[p + 1]; q++) {
+            const double *Jp = C.Jp + 6 * C.pt_obs[q];
+            for (int i = 0; i < 3; i++)
+              for (int j = 0; j < 3; j++) H[3 * i + j] += (Jp[i] * Jp[j] + Jp[3 + i] * Jp[3 + j]) * sc_pt[3 * p + i] * sc_pt[3 * p + j];
+          }
+          for (int i = 0; i < 3; i++) H[4 * i] += Dpt[3 * p + i] / radius;
+          const double c00 = H[4] * H[8] - H[5] * H[7], c01 = H[5] * H[6] - H[3] * H[8], c02 = H[3] * H[7] - H[4] * H[6];
+          const double det = H[0] * c00 + H[1] * c01 + H[2] * c02, id = 1.0 / det;
+          Hi[0] = c00 * id; Hi[1] = c01 * id; Hi[2] = c02 * id;
+          Hi[3] = Hi[1]; Hi[4] = (H[0] * H[8] - H[2] * H[6]) * id; Hi[5] = (H[2] * H[3] - H[0] * H[5]) * id;
+          Hi[6] = Hi[2]; Hi[7] = Hi[5]; Hi[8] = (H[0] * H[4] - H[1] * H[3]) * id;
+        }
+#pragma omp parallel
+        {
+          const int nt = omp_get_num_threads(), tn = omp_get_thread_num();
+          const int lo = (int)((int64_t)C.nsv * tn / nt), hi = (int)((int64_t)C.nsv * (tn + 1) / nt); /* shot variables this thread owns */
+          /* camera-side blocks from observations: the shot block and the (camera, shot) block belong to the shot's owner */
+          for (int64_t o = 0; o < M; o++) {
+            const int s = P->obs_shot[o];
+            const int sv = C.shot_var[s], cv = C.cam_var[P->shot_camera[s]];
+            if (sv < lo || sv >= hi) continue;
+            const double *Jc = C.Jc + 12 * o, *Jk = C.Jk + 6 * o;
+            for (int i = 0; i < 6; i++)
+              for (int j = 0; j <= i; j++)
+                SKY(6 * sv + i, 6 * sv + j) += (Jc[i] * Jc[j] + Jc[6 + i] * Jc[6 + j]) * sc_red[6 * sv + i] * sc_red[6 * sv + j];
+            if (cv >= 0) {
+              const int b = cam0 + 3 * cv;
+              for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 6; j++)
+                  SKY(b + i, 6 * sv + j) += (Jk[i] * Jc[j] + Jk[3 + i] * Jc[6 + j]) * sc_red[b + i] * sc_red[6 * sv + j];
+            }
+          }
+          for (int s = 0; s < S; s++) {
+            const int sv = C.shot_var[s];
+            if (sv < lo || sv >= hi) continue;
+            if (P->shot_gps && P->shot_gps_sigma && P->shot_gps_sigma[s] > 0) {
+              const double w = 1.0 / P->shot_gps_sigma[s];
+              for (int k = 0; k < 3; k++) SKY(6 * sv + 3 + k, 6 * sv + 3 + k) += w * w * sc_red[6 * sv + 3 + k] * sc_red[6 * sv + 3 + k];
+            }
+          }
+          for (int s = 0; s < S; s++) {
+            const int sv = C.shot_var[s];
+            if (sv < lo || sv >= hi) continue;
+            if (P->shot_up && P->shot_up_sigma && P->shot_up_sigma[s] > 0) {
+              const double *J = C.up_J + 9 * s;
+              for (int i = 0; i < 3; i++)
+                for (int j = 0; j <= i; j++)
+                  SKY(6 * sv + i, 6 * sv + j) += (J[i] * J[j] + J[3 + i] * J[3 + j] + J[6 + i] * J[6 + j]) * sc_red[6 * sv + i] * sc_red[6 * sv + j];
+            }
+          }
+          for (int i = 6 * lo; i < 6 * hi; i++) SKY(i, i) += Dred[i] / radius;
+          /* eliminate points: entries with a shot row belong to the owner of that shot, (camera, shot) entries to the owner of the
+           * shot of the COLUMN; (p, qa, qb) are walked in the serial order */
+          for (int p = 0; p < NP; p++) {
+            if (P->point_fixed && P->point_fixed[p]) continue;
+            const int64_t q0 = C.pt_off[p], q1 = C.pt_off[p + 1];
+            int mine = 0;
+            for (int64_t q = q0; q < q1 && !mine; q++) {
+              const int sv = C.shot_var[P->obs_shot[C.pt_obs[q]]];
+              mine = sv >= lo && sv < hi;
+            }
+            if (!mine) continue;
+            const double *Hi = Hpp_inv + 9 * (size_t)p;
+            double gp[3], Hg[3];
+            for (int i = 0; i < 3; i++) gp[i] = -g_pt[3 * p + i] * sc_pt[3 * p + i];
+            for (int i = 0; i < 3; i++) Hg[i] = Hi[3 * i] * gp[0] + Hi[3 * i + 1] * gp[1] + Hi[3 * i + 2] * gp[2];
+            for (int64_t qa = q0; qa < q1; qa++) {
+              const int64_t oa = C.pt_obs[qa];
+              const int sa = P->obs_shot[oa];
+              const int sva = C.shot_var[sa], cva = C.cam_var[P->shot_camera[sa]];
+              const int own_a = sva >= lo && sva < hi;
+              const double *Jpa = C.Jp + 6 * oa, *Jca = C.Jc + 12 * oa, *Jka = C.Jk + 6 * oa;
+              double Wa[9][3], WH[9][3];
+              int ia[9], na = 0;
+              if (sva >= 0)
+                for (int i = 0; i < 6; i++) {
+                  for (int j = 0; j < 3; j++) Wa[na][j] = (Jca[i] * Jpa[j] + Jca[6 + i] * Jpa[3 + j]) * sc_red[6 * sva + i] * sc_pt[3 * p + j];
+                  ia[na++] = 6 * sva + i;
+                }
+              if (cva >= 0)
+                for (int i = 0; i < 3; i++) {
+                  for (int j = 0; j < 3; j++) Wa[na][j] = (Jka[i] * Jpa[j] + Jka[3 + i] * Jpa[3 + j]) * sc_red[cam0 + 3 * cva + i] * sc_pt[3 * p + j];
+                  ia[na++] = cam0 + 3 * cva + i;
+                }
+              for (int i = 0; i < na; i++) {
+                for (int j = 0; j < 3; j++) WH[i][j] = Wa[i][0] * Hi[j] + Wa[i][1] * Hi[3 + j] + Wa[i][2] * Hi[6 + j];
+                if (ia[i] < cam0 && own_a) rhs[ia[i]] -= Wa[i][0] * Hg[0] + Wa[i][1] * Hg[1] + Wa[i][2] * Hg[2];
+              }
+              for (int64_t qb = q0; qb < q1; qb++) {
+                const int64_t ob = C.pt_obs[qb];
+                const int sb = P->obs_shot[ob];
+                const int svb = C.shot_var[sb];
+                if (svb < 0) continue; /* only shot columns here: camera columns are the camera x camera block below */
+                const int own_b = svb >= lo && svb < hi;
+                if (!own_a && !own_b) continue;
+                const double *Jpb = C.Jp + 6 * ob, *Jcb = C.Jc + 12 * ob;
+                double Wb[6][3];
+                for (int i = 0; i < 6; i++)
+                  for (int j = 0; j < 3; j++) Wb[i][j] = (Jcb[i] * Jpb[j] + Jcb[6 + i] * Jpb[3 + j]) * sc_red[6 * svb + i] * sc_pt[3 * p + j];
+                for (int i = 0; i < na; i++) {
+                  const int cam_row = ia[i] >= cam0;
+                  if (cam_row ? !own_b : !own_a) continue;
+                  for (int j = 0; j < 6; j++)
+                    if (6 * svb + j <= ia[i]) SKY(ia[i], 6 * svb + j) -= WH[i][0] * Wb[j][0] + WH[i][1] * Wb[j][1] + WH[i][2] * Wb[j][2];
+                }
+              }
+            }
+          }
+        }
+        if (ncc > 0) {
+          /* camera x camera block and the camera rows of the right-hand side: fixed chunks, summed in chunk order */
+#pragma omp parallel for schedule(dynamic, 1)
+          for (int ch = 0; ch < KCH; ch++) {
+            double *a1 = part1 + (size_t)ch * (size_t)(ncc2 + 1);
+            for (int64_t o = M * ch / KCH; o < M * (ch + 1) / KCH; o++) {
+              const int cv = C.cam_var[P->shot_camera[P->obs_shot[o]]];
+              if (cv < 0) continue;
+              const double *Jk = C.Jk + 6 * o;
+              const int b = cam0 + 3 * cv;
+              for (int i = 0; i < 3; i++)
+                for (int j = 0; j <= i; j++)
+                  a1[(3 * cv + i) * ncc + 3 * cv + j] += (Jk[i] * Jk[j] + Jk[3 + i] * Jk[3 + j]) * sc_red[b + i] * sc_red[b + j];
+            }
+            double *a2 = part2 + (size_t)ch * (size_t)(ncc2 + ncc + 1);
+            for (int p = (int)((int64_t)NP * ch / KCH); p < (int)((int64_t)NP * (ch + 1) / KCH); p++) {
+              if (P->point_fixed && P->point_fixed[p]) continue;
+              const double *Hi = Hpp_inv + 9 * (size_t)p;
+              double gp[3], Hg[3];
+              for (int i = 0; i < 3; i++) gp[i] = -g_pt[3 * p + i] * sc_pt[3 * p + i];
+              for (int i = 0; i < 3; i++) Hg[i] = Hi[3 * i] * gp[0] + Hi[3 * i + 1] * gp[1] + Hi[3 * i + 2] * gp[2];
+              const int64_t q0 = C.pt_off[p], q1 = C.pt_off[p + 1];
+              for (int64_t qa = q0; qa < q1; qa++) {
+                const int64_t oa = C.pt_obs[qa];
+                const int cva = C.cam_var[P->shot_camera[P->obs_shot[oa]]];
+                if (cva < 0) continue;
+                const double *Jpa = C.Jp + 6 * oa, *Jka = C.Jk + 6 * oa;
+                double Wa[3][3], WH[3][3];
+                for (int i = 0; i < 3; i++) {
+                  for (int j = 0; j < 3; j++) Wa[i][j] = (Jka[i] * Jpa[j] + Jka[3 + i] * Jpa[3 + j]) * sc_red[cam0 + 3 * cva + i] * sc_pt[3 * p + j];
+                  for (int j = 0; j < 3; j++) WH[i][j] = Wa[i][0] * Hi[j] + Wa[i][1] * Hi[3 + j] + Wa[i][2] * Hi[6 + j];
+                  a2[ncc2 + 3 * cva + i] += Wa[i][0] * Hg[0] + Wa[i][1] * Hg[1] + Wa[i][2] * Hg[2];
+                }
+                for (int64_t qb = q0; qb < q1; qb++) {
+                  const int64_t ob = C.pt_obs[qb];
+                  const int cvb = C.cam_var[P->shot_camera[P->obs_shot[ob]]];
+                  if (cvb < 0 || cvb > cva) continue;
+                  const double *Jpb = C.Jp + 6 * ob, *Jkb = C.Jk + 6 * ob;
+                  for (int j = 0; j < 3; j++) {
+                    double wb[3];
+                    for (int c = 0; c < 3; c++) wb[c] = (Jkb[j] * Jpb[c] + Jkb[3 + j] * Jpb[3 + c]) * sc_red[cam0 + 3 * cvb + j] * sc_pt[3 * p + c];
+                    for (int i = 0; i < 3; i++)
+                      if (3 * cvb + j <= 3 * cva + i) a2[(3 * cva + i) * ncc + 3 * cvb + j] += WH[i][0] * wb[0] + WH[i][1] * wb[1] + WH[i][2] * wb[2];
+                  }
+                }
+              }
+            }
+          }
+          for (int ch = 0; ch < KCH; ch++)
+            for (int i = 0; i < ncc; i++)
+              for (int j = 0; j <= i; j++) SKY(cam0 + i, cam0 + j) += part1[(size_t)ch * (size_t)(ncc2 + 1) + (size_t)i * ncc + j];
+          for (int c = 0; c < NC; c++) {
+            const int cv = C.cam_var[c];
+            if (cv < 0) continue;
+            const double *v = cams + 3 * c, *sg = P->cam_sigma + 3 * c;
+            const double j[3] = {1.0 / fmax(sg[0], eps), 1.0 / fmax(sg[1], eps), 1.0 / fmax(sg[2], eps) / v[2]};
+            for (int k = 0; k < 3; k++) SKY(cam0 + 3 * cv + k, cam0 + 3 * cv + k) += j[k] * j[k] * sc_red[cam0 + 3 * cv + k] * sc_red[cam0 + 3 * cv + k];
+          }
+          for (int i = cam0; i < nred; i++) SKY(i, i) += Dred[i] / radius;
+          for (int ch = 0; ch < KCH; ch++) {
+            const double *a2 = part2 + (size_t)ch * (size_t)(ncc2 + ncc + 1);
+            for (int i = 0; i < ncc; i++) {
+              for (int j = 0; j <= i; j++) SKY(cam0 + i, cam0 + j) -= a2[(size_t)i * ncc + j];
+              rhs[cam0 + i] -= a2[ncc2 + i];
+            }
+          }
+        }
+        free(part1);
+        free(part2);
+      } else {
       for (int64_t i = 0; i < A.off[nred]; i++) A.v[i] = 0;
       for (int i = 0; i < nred; i++) rhs[i] = -g_red[i] * sc_red[i];
       /* camera-side blocks from observations */
@@ -899,6 +1105,7 @@ int oracle_ba_solve(ba_problem *P, const ba_options *O, ba_report *Rp) {
                 }
           }
         }
+      }
       }
       /* factor + solve */
       double *dx = d_red;

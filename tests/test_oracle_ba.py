@@ -174,3 +174,30 @@ def test_full_intrinsics_jacobian_matches_golden(oracle_lib):
         assert Jk.shape == want.shape and np.abs(Jk - want).max() <= 1e-11 * max(1.0, np.abs(want).max()), c["model"]
         used += 1
     assert used == 9
+
+
+def test_parallel_schur_elimination_reproduces_the_serial_one(oracle_lib):
+    """The all-cores elimination (every entry of the reduced system owned by one thread, contributions in the serial order; only the
+    camera x camera block and the camera rows of the right-hand side from fixed-chunk partial sums) against the serial loops, and its
+    independence of the thread count: identical bits for 1, 3 and all threads."""
+    from opensfm_amd import synthetic
+
+    pr = synthetic.make_ba_scene(60, 3000, 6, seed=5)
+    kw = dict(max_iterations=6, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
+    n_all = oracle_lib.num_threads()
+    try:
+        oracle_lib.ba_set_parallel(False)
+        serial = oracle_lib.ba_solve(pr, **kw)
+        oracle_lib.ba_set_parallel(True)
+        runs = []
+        for nt in (1, 3, n_all):
+            oracle_lib.set_num_threads(nt)
+            runs.append(oracle_lib.ba_solve(pr, **kw))
+    finally:
+        oracle_lib.set_num_threads(n_all)
+        oracle_lib.ba_set_parallel(True)
+    for r in runs[1:]:
+        assert np.array_equal(r["points"], runs[0]["points"]) and np.array_equal(r["shot_pose"], runs[0]["shot_pose"])
+        assert np.allclose(r["cost_history"], runs[0]["cost_history"], rtol=1e-13)  # the cost itself is an OpenMP reduction
+    assert np.allclose(serial["cost_history"], runs[0]["cost_history"], rtol=1e-11)
+    assert np.abs(serial["points"] - runs[0]["points"]).max() < 1e-9 and np.abs(serial["shot_pose"] - runs[0]["shot_pose"]).max() < 1e-9
