@@ -51,6 +51,47 @@ def build_camera_ref(force: bool = False) -> Optional[str]:
     return so if os.path.exists(so) else None
 
 
+def build_hahog_ref(force: bool = False) -> Optional[str]:
+    """oracle/_ref/libhahog_ref.so: the reference's features::hahog (features/src/hahog.cc) compiled unmodified from /root/reference
+    with the vendored vlfeat sources it calls (ref_adapters/hahog_ref.cc, stand-ins for its pybind11 types under ref_adapters/stubs)."""
+    so = os.path.join(_HERE, "_ref", "libhahog_ref.so")
+    if os.path.isdir(REFERENCE_ROBUST):
+        deps = [os.path.join(_HERE, "ref_adapters", "hahog_ref.cc"), os.path.join(_HERE, "ref_adapters", "stubs", "foundation", "python_types.h")]
+        if force or not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+            subprocess.check_call(["make", "-C", _HERE, "-B", "_ref/libhahog_ref.so"], stdout=subprocess.DEVNULL)
+    return so if os.path.exists(so) else None
+
+
+_HAHOGREF = None
+
+
+def hahog_ref(image: np.ndarray, peak_threshold: float, edge_threshold: float, target_num_features: int):
+    """The REFERENCE's pyfeatures.hahog(image, peak_threshold, edge_threshold, target_num_features) (features/src/hahog.cc:125-206 over
+    vlfeat's covdet / sift), image float32 in [0, 1]: (points n x 4 [x, y, size, angle in degrees], descriptors n x 128 float32), or
+    None where the compiled reference is not available."""
+    global _HAHOGREF
+    if _HAHOGREF is None:
+        so = build_hahog_ref()
+        if so is None:
+            return None
+        _HAHOGREF = C.CDLL(so)
+        _HAHOGREF.hahog_ref.restype = C.c_long
+        _HAHOGREF.hahog_ref.argtypes = [C.POINTER(C.c_float), C.c_long, C.c_long, C.c_float, C.c_float, C.c_int, C.POINTER(C.c_float),
+                                        C.POINTER(C.c_float), C.c_long]
+    im = np.ascontiguousarray(image, np.float32)
+    cap = max(16, 4 * max(1, int(target_num_features)) if target_num_features else 1 << 20)
+    while True:
+        pts = np.zeros((cap, 4), np.float32)
+        desc = np.zeros((cap, 128), np.float32)
+        n = _HAHOGREF.hahog_ref(_p(im, C.c_float), im.shape[0], im.shape[1], peak_threshold, edge_threshold, int(target_num_features),
+                                _p(pts, C.c_float), _p(desc, C.c_float), cap)
+        if n < 0:
+            return None
+        if n <= cap:
+            return pts[:n].copy(), desc[:n].copy()
+        cap = int(n)
+
+
 _CAMREF = None
 
 

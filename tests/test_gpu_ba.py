@@ -186,7 +186,7 @@ def test_grid_topology_matches_oracle(oracle_lib, gpu_ctx):
     pr = synthetic.make_ba_scene_grid(12, 30, 6000, 9, seed=4)
     g = bundle.bundle_arrays(pr, {"bundle_max_iterations": 8}, **NO_TOL)
     o = oracle_lib.ba_solve(pr, max_iterations=8, **NO_TOL)
-    assert min(g["shot_bandwidth"], g["shot_bandwidth_input"]) > 15
+    assert g["shot_bandwidth"] > 15  # no renumbering brings a 2-D block under the band the preconditioner holds
     assert np.allclose(g["cost_history"], o["cost_history"], rtol=1e-7)
     assert abs(_rmse_px(g["reproj_err"]) - _rmse_px(o["reproj_err"])) < 1e-4
 
