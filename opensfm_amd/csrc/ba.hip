@@ -30,6 +30,8 @@ using namespace osfm_ba;
 
 namespace {
 
+constexpr int kCoopObs = 256;  // observations per workgroup of the cooperative per-track kernels (mat-vec, point gradient)
+
 template <bool JAC>
 __device__ __forceinline__ void project_obs(int model, const double *X, const double *pose, const double *R, const double *dR,
                                             const double *cam, double ox, double oy, double inv_sigma, double *res,
@@ -216,6 +218,7 @@ struct Dev {
   double *cLi, *cLit;       // inverse of the diagonal Cholesky factors and its transpose
   // block cyclic reduction of the cluster-tridiagonal system (parallel replacement of the chain)
   double *bD, *bE, *bG, *bH;  // ncl x ncd^2 each: D / Dinv, coupling to the left neighbour, Dinv*E, Dinv*E_right^T
+  double *bD2, *bGt, *bHt;    // the right neighbours' share of D (D = bD + bD2 until the cluster is eliminated); G^T, H^T
   double *bx;                 // ncl x ncd work vector
   double *zc;       // nred (unscaled J^T w)
   double *y;        // nred
@@ -278,6 +281,25 @@ __global__ void __launch_bounds__(TPB) eval_kernel(Dev d, const double *cams, co
         for (int i = 0; i < 12; i++) JA(o, 8 + i) = wt * Jc[i];
 #pragma unroll
         for (int i = 0; i < 6; i++) JA(o, 20 + i) = wt * Jk[i];
+        if (d.Epm) {  // E_o = Jc_o^T Jp_o (6 x 3) of the corrected blocks, 144 contiguous bytes per observation: the band assembly's operand
+          double jp[6];
+#pragma unroll
+          for (int j = 0; j < 6; j++) jp[j] = wt * Jp[j];
+          double2 *dst = reinterpret_cast<double2 *>(d.Epm + 18 * o);
+#pragma unroll
+          for (int i = 0; i < 6; i += 2) {
+            const double a0 = wt * Jc[i], b0 = wt * Jc[6 + i], a1 = wt * Jc[i + 1], b1 = wt * Jc[7 + i];
+            double e[6];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+              e[j] = a0 * jp[j] + b0 * jp[3 + j];
+              e[3 + j] = a1 * jp[j] + b1 * jp[3 + j];
+            }
+            dst[3 * (i / 2)] = make_double2(e[0], e[1]);
+            dst[3 * (i / 2) + 1] = make_double2(e[2], e[3]);
+            dst[3 * (i / 2) + 2] = make_double2(e[4], e[5]);
+          }
+        }
       }
     }
   }
@@ -355,33 +377,64 @@ __global__ void prior_cost_kernel(Dev d, const double *cams, const double *poses
   if (threadIdx.x == 0) out[0] += v[0];
 }
 
-// per point: gradient and J^T J block (unscaled, corrected Jacobian)
-__global__ void __launch_bounds__(TPB) point_grad_kernel(Dev d) {
-  const int p = blockIdx.x * TPB + threadIdx.x;
-  if (p >= d.P) return;
-  double g[3] = {0, 0, 0}, H[6] = {0, 0, 0, 0, 0, 0};
-  if (!(d.point_fixed && d.point_fixed[p])) {
-    for (long o = d.pt_off[p]; o < d.pt_off[p + 1]; o++) {
-      const double r0 = JA(o, 0), r1 = JA(o, 1);
-      double a[3], b[3];
+// per point: gradient and J^T J block (unscaled, corrected Jacobian).  Same partition as the Schur mat-vec: a workgroup owns a run of
+// whole tracks with at most kCoopObs observations; thread per observation reads its blocks (SoA: coalesced) and leaves the nine
+// products in LDS, thread per point adds its track's in observation order.  (A thread per point walking its track in global memory
+// read 64-byte pieces ten observations apart: 0.43 ms at configs[4] for 320 MB.)
+__global__ void __launch_bounds__(kCoopObs) point_grad_kernel(Dev d) {
+  __shared__ double c[9][kCoopObs];
+  const int tid = threadIdx.x;
+  const int p0 = d.wg_pt[blockIdx.x], p1 = d.wg_pt[blockIdx.x + 1];
+  const long o0 = d.pt_off[p0], o1 = d.pt_off[p1];
+  auto products = [&](long o, double (&v)[9]) {
+    const double r0 = JA(o, 0), r1 = JA(o, 1);
+    double a[3], b[3];
 #pragma unroll
-      for (int j = 0; j < 3; j++) {
-        a[j] = JA(o, 2 + j);
-        b[j] = JA(o, 5 + j);
-        g[j] += a[j] * r0 + b[j] * r1;
-      }
-      H[0] += a[0] * a[0] + b[0] * b[0];
-      H[1] += a[0] * a[1] + b[0] * b[1];
-      H[2] += a[0] * a[2] + b[0] * b[2];
-      H[3] += a[1] * a[1] + b[1] * b[1];
-      H[4] += a[1] * a[2] + b[1] * b[2];
-      H[5] += a[2] * a[2] + b[2] * b[2];
+    for (int j = 0; j < 3; j++) {
+      a[j] = JA(o, 2 + j);
+      b[j] = JA(o, 5 + j);
+      v[j] = a[j] * r0 + b[j] * r1;
     }
+    v[3] = a[0] * a[0] + b[0] * b[0];
+    v[4] = a[0] * a[1] + b[0] * b[1];
+    v[5] = a[0] * a[2] + b[0] * b[2];
+    v[6] = a[1] * a[1] + b[1] * b[1];
+    v[7] = a[1] * a[2] + b[1] * b[2];
+    v[8] = a[2] * a[2] + b[2] * b[2];
+  };
+  if (o1 - o0 <= kCoopObs) {
+    if (tid < o1 - o0) {
+      double v[9];
+      products(o0 + tid, v);
+#pragma unroll
+      for (int q = 0; q < 9; q++) c[q][tid] = v[q];
+    }
+    __syncthreads();
+    const int p = p0 + tid;
+    if (p >= p1) return;
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (!(d.point_fixed && d.point_fixed[p]))
+      for (int k = (int)(d.pt_off[p] - o0); k < (int)(d.pt_off[p + 1] - o0); k++)
+#pragma unroll
+        for (int q = 0; q < 9; q++) acc[q] += c[q][k];
+#pragma unroll
+    for (int j = 0; j < 3; j++) d.g_pt[3 * (long)p + j] = acc[j];
+#pragma unroll
+    for (int j = 0; j < 6; j++) d.Hpp[6 * (long)p + j] = acc[3 + j];
+  } else if (tid == 0) {  // one track longer than the tile
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (!(d.point_fixed && d.point_fixed[p0]))
+      for (long o = o0; o < o1; o++) {
+        double v[9];
+        products(o, v);
+#pragma unroll
+        for (int q = 0; q < 9; q++) acc[q] += v[q];
+      }
+#pragma unroll
+    for (int j = 0; j < 3; j++) d.g_pt[3 * (long)p0 + j] = acc[j];
+#pragma unroll
+    for (int j = 0; j < 6; j++) d.Hpp[6 * (long)p0 + j] = acc[3 + j];
   }
-#pragma unroll
-  for (int j = 0; j < 3; j++) d.g_pt[3 * (long)p + j] = g[j];
-#pragma unroll
-  for (int j = 0; j < 6; j++) d.Hpp[6 * (long)p + j] = H[j];
 }
 
 // per shot (one wavefront): gradient, J^T J block, partials of the camera block
@@ -695,30 +748,6 @@ __device__ __forceinline__ void jred_jp(const Dev &d, long k, double E[6][3]) { 
     for (int j = 0; j < 3; j++) E[i][j] = a * jp[j] + b * jp[3 + j];
   }
 }
-// E_o for every observation in point-major order, 144 contiguous bytes each: the inner loop of
-// the band assembly walks a track and reads them as one short burst per observation.
-__global__ void __launch_bounds__(TPB) epm_kernel(Dev d) {
-  const long o = (long)blockIdx.x * TPB + threadIdx.x;
-  if (o >= d.M) return;
-  double jp[6];
-#pragma unroll
-  for (int j = 0; j < 6; j++) jp[j] = JA(o, 2 + j);
-  double2 *dst = reinterpret_cast<double2 *>(d.Epm + 18 * o);
-#pragma unroll
-  for (int i = 0; i < 6; i += 2) {
-    const double a0 = JA(o, 8 + i), b0 = JA(o, 14 + i), a1 = JA(o, 9 + i), b1 = JA(o, 15 + i);
-    double e[6];
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-      e[j] = a0 * jp[j] + b0 * jp[3 + j];
-      e[3 + j] = a1 * jp[j] + b1 * jp[3 + j];
-    }
-    dst[3 * (i / 2)] = make_double2(e[0], e[1]);
-    dst[3 * (i / 2) + 1] = make_double2(e[2], e[3]);
-    dst[3 * (i / 2) + 2] = make_double2(e[4], e[5]);
-  }
-}
-
 // Band assembly: one workgroup per shot s builds the blocks (s, s - dk), dk = 0 .. bw:
 //   S_(s, s2) -= sum over the points p seen by both of  (E_o Hhat_p) E_o2^T,   o / o2 = the observations of p in s / s2.
 // Thread per observation of s, its track's E rows gathered from the point-major array, products added into LDS with fp64 atomics
@@ -1133,338 +1162,423 @@ __global__ void __launch_bounds__(64) ctri_inverse_kernel(Dev d) {
 //   kept j:        D_j -= E_j H_{j-st} + E_{j+st}^T G_{j+st},   E_j <- -E_j G_{j-st}
 //   solve down:    b_j -= H_{j-st}^T b_{j-st} + G_{j+st}^T b_{j+st}
 //   solve up:      x_i  = Dinv_i b_i - G_i x_{i-st} - H_i x_{i+st}
-template <int CS>
-__device__ void dense_chol_inverse(double *A, double *X, int tid, int &bad) {
-  // A (n x n, SPD, LDS) -> Cholesky factor in place (lower), X = inverse of the factor (lower)
-  constexpr int n = 6 * CS;
-#pragma unroll 1
-  for (int kb = 0; kb < CS; kb++) {
-    const int k0 = 6 * kb;
-    double L[21], Li[21];
+// ---- one launch per level (round 3) -----------------------------------------------------------------------------------
+// The workgroup of the eliminated cluster i does everything that depends on D_i alone:
+//   [D_i | E_i | E_r^T]  ->  [Dinv_i | G_i | H_i]   by in-place block Gauss-Jordan with 6 x 6 pivots (D_i is SPD: every pivot block is a
+//                            Schur complement of it, no pivoting needed); one 6 x 6 tile of the n x 3n array per thread, CS steps of
+//                            two barriers each -- the former Cholesky + triangular inverse + X^T X + two products were 114 us of
+//                            mostly serial work per level, and the neighbours' update a second launch
+//   D_{i+st} -= E_r H_i      into bD  (this workgroup is the only LEFT neighbour of i + st on this level)
+//   D_{i-st} -= E_i^T G_i    into bD2 (... the only RIGHT neighbour of i - st): D_j = bD[j] + bD2[j], summed when j is loaded,
+//                            so the two contributions need neither atomics nor a second launch and the sum is reproducible
+//   E_{i+st} <- -E_r G_i     the new coupling of i + st to i - st
+// G and H are also kept transposed (bGt, bHt): the solve's up sweep then reads columns, coalesced, like its down sweep.
+__device__ __forceinline__ void inv6_spd(double (&a)[6][6], int &bad) {
 #pragma unroll
-    for (int i = 0; i < 6; i++)
+  for (int c = 0; c < 6; c++) {
+    const double p = a[c][c];
+    if (!(p > 0)) bad = 1;
+    const double ip = 1.0 / p;
 #pragma unroll
-      for (int j = 0; j <= i; j++) {
-        double sum = A[(k0 + i) * n + k0 + j];
+    for (int j = 0; j < 6; j++) a[c][j] = (j == c) ? ip : a[c][j] * ip;
 #pragma unroll
-        for (int q = 0; q < j; q++) sum -= L[i * (i + 1) / 2 + q] * L[j * (j + 1) / 2 + q];
-        if (i == j) {
-          if (!(sum > 0)) { bad = 1; sum = 1.0; }
-          L[i * (i + 1) / 2 + i] = sqrt(sum);
-        } else {
-          L[i * (i + 1) / 2 + j] = sum / L[j * (j + 1) / 2 + j];
-        }
-      }
+    for (int r = 0; r < 6; r++) {
+      if (r == c) continue;
+      const double f = a[r][c];
 #pragma unroll
-    for (int cc = 0; cc < 6; cc++)
-#pragma unroll
-      for (int rr = cc; rr < 6; rr++) {
-        double sum = (rr == cc) ? 1.0 : 0.0;
-#pragma unroll
-        for (int q = cc; q < rr; q++) sum -= L[rr * (rr + 1) / 2 + q] * Li[q * (q + 1) / 2 + cc];
-        Li[rr * (rr + 1) / 2 + cc] = sum / L[rr * (rr + 1) / 2 + rr];
-      }
-    __syncthreads();
-    if (tid < 36) {
-      const int i = tid / 6, j = tid % 6;
-      A[(k0 + i) * n + k0 + j] = (j <= i) ? L[i * (i + 1) / 2 + j] : 0.0;
+      for (int j = 0; j < 6; j++) a[r][j] = (j == c) ? -f * ip : __builtin_fma(-f, a[c][j], a[r][j]);
     }
-    for (int row = k0 + 6 + tid; row < n; row += 256) {
-      double a[6], pnew[6];
-#pragma unroll
-      for (int q = 0; q < 6; q++) a[q] = A[row * n + k0 + q];
-#pragma unroll
-      for (int j = 0; j < 6; j++) {
-        double sum = 0;
-#pragma unroll
-        for (int q = 0; q <= j; q++) sum += a[q] * Li[j * (j + 1) / 2 + q];
-        pnew[j] = sum;
-      }
-#pragma unroll
-      for (int q = 0; q < 6; q++) A[row * n + k0 + q] = pnew[q];
-    }
-    __syncthreads();
-    const int m = n - k0 - 6;
-    for (int t = tid; t < m * m; t += 256) {
-      const int a = t / m, b = t - a * m;
-      if (b <= a) {
-        const double *pr = A + (k0 + 6 + a) * n + k0, *pq = A + (k0 + 6 + b) * n + k0;
-        A[(k0 + 6 + a) * n + k0 + 6 + b] -= ((pr[0] * pq[0] + pr[1] * pq[1]) + (pr[2] * pq[2] + pr[3] * pq[3])) + (pr[4] * pq[4] + pr[5] * pq[5]);
-      }
-    }
-    __syncthreads();
-  }
-  if (tid < n) {
-    const int cc = tid;
-    for (int r = 0; r < n; r++) {
-      if (r >= cc) {
-        double s0 = 0, s1 = 0;
-        int q = cc;
-        for (; q + 1 < r; q += 2) {
-          s0 += A[r * n + q] * X[q * n + cc];
-          s1 += A[r * n + q + 1] * X[(q + 1) * n + cc];
-        }
-        if (q < r) s0 += A[r * n + q] * X[q * n + cc];
-        X[r * n + cc] = (((r == cc) ? 1.0 : 0.0) - (s0 + s1)) / A[r * n + r];
-      } else {
-        X[r * n + cc] = 0.0;
-      }
-    }
-  }
-  __syncthreads();
-}
-
-// acc (6 x 3 tile at rows 6 tr.., columns 3 tq..) += sum_{v >= v0} A(r, v) B(v, q) with both n x n operands in LDS; TA / TB: the operand is
-// stored transposed.  One tile per thread (n = 6 CS: CS x 2 CS tiles <= 200 threads): 9 LDS reads per 18 multiply-adds instead of the
-// 36 of an element-per-thread product -- the dense products of the cyclic reduction are LDS-bandwidth bound.
-template <int n, bool TA, bool TB>
-__device__ __forceinline__ void tile_mac(const double *A, const double *B, int tr, int tq, int v0, double (&acc)[6][3]) {
-#pragma unroll 2
-  for (int v = v0; v < n; v++) {
-    double a[6], b[3];
-#pragma unroll
-    for (int i = 0; i < 6; i++) a[i] = TA ? A[v * n + 6 * tr + i] : A[(6 * tr + i) * n + v];
-#pragma unroll
-    for (int c = 0; c < 3; c++) b[c] = TB ? B[(3 * tq + c) * n + v] : B[v * n + 3 * tq + c];
-#pragma unroll
-    for (int i = 0; i < 6; i++)
-#pragma unroll
-      for (int c = 0; c < 3; c++) acc[i][c] += a[i] * b[c];
   }
 }
-#define OSFM_TILE_ZERO(acc)          \
-  _Pragma("unroll") for (int i_ = 0; i_ < 6; i_++) _Pragma("unroll") for (int c_ = 0; c_ < 3; c_++) acc[i_][c_] = 0.0;
-
+#ifdef OSFM_BCR_UBENCH
+__device__ int osfm_bcr_variant;
+#define OSFM_BCR_SKIP(bit) (osfm_bcr_variant & (bit))
+#else
+#define OSFM_BCR_SKIP(bit) false
+#endif
 template <int CS>
-__global__ void __launch_bounds__(256) bcr_elim_kernel(Dev d, int st, int root, int *status) {
+struct BcrShape {
+  static constexpr int n = 6 * CS, W = 3 * n, n2 = n * n;
+  static constexpr int tiles = 3 * CS * CS;                 // 6 x 6 tiles of the augmented array = threads that own one
+  static constexpr int threads = (tiles + 63) / 64 * 64;
+  static constexpr size_t lds_bytes = (size_t)5 * n2 * sizeof(double);  // n x 3n + the two original couplings
+};
+template <int CS>
+__global__ void __launch_bounds__(BcrShape<CS>::threads) bcr_level_kernel(Dev d, int st, int root, int *status) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  constexpr int n = 6 * CS, n2 = n * n;
-  double *B0 = lds, *B1 = lds + n2, *B2 = lds + 2 * n2;
+  constexpr int n = BcrShape<CS>::n, W = BcrShape<CS>::W, n2 = BcrShape<CS>::n2, T = BcrShape<CS>::threads;
+  double *Aug = lds, *Ei = lds + n * W, *Er = Ei + n2;
   const int tid = threadIdx.x;
   const int i = root ? 0 : (2 * blockIdx.x + 1) * st;
   if (i >= d.ncl) return;
-  int bad = 0;
-  for (int t = tid; t < n2; t += 256) B0[t] = d.bD[(long)i * n2 + t];
-  __syncthreads();
-  dense_chol_inverse<CS>(B0, B1, tid, bad);
-  // Dinv = X^T X  (X lower triangular, zeros above the diagonal): Dinv[r][q] = sum_{v >= max(r,q)} X[v][r] X[v][q]
-  constexpr int ntq = n / 3, ntile = (n / 6) * ntq;
-  const bool has_tile = tid < ntile;
-  const int tr = tid / ntq, tq = tid - tr * ntq;
-  double acc[6][3];
-  if (has_tile) {
-    OSFM_TILE_ZERO(acc)
-    tile_mac<n, true, false>(B1, B1, tr, tq, 6 * tr > 3 * tq ? 6 * tr : 3 * tq, acc);
+  const bool hasL = !root && i - st >= 0, hasR = !root && i + st < d.ncl;
+  {
+    // every global load of this workgroup is issued before the first LDS write (the blocks were written by the previous launch,
+    // mostly on another XCD: each dependent round trip is a microsecond)
+    const double *gD = d.bD + (long)i * n2, *gD2 = d.bD2 + (long)i * n2;
+    const double *gEi = d.bE + (long)i * n2, *gEr = d.bE + (long)(hasR ? i + st : i) * n2;
+    constexpr int NL = (n2 + T - 1) / T;
+    double vD[NL], vE[NL], vR[NL];
 #pragma unroll
-    for (int i = 0; i < 6; i++)
-#pragma unroll
-      for (int c = 0; c < 3; c++) B2[(6 * tr + i) * n + 3 * tq + c] = acc[i][c];
-  }
-  __syncthreads();
-  for (int t = tid; t < n2; t += 256) {
-    B0[t] = B2[t];
-    d.bD[(long)i * n2 + t] = B2[t];
-  }
-  __syncthreads();
-  if (bad) *status = 1;
-  if (root) return;
-  // G = Dinv * E_i
-  if (i - st >= 0) {
-    for (int t = tid; t < n2; t += 256) B1[t] = d.bE[(long)i * n2 + t];
-    __syncthreads();
-    if (has_tile) {
-      OSFM_TILE_ZERO(acc)
-      tile_mac<n, false, false>(B0, B1, tr, tq, 0, acc);
-#pragma unroll
-      for (int ii = 0; ii < 6; ii++)
-#pragma unroll
-        for (int c = 0; c < 3; c++) d.bG[(long)i * n2 + (6 * tr + ii) * n + 3 * tq + c] = acc[ii][c];
-    }
-    __syncthreads();
-  }
-  // H = Dinv * E_r^T,  r = i + st
-  if (i + st < d.ncl) {
-    for (int t = tid; t < n2; t += 256) B1[t] = d.bE[(long)(i + st) * n2 + t];
-    __syncthreads();
-    if (has_tile) {
-      OSFM_TILE_ZERO(acc)
-      tile_mac<n, false, true>(B0, B1, tr, tq, 0, acc);
-#pragma unroll
-      for (int ii = 0; ii < 6; ii++)
-#pragma unroll
-        for (int c = 0; c < 3; c++) d.bH[(long)i * n2 + (6 * tr + ii) * n + 3 * tq + c] = acc[ii][c];
-    }
-  }
-}
-
-template <int CS>
-__global__ void __launch_bounds__(256) bcr_update_kernel(Dev d, int st) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  constexpr int n = 6 * CS, n2 = n * n;
-  constexpr int ntq = n / 3, ntile = (n / 6) * ntq;
-  double *B0 = lds, *B1 = lds + n2;
-  const int tid = threadIdx.x;
-  const int j = 2 * blockIdx.x * st;
-  if (j >= d.ncl) return;
-  const int i1 = j - st, i2 = j + st;
-  const bool has_tile = tid < ntile;
-  const int tr = tid / ntq, tq = tid - tr * ntq;
-  double dacc[6][3];
-  OSFM_TILE_ZERO(dacc)
-  if (i1 >= 0) {
-    for (int t = tid; t < n2; t += 256) {
-      B0[t] = d.bE[(long)j * n2 + t];
-      B1[t] = d.bH[(long)i1 * n2 + t];
-    }
-    __syncthreads();
-    if (has_tile) tile_mac<n, false, false>(B0, B1, tr, tq, 0, dacc);  // E_j H_{i1}
-    __syncthreads();
-    if (i1 - st >= 0) {  // new coupling to j - 2 st:  E_j <- -E_j G_{i1}
-      for (int t = tid; t < n2; t += 256) B1[t] = d.bG[(long)i1 * n2 + t];
-      __syncthreads();
-      if (has_tile) {
-        double e[6][3];
-        OSFM_TILE_ZERO(e)
-        tile_mac<n, false, false>(B0, B1, tr, tq, 0, e);
-#pragma unroll
-        for (int ii = 0; ii < 6; ii++)
-#pragma unroll
-          for (int c = 0; c < 3; c++) d.bE[(long)j * n2 + (6 * tr + ii) * n + 3 * tq + c] = -e[ii][c];
+    for (int u = 0; u < NL; u++) {
+      const int t = tid + u * T;
+      const bool in = t < n2;
+      if (OSFM_BCR_SKIP(8)) {
+        vD[u] = (t / n == t % n) ? 4.0 : 0.01;
+        vE[u] = vR[u] = 0.02;
+        continue;
       }
-      __syncthreads();
+      vD[u] = in ? gD[t] + gD2[t] : 0.0;
+      vE[u] = (in && hasL) ? gEi[t] : 0.0;
+      vR[u] = (in && hasR) ? gEr[t] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < NL; u++) {
+      const int t = tid + u * T;
+      if (t < n2) {
+        const int r = t / n, c = t - r * n;
+        Aug[r * W + c] = vD[u];
+        Ei[t] = vE[u];
+        Er[t] = vR[u];
+        Aug[r * W + n + c] = vE[u];
+        Aug[c * W + 2 * n + r] = vR[u];
+      }
     }
   }
-  if (i2 < d.ncl) {
-    for (int t = tid; t < n2; t += 256) {
-      B0[t] = d.bE[(long)i2 * n2 + t];
-      B1[t] = d.bG[(long)i2 * n2 + t];
-    }
-    __syncthreads();
-    if (has_tile) tile_mac<n, true, false>(B0, B1, tr, tq, 0, dacc);  // (E_{i2}^T G_{i2})[r][q] = sum_v E[v][r] G[v][q]
-  }
+  __syncthreads();
+  const bool has_tile = tid < BcrShape<CS>::tiles;
+  const int tr = tid / (3 * CS), tq = tid - tr * (3 * CS);
+  int bad = 0;
+  double own[6][6];  // this thread's tile stays in registers over the steps (LDS keeps the copy the other threads read)
   if (has_tile) {
 #pragma unroll
-    for (int ii = 0; ii < 6; ii++)
+    for (int r = 0; r < 6; r++)
 #pragma unroll
-      for (int c = 0; c < 3; c++) d.bD[(long)j * n2 + (6 * tr + ii) * n + 3 * tq + c] -= dacc[ii][c];
+      for (int c = 0; c < 6; c++) own[r][c] = Aug[(6 * tr + r) * W + 6 * tq + c];
+  }
+#pragma unroll 1
+  for (int k = OSFM_BCR_SKIP(1) ? CS : 0; k < CS; k++) {
+    if (has_tile) {
+      double nr[6][6];  // the pivot block row after scaling, this tile's columns (the pivot block itself becomes Pinv)
+      {
+        double P[6][6];
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+          for (int b = 0; b < 6; b++) P[a][b] = Aug[(6 * k + a) * W + 6 * k + b];
+        inv6_spd(P, bad);
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+          for (int c = 0; c < 6; c++) nr[a][c] = 0.0;
+#pragma unroll
+        for (int b = 0; b < 6; b++) {
+          double pr[6];
+#pragma unroll
+          for (int c = 0; c < 6; c++) pr[c] = Aug[(6 * k + b) * W + 6 * tq + c];
+#pragma unroll
+          for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int c = 0; c < 6; c++) nr[a][c] = __builtin_fma(P[a][b], pr[c], nr[a][c]);
+        }
+        if (tq == k) {
+#pragma unroll
+          for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int c = 0; c < 6; c++) nr[a][c] = P[a][c];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 6; r++) {
+        double m[6];
+#pragma unroll
+        for (int b = 0; b < 6; b++) m[b] = Aug[(6 * tr + r) * W + 6 * k + b];
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+          double acc = (tq == k) ? 0.0 : own[r][c];
+#pragma unroll
+          for (int b = 0; b < 6; b++) acc = __builtin_fma(-m[b], nr[b][c], acc);
+          own[r][c] = (tr == k) ? nr[r][c] : acc;
+        }
+      }
+    }
+    __syncthreads();
+    if (has_tile) {
+#pragma unroll
+      for (int r = 0; r < 6; r++)
+#pragma unroll
+        for (int c = 0; c < 6; c++) Aug[(6 * tr + r) * W + 6 * tq + c] = own[r][c];
+    }
+    __syncthreads();
+  }
+  if (bad) *status = 1;
+  if (!OSFM_BCR_SKIP(2)) {
+    double *oD = d.bD + (long)i * n2, *oG = d.bG + (long)i * n2, *oH = d.bH + (long)i * n2;
+    double *oGt = d.bGt + (long)i * n2, *oHt = d.bHt + (long)i * n2;
+    for (int t = tid; t < n2; t += T) {
+      const int r = t / n, c = t - r * n;
+      oD[t] = Aug[r * W + c];
+      if (hasL) {
+        oG[t] = Aug[r * W + n + c];
+        oGt[t] = Aug[c * W + n + r];
+      }
+      if (hasR) {
+        oH[t] = Aug[r * W + 2 * n + c];
+        oHt[t] = Aug[c * W + 2 * n + r];
+      }
+    }
+  }
+  if (root || OSFM_BCR_SKIP(4)) return;
+  // the three products for the neighbours: CS x CS tiles each, one per thread; the results go through LDS (the augmented array is
+  // free by then) so that the read-modify-write of the neighbours' blocks is coalesced
+  const int which = tid / (CS * CS), tl = tid - which * (CS * CS), pr = tl / CS, pc = tl - pr * CS;
+  const bool act = has_tile && !((which == 0 && !hasR) || (which == 1 && !hasL) || (which == 2 && !(hasL && hasR)));
+  double acc[6][6];
+  if (act) {
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+      for (int b = 0; b < 6; b++) acc[a][b] = 0.0;
+    const int ycol = (which == 0 ? 2 * n : n) + 6 * pc;
+#pragma unroll 2
+    for (int v = 0; v < n; v++) {
+      double x[6], y[6];
+#pragma unroll
+      for (int a = 0; a < 6; a++) x[a] = (which == 1) ? Ei[v * n + 6 * pr + a] : Er[(6 * pr + a) * n + v];
+#pragma unroll
+      for (int b = 0; b < 6; b++) y[b] = Aug[v * W + ycol + b];
+#pragma unroll
+      for (int a = 0; a < 6; a++)
+#pragma unroll
+        for (int b = 0; b < 6; b++) acc[a][b] = __builtin_fma(x[a], y[b], acc[a][b]);
+    }
+  }
+  __syncthreads();
+  if (act) {
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+      for (int b = 0; b < 6; b++) Aug[which * n2 + (6 * pr + a) * n + 6 * pc + b] = acc[a][b];
+  }
+  __syncthreads();
+  if (hasR) {
+    double *dD = d.bD + (long)(i + st) * n2;
+    for (int t = tid; t < n2; t += T) dD[t] -= Aug[t];
+  }
+  if (hasL) {
+    double *dD2 = d.bD2 + (long)(i - st) * n2;
+    for (int t = tid; t < n2; t += T) dD2[t] -= Aug[n2 + t];
+  }
+  if (hasL && hasR) {
+    double *dE = d.bE + (long)(i + st) * n2;
+    for (int t = tid; t < n2; t += T) dE[t] = -Aug[2 * n2 + t];
   }
 }
 
-// assembled band -> level-0 BCR blocks (D symmetric full, E = coupling to the previous cluster)
-__global__ void bcr_scatter_kernel(Dev d) {
-  const int s = blockIdx.x;
-  const int R1 = d.bw + 1;
-  const long n2 = (long)d.ncd * d.ncd;
-  for (int t = threadIdx.x; t < R1 * 36; t += blockDim.x) {
-    const int k = t / 36, ij = t % 36, i = ij / 6, j = ij % 6;
-    const int s2 = s - k;
-    if (s2 < 0) continue;
-    const double val = d.band[((long)s * R1 + k) * 36 + ij];
-    const int c = s / d.cs, c2 = s2 / d.cs;
-    const int rl = 6 * s + i - c * d.ncd;
-    if (c2 == c) {
-      const int cl = 6 * s2 + j - c * d.ncd;
-      d.bD[c * n2 + (long)rl * d.ncd + cl] = val;
-      if (k > 0) d.bD[c * n2 + (long)cl * d.ncd + rl] = val;
-    } else {
-      const int cl = 6 * s2 + j - c2 * d.ncd;
-      d.bE[c * n2 + (long)rl * d.ncd + cl] = val;
+// assembled band -> level-0 blocks, one workgroup per cluster (gather: every entry of D, D2 = 0 and E is written, nothing to clear first)
+__global__ void __launch_bounds__(256) bcr_build_kernel(Dev d, int *status) {
+  const int c = blockIdx.x, n = d.ncd, R1 = d.bw + 1;
+  const long n2 = (long)n * n;
+  if (c == 0 && threadIdx.x == 0) *status = 0;
+  for (int t = threadIdx.x; t < n2; t += 256) {
+    const int rl = t / n, cl = t - rl * n;
+    const int s = c * d.cs + rl / 6, i = rl % 6, s2 = c * d.cs + cl / 6, j = cl % 6;
+    double v, e = 0.0;
+    if (s >= d.S || s2 >= d.S)
+      v = (rl == cl) ? 1.0 : 0.0;  // identity on the padding rows of the last cluster
+    else {
+      const int k = s - s2;
+      v = k >= 0 ? (k <= d.bw ? d.band[((long)s * R1 + k) * 36 + i * 6 + j] : 0.0) : (-k <= d.bw ? d.band[((long)s2 * R1 - k) * 36 + j * 6 + i] : 0.0);
     }
+    if (c > 0 && s < d.S) {
+      const int ke = s - ((c - 1) * d.cs + cl / 6);
+      if (ke <= d.bw) e = d.band[((long)s * R1 + ke) * 36 + i * 6 + j];
+    }
+    d.bD[c * n2 + t] = v;
+    d.bD2[c * n2 + t] = 0.0;
+    d.bE[c * n2 + t] = e;
   }
-}
-__global__ void bcr_pad_kernel(Dev d) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  const int first = 6 * d.S - (d.ncl - 1) * d.ncd;
-  if (p >= first && p < d.ncd) d.bD[(long)(d.ncl - 1) * d.ncd * d.ncd + (long)p * d.ncd + p] = 1.0;
 }
 
 // ---- BCR solve: one 64-lane workgroup per cluster, dense mat-vecs from global (L2) ----
-__device__ __forceinline__ double rowdot(const double *M, int n, int r, const double *x) {  // (M x)[r]
-  double a0 = 0, a1 = 0;
-  for (int q = 0; q + 1 < n; q += 2) {
-    a0 += M[r * n + q] * x[q];
-    a1 += M[r * n + q + 1] * x[q + 1];
+// sum_k (M_k^T x_k)[r] for up to three n x n blocks (n even, <= 64; a null block contributes nothing; x_k has 64 entries, zero from n
+// on).  The loads of a 16-row chunk of every block are issued before the first multiply: the sweeps are chains of L2 round trips, and
+// a plain dot-product loop waits for one of them per pair of rows (27 per block).  Per block the products are added in the order
+// (even rows) + (odd rows).
+template <int K>
+__device__ __forceinline__ void coldots(const double *const (&M)[K], const double *const (&x)[K], int n, int r, double (&out)[K]) {
+  double a0[K], a1[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) a0[k] = a1[k] = 0.0;
+  for (int q0 = 0; q0 < n; q0 += 16) {
+    double m[K][16];
+#pragma unroll
+    for (int k = 0; k < K; k++)
+#pragma unroll
+      for (int u = 0; u < 16; u++) m[k][u] = (M[k] && q0 + u < n) ? M[k][(q0 + u) * n + r] : 0.0;
+#pragma unroll
+    for (int k = 0; k < K; k++)
+#pragma unroll
+      for (int u = 0; u < 16; u += 2) {
+        a0[k] += m[k][u] * x[k][q0 + u];
+        a1[k] += m[k][u + 1] * x[k][q0 + u + 1];
+      }
   }
-  return a0 + a1;  // n is even
-}
-__device__ __forceinline__ double coldot(const double *M, int n, int r, const double *x) {  // (M^T x)[r]
-  double a0 = 0, a1 = 0;
-  for (int q = 0; q + 1 < n; q += 2) {
-    a0 += M[q * n + r] * x[q];
-    a1 += M[(q + 1) * n + r] * x[q + 1];
-  }
-  return a0 + a1;
+#pragma unroll
+  for (int k = 0; k < K; k++) out[k] = a0[k] + a1[k];
 }
 // The solve kernels take several right-hand sides at once (grid y = right-hand side q; vectors rin + q * rin_stride, z + q * z_stride,
 // work vector bx + q * ncl * ncd): the columns of the camera border go through one walk of the levels instead of one walk each.
-// (A single persistent launch for the whole walk was measured and dropped: cross-XCD synchronisation inside a kernel -- agent-scope
-// fences ~60 us, an arrival counter ~25 us, per-cluster progress words with sc1 accesses ~25 us per level -- costs more than the
-// 5-10 us of a back-to-back launch on this part.)
-__global__ void bcr_load_kernel(Dev d, const double *rin, long rin_stride) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x, q = blockIdx.y;
-  if (g < d.ncl * d.ncd) d.bx[(long)q * d.ncl * d.ncd + g] = g < 6 * d.S ? rin[q * rin_stride + g] : 0.0;
+// (A single persistent launch for the whole walk was measured and dropped in round 2: cross-XCD synchronisation inside a kernel --
+// agent-scope fences ~60 us, an arrival counter ~25 us, per-cluster progress words with sc1 accesses ~25 us per level -- costs more
+// than the 5-10 us of a back-to-back launch on this part.)  Round 3: the levels that have at most kMidWaves clusters left run inside
+// ONE workgroup (bcr_mid_kernel, a wavefront per cluster, __syncthreads between levels: no cross-XCD traffic at all), the first down
+// level reads the right-hand side itself and the last up level writes the result: 2 log2(N) + 3 launches become 2 log2(st0) + 1.
+__device__ __forceinline__ double bcr_rhs(const Dev &d, const double *rin, int cl, int r) {  // entry r of cluster cl of the padded rhs
+  const long g = (long)cl * d.ncd + r;
+  return g < 6L * d.S ? rin[g] : 0.0;
 }
-__global__ void __launch_bounds__(64) bcr_down_kernel(Dev d, int st) {
+// first: b comes from rin (and the odd clusters' part is copied into bx on the way)
+__global__ void __launch_bounds__(64) bcr_down_kernel(Dev d, int st, const double *rin, long rin_stride) {
   __shared__ double xl[64], xr[64];
   const int n = d.ncd, n2 = n * n, r = threadIdx.x;
   const int j = 2 * blockIdx.x * st;
   if (j >= d.ncl) return;
   double *bx = d.bx + (long)blockIdx.y * d.ncl * n;
   const int i1 = j - st, i2 = j + st;
-  xl[r] = (i1 >= 0 && r < n) ? bx[(long)i1 * n + r] : 0.0;
-  xr[r] = (i2 < d.ncl && r < n) ? bx[(long)i2 * n + r] : 0.0;
+  if (rin) {
+    const double *b = rin + blockIdx.y * rin_stride;
+    xl[r] = (i1 >= 0 && r < n) ? bcr_rhs(d, b, i1, r) : 0.0;
+    xr[r] = (i2 < d.ncl && r < n) ? bcr_rhs(d, b, i2, r) : 0.0;
+    if (i2 < d.ncl && r < n) bx[(long)i2 * n + r] = xr[r];
+  } else {
+    xl[r] = (i1 >= 0 && r < n) ? bx[(long)i1 * n + r] : 0.0;
+    xr[r] = (i2 < d.ncl && r < n) ? bx[(long)i2 * n + r] : 0.0;
+  }
   __syncthreads();
   if (r < n) {
-    double v = bx[(long)j * n + r];
-    if (i1 >= 0) v -= coldot(d.bH + (long)i1 * n2, n, r, xl);
-    if (i2 < d.ncl) v -= coldot(d.bG + (long)i2 * n2, n, r, xr);
+    double v = rin ? bcr_rhs(d, rin + blockIdx.y * rin_stride, j, r) : bx[(long)j * n + r];
+    const double *const Ms[2] = {i1 >= 0 ? d.bH + (long)i1 * n2 : nullptr, i2 < d.ncl ? d.bG + (long)i2 * n2 : nullptr};
+    const double *const xs2[2] = {xl, xr};
+    double t[2];
+    coldots<2>(Ms, xs2, n, r, t);
+    v -= t[0];
+    v -= t[1];
     bx[(long)j * n + r] = v;
   }
 }
-__global__ void __launch_bounds__(64) bcr_up_kernel(Dev d, int st, int root) {
+// last (z given): the result goes to z, the even clusters' part is copied along, and (cam_rows) the camera rows get their 3x3 blocks
+__global__ void __launch_bounds__(64) bcr_up_kernel(Dev d, int st, const double *rin, double *z, long z_stride, int cam_rows) {
   __shared__ double xs[64], xl[64], xr[64];
   const int n = d.ncd, n2 = n * n, r = threadIdx.x;
-  const int i = root ? 0 : (2 * blockIdx.x + 1) * st;
-  if (i >= d.ncl) return;
+  const int i = (2 * blockIdx.x + 1) * st;
   double *bx = d.bx + (long)blockIdx.y * d.ncl * n;
+  double *zq = z ? z + blockIdx.y * z_stride : nullptr;
   const int l = i - st, rr = i + st;
+  if (zq) {
+    if (l < d.ncl && r < n && (long)l * n + r < 6L * d.S) zq[(long)l * n + r] = bx[(long)l * n + r];
+    if (cam_rows) {
+      const int g = blockIdx.x * 64 + r;
+      if (g < d.NC) {
+        const double *Bi = d.Binv + 36 * (long)d.S + 9 * g, *rc = rin + d.cam0 + 3 * g;
+        for (int q = 0; q < 3; q++) zq[d.cam0 + 3 * g + q] = Bi[3 * q] * rc[0] + Bi[3 * q + 1] * rc[1] + Bi[3 * q + 2] * rc[2];
+      }
+    }
+  }
+  if (i >= d.ncl) return;
   xs[r] = r < n ? bx[(long)i * n + r] : 0.0;
-  xl[r] = (!root && l >= 0 && r < n) ? bx[(long)l * n + r] : 0.0;
-  xr[r] = (!root && rr < d.ncl && r < n) ? bx[(long)rr * n + r] : 0.0;
+  xl[r] = (l >= 0 && r < n) ? bx[(long)l * n + r] : 0.0;
+  xr[r] = (rr < d.ncl && r < n) ? bx[(long)rr * n + r] : 0.0;
   __syncthreads();
   if (r < n) {
-    double v = rowdot(d.bD + (long)i * n2, n, r, xs);
-    if (!root && l >= 0) v -= rowdot(d.bG + (long)i * n2, n, r, xl);
-    if (!root && rr < d.ncl) v -= rowdot(d.bH + (long)i * n2, n, r, xr);
-    bx[(long)i * n + r] = v;
+    const double *const Ms[3] = {d.bD + (long)i * n2, l >= 0 ? d.bGt + (long)i * n2 : nullptr, rr < d.ncl ? d.bHt + (long)i * n2 : nullptr};
+    const double *const xs3[3] = {xs, xl, xr};
+    double t[3];
+    coldots<3>(Ms, xs3, n, r, t);  // Dinv is symmetric
+    const double v = (t[0] - t[1]) - t[2];
+    if (zq) {
+      if ((long)i * n + r < 6L * d.S) zq[(long)i * n + r] = v;
+    } else
+      bx[(long)i * n + r] = v;
   }
 }
-// cam_rows: also the camera rows of z (3x3 block Jacobi), single right-hand side
-__global__ void bcr_store_kernel(Dev d, const double *rin, double *z, long z_stride, int cam_rows) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x, q = blockIdx.y;
-  if (g < 6 * d.S) z[q * z_stride + g] = d.bx[(long)q * d.ncl * d.ncd + g];
-  if (cam_rows && g < d.NC) {
-    const double *Bi = d.Binv + 36 * (long)d.S + 9 * g, *rr = rin + d.cam0 + 3 * g;
-    for (int i = 0; i < 3; i++) z[d.cam0 + 3 * g + i] = Bi[3 * i] * rr[0] + Bi[3 * i + 1] * rr[1] + Bi[3 * i + 2] * rr[2];
+constexpr int kMidWaves = 16;
+__global__ void __launch_bounds__(64 * kMidWaves) bcr_mid_kernel(Dev d, int st0) {
+  __shared__ double xs[kMidWaves][64], xl[kMidWaves][64], xr[kMidWaves][64];
+  const int n = d.ncd, n2 = n * n, N = d.ncl;
+  const int r = threadIdx.x & 63, w = threadIdx.x >> 6;
+  double *bx = d.bx + (long)blockIdx.y * N * n;
+  int st = st0;
+  for (; st < N; st *= 2) {
+    const int ne = (N + 2 * st - 1) / (2 * st);
+    for (int b0 = 0; b0 < ne; b0 += kMidWaves) {
+      const int j = 2 * (b0 + w) * st, i1 = j - st, i2 = j + st;
+      const bool on = j < N;
+      if (on) {
+        xl[w][r] = (i1 >= 0 && r < n) ? bx[(long)i1 * n + r] : 0.0;
+        xr[w][r] = (i2 < N && r < n) ? bx[(long)i2 * n + r] : 0.0;
+      }
+      __syncthreads();
+      if (on && r < n) {
+        double v = bx[(long)j * n + r];
+        const double *const Ms[2] = {i1 >= 0 ? d.bH + (long)i1 * n2 : nullptr, i2 < N ? d.bG + (long)i2 * n2 : nullptr};
+        const double *const xs2[2] = {xl[w], xr[w]};
+        double t[2];
+        coldots<2>(Ms, xs2, n, r, t);
+        v -= t[0];
+        v -= t[1];
+        bx[(long)j * n + r] = v;
+      }
+      __syncthreads();
+    }
+  }
+  if (w == 0) xs[0][r] = r < n ? bx[r] : 0.0;
+  __syncthreads();
+  if (w == 0 && r < n) {
+    const double *const Ms[1] = {d.bD};
+    const double *const xs1[1] = {xs[0]};
+    double t[1];
+    coldots<1>(Ms, xs1, n, r, t);
+    bx[r] = t[0];
+  }
+  __syncthreads();
+  for (st /= 2; st >= st0; st /= 2) {
+    const int ne = (N + 2 * st - 1) / (2 * st);
+    for (int b0 = 0; b0 < ne; b0 += kMidWaves) {
+      const int i = (2 * (b0 + w) + 1) * st, l = i - st, rr = i + st;
+      const bool on = i < N;
+      if (on) {
+        xs[w][r] = r < n ? bx[(long)i * n + r] : 0.0;
+        xl[w][r] = (l >= 0 && r < n) ? bx[(long)l * n + r] : 0.0;
+        xr[w][r] = (rr < N && r < n) ? bx[(long)rr * n + r] : 0.0;
+      }
+      __syncthreads();
+      if (on && r < n) {
+        const double *const Ms[3] = {d.bD + (long)i * n2, l >= 0 ? d.bGt + (long)i * n2 : nullptr, rr < N ? d.bHt + (long)i * n2 : nullptr};
+        const double *const xs3[3] = {xs[w], xl[w], xr[w]};
+        double t[3];
+        coldots<3>(Ms, xs3, n, r, t);
+        bx[(long)i * n + r] = (t[0] - t[1]) - t[2];
+      }
+      __syncthreads();
+    }
   }
 }
 
-typedef void (*bcr_elim_fn)(Dev, int, int, int *);
-typedef void (*bcr_update_fn)(Dev, int);
-#define OSFM_CS_SWITCH(FN, cs)     \
-  switch (cs) {                    \
-    case 2: return FN<2>;          \
-    case 3: return FN<3>;          \
-    case 4: return FN<4>;          \
-    case 5: return FN<5>;          \
-    case 6: return FN<6>;          \
-    case 7: return FN<7>;          \
-    case 8: return FN<8>;          \
-    case 9: return FN<9>;          \
-    default: return FN<10>;        \
+typedef void (*bcr_level_fn)(Dev, int, int, int *);
+struct BcrLaunch {
+  bcr_level_fn fn;
+  int threads;
+  size_t lds_bytes;
+};
+#define OSFM_CS_CASE(q) \
+  case q: return BcrLaunch{bcr_level_kernel<q>, BcrShape<q>::threads, BcrShape<q>::lds_bytes};
+inline BcrLaunch bcr_level_for(int cs) {
+  switch (cs) {
+    OSFM_CS_CASE(2) OSFM_CS_CASE(3) OSFM_CS_CASE(4) OSFM_CS_CASE(5) OSFM_CS_CASE(6) OSFM_CS_CASE(7) OSFM_CS_CASE(8) OSFM_CS_CASE(9)
+    default: return BcrLaunch{bcr_level_kernel<10>, BcrShape<10>::threads, BcrShape<10>::lds_bytes};
   }
-inline bcr_elim_fn bcr_elim_for(int cs) { OSFM_CS_SWITCH(bcr_elim_kernel, cs) }
-inline bcr_update_fn bcr_update_for(int cs) { OSFM_CS_SWITCH(bcr_update_kernel, cs) }
+}
 
 // z_shots = (L L^T)^-1 r_shots with the cluster factors; camera rows: 3x3 block Jacobi
 __global__ void __launch_bounds__(256) ctri_solve_kernel(Dev d, const double *rin, double *z) {
@@ -1552,7 +1666,6 @@ __global__ void scale_vec_kernel(const double *sc, const double *x, double *y, i
 // forms t_o and Jp^T t_o; thread-per-point sums its observations from LDS in a fixed order
 // (deterministic) and applies Hhat; thread-per-observation finishes w_o.  A single point with more
 // observations than the tile takes the strided path at the bottom.
-constexpr int kCoopObs = 256;
 // MODE 0: w_o = t_o - Jp_o Hhat sum(Jp^T t),  t_o = Jc_o y_s + Jk_o y_k     (mat-vec)
 // MODE 1: w_o = -Jp_o Hhat (-g_p)                                           (right-hand side)
 // MODE 2: d_pt = Hhat(-g_p - sum(Jp^T t))                                   (back-substitution)
@@ -1752,12 +1865,38 @@ __global__ void dot2_kernel(const double *a, const double *b, const double *c, c
     if (c) *o1 = v[1];
   }
 }
-__global__ void pcg_step1_kernel(double *x, double *r, const double *p, const double *Ap, int n, const double *scal) {
+// start of PCG in one launch: x = 0, r = b, p = z, and the two inner products dot2_kernel(r, z, b, b) would return (same order)
+__global__ void pcg_init_kernel(const double *b, const double *z, double *x, double *r, double *p, int n, double *o_rz, double *o_bb) {
+  __shared__ double lds[32];
+  double v[2] = {0, 0};
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const double bi = b[i], zi = z[i];
+    x[i] = 0.0;
+    r[i] = bi;
+    p[i] = zi;
+    v[0] += bi * zi;
+    v[1] += bi * bi;
+  }
+  block_sum<2>(v, lds);
+  if (threadIdx.x == 0) {
+    *o_rz = v[0];
+    *o_bb = v[1];
+  }
+}
+// also leaves the block's share of r.r in rr_part[block] (summed by the host in block order when it polls: deterministic)
+__global__ void __launch_bounds__(TPB) pcg_step1_kernel(double *x, double *r, const double *p, const double *Ap, int n, const double *scal, double *rr_part) {
+  __shared__ double lds[32];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const double alpha = scal[1] != 0.0 ? scal[0] / scal[1] : 0.0;
-  x[i] += alpha * p[i];
-  r[i] -= alpha * Ap[i];
+  double v[1] = {0.0};
+  if (i < n) {
+    const double alpha = scal[1] != 0.0 ? scal[0] / scal[1] : 0.0;
+    x[i] += alpha * p[i];
+    const double ri = r[i] - alpha * Ap[i];
+    r[i] = ri;
+    v[0] = ri * ri;
+  }
+  block_sum<1>(v, lds);
+  if (threadIdx.x == 0) rr_part[blockIdx.x] = v[0];
 }
 __global__ void precond_apply_kernel(Dev d, const double *r, double *z) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1975,6 +2114,40 @@ __global__ void border_update_kernel(const double *W, double *z, int nb, int n, 
 // camera's three columns only, so all NB = 3 NC columns are formed together: pass A reads Jp and Jk once (t_o is 2 x 3 on the
 // observation's camera columns, u_p = sum Jp^T t and v_p = Hhat u_p are 3 x NB per point, w_o = t_o - Jp v_p is 2 x NB), pass B reads
 // Jc and Jk once.  Same summation orders as schur_point_coop_kernel<0> / schur_shot_kernel column by column.
+// Sigma^-1 = (C - B^T W)^-1 by Gauss-Jordan with partial pivoting (nb <= 6), one lane; *status = 1 when Sigma is singular / not finite
+__global__ void border_sigma_kernel(const double *Cm, const double *dots, double *SigInv, int nb, int *status) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double Sg[36], Inv[36];
+  for (int i = 0; i < nb * nb; i++) {
+    Sg[i] = Cm[i] - dots[i];
+    Inv[i] = 0.0;
+  }
+  for (int i = 0; i < nb; i++) Inv[i * nb + i] = 1.0;
+  int bad = 0;
+  for (int c = 0; c < nb && !bad; c++) {
+    int piv = c;
+    for (int r2 = c + 1; r2 < nb; r2++)
+      if (fabs(Sg[r2 * nb + c]) > fabs(Sg[piv * nb + c])) piv = r2;
+    const double pv = Sg[piv * nb + c];
+    if (!(fabs(pv) > 0) || !(fabs(pv) < 1.0 / 0.0)) { bad = 1; break; }
+    for (int q = 0; q < nb; q++) {
+      const double t0 = Sg[c * nb + q], t1 = Inv[c * nb + q];
+      Sg[c * nb + q] = Sg[piv * nb + q];
+      Sg[piv * nb + q] = t0;
+      Inv[c * nb + q] = Inv[piv * nb + q];
+      Inv[piv * nb + q] = t1;
+    }
+    const double ip = 1.0 / Sg[c * nb + c];
+    for (int q = 0; q < nb; q++) { Sg[c * nb + q] *= ip; Inv[c * nb + q] *= ip; }
+    for (int r2 = 0; r2 < nb; r2++) {
+      if (r2 == c) continue;
+      const double f = Sg[r2 * nb + c];
+      for (int q = 0; q < nb; q++) { Sg[r2 * nb + q] -= f * Sg[c * nb + q]; Inv[r2 * nb + q] -= f * Inv[c * nb + q]; }
+    }
+  }
+  *status = bad;
+  for (int i = 0; i < nb * nb; i++) SigInv[i] = bad ? 0.0 : Inv[i];
+}
 template <int NB>
 __global__ void __launch_bounds__(kCoopObs) border_point_kernel(Dev d, double *wB) {
   constexpr int NC_ = NB / 3;
@@ -2266,8 +2439,8 @@ struct Solver {
 
   void rot(const double *poses) { hipLaunchKernelGGL(shot_rot_kernel, dim3(nblk(d.S, 64)), dim3(64), 0, st, d, poses); }
 
-  // cost (with priors) at (cams, poses, pts); optionally builds the Jacobian.  returns {cost, sumsq}
-  int eval(const double *cams, const double *poses, const double *pts, bool jac, double *cost, double *sumsq) {
+  // cost (with priors) at (cams, poses, pts) into scal[8] (and the sum of squares into scal[9]); optionally builds the Jacobian
+  void eval_enqueue(const double *cams, const double *poses, const double *pts, bool jac) {
     rot(poses);
     const int nb = nblk(d.M);
     if (jac) {
@@ -2278,6 +2451,9 @@ struct Solver {
     }
     hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(1024), 0, st, d.partial, (long)nb, 2, d.scal + 8);
     hipLaunchKernelGGL(prior_cost_kernel, dim3(1), dim3(256), 0, st, d, cams, poses, d.scal + 8, jac ? 1 : 0);
+  }
+  int eval(const double *cams, const double *poses, const double *pts, bool jac, double *cost, double *sumsq) {
+    eval_enqueue(cams, poses, pts, jac);
     OSFM_HIP(hipMemcpyAsync(hscal.data(), d.scal + 8, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
     OSFM_HIP(hipStreamSynchronize(st));
     *cost = hscal[0];
@@ -2285,7 +2461,7 @@ struct Solver {
     return OSFM_OK;
   }
   void gradients() {
-    hipLaunchKernelGGL(point_grad_kernel, dim3(nblk(d.P)), dim3(TPB), 0, st, d);
+    hipLaunchKernelGGL(point_grad_kernel, dim3(d.nwg), dim3(kCoopObs), 0, st, d);
     hipLaunchKernelGGL(shot_grad_kernel, dim3(d.S), dim3(64), 0, st, d, d.poses);
     hipLaunchKernelGGL(cam_reduce_kernel, dim3(d.NC), dim3(TPB), 0, st, d, 9);
     hipLaunchKernelGGL(cam_grad_kernel, dim3(nblk(d.NC, 64)), dim3(64), 0, st, d, d.cams);
@@ -2301,12 +2477,16 @@ struct Solver {
   void bcr_solve_multi(const double *r, long r_stride, double *z, long z_stride, int nrhs, bool cam_rows) {
     const int N = d.ncl;
     const unsigned q = (unsigned)nrhs;
-    hipLaunchKernelGGL(bcr_load_kernel, dim3(nblk((long)N * d.ncd), q), dim3(TPB), 0, st, d, r, r_stride);
-    int stq = 1;
-    for (; stq < N; stq *= 2) hipLaunchKernelGGL(bcr_down_kernel, dim3((N + 2 * stq - 1) / (2 * stq), q), dim3(64), 0, st, d, stq);
-    hipLaunchKernelGGL(bcr_up_kernel, dim3(1, q), dim3(64), 0, st, d, 0, 1);
-    for (stq /= 2; stq >= 1; stq /= 2) hipLaunchKernelGGL(bcr_up_kernel, dim3((N + 2 * stq - 1) / (2 * stq), q), dim3(64), 0, st, d, stq, 0);
-    hipLaunchKernelGGL(bcr_store_kernel, dim3(nblk(6L * d.S), q), dim3(TPB), 0, st, d, r, z, z_stride, cam_rows ? 1 : 0);
+    auto ne = [N](int s) { return (N + 2 * s - 1) / (2 * s); };
+    int st0 = 2;  // from here on at most kMidWaves clusters are left on a level: one workgroup walks those levels down and up again
+    while (ne(st0) > kMidWaves) st0 *= 2;
+    hipLaunchKernelGGL(bcr_down_kernel, dim3(ne(1), q), dim3(64), 0, st, d, 1, r, r_stride);
+    for (int s = 2; s < st0; s *= 2) hipLaunchKernelGGL(bcr_down_kernel, dim3(ne(s), q), dim3(64), 0, st, d, s, (const double *)nullptr, 0L);
+    hipLaunchKernelGGL(bcr_mid_kernel, dim3(1, q), dim3(64 * kMidWaves), 0, st, d, st0);
+    for (int s = st0 / 2; s >= 2; s /= 2)
+      hipLaunchKernelGGL(bcr_up_kernel, dim3(ne(s), q), dim3(64), 0, st, d, s, (const double *)nullptr, (double *)nullptr, 0L, 0);
+    hipLaunchKernelGGL(bcr_up_kernel, dim3(std::max(ne(1), cam_rows ? (d.NC + 63) / 64 : 0), q), dim3(64), 0, st, d, 1, r, z, z_stride,
+                       cam_rows ? 1 : 0);
   }
   void bcr_solve(const double *r, double *z) { bcr_solve_multi(r, 0, z, 0, 1, true); }
   void precond(const double *r, double *z) {
@@ -2566,7 +2746,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     }
   } side_stream{sv};
   if (getenv("OSFM_BA_ONE_STREAM") == nullptr) {  // measurement knob: everything on one stream
-    OSFM_HIP(hipStreamCreateWithFlags(&sv.st2, hipStreamNonBlocking));
+    OSFM_HIP(hipStreamCreateWithFlags(&sv.st2, hipStreamNonBlocking));  // (a low-priority side stream was measured: no difference)
     OSFM_HIP(hipEventCreateWithFlags(&sv.ev_fork, hipEventDisableTiming));
     OSFM_HIP(hipEventCreateWithFlags(&sv.ev_join, hipEventDisableTiming));
   }
@@ -2732,6 +2912,9 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     d.bE = A.alloc<double>(nb, e);
     d.bG = A.alloc<double>(nb, e);
     d.bH = A.alloc<double>(nb, e);
+    d.bD2 = A.alloc<double>(nb, e);
+    d.bGt = A.alloc<double>(nb, e);
+    d.bHt = A.alloc<double>(nb, e);
     d.bx = A.alloc<double>((size_t)6 * d.ncl * d.ncd, e);  // up to 6 right-hand sides at a time (the camera border)
     if (3 * NC <= 6) {  // exact camera border: see border_rhs_kernel
       sv.Bc = A.alloc<double>((size_t)3 * NC * 6 * S, e);
@@ -2772,17 +2955,22 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
   Rp->termination = 0;
   double lin_seconds = 0;
 
+  // after a Jacobian evaluation: gradients, (first time) the Jacobi scaling, the LM diagonal and max |gradient| into scal[10]
+  auto prepare_enqueue = [&]() -> int {
+    sv.gradients();
+    if (!have_scale) {
+      hipLaunchKernelGGL(scale_init_kernel, dim3(nblk(std::max<long>(nred, 3L * NP))), dim3(TPB), 0, st, d);
+      have_scale = true;
+    }
+    hipLaunchKernelGGL(lm_diag_kernel, dim3(nblk(std::max<long>(nred, 3L * NP))), dim3(TPB), 0, st, d);
+    OSFM_HIP(hipMemsetAsync(d.scal + 10, 0, sizeof(double), st));
+    hipLaunchKernelGGL(absmax_kernel, dim3(256), dim3(256), 0, st, d.g_red, (long)nred, d.g_pt, 3L * NP, d.scal + 10);
+    return OSFM_OK;
+  };
   for (;;) {
     if (need_prepare) {
-      sv.gradients();
-      if (d.bw > 0) hipLaunchKernelGGL(epm_kernel, dim3(nblk(M)), dim3(TPB), 0, st, d);
-      if (!have_scale) {
-        hipLaunchKernelGGL(scale_init_kernel, dim3(nblk(std::max<long>(nred, 3L * NP))), dim3(TPB), 0, st, d);
-        have_scale = true;
-      }
-      hipLaunchKernelGGL(lm_diag_kernel, dim3(nblk(std::max<long>(nred, 3L * NP))), dim3(TPB), 0, st, d);
-      OSFM_HIP(hipMemsetAsync(d.scal + 10, 0, sizeof(double), st));
-      hipLaunchKernelGGL(absmax_kernel, dim3(256), dim3(256), 0, st, d.g_red, (long)nred, d.g_pt, 3L * NP, d.scal + 10);
+      const int rcp = prepare_enqueue();
+      if (rcp != OSFM_OK) return rcp;
       OSFM_HIP(hipMemcpyAsync(hs.data(), d.scal + 10, sizeof(double), hipMemcpyDeviceToHost, st));
       OSFM_HIP(hipStreamSynchronize(st));
       gmax = hs[0];
@@ -2797,17 +2985,19 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     // ---- linear solve: PCG on the implicit Schur complement ----
     hipLaunchKernelGGL(point_hhat_kernel, dim3(nblk(NP)), dim3(TPB), 0, st, d, radius);
     sv.use_band = false;
-    if (d.bw > 0) {
-      hipLaunchKernelGGL(band_assemble_kernel, dim3(S), dim3(TPB), 0, st, d, radius);
-      sv.use_ctri = false;
-      sv.use_bcr = false;
-    }
-    // ---- fork: camera-border columns (if this problem uses them) and the right-hand side, concurrently with the factorisation ----
+    // ---- fork: camera-border columns (if this problem uses them) and the right-hand side only need the Jacobian and Hhat: they run on
+    //      the side stream next to the band assembly (a gather that leaves HBM bandwidth unused), so that the cyclic-reduction levels
+    //      -- workgroups that need a whole CU's LDS -- find the CUs free afterwards ----
     const bool want_border = d.bw > 0 && d.ncl > 0 && O->preconditioner == 0 && sv.Bc && border_ok;
     hipStream_t sx = sv.st2 ? sv.st2 : st;
     if (sv.st2) {
       OSFM_HIP(hipEventRecord(sv.ev_fork, st));
       OSFM_HIP(hipStreamWaitEvent(sv.st2, sv.ev_fork, 0));
+    }
+    if (d.bw > 0) {
+      hipLaunchKernelGGL(band_assemble_kernel, dim3(S), dim3(TPB), 0, st, d, radius);
+      sv.use_ctri = false;
+      sv.use_bcr = false;
     }
     if (want_border) {  // all nb columns of B (and of the camera block C) in one pass over the observations
       if (3 * NC == 3) {
@@ -2832,82 +3022,43 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       joined = true;
       return OSFM_OK;
     };
-    if (d.bw > 0) {
-      const int R = d.bw + 1;
-      if (d.ncl > 0 && O->preconditioner == 0) {
-        const size_t n2 = (size_t)d.ncd * d.ncd;
-        const int N = d.ncl;
-        OSFM_HIP(hipMemsetAsync(d.bD, 0, (size_t)N * n2 * sizeof(double), st));
-        OSFM_HIP(hipMemsetAsync(d.bE, 0, (size_t)N * n2 * sizeof(double), st));
-        hipLaunchKernelGGL(bcr_pad_kernel, dim3(1), dim3(64), 0, st, d);
-        hipLaunchKernelGGL(bcr_scatter_kernel, dim3(S), dim3(TPB), 0, st, d);
-        {
-          static OsfmPerDeviceOnce once;
-          const int rca = once.run(ctx->device, []() -> int {
-            for (int q = 2; q <= 10; q++) {
-              OSFM_HIP(hipFuncSetAttribute((const void *)bcr_elim_for(q), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-              OSFM_HIP(hipFuncSetAttribute((const void *)bcr_update_for(q), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            }
-            return OSFM_OK;
-          });
-          if (rca != OSFM_OK) return rca;
-        }
-        OSFM_HIP(hipMemsetAsync(d_status, 0, sizeof(int), st));
-        for (int stq = 1; stq < N; stq *= 2) {
-          const int ne = (N + 2 * stq - 1) / (2 * stq);
-          hipLaunchKernelGGL(bcr_elim_for(d.cs), dim3(ne), dim3(256), 3 * n2 * sizeof(double), st, d, stq, 0, d_status);
-          hipLaunchKernelGGL(bcr_update_for(d.cs), dim3(ne), dim3(256), 2 * n2 * sizeof(double), st, d, stq);
-        }
-        hipLaunchKernelGGL(bcr_elim_for(d.cs), dim3(1), dim3(256), 3 * n2 * sizeof(double), st, d, 1, 1, d_status);
-        int hst = 1;
-        OSFM_HIP(hipMemcpyAsync(&hst, d_status, sizeof(int), hipMemcpyDeviceToHost, st));
-        OSFM_HIP(hipStreamSynchronize(st));
-        sv.use_bcr = (hst == 0);
-        // exact camera border (few cameras, all free): B = S e_j restricted to the shot rows, W = A^-1 B
-        sv.use_border = false;
-        if (sv.use_bcr && sv.Bc && border_ok) {
-          const int nb = 3 * NC, n6 = 6 * S;
-          std::vector<double> Cm((size_t)nb * nb), Sg((size_t)nb * nb);
-          // the columns of B and C were formed on the side stream; W = A^-1 B for all of them in one walk of the levels
-          {
-            const int rcj = join();
-            if (rcj != OSFM_OK) return rcj;
-          }
-          sv.bcr_solve_multi(sv.Bc, n6, sv.Wb, n6, nb, false);
-          OSFM_HIP(hipMemcpyAsync(Cm.data(), sv.dCm, (size_t)nb * nb * sizeof(double), hipMemcpyDeviceToHost, st));
-          hipLaunchKernelGGL(border_dots_kernel, dim3(nb * nb), dim3(TPB), 0, st, sv.Bc, sv.Wb, nb, n6, sv.dots);
-          OSFM_HIP(hipMemcpyAsync(Sg.data(), sv.dots, (size_t)nb * nb * sizeof(double), hipMemcpyDeviceToHost, st));
-          OSFM_HIP(hipStreamSynchronize(st));
-          for (int i = 0; i < nb * nb; i++) Sg[(size_t)i] = Cm[(size_t)i] - Sg[(size_t)i];
-          // Sigma^-1 by Gauss-Jordan with partial pivoting (nb <= 6)
-          std::vector<double> Inv((size_t)nb * nb, 0.0);
-          for (int i = 0; i < nb; i++) Inv[(size_t)i * nb + i] = 1.0;
-          bool ok_inv = true;
-          for (int c = 0; c < nb && ok_inv; c++) {
-            int piv = c;
-            for (int r2 = c + 1; r2 < nb; r2++)
-              if (std::fabs(Sg[(size_t)r2 * nb + c]) > std::fabs(Sg[(size_t)piv * nb + c])) piv = r2;
-            if (!(std::fabs(Sg[(size_t)piv * nb + c]) > 0) || !std::isfinite(Sg[(size_t)piv * nb + c])) { ok_inv = false; break; }
-            for (int q = 0; q < nb; q++) {
-              std::swap(Sg[(size_t)c * nb + q], Sg[(size_t)piv * nb + q]);
-              std::swap(Inv[(size_t)c * nb + q], Inv[(size_t)piv * nb + q]);
-            }
-            const double ip = 1.0 / Sg[(size_t)c * nb + c];
-            for (int q = 0; q < nb; q++) { Sg[(size_t)c * nb + q] *= ip; Inv[(size_t)c * nb + q] *= ip; }
-            for (int r2 = 0; r2 < nb; r2++) {
-              if (r2 == c) continue;
-              const double f = Sg[(size_t)r2 * nb + c];
-              for (int q = 0; q < nb; q++) { Sg[(size_t)r2 * nb + q] -= f * Sg[(size_t)c * nb + q]; Inv[(size_t)r2 * nb + q] -= f * Inv[(size_t)c * nb + q]; }
-            }
-          }
-          if (ok_inv) {
-            OSFM_HIP(hipMemcpyAsync(sv.SigInv, Inv.data(), (size_t)nb * nb * sizeof(double), hipMemcpyHostToDevice, st));
-            OSFM_HIP(hipStreamSynchronize(st));
-            sv.use_border = true;
-          }
-        }
+    // The cyclic reduction (and the camera border on top of it) is issued without asking whether it succeeded: its status words come
+    // back with the first scalars of PCG -- one host round trip for the factorisation, the border and the start of the solve.  When a
+    // status says no (a pivot block that is not positive definite, a singular border) the fallbacks are issued and PCG starts again.
+    const bool try_bcr = d.bw > 0 && d.ncl > 0 && O->preconditioner == 0;
+    const bool try_border = try_bcr && sv.Bc && border_ok;
+    sv.use_bcr = false;
+    sv.use_border = false;
+    if (try_bcr) {
+      const int N = d.ncl;
+      hipLaunchKernelGGL(bcr_build_kernel, dim3(N), dim3(256), 0, st, d, d_status);
+      const BcrLaunch lv = bcr_level_for(d.cs);
+      {
+        static OsfmPerDeviceOnce once;
+        const int rca = once.run(ctx->device, []() -> int {
+          for (int q = 2; q <= 10; q++)
+            OSFM_HIP(hipFuncSetAttribute((const void *)bcr_level_for(q).fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+          return OSFM_OK;
+        });
+        if (rca != OSFM_OK) return rca;
       }
-      if (!sv.use_bcr) {
+      for (int stq = 1; stq < N; stq *= 2)
+        hipLaunchKernelGGL(lv.fn, dim3((N + 2 * stq - 1) / (2 * stq)), dim3(lv.threads), lv.lds_bytes, st, d, stq, 0, d_status);
+      hipLaunchKernelGGL(lv.fn, dim3(1), dim3(lv.threads), lv.lds_bytes, st, d, 1, 1, d_status);
+      sv.use_bcr = true;
+      if (try_border) {  // exact camera border (few cameras, all free): B = S e_j restricted to the shot rows, W = A^-1 B
+        const int nb = 3 * NC, n6 = 6 * S;
+        // the columns of B and C were formed on the side stream; W = A^-1 B for all of them in one walk of the levels
+        const int rcj = join();
+        if (rcj != OSFM_OK) return rcj;
+        sv.bcr_solve_multi(sv.Bc, n6, sv.Wb, n6, nb, false);
+        hipLaunchKernelGGL(border_dots_kernel, dim3(nb * nb), dim3(TPB), 0, st, sv.Bc, sv.Wb, nb, n6, sv.dots);
+        hipLaunchKernelGGL(border_sigma_kernel, dim3(1), dim3(64), 0, st, sv.dCm, sv.dots, sv.SigInv, nb, d_status + 1);
+        sv.use_border = true;
+      }
+    }
+    auto fallback_band = [&]() -> int {  // sequential banded block Cholesky (truncated band, or the cyclic reduction said no)
+      const int R = d.bw + 1;
       {
         static OsfmPerDeviceOnce once;
         const int rca = once.run(ctx->device, []() -> int {
@@ -2939,29 +3090,52 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
         hipLaunchKernelGGL(ctri_inverse_kernel, dim3(d.ncl), dim3(64), 2 * n2 * sizeof(double), st, d);
         sv.use_ctri = true;
       }
-      }
+      return OSFM_OK;
+    };
+    if (d.bw > 0 && !try_bcr) {
+      const int rcf = fallback_band();
+      if (rcf != OSFM_OK) return rcf;
     }
-    // block-Jacobi blocks (6x6 per shot, 3x3 per camera): the fallback preconditioner, and the camera rows of the band
-    // preconditioners -- not needed when the cyclic reduction came out with the exact camera border
     {
       const int rcj = join();  // the right-hand side (and its use of part / camred) is complete
       if (rcj != OSFM_OK) return rcj;
     }
-    if (!(sv.use_bcr && sv.use_border)) {
-      hipLaunchKernelGGL(precond_shot_kernel, dim3(S), dim3(64), 0, st, d, radius);
-      hipLaunchKernelGGL(cam_reduce_kernel, dim3(NC), dim3(TPB), 0, st, d, 6);
-      hipLaunchKernelGGL(precond_cam_kernel, dim3(nblk(NC, 64)), dim3(64), 0, st, d, radius);
+    int hst[2] = {0, 0};
+    auto start_pcg = [&]() -> int {
+      // block-Jacobi blocks (6x6 per shot, 3x3 per camera): the fallback preconditioner, and the camera rows of the band
+      // preconditioners -- not needed when the cyclic reduction came out with the exact camera border
+      if (!(sv.use_bcr && sv.use_border)) {
+        hipLaunchKernelGGL(precond_shot_kernel, dim3(S), dim3(64), 0, st, d, radius);
+        hipLaunchKernelGGL(cam_reduce_kernel, dim3(NC), dim3(TPB), 0, st, d, 6);
+        hipLaunchKernelGGL(precond_cam_kernel, dim3(nblk(NC, 64)), dim3(64), 0, st, d, radius);
+      }
+      sv.precond(d.b, d.z);
+      hipLaunchKernelGGL(pcg_init_kernel, dim3(1), dim3(1024), 0, st, d.b, d.z, d.x, d.r, d.p, nred, d.scal + 0, d.scal + 4);  // x = 0, r = b, p = z
+      OSFM_HIP(hipMemcpyAsync(hs.data(), d.scal, 5 * sizeof(double), hipMemcpyDeviceToHost, st));
+      if (try_bcr) OSFM_HIP(hipMemcpyAsync(hst, d_status, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+      OSFM_HIP(hipStreamSynchronize(st));
+      return OSFM_OK;
+    };
+    {
+      const int rcs = start_pcg();
+      if (rcs != OSFM_OK) return rcs;
     }
-    OSFM_HIP(hipMemsetAsync(d.x, 0, nred * sizeof(double), st));
-    OSFM_HIP(hipMemcpyAsync(d.r, d.b, nred * sizeof(double), hipMemcpyDeviceToDevice, st));
-    sv.precond(d.r, d.z);
-    OSFM_HIP(hipMemcpyAsync(d.p, d.z, nred * sizeof(double), hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(dot2_kernel, dim3(1), dim3(1024), 0, st, d.r, d.z, d.b, d.b, nred, d.scal + 0, d.scal + 4);
-    OSFM_HIP(hipMemcpyAsync(hs.data(), d.scal, 5 * sizeof(double), hipMemcpyDeviceToHost, st));
-    OSFM_HIP(hipStreamSynchronize(st));
+    if (try_bcr && (hst[0] != 0 || (try_border && hst[1] != 0))) {
+      if (hst[0] != 0) {
+        sv.use_bcr = false;
+        sv.use_border = false;
+        const int rcf = fallback_band();
+        if (rcf != OSFM_OK) return rcf;
+      } else {
+        sv.use_border = false;
+      }
+      const int rcs = start_pcg();
+      if (rcs != OSFM_OK) return rcs;
+    }
     const double bb = hs[4];
     bool bad = !(bb == bb) || std::isinf(bb);
     int k = 0;
+    std::vector<double> rr_part((size_t)nbr);
     if (!bad && bb > 0) {
       const double tol2 = O->pcg_tolerance * O->pcg_tolerance * bb;
       const int kmax = O->pcg_max_iterations > 0 ? O->pcg_max_iterations : 1000;
@@ -2969,17 +3143,22 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
         sv.matvec(d.p, d.Ap, radius);
         hipLaunchKernelGGL(dot2_kernel, dim3(1), dim3(1024), 0, st, d.p, d.Ap, (const double *)nullptr, (const double *)nullptr,
                            nred, d.scal + 1, d.scal + 15);
-        hipLaunchKernelGGL(pcg_step1_kernel, dim3(nbr), dim3(TPB), 0, st, d.x, d.r, d.p, d.Ap, nred, d.scal);
+        hipLaunchKernelGGL(pcg_step1_kernel, dim3(nbr), dim3(TPB), 0, st, d.x, d.r, d.p, d.Ap, nred, d.scal, d.partial);
+        // the convergence test comes before the preconditioner is applied to the new residual: the last iteration of a solve does not
+        // pay for a walk of the cyclic reduction whose result nobody reads
+        if ((k & 3) == 0 || k == kmax || (sv.use_border && k <= 2)) {
+          OSFM_HIP(hipMemcpyAsync(rr_part.data(), d.partial, (size_t)nbr * sizeof(double), hipMemcpyDeviceToHost, st));
+          OSFM_HIP(hipStreamSynchronize(st));
+          double rr = 0.0;
+          for (int q = 0; q < nbr; q++) rr += rr_part[(size_t)q];
+          if (!(rr == rr)) { bad = true; break; }
+          if (rr <= tol2) break;
+        }
         sv.precond(d.r, d.z);
-        hipLaunchKernelGGL(dot2_kernel, dim3(1), dim3(1024), 0, st, d.r, d.z, d.r, d.r, nred, d.scal + 2, d.scal + 3);
+        hipLaunchKernelGGL(dot2_kernel, dim3(1), dim3(1024), 0, st, d.r, d.z, (const double *)nullptr, (const double *)nullptr, nred,
+                           d.scal + 2, d.scal + 3);
         hipLaunchKernelGGL(pcg_step2_kernel, dim3(nbr), dim3(TPB), 0, st, d.p, d.z, nred, d.scal);
         hipLaunchKernelGGL(pcg_shift_kernel, dim3(1), dim3(1), 0, st, d.scal);
-        if ((k & 3) == 0 || k == kmax || (sv.use_border && k <= 2)) {
-          OSFM_HIP(hipMemcpyAsync(hs.data(), d.scal, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
-          OSFM_HIP(hipStreamSynchronize(st));
-          if (!(hs[3] == hs[3])) { bad = true; break; }
-          if (hs[3] <= tol2) break;
-        }
       }
       Rp->pcg_iterations_total += k;
     }
@@ -2991,20 +3170,21 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     hipLaunchKernelGGL(candidate_kernel, dim3(1), dim3(1024), 0, st, d, d.y, d.scal + 16);
     hipLaunchKernelGGL(candidate_points_kernel, dim3(nblk(3L * NP)), dim3(TPB), 0, st, d);
     hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(1024), 0, st, d.partial, (long)nblk(3L * NP), 2, d.scal + 20);
-    OSFM_HIP(hipMemcpyAsync(hs.data(), d.scal + 16, 6 * sizeof(double), hipMemcpyDeviceToHost, st));
+    // the candidate's cost is evaluated before the host has seen the model change: one round trip for both (an invalid step -- rare --
+    // has then paid for an evaluation it does not use)
+    sv.eval_enqueue(d.cams_n, d.poses_n, d.pts_n, false);
+    OSFM_HIP(hipMemcpyAsync(hs.data(), d.scal + 8, 14 * sizeof(double), hipMemcpyDeviceToHost, st));  // scal[8..21]
     OSFM_HIP(hipStreamSynchronize(st));
     lin_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_lin).count();
-    const double model_change = hs[0];
-    const double step_sq = hs[1] + hs[4], x_sq = hs[2] + hs[5];
+    const double model_change = hs[8];
+    const double step_sq = hs[9] + hs[12], x_sq = hs[10] + hs[13];
     if (bad || !(model_change > 0)) {  // HandleInvalidStep + StepIsInvalid
       radius *= 0.5;
       if (++n_invalid >= 5) { Rp->termination = -1; break; }
       continue;
     }
     n_invalid = 0;
-    double cost_n = 0;
-    rc = sv.eval(d.cams_n, d.poses_n, d.pts_n, false, &cost_n, nullptr);
-    if (rc != OSFM_OK) return rc;
+    const double cost_n = hs[0];
     const double step_norm = std::sqrt(step_sq), x_norm = std::sqrt(x_sq);
     if (step_norm <= O->parameter_tolerance * (x_norm + O->parameter_tolerance)) { Rp->termination = 3; break; }
     const double cost_change = cost - cost_n;
@@ -3021,9 +3201,14 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       radius = std::fmin(1e16, radius);
       decrease_factor = 2.0;
       Rp->successful_steps++;
-      rc = sv.eval(d.cams, d.poses, d.pts, true, &cost, &sumsq);
+      sv.eval_enqueue(d.cams, d.poses, d.pts, true);  // cost, sum of squares and max |gradient| come back together
+      rc = prepare_enqueue();
       if (rc != OSFM_OK) return rc;
-      need_prepare = true;
+      OSFM_HIP(hipMemcpyAsync(hs.data(), d.scal + 8, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+      OSFM_HIP(hipStreamSynchronize(st));
+      cost = hs[0];
+      sumsq = hs[1];
+      gmax = hs[2];
     } else {  // StepRejected
       radius = radius / decrease_factor;
       decrease_factor *= 2.0;
