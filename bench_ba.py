@@ -32,7 +32,9 @@ def lm_iteration_line(g: dict, nobs: int) -> dict:
 
 def run_grid(ctx, rows: int = 50, cols: int = 100, points: int = 500000, track: int = 9, iters: int = 10, seed: int = 42) -> dict:
     """The same size on a NON-sequence topology: a rows x cols block survey, shots numbered line after line, every
-    point seen from ~3 lines -- co-visibility half-width ~2 x cols in shot order, far above what the banded preconditioner holds."""
+    point seen from ~3 lines -- co-visibility half-width ~2 x cols in shot order.  The solver renumbers the shots by a sweep along the
+    block's long side (~2 x rows) and factorises the exact band directly (block LDL^T, ba.hip wide_*); the truncated 15-shot band of
+    round 2 needed ~1000 CG iterations per LM iteration here (0.126 LM-iters/s)."""
     pr = synthetic.make_ba_scene_grid(rows, cols, points, track, seed=seed)
     nobs = len(pr["obs_shot"])
     no_tol = dict(function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
@@ -45,7 +47,10 @@ def run_grid(ctx, rows: int = 50, cols: int = 100, points: int = 500000, track: 
             "shot_bandwidth": int(g.get("shot_bandwidth", -1)), "shots_reordered": int(g.get("shots_reordered", 0)),
             "preconditioner_bandwidth": int(g.get("preconditioner_bandwidth", -1)),
             "inlier_rmse_px": round(float(np.sqrt((g["reproj_err"][inl] ** 2).sum(1).mean()) * 2000.0), 4),
-            "cost": [float(g["initial_cost"]), float(g["final_cost"])], "lm_iteration": lm_iteration_line(g, nobs)}
+            "cost": [float(g["initial_cost"]), float(g["final_cost"])], "lm_iteration": lm_iteration_line(g, nobs),
+            "solver_note": "exact band of half-width `preconditioner_bandwidth` shots factorised directly (one launch per 16-shot block "
+                           "column, 16 pivot steps each: a latency chain, not flops) + one workgroup walking the block columns per "
+                           "solve; CG confirms in 1-2 iterations"}
 
 
 def run(ctx, shots: int = 5000, points: int = 500000, track: int = 10, iters: int = 20, cpu_baseline: bool = True,

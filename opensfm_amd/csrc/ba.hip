@@ -220,6 +220,9 @@ struct Dev {
   double *bD, *bE, *bG, *bH;  // ncl x ncd^2 each: D / Dinv, coupling to the left neighbour, Dinv*E, Dinv*E_right^T
   double *bD2, *bGt, *bHt;    // the right neighbours' share of D (D = bD + bD2 until the cluster is eliminated); G^T, H^T
   double *bx;                 // ncl x ncd work vector
+  // wide band (direct block LDL^T, kWB x kWB tiles): wNB block columns, window of wWb blocks below the diagonal
+  int wNB, wWb;
+  double *wA, *wL, *wLt, *wDinv, *wx;  // tiles A_{J+dI,J} (updated in place), L row-major / transposed, D^-1 blocks, right-hand sides
   double *zc;       // nred (unscaled J^T w)
   double *y;        // nred
   // pcg
@@ -756,15 +759,15 @@ __device__ __forceinline__ void jred_jp(const Dev &d, long k, double E[6][3]) { 
 // per six outputs accumulating in registers, deterministic): 2.28 ms with one gather in flight, 2.77 ms with two and 512 threads,
 // against 1.76 ms here -- the kernel is bound by the ~4 GB gather of partner blocks (every E row is wanted by the ~10 shots that see
 // its point, in ten different orders: the reuse misses the 4 MB L2s), not by the accumulation.
-__global__ void __launch_bounds__(TPB) band_assemble_kernel(Dev d, double radius) {
+__global__ void __launch_bounds__(TPB) band_assemble_kernel(Dev d, double radius, int copies) {
   // kBandCopies private copies of the accumulators, copy = lane & (kBandCopies - 1), interleaved so that the copies of one entry sit
   // in different banks: the lanes of a wavefront add into a handful of (dk, i, j) entries at a time, and same-address fp64 LDS
   // atomics serialise
-  __shared__ double acc[(kMaxBw + 1) * 36 * kBandCopies];
+  extern __shared__ __attribute__((aligned(16))) double acc[];  // (bw + 1) * 36 * copies (copies: a power of two, 8 where LDS allows)
   // blocks are dealt round-robin to the 8 XCDs: give every XCD a contiguous range of shots, whose workgroups gather the same E rows
   const int s = (int)xcd_contiguous(blockIdx.x, gridDim.x), nb = (d.bw + 1) * 36;
-  const int copy = threadIdx.x & (kBandCopies - 1);
-  for (int t = threadIdx.x; t < nb * kBandCopies; t += TPB) acc[t] = 0.0;
+  const int copy = threadIdx.x & (copies - 1);
+  for (int t = threadIdx.x; t < nb * copies; t += TPB) acc[t] = 0.0;
   __syncthreads();
   for (long k = d.shot_off[s] + threadIdx.x; k < d.shot_off[s + 1]; k += TPB) {
     const int p = d.sm_point[k];
@@ -793,7 +796,7 @@ __global__ void __launch_bounds__(TPB) band_assemble_kernel(Dev d, double radius
       for (int i = 0; i < 6; i++)
 #pragma unroll
         for (int j = 0; j < 6; j++)
-          atomicAdd(&acc[(dk * 36 + i * 6 + j) * kBandCopies + copy], EH[i][0] * Eb[j][0] + EH[i][1] * Eb[j][1] + EH[i][2] * Eb[j][2]);
+          atomicAdd(&acc[(dk * 36 + i * 6 + j) * copies + copy], EH[i][0] * Eb[j][0] + EH[i][1] * Eb[j][1] + EH[i][2] * Eb[j][2]);
     }
   }
   __syncthreads();
@@ -803,8 +806,7 @@ __global__ void __launch_bounds__(TPB) band_assemble_kernel(Dev d, double radius
     double val = 0.0;
     if (s2 >= 0) {
       double sum = 0.0;
-#pragma unroll
-      for (int c = 0; c < kBandCopies; c++) sum += acc[t * kBandCopies + c];
+      for (int c = 0; c < copies; c++) sum += acc[t * copies + c];
       val = -sum;
       if (dk == 0) {
         const int hi = i > j ? i : j, lo = i > j ? j : i;
@@ -1434,20 +1436,35 @@ __device__ __forceinline__ void coldots(const double *const (&M)[K], const doubl
 // than the 5-10 us of a back-to-back launch on this part.)  Round 3: the levels that have at most kMidWaves clusters left run inside
 // ONE workgroup (bcr_mid_kernel, a wavefront per cluster, __syncthreads between levels: no cross-XCD traffic at all), the first down
 // level reads the right-hand side itself and the last up level writes the result: 2 log2(N) + 3 launches become 2 log2(st0) + 1.
+// The right-hand sides of one walk: nrhs vectors r + q r_stride -> z + q z_stride, except index qx (if any), which is rx -> zx (the
+// camera border's columns and the solve's own right-hand side live in different buffers but go through one walk); the right-hand
+// side cam_q (if any) also gets the camera rows of its result (3x3 block Jacobi).
+struct RhsSet {
+  const double *r;
+  long r_stride;
+  double *z;
+  long z_stride;
+  int nrhs;
+  const double *rx;
+  double *zx;
+  int qx, cam_q;
+  __host__ __device__ const double *in(int q) const { return q == qx ? rx : r + q * r_stride; }
+  __host__ __device__ double *out(int q) const { return q == qx ? zx : z + q * z_stride; }
+};
 __device__ __forceinline__ double bcr_rhs(const Dev &d, const double *rin, int cl, int r) {  // entry r of cluster cl of the padded rhs
   const long g = (long)cl * d.ncd + r;
   return g < 6L * d.S ? rin[g] : 0.0;
 }
-// first: b comes from rin (and the odd clusters' part is copied into bx on the way)
-__global__ void __launch_bounds__(64) bcr_down_kernel(Dev d, int st, const double *rin, long rin_stride) {
+// first: b comes from the right-hand side itself (and the odd clusters' part is copied into bx on the way)
+__global__ void __launch_bounds__(64) bcr_down_kernel(Dev d, int st, RhsSet rs, int first) {
   __shared__ double xl[64], xr[64];
   const int n = d.ncd, n2 = n * n, r = threadIdx.x;
   const int j = 2 * blockIdx.x * st;
   if (j >= d.ncl) return;
   double *bx = d.bx + (long)blockIdx.y * d.ncl * n;
+  const double *b = first ? rs.in(blockIdx.y) : nullptr;
   const int i1 = j - st, i2 = j + st;
-  if (rin) {
-    const double *b = rin + blockIdx.y * rin_stride;
+  if (b) {
     xl[r] = (i1 >= 0 && r < n) ? bcr_rhs(d, b, i1, r) : 0.0;
     xr[r] = (i2 < d.ncl && r < n) ? bcr_rhs(d, b, i2, r) : 0.0;
     if (i2 < d.ncl && r < n) bx[(long)i2 * n + r] = xr[r];
@@ -1457,7 +1474,7 @@ __global__ void __launch_bounds__(64) bcr_down_kernel(Dev d, int st, const doubl
   }
   __syncthreads();
   if (r < n) {
-    double v = rin ? bcr_rhs(d, rin + blockIdx.y * rin_stride, j, r) : bx[(long)j * n + r];
+    double v = b ? bcr_rhs(d, b, j, r) : bx[(long)j * n + r];
     const double *const Ms[2] = {i1 >= 0 ? d.bH + (long)i1 * n2 : nullptr, i2 < d.ncl ? d.bG + (long)i2 * n2 : nullptr};
     const double *const xs2[2] = {xl, xr};
     double t[2];
@@ -1467,20 +1484,20 @@ __global__ void __launch_bounds__(64) bcr_down_kernel(Dev d, int st, const doubl
     bx[(long)j * n + r] = v;
   }
 }
-// last (z given): the result goes to z, the even clusters' part is copied along, and (cam_rows) the camera rows get their 3x3 blocks
-__global__ void __launch_bounds__(64) bcr_up_kernel(Dev d, int st, const double *rin, double *z, long z_stride, int cam_rows) {
+// last: the result goes to its z, the even clusters' part is copied along, and the right-hand side cam_q gets its camera rows
+__global__ void __launch_bounds__(64) bcr_up_kernel(Dev d, int st, RhsSet rs, int last) {
   __shared__ double xs[64], xl[64], xr[64];
   const int n = d.ncd, n2 = n * n, r = threadIdx.x;
   const int i = (2 * blockIdx.x + 1) * st;
   double *bx = d.bx + (long)blockIdx.y * d.ncl * n;
-  double *zq = z ? z + blockIdx.y * z_stride : nullptr;
+  double *zq = last ? rs.out(blockIdx.y) : nullptr;
   const int l = i - st, rr = i + st;
   if (zq) {
     if (l < d.ncl && r < n && (long)l * n + r < 6L * d.S) zq[(long)l * n + r] = bx[(long)l * n + r];
-    if (cam_rows) {
+    if ((int)blockIdx.y == rs.cam_q) {
       const int g = blockIdx.x * 64 + r;
       if (g < d.NC) {
-        const double *Bi = d.Binv + 36 * (long)d.S + 9 * g, *rc = rin + d.cam0 + 3 * g;
+        const double *Bi = d.Binv + 36 * (long)d.S + 9 * g, *rc = rs.in(blockIdx.y) + d.cam0 + 3 * g;
         for (int q = 0; q < 3; q++) zq[d.cam0 + 3 * g + q] = Bi[3 * q] * rc[0] + Bi[3 * q + 1] * rc[1] + Bi[3 * q + 2] * rc[2];
       }
     }
@@ -1577,6 +1594,385 @@ inline BcrLaunch bcr_level_for(int cs) {
   switch (cs) {
     OSFM_CS_CASE(2) OSFM_CS_CASE(3) OSFM_CS_CASE(4) OSFM_CS_CASE(5) OSFM_CS_CASE(6) OSFM_CS_CASE(7) OSFM_CS_CASE(8) OSFM_CS_CASE(9)
     default: return BcrLaunch{bcr_level_kernel<10>, BcrShape<10>::threads, BcrShape<10>::lds_bytes};
+  }
+}
+
+// ---- wide band: direct block LDL^T of the shot-shot Schur complement (round 3) --------------------------------------------------
+// Block surveys, loops, unordered collections: the co-visibility half-width is tens to hundreds of shots, beyond what the
+// cluster-tridiagonal cyclic reduction can hold in LDS (and a band truncated to 15 shots is a preconditioner in name only: ~1000 CG
+// iterations per LM iteration on a 50 x 100 grid).  The exact band is then factorised directly,  A = L D L^T  with kWB x kWB blocks
+// (kWcs = 16 shots): D_J are the pivot blocks themselves (not factorised further: their inverses come from the same block
+// Gauss-Jordan as the cyclic reduction's), L_IJ = A_IJ D_J^-1.  One launch per block column J, right-looking; the workgroup of window
+// tile (I, K), J < K <= I <= J + Wb, inverts D_J itself (the launch is a chain of 16 pivot steps either way; a separate launch for it
+// would only add its overhead), forms L_IJ and subtracts L_IJ A_KJ^T from A_IK.  Flops are n w^2 (11-44 GFLOP at configs[4] size with
+// w = 600-1200): irrelevant; the factorisation is the latency of S / 16 launches x 16 pivot steps.
+constexpr int kWcs = 16, kWB = 6 * kWcs, kWLd = kWB + 2;  // shots per block, block order, LDS row stride (even: 16-byte rows; 6 rows apart = 24 banks)
+constexpr int kWMaxBw = 368;                               // shot half-width: the backward walk keeps a window of x and its partial sums in LDS
+
+// in-place inverse of the SPD n x n block X (LDS, row stride kWLd), n = kWB: 16 x 16 tiles of 6 x 6, one per thread (256 threads)
+__device__ __forceinline__ void wide_gj_inverse(double *X, int tid, int &bad) {
+  constexpr int NT = kWB / 6;
+  const int tr = tid / NT, tq = tid - tr * NT;
+  double own[6][6];
+#pragma unroll
+  for (int r = 0; r < 6; r++)
+#pragma unroll
+    for (int c = 0; c < 6; c++) own[r][c] = X[(6 * tr + r) * kWLd + 6 * tq + c];
+#pragma unroll 1
+  for (int k = 0; k < NT; k++) {
+    double nr[6][6];
+    {
+      double P[6][6];
+#pragma unroll
+      for (int a = 0; a < 6; a++)
+#pragma unroll
+        for (int b = 0; b < 6; b++) P[a][b] = X[(6 * k + a) * kWLd + 6 * k + b];
+      inv6_spd(P, bad);
+#pragma unroll
+      for (int a = 0; a < 6; a++)
+#pragma unroll
+        for (int c = 0; c < 6; c++) nr[a][c] = 0.0;
+#pragma unroll
+      for (int b = 0; b < 6; b++) {
+        double pr[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) pr[c] = X[(6 * k + b) * kWLd + 6 * tq + c];
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+          for (int c = 0; c < 6; c++) nr[a][c] = __builtin_fma(P[a][b], pr[c], nr[a][c]);
+      }
+      if (tq == k) {
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+          for (int c = 0; c < 6; c++) nr[a][c] = P[a][c];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+      double m[6];
+#pragma unroll
+      for (int b = 0; b < 6; b++) m[b] = X[(6 * tr + r) * kWLd + 6 * k + b];
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        double acc = (tq == k) ? 0.0 : own[r][c];
+#pragma unroll
+        for (int b = 0; b < 6; b++) acc = __builtin_fma(-m[b], nr[b][c], acc);
+        own[r][c] = (tr == k) ? nr[r][c] : acc;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+      for (int c = 0; c < 6; c++) X[(6 * tr + r) * kWLd + 6 * tq + c] = own[r][c];
+    __syncthreads();
+  }
+}
+
+// assembled shot band -> kWB x kWB tiles: tile (J, dI) = A_{J+dI, J}, dI = 0 .. Wb (identity on the padding rows of the last block)
+__global__ void __launch_bounds__(256) wide_tiles_kernel(Dev d, int *status) {
+  const int J = blockIdx.x, dI = blockIdx.y, I = J + dI, R1 = d.bw + 1;
+  if (J == 0 && dI == 0 && threadIdx.x == 0) status[2] = 0;
+  double *T = d.wA + ((long)J * (d.wWb + 1) + dI) * kWB * kWB;
+  for (int t = threadIdx.x; t < kWB * kWB; t += 256) {
+    const int r = t / kWB, c = t - r * kWB;
+    const int s = I * kWcs + r / 6, i = r % 6, s2 = J * kWcs + c / 6, j = c % 6;
+    double v = 0.0;
+    if (I < d.wNB) {
+      if (s >= d.S || s2 >= d.S)
+        v = (dI == 0 && r == c) ? 1.0 : 0.0;
+      else {
+        const int k = s - s2;
+        if (k >= 0 && k <= d.bw) v = d.band[((long)s * R1 + k) * 36 + i * 6 + j];
+        else if (k < 0 && -k <= d.bw) v = d.band[((long)s2 * R1 - k) * 36 + j * 6 + i];
+      }
+    }
+    T[t] = v;
+  }
+}
+
+// one block column of the factorisation; blockIdx.x = 0: store D_J^-1; else the window tile (dI, dK), 1 <= dK <= dI <= Wb
+__global__ void __launch_bounds__(256) wide_factor_kernel(Dev d, int J, int *status) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double *X = lds, *Y = lds + kWB * kWLd;
+  const int tid = threadIdx.x, W1 = d.wWb + 1;
+  int dI = 0, dK = 0;
+  if (blockIdx.x > 0) {  // row-major enumeration of the lower triangle: index = dI (dI - 1) / 2 + (dK - 1)
+    const int q = blockIdx.x - 1;
+    dI = (int)((1.0 + sqrt(1.0 + 8.0 * q)) * 0.5);
+    while (dI * (dI - 1) / 2 > q) dI--;
+    while ((dI + 1) * dI / 2 <= q) dI++;
+    dK = q - dI * (dI - 1) / 2 + 1;
+    if (J + dI >= d.wNB) return;
+  }
+  const double *AJJ = d.wA + (long)J * W1 * kWB * kWB;
+  double v[kWB * kWB / 256];
+#pragma unroll
+  for (int u = 0; u < kWB * kWB / 256; u++) v[u] = AJJ[tid + u * 256];
+#pragma unroll
+  for (int u = 0; u < kWB * kWB / 256; u++) {
+    const int t = tid + u * 256;
+    X[(t / kWB) * kWLd + t % kWB] = v[u];
+  }
+  if (blockIdx.x > 0) {  // A_IJ, issued before the inversion starts
+    const double *AIJ = AJJ + (long)dI * kWB * kWB;
+#pragma unroll
+    for (int u = 0; u < kWB * kWB / 256; u++) v[u] = AIJ[tid + u * 256];
+#pragma unroll
+    for (int u = 0; u < kWB * kWB / 256; u++) {
+      const int t = tid + u * 256;
+      Y[(t / kWB) * kWLd + t % kWB] = v[u];
+    }
+  }
+  __syncthreads();
+  int bad = 0;
+  wide_gj_inverse(X, tid, bad);
+  if (bad) status[2] = 1;
+  if (blockIdx.x == 0) {
+    double *Dv = d.wDinv + (long)J * kWB * kWB;
+    for (int t = tid; t < kWB * kWB; t += 256) Dv[t] = X[(t / kWB) * kWLd + t % kWB];
+    return;
+  }
+  constexpr int NT = kWB / 6;
+  const int tr = tid / NT, tq = tid - tr * NT;
+  double acc[6][6];
+  // L_IJ = A_IJ D^-1
+#pragma unroll
+  for (int a = 0; a < 6; a++)
+#pragma unroll
+    for (int b = 0; b < 6; b++) acc[a][b] = 0.0;
+#pragma unroll 2
+  for (int k = 0; k < kWB; k++) {
+    double x[6], y[6];
+#pragma unroll
+    for (int a = 0; a < 6; a++) x[a] = Y[(6 * tr + a) * kWLd + k];
+#pragma unroll
+    for (int b = 0; b < 6; b++) y[b] = X[k * kWLd + 6 * tq + b];
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+      for (int b = 0; b < 6; b++) acc[a][b] = __builtin_fma(x[a], y[b], acc[a][b]);
+  }
+  // A_KJ (transposed into X once D^-1 has been read by everyone), L_IJ into Y
+  const double *AKJ = AJJ + (long)dK * kWB * kWB;
+#pragma unroll
+  for (int u = 0; u < kWB * kWB / 256; u++) v[u] = AKJ[tid + u * 256];
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < 6; a++)
+#pragma unroll
+    for (int b = 0; b < 6; b++) Y[(6 * tr + a) * kWLd + 6 * tq + b] = acc[a][b];
+#pragma unroll
+  for (int u = 0; u < kWB * kWB / 256; u++) {
+    const int t = tid + u * 256;
+    X[(t % kWB) * kWLd + t / kWB] = v[u];  // X[k][c] = A_KJ[c][k]
+  }
+  __syncthreads();
+  if (dK == 1) {  // this workgroup keeps L_IJ for the solves, row-major and transposed
+    double *Lr = d.wL + ((long)J * W1 + dI) * kWB * kWB, *Lt = d.wLt + ((long)J * W1 + dI) * kWB * kWB;
+    for (int t = tid; t < kWB * kWB; t += 256) {
+      Lr[t] = Y[(t / kWB) * kWLd + t % kWB];
+      Lt[t] = Y[(t % kWB) * kWLd + t / kWB];
+    }
+  }
+  // A_IK -= L_IJ A_KJ^T
+#pragma unroll
+  for (int a = 0; a < 6; a++)
+#pragma unroll
+    for (int b = 0; b < 6; b++) acc[a][b] = 0.0;
+#pragma unroll 2
+  for (int k = 0; k < kWB; k++) {
+    double x[6], y[6];
+#pragma unroll
+    for (int a = 0; a < 6; a++) x[a] = Y[(6 * tr + a) * kWLd + k];
+#pragma unroll
+    for (int b = 0; b < 6; b++) y[b] = X[k * kWLd + 6 * tq + b];
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+      for (int b = 0; b < 6; b++) acc[a][b] = __builtin_fma(x[a], y[b], acc[a][b]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < 6; a++)
+#pragma unroll
+    for (int b = 0; b < 6; b++) X[(6 * tr + a) * kWLd + 6 * tq + b] = acc[a][b];
+  __syncthreads();
+  double *AIK = d.wA + ((long)(J + dK) * W1 + (dI - dK)) * kWB * kWB;
+  for (int t = tid; t < kWB * kWB; t += 256) AIK[t] -= X[(t / kWB) * kWLd + t % kWB];
+}
+
+// ---- wide band solve: L y = b (one workgroup walks the block columns), z = D^-1 y (all blocks at once), L^T x = z (one workgroup).
+// NR right-hand sides side by side: wx[(block * kWB + r) * NR + q].  The walking workgroup keeps the window of the right-hand side
+// (forward: the Wb blocks below J that J still updates; backward: the Wb blocks of x that J reads) in an LDS ring, so the only global
+// traffic on the chain is the stream of L blocks; every dot product is split over kWKS adjacent lanes.
+constexpr int kWT = 1024, kWKS = 4;
+template <int NR>
+__device__ __forceinline__ void lds_vec(const double *p, double (&v)[NR]) {
+  if constexpr (NR == 4) {
+    const double2 a = reinterpret_cast<const double2 *>(p)[0], b = reinterpret_cast<const double2 *>(p)[1];
+    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+  } else {
+#pragma unroll
+    for (int q = 0; q < NR; q++) v[q] = p[q];
+  }
+}
+// position of entry (row r, rhs 0) of a block inside the LDS ring: the four k-ranges that the four lanes of a dot product read at the
+// same time start kWPad doubles further apart than their data, or their reads would sit in the same banks (768 bytes apart for NR = 4)
+constexpr int kWPad = 4;
+template <int NR>
+__device__ __forceinline__ int wpos(int r) { return r * NR + (r / (kWB / kWKS)) * kWPad; }
+template <int NR>
+__global__ void __launch_bounds__(kWT) wide_forward_kernel(Dev d) {
+  extern __shared__ __attribute__((aligned(16))) double win[];  // (Wb + 1) blocks of BP doubles
+  const int tid = threadIdx.x, W1 = d.wWb + 1, NB = d.wNB;
+  constexpr int KC = kWB / kWKS, BN = kWB * NR, BP = BN + kWKS * kWPad;
+  const int tr = tid / NR, tq = tid - tr * NR;  // this thread's (row, rhs) when it moves a block
+  for (int bl = 0; bl < min(W1, NB); bl++)
+    if (tid < BN) win[bl * BP + wpos<NR>(tr) + tq] = d.wx[(long)bl * BN + tid];
+  __syncthreads();
+  for (int J = 0; J < NB; J++) {
+    const int slot = J % W1;
+    const double *ys = win + slot * BP;
+    double pref = 0.0;  // the block that enters the window after this step
+    const bool enters = J + W1 < NB && tid < BN;
+    if (enters) pref = d.wx[(long)(J + W1) * BN + tid];
+    if (tid < BN) d.wx[(long)J * BN + tid] = ys[wpos<NR>(tr) + tq];
+    const int nI = min(d.wWb, NB - 1 - J);
+    const int total = nI * kWB * kWKS;
+    for (int it0 = 0; it0 < total; it0 += kWT) {
+      const int it = it0 + tid;
+      const bool on = it < total;
+      const int row = on ? it / kWKS : 0, ks = it % kWKS, dI = row / kWB + 1, r = row - (dI - 1) * kWB;
+      const double *Lt = d.wLt + ((long)J * W1 + dI) * kWB * kWB + (long)ks * KC * kWB + r;  // Lt[k][r]
+      double m[KC];
+#pragma unroll
+      for (int k = 0; k < KC; k++) m[k] = on ? Lt[(long)k * kWB] : 0.0;
+      const double *yk = ys + ks * (KC * NR + kWPad);
+      double a[NR];
+#pragma unroll
+      for (int q = 0; q < NR; q++) a[q] = 0.0;
+#pragma unroll
+      for (int k = 0; k < KC; k++) {
+        double y[NR];
+        lds_vec<NR>(yk + k * NR, y);
+#pragma unroll
+        for (int q = 0; q < NR; q++) a[q] = __builtin_fma(m[k], y[q], a[q]);
+      }
+#pragma unroll
+      for (int q = 0; q < NR; q++) {
+        a[q] += __shfl_xor(a[q], 1);
+        a[q] += __shfl_xor(a[q], 2);
+      }
+      if (on && ks == 0) {
+        double *dst = win + ((J + dI) % W1) * BP + wpos<NR>(r);
+#pragma unroll
+        for (int q = 0; q < NR; q++) dst[q] -= a[q];
+      }
+    }
+    __syncthreads();
+    if (enters) win[slot * BP + wpos<NR>(tr) + tq] = pref;
+    __syncthreads();
+  }
+}
+template <int NR>
+__global__ void __launch_bounds__(256) wide_diag_kernel(Dev d) {
+  __shared__ double ys[kWB * NR];
+  const int J = blockIdx.x, tid = threadIdx.x;
+  for (int t = tid; t < kWB * NR; t += 256) ys[t] = d.wx[(long)J * kWB * NR + t];
+  __syncthreads();
+  if (tid < kWB) {
+    const double *Dv = d.wDinv + (long)J * kWB * kWB + tid;  // symmetric: column tid
+    double a[NR];
+#pragma unroll
+    for (int q = 0; q < NR; q++) a[q] = 0.0;
+    for (int k0 = 0; k0 < kWB; k0 += 16) {
+      double m[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) m[u] = Dv[(long)(k0 + u) * kWB];
+#pragma unroll
+      for (int u = 0; u < 16; u++)
+#pragma unroll
+        for (int q = 0; q < NR; q++) a[q] = __builtin_fma(m[u], ys[(k0 + u) * NR + q], a[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < NR; q++) d.wx[((long)J * kWB + tid) * NR + q] = a[q];
+  }
+}
+template <int NR>
+__global__ void __launch_bounds__(kWT) wide_backward_kernel(Dev d) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int tid = threadIdx.x, W1 = d.wWb + 1, NB = d.wNB;
+  constexpr int RC = kWB / kWKS, BN = kWB * NR, BP = BN + kWKS * kWPad;
+  double *win = lds;             // (Wb + 1) blocks of BP doubles: x of the blocks J + 1 .. J + Wb (slot = block mod (Wb + 1))
+  double *part = lds + W1 * BP;  // Wb x kWB x NR
+  const int tr = tid / NR, tq = tid - tr * NR;
+  if (tid < BN) win[((NB - 1) % W1) * BP + wpos<NR>(tr) + tq] = d.wx[(long)(NB - 1) * BN + tid];
+  __syncthreads();
+  for (int J = NB - 2; J >= 0; J--) {
+    const int nI = min(d.wWb, NB - 1 - J);
+    double zj = 0.0;
+    if (tid < BN) zj = d.wx[(long)J * BN + tid];
+    const int total = nI * kWB * kWKS;
+    for (int it0 = 0; it0 < total; it0 += kWT) {
+      const int it = it0 + tid;
+      const bool on = it < total;
+      const int g = on ? it / kWKS : 0, rs = it % kWKS, dI = g / kWB + 1, c = g - (dI - 1) * kWB;
+      const double *Lr = d.wL + ((long)J * W1 + dI) * kWB * kWB + (long)rs * RC * kWB + c;  // L[r][c]
+      double m[RC];
+#pragma unroll
+      for (int r = 0; r < RC; r++) m[r] = on ? Lr[(long)r * kWB] : 0.0;
+      const double *xs = win + ((J + dI) % W1) * BP + rs * (RC * NR + kWPad);
+      double a[NR];
+#pragma unroll
+      for (int q = 0; q < NR; q++) a[q] = 0.0;
+#pragma unroll
+      for (int r = 0; r < RC; r++) {
+        double x[NR];
+        lds_vec<NR>(xs + r * NR, x);
+#pragma unroll
+        for (int q = 0; q < NR; q++) a[q] = __builtin_fma(m[r], x[q], a[q]);
+      }
+#pragma unroll
+      for (int q = 0; q < NR; q++) {
+        a[q] += __shfl_xor(a[q], 1);
+        a[q] += __shfl_xor(a[q], 2);
+      }
+      if (on && rs == 0) {
+#pragma unroll
+        for (int q = 0; q < NR; q++) part[(long)g * NR + q] = a[q];
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      double sum = 0.0;
+      for (int e = 0; e < nI; e++) sum += part[(long)e * BN + tid];
+      const double x = zj - sum;
+      win[(J % W1) * BP + wpos<NR>(tr) + tq] = x;
+      d.wx[(long)J * BN + tid] = x;
+    }
+    __syncthreads();
+  }
+}
+// right-hand sides in / results out (NR side by side in wx)
+template <int NR>
+__global__ void wide_load_kernel(Dev d, RhsSet rs) {
+  const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (long)d.wNB * kWB) return;
+#pragma unroll
+  for (int q = 0; q < NR; q++) d.wx[g * NR + q] = (q < rs.nrhs && g < 6L * d.S) ? rs.in(q)[g] : 0.0;
+}
+template <int NR>
+__global__ void wide_store_kernel(Dev d, RhsSet rs) {
+  const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < 6L * d.S)
+    for (int q = 0; q < rs.nrhs; q++) rs.out(q)[g] = d.wx[g * NR + q];
+  if (rs.cam_q >= 0 && g < d.NC) {
+    const double *Bi = d.Binv + 36 * (long)d.S + 9 * g, *rr = rs.in(rs.cam_q) + d.cam0 + 3 * g;
+    double *z = rs.out(rs.cam_q);
+    for (int i = 0; i < 3; i++) z[d.cam0 + 3 * g + i] = Bi[3 * i] * rr[0] + Bi[3 * i + 1] * rr[1] + Bi[3 * i + 2] * rr[2];
   }
 }
 
@@ -2474,29 +2870,56 @@ struct Solver {
   double *Bc = nullptr, *Wb = nullptr, *SigInv = nullptr, *dots = nullptr;  // border elimination (nb x 6S, nb x 6S, nb x nb, nb x nb)
   double *wB = nullptr, *partB = nullptr, *dCm = nullptr;                     // its columns in one pass: w (2 nb per observation), camera partials, C
   // z_q = A^-1 r_q for nrhs right-hand sides (strides in doubles) in one walk of the levels
-  void bcr_solve_multi(const double *r, long r_stride, double *z, long z_stride, int nrhs, bool cam_rows) {
+  void bcr_solve_set(const RhsSet &rs) {
     const int N = d.ncl;
-    const unsigned q = (unsigned)nrhs;
+    const unsigned q = (unsigned)rs.nrhs;
     auto ne = [N](int s) { return (N + 2 * s - 1) / (2 * s); };
     int st0 = 2;  // from here on at most kMidWaves clusters are left on a level: one workgroup walks those levels down and up again
     while (ne(st0) > kMidWaves) st0 *= 2;
-    hipLaunchKernelGGL(bcr_down_kernel, dim3(ne(1), q), dim3(64), 0, st, d, 1, r, r_stride);
-    for (int s = 2; s < st0; s *= 2) hipLaunchKernelGGL(bcr_down_kernel, dim3(ne(s), q), dim3(64), 0, st, d, s, (const double *)nullptr, 0L);
+    hipLaunchKernelGGL(bcr_down_kernel, dim3(ne(1), q), dim3(64), 0, st, d, 1, rs, 1);
+    for (int s = 2; s < st0; s *= 2) hipLaunchKernelGGL(bcr_down_kernel, dim3(ne(s), q), dim3(64), 0, st, d, s, rs, 0);
     hipLaunchKernelGGL(bcr_mid_kernel, dim3(1, q), dim3(64 * kMidWaves), 0, st, d, st0);
-    for (int s = st0 / 2; s >= 2; s /= 2)
-      hipLaunchKernelGGL(bcr_up_kernel, dim3(ne(s), q), dim3(64), 0, st, d, s, (const double *)nullptr, (double *)nullptr, 0L, 0);
-    hipLaunchKernelGGL(bcr_up_kernel, dim3(std::max(ne(1), cam_rows ? (d.NC + 63) / 64 : 0), q), dim3(64), 0, st, d, 1, r, z, z_stride,
-                       cam_rows ? 1 : 0);
+    for (int s = st0 / 2; s >= 2; s /= 2) hipLaunchKernelGGL(bcr_up_kernel, dim3(ne(s), q), dim3(64), 0, st, d, s, rs, 0);
+    hipLaunchKernelGGL(bcr_up_kernel, dim3(std::max(ne(1), rs.cam_q >= 0 ? (d.NC + 63) / 64 : 0), q), dim3(64), 0, st, d, 1, rs, 1);
   }
-  void bcr_solve(const double *r, double *z) { bcr_solve_multi(r, 0, z, 0, 1, true); }
-  void precond(const double *r, double *z) {
-    if (use_bcr && use_border) {
+  bool use_wide = false;
+  // the same for the wide band: right-hand sides side by side (at most 4 per walk) through L y = b, z = D^-1 y, L^T x = z
+  template <int NR>
+  void wide_walk(const RhsSet &rs) {
+    const int nrows = d.wNB * kWB;
+    const size_t ring = (size_t)(d.wWb + 1) * (kWB * NR + kWKS * kWPad) * sizeof(double);
+    hipLaunchKernelGGL(wide_load_kernel<NR>, dim3(nblk(nrows)), dim3(TPB), 0, st, d, rs);
+    hipLaunchKernelGGL(wide_forward_kernel<NR>, dim3(1), dim3(kWT), ring, st, d);
+    hipLaunchKernelGGL(wide_diag_kernel<NR>, dim3(d.wNB), dim3(256), 0, st, d);
+    hipLaunchKernelGGL(wide_backward_kernel<NR>, dim3(1), dim3(kWT), ring + (size_t)d.wWb * kWB * NR * sizeof(double), st, d);
+    hipLaunchKernelGGL(wide_store_kernel<NR>, dim3(nblk(std::max<long>(6L * d.S, d.NC))), dim3(TPB), 0, st, d, rs);
+  }
+  void wide_solve_set(const RhsSet &rs) {
+    if (rs.nrhs == 1) return wide_walk<1>(rs);
+    for (int q0 = 0; q0 < rs.nrhs; q0 += 4) {
+      RhsSet c = rs;
+      c.r = rs.r + q0 * rs.r_stride;
+      c.z = rs.z + q0 * rs.z_stride;
+      c.nrhs = std::min(4, rs.nrhs - q0);
+      c.qx = (rs.qx >= q0 && rs.qx < q0 + c.nrhs) ? rs.qx - q0 : -1;
+      c.cam_q = (rs.cam_q >= q0 && rs.cam_q < q0 + c.nrhs) ? rs.cam_q - q0 : -1;
+      wide_walk<4>(c);
+    }
+  }
+  void exact_solve_set(const RhsSet &rs) {
+    if (use_wide) wide_solve_set(rs);
+    else bcr_solve_set(rs);
+  }
+  // z = M^-1 r; solved: the exact band solve of r is already in z (it went through the walk of the camera border's columns)
+  void precond(const double *r, double *z, bool solved = false) {
+    const RhsSet one{r, 0, z, 0, 1, nullptr, nullptr, -1, 0};
+    if ((use_bcr || use_wide) && use_border) {
       const int nb = 3 * d.NC, n = 6 * d.S;
-      bcr_solve(r, z);
+      if (!solved) exact_solve_set(one);
       hipLaunchKernelGGL(border_rhs_kernel, dim3(1), dim3(1024), 0, st, Bc, SigInv, r, z, nb, n, d.cam0);
       hipLaunchKernelGGL(border_update_kernel, dim3(nblk(n)), dim3(TPB), 0, st, Wb, z, nb, n, d.cam0);
-    } else if (use_bcr)
-      bcr_solve(r, z);
+    } else if (use_bcr || use_wide)
+      exact_solve_set(one);
     else if (use_ctri)
       hipLaunchKernelGGL(ctri_solve_kernel, dim3(1), dim3(256), 0, st, d, r, z);
     else if (use_band)
@@ -2618,6 +3041,79 @@ static void rcm_shot_order(const osfm_ba_problem *P, std::vector<int> &new_of_ol
   for (int i = 0; i < S; i++) new_of_old[(size_t)order[(size_t)(S - 1 - i)]] = i;  // reversed
 }
 
+// A sweep over the block: shots grouped into lines across the principal axis of their positions (a new line wherever the sorted first
+// coordinate jumps by a quarter of the mean shot spacing, which follows from the extent of the two principal axes and the shot count), ordered
+// along the second axis inside a line -- the column-major numbering of a survey flown in lines, whichever way it was flown.
+static void sweep_shot_order(const osfm_ba_problem *P, std::vector<int> &new_of_old) {
+  const int S = P->n_shots;
+  double mean[3] = {0, 0, 0}, C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int s = 0; s < S; s++)
+    for (int i = 0; i < 3; i++) mean[i] += P->shot_pose[6 * (size_t)s + 3 + i] / S;
+  for (int s = 0; s < S; s++)
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) C[3 * i + j] += (P->shot_pose[6 * (size_t)s + 3 + i] - mean[i]) * (P->shot_pose[6 * (size_t)s + 3 + j] - mean[j]);
+  auto principal = [](const double *Cm, double *v) -> double {  // power iteration; returns the eigenvalue
+    v[0] = 1.0; v[1] = 0.7; v[2] = 0.3;
+    double lam = 0.0;
+    for (int it = 0; it < 100; it++) {
+      double w[3];
+      for (int i = 0; i < 3; i++) w[i] = Cm[3 * i] * v[0] + Cm[3 * i + 1] * v[1] + Cm[3 * i + 2] * v[2];
+      lam = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+      if (!(lam > 0)) return 0.0;
+      for (int i = 0; i < 3; i++) v[i] = w[i] / lam;
+    }
+    return lam;
+  };
+  double v1[3], v2[3];
+  const double l1 = principal(C, v1);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) C[3 * i + j] -= l1 * v1[i] * v1[j];
+  principal(C, v2);
+  std::vector<double> p1((size_t)S), p2((size_t)S);
+  double lo1 = 1e300, hi1 = -1e300, lo2 = 1e300, hi2 = -1e300;
+  for (int s = 0; s < S; s++) {
+    const double *t = P->shot_pose + 6 * (size_t)s + 3;
+    p1[(size_t)s] = t[0] * v1[0] + t[1] * v1[1] + t[2] * v1[2];
+    p2[(size_t)s] = t[0] * v2[0] + t[1] * v2[1] + t[2] * v2[2];
+    lo1 = std::min(lo1, p1[(size_t)s]); hi1 = std::max(hi1, p1[(size_t)s]);
+    lo2 = std::min(lo2, p2[(size_t)s]); hi2 = std::max(hi2, p2[(size_t)s]);
+  }
+  const double h = std::sqrt((hi1 - lo1) * (hi2 - lo2) / S);
+  // bins = runs of the sorted first coordinate without a gap of a quarter of the spacing (flight lines are such runs; where there are no gaps
+  // the order is simply the sweep along the first axis with everything in one bin sorted by the second: the caller keeps the better)
+  std::vector<int> by1((size_t)S);
+  for (int s = 0; s < S; s++) by1[(size_t)s] = s;
+  std::sort(by1.begin(), by1.end(), [&](int a, int b) { return p1[(size_t)a] != p1[(size_t)b] ? p1[(size_t)a] < p1[(size_t)b] : a < b; });
+  std::vector<std::pair<std::pair<long, double>, int>> key((size_t)S);
+  long bin = 0;
+  for (int i = 0; i < S; i++) {
+    const int s = by1[(size_t)i];
+    if (i > 0 && p1[(size_t)s] - p1[(size_t)by1[(size_t)i - 1]] > 0.25 * h) bin++;
+    key[(size_t)s] = {{bin, p2[(size_t)s]}, s};
+  }
+  if (bin == 0)  // no lines: plain sweep
+    for (int s = 0; s < S; s++) key[(size_t)s] = {{0L, p1[(size_t)s]}, s};
+  std::sort(key.begin(), key.end());
+  new_of_old.assign((size_t)S, 0);
+  for (int i = 0; i < S; i++) new_of_old[(size_t)key[(size_t)i].second] = i;
+}
+
+// the narrower of the two renumberings; returns its co-visibility half-width
+static int best_shot_order(const osfm_ba_problem *P, std::vector<int> &new_of_old) {
+  rcm_shot_order(P, new_of_old);
+  int bw = covis_half_bandwidth(P, new_of_old);
+  if (P->shot_pose) {  // breadth-first levels from a corner are diagonals of a block survey; a sweep along its long side is as narrow as
+    std::vector<int> sweep;  // the block is wide
+    sweep_shot_order(P, sweep);
+    const int bw2 = covis_half_bandwidth(P, sweep);
+    if (bw2 < bw) {
+      new_of_old.swap(sweep);
+      bw = bw2;
+    }
+  }
+  return bw;
+}
+
 static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_options *O, osfm_ba_report *Rp);
 
 // Host-only helper (no GPU needed): the renumbering osfm_ba_solve would apply.  new_of_old[n_shots] receives the
@@ -2630,9 +3126,9 @@ extern "C" int osfm_ba_shot_order(const osfm_ba_problem *P, int32_t *new_of_old,
                  OSFM_E_INVALID, "observation %ld references shot %d / point %d", o, P->obs_shot[o], P->obs_point[o]);
   std::vector<int> ident((size_t)P->n_shots), order;
   for (int s = 0; s < P->n_shots; s++) ident[(size_t)s] = s;
-  rcm_shot_order(P, order);
+  const int bw_after = best_shot_order(P, order);
   if (half_width_before) *half_width_before = covis_half_bandwidth(P, ident);
-  if (half_width_after) *half_width_after = covis_half_bandwidth(P, order);
+  if (half_width_after) *half_width_after = bw_after;
   for (int s = 0; s < P->n_shots; s++) new_of_old[s] = order[(size_t)s];
   return OSFM_OK;
 }
@@ -2650,8 +3146,7 @@ extern "C" int osfm_ba_solve(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_op
   for (int s = 0; s < S; s++) ident[(size_t)s] = s;
   const int bw0 = covis_half_bandwidth(P, ident);
   if (bw0 <= 10) return ba_solve_impl(ctx, P, O, Rp);  // already a narrow band: the exact cyclic-reduction path
-  rcm_shot_order(P, new_of_old);
-  const int bw1 = covis_half_bandwidth(P, new_of_old);
+  const int bw1 = best_shot_order(P, new_of_old);
   if (bw1 >= bw0) return ba_solve_impl(ctx, P, O, Rp);
   // relabelled copy of every per-shot input
   std::vector<int> old_of_new((size_t)S);
@@ -2892,8 +3387,12 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
   const long nbmax = std::max<long>(nblk(M), nblk(3L * NP));
   d.partial = A.alloc<double>((size_t)2 * nbmax + 16, e);
   // block half-bandwidth of the shot-shot coupling (shots in caller order): bw_true, from track_width_kernel above
-  d.bw = O->preconditioner == 1 ? 0 : std::min(bw_true, kMaxBw);
+  // half-width up to 10: exact band, cyclic reduction; up to kWMaxBw: exact band, direct block LDL^T (wide_*); beyond: truncated to kMaxBw
+  const bool wide = O->preconditioner == 0 && S >= 2 && bw_true > kMaxBw && bw_true <= kWMaxBw && getenv("OSFM_BA_NO_WIDE") == nullptr;
+  d.bw = O->preconditioner == 1 ? 0 : (wide ? bw_true : std::min(bw_true, kMaxBw));
   if (S < 2) d.bw = 0;
+  int band_copies = kBandCopies;  // private copies of the band assembly's LDS accumulators
+  while (band_copies > 1 && (size_t)(d.bw + 1) * 36 * band_copies * sizeof(double) > 150 * 1024) band_copies /= 2;
   d.band = A.alloc<double>((size_t)S * (d.bw + 1) * 36, e);
   d.Epm = d.bw > 0 ? A.alloc<double>((size_t)18 * M, e) : nullptr;
   d.dinv = A.alloc<double>((size_t)S * 36, e);
@@ -2915,16 +3414,27 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     d.bD2 = A.alloc<double>(nb, e);
     d.bGt = A.alloc<double>(nb, e);
     d.bHt = A.alloc<double>(nb, e);
-    d.bx = A.alloc<double>((size_t)6 * d.ncl * d.ncd, e);  // up to 6 right-hand sides at a time (the camera border)
-    if (3 * NC <= 6) {  // exact camera border: see border_rhs_kernel
-      sv.Bc = A.alloc<double>((size_t)3 * NC * 6 * S, e);
-      sv.Wb = A.alloc<double>((size_t)3 * NC * 6 * S, e);
-      sv.SigInv = A.alloc<double>(36, e);
-      sv.dots = A.alloc<double>(36, e);
-      sv.dCm = A.alloc<double>(36, e);
-      sv.wB = A.alloc<double>((size_t)2 * 3 * NC * M, e);
-      sv.partB = A.alloc<double>((size_t)S * 9 * NC, e);
-    }
+    d.bx = A.alloc<double>((size_t)7 * d.ncl * d.ncd, e);  // up to 7 right-hand sides at a time (the camera border's columns + the solve's)
+  }
+  d.wNB = 0; d.wWb = 0;
+  if (wide) {
+    d.wNB = (S + kWcs - 1) / kWcs;
+    d.wWb = std::min((d.bw + kWcs - 1) / kWcs, d.wNB - 1);
+    const size_t nt = (size_t)d.wNB * (d.wWb + 1) * kWB * kWB;
+    d.wA = A.alloc<double>(nt, e);
+    d.wL = A.alloc<double>(nt, e);
+    d.wLt = A.alloc<double>(nt, e);
+    d.wDinv = A.alloc<double>((size_t)d.wNB * kWB * kWB, e);
+    d.wx = A.alloc<double>((size_t)d.wNB * kWB * 4, e);  // up to 4 right-hand sides side by side
+  }
+  if ((d.ncl > 0 || wide) && 3 * NC <= 6) {  // exact camera border: see border_rhs_kernel
+    sv.Bc = A.alloc<double>((size_t)3 * NC * 6 * S, e);
+    sv.Wb = A.alloc<double>((size_t)3 * NC * 6 * S, e);
+    sv.SigInv = A.alloc<double>(36, e);
+    sv.dots = A.alloc<double>(36, e);
+    sv.dCm = A.alloc<double>(36, e);
+    sv.wB = A.alloc<double>((size_t)2 * 3 * NC * M, e);
+    sv.partB = A.alloc<double>((size_t)S * 9 * NC, e);
   }
   bool border_ok = getenv("OSFM_BA_NO_BORDER") == nullptr;  // exact camera border: every camera free
   for (int c = 0; c < NC; c++)
@@ -2988,14 +3498,25 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     // ---- fork: camera-border columns (if this problem uses them) and the right-hand side only need the Jacobian and Hhat: they run on
     //      the side stream next to the band assembly (a gather that leaves HBM bandwidth unused), so that the cyclic-reduction levels
     //      -- workgroups that need a whole CU's LDS -- find the CUs free afterwards ----
-    const bool want_border = d.bw > 0 && d.ncl > 0 && O->preconditioner == 0 && sv.Bc && border_ok;
+    const bool want_border = d.bw > 0 && (d.ncl > 0 || wide) && O->preconditioner == 0 && sv.Bc && border_ok;
     hipStream_t sx = sv.st2 ? sv.st2 : st;
     if (sv.st2) {
       OSFM_HIP(hipEventRecord(sv.ev_fork, st));
       OSFM_HIP(hipStreamWaitEvent(sv.st2, sv.ev_fork, 0));
     }
     if (d.bw > 0) {
-      hipLaunchKernelGGL(band_assemble_kernel, dim3(S), dim3(TPB), 0, st, d, radius);
+      static OsfmPerDeviceOnce once;
+      const int rca = once.run(ctx->device, []() -> int {
+        OSFM_HIP(hipFuncSetAttribute((const void *)band_assemble_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        OSFM_HIP(hipFuncSetAttribute((const void *)wide_factor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        OSFM_HIP(hipFuncSetAttribute((const void *)wide_forward_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        OSFM_HIP(hipFuncSetAttribute((const void *)wide_forward_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        OSFM_HIP(hipFuncSetAttribute((const void *)wide_backward_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        OSFM_HIP(hipFuncSetAttribute((const void *)wide_backward_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        return OSFM_OK;
+      });
+      if (rca != OSFM_OK) return rca;
+      hipLaunchKernelGGL(band_assemble_kernel, dim3(S), dim3(TPB), (size_t)(d.bw + 1) * 36 * band_copies * sizeof(double), st, d, radius, band_copies);
       sv.use_ctri = false;
       sv.use_bcr = false;
     }
@@ -3026,9 +3547,30 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     // back with the first scalars of PCG -- one host round trip for the factorisation, the border and the start of the solve.  When a
     // status says no (a pivot block that is not positive definite, a singular border) the fallbacks are issued and PCG starts again.
     const bool try_bcr = d.bw > 0 && d.ncl > 0 && O->preconditioner == 0;
-    const bool try_border = try_bcr && sv.Bc && border_ok;
+    const bool try_border = (try_bcr || wide) && sv.Bc && border_ok;
     sv.use_bcr = false;
+    sv.use_wide = false;
     sv.use_border = false;
+    bool z_solved = false;  // M^-1 b went through the border's walk
+    if (wide) {  // direct block LDL^T of the exact band: one launch per block column
+      hipLaunchKernelGGL(wide_tiles_kernel, dim3(d.wNB, d.wWb + 1), dim3(256), 0, st, d, d_status);
+      const int ntile = d.wWb * (d.wWb + 1) / 2;
+      for (int J = 0; J < d.wNB; J++) {
+        const int left = std::min(d.wWb, d.wNB - 1 - J);  // rows of the window that exist below block column J
+        hipLaunchKernelGGL(wide_factor_kernel, dim3(1 + (left == d.wWb ? ntile : left * (left + 1) / 2)), dim3(256), (size_t)2 * kWB * kWLd * sizeof(double), st, d, J, d_status);
+      }
+      sv.use_wide = true;
+      if (try_border) {
+        const int nb = 3 * NC, n6 = 6 * S;
+        const int rcj = join();
+        if (rcj != OSFM_OK) return rcj;
+        sv.wide_solve_set(RhsSet{sv.Bc, n6, sv.Wb, n6, nb + 1, d.b, d.z, nb, nb});  // the border's columns and the solve's own right-hand side
+        z_solved = true;
+        hipLaunchKernelGGL(border_dots_kernel, dim3(nb * nb), dim3(TPB), 0, st, sv.Bc, sv.Wb, nb, n6, sv.dots);
+        hipLaunchKernelGGL(border_sigma_kernel, dim3(1), dim3(64), 0, st, sv.dCm, sv.dots, sv.SigInv, nb, d_status + 1);
+        sv.use_border = true;
+      }
+    }
     if (try_bcr) {
       const int N = d.ncl;
       hipLaunchKernelGGL(bcr_build_kernel, dim3(N), dim3(256), 0, st, d, d_status);
@@ -3051,7 +3593,8 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
         // the columns of B and C were formed on the side stream; W = A^-1 B for all of them in one walk of the levels
         const int rcj = join();
         if (rcj != OSFM_OK) return rcj;
-        sv.bcr_solve_multi(sv.Bc, n6, sv.Wb, n6, nb, false);
+        sv.bcr_solve_set(RhsSet{sv.Bc, n6, sv.Wb, n6, nb + 1, d.b, d.z, nb, nb});  // the border's columns and the solve's own right-hand side
+        z_solved = true;
         hipLaunchKernelGGL(border_dots_kernel, dim3(nb * nb), dim3(TPB), 0, st, sv.Bc, sv.Wb, nb, n6, sv.dots);
         hipLaunchKernelGGL(border_sigma_kernel, dim3(1), dim3(64), 0, st, sv.dCm, sv.dots, sv.SigInv, nb, d_status + 1);
         sv.use_border = true;
@@ -3092,7 +3635,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       }
       return OSFM_OK;
     };
-    if (d.bw > 0 && !try_bcr) {
+    if (d.bw > 0 && !try_bcr && !wide) {
       const int rcf = fallback_band();
       if (rcf != OSFM_OK) return rcf;
     }
@@ -3100,19 +3643,20 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       const int rcj = join();  // the right-hand side (and its use of part / camred) is complete
       if (rcj != OSFM_OK) return rcj;
     }
-    int hst[2] = {0, 0};
+    int hst[3] = {0, 0, 0};
     auto start_pcg = [&]() -> int {
       // block-Jacobi blocks (6x6 per shot, 3x3 per camera): the fallback preconditioner, and the camera rows of the band
       // preconditioners -- not needed when the cyclic reduction came out with the exact camera border
-      if (!(sv.use_bcr && sv.use_border)) {
+      if (!((sv.use_bcr || sv.use_wide) && sv.use_border)) {
         hipLaunchKernelGGL(precond_shot_kernel, dim3(S), dim3(64), 0, st, d, radius);
         hipLaunchKernelGGL(cam_reduce_kernel, dim3(NC), dim3(TPB), 0, st, d, 6);
         hipLaunchKernelGGL(precond_cam_kernel, dim3(nblk(NC, 64)), dim3(64), 0, st, d, radius);
       }
-      sv.precond(d.b, d.z);
+      sv.precond(d.b, d.z, z_solved);
+      z_solved = false;
       hipLaunchKernelGGL(pcg_init_kernel, dim3(1), dim3(1024), 0, st, d.b, d.z, d.x, d.r, d.p, nred, d.scal + 0, d.scal + 4);  // x = 0, r = b, p = z
       OSFM_HIP(hipMemcpyAsync(hs.data(), d.scal, 5 * sizeof(double), hipMemcpyDeviceToHost, st));
-      if (try_bcr) OSFM_HIP(hipMemcpyAsync(hst, d_status, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+      if (try_bcr || wide) OSFM_HIP(hipMemcpyAsync(hst, d_status, 3 * sizeof(int), hipMemcpyDeviceToHost, st));
       OSFM_HIP(hipStreamSynchronize(st));
       return OSFM_OK;
     };
@@ -3120,12 +3664,15 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       const int rcs = start_pcg();
       if (rcs != OSFM_OK) return rcs;
     }
-    if (try_bcr && (hst[0] != 0 || (try_border && hst[1] != 0))) {
-      if (hst[0] != 0) {
+    if ((try_bcr && hst[0] != 0) || (sv.use_wide && hst[2] != 0) || (sv.use_border && hst[1] != 0)) {
+      if (try_bcr && hst[0] != 0) {
         sv.use_bcr = false;
         sv.use_border = false;
         const int rcf = fallback_band();
         if (rcf != OSFM_OK) return rcf;
+      } else if (sv.use_wide && hst[2] != 0) {  // a pivot block of the wide band is not positive definite: block Jacobi
+        sv.use_wide = false;
+        sv.use_border = false;
       } else {
         sv.use_border = false;
       }
@@ -3225,7 +3772,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
   {
     const int reps = 10;
     hipLaunchKernelGGL(point_hhat_kernel, dim3(nblk(NP)), dim3(TPB), 0, st, d, radius);
-    Rp->preconditioner_bandwidth = (sv.use_band || sv.use_ctri || sv.use_bcr) ? d.bw : 0;
+    Rp->preconditioner_bandwidth = (sv.use_band || sv.use_ctri || sv.use_bcr || sv.use_wide) ? d.bw : 0;
     Rp->shot_bandwidth = bw_true;
     OSFM_HIP(hipEventRecord(ctx->ev[6], st));
     for (int i = 0; i < reps; i++) sv.matvec(d.p, d.Ap, radius);

@@ -191,6 +191,40 @@ def test_grid_topology_matches_oracle(oracle_lib, gpu_ctx):
     assert abs(_rmse_px(g["reproj_err"]) - _rmse_px(o["reproj_err"])) < 1e-4
 
 
+def test_grid_topology_takes_the_wide_band_solver(oracle_lib, gpu_ctx):
+    """The block survey again, through what the solver reports: the shots are renumbered by the sweep along the long side, the exact
+    band (half-width above the 15 shots of the streaming band, below the wide solver's limit) is factorised directly, and CG needs one
+    or two iterations per LM iteration -- the preconditioner is the reduced matrix itself (a truncated band needed ~1000)."""
+    from opensfm_amd import bundle
+
+    pr = synthetic.make_ba_scene_grid(12, 30, 6000, 9, seed=4)
+    g = bundle.bundle_arrays(pr, {"bundle_max_iterations": 8}, **NO_TOL)
+    assert g["shots_reordered"] and g["shot_bandwidth_input"] == 62
+    assert 15 < g["shot_bandwidth"] <= 36 and g["preconditioner_bandwidth"] == g["shot_bandwidth"]
+    assert g["pcg_iterations"] <= 3 * g["iterations"]
+
+
+def test_two_free_cameras_on_a_grid(oracle_lib, gpu_ctx):
+    """Two free cameras shared by the shots of a block survey: the camera border has six columns, which go through the wide band's walk
+    in two groups together with the solve's own right-hand side."""
+    from opensfm_amd import bundle
+
+    pr = synthetic.make_ba_scene_grid(10, 24, 4000, 9, seed=6)
+    S = len(pr["shot_pose"])
+    base = pr["cam_params"][0]
+    pr["cam_params"] = np.array([base, base * [1.05, 0.95, 1.01]])
+    pr["cam_prior"] = np.tile(pr["cam_prior"][0], (2, 1))
+    pr["cam_sigma"] = np.tile(pr["cam_sigma"][0], (2, 1))
+    pr["cam_fixed"] = np.zeros(2, np.uint8)
+    pr["shot_camera"] = (np.arange(S) % 2).astype(np.int32)
+    g = bundle.bundle_arrays(pr, {"bundle_max_iterations": 8}, **NO_TOL)
+    o = oracle_lib.ba_solve(pr, max_iterations=8, **NO_TOL)
+    assert g["preconditioner_bandwidth"] > 15
+    assert np.allclose(g["cost_history"], o["cost_history"], rtol=1e-7)
+    assert np.allclose(g["cam_params"], o["cam_params"], atol=1e-6)
+    assert g["pcg_iterations"] <= 3 * g["iterations"]
+
+
 def test_long_tracks_take_the_strided_matvec_path(oracle_lib, gpu_ctx):
     """Tracks longer than the cooperative mat-vec tile (128 observations) use the strided
     workgroup path; the shot band is far wider than the preconditioner can hold."""

@@ -105,6 +105,34 @@ def test_shot_renumbering_restores_the_band_of_a_shuffled_sequence():
     assert span.max() == b1.value
 
 
+def test_shot_renumbering_sweeps_a_block_survey_along_its_long_side():
+    """A rows x cols block survey numbered line after line has a co-visibility half-width of ~2 cols; breadth-first levels from a
+    corner are diagonals and do not narrow it, the sweep along the long side (bins of one shot spacing along the principal axis of
+    the shot positions, the second axis inside a bin) does: ~2 rows."""
+    import ctypes as C
+
+    from opensfm_amd import _lib
+    from opensfm_amd._ba_abi import BaProblem
+
+    lib = _lib.load()
+    rows, cols = 12, 40
+    pr = synthetic.make_ba_scene_grid(rows, cols, 4000, 9, seed=3)
+    obs_shot = np.ascontiguousarray(pr["obs_shot"], np.int32)
+    obs_point = np.ascontiguousarray(pr["obs_point"], np.int32)
+    pose = np.ascontiguousarray(pr["shot_pose"], np.float64)
+    P = BaProblem()
+    P.n_cameras, P.n_shots, P.n_points, P.n_obs = 1, rows * cols, 4000, len(obs_shot)
+    P.obs_shot = obs_shot.ctypes.data_as(C.POINTER(C.c_int32))
+    P.obs_point = obs_point.ctypes.data_as(C.POINTER(C.c_int32))
+    P.shot_pose = pose.ctypes.data_as(C.POINTER(C.c_double))
+    order = np.zeros(rows * cols, np.int32)
+    b0, b1 = C.c_int32(), C.c_int32()
+    assert lib.osfm_ba_shot_order(C.byref(P), order.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(b0), C.byref(b1)) == 0
+    assert b0.value == 2 * cols + 2
+    assert b1.value <= 3 * rows, (b0.value, b1.value)  # 2 rows + 2 when every line is recognised, 3 rows - 1 for a plain sweep
+    assert np.array_equal(np.sort(order), np.arange(rows * cols))
+
+
 def test_product_package_never_touches_the_oracle():
     """The oracle is test infrastructure: nothing under opensfm_amd/ (Python or HIP sources) may import, include or load it."""
     import os

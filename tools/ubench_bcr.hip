@@ -80,7 +80,7 @@ int main() {
     int hst = -1;
     hipMemcpy(&hst, status, sizeof(int), hipMemcpyDeviceToHost);
     hipEventRecord(e0, 0);
-    for (int q = 0; q < 10; q++) sv.bcr_solve_multi(rin, 0, z, 0, 1, false);
+    for (int q = 0; q < 10; q++) sv.bcr_solve_set(RhsSet{rin, 0, z, 0, 1, nullptr, nullptr, -1, -1});
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     float ms2;
