@@ -59,11 +59,12 @@ def parse():
     ap.add_argument("--no-calibrated", action="store_true", help="skip the calibrated (essential-matrix) branch legs")
     ap.add_argument("--no-float", action="store_true", help="skip the float-descriptor (root-SIFT) workload")
     ap.add_argument("--no-guided", action="store_true", help="skip the guided-matching workload")
+    ap.add_argument("--no-hahog", action="store_true", help="skip the HAHOG extraction workload")
     ap.add_argument("--full-parity", action="store_true", help="check EVERY pair with matches + 5000 empties against the oracle (~1.5 min)")
     ap.add_argument("--headline-only", action="store_true", help="only the headline workload + its cpu_baseline (configs[3] runs)")
     a = ap.parse_args()
     if a.headline_only:
-        a.no_ba = a.no_tracks = a.no_overlap = a.no_calibrated = a.no_float = a.no_guided = True
+        a.no_ba = a.no_tracks = a.no_overlap = a.no_calibrated = a.no_float = a.no_guided = a.no_hahog = True
     return a
 
 
@@ -262,6 +263,8 @@ def main():
             section("cpu_baseline", cpu_baseline, scene, pairs_gathered, args.cpu_sample_pairs, graph, args.full_parity)
         if not args.no_tracks and graph is not None:
             section("tracks", tracks_bench, ctx, scene, pairs_gathered, graph, not args.no_cpu_baseline)
+        if not args.no_hahog:
+            section("hahog", hahog_bench, ctx, not args.no_cpu_baseline)
         if not args.no_ba:
             def ba_section():
                 import bench_ba as ba_bench
@@ -273,6 +276,52 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def hahog_bench(ctx, with_cpu, rows: int = 1536, cols: int = 2048, target: int = 10000, reps: int = 5):
+    """HAHOG extraction at OpenSfM's processing size (feature_process_size 2048, config.py:33) with its default
+    thresholds and feature_min_frames-like count: images per second of osfm_hahog_extract (upload of the grey image, every kernel,
+    download of keypoints and descriptors), next to the REFERENCE's features::hahog compiled from /root/reference (one thread: vlfeat
+    is built without OpenMP, as the reference's own CMake builds it) on the same image."""
+    from opensfm_amd import features
+
+    rng = np.random.default_rng(7)
+    yy, xx = np.mgrid[0:rows, 0:cols].astype(np.float32)
+    im = np.zeros((rows, cols), np.float32)
+    for _ in range(1500):
+        cx, cy, sg = rng.uniform(0, cols), rng.uniform(0, rows), rng.uniform(1.5, 24)
+        x0, x1, y0, y1 = int(max(0, cx - 4 * sg)), int(min(cols, cx + 4 * sg)), int(max(0, cy - 4 * sg)), int(min(rows, cy + 4 * sg))
+        im[y0:y1, x0:x1] += rng.uniform(-1, 1) * np.exp(-((xx[y0:y1, x0:x1] - cx) ** 2 + (yy[y0:y1, x0:x1] - cy) ** 2) / (2 * sg * sg))
+    im += 0.05 * rng.standard_normal((rows, cols)).astype(np.float32)
+    im = np.ascontiguousarray((im - im.min()) / (im.max() - im.min()), np.float32)
+    features.hahog(im, 1e-5, 10.0, target, ctx=ctx)  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        pts, desc = features.hahog(im, 1e-5, 10.0, target, ctx=ctx)
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    octaves = int(np.floor(np.log2((min(rows, cols) - 1) / 15.0))) + 1
+    px = sum((rows >> o) * (cols >> o) for o in range(octaves))
+    # algorithmic bytes: per level two separable passes (read + write each), the response (read + write), the extremum search reads the
+    # response once: 5 levels x (16 + 8 + 4) bytes per pixel of the pyramid; the per-feature patches are negligible beside it
+    alg_bytes = 5 * 28 * px
+    out = {"workload": f"{rows} x {cols} grey image, peak 1e-5, edge 10, {target} features", "value": round(1e3 / ms, 2), "unit": "images/s",
+           "ms_per_image": round(ms, 3), "features": int(len(pts)), "octaves": octaves,
+           "roofline": {"bound": "hbm", "unit": "GB/s", "peak": 8000.0, "achieved": round(alg_bytes / (ms * 1e-3) / 1e9, 1),
+                        "frac": round(alg_bytes / (ms * 1e-3) / 1e9 / 8000.0, 4), "algorithmic_bytes": alg_bytes,
+                        "note": "whole call (H2D of the image, ~50 launches, two host round trips for the feature counts, D2H of the results) "
+                                "against the streaming bytes of the pyramid"}}
+    if with_cpu:
+        import oracle
+
+        t0 = time.perf_counter()
+        ref = oracle.hahog_ref(im, 1e-5, 10.0, target)
+        dt = time.perf_counter() - t0
+        if ref is not None:
+            same = ref[0].shape == pts.shape and np.array_equal(ref[0][:, :3], pts[:, :3]) and np.array_equal(ref[1], desc)
+            out["cpu_baseline"] = {"value": round(1.0 / dt, 3), "unit": "images/s", "cores": 1, "kind": "reference",
+                                   "sample": f"the same image once ({dt:.2f} s; oracle/_ref/libhahog_ref.so = hahog.cc + vlfeat compiled from /root/reference)",
+                                   "identical_keypoints_and_descriptors": bool(same)}
+    return out
 
 
 def tracks_bench(ctx, scene, pairs_all, graph, with_cpu):

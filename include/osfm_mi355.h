@@ -466,6 +466,27 @@ int osfm_knn_points(osfm_ctx *ctx, const double *candidates, int n_candidates, c
 int osfm_radius_points(osfm_ctx *ctx, const double *candidates, int n_candidates, const double *queries, int n_queries,
                        double max_distance, uint32_t *out_mask);
 
+/* =====================================================================================
+ * HAHOG feature extraction
+ *
+ * osfm_hahog_extract replaces pyfeatures.hahog(image, peak_threshold, edge_threshold, target_num_features)
+ * (opensfm/src/features/src/hahog.cc:125-206; binding opensfm/src/features/python/pybind.cc) together with the descriptor
+ * post-processing of its only caller, features.extract_features_hahog (opensfm/features.py:516-534):
+ *   image     rows x cols float32 grey levels in [0, 1] (host), at least 17 x 17
+ *   points    n x 4: x, y, size, angle in degrees (hahog.cc:170-177);  desc  n x 128
+ *   flags     OSFM_HAHOG_ROOT: square roots (feature_root);  OSFM_HAHOG_UCHAR: x 362 (x 512 without ROOT), clipped to [0, 255] and
+ *             rounded (hahog_normalize_to_uchar) -- the integer-valued descriptors the matcher takes on its int8 path.  0: vlfeat's.
+ *   capacity  rows available in points / desc; 4 x target_num_features always suffices (at most four orientations per feature).
+ * Vlfeat's Hessian detector (covdet.c), the selection of the strongest features, orientations and SIFT descriptors (sift.c) are
+ * followed operation for operation: the detected set, keypoints and descriptors are the reference's (tests/test_gpu_hahog.py states
+ * the tolerance and what can differ).  target_num_features = 0 returns no features, as the reference does (hahog.cc:24-27 keeps
+ * `target` of the sorted list).  OSFM_E_INVALID when the features do not fit `capacity` (*n_features says how many there are).
+ * ===================================================================================== */
+#define OSFM_HAHOG_ROOT 1
+#define OSFM_HAHOG_UCHAR 2
+int osfm_hahog_extract(osfm_ctx *ctx, const float *image, int rows, int cols, float peak_threshold, float edge_threshold,
+                       int target_num_features, int flags, float *points, float *desc, int capacity, int *n_features);
+
 #ifdef __cplusplus
 }
 #endif

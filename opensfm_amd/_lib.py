@@ -143,6 +143,8 @@ SIGNATURES = {
     "osfm_knn_points": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_double,
                                   C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "osfm_radius_points": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_int, C.c_double, C.POINTER(C.c_uint32)]),
+    "osfm_hahog_extract": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int,
+                                     C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]),
     "osfm_ransac_fundamental": (
         C.c_int,
         [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.c_double, C.c_double, C.c_int,

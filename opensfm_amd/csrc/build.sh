@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-SRCS="api.hip match.hip ransac.hip ba.hip ba_general.hip tracks.hip relpose.hip calib.hip guided.hip words.hip"
+SRCS="api.hip match.hip ransac.hip ba.hip ba_general.hip tracks.hip relpose.hip calib.hip guided.hip words.hip hahog.hip"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function $EXTRA_HIPCC_FLAGS"
 mkdir -p build
 echo "$FLAGS" > build/.flags.new

@@ -1,0 +1,941 @@
+// hahog.hip -- HAHOG feature extraction on the GPU: what features::hahog (opensfm/src/features/src/hahog.cc:125-206)
+// computes through the vendored vlfeat (third_party/vlfeat/vl/covdet.c, scalespace.c, imopv.c, sift.c):
+//
+//   Gaussian scale space, first octave 0, 3 subdivisions + 2 extra levels per octave   scalespace.c:669-697,700-753,756-810, imopv.c:623-681
+//   scaled determinant of the Hessian on every level                                    covdet.c:1733-1821
+//   3-D local extrema above 0.8 x peak threshold, quadratic refinement, thresholds      covdet.c:1044-1117,1193-1316,1985-2030
+//   selection of the strongest target_num_features                                      hahog.cc:12-28,75-96
+//   orientation(s) of every feature from a 41 x 41 patch                                covdet.c:2685-2840,2153-2415
+//   31 x 31 patch, polar gradient, 4 x 4 x 8 SIFT histogram, normalisation              hahog.cc:163-200, imopv.c vl_imgradient_polar_f, sift.c:1754-1898
+//   square root / scaling to [0, 255] as the Python caller does                         opensfm/features.py:516-534
+//
+// The arithmetic follows the reference operation for operation (float where it is float, double where it promotes, products and sums
+// unfused, the taps of every Gaussian in vlfeat's order, histograms accumulated in raster order) so that the scale space, the
+// responses and with them the set of detected features are the reference's bit for bit; what can differ is the last bit of the few
+// libm calls made per FEATURE on the device (pow for the scale, exp for the patch filter, cos / sin / atan2 of the orientation) --
+// they enter float fields, where a last-bit difference of a double survives with probability ~1e-8.
+//
+// Kernels are plain HBM-bound stencils and per-feature workgroups (no matrix cores: there is no contraction here).
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include <rocprim/rocprim.hpp>
+
+#include "osfm_internal.h"
+
+namespace {
+
+constexpr int kFirstSub = -1, kLastSub = 3, kLev = kLastSub - kFirstSub + 1, kRes = 3;
+constexpr int kMaxTaps = 65;
+constexpr double kPi = 3.141592653589793;          // VL_PI
+constexpr float kEpsF = 1.19209290E-07F;          // VL_EPSILON_F
+constexpr double kEpsD = 2.220446049250313e-16;    // VL_EPSILON_D
+
+struct Octave {
+  float *gss, *css;  // kLev levels of h x w floats each, contiguous
+  int w, h;
+};
+constexpr int kMaxOct = 16;
+struct Pyramid {
+  Octave oct[kMaxOct];
+  int n_oct;
+  double base_scale;
+  double sigma[kMaxOct][kLev];  // vl_scalespace_get_level_sigma, computed by the host's libm
+};
+
+// ---- scale space ---------------------------------------------------------------------------------------------------------------
+// vl_imconvcol_vf (imopv.c:120-215 / imopv_sse2.c), VL_PAD_BY_CONTINUITY: dst(y) = sum_j src(clamp(y - W + j)) * filt[2W - j], the sum
+// started at 0 and taken in that order, product and sum rounded separately
+__global__ void conv_v_kernel(const float *src, float *dst, int w, int h, const float *taps, int W) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  float acc = 0.f;
+  for (int j = 0; j <= 2 * W; j++) {
+    int p = y - W + j;
+    p = p < 0 ? 0 : (p > h - 1 ? h - 1 : p);
+    acc = acc + src[(long)p * w + x] * taps[2 * W - j];
+  }
+  dst[(long)y * w + x] = acc;
+}
+__global__ void conv_h_kernel(const float *src, float *dst, int w, int h, const float *taps, int W) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  const float *row = src + (long)y * w;
+  float acc = 0.f;
+  for (int j = 0; j <= 2 * W; j++) {
+    int p = x - W + j;
+    p = p < 0 ? 0 : (p > w - 1 ? w - 1 : p);
+    acc = acc + row[p] * taps[2 * W - j];
+  }
+  dst[(long)y * w + x] = acc;
+}
+// copy_and_downsample by one octave (scalespace.c:497-520): every second pixel of every second row
+__global__ void downsample_kernel(const float *src, int w, int h, float *dst, int dw, int dh) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x < dw && y < dh) dst[(long)y * dw + x] = src[(long)(2 * y) * w + 2 * x];
+}
+// _vl_det_hessian_response (covdet.c:1733-1821): interior from the 3 x 3 neighbourhood, the border copies the nearest interior value
+__global__ void hessian_kernel(const float *im, float *out, int w, int h, float factor) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  const int c = x < 1 ? 1 : (x > w - 2 ? w - 2 : x), r = y < 1 ? 1 : (y > h - 2 ? h - 2 : y);
+  const float *p = im + (long)r * w + c;
+  const float p11 = p[-w - 1], p12 = p[-w], p13 = p[-w + 1], p21 = p[-1], p22 = p[0], p23 = p[1], p31 = p[w - 1], p32 = p[w], p33 = p[w + 1];
+  const float Lxx = (-p21 + 2 * p22 - p23);
+  const float Lyy = (-p12 + 2 * p22 - p32);
+  const float Lxy = ((p11 - p31 - p13 + p33) / 4.0f);
+  out[(long)y * w + x] = (Lxx * Lyy - Lxy * Lxy) * factor;
+}
+
+// ---- detection -----------------------------------------------------------------------------------------------------------------
+struct Features {  // structure of arrays, capacity cap
+  float *x, *y, *sigma, *peak, *edge;
+  int *o, *s;
+  unsigned long long *key;  // vlfeat's detection order: octaves from the last to the first, then z, y, x
+  int *count;
+  int cap;
+};
+
+__device__ __forceinline__ long vl_floor_d(double x) {
+  const long xi = (long)x;
+  return (x >= 0 || (double)xi == x) ? xi : xi - 1;
+}
+__device__ __forceinline__ long vl_floor_f(float x) {
+  const long xi = (long)x;
+  return (x >= 0 || (float)xi == x) ? xi : xi - 1;
+}
+
+// vl_gaussian_elimination for the 3 x 4 system (mathop.c:~860-960, column-major M[i + 3 j]); returns false when singular
+__device__ bool solve3(double *M) {
+#define MA(i, j) M[(i) + (j)*3]
+  for (int j = 0; j < 3; j++) {
+    double maxa = 0, maxabsa = 0;
+    int maxi = -1;
+    for (int i = j; i < 3; i++) {
+      const double a = MA(i, j), absa = fabs(a);
+      if (absa > maxabsa) {
+        maxa = a;
+        maxabsa = absa;
+        maxi = i;
+      }
+    }
+    if (maxabsa < 1e-10) return false;
+    const int i = maxi;
+    for (int jj = j; jj < 4; jj++) {
+      const double tmp = MA(i, jj);
+      MA(i, jj) = MA(j, jj);
+      MA(j, jj) = tmp;
+      MA(j, jj) /= maxa;
+    }
+    for (int ii = j + 1; ii < 3; ii++) {
+      const double x = MA(ii, j);
+      for (int jj = j; jj < 4; jj++) MA(ii, jj) -= x * MA(j, jj);
+    }
+  }
+  for (int i = 2; i > 0; i--)
+    for (int ii = i - 1; ii >= 0; ii--) {
+      const double x = MA(ii, i);
+      MA(ii, 3) -= x * MA(i, 3);
+    }
+#undef MA
+  return true;
+}
+
+// vl_find_local_extrema_3 + vl_refine_local_extreum_3 + the thresholds of vl_covdet_detect, one thread per sample of the octave's
+// interior
+__global__ void extrema_kernel(const float *css, int w, int h, int o, int last_octave, double step, double threshold08, double peak_threshold,
+                               double edge_threshold, double base_scale, Features F) {
+  const int x0 = blockIdx.x * blockDim.x + threadIdx.x + 1, y0 = blockIdx.y + 1, z = blockIdx.z + 1;
+  if (x0 > w - 2 || y0 > h - 2) return;
+  const long xo = 1, yo = w, zo = (long)w * h;
+  {
+    const float *pt = css + x0 * xo + y0 * yo + z * zo;
+    const float v = *pt;
+    bool mx = (double)v >= threshold08, mn = (double)v <= -threshold08;
+    if (!mx && !mn) return;
+    for (int dz = -1; dz <= 1 && (mx || mn); dz++)
+      for (int dy = -1; dy <= 1; dy++)
+        for (int dx = -1; dx <= 1; dx++) {
+          if (dx == 0 && dy == 0 && dz == 0) continue;
+          const float q = pt[dx * xo + dy * yo + dz * zo];
+          mx = mx && v > q;
+          mn = mn && v < q;
+        }
+    if (!mx && !mn) return;
+  }
+  // refinement
+  int x = x0, y = y0, dx = 0, dy = 0;
+  double Dx = 0, Dy = 0, Dz = 0, Dxx = 0, Dyy = 0, Dzz = 0, Dxy = 0, Dxz = 0, Dyz = 0, b[3] = {0, 0, 0};
+  const float *pt = nullptr;
+  bool ok = true;
+#define AT(ddx, ddy, ddz) (*(pt + (ddx)*xo + (ddy)*yo + (ddz)*zo))
+  for (int iter = 0; iter < 5; iter++) {
+    x += dx;
+    y += dy;
+    pt = css + x * xo + y * yo + z * zo;
+    Dx = 0.5 * (AT(+1, 0, 0) - AT(-1, 0, 0));
+    Dy = 0.5 * (AT(0, +1, 0) - AT(0, -1, 0));
+    Dz = 0.5 * (AT(0, 0, +1) - AT(0, 0, -1));
+    Dxx = (AT(+1, 0, 0) + AT(-1, 0, 0) - 2.0 * AT(0, 0, 0));
+    Dyy = (AT(0, +1, 0) + AT(0, -1, 0) - 2.0 * AT(0, 0, 0));
+    Dzz = (AT(0, 0, +1) + AT(0, 0, -1) - 2.0 * AT(0, 0, 0));
+    Dxy = 0.25 * (AT(+1, +1, 0) + AT(-1, -1, 0) - AT(-1, +1, 0) - AT(+1, -1, 0));
+    Dxz = 0.25 * (AT(+1, 0, +1) + AT(-1, 0, -1) - AT(-1, 0, +1) - AT(+1, 0, -1));
+    Dyz = 0.25 * (AT(0, +1, +1) + AT(0, -1, -1) - AT(0, -1, +1) - AT(0, +1, -1));
+    double M[12] = {Dxx, Dxy, Dxz, Dxy, Dyy, Dyz, Dxz, Dyz, Dzz, -Dx, -Dy, -Dz};
+    ok = solve3(M);
+    if (!ok) {
+      b[0] = b[1] = b[2] = 0;
+      break;
+    }
+    b[0] = M[9];
+    b[1] = M[10];
+    b[2] = M[11];
+    dx = (b[0] > 0.6 && x < w - 2 ? 1 : 0) + (b[0] < -0.6 && x > 1 ? -1 : 0);
+    dy = (b[1] > 0.6 && y < h - 2 ? 1 : 0) + (b[1] < -0.6 && y > 1 ? -1 : 0);
+    if (dx == 0 && dy == 0) break;
+  }
+  const double peakScore = AT(0, 0, 0) + 0.5 * (Dx * b[0] + Dy * b[1] + Dz * b[2]);
+#undef AT
+  const double alpha = (Dxx + Dyy) * (Dxx + Dyy) / (Dxx * Dyy - Dxy * Dxy);
+  double edgeScore;
+  if (alpha < 0)
+    edgeScore = INFINITY;
+  else {
+    const double t = 0.25 * alpha - 1;
+    edgeScore = (0.5 * alpha - 1) + sqrt((t > 0 ? t : 0) * alpha);
+  }
+  // VlCovDetExtremum3 keeps the refined position and the two scores as floats (covdet.c:994-1004): everything below sees those
+  const float rx = (float)(x + b[0]), ry = (float)(y + b[1]), rz = (float)(z + b[2]);
+  const float peakF = (float)peakScore, edgeF = (float)edgeScore;
+  ok = ok && fabs(b[0]) < 1.5 && fabs(b[1]) < 1.5 && fabs(b[2]) < 1.5 && 0 <= rx && rx <= w - 1 && 0 <= ry && ry <= h - 1 && 0 <= rz &&
+       rz <= kLev - 1;
+  ok = ok && fabs((double)peakF) > peak_threshold;
+  ok = ok && (double)edgeF < edge_threshold;
+  if (!ok) return;
+  // o + (refined.z + first) / resolution: a float and integers -- C evaluates the whole exponent in float (covdet.c:2007-2009)
+  const float expo = (float)o + (rz + (float)kFirstSub) / (float)kRes;
+  const double sigma = base_scale * pow(2.0, (double)expo);
+  const int slot = atomicAdd(F.count, 1);
+  if (slot >= F.cap) return;
+  F.x[slot] = (float)(rx * step);
+  F.y[slot] = (float)(ry * step);
+  F.sigma[slot] = (float)sigma;
+  F.o[slot] = o;
+  F.s[slot] = (int)round((double)rz);
+  F.peak[slot] = peakF;
+  F.edge[slot] = edgeF;
+  F.key[slot] = ((unsigned long long)(last_octave - o) << 56) | ((unsigned long long)z << 48) | ((unsigned long long)y0 << 24) | (unsigned long long)x0;
+}
+
+__global__ void iota_kernel(int *a, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] = i;
+}
+__global__ void gather_f_kernel(const int *idx, const float *src, float *dst, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[idx[i]];
+}
+__global__ void compose_kernel(const int *outer, const int *inner, int *dst, int n) {  // dst[i] = inner[outer[i]]
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = inner[outer[i]];
+}
+
+// ---- patches -------------------------------------------------------------------------------------------------------------------
+// vl_lapack_dlasv2 + vl_svd2 (mathop.c:641-838), singular values only (what the patch extraction needs of an oriented frame)
+__device__ __forceinline__ double sgn(double x) { return x >= 0.0 ? 1.0 : -1.0; }
+__device__ void svd2_values(const double *Mx, double *d1, double *d2) {
+  const double m11 = Mx[0], m21 = Mx[1], m12 = Mx[2], m22 = Mx[3];
+  double cu1 = m11, su1 = m21;
+  const double norm = sqrt(cu1 * cu1 + su1 * su1);
+  cu1 /= norm;
+  su1 /= norm;
+  const double f = cu1 * m11 + su1 * m21, g = cu1 * m12 + su1 * m22, h = -su1 * m12 + cu1 * m22;
+  double svt = 0, cvt = 0, sut = 0, cut = 0, ft = f, gt = g, ht = h, fa = fabs(f), ga = fabs(g), ha = fabs(h), smin = 0, smax = 0;
+  int pmax = 1, swap = 0, glarge = 0;
+  if (fa < ha) {
+    pmax = 3;
+    double tmp = ft; ft = ht; ht = tmp;
+    tmp = fa; fa = ha; ha = tmp;
+    swap = 1;
+  }
+  if (ga == 0.0) {
+    smin = ha;
+    smax = fa;
+    cut = 1.0; sut = 0.0; cvt = 1.0; svt = 0.0;
+  } else {
+    if (ga > fa) {
+      pmax = 2;
+      if ((fa / ga) < kEpsD) {
+        glarge = 1;
+        smax = ga;
+        if (ha > 1.0) smin = fa / (ga / ha);
+        else smin = (fa / ga) * ha;
+        cut = 1.0; sut = ht / gt; cvt = 1.0; svt = ft / gt;
+      }
+    }
+    if (glarge == 0) {
+      const double fmh = fa - ha;
+      const double d = (fmh == fa) ? 1.0 : fmh / fa;
+      const double q = gt / ft, s = 2.0 - d, dd = d * d, qq = q * q, ss = s * s;
+      const double spq = sqrt(ss + qq);
+      const double dpq = (d == 0.0) ? fabs(q) : sqrt(dd + qq);
+      const double a = 0.5 * (spq + dpq);
+      smin = ha / a;
+      smax = fa * a;
+      double tmp;
+      if (qq == 0.0) {
+        if (d == 0.0) tmp = sgn(ft) * 2 * sgn(gt);
+        else tmp = gt / (sgn(ft) * fmh) + q / s;
+      } else
+        tmp = (q / (spq + s) + q / (dpq + d)) * (1.0 + a);
+      const double tt = sqrt(tmp * tmp + 4.0);
+      cvt = 2.0 / tt;
+      svt = tmp / tt;
+      cut = (cvt + svt * q) / a;
+      sut = (ht / ft) * svt / a;
+    }
+  }
+  double cu, su, cv, sv;
+  if (swap == 1) { cu = svt; su = cvt; cv = sut; sv = cut; }
+  else { cu = cut; su = sut; cv = cvt; sv = svt; }
+  double tsign = 1.0;
+  if (pmax == 1) tsign = sgn(cv) * sgn(cu) * sgn(f);
+  if (pmax == 2) tsign = sgn(sv) * sgn(cu) * sgn(g);
+  if (pmax == 3) tsign = sgn(sv) * sgn(su) * sgn(h);
+  *d1 = (tsign >= 0 ? 1.0 : -1.0) * smax;
+  *d2 = ((tsign * sgn(f) * sgn(h)) >= 0 ? 1.0 : -1.0) * smin;
+}
+
+// What vl_covdet_extract_patch_helper (covdet.c:2153-2415) decides once per patch: the level, the frame in level coordinates and the
+// box of the padded copy it makes when the patch leaves the image.
+struct PatchPlan {
+  const float *level;
+  int width, height;       // of the level
+  double A[4], T[2];       // patch -> level coordinates (T relative to the padded copy when padded)
+  bool padded, zero;       // zero: the central band is empty (the reference clears the copy)
+  long x0i, y0i, padx0, pady0, padx1, pady1, pw, ph;
+  double sigma_level;      // sigma_ of the level
+};
+__device__ void plan_patch(const Pyramid &py, double extent, double sigma, const double *A_, const double *T_, double d1, double d2, PatchPlan &P) {
+  const int first_octave = 0, last_octave = py.n_oct - 1;
+  const double factor = 1.0 / (d1 < d2 ? d1 : d2);
+  long o, s;
+  double sigma_;
+  for (o = first_octave + 1; o <= last_octave; ++o) {
+    s = vl_floor_d(log2(sigma / (factor * py.base_scale)) - o);
+    s = s > kFirstSub ? s : kFirstSub;
+    s = s < kLastSub ? s : kLastSub;
+    sigma_ = py.base_scale * pow(2.0, o + (double)s / kRes);
+    if (factor * sigma_ > sigma) {
+      o--;
+      break;
+    }
+  }
+  o = o < last_octave ? o : last_octave;
+  s = vl_floor_d(log2(sigma / (factor * py.base_scale)) - o);
+  s = s > kFirstSub ? s : kFirstSub;
+  s = s < kLastSub ? s : kLastSub;
+  sigma_ = py.base_scale * pow(2.0, o + (double)s / kRes);
+  P.sigma_level = sigma_;
+  const Octave &oc = py.oct[o];
+  P.level = oc.gss + (long)(s - kFirstSub) * oc.w * oc.h;
+  P.width = oc.w;
+  P.height = oc.h;
+  const double step = (double)(1L << o);
+  for (int i = 0; i < 4; i++) P.A[i] = A_[i] / step;
+  P.T[0] = T_[0] / step;
+  P.T[1] = T_[1] / step;
+  double x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
+  const double boxx[4] = {extent, extent, -extent, -extent}, boxy[4] = {-extent, extent, extent, -extent};
+  for (int i = 0; i < 4; i++) {
+    const double x = P.A[0] * boxx[i] + P.A[2] * boxy[i] + P.T[0];
+    const double y = P.A[1] * boxx[i] + P.A[3] * boxy[i] + P.T[1];
+    x0 = x0 < x ? x0 : x;
+    x1 = x1 > x ? x1 : x;
+    y0 = y0 < y ? y0 : y;
+    y1 = y1 > y ? y1 : y;
+  }
+  P.x0i = (long)(floor(x0) - 1);
+  P.y0i = (long)(floor(y0) - 1);
+  const long x1i = (long)(ceil(x1) + 1), y1i = (long)(ceil(y1) + 1);
+  P.padded = P.x0i < 0 || x1i > P.width - 1 || P.y0i < 0 || y1i > P.height - 1;
+  P.zero = false;
+  if (P.padded) {
+    P.padx0 = -P.x0i > 0 ? -P.x0i : 0;
+    P.pady0 = -P.y0i > 0 ? -P.y0i : 0;
+    P.padx1 = x1i - (P.width - 1) > 0 ? x1i - (P.width - 1) : 0;
+    P.pady1 = y1i - (P.height - 1) > 0 ? y1i - (P.height - 1) : 0;
+    P.pw = x1i - P.x0i + 1;
+    P.ph = y1i - P.y0i + 1;
+    P.zero = !(P.pady0 < P.ph - P.pady1);
+    P.T[0] -= P.x0i;
+    P.T[1] -= P.y0i;
+  }
+}
+// sample (xi, yi) of the image the bilinear interpolation reads: the level itself, or the padded copy (covdet.c:2296-2330, including
+// how its rows are filled: the last two columns of a row repeat the column before them)
+__device__ __forceinline__ float plan_read(const PatchPlan &P, long xi, long yi) {
+  if (!P.padded) return P.level[yi * P.width + xi];
+  if (P.zero) return 0.f;
+  long m = yi < P.pady0 ? P.pady0 : (yi > P.ph - P.pady1 - 1 ? P.ph - P.pady1 - 1 : yi);
+  const long row = P.y0i + m;
+  long c0 = P.x0i < 0 ? 0 : P.x0i;
+  c0 = c0 < P.width - 1 ? c0 : P.width - 1;
+  long lim = P.pw - P.padx1 - 2 - P.padx0;
+  lim = lim > 0 ? lim : 0;
+  long k = xi - P.padx0;
+  k = k < 0 ? 0 : (k > lim ? lim : k);
+  return P.level[row * P.width + c0 + k];
+}
+// the resampling loop (covdet.c:2360-2405): patch[yyi][xxi], side = 2 resolution + 1; the running coordinates are sums, as there
+__device__ void sample_patch(const PatchPlan &P, float *patch, int resolution, double extent, int tid, int nthreads) {
+  const int side = 2 * resolution + 1;
+  const double stephat = extent / resolution;
+  for (int t = tid; t < side * side; t += nthreads) {
+    const int yyi = t / side, xxi = t - yyi * side;
+    double yhat = -extent;
+    for (int q = 0; q < yyi; q++) yhat += stephat;
+    double xhat = -extent;
+    for (int q = 0; q < xxi; q++) xhat += stephat;
+    const double rx = P.A[2] * yhat + P.T[0], ry = P.A[3] * yhat + P.T[1];
+    const double x = P.A[0] * xhat + rx, y = P.A[1] * xhat + ry;
+    const long xi = vl_floor_d(x), yi = vl_floor_d(y);
+    const double i00 = plan_read(P, xi, yi), i10 = plan_read(P, xi + 1, yi), i01 = plan_read(P, xi, yi + 1), i11 = plan_read(P, xi + 1, yi + 1);
+    const double wx = x - xi, wy = y - yi;
+    patch[t] = (float)((1.0 - wy) * ((1.0 - wx) * i00 + wx * i10) + wy * ((1.0 - wx) * i01 + wx * i11));
+  }
+}
+
+// vl_fast_atan2_f, vl_fast_resqrt_f, vl_fast_sqrt_f, vl_mod_2pi_f (mathop.h)
+__device__ __forceinline__ float fast_atan2_f(float y, float x) {
+  float angle, r;
+  const float c3 = 0.1821F, c1 = 0.9675F;
+  const float abs_y = fabsf(y) + kEpsF;
+  if (x >= 0) {
+    r = (x - abs_y) / (x + abs_y);
+    angle = (float)(kPi / 4);
+  } else {
+    r = (x + abs_y) / (abs_y - x);
+    angle = (float)(3 * kPi / 4);
+  }
+  angle += (c3 * r * r - c1) * r;
+  return (y < 0) ? -angle : angle;
+}
+__device__ __forceinline__ float fast_resqrt_f(float x) {
+  const float xhalf = (float)0.5 * x;
+  int i = __float_as_int(x);
+  i = 0x5f3759df - (i >> 1);
+  float u = __int_as_float(i);
+  u = u * ((float)1.5 - xhalf * u * u);
+  u = u * ((float)1.5 - xhalf * u * u);
+  return u;
+}
+__device__ __forceinline__ float fast_sqrt_f(float x) { return ((double)x < 1e-8) ? 0 : x * fast_resqrt_f(x); }
+__device__ __forceinline__ float mod_2pi_f(float x) {
+  while (x > (float)(2 * kPi)) x -= (float)(2 * kPi);
+  while (x < 0.0F) x += (float)(2 * kPi);
+  return x;
+}
+// vl_imgradient_polar_f on a side x side patch in LDS: modulus and angle of pixel t
+__device__ __forceinline__ void polar_gradient(const float *im, int side, int t, float *mod, float *ang) {
+  const int y = t / side, x = t - y * side;
+  const float *src = im + t;
+  float gx, gy;
+  if (x == 0) gx = src[1] - src[0];
+  else if (x == side - 1) gx = src[0] - src[-1];
+  else gx = 0.5 * (src[1] - src[-1]);
+  if (y == 0) gy = src[side] - src[0];
+  else if (y == side - 1) gy = src[0] - src[-side];
+  else gy = 0.5 * (src[side] - src[-side]);
+  *mod = fast_sqrt_f(gx * gx + gy * gy);
+  *ang = mod_2pi_f((float)(fast_atan2_f(gy, gx) + 2 * kPi));
+}
+
+// ---- orientations (vl_covdet_extract_orientations_for_frame, covdet.c:2685-2840; hahog.cc:98-123) --------------------------------
+constexpr int kOrRes = 20, kOrSide = 2 * kOrRes + 1, kOrBins = 36, kMaxOr = 4;
+constexpr double kOrExtent = 9.0;  // VL_COVDET_AA_PATCH_EXTENT = 3 * VL_COVDET_AA_RELATIVE_INTEGRATION_SIGMA
+struct Oriented {
+  float *x, *y, *a11, *a21, *a12, *a22;  // capacity 4 x features
+};
+__global__ void __launch_bounds__(256) orientation_kernel(Pyramid py, const float *fx, const float *fy, const float *fsigma, int n,
+                                                          const double *aa_mask, int *n_or, double *or_angle /* n x 4 */) {
+  __shared__ float patch[kOrSide * kOrSide], tmp[kOrSide * kOrSide];
+  __shared__ float pmod[kOrSide * kOrSide], pang[kOrSide * kOrSide];
+  __shared__ float taps1[kMaxTaps];
+  __shared__ int W1;
+  __shared__ PatchPlan P;
+  __shared__ double hist[kOrBins];
+  const int f = blockIdx.x, tid = threadIdx.x;
+  if (f >= n) return;
+  if (tid == 0) {
+    // the detector's frames are isotropic: A = sigma I, so vl_svd2 returns D = (sigma, sigma), U = V = I and theta0 = atan2(0, 1) = 0
+    const double sg = fsigma[f];
+    const double A[4] = {sg, 0.0, 0.0, sg}, T[2] = {fx[f], fy[f]};
+    plan_patch(py, kOrExtent, 1.0, A, T, sg, sg, P);
+    const double sigma1 = P.sigma_level / sg;
+    // vl_imsmooth_f(patch, deltaSigma1 / stephat, deltaSigma2 / stephat): one filter, both directions (sigma1 = sigma2)
+    const double t = 1.0 - sigma1 * sigma1;
+    const double delta = sqrt(t > 0 ? t : 0), stephat = kOrExtent / kOrRes;
+    const double sd = delta / stephat;
+    const int W = (int)ceil(sd * 3.0);
+    W1 = W;
+    float mass = (float)1.0;
+    taps1[W] = 1.0f;
+    for (int i = 1; i <= W; i++) {
+      const double xx = (double)i / sd;
+      const double g = exp(-0.5 * xx * xx);
+      mass += g + g;
+      taps1[W - i] = (float)g;
+      taps1[W + i] = (float)g;
+    }
+    for (int i = 0; i < 2 * W + 1; i++) taps1[i] /= mass;
+  }
+  if (tid < kOrBins) hist[tid] = 0.0;
+  __syncthreads();
+  sample_patch(P, patch, kOrRes, kOrExtent, tid, 256);
+  __syncthreads();
+  const int W = W1;
+  for (int t = tid; t < kOrSide * kOrSide; t += 256) {  // along y
+    const int y = t / kOrSide, x = t - y * kOrSide;
+    float acc = 0.f;
+    for (int j = 0; j <= 2 * W; j++) {
+      int p = y - W + j;
+      p = p < 0 ? 0 : (p > kOrSide - 1 ? kOrSide - 1 : p);
+      acc = acc + patch[p * kOrSide + x] * taps1[2 * W - j];
+    }
+    tmp[t] = acc;
+  }
+  __syncthreads();
+  for (int t = tid; t < kOrSide * kOrSide; t += 256) {  // along x
+    const int y = t / kOrSide, x = t - y * kOrSide;
+    float acc = 0.f;
+    for (int j = 0; j <= 2 * W; j++) {
+      int p = x - W + j;
+      p = p < 0 ? 0 : (p > kOrSide - 1 ? kOrSide - 1 : p);
+      acc = acc + tmp[y * kOrSide + p] * taps1[2 * W - j];
+    }
+    patch[t] = acc;
+  }
+  __syncthreads();
+  for (int t = tid; t < kOrSide * kOrSide; t += 256) polar_gradient(patch, kOrSide, t, &pmod[t], &pang[t]);
+  __syncthreads();
+  // histogram: bin b adds, in raster order, what the sequential loop adds to it
+  const double binExtent = 2 * kPi / kOrBins;
+  if (tid < kOrBins) {
+    double hsum = 0.0;
+    for (int k = 0; k < kOrSide * kOrSide; k++) {
+      const double modulus = pmod[k], angle = pang[k], weight = aa_mask[k];
+      const double xx = angle / binExtent;
+      const long bin = vl_floor_d(xx);
+      const double w2 = xx - bin, w1 = 1.0 - w2;
+      if ((bin + kOrBins) % kOrBins == tid) hsum += w1 * (modulus * weight);
+      if ((bin + kOrBins + 1) % kOrBins == tid) hsum += w2 * (modulus * weight);
+    }
+    hist[tid] = hsum;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int iter = 0; iter < 6; iter++) {
+      double prev = hist[kOrBins - 1];
+      const double first = hist[0];
+      int i;
+      for (i = 0; i < kOrBins - 1; ++i) {
+        const double curr = (prev + hist[i] + hist[(i + 1) % kOrBins]) / 3.0;
+        prev = hist[i];
+        hist[i] = curr;
+      }
+      hist[i] = (prev + hist[i] + first) / 3.0;
+    }
+    double maxPeak = 0;
+    for (int i = 0; i < kOrBins; i++) maxPeak = maxPeak > hist[i] ? maxPeak : hist[i];
+    double ang[kMaxOr], sc[kMaxOr];
+    int cnt = 0;
+    for (int i = 0; i < kOrBins; i++) {
+      const double h0 = hist[i], hm = hist[(i - 1 + kOrBins) % kOrBins], hp = hist[(i + 1 + kOrBins) % kOrBins];
+      if (h0 > 0.8 * maxPeak && h0 > hm && h0 > hp) {
+        const double di = -0.5 * (hp - hm) / (hp + hm - 2 * h0);
+        ang[cnt] = binExtent * (i + di) + 0.0;  // + theta0
+        sc[cnt] = h0;
+        cnt++;
+        if (cnt >= kMaxOr) break;
+      }
+    }
+    // qsort by decreasing score (glibc: merge sort, stable)
+    for (int i = 1; i < cnt; i++)
+      for (int j = i; j > 0 && sc[j] > sc[j - 1]; j--) {
+        double t0 = sc[j]; sc[j] = sc[j - 1]; sc[j - 1] = t0;
+        t0 = ang[j]; ang[j] = ang[j - 1]; ang[j - 1] = t0;
+      }
+    n_or[f] = cnt;
+    for (int i = 0; i < cnt; i++) or_angle[(long)f * kMaxOr + i] = ang[i];
+  }
+}
+// exclusive scan of the orientation counts, one workgroup (a few thousand features)
+__global__ void __launch_bounds__(1024) scan_kernel(const int *cnt, int n, int *off) {
+  __shared__ int part[1024];
+  const int tid = threadIdx.x;
+  const int per = (n + 1023) / 1024;
+  int s = 0;
+  for (int i = tid * per; i < (tid + 1) * per && i < n; i++) s += cnt[i];
+  part[tid] = s;
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int i = 0; i < 1024; i++) {
+      const int v = part[i];
+      part[i] = acc;
+      acc += v;
+    }
+    off[n] = acc;
+  }
+  __syncthreads();
+  int acc = part[tid];
+  for (int i = tid * per; i < (tid + 1) * per && i < n; i++) {
+    off[i] = acc;
+    acc += cnt[i];
+  }
+}
+// hahog.cc:98-123: one oriented copy of the frame per orientation
+__global__ void orient_frames_kernel(const float *fx, const float *fy, const float *fsigma, const int *off, const int *n_or, const double *or_angle,
+                                     int n, Oriented R) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n) return;
+  const double A[4] = {fsigma[f], 0.0f, 0.0f, fsigma[f]};  // a11, a21, a12, a22
+  for (int j = 0; j < n_or[f]; j++) {
+    const double r1 = cos(or_angle[(long)f * kMaxOr + j]), r2 = sin(or_angle[(long)f * kMaxOr + j]);
+    const int q = off[f] + j;
+    R.x[q] = fx[f];
+    R.y[q] = fy[f];
+    R.a11[q] = (float)(+A[0] * r1 + A[2] * r2);
+    R.a21[q] = (float)(+A[1] * r1 + A[3] * r2);
+    R.a12[q] = (float)(-A[0] * r2 + A[2] * r1);
+    R.a22[q] = (float)(-A[1] * r2 + A[3] * r1);
+  }
+}
+
+// ---- descriptors (hahog.cc:163-200; sift.c:1754-1898) -----------------------------------------------------------------------------
+constexpr int kDRes = 15, kDSide = 2 * kDRes + 1, kNBO = 8, kNBP = 4;
+constexpr double kDExtent = 7.5;
+__global__ void __launch_bounds__(256) descriptor_kernel(Pyramid py, Oriented R, int n, const double *expn_tab, double st0, double ct0, double sigma_d,
+                                                         int flags, float *points, float *desc) {
+  __shared__ float patch[kDSide * kDSide];
+  __shared__ float smod[kDSide * kDSide], sang[kDSide * kDSide];
+  __shared__ float swm[kDSide * kDSide], srx[kDSide * kDSide], sry[kDSide * kDSide], srt[kDSide * kDSide];
+  __shared__ int sbx[kDSide * kDSide], sby[kDSide * kDSide], sbt[kDSide * kDSide];
+  __shared__ float descr[kNBO * kNBP * kNBP];
+  __shared__ PatchPlan P;
+  const int f = blockIdx.x, tid = threadIdx.x;
+  if (f >= n) return;
+  if (tid == 0) {
+    const float a11 = R.a11[f], a21 = R.a21[f], a12 = R.a12[f], a22 = R.a22[f];
+    const float det = a11 * a22 - a12 * a21;
+    const float size = sqrtf(fabsf(det));
+    const float angle = (float)(atan2f(a21, a11) * 180.0f / M_PI);
+    points[4 * (long)f + 0] = R.x[f];
+    points[4 * (long)f + 1] = R.y[f];
+    points[4 * (long)f + 2] = size;
+    points[4 * (long)f + 3] = angle;
+    const double A[4] = {a11, a21, a12, a22}, T[2] = {R.x[f], R.y[f]};
+    double d1, d2;
+    svd2_values(A, &d1, &d2);
+    plan_patch(py, kDExtent, 1.0, A, T, d1, d2, P);
+  }
+  __syncthreads();
+  sample_patch(P, patch, kDRes, kDExtent, tid, 256);
+  __syncthreads();
+  for (int t = tid; t < kDSide * kDSide; t += 256) polar_gradient(patch, kDSide, t, &smod[t], &sang[t]);
+  __syncthreads();
+  // per pixel: window x modulus, the lower bin of the 2 x 2 x 2 it feeds and the three fractions (sift.c:1806-1850); x = y = 15,
+  // so xi = yi = 15 and every pixel of the patch is inside the window W = 21
+  const double x0 = (double)(kDSide - 1) / 2, y0 = (double)(kDSide - 1) / 2;
+  const int xi0 = (int)(x0 + 0.5), yi0 = (int)(y0 + 0.5);
+  const double SBP = 3.0 * sigma_d + kEpsD;
+  for (int t = tid; t < kDSide * kDSide; t += 256) {
+    const int py_ = t / kDSide, px_ = t - py_ * kDSide;
+    const float mod = smod[t], angle = sang[t];
+    const float theta = mod_2pi_f((float)(angle - (kPi / 2)));
+    const float dx = (float)(px_ - x0), dy = (float)(py_ - y0);
+    const float nx = (float)((ct0 * dx + st0 * dy) / SBP);
+    const float ny = (float)((-st0 * dx + ct0 * dy) / SBP);
+    const float nt = (float)(kNBO * theta / (2 * kPi));
+    const float wsigma = (float)(kNBP / 2);
+    double ex = (nx * nx + ny * ny) / (2.0 * wsigma * wsigma), win_d;
+    if (ex > 25.0) win_d = 0.0;
+    else {
+      ex *= 256 / 25.0;
+      const int i = (int)vl_floor_d(ex);
+      const double r = ex - i, a = expn_tab[i], b = expn_tab[i + 1];
+      win_d = a + r * (b - a);
+    }
+    const float win = (float)win_d;
+    const int binx = (int)vl_floor_f((float)(nx - 0.5)), biny = (int)vl_floor_f((float)(ny - 0.5)), bint = (int)vl_floor_f(nt);
+    srx[t] = (float)(nx - (binx + 0.5));
+    sry[t] = (float)(ny - (biny + 0.5));
+    srt[t] = nt - bint;
+    sbx[t] = binx;
+    sby[t] = biny;
+    sbt[t] = bint;
+    swm[t] = win * mod;
+    (void)xi0;
+    (void)yi0;
+  }
+  __syncthreads();
+  // bin (bx, by, bt) adds, in raster order, what the sequential loop adds to it
+  if (tid < kNBO * kNBP * kNBP) {
+    const int bt = tid % kNBO, bx = (tid / kNBO) % kNBP - kNBP / 2, by = tid / (kNBO * kNBP) - kNBP / 2;
+    float acc = 0.f;
+    for (int t = 0; t < kDSide * kDSide; t++) {
+      const int dbinx = bx - sbx[t], dbiny = by - sby[t];
+      if (dbinx < 0 || dbinx > 1 || dbiny < 0 || dbiny > 1) continue;
+      const int b0 = sbt[t] % kNBO, b1 = (sbt[t] + 1) % kNBO;
+      const float wm = swm[t], rx = srx[t], ry = sry[t], rt = srt[t];
+      if (b0 == bt) acc += wm * fabsf(1 - dbinx - rx) * fabsf(1 - dbiny - ry) * fabsf(1 - 0 - rt);
+      if (b1 == bt) acc += wm * fabsf(1 - dbinx - rx) * fabsf(1 - dbiny - ry) * fabsf(1 - 1 - rt);
+    }
+    descr[tid] = acc;
+  }
+  __syncthreads();
+  if (tid == 0) {  // normalise, clamp at 0.2, normalise (sift.c:1872-1896, norm_thresh = 0)
+    for (int pass = 0; pass < 2; pass++) {
+      float norm = 0.0f;
+      for (int i = 0; i < 128; i++) norm += descr[i] * descr[i];
+      norm = fast_sqrt_f(norm) + kEpsF;
+      for (int i = 0; i < 128; i++) descr[i] /= norm;
+      if (pass == 0)
+        for (int i = 0; i < 128; i++)
+          if ((double)descr[i] > 0.2) descr[i] = (float)0.2;
+    }
+  }
+  __syncthreads();
+  if (tid < 128) {
+    float v = descr[tid];
+    if (flags & OSFM_HAHOG_ROOT) v = sqrtf(v);                       // np.sqrt (features.py:526)
+    if (flags & OSFM_HAHOG_UCHAR) {                                  // (uchar_scaling * desc).clip(0, 255).round()  (features.py:527-534)
+      v = ((flags & OSFM_HAHOG_ROOT) ? 362.0f : 512.0f) * v;
+      v = v < 0.f ? 0.f : (v > 255.f ? 255.f : v);
+      v = rintf(v);
+    }
+    desc[128 * (long)f + tid] = v;
+  }
+}
+
+// _vl_new_gaussian_fitler_f (imopv.c:623-643)
+std::vector<float> gaussian_taps(double sigma, int *W) {
+  const long width = (long)std::ceil(sigma * 3.0);
+  std::vector<float> filt((size_t)(2 * width + 1));
+  float mass = (float)1.0;
+  filt[(size_t)width] = 1.0f;
+  for (long i = 1; i <= width; ++i) {
+    const double x = (double)i / sigma;
+    const double g = std::exp(-0.5 * x * x);
+    mass += g + g;
+    filt[(size_t)(width - i)] = (float)g;
+    filt[(size_t)(width + i)] = (float)g;
+  }
+  for (size_t i = 0; i < filt.size(); i++) filt[i] /= mass;
+  *W = (int)width;
+  return filt;
+}
+
+struct DevArena {
+  std::vector<void *> ptrs;
+  hipError_t err = hipSuccess;
+  ~DevArena() {
+    for (void *p : ptrs) (void)hipFree(p);
+  }
+  template <typename T>
+  T *alloc(size_t n) {
+    void *p = nullptr;
+    if (err != hipSuccess) return nullptr;
+    err = hipMalloc(&p, (n ? n : 1) * sizeof(T));
+    if (err == hipSuccess) ptrs.push_back(p);
+    return (T *)p;
+  }
+};
+
+inline dim3 grid2(int w, int h, int z = 1) { return dim3((unsigned)((w + 255) / 256), (unsigned)h, (unsigned)z); }
+
+}  // namespace
+
+extern "C" int osfm_hahog_extract(osfm_ctx *ctx, const float *image, int rows, int cols, float peak_threshold, float edge_threshold,
+                                  int target_num_features, int flags, float *points, float *desc, int capacity, int *n_features) {
+  OSFM_REQUIRE(ctx && image && n_features, OSFM_E_INVALID, "osfm_hahog_extract: null argument");
+  OSFM_REQUIRE(rows >= 17 && cols >= 17, OSFM_E_INVALID, "osfm_hahog_extract: image %d x %d is smaller than one 16-pixel octave", rows, cols);
+  OSFM_REQUIRE(target_num_features >= 0 && capacity >= 0, OSFM_E_INVALID, "osfm_hahog_extract: negative count");
+  OSFM_CTX_LOCK(ctx);
+  OSFM_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  *n_features = 0;
+  const int W0 = cols, H0 = rows;
+  // vl_covdet_put_image (covdet.c:1670-1725): (minOctaveSize - 1) 2^lastOctave <= min(width, height) - 1
+  const int last_octave = (int)std::floor(std::log2(std::min((double)W0 - 1, (double)H0 - 1) / 15.0));
+  OSFM_REQUIRE(last_octave >= 0 && last_octave < kMaxOct, OSFM_E_UNSUPPORTED, "osfm_hahog_extract: %d octaves", last_octave + 1);
+  Pyramid py;
+  memset(&py, 0, sizeof(py));
+  py.n_oct = last_octave + 1;
+  py.base_scale = 1.6 * std::pow(2.0, 1.0 / kRes);
+  DevArena A;
+  for (int o = 0; o <= last_octave; o++) {
+    py.oct[o].w = W0 >> o;
+    py.oct[o].h = H0 >> o;
+    const size_t n = (size_t)py.oct[o].w * py.oct[o].h * kLev;
+    py.oct[o].gss = A.alloc<float>(n);
+    py.oct[o].css = A.alloc<float>(n);
+    for (int s = kFirstSub; s <= kLastSub; s++) py.sigma[o][s - kFirstSub] = py.base_scale * std::pow(2.0, o + (double)s / kRes);
+  }
+  float *d_tmp = A.alloc<float>((size_t)W0 * H0);
+  float *d_taps = A.alloc<float>((size_t)kMaxTaps * (kLev + 1) * kMaxOct);
+  OSFM_REQUIRE(A.err == hipSuccess, OSFM_E_NOMEM, "osfm_hahog_extract: device allocation failed: %s", hipGetErrorString(A.err));
+  // every Gaussian of the pyramid, from the host's libm
+  std::vector<float> h_taps((size_t)kMaxTaps * (kLev + 1) * kMaxOct, 0.f);
+  std::vector<int> tapW((size_t)(kLev + 1) * kMaxOct, -1);
+  auto set_taps = [&](int slot, double sigma) -> int {
+    int W;
+    const std::vector<float> f = gaussian_taps(sigma, &W);
+    if ((int)f.size() > kMaxTaps) return -1;
+    memcpy(h_taps.data() + (size_t)slot * kMaxTaps, f.data(), f.size() * sizeof(float));
+    tapW[(size_t)slot] = W;
+    return W;
+  };
+  bool first_smooth[kMaxOct];
+  for (int o = 0; o <= last_octave; o++) {
+    const double step = std::pow(2.0, o);
+    const int base = o * (kLev + 1);
+    // first level of the octave (scalespace.c:741-752 from the image, :797-809 from the previous octave)
+    const double sigma = py.sigma[o][0];
+    const double prev = o == 0 ? 0.5 : py.sigma[o - 1][std::min(kFirstSub + kRes, kLastSub) - kFirstSub];
+    first_smooth[o] = sigma > prev;
+    if (first_smooth[o]) {
+      const double delta = std::sqrt(sigma * sigma - prev * prev);
+      OSFM_REQUIRE(set_taps(base, delta / step) >= 0, OSFM_E_UNSUPPORTED, "osfm_hahog_extract: Gaussian wider than %d taps", kMaxTaps);
+    }
+    for (int s = kFirstSub + 1; s <= kLastSub; s++) {  // scalespace.c:675-693 (sqrtf there)
+      const double sg = py.sigma[o][s - kFirstSub], pv = py.sigma[o][s - 1 - kFirstSub];
+      const double delta = sqrtf(sg * sg - pv * pv);
+      OSFM_REQUIRE(set_taps(base + (s - kFirstSub), delta / step) >= 0, OSFM_E_UNSUPPORTED, "osfm_hahog_extract: Gaussian wider than %d taps", kMaxTaps);
+    }
+  }
+  OSFM_HIP(hipMemcpyAsync(d_taps, h_taps.data(), h_taps.size() * sizeof(float), hipMemcpyHostToDevice, st));
+  auto smooth = [&](const float *src, float *dst, int w, int h, int slot) {
+    const int W = tapW[(size_t)slot];
+    hipLaunchKernelGGL(conv_v_kernel, grid2(w, h), dim3(256), 0, st, src, d_tmp, w, h, d_taps + (size_t)slot * kMaxTaps, W);
+    hipLaunchKernelGGL(conv_h_kernel, grid2(w, h), dim3(256), 0, st, (const float *)d_tmp, dst, w, h, d_taps + (size_t)slot * kMaxTaps, W);
+  };
+  // vl_scalespace_put_image
+  OSFM_HIP(hipMemcpyAsync(py.oct[0].gss, image, (size_t)W0 * H0 * sizeof(float), hipMemcpyHostToDevice, st));
+  for (int o = 0; o <= last_octave; o++) {
+    const Octave &oc = py.oct[o];
+    const size_t npx = (size_t)oc.w * oc.h;
+    const int base = o * (kLev + 1);
+    if (o > 0) {
+      const Octave &pv = py.oct[o - 1];
+      const int pl = std::min(kFirstSub + kRes, kLastSub) - kFirstSub;
+      hipLaunchKernelGGL(downsample_kernel, grid2(oc.w, oc.h), dim3(256), 0, st, (const float *)(pv.gss + (size_t)pl * pv.w * pv.h), pv.w, pv.h, oc.gss,
+                         oc.w, oc.h);
+    }
+    if (first_smooth[o]) smooth(oc.gss, oc.gss, oc.w, oc.h, base);
+    for (int l = 1; l < kLev; l++) smooth(oc.gss + (size_t)(l - 1) * npx, oc.gss + (size_t)l * npx, oc.w, oc.h, base + l);
+    for (int l = 0; l < kLev; l++) {
+      const double step = std::pow(2.0, o);
+      const float factor = (float)std::pow(py.sigma[o][l] / step, 4.0);
+      hipLaunchKernelGGL(hessian_kernel, grid2(oc.w, oc.h), dim3(256), 0, st, (const float *)(oc.gss + (size_t)l * npx), oc.css + (size_t)l * npx, oc.w,
+                         oc.h, factor);
+    }
+  }
+  // detection
+  Features F;
+  F.cap = 1 << 20;
+  F.x = A.alloc<float>((size_t)F.cap); F.y = A.alloc<float>((size_t)F.cap); F.sigma = A.alloc<float>((size_t)F.cap);
+  F.peak = A.alloc<float>((size_t)F.cap); F.edge = A.alloc<float>((size_t)F.cap);
+  F.o = A.alloc<int>((size_t)F.cap); F.s = A.alloc<int>((size_t)F.cap);
+  F.key = A.alloc<unsigned long long>((size_t)F.cap);
+  F.count = A.alloc<int>(4);
+  OSFM_REQUIRE(A.err == hipSuccess, OSFM_E_NOMEM, "osfm_hahog_extract: device allocation failed: %s", hipGetErrorString(A.err));
+  OSFM_HIP(hipMemsetAsync(F.count, 0, 4 * sizeof(int), st));
+  for (int o = last_octave; o >= 0; o--) {
+    const Octave &oc = py.oct[o];
+    if (oc.w < 3 || oc.h < 3) continue;
+    hipLaunchKernelGGL(extrema_kernel, grid2(oc.w - 2, oc.h - 2, kLev - 2), dim3(256), 0, st, (const float *)oc.css, oc.w, oc.h, o, last_octave,
+                       std::pow(2.0, o), 0.8 * (double)peak_threshold, (double)peak_threshold, (double)edge_threshold, py.base_scale, F);
+  }
+  int n0 = 0;
+  OSFM_HIP(hipMemcpyAsync(&n0, F.count, sizeof(int), hipMemcpyDeviceToHost, st));
+  OSFM_HIP(hipStreamSynchronize(st));
+  OSFM_REQUIRE(n0 <= F.cap, OSFM_E_UNSUPPORTED, "osfm_hahog_extract: %d extrema exceed the buffer of %d", n0, F.cap);
+  if (n0 == 0 || target_num_features == 0) return OSFM_OK;  // (hahog.cc:24-27 with target 0: the sorted list is cut to nothing)
+  // vlfeat's order of detection, then hahog.cc's selection (stable sorts: glibc's qsort is a merge sort)
+  const int nblk0 = (n0 + 255) / 256;
+  int *d_iota = A.alloc<int>((size_t)n0), *d_ord = A.alloc<int>((size_t)n0), *d_ord2 = A.alloc<int>((size_t)n0), *d_sel = A.alloc<int>((size_t)n0);
+  unsigned long long *d_keys = A.alloc<unsigned long long>((size_t)n0);
+  float *d_sc = A.alloc<float>((size_t)n0), *d_sc2 = A.alloc<float>((size_t)n0);
+  size_t tb1 = 0, tb2 = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, tb1, F.key, d_keys, d_iota, d_ord, (size_t)n0, 0u, 64u, st);
+  (void)rocprim::radix_sort_pairs_desc(nullptr, tb2, d_sc, d_sc2, d_iota, d_ord2, (size_t)n0, 0u, 32u, st);
+  unsigned char *d_tmpsort = A.alloc<unsigned char>(std::max(tb1, tb2) + 256);
+  OSFM_REQUIRE(A.err == hipSuccess, OSFM_E_NOMEM, "osfm_hahog_extract: device allocation failed: %s", hipGetErrorString(A.err));
+  hipLaunchKernelGGL(iota_kernel, dim3(nblk0), dim3(256), 0, st, d_iota, n0);
+  OSFM_HIP(rocprim::radix_sort_pairs(d_tmpsort, tb1, F.key, d_keys, d_iota, d_ord, (size_t)n0, 0u, 64u, st));
+  int n1 = n0;
+  const int *d_order = d_ord;  // feature i of the selection = detected feature d_order[i]
+  const int to_keep = 3 * target_num_features / 2;
+  if (n0 > target_num_features) {  // (n0 > to_keep: sort, keep to_keep; then n > target: sort again, keep target)
+    hipLaunchKernelGGL(gather_f_kernel, dim3(nblk0), dim3(256), 0, st, (const int *)d_ord, (const float *)F.peak, d_sc, n0);
+    OSFM_HIP(rocprim::radix_sort_pairs_desc(d_tmpsort, tb2, d_sc, d_sc2, d_iota, d_ord2, (size_t)n0, 0u, 32u, st));
+    hipLaunchKernelGGL(compose_kernel, dim3(nblk0), dim3(256), 0, st, (const int *)d_ord2, (const int *)d_ord, d_sel, n0);
+    d_order = d_sel;
+    n1 = std::min(n0, target_num_features);
+    (void)to_keep;
+  }
+  // selected features, gathered
+  float *sx = A.alloc<float>((size_t)n1), *sy = A.alloc<float>((size_t)n1), *ssg = A.alloc<float>((size_t)n1);
+  int *d_nor = A.alloc<int>((size_t)n1), *d_off = A.alloc<int>((size_t)n1 + 1);
+  double *d_ang = A.alloc<double>((size_t)n1 * kMaxOr);
+  // tables from the host's libm: the orientation mask (covdet.c:1536-1548) and fast_expn's (sift.c:714-720)
+  std::vector<double> h_tab((size_t)kOrSide * kOrSide + 257);
+  {
+    const int w = kOrRes;
+    const double step = (2.0 * kOrExtent) / (2 * w + 1), sigma = 3;
+    for (int j = -w; j <= w; ++j)
+      for (int i = -w; i <= w; ++i) {
+        const double dx = i * step / sigma, dy = j * step / sigma;
+        h_tab[(size_t)((i + w) + (2 * w + 1) * (j + w))] = (double)(float)std::exp(-0.5 * (dx * dx + dy * dy));  // `float aaMask[]` (covdet.c:1471)
+      }
+    for (int k = 0; k < 257; ++k) h_tab[(size_t)kOrSide * kOrSide + k] = std::exp(-(double)k * (25.0 / 256));
+  }
+  double *d_tab = A.alloc<double>(h_tab.size());
+  OSFM_REQUIRE(A.err == hipSuccess, OSFM_E_NOMEM, "osfm_hahog_extract: device allocation failed: %s", hipGetErrorString(A.err));
+  OSFM_HIP(hipMemcpyAsync(d_tab, h_tab.data(), h_tab.size() * sizeof(double), hipMemcpyHostToDevice, st));
+  const int nblk1 = (n1 + 255) / 256;
+  hipLaunchKernelGGL(gather_f_kernel, dim3(nblk1), dim3(256), 0, st, d_order, (const float *)F.x, sx, n1);
+  hipLaunchKernelGGL(gather_f_kernel, dim3(nblk1), dim3(256), 0, st, d_order, (const float *)F.y, sy, n1);
+  hipLaunchKernelGGL(gather_f_kernel, dim3(nblk1), dim3(256), 0, st, d_order, (const float *)F.sigma, ssg, n1);
+  hipLaunchKernelGGL(orientation_kernel, dim3(n1), dim3(256), 0, st, py, (const float *)sx, (const float *)sy, (const float *)ssg, n1,
+                     (const double *)d_tab, d_nor, d_ang);
+  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, (const int *)d_nor, n1, d_off);
+  int n2 = 0;
+  OSFM_HIP(hipMemcpyAsync(&n2, d_off + n1, sizeof(int), hipMemcpyDeviceToHost, st));
+  OSFM_HIP(hipStreamSynchronize(st));
+  *n_features = n2;
+  if (n2 == 0) return OSFM_OK;
+  OSFM_REQUIRE(points && desc && n2 <= capacity, OSFM_E_INVALID,
+               "osfm_hahog_extract: %d features do not fit the capacity of %d (4 x target_num_features always does)", n2, capacity);
+  Oriented R;
+  R.x = A.alloc<float>((size_t)n2); R.y = A.alloc<float>((size_t)n2);
+  R.a11 = A.alloc<float>((size_t)n2); R.a21 = A.alloc<float>((size_t)n2); R.a12 = A.alloc<float>((size_t)n2); R.a22 = A.alloc<float>((size_t)n2);
+  float *d_points = A.alloc<float>((size_t)4 * n2), *d_desc = A.alloc<float>((size_t)128 * n2);
+  OSFM_REQUIRE(A.err == hipSuccess, OSFM_E_NOMEM, "osfm_hahog_extract: device allocation failed: %s", hipGetErrorString(A.err));
+  hipLaunchKernelGGL(orient_frames_kernel, dim3(nblk1), dim3(256), 0, st, (const float *)sx, (const float *)sy, (const float *)ssg, (const int *)d_off,
+                     (const int *)d_nor, (const double *)d_ang, n1, R);
+  // hahog.cc:168-199: the descriptor's scale in patch pixels and the orientation pi / 2, with the host's libm
+  const double patchStep = (double)kDExtent / kDRes;
+  const double sigma_d = (double)kDExtent / (3.0 * (4 + 1) / 2) / patchStep;
+  hipLaunchKernelGGL(descriptor_kernel, dim3(n2), dim3(256), 0, st, py, R, n2, (const double *)(d_tab + (size_t)kOrSide * kOrSide), std::sin(kPi / 2),
+                     std::cos(kPi / 2), sigma_d, flags, d_points, d_desc);
+  OSFM_HIP(hipGetLastError());
+  OSFM_HIP(hipMemcpyAsync(points, d_points, (size_t)4 * n2 * sizeof(float), hipMemcpyDeviceToHost, st));
+  OSFM_HIP(hipMemcpyAsync(desc, d_desc, (size_t)128 * n2 * sizeof(float), hipMemcpyDeviceToHost, st));
+  OSFM_HIP(hipStreamSynchronize(st));
+  return OSFM_OK;
+}

@@ -56,7 +56,8 @@ def build_hahog_ref(force: bool = False) -> Optional[str]:
     with the vendored vlfeat sources it calls (ref_adapters/hahog_ref.cc, stand-ins for its pybind11 types under ref_adapters/stubs)."""
     so = os.path.join(_HERE, "_ref", "libhahog_ref.so")
     if os.path.isdir(REFERENCE_ROBUST):
-        deps = [os.path.join(_HERE, "ref_adapters", "hahog_ref.cc"), os.path.join(_HERE, "ref_adapters", "stubs", "foundation", "python_types.h")]
+        deps = [os.path.join(_HERE, "ref_adapters", "hahog_ref.cc"), os.path.join(_HERE, "ref_adapters", "covdet_ref.c"),
+                os.path.join(_HERE, "ref_adapters", "stubs", "foundation", "python_types.h")]
         if force or not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
             subprocess.check_call(["make", "-C", _HERE, "-B", "_ref/libhahog_ref.so"], stdout=subprocess.DEVNULL)
     return so if os.path.exists(so) else None

@@ -1,0 +1,103 @@
+"""HAHOG extraction on the GPU (csrc/hahog.hip) against the REFERENCE's own features::hahog -- opensfm/src/features/src/hahog.cc over the
+vendored vlfeat, compiled from /root/reference into oracle/_ref/libhahog_ref.so (oracle.hahog_ref) -- and against the golden vectors
+that library produced in the build container (tests/golden/hahog_berlin01.npz, made by tests/golden/make_hahog_golden.py from the
+reference's data/berlin/images/01.jpg).
+
+Stated tolerance.  The set of features, their order, x, y, size and all 128 descriptor values are expected to be the reference's BIT FOR
+BIT (the kernels follow vlfeat operation for operation; measured: identical on every case below).  The orientation angle in degrees
+goes through atan2f, whose last bit differs between glibc and the device library: |angle difference| <= 1e-4 degrees.  The few per-feature
+libm calls made on the device in double (pow, exp, cos, sin) feed float fields; should a last bit ever flip one, a row may differ by a
+float ulp -- the assertions therefore allow descriptor differences up to 2e-6 (1 level of 255 after scaling) in at most 1 row of 1000."""
+import os
+
+import numpy as np
+import pytest
+
+from opensfm_amd import features
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hahog_berlin01.npz")
+CFG = {"feature_root": True, "hahog_normalize_to_uchar": True, "hahog_peak_threshold": 1e-5, "hahog_edge_threshold": 10}
+
+
+def _compare(pts, desc, rp, rd, tol_desc=2e-6):
+    assert pts.shape == rp.shape and desc.shape == rd.shape, (pts.shape, rp.shape)
+    if len(pts) == 0:
+        return
+    assert np.array_equal(pts[:, :3], rp[:, :3]) or (np.abs(pts[:, :3] - rp[:, :3]).max(axis=1) > 0).sum() <= max(1, len(pts) // 1000)
+    dang = np.abs(pts[:, 3] - rp[:, 3])
+    dang = np.minimum(dang, 360.0 - dang)
+    assert dang.max() <= 1e-4, dang.max()
+    d = np.abs(desc - rd).max(axis=1)
+    assert d.max() <= tol_desc and (d > 0).sum() <= max(1, len(pts) // 1000), (d.max(), int((d > 0).sum()))
+
+
+def test_golden_vectors_of_the_reference(gpu_ctx):
+    g = np.load(GOLDEN)
+    grey = g["grey"]
+    pts, desc = features.hahog(grey.astype(np.float32) / 255, 1e-5, 10.0, 1500)
+    assert pts.shape == g["points"].shape
+    assert np.array_equal(pts[:, :3], g["points"][:, :3])
+    assert np.abs(pts[:, 3] - g["points"][:, 3]).max() <= 1e-4
+    assert np.abs(desc[:64] - g["desc_f32_head"]).max() <= 2e-6
+    # as features.extract_features_hahog returns them (square root, x 362, clip, round): integer levels
+    p8, d8 = features.extract_features_hahog(grey, CFG, 1500)
+    assert np.array_equal(p8[:, :3], g["points"][:, :3])
+    assert d8.dtype == np.float32 and np.array_equal(d8, np.round(d8)) and d8.min() >= 0 and d8.max() <= 255
+    diff = np.abs(d8 - g["desc_u8"].astype(np.float32))
+    assert diff.max() <= 1 and np.count_nonzero(diff) <= d8.size // 10000, (diff.max(), np.count_nonzero(diff))
+
+
+def _texture(rows, cols, seed):
+    """blobs, edges and noise at several scales, grey levels in [0, 1]"""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:rows, 0:cols].astype(np.float32)
+    im = np.zeros((rows, cols), np.float32)
+    for _ in range(300):
+        cx, cy, s = rng.uniform(0, cols), rng.uniform(0, rows), rng.uniform(1.5, 18)
+        im += rng.uniform(-1, 1) * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * s * s))
+    im += 0.3 * np.sin(xx / 7.0) * np.cos(yy / 11.0) + 0.05 * rng.standard_normal((rows, cols)).astype(np.float32)
+    im -= im.min()
+    return np.ascontiguousarray(im / im.max(), np.float32)
+
+
+@pytest.mark.parametrize("rows,cols,target,seed", [(333, 517, 400, 1), (480, 640, 100000, 2), (257, 129, 50, 3), (900, 1200, 3000, 4), (64, 64, 10, 5)])
+def test_matches_the_compiled_reference(oracle_lib, gpu_ctx, rows, cols, target, seed):
+    """odd sizes (the octaves halve by truncation), a target above the number of detections (no sort: vlfeat's detection order), features
+    at the border (padded patches), a tiny image"""
+    im = _texture(rows, cols, seed)
+    ref = oracle_lib.hahog_ref(im, 1e-5, 10.0, target)
+    if ref is None:
+        pytest.skip("oracle/_ref/libhahog_ref.so is not available (it is built where /root/reference is mounted)")
+    pts, desc = features.hahog(im, 1e-5, 10.0, target)
+    _compare(pts, desc, *ref)
+
+
+def test_thresholds_and_empty_results(oracle_lib, gpu_ctx):
+    im = _texture(200, 300, 9)
+    for peak, edge, target in ((1e-3, 10.0, 500), (1e-5, 2.0, 500), (10.0, 10.0, 500), (1e-5, 10.0, 0)):
+        pts, desc = features.hahog(im, peak, edge, target)
+        ref = oracle_lib.hahog_ref(im, peak, edge, target)
+        if ref is None:
+            pytest.skip("oracle/_ref/libhahog_ref.so is not available")
+        _compare(pts, desc, *ref)
+    assert len(features.hahog(im, 10.0, 10.0, 500)[0]) == 0
+    assert len(features.hahog(im, 1e-5, 10.0, 0)[0]) == 0  # hahog.cc:24-27 keeps `target` = 0 of the sorted list
+    assert features.hahog(np.zeros((0, 0), np.float32), 1e-5, 10.0, 10) is None  # hahog.cc:127-129
+
+
+def test_descriptors_feed_the_matcher(gpu_ctx):
+    """two crops of the example image: the integer-valued descriptors go straight into the resident store of the matcher"""
+    from opensfm_amd import matching
+
+    g = np.load(GOLDEN)
+    grey = g["grey"]
+    a, b = grey[:, :560], grey[:, 80:]
+    pa, da = features.extract_features_hahog(a, CFG, 1200)
+    pb, db = features.extract_features_hahog(b, CFG, 1200)
+    cfg = {"lowes_ratio": 0.8}
+    m = matching.match_brute_force_symmetric(da, db, cfg)
+    m = np.asarray(m)
+    assert len(m) > 200
+    dx = pb[m[:, 1], 0] - pa[m[:, 0], 0]
+    assert np.median(np.abs(dx + 80)) < 0.5  # the crops are 80 pixels apart
