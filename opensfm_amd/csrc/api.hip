@@ -263,54 +263,7 @@ __global__ void gather_matches_kernel(const int32_t *counts, const int64_t *offs
   }
 }
 
-struct DevBuf {
-  void *p = nullptr;
-  size_t bytes = 0;
-  osfm_ctx *pool = nullptr;  // non-null: taken from / returned to the context's cache (the caller holds the context lock)
-  ~DevBuf() { release(); }
-  void release() {
-    if (!p) return;
-    if (pool && pool->pool_bytes + bytes <= osfm_ctx::kPoolBytes && pool->pool.size() < 64) {
-      pool->pool.push_back({p, bytes});
-      pool->pool_bytes += bytes;
-    } else {
-      (void)hipFree(p);
-    }
-    p = nullptr;
-  }
-  hipError_t alloc(size_t want) {
-    bytes = want ? want : 16;
-    return hipMalloc(&p, bytes);
-  }
-  hipError_t alloc(osfm_ctx *ctx, size_t want) {
-    want = want ? want : 16;
-    pool = ctx;
-    int best = -1;
-    for (int i = 0; i < (int)ctx->pool.size(); ++i)
-      if (ctx->pool[i].bytes >= want && ctx->pool[i].bytes <= 2 * want + 4096 && (best < 0 || ctx->pool[i].bytes < ctx->pool[best].bytes)) best = i;
-    if (best >= 0) {
-      p = ctx->pool[best].p;
-      bytes = ctx->pool[best].bytes;
-      ctx->pool_bytes -= bytes;
-      ctx->pool.erase(ctx->pool.begin() + best);
-      return hipSuccess;
-    }
-    bytes = want;
-    hipError_t e = hipMalloc(&p, bytes);
-    if (e != hipSuccess && !ctx->pool.empty()) {  // out of memory with blocks cached: drop the cache and try again
-      for (auto &b : ctx->pool) (void)hipFree(b.p);
-      ctx->pool.clear();
-      ctx->pool_bytes = 0;
-      (void)hipGetLastError();
-      e = hipMalloc(&p, bytes);
-    }
-    return e;
-  }
-  template <typename T>
-  T *as() {
-    return (T *)p;
-  }
-};
+using DevBuf = OsfmPoolBuf;
 }  // namespace
 
 static int match_pairs_impl(osfm_ctx *ctx, const osfm_store *store, const int32_t *pairs, int64_t n_pairs,

@@ -462,7 +462,8 @@ struct Oriented {
 __global__ void __launch_bounds__(256) orientation_kernel(Pyramid py, const float *fx, const float *fy, const float *fsigma, int n,
                                                           const double *aa_mask, int *n_or, double *or_angle /* n x 4 */) {
   __shared__ float patch[kOrSide * kOrSide], tmp[kOrSide * kOrSide];
-  __shared__ float pmod[kOrSide * kOrSide], pang[kOrSide * kOrSide];
+  __shared__ int hbin[kOrSide * kOrSide];
+  __shared__ double hc1[kOrSide * kOrSide], hc2[kOrSide * kOrSide];
   __shared__ float taps1[kMaxTaps];
   __shared__ int W1;
   __shared__ PatchPlan P;
@@ -519,19 +520,28 @@ __global__ void __launch_bounds__(256) orientation_kernel(Pyramid py, const floa
     patch[t] = acc;
   }
   __syncthreads();
-  for (int t = tid; t < kOrSide * kOrSide; t += 256) polar_gradient(patch, kOrSide, t, &pmod[t], &pang[t]);
-  __syncthreads();
-  // histogram: bin b adds, in raster order, what the sequential loop adds to it
+  // per pixel, in parallel: the bin and the two products the sequential loop adds (covdet.c:2769-2781)
   const double binExtent = 2 * kPi / kOrBins;
+  for (int t = tid; t < kOrSide * kOrSide; t += 256) {
+    float fm, fa;
+    polar_gradient(patch, kOrSide, t, &fm, &fa);
+    const double modulus = fm, angle = fa, weight = aa_mask[t];
+    const double xx = angle / binExtent;
+    const long bin = vl_floor_d(xx);
+    const double w2 = xx - bin, w1 = 1.0 - w2;
+    hbin[t] = (int)((bin + kOrBins) % kOrBins);
+    hc1[t] = w1 * (modulus * weight);
+    hc2[t] = w2 * (modulus * weight);
+  }
+  __syncthreads();
+  // bin b adds, in raster order, what the sequential loop adds to it
   if (tid < kOrBins) {
+    const int prev = (tid + kOrBins - 1) % kOrBins;
     double hsum = 0.0;
     for (int k = 0; k < kOrSide * kOrSide; k++) {
-      const double modulus = pmod[k], angle = pang[k], weight = aa_mask[k];
-      const double xx = angle / binExtent;
-      const long bin = vl_floor_d(xx);
-      const double w2 = xx - bin, w1 = 1.0 - w2;
-      if ((bin + kOrBins) % kOrBins == tid) hsum += w1 * (modulus * weight);
-      if ((bin + kOrBins + 1) % kOrBins == tid) hsum += w2 * (modulus * weight);
+      const int b = hbin[k];
+      if (b == tid) hsum += hc1[k];
+      if (b == prev) hsum += hc2[k];
     }
     hist[tid] = hsum;
   }
@@ -739,21 +749,25 @@ std::vector<float> gaussian_taps(double sigma, int *W) {
   return filt;
 }
 
-struct DevArena {
-  std::vector<void *> ptrs;
-  hipError_t err = hipSuccess;
-  ~DevArena() {
-    for (void *p : ptrs) (void)hipFree(p);
-  }
+// Device memory of one call: two slabs from the context's cache of blocks (the pyramid and fixed-size buffers; what depends on the number
+// of detections), handed out in 256-byte steps -- a dozen hipMalloc / hipFree pairs per image cost more than the kernels
+struct Slab {
+  OsfmPoolBuf buf;
+  size_t used = 0;
+  bool overflow = false;
   template <typename T>
-  T *alloc(size_t n) {
-    void *p = nullptr;
-    if (err != hipSuccess) return nullptr;
-    err = hipMalloc(&p, (n ? n : 1) * sizeof(T));
-    if (err == hipSuccess) ptrs.push_back(p);
-    return (T *)p;
+  T *take(size_t n) {
+    const size_t bytes = ((n ? n : 1) * sizeof(T) + 255) / 256 * 256;
+    if (used + bytes > buf.bytes) {
+      overflow = true;
+      return nullptr;
+    }
+    T *p = (T *)((char *)buf.p + used);
+    used += bytes;
+    return p;
   }
 };
+inline size_t padded(size_t n, size_t elem) { return ((n ? n : 1) * elem + 255) / 256 * 256; }
 
 inline dim3 grid2(int w, int h, int z = 1) { return dim3((unsigned)((w + 255) / 256), (unsigned)h, (unsigned)z); }
 
@@ -776,18 +790,24 @@ extern "C" int osfm_hahog_extract(osfm_ctx *ctx, const float *image, int rows, i
   memset(&py, 0, sizeof(py));
   py.n_oct = last_octave + 1;
   py.base_scale = 1.6 * std::pow(2.0, 1.0 / kRes);
-  DevArena A;
+  Slab A, B;
+  constexpr int kFeatureCap = 1 << 20;
+  {
+    size_t need = padded((size_t)W0 * H0, 4) + padded((size_t)kMaxTaps * (kLev + 1) * kMaxOct, 4) + 5 * padded(kFeatureCap, 4) + 2 * padded(kFeatureCap, 4) +
+                  padded(kFeatureCap, 8) + padded(4, 4) + padded((size_t)kOrSide * kOrSide + 257, 8);
+    for (int o = 0; o <= last_octave; o++) need += 2 * padded((size_t)(W0 >> o) * (H0 >> o) * kLev, 4);
+    OSFM_REQUIRE(A.buf.alloc(ctx, need) == hipSuccess, OSFM_E_NOMEM, "osfm_hahog_extract: %zu bytes of device memory", need);
+  }
   for (int o = 0; o <= last_octave; o++) {
     py.oct[o].w = W0 >> o;
     py.oct[o].h = H0 >> o;
     const size_t n = (size_t)py.oct[o].w * py.oct[o].h * kLev;
-    py.oct[o].gss = A.alloc<float>(n);
-    py.oct[o].css = A.alloc<float>(n);
+    py.oct[o].gss = A.take<float>(n);
+    py.oct[o].css = A.take<float>(n);
     for (int s = kFirstSub; s <= kLastSub; s++) py.sigma[o][s - kFirstSub] = py.base_scale * std::pow(2.0, o + (double)s / kRes);
   }
-  float *d_tmp = A.alloc<float>((size_t)W0 * H0);
-  float *d_taps = A.alloc<float>((size_t)kMaxTaps * (kLev + 1) * kMaxOct);
-  OSFM_REQUIRE(A.err == hipSuccess, OSFM_E_NOMEM, "osfm_hahog_extract: device allocation failed: %s", hipGetErrorString(A.err));
+  float *d_tmp = A.take<float>((size_t)W0 * H0);
+  float *d_taps = A.take<float>((size_t)kMaxTaps * (kLev + 1) * kMaxOct);
   // every Gaussian of the pyramid, from the host's libm
   std::vector<float> h_taps((size_t)kMaxTaps * (kLev + 1) * kMaxOct, 0.f);
   std::vector<int> tapW((size_t)(kLev + 1) * kMaxOct, -1);
@@ -846,13 +866,14 @@ extern "C" int osfm_hahog_extract(osfm_ctx *ctx, const float *image, int rows, i
   }
   // detection
   Features F;
-  F.cap = 1 << 20;
-  F.x = A.alloc<float>((size_t)F.cap); F.y = A.alloc<float>((size_t)F.cap); F.sigma = A.alloc<float>((size_t)F.cap);
-  F.peak = A.alloc<float>((size_t)F.cap); F.edge = A.alloc<float>((size_t)F.cap);
-  F.o = A.alloc<int>((size_t)F.cap); F.s = A.alloc<int>((size_t)F.cap);
-  F.key = A.alloc<unsigned long long>((size_t)F.cap);
-  F.count = A.alloc<int>(4);
-  OSFM_REQUIRE(A.err == hipSuccess, OSFM_E_NOMEM, "osfm_hahog_extract: device allocation failed: %s", hipGetErrorString(A.err));
+  F.cap = kFeatureCap;
+  F.x = A.take<float>((size_t)F.cap); F.y = A.take<float>((size_t)F.cap); F.sigma = A.take<float>((size_t)F.cap);
+  F.peak = A.take<float>((size_t)F.cap); F.edge = A.take<float>((size_t)F.cap);
+  F.o = A.take<int>((size_t)F.cap); F.s = A.take<int>((size_t)F.cap);
+  F.key = A.take<unsigned long long>((size_t)F.cap);
+  F.count = A.take<int>(4);
+  double *d_tab = A.take<double>((size_t)kOrSide * kOrSide + 257);
+  OSFM_REQUIRE(!A.overflow, OSFM_E_NOMEM, "osfm_hahog_extract: internal: slab A too small");
   OSFM_HIP(hipMemsetAsync(F.count, 0, 4 * sizeof(int), st));
   for (int o = last_octave; o >= 0; o--) {
     const Octave &oc = py.oct[o];
@@ -867,31 +888,42 @@ extern "C" int osfm_hahog_extract(osfm_ctx *ctx, const float *image, int rows, i
   if (n0 == 0 || target_num_features == 0) return OSFM_OK;  // (hahog.cc:24-27 with target 0: the sorted list is cut to nothing)
   // vlfeat's order of detection, then hahog.cc's selection (stable sorts: glibc's qsort is a merge sort)
   const int nblk0 = (n0 + 255) / 256;
-  int *d_iota = A.alloc<int>((size_t)n0), *d_ord = A.alloc<int>((size_t)n0), *d_ord2 = A.alloc<int>((size_t)n0), *d_sel = A.alloc<int>((size_t)n0);
-  unsigned long long *d_keys = A.alloc<unsigned long long>((size_t)n0);
-  float *d_sc = A.alloc<float>((size_t)n0), *d_sc2 = A.alloc<float>((size_t)n0);
   size_t tb1 = 0, tb2 = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, tb1, F.key, d_keys, d_iota, d_ord, (size_t)n0, 0u, 64u, st);
-  (void)rocprim::radix_sort_pairs_desc(nullptr, tb2, d_sc, d_sc2, d_iota, d_ord2, (size_t)n0, 0u, 32u, st);
-  unsigned char *d_tmpsort = A.alloc<unsigned char>(std::max(tb1, tb2) + 256);
-  OSFM_REQUIRE(A.err == hipSuccess, OSFM_E_NOMEM, "osfm_hahog_extract: device allocation failed: %s", hipGetErrorString(A.err));
+  {
+    int *nul = nullptr;
+    unsigned long long *nulk = nullptr;
+    float *nulf = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, tb1, nulk, nulk, nul, nul, (size_t)n0, 0u, 64u, st);
+    (void)rocprim::radix_sort_pairs_desc(nullptr, tb2, nulf, nulf, nul, nul, (size_t)n0, 0u, 32u, st);
+  }
+  const int n1max = std::min(n0, target_num_features), n2max = kMaxOr * n1max;
+  {
+    const size_t need = 4 * padded((size_t)n0, 4) + padded((size_t)n0, 8) + 2 * padded((size_t)n0, 4) + padded(std::max(tb1, tb2) + 256, 1) +
+                        3 * padded((size_t)n1max, 4) + padded((size_t)n1max, 4) + padded((size_t)n1max + 1, 4) + padded((size_t)n1max * kMaxOr, 8) +
+                        6 * padded((size_t)n2max, 4) + padded((size_t)4 * n2max, 4) + padded((size_t)128 * n2max, 4);
+    // sizes rounded up so that images of one series reuse the cached block
+    OSFM_REQUIRE(B.buf.alloc(ctx, (need + ((size_t)1 << 20)) >> 20 << 20) == hipSuccess, OSFM_E_NOMEM, "osfm_hahog_extract: %zu bytes of device memory", need);
+  }
+  int *d_iota = B.take<int>((size_t)n0), *d_ord = B.take<int>((size_t)n0), *d_ord2 = B.take<int>((size_t)n0), *d_sel = B.take<int>((size_t)n0);
+  unsigned long long *d_keys = B.take<unsigned long long>((size_t)n0);
+  float *d_sc = B.take<float>((size_t)n0), *d_sc2 = B.take<float>((size_t)n0);
+  unsigned char *d_tmpsort = B.take<unsigned char>(std::max(tb1, tb2) + 256);
+  OSFM_REQUIRE(!B.overflow, OSFM_E_NOMEM, "osfm_hahog_extract: internal: slab B too small");
   hipLaunchKernelGGL(iota_kernel, dim3(nblk0), dim3(256), 0, st, d_iota, n0);
   OSFM_HIP(rocprim::radix_sort_pairs(d_tmpsort, tb1, F.key, d_keys, d_iota, d_ord, (size_t)n0, 0u, 64u, st));
   int n1 = n0;
   const int *d_order = d_ord;  // feature i of the selection = detected feature d_order[i]
-  const int to_keep = 3 * target_num_features / 2;
-  if (n0 > target_num_features) {  // (n0 > to_keep: sort, keep to_keep; then n > target: sort again, keep target)
+  if (n0 > target_num_features) {  // (hahog.cc:75-96: n0 > 3 target / 2: sort, keep that many; then n > target: sort again, keep target)
     hipLaunchKernelGGL(gather_f_kernel, dim3(nblk0), dim3(256), 0, st, (const int *)d_ord, (const float *)F.peak, d_sc, n0);
     OSFM_HIP(rocprim::radix_sort_pairs_desc(d_tmpsort, tb2, d_sc, d_sc2, d_iota, d_ord2, (size_t)n0, 0u, 32u, st));
     hipLaunchKernelGGL(compose_kernel, dim3(nblk0), dim3(256), 0, st, (const int *)d_ord2, (const int *)d_ord, d_sel, n0);
     d_order = d_sel;
     n1 = std::min(n0, target_num_features);
-    (void)to_keep;
   }
   // selected features, gathered
-  float *sx = A.alloc<float>((size_t)n1), *sy = A.alloc<float>((size_t)n1), *ssg = A.alloc<float>((size_t)n1);
-  int *d_nor = A.alloc<int>((size_t)n1), *d_off = A.alloc<int>((size_t)n1 + 1);
-  double *d_ang = A.alloc<double>((size_t)n1 * kMaxOr);
+  float *sx = B.take<float>((size_t)n1), *sy = B.take<float>((size_t)n1), *ssg = B.take<float>((size_t)n1);
+  int *d_nor = B.take<int>((size_t)n1), *d_off = B.take<int>((size_t)n1 + 1);
+  double *d_ang = B.take<double>((size_t)n1 * kMaxOr);
   // tables from the host's libm: the orientation mask (covdet.c:1536-1548) and fast_expn's (sift.c:714-720)
   std::vector<double> h_tab((size_t)kOrSide * kOrSide + 257);
   {
@@ -904,8 +936,7 @@ extern "C" int osfm_hahog_extract(osfm_ctx *ctx, const float *image, int rows, i
       }
     for (int k = 0; k < 257; ++k) h_tab[(size_t)kOrSide * kOrSide + k] = std::exp(-(double)k * (25.0 / 256));
   }
-  double *d_tab = A.alloc<double>(h_tab.size());
-  OSFM_REQUIRE(A.err == hipSuccess, OSFM_E_NOMEM, "osfm_hahog_extract: device allocation failed: %s", hipGetErrorString(A.err));
+  OSFM_REQUIRE(!B.overflow, OSFM_E_NOMEM, "osfm_hahog_extract: internal: slab B too small");
   OSFM_HIP(hipMemcpyAsync(d_tab, h_tab.data(), h_tab.size() * sizeof(double), hipMemcpyHostToDevice, st));
   const int nblk1 = (n1 + 255) / 256;
   hipLaunchKernelGGL(gather_f_kernel, dim3(nblk1), dim3(256), 0, st, d_order, (const float *)F.x, sx, n1);
@@ -922,10 +953,10 @@ extern "C" int osfm_hahog_extract(osfm_ctx *ctx, const float *image, int rows, i
   OSFM_REQUIRE(points && desc && n2 <= capacity, OSFM_E_INVALID,
                "osfm_hahog_extract: %d features do not fit the capacity of %d (4 x target_num_features always does)", n2, capacity);
   Oriented R;
-  R.x = A.alloc<float>((size_t)n2); R.y = A.alloc<float>((size_t)n2);
-  R.a11 = A.alloc<float>((size_t)n2); R.a21 = A.alloc<float>((size_t)n2); R.a12 = A.alloc<float>((size_t)n2); R.a22 = A.alloc<float>((size_t)n2);
-  float *d_points = A.alloc<float>((size_t)4 * n2), *d_desc = A.alloc<float>((size_t)128 * n2);
-  OSFM_REQUIRE(A.err == hipSuccess, OSFM_E_NOMEM, "osfm_hahog_extract: device allocation failed: %s", hipGetErrorString(A.err));
+  R.x = B.take<float>((size_t)n2); R.y = B.take<float>((size_t)n2);
+  R.a11 = B.take<float>((size_t)n2); R.a21 = B.take<float>((size_t)n2); R.a12 = B.take<float>((size_t)n2); R.a22 = B.take<float>((size_t)n2);
+  float *d_points = B.take<float>((size_t)4 * n2), *d_desc = B.take<float>((size_t)128 * n2);
+  OSFM_REQUIRE(!B.overflow, OSFM_E_NOMEM, "osfm_hahog_extract: internal: slab B too small");
   hipLaunchKernelGGL(orient_frames_kernel, dim3(nblk1), dim3(256), 0, st, (const float *)sx, (const float *)sy, (const float *)ssg, (const int *)d_off,
                      (const int *)d_nor, (const double *)d_ang, n1, R);
   // hahog.cc:168-199: the descriptor's scale in patch pixels and the orientation pi / 2, with the host's libm

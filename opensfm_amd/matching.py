@@ -640,17 +640,21 @@ def match_images_with_pairs(data, config_override: Dict[str, Any], exifs: Dict[s
     """
     config = dict(data.config)
     config.update(config_override)
-    use_words = str(_cfg(config, "matcher_type")).upper() == "WORDS"
-    if not use_words:
+    # guided matching always runs the brute-force matcher, whatever matcher_type says (matching.py:270-279 logs a warning and switches)
+    use_words = str(_cfg(config, "matcher_type")).upper() == "WORDS" and not poses
+    if not use_words and not poses:
         _matcher_flags(config)  # raises for matchers that are not on the GPU path
-    elif poses:
-        raise NotImplementedError("guided matching goes with the BRUTEFORCE matcher (matching.py:260-337)")
     if config.get("matching_use_segmentation"):  # matching.py:352: segmentation labels inside the descriptors: not implemented here
         raise NotImplementedError("config 'matching_use_segmentation' is not implemented on the GPU path")
     use_filters = bool(config.get("matching_use_filters"))
-    if int(_cfg(config, "robust_matching_min_match")) < 15:
-        raise NotImplementedError("robust_matching_min_match < 15 reaches cv2's LMedS branch inside match(); only the leaf "
-                                  "find_fundamental_ransac implements it")
+    lmeds_reachable = int(_cfg(config, "robust_matching_min_match")) < 15
+
+    def _check_f_route(pin: np.ndarray) -> None:
+        # cv2.findFundamentalMat switches to LMedS below 15 correspondences; the batched fundamental-matrix launch implements RANSAC only
+        # (the leaf find_fundamental_ransac has both).  Pairs on the calibrated route never reach cv2, so only they may go on.
+        if lmeds_reachable and pin.any():
+            raise NotImplementedError("robust_matching_min_match < 15 reaches cv2's LMedS branch inside match() for the pairs on the "
+                                      "fundamental-matrix route; only the leaf find_fundamental_ransac implements it")
     cameras = data.load_camera_models()
     images = sorted({im for pair in pairs for im in pair})
     index = {im: k for k, im in enumerate(images)}
@@ -685,8 +689,13 @@ def match_images_with_pairs(data, config_override: Dict[str, Any], exifs: Dict[s
         if use_words:  # feature_loader.load_words(data, image, masked=True) (feature_loader.py:96-107)
             w = np.zeros((0, 1), np.int32)
             if len(points):
-                w = np.asarray(data.load_words(im))
-                w = (w[mask] if mask is not None else w).astype(np.int32).reshape(len(points), -1)
+                w = data.load_words(im)
+                if w is None:  # matching.py:380-381: no words -> the dummy result for every pair of this image: a count-0 image
+                    descs[-1], pts[-1], masks[-1] = np.zeros((0, 128), np.float32), np.zeros((0, 3)), None
+                    w = np.zeros((0, 1), np.int32)
+                else:
+                    w = np.asarray(w)
+                    w = (w[mask] if mask is not None else w).astype(np.int32).reshape(len(points), -1)
             wordlists.append(w)
     ipairs = np.asarray([(index[a], index[b]) for a, b in pairs], np.int32).reshape(-1, 2)
     per_pair: List[np.ndarray] = [np.zeros((0, 2), np.int32)] * len(ipairs)
@@ -701,6 +710,8 @@ def match_images_with_pairs(data, config_override: Dict[str, Any], exifs: Dict[s
         store = DescriptorStore(descs, pts)
         try:
             pin = np.array([_is_pinhole(cams[a]) and _is_pinhole(cams[b]) for a, b in ipairs], bool)
+            if not use_filters:
+                _check_f_route(pin)
             if use_filters:  # matching.py:323-334: the filters follow the guided descriptor stage
                 counts, matches = match_pairs_guided(store, ipairs, bearings, rels, cfg_g, robust=False)
                 per_pair = _filter_then_robust(data, config, pairs, ipairs, split_matches(counts, matches), pts, cams)
@@ -738,6 +749,8 @@ def match_images_with_pairs(data, config_override: Dict[str, Any], exifs: Dict[s
         store = DescriptorStore(descs, pts)  # all descriptors resident in HBM for the batched launches
         try:
             pin = np.array([_is_pinhole(cams[a]) and _is_pinhole(cams[b]) for a, b in ipairs], bool)
+            if not use_filters:
+                _check_f_route(pin)
             if use_filters:  # matching.py:399-411: descriptor stage for every pair, filters on the host, robust stage through the leaves
                 counts, matches = match_pairs(store, ipairs, config, robust=False)
                 per_pair = _filter_then_robust(data, config, pairs, ipairs, split_matches(counts, matches), pts, cams)

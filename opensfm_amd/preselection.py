@@ -76,14 +76,31 @@ def radius_points(candidates: np.ndarray, queries: np.ndarray, max_distance: flo
     return bits[:, : len(cand)].astype(bool)
 
 
+_RADIUS_CHUNK = 4096  # queries per device call of the radius search: the dense hit table of a chunk is chunk x candidates bytes on the host
+
+
+def _radius_lists(points: np.ndarray, queries: np.ndarray, max_distance: float) -> List[np.ndarray]:
+    """per query the candidates within range, a chunk of queries at a time (host memory stays O(chunk x candidates + hits): the
+    reference asks its k-d tree one image at a time)"""
+    out: List[np.ndarray] = []
+    for q0 in range(0, len(queries), _RADIUS_CHUNK):
+        hit = radius_points(points, queries[q0:q0 + _RADIUS_CHUNK], max_distance)
+        out.extend(np.flatnonzero(row) for row in hit)
+    return out
+
+
 def _neighbours(points: np.ndarray, queries: np.ndarray, k_of_query: np.ndarray, max_distance: float) -> List[np.ndarray]:
     """per query the indices ``tree.query(point, k, distance_upper_bound)`` would return (without the "missing" entries)"""
     n = len(points)
+    if len(queries) == 0 or n == 0:
+        return [np.zeros(0, np.int64) for _ in range(len(queries))]
     kmax = int(k_of_query.max()) if len(k_of_query) else 0
-    if kmax >= n:  # every point within range qualifies: no ranking needed
-        hit = radius_points(points, queries, max_distance)
-        return [np.flatnonzero(row) for row in hit]
-    _, idx = knn_points(points, queries, kmax, max_distance)
+    if kmax <= 0:
+        return [np.zeros(0, np.int64) for _ in range(len(queries))]
+    if int(k_of_query.min()) >= n:  # EVERY query may take every point within range: no ranking needed
+        return _radius_lists(points, queries, max_distance)
+    # a query whose own k covers every candidate still gets the nearest min(k, n): rank with min(kmax, n), cut each row to its k
+    _, idx = knn_points(points, queries, min(kmax, n), max_distance)
     return [row[:k][row[:k] >= 0] for row, k in zip(idx, k_of_query)]
 
 

@@ -111,6 +111,39 @@ def test_by_distance_matches_the_reference(refps, host_search, neighbors, distan
     assert preselection.match_candidates_by_distance(images, images, exifs, reference, 6, 0) == set()
 
 
+def _np_knn(cand, qry, k, max_distance=np.inf, ctx=None):
+    cand, qry = np.asarray(cand, float).reshape(-1, 3), np.asarray(qry, float).reshape(-1, 3)
+    d = np.linalg.norm(qry[:, None, :] - cand[None, :, :], axis=2)
+    order = np.argsort(d, axis=1, kind="stable")[:, :k]
+    dist = np.take_along_axis(d, order, axis=1)
+    idx = np.where(dist <= max_distance, order, -1).astype(np.int32)
+    return np.where(idx >= 0, dist, np.inf), idx
+
+
+def _np_radius(cand, qry, max_distance, ctx=None):
+    cand, qry = np.asarray(cand, float).reshape(-1, 3), np.asarray(qry, float).reshape(-1, 3)
+    return np.linalg.norm(qry[:, None, :] - cand[None, :, :], axis=2) <= max_distance
+
+
+def test_neighbours_helper_with_mixed_k(monkeypatch):
+    """the host logic above the two device searches: queries whose own k covers every candidate next to queries whose k does not (the
+    radius shortcut applies only when EVERY query may take every point), no queries, k = 0"""
+    monkeypatch.setattr(preselection, "knn_points", _np_knn)
+    monkeypatch.setattr(preselection, "radius_points", _np_radius)
+    rng = np.random.default_rng(5)
+    pts = rng.uniform(-50, 50, (6, 3))
+    qry = np.vstack([pts[0], rng.uniform(-50, 50, (2, 3))])
+    for ks, dmax in (([6, 5, 5], np.inf), ([6, 6, 6], np.inf), ([6, 5, 5], 60.0), ([2, 1, 3], 40.0), ([9, 9, 9], 55.0)):
+        got = preselection._neighbours(pts, qry, np.array(ks), dmax)
+        want = kdtree_neighbours(pts, qry, np.array(ks), dmax)
+        assert [sorted(g.tolist()) for g in got] == [sorted(w.tolist()) for w in want], (ks, dmax)
+    assert preselection._neighbours(pts, np.zeros((0, 3)), np.zeros(0, int), np.inf) == []
+    assert [len(g) for g in preselection._neighbours(pts, qry, np.zeros(3, int), np.inf)] == [0, 0, 0]
+    monkeypatch.setattr(preselection, "_RADIUS_CHUNK", 2)  # several chunks of queries
+    got = preselection._neighbours(pts, qry, np.array([6, 6, 6]), 70.0)
+    assert [sorted(g.tolist()) for g in got] == [sorted(w.tolist()) for w in kdtree_neighbours(pts, qry, np.array([6, 6, 6]), 70.0)]
+
+
 @pytest.mark.parametrize("neighbors", [0, 1, 5, 100])
 def test_by_time_and_order_match_the_reference(refps, host_search, neighbors):
     exifs = make_exifs(50, 3)

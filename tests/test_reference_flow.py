@@ -285,38 +285,13 @@ def test_adhoc_filters_equal_the_reference(ref):
     assert len(product.apply_adhoc_filters(data, np.zeros((0, 2), int), "plain", cam("perspective"), p1, "plain", cam("perspective"), p2)) == 0
 
 
-@pytest.mark.parametrize("guided,filters", [(False, False), (True, False), (False, True), (True, True)])
-def test_match_flow_equals_the_product_host_flow(ref, oracle_lib, monkeypatch, guided, filters):
-    """The reference's match_unwrap_args -> match() (matching.py:182-214, 563-634; guided: 260-337) executed from its own file for
-    every pair of a mixed collection, against opensfm_amd.matching.match_images_with_pairs with its C-ABI calls redirected to the
-    host emulations: same gates, same dispatch, same unfiltered result for every pair."""
+def emulate_product_leaves(monkeypatch, oracle_lib):
+    """opensfm_amd.matching with every C-ABI call redirected to the host emulations / the oracle (no GPU): what the CPU flow tests run,
+    and what the GPU flow tests compare the device against (tests/test_gpu_flow.py)"""
     import test_guided_host as gh
     import test_relpose_core_host as rp
     from opensfm_amd import matching as product
 
-    matching, _ = ref
-    rng = np.random.default_rng(17 if guided else 16)
-    images, cams, cam_of, feats, masks, poses, config = _collection(oracle_lib, rng, guided)
-    exifs = {im: {"camera": cam_of[im]} for im in images}
-    pairs = [(a, b) for i, a in enumerate(images) for b in images[i + 1:]]
-    config["matching_use_filters"] = filters  # the ad-hoc filters between the descriptor stage and the gates (matching.py:323-334,399-411)
-    exif_of = {"a": {"make": "BlackVue", "model": "DR900"}, "b": {"make": "Canon", "model": "X"}, "c": {"make": "VTrans_Camera", "model": "VTrans_Camera"},
-               "d": {"make": "blackvue", "model": "x"}}
-    # ---- the reference side ----
-    feats_masked = {im: types.SimpleNamespace(points=feats[im].points[masks[im]], descriptors=feats[im].descriptors[masks[im]]) for im in images}
-    loader = types.SimpleNamespace(
-        load_all_data=lambda data, im, masked=True, segmentation_in_descriptor=False: feats_masked[im],
-        load_mask=lambda data, im: masks[im],
-        load_bearings=lambda data, im, masked=True, camera=None: camera.pixel_bearing_many(np.array(feats_masked[im].points[:, :2], dtype=float)))
-    monkeypatch.setattr(matching.feature_loader, "instance", loader, raising=False)
-    monkeypatch.setattr(matching.log, "setup", lambda: None, raising=False)
-    data = types.SimpleNamespace(config=config, load_camera_models=lambda: cams, load_features=lambda im: feats[im],
-                                 load_features_mask=lambda im, pts: masks[im], load_exif=lambda im: exif_of[im])
-    want = {}
-    for im1, im2 in pairs:
-        _, _, m = matching.match_unwrap_args((im1, im2, cams, exifs, data, {}, poses if guided else None))
-        want[im1, im2] = np.asarray(m)
-    # ---- the product side, leaves on the emulations ----
     bearings, relpose_pairs = rp._emulated_calls(rp.build_host())
     ghost = gh.build_host()
 
@@ -357,6 +332,41 @@ def test_match_flow_equals_the_product_host_flow(ref, oracle_lib, monkeypatch, g
     split = lambda st, arr: [arr[st.off[i]: st.off[i + 1]] for i in range(len(st.off) - 1)]
     monkeypatch.setattr(product, "match_pairs_guided", gh.composed_match_pairs_guided(product, guided_leaf, lambda st: split(st, st.desc),
                                                                                        lambda st: split(st, st.pts)))
+
+
+@pytest.mark.parametrize("guided,filters", [(False, False), (True, False), (False, True), (True, True)])
+def test_match_flow_equals_the_product_host_flow(ref, oracle_lib, monkeypatch, guided, filters):
+    """The reference's match_unwrap_args -> match() (matching.py:182-214, 563-634; guided: 260-337) executed from its own file for
+    every pair of a mixed collection, against opensfm_amd.matching.match_images_with_pairs with its C-ABI calls redirected to the
+    host emulations: same gates, same dispatch, same unfiltered result for every pair."""
+    import test_guided_host as gh
+    import test_relpose_core_host as rp
+    from opensfm_amd import matching as product
+
+    matching, _ = ref
+    rng = np.random.default_rng(17 if guided else 16)
+    images, cams, cam_of, feats, masks, poses, config = _collection(oracle_lib, rng, guided)
+    exifs = {im: {"camera": cam_of[im]} for im in images}
+    pairs = [(a, b) for i, a in enumerate(images) for b in images[i + 1:]]
+    config["matching_use_filters"] = filters  # the ad-hoc filters between the descriptor stage and the gates (matching.py:323-334,399-411)
+    exif_of = {"a": {"make": "BlackVue", "model": "DR900"}, "b": {"make": "Canon", "model": "X"}, "c": {"make": "VTrans_Camera", "model": "VTrans_Camera"},
+               "d": {"make": "blackvue", "model": "x"}}
+    # ---- the reference side ----
+    feats_masked = {im: types.SimpleNamespace(points=feats[im].points[masks[im]], descriptors=feats[im].descriptors[masks[im]]) for im in images}
+    loader = types.SimpleNamespace(
+        load_all_data=lambda data, im, masked=True, segmentation_in_descriptor=False: feats_masked[im],
+        load_mask=lambda data, im: masks[im],
+        load_bearings=lambda data, im, masked=True, camera=None: camera.pixel_bearing_many(np.array(feats_masked[im].points[:, :2], dtype=float)))
+    monkeypatch.setattr(matching.feature_loader, "instance", loader, raising=False)
+    monkeypatch.setattr(matching.log, "setup", lambda: None, raising=False)
+    data = types.SimpleNamespace(config=config, load_camera_models=lambda: cams, load_features=lambda im: feats[im],
+                                 load_features_mask=lambda im, pts: masks[im], load_exif=lambda im: exif_of[im])
+    want = {}
+    for im1, im2 in pairs:
+        _, _, m = matching.match_unwrap_args((im1, im2, cams, exifs, data, {}, poses if guided else None))
+        want[im1, im2] = np.asarray(m)
+    # ---- the product side, leaves on the emulations ----
+    emulate_product_leaves(monkeypatch, oracle_lib)
     got = product.match_images_with_pairs(data, {}, exifs, pairs, poses if guided else None)
     survivors = 0
     def rows(a):  # the reference returns a python set's order (matching.py:777), the product sorts by (i, j): compare as sets of rows
