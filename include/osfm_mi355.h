@@ -408,9 +408,8 @@ int osfm_match_pairs_calibrated(osfm_ctx *ctx, const osfm_store *store, const in
  *   (pose2.relative_to(pose1), matching.py:204-207), threshold = config guided_matching_threshold (radians).
  * f1: n1 x dim, f2: n2 x dim float32 (integer-valued in [0, 255], dim must be 128); out_pairs: cap x 2 int32 sorted by
  * (i, j); *out_n = number found (may exceed cap; only cap are written).
- * STATUS round 1: first-correct kernels (one wavefront per query descriptor), numerics pinned bit for bit against the
- * CPU oracle through a host emulation (tests/test_guided_host.py); first MI355X run in the last GPU call of the round
- * (profiles/r01_guided_bringup.txt): explicit and epipolar masks, both directions, identical to the oracle.
+ * This single-pair leaf takes integer-valued descriptors only (it is what the Python leaves match_brute_force[_symmetric](maskij)
+ * call); float descriptors go through the batched entry point below, whose store keeps their float rows.
  * ===================================================================================== */
 int osfm_match_guided(osfm_ctx *ctx, const float *f1, int n1, const float *f2, int n2, int dim, const uint8_t *mask,
                       const float *b1, const float *b2, const double *R, const double *t, double threshold, double ratio,
@@ -426,7 +425,9 @@ int osfm_match_guided(osfm_ctx *ctx, const float *f1, int n1, const float *f2, i
  * bearings: sum(counts) x 3 float32 in the store's image / feature order (feature_loader.load_bearings);
  * poses:    n_pairs x 12, per pair R = relative_pose.get_R_cam_to_world() (row-major) then t = relative_pose.get_origin(),
  *           relative_pose = pose2.relative_to(pose1) (matching.py:204-207);
- * threshold: config guided_matching_threshold (radians).  Integer-valued descriptors only.
+ * threshold: config guided_matching_threshold (radians).
+ * Integer-valued stores rank the candidates by the exact integer distance; float stores (root-SIFT, feature_root) by the float32
+ * distance in the oracle's accumulation order (oracle/guided_oracle.c l2sqr), read from the store's float rows.
  */
 int osfm_match_pairs_guided(osfm_ctx *ctx, const osfm_store *store, const float *bearings, const int32_t *pairs, int64_t n_pairs,
                             const double *poses, double threshold, const osfm_match_params *params, const int32_t *cam_model_or_null,

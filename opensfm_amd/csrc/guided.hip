@@ -232,6 +232,7 @@ struct GuidedPairsArgs {
   const int64_t *tile_off;
   const int32_t *counts;
   const float *bearings;  // store rows (tile * 32 + row) x 3, float32 as the reference's bearings
+  const float *descf;     // float store: rows (tile * 32 + row) x 128 (null for an integer store)
   const int32_t *pairs;
   const double *poses;  // n_pairs x 12: R (row-major) and t of the relative pose
   long n_pairs;
@@ -270,7 +271,8 @@ __device__ __forceinline__ Top2 top2_shfl_xor(const Top2 &t, int m) {
 
 constexpr int kGuidedWin = 512;                   // targets per window
 constexpr int kGuidedWpad = kGuidedWin / 64 + 1;  // 64-bit words per query row in LDS (odd: conflict-free per-lane rows)
-template <int DIR>  // 0: the queries are the features of the pair's first image, 1: of its second image (the transposed mask)
+template <int DIR, bool FLT>  // DIR 0: the queries are the features of the pair's first image, 1: of its second image (the transposed mask)
+                              // FLT: float store -- candidate distances in the oracle's float order (l2sqr_rows_f32) instead of exact int8
 __device__ __forceinline__ void guided_pairs_match_body(const GuidedPairsArgs &a, unsigned long long *bits) {
   const long p = blockIdx.z;
   const int lane = threadIdx.x;
@@ -292,6 +294,8 @@ __device__ __forceinline__ void guided_pairs_match_body(const GuidedPairsArgs &a
   const int8_t *tilesT = a.tiles + a.tile_off[imgT] * OSFM_TILE_BYTES;
   const int32_t *normT = a.norms + a.tile_off[imgT] * 32;
   const int qs = valid ? q : q0;
+  const float *descQ = FLT ? a.descf + a.tile_off[imgQ] * (long)(32 * 128) : nullptr;
+  const float *descT = FLT ? a.descf + a.tile_off[imgT] * (long)(32 * 128) : nullptr;
   const int nqn = (a.norms + a.tile_off[imgQ] * 32)[qs];
   v4i_g av[8];  // the query's descriptor stays in registers
   {
@@ -355,6 +359,10 @@ __device__ __forceinline__ void guided_pairs_match_body(const GuidedPairsArgs &a
         const int b = __builtin_ctzll(word);
         word &= word - 1;
         const int j = t0 + w * 64 + b;
+        if (FLT) {
+          top2_insert(t, sqrtf(l2sqr_rows_f32(descQ + (long)qs * 128, descT + (long)j * 128)), j);
+          continue;
+        }
         const int8_t *pb = tilesT + (long)(j >> 5) * OSFM_TILE_BYTES + (j & 31) * 16;
         v4i_g bv[8];
 #pragma unroll
@@ -375,12 +383,13 @@ __device__ __forceinline__ void guided_pairs_match_body(const GuidedPairsArgs &a
   if (valid) a.good[(p * 2 + DIR) * a.capr + q] = (t.n >= 2 && (double)t.d0 < a.ratio * (double)t.d1) ? t.j0 : -1;
 }
 
+template <bool FLT>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) guided_pairs_match_kernel(GuidedPairsArgs a) {
   __shared__ unsigned long long bits[64 * kGuidedWpad];  // [64 queries][kGuidedWpad words]: the mask bits of the current target window
   if (blockIdx.y == 0)
-    guided_pairs_match_body<0>(a, bits);
+    guided_pairs_match_body<0, FLT>(a, bits);
   else if (a.symmetric)
-    guided_pairs_match_body<1>(a, bits);
+    guided_pairs_match_body<1, FLT>(a, bits);
 }
 
 // pairs (i, j) sorted by i: good12[i] == j and (symmetric) good21[j] == i; packed like the fused matcher's output
@@ -451,7 +460,6 @@ int osfm_launch_guided_pairs(osfm_ctx *ctx, const osfm_store *store, const OsfmG
                              int64_t n_pairs, double ratio, int symmetric, int cap, int32_t *d_counts, uint32_t *d_matches, int32_t *d_flags,
                              double *d_six, int32_t *d_good, hipStream_t stream) {
   if (n_pairs == 0) return OSFM_OK;
-  OSFM_REQUIRE(!store->is_float, OSFM_E_UNSUPPORTED, "guided matching needs integer-valued descriptors in [0, 255]");
   OSFM_REQUIRE(n_pairs <= 65535, OSFM_E_INVALID, "guided chunk of %lld pairs", (long long)n_pairs);
   GuidedPairsArgs a;
   a.tiles = store->d_tiles;
@@ -459,6 +467,7 @@ int osfm_launch_guided_pairs(osfm_ctx *ctx, const osfm_store *store, const OsfmG
   a.tile_off = store->d_tile_off;
   a.counts = store->d_counts;
   a.bearings = gs.d_bearings;
+  a.descf = store->is_float ? store->d_descf : nullptr;
   a.pairs = d_pairs;
   a.poses = d_poses;
   a.n_pairs = n_pairs;
@@ -475,7 +484,10 @@ int osfm_launch_guided_pairs(osfm_ctx *ctx, const osfm_store *store, const OsfmG
   a.wpad = kGuidedWpad;
   const unsigned blocks = (unsigned)((store->max_count + 255) / 256), qblocks = (unsigned)((store->max_count + 63) / 64);
   hipLaunchKernelGGL(guided_pairs_prep_kernel, dim3(blocks ? blocks : 1, 2, (unsigned)n_pairs), dim3(256), 0, stream, a);
-  hipLaunchKernelGGL(guided_pairs_match_kernel, dim3(qblocks ? qblocks : 1, 2, (unsigned)n_pairs), dim3(64), 0, stream, a);
+  if (store->is_float)  // root-SIFT and the like: the candidates' distances are float sums in the oracle's order, from the float rows
+    hipLaunchKernelGGL(guided_pairs_match_kernel<true>, dim3(qblocks ? qblocks : 1, 2, (unsigned)n_pairs), dim3(64), 0, stream, a);
+  else
+    hipLaunchKernelGGL(guided_pairs_match_kernel<false>, dim3(qblocks ? qblocks : 1, 2, (unsigned)n_pairs), dim3(64), 0, stream, a);
   hipLaunchKernelGGL(guided_pairs_emit_kernel, dim3((unsigned)n_pairs), dim3(256), 0, stream, a);
   OSFM_HIP(hipGetLastError());
   return OSFM_OK;

@@ -174,35 +174,6 @@ __device__ __forceinline__ bool fq_surely_passes(int d0hi_sq, int d1lo_sq, doubl
   const double D1lo = fmax(sqrt((double)max(d1lo_sq, 0)) - eps, 0.0) * (1.0 - kFqSlack);
   return D0hi < r * D1lo && D0hi < D1lo;
 }
-// cv2's normL2Sqr_ on an AVX2 build as the oracle restates it (oracle/match_oracle.c l2sqr_f32): four 8-lane accumulators over
-// blocks of 32 dimensions, (d0 + d1) + (d2 + d3), then ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7)); no contraction
-__device__ __forceinline__ float l2sqr_rows_f32(const float *a, const float *b) {
-  float acc[4][8];
-#pragma unroll
-  for (int v = 0; v < 4; ++v)
-#pragma unroll
-    for (int l = 0; l < 8; ++l) acc[v][l] = 0.f;
-#pragma unroll
-  for (int jb = 0; jb < OSFM_DESC_DIM; jb += 32)
-#pragma unroll
-    for (int v = 0; v < 4; ++v)
-#pragma unroll
-      for (int l4 = 0; l4 < 8; l4 += 4) {
-        const float4 x = *(const float4 *)(a + jb + 8 * v + l4);
-        const float4 y = *(const float4 *)(b + jb + 8 * v + l4);
-        const float xx[4] = {x.x, x.y, x.z, x.w}, yy[4] = {y.x, y.y, y.z, y.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float d = xx[e] - yy[e];
-          const float sq = d * d;
-          acc[v][l4 + e] = acc[v][l4 + e] + sq;
-        }
-      }
-  float sv[8];
-#pragma unroll
-  for (int l = 0; l < 8; ++l) sv[l] = (acc[0][l] + acc[1][l]) + (acc[2][l] + acc[3][l]);
-  return ((sv[0] + sv[1]) + (sv[2] + sv[3])) + ((sv[4] + sv[5]) + (sv[6] + sv[7]));
-}
 __device__ __forceinline__ float wave_minf(float v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v = fminf(v, __shfl_xor(v, m));

@@ -237,3 +237,35 @@ int osfm_ransac_pairs_lds_points();  // the batched kernel
 int osfm_launch_ransac_single(osfm_ctx *ctx, const double *d_p1, const double *d_p2, int n, double thr,
                               double conf, int max_iters, double *d_F, uint8_t *d_mask,
                               int32_t *d_info);
+
+#ifdef __HIPCC__
+// cv2's normL2Sqr_ on an AVX2 build as the oracle restates it (oracle/match_oracle.c l2sqr_f32): four 8-lane accumulators over
+// blocks of 32 dimensions, (d0 + d1) + (d2 + d3), then ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7)); no contraction
+__device__ __forceinline__ float l2sqr_rows_f32(const float *a, const float *b) {
+  float acc[4][8];
+#pragma unroll
+  for (int v = 0; v < 4; ++v)
+#pragma unroll
+    for (int l = 0; l < 8; ++l) acc[v][l] = 0.f;
+#pragma unroll
+  for (int jb = 0; jb < 128; jb += 32)
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+      for (int l4 = 0; l4 < 8; l4 += 4) {
+        const float4 x = *(const float4 *)(a + jb + 8 * v + l4);
+        const float4 y = *(const float4 *)(b + jb + 8 * v + l4);
+        const float xx[4] = {x.x, x.y, x.z, x.w}, yy[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = xx[e] - yy[e];
+          const float sq = d * d;
+          acc[v][l4 + e] = acc[v][l4 + e] + sq;
+        }
+      }
+  float sv[8];
+#pragma unroll
+  for (int l = 0; l < 8; ++l) sv[l] = (acc[0][l] + acc[1][l]) + (acc[2][l] + acc[3][l]);
+  return ((sv[0] + sv[1]) + (sv[2] + sv[3])) + ((sv[4] + sv[5]) + (sv[6] + sv[7]));
+}
+#endif

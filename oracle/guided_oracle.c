@@ -61,10 +61,23 @@ void oracle_epipolar_mask(const float *b1, int n1, const float *b2, int n2, cons
   free(e2);
 }
 
-static float l2sqr(const float *a, const float *b, int n) { /* integer-valued descriptors: exact under any order */
-  float d = 0;
-  for (int k = 0; k < n; k++) {
-    const float t = a[k] - b[k];
+/* cv2's normL2Sqr_ on an AVX2 build, as oracle/match_oracle.c (l2sqr_f32) restates it: four 8-lane accumulators over blocks of 32
+ * dimensions, (d0 + d1) + (d2 + d3), the lanes pairwise, then the scalar tail.  Exact -- hence order-free -- for integer-valued
+ * descriptors; for float descriptors (root-SIFT) this order is what "the float distance" means in this repository. */
+static float l2sqr(const float *a, const float *b, int n) {
+  float acc[4][8] = {{0}};
+  int j = 0;
+  for (; j + 32 <= n; j += 32)
+    for (int v = 0; v < 4; v++)
+      for (int l = 0; l < 8; l++) {
+        const float t = a[j + 8 * v + l] - b[j + 8 * v + l];
+        acc[v][l] += t * t;
+      }
+  float sv[8];
+  for (int l = 0; l < 8; l++) sv[l] = (acc[0][l] + acc[1][l]) + (acc[2][l] + acc[3][l]);
+  float d = ((sv[0] + sv[1]) + (sv[2] + sv[3])) + ((sv[4] + sv[5]) + (sv[6] + sv[7]));
+  for (; j < n; j++) {
+    const float t = a[j] - b[j];
     d += t * t;
   }
   return d;

@@ -376,3 +376,39 @@ def test_batched_guided_with_fundamental_ransac(oracle_lib):
         assert np.array_equal(g, want if len(want) >= 20 else np.zeros((0, 2), np.int32))
         assert len(g) > 80
     store.close()
+
+
+def test_batched_guided_on_float_descriptors(oracle_lib):
+    """root-SIFT style float descriptors (feature_root, features.py:292-298) through osfm_match_pairs_guided: the candidates the epipolar
+    mask lets through are ranked by the float distance in the oracle's accumulation order (oracle/guided_oracle.c l2sqr =
+    oracle/match_oracle.c l2sqr_f32), read from the store's float rows -- not from the 8-bit quantisation the unguided matcher bounds with"""
+    import test_guided_host as gh
+    from opensfm_amd import matching
+
+    rng = np.random.default_rng(23)
+    sizes = [200, 640, 90]
+    descs, bears, pairs, rels = [], [], [], []
+    for k, n in enumerate(sizes):
+        d1, d2, b1, b2, R, o, perm = gh.guided_scene(rng, n // 2)
+
+        def root(d):  # L1-normalise, square root (features.root_feature): genuinely non-integer values
+            d = np.asarray(d, np.float32) + rng.uniform(0, 0.5, d.shape).astype(np.float32)
+            return np.sqrt(d / d.sum(axis=1, keepdims=True)).astype(np.float32)
+
+        descs += [root(d1), root(d2)]
+        bears += [b1, b2]
+        pairs.append((2 * k, 2 * k + 1))
+        rels.append(np.concatenate([np.asarray(R).reshape(9), np.asarray(o).reshape(3)]))
+    store = matching.DescriptorStore(descs, [np.zeros((len(d), 2)) for d in descs])
+    total = 0
+    for thr in (0.004, 0.02, 2.0):
+        for sym in (True, False):
+            cfg = {"lowes_ratio": 0.85, "guided_matching_threshold": thr, "symmetric_matching": sym}
+            counts, m = matching.match_pairs_guided(store, np.asarray(pairs, np.int32), bears, rels, cfg, robust=False)
+            for (a, b), rel, g in zip(pairs, rels, matching.split_matches(counts, m)):
+                emask, _ = oracle_lib.epipolar_mask(bears[a], bears[b], rel[:9].reshape(3, 3), rel[9:], thr)
+                want = oracle_lib.match_brute_force_masked(descs[a], descs[b], emask, 0.85, symmetric=sym)
+                assert np.array_equal(g, want), (thr, sym, a, b, len(g), len(want))
+                total += len(want)
+    assert total > 500
+    store.close()
