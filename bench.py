@@ -33,7 +33,7 @@ FLOP_PER_PAIR = 2.0 * 2000 * 2000 * 128  # one distance matrix s
 PEAK_F64_VALU_TFLOPS = 78.6  # fp64 vector peak (half the 157.3 TFLOP/s fp32 rate of MI355X_MICROARCH.md)
 RANSAC_FLOP_PER_MODEL_POINT = 40.0  # symmetric epipolar error of one correspondence under one F: two 3x3 products, two norms, compare
 RELPOSE_FLOP_PER_MODEL_POINT = 150.0  # RelativePose::Evaluate: rotate, midpoint triangulation, two reprojection cosines
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_match_pmc.json")  # HBM bytes per launch from the rocprofv3 --pmc passes of this command
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_match_pmc.json")  # HBM bytes per launch from the rocprofv3 --pmc passes of this command
 
 
 def parse():
@@ -181,7 +181,7 @@ def main():
     }
 
     # HBM traffic per launch: PMC passes cannot run inside this process, so the committed counters of the same command
-    # (tools/pmc_match.sh -> profiles/r02_match_pmc.json: FETCH_SIZE doubled as the gfx950 guide prescribes, + WRITE_SIZE) are quoted,
+    # (tools/r03_final_profiles.sh -> profiles/r03_match_pmc.json: FETCH_SIZE doubled as the gfx950 guide prescribes, + WRITE_SIZE) are quoted,
     # scaled to this run's pairs per launch
     if os.path.exists(PMC_FILE):
         try:

@@ -101,11 +101,11 @@ def run(ctx, shots: int = 5000, points: int = 500000, track: int = 10, iters: in
         "scene_gen_s": round(t_gen, 2),
     }
     # HBM traffic of one mat-vec: PMC passes cannot run inside this process; the committed counters of `tools/prof_ba.py` at the same size
-    # (tools/pmc_ba.sh -> profiles/r02_ba_pmc.json: FETCH_SIZE doubled as the gfx950 guide prescribes, + WRITE_SIZE) are quoted
+    # (tools/r03_final_profiles.sh -> profiles/r03_ba_pmc.json: FETCH_SIZE doubled as the gfx950 guide prescribes, + WRITE_SIZE) are quoted
     import json
     import os
 
-    pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_ba_pmc.json")
+    pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_ba_pmc.json")
     if os.path.exists(pmc_file):
         try:
             pmc = json.load(open(pmc_file))
