@@ -55,8 +55,8 @@ def main():
     json.dump({"kernel": "match_fused_kernel", "pairs_per_launch": ppl, "launches_sampled": [nf, nw],
                "fetch_size_kb_raw": f, "write_size_kb_raw": w,
                "fetch_bytes_corrected": 2.0 * f * 1024.0, "write_bytes": w * 1024.0,
-               "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `python bench.py --steps 1 --warmup 0 --no-ba --no-tracks "
-                         "--no-cpu-baseline --no-overlap --no-calibrated`; FETCH_SIZE x 2 per MI355X_MICROARCH.md (gfx950 reports 64 B per 128 B request); "
+               "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `python bench.py --headline-only --no-cpu-baseline --steps 1 "
+                         "--warmup 0`; FETCH_SIZE x 2 per MI355X_MICROARCH.md (gfx950 reports 64 B per 128 B request); "
                          "counter unit KiB"}, open(out, 'w'), indent=1)
     print(open(out).read())
 
