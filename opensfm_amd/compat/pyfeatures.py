@@ -16,8 +16,14 @@ def hahog(image, peak_threshold: float = 0.003, edge_threshold: float = 10, targ
 def match_using_words(features1, words1, features2, words2, lowes_ratio: float, max_checks: int):
     """features::match_using_words (matching.cc:73-88): (m, 2) int array of (index in features1, index in features2)"""
     f1, f2 = np.asarray(features1, np.float32), np.asarray(features2, np.float32)
-    w1, w2 = np.asarray(words1), np.asarray(words2)
-    store = _words.WordsStore([f1, f2], [w1.reshape(len(f1), -1), w2.reshape(len(f2), -1)])
+    # the queries (image 1) come with their n closest words, the indexed image with ONE word per feature (matching.py:637-656 passes
+    # words2[:, 0]); the resident store keeps one width per call and indexes an image by its features' first word
+    w1 = np.asarray(words1).reshape(len(f1), -1)
+    w2 = np.asarray(words2).reshape(len(f2), -1)
+    if w2.shape[1] != 1:
+        raise ValueError("words2 holds one word per feature of the second image (the reference passes words2[:, 0])")
+    w2 = np.repeat(w2, w1.shape[1], axis=1)
+    store = _words.WordsStore([f1, f2], [w1, w2])
     try:
         found, _ = _words.match_words_pairs(store, [(0, 1)], {"lowes_ratio": lowes_ratio, "bow_num_checks": max_checks}, symmetric=False)
     finally:

@@ -19,11 +19,10 @@ def test_pyfeatures(oracle_lib, gpu_ctx):
     f1 = rng.uniform(0, 255, (300, 128)).astype(np.float32)
     f2 = f1 + rng.normal(0, 1.0, f1.shape).astype(np.float32)
     words = rng.integers(0, 40, (300, 5)).astype(np.int32)
-    m = pyfeatures.match_using_words(f1, words[:, :1].copy(), f2, words, 0.99, 20)
+    m = pyfeatures.match_using_words(f1, words, f2, words[:, 0], 0.99, 20)  # as matching.match_words calls it (matching.py:656)
     assert m.shape[1] == 2 and len(m) > 250 and np.array_equal(m[:, 0], m[:, 1])
-    want = oracle_lib.match_using_words(f1, words[:, :1].copy(), f2, words, 0.99, 20) if hasattr(oracle_lib, "match_using_words") else None
-    if want is not None:
-        assert np.array_equal(np.asarray(m), np.asarray(want).reshape(-1, 2))
+    want = oracle_lib.match_words(f1, words, f2, words[:, 0].copy(), 0.99, 20)
+    assert np.array_equal(np.asarray(m), np.asarray(want).reshape(-1, 2))
     centers = rng.normal(0, 1, (8, 128)).astype(np.float32)
     v = pyfeatures.compute_vlad_descriptor(f1[:50], centers)
     assert v.shape == (8 * 128,)
