@@ -1607,7 +1607,7 @@ inline BcrLaunch bcr_level_for(int cs) {
 // would only add its overhead), forms L_IJ and subtracts L_IJ A_KJ^T from A_IK.  Flops are n w^2 (11-44 GFLOP at configs[4] size with
 // w = 600-1200): irrelevant; the factorisation is the latency of S / 16 launches x 16 pivot steps.
 constexpr int kWcs = 16, kWB = 6 * kWcs, kWLd = kWB + 2;  // shots per block, block order, LDS row stride (even: 16-byte rows; 6 rows apart = 24 banks)
-constexpr int kWMaxBw = 368;                               // shot half-width: the backward walk keeps a window of x and its partial sums in LDS
+constexpr int kWMaxBw = 520;                               // shot half-width the band assembly's LDS accumulators hold (one copy of (bw + 1) x 36 doubles)
 
 // in-place inverse of the SPD n x n block X (LDS, row stride kWLd), n = kWB: 16 x 16 tiles of 6 x 6, one per thread (256 threads)
 __device__ __forceinline__ void wide_gj_inverse(double *X, int tid, int &bad) {
@@ -1804,11 +1804,9 @@ __global__ void __launch_bounds__(256) wide_factor_kernel(Dev d, int J, int *sta
   for (int t = tid; t < kWB * kWB; t += 256) AIK[t] -= X[(t / kWB) * kWLd + t % kWB];
 }
 
-// ---- wide band solve: L y = b (one workgroup walks the block columns), z = D^-1 y (all blocks at once), L^T x = z (one workgroup).
-// NR right-hand sides side by side: wx[(block * kWB + r) * NR + q].  The walking workgroup keeps the window of the right-hand side
-// (forward: the Wb blocks below J that J still updates; backward: the Wb blocks of x that J reads) in an LDS ring, so the only global
-// traffic on the chain is the stream of L blocks; every dot product is split over kWKS adjacent lanes.
-constexpr int kWT = 1024, kWKS = 4;
+// ---- wide band solve: L y = b, z = D^-1 y (all blocks at once), L^T x = z.  NR right-hand sides side by side:
+// wx[(block * kWB + r) * NR + q].  Every dot product is split over kWKS adjacent lanes.
+constexpr int kWKS = 4;
 template <int NR>
 __device__ __forceinline__ void lds_vec(const double *p, double (&v)[NR]) {
   if constexpr (NR == 4) {
@@ -1817,64 +1815,6 @@ __device__ __forceinline__ void lds_vec(const double *p, double (&v)[NR]) {
   } else {
 #pragma unroll
     for (int q = 0; q < NR; q++) v[q] = p[q];
-  }
-}
-// position of entry (row r, rhs 0) of a block inside the LDS ring: the four k-ranges that the four lanes of a dot product read at the
-// same time start kWPad doubles further apart than their data, or their reads would sit in the same banks (768 bytes apart for NR = 4)
-constexpr int kWPad = 4;
-template <int NR>
-__device__ __forceinline__ int wpos(int r) { return r * NR + (r / (kWB / kWKS)) * kWPad; }
-template <int NR>
-__global__ void __launch_bounds__(kWT) wide_forward_kernel(Dev d) {
-  extern __shared__ __attribute__((aligned(16))) double win[];  // (Wb + 1) blocks of BP doubles
-  const int tid = threadIdx.x, W1 = d.wWb + 1, NB = d.wNB;
-  constexpr int KC = kWB / kWKS, BN = kWB * NR, BP = BN + kWKS * kWPad;
-  const int tr = tid / NR, tq = tid - tr * NR;  // this thread's (row, rhs) when it moves a block
-  for (int bl = 0; bl < min(W1, NB); bl++)
-    if (tid < BN) win[bl * BP + wpos<NR>(tr) + tq] = d.wx[(long)bl * BN + tid];
-  __syncthreads();
-  for (int J = 0; J < NB; J++) {
-    const int slot = J % W1;
-    const double *ys = win + slot * BP;
-    double pref = 0.0;  // the block that enters the window after this step
-    const bool enters = J + W1 < NB && tid < BN;
-    if (enters) pref = d.wx[(long)(J + W1) * BN + tid];
-    if (tid < BN) d.wx[(long)J * BN + tid] = ys[wpos<NR>(tr) + tq];
-    const int nI = min(d.wWb, NB - 1 - J);
-    const int total = nI * kWB * kWKS;
-    for (int it0 = 0; it0 < total; it0 += kWT) {
-      const int it = it0 + tid;
-      const bool on = it < total;
-      const int row = on ? it / kWKS : 0, ks = it % kWKS, dI = row / kWB + 1, r = row - (dI - 1) * kWB;
-      const double *Lt = d.wLt + ((long)J * W1 + dI) * kWB * kWB + (long)ks * KC * kWB + r;  // Lt[k][r]
-      double m[KC];
-#pragma unroll
-      for (int k = 0; k < KC; k++) m[k] = on ? Lt[(long)k * kWB] : 0.0;
-      const double *yk = ys + ks * (KC * NR + kWPad);
-      double a[NR];
-#pragma unroll
-      for (int q = 0; q < NR; q++) a[q] = 0.0;
-#pragma unroll
-      for (int k = 0; k < KC; k++) {
-        double y[NR];
-        lds_vec<NR>(yk + k * NR, y);
-#pragma unroll
-        for (int q = 0; q < NR; q++) a[q] = __builtin_fma(m[k], y[q], a[q]);
-      }
-#pragma unroll
-      for (int q = 0; q < NR; q++) {
-        a[q] += __shfl_xor(a[q], 1);
-        a[q] += __shfl_xor(a[q], 2);
-      }
-      if (on && ks == 0) {
-        double *dst = win + ((J + dI) % W1) * BP + wpos<NR>(r);
-#pragma unroll
-        for (int q = 0; q < NR; q++) dst[q] -= a[q];
-      }
-    }
-    __syncthreads();
-    if (enters) win[slot * BP + wpos<NR>(tr) + tq] = pref;
-    __syncthreads();
   }
 }
 template <int NR>
@@ -1901,61 +1841,49 @@ __global__ void __launch_bounds__(256) wide_diag_kernel(Dev d) {
     for (int q = 0; q < NR; q++) d.wx[((long)J * kWB + tid) * NR + q] = a[q];
   }
 }
-template <int NR>
-__global__ void __launch_bounds__(kWT) wide_backward_kernel(Dev d) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int tid = threadIdx.x, W1 = d.wWb + 1, NB = d.wNB;
-  constexpr int RC = kWB / kWKS, BN = kWB * NR, BP = BN + kWKS * kWPad;
-  double *win = lds;             // (Wb + 1) blocks of BP doubles: x of the blocks J + 1 .. J + Wb (slot = block mod (Wb + 1))
-  double *part = lds + W1 * BP;  // Wb x kWB x NR
-  const int tr = tid / NR, tq = tid - tr * NR;
-  if (tid < BN) win[((NB - 1) % W1) * BP + wpos<NR>(tr) + tq] = d.wx[(long)(NB - 1) * BN + tid];
+// The two sweeps, one small launch per block column in "push" form: the finished block J subtracts its products from the blocks it
+// couples to -- forward the Wb blocks below it through L, backward the Wb blocks above it through L^T.  A workgroup per target block, a
+// row (column) per four lanes, 24 loads in flight per lane: a step is a launch gap plus one round trip spread over Wb CUs.  (Round 3
+// first had ONE workgroup walk all block columns with the window of the right-hand side in an LDS ring: 30 us per step -- one CU
+// streaming half a megabyte and re-reading y from LDS in every lane -- against ~9 us here: 57.8 -> 39.2 ms per LM iteration on the
+// 50 x 100 grid.)
+template <int NR, bool BACK>
+__global__ void __launch_bounds__(kWB * kWKS) wide_push_kernel(Dev d, int J) {
+  __shared__ __attribute__((aligned(16))) double ys[kWB * NR];
+  const int tid = threadIdx.x, W1 = d.wWb + 1, dI = blockIdx.x + 1;
+  constexpr int KC = kWB / kWKS, BN = kWB * NR;
+  const int I = BACK ? J - dI : J + dI;  // the block that receives
+  if (I < 0 || I >= d.wNB) return;
+  for (int t = tid; t < BN; t += kWB * kWKS) ys[t] = d.wx[(long)J * BN + t];
   __syncthreads();
-  for (int J = NB - 2; J >= 0; J--) {
-    const int nI = min(d.wWb, NB - 1 - J);
-    double zj = 0.0;
-    if (tid < BN) zj = d.wx[(long)J * BN + tid];
-    const int total = nI * kWB * kWKS;
-    for (int it0 = 0; it0 < total; it0 += kWT) {
-      const int it = it0 + tid;
-      const bool on = it < total;
-      const int g = on ? it / kWKS : 0, rs = it % kWKS, dI = g / kWB + 1, c = g - (dI - 1) * kWB;
-      const double *Lr = d.wL + ((long)J * W1 + dI) * kWB * kWB + (long)rs * RC * kWB + c;  // L[r][c]
-      double m[RC];
+  const int row = tid / kWKS, ks = tid % kWKS;
+  // forward: L_{I,J} = tile (J, dI), transposed copy [k][r];  backward: (L_{J,I})^T, L_{J,I} = tile (I, dI), row-major [r][c]
+  const double *T = (BACK ? d.wL + ((long)I * W1 + dI) * kWB * kWB : d.wLt + ((long)J * W1 + dI) * kWB * kWB) + (long)ks * KC * kWB + row;
+  double m[KC];
 #pragma unroll
-      for (int r = 0; r < RC; r++) m[r] = on ? Lr[(long)r * kWB] : 0.0;
-      const double *xs = win + ((J + dI) % W1) * BP + rs * (RC * NR + kWPad);
-      double a[NR];
+  for (int k = 0; k < KC; k++) m[k] = T[(long)k * kWB];
+  double a[NR];
 #pragma unroll
-      for (int q = 0; q < NR; q++) a[q] = 0.0;
+  for (int q = 0; q < NR; q++) a[q] = 0.0;
 #pragma unroll
-      for (int r = 0; r < RC; r++) {
-        double x[NR];
-        lds_vec<NR>(xs + r * NR, x);
+  for (int k = 0; k < KC; k++) {
+    double y[NR];
+    lds_vec<NR>(ys + (ks * KC + k) * NR, y);
 #pragma unroll
-        for (int q = 0; q < NR; q++) a[q] = __builtin_fma(m[r], x[q], a[q]);
-      }
+    for (int q = 0; q < NR; q++) a[q] = __builtin_fma(m[k], y[q], a[q]);
+  }
 #pragma unroll
-      for (int q = 0; q < NR; q++) {
-        a[q] += __shfl_xor(a[q], 1);
-        a[q] += __shfl_xor(a[q], 2);
-      }
-      if (on && rs == 0) {
+  for (int q = 0; q < NR; q++) {
+    a[q] += __shfl_xor(a[q], 1);
+    a[q] += __shfl_xor(a[q], 2);
+  }
+  if (ks == 0) {
+    double *dst = d.wx + ((long)I * kWB + row) * NR;
 #pragma unroll
-        for (int q = 0; q < NR; q++) part[(long)g * NR + q] = a[q];
-      }
-    }
-    __syncthreads();
-    if (tid < BN) {
-      double sum = 0.0;
-      for (int e = 0; e < nI; e++) sum += part[(long)e * BN + tid];
-      const double x = zj - sum;
-      win[(J % W1) * BP + wpos<NR>(tr) + tq] = x;
-      d.wx[(long)J * BN + tid] = x;
-    }
-    __syncthreads();
+    for (int q = 0; q < NR; q++) dst[q] -= a[q];
   }
 }
+
 // right-hand sides in / results out (NR side by side in wx)
 template <int NR>
 __global__ void wide_load_kernel(Dev d, RhsSet rs) {
@@ -2887,11 +2815,11 @@ struct Solver {
   template <int NR>
   void wide_walk(const RhsSet &rs) {
     const int nrows = d.wNB * kWB;
-    const size_t ring = (size_t)(d.wWb + 1) * (kWB * NR + kWKS * kWPad) * sizeof(double);
     hipLaunchKernelGGL(wide_load_kernel<NR>, dim3(nblk(nrows)), dim3(TPB), 0, st, d, rs);
-    hipLaunchKernelGGL(wide_forward_kernel<NR>, dim3(1), dim3(kWT), ring, st, d);
+    for (int J = 0; J + 1 < d.wNB; J++)
+      hipLaunchKernelGGL((wide_push_kernel<NR, false>), dim3(std::min(d.wWb, d.wNB - 1 - J)), dim3(kWB * kWKS), 0, st, d, J);
     hipLaunchKernelGGL(wide_diag_kernel<NR>, dim3(d.wNB), dim3(256), 0, st, d);
-    hipLaunchKernelGGL(wide_backward_kernel<NR>, dim3(1), dim3(kWT), ring + (size_t)d.wWb * kWB * NR * sizeof(double), st, d);
+    for (int J = d.wNB - 1; J >= 1; J--) hipLaunchKernelGGL((wide_push_kernel<NR, true>), dim3(std::min(d.wWb, J)), dim3(kWB * kWKS), 0, st, d, J);
     hipLaunchKernelGGL(wide_store_kernel<NR>, dim3(nblk(std::max<long>(6L * d.S, d.NC))), dim3(TPB), 0, st, d, rs);
   }
   void wide_solve_set(const RhsSet &rs) {
@@ -3509,10 +3437,6 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       const int rca = once.run(ctx->device, []() -> int {
         OSFM_HIP(hipFuncSetAttribute((const void *)band_assemble_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         OSFM_HIP(hipFuncSetAttribute((const void *)wide_factor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        OSFM_HIP(hipFuncSetAttribute((const void *)wide_forward_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        OSFM_HIP(hipFuncSetAttribute((const void *)wide_forward_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        OSFM_HIP(hipFuncSetAttribute((const void *)wide_backward_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        OSFM_HIP(hipFuncSetAttribute((const void *)wide_backward_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         return OSFM_OK;
       });
       if (rca != OSFM_OK) return rca;
