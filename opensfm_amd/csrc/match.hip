@@ -26,6 +26,24 @@
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
+#ifdef OSFM_DBG_PHASES
+// instrumented builds only (tools/match_phases.py): 100 MHz ticks of workgroup thread 0, summed over the workgroups
+__device__ unsigned long long g_phase[16];
+#define OSFM_TICK(var) const unsigned long long var = wall_clock64();
+#define OSFM_PHASE(i, t0, t1) if (tid == 0) atomicAdd(&g_phase[i], (t1) - (t0));
+extern "C" int osfm_dbg_phases(unsigned long long *out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(g_phase)) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#else
+#define OSFM_TICK(var)
+#define OSFM_PHASE(i, t0, t1)
+#endif
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -440,6 +458,7 @@ __device__ __forceinline__ int query_pass(const QueryPassShared &sh, const int8_
       }
       ++sidx;
     };
+    OSFM_TICK(tk0)
     int rb = 0;
     for (; rb + 1 < nrb; rb += 2) {
       one_step(afA, afB, rb);
@@ -454,7 +473,9 @@ __device__ __forceinline__ int query_pass(const QueryPassShared &sh, const int8_
     }
 
     // ---- end of the chunk: merge the 8 partial classes (4 waves x 2 halves) of every query, decide, re-examine ----
+    OSFM_TICK(tk1)
     __syncthreads();  // everyone is done reading the chunk: its buffer becomes the scratch
+    OSFM_TICK(tk2)
     int *scr = (int *)(sh.bbuf + (c & 1) * kChunkBytes4);  // [8 parts][3][256]
     {
       const int part = w * 2 + (lane >> 5);
@@ -496,6 +517,10 @@ __device__ __forceinline__ int query_pass(const QueryPassShared &sh, const int8_
     //      gives the winner with cv2's lowest-index rule and a second max the runner-up; both are DPP reductions inside the row.
     unsigned long long pending = __ballot(want);
     unsigned long long redo = 0;  // queries that have to be re-done against all targets
+    OSFM_TICK(tk3)
+#ifdef OSFM_DBG_PHASES
+    if (tid == 0) atomicAdd(&g_phase[(GATHER ? 5 : 0) + 4], (unsigned long long)__popcll(pending));
+#endif
     while (pending) {
       int srcs[4];
 #pragma unroll
@@ -512,18 +537,22 @@ __device__ __forceinline__ int query_pass(const QueryPassShared &sh, const int8_
       const int row0 = (qrb * (kWaves * kRT) + qw * kRT) * 32 + (sl & 3) + 8 * (sl >> 2) + 4 * qh, row1 = row0 + 32;
       int k0 = INT_MIN, k1 = INT_MIN;
       if (src >= 0 && !tie) {
-        const int8_t *pa = tilesQ + (long)(qf >> 5) * OSFM_TILE_BYTES + (qf & 31) * 16;
-        const int8_t *p0 = tilesT + (long)(row0 >> 5) * OSFM_TILE_BYTES + (row0 & 31) * 16;
-        const int8_t *p1 = tilesT + (long)(row1 >> 5) * OSFM_TILE_BYTES + (row1 & 31) * 16;
+        // a row beyond the image reads row 0 instead (its key is dropped below): the ADDRESS is selected, never the loaded value, so
+        // that all 26 loads are in flight before the first wait (a value select made the compiler wait after every query slice:
+        // ten memory round trips per step, profiles/r03_match_phases.txt)
         const bool ok0 = row0 < nT, ok1 = row1 < nT;
+        const int r0 = ok0 ? row0 : 0, r1 = ok1 ? row1 : 0;
+        const int8_t *pa = tilesQ + (long)(qf >> 5) * OSFM_TILE_BYTES + (qf & 31) * 16;
+        const int8_t *p0 = tilesT + (long)(r0 >> 5) * OSFM_TILE_BYTES + (r0 & 31) * 16;
+        const int8_t *p1 = tilesT + (long)(r1 >> 5) * OSFM_TILE_BYTES + (r1 & 31) * 16;
         v4i av[8], bv0[8], bv1[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           av[q] = *(const v4i *)(pa + q * 512);
-          bv0[q] = ok0 ? *(const v4i *)(p0 + q * 512) : av[q];
-          bv1[q] = ok1 ? *(const v4i *)(p1 + q * 512) : av[q];
+          bv0[q] = *(const v4i *)(p0 + q * 512);
+          bv1[q] = *(const v4i *)(p1 + q * 512);
         }
-        const int n0 = ok0 ? normT[row0] : 0, n1 = ok1 ? normT[row1] : 0;
+        const int n0 = normT[r0], n1 = normT[r1];
         int s0 = 0, s1 = 0;
 #pragma unroll
         for (int q = 0; q < 8; ++q)
@@ -564,6 +593,11 @@ __device__ __forceinline__ int query_pass(const QueryPassShared &sh, const int8_
         redo |= (full && sl == 0) ? (1ull << src) : 0ull;
       }
     }
+    OSFM_TICK(tk4)
+    OSFM_PHASE((GATHER ? 5 : 0) + 0, tk0, tk1)  // sweep
+    OSFM_PHASE((GATHER ? 5 : 0) + 1, tk1, tk2)  // wait for the other waves
+    OSFM_PHASE((GATHER ? 5 : 0) + 2, tk2, tk3)  // merge + decide
+    OSFM_PHASE((GATHER ? 5 : 0) + 3, tk3, tk4)  // class re-examination
     // the rare queries whose decision needs every target: exact best (lowest index among equals) and exact second, by the whole wave
     {
       unsigned lo = (unsigned)redo, hi = (unsigned)(redo >> 32);
@@ -679,11 +713,14 @@ __global__ void __launch_bounds__(kThreads, 2) match_fused_kernel(MatchArgs a) {
   }
   __syncthreads();
   // FQ: the float rows of the two images and the quantisation error bound of the pair
+  OSFM_TICK(tq0)
   const float *descA = FQ ? a.descf + a.tile_off[imgA] * (long)(32 * OSFM_DESC_DIM) : nullptr;
   const float *descB = FQ ? a.descf + a.tile_off[imgB] * (long)(32 * OSFM_DESC_DIM) : nullptr;
   const double eps = FQ ? (double)a.qerr[imgA] + (double)a.qerr[imgB] : 0.0;
   int flag = query_pass<false, FQ>(sh, tilesA, normA, nA, nA, nullptr, tilesB, normB, hnegB, nB, tiles_pad, hneg_pad, resA, a.ratio, tid,
                                    descA, descB, eps);
+  OSFM_TICK(tq1)
+  OSFM_PHASE(10, tq0, tq1)  // pass A
   if (a.symmetric) {
     // candidates: the features of B that some row of A chose.  resB doubles as the mark array
     // (0 = chosen) until the candidate list is built, in ascending feature order.
@@ -714,10 +751,14 @@ __global__ void __launch_bounds__(kThreads, 2) match_fused_kernel(MatchArgs a) {
       __syncthreads();
     }
     const int nK = base;
+    OSFM_TICK(tq2)
+    OSFM_PHASE(11, tq1, tq2)  // candidate list
     if (nK > 0)
       flag += query_pass<true, FQ>(sh, tilesB, normB, nB, nK, cand, tilesA, normA, hnegA, nA, tiles_pad, hneg_pad, resB, a.ratio, tid, descB, descA,
                                    eps);
   }
+  OSFM_TICK(tq3)
+  OSFM_PHASE(12, tq1, tq3)  // candidate list + pass B
   // integer store: flag = the pair has to be re-run by the exact kernel; float store: the number of queries evaluated in float
   if (FQ) {
     if (lane == 0 && flag) atomicAdd(&misc[8], flag);
@@ -763,6 +804,12 @@ __global__ void __launch_bounds__(kThreads, 2) match_fused_kernel(MatchArgs a) {
     }
     if (tid == 0) a.out_counts[p] = base;
   }
+  OSFM_TICK(tq4)
+  OSFM_PHASE(13, tq3, tq4)  // emission
+  OSFM_PHASE(14, tq0, tq4)
+#ifdef OSFM_DBG_PHASES
+  if (tid == 0) atomicAdd(&g_phase[15], 1ull);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
