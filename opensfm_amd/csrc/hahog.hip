@@ -318,26 +318,30 @@ struct PatchPlan {
   long x0i, y0i, padx0, pady0, padx1, pady1, pw, ph;
   double sigma_level;      // sigma_ of the level
 };
-__device__ void plan_patch(const Pyramid &py, double extent, double sigma, const double *A_, const double *T_, double d1, double d2, PatchPlan &P) {
+// Run by all 64 lanes of the workgroup's first wave on identical arguments: the octave search (one log2 / pow pair per octave in the
+// reference's loop) is a lane per octave, lane 0 writes the plan; every lane returns sigma_ of the chosen level.
+__device__ double plan_patch(const Pyramid &py, double extent, double sigma, const double *A_, const double *T_, double d1, double d2, PatchPlan &P,
+                             int lane) {
   const int first_octave = 0, last_octave = py.n_oct - 1;
   const double factor = 1.0 / (d1 < d2 ? d1 : d2);
   long o, s;
   double sigma_;
-  for (o = first_octave + 1; o <= last_octave; ++o) {
-    s = vl_floor_d(log2(sigma / (factor * py.base_scale)) - o);
-    s = s > kFirstSub ? s : kFirstSub;
-    s = s < kLastSub ? s : kLastSub;
-    sigma_ = py.base_scale * pow(2.0, o + (double)s / kRes);
-    if (factor * sigma_ > sigma) {
-      o--;
-      break;
-    }
+  {
+    // the loop `for (o = first + 1; o <= last; ++o) { s, sigma_ of o; if (factor * sigma_ > sigma) { o--; break; } }`, then o = min(o, last)
+    // and s, sigma_ of that o once more: all functions of o alone
+    const long ol = lane <= last_octave ? lane : last_octave;
+    long sl = vl_floor_d(log2(sigma / (factor * py.base_scale)) - ol);
+    sl = sl > kFirstSub ? sl : kFirstSub;
+    sl = sl < kLastSub ? sl : kLastSub;
+    const double sgl = py.base_scale * pow(2.0, ol + (double)sl / kRes);
+    const bool stop = lane >= first_octave + 1 && lane <= last_octave && factor * sgl > sigma;
+    const unsigned long long mask = __ballot(stop);
+    o = mask ? (long)__builtin_ctzll(mask) - 1 : (long)last_octave + 1;
+    o = o < last_octave ? o : last_octave;
+    s = __shfl((int)sl, (int)o);
+    sigma_ = __shfl(sgl, (int)o);
   }
-  o = o < last_octave ? o : last_octave;
-  s = vl_floor_d(log2(sigma / (factor * py.base_scale)) - o);
-  s = s > kFirstSub ? s : kFirstSub;
-  s = s < kLastSub ? s : kLastSub;
-  sigma_ = py.base_scale * pow(2.0, o + (double)s / kRes);
+  if (lane != 0) return sigma_;
   P.sigma_level = sigma_;
   const Octave &oc = py.oct[o];
   P.level = oc.gss + (long)(s - kFirstSub) * oc.w * oc.h;
@@ -373,6 +377,7 @@ __device__ void plan_patch(const Pyramid &py, double extent, double sigma, const
     P.T[0] -= P.x0i;
     P.T[1] -= P.y0i;
   }
+  return sigma_;
 }
 // sample (xi, yi) of the image the bilinear interpolation reads: the level itself, or the padded copy (covdet.c:2296-2330, including
 // how its rows are filled: the last two columns of a row repeat the column before them)
@@ -463,35 +468,43 @@ __global__ void __launch_bounds__(256) orientation_kernel(Pyramid py, const floa
                                                           const double *aa_mask, int *n_or, double *or_angle /* n x 4 */) {
   __shared__ float patch[kOrSide * kOrSide], tmp[kOrSide * kOrSide];
   __shared__ int hbin[kOrSide * kOrSide];
-  __shared__ double hc1[kOrSide * kOrSide], hc2[kOrSide * kOrSide];
+  __shared__ double2 hc[kOrSide * kOrSide];  // what the pixel adds to its bin and to the next one
   __shared__ float taps1[kMaxTaps];
   __shared__ int W1;
   __shared__ PatchPlan P;
-  __shared__ double hist[kOrBins];
+  __shared__ double hist[kOrBins], hist2[kOrBins];
   const int f = blockIdx.x, tid = threadIdx.x;
   if (f >= n) return;
-  if (tid == 0) {
+  if (tid < 64) {  // wave 0
     // the detector's frames are isotropic: A = sigma I, so vl_svd2 returns D = (sigma, sigma), U = V = I and theta0 = atan2(0, 1) = 0
     const double sg = fsigma[f];
     const double A[4] = {sg, 0.0, 0.0, sg}, T[2] = {fx[f], fy[f]};
-    plan_patch(py, kOrExtent, 1.0, A, T, sg, sg, P);
-    const double sigma1 = P.sigma_level / sg;
+    const double sigma_level = plan_patch(py, kOrExtent, 1.0, A, T, sg, sg, P, tid);
+    const double sigma1 = sigma_level / sg;
     // vl_imsmooth_f(patch, deltaSigma1 / stephat, deltaSigma2 / stephat): one filter, both directions (sigma1 = sigma2)
     const double t = 1.0 - sigma1 * sigma1;
     const double delta = sqrt(t > 0 ? t : 0), stephat = kOrExtent / kOrRes;
     const double sd = delta / stephat;
     const int W = (int)ceil(sd * 3.0);
-    W1 = W;
-    float mass = (float)1.0;
-    taps1[W] = 1.0f;
-    for (int i = 1; i <= W; i++) {
-      const double xx = (double)i / sd;
-      const double g = exp(-0.5 * xx * xx);
-      mass += g + g;
-      taps1[W - i] = (float)g;
-      taps1[W + i] = (float)g;
+    // a lane per tap for the exponentials, lane 0 for the mass (its float accumulation order) -- W <= 7: sd <= 1 / stephat
+    double g = 0.0;
+    if (tid >= 1 && tid <= W) {
+      const double xx = (double)tid / sd;
+      g = exp(-0.5 * xx * xx);
     }
-    for (int i = 0; i < 2 * W + 1; i++) taps1[i] /= mass;
+    float mass = (float)1.0;
+    for (int i = 1; i <= W; i++) {
+      const double gi = __shfl(g, i);
+      mass += gi + gi;
+    }
+    if (tid == 0) {
+      W1 = W;
+      taps1[W] = 1.0f / mass;
+    }
+    if (tid >= 1 && tid <= W) {
+      taps1[W - tid] = (float)g / mass;
+      taps1[W + tid] = (float)g / mass;
+    }
   }
   if (tid < kOrBins) hist[tid] = 0.0;
   __syncthreads();
@@ -530,56 +543,73 @@ __global__ void __launch_bounds__(256) orientation_kernel(Pyramid py, const floa
     const long bin = vl_floor_d(xx);
     const double w2 = xx - bin, w1 = 1.0 - w2;
     hbin[t] = (int)((bin + kOrBins) % kOrBins);
-    hc1[t] = w1 * (modulus * weight);
-    hc2[t] = w2 * (modulus * weight);
+    hc[t] = make_double2(w1 * (modulus * weight), w2 * (modulus * weight));
   }
   __syncthreads();
-  // bin b adds, in raster order, what the sequential loop adds to it
+  // bin b adds, in raster order, what the sequential loop adds to it.  Branch-free: a pixel that does not feed the bin adds +0.0, which
+  // leaves a sum of non-negative terms unchanged, and every load is unconditional, so the 1 681 steps pipeline instead of paying an
+  // LDS round trip (or three) each
   if (tid < kOrBins) {
     const int prev = (tid + kOrBins - 1) % kOrBins;
     double hsum = 0.0;
+#pragma unroll 8
     for (int k = 0; k < kOrSide * kOrSide; k++) {
       const int b = hbin[k];
-      if (b == tid) hsum += hc1[k];
-      if (b == prev) hsum += hc2[k];
+      const double2 c = hc[k];
+      hsum += (b == tid) ? c.x : ((b == prev) ? c.y : 0.0);
     }
     hist[tid] = hsum;
   }
   __syncthreads();
-  if (tid == 0) {
-    for (int iter = 0; iter < 6; iter++) {
-      double prev = hist[kOrBins - 1];
-      const double first = hist[0];
-      int i;
-      for (i = 0; i < kOrBins - 1; ++i) {
-        const double curr = (prev + hist[i] + hist[(i + 1) % kOrBins]) / 3.0;
-        prev = hist[i];
-        hist[i] = curr;
-      }
-      hist[i] = (prev + hist[i] + first) / 3.0;
-    }
-    double maxPeak = 0;
-    for (int i = 0; i < kOrBins; i++) maxPeak = maxPeak > hist[i] ? maxPeak : hist[i];
-    double ang[kMaxOr], sc[kMaxOr];
-    int cnt = 0;
-    for (int i = 0; i < kOrBins; i++) {
-      const double h0 = hist[i], hm = hist[(i - 1 + kOrBins) % kOrBins], hp = hist[(i + 1 + kOrBins) % kOrBins];
-      if (h0 > 0.8 * maxPeak && h0 > hm && h0 > hp) {
+  // six passes of the circular box filter (covdet.c:2786-2799).  The in-place loop reads the OLD left neighbour (prev), the old centre
+  // and the old right neighbour, the last bin the old first one: a Jacobi step, a lane per bin, same operation order
+  for (int iter = 0; iter < 6; iter++) {
+    const double *src = (iter & 1) ? hist2 : hist;
+    double *dst = (iter & 1) ? hist : hist2;
+    if (tid < kOrBins) dst[tid] = (src[(tid + kOrBins - 1) % kOrBins] + src[tid] + src[(tid + 1) % kOrBins]) / 3.0;
+    __syncthreads();
+  }
+  // peaks (covdet.c:2801-2830): a lane per bin decides, the first four in bin order are kept (the loop's break), lane 0 sorts them
+  __shared__ double pk_ang[kMaxOr], pk_sc[kMaxOr];
+  __shared__ int pk_cnt;
+  if (tid < 64) {  // wave 0
+    bool peak = false;
+    double a = 0.0, h0 = 0.0;
+    if (tid < kOrBins) {
+      double maxPeak = 0;
+#pragma unroll
+      for (int i = 0; i < kOrBins; i++) maxPeak = maxPeak > hist[i] ? maxPeak : hist[i];
+      const int i = tid;
+      h0 = hist[i];
+      const double hm = hist[(i - 1 + kOrBins) % kOrBins], hp = hist[(i + 1 + kOrBins) % kOrBins];
+      peak = h0 > 0.8 * maxPeak && h0 > hm && h0 > hp;
+      if (peak) {
         const double di = -0.5 * (hp - hm) / (hp + hm - 2 * h0);
-        ang[cnt] = binExtent * (i + di) + 0.0;  // + theta0
-        sc[cnt] = h0;
-        cnt++;
-        if (cnt >= kMaxOr) break;
+        a = binExtent * (i + di) + 0.0;  // + theta0
       }
     }
+    const unsigned long long mask = __ballot(peak);
+    const int rank = __popcll(mask & ((1ull << tid) - 1ull));
+    if (peak && rank < kMaxOr) {
+      pk_ang[rank] = a;
+      pk_sc[rank] = h0;
+    }
+    if (tid == 0) {
+      const int c = __popcll(mask);
+      pk_cnt = c < kMaxOr ? c : kMaxOr;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const int cnt = pk_cnt;
     // qsort by decreasing score (glibc: merge sort, stable)
     for (int i = 1; i < cnt; i++)
-      for (int j = i; j > 0 && sc[j] > sc[j - 1]; j--) {
-        double t0 = sc[j]; sc[j] = sc[j - 1]; sc[j - 1] = t0;
-        t0 = ang[j]; ang[j] = ang[j - 1]; ang[j - 1] = t0;
+      for (int j = i; j > 0 && pk_sc[j] > pk_sc[j - 1]; j--) {
+        double t0 = pk_sc[j]; pk_sc[j] = pk_sc[j - 1]; pk_sc[j - 1] = t0;
+        t0 = pk_ang[j]; pk_ang[j] = pk_ang[j - 1]; pk_ang[j - 1] = t0;
       }
     n_or[f] = cnt;
-    for (int i = 0; i < cnt; i++) or_angle[(long)f * kMaxOr + i] = ang[i];
+    for (int i = 0; i < cnt; i++) or_angle[(long)f * kMaxOr + i] = pk_ang[i];
   }
 }
 // exclusive scan of the orientation counts, one workgroup (a few thousand features)
@@ -631,40 +661,40 @@ constexpr double kDExtent = 7.5;
 __global__ void __launch_bounds__(256) descriptor_kernel(Pyramid py, Oriented R, int n, const double *expn_tab, double st0, double ct0, double sigma_d,
                                                          int flags, float *points, float *desc) {
   __shared__ float patch[kDSide * kDSide];
-  __shared__ float smod[kDSide * kDSide], sang[kDSide * kDSide];
-  __shared__ float swm[kDSide * kDSide], srx[kDSide * kDSide], sry[kDSide * kDSide], srt[kDSide * kDSide];
-  __shared__ int sbx[kDSide * kDSide], sby[kDSide * kDSide], sbt[kDSide * kDSide];
+  __shared__ float4 sval[kDSide * kDSide];  // window x modulus and the three fractions of the pixel
+  __shared__ int scode[kDSide * kDSide];    // its lower bins: (binx + 128) | (biny + 128) << 8 | bint << 16
   __shared__ float descr[kNBO * kNBP * kNBP];
+  __shared__ float snorm;
   __shared__ PatchPlan P;
   const int f = blockIdx.x, tid = threadIdx.x;
   if (f >= n) return;
-  if (tid == 0) {
+  if (tid < 64) {  // wave 0
     const float a11 = R.a11[f], a21 = R.a21[f], a12 = R.a12[f], a22 = R.a22[f];
-    const float det = a11 * a22 - a12 * a21;
-    const float size = sqrtf(fabsf(det));
-    const float angle = (float)(atan2f(a21, a11) * 180.0f / M_PI);
-    points[4 * (long)f + 0] = R.x[f];
-    points[4 * (long)f + 1] = R.y[f];
-    points[4 * (long)f + 2] = size;
-    points[4 * (long)f + 3] = angle;
+    if (tid == 0) {
+      const float det = a11 * a22 - a12 * a21;
+      const float size = sqrtf(fabsf(det));
+      const float angle = (float)(atan2f(a21, a11) * 180.0f / M_PI);
+      points[4 * (long)f + 0] = R.x[f];
+      points[4 * (long)f + 1] = R.y[f];
+      points[4 * (long)f + 2] = size;
+      points[4 * (long)f + 3] = angle;
+    }
     const double A[4] = {a11, a21, a12, a22}, T[2] = {R.x[f], R.y[f]};
     double d1, d2;
     svd2_values(A, &d1, &d2);
-    plan_patch(py, kDExtent, 1.0, A, T, d1, d2, P);
+    plan_patch(py, kDExtent, 1.0, A, T, d1, d2, P, tid);
   }
   __syncthreads();
   sample_patch(P, patch, kDRes, kDExtent, tid, 256);
   __syncthreads();
-  for (int t = tid; t < kDSide * kDSide; t += 256) polar_gradient(patch, kDSide, t, &smod[t], &sang[t]);
-  __syncthreads();
   // per pixel: window x modulus, the lower bin of the 2 x 2 x 2 it feeds and the three fractions (sift.c:1806-1850); x = y = 15,
   // so xi = yi = 15 and every pixel of the patch is inside the window W = 21
   const double x0 = (double)(kDSide - 1) / 2, y0 = (double)(kDSide - 1) / 2;
-  const int xi0 = (int)(x0 + 0.5), yi0 = (int)(y0 + 0.5);
   const double SBP = 3.0 * sigma_d + kEpsD;
   for (int t = tid; t < kDSide * kDSide; t += 256) {
     const int py_ = t / kDSide, px_ = t - py_ * kDSide;
-    const float mod = smod[t], angle = sang[t];
+    float mod, angle;
+    polar_gradient(patch, kDSide, t, &mod, &angle);
     const float theta = mod_2pi_f((float)(angle - (kPi / 2)));
     const float dx = (float)(px_ - x0), dy = (float)(py_ - y0);
     const float nx = (float)((ct0 * dx + st0 * dy) / SBP);
@@ -681,44 +711,47 @@ __global__ void __launch_bounds__(256) descriptor_kernel(Pyramid py, Oriented R,
     }
     const float win = (float)win_d;
     const int binx = (int)vl_floor_f((float)(nx - 0.5)), biny = (int)vl_floor_f((float)(ny - 0.5)), bint = (int)vl_floor_f(nt);
-    srx[t] = (float)(nx - (binx + 0.5));
-    sry[t] = (float)(ny - (biny + 0.5));
-    srt[t] = nt - bint;
-    sbx[t] = binx;
-    sby[t] = biny;
-    sbt[t] = bint;
-    swm[t] = win * mod;
-    (void)xi0;
-    (void)yi0;
+    sval[t] = make_float4(win * mod, (float)(nx - (binx + 0.5)), (float)(ny - (biny + 0.5)), nt - bint);
+    scode[t] = (binx + 128) | ((biny + 128) << 8) | (bint << 16);
   }
   __syncthreads();
-  // bin (bx, by, bt) adds, in raster order, what the sequential loop adds to it
+  // bin (bx, by, bt) adds, in raster order, what the sequential loop adds to it.  Branch-free and with unconditional loads (two per
+  // pixel), so that the 961 steps pipeline: a pixel that does not feed the bin adds +0.0f, which leaves a sum of non-negative terms
+  // unchanged; a pixel feeds a bin through at most one of its two orientation bins
   if (tid < kNBO * kNBP * kNBP) {
     const int bt = tid % kNBO, bx = (tid / kNBO) % kNBP - kNBP / 2, by = tid / (kNBO * kNBP) - kNBP / 2;
     float acc = 0.f;
+#pragma unroll 8
     for (int t = 0; t < kDSide * kDSide; t++) {
-      const int dbinx = bx - sbx[t], dbiny = by - sby[t];
-      if (dbinx < 0 || dbinx > 1 || dbiny < 0 || dbiny > 1) continue;
-      const int b0 = sbt[t] % kNBO, b1 = (sbt[t] + 1) % kNBO;
-      const float wm = swm[t], rx = srx[t], ry = sry[t], rt = srt[t];
-      if (b0 == bt) acc += wm * fabsf(1 - dbinx - rx) * fabsf(1 - dbiny - ry) * fabsf(1 - 0 - rt);
-      if (b1 == bt) acc += wm * fabsf(1 - dbinx - rx) * fabsf(1 - dbiny - ry) * fabsf(1 - 1 - rt);
+      const int code = scode[t];
+      const float4 pv = sval[t];
+      const int dbinx = bx - ((code & 255) - 128), dbiny = by - (((code >> 8) & 255) - 128), sb = code >> 16;
+      const bool in = !(dbinx < 0 || dbinx > 1 || dbiny < 0 || dbiny > 1);
+      const int b0 = sb % kNBO, b1 = (sb + 1) % kNBO;
+      const float wm = pv.x, rx = pv.y, ry = pv.z, rt = pv.w;
+      const float v0 = wm * fabsf(1 - dbinx - rx) * fabsf(1 - dbiny - ry) * fabsf(1 - 0 - rt);
+      const float v1 = wm * fabsf(1 - dbinx - rx) * fabsf(1 - dbiny - ry) * fabsf(1 - 1 - rt);
+      acc += (in && b0 == bt) ? v0 : ((in && b1 == bt) ? v1 : 0.0f);
     }
     descr[tid] = acc;
   }
   __syncthreads();
-  if (tid == 0) {  // normalise, clamp at 0.2, normalise (sift.c:1872-1896, norm_thresh = 0)
-    for (int pass = 0; pass < 2; pass++) {
+  // normalise, clamp at 0.2, normalise (sift.c:1872-1896, norm_thresh = 0): the sum in index order by one lane, the divisions by all
+  for (int pass = 0; pass < 2; pass++) {
+    if (tid == 0) {
       float norm = 0.0f;
+#pragma unroll
       for (int i = 0; i < 128; i++) norm += descr[i] * descr[i];
-      norm = fast_sqrt_f(norm) + kEpsF;
-      for (int i = 0; i < 128; i++) descr[i] /= norm;
-      if (pass == 0)
-        for (int i = 0; i < 128; i++)
-          if ((double)descr[i] > 0.2) descr[i] = (float)0.2;
+      snorm = fast_sqrt_f(norm) + kEpsF;
     }
+    __syncthreads();
+    if (tid < 128) {
+      float v = descr[tid] / snorm;
+      if (pass == 0 && (double)v > 0.2) v = (float)0.2;
+      descr[tid] = v;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   if (tid < 128) {
     float v = descr[tid];
     if (flags & OSFM_HAHOG_ROOT) v = sqrtf(v);                       // np.sqrt (features.py:526)
