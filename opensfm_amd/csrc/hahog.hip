@@ -473,6 +473,7 @@ __global__ void __launch_bounds__(256) orientation_kernel(Pyramid py, const floa
   __shared__ int W1;
   __shared__ PatchPlan P;
   __shared__ double hist[kOrBins], hist2[kOrBins];
+  __shared__ int tot[kOrBins], start[kOrBins + 1], run[kOrBins], cw[4][kOrBins];
   const int f = blockIdx.x, tid = threadIdx.x;
   if (f >= n) return;
   if (tid < 64) {  // wave 0
@@ -506,7 +507,11 @@ __global__ void __launch_bounds__(256) orientation_kernel(Pyramid py, const floa
       taps1[W + tid] = (float)g / mass;
     }
   }
-  if (tid < kOrBins) hist[tid] = 0.0;
+  if (tid < kOrBins) {
+    hist[tid] = 0.0;
+    tot[tid] = 0;
+    run[tid] = 0;
+  }
   __syncthreads();
   sample_patch(P, patch, kOrRes, kOrExtent, tid, 256);
   __syncthreads();
@@ -544,20 +549,63 @@ __global__ void __launch_bounds__(256) orientation_kernel(Pyramid py, const floa
     const double w2 = xx - bin, w1 = 1.0 - w2;
     hbin[t] = (int)((bin + kOrBins) % kOrBins);
     hc[t] = make_double2(w1 * (modulus * weight), w2 * (modulus * weight));
+    atomicAdd(&tot[(int)((bin + kOrBins) % kOrBins)], 1);
   }
   __syncthreads();
-  // bin b adds, in raster order, what the sequential loop adds to it.  Branch-free: a pixel that does not feed the bin adds +0.0, which
-  // leaves a sum of non-negative terms unchanged, and every load is unconditional, so the 1 681 steps pipeline instead of paying an
-  // LDS round trip (or three) each
-  if (tid < kOrBins) {
-    const int prev = (tid + kOrBins - 1) % kOrBins;
-    double hsum = 0.0;
-#pragma unroll 8
-    for (int k = 0; k < kOrSide * kOrSide; k++) {
-      const int b = hbin[k];
-      const double2 c = hc[k];
-      hsum += (b == tid) ? c.x : ((b == prev) ? c.y : 0.0);
+  // Bin b adds, in raster order, what the sequential loop adds to it -- and nothing else: the 2 x 1 681 records (pixel t gives record 2t
+  // = its first product to bin hbin[t] and record 2t + 1 = its second product to the next bin) are sorted by bin with a STABLE counting
+  // sort, so a lane walks only its own ~93 records, in the reference's order.  (Scanning all pixels per bin, even branch-free, was a
+  // 190-cycle dependent step 1 681 times: 148 of the kernel's 187 us per workgroup, profiles/r03_hahog_phases_before_sort.txt.)
+  // Rank of a record inside its bin = number of earlier pixels whose hbin is the bin (their first records) or the bin before it (their
+  // second records): per chunk of 256 pixels a ballot per bin value, per-wave counts through LDS, a running count over the chunks.
+  unsigned short *order = reinterpret_cast<unsigned short *>(tmp);  // 2 x 1 681 record ids: exactly the smoothing buffer, free by now
+  if (tid == 0) {
+    int acc = 0;
+    for (int v = 0; v < kOrBins; v++) {
+      start[v] = acc;
+      acc += tot[v] + tot[(v + kOrBins - 1) % kOrBins];
     }
+    start[kOrBins] = acc;
+  }
+  {
+    const int lane = tid & 63, w = tid >> 6;
+    for (int c0 = 0; c0 < kOrSide * kOrSide; c0 += 256) {
+      const int t = c0 + tid;
+      const bool valid = t < kOrSide * kOrSide;
+      const int b = valid ? hbin[t] : -1;
+      const int bm1 = valid ? (b + kOrBins - 1) % kOrBins : -1, bp1 = valid ? (b + 1) % kOrBins : -1;
+      int p_m1 = 0, p_0 = 0, p_p1 = 0, mycnt = 0;
+#pragma unroll 4
+      for (int v = 0; v < kOrBins; v++) {
+        const unsigned long long m = __ballot(b == v);
+        const int pre = __popcll(m & ((1ull << lane) - 1ull));
+        p_0 = (v == b) ? pre : p_0;
+        p_m1 = (v == bm1) ? pre : p_m1;
+        p_p1 = (v == bp1) ? pre : p_p1;
+        mycnt = (lane == v) ? __popcll(m) : mycnt;
+      }
+      if (lane < kOrBins) cw[w][lane] = mycnt;
+      __syncthreads();  // cw of this chunk, start[] (first chunk), run[] of the previous chunk
+      if (valid) {
+        int e_m1 = run[bm1] + p_m1, e_0 = run[b] + p_0, e_p1 = run[bp1] + p_p1;
+        for (int w2 = 0; w2 < w; w2++) {
+          e_m1 += cw[w2][bm1];
+          e_0 += cw[w2][b];
+          e_p1 += cw[w2][bp1];
+        }
+        order[start[b] + e_0 + e_m1] = (unsigned short)(2 * t);
+        order[start[bp1] + e_p1 + e_0] = (unsigned short)(2 * t + 1);
+      }
+      __syncthreads();
+      if (tid < kOrBins) run[tid] += cw[0][tid] + cw[1][tid] + cw[2][tid] + cw[3][tid];
+      __syncthreads();
+    }
+  }
+  if (tid < kOrBins) {
+    const double *rec = reinterpret_cast<const double *>(hc);
+    const int k1 = start[tid + 1];
+    double hsum = 0.0;
+    for (int k = start[tid]; k < k1; k++) hsum += rec[order[k]];
     hist[tid] = hsum;
   }
   __syncthreads();
@@ -665,9 +713,17 @@ __global__ void __launch_bounds__(256) descriptor_kernel(Pyramid py, Oriented R,
   __shared__ int scode[kDSide * kDSide];    // its lower bins: (binx + 128) | (biny + 128) << 8 | bint << 16
   __shared__ float descr[kNBO * kNBP * kNBP];
   __shared__ float snorm;
+  __shared__ int rlo[2][kDSide], rhi[2][kDSide], clo[2][kDSide], chi[2][kDSide];  // per row / column: range of binx [0] and biny [1]
   __shared__ PatchPlan P;
   const int f = blockIdx.x, tid = threadIdx.x;
   if (f >= n) return;
+  if (tid >= 64 && tid < 64 + 2 * kDSide) {
+    const int i = tid - 64;
+    (&rlo[0][0])[i] = INT_MAX;
+    (&clo[0][0])[i] = INT_MAX;
+    (&rhi[0][0])[i] = INT_MIN;
+    (&chi[0][0])[i] = INT_MIN;
+  }
   if (tid < 64) {  // wave 0
     const float a11 = R.a11[f], a21 = R.a21[f], a12 = R.a12[f], a22 = R.a22[f];
     if (tid == 0) {
@@ -713,25 +769,47 @@ __global__ void __launch_bounds__(256) descriptor_kernel(Pyramid py, Oriented R,
     const int binx = (int)vl_floor_f((float)(nx - 0.5)), biny = (int)vl_floor_f((float)(ny - 0.5)), bint = (int)vl_floor_f(nt);
     sval[t] = make_float4(win * mod, (float)(nx - (binx + 0.5)), (float)(ny - (biny + 0.5)), nt - bint);
     scode[t] = (binx + 128) | ((biny + 128) << 8) | (bint << 16);
+    atomicMin(&rlo[0][py_], binx);
+    atomicMax(&rhi[0][py_], binx);
+    atomicMin(&rlo[1][py_], biny);
+    atomicMax(&rhi[1][py_], biny);
+    atomicMin(&clo[0][px_], binx);
+    atomicMax(&chi[0][px_], binx);
+    atomicMin(&clo[1][px_], biny);
+    atomicMax(&chi[1][px_], biny);
   }
   __syncthreads();
   // bin (bx, by, bt) adds, in raster order, what the sequential loop adds to it.  Branch-free and with unconditional loads (two per
   // pixel), so that the 961 steps pipeline: a pixel that does not feed the bin adds +0.0f, which leaves a sum of non-negative terms
   // unchanged; a pixel feeds a bin through at most one of its two orientation bins
+  // A pixel feeds bin (bx, by, .) only with binx in {bx - 1, bx} and biny in {by - 1, by}: the lane walks, in raster order, only the rows
+  // and the columns whose measured ranges of binx and biny admit that (a superset for any patch rotation; ~13 x 13 of the 31 x 31
+  // pixels), the rest as before.  (All 961 pixels per bin: 130 of the kernel's 166 us per workgroup, r03_hahog_phases_before_sort.txt.)
   if (tid < kNBO * kNBP * kNBP) {
     const int bt = tid % kNBO, bx = (tid / kNBO) % kNBP - kNBP / 2, by = tid / (kNBO * kNBP) - kNBP / 2;
+    unsigned rowmask = 0, colmask = 0;
+#pragma unroll
+    for (int i = 0; i < kDSide; i++) {
+      const bool r = rlo[0][i] <= bx && rhi[0][i] >= bx - 1 && rlo[1][i] <= by && rhi[1][i] >= by - 1;
+      const bool c = clo[0][i] <= bx && chi[0][i] >= bx - 1 && clo[1][i] <= by && chi[1][i] >= by - 1;
+      rowmask |= r ? (1u << i) : 0u;
+      colmask |= c ? (1u << i) : 0u;
+    }
     float acc = 0.f;
-#pragma unroll 8
-    for (int t = 0; t < kDSide * kDSide; t++) {
-      const int code = scode[t];
-      const float4 pv = sval[t];
-      const int dbinx = bx - ((code & 255) - 128), dbiny = by - (((code >> 8) & 255) - 128), sb = code >> 16;
-      const bool in = !(dbinx < 0 || dbinx > 1 || dbiny < 0 || dbiny > 1);
-      const int b0 = sb % kNBO, b1 = (sb + 1) % kNBO;
-      const float wm = pv.x, rx = pv.y, ry = pv.z, rt = pv.w;
-      const float v0 = wm * fabsf(1 - dbinx - rx) * fabsf(1 - dbiny - ry) * fabsf(1 - 0 - rt);
-      const float v1 = wm * fabsf(1 - dbinx - rx) * fabsf(1 - dbiny - ry) * fabsf(1 - 1 - rt);
-      acc += (in && b0 == bt) ? v0 : ((in && b1 == bt) ? v1 : 0.0f);
+    for (unsigned rm = rowmask; rm; rm &= rm - 1) {
+      const int yb = __builtin_ctz(rm) * kDSide;
+      for (unsigned cm = colmask; cm; cm &= cm - 1) {
+        const int t = yb + __builtin_ctz(cm);
+        const int code = scode[t];
+        const float4 pv = sval[t];
+        const int dbinx = bx - ((code & 255) - 128), dbiny = by - (((code >> 8) & 255) - 128), sb = code >> 16;
+        const bool in = !(dbinx < 0 || dbinx > 1 || dbiny < 0 || dbiny > 1);
+        const int b0 = sb % kNBO, b1 = (sb + 1) % kNBO;
+        const float wm = pv.x, rx = pv.y, ry = pv.z, rt = pv.w;
+        const float v0 = wm * fabsf(1 - dbinx - rx) * fabsf(1 - dbiny - ry) * fabsf(1 - 0 - rt);
+        const float v1 = wm * fabsf(1 - dbinx - rx) * fabsf(1 - dbiny - ry) * fabsf(1 - 1 - rt);
+        acc += (in && b0 == bt) ? v0 : ((in && b1 == bt) ? v1 : 0.0f);
+      }
     }
     descr[tid] = acc;
   }

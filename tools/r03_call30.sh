@@ -1,0 +1,28 @@
+#!/bin/bash
+OUT=/root/repo/gpurun_out/r03_c30
+mkdir -p $OUT
+cd /root/repo
+timeout 300 python -m pytest tests/test_gpu_hahog.py -q -x > $OUT/pytest.log 2>&1; tail -5 $OUT/pytest.log
+if ! grep -q " passed" $OUT/pytest.log || grep -q "failed" $OUT/pytest.log; then
+  for v in PLAIN_DE PLAIN_OR; do
+    OSFM_MI355_LIB=/root/repo/tools/libosfm_hahog_$v.so timeout 300 python -m pytest tests/test_gpu_hahog.py -q -x > $OUT/pytest_$v.log 2>&1; echo "== $v"; tail -5 $OUT/pytest_$v.log
+  done
+fi
+timeout 300 python - > $OUT/hahog_bench.json 2> $OUT/hahog_bench.err <<'PY'
+import json, sys
+sys.path.insert(0, '.')
+import bench
+from opensfm_amd._lib import default_context
+print(json.dumps(bench.hahog_bench(default_context(0), True)))
+PY
+tail -3 $OUT/hahog_bench.err; cat $OUT/hahog_bench.json
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --output-format rocpd -d $OUT/trace -- python -c "
+import sys; sys.path.insert(0, '/root/repo')
+import bench
+from opensfm_amd._lib import default_context
+bench.hahog_bench(default_context(0), False, reps=3)" > $OUT/trace.txt 2>&1
+cd /root/repo
+DB=$(find $OUT/trace -name "*.db" | head -1)
+python tools/rocpd_summary.py $DB --by-kernel > $OUT/hahog_kernels.txt 2>&1; head -8 $OUT/hahog_kernels.txt | cut -c1-150
+rm -rf $OUT/trace
