@@ -49,8 +49,8 @@ def run_grid(ctx, rows: int = 50, cols: int = 100, points: int = 500000, track: 
             "inlier_rmse_px": round(float(np.sqrt((g["reproj_err"][inl] ** 2).sum(1).mean()) * 2000.0), 4),
             "cost": [float(g["initial_cost"]), float(g["final_cost"])], "lm_iteration": lm_iteration_line(g, nobs),
             "solver_note": "exact band of half-width `preconditioner_bandwidth` shots factorised directly (one launch per 16-shot block "
-                           "column, 16 pivot steps each: a latency chain, not flops) + one workgroup walking the block columns per "
-                           "solve; CG confirms in 1-2 iterations"}
+                           "column, 16 pivot steps each: a latency chain, not flops); a solve = two sweeps of one small launch per block "
+                           "column in push form; CG confirms in 1-2 iterations"}
 
 
 def run(ctx, shots: int = 5000, points: int = 500000, track: int = 10, iters: int = 20, cpu_baseline: bool = True,
