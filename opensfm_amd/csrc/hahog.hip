@@ -26,6 +26,15 @@
 
 namespace {
 
+#ifdef OSFM_DBG_PHASES
+// instrumented builds only (tools/hahog_phases.py): 100 MHz ticks of thread 0 of every workgroup, summed per phase
+__device__ unsigned long long g_hphase[16];
+#define HTICK(var) const unsigned long long var = wall_clock64();
+#define HPHASE(i, t0, t1) if (threadIdx.x == 0) atomicAdd(&g_hphase[i], (t1) - (t0));
+#else
+#define HTICK(var)
+#define HPHASE(i, t0, t1)
+#endif
 constexpr int kFirstSub = -1, kLastSub = 3, kLev = kLastSub - kFirstSub + 1, kRes = 3;
 constexpr int kMaxTaps = 65;
 constexpr double kPi = 3.141592653589793;          // VL_PI
@@ -476,6 +485,7 @@ __global__ void __launch_bounds__(256) orientation_kernel(Pyramid py, const floa
   __shared__ int tot[kOrBins], start[kOrBins + 1], run[kOrBins], cw[4][kOrBins];
   const int f = blockIdx.x, tid = threadIdx.x;
   if (f >= n) return;
+  HTICK(h0)
   if (tid < 64) {  // wave 0
     // the detector's frames are isotropic: A = sigma I, so vl_svd2 returns D = (sigma, sigma), U = V = I and theta0 = atan2(0, 1) = 0
     const double sg = fsigma[f];
@@ -513,8 +523,10 @@ __global__ void __launch_bounds__(256) orientation_kernel(Pyramid py, const floa
     run[tid] = 0;
   }
   __syncthreads();
+  HTICK(h1)
   sample_patch(P, patch, kOrRes, kOrExtent, tid, 256);
   __syncthreads();
+  HTICK(h2)
   const int W = W1;
   for (int t = tid; t < kOrSide * kOrSide; t += 256) {  // along y
     const int y = t / kOrSide, x = t - y * kOrSide;
@@ -538,6 +550,7 @@ __global__ void __launch_bounds__(256) orientation_kernel(Pyramid py, const floa
     patch[t] = acc;
   }
   __syncthreads();
+  HTICK(h3)
   // per pixel, in parallel: the bin and the two products the sequential loop adds (covdet.c:2769-2781)
   const double binExtent = 2 * kPi / kOrBins;
   for (int t = tid; t < kOrSide * kOrSide; t += 256) {
@@ -552,6 +565,7 @@ __global__ void __launch_bounds__(256) orientation_kernel(Pyramid py, const floa
     atomicAdd(&tot[(int)((bin + kOrBins) % kOrBins)], 1);
   }
   __syncthreads();
+  HTICK(h4)
   // Bin b adds, in raster order, what the sequential loop adds to it -- and nothing else: the 2 x 1 681 records (pixel t gives record 2t
   // = its first product to bin hbin[t] and record 2t + 1 = its second product to the next bin) are sorted by bin with a STABLE counting
   // sort, so a lane walks only its own ~93 records, in the reference's order.  (Scanning all pixels per bin, even branch-free, was a
@@ -609,6 +623,7 @@ __global__ void __launch_bounds__(256) orientation_kernel(Pyramid py, const floa
     hist[tid] = hsum;
   }
   __syncthreads();
+  HTICK(h5)
   // six passes of the circular box filter (covdet.c:2786-2799).  The in-place loop reads the OLD left neighbour (prev), the old centre
   // and the old right neighbour, the last bin the old first one: a Jacobi step, a lane per bin, same operation order
   for (int iter = 0; iter < 6; iter++) {
@@ -659,6 +674,11 @@ __global__ void __launch_bounds__(256) orientation_kernel(Pyramid py, const floa
     n_or[f] = cnt;
     for (int i = 0; i < cnt; i++) or_angle[(long)f * kMaxOr + i] = pk_ang[i];
   }
+  HTICK(h6)
+  HPHASE(0, h0, h1) HPHASE(1, h1, h2) HPHASE(2, h2, h3) HPHASE(3, h3, h4) HPHASE(4, h4, h5) HPHASE(5, h5, h6) HPHASE(6, h0, h6)
+#ifdef OSFM_DBG_PHASES
+  if (tid == 0) atomicAdd(&g_hphase[7], 1ull);
+#endif
 }
 // exclusive scan of the orientation counts, one workgroup (a few thousand features)
 __global__ void __launch_bounds__(1024) scan_kernel(const int *cnt, int n, int *off) {
@@ -724,6 +744,7 @@ __global__ void __launch_bounds__(256) descriptor_kernel(Pyramid py, Oriented R,
     (&rhi[0][0])[i] = INT_MIN;
     (&chi[0][0])[i] = INT_MIN;
   }
+  HTICK(h0)
   if (tid < 64) {  // wave 0
     const float a11 = R.a11[f], a21 = R.a21[f], a12 = R.a12[f], a22 = R.a22[f];
     if (tid == 0) {
@@ -741,8 +762,10 @@ __global__ void __launch_bounds__(256) descriptor_kernel(Pyramid py, Oriented R,
     plan_patch(py, kDExtent, 1.0, A, T, d1, d2, P, tid);
   }
   __syncthreads();
+  HTICK(h1)
   sample_patch(P, patch, kDRes, kDExtent, tid, 256);
   __syncthreads();
+  HTICK(h2)
   // per pixel: window x modulus, the lower bin of the 2 x 2 x 2 it feeds and the three fractions (sift.c:1806-1850); x = y = 15,
   // so xi = yi = 15 and every pixel of the patch is inside the window W = 21
   const double x0 = (double)(kDSide - 1) / 2, y0 = (double)(kDSide - 1) / 2;
@@ -782,6 +805,7 @@ __global__ void __launch_bounds__(256) descriptor_kernel(Pyramid py, Oriented R,
   // bin (bx, by, bt) adds, in raster order, what the sequential loop adds to it.  Branch-free and with unconditional loads (two per
   // pixel), so that the 961 steps pipeline: a pixel that does not feed the bin adds +0.0f, which leaves a sum of non-negative terms
   // unchanged; a pixel feeds a bin through at most one of its two orientation bins
+  HTICK(h3)
   // A pixel feeds bin (bx, by, .) only with binx in {bx - 1, bx} and biny in {by - 1, by}: the lane walks, in raster order, only the rows
   // and the columns whose measured ranges of binx and biny admit that (a superset for any patch rotation; ~13 x 13 of the 31 x 31
   // pixels), the rest as before.  (All 961 pixels per bin: 130 of the kernel's 166 us per workgroup, r03_hahog_phases_before_sort.txt.)
@@ -814,6 +838,7 @@ __global__ void __launch_bounds__(256) descriptor_kernel(Pyramid py, Oriented R,
     descr[tid] = acc;
   }
   __syncthreads();
+  HTICK(h4)
   // normalise, clamp at 0.2, normalise (sift.c:1872-1896, norm_thresh = 0): the sum in index order by one lane, the divisions by all
   for (int pass = 0; pass < 2; pass++) {
     if (tid == 0) {
@@ -840,6 +865,11 @@ __global__ void __launch_bounds__(256) descriptor_kernel(Pyramid py, Oriented R,
     }
     desc[128 * (long)f + tid] = v;
   }
+  HTICK(h5)
+  HPHASE(8, h0, h1) HPHASE(9, h1, h2) HPHASE(10, h2, h3) HPHASE(11, h3, h4) HPHASE(12, h4, h5) HPHASE(13, h0, h5)
+#ifdef OSFM_DBG_PHASES
+  if (tid == 0) atomicAdd(&g_hphase[14], 1ull);
+#endif
 }
 
 // _vl_new_gaussian_fitler_f (imopv.c:623-643)
@@ -884,6 +914,16 @@ inline dim3 grid2(int w, int h, int z = 1) { return dim3((unsigned)((w + 255) / 
 
 }  // namespace
 
+#ifdef OSFM_DBG_PHASES
+extern "C" int osfm_dbg_hahog_phases(unsigned long long *out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hphase), sizeof(g_hphase)) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_hphase), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif
 extern "C" int osfm_hahog_extract(osfm_ctx *ctx, const float *image, int rows, int cols, float peak_threshold, float edge_threshold,
                                   int target_num_features, int flags, float *points, float *desc, int capacity, int *n_features) {
   OSFM_REQUIRE(ctx && image && n_features, OSFM_E_INVALID, "osfm_hahog_extract: null argument");

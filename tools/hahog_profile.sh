@@ -1,13 +1,10 @@
 #!/bin/bash
-OUT=/root/repo/gpurun_out/r03_c30
+# One gpurun call: HAHOG parity tests, the bench workload with the compiled reference beside it, and a kernel trace of the same
+# function summarised per (kernel, grid).  Outputs under gpurun_out/hahog/ (scratch).
+OUT=${OUT:-/root/repo/gpurun_out/hahog}
 mkdir -p $OUT
 cd /root/repo
 timeout 300 python -m pytest tests/test_gpu_hahog.py -q -x > $OUT/pytest.log 2>&1; tail -5 $OUT/pytest.log
-if ! grep -q " passed" $OUT/pytest.log || grep -q "failed" $OUT/pytest.log; then
-  for v in PLAIN_DE PLAIN_OR; do
-    OSFM_MI355_LIB=/root/repo/tools/libosfm_hahog_$v.so timeout 300 python -m pytest tests/test_gpu_hahog.py -q -x > $OUT/pytest_$v.log 2>&1; echo "== $v"; tail -5 $OUT/pytest_$v.log
-  done
-fi
 timeout 300 python - > $OUT/hahog_bench.json 2> $OUT/hahog_bench.err <<'PY'
 import json, sys
 sys.path.insert(0, '.')
