@@ -62,10 +62,22 @@ def parse():
     ap.add_argument("--no-hahog", action="store_true", help="skip the HAHOG extraction workload")
     ap.add_argument("--full-parity", action="store_true", help="check EVERY pair with matches + 5000 empties against the oracle (~1.5 min)")
     ap.add_argument("--headline-only", action="store_true", help="only the headline workload + its cpu_baseline (configs[3] runs)")
+    ap.add_argument("--all-sections", action="store_true", help="N > 1: also run the one-GPU secondary workloads and CPU baselines on rank 0")
     a = ap.parse_args()
     if a.headline_only:
         a.no_ba = a.no_tracks = a.no_overlap = a.no_calibrated = a.no_float = a.no_guided = a.no_hahog = True
     return a
+
+
+def headline_only_for_ranks(args, world: int) -> bool:
+    """N > 1: the line is the sharded headline workload only.  The secondary workloads and the CPU baselines are one-GPU / host
+    measurements (reported at N = 1, as the bench contract asks for cpu_baseline); repeating them on rank 0 would keep the other
+    ranks in the closing barrier for minutes.  Returns True when it switched them off."""
+    if world <= 1 or getattr(args, "all_sections", False):
+        return False
+    for flag in ("no_overlap", "no_calibrated", "no_float", "no_guided", "no_cpu_baseline", "no_tracks", "no_hahog", "no_ba"):
+        setattr(args, flag, True)
+    return True
 
 
 def self_launch(args) -> int:
@@ -251,6 +263,8 @@ def main():
 
                 out[name] = {"error": f"{type(exc).__name__}: {exc}", "traceback": traceback.format_exc()[-1500:]}
 
+        if headline_only_for_ranks(args, world):
+            out["note"] = "secondary workloads and cpu_baseline are measured at N = 1 (python bench.py); --all-sections repeats them on rank 0"
         if not args.no_overlap:
             section("overlap_workload", overlap_bench, args, ctx, store, scene, n_images, not args.no_cpu_baseline)
         if not args.no_calibrated:

@@ -206,3 +206,20 @@ def test_bench_gpus_flag_launches_ranks_and_never_mislabels(monkeypatch):
 
     with pytest.raises(AssertionError, match="--gpus 4 but WORLD_SIZE=2"):
         bench.main()
+
+
+def test_bench_line_at_n_above_one_is_the_headline_workload_only():
+    """the secondary workloads and the CPU baselines are one-GPU / host measurements: reported at N = 1, skipped on rank 0 at N > 1"""
+    import importlib
+    import os
+    import sys
+    import types
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    bench = importlib.import_module("bench")
+    flags = ("no_overlap", "no_calibrated", "no_float", "no_guided", "no_cpu_baseline", "no_tracks", "no_hahog", "no_ba")
+    a = types.SimpleNamespace(all_sections=False, **{f: False for f in flags})
+    assert not bench.headline_only_for_ranks(a, 1) and not any(getattr(a, f) for f in flags)
+    assert bench.headline_only_for_ranks(a, 8) and all(getattr(a, f) for f in flags)
+    b = types.SimpleNamespace(all_sections=True, **{f: False for f in flags})
+    assert not bench.headline_only_for_ranks(b, 8) and not any(getattr(b, f) for f in flags)
