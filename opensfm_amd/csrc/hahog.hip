@@ -802,13 +802,13 @@ __global__ void __launch_bounds__(256) descriptor_kernel(Pyramid py, Oriented R,
     atomicMax(&chi[1][px_], biny);
   }
   __syncthreads();
-  // bin (bx, by, bt) adds, in raster order, what the sequential loop adds to it.  Branch-free and with unconditional loads (two per
-  // pixel), so that the 961 steps pipeline: a pixel that does not feed the bin adds +0.0f, which leaves a sum of non-negative terms
-  // unchanged; a pixel feeds a bin through at most one of its two orientation bins
   HTICK(h3)
-  // A pixel feeds bin (bx, by, .) only with binx in {bx - 1, bx} and biny in {by - 1, by}: the lane walks, in raster order, only the rows
-  // and the columns whose measured ranges of binx and biny admit that (a superset for any patch rotation; ~13 x 13 of the 31 x 31
-  // pixels), the rest as before.  (All 961 pixels per bin: 130 of the kernel's 166 us per workgroup, r03_hahog_phases_before_sort.txt.)
+  // Bin (bx, by, bt) adds, in raster order, what the sequential loop adds to it.  A pixel feeds bin (bx, by, .) only with binx in
+  // {bx - 1, bx} and biny in {by - 1, by}: the lane walks, in raster order, only the rows and the columns whose measured ranges of binx
+  // and biny admit that (a superset for any patch rotation; ~13 x 13 of the 31 x 31 pixels).  Inside the walk everything is branch-free
+  // with unconditional loads (two per pixel), so that the steps pipeline: a pixel that does not feed the bin adds +0.0f, which leaves a
+  // sum of non-negative terms unchanged; a pixel feeds a bin through at most one of its two orientation bins.  (All 961 pixels per bin
+  // were 130 of the kernel's 166 us per workgroup, profiles/r03_hahog_phases_before_sort.txt.)
   if (tid < kNBO * kNBP * kNBP) {
     const int bt = tid % kNBO, bx = (tid / kNBO) % kNBP - kNBP / 2, by = tid / (kNBO * kNBP) - kNBP / 2;
     unsigned rowmask = 0, colmask = 0;
