@@ -251,8 +251,12 @@ def project_perspective(X: np.ndarray, pose: np.ndarray, cam: np.ndarray, model:
 def make_ba_scene(n_shots: int, n_points: int, track_len: int = 10, seed: int = 42, outlier_frac: float = 0.05,
                   px_noise: float = 1.0 / 2000.0, pose_noise_t: float = 0.05, pose_noise_r: float = 0.01,
                   point_noise: float = 0.05, gps_sigma: float = 5.0, use_gps: bool = True, model: str = "perspective",
-                  generic_params=None) -> dict:
+                  generic_params=None, ragged: bool = False) -> dict:
     """Street scene with `n_points` tracks of length `track_len` over `n_shots` cameras.
+
+    ``ragged``: tracks as a feature tracker leaves them instead of identical windows -- lengths 2 + Poisson(track_len - 2) (mean
+    `track_len`, up to ~2.5 x that), 15 % of the sightings inside a window missing (never below two per point).  No two points need
+    share a shot set any more, and the co-visibility half-width is the longest track, not `track_len` - 1.
 
     Returns the flat problem dict consumed by ``bundle_arrays`` / ``oracle.ba_solve``; ground truth
     under the ``gt_*`` keys.  Camera = shared perspective [k1, k2, focal] = [-0.1, 0.01, 0.7]
@@ -271,6 +275,19 @@ def make_ba_scene(n_shots: int, n_points: int, track_len: int = 10, seed: int = 
                        rng.uniform(4.0, 12.0, n_points)], axis=1)
     obs_point = np.repeat(np.arange(n_points, dtype=np.int32), L)
     obs_shot = (first[:, None] + np.arange(L)[None, :]).reshape(-1).astype(np.int32)
+    if ragged:
+        rr = np.random.default_rng(seed + 7919)  # its own stream: the plain scene of the same seed stays what it was
+        length = np.clip(2 + rr.poisson(max(L - 2, 0), n_points), 2, n_shots)
+        first = rr.integers(0, n_shots - length + 1)
+        centre = (first + (length - 1) / 2.0) * step
+        gt_pts[:, 0] = centre + rr.uniform(-0.4, 0.4, n_points)
+        obs_point = np.repeat(np.arange(n_points, dtype=np.int32), length)
+        within = np.arange(int(length.sum())) - np.repeat(np.cumsum(length) - length, length)
+        obs_shot = (np.repeat(first, length) + within).astype(np.int32)
+        keep = rr.random(len(obs_shot)) >= 0.15
+        keep[np.cumsum(length) - length] = True  # the first two sightings of every track stay
+        keep[np.cumsum(length) - length + 1] = True
+        obs_point, obs_shot = obs_point[keep], obs_shot[keep]
     order = np.lexsort((obs_point, obs_shot))  # shot-major like BAHelpers::Bundle's loops (ba_helpers.cc:685-699)
     obs_shot, obs_point = obs_shot[order], obs_point[order]
     xy = np.empty((len(obs_shot), 2))

@@ -201,3 +201,22 @@ def test_parallel_schur_elimination_reproduces_the_serial_one(oracle_lib):
         assert np.allclose(r["cost_history"], runs[0]["cost_history"], rtol=1e-13)  # the cost itself is an OpenMP reduction
     assert np.allclose(serial["cost_history"], runs[0]["cost_history"], rtol=1e-11)
     assert np.abs(serial["points"] - runs[0]["points"]).max() < 1e-9 and np.abs(serial["shot_pose"] - runs[0]["shot_pose"]).max() < 1e-9
+
+
+def test_ragged_tracks_scene(oracle_lib):
+    """make_ba_scene(ragged=True): track lengths 2 + Poisson, sightings missing inside a window -- the shape a feature tracker leaves.
+    The plain scene of the same seed is untouched, every point keeps two sightings, shot sets are no longer shared, and the oracle
+    converges on it as on the plain one."""
+    from opensfm_amd import synthetic
+
+    plain = synthetic.make_ba_scene(40, 900, 6, seed=3)
+    again = synthetic.make_ba_scene(40, 900, 6, seed=3)
+    assert all(np.array_equal(plain[k], again[k]) for k in plain)
+    pr = synthetic.make_ba_scene(40, 900, 6, seed=3, ragged=True)
+    n = np.bincount(pr["obs_point"], minlength=900)
+    assert n.min() >= 2 and n.max() > 6 and abs(n.mean() - 0.85 * 6) < 1.0
+    assert (np.diff(pr["obs_shot"]) >= 0).all()  # shot-major
+    sets = {pr["obs_shot"][pr["obs_point"] == p].tobytes() for p in range(900)}
+    assert len(sets) > 300  # the plain scene has at most 35 (one per window start)
+    r = oracle_lib.ba_solve(pr, max_iterations=30)
+    assert r["final_cost"] < 0.2 * r["initial_cost"]
