@@ -1,0 +1,101 @@
+"""Compile-time budgets of the hot kernels, checked without a GPU: hipcc cross-compiles gfx950 here, `-Rpass-analysis=kernel-resource-usage`
+reports registers / scratch / occupancy per kernel, and the device assembly shows whether a gather was issued in one piece.  These are
+the properties the measured numbers rest on; a change that silently spills the matcher's sweep, drops its
+occupancy, or lets the compiler serialise the re-examination's loads again (round 3: ten memory round trips per step instead of one,
+profiles/r03_match_phases_before.txt) fails here instead of showing up as a slower bench line."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "opensfm_amd", "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S", "--cuda-device-only",
+         "-Rpass-analysis=kernel-resource-usage"]  # the product's flags (csrc/build.sh) + assembly + remarks
+
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+
+
+def compile_device(name, tmp_path_factory, cache={}):
+    """(assembly text, {mangled kernel name: {field: int}}) of csrc/<name>.hip"""
+    if name in cache:
+        return cache[name]
+    out = tmp_path_factory.mktemp("isa") / (name + ".s")
+    r = subprocess.run([HIPCC, *FLAGS, os.path.join(CSRC, name + ".hip"), "-o", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    kernels, cur = {}, None
+    for line in r.stderr.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            cur = kernels.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+(VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|VGPRs Spill|SGPRs Spill|LDS Size \[bytes/block\]): (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1).split(" [")[0]] = int(m.group(2))
+    cache[name] = (out.read_text(), kernels)
+    return cache[name]
+
+
+def one(kernels, *parts):
+    hits = [k for k in kernels if all(p in k for p in parts)]
+    assert len(hits) == 1, (parts, hits)
+    return kernels[hits[0]], hits[0]
+
+
+def body(asm, mangled):
+    a = asm.index("\n" + mangled + ":")
+    return asm[a: asm.index("s_endpgm", a)]
+
+
+def test_matcher_sweep_keeps_its_registers_and_two_workgroups_per_cu(tmp_path_factory):
+    asm, k = compile_device("match", tmp_path_factory)
+    for fq in ("ILb0E", "ILb1E"):  # integer store / float store (FQ)
+        r, name = one(k, "match_fused_kernel", fq)
+        assert r["Occupancy"] == 2 and r["AGPRs"] == 0  # __launch_bounds__(256, 2): two workgroups of 78 KiB LDS per CU
+        assert r["ScratchSize"] <= 128 and r["VGPRs Spill"] <= 32, r  # a handful of values parked around the chunk boundary, nothing more
+        text = body(asm, name)
+        # no scratch traffic and no full wait inside a basic block that issues MFMAs (the sweep)
+        for block in re.split(r"\n\.LBB\d+_\d+:", text):
+            if "v_mfma_i32_32x32x32_i8" in block:
+                assert "scratch_" not in block
+        assert text.count("v_mfma_i32_32x32x32_i8") >= 2 * 64  # two instantiations of the 64-MFMA step (plain / gathered queries)
+
+
+def test_reexamination_issues_its_gather_in_one_piece(tmp_path_factory):
+    """the class re-examination: 8 query slices + 2 x 8 target slices + 2 norms per lane, all in flight before the first dot product"""
+    asm, k = compile_device("match", tmp_path_factory)
+    _, name = one(k, "match_fused_kernel", "ILb0E")
+    lines = [ln.strip() for ln in body(asm, name).splitlines() if ln.strip() and not ln.strip().startswith(";")]
+    dots = [i for i, ln in enumerate(lines) if ln.startswith("v_dot4")]
+    # the first long run of dot products is the re-examination of pass A (64 per step)
+    start = next(i for i in dots if sum(1 for j in dots if i <= j < i + 90) >= 60)
+    window = lines[max(0, start - 110): start]
+    loads = [i for i, ln in enumerate(window) if ln.startswith("global_load_dwordx4")]
+    assert len(loads) >= 24, len(loads)
+    between = window[loads[0]: loads[-1]]
+    assert not any(ln.startswith("s_waitcnt vmcnt(0)") for ln in between)  # was: one full wait per query slice
+    assert not any(ln.startswith("s_cbranch") for ln in between)            # and a branch around every target load
+
+
+def test_ba_streaming_kernels_do_not_spill(tmp_path_factory):
+    _, k = compile_device("ba", tmp_path_factory)
+    for parts in (("schur_point_coop_kernel", "ILi0E"), ("schur_shot_kernel",), ("eval_kernel", "ILb1ELb0E"), ("eval_kernel", "ILb1ELb1E"),
+                  ("band_assemble_kernel",), ("border_point_kernel", "ILi3E"), ("border_shot_kernel", "ILi3E"), ("point_grad_kernel",),
+                  ("shot_grad_kernel",), ("bcr_level_kernel", "ILi9E"), ("wide_factor_kernel",), ("wide_push_kernel", "ILi1ELb0E")):
+        r, name = one(k, *parts)
+        assert r["ScratchSize"] == 0 and r["VGPRs Spill"] == 0, (name, r)
+    r, _ = one(k, "schur_point_coop_kernel", "ILi0E")
+    assert r["Occupancy"] >= 4  # the mat-vec is a streaming kernel: it needs the waves to cover HBM latency
+    r, _ = one(k, "bcr_level_kernel", "ILi9E")
+    assert r["LDS Size"] <= 160 * 1024
+
+
+def test_hahog_per_feature_kernels(tmp_path_factory):
+    _, k = compile_device("hahog", tmp_path_factory)
+    r, _ = one(k, "orientation_kernel")
+    assert r["ScratchSize"] == 0 and r["LDS Size"] <= 52 * 1024  # three workgroups per CU
+    r, _ = one(k, "descriptor_kernel")
+    assert r["ScratchSize"] == 0 and r["LDS Size"] <= 26 * 1024  # six
