@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--full-parity", action="store_true", help="check EVERY pair with matches + 5000 empties against the oracle (~1.5 min)")
     ap.add_argument("--headline-only", action="store_true", help="only the headline workload + its cpu_baseline (configs[3] runs)")
     ap.add_argument("--all-sections", action="store_true", help="N > 1: also run the one-GPU secondary workloads and CPU baselines on rank 0")
+    ap.add_argument("--emulate-world", type=int, default=8, help="N = 1: size of the emulated exchange step (exchange_emulation section; 0 = skip)")
     a = ap.parse_args()
     if a.headline_only:
         a.no_ba = a.no_tracks = a.no_overlap = a.no_calibrated = a.no_float = a.no_guided = a.no_hahog = True
@@ -101,6 +102,8 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
+    # dmabuf IPC only on this driver: RCCL needs it in EVERY rank, also when the driver's torch.distributed.run started them
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -143,7 +146,11 @@ def main():
         # gathered order: no host-side scatter of the match rows inside the timed region
         g = matching.match_pairs(store, my_pairs, robust=robust, timings=tm, keep_device=True)
         try:
-            return odist.all_gather_match_graph_device(g, len(pairs_all), rank, world, local_rank, reorder=False)
+            xt = {}
+            res = odist.all_gather_match_graph_device(g, len(pairs_all), rank, world, local_rank, reorder=False, timings=xt)
+            if tm is not None:
+                exchange_tms.append(xt)
+            return res
         finally:
             g.close()
 
@@ -152,6 +159,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    exchange_tms = []
     for _ in range(args.warmup):
         step()
     tms = []
@@ -252,6 +260,12 @@ def main():
         },
         "setup_s": round(t_setup, 2),
     }
+    if exchange_tms:  # N > 1: this rank's exchange step, inside the timed region
+        ex = {k: round(float(np.mean([x[k] for x in exchange_tms])), 3) for k in ("collective_ms", "layout_ms", "d2h_ms")}
+        ex["ms_per_step"] = round(sum(ex.values()), 3)
+        ex["share_of_step"] = round(ex["ms_per_step"] / (1e3 * elapsed / args.steps), 4)
+        ex["bytes_to_host"] = int(exchange_tms[-1]["bytes_to_host"])
+        out["exchange"] = ex
 
     if rank == 0:
         def section(name, fn, *a):
@@ -265,6 +279,8 @@ def main():
 
         if headline_only_for_ranks(args, world):
             out["note"] = "secondary workloads and cpu_baseline are measured at N = 1 (python bench.py); --all-sections repeats them on rank 0"
+        if world == 1 and args.emulate_world > 1 and not args.headline_only:
+            section("exchange_emulation", exchange_emulation, args, store, my_pairs, local_rank, robust, out["ms_per_step"])
         if not args.no_overlap:
             section("overlap_workload", overlap_bench, args, ctx, store, scene, n_images, not args.no_cpu_baseline)
         if not args.no_calibrated:
@@ -290,6 +306,62 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def exchange_emulation(args, store, my_pairs, local_rank, robust, ms_per_step_n1, reps: int = 5):
+    """What the exchange step of an E-rank job costs each rank beyond the collective's wire time, measured on ONE GPU: a one-rank RCCL
+    group runs the very function the N-rank step calls (dist.all_gather_match_graph_device), with the receive buffers filled with E
+    copies of this rank's payload (emulate_world), so the device-side layout and the D2H of the gathered graph run at the E-rank size.
+    The xGMI transfer itself is replaced by D2D copies; its size is reported next to the link rate."""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    from opensfm_amd import dist as odist
+    from opensfm_amd import matching
+
+    E = int(args.emulate_world)
+    own_group = not dist.is_initialized()
+    if own_group:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+    try:
+        n = len(my_pairs)
+        t0 = time.perf_counter()
+        g = matching.match_pairs(store, my_pairs, robust=robust, keep_device=True)
+        match_ms = 1e3 * (time.perf_counter() - t0)
+        res = {}
+        try:
+            for reorder in (False, True):
+                odist.all_gather_match_graph_device(g, E * n, 0, 1, local_rank, block=n, reorder=reorder, emulate_world=E)  # warm-up: allocator caches
+                acc = []
+                for _ in range(reps):
+                    xt = {}
+                    t0 = time.perf_counter()
+                    c, m = odist.all_gather_match_graph_device(g, E * n, 0, 1, local_rank, block=n, reorder=reorder, emulate_world=E, timings=xt)
+                    xt["call_ms"] = 1e3 * (time.perf_counter() - t0)
+                    acc.append(xt)
+                    ok = len(c) == E * n and len(m) == E * g.total and np.array_equal(c[:n], g.counts) and np.array_equal(c[-n:], g.counts)
+                    del c, m
+                r = {k: round(float(np.mean([x[k] for x in acc])), 3) for k in ("call_ms", "collective_ms", "layout_ms", "d2h_ms")}
+                r["share_of_step"] = round(r["call_ms"] / (match_ms + r["call_ms"]), 4)
+                r["layout_checked"] = bool(ok)
+                res["rank_major" if not reorder else "original_pair_order"] = r
+        finally:
+            g.close()
+        to_host = 4 * E * n + 8 * E * g.total
+        return {"emulated_ranks": E, "pairs_per_rank": int(n), "match_rows_per_rank": int(g.total), "bytes_to_host_per_rank": int(to_host),
+                "bytes_over_xgmi_per_rank": int(to_host * (E - 1) // E), "xgmi_link_GBps": 153.0,
+                "est_wire_ms_one_link": round(to_host * (E - 1) / E / 153e9 * 1e3, 3),
+                "match_ms_keep_device": round(match_ms, 3), "ms_per_step_n1": ms_per_step_n1, **res,
+                "note": "bench.py's N-rank step uses the rank-major layout; share_of_step = exchange / (shard matching + exchange); the "
+                        "collective's wire time (est_wire_ms_one_link: ring all-gather bound by one 153 GB/s link) is NOT in the measured figure"}
+    finally:
+        if own_group:
+            dist.destroy_process_group()
 
 
 def hahog_bench(ctx, with_cpu, rows: int = 1536, cols: int = 2048, target: int = 10000, reps: int = 5):

@@ -104,42 +104,116 @@ def _assemble(allc: np.ndarray, allm: np.ndarray, idx, totals, n_pairs: int, wor
     return counts_g, matches_g
 
 
+@lru_cache(maxsize=8)
+def _gather_plan(n_pairs: int, world: int, block: int, dev_str: str):
+    """For the original-pair-order result: ``slot[p]`` = position of pair p in the gathered (world, maxn) count buffer, as a tensor on
+    the exchange device (built once per pair-list shape: n_pairs int64)."""
+    import torch
+
+    idx = _all_shards(n_pairs, world, block)
+    maxn = max(1, max(len(i) for i in idx))
+    slot = np.empty(n_pairs, np.int64)
+    for r in range(world):
+        slot[idx[r]] = r * maxn + np.arange(len(idx[r]), dtype=np.int64)
+    return torch.from_numpy(slot).to(torch.device(dev_str))
+
+
+def _host_result(n: int, dtype, on_gpu: bool):
+    """a fresh host tensor for a result of the exchange step: page-locked on a GPU box (torch's caching host allocator hands the block of
+    the previous step back once its numpy view is gone, so steady-state steps do not pay for hipHostMalloc); never shared between calls"""
+    import torch
+
+    return torch.empty(max(n, 1), dtype=dtype, pin_memory=on_gpu)
+
+
 def all_gather_match_graph_device(graph, n_pairs: int, rank: int, world: int, local_rank: Optional[int] = None, block: int = BLOCK,
-                                  reorder: bool = True, force_collective: bool = False) -> Tuple[np.ndarray, np.ndarray]:
+                                  reorder: bool = True, force_collective: bool = False, emulate_world: int = 0,
+                                  timings: Optional[dict] = None) -> Tuple[np.ndarray, np.ndarray]:
     """The exchange step straight from HBM: ``graph`` is the ``DeviceMatchGraph`` of this rank's shard
-    (``matching.match_pairs(..., keep_device=True)``).  The counts and the match rows are all-gathered (RCCL,
-    ``all_gather_into_tensor``) from the buffers the kernels wrote -- no D2H / H2D hop of the shard -- and the gathered graph comes
-    to the host once, into page-locked memory.  Same return value as ``all_gather_match_graph``.  RCCL only (the gloo tests go
-    through the host variant)."""
-    if world == 1 and not force_collective:
+    (``matching.match_pairs(..., keep_device=True)``).  The counts and the match rows are all-gathered
+    (``all_gather_into_tensor``: RCCL over xGMI between the buffers the kernels wrote -- no D2H / H2D hop of the shard), the global
+    graph is put into its FINAL layout on the device (rank-major: a compaction of the padded rows; original pair order: one gather
+    through a cached permutation) and comes to the host with one copy per array into page-locked memory -- the host does no
+    per-row work.  Same return value as ``all_gather_match_graph``.
+
+    The body does not depend on the backend: under gloo (the world-size-2 CPU test) ``graph`` hands out CPU tensors and the same
+    lines run.  ``emulate_world = E`` (one rank only, measurement): after the real one-rank collective the receive buffers are filled
+    with E copies of this rank's payload, so everything downstream of the collective -- compaction, D2H -- runs at the size an
+    E-rank job has; ``n_pairs`` is then the E-rank list's length and ``graph`` holds rank 0's shard of it.  ``timings`` receives
+    ``collective_ms``, ``layout_ms``, ``d2h_ms`` and ``bytes_to_host``."""
+    if world == 1 and not force_collective and not emulate_world:
         return graph.fetch()
+    import time
+
     import torch
     import torch.distributed as dist
 
-    dev = torch.device("cuda", local_rank if local_rank is not None else rank)
-    idx = _all_shards(n_pairs, world, block) if world > 1 else [np.arange(n_pairs, dtype=np.int64)]
-    maxn = max(1, max(len(i) for i in idx))
-    assert graph.n_pairs == len(idx[rank]), (graph.n_pairs, len(idx[rank]))
+    assert not emulate_world or world == 1, "emulate_world is a one-rank measurement"
+    on_gpu = dist.get_backend() == "nccl"
+    dev = torch.device("cuda", local_rank if local_rank is not None else rank) if on_gpu else torch.device("cpu")
+    W = emulate_world or world  # ranks the layout is built for
+
+    def sync():
+        if on_gpu:
+            torch.cuda.current_stream(dev).synchronize()
+
+    t0 = time.perf_counter()
+    idx = _all_shards(n_pairs, W, block) if W > 1 else [np.arange(n_pairs, dtype=np.int64)]
+    lens = [len(i) for i in idx]
+    maxn = max(1, max(lens))
+    assert graph.n_pairs == lens[rank], (graph.n_pairs, lens[rank])
     # counts: shards differ by at most one block, so the send buffer is the device counts padded with zeros
     send = torch.zeros(maxn, dtype=torch.int32, device=dev)
     send[: graph.n_pairs].copy_(graph.counts_tensor())
     recv = torch.empty(world * maxn, dtype=torch.int32, device=dev)
     dist.all_gather_into_tensor(recv, send)
-    allc = _pinned("counts_out", world * maxn, torch.int32)
-    allc.copy_(recv, non_blocking=True)
-    torch.cuda.current_stream(dev).synchronize()
-    allc = allc.numpy().reshape(world, maxn).copy()
-    totals = [int(allc[r][: len(idx[r])].sum()) for r in range(world)]
+    if emulate_world:
+        recv = recv.repeat(W)
+    recv2 = recv.view(W, maxn)
+    # per-rank totals (rows past a shard's length are padding): the one value the host needs before it can size the second collective
+    valid = torch.arange(maxn, device=dev)[None, :] < torch.tensor(lens, device=dev)[:, None]
+    totals = [int(v) for v in (recv2 * valid).sum(1, dtype=torch.int64).tolist()]
     assert totals[rank] == graph.total, (totals[rank], graph.total)
     maxm = max(1, max(totals))
     sendm = torch.empty(2 * maxm, dtype=torch.int32, device=dev)
     sendm[: 2 * graph.total].copy_(graph.matches_tensor())  # D2D; the tail is never read
     recvm = torch.empty(world * 2 * maxm, dtype=torch.int32, device=dev)
     dist.all_gather_into_tensor(recvm, sendm)
-    allm = _pinned("matches_out", world * 2 * maxm, torch.int32)
-    allm.copy_(recvm, non_blocking=True)
-    torch.cuda.current_stream(dev).synchronize()
-    return _assemble(allc, allm.numpy().reshape(world, 2 * maxm), idx, totals, n_pairs, world, reorder)
+    if emulate_world:
+        recvm = recvm.repeat(W)
+    sync()
+    t1 = time.perf_counter()
+    # ---- final layout on the device ----
+    total = int(sum(totals))
+    rows = recvm.view(W, maxm, 2)
+    if not reorder:
+        counts_d = torch.cat([recv2[r, : lens[r]] for r in range(W)]) if W > 1 else recv2[0, : lens[0]]
+        matches_d = torch.cat([rows[r, : totals[r]] for r in range(W)]) if W > 1 else rows[0, : totals[0]]
+    else:
+        slot = _gather_plan(n_pairs, W, block, str(dev)) if W > 1 else torch.arange(n_pairs, device=dev)
+        counts_d = recv[slot]  # counts in the original pair order
+        c64 = counts_d.to(torch.int64)
+        # first row of every pair inside its rank's padded block: the exclusive scan of the rank's own counts
+        rscan = torch.cumsum(recv2.to(torch.int64), 1) - recv2
+        src0 = (rscan + (torch.arange(W, device=dev) * maxm)[:, None]).view(-1)[slot]
+        goff = torch.cumsum(c64, 0) - c64
+        # row d of the result belongs to pair p(d); it is row src0[p] + (d - goff[p]) of the padded buffer
+        pair_of_row = torch.repeat_interleave(torch.arange(n_pairs, device=dev), c64, output_size=total)
+        src = (src0 - goff)[pair_of_row] + torch.arange(total, device=dev)
+        matches_d = rows.view(-1, 2)[src]
+    sync()
+    t2 = time.perf_counter()
+    # ---- one D2H per array, into page-locked memory ----
+    counts_h = _host_result(n_pairs, torch.int32, on_gpu)
+    matches_h = _host_result(2 * total, torch.int32, on_gpu)
+    counts_h[:n_pairs].copy_(counts_d.reshape(-1), non_blocking=on_gpu)
+    matches_h[: 2 * total].copy_(matches_d.reshape(-1), non_blocking=on_gpu)
+    sync()
+    t3 = time.perf_counter()
+    if timings is not None:
+        timings.update(collective_ms=1e3 * (t1 - t0), layout_ms=1e3 * (t2 - t1), d2h_ms=1e3 * (t3 - t2),
+                       bytes_to_host=4 * n_pairs + 8 * total, ranks=W)
+    return counts_h.numpy()[:n_pairs], matches_h.numpy()[: 2 * total].reshape(-1, 2)
 
 
 def all_gather_match_graph(counts: np.ndarray, matches: np.ndarray, n_pairs: int, rank: int, world: int,

@@ -63,9 +63,21 @@ def main():
                 else:
                     assert np.array_equal(cg, counts[order]) and np.array_equal(mg, want_rank_major)
                 assert np.array_equal(cd, cg) and np.array_equal(md, mg)
+        if world == 1:
+            # the one-GPU measurement mode of bench.py (exchange_emulation): E copies of this rank's payload downstream of the collective
+            g = matching.match_pairs(store, pairs, keep_device=True)
+            for reorder in (False, True):
+                tm = {}
+                ce, me = odist.all_gather_match_graph_device(g, 3 * len(pairs), 0, 1, local_rank, block=len(pairs), reorder=reorder,
+                                                             emulate_world=3, timings=tm)
+                assert np.array_equal(ce, np.tile(counts, 3)) and np.array_equal(me, np.tile(m, (3, 1))) and tm["ranks"] == 3
+            g.close()
         # an empty shard and an all-empty result go through the device path too
         g = matching.match_pairs(store, pairs[:0], keep_device=True)
         assert g.total == 0 and g.n_pairs == 0
+        if world == 1:
+            ce, me = odist.all_gather_match_graph_device(g, 0, 0, 1, local_rank, force_collective=True)
+            assert len(ce) == 0 and me.shape == (0, 2)
         g.close()
         t = torch.ones(1, device="cuda")
         dist.all_reduce(t)
