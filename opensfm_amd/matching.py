@@ -434,6 +434,9 @@ class DeviceMatchGraph:
         """a torch view (no copy) of n int32 at a device address, through __cuda_array_interface__"""
         import torch
 
+        if n == 0 or not ptr:
+            return torch.empty(0, dtype=torch.int32, device=torch.device("cuda", self.device))
+
         class _Buf:
             pass
 
