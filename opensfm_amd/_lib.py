@@ -75,6 +75,7 @@ SIGNATURES = {
     "osfm_ctx_destroy": (None, [C.c_void_p]),
     "osfm_ctx_device": (C.c_int, [C.c_void_p]),
     "osfm_ctx_num_cus": (C.c_int, [C.c_void_p]),
+    "osfm_ctx_trim_pool": (C.c_int64, [C.c_void_p]),
     "osfm_tracks_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int64, C.POINTER(C.c_int64),
                                      C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "osfm_tracks_num_tracks": (C.c_int64, [C.c_void_p]),

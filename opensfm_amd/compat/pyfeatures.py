@@ -1,5 +1,7 @@
 """``pyfeatures`` (opensfm/src/features/python/pybind.cc:55-63): ``hahog``, ``match_using_words``, ``compute_vlad_descriptor``,
-``compute_vlad_distances`` with the reference's arguments and return values."""
+``compute_vlad_distances`` with the reference's arguments and return values.  ``match_using_words`` is a functional shim: every call
+uploads both images into a resident ``WordsStore`` and tears it down again; batch users go through ``matching.match_images_with_pairs``
+(``matcher_type: WORDS``), which keeps the store resident over the whole pair list."""
 from typing import Dict, List, Tuple
 
 import numpy as np
@@ -16,6 +18,8 @@ def hahog(image, peak_threshold: float = 0.003, edge_threshold: float = 10, targ
 def match_using_words(features1, words1, features2, words2, lowes_ratio: float, max_checks: int):
     """features::match_using_words (matching.cc:73-88): (m, 2) int array of (index in features1, index in features2)"""
     f1, f2 = np.asarray(features1, np.float32), np.asarray(features2, np.float32)
+    if len(f1) == 0 or len(f2) == 0:  # masked features can leave an image empty (matching.match_words): no matches, as the reference
+        return np.zeros((0, 2), np.int32)
     # the queries (image 1) come with their n closest words, the indexed image with ONE word per feature (matching.py:637-656 passes
     # words2[:, 0]); the resident store keeps one width per call and indexes an image by its features' first word
     w1 = np.asarray(words1).reshape(len(f1), -1)

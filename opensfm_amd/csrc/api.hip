@@ -8,8 +8,10 @@
 #include "osfm_internal.h"
 
 static thread_local char g_err[1024] = "";
+thread_local unsigned osfm_error_epoch = 0;
 
 void osfm_set_error(const char *fmt, ...) {
+  ++osfm_error_epoch;
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
@@ -52,6 +54,27 @@ extern "C" void osfm_ctx_destroy(osfm_ctx *c) {
   delete c;
 }
 
+extern "C" int64_t osfm_ctx_trim_pool(osfm_ctx *c) {
+  if (!c) return 0;
+  OSFM_CTX_LOCK(c);
+  (void)hipSetDevice(c->device);
+  if (!c->pool.empty()) (void)hipDeviceSynchronize();
+  const int64_t freed = (int64_t)c->pool_bytes;
+  for (auto &b : c->pool) (void)hipFree(b.p);
+  c->pool.clear();
+  c->pool_bytes = 0;
+  return freed;
+}
+
+hipError_t osfm_malloc_retry(osfm_ctx *ctx, void **p, size_t bytes) {
+  hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+  if (e != hipSuccess && ctx && osfm_ctx_trim_pool(ctx) > 0) {
+    (void)hipGetLastError();
+    e = hipMalloc(p, bytes ? bytes : 16);
+  }
+  return e;
+}
+
 extern "C" int osfm_ctx_device(const osfm_ctx *c) { return c ? c->device : -1; }
 extern "C" int osfm_ctx_num_cus(const osfm_ctx *c) { return c ? c->num_cus : 0; }
 
@@ -86,12 +109,12 @@ extern "C" int osfm_store_create(osfm_ctx *ctx, int n_images, const int32_t *cou
   const int64_t nt = s->tile_off[n_images] + 4;  // +4 tiles of slack: chunk loads never run off the end
   hipError_t e;
   bool ok = true;
-  ok = ok && (e = hipMalloc((void **)&s->d_tiles, (size_t)nt * OSFM_TILE_BYTES)) == hipSuccess;
-  ok = ok && (e = hipMalloc((void **)&s->d_norms, (size_t)nt * 32 * sizeof(int32_t))) == hipSuccess;
-  ok = ok && (e = hipMalloc((void **)&s->d_hneg, (size_t)nt * 32 * sizeof(int32_t))) == hipSuccess;
-  ok = ok && (e = hipMalloc((void **)&s->d_pts, (size_t)nt * 32 * 2 * sizeof(double))) == hipSuccess;
-  ok = ok && (e = hipMalloc((void **)&s->d_counts, (size_t)(n_images + 1) * sizeof(int32_t))) == hipSuccess;
-  ok = ok && (e = hipMalloc((void **)&s->d_tile_off, (size_t)(n_images + 1) * sizeof(int64_t))) == hipSuccess;
+  ok = ok && (e = osfm_malloc_retry(ctx, (void **)&s->d_tiles, (size_t)nt * OSFM_TILE_BYTES)) == hipSuccess;
+  ok = ok && (e = osfm_malloc_retry(ctx, (void **)&s->d_norms, (size_t)nt * 32 * sizeof(int32_t))) == hipSuccess;
+  ok = ok && (e = osfm_malloc_retry(ctx, (void **)&s->d_hneg, (size_t)nt * 32 * sizeof(int32_t))) == hipSuccess;
+  ok = ok && (e = osfm_malloc_retry(ctx, (void **)&s->d_pts, (size_t)nt * 32 * 2 * sizeof(double))) == hipSuccess;
+  ok = ok && (e = osfm_malloc_retry(ctx, (void **)&s->d_counts, (size_t)(n_images + 1) * sizeof(int32_t))) == hipSuccess;
+  ok = ok && (e = osfm_malloc_retry(ctx, (void **)&s->d_tile_off, (size_t)(n_images + 1) * sizeof(int64_t))) == hipSuccess;
   if (!ok) {
     osfm_set_error("hipMalloc failed for a store of %lld tiles: %s", (long long)nt, hipGetErrorString(e));
     osfm_store_destroy(s);
@@ -202,13 +225,13 @@ static int store_upload(osfm_store *s, const T *desc, const double *pts) {
   }
   if (!integral) {
     if (!s->d_descf) {
-      OSFM_REQUIRE(hipMalloc((void **)&s->d_descf, descf.size() * sizeof(float)) == hipSuccess, OSFM_E_NOMEM,
+      OSFM_REQUIRE(osfm_malloc_retry(s->ctx, (void **)&s->d_descf, descf.size() * sizeof(float)) == hipSuccess, OSFM_E_NOMEM,
                    "osfm_store_upload: out of device memory for %lld float descriptors", (long long)(descf.size() / OSFM_DESC_DIM));
       s->bytes += (int64_t)descf.size() * (int64_t)sizeof(float);
     }
     OSFM_HIP(hipMemcpy(s->d_descf, descf.data(), descf.size() * sizeof(float), hipMemcpyHostToDevice));
     if (!s->d_qerr)
-      OSFM_REQUIRE(hipMalloc((void **)&s->d_qerr, qerr.size() * sizeof(float)) == hipSuccess, OSFM_E_NOMEM, "osfm_store_upload: out of device memory");
+      OSFM_REQUIRE(osfm_malloc_retry(s->ctx, (void **)&s->d_qerr, qerr.size() * sizeof(float)) == hipSuccess, OSFM_E_NOMEM, "osfm_store_upload: out of device memory");
     OSFM_HIP(hipMemcpy(s->d_qerr, qerr.data(), qerr.size() * sizeof(float), hipMemcpyHostToDevice));
   }
   OSFM_HIP(hipMemcpy(s->d_tiles, tiles.data(), tiles.size(), hipMemcpyHostToDevice));
@@ -355,8 +378,8 @@ static int match_pairs_impl(osfm_ctx *ctx, const osfm_store *store, const int32_
     res->on_device = true;
     res->device = ctx->device;
     res->d_cap = (ctx->match_hint + ctx->match_hint / 8) / 2 + 1024;  // rows; what the previous call on this context produced
-    OSFM_REQUIRE(hipMalloc((void **)&res->d_counts, (size_t)(n_pairs > 0 ? n_pairs : 1) * sizeof(int32_t)) == hipSuccess &&
-                     hipMalloc((void **)&res->d_matches, res->d_cap * 2 * sizeof(int32_t)) == hipSuccess,
+    OSFM_REQUIRE(osfm_malloc_retry(ctx, (void **)&res->d_counts, (size_t)(n_pairs > 0 ? n_pairs : 1) * sizeof(int32_t)) == hipSuccess &&
+                     osfm_malloc_retry(ctx, (void **)&res->d_matches, res->d_cap * 2 * sizeof(int32_t)) == hipSuccess,
                  OSFM_E_NOMEM, "hipMalloc failed for the device-resident result of %lld pairs", (long long)n_pairs);
     OSFM_HIP(hipMemsetAsync(res->d_counts, 0, (size_t)(n_pairs > 0 ? n_pairs : 1) * sizeof(int32_t), stA));
     OSFM_HIP(hipStreamSynchronize(stA));
@@ -452,7 +475,7 @@ static int match_pairs_impl(osfm_ctx *ctx, const osfm_store *store, const int32_
       if (base + (size_t)total > res->d_cap) {  // grow: D2D copy of what is there (stream B is idle, the host waited on it above)
         const size_t ncap = (base + (size_t)total) + (base + (size_t)total) / 2;
         int32_t *nb = nullptr;
-        OSFM_REQUIRE(hipMalloc((void **)&nb, ncap * 2 * sizeof(int32_t)) == hipSuccess, OSFM_E_NOMEM, "hipMalloc failed for %lld device-resident matches",
+        OSFM_REQUIRE(osfm_malloc_retry(ctx, (void **)&nb, ncap * 2 * sizeof(int32_t)) == hipSuccess, OSFM_E_NOMEM, "hipMalloc failed for %lld device-resident matches",
                      (long long)ncap);
         hipError_t ce = base ? hipMemcpyAsync(nb, res->d_matches, base * 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, stB) : hipSuccess;
         if (ce == hipSuccess) ce = hipStreamSynchronize(stB);

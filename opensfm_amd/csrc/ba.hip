@@ -2732,6 +2732,7 @@ __global__ void unpermute2_kernel(const int *perm, const double *in, long M, dou
 
 struct Arena {
   std::vector<void *> ptrs;
+  osfm_ctx *ctx = nullptr;  // set: an out-of-memory allocation drops the context's block cache and retries
   ~Arena() {
     for (void *p : ptrs) (void)hipFree(p);
   }
@@ -2739,7 +2740,7 @@ struct Arena {
   T *alloc(size_t n, hipError_t &e) {
     void *p = nullptr;
     if (e != hipSuccess) return nullptr;
-    e = hipMalloc(&p, (n ? n : 1) * sizeof(T));
+    e = osfm_malloc_retry(ctx, &p, (n ? n : 1) * sizeof(T));
     if (e == hipSuccess) ptrs.push_back(p);
     return (T *)p;
   }
@@ -3156,6 +3157,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
 
   // ---- device image ----
   Arena A;
+  A.ctx = ctx;
   hipError_t e = hipSuccess;
   Solver sv;
   sv.ctx = ctx;

@@ -835,13 +835,14 @@ __global__ void g_absmax_kernel(const double *a, long n, const double *b, long m
 struct Arena {  // one device allocation, released on scope exit
   std::vector<void *> blocks;
   hipError_t err = hipSuccess;
+  osfm_ctx *ctx = nullptr;  // set: an out-of-memory allocation drops the context's block cache and retries
   ~Arena() {
     for (void *b : blocks) (void)hipFree(b);
   }
   template <class T>
   T *alloc(size_t n) {
     void *p = nullptr;
-    const hipError_t e = hipMalloc(&p, (n ? n : 1) * sizeof(T));
+    const hipError_t e = osfm_malloc_retry(ctx, &p, (n ? n : 1) * sizeof(T));
     if (e != hipSuccess) {
       err = e;
       return nullptr;
@@ -949,6 +950,7 @@ extern "C" int osfm_bundle_solve(osfm_ctx *ctx, osfm_bundle_problem *P, const os
   }
 
   Arena A;
+  A.ctx = ctx;
   GDev d;
   memset(&d, 0, sizeof(d));
   d.NC = NC; d.NR = NR; d.NI = NI; d.S = S; d.P = NP; d.M = M; d.nred = nred;

@@ -927,8 +927,12 @@ extern "C" int osfm_dbg_hahog_phases(unsigned long long *out, int reset) {
 extern "C" int osfm_hahog_extract(osfm_ctx *ctx, const float *image, int rows, int cols, float peak_threshold, float edge_threshold,
                                   int target_num_features, int flags, float *points, float *desc, int capacity, int *n_features) {
   OSFM_REQUIRE(ctx && image && n_features, OSFM_E_INVALID, "osfm_hahog_extract: null argument");
-  OSFM_REQUIRE(rows >= 17 && cols >= 17, OSFM_E_INVALID, "osfm_hahog_extract: image %d x %d is smaller than one 16-pixel octave", rows, cols);
+  OSFM_REQUIRE(rows > 0 && cols > 0, OSFM_E_INVALID, "osfm_hahog_extract: image %d x %d", rows, cols);
   OSFM_REQUIRE(target_num_features >= 0 && capacity >= 0, OSFM_E_INVALID, "osfm_hahog_extract: negative count");
+  if (rows < 17 || cols < 17) {  // smaller than one 16-pixel octave (covdet.c:1686 gives lastOctave < firstOctave: vlfeat has no scale space
+    *n_features = 0;             // to search): a thumbnail or a masked crop yields no features instead of stopping a pipeline
+    return OSFM_OK;
+  }
   OSFM_CTX_LOCK(ctx);
   OSFM_HIP(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;

@@ -11,6 +11,13 @@
 #include "../../include/osfm_mi355.h"
 
 void osfm_set_error(const char *fmt, ...);
+// bumped by every osfm_set_error on this thread: a pooled device block released after an error was recorded may still be in use by
+// kernels of the failed call, so its release waits for the device before the block goes back to the cache (OsfmPoolBuf::release)
+extern thread_local unsigned osfm_error_epoch;
+struct osfm_ctx;
+// hipMalloc for the allocations that do not come from the context's block cache: when the device is out of memory while blocks sit
+// idle in the cache, the cache is dropped (osfm_ctx_trim_pool) and the allocation retried
+hipError_t osfm_malloc_retry(osfm_ctx *ctx, void **p, size_t bytes);
 
 #define OSFM_HIP(call)                                                                      \
   do {                                                                                      \
@@ -137,9 +144,12 @@ struct OsfmPoolBuf {
   void *p = nullptr;
   size_t bytes = 0;
   osfm_ctx *pool = nullptr;  // non-null: taken from / returned to the context's cache (the caller holds the context lock)
+  unsigned epoch = 0;        // osfm_error_epoch when the block was taken
   ~OsfmPoolBuf() { release(); }
   void release() {
     if (!p) return;
+    // error path (an early return after OSFM_HIP / OSFM_REQUIRE): kernels of the failed call may still read or write the block
+    if (epoch != osfm_error_epoch) (void)hipDeviceSynchronize();
     if (pool && pool->pool_bytes + bytes <= osfm_ctx::kPoolBytes && pool->pool.size() < 64) {
       pool->pool.push_back({p, bytes});
       pool->pool_bytes += bytes;
@@ -150,11 +160,13 @@ struct OsfmPoolBuf {
   }
   hipError_t alloc(size_t want) {
     bytes = want ? want : 16;
+    epoch = osfm_error_epoch;
     return hipMalloc(&p, bytes);
   }
   hipError_t alloc(osfm_ctx *ctx, size_t want) {
     want = want ? want : 16;
     pool = ctx;
+    epoch = osfm_error_epoch;
     int best = -1;
     for (int i = 0; i < (int)ctx->pool.size(); ++i)
       if (ctx->pool[i].bytes >= want && ctx->pool[i].bytes <= 2 * want + 4096 && (best < 0 || ctx->pool[i].bytes < ctx->pool[best].bytes)) best = i;

@@ -562,7 +562,7 @@ int osfm_launch_ransac_pairs(osfm_ctx *ctx, const osfm_store *store, const int32
     if (ctx->d_fr_scratch) (void)hipFree(ctx->d_fr_scratch);
     ctx->d_fr_scratch = nullptr;
     ctx->fr_scratch_bytes = 0;
-    OSFM_REQUIRE(hipMalloc(&ctx->d_fr_scratch, need + need / 8) == hipSuccess, OSFM_E_NOMEM, "hipMalloc failed for the RANSAC hand-over buffers");
+    OSFM_REQUIRE(osfm_malloc_retry(ctx, &ctx->d_fr_scratch, need + need / 8) == hipSuccess, OSFM_E_NOMEM, "hipMalloc failed for the RANSAC hand-over buffers");
     ctx->fr_scratch_bytes = need + need / 8;
   }
   RansacPairsArgs a;

@@ -23,6 +23,9 @@ def test_pyfeatures(oracle_lib, gpu_ctx):
     assert m.shape[1] == 2 and len(m) > 250 and np.array_equal(m[:, 0], m[:, 1])
     want = oracle_lib.match_words(f1, words, f2, words[:, 0].copy(), 0.99, 20)
     assert np.array_equal(np.asarray(m), np.asarray(want).reshape(-1, 2))
+    # an image whose mask left no features (matching.match_words can get there): no matches, no exception
+    assert pyfeatures.match_using_words(f1[:0], words[:0], f2, words[:, 0], 0.99, 20).shape == (0, 2)
+    assert pyfeatures.match_using_words(f1, words, f2[:0], words[:0, 0], 0.99, 20).shape == (0, 2)
     centers = rng.normal(0, 1, (8, 128)).astype(np.float32)
     v = pyfeatures.compute_vlad_descriptor(f1[:50], centers)
     assert v.shape == (8 * 128,)
@@ -32,7 +35,7 @@ def test_pyfeatures(oracle_lib, gpu_ctx):
     assert names == ["b", "c"] and abs(d[0] - np.sqrt(len(v))) < 1e-3
 
 
-def test_pyrobust(gpu_ctx):
+def test_pyrobust(oracle_lib, gpu_ctx):
     from opensfm_amd import matching
     from opensfm_amd.compat import pyrobust
 
@@ -50,6 +53,11 @@ def test_pyrobust(gpu_ctx):
     res = pyrobust.ransac_relative_pose(b1, b2, 1 - np.cos(0.004), params, pyrobust.RansacType.RANSAC)
     direct, mask, _ = matching.relpose_pairs(b1, b2, [0, 200], 1 - np.cos(0.004), mode="ransac", iterations=1000, probability=0.99)
     assert np.array_equal(res.lo_model, direct[0]["lo_model"]) and res.inliers_indices == list(np.flatnonzero(mask))
+    # against the ORACLE (robust_estimator.h's LO-RANSAC as oracle/relpose_oracle.c restates it, pinned to the reference's template
+    # compiled in oracle/_ref): score, both models and the inlier list, bit for bit
+    want = oracle_lib.ransac_relative_pose(b1, b2, 1 - np.cos(0.004), iterations=1000, probability=0.99)
+    assert res.score == want["score"] and res.inliers_indices == [int(i) for i in want["inliers"]]
+    assert np.array_equal(res.model, want["model"]) and np.array_equal(res.lo_model, want["lo_model"])
     assert len(res.inliers_indices) >= 170 and res.lo_model.shape == (3, 4)
     with pytest.raises(RuntimeError):
         pyrobust.ransac_relative_pose(b1, b2[:10], 1e-5, params, pyrobust.RANSAC)

@@ -3,11 +3,10 @@ vendored vlfeat, compiled from /root/reference into oracle/_ref/libhahog_ref.so 
 that library produced in the build container (tests/golden/hahog_berlin01.npz, made by tests/golden/make_hahog_golden.py from the
 reference's data/berlin/images/01.jpg).
 
-Stated tolerance.  The set of features, their order, x, y, size and all 128 descriptor values are expected to be the reference's BIT FOR
-BIT (the kernels follow vlfeat operation for operation; measured: identical on every case below).  The orientation angle in degrees
-goes through atan2f, whose last bit differs between glibc and the device library: |angle difference| <= 1e-4 degrees.  The few per-feature
-libm calls made on the device in double (pow, exp, cos, sin) feed float fields; should a last bit ever flip one, a row may differ by a
-float ulp -- the assertions therefore allow descriptor differences up to 2e-6 (1 level of 255 after scaling) in at most 1 row of 1000."""
+Stated tolerance.  The set of features, their order, x, y, size and all 128 descriptor values must be the reference's BIT FOR BIT (the
+kernels follow vlfeat operation for operation): the assertions are exact -- 0 differing keypoint rows, 0 differing descriptor values,
+0 differing uint8 levels.  The one exception is the orientation angle in degrees (column 3 of the points), which goes through atan2f,
+whose last bit differs between glibc and the device library: |angle difference| <= 1e-4 degrees."""
 import os
 
 import numpy as np
@@ -20,16 +19,17 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hah
 CFG = {"feature_root": True, "hahog_normalize_to_uchar": True, "hahog_peak_threshold": 1e-5, "hahog_edge_threshold": 10}
 
 
-def _compare(pts, desc, rp, rd, tol_desc=2e-6):
+def _compare(pts, desc, rp, rd):
     assert pts.shape == rp.shape and desc.shape == rd.shape, (pts.shape, rp.shape)
     if len(pts) == 0:
         return
-    assert np.array_equal(pts[:, :3], rp[:, :3]) or (np.abs(pts[:, :3] - rp[:, :3]).max(axis=1) > 0).sum() <= max(1, len(pts) // 1000)
+    bad_rows = int((pts[:, :3] != rp[:, :3]).any(axis=1).sum())
+    bad_vals = int((desc != rd).sum())
+    print("hahog parity: %d features, %d differing keypoint rows, %d differing descriptor values of %d" % (len(pts), bad_rows, bad_vals, desc.size))
+    assert bad_rows == 0 and bad_vals == 0, (bad_rows, bad_vals)
     dang = np.abs(pts[:, 3] - rp[:, 3])
     dang = np.minimum(dang, 360.0 - dang)
     assert dang.max() <= 1e-4, dang.max()
-    d = np.abs(desc - rd).max(axis=1)
-    assert d.max() <= tol_desc and (d > 0).sum() <= max(1, len(pts) // 1000), (d.max(), int((d > 0).sum()))
 
 
 def test_golden_vectors_of_the_reference(gpu_ctx):
@@ -39,13 +39,14 @@ def test_golden_vectors_of_the_reference(gpu_ctx):
     assert pts.shape == g["points"].shape
     assert np.array_equal(pts[:, :3], g["points"][:, :3])
     assert np.abs(pts[:, 3] - g["points"][:, 3]).max() <= 1e-4
-    assert np.abs(desc[:64] - g["desc_f32_head"]).max() <= 2e-6
+    assert np.array_equal(desc[:64], g["desc_f32_head"]), int((desc[:64] != g["desc_f32_head"]).sum())
     # as features.extract_features_hahog returns them (square root, x 362, clip, round): integer levels
     p8, d8 = features.extract_features_hahog(grey, CFG, 1500)
     assert np.array_equal(p8[:, :3], g["points"][:, :3])
     assert d8.dtype == np.float32 and np.array_equal(d8, np.round(d8)) and d8.min() >= 0 and d8.max() <= 255
     diff = np.abs(d8 - g["desc_u8"].astype(np.float32))
-    assert diff.max() <= 1 and np.count_nonzero(diff) <= d8.size // 10000, (diff.max(), np.count_nonzero(diff))
+    print("hahog golden: %d features, %d differing uint8 levels of %d" % (len(p8), np.count_nonzero(diff), d8.size))
+    assert np.count_nonzero(diff) == 0, (diff.max(), np.count_nonzero(diff))
 
 
 def _texture(rows, cols, seed):
@@ -84,6 +85,10 @@ def test_thresholds_and_empty_results(oracle_lib, gpu_ctx):
     assert len(features.hahog(im, 10.0, 10.0, 500)[0]) == 0
     assert len(features.hahog(im, 1e-5, 10.0, 0)[0]) == 0  # hahog.cc:24-27 keeps `target` = 0 of the sorted list
     assert features.hahog(np.zeros((0, 0), np.float32), 1e-5, 10.0, 10) is None  # hahog.cc:127-129
+    # below one 16-pixel octave vlfeat has no scale space: no features, no exception (thumbnails, masked crops)
+    for shape in ((16, 300), (40, 9), (1, 1)):
+        p0, d0 = features.hahog(np.full(shape, 0.5, np.float32), 1e-5, 10.0, 10)
+        assert p0.shape == (0, 4) and d0.shape == (0, 128)
 
 
 def test_descriptors_feed_the_matcher(gpu_ctx):
