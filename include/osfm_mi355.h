@@ -63,6 +63,18 @@ int64_t osfm_ctx_trim_pool(osfm_ctx *ctx);
 int osfm_store_create(osfm_ctx *ctx, int n_images, const int32_t *counts, osfm_store **out);
 int osfm_store_upload_f32(osfm_store *s, const float *desc, const double *pts);
 int osfm_store_upload_u8(osfm_store *s, const uint8_t *desc, const double *pts);
+/* Binary descriptors -- uint8 bit strings (AKAZE MLDB: 61 bytes, ORB: 32 bytes; width_bytes 1..64).  match_brute_force hands uint8
+ * arrays to cv2's "BruteForce-Hamming" matcher (opensfm/matching.py:737-740): integer Hamming distances, the same K = 2 insertion and
+ * Lowe's test on float32(int).  Instead of osfm_store_upload_f32/_u8; the store then runs osfm_match_pairs / _calibrated on the
+ * Hamming kernel (VALU popcount), gates and robust stage unchanged.  Not with OSFM_MATCH_SQUARED_RATIO, guided matching or a
+ * segmentation column (OSFM_E_UNSUPPORTED). */
+int osfm_store_upload_binary(osfm_store *s, const uint8_t *desc, int width_bytes, const double *pts);
+/* matching_use_segmentation (opensfm/feature_loading.py:118-155, matching.py:281,356): the reference appends a 129th column to the
+ * HAHOG uchar descriptors, SEGMENTATION_IN_DESCRIPTOR_MULT (35) x the feature's segmentation label.  column129: sum(counts) floats,
+ * that column (already multiplied).  A store that has one is matched with d^2 = d^2_128 + (c1 - c2)^2, added in float32 exactly where
+ * cv2's normL2Sqr_ adds a trailing element; such stores run on the exact (VALU) kernel, not on the int8 matrix path.
+ * Integer-valued stores only (the reference raises for anything but HAHOG uchar): OSFM_E_UNSUPPORTED otherwise. */
+int osfm_store_set_segmentation(osfm_store *s, const float *column129);
 void osfm_store_destroy(osfm_store *s);
 int64_t osfm_store_bytes(const osfm_store *s); /* device bytes held */
 
@@ -137,6 +149,10 @@ int osfm_match_l2_ratio(osfm_ctx *ctx, const float *A, int nA, const float *B, i
                         double ratio, int symmetric, int32_t *out_pairs, int cap, int *out_n);
 int osfm_match_l2_ratio_ex(osfm_ctx *ctx, const float *A, int nA, const float *B, int nB, int dim,
                            double ratio, int symmetric, int flags, int32_t *out_pairs, int cap, int *out_n);
+/* The same leaf for uint8 bit strings: match_brute_force[_symmetric] on uint8 arrays = cv2 BruteForce-Hamming (matching.py:737-740).
+ * A: nA x width_bytes, B: nB x width_bytes (1..64 bytes). */
+int osfm_match_hamming_ratio(osfm_ctx *ctx, const uint8_t *A, int nA, const uint8_t *B, int nB, int width_bytes,
+                             double ratio, int symmetric, int32_t *out_pairs, int cap, int *out_n);
 
 /*
  * Leaf: cv2.findFundamentalMat(p1, p2, FM_RANSAC, thr, conf) as used by
@@ -312,6 +328,13 @@ typedef struct {
   /* compass / inclinometer priors per shot (AddAbsolutePan / Tilt / Roll, absolute_motion_errors.h:40-137, Cauchy(1)):
      angle in radians and its sd (<= 0: none); NULL = none at all */
   const double *shot_pan, *shot_pan_sigma, *shot_tilt, *shot_tilt_sigma, *shot_roll, *shot_roll_sigma;
+  /* depth priors of the observations (map::Depth, observation.h:10-18; AddPointProjectionObservation's depth_prior argument as
+     BAHelpers passes it, ba_helpers.cc:695-696): RelativeDepthError (bundle/error/relative_depth_error.h, bundle_adjuster.cc:497-528),
+     one residual (depth_in_camera - depth) / sd per observation that has one, depth_in_camera = |X_cam| (radial) or its z, under the
+     point-projection loss.  n_obs each; obs_depth_sigma[o] <= 0: none; obs_depth / obs_depth_sigma NULL: none at all;
+     obs_depth_radial NULL: all radial.  A non-finite depth with a positive sd is OSFM_E_INVALID (the reference throws). */
+  const double *obs_depth, *obs_depth_sigma;
+  const uint8_t *obs_depth_radial;
 } osfm_bundle_problem;
 
 int osfm_bundle_solve(osfm_ctx *ctx, osfm_bundle_problem *problem, const osfm_ba_options *options, osfm_ba_report *report);

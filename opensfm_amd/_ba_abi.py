@@ -58,6 +58,7 @@ class BundleProblem(C.Structure):
         ("obs_sigma", C.POINTER(C.c_double)), ("reproj_err", C.POINTER(C.c_double)),
         ("shot_pan", C.POINTER(C.c_double)), ("shot_pan_sigma", C.POINTER(C.c_double)), ("shot_tilt", C.POINTER(C.c_double)),
         ("shot_tilt_sigma", C.POINTER(C.c_double)), ("shot_roll", C.POINTER(C.c_double)), ("shot_roll_sigma", C.POINTER(C.c_double)),
+        ("obs_depth", C.POINTER(C.c_double)), ("obs_depth_sigma", C.POINTER(C.c_double)), ("obs_depth_radial", C.POINTER(C.c_uint8)),
     ]
 
 
@@ -80,6 +81,7 @@ BUNDLE_FIELDS = [
     ("shot_pan", "float64", None, False, False), ("shot_pan_sigma", "float64", None, False, False),
     ("shot_tilt", "float64", None, False, False), ("shot_tilt_sigma", "float64", None, False, False),
     ("shot_roll", "float64", None, False, False), ("shot_roll_sigma", "float64", None, False, False),
+    ("obs_depth", "float64", None, False, False), ("obs_depth_sigma", "float64", None, False, False), ("obs_depth_radial", "uint8", None, False, False),
 ]
 _CT = {"int32": C.c_int32, "float64": C.c_double, "uint8": C.c_uint8}
 
@@ -114,7 +116,8 @@ def fill_bundle_problem(problem, struct_cls=BundleProblem):
                     ("shot_pan", P.n_shots), ("shot_pan_sigma", P.n_shots), ("shot_tilt", P.n_shots), ("shot_tilt_sigma", P.n_shots),
                     ("shot_roll", P.n_shots), ("shot_roll_sigma", P.n_shots),
                     ("point_fixed", P.n_points), ("point_prior", P.n_points), ("point_prior_sigma", P.n_points),
-                    ("point_prior_has_altitude", P.n_points), ("obs_point", P.n_obs), ("obs_xy", P.n_obs), ("obs_sigma", P.n_obs)):
+                    ("point_prior_has_altitude", P.n_points), ("obs_point", P.n_obs), ("obs_xy", P.n_obs), ("obs_sigma", P.n_obs),
+                    ("obs_depth", P.n_obs), ("obs_depth_sigma", P.n_obs), ("obs_depth_radial", P.n_obs)):
         if name in arrays and len(arrays[name]) != n:
             raise ValueError(f"bundle problem: {name!r} has {len(arrays[name])} rows, expected {n}")
     reproj = np.zeros((max(P.n_obs, 1), 3), np.float64)

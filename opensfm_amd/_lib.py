@@ -86,6 +86,10 @@ SIGNATURES = {
     "osfm_store_create": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_void_p)]),
     "osfm_store_upload_f32": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double)]),
     "osfm_store_upload_u8": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_double)]),
+    "osfm_store_set_segmentation": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "osfm_store_upload_binary": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint8), C.c_int, C.POINTER(C.c_double)]),
+    "osfm_match_hamming_ratio": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint8), C.c_int, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_double, C.c_int,
+                                           C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int)]),
     "osfm_store_destroy": (None, [C.c_void_p]),
     "osfm_store_bytes": (C.c_int64, [C.c_void_p]),
     "osfm_match_params_default": (None, [C.POINTER(MatchParams)]),

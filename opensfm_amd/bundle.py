@@ -325,7 +325,7 @@ class BundleAdjuster:
     fisheye cameras, one constant identity rig camera, one shot per instance, identity biases, no point priors).
     Cameras / poses / similarities are any objects with the reference's attributes (``geometry_types`` has plain ones).
     Not implemented (raise): relative motions / rotations, common positions, heatmaps, linear motion, reconstructions with shared
-    scales, depth priors, covariances -- none of which ``BAHelpers`` uses."""
+    scales, covariances -- none of which ``BAHelpers`` uses."""
 
     def __init__(self):
         self._cams: Dict[str, Dict[str, Any]] = {}
@@ -386,11 +386,16 @@ class BundleAdjuster:
         return point_id in self._points
 
     def add_point_projection_observation(self, shot, point, observation, std_deviation, depth_prior=None):
-        if depth_prior is not None:
-            raise NotImplementedError("depth priors (RelativeDepthError) are not on the GPU path")
+        """``BundleAdjuster::AddPointProjectionObservation`` (bundle_adjuster.cc:236-250); ``depth_prior``: a ``map::Depth``
+        (``.value``, ``.is_radial``, ``.std_deviation``, observation.h:10-18) -> a RelativeDepthError next to the reprojection"""
         if shot not in self._shots or point not in self._points:
             raise IndexError("unknown shot or point")  # std::map::at
-        self._obs.append((shot, point, float(observation[0]), float(observation[1]), float(std_deviation)))
+        depth = None
+        if depth_prior is not None:
+            depth = (float(depth_prior.value), float(depth_prior.std_deviation), bool(depth_prior.is_radial))
+            if not np.isfinite(depth[0]):
+                raise RuntimeError(str(shot) + " has non-finite depth prior")  # bundle_adjuster.cc:508-511 (thrown from Run)
+        self._obs.append((shot, point, float(observation[0]), float(observation[1]), float(std_deviation), depth))
 
     def _shot_prior(self, key, shot_id, value, std_deviation):
         self._shots[shot_id][key] = (value, float(std_deviation))
@@ -513,6 +518,10 @@ class BundleAdjuster:
             "obs_shot": np.array([si[o[0]] for o in self._obs], np.int32), "obs_point": np.array([pi[o[1]] for o in self._obs], np.int32),
             "obs_xy": np.array([[o[2], o[3]] for o in self._obs]).reshape(-1, 2), "obs_sigma": np.array([o[4] for o in self._obs]),
         }
+        if any(o[5] is not None for o in self._obs):  # depth priors (RelativeDepthError): sd 0 = none
+            prob["obs_depth"] = np.array([o[5][0] if o[5] else 0.0 for o in self._obs])
+            prob["obs_depth_sigma"] = np.array([o[5][1] if o[5] else 0.0 for o in self._obs])
+            prob["obs_depth_radial"] = np.array([o[5][2] if o[5] else 1 for o in self._obs], np.uint8)
         if gps_sd.max() > 0:
             prob.update(rig_instance_gps=gps, rig_instance_gps_sigma=gps_sd, rig_instance_bias_camera=bias_cam)
         if any(p["prior"] is not None for p in self._points.values()):
@@ -536,7 +545,7 @@ class BundleAdjuster:
         NI, S = len(prob["rig_instance_pose"]), len(prob["shot_camera"])
         if (S != NI or len(prob["rig_camera_pose"]) != 1 or not prob["rig_camera_fixed"][0] or prob["rig_camera_pose"].any()
                 or (prob["cam_model"] > 1).any() or not prob["bias_fixed"].all() or (prob["bias"] != [0, 0, 0, 0, 0, 0, 1.0]).any()
-                or "point_prior" in prob or any(k in prob for k in ("shot_pan", "shot_tilt", "shot_roll"))
+                or "point_prior" in prob or "obs_depth" in prob or any(k in prob for k in ("shot_pan", "shot_tilt", "shot_roll"))
                 or not np.array_equal(np.sort(prob["shot_rig_instance"]), np.arange(NI)) or len(prob["obs_shot"]) == 0):
             return None
         if "rig_instance_gps_sigma" in prob:

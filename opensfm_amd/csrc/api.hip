@@ -132,6 +132,8 @@ extern "C" void osfm_store_destroy(osfm_store *s) {
   (void)hipFree(s->d_norms);
   (void)hipFree(s->d_hneg);
   (void)hipFree(s->d_descf);
+  (void)hipFree(s->d_seg);
+  (void)hipFree(s->d_bin);
   (void)hipFree(s->d_qerr);
   (void)hipFree(s->d_pts);
   (void)hipFree(s->d_counts);
@@ -246,6 +248,67 @@ static int store_upload(osfm_store *s, const T *desc, const double *pts) {
   cnt.push_back(0);
   OSFM_HIP(hipMemcpy(s->d_counts, cnt.data(), cnt.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   OSFM_HIP(hipMemcpy(s->d_tile_off, s->tile_off.data(), s->tile_off.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+  return OSFM_OK;
+}
+
+// matching_use_segmentation (feature_loading.py:123-155): the reference appends one column, 35 x the feature's segmentation label,
+// to the HAHOG uchar descriptors, so d^2 = d^2_128 + (35 (s1 - s2))^2.  The store keeps the column; stores that have one are matched
+// by the exact kernel, which adds the term exactly as cv2's normL2Sqr_ accumulates a 129th element (scalar tail: d += t * t).
+extern "C" int osfm_store_set_segmentation(osfm_store *s, const float *column129) {
+  OSFM_REQUIRE(s && column129, OSFM_E_INVALID, "osfm_store_set_segmentation: null argument");
+  OSFM_REQUIRE(!s->is_float && !s->is_binary, OSFM_E_UNSUPPORTED,
+               "segmentation in the descriptor is defined for integer-valued (HAHOG uchar) descriptors only (feature_loading.py:126-133)");
+  OSFM_CTX_LOCK(s->ctx);
+  OSFM_HIP(hipSetDevice(s->ctx->device));
+  const int64_t nt = s->tile_off[s->n_images] + 4;
+  std::vector<float> seg((size_t)nt * 32, 0.0f);
+  for (int i = 0; i < s->n_images; ++i)
+    for (int r = 0; r < s->counts[i]; ++r) {
+      const float v = column129[s->row_off[i] + r];
+      OSFM_REQUIRE(std::isfinite(v), OSFM_E_INVALID, "osfm_store_set_segmentation: non-finite label of feature %d of image %d", r, i);
+      seg[(size_t)s->tile_off[i] * 32 + r] = v;
+    }
+  if (!s->d_seg) {
+    OSFM_REQUIRE(osfm_malloc_retry(s->ctx, (void **)&s->d_seg, seg.size() * sizeof(float)) == hipSuccess, OSFM_E_NOMEM,
+                 "osfm_store_set_segmentation: out of device memory");
+    s->bytes += (int64_t)seg.size() * 4;
+  }
+  OSFM_HIP(hipMemcpy(s->d_seg, seg.data(), seg.size() * sizeof(float), hipMemcpyHostToDevice));
+  return OSFM_OK;
+}
+
+// Binary descriptors (uint8 bit strings: AKAZE MLDB 61 bytes, ORB 32 bytes): the reference's match_brute_force switches cv2 to
+// "BruteForce-Hamming" for uint8 arrays (matching.py:737-740).  Rows are zero-padded to 64 bytes (zeros add nothing to a Hamming
+// distance); the keypoints go where the other stores keep them, so the gates and the robust stage are unchanged.
+extern "C" int osfm_store_upload_binary(osfm_store *s, const uint8_t *desc, int width_bytes, const double *pts) {
+  OSFM_REQUIRE(s && desc && pts, OSFM_E_INVALID, "osfm_store_upload_binary: null argument");
+  OSFM_REQUIRE(width_bytes >= 1 && width_bytes <= 64, OSFM_E_UNSUPPORTED, "osfm_store_upload_binary: %d bytes per descriptor (1..64)", width_bytes);
+  OSFM_REQUIRE(!s->d_seg, OSFM_E_UNSUPPORTED, "osfm_store_upload_binary: the store holds a segmentation column (integer-valued L2 descriptors only)");
+  OSFM_CTX_LOCK(s->ctx);
+  OSFM_HIP(hipSetDevice(s->ctx->device));
+  const int64_t nt = s->tile_off[s->n_images] + 4;
+  std::vector<uint32_t> bin((size_t)nt * 32 * 16, 0u);
+  std::vector<double> hp((size_t)nt * 64, 0.0);
+  for (int i = 0; i < s->n_images; ++i)
+    for (int r = 0; r < s->counts[i]; ++r) {
+      const int64_t src = s->row_off[i] + r, dst = s->tile_off[i] * 32 + r;
+      memcpy((uint8_t *)(bin.data() + (size_t)dst * 16), desc + (size_t)src * width_bytes, (size_t)width_bytes);
+      hp[(size_t)dst * 2] = pts[(size_t)src * 2];
+      hp[(size_t)dst * 2 + 1] = pts[(size_t)src * 2 + 1];
+    }
+  if (!s->d_bin) {
+    OSFM_REQUIRE(osfm_malloc_retry(s->ctx, (void **)&s->d_bin, bin.size() * sizeof(uint32_t)) == hipSuccess, OSFM_E_NOMEM,
+                 "osfm_store_upload_binary: out of device memory");
+    s->bytes += (int64_t)bin.size() * 4;
+  }
+  OSFM_HIP(hipMemcpy(s->d_bin, bin.data(), bin.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  OSFM_HIP(hipMemcpy(s->d_pts, hp.data(), hp.size() * sizeof(double), hipMemcpyHostToDevice));
+  std::vector<int32_t> cnt(s->counts);
+  cnt.push_back(0);
+  OSFM_HIP(hipMemcpy(s->d_counts, cnt.data(), cnt.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  OSFM_HIP(hipMemcpy(s->d_tile_off, s->tile_off.data(), s->tile_off.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+  s->is_binary = true;
+  s->is_float = false;
   return OSFM_OK;
 }
 
@@ -634,7 +697,8 @@ extern "C" int osfm_match_l2_ratio(osfm_ctx *ctx, const float *A, int nA, const 
 extern "C" int osfm_match_l2_ratio_ex(osfm_ctx *ctx, const float *A, int nA, const float *B, int nB, int dim, double ratio,
                                       int symmetric, int flags, int32_t *out_pairs, int cap, int *out_n) {
   OSFM_REQUIRE(ctx && out_n && (out_pairs || cap == 0), OSFM_E_INVALID, "osfm_match_l2_ratio: null argument");
-  OSFM_REQUIRE(dim == OSFM_DESC_DIM, OSFM_E_UNSUPPORTED, "descriptor dim %d (only 128 is implemented)", dim);
+  // 129 = 128 + the segmentation column (matching_use_segmentation, feature_loading.py:123-155)
+  OSFM_REQUIRE(dim == OSFM_DESC_DIM || dim == OSFM_DESC_DIM + 1, OSFM_E_UNSUPPORTED, "descriptor dim %d (128, or 129 with the segmentation column)", dim);
   OSFM_REQUIRE(nA >= 0 && nB >= 0 && (A || nA == 0) && (B || nB == 0), OSFM_E_INVALID, "bad descriptor arrays");
   *out_n = 0;
   OSFM_CTX_LOCK(ctx);
@@ -651,11 +715,18 @@ extern "C" int osfm_match_l2_ratio_ex(osfm_ctx *ctx, const float *A, int nA, con
   int rc = osfm_store_create(ctx, 2, counts, &st);
   if (rc != OSFM_OK) return rc;
   std::vector<float> desc((size_t)(mA + mB) * OSFM_DESC_DIM);
-  for (int r = 0; r < mA; ++r) memcpy(desc.data() + (size_t)r * OSFM_DESC_DIM, A + (size_t)(r < nA ? r : 0) * OSFM_DESC_DIM, OSFM_DESC_DIM * sizeof(float));
-  for (int r = 0; r < mB; ++r)
-    memcpy(desc.data() + (size_t)(mA + r) * OSFM_DESC_DIM, B + (size_t)(r < nB ? r : 0) * OSFM_DESC_DIM, OSFM_DESC_DIM * sizeof(float));
+  std::vector<float> seg(dim > OSFM_DESC_DIM ? (size_t)(mA + mB) : 0);
+  for (int r = 0; r < mA; ++r) {
+    memcpy(desc.data() + (size_t)r * OSFM_DESC_DIM, A + (size_t)(r < nA ? r : 0) * dim, OSFM_DESC_DIM * sizeof(float));
+    if (!seg.empty()) seg[(size_t)r] = A[(size_t)(r < nA ? r : 0) * dim + OSFM_DESC_DIM];
+  }
+  for (int r = 0; r < mB; ++r) {
+    memcpy(desc.data() + (size_t)(mA + r) * OSFM_DESC_DIM, B + (size_t)(r < nB ? r : 0) * dim, OSFM_DESC_DIM * sizeof(float));
+    if (!seg.empty()) seg[(size_t)(mA + r)] = B[(size_t)(r < nB ? r : 0) * dim + OSFM_DESC_DIM];
+  }
   std::vector<double> pts((size_t)(mA + mB) * 2, 0.0);
   rc = osfm_store_upload_f32(st, desc.data(), pts.data());
+  if (rc == OSFM_OK && !seg.empty()) rc = osfm_store_set_segmentation(st, seg.data());
   osfm_match_result *res = nullptr;
   if (rc == OSFM_OK) {
     osfm_match_params prm;
@@ -672,6 +743,54 @@ extern "C" int osfm_match_l2_ratio_ex(osfm_ctx *ctx, const float *A, int nA, con
     for (int k = 0; k < res->counts[0]; ++k) {
       const int i = res->matches[2 * k], j = res->matches[2 * k + 1];
       if (i >= nA || j >= nB) continue;  // the copy of a lone query
+      if (n < cap) {
+        out_pairs[2 * n] = i;
+        out_pairs[2 * n + 1] = j;
+      }
+      ++n;
+    }
+    *out_n = n;
+  }
+  osfm_result_destroy(res);
+  osfm_store_destroy(st);
+  return rc;
+}
+
+// match_brute_force[_symmetric] on uint8 arrays: cv2 BruteForce-Hamming (matching.py:737-740); same lone-query handling as the L2 leaf
+extern "C" int osfm_match_hamming_ratio(osfm_ctx *ctx, const uint8_t *A, int nA, const uint8_t *B, int nB, int width_bytes, double ratio,
+                                        int symmetric, int32_t *out_pairs, int cap, int *out_n) {
+  OSFM_REQUIRE(ctx && out_n && (out_pairs || cap == 0), OSFM_E_INVALID, "osfm_match_hamming_ratio: null argument");
+  OSFM_REQUIRE(width_bytes >= 1 && width_bytes <= 64, OSFM_E_UNSUPPORTED, "osfm_match_hamming_ratio: %d bytes per descriptor (1..64)", width_bytes);
+  OSFM_REQUIRE(nA >= 0 && nB >= 0 && (A || nA == 0) && (B || nB == 0), OSFM_E_INVALID, "bad descriptor arrays");
+  *out_n = 0;
+  OSFM_CTX_LOCK(ctx);
+  if (nB < 2 || nA < 1 || (symmetric && nA < 2)) return OSFM_OK;  // knnMatch returns < 2 neighbours for a train set of < 2 rows
+  const bool lone = nA == 1;
+  const int mA = lone ? 2 : nA;
+  const int32_t counts[2] = {mA, nB};
+  osfm_store *st = nullptr;
+  int rc = osfm_store_create(ctx, 2, counts, &st);
+  if (rc != OSFM_OK) return rc;
+  std::vector<uint8_t> desc((size_t)(mA + nB) * width_bytes);
+  for (int r = 0; r < mA; ++r) memcpy(desc.data() + (size_t)r * width_bytes, A + (size_t)(r < nA ? r : 0) * width_bytes, (size_t)width_bytes);
+  memcpy(desc.data() + (size_t)mA * width_bytes, B, (size_t)nB * width_bytes);
+  std::vector<double> pts((size_t)(mA + nB) * 2, 0.0);
+  rc = osfm_store_upload_binary(st, desc.data(), width_bytes, pts.data());
+  osfm_match_result *res = nullptr;
+  if (rc == OSFM_OK) {
+    osfm_match_params prm;
+    osfm_match_params_default(&prm);
+    prm.lowes_ratio = ratio;
+    prm.symmetric = symmetric;
+    prm.robust = 0;
+    const int32_t pair[2] = {0, 1};
+    rc = osfm_match_pairs(ctx, st, pair, 1, &prm, &res, nullptr);
+  }
+  if (rc == OSFM_OK) {
+    int n = 0;
+    for (int k = 0; k < res->counts[0]; ++k) {
+      const int i = res->matches[2 * k], j = res->matches[2 * k + 1];
+      if (i >= nA) continue;  // the copy of a lone query
       if (n < cap) {
         out_pairs[2 * n] = i;
         out_pairs[2 * n + 1] = j;

@@ -60,6 +60,7 @@ struct GDev {
   // observations, point-major
   const int *o_shot, *o_point;
   const double *o_x, *o_y, *o_sigma;
+  const unsigned char *o_kind;                // null, or per row: 0 = reprojection, 1 = depth prior on z, 2 = radial depth prior (o_x = depth, o_sigma = its sd)
   const long *pt_off;                         // P + 1
   double *J;                                  // M x kRowJ: corrected residual and Jacobian rows
   // points
@@ -133,7 +134,22 @@ __device__ void reproj_eval(const GDev &d, const double *cam, const double *rcp,
   // d residual / d Xc (nres x 3) and / d camera parameters
   double A[9], K[48];
   const double is = 1.0 / d.o_sigma[o];
-  if (model == OSFM_CAMERA_SPHERICAL) {  // ReprojectionError3D: unit bearing minus the observed bearing
+  const int kind = d.o_kind ? d.o_kind[o] : 0;
+  if (kind != 0) {  // RelativeDepthError (relative_depth_error.h:21-39): (depth in the camera - depth) / sd, on [instance | rig camera | point]
+    nres = 1;
+    const double n = sqrt(Xc[0] * Xc[0] + Xc[1] * Xc[1] + Xc[2] * Xc[2]);
+    res[0] = is * ((kind == 2 ? n : Xc[2]) - d.o_x[o]);
+    res[1] = res[2] = 0.0;
+    if (JAC) {
+      for (int e = 0; e < 9; e++) A[e] = 0.0;
+      if (kind == 2) {
+        for (int e = 0; e < 3; e++) A[e] = is * Xc[e] / n;
+      } else {
+        A[2] = is;
+      }
+      for (int e = 0; e < 48; e++) K[e] = 0.0;
+    }
+  } else if (model == OSFM_CAMERA_SPHERICAL) {  // ReprojectionError3D: unit bearing minus the observed bearing
     nres = 3;
     const double n2 = Xc[0] * Xc[0] + Xc[1] * Xc[1] + Xc[2] * Xc[2], n = sqrt(n2);
     const double lon = d.o_x[o] * 2 * M_PI, lat = -d.o_y[o] * 2 * M_PI;
@@ -232,7 +248,7 @@ __global__ void g_reproj_kernel(GDev d, double *out) {
   double res[3], dummy[1];
   int nres;
   reproj_eval<false>(d, d.cam, d.rc, d.inst, d.pts, o, res, nres, dummy, dummy, dummy, dummy);
-  const double sg = d.o_sigma[o];
+  const double sg = (d.o_kind && d.o_kind[o]) ? 0.0 : d.o_sigma[o];  // depth-prior rows are not reprojection errors
   for (int e = 0; e < 3; e++) out[3 * o + e] = res[e] * sg;
 }
 
@@ -869,8 +885,17 @@ extern "C" int osfm_bundle_solve(osfm_ctx *ctx, osfm_bundle_problem *P, const os
   OSFM_REQUIRE(ctx && P && O && Rp, OSFM_E_INVALID, "osfm_bundle_solve: null argument");
   memset(Rp, 0, sizeof(*Rp));
   const int NC = P->n_cameras, NR = P->n_rig_cameras, NI = P->n_rig_instances, S = P->n_shots, NP = P->n_points;
-  const long M = P->n_obs;
-  OSFM_REQUIRE(NC > 0 && NR > 0 && NI > 0 && S > 0 && NP >= 0 && M >= 0, OSFM_E_INVALID, "osfm_bundle_solve: empty problem");
+  const long M0 = P->n_obs;  // reprojection observations; M below also counts the depth-prior rows
+  OSFM_REQUIRE(NC > 0 && NR > 0 && NI > 0 && S > 0 && NP >= 0 && M0 >= 0, OSFM_E_INVALID, "osfm_bundle_solve: empty problem");
+  // depth priors become rows of their own (kind 1 / 2) behind the observation they belong to: same parameter blocks, one residual
+  std::vector<long> depth_obs;
+  if (P->obs_depth && P->obs_depth_sigma)
+    for (long o = 0; o < M0; o++)
+      if (P->obs_depth_sigma[o] > 0) {
+        OSFM_REQUIRE(std::isfinite(P->obs_depth[o]), OSFM_E_INVALID, "observation %ld (shot %d) has non-finite depth prior", o, P->obs_shot ? P->obs_shot[o] : -1);
+        depth_obs.push_back(o);
+      }
+  const long M = M0 + (long)depth_obs.size();
   OSFM_REQUIRE(P->cam_model && P->cam_params && P->cam_prior && P->cam_sigma && P->cam_fixed && P->rig_camera_pose && P->rig_camera_fixed &&
                    P->rig_instance_pose && P->shot_rig_instance && P->shot_rig_camera && P->shot_camera && (NP == 0 || P->points) &&
                    (M == 0 || (P->obs_shot && P->obs_point && P->obs_xy && P->obs_sigma)),
@@ -882,7 +907,7 @@ extern "C" int osfm_bundle_solve(osfm_ctx *ctx, osfm_bundle_problem *P, const os
     OSFM_REQUIRE(P->shot_rig_instance[s] >= 0 && P->shot_rig_instance[s] < NI && P->shot_rig_camera[s] >= 0 && P->shot_rig_camera[s] < NR &&
                      P->shot_camera[s] >= 0 && P->shot_camera[s] < NC,
                  OSFM_E_INVALID, "shot %d references a missing rig instance / rig camera / camera", s);
-  for (long o = 0; o < M; o++)
+  for (long o = 0; o < M0; o++)
     OSFM_REQUIRE(P->obs_shot[o] >= 0 && P->obs_shot[o] < S && P->obs_point[o] >= 0 && P->obs_point[o] < NP && P->obs_sigma[o] > 0, OSFM_E_INVALID,
                  "observation %ld is out of range", o);
   if (P->rig_instance_gps && P->rig_instance_gps_sigma)
@@ -933,20 +958,30 @@ extern "C" int osfm_bundle_solve(osfm_ctx *ctx, osfm_bundle_problem *P, const os
                "osfm_bundle_solve: %d reduced unknowns need a dense system beyond the device memory; use osfm_ba_solve for sequences of this size", nred);
 
   // ---- observations point-major ----
+  // row -> (source observation, kind); rows M0 .. M - 1 are the depth priors
+  auto src_of = [&](long o) { return o < M0 ? o : depth_obs[(size_t)(o - M0)]; };
   std::vector<long> pt_off((size_t)NP + 1, 0);
-  for (long o = 0; o < M; o++) pt_off[(size_t)P->obs_point[o] + 1]++;
+  for (long o = 0; o < M; o++) pt_off[(size_t)P->obs_point[src_of(o)] + 1]++;
   for (int p = 0; p < NP; p++) pt_off[(size_t)p + 1] += pt_off[(size_t)p];
   std::vector<long> fill(pt_off.begin(), pt_off.end() - 1), perm((size_t)M);
-  for (long o = 0; o < M; o++) perm[(size_t)fill[(size_t)P->obs_point[o]]++] = o;
+  for (long o = 0; o < M; o++) perm[(size_t)fill[(size_t)P->obs_point[src_of(o)]]++] = o;
   std::vector<int> o_shot((size_t)M), o_point((size_t)M);
   std::vector<double> o_x((size_t)M), o_y((size_t)M), o_sigma((size_t)M);
+  std::vector<unsigned char> o_kind((size_t)M, 0);
   for (long k = 0; k < M; k++) {
-    const long o = perm[(size_t)k];
-    o_shot[(size_t)k] = P->obs_shot[o];
-    o_point[(size_t)k] = P->obs_point[o];
-    o_x[(size_t)k] = P->obs_xy[2 * o];
-    o_y[(size_t)k] = P->obs_xy[2 * o + 1];
-    o_sigma[(size_t)k] = P->obs_sigma[o];
+    const long o = perm[(size_t)k], so = src_of(o);
+    o_shot[(size_t)k] = P->obs_shot[so];
+    o_point[(size_t)k] = P->obs_point[so];
+    if (o < M0) {
+      o_x[(size_t)k] = P->obs_xy[2 * o];
+      o_y[(size_t)k] = P->obs_xy[2 * o + 1];
+      o_sigma[(size_t)k] = P->obs_sigma[o];
+    } else {
+      o_x[(size_t)k] = P->obs_depth[so];
+      o_y[(size_t)k] = 0.0;
+      o_sigma[(size_t)k] = P->obs_depth_sigma[so];
+      o_kind[(size_t)k] = (!P->obs_depth_radial || P->obs_depth_radial[so]) ? 2 : 1;
+    }
   }
 
   Arena A;
@@ -1002,6 +1037,7 @@ extern "C" int osfm_bundle_solve(osfm_ctx *ctx, osfm_bundle_problem *P, const os
   d.o_x = A.upload(o_x.data(), (size_t)M, st);
   d.o_y = A.upload(o_y.data(), (size_t)M, st);
   d.o_sigma = A.upload(o_sigma.data(), (size_t)M, st);
+  d.o_kind = depth_obs.empty() ? nullptr : A.upload(o_kind.data(), (size_t)M, st);
   d.pt_off = A.upload(pt_off.data(), (size_t)NP + 1, st);
   d.J = A.alloc<double>((size_t)M * kRowJ);
   d.Hpp = A.alloc<double>((size_t)NP * 6); d.gpt = A.alloc<double>((size_t)NP * 3); d.Hhat = A.alloc<double>((size_t)NP * 6);
@@ -1152,7 +1188,8 @@ extern "C" int osfm_bundle_solve(osfm_ctx *ctx, osfm_bundle_problem *P, const os
     OSFM_HIP(hipMemcpyAsync(e.data(), d_err, (size_t)M * 3 * sizeof(double), hipMemcpyDeviceToHost, st));
     OSFM_HIP(hipStreamSynchronize(st));
     for (long k = 0; k < M; k++)
-      for (int a = 0; a < 3; a++) P->reproj_err[3 * perm[(size_t)k] + a] = e[(size_t)(3 * k + a)];
+      if (perm[(size_t)k] < M0)  // the depth-prior rows have no reprojection error
+        for (int a = 0; a < 3; a++) P->reproj_err[3 * perm[(size_t)k] + a] = e[(size_t)(3 * k + a)];
   }
   OSFM_HIP(hipStreamSynchronize(st));
   Rp->seconds_teardown = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_tear).count();

@@ -233,6 +233,7 @@ struct GuidedPairsArgs {
   const int32_t *counts;
   const float *bearings;  // store rows (tile * 32 + row) x 3, float32 as the reference's bearings
   const float *descf;     // float store: rows (tile * 32 + row) x 128 (null for an integer store)
+  const float *seg;       // segmentation column (129th descriptor dimension) per row, or null
   const int32_t *pairs;
   const double *poses;  // n_pairs x 12: R (row-major) and t of the relative pose
   long n_pairs;
@@ -297,6 +298,8 @@ __device__ __forceinline__ void guided_pairs_match_body(const GuidedPairsArgs &a
   const float *descQ = FLT ? a.descf + a.tile_off[imgQ] * (long)(32 * 128) : nullptr;
   const float *descT = FLT ? a.descf + a.tile_off[imgT] * (long)(32 * 128) : nullptr;
   const int nqn = (a.norms + a.tile_off[imgQ] * 32)[qs];
+  const float *segT = a.seg ? a.seg + a.tile_off[imgT] * 32 : nullptr;
+  const float segq = a.seg ? (a.seg + a.tile_off[imgQ] * 32)[qs] : 0.f;
   v4i_g av[8];  // the query's descriptor stays in registers
   {
     const int8_t *pa = tilesQ + (long)(qs >> 5) * OSFM_TILE_BYTES + (qs & 31) * 16;
@@ -376,7 +379,13 @@ __device__ __forceinline__ void guided_pairs_match_body(const GuidedPairsArgs &a
             s1 = __builtin_amdgcn_sdot4(av[k + 1][e], bv[k + 1][e], s1, false);
           }
         const int d2 = nqn + normT[j] - 2 * (s0 + s1);
-        top2_insert(t, sqrtf((float)d2), j);
+        float d2f = (float)d2;
+        if (segT) {  // matching_use_segmentation: the 129th dimension, added as cv2's scalar tail does (match.hip exact_direction)
+          const float ts = segq - segT[j];
+          const float tt = ts * ts;
+          d2f = d2f + tt;
+        }
+        top2_insert(t, sqrtf(d2f), j);
       }
     }
   }
@@ -461,6 +470,7 @@ int osfm_launch_guided_pairs(osfm_ctx *ctx, const osfm_store *store, const OsfmG
                              double *d_six, int32_t *d_good, hipStream_t stream) {
   if (n_pairs == 0) return OSFM_OK;
   OSFM_REQUIRE(n_pairs <= 65535, OSFM_E_INVALID, "guided chunk of %lld pairs", (long long)n_pairs);
+  OSFM_REQUIRE(!store->is_binary, OSFM_E_UNSUPPORTED, "guided matching on a binary (Hamming) store is not on the GPU path");
   GuidedPairsArgs a;
   a.tiles = store->d_tiles;
   a.norms = store->d_norms;
@@ -468,6 +478,7 @@ int osfm_launch_guided_pairs(osfm_ctx *ctx, const osfm_store *store, const OsfmG
   a.counts = store->d_counts;
   a.bearings = gs.d_bearings;
   a.descf = store->is_float ? store->d_descf : nullptr;
+  a.seg = store->d_seg;
   a.pairs = d_pairs;
   a.poses = d_poses;
   a.n_pairs = n_pairs;

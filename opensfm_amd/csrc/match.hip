@@ -90,6 +90,10 @@ struct MatchArgs {
   uint32_t *out_matches;
   int32_t *out_flags;
   long pad_tile;            // index of the store's first slack tile
+  // read by the exact / Hamming kernels only; kept behind the fused kernel's arguments so that its kernarg layout (and with it the
+  // register allocation tests/test_kernel_budgets.py pins) does not move
+  const uint32_t *bin;  // binary store: 16 dwords per row (tile * 32 + r)
+  const float *seg;     // segmentation column (129th descriptor dimension, label x 35) per row, or null
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -829,11 +833,12 @@ __device__ __forceinline__ void load_row(const int8_t *tiles, int row, v4i out[8
 
 __device__ void exact_direction(const int8_t *tilesQ, const int32_t *normQ, int nQ, const int8_t *tilesT,
                                 const int32_t *normT, int nT, double ratio, int tid, int *res_int,
-                                unsigned short *res_u16) {
+                                unsigned short *res_u16, const float *segQ, const float *segT) {
   for (int q = tid; q < nQ; q += kThreads) {
     v4i qa[8];
     load_row(tilesQ, q, qa);
     const int nq = normQ[q];
+    const float sq = segQ ? segQ[q] : 0.f;
     float bd0 = INFINITY, bd1 = INFINITY;
     int bi0 = kNone;
     for (int t = 0; t < nT; ++t) {
@@ -845,7 +850,13 @@ __device__ void exact_direction(const int8_t *tilesQ, const int32_t *normQ, int 
 #pragma unroll
         for (int e = 0; e < 4; ++e) sdot = __builtin_amdgcn_sdot4(qa[k][e], ta[k][e], sdot, false);
       const int d2i = nq + normT[t] - 2 * sdot;
-      const float d = ratio < 0.0 ? (float)d2i : sqrtf((float)d2i);  // squared mode: FLANN reports and compares squared distances
+      float d2f = (float)d2i;  // exact: < 2^24
+      if (segQ) {  // the 129th dimension as cv2's normL2Sqr_ adds it: the scalar tail after the vector blocks, d += t * t (no contraction)
+        const float ts = sq - segT[t];
+        const float tt = ts * ts;
+        d2f = d2f + tt;
+      }
+      const float d = ratio < 0.0 ? d2f : sqrtf(d2f);  // squared mode: FLANN reports and compares squared distances
       if (d < bd1) {  // cv2 batchDistance K=2 insertion
         if (bd0 > d) {
           bd1 = bd0;
@@ -882,8 +893,9 @@ __global__ void __launch_bounds__(kThreads) match_exact_kernel(MatchArgs a, int 
   const int8_t *tilesR = a.tiles + a.tile_off[imgR] * OSFM_TILE_BYTES;
   const int32_t *normC = a.norms + a.tile_off[imgC] * 32;
   const int32_t *normR = a.norms + a.tile_off[imgR] * 32;
-  exact_direction(tilesC, normC, nC, tilesR, normR, nR, a.ratio, tid, colBI, nullptr);
-  if (a.symmetric) exact_direction(tilesR, normR, nR, tilesC, normC, nC, a.ratio, tid, nullptr, rowres);
+  const float *segC = a.seg ? a.seg + a.tile_off[imgC] * 32 : nullptr, *segR = a.seg ? a.seg + a.tile_off[imgR] * 32 : nullptr;
+  exact_direction(tilesC, normC, nC, tilesR, normR, nR, a.ratio, tid, colBI, nullptr, segC, segR);
+  if (a.symmetric) exact_direction(tilesR, normR, nR, tilesC, normC, nC, a.ratio, tid, nullptr, rowres, segR, segC);
   __syncthreads();
   emit_matches(a, p, nC, colBI, rowres, misc, tid, qs);
 }
@@ -994,6 +1006,79 @@ __global__ void __launch_bounds__(kThreads) match_float_kernel(MatchArgs a) {
   emit_matches(a, p, nC, colBI, rowres, misc, tid, qs);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Hamming kernel: binary descriptors (uint8 bit strings; matching.py:737-740 switches cv2 to BruteForce-Hamming).  cv2's batchDistance
+// with NORM_HAMMING gives int distances, the same K = 2 insertion (strict <, lowest index first among equals) and DMatch.distance =
+// float(int); Lowe's test in doubles (matching.py:752).  Integer work, no matrix cores: one thread per query with its 512 bits in 16
+// registers, the targets staged through LDS 256 rows at a time and read as broadcasts, v_bcnt_u32_b32 (popcount + add) per dword.
+// ---------------------------------------------------------------------------------------------
+constexpr int kHamStageRows = 256;
+
+__device__ void hamming_direction(const uint32_t *binQ, int nQ, const uint32_t *binT, int nT, double ratio, int tid, uint32_t *stage, int *res_int,
+                                  unsigned short *res_u16) {
+  for (int q0 = 0; q0 < nQ; q0 += kThreads) {
+    const int q = q0 + tid;
+    const bool live = q < nQ;
+    uint4 qa[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) qa[k] = live ? *(const uint4 *)(binQ + (size_t)q * 16 + 4 * k) : make_uint4(0u, 0u, 0u, 0u);
+    int bd0 = 0x7fffffff, bd1 = 0x7fffffff, bi0 = kNone;
+    for (int t0 = 0; t0 < nT; t0 += kHamStageRows) {
+      const int nt = min(kHamStageRows, nT - t0);
+      __syncthreads();
+      for (int k = tid; k < nt * 4; k += kThreads) *(uint4 *)(stage + 4 * k) = *(const uint4 *)(binT + (size_t)t0 * 16 + 4 * k);
+      __syncthreads();
+      for (int t = 0; t < nt; ++t) {
+        const uint4 *b = (const uint4 *)(stage + t * 16);
+        int d = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint4 c = b[k];
+          d += __popc(qa[k].x ^ c.x) + __popc(qa[k].y ^ c.y) + __popc(qa[k].z ^ c.z) + __popc(qa[k].w ^ c.w);
+        }
+        if (d < bd1) {  // cv2 batchDistance K = 2 insertion
+          if (bd0 > d) {
+            bd1 = bd0;
+            bd0 = d;
+            bi0 = t0 + t;
+          } else {
+            bd1 = d;
+          }
+        }
+      }
+    }
+    if (live) {
+      const bool ok = (double)(float)bd0 < ratio * (double)(float)bd1;  // DMatch.distance is float32 of the int; nT >= 2: both are set
+      const int v = ok ? bi0 : kNone;
+      if (res_int) res_int[q] = v;
+      if (res_u16) res_u16[q] = (unsigned short)v;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kThreads) match_hamming_kernel(MatchArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint32_t *stage = (uint32_t *)smem;  // kHamStageRows target rows
+  int *colBI = (int *)(stage + kHamStageRows * 16);
+  unsigned short *rowres = (unsigned short *)(colBI + a.ncap);
+  int *misc = (int *)(rowres + a.ncap);
+  const int tid = threadIdx.x;
+  const long p = blockIdx.x;
+  if (tid == 0 && a.out_flags) a.out_flags[p] = 0;
+  const int imgC = a.pairs[2 * p], imgR = a.pairs[2 * p + 1];
+  const int nC = a.counts[imgC], nR = a.counts[imgR];
+  if (nC < 2 || nR < 2) {
+    if (tid == 0) a.out_counts[p] = 0;
+    return;
+  }
+  const uint32_t *binC = a.bin + a.tile_off[imgC] * (32 * 16);
+  const uint32_t *binR = a.bin + a.tile_off[imgR] * (32 * 16);
+  hamming_direction(binC, nC, binR, nR, a.ratio, tid, stage, colBI, nullptr);
+  if (a.symmetric) hamming_direction(binR, nR, binC, nC, a.ratio, tid, stage, nullptr, rowres);
+  __syncthreads();
+  emit_matches(a, p, nC, colBI, rowres, misc, tid, false);
+}
+
 }  // namespace
 
 size_t osfm_match_lds_bytes(int ncap) { return (size_t)2 * kChunkBytes4 + 2 * kChunkCols4 * 4 + 64 + (size_t)ncap * 6; }
@@ -1005,6 +1090,7 @@ static int ensure_kernel_attributes(int device) {
     OSFM_HIP(hipFuncSetAttribute((const void *)match_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     OSFM_HIP(hipFuncSetAttribute((const void *)match_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     OSFM_HIP(hipFuncSetAttribute((const void *)match_float_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    OSFM_HIP(hipFuncSetAttribute((const void *)match_hamming_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return OSFM_OK;
   });
 }
@@ -1019,6 +1105,8 @@ int osfm_launch_match(osfm_ctx *ctx, const osfm_store *store, const int32_t *d_p
   a.hneg = store->d_hneg;
   a.descf = store->d_descf;
   a.qerr = store->d_qerr;
+  a.seg = store->d_seg;
+  a.bin = store->d_bin;
   a.tile_off = store->d_tile_off;
   a.counts = store->d_counts;
   a.pairs = d_pairs;
@@ -1041,7 +1129,19 @@ int osfm_launch_match(osfm_ctx *ctx, const osfm_store *store, const int32_t *d_p
     const int rc = ensure_kernel_attributes(ctx->device);
     if (rc != OSFM_OK) return rc;
   }
-  if (store->is_float) {
+  if (store->is_binary) {
+    // bit strings: Hamming distance on the VALU, every pair in one launch; nothing is ever flagged for a second run
+    OSFM_REQUIRE(!squared_ratio, OSFM_E_UNSUPPORTED, "matcher_type FLANN on binary descriptors (cv2's LSH index) is not on the GPU path");
+    if (exact_kernel && d_flags != nullptr) return OSFM_OK;
+    const size_t lds = (size_t)kHamStageRows * 64 + (size_t)a.ncap * 6 + 64;
+    hipLaunchKernelGGL(match_hamming_kernel, dim3((unsigned)n_pairs), dim3(kThreads), lds, stream, a);
+  } else if (store->d_seg) {
+    // segmentation column: every pair on the exact kernel with the label term (the int8 matrix path has no 129th dimension)
+    if (exact_kernel && d_flags != nullptr) return OSFM_OK;  // "re-run the flagged pairs": none, the first launch was exact
+    if (d_flags) OSFM_HIP(hipMemsetAsync(d_flags, 0, (size_t)n_pairs * sizeof(int32_t), stream));
+    const size_t lds = (size_t)a.ncap * 6 + 64;
+    hipLaunchKernelGGL(match_exact_kernel, dim3((unsigned)n_pairs), dim3(kThreads), lds, stream, a, 0);
+  } else if (store->is_float) {
     // float store: the fused kernel on the 8-bit quantisation with rigorous bounds and float evaluation of what they leave open
     // (FQ mode); the exact float kernel for every pair when asked for (cross-check) or when the store could not be quantised.
     // Nothing is ever flagged for a second run: out_flags then counts the queries that went through the float evaluation.

@@ -85,6 +85,10 @@ struct osfm_store {
                                     // quantisation x^ = round((v - lo) * 255 / (hi - lo)) - 128 whose distances BOUND the float ones (match.hip)
   bool quantised = false;           // float store with a usable quantisation (finite values, sane dynamic range): fused kernel, FQ mode
   float *d_qerr = nullptr;          // float store: per image max_row ||x - x^||_2 in quantised units, rounded up (n_images + 1)
+  uint32_t *d_bin = nullptr;        // binary store (AKAZE MLDB / ORB bit strings, matched by Hamming distance): 16 dwords per row
+                                    // (tile * 32 + r), rows shorter than 64 bytes and padding rows zero-filled
+  bool is_binary = false;
+  float *d_seg = nullptr;           // matching_use_segmentation: the 129th descriptor column (label x 35) per row (tile * 32 + r), padding 0
   double *d_pts = nullptr;          // total_tiles * 32 * 2 (padded rows zero)
   int32_t *d_counts = nullptr;      // n_images
   int64_t *d_tile_off = nullptr;    // n_images + 1

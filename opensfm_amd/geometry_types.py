@@ -273,10 +273,18 @@ class ShotMeasurements:
         self.gps_accuracy = gps_accuracy
 
 
+class Depth:
+    """``map::Depth`` (map/observation.h:10-18): the depth prior of an observation"""
+
+    def __init__(self, value: float, is_radial: bool, std_deviation: float):
+        self.value, self.is_radial, self.std_deviation = float(value), bool(is_radial), float(std_deviation)
+
+
 class Observation:
-    def __init__(self, x: float, y: float, scale: float):
+    def __init__(self, x: float, y: float, scale: float, depth_prior: Optional[Depth] = None):
         self.point = np.array([x, y], float)
         self.scale = float(scale)
+        self.depth_prior = depth_prior  # map::Observation::depth_prior (observation.h:50)
 
 
 class RigCamera:

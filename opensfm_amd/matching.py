@@ -63,12 +63,28 @@ def _fptr(a: np.ndarray, t):
 # --------------------------------------------------------------------------------------------
 # leaf functions (drop-ins)
 # --------------------------------------------------------------------------------------------
+def _match_hamming_leaf(f1: np.ndarray, f2: np.ndarray, ratio: float, symmetric: bool, ctx=None) -> np.ndarray:
+    """uint8 bit strings (AKAZE MLDB, ORB): cv2's BruteForce-Hamming branch of match_brute_force (matching.py:737-740)"""
+    ctx = ctx or default_context()
+    a, b = np.ascontiguousarray(f1, np.uint8), np.ascontiguousarray(f2, np.uint8)
+    if a.ndim != 2 or b.ndim != 2 or a.shape[1] != b.shape[1]:
+        raise ValueError("binary descriptors must be two (n, width) uint8 arrays of the same width")
+    cap = max(1, min(len(a), len(b)) if symmetric else len(a))
+    out = np.empty((cap, 2), np.int32)
+    n = C.c_int(0)
+    check(_lib.load().osfm_match_hamming_ratio(ctx.handle, _fptr(a, C.c_uint8), len(a), _fptr(b, C.c_uint8), len(b), a.shape[1], float(ratio),
+                                               int(symmetric), _fptr(out, C.c_int32), cap, C.byref(n)), "osfm_match_hamming_ratio")
+    return out[: n.value]
+
+
 def _match_leaf(f1: np.ndarray, f2: np.ndarray, ratio: float, symmetric: bool, ctx=None, flags: int = 0) -> np.ndarray:
     assert f1.dtype.type == f2.dtype.type  # matching.py:737
     if f1.dtype.type == np.uint8:
         # matching.py:738-739: uint8 descriptors switch cv2 to Hamming; never reached by HAHOG/SIFT
         # (descriptors are float32 after loading, features.py:259-262)
-        raise NotImplementedError("uint8 descriptors take the reference's BruteForce-Hamming branch")
+        if flags & _lib.MATCH_SQUARED_RATIO:
+            raise NotImplementedError("FLANN semantics on binary descriptors (cv2's LSH index) are not on the GPU path")
+        return _match_hamming_leaf(f1, f2, ratio, symmetric, ctx)
     ctx = ctx or default_context()
     lib = _lib.load()
     a = np.ascontiguousarray(f1, np.float32)
@@ -334,12 +350,18 @@ class DescriptorStore:
 
     Replaces ``FeatureLoader.load_all_data`` + its LRU caches (``feature_loading.py:106-173``).
     ``descriptors``: list of (n_i, 128) arrays, float32 (integer-valued: exact int8 path; otherwise, e.g. root-SIFT: quantised
-    candidates + float32 evaluation, same results) or uint8;
+    candidates + float32 evaluation, same results) or uint8; or (n_i, 129) float32 arrays -- 128 integer-valued columns and the
+    segmentation column ``feature_loading.py:123-155`` appends (``matching_use_segmentation``): such a store is matched on the exact
+    kernel with the label term added in float32 where cv2 adds a 129th element;
     ``points``: list of (n_i, >=2) arrays (normalized image coordinates, ``features.py:324-331``).
     """
 
-    def __init__(self, descriptors: Sequence[np.ndarray], points: Sequence[np.ndarray], ctx=None):
+    def __init__(self, descriptors: Sequence[np.ndarray], points: Sequence[np.ndarray], ctx=None, hamming: bool = False):
+        """``hamming``: the descriptors are uint8 bit strings (AKAZE MLDB, ORB; 1..64 bytes wide) to be matched by Hamming distance,
+        as ``match_brute_force`` does for uint8 arrays (``matching.py:737-740``).  Without it a uint8 array is taken as 128 integer
+        VALUES (HAHOG uchar files, which the reference converts to float32 when it loads them, ``features.py:169-170``)."""
         self.ctx = ctx or default_context()
+        self.hamming = bool(hamming)
         lib = _lib.load()
         counts = np.asarray([len(d) for d in descriptors], np.int32)
         self.counts = counts
@@ -352,6 +374,33 @@ class DescriptorStore:
         pts = np.zeros((max(total, 1), 2), np.float64)
         if total:
             pts[:total] = np.concatenate([np.asarray(p, np.float64)[:, :2].reshape(-1, 2) for p in points])
+        widths = {np.asarray(d).shape[1] for d in descriptors if np.asarray(d).ndim == 2 and len(d)}
+        seg = None
+        if hamming:
+            if len(widths) > 1 or any(np.asarray(d).dtype != np.uint8 for d in descriptors if len(d)):
+                lib.osfm_store_destroy(h)
+                self.handle = None
+                raise ValueError("hamming=True takes uint8 descriptors of one width")
+            w = widths.pop() if widths else 32
+            desc = np.zeros((max(total, 1), w), np.uint8)
+            if total:
+                desc[:total] = np.concatenate([np.asarray(d, np.uint8).reshape(-1, w) for d in descriptors])
+            rc = lib.osfm_store_upload_binary(h, _fptr(desc, C.c_uint8), int(w), _fptr(pts, C.c_double))
+            if rc != 0:
+                msg = lib.osfm_last_error().decode()
+                lib.osfm_store_destroy(h)
+                self.handle = None
+                raise OsfmError(f"osfm_store_upload_binary failed ({rc}): {msg}")
+            return
+        if widths == {129}:  # segmentation in the descriptor: the last column goes into the store's label array
+            seg = np.zeros(max(total, 1), np.float32)
+            if total:
+                seg[:total] = np.concatenate([np.asarray(d, np.float32).reshape(-1, 129)[:, 128] for d in descriptors])
+            descriptors = [np.asarray(d, np.float32).reshape(-1, 129)[:, :128] for d in descriptors]
+        elif widths - {128}:
+            lib.osfm_store_destroy(h)
+            self.handle = None
+            raise ValueError(f"descriptors must all be 128 wide, or all 129 wide (segmentation column): got widths {sorted(widths)}")
         all_u8 = all(np.asarray(d).dtype == np.uint8 for d in descriptors)
         if all_u8:
             desc = np.zeros((max(total, 1), 128), np.uint8)
@@ -363,6 +412,8 @@ class DescriptorStore:
             if total:
                 desc[:total] = np.concatenate([np.asarray(d, np.float32).reshape(-1, 128) for d in descriptors])
             rc = lib.osfm_store_upload_f32(h, _fptr(desc, C.c_float), _fptr(pts, C.c_double))
+        if rc == 0 and seg is not None:
+            rc = lib.osfm_store_set_segmentation(h, _fptr(seg, C.c_float))
         if rc != 0:
             msg = lib.osfm_last_error().decode()
             lib.osfm_store_destroy(h)
@@ -370,10 +421,10 @@ class DescriptorStore:
             raise OsfmError(f"osfm_store_upload failed ({rc}): {msg}")
 
     @classmethod
-    def from_packed(cls, desc: np.ndarray, pts: np.ndarray, offsets: np.ndarray, ctx=None) -> "DescriptorStore":
+    def from_packed(cls, desc: np.ndarray, pts: np.ndarray, offsets: np.ndarray, ctx=None, hamming: bool = False) -> "DescriptorStore":
         ds = [desc[offsets[i]: offsets[i + 1]] for i in range(len(offsets) - 1)]
         ps = [pts[offsets[i]: offsets[i + 1]] for i in range(len(offsets) - 1)]
-        return cls(ds, ps, ctx)
+        return cls(ds, ps, ctx, hamming)
 
     @property
     def device_bytes(self) -> int:
@@ -575,6 +626,17 @@ def split_matches(counts: np.ndarray, matches: np.ndarray) -> List[np.ndarray]:
 # ad-hoc filters (``matching_use_filters``, matching.py:939-1064): per-match predicates on the keypoints between the descriptor stage and
 # the gates / robust stage -- host numpy, as in the reference (a few hundred matches per pair)
 # --------------------------------------------------------------------------------------------
+SEGMENTATION_IN_DESCRIPTOR_MULT = 35  # feature_loading.py:16-18
+
+
+def _segmentation_of(features_data):
+    """FeaturesData.get_segmentation (features.py:74-80): the per-feature class labels, or None"""
+    if hasattr(features_data, "get_segmentation"):
+        return features_data.get_segmentation()
+    semantic = getattr(features_data, "semantic", None)
+    return getattr(semantic, "segmentation", None) if semantic else None
+
+
 def _is_panorama(projection_type: str) -> bool:
     return projection_type in ("equirectangular", "spherical")  # pygeometry.Camera.is_panorama
 
@@ -647,8 +709,13 @@ def match_images_with_pairs(data, config_override: Dict[str, Any], exifs: Dict[s
     use_words = str(_cfg(config, "matcher_type")).upper() == "WORDS" and not poses
     if not use_words and not poses:
         _matcher_flags(config)  # raises for matchers that are not on the GPU path
-    if config.get("matching_use_segmentation"):  # matching.py:352: segmentation labels inside the descriptors: not implemented here
-        raise NotImplementedError("config 'matching_use_segmentation' is not implemented on the GPU path")
+    # matching.py:281,356 + feature_loading.py:118-155: the segmentation label of every feature as a 129th descriptor column
+    use_segmentation = bool(config.get("matching_use_segmentation"))
+    if use_segmentation:
+        if not config.get("hahog_normalize_to_uchar") or config.get("feature_type") != "HAHOG":
+            raise RuntimeError("Semantic segmentation in descriptor only supported for HAHOG UCHAR descriptors")  # feature_loading.py:126-133
+        if use_words:
+            raise NotImplementedError("matcher_type WORDS with matching_use_segmentation is not on the GPU path (the resident WordsStore holds 128-D rows)")
     use_filters = bool(config.get("matching_use_filters"))
     lmeds_reachable = int(_cfg(config, "robust_matching_min_match")) < 15
 
@@ -683,6 +750,13 @@ def match_images_with_pairs(data, config_override: Dict[str, Any], exifs: Dict[s
                 points, desc = points[mask], desc[mask]
             if len(points) < 2:  # the masked set decides (load_all_data(masked=True), matching.py:354-366)
                 points, desc = np.zeros((0, 3)), np.zeros((0, 128), np.float32)
+            elif use_segmentation:  # FeatureLoader._add_segmentation_in_descriptor (feature_loading.py:123-155), on the masked set
+                seg = _segmentation_of(fd)
+                if seg is not None:
+                    seg = np.asarray(seg)
+                    seg = seg[mask] if mask is not None else seg
+                    desc = np.concatenate((np.asarray(desc, np.float32), (np.array([seg]).T).astype(np.float32)), axis=1)
+                    desc[:, -1] *= SEGMENTATION_IN_DESCRIPTOR_MULT
         if len(points) > _lib.MAX_FEATURES:
             raise NotImplementedError(f"image {im} has {len(points)} features after masking; the GPU path holds at most "
                                       f"{_lib.MAX_FEATURES} per image (OSFM_MAX_FEATURES)")
@@ -702,6 +776,15 @@ def match_images_with_pairs(data, config_override: Dict[str, Any], exifs: Dict[s
             wordlists.append(w)
     ipairs = np.asarray([(index[a], index[b]) for a, b in pairs], np.int32).reshape(-1, 2)
     per_pair: List[np.ndarray] = [np.zeros((0, 2), np.int32)] * len(ipairs)
+    # uint8 descriptors (AKAZE MLDB, ORB): match_brute_force takes cv2's BruteForce-Hamming branch (matching.py:737-740); the data set hands
+    # HAHOG uchar descriptors over as float32 (features.py:169-170), like the reference's loader
+    live = [np.asarray(d) for d in descs if len(d)]
+    hamming = bool(live) and all(d.dtype == np.uint8 for d in live)
+    if hamming and (poses or use_words or use_segmentation or _matcher_flags(config) & _lib.MATCH_SQUARED_RATIO):
+        raise NotImplementedError("binary (uint8) descriptors are on the GPU path for matcher_type BRUTEFORCE without poses / segmentation")
+    if hamming:
+        width = live[0].shape[1]
+        descs = [np.asarray(d, np.uint8).reshape(-1, width) if len(d) else np.zeros((0, width), np.uint8) for d in descs]
     if poses:  # guided matching (matching.py:204-207,260-337,576-634): every pair in one osfm_match_pairs_guided call per robust branch
         ctx = default_context()
         bearings = [pixel_bearing_many(cams[k], np.asarray(pts[k], np.float64)[:, :2], ctx) if len(pts[k]) else np.zeros((0, 3))
@@ -749,7 +832,7 @@ def match_images_with_pairs(data, config_override: Dict[str, Any], exifs: Dict[s
             if len(rm) >= min_match and len(rm) > 0:
                 per_pair[p] = rm.astype(np.int32)
     else:
-        store = DescriptorStore(descs, pts)  # all descriptors resident in HBM for the batched launches
+        store = DescriptorStore(descs, pts, hamming=hamming)  # all descriptors resident in HBM for the batched launches
         try:
             pin = np.array([_is_pinhole(cams[a]) and _is_pinhole(cams[b]) for a, b in ipairs], bool)
             if not use_filters:

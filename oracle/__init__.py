@@ -224,6 +224,23 @@ def match_brute_force_symmetric(fi: np.ndarray, fj: np.ndarray, ratio: float = 0
     return out[:n].copy()
 
 
+def match_hamming(f1: np.ndarray, f2: np.ndarray, ratio: float = 0.8, symmetric: bool = False) -> np.ndarray:
+    """``match_brute_force[_symmetric]`` on uint8 bit strings (``matching.py:737-740``: cv2 BruteForce-Hamming); (K, 2) sorted by (i, j)."""
+    f1 = np.ascontiguousarray(f1, np.uint8)
+    f2 = np.ascontiguousarray(f2, np.uint8)
+    w = f1.shape[1]
+    if symmetric:
+        cap = max(1, min(len(f1), len(f2)))
+        out = np.empty((cap, 2), np.int32)
+        n = lib().oracle_match_hamming_symmetric(_p(f1, C.c_uint8), len(f1), _p(f2, C.c_uint8), len(f2), w, C.c_double(ratio), _p(out, C.c_int), cap)
+        return out[:n].copy()
+    good = np.empty(max(len(f1), 1), np.int32)
+    lib().oracle_match_hamming(_p(f1, C.c_uint8), len(f1), _p(f2, C.c_uint8), len(f2), w, C.c_double(ratio), _p(good, C.c_int))
+    good = good[: len(f1)]
+    i = np.flatnonzero(good >= 0)
+    return np.stack([i, good[i]], axis=1).astype(np.int32)
+
+
 def match_flann(f1: np.ndarray, f2: np.ndarray, ratio: float = 0.8) -> np.ndarray:
     """``matching.py:683-697`` with an exact search: index over ``f1``, queries ``f2``; (K, 2) of (index row, query row) in query order."""
     f1 = np.ascontiguousarray(f1, np.float32)

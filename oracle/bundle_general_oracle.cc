@@ -257,6 +257,8 @@ struct Problem {  // mirrors osfm_bundle_problem (include/osfm_mi355.h)
   const double* obs_sigma;
   double* reproj_err;
   const double *shot_pan, *shot_pan_sigma, *shot_tilt, *shot_tilt_sigma, *shot_roll, *shot_roll_sigma;
+  const double *obs_depth, *obs_depth_sigma;  // n_obs each or null; sigma <= 0: no depth prior for the observation
+  const uint8_t* obs_depth_radial;            // n_obs or null = all radial (map::Depth::is_radial)
 };
 struct Options {  // mirrors osfm_ba_options
   int32_t loss;
@@ -382,6 +384,17 @@ double evaluate(const Problem& P, const Options& O, const Layout& L, const State
     add_block<NR_>(A, r, nres, std::sqrt(rho1), idx);
     if (reproj)
       for (int e = 0; e < 3; e++) reproj[3 * o + e] = e < nres ? r[e].v * P.obs_sigma[o] : 0.0;
+    // RelativeDepthError (bundle/error/relative_depth_error.h:11-46, added right after the reprojection block of the same observation
+    // with the SAME loss function, bundle_adjuster.cc:497-528,812): one residual on [rig instance | rig camera | point]
+    if (P.obs_depth && P.obs_depth_sigma && P.obs_depth_sigma[o] > 0) {
+      T depth = Xc[2];
+      if (!P.obs_depth_radial || P.obs_depth_radial[o]) depth = sqrt(Xc[0] * Xc[0] + Xc[1] * Xc[1] + Xc[2] * Xc[2]);
+      T rd[1] = {(depth - P.obs_depth[o]) * (1.0 / P.obs_depth_sigma[o])};
+      double rho_d, rho1_d;
+      loss_eval(O.loss, O.loss_threshold, rd[0].v * rd[0].v, &rho_d, &rho1_d);
+      cost += 0.5 * rho_d;
+      add_block<NR_>(A, rd, 1, std::sqrt(rho1_d), idx);
+    }
   }
   // ---- camera priors (+ the dual barrier) ----
   for (int c = 0; c < P.n_cameras; c++) {

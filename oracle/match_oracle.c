@@ -198,6 +198,53 @@ int oracle_match_brute_force_symmetric(const float *fi, int ni, const float *fj,
   return n;
 }
 
+/* matching.py:737-740: uint8 descriptors -> cv2.DescriptorMatcher_create("BruteForce-Hamming"): batchDistance with NORM_HAMMING gives
+ * int distances (popcount of the xor over the row's bytes), the same K = 2 insertion as above on ints, DMatch.distance = float(int);
+ * Lowe's test in Python doubles (matching.py:752).  good[i] = j or -1.  parity unpinned vs cv2 (third party, restated). */
+void oracle_match_hamming(const uint8_t *f1, int n1, const uint8_t *f2, int n2, int width, double ratio, int *good) {
+#pragma omp parallel for schedule(dynamic, 16)
+  for (int i = 0; i < n1; i++) {
+    int bd0 = 0x7fffffff, bd1 = 0x7fffffff, bi0 = -1;
+    const uint8_t *a = f1 + (size_t)i * width;
+    for (int j = 0; j < n2; j++) {
+      const uint8_t *b = f2 + (size_t)j * width;
+      int d = 0;
+      for (int k = 0; k < width; k++) d += __builtin_popcount((unsigned)(a[k] ^ b[k]));
+      if (d < bd1) {
+        if (bd0 > d) {
+          bd1 = bd0;
+          bd0 = d;
+          bi0 = j;
+        } else {
+          bd1 = d;
+        }
+      }
+    }
+    good[i] = (n2 >= 2 && (double)(float)bd0 < ratio * (double)(float)bd1) ? bi0 : -1;
+  }
+}
+
+int oracle_match_hamming_symmetric(const uint8_t *fi, int ni, const uint8_t *fj, int nj, int width, double ratio, int *out_pairs, int cap) {
+  int *gij = (int *)malloc(sizeof(int) * (size_t)(ni > 0 ? ni : 1));
+  int *gji = (int *)malloc(sizeof(int) * (size_t)(nj > 0 ? nj : 1));
+  oracle_match_hamming(fi, ni, fj, nj, width, ratio, gij);
+  oracle_match_hamming(fj, nj, fi, ni, width, ratio, gji);
+  int n = 0;
+  for (int i = 0; i < ni; i++) {
+    int j = gij[i];
+    if (j >= 0 && gji[j] == i) {
+      if (n < cap) {
+        out_pairs[2 * n] = i;
+        out_pairs[2 * n + 1] = j;
+      }
+      n++;
+    }
+  }
+  free(gij);
+  free(gji);
+  return n;
+}
+
 int oracle_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -4,7 +4,7 @@ own ``opensfm/test/test_bundle.py`` cases that ``BAHelpers::Bundle`` can reach (
 import numpy as np
 
 from opensfm_amd import bundle, opensfm_adapter, synthetic
-from opensfm_amd.geometry_types import (Camera, GroundControlPoint, GroundControlPointObservation, Observation, Pose, Reconstruction,
+from opensfm_amd.geometry_types import (Camera, Depth, GroundControlPoint, GroundControlPointObservation, Observation, Pose, Reconstruction,
                                         RigCamera, RigInstance, Similarity)
 
 
@@ -102,6 +102,38 @@ def case_pair_with_points_priors():
     sa.add_point_prior("p2", np.array([1.5, 2, 2]), std_dev, True)
     sa.run()
     return sa
+
+
+def case_pair_with_depth_priors(contradict=False):
+    """the pair above with depth priors on p1 (RelativeDepthError, bundle_adjuster.cc:497-528): the z depth in shot 1 and the radial
+    depth in shot 2, taken from the optimum of the pair above -- the optimum stays; `contradict`: a strong radial prior 1.5 x too long in
+    shot 2, which the point follows (its position prior and reprojections give way)"""
+    ref = case_pair_with_points_priors()
+
+    def in_camera(shot):
+        pose = ref.get_rig_instance_pose(shot)
+        return pose.get_R_world_to_cam() @ ref.get_point("p1").p + pose.get_t_world_to_cam()
+
+    z1, r2 = in_camera("1")[2], np.linalg.norm(in_camera("2"))
+    sa = _adjuster()
+    for i in range(2):
+        sa.add_rig_instance(str(i + 1), Pose(np.array([1e-3, 1e-3, 1e-3]), np.array([1e-3, 1e-3, 1e-3])), {str(i + 1): "cam1"},
+                            {str(i + 1): "rig_cam1"}, False)
+    sa.add_point("p1", np.array([0, 0, 0]), False)
+    sa.add_point("p2", np.array([0, 0, 0]), False)
+    for s in ("1", "2"):
+        sa.add_absolute_roll(s, np.radians(90), 1)
+        sa.add_absolute_pan(s, -np.radians(90), 1)
+        sa.add_absolute_tilt(s, -np.radians(90), 1)
+    std_dev = np.array([1, 1, 1])
+    sa.add_point_projection_observation("1", "p1", np.array([0, 0]), 1, Depth(z1, False, 0.1))
+    sa.add_point_projection_observation("2", "p1", np.array([-0.5, 0]), 1, Depth(1.5 * r2, True, 1e-3) if contradict else Depth(r2, True, 0.1))
+    sa.add_point_prior("p1", np.array([-0.5, 2, 2]), std_dev, True)
+    sa.add_point_projection_observation("2", "p2", np.array([0, 0]), 1)
+    sa.add_point_projection_observation("1", "p2", np.array([0.5, 0]), 1)
+    sa.add_point_prior("p2", np.array([1.5, 2, 2]), std_dev, True)
+    sa.run()
+    return sa, (z1, r2)
 
 
 def _single_shot_reconstruction(rng):

@@ -47,6 +47,20 @@ def test_pair_with_points_priors(cpu_solver):
     assert set(sa.get_point("p1").reprojection_errors) == {"1", "2"}
 
 
+def test_pair_with_depth_priors(cpu_solver):
+    sa, (z1, r2) = cases.case_pair_with_depth_priors()
+    assert z1 > 1.0 and r2 > z1
+    assert np.allclose(sa.get_rig_instance_pose("1").translation, [0.5, -2, 2], atol=1e-2)
+    assert np.allclose(sa.get_point("p1").p, [-0.5, 2, 2], atol=1e-4)
+    assert set(sa.get_point("p1").reprojection_errors) == {"1", "2"}
+    sb, _ = cases.case_pair_with_depth_priors(contradict=True)
+    pose = sb.get_rig_instance_pose("2")
+    got = np.linalg.norm(pose.get_R_world_to_cam() @ sb.get_point("p1").p + pose.get_t_world_to_cam())
+    assert abs(got - 1.5 * r2) < 1e-2 * r2  # the strong prior is met
+    with pytest.raises(RuntimeError):  # bundle_adjuster.cc:508-511
+        sa.add_point_projection_observation("1", "p2", np.array([0, 0]), 1, cases.Depth(float("nan"), True, 1.0))
+
+
 def test_reference_void_gps_ignored(cpu_solver):
     cases.case_void_gps_ignored()
 

@@ -26,6 +26,17 @@ def test_pair_with_points_priors(gpu_ctx, oracle_lib):
     assert np.allclose(sa.get_point("p2").p, [1.5, 2, 2], atol=1e-6)
 
 
+def test_pair_with_depth_priors(gpu_ctx):
+    """depth priors through the facade on the real solver (RelativeDepthError, bundle_adjuster.cc:497-528)"""
+    sa, (z1, r2) = cases.case_pair_with_depth_priors()
+    assert np.allclose(sa.get_rig_instance_pose("1").translation, [0.5, -2, 2], atol=1e-2)
+    assert np.allclose(sa.get_point("p1").p, [-0.5, 2, 2], atol=1e-4)
+    sb, _ = cases.case_pair_with_depth_priors(contradict=True)
+    pose = sb.get_rig_instance_pose("2")
+    got = np.linalg.norm(pose.get_R_world_to_cam() @ sb.get_point("p1").p + pose.get_t_world_to_cam())
+    assert abs(got - 1.5 * r2) < 1e-2 * r2
+
+
 def test_reference_void_gps_ignored(gpu_ctx):
     cases.case_void_gps_ignored()
 

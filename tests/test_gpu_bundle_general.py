@@ -57,6 +57,44 @@ def test_rig_bias_control_points_up_vectors(oracle_lib, gpu_ctx):
     assert np.abs(g["bias"] - pr["bias"]).max() > 0
 
 
+def depth_priors_for(pr, rng, frac=0.4, noise=0.01):
+    """depth priors (map::Depth) for a fraction of the observations: the true depth of the point in its camera, radial or along z,
+    perturbed -- RelativeDepthError (relative_depth_error.h) next to the reprojection of the same observation"""
+    from scipy.spatial.transform import Rotation
+
+    M = len(pr["obs_shot"])
+    depth, sd, radial = np.zeros(M), np.zeros(M), np.ones(M, np.uint8)
+    for o in range(M):
+        if rng.random() > frac:
+            continue
+        s = pr["obs_shot"][o]
+        Xc = np.asarray(pr["points"][pr["obs_point"][o]], float)
+        for pose in (pr["rig_instance_pose"][pr["shot_rig_instance"][s]], pr["rig_camera_pose"][pr["shot_rig_camera"][s]]):
+            Xc = Rotation.from_rotvec(-np.asarray(pose[:3])).apply(Xc - pose[3:])  # WorldToLocal of a CAM_TO_WORLD pose
+        radial[o] = rng.random() < 0.5
+        depth[o] = (np.linalg.norm(Xc) if radial[o] else Xc[2]) * (1 + noise * rng.normal())
+        sd[o] = 0.05 * (1 + rng.random())
+    return {"obs_depth": depth, "obs_depth_sigma": sd, "obs_depth_radial": radial}
+
+
+@pytest.mark.parametrize("models,rig", [(("perspective",), False), (("brown", "fisheye"), True), (("spherical",), False)])
+def test_depth_priors(oracle_lib, gpu_ctx, models, rig):
+    """RelativeDepthError (bundle_adjuster.cc:497-528,812; ba_helpers.cc:695-696 passes obs.depth_prior): radial and z depths, with and
+    without a useful rig camera, under the same robust loss as the reprojections"""
+    pr = synthetic.make_bundle_scene(models=models, n_instances=8, n_points=100, rig=rig, gps=False, n_gcp=0, up_vectors=False, seed=13)
+    pr.update(depth_priors_for(pr, np.random.default_rng(3)))
+    g, o = _compare(oracle_lib, gpu_ctx, pr)
+    plain = {k: v for k, v in pr.items() if not k.startswith("obs_depth")}
+    o0 = oracle_lib.bundle_general(plain, max_iterations=8, **NO_TOL)
+    assert o["initial_cost"] > o0["initial_cost"] and not np.allclose(o["points"], o0["points"], atol=1e-9)  # the priors count
+    assert g["reproj_err"].shape == (len(pr["obs_shot"]), 3)
+    bad = dict(pr, obs_depth=np.where(np.arange(len(pr["obs_shot"])) == int(np.flatnonzero(pr["obs_depth_sigma"] > 0)[0]), np.nan, pr["obs_depth"]))
+    from opensfm_amd import bundle
+
+    with pytest.raises(Exception):
+        bundle.bundle_general_arrays(bad, {"bundle_max_iterations": 2}, ctx=gpu_ctx, **NO_TOL)
+
+
 def test_constant_blocks(oracle_lib, gpu_ctx):
     """constant cameras, constant rig cameras (non-identity: still part of the projection), constant biases, some constant instances and
     points: none of them moves, the rest agrees with the oracle"""

@@ -104,3 +104,40 @@ def test_full_scene_recovers_ground_truth(oracle_lib):
     assert np.sqrt((r["reproj_err"][inl, :2] ** 2).sum(1).mean()) < 6e-4
     assert np.abs(r["rig_camera_pose"][1] - pr["gt_rig_camera"][1]).max() < 0.02
     assert np.abs(r["bias"][:, 3:6] - pr["gt_bias"][:, 3:6]).max() < 0.1  # the bias absorbs the GPS offset
+
+
+def test_depth_prior_residual_known_answer(oracle_lib):
+    """RelativeDepthError (relative_depth_error.h:21-39) in the oracle against a numpy restatement: with the depth priors the initial
+    cost grows by exactly sum 1/2 rho(((depth in camera - depth) / sd)^2), rho = SoftLOne(1) like the reprojections
+    (bundle_adjuster.cc:812 hands the same loss to both blocks); z depth and radial depth, rig camera in the chain."""
+    from scipy.spatial.transform import Rotation
+
+    import test_gpu_bundle_general as gg
+
+    pr = synthetic.make_bundle_scene(models=("brown", "fisheye"), n_instances=6, n_points=60, rig=True, gps=False, n_gcp=0, up_vectors=False, seed=4)
+    extra = gg.depth_priors_for(pr, np.random.default_rng(1), frac=0.5, noise=0.2)
+    kw = dict(max_iterations=0, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
+    c0 = oracle_lib.bundle_general(pr, **kw)["initial_cost"]
+    c1 = oracle_lib.bundle_general(dict(pr, **extra), **kw)["initial_cost"]
+    want = 0.0
+    for o in np.flatnonzero(extra["obs_depth_sigma"] > 0):
+        s = pr["obs_shot"][o]
+        Xc = np.asarray(pr["points"][pr["obs_point"][o]], float)
+        for pose in (pr["rig_instance_pose"][pr["shot_rig_instance"][s]], pr["rig_camera_pose"][pr["shot_rig_camera"][s]]):
+            Xc = Rotation.from_rotvec(-np.asarray(pose[:3])).apply(Xc - pose[3:])
+        r = ((np.linalg.norm(Xc) if extra["obs_depth_radial"][o] else Xc[2]) - extra["obs_depth"][o]) / extra["obs_depth_sigma"][o]
+        want += 0.5 * 2.0 * (np.sqrt(1.0 + r * r) - 1.0)
+    assert want > 1.0 and abs((c1 - c0) - want) < 1e-9 * max(1.0, want)
+    # a single strong depth prior is met at the optimum (it removes the scale freedom this scene has without GPS)
+    one = {k: v.copy() for k, v in extra.items()}
+    keep = int(np.flatnonzero(extra["obs_depth_sigma"] > 0)[0])
+    one["obs_depth_sigma"][:] = 0.0
+    one["obs_depth_sigma"][keep] = 1e-4
+    one["obs_depth"][keep] *= 1.3
+    b = oracle_lib.bundle_general(dict(pr, **one), max_iterations=30, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
+    s_ = pr["obs_shot"][keep]
+    Xc = np.asarray(b["points"][pr["obs_point"][keep]], float)
+    for pose in (b["rig_instance_pose"][pr["shot_rig_instance"][s_]], b["rig_camera_pose"][pr["shot_rig_camera"][s_]]):
+        Xc = Rotation.from_rotvec(-np.asarray(pose[:3])).apply(Xc - pose[3:])
+    got = np.linalg.norm(Xc) if one["obs_depth_radial"][keep] else Xc[2]
+    assert abs(got - one["obs_depth"][keep]) < 2e-3 * one["obs_depth"][keep], (got, one["obs_depth"][keep])

@@ -251,7 +251,7 @@ def _collection(oracle_lib, rng, guided):
         px = cam.focal * u * (1 + r2 * (cam.k1 + cam.k2 * r2))[:, None]
         perm = rng.permutation(n)
         desc = np.clip((np.concatenate([base, base]) if guided else base) + rng.integers(-3, 4, (n, 128)), 0, 255).astype(np.float32)
-        feats[im] = types.SimpleNamespace(points=np.c_[px[perm], np.ones((n, 2))], descriptors=desc[perm])
+        feats[im] = types.SimpleNamespace(points=np.c_[px[perm], np.ones((n, 2))], descriptors=desc[perm], point_index=perm)
         masks[im] = rng.random(n) > 0.1
     config = {"matcher_type": "BRUTEFORCE", "symmetric_matching": True, "lowes_ratio": 0.8, "robust_matching_min_match": 20,
               "robust_matching_threshold": 0.004, "robust_matching_calib_threshold": 0.004, "five_point_refine_match_iterations": 10,
@@ -377,6 +377,78 @@ def test_match_flow_equals_the_product_host_flow(ref, oracle_lib, monkeypatch, g
         assert np.array_equal(rows(got[pair]), rows(want[pair])), pair
         survivors += len(want[pair]) > 0
     assert survivors >= 5
+
+
+def test_segmentation_in_descriptor_flow(ref, oracle_lib, monkeypatch):
+    """matching_use_segmentation: the reference's FeatureLoader.load_all_data / _add_segmentation_in_descriptor / mask handling
+    (feature_loading.py:106-173) executed from its own file feed the reference's match() with 129-column descriptors; the product's
+    match_images_with_pairs builds the same column from the same FeaturesData stand-ins.  The scene is repetitive (every descriptor
+    exists twice, so Lowe's test rejects everything) and the two copies carry different classes: only the column lets pairs match."""
+    from opensfm_amd import matching as product
+
+    matching, _ = ref
+    rng = np.random.default_rng(23)
+    images, cams, cam_of, feats, masks, poses, config = _collection(oracle_lib, rng, True)
+    config.update(matching_use_segmentation=True, feature_type="HAHOG", hahog_normalize_to_uchar=True)
+    exifs = {im: {"camera": cam_of[im]} for im in images}
+    pairs = [(a, b) for i, a in enumerate(images) for b in images[i + 1:]]
+    n = len(feats["a"].points)
+    label_of_point = np.r_[np.zeros(n // 2, int), 1 + rng.integers(0, 3, n - n // 2)]  # a scene point keeps its class in every image
+    # ---- the reference's feature_loading.py, from its file ----
+    ft = sys.modules["opensfm.features"] = _Stub("opensfm.features")
+
+    class FeaturesData:
+        def __init__(self, points, descriptors, colors, semantic):
+            self.points, self.descriptors, self.colors, self.semantic = points, descriptors, colors, semantic
+
+        def get_segmentation(self):
+            return None if not self.semantic else self.semantic.segmentation
+
+        def mask(self, mask):
+            sem = None if not self.semantic else types.SimpleNamespace(segmentation=self.semantic.segmentation[mask])
+            return FeaturesData(self.points[mask], self.descriptors[mask], None, sem)
+
+    ft.FeaturesData = FeaturesData
+    sys.modules["opensfm"].features = ft
+    spec = importlib.util.spec_from_file_location("opensfm.feature_loading", os.path.join(REF, "feature_loading.py"))
+    fl = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fl)
+    full = {}
+    for im in images:
+        lab = label_of_point[feats[im].point_index]
+        full[im] = FeaturesData(feats[im].points, feats[im].descriptors, None, types.SimpleNamespace(segmentation=lab))
+    Data = type("Data", (), {})  # hashable by identity: the reference's loaders sit behind lru_cache
+    data = Data()
+    data.config, data.load_camera_models, data.load_features = config, (lambda: cams), (lambda im: full[im])
+    data.load_features_mask, data.load_exif = (lambda im, pts: masks[im]), (lambda im: {"make": "Canon", "model": "X"})
+    loader = fl.FeatureLoader()
+    monkeypatch.setattr(loader, "_load_features_nocache", lambda d, im: full[im], raising=False)
+    monkeypatch.setattr(loader, "load_mask", lambda d, im: masks[im], raising=False)
+    monkeypatch.setattr(matching.feature_loader, "instance", loader, raising=False)
+    monkeypatch.setattr(matching.log, "setup", lambda: None, raising=False)
+    aug = loader.load_all_data(data, "a", masked=True, segmentation_in_descriptor=True)
+    assert aug.descriptors.shape[1] == 129 and set(np.unique(aug.descriptors[:, -1])) == {0.0, 35.0, 70.0, 105.0}
+    want = {}
+    for im1, im2 in pairs:
+        _, _, m = matching.match_unwrap_args((im1, im2, cams, exifs, data, {}, None))
+        want[im1, im2] = np.asarray(m)
+    emulate_product_leaves(monkeypatch, oracle_lib)
+    got = product.match_images_with_pairs(data, {}, exifs, pairs, None)
+
+    def rows(a):
+        a = np.asarray(a).reshape(-1, 2)
+        return a[np.lexsort((a[:, 1], a[:, 0]))]
+
+    for pair in pairs:
+        assert np.array_equal(rows(got[pair]), rows(want[pair])), pair
+    assert sum(len(w) > 0 for w in want.values()) >= 5
+    # without the column nothing passes Lowe's test: the labels decide
+    config["matching_use_segmentation"] = False
+    assert all(len(m) == 0 for m in product.match_images_with_pairs(data, {}, exifs, pairs, None).values())
+    # the reference's guard (feature_loading.py:126-133)
+    config.update(matching_use_segmentation=True, feature_type="SIFT")
+    with pytest.raises(RuntimeError):
+        product.match_images_with_pairs(data, {}, exifs, pairs, None)
 
 
 def test_matches_files_are_read_by_the_reference_dataset(tmp_path, oracle_lib):
