@@ -832,7 +832,7 @@ def match_images_with_pairs(data, config_override: Dict[str, Any], exifs: Dict[s
             if len(rm) >= min_match and len(rm) > 0:
                 per_pair[p] = rm.astype(np.int32)
     else:
-        store = DescriptorStore(descs, pts, hamming=hamming)  # all descriptors resident in HBM for the batched launches
+        store = DescriptorStore(descs, pts, hamming=True) if hamming else DescriptorStore(descs, pts)  # all descriptors resident in HBM
         try:
             pin = np.array([_is_pinhole(cams[a]) and _is_pinhole(cams[b]) for a, b in ipairs], bool)
             if not use_filters:

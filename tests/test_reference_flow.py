@@ -301,7 +301,8 @@ def emulate_product_leaves(monkeypatch, oracle_lib):
     class FakeStore:
         ctx = None
 
-        def __init__(self, descs, pts, ctx=None):
+        def __init__(self, descs, pts, ctx=None, hamming=False):
+            assert not hamming
             self.off = np.r_[0, np.cumsum([len(d) for d in descs])].astype(np.int64)
             self.desc = np.concatenate(descs).astype(np.float32)
             self.pts = np.concatenate([np.asarray(p, float)[:, :2] for p in pts])
