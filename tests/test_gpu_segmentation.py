@@ -42,8 +42,9 @@ def test_store_with_segmentation_column_pipeline(oracle_lib, gpu_ctx):
 
     sc = synthetic.make_matching_scene(6, 500, seed=21)
     rng = np.random.default_rng(5)
-    # a scene point keeps its class across images only half of the time: some true matches are broken, some false ones suppressed
-    desc = _with_labels(rng, sc.desc, 3)
+    # labels drawn per feature: two thirds of the true matches sit across classes.  The column is 350 x the label here (the store takes
+    # any float column): at the reference's 35 the penalty (1225) is far below this scene's second-nearest distances and changes nothing
+    desc = _with_labels(rng, sc.desc, 3, mult=350.0)
     pairs = synthetic.all_pairs(6)
     store = matching.DescriptorStore.from_packed(desc, sc.pts, sc.offsets)
     try:
