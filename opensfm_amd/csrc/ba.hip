@@ -211,6 +211,14 @@ struct Dev {
   int bw;           // block half-bandwidth actually used (0: block-Jacobi only)
   double *band;     // S x (bw+1) x 36: block (s, s-k), after factorisation the Cholesky factor L
   double *dinv;     // S x 36: inverse of the diagonal blocks of L
+  // band assembly on the matrix cores (band_mfma_kernel): points sorted by the first shot of their track (the anchor)
+  const int *bp_pts;            // P: point ids in that order
+  const int *bp_o0, *bp_last;   // P: first observation (point-major position) and last shot offset (from the first shot) of the sorted points
+  const unsigned char *bp_pos;  // P x 16: which observation of the sorted point sits at shot offset 0 .. 15 (255: the track misses that shot)
+  const int *bp_off;            // S + 1: first sorted position of every anchor
+  int bpMode;                   // measurement knob (OSFM_BA_BM_MODE): 1 = no products, 2 = every load from row 0
+  int bpNT, bpR, bpPC;          // 16-row tiles of an anchor's matrix, parts per anchor, points per staged chunk
+  double *bp_part;              // (S * bpR) x (bpNT (bpNT + 1) / 2) x 256: every workgroup's accumulator tiles
   // cluster block-tridiagonal form of the same band (cs >= bw shots per cluster, dense ncd x ncd blocks)
   int cs, ncl, ncd;
   double *cD;               // ncl x ncd^2: diagonal blocks of the factor (lower triangular)
@@ -818,6 +826,187 @@ __global__ void __launch_bounds__(TPB) band_assemble_kernel(Dev d, double radius
     }
     d.band[((long)s * (d.bw + 1) + dk) * 36 + ij] = val;
   }
+}
+
+// ---- band assembly on the matrix cores (round 4) ---------------------------------------------------------------------------------
+// The per-shot kernel above issues 36 fp64 LDS atomics per (observation, co-visible shot): 990 M at configs[4], 1.16 ms at the ~1.4 adds
+// per cycle and CU the LDS sustains.  Here nothing is added through memory.  Points are taken in the order of the FIRST shot of their
+// track (sorted once at setup); a unit of work = the points with first shot a (split into R parts when there are many).  For such a
+// point stack Y = [F_o] (6 rows per shot offset 0 .. bw from a, zero rows for the shots that do not see it; F_o = E_o Hhat_p, 6 x 3) and
+// Z = [E_o]: the point's contribution to every block (a + x, a + y) of the band is the 6 x 6 block (x, y) of Y Z^T -- a rank-3 update of
+// ONE matrix per anchor a, whatever shots inside the window the track has (no two points need share a shot set).  Y Z^T summed over the
+// unit's points is a GEMM with K = 3 per point: v_mfma_f64_16x16x4_f64 (K padded to 4), lower-triangular 16 x 16 tiles of the
+// 6 (bw + 1) rows, accumulators in registers for the whole unit.  The four wavefronts of a workgroup share the TILES (every wavefront
+// walks every point of a chunk staged in LDS; no reduction between them), operands come from LDS through a byte table
+// pos[point][shot offset] -> slot.  band_finish_kernel then adds, per band block (s, s - dk), the (at most bw + 1 - dk) anchors x R
+// parts that hold it, in a fixed order: no atomics anywhere, the band -- hence the preconditioner and the whole solve -- is
+// reproducible bit for bit.  Needs the exact band (bw = the widest track, at most kMaxBw) and one observation per (track, shot);
+// anything else keeps the kernel above.
+constexpr int kBmSlots = 128;          // (point, shot offset) slots staged per chunk: E and F, 2 x 18 x 136 doubles = 39 KB, twice (double buffer): two workgroups per CU
+constexpr int kBmStride = kBmSlots + 8;  // slot kBmSlots holds zeros: the operand of a lane whose row lies outside the band or whose K index is the pad
+typedef double bm_v4d __attribute__((ext_vector_type(4)));
+
+// LDS-only workgroup barrier: __syncthreads() would also wait for the global loads of the NEXT chunk, which are meant to stay in flight
+// underneath the products of this one
+__device__ __forceinline__ void bm_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int NT>  // 16-row tiles: 6 (bw + 1) <= 16 NT
+__global__ void __launch_bounds__(384) band_mfma_kernel(Dev d) {
+  constexpr int NTILES = NT * (NT + 1) / 2, MAXT = (NTILES + 3) / 4;
+  constexpr int kBuf = 36 * kBmStride;  // doubles of one staging buffer (E then F, 18 SoA rows each)
+  extern __shared__ __attribute__((aligned(16))) double bm_lds[];  // two staging buffers: one is filled while the other is multiplied
+  const int TL = d.bw + 1, PC = d.bpPC;
+  const int a = blockIdx.x / d.bpR, part = blockIdx.x - a * d.bpR;
+  const int n_all = d.bp_off[a + 1] - d.bp_off[a];
+  const int i0 = d.bp_off[a] + (int)((long)n_all * part / d.bpR), i1 = d.bp_off[a] + (int)((long)n_all * (part + 1) / d.bpR);
+  const int nch = (i1 - i0 + PC - 1) / PC;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (threadIdx.x < 72) bm_lds[(threadIdx.x / 36) * kBuf + (threadIdx.x % 36) * kBmStride + kBmSlots] = 0.0;  // the zero slot of both buffers
+  // Six wavefronts, two trades.  Wavefronts 4 and 5 STAGE: thread (t, sh) puts the observation of point t of the chunk in the shot a + sh
+  // into slot t TL + sh (zeros when the track misses that shot): E = Jc^T Jp from the point-major Jacobian copy, F = E Hhat.  What they
+  // need from the sorted tables is fetched two chunks ahead, the Jacobian entries and Hhat one chunk ahead; every load is unconditional
+  // (a thread with nothing to stage reads row 0 and discards it: a branch around the loads would make the compiler wait at its end).
+  // Wavefronts 0 .. 3 MULTIPLY the chunk staged one step before, each its own tiles.  One LDS barrier per chunk.
+  if (wave >= 4) {
+    const int lt = threadIdx.x - 256;
+    const int ut = lt / TL, ush = lt - ut * TL;
+    const bool loader = ut < PC;
+    const int u = ut * TL + ush;
+    int n_p, n_o0, n_k;
+    auto fetch_index = [&](int c) {
+      const bool on = loader && c + ut < i1;
+      const long r = d.bpMode == 2 ? 0 : on ? c + ut : i0 < i1 ? i0 : 0;
+      n_p = d.bp_pts[r];
+      n_o0 = d.bp_o0[r];
+      const int k = d.bp_pos[16 * r + ush];
+      n_k = on ? k : 255;
+    };
+    double jv[18], hh[6];
+    bool c_have = false;
+    auto fetch_blocks = [&]() {  // of the chunk whose index is in n_*
+      c_have = n_k != 255;
+      const long o = n_o0 + (c_have ? n_k : 0);
+#pragma unroll
+      for (int x = 0; x < 18; x++) jv[x] = JA(o, 2 + x);
+      const double *Hh = d.Hhat + 6L * n_p;
+#pragma unroll
+      for (int x = 0; x < 6; x++) hh[x] = Hh[x];
+    };
+    fetch_index(i0);
+    fetch_blocks();
+    fetch_index(i0 + PC);
+    for (int c = 0; c <= nch; c++) {
+      if (c < nch && loader) {
+        double *Es = bm_lds + (c & 1) * kBuf, *Fs = Es + 18 * kBmStride;
+        const double zf = c_have ? 1.0 : 0.0;
+        double E[18];  // E[i][j] = Jc[0][i] Jp[0][j] + Jc[1][i] Jp[1][j], the expression of eval_kernel's E block (jred_jp)
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+          for (int j = 0; j < 3; j++) E[3 * i + j] = jv[6 + i] * jv[j] + jv[12 + i] * jv[3 + j];
+        const double h[9] = {hh[0], hh[1], hh[2], hh[1], hh[3], hh[4], hh[2], hh[4], hh[5]};
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+          for (int j = 0; j < 3; j++) {
+            Es[(3 * i + j) * kBmStride + u] = c_have ? E[3 * i + j] : 0.0;
+            Fs[(3 * i + j) * kBmStride + u] = zf * (E[3 * i] * h[j] + E[3 * i + 1] * h[3 + j] + E[3 * i + 2] * h[6 + j]);
+          }
+      }
+      fetch_blocks();  // chunk c + 1: its index arrived during the chunk before
+      fetch_index(i0 + (c + 2) * PC);
+      bm_lds_barrier();
+    }
+    return;
+  }
+  const int li = lane & 15, kk = lane >> 4;
+  // this wavefront's tiles tau = wave + 4 m (tau enumerates (I, J), J <= I, row by row) and the lane's operand addresses in them
+  int adA[MAXT], adB[MAXT];
+  bool have[MAXT];
+#pragma unroll
+  for (int m = 0; m < MAXT; m++) {
+    const int tau = wave + 4 * m;
+    int I = 0;
+    while ((I + 1) * (I + 2) / 2 <= tau) I++;
+    const int J = tau - I * (I + 1) / 2;
+    have[m] = tau < NTILES;
+    const int yA = 16 * I + li, yB = 16 * J + li;
+    const int sA = yA / 6, sB = yB / 6;
+    adA[m] = (have[m] && kk < 3 && sA <= d.bw) ? ((yA - 6 * sA) * 3 + kk) * kBmStride + sA : -1;
+    adB[m] = (have[m] && kk < 3 && sB <= d.bw) ? ((yB - 6 * sB) * 3 + kk) * kBmStride + sB : -1;
+  }
+  bm_v4d acc[MAXT];
+#pragma unroll
+  for (int m = 0; m < MAXT; m++) acc[m] = (bm_v4d){0.0, 0.0, 0.0, 0.0};
+  for (int c = 0; c <= nch; c++) {
+    if (c >= 1) {
+      const int npt = min(PC, i1 - (i0 + (c - 1) * PC));
+      const int bo = ((c - 1) & 1) * kBuf;
+      int ia[MAXT], ib[MAXT];  // (indices, not pointers: a pointer into LDS that went through an array becomes a flat access, which waits for vmcnt)
+#pragma unroll
+      for (int m = 0; m < MAXT; m++) {
+        ia[m] = bo + 18 * kBmStride + (adA[m] < 0 ? kBmSlots : adA[m]);
+        ib[m] = bo + (adB[m] < 0 ? kBmSlots : adB[m]);
+      }
+      for (int t = 0; t < (d.bpMode == 1 ? 0 : npt); t++) {
+        double va[MAXT], vb[MAXT];
+#pragma unroll
+        for (int m = 0; m < MAXT; m++) {
+          va[m] = bm_lds[ia[m]];
+          vb[m] = bm_lds[ib[m]];
+          ia[m] += adA[m] < 0 ? 0 : TL;
+          ib[m] += adB[m] < 0 ? 0 : TL;
+        }
+#pragma unroll
+        for (int m = 0; m < MAXT; m++) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[m], vb[m], acc[m], 0, 0, 0);
+      }
+    }
+    bm_lds_barrier();
+  }
+#pragma unroll
+  for (int m = 0; m < MAXT; m++)
+    if (have[m]) {
+      double *dst = d.bp_part + ((long)blockIdx.x * NTILES + wave + 4 * m) * 256 + lane;
+#pragma unroll
+      for (int r = 0; r < 4; r++) dst[64 * r] = acc[m][r];
+    }
+}
+
+// block (s, s - dk) of the band: the sums of every anchor a = s - bw .. s - dk that holds both shots (rows 6 (s - a) + i, columns
+// 6 (s - dk - a) + j of its matrix; element (row, col) of a 16 x 16 accumulator tile sits in register row / 4 of lane 16 (row % 4) + col),
+// added in a fixed order, then what band_assemble_kernel does at its end -- sign, the shot's own J^T J block and priors on the
+// diagonal, Jacobi scaling, the LM diagonal
+__global__ void __launch_bounds__(TPB) band_finish_kernel(Dev d, double radius) {
+  const long t = (long)blockIdx.x * TPB + threadIdx.x;
+  const int R1 = d.bw + 1;
+  if (t >= (long)d.S * R1 * 36) return;
+  const int ij = (int)(t % 36), dk = (int)((t / 36) % R1), s = (int)(t / (36 * R1));
+  const int i = ij / 6, j = ij - 6 * i, s2 = s - dk;
+  double val = 0.0;
+  if (s2 >= 0) {
+    double sum = 0.0;
+    const int ntiles = d.bpNT * (d.bpNT + 1) / 2;
+    for (int a = max(0, s - d.bw); a <= s2; a++) {
+      int row = 6 * (s - a) + i, col = 6 * (s2 - a) + j;
+      if (col > row) {  // a diagonal block across a tile boundary: only the lower tiles exist, and E Hhat E^T is symmetric
+        const int tmp = row;
+        row = col;
+        col = tmp;
+      }
+      const int I = row >> 4, J = col >> 4, ri = row & 15, cj = col & 15;
+      const long e = ((long)(I * (I + 1) / 2 + J) * 4 + (ri >> 2)) * 64 + ((ri & 3) << 4) + cj;
+      for (int r = 0; r < d.bpR; r++) sum += d.bp_part[((long)a * d.bpR + r) * ntiles * 256 + e];
+    }
+    val = -sum;
+    if (dk == 0) {
+      const int hi = i > j ? i : j, lo = i > j ? j : i;
+      val += d.Hcc[21 * (long)s + hi * (hi + 1) / 2 + lo];
+      if (i == j) val += d.prior_diag[6 * s + i];
+    }
+    val *= d.sc_red[6 * s + i] * d.sc_red[6 * s2 + j];
+    if (dk == 0 && i == j) val += d.D_red[6 * s + i] / radius;
+  }
+  d.band[t] = val;
 }
 
 // sequential banded block Cholesky, one wavefront; ring[] keeps the last bw+1 factor rows in LDS
@@ -2054,14 +2243,24 @@ __global__ void __launch_bounds__(kCoopObs) schur_point_coop_kernel(Dev d, const
         d.d_pt[3 * (long)p] = v0;
         d.d_pt[3 * (long)p + 1] = v1;
         d.d_pt[3 * (long)p + 2] = v2;
-      } else {
-        vpt[3 * tid] = v0;
-        vpt[3 * tid + 1] = v1;
-        vpt[3 * tid + 2] = v2;
       }
+      vpt[3 * tid] = v0;
+      vpt[3 * tid + 1] = v1;
+      vpt[3 * tid + 2] = v2;
     }
-    if (MODE == 2) return;
     __syncthreads();
+    if (MODE == 2) {  // the observation part of the model cost change -m^T (r + m / 2), m = J delta, while Jp and Jc delta_c are at hand
+      double acc[1] = {0.0};
+      if (tid < nobs) {
+        const double v0 = vpt[3 * pl], v1 = vpt[3 * pl + 1], v2 = vpt[3 * pl + 2];
+        const double m0 = (jp[0] * v0 + jp[1] * v1 + jp[2] * v2) + t0, m1 = (jp[3] * v0 + jp[4] * v1 + jp[5] * v2) + t1;
+        acc[0] = -(m0 * (JA(o, 0) + 0.5 * m0) + m1 * (JA(o, 1) + 0.5 * m1));
+      }
+      __syncthreads();
+      block_sum<1>(acc, gsum);
+      if (tid == 0) d.partial[blockIdx.x] = acc[0];
+      return;
+    }
     if (tid < nobs) {
       const double v0 = vpt[3 * pl], v1 = vpt[3 * pl + 1], v2 = vpt[3 * pl + 2];
       double2 wv;
@@ -2113,6 +2312,25 @@ __global__ void __launch_bounds__(kCoopObs) schur_point_coop_kernel(Dev d, const
       d.d_pt[3 * (long)p0 + 1] = v1;
       d.d_pt[3 * (long)p0 + 2] = v2;
     }
+    double acc[1] = {0.0};
+    for (long o = o0 + tid; o < o1; o += kCoopObs) {
+      const int s = d.o_shot[o];
+      const double *ys = y + 6 * (long)s, *yk = y + d.cam0 + 3 * d.shot_camera[s];
+      double t0 = 0, t1 = 0;
+      for (int j = 0; j < 6; j++) {
+        t0 += JA(o, 8 + j) * ys[j];
+        t1 += JA(o, 14 + j) * ys[j];
+      }
+      for (int j = 0; j < 3; j++) {
+        t0 += JA(o, 20 + j) * yk[j];
+        t1 += JA(o, 23 + j) * yk[j];
+      }
+      const double m0 = (JA(o, 2) * v0 + JA(o, 3) * v1 + JA(o, 4) * v2) + t0, m1 = (JA(o, 5) * v0 + JA(o, 6) * v1 + JA(o, 7) * v2) + t1;
+      acc[0] += -(m0 * (JA(o, 0) + 0.5 * m0) + m1 * (JA(o, 1) + 0.5 * m1));
+    }
+    __syncthreads();
+    block_sum<1>(acc, gsum);
+    if (tid == 0) d.partial[blockIdx.x] = acc[0];
     return;
   }
   for (long o = o0 + tid; o < o1; o += kCoopObs) {
@@ -2245,35 +2463,6 @@ __global__ void pcg_step2_kernel(double *p, const double *z, int n, double *scal
 }
 __global__ void pcg_shift_kernel(double *scal) { scal[0] = scal[2]; }
 
-// model cost change -m^T (r + m/2), m = J delta: observation part
-__global__ void __launch_bounds__(TPB) model_change_kernel(Dev d, const double *y) {
-  __shared__ double lds[8];
-  const long o = (long)blockIdx.x * TPB + threadIdx.x;
-  double acc[1] = {0.0};
-  if (o < d.M) {
-    const int s = d.o_shot[o], p = d.o_point[o];
-    const double *ys = y + 6 * (long)s, *yk = y + d.cam0 + 3 * d.shot_camera[s], *dp = d.d_pt + 3 * (long)p;
-    double m0 = 0, m1 = 0;
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-      m0 += JA(o, 2 + j) * dp[j];
-      m1 += JA(o, 5 + j) * dp[j];
-    }
-#pragma unroll
-    for (int j = 0; j < 6; j++) {
-      m0 += JA(o, 8 + j) * ys[j];
-      m1 += JA(o, 14 + j) * ys[j];
-    }
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-      m0 += JA(o, 20 + j) * yk[j];
-      m1 += JA(o, 23 + j) * yk[j];
-    }
-    acc[0] = -(m0 * (JA(o, 0) + 0.5 * m0) + m1 * (JA(o, 1) + 0.5 * m1));
-  }
-  block_sum<1>(acc, lds);
-  if (threadIdx.x == 0) d.partial[blockIdx.x] = acc[0];
-}
 // prior part of the model change, and the candidate point x + delta with its norms
 // out: [0] += prior model change ; [1] step^2 ; [2] x^2  (over variable blocks only)
 __global__ void candidate_kernel(Dev d, const double *y, double *out) {
@@ -2699,6 +2888,66 @@ __global__ void track_width_kernel(const long *pt_off, const int *o_shot, int np
     mx = max(mx, s);
   }
   if (mx >= 0) atomicMax(out, mx - mn);
+}
+
+// first shot of every track (S for a point nobody observes: sorts behind every slab's reach) and whether some track sees a shot twice
+__global__ void track_first_kernel(const long *pt_off, const int *o_shot, int np, int S, int *first, int *dup) {
+  const int p = blockIdx.x * TPB + threadIdx.x;
+  if (p >= np) return;
+  int mn = 1 << 30, mx = -1;
+  const long a = pt_off[p], b = pt_off[p + 1];
+  for (long k = a; k < b; k++) {
+    const int s = o_shot[k];
+    mn = min(mn, s);
+    mx = max(mx, s);
+  }
+  first[p] = mx >= 0 ? mn : S;
+  if (b - a > 64) {  // such a track is wider than any band the window kernel takes, or it repeats a shot
+    atomicOr(dup, 1);
+    return;
+  }
+  for (long k = a + 1; k < b; k++)
+    for (long k2 = a; k2 < k; k2++)
+      if (o_shot[k] == o_shot[k2]) {
+        atomicOr(dup, 1);
+        return;
+      }
+}
+// the sorted points' tracks as the matrix-core band assembly reads them: first observation, the observation at every shot offset from
+// the first shot (tracks of at most 16 shots in a window of 16: checked by the caller), the last offset
+__global__ void sorted_tracks_kernel(const int *pts, const int *first, const long *pt_off, const int *o_shot, int np, int *o0, int *last,
+                                     unsigned char *pos) {
+  const int k = blockIdx.x * TPB + threadIdx.x;
+  if (k >= np) return;
+  const int p = pts[k], a = first[k];
+  const long b = pt_off[p], e = pt_off[p + 1];
+  o0[k] = (int)b;
+  unsigned int w[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+  int mx = -1;
+  for (long q = b; q < e; q++) {
+    const int sh = o_shot[q] - a;
+    if (sh >= 0 && sh < 16) {
+      w[sh >> 2] = (w[sh >> 2] & ~(0xffu << (8 * (sh & 3)))) | ((unsigned int)(q - b) << (8 * (sh & 3)));
+      mx = max(mx, sh);
+    }
+  }
+  last[k] = mx;
+  reinterpret_cast<uint4 *>(pos)[k] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+// off[v] = first position k with sorted[k] >= v * stride, v = 0 .. nv
+__global__ void slab_bound_kernel(const int *sorted, int n, int stride, int nv, int *off) {
+  const int v = blockIdx.x * TPB + threadIdx.x;
+  if (v > nv) return;
+  const long key = (long)v * stride;
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if ((long)sorted[mid] < key)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  off[v] = lo;
 }
 
 // ---- setup helpers: the observation arrays are permuted on the device (host only builds the index lists) ----
@@ -3219,6 +3468,8 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
   std::vector<long> pt_off((size_t)NP + 1, 0);
   int *d_perm = A.alloc<int>((size_t)M, e);
   int bw_true = 0;
+  int track_repeats_shot = 0;
+  int *bp_keys = nullptr, *bp_pts = nullptr;  // the points in the order of the first shot of their track (band_mfma_kernel)
   {
     int *raw_shot = A.upload(P->obs_shot, (size_t)M, e), *raw_point = A.upload(P->obs_point, (size_t)M, e);
     int *iota = A.alloc<int>((size_t)M, e), *o_point = A.alloc<int>((size_t)M, e), *o_shot = A.alloc<int>((size_t)M, e);
@@ -3227,10 +3478,15 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     int *d_bw = A.alloc<int>(4, e);
     auto bits_for = [](long n) { unsigned b = 1; while (b < 32 && (1L << b) < n) b++; return b; };
     const unsigned pbits = bits_for(NP), sbits = bits_for(S);
-    size_t need1 = 0, need2 = 0;
+    int *first_shot = A.alloc<int>((size_t)NP, e);
+    bp_keys = A.alloc<int>((size_t)NP, e);
+    bp_pts = A.alloc<int>((size_t)NP, e);
+    const unsigned fbits = bits_for((long)S + 1);
+    size_t need1 = 0, need2 = 0, need3 = 0;
     (void)rocprim::radix_sort_pairs(nullptr, need1, raw_point, o_point, iota, d_perm, (size_t)M, 0u, pbits, sv.st);
     (void)rocprim::radix_sort_pairs(nullptr, need2, o_shot, sm_keys, iota, shot_obs, (size_t)M, 0u, sbits, sv.st);
-    const size_t tb = std::max(need1, need2);
+    (void)rocprim::radix_sort_pairs(nullptr, need3, first_shot, bp_keys, iota, bp_pts, (size_t)NP, 0u, fbits, sv.st);
+    const size_t tb = std::max(std::max(need1, need2), need3);
     unsigned char *tmp = A.alloc<unsigned char>(tb + 256, e);
     OSFM_REQUIRE(e == hipSuccess, OSFM_E_NOMEM, "BA device allocation/upload failed: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(iota_int_kernel, dim3(nblk(M)), dim3(TPB), 0, sv.st, iota, M);
@@ -3240,11 +3496,18 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     hipLaunchKernelGGL(lower_bound_kernel, dim3(nblk(NP + 1L)), dim3(TPB), 0, sv.st, o_point, M, NP, d_pt_off);
     OSFM_HIP(rocprim::radix_sort_pairs(tmp, tb2, o_shot, sm_keys, iota, shot_obs, (size_t)M, 0u, sbits, sv.st));
     hipLaunchKernelGGL(lower_bound_kernel, dim3(nblk(S + 1L)), dim3(TPB), 0, sv.st, sm_keys, M, S, d_shot_off);
-    OSFM_HIP(hipMemsetAsync(d_bw, 0, sizeof(int), sv.st));
+    OSFM_HIP(hipMemsetAsync(d_bw, 0, 2 * sizeof(int), sv.st));
     hipLaunchKernelGGL(track_width_kernel, dim3(nblk(NP)), dim3(TPB), 0, sv.st, d_pt_off, o_shot, NP, d_bw);
+    hipLaunchKernelGGL(track_first_kernel, dim3(nblk(NP)), dim3(TPB), 0, sv.st, d_pt_off, o_shot, NP, S, first_shot, d_bw + 1);
+    if ((long)NP <= M) {  // iota holds 0 .. M - 1; a problem with more points than observations keeps the per-shot assembly
+      size_t tb3 = tb;
+      OSFM_HIP(rocprim::radix_sort_pairs(tmp, tb3, first_shot, bp_keys, iota, bp_pts, (size_t)NP, 0u, fbits, sv.st));
+    } else
+      bp_pts = nullptr;
     OSFM_HIP(hipGetLastError());
     OSFM_HIP(hipMemcpyAsync(pt_off.data(), d_pt_off, ((size_t)NP + 1) * sizeof(long), hipMemcpyDeviceToHost, sv.st));
     OSFM_HIP(hipMemcpyAsync(&bw_true, d_bw, sizeof(int), hipMemcpyDeviceToHost, sv.st));
+    OSFM_HIP(hipMemcpyAsync(&track_repeats_shot, d_bw + 1, sizeof(int), hipMemcpyDeviceToHost, sv.st));
     OSFM_HIP(hipStreamSynchronize(sv.st));
     d.o_shot = o_shot;
     d.o_point = o_point;
@@ -3314,7 +3577,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
   d.Ap = A.alloc<double>(nr, e);
   d.b = A.alloc<double>(nr, e);
   d.scal = A.alloc<double>(32, e);
-  const long nbmax = std::max<long>(nblk(M), nblk(3L * NP));
+  const long nbmax = std::max<long>(std::max<long>(nblk(M), nblk(3L * NP)), d.nwg);
   d.partial = A.alloc<double>((size_t)2 * nbmax + 16, e);
   // block half-bandwidth of the shot-shot coupling (shots in caller order): bw_true, from track_width_kernel above
   // half-width up to 10: exact band, cyclic reduction; up to kWMaxBw: exact band, direct block LDL^T (wide_*); beyond: truncated to kMaxBw
@@ -3324,7 +3587,33 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
   int band_copies = kBandCopies;  // private copies of the band assembly's LDS accumulators
   while (band_copies > 1 && (size_t)(d.bw + 1) * 36 * band_copies * sizeof(double) > 150 * 1024) band_copies /= 2;
   d.band = A.alloc<double>((size_t)S * (d.bw + 1) * 36, e);
-  d.Epm = d.bw > 0 ? A.alloc<double>((size_t)18 * M, e) : nullptr;
+  // exact narrow band, one observation per (track, shot): assembled on the matrix cores (band_mfma_kernel), else per shot with LDS atomics
+  const bool win_band = d.bw >= 1 && d.bw <= kMaxBw && d.bw == bw_true && !track_repeats_shot && bp_pts != nullptr && getenv("OSFM_BA_BAND_PER_SHOT") == nullptr;
+  size_t win_lds = 0;
+  int win_grid = 0;
+  // the E blocks as an array: the per-shot assembly's operand only (the matrix-core assembly forms them from the Jacobian copy it reads)
+  d.Epm = d.bw > 0 && (!win_band || getenv("OSFM_BA_CHECK_BAND") != nullptr) ? A.alloc<double>((size_t)18 * M, e) : nullptr;
+  if (win_band) {
+    const int TL = d.bw + 1;
+    d.bpNT = (6 * TL + 15) / 16;
+    d.bpMode = getenv("OSFM_BA_BM_MODE") ? atoi(getenv("OSFM_BA_BM_MODE")) : 0;
+    d.bpPC = kBmSlots / TL;
+    d.bpR = (int)std::min<long>(8, std::max<long>(1, ((long)NP + 128L * S - 1) / (128L * S)));
+    win_grid = S * d.bpR;
+    win_lds = (size_t)2 * 36 * kBmStride * sizeof(double);
+    int *off = A.alloc<int>((size_t)S + 1, e), *o0 = A.alloc<int>((size_t)NP, e), *ln = A.alloc<int>((size_t)NP, e);
+    unsigned char *tpos = A.alloc<unsigned char>((size_t)16 * NP, e);
+    d.bp_part = A.alloc<double>((size_t)win_grid * (d.bpNT * (d.bpNT + 1) / 2) * 256, e);
+    d.bp_pts = bp_pts;
+    d.bp_off = off;
+    d.bp_o0 = o0;
+    d.bp_last = ln;
+    d.bp_pos = tpos;
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(slab_bound_kernel, dim3(nblk(S + 1L)), dim3(TPB), 0, sv.st, bp_keys, NP, 1, S, off);
+      hipLaunchKernelGGL(sorted_tracks_kernel, dim3(nblk(NP)), dim3(TPB), 0, sv.st, bp_pts, bp_keys, d.pt_off, d.o_shot, NP, o0, ln, tpos);
+    }
+  }
   d.dinv = A.alloc<double>((size_t)S * 36, e);
   d.cs = 0; d.ncl = 0; d.ncd = 0;
   if (d.bw >= 1 && d.bw <= 10 && d.bw == bw_true && O->preconditioner == 0) {  // exact band, dense clusters fit LDS
@@ -3430,7 +3719,13 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     //      -- workgroups that need a whole CU's LDS -- find the CUs free afterwards ----
     const bool want_border = d.bw > 0 && (d.ncl > 0 || wide) && O->preconditioner == 0 && sv.Bc && border_ok;
     hipStream_t sx = sv.st2 ? sv.st2 : st;
-    if (sv.st2) {
+    // where the side stream starts: the per-shot assembly (LDS atomics) leaves HBM idle, so the border's passes run beside it; the
+    // matrix-core assembly fills the CUs (four workgroups of 39 KB LDS each), and the side stream starts after it, beside the cyclic
+    // reduction's levels -- one 117 KB workgroup per CU, which leaves the CU room for a border workgroup
+    int fork_at = win_band ? 1 : 0;  // 0: before the assembly, 1: after it, 2: after the first level of the cyclic reduction
+    if (const char *fk = getenv("OSFM_BA_FORK")) fork_at = fk[0] - '0';
+    const bool fork_late = fork_at >= 1;
+    if (sv.st2 && !fork_late) {
       OSFM_HIP(hipEventRecord(sv.ev_fork, st));
       OSFM_HIP(hipStreamWaitEvent(sv.st2, sv.ev_fork, 0));
     }
@@ -3442,27 +3737,79 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
         return OSFM_OK;
       });
       if (rca != OSFM_OK) return rca;
-      hipLaunchKernelGGL(band_assemble_kernel, dim3(S), dim3(TPB), (size_t)(d.bw + 1) * 36 * band_copies * sizeof(double), st, d, radius, band_copies);
+      if (win_band) {
+        static OsfmPerDeviceOnce once_w;
+        const int rcw = once_w.run(ctx->device, []() -> int {
+          OSFM_HIP(hipFuncSetAttribute((const void *)band_mfma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+          OSFM_HIP(hipFuncSetAttribute((const void *)band_mfma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+          OSFM_HIP(hipFuncSetAttribute((const void *)band_mfma_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+          OSFM_HIP(hipFuncSetAttribute((const void *)band_mfma_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+          OSFM_HIP(hipFuncSetAttribute((const void *)band_mfma_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+          OSFM_HIP(hipFuncSetAttribute((const void *)band_mfma_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+          return OSFM_OK;
+        });
+        if (rcw != OSFM_OK) return rcw;
+        switch (d.bpNT) {
+          case 1: hipLaunchKernelGGL(band_mfma_kernel<1>, dim3(win_grid), dim3(384), win_lds, st, d); break;
+          case 2: hipLaunchKernelGGL(band_mfma_kernel<2>, dim3(win_grid), dim3(384), win_lds, st, d); break;
+          case 3: hipLaunchKernelGGL(band_mfma_kernel<3>, dim3(win_grid), dim3(384), win_lds, st, d); break;
+          case 4: hipLaunchKernelGGL(band_mfma_kernel<4>, dim3(win_grid), dim3(384), win_lds, st, d); break;
+          case 5: hipLaunchKernelGGL(band_mfma_kernel<5>, dim3(win_grid), dim3(384), win_lds, st, d); break;
+          default: hipLaunchKernelGGL(band_mfma_kernel<6>, dim3(win_grid), dim3(384), win_lds, st, d); break;
+        }
+        hipLaunchKernelGGL(band_finish_kernel, dim3(nblk((long)S * (d.bw + 1) * 36)), dim3(TPB), 0, st, d, radius);
+        if (getenv("OSFM_BA_CHECK_BAND") != nullptr) {  // self-check knob of the tests: the per-shot kernel must agree to rounding
+          const size_t nbd = (size_t)S * (d.bw + 1) * 36;
+          std::vector<double> b_win(nbd), b_shot(nbd);
+          OSFM_HIP(hipMemcpyAsync(b_win.data(), d.band, nbd * sizeof(double), hipMemcpyDeviceToHost, st));
+          hipLaunchKernelGGL(band_assemble_kernel, dim3(S), dim3(TPB), (size_t)(d.bw + 1) * 36 * band_copies * sizeof(double), st, d, radius, band_copies);
+          OSFM_HIP(hipMemcpyAsync(b_shot.data(), d.band, nbd * sizeof(double), hipMemcpyDeviceToHost, st));
+          OSFM_HIP(hipStreamSynchronize(st));
+          double amax = 0, dmax = 0;
+          for (size_t q = 0; q < nbd; q++) {
+            amax = std::max(amax, std::fabs(b_shot[q]));
+            dmax = std::max(dmax, std::fabs(b_shot[q] - b_win[q]));
+          }
+          OSFM_REQUIRE(dmax <= 1e-10 * amax, OSFM_E_NUMERIC, "band_mfma_kernel differs from band_assemble_kernel: max |diff| %.3e against max |entry| %.3e",
+                       dmax, amax);
+          OSFM_HIP(hipMemcpyAsync(d.band, b_win.data(), nbd * sizeof(double), hipMemcpyHostToDevice, st));
+          OSFM_HIP(hipStreamSynchronize(st));
+        }
+      } else
+        hipLaunchKernelGGL(band_assemble_kernel, dim3(S), dim3(TPB), (size_t)(d.bw + 1) * 36 * band_copies * sizeof(double), st, d, radius, band_copies);
       sv.use_ctri = false;
       sv.use_bcr = false;
     }
-    if (want_border) {  // all nb columns of B (and of the camera block C) in one pass over the observations
-      if (3 * NC == 3) {
-        hipLaunchKernelGGL(border_point_kernel<3>, dim3(d.nwg), dim3(kCoopObs), 0, sx, d, sv.wB);
-        hipLaunchKernelGGL(border_shot_kernel<3>, dim3(S), dim3(64), 0, sx, d, sv.wB, sv.Bc, sv.partB);
-        hipLaunchKernelGGL(border_cam_kernel<3>, dim3(NC), dim3(TPB), 0, sx, d, sv.partB, sv.dCm, radius);
-      } else {
-        hipLaunchKernelGGL(border_point_kernel<6>, dim3(d.nwg), dim3(kCoopObs), 0, sx, d, sv.wB);
-        hipLaunchKernelGGL(border_shot_kernel<6>, dim3(S), dim3(64), 0, sx, d, sv.wB, sv.Bc, sv.partB);
-        hipLaunchKernelGGL(border_cam_kernel<6>, dim3(NC), dim3(TPB), 0, sx, d, sv.partB, sv.dCm, radius);
+    const bool fork_in_bcr = fork_at == 2 && sv.st2 && d.bw > 0 && d.ncl > 1 && O->preconditioner == 0;
+    // the side stream's work: the camera border's columns and the right-hand side, from the point of the main stream where it is called
+    auto side_work = [&](bool fork_here) -> int {
+      if (sv.st2 && fork_here) {
+        OSFM_HIP(hipEventRecord(sv.ev_fork, st));
+        OSFM_HIP(hipStreamWaitEvent(sv.st2, sv.ev_fork, 0));
       }
+      if (want_border) {  // all nb columns of B (and of the camera block C) in one pass over the observations
+        if (3 * NC == 3) {
+          hipLaunchKernelGGL(border_point_kernel<3>, dim3(d.nwg), dim3(kCoopObs), 0, sx, d, sv.wB);
+          hipLaunchKernelGGL(border_shot_kernel<3>, dim3(S), dim3(64), 0, sx, d, sv.wB, sv.Bc, sv.partB);
+          hipLaunchKernelGGL(border_cam_kernel<3>, dim3(NC), dim3(TPB), 0, sx, d, sv.partB, sv.dCm, radius);
+        } else {
+          hipLaunchKernelGGL(border_point_kernel<6>, dim3(d.nwg), dim3(kCoopObs), 0, sx, d, sv.wB);
+          hipLaunchKernelGGL(border_shot_kernel<6>, dim3(S), dim3(64), 0, sx, d, sv.wB, sv.Bc, sv.partB);
+          hipLaunchKernelGGL(border_cam_kernel<6>, dim3(NC), dim3(TPB), 0, sx, d, sv.partB, sv.dCm, radius);
+        }
+      }
+      // rhs
+      hipLaunchKernelGGL(schur_point_coop_kernel<1>, dim3(d.nwg), dim3(kCoopObs), 0, sx, d, d.y);
+      hipLaunchKernelGGL(schur_shot_kernel, dim3(S), dim3(64), 0, sx, d);
+      hipLaunchKernelGGL(cam_reduce_kernel, dim3(NC), dim3(TPB), 0, sx, d, 3);
+      hipLaunchKernelGGL(schur_finish_kernel, dim3(nbr), dim3(TPB), 0, sx, d, d.x, d.y, d.b, radius, 1);
+      if (sv.st2) OSFM_HIP(hipEventRecord(sv.ev_join, sv.st2));
+      return OSFM_OK;
+    };
+    if (!fork_in_bcr) {
+      const int rcs = side_work(fork_late);
+      if (rcs != OSFM_OK) return rcs;
     }
-    // rhs
-    hipLaunchKernelGGL(schur_point_coop_kernel<1>, dim3(d.nwg), dim3(kCoopObs), 0, sx, d, d.y);
-    hipLaunchKernelGGL(schur_shot_kernel, dim3(S), dim3(64), 0, sx, d);
-    hipLaunchKernelGGL(cam_reduce_kernel, dim3(NC), dim3(TPB), 0, sx, d, 3);
-    hipLaunchKernelGGL(schur_finish_kernel, dim3(nbr), dim3(TPB), 0, sx, d, d.x, d.y, d.b, radius, 1);
-    if (sv.st2) OSFM_HIP(hipEventRecord(sv.ev_join, sv.st2));
     bool joined = sv.st2 == nullptr;
     auto join = [&]() -> int {  // the main stream continues after the side stream's work
       if (!joined) OSFM_HIP(hipStreamWaitEvent(st, sv.ev_join, 0));
@@ -3510,8 +3857,13 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
         });
         if (rca != OSFM_OK) return rca;
       }
-      for (int stq = 1; stq < N; stq *= 2)
+      for (int stq = 1; stq < N; stq *= 2) {
         hipLaunchKernelGGL(lv.fn, dim3((N + 2 * stq - 1) / (2 * stq)), dim3(lv.threads), lv.lds_bytes, st, d, stq, 0, d_status);
+        if (stq == 1 && fork_in_bcr) {
+          const int rcs = side_work(true);
+          if (rcs != OSFM_OK) return rcs;
+        }
+      }
       hipLaunchKernelGGL(lv.fn, dim3(1), dim3(lv.threads), lv.lds_bytes, st, d, 1, 1, d_status);
       sv.use_bcr = true;
       if (try_border) {  // exact camera border (few cameras, all free): B = S e_j restricted to the shot rows, W = A^-1 B
@@ -3638,8 +3990,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     // back-substitution, model change, candidate
     hipLaunchKernelGGL(scale_vec_kernel, dim3(nbr), dim3(TPB), 0, st, d.sc_red, d.x, d.y, nred);
     hipLaunchKernelGGL(schur_point_coop_kernel<2>, dim3(d.nwg), dim3(kCoopObs), 0, st, d, d.y);
-    hipLaunchKernelGGL(model_change_kernel, dim3(nblk(M)), dim3(TPB), 0, st, d, d.y);
-    hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(1024), 0, st, d.partial, (long)nblk(M), 1, d.scal + 16);
+    hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(1024), 0, st, d.partial, (long)d.nwg, 1, d.scal + 16);  // the model change's observation part
     hipLaunchKernelGGL(candidate_kernel, dim3(1), dim3(1024), 0, st, d, d.y, d.scal + 16);
     hipLaunchKernelGGL(candidate_points_kernel, dim3(nblk(3L * NP)), dim3(TPB), 0, st, d);
     hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(1024), 0, st, d.partial, (long)nblk(3L * NP), 2, d.scal + 20);
