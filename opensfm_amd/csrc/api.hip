@@ -51,6 +51,7 @@ extern "C" void osfm_ctx_destroy(osfm_ctx *c) {
   if (c->d_fr_scratch) (void)hipFree(c->d_fr_scratch);
   for (auto &b : c->pool) (void)hipFree(b.p);
   if (c->stream_b) (void)hipStreamDestroy(c->stream_b);
+  if (c->blas && c->blas_destroy) c->blas_destroy(c->blas);
   delete c;
 }
 

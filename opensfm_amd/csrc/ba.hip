@@ -22,6 +22,7 @@
 #include <vector>
 
 #include <rocprim/rocprim.hpp>
+#include <rocblas/rocblas.h>
 
 #include "ba_math.h"
 #include "osfm_internal.h"
@@ -231,6 +232,15 @@ struct Dev {
   // wide band (direct block LDL^T, kWB x kWB tiles): wNB block columns, window of wWb blocks below the diagonal
   int wNB, wWb;
   double *wA, *wL, *wLt, *wDinv, *wx;  // tiles A_{J+dI,J} (updated in place), L row-major / transposed, D^-1 blocks, right-hand sides
+  // wide band, cyclic reduction over DENSE clusters of qcs >= bw shots (qm = 6 qcs unknowns, column-major qm x qm blocks in HBM)
+  int qcs, qm, qN;
+  double *qD;        // qN x qm^2: diagonal blocks (after a cluster's elimination: its inverse)
+  double *qE[2];     // qN x qm^2 each: coupling of a cluster to its current left neighbour, ping-pong over the levels
+  double *qX;        // qN x (qm x 2 qm): [G = D^-1 E | H = D^-1 E_right^T] of the eliminated clusters
+  double *qXt;       // qN x (qm x 2 qm): [G^T | H^T]
+  double *qx, *qy;   // right-hand sides (down sweep, in place) and results (up sweep), (qN qm) x NR, NR side by side
+  int qT;            // panel width of the blocked inversion (<= 96, a multiple of 6)
+  double *qP, *qR, *qRn, *qC;  // per cluster of a level: pivot block inverse (qT^2), row panel, P x row panel (qT x qm), column panel (qm x qT)
   double *zc;       // nred (unscaled J^T w)
   double *y;        // nred
   // pcg
@@ -1799,7 +1809,7 @@ constexpr int kWcs = 16, kWB = 6 * kWcs, kWLd = kWB + 2;  // shots per block, bl
 constexpr int kWMaxBw = 520;                               // shot half-width the band assembly's LDS accumulators hold (one copy of (bw + 1) x 36 doubles)
 
 // in-place inverse of the SPD n x n block X (LDS, row stride kWLd), n = kWB: 16 x 16 tiles of 6 x 6, one per thread (256 threads)
-__device__ __forceinline__ void wide_gj_inverse(double *X, int tid, int &bad) {
+__device__ __forceinline__ void wide_gj_inverse(double *X, int tid, int &bad, int npiv = kWB / 6) {
   constexpr int NT = kWB / 6;
   const int tr = tid / NT, tq = tid - tr * NT;
   double own[6][6];
@@ -1808,7 +1818,7 @@ __device__ __forceinline__ void wide_gj_inverse(double *X, int tid, int &bad) {
 #pragma unroll
     for (int c = 0; c < 6; c++) own[r][c] = X[(6 * tr + r) * kWLd + 6 * tq + c];
 #pragma unroll 1
-  for (int k = 0; k < NT; k++) {
+  for (int k = 0; k < npiv; k++) {  // (the rows from 6 npiv on are an identity block: nothing to eliminate)
     double nr[6][6];
     {
       double P[6][6];
@@ -2086,6 +2096,206 @@ __global__ void wide_store_kernel(Dev d, RhsSet rs) {
   const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (g < 6L * d.S)
     for (int q = 0; q < rs.nrhs; q++) rs.out(q)[g] = d.wx[g * NR + q];
+  if (rs.cam_q >= 0 && g < d.NC) {
+    const double *Bi = d.Binv + 36 * (long)d.S + 9 * g, *rr = rs.in(rs.cam_q) + d.cam0 + 3 * g;
+    double *z = rs.out(rs.cam_q);
+    for (int i = 0; i < 3; i++) z[d.cam0 + 3 * g + i] = Bi[3 * i] * rr[0] + Bi[3 * i + 1] * rr[1] + Bi[3 * i + 2] * rr[2];
+  }
+}
+
+
+// ---- wide band, round 4: block cyclic reduction over DENSE clusters ---------------------------------------------------------------
+// The block LDL^T above is a chain of S / 16 launches (28 ms at 5 000 shots) whatever the half-width.  Grouping qcs >= bw shots into
+// one cluster makes the band matrix block tridiagonal with qm = 6 qcs (150 ... 3 000) unknowns per block, and cyclic reduction
+// eliminates every second cluster of a level at once: log2(S / bw) levels (6-8) instead of S / 16 steps.  The blocks no longer fit a
+// workgroup's LDS, so they live in HBM (column-major) and a level works on all its clusters at once:
+//   D_i <- D_i^-1                       blocked Gauss-Jordan, in place: per panel of <= 96 columns the pivot block is inverted in LDS
+//                                       (dgj_pivot_kernel: the 6 x 6-pivot elimination of the other solvers) and the panel / trailing
+//                                       products are batched dgemm (rocBLAS: plain library GEMMs); ceil(qm / 96) steps per level
+//   G_i = D_i^-1 E_i,  H_i = D_i^-1 E_r^T,   D_{i+st} -= E_r H_i,   D_{i-st} -= E_i^T G_i,   E_{i+st} <- -E_r G_i      batched dgemm
+// (same algebra as bcr_level_kernel; the two updates of a surviving D are separate launches on one stream, so no second accumulator).
+// rocSOLVER's batched potrf / potrs were measured first (round 4): at qm = 612 they are chains of 24- and 32-thread kernels, 25 ms per
+// LM iteration on the 50 x 100 grid.  The solve's sweeps (a wavefront per row, deterministic sums) are hand-written below.
+__global__ void __launch_bounds__(256) dbcr_build_kernel(Dev d, int *status) {
+  const int c = blockIdx.y, m = d.qm, R1 = d.bw + 1;
+  const long m2 = (long)m * m, t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (c == 0 && blockIdx.x == 0 && threadIdx.x == 0) status[2] = 0;
+  if (t >= m2) return;
+  const int cl = (int)(t / m), rl = (int)(t - (long)cl * m);  // column-major: entry (rl, cl)
+  const int s = c * d.qcs + rl / 6, i = rl % 6, s2 = c * d.qcs + cl / 6, j = cl % 6;
+  double v, e = 0.0;
+  if (s >= d.S || s2 >= d.S)
+    v = (rl == cl) ? 1.0 : 0.0;  // identity on the padding rows of the last cluster
+  else {
+    const int k = s - s2;
+    v = k >= 0 ? (k <= d.bw ? d.band[((long)s * R1 + k) * 36 + i * 6 + j] : 0.0) : (-k <= d.bw ? d.band[((long)s2 * R1 - k) * 36 + j * 6 + i] : 0.0);
+  }
+  if (c > 0 && s < d.S) {  // E_c(r, col): row r of cluster c against column col of cluster c - 1
+    const int ke = s - ((c - 1) * d.qcs + cl / 6);
+    if (ke <= d.bw) e = d.band[((long)s * R1 + ke) * 36 + i * 6 + j];
+  }
+  d.qD[(long)c * m2 + t] = v;
+  d.qE[0][(long)c * m2 + t] = e;
+}
+// One panel step of the in-place inversion, first launch: workgroup 0 of a cluster inverts the pivot block A[j0 : j0 + w, j0 : j0 + w] (a
+// Schur complement of an SPD matrix: symmetric, no pivoting) into P; the others copy the row panel (w x m -> R, leading dimension T) and
+// the column panel (m x w -> C, its pivot rows zeroed: the trailing product must leave the pivot rows alone).
+__global__ void __launch_bounds__(256) dgj_pivot_kernel(double *A0, long strideA, int m, int T, int j0, int w, double *P0, double *R0, double *C0,
+                                                        int *status) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int tid = threadIdx.x;
+  double *A = A0 + (long)blockIdx.y * strideA;
+  if (blockIdx.x == 0) {
+    double *X = lds;
+    for (int t = tid; t < kWB * kWB; t += 256) {
+      const int c = t / kWB, r = t - c * kWB;
+      X[r * kWLd + c] = (r < w && c < w) ? A[(long)(j0 + c) * m + j0 + r] : (r == c ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    int bad = 0;
+    wide_gj_inverse(X, tid, bad, (w + 5) / 6);
+    if (bad) status[2] = 1;
+    double *P = P0 + (long)blockIdx.y * T * T;
+    for (int t = tid; t < w * w; t += 256) {
+      const int c = t / w, r = t - c * w;
+      P[(long)c * T + r] = X[r * kWLd + c];
+    }
+    return;
+  }
+  double *R = R0 + (long)blockIdx.y * T * m, *C = C0 + (long)blockIdx.y * T * m;
+  const long n = (long)w * m, nth = (long)(gridDim.x - 1) * 256;
+  for (long t = (long)(blockIdx.x - 1) * 256 + tid; t < n; t += nth) {
+    {  // row panel: entry (r, c), r < w: consecutive threads along a column of A
+      const int c = (int)(t / w), r = (int)(t - (long)c * w);
+      R[(long)c * T + r] = A[(long)c * m + j0 + r];
+    }
+    {  // column panel: entry (r, c), c < w
+      const int c = (int)(t / m), r = (int)(t - (long)c * m);
+      C[(long)c * m + r] = (r >= j0 && r < j0 + w) ? 0.0 : A[(long)(j0 + c) * m + r];
+    }
+  }
+}
+// last launch of the step: the pivot rows become P A_J,: (Rn), the pivot block P
+__global__ void __launch_bounds__(256) dgj_scatter_kernel(double *A0, long strideA, int m, int T, int j0, int w, const double *P0, const double *Rn0) {
+  double *A = A0 + (long)blockIdx.y * strideA;
+  const double *P = P0 + (long)blockIdx.y * T * T, *Rn = Rn0 + (long)blockIdx.y * T * m;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long)w * m) return;
+  const int c = (int)(t / w), r = (int)(t - (long)c * w);
+  A[(long)c * m + j0 + r] = (c >= j0 && c < j0 + w) ? P[(long)(c - j0) * T + r] : Rn[(long)c * T + r];
+}
+// dst_(k, w) = src_(k, w)^T for m x m column-major blocks; block (k, w) at base + k * stride_k + w * stride_w; 32 x 32 tiles through LDS
+__global__ void __launch_bounds__(256) dbcr_transpose_kernel(const double *src, long src_k, long src_w, double *dst, long dst_k, long dst_w, int m, int nw) {
+  __shared__ double tile[32][33];
+  const int k = blockIdx.z / nw, w = blockIdx.z - k * nw;
+  const double *S = src + (long)k * src_k + (long)w * src_w;
+  double *D = dst + (long)k * dst_k + (long)w * dst_w;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int c = c0 + ty + 8 * u, r = r0 + tx;
+    if (r < m && c < m) tile[ty + 8 * u][tx] = S[(long)c * m + r];  // tile[c - c0][r - r0] = S(r, c)
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int c = r0 + ty + 8 * u, r = c0 + tx;  // D(r, c) = S(c, r)
+    if (r < m && c < m) D[(long)c * m + r] = tile[tx][ty + 8 * u];
+  }
+}
+// One level of a solve, NR right-hand sides side by side: a wavefront per row of a target cluster, its lanes along the (contiguous)
+// column of every block that feeds the row, fixed summation order.  mode 0 (down): b_j -= H_{j-st}^T b_{j-st} + G_{j+st}^T b_{j+st} in
+// place in qx; mode 1 (up): x_i = D_i^-1 b_i - G_i x_{i-st} - H_i x_{i+st} into qy (transposed copies: row r of G = column r of G^T);
+// mode 2: x_0 = D_0^-1 b_0
+template <int NR>
+__global__ void __launch_bounds__(256) dbcr_sweep_kernel(Dev d, int st, int mode) {
+  const int m = d.qm, N = d.qN;
+  const long m2 = (long)m * m;
+  const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int tgt;
+  const double *M[3] = {nullptr, nullptr, nullptr}, *x[3] = {nullptr, nullptr, nullptr};
+  if (mode == 0) {
+    tgt = 2 * blockIdx.y * st;
+    if (tgt >= N) return;
+    const int i1 = tgt - st, i2 = tgt + st;
+    if (i1 >= 0) {
+      M[0] = d.qX + (long)i1 * 2 * m2 + m2;
+      x[0] = d.qx + (long)i1 * m * NR;
+    }
+    if (i2 < N) {
+      M[1] = d.qX + (long)i2 * 2 * m2;
+      x[1] = d.qx + (long)i2 * m * NR;
+    }
+  } else if (mode == 1) {
+    tgt = (2 * blockIdx.y + 1) * st;
+    if (tgt >= N) return;
+    M[0] = d.qD + (long)tgt * m2;  // D^-1 is symmetric: row r = column r
+    x[0] = d.qx + (long)tgt * m * NR;
+    M[1] = d.qXt + (long)tgt * 2 * m2;
+    x[1] = d.qy + (long)(tgt - st) * m * NR;
+    if (tgt + st < N) {
+      M[2] = d.qXt + (long)tgt * 2 * m2 + m2;
+      x[2] = d.qy + (long)(tgt + st) * m * NR;
+    }
+  } else {
+    tgt = 0;
+    M[0] = d.qD;
+    x[0] = d.qx;
+  }
+  if (r >= m) return;  // whole wavefronts
+  double acc[3][NR];
+#pragma unroll
+  for (int p = 0; p < 3; p++)
+#pragma unroll
+    for (int q = 0; q < NR; q++) acc[p][q] = 0.0;
+#pragma unroll
+  for (int p = 0; p < 3; p++) {
+    if (!M[p]) continue;
+    const double *col = M[p] + (long)r * m;
+    for (int k0 = lane; k0 < m; k0 += 256) {  // four loads of the column in flight per lane
+      double mv[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) mv[u] = k0 + 64 * u < m ? col[k0 + 64 * u] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        if (k0 + 64 * u >= m) continue;
+        const double *xv = x[p] + (long)(k0 + 64 * u) * NR;
+#pragma unroll
+        for (int q = 0; q < NR; q++) acc[p][q] = __builtin_fma(mv[u], xv[q], acc[p][q]);
+      }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < 3; p++)
+#pragma unroll
+    for (int q = 0; q < NR; q++)
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) acc[p][q] += __shfl_xor(acc[p][q], o);
+  if (lane == 0) {
+    if (mode == 0) {
+      double *b = d.qx + ((long)tgt * m + r) * NR;
+#pragma unroll
+      for (int q = 0; q < NR; q++) b[q] = (b[q] - acc[0][q]) - acc[1][q];
+    } else {
+      double *o = d.qy + ((long)tgt * m + r) * NR;
+#pragma unroll
+      for (int q = 0; q < NR; q++) o[q] = (acc[0][q] - acc[1][q]) - acc[2][q];
+    }
+  }
+}
+template <int NR>
+__global__ void dbcr_load_kernel(Dev d, RhsSet rs) {
+  const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (long)d.qN * d.qm) return;
+#pragma unroll
+  for (int q = 0; q < NR; q++) d.qx[g * NR + q] = (q < rs.nrhs && g < 6L * d.S) ? rs.in(q)[g] : 0.0;
+}
+template <int NR>
+__global__ void dbcr_store_kernel(Dev d, RhsSet rs) {
+  const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < 6L * d.S)
+    for (int q = 0; q < rs.nrhs; q++) rs.out(q)[g] = d.qy[g * NR + q];
   if (rs.cam_q >= 0 && g < d.NC) {
     const double *Bi = d.Binv + 36 * (long)d.S + 9 * g, *rr = rs.in(rs.cam_q) + d.cam0 + 3 * g;
     double *z = rs.out(rs.cam_q);
@@ -3072,8 +3282,107 @@ struct Solver {
     for (int J = d.wNB - 1; J >= 1; J--) hipLaunchKernelGGL((wide_push_kernel<NR, true>), dim3(std::min(d.wWb, J)), dim3(kWB * kWKS), 0, st, d, J);
     hipLaunchKernelGGL(wide_store_kernel<NR>, dim3(nblk(std::max<long>(6L * d.S, d.NC))), dim3(TPB), 0, st, d, rs);
   }
+  // ---- dense-cluster cyclic reduction of the wide band (kernels: dbcr_*) ----
+  rocblas_handle blas = nullptr;
+  // A_k <- A_k^-1 for `batch` SPD qm x qm blocks `strideA` apart: blocked Gauss-Jordan, panels of qT columns.  Per panel J:
+  //   P = A_JJ^-1 (LDS), R = A_J,: and C = A_:,J copied (C's pivot rows zeroed);  Rn = P R;  A -= C Rn;  A_:,J = -C P;  A_J,: = Rn, A_JJ = P
+  int dbcr_invert_batch(double *A, long strideA, int batch, int *d_status) {
+    const int m = d.qm, T = d.qT;
+    const double one = 1.0, neg = -1.0, zero = 0.0;
+    auto ok = [](rocblas_status r) { return r == rocblas_status_success; };
+    const long sP = (long)T * T, sR = (long)T * m;
+    for (int j0 = 0; j0 < m; j0 += T) {
+      const int w = std::min(T, m - j0);
+      const int ncopy = (int)std::min<long>(64, ((long)w * m + 255) / 256);
+      hipLaunchKernelGGL(dgj_pivot_kernel, dim3(1 + ncopy, batch), dim3(256), (size_t)kWB * kWLd * sizeof(double), st, A, strideA, m, T, j0, w, d.qP, d.qR,
+                         d.qC, d_status);
+      OSFM_REQUIRE(ok(rocblas_dgemm_strided_batched(blas, rocblas_operation_none, rocblas_operation_none, w, m, w, &one, d.qP, T, sP, d.qR, T, sR, &zero, d.qRn,
+                                                    T, sR, batch)),
+                   OSFM_E_HIP, "rocblas_dgemm_strided_batched failed");
+      OSFM_REQUIRE(ok(rocblas_dgemm_strided_batched(blas, rocblas_operation_none, rocblas_operation_none, m, m, w, &neg, d.qC, m, sR, d.qRn, T, sR, &one, A, m,
+                                                    strideA, batch)),
+                   OSFM_E_HIP, "rocblas_dgemm_strided_batched failed");
+      OSFM_REQUIRE(ok(rocblas_dgemm_strided_batched(blas, rocblas_operation_none, rocblas_operation_none, m, w, w, &neg, d.qC, m, sR, d.qP, T, sP, &zero,
+                                                    A + (long)j0 * m, m, strideA, batch)),
+                   OSFM_E_HIP, "rocblas_dgemm_strided_batched failed");
+      hipLaunchKernelGGL(dgj_scatter_kernel, dim3((unsigned)(((long)w * m + 255) / 256), batch), dim3(256), 0, st, A, strideA, m, T, j0, w, d.qP, d.qRn);
+    }
+    return OSFM_OK;
+  }
+  int dbcr_factor(int *d_status) {
+    const int m = d.qm, N = d.qN;
+    const long m2 = (long)m * m;
+    const double neg = -1.0, one = 1.0, zero = 0.0;
+    auto ok = [](rocblas_status r) { return r == rocblas_status_success; };
+    OSFM_REQUIRE(ok(rocblas_set_stream(blas, st)), OSFM_E_HIP, "rocblas_set_stream failed");
+    {
+      static OsfmPerDeviceOnce once;
+      const int rca = once.run(ctx->device, []() -> int {
+        OSFM_HIP(hipFuncSetAttribute((const void *)dgj_pivot_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        return OSFM_OK;
+      });
+      if (rca != OSFM_OK) return rca;
+    }
+    hipLaunchKernelGGL(dbcr_build_kernel, dim3((unsigned)((m2 + 255) / 256), (unsigned)N), dim3(256), 0, st, d, d_status);
+    const unsigned tl = (unsigned)((m + 31) / 32);
+    int cur = 0;
+    for (int s = 1; s < N; s *= 2) {
+      const int ne = (N - s - 1) / (2 * s) + 1;  // clusters (2k + 1) s < N
+      const int nR = (N - 1) / (2 * s);          // ... that have a right neighbour (2k + 2) s < N
+      const long sk = 2L * s * m2;               // from one cluster of the level to the next, in m x m blocks of one array
+      double *Di = d.qD + (long)s * m2, *Ei = d.qE[cur] + (long)s * m2, *Er = d.qE[cur] + 2L * s * m2, *Xi = d.qX + (long)s * 2 * m2;
+      const int rci = dbcr_invert_batch(Di, sk, ne, d_status);
+      if (rci != OSFM_OK) return rci;
+      // G_i = D_i^-1 E_i,  H_i = D_i^-1 E_r^T
+      OSFM_REQUIRE(ok(rocblas_dgemm_strided_batched(blas, rocblas_operation_none, rocblas_operation_none, m, m, m, &one, Di, m, sk, Ei, m, sk, &zero, Xi, m,
+                                                    2 * sk, ne)),
+                   OSFM_E_HIP, "rocblas_dgemm_strided_batched failed");
+      if (nR > 0)
+        OSFM_REQUIRE(ok(rocblas_dgemm_strided_batched(blas, rocblas_operation_none, rocblas_operation_transpose, m, m, m, &one, Di, m, sk, Er, m, sk, &zero,
+                                                      Xi + m2, m, 2 * sk, nR)),
+                     OSFM_E_HIP, "rocblas_dgemm_strided_batched failed");
+      hipLaunchKernelGGL(dbcr_transpose_kernel, dim3(tl, tl, 2 * ne), dim3(256), 0, st, Xi, 2 * sk, m2, d.qXt + (long)s * 2 * m2, 2 * sk, m2, m, 2);
+      if (nR > 0)  // D_{i+s} -= E_r H_i
+        OSFM_REQUIRE(ok(rocblas_dgemm_strided_batched(blas, rocblas_operation_none, rocblas_operation_none, m, m, m, &neg, Er, m, sk, Xi + m2, m, 2 * sk, &one,
+                                                      d.qD + 2L * s * m2, m, sk, nR)),
+                     OSFM_E_HIP, "rocblas_dgemm_strided_batched failed");
+      // D_{i-s} -= E_i^T G_i
+      OSFM_REQUIRE(ok(rocblas_dgemm_strided_batched(blas, rocblas_operation_transpose, rocblas_operation_none, m, m, m, &neg, Ei, m, sk, Xi, m, 2 * sk, &one,
+                                                    d.qD, m, sk, ne)),
+                   OSFM_E_HIP, "rocblas_dgemm_strided_batched failed");
+      if (nR > 0)  // E_{i+s} <- -E_r G_i (into the other buffer: E_r is an operand)
+        OSFM_REQUIRE(ok(rocblas_dgemm_strided_batched(blas, rocblas_operation_none, rocblas_operation_none, m, m, m, &neg, Er, m, sk, Xi, m, 2 * sk, &zero,
+                                                      d.qE[1 - cur] + 2L * s * m2, m, sk, nR)),
+                     OSFM_E_HIP, "rocblas_dgemm_strided_batched failed");
+      cur ^= 1;
+    }
+    const int rcr = dbcr_invert_batch(d.qD, m2, 1, d_status);  // the last cluster standing
+    if (rcr != OSFM_OK) return rcr;
+    OSFM_HIP(hipGetLastError());
+    return OSFM_OK;
+  }
+  template <int NR>
+  void dbcr_walk(const RhsSet &rs) {
+    const int N = d.qN, m = d.qm;
+    const unsigned gx = (unsigned)((m + 3) / 4);
+    hipLaunchKernelGGL(dbcr_load_kernel<NR>, dim3(nblk((long)N * m)), dim3(TPB), 0, st, d, rs);
+    int top = 1;
+    for (int s = 1; s < N; s *= 2) {
+      hipLaunchKernelGGL(dbcr_sweep_kernel<NR>, dim3(gx, (N + 2 * s - 1) / (2 * s)), dim3(256), 0, st, d, s, 0);
+      top = s;
+    }
+    hipLaunchKernelGGL(dbcr_sweep_kernel<NR>, dim3(gx, 1), dim3(256), 0, st, d, 1, 2);
+    if (N > 1)
+      for (int s = top; s >= 1; s /= 2) hipLaunchKernelGGL(dbcr_sweep_kernel<NR>, dim3(gx, (N - s - 1) / (2 * s) + 1), dim3(256), 0, st, d, s, 1);
+    hipLaunchKernelGGL(dbcr_store_kernel<NR>, dim3(nblk(std::max<long>(6L * d.S, d.NC))), dim3(TPB), 0, st, d, rs);
+  }
+  template <int NR>
+  void wide_or_dense_walk(const RhsSet &rs) {
+    if (d.qN > 0) dbcr_walk<NR>(rs);
+    else wide_walk<NR>(rs);
+  }
   void wide_solve_set(const RhsSet &rs) {
-    if (rs.nrhs == 1) return wide_walk<1>(rs);
+    if (rs.nrhs == 1) return wide_or_dense_walk<1>(rs);
     for (int q0 = 0; q0 < rs.nrhs; q0 += 4) {
       RhsSet c = rs;
       c.r = rs.r + q0 * rs.r_stride;
@@ -3081,7 +3390,7 @@ struct Solver {
       c.nrhs = std::min(4, rs.nrhs - q0);
       c.qx = (rs.qx >= q0 && rs.qx < q0 + c.nrhs) ? rs.qx - q0 : -1;
       c.cam_q = (rs.cam_q >= q0 && rs.cam_q < q0 + c.nrhs) ? rs.cam_q - q0 : -1;
-      wide_walk<4>(c);
+      wide_or_dense_walk<4>(c);
     }
   }
   void exact_solve_set(const RhsSet &rs) {
@@ -3636,7 +3945,39 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     d.bx = A.alloc<double>((size_t)7 * d.ncl * d.ncd, e);  // up to 7 right-hand sides at a time (the camera border's columns + the solve's)
   }
   d.wNB = 0; d.wWb = 0;
-  if (wide) {
+  d.qN = 0; d.qm = 0; d.qcs = 0;
+  // wide band: cyclic reduction over dense clusters (dbcr_*); OSFM_BA_WIDE_LDLT keeps round 3's block LDL^T chain (measurement knob)
+  const bool dense_cr = wide && getenv("OSFM_BA_WIDE_LDLT") == nullptr;
+  if (dense_cr) {
+    d.qcs = d.bw;
+    d.qm = 6 * d.qcs;
+    d.qN = (S + d.qcs - 1) / d.qcs;
+    const size_t m2 = (size_t)d.qm * d.qm, nq = (size_t)d.qN;
+    d.qD = A.alloc<double>(nq * m2, e);
+    d.qE[0] = A.alloc<double>(nq * m2, e);
+    d.qE[1] = A.alloc<double>(nq * m2, e);
+    d.qX = A.alloc<double>(nq * 2 * m2, e);
+    d.qXt = A.alloc<double>(nq * 2 * m2, e);
+    d.qx = A.alloc<double>(nq * d.qm * 4, e);
+    d.qy = A.alloc<double>(nq * d.qm * 4, e);
+    {  // panels of the blocked inversion: as few as 96 columns allow, balanced, multiples of 6
+      const int np = (d.qm + kWB - 1) / kWB;
+      d.qT = ((d.qm + np - 1) / np + 5) / 6 * 6;
+      const size_t nb = nq / 2 + 1;  // clusters of the largest level
+      d.qP = A.alloc<double>(nb * d.qT * d.qT, e);
+      d.qR = A.alloc<double>(nb * d.qT * d.qm, e);
+      d.qRn = A.alloc<double>(nb * d.qT * d.qm, e);
+      d.qC = A.alloc<double>(nb * d.qT * d.qm, e);
+    }
+    if (!ctx->blas) {
+      rocblas_handle h = nullptr;
+      OSFM_REQUIRE(rocblas_create_handle(&h) == rocblas_status_success, OSFM_E_HIP, "rocblas_create_handle failed");
+      ctx->blas = h;
+      ctx->blas_destroy = [](void *p) { (void)rocblas_destroy_handle((rocblas_handle)p); };
+    }
+    sv.blas = (rocblas_handle)ctx->blas;
+  }
+  if (wide && !dense_cr) {
     d.wNB = (S + kWcs - 1) / kWcs;
     d.wWb = std::min((d.bw + kWcs - 1) / kWcs, d.wNB - 1);
     const size_t nt = (size_t)d.wNB * (d.wWb + 1) * kWB * kWB;
@@ -3825,12 +4166,17 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     sv.use_wide = false;
     sv.use_border = false;
     bool z_solved = false;  // M^-1 b went through the border's walk
-    if (wide) {  // direct block LDL^T of the exact band: one launch per block column
-      hipLaunchKernelGGL(wide_tiles_kernel, dim3(d.wNB, d.wWb + 1), dim3(256), 0, st, d, d_status);
-      const int ntile = d.wWb * (d.wWb + 1) / 2;
-      for (int J = 0; J < d.wNB; J++) {
-        const int left = std::min(d.wWb, d.wNB - 1 - J);  // rows of the window that exist below block column J
-        hipLaunchKernelGGL(wide_factor_kernel, dim3(1 + (left == d.wWb ? ntile : left * (left + 1) / 2)), dim3(256), (size_t)2 * kWB * kWLd * sizeof(double), st, d, J, d_status);
+    if (wide) {
+      if (dense_cr) {  // cyclic reduction over dense clusters: log2(S / bw) levels of batched dense operations
+        const int rcq = sv.dbcr_factor(d_status);
+        if (rcq != OSFM_OK) return rcq;
+      } else {  // direct block LDL^T of the exact band: one launch per block column
+        hipLaunchKernelGGL(wide_tiles_kernel, dim3(d.wNB, d.wWb + 1), dim3(256), 0, st, d, d_status);
+        const int ntile = d.wWb * (d.wWb + 1) / 2;
+        for (int J = 0; J < d.wNB; J++) {
+          const int left = std::min(d.wWb, d.wNB - 1 - J);  // rows of the window that exist below block column J
+          hipLaunchKernelGGL(wide_factor_kernel, dim3(1 + (left == d.wWb ? ntile : left * (left + 1) / 2)), dim3(256), (size_t)2 * kWB * kWLd * sizeof(double), st, d, J, d_status);
+        }
       }
       sv.use_wide = true;
       if (try_border) {

@@ -60,6 +60,8 @@ struct osfm_ctx {
   static constexpr size_t kPoolBytes = (size_t)6 << 30;
   hipStream_t stream_b = nullptr;  // second stream of the batched matching calls (gather + D2H of chunk k under the matcher of k + 1)
   size_t match_hint = 0;        // int32 entries of the last batched call's match list: the next call reserves that much up front
+  void *blas = nullptr;         // ba.hip: rocblas_handle of the wide band's dense-cluster cyclic reduction, made on first use
+  void (*blas_destroy)(void *) = nullptr;
 };
 
 // Tile = 32 descriptors x 128 int8 in MFMA-operand order (4 KiB):

@@ -420,3 +420,34 @@ def test_band_by_windows_equals_band_per_shot(oracle_lib, gpu_ctx, monkeypatch, 
     monkeypatch.delenv("OSFM_BA_BAND_PER_SHOT")
     g2 = bundle.bundle_arrays(pr, {"bundle_max_iterations": 4}, **NO_TOL)
     assert np.array_equal(g["cost_history"], g2["cost_history"]) and np.array_equal(g["shot_pose"], g2["shot_pose"])
+
+
+@pytest.mark.parametrize("shots,points,track,seed", [(150, 5000, 12, 8), (400, 12000, 20, 9)])
+def test_ragged_tracks_match_oracle(oracle_lib, gpu_ctx, shots, points, track, seed):
+    """`make_ba_scene(ragged=True)`: track lengths 2 + Poisson with 15 % of the sightings missing -- no two tracks share a shot set and the
+    half-width is the longest track, beyond the cluster-tridiagonal band: the exact band goes through the wide solver (cyclic reduction over
+    dense clusters) and CG confirms in one or two iterations per LM iteration."""
+    from opensfm_amd import bundle
+
+    pr = synthetic.make_ba_scene(shots, points, track, seed=seed, ragged=True)
+    g = bundle.bundle_arrays(pr, {"bundle_max_iterations": 8}, **NO_TOL)
+    o = oracle_lib.ba_solve(pr, max_iterations=8, **NO_TOL)
+    assert g["preconditioner_bandwidth"] == g["shot_bandwidth"] > 10
+    assert np.allclose(g["cost_history"], o["cost_history"], rtol=1e-9)
+    assert np.abs(g["shot_pose"] - o["shot_pose"]).max() < 1e-7
+    assert g["pcg_iterations"] <= 3 * g["iterations"]
+
+
+def test_dense_cyclic_reduction_equals_block_ldlt(oracle_lib, gpu_ctx, monkeypatch):
+    """The two factorisations of the wide band (round 4: cyclic reduction over dense clusters; round 3: block LDL^T chain, kept under
+    OSFM_BA_WIDE_LDLT) are the same preconditioner: same CG iteration counts, same trajectory."""
+    from opensfm_amd import bundle
+
+    pr = synthetic.make_ba_scene_grid(12, 30, 6000, 9, seed=4)
+    a = bundle.bundle_arrays(pr, {"bundle_max_iterations": 6}, **NO_TOL)
+    monkeypatch.setenv("OSFM_BA_WIDE_LDLT", "1")
+    b = bundle.bundle_arrays(pr, {"bundle_max_iterations": 6}, **NO_TOL)
+    monkeypatch.delenv("OSFM_BA_WIDE_LDLT")
+    assert a["preconditioner_bandwidth"] == b["preconditioner_bandwidth"] > 15
+    assert a["pcg_iterations"] == b["pcg_iterations"]
+    assert np.allclose(a["cost_history"], b["cost_history"], rtol=1e-10)
