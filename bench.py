@@ -302,6 +302,12 @@ def main():
                 return ba_bench.run(ctx, args.ba_shots, args.ba_points, args.ba_track, args.ba_iters, cpu_baseline=not args.no_cpu_baseline)
 
             section("ba", ba_section)
+        # the JSON line is the LAST line of stdout: RCCL's version banner (written through C stdio when the exchange emulation makes its
+        # one-rank communicator) would otherwise be flushed behind it at exit
+        import ctypes
+
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
@@ -396,6 +402,32 @@ def hahog_bench(ctx, with_cpu, rows: int = 1536, cols: int = 2048, target: int =
                         "frac": round(alg_bytes / (ms * 1e-3) / 1e9 / 8000.0, 4), "algorithmic_bytes": alg_bytes,
                         "note": "whole call (H2D of the image, ~50 launches, two host round trips for the feature counts, D2H of the results) "
                                 "against the streaming bytes of the pyramid"}}
+    # a data set's worth of images in one call (osfm_hahog_extract_batch): several in flight on separate streams / host threads
+    try:
+        import torch
+
+        nb = 32
+        for conc in (4, 8):
+            features.hahog_batch([im] * 8, 1e-5, 10.0, target, concurrency=conc, ctx=ctx)  # warm-up: streams, block cache
+            t0 = time.perf_counter()
+            res = features.hahog_batch([im] * nb, 1e-5, 10.0, target, concurrency=conc, ctx=ctx)
+            dt = time.perf_counter() - t0
+            out[f"batch_host_images_x{conc}"] = {"value": round(nb / dt, 1), "unit": "images/s", "images": nb, "concurrency": conc,
+                                                 "identical_to_single": bool(all(np.array_equal(p, pts) and np.array_equal(dd, desc) for p, dd in res))}
+        dev = torch.from_numpy(im).to(f"cuda:{ctx.device}")
+        torch.cuda.synchronize()
+        for conc in (4, 8):
+            features.hahog_batch([dev.data_ptr()] * 8, 1e-5, 10.0, target, concurrency=conc, shapes=[im.shape] * 8, ctx=ctx)
+            t0 = time.perf_counter()
+            res = features.hahog_batch([dev.data_ptr()] * nb, 1e-5, 10.0, target, concurrency=conc, shapes=[im.shape] * nb, ctx=ctx)
+            dt = time.perf_counter() - t0
+            out[f"batch_resident_images_x{conc}"] = {
+                "value": round(nb / dt, 1), "unit": "images/s", "images": nb, "concurrency": conc,
+                "hbm_frac": round(alg_bytes * nb / dt / 1e9 / 8000.0, 4),
+                "identical_to_single": bool(all(np.array_equal(p, pts) and np.array_equal(dd, desc) for p, dd in res)),
+                "note": "images already in HBM (OSFM_HAHOG_IMAGE_ON_DEVICE); keypoints and descriptors still come back to the host"}
+    except Exception as exc:  # noqa: BLE001
+        out["batch_error"] = f"{type(exc).__name__}: {exc}"
     if with_cpu:
         import oracle
 

@@ -49,8 +49,8 @@ def run_grid(ctx, rows: int = 50, cols: int = 100, points: int = 500000, track: 
             "inlier_rmse_px": round(float(np.sqrt((g["reproj_err"][inl] ** 2).sum(1).mean()) * 2000.0), 4),
             "cost": [float(g["initial_cost"]), float(g["final_cost"])], "lm_iteration": lm_iteration_line(g, nobs),
             "solver_note": "exact band of half-width `preconditioner_bandwidth` shots, block tridiagonal over dense clusters of that many "
-                           "shots, factorised by cyclic reduction (log2(S / bw) levels of batched Cholesky / triangular solves / dgemm); a "
-                           "solve = one launch per level down and up; CG confirms in 1-2 iterations"}
+                           "shots, factorised by cyclic reduction (log2(S / bw) levels; per level a blocked in-place Gauss-Jordan inverse -- pivot "
+                           "panels in LDS -- and batched dgemm); a solve = one launch per level down and up; CG confirms in 1-2 iterations"}
     if cpu_iters > 0:
         out["cpu_baseline"] = _oracle_leg(pr, ctx, cpu_iters, "exact Schur + skyline Cholesky (serial) of half-width 6 x bandwidth")
     return out

@@ -513,6 +513,16 @@ int osfm_radius_points(osfm_ctx *ctx, const double *candidates, int n_candidates
 #define OSFM_HAHOG_UCHAR 2
 int osfm_hahog_extract(osfm_ctx *ctx, const float *image, int rows, int cols, float peak_threshold, float edge_threshold,
                        int target_num_features, int flags, float *points, float *desc, int capacity, int *n_features);
+/* The same for a list of images (what `opensfm detect_features` runs over a data set, one image per process in the reference:
+ * opensfm/actions/detect_features.py -> features_processing.run_features_processing): up to `concurrency` (0: 4; at most 16) images in
+ * flight, each on its own HIP stream and host thread, so that the ~130 short launches and the two host round trips of one image run
+ * underneath the kernels of the others.  images[i] is rows[i] x cols[i]; points[i] / desc[i] have capacities[i] rows; n_features[i] as
+ * above.  Results are those of osfm_hahog_extract image by image.  OSFM_HAHOG_IMAGE_ON_DEVICE: the image pointers are device memory
+ * (extraction from frames that are already resident, no host-to-device copy inside the call). */
+#define OSFM_HAHOG_IMAGE_ON_DEVICE 4
+int osfm_hahog_extract_batch(osfm_ctx *ctx, int n_images, const float *const *images, const int *rows, const int *cols, float peak_threshold,
+                             float edge_threshold, int target_num_features, int flags, float *const *points, float *const *desc,
+                             const int *capacities, int *n_features, int concurrency);
 
 #ifdef __cplusplus
 }

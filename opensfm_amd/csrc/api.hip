@@ -51,6 +51,7 @@ extern "C" void osfm_ctx_destroy(osfm_ctx *c) {
   if (c->d_fr_scratch) (void)hipFree(c->d_fr_scratch);
   for (auto &b : c->pool) (void)hipFree(b.p);
   if (c->stream_b) (void)hipStreamDestroy(c->stream_b);
+  for (hipStream_t a : c->aux_streams) (void)hipStreamDestroy(a);
   if (c->blas && c->blas_destroy) c->blas_destroy(c->blas);
   delete c;
 }
@@ -59,6 +60,7 @@ extern "C" int64_t osfm_ctx_trim_pool(osfm_ctx *c) {
   if (!c) return 0;
   OSFM_CTX_LOCK(c);
   (void)hipSetDevice(c->device);
+  std::lock_guard<std::mutex> g(c->pool_mu);
   if (!c->pool.empty()) (void)hipDeviceSynchronize();
   const int64_t freed = (int64_t)c->pool_bytes;
   for (auto &b : c->pool) (void)hipFree(b.p);

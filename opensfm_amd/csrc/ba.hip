@@ -777,13 +777,14 @@ __device__ __forceinline__ void jred_jp(const Dev &d, long k, double E[6][3]) { 
 // per six outputs accumulating in registers, deterministic): 2.28 ms with one gather in flight, 2.77 ms with two and 512 threads,
 // against 1.76 ms here -- the kernel is bound by the ~4 GB gather of partner blocks (every E row is wanted by the ~10 shots that see
 // its point, in ten different orders: the reuse misses the 4 MB L2s), not by the accumulation.
-__global__ void __launch_bounds__(TPB) band_assemble_kernel(Dev d, double radius, int copies) {
+// Half-widths beyond what one workgroup's LDS holds (round 4): the launch is repeated per slice of band columns dk_lo <= dk < dk_lo + ndk.
+__global__ void __launch_bounds__(TPB) band_assemble_kernel(Dev d, double radius, int copies, int dk_lo, int ndk) {
   // kBandCopies private copies of the accumulators, copy = lane & (kBandCopies - 1), interleaved so that the copies of one entry sit
   // in different banks: the lanes of a wavefront add into a handful of (dk, i, j) entries at a time, and same-address fp64 LDS
   // atomics serialise
   extern __shared__ __attribute__((aligned(16))) double acc[];  // (bw + 1) * 36 * copies (copies: a power of two, 8 where LDS allows)
   // blocks are dealt round-robin to the 8 XCDs: give every XCD a contiguous range of shots, whose workgroups gather the same E rows
-  const int s = (int)xcd_contiguous(blockIdx.x, gridDim.x), nb = (d.bw + 1) * 36;
+  const int s = (int)xcd_contiguous(blockIdx.x, gridDim.x), nb = ndk * 36;
   const int copy = threadIdx.x & (copies - 1);
   for (int t = threadIdx.x; t < nb * copies; t += TPB) acc[t] = 0.0;
   __syncthreads();
@@ -798,8 +799,8 @@ __global__ void __launch_bounds__(TPB) band_assemble_kernel(Dev d, double radius
 #pragma unroll
       for (int j = 0; j < 3; j++) EH[i][j] = Ea[i][0] * h[j] + Ea[i][1] * h[3 + j] + Ea[i][2] * h[6 + j];
     for (long o2 = d.pt_off[p]; o2 < d.pt_off[p + 1]; o2++) {
-      const int dk = s - d.o_shot[o2];
-      if (dk < 0 || dk > d.bw) continue;
+      const int dk = s - d.o_shot[o2] - dk_lo;
+      if (dk < 0 || dk >= ndk) continue;
       double Eb[6][3];
       {
         const double2 *src = reinterpret_cast<const double2 *>(d.Epm + 18 * o2);
@@ -819,7 +820,7 @@ __global__ void __launch_bounds__(TPB) band_assemble_kernel(Dev d, double radius
   }
   __syncthreads();
   for (int t = threadIdx.x; t < nb; t += TPB) {
-    const int dk = t / 36, ij = t % 36, i = ij / 6, j = ij % 6;
+    const int dk = dk_lo + t / 36, ij = t % 36, i = ij / 6, j = ij % 6;
     const int s2 = s - dk;
     double val = 0.0;
     if (s2 >= 0) {
@@ -1806,7 +1807,8 @@ inline BcrLaunch bcr_level_for(int cs) {
 // would only add its overhead), forms L_IJ and subtracts L_IJ A_KJ^T from A_IK.  Flops are n w^2 (11-44 GFLOP at configs[4] size with
 // w = 600-1200): irrelevant; the factorisation is the latency of S / 16 launches x 16 pivot steps.
 constexpr int kWcs = 16, kWB = 6 * kWcs, kWLd = kWB + 2;  // shots per block, block order, LDS row stride (even: 16-byte rows; 6 rows apart = 24 banks)
-constexpr int kWMaxBw = 520;                               // shot half-width the band assembly's LDS accumulators hold (one copy of (bw + 1) x 36 doubles)
+constexpr int kBandSlice = 520;                            // band columns the assembly's LDS accumulators hold (one copy of 520 x 36 doubles = 150 KB)
+constexpr int kWMaxBw = 2079;                              // widest exact band: four assembly passes; the dense-cluster blocks are (6 bw)^2 doubles each
 
 // in-place inverse of the SPD n x n block X (LDS, row stride kWLd), n = kWB: 16 x 16 tiles of 6 x 6, one per thread (256 threads)
 __device__ __forceinline__ void wide_gj_inverse(double *X, int tid, int &bad, int npiv = kWB / 6) {
@@ -3889,12 +3891,14 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
   const long nbmax = std::max<long>(std::max<long>(nblk(M), nblk(3L * NP)), d.nwg);
   d.partial = A.alloc<double>((size_t)2 * nbmax + 16, e);
   // block half-bandwidth of the shot-shot coupling (shots in caller order): bw_true, from track_width_kernel above
-  // half-width up to 10: exact band, cyclic reduction; up to kWMaxBw: exact band, direct block LDL^T (wide_*); beyond: truncated to kMaxBw
+  // half-width up to 10: exact band, cyclic reduction in LDS; up to kWMaxBw: exact band, cyclic reduction over dense clusters (dbcr_*); beyond: truncated to kMaxBw
   const bool wide = O->preconditioner == 0 && S >= 2 && bw_true > kMaxBw && bw_true <= kWMaxBw && getenv("OSFM_BA_NO_WIDE") == nullptr;
   d.bw = O->preconditioner == 1 ? 0 : (wide ? bw_true : std::min(bw_true, kMaxBw));
   if (S < 2) d.bw = 0;
+  // band columns per launch of the per-shot assembly: all of them when one copy fits a workgroup's LDS, else equal slices of at most kBandSlice
+  const int band_nslice = (d.bw + 1 + kBandSlice - 1) / kBandSlice, band_slice = (d.bw + 1 + band_nslice - 1) / band_nslice;
   int band_copies = kBandCopies;  // private copies of the band assembly's LDS accumulators
-  while (band_copies > 1 && (size_t)(d.bw + 1) * 36 * band_copies * sizeof(double) > 150 * 1024) band_copies /= 2;
+  while (band_copies > 1 && (size_t)band_slice * 36 * band_copies * sizeof(double) > 150 * 1024) band_copies /= 2;
   d.band = A.alloc<double>((size_t)S * (d.bw + 1) * 36, e);
   // exact narrow band, one observation per (track, shot): assembled on the matrix cores (band_mfma_kernel), else per shot with LDS atomics
   const bool win_band = d.bw >= 1 && d.bw <= kMaxBw && d.bw == bw_true && !track_repeats_shot && bp_pts != nullptr && getenv("OSFM_BA_BAND_PER_SHOT") == nullptr;
@@ -4103,7 +4107,8 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
           const size_t nbd = (size_t)S * (d.bw + 1) * 36;
           std::vector<double> b_win(nbd), b_shot(nbd);
           OSFM_HIP(hipMemcpyAsync(b_win.data(), d.band, nbd * sizeof(double), hipMemcpyDeviceToHost, st));
-          hipLaunchKernelGGL(band_assemble_kernel, dim3(S), dim3(TPB), (size_t)(d.bw + 1) * 36 * band_copies * sizeof(double), st, d, radius, band_copies);
+          hipLaunchKernelGGL(band_assemble_kernel, dim3(S), dim3(TPB), (size_t)(d.bw + 1) * 36 * band_copies * sizeof(double), st, d, radius, band_copies, 0,
+                             d.bw + 1);
           OSFM_HIP(hipMemcpyAsync(b_shot.data(), d.band, nbd * sizeof(double), hipMemcpyDeviceToHost, st));
           OSFM_HIP(hipStreamSynchronize(st));
           double amax = 0, dmax = 0;
@@ -4116,8 +4121,11 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
           OSFM_HIP(hipMemcpyAsync(d.band, b_win.data(), nbd * sizeof(double), hipMemcpyHostToDevice, st));
           OSFM_HIP(hipStreamSynchronize(st));
         }
-      } else
-        hipLaunchKernelGGL(band_assemble_kernel, dim3(S), dim3(TPB), (size_t)(d.bw + 1) * 36 * band_copies * sizeof(double), st, d, radius, band_copies);
+      } else {
+        for (int lo = 0; lo <= d.bw; lo += band_slice)
+          hipLaunchKernelGGL(band_assemble_kernel, dim3(S), dim3(TPB), (size_t)std::min(band_slice, d.bw + 1 - lo) * 36 * band_copies * sizeof(double), st, d,
+                             radius, band_copies, lo, std::min(band_slice, d.bw + 1 - lo));
+      }
       sv.use_ctri = false;
       sv.use_bcr = false;
     }

@@ -18,6 +18,9 @@
 // Kernels are plain HBM-bound stencils and per-feature workgroups (no matrix cores: there is no contraction here).
 #include <cmath>
 #include <cstring>
+#include <atomic>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include <rocprim/rocprim.hpp>
@@ -924,19 +927,15 @@ extern "C" int osfm_dbg_hahog_phases(unsigned long long *out, int reset) {
   return 0;
 }
 #endif
-extern "C" int osfm_hahog_extract(osfm_ctx *ctx, const float *image, int rows, int cols, float peak_threshold, float edge_threshold,
-                                  int target_num_features, int flags, float *points, float *desc, int capacity, int *n_features) {
+// one image on one stream (the caller holds the context lock; the block cache has its own)
+static int hahog_extract_on_stream(osfm_ctx *ctx, hipStream_t st, const float *image, int rows, int cols, float peak_threshold, float edge_threshold,
+                                   int target_num_features, int flags, float *points, float *desc, int capacity, int *n_features) {
   OSFM_REQUIRE(ctx && image && n_features, OSFM_E_INVALID, "osfm_hahog_extract: null argument");
   OSFM_REQUIRE(rows > 0 && cols > 0, OSFM_E_INVALID, "osfm_hahog_extract: image %d x %d", rows, cols);
   OSFM_REQUIRE(target_num_features >= 0 && capacity >= 0, OSFM_E_INVALID, "osfm_hahog_extract: negative count");
-  if (rows < 17 || cols < 17) {  // smaller than one 16-pixel octave (covdet.c:1686 gives lastOctave < firstOctave: vlfeat has no scale space
-    *n_features = 0;             // to search): a thumbnail or a masked crop yields no features instead of stopping a pipeline
-    return OSFM_OK;
-  }
-  OSFM_CTX_LOCK(ctx);
-  OSFM_HIP(hipSetDevice(ctx->device));
-  hipStream_t st = ctx->stream;
   *n_features = 0;
+  if (rows < 17 || cols < 17)  // smaller than one 16-pixel octave (covdet.c:1686 gives lastOctave < firstOctave: vlfeat has no scale space
+    return OSFM_OK;            // to search): a thumbnail or a masked crop yields no features instead of stopping a pipeline
   const int W0 = cols, H0 = rows;
   // vl_covdet_put_image (covdet.c:1670-1725): (minOctaveSize - 1) 2^lastOctave <= min(width, height) - 1
   const int last_octave = (int)std::floor(std::log2(std::min((double)W0 - 1, (double)H0 - 1) / 15.0));
@@ -999,7 +998,8 @@ extern "C" int osfm_hahog_extract(osfm_ctx *ctx, const float *image, int rows, i
     hipLaunchKernelGGL(conv_h_kernel, grid2(w, h), dim3(256), 0, st, (const float *)d_tmp, dst, w, h, d_taps + (size_t)slot * kMaxTaps, W);
   };
   // vl_scalespace_put_image
-  OSFM_HIP(hipMemcpyAsync(py.oct[0].gss, image, (size_t)W0 * H0 * sizeof(float), hipMemcpyHostToDevice, st));
+  OSFM_HIP(hipMemcpyAsync(py.oct[0].gss, image, (size_t)W0 * H0 * sizeof(float),
+                          (flags & OSFM_HAHOG_IMAGE_ON_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
   for (int o = 0; o <= last_octave; o++) {
     const Octave &oc = py.oct[o];
     const size_t npx = (size_t)oc.w * oc.h;
@@ -1123,5 +1123,64 @@ extern "C" int osfm_hahog_extract(osfm_ctx *ctx, const float *image, int rows, i
   OSFM_HIP(hipMemcpyAsync(points, d_points, (size_t)4 * n2 * sizeof(float), hipMemcpyDeviceToHost, st));
   OSFM_HIP(hipMemcpyAsync(desc, d_desc, (size_t)128 * n2 * sizeof(float), hipMemcpyDeviceToHost, st));
   OSFM_HIP(hipStreamSynchronize(st));
+  return OSFM_OK;
+}
+
+extern "C" int osfm_hahog_extract(osfm_ctx *ctx, const float *image, int rows, int cols, float peak_threshold, float edge_threshold,
+                                  int target_num_features, int flags, float *points, float *desc, int capacity, int *n_features) {
+  OSFM_REQUIRE(ctx && image && n_features, OSFM_E_INVALID, "osfm_hahog_extract: null argument");
+  OSFM_CTX_LOCK(ctx);
+  OSFM_HIP(hipSetDevice(ctx->device));
+  return hahog_extract_on_stream(ctx, ctx->stream, image, rows, cols, peak_threshold, edge_threshold, target_num_features, flags, points, desc, capacity,
+                                 n_features);
+}
+
+// Several images per call.  One image is ~130 short launches and two host round trips (the number of detections sizes the sorts, the
+// number of oriented frames the descriptor launch): a single stream leaves the chip idle between them.  Here up to `concurrency` images
+// are in flight, each on its own stream and host thread, so that the launches and round trips of one image run under the kernels of the
+// others.  Results are those of osfm_hahog_extract image by image.
+extern "C" int osfm_hahog_extract_batch(osfm_ctx *ctx, int n_images, const float *const *images, const int *rows, const int *cols, float peak_threshold,
+                                        float edge_threshold, int target_num_features, int flags, float *const *points, float *const *desc,
+                                        const int *capacities, int *n_features, int concurrency) {
+  OSFM_REQUIRE(ctx && n_images >= 0 && (n_images == 0 || (images && rows && cols && points && desc && capacities && n_features)), OSFM_E_INVALID,
+               "osfm_hahog_extract_batch: null argument");
+  if (n_images == 0) return OSFM_OK;
+  OSFM_CTX_LOCK(ctx);
+  OSFM_HIP(hipSetDevice(ctx->device));
+  const int K = std::max(1, std::min(n_images, concurrency > 0 ? std::min(concurrency, 16) : 4));
+  while ((int)ctx->aux_streams.size() < K) {
+    hipStream_t s = nullptr;
+    OSFM_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    ctx->aux_streams.push_back(s);
+  }
+  std::atomic<int> next{0};
+  std::vector<int> rc((size_t)K, OSFM_OK);
+  std::vector<std::string> err((size_t)K);
+  auto work = [&](int k) {
+    if (hipSetDevice(ctx->device) != hipSuccess) {
+      rc[(size_t)k] = OSFM_E_HIP;
+      err[(size_t)k] = "hipSetDevice failed in a worker thread";
+      return;
+    }
+    for (;;) {
+      const int i = next.fetch_add(1);
+      if (i >= n_images || rc[(size_t)k] != OSFM_OK) break;
+      const int r = hahog_extract_on_stream(ctx, ctx->aux_streams[(size_t)k], images[i], rows[i], cols[i], peak_threshold, edge_threshold,
+                                            target_num_features, flags, points[i], desc[i], capacities[i], &n_features[i]);
+      if (r != OSFM_OK) {
+        rc[(size_t)k] = r;
+        err[(size_t)k] = std::string("image ") + std::to_string(i) + ": " + osfm_last_error();  // this thread's message, for the caller's
+      }
+    }
+  };
+  std::vector<std::thread> th;
+  for (int k = 1; k < K; k++) th.emplace_back(work, k);
+  work(0);
+  for (auto &t : th) t.join();
+  for (int k = 0; k < K; k++)
+    if (rc[(size_t)k] != OSFM_OK) {
+      osfm_set_error("osfm_hahog_extract_batch: %s", err[(size_t)k].c_str());
+      return rc[(size_t)k];
+    }
   return OSFM_OK;
 }

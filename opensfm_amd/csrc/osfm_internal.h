@@ -57,6 +57,8 @@ struct osfm_ctx {
   };
   std::vector<PoolBlock> pool;
   size_t pool_bytes = 0;
+  std::mutex pool_mu;  // the block cache itself: osfm_hahog_extract_batch's worker threads take and return blocks while the caller holds `mu`
+  std::vector<hipStream_t> aux_streams;  // hahog.hip: one stream per concurrent image of a batch, made on first use
   static constexpr size_t kPoolBytes = (size_t)6 << 30;
   hipStream_t stream_b = nullptr;  // second stream of the batched matching calls (gather + D2H of chunk k under the matcher of k + 1)
   size_t match_hint = 0;        // int32 entries of the last batched call's match list: the next call reserves that much up front
@@ -156,12 +158,16 @@ struct OsfmPoolBuf {
     if (!p) return;
     // error path (an early return after OSFM_HIP / OSFM_REQUIRE): kernels of the failed call may still read or write the block
     if (epoch != osfm_error_epoch) (void)hipDeviceSynchronize();
-    if (pool && pool->pool_bytes + bytes <= osfm_ctx::kPoolBytes && pool->pool.size() < 64) {
-      pool->pool.push_back({p, bytes});
-      pool->pool_bytes += bytes;
-    } else {
-      (void)hipFree(p);
+    bool cached = false;
+    if (pool) {
+      std::lock_guard<std::mutex> g(pool->pool_mu);
+      if (pool->pool_bytes + bytes <= osfm_ctx::kPoolBytes && pool->pool.size() < 64) {
+        pool->pool.push_back({p, bytes});
+        pool->pool_bytes += bytes;
+        cached = true;
+      }
     }
+    if (!cached) (void)hipFree(p);
     p = nullptr;
   }
   hipError_t alloc(size_t want) {
@@ -173,6 +179,7 @@ struct OsfmPoolBuf {
     want = want ? want : 16;
     pool = ctx;
     epoch = osfm_error_epoch;
+    std::lock_guard<std::mutex> g(ctx->pool_mu);
     int best = -1;
     for (int i = 0; i < (int)ctx->pool.size(); ++i)
       if (ctx->pool[i].bytes >= want && ctx->pool[i].bytes <= 2 * want + 4096 && (best < 0 || ctx->pool[i].bytes < ctx->pool[best].bytes)) best = i;

@@ -2,7 +2,7 @@
 (``opensfm/src/features/src/hahog.cc:125-206``) and ``extract_features_hahog`` as ``opensfm/features.py:516-534`` calls it.  Thin ctypes
 glue over ``csrc/hahog.hip``; there is no CPU fallback."""
 import ctypes as C
-from typing import Any, Dict, Optional, Tuple
+from typing import Any, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -11,6 +11,7 @@ from ._lib import check, default_context
 
 HAHOG_ROOT = 1
 HAHOG_UCHAR = 2
+HAHOG_IMAGE_ON_DEVICE = 4
 
 
 def _extract(image: np.ndarray, peak_threshold: float, edge_threshold: float, target_num_features: int, flags: int, ctx=None):
@@ -29,6 +30,38 @@ def _extract(image: np.ndarray, peak_threshold: float, edge_threshold: float, ta
                                  float(edge_threshold), int(target_num_features), int(flags), pts.ctypes.data_as(C.POINTER(C.c_float)),
                                  desc.ctypes.data_as(C.POINTER(C.c_float)), cap, C.byref(n)), "osfm_hahog_extract")
     return pts[: n.value].copy(), desc[: n.value].copy()
+
+
+def hahog_batch(images: Sequence[Any], peak_threshold: float, edge_threshold: float, target_num_features: int, flags: int = 0, concurrency: int = 0,
+                shapes: Optional[Sequence[Tuple[int, int]]] = None, ctx=None) -> List[Tuple[np.ndarray, np.ndarray]]:
+    """``osfm_hahog_extract_batch``: the images of a data set in one call, up to ``concurrency`` (0: 4) in flight on separate streams.
+    ``images``: float32 arrays in [0, 1] (host), or -- with ``shapes`` = their (rows, cols) -- device addresses (ints) of resident images.
+    Returns the (points, descriptors) ``hahog`` returns for each image, in order."""
+    ctx = ctx or default_context()
+    lib = _lib.load()
+    n = len(images)
+    if n == 0:
+        return []
+    on_device = shapes is not None
+    if on_device:
+        flags |= HAHOG_IMAGE_ON_DEVICE
+        ims, rc = None, [(int(r), int(c)) for r, c in shapes]
+        ptrs = (C.c_void_p * n)(*[int(a) for a in images])
+    else:
+        ims = [np.ascontiguousarray(im, np.float32) for im in images]
+        if any(im.ndim != 2 or im.size == 0 for im in ims):
+            raise ValueError("hahog_batch takes non-empty grey-level images (rows x cols)")
+        rc = [im.shape for im in ims]
+        ptrs = (C.c_void_p * n)(*[im.ctypes.data for im in ims])
+    cap = max(16, 4 * int(target_num_features))
+    pts = [np.empty((cap, 4), np.float32) for _ in range(n)]
+    desc = [np.empty((cap, 128), np.float32) for _ in range(n)]
+    rows, cols = (C.c_int * n)(*[r for r, _ in rc]), (C.c_int * n)(*[c for _, c in rc])
+    caps, nf = (C.c_int * n)(*([cap] * n)), (C.c_int * n)()
+    pp, dp = (C.c_void_p * n)(*[a.ctypes.data for a in pts]), (C.c_void_p * n)(*[a.ctypes.data for a in desc])
+    check(lib.osfm_hahog_extract_batch(ctx.handle, n, ptrs, rows, cols, float(peak_threshold), float(edge_threshold), int(target_num_features), int(flags),
+                                       pp, dp, caps, nf, int(concurrency)), "osfm_hahog_extract_batch")
+    return [(pts[i][: nf[i]].copy(), desc[i][: nf[i]].copy()) for i in range(n)]
 
 
 def hahog(image: np.ndarray, peak_threshold: float, edge_threshold: float, target_num_features: int, ctx=None) -> Optional[Tuple[np.ndarray, np.ndarray]]:

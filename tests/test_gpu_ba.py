@@ -451,3 +451,18 @@ def test_dense_cyclic_reduction_equals_block_ldlt(oracle_lib, gpu_ctx, monkeypat
     assert a["preconditioner_bandwidth"] == b["preconditioner_bandwidth"] > 15
     assert a["pcg_iterations"] == b["pcg_iterations"]
     assert np.allclose(a["cost_history"], b["cost_history"], rtol=1e-10)
+
+
+def test_half_width_beyond_one_assembly_pass(gpu_ctx):
+    """Tracks 560 shots long: the exact band (half-width 559) is assembled in two passes of band columns (one workgroup's LDS holds 520)
+    and factorised by the dense-cluster cyclic reduction; CG confirms in one or two iterations per LM iteration, and the trajectory is the
+    one block-Jacobi PCG reaches with hundreds of iterations."""
+    from opensfm_amd import bundle
+
+    pr = synthetic.make_ba_scene(700, 260, 560, seed=21)
+    a = bundle.bundle_arrays(pr, {"bundle_max_iterations": 4}, **NO_TOL)
+    assert a["shot_bandwidth"] == 559 and a["preconditioner_bandwidth"] == 559
+    assert a["pcg_iterations"] <= 3 * a["iterations"]
+    b = bundle.bundle_arrays(pr, {"bundle_max_iterations": 4}, preconditioner=1, pcg_max_iterations=5000, **NO_TOL)
+    assert b["preconditioner_bandwidth"] == 0 and b["pcg_iterations"] > 10 * a["pcg_iterations"]
+    assert np.allclose(a["cost_history"], b["cost_history"], rtol=1e-6)

@@ -106,3 +106,26 @@ def test_descriptors_feed_the_matcher(gpu_ctx):
     assert len(m) > 200
     dx = pb[m[:, 1], 0] - pa[m[:, 0], 0]
     assert np.median(np.abs(dx + 80)) < 0.5  # the crops are 80 pixels apart
+
+
+def test_batch_equals_image_by_image(gpu_ctx):
+    """osfm_hahog_extract_batch: images of different sizes in flight on separate streams and host threads; every image's keypoints (all
+    four columns) and descriptors are bit for bit what the single-image call returns, whatever the concurrency."""
+    from opensfm_amd import features
+
+    rng = np.random.default_rng(5)
+    sizes = [(240, 320), (333, 257), (480, 640), (64, 64), (200, 500), (301, 299), (16, 40), (128, 130), (480, 640)]
+    ims = []
+    for r, c in sizes:
+        im = rng.random((r, c)).astype(np.float32)
+        k = np.ones(5, np.float32) / 5  # some structure: box blur of noise
+        im = np.apply_along_axis(lambda v: np.convolve(v, k, mode="same"), 1, np.apply_along_axis(lambda v: np.convolve(v, k, mode="same"), 0, im))
+        ims.append(np.ascontiguousarray(im, np.float32))
+    single = [features._extract(im, 1e-5, 10.0, 300, features.HAHOG_ROOT | features.HAHOG_UCHAR, gpu_ctx) for im in ims]
+    for conc in (1, 3, 8):
+        got = features.hahog_batch(ims, 1e-5, 10.0, 300, features.HAHOG_ROOT | features.HAHOG_UCHAR, concurrency=conc, ctx=gpu_ctx)
+        assert len(got) == len(single)
+        for (p, d), (ps, ds) in zip(got, single):
+            assert np.array_equal(p, ps) and np.array_equal(d, ds)
+    assert len(single[6][0]) == 0  # below one octave: no features, no error
+    assert sum(len(p) for p, _ in single) > 500
