@@ -404,8 +404,6 @@ def hahog_bench(ctx, with_cpu, rows: int = 1536, cols: int = 2048, target: int =
                                 "against the streaming bytes of the pyramid"}}
     # a data set's worth of images in one call (osfm_hahog_extract_batch): several in flight on separate streams / host threads
     try:
-        import torch
-
         nb = 32
         for conc in (4, 8):
             features.hahog_batch([im] * 8, 1e-5, 10.0, target, concurrency=conc, ctx=ctx)  # warm-up: streams, block cache
@@ -414,18 +412,25 @@ def hahog_bench(ctx, with_cpu, rows: int = 1536, cols: int = 2048, target: int =
             dt = time.perf_counter() - t0
             out[f"batch_host_images_x{conc}"] = {"value": round(nb / dt, 1), "unit": "images/s", "images": nb, "concurrency": conc,
                                                  "identical_to_single": bool(all(np.array_equal(p, pts) and np.array_equal(dd, desc) for p, dd in res))}
-        dev = torch.from_numpy(im).to(f"cuda:{ctx.device}")
-        torch.cuda.synchronize()
-        for conc in (4, 8):
-            features.hahog_batch([dev.data_ptr()] * 8, 1e-5, 10.0, target, concurrency=conc, shapes=[im.shape] * 8, ctx=ctx)
-            t0 = time.perf_counter()
-            res = features.hahog_batch([dev.data_ptr()] * nb, 1e-5, 10.0, target, concurrency=conc, shapes=[im.shape] * nb, ctx=ctx)
-            dt = time.perf_counter() - t0
-            out[f"batch_resident_images_x{conc}"] = {
-                "value": round(nb / dt, 1), "unit": "images/s", "images": nb, "concurrency": conc,
-                "hbm_frac": round(alg_bytes * nb / dt / 1e9 / 8000.0, 4),
-                "identical_to_single": bool(all(np.array_equal(p, pts) and np.array_equal(dd, desc) for p, dd in res)),
-                "note": "images already in HBM (OSFM_HAHOG_IMAGE_ON_DEVICE); keypoints and descriptors still come back to the host"}
+        import ctypes
+
+        hip = ctypes.CDLL("libamdhip64.so")  # a resident copy of the image without going through torch
+        dptr = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(dptr), ctypes.c_size_t(im.nbytes)) == 0
+        try:
+            assert hip.hipMemcpy(dptr, ctypes.c_void_p(im.ctypes.data), ctypes.c_size_t(im.nbytes), 1) == 0
+            for conc in (4, 8, 12):
+                features.hahog_batch([dptr.value] * 8, 1e-5, 10.0, target, concurrency=conc, shapes=[im.shape] * 8, ctx=ctx)
+                t0 = time.perf_counter()
+                res = features.hahog_batch([dptr.value] * nb, 1e-5, 10.0, target, concurrency=conc, shapes=[im.shape] * nb, ctx=ctx)
+                dt = time.perf_counter() - t0
+                out[f"batch_resident_images_x{conc}"] = {
+                    "value": round(nb / dt, 1), "unit": "images/s", "images": nb, "concurrency": conc,
+                    "hbm_frac": round(alg_bytes * nb / dt / 1e9 / 8000.0, 4),
+                    "identical_to_single": bool(all(np.array_equal(p, pts) and np.array_equal(dd, desc) for p, dd in res)),
+                    "note": "images already in HBM (OSFM_HAHOG_IMAGE_ON_DEVICE); keypoints and descriptors still come back to the host"}
+        finally:
+            hip.hipFree(dptr)
     except Exception as exc:  # noqa: BLE001
         out["batch_error"] = f"{type(exc).__name__}: {exc}"
     if with_cpu:

@@ -82,6 +82,89 @@ __global__ void conv_h_kernel(const float *src, float *dst, int w, int h, const 
   }
   dst[(long)y * w + x] = acc;
 }
+// The two passes in one launch (round 4): a workgroup owns a kSmX x kSmY tile of the output.  The source tile with its halo of W rows /
+// columns goes to LDS once (clamped indices: the padding by continuity of both passes), the column pass fills an LDS tile kSmY rows high
+// and kSmX + 2 W columns wide -- the columns the row pass of this tile reads, a clamped column being the column pass of the clamped
+// column --, the row pass writes the result.  Every output value is the same sequence of float products and sums as conv_v_kernel
+// followed by conv_h_kernel (bit-identical); the intermediate image never goes through HBM and each source pixel leaves L2 ~1.6 times
+// instead of 2 W + 1.  src and dst must not overlap (other workgroups read the halo).
+constexpr int kSmX = 64, kSmY = 32, kSmMaxW = 16, kSmR = 8;
+__host__ __device__ constexpr int sm_stride(int W) { return (kSmX + 2 * W) | 1; }  // odd: the row pass has a lane per tile row
+// Sliding windows (W is a template parameter so that they live in registers): a thread of the column pass owns kSmR consecutive rows of
+// one column and loads the kSmR + 2 W source values once; a thread of the row pass owns kSmR consecutive columns of one row.  The sums
+// stay what they were: sum_j value(j) * taps[2 W - j], j ascending from an accumulator of zero, product and sum rounded separately.
+// The Hessian response of the level it has just produced comes out of the same launch (_vl_det_hessian_response, the expression of
+// hessian_kernel below): the tile then carries a halo of two output pixels (the response of a border pixel is that of its nearest
+// interior pixel, one further in), i.e. 60 x 28 pixels of the level per 64 x 32 tile.
+constexpr int kSmHalo = 2;
+template <int W>
+__global__ void __launch_bounds__(256) smooth_fused_kernel(const float *src, float *dst, float *css, int w, int h, const float *taps, float factor) {
+  constexpr int SW = sm_stride(W), SH = kSmY + 2 * W, NT = 2 * W + 1;
+  __shared__ float S[SW * SH], T[SW * kSmY];  // source tile (later the output tile), column-pass tile
+  const int x0 = blockIdx.x * (kSmX - 2 * kSmHalo) - kSmHalo, y0 = blockIdx.y * (kSmY - 2 * kSmHalo) - kSmHalo, tid = threadIdx.x;
+  float tp[NT];
+#pragma unroll
+  for (int j = 0; j < NT; j++) tp[j] = taps[2 * W - j];
+  for (int t = tid; t < (kSmX + 2 * W) * SH; t += 256) {
+    const int r = t / (kSmX + 2 * W), c = t - r * (kSmX + 2 * W);
+    int gy = y0 - W + r, gx = x0 - W + c;
+    gy = gy < 0 ? 0 : (gy > h - 1 ? h - 1 : gy);
+    gx = gx < 0 ? 0 : (gx > w - 1 ? w - 1 : gx);
+    S[r * SW + c] = src[(long)gy * w + gx];
+  }
+  __syncthreads();
+  for (int t = tid; t < (kSmX + 2 * W) * (kSmY / kSmR); t += 256) {  // consecutive lanes: consecutive columns
+    const int g = t / (kSmX + 2 * W), c = t - g * (kSmX + 2 * W), r0 = g * kSmR;
+    float v[kSmR + 2 * W];
+#pragma unroll
+    for (int k = 0; k < kSmR + 2 * W; k++) v[k] = S[(r0 + k) * SW + c];
+#pragma unroll
+    for (int i = 0; i < kSmR; i++) {
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < NT; j++) acc = acc + v[i + j] * tp[j];
+      T[(r0 + i) * SW + c] = acc;
+    }
+  }
+  __syncthreads();
+  {  // 32 rows x 8 column groups = 256 threads; consecutive lanes: consecutive rows (odd stride: distinct banks)
+    const int r = tid % kSmY, c0 = (tid / kSmY) * kSmR;
+    float v[kSmR + 2 * W];
+#pragma unroll
+    for (int k = 0; k < kSmR + 2 * W; k++) v[k] = T[r * SW + c0 + k];
+#pragma unroll
+    for (int i = 0; i < kSmR; i++) {
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < NT; j++) acc = acc + v[i + j] * tp[j];
+      S[r * SW + c0 + i] = acc;  // the source tile is dead: every thread passed the barrier after its last read of S
+    }
+  }
+  __syncthreads();
+  // S[r][c] = the smoothed level at (x0 + c, y0 + r) wherever that is inside the image (a value outside is never read)
+  for (int t = tid; t < (kSmX - 2 * kSmHalo) * (kSmY - 2 * kSmHalo); t += 256) {
+    const int r = t / (kSmX - 2 * kSmHalo) + kSmHalo, c = t % (kSmX - 2 * kSmHalo) + kSmHalo;
+    const int x = x0 + c, y = y0 + r;
+    if (x >= w || y >= h) continue;
+    dst[(long)y * w + x] = S[r * SW + c];
+    const int cc = (x < 1 ? 1 : (x > w - 2 ? w - 2 : x)) - x0, rr = (y < 1 ? 1 : (y > h - 2 ? h - 2 : y)) - y0;
+    const float *p = S + rr * SW + cc;
+    const float p11 = p[-SW - 1], p12 = p[-SW], p13 = p[-SW + 1], p21 = p[-1], p22 = p[0], p23 = p[1], p31 = p[SW - 1], p32 = p[SW], p33 = p[SW + 1];
+    const float Lxx = (-p21 + 2 * p22 - p23);
+    const float Lyy = (-p12 + 2 * p22 - p32);
+    const float Lxy = ((p11 - p31 - p13 + p33) / 4.0f);
+    css[(long)y * w + x] = (Lxx * Lyy - Lxy * Lxy) * factor;
+  }
+}
+typedef void (*smooth_fn)(const float *, float *, float *, int, int, const float *, float);
+template <int W>
+struct SmoothTable {
+  static smooth_fn get(int q) { return q == W ? smooth_fused_kernel<W> : SmoothTable<W - 1>::get(q); }
+};
+template <>
+struct SmoothTable<0> {
+  static smooth_fn get(int) { return nullptr; }
+};
 // copy_and_downsample by one octave (scalespace.c:497-520): every second pixel of every second row
 __global__ void downsample_kernel(const float *src, int w, int h, float *dst, int dw, int dh) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
@@ -992,10 +1075,21 @@ static int hahog_extract_on_stream(osfm_ctx *ctx, hipStream_t st, const float *i
     }
   }
   OSFM_HIP(hipMemcpyAsync(d_taps, h_taps.data(), h_taps.size() * sizeof(float), hipMemcpyHostToDevice, st));
-  auto smooth = [&](const float *src, float *dst, int w, int h, int slot) {
+  const bool two_pass = getenv("OSFM_HAHOG_TWO_PASS") != nullptr;  // measurement / test knob: the separate column and row kernels
+  // one level from the previous one; returns 1 when the level's Hessian response (css, factor) came out of the same launch
+  auto smooth = [&](const float *src, float *dst, int w, int h, int slot, float *css, float factor) -> int {
     const int W = tapW[(size_t)slot];
-    hipLaunchKernelGGL(conv_v_kernel, grid2(w, h), dim3(256), 0, st, src, d_tmp, w, h, d_taps + (size_t)slot * kMaxTaps, W);
-    hipLaunchKernelGGL(conv_h_kernel, grid2(w, h), dim3(256), 0, st, (const float *)d_tmp, dst, w, h, d_taps + (size_t)slot * kMaxTaps, W);
+    if (W > kSmMaxW || W < 1 || two_pass || w < 3 || h < 3) {
+      hipLaunchKernelGGL(conv_v_kernel, grid2(w, h), dim3(256), 0, st, src, d_tmp, w, h, d_taps + (size_t)slot * kMaxTaps, W);
+      hipLaunchKernelGGL(conv_h_kernel, grid2(w, h), dim3(256), 0, st, (const float *)d_tmp, dst, w, h, d_taps + (size_t)slot * kMaxTaps, W);
+      return 0;
+    }
+    float *out = src == dst ? d_tmp : dst;  // in place (the first level of an octave): through the scratch image
+    constexpr int sx = kSmX - 2 * kSmHalo, sy = kSmY - 2 * kSmHalo;
+    hipLaunchKernelGGL(SmoothTable<kSmMaxW>::get(W), dim3((unsigned)((w + sx - 1) / sx), (unsigned)((h + sy - 1) / sy)), dim3(256), 0, st, src, out, css, w, h,
+                       d_taps + (size_t)slot * kMaxTaps, factor);
+    if (out != dst && hipMemcpyAsync(dst, out, (size_t)w * h * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return -1;
+    return 1;
   };
   // vl_scalespace_put_image
   OSFM_HIP(hipMemcpyAsync(py.oct[0].gss, image, (size_t)W0 * H0 * sizeof(float),
@@ -1010,14 +1104,23 @@ static int hahog_extract_on_stream(osfm_ctx *ctx, hipStream_t st, const float *i
       hipLaunchKernelGGL(downsample_kernel, grid2(oc.w, oc.h), dim3(256), 0, st, (const float *)(pv.gss + (size_t)pl * pv.w * pv.h), pv.w, pv.h, oc.gss,
                          oc.w, oc.h);
     }
-    if (first_smooth[o]) smooth(oc.gss, oc.gss, oc.w, oc.h, base);
-    for (int l = 1; l < kLev; l++) smooth(oc.gss + (size_t)(l - 1) * npx, oc.gss + (size_t)l * npx, oc.w, oc.h, base + l);
-    for (int l = 0; l < kLev; l++) {
-      const double step = std::pow(2.0, o);
-      const float factor = (float)std::pow(py.sigma[o][l] / step, 4.0);
-      hipLaunchKernelGGL(hessian_kernel, grid2(oc.w, oc.h), dim3(256), 0, st, (const float *)(oc.gss + (size_t)l * npx), oc.css + (size_t)l * npx, oc.w,
-                         oc.h, factor);
+    const double step = std::pow(2.0, o);
+    auto factor_of = [&](int l) { return (float)std::pow(py.sigma[o][l] / step, 4.0); };
+    bool have_css[kLev] = {};
+    if (first_smooth[o]) {
+      const int rcs = smooth(oc.gss, oc.gss, oc.w, oc.h, base, oc.css, factor_of(0));
+      OSFM_REQUIRE(rcs >= 0, OSFM_E_HIP, "osfm_hahog_extract: device copy failed");
+      have_css[0] = rcs == 1;
     }
+    for (int l = 1; l < kLev; l++) {
+      const int rcs = smooth(oc.gss + (size_t)(l - 1) * npx, oc.gss + (size_t)l * npx, oc.w, oc.h, base + l, oc.css + (size_t)l * npx, factor_of(l));
+      OSFM_REQUIRE(rcs >= 0, OSFM_E_HIP, "osfm_hahog_extract: device copy failed");
+      have_css[l] = rcs == 1;
+    }
+    for (int l = 0; l < kLev; l++)
+      if (!have_css[l])
+        hipLaunchKernelGGL(hessian_kernel, grid2(oc.w, oc.h), dim3(256), 0, st, (const float *)(oc.gss + (size_t)l * npx), oc.css + (size_t)l * npx, oc.w,
+                           oc.h, factor_of(l));
   }
   // detection
   Features F;

@@ -129,3 +129,21 @@ def test_batch_equals_image_by_image(gpu_ctx):
             assert np.array_equal(p, ps) and np.array_equal(d, ds)
     assert len(single[6][0]) == 0  # below one octave: no features, no error
     assert sum(len(p) for p, _ in single) > 500
+
+
+def test_fused_smoothing_equals_the_two_passes(gpu_ctx, monkeypatch):
+    """The scale space's separable Gaussian as one LDS-tiled launch (smooth_fused_kernel) against the column kernel followed by the row
+    kernel (OSFM_HAHOG_TWO_PASS): the same float operations in the same order, so every keypoint and descriptor is identical -- on sizes
+    that are not multiples of the tile and smaller than one."""
+    from opensfm_amd import features
+
+    rng = np.random.default_rng(11)
+    for r, c in [(480, 640), (333, 257), (65, 33), (40, 700)]:
+        im = rng.random((r, c)).astype(np.float32)
+        im = np.ascontiguousarray((im + np.roll(im, 1, 0) + np.roll(im, 1, 1) + np.roll(im, 2, 0) + np.roll(im, 2, 1)) / 5, np.float32)
+        a = features.hahog(im, 1e-5, 10.0, 500, ctx=gpu_ctx)
+        monkeypatch.setenv("OSFM_HAHOG_TWO_PASS", "1")
+        b = features.hahog(im, 1e-5, 10.0, 500, ctx=gpu_ctx)
+        monkeypatch.delenv("OSFM_HAHOG_TWO_PASS")
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (r, c)
+    assert len(a[0]) > 0
