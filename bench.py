@@ -701,12 +701,16 @@ def calibrated_bench(args, ctx, store, scene, n_images, with_cpu):
     pairs = neighbour_pairs(n_images, args.overlap_neighbors)
     cam = SimpleNamespace(projection_type="perspective", k1=1e-3, k2=0.0, focal=0.85)
     cams = [cam] * n_images
-    matching.match_pairs_calibrated(store, pairs[:256], cams)
+    tm0 = MatchTimings()
+    t0 = time.perf_counter()
+    matching.match_pairs_calibrated(store, pairs, cams, timings=tm0)  # first call on this context: allocator cache and ShouldStop tables cold
+    dt0 = time.perf_counter() - t0
     tm = MatchTimings()
     t0 = time.perf_counter()
     counts, m = matching.match_pairs_calibrated(store, pairs, cams, timings=tm)
     dt = time.perf_counter() - t0
     out["match_end_to_end"] = {
+        "first_call_ms": round(1e3 * dt0, 2), "first_call_geometric_stage_ms": round(float(tm0.ms_ransac_kernel), 2),
         "workload": f"{len(pairs)} neighbour pairs of the {n_images} x {args.features} store, camera perspective k1 = 1e-3 (calibrated branch)",
         "value": round(len(pairs) / dt, 1), "unit": "pairs/s", "call_ms": round(1e3 * dt, 2), "match_kernel_ms": round(float(tm.ms_match_kernel), 2),
         "geometric_stage_ms": round(float(tm.ms_ransac_kernel), 2), "pairs_reaching_geometric_stage": int(tm.pairs_ransac),

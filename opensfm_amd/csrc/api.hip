@@ -380,7 +380,9 @@ static int match_pairs_impl(osfm_ctx *ctx, const osfm_store *store, const int32_
   {
     const char *e = getenv("OSFM_MATCH_CHUNKS");  // measurement knob
     const int64_t nch = e ? std::max(1, atoi(e)) : 2;
-    if (n_pairs >= 8192) cp = std::min<int64_t>(cp, std::max<int64_t>(4096, (n_pairs + nch - 1) / nch));
+    // (the calibrated branch keeps one chunk while memory allows: its geometric stage is a chain of ~12 rounds of latency-bound kernels,
+    // ~17 ms whatever the number of pairs below ~10^5 -- two chunks pay for it twice, 59 -> 35 ms on the 15 864-pair neighbour list)
+    if (n_pairs >= 8192 && (!calib || e)) cp = std::min<int64_t>(cp, std::max<int64_t>(4096, (n_pairs + nch - 1) / nch));
   }
   if (guided) cp = std::min<int64_t>(cp, 8192);  // 96 B of epipolar vectors + 8 B of results per feature and pair in the chunk's scratch
   const int64_t nchunks = (n_pairs + cp - 1) / (cp > 0 ? cp : 1);

@@ -3931,6 +3931,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
   d.cs = 0; d.ncl = 0; d.ncd = 0;
   if (d.bw >= 1 && d.bw <= 10 && d.bw == bw_true && O->preconditioner == 0) {  // exact band, dense clusters fit LDS
     d.cs = d.bw < 2 ? 2 : d.bw;
+    if (const char *ecs = getenv("OSFM_BA_CS")) d.cs = std::min(10, std::max(d.cs, atoi(ecs)));  // measurement knob: larger clusters (>= bw)
     d.ncd = 6 * d.cs;
     d.ncl = (S + d.cs - 1) / d.cs;
     const size_t nb = (size_t)d.ncl * d.ncd * d.ncd;
@@ -4325,7 +4326,9 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
         hipLaunchKernelGGL(pcg_step1_kernel, dim3(nbr), dim3(TPB), 0, st, d.x, d.r, d.p, d.Ap, nred, d.scal, d.partial);
         // the convergence test comes before the preconditioner is applied to the new residual: the last iteration of a solve does not
         // pay for a walk of the cyclic reduction whose result nobody reads
-        if ((k & 3) == 0 || k == kmax || (sv.use_border && k <= 2)) {
+        // (an exact band -- with the camera border on top, or with constant cameras as in local bundle adjustment -- makes the
+        // preconditioner the matrix itself: CG is done after one or two iterations, so the first two are polled)
+        if ((k & 3) == 0 || k == kmax || ((sv.use_bcr || sv.use_wide) && k <= 2)) {
           OSFM_HIP(hipMemcpyAsync(rr_part.data(), d.partial, (size_t)nbr * sizeof(double), hipMemcpyDeviceToHost, st));
           OSFM_HIP(hipStreamSynchronize(st));
           double rr = 0.0;

@@ -146,18 +146,18 @@ int osfm_calibrated_filter_chunk(osfm_ctx *ctx, const osfm_store *store, const O
   const int nk = (int)kept.size();
   const int64_t total = off.back();
   if (pairs_filtered) *pairs_filtered = nk;
-  DevBuf d_kept, d_slot, d_off, d_b1, d_b2, d_mask, d_out;
-  OSFM_HIP(d_slot.alloc((size_t)n_pairs * 4));
+  OsfmPoolBuf d_kept, d_slot, d_off, d_b1, d_b2, d_mask, d_out;  // blocks of the context's cache (released after the stream has drained)
+  OSFM_HIP(d_slot.alloc(ctx, (size_t)n_pairs * 4));
   OSFM_HIP(hipMemcpyAsync(d_slot.p, slot.data(), (size_t)n_pairs * 4, hipMemcpyHostToDevice, stream));
-  OSFM_HIP(d_off.alloc((size_t)(nk + 1) * 8));
+  OSFM_HIP(d_off.alloc(ctx, (size_t)(nk + 1) * 8));
   OSFM_HIP(hipMemcpyAsync(d_off.p, off.data(), (size_t)(nk + 1) * 8, hipMemcpyHostToDevice, stream));
-  OSFM_HIP(d_mask.alloc((size_t)total));
+  OSFM_HIP(d_mask.alloc(ctx, (size_t)total));
   if (nk > 0) {
-    OSFM_HIP(d_kept.alloc((size_t)nk * 4));
+    OSFM_HIP(d_kept.alloc(ctx, (size_t)nk * 4));
     OSFM_HIP(hipMemcpyAsync(d_kept.p, kept.data(), (size_t)nk * 4, hipMemcpyHostToDevice, stream));
-    OSFM_HIP(d_b1.alloc((size_t)total * 24));
-    OSFM_HIP(d_b2.alloc((size_t)total * 24));
-    OSFM_HIP(d_out.alloc((size_t)nk * sizeof(osfm_relpose_result)));
+    OSFM_HIP(d_b1.alloc(ctx, (size_t)total * 24));
+    OSFM_HIP(d_b2.alloc(ctx, (size_t)total * 24));
+    OSFM_HIP(d_out.alloc(ctx, (size_t)nk * sizeof(osfm_relpose_result)));
     hipLaunchKernelGGL(gather_bearings_kernel, dim3(nk), dim3(128), 0, stream, d_kept.as<int32_t>(), d_off.as<int64_t>(), d_pairs, store->d_tile_off,
                        d_matches, cap, cs.d_bearings, d_b1.as<double>(), d_b2.as<double>());
     OSFM_HIP(hipGetLastError());

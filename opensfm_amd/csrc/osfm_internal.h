@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <mutex>
+#include <unordered_map>
 #include <string>
 #include <cstdlib>
 #include <vector>
@@ -62,6 +63,10 @@ struct osfm_ctx {
   static constexpr size_t kPoolBytes = (size_t)6 << 30;
   hipStream_t stream_b = nullptr;  // second stream of the batched matching calls (gather + D2H of chunk k under the matcher of k + 1)
   size_t match_hint = 0;        // int32 entries of the last batched call's match list: the next call reserves that much up front
+  // relpose.hip: ShouldStop's iteration bound for every (pair size n, best inlier count c <= n), tabulated with the host's libm (pow, log);
+  // kept between calls -- the pair sizes of a data set repeat, and a cold table for ~300 sizes is ~5 ms of libm calls
+  double stop_probability = -1.0;
+  std::unordered_map<int, std::vector<double>> stop_tables;
   void *blas = nullptr;         // ba.hip: rocblas_handle of the wide band's dense-cluster cyclic reduction, made on first use
   void (*blas_destroy)(void *) = nullptr;
 };

@@ -281,13 +281,24 @@ int osfm_relpose_run_device(osfm_ctx *ctx, hipStream_t st, const double *d_b1, c
   std::vector<double> stop;
   std::vector<int64_t> stop_off((size_t)n_pairs);
   {
+    if (ctx->stop_probability != prm->probability) {  // the context's tables are for one probability
+      ctx->stop_tables.clear();
+      ctx->stop_probability = prm->probability;
+    }
+    if (ctx->stop_tables.size() > 65536) ctx->stop_tables.clear();
     std::unordered_map<int, int64_t> table_of_n;
     for (int p = 0; p < n_pairs; p++) {
       const int n = (int)(offsets[p + 1] - offsets[p]);
       auto it = table_of_n.find(n);
       if (it == table_of_n.end()) {
         it = table_of_n.emplace(n, (int64_t)stop.size()).first;
-        for (int c = 0; c <= n; c++) stop.push_back(max_iterations_for(c, n > 0 ? n : 1, prm->probability));
+        auto ct = ctx->stop_tables.find(n);
+        if (ct == ctx->stop_tables.end()) {
+          std::vector<double> t((size_t)n + 1);
+          for (int c = 0; c <= n; c++) t[(size_t)c] = max_iterations_for(c, n > 0 ? n : 1, prm->probability);
+          ct = ctx->stop_tables.emplace(n, std::move(t)).first;
+        }
+        stop.insert(stop.end(), ct->second.begin(), ct->second.end());
       }
       stop_off[(size_t)p] = it->second;
     }
@@ -307,8 +318,8 @@ int osfm_relpose_run_device(osfm_ctx *ctx, hipStream_t st, const double *d_b1, c
     offs[i] = arena_bytes;
     arena_bytes += (sizes[i] + 255) / 256 * 256;
   }
-  DevBuf arena;
-  OSFM_HIP(arena.alloc(arena_bytes));
+  OsfmPoolBuf arena;  // from the context's cache of blocks (the caller holds the context lock): a hipMalloc / hipFree of this size is ~2 ms per call
+  OSFM_HIP(arena.alloc(ctx, arena_bytes));
   Sub sub[kBuffers];
   for (int i = 0; i < kBuffers; i++) sub[i].p = (char *)arena.p + offs[i];
   const Sub &d_u1 = sub[0], &d_u2 = sub[1], &d_stop = sub[2], &d_stopoff = sub[3], &d_st = sub[4], &d_sidx = sub[5], &d_posb = sub[6], &d_pos = sub[7],

@@ -1430,13 +1430,17 @@ OSFM_HD int refine_relative_pose(double* RT, int iterations, Eval& ev, double* c
       have_scale = 1;
     }
     double sums[43];
+    // sum q: gradient entry q < 6 (J_q scal_q) (-r); J^T J entry (a, b) = ((q - 6) / 6, (q - 6) % 6) for q < 42; q = 42: (-r) (-r).  Written as
+    // one product of two scaled columns of [r | J] (column 0 = r with factor -1: the negation, exactly) so that the lanes that own
+    // different kinds of sums run the same instructions
     ev.reduce(43, [&](int q, int i) {
-      if (q < 6) return (ev.jac(i, q) * scal[q]) * (-ev.res(i));
-      if (q < 42) {
-        const int a = (q - 6) / 6, b = (q - 6) % 6;
-        return (ev.jac(i, a) * scal[a]) * (ev.jac(i, b) * scal[b]);
+      const int ca = q < 6 ? 1 + q : (q < 42 ? 1 + (q - 6) / 6 : 0), cb = q < 6 ? 0 : (q < 42 ? 1 + (q - 6) % 6 : 0);
+      double sa = -1.0, sb = -1.0;
+      for (int k = 0; k < 6; k++) {
+        if (ca == 1 + k) sa = scal[k];
+        if (cb == 1 + k) sb = scal[k];
       }
-      return (-ev.res(i)) * (-ev.res(i));
+      return (ev.val(i, ca) * sa) * (ev.val(i, cb) * sb);
     }, sums);
     for (int a = 0; a < 6; a++) g[a] = sums[a];
     for (int k = 0; k < 36; k++) jtj[k] = sums[6 + k];

@@ -508,12 +508,23 @@ struct WaveRefineEval {
   }
   OSFM_HD double res(int i) const { return s.rbuf[i][0]; }
   OSFM_HD double jac(int i, int k) const { return s.rbuf[i][1 + k]; }
-  // out[q] = sum over i = 0 .. 100 (in order, from 0.0) of term(q, i), q < nsums <= 64: one sum per lane
+  OSFM_HD double val(int i, int c) const { return s.rbuf[i][c]; }  // column 0: the residual, 1 + k: its derivative k
+  // out[q] = sum over i = 0 .. 100 (in order, from 0.0) of term(q, i), q < nsums <= 64: one sum per lane.  The terms of eight
+  // consecutive i are formed before they are added (in order): their LDS reads are then in flight together instead of one round trip
+  // per addition -- the sum itself is the same chain of additions
   template <class F>
   OSFM_HD void reduce(int nsums, F term, double* out) {
     w.parallel_for(nsums, [&](int q) {
       double acc = 0.0;
-      for (int i = 0; i < kRefineResiduals + 1; i++) acc += term(q, i);
+      int i = 0;
+      for (; i + 8 <= kRefineResiduals + 1; i += 8) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) t[u] = term(q, i + u);
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc += t[u];
+      }
+      for (; i < kRefineResiduals + 1; i++) acc += term(q, i);
       s.sums[q] = acc;
     });
     for (int q = 0; q < nsums; q++) out[q] = s.sums[q];

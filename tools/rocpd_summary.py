@@ -45,5 +45,25 @@ def main(path, by_kernel=False):
             print(f"      {pn:34s} {v / d['calls']:18.1f}  (per call)")
 
 
+def timeline(path, substrings, last=400):
+    """dispatches whose kernel name contains one of `substrings`, in start order: start (ms from the first), duration, gap to the previous end"""
+    con = sqlite3.connect(path)
+    cur = con.cursor()
+    kd, ks = table(cur, 'rocpd_kernel_dispatch'), table(cur, 'rocpd_info_kernel_symbol')
+    cols = [r[1] for r in cur.execute(f"pragma table_info('{ks}')")]
+    namecol = 'kernel_name' if 'kernel_name' in cols else ('display_name' if 'display_name' in cols else cols[-2])
+    names = {r[0]: r[1] for r in cur.execute(f"select id, {namecol} from '{ks}'")}
+    rows = [(s, e, str(names.get(k, k)).split('(')[0][-48:], gx) for k, s, e, gx in cur.execute(f"select kernel_id, start, end, grid_size_x from '{kd}'")]
+    rows = sorted(r for r in rows if any(x in r[2] for x in substrings))[-last:]
+    t0, prev = rows[0][0], rows[0][0]
+    for s, e, n, gx in rows:
+        print(f"{(s - t0) / 1e6:10.3f} ms  dur {(e - s) / 1e3:9.1f} us  gap {(s - prev) / 1e3:8.1f} us  {n:48s} grid {gx}")
+        prev = max(prev, e)
+
+
 if __name__ == '__main__':
-    main(sys.argv[1], by_kernel='--by-kernel' in sys.argv[2:])
+    if '--timeline' in sys.argv[2:]:
+        i = sys.argv.index('--timeline')
+        timeline(sys.argv[1], sys.argv[i + 1].split(','), int(sys.argv[i + 2]) if len(sys.argv) > i + 2 else 400)
+    else:
+        main(sys.argv[1], by_kernel='--by-kernel' in sys.argv[2:])
