@@ -241,6 +241,9 @@ __device__ bool solve3(double *M) {
 // interior
 __global__ void extrema_kernel(const float *css, int w, int h, int o, int last_octave, double step, double threshold08, double peak_threshold,
                                double edge_threshold, double base_scale, Features F) {
+  // (a workgroup per row of 256 samples: 36 000 small workgroups on the first octave.  Eight rows per workgroup were measured in round 4,
+  // with and without loading the eight samples up front: 29 -> 56 / 65 us per launch -- the refinements of a wavefront's candidates then
+  // run one after the other instead of in eight wavefronts)
   const int x0 = blockIdx.x * blockDim.x + threadIdx.x + 1, y0 = blockIdx.y + 1, z = blockIdx.z + 1;
   if (x0 > w - 2 || y0 > h - 2) return;
   const long xo = 1, yo = w, zo = (long)w * h;
@@ -561,9 +564,12 @@ struct Oriented {
 };
 __global__ void __launch_bounds__(256) orientation_kernel(Pyramid py, const float *fx, const float *fy, const float *fsigma, int n,
                                                           const double *aa_mask, int *n_or, double *or_angle /* n x 4 */) {
-  __shared__ float patch[kOrSide * kOrSide], tmp[kOrSide * kOrSide];
-  __shared__ int hbin[kOrSide * kOrSide];
+  // 37 KB: four workgroups per CU.  The patch lives in the space of the per-pixel records (the gradient of every pixel is taken into
+  // registers first, then the patch is dead and the records are written); the bins are bytes
   __shared__ double2 hc[kOrSide * kOrSide];  // what the pixel adds to its bin and to the next one
+  __shared__ float tmp[kOrSide * kOrSide];
+  __shared__ unsigned char hbin[kOrSide * kOrSide];
+  float *patch = reinterpret_cast<float *>(hc);
   __shared__ float taps1[kMaxTaps];
   __shared__ int W1;
   __shared__ PatchPlan P;
@@ -639,14 +645,25 @@ __global__ void __launch_bounds__(256) orientation_kernel(Pyramid py, const floa
   HTICK(h3)
   // per pixel, in parallel: the bin and the two products the sequential loop adds (covdet.c:2769-2781)
   const double binExtent = 2 * kPi / kOrBins;
-  for (int t = tid; t < kOrSide * kOrSide; t += 256) {
-    float fm, fa;
-    polar_gradient(patch, kOrSide, t, &fm, &fa);
+  constexpr int kPerThread = (kOrSide * kOrSide + 255) / 256;
+  float gm[kPerThread], ga[kPerThread];
+#pragma unroll
+  for (int u = 0; u < kPerThread; u++) {
+    const int t = tid + 256 * u;
+    gm[u] = ga[u] = 0.f;
+    if (t < kOrSide * kOrSide) polar_gradient(patch, kOrSide, t, &gm[u], &ga[u]);
+  }
+  __syncthreads();  // the last read of the patch: its space becomes the records
+#pragma unroll
+  for (int u = 0; u < kPerThread; u++) {
+    const int t = tid + 256 * u;
+    if (t >= kOrSide * kOrSide) continue;
+    const float fm = gm[u], fa = ga[u];
     const double modulus = fm, angle = fa, weight = aa_mask[t];
     const double xx = angle / binExtent;
     const long bin = vl_floor_d(xx);
     const double w2 = xx - bin, w1 = 1.0 - w2;
-    hbin[t] = (int)((bin + kOrBins) % kOrBins);
+    hbin[t] = (unsigned char)((bin + kOrBins) % kOrBins);
     hc[t] = make_double2(w1 * (modulus * weight), w2 * (modulus * weight));
     atomicAdd(&tot[(int)((bin + kOrBins) % kOrBins)], 1);
   }

@@ -96,6 +96,6 @@ def test_ba_streaming_kernels_do_not_spill(tmp_path_factory):
 def test_hahog_per_feature_kernels(tmp_path_factory):
     _, k = compile_device("hahog", tmp_path_factory)
     r, _ = one(k, "orientation_kernel")
-    assert r["ScratchSize"] == 0 and r["LDS Size"] <= 52 * 1024  # three workgroups per CU
+    assert r["ScratchSize"] == 0 and r["LDS Size"] <= 40 * 1024  # four workgroups per CU (round 4: the patch shares the records' space)
     r, _ = one(k, "descriptor_kernel")
     assert r["ScratchSize"] == 0 and r["LDS Size"] <= 26 * 1024  # six
