@@ -1097,6 +1097,12 @@ static int hahog_extract_on_stream(osfm_ctx *ctx, hipStream_t st, const float *i
   auto smooth = [&](const float *src, float *dst, int w, int h, int slot, float *css, float factor) -> int {
     const int W = tapW[(size_t)slot];
     if (W > kSmMaxW || W < 1 || two_pass || w < 3 || h < 3) {
+      if (src == d_tmp) {  // a staged first level on the two-kernel path (a filter wider than the fused kernel takes): the level is the other buffer
+        hipLaunchKernelGGL(conv_v_kernel, grid2(w, h), dim3(256), 0, st, src, dst, w, h, d_taps + (size_t)slot * kMaxTaps, W);
+        hipLaunchKernelGGL(conv_h_kernel, grid2(w, h), dim3(256), 0, st, (const float *)dst, d_tmp, w, h, d_taps + (size_t)slot * kMaxTaps, W);
+        if (hipMemcpyAsync(dst, d_tmp, (size_t)w * h * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return -1;
+        return 0;
+      }
       hipLaunchKernelGGL(conv_v_kernel, grid2(w, h), dim3(256), 0, st, src, d_tmp, w, h, d_taps + (size_t)slot * kMaxTaps, W);
       hipLaunchKernelGGL(conv_h_kernel, grid2(w, h), dim3(256), 0, st, (const float *)d_tmp, dst, w, h, d_taps + (size_t)slot * kMaxTaps, W);
       return 0;
@@ -1109,7 +1115,10 @@ static int hahog_extract_on_stream(osfm_ctx *ctx, hipStream_t st, const float *i
     return 1;
   };
   // vl_scalespace_put_image
-  OSFM_HIP(hipMemcpyAsync(py.oct[0].gss, image, (size_t)W0 * H0 * sizeof(float),
+  // the first level of an octave is smoothed from a staging image (the caller's image / the decimated level of the octave before) straight
+  // into its place; without a smoothing step (never at vlfeat's defaults) the staging image is the level
+  const bool staged0 = first_smooth[0] && !two_pass;
+  OSFM_HIP(hipMemcpyAsync(staged0 ? d_tmp : py.oct[0].gss, image, (size_t)W0 * H0 * sizeof(float),
                           (flags & OSFM_HAHOG_IMAGE_ON_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
   for (int o = 0; o <= last_octave; o++) {
     const Octave &oc = py.oct[o];
@@ -1118,14 +1127,15 @@ static int hahog_extract_on_stream(osfm_ctx *ctx, hipStream_t st, const float *i
     if (o > 0) {
       const Octave &pv = py.oct[o - 1];
       const int pl = std::min(kFirstSub + kRes, kLastSub) - kFirstSub;
-      hipLaunchKernelGGL(downsample_kernel, grid2(oc.w, oc.h), dim3(256), 0, st, (const float *)(pv.gss + (size_t)pl * pv.w * pv.h), pv.w, pv.h, oc.gss,
-                         oc.w, oc.h);
+      hipLaunchKernelGGL(downsample_kernel, grid2(oc.w, oc.h), dim3(256), 0, st, (const float *)(pv.gss + (size_t)pl * pv.w * pv.h), pv.w, pv.h,
+                         (first_smooth[o] && !two_pass) ? d_tmp : oc.gss, oc.w, oc.h);
     }
+    const bool staged = first_smooth[o] && !two_pass;
     const double step = std::pow(2.0, o);
     auto factor_of = [&](int l) { return (float)std::pow(py.sigma[o][l] / step, 4.0); };
     bool have_css[kLev] = {};
     if (first_smooth[o]) {
-      const int rcs = smooth(oc.gss, oc.gss, oc.w, oc.h, base, oc.css, factor_of(0));
+      const int rcs = smooth(staged ? (const float *)d_tmp : (const float *)oc.gss, oc.gss, oc.w, oc.h, base, oc.css, factor_of(0));
       OSFM_REQUIRE(rcs >= 0, OSFM_E_HIP, "osfm_hahog_extract: device copy failed");
       have_css[0] = rcs == 1;
     }

@@ -76,7 +76,8 @@ def test_extreme_range_takes_exact_path(oracle_lib, gpu_ctx):
 
 def test_descriptor_value_validation(gpu_ctx):
     """non-integer descriptors are matched in float (tests/test_gpu_float_descriptors.py); a constant float store has no value range
-    to quantise and every distance 0: no match, as cv2 (0 < ratio * 0 is false); non-finite values and 8-bit dtypes are rejected"""
+    to quantise and every distance 0: no match, as cv2 (0 < ratio * 0 is false); non-finite values are rejected; a uint8 array is a bit
+    string matched by Hamming distance (matching.py:737-740; tests/test_gpu_hamming.py) -- up to 64 bytes wide, wider ones are refused"""
     from opensfm_amd import matching
     from opensfm_amd._lib import OsfmError
 
@@ -86,8 +87,8 @@ def test_descriptor_value_validation(gpu_ctx):
     g[3, 7] = np.nan
     with pytest.raises(OsfmError):
         matching.match_brute_force_symmetric(g, f, {})
-    with pytest.raises(NotImplementedError):
-        matching.match_brute_force(f.astype(np.uint8), f.astype(np.uint8), {})
+    with pytest.raises(OsfmError):
+        matching.match_brute_force(f.astype(np.uint8), f.astype(np.uint8), {})  # 128 bytes per descriptor
 
 
 def test_batched_descriptor_stage_equals_oracle_ragged(oracle_lib, gpu_ctx):
