@@ -493,21 +493,42 @@ __device__ __forceinline__ float plan_read(const PatchPlan &P, long xi, long yi)
   return P.level[row * P.width + c0 + k];
 }
 // the resampling loop (covdet.c:2360-2405): patch[yyi][xxi], side = 2 resolution + 1; the running coordinates are sums, as there
+// Round 4: the four samples of ALL the pixels of a thread (PER = ceil(side^2 / nthreads)) are requested before the first blend -- a plain
+// loop waited for one round trip to the level per pixel (26 of the orientation workgroup's 75 us); each pixel's arithmetic is unchanged.
+template <int PER, int G>  // G pixels in flight per thread (all seven of the orientation patch cost a fourth wave per SIMD in registers)
 __device__ void sample_patch(const PatchPlan &P, float *patch, int resolution, double extent, int tid, int nthreads) {
   const int side = 2 * resolution + 1;
   const double stephat = extent / resolution;
-  for (int t = tid; t < side * side; t += nthreads) {
-    const int yyi = t / side, xxi = t - yyi * side;
-    double yhat = -extent;
-    for (int q = 0; q < yyi; q++) yhat += stephat;
-    double xhat = -extent;
-    for (int q = 0; q < xxi; q++) xhat += stephat;
-    const double rx = P.A[2] * yhat + P.T[0], ry = P.A[3] * yhat + P.T[1];
-    const double x = P.A[0] * xhat + rx, y = P.A[1] * xhat + ry;
-    const long xi = vl_floor_d(x), yi = vl_floor_d(y);
-    const double i00 = plan_read(P, xi, yi), i10 = plan_read(P, xi + 1, yi), i01 = plan_read(P, xi, yi + 1), i11 = plan_read(P, xi + 1, yi + 1);
-    const double wx = x - xi, wy = y - yi;
-    patch[t] = (float)((1.0 - wy) * ((1.0 - wx) * i00 + wx * i10) + wy * ((1.0 - wx) * i01 + wx * i11));
+#pragma unroll
+  for (int g = 0; g < PER; g += G) {
+    double wxs[G], wys[G];
+    float v00[G], v10[G], v01[G], v11[G];
+#pragma unroll
+    for (int u = 0; u < G; u++) {
+      const int tq = tid + (g + u) * nthreads;
+      const int t = (g + u < PER && tq < side * side) ? tq : 0;  // a thread past the end samples pixel 0 and drops it
+      const int yyi = t / side, xxi = t - yyi * side;
+      double yhat = -extent;
+      for (int q = 0; q < yyi; q++) yhat += stephat;
+      double xhat = -extent;
+      for (int q = 0; q < xxi; q++) xhat += stephat;
+      const double rx = P.A[2] * yhat + P.T[0], ry = P.A[3] * yhat + P.T[1];
+      const double x = P.A[0] * xhat + rx, y = P.A[1] * xhat + ry;
+      const long xi = vl_floor_d(x), yi = vl_floor_d(y);
+      v00[u] = plan_read(P, xi, yi);
+      v10[u] = plan_read(P, xi + 1, yi);
+      v01[u] = plan_read(P, xi, yi + 1);
+      v11[u] = plan_read(P, xi + 1, yi + 1);
+      wxs[u] = x - xi;
+      wys[u] = y - yi;
+    }
+#pragma unroll
+    for (int u = 0; u < G; u++) {
+      const int t = tid + (g + u) * nthreads;
+      if (g + u >= PER || t >= side * side) continue;
+      const double i00 = v00[u], i10 = v10[u], i01 = v01[u], i11 = v11[u], wx = wxs[u], wy = wys[u];
+      patch[t] = (float)((1.0 - wy) * ((1.0 - wx) * i00 + wx * i10) + wy * ((1.0 - wx) * i01 + wx * i11));
+    }
   }
 }
 
@@ -616,7 +637,7 @@ __global__ void __launch_bounds__(256) orientation_kernel(Pyramid py, const floa
   }
   __syncthreads();
   HTICK(h1)
-  sample_patch(P, patch, kOrRes, kOrExtent, tid, 256);
+  sample_patch<(kOrSide * kOrSide + 255) / 256, 4>(P, patch, kOrRes, kOrExtent, tid, 256);
   __syncthreads();
   HTICK(h2)
   const int W = W1;
@@ -722,7 +743,18 @@ __global__ void __launch_bounds__(256) orientation_kernel(Pyramid py, const floa
     const double *rec = reinterpret_cast<const double *>(hc);
     const int k1 = start[tid + 1];
     double hsum = 0.0;
-    for (int k = start[tid]; k < k1; k++) hsum += rec[order[k]];
+    int k = start[tid];
+    for (; k + 8 <= k1; k += 8) {  // eight records in flight, added in order
+      int id[8];
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) id[u] = order[k + u];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = rec[id[u]];
+#pragma unroll
+      for (int u = 0; u < 8; u++) hsum += v[u];
+    }
+    for (; k < k1; k++) hsum += rec[order[k]];
     hist[tid] = hsum;
   }
   __syncthreads();
@@ -866,7 +898,7 @@ __global__ void __launch_bounds__(256) descriptor_kernel(Pyramid py, Oriented R,
   }
   __syncthreads();
   HTICK(h1)
-  sample_patch(P, patch, kDRes, kDExtent, tid, 256);
+  sample_patch<(kDSide * kDSide + 255) / 256, 2>(P, patch, kDRes, kDExtent, tid, 256);
   __syncthreads();
   HTICK(h2)
   // per pixel: window x modulus, the lower bin of the 2 x 2 x 2 it feeds and the three fractions (sift.c:1806-1850); x = y = 15,
@@ -925,17 +957,28 @@ __global__ void __launch_bounds__(256) descriptor_kernel(Pyramid py, Oriented R,
     float acc = 0.f;
     for (unsigned rm = rowmask; rm; rm &= rm - 1) {
       const int yb = __builtin_ctz(rm) * kDSide;
-      for (unsigned cm = colmask; cm; cm &= cm - 1) {
-        const int t = yb + __builtin_ctz(cm);
-        const int code = scode[t];
-        const float4 pv = sval[t];
-        const int dbinx = bx - ((code & 255) - 128), dbiny = by - (((code >> 8) & 255) - 128), sb = code >> 16;
-        const bool in = !(dbinx < 0 || dbinx > 1 || dbiny < 0 || dbiny > 1);
-        const int b0 = sb % kNBO, b1 = (sb + 1) % kNBO;
-        const float wm = pv.x, rx = pv.y, ry = pv.z, rt = pv.w;
-        const float v0 = wm * fabsf(1 - dbinx - rx) * fabsf(1 - dbiny - ry) * fabsf(1 - 0 - rt);
-        const float v1 = wm * fabsf(1 - dbinx - rx) * fabsf(1 - dbiny - ry) * fabsf(1 - 1 - rt);
-        acc += (in && b0 == bt) ? v0 : ((in && b1 == bt) ? v1 : 0.0f);
+      for (unsigned cm = colmask; cm;) {  // four pixels of the walk in flight (a missing one adds +0.0f), added in raster order
+        int code[4];
+        float4 pv[4];
+        bool on[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          on[u] = cm != 0;
+          const int t = yb + (on[u] ? __builtin_ctz(cm) : 0);
+          cm &= cm - 1;
+          code[u] = scode[t];
+          pv[u] = sval[t];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int dbinx = bx - ((code[u] & 255) - 128), dbiny = by - (((code[u] >> 8) & 255) - 128), sb = code[u] >> 16;
+          const bool in = on[u] && !(dbinx < 0 || dbinx > 1 || dbiny < 0 || dbiny > 1);
+          const int b0 = sb % kNBO, b1 = (sb + 1) % kNBO;
+          const float wm = pv[u].x, rx = pv[u].y, ry = pv[u].z, rt = pv[u].w;
+          const float v0 = wm * fabsf(1 - dbinx - rx) * fabsf(1 - dbiny - ry) * fabsf(1 - 0 - rt);
+          const float v1 = wm * fabsf(1 - dbinx - rx) * fabsf(1 - dbiny - ry) * fabsf(1 - 1 - rt);
+          acc += (in && b0 == bt) ? v0 : ((in && b1 == bt) ? v1 : 0.0f);
+        }
       }
     }
     descr[tid] = acc;
