@@ -374,10 +374,13 @@ __global__ void prior_cost_kernel(Dev d, const double *cams, const double *poses
     v[0] += 0.5 * (e0 * e0 + e1 * e1 + e2 * e2);
   }
   if (d.gps && d.gps_sigma)
-    for (int s = threadIdx.x; s < d.S; s += blockDim.x) {
-      if (!(d.gps_sigma[s] > 0) || (d.shot_fixed && d.shot_fixed[s])) continue;
+    for (int s = threadIdx.x; s < d.S; s += blockDim.x) {  // every load of a shot requested before the test on its sigma
+      const double sg = d.gps_sigma[s];
+      const bool fixed = d.shot_fixed && d.shot_fixed[s];
+      const double p3[3] = {poses[6 * s + 3], poses[6 * s + 4], poses[6 * s + 5]}, g3[3] = {d.gps[3 * s], d.gps[3 * s + 1], d.gps[3 * s + 2]};
+      if (!(sg > 0) || fixed) continue;
       for (int i = 0; i < 3; i++) {
-        const double e = (poses[6 * s + 3 + i] - d.gps[3 * s + i]) / d.gps_sigma[s];
+        const double e = (p3[i] - g3[i]) / sg;
         v[0] += 0.5 * e * e;
       }
     }
@@ -534,13 +537,30 @@ __global__ void __launch_bounds__(64) shot_grad_kernel(Dev d, const double *pose
 
 
 // camred[c][i] = sum over the shots of camera c of part[s][i]   (one block per camera, fixed order)
-__global__ void __launch_bounds__(TPB) cam_reduce_kernel(Dev d, int ncomp) {
-  __shared__ double lds[64];
+// (one workgroup per camera: 1 024 threads, four shots of a thread requested before they are added -- with 256 threads and a load behind
+// a branch per shot this was 20 dependent round trips, 27 us, four to five times per LM iteration)
+constexpr int kCamRedT = 1024;
+__global__ void __launch_bounds__(kCamRedT) cam_reduce_kernel(Dev d, int ncomp) {
+  __shared__ double lds[16 * 9];
   const int c = blockIdx.x;
   double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int s = threadIdx.x; s < d.S; s += TPB)
-    if (d.shot_camera[s] == c)
-      for (int i = 0; i < ncomp; i++) v[i] += d.part[9 * (long)s + i];
+  for (int s0 = threadIdx.x; s0 < d.S; s0 += 4 * kCamRedT) {
+    double p[4][9];
+    bool on[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int s = s0 + u * kCamRedT;
+      const bool in = s < d.S;
+      on[u] = in && d.shot_camera[in ? s : 0] == c;
+#pragma unroll
+      for (int i = 0; i < 9; i++) p[u][i] = (in && i < ncomp) ? d.part[9 * (long)s + i] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (on[u])
+#pragma unroll
+        for (int i = 0; i < 9; i++) v[i] += p[u][i];
+  }
   block_sum<9>(v, lds);
   if (threadIdx.x == 0)
     for (int i = 0; i < ncomp; i++) d.camred[9 * c + i] = v[i];
@@ -2609,7 +2629,8 @@ __global__ void schur_finish_kernel(Dev d, const double *x, const double *y, dou
 __global__ void dot2_kernel(const double *a, const double *b, const double *c, const double *e, int n, double *o0, double *o1) {
   __shared__ double lds[32];
   double v[2] = {0, 0};
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+#pragma unroll 4
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {  // (unrolled: the loads of four steps in flight, the additions in order)
     v[0] += a[i] * b[i];
     if (c) v[1] += c[i] * e[i];
   }
@@ -2623,6 +2644,7 @@ __global__ void dot2_kernel(const double *a, const double *b, const double *c, c
 __global__ void pcg_init_kernel(const double *b, const double *z, double *x, double *r, double *p, int n, double *o_rz, double *o_bb) {
   __shared__ double lds[32];
   double v[2] = {0, 0};
+#pragma unroll 4
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const double bi = b[i], zi = z[i];
     x[i] = 0.0;
@@ -2704,11 +2726,23 @@ __global__ void candidate_kernel(Dev d, const double *y, double *out) {
   }
   for (int s = threadIdx.x; s < d.S; s += blockDim.x) {
     const bool fixed = d.shot_fixed && d.shot_fixed[s];
-    if (!fixed && d.gps && d.gps_sigma && d.gps_sigma[s] > 0) {
-      const double wq = 1.0 / d.gps_sigma[s];
+    // the shot's step, pose and prior requested together (a load behind every test made this kernel six round trips per shot: 61 us)
+    double ys[6], ps[6], g3[3] = {0, 0, 0}, sg = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      ys[k] = y[6 * s + k];
+      ps[k] = d.poses[6 * s + k];
+    }
+    if (d.gps && d.gps_sigma) {
+      sg = d.gps_sigma[s];
+#pragma unroll
+      for (int k = 0; k < 3; k++) g3[k] = d.gps[3 * s + k];
+    }
+    if (!fixed && sg > 0) {
+      const double wq = 1.0 / sg;
       for (int k = 0; k < 3; k++) {
-        const double m = wq * y[6 * s + 3 + k];
-        const double e = wq * (d.poses[6 * s + 3 + k] - d.gps[3 * s + k]);
+        const double m = wq * ys[3 + k];
+        const double e = wq * (ps[3 + k] - g3[k]);
         v[0] -= m * (e + 0.5 * m);
       }
     }
@@ -2720,11 +2754,11 @@ __global__ void candidate_kernel(Dev d, const double *y, double *out) {
       }
     }
     for (int k = 0; k < 6; k++) {
-      const double dl = fixed ? 0.0 : y[6 * s + k];
-      d.poses_n[6 * s + k] = d.poses[6 * s + k] + dl;
+      const double dl = fixed ? 0.0 : ys[k];
+      d.poses_n[6 * s + k] = ps[k] + dl;
       if (!fixed) {
         v[1] += dl * dl;
-        v[2] += d.poses[6 * s + k] * d.poses[6 * s + k];
+        v[2] += ps[k] * ps[k];
       }
     }
   }
@@ -2802,6 +2836,7 @@ __global__ void border_dots_kernel(const double *Bc, const double *W, int nb, in
   __shared__ double lds[32];
   const int i = blockIdx.x / nb, j = blockIdx.x % nb;
   double v[1] = {0.0};
+#pragma unroll 4
   for (int t = threadIdx.x; t < n; t += blockDim.x) v[0] += Bc[(long)i * n + t] * W[(long)j * n + t];
   block_sum<1>(v, lds);
   if (threadIdx.x == 0) out[blockIdx.x] = v[0];
@@ -2810,7 +2845,7 @@ __global__ void border_dots_kernel(const double *Bc, const double *W, int nb, in
 __global__ void border_rhs_kernel(const double *Bc, const double *SigInv, const double *r, double *z, int nb, int n, int cam0) {
   __shared__ double lds[32];
   __shared__ double y[8];
-  for (int i = 0; i < nb; i++) {
+  for (int i = 0; i < nb; i++) {  // (all rows in one pass over z_s with six accumulators was measured in round 4: 37 against 33 us)
     double v[1] = {0.0};
     for (int t = threadIdx.x; t < n; t += blockDim.x) v[0] += Bc[(long)i * n + t] * z[t];
     block_sum<1>(v, lds);
@@ -3236,7 +3271,7 @@ struct Solver {
       hipLaunchKernelGGL((eval_kernel<false, false>), dim3(nb), dim3(TPB), 0, st, d, cams, poses, pts, loss, loss_a);
     }
     hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(1024), 0, st, d.partial, (long)nb, 2, d.scal + 8);
-    hipLaunchKernelGGL(prior_cost_kernel, dim3(1), dim3(256), 0, st, d, cams, poses, d.scal + 8, jac ? 1 : 0);
+    hipLaunchKernelGGL(prior_cost_kernel, dim3(1), dim3(1024), 0, st, d, cams, poses, d.scal + 8, jac ? 1 : 0);
   }
   int eval(const double *cams, const double *poses, const double *pts, bool jac, double *cost, double *sumsq) {
     eval_enqueue(cams, poses, pts, jac);
@@ -3249,7 +3284,7 @@ struct Solver {
   void gradients() {
     hipLaunchKernelGGL(point_grad_kernel, dim3(d.nwg), dim3(kCoopObs), 0, st, d);
     hipLaunchKernelGGL(shot_grad_kernel, dim3(d.S), dim3(64), 0, st, d, d.poses);
-    hipLaunchKernelGGL(cam_reduce_kernel, dim3(d.NC), dim3(TPB), 0, st, d, 9);
+    hipLaunchKernelGGL(cam_reduce_kernel, dim3(d.NC), dim3(kCamRedT), 0, st, d, 9);
     hipLaunchKernelGGL(cam_grad_kernel, dim3(nblk(d.NC, 64)), dim3(64), 0, st, d, d.cams);
   }
   bool use_band = false, use_ctri = false, use_bcr = false, use_border = false;
@@ -3420,7 +3455,7 @@ struct Solver {
     hipLaunchKernelGGL(scale_vec_kernel, dim3(nblk(d.nred)), dim3(TPB), 0, st, d.sc_red, x, d.y, d.nred);
     hipLaunchKernelGGL(schur_point_coop_kernel<0>, dim3(d.nwg), dim3(kCoopObs), 0, st, d, d.y);
     hipLaunchKernelGGL(schur_shot_kernel, dim3(d.S), dim3(64), 0, st, d);
-    hipLaunchKernelGGL(cam_reduce_kernel, dim3(d.NC), dim3(TPB), 0, st, d, 3);
+    hipLaunchKernelGGL(cam_reduce_kernel, dim3(d.NC), dim3(kCamRedT), 0, st, d, 3);
     hipLaunchKernelGGL(schur_finish_kernel, dim3(nblk(d.nred)), dim3(TPB), 0, st, d, x, d.y, out, radius, 0);
   }
 };
@@ -4151,7 +4186,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       // rhs
       hipLaunchKernelGGL(schur_point_coop_kernel<1>, dim3(d.nwg), dim3(kCoopObs), 0, sx, d, d.y);
       hipLaunchKernelGGL(schur_shot_kernel, dim3(S), dim3(64), 0, sx, d);
-      hipLaunchKernelGGL(cam_reduce_kernel, dim3(NC), dim3(TPB), 0, sx, d, 3);
+      hipLaunchKernelGGL(cam_reduce_kernel, dim3(NC), dim3(kCamRedT), 0, sx, d, 3);
       hipLaunchKernelGGL(schur_finish_kernel, dim3(nbr), dim3(TPB), 0, sx, d, d.x, d.y, d.b, radius, 1);
       if (sv.st2) OSFM_HIP(hipEventRecord(sv.ev_join, sv.st2));
       return OSFM_OK;
@@ -4282,7 +4317,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       // preconditioners -- not needed when the cyclic reduction came out with the exact camera border
       if (!((sv.use_bcr || sv.use_wide) && sv.use_border)) {
         hipLaunchKernelGGL(precond_shot_kernel, dim3(S), dim3(64), 0, st, d, radius);
-        hipLaunchKernelGGL(cam_reduce_kernel, dim3(NC), dim3(TPB), 0, st, d, 6);
+        hipLaunchKernelGGL(cam_reduce_kernel, dim3(NC), dim3(kCamRedT), 0, st, d, 6);
         hipLaunchKernelGGL(precond_cam_kernel, dim3(nblk(NC, 64)), dim3(64), 0, st, d, radius);
       }
       sv.precond(d.b, d.z, z_solved);
