@@ -97,5 +97,20 @@ def test_hahog_per_feature_kernels(tmp_path_factory):
     _, k = compile_device("hahog", tmp_path_factory)
     r, _ = one(k, "orientation_kernel")
     assert r["ScratchSize"] == 0 and r["LDS Size"] <= 40 * 1024  # four workgroups per CU (round 4: the patch shares the records' space)
+    assert r["Occupancy"] >= 4 and r["VGPRs"] <= 128  # four pixels of the resampling in flight, not seven (149 registers: three waves per SIMD)
     r, _ = one(k, "descriptor_kernel")
     assert r["ScratchSize"] == 0 and r["LDS Size"] <= 26 * 1024  # six
+    assert r["Occupancy"] >= 6 and r["VGPRs"] <= 84  # two pixels of the resampling in flight, not four (90 registers: five waves)
+
+
+def test_hahog_fused_smoothing_and_wide_band_kernels(tmp_path_factory):
+    """round 4: the fused separable smoothing keeps its sliding windows in registers (no scratch) and at least four workgroups per CU for
+    every tap count; the wide band's hand-written kernels do not spill"""
+    _, k = compile_device("hahog", tmp_path_factory)
+    for W in (1, 4, 5, 6, 8, 10, 16):
+        r, _ = one(k, "smooth_fused_kernel", "ILi%dE" % W)
+        assert r["ScratchSize"] == 0 and r["VGPRs Spill"] == 0 and r["LDS Size"] <= 40 * 1024 and r["Occupancy"] >= 4, (W, r)
+    _, k = compile_device("ba", tmp_path_factory)
+    for parts in (("dbcr_sweep_kernel", "ILi4E"), ("dbcr_sweep_kernel", "ILi1E"), ("dgj_pivot_kernel",), ("dbcr_transpose_kernel",), ("band_mfma_kernel", "ILi4E")):
+        r, _ = one(k, *parts)
+        assert r["ScratchSize"] == 0 and r["VGPRs Spill"] == 0, (parts, r)
