@@ -211,6 +211,7 @@ struct Dev {
   // banded preconditioner (shot-shot part of the Schur complement inside a block band of half-width bw)
   int bw;           // block half-bandwidth actually used (0: block-Jacobi only)
   double *band;     // S x (bw+1) x 36: block (s, s-k), after factorisation the Cholesky factor L
+  const unsigned char *bslot;  // S x (bw + 1) bytes or null: band_assemble_compact_kernel's accumulator slot of block (s, s - dk), 255 = no common point
   double *dinv;     // S x 36: inverse of the diagonal blocks of L
   // band assembly on the matrix cores (band_mfma_kernel): points sorted by the first shot of their track (the anchor)
   const int *bp_pts;            // P: point ids in that order
@@ -856,6 +857,95 @@ __global__ void __launch_bounds__(TPB) band_assemble_kernel(Dev d, double radius
       if (dk == 0 && i == j) val += d.D_red[6 * s + i] / radius;
     }
     d.band[((long)s * (d.bw + 1) + dk) * 36 + ij] = val;
+  }
+}
+
+// Wide bands (round 4).  A shot of a block survey has a band row of 100+ blocks of which ~15 hold anything (its neighbours along and
+// across the flight lines); accumulators for all of them leave room for four private copies and one workgroup per CU, and the kernel is
+// bound by same-address LDS atomics.  The topology does not change over the LM iterations: band_slots_kernel gives every shot, once at
+// setup, a table dk -> slot over the partners it really has; the accumulators then cover the slots only (eight copies, several
+// workgroups per CU, and no slicing whatever the half-width).  Same sums as band_assemble_kernel.
+__global__ void __launch_bounds__(TPB) band_slots_kernel(Dev d, unsigned char *table, int *max_slots) {
+  extern __shared__ int bs_present[];  // bw + 1
+  const int s = blockIdx.x, R1 = d.bw + 1;
+  for (int t = threadIdx.x; t < R1; t += TPB) bs_present[t] = 0;
+  __syncthreads();
+  for (long k = d.shot_off[s] + threadIdx.x; k < d.shot_off[s + 1]; k += TPB) {
+    const int p = d.sm_point[k];
+    for (long o2 = d.pt_off[p]; o2 < d.pt_off[p + 1]; o2++) {
+      const int dk = s - d.o_shot[o2];
+      if (dk >= 0 && dk <= d.bw) bs_present[dk] = 1;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int n = 0;
+    for (int t = 0; t < R1; t++) {
+      const bool on = bs_present[t] != 0 || t == 0;  // the diagonal block always exists
+      table[(long)s * R1 + t] = on ? (unsigned char)(n < 255 ? n : 255) : (unsigned char)255;
+      n += on ? 1 : 0;
+    }
+    atomicMax(max_slots, n);
+  }
+}
+__global__ void __launch_bounds__(TPB) band_assemble_compact_kernel(Dev d, double radius, int copies, int nslots) {
+  extern __shared__ __attribute__((aligned(16))) double acc[];  // nslots * 36 * copies doubles, then the shot's slot table (bw + 1 bytes)
+  const int s = (int)xcd_contiguous(blockIdx.x, gridDim.x), R1 = d.bw + 1;
+  unsigned char *slot = reinterpret_cast<unsigned char *>(acc + (long)nslots * 36 * copies);
+  const int copy = threadIdx.x & (copies - 1);
+  for (int t = threadIdx.x; t < nslots * 36 * copies; t += TPB) acc[t] = 0.0;
+  for (int t = threadIdx.x; t < R1; t += TPB) slot[t] = d.bslot[(long)s * R1 + t];
+  __syncthreads();
+  for (long k = d.shot_off[s] + threadIdx.x; k < d.shot_off[s + 1]; k += TPB) {
+    const int p = d.sm_point[k];
+    const double *Hh = d.Hhat + 6 * (long)p;
+    const double h[9] = {Hh[0], Hh[1], Hh[2], Hh[1], Hh[3], Hh[4], Hh[2], Hh[4], Hh[5]};
+    double Ea[6][3], EH[6][3];
+    jred_jp(d, k, Ea);
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) EH[i][j] = Ea[i][0] * h[j] + Ea[i][1] * h[3 + j] + Ea[i][2] * h[6 + j];
+    for (long o2 = d.pt_off[p]; o2 < d.pt_off[p + 1]; o2++) {
+      const int dk = s - d.o_shot[o2];
+      if (dk < 0 || dk > d.bw) continue;
+      const int sl = slot[dk];
+      double Eb[6][3];
+      {
+        const double2 *src = reinterpret_cast<const double2 *>(d.Epm + 18 * o2);
+#pragma unroll
+        for (int q = 0; q < 9; q++) {
+          const double2 v = src[q];
+          Eb[(2 * q) / 3][(2 * q) % 3] = v.x;
+          Eb[(2 * q + 1) / 3][(2 * q + 1) % 3] = v.y;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j < 6; j++)
+          atomicAdd(&acc[(sl * 36 + i * 6 + j) * copies + copy], EH[i][0] * Eb[j][0] + EH[i][1] * Eb[j][1] + EH[i][2] * Eb[j][2]);
+    }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < R1 * 36; t += TPB) {
+    const int dk = t / 36, ij = t % 36, i = ij / 6, j = ij % 6;
+    const int s2 = s - dk, sl = slot[dk];
+    double val = 0.0;
+    if (s2 >= 0) {
+      double sum = 0.0;
+      if (sl != 255)
+        for (int c = 0; c < copies; c++) sum += acc[(sl * 36 + ij) * copies + c];
+      val = -sum;
+      if (dk == 0) {
+        const int hi = i > j ? i : j, lo = i > j ? j : i;
+        val += d.Hcc[21 * (long)s + hi * (hi + 1) / 2 + lo];
+        if (i == j) val += d.prior_diag[6 * s + i];
+      }
+      val *= d.sc_red[6 * s + i] * d.sc_red[6 * s2 + j];
+      if (dk == 0 && i == j) val += d.D_red[6 * s + i] / radius;
+    }
+    d.band[((long)s * R1 + dk) * 36 + ij] = val;
   }
 }
 
@@ -3962,6 +4052,23 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       hipLaunchKernelGGL(sorted_tracks_kernel, dim3(nblk(NP)), dim3(TPB), 0, sv.st, bp_pts, bp_keys, d.pt_off, d.o_shot, NP, o0, ln, tpos);
     }
   }
+  // per-shot assembly with accumulators over the partners a shot really has (band_assemble_compact_kernel): tables once, at setup
+  d.bslot = nullptr;
+  int bslot_n = 0, bslot_copies = 1;
+  if (d.bw > kMaxBw && !win_band && getenv("OSFM_BA_BAND_FULL_ROWS") == nullptr) {
+    unsigned char *tab = A.alloc<unsigned char>((size_t)S * (d.bw + 1), e);
+    int *d_mx = A.alloc<int>(1, e);
+    OSFM_REQUIRE(e == hipSuccess, OSFM_E_NOMEM, "BA device allocation/upload failed: %s", hipGetErrorString(e));
+    OSFM_HIP(hipMemsetAsync(d_mx, 0, sizeof(int), sv.st));
+    hipLaunchKernelGGL(band_slots_kernel, dim3(S), dim3(TPB), (size_t)(d.bw + 1) * sizeof(int), sv.st, d, tab, d_mx);
+    OSFM_HIP(hipMemcpyAsync(&bslot_n, d_mx, sizeof(int), hipMemcpyDeviceToHost, sv.st));
+    OSFM_HIP(hipStreamSynchronize(sv.st));
+    if (bslot_n >= 1 && bslot_n <= 64) {  // (more distinct partners than that: the full rows, in slices)
+      d.bslot = tab;
+      bslot_copies = kBandCopies;
+      while (bslot_copies > 1 && (size_t)bslot_n * 36 * bslot_copies * sizeof(double) + d.bw + 1 > 72 * 1024) bslot_copies /= 2;  // two workgroups per CU
+    }
+  }
   d.dinv = A.alloc<double>((size_t)S * 36, e);
   d.cs = 0; d.ncl = 0; d.ncd = 0;
   if (d.bw >= 1 && d.bw <= 10 && d.bw == bw_true && O->preconditioner == 0) {  // exact band, dense clusters fit LDS
@@ -4157,6 +4264,15 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
           OSFM_HIP(hipMemcpyAsync(d.band, b_win.data(), nbd * sizeof(double), hipMemcpyHostToDevice, st));
           OSFM_HIP(hipStreamSynchronize(st));
         }
+      } else if (d.bslot) {
+        static OsfmPerDeviceOnce once_c;
+        const int rcc = once_c.run(ctx->device, []() -> int {
+          OSFM_HIP(hipFuncSetAttribute((const void *)band_assemble_compact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+          return OSFM_OK;
+        });
+        if (rcc != OSFM_OK) return rcc;
+        hipLaunchKernelGGL(band_assemble_compact_kernel, dim3(S), dim3(TPB), (size_t)bslot_n * 36 * bslot_copies * sizeof(double) + ((d.bw + 1 + 15) / 16) * 16, st, d,
+                           radius, bslot_copies, bslot_n);
       } else {
         for (int lo = 0; lo <= d.bw; lo += band_slice)
           hipLaunchKernelGGL(band_assemble_kernel, dim3(S), dim3(TPB), (size_t)std::min(band_slice, d.bw + 1 - lo) * 36 * band_copies * sizeof(double), st, d,
