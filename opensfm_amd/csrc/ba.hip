@@ -242,6 +242,7 @@ struct Dev {
   double *qx, *qy;   // right-hand sides (down sweep, in place) and results (up sweep), (qN qm) x NR, NR side by side
   int qT;            // panel width of the blocked inversion (<= 96, a multiple of 6)
   double *qP, *qR, *qRn, *qC;  // per cluster of a level: pivot block inverse (qT^2), row panel, P x row panel (qT x qm), column panel (qm x qT)
+  double *qP2, *qBn;           // look-ahead: the next panel's pivot inverse (the two alternate) and its pivot block before the trailing product
   double *zc;       // nred (unscaled J^T w)
   double *y;        // nred
   // pcg
@@ -2296,6 +2297,92 @@ __global__ void __launch_bounds__(256) dgj_scatter_kernel(double *A0, long strid
   const int c = (int)(t / w), r = (int)(t - (long)c * w);
   A[(long)c * m + j0 + r] = (c >= j0 && c < j0 + w) ? P[(long)(c - j0) * T + r] : Rn[(long)c * T + r];
 }
+// ---- the same inversion with the pivot chain taken off the trailing product (look-ahead) ----
+// Of everything panel J + 1 needs from panel J's trailing product A -= C R', only its own pivot block is on the critical path: it is
+// B - C[rows J + 1] R'[:, columns J + 1], a 96^3 product.  dgj_copy_kernel saves that block (B) with the panels before the products of
+// panel J start; as soon as R' exists, dgj_pivot_ahead_kernel forms the updated block itself, inverts it on a second stream and hands
+// P_{J+1} over with an event, while the main stream runs the three products and the scatter of panel J.
+__global__ void __launch_bounds__(256) dgj_copy_kernel(const double *A0, long strideA, int m, int T, int j0, int w, int jn, int wn, double *R0, double *C0,
+                                                       double *B0) {
+  const double *A = A0 + (long)blockIdx.y * strideA;
+  double *R = R0 + (long)blockIdx.y * T * m, *C = C0 + (long)blockIdx.y * T * m, *B = B0 + (long)blockIdx.y * T * T;
+  const long n = (long)w * m, nth = (long)gridDim.x * 256;
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < n; t += nth) {
+    {
+      const int c = (int)(t / w), r = (int)(t - (long)c * w);
+      R[(long)c * T + r] = A[(long)c * m + j0 + r];
+    }
+    {
+      const int c = (int)(t / m), r = (int)(t - (long)c * m);
+      C[(long)c * m + r] = (r >= j0 && r < j0 + w) ? 0.0 : A[(long)(j0 + c) * m + r];
+    }
+    if (t < (long)wn * wn) {
+      const int c = (int)(t / wn), r = (int)(t - (long)c * wn);
+      B[(long)c * T + r] = A[(long)(jn + c) * m + jn + r];
+    }
+  }
+}
+// first: the pivot block is A's own (panel 0 of a level); else B - C[rows jn ..] R'[:, columns jn ..] with the panels of width w before it
+__global__ void __launch_bounds__(256) dgj_pivot_ahead_kernel(const double *A0, long strideA, int m, int T, int first, int w, int jn, int wn, const double *C0,
+                                                              const double *Rn0, const double *B0, double *P0, int *status) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double *X = lds, *Z = lds + kWB * kWLd;
+  const int tid = threadIdx.x;
+  if (first) {
+    const double *A = A0 + (long)blockIdx.y * strideA;
+    for (int t = tid; t < kWB * kWB; t += 256) {
+      const int c = t / kWB, r = t - c * kWB;
+      X[r * kWLd + c] = (r < wn && c < wn) ? A[(long)(jn + c) * m + jn + r] : (r == c ? 1.0 : 0.0);
+    }
+  } else {
+    const double *C = C0 + (long)blockIdx.y * T * m, *Rn = Rn0 + (long)blockIdx.y * T * m, *B = B0 + (long)blockIdx.y * T * T;
+    for (int t = tid; t < kWB * kWB; t += 256) {
+      const int k = t / kWB, r = t - k * kWB;  // X[r][k] = C(jn + r, k): consecutive threads along a column of C
+      X[r * kWLd + k] = (r < wn && k < w) ? C[(long)k * m + jn + r] : 0.0;
+    }
+    for (int t = tid; t < kWB * kWB; t += 256) {
+      const int c = t / kWB, k = t - c * kWB;  // Z[k][c] = R'(k, jn + c)
+      Z[k * kWLd + c] = (k < w && c < wn) ? Rn[(long)(jn + c) * T + k] : 0.0;
+    }
+    __syncthreads();
+    constexpr int NT = kWB / 6;
+    const int tr = tid / NT, tq = tid - tr * NT;
+    double acc[6][6];
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+      for (int b = 0; b < 6; b++) acc[a][b] = 0.0;
+#pragma unroll 2
+    for (int k = 0; k < kWB; k++) {
+      double x[6], y[6];
+#pragma unroll
+      for (int a = 0; a < 6; a++) x[a] = X[(6 * tr + a) * kWLd + k];
+#pragma unroll
+      for (int b = 0; b < 6; b++) y[b] = Z[k * kWLd + 6 * tq + b];
+#pragma unroll
+      for (int a = 0; a < 6; a++)
+#pragma unroll
+        for (int b = 0; b < 6; b++) acc[a][b] = __builtin_fma(x[a], y[b], acc[a][b]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+      for (int b = 0; b < 6; b++) {
+        const int r = 6 * tr + a, c = 6 * tq + b;
+        X[r * kWLd + c] = (r < wn && c < wn) ? B[(long)c * T + r] - acc[a][b] : (r == c ? 1.0 : 0.0);
+      }
+  }
+  __syncthreads();
+  int bad = 0;
+  wide_gj_inverse(X, tid, bad, (wn + 5) / 6);
+  if (bad) status[2] = 1;
+  double *P = P0 + (long)blockIdx.y * T * T;
+  for (int t = tid; t < wn * wn; t += 256) {
+    const int c = t / wn, r = t - c * wn;
+    P[(long)c * T + r] = X[r * kWLd + c];
+  }
+}
 // dst_(k, w) = src_(k, w)^T for m x m column-major blocks; block (k, w) at base + k * stride_k + w * stride_w; 32 x 32 tiles through LDS
 __global__ void __launch_bounds__(256) dbcr_transpose_kernel(const double *src, long src_k, long src_w, double *dst, long dst_k, long dst_w, int m, int nw) {
   __shared__ double tile[32][33];
@@ -3413,7 +3500,48 @@ struct Solver {
   rocblas_handle blas = nullptr;
   // A_k <- A_k^-1 for `batch` SPD qm x qm blocks `strideA` apart: blocked Gauss-Jordan, panels of qT columns.  Per panel J:
   //   P = A_JJ^-1 (LDS), R = A_J,: and C = A_:,J copied (C's pivot rows zeroed);  Rn = P R;  A -= C Rn;  A_:,J = -C P;  A_J,: = Rn, A_JJ = P
+  // look-ahead: stream st3 runs the pivot chain (dgj_pivot_ahead_kernel) beside the products of the panel before
+  hipStream_t st3 = nullptr;
+  hipEvent_t ev_rn[2] = {nullptr, nullptr}, ev_p[2] = {nullptr, nullptr};
+  int dbcr_invert_batch_ahead(double *A, long strideA, int batch, int *d_status) {
+    const int m = d.qm, T = d.qT;
+    const double one = 1.0, neg = -1.0, zero = 0.0;
+    auto ok = [](rocblas_status r) { return r == rocblas_status_success; };
+    const long sP = (long)T * T, sR = (long)T * m;
+    const size_t lds = (size_t)2 * kWB * kWLd * sizeof(double);
+    double *Pb[2] = {d.qP, d.qP2};
+    hipLaunchKernelGGL(dgj_pivot_ahead_kernel, dim3(1, batch), dim3(256), lds, st, A, strideA, m, T, 1, 0, 0, std::min(T, m), (const double *)nullptr,
+                       (const double *)nullptr, (const double *)nullptr, Pb[0], d_status);
+    int J = 0;
+    for (int j0 = 0; j0 < m; j0 += T, J++) {
+      const int w = std::min(T, m - j0), jn = j0 + T, wn = jn < m ? std::min(T, m - jn) : 0;
+      double *P = Pb[J & 1];
+      const int ncopy = (int)std::min<long>(64, ((long)w * m + 255) / 256);
+      hipLaunchKernelGGL(dgj_copy_kernel, dim3(ncopy, batch), dim3(256), 0, st, (const double *)A, strideA, m, T, j0, w, jn, wn, d.qR, d.qC, d.qBn);
+      OSFM_REQUIRE(ok(rocblas_dgemm_strided_batched(blas, rocblas_operation_none, rocblas_operation_none, w, m, w, &one, P, T, sP, d.qR, T, sR, &zero, d.qRn, T,
+                                                    sR, batch)),
+                   OSFM_E_HIP, "rocblas_dgemm_strided_batched failed");
+      if (wn > 0) {
+        OSFM_HIP(hipEventRecord(ev_rn[J & 1], st));
+        OSFM_HIP(hipStreamWaitEvent(st3, ev_rn[J & 1], 0));
+        hipLaunchKernelGGL(dgj_pivot_ahead_kernel, dim3(1, batch), dim3(256), lds, st3, (const double *)A, strideA, m, T, 0, w, jn, wn, (const double *)d.qC,
+                           (const double *)d.qRn, (const double *)d.qBn, Pb[(J + 1) & 1], d_status);
+        OSFM_HIP(hipEventRecord(ev_p[(J + 1) & 1], st3));
+      }
+      OSFM_REQUIRE(ok(rocblas_dgemm_strided_batched(blas, rocblas_operation_none, rocblas_operation_none, m, m, w, &neg, d.qC, m, sR, d.qRn, T, sR, &one, A, m,
+                                                    strideA, batch)),
+                   OSFM_E_HIP, "rocblas_dgemm_strided_batched failed");
+      OSFM_REQUIRE(ok(rocblas_dgemm_strided_batched(blas, rocblas_operation_none, rocblas_operation_none, m, w, w, &neg, d.qC, m, sR, P, T, sP, &zero,
+                                                    A + (long)j0 * m, m, strideA, batch)),
+                   OSFM_E_HIP, "rocblas_dgemm_strided_batched failed");
+      hipLaunchKernelGGL(dgj_scatter_kernel, dim3((unsigned)(((long)w * m + 255) / 256), batch), dim3(256), 0, st, A, strideA, m, T, j0, w, (const double *)P,
+                         (const double *)d.qRn);
+      if (wn > 0) OSFM_HIP(hipStreamWaitEvent(st, ev_p[(J + 1) & 1], 0));  // before the next panel's copies overwrite what the pivot kernel reads
+    }
+    return OSFM_OK;
+  }
   int dbcr_invert_batch(double *A, long strideA, int batch, int *d_status) {
+    if (st3) return dbcr_invert_batch_ahead(A, strideA, batch, d_status);
     const int m = d.qm, T = d.qT;
     const double one = 1.0, neg = -1.0, zero = 0.0;
     auto ok = [](rocblas_status r) { return r == rocblas_status_success; };
@@ -3446,6 +3574,7 @@ struct Solver {
       static OsfmPerDeviceOnce once;
       const int rca = once.run(ctx->device, []() -> int {
         OSFM_HIP(hipFuncSetAttribute((const void *)dgj_pivot_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        OSFM_HIP(hipFuncSetAttribute((const void *)dgj_pivot_ahead_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         return OSFM_OK;
       });
       if (rca != OSFM_OK) return rca;
@@ -3853,6 +3982,11 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       if (sv.ev_fork) (void)hipEventDestroy(sv.ev_fork);
       if (sv.ev_join) (void)hipEventDestroy(sv.ev_join);
       if (sv.st2) (void)hipStreamDestroy(sv.st2);
+      for (int q = 0; q < 2; q++) {
+        if (sv.ev_rn[q]) (void)hipEventDestroy(sv.ev_rn[q]);
+        if (sv.ev_p[q]) (void)hipEventDestroy(sv.ev_p[q]);
+      }
+      if (sv.st3) (void)hipStreamDestroy(sv.st3);
     }
   } side_stream{sv};
   if (getenv("OSFM_BA_ONE_STREAM") == nullptr) {  // measurement knob: everything on one stream
@@ -4115,6 +4249,18 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       d.qR = A.alloc<double>(nb * d.qT * d.qm, e);
       d.qRn = A.alloc<double>(nb * d.qT * d.qm, e);
       d.qC = A.alloc<double>(nb * d.qT * d.qm, e);
+      d.qP2 = A.alloc<double>(nb * d.qT * d.qT, e);
+      d.qBn = A.alloc<double>(nb * d.qT * d.qT, e);
+    }
+    // (measured in round 4 and left off: 131.3 against 117.5 ms for ten LM iterations on the 50 x 100 grid, 68.2 against 66.2 ms on ragged
+    // tracks -- two cross-stream hand-overs per panel cost more than the 60 us of pivot inversion they hide, as with round 3's two-stream
+    // LDL^T; OSFM_BA_LOOKAHEAD=1 turns it on, tests/test_gpu_ba.py keeps it correct)
+    if (getenv("OSFM_BA_LOOKAHEAD") != nullptr && getenv("OSFM_BA_ONE_STREAM") == nullptr) {
+      OSFM_HIP(hipStreamCreateWithFlags(&sv.st3, hipStreamNonBlocking));
+      for (int q = 0; q < 2; q++) {
+        OSFM_HIP(hipEventCreateWithFlags(&sv.ev_rn[q], hipEventDisableTiming));
+        OSFM_HIP(hipEventCreateWithFlags(&sv.ev_p[q], hipEventDisableTiming));
+      }
     }
     if (!ctx->blas) {
       rocblas_handle h = nullptr;
