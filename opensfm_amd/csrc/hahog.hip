@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstring>
 #include <atomic>
+#include <exception>
 #include <string>
 #include <thread>
 #include <vector>
@@ -1347,7 +1348,15 @@ extern "C" int osfm_hahog_extract_batch(osfm_ctx *ctx, int n_images, const float
     }
   };
   std::vector<std::thread> th;
-  for (int k = 1; k < K; k++) th.emplace_back(work, k);
+  int started = 1;
+  try {
+    for (int k = 1; k < K; k++) {
+      th.emplace_back(work, k);
+      started++;
+    }
+  } catch (const std::exception &) {  // no more threads: the ones that exist share the images between them
+  }
+  (void)started;
   work(0);
   for (auto &t : th) t.join();
   for (int k = 0; k < K; k++)

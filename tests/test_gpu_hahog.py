@@ -147,3 +147,30 @@ def test_fused_smoothing_equals_the_two_passes(gpu_ctx, monkeypatch):
         monkeypatch.delenv("OSFM_HAHOG_TWO_PASS")
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (r, c)
     assert len(a[0]) > 0
+
+
+def test_batch_reports_the_image_that_failed(gpu_ctx):
+    """an image whose features do not fit the rows the caller offers stops the batch with OSFM_E_INVALID and names the image; the other
+    images' results are not handed out (the call failed), and the context keeps working afterwards"""
+    import ctypes as C
+
+    from opensfm_amd import _lib, features
+    from opensfm_amd._lib import OsfmError
+
+    rng = np.random.default_rng(2)
+    ims = [np.ascontiguousarray(rng.random((120, 160)), np.float32) for _ in range(3)]
+    lib = _lib.load()
+    n = len(ims)
+    caps = [64, 2, 64]  # image 1 has more than two features
+    pts = [np.empty((c, 4), np.float32) for c in caps]
+    desc = [np.empty((c, 128), np.float32) for c in caps]
+    ptrs = (C.c_void_p * n)(*[im.ctypes.data for im in ims])
+    rows, cols = (C.c_int * n)(*[120] * n), (C.c_int * n)(*[160] * n)
+    pp, dp = (C.c_void_p * n)(*[a.ctypes.data for a in pts]), (C.c_void_p * n)(*[a.ctypes.data for a in desc])
+    nf = (C.c_int * n)()
+    rc = lib.osfm_hahog_extract_batch(gpu_ctx.handle, n, ptrs, rows, cols, 1e-5, 10.0, 16, 0, pp, dp, (C.c_int * n)(*caps), nf, 2)
+    assert rc != 0 and b"image 1" in lib.osfm_last_error()
+    with pytest.raises(OsfmError):
+        _lib.check(rc, "osfm_hahog_extract_batch")
+    ok = features.hahog_batch(ims, 1e-5, 10.0, 16, ctx=gpu_ctx)
+    assert len(ok) == 3 and all(len(p) > 2 for p, _ in ok)
