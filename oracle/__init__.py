@@ -51,6 +51,17 @@ def build_camera_ref(force: bool = False) -> Optional[str]:
     return so if os.path.exists(so) else None
 
 
+def build_camera_ref_eigen(force: bool = False) -> Optional[str]:
+    """oracle/_ref/libcamera_ref_eigen.so: the reference's DistoBrown / Disto62 / Disto624 ::Backward compiled from /root/reference against the
+    small functional Eigen stand-in (ref_adapters/camera_ref_eigen.cc, ref_adapters/stubs_small_eigen)."""
+    so = os.path.join(_HERE, "_ref", "libcamera_ref_eigen.so")
+    if os.path.isdir(REFERENCE_ROBUST):
+        deps = [os.path.join(_HERE, "ref_adapters", "camera_ref_eigen.cc"), os.path.join(_HERE, "ref_adapters", "stubs_small_eigen", "Eigen", "Eigen")]
+        if force or not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+            subprocess.check_call(["make", "-C", _HERE, "-B", "_ref/libcamera_ref_eigen.so"], stdout=subprocess.DEVNULL)
+    return so if os.path.exists(so) else None
+
+
 def build_hahog_ref(force: bool = False) -> Optional[str]:
     """oracle/_ref/libhahog_ref.so: the reference's features::hahog (features/src/hahog.cc) compiled unmodified from /root/reference
     with the vendored vlfeat sources it calls (ref_adapters/hahog_ref.cc, stand-ins for its pybind11 types under ref_adapters/stubs)."""
@@ -114,6 +125,26 @@ def ref_camera(model, par, pts, backward: bool) -> Optional[np.ndarray]:
     pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 2 if backward else 3)
     out = np.zeros((len(pts), 3 if backward else 2))
     ok = camera_ref_lib().ref_camera(mid, int(backward), _p(par, C.c_double), _p(pts, C.c_double), len(pts), _p(out, C.c_double))
+    return out if ok else None
+
+
+_CAMREF_EIGEN = None
+
+
+def ref_camera_eigen_backward(model, par, px) -> Optional[np.ndarray]:
+    """The REFERENCE's bearings of the brown / fisheye62 / fisheye624 cameras (DISTO::Backward = Newton on a 2-vector, then PROJ::Backward),
+    native parameter order; None when the library is absent or the model is another one."""
+    global _CAMREF_EIGEN
+    if _CAMREF_EIGEN is None:
+        so = build_camera_ref_eigen()
+        if so is None:
+            return None
+        _CAMREF_EIGEN = C.CDLL(so)
+    mid = int(BEARING_MODELS[model] if isinstance(model, str) else model)
+    par = np.ascontiguousarray(np.r_[np.asarray(par, np.float64).reshape(-1), np.zeros(16)][:16])
+    px = np.ascontiguousarray(px, np.float64).reshape(-1, 2)
+    out = np.zeros((len(px), 3))
+    ok = _CAMREF_EIGEN.ref_camera_eigen_backward(mid, _p(par, C.c_double), _p(px, C.c_double), len(px), _p(out, C.c_double))
     return out if ok else None
 
 

@@ -359,7 +359,7 @@ def test_ransac_equals_the_reference_estimate_template(ref):
 def test_bearings_equal_the_reference_camera_functions(oracle_lib):
     """The reference's own PROJ::Backward / DISTO::Backward (camera_projections_functions.h, camera_distortions_functions.h with
     foundation::NewtonRaphson) compiled on this box: the oracle's bearings are the same doubles, bit for bit, for the seven camera
-    models whose code is plain scalar C++ (brown / fisheye62 / fisheye624 need Eigen types and stay pinned by round trips only)."""
+    models whose code is plain scalar C++ (brown / fisheye62 / fisheye624 need Eigen types: the next test)."""
     if oracle_lib.camera_ref_lib() is None:
         pytest.skip("oracle/_ref/libcamera_ref.so is absent and /root/reference is not mounted")
     rng = np.random.default_rng(31)
@@ -379,3 +379,28 @@ def test_bearings_equal_the_reference_camera_functions(oracle_lib):
         assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), model
         covered += 1
     assert covered == 7
+
+
+def test_bearings_equal_the_reference_undistortions_written_with_eigen(oracle_lib):
+    """brown / fisheye62 / fisheye624: DistoBrown / Disto62 / Disto624 ::Backward are Newton iterations on a 2-vector written with Eigen
+    types (camera_distortions_functions.h:420-447,627-658,776-799, foundation::NewtonRaphson<F, 2, 2, ManualDiff>, SolveDecr = (d^T d)^-1
+    d^T f).  They are compiled unmodified against a stand-in that implements the dozen fixed-size operations they use with Eigen's operation
+    order (oracle/ref_adapters/stubs_small_eigen): the functor, its derivative -- a row-major Jacobian written into a column-major Mat2, so
+    d is the TRANSPOSED Jacobian, which the oracle repeats --, the ten iterations and the 1e-6 stop on the step are the reference's own.
+    The oracle's bearings equal them to 1e-13 (measured: bit for bit on every point)."""
+    rng = np.random.default_rng(37)
+    covered = 0
+    for model in ("brown", "fisheye62", "fisheye624"):
+        par = _BEARING_CAMERAS[model]
+        ang, phi = rng.uniform(0, 0.6 if model == "brown" else 1.0, 3000), rng.uniform(0, 2 * np.pi, 3000)
+        X = np.c_[np.sin(ang) * np.cos(phi), np.sin(ang) * np.sin(phi), np.cos(ang)] * rng.uniform(0.5, 20, 3000)[:, None]
+        px = np.ascontiguousarray(_forward(model, par, X))
+        px[0] = 0.0
+        want = oracle_lib.ref_camera_eigen_backward(model, par, px)
+        if want is None:
+            pytest.skip("oracle/_ref/libcamera_ref_eigen.so is absent and /root/reference is not mounted")
+        got = oracle_lib.pixel_bearings_generic(model, par, px)
+        assert np.abs(got - want).max() < 1e-13, model
+        assert (got.view(np.uint64) == want.view(np.uint64)).all(1).mean() > 0.99, model
+        covered += 1
+    assert covered == 3
