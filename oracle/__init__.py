@@ -346,9 +346,9 @@ def set_num_threads(n: int) -> None:
     lib().oracle_set_num_threads(int(n))
 
 
-def ba_set_parallel(on: bool) -> None:
+def ba_set_parallel(on) -> None:
     """the BA oracle's Schur elimination on all cores (default) or with the serial loops that define its summation order"""
-    lib().oracle_ba_set_parallel(int(bool(on)))
+    lib().oracle_ba_set_parallel(int(on))  # 0 serial, 1 parallel (default), 2 parallel with the right-looking skyline factor forced
 
 
 # ------------------------------------------------------------------------------------------------

@@ -565,6 +565,87 @@ static int skyline_cholesky(skyline *A) {
   }
   return 0;
 }
+/* The same factor, right-looking and on all cores (round 4): column k is finished, then every row below it subtracts L[i][k] L[j][k] from its
+ * entries (j ascending) -- entry (i, j) loses the products of k = max(first[i], first[j]) .. j - 1 one by one in ascending k, from A[i][j], and
+ * is divided by L[j][j] when column j comes up: the sequence of operations of skyline_cholesky above, so the factor is the same bit for bit
+ * (tests/test_oracle_ba.py compares the two).  Two barriers per column: pays when the rows are wide (a block survey's half-width of ~600
+ * unknowns: the serial factor is most of the oracle's time there), not on a 60-wide sequence band -- the caller chooses. */
+static int skyline_cholesky_parallel(skyline *A) {
+  const int n = A->n;
+  /* last row that has an entry in column k (first[] need not be monotone) */
+  int *last = (int *)malloc((size_t)n * sizeof(int));
+  if (!last) return -1;
+  for (int k = 0; k < n; k++) last[k] = k;
+  {
+    /* last[k] = max row i with first[i] <= k: a running maximum over the rows bucketed by their first column */
+    int *best = (int *)calloc((size_t)n + 1, sizeof(int)); /* best[f] = max row with first == f */
+    if (!best) {
+      free(last);
+      return -1;
+    }
+    for (int f = 0; f <= n; f++) best[f] = -1;
+    for (int i = 0; i < n; i++)
+      if (i > best[A->first[i]]) best[A->first[i]] = i;
+    int run = -1;
+    for (int k = 0; k < n; k++) {
+      run = best[k] > run ? best[k] : run;
+      last[k] = run > k ? run : k;
+    }
+    free(best);
+  }
+  /* column k of L, gathered (the rows are stored row by row: reading L[j][k] down a column is a stride of a row length) */
+  double *colk = (double *)malloc((size_t)n * sizeof(double));
+  if (!colk) {
+    free(last);
+    return -1;
+  }
+  int monotone = 1; /* first[] nondecreasing (a band): every row between k and i then reaches column k, and the update is one dense axpy */
+  for (int i = 1; i < n; i++)
+    if (A->first[i] < A->first[i - 1]) monotone = 0;
+  int bad = 0;
+#pragma omp parallel
+  {
+    for (int k = 0; k < n; k++) {
+#pragma omp single
+      {
+        double *rk = A->v + A->off[k];
+        const double s = rk[k - A->first[k]];
+        if (!(s > 0)) bad = 1;
+        else rk[k - A->first[k]] = sqrt(s);
+      } /* implicit barrier */
+      if (bad) break;
+      const double dkk = A->v[A->off[k] + (k - A->first[k])];
+      const int hi = last[k];
+#pragma omp for schedule(static)
+      for (int i = k + 1; i <= hi; i++) {
+        const int fi = A->first[i];
+        double l = 0.0;
+        if (fi <= k) {
+          double *ri = A->v + A->off[i];
+          l = ri[k - fi] / dkk;
+          ri[k - fi] = l;
+        }
+        colk[i] = l;
+      } /* implicit barrier: column k of L is complete */
+#pragma omp for schedule(dynamic, 8)
+      for (int i = k + 1; i <= hi; i++) {
+        const int fi = A->first[i];
+        if (fi > k) continue;
+        double *ri = A->v + A->off[i] - fi;
+        const double lik = colk[i];
+        if (monotone) {
+          for (int j = k + 1; j <= i; j++) ri[j] -= lik * colk[j];
+        } else {
+          for (int j = k + 1; j <= i; j++)
+            if (A->first[j] <= k) ri[j] -= lik * colk[j];
+        }
+      } /* implicit barrier */
+    }
+  }
+  free(colk);
+  free(last);
+  return bad ? -1 : 0;
+}
 static void skyline_solve(const skyline *A, double *b) {
   const int n = A->n;
   for (int i = 0; i < n; i++) {
@@ -593,7 +674,7 @@ static double now_s(void) {
 /* 1 (default): the Schur elimination runs on all cores (entry-owner partition, see below); 0: the serial loops (kept: they define the
  * summation order the parallel path reproduces, and tests compare the two) */
 static int g_ba_parallel = 1;
-void oracle_ba_set_parallel(int on) { g_ba_parallel = on; }
+void oracle_ba_set_parallel(int on) { g_ba_parallel = on; } /* 2: also force the parallel skyline factor (tests) */
 void oracle_set_num_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }
 
 int oracle_ba_solve(ba_problem *P, const ba_options *O, ba_report *Rp) {
@@ -1110,7 +1191,17 @@ int oracle_ba_solve(ba_problem *P, const ba_options *O, ba_report *Rp) {
       /* factor + solve */
       double *dx = d_red;
       for (int i = 0; i < nred; i++) dx[i] = rhs[i];
-      int bad = nred > 0 ? skyline_cholesky(&A) : 0;
+      int bad = 0;
+      if (nred > 0) {
+        /* wide rows (mean profile width >= 128 unknowns, or forced: g_ba_parallel == 2): the right-looking factor on all cores */
+        const double mean_w = (double)(A.off[nred - 1] + (nred - 1 - A.first[nred - 1]) + 1) / (double)nred;
+#ifdef _OPENMP
+        const int many = omp_get_max_threads() > 1;
+#else
+        const int many = 0;
+#endif
+        bad = (g_ba_parallel == 2 || (g_ba_parallel && mean_w >= 128.0 && many)) ? skyline_cholesky_parallel(&A) : skyline_cholesky(&A);
+      }
       if (!bad && nred > 0) skyline_solve(&A, dx);
       Rp->seconds_linear_solver += now_s() - t_lin;
       if (bad) { /* factorisation failed: invalid step */

@@ -220,3 +220,25 @@ def test_ragged_tracks_scene(oracle_lib):
     assert len(sets) > 300  # the plain scene has at most 35 (one per window start)
     r = oracle_lib.ba_solve(pr, max_iterations=30)
     assert r["final_cost"] < 0.2 * r["initial_cost"]
+
+
+def test_parallel_skyline_factor_equals_the_serial_one(oracle_lib):
+    """The oracle's right-looking skyline Cholesky on all cores (used for wide profiles: block surveys) performs, per entry, the serial
+    up-looking factor's operations in the same order: the whole solve -- every point and pose after four LM iterations -- is identical bit for bit whether it is
+    forced on (ba_set_parallel(2)) or not, on a sequence band and on a block survey whose shots are not numbered along the band."""
+    from opensfm_amd import synthetic
+
+    kw = dict(max_iterations=4, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
+    n_all = oracle_lib.num_threads()
+    try:
+        for pr in (synthetic.make_ba_scene(50, 2000, 6, seed=9), synthetic.make_ba_scene_grid(6, 14, 1500, 9, seed=3)):
+            oracle_lib.set_num_threads(max(2, min(n_all, 7)))
+            oracle_lib.ba_set_parallel(1)
+            a = oracle_lib.ba_solve(pr, **kw)
+            oracle_lib.ba_set_parallel(2)
+            b = oracle_lib.ba_solve(pr, **kw)
+            assert np.array_equal(a["points"], b["points"]) and np.array_equal(a["shot_pose"], b["shot_pose"])
+            assert np.allclose(a["cost_history"], b["cost_history"], rtol=1e-13)  # the cost itself is an OpenMP reduction
+    finally:
+        oracle_lib.set_num_threads(n_all)
+        oracle_lib.ba_set_parallel(1)
