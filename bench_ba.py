@@ -52,7 +52,7 @@ def run_grid(ctx, rows: int = 50, cols: int = 100, points: int = 500000, track: 
                            "shots, factorised by cyclic reduction (log2(S / bw) levels; per level a blocked in-place Gauss-Jordan inverse -- pivot "
                            "panels in LDS -- and batched dgemm); a solve = one launch per level down and up; CG confirms in 1-2 iterations"}
     if cpu_iters > 0:
-        out["cpu_baseline"] = _oracle_leg(pr, ctx, cpu_iters, "exact Schur elimination and skyline Cholesky (profile half-width 6 x bandwidth), both on all cores")
+        out["cpu_baseline"] = _oracle_leg(pr, ctx, cpu_iters, "exact Schur elimination on all cores + skyline Cholesky (serial) of half-width 6 x bandwidth")
     return out
 
 
@@ -89,7 +89,7 @@ def run_ragged(ctx, shots: int = 5000, points: int = 500000, track: int = 10, it
            "inlier_rmse_px": round(float(np.sqrt((g["reproj_err"][inl] ** 2).sum(1).mean()) * 2000.0), 4),
            "cost": [float(g["initial_cost"]), float(g["final_cost"])], "lm_iteration": lm_iteration_line(g, nobs)}
     if cpu_iters > 0:
-        out["cpu_baseline"] = _oracle_leg(pr, ctx, cpu_iters, "exact Schur elimination and skyline Cholesky, both on all cores")
+        out["cpu_baseline"] = _oracle_leg(pr, ctx, cpu_iters, "exact Schur elimination on all cores + skyline Cholesky (serial)")
     return out
 
 
@@ -223,8 +223,7 @@ def run(ctx, shots: int = 5000, points: int = 500000, track: int = 10, iters: in
             "unit": "LM-iters/s",
             "cores": oracle.num_threads(),
             "kind": "port",
-            "kind_note": "port; OpenMP residuals / Jacobians AND Schur elimination (entry-owner partition); the skyline Cholesky is serial on this 60-wide band "
-                         "(its all-cores right-looking form pays from ~128-wide profiles: the grid / ragged legs)",
+            "kind_note": "port; OpenMP residuals / Jacobians AND Schur elimination (entry-owner partition), skyline Cholesky serial",
             "sample": f"all {cpu_iters} LM iterations of the same problem ({dt:.1f} s; exact Schur + skyline Cholesky on "
                       f"{oracle.num_threads()} threads)",
             "parity_iterations": int(cpu_iters),

@@ -569,7 +569,7 @@ static int skyline_cholesky(skyline *A) {
  * entries (j ascending) -- entry (i, j) loses the products of k = max(first[i], first[j]) .. j - 1 one by one in ascending k, from A[i][j], and
  * is divided by L[j][j] when column j comes up: the sequence of operations of skyline_cholesky above, so the factor is the same bit for bit
  * (tests/test_oracle_ba.py compares the two).  Two barriers per column: pays when the rows are wide (a block survey's half-width of ~600
- * unknowns: the serial factor is most of the oracle's time there), not on a 60-wide sequence band -- the caller chooses. */
+ * unknowns: the serial factor is most of the oracle's time there), not on a 60-wide sequence band.  Opt-in (oracle_ba_set_parallel(2)). */
 static int skyline_cholesky_parallel(skyline *A) {
   const int n = A->n;
   /* last row that has an entry in column k (first[] need not be monotone) */
@@ -603,7 +603,11 @@ static int skyline_cholesky_parallel(skyline *A) {
   for (int i = 1; i < n; i++)
     if (A->first[i] < A->first[i - 1]) monotone = 0;
   int bad = 0;
-#pragma omp parallel
+  int nt = 1;
+#ifdef _OPENMP
+  nt = omp_get_max_threads() < 16 ? omp_get_max_threads() : 16; /* two barriers per column: more threads cost more than they bring */
+#endif
+#pragma omp parallel num_threads(nt)
   {
     for (int k = 0; k < n; k++) {
 #pragma omp single
@@ -1193,14 +1197,10 @@ int oracle_ba_solve(ba_problem *P, const ba_options *O, ba_report *Rp) {
       for (int i = 0; i < nred; i++) dx[i] = rhs[i];
       int bad = 0;
       if (nred > 0) {
-        /* wide rows (mean profile width >= 128 unknowns, or forced: g_ba_parallel == 2): the right-looking factor on all cores */
-        const double mean_w = (double)(A.off[nred - 1] + (nred - 1 - A.first[nred - 1]) + 1) / (double)nred;
-#ifdef _OPENMP
-        const int many = omp_get_max_threads() > 1;
-#else
-        const int many = 0;
-#endif
-        bad = (g_ba_parallel == 2 || (g_ba_parallel && mean_w >= 128.0 && many)) ? skyline_cholesky_parallel(&A) : skyline_cholesky(&A);
+        /* g_ba_parallel == 2 (opt-in): the right-looking factor on up to 16 cores.  It is NOT the default: with hundreds of OpenMP threads --
+         * the GPU box's host, or several test workers at once -- its two barriers per column cost more than the factor itself (round 4: a run
+         * of the GPU suite with it on by default did not finish), and nothing on a GPU box may depend on an unmeasured path. */
+        bad = g_ba_parallel == 2 ? skyline_cholesky_parallel(&A) : skyline_cholesky(&A);
       }
       if (!bad && nred > 0) skyline_solve(&A, dx);
       Rp->seconds_linear_solver += now_s() - t_lin;
