@@ -169,6 +169,43 @@ __device__ __forceinline__ long xcd_contiguous(long b, long n) {  // bijection f
 // ------------------------------------------------------------------------------------------
 // device problem image
 // ------------------------------------------------------------------------------------------
+// generic mode (osfm_bundle_solve; kernels in ba_generic.inc): what the device image holds beyond the [k1 k2 focal] configuration.
+// In that mode a "shot" of the arrays below is a rig INSTANCE (the 6-parameter unknown of the band), a VIEW is one of the caller's
+// shots = (instance, rig camera, camera); the views of an instance are consecutive.
+struct GenDev {
+  int NRr;  // residual rows per observation: 2, or 3 when a spherical camera is present
+  int KW;   // border slots per observation row: camera parameters then the rig camera pose of the widest view
+  int NB;   // border unknowns: nred = 6 S + NB
+  int NV, NRC;
+  int oJp, oJc, oJb, ncomp;  // component offsets of a row: res [0, NRr) | Jp | Jc | Jb, ncomp in all
+  const int *view_inst, *view_rc, *view_cam;  // NV
+  const int *view_col;                        // NV x KW: border column of a slot, -1 = none
+  const long *view_off;                       // NV + 1: shot-major segments of the views
+  const int *inst_view0;                      // S + 1: first view of an instance
+  const int *o_view, *sm_view;                // per row, point-major / shot-major
+  const unsigned char *o_kind, *sm_kind;      // per row or null: 0 reprojection, 1 depth prior on z, 2 radial depth prior
+  double *cam, *cam_n;                        // NC x 16 native parameters, current / candidate
+  const double *cam_prior, *cam_sigma;        // NC x 16
+  double *rc, *rc_n;                          // NRC x 6 rig camera poses
+  const double *rc_prior, *rc_sigma;          // NRC x 6 or null
+  double *bias, *bias_n;                      // NC x 7
+  double *rcR;                                // NRC x 36: rotation blocks of the rig cameras (shot_rot_kernel's layout)
+  const unsigned char *rc_useful;             // the rig camera enters the projection (not a constant identity, bundle_adjuster.cc:17-20)
+  const int *cam_col, *rc_col, *bias_col;     // first border column of a free block, -1 = constant
+  const unsigned char *col_slot;              // NB x NV: the slot of view v that holds border column j, 255 = none
+  double *vpart;                              // NV x 2 KW: per-view partial sums on the border slots
+  double *yv;                                 // NV x KW: the border step gathered per view
+  double *PI, *Bpri, *Cpri;                   // prior blocks: S x 36, NB x 6 S, NB x NB
+  double *gpri;                               // nred: the priors' gradient
+  double *bdot;                               // NB
+  const double *gps, *gps_sigma;              // S x 3 each or null: instance position priors
+  const int *inst_bias_cam;                   // S
+  const double *up, *up_sigma;                // NV x 3, NV or null (unit vectors are formed in the kernel)
+  const double *pan, *pan_sigma, *tilt, *tilt_sigma, *roll, *roll_sigma;  // NV each or null
+  const double *pt_prior, *pt_prior_sigma;    // P x 3 each or null
+  const unsigned char *pt_prior_alt;          // P
+};
+
 struct Dev {
   int S, P, NC;
   long M;
@@ -249,6 +286,8 @@ struct Dev {
   double *x, *r, *z, *p, *Ap, *b;
   double *scal;     // device scalars
   double *partial;  // block partial sums
+  int gen;          // 1: generic mode, the fields of g are set
+  GenDev g;
 };
 
 #define JA(o, c) d.Jpm[(long)(c) * d.M + (o)]  /* point-major SoA */
@@ -596,7 +635,7 @@ __global__ void scale_init_kernel(Dev d) {
     if (i < d.cam0)
       fixed = d.shot_fixed && d.shot_fixed[i / 6];
     else
-      fixed = d.cam_fixed[(i - d.cam0) / 3];
+      fixed = d.gen ? false : (bool)d.cam_fixed[(i - d.cam0) / 3];
     d.sc_red[i] = fixed ? 0.0 : 1.0 / (1.0 + sqrt(d.diag_red[i]));
   }
   if (i < 3L * d.P) {
@@ -781,6 +820,13 @@ __device__ __forceinline__ void WAVE_SYNC() {
 }
 
 __device__ __forceinline__ void jred_jp(const Dev &d, long k, double E[6][3]) {  // shot-major position k
+  if (d.gen && d.g.NRr == 3) {  // rows of three residuals (a spherical camera is present): res 3 | Jp 9 | Jc 18
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) E[i][j] = (JS(k, 12 + i) * JS(k, 3 + j) + JS(k, 18 + i) * JS(k, 6 + j)) + JS(k, 24 + i) * JS(k, 9 + j);
+    return;
+  }
   double jp[6];
 #pragma unroll
   for (int j = 0; j < 6; j++) jp[j] = JS(k, 2 + j);
@@ -1366,8 +1412,8 @@ __global__ void __launch_bounds__(64) band_solve_kernel(Dev d, const double *rin
       }
     }
   }
-  // camera blocks
-  for (int cm = lane; cm < d.NC; cm += 64) {
+  // camera blocks (generic mode: the border rows are gen_precond_border_kernel's)
+  for (int cm = lane; cm < (d.gen ? 0 : d.NC); cm += 64) {
     const double *Bi = d.Binv + 36 * (long)d.S + 9 * cm, *rr = rin + d.cam0 + 3 * cm;
     for (int i = 0; i < 3; i++) z[d.cam0 + 3 * cm + i] = Bi[3 * i] * rr[0] + Bi[3 * i + 1] * rr[1] + Bi[3 * i + 2] * rr[2];
   }
@@ -2571,7 +2617,7 @@ __global__ void __launch_bounds__(256) ctri_solve_kernel(Dev d, const double *ri
     }
     __syncthreads();
   }
-  for (int cm = tid; cm < d.NC; cm += 256) {
+  for (int cm = tid; cm < (d.gen ? 0 : d.NC); cm += 256) {
     const double *Bi = d.Binv + 36 * (long)d.S + 9 * cm, *rr = rin + d.cam0 + 3 * cm;
     for (int i = 0; i < 3; i++) z[d.cam0 + 3 * cm + i] = Bi[3 * i] * rr[0] + Bi[3 * i + 1] * rr[1] + Bi[3 * i + 2] * rr[2];
   }
@@ -3283,6 +3329,15 @@ __global__ void iota_int_kernel(int *a, long n) {
   const long i = (long)blockIdx.x * TPB + threadIdx.x;
   if (i < n) a[i] = (int)i;
 }
+__global__ void gather_byte_kernel(const int *idx, const unsigned char *src, long n, unsigned char *dst) {
+  const long i = (long)blockIdx.x * TPB + threadIdx.x;
+  if (i < n) dst[i] = src[idx[i]];
+}
+// generic mode: an instance's shot-major segment starts where its first view's does
+__global__ void gen_shot_off_kernel(const long *view_off, const int *inst_view0, int S, long *shot_off) {
+  const int i = blockIdx.x * TPB + threadIdx.x;
+  if (i <= S) shot_off[i] = view_off[inst_view0[i]];
+}
 __global__ void gather_int_kernel(const int *idx, const int *src, long n, int *dst) {
   const long i = (long)blockIdx.x * TPB + threadIdx.x;
   if (i < n) dst[i] = src[idx[i]];
@@ -3395,6 +3450,14 @@ __global__ void gather_sm_kernel(const int *shot_obs, const int *o_shot, const i
   s_y[k] = o_y[o];
   s_sigma[k] = o_sigma[o];
 }
+__global__ void unpermute3_kernel(const int *perm, const double *in, long M, double *out) {
+  const long k = (long)blockIdx.x * TPB + threadIdx.x;
+  if (k >= M) return;
+  const long o = perm[k];
+  out[3 * o] = in[3 * k];
+  out[3 * o + 1] = in[3 * k + 1];
+  out[3 * o + 2] = in[3 * k + 2];
+}
 __global__ void unpermute2_kernel(const int *perm, const double *in, long M, double *out) {
   const long k = (long)blockIdx.x * TPB + threadIdx.x;
   if (k >= M) return;
@@ -3402,6 +3465,8 @@ __global__ void unpermute2_kernel(const int *perm, const double *in, long M, dou
   out[2 * o] = in[2 * k];
   out[2 * o + 1] = in[2 * k + 1];
 }
+
+#include "ba_generic.inc"
 
 struct Arena {
   std::vector<void *> ptrs;
@@ -3425,7 +3490,7 @@ struct Arena {
   }
 };
 
-inline int nblk(long n, int t = TPB) { return (int)((n + t - 1) / t); }
+inline int nblk(long n, int t = TPB) { return (int)std::max<long>(1, (n + t - 1) / t); }  // (never an empty grid: the kernels test their index)
 
 struct Solver {
   osfm_ctx *ctx;
@@ -3437,8 +3502,93 @@ struct Solver {
 
   void rot(const double *poses) { hipLaunchKernelGGL(shot_rot_kernel, dim3(nblk(d.S, 64)), dim3(64), 0, st, d, poses); }
 
+  // ---- generic mode (kernels: ba_generic.inc) ----
+  bool have_bpri = false;  // a prior couples an instance with a free border block (position prior with a free bias, up vector / compass with a free rig camera)
+#define OSFM_GEN_KW(NRV, KERNEL, grid, block, stream, ...)                                                    \
+  do {                                                                                                        \
+    if (d.g.KW <= 4) hipLaunchKernelGGL((KERNEL<NRV, 4>), grid, block, 0, stream, __VA_ARGS__);                \
+    else if (d.g.KW <= 9) hipLaunchKernelGGL((KERNEL<NRV, 9>), grid, block, 0, stream, __VA_ARGS__);           \
+    else if (d.g.KW <= 16) hipLaunchKernelGGL((KERNEL<NRV, 16>), grid, block, 0, stream, __VA_ARGS__);         \
+    else hipLaunchKernelGGL((KERNEL<NRV, kGenMaxKW>), grid, block, 0, stream, __VA_ARGS__);                    \
+  } while (0)
+#define OSFM_GEN_NR_KW(KERNEL, grid, block, stream, ...)                                       \
+  do {                                                                                         \
+    if (d.g.NRr == 3) OSFM_GEN_KW(3, KERNEL, grid, block, stream, __VA_ARGS__);                  \
+    else OSFM_GEN_KW(2, KERNEL, grid, block, stream, __VA_ARGS__);                               \
+  } while (0)
+  int gen_nprior() const { return d.NC + d.g.NRC + d.S + 4 * d.g.NV; }
+  // cost (with priors) at the given parameters into scal[8] (sum of squares of the reprojections into scal[9]); jac: the Jacobian rows
+  // and the prior blocks as well
+  void gen_eval_enqueue(const double *cam, const double *bias, const double *rcp, const double *poses, const double *pts, bool jac) {
+    rot(poses);
+    hipLaunchKernelGGL(gen_rc_rot_kernel, dim3(nblk(d.g.NRC, 64)), dim3(64), 0, st, d, rcp);
+    const int nb = nblk(d.M);
+    if (jac) {
+      (void)hipMemsetAsync(d.g.PI, 0, (size_t)36 * d.S * sizeof(double), st);
+      (void)hipMemsetAsync(d.g.Bpri, 0, (size_t)std::max(1, d.g.NB) * 6 * d.S * sizeof(double), st);
+      (void)hipMemsetAsync(d.g.Cpri, 0, (size_t)std::max(1, d.g.NB * d.g.NB) * sizeof(double), st);
+      (void)hipMemsetAsync(d.g.gpri, 0, (size_t)d.nred * sizeof(double), st);
+    }
+    if (d.M > 0) {
+      if (d.g.NRr == 3) {
+        if (jac) {
+          hipLaunchKernelGGL((gen_eval_kernel<3, true, false>), dim3(nb), dim3(TPB), 0, st, d, cam, rcp, poses, pts, loss, loss_a);
+          hipLaunchKernelGGL((gen_eval_kernel<3, true, true>), dim3(nb), dim3(TPB), 0, st, d, cam, rcp, poses, pts, loss, loss_a);
+        } else
+          hipLaunchKernelGGL((gen_eval_kernel<3, false, false>), dim3(nb), dim3(TPB), 0, st, d, cam, rcp, poses, pts, loss, loss_a);
+      } else {
+        if (jac) {
+          hipLaunchKernelGGL((gen_eval_kernel<2, true, false>), dim3(nb), dim3(TPB), 0, st, d, cam, rcp, poses, pts, loss, loss_a);
+          hipLaunchKernelGGL((gen_eval_kernel<2, true, true>), dim3(nb), dim3(TPB), 0, st, d, cam, rcp, poses, pts, loss, loss_a);
+        } else
+          hipLaunchKernelGGL((gen_eval_kernel<2, false, false>), dim3(nb), dim3(TPB), 0, st, d, cam, rcp, poses, pts, loss, loss_a);
+      }
+    }
+    hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(1024), 0, st, d.partial, (long)(d.M > 0 ? nb : 0), 2, d.scal + 8);
+    hipLaunchKernelGGL(gen_prior_kernel, dim3(nblk(gen_nprior(), 64)), dim3(64), 0, st, d, cam, bias, rcp, poses, jac ? 1 : 0, (const double *)nullptr,
+                       d.scal + 8);
+    if (d.g.pt_prior_sigma && d.P > 0) hipLaunchKernelGGL(gen_point_prior_kernel, dim3(nblk(d.P)), dim3(TPB), 0, st, d, pts, 0, d.scal + 8);
+  }
+  void gen_gradients() {
+    if (d.M > 0) {
+      if (d.g.NRr == 3) hipLaunchKernelGGL(gen_point_grad_kernel<3>, dim3(d.nwg), dim3(kCoopObs), 0, st, d);
+      else hipLaunchKernelGGL(gen_point_grad_kernel<2>, dim3(d.nwg), dim3(kCoopObs), 0, st, d);
+    } else if (d.P > 0)
+      hipLaunchKernelGGL(gen_point_grad_empty_kernel, dim3(nblk(d.P)), dim3(TPB), 0, st, d);
+    OSFM_GEN_NR_KW(gen_shot_grad_kernel, dim3(d.S), dim3(64), st, d);
+    if (d.g.NB > 0) {
+      hipLaunchKernelGGL(gen_border_reduce_kernel, dim3(d.g.NB), dim3(256), 0, st, d, 2 * d.g.KW, 0, 1);
+      hipLaunchKernelGGL(gen_border_reduce_kernel, dim3(d.g.NB), dim3(256), 0, st, d, 2 * d.g.KW, d.g.KW, 2);
+    }
+  }
+  // the observation rows' share of J^T (I - Jp Hhat Jp^T) J y (mode 0, y = d.y) or of the right-hand side (mode 1) into zc, on stream sq
+  void gen_rows_apply(int mode, hipStream_t sq) {
+    if (d.M <= 0) return;
+    if (mode == 0 && d.g.KW > 0) hipLaunchKernelGGL(gen_view_gather_kernel, dim3(nblk((long)d.g.NV * d.g.KW)), dim3(TPB), 0, sq, d, (const double *)d.y);
+    if (d.g.NRr == 3) {
+      if (mode == 0) hipLaunchKernelGGL((gen_schur_point_kernel<3, 0>), dim3(d.nwg), dim3(kCoopObs), 0, sq, d, (const double *)d.y);
+      else hipLaunchKernelGGL((gen_schur_point_kernel<3, 1>), dim3(d.nwg), dim3(kCoopObs), 0, sq, d, (const double *)d.y);
+    } else {
+      if (mode == 0) hipLaunchKernelGGL((gen_schur_point_kernel<2, 0>), dim3(d.nwg), dim3(kCoopObs), 0, sq, d, (const double *)d.y);
+      else hipLaunchKernelGGL((gen_schur_point_kernel<2, 1>), dim3(d.nwg), dim3(kCoopObs), 0, sq, d, (const double *)d.y);
+    }
+    OSFM_GEN_NR_KW(gen_schur_shot_kernel, dim3(d.S), dim3(64), sq, d);
+    if (d.g.NB > 0) hipLaunchKernelGGL(gen_border_reduce_kernel, dim3(d.g.NB), dim3(256), 0, sq, d, 2 * d.g.KW, 0, 0);
+  }
+  void gen_matvec(const double *x, double *out, double radius, hipStream_t sq) {
+    hipLaunchKernelGGL(scale_vec_kernel, dim3(nblk(d.nred)), dim3(TPB), 0, sq, d.sc_red, x, d.y, d.nred);
+    gen_rows_apply(0, sq);
+    if (have_bpri && d.g.NB > 0) hipLaunchKernelGGL(gen_bpri_dot_kernel, dim3(d.g.NB), dim3(256), 0, sq, d, (const double *)d.y);
+    hipLaunchKernelGGL(gen_schur_finish_kernel, dim3(nblk(d.nred)), dim3(TPB), 0, sq, d, x, (const double *)d.y, out, radius, 0, d.M > 0 ? 1 : 0,
+                       have_bpri ? 1 : 0);
+  }
+
   // cost (with priors) at (cams, poses, pts) into scal[8] (and the sum of squares into scal[9]); optionally builds the Jacobian
   void eval_enqueue(const double *cams, const double *poses, const double *pts, bool jac) {
+    if (d.gen) {  // the candidate lives in the *_n arrays of every block
+      const bool cand = poses == d.poses_n;
+      return gen_eval_enqueue(cand ? d.g.cam_n : d.g.cam, cand ? d.g.bias_n : d.g.bias, cand ? d.g.rc_n : d.g.rc, poses, pts, jac);
+    }
     rot(poses);
     const int nb = nblk(d.M);
     if (jac) {
@@ -3459,6 +3609,7 @@ struct Solver {
     return OSFM_OK;
   }
   void gradients() {
+    if (d.gen) return gen_gradients();
     hipLaunchKernelGGL(point_grad_kernel, dim3(d.nwg), dim3(kCoopObs), 0, st, d);
     hipLaunchKernelGGL(shot_grad_kernel, dim3(d.S), dim3(64), 0, st, d, d.poses);
     hipLaunchKernelGGL(cam_reduce_kernel, dim3(d.NC), dim3(kCamRedT), 0, st, d, 9);
@@ -3654,23 +3805,32 @@ struct Solver {
     else bcr_solve_set(rs);
   }
   // z = M^-1 r; solved: the exact band solve of r is already in z (it went through the walk of the camera border's columns)
+  double cur_radius = 0.0;  // generic mode: the border rows of the fallback preconditioners are the scaled diagonal at this radius
   void precond(const double *r, double *z, bool solved = false) {
-    const RhsSet one{r, 0, z, 0, 1, nullptr, nullptr, -1, 0};
+    const RhsSet one{r, 0, z, 0, 1, nullptr, nullptr, -1, d.gen ? -1 : 0};
     if ((use_bcr || use_wide) && use_border) {
-      const int nb = 3 * d.NC, n = 6 * d.S;
+      const int nb = d.gen ? d.g.NB : 3 * d.NC, n = 6 * d.S;
       if (!solved) exact_solve_set(one);
-      hipLaunchKernelGGL(border_rhs_kernel, dim3(1), dim3(1024), 0, st, Bc, SigInv, r, z, nb, n, d.cam0);
+      if (d.gen) hipLaunchKernelGGL(gen_border_rhs_kernel, dim3(1), dim3(1024), 0, st, Bc, SigInv, r, z, nb, n, d.cam0);
+      else hipLaunchKernelGGL(border_rhs_kernel, dim3(1), dim3(1024), 0, st, Bc, SigInv, r, z, nb, n, d.cam0);
       hipLaunchKernelGGL(border_update_kernel, dim3(nblk(n)), dim3(TPB), 0, st, Wb, z, nb, n, d.cam0);
-    } else if (use_bcr || use_wide)
+      return;
+    }
+    if (use_bcr || use_wide)
       exact_solve_set(one);
     else if (use_ctri)
       hipLaunchKernelGGL(ctri_solve_kernel, dim3(1), dim3(256), 0, st, d, r, z);
     else if (use_band)
       hipLaunchKernelGGL(band_solve_for(d.bw), dim3(1), dim3(64), 0, st, d, r, z);
-    else
+    else if (d.gen) {
+      hipLaunchKernelGGL(gen_precond_apply_kernel, dim3(nblk(d.S + d.g.NB)), dim3(TPB), 0, st, d, r, z, cur_radius);
+      return;
+    } else
       hipLaunchKernelGGL(precond_apply_kernel, dim3(nblk(d.S + d.NC)), dim3(TPB), 0, st, d, r, z);
+    if (d.gen && d.g.NB > 0) hipLaunchKernelGGL(gen_precond_border_kernel, dim3(nblk(d.g.NB, 64)), dim3(64), 0, st, d, r, z, cur_radius);
   }
   void matvec(const double *x, double *out, double radius) {
+    if (d.gen) return gen_matvec(x, out, radius, st);
     hipLaunchKernelGGL(scale_vec_kernel, dim3(nblk(d.nred)), dim3(TPB), 0, st, d.sc_red, x, d.y, d.nred);
     hipLaunchKernelGGL(schur_point_coop_kernel<0>, dim3(d.nwg), dim3(kCoopObs), 0, st, d, d.y);
     hipLaunchKernelGGL(schur_shot_kernel, dim3(d.S), dim3(64), 0, st, d);
@@ -3857,7 +4017,34 @@ static int best_shot_order(const osfm_ba_problem *P, std::vector<int> &new_of_ol
   return bw;
 }
 
-static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_options *O, osfm_ba_report *Rp);
+// The generic mode's inputs beyond what an osfm_ba_problem carries (host arrays, instances already in the order the band is built in;
+// ba_generic_host.inc builds it from an osfm_bundle_problem).  With it the osfm_ba_problem means: n_shots = rig instances, shot_pose =
+// their poses, shot_fixed, obs_shot = the INSTANCE of a row, obs_xy / obs_sigma of a row (a depth-prior row: x = the depth, sigma its
+// sd), points / point_fixed; its cam_params / cam_prior / cam_sigma / shot_camera / gps / up fields are unused.
+struct GenInput {
+  int NV, NRC;                                 // views (the caller's shots), rig cameras
+  const int *view_inst, *view_rc, *view_cam;   // NV; the views of an instance consecutive, instances ascending
+  const int *obs_view;                         // per row
+  const unsigned char *obs_kind;               // per row or null
+  const int *cam_model;                        // NC
+  double *cam;                                 // NC x 16, in / out
+  const double *cam_prior, *cam_sigma;         // NC x 16
+  const unsigned char *cam_fixed;              // NC
+  double *bias;                                // NC x 7, in / out
+  const unsigned char *bias_fixed;             // NC
+  double *rc_pose;                             // NRC x 6, in / out
+  const double *rc_prior, *rc_sigma;           // NRC x 6 or null
+  const unsigned char *rc_fixed;               // NRC
+  const double *gps, *gps_sigma;               // instances x 3 or null
+  const int *inst_bias_cam;                    // instances or null
+  const double *up, *up_sigma;                 // NV x 3, NV or null
+  const double *pan, *pan_sigma, *tilt, *tilt_sigma, *roll, *roll_sigma;  // NV each or null
+  const double *pt_prior, *pt_prior_sigma;     // points x 3 or null
+  const unsigned char *pt_prior_alt;           // points or null (= all 1)
+  double *reproj3;                             // rows x 3 or null: out, residuals with sigma 1 in the caller's row order
+  long rows0;                                  // reprojection rows (the depth-prior rows do not count in the RMSE)
+};
+static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_options *O, osfm_ba_report *Rp, const GenInput *G = nullptr);
 
 // Host-only helper (no GPU needed): the renumbering osfm_ba_solve would apply.  new_of_old[n_shots] receives the
 // reverse Cuthill-McKee order; returns the co-visibility half-width in the caller's order / after renumbering.
@@ -3937,12 +4124,19 @@ extern "C" int osfm_ba_solve(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_op
   return rc;
 }
 
-static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_options *O, osfm_ba_report *Rp) {
+static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_options *O, osfm_ba_report *Rp, const GenInput *G) {
   OSFM_REQUIRE(ctx && P && O && Rp, OSFM_E_INVALID, "osfm_ba_solve: null argument");
-  OSFM_REQUIRE(P->n_cameras > 0 && P->n_shots > 0 && P->n_points > 0 && P->n_obs > 0, OSFM_E_INVALID, "empty BA problem");
-  OSFM_REQUIRE(P->cam_params && P->cam_prior && P->cam_sigma && P->cam_fixed && P->shot_pose && P->shot_camera && P->points &&
-                   P->obs_shot && P->obs_point && P->obs_xy && P->obs_sigma,
-               OSFM_E_INVALID, "osfm_ba_solve: a required array is null");
+  const bool gen = G != nullptr;
+  if (gen) {
+    OSFM_REQUIRE(P->n_cameras > 0 && P->n_shots > 0 && P->n_points >= 0 && P->n_obs >= 0, OSFM_E_INVALID, "empty bundle problem");
+    OSFM_REQUIRE(P->shot_pose && (P->n_points == 0 || P->points) && (P->n_obs == 0 || (P->obs_shot && P->obs_point && P->obs_xy && P->obs_sigma && G->obs_view)),
+                 OSFM_E_INVALID, "osfm_bundle_solve: a required array is null");
+  } else {
+    OSFM_REQUIRE(P->n_cameras > 0 && P->n_shots > 0 && P->n_points > 0 && P->n_obs > 0, OSFM_E_INVALID, "empty BA problem");
+    OSFM_REQUIRE(P->cam_params && P->cam_prior && P->cam_sigma && P->cam_fixed && P->shot_pose && P->shot_camera && P->points &&
+                     P->obs_shot && P->obs_point && P->obs_xy && P->obs_sigma,
+                 OSFM_E_INVALID, "osfm_ba_solve: a required array is null");
+  }
   OSFM_REQUIRE(O->loss >= 0 && O->loss <= 3, OSFM_E_INVALID, "unknown loss %d (bundle_adjuster.cc:427 throws)", O->loss);
   const auto t_start = std::chrono::steady_clock::now();
   memset(Rp, 0, sizeof(*Rp));
@@ -3950,12 +4144,13 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
   OSFM_HIP(hipSetDevice(ctx->device));
   const int S = P->n_shots, NP = P->n_points, NC = P->n_cameras;
   const long M = P->n_obs;
+  const long G_rows0 = gen ? G->rows0 : M;
   for (long o = 0; o < M; o++) {
     OSFM_REQUIRE(P->obs_shot[o] >= 0 && P->obs_shot[o] < S && P->obs_point[o] >= 0 && P->obs_point[o] < NP, OSFM_E_INVALID,
                  "observation %ld references shot %d / point %d", o, P->obs_shot[o], P->obs_point[o]);
     OSFM_REQUIRE(P->obs_sigma[o] > 0, OSFM_E_INVALID, "observation %ld has std_deviation <= 0", o);
   }
-  if (P->cam_model)
+  if (P->cam_model && !gen)
     for (int c = 0; c < NC; c++)
     {
       OSFM_REQUIRE(P->cam_model[c] >= OSFM_CAMERA_PERSPECTIVE && P->cam_model[c] <= OSFM_CAMERA_SIMPLE_RADIAL, OSFM_E_UNSUPPORTED,
@@ -3964,7 +4159,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
                    "camera %d: projection type %d is supported as a CONSTANT camera only (cam_fixed = 1 and cam_ext given); its "
                    "intrinsics are not optimised on the GPU path", c, P->cam_model[c]);
     }
-  for (int s = 0; s < S; s++)
+  for (int s = 0; s < S && !gen; s++)
     OSFM_REQUIRE(P->shot_camera[s] >= 0 && P->shot_camera[s] < NC, OSFM_E_INVALID, "shot %d references camera %d", s, P->shot_camera[s]);
 
   OSFM_REQUIRE(M < (1L << 31), OSFM_E_UNSUPPORTED, "more than 2^31 observations");
@@ -4000,24 +4195,156 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
   memset(&d, 0, sizeof(d));
   d.S = S; d.P = NP; d.NC = NC; d.M = M;
   d.cam0 = 6 * S;
-  d.nred = 6 * S + 3 * NC;
-  d.cams = A.upload(P->cam_params, (size_t)3 * NC, e);
+  d.gen = gen ? 1 : 0;
+  GenDev &g = d.g;
+  std::vector<int> inst_view0;
+  if (gen) {  // border columns: free rig cameras, free cameras, free biases; per view the slots its rows touch
+    const int NV = G->NV, NRC = G->NRC;
+    g.NV = NV;
+    g.NRC = NRC;
+    std::vector<int> cam_col((size_t)NC, -1), rc_col((size_t)NRC, -1), bias_col((size_t)NC, -1);
+    std::vector<unsigned char> rc_useful((size_t)NRC, 1);
+    int nb = 0;
+    bool spherical = false;
+    for (int q = 0; q < NRC; q++) {
+      const bool fixed = G->rc_fixed[q] != 0;
+      bool zero = true;
+      for (int k = 0; k < 6; k++) zero = zero && G->rc_pose[6 * q + k] == 0.0;
+      rc_useful[(size_t)q] = !(fixed && zero);  // IsRigCameraUseful, bundle_adjuster.cc:17-20
+      if (!fixed) {
+        rc_col[(size_t)q] = nb;
+        nb += 6;
+      }
+    }
+    for (int c = 0; c < NC; c++) {
+      const int nk = model_num_params(G->cam_model[c]);
+      spherical = spherical || G->cam_model[c] == OSFM_CAMERA_SPHERICAL;
+      if (!G->cam_fixed[c] && nk > 0) {
+        cam_col[(size_t)c] = nb;
+        nb += nk;
+      }
+    }
+    for (int c = 0; c < NC; c++)
+      if (G->bias_fixed && !G->bias_fixed[c]) {
+        bias_col[(size_t)c] = nb;
+        nb += 7;
+      }
+    g.NB = nb;
+    g.NRr = spherical ? 3 : 2;
+    int KW = 0;
+    auto view_slots = [&](int v, int *cols) {  // returns the number of slots; cols[i] = border column of slot i
+      const int c = G->view_cam[v], q = G->view_rc[v];
+      int n = 0;
+      if (cam_col[(size_t)c] >= 0)
+        for (int k = 0; k < model_num_params(G->cam_model[c]); k++) cols[n++] = cam_col[(size_t)c] + k;
+      if (rc_col[(size_t)q] >= 0 && rc_useful[(size_t)q])
+        for (int k = 0; k < 6; k++) cols[n++] = rc_col[(size_t)q] + k;
+      return n;
+    };
+    int tmp[kGenMaxKW];
+    for (int v = 0; v < NV; v++) KW = std::max(KW, view_slots(v, tmp));
+    g.KW = KW;
+    g.oJp = g.NRr;
+    g.oJc = 4 * g.NRr;
+    g.oJb = 10 * g.NRr;
+    g.ncomp = g.NRr * (10 + KW);
+    std::vector<int> view_col((size_t)std::max(1, NV * KW), -1);
+    std::vector<unsigned char> col_slot((size_t)std::max(1, nb) * NV, 255);
+    for (int v = 0; v < NV; v++) {
+      const int n = view_slots(v, tmp);
+      for (int i = 0; i < n; i++) {
+        view_col[(size_t)v * KW + i] = tmp[i];
+        col_slot[(size_t)tmp[i] * NV + v] = (unsigned char)i;
+      }
+    }
+    inst_view0.assign((size_t)S + 1, 0);
+    for (int v = 0; v < NV; v++) {
+      OSFM_REQUIRE(G->view_inst[v] >= 0 && G->view_inst[v] < S && (v == 0 || G->view_inst[v] >= G->view_inst[v - 1]), OSFM_E_INVALID,
+                   "generic bundle: the views are not grouped by instance");
+      inst_view0[(size_t)G->view_inst[v] + 1]++;
+    }
+    for (int i = 0; i < S; i++) inst_view0[(size_t)i + 1] += inst_view0[(size_t)i];
+    g.view_inst = A.upload(G->view_inst, (size_t)NV, e);
+    g.view_rc = A.upload(G->view_rc, (size_t)NV, e);
+    g.view_cam = A.upload(G->view_cam, (size_t)NV, e);
+    g.view_col = A.upload(view_col.data(), view_col.size(), e);
+    g.col_slot = A.upload(col_slot.data(), col_slot.size(), e);
+    g.inst_view0 = A.upload(inst_view0.data(), inst_view0.size(), e);
+    g.cam_col = A.upload(cam_col.data(), (size_t)NC, e);
+    g.rc_col = A.upload(rc_col.data(), (size_t)NRC, e);
+    g.bias_col = A.upload(bias_col.data(), (size_t)NC, e);
+    g.rc_useful = A.upload(rc_useful.data(), (size_t)NRC, e);
+    g.cam = A.upload(G->cam, (size_t)16 * NC, e);
+    g.cam_n = A.alloc<double>((size_t)16 * NC, e);
+    g.cam_prior = A.upload(G->cam_prior, (size_t)16 * NC, e);
+    g.cam_sigma = A.upload(G->cam_sigma, (size_t)16 * NC, e);
+    g.bias = A.upload(G->bias, (size_t)7 * NC, e);
+    g.bias_n = A.alloc<double>((size_t)7 * NC, e);
+    g.rc = A.upload(G->rc_pose, (size_t)6 * NRC, e);
+    g.rc_n = A.alloc<double>((size_t)6 * NRC, e);
+    g.rcR = A.alloc<double>((size_t)36 * NRC, e);
+    if (G->rc_prior && G->rc_sigma) {
+      g.rc_prior = A.upload(G->rc_prior, (size_t)6 * NRC, e);
+      g.rc_sigma = A.upload(G->rc_sigma, (size_t)6 * NRC, e);
+    }
+    if (G->gps && G->gps_sigma && G->inst_bias_cam) {
+      g.gps = A.upload(G->gps, (size_t)3 * S, e);
+      g.gps_sigma = A.upload(G->gps_sigma, (size_t)3 * S, e);
+      g.inst_bias_cam = A.upload(G->inst_bias_cam, (size_t)S, e);
+      for (int i = 0; i < S; i++)
+        if (G->gps_sigma[3 * i] > 0 && bias_col[(size_t)G->inst_bias_cam[i]] >= 0) sv.have_bpri = true;
+    }
+    auto per_view = [&](const double *val, const double *sd, int width, const double *&dv, const double *&ds) {
+      if (!val || !sd) return;
+      dv = A.upload(val, (size_t)width * NV, e);
+      ds = A.upload(sd, (size_t)NV, e);
+      for (int v = 0; v < NV; v++)
+        if (sd[v] > 0 && rc_col[(size_t)G->view_rc[v]] >= 0) sv.have_bpri = true;
+    };
+    if (G->up && G->up_sigma)
+      for (int v = 0; v < NV; v++) {
+        const double *u = G->up + 3 * (size_t)v;
+        OSFM_REQUIRE(!(G->up_sigma[v] > 0) || std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]) >= 1e-10, OSFM_E_INVALID,
+                     "UpVectorError: acceleration vector has near-zero magnitude");
+      }
+    per_view(G->up, G->up_sigma, 3, g.up, g.up_sigma);
+    per_view(G->pan, G->pan_sigma, 1, g.pan, g.pan_sigma);
+    per_view(G->tilt, G->tilt_sigma, 1, g.tilt, g.tilt_sigma);
+    per_view(G->roll, G->roll_sigma, 1, g.roll, g.roll_sigma);
+    if (G->pt_prior && G->pt_prior_sigma && NP > 0) {
+      g.pt_prior = A.upload(G->pt_prior, (size_t)3 * NP, e);
+      g.pt_prior_sigma = A.upload(G->pt_prior_sigma, (size_t)3 * NP, e);
+      std::vector<unsigned char> alt((size_t)NP, 1);
+      if (G->pt_prior_alt) alt.assign(G->pt_prior_alt, G->pt_prior_alt + NP);
+      g.pt_prior_alt = A.upload(alt.data(), (size_t)NP, e);
+    }
+    g.PI = A.alloc<double>((size_t)36 * S, e);
+    g.Bpri = A.alloc<double>((size_t)std::max(1, nb) * 6 * S, e);
+    g.Cpri = A.alloc<double>((size_t)std::max(1, nb * nb), e);
+    g.gpri = A.alloc<double>((size_t)6 * S + nb, e);
+    g.bdot = A.alloc<double>((size_t)std::max(1, nb), e);
+    g.vpart = A.alloc<double>((size_t)std::max(1, NV * 2 * KW), e);
+    g.yv = A.alloc<double>((size_t)std::max(1, NV * KW), e);
+  }
+  const int nbord = gen ? g.NB : 3 * NC;  // border unknowns behind the 6 S of the band
+  d.nred = 6 * S + nbord;
+  d.cams = gen ? nullptr : A.upload(P->cam_params, (size_t)3 * NC, e);
   d.poses = A.upload(P->shot_pose, (size_t)6 * S, e);
   d.pts = A.upload(P->points, (size_t)3 * NP, e);
-  d.cams_n = A.alloc<double>((size_t)3 * NC, e);
+  d.cams_n = gen ? nullptr : A.alloc<double>((size_t)3 * NC, e);
   d.poses_n = A.alloc<double>((size_t)6 * S, e);
   d.pts_n = A.alloc<double>((size_t)3 * NP, e);
-  d.cam_prior = A.upload(P->cam_prior, (size_t)3 * NC, e);
-  d.cam_sigma = A.upload(P->cam_sigma, (size_t)3 * NC, e);
-  d.cam_fixed = A.upload(P->cam_fixed, (size_t)NC, e);
-  d.shot_camera = A.upload(P->shot_camera, (size_t)S, e);
-  d.cam_model = P->cam_model ? A.upload(P->cam_model, (size_t)NC, e) : nullptr;
-  d.cam_ext = P->cam_ext ? A.upload(P->cam_ext, (size_t)16 * NC, e) : nullptr;
+  d.cam_prior = gen ? nullptr : A.upload(P->cam_prior, (size_t)3 * NC, e);
+  d.cam_sigma = gen ? nullptr : A.upload(P->cam_sigma, (size_t)3 * NC, e);
+  d.cam_fixed = gen ? nullptr : A.upload(P->cam_fixed, (size_t)NC, e);
+  d.shot_camera = gen ? nullptr : A.upload(P->shot_camera, (size_t)S, e);
+  d.cam_model = gen ? A.upload(G->cam_model, (size_t)NC, e) : (P->cam_model ? A.upload(P->cam_model, (size_t)NC, e) : nullptr);
+  d.cam_ext = (!gen && P->cam_ext) ? A.upload(P->cam_ext, (size_t)16 * NC, e) : nullptr;
   d.shot_fixed = P->shot_fixed ? A.upload(P->shot_fixed, (size_t)S, e) : nullptr;
   d.point_fixed = P->point_fixed ? A.upload(P->point_fixed, (size_t)NP, e) : nullptr;
-  d.gps = (P->shot_gps && P->shot_gps_sigma) ? A.upload(P->shot_gps, (size_t)3 * S, e) : nullptr;
-  d.gps_sigma = (P->shot_gps && P->shot_gps_sigma) ? A.upload(P->shot_gps_sigma, (size_t)S, e) : nullptr;
-  if (P->shot_up && P->shot_up_sigma) {
+  d.gps = (!gen && P->shot_gps && P->shot_gps_sigma) ? A.upload(P->shot_gps, (size_t)3 * S, e) : nullptr;
+  d.gps_sigma = (!gen && P->shot_gps && P->shot_gps_sigma) ? A.upload(P->shot_gps_sigma, (size_t)S, e) : nullptr;
+  if (!gen && P->shot_up && P->shot_up_sigma) {
     std::vector<double> un((size_t)3 * S);
     for (int s = 0; s < S; s++) {
       const double *u = P->shot_up + 3 * (size_t)s;
@@ -4040,14 +4367,27 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
   int bw_true = 0;
   int track_repeats_shot = 0;
   int *bp_keys = nullptr, *bp_pts = nullptr;  // the points in the order of the first shot of their track (band_mfma_kernel)
-  {
+  if (M == 0) {  // (generic mode only) a problem of priors: empty segments everywhere
+    long *d_pt_off = A.alloc<long>((size_t)NP + 1, e), *d_shot_off = A.alloc<long>((size_t)S + 1, e), *d_view_off = A.alloc<long>((size_t)g.NV + 1, e);
+    OSFM_REQUIRE(e == hipSuccess, OSFM_E_NOMEM, "BA device allocation/upload failed: %s", hipGetErrorString(e));
+    OSFM_HIP(hipMemsetAsync(d_pt_off, 0, ((size_t)NP + 1) * sizeof(long), sv.st));
+    OSFM_HIP(hipMemsetAsync(d_shot_off, 0, ((size_t)S + 1) * sizeof(long), sv.st));
+    OSFM_HIP(hipMemsetAsync(d_view_off, 0, ((size_t)g.NV + 1) * sizeof(long), sv.st));
+    d.pt_off = d_pt_off;
+    d.shot_off = d_shot_off;
+    g.view_off = d_view_off;
+    d.o_shot = d.o_point = d.shot_obs = A.alloc<int>(1, e);
+    g.o_view = g.sm_view = d.o_shot;
+  } else {
     int *raw_shot = A.upload(P->obs_shot, (size_t)M, e), *raw_point = A.upload(P->obs_point, (size_t)M, e);
+    int *raw_view = gen ? A.upload(G->obs_view, (size_t)M, e) : nullptr, *o_view = gen ? A.alloc<int>((size_t)M, e) : nullptr;
+    long *d_view_off = gen ? A.alloc<long>((size_t)g.NV + 1, e) : nullptr;
     int *iota = A.alloc<int>((size_t)M, e), *o_point = A.alloc<int>((size_t)M, e), *o_shot = A.alloc<int>((size_t)M, e);
     int *sm_keys = A.alloc<int>((size_t)M, e), *shot_obs = A.alloc<int>((size_t)M, e);
     long *d_pt_off = A.alloc<long>((size_t)NP + 1, e), *d_shot_off = A.alloc<long>((size_t)S + 1, e);
     int *d_bw = A.alloc<int>(4, e);
     auto bits_for = [](long n) { unsigned b = 1; while (b < 32 && (1L << b) < n) b++; return b; };
-    const unsigned pbits = bits_for(NP), sbits = bits_for(S);
+    const unsigned pbits = bits_for(NP), sbits = bits_for(gen ? g.NV : S);  // (the shot-major order is keyed by VIEW in the generic mode)
     int *first_shot = A.alloc<int>((size_t)NP, e);
     bp_keys = A.alloc<int>((size_t)NP, e);
     bp_pts = A.alloc<int>((size_t)NP, e);
@@ -4064,8 +4404,18 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     OSFM_HIP(rocprim::radix_sort_pairs(tmp, tb1, raw_point, o_point, iota, d_perm, (size_t)M, 0u, pbits, sv.st));
     hipLaunchKernelGGL(gather_int_kernel, dim3(nblk(M)), dim3(TPB), 0, sv.st, d_perm, raw_shot, M, o_shot);
     hipLaunchKernelGGL(lower_bound_kernel, dim3(nblk(NP + 1L)), dim3(TPB), 0, sv.st, o_point, M, NP, d_pt_off);
-    OSFM_HIP(rocprim::radix_sort_pairs(tmp, tb2, o_shot, sm_keys, iota, shot_obs, (size_t)M, 0u, sbits, sv.st));
-    hipLaunchKernelGGL(lower_bound_kernel, dim3(nblk(S + 1L)), dim3(TPB), 0, sv.st, sm_keys, M, S, d_shot_off);
+    if (gen) {  // views of an instance are consecutive: sorted by view is sorted by instance, and an instance's segment is its views'
+      hipLaunchKernelGGL(gather_int_kernel, dim3(nblk(M)), dim3(TPB), 0, sv.st, d_perm, raw_view, M, o_view);
+      OSFM_HIP(rocprim::radix_sort_pairs(tmp, tb2, o_view, sm_keys, iota, shot_obs, (size_t)M, 0u, sbits, sv.st));
+      hipLaunchKernelGGL(lower_bound_kernel, dim3(nblk(g.NV + 1L)), dim3(TPB), 0, sv.st, sm_keys, M, g.NV, d_view_off);
+      hipLaunchKernelGGL(gen_shot_off_kernel, dim3(nblk(S + 1L)), dim3(TPB), 0, sv.st, (const long *)d_view_off, g.inst_view0, S, d_shot_off);
+      g.o_view = o_view;
+      g.sm_view = sm_keys;
+      g.view_off = d_view_off;
+    } else {
+      OSFM_HIP(rocprim::radix_sort_pairs(tmp, tb2, o_shot, sm_keys, iota, shot_obs, (size_t)M, 0u, sbits, sv.st));
+      hipLaunchKernelGGL(lower_bound_kernel, dim3(nblk(S + 1L)), dim3(TPB), 0, sv.st, sm_keys, M, S, d_shot_off);
+    }
     OSFM_HIP(hipMemsetAsync(d_bw, 0, 2 * sizeof(int), sv.st));
     hipLaunchKernelGGL(track_width_kernel, dim3(nblk(NP)), dim3(TPB), 0, sv.st, d_pt_off, o_shot, NP, d_bw);
     hipLaunchKernelGGL(track_first_kernel, dim3(nblk(NP)), dim3(TPB), 0, sv.st, d_pt_off, o_shot, NP, S, first_shot, d_bw + 1);
@@ -4088,10 +4438,19 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
   {
     double *raw_xy = A.upload(P->obs_xy, (size_t)2 * M, e), *raw_sg = A.upload(P->obs_sigma, (size_t)M, e);
     double *ox = A.alloc<double>((size_t)M, e), *oy = A.alloc<double>((size_t)M, e), *osg = A.alloc<double>((size_t)M, e);
-    if (e == hipSuccess) hipLaunchKernelGGL(gather_pm_kernel, dim3(nblk(M)), dim3(TPB), 0, sv.st, d_perm, raw_xy, raw_sg, M, ox, oy, osg);
+    if (e == hipSuccess && M > 0) hipLaunchKernelGGL(gather_pm_kernel, dim3(nblk(M)), dim3(TPB), 0, sv.st, d_perm, raw_xy, raw_sg, M, ox, oy, osg);
     d.o_x = ox;
     d.o_y = oy;
     d.o_sigma = osg;
+    if (gen && G->obs_kind && M > 0) {
+      unsigned char *raw_kind = A.upload(G->obs_kind, (size_t)M, e), *ok = A.alloc<unsigned char>((size_t)M, e), *sk = A.alloc<unsigned char>((size_t)M, e);
+      if (e == hipSuccess) {
+        hipLaunchKernelGGL(gather_byte_kernel, dim3(nblk(M)), dim3(TPB), 0, sv.st, (const int *)d_perm, (const unsigned char *)raw_kind, M, ok);
+        hipLaunchKernelGGL(gather_byte_kernel, dim3(nblk(M)), dim3(TPB), 0, sv.st, d.shot_obs, (const unsigned char *)ok, M, sk);
+      }
+      g.o_kind = ok;
+      g.sm_kind = sk;
+    }
   }
   {
     std::vector<int> wg_pt;
@@ -4103,16 +4462,17 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       wg_pt.push_back(pe);
       pcur = pe;
     }
+    if (wg_pt.size() < 2) wg_pt.push_back(0);  // (no points: one empty workgroup)
     d.nwg = (int)wg_pt.size() - 1;
     d.wg_pt = A.upload(wg_pt.data(), wg_pt.size(), e);
   }
   d.shotR = A.alloc<double>((size_t)36 * S, e);
-  d.Jpm = A.alloc<double>((size_t)26 * M, e);
-  d.Jsm = A.alloc<double>((size_t)26 * M, e);
+  d.Jpm = A.alloc<double>((size_t)(gen ? g.ncomp : 26) * M, e);
+  d.Jsm = A.alloc<double>((size_t)(gen ? g.ncomp : 26) * M, e);
   {
     int *ss = A.alloc<int>((size_t)M, e), *sp = A.alloc<int>((size_t)M, e);
     double *sx = A.alloc<double>((size_t)M, e), *sy = A.alloc<double>((size_t)M, e), *ssg = A.alloc<double>((size_t)M, e);
-    if (e == hipSuccess)
+    if (e == hipSuccess && M > 0)
       hipLaunchKernelGGL(gather_sm_kernel, dim3(nblk(M)), dim3(TPB), 0, sv.st, d.shot_obs, d.o_shot, d.o_point, d.o_x, d.o_y, d.o_sigma, M, ss,
                          sp, sx, sy, ssg);
     d.sm_shot = ss;
@@ -4121,7 +4481,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     d.sm_y = sy;
     d.sm_sigma = ssg;
   }
-  d.w = A.alloc<double>((size_t)2 * M, e);
+  d.w = A.alloc<double>((size_t)(gen ? g.NRr : 2) * M, e);
   d.g_pt = A.alloc<double>((size_t)3 * NP, e);
   d.Hpp = A.alloc<double>((size_t)6 * NP, e);
   d.Hhat = A.alloc<double>((size_t)6 * NP, e);
@@ -4135,7 +4495,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
   d.sc_red = A.alloc<double>(nr, e);
   d.D_red = A.alloc<double>(nr, e);
   d.Hcc = A.alloc<double>((size_t)21 * S + 6 * NC, e);
-  d.Binv = A.alloc<double>((size_t)36 * S + 9 * NC, e);
+  d.Binv = A.alloc<double>((size_t)36 * S + 9 * NC + nbord, e);
   d.part = A.alloc<double>((size_t)9 * S, e);
   d.camred = A.alloc<double>((size_t)9 * NC, e);
   d.zc = A.alloc<double>(nr, e);
@@ -4160,7 +4520,8 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
   while (band_copies > 1 && (size_t)band_slice * 36 * band_copies * sizeof(double) > 150 * 1024) band_copies /= 2;
   d.band = A.alloc<double>((size_t)S * (d.bw + 1) * 36, e);
   // exact narrow band, one observation per (track, shot): assembled on the matrix cores (band_mfma_kernel), else per shot with LDS atomics
-  const bool win_band = d.bw >= 1 && d.bw <= kMaxBw && d.bw == bw_true && !track_repeats_shot && bp_pts != nullptr && getenv("OSFM_BA_BAND_PER_SHOT") == nullptr;
+  const bool win_band = d.bw >= 1 && d.bw <= kMaxBw && d.bw == bw_true && !track_repeats_shot && bp_pts != nullptr && getenv("OSFM_BA_BAND_PER_SHOT") == nullptr &&
+                        !(gen && g.NRr == 3);  // (it forms E from the two-row layout of the Jacobian copy)
   size_t win_lds = 0;
   int win_grid = 0;
   // the E blocks as an array: the per-shot assembly's operand only (the matrix-core assembly forms them from the Jacobian copy it reads)
@@ -4280,20 +4641,22 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     d.wDinv = A.alloc<double>((size_t)d.wNB * kWB * kWB, e);
     d.wx = A.alloc<double>((size_t)d.wNB * kWB * 4, e);  // up to 4 right-hand sides side by side
   }
-  if ((d.ncl > 0 || wide) && 3 * NC <= 6) {  // exact camera border: see border_rhs_kernel
-    sv.Bc = A.alloc<double>((size_t)3 * NC * 6 * S, e);
-    sv.Wb = A.alloc<double>((size_t)3 * NC * 6 * S, e);
-    sv.SigInv = A.alloc<double>(36, e);
-    sv.dots = A.alloc<double>(36, e);
-    sv.dCm = A.alloc<double>(36, e);
-    sv.wB = A.alloc<double>((size_t)2 * 3 * NC * M, e);
-    sv.partB = A.alloc<double>((size_t)S * 9 * NC, e);
+  if ((d.ncl > 0 || wide) && nbord >= 1 && nbord <= (gen ? kGenMaxNB : 6)) {  // exact camera border: see border_rhs_kernel
+    sv.Bc = A.alloc<double>((size_t)nbord * 6 * S, e);
+    sv.Wb = A.alloc<double>((size_t)nbord * 6 * S, e);
+    sv.SigInv = A.alloc<double>((size_t)nbord * nbord, e);
+    sv.dots = A.alloc<double>((size_t)nbord * nbord, e);
+    sv.dCm = A.alloc<double>((size_t)nbord * nbord, e);
+    if (!gen) {
+      sv.wB = A.alloc<double>((size_t)2 * 3 * NC * M, e);
+      sv.partB = A.alloc<double>((size_t)S * 9 * NC, e);
+    }
   }
-  bool border_ok = getenv("OSFM_BA_NO_BORDER") == nullptr;  // exact camera border: every camera free
-  for (int c = 0; c < NC; c++)
+  bool border_ok = getenv("OSFM_BA_NO_BORDER") == nullptr;  // exact camera border: every camera free (generic mode: the border holds free blocks only)
+  for (int c = 0; c < NC && !gen; c++)
     if (P->cam_fixed[c]) border_ok = false;
   int *d_status = A.alloc<int>(4, e);
-  double *d_reproj = P->reproj_err ? A.alloc<double>((size_t)2 * M, e) : nullptr;
+  double *d_reproj = (gen ? G->reproj3 != nullptr : P->reproj_err != nullptr) ? A.alloc<double>((size_t)(gen ? 3 : 2) * M, e) : nullptr;
   OSFM_REQUIRE(e == hipSuccess, OSFM_E_NOMEM, "BA device allocation/upload failed: %s", hipGetErrorString(e));
   OSFM_HIP(hipMemsetAsync(d.scal, 0, 32 * sizeof(double), sv.st));
 
@@ -4306,9 +4669,25 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
   double cost = 0, sumsq = 0;
   int rc = sv.eval(d.cams, d.poses, d.pts, true, &cost, &sumsq);
   if (rc != OSFM_OK) return rc;
+  if (getenv("OSFM_BA_DEBUG_NAN") != nullptr) {  // debugging aid: which of the first evaluation's arrays hold a NaN
+    OSFM_HIP(hipStreamSynchronize(st));
+    auto scan = [&](const char *name, const double *p, size_t n) {
+      std::vector<double> h(n);
+      (void)hipMemcpy(h.data(), p, n * sizeof(double), hipMemcpyDeviceToHost);
+      size_t bad = 0;
+      for (double x : h) bad += !(x == x);
+      if (bad) fprintf(stderr, "[osfm_ba] %s: %zu of %zu not finite\n", name, bad, n);
+    };
+    scan("Jpm", d.Jpm, (size_t)(gen ? g.ncomp : 26) * M);
+    scan("Jsm", d.Jsm, (size_t)(gen ? g.ncomp : 26) * M);
+    if (gen) {
+      scan("PI", g.PI, (size_t)36 * S);
+      scan("gpri", g.gpri, (size_t)nred);
+    }
+  }
   Rp->initial_cost = cost;
   Rp->seconds_setup = std::chrono::duration<double>(t_run - t_start).count();
-  Rp->rmse_normalized_initial = std::sqrt(sumsq / (double)M);
+  Rp->rmse_normalized_initial = std::sqrt(sumsq / (double)std::max<long>(1, gen ? G_rows0 : M));
   Rp->cost_history[0] = cost;
   double radius = O->initial_radius > 0 ? O->initial_radius : 1e4;
   double decrease_factor = 2.0;
@@ -4348,6 +4727,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     // ---- linear solve: PCG on the implicit Schur complement ----
     hipLaunchKernelGGL(point_hhat_kernel, dim3(nblk(NP)), dim3(TPB), 0, st, d, radius);
     sv.use_band = false;
+    sv.cur_radius = radius;
     // ---- fork: camera-border columns (if this problem uses them) and the right-hand side only need the Jacobian and Hhat: they run on
     //      the side stream next to the band assembly (a gather that leaves HBM bandwidth unused), so that the cyclic-reduction levels
     //      -- workgroups that need a whole CU's LDS -- find the CUs free afterwards ----
@@ -4434,7 +4814,13 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
         OSFM_HIP(hipEventRecord(sv.ev_fork, st));
         OSFM_HIP(hipStreamWaitEvent(sv.st2, sv.ev_fork, 0));
       }
-      if (want_border) {  // all nb columns of B (and of the camera block C) in one pass over the observations
+      if (want_border && gen) {  // column j of the reduced matrix = the mat-vec of the unit vector e_(cam0 + j): its instance rows are B's, its border rows C's
+        for (int j = 0; j < nbord; j++) {
+          hipLaunchKernelGGL(unit_vec_kernel, dim3(nbr), dim3(TPB), 0, sx, d.p, nred, d.cam0 + j);
+          sv.gen_matvec(d.p, d.Ap, radius, sx);
+          hipLaunchKernelGGL(gen_border_store_kernel, dim3(nbr), dim3(TPB), 0, sx, (const double *)d.Ap, sv.Bc, sv.dCm, j, nbord, 6 * S);
+        }
+      } else if (want_border) {  // all nb columns of B (and of the camera block C) in one pass over the observations
         if (3 * NC == 3) {
           hipLaunchKernelGGL(border_point_kernel<3>, dim3(d.nwg), dim3(kCoopObs), 0, sx, d, sv.wB);
           hipLaunchKernelGGL(border_shot_kernel<3>, dim3(S), dim3(64), 0, sx, d, sv.wB, sv.Bc, sv.partB);
@@ -4446,10 +4832,15 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
         }
       }
       // rhs
-      hipLaunchKernelGGL(schur_point_coop_kernel<1>, dim3(d.nwg), dim3(kCoopObs), 0, sx, d, d.y);
-      hipLaunchKernelGGL(schur_shot_kernel, dim3(S), dim3(64), 0, sx, d);
-      hipLaunchKernelGGL(cam_reduce_kernel, dim3(NC), dim3(kCamRedT), 0, sx, d, 3);
-      hipLaunchKernelGGL(schur_finish_kernel, dim3(nbr), dim3(TPB), 0, sx, d, d.x, d.y, d.b, radius, 1);
+      if (gen) {
+        sv.gen_rows_apply(1, sx);
+        hipLaunchKernelGGL(gen_schur_finish_kernel, dim3(nbr), dim3(TPB), 0, sx, d, (const double *)d.x, (const double *)d.y, d.b, radius, 1, M > 0 ? 1 : 0, 0);
+      } else {
+        hipLaunchKernelGGL(schur_point_coop_kernel<1>, dim3(d.nwg), dim3(kCoopObs), 0, sx, d, d.y);
+        hipLaunchKernelGGL(schur_shot_kernel, dim3(S), dim3(64), 0, sx, d);
+        hipLaunchKernelGGL(cam_reduce_kernel, dim3(NC), dim3(kCamRedT), 0, sx, d, 3);
+        hipLaunchKernelGGL(schur_finish_kernel, dim3(nbr), dim3(TPB), 0, sx, d, d.x, d.y, d.b, radius, 1);
+      }
       if (sv.st2) OSFM_HIP(hipEventRecord(sv.ev_join, sv.st2));
       return OSFM_OK;
     };
@@ -4472,6 +4863,22 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     sv.use_wide = false;
     sv.use_border = false;
     bool z_solved = false;  // M^-1 b went through the border's walk
+    auto border_sigma = [&](int nb, int n6) -> int {  // Sigma^-1 = (C - B^T W)^-1 on the device; its status joins the factorisation's
+      hipLaunchKernelGGL(border_dots_kernel, dim3(nb * nb), dim3(TPB), 0, st, sv.Bc, sv.Wb, nb, n6, sv.dots);
+      if (nb <= 6) {
+        hipLaunchKernelGGL(border_sigma_kernel, dim3(1), dim3(64), 0, st, sv.dCm, sv.dots, sv.SigInv, nb, d_status + 1);
+      } else {
+        static OsfmPerDeviceOnce once_s;
+        const int rcs = once_s.run(ctx->device, []() -> int {
+          OSFM_HIP(hipFuncSetAttribute((const void *)gen_border_sigma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+          return OSFM_OK;
+        });
+        if (rcs != OSFM_OK) return rcs;
+        hipLaunchKernelGGL(gen_border_sigma_kernel, dim3(1), dim3(256), (size_t)nb * 2 * nb * sizeof(double), st, (const double *)sv.dCm, (const double *)sv.dots,
+                           sv.SigInv, nb, d_status + 1);
+      }
+      return OSFM_OK;
+    };
     if (wide) {
       if (dense_cr) {  // cyclic reduction over dense clusters: log2(S / bw) levels of batched dense operations
         const int rcq = sv.dbcr_factor(d_status);
@@ -4486,13 +4893,13 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       }
       sv.use_wide = true;
       if (try_border) {
-        const int nb = 3 * NC, n6 = 6 * S;
+        const int nb = nbord, n6 = 6 * S;
         const int rcj = join();
         if (rcj != OSFM_OK) return rcj;
-        sv.wide_solve_set(RhsSet{sv.Bc, n6, sv.Wb, n6, nb + 1, d.b, d.z, nb, nb});  // the border's columns and the solve's own right-hand side
+        sv.wide_solve_set(RhsSet{sv.Bc, n6, sv.Wb, n6, nb + 1, d.b, d.z, nb, gen ? -1 : nb});  // the border's columns and the solve's own right-hand side
         z_solved = true;
-        hipLaunchKernelGGL(border_dots_kernel, dim3(nb * nb), dim3(TPB), 0, st, sv.Bc, sv.Wb, nb, n6, sv.dots);
-        hipLaunchKernelGGL(border_sigma_kernel, dim3(1), dim3(64), 0, st, sv.dCm, sv.dots, sv.SigInv, nb, d_status + 1);
+        const int rcg = border_sigma(nb, n6);
+        if (rcg != OSFM_OK) return rcg;
         sv.use_border = true;
       }
     }
@@ -4519,14 +4926,17 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       hipLaunchKernelGGL(lv.fn, dim3(1), dim3(lv.threads), lv.lds_bytes, st, d, 1, 1, d_status);
       sv.use_bcr = true;
       if (try_border) {  // exact camera border (few cameras, all free): B = S e_j restricted to the shot rows, W = A^-1 B
-        const int nb = 3 * NC, n6 = 6 * S;
+        const int nb = nbord, n6 = 6 * S;
         // the columns of B and C were formed on the side stream; W = A^-1 B for all of them in one walk of the levels
         const int rcj = join();
         if (rcj != OSFM_OK) return rcj;
-        sv.bcr_solve_set(RhsSet{sv.Bc, n6, sv.Wb, n6, nb + 1, d.b, d.z, nb, nb});  // the border's columns and the solve's own right-hand side
+        for (int q0 = 0; q0 < nb + 1; q0 += 7) {  // (the work vectors of a walk hold seven right-hand sides)
+          const int cnt = std::min(7, nb + 1 - q0), qx = (nb >= q0 && nb < q0 + cnt) ? nb - q0 : -1;
+          sv.bcr_solve_set(RhsSet{sv.Bc + (long)q0 * n6, n6, sv.Wb + (long)q0 * n6, n6, cnt, d.b, d.z, qx, gen ? -1 : qx});  // the border's columns and the solve's own right-hand side
+        }
         z_solved = true;
-        hipLaunchKernelGGL(border_dots_kernel, dim3(nb * nb), dim3(TPB), 0, st, sv.Bc, sv.Wb, nb, n6, sv.dots);
-        hipLaunchKernelGGL(border_sigma_kernel, dim3(1), dim3(64), 0, st, sv.dCm, sv.dots, sv.SigInv, nb, d_status + 1);
+        const int rcg = border_sigma(nb, n6);
+        if (rcg != OSFM_OK) return rcg;
         sv.use_border = true;
       }
     }
@@ -4577,7 +4987,12 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     auto start_pcg = [&]() -> int {
       // block-Jacobi blocks (6x6 per shot, 3x3 per camera): the fallback preconditioner, and the camera rows of the band
       // preconditioners -- not needed when the cyclic reduction came out with the exact camera border
-      if (!((sv.use_bcr || sv.use_wide) && sv.use_border)) {
+      if (gen) {
+        if (!(sv.use_bcr || sv.use_wide || sv.use_ctri || sv.use_band)) {
+          if (g.NRr == 3) hipLaunchKernelGGL(gen_precond_shot_kernel<3>, dim3(S), dim3(64), 0, st, d, radius);
+          else hipLaunchKernelGGL(gen_precond_shot_kernel<2>, dim3(S), dim3(64), 0, st, d, radius);
+        }
+      } else if (!((sv.use_bcr || sv.use_wide) && sv.use_border)) {
         hipLaunchKernelGGL(precond_shot_kernel, dim3(S), dim3(64), 0, st, d, radius);
         hipLaunchKernelGGL(cam_reduce_kernel, dim3(NC), dim3(kCamRedT), 0, st, d, 6);
         hipLaunchKernelGGL(precond_cam_kernel, dim3(nblk(NC, 64)), dim3(64), 0, st, d, radius);
@@ -4643,9 +5058,20 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     }
     // back-substitution, model change, candidate
     hipLaunchKernelGGL(scale_vec_kernel, dim3(nbr), dim3(TPB), 0, st, d.sc_red, d.x, d.y, nred);
-    hipLaunchKernelGGL(schur_point_coop_kernel<2>, dim3(d.nwg), dim3(kCoopObs), 0, st, d, d.y);
+    if (gen) {
+      if (M > 0 && g.KW > 0) hipLaunchKernelGGL(gen_view_gather_kernel, dim3(nblk((long)g.NV * g.KW)), dim3(TPB), 0, st, d, (const double *)d.y);
+      if (g.NRr == 3) hipLaunchKernelGGL((gen_schur_point_kernel<3, 2>), dim3(d.nwg), dim3(kCoopObs), 0, st, d, (const double *)d.y);
+      else hipLaunchKernelGGL((gen_schur_point_kernel<2, 2>), dim3(d.nwg), dim3(kCoopObs), 0, st, d, (const double *)d.y);
+    } else
+      hipLaunchKernelGGL(schur_point_coop_kernel<2>, dim3(d.nwg), dim3(kCoopObs), 0, st, d, d.y);
     hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(1024), 0, st, d.partial, (long)d.nwg, 1, d.scal + 16);  // the model change's observation part
-    hipLaunchKernelGGL(candidate_kernel, dim3(1), dim3(1024), 0, st, d, d.y, d.scal + 16);
+    if (gen) {
+      hipLaunchKernelGGL(gen_candidate_kernel, dim3(1), dim3(1024), 0, st, d, (const double *)d.y, d.scal + 16);
+      hipLaunchKernelGGL(gen_prior_kernel, dim3(nblk(sv.gen_nprior(), 64)), dim3(64), 0, st, d, (const double *)g.cam, (const double *)g.bias, (const double *)g.rc,
+                         (const double *)d.poses, 2, (const double *)d.y, d.scal + 16);
+      if (g.pt_prior_sigma && NP > 0) hipLaunchKernelGGL(gen_point_prior_kernel, dim3(nblk(NP)), dim3(TPB), 0, st, d, (const double *)d.pts, 2, d.scal + 16);
+    } else
+      hipLaunchKernelGGL(candidate_kernel, dim3(1), dim3(1024), 0, st, d, d.y, d.scal + 16);
     hipLaunchKernelGGL(candidate_points_kernel, dim3(nblk(3L * NP)), dim3(TPB), 0, st, d);
     hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(1024), 0, st, d.partial, (long)nblk(3L * NP), 2, d.scal + 20);
     // the candidate's cost is evaluated before the host has seen the model change: one round trip for both (an invalid step -- rare --
@@ -4674,6 +5100,11 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       std::swap(d.cams, d.cams_n);
       std::swap(d.poses, d.poses_n);
       std::swap(d.pts, d.pts_n);
+      if (gen) {
+        std::swap(g.cam, g.cam_n);
+        std::swap(g.bias, g.bias_n);
+        std::swap(g.rc, g.rc_n);
+      }
       const double t = 2.0 * rho - 1.0;
       radius = radius / std::fmax(1.0 / 3.0, 1.0 - t * t * t);
       radius = std::fmin(1e16, radius);
@@ -4716,22 +5147,38 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
   }
   // outputs: parameters, reprojection errors (sigma = 1), NaN/Inf check (ba_helpers.cc:780-814)
   sv.rot(d.poses);
-  if (d_reproj) hipLaunchKernelGGL(reproj_kernel, dim3(nblk(M)), dim3(TPB), 0, st, d, d_reproj);
-  OSFM_HIP(hipMemcpyAsync(P->cam_params, d.cams, (size_t)3 * NC * sizeof(double), hipMemcpyDeviceToHost, st));
+  if (gen) {
+    hipLaunchKernelGGL(gen_rc_rot_kernel, dim3(nblk(g.NRC, 64)), dim3(64), 0, st, d, (const double *)g.rc);
+    if (d_reproj && M > 0) hipLaunchKernelGGL(gen_reproj_kernel, dim3(nblk(M)), dim3(TPB), 0, st, d, d_reproj);
+    OSFM_HIP(hipMemcpyAsync(G->cam, g.cam, (size_t)16 * NC * sizeof(double), hipMemcpyDeviceToHost, st));
+    OSFM_HIP(hipMemcpyAsync(G->bias, g.bias, (size_t)7 * NC * sizeof(double), hipMemcpyDeviceToHost, st));
+    OSFM_HIP(hipMemcpyAsync(G->rc_pose, g.rc, (size_t)6 * g.NRC * sizeof(double), hipMemcpyDeviceToHost, st));
+  } else {
+    if (d_reproj) hipLaunchKernelGGL(reproj_kernel, dim3(nblk(M)), dim3(TPB), 0, st, d, d_reproj);
+    OSFM_HIP(hipMemcpyAsync(P->cam_params, d.cams, (size_t)3 * NC * sizeof(double), hipMemcpyDeviceToHost, st));
+  }
   OSFM_HIP(hipMemcpyAsync(P->shot_pose, d.poses, (size_t)6 * S * sizeof(double), hipMemcpyDeviceToHost, st));
-  OSFM_HIP(hipMemcpyAsync(P->points, d.pts, (size_t)3 * NP * sizeof(double), hipMemcpyDeviceToHost, st));
-  if (d_reproj) {  // back to the caller's observation order on the device, one contiguous copy
+  if (NP > 0) OSFM_HIP(hipMemcpyAsync(P->points, d.pts, (size_t)3 * NP * sizeof(double), hipMemcpyDeviceToHost, st));
+  if (d_reproj && gen && M > 0) {
+    double *d_out = A.alloc<double>((size_t)3 * M, e);
+    OSFM_REQUIRE(e == hipSuccess, OSFM_E_NOMEM, "BA device allocation failed: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(unpermute3_kernel, dim3(nblk(M)), dim3(TPB), 0, st, d_perm, d_reproj, M, d_out);
+    OSFM_HIP(hipMemcpyAsync(G->reproj3, d_out, (size_t)3 * M * sizeof(double), hipMemcpyDeviceToHost, st));
+  } else if (d_reproj && !gen) {  // back to the caller's observation order on the device, one contiguous copy
     double *d_out = A.alloc<double>((size_t)2 * M, e);
     OSFM_REQUIRE(e == hipSuccess, OSFM_E_NOMEM, "BA device allocation failed: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(unpermute2_kernel, dim3(nblk(M)), dim3(TPB), 0, st, d_perm, d_reproj, M, d_out);
     OSFM_HIP(hipMemcpyAsync(P->reproj_err, d_out, (size_t)2 * M * sizeof(double), hipMemcpyDeviceToHost, st));
   }
   OSFM_HIP(hipStreamSynchronize(st));
-  Rp->rmse_normalized_final = std::sqrt(sumsq / (double)M);
+  Rp->rmse_normalized_final = std::sqrt(sumsq / (double)std::max<long>(1, gen ? G_rows0 : M));
   Rp->seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
   Rp->seconds_teardown = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_tear).count();
-  for (int i = 0; i < 3 * NC; i++) OSFM_REQUIRE(std::isfinite(P->cam_params[i]), OSFM_E_NUMERIC, "camera has either NaN or INF values");
+  for (int i = 0; i < (gen ? 16 : 3) * NC; i++)
+    OSFM_REQUIRE(std::isfinite(gen ? G->cam[i] : P->cam_params[i]), OSFM_E_NUMERIC, "camera has either NaN or INF values");
   for (long i = 0; i < 6L * S; i++) OSFM_REQUIRE(std::isfinite(P->shot_pose[i]), OSFM_E_NUMERIC, "shot pose has either NaN or INF values");
   for (long i = 0; i < 3L * NP; i++) OSFM_REQUIRE(std::isfinite(P->points[i]), OSFM_E_NUMERIC, "point has either NaN or INF values");
   return OSFM_OK;
 }
+
+#include "ba_generic_host.inc"

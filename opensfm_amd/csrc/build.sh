@@ -4,12 +4,12 @@
 set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-SRCS="api.hip match.hip ransac.hip ba.hip ba_general.hip tracks.hip relpose.hip calib.hip guided.hip words.hip hahog.hip"
+SRCS="api.hip match.hip ransac.hip ba.hip tracks.hip relpose.hip calib.hip guided.hip words.hip hahog.hip"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function $EXTRA_HIPCC_FLAGS"
 mkdir -p build
 echo "$FLAGS" > build/.flags.new
 if ! cmp -s build/.flags.new build/.flags; then rm -f build/*.o; mv build/.flags.new build/.flags; fi
-newest_header=$(ls -t *.h ../../include/*.h | head -1)
+newest_header=$(ls -t *.h *.inc ../../include/*.h | head -1)
 pids=()
 for s in $SRCS; do
   o=build/${s%.hip}.o
@@ -23,5 +23,5 @@ for p in "${pids[@]}"; do wait "$p" || rc=1; done
 [ $rc -eq 0 ] || { echo "build failed"; exit 1; }
 OBJS=""
 for s in $SRCS; do OBJS="$OBJS build/${s%.hip}.o"; done
-$HIPCC --offload-arch=gfx950 -fPIC -shared $OBJS -o libosfm_mi355.so -L/opt/rocm/lib -lrocsolver -lrocblas -Wl,-rpath,/opt/rocm/lib
+$HIPCC --offload-arch=gfx950 -fPIC -shared $OBJS -o libosfm_mi355.so -L/opt/rocm/lib -lrocblas -Wl,-rpath,/opt/rocm/lib
 echo "built $(pwd)/libosfm_mi355.so"

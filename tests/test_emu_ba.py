@@ -28,3 +28,52 @@ def test_streaming_solver_narrow_band_matches_oracle(oracle_lib):
     assert g["preconditioner_bandwidth"] == g["shot_bandwidth"] and g["shot_bandwidth"] >= 2
     assert np.allclose(g["cost_history"], o["cost_history"], rtol=1e-10)
     assert abs(_rmse_px(g["reproj_err"]) - _rmse_px(o["reproj_err"])) < 1e-4
+
+
+def _compare_general(oracle_lib, pr, iters=5, rtol=1e-9):
+    from opensfm_amd import bundle
+
+    with emulated():
+        g = bundle.bundle_general_arrays(pr, {"bundle_max_iterations": iters}, **NO_TOL)
+    o = oracle_lib.bundle_general(pr, max_iterations=iters, **NO_TOL)
+    assert g["iterations"] == o["iterations"] == iters
+    assert np.allclose(g["cost_history"], o["cost_history"], rtol=rtol), (g["cost_history"], o["cost_history"])
+    assert abs(_rmse_px(g["reproj_err"]) - _rmse_px(o["reproj_err"])) < 1e-4
+    for k in ("cam_params", "rig_camera_pose", "rig_instance_pose", "points"):
+        assert np.allclose(g[k], o[k], atol=1e-8), k
+    if "bias" in o:
+        assert np.allclose(g["bias"], o["bias"], atol=1e-8)
+    return g, o
+
+
+@pytest.mark.parametrize("model", ["brown", "fisheye_opencv", "spherical"])
+def test_generic_streaming_solver_camera_families(oracle_lib, model):
+    """osfm_bundle_solve = the streaming solver in its generic mode (ba_generic.inc): free native intrinsics in the border (9 columns for
+    Brown), the 3-row bearing residual of a spherical camera"""
+    pr = synthetic.make_bundle_scene(models=(model,), n_instances=8, n_points=100, rig=False, gps=False, n_gcp=0, up_vectors=False, seed=7)
+    g, _ = _compare_general(oracle_lib, pr)
+    if model != "spherical":
+        assert np.abs(g["cam_params"][0, :8] - pr["cam_params"][0, :8]).max() > 0
+
+
+def test_generic_streaming_solver_rig_bias_control_points_up_vectors(oracle_lib):
+    """everything BAHelpers::Bundle wires at once: two camera models on a two-camera rig with a free rig camera, position priors through
+    free biases, control points with and without altitude, up vectors -- border of 6 + 3 + 9 + 14 unknowns, two views per instance"""
+    pr = synthetic.make_bundle_scene(models=("perspective", "brown"), n_instances=8, n_points=90, seed=5)
+    g, _ = _compare_general(oracle_lib, pr, iters=4)
+    assert np.abs(g["rig_camera_pose"][1] - pr["rig_camera_pose"][1]).max() > 0 and np.abs(g["bias"] - pr["bias"]).max() > 0
+
+
+def test_generic_mode_equals_the_specialised_kernels(oracle_lib):
+    """on the domain both cover ([k1 k2 focal] perspective cameras, identity rig) the generic rows and the specialised ones walk the same
+    trajectory"""
+    import test_oracle_bundle_general as og
+
+    from opensfm_amd import bundle
+
+    pr = synthetic.make_ba_scene(16, 200, 5, seed=12)
+    with emulated():
+        a = bundle.bundle_arrays(pr, {"bundle_max_iterations": 4}, **NO_TOL)
+        b = bundle.bundle_general_arrays(og._as_general(pr), {"bundle_max_iterations": 4}, **NO_TOL)
+    assert np.allclose(a["cost_history"], b["cost_history"], rtol=1e-10)
+    assert np.allclose(a["shot_pose"], b["rig_instance_pose"], atol=1e-9)

@@ -82,15 +82,26 @@ def test_reexamination_issues_its_gather_in_one_piece(tmp_path_factory):
 
 def test_ba_streaming_kernels_do_not_spill(tmp_path_factory):
     _, k = compile_device("ba", tmp_path_factory)
-    for parts in (("schur_point_coop_kernel", "ILi0E"), ("schur_shot_kernel",), ("eval_kernel", "ILb1ELb0E"), ("eval_kernel", "ILb1ELb1E"),
-                  ("band_assemble_kernel",), ("border_point_kernel", "ILi3E"), ("border_shot_kernel", "ILi3E"), ("point_grad_kernel",),
-                  ("shot_grad_kernel",), ("bcr_level_kernel", "ILi9E"), ("wide_factor_kernel",), ("wide_push_kernel", "ILi1ELb0E")):
+    # (length-prefixed as in the mangled names: "17schur_shot_kernel" is not "21gen_schur_shot_kernel")
+    for parts in (("schur_point_coop_kernel", "ILi0E"), ("17schur_shot_kernel",), ("11eval_kernel", "ILb1ELb0E"), ("11eval_kernel", "ILb1ELb1E"),
+                  ("band_assemble_kernel",), ("border_point_kernel", "ILi3E"), ("border_shot_kernel", "ILi3E"), ("17point_grad_kernel",),
+                  ("16shot_grad_kernel",), ("bcr_level_kernel", "ILi9E"), ("wide_factor_kernel",), ("wide_push_kernel", "ILi1ELb0E")):
         r, name = one(k, *parts)
         assert r["ScratchSize"] == 0 and r["VGPRs Spill"] == 0, (name, r)
     r, _ = one(k, "schur_point_coop_kernel", "ILi0E")
     assert r["Occupancy"] >= 4  # the mat-vec is a streaming kernel: it needs the waves to cover HBM latency
     r, _ = one(k, "bcr_level_kernel", "ILi9E")
     assert r["LDS Size"] <= 160 * 1024
+    # the generic mode's streaming kernels (ba_generic.inc): the mat-vec pair without scratch at every border width, pass A at streaming occupancy
+    for nr in (2, 3):
+        for mode in (0, 1, 2):
+            r, name = one(k, "gen_schur_point_kernel", "ILi%dELi%dE" % (nr, mode))
+            assert r["ScratchSize"] == 0 and r["VGPRs Spill"] == 0 and r["Occupancy"] >= 4, (name, r)
+        for kw in (4, 9, 16, 22):
+            r, name = one(k, "gen_schur_shot_kernel", "ILi%dELi%dE" % (nr, kw))
+            assert r["ScratchSize"] == 0 and r["VGPRs Spill"] == 0 and r["Occupancy"] >= 4, (name, r)
+            r, name = one(k, "gen_shot_grad_kernel", "ILi%dELi%dE" % (nr, kw))
+            assert r["ScratchSize"] == 0 and r["VGPRs Spill"] == 0, (name, r)
 
 
 def test_hahog_per_feature_kernels(tmp_path_factory):
