@@ -93,6 +93,50 @@ def run_ragged(ctx, shots: int = 5000, points: int = 500000, track: int = 10, it
     return out
 
 
+def run_general(ctx, shots: int = 5000, points: int = 500000, track: int = 10, iters: int = 10, seed: int = 42, cpu_size=(200, 12000, 8), cpu_iters: int = 6) -> dict:
+    """What BAHelpers::Bundle builds on a CALIBRATED data set, at the headline size: a shared BROWN camera with its nine native intrinsics
+    free (+ priors), position priors through a free per-camera similarity bias (bundle_compensate_gps_bias), 20 ground control points.
+    `osfm_bundle_solve` = the streaming solver in its generic mode (csrc/ba_generic.inc): 16 border unknowns instead of 3, rows of
+    2 x (10 + 9) components.  Round 4 sent this to a dense reduced system + rocSOLVER (7.2 GB and O(n^3) at this size; no bench line).
+    The CPU leg: the general oracle (jets, points eliminated, dense Cholesky of the reduced system) on a smaller scene of the same
+    make-up, with the GPU's trajectory on that scene beside it."""
+    pr = synthetic.make_general_ba_scene(shots, points, track, model="brown", n_gcp=20, gps_bias=True, seed=seed)
+    nobs = len(pr["obs_shot"])
+    no_tol = dict(function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
+    bundle.bundle_general_arrays(pr, {"bundle_max_iterations": 1}, ctx=ctx, **no_tol)
+    g = bundle.bundle_general_arrays(pr, {"bundle_max_iterations": iters}, ctx=ctx, **no_tol)
+    inl = ~pr["is_outlier"]
+    out = {"workload": f"{shots} cams / {points} pts / {nobs} obs, shared BROWN camera (9 free intrinsics + priors), GPS priors through a free "
+                       "similarity bias, 20 control points, SoftLOne(1)",
+           "value": round(g["iterations"] / g["seconds_run"], 3), "unit": "LM-iters/s", "lm_iterations": int(g["iterations"]),
+           "pcg_iterations": int(g["pcg_iterations"]), "border_unknowns": 16, "shot_bandwidth": int(g["shot_bandwidth"]),
+           "preconditioner_bandwidth": int(g["preconditioner_bandwidth"]),
+           "setup_seconds": round(g["seconds_setup"], 4), "run_seconds": round(g["seconds_run"], 4),
+           "inlier_rmse_px": round(float(np.sqrt((g["reproj_err"][inl][:, :2] ** 2).sum(1).mean()) * 2000.0), 4),
+           "cost": [float(g["initial_cost"]), float(g["final_cost"])], "ms_per_matvec": g["ms_per_matvec"],
+           "bias": [float(x) for x in g["bias"][0]], "bias_true": [float(x) for x in pr["gt_bias"][0]],
+           "lm_iteration_ms": round(1e3 * g["seconds_run"] / max(1, g["iterations"]), 3)}
+    if cpu_iters > 0:
+        import oracle
+
+        ps = synthetic.make_general_ba_scene(cpu_size[0], cpu_size[1], cpu_size[2], model="brown", n_gcp=20, gps_bias=True, seed=seed)
+        t0 = time.perf_counter()
+        o = oracle.bundle_general(ps, max_iterations=cpu_iters, **no_tol)
+        dt = time.perf_counter() - t0
+        gs = bundle.bundle_general_arrays(ps, {"bundle_max_iterations": cpu_iters}, ctx=ctx, **no_tol)
+        ch_o, ch_g = np.asarray(o["cost_history"]), np.asarray(gs["cost_history"])
+        rm = lambda e: float(np.sqrt((np.asarray(e)[:, :2] ** 2).sum(1).mean()) * 2000.0)  # noqa: E731
+        out["cpu_baseline"] = {"value": round(o["iterations"] / dt, 4), "unit": "LM-iters/s", "cores": 1, "kind": "port",
+                               "sample": f"{cpu_size[0]} cams / {cpu_size[1]} pts / {len(ps['obs_shot'])} obs of the same make-up, {cpu_iters} LM iterations "
+                                         f"({dt:.1f} s): oracle/bundle_general_oracle.cc, jets + Schur elimination + dense Cholesky",
+                               "gpu_lm_iters_per_s_same_scene": round(gs["iterations"] / gs["seconds_run"], 3),
+                               "parity_iterations": int(cpu_iters),
+                               "cost_history_max_rel_diff": float(np.max(np.abs(ch_o - ch_g) / np.maximum(np.abs(ch_o), 1e-300))),
+                               "rmse_px_diff": abs(rm(o["reproj_err"]) - rm(gs["reproj_err"])),
+                               "max_abs_diff": {k: float(np.abs(o[k] - gs[k]).max()) for k in ("cam_params", "rig_instance_pose", "points", "bias")}}
+    return out
+
+
 def run_local(ctx, shots: int = 400, points: int = 40000, calls: int = 40, seed: int = 7, cpu_calls: int = 5) -> dict:
     """Local bundle adjustment as incremental reconstruction calls it (reconstruction.py:1512 -> BAHelpers::BundleLocal,
     ba_helpers.cc:117-311): once per added image, on the <= 30 interior shots around it + their boundary, cameras constant, 10 LM
@@ -204,7 +248,8 @@ def run(ctx, shots: int = 5000, points: int = 500000, track: int = 10, iters: in
     if grid:
         for key, fn in (("grid_topology", lambda: run_grid(ctx, points=points, seed=seed, cpu_iters=2 if cpu_baseline else 0)),
                         ("ragged_topology", lambda: run_ragged(ctx, shots, points, track, seed=seed, cpu_iters=3 if cpu_baseline else 0)),
-                        ("local_ba", lambda: run_local(ctx, cpu_calls=5 if cpu_baseline else 0))):
+                        ("local_ba", lambda: run_local(ctx, cpu_calls=5 if cpu_baseline else 0)),
+                        ("general", lambda: run_general(ctx, shots, points, track, seed=seed, cpu_iters=6 if cpu_baseline else 0))):
             try:
                 out[key] = fn()
             except Exception as exc:  # noqa: BLE001  (a secondary workload must not take the line down)

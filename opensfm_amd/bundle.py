@@ -145,8 +145,9 @@ def bundle_arrays(problem: Dict[str, np.ndarray], config: Optional[Dict[str, Any
 def bundle_general_arrays(problem: Dict[str, Any], config: Optional[Dict[str, Any]] = None, ctx=None, **overrides) -> Dict[str, Any]:
     """The general bundle adjustment over flat arrays (``osfm_bundle_solve``; field names and shapes: ``_ba_abi.BUNDLE_FIELDS`` =
     ``osfm_bundle_problem`` of ``include/osfm_mi355.h``): every camera model with free or constant intrinsics, rig cameras, rig
-    instances, GPS priors through per-camera biases, point priors (ground control points), up vectors.  Inputs are not modified;
-    returns the optimised parameter arrays, ``reproj_err`` (n_obs x 3, sigma 1) and the report."""
+    instances, GPS priors through per-camera biases, point priors (ground control points), up vectors, depth priors -- on the
+    streaming Schur solver (its generic mode, ``csrc/ba_generic.inc``): linear in the observations, no dense reduced system.
+    Inputs are not modified; returns the optimised parameter arrays, ``reproj_err`` (n_obs x 3, sigma 1) and the report."""
     ctx = ctx or default_context()
     lib = _lib.load()
     P, arr = fill_bundle_problem(problem)
@@ -162,9 +163,14 @@ def bundle_general_arrays(problem: Dict[str, Any], config: Optional[Dict[str, An
         "initial_cost": R.initial_cost, "final_cost": R.final_cost,
         "cost_history": np.array(R.cost_history[: min(R.iterations, 255) + 1]),
         "seconds_setup": R.seconds_setup, "seconds_run": R.seconds_run, "seconds_teardown": R.seconds_teardown,
-        "seconds_linear_solver": R.seconds_linear_solver,
-        "brief_report": "osfm-mi355 LM (dense Schur): iterations %d (successful %d), initial cost %.6e, final cost %.6e, termination: %s"
-                        % (R.iterations, R.successful_steps, R.initial_cost, R.final_cost, TERMINATION.get(R.termination, str(R.termination))),
+        "seconds_linear_solver": R.seconds_linear_solver, "seconds_solver": R.seconds_total,
+        "pcg_iterations": int(R.pcg_iterations_total), "ms_per_matvec": (R.ms_matvec_total / R.matvec_calls) if R.matvec_calls else None,
+        "shot_bandwidth": int(R.shot_bandwidth), "preconditioner_bandwidth": int(R.preconditioner_bandwidth),
+        "shots_reordered": int(R.shots_reordered), "shot_bandwidth_input": int(R.shot_bandwidth_input),
+        "brief_report": "osfm-mi355 LM (streaming Schur, generic rows): iterations %d (successful %d), initial cost %.6e, final cost %.6e, termination: %s, "
+                        "pcg iterations %d"
+                        % (R.iterations, R.successful_steps, R.initial_cost, R.final_cost, TERMINATION.get(R.termination, str(R.termination)),
+                           R.pcg_iterations_total),
         "wall_times": {"setup": R.seconds_setup, "run": R.seconds_run, "teardown": R.seconds_teardown},
         "num_images": int(P.n_shots), "num_points": int(P.n_points), "num_reprojections": int(P.n_obs),
     })

@@ -511,3 +511,47 @@ def make_bundle_scene(models=("perspective", "brown"), n_instances: int = 12, n_
             up[s] = Rcw.T @ np.array([0.0, 0.0, 1.0]) + rng.normal(0, 1e-3, 3)
         prob.update({"shot_up": up, "shot_up_sigma": np.full(S, 1e-2)})
     return prob
+
+
+def make_general_ba_scene(n_shots: int, n_points: int, track_len: int = 10, model: str = "brown", n_gcp: int = 20, gps_bias: bool = True,
+                          seed: int = 42, ragged: bool = False) -> dict:
+    """The street scene of ``make_ba_scene`` as ``BAHelpers::Bundle`` hands a CALIBRATED data set over (``osfm_bundle_problem`` layout): one
+    shared camera of ``model`` (Brown: 9 native parameters) with FREE intrinsics and their priors, a constant identity rig camera,
+    one shot per rig instance, position priors through a FREE per-camera similarity bias (``bundle_compensate_gps_bias``), ``n_gcp``
+    ground control points = points with position priors.  Scales to BASELINE.json configs[4] (5 000 / 500 000 / 5 000 000)."""
+    par = np.asarray(BUNDLE_TEST_CAMERAS[model], float)
+    base = make_ba_scene(n_shots, n_points, track_len, seed=seed, model=model if model in GENERIC_MODELS else "perspective",
+                         generic_params=par if model in GENERIC_MODELS else None, ragged=ragged)
+    if model not in GENERIC_MODELS and model != "perspective":
+        raise ValueError("make_general_ba_scene: model %r" % model)
+    rng = np.random.default_rng(seed + 1)
+    nk = len(par) if model in GENERIC_MODELS else 3
+    cam_gt = np.zeros((1, 16))
+    cam_gt[0, :nk] = par if model in GENERIC_MODELS else base["gt_cam"]
+    cam0 = cam_gt.copy()
+    cam0[0, :nk] *= 1.0 + rng.normal(0, 0.01, nk)
+    S, NP = n_shots, n_points
+    prob = {
+        "cam_model": np.asarray([MODEL_IDS[model]], np.int32), "cam_params": cam0, "cam_prior": cam_gt.copy(), "cam_sigma": np.full((1, 16), 0.01),
+        "cam_fixed": np.zeros(1, np.uint8),
+        "rig_camera_pose": np.zeros((1, 6)), "rig_camera_fixed": np.ones(1, np.uint8),
+        "rig_instance_pose": base["shot_pose"], "shot_rig_instance": np.arange(S, dtype=np.int32), "shot_rig_camera": np.zeros(S, np.int32),
+        "shot_camera": np.zeros(S, np.int32), "points": base["points"], "obs_shot": base["obs_shot"], "obs_point": base["obs_point"],
+        "obs_xy": base["obs_xy"], "obs_sigma": base["obs_sigma"], "is_outlier": base["is_outlier"], "gt_points": base["gt_points"],
+        "gt_rig_instance": base["gt_pose"], "gt_cam": cam_gt,
+    }
+    if gps_bias:  # measured positions g with t = s R(b) g + t_b: the bias maps the measurements into the reconstruction frame
+        b = np.array([0.0, 0.0, 0.02, 0.3, -0.2, 0.1, 1.01])
+        g = ((base["gt_pose"][:, 3:6] - b[3:6]) @ _rodrigues(b[:3])) / b[6]
+        prob.update({"rig_instance_gps": g + rng.normal(0, 0.05, g.shape), "rig_instance_gps_sigma": np.full((S, 3), 0.5),
+                     "rig_instance_bias_camera": np.zeros(S, np.int32), "bias": np.tile([0, 0, 0, 0, 0, 0, 1.0], (1, 1)),
+                     "bias_fixed": np.zeros(1, np.uint8), "gt_bias": b[None, :]})
+    if n_gcp:
+        pick = rng.choice(NP, min(n_gcp, NP), replace=False)
+        pp, ps = np.zeros((NP, 3)), np.zeros((NP, 3))
+        pp[pick] = base["gt_points"][pick] + rng.normal(0, 0.005, (len(pick), 3))
+        ps[pick] = [0.01, 0.01, 0.02]
+        alt = np.ones(NP, np.uint8)
+        alt[pick[::2]] = 0
+        prob.update({"point_prior": pp, "point_prior_sigma": ps, "point_prior_has_altitude": alt})
+    return prob

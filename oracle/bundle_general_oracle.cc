@@ -26,6 +26,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -294,11 +295,29 @@ struct State {
   std::vector<double> cam, bias, rc, inst, pts;
 };
 
-struct Accum {  // dense normal equations
+struct Accum {  // normal equations: dense, or (nr >= 0) in ARROW form for problems with many points
   int n;
   std::vector<double> H, g;
   double cost = 0.0;
+  // Arrow form.  The free-parameter vector lists the points last (Layout below): unknowns [0, nr) are everything else ("reduced"), then
+  // three per free point.  A residual block touches at most one point, so H = [R W; W^T blockdiag(Hpp)]: R dense nr x nr, per point the
+  // 3 x 3 block Hpp and the columns of W it has (reduced index -> 3 values).  Same sums as the dense form, entry by entry; the solve
+  // eliminates the points first (Schur complement) instead of factorising the whole matrix.
+  int nr = -1;
+  std::vector<double> R, Hpp;            // nr x nr, 9 per point
+  std::vector<std::vector<int>> wcol;    // per point: reduced indices
+  std::vector<std::vector<double>> wval; // per point: 3 values per entry of wcol
   explicit Accum(int n_) : n(n_), H((size_t)n_ * n_, 0.0), g(n_, 0.0) {}
+  Accum(int n_, int nr_) : n(n_), g(n_, 0.0), nr(nr_), R((size_t)nr_ * nr_, 0.0), Hpp((size_t)(n_ - nr_) * 3, 0.0), wcol((size_t)(n_ - nr_) / 3), wval((size_t)(n_ - nr_) / 3) {}
+  double *w_entry(int pt, int col) {
+    std::vector<int> &c = wcol[(size_t)pt];
+    for (size_t k = 0; k < c.size(); k++)
+      if (c[k] == col) return &wval[(size_t)pt][3 * k];
+    c.push_back(col);
+    wval[(size_t)pt].insert(wval[(size_t)pt].end(), 3, 0.0);
+    return &wval[(size_t)pt][3 * (c.size() - 1)];
+  }
+  double diag(int i) const { return nr < 0 ? H[(size_t)i * n + i] : (i < nr ? R[(size_t)i * nr + i] : Hpp[(size_t)((i - nr) / 3) * 9 + 4 * ((i - nr) % 3)]); }
 };
 
 // one residual block: nres jets over N local parameters with global indices idx[N] (-1: constant); wt = sqrt(rho')
@@ -314,7 +333,14 @@ void add_block(Accum* A, const Jet<N>* r, int nres, double wt, const int* idx) {
       if (idx[y] < 0) continue;
       double h = 0.0;
       for (int e = 0; e < nres; e++) h += wt * r[e].d[x] * wt * r[e].d[y];
-      A->H[(size_t)idx[x] * A->n + idx[y]] += h;
+      if (A->nr < 0) {
+        A->H[(size_t)idx[x] * A->n + idx[y]] += h;
+      } else {
+        const int ix = idx[x], iy = idx[y], nr = A->nr;
+        if (ix < nr && iy < nr) A->R[(size_t)ix * nr + iy] += h;
+        else if (ix >= nr && iy >= nr) A->Hpp[(size_t)((ix - nr) / 3) * 9 + 3 * ((ix - nr) % 3) + (iy - nr) % 3] += h;
+        else if (ix < nr) A->w_entry((iy - nr) / 3, ix)[(iy - nr) % 3] += h;  // (the mirror entry is not stored)
+      }
     }
   }
 }
@@ -579,6 +605,7 @@ bool cholesky_solve(std::vector<double>& Amat, std::vector<double>& b, int n) { 
     if (!(dgn > 0) || !std::isfinite(dgn)) return false;
     const double l = std::sqrt(dgn);
     Amat[(size_t)j * n + j] = l;
+#pragma omp parallel for schedule(static) if (n - j > 256)
     for (int i = j + 1; i < n; i++) {
       double v = Amat[(size_t)i * n + j];
       for (int k = 0; k < j; k++) v -= Amat[(size_t)i * n + k] * Amat[(size_t)j * n + k];
@@ -683,18 +710,101 @@ extern "C" int oracle_bundle_solve(Problem* P, const Options* O, Report* Rp) {
         for (int k = 0; k < 3; k++) s.pts[3 * p + k] = v[L.pt[p] + k];
   };
 
-  Accum A(n);
+  // many points: the arrow form (same normal equations, points eliminated first); ORACLE_BUNDLE_ARROW=1 / 0 forces either (tests)
+  const int nr_first_point = [&] {
+    int first = n;
+    for (int p = 0; p < NP; p++)
+      if (L.pt[p] >= 0) { first = L.pt[p]; break; }
+    return first;
+  }();
+  const char* env_arrow = getenv("ORACLE_BUNDLE_ARROW");
+  const bool arrow = env_arrow ? atoi(env_arrow) != 0 : n > 4000;
+  const int nr = arrow ? nr_first_point : -1, npt = arrow ? (n - nr_first_point) / 3 : 0;
+  auto fresh = [&]() { return arrow ? Accum(n, nr) : Accum(n); };
+  Accum A = fresh();
   double cost = evaluate(*P, *O, L, X, useful, &A, nullptr);
   Rp->initial_cost = cost;
   Rp->cost_history[0] = cost;
-  std::vector<double> scale(n, 1.0), x, xn, step(n), Hs((size_t)n * n);
+  std::vector<double> scale(n, 1.0), x, xn, step(n), Hs(arrow ? (size_t)nr * nr : (size_t)n * n);
+  // arrow form: solve (D H D + LM) s = -D g by eliminating the points; returns false when a block is not positive definite
+  auto arrow_solve = [&](double radius_) -> bool {
+    std::vector<double> Ainv((size_t)npt * 9), bp((size_t)npt * 3);
+    for (int i = 0; i < nr; i++)
+      for (int j = 0; j < nr; j++) Hs[(size_t)i * nr + j] = A.R[(size_t)i * nr + j] * scale[i] * scale[j];
+    for (int i = 0; i < nr; i++) {
+      const double dd = std::min(std::max(Hs[(size_t)i * nr + i], 1e-6), 1e32);
+      Hs[(size_t)i * nr + i] += dd / radius_;
+      step[i] = -A.g[i] * scale[i];
+    }
+    for (int p = 0; p < npt; p++) {
+      double B[9];
+      for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) B[3 * a + b] = A.Hpp[(size_t)p * 9 + 3 * a + b] * scale[nr + 3 * p + a] * scale[nr + 3 * p + b];
+      for (int a = 0; a < 3; a++) B[4 * a] += std::min(std::max(B[4 * a], 1e-6), 1e32) / radius_;
+      const double c00 = B[4] * B[8] - B[5] * B[7], c01 = B[5] * B[6] - B[3] * B[8], c02 = B[3] * B[7] - B[4] * B[6];
+      const double det = B[0] * c00 + B[1] * c01 + B[2] * c02;
+      if (!(det > 0) || !std::isfinite(det)) return false;
+      const double id = 1.0 / det;
+      double* I = &Ainv[(size_t)p * 9];
+      I[0] = c00 * id; I[1] = (B[2] * B[7] - B[1] * B[8]) * id; I[2] = (B[1] * B[5] - B[2] * B[4]) * id;
+      I[3] = c01 * id; I[4] = (B[0] * B[8] - B[2] * B[6]) * id; I[5] = (B[2] * B[3] - B[0] * B[5]) * id;
+      I[6] = c02 * id; I[7] = (B[1] * B[6] - B[0] * B[7]) * id; I[8] = (B[0] * B[4] - B[1] * B[3]) * id;
+      for (int a = 0; a < 3; a++) bp[(size_t)3 * p + a] = -A.g[nr + 3 * p + a] * scale[nr + 3 * p + a];
+      // Schur update: Hs -= Ws A^-1 Ws^T, step_r -= Ws A^-1 b_p   (Ws = D_r W D_p)
+      const std::vector<int>& wc = A.wcol[(size_t)p];
+      const size_t m = wc.size();
+      std::vector<double> T(3 * m);  // Ws A^-1
+      for (size_t k = 0; k < m; k++) {
+        double ws[3];
+        for (int a = 0; a < 3; a++) ws[a] = A.wval[(size_t)p][3 * k + a] * scale[wc[k]] * scale[nr + 3 * p + a];
+        for (int b = 0; b < 3; b++) T[3 * k + b] = ws[0] * I[b] + ws[1] * I[3 + b] + ws[2] * I[6 + b];
+        step[wc[k]] -= T[3 * k] * bp[(size_t)3 * p] + T[3 * k + 1] * bp[(size_t)3 * p + 1] + T[3 * k + 2] * bp[(size_t)3 * p + 2];
+      }
+      for (size_t k = 0; k < m; k++)
+        for (size_t k2 = 0; k2 < m; k2++) {
+          double v = 0.0;
+          for (int a = 0; a < 3; a++) v += T[3 * k + a] * A.wval[(size_t)p][3 * k2 + a] * scale[wc[k2]] * scale[nr + 3 * p + a];
+          Hs[(size_t)wc[k] * nr + wc[k2]] -= v;
+        }
+    }
+    std::vector<double> sr(step.begin(), step.begin() + nr);
+    if (nr > 0 && !cholesky_solve(Hs, sr, nr)) return false;
+    for (int i = 0; i < nr; i++) step[i] = sr[i];
+    for (int p = 0; p < npt; p++) {
+      double rhs[3] = {bp[(size_t)3 * p], bp[(size_t)3 * p + 1], bp[(size_t)3 * p + 2]};
+      const std::vector<int>& wc = A.wcol[(size_t)p];
+      for (size_t k = 0; k < wc.size(); k++)
+        for (int a = 0; a < 3; a++) rhs[a] -= A.wval[(size_t)p][3 * k + a] * scale[wc[k]] * scale[nr + 3 * p + a] * step[wc[k]];
+      const double* I = &Ainv[(size_t)p * 9];
+      for (int a = 0; a < 3; a++) step[nr + 3 * p + a] = I[3 * a] * rhs[0] + I[3 * a + 1] * rhs[1] + I[3 * a + 2] * rhs[2];
+    }
+    return true;
+  };
+  auto arrow_Hx = [&](const std::vector<double>& v, std::vector<double>& out) {  // out = H v
+    out.assign(n, 0.0);
+    for (int i = 0; i < nr; i++) {
+      double a = 0.0;
+      for (int j = 0; j < nr; j++) a += A.R[(size_t)i * nr + j] * v[j];
+      out[i] = a;
+    }
+    for (int p = 0; p < npt; p++) {
+      for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) out[nr + 3 * p + a] += A.Hpp[(size_t)p * 9 + 3 * a + b] * v[nr + 3 * p + b];
+      const std::vector<int>& wc = A.wcol[(size_t)p];
+      for (size_t k = 0; k < wc.size(); k++)
+        for (int a = 0; a < 3; a++) {
+          out[wc[k]] += A.wval[(size_t)p][3 * k + a] * v[nr + 3 * p + a];
+          out[nr + 3 * p + a] += A.wval[(size_t)p][3 * k + a] * v[wc[k]];
+        }
+    }
+  };
   bool have_scale = false;
   double radius = O->initial_radius, decrease = 2.0;
   int iter = 0, n_invalid = 0;
   Rp->termination = 0;
   for (;;) {
     if (!have_scale) {
-      for (int i = 0; i < n; i++) scale[i] = 1.0 / (1.0 + std::sqrt(A.H[(size_t)i * n + i]));
+      for (int i = 0; i < n; i++) scale[i] = 1.0 / (1.0 + std::sqrt(A.diag(i)));
       have_scale = true;
     }
     double gmax = 0.0;
@@ -704,22 +814,32 @@ extern "C" int oracle_bundle_solve(Problem* P, const Options* O, Report* Rp) {
     if (radius < 1e-32) { Rp->termination = 4; break; }
     iter++;
     if (iter < 256) Rp->cost_history[iter] = cost;
-    for (int i = 0; i < n; i++)
-      for (int j = 0; j < n; j++) Hs[(size_t)i * n + j] = A.H[(size_t)i * n + j] * scale[i] * scale[j];
-    for (int i = 0; i < n; i++) {
-      const double dd = std::min(std::max(Hs[(size_t)i * n + i], 1e-6), 1e32);
-      Hs[(size_t)i * n + i] += dd / radius;
-      step[i] = -A.g[i] * scale[i];
+    bool ok;
+    if (arrow) {
+      ok = arrow_solve(radius);
+    } else {
+      for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) Hs[(size_t)i * n + j] = A.H[(size_t)i * n + j] * scale[i] * scale[j];
+      for (int i = 0; i < n; i++) {
+        const double dd = std::min(std::max(Hs[(size_t)i * n + i], 1e-6), 1e32);
+        Hs[(size_t)i * n + i] += dd / radius;
+        step[i] = -A.g[i] * scale[i];
+      }
+      ok = cholesky_solve(Hs, step, n);
     }
-    const bool ok = cholesky_solve(Hs, step, n);
     double model_change = 0.0, step_sq = 0.0, x_sq = 0.0;
     if (ok) {
       for (int i = 0; i < n; i++) step[i] *= scale[i];
-      for (int i = 0; i < n; i++) {
-        double hd = 0.0;
-        for (int j = 0; j < n; j++) hd += A.H[(size_t)i * n + j] * step[j];
-        model_change -= step[i] * (A.g[i] + 0.5 * hd);
-      }
+      if (arrow) {
+        std::vector<double> hd;
+        arrow_Hx(step, hd);
+        for (int i = 0; i < n; i++) model_change -= step[i] * (A.g[i] + 0.5 * hd[i]);
+      } else
+        for (int i = 0; i < n; i++) {
+          double hd = 0.0;
+          for (int j = 0; j < n; j++) hd += A.H[(size_t)i * n + j] * step[j];
+          model_change -= step[i] * (A.g[i] + 0.5 * hd);
+        }
       flat(X, x);
       for (int i = 0; i < n; i++) {
         step_sq += step[i] * step[i];
@@ -747,7 +867,7 @@ extern "C" int oracle_bundle_solve(Problem* P, const Options* O, Report* Rp) {
       radius = std::min(1e16, radius / std::max(1.0 / 3.0, 1.0 - t * t * t));
       decrease = 2.0;
       Rp->successful_steps++;
-      A = Accum(n);
+      A = fresh();
       cost = evaluate(*P, *O, L, X, useful, &A, nullptr);
     } else {
       radius /= decrease;

@@ -1,7 +1,8 @@
-"""GPU parity of the general bundle adjustment (osfm_bundle_solve, opensfm_amd/csrc/ba_general.hip: analytic Jacobians, points
-eliminated, dense reduced system, rocSOLVER Cholesky) against the CPU oracle (oracle/bundle_general_oracle.cc: jets, full dense normal
-equations): same cost after the same number of LM iterations, reprojection RMSE within 1e-4 px (north_star), per camera family and
-per residual family.  1e-4 px at the synthetic 2000-px image = 5e-8 in normalized coordinates."""
+"""GPU parity of the general bundle adjustment (osfm_bundle_solve = the streaming Schur solver in its generic mode,
+opensfm_amd/csrc/ba_generic.inc: analytic Jacobians, points eliminated on the fly, exact band + exactly eliminated border, PCG) against
+the CPU oracle (oracle/bundle_general_oracle.cc: jets; full dense normal equations, or -- many points -- the same equations with the
+points eliminated first): same cost after the same number of LM iterations, reprojection RMSE within 1e-4 px (north_star), per camera
+family and per residual family, and at BASELINE configs[2] size.  1e-4 px at the synthetic 2000-px image = 5e-8 in normalized coordinates."""
 import numpy as np
 import pytest
 
@@ -122,3 +123,49 @@ def test_general_solver_equals_the_streaming_solver(oracle_lib, gpu_ctx):
     assert np.allclose(a["cost_history"], b["cost_history"], rtol=1e-7)
     assert np.allclose(a["shot_pose"], b["rig_instance_pose"], atol=1e-7)
     assert abs(_rmse_px(a["reproj_err"]) - _rmse_px(b["reproj_err"][:, :2])) < 1e-4
+
+
+def test_generic_mode_at_configs2_size_equals_the_schur_oracle(oracle_lib, gpu_ctx):
+    """BASELINE configs[2] (500 cams / 50 k points / 300 k observations, 20 LM iterations) through osfm_bundle_solve: the generic rows
+    walk the trajectory of oracle/ba_oracle.c (analytic derivatives, Schur + skyline Cholesky) -- RMSE within 1e-4 px after the same
+    iteration count"""
+    import test_oracle_bundle_general as og
+
+    from opensfm_amd import bundle
+
+    pr = synthetic.make_ba_scene(500, 50000, 6, seed=42)
+    g = bundle.bundle_general_arrays(og._as_general(pr), {"bundle_max_iterations": 20}, ctx=gpu_ctx, **NO_TOL)
+    o = oracle_lib.ba_solve(pr, max_iterations=20, **NO_TOL)
+    assert g["iterations"] == o["iterations"] == 20
+    assert np.allclose(g["cost_history"], o["cost_history"], rtol=1e-9)
+    assert abs(_rmse_px(g["reproj_err"][:, :2]) - _rmse_px(o["reproj_err"])) < 1e-4
+    assert np.allclose(g["rig_instance_pose"], o["shot_pose"], atol=1e-7) and np.allclose(g["cam_params"][:, :3], o["cam_params"], atol=1e-9)
+    assert g["preconditioner_bandwidth"] == g["shot_bandwidth"] and g["pcg_iterations"] <= 3 * 20  # exact band + exact border: CG only confirms
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_brown_camera_free_bias_control_points_at_scale(oracle_lib, gpu_ctx, ragged):
+    """what BAHelpers::Bundle builds on a calibrated data set -- a BROWN camera with nine free intrinsics, position priors through a free
+    similarity bias, 20 control points -- beyond what a dense reduced system could carry comfortably (1 500 reduced unknowns, 8 000 points):
+    the oracle eliminates the points and factorises the reduced system densely.  ragged: the wide band (cyclic reduction over dense
+    clusters) under the same border"""
+    from opensfm_amd import bundle
+
+    pr = synthetic.make_general_ba_scene(250, 8000, 8, model="brown", n_gcp=20, gps_bias=True, seed=5, ragged=ragged)
+    g = bundle.bundle_general_arrays(pr, {"bundle_max_iterations": 10}, ctx=gpu_ctx, **NO_TOL)
+    o = oracle_lib.bundle_general(pr, max_iterations=10, **NO_TOL)
+    assert g["iterations"] == o["iterations"] == 10
+    assert np.allclose(g["cost_history"], o["cost_history"], rtol=1e-8), (g["cost_history"], o["cost_history"])
+    assert abs(_rmse_px(g["reproj_err"][:, :2]) - _rmse_px(o["reproj_err"][:, :2])) < 1e-4
+    for k in ("cam_params", "rig_instance_pose", "points", "bias"):
+        assert np.allclose(g[k], o[k], atol=1e-6), k
+    assert np.abs(g["bias"][0] - pr["bias"][0]).max() > 1e-3 and np.abs(g["cam_params"][0, :9] - pr["cam_params"][0, :9]).max() > 0
+    assert g["preconditioner_bandwidth"] == g["shot_bandwidth"] and (g["shot_bandwidth"] > 10) == ragged
+
+
+def test_border_wider_than_the_exact_elimination_falls_back_to_pcg(oracle_lib, gpu_ctx):
+    """nine free BROWN cameras = 81 border unknowns, beyond the kGenMaxNB = 64 the exact border elimination carries: the band still
+    preconditions the instance block, the border rows are Jacobi-preconditioned, and CG carries the coupling -- same trajectory"""
+    pr = synthetic.make_bundle_scene(models=("brown",) * 9, n_instances=27, n_points=400, rig=False, gps=False, n_gcp=0, up_vectors=False, seed=3)
+    g, _ = _compare(oracle_lib, gpu_ctx, pr, iters=6)
+    assert g["pcg_iterations"] > 6 * 4
