@@ -287,3 +287,212 @@ def bundle(reconstruction, camera_priors: Dict[str, Any], rig_camera_priors: Dic
         "wall_times": {"setup": timer_setup - start, "run": timer_run - timer_setup, "teardown": timer_teardown - timer_run},
         "num_images": len(reconstruction.shots), "num_points": len(reconstruction.points), "num_reprojections": added_reprojections,
     }
+
+
+# ------------------------------------------------------------------------------------------------
+# local / pose-only bundle adjustment over reconstruction objects (reconstruction.py:89-149 calls these)
+# ------------------------------------------------------------------------------------------------
+DEFAULTS.update({"local_bundle_radius": 3, "local_bundle_min_common_points": 20, "local_bundle_max_shots": 30})  # config.py:296-300
+
+
+def _instance_id(shot) -> str:
+    return shot.rig_instance_id if hasattr(shot, "rig_instance_id") else shot.rig_instance.id
+
+
+def _rig_camera_id(shot) -> str:
+    return shot.rig_camera_id if hasattr(shot, "rig_camera_id") else shot.rig_camera.id
+
+
+def _instance_shot_ids(reconstruction, shot) -> List[str]:
+    """``RigInstance::GetShotIDs`` of the instance a shot belongs to"""
+    inst = reconstruction.rig_instances[_instance_id(shot)]
+    if hasattr(inst, "rig_camera_ids"):
+        return list(inst.rig_camera_ids.keys())
+    return list(inst.shots.keys())
+
+
+def _landmark_shots(reconstruction) -> Dict[str, List[str]]:
+    """landmark id -> the shots observing it (``Landmark::GetObservations``), from the shots' side of the map"""
+    out: Dict[str, List[str]] = {}
+    for shot_id, shot in reconstruction.shots.items():
+        for lm_id, _ in _shot_observations(shot):
+            out.setdefault(lm_id, []).append(shot_id)
+    return out
+
+
+def _direct_shot_neighbors(reconstruction, shot_ids: set, min_common_points: int, max_neighbors: int, lm_shots: Dict[str, List[str]]) -> set:
+    """``BAHelpers::DirectShotNeighbors`` (ba_helpers.cc:68-115): the shots outside ``shot_ids`` ranked by the number of points they share
+    with it, the first ``max_neighbors`` with at least ``min_common_points`` -- each with every shot of its rig instance.  (The
+    reference sorts the entries of an unordered_map: equal counts come out in an unspecified order there; here ties go to the
+    smaller shot id.)"""
+    points = set()
+    for sid in shot_ids:
+        for lm_id, _ in _shot_observations(reconstruction.shots[sid]):
+            points.add(lm_id)
+    common: Dict[str, int] = {}
+    for lm_id in points:
+        for sid in lm_shots.get(lm_id, ()):
+            if sid not in shot_ids:
+                common[sid] = common.get(sid, 0) + 1
+    pairs = sorted(common.items(), key=lambda kv: (-kv[1], kv[0]))
+    max_n = min(max_neighbors, len(pairs))
+    neighbors = set()
+    for idx, (sid, n) in enumerate(pairs):
+        if n >= min_common_points and idx < max_n:
+            neighbors.update(_instance_shot_ids(reconstruction, reconstruction.shots[sid]))
+        else:
+            break
+    return neighbors
+
+
+def shot_neighborhood_ids(reconstruction, central_shot_id: str, radius: int, min_common_points: int, max_interior_size: int,
+                          lm_shots: Optional[Dict[str, List[str]]] = None) -> Tuple[set, set]:
+    """``pysfm.BAHelpers.shot_neighborhood_ids`` (ba_helpers.cc:17-66): (interior, boundary) shot ids around a shot -- the central shot (and
+    its rig instance) at distance 0, shots at distance n + 1 share at least ``min_common_points`` points with those at distance n, up to
+    ``radius`` / ``max_interior_size``; the boundary = everything else sharing a point with the interior"""
+    lm_shots = lm_shots if lm_shots is not None else _landmark_shots(reconstruction)
+    central = reconstruction.shots[central_shot_id]
+    interior = set(_instance_shot_ids(reconstruction, central))
+    interior.add(central_shot_id)
+    distance = 1
+    while distance < radius and len(interior) < max_interior_size:
+        interior |= _direct_shot_neighbors(reconstruction, interior, min_common_points, max_interior_size - len(interior), lm_shots)
+        distance += 1
+    boundary = _direct_shot_neighbors(reconstruction, interior, 1, 1000000, lm_shots)
+    return interior, boundary
+
+
+def _set_internal_priors_and_loss(ba, config) -> None:
+    ba.set_point_projection_loss_function(_cfg(config, "loss_function"), _cfg(config, "loss_function_threshold"))
+    ba.set_internal_parameters_prior_sd(
+        _cfg(config, "exif_focal_sd"), _cfg(config, "aspect_ratio_sd"), _cfg(config, "principal_point_sd"),
+        _cfg(config, "radial_distortion_k1_sd"), _cfg(config, "radial_distortion_k2_sd"), _cfg(config, "tangential_distortion_p1_sd"),
+        _cfg(config, "tangential_distortion_p2_sd"), _cfg(config, "radial_distortion_k3_sd"), _cfg(config, "radial_distortion_k4_sd"))
+    ba.set_rig_parameters_prior_sd(_cfg(config, "rig_translation_sd"), _cfg(config, "rig_rotation_sd"))
+    ba.set_num_threads(int(_cfg(config, "processes")))
+
+
+def _add_instances(ba, reconstruction, rig_instance_ids, is_free_shot, config) -> None:
+    """the rig-instance loop BundleLocal and BundleShotPoses share (ba_helpers.cc:176-224, 467-511): an instance is constant as soon as
+    one of its shots is not to be optimised; moving instances get the average GPS position / accuracy of their free shots as a prior"""
+    use_gps = bool(_cfg(config, "bundle_use_gps"))
+    for rig_instance_id in rig_instance_ids:
+        instance = reconstruction.rig_instances[rig_instance_id]
+        shot_cameras, shot_rig_cameras = {}, {}
+        average_position, average_std, gps_count, fix_instance = np.zeros(3), 0.0, 0, False
+        for shot_id, rig_camera_id in instance.rig_camera_ids.items():
+            shot = reconstruction.shots[shot_id]
+            shot_cameras[shot_id] = shot.camera.id
+            shot_rig_cameras[shot_id] = rig_camera_id
+            if is_free_shot(shot_id):
+                pos, acc = _gps(shot)
+                if use_gps and pos is not None and acc is not None:
+                    average_position += pos
+                    average_std += acc
+                    gps_count += 1
+            else:
+                fix_instance = True
+        ba.add_rig_instance(rig_instance_id, instance.pose, shot_cameras, shot_rig_cameras, fix_instance)
+        if not fix_instance and gps_count > 0:
+            ba.add_rig_instance_position_prior(rig_instance_id, average_position / gps_count, np.full(3, average_std / gps_count), "dummy")
+
+
+def bundle_local(reconstruction, camera_priors: Dict[str, Any], rig_camera_priors: Dict[str, Any], gcp: Optional[List[Any]], central_shot_id: str,
+                 config: Optional[Dict[str, Any]] = None) -> Tuple[List[str], Dict[str, Any]]:
+    """``pysfm.BAHelpers.bundle_local`` (ba_helpers.cc:117-311; ``reconstruction.bundle_local``, reconstruction.py:107-127): ten LM
+    iterations over the rig instances of the interior of a shot's neighbourhood and every point they see, the boundary shots and all
+    cameras / rig cameras constant; updates the reconstruction in place and returns (ids of the adjusted points, report)"""
+    start = time.perf_counter()
+    gcp = list(gcp or [])
+    lm_shots = _landmark_shots(reconstruction)
+    interior, boundary = shot_neighborhood_ids(reconstruction, central_shot_id, int(_cfg(config, "local_bundle_radius")),
+                                               int(_cfg(config, "local_bundle_min_common_points")), int(_cfg(config, "local_bundle_max_shots")), lm_shots)
+    ba = _bundle.BundleAdjuster()
+    ba.set_use_analytic_derivatives(bool(_cfg(config, "bundle_analytic_derivatives")))
+    for cam_id, cam in reconstruction.cameras.items():
+        ba.add_camera(cam_id, cam, camera_priors[cam_id], True)
+    int_and_bound = sorted(interior | boundary)
+    rig_camera_ids = sorted({_rig_camera_id(reconstruction.shots[s]) for s in int_and_bound})
+    rig_instance_ids = sorted({_instance_id(reconstruction.shots[s]) for s in int_and_bound})
+    for rig_camera_id in rig_camera_ids:
+        ba.add_rig_camera(rig_camera_id, reconstruction.rig_cameras[rig_camera_id].pose, rig_camera_priors[rig_camera_id].pose, True)
+    _add_instances(ba, reconstruction, rig_instance_ids, lambda sid: sid not in boundary, config)
+    pt_ids: List[str] = []
+    points = set()
+    added_reprojections = 0
+    for shot_id in sorted(interior):
+        for lm_id, obs in _shot_observations(reconstruction.shots[shot_id]):
+            if lm_id not in points:
+                points.add(lm_id)
+                pt_ids.append(lm_id)
+                ba.add_point(lm_id, reconstruction.points[lm_id].coordinates, False)
+            ba.add_point_projection_observation(shot_id, lm_id, obs.point, obs.scale, optional_value(getattr(obs, "depth_prior", None)))
+            added_reprojections += 1
+    for shot_id in sorted(boundary):
+        for lm_id, obs in _shot_observations(reconstruction.shots[shot_id]):
+            if lm_id in points:
+                ba.add_point_projection_observation(shot_id, lm_id, obs.point, obs.scale, optional_value(getattr(obs, "depth_prior", None)))
+                added_reprojections += 1
+    if _cfg(config, "bundle_use_gcp") and gcp:
+        add_gcp_to_bundle(ba, reconstruction, gcp, config)
+    _set_internal_priors_and_loss(ba, config)
+    ba.set_max_num_iterations(10)
+    ba.set_linear_solver_type("DENSE_SCHUR")
+    timer_setup = time.perf_counter()
+    ba.run()
+    timer_run = time.perf_counter()
+    for rig_instance_id in rig_instance_ids:
+        reconstruction.rig_instances[rig_instance_id].pose = ba.get_rig_instance_pose(rig_instance_id)
+    for lm_id in pt_ids:
+        pt = ba.get_point(lm_id)
+        reconstruction.points[lm_id].coordinates = pt.p
+        reconstruction.points[lm_id].reprojection_errors = pt.reprojection_errors
+    timer_teardown = time.perf_counter()
+    report = {"brief_report": ba.brief_report(),
+              "wall_times": {"setup": timer_setup - start, "run": timer_run - timer_setup, "teardown": timer_teardown - timer_run},
+              "num_images": len(interior), "num_interior_images": len(interior), "num_boundary_images": len(boundary),
+              "num_other_images": len(reconstruction.shots) - len(interior) - len(boundary), "num_points": len(pt_ids),
+              "num_reprojections": added_reprojections}
+    return pt_ids, report
+
+
+def bundle_shot_poses(reconstruction, shot_ids, camera_priors: Dict[str, Any], rig_camera_priors: Dict[str, Any],
+                      config: Optional[Dict[str, Any]] = None) -> Dict[str, Any]:
+    """``pysfm.BAHelpers.bundle_shot_poses`` (ba_helpers.cc:408-579; ``reconstruction.bundle_shot_poses``, reconstruction.py:89-104):
+    ten LM iterations over the poses of the rig instances of ``shot_ids`` only -- cameras, rig cameras and every point they see
+    constant (resection refinement of a newly added image); updates the reconstruction in place and returns the report"""
+    start = time.perf_counter()
+    shot_ids = set(shot_ids)
+    ba = _bundle.BundleAdjuster()
+    ba.set_use_analytic_derivatives(bool(_cfg(config, "bundle_analytic_derivatives")))
+    rig_instance_ids = sorted({_instance_id(reconstruction.shots[s]) for s in shot_ids})
+    rig_camera_ids, camera_ids = set(), set()
+    for rig_instance_id in rig_instance_ids:
+        for shot_id, rig_camera_id in reconstruction.rig_instances[rig_instance_id].rig_camera_ids.items():
+            rig_camera_ids.add(rig_camera_id)
+            camera_ids.add(reconstruction.shots[shot_id].camera.id)
+    for rig_camera_id in sorted(rig_camera_ids):
+        ba.add_rig_camera(rig_camera_id, reconstruction.rig_cameras[rig_camera_id].pose, rig_camera_priors[rig_camera_id].pose, True)
+    for camera_id in sorted(camera_ids):
+        ba.add_camera(camera_id, reconstruction.cameras[camera_id], camera_priors[camera_id], True)
+    landmarks = set()
+    for shot_id in sorted(shot_ids):
+        for lm_id, _ in _shot_observations(reconstruction.shots[shot_id]):
+            if lm_id not in landmarks:
+                landmarks.add(lm_id)
+                ba.add_point(lm_id, reconstruction.points[lm_id].coordinates, True)
+    _add_instances(ba, reconstruction, rig_instance_ids, lambda sid: sid in shot_ids, config)
+    for shot_id in sorted(shot_ids):
+        for lm_id, obs in _shot_observations(reconstruction.shots[shot_id]):
+            ba.add_point_projection_observation(shot_id, lm_id, obs.point, obs.scale, optional_value(getattr(obs, "depth_prior", None)))
+    _set_internal_priors_and_loss(ba, config)
+    ba.set_max_num_iterations(10)
+    ba.set_linear_solver_type("DENSE_QR")
+    timer_setup = time.perf_counter()
+    ba.run()
+    timer_run = time.perf_counter()
+    for rig_instance_id in rig_instance_ids:
+        reconstruction.rig_instances[rig_instance_id].pose = ba.get_rig_instance_pose(rig_instance_id)
+    timer_teardown = time.perf_counter()
+    return {"brief_report": ba.brief_report(),
+            "wall_times": {"setup": timer_setup - start, "run": timer_run - timer_setup, "teardown": timer_teardown - timer_run}}

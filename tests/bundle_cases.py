@@ -260,3 +260,89 @@ def case_adapter_rig_gps_bias_gcp(n_instances=24):
     cfg = {"bundle_use_gcp": True, "bundle_compensate_gps_bias": True, "align_method": "naive", "bundle_max_iterations": 50}
     rep = opensfm_adapter.bundle(r, cams, rigs, gcp, cfg)
     return prob, r, rep
+
+
+# ---- local / pose-only bundle adjustment over reconstruction objects (reconstruction.py:89-149) ----
+def _local_scene(n_instances=14, n_points=260, seed=21):
+    models = ("perspective",)
+    prob = scene(models, rig=False, gps=True, free_cameras=False, px_noise=1e-4, outlier_frac=0.0, n_instances=n_instances, n_points=n_points, seed=seed)
+    r = reconstruction_from_problem(prob, models, gps_accuracy=5.0)
+    cams, rigs = priors_from_problem(prob, models)
+    return prob, r, cams, rigs
+
+
+def _interior_rmse(r, shots):
+    e = []
+    for sid in shots:
+        shot = r.shots[sid]
+        for lm_id, obs in shot.get_landmark_observations().items():
+            Xc = shot.pose.transform(r.points[lm_id].coordinates)
+            k1, k2, f = shot.camera.k1, shot.camera.k2, shot.camera.focal
+            u, v = Xc[0] / Xc[2], Xc[1] / Xc[2]
+            d = 1 + (u * u + v * v) * (k1 + k2 * (u * u + v * v))
+            e.append([f * d * u - obs.point[0], f * d * v - obs.point[1]])
+    return float(np.sqrt((np.asarray(e) ** 2).sum(1).mean()))
+
+
+def case_bundle_local():
+    """``pysfm.BAHelpers.bundle_local`` over map objects: the neighbourhood is the reference's (checked against a brute-force count of
+    shared points), only the interior instances and the points they see move, the boundary and everything else stay bit for bit"""
+    prob, r, cams, rigs = _local_scene()
+    cfg = {"local_bundle_radius": 3, "local_bundle_min_common_points": 8, "local_bundle_max_shots": 5, "bundle_use_gps": True}
+    central = "s006"
+    interior, boundary = opensfm_adapter.shot_neighborhood_ids(r, central, 3, 8, 5)
+    # brute force: grow by the shots sharing the most points with the current interior
+    seen = {sid: set(s.get_landmark_observations()) for sid, s in r.shots.items()}
+    want = {central}
+    for _ in range(2):
+        if len(want) >= 5:
+            break
+        pts = set().union(*(seen[s] for s in want))
+        ranked = sorted(((-len(seen[s] & pts), s) for s in r.shots if s not in want and seen[s] & pts))
+        want |= {s for n, s in ranked[: 5 - len(want)] if -n >= 8}
+    assert interior == want and central in interior and 2 <= len(interior) <= 5
+    pts = set().union(*(seen[s] for s in interior))
+    assert boundary == {s for s in r.shots if s not in interior and seen[s] & pts} and boundary
+    poses0 = {k: inst.pose.cam_to_world_parameters().copy() for k, inst in r.rig_instances.items()}
+    points0 = {k: p.coordinates.copy() for k, p in r.points.items()}
+    rm0 = _interior_rmse(r, interior)
+    pt_ids, rep = opensfm_adapter.bundle_local(r, cams, rigs, [], central, cfg)
+    assert set(pt_ids) == pts and len(pt_ids) == len(set(pt_ids)) == rep["num_points"]
+    assert rep["num_interior_images"] == len(interior) and rep["num_boundary_images"] == len(boundary)
+    assert rep["num_other_images"] == len(r.shots) - len(interior) - len(boundary) and set(rep["wall_times"]) == {"setup", "run", "teardown"}
+    assert rep["num_reprojections"] == sum(len(seen[s]) for s in interior) + sum(len(seen[s] & pts) for s in boundary)
+    # (the poses of interior AND boundary instances are written back, ba_helpers.cc:270-274: a constant one returns through the pose
+    # conversions, equal to rounding)
+    moved = {k for k, inst in r.rig_instances.items() if np.abs(inst.pose.cam_to_world_parameters() - poses0[k]).max() > 1e-12}
+    assert moved == {"i%d" % int(s[1:]) for s in interior}
+    untouched = set(r.rig_instances) - {"i%d" % int(s[1:]) for s in interior | boundary}
+    assert all(np.array_equal(r.rig_instances[k].pose.cam_to_world_parameters(), poses0[k]) for k in untouched)
+    assert {k for k, p in r.points.items() if not np.array_equal(p.coordinates, points0[k])} <= pts
+    assert _interior_rmse(r, interior) < 0.7 * rm0
+    assert all(set(r.points[k].reprojection_errors) == {s for s in (interior | boundary) if k in seen[s]} for k in pt_ids)
+    return r, rep, interior, boundary
+
+
+def case_bundle_shot_poses():
+    """``pysfm.BAHelpers.bundle_shot_poses``: two displaced shots are pulled back onto the (constant) points; nothing else moves"""
+    prob, r, cams, rigs = _local_scene(seed=22)
+    # a reconstruction at the optimum of everything else: the ground truth
+    for k, v in enumerate(prob["gt_rig_instance"]):
+        r.rig_instances["i%d" % k].pose = Pose.from_cam_to_world(v[:3], v[3:])
+    for k, X in enumerate(prob["gt_points"]):
+        r.points["p%d" % k].coordinates = np.array(X)
+    targets = ["s004", "s005"]
+    truth = {s: r.shots[s].rig_instance.pose.cam_to_world_parameters().copy() for s in targets}
+    for s in targets:
+        v = truth[s] + np.r_[0.01, -0.008, 0.006, 0.05, -0.04, 0.03]
+        r.shots[s].rig_instance.pose = Pose.from_cam_to_world(v[:3], v[3:])
+    poses0 = {k: inst.pose.cam_to_world_parameters().copy() for k, inst in r.rig_instances.items()}
+    points0 = {k: p.coordinates.copy() for k, p in r.points.items()}
+    rep = opensfm_adapter.bundle_shot_poses(r, targets, cams, rigs, {"bundle_use_gps": False})
+    assert set(rep) == {"brief_report", "wall_times"}
+    for s in targets:
+        assert np.abs(r.shots[s].rig_instance.pose.cam_to_world_parameters() - truth[s]).max() < 2e-3
+    assert all(np.array_equal(inst.pose.cam_to_world_parameters(), poses0[k]) for k, inst in r.rig_instances.items() if k not in ("i4", "i5"))
+    assert all(np.abs(r.rig_instances[k].pose.cam_to_world_parameters() - poses0[k]).max() > 1e-3 for k in ("i4", "i5"))
+    assert all(np.array_equal(p.coordinates, points0[k]) for k, p in r.points.items())
+    return r, rep

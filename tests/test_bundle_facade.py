@@ -256,3 +256,13 @@ def test_gcp_weights(cpu_solver):
     prior = [c for c in calls if c[0] == "prior"][0][1]
     assert prior[0] == "gcp-g" and np.allclose(prior[1], [1, 2, 0]) and np.allclose(prior[2], np.array([0.01, 0.01, 0.1]) / weight) and prior[3] is False
     assert [c[1] for c in calls if c[0] == "obs"] == [pytest.approx(0.001 / weight)] * 3
+
+
+def test_bundle_local_over_map_objects(cpu_solver):
+    """pysfm.BAHelpers.bundle_local / shot_neighborhood_ids as reconstruction.py:107-149 call them (the solver: the CPU oracle)"""
+    cases.case_bundle_local()
+
+
+def test_bundle_shot_poses_over_map_objects(cpu_solver):
+    """pysfm.BAHelpers.bundle_shot_poses as reconstruction.py:89-104 calls it"""
+    cases.case_bundle_shot_poses()

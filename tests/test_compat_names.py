@@ -47,8 +47,15 @@ def test_signatures_follow_the_pybind_definitions():
     p = compat.pyrobust.RobustEstimatorParams()
     assert (p.iterations, p.probability, p.use_local_optimization, p.use_iteration_reduction) == (100, 0.99, True, True)
     assert [m.name for m in compat.pyrobust.RansacType] == ["RANSAC", "MSAC", "LMedS"]
-    for name in ("bundle", "bundle_to_map", "detect_alignment_constraints", "add_gcp_to_bundle"):
+    for name in ("bundle", "bundle_local", "bundle_shot_poses", "shot_neighborhood_ids", "bundle_to_map", "detect_alignment_constraints", "add_gcp_to_bundle"):
         assert callable(getattr(compat.pysfm.BAHelpers, name))
+    # argument order of sfm/ba_helpers.h:15-49 as pybind11 exposes it
+    assert list(inspect.signature(compat.pysfm.BAHelpers.bundle_local).parameters)[:6] == ["reconstruction", "camera_priors", "rig_camera_priors", "gcp",
+                                                                                           "central_shot_id", "config"]
+    assert list(inspect.signature(compat.pysfm.BAHelpers.bundle_shot_poses).parameters)[:5] == ["reconstruction", "shot_ids", "camera_priors",
+                                                                                                "rig_camera_priors", "config"]
+    assert list(inspect.signature(compat.pysfm.BAHelpers.shot_neighborhood_ids).parameters)[:5] == ["reconstruction", "central_shot_id", "radius",
+                                                                                                    "min_common_points", "max_interior_size"]
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="the reference is not mounted")
@@ -64,7 +71,7 @@ def test_names_exist_in_the_references_bindings():
     for field in ("iterations", "probability", "use_local_optimization", "use_iteration_reduction", "score", "model", "lo_model", "inliers_indices"):
         assert f'"{field}"' in rob
     sfm = defined("sfm/python/pybind.cc", r'def_static\("(\w+)"')
-    assert {"bundle", "bundle_to_map", "detect_alignment_constraints", "add_gcp_to_bundle"} <= sfm
+    assert {"bundle", "bundle_local", "bundle_shot_poses", "shot_neighborhood_ids", "bundle_to_map", "detect_alignment_constraints", "add_gcp_to_bundle"} <= sfm
     bundle_methods = defined("bundle/python/pybind.cc", r'\.def\("(\w+)"')
     ours = {n for n, f in inspect.getmembers(compat.pybundle.BundleAdjuster, callable) if not n.startswith("_")}
     needed = {"run", "add_camera", "get_camera", "add_rig_camera", "get_rig_camera_pose", "add_rig_instance", "get_rig_instance_pose",

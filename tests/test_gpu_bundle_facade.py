@@ -107,3 +107,19 @@ def test_pan_tilt_roll_priors_match_the_oracle(gpu_ctx, oracle_lib, monkeypatch)
         assert np.allclose(g.get_rig_instance_pose("1").cam_to_world_parameters(), o.get_rig_instance_pose("1").cam_to_world_parameters(), atol=1e-9)
         assert g._report["iterations"] == o._report["iterations"]
         assert np.allclose(g._report["cost_history"], o._report["cost_history"], rtol=1e-9, atol=1e-18)
+
+
+def test_bundle_local_and_shot_poses_over_map_objects(gpu_ctx, oracle_lib, monkeypatch):
+    """pysfm.BAHelpers.bundle_local / bundle_shot_poses (reconstruction.py:89-127) on the real solver == the same flows with the oracle"""
+    rg, rep_g, interior, _ = cases.case_bundle_local()
+    sg, _ = cases.case_bundle_shot_poses()
+    monkeypatch.setattr(bundle, "bundle_general_arrays", cases.oracle_solver(oracle_lib))
+    monkeypatch.setattr(bundle.BundleAdjuster, "_streaming_form", staticmethod(lambda prob: None))
+    ro, rep_o, interior_o, _ = cases.case_bundle_local()
+    so, _ = cases.case_bundle_shot_poses()
+    assert interior == interior_o and rep_g["num_reprojections"] == rep_o["num_reprojections"]
+    for a, b in ((rg, ro), (sg, so)):
+        for k in a.rig_instances:
+            assert np.allclose(a.rig_instances[k].pose.cam_to_world_parameters(), b.rig_instances[k].pose.cam_to_world_parameters(), atol=1e-7)
+        for k in a.points:
+            assert np.allclose(a.points[k].coordinates, b.points[k].coordinates, atol=1e-7)
