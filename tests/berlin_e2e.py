@@ -65,7 +65,97 @@ def run(extract, match_pairs, create_tracks):
     ea = np.concatenate([off[PAIRS[p, 0]] + np.asarray(matches[p], np.int64).reshape(-1, 2)[:, 0] for p in range(len(PAIRS))])
     eb = np.concatenate([off[PAIRS[p, 1]] + np.asarray(matches[p], np.int64).reshape(-1, 2)[:, 1] for p in range(len(PAIRS))])
     ntr, ot, oi, of = create_tracks(ea.astype(np.int32), eb.astype(np.int32), off, CONFIG["min_track_length"])
-    return feats, matches, (ntr, ot, oi, of), compare(feats, (ntr, ot, oi, of), ref)
+    rep = compare(feats, (ntr, ot, oi, of), ref)
+    rep["missing_edges"] = classify_missing_edges(feats, matches, (ntr, ot, oi, of), ref)
+    return feats, matches, (ntr, ot, oi, of), rep
+
+
+def _reference_candidates(feats, ref):
+    """per row of the reference file: our features at its (x, y, scale) -- see compare()"""
+    from scipy.spatial import cKDTree
+
+    cands = [[] for _ in range(len(ref["track"]))]
+    for k in range(len(feats)):
+        sel = np.flatnonzero(ref["image"] == k)
+        hits = cKDTree(feats[k][0][:, :2]).query_ball_point(ref["xys"][sel, :2], 1e-6)
+        for r, h in zip(sel, hits):
+            cands[r] = [int(i) for i in h if abs(feats[k][0][i, 2] - ref["xys"][r, 2]) < 1e-6]
+    return cands
+
+
+def classify_missing_edges(feats, matches, tracks, ref, ratio=None):
+    """Why is an edge of data/berlin/tracks_example.csv (two rows of one of its tracks) not an edge of ours?  Every such edge gets the FIRST
+    reason that applies, walking the pipeline in order:
+
+      feature_missing    one of its two rows has no feature of ours at its (x, y, scale)                       [extraction]
+      nn_differs         the exact mutual nearest neighbours (L2 over the 128 root-HAHOG levels) do not pair the two features: the
+                         file's matcher (FLANN's randomised kd-forest at the time) returned a neighbour the exhaustive search does not,
+                         or the edge is transitive in the file (the two images were linked through the third)  [approximate search]
+      ratio_test         they ARE mutual nearest neighbours, but d1 < ratio * d2 fails in one direction with the exact second
+                         neighbour (an approximate search that misses the true second neighbour passes it)       [approximate search]
+      ransac_rejected    the pair passes the symmetric ratio test and the F-RANSAC restatement (oracle/ransac_oracle.c, on the GPU
+                         ransac.hip) drops it -- the only share that speaks about the cv2.findFundamentalMat restatement [robust stage]
+      track_stage        the match survives RANSAC and the edge is still missing: our track was dropped or split by the track
+                         filter (an image twice in a track, tracking.py:100-115)                                 [tracks]
+
+    Returns counts and shares over the missing edges (with both rows found / in all)."""
+    ratio = CONFIG["lowes_ratio"] if ratio is None else ratio
+    ntr, ot, oi, of = tracks
+    cands = _reference_candidates(feats, ref)
+    track_of = {(int(im), int(f)): int(t) for t, im, f in zip(ot, oi, of)}
+    kept = {}
+    for p, (a, b) in enumerate(PAIRS):
+        kept[(int(a), int(b))] = set(map(tuple, np.asarray(matches[p], np.int64).reshape(-1, 2).tolist()))
+    # exact top-2 in both directions for every image pair (fp32 squared distances on the integer-valued levels: exact)
+    top = {}
+    for a, b in PAIRS:
+        A, B = feats[a][1].astype(np.float64), feats[b][1].astype(np.float64)
+        d = (A * A).sum(1)[:, None] + (B * B).sum(1)[None, :] - 2.0 * (A @ B.T)
+        for (x, y, dm) in ((int(a), int(b), d), (int(b), int(a), d.T)):
+            idx = np.argpartition(dm, 1, axis=1)[:, :2]
+            dd = np.take_along_axis(dm, idx, 1)
+            sw = dd[:, 0] > dd[:, 1]
+            idx[sw] = idx[sw][:, ::-1]
+            dd[sw] = dd[sw][:, ::-1]
+            top[(x, y)] = (idx[:, 0], np.sqrt(np.maximum(dd, 0.0)))
+    out = {k: 0 for k in ("feature_missing", "nn_differs", "ratio_test", "ransac_rejected", "track_stage")}
+    missing = 0
+    for t in np.unique(ref["track"]):
+        rows = np.flatnonzero(ref["track"] == t)
+        for ia in range(len(rows)):
+            for ib in range(ia + 1, len(rows)):
+                ra, rb = rows[ia], rows[ib]
+                ka, kb = int(ref["image"][ra]), int(ref["image"][rb])
+                if ka == kb:
+                    continue
+                if ka > kb:
+                    ra, rb, ka, kb = rb, ra, kb, ka
+                ta = {track_of[(ka, f)] for f in cands[ra] if (ka, f) in track_of}
+                tb = {track_of[(kb, f)] for f in cands[rb] if (kb, f) in track_of}
+                if ta & tb:
+                    continue
+                missing += 1
+                if not cands[ra] or not cands[rb]:
+                    out["feature_missing"] += 1
+                    continue
+                (nn_ab, d_ab), (nn_ba, d_ba) = top[(ka, kb)], top[(kb, ka)]
+                pairs = [(fa, fb) for fa in cands[ra] for fb in cands[rb]]
+                mutual = [(fa, fb) for fa, fb in pairs if nn_ab[fa] == fb and nn_ba[fb] == fa]
+                if not mutual:
+                    out["nn_differs"] += 1
+                    continue
+                passing = [(fa, fb) for fa, fb in mutual if d_ab[fa, 0] < ratio * d_ab[fa, 1] and d_ba[fb, 0] < ratio * d_ba[fb, 1]]
+                if not passing:
+                    out["ratio_test"] += 1
+                    continue
+                if not any(pq in kept[(ka, kb)] for pq in passing):
+                    out["ransac_rejected"] += 1
+                    continue
+                out["track_stage"] += 1
+    found = missing - out["feature_missing"]
+    rep = {"missing_edges": missing, "counts": dict(out), "share_of_missing": {k: v / max(1, missing) for k, v in out.items()},
+           "share_of_missing_with_features": {k: v / max(1, found) for k, v in out.items() if k != "feature_missing"}}
+    return rep
 
 
 def compare(feats, tracks, ref):

@@ -8,8 +8,15 @@ import pytest
 import berlin_e2e
 import oracle
 
-# measured with this flow (tests/berlin_e2e.py): 0.981 / 0.887 / 0.867; the exact matcher cannot reproduce FLANN's misses
+# REGRESSION GUARDS, not parity statements: measured with this flow (tests/berlin_e2e.py) 0.981 / 0.887 / 0.867, set a margin below.
+# What the 11.3 % of the file's track edges that are NOT reproduced (222 of 1 971) are made of is measured by
+# berlin_e2e.classify_missing_edges and asserted below: 67 an endpoint feature absent (extraction), 51 + 74 the exact mutual nearest
+# neighbour / the exact ratio test disagree with what the file's approximate (FLANN) search returned, 29 rejected by the F-RANSAC
+# restatement, 1 lost in the track filter.  The robust stage -- the cv2.findFundamentalMat-shaped part -- accounts for 13 % of the gap
+# = 1.5 % of the file's edges; the descriptor stage's share is the approximate search's, not the float accumulation order's (the
+# root-HAHOG levels are integers: every order gives the same distances).
 MIN_FEATURE_ROWS, MIN_REF_EDGES, MIN_OUR_EDGES = 0.975, 0.87, 0.85
+MAX_RANSAC_SHARE_OF_GAP, MAX_RANSAC_SHARE_OF_EDGES = 0.20, 0.02
 
 
 def oracle_extract(gray, cfg):
@@ -28,6 +35,11 @@ def check_report(rep):
     assert rep["ref_track_edges_reproduced"] >= MIN_REF_EDGES, rep
     assert rep["our_track_edges_in_ref"] >= MIN_OUR_EDGES, rep
     assert abs(rep["tracks"] - rep["ref_tracks"]) <= 0.05 * rep["ref_tracks"], rep
+    gap = rep["missing_edges"]
+    assert sum(gap["counts"].values()) == gap["missing_edges"] == round((1 - rep["ref_track_edges_reproduced"]) * rep["ref_track_edges"]), gap
+    assert gap["share_of_missing"]["ransac_rejected"] <= MAX_RANSAC_SHARE_OF_GAP, gap
+    assert gap["counts"]["ransac_rejected"] <= MAX_RANSAC_SHARE_OF_EDGES * rep["ref_track_edges"], gap
+    assert gap["counts"]["track_stage"] <= 5, gap
 
 
 @pytest.mark.skipif(oracle.build_hahog_ref() is None, reason="needs the reference HAHOG compiled from /root/reference")
