@@ -3503,6 +3503,9 @@ struct Solver {
   void rot(const double *poses) { hipLaunchKernelGGL(shot_rot_kernel, dim3(nblk(d.S, 64)), dim3(64), 0, st, d, poses); }
 
   // ---- generic mode (kernels: ba_generic.inc) ----
+  int *g_cols = nullptr, *g_col_pos = nullptr;  // generic exact border: the border columns some view holds, and their positions (-1: none)
+  int g_ncols = 0;
+  double *g_wB = nullptr, *g_vpartB = nullptr;  // rows x ncols x NR, views x ncols x KW
   bool have_bpri = false;  // a prior couples an instance with a free border block (position prior with a free bias, up vector / compass with a free rig camera)
 #define OSFM_GEN_KW(NRV, KERNEL, grid, block, stream, ...)                                                    \
   do {                                                                                                        \
@@ -3574,6 +3577,29 @@ struct Solver {
     }
     OSFM_GEN_NR_KW(gen_schur_shot_kernel, dim3(d.S), dim3(64), sq, d);
     if (d.g.NB > 0) hipLaunchKernelGGL(gen_border_reduce_kernel, dim3(d.g.NB), dim3(256), 0, sq, d, 2 * d.g.KW, 0, 0);
+  }
+  // every column of the border in one pass over the observations (kernels at the end of ba_generic.inc) into Bc / dCm, on stream sq
+  template <int NRV, int KWT, int CH>
+  void gen_border_chunks(hipStream_t sq) {
+    for (int c0 = 0; c0 < g_ncols; c0 += CH)
+      hipLaunchKernelGGL((gen_border_shot_kernel<NRV, KWT, CH>), dim3(d.S), dim3(64), 0, sq, d, (const int *)g_cols, g_ncols, c0, (const double *)g_wB, Bc, g_vpartB);
+  }
+  template <int NRV>
+  void gen_border_columns_nr(hipStream_t sq) {
+    if (d.M > 0 && g_ncols > 0) {
+      hipLaunchKernelGGL(gen_border_point_kernel<NRV>, dim3(d.nwg), dim3(kCoopObs), 0, sq, d, (const int *)g_cols, g_ncols, g_wB);
+      if (d.g.KW <= 4) gen_border_chunks<NRV, 4, 4>(sq);
+      else if (d.g.KW <= 9) gen_border_chunks<NRV, 9, 3>(sq);
+      else if (d.g.KW <= 16) gen_border_chunks<NRV, 16, 2>(sq);
+      else gen_border_chunks<NRV, kGenMaxKW, 2>(sq);
+    }
+  }
+  void gen_border_columns(double radius, hipStream_t sq) {
+    if (d.g.NRr == 3) gen_border_columns_nr<3>(sq);
+    else gen_border_columns_nr<2>(sq);
+    const int NB = d.g.NB;
+    hipLaunchKernelGGL(gen_border_finish_kernel, dim3(NB * NB + nblk((long)NB * 6 * d.S)), dim3(256), 0, sq, d, (const int *)g_col_pos, std::max(1, g_ncols),
+                       (const double *)g_vpartB, Bc, dCm, radius, have_bpri ? 1 : 0);
   }
   void gen_matvec(const double *x, double *out, double radius, hipStream_t sq) {
     hipLaunchKernelGGL(scale_vec_kernel, dim3(nblk(d.nred)), dim3(TPB), 0, sq, d.sc_red, x, d.y, d.nred);
@@ -4198,6 +4224,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
   d.gen = gen ? 1 : 0;
   GenDev &g = d.g;
   std::vector<int> inst_view0;
+  std::vector<unsigned char> gen_col_slot_host;
   if (gen) {  // border columns: free rig cameras, free cameras, free biases; per view the slots its rows touch
     const int NV = G->NV, NRC = G->NRC;
     g.NV = NV;
@@ -4269,6 +4296,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     g.view_cam = A.upload(G->view_cam, (size_t)NV, e);
     g.view_col = A.upload(view_col.data(), view_col.size(), e);
     g.col_slot = A.upload(col_slot.data(), col_slot.size(), e);
+    gen_col_slot_host = col_slot;
     g.inst_view0 = A.upload(inst_view0.data(), inst_view0.size(), e);
     g.cam_col = A.upload(cam_col.data(), (size_t)NC, e);
     g.rc_col = A.upload(rc_col.data(), (size_t)NRC, e);
@@ -4650,6 +4678,22 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     if (!gen) {
       sv.wB = A.alloc<double>((size_t)2 * 3 * NC * M, e);
       sv.partB = A.alloc<double>((size_t)S * 9 * NC, e);
+    } else {
+      std::vector<int> cols, col_pos((size_t)nbord, -1);
+      for (int j = 0; j < nbord; j++) {
+        bool held = false;
+        for (int v = 0; v < G->NV && !held; v++) held = gen_col_slot_host[(size_t)j * G->NV + v] != 255;
+        if (held) {
+          col_pos[(size_t)j] = (int)cols.size();
+          cols.push_back(j);
+        }
+      }
+      sv.g_ncols = (int)cols.size();
+      if (cols.empty()) cols.push_back(0);
+      sv.g_cols = A.upload(cols.data(), cols.size(), e);
+      sv.g_col_pos = A.upload(col_pos.data(), col_pos.size(), e);
+      sv.g_wB = A.alloc<double>((size_t)std::max<long>(1, M) * std::max(1, sv.g_ncols) * g.NRr, e);
+      sv.g_vpartB = A.alloc<double>((size_t)std::max(1, G->NV) * std::max(1, sv.g_ncols) * std::max(1, g.KW), e);
     }
   }
   bool border_ok = getenv("OSFM_BA_NO_BORDER") == nullptr;  // exact camera border: every camera free (generic mode: the border holds free blocks only)
@@ -4814,7 +4858,9 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
         OSFM_HIP(hipEventRecord(sv.ev_fork, st));
         OSFM_HIP(hipStreamWaitEvent(sv.st2, sv.ev_fork, 0));
       }
-      if (want_border && gen) {  // column j of the reduced matrix = the mat-vec of the unit vector e_(cam0 + j): its instance rows are B's, its border rows C's
+      if (want_border && gen && getenv("OSFM_BA_BORDER_BY_MATVECS") == nullptr) {
+        sv.gen_border_columns(radius, sx);
+      } else if (want_border && gen) {  // (self-check knob) column j = the mat-vec of the unit vector e_(cam0 + j): its instance rows are B's, its border rows C's
         for (int j = 0; j < nbord; j++) {
           hipLaunchKernelGGL(unit_vec_kernel, dim3(nbr), dim3(TPB), 0, sx, d.p, nred, d.cam0 + j);
           sv.gen_matvec(d.p, d.Ap, radius, sx);
