@@ -399,8 +399,8 @@ class BundleAdjuster:
         depth = None
         if depth_prior is not None:
             depth = (float(depth_prior.value), float(depth_prior.std_deviation), bool(depth_prior.is_radial))
-            if not np.isfinite(depth[0]):
-                raise RuntimeError(str(shot) + " has non-finite depth prior")  # bundle_adjuster.cc:508-511 (thrown from Run)
+            if not depth[1] > 0:  # the reference scales the residual by 1 / sd whatever it is; the C ABI reads sd <= 0 as "no prior": say so
+                raise ValueError("depth prior of shot %s / point %s has std_deviation %r (must be > 0)" % (shot, point, depth[1]))
         self._obs.append((shot, point, float(observation[0]), float(observation[1]), float(std_deviation), depth))
 
     def _shot_prior(self, key, shot_id, value, std_deviation):
@@ -577,6 +577,9 @@ class BundleAdjuster:
 
         if not self._cams or not self._rig_cameras or not self._instances or not self._shots:
             raise RuntimeError("BundleAdjuster.run: nothing to adjust")
+        for o in self._obs:  # thrown from Run, with the shot id, as bundle_adjuster.cc:508-511 does
+            if o[5] is not None and not np.isfinite(o[5][0]):
+                raise RuntimeError(str(o[0]) + " has non-finite depth prior")
         prob = self._problem()
         cfg = {"loss_function": self._loss[0], "loss_function_threshold": self._loss[1], "bundle_max_iterations": self._max_iter}
         stream = None if self.force_general else self._streaming_form(prob)

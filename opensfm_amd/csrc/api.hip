@@ -163,6 +163,10 @@ static int store_upload(osfm_store *s, const T *desc, const double *pts) {
     integral = (v >= 0.0 && v <= 255.0) && v == std::floor(v);
   }
   s->is_float = !integral;
+  // a segmentation column (osfm_store_set_segmentation) is defined on integer-valued descriptors only: the exact int8 kernel it selects
+  // would run on the QUANTISED tiles of a float store and return wrong distances without a word
+  OSFM_REQUIRE(integral || !s->d_seg, OSFM_E_UNSUPPORTED,
+               "osfm_store_upload: the store holds a segmentation column and the new descriptors are not integer-valued (feature_loading.py:126-133)");
   std::vector<float> descf;
   // float store: next to the float rows an 8-bit quantisation on the store's value range [lo, hi]; ||x^_q - x^_t|| differs from the
   // (scaled) float distance by at most the two rows' residual norms, which the fused kernel turns into rigorous accept / reject

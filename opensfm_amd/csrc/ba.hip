@@ -4781,7 +4781,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     // matrix-core assembly fills the CUs (four workgroups of 39 KB LDS each), and the side stream starts after it, beside the cyclic
     // reduction's levels -- one 117 KB workgroup per CU, which leaves the CU room for a border workgroup
     int fork_at = win_band ? 1 : 0;  // 0: before the assembly, 1: after it, 2: after the first level of the cyclic reduction
-    if (const char *fk = getenv("OSFM_BA_FORK")) fork_at = fk[0] - '0';
+    if (const char *fk = getenv("OSFM_BA_FORK")) fork_at = std::min(2, std::max(0, fk[0] - '0'));
     const bool fork_late = fork_at >= 1;
     if (sv.st2 && !fork_late) {
       OSFM_HIP(hipEventRecord(sv.ev_fork, st));

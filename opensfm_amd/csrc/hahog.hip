@@ -1336,9 +1336,12 @@ extern "C" int osfm_hahog_extract_batch(osfm_ctx *ctx, int n_images, const float
       err[(size_t)k] = "hipSetDevice failed in a worker thread";
       return;
     }
+    // (worker code may only take device memory through OsfmPoolBuf::alloc(ctx, ...) -- the block cache has its own mutex -- and never
+    // anything that locks the context: the caller holds ctx->mu while it waits in join())
     for (;;) {
+      if (rc[(size_t)k] != OSFM_OK) break;  // before the next index is taken: an image must not be skipped by a worker that has stopped
       const int i = next.fetch_add(1);
-      if (i >= n_images || rc[(size_t)k] != OSFM_OK) break;
+      if (i >= n_images) break;
       const int r = hahog_extract_on_stream(ctx, ctx->aux_streams[(size_t)k], images[i], rows[i], cols[i], peak_threshold, edge_threshold,
                                             target_num_features, flags, points[i], desc[i], capacities[i], &n_features[i]);
       if (r != OSFM_OK) {

@@ -780,6 +780,13 @@ def match_images_with_pairs(data, config_override: Dict[str, Any], exifs: Dict[s
     # HAHOG uchar descriptors over as float32 (features.py:169-170), like the reference's loader
     live = [np.asarray(d) for d in descs if len(d)]
     hamming = bool(live) and all(d.dtype == np.uint8 for d in live)
+    if hamming and live[0].shape[1] > 64:
+        # cv2's BruteForce-Hamming has no width cap, the binary store holds 64 bytes (AKAZE MLDB 61, ORB 32): wider uint8 rows are HAHOG /
+        # SIFT uchar levels a caller did not convert to float32 as the reference's loader does (features.py:169-170) -- matched as values
+        if config.get("feature_type", "HAHOG").upper() in ("AKAZE", "ORB"):
+            raise NotImplementedError("binary descriptors of %d bytes: the GPU Hamming matcher holds 1..64 bytes per descriptor" % live[0].shape[1])
+        hamming = False
+        descs = [np.asarray(d, np.float32) for d in descs]
     if hamming and (poses or use_words or use_segmentation or _matcher_flags(config) & _lib.MATCH_SQUARED_RATIO):
         raise NotImplementedError("binary (uint8) descriptors are on the GPU path for matcher_type BRUTEFORCE without poses / segmentation")
     if hamming:

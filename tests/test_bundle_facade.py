@@ -57,8 +57,11 @@ def test_pair_with_depth_priors(cpu_solver):
     pose = sb.get_rig_instance_pose("2")
     got = np.linalg.norm(pose.get_R_world_to_cam() @ sb.get_point("p1").p + pose.get_t_world_to_cam())
     assert abs(got - 1.5 * r2) < 1e-2 * r2  # the strong prior is met
-    with pytest.raises(RuntimeError):  # bundle_adjuster.cc:508-511
-        sa.add_point_projection_observation("1", "p2", np.array([0, 0]), 1, cases.Depth(float("nan"), True, 1.0))
+    sa.add_point_projection_observation("1", "p2", np.array([0, 0]), 1, cases.Depth(float("nan"), True, 1.0))
+    with pytest.raises(RuntimeError, match="1 has non-finite depth prior"):  # thrown from Run with the shot id, bundle_adjuster.cc:508-511
+        sa.run()
+    with pytest.raises(ValueError):  # a standard deviation <= 0 is refused, not silently read as "no prior"
+        sa.add_point_projection_observation("1", "p2", np.array([0, 0]), 1, cases.Depth(1.0, True, 0.0))
 
 
 def test_reference_void_gps_ignored(cpu_solver):
