@@ -22,7 +22,6 @@
 #include <vector>
 
 #include <rocprim/rocprim.hpp>
-#include <rocblas/rocblas.h>
 
 #include "ba_math.h"
 #include "osfm_internal.h"
@@ -3466,6 +3465,102 @@ __global__ void unpermute2_kernel(const int *perm, const double *in, long M, dou
   out[2 * o + 1] = in[2 * k + 1];
 }
 
+
+// ---- batched fp64 GEMM on the matrix cores (round 5: replaces rocblas_dgemm_strided_batched in the dense-cluster cyclic reduction) ----
+// C = alpha op(A) op(B) + beta C, column-major, `batch` problems a stride apart (grid z).  A workgroup of four wavefronts owns a 64 x 64
+// tile of C, a wavefront a 32 x 32 quarter = 2 x 2 accumulators of v_mfma_f64_16x16x4_f64 (lane l feeds A[l % 16][l / 16] and
+// B[l / 16][l % 16]; register r of lane l holds C[4 r + l / 16][l % 16]).  K advances 16 at a time through LDS: the 64 x 16 panel of
+// op(A) and the 16 x 64 panel of op(B) are stored k-major with a row stride of 80 doubles, so the sixteen lanes of one k read 32
+// consecutive banks and the next k starts 32 banks on -- a half-wavefront's operand read is conflict-free.  The panels of step s + 1
+// are fetched into registers before the products of step s are issued (one LDS buffer, two barriers per step).  Edges (m, n, k not
+// multiples of the tile) are zero-filled on the way in and masked on the way out.  Flops are what this path is about: at the block
+// survey's 612-wide clusters a level is 2 m^3 x (5 products + the trailing updates of the blocked inversion) per cluster.
+constexpr int kGemmLd = 80;
+typedef double gemm_v4d __attribute__((ext_vector_type(4)));
+template <bool TA, bool TB>
+__global__ void __launch_bounds__(256) dgemm_mfma_kernel(int m, int n, int k, double alpha, const double *A0, int lda, long sa, const double *B0, int ldb, long sb,
+                                                          double beta, double *C0, int ldc, long sc) {
+  __shared__ double As[16 * kGemmLd], Bs[16 * kGemmLd];
+  const double *A = A0 + (long)blockIdx.z * sa, *B = B0 + (long)blockIdx.z * sb;
+  double *C = C0 + (long)blockIdx.z * sc;
+  const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wi = 32 * (wave & 1), wj = 32 * (wave >> 1);
+  const int li = lane & 15, lk = lane >> 4;
+  // this thread's four elements of each panel per step: (row in the panel's k, column in its i / j)
+  double ra[4], rb[4];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      int ia, ka, kb, jb;
+      if (!TA) {  // op(A)[i][k] = A[i + k lda]: contiguous in i
+        ia = tid & 63;
+        ka = (tid >> 6) + 4 * q;
+      } else {  // op(A)[i][k] = A[k + i lda]: contiguous in k
+        ka = tid & 15;
+        ia = (tid >> 4) + 16 * q;
+      }
+      if (!TB) {  // op(B)[k][j] = B[k + j ldb]: contiguous in k
+        kb = tid & 15;
+        jb = (tid >> 4) + 16 * q;
+      } else {  // op(B)[k][j] = B[j + k ldb]: contiguous in j
+        jb = tid & 63;
+        kb = (tid >> 6) + 4 * q;
+      }
+      const bool oa = i0 + ia < m && k0 + ka < k, ob = j0 + jb < n && k0 + kb < k;
+      const long xa = !TA ? (long)(i0 + ia) + (long)(k0 + ka) * lda : (long)(k0 + ka) + (long)(i0 + ia) * lda;
+      const long xb = !TB ? (long)(k0 + kb) + (long)(j0 + jb) * ldb : (long)(j0 + jb) + (long)(k0 + kb) * ldb;
+      ra[q] = oa ? A[xa] : 0.0;
+      rb[q] = ob ? B[xb] : 0.0;
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int ia = !TA ? (tid & 63) : (tid >> 4) + 16 * q, ka = !TA ? (tid >> 6) + 4 * q : (tid & 15);
+      const int jb = !TB ? (tid >> 4) + 16 * q : (tid & 63), kb = !TB ? (tid & 15) : (tid >> 6) + 4 * q;
+      As[ka * kGemmLd + ia] = ra[q];
+      Bs[kb * kGemmLd + jb] = rb[q];
+    }
+  };
+  gemm_v4d acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++) acc[a][b] = (gemm_v4d){0.0, 0.0, 0.0, 0.0};
+  fetch(0);
+  for (int k0 = 0; k0 < k; k0 += 16) {
+    stage();
+    __syncthreads();
+    if (k0 + 16 < k) fetch(k0 + 16);
+#pragma unroll
+    for (int kk = 0; kk < 16; kk += 4) {
+      double va[2], vb[2];
+#pragma unroll
+      for (int a = 0; a < 2; a++) va[a] = As[(kk + lk) * kGemmLd + wi + 16 * a + li];
+#pragma unroll
+      for (int b = 0; b < 2; b++) vb[b] = Bs[(kk + lk) * kGemmLd + wj + 16 * b + li];
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[a], vb[b], acc[a][b], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int i = i0 + wi + 16 * a + 4 * r + lk, j = j0 + wj + 16 * b + li;
+        if (i < m && j < n) {
+          double *dst = C + (long)i + (long)j * ldc;
+          *dst = alpha * acc[a][b][r] + (beta == 0.0 ? 0.0 : beta * *dst);
+        }
+      }
+}
+
 #include "ba_generic.inc"
 
 struct Arena {
@@ -3674,7 +3769,16 @@ struct Solver {
     hipLaunchKernelGGL(wide_store_kernel<NR>, dim3(nblk(std::max<long>(6L * d.S, d.NC))), dim3(TPB), 0, st, d, rs);
   }
   // ---- dense-cluster cyclic reduction of the wide band (kernels: dbcr_*) ----
-  rocblas_handle blas = nullptr;
+  // C = alpha op(A) op(B) + beta C for `batch` column-major problems a stride apart (dgemm_mfma_kernel)
+  void dgemm_sb(bool ta, bool tb, int m, int n, int k, double alpha, const double *A, int lda, long sa, const double *B, int ldb, long sb, double beta, double *C,
+                int ldc, long sc, int batch) {
+    if (m <= 0 || n <= 0 || batch <= 0) return;
+    const dim3 grid((unsigned)((m + 63) / 64), (unsigned)((n + 63) / 64), (unsigned)batch);
+    if (!ta && !tb) hipLaunchKernelGGL((dgemm_mfma_kernel<false, false>), grid, dim3(256), 0, st, m, n, k, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc);
+    else if (ta && !tb) hipLaunchKernelGGL((dgemm_mfma_kernel<true, false>), grid, dim3(256), 0, st, m, n, k, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc);
+    else if (!ta && tb) hipLaunchKernelGGL((dgemm_mfma_kernel<false, true>), grid, dim3(256), 0, st, m, n, k, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc);
+    else hipLaunchKernelGGL((dgemm_mfma_kernel<true, true>), grid, dim3(256), 0, st, m, n, k, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc);
+  }
   // A_k <- A_k^-1 for `batch` SPD qm x qm blocks `strideA` apart: blocked Gauss-Jordan, panels of qT columns.  Per panel J:
   //   P = A_JJ^-1 (LDS), R = A_J,: and C = A_:,J copied (C's pivot rows zeroed);  Rn = P R;  A -= C Rn;  A_:,J = -C P;  A_J,: = Rn, A_JJ = P
   // look-ahead: stream st3 runs the pivot chain (dgj_pivot_ahead_kernel) beside the products of the panel before
@@ -3683,7 +3787,6 @@ struct Solver {
   int dbcr_invert_batch_ahead(double *A, long strideA, int batch, int *d_status) {
     const int m = d.qm, T = d.qT;
     const double one = 1.0, neg = -1.0, zero = 0.0;
-    auto ok = [](rocblas_status r) { return r == rocblas_status_success; };
     const long sP = (long)T * T, sR = (long)T * m;
     const size_t lds = (size_t)2 * kWB * kWLd * sizeof(double);
     double *Pb[2] = {d.qP, d.qP2};
@@ -3695,9 +3798,7 @@ struct Solver {
       double *P = Pb[J & 1];
       const int ncopy = (int)std::min<long>(64, ((long)w * m + 255) / 256);
       hipLaunchKernelGGL(dgj_copy_kernel, dim3(ncopy, batch), dim3(256), 0, st, (const double *)A, strideA, m, T, j0, w, jn, wn, d.qR, d.qC, d.qBn);
-      OSFM_REQUIRE(ok(rocblas_dgemm_strided_batched(blas, rocblas_operation_none, rocblas_operation_none, w, m, w, &one, P, T, sP, d.qR, T, sR, &zero, d.qRn, T,
-                                                    sR, batch)),
-                   OSFM_E_HIP, "rocblas_dgemm_strided_batched failed");
+      dgemm_sb(false, false, w, m, w, one, P, T, sP, d.qR, T, sR, zero, d.qRn, T, sR, batch);
       if (wn > 0) {
         OSFM_HIP(hipEventRecord(ev_rn[J & 1], st));
         OSFM_HIP(hipStreamWaitEvent(st3, ev_rn[J & 1], 0));
@@ -3705,12 +3806,8 @@ struct Solver {
                            (const double *)d.qRn, (const double *)d.qBn, Pb[(J + 1) & 1], d_status);
         OSFM_HIP(hipEventRecord(ev_p[(J + 1) & 1], st3));
       }
-      OSFM_REQUIRE(ok(rocblas_dgemm_strided_batched(blas, rocblas_operation_none, rocblas_operation_none, m, m, w, &neg, d.qC, m, sR, d.qRn, T, sR, &one, A, m,
-                                                    strideA, batch)),
-                   OSFM_E_HIP, "rocblas_dgemm_strided_batched failed");
-      OSFM_REQUIRE(ok(rocblas_dgemm_strided_batched(blas, rocblas_operation_none, rocblas_operation_none, m, w, w, &neg, d.qC, m, sR, P, T, sP, &zero,
-                                                    A + (long)j0 * m, m, strideA, batch)),
-                   OSFM_E_HIP, "rocblas_dgemm_strided_batched failed");
+      dgemm_sb(false, false, m, m, w, neg, d.qC, m, sR, d.qRn, T, sR, one, A, m, strideA, batch);
+      dgemm_sb(false, false, m, w, w, neg, d.qC, m, sR, P, T, sP, zero, A + (long)j0 * m, m, strideA, batch);
       hipLaunchKernelGGL(dgj_scatter_kernel, dim3((unsigned)(((long)w * m + 255) / 256), batch), dim3(256), 0, st, A, strideA, m, T, j0, w, (const double *)P,
                          (const double *)d.qRn);
       if (wn > 0) OSFM_HIP(hipStreamWaitEvent(st, ev_p[(J + 1) & 1], 0));  // before the next panel's copies overwrite what the pivot kernel reads
@@ -3721,22 +3818,15 @@ struct Solver {
     if (st3) return dbcr_invert_batch_ahead(A, strideA, batch, d_status);
     const int m = d.qm, T = d.qT;
     const double one = 1.0, neg = -1.0, zero = 0.0;
-    auto ok = [](rocblas_status r) { return r == rocblas_status_success; };
     const long sP = (long)T * T, sR = (long)T * m;
     for (int j0 = 0; j0 < m; j0 += T) {
       const int w = std::min(T, m - j0);
       const int ncopy = (int)std::min<long>(64, ((long)w * m + 255) / 256);
       hipLaunchKernelGGL(dgj_pivot_kernel, dim3(1 + ncopy, batch), dim3(256), (size_t)kWB * kWLd * sizeof(double), st, A, strideA, m, T, j0, w, d.qP, d.qR,
                          d.qC, d_status);
-      OSFM_REQUIRE(ok(rocblas_dgemm_strided_batched(blas, rocblas_operation_none, rocblas_operation_none, w, m, w, &one, d.qP, T, sP, d.qR, T, sR, &zero, d.qRn,
-                                                    T, sR, batch)),
-                   OSFM_E_HIP, "rocblas_dgemm_strided_batched failed");
-      OSFM_REQUIRE(ok(rocblas_dgemm_strided_batched(blas, rocblas_operation_none, rocblas_operation_none, m, m, w, &neg, d.qC, m, sR, d.qRn, T, sR, &one, A, m,
-                                                    strideA, batch)),
-                   OSFM_E_HIP, "rocblas_dgemm_strided_batched failed");
-      OSFM_REQUIRE(ok(rocblas_dgemm_strided_batched(blas, rocblas_operation_none, rocblas_operation_none, m, w, w, &neg, d.qC, m, sR, d.qP, T, sP, &zero,
-                                                    A + (long)j0 * m, m, strideA, batch)),
-                   OSFM_E_HIP, "rocblas_dgemm_strided_batched failed");
+      dgemm_sb(false, false, w, m, w, one, d.qP, T, sP, d.qR, T, sR, zero, d.qRn, T, sR, batch);
+      dgemm_sb(false, false, m, m, w, neg, d.qC, m, sR, d.qRn, T, sR, one, A, m, strideA, batch);
+      dgemm_sb(false, false, m, w, w, neg, d.qC, m, sR, d.qP, T, sP, zero, A + (long)j0 * m, m, strideA, batch);
       hipLaunchKernelGGL(dgj_scatter_kernel, dim3((unsigned)(((long)w * m + 255) / 256), batch), dim3(256), 0, st, A, strideA, m, T, j0, w, d.qP, d.qRn);
     }
     return OSFM_OK;
@@ -3745,8 +3835,6 @@ struct Solver {
     const int m = d.qm, N = d.qN;
     const long m2 = (long)m * m;
     const double neg = -1.0, one = 1.0, zero = 0.0;
-    auto ok = [](rocblas_status r) { return r == rocblas_status_success; };
-    OSFM_REQUIRE(ok(rocblas_set_stream(blas, st)), OSFM_E_HIP, "rocblas_set_stream failed");
     {
       static OsfmPerDeviceOnce once;
       const int rca = once.run(ctx->device, []() -> int {
@@ -3767,26 +3855,16 @@ struct Solver {
       const int rci = dbcr_invert_batch(Di, sk, ne, d_status);
       if (rci != OSFM_OK) return rci;
       // G_i = D_i^-1 E_i,  H_i = D_i^-1 E_r^T
-      OSFM_REQUIRE(ok(rocblas_dgemm_strided_batched(blas, rocblas_operation_none, rocblas_operation_none, m, m, m, &one, Di, m, sk, Ei, m, sk, &zero, Xi, m,
-                                                    2 * sk, ne)),
-                   OSFM_E_HIP, "rocblas_dgemm_strided_batched failed");
+      dgemm_sb(false, false, m, m, m, one, Di, m, sk, Ei, m, sk, zero, Xi, m, 2 * sk, ne);
       if (nR > 0)
-        OSFM_REQUIRE(ok(rocblas_dgemm_strided_batched(blas, rocblas_operation_none, rocblas_operation_transpose, m, m, m, &one, Di, m, sk, Er, m, sk, &zero,
-                                                      Xi + m2, m, 2 * sk, nR)),
-                     OSFM_E_HIP, "rocblas_dgemm_strided_batched failed");
+        dgemm_sb(false, true, m, m, m, one, Di, m, sk, Er, m, sk, zero, Xi + m2, m, 2 * sk, nR);
       hipLaunchKernelGGL(dbcr_transpose_kernel, dim3(tl, tl, 2 * ne), dim3(256), 0, st, Xi, 2 * sk, m2, d.qXt + (long)s * 2 * m2, 2 * sk, m2, m, 2);
       if (nR > 0)  // D_{i+s} -= E_r H_i
-        OSFM_REQUIRE(ok(rocblas_dgemm_strided_batched(blas, rocblas_operation_none, rocblas_operation_none, m, m, m, &neg, Er, m, sk, Xi + m2, m, 2 * sk, &one,
-                                                      d.qD + 2L * s * m2, m, sk, nR)),
-                     OSFM_E_HIP, "rocblas_dgemm_strided_batched failed");
+        dgemm_sb(false, false, m, m, m, neg, Er, m, sk, Xi + m2, m, 2 * sk, one, d.qD + 2L * s * m2, m, sk, nR);
       // D_{i-s} -= E_i^T G_i
-      OSFM_REQUIRE(ok(rocblas_dgemm_strided_batched(blas, rocblas_operation_transpose, rocblas_operation_none, m, m, m, &neg, Ei, m, sk, Xi, m, 2 * sk, &one,
-                                                    d.qD, m, sk, ne)),
-                   OSFM_E_HIP, "rocblas_dgemm_strided_batched failed");
+      dgemm_sb(true, false, m, m, m, neg, Ei, m, sk, Xi, m, 2 * sk, one, d.qD, m, sk, ne);
       if (nR > 0)  // E_{i+s} <- -E_r G_i (into the other buffer: E_r is an operand)
-        OSFM_REQUIRE(ok(rocblas_dgemm_strided_batched(blas, rocblas_operation_none, rocblas_operation_none, m, m, m, &neg, Er, m, sk, Xi, m, 2 * sk, &zero,
-                                                      d.qE[1 - cur] + 2L * s * m2, m, sk, nR)),
-                     OSFM_E_HIP, "rocblas_dgemm_strided_batched failed");
+        dgemm_sb(false, false, m, m, m, neg, Er, m, sk, Xi, m, 2 * sk, zero, d.qE[1 - cur] + 2L * s * m2, m, sk, nR);
       cur ^= 1;
     }
     const int rcr = dbcr_invert_batch(d.qD, m2, 1, d_status);  // the last cluster standing
@@ -4651,13 +4729,6 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
         OSFM_HIP(hipEventCreateWithFlags(&sv.ev_p[q], hipEventDisableTiming));
       }
     }
-    if (!ctx->blas) {
-      rocblas_handle h = nullptr;
-      OSFM_REQUIRE(rocblas_create_handle(&h) == rocblas_status_success, OSFM_E_HIP, "rocblas_create_handle failed");
-      ctx->blas = h;
-      ctx->blas_destroy = [](void *p) { (void)rocblas_destroy_handle((rocblas_handle)p); };
-    }
-    sv.blas = (rocblas_handle)ctx->blas;
   }
   if (wide && !dense_cr) {
     d.wNB = (S + kWcs - 1) / kWcs;

@@ -23,5 +23,5 @@ for p in "${pids[@]}"; do wait "$p" || rc=1; done
 [ $rc -eq 0 ] || { echo "build failed"; exit 1; }
 OBJS=""
 for s in $SRCS; do OBJS="$OBJS build/${s%.hip}.o"; done
-$HIPCC --offload-arch=gfx950 -fPIC -shared $OBJS -o libosfm_mi355.so -L/opt/rocm/lib -lrocblas -Wl,-rpath,/opt/rocm/lib
+$HIPCC --offload-arch=gfx950 -fPIC -shared $OBJS -o libosfm_mi355.so
 echo "built $(pwd)/libosfm_mi355.so"
