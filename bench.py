@@ -266,6 +266,16 @@ def main():
         ex["share_of_step"] = round(ex["ms_per_step"] / (1e3 * elapsed / args.steps), 4)
         ex["bytes_to_host"] = int(exchange_tms[-1]["bytes_to_host"])
         out["exchange"] = ex
+    if dist is not None:  # N > 1: every rank's own clocks, so that a poor scaling curve can be read from one run
+        mine = {"rank": rank, "pairs": int(len(my_pairs)),
+                "match_call_ms": round(sum(float(t.ms_total) for t in tms) / args.steps, 3),
+                "match_kernel_ms": round(ms_kernel / args.steps, 3),
+                "ransac_kernel_ms": round(sum(float(t.ms_ransac_kernel) for t in tms) / args.steps, 3),
+                "exchange_ms": round(float(np.mean([x["collective_ms"] + x["layout_ms"] + x["d2h_ms"] for x in exchange_tms])), 3) if exchange_tms else None,
+                "exchange_collective_ms": round(float(np.mean([x["collective_ms"] for x in exchange_tms])), 3) if exchange_tms else None}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+        out["per_rank"] = per_rank
 
     if rank == 0:
         def section(name, fn, *a):

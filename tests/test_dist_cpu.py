@@ -17,7 +17,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_pairs, seed, q):
+def _worker(rank, world, port, n_pairs, seed, q, empty_rank=-1):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
 
@@ -27,6 +27,8 @@ def _worker(rank, world, port, n_pairs, seed, q):
     rng = np.random.default_rng(seed)
     counts_all = rng.integers(0, 7, n_pairs).astype(np.int32)
     counts_all[rng.random(n_pairs) < 0.5] = 0
+    if empty_rank >= 0:  # one rank whose shard has pairs but not a single match
+        counts_all[odist.shard_indices(n_pairs, empty_rank, world, block=16)] = 0
     off = np.concatenate([[0], np.cumsum(counts_all)])
     matches_all = rng.integers(0, 2000, (int(off[-1]), 2)).astype(np.int32)
     idx = odist.shard_indices(n_pairs, rank, world, block=16)
@@ -78,6 +80,25 @@ def test_all_gather_match_graph_world2(n_pairs):
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+@pytest.mark.parametrize("n_pairs,empty_rank", [(100, 2), (16 * 8 * 3 + 5, -1)])
+def test_all_gather_match_graph_world8(n_pairs, empty_rank):
+    """the shape of the driver's 8-GPU run on gloo: 100 pairs in blocks of 16 = seven ranks with pairs (the last block short) and one
+    rank with NONE, one of the others without a single match; 389 pairs = every rank busy, an uneven last block.  Both result orders,
+    host and device variants (the worker checks all four)"""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 8, port, n_pairs, 5, q, empty_rank)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, True) for r in range(8)]
 
 
 def test_shards_partition_the_pair_list():
