@@ -282,10 +282,14 @@ int osfm_ba_shot_order(const osfm_ba_problem *problem, int32_t *new_of_old, int3
  * ParameterBarrier), the SPHERICAL 3-D bearing residual (projection_errors.h:208-376), rig cameras with pose priors and rig
  * instances (error_utils.h:68-85 WorldToCameraCoordinatesRig), rig instance position priors through a per-camera GPS bias
  * (SimilarityPriorTransform, bias.h:33-53, bundle_adjuster.cc:745-778), point priors = ground control points
- * (bundle_adjuster.cc:688-707, ba_helpers.cc:349-406), absolute up vectors (absolute_motion_errors.h:12-39, Cauchy(1)).
- * Points are eliminated; the reduced system over all other free parameters is formed dense on the device and factorised
- * (the exact solve of Ceres' SPARSE_SCHUR).  osfm_ba_solve above is the streaming solver for the perspective / fisheye
- * [k1 k2 focal] configuration at benchmark scale; this entry point is the general one.
+ * (bundle_adjuster.cc:688-707, ba_helpers.cc:349-406), absolute up vectors (absolute_motion_errors.h:12-39, Cauchy(1)), compass /
+ * inclinometer priors, depth priors.
+ * Round 5: this entry point runs on the SAME streaming Schur solver as osfm_ba_solve (its generic mode, csrc/ba_generic.inc): points
+ * eliminated on the fly, the rig instances in a co-visibility band factorised exactly (cyclic reduction), the free rig cameras /
+ * camera intrinsics / biases as a border of up to 64 unknowns eliminated exactly (wider borders: preconditioned CG) -- time and
+ * memory linear in the observations, BASELINE configs[4] size with a BROWN camera in one call.  (Round 4 formed the reduced system
+ * densely and factorised it with rocSOLVER: n_r^2 doubles.)  osfm_ba_solve above remains the specialisation for the perspective /
+ * fisheye [k1 k2 focal] configuration the headline BA figure is quoted on.
  * Poses are CAM_TO_WORLD [rx ry rz tx ty tz] (bundle/data/pose.h:17,34-43); camera parameters in the native order of the
  * OSFM_CAMERA_* definitions, 16 slots per camera; in/out arrays are overwritten with the optimum.
  * ------------------------------------------------------------------------------------------ */
