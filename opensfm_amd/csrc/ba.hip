@@ -3615,6 +3615,7 @@ struct Solver {
     else OSFM_GEN_KW(2, KERNEL, grid, block, stream, __VA_ARGS__);                               \
   } while (0)
   int gen_nprior() const { return d.NC + d.g.NRC + d.S + 4 * d.g.NV; }
+  size_t gen_prior_lds() const { return (size_t)(d.g.NB * d.g.NB + d.g.NB + 2) * sizeof(double); }
   // cost (with priors) at the given parameters into scal[8] (sum of squares of the reprojections into scal[9]); jac: the Jacobian rows
   // and the prior blocks as well
   void gen_eval_enqueue(const double *cam, const double *bias, const double *rcp, const double *poses, const double *pts, bool jac) {
@@ -3643,8 +3644,8 @@ struct Solver {
       }
     }
     hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(1024), 0, st, d.partial, (long)(d.M > 0 ? nb : 0), 2, d.scal + 8);
-    hipLaunchKernelGGL(gen_prior_kernel, dim3(nblk(gen_nprior(), 64)), dim3(64), 0, st, d, cam, bias, rcp, poses, jac ? 1 : 0, (const double *)nullptr,
-                       d.scal + 8);
+    hipLaunchKernelGGL(gen_prior_kernel, dim3(nblk(gen_nprior(), 256)), dim3(256), gen_prior_lds(), st, d, cam, bias, rcp, poses, jac ? 1 : 0,
+                       (const double *)nullptr, d.scal + 8);
     if (d.g.pt_prior_sigma && d.P > 0) hipLaunchKernelGGL(gen_point_prior_kernel, dim3(nblk(d.P)), dim3(TPB), 0, st, d, pts, 0, d.scal + 8);
   }
   void gen_gradients() {
@@ -3699,7 +3700,7 @@ struct Solver {
   void gen_matvec(const double *x, double *out, double radius, hipStream_t sq) {
     hipLaunchKernelGGL(scale_vec_kernel, dim3(nblk(d.nred)), dim3(TPB), 0, sq, d.sc_red, x, d.y, d.nred);
     gen_rows_apply(0, sq);
-    if (have_bpri && d.g.NB > 0) hipLaunchKernelGGL(gen_bpri_dot_kernel, dim3(d.g.NB), dim3(256), 0, sq, d, (const double *)d.y);
+    if (have_bpri && d.g.NB > 0) hipLaunchKernelGGL(gen_bpri_dot_kernel, dim3(d.g.NB, kBpriSlices), dim3(256), 0, sq, d, (const double *)d.y);
     hipLaunchKernelGGL(gen_schur_finish_kernel, dim3(nblk(d.nred)), dim3(TPB), 0, sq, d, x, (const double *)d.y, out, radius, 0, d.M > 0 ? 1 : 0,
                        have_bpri ? 1 : 0);
   }
@@ -4428,7 +4429,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     g.Bpri = A.alloc<double>((size_t)std::max(1, nb) * 6 * S, e);
     g.Cpri = A.alloc<double>((size_t)std::max(1, nb * nb), e);
     g.gpri = A.alloc<double>((size_t)6 * S + nb, e);
-    g.bdot = A.alloc<double>((size_t)std::max(1, nb), e);
+    g.bdot = A.alloc<double>((size_t)std::max(1, nb) * kBpriSlices, e);
     g.vpart = A.alloc<double>((size_t)std::max(1, NV * 2 * KW), e);
     g.yv = A.alloc<double>((size_t)std::max(1, NV * KW), e);
   }
@@ -4804,6 +4805,18 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
   Rp->seconds_setup = std::chrono::duration<double>(t_run - t_start).count();
   Rp->rmse_normalized_initial = std::sqrt(sumsq / (double)std::max<long>(1, gen ? G_rows0 : M));
   Rp->cost_history[0] = cost;
+  const bool trace = getenv("OSFM_BA_TRACE") != nullptr;  // debugging aid: a line per phase with the stream drained, to see where a solve stalls
+  auto mark = [&](const char *what) -> int {
+    if (!trace) return OSFM_OK;
+    fprintf(stderr, "[osfm_ba trace] %s ...", what);
+    fflush(stderr);
+    OSFM_HIP(hipStreamSynchronize(st));
+    if (sv.st2) OSFM_HIP(hipStreamSynchronize(sv.st2));
+    OSFM_HIP(hipGetLastError());
+    fprintf(stderr, " done\n");
+    return OSFM_OK;
+  };
+  if (mark("first evaluation") != OSFM_OK) return OSFM_E_HIP;
   double radius = O->initial_radius > 0 ? O->initial_radius : 1e4;
   double decrease_factor = 2.0;
   bool need_prepare = true, have_scale = false;
@@ -4837,6 +4850,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     if (gmax <= O->gradient_tolerance) { Rp->termination = 2; break; }
     if (radius < 1e-32) { Rp->termination = 4; break; }
     iter++;
+    if (mark("gradients / scaling") != OSFM_OK) return OSFM_E_HIP;
     if (iter < 256) Rp->cost_history[iter] = cost;  // every exit below (tolerances, invalid step) leaves the slot of this iteration defined
     const auto t_lin = std::chrono::steady_clock::now();
     // ---- linear solve: PCG on the implicit Schur complement ----
@@ -4922,6 +4936,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       sv.use_ctri = false;
       sv.use_bcr = false;
     }
+    if (mark("band assembly") != OSFM_OK) return OSFM_E_HIP;
     const bool fork_in_bcr = fork_at == 2 && sv.st2 && d.bw > 0 && d.ncl > 1 && O->preconditioner == 0;
     // the side stream's work: the camera border's columns and the right-hand side, from the point of the main stream where it is called
     auto side_work = [&](bool fork_here) -> int {
@@ -4965,6 +4980,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       const int rcs = side_work(fork_late);
       if (rcs != OSFM_OK) return rcs;
     }
+    if (mark("side work (border columns, right-hand side)") != OSFM_OK) return OSFM_E_HIP;
     bool joined = sv.st2 == nullptr;
     auto join = [&]() -> int {  // the main stream continues after the side stream's work
       if (!joined) OSFM_HIP(hipStreamWaitEvent(st, sv.ev_join, 0));
@@ -5100,6 +5116,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       const int rcj = join();  // the right-hand side (and its use of part / camred) is complete
       if (rcj != OSFM_OK) return rcj;
     }
+    if (mark("factorisation + border solve") != OSFM_OK) return OSFM_E_HIP;
     int hst[3] = {0, 0, 0};
     auto start_pcg = [&]() -> int {
       // block-Jacobi blocks (6x6 per shot, 3x3 per camera): the fallback preconditioner, and the camera rows of the band
@@ -5173,6 +5190,9 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       }
       Rp->pcg_iterations_total += k;
     }
+    if (mark("pcg") != OSFM_OK) return OSFM_E_HIP;
+    if (trace) fprintf(stderr, "[osfm_ba trace] iteration %d: %d pcg iterations, status %d %d %d, band %d bcr %d wide %d border %d\n", iter, k, hst[0], hst[1], hst[2],
+                       (int)sv.use_band, (int)sv.use_bcr, (int)sv.use_wide, (int)sv.use_border);
     // back-substitution, model change, candidate
     hipLaunchKernelGGL(scale_vec_kernel, dim3(nbr), dim3(TPB), 0, st, d.sc_red, d.x, d.y, nred);
     if (gen) {
@@ -5184,8 +5204,8 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(1024), 0, st, d.partial, (long)d.nwg, 1, d.scal + 16);  // the model change's observation part
     if (gen) {
       hipLaunchKernelGGL(gen_candidate_kernel, dim3(1), dim3(1024), 0, st, d, (const double *)d.y, d.scal + 16);
-      hipLaunchKernelGGL(gen_prior_kernel, dim3(nblk(sv.gen_nprior(), 64)), dim3(64), 0, st, d, (const double *)g.cam, (const double *)g.bias, (const double *)g.rc,
-                         (const double *)d.poses, 2, (const double *)d.y, d.scal + 16);
+      hipLaunchKernelGGL(gen_prior_kernel, dim3(nblk(sv.gen_nprior(), 256)), dim3(256), sv.gen_prior_lds(), st, d, (const double *)g.cam, (const double *)g.bias,
+                         (const double *)g.rc, (const double *)d.poses, 2, (const double *)d.y, d.scal + 16);
       if (g.pt_prior_sigma && NP > 0) hipLaunchKernelGGL(gen_point_prior_kernel, dim3(nblk(NP)), dim3(TPB), 0, st, d, (const double *)d.pts, 2, d.scal + 16);
     } else
       hipLaunchKernelGGL(candidate_kernel, dim3(1), dim3(1024), 0, st, d, d.y, d.scal + 16);

@@ -338,6 +338,22 @@ def match_pairs(desc_f32: np.ndarray, pts: np.ndarray, offsets: np.ndarray, pair
     return [out[p, : counts[p]].copy() for p in range(npairs)]
 
 
+def match_pairs_gemm(desc_f32: np.ndarray, offsets: np.ndarray, pairs: np.ndarray, ratio: float = 0.8):
+    """the descriptor stage (symmetric ratio matches, before the robust stage) of every pair in GEMM form -- integer-valued descriptors
+    only; a blocked AVX micro-kernel, OpenMP over pairs (oracle/match_oracle.c): bench.py's second CPU figure.  Returns the list of
+    (K, 2) arrays ``match_pairs(..., stage=0)`` returns."""
+    desc_f32 = np.ascontiguousarray(desc_f32, np.float32)
+    offsets = np.ascontiguousarray(offsets, np.int64)
+    pairs = np.ascontiguousarray(pairs, np.int32)
+    npairs = len(pairs)
+    cap = int(np.max(np.diff(offsets))) if len(offsets) > 1 else 1
+    counts = np.zeros(max(npairs, 1), np.int32)
+    out = np.zeros((max(npairs, 1), cap, 2), np.int32)
+    lib().oracle_match_pairs_gemm(_p(desc_f32, C.c_float), _p(offsets, C.c_int64), desc_f32.shape[1], _p(pairs, C.c_int), npairs, C.c_double(ratio),
+                                  _p(counts, C.c_int), _p(out, C.c_int), cap)
+    return [out[p, : counts[p]].copy() for p in range(npairs)]
+
+
 def num_threads() -> int:
     return lib().oracle_num_threads()
 

@@ -605,7 +605,7 @@ bool cholesky_solve(std::vector<double>& Amat, std::vector<double>& b, int n) { 
     if (!(dgn > 0) || !std::isfinite(dgn)) return false;
     const double l = std::sqrt(dgn);
     Amat[(size_t)j * n + j] = l;
-#pragma omp parallel for schedule(static) if (n - j > 256)
+#pragma omp parallel for schedule(static) num_threads(8) if (n - j > 512)
     for (int i = j + 1; i < n; i++) {
       double v = Amat[(size_t)i * n + j];
       for (int k = 0; k < j; k++) v -= Amat[(size_t)i * n + k] * Amat[(size_t)j * n + k];

@@ -252,3 +252,112 @@ int oracle_num_threads(void) {
   return 1;
 #endif
 }
+
+/* ---- the CPU path someone would actually write (bench.py's second cpu_baseline figure, not a parity reference) -----------------------
+ * For INTEGER-VALUED descriptors in [0, 255] (HAHOG / SIFT uchar levels held in float32) the squared distance in GEMM form,
+ * |a|^2 + |b|^2 - 2 a.b, is exact in float32 -- every product <= 65 025, every partial sum < 2^24 -- and equal, bit for bit, to the
+ * sum of squared differences of the direct form above.  One 2000 x 2000 product then serves BOTH directions of the symmetric matcher:
+ * a register-blocked micro-kernel (4 rows x 64 columns of accumulators in sixteen 512-bit registers, B transposed once per pair so
+ * that the columns vectorise), the same top-2 insertion as oracle_knn2_l2 on the finished tile for the row's and for the column's
+ * running best (i and j visited in increasing order: the lowest index wins among equals, as cv2's batchDistance).  Returns what
+ * oracle_match_brute_force_symmetric(..., squared_mode = 0) returns; tests/test_oracle_matching.py asserts that. */
+typedef float v16f __attribute__((vector_size(64), aligned(4)));
+#pragma GCC push_options
+#pragma GCC optimize("fp-contract=fast") /* (exact either way: the products and sums are integers below 2^24) */
+static void gemm_tile_4x64(const float *a0, const float *a1, const float *a2, const float *a3, const float *bt, int ldb, int dim, v16f acc[4][4]) {
+  for (int r = 0; r < 4; r++)
+    for (int c = 0; c < 4; c++) acc[r][c] = (v16f){0};
+  for (int k = 0; k < dim; k++) {
+    const float *brow = bt + (size_t)k * ldb;
+    v16f b[4];
+    for (int c = 0; c < 4; c++) __builtin_memcpy(&b[c], brow + 16 * c, sizeof(v16f));
+    const float av[4] = {a0[k], a1[k], a2[k], a3[k]};
+    for (int r = 0; r < 4; r++) {
+      v16f a = (v16f){0} + av[r];
+      for (int c = 0; c < 4; c++) acc[r][c] += a * b[c];
+    }
+  }
+}
+#pragma GCC pop_options
+static inline void top2_insert(float d, float sq, int j, float *bd0, float *bd1, int *bi0) {
+  if (d < *bd1) {
+    if (*bd0 > d) {
+      *bd1 = *bd0;
+      *bd0 = d;
+      *bi0 = j;
+    } else {
+      *bd1 = d;
+    }
+  }
+  (void)sq;
+}
+int oracle_match_brute_force_symmetric_gemm(const float *fi, int ni, const float *fj, int nj, int dim, double ratio, int *out_pairs, int cap) {
+  if (ni < 2 || nj < 2) return 0;
+  const int njp = (nj + 63) / 64 * 64, nip = (ni + 3) / 4 * 4;
+  float *bt = (float *)calloc((size_t)dim * njp, sizeof(float)), *nb = (float *)calloc((size_t)njp, sizeof(float));
+  float *ap = (float *)calloc((size_t)nip * dim, sizeof(float)), *na = (float *)calloc((size_t)nip, sizeof(float));
+  for (int j = 0; j < nj; j++) {
+    float s = 0.f;
+    for (int k = 0; k < dim; k++) {
+      const float v = fj[(size_t)j * dim + k];
+      bt[(size_t)k * njp + j] = v;
+      s += v * v;
+    }
+    nb[j] = s;
+  }
+  for (int i = 0; i < ni; i++) {
+    float s = 0.f;
+    for (int k = 0; k < dim; k++) {
+      const float v = fi[(size_t)i * dim + k];
+      ap[(size_t)i * dim + k] = v;
+      s += v * v;
+    }
+    na[i] = s;
+  }
+  float *rd0 = (float *)malloc(sizeof(float) * ni), *rd1 = (float *)malloc(sizeof(float) * ni);
+  float *cd0 = (float *)malloc(sizeof(float) * njp), *cd1 = (float *)malloc(sizeof(float) * njp);
+  int *ri = (int *)malloc(sizeof(int) * ni), *ci = (int *)malloc(sizeof(int) * njp);
+  for (int i = 0; i < ni; i++) { rd0[i] = rd1[i] = INFINITY; ri[i] = -1; }
+  for (int j = 0; j < njp; j++) { cd0[j] = cd1[j] = INFINITY; ci[j] = -1; }
+  for (int i0 = 0; i0 < ni; i0 += 4)
+    for (int j0 = 0; j0 < nj; j0 += 64) {
+      v16f acc[4][4];
+      gemm_tile_4x64(ap + (size_t)i0 * dim, ap + (size_t)(i0 + 1) * dim, ap + (size_t)(i0 + 2) * dim, ap + (size_t)(i0 + 3) * dim, bt + j0, njp, dim, acc);
+      for (int r = 0; r < 4 && i0 + r < ni; r++) {
+        const int i = i0 + r;
+        const float *row = (const float *)&acc[r][0];
+        for (int c = 0; c < 64 && j0 + c < nj; c++) {
+          const int j = j0 + c;
+          const float sq = (na[i] + nb[j]) - 2.0f * row[c];
+          const float d = sqrtf(sq);
+          int dummy;
+          top2_insert(d, sq, j, &rd0[i], &rd1[i], &ri[i]);
+          top2_insert(d, sq, i, &cd0[j], &cd1[j], &ci[j]);
+          (void)dummy;
+        }
+      }
+    }
+  int n = 0;
+  for (int i = 0; i < ni; i++) {
+    const int j = ri[i];
+    if (j < 0 || !((double)rd0[i] < ratio * (double)rd1[i])) continue;
+    if (ci[j] != i || !((double)cd0[j] < ratio * (double)cd1[j])) continue;
+    if (n < cap) {
+      out_pairs[2 * n] = i;
+      out_pairs[2 * n + 1] = j;
+    }
+    n++;
+  }
+  free(bt); free(nb); free(ap); free(na); free(rd0); free(rd1); free(cd0); free(cd1); free(ri); free(ci);
+  return n;
+}
+/* the descriptor stage of `n_pairs` pairs of a packed store in GEMM form, OpenMP over pairs: counts only (a timing leg) */
+void oracle_match_pairs_gemm(const float *desc, const int64_t *offsets, int dim, const int *pairs, int n_pairs, double ratio, int *counts, int *out_pairs,
+                             int cap_per_pair) {
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int p = 0; p < n_pairs; p++) {
+    const int a = pairs[2 * p], b = pairs[2 * p + 1];
+    counts[p] = oracle_match_brute_force_symmetric_gemm(desc + offsets[a] * dim, (int)(offsets[a + 1] - offsets[a]), desc + offsets[b] * dim,
+                                                        (int)(offsets[b + 1] - offsets[b]), dim, ratio, out_pairs + (size_t)2 * cap_per_pair * p, cap_per_pair);
+  }
+}
