@@ -66,7 +66,23 @@ def _oracle_leg(pr: dict, ctx, iters: int, note: str) -> dict:
     dt = time.perf_counter() - t0
     g = bundle.bundle_arrays(pr, {"bundle_max_iterations": iters}, ctx=ctx, **no_tol)
     ch_o, ch_g = np.asarray(o["cost_history"]), np.asarray(g["cost_history"])
-    return {"value": round(o["iterations"] / o["seconds_total"], 4), "unit": "LM-iters/s", "cores": oracle.num_threads(), "kind": "port",
+    value, factor = o["iterations"] / o["seconds_total"], "serial skyline factor"
+    par = None
+    try:  # the skyline Cholesky right-looking on up to 16 cores (same operations in the same order: identical bits); the faster one is the baseline
+        oracle.ba_set_parallel(2)
+        t0 = time.perf_counter()
+        o2 = oracle.ba_solve(pr, max_iterations=iters, **no_tol)
+        dt2 = time.perf_counter() - t0
+        par = {"value": round(o2["iterations"] / o2["seconds_total"], 4), "seconds": round(dt2, 1),
+               "identical_to_serial_factor": bool(np.array_equal(np.asarray(o2["cost_history"]), ch_o))}
+        if par["value"] > value and par["identical_to_serial_factor"]:
+            value, factor = par["value"], "right-looking skyline factor on up to 16 cores"
+    except Exception as exc:  # noqa: BLE001
+        par = {"error": f"{type(exc).__name__}: {exc}"}
+    finally:
+        oracle.ba_set_parallel(1)
+    return {"value": round(value, 4), "unit": "LM-iters/s", "cores": oracle.num_threads(), "kind": "port", "factor": factor,
+            "serial_factor_value": round(o["iterations"] / o["seconds_total"], 4), "all_cores_factor": par,
             "sample": f"the first {iters} LM iterations of the same problem ({dt:.1f} s); {note}", "parity_iterations": int(iters),
             "cost_history_max_rel_diff": float(np.max(np.abs(ch_o - ch_g) / np.maximum(np.abs(ch_o), 1e-300))),
             "max_abs_diff": {"points": float(np.abs(o["points"] - g["points"]).max()), "shot_pose": float(np.abs(o["shot_pose"] - g["shot_pose"]).max())}}

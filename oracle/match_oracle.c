@@ -279,17 +279,20 @@ static void gemm_tile_4x64(const float *a0, const float *a1, const float *a2, co
   }
 }
 #pragma GCC pop_options
-static inline void top2_insert(float d, float sq, int j, float *bd0, float *bd1, int *bi0) {
+/* the insertion of oracle_knn2_l2 on (distance, squared distance): bs1 = the squared distance behind bd1, the pre-test's threshold */
+static inline void top2_insert(float d, float sq, int j, float *bd0, float *bd1, float *bs0, float *bs1, int *bi0) {
   if (d < *bd1) {
     if (*bd0 > d) {
       *bd1 = *bd0;
+      *bs1 = *bs0;
       *bd0 = d;
+      *bs0 = sq;
       *bi0 = j;
     } else {
       *bd1 = d;
+      *bs1 = sq;
     }
   }
-  (void)sq;
 }
 int oracle_match_brute_force_symmetric_gemm(const float *fi, int ni, const float *fj, int nj, int dim, double ratio, int *out_pairs, int cap) {
   if (ni < 2 || nj < 2) return 0;
@@ -314,26 +317,31 @@ int oracle_match_brute_force_symmetric_gemm(const float *fi, int ni, const float
     }
     na[i] = s;
   }
-  float *rd0 = (float *)malloc(sizeof(float) * ni), *rd1 = (float *)malloc(sizeof(float) * ni);
-  float *cd0 = (float *)malloc(sizeof(float) * njp), *cd1 = (float *)malloc(sizeof(float) * njp);
-  int *ri = (int *)malloc(sizeof(int) * ni), *ci = (int *)malloc(sizeof(int) * njp);
-  for (int i = 0; i < ni; i++) { rd0[i] = rd1[i] = INFINITY; ri[i] = -1; }
-  for (int j = 0; j < njp; j++) { cd0[j] = cd1[j] = INFINITY; ci[j] = -1; }
+  /* per row / column: best and second distance, their squares, the best index */
+  float *rd0 = (float *)malloc(sizeof(float) * nip * 4), *cd0 = (float *)malloc(sizeof(float) * njp * 4);
+  float *rd1 = rd0 + nip, *rs0 = rd0 + 2 * nip, *rs1 = rd0 + 3 * nip, *cd1 = cd0 + njp, *cs0 = cd0 + 2 * njp, *cs1 = cd0 + 3 * njp;
+  int *ri = (int *)malloc(sizeof(int) * nip), *ci = (int *)malloc(sizeof(int) * njp);
+  for (int i = 0; i < nip; i++) { rd0[i] = rd1[i] = rs0[i] = rs1[i] = INFINITY; ri[i] = -1; }
+  for (int j = 0; j < njp; j++) { cd0[j] = cd1[j] = cs0[j] = cs1[j] = INFINITY; ci[j] = -1; }
   for (int i0 = 0; i0 < ni; i0 += 4)
     for (int j0 = 0; j0 < nj; j0 += 64) {
       v16f acc[4][4];
       gemm_tile_4x64(ap + (size_t)i0 * dim, ap + (size_t)(i0 + 1) * dim, ap + (size_t)(i0 + 2) * dim, ap + (size_t)(i0 + 3) * dim, bt + j0, njp, dim, acc);
+      const int jn = nj - j0 < 64 ? nj - j0 : 64;
       for (int r = 0; r < 4 && i0 + r < ni; r++) {
         const int i = i0 + r;
+        float sqt[64];
         const float *row = (const float *)&acc[r][0];
-        for (int c = 0; c < 64 && j0 + c < nj; c++) {
+        for (int c = 0; c < 64; c++) sqt[c] = (na[i] + nb[j0 + c]) - 2.0f * row[c]; /* vectorised */
+        for (int c = 0; c < jn; c++) {
           const int j = j0 + c;
-          const float sq = (na[i] + nb[j]) - 2.0f * row[c];
-          const float d = sqrtf(sq);
-          int dummy;
-          top2_insert(d, sq, j, &rd0[i], &rd1[i], &ri[i]);
-          top2_insert(d, sq, i, &cd0[j], &cd1[j], &ci[j]);
-          (void)dummy;
+          const float sq = sqt[c];
+          /* sqrtf is monotone: a squared distance above the one behind the running second best cannot enter (d >= bd1) */
+          if (sq <= rs1[i] || sq <= cs1[j]) {
+            const float d = sqrtf(sq);
+            top2_insert(d, sq, j, &rd0[i], &rd1[i], &rs0[i], &rs1[i], &ri[i]);
+            top2_insert(d, sq, i, &cd0[j], &cd1[j], &cs0[j], &cs1[j], &ci[j]);
+          }
         }
       }
     }
@@ -348,7 +356,7 @@ int oracle_match_brute_force_symmetric_gemm(const float *fi, int ni, const float
     }
     n++;
   }
-  free(bt); free(nb); free(ap); free(na); free(rd0); free(rd1); free(cd0); free(cd1); free(ri); free(ci);
+  free(bt); free(nb); free(ap); free(na); free(rd0); free(cd0); free(ri); free(ci);
   return n;
 }
 /* the descriptor stage of `n_pairs` pairs of a packed store in GEMM form, OpenMP over pairs: counts only (a timing leg) */

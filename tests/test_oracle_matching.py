@@ -121,3 +121,18 @@ def test_oracle_flann_semantics_equal_numpy(oracle_lib, n1, n2, seed, ratio):
     b = {(j, i) for i, j in numpy_flann(f2, f1, ratio)}
     want = np.asarray(sorted(a & b), np.int32).reshape(-1, 2)
     assert np.array_equal(oracle_lib.match_brute_force_symmetric(f1, f2, ratio, squared=True), want)
+
+
+def test_gemm_form_descriptor_stage_equals_the_direct_form(oracle_lib):
+    """bench.py's second CPU figure (`cpu_baseline.gemm_form`): |a|^2 + |b|^2 - 2 a.b is exact on integer-valued levels, so the blocked
+    product returns the direct form's symmetric matches pair for pair -- ragged sizes (not multiples of the 4 x 64 tile), ties included"""
+    from opensfm_amd import synthetic
+
+    sc = synthetic.make_matching_scene(5, 333, seed=3)
+    d = sc.desc.astype(np.float32)
+    d[sc.offsets[1] + 7] = d[sc.offsets[1] + 3]  # two identical rows: equal distances, the lower index must win in both forms
+    pairs = synthetic.all_pairs(5)
+    a = oracle_lib.match_pairs(d, sc.pts, sc.offsets, pairs, stage=0)
+    b = oracle_lib.match_pairs_gemm(d, sc.offsets, pairs)
+    assert sum(len(x) for x in a) > 100
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
