@@ -74,7 +74,7 @@ def _oracle_leg(pr: dict, ctx, iters: int, note: str) -> dict:
         o2 = oracle.ba_solve(pr, max_iterations=iters, **no_tol)
         dt2 = time.perf_counter() - t0
         par = {"value": round(o2["iterations"] / o2["seconds_total"], 4), "seconds": round(dt2, 1),
-               "identical_to_serial_factor": bool(np.array_equal(np.asarray(o2["cost_history"]), ch_o))}
+               "identical_to_serial_factor": bool(np.asarray(o2["cost_history"]).shape == ch_o.shape and np.allclose(np.asarray(o2["cost_history"]), ch_o, rtol=1e-13, atol=0))}
         if par["value"] > value and par["identical_to_serial_factor"]:
             value, factor = par["value"], "right-looking skyline factor on up to 16 cores"
     except Exception as exc:  # noqa: BLE001

@@ -77,3 +77,16 @@ def test_generic_mode_equals_the_specialised_kernels(oracle_lib):
         b = bundle.bundle_general_arrays(og._as_general(pr), {"bundle_max_iterations": 4}, **NO_TOL)
     assert np.allclose(a["cost_history"], b["cost_history"], rtol=1e-10)
     assert np.allclose(a["shot_pose"], b["rig_instance_pose"], atol=1e-9)
+
+
+def test_generic_mode_constant_blocks_count_in_the_cost(oracle_lib):
+    """constant cameras / rig cameras / biases / some instances and points: none moves, and their priors still count in the cost (Ceres
+    folds residual blocks over constant parameter blocks into its fixed cost) -- the first GPU run of the generic mode had dropped them"""
+    pr = synthetic.make_bundle_scene(models=("fisheye", "radial"), n_instances=9, n_points=100, seed=9, free_cameras=False, free_rig_camera=False,
+                                     free_bias=False)
+    pr["rig_instance_fixed"] = np.zeros(9, np.uint8)
+    pr["rig_instance_fixed"][[0, 4]] = 1
+    pr["point_fixed"] = (np.arange(len(pr["points"])) % 7 == 0).astype(np.uint8)
+    g, _ = _compare_general(oracle_lib, pr, iters=3)
+    assert np.array_equal(g["cam_params"], pr["cam_params"]) and np.array_equal(g["rig_instance_pose"][[0, 4]], pr["rig_instance_pose"][[0, 4]])
+    assert np.array_equal(g["points"][pr["point_fixed"] == 1], pr["points"][pr["point_fixed"] == 1])
