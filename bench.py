@@ -33,7 +33,8 @@ FLOP_PER_PAIR = 2.0 * 2000 * 2000 * 128  # one distance matrix s
 PEAK_F64_VALU_TFLOPS = 78.6  # fp64 vector peak (half the 157.3 TFLOP/s fp32 rate of MI355X_MICROARCH.md)
 RANSAC_FLOP_PER_MODEL_POINT = 40.0  # symmetric epipolar error of one correspondence under one F: two 3x3 products, two norms, compare
 RELPOSE_FLOP_PER_MODEL_POINT = 150.0  # RelativePose::Evaluate: rotate, midpoint triangulation, two reprojection cosines
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_match_pmc.json")  # HBM bytes per launch from the rocprofv3 --pmc passes of this command
+PMC_FILE = os.path.join(ROOT, "profiles", "r05_match_pmc.json")  # HBM bytes per launch from the rocprofv3 --pmc passes of this command (tools/pmc_passes.sh)
+PMC_KERNEL = "match_fused_kernel"  # the kernel the roofline block is about: a counter file taken on another kernel is refused, not quoted
 
 
 def parse():
@@ -204,8 +205,9 @@ def main():
     # (tools/r03_final_profiles.sh -> profiles/r03_match_pmc.json: FETCH_SIZE doubled as the gfx950 guide prescribes, + WRITE_SIZE) are quoted,
     # scaled to this run's pairs per launch
     if os.path.exists(PMC_FILE):
+        pmc = json.load(open(PMC_FILE))
+        assert pmc.get("kernel") == PMC_KERNEL, f"{PMC_FILE} holds counters of {pmc.get('kernel')!r}, the roofline block is about {PMC_KERNEL!r}: re-run tools/pmc_passes.sh"
         try:
-            pmc = json.load(open(PMC_FILE))
             k = pairs_per_launch / float(pmc["pairs_per_launch"])
             roofline["traffic"] = {"hbm_read_bytes": pmc["fetch_bytes_corrected"] * k, "hbm_write_bytes": pmc["write_bytes"] * k,
                                    "algorithmic_bytes": 2 * n_avg * 128 * pairs_per_launch, "source": pmc["source"]}

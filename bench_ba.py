@@ -30,6 +30,23 @@ def lm_iteration_line(g: dict, nobs: int) -> dict:
                     "columns), right-hand side, PCG (1-2 mat-vecs), back-substitution, candidate cost"}
 
 
+def _pmc_traffic(name: str, kernels, nobs: int, alg_bytes_per_obs: float):
+    """the committed PMC counters of a mat-vec pair scaled to this run's observations; None when the file is absent; an assertion when its
+    kernel list is not the one the caller times (a stale file must not be quoted)"""
+    import json
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
+    if not os.path.exists(path):
+        return None
+    pmc = json.load(open(path))
+    got = tuple(row[0] for row in pmc["per_kernel"])
+    assert got == tuple(kernels), f"{path} holds counters of {got}, this run times {tuple(kernels)}: re-run tools/pmc_passes.sh"
+    k = nobs / float(pmc["units_per_launch"])
+    return {"hbm_read_bytes": pmc["fetch_bytes_corrected"] * k, "hbm_write_bytes": pmc["write_bytes"] * k,
+            "algorithmic_bytes": alg_bytes_per_obs * nobs, "source": pmc["source"], "file": "profiles/" + name}
+
+
 def run_grid(ctx, rows: int = 50, cols: int = 100, points: int = 500000, track: int = 9, iters: int = 10, seed: int = 42, cpu_iters: int = 0) -> dict:
     """The same size on a NON-sequence topology: a rows x cols block survey, shots numbered line after line, every
     point seen from ~3 lines -- co-visibility half-width ~2 x cols in shot order.  The solver renumbers the shots by a sweep along the
@@ -132,6 +149,13 @@ def run_general(ctx, shots: int = 5000, points: int = 500000, track: int = 10, i
            "cost": [float(g["initial_cost"]), float(g["final_cost"])], "ms_per_matvec": g["ms_per_matvec"],
            "bias": [float(x) for x in g["bias"][0]], "bias_true": [float(x) for x in pr["gt_bias"][0]],
            "lm_iteration_ms": round(1e3 * g["seconds_run"] / max(1, g["iterations"]), 3)}
+    # the generic rows' mat-vec: 2 x (6 Jp + 12 Jc + 2 x 9 border slots) doubles read by the two passes + w = 2 x 144 + 2 x 72 B / observation
+    alg = 288.0 + 144.0
+    if g["ms_per_matvec"]:
+        out["roofline"] = {"bound": "hbm", "kernel": "schur mat-vec, generic rows (gen_schur_point_kernel<2, 0> + gen_schur_shot_kernel<2, 9>)",
+                           "achieved": round(alg * nobs / (g["ms_per_matvec"] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(alg * nobs / (g["ms_per_matvec"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_obs": alg,
+                           "traffic": _pmc_traffic("r05_ba_generic_pmc.json", ("gen_schur_point_kernelILi2ELi0E", "gen_schur_shot_kernel"), nobs, alg)}
     if cpu_iters > 0:
         import oracle
 
@@ -247,19 +271,9 @@ def run(ctx, shots: int = 5000, points: int = 500000, track: int = 10, iters: in
         "scene_gen_s": round(t_gen, 2),
     }
     # HBM traffic of one mat-vec: PMC passes cannot run inside this process; the committed counters of `tools/prof_ba.py` at the same size
-    # (tools/r03_final_profiles.sh -> profiles/r03_ba_pmc.json: FETCH_SIZE doubled as the gfx950 guide prescribes, + WRITE_SIZE) are quoted
-    import json
-    import os
-
-    pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_ba_pmc.json")
-    if os.path.exists(pmc_file):
-        try:
-            pmc = json.load(open(pmc_file))
-            k = nobs / float(pmc["units_per_launch"])
-            out["roofline"]["traffic"] = {"hbm_read_bytes": pmc["fetch_bytes_corrected"] * k, "hbm_write_bytes": pmc["write_bytes"] * k,
-                                          "algorithmic_bytes": MATVEC_BYTES_PER_OBS * nobs, "source": pmc["source"]}
-        except (KeyError, ValueError):
-            pass
+    # (tools/pmc_passes.sh -> profiles/r05_ba_pmc.json: FETCH_SIZE doubled as the gfx950 guide prescribes, + WRITE_SIZE) are quoted -- and
+    # refused when they were taken on other kernels than the pair this block times
+    out["roofline"]["traffic"] = _pmc_traffic("r05_ba_pmc.json", ("23schur_point_coop_kernelILi0E", "17schur_shot_kernel"), nobs, MATVEC_BYTES_PER_OBS)
     out["lm_iteration"] = lm_iteration_line(g, nobs)
     if grid:
         for key, fn in (("grid_topology", lambda: run_grid(ctx, points=points, seed=seed, cpu_iters=2 if cpu_baseline else 0)),

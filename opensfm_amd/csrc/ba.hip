@@ -3469,44 +3469,52 @@ __global__ void unpermute2_kernel(const int *perm, const double *in, long M, dou
 // ---- batched fp64 GEMM on the matrix cores (round 5: replaces rocblas_dgemm_strided_batched in the dense-cluster cyclic reduction) ----
 // C = alpha op(A) op(B) + beta C, column-major, `batch` problems a stride apart (grid z).  A workgroup of four wavefronts owns a 64 x 64
 // tile of C, a wavefront a 32 x 32 quarter = 2 x 2 accumulators of v_mfma_f64_16x16x4_f64 (lane l feeds A[l % 16][l / 16] and
-// B[l / 16][l % 16]; register r of lane l holds C[4 r + l / 16][l % 16]).  K advances 16 at a time through LDS: the 64 x 16 panel of
-// op(A) and the 16 x 64 panel of op(B) are stored k-major with a row stride of 80 doubles, so the sixteen lanes of one k read 32
-// consecutive banks and the next k starts 32 banks on -- a half-wavefront's operand read is conflict-free.  The panels of step s + 1
-// are fetched into registers before the products of step s are issued (one LDS buffer, two barriers per step).  Edges (m, n, k not
-// multiples of the tile) are zero-filled on the way in and masked on the way out.  Flops are what this path is about: at the block
-// survey's 612-wide clusters a level is 2 m^3 x (5 products + the trailing updates of the blocked inversion) per cluster.
-constexpr int kGemmLd = 80;
+// B[l / 16][l % 16]; register r of lane l holds C[4 r + l / 16][l % 16]).  K advances 32 at a time through LDS: the 64 x 32 panel of
+// op(A) and the 32 x 64 panel of op(B) are stored k-major with a row stride of 80 doubles, so the sixteen lanes of one k read 32
+// consecutive banks and the next k starts 32 banks on -- a half-wavefront's operand read is conflict-free.  Two LDS buffers and two
+// register sets: while the 32 matrix instructions of step s run on one buffer, the panels of step s + 1 (fetched during step s - 1)
+// are written to the other and the global loads of step s + 3 are issued -- one barrier per step, and a load has two steps (~1 us of
+// matrix work) to arrive.  Most launches of this path are SMALL (ten to a hundred workgroups: a level's clusters x a panel's tiles),
+// i.e. bound by the latency chain of one workgroup's K loop, which is what the prefetch distance is for.  Edges (m, n, k not multiples
+// of the tile) are zero-filled on the way in and masked on the way out.
+constexpr int kGemmLd = 80, kGemmKs = 32;
+constexpr size_t kGemmLds = (size_t)4 * kGemmKs * kGemmLd * sizeof(double);  // A and B panels, twice
 typedef double gemm_v4d __attribute__((ext_vector_type(4)));
 template <bool TA, bool TB>
 __global__ void __launch_bounds__(256) dgemm_mfma_kernel(int m, int n, int k, double alpha, const double *A0, int lda, long sa, const double *B0, int ldb, long sb,
                                                           double beta, double *C0, int ldc, long sc) {
-  __shared__ double As[16 * kGemmLd], Bs[16 * kGemmLd];
+  extern __shared__ __attribute__((aligned(16))) double gemm_lds[];  // [buffer][A | B][kGemmKs][kGemmLd]
   const double *A = A0 + (long)blockIdx.z * sa, *B = B0 + (long)blockIdx.z * sb;
   double *C = C0 + (long)blockIdx.z * sc;
   const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wi = 32 * (wave & 1), wj = 32 * (wave >> 1);
   const int li = lane & 15, lk = lane >> 4;
-  // this thread's four elements of each panel per step: (row in the panel's k, column in its i / j)
-  double ra[4], rb[4];
-  auto fetch = [&](int k0) {
+  // this thread's eight elements of each panel per step: (k inside the panel, i / j inside the tile)
+  auto a_pos = [&](int q, int &ia, int &ka) {
+    if (!TA) {  // op(A)[i][k] = A[i + k lda]: contiguous in i
+      ia = tid & 63;
+      ka = (tid >> 6) + 4 * q;
+    } else {  // op(A)[i][k] = A[k + i lda]: contiguous in k
+      ka = tid & 31;
+      ia = (tid >> 5) + 8 * q;
+    }
+  };
+  auto b_pos = [&](int q, int &jb, int &kb) {
+    if (!TB) {  // op(B)[k][j] = B[k + j ldb]: contiguous in k
+      kb = tid & 31;
+      jb = (tid >> 5) + 8 * q;
+    } else {  // op(B)[k][j] = B[j + k ldb]: contiguous in j
+      jb = tid & 63;
+      kb = (tid >> 6) + 4 * q;
+    }
+  };
+  auto fetch = [&](int k0, double (&ra)[8], double (&rb)[8]) {
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      int ia, ka, kb, jb;
-      if (!TA) {  // op(A)[i][k] = A[i + k lda]: contiguous in i
-        ia = tid & 63;
-        ka = (tid >> 6) + 4 * q;
-      } else {  // op(A)[i][k] = A[k + i lda]: contiguous in k
-        ka = tid & 15;
-        ia = (tid >> 4) + 16 * q;
-      }
-      if (!TB) {  // op(B)[k][j] = B[k + j ldb]: contiguous in k
-        kb = tid & 15;
-        jb = (tid >> 4) + 16 * q;
-      } else {  // op(B)[k][j] = B[j + k ldb]: contiguous in j
-        jb = tid & 63;
-        kb = (tid >> 6) + 4 * q;
-      }
+    for (int q = 0; q < 8; q++) {
+      int ia, ka, jb, kb;
+      a_pos(q, ia, ka);
+      b_pos(q, jb, kb);
       const bool oa = i0 + ia < m && k0 + ka < k, ob = j0 + jb < n && k0 + kb < k;
       const long xa = !TA ? (long)(i0 + ia) + (long)(k0 + ka) * lda : (long)(k0 + ka) + (long)(i0 + ia) * lda;
       const long xb = !TB ? (long)(k0 + kb) + (long)(j0 + jb) * ldb : (long)(j0 + jb) + (long)(k0 + kb) * ldb;
@@ -3514,11 +3522,13 @@ __global__ void __launch_bounds__(256) dgemm_mfma_kernel(int m, int n, int k, do
       rb[q] = ob ? B[xb] : 0.0;
     }
   };
-  auto stage = [&]() {
+  auto stage = [&](int buf, const double (&ra)[8], const double (&rb)[8]) {
+    double *As = gemm_lds + (size_t)buf * 2 * kGemmKs * kGemmLd, *Bs = As + kGemmKs * kGemmLd;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int ia = !TA ? (tid & 63) : (tid >> 4) + 16 * q, ka = !TA ? (tid >> 6) + 4 * q : (tid & 15);
-      const int jb = !TB ? (tid >> 4) + 16 * q : (tid & 63), kb = !TB ? (tid & 15) : (tid >> 6) + 4 * q;
+    for (int q = 0; q < 8; q++) {
+      int ia, ka, jb, kb;
+      a_pos(q, ia, ka);
+      b_pos(q, jb, kb);
       As[ka * kGemmLd + ia] = ra[q];
       Bs[kb * kGemmLd + jb] = rb[q];
     }
@@ -3528,13 +3538,10 @@ __global__ void __launch_bounds__(256) dgemm_mfma_kernel(int m, int n, int k, do
   for (int a = 0; a < 2; a++)
 #pragma unroll
     for (int b = 0; b < 2; b++) acc[a][b] = (gemm_v4d){0.0, 0.0, 0.0, 0.0};
-  fetch(0);
-  for (int k0 = 0; k0 < k; k0 += 16) {
-    stage();
-    __syncthreads();
-    if (k0 + 16 < k) fetch(k0 + 16);
+  auto compute = [&](int buf) {
+    const double *As = gemm_lds + (size_t)buf * 2 * kGemmKs * kGemmLd, *Bs = As + kGemmKs * kGemmLd;
 #pragma unroll
-    for (int kk = 0; kk < 16; kk += 4) {
+    for (int kk = 0; kk < kGemmKs; kk += 4) {
       double va[2], vb[2];
 #pragma unroll
       for (int a = 0; a < 2; a++) va[a] = As[(kk + lk) * kGemmLd + wi + 16 * a + li];
@@ -3545,7 +3552,25 @@ __global__ void __launch_bounds__(256) dgemm_mfma_kernel(int m, int n, int k, do
 #pragma unroll
         for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[a], vb[b], acc[a][b], 0, 0, 0);
     }
+  };
+  const int nsteps = (k + kGemmKs - 1) / kGemmKs;
+  double fa0[8], fb0[8], fa1[8], fb1[8];
+  fetch(0, fa0, fb0);
+  stage(0, fa0, fb0);
+  fetch(kGemmKs, fa0, fb0);      // step 1
+  fetch(2 * kGemmKs, fa1, fb1);  // step 2
+  __syncthreads();
+  for (int s = 0; s < nsteps; s += 2) {
+    compute(0);  // step s
+    if (s + 1 < nsteps) stage(1, fa0, fb0);
+    fetch((s + 3) * kGemmKs, fa0, fb0);
     __syncthreads();
+    if (s + 1 < nsteps) {
+      compute(1);  // step s + 1
+      if (s + 2 < nsteps) stage(0, fa1, fb1);
+      fetch((s + 4) * kGemmKs, fa1, fb1);
+      __syncthreads();
+    }
   }
 #pragma unroll
   for (int a = 0; a < 2; a++)
@@ -3601,6 +3626,8 @@ struct Solver {
   int *g_cols = nullptr, *g_col_pos = nullptr;  // generic exact border: the border columns some view holds, and their positions (-1: none)
   int g_ncols = 0;
   double *g_wB = nullptr, *g_vpartB = nullptr;  // rows x ncols x NR, views x ncols x KW
+  bool gen_border_ch5 = getenv("OSFM_BA_BORDER_CH5") != nullptr;  // measurement knob: five columns per launch of gen_border_shot_kernel instead of three
+  int gen_uniform_model = -1;  // every camera has this projection type (the evaluation kernel is specialised for the common ones), -1: mixed
   bool have_bpri = false;  // a prior couples an instance with a free border block (position prior with a free bias, up vector / compass with a free rig camera)
 #define OSFM_GEN_KW(NRV, KERNEL, grid, block, stream, ...)                                                    \
   do {                                                                                                        \
@@ -3628,20 +3655,20 @@ struct Solver {
       (void)hipMemsetAsync(d.g.Cpri, 0, (size_t)std::max(1, d.g.NB * d.g.NB) * sizeof(double), st);
       (void)hipMemsetAsync(d.g.gpri, 0, (size_t)d.nred * sizeof(double), st);
     }
+#define OSFM_GEN_EVAL(NRV, MODELV)                                                                                                           \
+  do {                                                                                                                                       \
+    if (jac) {                                                                                                                               \
+      hipLaunchKernelGGL((gen_eval_kernel<NRV, true, false, MODELV>), dim3(nb), dim3(TPB), 0, st, d, cam, rcp, poses, pts, loss, loss_a);     \
+      hipLaunchKernelGGL((gen_eval_kernel<NRV, true, true, MODELV>), dim3(nb), dim3(TPB), 0, st, d, cam, rcp, poses, pts, loss, loss_a);      \
+    } else                                                                                                                                   \
+      hipLaunchKernelGGL((gen_eval_kernel<NRV, false, false, MODELV>), dim3(nb), dim3(TPB), 0, st, d, cam, rcp, poses, pts, loss, loss_a);    \
+  } while (0)
     if (d.M > 0) {
-      if (d.g.NRr == 3) {
-        if (jac) {
-          hipLaunchKernelGGL((gen_eval_kernel<3, true, false>), dim3(nb), dim3(TPB), 0, st, d, cam, rcp, poses, pts, loss, loss_a);
-          hipLaunchKernelGGL((gen_eval_kernel<3, true, true>), dim3(nb), dim3(TPB), 0, st, d, cam, rcp, poses, pts, loss, loss_a);
-        } else
-          hipLaunchKernelGGL((gen_eval_kernel<3, false, false>), dim3(nb), dim3(TPB), 0, st, d, cam, rcp, poses, pts, loss, loss_a);
-      } else {
-        if (jac) {
-          hipLaunchKernelGGL((gen_eval_kernel<2, true, false>), dim3(nb), dim3(TPB), 0, st, d, cam, rcp, poses, pts, loss, loss_a);
-          hipLaunchKernelGGL((gen_eval_kernel<2, true, true>), dim3(nb), dim3(TPB), 0, st, d, cam, rcp, poses, pts, loss, loss_a);
-        } else
-          hipLaunchKernelGGL((gen_eval_kernel<2, false, false>), dim3(nb), dim3(TPB), 0, st, d, cam, rcp, poses, pts, loss, loss_a);
-      }
+      if (d.g.NRr == 3) OSFM_GEN_EVAL(3, -1);
+      else if (gen_uniform_model == OSFM_CAMERA_BROWN) OSFM_GEN_EVAL(2, OSFM_CAMERA_BROWN);
+      else if (gen_uniform_model == OSFM_CAMERA_FISHEYE_OPENCV) OSFM_GEN_EVAL(2, OSFM_CAMERA_FISHEYE_OPENCV);
+      else if (gen_uniform_model == OSFM_CAMERA_PERSPECTIVE) OSFM_GEN_EVAL(2, OSFM_CAMERA_PERSPECTIVE);
+      else OSFM_GEN_EVAL(2, -1);
     }
     hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(1024), 0, st, d.partial, (long)(d.M > 0 ? nb : 0), 2, d.scal + 8);
     hipLaunchKernelGGL(gen_prior_kernel, dim3(nblk(gen_nprior(), 256)), dim3(256), gen_prior_lds(), st, d, cam, bias, rcp, poses, jac ? 1 : 0,
@@ -3685,6 +3712,7 @@ struct Solver {
     if (d.M > 0 && g_ncols > 0) {
       hipLaunchKernelGGL(gen_border_point_kernel<NRV>, dim3(d.nwg), dim3(kCoopObs), 0, sq, d, (const int *)g_cols, g_ncols, g_wB);
       if (d.g.KW <= 4) gen_border_chunks<NRV, 4, 4>(sq);
+      else if (d.g.KW <= 9 && gen_border_ch5) gen_border_chunks<NRV, 9, 5>(sq);
       else if (d.g.KW <= 9) gen_border_chunks<NRV, 9, 3>(sq);
       else if (d.g.KW <= 16) gen_border_chunks<NRV, 16, 2>(sq);
       else gen_border_chunks<NRV, kGenMaxKW, 2>(sq);
@@ -3775,10 +3803,10 @@ struct Solver {
                 int ldc, long sc, int batch) {
     if (m <= 0 || n <= 0 || batch <= 0) return;
     const dim3 grid((unsigned)((m + 63) / 64), (unsigned)((n + 63) / 64), (unsigned)batch);
-    if (!ta && !tb) hipLaunchKernelGGL((dgemm_mfma_kernel<false, false>), grid, dim3(256), 0, st, m, n, k, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc);
-    else if (ta && !tb) hipLaunchKernelGGL((dgemm_mfma_kernel<true, false>), grid, dim3(256), 0, st, m, n, k, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc);
-    else if (!ta && tb) hipLaunchKernelGGL((dgemm_mfma_kernel<false, true>), grid, dim3(256), 0, st, m, n, k, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc);
-    else hipLaunchKernelGGL((dgemm_mfma_kernel<true, true>), grid, dim3(256), 0, st, m, n, k, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc);
+    if (!ta && !tb) hipLaunchKernelGGL((dgemm_mfma_kernel<false, false>), grid, dim3(256), kGemmLds, st, m, n, k, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc);
+    else if (ta && !tb) hipLaunchKernelGGL((dgemm_mfma_kernel<true, false>), grid, dim3(256), kGemmLds, st, m, n, k, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc);
+    else if (!ta && tb) hipLaunchKernelGGL((dgemm_mfma_kernel<false, true>), grid, dim3(256), kGemmLds, st, m, n, k, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc);
+    else hipLaunchKernelGGL((dgemm_mfma_kernel<true, true>), grid, dim3(256), kGemmLds, st, m, n, k, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc);
   }
   // A_k <- A_k^-1 for `batch` SPD qm x qm blocks `strideA` apart: blocked Gauss-Jordan, panels of qT columns.  Per panel J:
   //   P = A_JJ^-1 (LDS), R = A_J,: and C = A_:,J copied (C's pivot rows zeroed);  Rn = P R;  A -= C Rn;  A_:,J = -C P;  A_J,: = Rn, A_JJ = P
@@ -3839,6 +3867,10 @@ struct Solver {
     {
       static OsfmPerDeviceOnce once;
       const int rca = once.run(ctx->device, []() -> int {
+        OSFM_HIP(hipFuncSetAttribute((const void *)dgemm_mfma_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        OSFM_HIP(hipFuncSetAttribute((const void *)dgemm_mfma_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        OSFM_HIP(hipFuncSetAttribute((const void *)dgemm_mfma_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        OSFM_HIP(hipFuncSetAttribute((const void *)dgemm_mfma_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         OSFM_HIP(hipFuncSetAttribute((const void *)dgj_pivot_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         OSFM_HIP(hipFuncSetAttribute((const void *)dgj_pivot_ahead_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         return OSFM_OK;
@@ -4337,6 +4369,10 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       }
     g.NB = nb;
     g.NRr = spherical ? 3 : 2;
+    sv.gen_uniform_model = G->cam_model[0];
+    for (int c = 1; c < NC; c++)
+      if (G->cam_model[c] != G->cam_model[0]) sv.gen_uniform_model = -1;
+    if (getenv("OSFM_BA_GENERIC_EVAL") != nullptr) sv.gen_uniform_model = -1;  // (self-check knob: the unspecialised evaluation kernel)
     int KW = 0;
     auto view_slots = [&](int v, int *cols) {  // returns the number of slots; cols[i] = border column of slot i
       const int c = G->view_cam[v], q = G->view_rc[v];

@@ -27,35 +27,37 @@ def per_call(path, kernel_substr, counter):
     return tot / max(1, len(calls)), len(calls)
 
 
-def main_ba():
+def main_ba(generic=False):
     """usage: pmc_to_json.py --ba <fetch.db> <write.db> <observations> <out.json>: one Schur mat-vec = schur_point_coop_kernel<0> +
-    schur_shot_kernel (per-call averages added)"""
+    schur_shot_kernel (per-call averages added); --ba-generic: the generic rows' pair, gen_schur_point_kernel<2, 0> + gen_schur_shot_kernel"""
     fetch_db, write_db, nobs, out = sys.argv[2], sys.argv[3], float(sys.argv[4]), sys.argv[5]
     f = w = 0.0
     calls = []
-    for k in ("schur_point_coop_kernelILi0E", "schur_shot_kernel"):
+    for k in (("gen_schur_point_kernelILi2ELi0E", "gen_schur_shot_kernel") if generic else ("23schur_point_coop_kernelILi0E", "17schur_shot_kernel")):
         fk, nf = per_call(fetch_db, k, 'FETCH_SIZE')
         wk, nw = per_call(write_db, k, 'WRITE_SIZE')
         f += fk
         w += wk
         calls.append([k, nf, nw, fk, wk])
-    json.dump({"kernel": "schur mat-vec (schur_point_coop_kernel<0> + schur_shot_kernel)", "units_per_launch": nobs, "per_kernel": calls,
+    json.dump({"kernel": "schur mat-vec, generic rows (gen_schur_point_kernel<2, 0> + gen_schur_shot_kernel)" if generic else
+               "schur mat-vec (schur_point_coop_kernel<0> + schur_shot_kernel)", "units_per_launch": nobs, "per_kernel": calls,
                "fetch_size_kb_raw": f, "write_size_kb_raw": w, "fetch_bytes_corrected": 2.0 * f * 1024.0, "write_bytes": w * 1024.0,
-               "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `python tools/prof_ba.py 5000 500000 10 5`; FETCH_SIZE x 2 per "
+               "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_passes.sh) of `python tools/prof_ba.py 5000 500000 10 5" +
+                         (" general" if generic else "") + "`; FETCH_SIZE x 2 per "
                          "MI355X_MICROARCH.md (gfx950 reports 64 B per 128 B request); counter unit KiB"}, open(out, 'w'), indent=1)
     print(open(out).read())
 
 
 def main():
-    if sys.argv[1] == "--ba":
-        return main_ba()
+    if sys.argv[1] in ("--ba", "--ba-generic"):
+        return main_ba(sys.argv[1] == "--ba-generic")
     fetch_db, write_db, ppl, out = sys.argv[1], sys.argv[2], float(sys.argv[3]), sys.argv[4]
     f, nf = per_call(fetch_db, 'match_fused_kernel', 'FETCH_SIZE')
     w, nw = per_call(write_db, 'match_fused_kernel', 'WRITE_SIZE')
     json.dump({"kernel": "match_fused_kernel", "pairs_per_launch": ppl, "launches_sampled": [nf, nw],
                "fetch_size_kb_raw": f, "write_size_kb_raw": w,
                "fetch_bytes_corrected": 2.0 * f * 1024.0, "write_bytes": w * 1024.0,
-               "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `python bench.py --headline-only --no-cpu-baseline --steps 1 "
+               "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_passes.sh) of `python bench.py --headline-only --no-cpu-baseline --steps 1 "
                          "--warmup 0`; FETCH_SIZE x 2 per MI355X_MICROARCH.md (gfx950 reports 64 B per 128 B request); "
                          "counter unit KiB"}, open(out, 'w'), indent=1)
     print(open(out).read())
