@@ -6,6 +6,10 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# The oracle's OpenMP loops on the GPU box's 256 hardware threads: test problems are small, and a parallel region per column of a
+# 400-row factorisation with 256 spinning threads once stalled a GPU test run for its whole time limit (round 5, first call).  The tests
+# do not measure the oracle (bench.py does, with every core): cap its team unless the caller has chosen.
+os.environ.setdefault("OMP_NUM_THREADS", "32")
 
 
 def pytest_configure(config):
