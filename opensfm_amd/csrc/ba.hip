@@ -3469,52 +3469,49 @@ __global__ void unpermute2_kernel(const int *perm, const double *in, long M, dou
 // ---- batched fp64 GEMM on the matrix cores (round 5: replaces rocblas_dgemm_strided_batched in the dense-cluster cyclic reduction) ----
 // C = alpha op(A) op(B) + beta C, column-major, `batch` problems a stride apart (grid z).  A workgroup of four wavefronts owns a 64 x 64
 // tile of C, a wavefront a 32 x 32 quarter = 2 x 2 accumulators of v_mfma_f64_16x16x4_f64 (lane l feeds A[l % 16][l / 16] and
-// B[l / 16][l % 16]; register r of lane l holds C[4 r + l / 16][l % 16]).  K advances 32 at a time through LDS: the 64 x 32 panel of
-// op(A) and the 32 x 64 panel of op(B) are stored k-major with a row stride of 80 doubles, so the sixteen lanes of one k read 32
-// consecutive banks and the next k starts 32 banks on -- a half-wavefront's operand read is conflict-free.  Two LDS buffers and two
-// register sets: while the 32 matrix instructions of step s run on one buffer, the panels of step s + 1 (fetched during step s - 1)
-// are written to the other and the global loads of step s + 3 are issued -- one barrier per step, and a load has two steps (~1 us of
-// matrix work) to arrive.  Most launches of this path are SMALL (ten to a hundred workgroups: a level's clusters x a panel's tiles),
-// i.e. bound by the latency chain of one workgroup's K loop, which is what the prefetch distance is for.  Edges (m, n, k not multiples
-// of the tile) are zero-filled on the way in and masked on the way out.
-constexpr int kGemmLd = 80, kGemmKs = 32;
-constexpr size_t kGemmLds = (size_t)4 * kGemmKs * kGemmLd * sizeof(double);  // A and B panels, twice
+// B[l / 16][l % 16]; register r of lane l holds C[4 r + l / 16][l % 16]).  K advances 16 at a time through LDS.  A panel is stored in
+// the orientation its GLOBAL layout is contiguous in, so that the wavefront's stores are consecutive addresses:
+//   contiguous along the tile's rows / columns (A not transposed, B transposed):  [k][i], row stride 80 doubles -- the sixteen lanes of
+//     one k read 32 consecutive banks and the next k starts 32 banks on;
+//   contiguous along k (A transposed, B not transposed):                          [i][k], row stride 18 doubles -- lane i of an operand
+//     read sits 36 banks after lane i - 1 (distinct multiples of four), the next k two banks on.
+// (The first version stored every panel [k][i]: the k-contiguous ones went in with a stride of 80 doubles between lanes -- two bank groups
+// for 64 lanes -- and the LDS stores, not the matrix pipe, set the pace: 2.2 x rocBLAS' time on the block survey.)  Two LDS buffers and
+// two register sets: while the matrix instructions of step s run on one buffer, the panels of step s + 1 are written to the other and
+// the global loads of step s + 3 are issued -- one barrier per step; 38 KB of LDS keeps four workgroups on a CU.  Edges (m, n, k not
+// multiples of the tile) are zero-filled on the way in and masked on the way out.  The C tile of an updating product (beta != 0) is
+// requested before the K loop.
+constexpr int kGemmKs = 16, kGemmLdM = 80, kGemmLdK = kGemmKs + 2;
+constexpr int kGemmPanel = 64 * kGemmLdK > kGemmKs * kGemmLdM ? 64 * kGemmLdK : kGemmKs * kGemmLdM;  // doubles of one panel in either orientation
+constexpr size_t kGemmLds = (size_t)4 * kGemmPanel * sizeof(double);                                  // A and B panels, twice
 typedef double gemm_v4d __attribute__((ext_vector_type(4)));
 template <bool TA, bool TB>
 __global__ void __launch_bounds__(256) dgemm_mfma_kernel(int m, int n, int k, double alpha, const double *A0, int lda, long sa, const double *B0, int ldb, long sb,
                                                           double beta, double *C0, int ldc, long sc) {
-  extern __shared__ __attribute__((aligned(16))) double gemm_lds[];  // [buffer][A | B][kGemmKs][kGemmLd]
+  extern __shared__ __attribute__((aligned(16))) double gemm_lds[];  // [buffer][A | B][kGemmPanel]
   const double *A = A0 + (long)blockIdx.z * sa, *B = B0 + (long)blockIdx.z * sb;
   double *C = C0 + (long)blockIdx.z * sc;
   const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wi = 32 * (wave & 1), wj = 32 * (wave >> 1);
   const int li = lane & 15, lk = lane >> 4;
-  // this thread's eight elements of each panel per step: (k inside the panel, i / j inside the tile)
-  auto a_pos = [&](int q, int &ia, int &ka) {
-    if (!TA) {  // op(A)[i][k] = A[i + k lda]: contiguous in i
-      ia = tid & 63;
-      ka = (tid >> 6) + 4 * q;
-    } else {  // op(A)[i][k] = A[k + i lda]: contiguous in k
-      ka = tid & 31;
-      ia = (tid >> 5) + 8 * q;
+  constexpr bool AK = TA, BK = !TB;  // the panel is contiguous along k in global memory
+  // this thread's four elements of each panel per step: (k inside the panel, row / column inside the tile)
+  auto pos = [&](bool kmajor, int q, int &x, int &kk) {
+    if (!kmajor) {  // contiguous along the tile's rows / columns
+      x = tid & 63;
+      kk = (tid >> 6) + 4 * q;
+    } else {  // contiguous along k
+      kk = tid & 15;
+      x = (tid >> 4) + 16 * q;
     }
   };
-  auto b_pos = [&](int q, int &jb, int &kb) {
-    if (!TB) {  // op(B)[k][j] = B[k + j ldb]: contiguous in k
-      kb = tid & 31;
-      jb = (tid >> 5) + 8 * q;
-    } else {  // op(B)[k][j] = B[j + k ldb]: contiguous in j
-      jb = tid & 63;
-      kb = (tid >> 6) + 4 * q;
-    }
-  };
-  auto fetch = [&](int k0, double (&ra)[8], double (&rb)[8]) {
+  auto fetch = [&](int k0, double (&ra)[4], double (&rb)[4]) {
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
+    for (int q = 0; q < 4; q++) {
       int ia, ka, jb, kb;
-      a_pos(q, ia, ka);
-      b_pos(q, jb, kb);
+      pos(AK, q, ia, ka);
+      pos(BK, q, jb, kb);
       const bool oa = i0 + ia < m && k0 + ka < k, ob = j0 + jb < n && k0 + kb < k;
       const long xa = !TA ? (long)(i0 + ia) + (long)(k0 + ka) * lda : (long)(k0 + ka) + (long)(i0 + ia) * lda;
       const long xb = !TB ? (long)(k0 + kb) + (long)(j0 + jb) * ldb : (long)(j0 + jb) + (long)(k0 + kb) * ldb;
@@ -3522,15 +3519,15 @@ __global__ void __launch_bounds__(256) dgemm_mfma_kernel(int m, int n, int k, do
       rb[q] = ob ? B[xb] : 0.0;
     }
   };
-  auto stage = [&](int buf, const double (&ra)[8], const double (&rb)[8]) {
-    double *As = gemm_lds + (size_t)buf * 2 * kGemmKs * kGemmLd, *Bs = As + kGemmKs * kGemmLd;
+  auto stage = [&](int buf, const double (&ra)[4], const double (&rb)[4]) {
+    double *As = gemm_lds + (size_t)buf * 2 * kGemmPanel, *Bs = As + kGemmPanel;
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
+    for (int q = 0; q < 4; q++) {
       int ia, ka, jb, kb;
-      a_pos(q, ia, ka);
-      b_pos(q, jb, kb);
-      As[ka * kGemmLd + ia] = ra[q];
-      Bs[kb * kGemmLd + jb] = rb[q];
+      pos(AK, q, ia, ka);
+      pos(BK, q, jb, kb);
+      As[AK ? ia * kGemmLdK + ka : ka * kGemmLdM + ia] = ra[q];
+      Bs[BK ? jb * kGemmLdK + kb : kb * kGemmLdM + jb] = rb[q];
     }
   };
   gemm_v4d acc[2][2];
@@ -3539,36 +3536,49 @@ __global__ void __launch_bounds__(256) dgemm_mfma_kernel(int m, int n, int k, do
 #pragma unroll
     for (int b = 0; b < 2; b++) acc[a][b] = (gemm_v4d){0.0, 0.0, 0.0, 0.0};
   auto compute = [&](int buf) {
-    const double *As = gemm_lds + (size_t)buf * 2 * kGemmKs * kGemmLd, *Bs = As + kGemmKs * kGemmLd;
+    const double *As = gemm_lds + (size_t)buf * 2 * kGemmPanel, *Bs = As + kGemmPanel;
 #pragma unroll
     for (int kk = 0; kk < kGemmKs; kk += 4) {
       double va[2], vb[2];
 #pragma unroll
-      for (int a = 0; a < 2; a++) va[a] = As[(kk + lk) * kGemmLd + wi + 16 * a + li];
+      for (int a = 0; a < 2; a++) va[a] = As[AK ? (wi + 16 * a + li) * kGemmLdK + kk + lk : (kk + lk) * kGemmLdM + wi + 16 * a + li];
 #pragma unroll
-      for (int b = 0; b < 2; b++) vb[b] = Bs[(kk + lk) * kGemmLd + wj + 16 * b + li];
+      for (int b = 0; b < 2; b++) vb[b] = Bs[BK ? (wj + 16 * b + li) * kGemmLdK + kk + lk : (kk + lk) * kGemmLdM + wj + 16 * b + li];
 #pragma unroll
       for (int a = 0; a < 2; a++)
 #pragma unroll
         for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[a], vb[b], acc[a][b], 0, 0, 0);
     }
   };
+  // the C tile of an updating product, requested before anything else
+  double cold[2][2][4];
+  if (beta != 0.0) {
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int b = 0; b < 2; b++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int i = i0 + wi + 16 * a + 4 * r + lk, j = j0 + wj + 16 * b + li;
+          cold[a][b][r] = (i < m && j < n) ? C[(long)i + (long)j * ldc] : 0.0;
+        }
+  }
   const int nsteps = (k + kGemmKs - 1) / kGemmKs;
-  double fa0[8], fb0[8], fa1[8], fb1[8];
+  double fa0[4], fb0[4], fa1[4], fb1[4];
   fetch(0, fa0, fb0);
+  fetch(kGemmKs, fa1, fb1);  // step 1
   stage(0, fa0, fb0);
-  fetch(kGemmKs, fa0, fb0);      // step 1
-  fetch(2 * kGemmKs, fa1, fb1);  // step 2
+  fetch(2 * kGemmKs, fa0, fb0);  // step 2
   __syncthreads();
   for (int s = 0; s < nsteps; s += 2) {
     compute(0);  // step s
-    if (s + 1 < nsteps) stage(1, fa0, fb0);
-    fetch((s + 3) * kGemmKs, fa0, fb0);
+    if (s + 1 < nsteps) stage(1, fa1, fb1);
+    fetch((s + 3) * kGemmKs, fa1, fb1);
     __syncthreads();
     if (s + 1 < nsteps) {
       compute(1);  // step s + 1
-      if (s + 2 < nsteps) stage(0, fa1, fb1);
-      fetch((s + 4) * kGemmKs, fa1, fb1);
+      if (s + 2 < nsteps) stage(0, fa0, fb0);
+      fetch((s + 4) * kGemmKs, fa0, fb0);
       __syncthreads();
     }
   }
@@ -3579,10 +3589,7 @@ __global__ void __launch_bounds__(256) dgemm_mfma_kernel(int m, int n, int k, do
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int i = i0 + wi + 16 * a + 4 * r + lk, j = j0 + wj + 16 * b + li;
-        if (i < m && j < n) {
-          double *dst = C + (long)i + (long)j * ldc;
-          *dst = alpha * acc[a][b][r] + (beta == 0.0 ? 0.0 : beta * *dst);
-        }
+        if (i < m && j < n) C[(long)i + (long)j * ldc] = alpha * acc[a][b][r] + (beta == 0.0 ? 0.0 : beta * cold[a][b][r]);
       }
 }
 
@@ -3626,7 +3633,9 @@ struct Solver {
   int *g_cols = nullptr, *g_col_pos = nullptr;  // generic exact border: the border columns some view holds, and their positions (-1: none)
   int g_ncols = 0;
   double *g_wB = nullptr, *g_vpartB = nullptr;  // rows x ncols x NR, views x ncols x KW
-  bool gen_border_ch5 = getenv("OSFM_BA_BORDER_CH5") != nullptr;  // measurement knob: five columns per launch of gen_border_shot_kernel instead of three
+  // five columns per launch of gen_border_shot_kernel for up to nine border slots (a Brown camera: two launches instead of three; measured 7.46
+  // against 7.96 ms per LM iteration at configs[4] although the kernel then runs one wave per SIMD); OSFM_BA_BORDER_CH3 = three per launch
+  bool gen_border_ch5 = getenv("OSFM_BA_BORDER_CH3") == nullptr;
   int gen_uniform_model = -1;  // every camera has this projection type (the evaluation kernel is specialised for the common ones), -1: mixed
   bool have_bpri = false;  // a prior couples an instance with a free border block (position prior with a free bias, up vector / compass with a free rig camera)
 #define OSFM_GEN_KW(NRV, KERNEL, grid, block, stream, ...)                                                    \

@@ -56,3 +56,16 @@ def test_product_path_fails_loudly_without_gpu_or_library(monkeypatch):
     monkeypatch.setattr(_lib, "_lib", None)
     with pytest.raises(_lib.OsfmError):
         _lib.load()
+
+
+def test_library_links_no_vendor_math_library():
+    """round 5: the dense reduced system + rocSOLVER Cholesky and the rocBLAS batched products are gone -- every kernel on the path is this
+    repository's; the shared library needs the HIP runtime only"""
+    import subprocess
+
+    from opensfm_amd import _lib
+
+    out = subprocess.run(["ldd", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "libamdhip64" in out
+    for name in ("rocblas", "rocsolver", "hipblas", "rocsparse", "MIOpen"):
+        assert name not in out, out

@@ -90,3 +90,16 @@ def test_generic_mode_constant_blocks_count_in_the_cost(oracle_lib):
     g, _ = _compare_general(oracle_lib, pr, iters=3)
     assert np.array_equal(g["cam_params"], pr["cam_params"]) and np.array_equal(g["rig_instance_pose"][[0, 4]], pr["rig_instance_pose"][[0, 4]])
     assert np.array_equal(g["points"][pr["point_fixed"] == 1], pr["points"][pr["point_fixed"] == 1])
+
+
+def test_wide_band_on_the_hand_written_gemm_matches_oracle(oracle_lib):
+    """ragged tracks: co-visibility half-width beyond the cluster-tridiagonal band -> cyclic reduction over dense clusters, every batched
+    product on dgemm_mfma_kernel (NN, NT and TN forms, edges that are not multiples of the 64 x 64 tile or of the K step of 32)"""
+    from opensfm_amd import bundle
+
+    pr = synthetic.make_ba_scene(90, 800, 8, seed=3, ragged=True)
+    with emulated():
+        g = bundle.bundle_arrays(pr, {"bundle_max_iterations": 2}, **NO_TOL)
+    o = oracle_lib.ba_solve(pr, max_iterations=2, **NO_TOL)
+    assert g["preconditioner_bandwidth"] == g["shot_bandwidth"] > 10
+    assert np.allclose(g["cost_history"], o["cost_history"], rtol=1e-10)
