@@ -3485,26 +3485,44 @@ constexpr int kGemmKs = 16, kGemmLdM = 80, kGemmLdK = kGemmKs + 2;
 constexpr int kGemmPanel = 64 * kGemmLdK > kGemmKs * kGemmLdM ? 64 * kGemmLdK : kGemmKs * kGemmLdM;  // doubles of one panel in either orientation
 constexpr size_t kGemmLds = (size_t)4 * kGemmPanel * sizeof(double);                                  // A and B panels, twice
 typedef double gemm_v4d __attribute__((ext_vector_type(4)));
-template <bool TA, bool TB>
-__global__ void __launch_bounds__(256) dgemm_mfma_kernel(int m, int n, int k, double alpha, const double *A0, int lda, long sa, const double *B0, int ldb, long sb,
-                                                          double beta, double *C0, int ldc, long sc) {
+// One launch carries up to three INDEPENDENT products (grid z = the sum of their batches): most launches of this path are small -- a
+// level's few clusters x a panel's tiles --, and products that do not depend on each other (G = D^-1 E and H = D^-1 E_r^T; the trailing
+// update of a panel and the panel's own column block) fill the chip together instead of one after the other.  skip_j0 .. skip_j1: columns
+// of C this product leaves alone (the trailing update of the blocked inversion skips the panel's columns, which its sibling writes).
+struct GemmProb {
+  int ta, tb, m, n, k, lda, ldb, ldc, batch, skip_j0, skip_j1;
+  double alpha, beta;
+  const double *A, *B;
+  double *C;
+  long sa, sb, sc;
+};
+struct GemmList {
+  int np;
+  GemmProb p[3];
+};
+__global__ void __launch_bounds__(256) dgemm_mfma_kernel(GemmList L) {
   extern __shared__ __attribute__((aligned(16))) double gemm_lds[];  // [buffer][A | B][kGemmPanel]
-  const double *A = A0 + (long)blockIdx.z * sa, *B = B0 + (long)blockIdx.z * sb;
-  double *C = C0 + (long)blockIdx.z * sc;
+  int which = 0, zq = blockIdx.z;
+  while (which + 1 < L.np && zq >= L.p[which].batch) {
+    zq -= L.p[which].batch;
+    which++;
+  }
+  const GemmProb &P = L.p[which];
+  const int m = P.m, n = P.n, k = P.k, lda = P.lda, ldb = P.ldb, ldc = P.ldc;
   const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
+  if (i0 >= m || j0 >= n) return;  // (the grid is sized for the largest product of the launch)
+  const double *A = P.A + (long)zq * P.sa, *B = P.B + (long)zq * P.sb;
+  double *C = P.C + (long)zq * P.sc;
+  const double alpha = P.alpha, beta = P.beta;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wi = 32 * (wave & 1), wj = 32 * (wave >> 1);
   const int li = lane & 15, lk = lane >> 4;
-  constexpr bool AK = TA, BK = !TB;  // the panel is contiguous along k in global memory
+  const bool TA = P.ta != 0, TB = P.tb != 0;
+  const bool AK = TA, BK = !TB;  // the panel is contiguous along k in global memory
   // this thread's four elements of each panel per step: (k inside the panel, row / column inside the tile)
   auto pos = [&](bool kmajor, int q, int &x, int &kk) {
-    if (!kmajor) {  // contiguous along the tile's rows / columns
-      x = tid & 63;
-      kk = (tid >> 6) + 4 * q;
-    } else {  // contiguous along k
-      kk = tid & 15;
-      x = (tid >> 4) + 16 * q;
-    }
+    x = kmajor ? (tid >> 4) + 16 * q : (tid & 63);
+    kk = kmajor ? (tid & 15) : (tid >> 6) + 4 * q;
   };
   auto fetch = [&](int k0, double (&ra)[4], double (&rb)[4]) {
 #pragma unroll
@@ -3535,15 +3553,18 @@ __global__ void __launch_bounds__(256) dgemm_mfma_kernel(int m, int n, int k, do
   for (int a = 0; a < 2; a++)
 #pragma unroll
     for (int b = 0; b < 2; b++) acc[a][b] = (gemm_v4d){0.0, 0.0, 0.0, 0.0};
+  // operand addresses inside a panel: base + kk * step
+  const int aBase = AK ? (wi + li) * kGemmLdK + lk : lk * kGemmLdM + wi + li, aTile = AK ? 16 * kGemmLdK : 16, aStep = AK ? 1 : kGemmLdM;
+  const int bBase = BK ? (wj + li) * kGemmLdK + lk : lk * kGemmLdM + wj + li, bTile = BK ? 16 * kGemmLdK : 16, bStep = BK ? 1 : kGemmLdM;
   auto compute = [&](int buf) {
     const double *As = gemm_lds + (size_t)buf * 2 * kGemmPanel, *Bs = As + kGemmPanel;
 #pragma unroll
     for (int kk = 0; kk < kGemmKs; kk += 4) {
       double va[2], vb[2];
 #pragma unroll
-      for (int a = 0; a < 2; a++) va[a] = As[AK ? (wi + 16 * a + li) * kGemmLdK + kk + lk : (kk + lk) * kGemmLdM + wi + 16 * a + li];
+      for (int a = 0; a < 2; a++) va[a] = As[aBase + a * aTile + kk * aStep];
 #pragma unroll
-      for (int b = 0; b < 2; b++) vb[b] = Bs[BK ? (wj + 16 * b + li) * kGemmLdK + kk + lk : (kk + lk) * kGemmLdM + wj + 16 * b + li];
+      for (int b = 0; b < 2; b++) vb[b] = Bs[bBase + b * bTile + kk * bStep];
 #pragma unroll
       for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -3589,7 +3610,7 @@ __global__ void __launch_bounds__(256) dgemm_mfma_kernel(int m, int n, int k, do
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int i = i0 + wi + 16 * a + 4 * r + lk, j = j0 + wj + 16 * b + li;
-        if (i < m && j < n) C[(long)i + (long)j * ldc] = alpha * acc[a][b][r] + (beta == 0.0 ? 0.0 : beta * cold[a][b][r]);
+        if (i < m && j < n && !(j >= P.skip_j0 && j < P.skip_j1)) C[(long)i + (long)j * ldc] = alpha * acc[a][b][r] + (beta == 0.0 ? 0.0 : beta * cold[a][b][r]);
       }
 }
 
@@ -3807,15 +3828,32 @@ struct Solver {
     hipLaunchKernelGGL(wide_store_kernel<NR>, dim3(nblk(std::max<long>(6L * d.S, d.NC))), dim3(TPB), 0, st, d, rs);
   }
   // ---- dense-cluster cyclic reduction of the wide band (kernels: dbcr_*) ----
-  // C = alpha op(A) op(B) + beta C for `batch` column-major problems a stride apart (dgemm_mfma_kernel)
+  // C = alpha op(A) op(B) + beta C for `batch` column-major problems a stride apart (dgemm_mfma_kernel); gemm_launch sends up to three
+  // independent products in one launch
+  static GemmProb gemm_prob(bool ta, bool tb, int m, int n, int k, double alpha, const double *A, int lda, long sa, const double *B, int ldb, long sb, double beta,
+                            double *C, int ldc, long sc, int batch, int skip_j0 = 0, int skip_j1 = 0) {
+    GemmProb p;
+    p.ta = ta; p.tb = tb; p.m = m; p.n = n; p.k = k; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.batch = batch; p.skip_j0 = skip_j0; p.skip_j1 = skip_j1;
+    p.alpha = alpha; p.beta = beta; p.A = A; p.B = B; p.C = C; p.sa = sa; p.sb = sb; p.sc = sc;
+    return p;
+  }
+  void gemm_launch(std::initializer_list<GemmProb> probs) {
+    GemmList L;
+    L.np = 0;
+    int mx = 0, nx = 0, z = 0;
+    for (const GemmProb &p : probs) {
+      if (p.m <= 0 || p.n <= 0 || p.batch <= 0) continue;
+      L.p[L.np++] = p;
+      mx = std::max(mx, p.m);
+      nx = std::max(nx, p.n);
+      z += p.batch;
+    }
+    if (L.np == 0) return;
+    hipLaunchKernelGGL(dgemm_mfma_kernel, dim3((unsigned)((mx + 63) / 64), (unsigned)((nx + 63) / 64), (unsigned)z), dim3(256), kGemmLds, st, L);
+  }
   void dgemm_sb(bool ta, bool tb, int m, int n, int k, double alpha, const double *A, int lda, long sa, const double *B, int ldb, long sb, double beta, double *C,
                 int ldc, long sc, int batch) {
-    if (m <= 0 || n <= 0 || batch <= 0) return;
-    const dim3 grid((unsigned)((m + 63) / 64), (unsigned)((n + 63) / 64), (unsigned)batch);
-    if (!ta && !tb) hipLaunchKernelGGL((dgemm_mfma_kernel<false, false>), grid, dim3(256), kGemmLds, st, m, n, k, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc);
-    else if (ta && !tb) hipLaunchKernelGGL((dgemm_mfma_kernel<true, false>), grid, dim3(256), kGemmLds, st, m, n, k, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc);
-    else if (!ta && tb) hipLaunchKernelGGL((dgemm_mfma_kernel<false, true>), grid, dim3(256), kGemmLds, st, m, n, k, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc);
-    else hipLaunchKernelGGL((dgemm_mfma_kernel<true, true>), grid, dim3(256), kGemmLds, st, m, n, k, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc);
+    gemm_launch({gemm_prob(ta, tb, m, n, k, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, batch)});
   }
   // A_k <- A_k^-1 for `batch` SPD qm x qm blocks `strideA` apart: blocked Gauss-Jordan, panels of qT columns.  Per panel J:
   //   P = A_JJ^-1 (LDS), R = A_J,: and C = A_:,J copied (C's pivot rows zeroed);  Rn = P R;  A -= C Rn;  A_:,J = -C P;  A_J,: = Rn, A_JJ = P
@@ -3844,8 +3882,8 @@ struct Solver {
                            (const double *)d.qRn, (const double *)d.qBn, Pb[(J + 1) & 1], d_status);
         OSFM_HIP(hipEventRecord(ev_p[(J + 1) & 1], st3));
       }
-      dgemm_sb(false, false, m, m, w, neg, d.qC, m, sR, d.qRn, T, sR, one, A, m, strideA, batch);
-      dgemm_sb(false, false, m, w, w, neg, d.qC, m, sR, P, T, sP, zero, A + (long)j0 * m, m, strideA, batch);
+      gemm_launch({gemm_prob(false, false, m, m, w, neg, d.qC, m, sR, d.qRn, T, sR, one, A, m, strideA, batch, j0, j0 + w),
+                   gemm_prob(false, false, m, w, w, neg, d.qC, m, sR, P, T, sP, zero, A + (long)j0 * m, m, strideA, batch)});
       hipLaunchKernelGGL(dgj_scatter_kernel, dim3((unsigned)(((long)w * m + 255) / 256), batch), dim3(256), 0, st, A, strideA, m, T, j0, w, (const double *)P,
                          (const double *)d.qRn);
       if (wn > 0) OSFM_HIP(hipStreamWaitEvent(st, ev_p[(J + 1) & 1], 0));  // before the next panel's copies overwrite what the pivot kernel reads
@@ -3863,8 +3901,9 @@ struct Solver {
       hipLaunchKernelGGL(dgj_pivot_kernel, dim3(1 + ncopy, batch), dim3(256), (size_t)kWB * kWLd * sizeof(double), st, A, strideA, m, T, j0, w, d.qP, d.qR,
                          d.qC, d_status);
       dgemm_sb(false, false, w, m, w, one, d.qP, T, sP, d.qR, T, sR, zero, d.qRn, T, sR, batch);
-      dgemm_sb(false, false, m, m, w, neg, d.qC, m, sR, d.qRn, T, sR, one, A, m, strideA, batch);
-      dgemm_sb(false, false, m, w, w, neg, d.qC, m, sR, d.qP, T, sP, zero, A + (long)j0 * m, m, strideA, batch);
+      // the trailing update (which leaves the panel's columns alone) and the panel's own column block, -C P, in one launch
+      gemm_launch({gemm_prob(false, false, m, m, w, neg, d.qC, m, sR, d.qRn, T, sR, one, A, m, strideA, batch, j0, j0 + w),
+                   gemm_prob(false, false, m, w, w, neg, d.qC, m, sR, d.qP, T, sP, zero, A + (long)j0 * m, m, strideA, batch)});
       hipLaunchKernelGGL(dgj_scatter_kernel, dim3((unsigned)(((long)w * m + 255) / 256), batch), dim3(256), 0, st, A, strideA, m, T, j0, w, d.qP, d.qRn);
     }
     return OSFM_OK;
@@ -3876,10 +3915,6 @@ struct Solver {
     {
       static OsfmPerDeviceOnce once;
       const int rca = once.run(ctx->device, []() -> int {
-        OSFM_HIP(hipFuncSetAttribute((const void *)dgemm_mfma_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        OSFM_HIP(hipFuncSetAttribute((const void *)dgemm_mfma_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        OSFM_HIP(hipFuncSetAttribute((const void *)dgemm_mfma_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        OSFM_HIP(hipFuncSetAttribute((const void *)dgemm_mfma_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         OSFM_HIP(hipFuncSetAttribute((const void *)dgj_pivot_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         OSFM_HIP(hipFuncSetAttribute((const void *)dgj_pivot_ahead_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         return OSFM_OK;
@@ -3897,16 +3932,15 @@ struct Solver {
       const int rci = dbcr_invert_batch(Di, sk, ne, d_status);
       if (rci != OSFM_OK) return rci;
       // G_i = D_i^-1 E_i,  H_i = D_i^-1 E_r^T
-      dgemm_sb(false, false, m, m, m, one, Di, m, sk, Ei, m, sk, zero, Xi, m, 2 * sk, ne);
-      if (nR > 0)
-        dgemm_sb(false, true, m, m, m, one, Di, m, sk, Er, m, sk, zero, Xi + m2, m, 2 * sk, nR);
+      gemm_launch({gemm_prob(false, false, m, m, m, one, Di, m, sk, Ei, m, sk, zero, Xi, m, 2 * sk, ne),
+                   gemm_prob(false, true, m, m, m, one, Di, m, sk, Er, m, sk, zero, Xi + m2, m, 2 * sk, nR)});
       hipLaunchKernelGGL(dbcr_transpose_kernel, dim3(tl, tl, 2 * ne), dim3(256), 0, st, Xi, 2 * sk, m2, d.qXt + (long)s * 2 * m2, 2 * sk, m2, m, 2);
-      if (nR > 0)  // D_{i+s} -= E_r H_i
-        dgemm_sb(false, false, m, m, m, neg, Er, m, sk, Xi + m2, m, 2 * sk, one, d.qD + 2L * s * m2, m, sk, nR);
-      // D_{i-s} -= E_i^T G_i
+      // D_{i+s} -= E_r H_i and E_{i+s} <- -E_r G_i (into the other buffer: E_r is an operand) together; D_{i-s} -= E_i^T G_i in a launch
+      // of its own: a surviving cluster is the right neighbour of one eliminated cluster and the left neighbour of the next, so the two
+      // updates of its D must not run side by side
+      gemm_launch({gemm_prob(false, false, m, m, m, neg, Er, m, sk, Xi + m2, m, 2 * sk, one, d.qD + 2L * s * m2, m, sk, nR),
+                   gemm_prob(false, false, m, m, m, neg, Er, m, sk, Xi, m, 2 * sk, zero, d.qE[1 - cur] + 2L * s * m2, m, sk, nR)});
       dgemm_sb(true, false, m, m, m, neg, Ei, m, sk, Xi, m, 2 * sk, one, d.qD, m, sk, ne);
-      if (nR > 0)  // E_{i+s} <- -E_r G_i (into the other buffer: E_r is an operand)
-        dgemm_sb(false, false, m, m, m, neg, Er, m, sk, Xi, m, 2 * sk, zero, d.qE[1 - cur] + 2L * s * m2, m, sk, nR);
       cur ^= 1;
     }
     const int rcr = dbcr_invert_batch(d.qD, m2, 1, d_status);  // the last cluster standing
