@@ -3500,7 +3500,7 @@ struct GemmList {
   int np;
   GemmProb p[3];
 };
-__global__ void __launch_bounds__(256) dgemm_mfma_kernel(GemmList L) {
+__global__ void __launch_bounds__(256, 4) dgemm_mfma_kernel(GemmList L) {
   extern __shared__ __attribute__((aligned(16))) double gemm_lds[];  // [buffer][A | B][kGemmPanel]
   int which = 0, zq = blockIdx.z;
   while (which + 1 < L.np && zq >= L.p[which].batch) {
@@ -3548,11 +3548,19 @@ __global__ void __launch_bounds__(256) dgemm_mfma_kernel(GemmList L) {
       Bs[BK ? jb * kGemmLdK + kb : kb * kGemmLdM + jb] = rb[q];
     }
   };
+  // The accumulators start from (beta / alpha) C -- alpha (op(A) op(B) + (beta / alpha) C) is the product asked for, exactly so for the
+  // +-1 and 0 this path passes: the C tile of an updating product is requested before anything else and needs no registers of its own
   gemm_v4d acc[2][2];
+  const double cscale = beta == 0.0 ? 0.0 : beta / alpha;
 #pragma unroll
   for (int a = 0; a < 2; a++)
 #pragma unroll
-    for (int b = 0; b < 2; b++) acc[a][b] = (gemm_v4d){0.0, 0.0, 0.0, 0.0};
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int i = i0 + wi + 16 * a + 4 * r + lk, j = j0 + wj + 16 * b + li;
+        acc[a][b][r] = (beta != 0.0 && i < m && j < n) ? cscale * C[(long)i + (long)j * ldc] : 0.0;
+      }
   // operand addresses inside a panel: base + kk * step
   const int aBase = AK ? (wi + li) * kGemmLdK + lk : lk * kGemmLdM + wi + li, aTile = AK ? 16 * kGemmLdK : 16, aStep = AK ? 1 : kGemmLdM;
   const int bBase = BK ? (wj + li) * kGemmLdK + lk : lk * kGemmLdM + wj + li, bTile = BK ? 16 * kGemmLdK : 16, bStep = BK ? 1 : kGemmLdM;
@@ -3571,19 +3579,6 @@ __global__ void __launch_bounds__(256) dgemm_mfma_kernel(GemmList L) {
         for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[a], vb[b], acc[a][b], 0, 0, 0);
     }
   };
-  // the C tile of an updating product, requested before anything else
-  double cold[2][2][4];
-  if (beta != 0.0) {
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-      for (int b = 0; b < 2; b++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int i = i0 + wi + 16 * a + 4 * r + lk, j = j0 + wj + 16 * b + li;
-          cold[a][b][r] = (i < m && j < n) ? C[(long)i + (long)j * ldc] : 0.0;
-        }
-  }
   const int nsteps = (k + kGemmKs - 1) / kGemmKs;
   double fa0[4], fb0[4], fa1[4], fb1[4];
   fetch(0, fa0, fb0);
@@ -3610,7 +3605,7 @@ __global__ void __launch_bounds__(256) dgemm_mfma_kernel(GemmList L) {
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int i = i0 + wi + 16 * a + 4 * r + lk, j = j0 + wj + 16 * b + li;
-        if (i < m && j < n && !(j >= P.skip_j0 && j < P.skip_j1)) C[(long)i + (long)j * ldc] = alpha * acc[a][b][r] + (beta == 0.0 ? 0.0 : beta * cold[a][b][r]);
+        if (i < m && j < n && !(j >= P.skip_j0 && j < P.skip_j1)) C[(long)i + (long)j * ldc] = alpha * acc[a][b][r];
       }
 }
 
