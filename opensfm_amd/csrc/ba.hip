@@ -4843,8 +4843,11 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     }
   }
   bool border_ok = getenv("OSFM_BA_NO_BORDER") == nullptr;  // exact camera border: every camera free (generic mode: the border holds free blocks only)
-  for (int c = 0; c < NC && !gen; c++)
+  bool all_cams_fixed = !gen;
+  for (int c = 0; c < NC && !gen; c++) {
     if (P->cam_fixed[c]) border_ok = false;
+    else all_cams_fixed = false;
+  }
   int *d_status = A.alloc<int>(4, e);
   double *d_reproj = (gen ? G->reproj3 != nullptr : P->reproj_err != nullptr) ? A.alloc<double>((size_t)(gen ? 3 : 2) * M, e) : nullptr;
   OSFM_REQUIRE(e == hipSuccess, OSFM_E_NOMEM, "BA device allocation/upload failed: %s", hipGetErrorString(e));
@@ -5200,6 +5203,11 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
           if (g.NRr == 3) hipLaunchKernelGGL(gen_precond_shot_kernel<3>, dim3(S), dim3(64), 0, st, d, radius);
           else hipLaunchKernelGGL(gen_precond_shot_kernel<2>, dim3(S), dim3(64), 0, st, d, radius);
         }
+      } else if ((sv.use_bcr || sv.use_wide) && all_cams_fixed) {
+        // local / pose-only bundle adjustment: the band is the whole preconditioner and the camera rows are inert (zero scale, zero right-hand
+        // side) -- their 3 x 3 blocks are the LM diagonal alone; the per-shot Schur blocks (63 us per LM iteration on a 48-shot problem) are not needed
+        OSFM_HIP(hipMemsetAsync(d.camred, 0, (size_t)9 * NC * sizeof(double), st));
+        hipLaunchKernelGGL(precond_cam_kernel, dim3(nblk(NC, 64)), dim3(64), 0, st, d, radius);
       } else if (!((sv.use_bcr || sv.use_wide) && sv.use_border)) {
         hipLaunchKernelGGL(precond_shot_kernel, dim3(S), dim3(64), 0, st, d, radius);
         hipLaunchKernelGGL(cam_reduce_kernel, dim3(NC), dim3(kCamRedT), 0, st, d, 6);

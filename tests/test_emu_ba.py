@@ -103,3 +103,18 @@ def test_wide_band_on_the_hand_written_gemm_matches_oracle(oracle_lib):
     o = oracle_lib.ba_solve(pr, max_iterations=2, **NO_TOL)
     assert g["preconditioner_bandwidth"] == g["shot_bandwidth"] > 10
     assert np.allclose(g["cost_history"], o["cost_history"], rtol=1e-10)
+
+
+def test_local_bundle_adjustment_problem_matches_oracle(oracle_lib):
+    """BAHelpers::BundleLocal's problem (interior free, boundary and cameras constant): the band alone is the preconditioner, the camera
+    rows are inert -- the per-shot block-Jacobi blocks are skipped (round 5) -- and CG confirms in one iteration per LM step"""
+    from opensfm_amd import bundle
+
+    pr = synthetic.make_ba_scene(40, 500, 6, seed=7)
+    sub = bundle.local_problem(pr, 20, {"local_bundle_radius": 3, "local_bundle_min_common_points": 20, "local_bundle_max_shots": 8})[0]
+    assert sub["cam_fixed"].all() and 0 < sub["shot_fixed"].sum() < len(sub["shot_fixed"])
+    with emulated():
+        g = bundle.bundle_arrays(sub, {"bundle_max_iterations": 4}, **NO_TOL)
+    o = oracle_lib.ba_solve(sub, max_iterations=4, **NO_TOL)
+    assert np.allclose(g["cost_history"], o["cost_history"], rtol=1e-11) and g["pcg_iterations"] <= 4
+    assert np.array_equal(g["shot_pose"][sub["shot_fixed"] == 1], sub["shot_pose"][sub["shot_fixed"] == 1])
