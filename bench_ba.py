@@ -67,7 +67,7 @@ def run_grid(ctx, rows: int = 50, cols: int = 100, points: int = 500000, track: 
             "cost": [float(g["initial_cost"]), float(g["final_cost"])], "lm_iteration": lm_iteration_line(g, nobs),
             "solver_note": "exact band of half-width `preconditioner_bandwidth` shots, block tridiagonal over dense clusters of that many "
                            "shots, factorised by cyclic reduction (log2(S / bw) levels; per level a blocked in-place Gauss-Jordan inverse -- pivot "
-                           "panels in LDS -- and batched dgemm); a solve = one launch per level down and up; CG confirms in 1-2 iterations"}
+                           "panels in LDS -- and the hand-written fp64-MFMA batched GEMM, dgemm_mfma_kernel); a solve = one launch per level down and up; CG confirms in 1-2 iterations"}
     if cpu_iters > 0:
         out["cpu_baseline"] = _oracle_leg(pr, ctx, cpu_iters, "exact Schur elimination on all cores + skyline Cholesky (serial) of half-width 6 x bandwidth")
     return out

@@ -2269,7 +2269,7 @@ __global__ void wide_store_kernel(Dev d, RhsSet rs) {
 // workgroup's LDS, so they live in HBM (column-major) and a level works on all its clusters at once:
 //   D_i <- D_i^-1                       blocked Gauss-Jordan, in place: per panel of <= 96 columns the pivot block is inverted in LDS
 //                                       (dgj_pivot_kernel: the 6 x 6-pivot elimination of the other solvers) and the panel / trailing
-//                                       products are batched dgemm (rocBLAS: plain library GEMMs); ceil(qm / 96) steps per level
+//                                       products are batched dgemm (dgemm_mfma_kernel below, hand-written since round 5); ceil(qm / 96) steps per level
 //   G_i = D_i^-1 E_i,  H_i = D_i^-1 E_r^T,   D_{i+st} -= E_r H_i,   D_{i-st} -= E_i^T G_i,   E_{i+st} <- -E_r G_i      batched dgemm
 // (same algebra as bcr_level_kernel; the two updates of a surviving D are separate launches on one stream, so no second accumulator).
 // rocSOLVER's batched potrf / potrs were measured first (round 4): at qm = 612 they are chains of 24- and 32-thread kernels, 25 ms per

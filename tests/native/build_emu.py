@@ -1,4 +1,4 @@
-"""Builds tests/native/_build/libosfm_ba_emu.so: the product's bundle-adjustment sources (opensfm_amd/csrc/ba.hip, ba_general.hip) compiled
+"""Builds tests/native/_build/libosfm_ba_emu.so: the product's bundle-adjustment sources (opensfm_amd/csrc/ba.hip with ba_generic.inc / ba_generic_host.inc) compiled
 for the HOST against the HIP emulation of tests/native/hipemu -- every kernel and the whole LM driver then run on the CPU.  TEST
 INFRASTRUCTURE: nothing under opensfm_amd/ loads this library.
 

@@ -1,6 +1,6 @@
 // hip_runtime.h -- a HOST EMULATION of the small part of HIP that opensfm_amd/csrc/ba*.hip use: TEST INFRASTRUCTURE ONLY.
 //
-// tests/native/build_emu.py compiles the product's own bundle-adjustment sources (ba.hip, ba_general.hip, unmodified apart from three
+// tests/native/build_emu.py compiles the product's own bundle-adjustment sources (ba.hip and its .inc files, unmodified apart from three
 // mechanical substitutions listed there) against this header with the host clang++, so that every kernel, every launch and the whole
 // Levenberg-Marquardt driver run on the CPU and can be compared with the oracle in the `-m "not gpu"` suite -- including under
 // AddressSanitizer.  Nothing in opensfm_amd/ ever includes it; the GPU library is built by hipcc against the real runtime.

@@ -1,4 +1,4 @@
-"""The product's bundle-adjustment kernels and LM driver (opensfm_amd/csrc/ba.hip, ba_general.hip) executed on the HOST by the HIP
+"""The product's bundle-adjustment kernels and LM driver (opensfm_amd/csrc/ba.hip with ba_generic.inc / ba_generic_host.inc) executed on the HOST by the HIP
 emulation of tests/native/hipemu -- every kernel, launch, LDS exchange, wavefront shuffle and fp64 MFMA of the real sources, workgroup by
 workgroup -- against the CPU oracle.  This is the `-m "not gpu"` twin of tests/test_gpu_ba.py / test_gpu_bundle_general.py at sizes the
 emulation finishes in seconds: it catches an indexing slip or an uninitialised read (emulated device memory and dynamic LDS are

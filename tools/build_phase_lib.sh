@@ -7,6 +7,6 @@ cd "$(dirname "$0")/../opensfm_amd/csrc"
 mkdir -p /tmp/osfm_dbg
 for f in match hahog; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DOSFM_DBG_PHASES -c $f.hip -o /tmp/osfm_dbg/$f.o; done
 OBJS=""
-for s in api ransac ba ba_general tracks relpose calib guided words; do OBJS="$OBJS build/$s.o"; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared /tmp/osfm_dbg/match.o /tmp/osfm_dbg/hahog.o $OBJS -o ../../tools/libosfm_dbg_phases.so -L/opt/rocm/lib -lrocsolver -lrocblas -Wl,-rpath,/opt/rocm/lib
+for s in api ransac ba tracks relpose calib guided words; do OBJS="$OBJS build/$s.o"; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared /tmp/osfm_dbg/match.o /tmp/osfm_dbg/hahog.o $OBJS -o ../../tools/libosfm_dbg_phases.so
 echo "built tools/libosfm_dbg_phases.so (git-ignored)"

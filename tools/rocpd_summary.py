@@ -53,11 +53,13 @@ def timeline(path, substrings, last=400):
     cols = [r[1] for r in cur.execute(f"pragma table_info('{ks}')")]
     namecol = 'kernel_name' if 'kernel_name' in cols else ('display_name' if 'display_name' in cols else cols[-2])
     names = {r[0]: r[1] for r in cur.execute(f"select id, {namecol} from '{ks}'")}
-    rows = [(s, e, str(names.get(k, k)).split('(')[0][-48:], gx) for k, s, e, gx in cur.execute(f"select kernel_id, start, end, grid_size_x from '{kd}'")]
+    dcols = [r[1] for r in cur.execute(f"pragma table_info('{kd}')")]
+    qcol = 'queue_id' if 'queue_id' in dcols else ('stream_id' if 'stream_id' in dcols else '0')  # which HIP stream's queue: overlap between streams
+    rows = [(s, e, str(names.get(k, k)).split('(')[0][-48:], gx, q) for k, s, e, gx, q in cur.execute(f"select kernel_id, start, end, grid_size_x, {qcol} from '{kd}'")]
     rows = sorted(r for r in rows if any(x in r[2] for x in substrings))[-last:]
     t0, prev = rows[0][0], rows[0][0]
-    for s, e, n, gx in rows:
-        print(f"{(s - t0) / 1e6:10.3f} ms  dur {(e - s) / 1e3:9.1f} us  gap {(s - prev) / 1e3:8.1f} us  {n:48s} grid {gx}")
+    for s, e, n, gx, q in rows:
+        print(f"{(s - t0) / 1e6:10.3f} ms  dur {(e - s) / 1e3:9.1f} us  gap {(s - prev) / 1e3:8.1f} us  q{q}  {n:48s} grid {gx}")
         prev = max(prev, e)
 
 

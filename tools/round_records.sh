@@ -11,7 +11,7 @@ python -c "import oracle; oracle.build()" > $OUT/oracle_build.log 2>&1
 timeout 600 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err; echo "bench rc $?"; tail -c 300 $OUT/${TAG}_bench.json; echo
 timeout 600 python -m pytest tests -m gpu -q --durations=8 -s > $OUT/${TAG}_pytest_gpu.txt 2>&1; echo "pytest rc $?"; tail -3 $OUT/${TAG}_pytest_gpu.txt
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/headline -o headline -- python /root/repo/bench.py --headline-only --no-cpu-baseline > $OUT/headline.json 2> $OUT/headline.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/headline -o headline -- python /root/repo/bench.py --headline-only --no-cpu-baseline > $OUT/headline.json 2> $OUT/headline.err
 cp $(find $OUT/headline -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_headline_rocprofv3_kernel_stats.csv 2>/dev/null
 rm -rf $OUT/headline
 trace() {  # name, command...
