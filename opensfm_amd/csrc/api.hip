@@ -52,7 +52,7 @@ extern "C" void osfm_ctx_destroy(osfm_ctx *c) {
   for (auto &b : c->pool) (void)hipFree(b.p);
   if (c->stream_b) (void)hipStreamDestroy(c->stream_b);
   for (hipStream_t a : c->aux_streams) (void)hipStreamDestroy(a);
-  if (c->blas && c->blas_destroy) c->blas_destroy(c->blas);
+  if (c->h_pinned) (void)hipHostFree(c->h_pinned);
   delete c;
 }
 

@@ -2028,6 +2028,105 @@ __device__ __forceinline__ void wide_gj_inverse(double *X, int tid, int &bad, in
   }
 }
 
+// ---- the same inverse on the matrix cores (round 5): 16 x 16 pivots ----
+// Nothing ties the pivot size to a shot's six unknowns: every leading block of an SPD matrix can be eliminated without pivoting.  Here a
+// step eliminates SIXTEEN unknowns with v_mfma_f64_16x16x4 on 16 x 16 tiles in LDS:
+//   A  wavefront 0 inverts the pivot block (inv16_spd_wave: Gauss-Jordan on registers, a lane owns a column of four rows, rows and columns
+//      travel by cross-lane reads)
+//   B  the pivot block row in place, R'_j = P X_kj for the other column tiles, tiles dealt to the four wavefronts
+//   C  X_ij -= X_ik R'_j for the tiles of the other rows; their pivot-column tiles -X_ik P go to Cbuf (X_ik is an operand of its whole row)
+//   D  Cbuf -> the pivot columns
+// six steps of four barriers for 96 unknowns.  Timestamps inside the kernel (MI355X, one workgroup per cluster, 90 unknowns): a step is
+// A 3.0 + B 0.6 + C 2.7 + D 1.1 (first version: R' and the columns both through buffers) = 7.4 us -- the chain of sixteen divisions with
+// two cross-lane round trips each sets the pace; 44 us for six steps against 45 us for the sixteen 6 x 6 steps of wide_gj_inverse, whose
+// threads invert the pivot redundantly in registers.  Measured and dropped: tile (k + 1, k + 1) updated and inverted by wavefront 0
+// BESIDE step k's other tiles (look-ahead inside the workgroup): 54 us against 50 for the kernel -- the cross-lane chain slows down by
+// more than it hides when three other wavefronts keep the LDS busy.  What did pay in dgj_pivot_kernel was outside the inversion: the 36
+// loads of the block issued before the first LDS write (60 -> 52 us).  X: row stride kWLd, identity beyond the block's order (its
+// 16-blocks invert to themselves); n16 = 16-blocks to eliminate.  scratch: kGj16Scratch doubles of LDS.
+constexpr int kGj16LdC = 18, kGj16Scratch = kWB * kGj16LdC;
+typedef double gj_v4d __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void inv16_spd_wave(double *M, int lane, int &bad) {  // M: 16 x 16, row stride kWLd, in LDS; one whole wavefront
+  const int j = lane & 15, r0 = (lane >> 4) * 4;
+  double v[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) v[q] = M[(r0 + q) * kWLd + j];
+  // four pivots per trip of a loop that is NOT unrolled further: the code of a kernel that runs as one workgroup per cluster is fetched
+  // cold, about a microsecond per kilobyte -- sixteen unrolled pivots were 19 us of instruction fetch before the first of them retired
+#pragma unroll 1
+  for (int cb = 0; cb < 4; cb++) {
+    const int owner = cb << 4;  // the lanes that hold rows 4 cb .. 4 cb + 3
+#pragma unroll
+    for (int cq = 0; cq < 4; cq++) {
+      const int c = 4 * cb + cq;
+      const double rowc = __shfl(v[cq], owner | j);
+      const double p = __shfl(v[cq], owner | c);
+      if (!(p > 0)) bad = 1;
+      const double ip = 1.0 / p;
+      const double srow = (j == c) ? ip : rowc * ip;
+      double f[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) f[q] = __shfl(v[q], (lane & 48) | c);
+#pragma unroll
+      for (int q = 0; q < 4; q++) v[q] = (r0 + q == c) ? srow : ((j == c) ? -f[q] * ip : __builtin_fma(-f[q], srow, v[q]));
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++) M[(r0 + q) * kWLd + j] = v[q];
+}
+__device__ __forceinline__ void wide_gj_inverse_mfma(double *X, double *scratch, int tid, int &bad, int n16) {
+  double *Cbuf = scratch;
+  const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+#pragma unroll 1
+  for (int k = 0; k < n16; k++) {
+    double *Pk = X + (16 * k) * kWLd + 16 * k;
+    if (wave == 0) inv16_spd_wave(Pk, lane, bad);
+    __syncthreads();
+    // B: the pivot block row in place, R'_j = P X_kj
+    for (int j = wave; j < n16; j += 4) {
+      if (j == k) continue;
+      double *T = X + (16 * k) * kWLd + 16 * j;
+      gj_v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int c = 0; c < 4; c++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Pk[li * kWLd + 4 * c + lk], T[(4 * c + lk) * kWLd + li], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; r++) T[(4 * r + lk) * kWLd + li] = acc[r];  // (the MFMAs have consumed the tile: one wavefront owns it)
+    }
+    __syncthreads();
+    // C: X_ij -= X_ik R'_j for the other rows; their pivot-column tiles -X_ik P go to Cbuf (X_ik is an operand of the whole row)
+    for (int u = wave; u < n16 * n16; u += 4) {
+      const int i = u / n16, j = u - i * n16;
+      if (i == k) continue;
+      double a[4];
+#pragma unroll
+      for (int c = 0; c < 4; c++) a[c] = -X[(16 * i + li) * kWLd + 16 * k + 4 * c + lk];
+      gj_v4d acc;
+      if (j == k) {
+        acc = (gj_v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int c = 0; c < 4; c++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[c], Pk[(4 * c + lk) * kWLd + li], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) Cbuf[(16 * i + 4 * r + lk) * kGj16LdC + li] = acc[r];
+      } else {
+        double *T = X + (16 * i) * kWLd + 16 * j;
+        const double *Rj = X + (16 * k) * kWLd + 16 * j;
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[r] = T[(4 * r + lk) * kWLd + li];
+#pragma unroll
+        for (int c = 0; c < 4; c++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[c], Rj[(4 * c + lk) * kWLd + li], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) T[(4 * r + lk) * kWLd + li] = acc[r];
+      }
+    }
+    __syncthreads();
+    for (int t = tid; t < 16 * 16 * n16; t += 256) {  // Cbuf -> the pivot columns
+      const int rr = t >> 4, cc = t & 15;
+      if ((rr >> 4) != k) X[rr * kWLd + 16 * k + cc] = Cbuf[rr * kGj16LdC + cc];
+    }
+    __syncthreads();
+  }
+}
+
 // assembled shot band -> kWB x kWB tiles: tile (J, dI) = A_{J+dI, J}, dI = 0 .. Wb (identity on the padding rows of the last block)
 __global__ void __launch_bounds__(256) wide_tiles_kernel(Dev d, int *status) {
   const int J = blockIdx.x, dI = blockIdx.y, I = J + dI, R1 = d.bw + 1;
@@ -2305,13 +2404,25 @@ __global__ void __launch_bounds__(256) dgj_pivot_kernel(double *A0, long strideA
   double *A = A0 + (long)blockIdx.y * strideA;
   if (blockIdx.x == 0) {
     double *X = lds;
-    for (int t = tid; t < kWB * kWB; t += 256) {
-      const int c = t / kWB, r = t - c * kWB;
-      X[r * kWLd + c] = (r < w && c < w) ? A[(long)(j0 + c) * m + j0 + r] : (r == c ? 1.0 : 0.0);
+    {
+      // all 36 loads of a thread are in flight before the first LDS write (a load -> store loop is 36 round trips to L2: 25 us of the
+      // kernel's 60 when one workgroup per cluster is all there is on the chip)
+      constexpr int NL = kWB * kWB / 256;
+      double v[NL];
+#pragma unroll
+      for (int u = 0; u < NL; u++) {
+        const int t = tid + 256 * u, c = t / kWB, r = t - c * kWB;
+        v[u] = (r < w && c < w) ? A[(long)(j0 + c) * m + j0 + r] : (r == c ? 1.0 : 0.0);
+      }
+#pragma unroll
+      for (int u = 0; u < NL; u++) {
+        const int t = tid + 256 * u, c = t / kWB, r = t - c * kWB;
+        X[r * kWLd + c] = v[u];
+      }
     }
     __syncthreads();
     int bad = 0;
-    wide_gj_inverse(X, tid, bad, (w + 5) / 6);
+    wide_gj_inverse_mfma(X, lds + kWB * kWLd, tid, bad, (w + 15) / 16);
     if (bad) status[2] = 1;
     double *P = P0 + (long)blockIdx.y * T * T;
     for (int t = tid; t < w * w; t += 256) {
@@ -2420,7 +2531,7 @@ __global__ void __launch_bounds__(256) dgj_pivot_ahead_kernel(const double *A0, 
   }
   __syncthreads();
   int bad = 0;
-  wide_gj_inverse(X, tid, bad, (wn + 5) / 6);
+  wide_gj_inverse_mfma(X, Z, tid, bad, (wn + 15) / 16);  // (Z held an operand of the product: free by now)
   if (bad) status[2] = 1;
   double *P = P0 + (long)blockIdx.y * T * T;
   for (int t = tid; t < wn * wn; t += 256) {
@@ -3641,7 +3752,26 @@ struct Solver {
   hipStream_t st;
   int loss;
   double loss_a;
-  std::vector<double> hscal = std::vector<double>(16, 0.0);
+  // the LM loop's scalars come back through PINNED host memory (kept by the context): a D2H copy into pageable memory is staged and
+  // synchronous in the runtime, ~25 us each; into pinned memory the copies of one round trip are queued back to back
+  double *hscal = nullptr;  // 32 doubles
+  int *hstat = nullptr;     // 4 ints
+  double *hrr = nullptr;    // the blocks' shares of r.r (nbr doubles)
+  int pinned(int nbr) {
+    const size_t need = (size_t)(32 + 2 + nbr + 8) * sizeof(double);
+    if (ctx->h_pinned_bytes < need) {
+      if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+      ctx->h_pinned = nullptr;
+      ctx->h_pinned_bytes = 0;
+      OSFM_HIP(hipHostMalloc(&ctx->h_pinned, std::max<size_t>(need, 65536), hipHostMallocDefault));
+      ctx->h_pinned_bytes = std::max<size_t>(need, 65536);
+    }
+    hscal = (double *)ctx->h_pinned;
+    hstat = (int *)(hscal + 32);
+    hrr = hscal + 34;
+    for (int i = 0; i < 34; i++) hscal[i] = 0.0;
+    return OSFM_OK;
+  }
 
   void rot(const double *poses) { hipLaunchKernelGGL(shot_rot_kernel, dim3(nblk(d.S, 64)), dim3(64), 0, st, d, poses); }
 
@@ -3777,7 +3907,7 @@ struct Solver {
   }
   int eval(const double *cams, const double *poses, const double *pts, bool jac, double *cost, double *sumsq) {
     eval_enqueue(cams, poses, pts, jac);
-    OSFM_HIP(hipMemcpyAsync(hscal.data(), d.scal + 8, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+    OSFM_HIP(hipMemcpyAsync(hscal, d.scal + 8, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
     OSFM_HIP(hipStreamSynchronize(st));
     *cost = hscal[0];
     if (sumsq) *sumsq = hscal[1];
@@ -3893,7 +4023,7 @@ struct Solver {
     for (int j0 = 0; j0 < m; j0 += T) {
       const int w = std::min(T, m - j0);
       const int ncopy = (int)std::min<long>(64, ((long)w * m + 255) / 256);
-      hipLaunchKernelGGL(dgj_pivot_kernel, dim3(1 + ncopy, batch), dim3(256), (size_t)kWB * kWLd * sizeof(double), st, A, strideA, m, T, j0, w, d.qP, d.qR,
+      hipLaunchKernelGGL(dgj_pivot_kernel, dim3(1 + ncopy, batch), dim3(256), (size_t)(kWB * kWLd + kGj16Scratch) * sizeof(double), st, A, strideA, m, T, j0, w, d.qP, d.qR,
                          d.qC, d_status);
       dgemm_sb(false, false, w, m, w, one, d.qP, T, sP, d.qR, T, sR, zero, d.qRn, T, sR, batch);
       // the trailing update (which leaves the panel's columns alone) and the panel's own column block, -C P, in one launch
@@ -4854,9 +4984,13 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
   OSFM_HIP(hipMemsetAsync(d.scal, 0, 32 * sizeof(double), sv.st));
 
   hipStream_t st = sv.st;
-  std::vector<double> &hs = sv.hscal;
   const int nred = d.nred;
   const int nbr = nblk(nred);
+  {
+    const int rcp = sv.pinned(nbr);
+    if (rcp != OSFM_OK) return rcp;
+  }
+  double *hs = sv.hscal;
   OSFM_HIP(hipStreamSynchronize(sv.st));
   const auto t_run = std::chrono::steady_clock::now();  // from here: what ceres::Solve would cover
   double cost = 0, sumsq = 0;
@@ -4918,7 +5052,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     if (need_prepare) {
       const int rcp = prepare_enqueue();
       if (rcp != OSFM_OK) return rcp;
-      OSFM_HIP(hipMemcpyAsync(hs.data(), d.scal + 10, sizeof(double), hipMemcpyDeviceToHost, st));
+      OSFM_HIP(hipMemcpyAsync(hs, d.scal + 10, sizeof(double), hipMemcpyDeviceToHost, st));
       OSFM_HIP(hipStreamSynchronize(st));
       gmax = hs[0];
       need_prepare = false;
@@ -5161,10 +5295,10 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
         if (rca != OSFM_OK) return rca;
       }
       hipLaunchKernelGGL(band_cholesky_kernel, dim3(1), dim3(64), (size_t)((kMaxBw + 1) * R * 36 + (kMaxBw + 1) * 36 + 72) * sizeof(double), st, d, d_status);
-      int hstatus = 1;
-      OSFM_HIP(hipMemcpyAsync(&hstatus, d_status, sizeof(int), hipMemcpyDeviceToHost, st));
+      sv.hstat[3] = 1;
+      OSFM_HIP(hipMemcpyAsync(sv.hstat + 3, d_status, sizeof(int), hipMemcpyDeviceToHost, st));
       OSFM_HIP(hipStreamSynchronize(st));
-      sv.use_band = (hstatus == 0);  // a truncated band may lose positive definiteness: fall back to block Jacobi
+      sv.use_band = (sv.hstat[3] == 0);  // a truncated band may lose positive definiteness: fall back to block Jacobi
       if (sv.use_band && d.ncl > 0) {
         const size_t n2 = (size_t)d.ncd * d.ncd;
         OSFM_HIP(hipMemsetAsync(d.cD, 0, (size_t)d.ncl * n2 * sizeof(double), st));
@@ -5194,7 +5328,8 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       if (rcj != OSFM_OK) return rcj;
     }
     if (mark("factorisation + border solve") != OSFM_OK) return OSFM_E_HIP;
-    int hst[3] = {0, 0, 0};
+    int *hst = sv.hstat;
+    hst[0] = hst[1] = hst[2] = 0;
     auto start_pcg = [&]() -> int {
       // block-Jacobi blocks (6x6 per shot, 3x3 per camera): the fallback preconditioner, and the camera rows of the band
       // preconditioners -- not needed when the cyclic reduction came out with the exact camera border
@@ -5216,7 +5351,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       sv.precond(d.b, d.z, z_solved);
       z_solved = false;
       hipLaunchKernelGGL(pcg_init_kernel, dim3(1), dim3(1024), 0, st, d.b, d.z, d.x, d.r, d.p, nred, d.scal + 0, d.scal + 4);  // x = 0, r = b, p = z
-      OSFM_HIP(hipMemcpyAsync(hs.data(), d.scal, 5 * sizeof(double), hipMemcpyDeviceToHost, st));
+      OSFM_HIP(hipMemcpyAsync(hs, d.scal, 5 * sizeof(double), hipMemcpyDeviceToHost, st));
       if (try_bcr || wide) OSFM_HIP(hipMemcpyAsync(hst, d_status, 3 * sizeof(int), hipMemcpyDeviceToHost, st));
       OSFM_HIP(hipStreamSynchronize(st));
       return OSFM_OK;
@@ -5243,7 +5378,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     const double bb = hs[4];
     bool bad = !(bb == bb) || std::isinf(bb);
     int k = 0;
-    std::vector<double> rr_part((size_t)nbr);
+    double *rr_part = sv.hrr;
     if (!bad && bb > 0) {
       const double tol2 = O->pcg_tolerance * O->pcg_tolerance * bb;
       const int kmax = O->pcg_max_iterations > 0 ? O->pcg_max_iterations : 1000;
@@ -5257,7 +5392,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
         // (an exact band -- with the camera border on top, or with constant cameras as in local bundle adjustment -- makes the
         // preconditioner the matrix itself: CG is done after one or two iterations, so the first two are polled)
         if ((k & 3) == 0 || k == kmax || ((sv.use_bcr || sv.use_wide) && k <= 2)) {
-          OSFM_HIP(hipMemcpyAsync(rr_part.data(), d.partial, (size_t)nbr * sizeof(double), hipMemcpyDeviceToHost, st));
+          OSFM_HIP(hipMemcpyAsync(rr_part, d.partial, (size_t)nbr * sizeof(double), hipMemcpyDeviceToHost, st));
           OSFM_HIP(hipStreamSynchronize(st));
           double rr = 0.0;
           for (int q = 0; q < nbr; q++) rr += rr_part[(size_t)q];
@@ -5296,7 +5431,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     // the candidate's cost is evaluated before the host has seen the model change: one round trip for both (an invalid step -- rare --
     // has then paid for an evaluation it does not use)
     sv.eval_enqueue(d.cams_n, d.poses_n, d.pts_n, false);
-    OSFM_HIP(hipMemcpyAsync(hs.data(), d.scal + 8, 14 * sizeof(double), hipMemcpyDeviceToHost, st));  // scal[8..21]
+    OSFM_HIP(hipMemcpyAsync(hs, d.scal + 8, 14 * sizeof(double), hipMemcpyDeviceToHost, st));  // scal[8..21]
     OSFM_HIP(hipStreamSynchronize(st));
     lin_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_lin).count();
     const double model_change = hs[8];
@@ -5332,7 +5467,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       sv.eval_enqueue(d.cams, d.poses, d.pts, true);  // cost, sum of squares and max |gradient| come back together
       rc = prepare_enqueue();
       if (rc != OSFM_OK) return rc;
-      OSFM_HIP(hipMemcpyAsync(hs.data(), d.scal + 8, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+      OSFM_HIP(hipMemcpyAsync(hs, d.scal + 8, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
       OSFM_HIP(hipStreamSynchronize(st));
       cost = hs[0];
       sumsq = hs[1];

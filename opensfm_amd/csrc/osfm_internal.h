@@ -67,8 +67,8 @@ struct osfm_ctx {
   // kept between calls -- the pair sizes of a data set repeat, and a cold table for ~300 sizes is ~5 ms of libm calls
   double stop_probability = -1.0;
   std::unordered_map<int, std::vector<double>> stop_tables;
-  void *blas = nullptr;         // ba.hip: rocblas_handle of the wide band's dense-cluster cyclic reduction, made on first use
-  void (*blas_destroy)(void *) = nullptr;
+  void *h_pinned = nullptr;     // ba.hip: pinned host memory the LM loop's scalars come back through, made on first use
+  size_t h_pinned_bytes = 0;
 };
 
 // Tile = 32 descriptors x 128 int8 in MFMA-operand order (4 KiB):

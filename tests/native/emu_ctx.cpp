@@ -31,7 +31,7 @@ extern "C" void osfm_ctx_destroy(osfm_ctx *c) {
   if (!c) return;
   for (int i = 0; i < 8; ++i) (void)hipEventDestroy(c->ev[i]);
   (void)hipStreamDestroy(c->stream);
-  if (c->blas && c->blas_destroy) c->blas_destroy(c->blas);
+  if (c->h_pinned) (void)hipHostFree(c->h_pinned);
   delete c;
 }
 extern "C" int64_t osfm_ctx_trim_pool(osfm_ctx *) { return 0; }

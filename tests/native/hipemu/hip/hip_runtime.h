@@ -78,6 +78,9 @@ static inline hipError_t hipFree(void *p) {
   free(p);
   return hipSuccess;
 }
+constexpr unsigned hipHostMallocDefault = 0;
+static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { return hipMalloc(p, n); }
+static inline hipError_t hipHostFree(void *p) { return hipFree(p); }
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) {
   if (n) memmove(d, s, n);
   return hipSuccess;

@@ -3,6 +3,8 @@ emulation of tests/native/hipemu -- every kernel, launch, LDS exchange, wavefron
 workgroup -- against the CPU oracle.  This is the `-m "not gpu"` twin of tests/test_gpu_ba.py / test_gpu_bundle_general.py at sizes the
 emulation finishes in seconds: it catches an indexing slip or an uninitialised read (emulated device memory and dynamic LDS are
 poisoned with NaNs) before a GPU lease is spent on it.  The emulated library is test infrastructure; the product never loads it."""
+import os
+
 import numpy as np
 import pytest
 
@@ -103,6 +105,9 @@ def test_wide_band_on_the_hand_written_gemm_matches_oracle(oracle_lib):
     o = oracle_lib.ba_solve(pr, max_iterations=2, **NO_TOL)
     assert g["preconditioner_bandwidth"] == g["shot_bandwidth"] > 10
     assert np.allclose(g["cost_history"], o["cost_history"], rtol=1e-10)
+    # the factorisation is exact (the pivot blocks' inverses by 16 x 16 pivots on the matrix cores, panels of 96 + 18 unknowns here): CG
+    # confirms in one iteration per LM step -- a wrong inverse would still converge, only slower
+    assert g["pcg_iterations"] <= g["iterations"] + 1
 
 
 def test_local_bundle_adjustment_problem_matches_oracle(oracle_lib):
@@ -118,3 +123,25 @@ def test_local_bundle_adjustment_problem_matches_oracle(oracle_lib):
     o = oracle_lib.ba_solve(sub, max_iterations=4, **NO_TOL)
     assert np.allclose(g["cost_history"], o["cost_history"], rtol=1e-11) and g["pcg_iterations"] <= 4
     assert np.array_equal(g["shot_pose"][sub["shot_fixed"] == 1], sub["shot_pose"][sub["shot_fixed"] == 1])
+
+
+def test_pivot_block_inverse_on_the_matrix_cores():
+    """dgj_pivot_kernel's inverse (16 x 16 pivots, v_mfma_f64_16x16x4 updates in LDS, the next pivot block inverted by wavefront 0 beside the
+    trailing tiles) on random SPD blocks of every order the panels take: max |A A^-1 - I| at rounding level"""
+    import re
+    import subprocess
+
+    import emu_util
+
+    build_emu = emu_util._builder()
+    build_emu.build()
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "native")
+    exe = os.path.join(here, "_build", "gj16_harness")
+    root = os.path.dirname(os.path.dirname(here))
+    subprocess.run([build_emu.CLANG, "-std=c++17", "-O1", "-ffp-contract=off", "-Wno-unknown-attributes", "-Wno-unused-value", "-I", os.path.join(here, "hipemu"),
+                    "-I", os.path.join(root, "opensfm_amd", "csrc"), "-I", os.path.join(root, "include"), "-I", os.path.join(here, "_build"),
+                    os.path.join(here, "gj16_harness.cpp"), os.path.join(here, "emu_ctx.cpp"), "-o", exe, "-lpthread"], check=True, timeout=600)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True, timeout=120).stdout
+    rows = re.findall(r"w (\d+): max \|A inv - I\| = (\S+) status (\d+)", out)
+    assert [int(r[0]) for r in rows] == [90, 96, 72, 36, 18, 6], out
+    assert all(float(r[1]) < 1e-13 and r[2] == "0" for r in rows), out
