@@ -4900,7 +4900,18 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
   d.wNB = 0; d.wWb = 0;
   d.qN = 0; d.qm = 0; d.qcs = 0;
   // wide band: cyclic reduction over dense clusters (dbcr_*); OSFM_BA_WIDE_LDLT keeps round 3's block LDL^T chain (measurement knob)
-  const bool dense_cr = wide && getenv("OSFM_BA_WIDE_LDLT") == nullptr;
+  bool dense_cr = wide && getenv("OSFM_BA_WIDE_LDLT") == nullptr;
+  if (dense_cr) {
+    // the dense-cluster blocks take ~9 (6 bw)^2 doubles per cluster plus the panel buffers, 2-3 x the LDL^T window's tiles: when the
+    // device cannot hold them beside everything already allocated, the block LDL^T chain below (slower, a third of the memory) solves
+    // the same band instead of the call failing with OSFM_E_NOMEM.  OSFM_BA_DENSE_CR_BUDGET (bytes) stands in for the free memory in tests.
+    const size_t qm = (size_t)6 * d.bw, nq = (size_t)(S + d.bw - 1) / d.bw, np = (qm + kWB - 1) / kWB, qT = ((qm + np - 1) / np + 5) / 6 * 6;
+    const size_t need = (nq * qm * qm * 9 + nq * qm * 8 + (nq / 2 + 1) * (3 * qT * qT + 3 * qT * qm)) * sizeof(double);
+    size_t free_b = 0, total_b = 0;
+    if (const char *bud = getenv("OSFM_BA_DENSE_CR_BUDGET")) free_b = (size_t)atoll(bud);
+    else if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = ~(size_t)0;
+    if (need > free_b - free_b / 8) dense_cr = false;
+  }
   if (dense_cr) {
     d.qcs = d.bw;
     d.qm = 6 * d.qcs;
@@ -5408,8 +5419,8 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       Rp->pcg_iterations_total += k;
     }
     if (mark("pcg") != OSFM_OK) return OSFM_E_HIP;
-    if (trace) fprintf(stderr, "[osfm_ba trace] iteration %d: %d pcg iterations, status %d %d %d, band %d bcr %d wide %d border %d\n", iter, k, hst[0], hst[1], hst[2],
-                       (int)sv.use_band, (int)sv.use_bcr, (int)sv.use_wide, (int)sv.use_border);
+    if (trace) fprintf(stderr, "[osfm_ba trace] iteration %d: %d pcg iterations, status %d %d %d, band %d bcr %d wide %d dense %d border %d\n", iter, k, hst[0], hst[1], hst[2],
+                       (int)sv.use_band, (int)sv.use_bcr, (int)sv.use_wide, (int)(sv.use_wide && dense_cr), (int)sv.use_border);
     // back-substitution, model change, candidate
     hipLaunchKernelGGL(scale_vec_kernel, dim3(nbr), dim3(TPB), 0, st, d.sc_red, d.x, d.y, nred);
     if (gen) {

@@ -145,3 +145,21 @@ def test_pivot_block_inverse_on_the_matrix_cores():
     rows = re.findall(r"w (\d+): max \|A inv - I\| = (\S+) status (\d+)", out)
     assert [int(r[0]) for r in rows] == [90, 96, 72, 36, 18, 6], out
     assert all(float(r[1]) < 1e-13 and r[2] == "0" for r in rows), out
+
+
+def test_wide_band_falls_back_to_the_ldlt_chain_when_the_dense_clusters_do_not_fit(capfd, monkeypatch):
+    """the dense-cluster blocks of the wide band are 2-3 x the memory of the block LDL^T window: when the device cannot hold them the
+    solver takes the LDL^T chain instead of returning OSFM_E_NOMEM (OSFM_BA_DENSE_CR_BUDGET stands in for the free memory) -- the same
+    exact band, the same trajectory"""
+    from opensfm_amd import bundle
+
+    pr = synthetic.make_ba_scene(90, 800, 8, seed=3, ragged=True)
+    monkeypatch.setenv("OSFM_BA_TRACE", "1")
+    with emulated():
+        a = bundle.bundle_arrays(pr, {"bundle_max_iterations": 2}, **NO_TOL)
+        err_a = capfd.readouterr().err
+        monkeypatch.setenv("OSFM_BA_DENSE_CR_BUDGET", "100000")
+        b = bundle.bundle_arrays(pr, {"bundle_max_iterations": 2}, **NO_TOL)
+        err_b = capfd.readouterr().err
+    assert "wide 1 dense 1" in err_a and "wide 1 dense 0" in err_b
+    assert np.allclose(a["cost_history"], b["cost_history"], rtol=1e-11) and b["pcg_iterations"] <= b["iterations"] + 1
