@@ -364,62 +364,89 @@ double evaluate(const Problem& P, const Options& O, const Layout& L, const State
   double cost = 0.0;
   // ---- reprojection errors: parameters [camera 16 | rig instance 6 | rig camera 6 | point 3] ----
   constexpr int NR_ = 31;
-  for (int64_t o = 0; o < P.n_obs; o++) {
-    const int s = P.obs_shot[o], p = P.obs_point[o];
-    const int c = P.shot_camera[s], i = P.shot_rig_instance[s], q = P.shot_rig_camera[s];
-    const int model = P.cam_model[c], nk = num_params(model);
-    typedef Jet<NR_> T;
-    T cam[16], inst[6], rcam[6], pt[3];
-    int idx[NR_];
-    for (int k = 0; k < 16; k++) {
-      cam[k] = T(X.cam[16 * c + k], k);
-      idx[k] = (L.cam[c] >= 0 && k < nk) ? L.cam[c] + k : -1;
+  // The jets of a chunk of observations are evaluated on all cores; the sums (cost, normal equations) are then taken by ONE thread in
+  // observation order, so the result does not depend on the thread count, bit for bit.
+  struct ObsOut {
+    Jet<NR_> r[3], rd;
+    int idx[NR_], nres;
+    double wt, half_rho, wt_d, half_rho_d;
+    bool has_depth;
+  };
+  const int64_t CH = 4096;
+  std::vector<ObsOut> buf((size_t)std::min<int64_t>(CH, std::max<int64_t>(P.n_obs, 1)));
+  for (int64_t o0 = 0; o0 < P.n_obs; o0 += CH) {
+    const int64_t o1 = std::min(P.n_obs, o0 + CH);
+#pragma omp parallel for schedule(static) if (o1 - o0 > 256)
+    for (int64_t o = o0; o < o1; o++) {
+      ObsOut &B = buf[(size_t)(o - o0)];
+      const int s = P.obs_shot[o], p = P.obs_point[o];
+      const int c = P.shot_camera[s], i = P.shot_rig_instance[s], q = P.shot_rig_camera[s];
+      const int model = P.cam_model[c], nk = num_params(model);
+      typedef Jet<NR_> T;
+      T cam[16], inst[6], rcam[6], pt[3];
+      int *idx = B.idx;
+      for (int k = 0; k < 16; k++) {
+        cam[k] = T(X.cam[16 * c + k], k);
+        idx[k] = (L.cam[c] >= 0 && k < nk) ? L.cam[c] + k : -1;
+      }
+      for (int k = 0; k < 6; k++) {
+        inst[k] = T(X.inst[6 * i + k], 16 + k);
+        idx[16 + k] = L.inst[i] >= 0 ? L.inst[i] + k : -1;
+        rcam[k] = T(X.rc[6 * q + k], 22 + k);
+        idx[22 + k] = (L.rc[q] >= 0 && useful[q]) ? L.rc[q] + k : -1;
+      }
+      for (int k = 0; k < 3; k++) {
+        pt[k] = T(X.pts[3 * p + k], 28 + k);
+        idx[28 + k] = L.pt[p] >= 0 ? L.pt[p] + k : -1;
+      }
+      T Xc[3];
+      T *r = B.r;
+      WorldToCameraCoordinatesRig<T>(inst, useful[q] ? rcam : nullptr, pt, Xc);
+      const double is = 1.0 / P.obs_sigma[o];
+      int nres;
+      if (model == SPHERICAL) {
+        nres = 3;
+        const T n = sqrt(Xc[0] * Xc[0] + Xc[1] * Xc[1] + Xc[2] * Xc[2]);
+        double b[3];
+        bearing_of(P.obs_xy + 2 * o, b);
+        for (int a = 0; a < 3; a++) r[a] = (Xc[a] / n - b[a]) * is;
+      } else {
+        nres = 2;
+        T pr[2];
+        project<T>(model, cam, Xc, pr);
+        r[0] = (pr[0] - P.obs_xy[2 * o]) * is;
+        r[1] = (pr[1] - P.obs_xy[2 * o + 1]) * is;
+      }
+      B.nres = nres;
+      double sq = 0.0;
+      for (int e = 0; e < nres; e++) sq += r[e].v * r[e].v;
+      double rho, rho1;
+      loss_eval(O.loss, O.loss_threshold, sq, &rho, &rho1);
+      B.half_rho = 0.5 * rho;
+      B.wt = std::sqrt(rho1);
+      if (reproj)
+        for (int e = 0; e < 3; e++) reproj[3 * o + e] = e < nres ? r[e].v * P.obs_sigma[o] : 0.0;
+      // RelativeDepthError (bundle/error/relative_depth_error.h:11-46, added right after the reprojection block of the same observation
+      // with the SAME loss function, bundle_adjuster.cc:497-528,812): one residual on [rig instance | rig camera | point]
+      B.has_depth = P.obs_depth && P.obs_depth_sigma && P.obs_depth_sigma[o] > 0;
+      if (B.has_depth) {
+        T depth = Xc[2];
+        if (!P.obs_depth_radial || P.obs_depth_radial[o]) depth = sqrt(Xc[0] * Xc[0] + Xc[1] * Xc[1] + Xc[2] * Xc[2]);
+        B.rd = (depth - P.obs_depth[o]) * (1.0 / P.obs_depth_sigma[o]);
+        double rho_d, rho1_d;
+        loss_eval(O.loss, O.loss_threshold, B.rd.v * B.rd.v, &rho_d, &rho1_d);
+        B.half_rho_d = 0.5 * rho_d;
+        B.wt_d = std::sqrt(rho1_d);
+      }
     }
-    for (int k = 0; k < 6; k++) {
-      inst[k] = T(X.inst[6 * i + k], 16 + k);
-      idx[16 + k] = L.inst[i] >= 0 ? L.inst[i] + k : -1;
-      rcam[k] = T(X.rc[6 * q + k], 22 + k);
-      idx[22 + k] = (L.rc[q] >= 0 && useful[q]) ? L.rc[q] + k : -1;
-    }
-    for (int k = 0; k < 3; k++) {
-      pt[k] = T(X.pts[3 * p + k], 28 + k);
-      idx[28 + k] = L.pt[p] >= 0 ? L.pt[p] + k : -1;
-    }
-    T Xc[3], r[3];
-    WorldToCameraCoordinatesRig<T>(inst, useful[q] ? rcam : nullptr, pt, Xc);
-    const double is = 1.0 / P.obs_sigma[o];
-    int nres;
-    if (model == SPHERICAL) {
-      nres = 3;
-      const T n = sqrt(Xc[0] * Xc[0] + Xc[1] * Xc[1] + Xc[2] * Xc[2]);
-      double b[3];
-      bearing_of(P.obs_xy + 2 * o, b);
-      for (int a = 0; a < 3; a++) r[a] = (Xc[a] / n - b[a]) * is;
-    } else {
-      nres = 2;
-      T pr[2];
-      project<T>(model, cam, Xc, pr);
-      r[0] = (pr[0] - P.obs_xy[2 * o]) * is;
-      r[1] = (pr[1] - P.obs_xy[2 * o + 1]) * is;
-    }
-    double sq = 0.0;
-    for (int e = 0; e < nres; e++) sq += r[e].v * r[e].v;
-    double rho, rho1;
-    loss_eval(O.loss, O.loss_threshold, sq, &rho, &rho1);
-    cost += 0.5 * rho;
-    add_block<NR_>(A, r, nres, std::sqrt(rho1), idx);
-    if (reproj)
-      for (int e = 0; e < 3; e++) reproj[3 * o + e] = e < nres ? r[e].v * P.obs_sigma[o] : 0.0;
-    // RelativeDepthError (bundle/error/relative_depth_error.h:11-46, added right after the reprojection block of the same observation
-    // with the SAME loss function, bundle_adjuster.cc:497-528,812): one residual on [rig instance | rig camera | point]
-    if (P.obs_depth && P.obs_depth_sigma && P.obs_depth_sigma[o] > 0) {
-      T depth = Xc[2];
-      if (!P.obs_depth_radial || P.obs_depth_radial[o]) depth = sqrt(Xc[0] * Xc[0] + Xc[1] * Xc[1] + Xc[2] * Xc[2]);
-      T rd[1] = {(depth - P.obs_depth[o]) * (1.0 / P.obs_depth_sigma[o])};
-      double rho_d, rho1_d;
-      loss_eval(O.loss, O.loss_threshold, rd[0].v * rd[0].v, &rho_d, &rho1_d);
-      cost += 0.5 * rho_d;
-      add_block<NR_>(A, rd, 1, std::sqrt(rho1_d), idx);
+    for (int64_t o = o0; o < o1; o++) {
+      const ObsOut &B = buf[(size_t)(o - o0)];
+      cost += B.half_rho;
+      add_block<NR_>(A, B.r, B.nres, B.wt, B.idx);
+      if (B.has_depth) {
+        cost += B.half_rho_d;
+        add_block<NR_>(A, &B.rd, 1, B.wt_d, B.idx);
+      }
     }
   }
   // ---- camera priors (+ the dual barrier) ----

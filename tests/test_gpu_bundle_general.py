@@ -163,6 +163,25 @@ def test_brown_camera_free_bias_control_points_at_scale(oracle_lib, gpu_ctx, rag
     assert g["preconditioner_bandwidth"] == g["shot_bandwidth"] and (g["shot_bandwidth"] > 10) == ragged
 
 
+def test_brown_camera_at_configs2_size_twenty_iterations(oracle_lib, gpu_ctx):
+    """BASELINE configs[2] (500 cams / 50 k points / 300 k observations, 20 LM iterations) with what BAHelpers::Bundle builds on a calibrated
+    data set: a BROWN camera with nine free intrinsics and their priors, GPS priors through a free similarity bias, 20 control points.
+    osfm_bundle_solve against oracle/bundle_general_oracle.cc (jets, arrow-form normal equations, points eliminated, dense Cholesky of
+    the 3 016 reduced unknowns): the same 20 steps, reprojection RMSE within 1e-4 px, the same parameters"""
+    from opensfm_amd import bundle
+
+    pr = synthetic.make_general_ba_scene(500, 50000, 6, model="brown", n_gcp=20, gps_bias=True, seed=42)
+    g = bundle.bundle_general_arrays(pr, {"bundle_max_iterations": 20}, ctx=gpu_ctx, **NO_TOL)
+    o = oracle_lib.bundle_general(pr, max_iterations=20, **NO_TOL)
+    assert g["iterations"] == o["iterations"] == 20 and len(pr["obs_shot"]) == 300000
+    assert np.allclose(g["cost_history"], o["cost_history"], rtol=1e-8), (g["cost_history"], o["cost_history"])
+    assert abs(_rmse_px(g["reproj_err"][:, :2]) - _rmse_px(o["reproj_err"][:, :2])) < 1e-4
+    assert np.abs(g["reproj_err"][:, :2] - o["reproj_err"][:, :2]).max() * 2000.0 < 1e-4  # every observation, in pixels of a 2000-px image
+    for k in ("cam_params", "rig_instance_pose", "points", "bias"):
+        assert np.allclose(g[k], o[k], atol=1e-6), k
+    assert g["preconditioner_bandwidth"] == g["shot_bandwidth"] and g["pcg_iterations"] <= 2 * 20
+
+
 def test_border_wider_than_the_exact_elimination_falls_back_to_pcg(oracle_lib, gpu_ctx):
     """nine free BROWN cameras = 81 border unknowns, beyond the kGenMaxNB = 64 the exact border elimination carries: the band still
     preconditions the instance block, the border rows are Jacobi-preconditioned, and CG carries the coupling -- same trajectory"""
