@@ -153,13 +153,13 @@ def test_wide_band_falls_back_to_the_ldlt_chain_when_the_dense_clusters_do_not_f
     exact band, the same trajectory"""
     from opensfm_amd import bundle
 
-    pr = synthetic.make_ba_scene(90, 800, 8, seed=3, ragged=True)
+    pr = synthetic.make_ba_scene(60, 500, 8, seed=3, ragged=True)
     monkeypatch.setenv("OSFM_BA_TRACE", "1")
     with emulated():
-        a = bundle.bundle_arrays(pr, {"bundle_max_iterations": 2}, **NO_TOL)
+        a = bundle.bundle_arrays(pr, {"bundle_max_iterations": 1}, **NO_TOL)
         err_a = capfd.readouterr().err
         monkeypatch.setenv("OSFM_BA_DENSE_CR_BUDGET", "100000")
-        b = bundle.bundle_arrays(pr, {"bundle_max_iterations": 2}, **NO_TOL)
+        b = bundle.bundle_arrays(pr, {"bundle_max_iterations": 1}, **NO_TOL)
         err_b = capfd.readouterr().err
     assert "wide 1 dense 1" in err_a and "wide 1 dense 0" in err_b
     assert np.allclose(a["cost_history"], b["cost_history"], rtol=1e-11) and b["pcg_iterations"] <= b["iterations"] + 1

@@ -84,7 +84,7 @@ def test_ba_streaming_kernels_do_not_spill(tmp_path_factory):
     _, k = compile_device("ba", tmp_path_factory)
     # (length-prefixed as in the mangled names: "17schur_shot_kernel" is not "21gen_schur_shot_kernel")
     for parts in (("schur_point_coop_kernel", "ILi0E"), ("17schur_shot_kernel",), ("11eval_kernel", "ILb1ELb0E"), ("11eval_kernel", "ILb1ELb1E"),
-                  ("band_assemble_kernel",), ("border_point_kernel", "ILi3E"), ("border_shot_kernel", "ILi3E"), ("17point_grad_kernel",),
+                  ("band_assemble_kernel",), ("19border_point_kernel", "ILi3E"), ("18border_shot_kernel", "ILi3E"), ("17point_grad_kernel",),
                   ("16shot_grad_kernel",), ("bcr_level_kernel", "ILi9E"), ("wide_factor_kernel",), ("wide_push_kernel", "ILi1ELb0E")):
         r, name = one(k, *parts)
         assert r["ScratchSize"] == 0 and r["VGPRs Spill"] == 0, (name, r)
