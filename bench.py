@@ -23,7 +23,11 @@ import os
 import sys
 import time
 
-import numpy as np
+# the CPU legs' OpenMP threads sleep between parallel regions instead of spinning: a GPU leg timed right after an oracle leg otherwise shares
+# the host cores with a few hundred busy-waiting threads (measured: 8 ms of solver run became 95 ms).  Read when the OpenMP runtime starts.
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

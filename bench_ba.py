@@ -163,10 +163,12 @@ def run_general(ctx, shots: int = 5000, points: int = 500000, track: int = 10, i
         t0 = time.perf_counter()
         o = oracle.bundle_general(ps, max_iterations=cpu_iters, **no_tol)
         dt = time.perf_counter() - t0
+        bundle.bundle_general_arrays(ps, {"bundle_max_iterations": 1}, ctx=ctx, **no_tol)  # first use of this problem shape (allocator blocks)
         gs = bundle.bundle_general_arrays(ps, {"bundle_max_iterations": cpu_iters}, ctx=ctx, **no_tol)
         ch_o, ch_g = np.asarray(o["cost_history"]), np.asarray(gs["cost_history"])
         rm = lambda e: float(np.sqrt((np.asarray(e)[:, :2] ** 2).sum(1).mean()) * 2000.0)  # noqa: E731
-        out["cpu_baseline"] = {"value": round(o["iterations"] / dt, 4), "unit": "LM-iters/s", "cores": 1, "kind": "port",
+        out["cpu_baseline"] = {"value": round(o["iterations"] / dt, 4), "unit": "LM-iters/s", "cores": min(16, oracle.num_threads()), "kind": "port",
+                               "kind_note": "the residuals' jets on up to 16 threads, the sums by one thread in observation order; elimination serial, Cholesky on 8",
                                "sample": f"{cpu_size[0]} cams / {cpu_size[1]} pts / {len(ps['obs_shot'])} obs of the same make-up, {cpu_iters} LM iterations "
                                          f"({dt:.1f} s): oracle/bundle_general_oracle.cc, jets + Schur elimination + dense Cholesky",
                                "gpu_lm_iters_per_s_same_scene": round(gs["iterations"] / gs["seconds_run"], 3),

@@ -23,6 +23,7 @@
 // check of the derivatives and of the elimination, not a comparison of a program with itself.
 // PARITY STATUS: residual values pinned by the golden vectors of the C oracle's projections (tests/test_oracle_bundle_general.py);
 // the LM trajectory is "parity unpinned" against Ceres itself (not available in this image).
+#include <omp.h>
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -373,10 +374,11 @@ double evaluate(const Problem& P, const Options& O, const Layout& L, const State
     bool has_depth;
   };
   const int64_t CH = 4096;
+  const int jet_threads = std::max(1, std::min(omp_get_max_threads(), 16));  // 256 observations per thread and chunk: more threads only add barriers
   std::vector<ObsOut> buf((size_t)std::min<int64_t>(CH, std::max<int64_t>(P.n_obs, 1)));
   for (int64_t o0 = 0; o0 < P.n_obs; o0 += CH) {
     const int64_t o1 = std::min(P.n_obs, o0 + CH);
-#pragma omp parallel for schedule(static) if (o1 - o0 > 256)
+#pragma omp parallel for schedule(static) num_threads(jet_threads) if (o1 - o0 > 256)
     for (int64_t o = o0; o < o1; o++) {
       ObsOut &B = buf[(size_t)(o - o0)];
       const int s = P.obs_shot[o], p = P.obs_point[o];

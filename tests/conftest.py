@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 # 400-row factorisation with 256 spinning threads once stalled a GPU test run for its whole time limit (round 5, first call).  The tests
 # do not measure the oracle (bench.py does, with every core): cap its team unless the caller has chosen.
 os.environ.setdefault("OMP_NUM_THREADS", "32")
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")  # idle OpenMP threads sleep: a GPU call after an oracle call keeps its host core
 
 
 def pytest_configure(config):
