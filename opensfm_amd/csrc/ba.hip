@@ -3917,10 +3917,14 @@ struct Solver {
     if (d.gen) return gen_gradients();
     hipLaunchKernelGGL(point_grad_kernel, dim3(d.nwg), dim3(kCoopObs), 0, st, d);
     hipLaunchKernelGGL(shot_grad_kernel, dim3(d.S), dim3(64), 0, st, d, d.poses);
-    hipLaunchKernelGGL(cam_reduce_kernel, dim3(d.NC), dim3(kCamRedT), 0, st, d, 9);
+    if (!cams_inert) hipLaunchKernelGGL(cam_reduce_kernel, dim3(d.NC), dim3(kCamRedT), 0, st, d, 9);
     hipLaunchKernelGGL(cam_grad_kernel, dim3(nblk(d.NC, 64)), dim3(64), 0, st, d, d.cams);
   }
   bool use_band = false, use_ctri = false, use_bcr = false, use_border = false;
+  // every camera constant (local / pose-only bundle adjustment): the camera rows have zero scale, zero gradient and zero right-hand side,
+  // so the per-camera sums over the shots (cam_reduce_kernel, 4 launches of ~10 us per LM iteration of a 48-shot problem) are skipped and
+  // camred stays at the zeros it is given at setup
+  bool cams_inert = false;
   // second stream: the camera-border columns and the right-hand side only need the Jacobian and Hhat, so they run underneath the
   // cyclic-reduction factorisation (a latency chain of ~22 small launches that leaves most CUs idle)
   hipStream_t st2 = nullptr;
@@ -4139,7 +4143,7 @@ struct Solver {
     hipLaunchKernelGGL(scale_vec_kernel, dim3(nblk(d.nred)), dim3(TPB), 0, st, d.sc_red, x, d.y, d.nred);
     hipLaunchKernelGGL(schur_point_coop_kernel<0>, dim3(d.nwg), dim3(kCoopObs), 0, st, d, d.y);
     hipLaunchKernelGGL(schur_shot_kernel, dim3(d.S), dim3(64), 0, st, d);
-    hipLaunchKernelGGL(cam_reduce_kernel, dim3(d.NC), dim3(kCamRedT), 0, st, d, 3);
+    if (!cams_inert) hipLaunchKernelGGL(cam_reduce_kernel, dim3(d.NC), dim3(kCamRedT), 0, st, d, 3);
     hipLaunchKernelGGL(schur_finish_kernel, dim3(nblk(d.nred)), dim3(TPB), 0, st, d, x, d.y, out, radius, 0);
   }
 };
@@ -4989,6 +4993,8 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     if (P->cam_fixed[c]) border_ok = false;
     else all_cams_fixed = false;
   }
+  sv.cams_inert = all_cams_fixed;
+  if (all_cams_fixed && e == hipSuccess) OSFM_HIP(hipMemsetAsync(d.camred, 0, (size_t)9 * NC * sizeof(double), sv.st));
   int *d_status = A.alloc<int>(4, e);
   double *d_reproj = (gen ? G->reproj3 != nullptr : P->reproj_err != nullptr) ? A.alloc<double>((size_t)(gen ? 3 : 2) * M, e) : nullptr;
   OSFM_REQUIRE(e == hipSuccess, OSFM_E_NOMEM, "BA device allocation/upload failed: %s", hipGetErrorString(e));
@@ -5192,7 +5198,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       } else {
         hipLaunchKernelGGL(schur_point_coop_kernel<1>, dim3(d.nwg), dim3(kCoopObs), 0, sx, d, d.y);
         hipLaunchKernelGGL(schur_shot_kernel, dim3(S), dim3(64), 0, sx, d);
-        hipLaunchKernelGGL(cam_reduce_kernel, dim3(NC), dim3(kCamRedT), 0, sx, d, 3);
+        if (!sv.cams_inert) hipLaunchKernelGGL(cam_reduce_kernel, dim3(NC), dim3(kCamRedT), 0, sx, d, 3);
         hipLaunchKernelGGL(schur_finish_kernel, dim3(nbr), dim3(TPB), 0, sx, d, d.x, d.y, d.b, radius, 1);
       }
       if (sv.st2) OSFM_HIP(hipEventRecord(sv.ev_join, sv.st2));
@@ -5352,8 +5358,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       } else if ((sv.use_bcr || sv.use_wide) && all_cams_fixed) {
         // local / pose-only bundle adjustment: the band is the whole preconditioner and the camera rows are inert (zero scale, zero right-hand
         // side) -- their 3 x 3 blocks are the LM diagonal alone; the per-shot Schur blocks (63 us per LM iteration on a 48-shot problem) are not needed
-        OSFM_HIP(hipMemsetAsync(d.camred, 0, (size_t)9 * NC * sizeof(double), st));
-        hipLaunchKernelGGL(precond_cam_kernel, dim3(nblk(NC, 64)), dim3(64), 0, st, d, radius);
+        hipLaunchKernelGGL(precond_cam_kernel, dim3(nblk(NC, 64)), dim3(64), 0, st, d, radius);  // (camred: zeros since setup)
       } else if (!((sv.use_bcr || sv.use_wide) && sv.use_border)) {
         hipLaunchKernelGGL(precond_shot_kernel, dim3(S), dim3(64), 0, st, d, radius);
         hipLaunchKernelGGL(cam_reduce_kernel, dim3(NC), dim3(kCamRedT), 0, st, d, 6);
