@@ -3722,19 +3722,51 @@ __global__ void __launch_bounds__(256, 4) dgemm_mfma_kernel(GemmList L) {
 
 #include "ba_generic.inc"
 
+// Device memory of one solve: slabs from the context's block cache, handed out by a bump pointer.  A solve makes ~100 arrays; as
+// hipMalloc / hipFree pairs they were 3 ms of a local bundle adjustment's set-up and tear-down (5 ms of run) -- now the slabs of the last
+// call of similar size are reused and nothing is freed.  512 bytes are left between arrays.  (The memory is NOT fresh: whatever the solver
+// reads it has written in this call -- the host emulation poisons every slab it hands out, tests/native.)
 struct Arena {
-  std::vector<void *> ptrs;
-  osfm_ctx *ctx = nullptr;  // set: an out-of-memory allocation drops the context's block cache and retries
+  std::vector<OsfmPoolBuf *> slabs;
+  osfm_ctx *ctx = nullptr;  // set: slabs come from / go back to the context's cache (the caller holds the context lock)
+  char *cur = nullptr;
+  size_t left = 0, next_slab = (size_t)32 << 20;
   ~Arena() {
-    for (void *p : ptrs) (void)hipFree(p);
+    for (OsfmPoolBuf *b : slabs) delete b;  // (OsfmPoolBuf returns the block to the cache, after a device sync when the call failed)
   }
   template <typename T>
   T *alloc(size_t n, hipError_t &e) {
-    void *p = nullptr;
     if (e != hipSuccess) return nullptr;
-    e = osfm_malloc_retry(ctx, &p, (n ? n : 1) * sizeof(T));
-    if (e == hipSuccess) ptrs.push_back(p);
-    return (T *)p;
+    const size_t bytes = (((n ? n : 1) * sizeof(T) + 255) / 256) * 256 + 512;
+    if (bytes > left) {
+      OsfmPoolBuf *b = new (std::nothrow) OsfmPoolBuf();
+      if (!b) {
+        e = hipErrorOutOfMemory;
+        return nullptr;
+      }
+      const size_t want = std::max(bytes, next_slab);
+      e = ctx ? b->alloc(ctx, want) : b->alloc(want);
+      if (e != hipSuccess && want > bytes) {  // a slab of the growing size does not fit any more: exactly what is asked for
+        (void)hipGetLastError();
+        e = ctx ? b->alloc(ctx, bytes) : b->alloc(bytes);
+      }
+      if (e != hipSuccess) {
+        b->p = nullptr;
+        delete b;
+        return nullptr;
+      }
+#ifdef OSFM_HIPEMU
+      memset(b->p, 0xFF, b->bytes);  // a reused slab must not look initialised
+#endif
+      slabs.push_back(b);
+      cur = (char *)b->p;
+      left = b->bytes;
+      next_slab = std::min(next_slab * 2, (size_t)2 << 30);
+    }
+    T *p = (T *)cur;
+    cur += bytes;
+    left -= bytes;
+    return p;
   }
   template <typename T>
   T *upload(const T *h, size_t n, hipError_t &e) {
@@ -4483,9 +4515,6 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
   struct SideStream {
     Solver &sv;
     ~SideStream() {
-      if (sv.ev_fork) (void)hipEventDestroy(sv.ev_fork);
-      if (sv.ev_join) (void)hipEventDestroy(sv.ev_join);
-      if (sv.st2) (void)hipStreamDestroy(sv.st2);
       for (int q = 0; q < 2; q++) {
         if (sv.ev_rn[q]) (void)hipEventDestroy(sv.ev_rn[q]);
         if (sv.ev_p[q]) (void)hipEventDestroy(sv.ev_p[q]);
@@ -4494,9 +4523,14 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     }
   } side_stream{sv};
   if (getenv("OSFM_BA_ONE_STREAM") == nullptr) {  // measurement knob: everything on one stream
-    OSFM_HIP(hipStreamCreateWithFlags(&sv.st2, hipStreamNonBlocking));  // (a low-priority side stream was measured: no difference)
-    OSFM_HIP(hipEventCreateWithFlags(&sv.ev_fork, hipEventDisableTiming));
-    OSFM_HIP(hipEventCreateWithFlags(&sv.ev_join, hipEventDisableTiming));
+    // the side stream and its two events live in the context (creating and destroying a stream per solve is a millisecond of a local
+    // bundle adjustment's call); (a low-priority side stream was measured: no difference)
+    if (!ctx->stream_b) OSFM_HIP(hipStreamCreateWithFlags(&ctx->stream_b, hipStreamNonBlocking));
+    for (int q = 0; q < 2; q++)
+      if (!ctx->ev_side[q]) OSFM_HIP(hipEventCreateWithFlags(&ctx->ev_side[q], hipEventDisableTiming));
+    sv.st2 = ctx->stream_b;
+    sv.ev_fork = ctx->ev_side[0];
+    sv.ev_join = ctx->ev_side[1];
   }
   sv.loss = O->loss;
   sv.loss_a = O->loss_threshold;

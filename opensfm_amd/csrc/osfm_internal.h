@@ -68,6 +68,7 @@ struct osfm_ctx {
   double stop_probability = -1.0;
   std::unordered_map<int, std::vector<double>> stop_tables;
   void *h_pinned = nullptr;     // ba.hip: pinned host memory the LM loop's scalars come back through, made on first use
+  hipEvent_t ev_side[2] = {nullptr, nullptr};  // ba.hip: fork / join of the solver's side stream (= stream_b), made on first use
   size_t h_pinned_bytes = 0;
 };
 

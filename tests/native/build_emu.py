@@ -36,7 +36,7 @@ def build(force: bool = False, sanitize: bool = False) -> str:
     deps.append(os.path.join(ROOT, "include", "osfm_mi355.h"))
     if not force and os.path.exists(so) and all(os.path.getmtime(so) >= os.path.getmtime(d) for d in deps):
         return so
-    flags = ["-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unknown-attributes", "-Wno-unused-value", "-I", os.path.join(HERE, "hipemu"), "-I", CSRC,
+    flags = ["-std=c++17", "-fPIC", "-ffp-contract=off", "-DOSFM_HIPEMU", "-Wno-unknown-attributes", "-Wno-unused-value", "-I", os.path.join(HERE, "hipemu"), "-I", CSRC,
              "-I", os.path.join(ROOT, "include")]
     flags += ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"] if sanitize else ["-O2"]
     objs = []

@@ -31,7 +31,11 @@ extern "C" void osfm_ctx_destroy(osfm_ctx *c) {
   if (!c) return;
   for (int i = 0; i < 8; ++i) (void)hipEventDestroy(c->ev[i]);
   (void)hipStreamDestroy(c->stream);
+  if (c->stream_b) (void)hipStreamDestroy(c->stream_b);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+  for (int i = 0; i < 2; ++i)
+    if (c->ev_side[i]) (void)hipEventDestroy(c->ev_side[i]);
+  for (auto &b : c->pool) (void)hipFree(b.p);
   delete c;
 }
 extern "C" int64_t osfm_ctx_trim_pool(osfm_ctx *) { return 0; }
