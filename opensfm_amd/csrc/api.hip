@@ -55,6 +55,9 @@ extern "C" void osfm_ctx_destroy(osfm_ctx *c) {
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
   for (int i = 0; i < 2; ++i)
     if (c->ev_side[i]) (void)hipEventDestroy(c->ev_side[i]);
+  for (int i = 0; i < 2; ++i)
+    if (c->ev_rp[i]) (void)hipEventDestroy(c->ev_rp[i]);
+  if (c->stream_c) (void)hipStreamDestroy(c->stream_c);
   delete c;
 }
 

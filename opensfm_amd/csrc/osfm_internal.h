@@ -69,6 +69,8 @@ struct osfm_ctx {
   std::unordered_map<int, std::vector<double>> stop_tables;
   void *h_pinned = nullptr;     // ba.hip: pinned host memory the LM loop's scalars come back through, made on first use
   hipEvent_t ev_side[2] = {nullptr, nullptr};  // ba.hip: fork / join of the solver's side stream (= stream_b), made on first use
+  hipStream_t stream_c = nullptr;              // relpose.hip: side stream of the LO-RANSAC rounds, with its fork / join events; made on first use
+  hipEvent_t ev_rp[2] = {nullptr, nullptr};
   size_t h_pinned_bytes = 0;
 };
 

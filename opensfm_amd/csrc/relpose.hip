@@ -333,23 +333,15 @@ int osfm_relpose_run_device(osfm_ctx *ctx, hipStream_t st, const double *d_b1, c
            (int)prm->lo_iterations, mode == OSFM_RELPOSE_MATCH ? 8 : 5, kMaxSlots, d_st.as<PairState>(), d_sidx.as<int>(), d_posb.as<int>(), d_pos.as<int>(),
            d_nm.as<int>(), d_models.as<double>(), d_lidx.as<int>(), d_lopos.as<int>(), d_look.as<int>(), d_lort.as<double>(), d_inl.as<int>(),
            d_at6.as<double>(), d_bas.as<double>(), d_ok5.as<int>(), d_E5.as<double>(), d_loE.as<double>(), d_l5.as<int>(), d_lN.as<int>(), d_cnt.as<int>()};
+  // the side stream and its two events live in the context (creating and destroying them per call is ~1 ms: most of a single pair's call)
+  if (!ctx->stream_c) OSFM_HIP(hipStreamCreateWithFlags(&ctx->stream_c, hipStreamNonBlocking));
+  for (int q = 0; q < 2; q++)
+    if (!ctx->ev_rp[q]) OSFM_HIP(hipEventCreateWithFlags(&ctx->ev_rp[q], hipEventDisableTiming));
   struct Stream2 {
     hipStream_t s = nullptr;
-    ~Stream2() {
-      if (s) (void)hipStreamDestroy(s);
-    }
   } st2;
-  OSFM_HIP(hipStreamCreateWithFlags(&st2.s, hipStreamNonBlocking));
-  struct Events {
-    hipEvent_t fork = nullptr, join = nullptr;
-    ~Events() {
-      if (fork) (void)hipEventDestroy(fork);
-      if (join) (void)hipEventDestroy(join);
-    }
-  } evs;
-  OSFM_HIP(hipEventCreateWithFlags(&evs.fork, hipEventDisableTiming));
-  OSFM_HIP(hipEventCreateWithFlags(&evs.join, hipEventDisableTiming));
-  hipEvent_t ev_fork = evs.fork, ev_join = evs.join;
+  st2.s = ctx->stream_c;
+  hipEvent_t ev_fork = ctx->ev_rp[0], ev_join = ctx->ev_rp[1];
   {
     const long first = (long)offsets[0], count = (long)(total - offsets[0]);  // this batch's correspondences
     const long items = std::max<long>(n_pairs, count);
