@@ -45,7 +45,8 @@ void osfm_ctx_destroy(osfm_ctx *ctx);
 /* Device the context is bound to and its CU count (0 on error). */
 int osfm_ctx_device(const osfm_ctx *ctx);
 int osfm_ctx_num_cus(const osfm_ctx *ctx);
-/* The context keeps the device blocks of the batched calls (chunk buffers, up to 6 GiB) cached between calls.  Waits for the device,
+/* The context keeps the device blocks of its calls (the matcher's chunk buffers, the slabs a bundle adjustment sub-allocates its arrays
+ * from; up to 24 GiB) cached between calls.  Waits for the device,
  * frees every cached block and returns the bytes released; the library calls it itself before it reports OSFM_E_NOMEM. */
 int64_t osfm_ctx_trim_pool(osfm_ctx *ctx);
 

@@ -60,7 +60,7 @@ struct osfm_ctx {
   size_t pool_bytes = 0;
   std::mutex pool_mu;  // the block cache itself: osfm_hahog_extract_batch's worker threads take and return blocks while the caller holds `mu`
   std::vector<hipStream_t> aux_streams;  // hahog.hip: one stream per concurrent image of a batch, made on first use
-  static constexpr size_t kPoolBytes = (size_t)6 << 30;
+  static constexpr size_t kPoolBytes = (size_t)24 << 30;  // (of 288 GB: a bundle adjustment at 5 M observations keeps ~16 GB of slabs between calls)
   hipStream_t stream_b = nullptr;  // second stream of the batched matching calls (gather + D2H of chunk k under the matcher of k + 1)
   size_t match_hint = 0;        // int32 entries of the last batched call's match list: the next call reserves that much up front
   // relpose.hip: ShouldStop's iteration bound for every (pair size n, best inlier count c <= n), tabulated with the host's libm (pow, log);
