@@ -131,6 +131,11 @@ int64_t osfm_result_num_pairs(const osfm_match_result *r);
 int64_t osfm_result_total_matches(const osfm_match_result *r);
 /* counts[n_pairs]; matches[total x 2] concatenated in pair order, each pair sorted by (i, j). */
 int osfm_result_fetch(const osfm_match_result *r, int32_t *counts, int32_t *matches);
+/* The same two arrays where the call left them in host memory -- no copy: valid until osfm_result_destroy, not to be written through.
+ * (What a binding wraps as its array type: the reference's match_images hands out per-pair numpy arrays, matching.py:563-634; the
+ * Python layer here views these buffers and destroys the result when the last view goes.)  OSFM_E_INVALID for a result kept on the
+ * device (OSFM_MATCH_KEEP_DEVICE: use osfm_result_fetch or osfm_result_dev_ptrs). */
+int osfm_result_host_ptrs(const osfm_match_result *r, const int32_t **counts, const int32_t **matches);
 /* Results of a call made with OSFM_MATCH_KEEP_DEVICE: device pointers (on osfm_result_device) to counts[n_pairs] and to the
  * concatenated matches[total x 2], valid until osfm_result_destroy; every kernel that wrote them has completed when the matching
  * call returns.  OSFM_E_INVALID for a result that was not kept on the device. */

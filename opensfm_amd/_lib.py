@@ -111,6 +111,7 @@ SIGNATURES = {
     "osfm_result_num_pairs": (C.c_int64, [C.c_void_p]),
     "osfm_result_total_matches": (C.c_int64, [C.c_void_p]),
     "osfm_result_fetch": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "osfm_result_host_ptrs": (C.c_int, [C.c_void_p, C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.POINTER(C.c_int32))]),
     "osfm_result_dev_ptrs": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "osfm_result_device": (C.c_int, [C.c_void_p]),
     "osfm_result_destroy": (None, [C.c_void_p]),

@@ -692,6 +692,13 @@ extern "C" int osfm_result_fetch(const osfm_match_result *r, int32_t *counts, in
   if (matches && !r->matches.empty()) memcpy(matches, r->matches.data(), r->matches.size() * sizeof(int32_t));
   return OSFM_OK;
 }
+extern "C" int osfm_result_host_ptrs(const osfm_match_result *r, const int32_t **counts, const int32_t **matches) {
+  OSFM_REQUIRE(r && counts && matches, OSFM_E_INVALID, "osfm_result_host_ptrs: null argument");
+  OSFM_REQUIRE(!r->on_device, OSFM_E_INVALID, "osfm_result_host_ptrs: the match rows of this result were kept on the device");
+  *counts = r->counts.data();
+  *matches = r->matches.data();
+  return OSFM_OK;
+}
 extern "C" int osfm_result_dev_ptrs(const osfm_match_result *r, const int32_t **d_counts, const int32_t **d_matches) {
   OSFM_REQUIRE(r && d_counts && d_matches, OSFM_E_INVALID, "osfm_result_dev_ptrs: null argument");
   OSFM_REQUIRE(r->on_device, OSFM_E_INVALID, "osfm_result_dev_ptrs: the result was not made with OSFM_MATCH_KEEP_DEVICE");
