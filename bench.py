@@ -418,6 +418,33 @@ def hahog_bench(ctx, with_cpu, rows: int = 1536, cols: int = 2048, target: int =
                         "frac": round(alg_bytes / (ms * 1e-3) / 1e9 / 8000.0, 4), "algorithmic_bytes": alg_bytes,
                         "note": "whole call (H2D of the image, ~50 launches, two host round trips for the feature counts, D2H of the results) "
                                 "against the streaming bytes of the pyramid"}}
+    # what the pipeline hands over: a decoded grey image, uint8 (features.extract_features_hahog, opensfm/features.py:516-534) -- the bytes go to the
+    # device as they are and level / 255 is formed there (OSFM_HAHOG_IMAGE_U8): no host-side float pass, a quarter of the PCIe bytes
+    try:
+        im8 = np.ascontiguousarray(np.round(255 * im), np.uint8)
+        cfg = {"feature_root": True, "hahog_normalize_to_uchar": True, "hahog_peak_threshold": 1e-5, "hahog_edge_threshold": 10.0}
+        features.extract_features_hahog(im8, cfg, target, ctx=ctx)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            p8, d8 = features.extract_features_hahog(im8, cfg, target, ctx=ctx)
+        ms8 = (time.perf_counter() - t0) / reps * 1e3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            pf, df = features.extract_features_hahog(im8.astype(np.float32), cfg, target, ctx=ctx)  # (a float image takes the host-side division)
+        msf = (time.perf_counter() - t0) / reps * 1e3
+        out["uint8_image"] = {"value": round(1e3 / ms8, 2), "unit": "images/s", "ms_per_image": round(ms8, 3), "features": int(len(p8)),
+                              "float_path_images_per_s": round(1e3 / msf, 2), "identical_to_float_path": bool(np.array_equal(p8, pf) and np.array_equal(d8, df)),
+                              "note": "features.extract_features_hahog on the decoded uint8 image (root + uchar descriptors), image by image"}
+        nb = 32
+        for conc in (8,):
+            features.hahog_batch([im8] * 8, 1e-5, 10.0, target, flags=features.HAHOG_ROOT | features.HAHOG_UCHAR, concurrency=conc, ctx=ctx)
+            t0 = time.perf_counter()
+            res8 = features.hahog_batch([im8] * nb, 1e-5, 10.0, target, flags=features.HAHOG_ROOT | features.HAHOG_UCHAR, concurrency=conc, ctx=ctx)
+            dt = time.perf_counter() - t0
+            out["uint8_image"][f"batch_host_images_x{conc}"] = {"value": round(nb / dt, 1), "unit": "images/s", "images": nb, "concurrency": conc,
+                                                               "identical_to_single": bool(all(np.array_equal(p, p8) and np.array_equal(dd, d8) for p, dd in res8))}
+    except Exception as e:  # noqa: BLE001
+        out["uint8_image"] = {"error": f"{type(e).__name__}: {e}"}
     # a data set's worth of images in one call (osfm_hahog_extract_batch): several in flight on separate streams / host threads
     try:
         nb = 32

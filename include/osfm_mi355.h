@@ -530,6 +530,10 @@ int osfm_hahog_extract(osfm_ctx *ctx, const float *image, int rows, int cols, fl
  * above.  Results are those of osfm_hahog_extract image by image.  OSFM_HAHOG_IMAGE_ON_DEVICE: the image pointers are device memory
  * (extraction from frames that are already resident, no host-to-device copy inside the call). */
 #define OSFM_HAHOG_IMAGE_ON_DEVICE 4
+/* OSFM_HAHOG_IMAGE_U8 (both entry points): the image pointers address uint8 grey levels 0 .. 255 (rows x cols bytes) instead of float32
+ * in [0, 1]; the library forms level / 255 in float32 on the device -- what features.extract_features_hahog (opensfm/features.py:524)
+ * does on the host before the call: identical features, a quarter of the bytes over PCIe and no host-side conversion pass. */
+#define OSFM_HAHOG_IMAGE_U8 8
 int osfm_hahog_extract_batch(osfm_ctx *ctx, int n_images, const float *const *images, const int *rows, const int *cols, float peak_threshold,
                              float edge_threshold, int target_num_features, int flags, float *const *points, float *const *desc,
                              const int *capacities, int *n_features, int concurrency);

@@ -1037,6 +1037,12 @@ std::vector<float> gaussian_taps(double sigma, int *W) {
   return filt;
 }
 
+// grey levels 0 .. 255 -> float32 in [0, 1]: numpy's image.astype(np.float32) / 255 (one correctly rounded float32 division per pixel)
+__global__ void __launch_bounds__(256) u8_to_unit_float_kernel(const unsigned char *src, float *dst, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = (float)src[i] / 255.0f;
+}
+
 // Device memory of one call: two slabs from the context's cache of blocks (the pyramid and fixed-size buffers; what depends on the number
 // of detections), handed out in 256-byte steps -- a dozen hipMalloc / hipFree pairs per image cost more than the kernels
 struct Slab {
@@ -1091,7 +1097,7 @@ static int hahog_extract_on_stream(osfm_ctx *ctx, hipStream_t st, const float *i
   Slab A, B;
   constexpr int kFeatureCap = 1 << 20;
   {
-    size_t need = padded((size_t)W0 * H0, 4) + padded((size_t)kMaxTaps * (kLev + 1) * kMaxOct, 4) + 5 * padded(kFeatureCap, 4) + 2 * padded(kFeatureCap, 4) +
+    size_t need = padded((size_t)W0 * H0, 4) + padded((size_t)W0 * H0, 1) + padded((size_t)kMaxTaps * (kLev + 1) * kMaxOct, 4) + 5 * padded(kFeatureCap, 4) + 2 * padded(kFeatureCap, 4) +
                   padded(kFeatureCap, 8) + padded(4, 4) + padded((size_t)kOrSide * kOrSide + 257, 8);
     for (int o = 0; o <= last_octave; o++) need += 2 * padded((size_t)(W0 >> o) * (H0 >> o) * kLev, 4);
     OSFM_REQUIRE(A.buf.alloc(ctx, need) == hipSuccess, OSFM_E_NOMEM, "osfm_hahog_extract: %zu bytes of device memory", need);
@@ -1105,6 +1111,7 @@ static int hahog_extract_on_stream(osfm_ctx *ctx, hipStream_t st, const float *i
     for (int s = kFirstSub; s <= kLastSub; s++) py.sigma[o][s - kFirstSub] = py.base_scale * std::pow(2.0, o + (double)s / kRes);
   }
   float *d_tmp = A.take<float>((size_t)W0 * H0);
+  unsigned char *d_u8 = A.take<unsigned char>((size_t)W0 * H0);  // OSFM_HAHOG_IMAGE_U8: the caller's grey levels, converted on the device
   float *d_taps = A.take<float>((size_t)kMaxTaps * (kLev + 1) * kMaxOct);
   // every Gaussian of the pyramid, from the host's libm
   std::vector<float> h_taps((size_t)kMaxTaps * (kLev + 1) * kMaxOct, 0.f);
@@ -1162,8 +1169,17 @@ static int hahog_extract_on_stream(osfm_ctx *ctx, hipStream_t st, const float *i
   // the first level of an octave is smoothed from a staging image (the caller's image / the decimated level of the octave before) straight
   // into its place; without a smoothing step (never at vlfeat's defaults) the staging image is the level
   const bool staged0 = first_smooth[0] && !two_pass;
-  OSFM_HIP(hipMemcpyAsync(staged0 ? d_tmp : py.oct[0].gss, image, (size_t)W0 * H0 * sizeof(float),
-                          (flags & OSFM_HAHOG_IMAGE_ON_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+  if (flags & OSFM_HAHOG_IMAGE_U8) {  // features.py:524: image.astype(np.float32) / 255 -- the same float32 division, a quarter of the bytes over PCIe
+    const unsigned char *src = reinterpret_cast<const unsigned char *>(image);
+    if (!(flags & OSFM_HAHOG_IMAGE_ON_DEVICE)) {
+      OSFM_HIP(hipMemcpyAsync(d_u8, src, (size_t)W0 * H0, hipMemcpyHostToDevice, st));
+      src = d_u8;
+    }
+    const long npx0 = (long)W0 * H0;
+    hipLaunchKernelGGL(u8_to_unit_float_kernel, dim3((unsigned)((npx0 + 255) / 256)), dim3(256), 0, st, src, staged0 ? d_tmp : py.oct[0].gss, npx0);
+  } else
+    OSFM_HIP(hipMemcpyAsync(staged0 ? d_tmp : py.oct[0].gss, image, (size_t)W0 * H0 * sizeof(float),
+                            (flags & OSFM_HAHOG_IMAGE_ON_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
   for (int o = 0; o <= last_octave; o++) {
     const Octave &oc = py.oct[o];
     const size_t npx = (size_t)oc.w * oc.h;

@@ -12,10 +12,11 @@ from ._lib import check, default_context
 HAHOG_ROOT = 1
 HAHOG_UCHAR = 2
 HAHOG_IMAGE_ON_DEVICE = 4
+HAHOG_IMAGE_U8 = 8  # the image is uint8 grey levels: level / 255 in float32 is formed on the device
 
 
 def _extract(image: np.ndarray, peak_threshold: float, edge_threshold: float, target_num_features: int, flags: int, ctx=None):
-    im = np.ascontiguousarray(image, np.float32)
+    im = np.ascontiguousarray(image, np.uint8 if flags & HAHOG_IMAGE_U8 else np.float32)
     if im.ndim != 2:
         raise ValueError("hahog takes one grey-level image (rows x cols)")
     if im.size == 0:
@@ -26,7 +27,7 @@ def _extract(image: np.ndarray, peak_threshold: float, edge_threshold: float, ta
     pts = np.empty((cap, 4), np.float32)
     desc = np.empty((cap, 128), np.float32)
     n = C.c_int(0)
-    check(lib.osfm_hahog_extract(ctx.handle, im.ctypes.data_as(C.POINTER(C.c_float)), im.shape[0], im.shape[1], float(peak_threshold),
+    check(lib.osfm_hahog_extract(ctx.handle, C.cast(im.ctypes.data, C.POINTER(C.c_float)), im.shape[0], im.shape[1], float(peak_threshold),
                                  float(edge_threshold), int(target_num_features), int(flags), pts.ctypes.data_as(C.POINTER(C.c_float)),
                                  desc.ctypes.data_as(C.POINTER(C.c_float)), cap, C.byref(n)), "osfm_hahog_extract")
     return pts[: n.value].copy(), desc[: n.value].copy()
@@ -35,7 +36,7 @@ def _extract(image: np.ndarray, peak_threshold: float, edge_threshold: float, ta
 def hahog_batch(images: Sequence[Any], peak_threshold: float, edge_threshold: float, target_num_features: int, flags: int = 0, concurrency: int = 0,
                 shapes: Optional[Sequence[Tuple[int, int]]] = None, ctx=None) -> List[Tuple[np.ndarray, np.ndarray]]:
     """``osfm_hahog_extract_batch``: the images of a data set in one call, up to ``concurrency`` (0: 4) in flight on separate streams.
-    ``images``: float32 arrays in [0, 1] (host), or -- with ``shapes`` = their (rows, cols) -- device addresses (ints) of resident images.
+    ``images``: float32 arrays in [0, 1] or uint8 arrays of grey levels (host), or -- with ``shapes`` = their (rows, cols) -- device addresses (ints) of resident images.
     Returns the (points, descriptors) ``hahog`` returns for each image, in order."""
     ctx = ctx or default_context()
     lib = _lib.load()
@@ -48,7 +49,10 @@ def hahog_batch(images: Sequence[Any], peak_threshold: float, edge_threshold: fl
         ims, rc = None, [(int(r), int(c)) for r, c in shapes]
         ptrs = (C.c_void_p * n)(*[int(a) for a in images])
     else:
-        ims = [np.ascontiguousarray(im, np.float32) for im in images]
+        u8 = all(np.asarray(im).dtype == np.uint8 for im in images)  # grey levels 0 .. 255: converted on the device (HAHOG_IMAGE_U8)
+        if u8:
+            flags |= HAHOG_IMAGE_U8
+        ims = [np.ascontiguousarray(im, np.uint8 if u8 else np.float32) for im in images]
         if any(im.ndim != 2 or im.size == 0 for im in ims):
             raise ValueError("hahog_batch takes non-empty grey-level images (rows x cols)")
         rc = [im.shape for im in ims]
@@ -74,7 +78,11 @@ def extract_features_hahog(image: np.ndarray, config: Dict[str, Any], features_c
     """``features.extract_features_hahog`` (features.py:516-534): grey image with levels 0..255 -> points, descriptors; the square root
     (``feature_root``) and the scaling to integer values in [0, 255] (``hahog_normalize_to_uchar``) are applied on the device."""
     flags = (HAHOG_ROOT if config["feature_root"] else 0) | (HAHOG_UCHAR if config["hahog_normalize_to_uchar"] else 0)
-    out = _extract(np.asarray(image).astype(np.float32) / 255, config["hahog_peak_threshold"], config["hahog_edge_threshold"], features_count, flags, ctx)
+    image = np.asarray(image)
+    if image.dtype == np.uint8:  # the usual case (a decoded grey image): the library divides by 255 on the device -- same float32 values
+        out = _extract(image, config["hahog_peak_threshold"], config["hahog_edge_threshold"], features_count, flags | HAHOG_IMAGE_U8, ctx)
+    else:
+        out = _extract(image.astype(np.float32) / 255, config["hahog_peak_threshold"], config["hahog_edge_threshold"], features_count, flags, ctx)
     if out is None:
         raise TypeError("cannot unpack non-iterable NoneType object")  # what the reference's tuple unpacking raises for an empty image
     return out

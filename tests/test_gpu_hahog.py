@@ -131,6 +131,33 @@ def test_batch_equals_image_by_image(gpu_ctx):
     assert sum(len(p) for p, _ in single) > 500
 
 
+def test_uint8_images_equal_their_float_form(gpu_ctx):
+    """OSFM_HAHOG_IMAGE_U8: grey levels handed over as bytes, level / 255 formed in float32 on the device -- the host-side
+    image.astype(np.float32) / 255 of features.extract_features_hahog (opensfm/features.py:524) bit for bit: identical keypoints and
+    descriptors, single image and batch"""
+    from opensfm_amd import features
+
+    rng = np.random.default_rng(11)
+    ims = []
+    for r, c in ((240, 320), (333, 257), (480, 640)):
+        im = rng.random((r, c))
+        k = np.ones(5) / 5
+        im = np.apply_along_axis(lambda v: np.convolve(v, k, mode="same"), 1, np.apply_along_axis(lambda v: np.convolve(v, k, mode="same"), 0, im))
+        ims.append(np.ascontiguousarray(np.round(255 * im / im.max()), np.uint8))
+    fl = features.HAHOG_ROOT | features.HAHOG_UCHAR
+    for im in ims:
+        pf, df = features._extract(im.astype(np.float32) / 255, 1e-5, 10.0, 400, fl, gpu_ctx)
+        pu, du = features._extract(im, 1e-5, 10.0, 400, fl | features.HAHOG_IMAGE_U8, gpu_ctx)
+        assert len(pf) > 50 and np.array_equal(pf, pu) and np.array_equal(df, du)
+        p2, d2 = features.extract_features_hahog(im, CFG, 400, ctx=gpu_ctx)  # the facade takes the byte path for uint8 input
+        p3, d3 = features.extract_features_hahog(im.astype(np.float64), CFG, 400, ctx=gpu_ctx)  # ... and the float path otherwise
+        assert np.array_equal(p2, p3) and np.array_equal(d2, d3)
+    got = features.hahog_batch(ims, 1e-5, 10.0, 400, fl, concurrency=3, ctx=gpu_ctx)
+    ref = features.hahog_batch([im.astype(np.float32) / 255 for im in ims], 1e-5, 10.0, 400, fl, concurrency=3, ctx=gpu_ctx)
+    for (p, d), (pr, dr) in zip(got, ref):
+        assert np.array_equal(p, pr) and np.array_equal(d, dr)
+
+
 def test_fused_smoothing_equals_the_two_passes(gpu_ctx, monkeypatch):
     """The scale space's separable Gaussian as one LDS-tiled launch (smooth_fused_kernel) against the column kernel followed by the row
     kernel (OSFM_HAHOG_TWO_PASS): the same float operations in the same order, so every keypoint and descriptor is identical -- on sizes
