@@ -3768,10 +3768,31 @@ struct Arena {
     left -= bytes;
     return p;
   }
+  // Small host arrays go through pinned staging memory of the context and an asynchronous copy on the solve's stream: a hipMemcpy from
+  // pageable memory is a synchronous round trip of 15 - 30 us whatever the size, and a solve uploads twenty to forty-five of them
+  // (0.3 ms of a local bundle adjustment's 0.5 ms set-up).  Large arrays (the observations) keep the direct copy.
+  hipStream_t st = nullptr;
+  size_t staged = 0;
+  static constexpr size_t kStageBytes = (size_t)4 << 20, kStageMax = (size_t)256 << 10;
   template <typename T>
   T *upload(const T *h, size_t n, hipError_t &e) {
     T *p = alloc<T>(n, e);
-    if (e == hipSuccess && n) e = hipMemcpy(p, h, n * sizeof(T), hipMemcpyHostToDevice);
+    if (e != hipSuccess || n == 0) return p;
+    const size_t bytes = n * sizeof(T), padded = (bytes + 63) / 64 * 64;
+    if (ctx && st && bytes <= kStageMax && staged + padded <= kStageBytes) {
+      if (!ctx->h_stage && hipHostMalloc(&ctx->h_stage, kStageBytes, hipHostMallocDefault) != hipSuccess) {
+        ctx->h_stage = nullptr;
+        (void)hipGetLastError();
+      }
+      if (ctx->h_stage) {
+        char *dst = (char *)ctx->h_stage + staged;
+        memcpy(dst, h, bytes);
+        staged += padded;
+        e = hipMemcpyAsync(p, dst, bytes, hipMemcpyHostToDevice, st);
+        return p;
+      }
+    }
+    e = hipMemcpy(p, h, bytes, hipMemcpyHostToDevice);
     return p;
   }
 };
@@ -4512,6 +4533,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
   Solver sv;
   sv.ctx = ctx;
   sv.st = ctx->stream;
+  A.st = sv.st;
   struct SideStream {
     Solver &sv;
     ~SideStream() {

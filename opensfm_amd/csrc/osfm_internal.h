@@ -72,6 +72,7 @@ struct osfm_ctx {
   hipStream_t stream_c = nullptr;              // relpose.hip: side stream of the LO-RANSAC rounds, with its fork / join events; made on first use
   hipEvent_t ev_rp[2] = {nullptr, nullptr};
   size_t h_pinned_bytes = 0;
+  void *h_stage = nullptr;      // ba.hip: pinned staging memory of a solve's small uploads (4 MiB), made on first use
 };
 
 // Tile = 32 descriptors x 128 int8 in MFMA-operand order (4 KiB):

@@ -33,6 +33,7 @@ extern "C" void osfm_ctx_destroy(osfm_ctx *c) {
   (void)hipStreamDestroy(c->stream);
   if (c->stream_b) (void)hipStreamDestroy(c->stream_b);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+  if (c->h_stage) (void)hipHostFree(c->h_stage);
   for (int i = 0; i < 2; ++i)
     if (c->ev_side[i]) (void)hipEventDestroy(c->ev_side[i]);
   for (auto &b : c->pool) (void)hipFree(b.p);
