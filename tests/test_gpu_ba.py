@@ -482,3 +482,28 @@ def test_lookahead_variant_of_the_wide_band_inversion(gpu_ctx, monkeypatch):
     assert a["preconditioner_bandwidth"] == b["preconditioner_bandwidth"] > 15
     assert abs(a["pcg_iterations"] - b["pcg_iterations"]) <= 2
     assert np.allclose(a["cost_history"], b["cost_history"], rtol=1e-10)
+
+
+def test_results_do_not_depend_on_what_the_cached_slabs_held(gpu_ctx):
+    """the solve's device arrays are sub-allocated from slabs the context keeps between calls (round 5): whatever a solve reads it must
+    have written in the same call.  Two different problems alternate on one context -- each run is bit for bit the run on a fresh
+    context (whose slabs come straight from the driver)."""
+    from opensfm_amd import _lib, bundle
+
+    problems = [synthetic.make_ba_scene(60, 2500, 7, seed=1), synthetic.make_ba_scene(45, 4000, 5, seed=2, ragged=True),
+                synthetic.make_ba_scene(60, 2500, 7, seed=3)]
+    fresh = []
+    for pr in problems:
+        c = _lib.Context(0)
+        fresh.append(bundle.bundle_arrays(pr, {"bundle_max_iterations": 5}, ctx=c, **NO_TOL))
+        c.close()
+    shared = _lib.Context(0)
+    try:
+        for rep in range(2):
+            for pr, f in zip(problems, fresh):
+                g = bundle.bundle_arrays(pr, {"bundle_max_iterations": 5}, ctx=shared, **NO_TOL)
+                assert np.array_equal(g["cost_history"], f["cost_history"]) and g["pcg_iterations"] == f["pcg_iterations"]
+                for k in ("shot_pose", "points", "cam_params", "reproj_err"):
+                    assert np.array_equal(g[k], f[k]), (rep, k)
+    finally:
+        shared.close()

@@ -305,3 +305,28 @@ def test_two_threads_share_the_library(oracle_lib, gpu_ctx):
             t.join()
         assert errors == []
         assert len(seen_ctx) == (1 if shared is not None else 2)  # per-thread default contexts
+
+
+def test_match_arrays_outlive_the_store_and_the_context():
+    """match_pairs hands out VIEWS of the buffers the call left in host memory (osfm_result_host_ptrs), and the result object lives as
+    long as one of them does: nothing may depend on the store, the context or the order in which Python collects things"""
+    import gc
+
+    from opensfm_amd import _lib, matching
+
+    sc = synthetic.make_matching_scene(8, 500, seed=5)
+    pairs = synthetic.all_pairs(8)
+    ctx = _lib.Context(0)
+    store = matching.DescriptorStore.from_packed(sc.desc, sc.pts, sc.offsets, ctx)
+    counts, m = matching.match_pairs(store, pairs)
+    assert not counts.flags.owndata and not m.flags.owndata and m.shape == (int(counts.sum()), 2) and len(m) > 100
+    c0, m0 = counts.copy(), m.copy()
+    first = m[:5]  # a slice keeps the result alive on its own
+    del store, counts, m
+    ctx.close()
+    del ctx
+    gc.collect()
+    junk = [np.random.default_rng(i).integers(0, 1 << 30, 1 << 18) for i in range(8)]  # churn the allocator
+    assert np.array_equal(first, m0[:5])
+    c1, m1 = matching.match_pairs(matching.DescriptorStore.from_packed(sc.desc, sc.pts, sc.offsets), pairs)
+    assert np.array_equal(c1, c0) and np.array_equal(m1, m0) and len(junk) == 8
