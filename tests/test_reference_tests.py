@@ -224,3 +224,45 @@ def test_reference_ordered_pairs_test_passes_on_the_product(reference_tests, mon
     t = reference_tests["test_matching"]
     monkeypatch.setattr(t, "pairs_selection", preselection)
     t.test_ordered_pairs()
+
+
+def test_reference_shot_neighborhood_tests_pass_on_the_adapter():
+    """opensfm/test/test_reconstruction_shot_neighborhood.py: the three tests of ``pysfm.BAHelpers.shot_neighborhood_ids(rec.map, ...)``
+    (linear graph, complete graph, ranking by common points) executed with ``opensfm_amd.compat.pysfm`` in the place of the compiled
+    module and ``opensfm_amd.geometry_types`` serving the map (the tests of the pure-Python ``reconstruction.shot_neighborhood`` next to
+    them need the whole of reconstruction.py and stay out)"""
+    from opensfm_amd import compat
+    from opensfm_amd import geometry_types as gt
+
+    class Rec(gt.Reconstruction):
+        def create_point(self, point_id, coordinates=(0.0, 0.0, 0.0)):
+            return super().create_point(point_id, np.asarray(coordinates, float))
+
+        @property
+        def map(self):  # the reference hands BAHelpers the pymap.Map of the reconstruction
+            return self
+
+    saved = {k: sys.modules.get(k) for k in list(sys.modules) if k == "opensfm" or k.startswith("opensfm.")}
+    pkg = types.ModuleType("opensfm")
+    pkg.__path__ = []
+    mods = {"opensfm": pkg, "opensfm.pygeometry": types.ModuleType("opensfm.pygeometry"), "opensfm.pymap": types.ModuleType("opensfm.pymap"),
+            "opensfm.pysfm": compat.pysfm, "opensfm.reconstruction": _Stub("opensfm.reconstruction"), "opensfm.types": types.ModuleType("opensfm.types")}
+    mods["opensfm.pygeometry"].Camera = gt.Camera
+    mods["opensfm.pymap"].Observation = lambda x, y, scale, r, g, b, feature_id, *rest: gt.Observation(x, y, scale)
+    mods["opensfm.types"].Reconstruction = Rec
+    try:
+        for name, m in mods.items():
+            sys.modules[name] = m
+            if "." in name:
+                setattr(pkg, name.split(".")[1], m)
+        spec = importlib.util.spec_from_file_location("opensfm.test.test_reconstruction_shot_neighborhood",
+                                                      os.path.join(REF, "test", "test_reconstruction_shot_neighborhood.py"))
+        t = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(t)
+        t.test_shot_neighborhood_linear_graph_cpp()
+        t.test_shot_neighborhood_complete_graph_cpp()
+        t.test_shot_neighborhood_sorted_results_cpp()
+    finally:
+        for k in [k for k in sys.modules if k == "opensfm" or k.startswith("opensfm.")]:
+            del sys.modules[k]
+        sys.modules.update({k: v for k, v in saved.items() if v is not None})
