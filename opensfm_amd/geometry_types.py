@@ -374,6 +374,11 @@ class Reconstruction:
         self.biases: Dict[str, Similarity] = {}
         self.reference = TopocentricConverter()
 
+    @property
+    def map(self) -> "Reconstruction":
+        """``types.Reconstruction.map`` (the pymap.Map the reference hands to ``pysfm.BAHelpers``): the bag of dicts itself"""
+        return self
+
     def add_camera(self, camera: Camera) -> Camera:
         self.cameras[camera.id] = camera
         self.biases.setdefault(camera.id, Similarity())

@@ -269,3 +269,12 @@ def test_bundle_local_over_map_objects(cpu_solver):
 def test_bundle_shot_poses_over_map_objects(cpu_solver):
     """pysfm.BAHelpers.bundle_shot_poses as reconstruction.py:89-104 calls it"""
     cases.case_bundle_shot_poses()
+
+
+def test_the_references_reconstruction_module_drives_the_adapter(cpu_solver):
+    """opensfm/reconstruction.py of the reference, loaded as it is: its bundle / bundle_local / bundle_shot_poses (and its log_bundle_stats)
+    on top of ``opensfm_amd.compat.pysfm`` -- the same results as the adapter called directly"""
+    ref = cases.load_reference_reconstruction()
+    if ref is None:
+        pytest.skip("/root/reference is not mounted")
+    assert cases.case_reference_reconstruction_module(ref)
