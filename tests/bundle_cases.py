@@ -424,3 +424,117 @@ def case_reference_reconstruction_module(ref):
     opensfm_adapter.bundle_shot_poses(rb, {"s004", "s005"}, cams, rigs, cfg)
     assert set(rep_a) == {"brief_report", "wall_times"} and all(np.array_equal(x, y) for x, y in zip(state(ra), state(rb)))
     return True
+
+
+def load_reference_test_bundle(ref_root="/root/reference/opensfm"):
+    """``opensfm/test/test_bundle.py`` of the reference with ``pybundle`` / ``pysfm`` = ``opensfm_amd.compat``, its own ``config.py``,
+    ``geometry.py``, ``transformations.py`` and ``reconstruction.py``, and map objects from ``opensfm_amd.geometry_types`` dressed with the two
+    pymap behaviours its tests rely on (``OptionalValue`` measurements; ``shot.pose`` writing through to the shot).  None where the
+    reference is not mounted."""
+    import importlib.util
+    import os
+    import sys
+    import types
+
+    from opensfm_amd import compat
+    from opensfm_amd import geometry_types as gt
+
+    if not os.path.isdir(ref_root):
+        return None
+
+    class Stub(types.ModuleType):
+        def __getattr__(self, name):
+            if name.startswith("__"):
+                raise AttributeError(name)
+            cls = type(name, (), {})
+            setattr(self, name, cls)
+            return cls
+
+    class OptionalValue:  # foundation::OptionalValue as pybind exposes it
+        def __init__(self):
+            self._v, self.has_value = None, False
+
+        @property
+        def value(self):
+            return self._v
+
+        @value.setter
+        def value(self, v):
+            self._v, self.has_value = v, True
+
+        def reset(self):
+            self._v, self.has_value = None, False
+
+    class Measurements:
+        def __init__(self):
+            self.gps_position, self.gps_accuracy = OptionalValue(), OptionalValue()
+
+    class BoundPose(gt.Pose):
+        """``shot.pose`` of pymap: a pose whose setters act on the shot (here: on its rig instance -- the rig camera is the identity)"""
+
+        def __init__(self, instance):
+            super().__init__(instance.pose.rotation, instance.pose.translation)
+            self._instance = instance
+
+        def set_origin(self, origin):
+            super().set_origin(origin)
+            self._instance.pose = gt.Pose(self.rotation, self.translation)
+
+    class Shot(gt.Shot):
+        @property
+        def pose(self):
+            return BoundPose(self.rig_instance)
+
+    class Rec(gt.Reconstruction):
+        def create_shot(self, shot_id, camera_id, pose=None, rig_camera_id=None, rig_instance_id=None):
+            base = super().create_shot(shot_id, camera_id, pose, rig_camera_id, rig_instance_id)
+            shot = Shot(base.id, base.camera, base.rig_instance, base.rig_camera)
+            shot.metadata = Measurements()
+            base.rig_instance.shots[shot_id] = shot
+            self.shots[shot_id] = shot
+            return shot
+
+    saved = {k: sys.modules.get(k) for k in list(sys.modules) if k == "cv2" or k == "opensfm" or k.startswith("opensfm.")}
+    pkg = types.ModuleType("opensfm")
+    pkg.__path__ = []
+    pygeometry = types.ModuleType("opensfm.pygeometry")
+    pygeometry.Camera, pygeometry.Pose = gt.Camera, gt.Pose
+    mods = {"cv2": Stub("cv2"), "opensfm": pkg, "opensfm.pysfm": compat.pysfm, "opensfm.pybundle": compat.pybundle, "opensfm.pygeometry": pygeometry}
+    for name in ("log", "matching", "multiview", "pymap", "reconstruction_helpers", "rig", "tracking", "types", "align", "context", "dataset_base",
+                 "synthetic_data", "synthetic_data.synthetic_scene"):
+        mods["opensfm." + name] = Stub("opensfm." + name)
+    mods["opensfm.types"].Reconstruction = Rec
+    mods["opensfm.dataset_base"].DataSetBase = object
+    mods["opensfm.synthetic_data"].synthetic_scene = mods["opensfm.synthetic_data.synthetic_scene"]
+    try:
+        for name, m in mods.items():
+            sys.modules[name] = m
+            if name.startswith("opensfm.") and name.count(".") == 1:
+                setattr(pkg, name.split(".")[1], m)
+        loaded = {}
+        for name, path in (("config", "config.py"), ("transformations", "transformations.py"), ("geometry", "geometry.py"),
+                           ("reconstruction", "reconstruction.py"), ("test.test_bundle", "test/test_bundle.py")):
+            spec = importlib.util.spec_from_file_location("opensfm." + name, os.path.join(ref_root, path))
+            mod = importlib.util.module_from_spec(spec)
+            sys.modules["opensfm." + name] = mod
+            if "." not in name:
+                setattr(pkg, name, mod)
+            spec.loader.exec_module(mod)
+            loaded[name] = mod
+        return loaded["test.test_bundle"]
+    finally:
+        for k in [k for k in sys.modules if k == "cv2" or k == "opensfm" or k.startswith("opensfm.")]:
+            del sys.modules[k]
+        sys.modules.update({k: v for k, v in saved.items() if v is not None})
+
+
+def case_reference_test_bundle(t):
+    """the test functions of the reference's test_bundle.py that ``BAHelpers`` can reach (no relative motions, heat maps, linear motion, and
+    no synthetic-scene fixture -- compiled code), run as they are; ``bundle_adjuster`` is their own fixture's body (test_bundle.py:38-44)"""
+    np.random.seed(3)
+    t.test_unicode_strings_in_bundle()
+    t.test_sigleton(_adjuster())
+    t.test_singleton_pan_tilt_roll(_adjuster())
+    t.test_bundle_void_gps_ignored()
+    t.test_bundle_alignment_prior()
+    return True

@@ -278,3 +278,12 @@ def test_the_references_reconstruction_module_drives_the_adapter(cpu_solver):
     if ref is None:
         pytest.skip("/root/reference is not mounted")
     assert cases.case_reference_reconstruction_module(ref)
+
+
+def test_the_references_test_bundle_functions_pass(cpu_solver):
+    """opensfm/test/test_bundle.py of the reference, executed: unicode ids, the singleton, pan / tilt / roll, void GPS values, the
+    alignment prior -- its assertions and tolerances, its config.default_config(), its reconstruction.bundle"""
+    t = cases.load_reference_test_bundle()
+    if t is None:
+        pytest.skip("/root/reference is not mounted")
+    assert cases.case_reference_test_bundle(t)
