@@ -266,3 +266,59 @@ def test_reference_shot_neighborhood_tests_pass_on_the_adapter():
         for k in [k for k in sys.modules if k == "opensfm" or k.startswith("opensfm.")]:
             del sys.modules[k]
         sys.modules.update({k: v for k, v in saved.items() if v is not None})
+
+
+def test_reference_vlad_tests_pass_on_the_host_layer(oracle_lib, monkeypatch):
+    """opensfm/test/test_vlad.py on the reference's own vlad.py with ``pyfeatures`` = ``opensfm_amd.compat.pyfeatures``: the host layer of the
+    product (opensfm_amd/words.py: guards, the sorted walk of the other images, array preparation) with the two device entry points
+    served by the oracle (no GPU in this suite; tests/test_gpu_words.py checks the kernels against the same oracle)"""
+    import ctypes as C
+
+    from opensfm_amd import compat, words
+
+    class Shim:
+        @staticmethod
+        def osfm_vlad_descriptor(ctx, feats, n, centers, k, dim, out):
+            f = np.ctypeslib.as_array(feats, (n, dim))
+            c = np.ctypeslib.as_array(centers, (k, dim))
+            np.ctypeslib.as_array(out, (k * dim,))[:] = oracle_lib.vlad_descriptor(f, c)
+            return 0
+
+        @staticmethod
+        def osfm_vlad_distances(ctx, ref, mat, n, dim, out):
+            r = np.ctypeslib.as_array(ref, (dim,))
+            m = np.ctypeslib.as_array(mat, (n, dim))
+            np.ctypeslib.as_array(out, (n,))[:] = oracle_lib.vlad_distances(r, m)
+            return 0
+
+    monkeypatch.setattr(words._lib, "load", lambda: Shim)
+    monkeypatch.setattr(words, "default_context", lambda: types.SimpleNamespace(handle=C.c_void_p()))
+    saved = {k: sys.modules.get(k) for k in list(sys.modules) if k == "opensfm" or k.startswith("opensfm.")}
+    pkg = types.ModuleType("opensfm")
+    pkg.__path__ = []
+    mods = {"opensfm": pkg, "opensfm.pyfeatures": compat.pyfeatures}
+    for name in ("bow", "feature_loader", "dataset_base"):
+        mods["opensfm." + name] = _Stub("opensfm." + name)
+    mods["opensfm.dataset_base"].DataSetBase = object
+    try:
+        for name, m in mods.items():
+            sys.modules[name] = m
+            if "." in name:
+                setattr(pkg, name.split(".")[1], m)
+        loaded = {}
+        for name, path in (("vlad", "vlad.py"), ("test.test_vlad", "test/test_vlad.py")):
+            spec = importlib.util.spec_from_file_location("opensfm." + name, os.path.join(REF, path))
+            mod = importlib.util.module_from_spec(spec)
+            sys.modules["opensfm." + name] = mod
+            if "." not in name:
+                setattr(pkg, name, mod)
+            spec.loader.exec_module(mod)
+            loaded[name] = mod
+        t = loaded["test.test_vlad"]
+        t.test_vlad_distances_order()
+        t.test_signed_square_root_normalize()
+        t.test_unnormalized_vlad()
+    finally:
+        for k in [k for k in sys.modules if k == "opensfm" or k.startswith("opensfm.")]:
+            del sys.modules[k]
+        sys.modules.update({k: v for k, v in saved.items() if v is not None})
