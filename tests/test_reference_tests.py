@@ -322,3 +322,42 @@ def test_reference_vlad_tests_pass_on_the_host_layer(oracle_lib, monkeypatch):
         for k in [k for k in sys.modules if k == "opensfm" or k.startswith("opensfm.")]:
             del sys.modules[k]
         sys.modules.update({k: v for k, v in saved.items() if v is not None})
+
+
+def test_reference_pairs_selection_unit_tests_pass_on_the_preselection_module():
+    """opensfm/test/test_pairs_selection.py: its four tests that need no data set (the representative point of an image from GPS / GPS +
+    omega-phi-kappa, the altitude where the viewing rays of a group of images meet) with ``opensfm.pairs_selection`` =
+    ``opensfm_amd.preselection`` and the reference's own geo.TopocentricConverter (the five data-set tests need images and the commands)"""
+    from opensfm_amd import preselection
+
+    saved = {k: sys.modules.get(k) for k in list(sys.modules) if k == "opensfm" or k.startswith("opensfm.")}
+    pkg = types.ModuleType("opensfm")
+    pkg.__path__ = []
+    mods = {"opensfm": pkg, "opensfm.pairs_selection": preselection}
+    for name in ("commands", "dataset", "feature_loader", "dataset_base", "test", "test.data_generation"):
+        mods["opensfm." + name] = _Stub("opensfm." + name)
+    mods["opensfm.dataset_base"].DataSetBase = object
+    mods["opensfm.test"].data_generation = mods["opensfm.test.data_generation"]
+    try:
+        for name, m in mods.items():
+            sys.modules[name] = m
+            if name.count(".") == 1:
+                setattr(pkg, name.split(".")[1], m)
+        loaded = {}
+        for name, path in (("geo", "geo.py"), ("test.test_pairs_selection", "test/test_pairs_selection.py")):
+            spec = importlib.util.spec_from_file_location("opensfm." + name, os.path.join(REF, path))
+            mod = importlib.util.module_from_spec(spec)
+            sys.modules["opensfm." + name] = mod
+            if "." not in name:
+                setattr(pkg, name, mod)
+            spec.loader.exec_module(mod)
+            loaded[name] = mod
+        t = loaded["test.test_pairs_selection"]
+        t.test_get_gps_point()
+        t.test_get_gps_opk_point()
+        t.test_find_best_altitude_convergent()
+        t.test_find_best_altitude_divergent()
+    finally:
+        for k in [k for k in sys.modules if k == "opensfm" or k.startswith("opensfm.")]:
+            del sys.modules[k]
+        sys.modules.update({k: v for k, v in saved.items() if v is not None})
