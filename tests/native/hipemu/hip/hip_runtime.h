@@ -85,6 +85,14 @@ static inline hipError_t hipMemGetInfo(size_t *free_b, size_t *total_b) {
 constexpr unsigned hipHostMallocDefault = 0;
 static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { return hipMalloc(p, n); }
 static inline hipError_t hipHostFree(void *p) { return hipFree(p); }
+static inline void __threadfence_system() {}
+#ifndef __HIP_MEMORY_SCOPE_SYSTEM
+#define __HIP_MEMORY_SCOPE_SYSTEM 5
+#endif
+static inline hipError_t hipHostGetDevicePointer(void **d, void *h, unsigned) {
+  *d = h;
+  return hipSuccess;
+}
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) {
   if (n) memmove(d, s, n);
   return hipSuccess;
