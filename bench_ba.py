@@ -137,7 +137,7 @@ def run_general(ctx, shots: int = 5000, points: int = 500000, track: int = 10, i
     nobs = len(pr["obs_shot"])
     no_tol = dict(function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
     bundle.bundle_general_arrays(pr, {"bundle_max_iterations": 1}, ctx=ctx, **no_tol)
-    g = bundle.bundle_general_arrays(pr, {"bundle_max_iterations": iters}, ctx=ctx, **no_tol)
+    g = bundle.bundle_general_arrays(pr, {"bundle_max_iterations": iters}, ctx=ctx, verbose=bundle.BA_TIME_MATVEC, **no_tol)
     inl = ~pr["is_outlier"]
     out = {"workload": f"{shots} cams / {points} pts / {nobs} obs, shared BROWN camera (9 free intrinsics + priors), GPS priors through a free "
                        "similarity bias, 20 control points, SoftLOne(1)",
@@ -234,7 +234,7 @@ def run(ctx, shots: int = 5000, points: int = 500000, track: int = 10, iters: in
     no_tol = dict(function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
     bundle.bundle_arrays(pr, {"bundle_max_iterations": 1}, ctx=ctx, **no_tol)  # warm-up
     t0 = time.perf_counter()
-    g = bundle.bundle_arrays(pr, {"bundle_max_iterations": iters}, ctx=ctx, **no_tol)
+    g = bundle.bundle_arrays(pr, {"bundle_max_iterations": iters}, ctx=ctx, verbose=bundle.BA_TIME_MATVEC, **no_tol)
     wall = time.perf_counter() - t0
     inl = ~pr["is_outlier"]
     rmse_px = float(np.sqrt((g["reproj_err"][inl] ** 2).sum(1).mean()) * 2000.0)

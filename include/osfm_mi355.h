@@ -241,12 +241,14 @@ typedef struct {
   double gradient_tolerance;  /* ceres default 1e-10                                          */
   double parameter_tolerance; /* ceres default 1e-8                                           */
   double initial_radius;      /* ceres initial_trust_region_radius 1e4                        */
-  int32_t verbose;
+  int32_t verbose;            /* bit 0: one progress line per LM iteration on stderr; OSFM_BA_TIME_MATVEC: ten extra Schur
+                                 mat-vecs are timed with HIP events after the solve (report: ms_matvec_total, matvec_calls) */
   double pcg_tolerance;       /* relative residual of the Schur-PCG solve (default 1e-10)     */
   int32_t pcg_max_iterations; /* default 1000                                                 */
   int32_t preconditioner;     /* 0 auto: banded block Cholesky when the shot coupling is banded
                                  (half-width <= 15 shots), else block Jacobi; 1: block Jacobi  */
 } osfm_ba_options;
+#define OSFM_BA_TIME_MATVEC 2
 
 void osfm_ba_options_default(osfm_ba_options *o);
 

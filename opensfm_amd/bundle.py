@@ -55,6 +55,9 @@ def _dp(a, t):
     return a.ctypes.data_as(C.POINTER(t))
 
 
+BA_TIME_MATVEC = 2  # options.verbose bit: time ten Schur mat-vecs after the solve (report['ms_per_matvec']; the bench's roofline block)
+
+
 def make_options(config: Optional[Dict[str, Any]] = None, **overrides) -> BaOptions:
     o = BaOptions()
     _lib.load().osfm_ba_options_default(C.byref(o))

@@ -5571,7 +5571,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     const double cost_change = cost - cost_n;
     if (std::fabs(cost_change) <= O->function_tolerance * cost) { Rp->termination = 1; break; }
     const double rho = cost_change / model_change;
-    if (O->verbose)
+    if (O->verbose & 1)
       fprintf(stderr, "[osfm_ba] it %d cost %.9e -> %.9e rho %.3f radius %.3e pcg %d\n", iter, cost, cost_n, rho, radius, k);
     if (rho > 1e-3) {  // StepAccepted
       std::swap(d.cams, d.cams_n);
@@ -5609,12 +5609,16 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
   OSFM_HIP(hipStreamSynchronize(st));
   const auto t_tear = std::chrono::steady_clock::now();
   Rp->seconds_run = std::chrono::duration<double>(t_tear - t_run).count();
-  // mat-vec timing sample (HIP events on the solver stream), for the roofline of the dominant kernel
-  {
+  Rp->preconditioner_bandwidth = (sv.use_band || sv.use_ctri || sv.use_bcr || sv.use_wide) ? d.bw : 0;
+  Rp->shot_bandwidth = bw_true;
+  Rp->ms_matvec_total = 0.0;
+  Rp->matvec_calls = 0;
+  // mat-vec timing sample (HIP events on the solver stream), for the roofline of the dominant kernel: ten extra mat-vecs, only when the
+  // caller asks (OSFM_BA_TIME_MATVEC in options->verbose: the bench does) -- they were 3.9 ms of every configs[4] call's tear-down and as
+  // much as a whole LM iteration of a local bundle adjustment
+  if (O->verbose & OSFM_BA_TIME_MATVEC) {
     const int reps = 10;
     hipLaunchKernelGGL(point_hhat_kernel, dim3(nblk(NP)), dim3(TPB), 0, st, d, radius);
-    Rp->preconditioner_bandwidth = (sv.use_band || sv.use_ctri || sv.use_bcr || sv.use_wide) ? d.bw : 0;
-    Rp->shot_bandwidth = bw_true;
     OSFM_HIP(hipEventRecord(ctx->ev[6], st));
     for (int i = 0; i < reps; i++) sv.matvec(d.p, d.Ap, radius);
     OSFM_HIP(hipEventRecord(ctx->ev[7], st));

@@ -18,5 +18,5 @@ else:
     solve = bundle.bundle_arrays
 if os.environ.get("PROF_WARM"):
     solve(pr, {"bundle_max_iterations": 1}, **no_tol)  # library initialisation, allocator caches
-g = solve(pr, {"bundle_max_iterations": iters}, **no_tol)
+g = solve(pr, {"bundle_max_iterations": iters}, verbose=bundle.BA_TIME_MATVEC, **no_tol)
 print(g["brief_report"]); print("setup", g["seconds_setup"], "run", g["seconds_run"], "teardown", g["seconds_teardown"]); print("solver s", g["seconds_solver"], "lin", g["seconds_linear_solver"], "ms/matvec", g["ms_per_matvec"], "bw", g["preconditioner_bandwidth"])
