@@ -3843,6 +3843,7 @@ struct Solver {
     // (measured on the local problem: 4.89 -> 4.63 - 4.80 ms of run for ten iterations, 4.24 -> 4.20 ms per LM iteration at configs[4]; OSFM_BA_NO_SPIN
     //  keeps the copy + stream synchronisation)
     spin = getenv("OSFM_BA_NO_SPIN") == nullptr;
+    if (const char *su = getenv("OSFM_BA_SPIN_US")) spin_us = atof(su);
     if (spin) OSFM_HIP(hipHostGetDevicePointer(&dev_pinned, ctx->h_pinned, 0));
     return OSFM_OK;
   }
@@ -3862,15 +3863,20 @@ struct Solver {
     double *dh = (double *)dev_pinned;
     const int want = ++seq;
     hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, st, a, na, dh + ha_off, b, nb, (int *)(dh + 32) + hb_off, c, nc, dh + 34, (int *)(dh + 34 + nbr_), want);
+    OSFM_HIP(hipGetLastError());  // (of this launch or of any launch since the last round trip)
+    // The host spins on the sequence number for a bounded time (spin_us, default 2 ms: a round trip of the LM loop is 20 us - 1 ms of queued
+    // kernels), then hands the wait to the runtime (hipStreamSynchronize blocks without burning the core): long queues -- the first
+    // evaluation of a cold context, a wide-band factorisation -- and OpenSfM's multi-process stages do not hold N cores at 100 %.
     const auto t0 = std::chrono::steady_clock::now();
     for (long it = 0; __atomic_load_n(hseq, __ATOMIC_ACQUIRE) != want; it++) {
-      if ((it & 0xFFFF) == 0xFFFF && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0) {
+      if ((it & 0x3FF) == 0x3FF && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e6 > spin_us) {
         OSFM_HIP(hipStreamSynchronize(st));  // a failed launch or a fault shows up here
         OSFM_REQUIRE(__atomic_load_n(hseq, __ATOMIC_ACQUIRE) == want, OSFM_E_HIP, "the device never published round trip %d", want);
       }
     }
     return OSFM_OK;
   }
+  double spin_us = 2000.0;
 
   void rot(const double *poses) { hipLaunchKernelGGL(shot_rot_kernel, dim3(nblk(d.S, 64)), dim3(64), 0, st, d, poses); }
 
@@ -3896,7 +3902,9 @@ struct Solver {
     else OSFM_GEN_KW(2, KERNEL, grid, block, stream, __VA_ARGS__);                               \
   } while (0)
   int gen_nprior() const { return d.NC + d.g.NRC + d.S + 4 * d.g.NV; }
-  size_t gen_prior_lds() const { return (size_t)(d.g.NB * d.g.NB + d.g.NB + 2) * sizeof(double); }
+  // dynamic LDS of gen_prior_kernel: the workgroup's copy of Cpri and of the border gradient in mode 1, while the border is narrow enough for it
+  // (beyond kGenPriorLdsMaxNB the kernel adds to the global arrays directly); modes 0 and 2 use none
+  size_t gen_prior_lds(int mode) const { return (mode == 1 && d.g.NB <= kGenPriorLdsMaxNB) ? (size_t)(d.g.NB * d.g.NB + d.g.NB + 2) * sizeof(double) : 0; }
   // cost (with priors) at the given parameters into scal[8] (sum of squares of the reprojections into scal[9]); jac: the Jacobian rows
   // and the prior blocks as well
   void gen_eval_enqueue(const double *cam, const double *bias, const double *rcp, const double *poses, const double *pts, bool jac) {
@@ -3925,7 +3933,7 @@ struct Solver {
       else OSFM_GEN_EVAL(2, -1);
     }
     hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(1024), 0, st, d.partial, (long)(d.M > 0 ? nb : 0), 2, d.scal + 8);
-    hipLaunchKernelGGL(gen_prior_kernel, dim3(nblk(gen_nprior(), 256)), dim3(256), gen_prior_lds(), st, d, cam, bias, rcp, poses, jac ? 1 : 0,
+    hipLaunchKernelGGL(gen_prior_kernel, dim3(nblk(gen_nprior(), 256)), dim3(256), gen_prior_lds(jac ? 1 : 0), st, d, cam, bias, rcp, poses, jac ? 1 : 0,
                        (const double *)nullptr, d.scal + 8);
     if (d.g.pt_prior_sigma && d.P > 0) hipLaunchKernelGGL(gen_point_prior_kernel, dim3(nblk(d.P)), dim3(TPB), 0, st, d, pts, 0, d.scal + 8);
   }
@@ -4006,6 +4014,7 @@ struct Solver {
   }
   int eval(const double *cams, const double *poses, const double *pts, bool jac, double *cost, double *sumsq) {
     eval_enqueue(cams, poses, pts, jac);
+    OSFM_HIP(hipGetLastError());  // a launch the runtime refused (LDS, grid) must not come back as a cost of stale numbers
     {
       const int rcf = fetch(d.scal + 8, 2, 0);
       if (rcf != OSFM_OK) return rcf;
@@ -5018,6 +5027,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     size_t free_b = 0, total_b = 0;
     if (const char *bud = getenv("OSFM_BA_DENSE_CR_BUDGET")) free_b = (size_t)atoll(bud);
     else if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = ~(size_t)0;
+    else free_b += ctx->pool_bytes;  // the context's cached blocks are not "free" to the runtime, but an allocation that fails takes them back
     if (need > free_b - free_b / 8) dense_cr = false;
   }
   if (dense_cr) {
@@ -5542,7 +5552,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(1024), 0, st, d.partial, (long)d.nwg, 1, d.scal + 16);  // the model change's observation part
     if (gen) {
       hipLaunchKernelGGL(gen_candidate_kernel, dim3(1), dim3(1024), 0, st, d, (const double *)d.y, d.scal + 16);
-      hipLaunchKernelGGL(gen_prior_kernel, dim3(nblk(sv.gen_nprior(), 256)), dim3(256), sv.gen_prior_lds(), st, d, (const double *)g.cam, (const double *)g.bias,
+      hipLaunchKernelGGL(gen_prior_kernel, dim3(nblk(sv.gen_nprior(), 256)), dim3(256), sv.gen_prior_lds(2), st, d, (const double *)g.cam, (const double *)g.bias,
                          (const double *)g.rc, (const double *)d.poses, 2, (const double *)d.y, d.scal + 16);
       if (g.pt_prior_sigma && NP > 0) hipLaunchKernelGGL(gen_point_prior_kernel, dim3(nblk(NP)), dim3(TPB), 0, st, d, (const double *)d.pts, 2, d.scal + 16);
     } else

@@ -61,6 +61,13 @@ struct osfm_ctx {
   std::mutex pool_mu;  // the block cache itself: osfm_hahog_extract_batch's worker threads take and return blocks while the caller holds `mu`
   std::vector<hipStream_t> aux_streams;  // hahog.hip: one stream per concurrent image of a batch, made on first use
   static constexpr size_t kPoolBytes = (size_t)24 << 30;  // (of 288 GB: a bundle adjustment at 5 M observations keeps ~16 GB of slabs between calls)
+  // what THIS context may keep cached between calls: kPoolBytes unless OSFM_POOL_BYTES says otherwise (several processes or contexts on one
+  // GPU -- OpenSfM's multi-process stages -- each hold their own cache, and an out-of-memory in one cannot reclaim another's: give each a share; osfm_ctx_trim_pool empties it)
+  size_t pool_limit = pool_limit_from_env();
+  static size_t pool_limit_from_env() {
+    const char *e = getenv("OSFM_POOL_BYTES");
+    return e ? (size_t)strtoull(e, nullptr, 10) : kPoolBytes;
+  }
   hipStream_t stream_b = nullptr;  // second stream of the batched matching calls (gather + D2H of chunk k under the matcher of k + 1)
   size_t match_hint = 0;        // int32 entries of the last batched call's match list: the next call reserves that much up front
   // relpose.hip: ShouldStop's iteration bound for every (pair size n, best inlier count c <= n), tabulated with the host's libm (pow, log);
@@ -170,7 +177,7 @@ struct OsfmPoolBuf {
     bool cached = false;
     if (pool) {
       std::lock_guard<std::mutex> g(pool->pool_mu);
-      if (pool->pool_bytes + bytes <= osfm_ctx::kPoolBytes && pool->pool.size() < 64) {
+      if (pool->pool_bytes + bytes <= pool->pool_limit && pool->pool.size() < 64) {
         pool->pool.push_back({p, bytes});
         pool->pool_bytes += bytes;
         cached = true;

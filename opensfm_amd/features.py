@@ -49,9 +49,12 @@ def hahog_batch(images: Sequence[Any], peak_threshold: float, edge_threshold: fl
         ims, rc = None, [(int(r), int(c)) for r, c in shapes]
         ptrs = (C.c_void_p * n)(*[int(a) for a in images])
     else:
-        u8 = all(np.asarray(im).dtype == np.uint8 for im in images)  # grey levels 0 .. 255: converted on the device (HAHOG_IMAGE_U8)
+        kinds = [np.asarray(im).dtype == np.uint8 for im in images]
+        u8 = all(kinds)  # grey levels 0 .. 255: converted on the device (HAHOG_IMAGE_U8)
         if u8:
             flags |= HAHOG_IMAGE_U8
+        elif any(kinds):  # one flag for the whole call: a list that mixes grey levels 0 .. 255 with floats in [0, 1] has no single meaning
+            raise ValueError("hahog_batch takes either uint8 grey levels for every image or float32 values in [0, 1] for every image, not a mix")
         ims = [np.ascontiguousarray(im, np.uint8 if u8 else np.float32) for im in images]
         if any(im.ndim != 2 or im.size == 0 for im in ims):
             raise ValueError("hahog_batch takes non-empty grey-level images (rows x cols)")

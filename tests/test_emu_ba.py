@@ -66,6 +66,13 @@ def test_generic_streaming_solver_rig_bias_control_points_up_vectors(oracle_lib)
     assert np.abs(g["rig_camera_pose"][1] - pr["rig_camera_pose"][1]).max() > 0 and np.abs(g["bias"] - pr["bias"]).max() > 0
 
 
+def test_generic_priors_with_a_border_beyond_the_lds_copy(oracle_lib):
+    """twelve free BROWN cameras = 108 border unknowns: the prior kernel's workgroup copy of the border block is only used up to
+    kGenPriorLdsMaxNB unknowns; beyond, the priors go to the global arrays directly -- the trajectory with the camera priors is the oracle's"""
+    pr = synthetic.make_bundle_scene(models=("brown",) * 12, n_instances=24, n_points=160, rig=False, gps=False, n_gcp=0, up_vectors=False, seed=5)
+    _compare_general(oracle_lib, pr, iters=3, rtol=1e-8)
+
+
 def test_generic_mode_equals_the_specialised_kernels(oracle_lib):
     """on the domain both cover ([k1 k2 focal] perspective cameras, identity rig) the generic rows and the specialised ones walk the same
     trajectory"""

@@ -112,7 +112,7 @@ def test_constant_blocks(oracle_lib, gpu_ctx):
 
 def test_general_solver_equals_the_streaming_solver(oracle_lib, gpu_ctx):
     """on the domain both cover (perspective [k1 k2 focal], identity rig, GPS priors) osfm_bundle_solve and osfm_ba_solve walk the same
-    LM trajectory: dense Cholesky of the reduced system vs implicit Schur-PCG at 1e-10"""
+    LM trajectory: the generic rows of the streaming solver (ba_generic.inc) vs its specialised [k1 k2 focal] kernels, both implicit Schur-PCG at 1e-10"""
     import test_oracle_bundle_general as og
 
     from opensfm_amd import bundle
@@ -188,3 +188,13 @@ def test_border_wider_than_the_exact_elimination_falls_back_to_pcg(oracle_lib, g
     pr = synthetic.make_bundle_scene(models=("brown",) * 9, n_instances=27, n_points=400, rig=False, gps=False, n_gcp=0, up_vectors=False, seed=3)
     g, _ = _compare(oracle_lib, gpu_ctx, pr, iters=6)
     assert g["pcg_iterations"] > 6 * 4
+
+
+def test_priors_of_a_border_wider_than_the_prior_kernels_lds_copy(oracle_lib, gpu_ctx):
+    """twelve free BROWN cameras = 108 border unknowns: gen_prior_kernel's per-workgroup copy of the border x border prior block (NB^2 + NB
+    doubles) would not fit the 64 KB a launch gets by default -- round 5 launched it anyway, the launch failed unnoticed and the camera
+    priors dropped out of the normal equations.  Beyond kGenPriorLdsMaxNB the kernel adds to the global arrays directly; the trajectory
+    (camera priors included: they are what holds nine intrinsics per camera on 3 shots each) is the oracle's"""
+    pr = synthetic.make_bundle_scene(models=("brown",) * 12, n_instances=36, n_points=500, rig=False, gps=False, n_gcp=0, up_vectors=False, seed=5)
+    g, o = _compare(oracle_lib, gpu_ctx, pr, iters=5)
+    assert np.abs(g["cam_params"][:, :9] - pr["cam_params"][:, :9]).max() > 0
