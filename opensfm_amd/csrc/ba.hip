@@ -229,10 +229,12 @@ struct Dev {
   const long *shot_off;  // S + 1
   const int *shot_obs;   // M: indices into the point-major arrays, grouped by shot
   double *shotR;         // S x 36
-  // per-observation residual + Jacobian blocks, components: res(2) Jp(6) Jc(12) Jk(6), kept twice:
+  // per-observation residual + Jacobian blocks, components: res(2) Jp(6) Jc(12) Jk(6), kept once, in point-major order:
   double *Epm;           // [M][18] AoS, point-major: E_o = Jc_o^T Jp_o (6x3), operand of the band assembly
   double *Jpm;           // [26][M] SoA in POINT-major observation order (thread-per-observation kernels coalesce)
-  double *Jsm;           // [26][M] SoA in SHOT-major order: a wavefront walks a shot's observations, coalesced
+  double *sm_wt;         // [M] in SHOT-major order: the robust weight sqrt(rho') of every observation at the linearisation point (written by the
+                         // per-shot gradient kernel, read by the other per-shot kernels, which recompute the Jacobian rows they need -- sm_row; rounds 1-5
+                         // kept a second, shot-major copy of all 26 components instead: a second evaluation launch, 208 bytes per observation written and re-read)
   const int *sm_shot, *sm_point;        // observation data in shot-major order (static)
   const double *sm_x, *sm_y, *sm_sigma;
   double *w;             // 2 x M
@@ -290,7 +292,6 @@ struct Dev {
 };
 
 #define JA(o, c) d.Jpm[(long)(c) * d.M + (o)]  /* point-major SoA */
-#define JS(k, c) d.Jsm[(long)(c) * d.M + (k)]  /* shot-major SoA  */
 
 __global__ void shot_rot_kernel(Dev d, const double *poses) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -298,78 +299,169 @@ __global__ void shot_rot_kernel(Dev d, const double *poses) {
   rot_and_derivs(poses + 6 * s, d.shotR + 36 * (long)s, d.shotR + 36 * (long)s + 9);
 }
 
-// residuals (+ Jacobian blocks), robust corrector, cost partials.
-// SM = false: point-major thread order, writes the AoS copy and the cost partials;
-// SM = true : shot-major thread order, writes the SoA copy only (the projection is recomputed --
-//             ~300 flops per observation are far cheaper than an uncoalesced 208-byte scatter).
-template <bool JAC, bool SM>
-__global__ void __launch_bounds__(TPB) eval_kernel(Dev d, const double *cams, const double *poses, const double *pts,
-                                                    int loss, double a) {
+// The frame of one shot as the per-shot kernels need it (wave-uniform: the compiler keeps it in scalar registers)
+struct ShotFrame {
+  int model;
+  const double *cam, *pose, *R;
+};
+__device__ __forceinline__ ShotFrame shot_frame(const Dev &d, int s) {
+  const int ci = d.shot_camera[s];
+  ShotFrame f;
+  f.model = d.cam_model ? d.cam_model[ci] : 0;
+  f.cam = f.model >= 2 ? d.cam_ext + 16 * ci : d.cams + 3 * ci;
+  f.pose = d.poses + 6 * (long)s;
+  f.R = d.shotR + 36 * (long)s;
+  return f;
+}
+// The row of shot-major position k (an observation of the shot of frame f) exactly as eval_kernel stores it in the point-major copy -- corrected
+// residual, Jp, Jc, Jk, all times the robust weight wt -- recomputed at the CURRENT parameters (the linearisation point: d.cams / d.poses /
+// d.pts, shotR).  Same device function, same operands, same operations as the stored copy: the same bits.  ~400 fp64 operations per
+// observation against 208 bytes read (and, once per linearisation, written): at configs[4] 2 GFLOP per pass, 0.05 ms of the vector units.
+__device__ __forceinline__ void sm_row(const Dev &d, const ShotFrame &f, long k, double wt, double (&r)[2], double (&Jp)[6], double (&Jc)[12], double (&Jk)[6]) {
+  const int p = d.sm_point[k];
+  project_obs<true>(f.model, d.pts + 3 * (long)p, f.pose, f.R, f.R + 9, f.cam, d.sm_x[k], d.sm_y[k], 1.0 / d.sm_sigma[k], r, Jp, Jc, Jk);
+  r[0] *= wt;
+  r[1] *= wt;
+#pragma unroll
+  for (int i = 0; i < 6; i++) Jp[i] *= wt;
+#pragma unroll
+  for (int i = 0; i < 12; i++) Jc[i] *= wt;
+#pragma unroll
+  for (int i = 0; i < 6; i++) Jk[i] *= wt;
+}
+
+// residuals, robust corrector, cost partials -- and with JAC the Jacobian rows (the point-major SoA copy; the E blocks when the per-shot band
+// assembly wants them) and the points' gradient and J^T J blocks.  One workgroup owns a run of whole tracks with at most kCoopObs
+// observations (the partition of the mat-vec, wg_pt): thread per observation evaluates and leaves the nine products of its point block
+// in LDS, thread per point adds its track's in observation order -- what point_grad_kernel did from a second read of the rows in rounds
+// 3-5 (0.10 ms at configs[4]).  Both variants sum the cost in this partition: a candidate's cost and the cost of the same point once it
+// is accepted are the same bits.  A single track longer than the tile is walked by the whole workgroup, its point block added by one
+// thread from the rows in memory (fixed order).
+template <bool JAC>
+__global__ void __launch_bounds__(kCoopObs) eval_kernel(Dev d, const double *cams, const double *poses, const double *pts, int loss, double a) {
+  __shared__ double c[JAC ? 9 : 1][kCoopObs];
   __shared__ double lds[8];
-  const long o = (long)blockIdx.x * TPB + threadIdx.x;
+  const int tid = threadIdx.x;
+  const int p0 = d.wg_pt[blockIdx.x], p1 = d.wg_pt[blockIdx.x + 1];
+  const long o0 = d.pt_off[p0], o1 = d.pt_off[p1];
   double acc[2] = {0.0, 0.0};
-  if (o < d.M) {
-    const int s = SM ? d.sm_shot[o] : d.o_shot[o], p = SM ? d.sm_point[o] : d.o_point[o];
+  auto one = [&](long o, double (&v)[9]) {
+    const int s = d.o_shot[o], p = d.o_point[o];
     const double *R = d.shotR + 36 * (long)s;
     double r[2], Jp[6], Jc[12], Jk[6];
-    const double sg = SM ? d.sm_sigma[o] : d.o_sigma[o];
+    const double sg = d.o_sigma[o];
     const int cmodel = d.cam_model ? d.cam_model[d.shot_camera[s]] : 0;
-    project_obs<JAC>(cmodel, pts + 3 * (long)p, poses + 6 * (long)s, R, R + 9,
-                     cmodel >= 2 ? d.cam_ext + 16 * d.shot_camera[s] : cams + 3 * d.shot_camera[s], SM ? d.sm_x[o] : d.o_x[o],
-                     SM ? d.sm_y[o] : d.o_y[o], 1.0 / sg, r, Jp, Jc, Jk);
+    project_obs<JAC>(cmodel, pts + 3 * (long)p, poses + 6 * (long)s, R, R + 9, cmodel >= 2 ? d.cam_ext + 16 * d.shot_camera[s] : cams + 3 * d.shot_camera[s], d.o_x[o],
+                     d.o_y[o], 1.0 / sg, r, Jp, Jc, Jk);
     const double sq = r[0] * r[0] + r[1] * r[1];
     double rho, rho1;
     loss_eval(loss, a, sq, rho, rho1);
-    acc[0] = 0.5 * rho;
-    acc[1] = sq * sg * sg;
+    acc[0] += 0.5 * rho;
+    acc[1] += sq * sg * sg;
     if (JAC) {
       const double wt = sqrt(rho1);
-      if (SM) {
-        JS(o, 0) = wt * r[0];
-        JS(o, 1) = wt * r[1];
+      const double r0 = wt * r[0], r1 = wt * r[1];
+      JA(o, 0) = r0;
+      JA(o, 1) = r1;
+      double jp[6];
 #pragma unroll
-        for (int i = 0; i < 6; i++) JS(o, 2 + i) = wt * Jp[i];
+      for (int i = 0; i < 6; i++) {
+        jp[i] = wt * Jp[i];
+        JA(o, 2 + i) = jp[i];
+      }
 #pragma unroll
-        for (int i = 0; i < 12; i++) JS(o, 8 + i) = wt * Jc[i];
+      for (int i = 0; i < 12; i++) JA(o, 8 + i) = wt * Jc[i];
 #pragma unroll
-        for (int i = 0; i < 6; i++) JS(o, 20 + i) = wt * Jk[i];
-      } else {
-        JA(o, 0) = wt * r[0];
-        JA(o, 1) = wt * r[1];
+      for (int i = 0; i < 6; i++) JA(o, 20 + i) = wt * Jk[i];
+      if (d.Epm) {  // E_o = Jc_o^T Jp_o (6 x 3) of the corrected blocks, 144 contiguous bytes per observation: the per-shot band assembly's operand
+        double2 *dst = reinterpret_cast<double2 *>(d.Epm + 18 * o);
 #pragma unroll
-        for (int i = 0; i < 6; i++) JA(o, 2 + i) = wt * Jp[i];
+        for (int i = 0; i < 6; i += 2) {
+          const double a0 = wt * Jc[i], b0 = wt * Jc[6 + i], a1 = wt * Jc[i + 1], b1 = wt * Jc[7 + i];
+          double e[6];
 #pragma unroll
-        for (int i = 0; i < 12; i++) JA(o, 8 + i) = wt * Jc[i];
+          for (int j = 0; j < 3; j++) {
+            e[j] = a0 * jp[j] + b0 * jp[3 + j];
+            e[3 + j] = a1 * jp[j] + b1 * jp[3 + j];
+          }
+          dst[3 * (i / 2)] = make_double2(e[0], e[1]);
+          dst[3 * (i / 2) + 1] = make_double2(e[2], e[3]);
+          dst[3 * (i / 2) + 2] = make_double2(e[4], e[5]);
+        }
+      }
+      // the point block's products (point_grad_kernel's expressions: the same sums, the same bits)
 #pragma unroll
-        for (int i = 0; i < 6; i++) JA(o, 20 + i) = wt * Jk[i];
-        if (d.Epm) {  // E_o = Jc_o^T Jp_o (6 x 3) of the corrected blocks, 144 contiguous bytes per observation: the band assembly's operand
-          double jp[6];
+      for (int j = 0; j < 3; j++) v[j] = jp[j] * r0 + jp[3 + j] * r1;
+      v[3] = jp[0] * jp[0] + jp[3] * jp[3];
+      v[4] = jp[0] * jp[1] + jp[3] * jp[4];
+      v[5] = jp[0] * jp[2] + jp[3] * jp[5];
+      v[6] = jp[1] * jp[1] + jp[4] * jp[4];
+      v[7] = jp[1] * jp[2] + jp[4] * jp[5];
+      v[8] = jp[2] * jp[2] + jp[5] * jp[5];
+    }
+  };
+  if (o1 - o0 <= kCoopObs) {
+    if (tid < o1 - o0) {
+      double v[9];
+      one(o0 + tid, v);
+      if (JAC) {
 #pragma unroll
-          for (int j = 0; j < 6; j++) jp[j] = wt * Jp[j];
-          double2 *dst = reinterpret_cast<double2 *>(d.Epm + 18 * o);
+        for (int q = 0; q < 9; q++) c[q][tid] = v[q];
+      }
+    }
+    if (JAC) {
+      __syncthreads();
+      const int p = p0 + tid;
+      if (p < p1) {
+        double s9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (!(d.point_fixed && d.point_fixed[p]))
+          for (int k = (int)(d.pt_off[p] - o0); k < (int)(d.pt_off[p + 1] - o0); k++)
 #pragma unroll
-          for (int i = 0; i < 6; i += 2) {
-            const double a0 = wt * Jc[i], b0 = wt * Jc[6 + i], a1 = wt * Jc[i + 1], b1 = wt * Jc[7 + i];
-            double e[6];
+            for (int q = 0; q < 9; q++) s9[q] += c[q][k];
+#pragma unroll
+        for (int j = 0; j < 3; j++) d.g_pt[3 * (long)p + j] = s9[j];
+#pragma unroll
+        for (int j = 0; j < 6; j++) d.Hpp[6 * (long)p + j] = s9[3 + j];
+      }
+    }
+  } else {  // one track longer than the tile
+    for (long o = o0 + tid; o < o1; o += kCoopObs) {
+      double v[9];
+      one(o, v);
+    }
+    if (JAC) {
+      __syncthreads();  // the track's rows are in memory
+      if (tid == 0) {
+        double s9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (!(d.point_fixed && d.point_fixed[p0]))
+          for (long o = o0; o < o1; o++) {
+            const double r0 = JA(o, 0), r1 = JA(o, 1);
+            double a3[3], b3[3];
 #pragma unroll
             for (int j = 0; j < 3; j++) {
-              e[j] = a0 * jp[j] + b0 * jp[3 + j];
-              e[3 + j] = a1 * jp[j] + b1 * jp[3 + j];
+              a3[j] = JA(o, 2 + j);
+              b3[j] = JA(o, 5 + j);
+              s9[j] += a3[j] * r0 + b3[j] * r1;
             }
-            dst[3 * (i / 2)] = make_double2(e[0], e[1]);
-            dst[3 * (i / 2) + 1] = make_double2(e[2], e[3]);
-            dst[3 * (i / 2) + 2] = make_double2(e[4], e[5]);
+            s9[3] += a3[0] * a3[0] + b3[0] * b3[0];
+            s9[4] += a3[0] * a3[1] + b3[0] * b3[1];
+            s9[5] += a3[0] * a3[2] + b3[0] * b3[2];
+            s9[6] += a3[1] * a3[1] + b3[1] * b3[1];
+            s9[7] += a3[1] * a3[2] + b3[1] * b3[2];
+            s9[8] += a3[2] * a3[2] + b3[2] * b3[2];
           }
-        }
+#pragma unroll
+        for (int j = 0; j < 3; j++) d.g_pt[3 * (long)p0 + j] = s9[j];
+#pragma unroll
+        for (int j = 0; j < 6; j++) d.Hpp[6 * (long)p0 + j] = s9[3 + j];
       }
     }
   }
-  if (!SM) {
-    block_sum<2>(acc, lds);
-    if (threadIdx.x == 0) {
-      d.partial[2 * blockIdx.x] = acc[0];
-      d.partial[2 * blockIdx.x + 1] = acc[1];
-    }
+  __syncthreads();
+  block_sum<2>(acc, lds);
+  if (tid == 0) {
+    d.partial[2 * blockIdx.x] = acc[0];
+    d.partial[2 * blockIdx.x + 1] = acc[1];
   }
 }
 
@@ -441,79 +533,30 @@ __global__ void prior_cost_kernel(Dev d, const double *cams, const double *poses
   if (threadIdx.x == 0) out[0] += v[0];
 }
 
-// per point: gradient and J^T J block (unscaled, corrected Jacobian).  Same partition as the Schur mat-vec: a workgroup owns a run of
-// whole tracks with at most kCoopObs observations; thread per observation reads its blocks (SoA: coalesced) and leaves the nine
-// products in LDS, thread per point adds its track's in observation order.  (A thread per point walking its track in global memory
-// read 64-byte pieces ten observations apart: 0.43 ms at configs[4] for 320 MB.)
-__global__ void __launch_bounds__(kCoopObs) point_grad_kernel(Dev d) {
-  __shared__ double c[9][kCoopObs];
-  const int tid = threadIdx.x;
-  const int p0 = d.wg_pt[blockIdx.x], p1 = d.wg_pt[blockIdx.x + 1];
-  const long o0 = d.pt_off[p0], o1 = d.pt_off[p1];
-  auto products = [&](long o, double (&v)[9]) {
-    const double r0 = JA(o, 0), r1 = JA(o, 1);
-    double a[3], b[3];
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-      a[j] = JA(o, 2 + j);
-      b[j] = JA(o, 5 + j);
-      v[j] = a[j] * r0 + b[j] * r1;
-    }
-    v[3] = a[0] * a[0] + b[0] * b[0];
-    v[4] = a[0] * a[1] + b[0] * b[1];
-    v[5] = a[0] * a[2] + b[0] * b[2];
-    v[6] = a[1] * a[1] + b[1] * b[1];
-    v[7] = a[1] * a[2] + b[1] * b[2];
-    v[8] = a[2] * a[2] + b[2] * b[2];
-  };
-  if (o1 - o0 <= kCoopObs) {
-    if (tid < o1 - o0) {
-      double v[9];
-      products(o0 + tid, v);
-#pragma unroll
-      for (int q = 0; q < 9; q++) c[q][tid] = v[q];
-    }
-    __syncthreads();
-    const int p = p0 + tid;
-    if (p >= p1) return;
-    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (!(d.point_fixed && d.point_fixed[p]))
-      for (int k = (int)(d.pt_off[p] - o0); k < (int)(d.pt_off[p + 1] - o0); k++)
-#pragma unroll
-        for (int q = 0; q < 9; q++) acc[q] += c[q][k];
-#pragma unroll
-    for (int j = 0; j < 3; j++) d.g_pt[3 * (long)p + j] = acc[j];
-#pragma unroll
-    for (int j = 0; j < 6; j++) d.Hpp[6 * (long)p + j] = acc[3 + j];
-  } else if (tid == 0) {  // one track longer than the tile
-    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (!(d.point_fixed && d.point_fixed[p0]))
-      for (long o = o0; o < o1; o++) {
-        double v[9];
-        products(o, v);
-#pragma unroll
-        for (int q = 0; q < 9; q++) acc[q] += v[q];
-      }
-#pragma unroll
-    for (int j = 0; j < 3; j++) d.g_pt[3 * (long)p0 + j] = acc[j];
-#pragma unroll
-    for (int j = 0; j < 6; j++) d.Hpp[6 * (long)p0 + j] = acc[3 + j];
-  }
-}
-
-// per shot (one wavefront): gradient, J^T J block, partials of the camera block
-__global__ void __launch_bounds__(64) shot_grad_kernel(Dev d, const double *poses) {
-  const int s = blockIdx.x, lane = threadIdx.x;
+// per shot (one wavefront): gradient, J^T J block, partials of the camera block.  The shot's rows are recomputed (sm_row's operations with
+// the robust weight formed here, as eval_kernel forms it) and the weight of every observation is left in sm_wt for the other per-shot kernels
+// of this linearisation: the launch stands in for rounds 1-5's second evaluation launch (which wrote the shot-major copy of the rows, 0.34 ms at
+// configs[4]) AND their gradient kernel (which read it back, 0.16 ms).
+__global__ void __launch_bounds__(64) shot_grad_kernel(Dev d, const double *poses, int loss, double la) {
+  const int s = (int)xcd_contiguous(blockIdx.x, gridDim.x), lane = threadIdx.x;
+  const ShotFrame f = shot_frame(d, s);
   double v[36];  // g(6) H(21) gk(3) Hk(6)
 #pragma unroll
   for (int i = 0; i < 36; i++) v[i] = 0;
   for (long k = d.shot_off[s] + lane; k < d.shot_off[s + 1]; k += 64) {
-    const double r0 = JS(k, 0), r1 = JS(k, 1);
+    double r[2], Jp[6], Jc[12], Jk[6];
+    const int p = d.sm_point[k];
+    project_obs<true>(f.model, d.pts + 3 * (long)p, f.pose, f.R, f.R + 9, f.cam, d.sm_x[k], d.sm_y[k], 1.0 / d.sm_sigma[k], r, Jp, Jc, Jk);
+    double rho, rho1;
+    loss_eval(loss, la, r[0] * r[0] + r[1] * r[1], rho, rho1);
+    const double wt = sqrt(rho1);
+    d.sm_wt[k] = wt;
+    const double r0 = wt * r[0], r1 = wt * r[1];
     double a[6], b[6];
 #pragma unroll
     for (int j = 0; j < 6; j++) {
-      a[j] = JS(k, 8 + j);
-      b[j] = JS(k, 14 + j);
+      a[j] = wt * Jc[j];
+      b[j] = wt * Jc[6 + j];
       v[j] += a[j] * r0 + b[j] * r1;
     }
     int q = 6;
@@ -524,8 +567,8 @@ __global__ void __launch_bounds__(64) shot_grad_kernel(Dev d, const double *pose
     double ka[3], kb[3];
 #pragma unroll
     for (int j = 0; j < 3; j++) {
-      ka[j] = JS(k, 20 + j);
-      kb[j] = JS(k, 23 + j);
+      ka[j] = wt * Jk[j];
+      kb[j] = wt * Jk[3 + j];
       v[27 + j] += ka[j] * r0 + kb[j] * r1;
     }
     v[30] += ka[0] * ka[0] + kb[0] * kb[0];
@@ -684,23 +727,23 @@ __global__ void __launch_bounds__(64) precond_shot_kernel(Dev d, double radius) 
   double v[27];  // 21 shot + 6 camera partial
 #pragma unroll
   for (int i = 0; i < 27; i++) v[i] = 0;
+  const ShotFrame f = shot_frame(d, s);
   for (long k = d.shot_off[s] + lane; k < d.shot_off[s + 1]; k += 64) {
     const int p = d.sm_point[k];
     const double *Hh = d.Hhat + 6 * (long)p;
     const double h[9] = {Hh[0], Hh[1], Hh[2], Hh[1], Hh[3], Hh[4], Hh[2], Hh[4], Hh[5]};
-    double jp[6];
-#pragma unroll
-    for (int j = 0; j < 6; j++) jp[j] = JS(k, 2 + j);
+    double rr[2], jp[6], jc[12], jk[6];
+    sm_row(d, f, k, d.sm_wt[k], rr, jp, jc, jk);
     double E[9][3];  // rows: 6 shot + 3 camera ; E = Jred^T Jp
 #pragma unroll
     for (int i = 0; i < 6; i++) {
-      const double a = JS(k, 8 + i), b = JS(k, 14 + i);
+      const double a = jc[i], b = jc[6 + i];
 #pragma unroll
       for (int j = 0; j < 3; j++) E[i][j] = a * jp[j] + b * jp[3 + j];
     }
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-      const double a = JS(k, 20 + i), b = JS(k, 23 + i);
+      const double a = jk[i], b = jk[3 + i];
 #pragma unroll
       for (int j = 0; j < 3; j++) E[6 + i][j] = a * jp[j] + b * jp[3 + j];
     }
@@ -818,22 +861,15 @@ __device__ __forceinline__ void WAVE_SYNC() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ void jred_jp(const Dev &d, long k, double E[6][3]) {  // shot-major position k
-  if (d.gen && d.g.NRr == 3) {  // rows of three residuals (a spherical camera is present): res 3 | Jp 9 | Jc 18
+// E_o = Jc_o^T Jp_o of the observation at shot-major position k: the evaluation kernel's E block (the per-shot assembly's operand array, in
+// point-major order), found through shot_obs.  (Rounds 1-5 formed it from the shot-major copy of the rows: the same expression, the same bits.)
+__device__ __forceinline__ void jred_jp(const Dev &d, long k, double E[6][3]) {
+  const double2 *src = reinterpret_cast<const double2 *>(d.Epm + 18 * (long)d.shot_obs[k]);
 #pragma unroll
-    for (int i = 0; i < 6; i++)
-#pragma unroll
-      for (int j = 0; j < 3; j++) E[i][j] = (JS(k, 12 + i) * JS(k, 3 + j) + JS(k, 18 + i) * JS(k, 6 + j)) + JS(k, 24 + i) * JS(k, 9 + j);
-    return;
-  }
-  double jp[6];
-#pragma unroll
-  for (int j = 0; j < 6; j++) jp[j] = JS(k, 2 + j);
-#pragma unroll
-  for (int i = 0; i < 6; i++) {
-    const double a = JS(k, 8 + i), b = JS(k, 14 + i);
-#pragma unroll
-    for (int j = 0; j < 3; j++) E[i][j] = a * jp[j] + b * jp[3 + j];
+  for (int q = 0; q < 9; q++) {
+    const double2 v = src[q];
+    E[(2 * q) / 3][(2 * q) % 3] = v.x;
+    E[(2 * q + 1) / 3][(2 * q + 1) % 3] = v.y;
   }
 }
 // Band assembly: one workgroup per shot s builds the blocks (s, s - dk), dk = 0 .. bw:
@@ -2914,14 +2950,17 @@ __global__ void __launch_bounds__(kCoopObs) schur_point_coop_kernel(Dev d, const
 // pass B, wavefront per shot: zc_s = sum Jc^T w ; camera partials
 __global__ void __launch_bounds__(64) schur_shot_kernel(Dev d) {
   const int s = (int)xcd_contiguous(blockIdx.x, gridDim.x), lane = threadIdx.x;
+  const ShotFrame f = shot_frame(d, s);
   double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (long k = d.shot_off[s] + lane; k < d.shot_off[s + 1]; k += 64) {
     const long o = d.shot_obs[k];  // w lives in point-major order: 2 gathered doubles per observation
     const double w0 = d.w[2 * o], w1 = d.w[2 * o + 1];
+    double rr[2], jp[6], jc[12], jk[6];  // (the rows recomputed: sm_row; the shot-major copy this kernel read until round 5 is gone)
+    sm_row(d, f, k, d.sm_wt[k], rr, jp, jc, jk);
 #pragma unroll
-    for (int j = 0; j < 6; j++) v[j] += JS(k, 8 + j) * w0 + JS(k, 14 + j) * w1;
+    for (int j = 0; j < 6; j++) v[j] += jc[j] * w0 + jc[6 + j] * w1;
 #pragma unroll
-    for (int j = 0; j < 3; j++) v[6 + j] += JS(k, 20 + j) * w0 + JS(k, 23 + j) * w1;
+    for (int j = 0; j < 3; j++) v[6 + j] += jk[j] * w0 + jk[3 + j] * w1;
   }
 #pragma unroll
   for (int i = 0; i < 9; i++)
@@ -3371,19 +3410,24 @@ __global__ void __launch_bounds__(64) border_shot_kernel(Dev d, const double *wB
   for (int c = 0; c < NB; c++)
 #pragma unroll
     for (int i = 0; i < 9; i++) v[c][i] = 0.0;
+  const ShotFrame f = shot_frame(d, s);
   for (long k = d.shot_off[s] + lane; k < d.shot_off[s + 1]; k += 64) {
     const long o = d.shot_obs[k];
     const double2 *src = reinterpret_cast<const double2 *>(wB + 2L * NB * o);
     double jc0[6], jc1[6], jk0[3], jk1[3];
+    {
+      double rr[2], jp[6], jc[12], jk[6];
+      sm_row(d, f, k, d.sm_wt[k], rr, jp, jc, jk);
 #pragma unroll
-    for (int j = 0; j < 6; j++) {
-      jc0[j] = JS(k, 8 + j);
-      jc1[j] = JS(k, 14 + j);
-    }
+      for (int j = 0; j < 6; j++) {
+        jc0[j] = jc[j];
+        jc1[j] = jc[6 + j];
+      }
 #pragma unroll
-    for (int j = 0; j < 3; j++) {
-      jk0[j] = JS(k, 20 + j);
-      jk1[j] = JS(k, 23 + j);
+      for (int j = 0; j < 3; j++) {
+        jk0[j] = jk[j];
+        jk1[j] = jk[3 + j];
+      }
     }
 #pragma unroll
     for (int c = 0; c < NB; c++) {
@@ -3879,6 +3923,13 @@ struct Solver {
   double spin_us = 2000.0;
 
   void rot(const double *poses) { hipLaunchKernelGGL(shot_rot_kernel, dim3(nblk(d.S, 64)), dim3(64), 0, st, d, poses); }
+  // The rotation blocks (shotR, and the rig cameras' in the generic mode) back at the CURRENT parameters after a candidate was evaluated and
+  // not taken: the per-shot kernels recompute their Jacobian rows from them (sm_row / gen_sm_row), so the next solve at the same
+  // linearisation point must find the blocks of that point, not the rejected candidate's.
+  void restore_rot() {
+    rot(d.poses);
+    if (d.gen) hipLaunchKernelGGL(gen_rc_rot_kernel, dim3(nblk(d.g.NRC, 64)), dim3(64), 0, st, d, (const double *)d.g.rc);
+  }
 
   // ---- generic mode (kernels: ba_generic.inc) ----
   int *g_cols = nullptr, *g_col_pos = nullptr;  // generic exact border: the border columns some view holds, and their positions (-1: none)
@@ -3889,17 +3940,22 @@ struct Solver {
   bool gen_border_ch5 = getenv("OSFM_BA_BORDER_CH3") == nullptr;
   int gen_uniform_model = -1;  // every camera has this projection type (the evaluation kernel is specialised for the common ones), -1: mixed
   bool have_bpri = false;  // a prior couples an instance with a free border block (position prior with a free bias, up vector / compass with a free rig camera)
-#define OSFM_GEN_KW(NRV, KERNEL, grid, block, stream, ...)                                                    \
+#define OSFM_GEN_KW(NRV, MV, KERNEL, grid, block, stream, ...)                                                \
   do {                                                                                                        \
-    if (d.g.KW <= 4) hipLaunchKernelGGL((KERNEL<NRV, 4>), grid, block, 0, stream, __VA_ARGS__);                \
-    else if (d.g.KW <= 9) hipLaunchKernelGGL((KERNEL<NRV, 9>), grid, block, 0, stream, __VA_ARGS__);           \
-    else if (d.g.KW <= 16) hipLaunchKernelGGL((KERNEL<NRV, 16>), grid, block, 0, stream, __VA_ARGS__);         \
-    else hipLaunchKernelGGL((KERNEL<NRV, kGenMaxKW>), grid, block, 0, stream, __VA_ARGS__);                    \
+    if (d.g.KW <= 4) hipLaunchKernelGGL((KERNEL<NRV, 4, MV>), grid, block, 0, stream, __VA_ARGS__);            \
+    else if (d.g.KW <= 9) hipLaunchKernelGGL((KERNEL<NRV, 9, MV>), grid, block, 0, stream, __VA_ARGS__);       \
+    else if (d.g.KW <= 16) hipLaunchKernelGGL((KERNEL<NRV, 16, MV>), grid, block, 0, stream, __VA_ARGS__);     \
+    else hipLaunchKernelGGL((KERNEL<NRV, kGenMaxKW, MV>), grid, block, 0, stream, __VA_ARGS__);                \
   } while (0)
-#define OSFM_GEN_NR_KW(KERNEL, grid, block, stream, ...)                                       \
-  do {                                                                                         \
-    if (d.g.NRr == 3) OSFM_GEN_KW(3, KERNEL, grid, block, stream, __VA_ARGS__);                  \
-    else OSFM_GEN_KW(2, KERNEL, grid, block, stream, __VA_ARGS__);                               \
+  // the per-instance kernels recompute their rows (gen_sm_row): specialised, like the evaluation kernel, for the projection type every camera of the
+  // problem has when that is one of the common three
+#define OSFM_GEN_NR_KW(KERNEL, grid, block, stream, ...)                                                                                \
+  do {                                                                                                                                  \
+    if (d.g.NRr == 3) OSFM_GEN_KW(3, -1, KERNEL, grid, block, stream, __VA_ARGS__);                                                       \
+    else if (gen_uniform_model == OSFM_CAMERA_BROWN) OSFM_GEN_KW(2, OSFM_CAMERA_BROWN, KERNEL, grid, block, stream, __VA_ARGS__);         \
+    else if (gen_uniform_model == OSFM_CAMERA_FISHEYE_OPENCV) OSFM_GEN_KW(2, OSFM_CAMERA_FISHEYE_OPENCV, KERNEL, grid, block, stream, __VA_ARGS__); \
+    else if (gen_uniform_model == OSFM_CAMERA_PERSPECTIVE) OSFM_GEN_KW(2, OSFM_CAMERA_PERSPECTIVE, KERNEL, grid, block, stream, __VA_ARGS__); \
+    else OSFM_GEN_KW(2, -1, KERNEL, grid, block, stream, __VA_ARGS__);                                                                    \
   } while (0)
   int gen_nprior() const { return d.NC + d.g.NRC + d.S + 4 * d.g.NV; }
   // dynamic LDS of gen_prior_kernel: the workgroup's copy of Cpri and of the border gradient in mode 1, while the border is narrow enough for it
@@ -3919,11 +3975,10 @@ struct Solver {
     }
 #define OSFM_GEN_EVAL(NRV, MODELV)                                                                                                           \
   do {                                                                                                                                       \
-    if (jac) {                                                                                                                               \
-      hipLaunchKernelGGL((gen_eval_kernel<NRV, true, false, MODELV>), dim3(nb), dim3(TPB), 0, st, d, cam, rcp, poses, pts, loss, loss_a);     \
-      hipLaunchKernelGGL((gen_eval_kernel<NRV, true, true, MODELV>), dim3(nb), dim3(TPB), 0, st, d, cam, rcp, poses, pts, loss, loss_a);      \
-    } else                                                                                                                                   \
-      hipLaunchKernelGGL((gen_eval_kernel<NRV, false, false, MODELV>), dim3(nb), dim3(TPB), 0, st, d, cam, rcp, poses, pts, loss, loss_a);    \
+    if (jac)                                                                                                                                 \
+      hipLaunchKernelGGL((gen_eval_kernel<NRV, true, MODELV>), dim3(nb), dim3(TPB), 0, st, d, cam, rcp, poses, pts, loss, loss_a);            \
+    else                                                                                                                                     \
+      hipLaunchKernelGGL((gen_eval_kernel<NRV, false, MODELV>), dim3(nb), dim3(TPB), 0, st, d, cam, rcp, poses, pts, loss, loss_a);           \
   } while (0)
     if (d.M > 0) {
       if (d.g.NRr == 3) OSFM_GEN_EVAL(3, -1);
@@ -3943,7 +3998,7 @@ struct Solver {
       else hipLaunchKernelGGL(gen_point_grad_kernel<2>, dim3(d.nwg), dim3(kCoopObs), 0, st, d);
     } else if (d.P > 0)
       hipLaunchKernelGGL(gen_point_grad_empty_kernel, dim3(nblk(d.P)), dim3(TPB), 0, st, d);
-    OSFM_GEN_NR_KW(gen_shot_grad_kernel, dim3(d.S), dim3(64), st, d);
+    OSFM_GEN_NR_KW(gen_shot_grad_kernel, dim3(d.S), dim3(64), st, d, loss, loss_a);
     if (d.g.NB > 0) {
       hipLaunchKernelGGL(gen_border_reduce_kernel, dim3(d.g.NB), dim3(256), 0, st, d, 2 * d.g.KW, 0, 1);
       hipLaunchKernelGGL(gen_border_reduce_kernel, dim3(d.g.NB), dim3(256), 0, st, d, 2 * d.g.KW, d.g.KW, 2);
@@ -3964,25 +4019,28 @@ struct Solver {
     if (d.g.NB > 0) hipLaunchKernelGGL(gen_border_reduce_kernel, dim3(d.g.NB), dim3(256), 0, sq, d, 2 * d.g.KW, 0, 0);
   }
   // every column of the border in one pass over the observations (kernels at the end of ba_generic.inc) into Bc / dCm, on stream sq
-  template <int NRV, int KWT, int CH>
+  template <int NRV, int KWT, int CH, int MV>
   void gen_border_chunks(hipStream_t sq) {
     for (int c0 = 0; c0 < g_ncols; c0 += CH)
-      hipLaunchKernelGGL((gen_border_shot_kernel<NRV, KWT, CH>), dim3(d.S), dim3(64), 0, sq, d, (const int *)g_cols, g_ncols, c0, (const double *)g_wB, Bc, g_vpartB);
+      hipLaunchKernelGGL((gen_border_shot_kernel<NRV, KWT, CH, MV>), dim3(d.S), dim3(64), 0, sq, d, (const int *)g_cols, g_ncols, c0, (const double *)g_wB, Bc, g_vpartB);
   }
-  template <int NRV>
+  template <int NRV, int MV>
   void gen_border_columns_nr(hipStream_t sq) {
     if (d.M > 0 && g_ncols > 0) {
       hipLaunchKernelGGL(gen_border_point_kernel<NRV>, dim3(d.nwg), dim3(kCoopObs), 0, sq, d, (const int *)g_cols, g_ncols, g_wB);
-      if (d.g.KW <= 4) gen_border_chunks<NRV, 4, 4>(sq);
-      else if (d.g.KW <= 9 && gen_border_ch5) gen_border_chunks<NRV, 9, 5>(sq);
-      else if (d.g.KW <= 9) gen_border_chunks<NRV, 9, 3>(sq);
-      else if (d.g.KW <= 16) gen_border_chunks<NRV, 16, 2>(sq);
-      else gen_border_chunks<NRV, kGenMaxKW, 2>(sq);
+      if (d.g.KW <= 4) gen_border_chunks<NRV, 4, 4, MV>(sq);
+      else if (d.g.KW <= 9 && gen_border_ch5) gen_border_chunks<NRV, 9, 5, MV>(sq);
+      else if (d.g.KW <= 9) gen_border_chunks<NRV, 9, 3, MV>(sq);
+      else if (d.g.KW <= 16) gen_border_chunks<NRV, 16, 2, MV>(sq);
+      else gen_border_chunks<NRV, kGenMaxKW, 2, MV>(sq);
     }
   }
   void gen_border_columns(double radius, hipStream_t sq) {
-    if (d.g.NRr == 3) gen_border_columns_nr<3>(sq);
-    else gen_border_columns_nr<2>(sq);
+    if (d.g.NRr == 3) gen_border_columns_nr<3, -1>(sq);
+    else if (gen_uniform_model == OSFM_CAMERA_BROWN) gen_border_columns_nr<2, OSFM_CAMERA_BROWN>(sq);
+    else if (gen_uniform_model == OSFM_CAMERA_FISHEYE_OPENCV) gen_border_columns_nr<2, OSFM_CAMERA_FISHEYE_OPENCV>(sq);
+    else if (gen_uniform_model == OSFM_CAMERA_PERSPECTIVE) gen_border_columns_nr<2, OSFM_CAMERA_PERSPECTIVE>(sq);
+    else gen_border_columns_nr<2, -1>(sq);
     const int NB = d.g.NB;
     hipLaunchKernelGGL(gen_border_finish_kernel, dim3(NB * NB + nblk((long)NB * 6 * d.S)), dim3(256), 0, sq, d, (const int *)g_col_pos, std::max(1, g_ncols),
                        (const double *)g_vpartB, Bc, dCm, radius, have_bpri ? 1 : 0);
@@ -4002,14 +4060,9 @@ struct Solver {
       return gen_eval_enqueue(cand ? d.g.cam_n : d.g.cam, cand ? d.g.bias_n : d.g.bias, cand ? d.g.rc_n : d.g.rc, poses, pts, jac);
     }
     rot(poses);
-    const int nb = nblk(d.M);
-    if (jac) {
-      hipLaunchKernelGGL((eval_kernel<true, false>), dim3(nb), dim3(TPB), 0, st, d, cams, poses, pts, loss, loss_a);
-      hipLaunchKernelGGL((eval_kernel<true, true>), dim3(nb), dim3(TPB), 0, st, d, cams, poses, pts, loss, loss_a);
-    } else {
-      hipLaunchKernelGGL((eval_kernel<false, false>), dim3(nb), dim3(TPB), 0, st, d, cams, poses, pts, loss, loss_a);
-    }
-    hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(1024), 0, st, d.partial, (long)nb, 2, d.scal + 8);
+    if (jac) hipLaunchKernelGGL(eval_kernel<true>, dim3(d.nwg), dim3(kCoopObs), 0, st, d, cams, poses, pts, loss, loss_a);  // rows, point blocks, cost
+    else hipLaunchKernelGGL(eval_kernel<false>, dim3(d.nwg), dim3(kCoopObs), 0, st, d, cams, poses, pts, loss, loss_a);
+    hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(1024), 0, st, d.partial, (long)d.nwg, 2, d.scal + 8);
     hipLaunchKernelGGL(prior_cost_kernel, dim3(1), dim3(1024), 0, st, d, cams, poses, d.scal + 8, jac ? 1 : 0);
   }
   int eval(const double *cams, const double *poses, const double *pts, bool jac, double *cost, double *sumsq) {
@@ -4025,8 +4078,7 @@ struct Solver {
   }
   void gradients() {
     if (d.gen) return gen_gradients();
-    hipLaunchKernelGGL(point_grad_kernel, dim3(d.nwg), dim3(kCoopObs), 0, st, d);
-    hipLaunchKernelGGL(shot_grad_kernel, dim3(d.S), dim3(64), 0, st, d, d.poses);
+    hipLaunchKernelGGL(shot_grad_kernel, dim3(d.S), dim3(64), 0, st, d, (const double *)d.poses, loss, loss_a);  // (the points' blocks: eval_kernel<true>)
     if (!cams_inert) hipLaunchKernelGGL(cam_reduce_kernel, dim3(d.NC), dim3(kCamRedT), 0, st, d, 9);
     hipLaunchKernelGGL(cam_grad_kernel, dim3(nblk(d.NC, 64)), dim3(64), 0, st, d, d.cams);
   }
@@ -4896,7 +4948,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
   }
   d.shotR = A.alloc<double>((size_t)36 * S, e);
   d.Jpm = A.alloc<double>((size_t)(gen ? g.ncomp : 26) * M, e);
-  d.Jsm = A.alloc<double>((size_t)(gen ? g.ncomp : 26) * M, e);
+  d.sm_wt = A.alloc<double>((size_t)std::max<long>(1, M), e);
   {
     int *ss = A.alloc<int>((size_t)M, e), *sp = A.alloc<int>((size_t)M, e);
     double *sx = A.alloc<double>((size_t)M, e), *sy = A.alloc<double>((size_t)M, e), *ssg = A.alloc<double>((size_t)M, e);
@@ -5137,7 +5189,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       if (bad) fprintf(stderr, "[osfm_ba] %s: %zu of %zu not finite\n", name, bad, n);
     };
     scan("Jpm", d.Jpm, (size_t)(gen ? g.ncomp : 26) * M);
-    scan("Jsm", d.Jsm, (size_t)(gen ? g.ncomp : 26) * M);
+    scan("sm_wt", d.sm_wt, (size_t)M);
     if (gen) {
       scan("PI", g.PI, (size_t)36 * S);
       scan("gpri", g.gpri, (size_t)nred);
@@ -5571,15 +5623,16 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     const double step_sq = hs[9] + hs[12], x_sq = hs[10] + hs[13];
     if (bad || !(model_change > 0)) {  // HandleInvalidStep + StepIsInvalid
       radius *= 0.5;
+      sv.restore_rot();
       if (++n_invalid >= 5) { Rp->termination = -1; break; }
       continue;
     }
     n_invalid = 0;
     const double cost_n = hs[0];
     const double step_norm = std::sqrt(step_sq), x_norm = std::sqrt(x_sq);
-    if (step_norm <= O->parameter_tolerance * (x_norm + O->parameter_tolerance)) { Rp->termination = 3; break; }
+    if (step_norm <= O->parameter_tolerance * (x_norm + O->parameter_tolerance)) { Rp->termination = 3; sv.restore_rot(); break; }
     const double cost_change = cost - cost_n;
-    if (std::fabs(cost_change) <= O->function_tolerance * cost) { Rp->termination = 1; break; }
+    if (std::fabs(cost_change) <= O->function_tolerance * cost) { Rp->termination = 1; sv.restore_rot(); break; }
     const double rho = cost_change / model_change;
     if (O->verbose & 1)
       fprintf(stderr, "[osfm_ba] it %d cost %.9e -> %.9e rho %.3f radius %.3e pcg %d\n", iter, cost, cost_n, rho, radius, k);
@@ -5610,6 +5663,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     } else {  // StepRejected
       radius = radius / decrease_factor;
       decrease_factor *= 2.0;
+      sv.restore_rot();
     }
     if (iter < 256) Rp->cost_history[iter] = cost;
   }
