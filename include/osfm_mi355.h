@@ -247,6 +247,13 @@ typedef struct {
   int32_t pcg_max_iterations; /* default 1000                                                 */
   int32_t preconditioner;     /* 0 auto: banded block Cholesky when the shot coupling is banded
                                  (half-width <= 15 shots), else block Jacobi; 1: block Jacobi  */
+  double pcg_direct_tolerance; /* relative residual at which the FIRST iterate is accepted when the preconditioner is the reduced matrix
+                                * itself (exact band by cyclic reduction + exact border, or constant cameras): that iterate is a direct solve
+                                * -- what Ceres' SPARSE_SCHUR stops at -- plus a line search, and lands at 1e-10 .. 1e-7 (conditioning x the
+                                * rounding of the explicit block inverses).  Default 1e-6: trajectories at 1e-6 and 1e-10 agree to 4e-16 in
+                                * the cost over 20 iterations at configs[4] (profiles/r06_pcg_tolerance.json).  <= pcg_tolerance: no such
+                                * rule.  Inexact preconditioners (block Jacobi, a truncated band, a border too wide for the exact elimination)
+                                * always iterate to pcg_tolerance. */
 } osfm_ba_options;
 #define OSFM_BA_TIME_MATVEC 2
 

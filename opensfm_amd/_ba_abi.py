@@ -22,7 +22,7 @@ class BaOptions(C.Structure):
         ("loss", C.c_int32), ("loss_threshold", C.c_double), ("max_iterations", C.c_int32),
         ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
         ("initial_radius", C.c_double), ("verbose", C.c_int32), ("pcg_tolerance", C.c_double),
-        ("pcg_max_iterations", C.c_int32), ("preconditioner", C.c_int32),
+        ("pcg_max_iterations", C.c_int32), ("preconditioner", C.c_int32), ("pcg_direct_tolerance", C.c_double),
     ]
 
 
