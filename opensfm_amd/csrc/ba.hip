@@ -32,10 +32,24 @@ namespace {
 
 constexpr int kCoopObs = 256;  // observations per workgroup of the cooperative per-track kernels (mat-vec, point gradient)
 
+// the six entries of Jk (d residual / d [k1 k2 focal]) from the point (u, v) of the undistorted image plane.  ONE function for the evaluation and
+// for the point-major kernels, which rebuild Jk from the (u, v) their rows keep (round 6): the same operations in the same order, the same bits.
+__device__ __forceinline__ void jk_entries(double inv_sigma, double k1, double k2, double f, double u, double v, double *Jk) {
+  const double r2 = u * u + v * v;
+  const double d = 1.0 + r2 * (k1 + k2 * r2);
+  Jk[0] = inv_sigma * f * r2 * u;
+  Jk[1] = inv_sigma * f * r2 * r2 * u;
+  Jk[2] = inv_sigma * d * u;
+  Jk[3] = inv_sigma * f * r2 * v;
+  Jk[4] = inv_sigma * f * r2 * r2 * v;
+  Jk[5] = inv_sigma * d * v;
+}
+
+// uv (optional, with JAC): the point (u, v) Jk was formed from -- (0, 0) for the constant cameras of another model, whose Jk is zero
 template <bool JAC>
 __device__ __forceinline__ void project_obs(int model, const double *X, const double *pose, const double *R, const double *dR,
                                             const double *cam, double ox, double oy, double inv_sigma, double *res,
-                                            double *Jp, double *Jc, double *Jk) {
+                                            double *Jp, double *Jc, double *Jk, double *uv = nullptr) {
   const double p[3] = {X[0] - pose[3], X[1] - pose[4], X[2] - pose[5]};
   double Xc[3];
 #pragma unroll
@@ -59,6 +73,7 @@ __device__ __forceinline__ void project_obs(int model, const double *X, const do
       for (int i = 0; i < 2; i++) Jc[6 * i + k] = -(M[3 * i] * q[0] + M[3 * i + 1] * q[1] + M[3 * i + 2] * q[2]);
     }
     for (int i = 0; i < 6; i++) Jk[i] = 0.0;
+    if (uv) uv[0] = uv[1] = 0.0;
     return;
   }
   const double k1 = cam[0], k2 = cam[1], f = cam[2];
@@ -96,12 +111,11 @@ __device__ __forceinline__ void project_obs(int model, const double *X, const do
 #pragma unroll
     for (int i = 0; i < 2; i++) Jc[6 * i + k] = -(M[3 * i] * q[0] + M[3 * i + 1] * q[1] + M[3 * i + 2] * q[2]);
   }
-  Jk[0] = inv_sigma * f * r2 * u;
-  Jk[1] = inv_sigma * f * r2 * r2 * u;
-  Jk[2] = inv_sigma * d * u;
-  Jk[3] = inv_sigma * f * r2 * v;
-  Jk[4] = inv_sigma * f * r2 * r2 * v;
-  Jk[5] = inv_sigma * d * v;
+  jk_entries(inv_sigma, k1, k2, f, u, v, Jk);
+  if (uv) {
+    uv[0] = u;
+    uv[1] = v;
+  }
 }
 
 __device__ __forceinline__ void loss_eval(int loss, double a, double s, double &rho, double &rho1) {
@@ -155,6 +169,33 @@ __device__ __forceinline__ void block_sum(double *v, double *lds /* [4*NV] */) {
       v[k] = s;
     }
 }
+
+// Sum of NV values per thread over a workgroup of W wavefronts, wavefront by wavefront in a fixed order; the result is valid on thread 0.
+// (the per-shot kernels: one wavefront per shot when there are thousands of shots, W = 4 when there are few -- a 48-shot local bundle
+// adjustment gave 48 wavefronts a thirteen-step loop of ~500 fp64 instructions each and left the other 1 000 SIMDs idle)
+template <int NV, int W>
+__device__ __forceinline__ void shot_sum(double (&v)[NV], double *lds /* [W * NV] when W > 1 */) {
+#pragma unroll
+  for (int i = 0; i < NV; i++)
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v[i] += __shfl_xor(v[i], m);
+  if (W == 1) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0)
+#pragma unroll
+    for (int i = 0; i < NV; i++) lds[w * NV + i] = v[i];
+  __syncthreads();
+  if (threadIdx.x == 0)
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+      double t = lds[i];
+#pragma unroll
+      for (int q = 1; q < W; q++) t += lds[q * NV + i];
+      v[i] = t;
+    }
+}
+constexpr int kShotWavesSmall = 4;   // wavefronts per shot of the per-shot kernels when the problem has at most kShotWavesBelow shots
+constexpr int kShotWavesBelow = 1024;
 
 // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  The per-shot kernels gather rows that the neighbouring shots
 // want too (the E blocks / w entries of the points they share), so every XCD gets a CONTIGUOUS range of shots: band assembly 1.76 ->
@@ -231,7 +272,7 @@ struct Dev {
   double *shotR;         // S x 36
   // per-observation residual + Jacobian blocks, components: res(2) Jp(6) Jc(12) Jk(6), kept once, in point-major order:
   double *Epm;           // [M][18] AoS, point-major: E_o = Jc_o^T Jp_o (6x3), operand of the band assembly
-  double *Jpm;           // [26][M] SoA in POINT-major observation order (thread-per-observation kernels coalesce)
+  double *Jpm;           // [kRowComps][M] SoA in POINT-major observation order (thread-per-observation kernels coalesce); generic mode: [g.ncomp][M]
   double *sm_wt;         // [M] in SHOT-major order: the robust weight sqrt(rho') of every observation at the linearisation point (written by the
                          // per-shot gradient kernel, read by the other per-shot kernels, which recompute the Jacobian rows they need -- sm_row; rounds 1-5
                          // kept a second, shot-major copy of all 26 components instead: a second evaluation launch, 208 bytes per observation written and re-read)
@@ -293,6 +334,24 @@ struct Dev {
 };
 
 #define JA(o, c) d.Jpm[(long)(c) * d.M + (o)]  /* point-major SoA */
+// Components of a point-major row (round 6: 17; rounds 1-5 stored 26 -- 208 bytes per observation through a write path that sustains ~2.5 TB/s
+// here).  The translation columns of Jc are -Jp; the six entries of Jk follow from (u, v), the robust weight, sigma and the camera (row_jk:
+// project_obs's own expressions): neither is stored.  res 2 | Jp 2 x 3 | Jr 2 x 3 (the ROTATION columns of Jc) | u | v | wt
+constexpr int kRowComps = 17;
+constexpr int R_JP = 2, R_JR = 8, R_U = 14, R_V = 15, R_WT = 16;
+
+// Jk of the observation at point-major position o (of shot s), times the robust weight, from what its row keeps
+__device__ __forceinline__ void row_jk(const Dev &d, long o, int s, double (&jk)[6]) {
+  const int ci = d.shot_camera[s];
+  const double u = JA(o, R_U), v = JA(o, R_V), wt = JA(o, R_WT), sg = d.o_sigma[o];
+  const double *cam = d.cams + 3 * ci;
+  const double k1 = cam[0], k2 = cam[1], f = cam[2];
+  const bool other = d.cam_model && d.cam_model[ci] >= 2;  // a constant camera of another model: no [k1 k2 focal] columns
+  double J[6];
+  jk_entries(1.0 / sg, k1, k2, f, u, v, J);
+#pragma unroll
+  for (int i = 0; i < 6; i++) jk[i] = other ? 0.0 : wt * J[i];
+}
 
 __global__ void shot_rot_kernel(Dev d, const double *poses) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -346,15 +405,16 @@ __global__ void __launch_bounds__(kCoopObs) eval_kernel(Dev d, const double *cam
   const int p0 = d.wg_pt[blockIdx.x], p1 = d.wg_pt[blockIdx.x + 1];
   const long o0 = d.pt_off[p0], o1 = d.pt_off[p1];
   double acc[2] = {0.0, 0.0};
-  // row: the 26 components of observation o as they are stored (res 2 | Jp 6 | Jc 12 | Jk 6, times the robust weight); the cost terms go to acc
-  auto compute = [&](long o, double (&row)[26]) {
+  // row: the kRowComps components of observation o as they are stored (res 2 | Jp 6 | Jr 6 | u | v | wt; residual and Jacobian entries times the
+  // robust weight); the cost terms go to acc
+  auto compute = [&](long o, double (&row)[kRowComps]) {
     const int s = d.o_shot[o], p = d.o_point[o];
     const double *R = d.shotR + 36 * (long)s;
-    double r[2], Jp[6], Jc[12], Jk[6];
+    double r[2], Jp[6], Jc[12], Jk[6], uv[2];
     const double sg = d.o_sigma[o];
     const int cmodel = d.cam_model ? d.cam_model[d.shot_camera[s]] : 0;
     project_obs<JAC>(cmodel, pts + 3 * (long)p, poses + 6 * (long)s, R, R + 9, cmodel >= 2 ? d.cam_ext + 16 * d.shot_camera[s] : cams + 3 * d.shot_camera[s], d.o_x[o],
-                     d.o_y[o], 1.0 / sg, r, Jp, Jc, Jk);
+                     d.o_y[o], 1.0 / sg, r, Jp, Jc, Jk, uv);
     const double sq = r[0] * r[0] + r[1] * r[1];
     double rho, rho1;
     loss_eval(loss, a, sq, rho, rho1);
@@ -365,17 +425,20 @@ __global__ void __launch_bounds__(kCoopObs) eval_kernel(Dev d, const double *cam
       row[0] = wt * r[0];
       row[1] = wt * r[1];
 #pragma unroll
-      for (int i = 0; i < 6; i++) row[2 + i] = wt * Jp[i];
+      for (int i = 0; i < 6; i++) row[R_JP + i] = wt * Jp[i];
 #pragma unroll
-      for (int i = 0; i < 12; i++) row[8 + i] = wt * Jc[i];
+      for (int i = 0; i < 2; i++)
 #pragma unroll
-      for (int i = 0; i < 6; i++) row[20 + i] = wt * Jk[i];
+        for (int k = 0; k < 3; k++) row[R_JR + 3 * i + k] = wt * Jc[6 * i + k];
+      row[R_U] = uv[0];
+      row[R_V] = uv[1];
+      row[R_WT] = wt;
     }
   };
   // the point block's products of a row (point_grad_kernel's expressions of rounds 3-5: the same sums, the same bits)
-  auto products = [&](const double (&row)[26], double (&v)[9]) {
+  auto products = [&](const double (&row)[kRowComps], double (&v)[9]) {
     const double r0 = row[0], r1 = row[1];
-    const double *jp = row + 2;
+    const double *jp = row + R_JP;
 #pragma unroll
     for (int j = 0; j < 3; j++) v[j] = jp[j] * r0 + jp[3 + j] * r1;
     v[3] = jp[0] * jp[0] + jp[3] * jp[3];
@@ -385,15 +448,16 @@ __global__ void __launch_bounds__(kCoopObs) eval_kernel(Dev d, const double *cam
     v[7] = jp[1] * jp[2] + jp[4] * jp[5];
     v[8] = jp[2] * jp[2] + jp[5] * jp[5];
   };
-  auto store = [&](long o, const double (&row)[26]) {
+  auto store = [&](long o, const double (&row)[kRowComps]) {
 #pragma unroll
-    for (int i = 0; i < 26; i++) JA(o, i) = row[i];
+    for (int i = 0; i < kRowComps; i++) JA(o, i) = row[i];
     if (d.Epm) {  // E_o = Jc_o^T Jp_o (6 x 3) of the corrected blocks, 144 contiguous bytes per observation: the per-shot band assembly's operand
-      const double *jp = row + 2;
+      const double *jp = row + R_JP;
       double2 *dst = reinterpret_cast<double2 *>(d.Epm + 18 * o);
 #pragma unroll
-      for (int i = 0; i < 6; i += 2) {
-        const double a0 = row[8 + i], b0 = row[14 + i], a1 = row[9 + i], b1 = row[15 + i];
+      for (int i = 0; i < 6; i += 2) {  // Jc[r][i] = Jr[r][i] for the rotation (i < 3), -Jp[r][i - 3] for the translation
+        const double a0 = i < 3 ? row[R_JR + i] : -jp[i - 3], b0 = i < 3 ? row[R_JR + 3 + i] : -jp[3 + i - 3];
+        const double a1 = i + 1 < 3 ? row[R_JR + i + 1] : -jp[i + 1 - 3], b1 = i + 1 < 3 ? row[R_JR + 3 + i + 1] : -jp[3 + i + 1 - 3];
         double e[6];
 #pragma unroll
         for (int j = 0; j < 3; j++) {
@@ -408,7 +472,7 @@ __global__ void __launch_bounds__(kCoopObs) eval_kernel(Dev d, const double *cam
   };
   if (o1 - o0 <= kCoopObs) {
     const bool on = tid < o1 - o0;
-    double row[26];
+    double row[kRowComps];
     if (on) {
       compute(o0 + tid, row);
       if (JAC) {
@@ -444,7 +508,7 @@ __global__ void __launch_bounds__(kCoopObs) eval_kernel(Dev d, const double *cam
   }
   {  // one track longer than the tile
     for (long o = o0 + tid; o < o1; o += kCoopObs) {
-      double row[26];
+      double row[kRowComps];
       compute(o, row);
       if (JAC) store(o, row);
     }
@@ -454,9 +518,9 @@ __global__ void __launch_bounds__(kCoopObs) eval_kernel(Dev d, const double *cam
         double s9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (!(d.point_fixed && d.point_fixed[p0]))
           for (long o = o0; o < o1; o++) {
-            double row[26], v[9];
+            double row[kRowComps], v[9];
 #pragma unroll
-            for (int i = 0; i < 8; i++) row[i] = JA(o, i);
+            for (int i = 0; i < R_JP + 6; i++) row[i] = JA(o, i);
             products(row, v);
 #pragma unroll
             for (int q = 0; q < 9; q++) s9[q] += v[q];
@@ -558,13 +622,15 @@ __global__ void __launch_bounds__(1024) prior_cost_kernel(Dev d, const double *c
 // the robust weight formed here, as eval_kernel forms it) and the weight of every observation is left in sm_wt for the other per-shot kernels
 // of this linearisation: the launch stands in for rounds 1-5's second evaluation launch (which wrote the shot-major copy of the rows, 0.34 ms at
 // configs[4]) AND their gradient kernel (which read it back, 0.16 ms).
-__global__ void __launch_bounds__(64) shot_grad_kernel(Dev d, const double *poses, int loss, double la) {
+template <int W>
+__global__ void __launch_bounds__(64 * W) shot_grad_kernel(Dev d, const double *poses, int loss, double la) {
+  __shared__ double red[W > 1 ? W * 36 : 1];
   const int s = (int)xcd_contiguous(blockIdx.x, gridDim.x), lane = threadIdx.x;
   const ShotFrame f = shot_frame(d, s);
   double v[36];  // g(6) H(21) gk(3) Hk(6)
 #pragma unroll
   for (int i = 0; i < 36; i++) v[i] = 0;
-  for (long k = d.shot_off[s] + lane; k < d.shot_off[s + 1]; k += 64) {
+  for (long k = d.shot_off[s] + lane; k < d.shot_off[s + 1]; k += 64 * W) {
     double r[2], Jp[6], Jc[12], Jk[6];
     const int p = d.sm_point[k];
     project_obs<true>(f.model, d.pts + 3 * (long)p, f.pose, f.R, f.R + 9, f.cam, d.sm_x[k], d.sm_y[k], 1.0 / d.sm_sigma[k], r, Jp, Jc, Jk);
@@ -599,10 +665,7 @@ __global__ void __launch_bounds__(64) shot_grad_kernel(Dev d, const double *pose
     v[34] += ka[2] * ka[1] + kb[2] * kb[1];
     v[35] += ka[2] * ka[2] + kb[2] * kb[2];
   }
-#pragma unroll
-  for (int i = 0; i < 36; i++)
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v[i] += __shfl_xor(v[i], m);
+  shot_sum<36, W>(v, red);
   if (lane == 0) {
     const bool fixed = d.shot_fixed && d.shot_fixed[s];
     double pd[6] = {0, 0, 0, 0, 0, 0};
@@ -1117,8 +1180,20 @@ __global__ void __launch_bounds__(384) band_mfma_kernel(Dev d) {
     auto fetch_blocks = [&]() {  // of the chunk whose index is in n_*
       c_have = n_k != 255;
       const long o = n_o0 + (c_have ? n_k : 0);
+      // jv: Jp (6) | Jc row 0 (6) | Jc row 1 (6).  The generic rows store all of it (res 2 | Jp 6 | Jc 12); the [k1 k2 focal] rows keep the rotation
+      // columns only (R_JR) -- the translation columns are -Jp, read a second time with the other sign (the same addresses: cache hits) so that the
+      // loads stay unconditional
+      const int rot1 = d.gen ? 14 : R_JR + 3, tr0 = d.gen ? 11 : R_JP, tr1 = d.gen ? 17 : R_JP + 3;
+      const double sgn = d.gen ? 1.0 : -1.0;
 #pragma unroll
-      for (int x = 0; x < 18; x++) jv[x] = JA(o, 2 + x);
+      for (int x = 0; x < 6; x++) jv[x] = JA(o, R_JP + x);
+#pragma unroll
+      for (int x = 0; x < 3; x++) {
+        jv[6 + x] = JA(o, R_JR + x);
+        jv[12 + x] = JA(o, rot1 + x);
+        jv[9 + x] = sgn * JA(o, tr0 + x);
+        jv[15 + x] = sgn * JA(o, tr1 + x);
+      }
       const double *Hh = d.Hhat + 6L * n_p;
 #pragma unroll
       for (int x = 0; x < 6; x++) hh[x] = Hh[x];
@@ -2819,31 +2894,44 @@ __global__ void __launch_bounds__(kCoopObs) schur_point_coop_kernel(Dev d, const
   const int p0 = d.wg_pt[blockIdx.x], p1 = d.wg_pt[blockIdx.x + 1];
   const long o0 = d.pt_off[p0], o1 = d.pt_off[p1];
   const int nobs = (int)(o1 - o0);
+  // t_o = Jc_o y_s + Jk_o y_k from the row's components, in the order the 26-component rows of rounds 1-5 were multiplied: the rotation columns
+  // (Jr), the translation columns (-Jp: (-a) b added = a b subtracted, the same bits), then Jk (row_jk)
+  auto row_t = [&](long o, const double (&jp)[6], double &t0, double &t1) {
+    const int s = d.o_shot[o];
+    const double *ys = y + 6 * (long)s, *yk = y + d.cam0 + 3 * d.shot_camera[s];
+    double jk[6];
+    row_jk(d, o, s, jk);
+    t0 = 0;
+    t1 = 0;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const double yj = ys[j];
+      t0 += JA(o, R_JR + j) * yj;
+      t1 += JA(o, R_JR + 3 + j) * yj;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const double yj = ys[3 + j];
+      t0 += (-jp[j]) * yj;
+      t1 += (-jp[3 + j]) * yj;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const double yj = yk[j];
+      t0 += jk[j] * yj;
+      t1 += jk[3 + j] * yj;
+    }
+  };
   if (nobs <= kCoopObs) {  // uniform per workgroup
     double t0 = 0, t1 = 0, jp[6] = {0, 0, 0, 0, 0, 0};
     int pl = 0;
     const long o = o0 + tid;
     if (tid < nobs) {
       pl = d.o_point[o] - p0;
+#pragma unroll
+      for (int j = 0; j < 6; j++) jp[j] = JA(o, R_JP + j);
       if (MODE != 1) {
-        const int s = d.o_shot[o];
-        const double *ys = y + 6 * (long)s, *yk = y + d.cam0 + 3 * d.shot_camera[s];
-#pragma unroll
-        for (int j = 0; j < 6; j++) {
-          const double yj = ys[j];
-          t0 += JA(o, 8 + j) * yj;
-          t1 += JA(o, 14 + j) * yj;
-        }
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-          const double yj = yk[j];
-          t0 += JA(o, 20 + j) * yj;
-          t1 += JA(o, 23 + j) * yj;
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 6; j++) jp[j] = JA(o, 2 + j);
-      if (MODE != 1) {
+        row_t(o, jp, t0, t1);
 #pragma unroll
         for (int j = 0; j < 3; j++) gsum[3 * tid + j] = jp[j] * t0 + jp[3 + j] * t1;
       }
@@ -2903,22 +2991,14 @@ __global__ void __launch_bounds__(kCoopObs) schur_point_coop_kernel(Dev d, const
   double u[3] = {0, 0, 0};
   if (MODE != 1) {
     for (long o = o0 + tid; o < o1; o += kCoopObs) {
-      const int s = d.o_shot[o];
-      const double *ys = y + 6 * (long)s, *yk = y + d.cam0 + 3 * d.shot_camera[s];
-      double t0 = 0, t1 = 0;
-      for (int j = 0; j < 6; j++) {
-        t0 += JA(o, 8 + j) * ys[j];
-        t1 += JA(o, 14 + j) * ys[j];
-      }
-      for (int j = 0; j < 3; j++) {
-        t0 += JA(o, 20 + j) * yk[j];
-        t1 += JA(o, 23 + j) * yk[j];
-      }
+      double jp[6], t0, t1;
+      for (int j = 0; j < 6; j++) jp[j] = JA(o, R_JP + j);
+      row_t(o, jp, t0, t1);
       if (MODE == 0) {
         d.w[2 * o] = t0;
         d.w[2 * o + 1] = t1;
       }
-      for (int j = 0; j < 3; j++) u[j] += JA(o, 2 + j) * t0 + JA(o, 5 + j) * t1;
+      for (int j = 0; j < 3; j++) u[j] += jp[j] * t0 + jp[3 + j] * t1;
     }
   }
   for (int j = 0; j < 3; j++) gsum[3 * tid + j] = u[j];
@@ -2943,18 +3023,10 @@ __global__ void __launch_bounds__(kCoopObs) schur_point_coop_kernel(Dev d, const
     }
     double acc[1] = {0.0};
     for (long o = o0 + tid; o < o1; o += kCoopObs) {
-      const int s = d.o_shot[o];
-      const double *ys = y + 6 * (long)s, *yk = y + d.cam0 + 3 * d.shot_camera[s];
-      double t0 = 0, t1 = 0;
-      for (int j = 0; j < 6; j++) {
-        t0 += JA(o, 8 + j) * ys[j];
-        t1 += JA(o, 14 + j) * ys[j];
-      }
-      for (int j = 0; j < 3; j++) {
-        t0 += JA(o, 20 + j) * yk[j];
-        t1 += JA(o, 23 + j) * yk[j];
-      }
-      const double m0 = (JA(o, 2) * v0 + JA(o, 3) * v1 + JA(o, 4) * v2) + t0, m1 = (JA(o, 5) * v0 + JA(o, 6) * v1 + JA(o, 7) * v2) + t1;
+      double jp[6], t0, t1;
+      for (int j = 0; j < 6; j++) jp[j] = JA(o, R_JP + j);
+      row_t(o, jp, t0, t1);
+      const double m0 = (jp[0] * v0 + jp[1] * v1 + jp[2] * v2) + t0, m1 = (jp[3] * v0 + jp[4] * v1 + jp[5] * v2) + t1;
       acc[0] += -(m0 * (JA(o, 0) + 0.5 * m0) + m1 * (JA(o, 1) + 0.5 * m1));
     }
     __syncthreads();
@@ -2963,8 +3035,8 @@ __global__ void __launch_bounds__(kCoopObs) schur_point_coop_kernel(Dev d, const
     return;
   }
   for (long o = o0 + tid; o < o1; o += kCoopObs) {
-    const double m0 = JA(o, 2) * v0 + JA(o, 3) * v1 + JA(o, 4) * v2;
-    const double m1 = JA(o, 5) * v0 + JA(o, 6) * v1 + JA(o, 7) * v2;
+    const double m0 = JA(o, R_JP) * v0 + JA(o, R_JP + 1) * v1 + JA(o, R_JP + 2) * v2;
+    const double m1 = JA(o, R_JP + 3) * v0 + JA(o, R_JP + 4) * v1 + JA(o, R_JP + 5) * v2;
     if (MODE == 0) {
       d.w[2 * o] -= m0;
       d.w[2 * o + 1] -= m1;
@@ -2976,11 +3048,13 @@ __global__ void __launch_bounds__(kCoopObs) schur_point_coop_kernel(Dev d, const
 }
 
 // pass B, wavefront per shot: zc_s = sum Jc^T w ; camera partials
-__global__ void __launch_bounds__(64) schur_shot_kernel(Dev d) {
+template <int W>
+__global__ void __launch_bounds__(64 * W) schur_shot_kernel(Dev d) {
+  __shared__ double red[W > 1 ? W * 9 : 1];
   const int s = (int)xcd_contiguous(blockIdx.x, gridDim.x), lane = threadIdx.x;
   const ShotFrame f = shot_frame(d, s);
   double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (long k = d.shot_off[s] + lane; k < d.shot_off[s + 1]; k += 64) {
+  for (long k = d.shot_off[s] + lane; k < d.shot_off[s + 1]; k += 64 * W) {
     const long o = d.shot_obs[k];  // w lives in point-major order: 2 gathered doubles per observation
     const double w0 = d.w[2 * o], w1 = d.w[2 * o + 1];
     double rr[2], jp[6], jc[12], jk[6];  // (the rows recomputed: sm_row; the shot-major copy this kernel read until round 5 is gone)
@@ -2990,10 +3064,7 @@ __global__ void __launch_bounds__(64) schur_shot_kernel(Dev d) {
 #pragma unroll
     for (int j = 0; j < 3; j++) v[6 + j] += jk[j] * w0 + jk[3 + j] * w1;
   }
-#pragma unroll
-  for (int i = 0; i < 9; i++)
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v[i] += __shfl_xor(v[i], m);
+  shot_sum<9, W>(v, red);
   if (lane == 0) {
     for (int j = 0; j < 6; j++) d.zc[6 * s + j] = v[j];
     for (int j = 0; j < 3; j++) d.part[9 * (long)s + j] = v[6 + j];
@@ -3385,15 +3456,18 @@ __global__ void __launch_bounds__(kCoopObs) border_point_kernel(Dev d, double *w
     const long o = o0 + tid;
     if (tid < nobs) {
       pl = d.o_point[o] - p0;
-      cam = d.shot_camera[d.o_shot[o]];
+      const int so = d.o_shot[o];
+      cam = d.shot_camera[so];
       const double *sck = d.sc_red + d.cam0 + 3 * cam;
+      double jk[6];
+      row_jk(d, o, so, jk);
 #pragma unroll
       for (int k = 0; k < 3; k++) {
-        t0[k] = JA(o, 20 + k) * sck[k];
-        t1[k] = JA(o, 23 + k) * sck[k];
+        t0[k] = jk[k] * sck[k];
+        t1[k] = jk[3 + k] * sck[k];
       }
 #pragma unroll
-      for (int j = 0; j < 6; j++) jp[j] = JA(o, 2 + j);
+      for (int j = 0; j < 6; j++) jp[j] = JA(o, R_JP + j);
 #pragma unroll
       for (int k = 0; k < 3; k++)
 #pragma unroll
@@ -3445,16 +3519,18 @@ __global__ void __launch_bounds__(kCoopObs) border_point_kernel(Dev d, double *w
 #pragma unroll
   for (int c = 0; c < NB; c++) u[c][0] = u[c][1] = u[c][2] = 0.0;
   for (long o = o0 + tid; o < o1; o += kCoopObs) {
-    const int cam = d.shot_camera[d.o_shot[o]];
+    const int so = d.o_shot[o], cam = d.shot_camera[so];
     const double *sck = d.sc_red + d.cam0 + 3 * cam;
+    double jk[6];
+    row_jk(d, o, so, jk);
 #pragma unroll
     for (int c = 0; c < NC_; c++)
       if (c == cam)
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-          const double t0 = JA(o, 20 + k) * sck[k], t1 = JA(o, 23 + k) * sck[k];
+          const double t0 = jk[k] * sck[k], t1 = jk[3 + k] * sck[k];
 #pragma unroll
-          for (int j = 0; j < 3; j++) u[3 * c + k][j] += JA(o, 2 + j) * t0 + JA(o, 5 + j) * t1;
+          for (int j = 0; j < 3; j++) u[3 * c + k][j] += JA(o, R_JP + j) * t0 + JA(o, R_JP + 3 + j) * t1;
         }
   }
 #pragma unroll
@@ -3477,22 +3553,25 @@ __global__ void __launch_bounds__(kCoopObs) border_point_kernel(Dev d, double *w
     v[c][2] = Hh[2] * u0 + Hh[4] * u1 + Hh[5] * u2;
   }
   for (long o = o0 + tid; o < o1; o += kCoopObs) {
-    const int cam = d.shot_camera[d.o_shot[o]];
+    const int so = d.o_shot[o], cam = d.shot_camera[so];
     const double *sck = d.sc_red + d.cam0 + 3 * cam;
+    double jk[6];
+    row_jk(d, o, so, jk);
 #pragma unroll
     for (int c = 0; c < NB; c++) {
       const bool own = (c / 3) == cam;
-      const double t0 = own ? JA(o, 20 + c % 3) * sck[c % 3] : 0.0, t1 = own ? JA(o, 23 + c % 3) * sck[c % 3] : 0.0;
-      wB[(2L * NB * o) + 2 * c] = t0 - (JA(o, 2) * v[c][0] + JA(o, 3) * v[c][1] + JA(o, 4) * v[c][2]);
-      wB[(2L * NB * o) + 2 * c + 1] = t1 - (JA(o, 5) * v[c][0] + JA(o, 6) * v[c][1] + JA(o, 7) * v[c][2]);
+      const double t0 = own ? jk[c % 3] * sck[c % 3] : 0.0, t1 = own ? jk[3 + c % 3] * sck[c % 3] : 0.0;
+      wB[(2L * NB * o) + 2 * c] = t0 - (JA(o, R_JP) * v[c][0] + JA(o, R_JP + 1) * v[c][1] + JA(o, R_JP + 2) * v[c][2]);
+      wB[(2L * NB * o) + 2 * c + 1] = t1 - (JA(o, R_JP + 3) * v[c][0] + JA(o, R_JP + 4) * v[c][1] + JA(o, R_JP + 5) * v[c][2]);
     }
   }
 }
 
 // pass B: wavefront per shot.  Bc[c][6 s + j] = sc (sum Jc^T w_c) (the finish of the mat-vec on shot rows: no diagonal terms for a
 // camera unit vector), partB[s][3 x NB] = sum Jk^T w_c
-template <int NB>
-__global__ void __launch_bounds__(64) border_shot_kernel(Dev d, const double *wB, double *Bc, double *partB) {
+template <int NB, int W>
+__global__ void __launch_bounds__(64 * W) border_shot_kernel(Dev d, const double *wB, double *Bc, double *partB) {
+  __shared__ double red[W > 1 ? W * 9 : 1];
   const int s = (int)xcd_contiguous(blockIdx.x, gridDim.x), lane = threadIdx.x;
   double v[NB][9];
 #pragma unroll
@@ -3500,7 +3579,7 @@ __global__ void __launch_bounds__(64) border_shot_kernel(Dev d, const double *wB
 #pragma unroll
     for (int i = 0; i < 9; i++) v[c][i] = 0.0;
   const ShotFrame f = shot_frame(d, s);
-  for (long k = d.shot_off[s] + lane; k < d.shot_off[s + 1]; k += 64) {
+  for (long k = d.shot_off[s] + lane; k < d.shot_off[s + 1]; k += 64 * W) {
     const long o = d.shot_obs[k];
     const double2 *src = reinterpret_cast<const double2 *>(wB + 2L * NB * o);
     double jc0[6], jc1[6], jk0[3], jk1[3];
@@ -3528,11 +3607,10 @@ __global__ void __launch_bounds__(64) border_shot_kernel(Dev d, const double *wB
     }
   }
 #pragma unroll
-  for (int c = 0; c < NB; c++)
-#pragma unroll
-    for (int i = 0; i < 9; i++)
-#pragma unroll
-      for (int m = 32; m >= 1; m >>= 1) v[c][i] += __shfl_xor(v[c][i], m);
+  for (int c = 0; c < NB; c++) {  // (column by column through the same nine slots of LDS)
+    shot_sum<9, W>(v[c], red);
+    if (W > 1) __syncthreads();
+  }
   if (lane == 0) {
     const long n6 = 6L * d.S;
 #pragma unroll
@@ -4160,7 +4238,8 @@ struct Solver {
   }
   void gradients() {
     if (d.gen) return gen_gradients();
-    hipLaunchKernelGGL(shot_grad_kernel, dim3(d.S), dim3(64), 0, st, d, (const double *)d.poses, loss, loss_a);  // (the points' blocks: eval_kernel<true>)
+    if (shot_waves() > 1) hipLaunchKernelGGL(shot_grad_kernel<kShotWavesSmall>, dim3(d.S), dim3(64 * kShotWavesSmall), 0, st, d, (const double *)d.poses, loss, loss_a);
+    else hipLaunchKernelGGL(shot_grad_kernel<1>, dim3(d.S), dim3(64), 0, st, d, (const double *)d.poses, loss, loss_a);  // (the points' blocks: eval_kernel<true>)
     if (!cams_inert) hipLaunchKernelGGL(cam_reduce_kernel, dim3(d.NC), dim3(kCamRedT), 0, st, d, 9, (const double *)d.cams);
     else hipLaunchKernelGGL(cam_grad_kernel, dim3(nblk(d.NC, 64)), dim3(64), 0, st, d, d.cams);
   }
@@ -4382,6 +4461,11 @@ struct Solver {
       hipLaunchKernelGGL(precond_apply_kernel, dim3(nblk(d.S + d.NC)), dim3(TPB), 0, st, d, r, z);
     if (d.gen && d.g.NB > 0) hipLaunchKernelGGL(gen_precond_border_kernel, dim3(nblk(d.g.NB, 64)), dim3(64), 0, st, d, r, z, cur_radius);
   }
+  int shot_waves() const { return d.S <= kShotWavesBelow ? kShotWavesSmall : 1; }
+  void schur_shot(hipStream_t sq) {
+    if (shot_waves() > 1) hipLaunchKernelGGL(schur_shot_kernel<kShotWavesSmall>, dim3(d.S), dim3(64 * kShotWavesSmall), 0, sq, d);
+    else hipLaunchKernelGGL(schur_shot_kernel<1>, dim3(d.S), dim3(64), 0, sq, d);
+  }
   // workgroups of the finish kernel = entries of the p . Ap shares
   int matvec_parts() const { return d.gen ? nblk(d.nred) : nblk(d.cam0) + d.NC; }
   // y_ready: d.y = sc x is there already (PCG's vector kernels leave it); dot_part: the shares of x . out as well (PCG's p . Ap).  Three launches
@@ -4390,7 +4474,7 @@ struct Solver {
     if (d.gen) return gen_matvec(x, out, radius, st, y_ready, dot_part);
     if (!y_ready) hipLaunchKernelGGL(scale_vec_kernel, dim3(nblk(d.nred)), dim3(TPB), 0, st, d.sc_red, x, d.y, d.nred);
     hipLaunchKernelGGL(schur_point_coop_kernel<0>, dim3(d.nwg), dim3(kCoopObs), 0, st, d, d.y);
-    hipLaunchKernelGGL(schur_shot_kernel, dim3(d.S), dim3(64), 0, st, d);
+    schur_shot(st);
     hipLaunchKernelGGL(schur_finish_kernel, dim3(matvec_parts()), dim3(TPB), 0, st, d, x, (const double *)d.y, out, radius, 0, cams_inert ? 1 : 0, dot_part);
   }
 };
@@ -5040,7 +5124,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     d.wg_pt = A.upload(wg_pt.data(), wg_pt.size(), e);
   }
   d.shotR = A.alloc<double>((size_t)36 * S, e);
-  d.Jpm = A.alloc<double>((size_t)(gen ? g.ncomp : 26) * M, e);
+  d.Jpm = A.alloc<double>((size_t)(gen ? g.ncomp : kRowComps) * M, e);
   d.sm_wt = A.alloc<double>((size_t)std::max<long>(1, M), e);
   {
     int *ss = A.alloc<int>((size_t)M, e), *sp = A.alloc<int>((size_t)M, e);
@@ -5282,7 +5366,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       for (double x : h) bad += !(x == x);
       if (bad) fprintf(stderr, "[osfm_ba] %s: %zu of %zu not finite\n", name, bad, n);
     };
-    scan("Jpm", d.Jpm, (size_t)(gen ? g.ncomp : 26) * M);
+    scan("Jpm", d.Jpm, (size_t)(gen ? g.ncomp : kRowComps) * M);
     scan("sm_wt", d.sm_wt, (size_t)M);
     if (gen) {
       scan("PI", g.PI, (size_t)36 * S);
@@ -5445,11 +5529,13 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       } else if (want_border) {  // all nb columns of B (and of the camera block C) in one pass over the observations
         if (3 * NC == 3) {
           hipLaunchKernelGGL(border_point_kernel<3>, dim3(d.nwg), dim3(kCoopObs), 0, sx, d, sv.wB);
-          hipLaunchKernelGGL(border_shot_kernel<3>, dim3(S), dim3(64), 0, sx, d, sv.wB, sv.Bc, sv.partB);
+          if (sv.shot_waves() > 1) hipLaunchKernelGGL((border_shot_kernel<3, kShotWavesSmall>), dim3(S), dim3(64 * kShotWavesSmall), 0, sx, d, sv.wB, sv.Bc, sv.partB);
+          else hipLaunchKernelGGL((border_shot_kernel<3, 1>), dim3(S), dim3(64), 0, sx, d, sv.wB, sv.Bc, sv.partB);
           hipLaunchKernelGGL(border_cam_kernel<3>, dim3(NC), dim3(TPB), 0, sx, d, sv.partB, sv.dCm, radius);
         } else {
           hipLaunchKernelGGL(border_point_kernel<6>, dim3(d.nwg), dim3(kCoopObs), 0, sx, d, sv.wB);
-          hipLaunchKernelGGL(border_shot_kernel<6>, dim3(S), dim3(64), 0, sx, d, sv.wB, sv.Bc, sv.partB);
+          if (sv.shot_waves() > 1) hipLaunchKernelGGL((border_shot_kernel<6, kShotWavesSmall>), dim3(S), dim3(64 * kShotWavesSmall), 0, sx, d, sv.wB, sv.Bc, sv.partB);
+          else hipLaunchKernelGGL((border_shot_kernel<6, 1>), dim3(S), dim3(64), 0, sx, d, sv.wB, sv.Bc, sv.partB);
           hipLaunchKernelGGL(border_cam_kernel<6>, dim3(NC), dim3(TPB), 0, sx, d, sv.partB, sv.dCm, radius);
         }
       }
@@ -5459,7 +5545,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
         hipLaunchKernelGGL(gen_schur_finish_kernel, dim3(nbr), dim3(TPB), 0, sx, d, (const double *)d.x, (const double *)d.y, d.b, radius, 1, M > 0 ? 1 : 0, 0, (double *)nullptr);
       } else {
         hipLaunchKernelGGL(schur_point_coop_kernel<1>, dim3(d.nwg), dim3(kCoopObs), 0, sx, d, d.y);
-        hipLaunchKernelGGL(schur_shot_kernel, dim3(S), dim3(64), 0, sx, d);
+        sv.schur_shot(sx);
         hipLaunchKernelGGL(schur_finish_kernel, dim3(sv.matvec_parts()), dim3(TPB), 0, sx, d, (const double *)d.x, (const double *)d.y, d.b, radius, 1, sv.cams_inert ? 1 : 0,
                            (double *)nullptr);
       }

@@ -736,14 +736,23 @@ def match_images_with_pairs(data, config_override: Dict[str, Any], exifs: Dict[s
         if use_words:
             raise NotImplementedError("matcher_type WORDS with matching_use_segmentation is not on the GPU path (the resident WordsStore holds 128-D rows)")
     use_filters = bool(config.get("matching_use_filters"))
+    # cv2.findFundamentalMat switches to LMedS below 15 correspondences; the batched fundamental-matrix launch implements RANSAC only (the
+    # leaf find_fundamental_ransac has both: osfm_ransac_fundamental).  With robust_matching_min_match < 15 -- not the default 20 -- a pair on
+    # the fundamental-matrix route can reach that branch, so those pairs take the batched descriptor stage and then the robust stage pair
+    # by pair through the leaf (round 6; rounds 1-5 raised).  Pairs on the calibrated route never reach cv2.
     lmeds_reachable = int(_cfg(config, "robust_matching_min_match")) < 15
 
-    def _check_f_route(pin: np.ndarray) -> None:
-        # cv2.findFundamentalMat switches to LMedS below 15 correspondences; the batched fundamental-matrix launch implements RANSAC only
-        # (the leaf find_fundamental_ransac has both).  Pairs on the calibrated route never reach cv2, so only they may go on.
-        if lmeds_reachable and pin.any():
-            raise NotImplementedError("robust_matching_min_match < 15 reaches cv2's LMedS branch inside match() for the pairs on the "
-                                      "fundamental-matrix route; only the leaf find_fundamental_ransac implements it")
+    def _robust_through_leaves(sel_ipairs, found) -> List[np.ndarray]:
+        min_match = int(_cfg(config, "robust_matching_min_match"))
+        res = []
+        for (a, b), m in zip(sel_ipairs, found):
+            r = np.zeros((0, 2), np.int32)
+            if len(m) >= min_match:
+                rm = np.asarray(robust_match(pts[a], pts[b], cams[a], cams[b], m, config)).reshape(-1, 2)
+                if len(rm) >= min_match and len(rm) > 0:
+                    r = rm.astype(np.int32)
+            res.append(r)
+        return res
     cameras = data.load_camera_models()
     images = sorted({im for pair in pairs for im in pair})
     index = {im: k for k, im in enumerate(images)}
@@ -822,8 +831,6 @@ def match_images_with_pairs(data, config_override: Dict[str, Any], exifs: Dict[s
         store = DescriptorStore(descs, pts)
         try:
             pin = np.array([_is_pinhole(cams[a]) and _is_pinhole(cams[b]) for a, b in ipairs], bool)
-            if not use_filters:
-                _check_f_route(pin)
             if use_filters:  # matching.py:323-334: the filters follow the guided descriptor stage
                 counts, matches = match_pairs_guided(store, ipairs, bearings, rels, cfg_g, robust=False)
                 per_pair = _filter_then_robust(data, config, pairs, ipairs, split_matches(counts, matches), pts, cams)
@@ -832,8 +839,10 @@ def match_images_with_pairs(data, config_override: Dict[str, Any], exifs: Dict[s
                 if not sel.any():
                     continue
                 idx = np.flatnonzero(sel)
-                counts, matches = match_pairs_guided(store, ipairs[idx], bearings, [rels[p] for p in idx], cfg_g, robust=True, cameras=camarg)
-                for p, m in zip(idx, split_matches(counts, matches)):
+                leaves = camarg is None and lmeds_reachable  # fundamental-matrix route with cv2's LMedS branch in reach
+                counts, matches = match_pairs_guided(store, ipairs[idx], bearings, [rels[p] for p in idx], cfg_g, robust=not leaves, cameras=camarg)
+                found = split_matches(counts, matches)
+                for p, m in zip(idx, _robust_through_leaves(ipairs[idx], found) if leaves else found):
                     per_pair[p] = m
         finally:
             store.close()
@@ -861,15 +870,14 @@ def match_images_with_pairs(data, config_override: Dict[str, Any], exifs: Dict[s
         store = DescriptorStore(descs, pts, hamming=True) if hamming else DescriptorStore(descs, pts)  # all descriptors resident in HBM
         try:
             pin = np.array([_is_pinhole(cams[a]) and _is_pinhole(cams[b]) for a, b in ipairs], bool)
-            if not use_filters:
-                _check_f_route(pin)
             if use_filters:  # matching.py:399-411: descriptor stage for every pair, filters on the host, robust stage through the leaves
                 counts, matches = match_pairs(store, ipairs, config, robust=False)
                 per_pair = _filter_then_robust(data, config, pairs, ipairs, split_matches(counts, matches), pts, cams)
                 pin = np.zeros(0, bool)
             if pin.any():
-                counts, matches = match_pairs(store, ipairs[pin], config, robust=True)
-                for p, m in zip(np.flatnonzero(pin), split_matches(counts, matches)):
+                counts, matches = match_pairs(store, ipairs[pin], config, robust=not lmeds_reachable)
+                found = split_matches(counts, matches)
+                for p, m in zip(np.flatnonzero(pin), _robust_through_leaves(ipairs[pin], found) if lmeds_reachable else found):
                     per_pair[p] = m
             if (~pin).any():
                 counts, matches = match_pairs_calibrated(store, ipairs[~pin], cams, pts, config)

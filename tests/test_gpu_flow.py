@@ -67,3 +67,27 @@ def test_match_images_on_the_device(oracle_lib, gpu_ctx, monkeypatch):
     for pair in want:
         assert np.array_equal(_rows(got[pair]), _rows(want[pair])), pair
     assert report["num_pairs_order"] == 3
+
+
+@pytest.mark.parametrize("guided", [False, True])
+def test_lmeds_branch_in_reach_goes_through_the_leaf(oracle_lib, gpu_ctx, monkeypatch, guided):
+    """robust_matching_min_match = 8 and an image with a dozen features: the pinhole pair reaches cv2.findFundamentalMat's LMedS branch
+    (8 <= n < 15), which the batched launch does not implement -- the batch path sends those pairs' robust stage through the leaf
+    (osfm_ransac_fundamental; rounds 1-5 raised NotImplementedError).  Device flow = host-emulated flow, pair for pair."""
+    import test_reference_flow as rf
+    from opensfm_amd import matching as product
+
+    data, exifs, pairs, poses, _ = _data(oracle_lib, guided, False, 17 if guided else 16)
+    data.config["robust_matching_min_match"] = 8
+    m = data.load_features_mask("b", None)
+    keep = np.flatnonzero(m)[:12]
+    m[:] = False
+    m[keep] = True
+    got = product.match_images_with_pairs(data, {}, exifs, pairs, poses if guided else None)
+    with monkeypatch.context() as mp:
+        rf.emulate_product_leaves(mp, oracle_lib)
+        want = product.match_images_with_pairs(data, {}, exifs, pairs, poses if guided else None)
+    for pair in pairs:
+        assert np.array_equal(_rows(got[pair]), _rows(want[pair])), pair
+    if not guided:
+        assert 8 <= len(want["a", "b"]) < 15

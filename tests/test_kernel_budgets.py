@@ -83,16 +83,16 @@ def test_reexamination_issues_its_gather_in_one_piece(tmp_path_factory):
 def test_ba_streaming_kernels_do_not_spill(tmp_path_factory):
     _, k = compile_device("ba", tmp_path_factory)
     # (length-prefixed as in the mangled names: "17schur_shot_kernel" is not "21gen_schur_shot_kernel")
-    for parts in (("schur_point_coop_kernel", "ILi0E"), ("17schur_shot_kernel",), ("11eval_kernel", "ILb1E"), ("11eval_kernel", "ILb0E"),
-                  ("band_assemble_kernel",), ("19border_point_kernel", "ILi3E"), ("18border_shot_kernel", "ILi3E"), ("19precond_shot_kernel",),
-                  ("16shot_grad_kernel",), ("bcr_level_kernel", "ILi9E"), ("wide_factor_kernel",), ("wide_push_kernel", "ILi1ELb0E")):
+    for parts in (("schur_point_coop_kernel", "ILi0E"), ("17schur_shot_kernel", "ILi1E"), ("17schur_shot_kernel", "ILi4E"), ("11eval_kernel", "ILb1E"), ("11eval_kernel", "ILb0E"),
+                  ("band_assemble_kernel",), ("19border_point_kernel", "ILi3E"), ("18border_shot_kernel", "ILi3ELi1E"), ("18border_shot_kernel", "ILi3ELi4E"), ("19precond_shot_kernel",),
+                  ("16shot_grad_kernel", "ILi1E"), ("16shot_grad_kernel", "ILi4E"), ("bcr_level_kernel", "ILi9E"), ("wide_factor_kernel",), ("wide_push_kernel", "ILi1ELb0E")):
         r, name = one(k, *parts)
         assert r["ScratchSize"] == 0 and r["VGPRs Spill"] == 0, (name, r)
     r, _ = one(k, "schur_point_coop_kernel", "ILi0E")
     assert r["Occupancy"] >= 4  # the mat-vec is a streaming kernel: it needs the waves to cover HBM latency
     # round 6: pass B of the mat-vec recomputes its Jacobian rows (sm_row: ~400 fp64 operations per observation instead of 160 bytes read); it must
     # keep the shot's frame in scalar registers and three waves per SIMD to cover the gathers of w and of the points
-    r, _ = one(k, "17schur_shot_kernel")
+    r, _ = one(k, "17schur_shot_kernel", "ILi1E")
     assert r["Occupancy"] >= 3, r
     r, _ = one(k, "bcr_level_kernel", "ILi9E")
     assert r["LDS Size"] <= 160 * 1024

@@ -335,11 +335,14 @@ def emulate_product_leaves(monkeypatch, oracle_lib):
                                                                                        lambda st: split(st, st.pts)))
 
 
-@pytest.mark.parametrize("guided,filters", [(False, False), (True, False), (False, True), (True, True)])
-def test_match_flow_equals_the_product_host_flow(ref, oracle_lib, monkeypatch, guided, filters):
+@pytest.mark.parametrize("guided,filters,lmeds", [(False, False, False), (True, False, False), (False, True, False), (True, True, False),
+                                                   (False, False, True), (True, False, True)])
+def test_match_flow_equals_the_product_host_flow(ref, oracle_lib, monkeypatch, guided, filters, lmeds):
     """The reference's match_unwrap_args -> match() (matching.py:182-214, 563-634; guided: 260-337) executed from its own file for
     every pair of a mixed collection, against opensfm_amd.matching.match_images_with_pairs with its C-ABI calls redirected to the
-    host emulations: same gates, same dispatch, same unfiltered result for every pair."""
+    host emulations: same gates, same dispatch, same unfiltered result for every pair.  lmeds: robust_matching_min_match = 8 and an image
+    with a dozen features, so the pinhole pair reaches cv2.findFundamentalMat with 8 <= n < 15 correspondences -- cv2's LMedS branch, which
+    the batch path sends through the leaf (rounds 1-5: NotImplementedError)."""
     import test_guided_host as gh
     import test_relpose_core_host as rp
     from opensfm_amd import matching as product
@@ -350,6 +353,16 @@ def test_match_flow_equals_the_product_host_flow(ref, oracle_lib, monkeypatch, g
     exifs = {im: {"camera": cam_of[im]} for im in images}
     pairs = [(a, b) for i, a in enumerate(images) for b in images[i + 1:]]
     config["matching_use_filters"] = filters  # the ad-hoc filters between the descriptor stage and the gates (matching.py:323-334,399-411)
+    if lmeds:
+        config["robust_matching_min_match"] = 8
+        keep = np.flatnonzero(masks["b"])[:12]
+        masks["b"][:] = False
+        masks["b"][keep] = True
+        # LMedS on a dozen correspondences depends on their ORDER (its subsets are drawn by index).  The reference hands cv2 the order a python
+        # set of tuples happens to iterate in (matching.py:777); the product hands every robust stage the matches sorted by (i, j) (the one order
+        # a batched kernel can produce, and the oracle pipeline's).  Same matches, the product's order, for the reference's robust stage:
+        orig_sym = matching.match_brute_force_symmetric
+        monkeypatch.setattr(matching, "match_brute_force_symmetric", lambda *a, **k: sorted(orig_sym(*a, **k)))
     exif_of = {"a": {"make": "BlackVue", "model": "DR900"}, "b": {"make": "Canon", "model": "X"}, "c": {"make": "VTrans_Camera", "model": "VTrans_Camera"},
                "d": {"make": "blackvue", "model": "x"}}
     # ---- the reference side ----
@@ -377,7 +390,9 @@ def test_match_flow_equals_the_product_host_flow(ref, oracle_lib, monkeypatch, g
     for pair in pairs:
         assert np.array_equal(rows(got[pair]), rows(want[pair])), pair
         survivors += len(want[pair]) > 0
-    assert survivors >= 5
+    assert survivors >= (3 if lmeds else 5)
+    if lmeds and not guided:
+        assert 8 <= len(want["a", "b"]) < 15  # the pinhole pair went through LMedS and survived
 
 
 def test_segmentation_in_descriptor_flow(ref, oracle_lib, monkeypatch):
