@@ -155,7 +155,7 @@ def run_general(ctx, shots: int = 5000, points: int = 500000, track: int = 10, i
         out["roofline"] = {"bound": "hbm", "kernel": "schur mat-vec, generic rows (gen_schur_point_kernel<2, 0> + gen_schur_shot_kernel<2, 9>)",
                            "achieved": round(alg * nobs / (g["ms_per_matvec"] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(alg * nobs / (g["ms_per_matvec"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_obs": alg,
-                           "traffic": _pmc_traffic("r05_ba_generic_pmc.json", ("gen_schur_point_kernelILi2ELi0E", "gen_schur_shot_kernel"), nobs, alg)}
+                           "traffic": _pmc_traffic("r06_ba_generic_pmc.json", ("gen_schur_point_kernelILi2ELi0E", "gen_schur_shot_kernel"), nobs, alg)}
     if cpu_iters > 0:
         import oracle
 
@@ -269,13 +269,17 @@ def run(ctx, shots: int = 5000, points: int = 500000, track: int = 10, iters: in
             "traffic": None,
             "avg_matvec_ms": round(ms_mv, 4) if ms_mv else None,
             "algorithmic_bytes_per_obs": MATVEC_BYTES_PER_OBS,
+            # round 6: what the two kernels are DESIGNED to move per observation -- pass A reads the compact row's Jp 48 + Jr 48 + (u, v, wt) 24 + sigma 8 +
+            # two indices 8 and writes w 16; pass B recomputes its rows from xy 16 + sigma 8 + wt 8 + two indices 8 + the point 24 and gathers w 16 --
+            # against the 288 B of SURVEY 8(d)'s stored-block mat-vec, which `achieved` keeps as its numerator (the contract's figure)
+            "designed_bytes_per_obs": 232.0,
         },
         "scene_gen_s": round(t_gen, 2),
     }
     # HBM traffic of one mat-vec: PMC passes cannot run inside this process; the committed counters of `tools/prof_ba.py` at the same size
-    # (tools/pmc_passes.sh -> profiles/r05_ba_pmc.json: FETCH_SIZE doubled as the gfx950 guide prescribes, + WRITE_SIZE) are quoted -- and
+    # (tools/pmc_passes.sh -> profiles/r06_ba_pmc.json: FETCH_SIZE doubled as the gfx950 guide prescribes, + WRITE_SIZE) are quoted -- and
     # refused when they were taken on other kernels than the pair this block times
-    out["roofline"]["traffic"] = _pmc_traffic("r05_ba_pmc.json", ("23schur_point_coop_kernelILi0E", "17schur_shot_kernel"), nobs, MATVEC_BYTES_PER_OBS)
+    out["roofline"]["traffic"] = _pmc_traffic("r06_ba_pmc.json", ("23schur_point_coop_kernelILi0E", "17schur_shot_kernel"), nobs, MATVEC_BYTES_PER_OBS)
     out["lm_iteration"] = lm_iteration_line(g, nobs)
     if grid:
         for key, fn in (("grid_topology", lambda: run_grid(ctx, points=points, seed=seed, cpu_iters=2 if cpu_baseline else 0)),

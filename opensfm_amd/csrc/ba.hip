@@ -5439,7 +5439,10 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     // where the side stream starts: the per-shot assembly (LDS atomics) leaves HBM idle, so the border's passes run beside it; the
     // matrix-core assembly fills the CUs (four workgroups of 39 KB LDS each), and the side stream starts after it, beside the cyclic
     // reduction's levels -- one 117 KB workgroup per CU, which leaves the CU room for a border workgroup
-    int fork_at = win_band ? 1 : 0;  // 0: before the assembly, 1: after it, 2: after the first level of the cyclic reduction
+    // (round 6: with the matrix-core assembly the side stream starts behind the FIRST LEVEL of the cyclic reduction -- its 278 workgroups of 117 KB
+    //  LDS need every CU twice over, the later levels leave half of them and more to the border's kernels: 3.13 -> 3.09 ms per LM iteration at
+    //  configs[4], profiles/r06_ba_variants.json; everything on one stream: 3.31)
+    int fork_at = win_band ? (d.ncl > 1 && O->preconditioner == 0 ? 2 : 1) : 0;  // 0: before the assembly, 1: after it, 2: after the first level of the cyclic reduction
     if (const char *fk = getenv("OSFM_BA_FORK")) fork_at = std::min(2, std::max(0, fk[0] - '0'));
     const bool fork_late = fork_at >= 1;
     if (sv.st2 && !fork_late) {

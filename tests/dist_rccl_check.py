@@ -57,6 +57,13 @@ def main():
                 assert np.array_equal(fc, c_s) and np.array_equal(fm, m_s)
                 cd, md = odist.all_gather_match_graph_device(g, len(pairs), rank, world, local_rank, block=block, reorder=reorder,
                                                              force_collective=True)
+                # (c) the deferred host copy (bench.py's N-rank step): the handle is waited for after another matching call has been queued
+                h = odist.all_gather_match_graph_device(g, len(pairs), rank, world, local_rank, block=block, reorder=reorder, force_collective=True,
+                                                        defer_host_copy=True)
+                g2 = matching.match_pairs(store, mine, keep_device=True)
+                ch, mh = h.wait()
+                g2.close()
+                assert np.array_equal(ch, cd) and np.array_equal(mh, md)
                 g.close()
                 if reorder:
                     assert np.array_equal(cg, counts) and np.array_equal(mg, m)

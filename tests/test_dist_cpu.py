@@ -62,6 +62,10 @@ def _worker(rank, world, port, n_pairs, seed, q, empty_rank=-1):
     c4, m4 = odist.all_gather_match_graph_device(HostGraph(counts_all[idx], mine), n_pairs, rank, world, block=16, reorder=False)
     ok = ok and np.array_equal(c4, counts_all[order]) and np.array_equal(m4, want_m.reshape(-1, 2))
     ok = ok and tm["bytes_to_host"] == 4 * n_pairs + 8 * len(matches_all)
+    # the deferred form bench.py's N-rank step uses (round 6): a handle comes back, wait() hands over the same graph
+    h = odist.all_gather_match_graph_device(HostGraph(counts_all[idx], mine), n_pairs, rank, world, block=16, reorder=False, defer_host_copy=True)
+    c5, m5 = h.wait()
+    ok = ok and isinstance(h, odist.PendingGraph) and np.array_equal(c5, c4) and np.array_equal(m5, m4)
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 

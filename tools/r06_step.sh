@@ -8,7 +8,7 @@ cd /root/repo
 python -c "import oracle; oracle.build()" > $OUT/oracle_build.log 2>&1
 for what in "$@"; do
   case $what in
-    tests) timeout 900 python -m pytest tests/test_gpu_ba.py tests/test_gpu_bundle_general.py tests/test_gpu_bundle_facade.py tests/test_gpu_golden_fisheye624.py tests/test_gpu_berlin.py tests/test_gpu_compat.py -m gpu -q -x --durations=5 > $OUT/pytest_ba.txt 2>&1; echo "pytest rc $?"; tail -12 $OUT/pytest_ba.txt ;;
+    tests) timeout 900 python -m pytest tests/test_gpu_ba.py tests/test_gpu_bundle_general.py tests/test_gpu_bundle_facade.py tests/test_gpu_golden_fisheye624.py tests/test_gpu_berlin.py tests/test_gpu_compat.py tests/test_gpu_flow.py -m gpu -q -x --durations=5 > $OUT/pytest_ba.txt 2>&1; echo "pytest rc $?"; tail -12 $OUT/pytest_ba.txt ;;
     alltests) timeout 1200 python -m pytest tests -m gpu -q --durations=8 > $OUT/pytest_gpu.txt 2>&1; echo "pytest rc $?"; tail -14 $OUT/pytest_gpu.txt ;;
     lines) timeout 900 python tools/r06_ba_quick.py lines > $OUT/ba_lines.json 2> $OUT/ba_lines.err; echo "lines rc $?"; cat $OUT/ba_lines.json | python -c "
 import json,sys
