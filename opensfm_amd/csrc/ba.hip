@@ -329,6 +329,8 @@ struct Dev {
   double *scal;     // device scalars
   double *partial;  // block partial sums
   double *dotp;     // the mat-vec's shares of p . Ap, one per workgroup of the finish kernel
+  double *rrp;      // pcg_step1_kernel's shares of r . r, one per workgroup (their own buffer: the straight-line iteration reads them after the
+                    // back-substitution and the evaluation have reused `partial`)
   int gen;          // 1: generic mode, the fields of g are set
   GenDev g;
 };
@@ -5167,6 +5169,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
   const long nbmax = std::max<long>(std::max<long>(nblk(M), nblk(3L * NP)), d.nwg);
   d.partial = A.alloc<double>((size_t)2 * nbmax + 16, e);
   d.dotp = A.alloc<double>((size_t)nblk(d.nred) + NC + 16, e);
+  d.rrp = A.alloc<double>((size_t)nblk(d.nred) + 16, e);
   // block half-bandwidth of the shot-shot coupling (shots in caller order): bw_true, from track_width_kernel above
   // half-width up to 10: exact band, cyclic reduction in LDS; up to kWMaxBw: exact band, cyclic reduction over dense clusters (dbcr_*); beyond: truncated to kMaxBw
   const bool wide = O->preconditioner == 0 && S >= 2 && bw_true > kMaxBw && bw_true <= kWMaxBw && getenv("OSFM_BA_NO_WIDE") == nullptr;
@@ -5392,6 +5395,8 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
   double radius = O->initial_radius > 0 ? O->initial_radius : 1e4;
   double decrease_factor = 2.0;
   bool need_prepare = true, have_scale = false;
+  bool fast_ok = getenv("OSFM_BA_NO_FAST") == nullptr;  // the straight-line iteration is tried (until it fails once in this solve)
+  const int fast_fail_at = getenv("OSFM_BA_FAST_FAIL_AT") ? atoi(getenv("OSFM_BA_FAST_FAIL_AT")) : -1;
   int n_invalid = 0, iter = 0;
   double gmax = 0;
   Rp->termination = 0;
@@ -5698,7 +5703,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     if (mark("factorisation + border solve") != OSFM_OK) return OSFM_E_HIP;
     int *hst = sv.hstat;
     hst[0] = hst[1] = hst[2] = 0;
-    auto start_pcg = [&]() -> int {
+    auto start_pcg_enqueue = [&]() {
       // block-Jacobi blocks (6x6 per shot, 3x3 per camera): the fallback preconditioner, and the camera rows of the band
       // preconditioners -- not needed when the cyclic reduction came out with the exact camera border
       if (gen) {
@@ -5718,8 +5723,102 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       sv.precond(d.b, d.z, z_solved);
       z_solved = false;
       hipLaunchKernelGGL(pcg_init_kernel, dim3(1), dim3(1024), 0, st, d.b, d.z, d.x, d.r, d.p, nred, d.scal + 0, d.scal + 4, (const double *)d.sc_red, d.y);  // x = 0, r = b, p = z, y = sc p
+    };
+    auto start_pcg = [&]() -> int {
+      start_pcg_enqueue();
       return sv.fetch(d.scal, 5, 0, d_status, (try_bcr || wide) ? 3 : 0, 0);
     };
+    // one CG iteration's first half: the mat-vec and x += alpha p, r -= alpha Ap (r . r shares into rrp)
+    auto pcg_half = [&](int rz_cur) {
+      sv.matvec(d.p, d.Ap, radius, true, d.dotp);
+      hipLaunchKernelGGL(pcg_step1_kernel, dim3(nbr), dim3(TPB), 0, st, d.x, d.r, (const double *)d.p, (const double *)d.Ap, nred, (const double *)(d.scal + rz_cur),
+                         (const double *)d.dotp, sv.matvec_parts(), d.scal + 1, d.rrp);
+    };
+    auto swap_blocks = [&]() {
+      std::swap(d.cams, d.cams_n);
+      std::swap(d.poses, d.poses_n);
+      std::swap(d.pts, d.pts_n);
+      if (gen) {
+        std::swap(g.cam, g.cam_n);
+        std::swap(g.bias, g.bias_n);
+        std::swap(g.rc, g.rc_n);
+      }
+    };
+    auto relinearise_old_point = [&]() -> int {
+      swap_blocks();
+      sv.eval_enqueue(d.cams, d.poses, d.pts, true);
+      return prepare_enqueue();  // (nothing to read: cost, sum of squares and max |gradient| of this point are on the host already)
+    };
+    // Back-substitution, model change, candidate -- and the candidate is LINEARISED before the host has seen the model change (round 6;
+    // rounds 2-5 evaluated its cost alone here and, once the host had accepted the step, came back for the Jacobian): the blocks change
+    // places, the evaluation with Jacobian rows, the gradients, the LM diagonal and max |gradient| are queued behind the back-substitution,
+    // and ONE round trip brings the model change, the step's norms, the candidate's cost and its gradient norm.  An accepted step -- nearly
+    // every step of a converging problem -- has then cost one evaluation instead of two (0.09 ms at configs[4]) and one round trip instead
+    // of two; a rejected or invalid step puts the blocks back and linearises the old point again (the same kernels on the same inputs: the
+    // same bits as before).
+    auto candidate_enqueue = [&]() -> int {
+      hipLaunchKernelGGL(scale_vec_kernel, dim3(nbr), dim3(TPB), 0, st, d.sc_red, d.x, d.y, nred);
+      if (gen) {
+        if (M > 0 && g.KW > 0) hipLaunchKernelGGL(gen_view_gather_kernel, dim3(nblk((long)g.NV * g.KW)), dim3(TPB), 0, st, d, (const double *)d.y);
+        if (g.NRr == 3) hipLaunchKernelGGL((gen_schur_point_kernel<3, 2>), dim3(d.nwg), dim3(kCoopObs), 0, st, d, (const double *)d.y);
+        else hipLaunchKernelGGL((gen_schur_point_kernel<2, 2>), dim3(d.nwg), dim3(kCoopObs), 0, st, d, (const double *)d.y);
+      } else
+        hipLaunchKernelGGL(schur_point_coop_kernel<2>, dim3(d.nwg), dim3(kCoopObs), 0, st, d, d.y);
+      if (gen) hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(1024), 0, st, d.partial, (long)d.nwg, 1, d.scal + 16);  // the model change's observation part
+      if (gen) {
+        hipLaunchKernelGGL(gen_candidate_kernel, dim3(1), dim3(1024), 0, st, d, (const double *)d.y, d.scal + 16);
+        hipLaunchKernelGGL(gen_prior_kernel, dim3(nblk(sv.gen_nprior(), 256)), dim3(256), sv.gen_prior_lds(2), st, d, (const double *)g.cam, (const double *)g.bias,
+                           (const double *)g.rc, (const double *)d.poses, 2, (const double *)d.y, d.scal + 16);
+        if (g.pt_prior_sigma && NP > 0) hipLaunchKernelGGL(gen_point_prior_kernel, dim3(nblk(NP)), dim3(TPB), 0, st, d, (const double *)d.pts, 2, d.scal + 16);
+      } else
+        hipLaunchKernelGGL(candidate_kernel, dim3(1), dim3(1024), 0, st, d, (const double *)d.y, (const double *)d.partial, (long)d.nwg, d.scal + 16);
+      hipLaunchKernelGGL(candidate_points_kernel, dim3(nblk(3L * NP)), dim3(TPB), 0, st, d);
+      hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(1024), 0, st, d.partial, (long)nblk(3L * NP), 2, d.scal + 20);
+      swap_blocks();
+      sv.eval_enqueue(d.cams, d.poses, d.pts, true);
+      return prepare_enqueue();
+    };
+    bool bad = false;
+    int k = 0;
+    double *rr_part = sv.hrr;
+    const double *dec = hs;  // scal[8 .. 21] of the iteration's last round trip
+    // ---- the straight-line iteration (round 6) ----
+    // With the exact band and the exact border (or constant cameras) the preconditioner is the reduced matrix: CG is one mat-vec, and nothing
+    // the host learns on the way -- the factorisation's status words, |b|, the residual after the first iterate -- changes what is launched
+    // next, except in the rare failure.  So everything is queued back to back: the start of PCG, its first iteration, the back-substitution,
+    // the candidate and its linearisation; ONE round trip brings the status words, the PCG scalars, the shares of r . r, the model change
+    // and the candidate's cost.  When a status word or the residual says no, the blocks go back, the old point is linearised again and the
+    // iteration is redone on the careful path below (which also keeps the fallbacks); after one such failure a solve stays on the careful
+    // path.  Three round trips per LM iteration become one (OSFM_BA_NO_FAST keeps the careful path: the cross-check of the tests).
+    bool fast_done = false;
+    const bool exact_expected = (try_bcr || wide) && (try_border || (gen ? g.NB == 0 : all_cams_fixed)) && O->pcg_direct_tolerance > O->pcg_tolerance;
+    if (exact_expected && fast_ok && !trace) {
+      start_pcg_enqueue();
+      pcg_half(0);
+      rc = candidate_enqueue();
+      if (rc != OSFM_OK) return rc;
+      {
+        const int rcf = sv.fetch(d.scal, 22, 0, d_status, 3, 0, d.rrp, nbr);
+        if (rcf != OSFM_OK) return rcf;
+      }
+      const double bb1 = hs[4];
+      double rr = 0.0;
+      for (int q = 0; q < nbr; q++) rr += rr_part[(size_t)q];
+      const bool status_ok = !((try_bcr && hst[0] != 0) || (sv.use_wide && hst[2] != 0) || (sv.use_border && hst[1] != 0));
+      const double tol_first = std::max(O->pcg_tolerance, O->pcg_direct_tolerance);
+      const bool forced_failure = fast_fail_at == iter;  // test knob OSFM_BA_FAST_FAIL_AT: the way back to the careful path, exercised on purpose
+      if (!forced_failure && status_ok && bb1 == bb1 && !std::isinf(bb1) && bb1 > 0 && rr == rr && rr <= tol_first * tol_first * bb1) {
+        k = 1;
+        Rp->pcg_iterations_total += 1;
+        dec = hs + 8;
+        fast_done = true;
+      } else {  // back to the old point; the factorisation, the border and the right-hand side stand (the status words are read again below)
+        fast_ok = false;
+        rc = relinearise_old_point();
+        if (rc != OSFM_OK) return rc;
+      }
+    }
+    if (!fast_done) {
     {
       const int rcs = start_pcg();
       if (rcs != OSFM_OK) return rcs;
@@ -5740,9 +5839,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       if (rcs != OSFM_OK) return rcs;
     }
     const double bb = hs[4];
-    bool bad = !(bb == bb) || std::isinf(bb);
-    int k = 0;
-    double *rr_part = sv.hrr;
+    bad = !(bb == bb) || std::isinf(bb);
     if (!bad && bb > 0) {
       const double tol2 = O->pcg_tolerance * O->pcg_tolerance * bb;
       // the preconditioner is the reduced matrix itself: the first iterate is a direct solve (see osfm_ba_options_default)
@@ -5752,16 +5849,14 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       // r.z lives in scal[0] and scal[2] alternately (rz_cur: the current one); p . Ap is added up from the mat-vec's shares by the step kernel
       int rz_cur = 0, rz_nxt = 2;
       for (k = 1; k <= kmax; k++) {
-        sv.matvec(d.p, d.Ap, radius, true, d.dotp);
-        hipLaunchKernelGGL(pcg_step1_kernel, dim3(nbr), dim3(TPB), 0, st, d.x, d.r, (const double *)d.p, (const double *)d.Ap, nred, (const double *)(d.scal + rz_cur),
-                           (const double *)d.dotp, sv.matvec_parts(), d.scal + 1, d.partial);
+        pcg_half(rz_cur);
         // the convergence test comes before the preconditioner is applied to the new residual: the last iteration of a solve does not
         // pay for a walk of the cyclic reduction whose result nobody reads
         // (an exact band -- with the camera border on top, or with constant cameras as in local bundle adjustment -- makes the
         // preconditioner the matrix itself: CG is done after one or two iterations, so the first two are polled)
         if ((k & 3) == 0 || k == kmax || ((sv.use_bcr || sv.use_wide) && k <= 2)) {
           {
-            const int rcf = sv.fetch(nullptr, 0, 0, nullptr, 0, 0, d.partial, nbr);
+            const int rcf = sv.fetch(nullptr, 0, 0, nullptr, 0, 0, d.rrp, nbr);
             if (rcf != OSFM_OK) return rcf;
           }
           double rr = 0.0;
@@ -5781,56 +5876,17 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     if (mark("pcg") != OSFM_OK) return OSFM_E_HIP;
     if (trace) fprintf(stderr, "[osfm_ba trace] iteration %d: %d pcg iterations, status %d %d %d, band %d bcr %d wide %d dense %d border %d\n", iter, k, hst[0], hst[1], hst[2],
                        (int)sv.use_band, (int)sv.use_bcr, (int)sv.use_wide, (int)(sv.use_wide && dense_cr), (int)sv.use_border);
-    // back-substitution, model change, candidate
-    hipLaunchKernelGGL(scale_vec_kernel, dim3(nbr), dim3(TPB), 0, st, d.sc_red, d.x, d.y, nred);
-    if (gen) {
-      if (M > 0 && g.KW > 0) hipLaunchKernelGGL(gen_view_gather_kernel, dim3(nblk((long)g.NV * g.KW)), dim3(TPB), 0, st, d, (const double *)d.y);
-      if (g.NRr == 3) hipLaunchKernelGGL((gen_schur_point_kernel<3, 2>), dim3(d.nwg), dim3(kCoopObs), 0, st, d, (const double *)d.y);
-      else hipLaunchKernelGGL((gen_schur_point_kernel<2, 2>), dim3(d.nwg), dim3(kCoopObs), 0, st, d, (const double *)d.y);
-    } else
-      hipLaunchKernelGGL(schur_point_coop_kernel<2>, dim3(d.nwg), dim3(kCoopObs), 0, st, d, d.y);
-    if (gen) hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(1024), 0, st, d.partial, (long)d.nwg, 1, d.scal + 16);  // the model change's observation part
-    if (gen) {
-      hipLaunchKernelGGL(gen_candidate_kernel, dim3(1), dim3(1024), 0, st, d, (const double *)d.y, d.scal + 16);
-      hipLaunchKernelGGL(gen_prior_kernel, dim3(nblk(sv.gen_nprior(), 256)), dim3(256), sv.gen_prior_lds(2), st, d, (const double *)g.cam, (const double *)g.bias,
-                         (const double *)g.rc, (const double *)d.poses, 2, (const double *)d.y, d.scal + 16);
-      if (g.pt_prior_sigma && NP > 0) hipLaunchKernelGGL(gen_point_prior_kernel, dim3(nblk(NP)), dim3(TPB), 0, st, d, (const double *)d.pts, 2, d.scal + 16);
-    } else
-      hipLaunchKernelGGL(candidate_kernel, dim3(1), dim3(1024), 0, st, d, (const double *)d.y, (const double *)d.partial, (long)d.nwg, d.scal + 16);
-    hipLaunchKernelGGL(candidate_points_kernel, dim3(nblk(3L * NP)), dim3(TPB), 0, st, d);
-    hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(1024), 0, st, d.partial, (long)nblk(3L * NP), 2, d.scal + 20);
-    // The candidate is LINEARISED before the host has seen the model change (round 6; rounds 2-5 evaluated its cost alone here and, once the
-    // host had accepted the step, came back for the Jacobian): the blocks change places, the evaluation with Jacobian rows, the gradients, the
-    // LM diagonal and max |gradient| are queued behind the back-substitution, and ONE round trip brings the model change, the step's norms,
-    // the candidate's cost and its gradient norm.  An accepted step -- nearly every step of a converging problem -- has then cost one
-    // evaluation instead of two (0.09 ms at configs[4]) and one round trip instead of two; a rejected or invalid step puts the blocks back
-    // and linearises the old point again (the same kernels on the same inputs: the same bits as before).
-    auto swap_blocks = [&]() {
-      std::swap(d.cams, d.cams_n);
-      std::swap(d.poses, d.poses_n);
-      std::swap(d.pts, d.pts_n);
-      if (gen) {
-        std::swap(g.cam, g.cam_n);
-        std::swap(g.bias, g.bias_n);
-        std::swap(g.rc, g.rc_n);
-      }
-    };
-    auto relinearise_old_point = [&]() -> int {
-      swap_blocks();
-      sv.eval_enqueue(d.cams, d.poses, d.pts, true);
-      return prepare_enqueue();  // (nothing to read: cost, sum of squares and max |gradient| of this point are on the host already)
-    };
-    swap_blocks();
-    sv.eval_enqueue(d.cams, d.poses, d.pts, true);
-    rc = prepare_enqueue();
+    rc = candidate_enqueue();
     if (rc != OSFM_OK) return rc;
     {
       const int rcf = sv.fetch(d.scal + 8, 14, 0);  // scal[8..21]
       if (rcf != OSFM_OK) return rcf;
     }
+    dec = hs;
+    }  // (careful path)
     lin_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_lin).count();
-    const double model_change = hs[8];
-    const double step_sq = hs[9] + hs[12], x_sq = hs[10] + hs[13];
+    const double model_change = dec[8];
+    const double step_sq = dec[9] + dec[12], x_sq = dec[10] + dec[13];
     if (bad || !(model_change > 0)) {  // HandleInvalidStep + StepIsInvalid
       radius *= 0.5;
       rc = relinearise_old_point();
@@ -5839,7 +5895,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       continue;
     }
     n_invalid = 0;
-    const double cost_n = hs[0];
+    const double cost_n = dec[0];
     const double step_norm = std::sqrt(step_sq), x_norm = std::sqrt(x_sq);
     if (step_norm <= O->parameter_tolerance * (x_norm + O->parameter_tolerance)) {
       Rp->termination = 3;
@@ -5861,9 +5917,9 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       radius = std::fmin(1e16, radius);
       decrease_factor = 2.0;
       Rp->successful_steps++;
-      cost = hs[0];
-      sumsq = hs[1];
-      gmax = hs[2];
+      cost = dec[0];
+      sumsq = dec[1];
+      gmax = dec[2];
     } else {  // StepRejected
       radius = radius / decrease_factor;
       decrease_factor *= 2.0;

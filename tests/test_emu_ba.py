@@ -73,6 +73,40 @@ def test_generic_priors_with_a_border_beyond_the_lds_copy(oracle_lib):
     _compare_general(oracle_lib, pr, iters=3, rtol=1e-8)
 
 
+def test_straight_line_iteration_equals_the_careful_path(monkeypatch):
+    """round 6: an LM iteration whose preconditioner is expected to be exact is queued in one piece (start of PCG, its one iteration, the
+    back-substitution, the candidate and its linearisation) and verified by a single round trip.  Same kernels on the same inputs as the
+    careful path (OSFM_BA_NO_FAST): the same bits -- also when the verification fails (forced here at LM iteration 2: the blocks go back, the old
+    point is linearised again, the iteration is redone on the careful path), for the [k1 k2 focal] kernels, a local problem (constant
+    cameras) and the generic rows"""
+    from opensfm_amd import bundle
+
+    def runs(solve, pr, iters):
+        out = []
+        for env in ({"OSFM_BA_NO_FAST": "1"}, {}, {"OSFM_BA_FAST_FAIL_AT": "2"}):
+            with monkeypatch.context() as mp:
+                for k, v in env.items():
+                    mp.setenv(k, v)
+                with emulated():
+                    out.append(solve(pr, {"bundle_max_iterations": iters}, **NO_TOL))
+        return out
+
+    pr = synthetic.make_ba_scene(20, 300, 5, seed=11)
+    careful, fast, failed = runs(bundle.bundle_arrays, pr, 4)
+    assert careful["pcg_iterations"] >= 4
+    for g in (fast, failed):
+        assert np.array_equal(g["cost_history"], careful["cost_history"]) and np.array_equal(g["shot_pose"], careful["shot_pose"])
+        assert np.array_equal(g["points"], careful["points"]) and np.array_equal(g["cam_params"], careful["cam_params"])
+    sub = bundle.local_problem(synthetic.make_ba_scene(60, 900, 6, seed=7), 30)[0]
+    careful, fast, failed = runs(bundle.bundle_arrays, sub, 3)
+    for g in (fast, failed):
+        assert np.array_equal(g["cost_history"], careful["cost_history"]) and np.array_equal(g["shot_pose"], careful["shot_pose"])
+    prg = synthetic.make_bundle_scene(models=("brown",), n_instances=8, n_points=100, rig=False, gps=False, n_gcp=0, up_vectors=False, seed=7)
+    careful, fast, failed = runs(bundle.bundle_general_arrays, prg, 3)
+    for g in (fast, failed):
+        assert np.array_equal(g["cost_history"], careful["cost_history"]) and np.array_equal(g["rig_instance_pose"], careful["rig_instance_pose"])
+
+
 def test_generic_mode_equals_the_specialised_kernels(oracle_lib):
     """on the domain both cover ([k1 k2 focal] perspective cameras, identity rig) the generic rows and the specialised ones walk the same
     trajectory"""
