@@ -627,28 +627,42 @@ double evaluate(const Problem& P, const Options& O, const Layout& L, const State
   return cost;
 }
 
-bool cholesky_solve(std::vector<double>& Amat, std::vector<double>& b, int n) {  // in place, lower
+// In place, lower.  Round 6: the factorisation keeps to the ENVELOPE of the matrix (first[i] = the first non-zero column of row i; the factor's
+// fill stays inside it): the reduced system of a sequence is a band plus a few dense border rows, and the plain triple loop -- 9e12 multiply-adds
+// at the 30 016 unknowns of configs[4] -- was what kept the oracle from following the product to that size.  The terms left out are products
+// with exact zeros, so every entry is the same sum as before: the same bits (tests/test_oracle_bundle_general.py compares the two forms).
+bool cholesky_solve(std::vector<double>& Amat, std::vector<double>& b, int n) {
+  std::vector<int> first((size_t)n);
+#pragma omp parallel for schedule(static) num_threads(8) if (n > 512)
+  for (int i = 0; i < n; i++) {
+    int k = 0;
+    while (k < i && Amat[(size_t)i * n + k] == 0.0) k++;
+    first[(size_t)i] = k;
+  }
   for (int j = 0; j < n; j++) {
     double dgn = Amat[(size_t)j * n + j];
-    for (int k = 0; k < j; k++) dgn -= Amat[(size_t)j * n + k] * Amat[(size_t)j * n + k];
+    const int fj = first[(size_t)j];
+    for (int k = fj; k < j; k++) dgn -= Amat[(size_t)j * n + k] * Amat[(size_t)j * n + k];
     if (!(dgn > 0) || !std::isfinite(dgn)) return false;
     const double l = std::sqrt(dgn);
     Amat[(size_t)j * n + j] = l;
 #pragma omp parallel for schedule(static) num_threads(8) if (n - j > 512)
     for (int i = j + 1; i < n; i++) {
+      if (first[(size_t)i] > j) continue;  // outside the envelope: the entry is zero and stays zero
       double v = Amat[(size_t)i * n + j];
-      for (int k = 0; k < j; k++) v -= Amat[(size_t)i * n + k] * Amat[(size_t)j * n + k];
+      for (int k = std::max(first[(size_t)i], fj); k < j; k++) v -= Amat[(size_t)i * n + k] * Amat[(size_t)j * n + k];
       Amat[(size_t)i * n + j] = v / l;
     }
   }
   for (int i = 0; i < n; i++) {
     double v = b[i];
-    for (int k = 0; k < i; k++) v -= Amat[(size_t)i * n + k] * b[k];
+    for (int k = first[(size_t)i]; k < i; k++) v -= Amat[(size_t)i * n + k] * b[k];
     b[i] = v / Amat[(size_t)i * n + i];
   }
-  for (int i = n - 1; i >= 0; i--) {
+  for (int i = n - 1; i >= 0; i--) {  // (column i of the factor: rows k whose envelope reaches column i)
     double v = b[i];
-    for (int k = i + 1; k < n; k++) v -= Amat[(size_t)k * n + i] * b[k];
+    for (int k = i + 1; k < n; k++)
+      if (first[(size_t)k] <= i) v -= Amat[(size_t)k * n + i] * b[k];
     b[i] = v / Amat[(size_t)i * n + i];
   }
   return true;
