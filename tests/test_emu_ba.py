@@ -107,6 +107,23 @@ def test_straight_line_iteration_equals_the_careful_path(monkeypatch):
         assert np.array_equal(g["cost_history"], careful["cost_history"]) and np.array_equal(g["rig_instance_pose"], careful["rig_instance_pose"])
 
 
+@pytest.mark.skipif(not os.environ.get("OSFM_SLOW_TESTS"), reason="seven minutes on the emulation (hundreds of block-Jacobi CG iterations, a barrier tree per mat-vec); "
+                    "tests/test_gpu_ba.py::test_tracks_longer_than_the_cooperative_tile runs the same on the device")
+def test_tracks_longer_than_the_cooperative_tile(oracle_lib):
+    """a point seen from more than 256 shots: the evaluation (its point block is added from the stored rows by one thread), the mat-vec's pass A,
+    the right-hand side and the back-substitution take their strided whole-workgroup paths; block-Jacobi preconditioner (the band of such a
+    scene is the whole matrix)"""
+    from opensfm_amd import bundle
+
+    pr = synthetic.make_ba_scene(300, 12, 290, seed=15, outlier_frac=0.0)
+    assert np.bincount(pr["obs_point"]).max() > 256
+    with emulated():
+        g = bundle.bundle_arrays(pr, {"bundle_max_iterations": 3}, preconditioner=1, **NO_TOL)
+    o = oracle_lib.ba_solve(pr, max_iterations=3, **NO_TOL)
+    assert np.allclose(g["cost_history"], o["cost_history"], rtol=1e-8), (g["cost_history"], o["cost_history"])
+    assert abs(_rmse_px(g["reproj_err"]) - _rmse_px(o["reproj_err"])) < 1e-4
+
+
 def test_generic_mode_equals_the_specialised_kernels(oracle_lib):
     """on the domain both cover ([k1 k2 focal] perspective cameras, identity rig) the generic rows and the specialised ones walk the same
     trajectory"""

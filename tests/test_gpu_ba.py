@@ -238,6 +238,20 @@ def test_long_tracks_take_the_strided_matvec_path(oracle_lib, gpu_ctx):
     assert abs(_rmse_px(g["reproj_err"]) - _rmse_px(o["reproj_err"])) < 1e-4
 
 
+def test_tracks_longer_than_the_cooperative_tile(oracle_lib, gpu_ctx):
+    """points seen from more than 256 shots (the tile of the cooperative kernels): the evaluation, pass A of the mat-vec, the camera border's
+    pass A, the right-hand side and the back-substitution take their strided paths; the exact band of such a scene is the whole matrix"""
+    from opensfm_amd import bundle
+
+    pr = synthetic.make_ba_scene(300, 40, 290, seed=15, outlier_frac=0.0)
+    assert np.bincount(pr["obs_point"]).max() > 256
+    o = oracle_lib.ba_solve(pr, max_iterations=5, **NO_TOL)
+    for pre in (0, 1):
+        g = bundle.bundle_arrays(pr, {"bundle_max_iterations": 5}, preconditioner=pre, **NO_TOL)
+        assert np.allclose(g["cost_history"], o["cost_history"], rtol=1e-7), pre
+        assert abs(_rmse_px(g["reproj_err"]) - _rmse_px(o["reproj_err"])) < 1e-4
+
+
 def test_up_vector_prior_matches_oracle(oracle_lib, gpu_ctx):
     """Absolute up-vector prior (align_method orientation_prior, ba_helpers.cc:609-621,688-692;
     UpVectorError + CauchyLoss(1), bundle_adjuster.cc:955-970): a dense 3x3 prior block on every
