@@ -159,6 +159,11 @@ int osfm_match_l2_ratio_ex(osfm_ctx *ctx, const float *A, int nA, const float *B
  * A: nA x width_bytes, B: nB x width_bytes (1..64 bytes). */
 int osfm_match_hamming_ratio(osfm_ctx *ctx, const uint8_t *A, int nA, const uint8_t *B, int nB, int width_bytes,
                              double ratio, int symmetric, int32_t *out_pairs, int cap, int *out_n);
+/* ... with flags: OSFM_MATCH_SQUARED_RATIO = match_flann / match_flann_symmetric on bit strings (matching.py:683-720; features.py:660-667 builds
+ * cv2's LSH index for uint8 descriptors): searched exactly here, the test `d0 < lowes_ratio ** 2 * d1` in doubles on the int Hamming distances,
+ * one-way matching queries with B (round 6) */
+int osfm_match_hamming_ratio_ex(osfm_ctx *ctx, const uint8_t *A, int nA, const uint8_t *B, int nB, int width_bytes,
+                                double ratio, int symmetric, int flags, int32_t *out_pairs, int cap, int *out_n);
 
 /*
  * Leaf: cv2.findFundamentalMat(p1, p2, FM_RANSAC, thr, conf) as used by

@@ -90,6 +90,8 @@ SIGNATURES = {
     "osfm_store_upload_binary": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint8), C.c_int, C.POINTER(C.c_double)]),
     "osfm_match_hamming_ratio": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint8), C.c_int, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_double, C.c_int,
                                            C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int)]),
+    "osfm_match_hamming_ratio_ex": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint8), C.c_int, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
+                                              C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int)]),
     "osfm_store_destroy": (None, [C.c_void_p]),
     "osfm_store_bytes": (C.c_int64, [C.c_void_p]),
     "osfm_match_params_default": (None, [C.POINTER(MatchParams)]),

@@ -779,24 +779,27 @@ extern "C" int osfm_match_l2_ratio_ex(osfm_ctx *ctx, const float *A, int nA, con
 }
 
 // match_brute_force[_symmetric] on uint8 arrays: cv2 BruteForce-Hamming (matching.py:737-740); same lone-query handling as the L2 leaf
-extern "C" int osfm_match_hamming_ratio(osfm_ctx *ctx, const uint8_t *A, int nA, const uint8_t *B, int nB, int width_bytes, double ratio,
-                                        int symmetric, int32_t *out_pairs, int cap, int *out_n) {
+extern "C" int osfm_match_hamming_ratio_ex(osfm_ctx *ctx, const uint8_t *A, int nA, const uint8_t *B, int nB, int width_bytes, double ratio,
+                                           int symmetric, int flags, int32_t *out_pairs, int cap, int *out_n) {
   OSFM_REQUIRE(ctx && out_n && (out_pairs || cap == 0), OSFM_E_INVALID, "osfm_match_hamming_ratio: null argument");
   OSFM_REQUIRE(width_bytes >= 1 && width_bytes <= 64, OSFM_E_UNSUPPORTED, "osfm_match_hamming_ratio: %d bytes per descriptor (1..64)", width_bytes);
   OSFM_REQUIRE(nA >= 0 && nB >= 0 && (A || nA == 0) && (B || nB == 0), OSFM_E_INVALID, "bad descriptor arrays");
   *out_n = 0;
   OSFM_CTX_LOCK(ctx);
-  if (nB < 2 || nA < 1 || (symmetric && nA < 2)) return OSFM_OK;  // knnMatch returns < 2 neighbours for a train set of < 2 rows
-  const bool lone = nA == 1;
-  const int mA = lone ? 2 : nA;
-  const int32_t counts[2] = {mA, nB};
+  // (the lone-query rule and match_flann's query side: as osfm_match_l2_ratio_ex)
+  const bool query_is_b = !symmetric && (flags & OSFM_MATCH_SQUARED_RATIO);
+  const int n_query = query_is_b ? nB : nA, n_train = query_is_b ? nA : nB;
+  if (n_train < 2 || n_query < 1 || (symmetric && n_query < 2)) return OSFM_OK;  // knnMatch returns < 2 neighbours for a train set of < 2 rows
+  const bool lone = n_query == 1;
+  const int mA = (lone && !query_is_b) ? 2 : nA, mB = (lone && query_is_b) ? 2 : nB;
+  const int32_t counts[2] = {mA, mB};
   osfm_store *st = nullptr;
   int rc = osfm_store_create(ctx, 2, counts, &st);
   if (rc != OSFM_OK) return rc;
-  std::vector<uint8_t> desc((size_t)(mA + nB) * width_bytes);
+  std::vector<uint8_t> desc((size_t)(mA + mB) * width_bytes);
   for (int r = 0; r < mA; ++r) memcpy(desc.data() + (size_t)r * width_bytes, A + (size_t)(r < nA ? r : 0) * width_bytes, (size_t)width_bytes);
-  memcpy(desc.data() + (size_t)mA * width_bytes, B, (size_t)nB * width_bytes);
-  std::vector<double> pts((size_t)(mA + nB) * 2, 0.0);
+  for (int r = 0; r < mB; ++r) memcpy(desc.data() + (size_t)(mA + r) * width_bytes, B + (size_t)(r < nB ? r : 0) * width_bytes, (size_t)width_bytes);
+  std::vector<double> pts((size_t)(mA + mB) * 2, 0.0);
   rc = osfm_store_upload_binary(st, desc.data(), width_bytes, pts.data());
   osfm_match_result *res = nullptr;
   if (rc == OSFM_OK) {
@@ -804,6 +807,7 @@ extern "C" int osfm_match_hamming_ratio(osfm_ctx *ctx, const uint8_t *A, int nA,
     osfm_match_params_default(&prm);
     prm.lowes_ratio = ratio;
     prm.symmetric = symmetric;
+    prm.flags = flags;
     prm.robust = 0;
     const int32_t pair[2] = {0, 1};
     rc = osfm_match_pairs(ctx, st, pair, 1, &prm, &res, nullptr);
@@ -812,7 +816,7 @@ extern "C" int osfm_match_hamming_ratio(osfm_ctx *ctx, const uint8_t *A, int nA,
     int n = 0;
     for (int k = 0; k < res->counts[0]; ++k) {
       const int i = res->matches[2 * k], j = res->matches[2 * k + 1];
-      if (i >= nA) continue;  // the copy of a lone query
+      if (i >= nA || j >= nB) continue;  // the copy of a lone query
       if (n < cap) {
         out_pairs[2 * n] = i;
         out_pairs[2 * n + 1] = j;
@@ -824,4 +828,9 @@ extern "C" int osfm_match_hamming_ratio(osfm_ctx *ctx, const uint8_t *A, int nA,
   osfm_result_destroy(res);
   osfm_store_destroy(st);
   return rc;
+}
+
+extern "C" int osfm_match_hamming_ratio(osfm_ctx *ctx, const uint8_t *A, int nA, const uint8_t *B, int nB, int width_bytes, double ratio,
+                                        int symmetric, int32_t *out_pairs, int cap, int *out_n) {
+  return osfm_match_hamming_ratio_ex(ctx, A, nA, B, nB, width_bytes, ratio, symmetric, 0, out_pairs, cap, out_n);
 }

@@ -1065,7 +1065,8 @@ __global__ void __launch_bounds__(kThreads) match_hamming_kernel(MatchArgs a) {
   const int tid = threadIdx.x;
   const long p = blockIdx.x;
   if (tid == 0 && a.out_flags) a.out_flags[p] = 0;
-  const int imgC = a.pairs[2 * p], imgR = a.pairs[2 * p + 1];
+  const bool qs = !a.symmetric && a.query_second;  // queries = the pair's second image (match_flann on bit strings, round 6)
+  const int imgC = a.pairs[2 * p + (qs ? 1 : 0)], imgR = a.pairs[2 * p + (qs ? 0 : 1)];
   const int nC = a.counts[imgC], nR = a.counts[imgR];
   if (nC < 2 || nR < 2) {
     if (tid == 0) a.out_counts[p] = 0;
@@ -1076,7 +1077,7 @@ __global__ void __launch_bounds__(kThreads) match_hamming_kernel(MatchArgs a) {
   hamming_direction(binC, nC, binR, nR, a.ratio, tid, stage, colBI, nullptr);
   if (a.symmetric) hamming_direction(binR, nR, binC, nC, a.ratio, tid, stage, nullptr, rowres);
   __syncthreads();
-  emit_matches(a, p, nC, colBI, rowres, misc, tid, false);
+  emit_matches(a, p, nC, colBI, rowres, misc, tid, qs);
 }
 
 }  // namespace
@@ -1130,8 +1131,11 @@ int osfm_launch_match(osfm_ctx *ctx, const osfm_store *store, const int32_t *d_p
     if (rc != OSFM_OK) return rc;
   }
   if (store->is_binary) {
-    // bit strings: Hamming distance on the VALU, every pair in one launch; nothing is ever flagged for a second run
-    OSFM_REQUIRE(!squared_ratio, OSFM_E_UNSUPPORTED, "matcher_type FLANN on binary descriptors (cv2's LSH index) is not on the GPU path");
+    // bit strings: Hamming distance on the VALU, every pair in one launch; nothing is ever flagged for a second run.
+    // matcher_type FLANN on bit strings (round 6; cv2's LSH index searched EXACTLY, as the kd-forest is for floats): knnSearch returns int32
+    // Hamming distances, so `dists[:, 0] < lowes_ratio ** 2 * dists[:, 1]` (matching.py:695-696) is a test in DOUBLES with the squared ratio --
+    // the kernel's own test with that ratio (positive: nothing here takes a square root); one-way matching queries with the second image
+    if (squared_ratio) a.ratio = ratio * ratio;
     if (exact_kernel && d_flags != nullptr) return OSFM_OK;
     const size_t lds = (size_t)kHamStageRows * 64 + (size_t)a.ncap * 6 + 64;
     hipLaunchKernelGGL(match_hamming_kernel, dim3((unsigned)n_pairs), dim3(kThreads), lds, stream, a);

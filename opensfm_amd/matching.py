@@ -63,17 +63,19 @@ def _fptr(a: np.ndarray, t):
 # --------------------------------------------------------------------------------------------
 # leaf functions (drop-ins)
 # --------------------------------------------------------------------------------------------
-def _match_hamming_leaf(f1: np.ndarray, f2: np.ndarray, ratio: float, symmetric: bool, ctx=None) -> np.ndarray:
-    """uint8 bit strings (AKAZE MLDB, ORB): cv2's BruteForce-Hamming branch of match_brute_force (matching.py:737-740)"""
+def _match_hamming_leaf(f1: np.ndarray, f2: np.ndarray, ratio: float, symmetric: bool, ctx=None, flags: int = 0) -> np.ndarray:
+    """uint8 bit strings (AKAZE MLDB, ORB): cv2's BruteForce-Hamming branch of match_brute_force (matching.py:737-740); with
+    ``MATCH_SQUARED_RATIO`` the FLANN semantics on bit strings (matching.py:683-720 over the LSH index of features.py:660-667, searched
+    exactly): ``d0 < lowes_ratio ** 2 * d1`` in doubles on the int Hamming distances, one-way matching queries with ``f2``"""
     ctx = ctx or default_context()
     a, b = np.ascontiguousarray(f1, np.uint8), np.ascontiguousarray(f2, np.uint8)
     if a.ndim != 2 or b.ndim != 2 or a.shape[1] != b.shape[1]:
         raise ValueError("binary descriptors must be two (n, width) uint8 arrays of the same width")
-    cap = max(1, min(len(a), len(b)) if symmetric else len(a))
+    cap = max(1, min(len(a), len(b)) if symmetric else max(len(a), len(b)))
     out = np.empty((cap, 2), np.int32)
     n = C.c_int(0)
-    check(_lib.load().osfm_match_hamming_ratio(ctx.handle, _fptr(a, C.c_uint8), len(a), _fptr(b, C.c_uint8), len(b), a.shape[1], float(ratio),
-                                               int(symmetric), _fptr(out, C.c_int32), cap, C.byref(n)), "osfm_match_hamming_ratio")
+    check(_lib.load().osfm_match_hamming_ratio_ex(ctx.handle, _fptr(a, C.c_uint8), len(a), _fptr(b, C.c_uint8), len(b), a.shape[1], float(ratio),
+                                                  int(symmetric), int(flags), _fptr(out, C.c_int32), cap, C.byref(n)), "osfm_match_hamming_ratio")
     return out[: n.value]
 
 
@@ -82,9 +84,7 @@ def _match_leaf(f1: np.ndarray, f2: np.ndarray, ratio: float, symmetric: bool, c
     if f1.dtype.type == np.uint8:
         # matching.py:738-739: uint8 descriptors switch cv2 to Hamming; never reached by HAHOG/SIFT
         # (descriptors are float32 after loading, features.py:259-262)
-        if flags & _lib.MATCH_SQUARED_RATIO:
-            raise NotImplementedError("FLANN semantics on binary descriptors (cv2's LSH index) are not on the GPU path")
-        return _match_hamming_leaf(f1, f2, ratio, symmetric, ctx)
+        return _match_hamming_leaf(f1, f2, ratio, symmetric, ctx, flags)
     ctx = ctx or default_context()
     lib = _lib.load()
     a = np.ascontiguousarray(f1, np.float32)
@@ -161,7 +161,9 @@ class ExactIndex:
     the true two nearest neighbours, i.e. the result the reference converges to as ``checks`` grows."""
 
     def __init__(self, features: np.ndarray):
-        self.features = np.ascontiguousarray(features, np.float32).reshape(-1, 128)
+        f = np.asarray(features)
+        # uint8 bit strings (features.py:660-667 builds cv2's LSH index for them): kept as they are, searched exactly by Hamming distance
+        self.features = np.ascontiguousarray(f, np.uint8) if f.dtype == np.uint8 else np.ascontiguousarray(f, np.float32).reshape(-1, 128)
 
     def __len__(self) -> int:
         return len(self.features)
@@ -815,8 +817,8 @@ def match_images_with_pairs(data, config_override: Dict[str, Any], exifs: Dict[s
             raise NotImplementedError("binary descriptors of %d bytes: the GPU Hamming matcher holds 1..64 bytes per descriptor" % live[0].shape[1])
         hamming = False
         descs = [np.asarray(d, np.float32) for d in descs]
-    if hamming and (poses or use_words or use_segmentation or _matcher_flags(config) & _lib.MATCH_SQUARED_RATIO):
-        raise NotImplementedError("binary (uint8) descriptors are on the GPU path for matcher_type BRUTEFORCE without poses / segmentation")
+    if hamming and (poses or use_words or use_segmentation):
+        raise NotImplementedError("binary (uint8) descriptors are on the GPU path for matcher_type BRUTEFORCE / FLANN without poses / segmentation")
     if hamming:
         width = live[0].shape[1]
         descs = [np.asarray(d, np.uint8).reshape(-1, width) if len(d) else np.zeros((0, width), np.uint8) for d in descs]

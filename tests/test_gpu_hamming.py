@@ -61,5 +61,38 @@ def test_hamming_store_pipeline(oracle_lib, gpu_ctx):
             assert counts.sum() > 200, counts
     finally:
         store.close()
-    with pytest.raises(matching.OsfmError):
-        matching.match_pairs(matching.DescriptorStore.from_packed(desc, sc.pts, sc.offsets, hamming=True), pairs, {"matcher_type": "FLANN"})
+    # matcher_type FLANN on the binary store (round 6; rounds 4-5 refused it): the exact search with FLANN's test, `d0 < lowes_ratio ** 2 * d1` in
+    # doubles on the int distances (matching.py:695-696) -- the oracle's Hamming matcher with the squared ratio
+    store = matching.DescriptorStore.from_packed(desc, sc.pts, sc.offsets, hamming=True)
+    try:
+        counts, m = matching.match_pairs(store, pairs, {"matcher_type": "FLANN", "lowes_ratio": 0.9, "symmetric_matching": True,
+                                                        "robust_matching_min_match": 20, "robust_matching_threshold": 0.004}, robust=False)
+        for (i, j), g in zip(pairs, matching.split_matches(counts, m)):
+            di, dj = desc[sc.offsets[i]: sc.offsets[i + 1]], desc[sc.offsets[j]: sc.offsets[j + 1]]
+            mm = oracle_lib.match_hamming(di, dj, 0.9 ** 2, symmetric=True)
+            assert np.array_equal(g, mm if len(mm) >= 20 else np.zeros((0, 2), np.int32)), (i, j)
+    finally:
+        store.close()
+
+
+def test_flann_semantics_on_bit_strings_leaves(oracle_lib, gpu_ctx):
+    """match_flann / match_flann_symmetric on uint8 descriptors (the reference builds cv2's LSH index for them, features.py:660-667): the exact
+    Hamming search with the squared-ratio test in doubles; one-way matching queries with the SECOND image and lists (index feature, query
+    feature) in query order (matching.py:683-697)"""
+    from opensfm_amd import matching
+
+    rng = np.random.default_rng(9)
+    base = rng.integers(0, 256, (300, 32)).astype(np.uint8)
+    f1 = base.copy()
+    f2 = (base[rng.permutation(300)[:260]] ^ np.packbits(rng.random((260, 256)) < 0.03, axis=1)).astype(np.uint8)
+    cfg = {"lowes_ratio": 0.85}
+    i1, i2 = matching.build_flann_index(f1, cfg), matching.build_flann_index(f2, cfg)
+    assert i1.features.dtype == np.uint8
+    got = np.asarray(matching.match_flann(i1, f2, cfg)).reshape(-1, 2)
+    want = oracle_lib.match_hamming(f2, f1, 0.85 ** 2, symmetric=False)[:, ::-1]  # (query in f2, target in f1) -> (index feature, f2 feature)
+    assert len(got) > 150 and np.array_equal(got, want)
+    gs = np.asarray(matching.match_flann_symmetric(f1, i1, f2, i2, cfg)).reshape(-1, 2)
+    assert len(gs) > 150 and np.array_equal(gs, oracle_lib.match_hamming(f1, f2, 0.85 ** 2, symmetric=True))
+    # a lone query of the second image, and a train set of one row (knnSearch has no second neighbour: no match)
+    assert np.array_equal(np.asarray(matching.match_flann(i1, f2[:1], cfg)).reshape(-1, 2), oracle_lib.match_hamming(f2[:1], f1, 0.85 ** 2)[:, ::-1])
+    assert len(matching.match_flann(matching.build_flann_index(f1[:1], cfg), f2, cfg)) == 0
