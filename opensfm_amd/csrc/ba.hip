@@ -32,6 +32,32 @@ namespace {
 
 constexpr int kCoopObs = 256;  // observations per workgroup of the cooperative per-track kernels (mat-vec, point gradient)
 
+// Streaming stores (round 6): the Jacobian rows are written once by the evaluation and read much later by other kernels, 680 MB that no cache
+// holds -- written past the caches (`nt`) they cost 3 % of an LM iteration less (3.08 -> 3.00 ms at configs[4], profiles/r06_ba_variants2.json).
+// OSFM_BA_NT_LEVEL (build knob): 0 none, 1 the evaluation's rows (default), 2 every streaming store (the E blocks, w, the border's w), 3 also the
+// streaming LOADS of the rows -- levels 2 and 3 measured level with 1 (profiles/r06_ba_variants3.json: w is read back by the very next kernel)
+#ifndef OSFM_BA_NT_LEVEL
+#define OSFM_BA_NT_LEVEL 1
+#endif
+typedef double osfm_v2d __attribute__((ext_vector_type(2)));
+template <int LEVEL>
+__device__ __forceinline__ void st_stream(double *p, double v) {
+  if (OSFM_BA_NT_LEVEL >= LEVEL) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+template <int LEVEL>
+__device__ __forceinline__ void st_stream2(double *p, double a, double b) {  // p: 16-byte aligned
+  osfm_v2d v;
+  v.x = a;
+  v.y = b;
+  if (OSFM_BA_NT_LEVEL >= LEVEL) __builtin_nontemporal_store(v, reinterpret_cast<osfm_v2d *>(p));
+  else *reinterpret_cast<osfm_v2d *>(p) = v;
+}
+__device__ __forceinline__ double ld_stream(const double *p) {
+  if (OSFM_BA_NT_LEVEL >= 3) return __builtin_nontemporal_load(p);
+  return *p;
+}
+
 // the six entries of Jk (d residual / d [k1 k2 focal]) from the point (u, v) of the undistorted image plane.  ONE function for the evaluation and
 // for the point-major kernels, which rebuild Jk from the (u, v) their rows keep (round 6): the same operations in the same order, the same bits.
 __device__ __forceinline__ void jk_entries(double inv_sigma, double k1, double k2, double f, double u, double v, double *Jk) {
@@ -336,6 +362,7 @@ struct Dev {
 };
 
 #define JA(o, c) d.Jpm[(long)(c) * d.M + (o)]  /* point-major SoA */
+#define JL(o, c) ld_stream(&d.Jpm[(long)(c) * d.M + (o)])  /* ... a row's component read once by a streaming pass */
 // Components of a point-major row (round 6: 17; rounds 1-5 stored 26 -- 208 bytes per observation through a write path that sustains ~2.5 TB/s
 // here).  The translation columns of Jc are -Jp; the six entries of Jk follow from (u, v), the robust weight, sigma and the camera (row_jk:
 // project_obs's own expressions): neither is stored.  res 2 | Jp 2 x 3 | Jr 2 x 3 (the ROTATION columns of Jc) | u | v | wt
@@ -345,7 +372,7 @@ constexpr int R_JP = 2, R_JR = 8, R_U = 14, R_V = 15, R_WT = 16;
 // Jk of the observation at point-major position o (of shot s), times the robust weight, from what its row keeps
 __device__ __forceinline__ void row_jk(const Dev &d, long o, int s, double (&jk)[6]) {
   const int ci = d.shot_camera[s];
-  const double u = JA(o, R_U), v = JA(o, R_V), wt = JA(o, R_WT), sg = d.o_sigma[o];
+  const double u = JL(o, R_U), v = JL(o, R_V), wt = JL(o, R_WT), sg = d.o_sigma[o];
   const double *cam = d.cams + 3 * ci;
   const double k1 = cam[0], k2 = cam[1], f = cam[2];
   const bool other = d.cam_model && d.cam_model[ci] >= 2;  // a constant camera of another model: no [k1 k2 focal] columns
@@ -451,8 +478,9 @@ __global__ void __launch_bounds__(kCoopObs) eval_kernel(Dev d, const double *cam
     v[8] = jp[2] * jp[2] + jp[5] * jp[5];
   };
   auto store = [&](long o, const double (&row)[kRowComps]) {
+    if (d.bpMode == 3) return;  // measurement knob (OSFM_BA_BM_MODE=3): the evaluation without its row stores (results are garbage)
 #pragma unroll
-    for (int i = 0; i < kRowComps; i++) JA(o, i) = row[i];
+    for (int i = 0; i < kRowComps; i++) st_stream<1>(&JA(o, i), row[i]);
     if (d.Epm) {  // E_o = Jc_o^T Jp_o (6 x 3) of the corrected blocks, 144 contiguous bytes per observation: the per-shot band assembly's operand
       const double *jp = row + R_JP;
       double2 *dst = reinterpret_cast<double2 *>(d.Epm + 18 * o);
@@ -466,9 +494,9 @@ __global__ void __launch_bounds__(kCoopObs) eval_kernel(Dev d, const double *cam
           e[j] = a0 * jp[j] + b0 * jp[3 + j];
           e[3 + j] = a1 * jp[j] + b1 * jp[3 + j];
         }
-        dst[3 * (i / 2)] = make_double2(e[0], e[1]);
-        dst[3 * (i / 2) + 1] = make_double2(e[2], e[3]);
-        dst[3 * (i / 2) + 2] = make_double2(e[4], e[5]);
+        st_stream2<2>(reinterpret_cast<double *>(dst + 3 * (i / 2)), e[0], e[1]);
+        st_stream2<2>(reinterpret_cast<double *>(dst + 3 * (i / 2) + 1), e[2], e[3]);
+        st_stream2<2>(reinterpret_cast<double *>(dst + 3 * (i / 2) + 2), e[4], e[5]);
       }
     }
   };
@@ -2908,8 +2936,8 @@ __global__ void __launch_bounds__(kCoopObs) schur_point_coop_kernel(Dev d, const
 #pragma unroll
     for (int j = 0; j < 3; j++) {
       const double yj = ys[j];
-      t0 += JA(o, R_JR + j) * yj;
-      t1 += JA(o, R_JR + 3 + j) * yj;
+      t0 += JL(o, R_JR + j) * yj;
+      t1 += JL(o, R_JR + 3 + j) * yj;
     }
 #pragma unroll
     for (int j = 0; j < 3; j++) {
@@ -2931,7 +2959,7 @@ __global__ void __launch_bounds__(kCoopObs) schur_point_coop_kernel(Dev d, const
     if (tid < nobs) {
       pl = d.o_point[o] - p0;
 #pragma unroll
-      for (int j = 0; j < 6; j++) jp[j] = JA(o, R_JP + j);
+      for (int j = 0; j < 6; j++) jp[j] = JL(o, R_JP + j);
       if (MODE != 1) {
         row_t(o, jp, t0, t1);
 #pragma unroll
@@ -2982,10 +3010,7 @@ __global__ void __launch_bounds__(kCoopObs) schur_point_coop_kernel(Dev d, const
     }
     if (tid < nobs) {
       const double v0 = vpt[3 * pl], v1 = vpt[3 * pl + 1], v2 = vpt[3 * pl + 2];
-      double2 wv;
-      wv.x = t0 - (jp[0] * v0 + jp[1] * v1 + jp[2] * v2);
-      wv.y = t1 - (jp[3] * v0 + jp[4] * v1 + jp[5] * v2);
-      *reinterpret_cast<double2 *>(d.w + 2 * o) = wv;
+      st_stream2<2>(d.w + 2 * o, t0 - (jp[0] * v0 + jp[1] * v1 + jp[2] * v2), t1 - (jp[3] * v0 + jp[4] * v1 + jp[5] * v2));
     }
     return;
   }
@@ -3469,7 +3494,7 @@ __global__ void __launch_bounds__(kCoopObs) border_point_kernel(Dev d, double *w
         t1[k] = jk[3 + k] * sck[k];
       }
 #pragma unroll
-      for (int j = 0; j < 6; j++) jp[j] = JA(o, R_JP + j);
+      for (int j = 0; j < 6; j++) jp[j] = JL(o, R_JP + j);
 #pragma unroll
       for (int k = 0; k < 3; k++)
 #pragma unroll
@@ -3508,10 +3533,8 @@ __global__ void __launch_bounds__(kCoopObs) border_point_kernel(Dev d, double *w
       for (int c = 0; c < NB; c++) {
         const double v0 = vpt[(3 * pl + 0) * NB + c], v1 = vpt[(3 * pl + 1) * NB + c], v2 = vpt[(3 * pl + 2) * NB + c];
         const bool own = (c / 3) == cam;
-        double2 wv;
-        wv.x = (own ? t0[c % 3] : 0.0) - (jp[0] * v0 + jp[1] * v1 + jp[2] * v2);
-        wv.y = (own ? t1[c % 3] : 0.0) - (jp[3] * v0 + jp[4] * v1 + jp[5] * v2);
-        dst[c] = wv;
+        st_stream2<2>(reinterpret_cast<double *>(dst + c), (own ? t0[c % 3] : 0.0) - (jp[0] * v0 + jp[1] * v1 + jp[2] * v2),
+                      (own ? t1[c % 3] : 0.0) - (jp[3] * v0 + jp[4] * v1 + jp[5] * v2));
       }
     }
     return;
