@@ -4858,6 +4858,9 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
   if (getenv("OSFM_BA_ONE_STREAM") == nullptr) {  // measurement knob: everything on one stream
     // the side stream and its two events live in the context (creating and destroying a stream per solve is a millisecond of a local
     // bundle adjustment's call); (a low-priority side stream was measured: no difference)
+    // (round 6, measured and dropped: the side stream confined to 192 / 128 / 64 CUs by hipExtStreamCreateWithCUMask so that the cyclic
+    //  reduction's 117 KB workgroups find free LDS elsewhere -- 2.93 - 2.98 ms per LM iteration at configs[4] for every mask, as without one:
+    //  profiles/r06_ba_variants4_side_cu_mask.json)
     if (!ctx->stream_b) OSFM_HIP(hipStreamCreateWithFlags(&ctx->stream_b, hipStreamNonBlocking));
     for (int q = 0; q < 2; q++)
       if (!ctx->ev_side[q]) OSFM_HIP(hipEventCreateWithFlags(&ctx->ev_side[q], hipEventDisableTiming));
