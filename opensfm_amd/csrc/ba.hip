@@ -5198,7 +5198,10 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
   d.rrp = A.alloc<double>((size_t)nblk(d.nred) + 16, e);
   // block half-bandwidth of the shot-shot coupling (shots in caller order): bw_true, from track_width_kernel above
   // half-width up to 10: exact band, cyclic reduction in LDS; up to kWMaxBw: exact band, cyclic reduction over dense clusters (dbcr_*); beyond: truncated to kMaxBw
-  const bool wide = O->preconditioner == 0 && S >= 2 && bw_true > kMaxBw && bw_true <= kWMaxBw && getenv("OSFM_BA_NO_WIDE") == nullptr;
+  // (round 6: the dense-cluster solver takes over where the LDS clusters end, at half-width 11 -- until round 5 at 16, and half-widths 11 .. 15 fell to
+  //  the sequential band Cholesky WITHOUT the exact border: 180 - 244 CG iterations per LM iteration on a 27-shot scene with nine free cameras)
+  constexpr int kLdsBw = 10;  // widest band whose clusters (6 cs unknowns, cs >= bw) the cyclic reduction holds in LDS
+  const bool wide = O->preconditioner == 0 && S >= 2 && bw_true > kLdsBw && bw_true <= kWMaxBw && getenv("OSFM_BA_NO_WIDE") == nullptr;
   d.bw = O->preconditioner == 1 ? 0 : (wide ? bw_true : std::min(bw_true, kMaxBw));
   if (S < 2) d.bw = 0;
   // band columns per launch of the per-shot assembly: all of them when one copy fits a workgroup's LDS, else equal slices of at most kBandSlice
@@ -5253,7 +5256,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
   }
   d.dinv = A.alloc<double>((size_t)S * 36, e);
   d.cs = 0; d.ncl = 0; d.ncd = 0;
-  if (d.bw >= 1 && d.bw <= 10 && d.bw == bw_true && O->preconditioner == 0) {  // exact band, dense clusters fit LDS
+  if (d.bw >= 1 && d.bw <= kLdsBw && d.bw == bw_true && O->preconditioner == 0) {  // exact band, dense clusters fit LDS
     d.cs = d.bw < 2 ? 2 : d.bw;
     if (const char *ecs = getenv("OSFM_BA_CS")) d.cs = std::min(10, std::max(d.cs, atoi(ecs)));  // measurement knob: larger clusters (>= bw)
     d.ncd = 6 * d.cs;
@@ -5613,7 +5616,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       } else {
         static OsfmPerDeviceOnce once_s;
         const int rcs = once_s.run(ctx->device, []() -> int {
-          OSFM_HIP(hipFuncSetAttribute((const void *)gen_border_sigma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+          OSFM_HIP(hipFuncSetAttribute((const void *)gen_border_sigma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));  // (the kernel also has two static words)
           return OSFM_OK;
         });
         if (rcs != OSFM_OK) return rcs;
