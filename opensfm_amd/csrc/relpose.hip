@@ -4,7 +4,8 @@
 // (opensfm/src/robust/src/instanciations.cc:33-48, robust_estimator.h:37-119), Camera::BearingsMany (opensfm/src/geometry/camera.cc).
 // The numerics live in relpose_core.h (per lane), the organisation of the LO-RANSAC in relpose_rounds.h: all pairs of a batch go
 // through rounds of kernels -- walk (one wavefront per pair: scoring + the reference's decision rules + the draws of the samples
-// it will need next), solve5a / solve5b / solveN (one LANE per five-point / N-point problem from a work list; matrices in LDS or
+// it will need next), solve5a / eig5 / vec5 / solveN (five-point stage A: one LANE per problem; its eigenvalues: sixteen lanes per problem; one lane per
+// (problem, eigenvalue) for the solutions; one lane per N-point problem -- all from work lists; matrices in LDS or
 // registers), pose (one lane per essential matrix) -- and one launch of the refinement stage at the end.  This file adds the GPU wave policy, the kernels, the round loop and the C ABI.
 //
 // History (profiles/r02_relpose_*.json): the first version solved 64 speculative five-point problems per wavefront with the
@@ -126,6 +127,7 @@ __global__ __launch_bounds__(kWave) void rp_solve5a_kernel(Rounds R, int count) 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int k = blockIdx.x * kWave + threadIdx.x;
   if (k >= count) return;
+  __builtin_amdgcn_s_setprio(3);  // the five-point chain is the round's critical path: issue ahead of the N-point waves on the same SIMD
   typedef LaneArr<double, kWave> D;
   typedef LaneArr<int, kWave> I;
   const D base{(double *)smem + threadIdx.x};
@@ -133,11 +135,25 @@ __global__ __launch_bounds__(kWave) void rp_solve5a_kernel(Rounds R, int count) 
   solve5_stage_a(R, k, base, base + 36, ibase);
 }
 
-__global__ __launch_bounds__(kWave) void rp_solve5b_kernel(Rounds R, int count) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int k = blockIdx.x * kWave + threadIdx.x;
+// Stage B1: the eigenvalues of the 10 x 10 action matrices, kEigGroup lanes per problem (real_eigenvalues10_group), four problems per
+// wavefront, sixteen per workgroup; a problem's matrix is 100 doubles of LDS its lanes share
+constexpr int kEigBlock = 256;
+constexpr int kEigPerBlock = kEigBlock / kEigGroup;
+__global__ __launch_bounds__(kEigBlock) void rp_eig5_kernel(Rounds R, int count) {
+  __shared__ double mats[kEigPerBlock][104];
+  const int g = threadIdx.x / kEigGroup, glane = threadIdx.x % kEigGroup;
+  const int k = blockIdx.x * kEigPerBlock + g;
   if (k >= count) return;
-  solve5_stage_b(R, k, LaneArr<double, kWave>{(double *)smem + threadIdx.x});
+  __builtin_amdgcn_s_setprio(3);
+  solve5_stage_b1_group(R, k, &mats[g][0], glane);
+}
+// Stage B2: one lane per (problem, eigenvalue): its 10 x 10 elimination in LDS (element-major, lane-minor)
+__global__ __launch_bounds__(kWave) void rp_vec5_kernel(Rounds R, int count) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int q = blockIdx.x * kWave + threadIdx.x;
+  if (q >= count * kMaxModels) return;
+  __builtin_amdgcn_s_setprio(3);
+  solve5_stage_b2(R, q, LaneArr<double, kWave>{(double *)smem + threadIdx.x});
 }
 
 // One lane per non-minimal problem.  The 9 x 9 matrix and its eigenvectors (162 doubles) stay in the register file: the rotation
@@ -159,7 +175,8 @@ __global__ __launch_bounds__(256, 4) void rp_pose_kernel(Rounds R, int count5, i
 }
 
 // After the rounds: the inlier mask of the RANSAC (mode 0) or the refinement stage of robust_match_calibrated (mode 1), results out
-__global__ __launch_bounds__(kWave) void rp_finish_kernel(Rounds R, int mode, double threshold_angle, int refine_iterations, int *sub_ws,
+template <int WPE>
+__global__ __launch_bounds__(kWave, WPE) void rp_finish_kernel(Rounds R, int mode, double threshold_angle, int refine_iterations, int *sub_ws,
                                                           uint8_t *mask, PairOut *out) {
   __shared__ RefineShared sh;
   const int p = (int)blockIdx.x;
@@ -169,28 +186,36 @@ __global__ __launch_bounds__(kWave) void rp_finish_kernel(Rounds R, int mode, do
   const int n = (int)(R.offsets[p + 1] - o);
   const PairState &S = R.st[p];
   for (int i = w.lane; i < n; i += kWave) mask[o + i] = 0;
-  PairOut r;
-  for (int i = 0; i < 12; i++) {
-    r.model[i] = S.model[i];
-    r.lo_model[i] = S.lo_model[i];
+  // the result goes out in pieces (lane 0): a PairOut kept in registers across the refinement is 72 of them in every lane
+  __shared__ double Rt[12];
+  if (w.lane == 0) {
+    PairOut &r = out[p];
+    for (int i = 0; i < 12; i++) {
+      r.model[i] = S.model[i];
+      r.lo_model[i] = S.lo_model[i];
+    }
+    r.score = S.best_score;
+    r.iterations = S.it;
+    r.pad = 0;
   }
-  for (int i = 0; i < 9; i++) r.R[i] = 0.0;
-  for (int i = 0; i < 3; i++) r.t[i] = 0.0;
-  r.score = S.best_score;
-  r.iterations = S.it;
-  r.pad = 0;
+  if (w.lane < 12) Rt[w.lane] = 0.0;
+  __syncthreads();
   const int *list = R.inliers + o;
   int count = S.best_score;
   if (mode == 1) {
     count = 0;
     list = sub_ws + o;
     if (!S.rejected)
-      count = robust_match_finish_wave(w, sh, R.b1 + 3 * o, R.b2 + 3 * o, n, S.lo_model, threshold_angle, refine_iterations, sub_ws + o, r.R, r.t);
+      count = robust_match_finish_wave(w, sh, R.b1 + 3 * o, R.b2 + 3 * o, n, S.lo_model, threshold_angle, refine_iterations, sub_ws + o, Rt, Rt + 9);
   }
-  r.n_inliers = count;
   __syncthreads();
   for (int i = w.lane; i < count; i += kWave) mask[o + list[i]] = 1;
-  if (w.lane == 0) out[p] = r;
+  if (w.lane == 0) {
+    PairOut &r = out[p];
+    for (int i = 0; i < 9; i++) r.R[i] = Rt[i];
+    for (int i = 0; i < 3; i++) r.t[i] = Rt[9 + i];
+    r.n_inliers = count;
+  }
 }
 
 struct CameraParams {
@@ -253,7 +278,7 @@ int ensure_relpose_attributes(int device) {
   static OsfmPerDeviceOnce once;
   return once.run(device, []() -> int {
     OSFM_HIP(hipFuncSetAttribute((const void *)rp_solve5a_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    OSFM_HIP(hipFuncSetAttribute((const void *)rp_solve5b_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    OSFM_HIP(hipFuncSetAttribute((const void *)rp_vec5_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     return OSFM_OK;
   });
 }
@@ -311,7 +336,8 @@ int osfm_relpose_run_device(osfm_ctx *ctx, hipStream_t st, const double *d_b1, c
       (size_t)n_pairs * kMaxSlots * 5 * 4, (size_t)n_pairs * kMaxSlots * 4, (size_t)n_pairs * kMaxSlots * 4, (size_t)n_pairs * kMaxSlots * 4,
       (size_t)n_pairs * kMaxSlots * kMaxModels * 12 * 8, (size_t)n_pairs * lo * kLoSampleMax * 4, (size_t)n_pairs * lo * 4,
       (size_t)n_pairs * lo * 4, (size_t)n_pairs * lo * 12 * 8, (size_t)total * 4, (size_t)total * 4, (size_t)n_pairs * kMaxSlots * 4,
-      (size_t)n_pairs * lo * 4, 4 * 4, cap5 * 60 * 8, cap5 * 36 * 8, cap5 * 4, cap5 * kMaxModels * 9 * 8, (size_t)n_pairs * lo * 9 * 8};
+      (size_t)n_pairs * lo * 4, 4 * 4, cap5 * 60 * 8, cap5 * 36 * 8, cap5 * 4, cap5 * kMaxModels * 9 * 8, (size_t)n_pairs * lo * 9 * 8,
+      cap5 * kMaxModels * 8, cap5 * 4, cap5 * kMaxModels * 4};
   constexpr int kBuffers = sizeof(sizes) / sizeof(sizes[0]);
   size_t offs[kBuffers], arena_bytes = 0;
   for (int i = 0; i < kBuffers; i++) {
@@ -325,14 +351,15 @@ int osfm_relpose_run_device(osfm_ctx *ctx, hipStream_t st, const double *d_b1, c
   const Sub &d_u1 = sub[0], &d_u2 = sub[1], &d_stop = sub[2], &d_stopoff = sub[3], &d_st = sub[4], &d_sidx = sub[5], &d_posb = sub[6], &d_pos = sub[7],
             &d_nm = sub[8], &d_models = sub[9], &d_lidx = sub[10], &d_lopos = sub[11], &d_look = sub[12], &d_lort = sub[13], &d_inl = sub[14],
             &d_sub = sub[15], &d_l5 = sub[16], &d_lN = sub[17], &d_cnt = sub[18], &d_at6 = sub[19], &d_bas = sub[20], &d_ok5 = sub[21],
-            &d_E5 = sub[22], &d_loE = sub[23];
-  static_assert(kBuffers == 24, "buffer list and names must match");
+            &d_E5 = sub[22], &d_loE = sub[23], &d_wr = sub[24], &d_nreal = sub[25], &d_valid = sub[26];
+  static_assert(kBuffers == 27, "buffer list and names must match");
   OSFM_HIP(hipMemcpyAsync(d_stop.p, stop.data(), stop.size() * 8, hipMemcpyHostToDevice, st));
   OSFM_HIP(hipMemcpyAsync(d_stopoff.p, stop_off.data(), stop_off.size() * 8, hipMemcpyHostToDevice, st));
   Rounds R{d_b1, d_b2, d_u1.as<double>(), d_u2.as<double>(), d_off, n_pairs, d_stop.as<double>(), d_stopoff.as<int64_t>(), rng, 1.0 - cos(prm->threshold), (int)prm->iterations, (int)prm->use_lo,
            (int)prm->lo_iterations, mode == OSFM_RELPOSE_MATCH ? 8 : 5, kMaxSlots, d_st.as<PairState>(), d_sidx.as<int>(), d_posb.as<int>(), d_pos.as<int>(),
            d_nm.as<int>(), d_models.as<double>(), d_lidx.as<int>(), d_lopos.as<int>(), d_look.as<int>(), d_lort.as<double>(), d_inl.as<int>(),
-           d_at6.as<double>(), d_bas.as<double>(), d_ok5.as<int>(), d_E5.as<double>(), d_loE.as<double>(), d_l5.as<int>(), d_lN.as<int>(), d_cnt.as<int>()};
+           d_at6.as<double>(), d_bas.as<double>(), d_ok5.as<int>(), d_E5.as<double>(), d_loE.as<double>(), d_l5.as<int>(), d_lN.as<int>(), d_cnt.as<int>(),
+           d_wr.as<double>(), d_nreal.as<int>(), d_valid.as<int>()};
   // the side stream and its two events live in the context (creating and destroying them per call is ~1 ms: most of a single pair's call)
   if (!ctx->stream_c) OSFM_HIP(hipStreamCreateWithFlags(&ctx->stream_c, hipStreamNonBlocking));
   for (int q = 0; q < 2; q++)
@@ -369,7 +396,8 @@ int osfm_relpose_run_device(osfm_ctx *ctx, hipStream_t st, const double *d_b1, c
     }
     if (h[0] > 0) {
       hipLaunchKernelGGL(rp_solve5a_kernel, dim3((h[0] + kWave - 1) / kWave), dim3(kWave), kStageALds, st, R, h[0]);
-      hipLaunchKernelGGL(rp_solve5b_kernel, dim3((h[0] + kWave - 1) / kWave), dim3(kWave), kStageBLds, st, R, h[0]);
+      hipLaunchKernelGGL(rp_eig5_kernel, dim3((h[0] + kEigPerBlock - 1) / kEigPerBlock), dim3(kEigBlock), 0, st, R, h[0]);
+      hipLaunchKernelGGL(rp_vec5_kernel, dim3((h[0] * kMaxModels + kWave - 1) / kWave), dim3(kWave), kStageBLds, st, R, h[0]);
     }
     if (h[1] > 0) OSFM_HIP(hipStreamWaitEvent(st, ev_join, 0));
     {
@@ -379,8 +407,13 @@ int osfm_relpose_run_device(osfm_ctx *ctx, hipStream_t st, const double *d_b1, c
     OSFM_HIP(hipGetLastError());
     OSFM_REQUIRE(rounds < 100000, OSFM_E_NUMERIC, "osfm_relpose_pairs: the rounds do not terminate");
   }
-  hipLaunchKernelGGL(rp_finish_kernel, dim3(n_pairs), dim3(kWave), 0, st, R, mode, prm->threshold, (int)prm->refine_iterations, d_sub.as<int>(), d_mask,
-                     (PairOut *)d_out);
+  static const int finish_wpe = getenv("OSFM_RP_FINISH_WPE") ? atoi(getenv("OSFM_RP_FINISH_WPE")) : 2;
+  if (finish_wpe == 2)
+    hipLaunchKernelGGL(rp_finish_kernel<2>, dim3(n_pairs), dim3(kWave), 0, st, R, mode, prm->threshold, (int)prm->refine_iterations, d_sub.as<int>(), d_mask,
+                       (PairOut *)d_out);
+  else
+    hipLaunchKernelGGL(rp_finish_kernel<1>, dim3(n_pairs), dim3(kWave), 0, st, R, mode, prm->threshold, (int)prm->refine_iterations, d_sub.as<int>(), d_mask,
+                       (PairOut *)d_out);
   OSFM_HIP(hipGetLastError());
   OSFM_HIP(hipStreamSynchronize(st));  // the work buffers above are released on return
   if (rounds_out) *rounds_out = rounds;

@@ -502,20 +502,13 @@ OSFM_HD double action_matrix_entry(PA At6, int i) {
 // Stage B.  At6: rows 0..5 of the action matrix (60 entries, read-only), basis: the null space (36, read-only), S: 100 doubles of
 // work space.  Every real solution is handed to emit(E) -- a row-major 3 x 3 of unit Frobenius norm -- in eigenvalue order;
 // returns how many (<= 10).
-template <class PA, class PB, class PS, class Emit>
-OSFM_HD int five_point_solutions(PA At6, PB basis, PS S, Emit emit) {
-  OSFM_UNROLL for (int i = 0; i < 100; i++) S[i] = action_matrix_entry(At6, i);
-  double wr[10];
-  OSFM_UNROLL for (int q = 0; q < 10; q++) wr[q] = 0.0;
-  const int nreal = real_eigenvalues10_put(S, [&](int k, double val) {
-    OSFM_UNROLL for (int q = 0; q < 10; q++)
-      if (q == k) wr[q] = val;
-  });
-  int count = 0;
-  for (int e = 0; e < nreal && count < 10; e++) {
-    double lam = 0.0;
-    OSFM_UNROLL for (int q = 0; q < 10; q++)
-      if (q == e) lam = wr[q];
+// The solution that belongs to one real eigenvalue lam of the action matrix: the eigenvector by Gauss-Jordan with complete pivoting on
+// A - lam I (S: 100 doubles of work space), its entries (x, y, z, 1), E = x E0 + y E1 + z E2 + E3 normalised.  False when the
+// elimination breaks down or the vector has no finite dehomogenisation.  (Round 6: a function of its own -- the GPU runs one lane per
+// (problem, eigenvalue), solve5_stage_b2; five_point_solutions below calls it in eigenvalue order.)
+template <class PA, class PB, class PS>
+OSFM_HD bool five_point_solution_at(PA At6, PB basis, PS S, double lam, double* Em) {
+  {
     OSFM_UNROLL for (int i = 0; i < 100; i++) S[i] = (i % 11 == 0) ? action_matrix_entry(At6, i) - lam : action_matrix_entry(At6, i);
     int cp[10];  // column permutation, in registers: k is a constant in the unrolled elimination, pc goes through a select chain
     OSFM_UNROLL for (int j = 0; j < 10; j++) cp[j] = j;
@@ -583,7 +576,7 @@ OSFM_HD int five_point_solutions(PA At6, PB basis, PS S, Emit emit) {
         }
       }
     }
-    if (!ok) continue;
+    if (!ok) return false;
     // v[cp[9]] = 1, v[cp[k]] = -S[k][9]; only the entries 6..9 (x, y, z, 1) of the monomial vector are needed
     double v6 = 0.0, v7 = 0.0, v8 = 0.0, v9 = 0.0;
     OSFM_UNROLL for (int k = 0; k < 10; k++) {
@@ -593,16 +586,35 @@ OSFM_HD int five_point_solutions(PA At6, PB basis, PS S, Emit emit) {
       if (cp[k] == 8) v8 = val;
       if (cp[k] == 9) v9 = val;
     }
-    if (v9 == 0.0) continue;
+    if (v9 == 0.0) return false;
     const double x = v6 / v9, y = v7 / v9, z = v8 / v9;
-    double Em[9], nrm = 0.0;
+    double nrm = 0.0;
     OSFM_UNROLL for (int i = 0; i < 9; i++) {
       Em[i] = x * basis[i * 4 + 0] + y * basis[i * 4 + 1] + z * basis[i * 4 + 2] + basis[i * 4 + 3];
       nrm += Em[i] * Em[i];
     }
     nrm = sqrt(nrm);
-    if (!(nrm > 0) || !isfinite(nrm)) continue;
+    if (!(nrm > 0) || !isfinite(nrm)) return false;
     OSFM_UNROLL for (int i = 0; i < 9; i++) Em[i] = Em[i] / nrm;
+    return true;
+  }
+}
+template <class PA, class PB, class PS, class Emit>
+OSFM_HD int five_point_solutions(PA At6, PB basis, PS S, Emit emit) {
+  OSFM_UNROLL for (int i = 0; i < 100; i++) S[i] = action_matrix_entry(At6, i);
+  double wr[10];
+  OSFM_UNROLL for (int q = 0; q < 10; q++) wr[q] = 0.0;
+  const int nreal = real_eigenvalues10_put(S, [&](int k, double val) {
+    OSFM_UNROLL for (int q = 0; q < 10; q++)
+      if (q == k) wr[q] = val;
+  });
+  int count = 0;
+  for (int e = 0; e < nreal && count < 10; e++) {
+    double lam = 0.0;
+    OSFM_UNROLL for (int q = 0; q < 10; q++)
+      if (q == e) lam = wr[q];
+    double Em[9];
+    if (!five_point_solution_at(At6, basis, S, lam, Em)) continue;
     emit(Em);
     count++;
   }
@@ -618,6 +630,213 @@ OSFM_HD int essential_five_points(const double* b1, const double* b2, double* Es
     for (int i = 0; i < 9; i++) Es[9 * n + i] = Em[i];
     n++;
   });
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same eigenvalues by a GROUP of lanes (round 6): the matrix lies in memory the group shares (LDS on the GPU), lane j of the group
+// owns column j in the row operations and row j in the column operations, and every lane runs the scalar bookkeeping (pivot
+// searches, shifts, the Householder vectors) redundantly from the same operands -- so the control flow is uniform inside a
+// group and every element goes through the same expressions, in the same order, as in real_eigenvalues10_put: the same bits.
+// What one lane did in ~30 k dependent LDS operations takes ~1/6 of that per lane here; the kernel's critical path is the
+// scalar chain (divisions, one square root per reflection).
+// OSFM_GROUP_FOR(j, glane) { body } runs the body for the calling lane on the device and for j = 0 .. 15 in turn on the host
+// (tests/native/relpose_core_host.cpp): a body only touches what its own j owns between two OSFM_GROUP_SYNCs, so both
+// orders of execution give the same memory.  OSFM_GROUP_SYNC keeps the compiler from moving shared accesses across it (the
+// lanes of a wavefront run in lockstep and its LDS operations complete in order: no hardware barrier is needed).
+// ---------------------------------------------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+#define OSFM_GROUP_FOR(j, glane) for (int j = (glane), osfm_once_ = 1; osfm_once_; osfm_once_ = 0)
+#define OSFM_GROUP_SYNC()                               \
+  do {                                                  \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+    __builtin_amdgcn_wave_barrier();                    \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+  } while (0)
+#else
+#define OSFM_GROUP_FOR(j, glane) for (int j = 0; j < 16; j++)
+#define OSFM_GROUP_SYNC() do { } while (0)
+#endif
+constexpr int kEigGroup = 16;  // lanes per 10 x 10 eigenproblem (ten of them own a column / a row)
+
+template <class PA, class Put>
+OSFM_HD int real_eigenvalues10_group(PA a, int glane, Put put) {
+  constexpr int n = 10;
+  (void)glane;
+  for (int m = 1; m < n - 1; m++) {
+    double x = 0.0;
+    int i = m;
+    for (int j = m; j < n; j++) {
+      const double c = a[j * n + m - 1];
+      if (fabs(c) > fabs(x)) {
+        x = c;
+        i = j;
+      }
+    }
+    if (i != m) {
+      OSFM_GROUP_FOR(j, glane) if (j < n && j >= m - 1) {
+        const double ri = a[i * n + j], rm = a[m * n + j];
+        a[i * n + j] = rm;
+        a[m * n + j] = ri;
+      }
+      OSFM_GROUP_SYNC();
+      OSFM_GROUP_FOR(j, glane) if (j < n) {
+        const double ci = a[j * n + i], cm = a[j * n + m];
+        a[j * n + i] = cm;
+        a[j * n + m] = ci;
+      }
+      OSFM_GROUP_SYNC();
+    }
+    if (x != 0.0) {
+      for (i = m + 1; i < n; i++) {
+        double y = a[i * n + m - 1];
+        if (y != 0.0) {
+          y /= x;
+          OSFM_GROUP_SYNC();
+          OSFM_GROUP_FOR(j, glane) {
+            if (j == m - 1) a[i * n + m - 1] = y;
+            if (j < n && j >= m) a[i * n + j] = a[i * n + j] - y * a[m * n + j];
+          }
+          OSFM_GROUP_SYNC();
+          OSFM_GROUP_FOR(j, glane) if (j < n) a[j * n + m] = a[j * n + m] + y * a[j * n + i];
+          OSFM_GROUP_SYNC();
+        }
+      }
+    }
+  }
+  OSFM_GROUP_FOR(j, glane) if (j < n)
+    for (int i = j + 2; i < n; i++) a[i * n + j] = 0.0;
+  OSFM_GROUP_SYNC();
+  int nreal = 0, nn = n - 1, its;
+  double anorm = 0.0, t = 0.0, p = 0, q = 0, r = 0, s, w, x, y, z;
+  for (int i = 0; i < n; i++)
+    for (int j = (i > 0 ? i - 1 : 0); j < n; j++) anorm += fabs(a[i * n + j]);
+  while (nn >= 0) {
+    its = 0;
+    int l;
+    do {
+      for (l = nn; l >= 1; l--) {
+        s = fabs(a[(l - 1) * n + l - 1]) + fabs(a[l * n + l]);
+        if (s == 0.0) s = anorm;
+        if (fabs(a[l * n + l - 1]) + s == s) {
+          OSFM_GROUP_SYNC();
+          OSFM_GROUP_FOR(j, glane) if (j == 0) a[l * n + l - 1] = 0.0;
+          OSFM_GROUP_SYNC();
+          break;
+        }
+      }
+      x = a[nn * n + nn];
+      if (l == nn) {
+        put(nreal, x + t);
+        nreal++;
+        nn--;
+      } else {
+        y = a[(nn - 1) * n + nn - 1];
+        w = a[nn * n + nn - 1] * a[(nn - 1) * n + nn];
+        if (l == nn - 1) {
+          p = 0.5 * (y - x);
+          q = p * p + w;
+          z = sqrt(fabs(q));
+          x += t;
+          if (q >= 0.0) {
+            z = p + (p >= 0.0 ? fabs(z) : -fabs(z));
+            put(nreal, x + z);
+            put(nreal + 1, z != 0.0 ? x - w / z : x + z);
+            nreal += 2;
+          }
+          nn -= 2;
+        } else {
+          if (its == 60) return nreal;
+          if (its == 10 || its == 20) {
+            t += x;
+            OSFM_GROUP_SYNC();
+            OSFM_GROUP_FOR(j, glane) if (j <= nn) a[j * n + j] -= x;
+            OSFM_GROUP_SYNC();
+            s = fabs(a[nn * n + nn - 1]) + fabs(a[(nn - 1) * n + nn - 2]);
+            y = x = 0.75 * s;
+            w = -0.4375 * s * s;
+          }
+          ++its;
+          int m;
+          for (m = nn - 2; m >= l; m--) {
+            z = a[m * n + m];
+            r = x - z;
+            s = y - z;
+            p = (r * s - w) / a[(m + 1) * n + m] + a[m * n + m + 1];
+            q = a[(m + 1) * n + m + 1] - z - r - s;
+            r = a[(m + 2) * n + m + 1];
+            s = fabs(p) + fabs(q) + fabs(r);
+            p /= s;
+            q /= s;
+            r /= s;
+            if (m == l) break;
+            const double u = fabs(a[m * n + m - 1]) * (fabs(q) + fabs(r));
+            const double v = fabs(p) * (fabs(a[(m - 1) * n + m - 1]) + fabs(z) + fabs(a[(m + 1) * n + m + 1]));
+            if (u + v == v) break;
+          }
+          OSFM_GROUP_SYNC();
+          OSFM_GROUP_FOR(i, glane) if (i >= m + 2 && i <= nn) {
+            a[i * n + i - 2] = 0.0;
+            if (i != m + 2) a[i * n + i - 3] = 0.0;
+          }
+          OSFM_GROUP_SYNC();
+          for (int k = m; k <= nn - 1; k++) {
+            if (k != m) {
+              p = a[k * n + k - 1];
+              q = a[(k + 1) * n + k - 1];
+              r = 0.0;
+              if (k != nn - 1) r = a[(k + 2) * n + k - 1];
+              if ((x = fabs(p) + fabs(q) + fabs(r)) != 0.0) {
+                p /= x;
+                q /= x;
+                r /= x;
+              }
+            }
+            const double sg = sqrt(p * p + q * q + r * r);
+            s = p >= 0.0 ? sg : -sg;
+            if (s != 0.0) {
+              OSFM_GROUP_SYNC();
+              if (k == m) {
+                if (l != m) OSFM_GROUP_FOR(j, glane) if (j == 0) a[k * n + k - 1] = -a[k * n + k - 1];
+              } else {
+                OSFM_GROUP_FOR(j, glane) if (j == 0) a[k * n + k - 1] = -s * x;
+              }
+              p += s;
+              x = p / s;
+              y = q / s;
+              z = r / s;
+              q /= p;
+              r /= p;
+              const bool three = (k != nn - 1);
+              OSFM_GROUP_FOR(j, glane) if (j >= k && j <= nn) {  // rows k, k + 1 (, k + 2): lane j owns column j
+                const double r0 = a[k * n + j], r1 = a[(k + 1) * n + j], r2 = three ? a[(k + 2) * n + j] : 0.0;
+                double pj = r0 + q * r1;
+                if (three) {
+                  pj += r * r2;
+                  a[(k + 2) * n + j] = r2 - pj * z;
+                }
+                a[(k + 1) * n + j] = r1 - pj * y;
+                a[k * n + j] = r0 - pj * x;
+              }
+              OSFM_GROUP_SYNC();
+              const int mmin = nn < k + 3 ? nn : k + 3;
+              OSFM_GROUP_FOR(i, glane) if (i >= l && i <= mmin) {  // columns k, k + 1 (, k + 2): lane i owns row i
+                const double c0 = a[i * n + k], c1 = a[i * n + k + 1], c2 = three ? a[i * n + k + 2] : 0.0;
+                double pi = x * c0 + y * c1;
+                if (three) {
+                  pi += z * c2;
+                  a[i * n + k + 2] = c2 - pi * r;
+                }
+                a[i * n + k + 1] = c1 - pi * q;
+                a[i * n + k] = c0 - pi;
+              }
+              OSFM_GROUP_SYNC();
+            }
+          }
+        }
+      }
+    } while (l < nn - 1);
+  }
+  return nreal;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1196,43 +1415,51 @@ OSFM_HD void refinement_picks(int n, int* picked) {
   }
 }
 
-struct D6 {
-  double v, d[6];
+// A value with NDUAL of its six derivatives (forward mode).  Every derivative component goes through its own copy of the same
+// expression, so a residual evaluated in two halves of three derivatives (refine_residual: kRefineDualWidth) has the bits of one
+// evaluation with all six -- and half the live registers: the refinement kernel fits two wavefronts on a SIMD (round 6; with six
+// derivatives it held 512 registers and spilled).  The value part is computed once per half.
+template <int NDUAL>
+struct Dn {
+  double v, d[NDUAL];
 };
+constexpr int kRefineDualWidth = 3;
+typedef Dn<kRefineDualWidth> D6;  // (the name predates the halves)
 OSFM_HD D6 dc(double c) {
   D6 r;
   r.v = c;
-  for (int i = 0; i < 6; i++) r.d[i] = 0;
+  for (int i = 0; i < kRefineDualWidth; i++) r.d[i] = 0;
   return r;
 }
-OSFM_HD D6 dvar(double c, int k) {
+OSFM_HD D6 dvar(double c, int k) {  // k outside 0 .. kRefineDualWidth - 1: a parameter of the other half, a constant here
   D6 r = dc(c);
-  r.d[k] = 1.0;
+  for (int i = 0; i < kRefineDualWidth; i++)
+    if (i == k) r.d[i] = 1.0;
   return r;
 }
 OSFM_HD D6 dadd(D6 a, const D6& b) {
-  for (int i = 0; i < 6; i++) a.d[i] += b.d[i];
+  for (int i = 0; i < kRefineDualWidth; i++) a.d[i] += b.d[i];
   a.v += b.v;
   return a;
 }
 OSFM_HD D6 dsub(D6 a, const D6& b) {
-  for (int i = 0; i < 6; i++) a.d[i] -= b.d[i];
+  for (int i = 0; i < kRefineDualWidth; i++) a.d[i] -= b.d[i];
   a.v -= b.v;
   return a;
 }
 OSFM_HD D6 dneg(D6 a) {
-  for (int i = 0; i < 6; i++) a.d[i] = -a.d[i];
+  for (int i = 0; i < kRefineDualWidth; i++) a.d[i] = -a.d[i];
   a.v = -a.v;
   return a;
 }
 OSFM_HD D6 dmul(const D6& a, const D6& b) {
   D6 r;
   r.v = a.v * b.v;
-  for (int i = 0; i < 6; i++) r.d[i] = a.d[i] * b.v + a.v * b.d[i];
+  for (int i = 0; i < kRefineDualWidth; i++) r.d[i] = a.d[i] * b.v + a.v * b.d[i];
   return r;
 }
 OSFM_HD D6 dmulc(D6 a, double c) {
-  for (int i = 0; i < 6; i++) a.d[i] *= c;
+  for (int i = 0; i < kRefineDualWidth; i++) a.d[i] *= c;
   a.v *= c;
   return a;
 }
@@ -1240,28 +1467,28 @@ OSFM_HD D6 ddiv(const D6& a, const D6& b) {
   D6 r;
   const double ib = 1.0 / b.v;
   r.v = a.v * ib;
-  for (int i = 0; i < 6; i++) r.d[i] = (a.d[i] - r.v * b.d[i]) * ib;
+  for (int i = 0; i < kRefineDualWidth; i++) r.d[i] = (a.d[i] - r.v * b.d[i]) * ib;
   return r;
 }
 OSFM_HD D6 dsqrt(const D6& a) {
   D6 r;
   r.v = sqrt(a.v);
   const double h = 0.5 / r.v;
-  for (int i = 0; i < 6; i++) r.d[i] = a.d[i] * h;
+  for (int i = 0; i < kRefineDualWidth; i++) r.d[i] = a.d[i] * h;
   return r;
 }
 OSFM_HD D6 dsin(const D6& a) {
   D6 r;
   r.v = sin(a.v);
   const double c = cos(a.v);
-  for (int i = 0; i < 6; i++) r.d[i] = a.d[i] * c;
+  for (int i = 0; i < kRefineDualWidth; i++) r.d[i] = a.d[i] * c;
   return r;
 }
 OSFM_HD D6 dcos(const D6& a) {
   D6 r;
   r.v = cos(a.v);
   const double s = -sin(a.v);
-  for (int i = 0; i < 6; i++) r.d[i] = a.d[i] * s;
+  for (int i = 0; i < kRefineDualWidth; i++) r.d[i] = a.d[i] * s;
   return r;
 }
 OSFM_HD D6 ddot3(const D6* a, const D6* b) { return dadd(dadd(dmul(a[0], b[0]), dmul(a[1], b[1])), dmul(a[2], b[2])); }
@@ -1283,11 +1510,11 @@ OSFM_HD void aa_rotate(const D6* aa, const D6* pt, D6* out) {
 }
 // One residual of RelativePoseCost: i < 100 -> bearing pair (xs, ys); i == 100 -> 1 - |c| (xs, ys unused).
 // par = [angle-axis of R, centre c = -R^T t].  out[0] = residual, out[1..6] = its gradient.
-OSFM_HD void refine_residual(int i, const double* par, const double* xs, const double* ys, double* out) {
+OSFM_HD void refine_residual_half(int i, const double* par, const double* xs, const double* ys, int k0, double* val, double* grad) {
   D6 rot[3], tr[3], rot_t[3];
   for (int k = 0; k < 3; k++) {
-    rot[k] = dvar(par[k], k);
-    tr[k] = dvar(par[3 + k], 3 + k);
+    rot[k] = dvar(par[k], k - k0);
+    tr[k] = dvar(par[3 + k], 3 + k - k0);
     rot_t[k] = dneg(rot[k]);
   }
   D6 r;
@@ -1314,8 +1541,12 @@ OSFM_HD void refine_residual(int i, const double* par, const double* xs, const d
   } else {
     r = dsub(dc(1.0), dsqrt(ddot3(tr, tr)));
   }
-  out[0] = r.v;
-  for (int k = 0; k < 6; k++) out[1 + k] = r.d[k];
+  *val = r.v;
+  for (int k = 0; k < kRefineDualWidth; k++) grad[k] = r.d[k];
+}
+OSFM_HD void refine_residual(int i, const double* par, const double* xs, const double* ys, double* out) {
+  static_assert(6 % kRefineDualWidth == 0, "the six derivatives in equal parts");
+  OSFM_NOUNROLL for (int k0 = 0; k0 < 6; k0 += kRefineDualWidth) refine_residual_half(i, par, xs, ys, k0, out, out + 1 + k0);
 }
 // ceres RotationMatrixToAngleAxis (through the quaternion) / AngleAxisToRotationMatrix, R row-major
 OSFM_HD void rotmat_to_aa(const double* R, double* aa) {
@@ -1417,12 +1648,15 @@ OSFM_HD int refine_relative_pose(double* RT, int iterations, Eval& ev, double* c
     for (int b = 0; b < 3; b++) R[3 * a + b] = RT[4 * a + b];
   rotmat_to_aa(R, x);
   for (int a = 0; a < 3; a++) x[3 + a] = -(R[a] * RT[3] + R[3 + a] * RT[7] + R[6 + a] * RT[11]);
-  double scal[6], jtj[36], g[6], cost = 0;
+  double scal[6], g[6], cost = 0;  // J^T J lives with the evaluator (ev.keep / ev.kept, entries 0 .. 35): the same in every lane, and 72 registers otherwise
   int have_scale = 0, it = 0;
   // every sum below runs over the residuals i = 0 .. NR - 1 in order, from 0.0 (the oracle's order); ev.reduce() may give each
   // sum to a different lane
-  auto update = [&]() {
-    ev.eval(x, 1);
+  // fresh = false: the evaluator's buffers already hold the residuals AND Jacobians at x -- the trial evaluation of an accepted step
+  // (every evaluation forms the duals: eval's second argument is a wish, not a switch), the same operands through the same
+  // operations, so evaluating again would reproduce them bit for bit (round 6: a third of the refinement's evaluations)
+  auto update = [&](bool fresh) {
+    if (fresh) ev.eval(x, 1);
     if (!have_scale) {
       double ss[6];
       ev.reduce(6, [&](int k, int i) { return ev.jac(i, k) * ev.jac(i, k); }, ss);
@@ -1443,10 +1677,10 @@ OSFM_HD int refine_relative_pose(double* RT, int iterations, Eval& ev, double* c
       return (ev.val(i, ca) * sa) * (ev.val(i, cb) * sb);
     }, sums);
     for (int a = 0; a < 6; a++) g[a] = sums[a];
-    for (int k = 0; k < 36; k++) jtj[k] = sums[6 + k];
+    for (int k = 0; k < 36; k++) ev.keep(k, sums[6 + k]);
     cost = sums[42] * 0.5;
   };
-  update();
+  update(true);
   if (costs) costs[0] = cost;
   double gmax = 0;
   for (int k = 0; k < 6; k++) gmax = fmax(gmax, fabs(g[k]));
@@ -1454,8 +1688,8 @@ OSFM_HD int refine_relative_pose(double* RT, int iterations, Eval& ev, double* c
   if (!(gmax < 1e-10) && !(cost < kEps)) {
     for (it = 1; it < iterations; it++) {
       double reg[36], step[6], dx[6], xn[6];
-      for (int k = 0; k < 36; k++) reg[k] = jtj[k];
-      for (int k = 0; k < 6; k++) reg[7 * k] += u * fmin(fmax(jtj[7 * k], 1e-6), 1e32);
+      for (int k = 0; k < 36; k++) reg[k] = ev.kept(k);
+      for (int k = 0; k < 6; k++) reg[7 * k] += u * fmin(fmax(ev.kept(7 * k), 1e-6), 1e32);
       if (!ldlt_solve6(reg, g, step)) {
         u *= v;
         v *= 2;
@@ -1469,20 +1703,20 @@ OSFM_HD int refine_relative_pose(double* RT, int iterations, Eval& ev, double* c
       }
       if (sqrt(dxn) < 1e-8 * (sqrt(xnorm) + 1e-8)) break;
       for (int k = 0; k < 6; k++) xn[k] = x[k] + dx[k];
-      ev.eval(xn, 0);
+      ev.eval(xn, 1);
       double fn2 = 0;
       ev.reduce(1, [&](int, int i) { return ev.res(i) * ev.res(i); }, &fn2);
       const double cost_change = 2.0 * cost - fn2;
       double mc = 0;
       for (int a = 0; a < 6; a++) {
         double s = 2.0 * g[a];
-        for (int b = 0; b < 6; b++) s -= jtj[6 * a + b] * step[b];
+        for (int b = 0; b < 6; b++) s -= ev.kept(6 * a + b) * step[b];
         mc += step[a] * s;
       }
       const double rho = cost_change / mc;
       if (rho > 0) {
         for (int k = 0; k < 6; k++) x[k] = xn[k];
-        update();
+        update(false);
         gmax = 0;
         for (int k = 0; k < 6; k++) gmax = fmax(gmax, fabs(g[k]));
         if (gmax < 1e-10 || cost < kEps) {

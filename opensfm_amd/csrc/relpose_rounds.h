@@ -160,6 +160,10 @@ struct Rounds {
   int* list5;         // work list of five-point problems: pair * kMaxSlots + slot
   int* listN;         // work list of N-point problems: pair * lo_iterations + l
   int* counters;      // [0] five-point problems, [1] N-point problems, [2] pairs still running, [3] table overflow
+  // stage B in two parts (round 6): the real eigenvalues of the action matrix, then one solution per (problem, eigenvalue)
+  double* s5_wr;      // [k][10] real eigenvalues in the order the iteration deflates them
+  int* s5_nreal;      // [k] how many (0 when stage A failed)
+  int* s5_valid;      // [k][10] 1 where s5_E[k][e] holds a solution
 };
 
 // ---- the solver stages.  k = position in the round's work list; problems are grouped in blocks of 64 (one per lane), and what one
@@ -191,33 +195,72 @@ OSFM_HD void solve5_stage_a(const Rounds& R, int k, D basis, D M, I colperm) {
   OSFM_UNROLL for (int i = 0; i < 36; i++) bas[i] = basis[i];
 }
 
-// solve5 stage B: action matrix -> essential matrices (five_point_solutions); S: 100 doubles of work space
+// solve5 stage B1: action matrix -> its real eigenvalues (Hessenberg + Francis QR), by ONE lane; S: 100 doubles of work space
 template <class D>
-OSFM_HD void solve5_stage_b(const Rounds& R, int k, D S) {
+OSFM_HD void solve5_stage_b1(const Rounds& R, int k, D S) {
   int n = 0;
   if (R.s5_ok[k]) {
     const LaneArr<const double, kWave> at6{R.s5_at6 + (size_t)(k / kWave) * 60 * kWave + k % kWave};
-    const LaneArr<const double, kWave> bas{R.s5_basis + (size_t)(k / kWave) * 36 * kWave + k % kWave};
-    double* out = R.s5_E + (size_t)k * kMaxModels * 9;
-    n = five_point_solutions(at6, bas, S, [&](const double* Em) {
-      for (int i = 0; i < 9; i++) out[9 * n + i] = Em[i];
-      n++;
+    OSFM_UNROLL for (int i = 0; i < 100; i++) S[i] = action_matrix_entry(at6, i);
+    double* wr = R.s5_wr + (size_t)k * kMaxModels;
+    n = real_eigenvalues10_put(S, [&](int q, double val) { wr[q] = val; });
+  }
+  R.s5_nreal[k] = n;
+}
+// ... the same by a group of kEigGroup lanes (real_eigenvalues10_group): `a` = 100 doubles the group shares, glane = 0 .. 15.
+// This is what the GPU runs (rp_eig5_kernel); the host harness runs both and the results must agree bit for bit.
+template <class PA>
+OSFM_HD void solve5_stage_b1_group(const Rounds& R, int k, PA a, int glane) {
+  int n = 0;
+  if (R.s5_ok[k]) {
+    const LaneArr<const double, kWave> at6{R.s5_at6 + (size_t)(k / kWave) * 60 * kWave + k % kWave};
+    OSFM_GROUP_FOR(j, glane)
+      for (int i = j; i < 100; i += kEigGroup) a[i] = action_matrix_entry(at6, i);
+    OSFM_GROUP_SYNC();
+    double* wr = R.s5_wr + (size_t)k * kMaxModels;
+    n = real_eigenvalues10_group(a, glane, [&](int q, double val) {
+      OSFM_GROUP_FOR(j, glane) if (j == 0) wr[q] = val;
     });
   }
-  R.nmodels[R.list5[k]] = n;
+  OSFM_GROUP_FOR(j, glane) if (j == 0) R.s5_nreal[k] = n;
+}
+// solve5 stage B2: lane q = (problem k, eigenvalue e) -> the essential matrix of that eigenvalue, if it has one; S: 100 doubles
+template <class D>
+OSFM_HD void solve5_stage_b2(const Rounds& R, int q, D S) {
+  const int k = q / kMaxModels, e = q % kMaxModels;
+  int valid = 0;
+  if (R.s5_ok[k] && e < R.s5_nreal[k]) {
+    const LaneArr<const double, kWave> at6{R.s5_at6 + (size_t)(k / kWave) * 60 * kWave + k % kWave};
+    const LaneArr<const double, kWave> bas{R.s5_basis + (size_t)(k / kWave) * 36 * kWave + k % kWave};
+    double Em[9];
+    if (five_point_solution_at(at6, bas, S, R.s5_wr[q], Em)) {
+      valid = 1;
+      double* out = R.s5_E + (size_t)q * 9;
+      for (int i = 0; i < 9; i++) out[i] = Em[i];
+    }
+  }
+  R.s5_valid[q] = valid;
 }
 
-// pose stage, five-point side: lane q = (problem k, solution j) -> RelativePoseFromEssential on the sample
+// pose stage, five-point side: lane q = (problem k, eigenvalue e) -> RelativePoseFromEssential on the sample.  The models of a slot are the
+// solutions in eigenvalue order with the failed ones left out: model index = the number of valid solutions before e
 OSFM_HD void pose5_item(const Rounds& R, int q) {
-  const int k = q / kMaxModels, j = q % kMaxModels;
+  const int k = q / kMaxModels, e = q % kMaxModels;
   const int item = R.list5[k];
-  if (j >= R.nmodels[item]) return;
+  const int* valid = R.s5_valid + (size_t)k * kMaxModels;
+  int j = 0, total = 0;
+  for (int i = 0; i < kMaxModels; i++) {
+    j += i < e ? valid[i] : 0;
+    total += valid[i];
+  }
+  if (e == 0) R.nmodels[item] = total;
+  if (!valid[e]) return;
   const int p = item / kMaxSlots;
   const int64_t o = R.offsets[p];
   const double *b1 = R.b1 + 3 * o, *b2 = R.b2 + 3 * o;
   const int* s = R.sidx + (size_t)item * 5;
   double E[9], RT[12];
-  for (int i = 0; i < 9; i++) E[i] = R.s5_E[((size_t)k * kMaxModels + j) * 9 + i];
+  for (int i = 0; i < 9; i++) E[i] = R.s5_E[(size_t)q * 9 + i];
   for (int i = 0; i < 12; i++) RT[i] = 0.0;
   relative_pose_from_essential(E, b1, b2, s, 5, RT);  // the sample's bearings straight from the pair's arrays
   double* out = R.models + ((size_t)item * kMaxModels + j) * 12;
@@ -486,6 +529,7 @@ struct RefineShared {
   int picked[kRefineResiduals];
   double rbuf[kRefineResiduals + 1][7];  // residual + gradient of the refinement
   double sums[64];                       // results of WaveRefineEval::reduce
+  double keep[48];                       // the driver's wave-uniform arrays that outlive an evaluation (J^T J): LDS instead of 72 registers
 };
 
 // Evaluator of the refinement residuals over the wavefront (see refine_relative_pose in relpose_core.h)
@@ -509,6 +553,9 @@ struct WaveRefineEval {
   OSFM_HD double res(int i) const { return s.rbuf[i][0]; }
   OSFM_HD double jac(int i, int k) const { return s.rbuf[i][1 + k]; }
   OSFM_HD double val(int i, int c) const { return s.rbuf[i][c]; }  // column 0: the residual, 1 + k: its derivative k
+  // 48 doubles of the driver's own, the same value in every lane (what one lane stores every lane loads: wave-uniform)
+  OSFM_HD void keep(int k, double v) { s.keep[k] = v; }
+  OSFM_HD double kept(int k) const { return s.keep[k]; }
   // out[q] = sum over i = 0 .. 100 (in order, from 0.0) of term(q, i), q < nsums <= 64: one sum per lane.  The terms of eight
   // consecutive i are formed before they are added (in order): their LDS reads are then in flight together instead of one round trip
   // per addition -- the sum itself is the same chain of additions

@@ -16,6 +16,10 @@ using namespace osfm_rp;
 
 static int g_max_width = kMaxSlots;  // cap of the speculative width (Rounds::max_width); results must not depend on it
 extern "C" void host_set_max_width(int b) { g_max_width = b; }
+// stage B1 by the group of lanes against stage B1 by one lane, over every five-point problem the rounds of this process solved
+static long g_eig_problems = 0, g_eig_mismatches = 0;
+extern "C" long host_eig_problems() { return g_eig_problems; }
+extern "C" long host_eig_mismatches() { return g_eig_mismatches; }
 
 struct LoopWave {  // "lanes" are loop iterations; single() runs once
   template <class F> void single(F f) { f(); }
@@ -58,6 +62,9 @@ struct HostRounds {
   std::vector<PairState> st;
   std::vector<int> sidx, pos_before, pos_after, nmodels, lidx, lo_pos_after, lo_ok, inliers, list5, listN, counters;
   std::vector<double> models, lo_rt, stop, u1, u2, s5_at6, s5_basis, s5_E, lo_E;
+  std::vector<double> s5_wr, s5_wr_check;
+  std::vector<int> s5_nreal, s5_nreal_check, s5_valid;
+  long eig_mismatches = 0;
   std::vector<int> s5_ok;
   std::vector<int64_t> stop_off;
   int rounds_run = 0;
@@ -84,6 +91,11 @@ struct HostRounds {
     s5_ok.resize(cap5);
     s5_E.resize(cap5 * kMaxModels * 9);
     lo_E.resize((size_t)n_pairs * lo * 9);
+    s5_wr.assign(cap5 * kMaxModels, 0.0);
+    s5_wr_check.assign(cap5 * kMaxModels, 0.0);
+    s5_nreal.assign(cap5, 0);
+    s5_nreal_check.assign(cap5, 0);
+    s5_valid.assign(cap5 * kMaxModels, 0);
     listN.resize((size_t)n_pairs * lo);
     counters.assign(4, 0);
     stop.resize((size_t)total + n_pairs);
@@ -97,7 +109,8 @@ struct HostRounds {
     u2.resize((size_t)(total > 0 ? total : 1) * 3);
     R = Rounds{b1, b2, u1.data(), u2.data(), off, n_pairs, stop.data(), stop_off.data(), RngTable{rng_table().data(), (int)rng_table().size()}, 1.0 - cos(thr), iterations, use_lo,
                lo_it, min_n, g_max_width, st.data(), sidx.data(), pos_before.data(), pos_after.data(), nmodels.data(), models.data(), lidx.data(),
-               lo_pos_after.data(), lo_ok.data(), lo_rt.data(), inliers.data(), s5_at6.data(), s5_basis.data(), s5_ok.data(), s5_E.data(), lo_E.data(), list5.data(), listN.data(), counters.data()};
+               lo_pos_after.data(), lo_ok.data(), lo_rt.data(), inliers.data(), s5_at6.data(), s5_basis.data(), s5_ok.data(), s5_E.data(), lo_E.data(), list5.data(), listN.data(), counters.data(),
+               s5_wr.data(), s5_nreal.data(), s5_valid.data()};
   }
   void run() {
     LoopWave w;
@@ -115,6 +128,8 @@ struct HostRounds {
                 st[0].pos, counters[0], counters[1], st[0].lo_l, st[0].cur_slot, st[0].nslots, st[0].cur_model);
       if (counters[2] == 0) {
         delete sh;
+        g_eig_mismatches += eig_mismatches;
+        g_eig_problems += solved5;
         break;
       }
       solved5 += counters[0];
@@ -126,9 +141,26 @@ struct HostRounds {
         D base{lds5.data() + lane};
         solve5_stage_a(R, k, base, base + 36, I{ldsI.data() + lane});
       }
-      for (int k = 0; k < counters[0]; k++) {  // stage B: LDS layout S
+      // stage B1 twice: by the group of lanes the GPU uses (here its lane loops run in turn) and by one lane; the eigenvalues must
+      // agree bit for bit (eig_mismatches is checked by the test)
+      for (int k = 0; k < counters[0]; k++) {
+        double shared_a[104];
+        solve5_stage_b1_group(R, k, shared_a, 0);
+      }
+      for (int k = 0; k < counters[0]; k++) {
+        s5_nreal_check[k] = s5_nreal[k];
+        for (int q = 0; q < kMaxModels; q++) s5_wr_check[(size_t)k * kMaxModels + q] = s5_wr[(size_t)k * kMaxModels + q];
+      }
+      for (int k = 0; k < counters[0]; k++) {
         const int lane = k % 64;
-        solve5_stage_b(R, k, D{lds5.data() + lane});
+        solve5_stage_b1(R, k, D{lds5.data() + lane});
+        if (s5_nreal[k] != s5_nreal_check[k]) eig_mismatches++;
+        for (int q = 0; q < s5_nreal[k] && q < s5_nreal_check[k]; q++)
+          if (memcmp(&s5_wr[(size_t)k * kMaxModels + q], &s5_wr_check[(size_t)k * kMaxModels + q], 8) != 0) eig_mismatches++;
+      }
+      for (int q = 0; q < counters[0] * kMaxModels; q++) {  // stage B2: LDS layout S
+        const int lane = q % 64;
+        solve5_stage_b2(R, q, D{lds5.data() + lane});
       }
       for (int q = 0; q < counters[0] * kMaxModels; q++) pose5_item(R, q);
       for (int k = 0; k < counters[1]; k++) {  // N-point: registers on the GPU, plain arrays here

@@ -243,6 +243,26 @@ def test_a_batch_of_pairs_goes_through_the_rounds_together(host, oracle_lib):
         host.host_set_max_width(16)
 
 
+def test_group_eigenvalues_equal_the_single_lane_ones(host, oracle_lib):
+    """stage B1 as the GPU runs it (real_eigenvalues10_group: sixteen lanes share the matrix, lane j owns column j / row j; the harness
+    runs its lane loops in turn) against stage B1 by one lane, on every five-point problem of a batch: counts and bits"""
+    host.host_eig_problems.restype = C.c_long
+    host.host_eig_mismatches.restype = C.c_long
+    before = host.host_eig_problems()
+    rng = np.random.default_rng(5)
+    sizes = [40, 200, 300, 64, 9, 150]
+    scenes = [_scene(rng, n, outliers=o, noise=nz) for n, o, nz in zip(sizes, (0.3, 0.6, 0.8, 0.0, 0.2, 0.5), (1e-3, 1e-3, 1e-2, 0.0, 1e-4, 3e-3))]
+    b1 = np.ascontiguousarray(np.concatenate([s[0] for s in scenes]))
+    b2 = np.ascontiguousarray(np.concatenate([s[1] for s in scenes]))
+    off = np.r_[0, np.cumsum(sizes)].astype(np.int64)
+    scores, iters = np.zeros(len(sizes), np.int32), np.zeros(len(sizes), np.int32)
+    models, mask = np.zeros((len(sizes), 24)), np.zeros(len(b1), np.uint8)
+    host.host_rounds_ransac_batch(_p(b1, C.c_double), _p(b2, C.c_double), _p(off, C.c_int64), len(sizes), C.c_double(0.004), 1000, C.c_double(0.99),
+                                  1, 10, _p(scores, C.c_int32), _p(iters, C.c_int32), _p(models, C.c_double), _p(mask, C.c_uint8))
+    assert host.host_eig_problems() - before > 500
+    assert host.host_eig_mismatches() == 0
+
+
 def test_refinement_bits(host, oracle_lib):
     rng = np.random.default_rng(3)
     for trial in range(20):
