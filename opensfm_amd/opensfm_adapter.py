@@ -374,7 +374,13 @@ def _set_internal_priors_and_loss(ba, config) -> None:
 
 def _add_instances(ba, reconstruction, rig_instance_ids, is_free_shot, config) -> None:
     """the rig-instance loop BundleLocal and BundleShotPoses share (ba_helpers.cc:176-224, 467-511): an instance is constant as soon as
-    one of its shots is not to be optimised; moving instances get the average GPS position / accuracy of their free shots as a prior"""
+    one of its shots is not to be optimised; moving instances get the average GPS position / accuracy of their free shots as a prior.
+
+    Known divergence, on purpose: BundleShotPoses (ba_helpers.cc:467-511) calls AddRigInstance and AddRigInstancePositionPrior INSIDE
+    its loop over the instance's shots, dividing the running sums by the running count each time -- for an instance with three or
+    more free shots (or free and fixed shots mixed) the prior it ends with depends on the iteration order of an unordered_map.
+    BundleLocal (:176-224) adds once, after the loop, which is what this function does for both; instances of one or two shots
+    (every data set without a multi-camera rig) get identical priors either way."""
     use_gps = bool(_cfg(config, "bundle_use_gps"))
     for rig_instance_id in rig_instance_ids:
         instance = reconstruction.rig_instances[rig_instance_id]
