@@ -3417,6 +3417,24 @@ __global__ void border_rhs_kernel(const double *Bc, const double *SigInv, const 
     z[cam0 + threadIdx.x] = acc;
   }
 }
+// ... the same in two launches for long rows (round 6): row i of B^T z_s by workgroup i -- the same threads add the same entries in the same
+// order as in the single block, so y has the same bits --, then z_c = SigInv y.  The single block walked its nb rows one after the other:
+// 129 us for the sixteen border rows of a Brown camera with a GPS bias at configs[4] (6 S = 30 000 entries each), 12 us this way.
+__global__ void __launch_bounds__(1024) border_rhs_dots_kernel(const double *Bc, const double *r, const double *z, double *y, int n, int cam0) {
+  __shared__ double lds[32];
+  const int i = blockIdx.x;
+  double v[1] = {0.0};
+  for (int t = threadIdx.x; t < n; t += blockDim.x) v[0] += Bc[(long)i * n + t] * z[t];
+  block_sum<1>(v, lds);
+  if (threadIdx.x == 0) y[i] = r[cam0 + i] - v[0];
+}
+__global__ void border_rhs_apply_kernel(const double *SigInv, const double *y, double *z, int nb, int cam0) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nb) return;
+  double acc = 0.0;
+  for (int j = 0; j < nb; j++) acc += SigInv[i * nb + j] * y[j];
+  z[cam0 + i] = acc;
+}
 // z_s -= W z_c
 __global__ void border_update_kernel(const double *W, double *z, int nb, int n, int cam0) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -4145,7 +4163,9 @@ struct Solver {
   int gen_nprior() const { return d.NC + d.g.NRC + d.S + 4 * d.g.NV; }
   // dynamic LDS of gen_prior_kernel: the workgroup's copy of Cpri and of the border gradient in mode 1, while the border is narrow enough for it
   // (beyond kGenPriorLdsMaxNB the kernel adds to the global arrays directly); modes 0 and 2 use none
-  size_t gen_prior_lds(int mode) const { return (mode == 1 && d.g.NB <= kGenPriorLdsMaxNB) ? (size_t)(d.g.NB * d.g.NB + d.g.NB + 2) * sizeof(double) : 0; }
+  size_t gen_prior_lds(int mode) const {
+    return (mode == 1 && d.g.NB <= kGenPriorLdsMaxNB) ? (size_t)((d.g.NB * d.g.NB + d.g.NB) * gen_prior_copies(d.g.NB) + 2) * sizeof(double) : 0;
+  }
   // cost (with priors) at the given parameters into scal[8] (sum of squares of the reprojections into scal[9]); jac: the Jacobian rows
   // and the prior blocks as well
   void gen_eval_enqueue(const double *cam, const double *bias, const double *rcp, const double *poses, const double *pts, bool jac) {
@@ -4278,6 +4298,8 @@ struct Solver {
   hipStream_t st2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   double *Bc = nullptr, *Wb = nullptr, *SigInv = nullptr, *dots = nullptr;  // border elimination (nb x 6S, nb x 6S, nb x nb, nb x nb)
+  double *yb = nullptr;                                                     // ... r_c - B^T z_s (nb) between the two launches of the long-row path
+  static constexpr int kBorderRhsSplit = 6 * 512;                           // rows of at least this many entries take the two-launch path
   double *wB = nullptr, *partB = nullptr, *dCm = nullptr;                     // its columns in one pass: w (2 nb per observation), camera partials, C
   // z_q = A^-1 r_q for nrhs right-hand sides (strides in doubles) in one walk of the levels
   void bcr_solve_set(const RhsSet &rs) {
@@ -4468,8 +4490,14 @@ struct Solver {
     if ((use_bcr || use_wide) && use_border) {
       const int nb = d.gen ? d.g.NB : 3 * d.NC, n = 6 * d.S;
       if (!solved) exact_solve_set(one);
-      if (d.gen) hipLaunchKernelGGL(gen_border_rhs_kernel, dim3(1), dim3(1024), 0, st, Bc, SigInv, r, z, nb, n, d.cam0);
-      else hipLaunchKernelGGL(border_rhs_kernel, dim3(1), dim3(1024), 0, st, Bc, SigInv, r, z, nb, n, d.cam0);
+      if (n >= kBorderRhsSplit) {  // long rows: a workgroup per row, then the nb x nb product (same bits as the single block)
+        hipLaunchKernelGGL(border_rhs_dots_kernel, dim3(nb), dim3(1024), 0, st, Bc, r, (const double *)z, yb, n, d.cam0);
+        hipLaunchKernelGGL(border_rhs_apply_kernel, dim3((nb + 63) / 64), dim3(64), 0, st, SigInv, (const double *)yb, z, nb, d.cam0);
+      } else if (d.gen) {
+        hipLaunchKernelGGL(gen_border_rhs_kernel, dim3(1), dim3(1024), 0, st, Bc, SigInv, r, z, nb, n, d.cam0);
+      } else {
+        hipLaunchKernelGGL(border_rhs_kernel, dim3(1), dim3(1024), 0, st, Bc, SigInv, r, z, nb, n, d.cam0);
+      }
       hipLaunchKernelGGL(border_update_kernel, dim3(nblk(n)), dim3(TPB), 0, st, Wb, z, nb, n, d.cam0);
       return;
     }
@@ -5340,6 +5368,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     sv.Bc = A.alloc<double>((size_t)nbord * 6 * S, e);
     sv.Wb = A.alloc<double>((size_t)nbord * 6 * S, e);
     sv.SigInv = A.alloc<double>((size_t)nbord * nbord, e);
+    sv.yb = A.alloc<double>((size_t)nbord + 8, e);
     sv.dots = A.alloc<double>((size_t)nbord * nbord, e);
     sv.dCm = A.alloc<double>((size_t)nbord * nbord, e);
     if (!gen) {
