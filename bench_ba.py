@@ -126,7 +126,8 @@ def run_ragged(ctx, shots: int = 5000, points: int = 500000, track: int = 10, it
     return out
 
 
-def run_general(ctx, shots: int = 5000, points: int = 500000, track: int = 10, iters: int = 10, seed: int = 42, cpu_size=(200, 12000, 8), cpu_iters: int = 6) -> dict:
+def run_general(ctx, shots: int = 5000, points: int = 500000, track: int = 10, iters: int = 10, seed: int = 42, cpu_size=(200, 12000, 8), cpu_iters: int = 6,
+                at_size_iters: int = 2) -> dict:
     """What BAHelpers::Bundle builds on a CALIBRATED data set, at the headline size: a shared BROWN camera with its nine native intrinsics
     free (+ priors), position priors through a free per-camera similarity bias (bundle_compensate_gps_bias), 20 ground control points.
     `osfm_bundle_solve` = the streaming solver in its generic mode (csrc/ba_generic.inc): 16 border unknowns instead of 3, rows of
@@ -176,6 +177,20 @@ def run_general(ctx, shots: int = 5000, points: int = 500000, track: int = 10, i
                                "cost_history_max_rel_diff": float(np.max(np.abs(ch_o - ch_g) / np.maximum(np.abs(ch_o), 1e-300))),
                                "rmse_px_diff": abs(rm(o["reproj_err"]) - rm(gs["reproj_err"])),
                                "max_abs_diff": {k: float(np.abs(o[k] - gs[k]).max()) for k in ("cam_params", "rig_instance_pose", "points", "bias")}}
+        if at_size_iters > 0:
+            # the SAME problem as the line above, at configs[4] size, against the arrow-form oracle (envelope Cholesky of the 30 016 reduced
+            # unknowns) over the first LM iterations: parity at the size the figure is quoted on, ~1 minute of host work
+            t0 = time.perf_counter()
+            oa = oracle.bundle_general(pr, max_iterations=at_size_iters, **no_tol)
+            dta = time.perf_counter() - t0
+            ga = bundle.bundle_general_arrays(pr, {"bundle_max_iterations": at_size_iters}, ctx=ctx, **no_tol)
+            ca_o, ca_g = np.asarray(oa["cost_history"]), np.asarray(ga["cost_history"])
+            out["cpu_baseline"]["at_size"] = {
+                "sample": f"the first {at_size_iters} LM iterations of the line's own problem ({dta:.1f} s on {oracle.num_threads()} threads)",
+                "value": round(oa["iterations"] / dta, 4), "unit": "LM-iters/s", "parity_iterations": int(at_size_iters),
+                "cost_history_max_rel_diff": float(np.max(np.abs(ca_o - ca_g) / np.maximum(np.abs(ca_o), 1e-300))),
+                "rmse_px_diff": abs(rm(oa["reproj_err"]) - rm(ga["reproj_err"])),
+                "max_abs_diff": {k: float(np.abs(oa[k] - ga[k]).max()) for k in ("cam_params", "rig_instance_pose", "points", "bias")}}
     return out
 
 
