@@ -354,6 +354,7 @@ struct Dev {
   double *x, *r, *z, *p, *Ap, *b;
   double *scal;     // device scalars
   double *partial;  // block partial sums
+  double *partial2; // ... of candidate_points_kernel (it runs in front of candidate_kernel, which still reads the back-substitution's shares in `partial`)
   double *dotp;     // the mat-vec's shares of p . Ap, one per workgroup of the finish kernel
   double *rrp;      // pcg_step1_kernel's shares of r . r, one per workgroup (their own buffer: the straight-line iteration reads them after the
                     // back-substitution and the evaluation have reused `partial`)
@@ -932,9 +933,14 @@ __global__ void __launch_bounds__(64) precond_shot_kernel(Dev d, double radius) 
   }
 }
 
+__device__ __forceinline__ void precond_cam_one(const Dev &d, int c, double radius);
 __global__ void precond_cam_kernel(Dev d, double radius) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= d.NC) return;
+  precond_cam_one(d, c, radius);
+}
+// the 3 x 3 block-Jacobi block of camera c (inverse into Binv's camera part)
+__device__ __forceinline__ void precond_cam_one(const Dev &d, int c, double radius) {
   double v[6];
   for (int i = 0; i < 6; i++) v[i] = d.camred[9 * c + i];
   double B[3][3];
@@ -2122,6 +2128,253 @@ inline BcrLaunch bcr_level_for(int cs) {
   }
 }
 
+// ---- small problems: the exact band factorised by ONE workgroup, A = L D L^T (round 6) ---------------------------------------------
+// Local bundle adjustment (BAHelpers::BundleLocal, ba_helpers.cc:117-311: ~50 shots, once per added image) has a handful of clusters: the
+// cyclic reduction above is then build + four dependent level launches of one to three workgroups (36-48 us each: nine pivot steps of a
+// 54 x 54 Gauss-Jordan and three products per level) + three walk launches -- 227 us of the 390 us an LM iteration takes.  When the whole
+// band (S (bw + 1) blocks of 6 x 6) fits one workgroup's LDS it is factorised right-looking with 6 x 6 pivots in one launch:
+//   step j:  Dinv_j = A_jj^-1,  L_ij = A_ij Dinv_j (j < i <= j + bw),  A_ik -= L_ij A_kj^T (j < k <= i <= j + bw)
+// The chain is the pivot inverse (the same in-register Gauss-Jordan as the cyclic reduction's, ~0.5 us), so it is taken off the rest:
+// wavefront 0 updates the next pivot block A_(j+1)(j+1) (an entry per lane) and inverts it while the other three wavefronts apply step j to
+// every other block of the window (a 3 x 3 quarter per lane); behind a barrier wavefront 0 forms the rows of L_(., j+1) from the inverse in its
+// registers; two barriers per step.  (Round 5 measured a one-workgroup band Cholesky at 4.3 us per shot -- five barriers and a serial 6 x 6
+// factor per shot -- and dropped it.)
+// Output, in the band's own layout: slot 0 of row j = the pivot block D_j (the solve inverts it again while it loads the factor: 48 threads, ~1 us),
+// slot a = L_(j, j-a).  The band itself is left as assembled (the fallback reads it).
+// Measured (profiles/r06_local_ba_kernels_by_grid.txt): 2.0 us per step -- ~450 fp64 / LDS instructions of wavefront 0 at the ~8 cycles each that a
+// single wavefront per SIMD sustains -- 93 us for 48 shots against 209 us for build + four levels.  Measured and dropped: the pivot's inverse through
+// its 3 x 3 quarters (adjugates, two divisions instead of six: 97 -> 93 us, and the facade's two-shot scene with weak priors lost three digits).
+constexpr int kSbThreads = 256;
+constexpr size_t kSbLdsMax = 160 * 1024 - 512;
+constexpr int kSbSolveWaves = 4;  // right-hand sides per workgroup of the solve (a wavefront each, one copy of the factor in LDS)
+inline size_t sband_factor_lds(int S, int bw) { return ((size_t)S * (bw + 1) * 36 + (size_t)2 * bw * 36) * sizeof(double); }
+inline size_t sband_solve_lds(int S, int bw) { return ((size_t)S * (bw + 1) * 36 + (size_t)kSbSolveWaves * 6 * S) * sizeof(double); }
+// A_ik[3 qr .. +3][3 qc .. +3] -= (L_ij A_kj^T)[...]: Lr = rows 3 qr.. of L_ij, Ak = rows 3 qc.. of A_kj, Aq = the quarter's first entry
+__device__ __forceinline__ void sband_quarter(const double *Lr, const double *Ak, double *Aq) {
+  double l[3][6], a[3][6];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int m = 0; m < 6; m++) {
+      l[r][m] = Lr[6 * r + m];
+      a[r][m] = Ak[6 * r + m];
+    }
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      double acc = Aq[6 * r + c];
+#pragma unroll
+      for (int m = 0; m < 6; m++) acc = __builtin_fma(-l[r][m], a[c][m], acc);
+      Aq[6 * r + c] = acc;
+    }
+}
+__global__ void __launch_bounds__(kSbThreads) sband_factor_kernel(Dev d, double *sbL, int *status) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  __shared__ unsigned char pair_a[64], pair_b[64];
+  const int S = d.S, bw = d.bw, R1 = bw + 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double *Ab = lds, *Lb = lds + (size_t)S * R1 * 36;  // the band; the rows of L_(., j) of two consecutive steps
+  const int total = S * R1 * 36;
+  for (int t = tid; t < total; t += kSbThreads) Ab[t] = d.band[t];
+  const int npairs = bw * (bw + 1) / 2 - 1;  // (a, b), 1 <= b <= a <= bw without (1, 1): the blocks wavefronts 1 .. 3 update
+  if (tid == 0) {
+    *status = 0;
+    int n = 0;
+    for (int a = 2; a <= bw; a++)
+      for (int b = 1; b <= a; b++) {
+        pair_a[n] = (unsigned char)a;
+        pair_b[n] = (unsigned char)b;
+        n++;
+      }
+  }
+  __syncthreads();
+  int bad = 0;
+  double P[6][6];  // wavefront 0: Dinv_j, in every lane
+  auto invert = [&](int j) {
+    const double *Ajj = Ab + (size_t)j * R1 * 36;
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+      for (int c = 0; c < 6; c++) P[r][c] = Ajj[6 * r + c];
+    inv6_spd(P, bad);
+  };
+  auto l_rows = [&](int j) {  // the rows of L_(., j) = A_(., j) Dinv_j: lane = (a - 1) 6 + r
+    const int na = min(bw, S - 1 - j);
+    double *Lj = Lb + (size_t)(j & 1) * bw * 36;
+    if (lane < 6 * na) {
+      const int a = 1 + lane / 6, r = lane - 6 * (a - 1);
+      const double *Ar = Ab + ((size_t)(j + a) * R1 + a) * 36 + 6 * r;
+      double x[6], v[6];
+#pragma unroll
+      for (int m = 0; m < 6; m++) x[m] = Ar[m];
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        double s = 0.0;
+#pragma unroll
+        for (int m = 0; m < 6; m++) s = __builtin_fma(x[m], P[m][c], s);
+        v[c] = s;
+      }
+      double *go = sbL + ((size_t)(j + a) * R1 + a) * 36 + 6 * r;
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        Lj[(a - 1) * 36 + 6 * r + c] = v[c];
+        go[c] = v[c];
+      }
+    }
+  };
+  if (wave == 0) {
+    invert(0);
+    l_rows(0);
+  }
+  __syncthreads();
+  for (int j = 0; j + 1 < S; j++) {
+    const double *Lj = Lb + (size_t)(j & 1) * bw * 36;
+    const int na = min(bw, S - 1 - j);
+    if (wave == 0) {  // the next pivot block, an entry per lane, and its inverse
+      if (lane < 36) {
+        const int r = lane / 6, c = lane - 6 * r;
+        const double *Lr = Lj + 6 * r, *Ak = Ab + ((size_t)(j + 1) * R1 + 1) * 36 + 6 * c;
+        double *Aq = Ab + (size_t)(j + 1) * R1 * 36 + lane;
+        double acc = *Aq;
+#pragma unroll
+        for (int m = 0; m < 6; m++) acc = __builtin_fma(-Lr[m], Ak[m], acc);
+        *Aq = acc;
+      }
+      WAVE_SYNC();
+      invert(j + 1);
+    } else {  // every other block of the window
+      for (int t = tid - 64; t < 4 * npairs; t += kSbThreads - 64) {
+        const int p = t >> 2, q = t & 3, qr = q >> 1, qc = q & 1, a = pair_a[p], b = pair_b[p];
+        if (a > na) continue;
+        sband_quarter(Lj + (a - 1) * 36 + 18 * qr, Ab + ((size_t)(j + b) * R1 + b) * 36 + 18 * qc, Ab + ((size_t)(j + a) * R1 + (a - b)) * 36 + 18 * qr + 3 * qc);
+      }
+    }
+    __syncthreads();
+    if (wave == 0) l_rows(j + 1);  // (column j + 1 is complete: wavefronts 1 .. 3 updated its blocks below the pivot)
+    __syncthreads();
+  }
+  // the pivot blocks as they were when they were inverted (slot 0 of their rows: nothing writes them afterwards); the solve inverts them again
+  // on its way in -- the inverse's 36 stores by masked lanes were 40 instructions on wavefront 0's chain of every step
+  for (int t = tid; t < S * 36; t += kSbThreads) {
+    const int j = t / 36, e = t - 36 * j;
+    sbL[(size_t)j * R1 * 36 + e] = Ab[(size_t)j * R1 * 36 + e];
+  }
+  if (bad) *status = 1;
+}
+// z_q = (L D L^T)^-1 r_q: a wavefront per right-hand side, kSbSolveWaves of them share the workgroup's copy of the factor.  Both sweeps are
+// column-oriented (no reductions across lanes): forward, lane (a, r) takes L_(j+a, j)[r, :] y_j off row (j + a, r); backward, lane (a, c)
+// takes L_(i, i-a)[:, c]^T x_i off row (i - a, c).  The camera rows of right-hand side cam_q: 3 x 3 block Jacobi, as bcr_up_kernel does.
+// fuse.on (one right-hand side, every camera constant: local / pose-only bundle adjustment): the camera rows' blocks are formed here
+// (precond_cam_kernel's launch) and the start of PCG follows the solve (pcg_init_kernel's launch: x = 0, r = b, p = z, y = sc p, r . z, b . b)
+struct SbFuse {
+  int on;
+  double radius;
+  double *x, *r, *p, *y, *o_rz, *o_bb;
+  const double *sc;
+};
+__global__ void __launch_bounds__(64 * kSbSolveWaves) sband_solve_kernel(Dev d, const double *sbL, RhsSet rs, SbFuse fuse) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int S = d.S, bw = d.bw, R1 = bw + 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double *Lb = lds, *xv = lds + (size_t)S * R1 * 36 + (size_t)wave * 6 * S;
+  const int total = S * R1 * 36, n6 = 6 * S;
+  for (int t = tid; t < total; t += 64 * kSbSolveWaves) Lb[t] = sbL[t];
+  const int q = blockIdx.x * kSbSolveWaves + wave;
+  const bool on = q < rs.nrhs;
+  if (on) {
+    const double *in = rs.in(q);
+    for (int t = lane; t < n6; t += 64) xv[t] = in[t];
+  }
+  __syncthreads();
+  for (int j = tid; j < S; j += 64 * kSbSolveWaves) {  // slot 0 of row j: the pivot block D_j -> Dinv_j (positive definite: the factorisation's status said so)
+    double P[6][6];
+    double *Dj = Lb + (size_t)j * R1 * 36;
+    int bad = 0;
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+      for (int c = 0; c < 6; c++) P[r][c] = Dj[6 * r + c];
+    inv6_spd(P, bad);
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+      for (int c = 0; c < 6; c++) Dj[6 * r + c] = P[r][c];
+  }
+  __syncthreads();
+  if (!on) return;
+  const int a = 1 + lane / 6, r = lane - 6 * (a - 1);
+  for (int j = 0; j + 1 < S; j++) {
+    if (a <= min(bw, S - 1 - j)) {
+      const double *Lr = Lb + ((size_t)(j + a) * R1 + a) * 36 + 6 * r;
+      double s = xv[6 * (j + a) + r];
+#pragma unroll
+      for (int m = 0; m < 6; m++) s = __builtin_fma(-Lr[m], xv[6 * j + m], s);
+      xv[6 * (j + a) + r] = s;
+    }
+    WAVE_SYNC();
+  }
+  for (int t0 = 0; t0 < n6; t0 += 60) {  // z_j = Dinv_j y_j, ten shots at a time (a shot's six rows are read before any of them is written)
+    const int t = t0 + lane;
+    double s = 0.0;
+    if (lane < 60 && t < n6) {
+      const int j = t / 6, rr = t - 6 * j;
+      const double *Dr = Lb + (size_t)j * R1 * 36 + 6 * rr;
+#pragma unroll
+      for (int m = 0; m < 6; m++) s = __builtin_fma(Dr[m], xv[6 * j + m], s);
+    }
+    WAVE_SYNC();
+    if (lane < 60 && t < n6) xv[t] = s;
+  }
+  WAVE_SYNC();
+  for (int i = S - 1; i >= 1; i--) {
+    if (a <= min(bw, i)) {
+      const double *Lc = Lb + ((size_t)i * R1 + a) * 36 + r;
+      double s = xv[6 * (i - a) + r];
+#pragma unroll
+      for (int m = 0; m < 6; m++) s = __builtin_fma(-Lc[6 * m], xv[6 * i + m], s);
+      xv[6 * (i - a) + r] = s;
+    }
+    WAVE_SYNC();
+  }
+  double *zq = rs.out(q);
+  const double *rin = rs.in(q);
+  double dots[2] = {0.0, 0.0};
+  auto start_pcg = [&](int t, double zi) {
+    const double bi = rin[t];
+    fuse.x[t] = 0.0;
+    fuse.r[t] = bi;
+    fuse.p[t] = zi;
+    fuse.y[t] = fuse.sc[t] * zi;
+    dots[0] += bi * zi;
+    dots[1] += bi * bi;
+  };
+  for (int t = lane; t < n6; t += 64) {
+    zq[t] = xv[t];
+    if (fuse.on) start_pcg(t, xv[t]);
+  }
+  if (q == rs.cam_q) {
+    for (int g = lane; g < d.NC; g += 64) {
+      if (fuse.on) precond_cam_one(d, g, fuse.radius);  // (this lane reads back what it has just written)
+      const double *Bi = d.Binv + 36 * (long)d.S + 9 * g, *rc = rin + d.cam0 + 3 * g;
+      for (int k = 0; k < 3; k++) {
+        const double zi = Bi[3 * k] * rc[0] + Bi[3 * k + 1] * rc[1] + Bi[3 * k + 2] * rc[2];
+        zq[d.cam0 + 3 * g + k] = zi;
+        if (fuse.on) start_pcg(d.cam0 + 3 * g + k, zi);
+      }
+    }
+  }
+  if (fuse.on) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      dots[0] += __shfl_xor(dots[0], m);
+      dots[1] += __shfl_xor(dots[1], m);
+    }
+    if (lane == 0) {
+      *fuse.o_rz = dots[0];
+      *fuse.o_bb = dots[1];
+    }
+  }
+}
+
 // ---- wide band: direct block LDL^T of the shot-shot Schur complement (round 3) --------------------------------------------------
 // Block surveys, loops, unordered collections: the co-visibility half-width is tens to hundreds of shots, beyond what the
 // cluster-tridiagonal cyclic reduction can hold in LDS (and a band truncated to 15 shots is a preconditioner in name only: ~1000 CG
@@ -3190,8 +3443,9 @@ __global__ void pcg_init_kernel(const double *b, const double *z, double *x, dou
 // x += alpha p, r -= alpha Ap with alpha = rz / pAp, pAp = the sum of the mat-vec's shares dot_part[0 .. nparts) in workgroup order (every
 // workgroup adds them the same way: the same alpha everywhere; dot_part == nullptr: pAp is in *o_pAp already).  Also leaves the block's share
 // of r.r in rr_part[block] (summed by the host in block order when it polls: deterministic).
+// y_out (if any) = sc x for the back-substitution that follows the last iteration (scale_vec_kernel's launch)
 __global__ void __launch_bounds__(TPB) pcg_step1_kernel(double *x, double *r, const double *p, const double *Ap, int n, const double *rz, const double *dot_part, int nparts,
-                                                         double *o_pAp, double *rr_part) {
+                                                         double *o_pAp, double *rr_part, const double *sc = nullptr, double *y_out = nullptr) {
   __shared__ double lds[32];
   __shared__ double s_alpha;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -3213,7 +3467,9 @@ __global__ void __launch_bounds__(TPB) pcg_step1_kernel(double *x, double *r, co
   double v[1] = {0.0};
   if (i < n) {
     const double alpha = s_alpha;
-    x[i] += alpha * p[i];
+    const double xi = x[i] + alpha * p[i];
+    x[i] = xi;
+    if (y_out) y_out[i] = sc[i] * xi;
     const double ri = r[i] - alpha * Ap[i];
     r[i] = ri;
     v[0] = ri * ri;
@@ -3251,13 +3507,24 @@ __global__ void pcg_step2_kernel(double *p, const double *z, int n, const double
 // out: [0] += prior model change ; [1] step^2 ; [2] x^2  (over variable blocks only)
 // (round 6: out[0] starts from the sum of the back-substitution's npart workgroup shares of the observations' model change, partial[0 .. npart)
 // in workgroup order -- finish_reduce_kernel's launch in front of this one is gone)
-__global__ void __launch_bounds__(1024) candidate_kernel(Dev d, const double *y, const double *partial, long npart, double *out) {
+// (later in round 6: the points' shares of the step's norms -- candidate_points_kernel's part2[0 .. 2 npart2), launched in FRONT of this kernel now -- are
+// summed here too, out2[c] = sum_i part2[2 i + c] as finish_reduce_kernel formed them, and the candidate's rotation blocks are written with its poses:
+// finish_reduce_kernel's and shot_rot_kernel's launches behind this one are gone)
+__global__ void __launch_bounds__(1024) candidate_kernel(Dev d, const double *y, const double *partial, long npart, double *out, const double *part2, long npart2,
+                                                         double *out2, int do_rot) {
   __shared__ double lds[32];
   {
     double m[1] = {0.0};
     for (long i = threadIdx.x; i < npart; i += blockDim.x) m[0] += partial[i];
     block_sum<1>(m, lds);
     if (threadIdx.x == 0) out[0] = m[0];
+    __syncthreads();
+  }
+  for (int c = 0; c < 2; c++) {
+    double m[1] = {0.0};
+    for (long i = threadIdx.x; i < npart2; i += blockDim.x) m[0] += part2[2 * i + c];
+    block_sum<1>(m, lds);
+    if (threadIdx.x == 0) out2[c] = m[0];
     __syncthreads();
   }
   double v[3] = {0, 0, 0};
@@ -3312,14 +3579,19 @@ __global__ void __launch_bounds__(1024) candidate_kernel(Dev d, const double *y,
         v[0] -= m * (ru[i] + 0.5 * m);
       }
     }
+    double pn[6];
     for (int k = 0; k < 6; k++) {
       const double dl = fixed ? 0.0 : ys[k];
-      d.poses_n[6 * s + k] = ps[k] + dl;
+      pn[k] = ps[k] + dl;
+      d.poses_n[6 * s + k] = pn[k];
       if (!fixed) {
         v[1] += dl * dl;
         v[2] += ps[k] * ps[k];
       }
     }
+    // shot_rot_kernel's work for the candidate (up_r / up_J above are arrays of the old point): while a thread has one shot -- 5 000 shots' blocks by
+    // one workgroup were 67 us at configs[4] against the 6 us of the launch
+    if (do_rot) rot_and_derivs(pn, d.shotR + 36 * (long)s, d.shotR + 36 * (long)s + 9);
   }
   block_sum<3>(v, lds);
   if (threadIdx.x == 0) {
@@ -3328,7 +3600,7 @@ __global__ void __launch_bounds__(1024) candidate_kernel(Dev d, const double *y,
     out[2] = v[2];
   }
 }
-__global__ void __launch_bounds__(TPB) candidate_points_kernel(Dev d) {
+__global__ void __launch_bounds__(TPB) candidate_points_kernel(Dev d, double *part) {
   __shared__ double lds[16];
   const long i = (long)blockIdx.x * TPB + threadIdx.x;
   double v[2] = {0, 0};
@@ -3343,8 +3615,8 @@ __global__ void __launch_bounds__(TPB) candidate_points_kernel(Dev d) {
   }
   block_sum<2>(v, lds);
   if (threadIdx.x == 0) {
-    d.partial[2 * blockIdx.x] = v[0];
-    d.partial[2 * blockIdx.x + 1] = v[1];
+    part[2 * blockIdx.x] = v[0];
+    part[2 * blockIdx.x + 1] = v[1];
   }
 }
 __global__ void absmax_kernel(const double *a, long n, const double *b, long m, double *out) {
@@ -3355,6 +3627,31 @@ __global__ void absmax_kernel(const double *a, long n, const double *b, long m, 
   const long stride = (long)gridDim.x * blockDim.x, t0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
   for (long i = t0; i < n; i += stride) v = fmax(v, fabs(a[i]));
   for (long i = t0; i < m; i += stride) v = fmax(v, fabs(b[i]));
+  for (int k = 32; k >= 1; k >>= 1) v = fmax(v, __shfl_xor(v, k));
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (unsigned w = 1; w < (blockDim.x + 63) / 64; w++) v = fmax(v, lds[w]);
+    atomicMax((unsigned long long *)out, (unsigned long long)__double_as_longlong(v));
+  }
+}
+// lm_diag_kernel and absmax_kernel(g_red, g_pt) in one launch (they read and write different arrays); *out must be zeroed first
+__global__ void __launch_bounds__(256) lm_diag_absmax_kernel(Dev d, double *out) {
+  __shared__ double lds[32];
+  const long stride = (long)gridDim.x * blockDim.x, t0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n = d.nred, m = 3L * d.P;
+  double v = 0;
+  for (long i = t0; i < n; i += stride) {
+    d.D_red[i] = fmin(fmax(d.diag_red[i] * d.sc_red[i] * d.sc_red[i], 1e-6), 1e32);
+    v = fmax(v, fabs(d.g_red[i]));
+  }
+  for (long i = t0; i < m; i += stride) {
+    const long p = i / 3;
+    const int j = (int)(i - 3 * p);
+    const int dg[3] = {0, 3, 5};
+    d.D_pt[i] = fmin(fmax(d.Hpp[6 * p + dg[j]] * d.sc_pt[i] * d.sc_pt[i], 1e-6), 1e32);
+    v = fmax(v, fabs(d.g_pt[i]));
+  }
   for (int k = 32; k >= 1; k >>= 1) v = fmax(v, __shfl_xor(v, k));
   if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
   __syncthreads();
@@ -4260,12 +4557,13 @@ struct Solver {
   }
 
   // cost (with priors) at (cams, poses, pts) into scal[8] (and the sum of squares into scal[9]); optionally builds the Jacobian
-  void eval_enqueue(const double *cams, const double *poses, const double *pts, bool jac) {
+  // rot_done: shotR holds the rotation blocks of `poses` already (candidate_kernel writes them with the candidate)
+  void eval_enqueue(const double *cams, const double *poses, const double *pts, bool jac, bool rot_done = false) {
     if (d.gen) {  // the candidate lives in the *_n arrays of every block
       const bool cand = poses == d.poses_n;
       return gen_eval_enqueue(cand ? d.g.cam_n : d.g.cam, cand ? d.g.bias_n : d.g.bias, cand ? d.g.rc_n : d.g.rc, poses, pts, jac);
     }
-    rot(poses);
+    if (!rot_done) rot(poses);
     if (jac) hipLaunchKernelGGL(eval_kernel<true>, dim3(d.nwg), dim3(kCoopObs), 0, st, d, cams, poses, pts, loss, loss_a);  // rows, point blocks, cost
     else hipLaunchKernelGGL(eval_kernel<false>, dim3(d.nwg), dim3(kCoopObs), 0, st, d, cams, poses, pts, loss, loss_a);
     hipLaunchKernelGGL(prior_cost_kernel, dim3(1), dim3(1024), 0, st, d, cams, poses, (const double *)d.partial, (long)d.nwg, d.scal + 8, d.scal + 10, jac ? 1 : 0);
@@ -4302,7 +4600,14 @@ struct Solver {
   static constexpr int kBorderRhsSplit = 6 * 512;                           // rows of at least this many entries take the two-launch path
   double *wB = nullptr, *partB = nullptr, *dCm = nullptr;                     // its columns in one pass: w (2 nb per observation), camera partials, C
   // z_q = A^-1 r_q for nrhs right-hand sides (strides in doubles) in one walk of the levels
+  bool use_sband = false;   // the band is factorised by one workgroup (sband_factor_kernel): few shots
+  double *sbL = nullptr;    // ... its factor, in the band's layout
   void bcr_solve_set(const RhsSet &rs) {
+    if (use_sband) {
+      hipLaunchKernelGGL(sband_solve_kernel, dim3((rs.nrhs + kSbSolveWaves - 1) / kSbSolveWaves), dim3(64 * kSbSolveWaves), sband_solve_lds(d.S, d.bw), st, d,
+                         (const double *)sbL, rs, SbFuse{0, 0.0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr});
+      return;
+    }
     const int N = d.ncl;
     const unsigned q = (unsigned)rs.nrhs;
     auto ne = [N](int s) { return (N + 2 * s - 1) / (2 * s); };
@@ -5222,6 +5527,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
   d.scal = A.alloc<double>(32, e);
   const long nbmax = std::max<long>(std::max<long>(nblk(M), nblk(3L * NP)), d.nwg);
   d.partial = A.alloc<double>((size_t)2 * nbmax + 16, e);
+  d.partial2 = A.alloc<double>((size_t)2 * nblk(3L * NP) + 16, e);
   d.dotp = A.alloc<double>((size_t)nblk(d.nred) + NC + 16, e);
   d.rrp = A.alloc<double>((size_t)nblk(d.nred) + 16, e);
   // block half-bandwidth of the shot-shot coupling (shots in caller order): bw_true, from track_width_kernel above
@@ -5303,6 +5609,9 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     d.bGt = A.alloc<double>(nb, e);
     d.bHt = A.alloc<double>(nb, e);
     d.bx = A.alloc<double>((size_t)7 * d.ncl * d.ncd, e);  // up to 7 right-hand sides at a time (the camera border's columns + the solve's)
+    // few shots: the whole band in one workgroup's LDS (OSFM_BA_NO_SBAND keeps the cyclic reduction: the cross-check of the tests)
+    sv.use_sband = sband_factor_lds(S, d.bw) <= kSbLdsMax && sband_solve_lds(S, d.bw) <= kSbLdsMax && getenv("OSFM_BA_NO_SBAND") == nullptr;
+    if (sv.use_sband) sv.sbL = A.alloc<double>((size_t)S * (d.bw + 1) * 36, e);
   }
   d.wNB = 0; d.wWb = 0;
   d.qN = 0; d.qm = 0; d.qcs = 0;
@@ -5467,9 +5776,9 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       hipLaunchKernelGGL(scale_init_kernel, dim3(nblk(std::max<long>(nred, 3L * NP))), dim3(TPB), 0, st, d);
       have_scale = true;
     }
-    hipLaunchKernelGGL(lm_diag_kernel, dim3(nblk(std::max<long>(nred, 3L * NP))), dim3(TPB), 0, st, d);
     if (gen) OSFM_HIP(hipMemsetAsync(d.scal + 10, 0, sizeof(double), st));  // (the [k1 k2 focal] mode: cleared by prior_cost_kernel, which every evaluation runs)
-    hipLaunchKernelGGL(absmax_kernel, dim3(256), dim3(256), 0, st, d.g_red, (long)nred, d.g_pt, 3L * NP, d.scal + 10);
+    // the LM diagonal and max |gradient| in one launch (two until round 6)
+    hipLaunchKernelGGL(lm_diag_absmax_kernel, dim3((unsigned)std::min<long>(2048, nblk(std::max<long>(nred, 3L * NP)))), dim3(256), 0, st, d, d.scal + 10);
     return OSFM_OK;
   };
   for (;;) {
@@ -5680,6 +5989,20 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     }
     if (try_bcr) {
       const int N = d.ncl;
+      if (sv.use_sband) {  // one workgroup factorises the band; the side stream's work runs beside it
+        static OsfmPerDeviceOnce once;
+        const int rca = once.run(ctx->device, []() -> int {
+          OSFM_HIP(hipFuncSetAttribute((const void *)sband_factor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));  // (+ its two static tables)
+          OSFM_HIP(hipFuncSetAttribute((const void *)sband_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+          return OSFM_OK;
+        });
+        if (rca != OSFM_OK) return rca;
+        if (fork_in_bcr) {
+          const int rcs = side_work(true);
+          if (rcs != OSFM_OK) return rcs;
+        }
+        hipLaunchKernelGGL(sband_factor_kernel, dim3(1), dim3(kSbThreads), sband_factor_lds(S, d.bw), st, d, sv.sbL, d_status);
+      } else {
       hipLaunchKernelGGL(bcr_build_kernel, dim3(N), dim3(256), 0, st, d, d_status);
       const BcrLaunch lv = bcr_level_for(d.cs);
       {
@@ -5699,6 +6022,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
         }
       }
       hipLaunchKernelGGL(lv.fn, dim3(1), dim3(lv.threads), lv.lds_bytes, st, d, 1, 1, d_status);
+      }
       sv.use_bcr = true;
       if (try_border) {  // exact camera border (few cameras, all free): B = S e_j restricted to the shot rows, W = A^-1 B
         const int nb = nbord, n6 = 6 * S;
@@ -5769,6 +6093,11 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
           if (g.NRr == 3) hipLaunchKernelGGL(gen_precond_shot_kernel<3>, dim3(S), dim3(64), 0, st, d, radius);
           else hipLaunchKernelGGL(gen_precond_shot_kernel<2>, dim3(S), dim3(64), 0, st, d, radius);
         }
+      } else if (sv.use_bcr && sv.use_sband && !sv.use_border && all_cams_fixed && !z_solved) {
+        // ... and with the one-workgroup band solve the camera blocks, the solve and the start of PCG are ONE launch (three until round 6)
+        hipLaunchKernelGGL(sband_solve_kernel, dim3(1), dim3(64 * kSbSolveWaves), sband_solve_lds(S, d.bw), st, d, (const double *)sv.sbL,
+                           RhsSet{d.b, 0, d.z, 0, 1, nullptr, nullptr, -1, 0}, SbFuse{1, radius, d.x, d.r, d.p, d.y, d.scal + 0, d.scal + 4, d.sc_red});
+        return;
       } else if ((sv.use_bcr || sv.use_wide) && all_cams_fixed) {
         // local / pose-only bundle adjustment: the band is the whole preconditioner and the camera rows are inert (zero scale, zero right-hand
         // side) -- their 3 x 3 blocks are the LM diagonal alone; the per-shot Schur blocks (63 us per LM iteration on a 48-shot problem) are not needed
@@ -5787,10 +6116,10 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       return sv.fetch(d.scal, 5, 0, d_status, (try_bcr || wide) ? 3 : 0, 0);
     };
     // one CG iteration's first half: the mat-vec and x += alpha p, r -= alpha Ap (r . r shares into rrp)
-    auto pcg_half = [&](int rz_cur) {
+    auto pcg_half = [&](int rz_cur, bool leave_y = false) {  // leave_y: y = sc x behind the step (the straight-line iteration goes on to the back-substitution)
       sv.matvec(d.p, d.Ap, radius, true, d.dotp);
       hipLaunchKernelGGL(pcg_step1_kernel, dim3(nbr), dim3(TPB), 0, st, d.x, d.r, (const double *)d.p, (const double *)d.Ap, nred, (const double *)(d.scal + rz_cur),
-                         (const double *)d.dotp, sv.matvec_parts(), d.scal + 1, d.rrp);
+                         (const double *)d.dotp, sv.matvec_parts(), d.scal + 1, d.rrp, (const double *)d.sc_red, leave_y ? d.y : (double *)nullptr);
     };
     auto swap_blocks = [&]() {
       std::swap(d.cams, d.cams_n);
@@ -5814,8 +6143,8 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     // every step of a converging problem -- has then cost one evaluation instead of two (0.09 ms at configs[4]) and one round trip instead
     // of two; a rejected or invalid step puts the blocks back and linearises the old point again (the same kernels on the same inputs: the
     // same bits as before).
-    auto candidate_enqueue = [&]() -> int {
-      hipLaunchKernelGGL(scale_vec_kernel, dim3(nbr), dim3(TPB), 0, st, d.sc_red, d.x, d.y, nred);
+    auto candidate_enqueue = [&](bool y_ready = false) -> int {
+      if (!y_ready) hipLaunchKernelGGL(scale_vec_kernel, dim3(nbr), dim3(TPB), 0, st, d.sc_red, d.x, d.y, nred);
       if (gen) {
         if (M > 0 && g.KW > 0) hipLaunchKernelGGL(gen_view_gather_kernel, dim3(nblk((long)g.NV * g.KW)), dim3(TPB), 0, st, d, (const double *)d.y);
         if (g.NRr == 3) hipLaunchKernelGGL((gen_schur_point_kernel<3, 2>), dim3(d.nwg), dim3(kCoopObs), 0, st, d, (const double *)d.y);
@@ -5828,12 +6157,17 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
         hipLaunchKernelGGL(gen_prior_kernel, dim3(nblk(sv.gen_nprior(), 256)), dim3(256), sv.gen_prior_lds(2), st, d, (const double *)g.cam, (const double *)g.bias,
                            (const double *)g.rc, (const double *)d.poses, 2, (const double *)d.y, d.scal + 16);
         if (g.pt_prior_sigma && NP > 0) hipLaunchKernelGGL(gen_point_prior_kernel, dim3(nblk(NP)), dim3(TPB), 0, st, d, (const double *)d.pts, 2, d.scal + 16);
-      } else
-        hipLaunchKernelGGL(candidate_kernel, dim3(1), dim3(1024), 0, st, d, (const double *)d.y, (const double *)d.partial, (long)d.nwg, d.scal + 16);
-      hipLaunchKernelGGL(candidate_points_kernel, dim3(nblk(3L * NP)), dim3(TPB), 0, st, d);
-      hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(1024), 0, st, d.partial, (long)nblk(3L * NP), 2, d.scal + 20);
+      }
+      if (gen) {
+        hipLaunchKernelGGL(candidate_points_kernel, dim3(nblk(3L * NP)), dim3(TPB), 0, st, d, d.partial);
+        hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(1024), 0, st, d.partial, (long)nblk(3L * NP), 2, d.scal + 20);
+      } else {  // the points' candidate first (its shares in partial2), then the cameras' and shots' with both sums and the candidate's rotation blocks
+        hipLaunchKernelGGL(candidate_points_kernel, dim3(nblk(3L * NP)), dim3(TPB), 0, st, d, d.partial2);
+        hipLaunchKernelGGL(candidate_kernel, dim3(1), dim3(1024), 0, st, d, (const double *)d.y, (const double *)d.partial, (long)d.nwg, d.scal + 16,
+                           (const double *)d.partial2, (long)nblk(3L * NP), d.scal + 20, S <= 1024 ? 1 : 0);
+      }
       swap_blocks();
-      sv.eval_enqueue(d.cams, d.poses, d.pts, true);
+      sv.eval_enqueue(d.cams, d.poses, d.pts, true, !gen && S <= 1024);
       return prepare_enqueue();
     };
     bool bad = false;
@@ -5852,8 +6186,8 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     const bool exact_expected = (try_bcr || wide) && (try_border || (gen ? g.NB == 0 : all_cams_fixed)) && O->pcg_direct_tolerance > O->pcg_tolerance;
     if (exact_expected && fast_ok && !trace) {
       start_pcg_enqueue();
-      pcg_half(0);
-      rc = candidate_enqueue();
+      pcg_half(0, true);
+      rc = candidate_enqueue(true);
       if (rc != OSFM_OK) return rc;
       {
         const int rcf = sv.fetch(d.scal, 22, 0, d_status, 3, 0, d.rrp, nbr);
@@ -5932,8 +6266,8 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       Rp->pcg_iterations_total += k;
     }
     if (mark("pcg") != OSFM_OK) return OSFM_E_HIP;
-    if (trace) fprintf(stderr, "[osfm_ba trace] iteration %d: %d pcg iterations, status %d %d %d, band %d bcr %d wide %d dense %d border %d\n", iter, k, hst[0], hst[1], hst[2],
-                       (int)sv.use_band, (int)sv.use_bcr, (int)sv.use_wide, (int)(sv.use_wide && dense_cr), (int)sv.use_border);
+    if (trace) fprintf(stderr, "[osfm_ba trace] iteration %d: %d pcg iterations, status %d %d %d, band %d bcr %d (one workgroup: %d) wide %d dense %d border %d\n", iter, k, hst[0], hst[1],
+                       hst[2], (int)sv.use_band, (int)sv.use_bcr, (int)(sv.use_bcr && sv.use_sband), (int)sv.use_wide, (int)(sv.use_wide && dense_cr), (int)sv.use_border);
     rc = candidate_enqueue();
     if (rc != OSFM_OK) return rc;
     {

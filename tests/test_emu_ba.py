@@ -183,6 +183,32 @@ def test_local_bundle_adjustment_problem_matches_oracle(oracle_lib):
     assert np.array_equal(g["shot_pose"][sub["shot_fixed"] == 1], sub["shot_pose"][sub["shot_fixed"] == 1])
 
 
+def test_one_workgroup_band_factor_equals_the_cyclic_reduction(monkeypatch):
+    """Few shots: the band is factorised by ONE workgroup (sband_factor_kernel: block LDL^T with 6 x 6 pivots, the next pivot inverted by wavefront 0
+    beside the trailing update) and applied by sband_solve_kernel -- against the cyclic reduction of the same band (OSFM_BA_NO_SBAND): both are exact,
+    CG confirms in one iteration per LM step, the trajectories agree to rounding.  A local problem (constant cameras) and a full one (the shared
+    camera's exact border: four right-hand sides through the one-workgroup solve)."""
+    from opensfm_amd import bundle
+
+    pr = synthetic.make_ba_scene(40, 500, 6, seed=7)
+    sub = bundle.local_problem(pr, 20, {"local_bundle_radius": 3, "local_bundle_min_common_points": 20, "local_bundle_max_shots": 8})[0]
+    full = synthetic.make_ba_scene(14, 300, 5, seed=3)
+    for prob in (sub, full):
+        res = []
+        for no_sband in (False, True):
+            if no_sband:
+                monkeypatch.setenv("OSFM_BA_NO_SBAND", "1")
+            else:
+                monkeypatch.delenv("OSFM_BA_NO_SBAND", raising=False)
+            with emulated():
+                res.append(bundle.bundle_arrays(prob, {"bundle_max_iterations": 4}, **NO_TOL))
+        a, b = res
+        assert a["pcg_iterations"] == b["pcg_iterations"] == a["iterations"]
+        assert np.allclose(a["cost_history"], b["cost_history"], rtol=1e-12)
+        # (the full problem has its gauge held by the GPS priors alone: two exact solves differ by rounding times the gauge's conditioning)
+        assert np.abs(a["shot_pose"] - b["shot_pose"]).max() < 1e-8 and np.abs(a["points"] - b["points"]).max() < 1e-8
+
+
 def test_pivot_block_inverse_on_the_matrix_cores():
     """dgj_pivot_kernel's inverse (16 x 16 pivots, v_mfma_f64_16x16x4 updates in LDS, the next pivot block inverted by wavefront 0 beside the
     trailing tiles) on random SPD blocks of every order the panels take: max |A A^-1 - I| at rounding level"""

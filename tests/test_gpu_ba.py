@@ -323,6 +323,33 @@ def test_bundle_local_and_shot_poses(oracle_lib, gpu_ctx):
     assert np.array_equal(sp["shot_pose"][other], pr["shot_pose"][other])
 
 
+@pytest.mark.parametrize("shots,track", [(48, 10), (30, 6), (14, 5), (3, 3)])
+def test_one_workgroup_band_factor_equals_the_cyclic_reduction(oracle_lib, gpu_ctx, monkeypatch, shots, track):
+    """Few shots: sband_factor_kernel / sband_solve_kernel (the band factorised and applied by one workgroup) against the cyclic reduction
+    (OSFM_BA_NO_SBAND) and the oracle, on a local problem (constant cameras: the band is the reduced matrix) and on the full one (the shared
+    camera's exact border: its columns go through the one-workgroup solve four right-hand sides at a time).  Both factorisations are exact."""
+    from opensfm_amd import bundle
+
+    pr = synthetic.make_ba_scene(shots, 40 * shots, track, seed=100 + shots)
+    local = bundle.local_problem(pr, shots // 2, {"local_bundle_radius": 3, "local_bundle_min_common_points": 10, "local_bundle_max_shots": 30})[0]
+    for prob in (local, pr):
+        res = []
+        for no_sband in (False, True):
+            if no_sband:
+                monkeypatch.setenv("OSFM_BA_NO_SBAND", "1")
+            else:
+                monkeypatch.delenv("OSFM_BA_NO_SBAND", raising=False)
+            res.append(bundle.bundle_arrays(prob, {"bundle_max_iterations": 6}, **NO_TOL))
+        a, b = res
+        o = oracle_lib.ba_solve(prob, max_iterations=6, **NO_TOL)
+        assert a["pcg_iterations"] == b["pcg_iterations"] == a["iterations"]
+        assert np.allclose(a["cost_history"], b["cost_history"], rtol=1e-12)
+        assert np.allclose(a["cost_history"], o["cost_history"], rtol=1e-10)
+        # (the full problem's gauge is held by the GPS priors alone: two exact solves differ by rounding times the gauge's conditioning)
+        tol = 1e-9 if prob is local else 1e-6
+        assert np.abs(a["shot_pose"] - b["shot_pose"]).max() < tol and np.abs(a["points"] - b["points"]).max() < tol
+
+
 def test_fisheye_camera_model(oracle_lib, gpu_ctx):
     """FisheyeCamera = <FisheyeProjection, Disto24, UniformScale> (camera_instances.h:187): same
     [k1, k2, focal] parameters, equidistant projection; mixed with a perspective camera."""
