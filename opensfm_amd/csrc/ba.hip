@@ -2051,6 +2051,9 @@ __global__ void __launch_bounds__(64) bcr_up_kernel(Dev d, int st, RhsSet rs, in
   }
 }
 constexpr int kMidWaves = 16;
+// right-hand sides per walk of the levels (grid y).  Seven until round 6: the sixteen border columns of a Brown camera with a free bias, and the solve's own
+// right-hand side, were three walks of ~0.2 ms each whatever they carry -- the walk is the latency of its eleven levels, not their bytes
+constexpr int kWalkRhs = 34;
 __global__ void __launch_bounds__(64 * kMidWaves) bcr_mid_kernel(Dev d, int st0) {
   __shared__ double xs[kMidWaves][64], xl[kMidWaves][64], xr[kMidWaves][64];
   const int n = d.ncd, n2 = n * n, N = d.ncl;
@@ -5608,7 +5611,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     d.bD2 = A.alloc<double>(nb, e);
     d.bGt = A.alloc<double>(nb, e);
     d.bHt = A.alloc<double>(nb, e);
-    d.bx = A.alloc<double>((size_t)7 * d.ncl * d.ncd, e);  // up to 7 right-hand sides at a time (the camera border's columns + the solve's)
+    d.bx = A.alloc<double>((size_t)kWalkRhs * d.ncl * d.ncd, e);  // up to kWalkRhs right-hand sides at a time (the camera border's columns + the solve's)
     // few shots: the whole band in one workgroup's LDS (OSFM_BA_NO_SBAND keeps the cyclic reduction: the cross-check of the tests)
     sv.use_sband = sband_factor_lds(S, d.bw) <= kSbLdsMax && sband_solve_lds(S, d.bw) <= kSbLdsMax && getenv("OSFM_BA_NO_SBAND") == nullptr;
     if (sv.use_sband) sv.sbL = A.alloc<double>((size_t)S * (d.bw + 1) * 36, e);
@@ -6029,8 +6032,8 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
         // the columns of B and C were formed on the side stream; W = A^-1 B for all of them in one walk of the levels
         const int rcj = join();
         if (rcj != OSFM_OK) return rcj;
-        for (int q0 = 0; q0 < nb + 1; q0 += 7) {  // (the work vectors of a walk hold seven right-hand sides)
-          const int cnt = std::min(7, nb + 1 - q0), qx = (nb >= q0 && nb < q0 + cnt) ? nb - q0 : -1;
+        for (int q0 = 0; q0 < nb + 1; q0 += kWalkRhs) {  // (the work vectors of a walk hold kWalkRhs right-hand sides)
+          const int cnt = std::min(kWalkRhs, nb + 1 - q0), qx = (nb >= q0 && nb < q0 + cnt) ? nb - q0 : -1;
           sv.bcr_solve_set(RhsSet{sv.Bc + (long)q0 * n6, n6, sv.Wb + (long)q0 * n6, n6, cnt, d.b, d.z, qx, gen ? -1 : qx});  // the border's columns and the solve's own right-hand side
         }
         z_solved = true;
