@@ -2150,7 +2150,7 @@ inline BcrLaunch bcr_level_for(int cs) {
 constexpr int kSbThreads = 256;
 constexpr size_t kSbLdsMax = 160 * 1024 - 512;
 constexpr int kSbSolveWaves = 4;  // right-hand sides per workgroup of the solve (a wavefront each, one copy of the factor in LDS)
-inline size_t sband_factor_lds(int S, int bw) { return ((size_t)S * (bw + 1) * 36 + (size_t)2 * bw * 36) * sizeof(double); }
+inline size_t sband_factor_lds(int S, int bw) { return ((size_t)S * (bw + 1) * 36 + (size_t)2 * bw * 36 + (size_t)6 * S) * sizeof(double); }
 inline size_t sband_solve_lds(int S, int bw) { return ((size_t)S * (bw + 1) * 36 + (size_t)kSbSolveWaves * 6 * S) * sizeof(double); }
 // A_ik[3 qr .. +3][3 qc .. +3] -= (L_ij A_kj^T)[...]: Lr = rows 3 qr.. of L_ij, Ak = rows 3 qc.. of A_kj, Aq = the quarter's first entry
 __device__ __forceinline__ void sband_quarter(const double *Lr, const double *Ak, double *Aq) {
@@ -2172,13 +2172,145 @@ __device__ __forceinline__ void sband_quarter(const double *Lr, const double *Ak
       Aq[6 * r + c] = acc;
     }
 }
-__global__ void __launch_bounds__(kSbThreads) sband_factor_kernel(Dev d, double *sbL, int *status) {
+// z_q = (L D L^T)^-1 r_q: a wavefront per right-hand side, kSbSolveWaves of them share the workgroup's copy of the factor.  Both sweeps are
+// column-oriented (no reductions across lanes): forward, lane (a, r) takes L_(j+a, j)[r, :] y_j off row (j + a, r); backward, lane (a, c)
+// takes L_(i, i-a)[:, c]^T x_i off row (i - a, c).  The camera rows of right-hand side cam_q: 3 x 3 block Jacobi, as bcr_up_kernel does.
+// fuse.on (one right-hand side, every camera constant: local / pose-only bundle adjustment): the camera rows' blocks are formed here
+// (precond_cam_kernel's launch) and the start of PCG follows the solve (pcg_init_kernel's launch: x = 0, r = b, p = z, y = sc p, r . z, b . b)
+struct SbFuse {
+  int on;
+  double radius;
+  double *x, *r, *p, *y, *o_rz, *o_bb;
+  const double *sc;
+};
+// slot 0 of every row of the factor's LDS copy: the pivot block D_j -> Dinv_j (positive definite: the factorisation's status said so); all threads
+__device__ __forceinline__ void sband_invert_pivots(double *Lb, int S, int R1, int tid, int nthreads) {
+  for (int j = tid; j < S; j += nthreads) {
+    double P[6][6];
+    double *Dj = Lb + (size_t)j * R1 * 36;
+    int bad = 0;
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+      for (int c = 0; c < 6; c++) P[r][c] = Dj[6 * r + c];
+    inv6_spd(P, bad);
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+      for (int c = 0; c < 6; c++) Dj[6 * r + c] = P[r][c];
+  }
+}
+// one wavefront: xv = y (the forward sweep's result) -> z = Dinv y -> x = L^-T z -> the result's rows, the camera rows, the start of PCG
+__device__ __forceinline__ void sband_back_half(const Dev &d, const double *Lb, double *xv, const RhsSet &rs, int q, const SbFuse &fuse, int lane) {
+  const int S = d.S, bw = d.bw, R1 = bw + 1, n6 = 6 * S;
+  const int a = 1 + lane / 6, r = lane - 6 * (a - 1);
+  for (int t0 = 0; t0 < n6; t0 += 60) {  // z_j = Dinv_j y_j, ten shots at a time (a shot's six rows are read before any of them is written)
+    const int t = t0 + lane;
+    double s = 0.0;
+    if (lane < 60 && t < n6) {
+      const int j = t / 6, rr = t - 6 * j;
+      const double *Dr = Lb + (size_t)j * R1 * 36 + 6 * rr;
+#pragma unroll
+      for (int m = 0; m < 6; m++) s = __builtin_fma(Dr[m], xv[6 * j + m], s);
+    }
+    WAVE_SYNC();
+    if (lane < 60 && t < n6) xv[t] = s;
+  }
+  WAVE_SYNC();
+  for (int i = S - 1; i >= 1; i--) {
+    if (a <= min(bw, i)) {
+      const double *Lc = Lb + ((size_t)i * R1 + a) * 36 + r;
+      double s = xv[6 * (i - a) + r];
+#pragma unroll
+      for (int m = 0; m < 6; m++) s = __builtin_fma(-Lc[6 * m], xv[6 * i + m], s);
+      xv[6 * (i - a) + r] = s;
+    }
+    WAVE_SYNC();
+  }
+  double *zq = rs.out(q);
+  const double *rin = rs.in(q);
+  double dots[2] = {0.0, 0.0};
+  auto start_pcg = [&](int t, double zi) {
+    const double bi = rin[t];
+    fuse.x[t] = 0.0;
+    fuse.r[t] = bi;
+    fuse.p[t] = zi;
+    fuse.y[t] = fuse.sc[t] * zi;
+    dots[0] += bi * zi;
+    dots[1] += bi * bi;
+  };
+  for (int t = lane; t < n6; t += 64) {
+    zq[t] = xv[t];
+    if (fuse.on) start_pcg(t, xv[t]);
+  }
+  if (q == rs.cam_q) {
+    for (int g = lane; g < d.NC; g += 64) {
+      if (fuse.on) precond_cam_one(d, g, fuse.radius);  // (this lane reads back what it has just written)
+      const double *Bi = d.Binv + 36 * (long)d.S + 9 * g, *rc = rin + d.cam0 + 3 * g;
+      for (int k = 0; k < 3; k++) {
+        const double zi = Bi[3 * k] * rc[0] + Bi[3 * k + 1] * rc[1] + Bi[3 * k + 2] * rc[2];
+        zq[d.cam0 + 3 * g + k] = zi;
+        if (fuse.on) start_pcg(d.cam0 + 3 * g + k, zi);
+      }
+    }
+  }
+  if (fuse.on) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      dots[0] += __shfl_xor(dots[0], m);
+      dots[1] += __shfl_xor(dots[1], m);
+    }
+    if (lane == 0) {
+      *fuse.o_rz = dots[0];
+      *fuse.o_bb = dots[1];
+    }
+  }
+}
+__global__ void __launch_bounds__(64 * kSbSolveWaves) sband_solve_kernel(Dev d, const double *sbL, RhsSet rs, SbFuse fuse) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int S = d.S, bw = d.bw, R1 = bw + 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double *Lb = lds, *xv = lds + (size_t)S * R1 * 36 + (size_t)wave * 6 * S;
+  const int total = S * R1 * 36, n6 = 6 * S;
+  for (int t = tid; t < total; t += 64 * kSbSolveWaves) Lb[t] = sbL[t];
+  const int q = blockIdx.x * kSbSolveWaves + wave;
+  const bool on = q < rs.nrhs;
+  if (on) {
+    const double *in = rs.in(q);
+    for (int t = lane; t < n6; t += 64) xv[t] = in[t];
+  }
+  __syncthreads();
+  sband_invert_pivots(Lb, S, R1, tid, 64 * kSbSolveWaves);
+  __syncthreads();
+  if (!on) return;
+  const int a = 1 + lane / 6, r = lane - 6 * (a - 1);
+  for (int j = 0; j + 1 < S; j++) {
+    if (a <= min(bw, S - 1 - j)) {
+      const double *Lr = Lb + ((size_t)(j + a) * R1 + a) * 36 + 6 * r;
+      double s = xv[6 * (j + a) + r];
+#pragma unroll
+      for (int m = 0; m < 6; m++) s = __builtin_fma(-Lr[m], xv[6 * j + m], s);
+      xv[6 * (j + a) + r] = s;
+    }
+    WAVE_SYNC();
+  }
+  sband_back_half(d, Lb, xv, rs, q, fuse, lane);
+}
+
+// fuse.on (one right-hand side rs, every camera constant): the solve rides along -- the forward sweep's step j by wavefront 3 beside the window's update,
+// L_(., j) written over the dead blocks of column j so that the factor is in LDS when the loop ends, then sband_back_half: sband_solve_kernel's launch,
+// its 138 KB load of the factor and its forward sweep are gone (local bundle adjustment: 68 + 28 us -> ~80 us)
+__global__ void __launch_bounds__(kSbThreads) sband_factor_kernel(Dev d, double *sbL, int *status, RhsSet rs, SbFuse fuse) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   __shared__ unsigned char pair_a[64], pair_b[64];
   const int S = d.S, bw = d.bw, R1 = bw + 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double *Ab = lds, *Lb = lds + (size_t)S * R1 * 36;  // the band; the rows of L_(., j) of two consecutive steps
+  double *xv = Lb + (size_t)2 * bw * 36;             // fuse.on: the right-hand side on its way to the solution
   const int total = S * R1 * 36;
   for (int t = tid; t < total; t += kSbThreads) Ab[t] = d.band[t];
+  if (fuse.on) {
+    const double *in = rs.in(0);
+    for (int t = tid; t < 6 * S; t += kSbThreads) xv[t] = in[t];
+  }
   const int npairs = bw * (bw + 1) / 2 - 1;  // (a, b), 1 <= b <= a <= bw without (1, 1): the blocks wavefronts 1 .. 3 update
   if (tid == 0) {
     *status = 0;
@@ -2251,9 +2383,22 @@ __global__ void __launch_bounds__(kSbThreads) sband_factor_kernel(Dev d, double 
         if (a > na) continue;
         sband_quarter(Lj + (a - 1) * 36 + 18 * qr, Ab + ((size_t)(j + b) * R1 + b) * 36 + 18 * qc, Ab + ((size_t)(j + a) * R1 + (a - b)) * 36 + 18 * qr + 3 * qc);
       }
+      if (fuse.on && wave == 3 && lane < 6 * na) {  // forward sweep, step j: y_j is final, row (j + a, r) loses L_(j+a, j)[r, :] y_j
+        const int a = 1 + lane / 6, r = lane - 6 * (a - 1);
+        const double *Lr = Lj + (a - 1) * 36 + 6 * r;
+        double sacc = xv[6 * (j + a) + r];
+#pragma unroll
+        for (int m = 0; m < 6; m++) sacc = __builtin_fma(-Lr[m], xv[6 * j + m], sacc);
+        xv[6 * (j + a) + r] = sacc;
+      }
     }
     __syncthreads();
     if (wave == 0) l_rows(j + 1);  // (column j + 1 is complete: wavefronts 1 .. 3 updated its blocks below the pivot)
+    if (fuse.on && wave == 1)      // column j's blocks are dead (step j has read them): L_(., j) takes their place
+      for (int t = lane; t < 36 * na; t += 64) {
+        const int a = 1 + t / 36, e = t - 36 * (a - 1);
+        Ab[((size_t)(j + a) * R1 + a) * 36 + e] = Lj[t];
+      }
     __syncthreads();
   }
   // the pivot blocks as they were when they were inverted (slot 0 of their rows: nothing writes them afterwards); the solve inverts them again
@@ -2263,121 +2408,12 @@ __global__ void __launch_bounds__(kSbThreads) sband_factor_kernel(Dev d, double 
     sbL[(size_t)j * R1 * 36 + e] = Ab[(size_t)j * R1 * 36 + e];
   }
   if (bad) *status = 1;
-}
-// z_q = (L D L^T)^-1 r_q: a wavefront per right-hand side, kSbSolveWaves of them share the workgroup's copy of the factor.  Both sweeps are
-// column-oriented (no reductions across lanes): forward, lane (a, r) takes L_(j+a, j)[r, :] y_j off row (j + a, r); backward, lane (a, c)
-// takes L_(i, i-a)[:, c]^T x_i off row (i - a, c).  The camera rows of right-hand side cam_q: 3 x 3 block Jacobi, as bcr_up_kernel does.
-// fuse.on (one right-hand side, every camera constant: local / pose-only bundle adjustment): the camera rows' blocks are formed here
-// (precond_cam_kernel's launch) and the start of PCG follows the solve (pcg_init_kernel's launch: x = 0, r = b, p = z, y = sc p, r . z, b . b)
-struct SbFuse {
-  int on;
-  double radius;
-  double *x, *r, *p, *y, *o_rz, *o_bb;
-  const double *sc;
-};
-__global__ void __launch_bounds__(64 * kSbSolveWaves) sband_solve_kernel(Dev d, const double *sbL, RhsSet rs, SbFuse fuse) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int S = d.S, bw = d.bw, R1 = bw + 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  double *Lb = lds, *xv = lds + (size_t)S * R1 * 36 + (size_t)wave * 6 * S;
-  const int total = S * R1 * 36, n6 = 6 * S;
-  for (int t = tid; t < total; t += 64 * kSbSolveWaves) Lb[t] = sbL[t];
-  const int q = blockIdx.x * kSbSolveWaves + wave;
-  const bool on = q < rs.nrhs;
-  if (on) {
-    const double *in = rs.in(q);
-    for (int t = lane; t < n6; t += 64) xv[t] = in[t];
-  }
+  if (!fuse.on) return;
   __syncthreads();
-  for (int j = tid; j < S; j += 64 * kSbSolveWaves) {  // slot 0 of row j: the pivot block D_j -> Dinv_j (positive definite: the factorisation's status said so)
-    double P[6][6];
-    double *Dj = Lb + (size_t)j * R1 * 36;
-    int bad = 0;
-#pragma unroll
-    for (int r = 0; r < 6; r++)
-#pragma unroll
-      for (int c = 0; c < 6; c++) P[r][c] = Dj[6 * r + c];
-    inv6_spd(P, bad);
-#pragma unroll
-    for (int r = 0; r < 6; r++)
-#pragma unroll
-      for (int c = 0; c < 6; c++) Dj[6 * r + c] = P[r][c];
-  }
+  sband_invert_pivots(Ab, S, R1, tid, kSbThreads);
   __syncthreads();
-  if (!on) return;
-  const int a = 1 + lane / 6, r = lane - 6 * (a - 1);
-  for (int j = 0; j + 1 < S; j++) {
-    if (a <= min(bw, S - 1 - j)) {
-      const double *Lr = Lb + ((size_t)(j + a) * R1 + a) * 36 + 6 * r;
-      double s = xv[6 * (j + a) + r];
-#pragma unroll
-      for (int m = 0; m < 6; m++) s = __builtin_fma(-Lr[m], xv[6 * j + m], s);
-      xv[6 * (j + a) + r] = s;
-    }
-    WAVE_SYNC();
-  }
-  for (int t0 = 0; t0 < n6; t0 += 60) {  // z_j = Dinv_j y_j, ten shots at a time (a shot's six rows are read before any of them is written)
-    const int t = t0 + lane;
-    double s = 0.0;
-    if (lane < 60 && t < n6) {
-      const int j = t / 6, rr = t - 6 * j;
-      const double *Dr = Lb + (size_t)j * R1 * 36 + 6 * rr;
-#pragma unroll
-      for (int m = 0; m < 6; m++) s = __builtin_fma(Dr[m], xv[6 * j + m], s);
-    }
-    WAVE_SYNC();
-    if (lane < 60 && t < n6) xv[t] = s;
-  }
-  WAVE_SYNC();
-  for (int i = S - 1; i >= 1; i--) {
-    if (a <= min(bw, i)) {
-      const double *Lc = Lb + ((size_t)i * R1 + a) * 36 + r;
-      double s = xv[6 * (i - a) + r];
-#pragma unroll
-      for (int m = 0; m < 6; m++) s = __builtin_fma(-Lc[6 * m], xv[6 * i + m], s);
-      xv[6 * (i - a) + r] = s;
-    }
-    WAVE_SYNC();
-  }
-  double *zq = rs.out(q);
-  const double *rin = rs.in(q);
-  double dots[2] = {0.0, 0.0};
-  auto start_pcg = [&](int t, double zi) {
-    const double bi = rin[t];
-    fuse.x[t] = 0.0;
-    fuse.r[t] = bi;
-    fuse.p[t] = zi;
-    fuse.y[t] = fuse.sc[t] * zi;
-    dots[0] += bi * zi;
-    dots[1] += bi * bi;
-  };
-  for (int t = lane; t < n6; t += 64) {
-    zq[t] = xv[t];
-    if (fuse.on) start_pcg(t, xv[t]);
-  }
-  if (q == rs.cam_q) {
-    for (int g = lane; g < d.NC; g += 64) {
-      if (fuse.on) precond_cam_one(d, g, fuse.radius);  // (this lane reads back what it has just written)
-      const double *Bi = d.Binv + 36 * (long)d.S + 9 * g, *rc = rin + d.cam0 + 3 * g;
-      for (int k = 0; k < 3; k++) {
-        const double zi = Bi[3 * k] * rc[0] + Bi[3 * k + 1] * rc[1] + Bi[3 * k + 2] * rc[2];
-        zq[d.cam0 + 3 * g + k] = zi;
-        if (fuse.on) start_pcg(d.cam0 + 3 * g + k, zi);
-      }
-    }
-  }
-  if (fuse.on) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-      dots[0] += __shfl_xor(dots[0], m);
-      dots[1] += __shfl_xor(dots[1], m);
-    }
-    if (lane == 0) {
-      *fuse.o_rz = dots[0];
-      *fuse.o_bb = dots[1];
-    }
-  }
+  if (wave == 0) sband_back_half(d, Ab, xv, rs, 0, fuse, lane);
 }
-
 // ---- wide band: direct block LDL^T of the shot-shot Schur complement (round 3) --------------------------------------------------
 // Block surveys, loops, unordered collections: the co-visibility half-width is tens to hundreds of shots, beyond what the
 // cluster-tridiagonal cyclic reduction can hold in LDS (and a band truncated to 15 shots is a preconditioner in name only: ~1000 CG
@@ -4604,6 +4640,7 @@ struct Solver {
   double *wB = nullptr, *partB = nullptr, *dCm = nullptr;                     // its columns in one pass: w (2 nb per observation), camera partials, C
   // z_q = A^-1 r_q for nrhs right-hand sides (strides in doubles) in one walk of the levels
   bool use_sband = false;   // the band is factorised by one workgroup (sband_factor_kernel): few shots
+  bool sband_solved = false;  // ... and this iteration's factorisation launch carried the solve of d.b and the start of PCG with it
   double *sbL = nullptr;    // ... its factor, in the band's layout
   void bcr_solve_set(const RhsSet &rs) {
     if (use_sband) {
@@ -5810,7 +5847,12 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     //      the side stream next to the band assembly (a gather that leaves HBM bandwidth unused), so that the cyclic-reduction levels
     //      -- workgroups that need a whole CU's LDS -- find the CUs free afterwards ----
     const bool want_border = d.bw > 0 && (d.ncl > 0 || wide) && O->preconditioner == 0 && sv.Bc && border_ok;
-    hipStream_t sx = sv.st2 ? sv.st2 : st;
+    // few shots, constant cameras: the one-workgroup factorisation carries the solve, so the right-hand side goes in front of it, on the main stream -- the
+    // side stream has nothing to do in such an iteration (side2 = null)
+    const bool sband_fuse = sv.use_sband && !gen && all_cams_fixed && d.bw > 0 && d.ncl > 0 && O->preconditioner == 0 && !want_border &&
+                            getenv("OSFM_BA_NO_SBAND_FUSE") == nullptr;
+    hipStream_t side2 = sband_fuse ? nullptr : sv.st2;
+    hipStream_t sx = side2 ? side2 : st;
     // where the side stream starts: the per-shot assembly (LDS atomics) leaves HBM idle, so the border's passes run beside it; the
     // matrix-core assembly fills the CUs (four workgroups of 39 KB LDS each), and the side stream starts after it, beside the cyclic
     // reduction's levels -- one 117 KB workgroup per CU, which leaves the CU room for a border workgroup
@@ -5818,11 +5860,19 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     //  LDS need every CU twice over, the later levels leave half of them and more to the border's kernels: 3.13 -> 3.09 ms per LM iteration at
     //  configs[4], profiles/r06_ba_variants.json; everything on one stream: 3.31)
     int fork_at = win_band ? (d.ncl > 1 && O->preconditioner == 0 ? 2 : 1) : 0;  // 0: before the assembly, 1: after it, 2: after the first level of the cyclic reduction
+    sv.sband_solved = false;
+    if (sband_fuse) {  // (three launches of ~17 us in all: on the main stream, in front of the assembly -- a fork and a join cost as much in event latencies)
+      hipLaunchKernelGGL(schur_point_coop_kernel<1>, dim3(d.nwg), dim3(kCoopObs), 0, st, d, d.y);
+      sv.schur_shot(st);
+      hipLaunchKernelGGL(schur_finish_kernel, dim3(sv.matvec_parts()), dim3(TPB), 0, st, d, (const double *)d.x, (const double *)d.y, d.b, radius, 1, sv.cams_inert ? 1 : 0,
+                         (double *)nullptr);
+      fork_at = 0;
+    }
     if (const char *fk = getenv("OSFM_BA_FORK")) fork_at = std::min(2, std::max(0, fk[0] - '0'));
     const bool fork_late = fork_at >= 1;
-    if (sv.st2 && !fork_late) {
+    if (side2 && !fork_late) {
       OSFM_HIP(hipEventRecord(sv.ev_fork, st));
-      OSFM_HIP(hipStreamWaitEvent(sv.st2, sv.ev_fork, 0));
+      OSFM_HIP(hipStreamWaitEvent(side2, sv.ev_fork, 0));
     }
     if (d.bw > 0) {
       static OsfmPerDeviceOnce once;
@@ -5889,12 +5939,12 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       sv.use_bcr = false;
     }
     if (mark("band assembly") != OSFM_OK) return OSFM_E_HIP;
-    const bool fork_in_bcr = fork_at == 2 && sv.st2 && d.bw > 0 && d.ncl > 1 && O->preconditioner == 0;
+    const bool fork_in_bcr = fork_at == 2 && side2 && d.bw > 0 && d.ncl > 1 && O->preconditioner == 0;
     // the side stream's work: the camera border's columns and the right-hand side, from the point of the main stream where it is called
     auto side_work = [&](bool fork_here) -> int {
-      if (sv.st2 && fork_here) {
+      if (side2 && fork_here) {
         OSFM_HIP(hipEventRecord(sv.ev_fork, st));
-        OSFM_HIP(hipStreamWaitEvent(sv.st2, sv.ev_fork, 0));
+        OSFM_HIP(hipStreamWaitEvent(side2, sv.ev_fork, 0));
       }
       if (want_border && gen && getenv("OSFM_BA_BORDER_BY_MATVECS") == nullptr) {
         sv.gen_border_columns(radius, sx);
@@ -5918,7 +5968,9 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
         }
       }
       // rhs
-      if (gen) {
+      if (sband_fuse) {
+        // (done already, on the main stream)
+      } else if (gen) {
         sv.gen_rows_apply(1, sx);
         hipLaunchKernelGGL(gen_schur_finish_kernel, dim3(nbr), dim3(TPB), 0, sx, d, (const double *)d.x, (const double *)d.y, d.b, radius, 1, M > 0 ? 1 : 0, 0, (double *)nullptr);
       } else {
@@ -5927,7 +5979,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
         hipLaunchKernelGGL(schur_finish_kernel, dim3(sv.matvec_parts()), dim3(TPB), 0, sx, d, (const double *)d.x, (const double *)d.y, d.b, radius, 1, sv.cams_inert ? 1 : 0,
                            (double *)nullptr);
       }
-      if (sv.st2) OSFM_HIP(hipEventRecord(sv.ev_join, sv.st2));
+      if (side2) OSFM_HIP(hipEventRecord(sv.ev_join, side2));
       return OSFM_OK;
     };
     if (!fork_in_bcr) {
@@ -5935,7 +5987,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       if (rcs != OSFM_OK) return rcs;
     }
     if (mark("side work (border columns, right-hand side)") != OSFM_OK) return OSFM_E_HIP;
-    bool joined = sv.st2 == nullptr;
+    bool joined = side2 == nullptr;
     auto join = [&]() -> int {  // the main stream continues after the side stream's work
       if (!joined) OSFM_HIP(hipStreamWaitEvent(st, sv.ev_join, 0));
       joined = true;
@@ -6004,7 +6056,16 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
           const int rcs = side_work(true);
           if (rcs != OSFM_OK) return rcs;
         }
-        hipLaunchKernelGGL(sband_factor_kernel, dim3(1), dim3(kSbThreads), sband_factor_lds(S, d.bw), st, d, sv.sbL, d_status);
+        if (sband_fuse) {  // the right-hand side must be there: the side stream was forked before the assembly
+          const int rcj = join();
+          if (rcj != OSFM_OK) return rcj;
+          hipLaunchKernelGGL(sband_factor_kernel, dim3(1), dim3(kSbThreads), sband_factor_lds(S, d.bw), st, d, sv.sbL, d_status, RhsSet{d.b, 0, d.z, 0, 1, nullptr, nullptr, -1, 0},
+                             SbFuse{1, radius, d.x, d.r, d.p, d.y, d.scal + 0, d.scal + 4, d.sc_red});
+          sv.sband_solved = true;
+        } else {
+          hipLaunchKernelGGL(sband_factor_kernel, dim3(1), dim3(kSbThreads), sband_factor_lds(S, d.bw), st, d, sv.sbL, d_status, RhsSet{nullptr, 0, nullptr, 0, 0, nullptr, nullptr, -1, -1},
+                             SbFuse{0, 0.0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr});
+        }
       } else {
       hipLaunchKernelGGL(bcr_build_kernel, dim3(N), dim3(256), 0, st, d, d_status);
       const BcrLaunch lv = bcr_level_for(d.cs);
@@ -6097,7 +6158,12 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
           else hipLaunchKernelGGL(gen_precond_shot_kernel<2>, dim3(S), dim3(64), 0, st, d, radius);
         }
       } else if (sv.use_bcr && sv.use_sband && !sv.use_border && all_cams_fixed && !z_solved) {
-        // ... and with the one-workgroup band solve the camera blocks, the solve and the start of PCG are ONE launch (three until round 6)
+        // ... and with the one-workgroup band solve the camera blocks, the solve and the start of PCG are ONE launch (three until round 6) --
+        // or none: the factorisation's launch has done it all
+        if (sv.sband_solved) {
+          sv.sband_solved = false;
+          return;
+        }
         hipLaunchKernelGGL(sband_solve_kernel, dim3(1), dim3(64 * kSbSolveWaves), sband_solve_lds(S, d.bw), st, d, (const double *)sv.sbL,
                            RhsSet{d.b, 0, d.z, 0, 1, nullptr, nullptr, -1, 0}, SbFuse{1, radius, d.x, d.r, d.p, d.y, d.scal + 0, d.scal + 4, d.sc_red});
         return;
