@@ -1219,8 +1219,8 @@ __global__ void __launch_bounds__(384) band_mfma_kernel(Dev d) {
       // jv: Jp (6) | Jc row 0 (6) | Jc row 1 (6).  The generic rows store all of it (res 2 | Jp 6 | Jc 12); the [k1 k2 focal] rows keep the rotation
       // columns only (R_JR) -- the translation columns are -Jp, read a second time with the other sign (the same addresses: cache hits) so that the
       // loads stay unconditional
-      const int rot1 = d.gen ? 14 : R_JR + 3, tr0 = d.gen ? 11 : R_JP, tr1 = d.gen ? 17 : R_JP + 3;
-      const double sgn = d.gen ? 1.0 : -1.0;
+      const int rot1 = d.gen ? 14 : R_JR + 3, tr0 = R_JP, tr1 = R_JP + 3;  // (the generic rows do not store their translation columns either: round 6)
+      const double sgn = -1.0;
 #pragma unroll
       for (int x = 0; x < 6; x++) jv[x] = JA(o, R_JP + x);
 #pragma unroll
