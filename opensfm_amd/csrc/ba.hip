@@ -4477,6 +4477,9 @@ struct Solver {
   // five columns per launch of gen_border_shot_kernel for up to nine border slots (a Brown camera: two launches instead of three; measured 7.46
   // against 7.96 ms per LM iteration at configs[4] although the kernel then runs one wave per SIMD); OSFM_BA_BORDER_CH3 = three per launch
   bool gen_border_ch5 = getenv("OSFM_BA_BORDER_CH3") == nullptr;
+  // round 6: all nine columns of a Brown camera in ONE launch (the rows are recomputed once, a record of wB is read once: 5.31 -> 5.16 ms per LM iteration
+  // at configs[4]; OSFM_BA_BORDER_CH5 keeps the two launches of five and four columns)
+  bool gen_border_ch9 = getenv("OSFM_BA_BORDER_CH5") == nullptr;
   int gen_uniform_model = -1;  // every camera has this projection type (the evaluation kernel is specialised for the common ones), -1: mixed
   bool have_bpri = false;  // a prior couples an instance with a free border block (position prior with a free bias, up vector / compass with a free rig camera)
 #define OSFM_GEN_KW(NRV, MV, KERNEL, grid, block, stream, ...)                                                \
@@ -4570,6 +4573,7 @@ struct Solver {
     if (d.M > 0 && g_ncols > 0) {
       hipLaunchKernelGGL(gen_border_point_kernel<NRV>, dim3(d.nwg), dim3(kCoopObs), 0, sq, d, (const int *)g_cols, g_ncols, g_wB);
       if (d.g.KW <= 4) gen_border_chunks<NRV, 4, 4, MV>(sq);
+      else if (d.g.KW <= 9 && g_ncols > 5 && gen_border_ch9) gen_border_chunks<NRV, 9, 9, MV>(sq);
       else if (d.g.KW <= 9 && gen_border_ch5) gen_border_chunks<NRV, 9, 5, MV>(sq);
       else if (d.g.KW <= 9) gen_border_chunks<NRV, 9, 3, MV>(sq);
       else if (d.g.KW <= 16) gen_border_chunks<NRV, 16, 2, MV>(sq);
@@ -5817,8 +5821,12 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       have_scale = true;
     }
     if (gen) OSFM_HIP(hipMemsetAsync(d.scal + 10, 0, sizeof(double), st));  // (the [k1 k2 focal] mode: cleared by prior_cost_kernel, which every evaluation runs)
-    // the LM diagonal and max |gradient| in one launch (two until round 6)
-    hipLaunchKernelGGL(lm_diag_absmax_kernel, dim3((unsigned)std::min<long>(2048, nblk(std::max<long>(nred, 3L * NP)))), dim3(256), 0, st, d, d.scal + 10);
+    if (std::max<long>(nred, 3L * NP) <= 65536) {  // small problems: the LM diagonal and max |gradient| in one launch (at configs[4] size the fused kernel was 34 us against 10 + 13)
+      hipLaunchKernelGGL(lm_diag_absmax_kernel, dim3((unsigned)nblk(std::max<long>(nred, 3L * NP))), dim3(256), 0, st, d, d.scal + 10);
+    } else {
+      hipLaunchKernelGGL(lm_diag_kernel, dim3(nblk(std::max<long>(nred, 3L * NP))), dim3(TPB), 0, st, d);
+      hipLaunchKernelGGL(absmax_kernel, dim3(256), dim3(256), 0, st, d.g_red, (long)nred, d.g_pt, 3L * NP, d.scal + 10);
+    }
     return OSFM_OK;
   };
   for (;;) {
