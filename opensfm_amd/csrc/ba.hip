@@ -4481,6 +4481,7 @@ struct Solver {
   // at configs[4]; OSFM_BA_BORDER_CH5 keeps the two launches of five and four columns)
   bool gen_border_ch9 = getenv("OSFM_BA_BORDER_CH5") == nullptr;
   int gen_uniform_model = -1;  // every camera has this projection type (the evaluation kernel is specialised for the common ones), -1: mixed
+  bool gen_compact = false;    // ... and the rows keep (Xc, wt) instead of their border slots (gen_eval_kernel's COMPACT layout)
   bool have_bpri = false;  // a prior couples an instance with a free border block (position prior with a free bias, up vector / compass with a free rig camera)
 #define OSFM_GEN_KW(NRV, MV, KERNEL, grid, block, stream, ...)                                                \
   do {                                                                                                        \
@@ -4519,7 +4520,9 @@ struct Solver {
     }
 #define OSFM_GEN_EVAL(NRV, MODELV)                                                                                                           \
   do {                                                                                                                                       \
-    if (jac)                                                                                                                                 \
+    if (jac && gen_compact && MODELV >= 0)                                                                                                   \
+      hipLaunchKernelGGL((gen_eval_kernel<NRV, true, MODELV, (MODELV >= 0)>), dim3(nb), dim3(TPB), 0, st, d, cam, rcp, poses, pts, loss, loss_a); \
+    else if (jac)                                                                                                                            \
       hipLaunchKernelGGL((gen_eval_kernel<NRV, true, MODELV>), dim3(nb), dim3(TPB), 0, st, d, cam, rcp, poses, pts, loss, loss_a);            \
     else                                                                                                                                     \
       hipLaunchKernelGGL((gen_eval_kernel<NRV, false, MODELV>), dim3(nb), dim3(TPB), 0, st, d, cam, rcp, poses, pts, loss, loss_a);           \
@@ -4548,6 +4551,24 @@ struct Solver {
       hipLaunchKernelGGL(gen_border_reduce_kernel, dim3(d.g.NB), dim3(256), 0, st, d, 2 * d.g.KW, d.g.KW, 2);
     }
   }
+  // pass A over two-row observations, mode 0 (mat-vec) / 1 (right-hand side) / 2 (back-substitution): the COMPACT rows' readers are specialised per projection type
+  template <int MODE>
+  void gen_schur_point2_mode(hipStream_t sq) {
+    const dim3 grid(d.nwg), block(kCoopObs);
+    if (MODE != 1 && gen_compact && gen_uniform_model == OSFM_CAMERA_BROWN)
+      hipLaunchKernelGGL((gen_schur_point_kernel<2, MODE, OSFM_CAMERA_BROWN, (MODE != 1)>), grid, block, 0, sq, d, (const double *)d.y);
+    else if (MODE != 1 && gen_compact && gen_uniform_model == OSFM_CAMERA_FISHEYE_OPENCV)
+      hipLaunchKernelGGL((gen_schur_point_kernel<2, MODE, OSFM_CAMERA_FISHEYE_OPENCV, (MODE != 1)>), grid, block, 0, sq, d, (const double *)d.y);
+    else if (MODE != 1 && gen_compact && gen_uniform_model == OSFM_CAMERA_PERSPECTIVE)
+      hipLaunchKernelGGL((gen_schur_point_kernel<2, MODE, OSFM_CAMERA_PERSPECTIVE, (MODE != 1)>), grid, block, 0, sq, d, (const double *)d.y);
+    else
+      hipLaunchKernelGGL((gen_schur_point_kernel<2, MODE>), grid, block, 0, sq, d, (const double *)d.y);
+  }
+  void gen_schur_point2(int mode, hipStream_t sq) {
+    if (mode == 0) gen_schur_point2_mode<0>(sq);
+    else if (mode == 1) gen_schur_point2_mode<1>(sq);
+    else gen_schur_point2_mode<2>(sq);
+  }
   // the observation rows' share of J^T (I - Jp Hhat Jp^T) J y (mode 0, y = d.y) or of the right-hand side (mode 1) into zc, on stream sq
   void gen_rows_apply(int mode, hipStream_t sq) {
     if (d.M <= 0) return;
@@ -4556,8 +4577,7 @@ struct Solver {
       if (mode == 0) hipLaunchKernelGGL((gen_schur_point_kernel<3, 0>), dim3(d.nwg), dim3(kCoopObs), 0, sq, d, (const double *)d.y);
       else hipLaunchKernelGGL((gen_schur_point_kernel<3, 1>), dim3(d.nwg), dim3(kCoopObs), 0, sq, d, (const double *)d.y);
     } else {
-      if (mode == 0) hipLaunchKernelGGL((gen_schur_point_kernel<2, 0>), dim3(d.nwg), dim3(kCoopObs), 0, sq, d, (const double *)d.y);
-      else hipLaunchKernelGGL((gen_schur_point_kernel<2, 1>), dim3(d.nwg), dim3(kCoopObs), 0, sq, d, (const double *)d.y);
+      gen_schur_point2(mode, sq);
     }
     OSFM_GEN_NR_KW(gen_schur_shot_kernel, dim3(d.S), dim3(64), sq, d);
     if (d.g.NB > 0) hipLaunchKernelGGL(gen_border_reduce_kernel, dim3(d.g.NB), dim3(256), 0, sq, d, 2 * d.g.KW, 0, 0);
@@ -4571,7 +4591,10 @@ struct Solver {
   template <int NRV, int MV>
   void gen_border_columns_nr(hipStream_t sq) {
     if (d.M > 0 && g_ncols > 0) {
-      hipLaunchKernelGGL(gen_border_point_kernel<NRV>, dim3(d.nwg), dim3(kCoopObs), 0, sq, d, (const int *)g_cols, g_ncols, g_wB);
+      if (gen_compact && MV >= 0)
+        hipLaunchKernelGGL((gen_border_point_kernel<NRV, MV, (MV >= 0)>), dim3(d.nwg), dim3(kCoopObs), 0, sq, d, (const int *)g_cols, g_ncols, g_wB);
+      else
+        hipLaunchKernelGGL((gen_border_point_kernel<NRV>), dim3(d.nwg), dim3(kCoopObs), 0, sq, d, (const int *)g_cols, g_ncols, g_wB);
       if (d.g.KW <= 4) gen_border_chunks<NRV, 4, 4, MV>(sq);
       else if (d.g.KW <= 9 && g_ncols > 5 && gen_border_ch9) gen_border_chunks<NRV, 9, 9, MV>(sq);
       else if (d.g.KW <= 9 && gen_border_ch5) gen_border_chunks<NRV, 9, 5, MV>(sq);
@@ -5292,6 +5315,15 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     for (int c = 1; c < NC; c++)
       if (G->cam_model[c] != G->cam_model[0]) sv.gen_uniform_model = -1;
     if (getenv("OSFM_BA_GENERIC_EVAL") != nullptr) sv.gen_uniform_model = -1;  // (self-check knob: the unspecialised evaluation kernel)
+    {  // the COMPACT rows: one 2-D projection type, reprojection rows only, no free rig camera (its six columns are border slots too); OSFM_BA_GEN_FULL_ROWS keeps the slots
+      bool rc_free = false, depth_rows = false;
+      for (int q = 0; q < NRC; q++) rc_free = rc_free || (rc_col[(size_t)q] >= 0 && rc_useful[(size_t)q]);
+      if (G->obs_kind)
+        for (long o = 0; o < M && !depth_rows; o++) depth_rows = G->obs_kind[o] != 0;
+      const int um = sv.gen_uniform_model;
+      sv.gen_compact = !spherical && !rc_free && !depth_rows && getenv("OSFM_BA_GEN_FULL_ROWS") == nullptr &&
+                       (um == OSFM_CAMERA_BROWN || um == OSFM_CAMERA_FISHEYE_OPENCV || um == OSFM_CAMERA_PERSPECTIVE);
+    }
     int KW = 0;
     auto view_slots = [&](int v, int *cols) {  // returns the number of slots; cols[i] = border column of slot i
       const int c = G->view_cam[v], q = G->view_rc[v];
@@ -5308,7 +5340,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
     g.oJp = g.NRr;
     g.oJc = 4 * g.NRr;
     g.oJb = 10 * g.NRr;
-    g.ncomp = g.NRr * (10 + KW);
+    g.ncomp = sv.gen_compact ? g.NRr * 10 + 4 : g.NRr * (10 + KW);  // (COMPACT: Xc | wt in place of the 2 KW border slots)
     std::vector<int> view_col((size_t)std::max(1, NV * KW), -1);
     std::vector<unsigned char> col_slot((size_t)std::max(1, nb) * NV, 255);
     for (int v = 0; v < NV; v++) {
@@ -6225,7 +6257,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       if (gen) {
         if (M > 0 && g.KW > 0) hipLaunchKernelGGL(gen_view_gather_kernel, dim3(nblk((long)g.NV * g.KW)), dim3(TPB), 0, st, d, (const double *)d.y);
         if (g.NRr == 3) hipLaunchKernelGGL((gen_schur_point_kernel<3, 2>), dim3(d.nwg), dim3(kCoopObs), 0, st, d, (const double *)d.y);
-        else hipLaunchKernelGGL((gen_schur_point_kernel<2, 2>), dim3(d.nwg), dim3(kCoopObs), 0, st, d, (const double *)d.y);
+        else sv.gen_schur_point2(2, st);
       } else
         hipLaunchKernelGGL(schur_point_coop_kernel<2>, dim3(d.nwg), dim3(kCoopObs), 0, st, d, d.y);
       if (gen) hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(1024), 0, st, d.partial, (long)d.nwg, 1, d.scal + 16);  // the model change's observation part

@@ -183,6 +183,26 @@ def test_local_bundle_adjustment_problem_matches_oracle(oracle_lib):
     assert np.array_equal(g["shot_pose"][sub["shot_fixed"] == 1], sub["shot_pose"][sub["shot_fixed"] == 1])
 
 
+def test_compact_generic_rows_equal_the_rows_with_border_slots(monkeypatch):
+    """gen_eval_kernel's COMPACT layout (round 6: (Xc, wt) instead of the 2 KW border slots; pass A of the mat-vec, the back-substitution and the border's
+    point pass rebuild the slots with project_full on the same Xc) against OSFM_BA_GEN_FULL_ROWS: the same expressions, the same bits"""
+    from opensfm_amd import bundle
+
+    pr = synthetic.make_general_ba_scene(20, 300, 5, model="brown", n_gcp=3, gps_bias=True, seed=11)
+    res = []
+    for full in (False, True):
+        if full:
+            monkeypatch.setenv("OSFM_BA_GEN_FULL_ROWS", "1")
+        else:
+            monkeypatch.delenv("OSFM_BA_GEN_FULL_ROWS", raising=False)
+        with emulated():
+            res.append(bundle.bundle_general_arrays(pr, {"bundle_max_iterations": 3}, **NO_TOL))
+    a, b = res
+    assert np.array_equal(a["cost_history"], b["cost_history"])
+    for k in ("cam_params", "rig_instance_pose", "points", "bias"):
+        assert np.array_equal(a[k], b[k]), k
+
+
 def test_one_workgroup_band_factor_equals_the_cyclic_reduction(monkeypatch):
     """Few shots: the band is factorised by ONE workgroup (sband_factor_kernel: block LDL^T with 6 x 6 pivots, the next pivot inverted by wavefront 0
     beside the trailing update) and applied by sband_solve_kernel -- against the cyclic reduction of the same band (OSFM_BA_NO_SBAND): both are exact,

@@ -182,6 +182,31 @@ def test_brown_camera_at_configs2_size_twenty_iterations(oracle_lib, gpu_ctx):
     assert g["preconditioner_bandwidth"] == g["shot_bandwidth"] and g["pcg_iterations"] <= 2 * 20
 
 
+@pytest.mark.parametrize("model", ["brown", "fisheye_opencv", "perspective"])
+def test_compact_rows_equal_the_rows_with_border_slots(gpu_ctx, monkeypatch, model):
+    """One 2-D projection type, reprojection rows only, no free rig camera: the rows keep (Xc, wt) instead of their 2 KW border slots
+    (gen_eval_kernel's COMPACT layout, round 6) and pass A of the mat-vec, the back-substitution and the border's point pass rebuild the slots with
+    project_full on the same Xc -- the expressions of the evaluation kernel, operation by operation (bit for bit on the host emulation and on fresh
+    contexts, `tools/r06_compact_diag.py`; here to 1e-10: the prior blocks are accumulated with atomics, whose order is not fixed between two runs).
+    Long tracks (the strided path of the three kernels) ride along in the second scene."""
+    from opensfm_amd import bundle
+
+    scenes = [synthetic.make_general_ba_scene(60, 1500, 6, model=model, n_gcp=5, gps_bias=True, seed=11),
+              synthetic.make_general_ba_scene(300, 40, 290, model=model, n_gcp=0, gps_bias=True, seed=12)]
+    for pr in scenes:
+        res = []
+        for full in (False, True):
+            if full:
+                monkeypatch.setenv("OSFM_BA_GEN_FULL_ROWS", "1")
+            else:
+                monkeypatch.delenv("OSFM_BA_GEN_FULL_ROWS", raising=False)
+            res.append(bundle.bundle_general_arrays(pr, {"bundle_max_iterations": 5}, ctx=gpu_ctx, **NO_TOL))
+        a, b = res
+        assert np.allclose(a["cost_history"], b["cost_history"], rtol=1e-10, atol=0)
+        for k in ("cam_params", "rig_instance_pose", "points", "bias"):
+            assert np.allclose(a[k], b[k], rtol=0, atol=1e-7), k
+
+
 def test_nine_free_cameras_keep_the_exact_border(oracle_lib, gpu_ctx):
     """nine free BROWN cameras = 81 border unknowns: inside the kGenMaxNB = 100 the exact border elimination carries since round 6 (64 until round
     5, when this scene fell back to Jacobi-preconditioned border rows and more than four CG iterations per LM iteration): the preconditioner
