@@ -150,8 +150,10 @@ def run_general(ctx, shots: int = 5000, points: int = 500000, track: int = 10, i
            "cost": [float(g["initial_cost"]), float(g["final_cost"])], "ms_per_matvec": g["ms_per_matvec"],
            "bias": [float(x) for x in g["bias"][0]], "bias_true": [float(x) for x in pr["gt_bias"][0]],
            "lm_iteration_ms": round(1e3 * g["seconds_run"] / max(1, g["iterations"]), 3)}
-    # the generic rows' mat-vec: 2 x (6 Jp + 12 Jc + 2 x 9 border slots) doubles read by the two passes + w = 2 x 144 + 2 x 72 B / observation
-    alg = 288.0 + 144.0
+    # the generic rows' mat-vec against the SAME figure as the specialised path: SURVEY 8(d)'s 288 B per observation and mat-vec.  (Rounds 4-5 priced the
+    # generic rows at 432 B -- the two passes then read the 2 x 9 border slots of a stored row on top; since round 6 the COMPACT rows rebuild the slots from
+    # (Xc, wt) and the passes move ~250 B per observation by the counters, so 432 would flatter the kernel.)
+    alg = float(MATVEC_BYTES_PER_OBS)
     if g["ms_per_matvec"]:
         out["roofline"] = {"bound": "hbm", "kernel": "schur mat-vec, generic rows (gen_schur_point_kernel<2, 0> + gen_schur_shot_kernel<2, 9>)",
                            "achieved": round(alg * nobs / (g["ms_per_matvec"] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
