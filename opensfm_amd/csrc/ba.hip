@@ -4555,14 +4555,21 @@ struct Solver {
   template <int MODE>
   void gen_schur_point2_mode(hipStream_t sq) {
     const dim3 grid(d.nwg), block(kCoopObs);
-    if (MODE != 1 && gen_compact && gen_uniform_model == OSFM_CAMERA_BROWN)
-      hipLaunchKernelGGL((gen_schur_point_kernel<2, MODE, OSFM_CAMERA_BROWN, (MODE != 1)>), grid, block, 0, sq, d, (const double *)d.y);
-    else if (MODE != 1 && gen_compact && gen_uniform_model == OSFM_CAMERA_FISHEYE_OPENCV)
-      hipLaunchKernelGGL((gen_schur_point_kernel<2, MODE, OSFM_CAMERA_FISHEYE_OPENCV, (MODE != 1)>), grid, block, 0, sq, d, (const double *)d.y);
-    else if (MODE != 1 && gen_compact && gen_uniform_model == OSFM_CAMERA_PERSPECTIVE)
-      hipLaunchKernelGGL((gen_schur_point_kernel<2, MODE, OSFM_CAMERA_PERSPECTIVE, (MODE != 1)>), grid, block, 0, sq, d, (const double *)d.y);
-    else
-      hipLaunchKernelGGL((gen_schur_point_kernel<2, MODE>), grid, block, 0, sq, d, (const double *)d.y);
+    if constexpr (MODE != 1) {  // (mode 1, the right-hand side, does not read the border slots)
+      if (gen_compact && gen_uniform_model == OSFM_CAMERA_BROWN) {
+        hipLaunchKernelGGL((gen_schur_point_kernel<2, MODE, OSFM_CAMERA_BROWN, true>), grid, block, 0, sq, d, (const double *)d.y);
+        return;
+      }
+      if (gen_compact && gen_uniform_model == OSFM_CAMERA_FISHEYE_OPENCV) {
+        hipLaunchKernelGGL((gen_schur_point_kernel<2, MODE, OSFM_CAMERA_FISHEYE_OPENCV, true>), grid, block, 0, sq, d, (const double *)d.y);
+        return;
+      }
+      if (gen_compact && gen_uniform_model == OSFM_CAMERA_PERSPECTIVE) {
+        hipLaunchKernelGGL((gen_schur_point_kernel<2, MODE, OSFM_CAMERA_PERSPECTIVE, true>), grid, block, 0, sq, d, (const double *)d.y);
+        return;
+      }
+    }
+    hipLaunchKernelGGL((gen_schur_point_kernel<2, MODE>), grid, block, 0, sq, d, (const double *)d.y);
   }
   void gen_schur_point2(int mode, hipStream_t sq) {
     if (mode == 0) gen_schur_point2_mode<0>(sq);

@@ -99,8 +99,14 @@ def test_ba_streaming_kernels_do_not_spill(tmp_path_factory):
     # the generic mode's streaming kernels (ba_generic.inc): the mat-vec pair without scratch at every border width, pass A at streaming occupancy
     for nr in (2, 3):
         for mode in (0, 1, 2):
-            r, name = one(k, "gen_schur_point_kernel", "ILi%dELi%dE" % (nr, mode))
-            assert r["ScratchSize"] == 0 and r["VGPRs Spill"] == 0 and r["Occupancy"] >= 4, (name, r)
+            # (round 6: modes 0 and 2 of the two-row kernel also come specialised per projection type for the COMPACT rows, whose border slots they
+            #  rebuild with project_full: the same budget)
+            hits = [n for n in k if "gen_schur_point_kernelILi%dELi%dE" % (nr, mode) in n]
+            assert len(hits) == (4 if nr == 2 and mode != 1 else 1), hits
+            for name in hits:
+                r = k[name]
+                compact = name.endswith("ELb1EEEvNS_3DevEPKd")  # (project_full inlined: the fisheye_opencv form takes 160 registers, three waves per SIMD)
+                assert r["ScratchSize"] == 0 and r["VGPRs Spill"] == 0 and r["Occupancy"] >= (3 if compact else 4), (name, r)
     # round 6: the generic per-instance kernels recompute their rows too (gen_sm_row).  Specialised for the projection type every camera has (BROWN 2,
     # FISHEYE_OPENCV 3, PERSPECTIVE 0) they use no scratch memory; the unspecialised ones (mixed models, spherical) index the parameter
     # Jacobian dynamically and do -- the price of the evaluation kernel's unspecialised form as well
