@@ -238,31 +238,95 @@ __device__ bool solve3(double *M) {
   return true;
 }
 
-// vl_find_local_extrema_3 + vl_refine_local_extreum_3 + the thresholds of vl_covdet_detect, one thread per sample of the octave's
-// interior
-__global__ void extrema_kernel(const float *css, int w, int h, int o, int last_octave, double step, double threshold08, double peak_threshold,
-                               double edge_threshold, double base_scale, Features F) {
-  // (a workgroup per row of 256 samples: 36 000 small workgroups on the first octave.  Eight rows per workgroup were measured in round 4,
-  // with and without loading the eight samples up front: 29 -> 56 / 65 us per launch -- the refinements of a wavefront's candidates then
-  // run one after the other instead of in eight wavefronts)
-  const int x0 = blockIdx.x * blockDim.x + threadIdx.x + 1, y0 = blockIdx.y + 1, z = blockIdx.z + 1;
-  if (x0 > w - 2 || y0 > h - 2) return;
+// vl_find_local_extrema_3 + vl_refine_local_extreum_3 + the thresholds of vl_covdet_detect, all three interior levels of an octave in one
+// workgroup.  Round 6: two phases.
+//   A  the 26 strict comparisons of a sample as ONE comparison with the largest (smallest) of its neighbours, built from row maxima: a lane owns a
+//      column, takes the kExRows + 2 rows of the five levels into registers (50 coalesced loads in flight, every response read once per workgroup
+//      instead of 27 times through the L1: the old kernel's 27 unaligned loads per sample were what bound it, 65 us on the first octave), gets the
+//      two neighbouring columns from the lanes beside it (DPP wave shifts: lanes 0 and 63 of a wavefront are halo columns, a wavefront yields 62
+//      columns) and forms max3 / min3 along x, then along y, then across the levels.  v > every neighbour <=> v > their maximum: the same
+//      decisions.  The strict extrema go onto a list in LDS.
+//   B  the fp64 refinement, one lane per LISTED sample (1 - 2 % of the samples of a noisy image at OpenSfM's peak threshold of 1e-5).
+// The list's order does not matter: the features are put in vlfeat's order of detection by F.key afterwards.
+constexpr int kExRows = 8, kExWaveCols = 62, kExCols = 4 * kExWaveCols;
+__device__ __forceinline__ float lane_left(float v) {  // the value of lane - 1 (wave_shr:1)
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_right(float v) {  // the value of lane + 1 (wave_shl:1)
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+__device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
+// (every octave in ONE launch: a workgroup's path -- fifty loads, the comparisons, a barrier, five dependent fp64 refinement steps -- is ~10 us
+//  long whatever the octave's size, and seven launches one behind the other paid it seven times: 125 -> see profiles/r06_hahog_*)
+struct ExtremaPlan {
+  int first[kMaxOct + 1];  // first workgroup of octave k's tiles (octave 0, the largest, first); first[n_oct] = the grid
+  int gx[kMaxOct];         // tiles along x
+};
+__global__ void __launch_bounds__(256) extrema_kernel(Pyramid py, ExtremaPlan plan, double threshold08, double peak_threshold, double edge_threshold,
+                                                      Features F) {
+  __shared__ int cand[kExCols * kExRows * (kLev - 2) / 2 + 64];  // level << 19 | row << 16 | x (a strict maximum has no strict maximum beside it)
+  __shared__ int ncand;
+  int o = 0;
+  while (o + 1 < py.n_oct && (int)blockIdx.x >= plan.first[o + 1]) o++;
+  const int tile = blockIdx.x - plan.first[o], tile_y = tile / plan.gx[o], tile_x = tile - tile_y * plan.gx[o];
+  const float *css = py.oct[o].css;
+  const int w = py.oct[o].w, h = py.oct[o].h, last_octave = py.n_oct - 1;
+  const double step = (double)(1 << o), base_scale = py.base_scale;
   const long xo = 1, yo = w, zo = (long)w * h;
+  const int yb = tile_y * kExRows + 1;
+  if (threadIdx.x == 0) ncand = 0;
+  __syncthreads();
   {
-    const float *pt = css + x0 * xo + y0 * yo + z * zo;
-    const float v = *pt;
-    bool mx = (double)v >= threshold08, mn = (double)v <= -threshold08;
-    if (!mx && !mn) return;
-    for (int dz = -1; dz <= 1 && (mx || mn); dz++)
-      for (int dy = -1; dy <= 1; dy++)
-        for (int dx = -1; dx <= 1; dx++) {
-          if (dx == 0 && dy == 0 && dz == 0) continue;
-          const float q = pt[dx * xo + dy * yo + dz * zo];
-          mx = mx && v > q;
-          mn = mn && v < q;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int xs = tile_x * kExCols + wv * kExWaveCols + lane;  // lanes 1 .. 62 decide, lanes 0 and 63 carry the columns beside them
+    const int xl = xs < w - 1 ? xs : w - 1;
+    float hm[kLev][kExRows + 2], hn[kLev][kExRows + 2], vc[kLev - 2][kExRows], sm[kLev - 2][kExRows], sn[kLev - 2][kExRows];
+    {
+      float v[kLev][kExRows + 2];
+#pragma unroll
+      for (int j = 0; j < kExRows + 2; j++) {
+        const int yy = yb - 1 + j, yl = yy < h - 1 ? yy : h - 1;
+#pragma unroll
+        for (int l = 0; l < kLev; l++) v[l][j] = css[l * zo + (long)yl * yo + xl];
+      }
+#pragma unroll
+      for (int j = 0; j < kExRows + 2; j++)
+#pragma unroll
+        for (int l = 0; l < kLev; l++) {
+          const float c = v[l][j], lf = lane_left(c), rt = lane_right(c);
+          hm[l][j] = max3f(lf, c, rt);
+          hn[l][j] = min3f(lf, c, rt);
+          if (l >= 1 && l <= kLev - 2 && j >= 1 && j <= kExRows) {
+            vc[l - 1][j - 1] = c;
+            sm[l - 1][j - 1] = fmaxf(lf, rt);
+            sn[l - 1][j - 1] = fminf(lf, rt);
+          }
         }
-    if (!mx && !mn) return;
+    }
+    const bool col_ok = lane >= 1 && lane <= kExWaveCols && xs <= w - 2;
+#pragma unroll
+    for (int j = 1; j <= kExRows; j++) {
+      float vm[kLev], vn[kLev];  // the 3 x 3 window of every level around (xs, row j)
+#pragma unroll
+      for (int l = 0; l < kLev; l++) {
+        vm[l] = max3f(hm[l][j - 1], hm[l][j], hm[l][j + 1]);
+        vn[l] = min3f(hn[l][j - 1], hn[l][j], hn[l][j + 1]);
+      }
+#pragma unroll
+      for (int l = 1; l <= kLev - 2; l++) {
+        const float c = vc[l - 1][j - 1];
+        const float nbmax = max3f(vm[l - 1], vm[l + 1], max3f(hm[l][j - 1], hm[l][j + 1], sm[l - 1][j - 1]));
+        const float nbmin = min3f(vn[l - 1], vn[l + 1], min3f(hn[l][j - 1], hn[l][j + 1], sn[l - 1][j - 1]));
+        const bool mx = (double)c >= threshold08 && c > nbmax, mn = (double)c <= -threshold08 && c < nbmin;
+        if ((mx || mn) && col_ok && yb - 1 + j <= h - 2) cand[atomicAdd(&ncand, 1)] = ((l - 1) << 19) | ((j - 1) << 16) | xs;
+      }
+    }
   }
+  __syncthreads();
+  const int nc = ncand;
+  for (int ci = threadIdx.x; ci < nc; ci += 256) {
+  const int x0 = cand[ci] & 0xffff, y0 = yb + ((cand[ci] >> 16) & 7), z = (cand[ci] >> 19) + 1;
   // refinement
   int x = x0, y = y0, dx = 0, dy = 0;
   double Dx = 0, Dy = 0, Dz = 0, Dxx = 0, Dyy = 0, Dzz = 0, Dxy = 0, Dxz = 0, Dyz = 0, b[3] = {0, 0, 0};
@@ -312,12 +376,12 @@ __global__ void extrema_kernel(const float *css, int w, int h, int o, int last_o
        rz <= kLev - 1;
   ok = ok && fabs((double)peakF) > peak_threshold;
   ok = ok && (double)edgeF < edge_threshold;
-  if (!ok) return;
+  if (!ok) continue;
   // o + (refined.z + first) / resolution: a float and integers -- C evaluates the whole exponent in float (covdet.c:2007-2009)
   const float expo = (float)o + (rz + (float)kFirstSub) / (float)kRes;
   const double sigma = base_scale * pow(2.0, (double)expo);
   const int slot = atomicAdd(F.count, 1);
-  if (slot >= F.cap) return;
+  if (slot >= F.cap) continue;
   F.x[slot] = (float)(rx * step);
   F.y[slot] = (float)(ry * step);
   F.sigma[slot] = (float)sigma;
@@ -326,6 +390,7 @@ __global__ void extrema_kernel(const float *css, int w, int h, int o, int last_o
   F.peak[slot] = peakF;
   F.edge[slot] = edgeF;
   F.key[slot] = ((unsigned long long)(last_octave - o) << 56) | ((unsigned long long)z << 48) | ((unsigned long long)y0 << 24) | (unsigned long long)x0;
+  }
 }
 
 __global__ void iota_kernel(int *a, int n) {
@@ -1220,11 +1285,22 @@ static int hahog_extract_on_stream(osfm_ctx *ctx, hipStream_t st, const float *i
   double *d_tab = A.take<double>((size_t)kOrSide * kOrSide + 257);
   OSFM_REQUIRE(!A.overflow, OSFM_E_NOMEM, "osfm_hahog_extract: internal: slab A too small");
   OSFM_HIP(hipMemsetAsync(F.count, 0, 4 * sizeof(int), st));
-  for (int o = last_octave; o >= 0; o--) {
-    const Octave &oc = py.oct[o];
-    if (oc.w < 3 || oc.h < 3) continue;
-    hipLaunchKernelGGL(extrema_kernel, grid2(oc.w - 2, oc.h - 2, kLev - 2), dim3(256), 0, st, (const float *)oc.css, oc.w, oc.h, o, last_octave,
-                       std::pow(2.0, o), 0.8 * (double)peak_threshold, (double)peak_threshold, (double)edge_threshold, py.base_scale, F);
+  {
+    ExtremaPlan plan;
+    int nwg = 0;
+    for (int o = 0; o <= last_octave; o++) {
+      const Octave &oc = py.oct[o];
+      plan.first[o] = nwg;
+      plan.gx[o] = 1;
+      if (oc.w < 3 || oc.h < 3) continue;
+      plan.gx[o] = (oc.w - 2 + kExCols - 1) / kExCols;
+      nwg += plan.gx[o] * ((oc.h - 2 + kExRows - 1) / kExRows);
+    }
+    for (int o = last_octave + 1; o <= kMaxOct; o++) plan.first[o] = nwg;
+    for (int o = last_octave + 1; o < kMaxOct; o++) plan.gx[o] = 1;
+    if (nwg > 0)
+      hipLaunchKernelGGL(extrema_kernel, dim3((unsigned)nwg), dim3(256), 0, st, py, plan, 0.8 * (double)peak_threshold, (double)peak_threshold,
+                         (double)edge_threshold, F);
   }
   int n0 = 0;
   OSFM_HIP(hipMemcpyAsync(&n0, F.count, sizeof(int), hipMemcpyDeviceToHost, st));
