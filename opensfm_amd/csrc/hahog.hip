@@ -561,10 +561,28 @@ __device__ __forceinline__ float plan_read(const PatchPlan &P, long xi, long yi)
 // the resampling loop (covdet.c:2360-2405): patch[yyi][xxi], side = 2 resolution + 1; the running coordinates are sums, as there
 // Round 4: the four samples of ALL the pixels of a thread (PER = ceil(side^2 / nthreads)) are requested before the first blend -- a plain
 // loop waited for one round trip to the level per pixel (26 of the orientation workgroup's 75 us); each pixel's arithmetic is unchanged.
-template <int PER, int G>  // G pixels in flight per thread (all seven of the orientation patch cost a fourth wave per SIMD in registers)
-__device__ void sample_patch(const PatchPlan &P, float *patch, int resolution, double extent, int tid, int nthreads) {
+// Round 6: the instruction diet.  The kernels are bound by what a SIMD issues for its four to six resident wavefronts, and a pixel of this
+// loop cost several hundred instructions: the running sums redone per pixel (up to 40 + 40 dependent fp64 additions), double -> int64 -> double
+// conversions for the floor, 64-bit index arithmetic and the padded copy's clamps on every one of the four reads.  Now the running sums are a
+// table in LDS (`hat`: entry q = -extent + stephat + ... + stephat, q additions in the reference's order, filled once per workgroup by
+// patch_hat_table), the floor is v_floor_f64 (|x| < 2^31: the same integer, and x - floor(x) the same double), the indices are 32-bit, and a
+// patch that lies inside its level (wave-uniform) reads the level directly.  Each pixel's arithmetic is unchanged.
+__device__ __forceinline__ void patch_hat_table(double *hat, int resolution, double extent, int lane) {  // one wavefront, a lane per entry
   const int side = 2 * resolution + 1;
   const double stephat = extent / resolution;
+  if (lane < side) {
+    double a = -extent;
+    for (int q = 0; q < lane; q++) a += stephat;
+    hat[lane] = a;
+  }
+}
+template <int PER, int G>  // G pixels in flight per thread (all seven of the orientation patch cost a fourth wave per SIMD in registers)
+__device__ void sample_patch(const PatchPlan &P, const double *hat, float *patch, int resolution, int tid, int nthreads) {
+  const int side = 2 * resolution + 1;
+  const double A0 = P.A[0], A1 = P.A[1], A2 = P.A[2], A3 = P.A[3], T0 = P.T[0], T1 = P.T[1];
+  const bool padded = P.padded;
+  const float *level = P.level;
+  const int width = P.width;
 #pragma unroll
   for (int g = 0; g < PER; g += G) {
     double wxs[G], wys[G];
@@ -574,19 +592,25 @@ __device__ void sample_patch(const PatchPlan &P, float *patch, int resolution, d
       const int tq = tid + (g + u) * nthreads;
       const int t = (g + u < PER && tq < side * side) ? tq : 0;  // a thread past the end samples pixel 0 and drops it
       const int yyi = t / side, xxi = t - yyi * side;
-      double yhat = -extent;
-      for (int q = 0; q < yyi; q++) yhat += stephat;
-      double xhat = -extent;
-      for (int q = 0; q < xxi; q++) xhat += stephat;
-      const double rx = P.A[2] * yhat + P.T[0], ry = P.A[3] * yhat + P.T[1];
-      const double x = P.A[0] * xhat + rx, y = P.A[1] * xhat + ry;
-      const long xi = vl_floor_d(x), yi = vl_floor_d(y);
-      v00[u] = plan_read(P, xi, yi);
-      v10[u] = plan_read(P, xi + 1, yi);
-      v01[u] = plan_read(P, xi, yi + 1);
-      v11[u] = plan_read(P, xi + 1, yi + 1);
-      wxs[u] = x - xi;
-      wys[u] = y - yi;
+      const double yhat = hat[yyi], xhat = hat[xxi];
+      const double rx = A2 * yhat + T0, ry = A3 * yhat + T1;
+      const double x = A0 * xhat + rx, y = A1 * xhat + ry;
+      const double fx = floor(x), fy = floor(y);
+      const int xi = (int)fx, yi = (int)fy;
+      if (!padded) {
+        const float *q = level + (yi * width + xi);
+        v00[u] = q[0];
+        v10[u] = q[1];
+        v01[u] = q[width];
+        v11[u] = q[width + 1];
+      } else {
+        v00[u] = plan_read(P, xi, yi);
+        v10[u] = plan_read(P, xi + 1, yi);
+        v01[u] = plan_read(P, xi, yi + 1);
+        v11[u] = plan_read(P, xi + 1, yi + 1);
+      }
+      wxs[u] = x - fx;
+      wys[u] = y - fy;
     }
 #pragma unroll
     for (int u = 0; u < G; u++) {
@@ -660,7 +684,7 @@ __global__ void __launch_bounds__(256) orientation_kernel(Pyramid py, const floa
   __shared__ float taps1[kMaxTaps];
   __shared__ int W1;
   __shared__ PatchPlan P;
-  __shared__ double hist[kOrBins], hist2[kOrBins];
+  __shared__ double hist[kOrBins], hist2[kOrBins], hat[kOrSide];
   __shared__ int tot[kOrBins], start[kOrBins + 1], run[kOrBins], cw[4][kOrBins];
   const int f = blockIdx.x, tid = threadIdx.x;
   if (f >= n) return;
@@ -696,6 +720,8 @@ __global__ void __launch_bounds__(256) orientation_kernel(Pyramid py, const floa
       taps1[W + tid] = (float)g / mass;
     }
   }
+  else if (tid < 128)  // wave 1, beside wave 0's plan
+    patch_hat_table(hat, kOrRes, kOrExtent, tid - 64);
   if (tid < kOrBins) {
     hist[tid] = 0.0;
     tot[tid] = 0;
@@ -703,7 +729,7 @@ __global__ void __launch_bounds__(256) orientation_kernel(Pyramid py, const floa
   }
   __syncthreads();
   HTICK(h1)
-  sample_patch<(kOrSide * kOrSide + 255) / 256, 4>(P, patch, kOrRes, kOrExtent, tid, 256);
+  sample_patch<(kOrSide * kOrSide + 255) / 256, 4>(P, hat, patch, kOrRes, tid, 256);
   __syncthreads();
   HTICK(h2)
   const int W = W1;
@@ -936,8 +962,10 @@ __global__ void __launch_bounds__(256) descriptor_kernel(Pyramid py, Oriented R,
   __shared__ float snorm;
   __shared__ int rlo[2][kDSide], rhi[2][kDSide], clo[2][kDSide], chi[2][kDSide];  // per row / column: range of binx [0] and biny [1]
   __shared__ PatchPlan P;
+  __shared__ double hat[kDSide];
   const int f = blockIdx.x, tid = threadIdx.x;
   if (f >= n) return;
+  if (tid >= 128 && tid < 192) patch_hat_table(hat, kDRes, kDExtent, tid - 128);  // wave 2, beside wave 0's plan
   if (tid >= 64 && tid < 64 + 2 * kDSide) {
     const int i = tid - 64;
     (&rlo[0][0])[i] = INT_MAX;
@@ -964,7 +992,7 @@ __global__ void __launch_bounds__(256) descriptor_kernel(Pyramid py, Oriented R,
   }
   __syncthreads();
   HTICK(h1)
-  sample_patch<(kDSide * kDSide + 255) / 256, 2>(P, patch, kDRes, kDExtent, tid, 256);
+  sample_patch<(kDSide * kDSide + 255) / 256, 2>(P, hat, patch, kDRes, tid, 256);
   __syncthreads();
   HTICK(h2)
   // per pixel: window x modulus, the lower bin of the 2 x 2 x 2 it feeds and the three fractions (sift.c:1806-1850); x = y = 15,
