@@ -4535,7 +4535,7 @@ struct Solver {
       else OSFM_GEN_EVAL(2, -1);
     }
     hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(1024), 0, st, d.partial, (long)(d.M > 0 ? nb : 0), 2, d.scal + 8);
-    hipLaunchKernelGGL(gen_prior_kernel, dim3(nblk(gen_nprior(), 256)), dim3(256), gen_prior_lds(jac ? 1 : 0), st, d, cam, bias, rcp, poses, jac ? 1 : 0,
+    hipLaunchKernelGGL(gen_prior_kernel, dim3(nblk(gen_nprior(), kGenPriorTPB)), dim3(kGenPriorTPB), gen_prior_lds(jac ? 1 : 0), st, d, cam, bias, rcp, poses, jac ? 1 : 0,
                        (const double *)nullptr, d.scal + 8);
     if (d.g.pt_prior_sigma && d.P > 0) hipLaunchKernelGGL(gen_point_prior_kernel, dim3(nblk(d.P)), dim3(TPB), 0, st, d, pts, 0, d.scal + 8);
   }
@@ -6270,7 +6270,7 @@ static int ba_solve_impl(osfm_ctx *ctx, osfm_ba_problem *P, const osfm_ba_option
       if (gen) hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(1024), 0, st, d.partial, (long)d.nwg, 1, d.scal + 16);  // the model change's observation part
       if (gen) {
         hipLaunchKernelGGL(gen_candidate_kernel, dim3(1), dim3(1024), 0, st, d, (const double *)d.y, d.scal + 16);
-        hipLaunchKernelGGL(gen_prior_kernel, dim3(nblk(sv.gen_nprior(), 256)), dim3(256), sv.gen_prior_lds(2), st, d, (const double *)g.cam, (const double *)g.bias,
+        hipLaunchKernelGGL(gen_prior_kernel, dim3(nblk(sv.gen_nprior(), kGenPriorTPB)), dim3(kGenPriorTPB), sv.gen_prior_lds(2), st, d, (const double *)g.cam, (const double *)g.bias,
                            (const double *)g.rc, (const double *)d.poses, 2, (const double *)d.y, d.scal + 16);
         if (g.pt_prior_sigma && NP > 0) hipLaunchKernelGGL(gen_point_prior_kernel, dim3(nblk(NP)), dim3(TPB), 0, st, d, (const double *)d.pts, 2, d.scal + 16);
       }

@@ -129,6 +129,17 @@ def test_hahog_per_feature_kernels(tmp_path_factory):
     assert r["Occupancy"] >= 6 and r["VGPRs"] <= 84  # two pixels of the resampling in flight, not four (90 registers: five waves)
 
 
+def test_hahog_extremum_search_holds_its_rows_in_registers(tmp_path_factory):
+    """round 6: the extremum search takes the ten rows of the five levels into registers (no scratch), gets the columns beside a lane by DPP
+    wave shifts (no LDS traffic for them) and keeps the candidate list of a tile within 16 KB of LDS"""
+    asm, k = compile_device("hahog", tmp_path_factory)
+    r, name = one(k, "extrema_kernel")
+    assert r["ScratchSize"] == 0 and r["VGPRs Spill"] == 0 and r["LDS Size"] <= 16 * 1024 and r["Occupancy"] >= 3, r
+    b = body(asm, name)
+    assert b.count("wave_shr:1") == 50 and b.count("wave_shl:1") == 50, (b.count("wave_shr:1"), b.count("wave_shl:1"))  # 5 levels x 10 rows, both sides
+    assert "ds_bpermute" not in b
+
+
 def test_hahog_fused_smoothing_and_wide_band_kernels(tmp_path_factory):
     """round 4: the fused separable smoothing keeps its sliding windows in registers (no scratch) and at least four workgroups per CU for
     every tap count; the wide band's hand-written kernels do not spill"""
