@@ -804,16 +804,22 @@ __global__ void __launch_bounds__(256) orientation_kernel(Pyramid py, const floa
       const bool valid = t < kOrSide * kOrSide;
       const int b = valid ? hbin[t] : -1;
       const int bm1 = valid ? (b + kOrBins - 1) % kOrBins : -1, bp1 = valid ? (b + 1) % kOrBins : -1;
-      int p_m1 = 0, p_0 = 0, p_p1 = 0, mycnt = 0;
-#pragma unroll 4
-      for (int v = 0; v < kOrBins; v++) {
-        const unsigned long long m = __ballot(b == v);
-        const int pre = __popcll(m & ((1ull << lane) - 1ull));
-        p_0 = (v == b) ? pre : p_0;
-        p_m1 = (v == bm1) ? pre : p_m1;
-        p_p1 = (v == bp1) ? pre : p_p1;
-        mycnt = (lane == v) ? __popcll(m) : mycnt;
-      }
+      // Round 6: the lanes holding a given bin value from SIX ballots (one per bit of the bin index) instead of one ballot per bin value:
+      // mask(t) = valid & AND_k (bit k of t ? B_k : ~B_k).  A lane needs four such masks (its bin, the bins beside it, and -- as the
+      // counter of bin `lane` -- the bin whose number it carries): ~120 instructions per chunk of 256 pixels against ~500 for the 36 ballots
+      // with their selects, seven chunks per workgroup.  The same counts.
+      unsigned long long Bk[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) Bk[k] = __ballot(valid && ((b >> k) & 1));
+      const unsigned long long Vm = __ballot(valid), below = (1ull << lane) - 1ull;
+      auto lanes_with = [&](int t) {
+        unsigned long long m = Vm;
+#pragma unroll
+        for (int k = 0; k < 6; k++) m &= ((t >> k) & 1) ? Bk[k] : ~Bk[k];
+        return m;
+      };
+      const int p_0 = __popcll(lanes_with(b) & below), p_m1 = __popcll(lanes_with(bm1) & below), p_p1 = __popcll(lanes_with(bp1) & below);
+      const int mycnt = __popcll(lanes_with(lane));
       if (lane < kOrBins) cw[w][lane] = mycnt;
       __syncthreads();  // cw of this chunk, start[] (first chunk), run[] of the previous chunk
       if (valid) {
@@ -953,26 +959,79 @@ __global__ void orient_frames_kernel(const float *fx, const float *fy, const flo
 // ---- descriptors (hahog.cc:163-200; sift.c:1754-1898) -----------------------------------------------------------------------------
 constexpr int kDRes = 15, kDSide = 2 * kDRes + 1, kNBO = 8, kNBP = 4;
 constexpr double kDExtent = 7.5;
-__global__ void __launch_bounds__(256) descriptor_kernel(Pyramid py, Oriented R, int n, const double *expn_tab, double st0, double ct0, double sigma_d,
-                                                         int flags, float *points, float *desc) {
+// What a pixel of the 31 x 31 patch contributes apart from its gradient does not depend on the feature (round 6): hahog.cc describes every patch
+// at its centre with angle0 = pi / 2 and one sigma, so the normalised coordinates (nx, ny), the Gaussian window, the lower spatial bins and the two
+// spatial fractions of pixel t -- two fp64 divisions, the exp-table interpolation, three float -> int64 floors and eight LDS atomics per pixel --
+// are the same 961 values for all ~5 000 features of an image, and so are the rows and columns a spatial bin walks.  desc_table_kernel computes
+// them once per call with the expressions the descriptor kernel used to evaluate per feature (the same bits); descriptor_kernel reads them.
+struct DescTable {
+  float4 pix[kDSide * kDSide];               // window, nx - (binx + 0.5), ny - (biny + 0.5), bits of (binx + 128) | (biny + 128) << 8
+  unsigned rowmask[kNBP * kNBP], colmask[kNBP * kNBP];  // per spatial bin (bx + 2) + 4 (by + 2): the rows / columns whose bin ranges admit it
+};
+__global__ void __launch_bounds__(256) desc_table_kernel(const double *expn_tab, double st0, double ct0, double sigma_d, DescTable *tab) {
+  __shared__ int rlo[2][kDSide], rhi[2][kDSide], clo[2][kDSide], chi[2][kDSide];  // per row / column: range of binx [0] and biny [1]
+  const int tid = threadIdx.x;
+  if (tid < 2 * kDSide) {
+    (&rlo[0][0])[tid] = INT_MAX;
+    (&clo[0][0])[tid] = INT_MAX;
+    (&rhi[0][0])[tid] = INT_MIN;
+    (&chi[0][0])[tid] = INT_MIN;
+  }
+  __syncthreads();
+  // (sift.c:1806-1850; x = y = 15, so xi = yi = 15 and every pixel of the patch is inside the window W = 21)
+  const double x0 = (double)(kDSide - 1) / 2, y0 = (double)(kDSide - 1) / 2;
+  const double SBP = 3.0 * sigma_d + kEpsD;
+  for (int t = tid; t < kDSide * kDSide; t += 256) {
+    const int py_ = t / kDSide, px_ = t - py_ * kDSide;
+    const float dx = (float)(px_ - x0), dy = (float)(py_ - y0);
+    const float nx = (float)((ct0 * dx + st0 * dy) / SBP);
+    const float ny = (float)((-st0 * dx + ct0 * dy) / SBP);
+    const float wsigma = (float)(kNBP / 2);
+    double ex = (nx * nx + ny * ny) / (2.0 * wsigma * wsigma), win_d;
+    if (ex > 25.0) win_d = 0.0;
+    else {
+      ex *= 256 / 25.0;
+      const int i = (int)vl_floor_d(ex);
+      const double r = ex - i, a = expn_tab[i], b = expn_tab[i + 1];
+      win_d = a + r * (b - a);
+    }
+    const float win = (float)win_d;
+    const int binx = (int)vl_floor_f((float)(nx - 0.5)), biny = (int)vl_floor_f((float)(ny - 0.5));
+    tab->pix[t] = make_float4(win, (float)(nx - (binx + 0.5)), (float)(ny - (biny + 0.5)), __int_as_float((binx + 128) | ((biny + 128) << 8)));
+    atomicMin(&rlo[0][py_], binx);
+    atomicMax(&rhi[0][py_], binx);
+    atomicMin(&rlo[1][py_], biny);
+    atomicMax(&rhi[1][py_], biny);
+    atomicMin(&clo[0][px_], binx);
+    atomicMax(&chi[0][px_], binx);
+    atomicMin(&clo[1][px_], biny);
+    atomicMax(&chi[1][px_], biny);
+  }
+  __syncthreads();
+  if (tid < kNBP * kNBP) {
+    const int bx = tid % kNBP - kNBP / 2, by = tid / kNBP - kNBP / 2;
+    unsigned rowmask = 0, colmask = 0;
+    for (int i = 0; i < kDSide; i++) {
+      const bool r = rlo[0][i] <= bx && rhi[0][i] >= bx - 1 && rlo[1][i] <= by && rhi[1][i] >= by - 1;
+      const bool c = clo[0][i] <= bx && chi[0][i] >= bx - 1 && clo[1][i] <= by && chi[1][i] >= by - 1;
+      rowmask |= r ? (1u << i) : 0u;
+      colmask |= c ? (1u << i) : 0u;
+    }
+    tab->rowmask[tid] = rowmask;
+    tab->colmask[tid] = colmask;
+  }
+}
+__global__ void __launch_bounds__(256) descriptor_kernel(Pyramid py, Oriented R, int n, const DescTable *tab, int flags, float *points, float *desc) {
   __shared__ float patch[kDSide * kDSide];
   __shared__ float4 sval[kDSide * kDSide];  // window x modulus and the three fractions of the pixel
   __shared__ int scode[kDSide * kDSide];    // its lower bins: (binx + 128) | (biny + 128) << 8 | bint << 16
   __shared__ float descr[kNBO * kNBP * kNBP];
   __shared__ float snorm;
-  __shared__ int rlo[2][kDSide], rhi[2][kDSide], clo[2][kDSide], chi[2][kDSide];  // per row / column: range of binx [0] and biny [1]
   __shared__ PatchPlan P;
   __shared__ double hat[kDSide];
   const int f = blockIdx.x, tid = threadIdx.x;
   if (f >= n) return;
   if (tid >= 128 && tid < 192) patch_hat_table(hat, kDRes, kDExtent, tid - 128);  // wave 2, beside wave 0's plan
-  if (tid >= 64 && tid < 64 + 2 * kDSide) {
-    const int i = tid - 64;
-    (&rlo[0][0])[i] = INT_MAX;
-    (&clo[0][0])[i] = INT_MAX;
-    (&rhi[0][0])[i] = INT_MIN;
-    (&chi[0][0])[i] = INT_MIN;
-  }
   HTICK(h0)
   if (tid < 64) {  // wave 0
     const float a11 = R.a11[f], a21 = R.a21[f], a12 = R.a12[f], a22 = R.a22[f];
@@ -995,40 +1054,18 @@ __global__ void __launch_bounds__(256) descriptor_kernel(Pyramid py, Oriented R,
   sample_patch<(kDSide * kDSide + 255) / 256, 2>(P, hat, patch, kDRes, tid, 256);
   __syncthreads();
   HTICK(h2)
-  // per pixel: window x modulus, the lower bin of the 2 x 2 x 2 it feeds and the three fractions (sift.c:1806-1850); x = y = 15,
-  // so xi = yi = 15 and every pixel of the patch is inside the window W = 21
-  const double x0 = (double)(kDSide - 1) / 2, y0 = (double)(kDSide - 1) / 2;
-  const double SBP = 3.0 * sigma_d + kEpsD;
+  // per pixel: window x modulus, the lower bin of the 2 x 2 x 2 it feeds and the three fractions (sift.c:1806-1850): the gradient and its
+  // orientation bin here, everything else from the table
   for (int t = tid; t < kDSide * kDSide; t += 256) {
-    const int py_ = t / kDSide, px_ = t - py_ * kDSide;
     float mod, angle;
     polar_gradient(patch, kDSide, t, &mod, &angle);
     const float theta = mod_2pi_f((float)(angle - (kPi / 2)));
-    const float dx = (float)(px_ - x0), dy = (float)(py_ - y0);
-    const float nx = (float)((ct0 * dx + st0 * dy) / SBP);
-    const float ny = (float)((-st0 * dx + ct0 * dy) / SBP);
     const float nt = (float)(kNBO * theta / (2 * kPi));
-    const float wsigma = (float)(kNBP / 2);
-    double ex = (nx * nx + ny * ny) / (2.0 * wsigma * wsigma), win_d;
-    if (ex > 25.0) win_d = 0.0;
-    else {
-      ex *= 256 / 25.0;
-      const int i = (int)vl_floor_d(ex);
-      const double r = ex - i, a = expn_tab[i], b = expn_tab[i + 1];
-      win_d = a + r * (b - a);
-    }
-    const float win = (float)win_d;
-    const int binx = (int)vl_floor_f((float)(nx - 0.5)), biny = (int)vl_floor_f((float)(ny - 0.5)), bint = (int)vl_floor_f(nt);
-    sval[t] = make_float4(win * mod, (float)(nx - (binx + 0.5)), (float)(ny - (biny + 0.5)), nt - bint);
-    scode[t] = (binx + 128) | ((biny + 128) << 8) | (bint << 16);
-    atomicMin(&rlo[0][py_], binx);
-    atomicMax(&rhi[0][py_], binx);
-    atomicMin(&rlo[1][py_], biny);
-    atomicMax(&rhi[1][py_], biny);
-    atomicMin(&clo[0][px_], binx);
-    atomicMax(&chi[0][px_], binx);
-    atomicMin(&clo[1][px_], biny);
-    atomicMax(&chi[1][px_], biny);
+    const float fl = floorf(nt);  // vl_floor_f: 0 <= nt <= 8
+    const int bint = (int)fl;
+    const float4 c = tab->pix[t];
+    sval[t] = make_float4(c.x * mod, c.y, c.z, nt - bint);
+    scode[t] = __float_as_int(c.w) | (bint << 16);
   }
   __syncthreads();
   HTICK(h3)
@@ -1040,14 +1077,7 @@ __global__ void __launch_bounds__(256) descriptor_kernel(Pyramid py, Oriented R,
   // were 130 of the kernel's 166 us per workgroup, profiles/r03_hahog_phases_before_sort.txt.)
   if (tid < kNBO * kNBP * kNBP) {
     const int bt = tid % kNBO, bx = (tid / kNBO) % kNBP - kNBP / 2, by = tid / (kNBO * kNBP) - kNBP / 2;
-    unsigned rowmask = 0, colmask = 0;
-#pragma unroll
-    for (int i = 0; i < kDSide; i++) {
-      const bool r = rlo[0][i] <= bx && rhi[0][i] >= bx - 1 && rlo[1][i] <= by && rhi[1][i] >= by - 1;
-      const bool c = clo[0][i] <= bx && chi[0][i] >= bx - 1 && clo[1][i] <= by && chi[1][i] >= by - 1;
-      rowmask |= r ? (1u << i) : 0u;
-      colmask |= c ? (1u << i) : 0u;
-    }
+    const unsigned rowmask = tab->rowmask[tid / kNBO], colmask = tab->colmask[tid / kNBO];
     float acc = 0.f;
     for (unsigned rm = rowmask; rm; rm &= rm - 1) {
       const int yb = __builtin_ctz(rm) * kDSide;
@@ -1191,7 +1221,7 @@ static int hahog_extract_on_stream(osfm_ctx *ctx, hipStream_t st, const float *i
   constexpr int kFeatureCap = 1 << 20;
   {
     size_t need = padded((size_t)W0 * H0, 4) + padded((size_t)W0 * H0, 1) + padded((size_t)kMaxTaps * (kLev + 1) * kMaxOct, 4) + 5 * padded(kFeatureCap, 4) + 2 * padded(kFeatureCap, 4) +
-                  padded(kFeatureCap, 8) + padded(4, 4) + padded((size_t)kOrSide * kOrSide + 257, 8);
+                  padded(kFeatureCap, 8) + padded(4, 4) + padded((size_t)kOrSide * kOrSide + 257, 8) + padded(sizeof(DescTable) + 16, 1);
     for (int o = 0; o <= last_octave; o++) need += 2 * padded((size_t)(W0 >> o) * (H0 >> o) * kLev, 4);
     OSFM_REQUIRE(A.buf.alloc(ctx, need) == hipSuccess, OSFM_E_NOMEM, "osfm_hahog_extract: %zu bytes of device memory", need);
   }
@@ -1311,6 +1341,7 @@ static int hahog_extract_on_stream(osfm_ctx *ctx, hipStream_t st, const float *i
   F.key = A.take<unsigned long long>((size_t)F.cap);
   F.count = A.take<int>(4);
   double *d_tab = A.take<double>((size_t)kOrSide * kOrSide + 257);
+  DescTable *d_dtab = (DescTable *)A.take<float4>(sizeof(DescTable) / sizeof(float4) + 1);
   OSFM_REQUIRE(!A.overflow, OSFM_E_NOMEM, "osfm_hahog_extract: internal: slab A too small");
   OSFM_HIP(hipMemsetAsync(F.count, 0, 4 * sizeof(int), st));
   {
@@ -1411,8 +1442,9 @@ static int hahog_extract_on_stream(osfm_ctx *ctx, hipStream_t st, const float *i
   // hahog.cc:168-199: the descriptor's scale in patch pixels and the orientation pi / 2, with the host's libm
   const double patchStep = (double)kDExtent / kDRes;
   const double sigma_d = (double)kDExtent / (3.0 * (4 + 1) / 2) / patchStep;
-  hipLaunchKernelGGL(descriptor_kernel, dim3(n2), dim3(256), 0, st, py, R, n2, (const double *)(d_tab + (size_t)kOrSide * kOrSide), std::sin(kPi / 2),
-                     std::cos(kPi / 2), sigma_d, flags, d_points, d_desc);
+  hipLaunchKernelGGL(desc_table_kernel, dim3(1), dim3(256), 0, st, (const double *)(d_tab + (size_t)kOrSide * kOrSide), std::sin(kPi / 2), std::cos(kPi / 2),
+                     sigma_d, d_dtab);
+  hipLaunchKernelGGL(descriptor_kernel, dim3(n2), dim3(256), 0, st, py, R, n2, (const DescTable *)d_dtab, flags, d_points, d_desc);
   OSFM_HIP(hipGetLastError());
   OSFM_HIP(hipMemcpyAsync(points, d_points, (size_t)4 * n2 * sizeof(float), hipMemcpyDeviceToHost, st));
   OSFM_HIP(hipMemcpyAsync(desc, d_desc, (size_t)128 * n2 * sizeof(float), hipMemcpyDeviceToHost, st));
