@@ -17,6 +17,7 @@
 //
 // Kernels are plain HBM-bound stencils and per-feature workgroups (no matrix cores: there is no contraction here).
 #include <cmath>
+#include <cstddef>
 #include <cstring>
 #include <atomic>
 #include <exception>
@@ -482,30 +483,34 @@ struct PatchPlan {
   long x0i, y0i, padx0, pady0, padx1, pady1, pw, ph;
   double sigma_level;      // sigma_ of the level
 };
-// Run by all 64 lanes of the workgroup's first wave on identical arguments: the octave search (one log2 / pow pair per octave in the
-// reference's loop) is a lane per octave, lane 0 writes the plan; every lane returns sigma_ of the chosen level.
-__device__ double plan_patch(const Pyramid &py, double extent, double sigma, const double *A_, const double *T_, double d1, double d2, PatchPlan &P,
-                             int lane) {
-  const int first_octave = 0, last_octave = py.n_oct - 1;
+// One thread plans one patch (round 6: or_plan_kernel / desc_plan_kernel, a thread per feature, in front of the per-feature kernels.  The plan
+// used to be made inside them by the first wavefront of every workgroup -- sixty-four lanes on identical arguments, a lane per octave for the
+// search, three wavefronts waiting at the barrier: 8 and 14 us of a 47 / 52 us workgroup.)  The octave search is the reference's loop.
+__device__ double plan_patch(const Pyramid &py, double extent, double sigma, const double *A_, const double *T_, double d1, double d2, PatchPlan &P) {
+  const int last_octave = py.n_oct - 1;
   const double factor = 1.0 / (d1 < d2 ? d1 : d2);
-  long o, s;
-  double sigma_;
+  long o, s = 0;
+  double sigma_ = 0.0;
   {
-    // the loop `for (o = first + 1; o <= last; ++o) { s, sigma_ of o; if (factor * sigma_ > sigma) { o--; break; } }`, then o = min(o, last)
-    // and s, sigma_ of that o once more: all functions of o alone
-    const long ol = lane <= last_octave ? lane : last_octave;
-    long sl = vl_floor_d(log2(sigma / (factor * py.base_scale)) - ol);
-    sl = sl > kFirstSub ? sl : kFirstSub;
-    sl = sl < kLastSub ? sl : kLastSub;
-    const double sgl = py.base_scale * pow(2.0, ol + (double)sl / kRes);
-    const bool stop = lane >= first_octave + 1 && lane <= last_octave && factor * sgl > sigma;
-    const unsigned long long mask = __ballot(stop);
-    o = mask ? (long)__builtin_ctzll(mask) - 1 : (long)last_octave + 1;
+    // `for (o = first + 1; o <= last; ++o) { s, sigma_ of o; if (factor * sigma_ > sigma) { o--; break; } }`, then o = min(o, last) and s, sigma_
+    // of that o once more (covdet.c:2196-2216)
+    auto level_of = [&](long oo) {
+      long sl = vl_floor_d(log2(sigma / (factor * py.base_scale)) - oo);
+      sl = sl > kFirstSub ? sl : kFirstSub;
+      sl = sl < kLastSub ? sl : kLastSub;
+      s = sl;
+      sigma_ = py.base_scale * pow(2.0, oo + (double)sl / kRes);
+    };
+    for (o = 1; o <= last_octave; ++o) {
+      level_of(o);
+      if (factor * sigma_ > sigma) {
+        o--;
+        break;
+      }
+    }
     o = o < last_octave ? o : last_octave;
-    s = __shfl((int)sl, (int)o);
-    sigma_ = __shfl(sgl, (int)o);
+    level_of(o);
   }
-  if (lane != 0) return sigma_;
   P.sigma_level = sigma_;
   const Octave &oc = py.oct[o];
   P.level = oc.gss + (long)(s - kFirstSub) * oc.w * oc.h;
@@ -673,8 +678,51 @@ constexpr double kOrExtent = 9.0;  // VL_COVDET_AA_PATCH_EXTENT = 3 * VL_COVDET_
 struct Oriented {
   float *x, *y, *a11, *a21, *a12, *a22;  // capacity 4 x features
 };
-__global__ void __launch_bounds__(256) orientation_kernel(Pyramid py, const float *fx, const float *fy, const float *fsigma, int n,
-                                                          const double *aa_mask, int *n_or, double *or_angle /* n x 4 */) {
+struct OrPlan {  // what or_plan_kernel hands a workgroup of orientation_kernel
+  PatchPlan P;
+  float taps[16];  // the smoothing of the patch: W <= 7 (sd <= 1 / stephat)
+  int W, pad;
+};
+// a thread per selected feature: its position and scale gathered from the detections, the patch plan, the taps of vl_imsmooth_f
+__global__ void __launch_bounds__(64) or_plan_kernel(Pyramid py, const int *order, const float *Fx, const float *Fy, const float *Fsigma, int n, float *fx,
+                                                     float *fy, float *fsigma, OrPlan *plans) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n) return;
+  const int src = order[f];
+  const float x = Fx[src], y = Fy[src], sgf = Fsigma[src];
+  fx[f] = x;
+  fy[f] = y;
+  fsigma[f] = sgf;
+  OrPlan L;
+  // the detector's frames are isotropic: A = sigma I, so vl_svd2 returns D = (sigma, sigma), U = V = I and theta0 = atan2(0, 1) = 0
+  const double sg = sgf;
+  const double A[4] = {sg, 0.0, 0.0, sg}, T[2] = {x, y};
+  const double sigma_level = plan_patch(py, kOrExtent, 1.0, A, T, sg, sg, L.P);
+  const double sigma1 = sigma_level / sg;
+  // vl_imsmooth_f(patch, deltaSigma1 / stephat, deltaSigma2 / stephat): one filter, both directions (sigma1 = sigma2)
+  const double t = 1.0 - sigma1 * sigma1;
+  const double delta = sqrt(t > 0 ? t : 0), stephat = kOrExtent / kOrRes;
+  const double sd = delta / stephat;
+  const int W = (int)ceil(sd * 3.0);
+  double g[8];
+  float mass = (float)1.0;
+  for (int i = 1; i <= W && i < 8; i++) {
+    const double xx = (double)i / sd;
+    g[i] = exp(-0.5 * xx * xx);
+    mass += g[i] + g[i];
+  }
+  for (int i = 0; i < 16; i++) L.taps[i] = 0.f;
+  L.taps[W] = 1.0f / mass;
+  for (int i = 1; i <= W && i < 8; i++) {
+    L.taps[W - i] = (float)g[i] / mass;
+    L.taps[W + i] = (float)g[i] / mass;
+  }
+  L.W = W;
+  L.pad = 0;
+  plans[f] = L;
+}
+__global__ void __launch_bounds__(256) orientation_kernel(Pyramid py, const OrPlan *plans, int n, const double *aa_mask, int *n_or,
+                                                          double *or_angle /* n x 4 */) {
   // 37 KB: four workgroups per CU.  The patch lives in the space of the per-pixel records (the gradient of every pixel is taken into
   // registers first, then the patch is dead and the records are written); the bins are bytes
   __shared__ double2 hc[kOrSide * kOrSide];  // what the pixel adds to its bin and to the next one
@@ -689,36 +737,12 @@ __global__ void __launch_bounds__(256) orientation_kernel(Pyramid py, const floa
   const int f = blockIdx.x, tid = threadIdx.x;
   if (f >= n) return;
   HTICK(h0)
-  if (tid < 64) {  // wave 0
-    // the detector's frames are isotropic: A = sigma I, so vl_svd2 returns D = (sigma, sigma), U = V = I and theta0 = atan2(0, 1) = 0
-    const double sg = fsigma[f];
-    const double A[4] = {sg, 0.0, 0.0, sg}, T[2] = {fx[f], fy[f]};
-    const double sigma_level = plan_patch(py, kOrExtent, 1.0, A, T, sg, sg, P, tid);
-    const double sigma1 = sigma_level / sg;
-    // vl_imsmooth_f(patch, deltaSigma1 / stephat, deltaSigma2 / stephat): one filter, both directions (sigma1 = sigma2)
-    const double t = 1.0 - sigma1 * sigma1;
-    const double delta = sqrt(t > 0 ? t : 0), stephat = kOrExtent / kOrRes;
-    const double sd = delta / stephat;
-    const int W = (int)ceil(sd * 3.0);
-    // a lane per tap for the exponentials, lane 0 for the mass (its float accumulation order) -- W <= 7: sd <= 1 / stephat
-    double g = 0.0;
-    if (tid >= 1 && tid <= W) {
-      const double xx = (double)tid / sd;
-      g = exp(-0.5 * xx * xx);
-    }
-    float mass = (float)1.0;
-    for (int i = 1; i <= W; i++) {
-      const double gi = __shfl(g, i);
-      mass += gi + gi;
-    }
-    if (tid == 0) {
-      W1 = W;
-      taps1[W] = 1.0f / mass;
-    }
-    if (tid >= 1 && tid <= W) {
-      taps1[W - tid] = (float)g / mass;
-      taps1[W + tid] = (float)g / mass;
-    }
+  static_assert(sizeof(OrPlan) % 4 == 0 && offsetof(OrPlan, taps) == sizeof(PatchPlan) && sizeof(PatchPlan) % 4 == 0, "layout of OrPlan");
+  if (tid < 64) {  // wave 0: the plan or_plan_kernel made
+    const int *src = reinterpret_cast<const int *>(plans + f);
+    for (int q = tid; q < (int)(sizeof(PatchPlan) / 4); q += 64) reinterpret_cast<int *>(&P)[q] = src[q];
+    if (tid < 16) taps1[tid] = plans[f].taps[tid];
+    if (tid == 0) W1 = plans[f].W;
   }
   else if (tid < 128)  // wave 1, beside wave 0's plan
     patch_hat_table(hat, kOrRes, kOrExtent, tid - 64);
@@ -1021,7 +1045,28 @@ __global__ void __launch_bounds__(256) desc_table_kernel(const double *expn_tab,
     tab->colmask[tid] = colmask;
   }
 }
-__global__ void __launch_bounds__(256) descriptor_kernel(Pyramid py, Oriented R, int n, const DescTable *tab, int flags, float *points, float *desc) {
+// a thread per oriented feature: the keypoint row (hahog.cc:188-196) and the plan of its 31 x 31 patch
+__global__ void __launch_bounds__(64) desc_plan_kernel(Pyramid py, Oriented R, int n, float *points, PatchPlan *plans) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n) return;
+  const float a11 = R.a11[f], a21 = R.a21[f], a12 = R.a12[f], a22 = R.a22[f];
+  {
+    const float det = a11 * a22 - a12 * a21;
+    const float size = sqrtf(fabsf(det));
+    const float angle = (float)(atan2f(a21, a11) * 180.0f / M_PI);
+    points[4 * (long)f + 0] = R.x[f];
+    points[4 * (long)f + 1] = R.y[f];
+    points[4 * (long)f + 2] = size;
+    points[4 * (long)f + 3] = angle;
+  }
+  const double A[4] = {a11, a21, a12, a22}, T[2] = {R.x[f], R.y[f]};
+  double d1, d2;
+  svd2_values(A, &d1, &d2);
+  PatchPlan L;
+  plan_patch(py, kDExtent, 1.0, A, T, d1, d2, L);
+  plans[f] = L;
+}
+__global__ void __launch_bounds__(256) descriptor_kernel(const PatchPlan *plans, int n, const DescTable *tab, int flags, float *desc) {
   __shared__ float patch[kDSide * kDSide];
   __shared__ float4 sval[kDSide * kDSide];  // window x modulus and the three fractions of the pixel
   __shared__ int scode[kDSide * kDSide];    // its lower bins: (binx + 128) | (biny + 128) << 8 | bint << 16
@@ -1033,22 +1078,7 @@ __global__ void __launch_bounds__(256) descriptor_kernel(Pyramid py, Oriented R,
   if (f >= n) return;
   if (tid >= 128 && tid < 192) patch_hat_table(hat, kDRes, kDExtent, tid - 128);  // wave 2, beside wave 0's plan
   HTICK(h0)
-  if (tid < 64) {  // wave 0
-    const float a11 = R.a11[f], a21 = R.a21[f], a12 = R.a12[f], a22 = R.a22[f];
-    if (tid == 0) {
-      const float det = a11 * a22 - a12 * a21;
-      const float size = sqrtf(fabsf(det));
-      const float angle = (float)(atan2f(a21, a11) * 180.0f / M_PI);
-      points[4 * (long)f + 0] = R.x[f];
-      points[4 * (long)f + 1] = R.y[f];
-      points[4 * (long)f + 2] = size;
-      points[4 * (long)f + 3] = angle;
-    }
-    const double A[4] = {a11, a21, a12, a22}, T[2] = {R.x[f], R.y[f]};
-    double d1, d2;
-    svd2_values(A, &d1, &d2);
-    plan_patch(py, kDExtent, 1.0, A, T, d1, d2, P, tid);
-  }
+  if (tid < (int)(sizeof(PatchPlan) / 4)) reinterpret_cast<int *>(&P)[tid] = reinterpret_cast<const int *>(plans + f)[tid];  // desc_plan_kernel's
   __syncthreads();
   HTICK(h1)
   sample_patch<(kDSide * kDSide + 255) / 256, 2>(P, hat, patch, kDRes, tid, 256);
@@ -1380,7 +1410,8 @@ static int hahog_extract_on_stream(osfm_ctx *ctx, hipStream_t st, const float *i
   {
     const size_t need = 4 * padded((size_t)n0, 4) + padded((size_t)n0, 8) + 2 * padded((size_t)n0, 4) + padded(std::max(tb1, tb2) + 256, 1) +
                         3 * padded((size_t)n1max, 4) + padded((size_t)n1max, 4) + padded((size_t)n1max + 1, 4) + padded((size_t)n1max * kMaxOr, 8) +
-                        6 * padded((size_t)n2max, 4) + padded((size_t)4 * n2max, 4) + padded((size_t)128 * n2max, 4);
+                        6 * padded((size_t)n2max, 4) + padded((size_t)4 * n2max, 4) + padded((size_t)128 * n2max, 4) + padded((size_t)n1max * sizeof(OrPlan), 1) +
+                        padded((size_t)n2max * sizeof(PatchPlan), 1);
     // sizes rounded up so that images of one series reuse the cached block
     OSFM_REQUIRE(B.buf.alloc(ctx, (need + ((size_t)1 << 20)) >> 20 << 20) == hipSuccess, OSFM_E_NOMEM, "osfm_hahog_extract: %zu bytes of device memory", need);
   }
@@ -1404,6 +1435,7 @@ static int hahog_extract_on_stream(osfm_ctx *ctx, hipStream_t st, const float *i
   float *sx = B.take<float>((size_t)n1), *sy = B.take<float>((size_t)n1), *ssg = B.take<float>((size_t)n1);
   int *d_nor = B.take<int>((size_t)n1), *d_off = B.take<int>((size_t)n1 + 1);
   double *d_ang = B.take<double>((size_t)n1 * kMaxOr);
+  OrPlan *d_orplan = (OrPlan *)B.take<double>((size_t)n1 * (sizeof(OrPlan) / 8));
   // tables from the host's libm: the orientation mask (covdet.c:1536-1548) and fast_expn's (sift.c:714-720)
   std::vector<double> h_tab((size_t)kOrSide * kOrSide + 257);
   {
@@ -1419,11 +1451,9 @@ static int hahog_extract_on_stream(osfm_ctx *ctx, hipStream_t st, const float *i
   OSFM_REQUIRE(!B.overflow, OSFM_E_NOMEM, "osfm_hahog_extract: internal: slab B too small");
   OSFM_HIP(hipMemcpyAsync(d_tab, h_tab.data(), h_tab.size() * sizeof(double), hipMemcpyHostToDevice, st));
   const int nblk1 = (n1 + 255) / 256;
-  hipLaunchKernelGGL(gather_f_kernel, dim3(nblk1), dim3(256), 0, st, d_order, (const float *)F.x, sx, n1);
-  hipLaunchKernelGGL(gather_f_kernel, dim3(nblk1), dim3(256), 0, st, d_order, (const float *)F.y, sy, n1);
-  hipLaunchKernelGGL(gather_f_kernel, dim3(nblk1), dim3(256), 0, st, d_order, (const float *)F.sigma, ssg, n1);
-  hipLaunchKernelGGL(orientation_kernel, dim3(n1), dim3(256), 0, st, py, (const float *)sx, (const float *)sy, (const float *)ssg, n1,
-                     (const double *)d_tab, d_nor, d_ang);
+  hipLaunchKernelGGL(or_plan_kernel, dim3((unsigned)((n1 + 63) / 64)), dim3(64), 0, st, py, d_order, (const float *)F.x, (const float *)F.y,
+                     (const float *)F.sigma, n1, sx, sy, ssg, d_orplan);
+  hipLaunchKernelGGL(orientation_kernel, dim3(n1), dim3(256), 0, st, py, (const OrPlan *)d_orplan, n1, (const double *)d_tab, d_nor, d_ang);
   hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, (const int *)d_nor, n1, d_off);
   int n2 = 0;
   OSFM_HIP(hipMemcpyAsync(&n2, d_off + n1, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1436,6 +1466,7 @@ static int hahog_extract_on_stream(osfm_ctx *ctx, hipStream_t st, const float *i
   R.x = B.take<float>((size_t)n2); R.y = B.take<float>((size_t)n2);
   R.a11 = B.take<float>((size_t)n2); R.a21 = B.take<float>((size_t)n2); R.a12 = B.take<float>((size_t)n2); R.a22 = B.take<float>((size_t)n2);
   float *d_points = B.take<float>((size_t)4 * n2), *d_desc = B.take<float>((size_t)128 * n2);
+  PatchPlan *d_dplan = (PatchPlan *)B.take<double>((size_t)n2 * (sizeof(PatchPlan) / 8));
   OSFM_REQUIRE(!B.overflow, OSFM_E_NOMEM, "osfm_hahog_extract: internal: slab B too small");
   hipLaunchKernelGGL(orient_frames_kernel, dim3(nblk1), dim3(256), 0, st, (const float *)sx, (const float *)sy, (const float *)ssg, (const int *)d_off,
                      (const int *)d_nor, (const double *)d_ang, n1, R);
@@ -1444,7 +1475,8 @@ static int hahog_extract_on_stream(osfm_ctx *ctx, hipStream_t st, const float *i
   const double sigma_d = (double)kDExtent / (3.0 * (4 + 1) / 2) / patchStep;
   hipLaunchKernelGGL(desc_table_kernel, dim3(1), dim3(256), 0, st, (const double *)(d_tab + (size_t)kOrSide * kOrSide), std::sin(kPi / 2), std::cos(kPi / 2),
                      sigma_d, d_dtab);
-  hipLaunchKernelGGL(descriptor_kernel, dim3(n2), dim3(256), 0, st, py, R, n2, (const DescTable *)d_dtab, flags, d_points, d_desc);
+  hipLaunchKernelGGL(desc_plan_kernel, dim3((unsigned)((n2 + 63) / 64)), dim3(64), 0, st, py, R, n2, d_points, d_dplan);
+  hipLaunchKernelGGL(descriptor_kernel, dim3(n2), dim3(256), 0, st, (const PatchPlan *)d_dplan, n2, (const DescTable *)d_dtab, flags, d_desc);
   OSFM_HIP(hipGetLastError());
   OSFM_HIP(hipMemcpyAsync(points, d_points, (size_t)4 * n2 * sizeof(float), hipMemcpyDeviceToHost, st));
   OSFM_HIP(hipMemcpyAsync(desc, d_desc, (size_t)128 * n2 * sizeof(float), hipMemcpyDeviceToHost, st));
