@@ -74,6 +74,21 @@ def test_matches_the_compiled_reference(oracle_lib, gpu_ctx, rows, cols, target,
     _compare(pts, desc, *ref)
 
 
+@pytest.mark.parametrize("rows,cols,seed", [(75, 64, 11), (76, 65, 12), (90, 250, 13), (91, 251, 14), (83, 311, 15), (26, 498, 16), (19, 17, 17)])
+def test_extremum_search_tile_borders(oracle_lib, gpu_ctx, rows, cols, seed):
+    """round 6: the extremum search tiles an octave by 62 columns per wavefront (lanes 0 and 63 carry the columns beside them), 248 per
+    workgroup and 8 rows: interiors of exactly 62, 63, 248, 249 columns, a second workgroup of one column, heights of 8 k + 1 ... rows, the
+    smallest image that has an octave -- every detection of the reference, nothing else, and the keypoints / descriptors that follow from them"""
+    rng = np.random.default_rng(seed)
+    im = _texture(rows, cols, seed)
+    im = np.ascontiguousarray(np.clip(im + 0.2 * rng.standard_normal((rows, cols)).astype(np.float32), 0, 1), np.float32)  # extrema everywhere
+    ref = oracle_lib.hahog_ref(im, 1e-5, 10.0, 100000)
+    if ref is None:
+        pytest.skip("oracle/_ref/libhahog_ref.so is not available (it is built where /root/reference is mounted)")
+    pts, desc = features.hahog(im, 1e-5, 10.0, 100000)
+    _compare(pts, desc, *ref)
+
+
 def test_thresholds_and_empty_results(oracle_lib, gpu_ctx):
     im = _texture(200, 300, 9)
     for peak, edge, target in ((1e-3, 10.0, 500), (1e-5, 2.0, 500), (10.0, 10.0, 500), (1e-5, 10.0, 0)):
