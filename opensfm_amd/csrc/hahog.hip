@@ -678,6 +678,37 @@ constexpr double kOrExtent = 9.0;  // VL_COVDET_AA_PATCH_EXTENT = 3 * VL_COVDET_
 struct Oriented {
   float *x, *y, *a11, *a21, *a12, *a22;  // capacity 4 x features
 };
+// vl_imsmooth_f on the 41 x 41 patch in LDS (imopv.c: columns, then rows, padding by continuity), W taps on either side
+template <int W>
+__device__ __forceinline__ void or_smooth(float *patch, float *tmp, const float *taps1, int tid) {
+  float tp[2 * W + 1];
+#pragma unroll
+  for (int j = 0; j <= 2 * W; j++) tp[j] = taps1[2 * W - j];
+  for (int t = tid; t < kOrSide * kOrSide; t += 256) {  // along y
+    const int y = t / kOrSide, x = t - y * kOrSide;
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j <= 2 * W; j++) {
+      int p = y - W + j;
+      p = p < 0 ? 0 : (p > kOrSide - 1 ? kOrSide - 1 : p);
+      acc = acc + patch[p * kOrSide + x] * tp[j];
+    }
+    tmp[t] = acc;
+  }
+  __syncthreads();
+  for (int t = tid; t < kOrSide * kOrSide; t += 256) {  // along x
+    const int y = t / kOrSide, x = t - y * kOrSide;
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j <= 2 * W; j++) {
+      int p = x - W + j;
+      p = p < 0 ? 0 : (p > kOrSide - 1 ? kOrSide - 1 : p);
+      acc = acc + tmp[y * kOrSide + p] * tp[j];
+    }
+    patch[t] = acc;
+  }
+  __syncthreads();
+}
 struct OrPlan {  // what or_plan_kernel hands a workgroup of orientation_kernel
   PatchPlan P;
   float taps[16];  // the smoothing of the patch: W <= 7 (sd <= 1 / stephat)
@@ -756,29 +787,16 @@ __global__ void __launch_bounds__(256) orientation_kernel(Pyramid py, const OrPl
   sample_patch<(kOrSide * kOrSide + 255) / 256, 4>(P, hat, patch, kOrRes, tid, 256);
   __syncthreads();
   HTICK(h2)
-  const int W = W1;
-  for (int t = tid; t < kOrSide * kOrSide; t += 256) {  // along y
-    const int y = t / kOrSide, x = t - y * kOrSide;
-    float acc = 0.f;
-    for (int j = 0; j <= 2 * W; j++) {
-      int p = y - W + j;
-      p = p < 0 ? 0 : (p > kOrSide - 1 ? kOrSide - 1 : p);
-      acc = acc + patch[p * kOrSide + x] * taps1[2 * W - j];
-    }
-    tmp[t] = acc;
+  switch (W1) {  // (uniform over the workgroup; W <= 7.  Round 6: the taps in registers, the tap loops unrolled -- the same sums in the same order)
+    case 0: or_smooth<0>(patch, tmp, taps1, tid); break;
+    case 1: or_smooth<1>(patch, tmp, taps1, tid); break;
+    case 2: or_smooth<2>(patch, tmp, taps1, tid); break;
+    case 3: or_smooth<3>(patch, tmp, taps1, tid); break;
+    case 4: or_smooth<4>(patch, tmp, taps1, tid); break;
+    case 5: or_smooth<5>(patch, tmp, taps1, tid); break;
+    case 6: or_smooth<6>(patch, tmp, taps1, tid); break;
+    default: or_smooth<7>(patch, tmp, taps1, tid); break;
   }
-  __syncthreads();
-  for (int t = tid; t < kOrSide * kOrSide; t += 256) {  // along x
-    const int y = t / kOrSide, x = t - y * kOrSide;
-    float acc = 0.f;
-    for (int j = 0; j <= 2 * W; j++) {
-      int p = x - W + j;
-      p = p < 0 ? 0 : (p > kOrSide - 1 ? kOrSide - 1 : p);
-      acc = acc + tmp[y * kOrSide + p] * taps1[2 * W - j];
-    }
-    patch[t] = acc;
-  }
-  __syncthreads();
   HTICK(h3)
   // per pixel, in parallel: the bin and the two products the sequential loop adds (covdet.c:2769-2781)
   const double binExtent = 2 * kPi / kOrBins;
@@ -798,11 +816,12 @@ __global__ void __launch_bounds__(256) orientation_kernel(Pyramid py, const OrPl
     const float fm = gm[u], fa = ga[u];
     const double modulus = fm, angle = fa, weight = aa_mask[t];
     const double xx = angle / binExtent;
-    const long bin = vl_floor_d(xx);
-    const double w2 = xx - bin, w1 = 1.0 - w2;
-    hbin[t] = (unsigned char)((bin + kOrBins) % kOrBins);
+    const double fb = floor(xx);  // vl_floor_d: 0 <= angle <= 2 pi, the same integer without the double -> int64 -> double round trip ...
+    const int bin = ((int)fb + kOrBins) % kOrBins;  // ... and a 32-bit remainder instead of two 64-bit ones (round 6)
+    const double w2 = xx - fb, w1 = 1.0 - w2;
+    hbin[t] = (unsigned char)bin;
     hc[t] = make_double2(w1 * (modulus * weight), w2 * (modulus * weight));
-    atomicAdd(&tot[(int)((bin + kOrBins) % kOrBins)], 1);
+    atomicAdd(&tot[bin], 1);
   }
   __syncthreads();
   HTICK(h4)
