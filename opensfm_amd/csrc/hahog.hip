@@ -764,7 +764,9 @@ __global__ void __launch_bounds__(256) orientation_kernel(Pyramid py, const OrPl
   __shared__ int W1;
   __shared__ PatchPlan P;
   __shared__ double hist[kOrBins], hist2[kOrBins], hat[kOrSide];
-  __shared__ int tot[kOrBins], start[kOrBins + 1], run[kOrBins], cw[4][kOrBins];
+  constexpr int kOrChunks = (kOrSide * kOrSide + 255) / 256;
+  __shared__ int start[kOrBins + 1];
+  __shared__ unsigned short cwa[kOrChunks][4][kOrBins];  // pixels of (chunk, wavefront) in a bin, then their exclusive prefix
   const int f = blockIdx.x, tid = threadIdx.x;
   if (f >= n) return;
   HTICK(h0)
@@ -777,11 +779,7 @@ __global__ void __launch_bounds__(256) orientation_kernel(Pyramid py, const OrPl
   }
   else if (tid < 128)  // wave 1, beside wave 0's plan
     patch_hat_table(hat, kOrRes, kOrExtent, tid - 64);
-  if (tid < kOrBins) {
-    hist[tid] = 0.0;
-    tot[tid] = 0;
-    run[tid] = 0;
-  }
+  if (tid < kOrBins) hist[tid] = 0.0;
   __syncthreads();
   HTICK(h1)
   sample_patch<(kOrSide * kOrSide + 255) / 256, 4>(P, hat, patch, kOrRes, tid, 256);
@@ -821,7 +819,6 @@ __global__ void __launch_bounds__(256) orientation_kernel(Pyramid py, const OrPl
     const double w2 = xx - fb, w1 = 1.0 - w2;
     hbin[t] = (unsigned char)bin;
     hc[t] = make_double2(w1 * (modulus * weight), w2 * (modulus * weight));
-    atomicAdd(&tot[bin], 1);
   }
   __syncthreads();
   HTICK(h4)
@@ -830,56 +827,79 @@ __global__ void __launch_bounds__(256) orientation_kernel(Pyramid py, const OrPl
   // sort, so a lane walks only its own ~93 records, in the reference's order.  (Scanning all pixels per bin, even branch-free, was a
   // 190-cycle dependent step 1 681 times: 148 of the kernel's 187 us per workgroup, profiles/r03_hahog_phases_before_sort.txt.)
   // Rank of a record inside its bin = number of earlier pixels whose hbin is the bin (their first records) or the bin before it (their
-  // second records): per chunk of 256 pixels a ballot per bin value, per-wave counts through LDS, a running count over the chunks.
+  // second records).
   unsigned short *order = reinterpret_cast<unsigned short *>(tmp);  // 2 x 1 681 record ids: exactly the smoothing buffer, free by now
-  if (tid == 0) {
-    int acc = 0;
-    for (int v = 0; v < kOrBins; v++) {
-      start[v] = acc;
-      acc += tot[v] + tot[(v + kOrBins - 1) % kOrBins];
-    }
-    start[kOrBins] = acc;
-  }
+  // Round 6: three barriers instead of twenty-one.  Pass 1 (no barrier): every chunk's ranks inside the wavefront and the wavefront's count per bin
+  // (the lanes holding a bin value come from SIX ballots, one per bit of the bin index: mask(t) = valid & AND_k (bit k of t ? B_k : ~B_k); a lane
+  // needs four such masks -- its bin, the bins beside it and, as the counter of bin `lane`, the bin whose number it carries).  Then wave 0: lane b
+  // turns bin b's 7 x 4 counts into their exclusive prefix (chunk-major, wave-minor: the raster order), the totals give start[] by a scan over
+  // the lanes.  Pass 2: the records go to their places.  (Until round 6: a running count per bin carried from chunk to chunk between barriers, the
+  // totals from 1 681 LDS atomics, start[] by one thread.)  The same ranks.
+  unsigned pk[kOrChunks];
   {
     const int lane = tid & 63, w = tid >> 6;
-    for (int c0 = 0; c0 < kOrSide * kOrSide; c0 += 256) {
-      const int t = c0 + tid;
+#pragma unroll
+    for (int ci = 0; ci < kOrChunks; ci++) {
+      const int t = ci * 256 + tid;
       const bool valid = t < kOrSide * kOrSide;
       const int b = valid ? hbin[t] : -1;
       const int bm1 = valid ? (b + kOrBins - 1) % kOrBins : -1, bp1 = valid ? (b + 1) % kOrBins : -1;
-      // Round 6: the lanes holding a given bin value from SIX ballots (one per bit of the bin index) instead of one ballot per bin value:
-      // mask(t) = valid & AND_k (bit k of t ? B_k : ~B_k).  A lane needs four such masks (its bin, the bins beside it, and -- as the
-      // counter of bin `lane` -- the bin whose number it carries): ~120 instructions per chunk of 256 pixels against ~500 for the 36 ballots
-      // with their selects, seven chunks per workgroup.  The same counts.
       unsigned long long Bk[6];
 #pragma unroll
       for (int k = 0; k < 6; k++) Bk[k] = __ballot(valid && ((b >> k) & 1));
       const unsigned long long Vm = __ballot(valid), below = (1ull << lane) - 1ull;
-      auto lanes_with = [&](int t) {
+      auto lanes_with = [&](int tv) {
         unsigned long long m = Vm;
 #pragma unroll
-        for (int k = 0; k < 6; k++) m &= ((t >> k) & 1) ? Bk[k] : ~Bk[k];
+        for (int k = 0; k < 6; k++) m &= ((tv >> k) & 1) ? Bk[k] : ~Bk[k];
         return m;
       };
       const int p_0 = __popcll(lanes_with(b) & below), p_m1 = __popcll(lanes_with(bm1) & below), p_p1 = __popcll(lanes_with(bp1) & below);
-      const int mycnt = __popcll(lanes_with(lane));
-      if (lane < kOrBins) cw[w][lane] = mycnt;
-      __syncthreads();  // cw of this chunk, start[] (first chunk), run[] of the previous chunk
-      if (valid) {
-        int e_m1 = run[bm1] + p_m1, e_0 = run[b] + p_0, e_p1 = run[bp1] + p_p1;
-        for (int w2 = 0; w2 < w; w2++) {
-          e_m1 += cw[w2][bm1];
-          e_0 += cw[w2][b];
-          e_p1 += cw[w2][bp1];
-        }
+      pk[ci] = (unsigned)p_0 | ((unsigned)p_m1 << 8) | ((unsigned)p_p1 << 16);
+      if (lane < kOrBins) cwa[ci][w][lane] = (unsigned short)__popcll(lanes_with(lane));
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {  // wave 0
+    int totb = 0;
+    if (tid < kOrBins) {
+      unsigned short *cell = &cwa[0][0][0] + tid;
+      int v[kOrChunks * 4];
+#pragma unroll
+      for (int q = 0; q < kOrChunks * 4; q++) v[q] = cell[q * kOrBins];
+#pragma unroll
+      for (int q = 0; q < kOrChunks * 4; q++) {
+        cell[q * kOrBins] = (unsigned short)totb;
+        totb += v[q];
+      }
+    }
+    const int prev = __shfl(totb, (tid + kOrBins - 1) % kOrBins);
+    const int cnt = tid < kOrBins ? totb + prev : 0;  // records of bin b: its pixels' first products and the second products of the bin before it
+    int inc = cnt;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+      const int o = __shfl_up(inc, m);
+      if (tid >= m) inc += o;
+    }
+    if (tid < kOrBins) start[tid] = inc - cnt;
+    if (tid == kOrBins - 1) start[kOrBins] = inc;
+  }
+  __syncthreads();
+  {
+    const int w = tid >> 6;
+#pragma unroll
+    for (int ci = 0; ci < kOrChunks; ci++) {
+      const int t = ci * 256 + tid;
+      if (t < kOrSide * kOrSide) {
+        const int b = hbin[t], bm1 = (b + kOrBins - 1) % kOrBins, bp1 = (b + 1) % kOrBins;
+        const int e_0 = cwa[ci][w][b] + (int)(pk[ci] & 255u), e_m1 = cwa[ci][w][bm1] + (int)((pk[ci] >> 8) & 255u),
+                  e_p1 = cwa[ci][w][bp1] + (int)((pk[ci] >> 16) & 255u);
         order[start[b] + e_0 + e_m1] = (unsigned short)(2 * t);
         order[start[bp1] + e_p1 + e_0] = (unsigned short)(2 * t + 1);
       }
-      __syncthreads();
-      if (tid < kOrBins) run[tid] += cw[0][tid] + cw[1][tid] + cw[2][tid] + cw[3][tid];
-      __syncthreads();
     }
   }
+  __syncthreads();
   if (tid < kOrBins) {
     const double *rec = reinterpret_cast<const double *>(hc);
     const int k1 = start[tid + 1];
