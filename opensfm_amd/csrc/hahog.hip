@@ -1164,9 +1164,11 @@ __global__ void __launch_bounds__(256) descriptor_kernel(const PatchPlan *plans,
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-          const int dbinx = bx - ((code[u] & 255) - 128), dbiny = by - (((code[u] >> 8) & 255) - 128), sb = code[u] >> 16;
+          const int dbinx = bx - ((code[u] & 255) - 128), dbiny = by - (((code[u] >> 8) & 255) - 128);
+          const unsigned sb = (unsigned)code[u] >> 16;  // 0 .. 8: the remainders below are masks (round 6; signed remainders cost eight instructions a pixel)
           const bool in = on[u] && !(dbinx < 0 || dbinx > 1 || dbiny < 0 || dbiny > 1);
-          const int b0 = sb % kNBO, b1 = (sb + 1) % kNBO;
+          const int b0 = (int)(sb & (kNBO - 1)), b1 = (int)((sb + 1) & (kNBO - 1));
+          static_assert((kNBO & (kNBO - 1)) == 0, "kNBO is a power of two");
           const float wm = pv[u].x, rx = pv[u].y, ry = pv[u].z, rt = pv[u].w;
           const float v0 = wm * fabsf(1 - dbinx - rx) * fabsf(1 - dbiny - ry) * fabsf(1 - 0 - rt);
           const float v1 = wm * fabsf(1 - dbinx - rx) * fabsf(1 - dbiny - ry) * fabsf(1 - 1 - rt);
