@@ -54,6 +54,7 @@ extern "C" void osfm_ctx_destroy(osfm_ctx *c) {
   for (hipStream_t a : c->aux_streams) (void)hipStreamDestroy(a);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
+  if (c->d_hahog_tables) (void)hipFree(c->d_hahog_tables);
   for (int i = 0; i < 2; ++i)
     if (c->ev_side[i]) (void)hipEventDestroy(c->ev_side[i]);
   for (int i = 0; i < 2; ++i)

@@ -1271,6 +1271,46 @@ extern "C" int osfm_dbg_hahog_phases(unsigned long long *out, int reset) {
   return 0;
 }
 #endif
+// The tables that do not depend on the image (round 6: once per context, not once per image -- 1 938 libm exponentials on the host, a pageable
+// upload and the table kernel were ~40 us of every call): the orientation mask (covdet.c:1536-1548) and fast_expn's table (sift.c:714-720) from the
+// host's libm, then the descriptor's per-pixel table by desc_table_kernel.  Made under the context's hahog_mu and complete when this returns.
+static int hahog_tables(osfm_ctx *ctx, hipStream_t st, double **d_tab, DescTable **d_dtab) {
+  constexpr size_t n_tab = (size_t)kOrSide * kOrSide + 257, tab_bytes = (n_tab * sizeof(double) + 255) / 256 * 256;
+  std::lock_guard<std::mutex> g(ctx->hahog_mu);
+  if (!ctx->d_hahog_tables) {
+    void *p = nullptr;
+    OSFM_REQUIRE(osfm_malloc_retry(ctx, &p, tab_bytes + sizeof(DescTable)) == hipSuccess, OSFM_E_NOMEM, "osfm_hahog_extract: device memory for the tables");
+    std::vector<double> h_tab(n_tab);
+    {
+      const int w = kOrRes;
+      const double step = (2.0 * kOrExtent) / (2 * w + 1), sigma = 3;
+      for (int j = -w; j <= w; ++j)
+        for (int i = -w; i <= w; ++i) {
+          const double dx = i * step / sigma, dy = j * step / sigma;
+          h_tab[(size_t)((i + w) + (2 * w + 1) * (j + w))] = (double)(float)std::exp(-0.5 * (dx * dx + dy * dy));  // `float aaMask[]` (covdet.c:1471)
+        }
+      for (int k = 0; k < 257; ++k) h_tab[(size_t)kOrSide * kOrSide + k] = std::exp(-(double)k * (25.0 / 256));
+    }
+    const double patchStep = (double)kDExtent / kDRes;
+    const double sigma_d = (double)kDExtent / (3.0 * (4 + 1) / 2) / patchStep;
+    hipError_t e = hipMemcpyAsync(p, h_tab.data(), n_tab * sizeof(double), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(desc_table_kernel, dim3(1), dim3(256), 0, st, (const double *)p + (size_t)kOrSide * kOrSide, std::sin(kPi / 2), std::cos(kPi / 2), sigma_d,
+                         (DescTable *)((char *)p + tab_bytes));
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+      (void)hipFree(p);
+      osfm_set_error("osfm_hahog_extract: the constant tables: %s", hipGetErrorString(e));
+      return OSFM_E_HIP;
+    }
+    ctx->d_hahog_tables = p;
+  }
+  *d_tab = (double *)ctx->d_hahog_tables;
+  *d_dtab = (DescTable *)((char *)ctx->d_hahog_tables + tab_bytes);
+  return OSFM_OK;
+}
 // one image on one stream (the caller holds the context lock; the block cache has its own)
 static int hahog_extract_on_stream(osfm_ctx *ctx, hipStream_t st, const float *image, int rows, int cols, float peak_threshold, float edge_threshold,
                                    int target_num_features, int flags, float *points, float *desc, int capacity, int *n_features) {
@@ -1292,7 +1332,7 @@ static int hahog_extract_on_stream(osfm_ctx *ctx, hipStream_t st, const float *i
   constexpr int kFeatureCap = 1 << 20;
   {
     size_t need = padded((size_t)W0 * H0, 4) + padded((size_t)W0 * H0, 1) + padded((size_t)kMaxTaps * (kLev + 1) * kMaxOct, 4) + 5 * padded(kFeatureCap, 4) + 2 * padded(kFeatureCap, 4) +
-                  padded(kFeatureCap, 8) + padded(4, 4) + padded((size_t)kOrSide * kOrSide + 257, 8) + padded(sizeof(DescTable) + 16, 1);
+                  padded(kFeatureCap, 8) + padded(4, 4);
     for (int o = 0; o <= last_octave; o++) need += 2 * padded((size_t)(W0 >> o) * (H0 >> o) * kLev, 4);
     OSFM_REQUIRE(A.buf.alloc(ctx, need) == hipSuccess, OSFM_E_NOMEM, "osfm_hahog_extract: %zu bytes of device memory", need);
   }
@@ -1411,8 +1451,12 @@ static int hahog_extract_on_stream(osfm_ctx *ctx, hipStream_t st, const float *i
   F.o = A.take<int>((size_t)F.cap); F.s = A.take<int>((size_t)F.cap);
   F.key = A.take<unsigned long long>((size_t)F.cap);
   F.count = A.take<int>(4);
-  double *d_tab = A.take<double>((size_t)kOrSide * kOrSide + 257);
-  DescTable *d_dtab = (DescTable *)A.take<float4>(sizeof(DescTable) / sizeof(float4) + 1);
+  double *d_tab = nullptr;  // the constant tables of the context (hahog_tables)
+  DescTable *d_dtab = nullptr;
+  {
+    const int rct = hahog_tables(ctx, st, &d_tab, &d_dtab);
+    if (rct != OSFM_OK) return rct;
+  }
   OSFM_REQUIRE(!A.overflow, OSFM_E_NOMEM, "osfm_hahog_extract: internal: slab A too small");
   OSFM_HIP(hipMemsetAsync(F.count, 0, 4 * sizeof(int), st));
   {
@@ -1477,20 +1521,7 @@ static int hahog_extract_on_stream(osfm_ctx *ctx, hipStream_t st, const float *i
   int *d_nor = B.take<int>((size_t)n1), *d_off = B.take<int>((size_t)n1 + 1);
   double *d_ang = B.take<double>((size_t)n1 * kMaxOr);
   OrPlan *d_orplan = (OrPlan *)B.take<double>((size_t)n1 * (sizeof(OrPlan) / 8));
-  // tables from the host's libm: the orientation mask (covdet.c:1536-1548) and fast_expn's (sift.c:714-720)
-  std::vector<double> h_tab((size_t)kOrSide * kOrSide + 257);
-  {
-    const int w = kOrRes;
-    const double step = (2.0 * kOrExtent) / (2 * w + 1), sigma = 3;
-    for (int j = -w; j <= w; ++j)
-      for (int i = -w; i <= w; ++i) {
-        const double dx = i * step / sigma, dy = j * step / sigma;
-        h_tab[(size_t)((i + w) + (2 * w + 1) * (j + w))] = (double)(float)std::exp(-0.5 * (dx * dx + dy * dy));  // `float aaMask[]` (covdet.c:1471)
-      }
-    for (int k = 0; k < 257; ++k) h_tab[(size_t)kOrSide * kOrSide + k] = std::exp(-(double)k * (25.0 / 256));
-  }
   OSFM_REQUIRE(!B.overflow, OSFM_E_NOMEM, "osfm_hahog_extract: internal: slab B too small");
-  OSFM_HIP(hipMemcpyAsync(d_tab, h_tab.data(), h_tab.size() * sizeof(double), hipMemcpyHostToDevice, st));
   const int nblk1 = (n1 + 255) / 256;
   hipLaunchKernelGGL(or_plan_kernel, dim3((unsigned)((n1 + 63) / 64)), dim3(64), 0, st, py, d_order, (const float *)F.x, (const float *)F.y,
                      (const float *)F.sigma, n1, sx, sy, ssg, d_orplan);
@@ -1512,10 +1543,6 @@ static int hahog_extract_on_stream(osfm_ctx *ctx, hipStream_t st, const float *i
   hipLaunchKernelGGL(orient_frames_kernel, dim3(nblk1), dim3(256), 0, st, (const float *)sx, (const float *)sy, (const float *)ssg, (const int *)d_off,
                      (const int *)d_nor, (const double *)d_ang, n1, R);
   // hahog.cc:168-199: the descriptor's scale in patch pixels and the orientation pi / 2, with the host's libm
-  const double patchStep = (double)kDExtent / kDRes;
-  const double sigma_d = (double)kDExtent / (3.0 * (4 + 1) / 2) / patchStep;
-  hipLaunchKernelGGL(desc_table_kernel, dim3(1), dim3(256), 0, st, (const double *)(d_tab + (size_t)kOrSide * kOrSide), std::sin(kPi / 2), std::cos(kPi / 2),
-                     sigma_d, d_dtab);
   hipLaunchKernelGGL(desc_plan_kernel, dim3((unsigned)((n2 + 63) / 64)), dim3(64), 0, st, py, R, n2, d_points, d_dplan);
   hipLaunchKernelGGL(descriptor_kernel, dim3(n2), dim3(256), 0, st, (const PatchPlan *)d_dplan, n2, (const DescTable *)d_dtab, flags, d_desc);
   OSFM_HIP(hipGetLastError());

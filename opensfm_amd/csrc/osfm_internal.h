@@ -80,6 +80,8 @@ struct osfm_ctx {
   hipEvent_t ev_rp[2] = {nullptr, nullptr};
   size_t h_pinned_bytes = 0;
   void *h_stage = nullptr;      // ba.hip: pinned staging memory of a solve's small uploads (4 MiB), made on first use
+  void *d_hahog_tables = nullptr;  // hahog.hip: the orientation mask, the exp table and the descriptor's per-pixel table (constants), made on first use
+  std::mutex hahog_mu;             // ... under this lock (the batch's worker threads arrive together)
 };
 
 // Tile = 32 descriptors x 128 int8 in MFMA-operand order (4 KiB):
