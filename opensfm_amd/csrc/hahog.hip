@@ -1274,12 +1274,56 @@ extern "C" int osfm_dbg_hahog_phases(unsigned long long *out, int reset) {
 // The tables that do not depend on the image (round 6: once per context, not once per image -- 1 938 libm exponentials on the host, a pageable
 // upload and the table kernel were ~40 us of every call): the orientation mask (covdet.c:1536-1548) and fast_expn's table (sift.c:714-720) from the
 // host's libm, then the descriptor's per-pixel table by desc_table_kernel.  Made under the context's hahog_mu and complete when this returns.
-static int hahog_tables(osfm_ctx *ctx, hipStream_t st, double **d_tab, DescTable **d_dtab) {
+// The Gaussians of the scale space, from the host's libm: octave o, level l -> slot o (kLev + 1) + l (vl_scalespace: the first level of an octave
+// from the image or from the previous octave's level, scalespace.c:741-752 / :797-809; the others from the level before, :675-693 with its sqrtf)
+struct TapPlan {
+  std::vector<float> taps;          // kMaxTaps per slot
+  int W[(kLev + 1) * kMaxOct];      // half-width per slot, -1: none
+  bool first[kMaxOct];              // the octave's first level is smoothed
+  int octaves_ok = 0;               // octaves whose filters fit kMaxTaps
+};
+static const TapPlan &tap_plan() {
+  static const TapPlan plan = []() {
+    TapPlan t;
+    t.taps.assign((size_t)kMaxTaps * (kLev + 1) * kMaxOct, 0.f);
+    for (int &w : t.W) w = -1;
+    const double base_scale = 1.6 * std::pow(2.0, 1.0 / kRes);
+    auto sigma_of = [&](int o, int s) { return base_scale * std::pow(2.0, o + (double)s / kRes); };
+    auto set_taps = [&](int slot, double sigma) -> bool {
+      int W;
+      const std::vector<float> f = gaussian_taps(sigma, &W);
+      if ((int)f.size() > kMaxTaps) return false;
+      memcpy(t.taps.data() + (size_t)slot * kMaxTaps, f.data(), f.size() * sizeof(float));
+      t.W[slot] = W;
+      return true;
+    };
+    bool ok = true;
+    for (int o = 0; o < kMaxOct && ok; o++) {
+      const double step = std::pow(2.0, o);
+      const int base = o * (kLev + 1);
+      const double sigma = sigma_of(o, kFirstSub);
+      const double prev = o == 0 ? 0.5 : sigma_of(o - 1, std::min(kFirstSub + kRes, kLastSub));
+      t.first[o] = sigma > prev;
+      if (t.first[o]) ok = ok && set_taps(base, std::sqrt(sigma * sigma - prev * prev) / step);
+      for (int s = kFirstSub + 1; s <= kLastSub && ok; s++) {
+        const double sg = sigma_of(o, s), pv = sigma_of(o, s - 1);
+        const double delta = sqrtf(sg * sg - pv * pv);
+        ok = ok && set_taps(base + (s - kFirstSub), delta / step);
+      }
+      if (ok) t.octaves_ok = o + 1;
+    }
+    return t;
+  }();
+  return plan;
+}
+static int hahog_tables(osfm_ctx *ctx, hipStream_t st, double **d_tab, DescTable **d_dtab, const float **d_taps) {
   constexpr size_t n_tab = (size_t)kOrSide * kOrSide + 257, tab_bytes = (n_tab * sizeof(double) + 255) / 256 * 256;
+  constexpr size_t dt_bytes = (sizeof(DescTable) + 255) / 256 * 256;
+  const TapPlan &tp = tap_plan();
   std::lock_guard<std::mutex> g(ctx->hahog_mu);
   if (!ctx->d_hahog_tables) {
     void *p = nullptr;
-    OSFM_REQUIRE(osfm_malloc_retry(ctx, &p, tab_bytes + sizeof(DescTable)) == hipSuccess, OSFM_E_NOMEM, "osfm_hahog_extract: device memory for the tables");
+    OSFM_REQUIRE(osfm_malloc_retry(ctx, &p, tab_bytes + dt_bytes + tp.taps.size() * sizeof(float)) == hipSuccess, OSFM_E_NOMEM, "osfm_hahog_extract: device memory for the tables");
     std::vector<double> h_tab(n_tab);
     {
       const int w = kOrRes;
@@ -1294,6 +1338,7 @@ static int hahog_tables(osfm_ctx *ctx, hipStream_t st, double **d_tab, DescTable
     const double patchStep = (double)kDExtent / kDRes;
     const double sigma_d = (double)kDExtent / (3.0 * (4 + 1) / 2) / patchStep;
     hipError_t e = hipMemcpyAsync(p, h_tab.data(), n_tab * sizeof(double), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync((char *)p + tab_bytes + dt_bytes, tp.taps.data(), tp.taps.size() * sizeof(float), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
       hipLaunchKernelGGL(desc_table_kernel, dim3(1), dim3(256), 0, st, (const double *)p + (size_t)kOrSide * kOrSide, std::sin(kPi / 2), std::cos(kPi / 2), sigma_d,
                          (DescTable *)((char *)p + tab_bytes));
@@ -1309,6 +1354,7 @@ static int hahog_tables(osfm_ctx *ctx, hipStream_t st, double **d_tab, DescTable
   }
   *d_tab = (double *)ctx->d_hahog_tables;
   *d_dtab = (DescTable *)((char *)ctx->d_hahog_tables + tab_bytes);
+  *d_taps = (const float *)((char *)ctx->d_hahog_tables + tab_bytes + dt_bytes);
   return OSFM_OK;
 }
 // one image on one stream (the caller holds the context lock; the block cache has its own)
@@ -1331,7 +1377,7 @@ static int hahog_extract_on_stream(osfm_ctx *ctx, hipStream_t st, const float *i
   Slab A, B;
   constexpr int kFeatureCap = 1 << 20;
   {
-    size_t need = padded((size_t)W0 * H0, 4) + padded((size_t)W0 * H0, 1) + padded((size_t)kMaxTaps * (kLev + 1) * kMaxOct, 4) + 5 * padded(kFeatureCap, 4) + 2 * padded(kFeatureCap, 4) +
+    size_t need = padded((size_t)W0 * H0, 4) + padded((size_t)W0 * H0, 1) + 5 * padded(kFeatureCap, 4) + 2 * padded(kFeatureCap, 4) +
                   padded(kFeatureCap, 8) + padded(4, 4);
     for (int o = 0; o <= last_octave; o++) need += 2 * padded((size_t)(W0 >> o) * (H0 >> o) * kLev, 4);
     OSFM_REQUIRE(A.buf.alloc(ctx, need) == hipSuccess, OSFM_E_NOMEM, "osfm_hahog_extract: %zu bytes of device memory", need);
@@ -1346,41 +1392,22 @@ static int hahog_extract_on_stream(osfm_ctx *ctx, hipStream_t st, const float *i
   }
   float *d_tmp = A.take<float>((size_t)W0 * H0);
   unsigned char *d_u8 = A.take<unsigned char>((size_t)W0 * H0);  // OSFM_HAHOG_IMAGE_U8: the caller's grey levels, converted on the device
-  float *d_taps = A.take<float>((size_t)kMaxTaps * (kLev + 1) * kMaxOct);
-  // every Gaussian of the pyramid, from the host's libm
-  std::vector<float> h_taps((size_t)kMaxTaps * (kLev + 1) * kMaxOct, 0.f);
-  std::vector<int> tapW((size_t)(kLev + 1) * kMaxOct, -1);
-  auto set_taps = [&](int slot, double sigma) -> int {
-    int W;
-    const std::vector<float> f = gaussian_taps(sigma, &W);
-    if ((int)f.size() > kMaxTaps) return -1;
-    memcpy(h_taps.data() + (size_t)slot * kMaxTaps, f.data(), f.size() * sizeof(float));
-    tapW[(size_t)slot] = W;
-    return W;
-  };
-  bool first_smooth[kMaxOct];
-  for (int o = 0; o <= last_octave; o++) {
-    const double step = std::pow(2.0, o);
-    const int base = o * (kLev + 1);
-    // first level of the octave (scalespace.c:741-752 from the image, :797-809 from the previous octave)
-    const double sigma = py.sigma[o][0];
-    const double prev = o == 0 ? 0.5 : py.sigma[o - 1][std::min(kFirstSub + kRes, kLastSub) - kFirstSub];
-    first_smooth[o] = sigma > prev;
-    if (first_smooth[o]) {
-      const double delta = std::sqrt(sigma * sigma - prev * prev);
-      OSFM_REQUIRE(set_taps(base, delta / step) >= 0, OSFM_E_UNSUPPORTED, "osfm_hahog_extract: Gaussian wider than %d taps", kMaxTaps);
-    }
-    for (int s = kFirstSub + 1; s <= kLastSub; s++) {  // scalespace.c:675-693 (sqrtf there)
-      const double sg = py.sigma[o][s - kFirstSub], pv = py.sigma[o][s - 1 - kFirstSub];
-      const double delta = sqrtf(sg * sg - pv * pv);
-      OSFM_REQUIRE(set_taps(base + (s - kFirstSub), delta / step) >= 0, OSFM_E_UNSUPPORTED, "osfm_hahog_extract: Gaussian wider than %d taps", kMaxTaps);
-    }
+  // every Gaussian of the pyramid (they depend on the octave and the level, not on the image): made once, tap_plan / hahog_tables
+  const TapPlan &tp = tap_plan();
+  OSFM_REQUIRE(tp.octaves_ok > last_octave, OSFM_E_UNSUPPORTED, "osfm_hahog_extract: Gaussian wider than %d taps", kMaxTaps);
+  const int *tapW = tp.W;
+  const bool *first_smooth = tp.first;
+  const float *d_taps = nullptr;
+  double *d_tab = nullptr;  // the constant tables of the context (hahog_tables)
+  DescTable *d_dtab = nullptr;
+  {
+    const int rct = hahog_tables(ctx, st, &d_tab, &d_dtab, &d_taps);
+    if (rct != OSFM_OK) return rct;
   }
-  OSFM_HIP(hipMemcpyAsync(d_taps, h_taps.data(), h_taps.size() * sizeof(float), hipMemcpyHostToDevice, st));
   const bool two_pass = getenv("OSFM_HAHOG_TWO_PASS") != nullptr;  // measurement / test knob: the separate column and row kernels
   // one level from the previous one; returns 1 when the level's Hessian response (css, factor) came out of the same launch
   auto smooth = [&](const float *src, float *dst, int w, int h, int slot, float *css, float factor) -> int {
-    const int W = tapW[(size_t)slot];
+    const int W = tapW[slot];
     if (W > kSmMaxW || W < 1 || two_pass || w < 3 || h < 3) {
       if (src == d_tmp) {  // a staged first level on the two-kernel path (a filter wider than the fused kernel takes): the level is the other buffer
         hipLaunchKernelGGL(conv_v_kernel, grid2(w, h), dim3(256), 0, st, src, dst, w, h, d_taps + (size_t)slot * kMaxTaps, W);
@@ -1451,12 +1478,6 @@ static int hahog_extract_on_stream(osfm_ctx *ctx, hipStream_t st, const float *i
   F.o = A.take<int>((size_t)F.cap); F.s = A.take<int>((size_t)F.cap);
   F.key = A.take<unsigned long long>((size_t)F.cap);
   F.count = A.take<int>(4);
-  double *d_tab = nullptr;  // the constant tables of the context (hahog_tables)
-  DescTable *d_dtab = nullptr;
-  {
-    const int rct = hahog_tables(ctx, st, &d_tab, &d_dtab);
-    if (rct != OSFM_OK) return rct;
-  }
   OSFM_REQUIRE(!A.overflow, OSFM_E_NOMEM, "osfm_hahog_extract: internal: slab A too small");
   OSFM_HIP(hipMemsetAsync(F.count, 0, 4 * sizeof(int), st));
   {
