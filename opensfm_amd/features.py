@@ -30,7 +30,9 @@ def _extract(image: np.ndarray, peak_threshold: float, edge_threshold: float, ta
     check(lib.osfm_hahog_extract(ctx.handle, C.cast(im.ctypes.data, C.POINTER(C.c_float)), im.shape[0], im.shape[1], float(peak_threshold),
                                  float(edge_threshold), int(target_num_features), int(flags), pts.ctypes.data_as(C.POINTER(C.c_float)),
                                  desc.ctypes.data_as(C.POINTER(C.c_float)), cap, C.byref(n)), "osfm_hahog_extract")
-    return pts[: n.value].copy(), desc[: n.value].copy()
+    # views, not copies (round 6): the buffers are fresh and lazily committed -- only the n rows the library wrote are resident -- and copying 2.8 MB of
+    # descriptors into a second fresh array was 0.1 - 0.3 ms of a 1.3 ms call; the unused tail is address space, not memory
+    return pts[: n.value], desc[: n.value]
 
 
 def hahog_batch(images: Sequence[Any], peak_threshold: float, edge_threshold: float, target_num_features: int, flags: int = 0, concurrency: int = 0,
@@ -68,7 +70,7 @@ def hahog_batch(images: Sequence[Any], peak_threshold: float, edge_threshold: fl
     pp, dp = (C.c_void_p * n)(*[a.ctypes.data for a in pts]), (C.c_void_p * n)(*[a.ctypes.data for a in desc])
     check(lib.osfm_hahog_extract_batch(ctx.handle, n, ptrs, rows, cols, float(peak_threshold), float(edge_threshold), int(target_num_features), int(flags),
                                        pp, dp, caps, nf, int(concurrency)), "osfm_hahog_extract_batch")
-    return [(pts[i][: nf[i]].copy(), desc[i][: nf[i]].copy()) for i in range(n)]
+    return [(pts[i][: nf[i]], desc[i][: nf[i]]) for i in range(n)]  # views of fresh, lazily committed buffers (see _extract)
 
 
 def hahog(image: np.ndarray, peak_threshold: float, edge_threshold: float, target_num_features: int, ctx=None) -> Optional[Tuple[np.ndarray, np.ndarray]]:
