@@ -100,7 +100,9 @@ __host__ __device__ constexpr int sm_stride(int W) { return (kSmX + 2 * W) | 1; 
 // interior pixel, one further in), i.e. 60 x 28 pixels of the level per 64 x 32 tile.
 constexpr int kSmHalo = 2;
 template <int W>
-__global__ void __launch_bounds__(256) smooth_fused_kernel(const float *src, float *dst, float *css, int w, int h, const float *taps, float factor) {
+__global__ void __launch_bounds__(256) smooth_fused_kernel(const float *src, float *dst, float *css, int w, int h, const float *taps, float factor, int src_w,
+                                                           int src_mul) {  // sample (x, y) of the source image is src[(y src_mul) src_w + x src_mul]: 2 = every second pixel of
+                                                                           // every second row of the octave before (copy_and_downsample, scalespace.c:497-520)
   constexpr int SW = sm_stride(W), SH = kSmY + 2 * W, NT = 2 * W + 1;
   __shared__ float S[SW * SH], T[SW * kSmY];  // source tile (later the output tile), column-pass tile
   const int x0 = blockIdx.x * (kSmX - 2 * kSmHalo) - kSmHalo, y0 = blockIdx.y * (kSmY - 2 * kSmHalo) - kSmHalo, tid = threadIdx.x;
@@ -112,7 +114,7 @@ __global__ void __launch_bounds__(256) smooth_fused_kernel(const float *src, flo
     int gy = y0 - W + r, gx = x0 - W + c;
     gy = gy < 0 ? 0 : (gy > h - 1 ? h - 1 : gy);
     gx = gx < 0 ? 0 : (gx > w - 1 ? w - 1 : gx);
-    S[r * SW + c] = src[(long)gy * w + gx];
+    S[r * SW + c] = src[(long)(gy * src_mul) * src_w + gx * src_mul];
   }
   __syncthreads();
   for (int t = tid; t < (kSmX + 2 * W) * (kSmY / kSmR); t += 256) {  // consecutive lanes: consecutive columns
@@ -158,7 +160,7 @@ __global__ void __launch_bounds__(256) smooth_fused_kernel(const float *src, flo
     css[(long)y * w + x] = (Lxx * Lyy - Lxy * Lxy) * factor;
   }
 }
-typedef void (*smooth_fn)(const float *, float *, float *, int, int, const float *, float);
+typedef void (*smooth_fn)(const float *, float *, float *, int, int, const float *, float, int, int);
 template <int W>
 struct SmoothTable {
   static smooth_fn get(int q) { return q == W ? smooth_fused_kernel<W> : SmoothTable<W - 1>::get(q); }
@@ -183,6 +185,22 @@ __global__ void hessian_kernel(const float *im, float *out, int w, int h, float 
   const float Lyy = (-p12 + 2 * p22 - p32);
   const float Lxy = ((p11 - p31 - p13 + p33) / 4.0f);
   out[(long)y * w + x] = (Lxx * Lyy - Lxy * Lxy) * factor;
+}
+
+// The first level of an octave that is not smoothed (round 6, one launch instead of two): copy_and_downsample of the level of the octave before
+// and the Hessian response of the result, the expressions of downsample_kernel and hessian_kernel on the same values
+__global__ void downsample_hessian_kernel(const float *src, int sw, float *dst, float *css, int w, int h, float factor) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  dst[(long)y * w + x] = src[(long)(2 * y) * sw + 2 * x];
+  const int c = x < 1 ? 1 : (x > w - 2 ? w - 2 : x), r = y < 1 ? 1 : (y > h - 2 ? h - 2 : y);
+  auto at = [&](int rr, int cc) { return src[(long)(2 * rr) * sw + 2 * cc]; };
+  const float p11 = at(r - 1, c - 1), p12 = at(r - 1, c), p13 = at(r - 1, c + 1), p21 = at(r, c - 1), p22 = at(r, c), p23 = at(r, c + 1), p31 = at(r + 1, c - 1),
+              p32 = at(r + 1, c), p33 = at(r + 1, c + 1);
+  const float Lxx = (-p21 + 2 * p22 - p23);
+  const float Lyy = (-p12 + 2 * p22 - p32);
+  const float Lxy = ((p11 - p31 - p13 + p33) / 4.0f);
+  css[(long)y * w + x] = (Lxx * Lyy - Lxy * Lxy) * factor;
 }
 
 // ---- detection -----------------------------------------------------------------------------------------------------------------
@@ -1406,9 +1424,10 @@ static int hahog_extract_on_stream(osfm_ctx *ctx, hipStream_t st, const float *i
   }
   const bool two_pass = getenv("OSFM_HAHOG_TWO_PASS") != nullptr;  // measurement / test knob: the separate column and row kernels
   // one level from the previous one; returns 1 when the level's Hessian response (css, factor) came out of the same launch
-  auto smooth = [&](const float *src, float *dst, int w, int h, int slot, float *css, float factor) -> int {
+  auto fused_ok = [&](int slot, int w, int h) { return !(tapW[slot] > kSmMaxW || tapW[slot] < 1 || two_pass || w < 3 || h < 3); };
+  auto smooth = [&](const float *src, float *dst, int w, int h, int slot, float *css, float factor, int src_w = 0, int src_mul = 1) -> int {
     const int W = tapW[slot];
-    if (W > kSmMaxW || W < 1 || two_pass || w < 3 || h < 3) {
+    if (!fused_ok(slot, w, h)) {
       if (src == d_tmp) {  // a staged first level on the two-kernel path (a filter wider than the fused kernel takes): the level is the other buffer
         hipLaunchKernelGGL(conv_v_kernel, grid2(w, h), dim3(256), 0, st, src, dst, w, h, d_taps + (size_t)slot * kMaxTaps, W);
         hipLaunchKernelGGL(conv_h_kernel, grid2(w, h), dim3(256), 0, st, (const float *)dst, d_tmp, w, h, d_taps + (size_t)slot * kMaxTaps, W);
@@ -1422,7 +1441,7 @@ static int hahog_extract_on_stream(osfm_ctx *ctx, hipStream_t st, const float *i
     float *out = src == dst ? d_tmp : dst;  // in place (the first level of an octave): through the scratch image
     constexpr int sx = kSmX - 2 * kSmHalo, sy = kSmY - 2 * kSmHalo;
     hipLaunchKernelGGL(SmoothTable<kSmMaxW>::get(W), dim3((unsigned)((w + sx - 1) / sx), (unsigned)((h + sy - 1) / sy)), dim3(256), 0, st, src, out, css, w, h,
-                       d_taps + (size_t)slot * kMaxTaps, factor);
+                       d_taps + (size_t)slot * kMaxTaps, factor, src_w > 0 ? src_w : w, src_mul);
     if (out != dst && hipMemcpyAsync(dst, out, (size_t)w * h * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return -1;
     return 1;
   };
@@ -1445,17 +1464,31 @@ static int hahog_extract_on_stream(osfm_ctx *ctx, hipStream_t st, const float *i
     const Octave &oc = py.oct[o];
     const size_t npx = (size_t)oc.w * oc.h;
     const int base = o * (kLev + 1);
-    if (o > 0) {
-      const Octave &pv = py.oct[o - 1];
-      const int pl = std::min(kFirstSub + kRes, kLastSub) - kFirstSub;
-      hipLaunchKernelGGL(downsample_kernel, grid2(oc.w, oc.h), dim3(256), 0, st, (const float *)(pv.gss + (size_t)pl * pv.w * pv.h), pv.w, pv.h,
-                         (first_smooth[o] && !two_pass) ? d_tmp : oc.gss, oc.w, oc.h);
-    }
     const bool staged = first_smooth[o] && !two_pass;
     const double step = std::pow(2.0, o);
     auto factor_of = [&](int l) { return (float)std::pow(py.sigma[o][l] / step, 4.0); };
     bool have_css[kLev] = {};
-    if (first_smooth[o]) {
+    bool first_done = false;
+    if (o > 0) {
+      // copy_and_downsample of the level of the octave before.  Round 6: not a launch of its own when the first level goes through the fused
+      // smoothing (which then reads every second pixel of every second row of that level) or is not smoothed at all (downsample_hessian_kernel)
+      const Octave &pv = py.oct[o - 1];
+      const int pl = std::min(kFirstSub + kRes, kLastSub) - kFirstSub;
+      const float *plevel = pv.gss + (size_t)pl * pv.w * pv.h;
+      if (first_smooth[o] && fused_ok(base, oc.w, oc.h)) {
+        const int rcs = smooth(plevel, oc.gss, oc.w, oc.h, base, oc.css, factor_of(0), pv.w, 2);
+        OSFM_REQUIRE(rcs >= 0, OSFM_E_HIP, "osfm_hahog_extract: device copy failed");
+        have_css[0] = rcs == 1;
+        first_done = true;
+      } else if (!first_smooth[o] && !two_pass) {
+        hipLaunchKernelGGL(downsample_hessian_kernel, grid2(oc.w, oc.h), dim3(256), 0, st, plevel, pv.w, oc.gss, oc.css, oc.w, oc.h, factor_of(0));
+        have_css[0] = true;
+        first_done = true;
+      } else {
+        hipLaunchKernelGGL(downsample_kernel, grid2(oc.w, oc.h), dim3(256), 0, st, plevel, pv.w, pv.h, staged ? d_tmp : oc.gss, oc.w, oc.h);
+      }
+    }
+    if (first_smooth[o] && !first_done) {
       const int rcs = smooth(staged ? (const float *)d_tmp : (const float *)oc.gss, oc.gss, oc.w, oc.h, base, oc.css, factor_of(0));
       OSFM_REQUIRE(rcs >= 0, OSFM_E_HIP, "osfm_hahog_extract: device copy failed");
       have_css[0] = rcs == 1;
