@@ -1045,9 +1045,16 @@ constexpr double kDExtent = 7.5;
 // spatial fractions of pixel t -- two fp64 divisions, the exp-table interpolation, three float -> int64 floors and eight LDS atomics per pixel --
 // are the same 961 values for all ~5 000 features of an image, and so are the rows and columns a spatial bin walks.  desc_table_kernel computes
 // them once per call with the expressions the descriptor kernel used to evaluate per feature (the same bits); descriptor_kernel reads them.
+constexpr int kDescListCap = (kDSide * kDSide + 3) / 4 * 4;
+constexpr unsigned kDescPad = 0x8000u;
+static_assert(kDSide * kDSide <= 1024 && (kDescListCap * 2) % 8 == 0, "list entries: ten bits of pixel, 8-byte rows");
 struct DescTable {
   float4 pix[kDSide * kDSide];               // window, nx - (binx + 0.5), ny - (biny + 0.5), bits of (binx + 128) | (biny + 128) << 8
   unsigned rowmask[kNBP * kNBP], colmask[kNBP * kNBP];  // per spatial bin (bx + 2) + 4 (by + 2): the rows / columns whose bin ranges admit it
+  // per spatial bin: the pixels that feed it, in raster order: t | (2 dx + dy) << 10 (dx = bx - binx, dy = by - biny, both in {0, 1}); padded to a
+  // multiple of four with kDescPad
+  unsigned short list[kNBP * kNBP][kDescListCap];
+  int nlist[kNBP * kNBP];
 };
 __global__ void __launch_bounds__(256) desc_table_kernel(const double *expn_tab, double st0, double ct0, double sigma_d, DescTable *tab) {
   __shared__ int rlo[2][kDSide], rhi[2][kDSide], clo[2][kDSide], chi[2][kDSide];  // per row / column: range of binx [0] and biny [1]
@@ -1100,6 +1107,14 @@ __global__ void __launch_bounds__(256) desc_table_kernel(const double *expn_tab,
     }
     tab->rowmask[tid] = rowmask;
     tab->colmask[tid] = colmask;
+    int n = 0;
+    for (int t = 0; t < kDSide * kDSide; t++) {  // (the pix entries of this workgroup's other threads: the barrier above made them visible)
+      const int cw = __float_as_int(tab->pix[t].w);
+      const int dbinx = bx - ((cw & 255) - 128), dbiny = by - (((cw >> 8) & 255) - 128);
+      if ((unsigned)(dbinx | dbiny) <= 1u) tab->list[tid][n++] = (unsigned short)(t | ((2 * dbinx + dbiny) << 10));
+    }
+    while (n % 4) tab->list[tid][n++] = (unsigned short)kDescPad;
+    tab->nlist[tid] = n;
   }
 }
 // a thread per oriented feature: the keypoint row (hahog.cc:188-196) and the plan of its 31 x 31 patch
@@ -1125,8 +1140,11 @@ __global__ void __launch_bounds__(64) desc_plan_kernel(Pyramid py, Oriented R, i
 }
 __global__ void __launch_bounds__(256) descriptor_kernel(const PatchPlan *plans, int n, const DescTable *tab, int flags, float *desc) {
   __shared__ float patch[kDSide * kDSide];
-  __shared__ float4 sval[kDSide * kDSide];  // window x modulus and the three fractions of the pixel
-  __shared__ int scode[kDSide * kDSide];    // its lower bins: (binx + 128) | (biny + 128) << 8 | bint << 16
+  // Round 6: what a pixel gives each of the 2 x 2 spatial bins it feeds -- (window x modulus) |1 - dx - rx| |1 - dy - ry|, the first three factors of the
+  // reference's product in its order -- is formed once per pixel, and a bin walks the LIST of the pixels that feed it (DescTable::list: the same for every
+  // feature), not a rectangle of candidates it has to test: ~19 instructions a walked pixel instead of 41, and the walk is nearly all this kernel issues
+  __shared__ float sbase[4 * kDSide * kDSide];  // at [4 t + 2 dx + dy]
+  __shared__ float snt[kDSide * kDSide];        // the orientation coordinate nt: lower bin floor(nt), fraction nt - floor(nt)
   __shared__ float descr[kNBO * kNBP * kNBP];
   __shared__ float snorm;
   __shared__ PatchPlan P;
@@ -1148,11 +1166,11 @@ __global__ void __launch_bounds__(256) descriptor_kernel(const PatchPlan *plans,
     polar_gradient(patch, kDSide, t, &mod, &angle);
     const float theta = mod_2pi_f((float)(angle - (kPi / 2)));
     const float nt = (float)(kNBO * theta / (2 * kPi));
-    const float fl = floorf(nt);  // vl_floor_f: 0 <= nt <= 8
-    const int bint = (int)fl;
     const float4 c = tab->pix[t];
-    sval[t] = make_float4(c.x * mod, c.y, c.z, nt - bint);
-    scode[t] = __float_as_int(c.w) | (bint << 16);
+    const float wm = c.x * mod, rx = c.y, ry = c.z;
+    const float ax0 = fabsf(1 - 0 - rx), ax1 = fabsf(1 - 1 - rx), ay0 = fabsf(1 - 0 - ry), ay1 = fabsf(1 - 1 - ry);
+    *reinterpret_cast<float4 *>(sbase + 4 * t) = make_float4(wm * ax0 * ay0, wm * ax0 * ay1, wm * ax1 * ay0, wm * ax1 * ay1);
+    snt[t] = nt;
   }
   __syncthreads();
   HTICK(h3)
@@ -1163,35 +1181,33 @@ __global__ void __launch_bounds__(256) descriptor_kernel(const PatchPlan *plans,
   // sum of non-negative terms unchanged; a pixel feeds a bin through at most one of its two orientation bins.  (All 961 pixels per bin
   // were 130 of the kernel's 166 us per workgroup, profiles/r03_hahog_phases_before_sort.txt.)
   if (tid < kNBO * kNBP * kNBP) {
-    const int bt = tid % kNBO, bx = (tid / kNBO) % kNBP - kNBP / 2, by = tid / (kNBO * kNBP) - kNBP / 2;
-    const unsigned rowmask = tab->rowmask[tid / kNBO], colmask = tab->colmask[tid / kNBO];
+    const int bt = tid % kNBO;
+    const unsigned short *lst = tab->list[tid / kNBO];
+    const int n = tab->nlist[tid / kNBO];
     float acc = 0.f;
-    for (unsigned rm = rowmask; rm; rm &= rm - 1) {
-      const int yb = __builtin_ctz(rm) * kDSide;
-      for (unsigned cm = colmask; cm;) {  // four pixels of the walk in flight (a missing one adds +0.0f), added in raster order
-        int code[4];
-        float4 pv[4];
-        bool on[4];
+    uint2 nxt = *reinterpret_cast<const uint2 *>(lst);  // four entries; the next four are requested a step ahead
+    for (int k = 0; k < n; k += 4) {
+      const uint2 e4 = nxt;
+      if (k + 4 < n) nxt = *reinterpret_cast<const uint2 *>(lst + k + 4);
+      const unsigned e[4] = {e4.x & 0xffffu, e4.x >> 16, e4.y & 0xffffu, e4.y >> 16};
+      float base[4], nt[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-          on[u] = cm != 0;
-          const int t = yb + (on[u] ? __builtin_ctz(cm) : 0);
-          cm &= cm - 1;
-          code[u] = scode[t];
-          pv[u] = sval[t];
-        }
+      for (int u = 0; u < 4; u++) {  // four pixels of the walk in flight (a padding entry adds +0.0f), added in raster order
+        const int t = (int)(e[u] & 1023u);
+        base[u] = sbase[4 * t + (int)((e[u] >> 10) & 3u)];
+        nt[u] = snt[t];
+      }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int dbinx = bx - ((code[u] & 255) - 128), dbiny = by - (((code[u] >> 8) & 255) - 128);
-          const unsigned sb = (unsigned)code[u] >> 16;  // 0 .. 8: the remainders below are masks (round 6; signed remainders cost eight instructions a pixel)
-          const bool in = on[u] && !(dbinx < 0 || dbinx > 1 || dbiny < 0 || dbiny > 1);
-          const int b0 = (int)(sb & (kNBO - 1)), b1 = (int)((sb + 1) & (kNBO - 1));
-          static_assert((kNBO & (kNBO - 1)) == 0, "kNBO is a power of two");
-          const float wm = pv[u].x, rx = pv[u].y, ry = pv[u].z, rt = pv[u].w;
-          const float v0 = wm * fabsf(1 - dbinx - rx) * fabsf(1 - dbiny - ry) * fabsf(1 - 0 - rt);
-          const float v1 = wm * fabsf(1 - dbinx - rx) * fabsf(1 - dbiny - ry) * fabsf(1 - 1 - rt);
-          acc += (in && b0 == bt) ? v0 : ((in && b1 == bt) ? v1 : 0.0f);
-        }
+      for (int u = 0; u < 4; u++) {
+        const bool on = !(e[u] & kDescPad);
+        const float fl = floorf(nt[u]);  // vl_floor_f: 0 <= nt <= 8
+        const float rt = nt[u] - fl;
+        const unsigned sb = (unsigned)fl;  // 0 .. 8: the remainders below are masks
+        const int b0 = (int)(sb & (kNBO - 1)), b1 = (int)((sb + 1) & (kNBO - 1));
+        static_assert((kNBO & (kNBO - 1)) == 0, "kNBO is a power of two");
+        const float v0 = base[u] * fabsf(1 - 0 - rt);
+        const float v1 = base[u] * fabsf(1 - 1 - rt);
+        acc += (on && b0 == bt) ? v0 : ((on && b1 == bt) ? v1 : 0.0f);
       }
     }
     descr[tid] = acc;
