@@ -1043,29 +1043,20 @@ constexpr double kDExtent = 7.5;
 // What a pixel of the 31 x 31 patch contributes apart from its gradient does not depend on the feature (round 6): hahog.cc describes every patch
 // at its centre with angle0 = pi / 2 and one sigma, so the normalised coordinates (nx, ny), the Gaussian window, the lower spatial bins and the two
 // spatial fractions of pixel t -- two fp64 divisions, the exp-table interpolation, three float -> int64 floors and eight LDS atomics per pixel --
-// are the same 961 values for all ~5 000 features of an image, and so are the rows and columns a spatial bin walks.  desc_table_kernel computes
-// them once per call with the expressions the descriptor kernel used to evaluate per feature (the same bits); descriptor_kernel reads them.
+// are the same 961 values for all ~5 000 features of an image, and so are the pixels that feed a spatial bin.  desc_table_kernel computes
+// them once per context with the expressions the descriptor kernel used to evaluate per feature (the same bits); descriptor_kernel reads them.
 constexpr int kDescListCap = (kDSide * kDSide + 3) / 4 * 4;
 constexpr unsigned kDescPad = 0x8000u;
 static_assert(kDSide * kDSide <= 1024 && (kDescListCap * 2) % 8 == 0, "list entries: ten bits of pixel, 8-byte rows");
 struct DescTable {
   float4 pix[kDSide * kDSide];               // window, nx - (binx + 0.5), ny - (biny + 0.5), bits of (binx + 128) | (biny + 128) << 8
-  unsigned rowmask[kNBP * kNBP], colmask[kNBP * kNBP];  // per spatial bin (bx + 2) + 4 (by + 2): the rows / columns whose bin ranges admit it
-  // per spatial bin: the pixels that feed it, in raster order: t | (2 dx + dy) << 10 (dx = bx - binx, dy = by - biny, both in {0, 1}); padded to a
+  // per spatial bin (bx + 2) + 4 (by + 2): the pixels that feed it, in raster order: t | (2 dx + dy) << 10 (dx = bx - binx, dy = by - biny, both in {0, 1}); padded to a
   // multiple of four with kDescPad
   unsigned short list[kNBP * kNBP][kDescListCap];
   int nlist[kNBP * kNBP];
 };
 __global__ void __launch_bounds__(256) desc_table_kernel(const double *expn_tab, double st0, double ct0, double sigma_d, DescTable *tab) {
-  __shared__ int rlo[2][kDSide], rhi[2][kDSide], clo[2][kDSide], chi[2][kDSide];  // per row / column: range of binx [0] and biny [1]
   const int tid = threadIdx.x;
-  if (tid < 2 * kDSide) {
-    (&rlo[0][0])[tid] = INT_MAX;
-    (&clo[0][0])[tid] = INT_MAX;
-    (&rhi[0][0])[tid] = INT_MIN;
-    (&chi[0][0])[tid] = INT_MIN;
-  }
-  __syncthreads();
   // (sift.c:1806-1850; x = y = 15, so xi = yi = 15 and every pixel of the patch is inside the window W = 21)
   const double x0 = (double)(kDSide - 1) / 2, y0 = (double)(kDSide - 1) / 2;
   const double SBP = 3.0 * sigma_d + kEpsD;
@@ -1086,27 +1077,10 @@ __global__ void __launch_bounds__(256) desc_table_kernel(const double *expn_tab,
     const float win = (float)win_d;
     const int binx = (int)vl_floor_f((float)(nx - 0.5)), biny = (int)vl_floor_f((float)(ny - 0.5));
     tab->pix[t] = make_float4(win, (float)(nx - (binx + 0.5)), (float)(ny - (biny + 0.5)), __int_as_float((binx + 128) | ((biny + 128) << 8)));
-    atomicMin(&rlo[0][py_], binx);
-    atomicMax(&rhi[0][py_], binx);
-    atomicMin(&rlo[1][py_], biny);
-    atomicMax(&rhi[1][py_], biny);
-    atomicMin(&clo[0][px_], binx);
-    atomicMax(&chi[0][px_], binx);
-    atomicMin(&clo[1][px_], biny);
-    atomicMax(&chi[1][px_], biny);
   }
   __syncthreads();
   if (tid < kNBP * kNBP) {
     const int bx = tid % kNBP - kNBP / 2, by = tid / kNBP - kNBP / 2;
-    unsigned rowmask = 0, colmask = 0;
-    for (int i = 0; i < kDSide; i++) {
-      const bool r = rlo[0][i] <= bx && rhi[0][i] >= bx - 1 && rlo[1][i] <= by && rhi[1][i] >= by - 1;
-      const bool c = clo[0][i] <= bx && chi[0][i] >= bx - 1 && clo[1][i] <= by && chi[1][i] >= by - 1;
-      rowmask |= r ? (1u << i) : 0u;
-      colmask |= c ? (1u << i) : 0u;
-    }
-    tab->rowmask[tid] = rowmask;
-    tab->colmask[tid] = colmask;
     int n = 0;
     for (int t = 0; t < kDSide * kDSide; t++) {  // (the pix entries of this workgroup's other threads: the barrier above made them visible)
       const int cw = __float_as_int(tab->pix[t].w);

@@ -116,3 +116,35 @@ def test_rows_and_columns_that_can_feed_a_bin_give_the_full_walk():
                     assert np.float32(full).view(np.int32) == np.float32(part).view(np.int32)
         if angle == np.pi / 2:
             assert len(some) < len(everything) // 3  # and it is a real saving for the product's axis-aligned bins
+
+
+def test_the_list_of_a_spatial_bin_gives_the_full_walk():
+    """round 6: a lane walks the LIST of the pixels that feed its spatial bin (raster order; which pixels and through which of their four spatial
+    products (window x modulus) |1 - dx - rx| |1 - dy - ry| does not depend on the feature), the products formed once per pixel: the same float32
+    sum as the walk over all 961 pixels, for every bin"""
+    rng = np.random.default_rng(9)
+    for angle in (np.pi / 2, 0.3):
+        px = _descriptor_pixels(rng, angle)
+        binx, biny, bint, rx, ry, rt, wm = px
+        everything = [(y, x) for y in range(SIDE) for x in range(SIDE)]
+        # once per pixel: base[2 dx + dy], the first three factors in the reference's order
+        base = np.empty((SIDE, SIDE, 4), np.float32)
+        for dx in (0, 1):
+            for dy in (0, 1):
+                base[:, :, 2 * dx + dy] = wm * np.abs(np.float32(1 - dx) - rx) * np.abs(np.float32(1 - dy) - ry)
+        nt = bint.astype(np.float32) + rt
+        for bx in range(-NBP // 2, NBP // 2):
+            for by in range(-NBP // 2, NBP // 2):
+                lst = [(y, x, 2 * (bx - binx[y, x]) + (by - biny[y, x])) for (y, x) in everything if 0 <= bx - binx[y, x] <= 1 and 0 <= by - biny[y, x] <= 1]
+                for bt in (0, 3, 7):
+                    acc = np.float32(0)
+                    for (y, x, idx) in lst:
+                        fl = np.floor(nt[y, x])
+                        r = nt[y, x] - fl
+                        sb = int(fl)
+                        v0, v1 = base[y, x, idx] * np.abs(np.float32(1) - r), base[y, x, idx] * np.abs(np.float32(0) - r)
+                        acc = acc + (v0 if (sb & 7) == bt else (v1 if ((sb + 1) & 7) == bt else np.float32(0)))
+                    full = _bin_sum(bx, by, bt, px, everything)
+                    assert np.float32(full).view(np.int32) == np.float32(acc).view(np.int32), (angle, bx, by, bt)
+        if angle == np.pi / 2:
+            assert len(lst) < len(everything) // 3
